@@ -1,0 +1,136 @@
+/*
+ * kpd.h -- C ABI of libkpd_hip.so: the MI355X (gfx950) denoising hot path of
+ * Dunni3/keypoint-diffusion behind plain pointers and sizes.
+ *
+ * The reference is pure Python; its "FFI" for this path is the set of third-party native
+ * ops it calls every reverse-diffusion step (torch_cluster.radius_graph / knn,
+ * DGL apply_edges / multi_update_all, torch.nn.Linear / LayerNorm) from
+ *   models/dynamics.py:342-441        LigRecDynamics.forward  (+ LigRecEGNN, LigRecConv)
+ *   models/dynamics_gvp.py:149-255    LigRecDynamicsGVP.forward (+ gvp.py GVPMultiEdgeConv)
+ *   models/receptor_encoder_gvp.py:212-321  ReceptorEncoderGVP.forward
+ *   models/ligand_diffuser.py:497-538 KeypointDiffusion.sample_p_zs_given_zt
+ * Each entry point below replaces one of those call sites as a whole and cites it.
+ *
+ * Conventions
+ *   - every pointer named *_dev / marked [dev] is a device (HBM) pointer, fp32 or int32,
+ *     contiguous, row-major; everything else is host memory;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, no hidden
+ *     synchronisation, no allocation inside forward calls (kpd_*_reserve allocates);
+ *   - node arrays are flat and graph-major: complex b owns rows [ptr[b], ptr[b+1]);
+ *   - every call returns KPD_OK or a negative kpd_status; kpd_last_error() gives text.
+ */
+#ifndef KPD_H
+#define KPD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum kpd_status {
+    KPD_OK = 0,
+    KPD_ERR_INVALID = -1,      /* bad argument / unsupported configuration              */
+    KPD_ERR_CAPACITY = -2,     /* batch larger than the reserved workspace               */
+    KPD_ERR_WEIGHTS = -3,      /* unknown weight name, wrong shape, or weights missing   */
+    KPD_ERR_HIP = -4,          /* a HIP runtime call failed                              */
+    KPD_ERR_STATE = -5         /* call order violated (e.g. forward before commit)       */
+} kpd_status;
+
+const char *kpd_last_error(void);
+int kpd_version(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Batch of complexes (the tensors the reference keeps in a batched DGL heterograph).
+ * kk edges are static during sampling (ligand_diffuser.py:201-202 translates keypoints
+ * rigidly) and are passed dst-sorted with their CSR row pointer.
+ * ------------------------------------------------------------------------------------- */
+typedef struct kpd_batch {
+    int32_t B;                 /* complexes                                              */
+    int32_t n_lig, n_kp;       /* total ligand atoms / keypoints                         */
+    int32_t max_lig, max_kp;   /* largest per-complex counts (host-known)                */
+    const int32_t *lig_ptr;    /* [dev] [B+1]                                            */
+    const int32_t *kp_ptr;     /* [dev] [B+1]                                            */
+    const float *lig_x;        /* [dev] [n_lig,3]        g.nodes['lig'].data['x_0']      */
+    const float *lig_h;        /* [dev] [n_lig,atom_nf]  g.nodes['lig'].data['h_0']      */
+    const float *kp_x;         /* [dev] [n_kp,3]                                         */
+    const float *kp_h;         /* [dev] [n_kp,rec_nf]                                    */
+    const float *kp_v;         /* [dev] [n_kp,V,3] (GVP only, else NULL)                 */
+    int32_t n_kk;              /* kk edges                                               */
+    const int32_t *kk_src;     /* [dev] [n_kk] sorted by (dst, src)                      */
+    const int32_t *kk_dst;     /* [dev] [n_kk]                                           */
+    const int32_t *kk_rowptr;  /* [dev] [n_kp+1]                                         */
+} kpd_batch;
+
+/* ---------------------------------------------------------------------------------------
+ * Per-step ligand graph build.  Replaces add_lig_edges (models/dynamics.py:387-420,
+ * models/dynamics_gvp.py:201-234): torch_cluster.radius_graph(lig, r=ll) and
+ * torch_cluster.knn(x=lig, y=kp, k) plus the DGL add_edges / batch bookkeeping.
+ * Output: dst-sorted COO + CSR row pointers for ll (dst lig), kl (src kp -> dst lig) and
+ * lk (src lig -> dst kp), in caller buffers of the stated capacity.
+ * ------------------------------------------------------------------------------------- */
+typedef struct kpd_lig_graph {
+    int32_t cap_ll, cap_kl;    /* capacities (edges) of the arrays below                 */
+    int32_t *ll_src, *ll_dst, *ll_rowptr;   /* [dev] [cap_ll],[cap_ll],[n_lig+1]         */
+    int32_t *kl_src, *kl_dst, *kl_rowptr;   /* [dev] [cap_kl],[cap_kl],[n_lig+1]         */
+    int32_t *lk_src, *lk_dst, *lk_rowptr;   /* [dev] [cap_kl],[cap_kl],[n_kp+1]          */
+    int32_t *ll_per_graph;     /* [dev] [B] ll edges per complex                          */
+    int32_t *counts;           /* [dev] [2]: {E_ll, E_kl}                                 */
+} kpd_lig_graph;
+
+kpd_status kpd_build_lig_graph(const kpd_batch *batch, float ll_cutoff, int32_t kl_k,
+                               const kpd_lig_graph *out, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * EGNN denoiser.  Replaces LigRecDynamics.forward (models/dynamics.py:342-385) including
+ * lig/rec encoders, edge build, the LigRecEGNN stack (:266-294, LigRecConv :89-217) and
+ * the decoder.  Constructor fields mirror LigRecDynamics.__init__ (:300-340).
+ * ------------------------------------------------------------------------------------- */
+typedef struct kpd_egnn_config {
+    int32_t atom_nf, rec_nf;
+    int32_t n_layers, hidden_nf;       /* hidden_nf must be 256 (every shipped config)   */
+    int32_t use_tanh, norm, update_kp_feat;
+    float message_norm;                /* 0 => per-graph average in-degree + 1           */
+    int32_t ll_k, kl_k;                /* ll_k must be 0 (radius graph); kl_k in 1..16   */
+    float ll_cutoff, kl_cutoff;
+    float coords_range;                /* 10 in the reference (dynamics.py:15)           */
+} kpd_egnn_config;
+
+typedef struct kpd_egnn kpd_egnn;
+
+kpd_status kpd_egnn_create(const kpd_egnn_config *cfg, kpd_egnn **out);
+void kpd_egnn_destroy(kpd_egnn *m);
+/* One state-dict tensor of the reference `dynamics` module, by its reference name
+ * (e.g. "egnn.conv_layers.3.edge_mlp.kl.2.weight"); repacked on device for the kernels. */
+kpd_status kpd_egnn_load_weight(kpd_egnn *m, const char *name, const float *w_dev,
+                                const int64_t *shape, int32_t ndim, void *stream);
+kpd_status kpd_egnn_commit(kpd_egnn *m);          /* checks every tensor was loaded        */
+/* Allocate workspace for batches up to these sizes (grow-only; not stream-ordered). */
+kpd_status kpd_egnn_reserve(kpd_egnn *m, int32_t max_B, int32_t max_n_lig, int32_t max_n_kp,
+                            int32_t max_n_kk, int32_t max_lig_per_graph, int32_t max_kp_per_graph);
+/* eps_h [n_lig, atom_nf], eps_x [n_lig, 3];  t [B] in (0,1]. */
+kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *batch, const float *t_dev,
+                            float *eps_h_dev, float *eps_x_dev, void *stream);
+/* Debug/test taps: copy of the node state after `layer` (h [n,257] with row stride 264). */
+kpd_status kpd_egnn_debug_state(kpd_egnn *m, const char *what, float *out_dev, int64_t n_floats,
+                                void *stream);
+/* Launch geometry of the last forward: {E_ll, E_kl, E_lk, E_kk, edge tiles}. */
+kpd_status kpd_egnn_last_counts(kpd_egnn *m, int32_t out[8], void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Reverse-diffusion update around the denoiser.  Replaces the elementwise part of
+ * KeypointDiffusion.sample_p_zs_given_zt (models/ligand_diffuser.py:515-536):
+ *   z_s = z_t / alpha_ts - var_terms * eps + sigma * noise, then ligand-COM removal from
+ *   ligand and keypoints (remove_com :185-203).  coef [B,3] = {1/alpha_ts, var_terms, sigma}.
+ * Updates lig_x, lig_h, kp_x in place.
+ * ------------------------------------------------------------------------------------- */
+kpd_status kpd_sample_update(int32_t B, const int32_t *lig_ptr, const int32_t *kp_ptr,
+                             int32_t atom_nf, float *lig_x, float *lig_h, float *kp_x,
+                             const float *eps_x, const float *eps_h,
+                             const float *noise_x, const float *noise_h,
+                             const float *coef, int32_t max_lig, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KPD_H */

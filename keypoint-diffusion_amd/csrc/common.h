@@ -1,0 +1,46 @@
+// Shared host/device helpers for libkpd_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/kpd.h"
+
+namespace kpd {
+
+void set_error(const char *fmt, ...);
+
+#define KPD_HIP(call)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            kpd::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+            return KPD_ERR_HIP;                                                                \
+        }                                                                                      \
+    } while (0)
+
+#define KPD_REQUIRE(cond, code, ...)        \
+    do {                                    \
+        if (!(cond)) {                      \
+            kpd::set_error(__VA_ARGS__);    \
+            return (code);                  \
+        }                                   \
+    } while (0)
+
+#define KPD_LAUNCH_CHECK() KPD_HIP(hipGetLastError())
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- geometry of the fp32-MFMA row-tile kernels ------------------------------------------
+constexpr int TM = 64;        // rows (edges or nodes) per workgroup tile
+constexpr int HID = 256;      // hidden_nf
+constexpr int HW = 257;       // hidden_nf + 1 (timestep column), the reference's layer width
+constexpr int HS = 264;       // row stride of width-257 arrays in HBM (floats, multiple of 8)
+constexpr int KP = 264;       // K of every GEMM, zero padded
+constexpr int NG = KP / 8;    // k-groups of 8 (4 MFMA k-steps of 2)
+constexpr int SA = 268;       // LDS row stride of the A / T tile (floats); 16-B aligned rows
+constexpr int WP_FLOATS = NG * 4 * 64 * 8;   // packed 256-column weight block
+constexpr int KL_KMAX = 16;   // largest supported kl_k
+
+}  // namespace kpd

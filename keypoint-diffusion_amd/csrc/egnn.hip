@@ -1,0 +1,536 @@
+// EGNN denoiser engine: weights, workspace and the per-call launch sequence behind the
+// kpd_egnn_* C ABI (include/kpd.h).  Replaces LigRecDynamics.forward
+// (models/dynamics.py:342-385) as a whole.
+#include <string.h>
+
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "egnn_kernels.h"
+
+using namespace kpd;
+
+namespace {
+
+struct LayerW {
+    // per edge type
+    float *wp_e[4], *wx_e[4], *b_e[4], *wr_e[4], *watt[4];
+    float *wp_c[4], *wx_c[4], *b_c[4], *wr_c[4], *w3[4];
+    // per node type, per projection slot
+    float *wp_p[2][NSLOT], *wx_p[2][NSLOT], *b_p[2][NSLOT];
+    // node MLP + LayerNorm per node type
+    float *wp_a[2], *wx_a[2], *wp_b[2], *wx_b[2], *b0[2], *wp_2[2], *wx_2[2], *b2[2], *ln_w[2], *ln_b[2];
+};
+
+const int kSrcNt[4] = {NT_LIG, NT_KP, NT_LIG, NT_KP};
+const int kDstNt[4] = {NT_LIG, NT_LIG, NT_KP, NT_KP};
+const int kSrcSlot[4] = {0, 0, 6, 4};
+const int kDstSlot[4] = {2, 4, 2, 6};
+const char *kEtName[4] = {"ll", "kl", "lk", "kk"};
+const char *kNtName[2] = {"lig", "kp"};
+
+std::vector<std::string> split(const std::string &s, char c) {
+    std::vector<std::string> out;
+    size_t p = 0;
+    while (true) {
+        size_t q = s.find(c, p);
+        out.push_back(s.substr(p, q == std::string::npos ? q : q - p));
+        if (q == std::string::npos) break;
+        p = q + 1;
+    }
+    return out;
+}
+
+int et_index(const std::string &s) {
+    for (int i = 0; i < 4; ++i)
+        if (s == kEtName[i]) return i;
+    return -1;
+}
+int nt_index(const std::string &s) {
+    for (int i = 0; i < 2; ++i)
+        if (s == kNtName[i]) return i;
+    return -1;
+}
+
+}  // namespace
+
+struct kpd_egnn {
+    kpd_egnn_config cfg;
+    int n_et;                 // 2 or 4 active edge types
+    int n_upd;                // 1 or 2 updated node types
+    bool rec_identity;
+    Arena warena, ws;
+    std::vector<LayerW> L;
+    // encoders / decoder
+    float *le_W0, *le_b0, *le_W1t, *le_b1;
+    float *re_W0, *re_b0, *re_W1t, *re_b1;
+    float *de_W0, *de_b0, *de_W1, *de_b1;
+    std::set<std::string> expected, loaded;
+    bool committed = false;
+    int debug_layers = -1;
+
+    // workspace (valid after reserve)
+    int cap_B = 0, cap_lig = 0, cap_kp = 0, cap_kk = 0, cap_ll = 0, cap_kl = 0, cap_maxlig = 0, cap_maxkp = 0;
+    int tile_cap = 0, tiles_et_cap[4] = {0, 0, 0, 0};
+    float *h[2], *x[2], *P[2];
+    float *hn_main[4], *hn_cont[4], *xn_main[4], *xn_cont[4];
+    int *bidx[2];
+    float *z[2];
+    int *meta, *ll_deg, *ll_off, *kl_off;
+    kpd_lig_graph lg;
+};
+
+static kpd_status build_weight_arena(kpd_egnn *m) {
+    const kpd_egnn_config &c = m->cfg;
+    const size_t wpB = (size_t)WP_FLOATS * 4 + 256, vB = (size_t)HS * 4 + 256;
+    const int n_gemm_layer = m->n_et * 2 + 16 + m->n_upd * 3;
+    size_t bytes = (size_t)c.n_layers * (n_gemm_layer * (wpB + vB) + (m->n_et * 6 + 16 + m->n_upd * 4) * vB);
+    bytes += (size_t)(64 * c.atom_nf + 64 + 64 * 256 + 256 + 2 * c.rec_nf * c.rec_nf + 2 * c.rec_nf +
+                      2 * c.rec_nf * 256 + 256 + 2 * c.atom_nf * 256 + 2 * c.atom_nf + 2 * c.atom_nf * c.atom_nf +
+                      c.atom_nf) * 4 + 64 * 256;
+    bytes += 1 << 20;
+    kpd_status st = m->warena.reserve(bytes);
+    if (st != KPD_OK) return st;
+    Arena &A = m->warena;
+    m->L.assign(c.n_layers, LayerW());
+    auto wp = [&]() { return A.take<float>(WP_FLOATS); };
+    auto vec = [&]() { return A.take<float>(HS); };
+    for (int i = 0; i < c.n_layers; ++i) {
+        LayerW &w = m->L[i];
+        memset(&w, 0, sizeof(w));
+        const std::string pre = "egnn.conv_layers." + std::to_string(i) + ".";
+        for (int et = 0; et < m->n_et; ++et) {
+            w.wp_e[et] = wp(); w.wx_e[et] = vec(); w.b_e[et] = vec(); w.wr_e[et] = vec(); w.watt[et] = vec();
+            w.wp_c[et] = wp(); w.wx_c[et] = vec(); w.b_c[et] = vec(); w.wr_c[et] = vec(); w.w3[et] = vec();
+            for (int var = 0; var < 2; ++var) {
+                const int ss = kSrcSlot[et] + var, ds = kDstSlot[et] + var;
+                w.wp_p[kSrcNt[et]][ss] = wp(); w.wx_p[kSrcNt[et]][ss] = vec();
+                w.wp_p[kDstNt[et]][ds] = wp(); w.wx_p[kDstNt[et]][ds] = vec(); w.b_p[kDstNt[et]][ds] = vec();
+            }
+            const std::string e = kEtName[et];
+            for (const char *blk : {"edge_mlp.", "coord_mlp."})
+                for (const char *s : {".0.weight", ".0.bias", ".2.weight", ".2.bias"}) m->expected.insert(pre + blk + e + s);
+            m->expected.insert(pre + "coord_mlp." + e + ".4.weight");
+            m->expected.insert(pre + "soft_attention." + e + ".0.weight");
+            m->expected.insert(pre + "soft_attention." + e + ".0.bias");
+        }
+        for (int nt = 0; nt < m->n_upd; ++nt) {
+            w.wp_a[nt] = wp(); w.wx_a[nt] = vec(); w.wp_b[nt] = wp(); w.wx_b[nt] = vec(); w.b0[nt] = vec();
+            w.wp_2[nt] = wp(); w.wx_2[nt] = vec(); w.b2[nt] = vec(); w.ln_w[nt] = vec(); w.ln_b[nt] = vec();
+            const std::string n = kNtName[nt];
+            for (const char *s : {".0.weight", ".0.bias", ".2.weight", ".2.bias"}) m->expected.insert(pre + "node_mlp." + n + s);
+            if (c.norm) {
+                m->expected.insert(pre + "layer_norm." + n + ".weight");
+                m->expected.insert(pre + "layer_norm." + n + ".bias");
+            }
+        }
+    }
+    m->le_W0 = A.take<float>(64 * c.atom_nf); m->le_b0 = A.take<float>(64);
+    m->le_W1t = A.take<float>(64 * 256); m->le_b1 = A.take<float>(256);
+    for (const char *s : {"lig_encoder.0.weight", "lig_encoder.0.bias", "lig_encoder.2.weight", "lig_encoder.2.bias",
+                          "lig_decoder.0.weight", "lig_decoder.0.bias", "lig_decoder.2.weight", "lig_decoder.2.bias"})
+        m->expected.insert(s);
+    if (!m->rec_identity) {
+        m->re_W0 = A.take<float>(2 * c.rec_nf * c.rec_nf); m->re_b0 = A.take<float>(2 * c.rec_nf);
+        m->re_W1t = A.take<float>(2 * c.rec_nf * 256); m->re_b1 = A.take<float>(256);
+        for (const char *s : {"rec_encoder.0.weight", "rec_encoder.0.bias", "rec_encoder.2.weight", "rec_encoder.2.bias"})
+            m->expected.insert(s);
+    } else {
+        m->re_W0 = m->re_b0 = m->re_W1t = m->re_b1 = nullptr;
+    }
+    m->de_W0 = A.take<float>(2 * c.atom_nf * 256); m->de_b0 = A.take<float>(2 * c.atom_nf);
+    m->de_W1 = A.take<float>(2 * c.atom_nf * c.atom_nf); m->de_b1 = A.take<float>(c.atom_nf);
+    KPD_REQUIRE(m->de_b1 != nullptr, KPD_ERR_HIP, "weight arena too small (internal sizing error)");
+    return KPD_OK;
+}
+
+extern "C" kpd_status kpd_egnn_create(const kpd_egnn_config *cfg, kpd_egnn **out) {
+    KPD_REQUIRE(cfg && out, KPD_ERR_INVALID, "null argument");
+    KPD_REQUIRE(cfg->hidden_nf == HID, KPD_ERR_INVALID, "hidden_nf=%d: the HIP path is built for hidden_nf=256", cfg->hidden_nf);
+    KPD_REQUIRE(cfg->ll_k == 0, KPD_ERR_INVALID, "ll_k=%d: only the radius lig-lig graph (ll_k=0) is implemented", cfg->ll_k);
+    KPD_REQUIRE(cfg->kl_k >= 1 && cfg->kl_k <= KL_KMAX, KPD_ERR_INVALID,
+                "kl_k=%d: only the kNN keypoint->ligand graph with 1 <= k <= %d is implemented", cfg->kl_k, KL_KMAX);
+    KPD_REQUIRE(cfg->n_layers >= 1 && cfg->n_layers <= 64, KPD_ERR_INVALID, "n_layers=%d", cfg->n_layers);
+    KPD_REQUIRE(cfg->atom_nf >= 1 && cfg->atom_nf <= 32, KPD_ERR_INVALID, "atom_nf=%d outside 1..32", cfg->atom_nf);
+    KPD_REQUIRE(cfg->rec_nf >= 1 && (cfg->rec_nf <= 128 || cfg->rec_nf == 256), KPD_ERR_INVALID, "rec_nf=%d", cfg->rec_nf);
+    KPD_REQUIRE(cfg->message_norm >= 0.0f, KPD_ERR_INVALID, "message_norm=%f", cfg->message_norm);
+    kpd_status st = egnn_kernels_init();
+    if (st != KPD_OK) return st;
+    kpd_egnn *m = new kpd_egnn();
+    m->cfg = *cfg;
+    m->n_et = cfg->update_kp_feat ? 4 : 2;
+    m->n_upd = cfg->update_kp_feat ? 2 : 1;
+    m->rec_identity = cfg->rec_nf == cfg->hidden_nf;   // dynamics.py:326-334
+    st = build_weight_arena(m);
+    if (st != KPD_OK) {
+        kpd_egnn_destroy(m);
+        return st;
+    }
+    *out = m;
+    return KPD_OK;
+}
+
+extern "C" void kpd_egnn_destroy(kpd_egnn *m) {
+    if (!m) return;
+    m->warena.release();
+    m->ws.release();
+    delete m;
+}
+
+static kpd_status expect_shape(const char *name, const int64_t *shape, int ndim, std::initializer_list<int64_t> want) {
+    bool ok = ndim == (int)want.size();
+    int i = 0;
+    for (int64_t w : want) {
+        if (ok && shape[i] != w) ok = false;
+        ++i;
+    }
+    if (!ok) {
+        std::string got, exp;
+        for (int j = 0; j < ndim; ++j) got += std::to_string(shape[j]) + (j + 1 < ndim ? "," : "");
+        for (int64_t w : want) exp += std::to_string(w) + ",";
+        set_error("weight %s has shape [%s], expected [%s]", name, got.c_str(), exp.c_str());
+        return KPD_ERR_WEIGHTS;
+    }
+    return KPD_OK;
+}
+
+#define KPD_TRY(expr)                  \
+    do {                               \
+        kpd_status s_ = (expr);        \
+        if (s_ != KPD_OK) return s_;   \
+    } while (0)
+
+extern "C" kpd_status kpd_egnn_load_weight(kpd_egnn *m, const char *name, const float *w, const int64_t *shape,
+                                           int32_t ndim, void *stream) {
+    KPD_REQUIRE(m && name && w && shape, KPD_ERR_INVALID, "null argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const kpd_egnn_config &c = m->cfg;
+    const std::string nm(name);
+    if (!m->expected.count(nm)) {
+        set_error("unknown or unused weight name '%s' for this configuration", name);
+        return KPD_ERR_WEIGHTS;
+    }
+    const std::vector<std::string> tk = split(nm, '.');
+    const bool is_w = tk.back() == "weight";
+    if (tk[0] == "lig_encoder") {
+        if (tk[1] == "0") {
+            if (is_w) { KPD_TRY(expect_shape(name, shape, ndim, {64, c.atom_nf})); KPD_TRY(copy_pad(w, 64 * c.atom_nf, m->le_W0, 64 * c.atom_nf, st)); }
+            else { KPD_TRY(expect_shape(name, shape, ndim, {64})); KPD_TRY(copy_pad(w, 64, m->le_b0, 64, st)); }
+        } else {
+            if (is_w) { KPD_TRY(expect_shape(name, shape, ndim, {256, 64})); KPD_TRY(transpose2d(w, 256, 64, m->le_W1t, st)); }
+            else { KPD_TRY(expect_shape(name, shape, ndim, {256})); KPD_TRY(copy_pad(w, 256, m->le_b1, 256, st)); }
+        }
+    } else if (tk[0] == "rec_encoder") {
+        const int r = c.rec_nf;
+        if (tk[1] == "0") {
+            if (is_w) { KPD_TRY(expect_shape(name, shape, ndim, {2 * r, r})); KPD_TRY(copy_pad(w, 2 * r * r, m->re_W0, 2 * r * r, st)); }
+            else { KPD_TRY(expect_shape(name, shape, ndim, {2 * r})); KPD_TRY(copy_pad(w, 2 * r, m->re_b0, 2 * r, st)); }
+        } else {
+            if (is_w) { KPD_TRY(expect_shape(name, shape, ndim, {256, 2 * r})); KPD_TRY(transpose2d(w, 256, 2 * r, m->re_W1t, st)); }
+            else { KPD_TRY(expect_shape(name, shape, ndim, {256})); KPD_TRY(copy_pad(w, 256, m->re_b1, 256, st)); }
+        }
+    } else if (tk[0] == "lig_decoder") {
+        const int a = c.atom_nf;
+        if (tk[1] == "0") {
+            if (is_w) { KPD_TRY(expect_shape(name, shape, ndim, {2 * a, 256})); KPD_TRY(copy_pad(w, 2 * a * 256, m->de_W0, 2 * a * 256, st)); }
+            else { KPD_TRY(expect_shape(name, shape, ndim, {2 * a})); KPD_TRY(copy_pad(w, 2 * a, m->de_b0, 2 * a, st)); }
+        } else {
+            if (is_w) { KPD_TRY(expect_shape(name, shape, ndim, {a, 2 * a})); KPD_TRY(copy_pad(w, 2 * a * a, m->de_W1, 2 * a * a, st)); }
+            else { KPD_TRY(expect_shape(name, shape, ndim, {a})); KPD_TRY(copy_pad(w, a, m->de_b1, a, st)); }
+        }
+    } else {
+        // egnn.conv_layers.<i>.<block>.<et|nt>.<idx>.<param>  |  egnn.conv_layers.<i>.layer_norm.<nt>.<param>
+        const int i = atoi(tk[2].c_str());
+        LayerW &L = m->L[i];
+        const std::string &blk = tk[3];
+        if (blk == "layer_norm") {
+            const int nt = nt_index(tk[4]);
+            KPD_TRY(expect_shape(name, shape, ndim, {HW}));
+            KPD_TRY(copy_pad(w, HW, is_w ? L.ln_w[nt] : L.ln_b[nt], HS, st));
+        } else if (blk == "node_mlp") {
+            const int nt = nt_index(tk[4]);
+            if (tk[5] == "0") {
+                if (is_w) {
+                    KPD_TRY(expect_shape(name, shape, ndim, {HW, 2 * HW}));
+                    KPD_TRY(pack_gemm_weight(w, HW, 2 * HW, 0, HW, L.wp_a[nt], L.wx_a[nt], st));
+                    KPD_TRY(pack_gemm_weight(w, HW, 2 * HW, HW, HW, L.wp_b[nt], L.wx_b[nt], st));
+                } else {
+                    KPD_TRY(expect_shape(name, shape, ndim, {HW}));
+                    KPD_TRY(copy_pad(w, HW, L.b0[nt], HS, st));
+                }
+            } else {
+                if (is_w) {
+                    KPD_TRY(expect_shape(name, shape, ndim, {HW, HW}));
+                    KPD_TRY(pack_gemm_weight(w, HW, HW, 0, HW, L.wp_2[nt], L.wx_2[nt], st));
+                } else {
+                    KPD_TRY(expect_shape(name, shape, ndim, {HW}));
+                    KPD_TRY(copy_pad(w, HW, L.b2[nt], HS, st));
+                }
+            }
+        } else if (blk == "soft_attention") {
+            const int et = et_index(tk[4]);
+            if (is_w) {
+                KPD_TRY(expect_shape(name, shape, ndim, {1, HW}));
+                KPD_TRY(copy_pad(w, HW, L.watt[et], ATT_BIAS_AT, st));     // keeps [260] (bias) intact
+            } else {
+                KPD_TRY(expect_shape(name, shape, ndim, {1}));
+                KPD_TRY(copy_pad(w, 1, L.watt[et] + ATT_BIAS_AT, 1, st));
+            }
+        } else {   // edge_mlp / coord_mlp
+            const int var = blk == "coord_mlp" ? 1 : 0;
+            const int et = et_index(tk[4]);
+            const int snt = kSrcNt[et], dnt = kDstNt[et], ss = kSrcSlot[et] + var, ds = kDstSlot[et] + var;
+            if (tk[5] == "0") {
+                if (is_w) {
+                    KPD_TRY(expect_shape(name, shape, ndim, {HW, 2 * HW + 1}));
+                    const int ld = 2 * HW + 1;
+                    KPD_TRY(pack_gemm_weight(w, HW, ld, 0, HW, L.wp_p[snt][ss], L.wx_p[snt][ss], st));
+                    KPD_TRY(pack_gemm_weight(w, HW, ld, HW, HW, L.wp_p[dnt][ds], L.wx_p[dnt][ds], st));
+                    KPD_TRY(copy_col_pad(w, HW, ld, 2 * HW, var ? L.wr_c[et] : L.wr_e[et], HS, st));
+                } else {
+                    KPD_TRY(expect_shape(name, shape, ndim, {HW}));
+                    KPD_TRY(copy_pad(w, HW, L.b_p[dnt][ds], HS, st));
+                }
+            } else if (tk[5] == "2") {
+                if (is_w) {
+                    KPD_TRY(expect_shape(name, shape, ndim, {HW, HW}));
+                    KPD_TRY(pack_gemm_weight(w, HW, HW, 0, HW, var ? L.wp_c[et] : L.wp_e[et], var ? L.wx_c[et] : L.wx_e[et], st));
+                } else {
+                    KPD_TRY(expect_shape(name, shape, ndim, {HW}));
+                    KPD_TRY(copy_pad(w, HW, var ? L.b_c[et] : L.b_e[et], HS, st));
+                }
+            } else {   // coord_mlp.<et>.4.weight
+                KPD_TRY(expect_shape(name, shape, ndim, {1, HW}));
+                KPD_TRY(copy_pad(w, HW, L.w3[et], HS, st));
+            }
+        }
+    }
+    m->loaded.insert(nm);
+    m->committed = false;
+    return KPD_OK;
+}
+
+extern "C" kpd_status kpd_egnn_commit(kpd_egnn *m) {
+    KPD_REQUIRE(m, KPD_ERR_INVALID, "null handle");
+    for (const std::string &n : m->expected)
+        if (!m->loaded.count(n)) {
+            set_error("weight '%s' was never loaded (%zu of %zu loaded)", n.c_str(), m->loaded.size(), m->expected.size());
+            return KPD_ERR_WEIGHTS;
+        }
+    m->committed = true;
+    return KPD_OK;
+}
+
+extern "C" kpd_status kpd_egnn_reserve(kpd_egnn *m, int32_t max_B, int32_t max_n_lig, int32_t max_n_kp, int32_t max_n_kk,
+                                       int32_t max_lig_pg, int32_t max_kp_pg) {
+    KPD_REQUIRE(m, KPD_ERR_INVALID, "null handle");
+    KPD_REQUIRE(max_B >= 1 && max_n_lig >= 1 && max_n_kp >= 1 && max_n_kk >= 0 && max_lig_pg >= 1 && max_kp_pg >= 1,
+                KPD_ERR_INVALID, "reserve: non-positive size");
+    if (max_B <= m->cap_B && max_n_lig <= m->cap_lig && max_n_kp <= m->cap_kp && max_n_kk <= m->cap_kk &&
+        max_lig_pg <= m->cap_maxlig && max_kp_pg <= m->cap_maxkp)
+        return KPD_OK;
+    max_B = std::max(max_B, m->cap_B); max_n_lig = std::max(max_n_lig, m->cap_lig); max_n_kp = std::max(max_n_kp, m->cap_kp);
+    max_n_kk = std::max(max_n_kk, m->cap_kk); max_lig_pg = std::max(max_lig_pg, m->cap_maxlig); max_kp_pg = std::max(max_kp_pg, m->cap_maxkp);
+    const long cap_ll_l = (long)max_n_lig * std::min(max_lig_pg - 1, 200);
+    const long cap_kl_l = (long)max_n_kp * m->cfg.kl_k;
+    KPD_REQUIRE(cap_ll_l < (1l << 30) && cap_kl_l < (1l << 30), KPD_ERR_CAPACITY, "edge capacity overflows int32");
+    const int cap_ll = std::max<long>(cap_ll_l, 1), cap_kl = std::max<long>(cap_kl_l, 1);
+    const int E_cap[4] = {cap_ll, cap_kl, cap_kl, std::max(max_n_kk, 1)};
+    int tiles[4], tile_cap = 0;
+    for (int et = 0; et < 4; ++et) {
+        tiles[et] = cdiv(E_cap[et], TM) + 1;
+        tile_cap += tiles[et];
+    }
+    const int n[2] = {max_n_lig, max_n_kp};
+    size_t bytes = 1 << 20;
+    auto add = [&](size_t cnt, size_t sz) { bytes += ((cnt * sz + 255) & ~size_t(255)); };
+    for (int nt = 0; nt < 2; ++nt) {
+        add((size_t)n[nt] * HS, 4); add((size_t)n[nt] * 3, 4); add((size_t)n[nt] * NSLOT * HS, 4);
+        add(n[nt], 4); add(max_B, 4);
+    }
+    for (int et = 0; et < 4; ++et) {
+        add((size_t)n[kDstNt[et]] * HS, 4); add((size_t)tiles[et] * HS, 4);
+        add((size_t)n[kDstNt[et]] * 4, 4); add((size_t)tiles[et] * 4, 4);
+    }
+    add(16, 4); add(max_n_lig, 4); add(max_B + 1, 4); add(max_B + 1, 4);
+    add(cap_ll, 4); add(cap_ll, 4); add(max_n_lig + 1, 4);
+    for (int i = 0; i < 4; ++i) add(cap_kl, 4);
+    add(max_n_lig + 1, 4); add(max_n_kp + 1, 4); add(max_B, 4); add(8, 4);
+    KPD_TRY(m->ws.reserve(bytes));
+    Arena &W = m->ws;
+    for (int nt = 0; nt < 2; ++nt) {
+        m->h[nt] = W.take<float>((size_t)n[nt] * HS);
+        m->x[nt] = W.take<float>((size_t)n[nt] * 3);
+        m->P[nt] = W.take<float>((size_t)n[nt] * NSLOT * HS);
+        m->bidx[nt] = W.take<int>(n[nt]);
+        m->z[nt] = W.take<float>(max_B);
+    }
+    for (int et = 0; et < 4; ++et) {
+        m->hn_main[et] = W.take<float>((size_t)n[kDstNt[et]] * HS);
+        m->hn_cont[et] = W.take<float>((size_t)tiles[et] * HS);
+        m->xn_main[et] = W.take<float>((size_t)n[kDstNt[et]] * 4);
+        m->xn_cont[et] = W.take<float>((size_t)tiles[et] * 4);
+        m->tiles_et_cap[et] = tiles[et];
+    }
+    m->meta = W.take<int>(16);
+    m->ll_deg = W.take<int>(max_n_lig);
+    m->ll_off = W.take<int>(max_B + 1);
+    m->kl_off = W.take<int>(max_B + 1);
+    kpd_lig_graph &g = m->lg;
+    g.cap_ll = cap_ll; g.cap_kl = cap_kl;
+    g.ll_src = W.take<int>(cap_ll); g.ll_dst = W.take<int>(cap_ll); g.ll_rowptr = W.take<int>(max_n_lig + 1);
+    g.kl_src = W.take<int>(cap_kl); g.kl_dst = W.take<int>(cap_kl); g.kl_rowptr = W.take<int>(max_n_lig + 1);
+    g.lk_src = W.take<int>(cap_kl); g.lk_dst = W.take<int>(cap_kl); g.lk_rowptr = W.take<int>(max_n_kp + 1);
+    g.ll_per_graph = W.take<int>(max_B);
+    g.counts = W.take<int>(8);
+    KPD_REQUIRE(g.counts != nullptr, KPD_ERR_HIP, "workspace arena too small (internal sizing error)");
+    m->cap_B = max_B; m->cap_lig = max_n_lig; m->cap_kp = max_n_kp; m->cap_kk = max_n_kk;
+    m->cap_ll = cap_ll; m->cap_kl = cap_kl; m->cap_maxlig = max_lig_pg; m->cap_maxkp = max_kp_pg;
+    m->tile_cap = tile_cap;
+    return KPD_OK;
+}
+
+extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const float *t_dev, float *eps_h, float *eps_x,
+                                       void *stream) {
+    KPD_REQUIRE(m && bt && t_dev && eps_h && eps_x, KPD_ERR_INVALID, "null argument");
+    KPD_REQUIRE(m->committed, KPD_ERR_STATE, "kpd_egnn_forward before kpd_egnn_commit");
+    KPD_REQUIRE(bt->B >= 1 && bt->n_lig >= 1 && bt->n_kp >= 1, KPD_ERR_INVALID, "empty batch (B=%d n_lig=%d n_kp=%d)", bt->B, bt->n_lig, bt->n_kp);
+    KPD_REQUIRE(bt->B <= m->cap_B && bt->n_lig <= m->cap_lig && bt->n_kp <= m->cap_kp && bt->n_kk <= m->cap_kk &&
+                    bt->max_lig <= m->cap_maxlig && bt->max_kp <= m->cap_maxkp,
+                KPD_ERR_CAPACITY, "batch (B=%d lig=%d kp=%d kk=%d maxlig=%d maxkp=%d) exceeds reserved workspace (%d %d %d %d %d %d)",
+                bt->B, bt->n_lig, bt->n_kp, bt->n_kk, bt->max_lig, bt->max_kp, m->cap_B, m->cap_lig, m->cap_kp, m->cap_kk,
+                m->cap_maxlig, m->cap_maxkp);
+    KPD_REQUIRE(!m->cfg.update_kp_feat || bt->n_kk == 0 || (bt->kk_src && bt->kk_dst), KPD_ERR_INVALID, "kk edges missing");
+    KPD_REQUIRE(bt->kk_rowptr, KPD_ERR_INVALID, "kk_rowptr missing");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const kpd_egnn_config &c = m->cfg;
+
+    KPD_HIP(hipMemcpyAsync(m->x[NT_LIG], bt->lig_x, (size_t)bt->n_lig * 12, hipMemcpyDeviceToDevice, st));
+    KPD_HIP(hipMemcpyAsync(m->x[NT_KP], bt->kp_x, (size_t)bt->n_kp * 12, hipMemcpyDeviceToDevice, st));
+    KPD_TRY(launch_node_graph_index(bt->lig_ptr, bt->B, bt->n_lig, m->bidx[NT_LIG], st));
+    KPD_TRY(launch_node_graph_index(bt->kp_ptr, bt->B, bt->n_kp, m->bidx[NT_KP], st));
+    KPD_TRY(launch_lig_graph(bt, c.ll_cutoff, c.kl_k, &m->lg, m->ll_deg, m->ll_off, m->kl_off, st));
+    const int active = c.update_kp_feat ? 0xF : 0x3;
+    KPD_TRY(launch_egnn_meta(m->lg.counts, bt->n_kk, active, bt->lig_ptr, bt->kp_ptr, m->lg.ll_per_graph, bt->kk_rowptr,
+                             bt->B, c.kl_k, c.message_norm, c.update_kp_feat, m->meta, m->z[NT_LIG], m->z[NT_KP], st));
+    KPD_TRY(launch_embed(bt->lig_h, bt->n_lig, c.atom_nf, m->le_W0, m->le_b0, 64, m->le_W1t, m->le_b1, t_dev,
+                         m->bidx[NT_LIG], m->h[NT_LIG], 0, st));
+    KPD_TRY(launch_embed(bt->kp_h, bt->n_kp, c.rec_nf, m->re_W0, m->re_b0, 2 * c.rec_nf, m->re_W1t, m->re_b1, t_dev,
+                         m->bidx[NT_KP], m->h[NT_KP], m->rec_identity ? 1 : 0, st));
+
+    // tile capacity for this batch (host-known upper bound; the kernel exits early past the device-side total)
+    const int E_cap[4] = {std::max<int>((long)bt->n_lig * std::min(bt->max_lig - 1, 200), 1), bt->n_kp * c.kl_k,
+                          bt->n_kp * c.kl_k, bt->n_kk};
+    int tile_cap = 0;
+    for (int et = 0; et < m->n_et; ++et) tile_cap += cdiv(E_cap[et], TM);
+
+    const int n[2] = {bt->n_lig, bt->n_kp};
+    const int *esrc[4] = {m->lg.ll_src, m->lg.kl_src, m->lg.lk_src, bt->kk_src};
+    const int *edst[4] = {m->lg.ll_dst, m->lg.kl_dst, m->lg.lk_dst, bt->kk_dst};
+    const int *rowptr[4] = {m->lg.ll_rowptr, m->lg.kl_rowptr, m->lg.lk_rowptr, bt->kk_rowptr};
+    const int n_layers = m->debug_layers >= 0 ? std::min(m->debug_layers, c.n_layers) : c.n_layers;
+
+    for (int li = 0; li < n_layers; ++li) {
+        const LayerW &L = m->L[li];
+        for (int nt = 0; nt < 2; ++nt) {
+            ProjArgs pa;
+            memset(&pa, 0, sizeof(pa));
+            pa.h = m->h[nt]; pa.n = n[nt]; pa.P = m->P[nt];
+            int k = 0;
+            for (int s = 0; s < NSLOT; ++s)
+                if (L.wp_p[nt][s]) {
+                    pa.wp[k] = L.wp_p[nt][s]; pa.wx[k] = L.wx_p[nt][s]; pa.bias[k] = L.b_p[nt][s]; pa.slot[k] = s;
+                    ++k;
+                }
+            KPD_TRY(launch_node_proj(pa, k, st));
+        }
+        EdgeArgs ea;
+        memset(&ea, 0, sizeof(ea));
+        ea.meta = m->meta;
+        ea.x[0] = m->x[0]; ea.x[1] = m->x[1]; ea.P[0] = m->P[0]; ea.P[1] = m->P[1];
+        ea.use_tanh = c.use_tanh; ea.coords_range = c.coords_range;
+        for (int et = 0; et < 4; ++et) {
+            ea.src[et] = esrc[et]; ea.dst[et] = edst[et];
+            ea.src_nt[et] = kSrcNt[et]; ea.dst_nt[et] = kDstNt[et]; ea.src_slot[et] = kSrcSlot[et]; ea.dst_slot[et] = kDstSlot[et];
+            ea.wr_e[et] = L.wr_e[et]; ea.wr_c[et] = L.wr_c[et];
+            ea.wp_e[et] = L.wp_e[et]; ea.wx_e[et] = L.wx_e[et]; ea.b_e[et] = L.b_e[et];
+            ea.wp_c[et] = L.wp_c[et]; ea.wx_c[et] = L.wx_c[et]; ea.b_c[et] = L.b_c[et];
+            ea.watt[et] = L.watt[et]; ea.w3[et] = L.w3[et];
+            ea.hn_main[et] = m->hn_main[et]; ea.hn_cont[et] = m->hn_cont[et];
+            ea.xn_main[et] = m->xn_main[et]; ea.xn_cont[et] = m->xn_cont[et];
+        }
+        KPD_TRY(launch_egnn_edge(ea, tile_cap, st));
+        for (int nt = 0; nt < m->n_upd; ++nt) {
+            NodeArgs na;
+            memset(&na, 0, sizeof(na));
+            na.n = n[nt]; na.h = m->h[nt]; na.x = m->x[nt]; na.bidx = m->bidx[nt]; na.z = m->z[nt];
+            int k = 0;
+            for (int et = 0; et < m->n_et; ++et)
+                if (kDstNt[et] == nt) {
+                    na.rowptr[k] = rowptr[et];
+                    na.hn_main[k] = m->hn_main[et]; na.hn_cont[k] = m->hn_cont[et];
+                    na.xn_main[k] = m->xn_main[et]; na.xn_cont[k] = m->xn_cont[et];
+                    ++k;
+                }
+            na.n_in = k;
+            na.wp_a = L.wp_a[nt]; na.wx_a = L.wx_a[nt]; na.wp_b = L.wp_b[nt]; na.wx_b = L.wx_b[nt]; na.b0 = L.b0[nt];
+            na.wp_2 = L.wp_2[nt]; na.wx_2 = L.wx_2[nt]; na.b2 = L.b2[nt]; na.ln_w = L.ln_w[nt]; na.ln_b = L.ln_b[nt];
+            na.norm = c.norm;
+            KPD_TRY(launch_node_update(na, st));
+        }
+    }
+    KPD_TRY(launch_decode(m->h[NT_LIG], m->x[NT_LIG], bt->lig_x, bt->n_lig, c.atom_nf, 2 * c.atom_nf, m->de_W0, m->de_b0,
+                          m->de_W1, m->de_b1, eps_h, eps_x, st));
+    return KPD_OK;
+}
+
+extern "C" kpd_status kpd_egnn_debug_state(kpd_egnn *m, const char *what, float *out, int64_t n_floats, void *stream) {
+    KPD_REQUIRE(m && what && out, KPD_ERR_INVALID, "null argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const std::string w(what);
+    const float *src = nullptr;
+    if (w == "h_lig") src = m->h[0];
+    else if (w == "h_kp") src = m->h[1];
+    else if (w == "x_lig") src = m->x[0];
+    else if (w == "x_kp") src = m->x[1];
+    else if (w == "z_lig") src = m->z[0];
+    else if (w == "z_kp") src = m->z[1];
+    else if (w.rfind("layers=", 0) == 0) {
+        m->debug_layers = atoi(w.c_str() + 7);
+        return KPD_OK;
+    }
+    KPD_REQUIRE(src, KPD_ERR_INVALID, "unknown debug tap '%s'", what);
+    KPD_HIP(hipMemcpyAsync(out, src, (size_t)n_floats * 4, hipMemcpyDeviceToDevice, st));
+    return KPD_OK;
+}
+
+extern "C" kpd_status kpd_egnn_last_counts(kpd_egnn *m, int32_t out[8], void *stream) {
+    KPD_REQUIRE(m && out && m->ws.base, KPD_ERR_INVALID, "null argument or no workspace");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int host[9];
+    KPD_HIP(hipMemcpyAsync(host, m->meta, sizeof(host), hipMemcpyDeviceToHost, st));
+    KPD_HIP(hipStreamSynchronize(st));
+    for (int i = 0; i < 4; ++i) out[i] = host[i];
+    out[4] = host[8];
+    out[5] = out[6] = out[7] = 0;
+    return KPD_OK;
+}
+
+extern "C" kpd_status kpd_build_lig_graph(const kpd_batch *bt, float ll_cutoff, int32_t kl_k, const kpd_lig_graph *out,
+                                          void *stream) {
+    KPD_REQUIRE(bt && out, KPD_ERR_INVALID, "null argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // scratch: carve from a small per-call allocation (this entry point is for tests and
+    // standalone use; the engines use their own workspace and never allocate per call)
+    int *tmp = nullptr;
+    const size_t cnt = (size_t)bt->n_lig + 2 * ((size_t)bt->B + 1);
+    KPD_HIP(hipMalloc(reinterpret_cast<void **>(&tmp), cnt * sizeof(int)));
+    kpd_status s = launch_lig_graph(bt, ll_cutoff, kl_k, out, tmp, tmp + bt->n_lig, tmp + bt->n_lig + bt->B + 1, st);
+    hipError_t e = hipStreamSynchronize(st);
+    (void)hipFree(tmp);
+    if (s != KPD_OK) return s;
+    KPD_HIP(e);
+    return KPD_OK;
+}

@@ -1,0 +1,73 @@
+// Argument blocks and launchers of the EGNN kernels (egnn_kernels.hip).
+#pragma once
+#include "engine.h"
+
+namespace kpd {
+
+constexpr int NSLOT = 8;            // projection slots per node row of P
+constexpr int ATT_BIAS_AT = 260;    // soft_attention bias is parked in the pad of its weight row
+constexpr int ET_LL = 0, ET_KL = 1, ET_LK = 2, ET_KK = 3;
+constexpr int NT_LIG = 0, NT_KP = 1;
+
+constexpr int PROJ_LDS_BYTES = TM * SA * 4;
+constexpr int EDGE_LDS_BYTES = TM * SA * 4 + (TM * 2 + TM + 3 * TM + TM + 3 * TM + 4) * 4;
+constexpr int NODE_LDS_BYTES = TM * SA * 4 + 3 * TM * 4;
+
+struct ProjArgs {
+    const float *h;                 // [n][HS]
+    int n;
+    float *P;                       // [n][NSLOT][HS]
+    const float *wp[NSLOT];
+    const float *wx[NSLOT];
+    const float *bias[NSLOT];       // nullptr for src slots
+    int slot[NSLOT];
+};
+
+struct EdgeArgs {
+    const int *meta;                // [9] device: E[4], first tile[5]
+    const int *src[4];
+    const int *dst[4];
+    const float *x[2];              // current coordinates [n][3]: lig, kp
+    const float *P[2];
+    int src_nt[4], dst_nt[4], src_slot[4], dst_slot[4];
+    const float *wr_e[4], *wr_c[4];
+    const float *wp_e[4], *wx_e[4], *b_e[4];
+    const float *wp_c[4], *wx_c[4], *b_c[4];
+    const float *watt[4];
+    const float *w3[4];
+    float *hn_main[4], *hn_cont[4];
+    float *xn_main[4], *xn_cont[4];
+    int use_tanh;
+    float coords_range;
+};
+
+struct NodeArgs {
+    int n;
+    float *h;                       // [n][HS] in/out
+    float *x;                       // [n][3] in/out
+    const int *bidx;
+    const float *z;                 // [B]
+    int n_in;
+    const int *rowptr[2];
+    const float *hn_main[2], *hn_cont[2];
+    const float *xn_main[2], *xn_cont[2];
+    const float *wp_a, *wx_a, *wp_b, *wx_b, *b0;
+    const float *wp_2, *wx_2, *b2;
+    const float *ln_w, *ln_b;
+    int norm;
+};
+
+kpd_status egnn_kernels_init();
+kpd_status launch_node_graph_index(const int *ptr, int B, int n, int *bidx, hipStream_t st);
+kpd_status launch_egnn_meta(const int *counts, int e_kk, int active_mask, const int *lig_ptr, const int *kp_ptr,
+                            const int *ll_per_graph, const int *kk_rowptr, int B, int kl_k, float message_norm,
+                            int update_kp, int *meta, float *z_lig, float *z_kp, hipStream_t st);
+kpd_status launch_embed(const float *in, int n, int fin, const float *W0, const float *b0, int hid, const float *W1t,
+                        const float *b1, const float *t, const int *bidx, float *out, int identity, hipStream_t st);
+kpd_status launch_decode(const float *h, const float *x, const float *x0, int n, int atom_nf, int hid, const float *W0,
+                         const float *b0, const float *W1, const float *b1, float *eps_h, float *eps_x, hipStream_t st);
+kpd_status launch_node_proj(const ProjArgs &a, int n_slots, hipStream_t st);
+kpd_status launch_egnn_edge(const EdgeArgs &a, int tile_cap, hipStream_t st);
+kpd_status launch_node_update(const NodeArgs &a, hipStream_t st);
+
+}  // namespace kpd

@@ -1,0 +1,612 @@
+// EGNN denoiser kernels (LigRecDynamics, models/dynamics.py:9-385) for gfx950.
+//
+// Per layer (LigRecConv.forward, dynamics.py:124-207) three kernels run:
+//   k_node_proj   P[node][slot] = W1[:, h-part] . h[node] (+ b1 on dst slots)
+//                 -- the first Linear(515, 257) of edge_mlp / coord_mlp is linear in
+//                    [h_src, h_dst, d_ij], so its two 257-wide blocks are applied once per
+//                    NODE instead of once per EDGE (3x fewer edge FLOPs);
+//   k_egnn_edge   per tile of 64 same-type edges (dst-sorted): gather P_src + P_dst + d*w_r,
+//                 SiLU, the 257x257 second Linear on fp32 MFMA, SiLU, soft attention,
+//                 coordinate head, and the segmented sum over destination nodes -- all in
+//                 one workgroup, intermediates never leave LDS/registers;
+//   k_node_update h' = LN(h + node_mlp([h, h_neigh / z])), x' = x + x_neigh / z.
+// Segment pieces: a tile writes the sum of each run of equal dst either to main[dst]
+// (run starts the segment) or to cont[tile] (run continues a segment begun in an earlier
+// tile); k_node_update adds main + cont pieces in tile order => deterministic, no atomics.
+#include "egnn_kernels.h"
+#include "mfma_core.h"
+
+namespace kpd {
+
+// ---- small helpers ------------------------------------------------------------------------
+__global__ void k_node_graph_index(const int *__restrict__ ptr, int B, int n, int *__restrict__ bidx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int lo = 0, hi = B;                       // largest b with ptr[b] <= i
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (ptr[mid] <= i) lo = mid; else hi = mid;
+    }
+    bidx[i] = lo;
+}
+
+// meta layout: [0..3] E per etype (ll, kl, lk, kk), [4..8] first tile of each etype (+total).
+// z: per-graph message normaliser (dynamics.py:277-285).
+__global__ void k_egnn_meta(const int *__restrict__ counts, int e_kk, int active_mask, const int *__restrict__ lig_ptr,
+                            const int *__restrict__ kp_ptr, const int *__restrict__ ll_per_graph,
+                            const int *__restrict__ kk_rowptr, int B, int kl_k, float message_norm, int update_kp,
+                            int *__restrict__ meta, float *__restrict__ z_lig, float *__restrict__ z_kp) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int E[4] = {counts[0], counts[1], counts[1], e_kk};
+        int run = 0;
+        for (int et = 0; et < 4; ++et) {
+            if (!((active_mask >> et) & 1)) E[et] = 0;
+            meta[et] = E[et];
+            meta[4 + et] = run;
+            run += (E[et] + TM - 1) / TM;
+        }
+        meta[8] = run;
+    }
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
+        const int nl = lig_ptr[b + 1] - lig_ptr[b], nk = kp_ptr[b + 1] - kp_ptr[b];
+        if (message_norm == 0.0f) {
+            const int e_kl = nk * min(kl_k, nl);
+            const int e_kk_b = kk_rowptr[kp_ptr[b + 1]] - kk_rowptr[kp_ptr[b]];
+            z_lig[b] = (float)(ll_per_graph[b] + e_kl) / (float)nl + 1.0f;
+            z_kp[b] = update_kp ? (float)(e_kl + e_kk_b) / (float)nk + 1.0f : 1.0f;
+        } else {
+            z_lig[b] = message_norm;
+            z_kp[b] = message_norm;
+        }
+    }
+}
+
+// ---- encoders (dynamics.py:313-318, 326-334, 355-363) -------------------------------------
+// out[node][0..255] = SiLU(W1 SiLU(W0 in + b0) + b1), out[node][256] = t[graph], pads 0.
+// W1t is stored transposed [hid][256] so that consecutive threads read consecutive floats.
+constexpr int EMB_NODES = 8;
+__global__ __launch_bounds__(256) void k_embed(const float *__restrict__ in, int n, int fin,
+                                               const float *__restrict__ W0, const float *__restrict__ b0, int hid,
+                                               const float *__restrict__ W1t, const float *__restrict__ b1,
+                                               const float *__restrict__ t, const int *__restrict__ bidx,
+                                               float *__restrict__ out, int identity) {
+    __shared__ float s_in[EMB_NODES][256];
+    __shared__ float s_hid[EMB_NODES][256];
+    const int node0 = blockIdx.x * EMB_NODES, tid = threadIdx.x;
+    for (int i = tid; i < EMB_NODES * fin; i += 256) {
+        const int j = i / fin, k = i - j * fin;
+        s_in[j][k] = node0 + j < n ? in[(size_t)(node0 + j) * fin + k] : 0.0f;
+    }
+    __syncthreads();
+    if (!identity) {
+        for (int u = tid; u < hid; u += 256) {
+            float a[EMB_NODES];
+#pragma unroll
+            for (int j = 0; j < EMB_NODES; ++j) a[j] = b0[u];
+            for (int k = 0; k < fin; ++k) {
+                const float w = W0[(size_t)u * fin + k];
+#pragma unroll
+                for (int j = 0; j < EMB_NODES; ++j) a[j] = fmaf(w, s_in[j][k], a[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < EMB_NODES; ++j) s_hid[j][u] = silu(a[j]);
+        }
+        __syncthreads();
+        float a[EMB_NODES];
+#pragma unroll
+        for (int j = 0; j < EMB_NODES; ++j) a[j] = b1[tid];
+        for (int u = 0; u < hid; ++u) {
+            const float w = W1t[(size_t)u * 256 + tid];
+#pragma unroll
+            for (int j = 0; j < EMB_NODES; ++j) a[j] = fmaf(w, s_hid[j][u], a[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < EMB_NODES; ++j)
+            if (node0 + j < n) out[(size_t)(node0 + j) * HS + tid] = silu(a[j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < EMB_NODES; ++j)
+            if (node0 + j < n) out[(size_t)(node0 + j) * HS + tid] = s_in[j][tid];
+    }
+    if (tid < EMB_NODES * 8) {
+        const int j = tid >> 3, c = tid & 7;
+        if (node0 + j < n) out[(size_t)(node0 + j) * HS + 256 + c] = c == 0 ? t[bidx[node0 + j]] : 0.0f;
+    }
+}
+
+// ---- decoder (dynamics.py:320-324, 376-381) -----------------------------------------------
+// One wave per ligand atom.  eps_h = W1 SiLU(W0 h[:256] + b0) + b1;  eps_x = x - x_0.
+__global__ __launch_bounds__(64) void k_decode(const float *__restrict__ h, const float *__restrict__ x,
+                                               const float *__restrict__ x0, int n, int atom_nf, int hid,
+                                               const float *__restrict__ W0, const float *__restrict__ b0,
+                                               const float *__restrict__ W1, const float *__restrict__ b1,
+                                               float *__restrict__ eps_h, float *__restrict__ eps_x) {
+    __shared__ float s_hid[64];
+    const int v = blockIdx.x, lane = threadIdx.x;
+    if (v >= n) return;
+    const f32x4 hv = *reinterpret_cast<const f32x4 *>(h + (size_t)v * HS + 4 * lane);
+    for (int u = 0; u < hid; ++u) {
+        const f32x4 w = *reinterpret_cast<const f32x4 *>(W0 + (size_t)u * 256 + 4 * lane);
+        float s = hv[0] * w[0] + hv[1] * w[1] + hv[2] * w[2] + hv[3] * w[3];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) s_hid[u] = silu(s + b0[u]);
+    }
+    __syncthreads();
+    if (lane < atom_nf) {
+        float s = b1[lane];
+        for (int u = 0; u < hid; ++u) s = fmaf(W1[(size_t)lane * hid + u], s_hid[u], s);
+        eps_h[(size_t)v * atom_nf + lane] = s;
+    }
+    if (lane < 3) eps_x[(size_t)v * 3 + lane] = x[(size_t)v * 3 + lane] - x0[(size_t)v * 3 + lane];
+}
+
+// ---- node projection ----------------------------------------------------------------------
+// LDS: A tile only.
+__global__ __launch_bounds__(256, 2) void k_node_proj(ProjArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *A = smem;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int node0 = blockIdx.x * TM, s = blockIdx.y;
+
+    for (int rr = 0; rr < 16; ++rr) {
+        const int r = wave * 16 + rr, v = node0 + r;
+        f32x4 val = {0.f, 0.f, 0.f, 0.f}, val2 = {0.f, 0.f, 0.f, 0.f};
+        if (v < a.n) {
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(a.h + (size_t)v * HS);
+            val = src[lane];
+            if (lane < 2) val2 = src[64 + lane];
+        }
+        *reinterpret_cast<f32x4 *>(A + r * SA + 4 * lane) = val;
+        if (lane < 2) *reinterpret_cast<f32x4 *>(A + r * SA + 256 + 4 * lane) = val2;
+    }
+    __syncthreads();
+
+    f32x16 acc[2][2];
+    acc_zero(acc);
+    gemm_rows64(A, a.wp[s], acc, wave, lane);
+    const float ex = extra_col(A, a.wx[s], tid);
+
+    const float *bias = a.bias[s];
+    float *out = a.P + (size_t)a.slot[s] * HS;
+    const size_t prow = (size_t)NSLOT * HS;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int col = acc_col(nt, wave, lane);
+        const float b = bias ? bias[col] : 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int v = node0 + acc_row(mt, reg, lane);
+                if (v < a.n) out[v * prow + col] = acc[mt][nt][reg] + b;
+            }
+    }
+    if ((tid & 3) == 0) {
+        const int v = node0 + (tid >> 2);
+        if (v < a.n) out[v * prow + 256] = ex + (bias ? bias[256] : 0.0f);
+    }
+}
+
+// ---- fused edge kernel --------------------------------------------------------------------
+struct EdgeSmem {
+    float *A;
+    int *src, *dst;
+    float *d, *xd, *att, *mx;
+    int *misc;
+};
+
+__device__ __forceinline__ EdgeSmem edge_smem(float *smem) {
+    EdgeSmem s;
+    s.A = smem;
+    s.src = reinterpret_cast<int *>(smem + TM * SA);
+    s.dst = s.src + TM;
+    s.d = reinterpret_cast<float *>(s.dst + TM);
+    s.xd = s.d + TM;
+    s.att = s.xd + 3 * TM;
+    s.mx = s.att + TM;
+    s.misc = reinterpret_cast<int *>(s.mx + 3 * TM);
+    return s;
+}
+
+// A[r][:] = SiLU(Ps[src_r] + Pd[dst_r] + d_r * w_r)   (first Linear of edge_mlp / coord_mlp;
+// its bias is folded into Pd by k_node_proj)
+__device__ __forceinline__ void build_edge_A(const EdgeSmem &s, const float *__restrict__ Ps, const float *__restrict__ Pd,
+                                             const float *__restrict__ wr, int wave, int lane) {
+    const size_t prow = (size_t)NSLOT * HS;
+    const f32x4 w0 = reinterpret_cast<const f32x4 *>(wr)[lane];
+    f32x4 w1 = {0.f, 0.f, 0.f, 0.f};
+    if (lane < 2) w1 = reinterpret_cast<const f32x4 *>(wr)[64 + lane];
+#pragma unroll 4
+    for (int rr = 0; rr < 16; ++rr) {
+        const int r = wave * 16 + rr;
+        const float d = s.d[r];
+        const f32x4 *ps = reinterpret_cast<const f32x4 *>(Ps + s.src[r] * prow);
+        const f32x4 *pd = reinterpret_cast<const f32x4 *>(Pd + s.dst[r] * prow);
+        f32x4 v = ps[lane] + pd[lane] + d * w0;
+        v[0] = silu(v[0]); v[1] = silu(v[1]); v[2] = silu(v[2]); v[3] = silu(v[3]);
+        *reinterpret_cast<f32x4 *>(s.A + r * SA + 4 * lane) = v;
+        if (lane < 2) {
+            f32x4 u = ps[64 + lane] + pd[64 + lane] + d * w1;
+            u[0] = silu(u[0]); u[1] = silu(u[1]); u[2] = silu(u[2]); u[3] = silu(u[3]);
+            *reinterpret_cast<f32x4 *>(s.A + r * SA + 256 + 4 * lane) = u;
+        }
+    }
+}
+
+// T[row][col] = SiLU(acc + b[col]) for the 257 valid columns.
+__device__ __forceinline__ void store_T_silu(float *T, const f32x16 (&acc)[2][2], float ex, const float *__restrict__ b,
+                                             int tid, int wave, int lane) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int col = acc_col(nt, wave, lane);
+        const float bb = b[col];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) T[acc_row(mt, reg, lane) * SA + col] = silu(acc[mt][nt][reg] + bb);
+    }
+    if ((tid & 3) == 0) T[(tid >> 2) * SA + 256] = silu(ex + b[256]);
+}
+
+__global__ __launch_bounds__(256, 2) void k_egnn_edge(EdgeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const EdgeSmem s = edge_smem(smem);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+
+    // tile decode (XCD-aware: consecutive tiles -- neighbouring edges of one complex, which
+    // share P rows -- go to the same XCD / L2)
+    const int T = a.meta[8];
+    const int chunk = (T + 7) >> 3;
+    const int bi = blockIdx.x >> 3;
+    if (bi >= chunk) return;
+    const int tile = (blockIdx.x & 7) * chunk + bi;
+    if (tile >= T) return;
+    int et = 0;
+#pragma unroll
+    for (int e = 1; e < 4; ++e)
+        if (tile >= a.meta[4 + e]) et = e;
+    const int tile_in_et = tile - a.meta[4 + et];
+    const int e0 = tile_in_et * TM;
+    const int ne = min(TM, a.meta[et] - e0);
+    const int snt = a.src_nt[et], dnt = a.dst_nt[et];
+    const int *__restrict__ esrc = a.src[et];
+    const int *__restrict__ edst = a.dst[et];
+
+    // phase 0: edge endpoints and geometry (dynamics.py:160-169, 209-217)
+    if (tid < TM) {
+        const int e = e0 + min(tid, ne - 1);
+        const int u = esrc[e], v = edst[e];
+        s.src[tid] = u;
+        s.dst[tid] = v;
+        const float *xs = a.x[snt] + (size_t)u * 3, *xd = a.x[dnt] + (size_t)v * 3;
+        const float dx = xs[0] - xd[0], dy = xs[1] - xd[1], dz = xs[2] - xd[2];
+        const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float inv = 1.0f / (d + 1.0f);
+        s.d[tid] = d;
+        s.xd[3 * tid] = dx * inv;
+        s.xd[3 * tid + 1] = dy * inv;
+        s.xd[3 * tid + 2] = dz * inv;
+        if (tid == 0) s.misc[0] = (e0 > 0 && edst[e0 - 1] == v) ? 1 : 0;
+    }
+    __syncthreads();
+
+    const float *Ps = a.P[snt] + (size_t)a.src_slot[et] * HS;
+    const float *Pd = a.P[dnt] + (size_t)a.dst_slot[et] * HS;
+    const int first_is_cont = s.misc[0];
+    f32x16 acc[2][2];
+
+    // ---- feature messages: m = edge_mlp(f); msg_h = m * sigmoid(att(m)) (dynamics.py:111-112)
+    build_edge_A(s, Ps, Pd, a.wr_e[et], wave, lane);
+    __syncthreads();
+    acc_zero(acc);
+    gemm_rows64(s.A, a.wp_e[et], acc, wave, lane);
+    float ex = extra_col(s.A, a.wx_e[et], tid);
+    __syncthreads();
+    store_T_silu(s.A, acc, ex, a.b_e[et], tid, wave, lane);
+    __syncthreads();
+    {
+        const float dot = row_dot257(s.A, a.watt[et], tid);
+        const int row = tid >> 2;
+        if ((tid & 3) == 0) s.att[row] = row < ne ? sigmoidf_(dot + a.watt[et][ATT_BIAS_AT]) : 0.0f;
+    }
+    __syncthreads();
+    {
+        // segmented sum over dst (dynamics.py:182-185): thread = column, rows in order
+        float *hmain = a.hn_main[et], *hcont = a.hn_cont[et] + (size_t)tile_in_et * HS;
+        float run = 0.0f, run2 = 0.0f;
+        int piece = 0;
+        for (int r = 0; r < ne; ++r) {
+            const float w = s.att[r];
+            run = fmaf(s.A[r * SA + tid], w, run);
+            if (tid == 0) run2 = fmaf(s.A[r * SA + 256], w, run2);
+            const bool end = (r == ne - 1) || (s.dst[r + 1] != s.dst[r]);
+            if (end) {
+                float *out = (piece == 0 && first_is_cont) ? hcont : hmain + (size_t)s.dst[r] * HS;
+                out[tid] = run;
+                if (tid == 0) out[256] = run2;
+                run = 0.0f;
+                run2 = 0.0f;
+                ++piece;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- coordinate messages: msg_x = tanh(coord_mlp(f)) * x_diff * range (dynamics.py:113-120)
+    build_edge_A(s, Ps + HS, Pd + HS, a.wr_c[et], wave, lane);
+    __syncthreads();
+    acc_zero(acc);
+    gemm_rows64(s.A, a.wp_c[et], acc, wave, lane);
+    ex = extra_col(s.A, a.wx_c[et], tid);
+    __syncthreads();
+    store_T_silu(s.A, acc, ex, a.b_c[et], tid, wave, lane);
+    __syncthreads();
+    {
+        const float dot = row_dot257(s.A, a.w3[et], tid);
+        const int row = tid >> 2;
+        if ((tid & 3) == 0) {
+            float c = a.use_tanh ? tanhf(dot) * a.coords_range : dot;
+            if (row >= ne) c = 0.0f;
+            s.mx[3 * row] = c * s.xd[3 * row];
+            s.mx[3 * row + 1] = c * s.xd[3 * row + 1];
+            s.mx[3 * row + 2] = c * s.xd[3 * row + 2];
+        }
+    }
+    __syncthreads();
+    if (tid < 3) {
+        float *xmain = a.xn_main[et], *xcont = a.xn_cont[et] + (size_t)tile_in_et * 4;
+        float run = 0.0f;
+        int piece = 0;
+        for (int r = 0; r < ne; ++r) {
+            run += s.mx[3 * r + tid];
+            const bool end = (r == ne - 1) || (s.dst[r + 1] != s.dst[r]);
+            if (end) {
+                float *out = (piece == 0 && first_is_cont) ? xcont : xmain + (size_t)s.dst[r] * 4;
+                out[tid] = run;
+                run = 0.0f;
+                ++piece;
+            }
+        }
+    }
+}
+
+// ---- node update --------------------------------------------------------------------------
+struct NodeSmem {
+    float *A;
+    float *zinv, *mean, *rstd;
+};
+
+__global__ __launch_bounds__(256, 2) void k_node_update(NodeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *A = smem;
+    float *s_z = smem + TM * SA;        // [64] z of the row's graph
+    float *s_mean = s_z + TM;           // [64]
+    float *s_rstd = s_mean + TM;        // [64]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int node0 = blockIdx.x * TM;
+
+    // coordinates: x' = x + x_neigh / z (dynamics.py:190-192, 206)
+    if (tid < TM) {
+        const int v = node0 + tid;
+        float z = 1.0f;
+        if (v < a.n) {
+            z = a.z[a.bidx[v]];
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+            for (int i = 0; i < a.n_in; ++i) {
+                const int lo = a.rowptr[i][v], hi = a.rowptr[i][v + 1];
+                if (hi > lo) {
+                    const float *p = a.xn_main[i] + (size_t)v * 4;
+                    sx += p[0]; sy += p[1]; sz += p[2];
+                    for (int t = lo / TM + 1; t <= (hi - 1) / TM; ++t) {
+                        const float *q = a.xn_cont[i] + (size_t)t * 4;
+                        sx += q[0]; sy += q[1]; sz += q[2];
+                    }
+                }
+            }
+            float *xv = a.x + (size_t)v * 3;
+            xv[0] += sx / z; xv[1] += sy / z; xv[2] += sz / z;
+        }
+        s_z[tid] = z;
+    }
+
+    // GEMM 1a: W[:, :257] . h
+    for (int rr = 0; rr < 16; ++rr) {
+        const int r = wave * 16 + rr, v = node0 + r;
+        f32x4 val = {0.f, 0.f, 0.f, 0.f}, val2 = {0.f, 0.f, 0.f, 0.f};
+        if (v < a.n) {
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(a.h + (size_t)v * HS);
+            val = src[lane];
+            if (lane < 2) val2 = src[64 + lane];
+        }
+        *reinterpret_cast<f32x4 *>(A + r * SA + 4 * lane) = val;
+        if (lane < 2) *reinterpret_cast<f32x4 *>(A + r * SA + 256 + 4 * lane) = val2;
+    }
+    __syncthreads();
+    f32x16 acc[2][2];
+    acc_zero(acc);
+    gemm_rows64(A, a.wp_a, acc, wave, lane);
+    float ex = extra_col(A, a.wx_a, tid);
+    __syncthreads();
+
+    // GEMM 1b: + W[:, 257:] . (h_neigh / z); h_neigh = sum of segment pieces over the
+    // incoming edge types in fixed order (multi_update_all cross_reducer='sum')
+    for (int rr = 0; rr < 16; ++rr) {
+        const int r = wave * 16 + rr, v = node0 + r;
+        f32x4 val = {0.f, 0.f, 0.f, 0.f}, val2 = {0.f, 0.f, 0.f, 0.f};
+        if (v < a.n) {
+            for (int i = 0; i < a.n_in; ++i) {
+                const int lo = a.rowptr[i][v], hi = a.rowptr[i][v + 1];
+                if (hi > lo) {
+                    const f32x4 *p = reinterpret_cast<const f32x4 *>(a.hn_main[i] + (size_t)v * HS);
+                    val += p[lane];
+                    if (lane < 2) val2 += p[64 + lane];
+                    for (int t = lo / TM + 1; t <= (hi - 1) / TM; ++t) {
+                        const f32x4 *q = reinterpret_cast<const f32x4 *>(a.hn_cont[i] + (size_t)t * HS);
+                        val += q[lane];
+                        if (lane < 2) val2 += q[64 + lane];
+                    }
+                }
+            }
+            const float z = s_z[r];
+            val /= z;
+            val2 /= z;
+        }
+        *reinterpret_cast<f32x4 *>(A + r * SA + 4 * lane) = val;
+        if (lane < 2) *reinterpret_cast<f32x4 *>(A + r * SA + 256 + 4 * lane) = val2;
+    }
+    __syncthreads();
+    gemm_rows64(A, a.wp_b, acc, wave, lane);
+    ex += extra_col(A, a.wx_b, tid);
+    __syncthreads();
+
+    // hidden = SiLU(. + b0) -> T (pad columns 257..263 stay 0 from the h_neigh tile)
+    store_T_silu(A, acc, ex, a.b0, tid, wave, lane);
+    __syncthreads();
+
+    // GEMM 2 + bias + residual (dynamics.py:201-203)
+    acc_zero(acc);
+    gemm_rows64(A, a.wp_2, acc, wave, lane);
+    ex = extra_col(A, a.wx_2, tid);
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int col = acc_col(nt, wave, lane);
+        const float bb = a.b2[col];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int r = acc_row(mt, reg, lane), v = node0 + r;
+                const float res = v < a.n ? a.h[(size_t)v * HS + col] : 0.0f;
+                A[r * SA + col] = acc[mt][nt][reg] + bb + res;
+            }
+    }
+    if ((tid & 3) == 0) {
+        const int r = tid >> 2, v = node0 + r;
+        A[r * SA + 256] = ex + a.b2[256] + (v < a.n ? a.h[(size_t)v * HS + 256] : 0.0f);
+    }
+    __syncthreads();
+
+    // LayerNorm(257) (dynamics.py:81-87, 204), biased variance, eps = 1e-5
+    if (a.norm) {
+        const int row = tid >> 2, q = tid & 3;
+        const float *tr = A + row * SA + q;
+        float sum = 0.0f;
+        for (int i = 0; i < 64; ++i) sum += tr[4 * i];
+        if (q == 0) sum += A[row * SA + 256];
+        sum += __shfl_xor(sum, 1);
+        sum += __shfl_xor(sum, 2);
+        const float mean = sum * (1.0f / HW);
+        float var = 0.0f;
+        for (int i = 0; i < 64; ++i) {
+            const float dlt = tr[4 * i] - mean;
+            var = fmaf(dlt, dlt, var);
+        }
+        if (q == 0) {
+            const float dlt = A[row * SA + 256] - mean;
+            var = fmaf(dlt, dlt, var);
+        }
+        var += __shfl_xor(var, 1);
+        var += __shfl_xor(var, 2);
+        if (q == 0) {
+            s_mean[row] = mean;
+            s_rstd[row] = 1.0f / sqrtf(var * (1.0f / HW) + 1e-5f);
+        }
+    }
+    __syncthreads();
+    for (int rr = 0; rr < 16; ++rr) {
+        const int r = wave * 16 + rr, v = node0 + r;
+        if (v >= a.n) continue;
+        f32x4 val = *reinterpret_cast<const f32x4 *>(A + r * SA + 4 * lane);
+        float last = A[r * SA + 256];
+        if (a.norm) {
+            const float mean = s_mean[r], rstd = s_rstd[r];
+            const f32x4 w = reinterpret_cast<const f32x4 *>(a.ln_w)[lane];
+            const f32x4 b = reinterpret_cast<const f32x4 *>(a.ln_b)[lane];
+            val = (val - mean) * rstd * w + b;
+            last = (last - mean) * rstd * a.ln_w[256] + a.ln_b[256];
+        }
+        f32x4 *dst = reinterpret_cast<f32x4 *>(a.h + (size_t)v * HS);
+        dst[lane] = val;
+        if (lane == 0) {
+            const f32x4 t = {last, 0.f, 0.f, 0.f};
+            dst[64] = t;
+        }
+    }
+}
+
+// ---- launchers ----------------------------------------------------------------------------
+static bool g_attr_set = false;
+
+kpd_status egnn_kernels_init() {
+    if (g_attr_set) return KPD_OK;
+    KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_proj), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                PROJ_LDS_BYTES));
+    KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_egnn_edge), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                EDGE_LDS_BYTES));
+    KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_update),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, NODE_LDS_BYTES));
+    g_attr_set = true;
+    return KPD_OK;
+}
+
+kpd_status launch_node_graph_index(const int *ptr, int B, int n, int *bidx, hipStream_t st) {
+    if (n == 0) return KPD_OK;
+    hipLaunchKernelGGL(k_node_graph_index, dim3(cdiv(n, 256)), dim3(256), 0, st, ptr, B, n, bidx);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+kpd_status launch_egnn_meta(const int *counts, int e_kk, int active_mask, const int *lig_ptr, const int *kp_ptr,
+                            const int *ll_per_graph, const int *kk_rowptr, int B, int kl_k, float message_norm,
+                            int update_kp, int *meta, float *z_lig, float *z_kp, hipStream_t st) {
+    hipLaunchKernelGGL(k_egnn_meta, dim3(cdiv(B, 256)), dim3(256), 0, st, counts, e_kk, active_mask, lig_ptr, kp_ptr,
+                       ll_per_graph, kk_rowptr, B, kl_k, message_norm, update_kp, meta, z_lig, z_kp);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+kpd_status launch_embed(const float *in, int n, int fin, const float *W0, const float *b0, int hid, const float *W1t,
+                        const float *b1, const float *t, const int *bidx, float *out, int identity, hipStream_t st) {
+    if (n == 0) return KPD_OK;
+    KPD_REQUIRE(fin <= 256 && hid <= 256, KPD_ERR_INVALID, "embed: fin=%d hid=%d exceed 256", fin, hid);
+    KPD_REQUIRE(!identity || fin == 256, KPD_ERR_INVALID, "identity encoder needs 256 input features");
+    hipLaunchKernelGGL(k_embed, dim3(cdiv(n, EMB_NODES)), dim3(256), 0, st, in, n, fin, W0, b0, hid, W1t, b1, t, bidx,
+                       out, identity);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+kpd_status launch_decode(const float *h, const float *x, const float *x0, int n, int atom_nf, int hid, const float *W0,
+                         const float *b0, const float *W1, const float *b1, float *eps_h, float *eps_x,
+                         hipStream_t st) {
+    if (n == 0) return KPD_OK;
+    KPD_REQUIRE(hid <= 64 && atom_nf <= 64, KPD_ERR_INVALID, "decode: hid=%d atom_nf=%d exceed 64", hid, atom_nf);
+    hipLaunchKernelGGL(k_decode, dim3(n), dim3(64), 0, st, h, x, x0, n, atom_nf, hid, W0, b0, W1, b1, eps_h, eps_x);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+kpd_status launch_node_proj(const ProjArgs &a, int n_slots, hipStream_t st) {
+    if (a.n == 0 || n_slots == 0) return KPD_OK;
+    hipLaunchKernelGGL(k_node_proj, dim3(cdiv(a.n, TM), n_slots), dim3(256), PROJ_LDS_BYTES, st, a);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+kpd_status launch_egnn_edge(const EdgeArgs &a, int tile_cap, hipStream_t st) {
+    if (tile_cap == 0) return KPD_OK;
+    hipLaunchKernelGGL(k_egnn_edge, dim3(8 * cdiv(tile_cap, 8)), dim3(256), EDGE_LDS_BYTES, st, a);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+kpd_status launch_node_update(const NodeArgs &a, hipStream_t st) {
+    if (a.n == 0) return KPD_OK;
+    hipLaunchKernelGGL(k_node_update, dim3(cdiv(a.n, TM)), dim3(256), NODE_LDS_BYTES, st, a);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+}  // namespace kpd

@@ -1,0 +1,37 @@
+// Internal declarations shared between the translation units of libkpd_hip.so.
+#pragma once
+#include "common.h"
+
+namespace kpd {
+
+kpd_status launch_lig_graph(const kpd_batch *bt, float ll_cutoff, int kl_k, const kpd_lig_graph *g,
+                            int *ll_deg_tmp, int *ll_off_tmp, int *kl_off_tmp, hipStream_t st);
+
+// Grow-only device arena: one hipMalloc, carved with 256-B alignment, zero-filled.
+struct Arena {
+    char *base = nullptr;
+    size_t cap = 0, used = 0;
+    kpd_status reserve(size_t bytes);
+    void release();
+    void reset() { used = 0; }
+    template <typename T>
+    T *take(size_t count) {
+        size_t bytes = (count * sizeof(T) + 255) & ~size_t(255);
+        if (used + bytes > cap) return nullptr;
+        T *p = reinterpret_cast<T *>(base + used);
+        used += bytes;
+        return p;
+    }
+};
+
+// Weight repacking helpers (pack.hip).
+// src: torch Linear weight [n_out, ld] row-major on device; uses columns [col0, col0 + K).
+kpd_status pack_gemm_weight(const float *src, int n_out, int ld, int col0, int K, float *wp, float *wx, hipStream_t st);
+// dst[0..n_dst) = src[0..n_src) then zeros.
+kpd_status copy_pad(const float *src, int n_src, float *dst, int n_dst, hipStream_t st);
+// dst[c][r] = src[r][c]
+kpd_status transpose2d(const float *src, int rows, int cols, float *dst, hipStream_t st);
+// strided column gather: dst[i] = src[i * ld + col] for i < n, zeros up to n_dst
+kpd_status copy_col_pad(const float *src, int n, int ld, int col, float *dst, int n_dst, hipStream_t st);
+
+}  // namespace kpd

@@ -1,0 +1,260 @@
+// Per-step ligand graph build on the GPU: lig-lig radius graph and keypoint->ligand kNN,
+// emitted directly as dst-sorted COO + CSR in preallocated buffers (no host sync, fixed
+// launch geometry).  Replaces torch_cluster.radius_graph / torch_cluster.knn + DGL
+// add_edges in models/dynamics.py:387-420 and models/dynamics_gvp.py:201-234.
+//
+// One workgroup per complex; ligand coordinates are staged in LDS.  These kernels are tiny
+// (<= a few thousand distance tests per complex) and latency bound.
+#include "common.h"
+
+namespace kpd {
+
+// ---- ll: radius graph ---------------------------------------------------------------------
+// Pass 1: in-degree of every ligand atom (neighbours j != i, same complex, |xi-xj| < r, at
+// most `max_nn` in index order) and edges per complex.
+__global__ void k_ll_count(const float *__restrict__ x, const int *__restrict__ ptr, float r2, int max_nn,
+                           int *__restrict__ deg, int *__restrict__ per_graph) {
+    extern __shared__ float sx[];
+    const int b = blockIdx.x;
+    const int lo = ptr[b], n = ptr[b + 1] - lo;
+    for (int i = threadIdx.x; i < n * 3; i += blockDim.x) sx[i] = x[(size_t)lo * 3 + i];
+    __shared__ int s_tot;
+    if (threadIdx.x == 0) s_tot = 0;
+    __syncthreads();
+    int local = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float xi = sx[3 * i], yi = sx[3 * i + 1], zi = sx[3 * i + 2];
+        int c = 0;
+        for (int j = 0; j < n; ++j) {
+            const float dx = sx[3 * j] - xi, dy = sx[3 * j + 1] - yi, dz = sx[3 * j + 2] - zi;
+            const float d2 = dx * dx + dy * dy + dz * dz;
+            c += (j != i && d2 < r2) ? 1 : 0;
+        }
+        c = min(c, max_nn);
+        deg[lo + i] = c;
+        local += c;
+    }
+    atomicAdd(&s_tot, local);
+    __syncthreads();
+    if (threadIdx.x == 0) per_graph[b] = s_tot;
+}
+
+// Pass 2 (single workgroup): exclusive scan of the per-complex ll counts; totals.
+// counts[0] = E_ll, counts[1] = E_kl (= kl_off[B], data independent).
+__global__ void k_scan_graph_counts(const int *__restrict__ per_graph, int B, int *__restrict__ off,
+                                    const int *__restrict__ kl_off, int *__restrict__ counts) {
+    __shared__ int s_part[1024];
+    __shared__ int s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < B; base += blockDim.x) {
+        const int i = base + threadIdx.x;
+        const int v = i < B ? per_graph[i] : 0;
+        s_part[threadIdx.x] = v;
+        __syncthreads();
+        for (int s = 1; s < blockDim.x; s <<= 1) {          // Hillis-Steele inclusive scan
+            int t = threadIdx.x >= s ? s_part[threadIdx.x - s] : 0;
+            __syncthreads();
+            s_part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < B) off[i] = s_carry + s_part[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == blockDim.x - 1) s_carry += s_part[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        off[B] = s_carry;
+        counts[0] = s_carry;
+        counts[1] = kl_off[B];
+    }
+}
+
+// Pass 3: fill.  Edge order: dst (centre) major, src ascending.
+__global__ void k_ll_fill(const float *__restrict__ x, const int *__restrict__ ptr, float r2, int max_nn,
+                          const int *__restrict__ deg, const int *__restrict__ off, int n_total, int cap,
+                          int *__restrict__ src, int *__restrict__ dst, int *__restrict__ rowptr) {
+    extern __shared__ float sx[];
+    const int b = blockIdx.x;
+    const int lo = ptr[b], n = ptr[b + 1] - lo;
+    int *s_start = reinterpret_cast<int *>(sx + 3 * n);
+    for (int i = threadIdx.x; i < n * 3; i += blockDim.x) sx[i] = x[(size_t)lo * 3 + i];
+    __syncthreads();
+    if (threadIdx.x == 0) {                                  // n <= a few hundred: serial prefix
+        int run = off[b];
+        for (int i = 0; i < n; ++i) {
+            s_start[i] = run;
+            rowptr[lo + i] = run;
+            run += deg[lo + i];
+        }
+        if (lo + n == n_total) rowptr[n_total] = run;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float xi = sx[3 * i], yi = sx[3 * i + 1], zi = sx[3 * i + 2];
+        int w = s_start[i], c = 0;
+        for (int j = 0; j < n && c < max_nn; ++j) {
+            const float dx = sx[3 * j] - xi, dy = sx[3 * j + 1] - yi, dz = sx[3 * j + 2] - zi;
+            const float d2 = dx * dx + dy * dy + dz * dz;
+            if (j != i && d2 < r2) {
+                if (w < cap) {
+                    src[w] = lo + j;
+                    dst[w] = lo + i;
+                }
+                ++w;
+                ++c;
+            }
+        }
+    }
+}
+
+// ---- kl / lk: for every keypoint its k nearest ligand atoms -------------------------------
+// lk (src lig -> dst kp) is emitted kp-major, nearest first (ties: lower index).
+// kl (src kp -> dst lig) is the same pair list sorted by (lig, kp): ranks come from a
+// per-ligand-atom bitmask over keypoints kept in LDS.
+// Dynamic LDS: 3*max_lig floats + max_lig*(words+1) ints + (max_lig+1) ints.
+__global__ void k_kl_build(const float *__restrict__ lig_x, const int *__restrict__ lig_ptr,
+                           const float *__restrict__ kp_x, const int *__restrict__ kp_ptr,
+                           const int *__restrict__ kl_off, int k, int words, int n_lig_total, int n_kp_total,
+                           int *__restrict__ kl_src, int *__restrict__ kl_dst, int *__restrict__ kl_rowptr,
+                           int *__restrict__ lk_src, int *__restrict__ lk_dst, int *__restrict__ lk_rowptr) {
+    extern __shared__ float smem[];
+    const int b = blockIdx.x;
+    const int llo = lig_ptr[b], nl = lig_ptr[b + 1] - llo;
+    const int klo = kp_ptr[b], nk = kp_ptr[b + 1] - klo;
+    float *sx = smem;
+    unsigned *mask = reinterpret_cast<unsigned *>(smem + 3 * nl);
+    int *start = reinterpret_cast<int *>(mask + (size_t)nl * words);
+    const int kk = min(k, nl);
+    const int base = kl_off[b];
+
+    for (int i = threadIdx.x; i < nl * 3; i += blockDim.x) sx[i] = lig_x[(size_t)llo * 3 + i];
+    for (int i = threadIdx.x; i < nl * words; i += blockDim.x) mask[i] = 0u;
+    __syncthreads();
+
+    // phase 1: top-k per keypoint, lk lists, selection bitmasks
+    for (int p = threadIdx.x; p < nk; p += blockDim.x) {
+        const float px = kp_x[(size_t)(klo + p) * 3], py = kp_x[(size_t)(klo + p) * 3 + 1],
+                    pz = kp_x[(size_t)(klo + p) * 3 + 2];
+        float bd[KL_KMAX];
+        int bi[KL_KMAX];
+#pragma unroll
+        for (int j = 0; j < KL_KMAX; ++j) {
+            bd[j] = 3.0e38f;
+            bi[j] = -1;
+        }
+        for (int l = 0; l < nl; ++l) {
+            const float dx = sx[3 * l] - px, dy = sx[3 * l + 1] - py, dz = sx[3 * l + 2] - pz;
+            float d = dx * dx + dy * dy + dz * dz;
+            int id = l;
+            // insertion into the sorted best-list (strict < keeps the lower index on ties)
+#pragma unroll
+            for (int j = 0; j < KL_KMAX; ++j) {
+                if (j < kk && d < bd[j]) {
+                    const float td = bd[j];
+                    const int ti = bi[j];
+                    bd[j] = d;
+                    bi[j] = id;
+                    d = td;
+                    id = ti;
+                }
+            }
+        }
+        lk_rowptr[klo + p] = base + p * kk;
+#pragma unroll
+        for (int j = 0; j < KL_KMAX; ++j) {
+            if (j < kk) {
+                lk_src[base + p * kk + j] = llo + bi[j];
+                lk_dst[base + p * kk + j] = klo + p;
+                atomicOr(&mask[(size_t)bi[j] * words + (p >> 5)], 1u << (p & 31));
+            }
+        }
+    }
+    if (threadIdx.x == 0 && klo + nk == n_kp_total) lk_rowptr[n_kp_total] = base + nk * kk;
+    __syncthreads();
+
+    // phase 2: kl row pointers (ligand atoms of this complex)
+    if (threadIdx.x == 0) {
+        int run = base;
+        for (int l = 0; l < nl; ++l) {
+            start[l] = run;
+            kl_rowptr[llo + l] = run;
+            int c = 0;
+            for (int w = 0; w < words; ++w) c += __popc(mask[(size_t)l * words + w]);
+            run += c;
+        }
+        if (llo + nl == n_lig_total) kl_rowptr[n_lig_total] = run;
+    }
+    __syncthreads();
+
+    // phase 3: kl fill, (lig, kp)-sorted: one thread per (ligand atom, mask word)
+    for (int it = threadIdx.x; it < nl * words; it += blockDim.x) {
+        const int l = it / words, w = it - l * words;
+        int pos = start[l];
+        for (int ww = 0; ww < w; ++ww) pos += __popc(mask[(size_t)l * words + ww]);
+        unsigned m = mask[(size_t)l * words + w];
+        while (m) {
+            const int bit = __ffs(m) - 1;
+            m &= m - 1;
+            kl_src[pos] = klo + w * 32 + bit;
+            kl_dst[pos] = llo + l;
+            ++pos;
+        }
+    }
+}
+
+// Per-complex static kl offsets: off[b] = sum_{b'<b} n_kp[b'] * min(k, n_lig[b']); off[B] = total.
+__global__ void k_kl_offsets(const int *__restrict__ lig_ptr, const int *__restrict__ kp_ptr, int B, int k,
+                             int *__restrict__ off) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int run = 0;
+        for (int b = 0; b < B; ++b) {
+            off[b] = run;
+            run += (kp_ptr[b + 1] - kp_ptr[b]) * min(k, lig_ptr[b + 1] - lig_ptr[b]);
+        }
+        off[B] = run;
+    }
+}
+
+}  // namespace kpd
+
+using namespace kpd;
+
+// Host-side launcher shared with the denoiser engines (declared in engine.h).
+namespace kpd {
+kpd_status launch_lig_graph(const kpd_batch *bt, float ll_cutoff, int kl_k, const kpd_lig_graph *g,
+                            int *ll_deg_tmp, int *ll_off_tmp, int *kl_off_tmp, hipStream_t st) {
+    KPD_REQUIRE(kl_k >= 1 && kl_k <= KL_KMAX, KPD_ERR_INVALID, "kl_k=%d outside 1..%d", kl_k, KL_KMAX);
+    KPD_REQUIRE(bt->max_lig >= 1 && bt->max_lig <= 1024, KPD_ERR_INVALID, "max_lig=%d outside 1..1024", bt->max_lig);
+    const int B = bt->B;
+    const int threads = 256;
+    const float r2 = ll_cutoff * ll_cutoff;
+    KPD_REQUIRE(g->cap_kl >= bt->n_kp * kl_k, KPD_ERR_CAPACITY, "cap_kl=%d < n_kp*k=%d", g->cap_kl, bt->n_kp * kl_k);
+    {
+        const long need = (long)bt->n_lig * (bt->max_lig - 1 < 200 ? bt->max_lig - 1 : 200);
+        KPD_REQUIRE(g->cap_ll >= need, KPD_ERR_CAPACITY, "cap_ll=%d < %ld", g->cap_ll, need);
+    }
+    size_t lds = (size_t)bt->max_lig * 3 * sizeof(float);
+    hipLaunchKernelGGL(k_ll_count, dim3(B), dim3(threads), lds, st, bt->lig_x, bt->lig_ptr, r2, 200, ll_deg_tmp,
+                       g->ll_per_graph);
+    KPD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_kl_offsets, dim3(1), dim3(64), 0, st, bt->lig_ptr, bt->kp_ptr, B, kl_k, kl_off_tmp);
+    KPD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_scan_graph_counts, dim3(1), dim3(1024), 0, st, g->ll_per_graph, B, ll_off_tmp, kl_off_tmp,
+                       g->counts);
+    KPD_LAUNCH_CHECK();
+    lds = (size_t)bt->max_lig * (3 * sizeof(float) + sizeof(int));
+    hipLaunchKernelGGL(k_ll_fill, dim3(B), dim3(threads), lds, st, bt->lig_x, bt->lig_ptr, r2, 200, ll_deg_tmp,
+                       ll_off_tmp, bt->n_lig, g->cap_ll, g->ll_src, g->ll_dst, g->ll_rowptr);
+    KPD_LAUNCH_CHECK();
+    const int words = cdiv(bt->max_kp, 32);
+    lds = (size_t)bt->max_lig * (3 * sizeof(float) + (size_t)words * sizeof(unsigned) + sizeof(int)) + 16;
+    KPD_REQUIRE(lds <= 64 * 1024, KPD_ERR_INVALID, "kl build needs %zu B of LDS (max_lig=%d, max_kp=%d)", lds,
+                bt->max_lig, bt->max_kp);
+    hipLaunchKernelGGL(k_kl_build, dim3(B), dim3(threads), lds, st, bt->lig_x, bt->lig_ptr, bt->kp_x, bt->kp_ptr,
+                       kl_off_tmp, kl_k, words, bt->n_lig, bt->n_kp, g->kl_src, g->kl_dst, g->kl_rowptr, g->lk_src,
+                       g->lk_dst, g->lk_rowptr);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+}  // namespace kpd

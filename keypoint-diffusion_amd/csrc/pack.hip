@@ -1,0 +1,96 @@
+// Library-wide utilities: error text, device arena, weight repacking kernels.
+#include <stdarg.h>
+
+#include "engine.h"
+
+namespace kpd {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+kpd_status Arena::reserve(size_t bytes) {
+    if (bytes <= cap) {
+        used = 0;
+        return KPD_OK;
+    }
+    release();
+    KPD_HIP(hipMalloc(reinterpret_cast<void **>(&base), bytes));
+    KPD_HIP(hipMemset(base, 0, bytes));
+    cap = bytes;
+    used = 0;
+    return KPD_OK;
+}
+
+void Arena::release() {
+    if (base) (void)hipFree(base);
+    base = nullptr;
+    cap = used = 0;
+}
+
+__global__ void k_pack_gemm_weight(const float *__restrict__ src, int n_out, int ld, int col0, int K,
+                                   float *__restrict__ wp, float *__restrict__ wx) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < WP_FLOATS) {
+        const int j = idx & 3, nt = (idx >> 2) & 1, lane = (idx >> 3) & 63, wave = (idx >> 9) & 3, g = idx >> 11;
+        const int k = 8 * g + 4 * (lane >> 5) + j;
+        const int n = 64 * wave + 32 * nt + (lane & 31);
+        wp[idx] = (k < K && n < n_out) ? src[(size_t)n * ld + col0 + k] : 0.0f;
+    }
+    if (idx < KP) wx[idx] = (idx < K && n_out > 256) ? src[(size_t)256 * ld + col0 + idx] : 0.0f;
+}
+
+kpd_status pack_gemm_weight(const float *src, int n_out, int ld, int col0, int K, float *wp, float *wx,
+                            hipStream_t st) {
+    KPD_REQUIRE(K <= KP && n_out <= HW, KPD_ERR_WEIGHTS, "pack: K=%d n_out=%d exceed %d/%d", K, n_out, KP, HW);
+    hipLaunchKernelGGL(k_pack_gemm_weight, dim3(cdiv(WP_FLOATS, 256)), dim3(256), 0, st, src, n_out, ld, col0, K, wp, wx);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+__global__ void k_copy_pad(const float *__restrict__ src, int n_src, float *__restrict__ dst, int n_dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_dst) dst[i] = i < n_src ? src[i] : 0.0f;
+}
+
+kpd_status copy_pad(const float *src, int n_src, float *dst, int n_dst, hipStream_t st) {
+    hipLaunchKernelGGL(k_copy_pad, dim3(cdiv(n_dst, 256)), dim3(256), 0, st, src, n_src, dst, n_dst);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+__global__ void k_copy_col_pad(const float *__restrict__ src, int n, int ld, int col, float *__restrict__ dst,
+                               int n_dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_dst) dst[i] = i < n ? src[(size_t)i * ld + col] : 0.0f;
+}
+
+kpd_status copy_col_pad(const float *src, int n, int ld, int col, float *dst, int n_dst, hipStream_t st) {
+    hipLaunchKernelGGL(k_copy_col_pad, dim3(cdiv(n_dst, 256)), dim3(256), 0, st, src, n, ld, col, dst, n_dst);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+__global__ void k_transpose2d(const float *__restrict__ src, int rows, int cols, float *__restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows * cols) {
+        const int r = i / cols, c = i - r * cols;
+        dst[(size_t)c * rows + r] = src[i];
+    }
+}
+
+kpd_status transpose2d(const float *src, int rows, int cols, float *dst, hipStream_t st) {
+    hipLaunchKernelGGL(k_transpose2d, dim3(cdiv(rows * cols, 256)), dim3(256), 0, st, src, rows, cols, dst);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+}  // namespace kpd
+
+extern "C" const char *kpd_last_error(void) { return kpd::g_err; }
+extern "C" int kpd_version(void) { return 100; }

@@ -1,0 +1,57 @@
+// Reverse-diffusion state update around the denoiser: the elementwise part of
+// KeypointDiffusion.sample_p_zs_given_zt (models/ligand_diffuser.py:515-536) fused with the
+// ligand-COM removal (remove_com :185-203).  One workgroup per complex; the new ligand
+// coordinates are staged in LDS so the COM is a fixed-order sum (deterministic).
+#include "engine.h"
+
+namespace kpd {
+
+// coef[b] = {alpha_t_given_s, var_terms, sigma}
+__global__ __launch_bounds__(256) void k_sample_update(const int *__restrict__ lig_ptr, const int *__restrict__ kp_ptr,
+                                                       int atom_nf, float *__restrict__ lig_x, float *__restrict__ lig_h,
+                                                       float *__restrict__ kp_x, const float *__restrict__ eps_x,
+                                                       const float *__restrict__ eps_h, const float *__restrict__ noise_x,
+                                                       const float *__restrict__ noise_h, const float *__restrict__ coef) {
+    extern __shared__ float sx[];          // [3 * n_lig of this complex]
+    __shared__ float s_com[3];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int llo = lig_ptr[b], nl = lig_ptr[b + 1] - llo;
+    const int klo = kp_ptr[b], nk = kp_ptr[b + 1] - klo;
+    const float alpha = coef[3 * b], var = coef[3 * b + 1], sigma = coef[3 * b + 2];
+
+    for (int i = tid; i < nl * 3; i += blockDim.x) {
+        const size_t g = (size_t)llo * 3 + i;
+        sx[i] = lig_x[g] / alpha - var * eps_x[g] + sigma * noise_x[g];
+    }
+    for (int i = tid; i < nl * atom_nf; i += blockDim.x) {
+        const size_t g = (size_t)llo * atom_nf + i;
+        lig_h[g] = lig_h[g] / alpha - var * eps_h[g] + sigma * noise_h[g];
+    }
+    __syncthreads();
+    if (tid < 3) {
+        float s = 0.0f;
+        for (int i = 0; i < nl; ++i) s += sx[3 * i + tid];
+        s_com[tid] = s / (float)nl;
+    }
+    __syncthreads();
+    for (int i = tid; i < nl * 3; i += blockDim.x) lig_x[(size_t)llo * 3 + i] = sx[i] - s_com[i % 3];
+    for (int i = tid; i < nk * 3; i += blockDim.x) kp_x[(size_t)klo * 3 + i] -= s_com[i % 3];
+}
+
+}  // namespace kpd
+
+using namespace kpd;
+
+extern "C" kpd_status kpd_sample_update(int32_t B, const int32_t *lig_ptr, const int32_t *kp_ptr, int32_t atom_nf,
+                                        float *lig_x, float *lig_h, float *kp_x, const float *eps_x, const float *eps_h,
+                                        const float *noise_x, const float *noise_h, const float *coef, int32_t max_lig,
+                                        void *stream) {
+    KPD_REQUIRE(lig_ptr && kp_ptr && lig_x && lig_h && kp_x && eps_x && eps_h && noise_x && noise_h && coef,
+                KPD_ERR_INVALID, "null argument");
+    KPD_REQUIRE(B >= 1 && max_lig >= 1 && max_lig <= 4096, KPD_ERR_INVALID, "B=%d max_lig=%d", B, max_lig);
+    hipLaunchKernelGGL(k_sample_update, dim3(B), dim3(256), (size_t)max_lig * 3 * sizeof(float),
+                       static_cast<hipStream_t>(stream), lig_ptr, kp_ptr, atom_nf, lig_x, lig_h, kp_x, eps_x, eps_h,
+                       noise_x, noise_h, coef);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}

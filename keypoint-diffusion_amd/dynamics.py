@@ -1,0 +1,117 @@
+"""EGNN denoiser behind the reference's module interface.
+
+`LigRecDynamics` keeps the constructor signature, `forward(g, timestep, batch_idxs)` contract and
+state-dict layout of models/dynamics.py:298-385 (LigRecConv :9-87, LigRecEGNN :221-264), so a
+reference `model.pt` loads unchanged.  The modules below only own parameters; the arithmetic of
+`forward` -- encoders, per-step radius/kNN graph build, the EGNN stack and the decoder -- runs in
+libkpd_hip.so (csrc/egnn.hip).  Training (autograd through the fused kernels) is not implemented.
+"""
+from typing import Dict
+
+import torch
+import torch.nn as nn
+
+from . import hip
+from .graph import HeteroBatch
+
+
+def _mlp2(n_in, n_hidden, n_out, final_act):
+    layers = [nn.Linear(n_in, n_hidden), nn.SiLU(), nn.Linear(n_hidden, n_out)]
+    if final_act:
+        layers.append(nn.SiLU())
+    return nn.Sequential(*layers)
+
+
+class LigRecConv(nn.Module):
+    """Weights of one heterogeneous EGNN layer (models/dynamics.py:15-87)."""
+
+    def __init__(self, in_size, hidden_size, out_size, edge_feat_size=0, use_tanh=False, coords_range=10,
+                 update_kp_feat: bool = False, norm: bool = False):
+        super().__init__()
+        if edge_feat_size:
+            raise NotImplementedError('edge features are not implemented (as in the reference, dynamics.py:153)')
+        self.in_size, self.hidden_size, self.out_size = in_size, hidden_size, out_size
+        self.use_tanh, self.coords_range, self.update_kp_feat, self.norm = use_tanh, coords_range, update_kp_feat, norm
+        self.edge_types = ['ll', 'kl', 'lk', 'kk'] if update_kp_feat else ['ll', 'kl']
+        self.updated_node_types = ['lig', 'kp'] if update_kp_feat else ['lig']
+        f_in = 2 * in_size + 1                                   # [h_src, h_dst, d_ij]
+        self.edge_mlp = nn.ModuleDict({et: _mlp2(f_in, hidden_size, hidden_size, True) for et in self.edge_types})
+        self.soft_attention = nn.ModuleDict(
+            {et: nn.Sequential(nn.Linear(hidden_size, 1), nn.Sigmoid()) for et in self.edge_types})
+        self.node_mlp = nn.ModuleDict(
+            {nt: _mlp2(in_size + hidden_size, hidden_size, out_size, False) for nt in self.updated_node_types})
+        self.coord_mlp = nn.ModuleDict()
+        for et in self.edge_types:
+            head = nn.Linear(hidden_size, 1, bias=False)
+            nn.init.xavier_uniform_(head.weight, gain=0.001)
+            self.coord_mlp[et] = nn.Sequential(*_mlp2(f_in, hidden_size, hidden_size, True), head)
+        self.layer_norm = nn.ModuleDict(
+            {nt: nn.LayerNorm(out_size) if norm else nn.Identity() for nt in self.updated_node_types})
+
+
+class LigRecEGNN(nn.Module):
+    def __init__(self, n_layers, in_size, hidden_size, out_size, use_tanh=False, message_norm=1,
+                 update_kp_feat: bool = False, norm: bool = False):
+        super().__init__()
+        if not (in_size == hidden_size == out_size):
+            raise NotImplementedError('the fused layers assume in = hidden = out width (true for LigRecDynamics)')
+        self.n_layers, self.message_norm = n_layers, message_norm
+        self.update_kp_feat, self.norm = update_kp_feat, norm
+        self.conv_layers = nn.ModuleList([
+            LigRecConv(in_size, hidden_size, out_size, use_tanh=use_tanh, update_kp_feat=update_kp_feat, norm=norm)
+            for _ in range(n_layers)])
+
+
+class LigRecDynamics(nn.Module):
+
+    def __init__(self, atom_nf, rec_nf, n_layers=4, hidden_nf=255, act_fn=nn.SiLU, use_tanh=False, message_norm=1,
+                 no_cg: bool = False, n_keypoints: int = 20, graph_cutoffs: dict = {}, update_kp_feat: bool = False,
+                 norm: bool = False, ll_k: int = 0, kl_k: int = 0):
+        super().__init__()
+        if act_fn is not nn.SiLU:
+            raise NotImplementedError('only SiLU activations are implemented (every shipped config)')
+        self.atom_nf, self.rec_nf, self.n_layers, self.hidden_nf = atom_nf, rec_nf, n_layers, hidden_nf
+        self.use_tanh, self.message_norm, self.norm = use_tanh, message_norm, norm
+        self.no_cg, self.n_keypoints, self.graph_cutoffs = no_cg, n_keypoints, graph_cutoffs
+        self.update_kp_feat, self.ll_k, self.kl_k = update_kp_feat, ll_k, kl_k
+
+        self.lig_encoder = _mlp2(atom_nf, 64, hidden_nf, True)
+        self.lig_decoder = _mlp2(hidden_nf, 2 * atom_nf, atom_nf, False)
+        self.rec_encoder = _mlp2(rec_nf, 2 * rec_nf, hidden_nf, True) if rec_nf != hidden_nf else nn.Identity()
+        # +1: the timestep is appended to the encoded features (dynamics.py:337, 359-363)
+        self.egnn = LigRecEGNN(n_layers=n_layers, in_size=hidden_nf + 1, hidden_size=hidden_nf + 1,
+                               out_size=hidden_nf + 1, use_tanh=use_tanh, message_norm=message_norm,
+                               update_kp_feat=update_kp_feat, norm=norm)
+        self._engine = None
+        self._engine_key = None
+
+    # ---- HIP engine management ---------------------------------------------------------
+    def _weights_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def engine(self) -> 'hip.EgnnEngine':
+        """(Re)build the device engine when weights were replaced or modified in place."""
+        key = self._weights_key()
+        if self._engine is None or key != self._engine_key:
+            if self.ll_k != 0:
+                raise NotImplementedError('ll_k > 0 (kNN lig-lig graph) is not implemented in the HIP path')
+            if self.kl_k <= 0:
+                raise NotImplementedError('kl_k = 0 (radius keypoint->ligand graph) is not implemented in the HIP path')
+            if isinstance(self.message_norm, (dict, str)):
+                raise ValueError(f'message_norm must be a number for the EGNN denoiser, got {self.message_norm!r}')
+            eng = hip.EgnnEngine(self.atom_nf, self.rec_nf, self.n_layers, self.hidden_nf, self.use_tanh, self.norm,
+                                 self.update_kp_feat, self.message_norm, self.ll_k, self.kl_k,
+                                 self.graph_cutoffs['ll'], self.graph_cutoffs.get('kl', 0.0))
+            eng.load_state_dict(self.state_dict())
+            self._engine, self._engine_key = eng, key
+        return self._engine
+
+    def forward(self, g: HeteroBatch, timestep: torch.Tensor, batch_idxs: Dict[str, torch.Tensor] = None):
+        """Predicted noise (eps_h [N_lig, atom_nf], eps_x [N_lig, 3]); `batch_idxs` is accepted for
+        signature compatibility, the per-complex offsets are taken from the graph's batch info."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError('the HIP denoiser is forward-only; call it under torch.no_grad() '
+                                      '(backward kernels are listed as next work in DESIGN.md)')
+        pb = g.prepared()
+        lig, kp = g.nodes['lig'].data, g.nodes['kp'].data
+        return self.engine().forward(pb, lig['x_0'], lig['h_0'], kp['x_0'], kp['h_0'], timestep)

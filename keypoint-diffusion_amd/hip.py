@@ -1,0 +1,222 @@
+"""ctypes binding of libkpd_hip.so (C ABI in include/kpd.h).
+
+The library is the product: there is no PyTorch / CPU fallback.  If the shared object has
+not been built (`python __graft_entry__.py` or `make -C keypoint-diffusion_amd/csrc`) every
+entry point raises.
+"""
+import ctypes as C
+import os
+from typing import Dict, Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libkpd_hip.so')
+_lib = None
+
+c_int_p = C.POINTER(C.c_int32)
+c_float_p = C.POINTER(C.c_float)
+
+
+class KpdBatch(C.Structure):
+    _fields_ = [('B', C.c_int32), ('n_lig', C.c_int32), ('n_kp', C.c_int32), ('max_lig', C.c_int32),
+                ('max_kp', C.c_int32), ('lig_ptr', C.c_void_p), ('kp_ptr', C.c_void_p), ('lig_x', C.c_void_p),
+                ('lig_h', C.c_void_p), ('kp_x', C.c_void_p), ('kp_h', C.c_void_p), ('kp_v', C.c_void_p),
+                ('n_kk', C.c_int32), ('kk_src', C.c_void_p), ('kk_dst', C.c_void_p), ('kk_rowptr', C.c_void_p)]
+
+
+class KpdLigGraph(C.Structure):
+    _fields_ = [('cap_ll', C.c_int32), ('cap_kl', C.c_int32),
+                ('ll_src', C.c_void_p), ('ll_dst', C.c_void_p), ('ll_rowptr', C.c_void_p),
+                ('kl_src', C.c_void_p), ('kl_dst', C.c_void_p), ('kl_rowptr', C.c_void_p),
+                ('lk_src', C.c_void_p), ('lk_dst', C.c_void_p), ('lk_rowptr', C.c_void_p),
+                ('ll_per_graph', C.c_void_p), ('counts', C.c_void_p)]
+
+
+class KpdEgnnConfig(C.Structure):
+    _fields_ = [('atom_nf', C.c_int32), ('rec_nf', C.c_int32), ('n_layers', C.c_int32), ('hidden_nf', C.c_int32),
+                ('use_tanh', C.c_int32), ('norm', C.c_int32), ('update_kp_feat', C.c_int32),
+                ('message_norm', C.c_float), ('ll_k', C.c_int32), ('kl_k', C.c_int32),
+                ('ll_cutoff', C.c_float), ('kl_cutoff', C.c_float), ('coords_range', C.c_float)]
+
+
+class KpdError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the HIP library; raise loudly when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KpdError(f'{LIB_PATH} not found: the HIP extension must be built first '
+                       f'(python -c "import __graft_entry__ as g; g.build()"). There is no CPU fallback.')
+    L = C.CDLL(LIB_PATH)
+    L.kpd_last_error.restype = C.c_char_p
+    L.kpd_version.restype = C.c_int
+    for name in EXPORTS:
+        getattr(L, name)          # AttributeError if a declared symbol is not exported
+    L.kpd_egnn_create.argtypes = [C.POINTER(KpdEgnnConfig), C.POINTER(C.c_void_p)]
+    L.kpd_egnn_destroy.argtypes = [C.c_void_p]
+    L.kpd_egnn_destroy.restype = None
+    L.kpd_egnn_load_weight.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_void_p]
+    L.kpd_egnn_commit.argtypes = [C.c_void_p]
+    L.kpd_egnn_reserve.argtypes = [C.c_void_p] + [C.c_int32] * 6
+    L.kpd_egnn_forward.argtypes = [C.c_void_p, C.POINTER(KpdBatch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.kpd_egnn_debug_state.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p]
+    L.kpd_egnn_last_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]
+    L.kpd_build_lig_graph.argtypes = [C.POINTER(KpdBatch), C.c_float, C.c_int32, C.POINTER(KpdLigGraph), C.c_void_p]
+    L.kpd_sample_update.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 8 + [C.c_int32, C.c_void_p]
+    _lib = L
+    return L
+
+
+# every symbol include/kpd.h declares (checked by tests/test_abi.py against the header text)
+EXPORTS = [
+    'kpd_last_error', 'kpd_version', 'kpd_build_lig_graph',
+    'kpd_egnn_create', 'kpd_egnn_destroy', 'kpd_egnn_load_weight', 'kpd_egnn_commit', 'kpd_egnn_reserve',
+    'kpd_egnn_forward', 'kpd_egnn_debug_state', 'kpd_egnn_last_counts', 'kpd_sample_update',
+]
+
+
+def check(status: int):
+    if status != 0:
+        raise KpdError(f'kpd status {status}: {lib().kpd_last_error().decode()}')
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _dev_f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise KpdError(f'{name} must live on the GPU (got {t.device}); the hot path has no CPU implementation')
+    return t.contiguous().float()
+
+
+class PreparedBatch:
+    """Device-side, int32, dst-sorted view of the static part of a batch (built once per batch)."""
+
+    def __init__(self, lig_counts: torch.Tensor, kp_counts: torch.Tensor, kk_src: torch.Tensor, kk_dst: torch.Tensor,
+                 device):
+        lig_counts = lig_counts.cpu().long()
+        kp_counts = kp_counts.cpu().long()
+        self.B = int(lig_counts.numel())
+        self.n_lig = int(lig_counts.sum())
+        self.n_kp = int(kp_counts.sum())
+        self.max_lig = int(lig_counts.max())
+        self.max_kp = int(kp_counts.max())
+        if int(lig_counts.min()) < 1 or int(kp_counts.min()) < 1:
+            raise KpdError('every complex needs at least one ligand atom and one keypoint')
+        zero = torch.zeros(1, dtype=torch.long)
+        self.lig_ptr = torch.cat([zero, lig_counts.cumsum(0)]).int().to(device)
+        self.kp_ptr = torch.cat([zero, kp_counts.cumsum(0)]).int().to(device)
+        kk_src = kk_src.to(device).long()
+        kk_dst = kk_dst.to(device).long()
+        if kk_src.numel():
+            order = torch.argsort(kk_dst * (self.n_kp + 1) + kk_src)      # (dst, src) lexicographic
+            kk_src, kk_dst = kk_src[order], kk_dst[order]
+        self.n_kk = int(kk_src.numel())
+        self.kk_src = kk_src.int().contiguous()
+        self.kk_dst = kk_dst.int().contiguous()
+        deg = torch.bincount(kk_dst, minlength=self.n_kp) if self.n_kk else torch.zeros(self.n_kp, dtype=torch.long, device=device)
+        self.kk_rowptr = torch.cat([torch.zeros(1, dtype=torch.long, device=device), deg.cumsum(0)]).int().contiguous()
+
+    def struct(self, lig_x, lig_h, kp_x, kp_h, kp_v=None) -> KpdBatch:
+        return KpdBatch(self.B, self.n_lig, self.n_kp, self.max_lig, self.max_kp, _ptr(self.lig_ptr), _ptr(self.kp_ptr),
+                        _ptr(lig_x), _ptr(lig_h), _ptr(kp_x), _ptr(kp_h), _ptr(kp_v), self.n_kk, _ptr(self.kk_src),
+                        _ptr(self.kk_dst), _ptr(self.kk_rowptr))
+
+
+def build_lig_graph(pb: PreparedBatch, lig_x: torch.Tensor, kp_x: torch.Tensor, ll_cutoff: float, kl_k: int):
+    """Standalone graph build (kpd_build_lig_graph); returns a dict of int32 device tensors."""
+    dev = lig_x.device
+    lig_x, kp_x = _dev_f32(lig_x, 'lig_x'), _dev_f32(kp_x, 'kp_x')
+    cap_ll = max(pb.n_lig * min(pb.max_lig - 1, 200), 1)
+    cap_kl = max(pb.n_kp * kl_k, 1)
+    i32 = lambda n: torch.zeros(n, dtype=torch.int32, device=dev)
+    out = dict(ll_src=i32(cap_ll), ll_dst=i32(cap_ll), ll_rowptr=i32(pb.n_lig + 1),
+               kl_src=i32(cap_kl), kl_dst=i32(cap_kl), kl_rowptr=i32(pb.n_lig + 1),
+               lk_src=i32(cap_kl), lk_dst=i32(cap_kl), lk_rowptr=i32(pb.n_kp + 1),
+               ll_per_graph=i32(pb.B), counts=i32(8))
+    lg = KpdLigGraph(cap_ll, cap_kl, *[_ptr(out[k]) for k in
+                                      ('ll_src', 'll_dst', 'll_rowptr', 'kl_src', 'kl_dst', 'kl_rowptr',
+                                       'lk_src', 'lk_dst', 'lk_rowptr', 'll_per_graph', 'counts')])
+    bt = pb.struct(lig_x, None, kp_x, None)
+    check(lib().kpd_build_lig_graph(C.byref(bt), float(ll_cutoff), int(kl_k), C.byref(lg), _stream()))
+    return out
+
+
+class EgnnEngine:
+    """Owns one kpd_egnn handle: packed weights + workspace for LigRecDynamics.forward."""
+
+    def __init__(self, atom_nf, rec_nf, n_layers, hidden_nf, use_tanh, norm, update_kp_feat, message_norm, ll_k, kl_k,
+                 ll_cutoff, kl_cutoff, coords_range=10.0):
+        self.cfg = KpdEgnnConfig(int(atom_nf), int(rec_nf), int(n_layers), int(hidden_nf), int(bool(use_tanh)),
+                                 int(bool(norm)), int(bool(update_kp_feat)), float(message_norm), int(ll_k), int(kl_k),
+                                 float(ll_cutoff), float(kl_cutoff), float(coords_range))
+        self.atom_nf = int(atom_nf)
+        self._h = C.c_void_p()
+        check(lib().kpd_egnn_create(C.byref(self.cfg), C.byref(self._h)))
+        self._reserved = None
+
+    def __del__(self):
+        if getattr(self, '_h', None) and _lib is not None:
+            _lib.kpd_egnn_destroy(self._h)
+            self._h = None
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+        L = lib()
+        st = _stream()
+        keep = []
+        for name, t in sd.items():
+            t = _dev_f32(t.detach(), name)
+            keep.append(t)
+            shape = (C.c_int64 * t.dim())(*t.shape)
+            check(L.kpd_egnn_load_weight(self._h, name.encode(), t.data_ptr(), shape, t.dim(), st))
+        torch.cuda.current_stream().synchronize()     # packing kernels read the source tensors
+        check(L.kpd_egnn_commit(self._h))
+
+    def reserve(self, pb: PreparedBatch):
+        key = (pb.B, pb.n_lig, pb.n_kp, pb.n_kk, pb.max_lig, pb.max_kp)
+        if self._reserved is not None and all(a <= b for a, b in zip(key, self._reserved)):
+            return
+        torch.cuda.synchronize()
+        check(lib().kpd_egnn_reserve(self._h, *key))
+        self._reserved = key if self._reserved is None else tuple(max(a, b) for a, b in zip(key, self._reserved))
+
+    def forward(self, pb: PreparedBatch, lig_x, lig_h, kp_x, kp_h, t):
+        self.reserve(pb)
+        lig_x, lig_h = _dev_f32(lig_x, 'lig x_0'), _dev_f32(lig_h, 'lig h_0')
+        kp_x, kp_h = _dev_f32(kp_x, 'kp x_0'), _dev_f32(kp_h, 'kp h_0')
+        t = _dev_f32(t, 'timestep')
+        eps_h = torch.empty(pb.n_lig, self.atom_nf, device=lig_x.device)
+        eps_x = torch.empty(pb.n_lig, 3, device=lig_x.device)
+        bt = pb.struct(lig_x, lig_h, kp_x, kp_h)
+        check(lib().kpd_egnn_forward(self._h, C.byref(bt), t.data_ptr(), eps_h.data_ptr(), eps_x.data_ptr(), _stream()))
+        return eps_h, eps_x
+
+    def debug(self, what: str, n_floats: int = 0, device=None) -> Optional[torch.Tensor]:
+        out = torch.empty(max(n_floats, 1), device=device or 'cuda')
+        check(lib().kpd_egnn_debug_state(self._h, what.encode(), out.data_ptr(), n_floats, _stream()))
+        return out if n_floats else None
+
+    def last_counts(self):
+        arr = (C.c_int32 * 8)()
+        check(lib().kpd_egnn_last_counts(self._h, arr, _stream()))
+        return dict(E_ll=arr[0], E_kl=arr[1], E_lk=arr[2], E_kk=arr[3], tiles=arr[4])
+
+
+def sample_update(pb: PreparedBatch, atom_nf, lig_x, lig_h, kp_x, eps_x, eps_h, noise_x, noise_h, coef):
+    """In-place reverse-diffusion update + ligand-COM removal (kpd_sample_update)."""
+    for t in (lig_x, lig_h, kp_x):
+        if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
+            raise KpdError('sample_update state tensors must be contiguous fp32 GPU tensors (updated in place)')
+    args = [_dev_f32(a, 'arg') for a in (eps_x, eps_h, noise_x, noise_h, coef)]
+    check(lib().kpd_sample_update(pb.B, _ptr(pb.lig_ptr), _ptr(pb.kp_ptr), int(atom_nf), _ptr(lig_x), _ptr(lig_h),
+                                  _ptr(kp_x), *[a.data_ptr() for a in args], pb.max_lig, _stream()))

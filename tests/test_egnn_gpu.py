@@ -1,0 +1,119 @@
+"""GPU parity of the HIP EGNN denoiser (through the C ABI) against the CPU oracle."""
+import pytest
+import torch
+
+from keypoint_diffusion_amd import graph as G
+from keypoint_diffusion_amd import hip, synth
+from keypoint_diffusion_amd.dynamics import LigRecDynamics
+from oracle import egnn as oegnn
+from oracle import graph_ops as og
+
+from . import util
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4          # BASELINE.json north_star: "within 1e-4 rel fp32"
+
+
+def _edges_from_hip(out, n):
+    E_ll, E_kl = int(out['counts'][0]), int(out['counts'][1])
+    return {
+        'll': (out['ll_src'][:E_ll].long().cpu(), out['ll_dst'][:E_ll].long().cpu()),
+        'kl': (out['kl_src'][:E_kl].long().cpu(), out['kl_dst'][:E_kl].long().cpu()),
+        'lk': (out['lk_src'][:E_kl].long().cpu(), out['lk_dst'][:E_kl].long().cpu()),
+    }
+
+
+def _edge_set(src, dst):
+    return set(zip(src.tolist(), dst.tolist()))
+
+
+@pytest.mark.parametrize('n_rec,n_lig', [([60], [20]), ([300, 150, 420], [25, 4, 37]), ([35, 600], [60, 3])])
+def test_lig_graph_build(cuda, n_rec, n_lig):
+    g = util.fixed_encode(util.make_batch(n_rec, n_lig)).to(cuda)
+    pb = g.prepared()
+    lx, kx = g.nodes['lig'].data['x_0'], g.nodes['kp'].data['x_0']
+    out = hip.build_lig_graph(pb, lx, kx, 6.0, 5)
+    torch.cuda.synchronize()
+    e = _edges_from_hip(out, pb)
+    ob = util.to_obatch(g)
+    ref = oegnn.lig_edges(ob, dict(graph_cutoffs={'ll': 6.0}, kl_k=5, ll_k=0))
+    # ll: identical edge set, dst-sorted, rowptr consistent
+    assert _edge_set(*e['ll']) == _edge_set(*ref['ll'])
+    assert torch.equal(e['ll'][0], ref['ll'][0]) and torch.equal(e['ll'][1], ref['ll'][1])
+    deg = torch.bincount(e['ll'][1], minlength=pb.n_lig)
+    assert torch.equal(out['ll_rowptr'].long().cpu()[1:] - out['ll_rowptr'].long().cpu()[:-1], deg)
+    assert torch.equal(out['ll_per_graph'].long().cpu(), og.edges_per_graph(ref['ll'][1], ob.n['lig']))
+    # kl / lk: same pairs (oracle kl is kp-major; HIP kl is lig-major, lk is kp-major nearest first)
+    assert _edge_set(*e['kl']) == _edge_set(*ref['kl'])
+    assert torch.equal(e['lk'][0], ref['lk'][0]) and torch.equal(e['lk'][1], ref['lk'][1])
+    assert bool((e['kl'][1][1:] >= e['kl'][1][:-1]).all())
+    deg = torch.bincount(e['kl'][1], minlength=pb.n_lig)
+    assert torch.equal(out['kl_rowptr'].long().cpu()[1:] - out['kl_rowptr'].long().cpu()[:-1], deg)
+
+
+def _run_pair(cuda, cfg, n_rec, n_lig, seed=3, rec_nf=10, layers=None):
+    g = util.fixed_encode(util.make_batch(n_rec, n_lig, n_rec_feat=rec_nf))
+    model = LigRecDynamics(10, rec_nf, graph_cutoffs=util.CUTOFFS_ALL_ATOM, **cfg)
+    synth.fill_state_dict_(model, seed)
+    model.eval()
+    B = g.batch_size
+    t = (torch.arange(B, dtype=torch.float32) + 1) / (B + 1)
+    ob = util.to_obatch(g)
+    ocfg = dict(cfg, graph_cutoffs=util.CUTOFFS_ALL_ATOM)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    if layers is not None:
+        ocfg['n_layers'] = layers
+    ref_h, ref_x = oegnn.egnn_dynamics_forward(sd, ocfg, ob, t)
+    model = model.to(cuda)
+    gd = g.to(cuda)
+    with torch.no_grad():
+        if layers is not None:
+            model.engine().debug(f'layers={layers}')
+        eps_h, eps_x = model(gd, t.to(cuda), G.get_batch_idxs(gd))
+    torch.cuda.synchronize()
+    return (eps_h.cpu(), eps_x.cpu()), (ref_h, ref_x), model
+
+
+@pytest.mark.parametrize('layers', [0, 1, 2, 6])
+def test_egnn_c2_shape_layers(cuda, layers):
+    (h, x), (rh, rx), _ = _run_pair(cuda, util.EGNN_C2, [300, 150], [25, 9], layers=layers)
+    assert util.rel_err(h, rh) < TOL, f'eps_h rel err {util.rel_err(h, rh)}'
+    if layers > 0:
+        assert util.rel_err(x, rx) < TOL, f'eps_x rel err {util.rel_err(x, rx)}'
+    else:
+        assert float(x.abs().max()) == 0.0
+
+
+def test_egnn_ragged_batch(cuda):
+    (h, x), (rh, rx), model = _run_pair(cuda, util.EGNN_C2, [150, 600, 35, 300, 64], [15, 35, 3, 60, 25])
+    assert util.rel_err(h, rh) < TOL and util.rel_err(x, rx) < TOL
+    c = model.engine().last_counts()
+    assert c['E_kl'] == c['E_lk'] and c['tiles'] > 0
+
+
+def test_egnn_dev_config_no_kp_update(cuda):
+    # configs/dev_config.yml: update_kp_feat False, C-alpha pocket (rec_nf 20), ll cutoff from graph section
+    (h, x), (rh, rx), _ = _run_pair(cuda, util.EGNN_DEV, [60], [20], rec_nf=20)
+    assert util.rel_err(h, rh) < TOL and util.rel_err(x, rx) < TOL
+
+
+def test_egnn_const_message_norm_no_tanh_no_norm(cuda):
+    cfg = dict(util.EGNN_C2, message_norm=5.0, use_tanh=False, norm=False, n_layers=3, kl_k=7)
+    (h, x), (rh, rx), _ = _run_pair(cuda, cfg, [120, 90], [12, 30])
+    assert util.rel_err(h, rh) < TOL and util.rel_err(x, rx) < TOL
+
+
+def test_batch_independence(cuda):
+    """Batched output equals per-complex outputs (every graph op is batch-masked)."""
+    n_rec, n_lig = [200, 90, 310], [25, 11, 18]
+    (h, x), _, model = _run_pair(cuda, util.EGNN_C2, n_rec, n_lig)
+    off = 0
+    for i, (nr, nl) in enumerate(zip(n_rec, n_lig)):
+        gs = synth.synth_complexes(n_rec, n_lig, 20, util.CUTOFFS_ALL_ATOM, seed=1234)
+        g1 = util.fixed_encode(G.batch([gs[i]])).to(cuda)
+        t = torch.tensor([(i + 1) / (len(n_rec) + 1)], device=cuda)
+        with torch.no_grad():
+            h1, x1 = model(g1, t, None)
+        assert util.rel_err(h1.cpu(), h[off:off + nl]) < 1e-5
+        assert util.rel_err(x1.cpu(), x[off:off + nl]) < 1e-5
+        off += nl
