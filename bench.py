@@ -1,0 +1,191 @@
+#!/usr/bin/env python
+"""Headline benchmark: denoising steps/sec of the reverse-diffusion hot path on MI355X.
+
+A *step* is one reverse-diffusion step (`KeypointDiffusion.sample_p_zs_given_zt`:
+denoiser forward + z_s update + COM removal) over one batch of B synthetic complexes that
+is already resident in HBM.  Workload = BASELINE.json configs[1]:
+egnn_all_atom dynamics, B = 64 synthetic 300-atom pockets / 25-atom ligands, T = 500.
+
+    python bench.py --gpus N --steps K --warmup W
+N > 1: launched by torch.distributed.run, one rank per GPU; every rank owns its own batch of B
+complexes (weak scaling, no data-path collective), one RCCL all-gather of the ligand tensors
+at the end of the timed region (the exchange the sampler performs after the last step).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from keypoint_diffusion_amd import graph as G            # noqa: E402
+from keypoint_diffusion_amd import synth                 # noqa: E402
+from keypoint_diffusion_amd.ligand_diffuser import KeypointDiffusion   # noqa: E402
+
+CUTOFFS = {'kk': 8, 'kl': 6, 'll': 6, 'rk': 100, 'rr': 3.5}      # trained_models/egnn_all_atom/config.yml
+DYNAMICS = dict(hidden_nf=256, kl_k=5, ll_k=0, message_norm=0, n_layers=6, no_cg=False, norm=True,
+                update_kp_feat=True, use_tanh=True)
+N_TIMESTEPS = 500
+PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+# FLOPs the fused edge kernel is responsible for, per edge per layer: the two 257x257 second
+# Linears of edge_mlp / coord_mlp plus the attention and coordinate heads
+EDGE_KERNEL_FLOP_PER_EDGE = 2 * (2 * 257 * 257) + 2 * (2 * 257)
+# reference formulation of the same edge work: both Linears of both MLPs
+EDGE_ALGO_FLOP_PER_EDGE = 2 * (515 * 257 + 257 * 257) * 2 + 4 * 257
+EDGE_ALGO_BYTES_PER_EDGE = 4 * 257 + 16          # gathered row + coords + index
+
+
+def build_model(device):
+    model = KeypointDiffusion(10, 10, None, n_timesteps=N_TIMESTEPS, architecture='egnn', rec_encoder_type='fixed',
+                              graph_config=dict(n_keypoints=20, graph_cutoffs=CUTOFFS), dynamics_config=DYNAMICS,
+                              rec_encoder_config={}, precision=1e-5)
+    synth.fill_state_dict_(model, seed=0)
+    return model.eval().to(device)
+
+
+def build_batch(model, B, n_rec, n_lig, seed, device):
+    gs = synth.synth_complexes([n_rec] * B, [n_lig] * B, 20, CUTOFFS, seed=seed)
+    g = model.encode_receptors(G.batch(gs))          # fixed encoder: kp := rec, kk := rr
+    return g.to(device)
+
+
+def cpu_baseline(B_sample=4, steps=2):
+    """Oracle (CPU restatement of the reference path) on this box's host cores, same shape."""
+    from oracle import diffusion as odiff
+    from oracle import egnn as oegnn
+    from tests.util import to_obatch
+    model = build_model('cpu')
+    g = build_batch(model, B_sample, 300, 25, seed=99, device='cpu')
+    ob = to_obatch(g)
+    sd = {k[len('dynamics.'):]: v for k, v in model.state_dict().items() if k.startswith('dynamics.')}
+    cfg = dict(DYNAMICS, graph_cutoffs=CUTOFFS)
+    table = odiff.gamma_table(N_TIMESTEPS, 1e-5)
+    gen = torch.Generator().manual_seed(5)
+
+    def one(si):
+        s = torch.full((B_sample,), si / N_TIMESTEPS)
+        t = torch.full((B_sample,), (si + 1) / N_TIMESTEPS)
+        eh, ex = oegnn.egnn_dynamics_forward(sd, cfg, ob, t)
+        odiff.sample_step(ob, eh, ex, s, t, table, N_TIMESTEPS, torch.randn(ob.x['lig'].shape, generator=gen),
+                          torch.randn(ob.h['lig'].shape, generator=gen))
+
+    with torch.no_grad():
+        one(N_TIMESTEPS - 1)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            one(N_TIMESTEPS - 2 - i)
+        dt = time.perf_counter() - t0
+    complex_steps_per_s = B_sample * steps / dt
+    return {'value': complex_steps_per_s / 64.0, 'unit': 'steps/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'complex_steps_per_s': complex_steps_per_s,
+            'sample': f'oracle (plain PyTorch fp32 CPU restatement) on {B_sample} complexes of the same 300/25 shape x '
+                      f'{steps} reverse steps after 1 warm-up, scaled to the B=64 batch'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=64)
+    ap.add_argument('--n-rec', type=int, default=300)
+    ap.add_argument('--n-lig', type=int, default=25)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the hot path has no CPU implementation')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=device)
+    if args.gpus != world:
+        print(f'[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}', file=sys.stderr)
+
+    torch.manual_seed(1000 + rank)
+    model = build_model(device)
+    B = args.batch
+    g = build_batch(model, B, args.n_rec, args.n_lig, seed=1234 + rank * B, device=device)
+    bidx = G.get_batch_idxs(g)
+    eng = model.dynamics.engine()
+    ones = torch.ones(B, device=device)
+
+    def step(i):
+        si = N_TIMESTEPS - 1 - (i % N_TIMESTEPS)
+        model.sample_p_zs_given_zt(ones * (si / N_TIMESTEPS), ones * ((si + 1) / N_TIMESTEPS), g, bidx)
+
+    with torch.no_grad():
+        for i in range(args.warmup):
+            step(i)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        eng.profile(True)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i)
+        if dist is not None:
+            from keypoint_diffusion_amd.dist import all_gather_ligands
+            all_gather_ligands(g)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    edge_ms, edge_launches = eng.profile_read()
+    eng.profile(False)
+    counts = eng.last_counts()
+
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        steps_per_s = world * args.steps / elapsed
+        n_edges = counts['E_ll'] + counts['E_kl'] + counts['E_lk'] + counts['E_kk']
+        edge_avg_s = edge_ms / max(edge_launches, 1) * 1e-3
+        achieved = n_edges * EDGE_KERNEL_FLOP_PER_EDGE / edge_avg_s / 1e12 if edge_avg_s > 0 else 0.0
+        hbm_gbs = n_edges * EDGE_ALGO_BYTES_PER_EDGE / edge_avg_s / 1e9 if edge_avg_s > 0 else 0.0
+        out = {
+            'metric': 'denoising steps/sec', 'value': steps_per_s, 'unit': 'steps/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'egnn_all_atom dynamics (6 EGNN layers, hidden 256, update_kp_feat), batch of {B} '
+                                   f'synthetic {args.n_rec}-atom pockets / {args.n_lig}-atom ligands per GPU, '
+                                   f'T={N_TIMESTEPS}, seeded random-init weights',
+                       'batch_per_gpu': B, 'n_rec': args.n_rec, 'n_lig': args.n_lig, 'parallelism': f'dp{world}'},
+            'complex_steps_per_s': steps_per_s * B,
+            'ligands_per_min': steps_per_s * B * 60.0 / N_TIMESTEPS,
+            'edges_per_step_layer': counts,
+            'roofline': {'kernel': 'k_egnn_edge', 'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MATRIX_TFLOPS,
+                         'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MATRIX_TFLOPS, 'traffic': None,
+                         'avg_launch_ms': edge_avg_s * 1e3, 'launches': edge_launches,
+                         'flop_per_launch': n_edges * EDGE_KERNEL_FLOP_PER_EDGE,
+                         'reference_formulation_tflops': n_edges * EDGE_ALGO_FLOP_PER_EDGE / edge_avg_s / 1e12
+                         if edge_avg_s > 0 else 0.0,
+                         'hbm': {'achieved': hbm_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': hbm_gbs / PEAK_HBM_GBS,
+                                 'bytes_per_launch': n_edges * EDGE_ALGO_BYTES_PER_EDGE}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+            out['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -114,6 +114,10 @@ kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *batch, const float *t_
 /* Debug/test taps: copy of the node state after `layer` (h [n,257] with row stride 264). */
 kpd_status kpd_egnn_debug_state(kpd_egnn *m, const char *what, float *out_dev, int64_t n_floats,
                                 void *stream);
+/* HIP-event timing of the dominant kernel (the fused edge kernel), recorded on the caller's
+ * stream around each of its launches while enabled (up to 8192 launches per enable). */
+kpd_status kpd_egnn_profile(kpd_egnn *m, int32_t enable);
+kpd_status kpd_egnn_profile_read(kpd_egnn *m, double *total_ms, int32_t *launches);
 /* Launch geometry of the last forward: {E_ll, E_kl, E_lk, E_kk, edge tiles}. */
 kpd_status kpd_egnn_last_counts(kpd_egnn *m, int32_t out[8], void *stream);
 

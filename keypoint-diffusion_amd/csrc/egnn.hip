@@ -70,6 +70,10 @@ struct kpd_egnn {
     std::set<std::string> expected, loaded;
     bool committed = false;
     int debug_layers = -1;
+    // optional HIP-event timing of the dominant kernel (k_egnn_edge), for bench.py's roofline
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;
+    size_t prof_used = 0;
 
     // workspace (valid after reserve)
     int cap_B = 0, cap_lig = 0, cap_kp = 0, cap_kk = 0, cap_ll = 0, cap_kl = 0, cap_maxlig = 0, cap_maxkp = 0;
@@ -174,6 +178,7 @@ extern "C" kpd_status kpd_egnn_create(const kpd_egnn_config *cfg, kpd_egnn **out
 
 extern "C" void kpd_egnn_destroy(kpd_egnn *m) {
     if (!m) return;
+    for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
     m->warena.release();
     m->ws.release();
     delete m;
@@ -461,7 +466,13 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
             ea.hn_main[et] = m->hn_main[et]; ea.hn_cont[et] = m->hn_cont[et];
             ea.xn_main[et] = m->xn_main[et]; ea.xn_cont[et] = m->xn_cont[et];
         }
+        const bool prof = m->prof_on && m->prof_used + 2 <= m->prof_ev.size();
+        if (prof) KPD_HIP(hipEventRecord(m->prof_ev[m->prof_used], st));
         KPD_TRY(launch_egnn_edge(ea, tile_cap, st));
+        if (prof) {
+            KPD_HIP(hipEventRecord(m->prof_ev[m->prof_used + 1], st));
+            m->prof_used += 2;
+        }
         for (int nt = 0; nt < m->n_upd; ++nt) {
             NodeArgs na;
             memset(&na, 0, sizeof(na));
@@ -503,6 +514,31 @@ extern "C" kpd_status kpd_egnn_debug_state(kpd_egnn *m, const char *what, float 
     }
     KPD_REQUIRE(src, KPD_ERR_INVALID, "unknown debug tap '%s'", what);
     KPD_HIP(hipMemcpyAsync(out, src, (size_t)n_floats * 4, hipMemcpyDeviceToDevice, st));
+    return KPD_OK;
+}
+
+extern "C" kpd_status kpd_egnn_profile(kpd_egnn *m, int32_t enable) {
+    KPD_REQUIRE(m, KPD_ERR_INVALID, "null handle");
+    if (enable && m->prof_ev.empty()) {
+        m->prof_ev.resize(2 * 8192);
+        for (hipEvent_t &e : m->prof_ev) KPD_HIP(hipEventCreate(&e));
+    }
+    m->prof_on = enable != 0;
+    m->prof_used = 0;
+    return KPD_OK;
+}
+
+extern "C" kpd_status kpd_egnn_profile_read(kpd_egnn *m, double *total_ms, int32_t *launches) {
+    KPD_REQUIRE(m && total_ms && launches, KPD_ERR_INVALID, "null argument");
+    double tot = 0.0;
+    for (size_t i = 0; i + 1 < m->prof_used; i += 2) {
+        KPD_HIP(hipEventSynchronize(m->prof_ev[i + 1]));
+        float ms = 0.0f;
+        KPD_HIP(hipEventElapsedTime(&ms, m->prof_ev[i], m->prof_ev[i + 1]));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *launches = (int32_t)(m->prof_used / 2);
     return KPD_OK;
 }
 

@@ -1,0 +1,81 @@
+"""GVP denoiser behind the reference's module interface (models/dynamics_gvp.py:10-199).
+
+Parameter containers with the reference state-dict layout; `forward` runs in libkpd_hip.so
+(csrc/gvp.hip).
+"""
+from typing import Dict, Union
+
+import torch
+import torch.nn as nn
+
+from . import hip
+from .graph import HeteroBatch
+from .gvp import GVP, GVPMultiEdgeConv
+
+
+class NoisePredictionBlock(nn.Module):
+    """dynamics_gvp.py:12-36: n GVPs, the last one to (64 scalars, 1 vector, identity vector act)."""
+
+    def __init__(self, in_scalar_dim: int, out_scalar_dim: int, vector_size: int, n_gvps: int = 3,
+                 intermediate_scalar_dim: int = 64):
+        super().__init__()
+        gvps = []
+        for i in range(n_gvps):
+            last = i == n_gvps - 1
+            gvps.append(GVP(dim_vectors_in=vector_size, dim_vectors_out=1 if last else vector_size,
+                            dim_feats_in=in_scalar_dim, dim_feats_out=intermediate_scalar_dim if last else in_scalar_dim,
+                            vectors_activation=nn.Identity() if last else nn.Sigmoid()))
+        self.gvps = nn.Sequential(*gvps)
+        self.to_scalar_output = nn.Linear(intermediate_scalar_dim, out_scalar_dim)
+
+
+class LigRecGVP(nn.Module):
+    no_kp_update_edges = [('lig', 'll', 'lig'), ('kp', 'kl', 'lig')]
+    kp_update_edges = no_kp_update_edges + [('lig', 'lk', 'kp'), ('kp', 'kk', 'kp')]
+
+    def __init__(self, in_scalar_dim: int, in_vector_dim: int, out_scalar_dim: int, update_kp: bool = False,
+                 n_convs: int = 4, n_message_gvps: int = 3, n_update_gvps: int = 2,
+                 message_norm: Union[float, str, Dict] = 10, n_noise_gvps: int = 3, dropout: float = 0.0):
+        super().__init__()
+        self.update_kp = update_kp
+        self.conv_layers = nn.ModuleList()
+        for i in range(n_convs):
+            # keypoints are not updated by the last convolution (dynamics_gvp.py:67-72)
+            ets = self.kp_update_edges if (update_kp and i != n_convs - 1) else self.no_kp_update_edges
+            self.conv_layers.append(GVPMultiEdgeConv(etypes=ets, scalar_size=in_scalar_dim, vector_size=in_vector_dim,
+                                                     n_message_gvps=n_message_gvps, n_update_gvps=n_update_gvps,
+                                                     message_norm=message_norm, dropout=dropout))
+        self.noise_predictor = NoisePredictionBlock(in_scalar_dim=in_scalar_dim, out_scalar_dim=out_scalar_dim,
+                                                    vector_size=in_vector_dim, n_gvps=n_noise_gvps)
+
+
+class LigRecDynamicsGVP(nn.Module):
+
+    def __init__(self, n_lig_scalars, n_kp_scalars, vector_size: int = 16, n_convs=4, n_hidden_scalars=128,
+                 act_fn=nn.SiLU, message_norm=1, no_cg: bool = False, n_keypoints: int = 20, graph_cutoffs: dict = {},
+                 update_kp: bool = False, ll_k: int = 0, kl_k: int = 0, n_message_gvps: int = 3, n_update_gvps: int = 2,
+                 n_noise_gvps: int = 3, dropout: float = 0.0):
+        super().__init__()
+        if no_cg:
+            raise NotImplementedError('No CG is not implemented for GVP')
+        if act_fn is not nn.SiLU:
+            raise NotImplementedError('only SiLU activations are implemented (every shipped config)')
+        if not update_kp and n_convs > 1:
+            # the reference drops 'kp' from node_data after the first conv and fails (gvp.py:501, 536)
+            raise NotImplementedError('update_kp=False with more than one convolution cannot run in the reference')
+        self.n_keypoints, self.graph_cutoffs, self.update_kp = n_keypoints, graph_cutoffs, update_kp
+        self.n_lig_scalars, self.n_kp_scalars, self.vector_size = n_lig_scalars, n_kp_scalars, vector_size
+        self.n_convs, self.n_hidden_scalars, self.message_norm = n_convs, n_hidden_scalars, message_norm
+        self.n_message_gvps, self.n_update_gvps, self.n_noise_gvps = n_message_gvps, n_update_gvps, n_noise_gvps
+        self.ll_k, self.kl_k = ll_k, kl_k
+        self.lig_encoder = nn.Sequential(nn.Linear(n_lig_scalars + 1, n_hidden_scalars), act_fn(), nn.LayerNorm(n_hidden_scalars))
+        self.kp_encoder = nn.Sequential(nn.Linear(n_kp_scalars + 1, n_hidden_scalars), act_fn(), nn.LayerNorm(n_hidden_scalars))
+        self.noise_predictor = LigRecGVP(in_scalar_dim=n_hidden_scalars, in_vector_dim=vector_size,
+                                         out_scalar_dim=n_lig_scalars, update_kp=update_kp, n_convs=n_convs,
+                                         n_message_gvps=n_message_gvps, n_update_gvps=n_update_gvps,
+                                         n_noise_gvps=n_noise_gvps, message_norm=message_norm, dropout=dropout)
+        self._engine = None
+        self._engine_key = None
+
+    def forward(self, g: HeteroBatch, timestep: torch.Tensor, batch_idxs: Dict[str, torch.Tensor] = None):
+        raise NotImplementedError('the GVP denoiser HIP path is not built yet in this revision')

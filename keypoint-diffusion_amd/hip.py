@@ -66,6 +66,8 @@ def lib():
     L.kpd_egnn_forward.argtypes = [C.c_void_p, C.POINTER(KpdBatch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.kpd_egnn_debug_state.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p]
     L.kpd_egnn_last_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]
+    L.kpd_egnn_profile.argtypes = [C.c_void_p, C.c_int32]
+    L.kpd_egnn_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     L.kpd_build_lig_graph.argtypes = [C.POINTER(KpdBatch), C.c_float, C.c_int32, C.POINTER(KpdLigGraph), C.c_void_p]
     L.kpd_sample_update.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 8 + [C.c_int32, C.c_void_p]
     _lib = L
@@ -76,7 +78,8 @@ def lib():
 EXPORTS = [
     'kpd_last_error', 'kpd_version', 'kpd_build_lig_graph',
     'kpd_egnn_create', 'kpd_egnn_destroy', 'kpd_egnn_load_weight', 'kpd_egnn_commit', 'kpd_egnn_reserve',
-    'kpd_egnn_forward', 'kpd_egnn_debug_state', 'kpd_egnn_last_counts', 'kpd_sample_update',
+    'kpd_egnn_forward', 'kpd_egnn_debug_state', 'kpd_egnn_last_counts', 'kpd_egnn_profile',
+    'kpd_egnn_profile_read', 'kpd_sample_update',
 ]
 
 
@@ -205,6 +208,15 @@ class EgnnEngine:
         out = torch.empty(max(n_floats, 1), device=device or 'cuda')
         check(lib().kpd_egnn_debug_state(self._h, what.encode(), out.data_ptr(), n_floats, _stream()))
         return out if n_floats else None
+
+    def profile(self, enable: bool):
+        check(lib().kpd_egnn_profile(self._h, int(enable)))
+
+    def profile_read(self):
+        """(total ms, launches) of the fused edge kernel since profile(True)."""
+        ms, n = C.c_double(), C.c_int32()
+        check(lib().kpd_egnn_profile_read(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def last_counts(self):
         arr = (C.c_int32 * 8)()

@@ -1,0 +1,258 @@
+"""`KeypointDiffusion`: the diffusion wrapper around the denoiser, with the reference's public
+surface (models/ligand_diffuser.py:24-538) on the HIP hot path.
+
+Host code (this file) is tensor plumbing and the noise schedule; every per-timestep tensor
+operation -- denoiser forward, z_s update, COM removal -- is a call into libkpd_hip.so.
+`LigandDiffuser` is kept as an alias (BASELINE.json names the class that way).
+"""
+import pickle
+from math import ceil
+from pathlib import Path
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import graph as G
+from . import hip
+from .dynamics import LigRecDynamics
+from .dynamics_gvp import LigRecDynamicsGVP
+from .receptor_encoder_fixed import FixedReceptorEncoder
+from .receptor_encoder_gvp import ReceptorEncoderGVP
+
+
+class LigandSizeDistribution:
+    """P(n_lig | n_rec) from the shipped joint histogram (models/n_nodes_dist.py:7-59)."""
+
+    def __init__(self, processed_dataset_dir: Path):
+        f = Path(processed_dataset_dir) / 'train_n_node_joint_dist.pkl'
+        if not f.exists():
+            raise ValueError(f'Joint distribution file {f} does not exist')
+        with open(f, 'rb') as fh:
+            hist, self.rec_bounds, self.lig_bounds = pickle.load(fh)
+        self.joint_histogram = torch.from_numpy(hist)
+        self.rec_idx_to_size = torch.arange(self.rec_bounds[0], self.rec_bounds[1] + 1)
+        self.lig_idx_to_size = torch.arange(self.lig_bounds[0], self.lig_bounds[1] + 1)
+
+    def sample(self, n_nodes_rec: torch.Tensor, n_replicates: int) -> torch.Tensor:
+        lo, hi = self.rec_bounds
+        clipped = n_nodes_rec.clamp(min=lo, max=hi)
+        for a, b in zip(n_nodes_rec.tolist(), clipped.tolist()):
+            if a != b:
+                print(f'WARNING: Number of receptor nodes {a} is not in the range {self.rec_bounds} from the '
+                      f'training set; conditioning on {b} nodes')
+        rows = self.joint_histogram[(clipped - lo).long()]
+        idx = torch.multinomial(rows, n_replicates, replacement=True)
+        return self.lig_idx_to_size[idx]
+
+
+def polynomial_schedule(timesteps: int, s: float = 1e-4, power: float = 3.0) -> np.ndarray:
+    """alpha^2 of the clipped polynomial schedule (ligand_diffuser.py:620-650)."""
+    steps = timesteps + 1
+    t = np.linspace(0, steps, steps)
+    a2 = np.concatenate([np.ones(1), (1 - np.power(t / steps, power)) ** 2])
+    a2 = np.cumprod(np.clip(a2[1:] / a2[:-1], a_min=0.001, a_max=1.0))
+    return (1 - 2 * s) * a2 + s
+
+
+class PredefinedNoiseSchedule(nn.Module):
+    """Lookup table gamma[0..T] = -(log alpha^2 - log sigma^2) (ligand_diffuser.py:654-690)."""
+
+    def __init__(self, noise_schedule: str, timesteps: int, precision: float):
+        super().__init__()
+        self.timesteps = timesteps
+        if not noise_schedule.startswith('polynomial_'):
+            raise ValueError(noise_schedule)
+        a2 = polynomial_schedule(timesteps, s=precision, power=float(noise_schedule.split('_')[1]))
+        gamma = -(np.log(a2) - np.log(1 - a2))
+        self.gamma = nn.Parameter(torch.from_numpy(gamma).float(), requires_grad=False)
+
+    def forward(self, t: torch.Tensor) -> torch.Tensor:
+        return self.gamma[torch.round(t * self.timesteps).long()]
+
+
+class KeypointDiffusion(nn.Module):
+
+    def __init__(self, atom_nf, rec_nf, processed_dataset_dir: Optional[Path], n_timesteps: int = 1000,
+                 keypoint_centered=False, architecture: str = 'egnn', rec_encoder_type: str = 'learned',
+                 graph_config={}, dynamics_config={}, rec_encoder_config={}, rec_encoder_loss_config={},
+                 precision=1e-4, lig_feat_norm_constant=1, rl_dist_threshold=0, use_fake_atoms=False):
+        super().__init__()
+        if architecture not in ('egnn', 'gvp'):
+            raise ValueError(f'Unsupported architecture: {architecture}')
+        if rec_encoder_type not in ('learned', 'fixed'):
+            raise ValueError(f'Receptor encoder type must be either "learned" or "fixed". Got {rec_encoder_type=} instead.')
+        self.n_lig_features, self.n_kp_feat, self.n_timesteps = atom_nf, rec_nf, n_timesteps
+        self.lig_feat_norm_constant = lig_feat_norm_constant
+        self.use_fake_atoms, self.rec_encoder_type, self.architecture = use_fake_atoms, rec_encoder_type, architecture
+        if use_fake_atoms:
+            raise NotImplementedError('fake atoms are unused by every shipped config (max_fake_atom_frac: 0.0) and '
+                                      'the reference implementation of their removal cannot run (ligand_diffuser.py:559)')
+        # the ligand-size prior is host-side and optional here: synthetic benches have no dataset directory
+        self.lig_size_dist = LigandSizeDistribution(processed_dataset_dir) if processed_dataset_dir is not None else None
+        self.gamma = PredefinedNoiseSchedule('polynomial_2', timesteps=n_timesteps, precision=precision)
+
+        dynamics_config = dict(dynamics_config)
+        if 'no_cg' in rec_encoder_config:
+            dynamics_config['no_cg'] = rec_encoder_config['no_cg']
+        dyn_cls = LigRecDynamics if architecture == 'egnn' else LigRecDynamicsGVP
+        self.dynamics = dyn_cls(atom_nf, rec_nf, **graph_config, **dynamics_config)
+
+        if rec_encoder_type == 'learned':
+            if architecture == 'egnn':
+                raise NotImplementedError('the EGNN receptor encoder (models/receptor_encoder.py) is outside the '
+                                          'accelerated path (SURVEY.md section 8(f)); use rec_encoder_type="fixed" '
+                                          'or the GVP architecture')
+            self.rec_encoder = ReceptorEncoderGVP(**graph_config, **rec_encoder_config)
+        else:
+            self.rec_encoder = FixedReceptorEncoder(
+                n_vec_feats=rec_encoder_config['vector_size'] if architecture == 'gvp' else None)
+
+    # ---- training entry point ----------------------------------------------------------
+    def forward(self, complex_graphs, interface_points):
+        raise NotImplementedError('training (loss + backward, ligand_diffuser.py:89-175) is outside the accelerated '
+                                  'path: the HIP kernels are forward-only')
+
+    # ---- small host helpers ------------------------------------------------------------
+    def normalize(self, g):
+        g.nodes['lig'].data['h_0'] = g.nodes['lig'].data['h_0'] / self.lig_feat_norm_constant
+        return g
+
+    def unnormalize(self, g):
+        g.nodes['lig'].data['h_0'] = g.nodes['lig'].data['h_0'] * self.lig_feat_norm_constant
+        return g
+
+    def remove_com(self, g, lig_batch_idx, kp_batch_idx, com: str = None):
+        if com is None:
+            raise NotImplementedError('removing COM of receptor/ligand complex not implemented')
+        if com not in ('ligand', 'receptor'):
+            raise ValueError(f'invalid value for com: {com=}')
+        c = G.readout_nodes(g, feat='x_0', ntype='lig' if com == 'ligand' else 'kp', op='mean')
+        g.nodes['lig'].data['x_0'] = g.nodes['lig'].data['x_0'] - c[lig_batch_idx]
+        g.nodes['kp'].data['x_0'] = g.nodes['kp'].data['x_0'] - c[kp_batch_idx]
+        return g
+
+    def sigma(self, gamma):
+        return torch.sqrt(torch.sigmoid(gamma))
+
+    def alpha(self, gamma):
+        return torch.sqrt(torch.sigmoid(-gamma))
+
+    def sigma_and_alpha_t_given_s(self, gamma_t, gamma_s):
+        sigma2 = -torch.expm1(F.softplus(gamma_s) - F.softplus(gamma_t))
+        log_alpha2 = F.logsigmoid(-gamma_t) - F.logsigmoid(-gamma_s)
+        return sigma2, torch.sqrt(sigma2), torch.exp(0.5 * log_alpha2)
+
+    # ---- sampling ----------------------------------------------------------------------
+    def encode_receptors(self, g):
+        return self.rec_encoder(g, G.get_batch_idxs(g))
+
+    def step_coefficients(self, s: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+        """[B,3] = (alpha_t|s, sigma^2_t|s / alpha_t|s / sigma_t, sigma_t|s sigma_s / sigma_t)
+        (ligand_diffuser.py:505-526); O(B) host-launched arithmetic."""
+        g_s, g_t = self.gamma(s), self.gamma(t)
+        sigma2_ts, sigma_ts, alpha_ts = self.sigma_and_alpha_t_given_s(g_t, g_s)
+        sig_s, sig_t = self.sigma(g_s), self.sigma(g_t)
+        return torch.stack([alpha_ts, sigma2_ts / alpha_ts / sig_t, sigma_ts * sig_s / sig_t], dim=1).contiguous()
+
+    def sample_p_zs_given_zt(self, s, t, g, batch_idxs=None, noise=None):
+        """One reverse step (ligand_diffuser.py:497-538).  `noise` = (pos_noise, feat_noise) may be
+        injected for reproducible parity tests; by default it is drawn with torch.randn as upstream."""
+        lig, kp = g.nodes['lig'].data, g.nodes['kp'].data
+        for d, k in ((lig, 'x_0'), (lig, 'h_0'), (kp, 'x_0')):
+            if not (d[k].is_contiguous() and d[k].dtype == torch.float32):
+                d[k] = d[k].contiguous().float()
+        coef = self.step_coefficients(s, t)
+        eps_h, eps_x = self.dynamics(g, t, batch_idxs)
+        if noise is None:
+            noise = (torch.randn(lig['x_0'].shape, device=g.device), torch.randn(lig['h_0'].shape, device=g.device))
+        hip.sample_update(g.prepared(), self.n_lig_features, lig['x_0'], lig['h_0'], kp['x_0'], eps_x, eps_h,
+                          noise[0], noise[1], coef)
+        return g
+
+    @torch.no_grad()
+    def sample_from_encoded_receptors(self, g, visualize=False, init_lig_pos: torch.Tensor = None):
+        """Full reverse loop for a batch of encoded pockets (ligand_diffuser.py:342-469)."""
+        device, B = g.device, g.batch_size
+        init_kp_com = G.readout_nodes(g, feat='x_0', op='mean', ntype='kp')
+        bidx = G.get_batch_idxs(g)
+        lig_b, kp_b = bidx['lig'], bidx['kp']
+        if init_lig_pos is not None:
+            assert init_lig_pos.shape == (B, 3)
+            frame = init_lig_pos
+        else:
+            frame = G.readout_nodes(g, feat='x_0', op='mean', ntype='rec')
+        g.nodes['kp'].data['x_0'] = g.nodes['kp'].data['x_0'] - frame[kp_b]
+        for feat in ('x_0', 'h_0'):
+            g.nodes['lig'].data[feat] = torch.randn(g.nodes['lig'].data[feat].shape, device=device)
+        g = self.remove_com(g, lig_b, kp_b, com='ligand')
+
+        def snapshot():
+            f = G.copy_graph(g, n_copies=1, batched_graph=True)[0]
+            f = self.unnormalize(f)
+            delta = init_kp_com - G.readout_nodes(f, feat='x_0', ntype='kp', op='mean')
+            f.nodes['lig'].data['x_0'] = f.nodes['lig'].data['x_0'] + delta[lig_b]
+            parts = G.unbatch(f.to('cpu'))
+            return [p.nodes['lig'].data['x_0'] for p in parts], [p.nodes['lig'].data['h_0'] for p in parts]
+
+        frames_x, frames_h = [], []
+        if visualize:
+            fx, fh = snapshot()
+            frames_x.append(fx), frames_h.append(fh)
+        ones = torch.ones(B, device=device)
+        for s in reversed(range(self.n_timesteps)):
+            g = self.sample_p_zs_given_zt(ones * (s / self.n_timesteps), ones * ((s + 1) / self.n_timesteps), g, bidx)
+            if visualize:
+                fx, fh = snapshot()
+                frames_x.append(fx), frames_h.append(fh)
+
+        g = self.remove_com(g, lig_b, kp_b, com='receptor')
+        for nt in ('lig', 'kp'):
+            g.nodes[nt].data['x_0'] = g.nodes[nt].data['x_0'] + init_kp_com[bidx[nt]]
+        g = self.unnormalize(g)
+        if visualize:
+            return list(zip(*frames_x)), list(zip(*frames_h))
+        parts = G.unbatch(g.to('cpu'))
+        return [p.nodes['lig'].data['x_0'] for p in parts], [p.nodes['lig'].data['h_0'] for p in parts]
+
+    @torch.no_grad()
+    def _sample(self, ref_graphs: List[G.HeteroBatch], n_lig_atoms: List[List[int]], rec_enc_batch_size: int = 32,
+                diff_batch_size: int = 32, visualize=False, use_ref_lig_com: bool = False):
+        """Several pockets x several ligands per pocket (ligand_diffuser.py:271-340)."""
+        encoded = self.encode_receptors(G.batch(ref_graphs))
+        graphs = []
+        for i, ref in enumerate(G.unbatch(encoded)):
+            graphs.extend(G.copy_graph(ref, n_copies=len(n_lig_atoms[i]), lig_atoms_per_copy=torch.tensor(n_lig_atoms[i])))
+        lig_pos, lig_feat = [], []
+        for b in range(ceil(len(graphs) / diff_batch_size)):
+            bg = G.batch(graphs[b * diff_batch_size:(b + 1) * diff_batch_size])
+            init = G.readout_nodes(bg, feat='x_0', op='mean', ntype='lig') if use_ref_lig_com else None
+            p, f = self.sample_from_encoded_receptors(bg, visualize=visualize, init_lig_pos=init)
+            lig_pos.extend(p), lig_feat.extend(f)
+        samples, end = [], 0
+        for i in range(len(ref_graphs)):
+            start, end = end, end + len(n_lig_atoms[i])
+            samples.append({'positions': lig_pos[start:end], 'features': lig_feat[start:end]})
+        return samples
+
+    @torch.no_grad()
+    def sample_given_pocket(self, rec_graph, n_lig_atoms: torch.Tensor, rec_enc_batch_size: int = 32,
+                            diff_batch_size: int = 32, visualize=False):
+        s = self._sample([rec_graph], n_lig_atoms=[n_lig_atoms.tolist()], rec_enc_batch_size=rec_enc_batch_size,
+                         diff_batch_size=diff_batch_size, visualize=visualize)
+        return s[0]['positions'], s[0]['features']
+
+    @torch.no_grad()
+    def sample_random_sizes(self, ref_graphs, n_replicates: int = 10, rec_enc_batch_size: int = 32,
+                            diff_batch_size: int = 32):
+        if self.lig_size_dist is None:
+            raise ValueError('no processed_dataset_dir was given: the ligand-size prior is unavailable')
+        n_rec = torch.tensor([g.num_nodes('rec') for g in ref_graphs])
+        n_lig = self.lig_size_dist.sample(n_rec, n_replicates)
+        return self._sample(ref_graphs, n_lig_atoms=n_lig.tolist(), rec_enc_batch_size=rec_enc_batch_size,
+                            diff_batch_size=diff_batch_size)
+
+
+LigandDiffuser = KeypointDiffusion
