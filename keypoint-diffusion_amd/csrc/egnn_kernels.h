@@ -10,7 +10,7 @@ constexpr int ET_LL = 0, ET_KL = 1, ET_LK = 2, ET_KK = 3;
 constexpr int NT_LIG = 0, NT_KP = 1;
 
 constexpr int PROJ_LDS_BYTES = TM * SA * 4;
-constexpr int EDGE_LDS_BYTES = TM * SA * 4 + (TM * 2 + TM + 3 * TM + TM + 3 * TM + 4) * 4;
+constexpr int EDGE_LDS_BYTES = TM * SA * 4 + (TM * 2 + TM + 3 * TM + TM + 3 * TM + 2 * HS + 8) * 4;
 constexpr int NODE_LDS_BYTES = TM * SA * 4 + 3 * TM * 4;
 
 struct ProjArgs {

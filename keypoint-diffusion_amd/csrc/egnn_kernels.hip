@@ -164,8 +164,8 @@ __global__ __launch_bounds__(256, 2) void k_node_proj(ProjArgs a) {
 
     f32x16 acc[2][2];
     acc_zero(acc);
-    gemm_rows64(A, a.wp[s], acc, wave, lane);
-    const float ex = extra_col(A, a.wx[s], tid);
+    float ex0 = 0.0f, ex1 = 0.0f;
+    gemm_rows64(A, a.wp[s], a.wx[s], acc, ex0, ex1, wave, lane);
 
     const float *bias = a.bias[s];
     float *out = a.P + (size_t)a.slot[s] * HS;
@@ -182,9 +182,11 @@ __global__ __launch_bounds__(256, 2) void k_node_proj(ProjArgs a) {
                 if (v < a.n) out[v * prow + col] = acc[mt][nt][reg] + b;
             }
     }
-    if ((tid & 3) == 0) {
-        const int v = node0 + (tid >> 2);
-        if (v < a.n) out[v * prow + 256] = ex + (bias ? bias[256] : 0.0f);
+    if (wave == 0 && lane < 32) {
+        const float b = bias ? bias[256] : 0.0f;
+        const int v0 = node0 + lane, v1 = node0 + 32 + lane;
+        if (v0 < a.n) out[v0 * prow + 256] = ex0 + b;
+        if (v1 < a.n) out[v1 * prow + 256] = ex1 + b;
     }
 }
 
@@ -193,7 +195,8 @@ struct EdgeSmem {
     float *A;
     int *src, *dst;
     float *d, *xd, *att, *mx;
-    int *misc;
+    float *wv;          // [2][HS]: soft-attention row (+bias at ATT_BIAS_AT) and coordinate head row
+    int *misc;          // [0] first run continues the previous tile, [2..3] segment-end mask, [4..5] head mask
 };
 
 __device__ __forceinline__ EdgeSmem edge_smem(float *smem) {
@@ -205,7 +208,8 @@ __device__ __forceinline__ EdgeSmem edge_smem(float *smem) {
     s.xd = s.d + TM;
     s.att = s.xd + 3 * TM;
     s.mx = s.att + TM;
-    s.misc = reinterpret_cast<int *>(s.mx + 3 * TM);
+    s.wv = s.mx + 3 * TM;
+    s.misc = reinterpret_cast<int *>(s.wv + 2 * HS);
     return s;
 }
 
@@ -217,7 +221,7 @@ __device__ __forceinline__ void build_edge_A(const EdgeSmem &s, const float *__r
     const f32x4 w0 = reinterpret_cast<const f32x4 *>(wr)[lane];
     f32x4 w1 = {0.f, 0.f, 0.f, 0.f};
     if (lane < 2) w1 = reinterpret_cast<const f32x4 *>(wr)[64 + lane];
-#pragma unroll 4
+#pragma unroll 8
     for (int rr = 0; rr < 16; ++rr) {
         const int r = wave * 16 + rr;
         const float d = s.d[r];
@@ -235,8 +239,8 @@ __device__ __forceinline__ void build_edge_A(const EdgeSmem &s, const float *__r
 }
 
 // T[row][col] = SiLU(acc + b[col]) for the 257 valid columns.
-__device__ __forceinline__ void store_T_silu(float *T, const f32x16 (&acc)[2][2], float ex, const float *__restrict__ b,
-                                             int tid, int wave, int lane) {
+__device__ __forceinline__ void store_T_silu(float *T, const f32x16 (&acc)[2][2], float ex0, float ex1,
+                                             const float *__restrict__ b, int wave, int lane) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int col = acc_col(nt, wave, lane);
@@ -246,7 +250,11 @@ __device__ __forceinline__ void store_T_silu(float *T, const f32x16 (&acc)[2][2]
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) T[acc_row(mt, reg, lane) * SA + col] = silu(acc[mt][nt][reg] + bb);
     }
-    if ((tid & 3) == 0) T[(tid >> 2) * SA + 256] = silu(ex + b[256]);
+    if (wave == 0 && lane < 32) {
+        const float bb = b[256];
+        T[lane * SA + 256] = silu(ex0 + bb);
+        T[(32 + lane) * SA + 256] = silu(ex1 + bb);
+    }
 }
 
 __global__ __launch_bounds__(256, 2) void k_egnn_edge(EdgeArgs a) {
@@ -273,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge(EdgeArgs a) {
     const int *__restrict__ esrc = a.src[et];
     const int *__restrict__ edst = a.dst[et];
 
-    // phase 0: edge endpoints and geometry (dynamics.py:160-169, 209-217)
+    // phase 0: edge endpoints and geometry (dynamics.py:160-169, 209-217); head weights to LDS
     if (tid < TM) {
         const int e = e0 + min(tid, ne - 1);
         const int u = esrc[e], v = edst[e];
@@ -287,47 +295,78 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge(EdgeArgs a) {
         s.xd[3 * tid] = dx * inv;
         s.xd[3 * tid + 1] = dy * inv;
         s.xd[3 * tid + 2] = dz * inv;
-        if (tid == 0) s.misc[0] = (e0 > 0 && edst[e0 - 1] == v) ? 1 : 0;
+        // run structure of the dst-sorted tile as two 64-bit masks (wave 0 == rows 0..63)
+        const int vprev = tid > 0 ? edst[e0 + min(tid - 1, ne - 1)] : (e0 > 0 ? edst[e0 - 1] : -1);
+        const int vnext = tid + 1 < ne ? edst[e0 + tid + 1] : -2;
+        const unsigned long long heads = __ballot(tid < ne && (tid == 0 || vprev != v));
+        const unsigned long long ends = __ballot(tid < ne && vnext != v);
+        if (tid == 0) {
+            s.misc[0] = (vprev == v) ? 1 : 0;
+            s.misc[2] = (int)(ends & 0xffffffffu);
+            s.misc[3] = (int)(ends >> 32);
+            s.misc[4] = (int)(heads & 0xffffffffu);
+            s.misc[5] = (int)(heads >> 32);
+        }
+    } else if (tid < TM + 66) {
+        const int i = tid - TM;          // 66 float4 = one HS row
+        reinterpret_cast<f32x4 *>(s.wv)[i] = reinterpret_cast<const f32x4 *>(a.watt[et])[i];
+    } else if (tid < TM + 132) {
+        const int i = tid - TM - 66;
+        reinterpret_cast<f32x4 *>(s.wv + HS)[i] = reinterpret_cast<const f32x4 *>(a.w3[et])[i];
     }
     __syncthreads();
 
     const float *Ps = a.P[snt] + (size_t)a.src_slot[et] * HS;
     const float *Pd = a.P[dnt] + (size_t)a.dst_slot[et] * HS;
     const int first_is_cont = s.misc[0];
+    const unsigned long long endmask =
+        ((unsigned long long)(unsigned)s.misc[3] << 32) | (unsigned long long)(unsigned)s.misc[2];
     f32x16 acc[2][2];
+    float ex0, ex1;
 
     // ---- feature messages: m = edge_mlp(f); msg_h = m * sigmoid(att(m)) (dynamics.py:111-112)
     build_edge_A(s, Ps, Pd, a.wr_e[et], wave, lane);
     __syncthreads();
     acc_zero(acc);
-    gemm_rows64(s.A, a.wp_e[et], acc, wave, lane);
-    float ex = extra_col(s.A, a.wx_e[et], tid);
+    ex0 = ex1 = 0.0f;
+    gemm_rows64(s.A, a.wp_e[et], a.wx_e[et], acc, ex0, ex1, wave, lane);
     __syncthreads();
-    store_T_silu(s.A, acc, ex, a.b_e[et], tid, wave, lane);
+    store_T_silu(s.A, acc, ex0, ex1, a.b_e[et], wave, lane);
     __syncthreads();
     {
-        const float dot = row_dot257(s.A, a.watt[et], tid);
+        const float dot = row_dot257(s.A, s.wv, tid);
         const int row = tid >> 2;
-        if ((tid & 3) == 0) s.att[row] = row < ne ? sigmoidf_(dot + a.watt[et][ATT_BIAS_AT]) : 0.0f;
+        if ((tid & 3) == 0) s.att[row] = row < ne ? sigmoidf_(dot + s.wv[ATT_BIAS_AT]) : 0.0f;
     }
     __syncthreads();
     {
-        // segmented sum over dst (dynamics.py:182-185): thread = column, rows in order
+        // segmented sum over dst (dynamics.py:182-185): thread = column, rows in order; the run
+        // boundaries are wave-uniform (endmask), LDS reads are issued 16 rows at a time
         float *hmain = a.hn_main[et], *hcont = a.hn_cont[et] + (size_t)tile_in_et * HS;
         float run = 0.0f, run2 = 0.0f;
         int piece = 0;
-        for (int r = 0; r < ne; ++r) {
-            const float w = s.att[r];
-            run = fmaf(s.A[r * SA + tid], w, run);
-            if (tid == 0) run2 = fmaf(s.A[r * SA + 256], w, run2);
-            const bool end = (r == ne - 1) || (s.dst[r + 1] != s.dst[r]);
-            if (end) {
-                float *out = (piece == 0 && first_is_cont) ? hcont : hmain + (size_t)s.dst[r] * HS;
-                out[tid] = run;
-                if (tid == 0) out[256] = run2;
-                run = 0.0f;
-                run2 = 0.0f;
-                ++piece;
+#pragma unroll 1
+        for (int r0 = 0; r0 < TM; r0 += 16) {
+            if (r0 >= ne) break;
+            float v[16], v2[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float w = s.att[r0 + i];
+                v[i] = s.A[(r0 + i) * SA + tid] * w;
+                v2[i] = tid == 0 ? s.A[(r0 + i) * SA + 256] * w : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                run += v[i];
+                run2 += v2[i];
+                if ((endmask >> (r0 + i)) & 1ull) {
+                    float *out = (piece == 0 && first_is_cont) ? hcont : hmain + (size_t)s.dst[r0 + i] * HS;
+                    out[tid] = run;
+                    if (tid == 0) out[256] = run2;
+                    run = 0.0f;
+                    run2 = 0.0f;
+                    ++piece;
+                }
             }
         }
     }
@@ -337,13 +376,13 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge(EdgeArgs a) {
     build_edge_A(s, Ps + HS, Pd + HS, a.wr_c[et], wave, lane);
     __syncthreads();
     acc_zero(acc);
-    gemm_rows64(s.A, a.wp_c[et], acc, wave, lane);
-    ex = extra_col(s.A, a.wx_c[et], tid);
+    ex0 = ex1 = 0.0f;
+    gemm_rows64(s.A, a.wp_c[et], a.wx_c[et], acc, ex0, ex1, wave, lane);
     __syncthreads();
-    store_T_silu(s.A, acc, ex, a.b_c[et], tid, wave, lane);
+    store_T_silu(s.A, acc, ex0, ex1, a.b_c[et], wave, lane);
     __syncthreads();
     {
-        const float dot = row_dot257(s.A, a.w3[et], tid);
+        const float dot = row_dot257(s.A, s.wv + HS, tid);
         const int row = tid >> 2;
         if ((tid & 3) == 0) {
             float c = a.use_tanh ? tanhf(dot) * a.coords_range : dot;
@@ -354,19 +393,29 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge(EdgeArgs a) {
         }
     }
     __syncthreads();
-    if (tid < 3) {
-        float *xmain = a.xn_main[et], *xcont = a.xn_cont[et] + (size_t)tile_in_et * 4;
-        float run = 0.0f;
-        int piece = 0;
-        for (int r = 0; r < ne; ++r) {
-            run += s.mx[3 * r + tid];
-            const bool end = (r == ne - 1) || (s.dst[r + 1] != s.dst[r]);
-            if (end) {
-                float *out = (piece == 0 && first_is_cont) ? xcont : xmain + (size_t)s.dst[r] * 4;
-                out[tid] = run;
-                run = 0.0f;
-                ++piece;
+    if (wave == 0) {
+        // segmented inclusive scan across lanes (lane = row), then the last lane of every run writes
+        const unsigned long long heads =
+            ((unsigned long long)(unsigned)s.misc[5] << 32) | (unsigned long long)(unsigned)s.misc[4];
+        const unsigned long long upto = lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull);
+        const int start = 63 - __clzll((long long)(heads & upto | 1ull));
+        float vx = s.mx[3 * lane], vy = s.mx[3 * lane + 1], vz = s.mx[3 * lane + 2];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float tx = __shfl_up(vx, off), ty = __shfl_up(vy, off), tz = __shfl_up(vz, off);
+            if (lane - off >= start) {
+                vx += tx;
+                vy += ty;
+                vz += tz;
             }
+        }
+        if ((endmask >> lane) & 1ull) {
+            const int piece = __popcll(endmask & ((1ull << lane) - 1ull));
+            float *out = (piece == 0 && first_is_cont) ? a.xn_cont[et] + (size_t)tile_in_et * 4
+                                                       : a.xn_main[et] + (size_t)s.dst[lane] * 4;
+            out[0] = vx;
+            out[1] = vy;
+            out[2] = vz;
         }
     }
 }
@@ -425,8 +474,8 @@ __global__ __launch_bounds__(256, 2) void k_node_update(NodeArgs a) {
     __syncthreads();
     f32x16 acc[2][2];
     acc_zero(acc);
-    gemm_rows64(A, a.wp_a, acc, wave, lane);
-    float ex = extra_col(A, a.wx_a, tid);
+    float ex0 = 0.0f, ex1 = 0.0f;
+    gemm_rows64(A, a.wp_a, a.wx_a, acc, ex0, ex1, wave, lane);
     __syncthreads();
 
     // GEMM 1b: + W[:, 257:] . (h_neigh / z); h_neigh = sum of segment pieces over the
@@ -456,18 +505,17 @@ __global__ __launch_bounds__(256, 2) void k_node_update(NodeArgs a) {
         if (lane < 2) *reinterpret_cast<f32x4 *>(A + r * SA + 256 + 4 * lane) = val2;
     }
     __syncthreads();
-    gemm_rows64(A, a.wp_b, acc, wave, lane);
-    ex += extra_col(A, a.wx_b, tid);
+    gemm_rows64(A, a.wp_b, a.wx_b, acc, ex0, ex1, wave, lane);
     __syncthreads();
 
     // hidden = SiLU(. + b0) -> T (pad columns 257..263 stay 0 from the h_neigh tile)
-    store_T_silu(A, acc, ex, a.b0, tid, wave, lane);
+    store_T_silu(A, acc, ex0, ex1, a.b0, wave, lane);
     __syncthreads();
 
     // GEMM 2 + bias + residual (dynamics.py:201-203)
     acc_zero(acc);
-    gemm_rows64(A, a.wp_2, acc, wave, lane);
-    ex = extra_col(A, a.wx_2, tid);
+    ex0 = ex1 = 0.0f;
+    gemm_rows64(A, a.wp_2, a.wx_2, acc, ex0, ex1, wave, lane);
     __syncthreads();
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
@@ -482,9 +530,11 @@ __global__ __launch_bounds__(256, 2) void k_node_update(NodeArgs a) {
                 A[r * SA + col] = acc[mt][nt][reg] + bb + res;
             }
     }
-    if ((tid & 3) == 0) {
-        const int r = tid >> 2, v = node0 + r;
-        A[r * SA + 256] = ex + a.b2[256] + (v < a.n ? a.h[(size_t)v * HS + 256] : 0.0f);
+    if (wave == 0 && lane < 32) {
+        const float bb = a.b2[256];
+        const int v0 = node0 + lane, v1 = node0 + 32 + lane;
+        A[lane * SA + 256] = ex0 + bb + (v0 < a.n ? a.h[(size_t)v0 * HS + 256] : 0.0f);
+        A[(32 + lane) * SA + 256] = ex1 + bb + (v1 < a.n ? a.h[(size_t)v1 * HS + 256] : 0.0f);
     }
     __syncthreads();
 

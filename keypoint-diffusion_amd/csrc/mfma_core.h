@@ -24,8 +24,10 @@ namespace kpd {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp each): far inside the 1e-4 parity budget, ~4x fewer VALU ops than
+// the IEEE division sequence.
+__device__ __forceinline__ float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 __device__ __forceinline__ void acc_zero(f32x16 (&acc)[2][2]) {
 #pragma unroll
@@ -36,30 +38,41 @@ __device__ __forceinline__ void acc_zero(f32x16 (&acc)[2][2]) {
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
 }
 
-// acc[mt][nt] += A[64 x KP] * W[KP x (this wave's 64 columns)]
+// acc[mt][nt] += A[64 x KP] * W[KP x (this wave's 64 columns)].
+// Output column 256 rides along on the VALU: every lane already holds A[r][k] and A[32 + r][k]
+// for its k's, so ex0 / ex1 accumulate A[r][:] . wx and A[32 + r][:] . wx (8 FMAs per 16 MFMAs);
+// after the final cross-half add every lane of every wave holds the dots of rows r and 32 + r.
 __device__ __forceinline__ void gemm_rows64(const float *__restrict__ A, const float *__restrict__ Wp,
-                                            f32x16 (&acc)[2][2], int wave, int lane) {
+                                            const float *__restrict__ wx, f32x16 (&acc)[2][2], float &ex0,
+                                            float &ex1, int wave, int lane) {
     const int r = lane & 31, h = lane >> 5;
     const float *a0p = A + r * SA + 4 * h;
     const float *a1p = A + (32 + r) * SA + 4 * h;
     const f32x4 *bp = reinterpret_cast<const f32x4 *>(Wp) + (wave * 64 + lane) * 2;
-    f32x4 b0 = bp[0], b1 = bp[1];
+    const f32x4 *wxp = reinterpret_cast<const f32x4 *>(wx) + h;
+    f32x4 b0 = bp[0], b1 = bp[1], w = wxp[0];
+    float e0 = 0.0f, e1 = 0.0f;
 #pragma unroll 1
     for (int g = 0; g < NG; ++g) {
         const f32x4 a0 = *reinterpret_cast<const f32x4 *>(a0p + 8 * g);
         const f32x4 a1 = *reinterpret_cast<const f32x4 *>(a1p + 8 * g);
         const int gn = g + 1 < NG ? g + 1 : g;
-        const f32x4 nb0 = bp[gn * 512], nb1 = bp[gn * 512 + 1];
+        const f32x4 nb0 = bp[gn * 512], nb1 = bp[gn * 512 + 1], nw = wxp[2 * gn];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
+            e0 = fmaf(a0[j], w[j], e0);
+            e1 = fmaf(a1[j], w[j], e1);
         }
         b0 = nb0;
         b1 = nb1;
+        w = nw;
     }
+    ex0 += e0 + __shfl_xor(e0, 32);
+    ex1 += e1 + __shfl_xor(e1, 32);
 }
 
 // Row/column owned by accumulator register `reg` of tile (mt, nt) on this lane.
@@ -68,20 +81,9 @@ __device__ __forceinline__ int acc_row(int mt, int reg, int lane) {
 }
 __device__ __forceinline__ int acc_col(int nt, int wave, int lane) { return 64 * wave + 32 * nt + (lane & 31); }
 
-// Output column 256: every group of 4 consecutive threads owns one row (row = tid >> 2) and
-// strides k by 4 (conflict-free at SA = 268).  Returns the full dot on all 4 lanes.
-__device__ __forceinline__ float extra_col(const float *__restrict__ A, const float *__restrict__ wx, int tid) {
-    const int row = tid >> 2, q = tid & 3;
-    const float *a = A + row * SA + q;
-    float s = 0.0f;
-#pragma unroll 6
-    for (int i = 0; i < KP / 4; ++i) s = fmaf(a[4 * i], wx[4 * i + q], s);
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
-    return s;
-}
-
-// dot over the 257 valid columns of row (tid >> 2) of a T tile with a weight vector.
+// dot over the 257 valid columns of row (tid >> 2) of a T tile with a weight vector (w in LDS
+// or global).  Groups of 4 consecutive threads own a row and stride the columns by 4
+// (conflict-free at SA = 268).  Returns the full dot on all 4 lanes.
 __device__ __forceinline__ float row_dot257(const float *__restrict__ T, const float *__restrict__ w, int tid) {
     const int row = tid >> 2, q = tid & 3;
     const float *a = T + row * SA + q;
