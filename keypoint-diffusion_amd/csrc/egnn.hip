@@ -71,6 +71,7 @@ struct kpd_egnn {
     bool committed = false;
     int debug_layers = -1;
     // optional HIP-event timing of the dominant kernel (k_egnn_edge), for bench.py's roofline
+    unsigned long long *stamps = nullptr;      // device [16], diagnostics (kpd_egnn_debug_state "stamps=1")
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;
     size_t prof_used = 0;
@@ -456,6 +457,7 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
         ea.meta = m->meta;
         ea.x[0] = m->x[0]; ea.x[1] = m->x[1]; ea.P[0] = m->P[0]; ea.P[1] = m->P[1];
         ea.use_tanh = c.use_tanh; ea.coords_range = c.coords_range;
+        ea.stamps = m->stamps;
         for (int et = 0; et < 4; ++et) {
             ea.src[et] = esrc[et]; ea.dst[et] = edst[et];
             ea.src_nt[et] = kSrcNt[et]; ea.dst_nt[et] = kDstNt[et]; ea.src_slot[et] = kSrcSlot[et]; ea.dst_slot[et] = kDstSlot[et];
@@ -510,6 +512,14 @@ extern "C" kpd_status kpd_egnn_debug_state(kpd_egnn *m, const char *what, float 
     else if (w == "z_kp") src = m->z[1];
     else if (w.rfind("layers=", 0) == 0) {
         m->debug_layers = atoi(w.c_str() + 7);
+        return KPD_OK;
+    } else if (w == "stamps=1") {            // start accumulating per-phase cycle sums of the edge kernel
+        if (!m->stamps) KPD_HIP(hipMalloc(reinterpret_cast<void **>(&m->stamps), 16 * sizeof(unsigned long long)));
+        KPD_HIP(hipMemsetAsync(m->stamps, 0, 16 * sizeof(unsigned long long), st));
+        return KPD_OK;
+    } else if (w == "stamps") {              // read them back (as 32 floats: lo/hi 24-bit split is avoided by copying raw)
+        KPD_REQUIRE(m->stamps && n_floats >= 32, KPD_ERR_INVALID, "stamps not enabled or buffer < 32 floats");
+        KPD_HIP(hipMemcpyAsync(out, m->stamps, 16 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
         return KPD_OK;
     }
     KPD_REQUIRE(src, KPD_ERR_INVALID, "unknown debug tap '%s'", what);

@@ -39,6 +39,7 @@ struct EdgeArgs {
     float *xn_main[4], *xn_cont[4];
     int use_tanh;
     float coords_range;
+    unsigned long long *stamps;     // [16] phase-cycle sums, diagnostics only (null in production)
 };
 
 struct NodeArgs {

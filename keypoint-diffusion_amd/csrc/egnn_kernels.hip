@@ -13,6 +13,8 @@
 // Segment pieces: a tile writes the sum of each run of equal dst either to main[dst]
 // (run starts the segment) or to cont[tile] (run continues a segment begun in an earlier
 // tile); k_node_update adds main + cont pieces in tile order => deterministic, no atomics.
+#include <stdlib.h>
+
 #include "egnn_kernels.h"
 #include "mfma_core.h"
 
@@ -160,12 +162,12 @@ __global__ __launch_bounds__(256, 2) void k_node_proj(ProjArgs a) {
         *reinterpret_cast<f32x4 *>(A + r * SA + 4 * lane) = val;
         if (lane < 2) *reinterpret_cast<f32x4 *>(A + r * SA + 256 + 4 * lane) = val2;
     }
-    __syncthreads();
+    lds_barrier();
 
     f32x16 acc[2][2];
     acc_zero(acc);
-    float ex0 = 0.0f, ex1 = 0.0f;
-    gemm_rows64(A, a.wp[s], a.wx[s], acc, ex0, ex1, wave, lane);
+    gemm_rows64(A, a.wp[s], acc, wave, lane);
+    const float ex = extra_col(A, a.wx[s], tid);
 
     const float *bias = a.bias[s];
     float *out = a.P + (size_t)a.slot[s] * HS;
@@ -182,11 +184,9 @@ __global__ __launch_bounds__(256, 2) void k_node_proj(ProjArgs a) {
                 if (v < a.n) out[v * prow + col] = acc[mt][nt][reg] + b;
             }
     }
-    if (wave == 0 && lane < 32) {
-        const float b = bias ? bias[256] : 0.0f;
-        const int v0 = node0 + lane, v1 = node0 + 32 + lane;
-        if (v0 < a.n) out[v0 * prow + 256] = ex0 + b;
-        if (v1 < a.n) out[v1 * prow + 256] = ex1 + b;
+    if ((tid & 3) == 0) {
+        const int v = node0 + (tid >> 2);
+        if (v < a.n) out[v * prow + 256] = ex + (bias ? bias[256] : 0.0f);
     }
 }
 
@@ -219,9 +219,8 @@ __device__ __forceinline__ void build_edge_A(const EdgeSmem &s, const float *__r
                                              const float *__restrict__ wr, int wave, int lane) {
     const size_t prow = (size_t)NSLOT * HS;
     const f32x4 w0 = reinterpret_cast<const f32x4 *>(wr)[lane];
-    f32x4 w1 = {0.f, 0.f, 0.f, 0.f};
-    if (lane < 2) w1 = reinterpret_cast<const f32x4 *>(wr)[64 + lane];
-#pragma unroll 8
+    // columns 0..255: one 1-KiB row segment per wave instruction, all 16 rows (32 loads) in flight
+#pragma unroll 16
     for (int rr = 0; rr < 16; ++rr) {
         const int r = wave * 16 + rr;
         const float d = s.d[r];
@@ -230,17 +229,25 @@ __device__ __forceinline__ void build_edge_A(const EdgeSmem &s, const float *__r
         f32x4 v = ps[lane] + pd[lane] + d * w0;
         v[0] = silu(v[0]); v[1] = silu(v[1]); v[2] = silu(v[2]); v[3] = silu(v[3]);
         *reinterpret_cast<f32x4 *>(s.A + r * SA + 4 * lane) = v;
-        if (lane < 2) {
-            f32x4 u = ps[64 + lane] + pd[64 + lane] + d * w1;
+    }
+    // columns 256..263 of all 16 rows in one pass (lane = row * 4 + chunk): keeping this out of the
+    // row loop halves the VALU work, which on gfx950 is paid in MFMA time
+    {
+        const int r = wave * 16 + (lane >> 2), c = lane & 3;
+        if (c < 2) {
+            const f32x4 w1 = reinterpret_cast<const f32x4 *>(wr)[64 + c];
+            const f32x4 *ps = reinterpret_cast<const f32x4 *>(Ps + s.src[r] * prow);
+            const f32x4 *pd = reinterpret_cast<const f32x4 *>(Pd + s.dst[r] * prow);
+            f32x4 u = ps[64 + c] + pd[64 + c] + s.d[r] * w1;
             u[0] = silu(u[0]); u[1] = silu(u[1]); u[2] = silu(u[2]); u[3] = silu(u[3]);
-            *reinterpret_cast<f32x4 *>(s.A + r * SA + 256 + 4 * lane) = u;
+            *reinterpret_cast<f32x4 *>(s.A + r * SA + 256 + 4 * c) = u;
         }
     }
 }
 
 // T[row][col] = SiLU(acc + b[col]) for the 257 valid columns.
-__device__ __forceinline__ void store_T_silu(float *T, const f32x16 (&acc)[2][2], float ex0, float ex1,
-                                             const float *__restrict__ b, int wave, int lane) {
+__device__ __forceinline__ void store_T_silu(float *T, const f32x16 (&acc)[2][2], float ex,
+                                             const float *__restrict__ b, int tid, int wave, int lane) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int col = acc_col(nt, wave, lane);
@@ -250,17 +257,23 @@ __device__ __forceinline__ void store_T_silu(float *T, const f32x16 (&acc)[2][2]
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) T[acc_row(mt, reg, lane) * SA + col] = silu(acc[mt][nt][reg] + bb);
     }
-    if (wave == 0 && lane < 32) {
-        const float bb = b[256];
-        T[lane * SA + 256] = silu(ex0 + bb);
-        T[(32 + lane) * SA + 256] = silu(ex1 + bb);
-    }
+    if ((tid & 3) == 0) T[(tid >> 2) * SA + 256] = silu(ex + b[256]);
 }
+
+// Phase stamps (diagnostic builds of the timeline only; a.stamps is null in production): wave 0 of
+// every workgroup adds the s_memtime delta of each phase to a.stamps[phase].
+#define KPD_STAMP(idx)                                                                     \
+    if (a.stamps && tid == 0) {                                                            \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                      \
+        atomicAdd(&a.stamps[idx], (unsigned long long)(now_ - t_prev_));                   \
+        t_prev_ = now_;                                                                    \
+    }
 
 __global__ __launch_bounds__(256, 2) void k_egnn_edge(EdgeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const EdgeSmem s = edge_smem(smem);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    unsigned long long t_prev_ = a.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
 
     // tile decode (XCD-aware: consecutive tiles -- neighbouring edges of one complex, which
     // share P rows -- go to the same XCD / L2)
@@ -314,7 +327,8 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge(EdgeArgs a) {
         const int i = tid - TM - 66;
         reinterpret_cast<f32x4 *>(s.wv + HS)[i] = reinterpret_cast<const f32x4 *>(a.w3[et])[i];
     }
-    __syncthreads();
+    lds_barrier();
+    KPD_STAMP(0)
 
     const float *Ps = a.P[snt] + (size_t)a.src_slot[et] * HS;
     const float *Pd = a.P[dnt] + (size_t)a.dst_slot[et] * HS;
@@ -322,65 +336,87 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge(EdgeArgs a) {
     const unsigned long long endmask =
         ((unsigned long long)(unsigned)s.misc[3] << 32) | (unsigned long long)(unsigned)s.misc[2];
     f32x16 acc[2][2];
-    float ex0, ex1;
+    float ex;
 
     // ---- feature messages: m = edge_mlp(f); msg_h = m * sigmoid(att(m)) (dynamics.py:111-112)
     build_edge_A(s, Ps, Pd, a.wr_e[et], wave, lane);
-    __syncthreads();
+    lds_barrier();
+    KPD_STAMP(1)
     acc_zero(acc);
-    ex0 = ex1 = 0.0f;
-    gemm_rows64(s.A, a.wp_e[et], a.wx_e[et], acc, ex0, ex1, wave, lane);
-    __syncthreads();
-    store_T_silu(s.A, acc, ex0, ex1, a.b_e[et], wave, lane);
-    __syncthreads();
+    gemm_rows64(s.A, a.wp_e[et], acc, wave, lane);
+    ex = extra_col(s.A, a.wx_e[et], tid);
+    lds_barrier();
+    KPD_STAMP(2)
+    store_T_silu(s.A, acc, ex, a.b_e[et], tid, wave, lane);
+    lds_barrier();
+    KPD_STAMP(3)
     {
         const float dot = row_dot257(s.A, s.wv, tid);
         const int row = tid >> 2;
         if ((tid & 3) == 0) s.att[row] = row < ne ? sigmoidf_(dot + s.wv[ATT_BIAS_AT]) : 0.0f;
     }
-    __syncthreads();
+    lds_barrier();
+    KPD_STAMP(4)
     {
         // segmented sum over dst (dynamics.py:182-185): thread = column, rows in order; the run
         // boundaries are wave-uniform (endmask), LDS reads are issued 16 rows at a time
         float *hmain = a.hn_main[et], *hcont = a.hn_cont[et] + (size_t)tile_in_et * HS;
-        float run = 0.0f, run2 = 0.0f;
+        float run = 0.0f;
         int piece = 0;
 #pragma unroll 1
         for (int r0 = 0; r0 < TM; r0 += 16) {
             if (r0 >= ne) break;
-            float v[16], v2[16];
+            float v[16], w[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float w = s.att[r0 + i];
-                v[i] = s.A[(r0 + i) * SA + tid] * w;
-                v2[i] = tid == 0 ? s.A[(r0 + i) * SA + 256] * w : 0.0f;
+                w[i] = s.att[r0 + i];
+                v[i] = s.A[(r0 + i) * SA + tid];
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                run += v[i];
-                run2 += v2[i];
+                run = fmaf(v[i], w[i], run);
                 if ((endmask >> (r0 + i)) & 1ull) {
                     float *out = (piece == 0 && first_is_cont) ? hcont : hmain + (size_t)s.dst[r0 + i] * HS;
                     out[tid] = run;
-                    if (tid == 0) out[256] = run2;
                     run = 0.0f;
-                    run2 = 0.0f;
                     ++piece;
                 }
             }
         }
+        // column 256: lane = row on wave 3, segmented inclusive scan across lanes
+        if (wave == 3) {
+            const unsigned long long heads =
+                ((unsigned long long)(unsigned)s.misc[5] << 32) | (unsigned long long)(unsigned)s.misc[4];
+            const unsigned long long upto = lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull);
+            const int start = 63 - __clzll((long long)((heads & upto) | 1ull));
+            float v = s.A[lane * SA + 256] * s.att[lane];
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const float t = __shfl_up(v, off);
+                if (lane - off >= start) v += t;
+            }
+            if ((endmask >> lane) & 1ull) {
+                const int pc = __popcll(endmask & ((1ull << lane) - 1ull));
+                float *out = (pc == 0 && first_is_cont) ? hcont : hmain + (size_t)s.dst[lane] * HS;
+                out[256] = v;
+            }
+        }
     }
-    __syncthreads();
+    lds_barrier();
+    KPD_STAMP(5)
 
     // ---- coordinate messages: msg_x = tanh(coord_mlp(f)) * x_diff * range (dynamics.py:113-120)
     build_edge_A(s, Ps + HS, Pd + HS, a.wr_c[et], wave, lane);
-    __syncthreads();
+    lds_barrier();
+    KPD_STAMP(6)
     acc_zero(acc);
-    ex0 = ex1 = 0.0f;
-    gemm_rows64(s.A, a.wp_c[et], a.wx_c[et], acc, ex0, ex1, wave, lane);
-    __syncthreads();
-    store_T_silu(s.A, acc, ex0, ex1, a.b_c[et], wave, lane);
-    __syncthreads();
+    gemm_rows64(s.A, a.wp_c[et], acc, wave, lane);
+    ex = extra_col(s.A, a.wx_c[et], tid);
+    lds_barrier();
+    KPD_STAMP(7)
+    store_T_silu(s.A, acc, ex, a.b_c[et], tid, wave, lane);
+    lds_barrier();
+    KPD_STAMP(8)
     {
         const float dot = row_dot257(s.A, s.wv + HS, tid);
         const int row = tid >> 2;
@@ -392,13 +428,14 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge(EdgeArgs a) {
             s.mx[3 * row + 2] = c * s.xd[3 * row + 2];
         }
     }
-    __syncthreads();
+    lds_barrier();
+    KPD_STAMP(9)
     if (wave == 0) {
         // segmented inclusive scan across lanes (lane = row), then the last lane of every run writes
         const unsigned long long heads =
             ((unsigned long long)(unsigned)s.misc[5] << 32) | (unsigned long long)(unsigned)s.misc[4];
         const unsigned long long upto = lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull);
-        const int start = 63 - __clzll((long long)(heads & upto | 1ull));
+        const int start = 63 - __clzll((long long)((heads & upto) | 1ull));
         float vx = s.mx[3 * lane], vy = s.mx[3 * lane + 1], vz = s.mx[3 * lane + 2];
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -418,6 +455,7 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge(EdgeArgs a) {
             out[2] = vz;
         }
     }
+    KPD_STAMP(10)
 }
 
 // ---- node update --------------------------------------------------------------------------
@@ -471,12 +509,12 @@ __global__ __launch_bounds__(256, 2) void k_node_update(NodeArgs a) {
         *reinterpret_cast<f32x4 *>(A + r * SA + 4 * lane) = val;
         if (lane < 2) *reinterpret_cast<f32x4 *>(A + r * SA + 256 + 4 * lane) = val2;
     }
-    __syncthreads();
+    lds_barrier();
     f32x16 acc[2][2];
     acc_zero(acc);
-    float ex0 = 0.0f, ex1 = 0.0f;
-    gemm_rows64(A, a.wp_a, a.wx_a, acc, ex0, ex1, wave, lane);
-    __syncthreads();
+    gemm_rows64(A, a.wp_a, acc, wave, lane);
+    float ex = extra_col(A, a.wx_a, tid);
+    lds_barrier();
 
     // GEMM 1b: + W[:, 257:] . (h_neigh / z); h_neigh = sum of segment pieces over the
     // incoming edge types in fixed order (multi_update_all cross_reducer='sum')
@@ -504,19 +542,20 @@ __global__ __launch_bounds__(256, 2) void k_node_update(NodeArgs a) {
         *reinterpret_cast<f32x4 *>(A + r * SA + 4 * lane) = val;
         if (lane < 2) *reinterpret_cast<f32x4 *>(A + r * SA + 256 + 4 * lane) = val2;
     }
-    __syncthreads();
-    gemm_rows64(A, a.wp_b, a.wx_b, acc, ex0, ex1, wave, lane);
-    __syncthreads();
+    lds_barrier();
+    gemm_rows64(A, a.wp_b, acc, wave, lane);
+    ex += extra_col(A, a.wx_b, tid);
+    lds_barrier();
 
     // hidden = SiLU(. + b0) -> T (pad columns 257..263 stay 0 from the h_neigh tile)
-    store_T_silu(A, acc, ex0, ex1, a.b0, wave, lane);
-    __syncthreads();
+    store_T_silu(A, acc, ex, a.b0, tid, wave, lane);
+    lds_barrier();
 
     // GEMM 2 + bias + residual (dynamics.py:201-203)
     acc_zero(acc);
-    ex0 = ex1 = 0.0f;
-    gemm_rows64(A, a.wp_2, a.wx_2, acc, ex0, ex1, wave, lane);
-    __syncthreads();
+    gemm_rows64(A, a.wp_2, acc, wave, lane);
+    ex = extra_col(A, a.wx_2, tid);
+    lds_barrier();
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int col = acc_col(nt, wave, lane);
@@ -530,13 +569,11 @@ __global__ __launch_bounds__(256, 2) void k_node_update(NodeArgs a) {
                 A[r * SA + col] = acc[mt][nt][reg] + bb + res;
             }
     }
-    if (wave == 0 && lane < 32) {
-        const float bb = a.b2[256];
-        const int v0 = node0 + lane, v1 = node0 + 32 + lane;
-        A[lane * SA + 256] = ex0 + bb + (v0 < a.n ? a.h[(size_t)v0 * HS + 256] : 0.0f);
-        A[(32 + lane) * SA + 256] = ex1 + bb + (v1 < a.n ? a.h[(size_t)v1 * HS + 256] : 0.0f);
+    if ((tid & 3) == 0) {
+        const int r = tid >> 2, v = node0 + r;
+        A[r * SA + 256] = ex + a.b2[256] + (v < a.n ? a.h[(size_t)v * HS + 256] : 0.0f);
     }
-    __syncthreads();
+    lds_barrier();
 
     // LayerNorm(257) (dynamics.py:81-87, 204), biased variance, eps = 1e-5
     if (a.norm) {
@@ -564,7 +601,7 @@ __global__ __launch_bounds__(256, 2) void k_node_update(NodeArgs a) {
             s_rstd[row] = 1.0f / sqrtf(var * (1.0f / HW) + 1e-5f);
         }
     }
-    __syncthreads();
+    lds_barrier();
     for (int rr = 0; rr < 16; ++rr) {
         const int r = wave * 16 + rr, v = node0 + r;
         if (v >= a.n) continue;
@@ -594,7 +631,7 @@ kpd_status egnn_kernels_init() {
     KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_proj), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 PROJ_LDS_BYTES));
     KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_egnn_edge), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                EDGE_LDS_BYTES));
+                                160 * 1024));
     KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_update),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, NODE_LDS_BYTES));
     g_attr_set = true;
@@ -647,7 +684,9 @@ kpd_status launch_node_proj(const ProjArgs &a, int n_slots, hipStream_t st) {
 
 kpd_status launch_egnn_edge(const EdgeArgs &a, int tile_cap, hipStream_t st) {
     if (tile_cap == 0) return KPD_OK;
-    hipLaunchKernelGGL(k_egnn_edge, dim3(8 * cdiv(tile_cap, 8)), dim3(256), EDGE_LDS_BYTES, st, a);
+    // KPD_EDGE_LDS_PAD (diagnostics): extra dynamic LDS to force one workgroup per CU
+    static const int pad = getenv("KPD_EDGE_LDS_PAD") ? atoi(getenv("KPD_EDGE_LDS_PAD")) : 0;
+    hipLaunchKernelGGL(k_egnn_edge, dim3(8 * cdiv(tile_cap, 8)), dim3(256), EDGE_LDS_BYTES + pad, st, a);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
 }

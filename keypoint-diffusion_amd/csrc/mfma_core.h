@@ -39,40 +39,81 @@ __device__ __forceinline__ void acc_zero(f32x16 (&acc)[2][2]) {
 }
 
 // acc[mt][nt] += A[64 x KP] * W[KP x (this wave's 64 columns)].
-// Output column 256 rides along on the VALU: every lane already holds A[r][k] and A[32 + r][k]
-// for its k's, so ex0 / ex1 accumulate A[r][:] . wx and A[32 + r][:] . wx (8 FMAs per 16 MFMAs);
-// after the final cross-half add every lane of every wave holds the dots of rows r and 32 + r.
+// One k-group: 16 MFMAs.
+#define KPD_GEMM_STEP(A0, A1, B0, B1)                                                             \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[j], B0[j], acc[0][0], 0, 0, 0);       \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[j], B1[j], acc[0][1], 0, 0, 0);       \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[j], B0[j], acc[1][0], 0, 0, 0);       \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[j], B1[j], acc[1][1], 0, 0, 0);       \
+    }
+
+#define KPD_GEMM_LOAD(A0, A1, B0, B1, G)                              \
+    A0 = *reinterpret_cast<const f32x4 *>(a0p + 8 * (G));             \
+    A1 = *reinterpret_cast<const f32x4 *>(a1p + 8 * (G));             \
+    B0 = bp[(G) * 512];                                               \
+    B1 = bp[(G) * 512 + 1];
+
 __device__ __forceinline__ void gemm_rows64(const float *__restrict__ A, const float *__restrict__ Wp,
-                                            const float *__restrict__ wx, f32x16 (&acc)[2][2], float &ex0,
-                                            float &ex1, int wave, int lane) {
+                                            f32x16 (&acc)[2][2], int wave, int lane) {
     const int r = lane & 31, h = lane >> 5;
     const float *a0p = A + r * SA + 4 * h;
     const float *a1p = A + (32 + r) * SA + 4 * h;
     const f32x4 *bp = reinterpret_cast<const f32x4 *>(Wp) + (wave * 64 + lane) * 2;
-    const f32x4 *wxp = reinterpret_cast<const f32x4 *>(wx) + h;
-    f32x4 b0 = bp[0], b1 = bp[1], w = wxp[0];
-    float e0 = 0.0f, e1 = 0.0f;
+    // Two operand register sets X / Y alternate (no register rotation: on gfx950 the f32 MFMA and
+    // ordinary VALU work do not overlap, so every VALU instruction in this loop is lost MFMA time).
+    // The set that was just consumed is refilled for two k-groups ahead right after its MFMAs
+    // issue, so each refill has one full group (16 MFMAs = 1024 cycles) to land.  sched_barriers
+    // pin that order; without them the scheduler sinks the loads next to their use.
+    f32x4 xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1;
+    KPD_GEMM_LOAD(xa0, xa1, xb0, xb1, 0)
+    KPD_GEMM_LOAD(ya0, ya1, yb0, yb1, 1)
+    static_assert(NG % 2 == 1, "loop below assumes an odd number of k-groups");
 #pragma unroll 1
-    for (int g = 0; g < NG; ++g) {
-        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(a0p + 8 * g);
-        const f32x4 a1 = *reinterpret_cast<const f32x4 *>(a1p + 8 * g);
-        const int gn = g + 1 < NG ? g + 1 : g;
-        const f32x4 nb0 = bp[gn * 512], nb1 = bp[gn * 512 + 1], nw = wxp[2 * gn];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
-            e0 = fmaf(a0[j], w[j], e0);
-            e1 = fmaf(a1[j], w[j], e1);
-        }
-        b0 = nb0;
-        b1 = nb1;
-        w = nw;
+    for (int g = 0; g < NG - 1; g += 2) {
+        __builtin_amdgcn_sched_barrier(0);
+        KPD_GEMM_STEP(xa0, xa1, xb0, xb1)
+        __builtin_amdgcn_sched_barrier(0);
+        KPD_GEMM_LOAD(xa0, xa1, xb0, xb1, g + 2)
+        __builtin_amdgcn_sched_barrier(0);
+        KPD_GEMM_STEP(ya0, ya1, yb0, yb1)
+        __builtin_amdgcn_sched_barrier(0);
+        const int g3 = g + 3 < NG ? g + 3 : NG - 1;
+        KPD_GEMM_LOAD(ya0, ya1, yb0, yb1, g3)
     }
-    ex0 += e0 + __shfl_xor(e0, 32);
-    ex1 += e1 + __shfl_xor(e1, 32);
+    __builtin_amdgcn_sched_barrier(0);
+    KPD_GEMM_STEP(xa0, xa1, xb0, xb1)
+}
+
+// Output column 256 (the "+1" of hidden_nf + 1): dot of every A row with wx[k] = W[256][k] on the
+// VALU.  Four consecutive threads own row tid >> 2 and stride the 66 float4 chunks of the row.
+// Returns the full dot on all 4 lanes.
+__device__ __forceinline__ float extra_col(const float *__restrict__ A, const float *__restrict__ wx, int tid) {
+    const int row = tid >> 2, q = tid & 3;
+    const f32x4 *a = reinterpret_cast<const f32x4 *>(A + row * SA);
+    const f32x4 *w = reinterpret_cast<const f32x4 *>(wx);
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 17; ++i) {
+        const int c = q + 4 * i;
+        if (c < KP / 4) {
+            const f32x4 av = a[c], wv = w[c];
+            s = fmaf(av[0], wv[0], s);
+            s = fmaf(av[1], wv[1], s);
+            s = fmaf(av[2], wv[2], s);
+            s = fmaf(av[3], wv[3], s);
+        }
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    return s;
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
+// counter, i.e. every wave would wait at each barrier for its outstanding global stores (segment
+// pieces, projections) to be acknowledged; nothing in these kernels reads those back.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 // Row/column owned by accumulator register `reg` of tile (mt, nt) on this lane.
@@ -81,15 +122,22 @@ __device__ __forceinline__ int acc_row(int mt, int reg, int lane) {
 }
 __device__ __forceinline__ int acc_col(int nt, int wave, int lane) { return 64 * wave + 32 * nt + (lane & 31); }
 
-// dot over the 257 valid columns of row (tid >> 2) of a T tile with a weight vector (w in LDS
-// or global).  Groups of 4 consecutive threads own a row and stride the columns by 4
-// (conflict-free at SA = 268).  Returns the full dot on all 4 lanes.
+// dot over the 257 valid columns of row (tid >> 2) of a T tile with a weight vector (w in LDS or
+// global, 16-B aligned).  Four consecutive threads own a row and stride its 64 float4 chunks.
+// Returns the full dot on all 4 lanes.
 __device__ __forceinline__ float row_dot257(const float *__restrict__ T, const float *__restrict__ w, int tid) {
     const int row = tid >> 2, q = tid & 3;
-    const float *a = T + row * SA + q;
+    const f32x4 *a = reinterpret_cast<const f32x4 *>(T + row * SA);
+    const f32x4 *wv = reinterpret_cast<const f32x4 *>(w);
     float s = 0.0f;
-#pragma unroll 8
-    for (int i = 0; i < 64; ++i) s = fmaf(a[4 * i], w[4 * i + q], s);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const f32x4 av = a[q + 4 * i], wq = wv[q + 4 * i];
+        s = fmaf(av[0], wq[0], s);
+        s = fmaf(av[1], wq[1], s);
+        s = fmaf(av[2], wq[2], s);
+        s = fmaf(av[3], wq[3], s);
+    }
     if (q == 0) s = fmaf(T[row * SA + 256], w[256], s);
     s += __shfl_xor(s, 1);
     s += __shfl_xor(s, 2);
