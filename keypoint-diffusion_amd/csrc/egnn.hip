@@ -440,9 +440,10 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
 
     for (int li = 0; li < n_layers; ++li) {
         const LayerW &L = m->L[li];
+        ProjPair pp;
+        memset(&pp, 0, sizeof(pp));
         for (int nt = 0; nt < 2; ++nt) {
-            ProjArgs pa;
-            memset(&pa, 0, sizeof(pa));
+            ProjArgs &pa = pp.nt[nt];
             pa.h = m->h[nt]; pa.n = n[nt]; pa.P = m->P[nt];
             int k = 0;
             for (int s = 0; s < NSLOT; ++s)
@@ -450,8 +451,10 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
                     pa.wp[k] = L.wp_p[nt][s]; pa.wx[k] = L.wx_p[nt][s]; pa.bias[k] = L.b_p[nt][s]; pa.slot[k] = s;
                     ++k;
                 }
-            KPD_TRY(launch_node_proj(pa, k, st));
+            pp.n_slots[nt] = k;
         }
+        pp.tiles0 = cdiv(n[0], TM);
+        KPD_TRY(launch_node_proj(pp, st));
         EdgeArgs ea;
         memset(&ea, 0, sizeof(ea));
         ea.meta = m->meta;
@@ -475,9 +478,10 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
             KPD_HIP(hipEventRecord(m->prof_ev[m->prof_used + 1], st));
             m->prof_used += 2;
         }
+        NodePair np;
+        memset(&np, 0, sizeof(np));
         for (int nt = 0; nt < m->n_upd; ++nt) {
-            NodeArgs na;
-            memset(&na, 0, sizeof(na));
+            NodeArgs &na = np.nt[nt];
             na.n = n[nt]; na.h = m->h[nt]; na.x = m->x[nt]; na.bidx = m->bidx[nt]; na.z = m->z[nt];
             int k = 0;
             for (int et = 0; et < m->n_et; ++et)
@@ -491,8 +495,9 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
             na.wp_a = L.wp_a[nt]; na.wx_a = L.wx_a[nt]; na.wp_b = L.wp_b[nt]; na.wx_b = L.wx_b[nt]; na.b0 = L.b0[nt];
             na.wp_2 = L.wp_2[nt]; na.wx_2 = L.wx_2[nt]; na.b2 = L.b2[nt]; na.ln_w = L.ln_w[nt]; na.ln_b = L.ln_b[nt];
             na.norm = c.norm;
-            KPD_TRY(launch_node_update(na, st));
         }
+        np.tiles0 = cdiv(n[0], TM);
+        KPD_TRY(launch_node_update(np, st));
     }
     KPD_TRY(launch_decode(m->h[NT_LIG], m->x[NT_LIG], bt->lig_x, bt->n_lig, c.atom_nf, 2 * c.atom_nf, m->de_W0, m->de_b0,
                           m->de_W1, m->de_b1, eps_h, eps_x, st));

@@ -23,6 +23,12 @@ struct ProjArgs {
     int slot[NSLOT];
 };
 
+struct ProjPair {
+    ProjArgs nt[2];
+    int tiles0;                     // workgroups (64-node tiles) of nt[0]
+    int n_slots[2];
+};
+
 struct EdgeArgs {
     const int *meta;                // [9] device: E[4], first tile[5]
     const int *src[4];
@@ -58,6 +64,11 @@ struct NodeArgs {
     int norm;
 };
 
+struct NodePair {
+    NodeArgs nt[2];                 // nt[1].n == 0 when only one node type is updated
+    int tiles0;
+};
+
 kpd_status egnn_kernels_init();
 kpd_status launch_node_graph_index(const int *ptr, int B, int n, int *bidx, hipStream_t st);
 kpd_status launch_egnn_meta(const int *counts, int e_kk, int active_mask, const int *lig_ptr, const int *kp_ptr,
@@ -67,8 +78,8 @@ kpd_status launch_embed(const float *in, int n, int fin, const float *W0, const 
                         const float *b1, const float *t, const int *bidx, float *out, int identity, hipStream_t st);
 kpd_status launch_decode(const float *h, const float *x, const float *x0, int n, int atom_nf, int hid, const float *W0,
                          const float *b0, const float *W1, const float *b1, float *eps_h, float *eps_x, hipStream_t st);
-kpd_status launch_node_proj(const ProjArgs &a, int n_slots, hipStream_t st);
+kpd_status launch_node_proj(const ProjPair &p, hipStream_t st);
 kpd_status launch_egnn_edge(const EdgeArgs &a, int tile_cap, hipStream_t st);
-kpd_status launch_node_update(const NodeArgs &a, hipStream_t st);
+kpd_status launch_node_update(const NodePair &p, hipStream_t st);
 
 }  // namespace kpd

@@ -15,6 +15,8 @@
 // tile); k_node_update adds main + cont pieces in tile order => deterministic, no atomics.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "egnn_kernels.h"
 #include "mfma_core.h"
 
@@ -145,11 +147,16 @@ __global__ __launch_bounds__(64) void k_decode(const float *__restrict__ h, cons
 
 // ---- node projection ----------------------------------------------------------------------
 // LDS: A tile only.
-__global__ __launch_bounds__(256, 2) void k_node_proj(ProjArgs a) {
+// One launch covers both node types: workgroups [0, tiles0) belong to p.nt[0], the rest to p.nt[1].
+__global__ __launch_bounds__(256, 2) void k_node_proj(ProjPair p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *A = smem;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int node0 = blockIdx.x * TM, s = blockIdx.y;
+    const int which = blockIdx.x >= p.tiles0 ? 1 : 0;
+    const int s = blockIdx.y;
+    if (s >= p.n_slots[which]) return;
+    const ProjArgs &a = p.nt[which];
+    const int node0 = (blockIdx.x - (which ? p.tiles0 : 0)) * TM;
 
     for (int rr = 0; rr < 16; ++rr) {
         const int r = wave * 16 + rr, v = node0 + r;
@@ -464,14 +471,18 @@ struct NodeSmem {
     float *zinv, *mean, *rstd;
 };
 
-__global__ __launch_bounds__(256, 2) void k_node_update(NodeArgs a) {
+// One launch covers both updated node types (ligand tiles first: fewer, but each gathers long
+// kl segments; the keypoint tiles fill the rest of the chip).
+__global__ __launch_bounds__(256, 2) void k_node_update(NodePair p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *A = smem;
     float *s_z = smem + TM * SA;        // [64] z of the row's graph
     float *s_mean = s_z + TM;           // [64]
     float *s_rstd = s_mean + TM;        // [64]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int node0 = blockIdx.x * TM;
+    const int which = blockIdx.x >= p.tiles0 ? 1 : 0;
+    const NodeArgs &a = p.nt[which];
+    const int node0 = (blockIdx.x - (which ? p.tiles0 : 0)) * TM;
 
     // coordinates: x' = x + x_neigh / z (dynamics.py:190-192, 206)
     if (tid < TM) {
@@ -675,9 +686,11 @@ kpd_status launch_decode(const float *h, const float *x, const float *x0, int n,
     return KPD_OK;
 }
 
-kpd_status launch_node_proj(const ProjArgs &a, int n_slots, hipStream_t st) {
-    if (a.n == 0 || n_slots == 0) return KPD_OK;
-    hipLaunchKernelGGL(k_node_proj, dim3(cdiv(a.n, TM), n_slots), dim3(256), PROJ_LDS_BYTES, st, a);
+kpd_status launch_node_proj(const ProjPair &p, hipStream_t st) {
+    const int tiles = p.tiles0 + cdiv(p.nt[1].n, TM);
+    const int slots = std::max(p.n_slots[0], p.n_slots[1]);
+    if (tiles == 0 || slots == 0) return KPD_OK;
+    hipLaunchKernelGGL(k_node_proj, dim3(tiles, slots), dim3(256), PROJ_LDS_BYTES, st, p);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
 }
@@ -691,9 +704,10 @@ kpd_status launch_egnn_edge(const EdgeArgs &a, int tile_cap, hipStream_t st) {
     return KPD_OK;
 }
 
-kpd_status launch_node_update(const NodeArgs &a, hipStream_t st) {
-    if (a.n == 0) return KPD_OK;
-    hipLaunchKernelGGL(k_node_update, dim3(cdiv(a.n, TM)), dim3(256), NODE_LDS_BYTES, st, a);
+kpd_status launch_node_update(const NodePair &p, hipStream_t st) {
+    const int tiles = p.tiles0 + cdiv(p.nt[1].n, TM);
+    if (tiles == 0) return KPD_OK;
+    hipLaunchKernelGGL(k_node_update, dim3(tiles), dim3(256), NODE_LDS_BYTES, st, p);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
 }
