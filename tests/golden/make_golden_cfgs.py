@@ -1,0 +1,17 @@
+"""Configurations of the composed golden fixtures (shared by the generator and the tests)."""
+
+GVP_CFGS = {
+    'gvp_kp': dict(vector_size=16, n_convs=3, n_hidden_scalars=256, message_norm=10.0, update_kp=True, ll_k=0, kl_k=7,
+                   n_message_gvps=3, n_update_gvps=2, n_noise_gvps=4, dropout=0.1),
+    'gvp_mean': dict(vector_size=16, n_convs=2, n_hidden_scalars=128, message_norm='mean', update_kp=True, ll_k=0,
+                     kl_k=5, n_message_gvps=3, n_update_gvps=2, n_noise_gvps=4, dropout=0.1),
+    'gvp_norm0': dict(vector_size=16, n_convs=2, n_hidden_scalars=128, message_norm=0, update_kp=True, ll_k=0,
+                      kl_k=5, n_message_gvps=2, n_update_gvps=1, n_noise_gvps=3, dropout=0.0),
+}
+
+RECENC_CFGS = {'recenc_mean': dict(in_scalar_size=10, out_scalar_size=128, n_message_gvps=3, n_update_gvps=2, vector_size=16,
+                        n_rr_convs=2, n_rk_convs=2, message_norm='mean', k_closest=5, kp_rad=0, dropout=0.1,
+                        n_keypoints=6),
+    'recenc_norm10': dict(in_scalar_size=10, out_scalar_size=128, n_message_gvps=1, n_update_gvps=1, vector_size=16,
+                          n_rr_convs=3, n_rk_convs=2, message_norm=10.0, k_closest=4, kp_rad=0, dropout=0.0,
+                          n_keypoints=5)}

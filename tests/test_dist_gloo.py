@@ -1,0 +1,73 @@
+"""Multi-rank path on CPU: complexes sharded over ranks, one all-gather of the ligand tensors
+(gloo here; the same code runs over RCCL on the GPU box)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from keypoint_diffusion_amd import graph as G
+from keypoint_diffusion_amd import synth
+from keypoint_diffusion_amd.dist import all_gather_ligands, shard_complexes
+
+from . import util
+
+N_REC = [20, 35, 12, 28, 16]
+N_LIG = [5, 9, 3, 7, 4]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    gs = synth.synth_complexes(N_REC, N_LIG, 4, util.CUTOFFS_ALL_ATOM, seed=40)
+    mine = shard_complexes(N_REC, world)[rank]
+    g = G.batch([gs[i] for i in mine])
+    # stand-in for the sampler's output: mark every ligand with its global complex index
+    off = 0
+    for i in mine:
+        g.nodes['lig'].data['x_0'][off:off + N_LIG[i]] += 100.0 * i
+        off += N_LIG[i]
+    pos, feat = all_gather_ligands(g)
+    q.put((rank, [p.clone() for p in pos], [f.clone() for f in feat]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_is_contiguous_and_balanced():
+    for world in (1, 2, 3, 5):
+        parts = shard_complexes(N_REC, world)
+        assert len(parts) == world
+        flat = [i for r in parts for i in r]
+        assert flat == list(range(len(N_REC)))
+        assert all(len(r) >= 1 for r in parts)
+    parts = shard_complexes([600, 150, 150, 150, 150], 2)
+    assert list(parts[0]) == [0]                         # cost-balanced, not count-balanced
+
+
+def test_all_gather_ligands_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    gs = synth.synth_complexes(N_REC, N_LIG, 4, util.CUTOFFS_ALL_ATOM, seed=40)
+    for rank, pos, feat in res:
+        assert len(pos) == len(N_LIG)
+        for i, (p, f) in enumerate(zip(pos, feat)):
+            assert p.shape == (N_LIG[i], 3) and f.shape == (N_LIG[i], 10)
+            assert torch.allclose(p, gs[i].nodes['lig'].data['x_0'] + 100.0 * i, atol=1e-5)
+            assert torch.allclose(f, gs[i].nodes['lig'].data['h_0'], atol=1e-6)
