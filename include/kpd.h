@@ -122,6 +122,42 @@ kpd_status kpd_egnn_profile_read(kpd_egnn *m, double *total_ms, int32_t *launche
 kpd_status kpd_egnn_last_counts(kpd_egnn *m, int32_t out[8], void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * GVP denoiser.  Replaces LigRecDynamicsGVP.forward (models/dynamics_gvp.py:149-199): encoders
+ * (:124-134), edge build (:201-234), the GVPMultiEdgeConv stack (models/gvp.py:343-551; GVP :43-116,
+ * GVPLayerNorm :152-166) and the NoisePredictionBlock (:10-44).  Fields mirror
+ * LigRecDynamicsGVP.__init__ (:106-147).  kpd_batch.kp_v carries the keypoint vector features v_0.
+ * ------------------------------------------------------------------------------------- */
+typedef struct kpd_gvp_config {
+    int32_t n_lig_scalars, n_kp_scalars;
+    int32_t vector_size;               /* must be 16                                       */
+    int32_t n_convs, n_hidden_scalars; /* n_hidden_scalars in {128, 256}                   */
+    int32_t update_kp;
+    int32_t message_norm_mode;         /* 0: constant message_norm, 1: 'mean', 2: message_norm == 0
+                                          (per-graph average in-degree + 1, gvp.py:504-507)  */
+    float message_norm;
+    int32_t ll_k, kl_k;                /* ll_k must be 0; kl_k in 1..16                    */
+    float ll_cutoff, kl_cutoff;
+    int32_t n_message_gvps, n_update_gvps, n_noise_gvps;   /* each in 1..4                 */
+} kpd_gvp_config;
+
+typedef struct kpd_gvp kpd_gvp;
+
+kpd_status kpd_gvp_create(const kpd_gvp_config *cfg, kpd_gvp **out);
+void kpd_gvp_destroy(kpd_gvp *m);
+/* Reference state-dict names of the `dynamics` module, e.g.
+ * "noise_predictor.conv_layers.2.edge_message_fns.kp_kl_lig.0.to_feats_out.0.weight". */
+kpd_status kpd_gvp_load_weight(kpd_gvp *m, const char *name, const float *w_dev,
+                               const int64_t *shape, int32_t ndim, void *stream);
+kpd_status kpd_gvp_commit(kpd_gvp *m);
+kpd_status kpd_gvp_reserve(kpd_gvp *m, int32_t max_B, int32_t max_n_lig, int32_t max_n_kp,
+                           int32_t max_n_kk, int32_t max_lig_per_graph, int32_t max_kp_per_graph);
+kpd_status kpd_gvp_forward(kpd_gvp *m, const kpd_batch *batch, const float *t_dev,
+                           float *eps_h_dev, float *eps_x_dev, void *stream);
+/* Debug/test taps: "convs=<n>" limits the conv stack; "s_lig", "s_kp", "v_lig", "v_kp" copy state. */
+kpd_status kpd_gvp_debug_state(kpd_gvp *m, const char *what, float *out_dev, int64_t n_floats,
+                               void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Reverse-diffusion update around the denoiser.  Replaces the elementwise part of
  * KeypointDiffusion.sample_p_zs_given_zt (models/ligand_diffuser.py:515-536):
  *   z_s = z_t / alpha_ts - var_terms * eps + sigma * noise, then ligand-COM removal from

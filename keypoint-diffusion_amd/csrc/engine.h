@@ -27,6 +27,9 @@ struct Arena {
 // Weight repacking helpers (pack.hip).
 // src: torch Linear weight [n_out, ld] row-major on device; uses columns [col0, col0 + K).
 kpd_status pack_gemm_weight(const float *src, int n_out, int ld, int col0, int K, float *wp, float *wx, hipStream_t st);
+// General K (padded to 8 ng) and N <= 256 (no extra column): packed block of ng*2048 floats.
+kpd_status pack_gemm_weight_ng(const float *src, int n_out, int ld, int col0, int K, int ng, float *wp, hipStream_t st);
+kpd_status pack_gate_weight(const float *src, int vout, int K, float *dst, hipStream_t st);
 // dst[0..n_dst) = src[0..n_src) then zeros.
 kpd_status copy_pad(const float *src, int n_src, float *dst, int n_dst, hipStream_t st);
 // dst[c][r] = src[r][c]

@@ -1,0 +1,505 @@
+// GVP denoiser engine behind the kpd_gvp_* C ABI (include/kpd.h).  Replaces
+// LigRecDynamicsGVP.forward (models/dynamics_gvp.py:149-199) as a whole: encoders, per-step edge
+// build, the GVPMultiEdgeConv stack (models/gvp.py:459-551) and the NoisePredictionBlock.
+#include <string.h>
+
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "egnn_kernels.h"
+#include "gvp_kernels.h"
+
+using namespace kpd;
+
+namespace {
+
+const int kSrcNtG[4] = {0, 1, 0, 1};     // ll, kl, lk, kk  (0 = lig, 1 = kp)
+const int kDstNtG[4] = {0, 0, 1, 1};
+const char *kCanon[4] = {"lig_ll_lig", "kp_kl_lig", "lig_lk_kp", "kp_kk_kp"};
+const char *kNtNameG[2] = {"lig", "kp"};
+
+// Host-side description of one GVP + its device buffers.
+struct HostGvp {
+    int vin = 0, h = 0, vout = 0, s_in = 0, sout = 0;   // s_in = scalar inputs of to_feats_out (without sh)
+    bool split_src = false;                             // first message GVP: h_src block handled by k_gvp_proj
+    int S = 0;                                          // width of the h_src block when split
+    float *Wh = nullptr, *Wu = nullptr, *wp = nullptr, *b = nullptr, *wg = nullptr, *bg = nullptr;
+    float *wproj = nullptr, *bproj = nullptr;           // split only
+    int ng = 0;
+    int vec_sigmoid = 1;
+    GvpW dev() const {
+        GvpW w;
+        w.Wh = Wh; w.Wu = Wu; w.wp = wp; w.b = b; w.wg = wg; w.bg = bg;
+        w.vin = vin; w.h = h; w.vout = vout;
+        w.n_s = split_src ? s_in - S : s_in;
+        w.sout = sout; w.ng = ng; w.vec_sigmoid = vec_sigmoid;
+        return w;
+    }
+};
+
+std::vector<std::string> split_dots(const std::string &s) {
+    std::vector<std::string> out;
+    size_t p = 0;
+    while (true) {
+        size_t q = s.find('.', p);
+        out.push_back(s.substr(p, q == std::string::npos ? q : q - p));
+        if (q == std::string::npos) break;
+        p = q + 1;
+    }
+    return out;
+}
+
+}  // namespace
+
+struct kpd_gvp {
+    kpd_gvp_config cfg;
+    int S, V;
+    Arena warena, ws;
+    // weights
+    std::vector<std::vector<std::vector<HostGvp>>> msg;   // [conv][et][j]
+    std::vector<std::vector<std::vector<HostGvp>>> upd;   // [conv][nt][j]
+    std::vector<std::vector<float *>> ln1w, ln1b, ln2w, ln2b;   // [conv][nt]
+    std::vector<HostGvp> noise;
+    float *enc_W[2], *enc_b[2], *enc_lw[2], *enc_lb[2];
+    float *out_W, *out_b;
+    std::set<std::string> expected, loaded;
+    bool committed = false;
+    int debug_convs = -1;
+    // workspace
+    int cap_B = 0, cap_lig = 0, cap_kp = 0, cap_kk = 0, cap_maxlig = 0, cap_maxkp = 0;
+    float *s[2], *v[2], *s_tmp[2];
+    float *Psrc[4];
+    float *ms_main[4], *ms_cont[4], *mv_main[4], *mv_cont[4];
+    int *bidx[2];
+    float *z[2];
+    int *meta4, *meta2, *ll_deg, *ll_off, *kl_off;
+    kpd_lig_graph lg;
+
+    int n_et(int conv) const { return (cfg.update_kp && conv != cfg.n_convs - 1) ? 4 : 2; }
+};
+
+#define KPD_TRY(expr)                  \
+    do {                               \
+        kpd_status s_ = (expr);        \
+        if (s_ != KPD_OK) return s_;   \
+    } while (0)
+
+static void alloc_gvp(Arena &A, HostGvp &g, std::set<std::string> &expected, const std::string &prefix) {
+    g.h = std::max(g.vin, g.vout);
+    const int k_edge = (g.split_src ? g.s_in - g.S : g.s_in) + g.h;
+    g.ng = (k_edge + 7) / 8;
+    g.Wh = A.take<float>(g.vin * g.h);
+    g.Wu = A.take<float>(g.h * g.vout);
+    g.wp = A.take<float>((size_t)g.ng * 2048);
+    g.b = A.take<float>(256);
+    g.wg = A.take<float>((size_t)(g.sout / 16) * 256);
+    g.bg = A.take<float>(16);
+    if (g.split_src) {
+        g.wproj = A.take<float>((size_t)(g.S / 8) * 2048);
+        g.bproj = A.take<float>(256);
+    }
+    for (const char *s : {".Wh", ".Wu", ".to_feats_out.0.weight", ".to_feats_out.0.bias", ".scalar_to_vector_gates.weight",
+                          ".scalar_to_vector_gates.bias"})
+        expected.insert(prefix + s);
+}
+
+extern "C" kpd_status kpd_gvp_create(const kpd_gvp_config *cfg, kpd_gvp **out) {
+    KPD_REQUIRE(cfg && out, KPD_ERR_INVALID, "null argument");
+    KPD_REQUIRE(cfg->vector_size == GV, KPD_ERR_INVALID, "vector_size=%d: the HIP path is built for 16", cfg->vector_size);
+    KPD_REQUIRE(cfg->n_hidden_scalars == 256 || cfg->n_hidden_scalars == 128, KPD_ERR_INVALID,
+                "n_hidden_scalars=%d: supported widths are 128 and 256", cfg->n_hidden_scalars);
+    KPD_REQUIRE(cfg->ll_k == 0, KPD_ERR_INVALID, "ll_k=%d: only the radius lig-lig graph is implemented", cfg->ll_k);
+    KPD_REQUIRE(cfg->kl_k >= 1 && cfg->kl_k <= KL_KMAX, KPD_ERR_INVALID, "kl_k=%d outside 1..%d", cfg->kl_k, KL_KMAX);
+    KPD_REQUIRE(cfg->n_convs >= 1 && cfg->n_convs <= 32, KPD_ERR_INVALID, "n_convs=%d", cfg->n_convs);
+    KPD_REQUIRE(cfg->update_kp || cfg->n_convs == 1, KPD_ERR_INVALID,
+                "update_kp=0 with more than one convolution cannot run in the reference (gvp.py:501, 536)");
+    KPD_REQUIRE(cfg->n_message_gvps >= 1 && cfg->n_message_gvps <= GVP_MAX_CHAIN && cfg->n_update_gvps >= 1 &&
+                    cfg->n_update_gvps <= GVP_MAX_CHAIN && cfg->n_noise_gvps >= 1 && cfg->n_noise_gvps <= GVP_MAX_CHAIN,
+                KPD_ERR_INVALID, "GVP chain lengths must be within 1..%d", GVP_MAX_CHAIN);
+    KPD_REQUIRE(cfg->n_lig_scalars >= 1 && cfg->n_lig_scalars <= 64 && cfg->n_kp_scalars >= 1 && cfg->n_kp_scalars <= 256,
+                KPD_ERR_INVALID, "feature widths out of range");
+    KPD_REQUIRE(cfg->message_norm_mode >= 0 && cfg->message_norm_mode <= 2, KPD_ERR_INVALID, "message_norm_mode");
+    KPD_TRY(egnn_kernels_init());
+    KPD_TRY(gvp_kernels_init());
+    kpd_gvp *m = new kpd_gvp();
+    m->cfg = *cfg;
+    m->S = cfg->n_hidden_scalars;
+    m->V = GV;
+    const int S = m->S, C = cfg->n_convs;
+    size_t per_gvp = ((size_t)NG_G * 2048 + 17 * 17 + 17 * 16 + 256 + 16 * 256 + 16 + (size_t)(S / 8) * 2048 + 256) * 4 + 4096;
+    size_t bytes = per_gvp * ((size_t)C * (4 * cfg->n_message_gvps + 2 * cfg->n_update_gvps) + cfg->n_noise_gvps) +
+                   (size_t)C * 2 * 4 * (S * 4 + 256) + (size_t)2 * (S * 260 + 3 * S) * 4 + 64 * 64 * 4 + (1 << 20);
+    kpd_status st = m->warena.reserve(bytes);
+    if (st != KPD_OK) {
+        delete m;
+        return st;
+    }
+    Arena &A = m->warena;
+    m->msg.resize(C); m->upd.resize(C); m->ln1w.resize(C); m->ln1b.resize(C); m->ln2w.resize(C); m->ln2b.resize(C);
+    for (int i = 0; i < C; ++i) {
+        const std::string pre = "noise_predictor.conv_layers." + std::to_string(i) + ".";
+        const int net = m->n_et(i), nnt = net == 4 ? 2 : 1;
+        m->msg[i].resize(4); m->upd[i].resize(2);
+        m->ln1w[i].assign(2, nullptr); m->ln1b[i].assign(2, nullptr); m->ln2w[i].assign(2, nullptr); m->ln2b[i].assign(2, nullptr);
+        for (int et = 0; et < net; ++et) {
+            m->msg[i][et].resize(cfg->n_message_gvps);
+            for (int j = 0; j < cfg->n_message_gvps; ++j) {
+                HostGvp &g = m->msg[i][et][j];
+                g.vin = j == 0 ? GV + 1 : GV; g.vout = GV;
+                g.s_in = j == 0 ? S + 16 : S; g.sout = S;
+                g.split_src = j == 0; g.S = S;
+                alloc_gvp(A, g, m->expected, pre + "edge_message_fns." + kCanon[et] + "." + std::to_string(j));
+            }
+        }
+        for (int nt = 0; nt < nnt; ++nt) {
+            m->upd[i][nt].resize(cfg->n_update_gvps);
+            for (int j = 0; j < cfg->n_update_gvps; ++j) {
+                HostGvp &g = m->upd[i][nt][j];
+                g.vin = GV; g.vout = GV; g.s_in = S; g.sout = S;
+                alloc_gvp(A, g, m->expected, pre + "node_update_fns." + kNtNameG[nt] + "." + std::to_string(j));
+            }
+            m->ln1w[i][nt] = A.take<float>(S); m->ln1b[i][nt] = A.take<float>(S);
+            m->ln2w[i][nt] = A.take<float>(S); m->ln2b[i][nt] = A.take<float>(S);
+            for (const char *s : {".feat_norm.weight", ".feat_norm.bias"}) {
+                m->expected.insert(pre + "message_layer_norms." + kNtNameG[nt] + s);
+                m->expected.insert(pre + "update_layer_norms." + kNtNameG[nt] + s);
+            }
+        }
+    }
+    m->noise.resize(cfg->n_noise_gvps);
+    for (int j = 0; j < cfg->n_noise_gvps; ++j) {
+        HostGvp &g = m->noise[j];
+        const bool last = j == cfg->n_noise_gvps - 1;
+        g.vin = GV; g.vout = last ? 1 : GV; g.s_in = S; g.sout = last ? 64 : S;
+        g.vec_sigmoid = last ? 0 : 1;
+        alloc_gvp(A, g, m->expected, "noise_predictor.noise_predictor.gvps." + std::to_string(j));
+    }
+    const int fin[2] = {cfg->n_lig_scalars + 1, cfg->n_kp_scalars + 1};
+    for (int nt = 0; nt < 2; ++nt) {
+        m->enc_W[nt] = A.take<float>((size_t)S * fin[nt]); m->enc_b[nt] = A.take<float>(S);
+        m->enc_lw[nt] = A.take<float>(S); m->enc_lb[nt] = A.take<float>(S);
+        const std::string e = std::string(kNtNameG[nt]) + "_encoder.";
+        for (const char *s : {"0.weight", "0.bias", "2.weight", "2.bias"}) m->expected.insert(e + s);
+    }
+    m->out_W = A.take<float>((size_t)cfg->n_lig_scalars * 64);
+    m->out_b = A.take<float>(cfg->n_lig_scalars);
+    m->expected.insert("noise_predictor.noise_predictor.to_scalar_output.weight");
+    m->expected.insert("noise_predictor.noise_predictor.to_scalar_output.bias");
+    if (!m->out_b) {
+        set_error("gvp weight arena too small (internal sizing error)");
+        kpd_gvp_destroy(m);
+        return KPD_ERR_HIP;
+    }
+    *out = m;
+    return KPD_OK;
+}
+
+extern "C" void kpd_gvp_destroy(kpd_gvp *m) {
+    if (!m) return;
+    m->warena.release();
+    m->ws.release();
+    delete m;
+}
+
+static kpd_status want_shape(const char *name, const int64_t *shape, int ndim, std::initializer_list<int64_t> want) {
+    bool ok = ndim == (int)want.size();
+    int i = 0;
+    for (int64_t w : want) {
+        if (ok && shape[i] != w) ok = false;
+        ++i;
+    }
+    if (!ok) {
+        std::string got;
+        for (int j = 0; j < ndim; ++j) got += std::to_string(shape[j]) + ",";
+        std::string exp;
+        for (int64_t w : want) exp += std::to_string(w) + ",";
+        set_error("weight %s has shape [%s], expected [%s]", name, got.c_str(), exp.c_str());
+        return KPD_ERR_WEIGHTS;
+    }
+    return KPD_OK;
+}
+
+static kpd_status load_gvp_tensor(HostGvp &g, const std::string &param, const char *name, const float *w, const int64_t *shape,
+                                  int ndim, hipStream_t st) {
+    const int k_all = g.s_in + g.h;
+    if (param == "Wh") {
+        KPD_TRY(want_shape(name, shape, ndim, {g.vin, g.h}));
+        KPD_TRY(copy_pad(w, g.vin * g.h, g.Wh, g.vin * g.h, st));
+    } else if (param == "Wu") {
+        KPD_TRY(want_shape(name, shape, ndim, {g.h, g.vout}));
+        KPD_TRY(copy_pad(w, g.h * g.vout, g.Wu, g.h * g.vout, st));
+    } else if (param == "to_feats_out.0.weight") {
+        KPD_TRY(want_shape(name, shape, ndim, {g.sout, k_all}));
+        if (g.split_src) {
+            KPD_TRY(pack_gemm_weight_ng(w, g.sout, k_all, 0, g.S, g.S / 8, g.wproj, st));
+            KPD_TRY(pack_gemm_weight_ng(w, g.sout, k_all, g.S, k_all - g.S, g.ng, g.wp, st));
+        } else {
+            KPD_TRY(pack_gemm_weight_ng(w, g.sout, k_all, 0, k_all, g.ng, g.wp, st));
+        }
+    } else if (param == "to_feats_out.0.bias") {
+        KPD_TRY(want_shape(name, shape, ndim, {g.sout}));
+        // split: the bias rides with the per-node projection; the per-edge stage adds nothing
+        KPD_TRY(copy_pad(w, g.sout, g.split_src ? g.bproj : g.b, 256, st));
+    } else if (param == "scalar_to_vector_gates.weight") {
+        KPD_TRY(want_shape(name, shape, ndim, {g.vout, g.sout}));
+        KPD_TRY(pack_gate_weight(w, g.vout, g.sout, g.wg, st));
+    } else if (param == "scalar_to_vector_gates.bias") {
+        KPD_TRY(want_shape(name, shape, ndim, {g.vout}));
+        KPD_TRY(copy_pad(w, g.vout, g.bg, 16, st));
+    } else {
+        set_error("unknown GVP parameter '%s'", name);
+        return KPD_ERR_WEIGHTS;
+    }
+    return KPD_OK;
+}
+
+extern "C" kpd_status kpd_gvp_load_weight(kpd_gvp *m, const char *name, const float *w, const int64_t *shape, int32_t ndim,
+                                          void *stream) {
+    KPD_REQUIRE(m && name && w && shape, KPD_ERR_INVALID, "null argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const std::string nm(name);
+    if (!m->expected.count(nm)) {
+        set_error("unknown or unused weight name '%s' for this configuration", name);
+        return KPD_ERR_WEIGHTS;
+    }
+    const int S = m->S;
+    const std::vector<std::string> tk = split_dots(nm);
+    auto tail_from = [&](size_t i) {
+        std::string t;
+        for (size_t k = i; k < tk.size(); ++k) t += (k > i ? "." : "") + tk[k];
+        return t;
+    };
+    if (tk[0] == "lig_encoder" || tk[0] == "kp_encoder") {
+        const int nt = tk[0] == "lig_encoder" ? 0 : 1;
+        const int fin = (nt == 0 ? m->cfg.n_lig_scalars : m->cfg.n_kp_scalars) + 1;
+        const bool is_w = tk[2] == "weight";
+        if (tk[1] == "0") {
+            if (is_w) { KPD_TRY(want_shape(name, shape, ndim, {S, fin})); KPD_TRY(copy_pad(w, S * fin, m->enc_W[nt], S * fin, st)); }
+            else { KPD_TRY(want_shape(name, shape, ndim, {S})); KPD_TRY(copy_pad(w, S, m->enc_b[nt], S, st)); }
+        } else {
+            KPD_TRY(want_shape(name, shape, ndim, {S}));
+            KPD_TRY(copy_pad(w, S, is_w ? m->enc_lw[nt] : m->enc_lb[nt], S, st));
+        }
+    } else if (tk[1] == "noise_predictor") {
+        if (tk[2] == "to_scalar_output") {
+            const int F = m->cfg.n_lig_scalars;
+            if (tk[3] == "weight") { KPD_TRY(want_shape(name, shape, ndim, {F, 64})); KPD_TRY(copy_pad(w, F * 64, m->out_W, F * 64, st)); }
+            else { KPD_TRY(want_shape(name, shape, ndim, {F})); KPD_TRY(copy_pad(w, F, m->out_b, F, st)); }
+        } else {   // noise_predictor.noise_predictor.gvps.<j>.<param>
+            const int j = atoi(tk[3].c_str());
+            KPD_TRY(load_gvp_tensor(m->noise[j], tail_from(4), name, w, shape, ndim, st));
+        }
+    } else {       // noise_predictor.conv_layers.<i>.<block>.<key>...
+        const int i = atoi(tk[2].c_str());
+        const std::string &blk = tk[3];
+        if (blk == "edge_message_fns") {
+            int et = -1;
+            for (int e = 0; e < 4; ++e)
+                if (tk[4] == kCanon[e]) et = e;
+            KPD_TRY(load_gvp_tensor(m->msg[i][et][atoi(tk[5].c_str())], tail_from(6), name, w, shape, ndim, st));
+        } else if (blk == "node_update_fns") {
+            const int nt = tk[4] == "lig" ? 0 : 1;
+            KPD_TRY(load_gvp_tensor(m->upd[i][nt][atoi(tk[5].c_str())], tail_from(6), name, w, shape, ndim, st));
+        } else {   // message_layer_norms / update_layer_norms .<nt>.feat_norm.<param>
+            const int nt = tk[4] == "lig" ? 0 : 1;
+            const bool is_w = tk[6] == "weight";
+            KPD_TRY(want_shape(name, shape, ndim, {S}));
+            float *dst = blk == "message_layer_norms" ? (is_w ? m->ln1w[i][nt] : m->ln1b[i][nt])
+                                                      : (is_w ? m->ln2w[i][nt] : m->ln2b[i][nt]);
+            KPD_TRY(copy_pad(w, S, dst, S, st));
+        }
+    }
+    m->loaded.insert(nm);
+    m->committed = false;
+    return KPD_OK;
+}
+
+extern "C" kpd_status kpd_gvp_commit(kpd_gvp *m) {
+    KPD_REQUIRE(m, KPD_ERR_INVALID, "null handle");
+    for (const std::string &n : m->expected)
+        if (!m->loaded.count(n)) {
+            set_error("weight '%s' was never loaded (%zu of %zu loaded)", n.c_str(), m->loaded.size(), m->expected.size());
+            return KPD_ERR_WEIGHTS;
+        }
+    m->committed = true;
+    return KPD_OK;
+}
+
+extern "C" kpd_status kpd_gvp_reserve(kpd_gvp *m, int32_t max_B, int32_t max_n_lig, int32_t max_n_kp, int32_t max_n_kk,
+                                      int32_t max_lig_pg, int32_t max_kp_pg) {
+    KPD_REQUIRE(m, KPD_ERR_INVALID, "null handle");
+    KPD_REQUIRE(max_B >= 1 && max_n_lig >= 1 && max_n_kp >= 1 && max_n_kk >= 0 && max_lig_pg >= 1 && max_kp_pg >= 1,
+                KPD_ERR_INVALID, "reserve: non-positive size");
+    if (max_B <= m->cap_B && max_n_lig <= m->cap_lig && max_n_kp <= m->cap_kp && max_n_kk <= m->cap_kk &&
+        max_lig_pg <= m->cap_maxlig && max_kp_pg <= m->cap_maxkp)
+        return KPD_OK;
+    max_B = std::max(max_B, m->cap_B); max_n_lig = std::max(max_n_lig, m->cap_lig); max_n_kp = std::max(max_n_kp, m->cap_kp);
+    max_n_kk = std::max(max_n_kk, m->cap_kk); max_lig_pg = std::max(max_lig_pg, m->cap_maxlig); max_kp_pg = std::max(max_kp_pg, m->cap_maxkp);
+    const long cap_ll_l = (long)max_n_lig * std::min(max_lig_pg - 1, 200), cap_kl_l = (long)max_n_kp * m->cfg.kl_k;
+    KPD_REQUIRE(cap_ll_l < (1l << 30) && cap_kl_l < (1l << 30), KPD_ERR_CAPACITY, "edge capacity overflows int32");
+    const int cap_ll = std::max<long>(cap_ll_l, 1), cap_kl = std::max<long>(cap_kl_l, 1);
+    const int E_cap[4] = {cap_ll, cap_kl, cap_kl, std::max(max_n_kk, 1)};
+    const int S = m->S, n[2] = {max_n_lig, max_n_kp};
+    int tiles[4];
+    size_t bytes = 1 << 20;
+    auto add = [&](size_t cnt) { bytes += ((cnt * 4 + 255) & ~size_t(255)); };
+    for (int nt = 0; nt < 2; ++nt) { add((size_t)n[nt] * S); add((size_t)n[nt] * S); add((size_t)n[nt] * 48); add(n[nt]); add(max_B); }
+    for (int et = 0; et < 4; ++et) {
+        tiles[et] = cdiv(E_cap[et], TM) + 1;
+        add((size_t)n[kSrcNtG[et]] * S);
+        add((size_t)n[kDstNtG[et]] * S); add((size_t)tiles[et] * S); add((size_t)n[kDstNtG[et]] * 48); add((size_t)tiles[et] * 48);
+    }
+    add(16); add(16); add(max_n_lig); add(max_B + 1); add(max_B + 1);
+    add(cap_ll); add(cap_ll); add(max_n_lig + 1);
+    for (int i = 0; i < 4; ++i) add(cap_kl);
+    add(max_n_lig + 1); add(max_n_kp + 1); add(max_B); add(8);
+    KPD_TRY(m->ws.reserve(bytes));
+    Arena &W = m->ws;
+    for (int nt = 0; nt < 2; ++nt) {
+        m->s[nt] = W.take<float>((size_t)n[nt] * S); m->s_tmp[nt] = W.take<float>((size_t)n[nt] * S);
+        m->v[nt] = W.take<float>((size_t)n[nt] * 48);
+        m->bidx[nt] = W.take<int>(n[nt]); m->z[nt] = W.take<float>(max_B);
+    }
+    for (int et = 0; et < 4; ++et) {
+        m->Psrc[et] = W.take<float>((size_t)n[kSrcNtG[et]] * S);
+        m->ms_main[et] = W.take<float>((size_t)n[kDstNtG[et]] * S); m->ms_cont[et] = W.take<float>((size_t)tiles[et] * S);
+        m->mv_main[et] = W.take<float>((size_t)n[kDstNtG[et]] * 48); m->mv_cont[et] = W.take<float>((size_t)tiles[et] * 48);
+    }
+    m->meta4 = W.take<int>(16); m->meta2 = W.take<int>(16);
+    m->ll_deg = W.take<int>(max_n_lig); m->ll_off = W.take<int>(max_B + 1); m->kl_off = W.take<int>(max_B + 1);
+    kpd_lig_graph &g = m->lg;
+    g.cap_ll = cap_ll; g.cap_kl = cap_kl;
+    g.ll_src = W.take<int>(cap_ll); g.ll_dst = W.take<int>(cap_ll); g.ll_rowptr = W.take<int>(max_n_lig + 1);
+    g.kl_src = W.take<int>(cap_kl); g.kl_dst = W.take<int>(cap_kl); g.kl_rowptr = W.take<int>(max_n_lig + 1);
+    g.lk_src = W.take<int>(cap_kl); g.lk_dst = W.take<int>(cap_kl); g.lk_rowptr = W.take<int>(max_n_kp + 1);
+    g.ll_per_graph = W.take<int>(max_B);
+    g.counts = W.take<int>(8);
+    KPD_REQUIRE(g.counts != nullptr, KPD_ERR_HIP, "gvp workspace arena too small (internal sizing error)");
+    m->cap_B = max_B; m->cap_lig = max_n_lig; m->cap_kp = max_n_kp; m->cap_kk = max_n_kk;
+    m->cap_maxlig = max_lig_pg; m->cap_maxkp = max_kp_pg;
+    return KPD_OK;
+}
+
+extern "C" kpd_status kpd_gvp_forward(kpd_gvp *m, const kpd_batch *bt, const float *t_dev, float *eps_h, float *eps_x,
+                                      void *stream) {
+    KPD_REQUIRE(m && bt && t_dev && eps_h && eps_x, KPD_ERR_INVALID, "null argument");
+    KPD_REQUIRE(m->committed, KPD_ERR_STATE, "kpd_gvp_forward before kpd_gvp_commit");
+    KPD_REQUIRE(bt->B >= 1 && bt->n_lig >= 1 && bt->n_kp >= 1, KPD_ERR_INVALID, "empty batch");
+    KPD_REQUIRE(bt->kp_v, KPD_ERR_INVALID, "kp_v (keypoint vector features v_0) missing");
+    KPD_REQUIRE(bt->B <= m->cap_B && bt->n_lig <= m->cap_lig && bt->n_kp <= m->cap_kp && bt->n_kk <= m->cap_kk &&
+                    bt->max_lig <= m->cap_maxlig && bt->max_kp <= m->cap_maxkp,
+                KPD_ERR_CAPACITY, "batch exceeds reserved workspace (call kpd_gvp_reserve)");
+    KPD_REQUIRE(bt->kk_rowptr && (bt->n_kk == 0 || (bt->kk_src && bt->kk_dst)), KPD_ERR_INVALID, "kk edges missing");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const kpd_gvp_config &c = m->cfg;
+    const int S = m->S;
+    const int n[2] = {bt->n_lig, bt->n_kp};
+
+    KPD_TRY(launch_node_graph_index(bt->lig_ptr, bt->B, bt->n_lig, m->bidx[0], st));
+    KPD_TRY(launch_node_graph_index(bt->kp_ptr, bt->B, bt->n_kp, m->bidx[1], st));
+    KPD_TRY(launch_lig_graph(bt, c.ll_cutoff, c.kl_k, &m->lg, m->ll_deg, m->ll_off, m->kl_off, st));
+    // tile tables for convs over all four edge types and over ll + kl only; z for message_norm == 0
+    const float mn = c.message_norm_mode == 2 ? 0.0f : 1.0f;
+    KPD_TRY(launch_egnn_meta(m->lg.counts, bt->n_kk, 0xF, bt->lig_ptr, bt->kp_ptr, m->lg.ll_per_graph, bt->kk_rowptr, bt->B,
+                             c.kl_k, mn, 1, m->meta4, m->z[0], m->z[1], st));
+    KPD_TRY(launch_egnn_meta(m->lg.counts, bt->n_kk, 0x3, bt->lig_ptr, bt->kp_ptr, m->lg.ll_per_graph, bt->kk_rowptr, bt->B,
+                             c.kl_k, mn, 1, m->meta2, m->z[0], m->z[1], st));
+    KPD_TRY(launch_gvp_embed(bt->lig_h, bt->n_lig, c.n_lig_scalars, m->enc_W[0], m->enc_b[0], m->enc_lw[0], m->enc_lb[0],
+                             t_dev, m->bidx[0], S, m->s[0], st));
+    KPD_TRY(launch_gvp_embed(bt->kp_h, bt->n_kp, c.n_kp_scalars, m->enc_W[1], m->enc_b[1], m->enc_lw[1], m->enc_lb[1],
+                             t_dev, m->bidx[1], S, m->s[1], st));
+    KPD_HIP(hipMemsetAsync(m->v[0], 0, (size_t)bt->n_lig * 48 * 4, st));                      // dynamics_gvp.py:179-184
+    KPD_HIP(hipMemcpyAsync(m->v[1], bt->kp_v, (size_t)bt->n_kp * 48 * 4, hipMemcpyDeviceToDevice, st));
+
+    const int E_cap[4] = {std::max<int>((long)bt->n_lig * std::min(bt->max_lig - 1, 200), 1), bt->n_kp * c.kl_k,
+                          bt->n_kp * c.kl_k, bt->n_kk};
+    const int *esrc[4] = {m->lg.ll_src, m->lg.kl_src, m->lg.lk_src, bt->kk_src};
+    const int *edst[4] = {m->lg.ll_dst, m->lg.kl_dst, m->lg.lk_dst, bt->kk_dst};
+    const int *rowptr[4] = {m->lg.ll_rowptr, m->lg.kl_rowptr, m->lg.lk_rowptr, bt->kk_rowptr};
+    const float *x[2] = {bt->lig_x, bt->kp_x};
+    const int n_convs = m->debug_convs >= 0 ? std::min(m->debug_convs, c.n_convs) : c.n_convs;
+
+    for (int ci = 0; ci < n_convs; ++ci) {
+        const int net = m->n_et(ci), nnt = net == 4 ? 2 : 1;
+        GvpProjArgs pa;
+        memset(&pa, 0, sizeof(pa));
+        pa.S = S;
+        int run = 0, tile_cap = 0;
+        for (int et = 0; et < 4; ++et) {
+            pa.tiles_first[et] = run;
+            if (et < net) {
+                const HostGvp &g = m->msg[ci][et][0];
+                pa.s[et] = m->s[kSrcNtG[et]]; pa.n[et] = n[kSrcNtG[et]]; pa.wp[et] = g.wproj; pa.b[et] = g.bproj; pa.P[et] = m->Psrc[et];
+                run += cdiv(n[kSrcNtG[et]], TM);
+                tile_cap += cdiv(E_cap[et], TM);
+            }
+        }
+        pa.tiles_first[4] = run;
+        KPD_TRY(launch_gvp_proj(pa, st));
+
+        GvpEdgeArgs ea;
+        memset(&ea, 0, sizeof(ea));
+        ea.meta = net == 4 ? m->meta4 : m->meta2;
+        ea.x[0] = x[0]; ea.x[1] = x[1]; ea.v[0] = m->v[0]; ea.v[1] = m->v[1];
+        ea.n_gvps = c.n_message_gvps; ea.S = S; ea.rbf_dmax = 15.0f;            // gvp.py:350 default, not overridden
+        for (int et = 0; et < net; ++et) {
+            ea.src[et] = esrc[et]; ea.dst[et] = edst[et]; ea.Psrc[et] = m->Psrc[et];
+            for (int j = 0; j < c.n_message_gvps; ++j) ea.g[et][j] = m->msg[ci][et][j].dev();
+            ea.ms_main[et] = m->ms_main[et]; ea.ms_cont[et] = m->ms_cont[et];
+            ea.mv_main[et] = m->mv_main[et]; ea.mv_cont[et] = m->mv_cont[et];
+        }
+        KPD_TRY(launch_gvp_edge(ea, tile_cap, st));
+
+        GvpNodePair np;
+        memset(&np, 0, sizeof(np));
+        for (int nt = 0; nt < nnt; ++nt) {
+            GvpNodeArgs &na = np.nt[nt];
+            na.n = n[nt]; na.s = m->s[nt]; na.v = m->v[nt]; na.s_tmp = m->s_tmp[nt]; na.bidx = m->bidx[nt];
+            na.mean = c.message_norm_mode == 1;
+            na.z = c.message_norm_mode == 2 ? m->z[nt] : nullptr;
+            na.norm_const = c.message_norm_mode == 0 ? c.message_norm : 1.0f;
+            int k = 0;
+            for (int et = 0; et < net; ++et)
+                if (kDstNtG[et] == nt) {
+                    na.rowptr[k] = rowptr[et];
+                    na.ms_main[k] = m->ms_main[et]; na.ms_cont[k] = m->ms_cont[et];
+                    na.mv_main[k] = m->mv_main[et]; na.mv_cont[k] = m->mv_cont[et];
+                    ++k;
+                }
+            na.n_in = k;
+            na.ln1_w = m->ln1w[ci][nt]; na.ln1_b = m->ln1b[ci][nt]; na.ln2_w = m->ln2w[ci][nt]; na.ln2_b = m->ln2b[ci][nt];
+            na.n_gvps = c.n_update_gvps; na.S = S;
+            for (int j = 0; j < c.n_update_gvps; ++j) na.g[j] = m->upd[ci][nt][j].dev();
+        }
+        np.tiles0 = cdiv(n[0], TM);
+        KPD_TRY(launch_gvp_node(np, st));
+    }
+
+    GvpNoiseArgs no;
+    memset(&no, 0, sizeof(no));
+    no.n = bt->n_lig; no.s = m->s[0]; no.v = m->v[0]; no.n_gvps = c.n_noise_gvps; no.S = S;
+    for (int j = 0; j < c.n_noise_gvps; ++j) no.g[j] = m->noise[j].dev();
+    no.Wout = m->out_W; no.bout = m->out_b; no.F = c.n_lig_scalars; no.eps_h = eps_h; no.eps_x = eps_x;
+    KPD_TRY(launch_gvp_noise(no, st));
+    return KPD_OK;
+}
+
+extern "C" kpd_status kpd_gvp_debug_state(kpd_gvp *m, const char *what, float *out, int64_t n_floats, void *stream) {
+    KPD_REQUIRE(m && what, KPD_ERR_INVALID, "null argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const std::string w(what);
+    if (w.rfind("convs=", 0) == 0) {
+        m->debug_convs = atoi(w.c_str() + 6);
+        return KPD_OK;
+    }
+    const float *src = nullptr;
+    if (w == "s_lig") src = m->s[0];
+    else if (w == "s_kp") src = m->s[1];
+    else if (w == "v_lig") src = m->v[0];
+    else if (w == "v_kp") src = m->v[1];
+    KPD_REQUIRE(src && out, KPD_ERR_INVALID, "unknown debug tap '%s'", what);
+    KPD_HIP(hipMemcpyAsync(out, src, (size_t)n_floats * 4, hipMemcpyDeviceToDevice, st));
+    return KPD_OK;
+}

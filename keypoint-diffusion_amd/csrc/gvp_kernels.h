@@ -1,0 +1,97 @@
+// Argument blocks and launchers of the GVP kernels (gvp_kernels.hip).
+#pragma once
+#include "engine.h"
+
+namespace kpd {
+
+constexpr int GV = 16;                 // vector channels (vector_size; 16 in every config)
+constexpr int GVH = 17;                // largest hidden vector width (x_diff + 16 source vectors)
+constexpr int VST = 52;                // floats per row of an LDS vector buffer (17 x 3, padded)
+constexpr int NG_G = 34;               // k-groups of the widest GVP GEMM (K = 256 + 16 = 272)
+constexpr int SA_G = 276;              // LDS row stride of the GVP A tile
+constexpr int GVP_LDS_FLOATS = TM * SA_G + 3 * TM * VST + TM * GV + 2 * 320 + 4 * TM + 16;
+constexpr int GVP_LDS_BYTES = GVP_LDS_FLOATS * 4;
+
+// One GVP (models/gvp.py:43-116) in kernel-ready form.
+struct GvpW {
+    const float *Wh;      // [vin][h]   as stored (models/gvp.py:68)
+    const float *Wu;      // [h][vout]
+    const float *wp;      // packed to_feats_out block for the A-tile columns (ng * 2048 floats)
+    const float *b;       // [256] bias, zero padded
+    const float *wg;      // packed scalar_to_vector_gates for the 16x16x4 MFMA ([sout/16][64][4])
+    const float *bg;      // [16]
+    int vin, h, vout;
+    int n_s;              // A-tile columns holding the scalar inputs; sh goes to [n_s, n_s + h)
+    int sout;             // valid scalar outputs (256, 128 or 64)
+    int ng;               // k-groups of the packed block
+    int vec_sigmoid;      // 1: sigmoid gate, 0: identity (last noise GVP)
+};
+
+constexpr int GVP_MAX_CHAIN = 4;
+
+struct GvpEdgeArgs {
+    const int *meta;              // [9]: E[4], first tile[5]
+    const int *src[4], *dst[4];
+    const float *x[2];            // positions (constant in the GVP denoiser)
+    const float *v[2];            // [n][16][3]
+    const float *Psrc[4];         // [n_src][S]: W0[:, :S] . s_src + b0, per edge type
+    GvpW g[4][GVP_MAX_CHAIN];     // per edge type, message chain
+    int n_gvps;
+    int S;
+    float rbf_dmax;
+    float *ms_main[4], *ms_cont[4];   // [n_dst][S], [tiles][S]
+    float *mv_main[4], *mv_cont[4];   // [n_dst][48], [tiles][48]
+};
+
+struct GvpNodeArgs {
+    int n;
+    float *s;                     // [n][S] in/out
+    float *v;                     // [n][16][3] in/out
+    float *s_tmp;                 // [n][S] scratch (residual of the update block)
+    const int *bidx;
+    const float *z;               // [B] per-graph normaliser (message_norm == 0) or nullptr
+    float norm_const;             // otherwise
+    int mean;                     // per-edge-type mean instead of sum
+    int n_in;
+    const int *rowptr[2];
+    const float *ms_main[2], *ms_cont[2], *mv_main[2], *mv_cont[2];
+    const float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+    GvpW g[GVP_MAX_CHAIN];
+    int n_gvps;
+    int S;
+};
+
+struct GvpNodePair {
+    GvpNodeArgs nt[2];
+    int tiles0;
+};
+
+struct GvpProjArgs {
+    const float *s[4];            // source scalar state per edge type
+    int n[4];
+    const float *wp[4], *b[4];
+    float *P[4];
+    int tiles_first[5];
+    int S;
+};
+
+struct GvpNoiseArgs {
+    int n;
+    const float *s, *v;
+    GvpW g[GVP_MAX_CHAIN];
+    int n_gvps;
+    int S;
+    const float *Wout, *bout;     // [F][64], [F]
+    int F;
+    float *eps_h, *eps_x;
+};
+
+kpd_status gvp_kernels_init();
+kpd_status launch_gvp_embed(const float *in, int n, int fin, const float *W, const float *b, const float *ln_w,
+                            const float *ln_b, const float *t, const int *bidx, int S, float *out, hipStream_t st);
+kpd_status launch_gvp_proj(const GvpProjArgs &a, hipStream_t st);
+kpd_status launch_gvp_edge(const GvpEdgeArgs &a, int tile_cap, hipStream_t st);
+kpd_status launch_gvp_node(const GvpNodePair &p, hipStream_t st);
+kpd_status launch_gvp_noise(const GvpNoiseArgs &a, hipStream_t st);
+
+}  // namespace kpd

@@ -1,0 +1,580 @@
+// GVP denoiser kernels (models/gvp.py GVP :89-116, GVPLayerNorm :159-166, GVPMultiEdgeConv
+// :459-551; models/dynamics_gvp.py NoisePredictionBlock :38-44, LigRecDynamicsGVP :149-199)
+// on the fp32-MFMA row-tile core.
+//
+// A "GVP stage" on a 64-row tile (rows = edges or nodes) keeps the scalar inputs in the LDS A tile
+// and the vector inputs in an LDS vector buffer, and runs
+//   vec1  Vh = Wh^T v (per xyz),  sh = |Vh|  -> appended to the A tile behind the scalars
+//   GEMM  s' = act(W [s, sh] + b [+ gathered per-row term])          (32x32x2 f32 MFMA)
+//   gate  g  = Wg s' + bg                                            (16x16x4 f32 MFMA)
+//   vec2  v' = sigmoid(g) * (Wu^T Vh)
+// with s' written back over the A tile and v' over the vector buffer, ready for the next stage.
+// The first Linear of an edge message is linear in h_src, so its 256-wide block is applied once
+// per source node (k_gvp_proj) and enters the edge stage as the gathered per-row term.
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "gvp_kernels.h"
+#include "mfma_core.h"
+
+namespace kpd {
+
+typedef float f32x4_ __attribute__((ext_vector_type(4)));
+
+struct GvpSmem {
+    float *A;                 // [64][SA_G]
+    float *V0, *V1, *V2;      // [64][VST]: current vectors, hidden vectors, residual vectors
+    float *G;                 // [64][16] gates
+    float *Wh, *Wu;           // [320] each
+    int *src, *dst;           // [64]
+    float *rowf;              // [128] per-row scratch (LN statistics)
+    int *misc;                // [16]
+};
+
+__device__ __forceinline__ GvpSmem gvp_smem(float *smem) {
+    GvpSmem s;
+    s.A = smem;
+    s.V0 = s.A + TM * SA_G;
+    s.V1 = s.V0 + TM * VST;
+    s.V2 = s.V1 + TM * VST;
+    s.G = s.V2 + TM * VST;
+    s.Wh = s.G + TM * GV;
+    s.Wu = s.Wh + 320;
+    s.src = reinterpret_cast<int *>(s.Wu + 320);
+    s.dst = s.src + TM;
+    s.rowf = reinterpret_cast<float *>(s.dst + TM);
+    s.misc = reinterpret_cast<int *>(s.rowf + 2 * TM);
+    return s;
+}
+
+// ---- one GVP stage ------------------------------------------------------------------------
+// add_row (optional): per-row term added before the activation, add_row[row_index[r] * add_ld + col].
+__device__ __forceinline__ void gvp_stage(const GvpSmem &s, const GvpW &w, const float *__restrict__ add_row,
+                                          const int *row_index, int add_ld, int tid) {
+    const int wave = tid >> 6, lane = tid & 63;
+    const int row = tid >> 2, q = tid & 3;
+    // Wh / Wu -> LDS
+    for (int i = tid; i < w.vin * w.h; i += 256) s.Wh[i] = w.Wh[i];
+    for (int i = tid; i < w.h * w.vout; i += 256) s.Wu[i] = w.Wu[i];
+    lds_barrier();
+
+    // vec1: Vh[h][c] = sum_v Wh[v][h] v[v][c]; sh[h] = sqrt(max(|Vh[h]|^2, 1e-8))  (gvp.py:96-99)
+    {
+        float a[5][3];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) a[i][0] = a[i][1] = a[i][2] = 0.0f;
+        const float *vin = s.V0 + row * VST;
+        for (int v = 0; v < w.vin; ++v) {
+            const float x0 = vin[3 * v], x1 = vin[3 * v + 1], x2 = vin[3 * v + 2];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int h = q + 4 * i;
+                const float wv = h < w.h ? s.Wh[v * w.h + h] : 0.0f;
+                a[i][0] = fmaf(wv, x0, a[i][0]);
+                a[i][1] = fmaf(wv, x1, a[i][1]);
+                a[i][2] = fmaf(wv, x2, a[i][2]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int h = q + 4 * i;
+            if (h < w.h) {
+                float *o = s.V1 + row * VST + 3 * h;
+                o[0] = a[i][0]; o[1] = a[i][1]; o[2] = a[i][2];
+                const float n2 = a[i][0] * a[i][0] + a[i][1] * a[i][1] + a[i][2] * a[i][2];
+                s.A[row * SA_G + w.n_s + h] = sqrtf(fmaxf(n2, 1e-8f));
+            }
+        }
+        // zero the K padding behind sh (the packed weight rows there are zero, the A values must be finite)
+        for (int c = w.n_s + w.h + q; c < 8 * w.ng; c += 4) s.A[row * SA_G + c] = 0.0f;
+    }
+    lds_barrier();
+
+    // GEMM + activation -> A tile columns 0..255
+    {
+        f32x16 acc[2][2];
+        acc_zero(acc);
+        gemm_rows64_rt<SA_G>(s.A, w.wp, w.ng, acc, wave, lane);
+        lds_barrier();
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int col = acc_col(nt, wave, lane);
+            const float bb = w.b[col];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int r = acc_row(mt, reg, lane);
+                    float val = acc[mt][nt][reg] + bb;
+                    if (add_row && col < add_ld) val += add_row[(size_t)row_index[r] * add_ld + col];
+                    s.A[r * SA_G + col] = silu(val);
+                }
+        }
+    }
+    lds_barrier();
+
+    // gates: 16 rows per wave on the 16x16x4 MFMA, K = sout  (gvp.py:105-107)
+    {
+        f32x4_ c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+        const float *ap = s.A + (16 * wave + (lane & 15)) * SA_G + 4 * (lane >> 4);
+        const f32x4_ *bp = reinterpret_cast<const f32x4_ *>(w.wg) + lane;
+        const int groups = w.sout >> 4;
+        for (int g = 0; g < groups; ++g) {
+            const f32x4_ a = *reinterpret_cast<const f32x4_ *>(ap + 16 * g);
+            const f32x4_ b = bp[g * 64];
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c1, 0, 0, 0);
+        }
+        const int u = lane & 15;
+        const float bg = w.bg[u];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) s.G[(16 * wave + 4 * (lane >> 4) + reg) * GV + u] = c0[reg] + c1[reg] + bg;
+    }
+    lds_barrier();
+
+    // vec2: v'[u][c] = act(gate[u]) * sum_h Wu[h][u] Vh[h][c]  (gvp.py:97, 111)
+    {
+        const float *vh = s.V1 + row * VST;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int u = q + 4 * i;
+            if (u < w.vout) {
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+                for (int h = 0; h < w.h; ++h) {
+                    const float wv = s.Wu[h * w.vout + u];
+                    a0 = fmaf(wv, vh[3 * h], a0);
+                    a1 = fmaf(wv, vh[3 * h + 1], a1);
+                    a2 = fmaf(wv, vh[3 * h + 2], a2);
+                }
+                float gte = s.G[row * GV + u];
+                if (w.vec_sigmoid) gte = sigmoidf_(gte);
+                float *o = s.V0 + row * VST + 3 * u;
+                o[0] = gte * a0; o[1] = gte * a1; o[2] = gte * a2;
+            }
+        }
+    }
+    lds_barrier();
+}
+
+// LayerNorm over the first S columns of every A-tile row (affine), in place.  (gvp.py:161)
+__device__ __forceinline__ void tile_layernorm(const GvpSmem &s, int S, const float *__restrict__ lw,
+                                               const float *__restrict__ lb, int tid) {
+    const int row = tid >> 2, q = tid & 3;
+    float *tr = s.A + row * SA_G;
+    float sum = 0.0f;
+    for (int c = q; c < S; c += 4) sum += tr[c];
+    sum += __shfl_xor(sum, 1);
+    sum += __shfl_xor(sum, 2);
+    const float mean = sum / (float)S;
+    float var = 0.0f;
+    for (int c = q; c < S; c += 4) {
+        const float d = tr[c] - mean;
+        var = fmaf(d, d, var);
+    }
+    var += __shfl_xor(var, 1);
+    var += __shfl_xor(var, 2);
+    const float rstd = 1.0f / sqrtf(var / (float)S + 1e-5f);
+    for (int c = q; c < S; c += 4) tr[c] = (tr[c] - mean) * rstd * lw[c] + lb[c];
+}
+
+// Vector half of GVPLayerNorm (gvp.py:163-165): v / (sqrt(mean_i max(|v_i|^2, 1e-8) + eps) + eps), in place on V0.
+__device__ __forceinline__ void tile_vecnorm(const GvpSmem &s, int tid) {
+    const int row = tid >> 2, q = tid & 3;
+    float *v = s.V0 + row * VST;
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float *p = v + 3 * (q + 4 * i);
+        acc += fmaxf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2], 1e-8f);
+    }
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    const float vn = sqrtf(acc * (1.0f / GV) + 1e-5f) + 1e-5f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float *p = v + 3 * (q + 4 * i);
+        p[0] /= vn; p[1] /= vn; p[2] /= vn;
+    }
+}
+
+// ---- encoders (dynamics_gvp.py:124-134, 161-169): out = LN(SiLU(W [h, t] + b)) --------------
+constexpr int GEMB_NODES = 4;
+__global__ __launch_bounds__(256) void k_gvp_embed(const float *__restrict__ in, int n, int fin,
+                                                   const float *__restrict__ W, const float *__restrict__ b,
+                                                   const float *__restrict__ lw, const float *__restrict__ lb,
+                                                   const float *__restrict__ t, const int *__restrict__ bidx, int S,
+                                                   float *__restrict__ out) {
+    __shared__ float s_in[GEMB_NODES][260];
+    __shared__ float s_red[GEMB_NODES][2][4];
+    const int node0 = blockIdx.x * GEMB_NODES, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < GEMB_NODES * (fin + 1); i += 256) {
+        const int j = i / (fin + 1), k = i - j * (fin + 1);
+        const int v = node0 + j;
+        s_in[j][k] = v < n ? (k < fin ? in[(size_t)v * fin + k] : t[bidx[v]]) : 0.0f;
+    }
+    __syncthreads();
+    float y[GEMB_NODES];
+    const bool on = tid < S;
+#pragma unroll
+    for (int j = 0; j < GEMB_NODES; ++j) y[j] = on ? b[tid] : 0.0f;
+    if (on)
+        for (int k = 0; k <= fin; ++k) {
+            const float wv = W[(size_t)tid * (fin + 1) + k];
+#pragma unroll
+            for (int j = 0; j < GEMB_NODES; ++j) y[j] = fmaf(wv, s_in[j][k], y[j]);
+        }
+#pragma unroll
+    for (int j = 0; j < GEMB_NODES; ++j) y[j] = on ? silu(y[j]) : 0.0f;
+    // LayerNorm over the S features of each node: two block reductions
+    float mean[GEMB_NODES], rstd[GEMB_NODES];
+#pragma unroll
+    for (int j = 0; j < GEMB_NODES; ++j) {
+        float v = y[j];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) s_red[j][0][wave] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < GEMB_NODES; ++j)
+        mean[j] = (s_red[j][0][0] + s_red[j][0][1] + s_red[j][0][2] + s_red[j][0][3]) / (float)S;
+#pragma unroll
+    for (int j = 0; j < GEMB_NODES; ++j) {
+        const float d = on ? y[j] - mean[j] : 0.0f;
+        float v = d * d;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) s_red[j][1][wave] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < GEMB_NODES; ++j) {
+        rstd[j] = 1.0f / sqrtf((s_red[j][1][0] + s_red[j][1][1] + s_red[j][1][2] + s_red[j][1][3]) / (float)S + 1e-5f);
+        const int v = node0 + j;
+        if (on && v < n) out[(size_t)v * S + tid] = (y[j] - mean[j]) * rstd[j] * lw[tid] + lb[tid];
+    }
+}
+
+// ---- source-node projection of the first message GVP ----------------------------------------
+// P[et][node][:] = W0[:, :S] s[node] + b0   (the h_src block of to_feats_out, gvp.py:545-549)
+__global__ __launch_bounds__(256, 2) void k_gvp_proj(GvpProjArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *A = smem;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int et = 0;
+#pragma unroll
+    for (int e = 1; e < 4; ++e)
+        if ((int)blockIdx.x >= a.tiles_first[e]) et = e;
+    const int node0 = ((int)blockIdx.x - a.tiles_first[et]) * TM;
+    const int n = a.n[et], S = a.S;
+    const float *src = a.s[et];
+    const int chunks = S >> 2;
+    for (int rr = 0; rr < 16; ++rr) {
+        const int r = wave * 16 + rr, v = node0 + r;
+        for (int c = lane; c < chunks; c += 64) {
+            f32x4_ val = {0.f, 0.f, 0.f, 0.f};
+            if (v < n) val = reinterpret_cast<const f32x4_ *>(src + (size_t)v * S)[c];
+            *reinterpret_cast<f32x4_ *>(A + r * SA_G + 4 * c) = val;
+        }
+    }
+    lds_barrier();
+    f32x16 acc[2][2];
+    acc_zero(acc);
+    gemm_rows64_rt<SA_G>(A, a.wp[et], S >> 3, acc, wave, lane);
+    float *out = a.P[et];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int col = acc_col(nt, wave, lane);
+        if (col < S) {
+            const float bb = a.b[et][col];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int v = node0 + acc_row(mt, reg, lane);
+                    if (v < n) out[(size_t)v * S + col] = acc[mt][nt][reg] + bb;
+                }
+        }
+    }
+}
+
+// ---- fused edge kernel: geometry, message GVP chain, segmented sum ----------------------------
+__global__ __launch_bounds__(256) void k_gvp_edge(GvpEdgeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const GvpSmem s = gvp_smem(smem);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int S = a.S;
+
+    const int T = a.meta[8];
+    const int chunk = (T + 7) >> 3;
+    const int bi = blockIdx.x >> 3;
+    if (bi >= chunk) return;
+    const int tile = (blockIdx.x & 7) * chunk + bi;
+    if (tile >= T) return;
+    int et = 0;
+#pragma unroll
+    for (int e = 1; e < 4; ++e)
+        if (tile >= a.meta[4 + e]) et = e;
+    const int tile_in_et = tile - a.meta[4 + et];
+    const int e0 = tile_in_et * TM;
+    const int ne = min(TM, a.meta[et] - e0);
+    const int snt = (et == 1 || et == 3) ? 1 : 0, dnt = (et >= 2) ? 1 : 0;      // ll, kl, lk, kk
+    const int *__restrict__ esrc = a.src[et];
+    const int *__restrict__ edst = a.dst[et];
+
+    // phase 0: endpoints, unit difference vector, rbf embedding (gvp.py:474-480, 26-41)
+    if (tid < TM) {
+        const int e = e0 + min(tid, ne - 1);
+        const int u = esrc[e], v = edst[e];
+        s.src[tid] = u;
+        s.dst[tid] = v;
+        const float *xs = a.x[snt] + (size_t)u * 3, *xd = a.x[dnt] + (size_t)v * 3;
+        const float dx = xs[0] - xd[0], dy = xs[1] - xd[1], dz = xs[2] - xd[2];
+        const float dij = sqrtf(fmaxf(dx * dx + dy * dy + dz * dz, 1e-8f)) + 1e-8f;
+        float *v0 = s.V0 + tid * VST;
+        v0[0] = dx / dij; v0[1] = dy / dij; v0[2] = dz / dij;
+        const float sigma = a.rbf_dmax / 16.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float mu = a.rbf_dmax * (float)i / 15.0f;
+            const float zz = (dij - mu) / sigma;
+            s.A[tid * SA_G + i] = expf(-zz * zz);
+        }
+        const int vprev = tid > 0 ? edst[e0 + min(tid - 1, ne - 1)] : (e0 > 0 ? edst[e0 - 1] : -1);
+        const int vnext = tid + 1 < ne ? edst[e0 + tid + 1] : -2;
+        const unsigned long long ends = __ballot(tid < ne && vnext != v);
+        if (tid == 0) {
+            s.misc[0] = (vprev == v) ? 1 : 0;
+            s.misc[2] = (int)(ends & 0xffffffffu);
+            s.misc[3] = (int)(ends >> 32);
+        }
+    }
+    lds_barrier();
+    {   // source vectors: 48 floats per edge, 4 threads x 3 float4
+        const int row = tid >> 2, q = tid & 3;
+        const f32x4_ *vs = reinterpret_cast<const f32x4_ *>(a.v[snt] + (size_t)s.src[row] * 48);
+        float *o = s.V0 + row * VST + 3;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const f32x4_ val = vs[q * 3 + i];
+            o[(q * 3 + i) * 4 + 0] = val[0]; o[(q * 3 + i) * 4 + 1] = val[1];
+            o[(q * 3 + i) * 4 + 2] = val[2]; o[(q * 3 + i) * 4 + 3] = val[3];
+        }
+    }
+    lds_barrier();
+
+    for (int k = 0; k < a.n_gvps; ++k)
+        gvp_stage(s, a.g[et][k], k == 0 ? a.Psrc[et] : nullptr, s.src, S, tid);
+
+    // segmented sums over dst: scalars (thread = column), then the 48 vector floats
+    const int first_is_cont = s.misc[0];
+    const unsigned long long endmask =
+        ((unsigned long long)(unsigned)s.misc[3] << 32) | (unsigned long long)(unsigned)s.misc[2];
+    if (tid < S) {
+        float *smain = a.ms_main[et], *scont = a.ms_cont[et] + (size_t)tile_in_et * S;
+        float run = 0.0f;
+        int piece = 0;
+        for (int r = 0; r < ne; ++r) {
+            run += s.A[r * SA_G + tid];
+            if ((endmask >> r) & 1ull) {
+                float *out = (piece == 0 && first_is_cont) ? scont : smain + (size_t)s.dst[r] * S;
+                out[tid] = run;
+                run = 0.0f;
+                ++piece;
+            }
+        }
+    }
+    if (tid < 48) {
+        float *vmain = a.mv_main[et], *vcont = a.mv_cont[et] + (size_t)tile_in_et * 48;
+        float run = 0.0f;
+        int piece = 0;
+        for (int r = 0; r < ne; ++r) {
+            run += s.V0[r * VST + tid];
+            if ((endmask >> r) & 1ull) {
+                float *out = (piece == 0 && first_is_cont) ? vcont : vmain + (size_t)s.dst[r] * 48;
+                out[tid] = run;
+                run = 0.0f;
+                ++piece;
+            }
+        }
+    }
+}
+
+// ---- node update (gvp.py:499-536) ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gvp_node(GvpNodePair p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const GvpSmem s = gvp_smem(smem);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int which = (int)blockIdx.x >= p.tiles0 ? 1 : 0;
+    const GvpNodeArgs &a = p.nt[which];
+    const int node0 = ((int)blockIdx.x - (which ? p.tiles0 : 0)) * TM;
+    const int S = a.S, chunks = S >> 2;
+
+    // s + msg / norm -> A tile; v + msg_v / norm -> V0   (aggregation: per-etype sum or mean, cross-etype sum)
+    for (int rr = 0; rr < 16; ++rr) {
+        const int r = wave * 16 + rr, v = node0 + r;
+        float norm = a.norm_const;
+        if (v < a.n && a.z) norm = a.z[a.bidx[v]];
+        for (int c = lane; c < chunks; c += 64) {
+            f32x4_ val = {0.f, 0.f, 0.f, 0.f};
+            if (v < a.n) {
+                f32x4_ msg = {0.f, 0.f, 0.f, 0.f};
+                for (int i = 0; i < a.n_in; ++i) {
+                    const int lo = a.rowptr[i][v], hi = a.rowptr[i][v + 1];
+                    if (hi > lo) {
+                        f32x4_ m = reinterpret_cast<const f32x4_ *>(a.ms_main[i] + (size_t)v * S)[c];
+                        for (int t = lo / TM + 1; t <= (hi - 1) / TM; ++t)
+                            m += reinterpret_cast<const f32x4_ *>(a.ms_cont[i] + (size_t)t * S)[c];
+                        if (a.mean) m /= (float)(hi - lo);
+                        msg += m;
+                    }
+                }
+                val = reinterpret_cast<const f32x4_ *>(a.s + (size_t)v * S)[c] + msg / norm;
+            }
+            *reinterpret_cast<f32x4_ *>(s.A + r * SA_G + 4 * c) = val;
+        }
+        if (lane < 48) {
+            float val = 0.0f;
+            if (v < a.n) {
+                float msg = 0.0f;
+                for (int i = 0; i < a.n_in; ++i) {
+                    const int lo = a.rowptr[i][v], hi = a.rowptr[i][v + 1];
+                    if (hi > lo) {
+                        float m = a.mv_main[i][(size_t)v * 48 + lane];
+                        for (int t = lo / TM + 1; t <= (hi - 1) / TM; ++t) m += a.mv_cont[i][(size_t)t * 48 + lane];
+                        if (a.mean) m /= (float)(hi - lo);
+                        msg += m;
+                    }
+                }
+                val = a.v[(size_t)v * 48 + lane] + msg / norm;
+            }
+            s.V0[r * VST + lane] = val;
+        }
+    }
+    lds_barrier();
+    // message layer norm (gvp.py:519-521)
+    tile_layernorm(s, S, a.ln1_w, a.ln1_b, tid);
+    tile_vecnorm(s, tid);
+    lds_barrier();
+    // stash the residual of the update block: scalars to HBM scratch, vectors to V2
+    for (int rr = 0; rr < 16; ++rr) {
+        const int r = wave * 16 + rr, v = node0 + r;
+        if (v < a.n)
+            for (int c = lane; c < chunks; c += 64)
+                reinterpret_cast<f32x4_ *>(a.s_tmp + (size_t)v * S)[c] = *reinterpret_cast<const f32x4_ *>(s.A + r * SA_G + 4 * c);
+        if (lane < 48) s.V2[r * VST + lane] = s.V0[r * VST + lane];
+    }
+    lds_barrier();
+    for (int k = 0; k < a.n_gvps; ++k) gvp_stage(s, a.g[k], nullptr, nullptr, 0, tid);
+    // residual + update layer norm (gvp.py:524-532)
+    for (int rr = 0; rr < 16; ++rr) {
+        const int r = wave * 16 + rr, v = node0 + r;
+        for (int c = lane; c < chunks; c += 64) {
+            f32x4_ res = {0.f, 0.f, 0.f, 0.f};
+            if (v < a.n) res = reinterpret_cast<const f32x4_ *>(a.s_tmp + (size_t)v * S)[c];
+            *reinterpret_cast<f32x4_ *>(s.A + r * SA_G + 4 * c) += res;
+        }
+        if (lane < 48) s.V0[r * VST + lane] += s.V2[r * VST + lane];
+    }
+    lds_barrier();
+    tile_layernorm(s, S, a.ln2_w, a.ln2_b, tid);
+    tile_vecnorm(s, tid);
+    lds_barrier();
+    for (int rr = 0; rr < 16; ++rr) {
+        const int r = wave * 16 + rr, v = node0 + r;
+        if (v >= a.n) continue;
+        for (int c = lane; c < chunks; c += 64)
+            reinterpret_cast<f32x4_ *>(a.s + (size_t)v * S)[c] = *reinterpret_cast<const f32x4_ *>(s.A + r * SA_G + 4 * c);
+        if (lane < 48) a.v[(size_t)v * 48 + lane] = s.V0[r * VST + lane];
+    }
+}
+
+// ---- noise prediction block (dynamics_gvp.py:38-44) ----------------------------------------------
+__global__ __launch_bounds__(256) void k_gvp_noise(GvpNoiseArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const GvpSmem s = gvp_smem(smem);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int node0 = blockIdx.x * TM;
+    const int S = a.S, chunks = S >> 2;
+    for (int rr = 0; rr < 16; ++rr) {
+        const int r = wave * 16 + rr, v = node0 + r;
+        for (int c = lane; c < chunks; c += 64) {
+            f32x4_ val = {0.f, 0.f, 0.f, 0.f};
+            if (v < a.n) val = reinterpret_cast<const f32x4_ *>(a.s + (size_t)v * S)[c];
+            *reinterpret_cast<f32x4_ *>(s.A + r * SA_G + 4 * c) = val;
+        }
+        if (lane < 48) s.V0[r * VST + lane] = v < a.n ? a.v[(size_t)v * 48 + lane] : 0.0f;
+    }
+    lds_barrier();
+    for (int k = 0; k < a.n_gvps; ++k) gvp_stage(s, a.g[k], nullptr, nullptr, 0, tid);
+    // eps_h = W_out s (64 -> F), eps_x = the single output vector
+    const int row = tid >> 2, q = tid & 3, v = node0 + row;
+    if (v < a.n) {
+        for (int f = q; f < a.F; f += 4) {
+            float acc = a.bout[f];
+            for (int k = 0; k < 64; ++k) acc = fmaf(a.Wout[f * 64 + k], s.A[row * SA_G + k], acc);
+            a.eps_h[(size_t)v * a.F + f] = acc;
+        }
+        if (q < 3) a.eps_x[(size_t)v * 3 + q] = s.V0[row * VST + q];
+    }
+}
+
+// ---- launchers ---------------------------------------------------------------------------------------
+static bool g_gvp_attr = false;
+
+kpd_status gvp_kernels_init() {
+    if (g_gvp_attr) return KPD_OK;
+    KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gvp_proj), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                TM * SA_G * 4));
+    KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gvp_edge), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                GVP_LDS_BYTES));
+    KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gvp_node), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                GVP_LDS_BYTES));
+    KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gvp_noise), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                GVP_LDS_BYTES));
+    g_gvp_attr = true;
+    return KPD_OK;
+}
+
+kpd_status launch_gvp_embed(const float *in, int n, int fin, const float *W, const float *b, const float *ln_w,
+                            const float *ln_b, const float *t, const int *bidx, int S, float *out, hipStream_t st) {
+    if (n == 0) return KPD_OK;
+    KPD_REQUIRE(fin + 1 <= 260 && S <= 256, KPD_ERR_INVALID, "gvp embed: fin=%d S=%d", fin, S);
+    hipLaunchKernelGGL(k_gvp_embed, dim3(cdiv(n, GEMB_NODES)), dim3(256), 0, st, in, n, fin, W, b, ln_w, ln_b, t, bidx, S, out);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+kpd_status launch_gvp_proj(const GvpProjArgs &a, hipStream_t st) {
+    if (a.tiles_first[4] == 0) return KPD_OK;
+    hipLaunchKernelGGL(k_gvp_proj, dim3(a.tiles_first[4]), dim3(256), TM * SA_G * 4, st, a);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+kpd_status launch_gvp_edge(const GvpEdgeArgs &a, int tile_cap, hipStream_t st) {
+    if (tile_cap == 0) return KPD_OK;
+    hipLaunchKernelGGL(k_gvp_edge, dim3(8 * cdiv(tile_cap, 8)), dim3(256), GVP_LDS_BYTES, st, a);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+kpd_status launch_gvp_node(const GvpNodePair &p, hipStream_t st) {
+    const int tiles = p.tiles0 + cdiv(p.nt[1].n, TM);
+    if (tiles == 0) return KPD_OK;
+    hipLaunchKernelGGL(k_gvp_node, dim3(tiles), dim3(256), GVP_LDS_BYTES, st, p);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+kpd_status launch_gvp_noise(const GvpNoiseArgs &a, hipStream_t st) {
+    if (a.n == 0) return KPD_OK;
+    hipLaunchKernelGGL(k_gvp_noise, dim3(cdiv(a.n, TM)), dim3(256), GVP_LDS_BYTES, st, a);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+}  // namespace kpd

@@ -54,11 +54,13 @@ __device__ __forceinline__ void acc_zero(f32x16 (&acc)[2][2]) {
     B0 = bp[(G) * 512];                                               \
     B1 = bp[(G) * 512 + 1];
 
-__device__ __forceinline__ void gemm_rows64(const float *__restrict__ A, const float *__restrict__ Wp,
-                                            f32x16 (&acc)[2][2], int wave, int lane) {
+// NG_ = k-groups of 8 (K padded to 8 NG_), SA_ = LDS row stride of the A tile in floats.
+template <int NG_, int SA_>
+__device__ __forceinline__ void gemm_rows64_t(const float *__restrict__ A, const float *__restrict__ Wp,
+                                              f32x16 (&acc)[2][2], int wave, int lane) {
     const int r = lane & 31, h = lane >> 5;
-    const float *a0p = A + r * SA + 4 * h;
-    const float *a1p = A + (32 + r) * SA + 4 * h;
+    const float *a0p = A + r * SA_ + 4 * h;
+    const float *a1p = A + (32 + r) * SA_ + 4 * h;
     const f32x4 *bp = reinterpret_cast<const f32x4 *>(Wp) + (wave * 64 + lane) * 2;
     // Two operand register sets X / Y alternate (no register rotation: on gfx950 the f32 MFMA and
     // ordinary VALU work do not overlap, so every VALU instruction in this loop is lost MFMA time).
@@ -67,22 +69,69 @@ __device__ __forceinline__ void gemm_rows64(const float *__restrict__ A, const f
     // pin that order; without them the scheduler sinks the loads next to their use.
     f32x4 xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1;
     KPD_GEMM_LOAD(xa0, xa1, xb0, xb1, 0)
-    KPD_GEMM_LOAD(ya0, ya1, yb0, yb1, 1)
-    static_assert(NG % 2 == 1, "loop below assumes an odd number of k-groups");
+    if (NG_ > 1) {
+        KPD_GEMM_LOAD(ya0, ya1, yb0, yb1, 1)
+    }
+    constexpr int PAIRS = NG_ / 2;          // full (X, Y) pairs
 #pragma unroll 1
-    for (int g = 0; g < NG - 1; g += 2) {
+    for (int p = 0; p < PAIRS; ++p) {
+        const int g = 2 * p;
         __builtin_amdgcn_sched_barrier(0);
         KPD_GEMM_STEP(xa0, xa1, xb0, xb1)
         __builtin_amdgcn_sched_barrier(0);
-        KPD_GEMM_LOAD(xa0, xa1, xb0, xb1, g + 2)
+        const int g2 = g + 2 < NG_ ? g + 2 : NG_ - 1;
+        KPD_GEMM_LOAD(xa0, xa1, xb0, xb1, g2)
         __builtin_amdgcn_sched_barrier(0);
         KPD_GEMM_STEP(ya0, ya1, yb0, yb1)
         __builtin_amdgcn_sched_barrier(0);
-        const int g3 = g + 3 < NG ? g + 3 : NG - 1;
+        const int g3 = g + 3 < NG_ ? g + 3 : NG_ - 1;
         KPD_GEMM_LOAD(ya0, ya1, yb0, yb1, g3)
     }
-    __builtin_amdgcn_sched_barrier(0);
-    KPD_GEMM_STEP(xa0, xa1, xb0, xb1)
+    if (NG_ & 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        KPD_GEMM_STEP(xa0, xa1, xb0, xb1)
+    }
+}
+
+__device__ __forceinline__ void gemm_rows64(const float *__restrict__ A, const float *__restrict__ Wp,
+                                            f32x16 (&acc)[2][2], int wave, int lane) {
+    gemm_rows64_t<NG, SA>(A, Wp, acc, wave, lane);
+}
+
+// Same pipeline with a run-time number of k-groups (the GVP blocks use K = 40 ... 272).
+template <int SA_>
+__device__ __forceinline__ void gemm_rows64_rt(const float *__restrict__ A, const float *__restrict__ Wp, int ng,
+                                               f32x16 (&acc)[2][2], int wave, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+    const float *a0p = A + r * SA_ + 4 * h;
+    const float *a1p = A + (32 + r) * SA_ + 4 * h;
+    const f32x4 *bp = reinterpret_cast<const f32x4 *>(Wp) + (wave * 64 + lane) * 2;
+    f32x4 xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1;
+    const int last = ng - 1;
+    KPD_GEMM_LOAD(xa0, xa1, xb0, xb1, 0)
+    {
+        const int g1 = 1 < ng ? 1 : last;
+        KPD_GEMM_LOAD(ya0, ya1, yb0, yb1, g1)
+    }
+    const int pairs = ng >> 1;
+#pragma unroll 1
+    for (int p = 0; p < pairs; ++p) {
+        const int g = 2 * p;
+        __builtin_amdgcn_sched_barrier(0);
+        KPD_GEMM_STEP(xa0, xa1, xb0, xb1)
+        __builtin_amdgcn_sched_barrier(0);
+        const int g2 = g + 2 < ng ? g + 2 : last;
+        KPD_GEMM_LOAD(xa0, xa1, xb0, xb1, g2)
+        __builtin_amdgcn_sched_barrier(0);
+        KPD_GEMM_STEP(ya0, ya1, yb0, yb1)
+        __builtin_amdgcn_sched_barrier(0);
+        const int g3 = g + 3 < ng ? g + 3 : last;
+        KPD_GEMM_LOAD(ya0, ya1, yb0, yb1, g3)
+    }
+    if (ng & 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        KPD_GEMM_STEP(xa0, xa1, xb0, xb1)
+    }
 }
 
 // Output column 256 (the "+1" of hidden_nf + 1): dot of every A row with wx[k] = W[256][k] on the

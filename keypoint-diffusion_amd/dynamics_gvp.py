@@ -77,5 +77,31 @@ class LigRecDynamicsGVP(nn.Module):
         self._engine = None
         self._engine_key = None
 
+    def _weights_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def engine(self) -> 'hip.GvpEngine':
+        """(Re)build the device engine when weights were replaced or modified in place."""
+        key = self._weights_key()
+        if self._engine is None or key != self._engine_key:
+            if self.ll_k != 0:
+                raise NotImplementedError('ll_k > 0 (kNN lig-lig graph) is not implemented in the HIP path')
+            if self.kl_k <= 0:
+                raise NotImplementedError('kl_k = 0 (radius keypoint->ligand graph) is not implemented in the HIP path')
+            eng = hip.GvpEngine(self.n_lig_scalars, self.n_kp_scalars, self.vector_size, self.n_convs,
+                                self.n_hidden_scalars, self.update_kp, self.message_norm, self.ll_k, self.kl_k,
+                                self.graph_cutoffs['ll'], self.graph_cutoffs.get('kl', 0.0), self.n_message_gvps,
+                                self.n_update_gvps, self.n_noise_gvps)
+            eng.load_state_dict(self.state_dict())
+            self._engine, self._engine_key = eng, key
+        return self._engine
+
     def forward(self, g: HeteroBatch, timestep: torch.Tensor, batch_idxs: Dict[str, torch.Tensor] = None):
-        raise NotImplementedError('the GVP denoiser HIP path is not built yet in this revision')
+        """Predicted noise (eps_h [N_lig, n_lig_scalars], eps_x [N_lig, 3]) -- eval mode (dropout is the identity)."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError('the HIP denoiser is forward-only; call it under torch.no_grad()')
+        if self.training:
+            raise NotImplementedError('dropout is not implemented: call model.eval() (every sampling path does)')
+        pb = g.prepared()
+        lig, kp = g.nodes['lig'].data, g.nodes['kp'].data
+        return self.engine().forward(pb, lig['x_0'], lig['h_0'], kp['x_0'], kp['h_0'], kp['v_0'], timestep)

@@ -40,6 +40,14 @@ class KpdEgnnConfig(C.Structure):
                 ('ll_cutoff', C.c_float), ('kl_cutoff', C.c_float), ('coords_range', C.c_float)]
 
 
+class KpdGvpConfig(C.Structure):
+    _fields_ = [('n_lig_scalars', C.c_int32), ('n_kp_scalars', C.c_int32), ('vector_size', C.c_int32),
+                ('n_convs', C.c_int32), ('n_hidden_scalars', C.c_int32), ('update_kp', C.c_int32),
+                ('message_norm_mode', C.c_int32), ('message_norm', C.c_float), ('ll_k', C.c_int32), ('kl_k', C.c_int32),
+                ('ll_cutoff', C.c_float), ('kl_cutoff', C.c_float), ('n_message_gvps', C.c_int32),
+                ('n_update_gvps', C.c_int32), ('n_noise_gvps', C.c_int32)]
+
+
 class KpdError(RuntimeError):
     pass
 
@@ -68,6 +76,14 @@ def lib():
     L.kpd_egnn_last_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]
     L.kpd_egnn_profile.argtypes = [C.c_void_p, C.c_int32]
     L.kpd_egnn_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    L.kpd_gvp_create.argtypes = [C.POINTER(KpdGvpConfig), C.POINTER(C.c_void_p)]
+    L.kpd_gvp_destroy.argtypes = [C.c_void_p]
+    L.kpd_gvp_destroy.restype = None
+    L.kpd_gvp_load_weight.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_void_p]
+    L.kpd_gvp_commit.argtypes = [C.c_void_p]
+    L.kpd_gvp_reserve.argtypes = [C.c_void_p] + [C.c_int32] * 6
+    L.kpd_gvp_forward.argtypes = [C.c_void_p, C.POINTER(KpdBatch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.kpd_gvp_debug_state.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p]
     L.kpd_build_lig_graph.argtypes = [C.POINTER(KpdBatch), C.c_float, C.c_int32, C.POINTER(KpdLigGraph), C.c_void_p]
     L.kpd_sample_update.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 8 + [C.c_int32, C.c_void_p]
     _lib = L
@@ -80,6 +96,8 @@ EXPORTS = [
     'kpd_egnn_create', 'kpd_egnn_destroy', 'kpd_egnn_load_weight', 'kpd_egnn_commit', 'kpd_egnn_reserve',
     'kpd_egnn_forward', 'kpd_egnn_debug_state', 'kpd_egnn_last_counts', 'kpd_egnn_profile',
     'kpd_egnn_profile_read', 'kpd_sample_update',
+    'kpd_gvp_create', 'kpd_gvp_destroy', 'kpd_gvp_load_weight', 'kpd_gvp_commit', 'kpd_gvp_reserve',
+    'kpd_gvp_forward', 'kpd_gvp_debug_state',
 ]
 
 
@@ -222,6 +240,70 @@ class EgnnEngine:
         arr = (C.c_int32 * 8)()
         check(lib().kpd_egnn_last_counts(self._h, arr, _stream()))
         return dict(E_ll=arr[0], E_kl=arr[1], E_lk=arr[2], E_kk=arr[3], tiles=arr[4])
+
+
+class GvpEngine:
+    """Owns one kpd_gvp handle: packed weights + workspace for LigRecDynamicsGVP.forward."""
+
+    def __init__(self, n_lig_scalars, n_kp_scalars, vector_size, n_convs, n_hidden_scalars, update_kp, message_norm,
+                 ll_k, kl_k, ll_cutoff, kl_cutoff, n_message_gvps, n_update_gvps, n_noise_gvps):
+        if message_norm == 'mean':
+            mode, val = 1, 1.0
+        elif message_norm == 0:
+            mode, val = 2, 0.0
+        else:
+            mode, val = 0, float(message_norm)
+        self.cfg = KpdGvpConfig(int(n_lig_scalars), int(n_kp_scalars), int(vector_size), int(n_convs),
+                                int(n_hidden_scalars), int(bool(update_kp)), mode, val, int(ll_k), int(kl_k),
+                                float(ll_cutoff), float(kl_cutoff), int(n_message_gvps), int(n_update_gvps),
+                                int(n_noise_gvps))
+        self.n_lig_scalars = int(n_lig_scalars)
+        self._h = C.c_void_p()
+        check(lib().kpd_gvp_create(C.byref(self.cfg), C.byref(self._h)))
+        self._reserved = None
+
+    def __del__(self):
+        if getattr(self, '_h', None) and _lib is not None:
+            _lib.kpd_gvp_destroy(self._h)
+            self._h = None
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+        L = lib()
+        st = _stream()
+        keep = []
+        for name, t in sd.items():
+            if t.numel() == 0:                     # dropout.vector_dropout.dummy_param
+                continue
+            t = _dev_f32(t.detach(), name)
+            keep.append(t)
+            shape = (C.c_int64 * t.dim())(*t.shape)
+            check(L.kpd_gvp_load_weight(self._h, name.encode(), t.data_ptr(), shape, t.dim(), st))
+        torch.cuda.current_stream().synchronize()
+        check(L.kpd_gvp_commit(self._h))
+
+    def reserve(self, pb: PreparedBatch):
+        key = (pb.B, pb.n_lig, pb.n_kp, pb.n_kk, pb.max_lig, pb.max_kp)
+        if self._reserved is not None and all(a <= b for a, b in zip(key, self._reserved)):
+            return
+        torch.cuda.synchronize()
+        check(lib().kpd_gvp_reserve(self._h, *key))
+        self._reserved = key if self._reserved is None else tuple(max(a, b) for a, b in zip(key, self._reserved))
+
+    def forward(self, pb: PreparedBatch, lig_x, lig_h, kp_x, kp_h, kp_v, t):
+        self.reserve(pb)
+        lig_x, lig_h = _dev_f32(lig_x, 'lig x_0'), _dev_f32(lig_h, 'lig h_0')
+        kp_x, kp_h, kp_v = _dev_f32(kp_x, 'kp x_0'), _dev_f32(kp_h, 'kp h_0'), _dev_f32(kp_v, 'kp v_0')
+        t = _dev_f32(t, 'timestep')
+        eps_h = torch.empty(pb.n_lig, self.n_lig_scalars, device=lig_x.device)
+        eps_x = torch.empty(pb.n_lig, 3, device=lig_x.device)
+        bt = pb.struct(lig_x, lig_h, kp_x, kp_h, kp_v)
+        check(lib().kpd_gvp_forward(self._h, C.byref(bt), t.data_ptr(), eps_h.data_ptr(), eps_x.data_ptr(), _stream()))
+        return eps_h, eps_x
+
+    def debug(self, what: str, n_floats: int = 0, device=None) -> Optional[torch.Tensor]:
+        out = torch.empty(max(n_floats, 1), device=device or 'cuda')
+        check(lib().kpd_gvp_debug_state(self._h, what.encode(), out.data_ptr(), n_floats, _stream()))
+        return out if n_floats else None
 
 
 def sample_update(pb: PreparedBatch, atom_nf, lig_x, lig_h, kp_x, eps_x, eps_h, noise_x, noise_h, coef):

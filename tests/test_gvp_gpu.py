@@ -1,0 +1,86 @@
+"""GPU parity of the HIP GVP denoiser (through the C ABI) against the CPU oracle."""
+import pytest
+import torch
+
+from keypoint_diffusion_amd import graph as G
+from keypoint_diffusion_amd import synth
+from keypoint_diffusion_amd.dynamics_gvp import LigRecDynamicsGVP
+from oracle import gvp as ogvp
+
+from . import util
+from .golden.make_golden_cfgs import GVP_CFGS
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+CUT = util.CUTOFFS_ALL_ATOM
+
+GVP_40KP = dict(vector_size=16, n_convs=6, n_hidden_scalars=256, message_norm=10.0, update_kp=True, ll_k=0, kl_k=7,
+                n_message_gvps=3, n_update_gvps=2, n_noise_gvps=4, dropout=0.1)          # trained_models/gvp_40kp
+GVP_ALL_ATOM = dict(GVP_40KP, message_norm='mean')                                       # trained_models/gvp_all_atom
+
+
+def _run(cuda, cfg, n_rec, n_lig, n_kp_scalars=10, convs=None, seed=7, rand_v=True):
+    g = util.fixed_encode(util.make_batch(n_rec, n_lig, seed=31), n_vec=16)
+    gen = torch.Generator().manual_seed(3)
+    if rand_v:
+        g.nodes['kp'].data['v_0'] = 0.5 * torch.randn(g.num_nodes('kp'), 16, 3, generator=gen)
+    if n_kp_scalars != 10:
+        g.nodes['kp'].data['h_0'] = torch.randn(g.num_nodes('kp'), n_kp_scalars, generator=gen)
+    model = LigRecDynamicsGVP(10, n_kp_scalars, graph_cutoffs=CUT, **cfg)
+    synth.fill_state_dict_(model, seed)
+    model.eval()
+    B = g.batch_size
+    t = (torch.arange(B, dtype=torch.float32) + 1) / (B + 1)
+    ocfg = dict(cfg, graph_cutoffs=CUT)
+    if convs is not None:
+        ocfg['n_convs_run'] = convs
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    ref_h, ref_x = ogvp.gvp_dynamics_forward(sd, ocfg, util.to_obatch(g), t)
+    model = model.to(cuda)
+    gd = g.to(cuda)
+    with torch.no_grad():
+        eps_h, eps_x = model(gd, t.to(cuda), G.get_batch_idxs(gd))
+    torch.cuda.synchronize()
+    return (eps_h.cpu(), eps_x.cpu()), (ref_h, ref_x)
+
+
+@pytest.mark.parametrize('tag', list(GVP_CFGS))
+def test_gvp_small_configs(cuda, tag):
+    cfg = GVP_CFGS[tag]
+    (h, x), (rh, rx) = _run(cuda, cfg, [26, 19], [7, 10], n_kp_scalars=128 if tag == 'gvp_kp' else 10)
+    assert util.rel_err(h, rh) < TOL, util.rel_err(h, rh)
+    assert util.rel_err(x, rx) < TOL, util.rel_err(x, rx)
+
+
+def test_gvp_40kp_shape(cuda):
+    # 40 learned keypoints with 128 scalars + vectors, complete kk graph inside 8 A (C3 shape)
+    gs = []
+    for i, nl in enumerate([25, 12]):
+        gen = torch.Generator().manual_seed(50 + i)
+        kp_pos = torch.randn(40, 3, generator=gen) * 2.5
+        src, dst = synth.radius_graph_dense(kp_pos, 8.0)
+        g = G.heterograph({('kp', 'kk', 'kp'): (src, dst)}, {'rec': 0, 'kp': 40, 'lig': nl})
+        g.nodes['kp'].data['x_0'] = kp_pos
+        g.nodes['kp'].data['h_0'] = torch.randn(40, 128, generator=gen)
+        g.nodes['kp'].data['v_0'] = 0.5 * torch.randn(40, 16, 3, generator=gen)
+        lx = torch.randn(nl, 3, generator=gen)
+        g.nodes['lig'].data['x_0'] = lx - lx.mean(0, keepdim=True)
+        g.nodes['lig'].data['h_0'] = torch.randn(nl, 10, generator=gen)
+        g.nodes['rec'].data['x_0'] = torch.zeros(0, 3)
+        g.nodes['rec'].data['h_0'] = torch.zeros(0, 10)
+        gs.append(g)
+    g = G.batch(gs)
+    model = synth.fill_state_dict_(LigRecDynamicsGVP(10, 128, graph_cutoffs=CUT, **GVP_40KP), 5).eval()
+    t = torch.tensor([0.3, 0.8])
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    rh, rx = ogvp.gvp_dynamics_forward(sd, dict(GVP_40KP, graph_cutoffs=CUT), util.to_obatch(g), t)
+    model = model.to(cuda)
+    gd = g.to(cuda)
+    with torch.no_grad():
+        h, x = model(gd, t.to(cuda), None)
+    assert util.rel_err(h.cpu(), rh) < TOL and util.rel_err(x.cpu(), rx) < TOL
+
+
+def test_gvp_all_atom_ragged(cuda):
+    (h, x), (rh, rx) = _run(cuda, GVP_ALL_ATOM, [150, 420, 64], [15, 35, 3], rand_v=False)
+    assert util.rel_err(h, rh) < TOL and util.rel_err(x, rx) < TOL
