@@ -1,0 +1,79 @@
+"""GPU tests of the diffusion wrapper: one reverse step against the oracle (noise injected), and the
+public sampling entry points end to end."""
+import pytest
+import torch
+
+from keypoint_diffusion_amd import graph as G
+from keypoint_diffusion_amd import synth
+from keypoint_diffusion_amd.ligand_diffuser import KeypointDiffusion, LigandDiffuser
+from oracle import diffusion as odiff
+from oracle import egnn as oegnn
+from oracle import gvp as ogvp
+
+from . import util
+from .test_gvp_gpu import GVP_ALL_ATOM
+
+pytestmark = pytest.mark.gpu
+CUT = util.CUTOFFS_ALL_ATOM
+
+
+def _model(arch, T=50):
+    dyn = util.EGNN_C2 if arch == 'egnn' else dict(GVP_ALL_ATOM, n_convs=3)
+    m = KeypointDiffusion(10, 10, None, n_timesteps=T, architecture=arch, rec_encoder_type='fixed',
+                          graph_config=dict(n_keypoints=20, graph_cutoffs=CUT), dynamics_config=dyn,
+                          rec_encoder_config={'vector_size': 16}, precision=1e-5)
+    synth.fill_state_dict_(m, 13)
+    return m.eval()
+
+
+@pytest.mark.parametrize('arch', ['egnn', 'gvp'])
+def test_reverse_step_matches_oracle(cuda, arch):
+    assert LigandDiffuser is KeypointDiffusion
+    T = 50
+    model = _model(arch, T)
+    gs = synth.synth_complexes([90, 140], [11, 17], 20, CUT, seed=3)
+    g = model.encode_receptors(G.batch(gs))
+    ob = util.to_obatch(g)
+    s = torch.tensor([20.0, 31.0]) / T
+    t = s + 1.0 / T
+    gen = torch.Generator().manual_seed(1)
+    nx, nh = torch.randn(ob.x['lig'].shape, generator=gen), torch.randn(ob.h['lig'].shape, generator=gen)
+    sd = {k[len('dynamics.'):]: v.clone() for k, v in model.state_dict().items() if k.startswith('dynamics.')}
+    if arch == 'egnn':
+        eh, ex = oegnn.egnn_dynamics_forward(sd, dict(util.EGNN_C2, graph_cutoffs=CUT), ob, t)
+    else:
+        eh, ex = ogvp.gvp_dynamics_forward(sd, dict(GVP_ALL_ATOM, n_convs=3, graph_cutoffs=CUT), ob, t)
+    ref = odiff.sample_step(ob.clone(), eh, ex, s, t, odiff.gamma_table(T, 1e-5), T, nx, nh)
+    model = model.to(cuda)
+    gd = g.to(cuda)
+    with torch.no_grad():
+        model.sample_p_zs_given_zt(s.to(cuda), t.to(cuda), gd, G.get_batch_idxs(gd), noise=(nx.to(cuda), nh.to(cuda)))
+    torch.cuda.synchronize()
+    assert util.rel_err(gd.nodes['lig'].data['x_0'], ref.x['lig']) < 1e-4
+    assert util.rel_err(gd.nodes['lig'].data['h_0'], ref.h['lig']) < 1e-4
+    assert util.rel_err(gd.nodes['kp'].data['x_0'], ref.x['kp']) < 1e-5
+    # ligand COM is zero after the step (remove_com, ligand_diffuser.py:536)
+    com = G.readout_nodes(gd, 'x_0', op='mean', ntype='lig')
+    assert float(com.abs().max()) < 1e-5
+
+
+def test_sample_given_pocket_end_to_end(cuda):
+    model = _model('egnn', T=8).to(cuda)
+    pocket = synth.synth_complexes([70], [1], 20, CUT, seed=9)[0].to(cuda)
+    pocket.remove_nodes(pocket.nodes('lig'), ntype='lig')
+    pos, feat = model.sample_given_pocket(pocket, torch.tensor([6, 9, 9]), diff_batch_size=2)
+    assert [p.shape for p in pos] == [(6, 3), (9, 3), (9, 3)]
+    assert [f.shape for f in feat] == [(6, 10), (9, 10), (9, 10)]
+    assert all(torch.isfinite(p).all() and p.device.type == 'cpu' for p in pos)
+    # visualize=True returns one trajectory per ligand with T + 1 frames
+    fx, fh = model.sample_given_pocket(pocket, torch.tensor([5]), visualize=True)
+    assert len(fx) == 1 and len(fx[0]) == 9 and fx[0][0].shape == (5, 3)
+
+
+def test_forward_only_contract(cuda):
+    model = _model('egnn').to(cuda)
+    g = model.encode_receptors(G.batch(synth.synth_complexes([30], [5], 20, CUT))).to(cuda)
+    with pytest.raises(NotImplementedError):
+        model.dynamics(g, torch.tensor([0.5], device=cuda), None)          # grad enabled: backward not implemented
+    with pytest.raises(NotImplementedError):
+        model(g, None)
