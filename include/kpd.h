@@ -158,6 +158,60 @@ kpd_status kpd_gvp_debug_state(kpd_gvp *m, const char *what, float *out_dev, int
                                void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * GVP keypoint receptor encoder (once per pocket).  Replaces ReceptorEncoderGVP.forward
+ * (models/receptor_encoder_gvp.py:212-294): scalar embedding, rec-rec GVPEdgeConv stack
+ * (models/gvp.py:170-341), KeypointInitializer (:15-93), kNN rec->kp edges (update_rk_edges
+ * :297-321), rec-kp GVPEdgeConv stack, keypoint radius graph.  Fields mirror
+ * ReceptorEncoderGVP.__init__ (:99-114) + graph_cutoffs.
+ * ------------------------------------------------------------------------------------- */
+typedef struct kpd_recenc_config {
+    int32_t in_scalar_size, out_scalar_size;   /* out_scalar_size in {128, 256}            */
+    int32_t vector_size;                       /* must be 16                               */
+    int32_t n_rr_convs, n_rk_convs, n_message_gvps, n_update_gvps;
+    int32_t message_norm_mode;                 /* 0 constant, 1 'mean', 2 message_norm == 0 */
+    float message_norm;
+    int32_t k_closest;                         /* kNN rec->kp, 1..16 (kp_rad is not implemented) */
+    int32_t n_keypoints;
+    float rr_cutoff, rk_cutoff, kk_cutoff;     /* graph_cutoffs['rr'|'rk'|'kk'] (rbf D_max, kk radius) */
+} kpd_recenc_config;
+
+typedef struct kpd_rec_batch {
+    int32_t B, n_rec, max_rec;
+    const int32_t *rec_ptr;     /* [dev] [B+1]                                             */
+    const float *rec_x;         /* [dev] [n_rec,3]                                         */
+    const float *rec_h;         /* [dev] [n_rec,in_scalar_size]                            */
+    int32_t n_rr;
+    const int32_t *rr_src;      /* [dev] [n_rr] sorted by (dst, src)                       */
+    const int32_t *rr_dst;
+    const int32_t *rr_rowptr;   /* [dev] [n_rec+1]                                         */
+} kpd_rec_batch;
+
+typedef struct kpd_rec_out {
+    float *kp_x;                /* [dev] [B*K,3]    keypoint positions                     */
+    float *kp_h;                /* [dev] [B*K,S]    keypoint scalars                       */
+    float *kp_v;                /* [dev] [B*K,16,3] keypoint vectors                       */
+    int32_t *rk_src, *rk_dst;   /* [dev] [B*K*k_closest] rec->kp edges, kp-major           */
+    int32_t cap_kk;             /* capacity of kk_src / kk_dst (>= B*K*min(K-1,100))       */
+    int32_t *kk_src, *kk_dst;   /* [dev] kp-kp radius graph, dst-sorted                    */
+    int32_t *kk_per_graph;      /* [dev] [B]                                               */
+    int32_t *counts;            /* [dev] [2]: {E_kk, E_rk}                                 */
+} kpd_rec_out;
+
+typedef struct kpd_recenc kpd_recenc;
+
+kpd_status kpd_recenc_create(const kpd_recenc_config *cfg, kpd_recenc **out);
+void kpd_recenc_destroy(kpd_recenc *m);
+/* Reference state-dict names of the `rec_encoder` module, e.g.
+ * "rk_conv_layers.1.edge_message.0.to_feats_out.0.weight". */
+kpd_status kpd_recenc_load_weight(kpd_recenc *m, const char *name, const float *w_dev,
+                                  const int64_t *shape, int32_t ndim, void *stream);
+kpd_status kpd_recenc_commit(kpd_recenc *m);
+kpd_status kpd_recenc_reserve(kpd_recenc *m, int32_t max_B, int32_t max_n_rec, int32_t max_n_rr,
+                              int32_t max_rec_per_graph);
+kpd_status kpd_recenc_forward(kpd_recenc *m, const kpd_rec_batch *batch, const kpd_rec_out *out,
+                              void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Reverse-diffusion update around the denoiser.  Replaces the elementwise part of
  * KeypointDiffusion.sample_p_zs_given_zt (models/ligand_diffuser.py:515-536):
  *   z_s = z_t / alpha_ts - var_terms * eps + sigma * noise, then ligand-COM removal from

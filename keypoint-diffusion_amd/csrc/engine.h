@@ -7,6 +7,13 @@ namespace kpd {
 kpd_status launch_lig_graph(const kpd_batch *bt, float ll_cutoff, int kl_k, const kpd_lig_graph *g,
                             int *ll_deg_tmp, int *ll_off_tmp, int *kl_off_tmp, hipStream_t st);
 
+kpd_status launch_radius_graph(const float *x, const int *ptr, int B, int n_total, int max_per_graph, float r, int max_nn,
+                               int cap, int *src, int *dst, int *rowptr, int *per_graph, int *deg_tmp, int *off_tmp,
+                               const int *kl_off_for_counts, int *counts, hipStream_t st);
+kpd_status launch_knn_bipartite(const float *x, const int *x_ptr, int n_x, int max_x, const float *y, const int *y_ptr, int n_y,
+                                int max_y, int B, int k, int *off_tmp, int *xm_src, int *xm_dst, int *xm_rowptr, int *ym_src,
+                                int *ym_dst, int *ym_rowptr, hipStream_t st);
+
 // Grow-only device arena: one hipMalloc, carved with 256-B alignment, zero-filled.
 struct Arena {
     char *base = nullptr;
@@ -29,6 +36,8 @@ struct Arena {
 kpd_status pack_gemm_weight(const float *src, int n_out, int ld, int col0, int K, float *wp, float *wx, hipStream_t st);
 // General K (padded to 8 ng) and N <= 256 (no extra column): packed block of ng*2048 floats.
 kpd_status pack_gemm_weight_ng(const float *src, int n_out, int ld, int col0, int K, int ng, float *wp, hipStream_t st);
+kpd_status pack_gemm_weight_2ranges(const float *src, int n_out, int ld, int col0, int len0, int col1, int len1, int ng,
+                                    float *wp, hipStream_t st);
 kpd_status pack_gate_weight(const float *src, int vout, int K, float *dst, hipStream_t st);
 // dst[0..n_dst) = src[0..n_src) then zeros.
 kpd_status copy_pad(const float *src, int n_src, float *dst, int n_dst, hipStream_t st);

@@ -66,7 +66,7 @@ __global__ void k_scan_graph_counts(const int *__restrict__ per_graph, int B, in
     if (threadIdx.x == 0) {
         off[B] = s_carry;
         counts[0] = s_carry;
-        counts[1] = kl_off[B];
+        counts[1] = kl_off ? kl_off[B] : 0;
     }
 }
 
@@ -220,41 +220,66 @@ __global__ void k_kl_offsets(const int *__restrict__ lig_ptr, const int *__restr
 
 using namespace kpd;
 
-// Host-side launcher shared with the denoiser engines (declared in engine.h).
+// Host-side launchers shared by the engines (declared in engine.h).
 namespace kpd {
+
+// radius graph of one point set (torch_cluster.radius_graph): dst-sorted COO + CSR, per-graph counts
+kpd_status launch_radius_graph(const float *x, const int *ptr, int B, int n_total, int max_per_graph, float r, int max_nn,
+                               int cap, int *src, int *dst, int *rowptr, int *per_graph, int *deg_tmp, int *off_tmp,
+                               const int *kl_off_for_counts, int *counts, hipStream_t st) {
+    KPD_REQUIRE(max_per_graph >= 1 && max_per_graph <= 2048, KPD_ERR_INVALID, "radius graph: %d nodes per graph (max 2048)", max_per_graph);
+    const int threads = 256;
+    const float r2 = r * r;
+    size_t lds = (size_t)max_per_graph * 3 * sizeof(float);
+    hipLaunchKernelGGL(k_ll_count, dim3(B), dim3(threads), lds, st, x, ptr, r2, max_nn, deg_tmp, per_graph);
+    KPD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_scan_graph_counts, dim3(1), dim3(1024), 0, st, per_graph, B, off_tmp, kl_off_for_counts, counts);
+    KPD_LAUNCH_CHECK();
+    lds = (size_t)max_per_graph * (3 * sizeof(float) + sizeof(int));
+    hipLaunchKernelGGL(k_ll_fill, dim3(B), dim3(threads), lds, st, x, ptr, r2, max_nn, deg_tmp, off_tmp, n_total, cap, src, dst,
+                       rowptr);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+// for every y its k nearest x of the same graph (torch_cluster.knn): y-major list (src = x, dst = y) and the
+// same pairs x-major (src = y, dst = x), both with CSR row pointers
+kpd_status launch_knn_bipartite(const float *x, const int *x_ptr, int n_x, int max_x, const float *y, const int *y_ptr, int n_y,
+                                int max_y, int B, int k, int *off_tmp, int *xm_src, int *xm_dst, int *xm_rowptr, int *ym_src,
+                                int *ym_dst, int *ym_rowptr, hipStream_t st) {
+    KPD_REQUIRE(k >= 1 && k <= KL_KMAX, KPD_ERR_INVALID, "knn k=%d outside 1..%d", k, KL_KMAX);
+    hipLaunchKernelGGL(k_kl_offsets, dim3(1), dim3(64), 0, st, x_ptr, y_ptr, B, k, off_tmp);
+    KPD_LAUNCH_CHECK();
+    const int words = cdiv(max_y, 32);
+    const size_t lds = (size_t)max_x * (3 * sizeof(float) + (size_t)words * sizeof(unsigned) + sizeof(int)) + 16;
+    KPD_REQUIRE(lds <= 150 * 1024, KPD_ERR_INVALID, "knn needs %zu B of LDS (max_x=%d, max_y=%d)", lds, max_x, max_y);
+    static bool attr = false;
+    if (!attr) {
+        KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kl_build), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    150 * 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL(k_kl_build, dim3(B), dim3(256), lds, st, x, x_ptr, y, y_ptr, off_tmp, k, words, n_x, n_y, xm_src, xm_dst,
+                       xm_rowptr, ym_src, ym_dst, ym_rowptr);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
 kpd_status launch_lig_graph(const kpd_batch *bt, float ll_cutoff, int kl_k, const kpd_lig_graph *g,
                             int *ll_deg_tmp, int *ll_off_tmp, int *kl_off_tmp, hipStream_t st) {
     KPD_REQUIRE(kl_k >= 1 && kl_k <= KL_KMAX, KPD_ERR_INVALID, "kl_k=%d outside 1..%d", kl_k, KL_KMAX);
     KPD_REQUIRE(bt->max_lig >= 1 && bt->max_lig <= 1024, KPD_ERR_INVALID, "max_lig=%d outside 1..1024", bt->max_lig);
-    const int B = bt->B;
-    const int threads = 256;
-    const float r2 = ll_cutoff * ll_cutoff;
     KPD_REQUIRE(g->cap_kl >= bt->n_kp * kl_k, KPD_ERR_CAPACITY, "cap_kl=%d < n_kp*k=%d", g->cap_kl, bt->n_kp * kl_k);
     {
         const long need = (long)bt->n_lig * (bt->max_lig - 1 < 200 ? bt->max_lig - 1 : 200);
         KPD_REQUIRE(g->cap_ll >= need, KPD_ERR_CAPACITY, "cap_ll=%d < %ld", g->cap_ll, need);
     }
-    size_t lds = (size_t)bt->max_lig * 3 * sizeof(float);
-    hipLaunchKernelGGL(k_ll_count, dim3(B), dim3(threads), lds, st, bt->lig_x, bt->lig_ptr, r2, 200, ll_deg_tmp,
-                       g->ll_per_graph);
-    KPD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_kl_offsets, dim3(1), dim3(64), 0, st, bt->lig_ptr, bt->kp_ptr, B, kl_k, kl_off_tmp);
-    KPD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_scan_graph_counts, dim3(1), dim3(1024), 0, st, g->ll_per_graph, B, ll_off_tmp, kl_off_tmp,
-                       g->counts);
-    KPD_LAUNCH_CHECK();
-    lds = (size_t)bt->max_lig * (3 * sizeof(float) + sizeof(int));
-    hipLaunchKernelGGL(k_ll_fill, dim3(B), dim3(threads), lds, st, bt->lig_x, bt->lig_ptr, r2, 200, ll_deg_tmp,
-                       ll_off_tmp, bt->n_lig, g->cap_ll, g->ll_src, g->ll_dst, g->ll_rowptr);
-    KPD_LAUNCH_CHECK();
-    const int words = cdiv(bt->max_kp, 32);
-    lds = (size_t)bt->max_lig * (3 * sizeof(float) + (size_t)words * sizeof(unsigned) + sizeof(int)) + 16;
-    KPD_REQUIRE(lds <= 64 * 1024, KPD_ERR_INVALID, "kl build needs %zu B of LDS (max_lig=%d, max_kp=%d)", lds,
-                bt->max_lig, bt->max_kp);
-    hipLaunchKernelGGL(k_kl_build, dim3(B), dim3(threads), lds, st, bt->lig_x, bt->lig_ptr, bt->kp_x, bt->kp_ptr,
-                       kl_off_tmp, kl_k, words, bt->n_lig, bt->n_kp, g->kl_src, g->kl_dst, g->kl_rowptr, g->lk_src,
-                       g->lk_dst, g->lk_rowptr);
-    KPD_LAUNCH_CHECK();
-    return KPD_OK;
+    // kl first: its offsets table also yields E_kl for counts[1]
+    kpd_status s = launch_knn_bipartite(bt->lig_x, bt->lig_ptr, bt->n_lig, bt->max_lig, bt->kp_x, bt->kp_ptr, bt->n_kp, bt->max_kp,
+                                        bt->B, kl_k, kl_off_tmp, g->kl_src, g->kl_dst, g->kl_rowptr, g->lk_src, g->lk_dst,
+                                        g->lk_rowptr, st);
+    if (s != KPD_OK) return s;
+    return launch_radius_graph(bt->lig_x, bt->lig_ptr, bt->B, bt->n_lig, bt->max_lig, ll_cutoff, 200, g->cap_ll, g->ll_src,
+                               g->ll_dst, g->ll_rowptr, g->ll_per_graph, ll_deg_tmp, ll_off_tmp, kl_off_tmp, g->counts, st);
 }
 }  // namespace kpd

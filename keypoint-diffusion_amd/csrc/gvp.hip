@@ -9,7 +9,7 @@
 #include <vector>
 
 #include "egnn_kernels.h"
-#include "gvp_kernels.h"
+#include "gvp_host.h"
 
 using namespace kpd;
 
@@ -19,37 +19,6 @@ const int kSrcNtG[4] = {0, 1, 0, 1};     // ll, kl, lk, kk  (0 = lig, 1 = kp)
 const int kDstNtG[4] = {0, 0, 1, 1};
 const char *kCanon[4] = {"lig_ll_lig", "kp_kl_lig", "lig_lk_kp", "kp_kk_kp"};
 const char *kNtNameG[2] = {"lig", "kp"};
-
-// Host-side description of one GVP + its device buffers.
-struct HostGvp {
-    int vin = 0, h = 0, vout = 0, s_in = 0, sout = 0;   // s_in = scalar inputs of to_feats_out (without sh)
-    bool split_src = false;                             // first message GVP: h_src block handled by k_gvp_proj
-    int S = 0;                                          // width of the h_src block when split
-    float *Wh = nullptr, *Wu = nullptr, *wp = nullptr, *b = nullptr, *wg = nullptr, *bg = nullptr;
-    float *wproj = nullptr, *bproj = nullptr;           // split only
-    int ng = 0;
-    int vec_sigmoid = 1;
-    GvpW dev() const {
-        GvpW w;
-        w.Wh = Wh; w.Wu = Wu; w.wp = wp; w.b = b; w.wg = wg; w.bg = bg;
-        w.vin = vin; w.h = h; w.vout = vout;
-        w.n_s = split_src ? s_in - S : s_in;
-        w.sout = sout; w.ng = ng; w.vec_sigmoid = vec_sigmoid;
-        return w;
-    }
-};
-
-std::vector<std::string> split_dots(const std::string &s) {
-    std::vector<std::string> out;
-    size_t p = 0;
-    while (true) {
-        size_t q = s.find('.', p);
-        out.push_back(s.substr(p, q == std::string::npos ? q : q - p));
-        if (q == std::string::npos) break;
-        p = q + 1;
-    }
-    return out;
-}
 
 }  // namespace
 
@@ -80,31 +49,6 @@ struct kpd_gvp {
     int n_et(int conv) const { return (cfg.update_kp && conv != cfg.n_convs - 1) ? 4 : 2; }
 };
 
-#define KPD_TRY(expr)                  \
-    do {                               \
-        kpd_status s_ = (expr);        \
-        if (s_ != KPD_OK) return s_;   \
-    } while (0)
-
-static void alloc_gvp(Arena &A, HostGvp &g, std::set<std::string> &expected, const std::string &prefix) {
-    g.h = std::max(g.vin, g.vout);
-    const int k_edge = (g.split_src ? g.s_in - g.S : g.s_in) + g.h;
-    g.ng = (k_edge + 7) / 8;
-    g.Wh = A.take<float>(g.vin * g.h);
-    g.Wu = A.take<float>(g.h * g.vout);
-    g.wp = A.take<float>((size_t)g.ng * 2048);
-    g.b = A.take<float>(256);
-    g.wg = A.take<float>((size_t)(g.sout / 16) * 256);
-    g.bg = A.take<float>(16);
-    if (g.split_src) {
-        g.wproj = A.take<float>((size_t)(g.S / 8) * 2048);
-        g.bproj = A.take<float>(256);
-    }
-    for (const char *s : {".Wh", ".Wu", ".to_feats_out.0.weight", ".to_feats_out.0.bias", ".scalar_to_vector_gates.weight",
-                          ".scalar_to_vector_gates.bias"})
-        expected.insert(prefix + s);
-}
-
 extern "C" kpd_status kpd_gvp_create(const kpd_gvp_config *cfg, kpd_gvp **out) {
     KPD_REQUIRE(cfg && out, KPD_ERR_INVALID, "null argument");
     KPD_REQUIRE(cfg->vector_size == GV, KPD_ERR_INVALID, "vector_size=%d: the HIP path is built for 16", cfg->vector_size);
@@ -128,7 +72,7 @@ extern "C" kpd_status kpd_gvp_create(const kpd_gvp_config *cfg, kpd_gvp **out) {
     m->S = cfg->n_hidden_scalars;
     m->V = GV;
     const int S = m->S, C = cfg->n_convs;
-    size_t per_gvp = ((size_t)NG_G * 2048 + 17 * 17 + 17 * 16 + 256 + 16 * 256 + 16 + (size_t)(S / 8) * 2048 + 256) * 4 + 4096;
+    size_t per_gvp = gvp_arena_bytes(S);
     size_t bytes = per_gvp * ((size_t)C * (4 * cfg->n_message_gvps + 2 * cfg->n_update_gvps) + cfg->n_noise_gvps) +
                    (size_t)C * 2 * 4 * (S * 4 + 256) + (size_t)2 * (S * 260 + 3 * S) * 4 + 64 * 64 * 4 + (1 << 20);
     kpd_status st = m->warena.reserve(bytes);
@@ -149,7 +93,7 @@ extern "C" kpd_status kpd_gvp_create(const kpd_gvp_config *cfg, kpd_gvp **out) {
                 HostGvp &g = m->msg[i][et][j];
                 g.vin = j == 0 ? GV + 1 : GV; g.vout = GV;
                 g.s_in = j == 0 ? S + 16 : S; g.sout = S;
-                g.split_src = j == 0; g.S = S;
+                g.split = j == 0 ? SPLIT_SRC : SPLIT_NONE; g.S = S;
                 alloc_gvp(A, g, m->expected, pre + "edge_message_fns." + kCanon[et] + "." + std::to_string(j));
             }
         }
@@ -201,58 +145,6 @@ extern "C" void kpd_gvp_destroy(kpd_gvp *m) {
     m->warena.release();
     m->ws.release();
     delete m;
-}
-
-static kpd_status want_shape(const char *name, const int64_t *shape, int ndim, std::initializer_list<int64_t> want) {
-    bool ok = ndim == (int)want.size();
-    int i = 0;
-    for (int64_t w : want) {
-        if (ok && shape[i] != w) ok = false;
-        ++i;
-    }
-    if (!ok) {
-        std::string got;
-        for (int j = 0; j < ndim; ++j) got += std::to_string(shape[j]) + ",";
-        std::string exp;
-        for (int64_t w : want) exp += std::to_string(w) + ",";
-        set_error("weight %s has shape [%s], expected [%s]", name, got.c_str(), exp.c_str());
-        return KPD_ERR_WEIGHTS;
-    }
-    return KPD_OK;
-}
-
-static kpd_status load_gvp_tensor(HostGvp &g, const std::string &param, const char *name, const float *w, const int64_t *shape,
-                                  int ndim, hipStream_t st) {
-    const int k_all = g.s_in + g.h;
-    if (param == "Wh") {
-        KPD_TRY(want_shape(name, shape, ndim, {g.vin, g.h}));
-        KPD_TRY(copy_pad(w, g.vin * g.h, g.Wh, g.vin * g.h, st));
-    } else if (param == "Wu") {
-        KPD_TRY(want_shape(name, shape, ndim, {g.h, g.vout}));
-        KPD_TRY(copy_pad(w, g.h * g.vout, g.Wu, g.h * g.vout, st));
-    } else if (param == "to_feats_out.0.weight") {
-        KPD_TRY(want_shape(name, shape, ndim, {g.sout, k_all}));
-        if (g.split_src) {
-            KPD_TRY(pack_gemm_weight_ng(w, g.sout, k_all, 0, g.S, g.S / 8, g.wproj, st));
-            KPD_TRY(pack_gemm_weight_ng(w, g.sout, k_all, g.S, k_all - g.S, g.ng, g.wp, st));
-        } else {
-            KPD_TRY(pack_gemm_weight_ng(w, g.sout, k_all, 0, k_all, g.ng, g.wp, st));
-        }
-    } else if (param == "to_feats_out.0.bias") {
-        KPD_TRY(want_shape(name, shape, ndim, {g.sout}));
-        // split: the bias rides with the per-node projection; the per-edge stage adds nothing
-        KPD_TRY(copy_pad(w, g.sout, g.split_src ? g.bproj : g.b, 256, st));
-    } else if (param == "scalar_to_vector_gates.weight") {
-        KPD_TRY(want_shape(name, shape, ndim, {g.vout, g.sout}));
-        KPD_TRY(pack_gate_weight(w, g.vout, g.sout, g.wg, st));
-    } else if (param == "scalar_to_vector_gates.bias") {
-        KPD_TRY(want_shape(name, shape, ndim, {g.vout}));
-        KPD_TRY(copy_pad(w, g.vout, g.bg, 16, st));
-    } else {
-        set_error("unknown GVP parameter '%s'", name);
-        return KPD_ERR_WEIGHTS;
-    }
-    return KPD_OK;
 }
 
 extern "C" kpd_status kpd_gvp_load_weight(kpd_gvp *m, const char *name, const float *w, const int64_t *shape, int32_t ndim,
@@ -427,16 +319,15 @@ extern "C" kpd_status kpd_gvp_forward(kpd_gvp *m, const kpd_batch *bt, const flo
         memset(&pa, 0, sizeof(pa));
         pa.S = S;
         int run = 0, tile_cap = 0;
-        for (int et = 0; et < 4; ++et) {
+        for (int et = 0; et < net; ++et) {
+            const HostGvp &g = m->msg[ci][et][0];
             pa.tiles_first[et] = run;
-            if (et < net) {
-                const HostGvp &g = m->msg[ci][et][0];
-                pa.s[et] = m->s[kSrcNtG[et]]; pa.n[et] = n[kSrcNtG[et]]; pa.wp[et] = g.wproj; pa.b[et] = g.bproj; pa.P[et] = m->Psrc[et];
-                run += cdiv(n[kSrcNtG[et]], TM);
-                tile_cap += cdiv(E_cap[et], TM);
-            }
+            pa.s[et] = m->s[kSrcNtG[et]]; pa.n[et] = n[kSrcNtG[et]]; pa.wp[et] = g.wproj; pa.b[et] = g.bproj; pa.P[et] = m->Psrc[et];
+            run += cdiv(n[kSrcNtG[et]], TM);
+            tile_cap += cdiv(E_cap[et], TM);
         }
-        pa.tiles_first[4] = run;
+        pa.n_slots = net;
+        pa.tiles_first[net] = run;
         KPD_TRY(launch_gvp_proj(pa, st));
 
         GvpEdgeArgs ea;

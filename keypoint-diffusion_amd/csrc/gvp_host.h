@@ -1,0 +1,52 @@
+// Host-side description of one GVP's weights and their device buffers, shared by the GVP denoiser
+// engine (gvp.hip) and the GVP receptor encoder engine (rec_encoder.hip).
+#pragma once
+#include <algorithm>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "gvp_kernels.h"
+
+namespace kpd {
+
+#define KPD_TRY(expr)                  \
+    do {                               \
+        kpd_status s_ = (expr);        \
+        if (s_ != KPD_OK) return s_;   \
+    } while (0)
+
+// How the first Linear (to_feats_out) of a message GVP is split.  Its input is
+// [h_src (S) | rbf (16) | (h_dst (S)) | sh (h)]; blocks that depend on one node only are applied per
+// node by k_gvp_proj and enter the edge stage as gathered per-row terms.
+enum GvpSplit { SPLIT_NONE = 0, SPLIT_SRC = 1, SPLIT_SRC_DST = 2 };
+
+struct HostGvp {
+    int vin = 0, h = 0, vout = 0, s_in = 0, sout = 0;   // s_in = scalar inputs of to_feats_out (without sh)
+    int split = SPLIT_NONE;
+    int S = 0;                                          // width of the node blocks when split
+    float *Wh = nullptr, *Wu = nullptr, *wp = nullptr, *b = nullptr, *wg = nullptr, *bg = nullptr;
+    float *wproj = nullptr, *bproj = nullptr;           // h_src block (+ bias)
+    float *wproj_dst = nullptr;                         // h_dst block
+    int ng = 0;
+    int vec_sigmoid = 1;
+    int edge_scalars() const { return split == SPLIT_NONE ? s_in : 16; }
+    GvpW dev() const {
+        GvpW w;
+        w.Wh = Wh; w.Wu = Wu; w.wp = wp; w.b = b; w.wg = wg; w.bg = bg;
+        w.vin = vin; w.h = h; w.vout = vout;
+        w.n_s = edge_scalars();
+        w.sout = sout; w.ng = ng; w.vec_sigmoid = vec_sigmoid;
+        return w;
+    }
+};
+
+std::vector<std::string> split_dots(const std::string &s);
+void alloc_gvp(Arena &A, HostGvp &g, std::set<std::string> &expected, const std::string &prefix);
+kpd_status want_shape(const char *name, const int64_t *shape, int ndim, std::initializer_list<int64_t> want);
+kpd_status load_gvp_tensor(HostGvp &g, const std::string &param, const char *name, const float *w, const int64_t *shape,
+                           int ndim, hipStream_t st);
+// bytes one HostGvp can take from the arena (upper bound)
+size_t gvp_arena_bytes(int S);
+
+}  // namespace kpd

@@ -5,11 +5,11 @@
 namespace kpd {
 
 constexpr int GV = 16;                 // vector channels (vector_size; 16 in every config)
-constexpr int GVH = 17;                // largest hidden vector width (x_diff + 16 source vectors)
-constexpr int VST = 52;                // floats per row of an LDS vector buffer (17 x 3, padded)
+constexpr int GVH = 33;                // largest hidden vector width (x_diff + 16 source + 16 destination vectors)
+constexpr int VST = 100;               // floats per row of an LDS vector buffer (33 x 3, padded)
 constexpr int NG_G = 34;               // k-groups of the widest GVP GEMM (K = 256 + 16 = 272)
 constexpr int SA_G = 276;              // LDS row stride of the GVP A tile
-constexpr int GVP_LDS_FLOATS = TM * SA_G + 3 * TM * VST + TM * GV + 2 * 320 + 4 * TM + 16;
+constexpr int GVP_LDS_FLOATS = TM * SA_G + 3 * TM * VST + TM * GV + 2 * 1120 + 4 * TM + 16;
 constexpr int GVP_LDS_BYTES = GVP_LDS_FLOATS * 4;
 
 // One GVP (models/gvp.py:43-116) in kernel-ready form.
@@ -35,6 +35,8 @@ struct GvpEdgeArgs {
     const float *x[2];            // positions (constant in the GVP denoiser)
     const float *v[2];            // [n][16][3]
     const float *Psrc[4];         // [n_src][S]: W0[:, :S] . s_src + b0, per edge type
+    const float *Pdst[4];         // [n_dst][S]: h_dst block of the first message GVP (use_dst_feats, gvp.py:323-337)
+    int use_dst;                  // message input also carries the destination node's scalars / vectors
     GvpW g[4][GVP_MAX_CHAIN];     // per edge type, message chain
     int n_gvps;
     int S;
@@ -66,12 +68,14 @@ struct GvpNodePair {
     int tiles0;
 };
 
+constexpr int GVP_PROJ_SLOTS = 8;
 struct GvpProjArgs {
-    const float *s[4];            // source scalar state per edge type
-    int n[4];
-    const float *wp[4], *b[4];
-    float *P[4];
-    int tiles_first[5];
+    const float *s[GVP_PROJ_SLOTS];    // scalar state to project, per slot
+    int n[GVP_PROJ_SLOTS];
+    const float *wp[GVP_PROJ_SLOTS], *b[GVP_PROJ_SLOTS];   // b may be nullptr
+    float *P[GVP_PROJ_SLOTS];
+    int tiles_first[GVP_PROJ_SLOTS + 1];
+    int n_slots;
     int S;
 };
 

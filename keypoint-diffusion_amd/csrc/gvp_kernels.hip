@@ -26,7 +26,7 @@ struct GvpSmem {
     float *A;                 // [64][SA_G]
     float *V0, *V1, *V2;      // [64][VST]: current vectors, hidden vectors, residual vectors
     float *G;                 // [64][16] gates
-    float *Wh, *Wu;           // [320] each
+    float *Wh, *Wu;           // [1120] each (33 x 33 at most)
     int *src, *dst;           // [64]
     float *rowf;              // [128] per-row scratch (LN statistics)
     int *misc;                // [16]
@@ -40,8 +40,8 @@ __device__ __forceinline__ GvpSmem gvp_smem(float *smem) {
     s.V2 = s.V1 + TM * VST;
     s.G = s.V2 + TM * VST;
     s.Wh = s.G + TM * GV;
-    s.Wu = s.Wh + 320;
-    s.src = reinterpret_cast<int *>(s.Wu + 320);
+    s.Wu = s.Wh + 1120;
+    s.src = reinterpret_cast<int *>(s.Wu + 1120);
     s.dst = s.src + TM;
     s.rowf = reinterpret_cast<float *>(s.dst + TM);
     s.misc = reinterpret_cast<int *>(s.rowf + 2 * TM);
@@ -49,9 +49,11 @@ __device__ __forceinline__ GvpSmem gvp_smem(float *smem) {
 }
 
 // ---- one GVP stage ------------------------------------------------------------------------
-// add_row (optional): per-row term added before the activation, add_row[row_index[r] * add_ld + col].
+// add_row / add_row2 (optional): per-row terms added before the activation,
+// add_row[row_index[r] * add_ld + col] (+ add_row2[row_index2[r] * add_ld + col]).
 __device__ __forceinline__ void gvp_stage(const GvpSmem &s, const GvpW &w, const float *__restrict__ add_row,
-                                          const int *row_index, int add_ld, int tid) {
+                                          const int *row_index, int add_ld, int tid,
+                                          const float *__restrict__ add_row2 = nullptr, const int *row_index2 = nullptr) {
     const int wave = tid >> 6, lane = tid & 63;
     const int row = tid >> 2, q = tid & 3;
     // Wh / Wu -> LDS
@@ -61,23 +63,28 @@ __device__ __forceinline__ void gvp_stage(const GvpSmem &s, const GvpW &w, const
 
     // vec1: Vh[h][c] = sum_v Wh[v][h] v[v][c]; sh[h] = sqrt(max(|Vh[h]|^2, 1e-8))  (gvp.py:96-99)
     {
-        float a[5][3];
+        // each thread owns hidden channels q, q + 4, ...; `nh` (wave-uniform) bounds the unrolled loops
+        constexpr int NHMAX = (GVH + 3) / 4;
+        const int nh = (w.h + 3) >> 2;
+        float a[NHMAX][3];
 #pragma unroll
-        for (int i = 0; i < 5; ++i) a[i][0] = a[i][1] = a[i][2] = 0.0f;
+        for (int i = 0; i < NHMAX; ++i) a[i][0] = a[i][1] = a[i][2] = 0.0f;
         const float *vin = s.V0 + row * VST;
         for (int v = 0; v < w.vin; ++v) {
             const float x0 = vin[3 * v], x1 = vin[3 * v + 1], x2 = vin[3 * v + 2];
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const int h = q + 4 * i;
-                const float wv = h < w.h ? s.Wh[v * w.h + h] : 0.0f;
-                a[i][0] = fmaf(wv, x0, a[i][0]);
-                a[i][1] = fmaf(wv, x1, a[i][1]);
-                a[i][2] = fmaf(wv, x2, a[i][2]);
+            for (int i = 0; i < NHMAX; ++i) {
+                if (i < nh) {
+                    const int h = q + 4 * i;
+                    const float wv = h < w.h ? s.Wh[v * w.h + h] : 0.0f;
+                    a[i][0] = fmaf(wv, x0, a[i][0]);
+                    a[i][1] = fmaf(wv, x1, a[i][1]);
+                    a[i][2] = fmaf(wv, x2, a[i][2]);
+                }
             }
         }
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
+        for (int i = 0; i < NHMAX; ++i) {
             const int h = q + 4 * i;
             if (h < w.h) {
                 float *o = s.V1 + row * VST + 3 * h;
@@ -108,6 +115,7 @@ __device__ __forceinline__ void gvp_stage(const GvpSmem &s, const GvpW &w, const
                     const int r = acc_row(mt, reg, lane);
                     float val = acc[mt][nt][reg] + bb;
                     if (add_row && col < add_ld) val += add_row[(size_t)row_index[r] * add_ld + col];
+                    if (add_row2 && col < add_ld) val += add_row2[(size_t)row_index2[r] * add_ld + col];
                     s.A[r * SA_G + col] = silu(val);
                 }
         }
@@ -264,13 +272,13 @@ __global__ __launch_bounds__(256, 2) void k_gvp_proj(GvpProjArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *A = smem;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    int et = 0;
+    int sl = 0;
 #pragma unroll
-    for (int e = 1; e < 4; ++e)
-        if ((int)blockIdx.x >= a.tiles_first[e]) et = e;
-    const int node0 = ((int)blockIdx.x - a.tiles_first[et]) * TM;
-    const int n = a.n[et], S = a.S;
-    const float *src = a.s[et];
+    for (int e = 1; e < GVP_PROJ_SLOTS; ++e)
+        if (e < a.n_slots && (int)blockIdx.x >= a.tiles_first[e]) sl = e;
+    const int node0 = ((int)blockIdx.x - a.tiles_first[sl]) * TM;
+    const int n = a.n[sl], S = a.S;
+    const float *src = a.s[sl];
     const int chunks = S >> 2;
     for (int rr = 0; rr < 16; ++rr) {
         const int r = wave * 16 + rr, v = node0 + r;
@@ -283,13 +291,14 @@ __global__ __launch_bounds__(256, 2) void k_gvp_proj(GvpProjArgs a) {
     lds_barrier();
     f32x16 acc[2][2];
     acc_zero(acc);
-    gemm_rows64_rt<SA_G>(A, a.wp[et], S >> 3, acc, wave, lane);
-    float *out = a.P[et];
+    gemm_rows64_rt<SA_G>(A, a.wp[sl], S >> 3, acc, wave, lane);
+    float *out = a.P[sl];
+    const float *bias = a.b[sl];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int col = acc_col(nt, wave, lane);
         if (col < S) {
-            const float bb = a.b[et][col];
+            const float bb = bias ? bias[col] : 0.0f;
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(256) void k_gvp_edge(GvpEdgeArgs a) {
         }
     }
     lds_barrier();
-    {   // source vectors: 48 floats per edge, 4 threads x 3 float4
+    {   // source (and destination) vectors: 48 floats per edge each, 4 threads x 3 float4
         const int row = tid >> 2, q = tid & 3;
         const f32x4_ *vs = reinterpret_cast<const f32x4_ *>(a.v[snt] + (size_t)s.src[row] * 48);
         float *o = s.V0 + row * VST + 3;
@@ -363,11 +372,22 @@ __global__ __launch_bounds__(256) void k_gvp_edge(GvpEdgeArgs a) {
             o[(q * 3 + i) * 4 + 0] = val[0]; o[(q * 3 + i) * 4 + 1] = val[1];
             o[(q * 3 + i) * 4 + 2] = val[2]; o[(q * 3 + i) * 4 + 3] = val[3];
         }
+        if (a.use_dst) {
+            const f32x4_ *vd = reinterpret_cast<const f32x4_ *>(a.v[dnt] + (size_t)s.dst[row] * 48);
+            float *od = o + 48;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const f32x4_ val = vd[q * 3 + i];
+                od[(q * 3 + i) * 4 + 0] = val[0]; od[(q * 3 + i) * 4 + 1] = val[1];
+                od[(q * 3 + i) * 4 + 2] = val[2]; od[(q * 3 + i) * 4 + 3] = val[3];
+            }
+        }
     }
     lds_barrier();
 
     for (int k = 0; k < a.n_gvps; ++k)
-        gvp_stage(s, a.g[et][k], k == 0 ? a.Psrc[et] : nullptr, s.src, S, tid);
+        gvp_stage(s, a.g[et][k], k == 0 ? a.Psrc[et] : nullptr, s.src, S, tid,
+                  (k == 0 && a.use_dst) ? a.Pdst[et] : nullptr, s.dst);
 
     // segmented sums over dst: scalars (thread = column), then the 48 vector floats
     const int first_is_cont = s.misc[0];
@@ -549,8 +569,8 @@ kpd_status launch_gvp_embed(const float *in, int n, int fin, const float *W, con
 }
 
 kpd_status launch_gvp_proj(const GvpProjArgs &a, hipStream_t st) {
-    if (a.tiles_first[4] == 0) return KPD_OK;
-    hipLaunchKernelGGL(k_gvp_proj, dim3(a.tiles_first[4]), dim3(256), TM * SA_G * 4, st, a);
+    if (a.n_slots == 0 || a.tiles_first[a.n_slots] == 0) return KPD_OK;
+    hipLaunchKernelGGL(k_gvp_proj, dim3(a.tiles_first[a.n_slots]), dim3(256), TM * SA_G * 4, st, a);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
 }

@@ -48,6 +48,26 @@ class KpdGvpConfig(C.Structure):
                 ('n_update_gvps', C.c_int32), ('n_noise_gvps', C.c_int32)]
 
 
+class KpdRecencConfig(C.Structure):
+    _fields_ = [('in_scalar_size', C.c_int32), ('out_scalar_size', C.c_int32), ('vector_size', C.c_int32),
+                ('n_rr_convs', C.c_int32), ('n_rk_convs', C.c_int32), ('n_message_gvps', C.c_int32),
+                ('n_update_gvps', C.c_int32), ('message_norm_mode', C.c_int32), ('message_norm', C.c_float),
+                ('k_closest', C.c_int32), ('n_keypoints', C.c_int32), ('rr_cutoff', C.c_float), ('rk_cutoff', C.c_float),
+                ('kk_cutoff', C.c_float)]
+
+
+class KpdRecBatch(C.Structure):
+    _fields_ = [('B', C.c_int32), ('n_rec', C.c_int32), ('max_rec', C.c_int32), ('rec_ptr', C.c_void_p),
+                ('rec_x', C.c_void_p), ('rec_h', C.c_void_p), ('n_rr', C.c_int32), ('rr_src', C.c_void_p),
+                ('rr_dst', C.c_void_p), ('rr_rowptr', C.c_void_p)]
+
+
+class KpdRecOut(C.Structure):
+    _fields_ = [('kp_x', C.c_void_p), ('kp_h', C.c_void_p), ('kp_v', C.c_void_p), ('rk_src', C.c_void_p),
+                ('rk_dst', C.c_void_p), ('cap_kk', C.c_int32), ('kk_src', C.c_void_p), ('kk_dst', C.c_void_p),
+                ('kk_per_graph', C.c_void_p), ('counts', C.c_void_p)]
+
+
 class KpdError(RuntimeError):
     pass
 
@@ -84,6 +104,13 @@ def lib():
     L.kpd_gvp_reserve.argtypes = [C.c_void_p] + [C.c_int32] * 6
     L.kpd_gvp_forward.argtypes = [C.c_void_p, C.POINTER(KpdBatch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.kpd_gvp_debug_state.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p]
+    L.kpd_recenc_create.argtypes = [C.POINTER(KpdRecencConfig), C.POINTER(C.c_void_p)]
+    L.kpd_recenc_destroy.argtypes = [C.c_void_p]
+    L.kpd_recenc_destroy.restype = None
+    L.kpd_recenc_load_weight.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_void_p]
+    L.kpd_recenc_commit.argtypes = [C.c_void_p]
+    L.kpd_recenc_reserve.argtypes = [C.c_void_p] + [C.c_int32] * 4
+    L.kpd_recenc_forward.argtypes = [C.c_void_p, C.POINTER(KpdRecBatch), C.POINTER(KpdRecOut), C.c_void_p]
     L.kpd_build_lig_graph.argtypes = [C.POINTER(KpdBatch), C.c_float, C.c_int32, C.POINTER(KpdLigGraph), C.c_void_p]
     L.kpd_sample_update.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 8 + [C.c_int32, C.c_void_p]
     _lib = L
@@ -98,6 +125,8 @@ EXPORTS = [
     'kpd_egnn_profile_read', 'kpd_sample_update',
     'kpd_gvp_create', 'kpd_gvp_destroy', 'kpd_gvp_load_weight', 'kpd_gvp_commit', 'kpd_gvp_reserve',
     'kpd_gvp_forward', 'kpd_gvp_debug_state',
+    'kpd_recenc_create', 'kpd_recenc_destroy', 'kpd_recenc_load_weight', 'kpd_recenc_commit', 'kpd_recenc_reserve',
+    'kpd_recenc_forward',
 ]
 
 
@@ -304,6 +333,85 @@ class GvpEngine:
         out = torch.empty(max(n_floats, 1), device=device or 'cuda')
         check(lib().kpd_gvp_debug_state(self._h, what.encode(), out.data_ptr(), n_floats, _stream()))
         return out if n_floats else None
+
+
+def _norm_mode(message_norm):
+    if message_norm == 'mean':
+        return 1, 1.0
+    if message_norm == 0:
+        return 2, 0.0
+    return 0, float(message_norm)
+
+
+def sorted_csr(src: torch.Tensor, dst: torch.Tensor, n_dst: int, device):
+    """(src, dst) sorted by (dst, src) as int32 + CSR row pointer over dst."""
+    src, dst = src.to(device).long(), dst.to(device).long()
+    if src.numel():
+        order = torch.argsort(dst * (int(src.max()) + 1) + src)
+        src, dst = src[order], dst[order]
+    deg = torch.bincount(dst, minlength=n_dst) if src.numel() else torch.zeros(n_dst, dtype=torch.long, device=device)
+    rowptr = torch.cat([torch.zeros(1, dtype=torch.long, device=device), deg.cumsum(0)])
+    return src.int().contiguous(), dst.int().contiguous(), rowptr.int().contiguous()
+
+
+class RecEncEngine:
+    """Owns one kpd_recenc handle: packed weights + workspace for ReceptorEncoderGVP.forward."""
+
+    def __init__(self, in_scalar_size, out_scalar_size, vector_size, n_rr_convs, n_rk_convs, n_message_gvps, n_update_gvps,
+                 message_norm, k_closest, n_keypoints, rr_cutoff, rk_cutoff, kk_cutoff):
+        mode, val = _norm_mode(message_norm)
+        self.cfg = KpdRecencConfig(int(in_scalar_size), int(out_scalar_size), int(vector_size), int(n_rr_convs),
+                                   int(n_rk_convs), int(n_message_gvps), int(n_update_gvps), mode, val, int(k_closest),
+                                   int(n_keypoints), float(rr_cutoff), float(rk_cutoff), float(kk_cutoff))
+        self.S, self.K, self.k = int(out_scalar_size), int(n_keypoints), int(k_closest)
+        self._h = C.c_void_p()
+        check(lib().kpd_recenc_create(C.byref(self.cfg), C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, '_h', None) and _lib is not None:
+            _lib.kpd_recenc_destroy(self._h)
+            self._h = None
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+        L = lib()
+        st = _stream()
+        keep = []
+        for name, t in sd.items():
+            if t.numel() == 0:
+                continue
+            t = _dev_f32(t.detach(), name)
+            keep.append(t)
+            shape = (C.c_int64 * t.dim())(*t.shape)
+            check(L.kpd_recenc_load_weight(self._h, name.encode(), t.data_ptr(), shape, t.dim(), st))
+        torch.cuda.current_stream().synchronize()
+        check(L.kpd_recenc_commit(self._h))
+
+    def forward(self, rec_counts: torch.Tensor, rec_x, rec_h, rr_src, rr_dst):
+        dev = rec_x.device
+        rec_counts = rec_counts.cpu().long()
+        B, n_rec, max_rec = int(rec_counts.numel()), int(rec_counts.sum()), int(rec_counts.max())
+        if int(rec_counts.min()) < 1:
+            raise KpdError('every pocket needs at least one receptor atom')
+        rec_ptr = torch.cat([torch.zeros(1, dtype=torch.long), rec_counts.cumsum(0)]).int().to(dev)
+        rec_x, rec_h = _dev_f32(rec_x, 'rec x_0'), _dev_f32(rec_h, 'rec h_0')
+        s, d, rowptr = sorted_csr(rr_src, rr_dst, n_rec, dev)
+        torch.cuda.synchronize()
+        check(lib().kpd_recenc_reserve(self._h, B, n_rec, int(s.numel()), max_rec))
+        n_kp = B * self.K
+        cap_kk = max(n_kp * min(self.K - 1, 100), 1)
+        f32 = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+        i32 = lambda n: torch.zeros(n, device=dev, dtype=torch.int32)
+        out = dict(kp_x=f32(n_kp, 3), kp_h=f32(n_kp, self.S), kp_v=f32(n_kp, 16, 3), rk_src=i32(n_kp * self.k),
+                   rk_dst=i32(n_kp * self.k), kk_src=i32(cap_kk), kk_dst=i32(cap_kk), kk_per_graph=i32(B), counts=i32(2))
+        bt = KpdRecBatch(B, n_rec, max_rec, _ptr(rec_ptr), _ptr(rec_x), _ptr(rec_h), int(s.numel()), _ptr(s), _ptr(d),
+                         _ptr(rowptr))
+        ro = KpdRecOut(_ptr(out['kp_x']), _ptr(out['kp_h']), _ptr(out['kp_v']), _ptr(out['rk_src']), _ptr(out['rk_dst']),
+                       cap_kk, _ptr(out['kk_src']), _ptr(out['kk_dst']), _ptr(out['kk_per_graph']), _ptr(out['counts']))
+        check(lib().kpd_recenc_forward(self._h, C.byref(bt), C.byref(ro), _stream()))
+        e_kk, e_rk = out['counts'].tolist()            # once per pocket: a host sync here is fine
+        out['kk_src'], out['kk_dst'] = out['kk_src'][:e_kk], out['kk_dst'][:e_kk]
+        out['rk_src'], out['rk_dst'] = out['rk_src'][:e_rk], out['rk_dst'][:e_rk]
+        return out
 
 
 def sample_update(pb: PreparedBatch, atom_nf, lig_x, lig_h, kp_x, eps_x, eps_h, noise_x, noise_h, coef):

@@ -7,7 +7,7 @@ from typing import Dict, Union
 import torch
 import torch.nn as nn
 
-from .graph import HeteroBatch
+from .graph import HeteroBatch, get_batch_info
 from .gvp import GVPEdgeConv
 
 
@@ -61,5 +61,47 @@ class ReceptorEncoderGVP(nn.Module):
             [GVPEdgeConv(edge_type=('rec', 'rk', 'kp'), use_dst_feats=(i != 0), rbf_dmax=graph_cutoffs['rk'], **common)
              for i in range(n_rk_convs)])
 
+        self._engine = None
+        self._engine_key = None
+
+    def engine(self):
+        from . import hip
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._engine is None or key != self._engine_key:
+            if self.rk_graph_type != 'knn':
+                raise NotImplementedError('kp_rad > 0 (radius rec->kp graph) is not implemented in the HIP path')
+            if self.use_sameres_feat:
+                raise NotImplementedError('use_sameres_feat is not implemented (unused by every shipped config)')
+            eng = hip.RecEncEngine(self.in_scalar_size, self.out_scalar_size, self.vector_size, self.n_rr_convs,
+                                   self.n_rk_convs, self.n_message_gvps, self.n_update_gvps, self.message_norm,
+                                   self.k_closest, self.n_keypoints, self.graph_cutoffs['rr'], self.graph_cutoffs['rk'],
+                                   self.graph_cutoffs['kk'])
+            eng.load_state_dict(self.state_dict())
+            self._engine, self._engine_key = eng, key
+        return self._engine
+
     def forward(self, g: HeteroBatch, batch_idxs: Dict[str, torch.Tensor] = None) -> HeteroBatch:
-        raise NotImplementedError('the GVP receptor encoder HIP path is not built yet in this revision')
+        """Writes keypoint x_0 / h_0 / v_0, replaces the rk edges by the kNN edges and adds the kk radius
+        graph (receptor_encoder_gvp.py:212-294); eval mode only."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError('the HIP encoder is forward-only; call it under torch.no_grad()')
+        if self.training:
+            raise NotImplementedError('dropout is not implemented: call model.eval()')
+        B, K = g.batch_size, self.n_keypoints
+        if g.num_nodes('kp') != B * K:
+            raise ValueError(f'expected {K} keypoint nodes per complex, graph has {g.num_nodes("kp")} for {B} complexes')
+        rec = g.nodes['rec'].data
+        rr_src, rr_dst = g.edges(etype='rr')
+        n_rec = g.batch_num_nodes('rec')
+        out = self.engine().forward(n_rec, rec['x_0'], rec['h_0'], rr_src, rr_dst)
+        kp = g.nodes['kp'].data
+        kp['x_0'], kp['h_0'], kp['v_0'] = out['kp_x'], out['kp_h'], out['kp_v']
+        nodes, edges = get_batch_info(g)
+        g.remove_edges(g.edges(form='eid', etype='rk'), etype='rk')
+        g.add_edges(out['rk_src'].long(), out['rk_dst'].long(), etype='rk')
+        g.add_edges(out['kk_src'].long(), out['kk_dst'].long(), etype='kk')
+        edges[('rec', 'rk', 'kp')] = K * torch.clamp(n_rec, max=self.k_closest)
+        edges[('kp', 'kk', 'kp')] = out['kk_per_graph'].long()
+        g.set_batch_num_nodes(nodes)
+        g.set_batch_num_edges(edges)
+        return g
