@@ -221,15 +221,17 @@ __device__ __forceinline__ EdgeSmem edge_smem(float *smem) {
 }
 
 // A[r][:] = SiLU(Ps[src_r] + Pd[dst_r] + d_r * w_r)   (first Linear of edge_mlp / coord_mlp;
-// its bias is folded into Pd by k_node_proj)
+// its bias is folded into Pd by k_node_proj).  Each of the NW waves owns 64 / NW rows.
+template <int NW>
 __device__ __forceinline__ void build_edge_A(const EdgeSmem &s, const float *__restrict__ Ps, const float *__restrict__ Pd,
                                              const float *__restrict__ wr, int wave, int lane) {
+    constexpr int RPW = TM / NW;
     const size_t prow = (size_t)NSLOT * HS;
     const f32x4 w0 = reinterpret_cast<const f32x4 *>(wr)[lane];
-    // columns 0..255: one 1-KiB row segment per wave instruction, all 16 rows (32 loads) in flight
-#pragma unroll 16
-    for (int rr = 0; rr < 16; ++rr) {
-        const int r = wave * 16 + rr;
+    // columns 0..255: one 1-KiB row segment per wave instruction, all rows of the wave in flight
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int r = wave * RPW + rr;
         const float d = s.d[r];
         const f32x4 *ps = reinterpret_cast<const f32x4 *>(Ps + s.src[r] * prow);
         const f32x4 *pd = reinterpret_cast<const f32x4 *>(Pd + s.dst[r] * prow);
@@ -237,10 +239,10 @@ __device__ __forceinline__ void build_edge_A(const EdgeSmem &s, const float *__r
         v[0] = silu(v[0]); v[1] = silu(v[1]); v[2] = silu(v[2]); v[3] = silu(v[3]);
         *reinterpret_cast<f32x4 *>(s.A + r * SA + 4 * lane) = v;
     }
-    // columns 256..263 of all 16 rows in one pass (lane = row * 4 + chunk): keeping this out of the
+    // columns 256..263 of the wave's rows in one pass (lane = row * 4 + chunk): keeping this out of the
     // row loop halves the VALU work, which on gfx950 is paid in MFMA time
-    {
-        const int r = wave * 16 + (lane >> 2), c = lane & 3;
+    if (lane < 4 * RPW) {
+        const int r = wave * RPW + (lane >> 2), c = lane & 3;
         if (c < 2) {
             const f32x4 w1 = reinterpret_cast<const f32x4 *>(wr)[64 + c];
             const f32x4 *ps = reinterpret_cast<const f32x4 *>(Ps + s.src[r] * prow);
@@ -253,18 +255,20 @@ __device__ __forceinline__ void build_edge_A(const EdgeSmem &s, const float *__r
 }
 
 // T[row][col] = SiLU(acc + b[col]) for the 257 valid columns.
-__device__ __forceinline__ void store_T_silu(float *T, const f32x16 (&acc)[2][2], float ex,
-                                             const float *__restrict__ b, int tid, int wave, int lane) {
+template <int NW>
+__device__ __forceinline__ void store_T_silu_w(float *T, const f32x16 (&acc)[2][WaveCols<NW>::NT], float ex,
+                                               const float *__restrict__ b, int tid, int wave, int lane) {
+    constexpr int TPR = NW;      // threads per row = 64 NW / 64
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int col = acc_col(nt, wave, lane);
+    for (int nt = 0; nt < WaveCols<NW>::NT; ++nt) {
+        const int col = acc_col_w<NW>(nt, wave, lane);
         const float bb = b[col];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) T[acc_row(mt, reg, lane) * SA + col] = silu(acc[mt][nt][reg] + bb);
     }
-    if ((tid & 3) == 0) T[(tid >> 2) * SA + 256] = silu(ex + b[256]);
+    if ((tid % TPR) == 0) T[(tid / TPR) * SA + 256] = silu(ex + b[256]);
 }
 
 // Phase stamps (diagnostic builds of the timeline only; a.stamps is null in production): wave 0 of
@@ -276,7 +280,9 @@ __device__ __forceinline__ void store_T_silu(float *T, const f32x16 (&acc)[2][2]
         t_prev_ = now_;                                                                    \
     }
 
-__global__ __launch_bounds__(256, 2) void k_egnn_edge(EdgeArgs a) {
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs a) {
+    constexpr int TPR = NW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const EdgeSmem s = edge_smem(smem);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -342,25 +348,28 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge(EdgeArgs a) {
     const int first_is_cont = s.misc[0];
     const unsigned long long endmask =
         ((unsigned long long)(unsigned)s.misc[3] << 32) | (unsigned long long)(unsigned)s.misc[2];
-    f32x16 acc[2][2];
+    f32x16 acc[2][WaveCols<NW>::NT];
     float ex;
 
     // ---- feature messages: m = edge_mlp(f); msg_h = m * sigmoid(att(m)) (dynamics.py:111-112)
-    build_edge_A(s, Ps, Pd, a.wr_e[et], wave, lane);
+    build_edge_A<NW>(s, Ps, Pd, a.wr_e[et], wave, lane);
     lds_barrier();
     KPD_STAMP(1)
-    acc_zero(acc);
-    gemm_rows64(s.A, a.wp_e[et], acc, wave, lane);
-    ex = extra_col(s.A, a.wx_e[et], tid);
+    acc_zero_w<NW>(acc);
+    gemm_rows64_w<NW, NG, SA>(s.A, a.wp_e[et], acc, wave, lane);
+    ex = row_dot_chunks<TPR>(s.A, a.wx_e[et], KP / 4, tid);
     lds_barrier();
     KPD_STAMP(2)
-    store_T_silu(s.A, acc, ex, a.b_e[et], tid, wave, lane);
+    store_T_silu_w<NW>(s.A, acc, ex, a.b_e[et], tid, wave, lane);
     lds_barrier();
     KPD_STAMP(3)
     {
-        const float dot = row_dot257(s.A, s.wv, tid);
-        const int row = tid >> 2;
-        if ((tid & 3) == 0) s.att[row] = row < ne ? sigmoidf_(dot + s.wv[ATT_BIAS_AT]) : 0.0f;
+        float dot = row_dot_chunks<TPR>(s.A, s.wv, 64, tid);
+        const int row = tid / TPR;
+        if ((tid % TPR) == 0) {
+            dot = fmaf(s.A[row * SA + 256], s.wv[256], dot);
+            s.att[row] = row < ne ? sigmoidf_(dot + s.wv[ATT_BIAS_AT]) : 0.0f;
+        }
     }
     lds_barrier();
     KPD_STAMP(4)
@@ -368,30 +377,32 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge(EdgeArgs a) {
         // segmented sum over dst (dynamics.py:182-185): thread = column, rows in order; the run
         // boundaries are wave-uniform (endmask), LDS reads are issued 16 rows at a time
         float *hmain = a.hn_main[et], *hcont = a.hn_cont[et] + (size_t)tile_in_et * HS;
-        float run = 0.0f;
-        int piece = 0;
+        if (tid < 256) {
+            float run = 0.0f;
+            int piece = 0;
 #pragma unroll 1
-        for (int r0 = 0; r0 < TM; r0 += 16) {
-            if (r0 >= ne) break;
-            float v[16], w[16];
+            for (int r0 = 0; r0 < TM; r0 += 16) {
+                if (r0 >= ne) break;
+                float v[16], w[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                w[i] = s.att[r0 + i];
-                v[i] = s.A[(r0 + i) * SA + tid];
-            }
+                for (int i = 0; i < 16; ++i) {
+                    w[i] = s.att[r0 + i];
+                    v[i] = s.A[(r0 + i) * SA + tid];
+                }
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                run = fmaf(v[i], w[i], run);
-                if ((endmask >> (r0 + i)) & 1ull) {
-                    float *out = (piece == 0 && first_is_cont) ? hcont : hmain + (size_t)s.dst[r0 + i] * HS;
-                    out[tid] = run;
-                    run = 0.0f;
-                    ++piece;
+                for (int i = 0; i < 16; ++i) {
+                    run = fmaf(v[i], w[i], run);
+                    if ((endmask >> (r0 + i)) & 1ull) {
+                        float *out = (piece == 0 && first_is_cont) ? hcont : hmain + (size_t)s.dst[r0 + i] * HS;
+                        out[tid] = run;
+                        run = 0.0f;
+                        ++piece;
+                    }
                 }
             }
         }
-        // column 256: lane = row on wave 3, segmented inclusive scan across lanes
-        if (wave == 3) {
+        // column 256: lane = row on the last wave, segmented inclusive scan across lanes
+        if (wave == NW - 1) {
             const unsigned long long heads =
                 ((unsigned long long)(unsigned)s.misc[5] << 32) | (unsigned long long)(unsigned)s.misc[4];
             const unsigned long long upto = lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull);
@@ -413,21 +424,22 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge(EdgeArgs a) {
     KPD_STAMP(5)
 
     // ---- coordinate messages: msg_x = tanh(coord_mlp(f)) * x_diff * range (dynamics.py:113-120)
-    build_edge_A(s, Ps + HS, Pd + HS, a.wr_c[et], wave, lane);
+    build_edge_A<NW>(s, Ps + HS, Pd + HS, a.wr_c[et], wave, lane);
     lds_barrier();
     KPD_STAMP(6)
-    acc_zero(acc);
-    gemm_rows64(s.A, a.wp_c[et], acc, wave, lane);
-    ex = extra_col(s.A, a.wx_c[et], tid);
+    acc_zero_w<NW>(acc);
+    gemm_rows64_w<NW, NG, SA>(s.A, a.wp_c[et], acc, wave, lane);
+    ex = row_dot_chunks<TPR>(s.A, a.wx_c[et], KP / 4, tid);
     lds_barrier();
     KPD_STAMP(7)
-    store_T_silu(s.A, acc, ex, a.b_c[et], tid, wave, lane);
+    store_T_silu_w<NW>(s.A, acc, ex, a.b_c[et], tid, wave, lane);
     lds_barrier();
     KPD_STAMP(8)
     {
-        const float dot = row_dot257(s.A, s.wv + HS, tid);
-        const int row = tid >> 2;
-        if ((tid & 3) == 0) {
+        float dot = row_dot_chunks<TPR>(s.A, s.wv + HS, 64, tid);
+        const int row = tid / TPR;
+        if ((tid % TPR) == 0) {
+            dot = fmaf(s.A[row * SA + 256], s.wv[HS + 256], dot);
             float c = a.use_tanh ? tanhf(dot) * a.coords_range : dot;
             if (row >= ne) c = 0.0f;
             s.mx[3 * row] = c * s.xd[3 * row];
@@ -463,6 +475,11 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge(EdgeArgs a) {
         }
     }
     KPD_STAMP(10)
+}
+
+__device__ __forceinline__ void store_T_silu(float *T, const f32x16 (&acc)[2][2], float ex, const float *__restrict__ b,
+                                             int tid, int wave, int lane) {
+    store_T_silu_w<4>(T, acc, ex, b, tid, wave, lane);
 }
 
 // ---- node update --------------------------------------------------------------------------
@@ -641,7 +658,9 @@ kpd_status egnn_kernels_init() {
     if (g_attr_set) return KPD_OK;
     KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_proj), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 PROJ_LDS_BYTES));
-    KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_egnn_edge), hipFuncAttributeMaxDynamicSharedMemorySize,
+    KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_egnn_edge<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024));
+    KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_egnn_edge<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024));
     KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_update),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, NODE_LDS_BYTES));
@@ -699,7 +718,12 @@ kpd_status launch_egnn_edge(const EdgeArgs &a, int tile_cap, hipStream_t st) {
     if (tile_cap == 0) return KPD_OK;
     // KPD_EDGE_LDS_PAD (diagnostics): extra dynamic LDS to force one workgroup per CU
     static const int pad = getenv("KPD_EDGE_LDS_PAD") ? atoi(getenv("KPD_EDGE_LDS_PAD")) : 0;
-    hipLaunchKernelGGL(k_egnn_edge, dim3(8 * cdiv(tile_cap, 8)), dim3(256), EDGE_LDS_BYTES + pad, st, a);
+    // 8 waves per workgroup (two per SIMD) by default; KPD_EDGE_NW=4 selects the 4-wave build for A/B runs
+    static const int nw = getenv("KPD_EDGE_NW") ? atoi(getenv("KPD_EDGE_NW")) : 8;
+    if (nw == 4)
+        hipLaunchKernelGGL(k_egnn_edge<4>, dim3(8 * cdiv(tile_cap, 8)), dim3(256), EDGE_LDS_BYTES + pad, st, a);
+    else
+        hipLaunchKernelGGL(k_egnn_edge<8>, dim3(8 * cdiv(tile_cap, 8)), dim3(512), EDGE_LDS_BYTES + pad, st, a);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
 }

@@ -134,6 +134,103 @@ __device__ __forceinline__ void gemm_rows64_rt(const float *__restrict__ A, cons
     }
 }
 
+// ---- wave-count-generic variants ------------------------------------------------------------------
+// NW waves share the 256 output columns: NW = 4 -> 64 columns (2 column tiles) per wave, NW = 8 -> 32
+// columns (1 column tile) per wave.  Same packed weight buffer: wave w of 8 reads column tile (w & 1) of
+// the block of wave (w >> 1) of 4.  With 8 waves a workgroup puts two waves on every SIMD, which gives
+// the scheduler something to issue while the other wave sits in a gather, LDS round trip or barrier.
+template <int NW>
+struct WaveCols {
+    static constexpr int NT = 8 / NW;
+};
+
+template <int NW>
+__device__ __forceinline__ void acc_zero_w(f32x16 (&acc)[2][WaveCols<NW>::NT]) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < WaveCols<NW>::NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+}
+
+template <int NW>
+__device__ __forceinline__ int acc_col_w(int nt, int wave, int lane) {
+    return NW == 4 ? 64 * wave + 32 * nt + (lane & 31) : 32 * wave + (lane & 31);
+}
+
+template <int NW, int NG_, int SA_>
+__device__ __forceinline__ void gemm_rows64_w(const float *__restrict__ A, const float *__restrict__ Wp,
+                                              f32x16 (&acc)[2][WaveCols<NW>::NT], int wave, int lane) {
+    if constexpr (NW == 4) {
+        gemm_rows64_t<NG_, SA_>(A, Wp, acc, wave, lane);
+    } else {
+        const int r = lane & 31, h = lane >> 5;
+        const float *a0p = A + r * SA_ + 4 * h;
+        const float *a1p = A + (32 + r) * SA_ + 4 * h;
+        const f32x4 *bp = reinterpret_cast<const f32x4 *>(Wp) + ((wave >> 1) * 64 + lane) * 2 + (wave & 1);
+        f32x4 xa0, xa1, xb0, ya0, ya1, yb0;
+#define KPD_LOAD1(A0, A1, B0, G)                                      \
+    A0 = *reinterpret_cast<const f32x4 *>(a0p + 8 * (G));             \
+    A1 = *reinterpret_cast<const f32x4 *>(a1p + 8 * (G));             \
+    B0 = bp[(G) * 512];
+#define KPD_STEP1(A0, A1, B0)                                                                     \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[j], B0[j], acc[0][0], 0, 0, 0);       \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[j], B0[j], acc[1][0], 0, 0, 0);       \
+    }
+        KPD_LOAD1(xa0, xa1, xb0, 0)
+        if (NG_ > 1) {
+            KPD_LOAD1(ya0, ya1, yb0, 1)
+        }
+        constexpr int PAIRS = NG_ / 2;
+#pragma unroll 1
+        for (int p = 0; p < PAIRS; ++p) {
+            const int g = 2 * p;
+            __builtin_amdgcn_sched_barrier(0);
+            KPD_STEP1(xa0, xa1, xb0)
+            __builtin_amdgcn_sched_barrier(0);
+            const int g2 = g + 2 < NG_ ? g + 2 : NG_ - 1;
+            KPD_LOAD1(xa0, xa1, xb0, g2)
+            __builtin_amdgcn_sched_barrier(0);
+            KPD_STEP1(ya0, ya1, yb0)
+            __builtin_amdgcn_sched_barrier(0);
+            const int g3 = g + 3 < NG_ ? g + 3 : NG_ - 1;
+            KPD_LOAD1(ya0, ya1, yb0, g3)
+        }
+        if (NG_ & 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            KPD_STEP1(xa0, xa1, xb0)
+        }
+#undef KPD_LOAD1
+#undef KPD_STEP1
+    }
+}
+
+// dot of row (tid / TPR) of an LDS tile (stride SA, 16-B aligned) with a vector over the first `chunks`
+// float4 chunks; TPR consecutive threads own one row.  Returns the full dot on all TPR lanes.
+template <int TPR>
+__device__ __forceinline__ float row_dot_chunks(const float *__restrict__ T, const float *__restrict__ w, int chunks, int tid) {
+    const int row = tid / TPR, q = tid % TPR;
+    const f32x4 *a = reinterpret_cast<const f32x4 *>(T + row * SA);
+    const f32x4 *wv = reinterpret_cast<const f32x4 *>(w);
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < (66 + TPR - 1) / TPR; ++i) {
+        const int c = q + TPR * i;
+        if (c < chunks) {
+            const f32x4 av = a[c], wq = wv[c];
+            s = fmaf(av[0], wq[0], s);
+            s = fmaf(av[1], wq[1], s);
+            s = fmaf(av[2], wq[2], s);
+            s = fmaf(av[3], wq[3], s);
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < TPR; o <<= 1) s += __shfl_xor(s, o);
+    return s;
+}
+
 // Output column 256 (the "+1" of hidden_nf + 1): dot of every A row with wx[k] = W[256][k] on the
 // VALU.  Four consecutive threads own row tid >> 2 and stride the 66 float4 chunks of the row.
 // Returns the full dot on all 4 lanes.

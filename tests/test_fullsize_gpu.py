@@ -1,0 +1,85 @@
+"""BASELINE.json full-size workloads on the GPU, checked through size-independent properties
+(E(3) equivariance, batch independence, determinism) plus an oracle spot check on a slice."""
+import math
+
+import pytest
+import torch
+
+from keypoint_diffusion_amd import graph as G
+from keypoint_diffusion_amd import synth
+from keypoint_diffusion_amd.dynamics import LigRecDynamics
+from keypoint_diffusion_amd.dynamics_gvp import LigRecDynamicsGVP
+from oracle import egnn as oegnn
+
+from . import util
+from .test_gvp_gpu import GVP_ALL_ATOM
+
+pytestmark = pytest.mark.gpu
+CUT = util.CUTOFFS_ALL_ATOM
+
+
+def _rot(seed):
+    q, _ = torch.linalg.qr(torch.randn(3, 3, generator=torch.Generator().manual_seed(seed)))
+    if torch.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    return q
+
+
+def _batch(B, n_rec, n_lig, v=None):
+    gs = synth.synth_complexes(n_rec, n_lig, 20, CUT, seed=4242)
+    return gs, util.fixed_encode(G.batch(gs), n_vec=v)
+
+
+def test_c2_full_batch_properties(cuda):
+    """configs[1]: egnn_all_atom, B = 64 x (300, 25)."""
+    B = 64
+    gs, g = _batch(B, [300] * B, [25] * B)
+    model = synth.fill_state_dict_(LigRecDynamics(10, 10, graph_cutoffs=CUT, **util.EGNN_C2), 0).eval()
+    t = torch.linspace(0.05, 1.0, B)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(cuda)
+    gd = g.to(cuda)
+    with torch.no_grad():
+        h, x = model(gd, t.to(cuda), None)
+        h2, x2 = model(gd, t.to(cuda), None)
+    assert torch.equal(h, h2) and torch.equal(x, x2)                 # no atomics: bitwise reproducible
+    # oracle on the first two complexes only (batch independence makes the slice meaningful)
+    sub = util.to_obatch(util.fixed_encode(G.batch(gs[:2])))
+    rh, rx = oegnn.egnn_dynamics_forward(sd, dict(util.EGNN_C2, graph_cutoffs=CUT), sub, t[:2])
+    assert util.rel_err(h[:50].cpu(), rh) < 1e-4 and util.rel_err(x[:50].cpu(), rx) < 1e-4
+    # E(3): rotate + translate every complex, eps_x rotates, eps_h is unchanged
+    R, shift = _rot(3).to(cuda), torch.tensor([4.0, -7.0, 2.5], device=cuda)
+    for nt in ('lig', 'kp'):
+        gd.nodes[nt].data['x_0'] = gd.nodes[nt].data['x_0'] @ R.T + shift
+    with torch.no_grad():
+        hr, xr = model(gd, t.to(cuda), None)
+    assert util.rel_err(hr, h) < 1e-4
+    assert util.rel_err(xr, x @ R.T) < 1e-4
+
+
+def test_c5_ragged_gvp_properties(cuda):
+    """configs[4] shape on one GPU: gvp_all_atom, ragged pockets 150-600 atoms, ligands 15-35 atoms."""
+    gen = torch.Generator().manual_seed(9)
+    B = 24
+    n_rec = torch.randint(150, 601, (B,), generator=gen).tolist()
+    n_lig = torch.randint(15, 36, (B,), generator=gen).tolist()
+    gs, g = _batch(B, n_rec, n_lig, v=16)
+    model = synth.fill_state_dict_(LigRecDynamicsGVP(10, 10, graph_cutoffs=CUT, **GVP_ALL_ATOM), 1).eval().to(cuda)
+    t = torch.linspace(0.1, 1.0, B).to(cuda)
+    gd = g.to(cuda)
+    with torch.no_grad():
+        h, x = model(gd, t, None)
+        # batch independence: complex 5 alone
+        i = 5
+        g1 = util.fixed_encode(G.batch([gs[i]]), n_vec=16).to(cuda)
+        h1, x1 = model(g1, t[i:i + 1], None)
+    off = sum(n_lig[:i])
+    assert util.rel_err(h1, h[off:off + n_lig[i]]) < 1e-5 and util.rel_err(x1, x[off:off + n_lig[i]]) < 1e-5
+    R, shift = _rot(5).to(cuda), torch.tensor([-3.0, 1.0, 8.0], device=cuda)
+    for nt in ('lig', 'kp'):
+        gd.nodes[nt].data['x_0'] = gd.nodes[nt].data['x_0'] @ R.T + shift
+    with torch.no_grad():
+        hr, xr = model(gd, t, None)
+    assert torch.isfinite(h).all() and torch.isfinite(x).all()
+    assert util.rel_err(hr, h) < 1e-4
+    assert util.rel_err(xr, x @ R.T) < 1e-4
