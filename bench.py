@@ -41,17 +41,41 @@ EDGE_ALGO_FLOP_PER_EDGE = 2 * (515 * 257 + 257 * 257) * 2 + 4 * 257
 EDGE_ALGO_BYTES_PER_EDGE = 4 * 257 + 16          # gathered row + coords + index
 
 
-def build_model(device):
-    model = KeypointDiffusion(10, 10, None, n_timesteps=N_TIMESTEPS, architecture='egnn', rec_encoder_type='fixed',
-                              graph_config=dict(n_keypoints=20, graph_cutoffs=CUTOFFS), dynamics_config=DYNAMICS,
-                              rec_encoder_config={}, precision=1e-5)
+# secondary workloads (BASELINE.json configs[2] and configs[4]); the JSON contract line is always configs[1]
+GVP_DYN = dict(vector_size=16, n_convs=6, n_hidden_scalars=256, message_norm=10.0, update_kp=True, ll_k=0, kl_k=7,
+               n_message_gvps=3, n_update_gvps=2, n_noise_gvps=4, dropout=0.1)
+GVP_ENC = dict(out_scalar_size=128, n_message_gvps=3, n_update_gvps=2, vector_size=16, n_rr_convs=4, n_rk_convs=2,
+               message_norm=10.0, k_closest=5, kp_rad=0, dropout=0.1)
+WORKLOADS = {
+    'egnn_all_atom': dict(arch='egnn', enc='fixed', dyn=DYNAMICS, n_kp=20, cutoffs=CUTOFFS),
+    'gvp_40kp': dict(arch='gvp', enc='learned', dyn=GVP_DYN, n_kp=40, cutoffs=dict(CUTOFFS, kl=8, ll=6.0)),
+    'gvp_all_atom': dict(arch='gvp', enc='fixed', dyn=dict(GVP_DYN, message_norm='mean'), n_kp=20, cutoffs=CUTOFFS),
+}
+
+
+def build_model(device, workload='egnn_all_atom'):
+    w = WORKLOADS[workload]
+    rec_cfg = dict(GVP_ENC) if w['arch'] == 'gvp' else {}
+    if w['enc'] == 'learned':
+        rec_cfg['in_scalar_size'] = 10
+    model = KeypointDiffusion(10, 128 if w['enc'] == 'learned' else 10, None, n_timesteps=N_TIMESTEPS,
+                              architecture=w['arch'], rec_encoder_type=w['enc'],
+                              graph_config=dict(n_keypoints=w['n_kp'], graph_cutoffs=w['cutoffs']),
+                              dynamics_config=w['dyn'], rec_encoder_config=rec_cfg, precision=1e-5)
     synth.fill_state_dict_(model, seed=0)
     return model.eval().to(device)
 
 
-def build_batch(model, B, n_rec, n_lig, seed, device):
-    gs = synth.synth_complexes([n_rec] * B, [n_lig] * B, 20, CUTOFFS, seed=seed)
-    g = model.encode_receptors(G.batch(gs))          # fixed encoder: kp := rec, kk := rr
+def build_batch(model, B, n_rec, n_lig, seed, device, workload='egnn_all_atom'):
+    w = WORKLOADS[workload]
+    if isinstance(n_rec, int):
+        n_rec, n_lig = [n_rec] * B, [n_lig] * B
+    gs = synth.synth_complexes(n_rec, n_lig, w['n_kp'], w['cutoffs'], seed=seed)
+    g = G.batch(gs)
+    if w['enc'] == 'learned':
+        g = g.to(device)                             # the GVP encoder runs on the GPU (once per pocket)
+    with torch.no_grad():
+        g = model.encode_receptors(g)                # fixed encoder: kp := rec, kk := rr
     return g.to(device)
 
 
@@ -97,6 +121,9 @@ def main():
     ap.add_argument('--n-rec', type=int, default=300)
     ap.add_argument('--n-lig', type=int, default=25)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--workload', default='egnn_all_atom', choices=list(WORKLOADS),
+                    help='egnn_all_atom = BASELINE.json configs[1] (the contract line); the others are secondary')
+    ap.add_argument('--ragged', action='store_true', help='pockets 150-600 atoms, ligands 15-35 atoms (configs[4] shape)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -104,21 +131,35 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the hot path has no CPU implementation')
+    # KPD_BENCH_SHARE_GPU=1 (functional rehearsal on a one-GPU box only): every rank uses cuda:0 and the
+    # process group runs over gloo, because RCCL refuses two ranks on one device
+    share = os.environ.get('KPD_BENCH_SHARE_GPU') == '1'
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=device)
+        if share:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=device)
     if args.gpus != world:
         print(f'[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}', file=sys.stderr)
 
     torch.manual_seed(1000 + rank)
-    model = build_model(device)
+    model = build_model(device, args.workload)
     B = args.batch
-    g = build_batch(model, B, args.n_rec, args.n_lig, seed=1234 + rank * B, device=device)
+    n_rec, n_lig = args.n_rec, args.n_lig
+    if args.ragged:
+        gen = torch.Generator().manual_seed(77 + rank)
+        n_rec = torch.randint(150, 601, (B,), generator=gen).tolist()
+        n_lig = torch.randint(15, 36, (B,), generator=gen).tolist()
+    g = build_batch(model, B, n_rec, n_lig, seed=1234 + rank * B, device=device, workload=args.workload)
     bidx = G.get_batch_idxs(g)
     eng = model.dynamics.engine()
+    is_egnn = args.workload == 'egnn_all_atom'
     ones = torch.ones(B, device=device)
     # Random-init weights do not denoise: left to itself the chain drives the ligand atoms apart and
     # the lig-lig radius graph empties within ~20 steps, which would shrink the measured work.  Every
@@ -139,7 +180,8 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-        eng.profile(True)
+        if is_egnn:
+            eng.profile(True)
         t0 = time.perf_counter()
         for i in range(args.steps):
             step(args.warmup + i)
@@ -151,12 +193,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+    if not is_egnn:
+        if rank == 0:
+            print(json.dumps({'metric': 'denoising steps/sec', 'value': world * args.steps / elapsed, 'unit': 'steps/s',
+                              'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                              'ms_per_step': 1e3 * elapsed / args.steps, 'dtype': 'f32', 'data': 'synthetic',
+                              'config': {'workload': args.workload + (' ragged 150-600/15-35' if args.ragged else ''),
+                                         'batch_per_gpu': B, 'n_kp_total': g.num_nodes('kp'), 'n_lig_total': g.num_nodes('lig'),
+                                         'n_kk': g.num_edges('kk')},
+                              'complex_steps_per_s': world * args.steps / elapsed * B}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     edge_ms, edge_launches = eng.profile_read()
     eng.profile(False)
     counts = eng.last_counts()
 
     if dist is not None:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device='cpu' if share else device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

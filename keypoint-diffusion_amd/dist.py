@@ -36,9 +36,10 @@ def shard_complexes(costs: Sequence[float], world: int) -> List[range]:
 def all_gather_ligands(g: G.HeteroBatch, group=None) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
     """Every rank returns the ligand positions / features of ALL ranks' complexes, rank-major."""
     world = dist.get_world_size(group)
-    dev = g.device
+    # RCCL moves device tensors; gloo (CPU tests, one-GPU rehearsals) wants host tensors
+    dev = g.device if dist.get_backend(group) == 'nccl' else torch.device('cpu')
     counts = g.batch_num_nodes('lig').to(dev).int()
-    x, h = g.nodes['lig'].data['x_0'], g.nodes['lig'].data['h_0']
+    x, h = g.nodes['lig'].data['x_0'].to(dev), g.nodes['lig'].data['h_0'].to(dev)
     F = h.shape[1]
     # 1) how many complexes / atoms everybody has
     meta = torch.tensor([counts.numel(), int(counts.max()) if counts.numel() else 0], device=dev, dtype=torch.int32)
