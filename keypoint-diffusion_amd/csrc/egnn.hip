@@ -353,7 +353,7 @@ extern "C" kpd_status kpd_egnn_reserve(kpd_egnn *m, int32_t max_B, int32_t max_n
     size_t bytes = 1 << 20;
     auto add = [&](size_t cnt, size_t sz) { bytes += ((cnt * sz + 255) & ~size_t(255)); };
     for (int nt = 0; nt < 2; ++nt) {
-        add((size_t)n[nt] * HS, 4); add((size_t)n[nt] * 3, 4); add((size_t)n[nt] * NSLOT * HS, 4);
+        add((size_t)(n[nt] + TM) * HS, 4); add((size_t)n[nt] * 3, 4); add((size_t)(n[nt] + TM) * NSLOT * HS, 4);
         add(n[nt], 4); add(max_B, 4);
     }
     for (int et = 0; et < 4; ++et) {
@@ -367,9 +367,9 @@ extern "C" kpd_status kpd_egnn_reserve(kpd_egnn *m, int32_t max_B, int32_t max_n
     KPD_TRY(m->ws.reserve(bytes));
     Arena &W = m->ws;
     for (int nt = 0; nt < 2; ++nt) {
-        m->h[nt] = W.take<float>((size_t)n[nt] * HS);
+        m->h[nt] = W.take<float>((size_t)(n[nt] + TM) * HS);          // + one tile: kernels touch whole tiles
         m->x[nt] = W.take<float>((size_t)n[nt] * 3);
-        m->P[nt] = W.take<float>((size_t)n[nt] * NSLOT * HS);
+        m->P[nt] = W.take<float>((size_t)(n[nt] + TM) * NSLOT * HS);
         m->bidx[nt] = W.take<int>(n[nt]);
         m->z[nt] = W.take<float>(max_B);
     }
@@ -438,23 +438,50 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
     const int *rowptr[4] = {m->lg.ll_rowptr, m->lg.kl_rowptr, m->lg.lk_rowptr, bt->kk_rowptr};
     const int n_layers = m->debug_layers >= 0 ? std::min(m->debug_layers, c.n_layers) : c.n_layers;
 
+    // fills the projection part of a fused node launch with the first-layer weights of layer `lw`
+    auto fill_proj = [&](NodeLayerArgs &na, int nt, const LayerW &W) {
+        na.do_proj = 1;
+        na.P = m->P[nt];
+        int k = 0;
+        for (int s = 0; s < NSLOT; ++s)
+            if (W.wp_p[nt][s]) {
+                na.wp[k] = W.wp_p[nt][s]; na.wx[k] = W.wx_p[nt][s]; na.bias[k] = W.b_p[nt][s]; na.slot[k] = s;
+                ++k;
+            }
+        na.n_slots = k;
+    };
+    static const bool fused_nodes = !(getenv("KPD_NODE_FUSED") && atoi(getenv("KPD_NODE_FUSED")) == 0);
+
     for (int li = 0; li < n_layers; ++li) {
         const LayerW &L = m->L[li];
-        ProjPair pp;
-        memset(&pp, 0, sizeof(pp));
-        for (int nt = 0; nt < 2; ++nt) {
-            ProjArgs &pa = pp.nt[nt];
-            pa.h = m->h[nt]; pa.n = n[nt]; pa.P = m->P[nt];
-            int k = 0;
-            for (int s = 0; s < NSLOT; ++s)
-                if (L.wp_p[nt][s]) {
-                    pa.wp[k] = L.wp_p[nt][s]; pa.wx[k] = L.wx_p[nt][s]; pa.bias[k] = L.b_p[nt][s]; pa.slot[k] = s;
-                    ++k;
+        if (!fused_nodes || li == 0) {
+            if (fused_nodes) {
+                NodeLayerPair lp;
+                memset(&lp, 0, sizeof(lp));
+                for (int nt = 0; nt < 2; ++nt) {
+                    lp.nt[nt].u.n = n[nt]; lp.nt[nt].u.h = m->h[nt];
+                    fill_proj(lp.nt[nt], nt, L);
                 }
-            pp.n_slots[nt] = k;
+                lp.tiles0 = cdiv(n[0], TN);
+                KPD_TRY(launch_node_layer(lp, st));
+            } else {
+                ProjPair pp;
+                memset(&pp, 0, sizeof(pp));
+                for (int nt = 0; nt < 2; ++nt) {
+                    ProjArgs &pa = pp.nt[nt];
+                    pa.h = m->h[nt]; pa.n = n[nt]; pa.P = m->P[nt];
+                    int k = 0;
+                    for (int s = 0; s < NSLOT; ++s)
+                        if (L.wp_p[nt][s]) {
+                            pa.wp[k] = L.wp_p[nt][s]; pa.wx[k] = L.wx_p[nt][s]; pa.bias[k] = L.b_p[nt][s]; pa.slot[k] = s;
+                            ++k;
+                        }
+                    pp.n_slots[nt] = k;
+                }
+                pp.tiles0 = cdiv(n[0], TM);
+                KPD_TRY(launch_node_proj(pp, st));
+            }
         }
-        pp.tiles0 = cdiv(n[0], TM);
-        KPD_TRY(launch_node_proj(pp, st));
         EdgeArgs ea;
         memset(&ea, 0, sizeof(ea));
         ea.meta = m->meta;
@@ -478,10 +505,7 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
             KPD_HIP(hipEventRecord(m->prof_ev[m->prof_used + 1], st));
             m->prof_used += 2;
         }
-        NodePair np;
-        memset(&np, 0, sizeof(np));
-        for (int nt = 0; nt < m->n_upd; ++nt) {
-            NodeArgs &na = np.nt[nt];
+        auto fill_update = [&](NodeArgs &na, int nt) {
             na.n = n[nt]; na.h = m->h[nt]; na.x = m->x[nt]; na.bidx = m->bidx[nt]; na.z = m->z[nt];
             int k = 0;
             for (int et = 0; et < m->n_et; ++et)
@@ -495,9 +519,31 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
             na.wp_a = L.wp_a[nt]; na.wx_a = L.wx_a[nt]; na.wp_b = L.wp_b[nt]; na.wx_b = L.wx_b[nt]; na.b0 = L.b0[nt];
             na.wp_2 = L.wp_2[nt]; na.wx_2 = L.wx_2[nt]; na.b2 = L.b2[nt]; na.ln_w = L.ln_w[nt]; na.ln_b = L.ln_b[nt];
             na.norm = c.norm;
+        };
+        if (fused_nodes) {
+            NodeLayerPair lp;
+            memset(&lp, 0, sizeof(lp));
+            const bool more = li + 1 < n_layers;
+            for (int nt = 0; nt < 2; ++nt) {
+                NodeLayerArgs &na = lp.nt[nt];
+                na.u.n = n[nt]; na.u.h = m->h[nt];
+                if (nt < m->n_upd) {
+                    fill_update(na.u, nt);
+                    na.do_update = 1;
+                }
+                if (more) fill_proj(na, nt, m->L[li + 1]);
+                if (!na.do_update && !na.do_proj) na.u.n = 0;          // nothing to do for this node type
+            }
+            lp.tiles0 = cdiv(lp.nt[0].u.n, TN);
+            lp.stamps = m->stamps ? m->stamps + 16 : nullptr;
+            KPD_TRY(launch_node_layer(lp, st));
+        } else {
+            NodePair np;
+            memset(&np, 0, sizeof(np));
+            for (int nt = 0; nt < m->n_upd; ++nt) fill_update(np.nt[nt], nt);
+            np.tiles0 = cdiv(n[0], TM);
+            KPD_TRY(launch_node_update(np, st));
         }
-        np.tiles0 = cdiv(n[0], TM);
-        KPD_TRY(launch_node_update(np, st));
     }
     KPD_TRY(launch_decode(m->h[NT_LIG], m->x[NT_LIG], bt->lig_x, bt->n_lig, c.atom_nf, 2 * c.atom_nf, m->de_W0, m->de_b0,
                           m->de_W1, m->de_b1, eps_h, eps_x, st));
@@ -519,12 +565,12 @@ extern "C" kpd_status kpd_egnn_debug_state(kpd_egnn *m, const char *what, float 
         m->debug_layers = atoi(w.c_str() + 7);
         return KPD_OK;
     } else if (w == "stamps=1") {            // start accumulating per-phase cycle sums of the edge kernel
-        if (!m->stamps) KPD_HIP(hipMalloc(reinterpret_cast<void **>(&m->stamps), 16 * sizeof(unsigned long long)));
-        KPD_HIP(hipMemsetAsync(m->stamps, 0, 16 * sizeof(unsigned long long), st));
+        if (!m->stamps) KPD_HIP(hipMalloc(reinterpret_cast<void **>(&m->stamps), 32 * sizeof(unsigned long long)));
+        KPD_HIP(hipMemsetAsync(m->stamps, 0, 32 * sizeof(unsigned long long), st));
         return KPD_OK;
     } else if (w == "stamps") {              // read them back (as 32 floats: lo/hi 24-bit split is avoided by copying raw)
-        KPD_REQUIRE(m->stamps && n_floats >= 32, KPD_ERR_INVALID, "stamps not enabled or buffer < 32 floats");
-        KPD_HIP(hipMemcpyAsync(out, m->stamps, 16 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
+        KPD_REQUIRE(m->stamps && n_floats >= 64, KPD_ERR_INVALID, "stamps not enabled or buffer < 64 floats");
+        KPD_HIP(hipMemcpyAsync(out, m->stamps, 32 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
         return KPD_OK;
     }
     KPD_REQUIRE(src, KPD_ERR_INVALID, "unknown debug tap '%s'", what);

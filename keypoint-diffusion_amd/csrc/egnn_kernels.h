@@ -27,6 +27,7 @@ struct ProjPair {
     ProjArgs nt[2];
     int tiles0;                     // workgroups (64-node tiles) of nt[0]
     int n_slots[2];
+    int slots_per_block;            // consecutive slots one workgroup computes from its resident A tile
 };
 
 struct EdgeArgs {
@@ -64,6 +65,26 @@ struct NodeArgs {
     int norm;
 };
 
+// Fused node kernel (32-node tiles): [update of layer i] -> [first-layer projections of layer i + 1].
+struct NodeLayerArgs {
+    NodeArgs u;                     // update part (do_update) -- u.n / u.h are always valid
+    int do_update, do_proj;
+    float *P;                       // [n][NSLOT][HS]
+    int n_slots;
+    const float *wp[NSLOT], *wx[NSLOT], *bias[NSLOT];
+    int slot[NSLOT];
+};
+
+struct NodeLayerPair {
+    NodeLayerArgs nt[2];
+    int tiles0;                     // 32-node tiles of nt[0]
+    unsigned long long *stamps;     // [16] phase-cycle sums (diagnostics only, null in production)
+    int dbg;                        // ablation switches for timing experiments (KPD_NODE_ABLATE), 0 in production
+};
+
+constexpr int TN = 32;              // rows per workgroup of the fused node kernel
+constexpr int NODE_LAYER_LDS_BYTES = TN * SA * 4 + 3 * TN * 4;
+
 struct NodePair {
     NodeArgs nt[2];                 // nt[1].n == 0 when only one node type is updated
     int tiles0;
@@ -81,5 +102,6 @@ kpd_status launch_decode(const float *h, const float *x, const float *x0, int n,
 kpd_status launch_node_proj(const ProjPair &p, hipStream_t st);
 kpd_status launch_egnn_edge(const EdgeArgs &a, int tile_cap, hipStream_t st);
 kpd_status launch_node_update(const NodePair &p, hipStream_t st);
+kpd_status launch_node_layer(const NodeLayerPair &p, hipStream_t st);
 
 }  // namespace kpd

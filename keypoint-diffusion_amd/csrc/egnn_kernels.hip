@@ -153,47 +153,47 @@ __global__ __launch_bounds__(256, 2) void k_node_proj(ProjPair p) {
     float *A = smem;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int which = blockIdx.x >= p.tiles0 ? 1 : 0;
-    const int s = blockIdx.y;
-    if (s >= p.n_slots[which]) return;
     const ProjArgs &a = p.nt[which];
+    const int s0 = blockIdx.y * p.slots_per_block;
+    if (s0 >= p.n_slots[which]) return;
+    const int s1 = min(s0 + p.slots_per_block, p.n_slots[which]);
     const int node0 = (blockIdx.x - (which ? p.tiles0 : 0)) * TM;
 
+    // h is padded to whole tiles (rows past n are zero), so the tile is copied unconditionally
+#pragma unroll 8
     for (int rr = 0; rr < 16; ++rr) {
-        const int r = wave * 16 + rr, v = node0 + r;
-        f32x4 val = {0.f, 0.f, 0.f, 0.f}, val2 = {0.f, 0.f, 0.f, 0.f};
-        if (v < a.n) {
-            const f32x4 *src = reinterpret_cast<const f32x4 *>(a.h + (size_t)v * HS);
-            val = src[lane];
-            if (lane < 2) val2 = src[64 + lane];
-        }
-        *reinterpret_cast<f32x4 *>(A + r * SA + 4 * lane) = val;
-        if (lane < 2) *reinterpret_cast<f32x4 *>(A + r * SA + 256 + 4 * lane) = val2;
+        const int r = wave * 16 + rr;
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(a.h + (size_t)(node0 + r) * HS);
+        *reinterpret_cast<f32x4 *>(A + r * SA + 4 * lane) = src[lane];
+        if (lane < 2) *reinterpret_cast<f32x4 *>(A + r * SA + 256 + 4 * lane) = src[64 + lane];
     }
     lds_barrier();
 
-    f32x16 acc[2][2];
-    acc_zero(acc);
-    gemm_rows64(A, a.wp[s], acc, wave, lane);
-    const float ex = extra_col(A, a.wx[s], tid);
-
-    const float *bias = a.bias[s];
-    float *out = a.P + (size_t)a.slot[s] * HS;
     const size_t prow = (size_t)NSLOT * HS;
+    for (int s = s0; s < s1; ++s) {
+        f32x16 acc[2][2];
+        acc_zero(acc);
+        gemm_rows64(A, a.wp[s], acc, wave, lane);
+        const float ex = extra_col(A, a.wx[s], tid);
+        const float *bias = a.bias[s];
+        // P is padded to whole tiles: rows past n are written unconditionally (never read back);
+        // addressing = wave-uniform base (+ compile-time row term) + one 32-bit lane offset
+        char *obase = reinterpret_cast<char *>(a.P + ((size_t)node0 * NSLOT + a.slot[s]) * HS);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int col = acc_col(nt, wave, lane);
-        const float b = bias ? bias[col] : 0.0f;
+        for (int nt = 0; nt < 2; ++nt) {
+            const int col = acc_col(nt, wave, lane);
+            const float b = bias ? bias[col] : 0.0f;
+            const unsigned lane_off = (unsigned)((4 * (lane >> 5)) * (int)prow + col) * 4u;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int v = node0 + acc_row(mt, reg, lane);
-                if (v < a.n) out[v * prow + col] = acc[mt][nt][reg] + b;
-            }
-    }
-    if ((tid & 3) == 0) {
-        const int v = node0 + (tid >> 2);
-        if (v < a.n) out[v * prow + 256] = ex + (bias ? bias[256] : 0.0f);
+                for (int reg = 0; reg < 16; ++reg) {
+                    const unsigned row_off = (unsigned)((32 * mt + (reg & 3) + 8 * (reg >> 2)) * (int)prow) * 4u;
+                    *reinterpret_cast<float *>(obase + row_off + lane_off) = acc[mt][nt][reg] + b;
+                }
+        }
+        if ((tid & 3) == 0)
+            *reinterpret_cast<float *>(obase + (unsigned)((tid >> 2) * (int)prow + 256) * 4u) = ex + (bias ? bias[256] : 0.0f);
     }
 }
 
@@ -591,15 +591,17 @@ __global__ __launch_bounds__(256, 2) void k_node_update(NodePair p) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int r = acc_row(mt, reg, lane), v = node0 + r;
-                const float res = v < a.n ? a.h[(size_t)v * HS + col] : 0.0f;
-                A[r * SA + col] = acc[mt][nt][reg] + bb + res;
-            }
+            for (int reg = 0; reg < 16; ++reg) A[acc_row(mt, reg, lane) * SA + col] = acc[mt][nt][reg] + bb;
     }
-    if ((tid & 3) == 0) {
-        const int r = tid >> 2, v = node0 + r;
-        A[r * SA + 256] = ex + a.b2[256] + (v < a.n ? a.h[(size_t)v * HS + 256] : 0.0f);
+    if ((tid & 3) == 0) A[(tid >> 2) * SA + 256] = ex + a.b2[256];
+    lds_barrier();
+    // residual h (row-wise, coalesced; h is padded to whole tiles, rows >= n read zeros)
+#pragma unroll 8
+    for (int rr = 0; rr < 16; ++rr) {
+        const int r = wave * 16 + rr;
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(a.h + (size_t)(node0 + r) * HS);
+        *reinterpret_cast<f32x4 *>(A + r * SA + 4 * lane) += src[lane];
+        if (lane == 0) A[r * SA + 256] += a.h[(size_t)(node0 + r) * HS + 256];
     }
     lds_barrier();
 
@@ -651,6 +653,246 @@ __global__ __launch_bounds__(256, 2) void k_node_update(NodePair p) {
     }
 }
 
+// ---- fused node kernel: update of layer i, then the first-layer projections of layer i + 1 ----------------
+// 32-node tiles (4 workgroups per CU) so that the 20 800 nodes of a C2 batch make 650 work items on 256
+// CUs instead of 325, and the updated h never leaves LDS between the update and the projections.
+__global__ __launch_bounds__(256, 3) void k_node_layer(NodeLayerPair p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *A = smem;
+    float *s_z = smem + TN * SA;
+    float *s_mean = s_z + TN;
+    float *s_rstd = s_mean + TN;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int which = blockIdx.x >= p.tiles0 ? 1 : 0;
+    const NodeLayerArgs &L = p.nt[which];
+    const NodeArgs &a = L.u;
+    const int node0 = (blockIdx.x - (which ? p.tiles0 : 0)) * TN;
+    constexpr int RPW = TN / 4;          // rows per wave in the copy loops
+    constexpr int TPR = 256 / TN;        // threads per row in the row-wise passes
+    unsigned long long t_prev_ = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+#define NL_STAMP(idx)                                                                      \
+    if (p.stamps && tid == 0) {                                                            \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                      \
+        atomicAdd(&p.stamps[idx], (unsigned long long)(now_ - t_prev_));                   \
+        t_prev_ = now_;                                                                    \
+    }
+
+    auto load_h = [&]() {
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int r = wave * RPW + rr, v = node0 + r;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f}, val2 = {0.f, 0.f, 0.f, 0.f};
+            if (v < a.n) {
+                const f32x4 *src = reinterpret_cast<const f32x4 *>(a.h + (size_t)v * HS);
+                val = src[lane];
+                if (lane < 2) val2 = src[64 + lane];
+            }
+            *reinterpret_cast<f32x4 *>(A + r * SA + 4 * lane) = val;
+            if (lane < 2) *reinterpret_cast<f32x4 *>(A + r * SA + 256 + 4 * lane) = val2;
+        }
+    };
+
+    f32x16 acc[2];
+    if (L.do_update) {
+        // coordinates: x' = x + x_neigh / z (dynamics.py:190-192, 206)
+        if (tid < TN) {
+            const int v = node0 + tid;
+            float z = 1.0f;
+            if (v < a.n) {
+                z = a.z[a.bidx[v]];
+                float sx = 0.f, sy = 0.f, sz = 0.f;
+                for (int i = 0; i < a.n_in; ++i) {
+                    const int lo = a.rowptr[i][v], hi = a.rowptr[i][v + 1];
+                    if (hi > lo) {
+                        const float *pm = a.xn_main[i] + (size_t)v * 4;
+                        sx += pm[0]; sy += pm[1]; sz += pm[2];
+                        for (int t = lo / TM + 1; t <= (hi - 1) / TM; ++t) {
+                            const float *q = a.xn_cont[i] + (size_t)t * 4;
+                            sx += q[0]; sy += q[1]; sz += q[2];
+                        }
+                    }
+                }
+                float *xv = a.x + (size_t)v * 3;
+                xv[0] += sx / z; xv[1] += sy / z; xv[2] += sz / z;
+            }
+            s_z[tid] = z;
+        }
+        // GEMM 1a: W[:, :257] . h
+        load_h();
+        lds_barrier();
+        NL_STAMP(0)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.0f;
+        gemm_rows32_t<NG, SA>(A, a.wp_a, acc, wave, lane);
+        float ex = row_dot_chunks<TPR>(A, a.wx_a, KP / 4, tid);
+        lds_barrier();
+        NL_STAMP(1)
+        // GEMM 1b: + W[:, 257:] . (h_neigh / z); h_neigh = sum of segment pieces over the incoming edge
+        // types in fixed order (multi_update_all cross_reducer='sum')
+#pragma unroll 2
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int r = wave * RPW + rr, v = node0 + r;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f}, val2 = {0.f, 0.f, 0.f, 0.f};
+            if (v < a.n) {
+                for (int i = 0; i < a.n_in; ++i) {
+                    const int lo = a.rowptr[i][v], hi = a.rowptr[i][v + 1];
+                    if (hi > lo) {
+                        const f32x4 *pm = reinterpret_cast<const f32x4 *>(a.hn_main[i] + (size_t)v * HS);
+                        val += pm[lane];
+                        if (lane < 2) val2 += pm[64 + lane];
+                        for (int t = lo / TM + 1; t <= (hi - 1) / TM; ++t) {
+                            const f32x4 *q = reinterpret_cast<const f32x4 *>(a.hn_cont[i] + (size_t)t * HS);
+                            val += q[lane];
+                            if (lane < 2) val2 += q[64 + lane];
+                        }
+                    }
+                }
+                const float z = s_z[r];
+                val /= z;
+                val2 /= z;
+            }
+            *reinterpret_cast<f32x4 *>(A + r * SA + 4 * lane) = val;
+            if (lane < 2) *reinterpret_cast<f32x4 *>(A + r * SA + 256 + 4 * lane) = val2;
+        }
+        lds_barrier();
+        NL_STAMP(2)
+        gemm_rows32_t<NG, SA>(A, a.wp_b, acc, wave, lane);
+        ex += row_dot_chunks<TPR>(A, a.wx_b, KP / 4, tid);
+        lds_barrier();
+        NL_STAMP(3)
+        // hidden = SiLU(. + b0) -> T (pad columns 257..263 stay 0 from the h_neigh tile)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int col = acc_col(nt, wave, lane);
+            const float bb = a.b0[col];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) A[acc_row32(reg, lane) * SA + col] = silu(acc[nt][reg] + bb);
+        }
+        if ((tid % TPR) == 0) A[(tid / TPR) * SA + 256] = silu(ex + a.b0[256]);
+        lds_barrier();
+        NL_STAMP(4)
+        // GEMM 2 + bias + residual (dynamics.py:201-203)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.0f;
+        gemm_rows32_t<NG, SA>(A, a.wp_2, acc, wave, lane);
+        ex = row_dot_chunks<TPR>(A, a.wx_2, KP / 4, tid);
+        lds_barrier();
+        NL_STAMP(5)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int col = acc_col(nt, wave, lane);
+            const float bb = a.b2[col];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) A[acc_row32(reg, lane) * SA + col] = acc[nt][reg] + bb;
+        }
+        if ((tid % TPR) == 0) A[(tid / TPR) * SA + 256] = ex + a.b2[256];
+        lds_barrier();
+        // residual h (row-wise, coalesced; the h array is padded to a whole tile, rows >= n read zeros)
+#pragma unroll 4
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int r = wave * RPW + rr;
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(a.h + (size_t)(node0 + r) * HS);
+            *reinterpret_cast<f32x4 *>(A + r * SA + 4 * lane) += src[lane];
+            if (lane == 0) A[r * SA + 256] += a.h[(size_t)(node0 + r) * HS + 256];
+        }
+        lds_barrier();
+        NL_STAMP(6)
+        // LayerNorm(257) (dynamics.py:81-87, 204), biased variance, eps = 1e-5
+        if (a.norm) {
+            const int row = tid / TPR, q = tid % TPR;
+            const float *tr = A + row * SA + q;
+            float sum = 0.0f;
+            for (int i = 0; i < 256 / TPR; ++i) sum += tr[TPR * i];
+            if (q == 0) sum += A[row * SA + 256];
+#pragma unroll
+            for (int o = 1; o < TPR; o <<= 1) sum += __shfl_xor(sum, o);
+            const float mean = sum * (1.0f / HW);
+            float var = 0.0f;
+            for (int i = 0; i < 256 / TPR; ++i) {
+                const float dlt = tr[TPR * i] - mean;
+                var = fmaf(dlt, dlt, var);
+            }
+            if (q == 0) {
+                const float dlt = A[row * SA + 256] - mean;
+                var = fmaf(dlt, dlt, var);
+            }
+#pragma unroll
+            for (int o = 1; o < TPR; o <<= 1) var += __shfl_xor(var, o);
+            if (q == 0) {
+                s_mean[row] = mean;
+                s_rstd[row] = 1.0f / sqrtf(var * (1.0f / HW) + 1e-5f);
+            }
+        }
+        lds_barrier();
+        NL_STAMP(7)
+        // normalise in place (the tile becomes the A operand of the projections) and write h' back
+#pragma unroll 2
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int r = wave * RPW + rr, v = node0 + r;
+            f32x4 val = *reinterpret_cast<const f32x4 *>(A + r * SA + 4 * lane);
+            float last = A[r * SA + 256];
+            if (a.norm) {
+                const float mean = s_mean[r], rstd = s_rstd[r];
+                const f32x4 w = reinterpret_cast<const f32x4 *>(a.ln_w)[lane];
+                const f32x4 b = reinterpret_cast<const f32x4 *>(a.ln_b)[lane];
+                val = (val - mean) * rstd * w + b;
+                last = (last - mean) * rstd * a.ln_w[256] + a.ln_b[256];
+            }
+            if (v >= a.n) {
+                val = f32x4{0.f, 0.f, 0.f, 0.f};
+                last = 0.0f;
+            }
+            *reinterpret_cast<f32x4 *>(A + r * SA + 4 * lane) = val;
+            const f32x4 t = {last, 0.f, 0.f, 0.f};
+            if (lane == 0) *reinterpret_cast<f32x4 *>(A + r * SA + 256) = t;
+            if (lane == 1) *reinterpret_cast<f32x4 *>(A + r * SA + 260) = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (v < a.n) {
+                f32x4 *dst = reinterpret_cast<f32x4 *>(a.h + (size_t)v * HS);
+                dst[lane] = val;
+                if (lane == 0) dst[64] = t;
+            }
+        }
+        lds_barrier();
+        NL_STAMP(8)
+    } else {
+        load_h();
+        lds_barrier();
+        NL_STAMP(0)
+    }
+
+    // first-layer projections of the next layer: P[node][slot] = W1[:, block] . h' (+ b1 on dst slots)
+    if (L.do_proj) {
+        const size_t prow = (size_t)NSLOT * HS;
+        for (int si = 0; si < L.n_slots; ++si) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.0f;
+            if (!(p.dbg & 1)) gemm_rows32_t<NG, SA>(A, L.wp[si], acc, wave, lane);
+            NL_STAMP(9)
+            if (p.dbg & 2) continue;
+            const float ex = row_dot_chunks<TPR>(A, L.wx[si], KP / 4, tid);
+            const float *bias = L.bias[si];
+            // P is padded to whole tiles, so rows past n are written unconditionally (never read back);
+            // addressing = wave-uniform base (+ compile-time row term) + one 32-bit lane offset
+            char *obase = reinterpret_cast<char *>(L.P + ((size_t)node0 * NSLOT + L.slot[si]) * HS);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int col = acc_col(nt, wave, lane);
+                const float b = bias ? bias[col] : 0.0f;
+                const unsigned lane_off = (unsigned)((4 * (lane >> 5)) * (int)prow + col) * 4u;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const unsigned row_off = (unsigned)(((reg & 3) + 8 * (reg >> 2)) * (int)prow) * 4u;
+                    *reinterpret_cast<float *>(obase + row_off + lane_off) = acc[nt][reg] + b;
+                }
+            }
+            if ((tid % TPR) == 0)
+                *reinterpret_cast<float *>(obase + (unsigned)((tid / TPR) * (int)prow + 256) * 4u) = ex + (bias ? bias[256] : 0.0f);
+            NL_STAMP(10)
+        }
+    }
+#undef NL_STAMP
+}
+
 // ---- launchers ----------------------------------------------------------------------------
 static bool g_attr_set = false;
 
@@ -661,6 +903,8 @@ kpd_status egnn_kernels_init() {
     KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_egnn_edge<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024));
     KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_egnn_edge<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024));
+    KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_layer), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024));
     KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_update),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, NODE_LDS_BYTES));
@@ -709,7 +953,10 @@ kpd_status launch_node_proj(const ProjPair &p, hipStream_t st) {
     const int tiles = p.tiles0 + cdiv(p.nt[1].n, TM);
     const int slots = std::max(p.n_slots[0], p.n_slots[1]);
     if (tiles == 0 || slots == 0) return KPD_OK;
-    hipLaunchKernelGGL(k_node_proj, dim3(tiles, slots), dim3(256), PROJ_LDS_BYTES, st, p);
+    static const int spb = getenv("KPD_PROJ_SPB") ? std::max(1, atoi(getenv("KPD_PROJ_SPB"))) : 2;
+    ProjPair q = p;
+    q.slots_per_block = spb;
+    hipLaunchKernelGGL(k_node_proj, dim3(tiles, cdiv(slots, spb)), dim3(256), PROJ_LDS_BYTES, st, q);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
 }
@@ -724,6 +971,19 @@ kpd_status launch_egnn_edge(const EdgeArgs &a, int tile_cap, hipStream_t st) {
         hipLaunchKernelGGL(k_egnn_edge<4>, dim3(8 * cdiv(tile_cap, 8)), dim3(256), EDGE_LDS_BYTES + pad, st, a);
     else
         hipLaunchKernelGGL(k_egnn_edge<8>, dim3(8 * cdiv(tile_cap, 8)), dim3(512), EDGE_LDS_BYTES + pad, st, a);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+kpd_status launch_node_layer(const NodeLayerPair &p, hipStream_t st) {
+    const int tiles = p.tiles0 + cdiv(p.nt[1].u.n, TN);
+    if (tiles == 0) return KPD_OK;
+    // KPD_NODE_LDS_PAD (diagnostics): extra dynamic LDS to lower the number of co-resident workgroups
+    static const int pad = getenv("KPD_NODE_LDS_PAD") ? atoi(getenv("KPD_NODE_LDS_PAD")) : 0;
+    static const int dbg = getenv("KPD_NODE_ABLATE") ? atoi(getenv("KPD_NODE_ABLATE")) : 0;
+    NodeLayerPair q = p;
+    q.dbg = dbg;
+    hipLaunchKernelGGL(k_node_layer, dim3(tiles), dim3(256), NODE_LAYER_LDS_BYTES + pad, st, q);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
 }

@@ -134,6 +134,56 @@ __device__ __forceinline__ void gemm_rows64_rt(const float *__restrict__ A, cons
     }
 }
 
+// ---- 32-row tile variant (node kernels: 4 workgroups per CU, finer work items) --------------------------
+// acc[nt] += A[32 x 8 NG_] * W[.. x (this wave's 64 columns)]; one A read + two B loads per 8 MFMAs.
+template <int NG_, int SA_>
+__device__ __forceinline__ void gemm_rows32_t(const float *__restrict__ A, const float *__restrict__ Wp,
+                                              f32x16 (&acc)[2], int wave, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+    const float *a0p = A + r * SA_ + 4 * h;
+    const f32x4 *bp = reinterpret_cast<const f32x4 *>(Wp) + (wave * 64 + lane) * 2;
+    // A k-group is only 8 MFMAs (512 cycles) here, less than an L2 round trip under load, so the operand
+    // ring is four sets deep: the set consumed at group g is refilled for group g + 4, i.e. every refill has
+    // three groups (~1500 cycles) to land.
+    f32x4 a0[4], b0[4], b1[4];
+#define KPD_LOAD32(S, G)                                                  \
+    a0[S] = *reinterpret_cast<const f32x4 *>(a0p + 8 * (G));              \
+    b0[S] = bp[(G) * 512];                                                \
+    b1[S] = bp[(G) * 512 + 1];
+#define KPD_STEP32(S)                                                                             \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[S][j], b0[S][j], acc[0], 0, 0, 0);       \
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[S][j], b1[S][j], acc[1], 0, 0, 0);       \
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int g = i < NG_ ? i : NG_ - 1;
+        KPD_LOAD32(i, g)
+    }
+    constexpr int QUADS = NG_ / 4;
+#pragma unroll 1
+    for (int q = 0; q < QUADS; ++q) {
+        const int g = 4 * q;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_barrier(0);
+            KPD_STEP32(i)
+            __builtin_amdgcn_sched_barrier(0);
+            const int gn = g + 4 + i < NG_ ? g + 4 + i : NG_ - 1;
+            KPD_LOAD32(i, gn)
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < (NG_ & 3); ++i) {
+        __builtin_amdgcn_sched_barrier(0);
+        KPD_STEP32(i)
+    }
+#undef KPD_LOAD32
+#undef KPD_STEP32
+}
+
+__device__ __forceinline__ int acc_row32(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
 // ---- wave-count-generic variants ------------------------------------------------------------------
 // NW waves share the 256 output columns: NW = 4 -> 64 columns (2 column tiles) per wave, NW = 8 -> 32
 // columns (1 column tile) per wave.  Same packed weight buffer: wave w of 8 reads column tile (w & 1) of

@@ -19,9 +19,8 @@ with torch.no_grad():
     for _ in range(n):
         model.dynamics(g, t, None)
     torch.cuda.synchronize()
-    raw = eng.debug('stamps', 32).view(torch.int64)[:11].cpu().tolist() if False else eng.debug('stamps', 32)
-    raw = raw.view(torch.int32).view(-1)  # reinterpret float buffer as ints
-    vals = raw.view(torch.int64)[:11].cpu().tolist()
+    raw = eng.debug('stamps', 64).view(torch.int32).view(-1).view(torch.int64).cpu().tolist()
+    vals, nvals = raw[:11], raw[16:27]
 c = eng.last_counts()
 tiles = c['tiles'] * 6 * n
 tot = sum(vals)
@@ -29,3 +28,10 @@ print('tiles', c['tiles'], 'per-tile cycles (s_memtime ticks = 100 MHz? see note
 for nm, v in zip(names, vals):
     print(f'  {nm:12s} {v / tiles:10.1f}  {100 * v / tot:5.1f} %')
 print('  total        %10.1f' % (tot / tiles))
+
+nn = ['load h/x', 'GEMM 1a', 'gather hn', 'GEMM 1b', 'T-store', 'GEMM 2', 'resid', 'LN', 'writeback', 'proj GEMMs', 'proj store']
+ntiles = (20800 // 32 + 1) * 5 * n          # fused launches with update+proj in the timed forwards (approx.)
+tot = sum(nvals)
+print('node_layer per-tile cycles (approx. per fused launch tile):')
+for nm, v in zip(nn, nvals):
+    print(f'  {nm:12s} {v / ntiles:10.1f}  {100 * v / max(tot,1):5.1f} %')
