@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "egnn_kernels.h"
+#include "mfma_core.h"
 
 using namespace kpd;
 
@@ -280,6 +281,7 @@ extern "C" kpd_status kpd_egnn_load_weight(kpd_egnn *m, const char *name, const 
             if (is_w) {
                 KPD_TRY(expect_shape(name, shape, ndim, {1, HW}));
                 KPD_TRY(copy_pad(w, HW, L.watt[et], ATT_BIAS_AT, st));     // keeps [260] (bias) intact
+                KPD_TRY(scale_inplace(L.watt[et], HW, 1.0f / SILU_C, st)); // consumes c * m (pre-scaled SiLU)
             } else {
                 KPD_TRY(expect_shape(name, shape, ndim, {1}));
                 KPD_TRY(copy_pad(w, 1, L.watt[et] + ATT_BIAS_AT, 1, st));
@@ -295,9 +297,16 @@ extern "C" kpd_status kpd_egnn_load_weight(kpd_egnn *m, const char *name, const 
                     KPD_TRY(pack_gemm_weight(w, HW, ld, 0, HW, L.wp_p[snt][ss], L.wx_p[snt][ss], st));
                     KPD_TRY(pack_gemm_weight(w, HW, ld, HW, HW, L.wp_p[dnt][ds], L.wx_p[dnt][ds], st));
                     KPD_TRY(copy_col_pad(w, HW, ld, 2 * HW, var ? L.wr_c[et] : L.wr_e[et], HS, st));
+                    // the first Linear produces c * (pre-activation): see silu_pre() in mfma_core.h
+                    KPD_TRY(scale_inplace(L.wp_p[snt][ss], WP_FLOATS, SILU_C, st));
+                    KPD_TRY(scale_inplace(L.wx_p[snt][ss], KP, SILU_C, st));
+                    KPD_TRY(scale_inplace(L.wp_p[dnt][ds], WP_FLOATS, SILU_C, st));
+                    KPD_TRY(scale_inplace(L.wx_p[dnt][ds], KP, SILU_C, st));
+                    KPD_TRY(scale_inplace(var ? L.wr_c[et] : L.wr_e[et], HS, SILU_C, st));
                 } else {
                     KPD_TRY(expect_shape(name, shape, ndim, {HW}));
                     KPD_TRY(copy_pad(w, HW, L.b_p[dnt][ds], HS, st));
+                    KPD_TRY(scale_inplace(L.b_p[dnt][ds], HS, SILU_C, st));
                 }
             } else if (tk[5] == "2") {
                 if (is_w) {
@@ -310,6 +319,7 @@ extern "C" kpd_status kpd_egnn_load_weight(kpd_egnn *m, const char *name, const 
             } else {   // coord_mlp.<et>.4.weight
                 KPD_TRY(expect_shape(name, shape, ndim, {1, HW}));
                 KPD_TRY(copy_pad(w, HW, L.w3[et], HS, st));
+                KPD_TRY(scale_inplace(L.w3[et], HS, 1.0f / SILU_C, st));
             }
         }
     }
@@ -325,6 +335,14 @@ extern "C" kpd_status kpd_egnn_commit(kpd_egnn *m) {
             set_error("weight '%s' was never loaded (%zu of %zu loaded)", n.c_str(), m->loaded.size(), m->expected.size());
             return KPD_ERR_WEIGHTS;
         }
+    // the bias of edge_mlp.2 / coord_mlp.2 rides in the GEMM as weight row BIAS_K against a constant-1 column of
+    // the A tile (scaled by c for the pre-scaled SiLU); patched here because weight and bias arrive separately
+    for (LayerW &L : m->L)
+        for (int et = 0; et < m->n_et; ++et) {
+            KPD_TRY(patch_bias_row(L.wp_e[et], L.wx_e[et], L.b_e[et], SILU_C, BIAS_K, nullptr));
+            KPD_TRY(patch_bias_row(L.wp_c[et], L.wx_c[et], L.b_c[et], SILU_C, BIAS_K, nullptr));
+        }
+    KPD_HIP(hipDeviceSynchronize());
     m->committed = true;
     return KPD_OK;
 }

@@ -235,8 +235,8 @@ __device__ __forceinline__ void build_edge_A(const EdgeSmem &s, const float *__r
         const float d = s.d[r];
         const f32x4 *ps = reinterpret_cast<const f32x4 *>(Ps + s.src[r] * prow);
         const f32x4 *pd = reinterpret_cast<const f32x4 *>(Pd + s.dst[r] * prow);
-        f32x4 v = ps[lane] + pd[lane] + d * w0;
-        v[0] = silu(v[0]); v[1] = silu(v[1]); v[2] = silu(v[2]); v[3] = silu(v[3]);
+        f32x4 v = ps[lane] + pd[lane] + d * w0;             // = c * pre-activation (P, w_r carry c)
+        v[0] = silu_pre(v[0]); v[1] = silu_pre(v[1]); v[2] = silu_pre(v[2]); v[3] = silu_pre(v[3]);
         *reinterpret_cast<f32x4 *>(s.A + r * SA + 4 * lane) = v;
     }
     // columns 256..263 of the wave's rows in one pass (lane = row * 4 + chunk): keeping this out of the
@@ -248,27 +248,30 @@ __device__ __forceinline__ void build_edge_A(const EdgeSmem &s, const float *__r
             const f32x4 *ps = reinterpret_cast<const f32x4 *>(Ps + s.src[r] * prow);
             const f32x4 *pd = reinterpret_cast<const f32x4 *>(Pd + s.dst[r] * prow);
             f32x4 u = ps[64 + c] + pd[64 + c] + s.d[r] * w1;
-            u[0] = silu(u[0]); u[1] = silu(u[1]); u[2] = silu(u[2]); u[3] = silu(u[3]);
+            u[0] = silu_pre(u[0]); u[1] = silu_pre(u[1]); u[2] = silu_pre(u[2]); u[3] = silu_pre(u[3]);
+            if (c == 0) u[BIAS_K - 256] = 1.0f;           // constant-1 column: the GEMM adds the bias row itself
             *reinterpret_cast<f32x4 *>(s.A + r * SA + 256 + 4 * c) = u;
         }
     }
 }
 
-// T[row][col] = SiLU(acc + b[col]) for the 257 valid columns.
-template <int NW>
+// T[row][col] = SiLU(acc + b[col]) for the 257 valid columns.  PRE: the accumulator already holds
+// c * (W a + b) (bias row in the GEMM, pre-scaled SiLU) and T receives c * SiLU(.).
+template <int NW, bool PRE>
 __device__ __forceinline__ void store_T_silu_w(float *T, const f32x16 (&acc)[2][WaveCols<NW>::NT], float ex,
                                                const float *__restrict__ b, int tid, int wave, int lane) {
     constexpr int TPR = NW;      // threads per row = 64 NW / 64
 #pragma unroll
     for (int nt = 0; nt < WaveCols<NW>::NT; ++nt) {
         const int col = acc_col_w<NW>(nt, wave, lane);
-        const float bb = b[col];
+        const float bb = PRE ? 0.0f : b[col];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) T[acc_row(mt, reg, lane) * SA + col] = silu(acc[mt][nt][reg] + bb);
+            for (int reg = 0; reg < 16; ++reg)
+                T[acc_row(mt, reg, lane) * SA + col] = PRE ? silu_pre(acc[mt][nt][reg]) : silu(acc[mt][nt][reg] + bb);
     }
-    if ((tid % TPR) == 0) T[(tid / TPR) * SA + 256] = silu(ex + b[256]);
+    if ((tid % TPR) == 0) T[(tid / TPR) * SA + 256] = PRE ? silu_pre(ex) : silu(ex + b[256]);
 }
 
 // Phase stamps (diagnostic builds of the timeline only; a.stamps is null in production): wave 0 of
@@ -360,7 +363,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
     ex = row_dot_chunks<TPR>(s.A, a.wx_e[et], KP / 4, tid);
     lds_barrier();
     KPD_STAMP(2)
-    store_T_silu_w<NW>(s.A, acc, ex, a.b_e[et], tid, wave, lane);
+    store_T_silu_w<NW, true>(s.A, acc, ex, a.b_e[et], tid, wave, lane);
     lds_barrier();
     KPD_STAMP(3)
     {
@@ -368,7 +371,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
         const int row = tid / TPR;
         if ((tid % TPR) == 0) {
             dot = fmaf(s.A[row * SA + 256], s.wv[256], dot);
-            s.att[row] = row < ne ? sigmoidf_(dot + s.wv[ATT_BIAS_AT]) : 0.0f;
+            // T holds c * m, w_att carries 1 / c; the returned weight carries 1 / c so that T * att = m * sigmoid(.)
+            s.att[row] = row < ne ? sigmoidf_(dot + s.wv[ATT_BIAS_AT]) * (1.0f / SILU_C) : 0.0f;
         }
     }
     lds_barrier();
@@ -432,7 +436,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
     ex = row_dot_chunks<TPR>(s.A, a.wx_c[et], KP / 4, tid);
     lds_barrier();
     KPD_STAMP(7)
-    store_T_silu_w<NW>(s.A, acc, ex, a.b_c[et], tid, wave, lane);
+    store_T_silu_w<NW, true>(s.A, acc, ex, a.b_c[et], tid, wave, lane);
     lds_barrier();
     KPD_STAMP(8)
     {
@@ -479,7 +483,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
 
 __device__ __forceinline__ void store_T_silu(float *T, const f32x16 (&acc)[2][2], float ex, const float *__restrict__ b,
                                              int tid, int wave, int lane) {
-    store_T_silu_w<4>(T, acc, ex, b, tid, wave, lane);
+    store_T_silu_w<4, false>(T, acc, ex, b, tid, wave, lane);
 }
 
 // ---- node update --------------------------------------------------------------------------

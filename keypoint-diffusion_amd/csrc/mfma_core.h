@@ -27,6 +27,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // v_exp_f32 + v_rcp_f32 (1 ulp each): far inside the 1e-4 parity budget, ~4x fewer VALU ops than
 // the IEEE division sequence.
 __device__ __forceinline__ float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+// SiLU in "pre-scaled" form: for x' = c x with c = -log2(e), x' / (1 + 2^x') = c silu(x).  The producers of x'
+// (packed weights, biases) carry the factor c and the linear consumers carry 1 / c, so the activation is
+// v_exp_f32 + v_add + v_rcp_f32 + v_mul -- one VALU multiply fewer per element than silu().
+constexpr float SILU_C = -1.4426950408889634f;
+__device__ __forceinline__ float silu_pre(float xs) { return xs * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(xs)); }
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 __device__ __forceinline__ void acc_zero(f32x16 (&acc)[2][2]) {

@@ -119,6 +119,35 @@ kpd_status pack_gate_weight(const float *src, int vout, int K, float *dst, hipSt
     return KPD_OK;
 }
 
+__global__ void k_scale_inplace(float *__restrict__ p, int n, float f) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] *= f;
+}
+
+kpd_status scale_inplace(float *p, int n, float f, hipStream_t st) {
+    hipLaunchKernelGGL(k_scale_inplace, dim3(cdiv(n, 256)), dim3(256), 0, st, p, n, f);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+// Writes the bias as weight row k (the A tile carries a constant 1 in column k): wp[..k..][n] = f * bias[n] for the
+// 256 MFMA columns, wx[k] = f * bias[256] for the extra column.
+__global__ void k_patch_bias_row(float *__restrict__ wp, float *__restrict__ wx, const float *__restrict__ bias, float f, int k) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < 256) {
+        const int g = k >> 3, h = (k >> 2) & 1, j = k & 3;
+        const int wave = n >> 6, nt = (n >> 5) & 1, lane = (n & 31) + 32 * h;
+        wp[((size_t)(g * 4 + wave) * 64 + lane) * 8 + nt * 4 + j] = f * bias[n];
+    }
+    if (n == 256) wx[k] = f * bias[256];
+}
+
+kpd_status patch_bias_row(float *wp, float *wx, const float *bias, float f, int k, hipStream_t st) {
+    hipLaunchKernelGGL(k_patch_bias_row, dim3(2), dim3(256), 0, st, wp, wx, bias, f, k);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
 __global__ void k_copy_pad(const float *__restrict__ src, int n_src, float *__restrict__ dst, int n_dst) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_dst) dst[i] = i < n_src ? src[i] : 0.0f;
