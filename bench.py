@@ -215,6 +215,12 @@ def main():
         elapsed = float(tmax.item())
 
     if rank == 0:
+        # HBM traffic of the dominant kernel comes from PMC counters, which need their own rocprofv3 passes
+        # (profiles/tools/collect_round.sh); the committed per-launch figure for this workload is attached
+        traffic = None
+        tfile = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+        if os.path.exists(tfile) and B == 64 and args.n_rec == 300 and args.n_lig == 25:
+            traffic = json.load(open(tfile))['hbm_bytes_per_launch']
         steps_per_s = world * args.steps / elapsed
         n_edges = counts['E_ll'] + counts['E_kl'] + counts['E_lk'] + counts['E_kk']
         edge_avg_s = edge_ms / max(edge_launches, 1) * 1e-3
@@ -232,7 +238,8 @@ def main():
             'ligands_per_min': steps_per_s * B * 60.0 / N_TIMESTEPS,
             'edges_per_step_layer': counts,
             'roofline': {'kernel': 'k_egnn_edge', 'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MATRIX_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MATRIX_TFLOPS, 'traffic': None,
+                         'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MATRIX_TFLOPS, 'traffic': traffic,
+                         'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, 2 x FETCH_SIZE + WRITE_SIZE, separate passes)',
                          'avg_launch_ms': edge_avg_s * 1e3, 'launches': edge_launches,
                          'flop_per_launch': n_edges * EDGE_KERNEL_FLOP_PER_EDGE,
                          'reference_formulation_tflops': n_edges * EDGE_ALGO_FLOP_PER_EDGE / edge_avg_s / 1e12
