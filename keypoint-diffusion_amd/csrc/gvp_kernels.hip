@@ -104,6 +104,7 @@ __device__ __forceinline__ void gvp_stage(const GvpSmem &s, const GvpW &w, const
         acc_zero(acc);
         gemm_rows64_rt<SA_G>(s.A, w.wp, w.ng, acc, wave, lane);
         lds_barrier();
+        const bool fused_act = add_row == nullptr;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int col = acc_col(nt, wave, lane);
@@ -112,12 +113,26 @@ __device__ __forceinline__ void gvp_stage(const GvpSmem &s, const GvpW &w, const
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
-                    const int r = acc_row(mt, reg, lane);
-                    float val = acc[mt][nt][reg] + bb;
-                    if (add_row && col < add_ld) val += add_row[(size_t)row_index[r] * add_ld + col];
-                    if (add_row2 && col < add_ld) val += add_row2[(size_t)row_index2[r] * add_ld + col];
-                    s.A[r * SA_G + col] = silu(val);
+                    const float val = acc[mt][nt][reg] + bb;
+                    s.A[acc_row(mt, reg, lane) * SA_G + col] = fused_act ? silu(val) : val;
                 }
+        }
+        if (!fused_act) {
+            // gathered per-row terms (node projections of the first message Linear): row-wise and coalesced --
+            // one 16-B load per lane per row instead of 64 scattered dword loads in the accumulator layout
+            lds_barrier();
+            const int chunks = add_ld >> 2;
+#pragma unroll 4
+            for (int rr = 0; rr < 16; ++rr) {
+                const int r = wave * 16 + rr;
+                if (lane < chunks) {
+                    f32x4_ v = *reinterpret_cast<const f32x4_ *>(s.A + r * SA_G + 4 * lane);
+                    v += reinterpret_cast<const f32x4_ *>(add_row + (size_t)row_index[r] * add_ld)[lane];
+                    if (add_row2) v += reinterpret_cast<const f32x4_ *>(add_row2 + (size_t)row_index2[r] * add_ld)[lane];
+                    v[0] = silu(v[0]); v[1] = silu(v[1]); v[2] = silu(v[2]); v[3] = silu(v[3]);
+                    *reinterpret_cast<f32x4_ *>(s.A + r * SA_G + 4 * lane) = v;
+                }
+            }
         }
     }
     lds_barrier();
@@ -397,13 +412,21 @@ __global__ __launch_bounds__(256) void k_gvp_edge(GvpEdgeArgs a) {
         float *smain = a.ms_main[et], *scont = a.ms_cont[et] + (size_t)tile_in_et * S;
         float run = 0.0f;
         int piece = 0;
-        for (int r = 0; r < ne; ++r) {
-            run += s.A[r * SA_G + tid];
-            if ((endmask >> r) & 1ull) {
-                float *out = (piece == 0 && first_is_cont) ? scont : smain + (size_t)s.dst[r] * S;
-                out[tid] = run;
-                run = 0.0f;
-                ++piece;
+#pragma unroll 1
+        for (int r0 = 0; r0 < TM; r0 += 16) {
+            if (r0 >= ne) break;
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = s.A[(r0 + i) * SA_G + tid];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (r0 + i < ne) run += v[i];
+                if ((endmask >> (r0 + i)) & 1ull) {
+                    float *out = (piece == 0 && first_is_cont) ? scont : smain + (size_t)s.dst[r0 + i] * S;
+                    out[tid] = run;
+                    run = 0.0f;
+                    ++piece;
+                }
             }
         }
     }
