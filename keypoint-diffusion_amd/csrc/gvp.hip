@@ -36,6 +36,7 @@ struct kpd_gvp {
     std::set<std::string> expected, loaded;
     bool committed = false;
     int debug_convs = -1;
+    unsigned long long *stamps = nullptr;     // device [32], diagnostics
     // workspace
     int cap_B = 0, cap_lig = 0, cap_kp = 0, cap_kk = 0, cap_maxlig = 0, cap_maxkp = 0;
     float *s[2], *v[2], *s_tmp[2];
@@ -335,6 +336,7 @@ extern "C" kpd_status kpd_gvp_forward(kpd_gvp *m, const kpd_batch *bt, const flo
         ea.meta = net == 4 ? m->meta4 : m->meta2;
         ea.x[0] = x[0]; ea.x[1] = x[1]; ea.v[0] = m->v[0]; ea.v[1] = m->v[1];
         ea.n_gvps = c.n_message_gvps; ea.S = S; ea.rbf_dmax = 15.0f;            // gvp.py:350 default, not overridden
+        ea.stamps = m->stamps;
         for (int et = 0; et < net; ++et) {
             ea.src[et] = esrc[et]; ea.dst[et] = edst[et]; ea.Psrc[et] = m->Psrc[et];
             for (int j = 0; j < c.n_message_gvps; ++j) ea.g[et][j] = m->msg[ci][et][j].dev();
@@ -383,6 +385,16 @@ extern "C" kpd_status kpd_gvp_debug_state(kpd_gvp *m, const char *what, float *o
     const std::string w(what);
     if (w.rfind("convs=", 0) == 0) {
         m->debug_convs = atoi(w.c_str() + 6);
+        return KPD_OK;
+    }
+    if (w == "stamps=1") {
+        if (!m->stamps) KPD_HIP(hipMalloc(reinterpret_cast<void **>(&m->stamps), 32 * sizeof(unsigned long long)));
+        KPD_HIP(hipMemsetAsync(m->stamps, 0, 32 * sizeof(unsigned long long), st));
+        return KPD_OK;
+    }
+    if (w == "stamps") {
+        KPD_REQUIRE(m->stamps && out && n_floats >= 64, KPD_ERR_INVALID, "stamps not enabled or buffer < 64 floats");
+        KPD_HIP(hipMemcpyAsync(out, m->stamps, 32 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
         return KPD_OK;
     }
     const float *src = nullptr;

@@ -9,7 +9,7 @@ constexpr int GVH = 33;                // largest hidden vector width (x_diff + 
 constexpr int VST = 100;               // floats per row of an LDS vector buffer (33 x 3, padded)
 constexpr int NG_G = 34;               // k-groups of the widest GVP GEMM (K = 256 + 16 = 272)
 constexpr int SA_G = 276;              // LDS row stride of the GVP A tile
-constexpr int GVP_LDS_FLOATS = TM * SA_G + 3 * TM * VST + TM * GV + 2 * 1120 + 4 * TM + 16;
+constexpr int GVP_LDS_FLOATS = TM * SA_G + 3 * TM * VST + 4 * TM + 16;
 constexpr int GVP_LDS_BYTES = GVP_LDS_FLOATS * 4;
 
 // One GVP (models/gvp.py:43-116) in kernel-ready form.
@@ -43,6 +43,7 @@ struct GvpEdgeArgs {
     float rbf_dmax;
     float *ms_main[4], *ms_cont[4];   // [n_dst][S], [tiles][S]
     float *mv_main[4], *mv_cont[4];   // [n_dst][48], [tiles][48]
+    unsigned long long *stamps;       // [32] phase-cycle sums (diagnostics only, null in production)
 };
 
 struct GvpNodeArgs {

@@ -25,8 +25,6 @@ typedef float f32x4_ __attribute__((ext_vector_type(4)));
 struct GvpSmem {
     float *A;                 // [64][SA_G]
     float *V0, *V1, *V2;      // [64][VST]: current vectors, hidden vectors, residual vectors
-    float *G;                 // [64][16] gates
-    float *Wh, *Wu;           // [1120] each (33 x 33 at most)
     int *src, *dst;           // [64]
     float *rowf;              // [128] per-row scratch (LN statistics)
     int *misc;                // [16]
@@ -38,10 +36,7 @@ __device__ __forceinline__ GvpSmem gvp_smem(float *smem) {
     s.V0 = s.A + TM * SA_G;
     s.V1 = s.V0 + TM * VST;
     s.V2 = s.V1 + TM * VST;
-    s.G = s.V2 + TM * VST;
-    s.Wh = s.G + TM * GV;
-    s.Wu = s.Wh + 1120;
-    s.src = reinterpret_cast<int *>(s.Wu + 1120);
+    s.src = reinterpret_cast<int *>(s.V2 + TM * VST);
     s.dst = s.src + TM;
     s.rowf = reinterpret_cast<float *>(s.dst + TM);
     s.misc = reinterpret_cast<int *>(s.rowf + 2 * TM);
@@ -51,52 +46,79 @@ __device__ __forceinline__ GvpSmem gvp_smem(float *smem) {
 // ---- one GVP stage ------------------------------------------------------------------------
 // add_row / add_row2 (optional): per-row terms added before the activation,
 // add_row[row_index[r] * add_ld + col] (+ add_row2[row_index2[r] * add_ld + col]).
+#define GVP_STAMP(idx)                                                                     \
+    if (stamps && tid == 0) {                                                              \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                      \
+        atomicAdd(&stamps[idx], (unsigned long long)(now_ - *t_prev));                     \
+        *t_prev = now_;                                                                    \
+    }
+
 __device__ __forceinline__ void gvp_stage(const GvpSmem &s, const GvpW &w, const float *__restrict__ add_row,
                                           const int *row_index, int add_ld, int tid,
-                                          const float *__restrict__ add_row2 = nullptr, const int *row_index2 = nullptr) {
+                                          const float *__restrict__ add_row2 = nullptr, const int *row_index2 = nullptr,
+                                          unsigned long long *stamps = nullptr, unsigned long long *t_prev = nullptr,
+                                          int stamp_base = 0) {
     const int wave = tid >> 6, lane = tid & 63;
-    const int row = tid >> 2, q = tid & 3;
-    // Wh / Wu -> LDS
-    for (int i = tid; i < w.vin * w.h; i += 256) s.Wh[i] = w.Wh[i];
-    for (int i = tid; i < w.h * w.vout; i += 256) s.Wu[i] = w.Wu[i];
-    lds_barrier();
+    // 16x16x4 MFMA roles of this lane: rows (edges / nodes) 16 wave + (lane & 15) as A operand, output
+    // column lane & 15, output rows 16 wave + 4 (lane >> 4) + reg.  Every wave works on its own 16 rows in the
+    // vector stages and the gate GEMM, so those need no workgroup barrier between them.
+    constexpr int KSMAX = (GVH + 3) / 4, NTMAX = (GVH + 15) / 16;
+    const int lrow = 16 * wave + (lane & 15), kq = lane >> 4, ncol = lane & 15;
+    const int orow0 = 16 * wave + 4 * kq;
 
-    // vec1: Vh[h][c] = sum_v Wh[v][h] v[v][c]; sh[h] = sqrt(max(|Vh[h]|^2, 1e-8))  (gvp.py:96-99)
+    // vec1: Vh[(c, e)][h] = sum_v v[e][v][c] Wh[v][h] as three 16-row MFMA products (one per xyz component, so
+    // that the three components of one Vh entry sit at the same register of three accumulators);
+    // sh[h] = sqrt(max(|Vh[h]|^2, 1e-8)) goes behind the scalars in the A tile            (gvp.py:96-99)
     {
-        // each thread owns hidden channels q, q + 4, ...; `nh` (wave-uniform) bounds the unrolled loops
-        constexpr int NHMAX = (GVH + 3) / 4;
-        const int nh = (w.h + 3) >> 2;
-        float a[NHMAX][3];
+        const int ksn = (w.vin + 3) >> 2, ntn = (w.h + 15) >> 4;
+        float av[3][KSMAX], bv[NTMAX][KSMAX];
+        const float *vin = s.V0 + lrow * VST;
 #pragma unroll
-        for (int i = 0; i < NHMAX; ++i) a[i][0] = a[i][1] = a[i][2] = 0.0f;
-        const float *vin = s.V0 + row * VST;
-        for (int v = 0; v < w.vin; ++v) {
-            const float x0 = vin[3 * v], x1 = vin[3 * v + 1], x2 = vin[3 * v + 2];
+        for (int ks = 0; ks < KSMAX; ++ks) {
+            const int k = 4 * ks + kq;
+            if (ks < ksn) {
+                const bool kin = k < w.vin;
 #pragma unroll
-            for (int i = 0; i < NHMAX; ++i) {
-                if (i < nh) {
-                    const int h = q + 4 * i;
-                    const float wv = h < w.h ? s.Wh[v * w.h + h] : 0.0f;
-                    a[i][0] = fmaf(wv, x0, a[i][0]);
-                    a[i][1] = fmaf(wv, x1, a[i][1]);
-                    a[i][2] = fmaf(wv, x2, a[i][2]);
+                for (int c = 0; c < 3; ++c) av[c][ks] = kin ? vin[3 * k + c] : 0.0f;
+#pragma unroll
+                for (int nt = 0; nt < NTMAX; ++nt)
+                    if (nt < ntn) {
+                        const int h = 16 * nt + ncol;
+                        bv[nt][ks] = (kin && h < w.h) ? w.Wh[k * w.h + h] : 0.0f;
+                    }
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTMAX; ++nt) {
+            if (nt < ntn) {
+                f32x4_ acc[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[c] = f32x4_{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KSMAX; ++ks)
+                    if (ks < ksn) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+                            acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][ks], bv[nt][ks], acc[c], 0, 0, 0);
+                    }
+                const int h = 16 * nt + ncol;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int e = orow0 + reg;
+                    if (h < w.h) {
+                        float *o = s.V1 + e * VST + 3 * h;
+                        o[0] = acc[0][reg]; o[1] = acc[1][reg]; o[2] = acc[2][reg];
+                        const float n2 = acc[0][reg] * acc[0][reg] + acc[1][reg] * acc[1][reg] + acc[2][reg] * acc[2][reg];
+                        s.A[e * SA_G + w.n_s + h] = sqrtf(fmaxf(n2, 1e-8f));
+                    } else if (w.n_s + h < 8 * w.ng) {
+                        s.A[e * SA_G + w.n_s + h] = 0.0f;   // K padding: the packed weight rows are zero, A must be finite
+                    }
                 }
             }
         }
-#pragma unroll
-        for (int i = 0; i < NHMAX; ++i) {
-            const int h = q + 4 * i;
-            if (h < w.h) {
-                float *o = s.V1 + row * VST + 3 * h;
-                o[0] = a[i][0]; o[1] = a[i][1]; o[2] = a[i][2];
-                const float n2 = a[i][0] * a[i][0] + a[i][1] * a[i][1] + a[i][2] * a[i][2];
-                s.A[row * SA_G + w.n_s + h] = sqrtf(fmaxf(n2, 1e-8f));
-            }
-        }
-        // zero the K padding behind sh (the packed weight rows there are zero, the A values must be finite)
-        for (int c = w.n_s + w.h + q; c < 8 * w.ng; c += 4) s.A[row * SA_G + c] = 0.0f;
     }
     lds_barrier();
+    GVP_STAMP(stamp_base + 0)
 
     // GEMM + activation -> A tile columns 0..255
     {
@@ -104,6 +126,7 @@ __device__ __forceinline__ void gvp_stage(const GvpSmem &s, const GvpW &w, const
         acc_zero(acc);
         gemm_rows64_rt<SA_G>(s.A, w.wp, w.ng, acc, wave, lane);
         lds_barrier();
+        GVP_STAMP(stamp_base + 1)
         const bool fused_act = add_row == nullptr;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
@@ -136,50 +159,68 @@ __device__ __forceinline__ void gvp_stage(const GvpSmem &s, const GvpW &w, const
         }
     }
     lds_barrier();
+    GVP_STAMP(stamp_base + 2)
 
-    // gates: 16 rows per wave on the 16x16x4 MFMA, K = sout  (gvp.py:105-107)
+    // gates (gvp.py:105-107): 16 rows per wave, K = sout; the result stays in registers -- its layout
+    // (column u on the lane, rows in the 4 registers) is exactly that of the vec2 product below
+    f32x4_ gate;
     {
         f32x4_ c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
-        const float *ap = s.A + (16 * wave + (lane & 15)) * SA_G + 4 * (lane >> 4);
+        const float *ap = s.A + lrow * SA_G + 4 * kq;
         const f32x4_ *bp = reinterpret_cast<const f32x4_ *>(w.wg) + lane;
         const int groups = w.sout >> 4;
+        f32x4_ b_next = bp[0];
+#pragma unroll 4
         for (int g = 0; g < groups; ++g) {
             const f32x4_ a = *reinterpret_cast<const f32x4_ *>(ap + 16 * g);
-            const f32x4_ b = bp[g * 64];
+            const f32x4_ b = b_next;
+            b_next = bp[(g + 1 < groups ? g + 1 : g) * 64];
             c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c0, 0, 0, 0);
             c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c1, 0, 0, 0);
             c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c0, 0, 0, 0);
             c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c1, 0, 0, 0);
         }
-        const int u = lane & 15;
-        const float bg = w.bg[u];
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) s.G[(16 * wave + 4 * (lane >> 4) + reg) * GV + u] = c0[reg] + c1[reg] + bg;
+        gate = c0 + c1 + w.bg[ncol];
+        if (w.vec_sigmoid) {
+            gate[0] = sigmoidf_(gate[0]); gate[1] = sigmoidf_(gate[1]);
+            gate[2] = sigmoidf_(gate[2]); gate[3] = sigmoidf_(gate[3]);
+        }
     }
-    lds_barrier();
+    GVP_STAMP(stamp_base + 3)
 
-    // vec2: v'[u][c] = act(gate[u]) * sum_h Wu[h][u] Vh[h][c]  (gvp.py:97, 111)
+    // vec2: v'[e][u][c] = act(gate[e][u]) * sum_h Vh[e][h][c] Wu[h][u]  (gvp.py:97, 111), same MFMA shape
     {
-        const float *vh = s.V1 + row * VST;
+        const int ksn = (w.h + 3) >> 2;
+        float av[3][KSMAX], bv[KSMAX];
+        const float *vh = s.V1 + lrow * VST;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int u = q + 4 * i;
-            if (u < w.vout) {
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-                for (int h = 0; h < w.h; ++h) {
-                    const float wv = s.Wu[h * w.vout + u];
-                    a0 = fmaf(wv, vh[3 * h], a0);
-                    a1 = fmaf(wv, vh[3 * h + 1], a1);
-                    a2 = fmaf(wv, vh[3 * h + 2], a2);
-                }
-                float gte = s.G[row * GV + u];
-                if (w.vec_sigmoid) gte = sigmoidf_(gte);
-                float *o = s.V0 + row * VST + 3 * u;
-                o[0] = gte * a0; o[1] = gte * a1; o[2] = gte * a2;
+        for (int ks = 0; ks < KSMAX; ++ks)
+            if (ks < ksn) {
+                const int k = 4 * ks + kq;
+                const bool kin = k < w.h;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) av[c][ks] = kin ? vh[3 * k + c] : 0.0f;
+                bv[ks] = (kin && ncol < w.vout) ? w.Wu[k * w.vout + ncol] : 0.0f;
+            }
+        f32x4_ acc[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] = f32x4_{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KSMAX; ++ks)
+            if (ks < ksn) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][ks], bv[ks], acc[c], 0, 0, 0);
+            }
+        if (ncol < w.vout) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                float *o = s.V0 + (orow0 + reg) * VST + 3 * ncol;
+                o[0] = gate[reg] * acc[0][reg]; o[1] = gate[reg] * acc[1][reg]; o[2] = gate[reg] * acc[2][reg];
             }
         }
     }
     lds_barrier();
+    GVP_STAMP(stamp_base + 4)
 }
 
 // LayerNorm over the first S columns of every A-tile row (affine), in place.  (gvp.py:161)
@@ -331,6 +372,8 @@ __global__ __launch_bounds__(256) void k_gvp_edge(GvpEdgeArgs a) {
     const GvpSmem s = gvp_smem(smem);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int S = a.S;
+    unsigned long long *stamps = a.stamps;
+    unsigned long long t_prev_v = stamps ? __builtin_amdgcn_s_memtime() : 0ull, *t_prev = &t_prev_v;
 
     const int T = a.meta[8];
     const int chunk = (T + 7) >> 3;
@@ -399,10 +442,11 @@ __global__ __launch_bounds__(256) void k_gvp_edge(GvpEdgeArgs a) {
         }
     }
     lds_barrier();
+    GVP_STAMP(0)
 
     for (int k = 0; k < a.n_gvps; ++k)
         gvp_stage(s, a.g[et][k], k == 0 ? a.Psrc[et] : nullptr, s.src, S, tid,
-                  (k == 0 && a.use_dst) ? a.Pdst[et] : nullptr, s.dst);
+                  (k == 0 && a.use_dst) ? a.Pdst[et] : nullptr, s.dst, stamps, t_prev, 1 + 5 * k);
 
     // segmented sums over dst: scalars (thread = column), then the 48 vector floats
     const int first_is_cont = s.misc[0];
@@ -434,16 +478,25 @@ __global__ __launch_bounds__(256) void k_gvp_edge(GvpEdgeArgs a) {
         float *vmain = a.mv_main[et], *vcont = a.mv_cont[et] + (size_t)tile_in_et * 48;
         float run = 0.0f;
         int piece = 0;
-        for (int r = 0; r < ne; ++r) {
-            run += s.V0[r * VST + tid];
-            if ((endmask >> r) & 1ull) {
-                float *out = (piece == 0 && first_is_cont) ? vcont : vmain + (size_t)s.dst[r] * 48;
-                out[tid] = run;
-                run = 0.0f;
-                ++piece;
+#pragma unroll 1
+        for (int r0 = 0; r0 < TM; r0 += 16) {
+            if (r0 >= ne) break;
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = s.V0[(r0 + i) * VST + tid];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (r0 + i < ne) run += v[i];
+                if ((endmask >> (r0 + i)) & 1ull) {
+                    float *out = (piece == 0 && first_is_cont) ? vcont : vmain + (size_t)s.dst[r0 + i] * 48;
+                    out[tid] = run;
+                    run = 0.0f;
+                    ++piece;
+                }
             }
         }
     }
+    GVP_STAMP(31)
 }
 
 // ---- node update (gvp.py:499-536) ---------------------------------------------------------------

@@ -1,0 +1,29 @@
+"""Per-phase cycle shares of k_gvp_edge (diagnostic run)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+import bench
+
+dev = torch.device('cuda:0')
+wl = sys.argv[1] if len(sys.argv) > 1 else 'gvp_all_atom'
+model = bench.build_model(dev, wl)
+g = bench.build_batch(model, 64, 300, 25, 1234, dev, workload=wl)
+eng = model.dynamics.engine()
+t = torch.full((64,), 0.9, device=dev)
+with torch.no_grad():
+    for _ in range(2):
+        model.dynamics(g, t, None)
+    eng.debug('stamps=1')
+    n = 3
+    for _ in range(n):
+        model.dynamics(g, t, None)
+    torch.cuda.synchronize()
+    vals = eng.debug('stamps', 64).view(torch.int32).view(-1).view(torch.int64).cpu().tolist()
+names = {0: 'geometry+gather', 31: 'segmented sums'}
+for k in range(3):
+    for i, nm in enumerate(['W->LDS + vec1', 'GEMM', 'T-store(+gather)', 'gates', 'vec2']):
+        names[1 + 5 * k + i] = f'GVP{k} {nm}'
+tot = sum(vals)
+print(wl, 'k_gvp_edge phase shares:')
+for i in sorted(names):
+    print(f'  {names[i]:26s} {100 * vals[i] / tot:5.1f} %   {vals[i] / 1e6:10.1f} Mcycles')
