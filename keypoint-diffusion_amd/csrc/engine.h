@@ -41,6 +41,12 @@ kpd_status pack_gemm_weight_2ranges(const float *src, int n_out, int ld, int col
 kpd_status scale_inplace(float *p, int n, float f, hipStream_t st);
 kpd_status patch_bias_row(float *wp, float *wx, const float *bias, float f, int k, hipStream_t st);
 kpd_status pack_gate_weight(const float *src, int vout, int K, float *dst, hipStream_t st);
+// 16x16x4 MFMA A-operand fragments of a [n][k] matrix with element (n, k) at src[n * sn + k * sk]:
+// dst[(mt * 64 + lane) * 4 + r] = element(16 mt + (lane & 15), k_base + 4 (lane >> 4) + r), zero outside
+// n < n_valid / 4 (lane >> 4) + r < k_valid.  One call packs the 16 k-rows [k_base, k_base + 16) for n_tiles
+// 16-wide output tiles (the chained GVP edge kernel, gvp_chain.hip).
+kpd_status pack_chain_frag(const float *src, int sn, int sk, int n_valid, int k_base, int k_valid, int n_tiles, float *dst,
+                           hipStream_t st);
 // dst[0..n_dst) = src[0..n_src) then zeros.
 kpd_status copy_pad(const float *src, int n_src, float *dst, int n_dst, hipStream_t st);
 // dst[c][r] = src[r][c]

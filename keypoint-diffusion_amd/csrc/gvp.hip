@@ -95,6 +95,7 @@ extern "C" kpd_status kpd_gvp_create(const kpd_gvp_config *cfg, kpd_gvp **out) {
                 g.vin = j == 0 ? GV + 1 : GV; g.vout = GV;
                 g.s_in = j == 0 ? S + 16 : S; g.sout = S;
                 g.split = j == 0 ? SPLIT_SRC : SPLIT_NONE; g.S = S;
+                g.chain_pos = j;
                 alloc_gvp(A, g, m->expected, pre + "edge_message_fns." + kCanon[et] + "." + std::to_string(j));
             }
         }

@@ -1,0 +1,460 @@
+// Edge-message GVP chain with the activations kept in registers (models/gvp.py:43-116, 287-345, 474-497).
+//
+// One workgroup = 64 edges, one wave = 16 of them, and a wave carries its 16 edges through the whole message
+// chain on its own.  Every product is computed transposed, T^T[n][e] = sum_k W[n][k] X^T[k][e], on the 16x16x4
+// fp32 MFMA: the weight is the A operand, the activations the B operand, and the result lands with the edge on
+// the lane (e = lane & 15) and four consecutive features n = 4 (lane >> 4) + r in the four result registers.
+// That is exactly the B-operand layout of the next product (k = 4 (lane >> 4) + r per 16-wide k tile), so
+// scalars, hidden vectors, gates and output vectors of one GVP feed the next GVP straight from registers: no
+// LDS round trip, and no workgroup barrier between the stages of a GVP.  Only the weights go through LDS: the
+// to_feats_out / gate matrices are streamed as 16-row k-slabs ("chunks", pre-packed in A-fragment order by
+// gvp_host.hip) through a two-buffer ring that the four waves share, one barrier per chunk.
+//
+// Per 64-edge tile this leaves LDS traffic of one ds_read_b128 per four MFMAs and an LDS footprint of 79 KB
+// (the ring is reused for the final segmented sum), so two workgroups fit a CU and one's epilogues and
+// gathers overlap the other's MFMA stream.
+#include "gvp_kernels.h"
+#include "mfma_core.h"
+
+namespace kpd {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ v4f mfma16(float a, float b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ v4f zero4() { return v4f{0.f, 0.f, 0.f, 0.f}; }
+
+// acc[mt] += W_chunk[16 mt .. +15][16 k] * xin (k = 4 (lane >> 4) + r), chunk laid out [mt][lane][r] in LDS.
+// Four output tiles per LDS batch so that consecutive MFMAs never hit the same accumulator.
+template <int NTS>
+__device__ __forceinline__ void chunk_gemm(const v4f *__restrict__ buf, v4f xin, v4f (&acc)[NTS], int lane, int nreg) {
+    const v4f *wp = buf + lane;
+    v4f w[2][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) w[0][m] = wp[m * 64];
+#pragma unroll
+    for (int g = 0; g < NTS / 4; ++g) {
+        if (g + 1 < NTS / 4) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) w[(g + 1) & 1][m] = wp[(4 * (g + 1) + m) * 64];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (r < nreg) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[4 * g + m] = mfma16(w[g & 1][m][r], xin[r], acc[4 * g + m]);
+            }
+        }
+    }
+}
+
+template <int NTS>
+struct ChainSmem {
+    static constexpr int S = 16 * NTS;
+    static constexpr int CH4 = NTS * 64;                 // float4 per chunk
+    static constexpr int SO = S + 4;                     // row stride of the output staging tile
+    static constexpr int REGION0 = (2 * CH4 * 4 > TM * SO) ? 2 * CH4 * 4 : TM * SO;   // ring / output tile (floats)
+    static constexpr int FLOATS = REGION0 + TM * 48 + TM + 16;
+};
+
+}  // namespace
+
+template <int NTS>
+__global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
+    using L = ChainSmem<NTS>;
+    constexpr int S = L::S, CH4 = L::CH4, SO = L::SO, PT = CH4 / 256;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    v4f *ring = reinterpret_cast<v4f *>(smem);
+    float *O = smem;
+    float *Vout = smem + L::REGION0;
+    int *sdst = reinterpret_cast<int *>(Vout + TM * 48);
+    int *misc = sdst + TM;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int T = a.meta[8];
+    const int chunk_tiles = (T + 7) >> 3;
+    const int bi = blockIdx.x >> 3;
+    if (bi >= chunk_tiles) return;
+    const int tile = (blockIdx.x & 7) * chunk_tiles + bi;      // consecutive tiles stay on one XCD (shared weights in L2)
+    if (tile >= T) return;
+    int et = 0;
+#pragma unroll
+    for (int e = 1; e < 4; ++e)
+        if (tile >= a.meta[4 + e]) et = e;
+    const int tile_in_et = tile - a.meta[4 + et];
+    const int e0 = tile_in_et * TM;
+    const int ne = min(TM, a.meta[et] - e0);
+    const int snt = (et == 1 || et == 3) ? 1 : 0, dnt = (et >= 2) ? 1 : 0;      // ll, kl, lk, kk
+    const int *__restrict__ esrc = a.src[et];
+    const int *__restrict__ edst = a.dst[et];
+    const int n_gvps = a.n_gvps;
+
+    // ---- weight chunk pipeline ----------------------------------------------------------------------
+    const int h0 = a.g[et][0].h;
+    const int n_ht = (h0 + 15) >> 4;
+    const int n0 = 2 + n_ht;
+    const int total = n0 + (n_gvps - 1) * (NTS + 2);
+    int cur = 0;
+    auto chunk_src = [&](int c) -> const v4f * {
+        int stage = 0, local = c;
+        if (c >= n0) {
+            stage = 1 + (c - n0) / (NTS + 2);
+            local = (c - n0) - (stage - 1) * (NTS + 2);
+        }
+        return reinterpret_cast<const v4f *>(a.g[et][stage].chain) + (size_t)local * CH4 + tid;
+    };
+    v4f pr[PT];
+    {
+        const v4f *g0 = chunk_src(0);
+#pragma unroll
+        for (int j = 0; j < PT; ++j) pr[j] = g0[256 * j];
+#pragma unroll
+        for (int j = 0; j < PT; ++j) ring[tid + 256 * j] = pr[j];
+        const v4f *g1 = chunk_src(min(1, total - 1));
+#pragma unroll
+        for (int j = 0; j < PT; ++j) pr[j] = g1[256 * j];
+    }
+    // acquire(): publish the prefetched chunk cur + 1 into the other ring buffer (its last readers finished before
+    // the previous barrier), start fetching chunk cur + 2, return the buffer of chunk cur.  release(): barrier.
+    auto acquire = [&]() -> const v4f * {
+        v4f *nb = ring + ((cur + 1) & 1) * CH4;
+#pragma unroll
+        for (int j = 0; j < PT; ++j) nb[tid + 256 * j] = pr[j];
+        const v4f *gn = chunk_src(min(cur + 2, total - 1));
+#pragma unroll
+        for (int j = 0; j < PT; ++j) pr[j] = gn[256 * j];
+        __builtin_amdgcn_sched_barrier(0);      // keep the fetch at the head of the chunk: it has one chunk time to land
+        return ring + (cur & 1) * CH4;
+    };
+    auto release = [&]() {
+        lds_barrier();
+        ++cur;
+    };
+
+    // ---- this lane's edge ---------------------------------------------------------------------------
+    const int el = lane & 15, q = lane >> 4;
+    const int row = 16 * wave + el;
+    const int eidx = e0 + min(row, ne - 1);
+    const int u = esrc[eidx], vd = edst[eidx];
+
+    // run boundaries of the dst-sorted tile for the segmented sum (wave 0, one lane per row)
+    if (tid < TM) {
+        const int e = e0 + min(tid, ne - 1);
+        const int v = edst[e];
+        sdst[tid] = v;
+        const int vprev = tid > 0 ? edst[e0 + min(tid - 1, ne - 1)] : (e0 > 0 ? edst[e0 - 1] : -1);
+        const int vnext = tid + 1 < ne ? edst[e0 + tid + 1] : -2;
+        const unsigned long long ends = __ballot(tid < ne && vnext != v);
+        if (tid == 0) {
+            misc[0] = (vprev == v) ? 1 : 0;
+            misc[2] = (int)(ends & 0xffffffffu);
+            misc[3] = (int)(ends >> 32);
+        }
+    }
+
+    // ---- GVP 0: inputs ------------------------------------------------------------------------------
+    v4f acc[NTS];
+    {   // per-node blocks of to_feats_out (k_gvp_proj) enter as the accumulator's initial value
+        const float *ps = a.Psrc[et] + (size_t)u * S + 4 * q;
+#pragma unroll
+        for (int mt = 0; mt < NTS; ++mt) acc[mt] = *reinterpret_cast<const v4f *>(ps + 16 * mt);
+        if (a.use_dst) {
+            const float *pd = a.Pdst[et] + (size_t)vd * S + 4 * q;
+#pragma unroll
+            for (int mt = 0; mt < NTS; ++mt) acc[mt] += *reinterpret_cast<const v4f *>(pd + 16 * mt);
+        }
+    }
+    v4f Vc[3];          // current vectors: Vc[c][r] = v[e][4 q + r][c]
+    v4f x[NTS];         // current scalars: x[nt][r] = s[e][16 nt + 4 q + r]
+    v4f gate;
+    {
+        const GvpW &g0 = a.g[et][0];
+        const float *xs = a.x[snt] + (size_t)u * 3, *xd = a.x[dnt] + (size_t)vd * 3;
+        const float dx = xs[0] - xd[0], dy = xs[1] - xd[1], dz = xs[2] - xd[2];
+        const float dij = sqrtf(fmaxf(dx * dx + dy * dy + dz * dz, 1e-8f)) + 1e-8f;
+        const float xdv[3] = {dx / dij, dy / dij, dz / dij};
+        v4f rbf;
+        {
+            const float sigma = a.rbf_dmax / 16.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float mu = a.rbf_dmax * (float)(4 * q + r) / 15.0f;
+                const float zz = (dij - mu) / sigma;
+                rbf[r] = expf(-zz * zz);
+            }
+        }
+        // vectors of the two end points: 12 consecutive floats (4 channels x xyz) per lane
+        v4f Vs[3], Vd[3];
+        {
+            const v4f *vs = reinterpret_cast<const v4f *>(a.v[snt] + (size_t)u * 48 + 12 * q);
+            const v4f t0 = vs[0], t1 = vs[1], t2 = vs[2];
+            const float f[12] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3], t2[0], t2[1], t2[2], t2[3]};
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Vs[c][r] = f[3 * r + c];
+        }
+        if (a.use_dst) {
+            const v4f *vs = reinterpret_cast<const v4f *>(a.v[dnt] + (size_t)vd * 48 + 12 * q);
+            const v4f t0 = vs[0], t1 = vs[1], t2 = vs[2];
+            const float f[12] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3], t2[0], t2[1], t2[2], t2[3]};
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Vd[c][r] = f[3 * r + c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Vd[c] = zero4();
+        }
+
+        // vec1: Vh = Wh^T [source | destination | x_diff], sh = |Vh|                     (gvp.py:96-99)
+        const v4f *whp = reinterpret_cast<const v4f *>(g0.whp) + lane;
+        v4f Vh[3][3], sh[3];
+#pragma unroll
+        for (int ht = 0; ht < 3; ++ht) {
+            if (ht < n_ht) {
+                const v4f ws = whp[(0 * 3 + ht) * 64], wx = whp[(2 * 3 + ht) * 64];
+                v4f wd = zero4();
+                if (a.use_dst) wd = whp[(1 * 3 + ht) * 64];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    v4f t = zero4();
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) t = mfma16(ws[r], Vs[c][r], t);
+                    if (a.use_dst) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) t = mfma16(wd[r], Vd[c][r], t);
+                    }
+                    t = mfma16(wx[0], q == 0 ? xdv[c] : 0.0f, t);
+                    Vh[ht][c] = t;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    sh[ht][r] = sqrtf(fmaxf(Vh[ht][0][r] * Vh[ht][0][r] + Vh[ht][1][r] * Vh[ht][1][r] + Vh[ht][2][r] * Vh[ht][2][r], 1e-8f));
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Vh[ht][c] = zero4();
+                sh[ht] = zero4();
+            }
+        }
+        const int tail = h0 - 16 * (n_ht - 1);            // valid rows of the last hidden tile
+        const int tail_reg = min(4, tail);
+
+        lds_barrier();                                    // chunk 0 is in the ring
+        // scalar GEMM: [rbf | sh] part of to_feats_out
+        {
+            const v4f *buf = acquire();
+            chunk_gemm<NTS>(buf, rbf, acc, lane, 4);
+            release();
+        }
+#pragma unroll
+        for (int ht = 0; ht < 3; ++ht) {
+            if (ht < n_ht) {
+                const v4f *buf = acquire();
+                chunk_gemm<NTS>(buf, sh[ht], acc, lane, ht == n_ht - 1 ? tail_reg : 4);
+                release();
+            }
+        }
+        const v4f bgv = *reinterpret_cast<const v4f *>(g0.bg + 4 * q);
+        const v4f *wup = reinterpret_cast<const v4f *>(g0.wup) + lane;
+        v4f wu[3];
+#pragma unroll
+        for (int ht = 0; ht < 3; ++ht) wu[ht] = ht < n_ht ? wup[ht * 64] : zero4();
+#pragma unroll
+        for (int mt = 0; mt < NTS; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[mt][r] = silu(acc[mt][r]);
+        if (n_gvps > 1) {
+            const float *bn = a.g[et][1].b + 4 * q;
+#pragma unroll
+            for (int mt = 0; mt < NTS; ++mt) acc[mt] = *reinterpret_cast<const v4f *>(bn + 16 * mt);
+        }
+        // gates                                                                       (gvp.py:105-107)
+        {
+            const v4f *buf = acquire() + lane;
+            v4f ga[4] = {zero4(), zero4(), zero4(), zero4()};
+#pragma unroll
+            for (int nt = 0; nt < NTS; ++nt) {
+                const v4f wg = buf[nt * 64];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ga[r] = mfma16(wg[r], x[nt][r], ga[r]);
+            }
+            release();
+            gate = (ga[0] + ga[1]) + (ga[2] + ga[3]) + bgv;
+            if (g0.vec_sigmoid) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gate[r] = sigmoidf_(gate[r]);
+            }
+        }
+        // vec2: v' = gate * Wu^T Vh                                                   (gvp.py:97, 111)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            v4f t = zero4();
+#pragma unroll
+            for (int ht = 0; ht < 3; ++ht) {
+                if (ht < n_ht) {
+                    const int nr = ht == n_ht - 1 ? tail_reg : 4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (r < nr) t = mfma16(wu[ht][r], Vh[ht][c][r], t);
+                }
+            }
+            Vc[c] = gate * t;
+        }
+    }
+
+    // ---- GVP 1 .. n-1: scalars and vectors come from the previous GVP's registers ------------------------
+#pragma unroll 1
+    for (int k = 1; k < n_gvps; ++k) {
+        const GvpW &gk = a.g[et][k];
+        const v4f wh = reinterpret_cast<const v4f *>(gk.whp)[lane];
+        v4f Vh[3], sh;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            v4f t = zero4();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t = mfma16(wh[r], Vc[c][r], t);
+            Vh[c] = t;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            sh[r] = sqrtf(fmaxf(Vh[0][r] * Vh[0][r] + Vh[1][r] * Vh[1][r] + Vh[2][r] * Vh[2][r], 1e-8f));
+#pragma unroll
+        for (int nt = 0; nt < NTS; ++nt) {
+            const v4f *buf = acquire();
+            chunk_gemm<NTS>(buf, x[nt], acc, lane, 4);
+            release();
+        }
+        {
+            const v4f *buf = acquire();
+            chunk_gemm<NTS>(buf, sh, acc, lane, 4);
+            release();
+        }
+        const v4f bgv = *reinterpret_cast<const v4f *>(gk.bg + 4 * q);
+        const v4f wu = reinterpret_cast<const v4f *>(gk.wup)[lane];
+#pragma unroll
+        for (int mt = 0; mt < NTS; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[mt][r] = silu(acc[mt][r]);
+        if (k + 1 < n_gvps) {
+            const float *bn = a.g[et][k + 1].b + 4 * q;
+#pragma unroll
+            for (int mt = 0; mt < NTS; ++mt) acc[mt] = *reinterpret_cast<const v4f *>(bn + 16 * mt);
+        }
+        {
+            const v4f *buf = acquire() + lane;
+            v4f ga[4] = {zero4(), zero4(), zero4(), zero4()};
+#pragma unroll
+            for (int nt = 0; nt < NTS; ++nt) {
+                const v4f wg = buf[nt * 64];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ga[r] = mfma16(wg[r], x[nt][r], ga[r]);
+            }
+            release();
+            gate = (ga[0] + ga[1]) + (ga[2] + ga[3]) + bgv;
+            if (gk.vec_sigmoid) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gate[r] = sigmoidf_(gate[r]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            v4f t = zero4();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t = mfma16(wu[r], Vh[c][r], t);
+            Vc[c] = gate * t;
+        }
+    }
+
+    // ---- messages -> LDS (the ring is free: every wave passed the last chunk's barrier) ------------------
+    {
+        float *orow = O + row * SO + 4 * q;
+#pragma unroll
+        for (int mt = 0; mt < NTS; ++mt) *reinterpret_cast<v4f *>(orow + 16 * mt) = x[mt];
+        float f[12];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) f[3 * r + c] = Vc[c][r];
+        v4f *vo = reinterpret_cast<v4f *>(Vout + row * 48 + 12 * q);
+        vo[0] = v4f{f[0], f[1], f[2], f[3]};
+        vo[1] = v4f{f[4], f[5], f[6], f[7]};
+        vo[2] = v4f{f[8], f[9], f[10], f[11]};
+    }
+    lds_barrier();
+
+    // ---- segmented sums over dst: scalars (thread = column), then the 48 vector floats ------------------
+    const int first_is_cont = misc[0];
+    const unsigned long long endmask =
+        ((unsigned long long)(unsigned)misc[3] << 32) | (unsigned long long)(unsigned)misc[2];
+    if (tid < S) {
+        float *smain = a.ms_main[et], *scont = a.ms_cont[et] + (size_t)tile_in_et * S;
+        float run = 0.0f;
+        int piece = 0;
+#pragma unroll 1
+        for (int r0 = 0; r0 < TM; r0 += 16) {
+            if (r0 >= ne) break;
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = O[(r0 + i) * SO + tid];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (r0 + i < ne) run += v[i];
+                if ((endmask >> (r0 + i)) & 1ull) {
+                    float *out = (piece == 0 && first_is_cont) ? scont : smain + (size_t)sdst[r0 + i] * S;
+                    out[tid] = run;
+                    run = 0.0f;
+                    ++piece;
+                }
+            }
+        }
+    }
+    // the vector sums run on the last wave's spare lanes when S leaves one, else after the scalar pass
+    const int vt = S < 256 ? tid - 192 : tid;
+    if (vt >= 0 && vt < 48) {
+        float *vmain = a.mv_main[et], *vcont = a.mv_cont[et] + (size_t)tile_in_et * 48;
+        float run = 0.0f;
+        int piece = 0;
+#pragma unroll 1
+        for (int r0 = 0; r0 < TM; r0 += 16) {
+            if (r0 >= ne) break;
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = Vout[(r0 + i) * 48 + vt];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (r0 + i < ne) run += v[i];
+                if ((endmask >> (r0 + i)) & 1ull) {
+                    float *out = (piece == 0 && first_is_cont) ? vcont : vmain + (size_t)sdst[r0 + i] * 48;
+                    out[vt] = run;
+                    run = 0.0f;
+                    ++piece;
+                }
+            }
+        }
+    }
+}
+
+static bool g_chain_attr = false;
+
+kpd_status launch_gvp_chain(const GvpEdgeArgs &a, int tile_cap, hipStream_t st) {
+    if (tile_cap == 0) return KPD_OK;
+    if (!g_chain_attr) {
+        KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gvp_chain<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    ChainSmem<16>::FLOATS * 4));
+        KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gvp_chain<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    ChainSmem<8>::FLOATS * 4));
+        g_chain_attr = true;
+    }
+    KPD_REQUIRE(a.S == 256 || a.S == 128, KPD_ERR_INVALID, "gvp chain kernel: S=%d (supported 128, 256)", a.S);
+    const dim3 grid(8 * cdiv(tile_cap, 8));
+    if (a.S == 256)
+        hipLaunchKernelGGL(k_gvp_chain<16>, grid, dim3(256), ChainSmem<16>::FLOATS * 4, st, a);
+    else
+        hipLaunchKernelGGL(k_gvp_chain<8>, grid, dim3(256), ChainSmem<8>::FLOATS * 4, st, a);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+}  // namespace kpd

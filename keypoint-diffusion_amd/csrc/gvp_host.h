@@ -30,6 +30,10 @@ struct HostGvp {
     float *wproj_dst = nullptr;                         // h_dst block
     int ng = 0;
     int vec_sigmoid = 1;
+    int chain_pos = -1;                                 // position in an edge-message chain (-1: not a message GVP)
+    float *chain = nullptr, *whp = nullptr, *wup = nullptr;   // fragments for the chained edge kernel
+    int n_ht() const { return (h + 15) / 16; }
+    int chain_chunks() const { return chain_pos == 0 ? 2 + n_ht() : sout / 16 + 2; }
     int edge_scalars() const { return split == SPLIT_NONE ? s_in : 16; }
     GvpW dev() const {
         GvpW w;
@@ -37,6 +41,7 @@ struct HostGvp {
         w.vin = vin; w.h = h; w.vout = vout;
         w.n_s = edge_scalars();
         w.sout = sout; w.ng = ng; w.vec_sigmoid = vec_sigmoid;
+        w.chain = chain; w.whp = whp; w.wup = wup;
         return w;
     }
 };

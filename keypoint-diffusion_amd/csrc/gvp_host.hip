@@ -16,7 +16,8 @@ std::vector<std::string> split_dots(const std::string &s) {
 }
 
 size_t gvp_arena_bytes(int S) {
-    return ((size_t)NG_G * 2048 + 2 * GVH * GVH + 256 + 16 * 256 + 16 + 2 * (size_t)(S / 8) * 2048 + 256) * 4 + 8192;
+    return ((size_t)NG_G * 2048 + 2 * GVH * GVH + 256 + 16 * 256 + 16 + 2 * (size_t)(S / 8) * 2048 + 256 +
+            (size_t)(S / 16 + 2) * (S / 16) * 256 + 12 * 256) * 4 + 16384;
 }
 
 void alloc_gvp(Arena &A, HostGvp &g, std::set<std::string> &expected, const std::string &prefix) {
@@ -34,6 +35,11 @@ void alloc_gvp(Arena &A, HostGvp &g, std::set<std::string> &expected, const std:
         g.bproj = A.take<float>(256);
     }
     if (g.split == SPLIT_SRC_DST) g.wproj_dst = A.take<float>((size_t)(g.S / 8) * 2048);
+    if (g.chain_pos >= 0) {
+        g.chain = A.take<float>((size_t)g.chain_chunks() * (g.sout / 16) * 256);
+        g.whp = A.take<float>(g.chain_pos == 0 ? 9 * 256 : 256);
+        g.wup = A.take<float>((size_t)g.n_ht() * 256);
+    }
     for (const char *s : {".Wh", ".Wu", ".to_feats_out.0.weight", ".to_feats_out.0.bias", ".scalar_to_vector_gates.weight",
                           ".scalar_to_vector_gates.bias"})
         expected.insert(prefix + s);
@@ -63,9 +69,22 @@ kpd_status load_gvp_tensor(HostGvp &g, const std::string &param, const char *nam
     if (param == "Wh") {
         KPD_TRY(want_shape(name, shape, ndim, {g.vin, g.h}));
         KPD_TRY(copy_pad(w, g.vin * g.h, g.Wh, g.vin * g.h, st));
+        if (g.chain_pos == 0) {
+            // input vectors arrive as [x_diff | 16 source | (16 destination)] (gvp.py:474-480); the kernel feeds them as
+            // tiles [source], [destination], [x_diff]
+            const bool dst = g.vin == 2 * GV + 1;
+            KPD_TRY(pack_chain_frag(w, 1, g.h, g.h, 1, GV, g.n_ht(), g.whp, st));
+            if (dst) KPD_TRY(pack_chain_frag(w, 1, g.h, g.h, 1 + GV, GV, g.n_ht(), g.whp + 3 * 256, st));
+            KPD_TRY(pack_chain_frag(w, 1, g.h, g.h, 0, 1, g.n_ht(), g.whp + 6 * 256, st));
+        } else if (g.chain_pos > 0) {
+            KPD_TRY(pack_chain_frag(w, 1, g.h, g.h, 0, g.vin, 1, g.whp, st));
+        }
     } else if (param == "Wu") {
         KPD_TRY(want_shape(name, shape, ndim, {g.h, g.vout}));
         KPD_TRY(copy_pad(w, g.h * g.vout, g.Wu, g.h * g.vout, st));
+        if (g.chain_pos >= 0)
+            for (int ht = 0; ht < g.n_ht(); ++ht)
+                KPD_TRY(pack_chain_frag(w, 1, g.vout, g.vout, 16 * ht, std::min(16, g.h - 16 * ht), 1, g.wup + ht * 256, st));
     } else if (param == "to_feats_out.0.weight") {
         KPD_TRY(want_shape(name, shape, ndim, {g.sout, k_all}));
         if (g.split == SPLIT_SRC) {             // [h_src S | rbf 16 | sh h]
@@ -78,6 +97,21 @@ kpd_status load_gvp_tensor(HostGvp &g, const std::string &param, const char *nam
         } else {
             KPD_TRY(pack_gemm_weight_ng(w, g.sout, k_all, 0, k_all, g.ng, g.wp, st));
         }
+        if (g.chain_pos >= 0) {
+            const int nts = g.sout / 16, ch = nts * 256;
+            int c = 0;
+            if (g.chain_pos == 0) {
+                const int sh0 = g.split == SPLIT_SRC_DST ? 2 * g.S + 16 : g.S + 16;
+                KPD_TRY(pack_chain_frag(w, k_all, 1, g.sout, g.S, 16, nts, g.chain + (size_t)(c++) * ch, st));          // rbf
+                for (int ht = 0; ht < g.n_ht(); ++ht)
+                    KPD_TRY(pack_chain_frag(w, k_all, 1, g.sout, sh0 + 16 * ht, std::min(16, g.h - 16 * ht), nts,
+                                            g.chain + (size_t)(c++) * ch, st));
+            } else {
+                for (int nt = 0; nt < nts; ++nt)
+                    KPD_TRY(pack_chain_frag(w, k_all, 1, g.sout, 16 * nt, 16, nts, g.chain + (size_t)(c++) * ch, st));
+                KPD_TRY(pack_chain_frag(w, k_all, 1, g.sout, g.s_in, std::min(16, g.h), nts, g.chain + (size_t)(c++) * ch, st));
+            }
+        }
     } else if (param == "to_feats_out.0.bias") {
         KPD_TRY(want_shape(name, shape, ndim, {g.sout}));
         // split: the bias rides with the per-node source projection; the per-edge stage adds nothing
@@ -85,6 +119,11 @@ kpd_status load_gvp_tensor(HostGvp &g, const std::string &param, const char *nam
     } else if (param == "scalar_to_vector_gates.weight") {
         KPD_TRY(want_shape(name, shape, ndim, {g.vout, g.sout}));
         KPD_TRY(pack_gate_weight(w, g.vout, g.sout, g.wg, st));
+        if (g.chain_pos >= 0) {
+            float *gch = g.chain + (size_t)(g.chain_chunks() - 1) * (g.sout / 16) * 256;
+            for (int nt = 0; nt < g.sout / 16; ++nt)
+                KPD_TRY(pack_chain_frag(w, g.sout, 1, g.vout, 16 * nt, 16, 1, gch + nt * 256, st));
+        }
     } else if (param == "scalar_to_vector_gates.bias") {
         KPD_TRY(want_shape(name, shape, ndim, {g.vout}));
         KPD_TRY(copy_pad(w, g.vout, g.bg, 16, st));

@@ -25,6 +25,10 @@ struct GvpW {
     int sout;             // valid scalar outputs (256, 128 or 64)
     int ng;               // k-groups of the packed block
     int vec_sigmoid;      // 1: sigmoid gate, 0: identity (last noise GVP)
+    // chained edge kernel (gvp_chain.hip): 16x16x4 A-operand fragments, see HostGvp / load_gvp_tensor
+    const float *chain;   // weight chunks streamed through LDS: scalar GEMM k-slabs, then the gate slab
+    const float *whp;     // Wh fragments ([3 input tiles][3 hidden tiles][256] first GVP, [256] otherwise)
+    const float *wup;     // Wu fragments ([hidden tile][256])
 };
 
 constexpr int GVP_MAX_CHAIN = 4;
@@ -96,6 +100,8 @@ kpd_status launch_gvp_embed(const float *in, int n, int fin, const float *W, con
                             const float *ln_b, const float *t, const int *bidx, int S, float *out, hipStream_t st);
 kpd_status launch_gvp_proj(const GvpProjArgs &a, hipStream_t st);
 kpd_status launch_gvp_edge(const GvpEdgeArgs &a, int tile_cap, hipStream_t st);
+// same arguments, register-chained formulation (requires message chains prepared with chain_pos >= 0)
+kpd_status launch_gvp_chain(const GvpEdgeArgs &a, int tile_cap, hipStream_t st);
 kpd_status launch_gvp_node(const GvpNodePair &p, hipStream_t st);
 kpd_status launch_gvp_noise(const GvpNoiseArgs &a, hipStream_t st);
 

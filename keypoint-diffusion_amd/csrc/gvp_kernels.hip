@@ -15,6 +15,7 @@
 
 #include <algorithm>
 
+#include <cstdlib>
 #include "gvp_kernels.h"
 #include "mfma_core.h"
 
@@ -653,6 +654,12 @@ kpd_status launch_gvp_proj(const GvpProjArgs &a, hipStream_t st) {
 
 kpd_status launch_gvp_edge(const GvpEdgeArgs &a, int tile_cap, hipStream_t st) {
     if (tile_cap == 0) return KPD_OK;
+    // default: register-chained kernel (gvp_chain.hip); the LDS-staged kernel below stays for A/B runs and phase stamps
+    static const bool staged = getenv("KPD_GVP_EDGE_STAGED") && atoi(getenv("KPD_GVP_EDGE_STAGED")) != 0;
+    bool chained = true;
+    for (int et = 0; et < 4; ++et)
+        if (a.src[et] && !a.g[et][0].chain) chained = false;
+    if (!staged && !a.stamps && chained) return launch_gvp_chain(a, tile_cap, st);
     hipLaunchKernelGGL(k_gvp_edge, dim3(8 * cdiv(tile_cap, 8)), dim3(256), GVP_LDS_BYTES, st, a);
     KPD_LAUNCH_CHECK();
     return KPD_OK;

@@ -119,6 +119,23 @@ kpd_status pack_gate_weight(const float *src, int vout, int K, float *dst, hipSt
     return KPD_OK;
 }
 
+__global__ void k_pack_chain_frag(const float *__restrict__ src, int sn, int sk, int n_valid, int k_base, int k_valid,
+                                  int n_tiles, float *__restrict__ dst) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_tiles * 256) return;
+    const int r = idx & 3, lane = (idx >> 2) & 63, mt = idx >> 8;
+    const int n = 16 * mt + (lane & 15), i = 4 * (lane >> 4) + r;
+    dst[idx] = (n < n_valid && i < k_valid) ? src[(size_t)n * sn + (size_t)(k_base + i) * sk] : 0.0f;
+}
+
+kpd_status pack_chain_frag(const float *src, int sn, int sk, int n_valid, int k_base, int k_valid, int n_tiles, float *dst,
+                           hipStream_t st) {
+    KPD_REQUIRE(n_tiles >= 1 && k_valid >= 0 && k_valid <= 16, KPD_ERR_WEIGHTS, "pack_chain_frag: bad tile (%d, %d)", n_tiles, k_valid);
+    hipLaunchKernelGGL(k_pack_chain_frag, dim3(n_tiles), dim3(256), 0, st, src, sn, sk, n_valid, k_base, k_valid, n_tiles, dst);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
 __global__ void k_scale_inplace(float *__restrict__ p, int n, float f) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] *= f;

@@ -249,6 +249,7 @@ static void alloc_conv(kpd_recenc *m, Arena &A, std::vector<HostGvp> &msg, std::
         g.sout = S;
         g.split = j == 0 ? (use_dst ? SPLIT_SRC_DST : SPLIT_SRC) : SPLIT_NONE;
         g.S = S;
+        g.chain_pos = j;
         alloc_gvp(A, g, m->expected, pre + "edge_message." + std::to_string(j));
     }
     for (int j = 0; j < c.n_update_gvps; ++j) {
