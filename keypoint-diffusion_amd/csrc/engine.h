@@ -36,8 +36,6 @@ struct Arena {
 kpd_status pack_gemm_weight(const float *src, int n_out, int ld, int col0, int K, float *wp, float *wx, hipStream_t st);
 // General K (padded to 8 ng) and N <= 256 (no extra column): packed block of ng*2048 floats.
 kpd_status pack_gemm_weight_ng(const float *src, int n_out, int ld, int col0, int K, int ng, float *wp, hipStream_t st);
-kpd_status pack_gemm_weight_2ranges(const float *src, int n_out, int ld, int col0, int len0, int col1, int len1, int ng,
-                                    float *wp, hipStream_t st);
 kpd_status scale_inplace(float *p, int n, float f, hipStream_t st);
 kpd_status patch_bias_row(float *wp, float *wx, const float *bias, float f, int k, hipStream_t st);
 kpd_status pack_gate_weight(const float *src, int vout, int K, float *dst, hipStream_t st);

@@ -60,6 +60,14 @@ struct ChainSmem {
 
 }  // namespace
 
+// phase-cycle sums for profiles/tools/gvp_stamps.py (a.stamps is null in production)
+#define CHAIN_STAMP(idx)                                                                   \
+    if (stamps && tid == 0) {                                                              \
+        const unsigned long long t_now = __builtin_amdgcn_s_memtime();                     \
+        atomicAdd(stamps + (idx), t_now - t_prev);                                         \
+        t_prev = t_now;                                                                    \
+    }
+
 template <int NTS>
 __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
     using L = ChainSmem<NTS>;
@@ -72,6 +80,8 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
     int *misc = sdst + TM;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    unsigned long long *stamps = a.stamps;
+    unsigned long long t_prev = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
     const int T = a.meta[8];
     const int chunk_tiles = (T + 7) >> 3;
     const int bi = blockIdx.x >> 3;
@@ -125,12 +135,18 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
 #pragma unroll
         for (int j = 0; j < PT; ++j) pr[j] = gn[256 * j];
         __builtin_amdgcn_sched_barrier(0);      // keep the fetch at the head of the chunk: it has one chunk time to land
+        // MFMA streams yield to the other workgroup's epilogues, gathers and ring hand-offs (which run at priority 2):
+        // those are short and latency bound, and a wave stuck behind a full-rate MFMA stream stalls its whole workgroup
+        // at the next barrier
+        __builtin_amdgcn_s_setprio(0);
         return ring + (cur & 1) * CH4;
     };
     auto release = [&]() {
+        __builtin_amdgcn_s_setprio(2);
         lds_barrier();
         ++cur;
     };
+    __builtin_amdgcn_s_setprio(2);
 
     // ---- this lane's edge ---------------------------------------------------------------------------
     const int el = lane & 15, q = lane >> 4;
@@ -242,6 +258,7 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
         const int tail_reg = min(4, tail);
 
         lds_barrier();                                    // chunk 0 is in the ring
+        CHAIN_STAMP(0)
         // scalar GEMM: [rbf | sh] part of to_feats_out
         {
             const v4f *buf = acquire();
@@ -256,6 +273,7 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
                 release();
             }
         }
+        CHAIN_STAMP(1)
         const v4f bgv = *reinterpret_cast<const v4f *>(g0.bg + 4 * q);
         const v4f *wup = reinterpret_cast<const v4f *>(g0.wup) + lane;
         v4f wu[3];
@@ -270,6 +288,7 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
 #pragma unroll
             for (int mt = 0; mt < NTS; ++mt) acc[mt] = *reinterpret_cast<const v4f *>(bn + 16 * mt);
         }
+        CHAIN_STAMP(2)
         // gates                                                                       (gvp.py:105-107)
         {
             const v4f *buf = acquire() + lane;
@@ -287,6 +306,7 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
                 for (int r = 0; r < 4; ++r) gate[r] = sigmoidf_(gate[r]);
             }
         }
+        CHAIN_STAMP(3)
         // vec2: v' = gate * Wu^T Vh                                                   (gvp.py:97, 111)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -302,6 +322,7 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
             }
             Vc[c] = gate * t;
         }
+        CHAIN_STAMP(4)
     }
 
     // ---- GVP 1 .. n-1: scalars and vectors come from the previous GVP's registers ------------------------
@@ -320,6 +341,7 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             sh[r] = sqrtf(fmaxf(Vh[0][r] * Vh[0][r] + Vh[1][r] * Vh[1][r] + Vh[2][r] * Vh[2][r], 1e-8f));
+        CHAIN_STAMP(5)
 #pragma unroll
         for (int nt = 0; nt < NTS; ++nt) {
             const v4f *buf = acquire();
@@ -331,6 +353,7 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
             chunk_gemm<NTS>(buf, sh, acc, lane, 4);
             release();
         }
+        CHAIN_STAMP(6)
         const v4f bgv = *reinterpret_cast<const v4f *>(gk.bg + 4 * q);
         const v4f wu = reinterpret_cast<const v4f *>(gk.wup)[lane];
 #pragma unroll
@@ -342,6 +365,7 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
 #pragma unroll
             for (int mt = 0; mt < NTS; ++mt) acc[mt] = *reinterpret_cast<const v4f *>(bn + 16 * mt);
         }
+        CHAIN_STAMP(7)
         {
             const v4f *buf = acquire() + lane;
             v4f ga[4] = {zero4(), zero4(), zero4(), zero4()};
@@ -358,6 +382,7 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
                 for (int r = 0; r < 4; ++r) gate[r] = sigmoidf_(gate[r]);
             }
         }
+        CHAIN_STAMP(8)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             v4f t = zero4();
@@ -365,6 +390,7 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
             for (int r = 0; r < 4; ++r) t = mfma16(wu[r], Vh[c][r], t);
             Vc[c] = gate * t;
         }
+        CHAIN_STAMP(9)
     }
 
     // ---- messages -> LDS (the ring is free: every wave passed the last chunk's barrier) ------------------
@@ -383,6 +409,7 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
         vo[2] = v4f{f[8], f[9], f[10], f[11]};
     }
     lds_barrier();
+    CHAIN_STAMP(10)
 
     // ---- segmented sums over dst: scalars (thread = column), then the 48 vector floats ------------------
     const int first_is_cont = misc[0];
@@ -434,12 +461,18 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
             }
         }
     }
+    CHAIN_STAMP(11)
 }
 
 static bool g_chain_attr = false;
 
-kpd_status launch_gvp_chain(const GvpEdgeArgs &a, int tile_cap, hipStream_t st) {
+kpd_status launch_gvp_edge(const GvpEdgeArgs &a, int tile_cap, hipStream_t st) {
     if (tile_cap == 0) return KPD_OK;
+    for (int et = 0; et < 4; ++et)
+        if (a.src[et])
+            for (int k = 0; k < a.n_gvps; ++k)
+                KPD_REQUIRE(a.g[et][k].chain && a.g[et][k].whp && a.g[et][k].wup, KPD_ERR_STATE,
+                            "message GVP %d of edge type %d was not prepared for the chained edge kernel", k, et);
     if (!g_chain_attr) {
         KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gvp_chain<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     ChainSmem<16>::FLOATS * 4));

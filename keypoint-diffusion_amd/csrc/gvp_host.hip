@@ -24,17 +24,21 @@ void alloc_gvp(Arena &A, HostGvp &g, std::set<std::string> &expected, const std:
     g.h = std::max(g.vin, g.vout);
     const int k_edge = g.edge_scalars() + g.h;
     g.ng = (k_edge + 7) / 8;
-    g.Wh = A.take<float>(g.vin * g.h);
-    g.Wu = A.take<float>(g.h * g.vout);
-    g.wp = A.take<float>((size_t)g.ng * 2048);
     g.b = A.take<float>(256);
-    g.wg = A.take<float>((size_t)(g.sout / 16) * 256);
     g.bg = A.take<float>(16);
+    if (g.chain_pos < 0) {      // LDS-staged form (gvp_stage: node update, noise head)
+        g.Wh = A.take<float>(g.vin * g.h);
+        g.Wu = A.take<float>(g.h * g.vout);
+        g.wp = A.take<float>((size_t)g.ng * 2048);
+        g.wg = A.take<float>((size_t)(g.sout / 16) * 256);
+    }
     if (g.split != SPLIT_NONE) {
         g.wproj = A.take<float>((size_t)(g.S / 8) * 2048);
         g.bproj = A.take<float>(256);
     }
     if (g.split == SPLIT_SRC_DST) g.wproj_dst = A.take<float>((size_t)(g.S / 8) * 2048);
+    // a split first Linear exists only at the head of an edge-message chain
+    if ((g.split != SPLIT_NONE) != (g.chain_pos == 0)) set_error("internal: GVP split/chain position mismatch");
     if (g.chain_pos >= 0) {
         g.chain = A.take<float>((size_t)g.chain_chunks() * (g.sout / 16) * 256);
         g.whp = A.take<float>(g.chain_pos == 0 ? 9 * 256 : 256);
@@ -68,7 +72,7 @@ kpd_status load_gvp_tensor(HostGvp &g, const std::string &param, const char *nam
     const int k_all = g.s_in + g.h;
     if (param == "Wh") {
         KPD_TRY(want_shape(name, shape, ndim, {g.vin, g.h}));
-        KPD_TRY(copy_pad(w, g.vin * g.h, g.Wh, g.vin * g.h, st));
+        if (g.chain_pos < 0) KPD_TRY(copy_pad(w, g.vin * g.h, g.Wh, g.vin * g.h, st));
         if (g.chain_pos == 0) {
             // input vectors arrive as [x_diff | 16 source | (16 destination)] (gvp.py:474-480); the kernel feeds them as
             // tiles [source], [destination], [x_diff]
@@ -81,7 +85,7 @@ kpd_status load_gvp_tensor(HostGvp &g, const std::string &param, const char *nam
         }
     } else if (param == "Wu") {
         KPD_TRY(want_shape(name, shape, ndim, {g.h, g.vout}));
-        KPD_TRY(copy_pad(w, g.h * g.vout, g.Wu, g.h * g.vout, st));
+        if (g.chain_pos < 0) KPD_TRY(copy_pad(w, g.h * g.vout, g.Wu, g.h * g.vout, st));
         if (g.chain_pos >= 0)
             for (int ht = 0; ht < g.n_ht(); ++ht)
                 KPD_TRY(pack_chain_frag(w, 1, g.vout, g.vout, 16 * ht, std::min(16, g.h - 16 * ht), 1, g.wup + ht * 256, st));
@@ -89,12 +93,10 @@ kpd_status load_gvp_tensor(HostGvp &g, const std::string &param, const char *nam
         KPD_TRY(want_shape(name, shape, ndim, {g.sout, k_all}));
         if (g.split == SPLIT_SRC) {             // [h_src S | rbf 16 | sh h]
             KPD_TRY(pack_gemm_weight_ng(w, g.sout, k_all, 0, g.S, g.S / 8, g.wproj, st));
-            KPD_TRY(pack_gemm_weight_ng(w, g.sout, k_all, g.S, k_all - g.S, g.ng, g.wp, st));
         } else if (g.split == SPLIT_SRC_DST) {  // [h_src S | rbf 16 | h_dst S | sh h]
             KPD_TRY(pack_gemm_weight_ng(w, g.sout, k_all, 0, g.S, g.S / 8, g.wproj, st));
             KPD_TRY(pack_gemm_weight_ng(w, g.sout, k_all, g.S + 16, g.S, g.S / 8, g.wproj_dst, st));
-            KPD_TRY(pack_gemm_weight_2ranges(w, g.sout, k_all, g.S, 16, 2 * g.S + 16, g.h, g.ng, g.wp, st));
-        } else {
+        } else if (g.chain_pos < 0) {
             KPD_TRY(pack_gemm_weight_ng(w, g.sout, k_all, 0, k_all, g.ng, g.wp, st));
         }
         if (g.chain_pos >= 0) {
@@ -118,7 +120,7 @@ kpd_status load_gvp_tensor(HostGvp &g, const std::string &param, const char *nam
         KPD_TRY(copy_pad(w, g.sout, g.split != SPLIT_NONE ? g.bproj : g.b, 256, st));
     } else if (param == "scalar_to_vector_gates.weight") {
         KPD_TRY(want_shape(name, shape, ndim, {g.vout, g.sout}));
-        KPD_TRY(pack_gate_weight(w, g.vout, g.sout, g.wg, st));
+        if (g.chain_pos < 0) KPD_TRY(pack_gate_weight(w, g.vout, g.sout, g.wg, st));
         if (g.chain_pos >= 0) {
             float *gch = g.chain + (size_t)(g.chain_chunks() - 1) * (g.sout / 16) * 256;
             for (int nt = 0; nt < g.sout / 16; ++nt)

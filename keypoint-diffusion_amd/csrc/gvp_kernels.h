@@ -99,9 +99,8 @@ kpd_status gvp_kernels_init();
 kpd_status launch_gvp_embed(const float *in, int n, int fin, const float *W, const float *b, const float *ln_w,
                             const float *ln_b, const float *t, const int *bidx, int S, float *out, hipStream_t st);
 kpd_status launch_gvp_proj(const GvpProjArgs &a, hipStream_t st);
+// edge messages + segmented sums (gvp_chain.hip); message chains are HostGvp with chain_pos >= 0
 kpd_status launch_gvp_edge(const GvpEdgeArgs &a, int tile_cap, hipStream_t st);
-// same arguments, register-chained formulation (requires message chains prepared with chain_pos >= 0)
-kpd_status launch_gvp_chain(const GvpEdgeArgs &a, int tile_cap, hipStream_t st);
 kpd_status launch_gvp_node(const GvpNodePair &p, hipStream_t st);
 kpd_status launch_gvp_noise(const GvpNoiseArgs &a, hipStream_t st);
 

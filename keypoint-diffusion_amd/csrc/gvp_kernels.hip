@@ -15,7 +15,6 @@
 
 #include <algorithm>
 
-#include <cstdlib>
 #include "gvp_kernels.h"
 #include "mfma_core.h"
 
@@ -45,20 +44,8 @@ __device__ __forceinline__ GvpSmem gvp_smem(float *smem) {
 }
 
 // ---- one GVP stage ------------------------------------------------------------------------
-// add_row / add_row2 (optional): per-row terms added before the activation,
-// add_row[row_index[r] * add_ld + col] (+ add_row2[row_index2[r] * add_ld + col]).
-#define GVP_STAMP(idx)                                                                     \
-    if (stamps && tid == 0) {                                                              \
-        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                      \
-        atomicAdd(&stamps[idx], (unsigned long long)(now_ - *t_prev));                     \
-        *t_prev = now_;                                                                    \
-    }
-
-__device__ __forceinline__ void gvp_stage(const GvpSmem &s, const GvpW &w, const float *__restrict__ add_row,
-                                          const int *row_index, int add_ld, int tid,
-                                          const float *__restrict__ add_row2 = nullptr, const int *row_index2 = nullptr,
-                                          unsigned long long *stamps = nullptr, unsigned long long *t_prev = nullptr,
-                                          int stamp_base = 0) {
+// (node-update and noise-head GVPs; the edge-message chains run in gvp_chain.hip)
+__device__ __forceinline__ void gvp_stage(const GvpSmem &s, const GvpW &w, int tid) {
     const int wave = tid >> 6, lane = tid & 63;
     // 16x16x4 MFMA roles of this lane: rows (edges / nodes) 16 wave + (lane & 15) as A operand, output
     // column lane & 15, output rows 16 wave + 4 (lane >> 4) + reg.  Every wave works on its own 16 rows in the
@@ -119,7 +106,6 @@ __device__ __forceinline__ void gvp_stage(const GvpSmem &s, const GvpW &w, const
         }
     }
     lds_barrier();
-    GVP_STAMP(stamp_base + 0)
 
     // GEMM + activation -> A tile columns 0..255
     {
@@ -127,8 +113,6 @@ __device__ __forceinline__ void gvp_stage(const GvpSmem &s, const GvpW &w, const
         acc_zero(acc);
         gemm_rows64_rt<SA_G>(s.A, w.wp, w.ng, acc, wave, lane);
         lds_barrier();
-        GVP_STAMP(stamp_base + 1)
-        const bool fused_act = add_row == nullptr;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int col = acc_col(nt, wave, lane);
@@ -138,29 +122,11 @@ __device__ __forceinline__ void gvp_stage(const GvpSmem &s, const GvpW &w, const
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const float val = acc[mt][nt][reg] + bb;
-                    s.A[acc_row(mt, reg, lane) * SA_G + col] = fused_act ? silu(val) : val;
+                    s.A[acc_row(mt, reg, lane) * SA_G + col] = silu(val);
                 }
-        }
-        if (!fused_act) {
-            // gathered per-row terms (node projections of the first message Linear): row-wise and coalesced --
-            // one 16-B load per lane per row instead of 64 scattered dword loads in the accumulator layout
-            lds_barrier();
-            const int chunks = add_ld >> 2;
-#pragma unroll 4
-            for (int rr = 0; rr < 16; ++rr) {
-                const int r = wave * 16 + rr;
-                if (lane < chunks) {
-                    f32x4_ v = *reinterpret_cast<const f32x4_ *>(s.A + r * SA_G + 4 * lane);
-                    v += reinterpret_cast<const f32x4_ *>(add_row + (size_t)row_index[r] * add_ld)[lane];
-                    if (add_row2) v += reinterpret_cast<const f32x4_ *>(add_row2 + (size_t)row_index2[r] * add_ld)[lane];
-                    v[0] = silu(v[0]); v[1] = silu(v[1]); v[2] = silu(v[2]); v[3] = silu(v[3]);
-                    *reinterpret_cast<f32x4_ *>(s.A + r * SA_G + 4 * lane) = v;
-                }
-            }
         }
     }
     lds_barrier();
-    GVP_STAMP(stamp_base + 2)
 
     // gates (gvp.py:105-107): 16 rows per wave, K = sout; the result stays in registers -- its layout
     // (column u on the lane, rows in the 4 registers) is exactly that of the vec2 product below
@@ -187,7 +153,6 @@ __device__ __forceinline__ void gvp_stage(const GvpSmem &s, const GvpW &w, const
             gate[2] = sigmoidf_(gate[2]); gate[3] = sigmoidf_(gate[3]);
         }
     }
-    GVP_STAMP(stamp_base + 3)
 
     // vec2: v'[e][u][c] = act(gate[e][u]) * sum_h Vh[e][h][c] Wu[h][u]  (gvp.py:97, 111), same MFMA shape
     {
@@ -221,7 +186,6 @@ __device__ __forceinline__ void gvp_stage(const GvpSmem &s, const GvpW &w, const
         }
     }
     lds_barrier();
-    GVP_STAMP(stamp_base + 4)
 }
 
 // LayerNorm over the first S columns of every A-tile row (affine), in place.  (gvp.py:161)
@@ -367,139 +331,6 @@ __global__ __launch_bounds__(256, 2) void k_gvp_proj(GvpProjArgs a) {
     }
 }
 
-// ---- fused edge kernel: geometry, message GVP chain, segmented sum ----------------------------
-__global__ __launch_bounds__(256) void k_gvp_edge(GvpEdgeArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const GvpSmem s = gvp_smem(smem);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int S = a.S;
-    unsigned long long *stamps = a.stamps;
-    unsigned long long t_prev_v = stamps ? __builtin_amdgcn_s_memtime() : 0ull, *t_prev = &t_prev_v;
-
-    const int T = a.meta[8];
-    const int chunk = (T + 7) >> 3;
-    const int bi = blockIdx.x >> 3;
-    if (bi >= chunk) return;
-    const int tile = (blockIdx.x & 7) * chunk + bi;
-    if (tile >= T) return;
-    int et = 0;
-#pragma unroll
-    for (int e = 1; e < 4; ++e)
-        if (tile >= a.meta[4 + e]) et = e;
-    const int tile_in_et = tile - a.meta[4 + et];
-    const int e0 = tile_in_et * TM;
-    const int ne = min(TM, a.meta[et] - e0);
-    const int snt = (et == 1 || et == 3) ? 1 : 0, dnt = (et >= 2) ? 1 : 0;      // ll, kl, lk, kk
-    const int *__restrict__ esrc = a.src[et];
-    const int *__restrict__ edst = a.dst[et];
-
-    // phase 0: endpoints, unit difference vector, rbf embedding (gvp.py:474-480, 26-41)
-    if (tid < TM) {
-        const int e = e0 + min(tid, ne - 1);
-        const int u = esrc[e], v = edst[e];
-        s.src[tid] = u;
-        s.dst[tid] = v;
-        const float *xs = a.x[snt] + (size_t)u * 3, *xd = a.x[dnt] + (size_t)v * 3;
-        const float dx = xs[0] - xd[0], dy = xs[1] - xd[1], dz = xs[2] - xd[2];
-        const float dij = sqrtf(fmaxf(dx * dx + dy * dy + dz * dz, 1e-8f)) + 1e-8f;
-        float *v0 = s.V0 + tid * VST;
-        v0[0] = dx / dij; v0[1] = dy / dij; v0[2] = dz / dij;
-        const float sigma = a.rbf_dmax / 16.0f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float mu = a.rbf_dmax * (float)i / 15.0f;
-            const float zz = (dij - mu) / sigma;
-            s.A[tid * SA_G + i] = expf(-zz * zz);
-        }
-        const int vprev = tid > 0 ? edst[e0 + min(tid - 1, ne - 1)] : (e0 > 0 ? edst[e0 - 1] : -1);
-        const int vnext = tid + 1 < ne ? edst[e0 + tid + 1] : -2;
-        const unsigned long long ends = __ballot(tid < ne && vnext != v);
-        if (tid == 0) {
-            s.misc[0] = (vprev == v) ? 1 : 0;
-            s.misc[2] = (int)(ends & 0xffffffffu);
-            s.misc[3] = (int)(ends >> 32);
-        }
-    }
-    lds_barrier();
-    {   // source (and destination) vectors: 48 floats per edge each, 4 threads x 3 float4
-        const int row = tid >> 2, q = tid & 3;
-        const f32x4_ *vs = reinterpret_cast<const f32x4_ *>(a.v[snt] + (size_t)s.src[row] * 48);
-        float *o = s.V0 + row * VST + 3;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const f32x4_ val = vs[q * 3 + i];
-            o[(q * 3 + i) * 4 + 0] = val[0]; o[(q * 3 + i) * 4 + 1] = val[1];
-            o[(q * 3 + i) * 4 + 2] = val[2]; o[(q * 3 + i) * 4 + 3] = val[3];
-        }
-        if (a.use_dst) {
-            const f32x4_ *vd = reinterpret_cast<const f32x4_ *>(a.v[dnt] + (size_t)s.dst[row] * 48);
-            float *od = o + 48;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const f32x4_ val = vd[q * 3 + i];
-                od[(q * 3 + i) * 4 + 0] = val[0]; od[(q * 3 + i) * 4 + 1] = val[1];
-                od[(q * 3 + i) * 4 + 2] = val[2]; od[(q * 3 + i) * 4 + 3] = val[3];
-            }
-        }
-    }
-    lds_barrier();
-    GVP_STAMP(0)
-
-    for (int k = 0; k < a.n_gvps; ++k)
-        gvp_stage(s, a.g[et][k], k == 0 ? a.Psrc[et] : nullptr, s.src, S, tid,
-                  (k == 0 && a.use_dst) ? a.Pdst[et] : nullptr, s.dst, stamps, t_prev, 1 + 5 * k);
-
-    // segmented sums over dst: scalars (thread = column), then the 48 vector floats
-    const int first_is_cont = s.misc[0];
-    const unsigned long long endmask =
-        ((unsigned long long)(unsigned)s.misc[3] << 32) | (unsigned long long)(unsigned)s.misc[2];
-    if (tid < S) {
-        float *smain = a.ms_main[et], *scont = a.ms_cont[et] + (size_t)tile_in_et * S;
-        float run = 0.0f;
-        int piece = 0;
-#pragma unroll 1
-        for (int r0 = 0; r0 < TM; r0 += 16) {
-            if (r0 >= ne) break;
-            float v[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = s.A[(r0 + i) * SA_G + tid];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if (r0 + i < ne) run += v[i];
-                if ((endmask >> (r0 + i)) & 1ull) {
-                    float *out = (piece == 0 && first_is_cont) ? scont : smain + (size_t)s.dst[r0 + i] * S;
-                    out[tid] = run;
-                    run = 0.0f;
-                    ++piece;
-                }
-            }
-        }
-    }
-    if (tid < 48) {
-        float *vmain = a.mv_main[et], *vcont = a.mv_cont[et] + (size_t)tile_in_et * 48;
-        float run = 0.0f;
-        int piece = 0;
-#pragma unroll 1
-        for (int r0 = 0; r0 < TM; r0 += 16) {
-            if (r0 >= ne) break;
-            float v[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = s.V0[(r0 + i) * VST + tid];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if (r0 + i < ne) run += v[i];
-                if ((endmask >> (r0 + i)) & 1ull) {
-                    float *out = (piece == 0 && first_is_cont) ? vcont : vmain + (size_t)s.dst[r0 + i] * 48;
-                    out[tid] = run;
-                    run = 0.0f;
-                    ++piece;
-                }
-            }
-        }
-    }
-    GVP_STAMP(31)
-}
-
 // ---- node update (gvp.py:499-536) ---------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_gvp_node(GvpNodePair p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -565,7 +396,7 @@ __global__ __launch_bounds__(256) void k_gvp_node(GvpNodePair p) {
         if (lane < 48) s.V2[r * VST + lane] = s.V0[r * VST + lane];
     }
     lds_barrier();
-    for (int k = 0; k < a.n_gvps; ++k) gvp_stage(s, a.g[k], nullptr, nullptr, 0, tid);
+    for (int k = 0; k < a.n_gvps; ++k) gvp_stage(s, a.g[k], tid);
     // residual + update layer norm (gvp.py:524-532)
     for (int rr = 0; rr < 16; ++rr) {
         const int r = wave * 16 + rr, v = node0 + r;
@@ -606,7 +437,7 @@ __global__ __launch_bounds__(256) void k_gvp_noise(GvpNoiseArgs a) {
         if (lane < 48) s.V0[r * VST + lane] = v < a.n ? a.v[(size_t)v * 48 + lane] : 0.0f;
     }
     lds_barrier();
-    for (int k = 0; k < a.n_gvps; ++k) gvp_stage(s, a.g[k], nullptr, nullptr, 0, tid);
+    for (int k = 0; k < a.n_gvps; ++k) gvp_stage(s, a.g[k], tid);
     // eps_h = W_out s (64 -> F), eps_x = the single output vector
     const int row = tid >> 2, q = tid & 3, v = node0 + row;
     if (v < a.n) {
@@ -626,8 +457,6 @@ kpd_status gvp_kernels_init() {
     if (g_gvp_attr) return KPD_OK;
     KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gvp_proj), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 TM * SA_G * 4));
-    KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gvp_edge), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                GVP_LDS_BYTES));
     KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gvp_node), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 GVP_LDS_BYTES));
     KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gvp_noise), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -648,19 +477,6 @@ kpd_status launch_gvp_embed(const float *in, int n, int fin, const float *W, con
 kpd_status launch_gvp_proj(const GvpProjArgs &a, hipStream_t st) {
     if (a.n_slots == 0 || a.tiles_first[a.n_slots] == 0) return KPD_OK;
     hipLaunchKernelGGL(k_gvp_proj, dim3(a.tiles_first[a.n_slots]), dim3(256), TM * SA_G * 4, st, a);
-    KPD_LAUNCH_CHECK();
-    return KPD_OK;
-}
-
-kpd_status launch_gvp_edge(const GvpEdgeArgs &a, int tile_cap, hipStream_t st) {
-    if (tile_cap == 0) return KPD_OK;
-    // default: register-chained kernel (gvp_chain.hip); the LDS-staged kernel below stays for A/B runs and phase stamps
-    static const bool staged = getenv("KPD_GVP_EDGE_STAGED") && atoi(getenv("KPD_GVP_EDGE_STAGED")) != 0;
-    bool chained = true;
-    for (int et = 0; et < 4; ++et)
-        if (a.src[et] && !a.g[et][0].chain) chained = false;
-    if (!staged && !a.stamps && chained) return launch_gvp_chain(a, tile_cap, st);
-    hipLaunchKernelGGL(k_gvp_edge, dim3(8 * cdiv(tile_cap, 8)), dim3(256), GVP_LDS_BYTES, st, a);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
 }

@@ -67,32 +67,6 @@ kpd_status pack_gemm_weight(const float *src, int n_out, int ld, int col0, int K
     return KPD_OK;
 }
 
-// K rows taken from two column ranges of the source: k < len0 -> col0 + k, else col1 + (k - len0).
-__global__ void k_pack_gemm_weight_2r(const float *__restrict__ src, int n_out, int ld, int col0, int len0, int col1, int len1,
-                                      float *__restrict__ wp, int wp_floats) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < wp_floats) {
-        const int j = idx & 3, nt = (idx >> 2) & 1, lane = (idx >> 3) & 63, wave = (idx >> 9) & 3, g = idx >> 11;
-        const int k = 8 * g + 4 * (lane >> 5) + j;
-        const int n = 64 * wave + 32 * nt + (lane & 31);
-        float v = 0.0f;
-        if (n < n_out) {
-            if (k < len0) v = src[(size_t)n * ld + col0 + k];
-            else if (k < len0 + len1) v = src[(size_t)n * ld + col1 + (k - len0)];
-        }
-        wp[idx] = v;
-    }
-}
-
-kpd_status pack_gemm_weight_2ranges(const float *src, int n_out, int ld, int col0, int len0, int col1, int len1, int ng,
-                                    float *wp, hipStream_t st) {
-    KPD_REQUIRE(len0 + len1 <= 8 * ng && n_out <= 256, KPD_ERR_WEIGHTS, "pack2r: K=%d n_out=%d", len0 + len1, n_out);
-    const int n = ng * 4 * 64 * 8;
-    hipLaunchKernelGGL(k_pack_gemm_weight_2r, dim3(cdiv(n, 256)), dim3(256), 0, st, src, n_out, ld, col0, len0, col1, len1, wp, n);
-    KPD_LAUNCH_CHECK();
-    return KPD_OK;
-}
-
 kpd_status pack_gemm_weight_ng(const float *src, int n_out, int ld, int col0, int K, int ng, float *wp, hipStream_t st) {
     KPD_REQUIRE(K <= 8 * ng && n_out <= 256, KPD_ERR_WEIGHTS, "pack: K=%d n_out=%d exceed %d/256", K, n_out, 8 * ng);
     const int n = ng * 4 * 64 * 8;

@@ -19,11 +19,18 @@ with torch.no_grad():
         model.dynamics(g, t, None)
     torch.cuda.synchronize()
     vals = eng.debug('stamps', 64).view(torch.int32).view(-1).view(torch.int64).cpu().tolist()
-names = {0: 'geometry+gather', 31: 'segmented sums'}
-for k in range(3):
-    for i, nm in enumerate(['W->LDS + vec1', 'GEMM', 'T-store(+gather)', 'gates', 'vec2']):
-        names[1 + 5 * k + i] = f'GVP{k} {nm}'
+if os.environ.get('KPD_GVP_EDGE_STAGED', '0') != '0':
+    names = {0: 'geometry+gather', 31: 'segmented sums'}
+    for k in range(3):
+        for i, nm in enumerate(['W->LDS + vec1', 'GEMM', 'T-store(+gather)', 'gates', 'vec2']):
+            names[1 + 5 * k + i] = f'GVP{k} {nm}'
+    kernel = 'k_gvp_edge'
+else:
+    names = dict(enumerate(['gathers + geometry + vec1 (GVP0)', 'GVP0 GEMM chunks', 'GVP0 SiLU + bias preload', 'GVP0 gates',
+                            'GVP0 vec2', 'GVP1+ vec1', 'GVP1+ GEMM chunks', 'GVP1+ SiLU + bias preload', 'GVP1+ gates',
+                            'GVP1+ vec2', 'messages -> LDS', 'segmented sums']))
+    kernel = 'k_gvp_chain'
 tot = sum(vals)
-print(wl, 'k_gvp_edge phase shares:')
+print(wl, kernel, 'phase shares (wave 0 of every workgroup):')
 for i in sorted(names):
-    print(f'  {names[i]:26s} {100 * vals[i] / tot:5.1f} %   {vals[i] / 1e6:10.1f} Mcycles')
+    print(f'  {names[i]:34s} {100 * vals[i] / tot:5.1f} %   {vals[i] / 1e6:10.1f} Mcycles')
