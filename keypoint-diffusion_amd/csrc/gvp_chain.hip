@@ -54,7 +54,7 @@ struct ChainSmem {
     static constexpr int S = 16 * NTS;
     static constexpr int CH4 = NTS * 64;                 // float4 per chunk
     static constexpr int SO = S + 4;                     // row stride of the output staging tile
-    static constexpr int REGION0 = (2 * CH4 * 4 > TM * SO) ? 2 * CH4 * 4 : TM * SO;   // ring / output tile (floats)
+    static constexpr int REGION0 = (3 * CH4 * 4 > TM * SO) ? 3 * CH4 * 4 : TM * SO;   // ring / output tile (floats)
     static constexpr int FLOATS = REGION0 + TM * 48 + TM + 16;
 };
 
@@ -114,35 +114,37 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
         }
         return reinterpret_cast<const v4f *>(a.g[et][stage].chain) + (size_t)local * CH4 + tid;
     };
-    v4f pr[PT];
-    {
-        const v4f *g0 = chunk_src(0);
+    // Chunks travel global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write), two
+    // chunks ahead of the one being consumed, through a ring of three buffers.
+    //   acquire(): every wave has passed the barrier that ended chunk cur - 1, so buffer (cur + 2) % 3 (last read
+    //              for chunk cur - 1) is free: start chunk cur + 2 into it; return the buffer of chunk cur.
+    //   release(): wait for this thread's pieces of chunk cur + 1 (the PT pieces of chunk cur + 2 may stay in
+    //              flight), then barrier: everybody's pieces of chunk cur + 1 are in LDS and chunk cur is retired.
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+    auto fetch = [&](int c, int b) {
+        const v4f *g = chunk_src(min(c, total - 1));
+        v4f *dst = ring + b * CH4 + 64 * wave;
 #pragma unroll
-        for (int j = 0; j < PT; ++j) pr[j] = g0[256 * j];
-#pragma unroll
-        for (int j = 0; j < PT; ++j) ring[tid + 256 * j] = pr[j];
-        const v4f *g1 = chunk_src(min(1, total - 1));
-#pragma unroll
-        for (int j = 0; j < PT; ++j) pr[j] = g1[256 * j];
-    }
-    // acquire(): publish the prefetched chunk cur + 1 into the other ring buffer (its last readers finished before
-    // the previous barrier), start fetching chunk cur + 2, return the buffer of chunk cur.  release(): barrier.
+        for (int j = 0; j < PT; ++j)
+            __builtin_amdgcn_global_load_lds((glb_void *)(g + 256 * j), (lds_void *)(dst + 256 * j), 16, 0, 0);
+    };
+    fetch(0, 0);
+    fetch(1, 1);
     auto acquire = [&]() -> const v4f * {
-        v4f *nb = ring + ((cur + 1) & 1) * CH4;
-#pragma unroll
-        for (int j = 0; j < PT; ++j) nb[tid + 256 * j] = pr[j];
-        const v4f *gn = chunk_src(min(cur + 2, total - 1));
-#pragma unroll
-        for (int j = 0; j < PT; ++j) pr[j] = gn[256 * j];
-        __builtin_amdgcn_sched_barrier(0);      // keep the fetch at the head of the chunk: it has one chunk time to land
-        // MFMA streams yield to the other workgroup's epilogues, gathers and ring hand-offs (which run at priority 2):
-        // those are short and latency bound, and a wave stuck behind a full-rate MFMA stream stalls its whole workgroup
-        // at the next barrier
+        int b2 = cur + 2;
+        b2 -= 3 * (b2 / 3);
+        fetch(cur + 2, b2);
+        __builtin_amdgcn_sched_barrier(0);
+        // MFMA streams yield to the other workgroup's epilogues, gathers and ring hand-offs (priority 2): those are
+        // short and latency bound, and a wave stuck behind a full-rate MFMA stream stalls its whole workgroup
         __builtin_amdgcn_s_setprio(0);
-        return ring + (cur & 1) * CH4;
+        return ring + (cur - 3 * (cur / 3)) * CH4;
     };
     auto release = [&]() {
         __builtin_amdgcn_s_setprio(2);
+        if (PT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         lds_barrier();
         ++cur;
     };
@@ -257,7 +259,9 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
         const int tail = h0 - 16 * (n_ht - 1);            // valid rows of the last hidden tile
         const int tail_reg = min(4, tail);
 
-        lds_barrier();                                    // chunk 0 is in the ring
+        if (PT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // chunk 0 has landed (chunk 1 may be in flight)
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        lds_barrier();
         CHAIN_STAMP(0)
         // scalar GEMM: [rbf | sh] part of to_feats_out
         {
@@ -393,7 +397,9 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
         CHAIN_STAMP(9)
     }
 
-    // ---- messages -> LDS (the ring is free: every wave passed the last chunk's barrier) ------------------
+    // ---- messages -> LDS: the ring is reused, so drain the (redundant) tail fetches first -----------------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
     {
         float *orow = O + row * SO + 4 * q;
 #pragma unroll
