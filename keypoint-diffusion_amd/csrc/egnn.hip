@@ -18,6 +18,7 @@ namespace {
 struct LayerW {
     // per edge type
     float *wp_e[4], *wx_e[4], *b_e[4], *wr_e[4], *watt[4];
+    float *chain[4], *wcol_e[4], *wcol_c[4];    // chained edge kernel: W2 chunks [coord 16 | edge 16], column 256 of W2
     float *wp_c[4], *wx_c[4], *b_c[4], *wr_c[4], *w3[4];
     // per node type, per projection slot
     float *wp_p[2][NSLOT], *wx_p[2][NSLOT], *b_p[2][NSLOT];
@@ -71,6 +72,7 @@ struct kpd_egnn {
     std::set<std::string> expected, loaded;
     bool committed = false;
     int debug_layers = -1;
+    int edge_chain = -1;                       // 1: register-chained edge kernel (egnn_chain.hip); -1: KPD_EDGE_CHAIN or staged
     // optional HIP-event timing of the dominant kernel (k_egnn_edge), for bench.py's roofline
     unsigned long long *stamps = nullptr;      // device [16], diagnostics (kpd_egnn_debug_state "stamps=1")
     bool prof_on = false;
@@ -96,6 +98,7 @@ static kpd_status build_weight_arena(kpd_egnn *m) {
     bytes += (size_t)(64 * c.atom_nf + 64 + 64 * 256 + 256 + 2 * c.rec_nf * c.rec_nf + 2 * c.rec_nf +
                       2 * c.rec_nf * 256 + 256 + 2 * c.atom_nf * 256 + 2 * c.atom_nf + 2 * c.atom_nf * c.atom_nf +
                       c.atom_nf) * 4 + 64 * 256;
+    bytes += (size_t)c.n_layers * m->n_et * (32 * 4096 + 2 * HS + 64) * 4;
     bytes += 1 << 20;
     kpd_status st = m->warena.reserve(bytes);
     if (st != KPD_OK) return st;
@@ -110,6 +113,7 @@ static kpd_status build_weight_arena(kpd_egnn *m) {
         for (int et = 0; et < m->n_et; ++et) {
             w.wp_e[et] = wp(); w.wx_e[et] = vec(); w.b_e[et] = vec(); w.wr_e[et] = vec(); w.watt[et] = vec();
             w.wp_c[et] = wp(); w.wx_c[et] = vec(); w.b_c[et] = vec(); w.wr_c[et] = vec(); w.w3[et] = vec();
+            w.chain[et] = A.take<float>(32 * 4096); w.wcol_e[et] = vec(); w.wcol_c[et] = vec();
             for (int var = 0; var < 2; ++var) {
                 const int ss = kSrcSlot[et] + var, ds = kDstSlot[et] + var;
                 w.wp_p[kSrcNt[et]][ss] = wp(); w.wx_p[kSrcNt[et]][ss] = vec();
@@ -312,6 +316,10 @@ extern "C" kpd_status kpd_egnn_load_weight(kpd_egnn *m, const char *name, const 
                 if (is_w) {
                     KPD_TRY(expect_shape(name, shape, ndim, {HW, HW}));
                     KPD_TRY(pack_gemm_weight(w, HW, HW, 0, HW, var ? L.wp_c[et] : L.wp_e[et], var ? L.wx_c[et] : L.wx_e[et], st));
+                    // chained kernel (egnn_chain.hip): the 256 x 256 block as sixteen 16-row k-slabs, column 256 apart
+                    for (int kc = 0; kc < 16; ++kc)
+                        KPD_TRY(pack_chain_frag(w, HW, 1, 256, 16 * kc, 16, 16, L.chain[et] + (size_t)((var ? 0 : 16) + kc) * 4096, st));
+                    KPD_TRY(copy_col_pad(w, 256, HW, 256, var ? L.wcol_c[et] : L.wcol_e[et], HS, st));
                 } else {
                     KPD_TRY(expect_shape(name, shape, ndim, {HW}));
                     KPD_TRY(copy_pad(w, HW, var ? L.b_c[et] : L.b_e[et], HS, st));
@@ -511,6 +519,7 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
             ea.src_nt[et] = kSrcNt[et]; ea.dst_nt[et] = kDstNt[et]; ea.src_slot[et] = kSrcSlot[et]; ea.dst_slot[et] = kDstSlot[et];
             ea.wr_e[et] = L.wr_e[et]; ea.wr_c[et] = L.wr_c[et];
             ea.wp_e[et] = L.wp_e[et]; ea.wx_e[et] = L.wx_e[et]; ea.b_e[et] = L.b_e[et];
+            ea.chain[et] = L.chain[et]; ea.wcol_e[et] = L.wcol_e[et]; ea.wcol_c[et] = L.wcol_c[et];
             ea.wp_c[et] = L.wp_c[et]; ea.wx_c[et] = L.wx_c[et]; ea.b_c[et] = L.b_c[et];
             ea.watt[et] = L.watt[et]; ea.w3[et] = L.w3[et];
             ea.hn_main[et] = m->hn_main[et]; ea.hn_cont[et] = m->hn_cont[et];
@@ -518,7 +527,9 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
         }
         const bool prof = m->prof_on && m->prof_used + 2 <= m->prof_ev.size();
         if (prof) KPD_HIP(hipEventRecord(m->prof_ev[m->prof_used], st));
-        KPD_TRY(launch_egnn_edge(ea, tile_cap, st));
+        static const bool chain_env = getenv("KPD_EDGE_CHAIN") && atoi(getenv("KPD_EDGE_CHAIN")) != 0;
+        if (m->edge_chain >= 0 ? m->edge_chain != 0 : chain_env) KPD_TRY(launch_egnn_chain(ea, tile_cap, st));
+        else KPD_TRY(launch_egnn_edge(ea, tile_cap, st));
         if (prof) {
             KPD_HIP(hipEventRecord(m->prof_ev[m->prof_used + 1], st));
             m->prof_used += 2;
@@ -581,6 +592,9 @@ extern "C" kpd_status kpd_egnn_debug_state(kpd_egnn *m, const char *what, float 
     else if (w == "z_kp") src = m->z[1];
     else if (w.rfind("layers=", 0) == 0) {
         m->debug_layers = atoi(w.c_str() + 7);
+        return KPD_OK;
+    } else if (w.rfind("edge_chain=", 0) == 0) {   // A/B switch between the two edge kernels (tests, profiles/tools)
+        m->edge_chain = atoi(w.c_str() + 11);
         return KPD_OK;
     } else if (w == "stamps=1") {            // start accumulating per-phase cycle sums of the edge kernel
         if (!m->stamps) KPD_HIP(hipMalloc(reinterpret_cast<void **>(&m->stamps), 32 * sizeof(unsigned long long)));

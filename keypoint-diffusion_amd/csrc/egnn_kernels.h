@@ -43,6 +43,8 @@ struct EdgeArgs {
     const float *wp_c[4], *wx_c[4], *b_c[4];
     const float *watt[4];
     const float *w3[4];
+    const float *chain[4];          // W2 of coord_mlp then edge_mlp as 16x16x4 A-fragment chunks (egnn_chain.hip)
+    const float *wcol_e[4], *wcol_c[4];   // W2[:, 256]
     float *hn_main[4], *hn_cont[4];
     float *xn_main[4], *xn_cont[4];
     int use_tanh;
@@ -102,6 +104,7 @@ kpd_status launch_decode(const float *h, const float *x, const float *x0, int n,
                          const float *b0, const float *W1, const float *b1, float *eps_h, float *eps_x, hipStream_t st);
 kpd_status launch_node_proj(const ProjPair &p, hipStream_t st);
 kpd_status launch_egnn_edge(const EdgeArgs &a, int tile_cap, hipStream_t st);
+kpd_status launch_egnn_chain(const EdgeArgs &a, int tile_cap, hipStream_t st);
 kpd_status launch_node_update(const NodePair &p, hipStream_t st);
 kpd_status launch_node_layer(const NodeLayerPair &p, hipStream_t st);
 

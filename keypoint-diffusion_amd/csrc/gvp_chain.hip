@@ -8,46 +8,17 @@
 // scalars, hidden vectors, gates and output vectors of one GVP feed the next GVP straight from registers: no
 // LDS round trip, and no workgroup barrier between the stages of a GVP.  Only the weights go through LDS: the
 // to_feats_out / gate matrices are streamed as 16-row k-slabs ("chunks", pre-packed in A-fragment order by
-// gvp_host.hip) through a two-buffer ring that the four waves share, one barrier per chunk.
+// gvp_host.hip) through the LDS-DMA ring of chain_core.h that the four waves share, one barrier per chunk.
 //
 // Per 64-edge tile this leaves LDS traffic of one ds_read_b128 per four MFMAs and an LDS footprint of 79 KB
 // (the ring is reused for the final segmented sum), so two workgroups fit a CU and one's epilogues and
 // gathers overlap the other's MFMA stream.
+#include "chain_core.h"
 #include "gvp_kernels.h"
-#include "mfma_core.h"
 
 namespace kpd {
 
-typedef float v4f __attribute__((ext_vector_type(4)));
-
 namespace {
-
-__device__ __forceinline__ v4f mfma16(float a, float b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ v4f zero4() { return v4f{0.f, 0.f, 0.f, 0.f}; }
-
-// acc[mt] += W_chunk[16 mt .. +15][16 k] * xin (k = 4 (lane >> 4) + r), chunk laid out [mt][lane][r] in LDS.
-// Four output tiles per LDS batch so that consecutive MFMAs never hit the same accumulator.
-template <int NTS>
-__device__ __forceinline__ void chunk_gemm(const v4f *__restrict__ buf, v4f xin, v4f (&acc)[NTS], int lane, int nreg) {
-    const v4f *wp = buf + lane;
-    v4f w[2][4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) w[0][m] = wp[m * 64];
-#pragma unroll
-    for (int g = 0; g < NTS / 4; ++g) {
-        if (g + 1 < NTS / 4) {
-#pragma unroll
-            for (int m = 0; m < 4; ++m) w[(g + 1) & 1][m] = wp[(4 * (g + 1) + m) * 64];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (r < nreg) {
-#pragma unroll
-                for (int m = 0; m < 4; ++m) acc[4 * g + m] = mfma16(w[g & 1][m][r], xin[r], acc[4 * g + m]);
-            }
-        }
-    }
-}
 
 template <int NTS>
 struct ChainSmem {
@@ -71,9 +42,8 @@ struct ChainSmem {
 template <int NTS>
 __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
     using L = ChainSmem<NTS>;
-    constexpr int S = L::S, CH4 = L::CH4, SO = L::SO, PT = CH4 / 256;
+    constexpr int S = L::S, CH4 = L::CH4, SO = L::SO;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    v4f *ring = reinterpret_cast<v4f *>(smem);
     float *O = smem;
     float *Vout = smem + L::REGION0;
     int *sdst = reinterpret_cast<int *>(Vout + TM * 48);
@@ -105,7 +75,6 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
     const int n_ht = (h0 + 15) >> 4;
     const int n0 = 2 + n_ht;
     const int total = n0 + (n_gvps - 1) * (NTS + 2);
-    int cur = 0;
     auto chunk_src = [&](int c) -> const v4f * {
         int stage = 0, local = c;
         if (c >= n0) {
@@ -114,41 +83,11 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
         }
         return reinterpret_cast<const v4f *>(a.g[et][stage].chain) + (size_t)local * CH4 + tid;
     };
-    // Chunks travel global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write), two
-    // chunks ahead of the one being consumed, through a ring of three buffers.
-    //   acquire(): every wave has passed the barrier that ended chunk cur - 1, so buffer (cur + 2) % 3 (last read
-    //              for chunk cur - 1) is free: start chunk cur + 2 into it; return the buffer of chunk cur.
-    //   release(): wait for this thread's pieces of chunk cur + 1 (the PT pieces of chunk cur + 2 may stay in
-    //              flight), then barrier: everybody's pieces of chunk cur + 1 are in LDS and chunk cur is retired.
-    typedef __attribute__((address_space(3))) void lds_void;
-    typedef const __attribute__((address_space(1))) void glb_void;
-    auto fetch = [&](int c, int b) {
-        const v4f *g = chunk_src(min(c, total - 1));
-        v4f *dst = ring + b * CH4 + 64 * wave;
-#pragma unroll
-        for (int j = 0; j < PT; ++j)
-            __builtin_amdgcn_global_load_lds((glb_void *)(g + 256 * j), (lds_void *)(dst + 256 * j), 16, 0, 0);
-    };
-    fetch(0, 0);
-    fetch(1, 1);
-    auto acquire = [&]() -> const v4f * {
-        int b2 = cur + 2;
-        b2 -= 3 * (b2 / 3);
-        fetch(cur + 2, b2);
-        __builtin_amdgcn_sched_barrier(0);
-        // MFMA streams yield to the other workgroup's epilogues, gathers and ring hand-offs (priority 2): those are
-        // short and latency bound, and a wave stuck behind a full-rate MFMA stream stalls its whole workgroup
-        __builtin_amdgcn_s_setprio(0);
-        return ring + (cur - 3 * (cur / 3)) * CH4;
-    };
-    auto release = [&]() {
-        __builtin_amdgcn_s_setprio(2);
-        if (PT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        lds_barrier();
-        ++cur;
-    };
-    __builtin_amdgcn_s_setprio(2);
+    ChunkRing<CH4> ring;
+    ring.init(smem, total, wave);
+    ring.start(chunk_src);
+    auto acquire = [&]() -> const v4f * { return ring.acquire(chunk_src); };
+    auto release = [&]() { ring.release(); };
 
     // ---- this lane's edge ---------------------------------------------------------------------------
     const int el = lane & 15, q = lane >> 4;
@@ -259,9 +198,7 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
         const int tail = h0 - 16 * (n_ht - 1);            // valid rows of the last hidden tile
         const int tail_reg = min(4, tail);
 
-        if (PT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // chunk 0 has landed (chunk 1 may be in flight)
-        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        lds_barrier();
+        ring.first();
         CHAIN_STAMP(0)
         // scalar GEMM: [rbf | sh] part of to_feats_out
         {
@@ -398,8 +335,7 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
     }
 
     // ---- messages -> LDS: the ring is reused, so drain the (redundant) tail fetches first -----------------
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    lds_barrier();
+    ring.drain();
     {
         float *orow = O + row * SO + 4 * q;
 #pragma unroll

@@ -10,7 +10,11 @@ model = bench.build_model(dev)
 g = bench.build_batch(model, 64, 300, 25, 1234, dev)
 eng = model.dynamics.engine()
 t = torch.full((64,), 0.9, device=dev)
-names = ['geometry', 'A-build e', 'GEMM e', 'T-store e', 'att dot', 'reduce h', 'A-build c', 'GEMM c', 'T-store c', 'coord dot', 'reduce x']
+if os.environ.get('KPD_EDGE_CHAIN', '0') == '0':
+    names = ['geometry', 'A-build e', 'GEMM e', 'T-store e', 'att dot', 'reduce h', 'A-build c', 'GEMM c', 'T-store c', 'coord dot', 'reduce x']
+else:   # k_egnn_chain
+    names = ['prologue (geometry, vectors -> LDS)', 'e: gathers + f1 + acc init', 'e: GEMM chunks', 'e: SiLU + attention', '-',
+             'c: gathers + f1 + acc init', 'c: GEMM chunks', 'c: SiLU + coord head', '-', 'messages -> LDS', 'segmented sums']
 with torch.no_grad():
     for _ in range(2):
         model.dynamics(g, t, None)
@@ -26,7 +30,7 @@ tiles = c['tiles'] * 6 * n
 tot = sum(vals)
 print('tiles', c['tiles'], 'per-tile cycles (s_memtime ticks = 100 MHz? see note):')
 for nm, v in zip(names, vals):
-    print(f'  {nm:12s} {v / tiles:10.1f}  {100 * v / tot:5.1f} %')
+    print(f'  {nm:36s} {v / tiles:10.1f}  {100 * v / tot:5.1f} %')
 print('  total        %10.1f' % (tot / tiles))
 
 nn = ['load h/x', 'GEMM 1a', 'gather hn', 'GEMM 1b', 'T-store', 'GEMM 2', 'resid', 'LN', 'writeback', 'proj GEMMs', 'proj store']

@@ -51,7 +51,7 @@ def test_lig_graph_build(cuda, n_rec, n_lig):
     assert torch.equal(out['kl_rowptr'].long().cpu()[1:] - out['kl_rowptr'].long().cpu()[:-1], deg)
 
 
-def _run_pair(cuda, cfg, n_rec, n_lig, seed=3, rec_nf=10, layers=None):
+def _run_pair(cuda, cfg, n_rec, n_lig, seed=3, rec_nf=10, layers=None, edge_chain=None):
     g = util.fixed_encode(util.make_batch(n_rec, n_lig, n_rec_feat=rec_nf))
     model = LigRecDynamics(10, rec_nf, graph_cutoffs=util.CUTOFFS_ALL_ATOM, **cfg)
     synth.fill_state_dict_(model, seed)
@@ -69,9 +69,18 @@ def _run_pair(cuda, cfg, n_rec, n_lig, seed=3, rec_nf=10, layers=None):
     with torch.no_grad():
         if layers is not None:
             model.engine().debug(f'layers={layers}')
+        if edge_chain is not None:
+            model.engine().debug(f'edge_chain={edge_chain}')
         eps_h, eps_x = model(gd, t.to(cuda), G.get_batch_idxs(gd))
     torch.cuda.synchronize()
     return (eps_h.cpu(), eps_x.cpu()), (ref_h, ref_x), model
+
+
+def test_egnn_chained_edge_kernel(cuda):
+    """The opt-in register-chained edge kernel (egnn_chain.hip, KPD_EDGE_CHAIN=1) honours the same contract."""
+    (h, x), (rh, rx), _ = _run_pair(cuda, util.EGNN_C2, [300, 150, 40], [25, 9, 3], edge_chain=1)
+    assert util.rel_err(h, rh) < TOL, f'eps_h rel err {util.rel_err(h, rh)}'
+    assert util.rel_err(x, rx) < TOL, f'eps_x rel err {util.rel_err(x, rx)}'
 
 
 @pytest.mark.parametrize('layers', [0, 1, 2, 6])
