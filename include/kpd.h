@@ -224,6 +224,14 @@ kpd_status kpd_sample_update(int32_t B, const int32_t *lig_ptr, const int32_t *k
                              const float *noise_x, const float *noise_h,
                              const float *coef, int32_t max_lig, void *stream);
 
+/* Coefficients of that update for every complex of the batch, from the noise-schedule table.
+ * Replaces PredefinedNoiseSchedule.forward (models/ligand_diffuser.py:654-690) and the gamma / sigma / alpha
+ * arithmetic of sample_p_zs_given_zt (:505-526, sigma_and_alpha_t_given_s :552-566):
+ *   gamma [n_gamma] device table (n_gamma = timesteps + 1), s, t [B] device, coef [B,3] device out =
+ *   {alpha_t|s, sigma^2_t|s / alpha_t|s / sigma_t, sigma_t|s sigma_s / sigma_t}. */
+kpd_status kpd_step_coefficients(const float *gamma, int32_t n_gamma, const float *s, const float *t,
+                                 int32_t B, float *coef, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

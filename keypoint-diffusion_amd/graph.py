@@ -208,11 +208,15 @@ class HeteroBatch:
         CSR) consumed by the HIP engines; cached until node counts or kk edges change."""
         from . import hip
         kk_s, kk_d = self._edges['kk']
-        key = (tuple(self._bnn['lig'].tolist()), tuple(self._bnn['kp'].tolist()), kk_s.data_ptr(), kk_s._version,
+        # The key identifies the tensors by storage and version counter, never by value: reading the per-complex
+        # counts back (.tolist()) would synchronise with the GPU on every reverse step and drain the launch queue.
+        # The cache entry keeps the keyed tensors alive, so a data_ptr cannot be recycled by another tensor.
+        bl, bk = self._bnn['lig'], self._bnn['kp']
+        key = (bl.data_ptr(), bl._version, int(bl.shape[0]), bk.data_ptr(), bk._version, kk_s.data_ptr(), kk_s._version,
                int(kk_s.shape[0]), str(self.device))
         cache = getattr(self, '_prepared', None)
         if cache is None or cache[0] != key:
-            self._prepared = (key, hip.PreparedBatch(self._bnn['lig'], self._bnn['kp'], kk_s, kk_d, self.device))
+            self._prepared = (key, hip.PreparedBatch(bl, bk, kk_s, kk_d, self.device), (bl, bk, kk_s, kk_d))
         return self._prepared[1]
 
     def node_ptr(self, ntype) -> torch.Tensor:

@@ -113,6 +113,7 @@ def lib():
     L.kpd_recenc_forward.argtypes = [C.c_void_p, C.POINTER(KpdRecBatch), C.POINTER(KpdRecOut), C.c_void_p]
     L.kpd_build_lig_graph.argtypes = [C.POINTER(KpdBatch), C.c_float, C.c_int32, C.POINTER(KpdLigGraph), C.c_void_p]
     L.kpd_sample_update.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 8 + [C.c_int32, C.c_void_p]
+    L.kpd_step_coefficients.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -122,7 +123,7 @@ EXPORTS = [
     'kpd_last_error', 'kpd_version', 'kpd_build_lig_graph',
     'kpd_egnn_create', 'kpd_egnn_destroy', 'kpd_egnn_load_weight', 'kpd_egnn_commit', 'kpd_egnn_reserve',
     'kpd_egnn_forward', 'kpd_egnn_debug_state', 'kpd_egnn_last_counts', 'kpd_egnn_profile',
-    'kpd_egnn_profile_read', 'kpd_sample_update',
+    'kpd_egnn_profile_read', 'kpd_sample_update', 'kpd_step_coefficients',
     'kpd_gvp_create', 'kpd_gvp_destroy', 'kpd_gvp_load_weight', 'kpd_gvp_commit', 'kpd_gvp_reserve',
     'kpd_gvp_forward', 'kpd_gvp_debug_state',
     'kpd_recenc_create', 'kpd_recenc_destroy', 'kpd_recenc_load_weight', 'kpd_recenc_commit', 'kpd_recenc_reserve',
@@ -412,6 +413,17 @@ class RecEncEngine:
         out['kk_src'], out['kk_dst'] = out['kk_src'][:e_kk], out['kk_dst'][:e_kk]
         out['rk_src'], out['rk_dst'] = out['rk_src'][:e_rk], out['rk_dst'][:e_rk]
         return out
+
+
+def step_coefficients(gamma: torch.Tensor, s: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    """[B,3] reverse-step coefficients from the gamma table (kpd_step_coefficients): one launch per step."""
+    gamma, s, t = _dev_f32(gamma, 'gamma'), _dev_f32(s, 's'), _dev_f32(t, 't')
+    if s.shape != t.shape or s.dim() != 1:
+        raise KpdError(f'step_coefficients: s {tuple(s.shape)} and t {tuple(t.shape)} must be equal 1-D tensors')
+    coef = torch.empty(s.shape[0], 3, device=s.device)
+    check(lib().kpd_step_coefficients(gamma.data_ptr(), int(gamma.shape[0]), s.data_ptr(), t.data_ptr(), int(s.shape[0]),
+                                      coef.data_ptr(), _stream()))
+    return coef
 
 
 def sample_update(pb: PreparedBatch, atom_nf, lig_x, lig_h, kp_x, eps_x, eps_h, noise_x, noise_h, coef):

@@ -151,7 +151,10 @@ class KeypointDiffusion(nn.Module):
 
     def step_coefficients(self, s: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
         """[B,3] = (alpha_t|s, sigma^2_t|s / alpha_t|s / sigma_t, sigma_t|s sigma_s / sigma_t)
-        (ligand_diffuser.py:505-526); O(B) host-launched arithmetic."""
+        (ligand_diffuser.py:505-526).  On the GPU this is one kernel (kpd_step_coefficients); host tensors take
+        the same arithmetic through the torch mirror below (schedule inspection, tests)."""
+        if s.is_cuda:
+            return hip.step_coefficients(self.gamma.gamma, s, t)
         g_s, g_t = self.gamma(s), self.gamma(t)
         sigma2_ts, sigma_ts, alpha_ts = self.sigma_and_alpha_t_given_s(g_t, g_s)
         sig_s, sig_t = self.sigma(g_s), self.sigma(g_t)

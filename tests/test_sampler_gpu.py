@@ -57,6 +57,24 @@ def test_reverse_step_matches_oracle(cuda, arch):
     assert float(com.abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize('T,precision', [(500, 1e-5), (50, 1e-4), (1000, 1e-5)])
+def test_step_coefficients_all_timesteps(cuda, T, precision):
+    """kpd_step_coefficients against the oracle's schedule arithmetic for every (s, t) = (i / T, (i + 1) / T)."""
+    from keypoint_diffusion_amd import hip
+    table = odiff.gamma_table(T, precision)
+    s = torch.arange(T, dtype=torch.float32) / T
+    t = (torch.arange(T, dtype=torch.float32) + 1) / T
+    g_s, g_t = odiff.gamma_at(table, s, T), odiff.gamma_at(table, t, T)
+    s2, s_ts, a_ts = odiff.sigma_and_alpha_t_given_s(g_t, g_s)
+    ref = torch.stack([a_ts, s2 / a_ts / odiff.sigma(g_t), s_ts * odiff.sigma(g_s) / odiff.sigma(g_t)], dim=1)
+    got = hip.step_coefficients(table.float().to(cuda), s.to(cuda), t.to(cuda)).cpu()
+    assert got.shape == (T, 3)
+    assert float(((got - ref.float()).abs() / ref.float().abs().clamp_min(1e-6)).max()) < 1e-4
+    # the module-level mirror takes the same path on the GPU
+    m = _model('egnn', T).to(cuda)
+    assert torch.equal(m.step_coefficients(s.to(cuda), t.to(cuda)).cpu(), hip.step_coefficients(m.gamma.gamma, s.to(cuda), t.to(cuda)).cpu())
+
+
 def test_sample_given_pocket_end_to_end(cuda):
     model = _model('egnn', T=8).to(cuda)
     pocket = synth.synth_complexes([70], [1], 20, CUT, seed=9)[0].to(cuda)
