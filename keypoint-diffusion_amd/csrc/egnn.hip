@@ -22,6 +22,7 @@ struct LayerW {
     float *wp_c[4], *wx_c[4], *b_c[4], *wr_c[4], *w3[4];
     // per node type, per projection slot
     float *wp_p[2][NSLOT], *wx_p[2][NSLOT], *b_p[2][NSLOT];
+    float *ch_p[2][NSLOT], *wcol_p[2][NSLOT];   // k_proj_chain form of the same blocks
     // node MLP + LayerNorm per node type
     float *wp_a[2], *wx_a[2], *wp_b[2], *wx_b[2], *b0[2], *wp_2[2], *wx_2[2], *b2[2], *ln_w[2], *ln_b[2];
 };
@@ -99,6 +100,7 @@ static kpd_status build_weight_arena(kpd_egnn *m) {
                       2 * c.rec_nf * 256 + 256 + 2 * c.atom_nf * 256 + 2 * c.atom_nf + 2 * c.atom_nf * c.atom_nf +
                       c.atom_nf) * 4 + 64 * 256;
     bytes += (size_t)c.n_layers * m->n_et * (32 * 4096 + 2 * HS + 64) * 4;
+    bytes += (size_t)c.n_layers * m->n_et * 4 * (16 * 4096 + HS + 64) * 4;
     bytes += 1 << 20;
     kpd_status st = m->warena.reserve(bytes);
     if (st != KPD_OK) return st;
@@ -118,6 +120,8 @@ static kpd_status build_weight_arena(kpd_egnn *m) {
                 const int ss = kSrcSlot[et] + var, ds = kDstSlot[et] + var;
                 w.wp_p[kSrcNt[et]][ss] = wp(); w.wx_p[kSrcNt[et]][ss] = vec();
                 w.wp_p[kDstNt[et]][ds] = wp(); w.wx_p[kDstNt[et]][ds] = vec(); w.b_p[kDstNt[et]][ds] = vec();
+                w.ch_p[kSrcNt[et]][ss] = A.take<float>(16 * 4096); w.wcol_p[kSrcNt[et]][ss] = vec();
+                w.ch_p[kDstNt[et]][ds] = A.take<float>(16 * 4096); w.wcol_p[kDstNt[et]][ds] = vec();
             }
             const std::string e = kEtName[et];
             for (const char *blk : {"edge_mlp.", "coord_mlp."})
@@ -307,6 +311,14 @@ extern "C" kpd_status kpd_egnn_load_weight(kpd_egnn *m, const char *name, const 
                     KPD_TRY(scale_inplace(L.wp_p[dnt][ds], WP_FLOATS, SILU_C, st));
                     KPD_TRY(scale_inplace(L.wx_p[dnt][ds], KP, SILU_C, st));
                     KPD_TRY(scale_inplace(var ? L.wr_c[et] : L.wr_e[et], HS, SILU_C, st));
+                    for (int side = 0; side < 2; ++side) {      // the same two blocks for k_proj_chain
+                        float *ch = side ? L.ch_p[dnt][ds] : L.ch_p[snt][ss], *wc = side ? L.wcol_p[dnt][ds] : L.wcol_p[snt][ss];
+                        const float *blk0 = w + side * HW;
+                        for (int kc = 0; kc < 16; ++kc) KPD_TRY(pack_chain_frag(blk0, ld, 1, 256, 16 * kc, 16, 16, ch + (size_t)kc * 4096, st));
+                        KPD_TRY(copy_col_pad(blk0, 256, ld, 256, wc, HS, st));
+                        KPD_TRY(scale_inplace(ch, 16 * 4096, SILU_C, st));
+                        KPD_TRY(scale_inplace(wc, HS, SILU_C, st));
+                    }
                 } else {
                     KPD_TRY(expect_shape(name, shape, ndim, {HW}));
                     KPD_TRY(copy_pad(w, HW, L.b_p[dnt][ds], HS, st));
@@ -476,7 +488,17 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
             }
         na.n_slots = k;
     };
-    static const bool fused_nodes = !(getenv("KPD_NODE_FUSED") && atoi(getenv("KPD_NODE_FUSED")) == 0);
+    // Node-side orchestration per layer (KPD_NODE_MODE, A/B runs in profiles/tools/node_modes.sh):
+    //   split  (default) k_node_layer (update only) + k_proj_chain (next layer's projections, one slot per workgroup)
+    //   fused            k_node_layer does both from its resident 32-node tile
+    //   staged           k_node_update + k_node_proj (64-node LDS-staged tiles)
+    enum { MODE_SPLIT = 0, MODE_FUSED = 1, MODE_STAGED = 2 };
+    static const int node_mode = [] {
+        const char *e = getenv("KPD_NODE_MODE");
+        if (!e) return (int)MODE_SPLIT;
+        return !strcmp(e, "fused") ? (int)MODE_FUSED : !strcmp(e, "staged") ? (int)MODE_STAGED : (int)MODE_SPLIT;
+    }();
+    const bool fused_nodes = node_mode == MODE_FUSED;
 
     for (int li = 0; li < n_layers; ++li) {
         const LayerW &L = m->L[li];
@@ -500,12 +522,13 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
                     for (int s = 0; s < NSLOT; ++s)
                         if (L.wp_p[nt][s]) {
                             pa.wp[k] = L.wp_p[nt][s]; pa.wx[k] = L.wx_p[nt][s]; pa.bias[k] = L.b_p[nt][s]; pa.slot[k] = s;
+                            pa.chain[k] = L.ch_p[nt][s]; pa.wcol[k] = L.wcol_p[nt][s];
                             ++k;
                         }
                     pp.n_slots[nt] = k;
                 }
                 pp.tiles0 = cdiv(n[0], TM);
-                KPD_TRY(launch_node_proj(pp, st));
+                KPD_TRY(node_mode == MODE_SPLIT ? launch_proj_chain(pp, st) : launch_node_proj(pp, st));
             }
         }
         EdgeArgs ea;
@@ -549,10 +572,10 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
             na.wp_2 = L.wp_2[nt]; na.wx_2 = L.wx_2[nt]; na.b2 = L.b2[nt]; na.ln_w = L.ln_w[nt]; na.ln_b = L.ln_b[nt];
             na.norm = c.norm;
         };
-        if (fused_nodes) {
+        if (node_mode != MODE_STAGED) {
             NodeLayerPair lp;
             memset(&lp, 0, sizeof(lp));
-            const bool more = li + 1 < n_layers;
+            const bool more = fused_nodes && li + 1 < n_layers;
             for (int nt = 0; nt < 2; ++nt) {
                 NodeLayerArgs &na = lp.nt[nt];
                 na.u.n = n[nt]; na.u.h = m->h[nt];

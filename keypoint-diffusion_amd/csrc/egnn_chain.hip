@@ -11,6 +11,8 @@
 // feature does not fit the 16-wide tiles: its input column and output row are rank-1 updates on the VALU.
 // The coordinate branch runs first so that the feature messages can be staged for the segmented sum in the LDS the
 // ring occupied.
+#include <algorithm>
+
 #include "chain_core.h"
 #include "egnn_kernels.h"
 
@@ -298,6 +300,82 @@ kpd_status launch_egnn_chain(const EdgeArgs &a, int tile_cap, hipStream_t st) {
         g_echain_attr = true;
     }
     hipLaunchKernelGGL(k_egnn_chain, dim3(8 * cdiv(tile_cap, 8)), dim3(256), ECHAIN_FLOATS * 4, st, a);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+}  // namespace kpd
+
+// ---- node projections, register-chained -------------------------------------------------------------------
+// P[node][slot][:] = c (W1_block h[node] (+ b1)) for one 64-node tile and ONE projection slot per workgroup (same
+// contract as k_node_proj, egnn_kernels.hip).  The nodes' features are read straight into B-operand registers, the
+// 256 x 256 block of the slot's weight streams through the LDS ring, feature 256 on either side is a rank-1 / dot
+// product update on the VALU.  Many small workgroups (tiles x slots) keep the hardware dispatcher balanced.
+namespace kpd {
+
+__global__ __launch_bounds__(256, 2) void k_proj_chain(ProjPair p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int which = blockIdx.x >= p.tiles0 ? 1 : 0;
+    const ProjArgs &a = p.nt[which];
+    const int s = blockIdx.y;
+    if (s >= p.n_slots[which]) return;
+    const int node0 = (blockIdx.x - (which ? p.tiles0 : 0)) * TM;
+
+    const v4f *stream = reinterpret_cast<const v4f *>(a.chain[s]) + tid;
+    auto chunk_src = [&](int c) -> const v4f * { return stream + (size_t)c * ECH4; };
+    ChunkRing<ECH4> ring;
+    ring.init(smem, ENT, wave);
+    ring.start(chunk_src);
+
+    const int el = lane & 15, q = lane >> 4;
+    const int row = 16 * wave + el;
+    // h and P are padded to whole tiles (rows past n: zero / never read back), so no row predicate
+    const float *hrow = a.h + (size_t)(node0 + row) * HS;
+    v4f x[ENT];
+#pragma unroll
+    for (int nt = 0; nt < ENT; ++nt) x[nt] = *reinterpret_cast<const v4f *>(hrow + 16 * nt + 4 * q);
+    const float h256 = hrow[256];
+    const float *bias = a.bias[s], *wcol = a.wcol[s], *wrow = a.wx[s];
+    v4f acc[ENT];
+    float part = 0.0f;
+#pragma unroll
+    for (int mt = 0; mt < ENT; ++mt) {
+        acc[mt] = h256 * *reinterpret_cast<const v4f *>(wcol + 16 * mt + 4 * q);
+        if (bias) acc[mt] += *reinterpret_cast<const v4f *>(bias + 16 * mt + 4 * q);
+        const v4f wv = *reinterpret_cast<const v4f *>(wrow + 16 * mt + 4 * q);
+        part += x[mt][0] * wv[0] + x[mt][1] * wv[1] + x[mt][2] * wv[2] + x[mt][3] * wv[3];
+    }
+    const float out256 = reduce_q(part) + (bias ? bias[256] : 0.0f) + h256 * wrow[256];
+    ring.first();
+#pragma unroll
+    for (int nt = 0; nt < ENT; ++nt) {
+        const v4f *buf = ring.acquire(chunk_src);
+        chunk_gemm<ENT>(buf, x[nt], acc, lane, 4);
+        ring.release();
+    }
+    float *orow = a.P + ((size_t)(node0 + row) * NSLOT + a.slot[s]) * HS;
+#pragma unroll
+    for (int mt = 0; mt < ENT; ++mt) *reinterpret_cast<v4f *>(orow + 16 * mt + 4 * q) = acc[mt];
+    if (q == 0) orow[256] = out256;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the ring's tail fetches must not outlive the workgroup's LDS
+}
+
+static bool g_pchain_attr = false;
+
+kpd_status launch_proj_chain(const ProjPair &p, hipStream_t st) {
+    const int tiles = p.tiles0 + cdiv(p.nt[1].n, TM);
+    const int slots = std::max(p.n_slots[0], p.n_slots[1]);
+    if (tiles == 0 || slots == 0) return KPD_OK;
+    for (int nt = 0; nt < 2; ++nt)
+        for (int s = 0; s < p.n_slots[nt]; ++s)
+            KPD_REQUIRE(p.nt[nt].chain[s] && p.nt[nt].wcol[s], KPD_ERR_STATE, "projection slot %d not packed for k_proj_chain", s);
+    if (!g_pchain_attr) {
+        KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_chain), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    3 * ECH4 * 16));
+        g_pchain_attr = true;
+    }
+    hipLaunchKernelGGL(k_proj_chain, dim3(tiles, slots), dim3(256), 3 * ECH4 * 16, st, p);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
 }

@@ -22,6 +22,8 @@ struct ProjArgs {
     const float *wx[NSLOT];
     const float *bias[NSLOT];       // nullptr for src slots
     int slot[NSLOT];
+    const float *chain[NSLOT];      // k_proj_chain: the 256 x 256 block as 16 A-fragment chunks, and W[:, 256]
+    const float *wcol[NSLOT];
 };
 
 struct ProjPair {
@@ -105,6 +107,7 @@ kpd_status launch_decode(const float *h, const float *x, const float *x0, int n,
 kpd_status launch_node_proj(const ProjPair &p, hipStream_t st);
 kpd_status launch_egnn_edge(const EdgeArgs &a, int tile_cap, hipStream_t st);
 kpd_status launch_egnn_chain(const EdgeArgs &a, int tile_cap, hipStream_t st);
+kpd_status launch_proj_chain(const ProjPair &p, hipStream_t st);
 kpd_status launch_node_update(const NodePair &p, hipStream_t st);
 kpd_status launch_node_layer(const NodeLayerPair &p, hipStream_t st);
 
