@@ -12,6 +12,7 @@
 // The coordinate branch runs first so that the feature messages can be staged for the segmented sum in the LDS the
 // ring occupied.
 #include <algorithm>
+#include <cstdlib>
 
 #include "chain_core.h"
 #include "egnn_kernels.h"
@@ -307,7 +308,7 @@ kpd_status launch_egnn_chain(const EdgeArgs &a, int tile_cap, hipStream_t st) {
 }  // namespace kpd
 
 // ---- node projections, register-chained -------------------------------------------------------------------
-// P[node][slot][:] = c (W1_block h[node] (+ b1)) for one 64-node tile and ONE projection slot per workgroup (same
+// P[node][slot][:] = c (W1_block h[node] (+ b1)) for one 64-node tile and slots_per_block slots per workgroup (same
 // contract as k_node_proj, egnn_kernels.hip).  The nodes' features are read straight into B-operand registers, the
 // 256 x 256 block of the slot's weight streams through the LDS ring, feature 256 on either side is a rank-1 / dot
 // product update on the VALU.  Many small workgroups (tiles x slots) keep the hardware dispatcher balanced.
@@ -318,14 +319,17 @@ __global__ __launch_bounds__(256, 2) void k_proj_chain(ProjPair p) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int which = blockIdx.x >= p.tiles0 ? 1 : 0;
     const ProjArgs &a = p.nt[which];
-    const int s = blockIdx.y;
-    if (s >= p.n_slots[which]) return;
+    const int s0 = blockIdx.y * p.slots_per_block;
+    if (s0 >= p.n_slots[which]) return;
+    const int ns = min(p.slots_per_block, p.n_slots[which] - s0);
     const int node0 = (blockIdx.x - (which ? p.tiles0 : 0)) * TM;
 
-    const v4f *stream = reinterpret_cast<const v4f *>(a.chain[s]) + tid;
-    auto chunk_src = [&](int c) -> const v4f * { return stream + (size_t)c * ECH4; };
-    ChunkRing<ECH4> ring;
-    ring.init(smem, ENT, wave);
+    // chunks of two k-slabs (32 KB): slab pairs are contiguous in the packed stream
+    auto chunk_src = [&](int c) -> const v4f * {
+        return reinterpret_cast<const v4f *>(a.chain[s0 + (c >> 3)]) + (size_t)(c & 7) * (2 * ECH4) + tid;
+    };
+    ChunkRing2<2 * ECH4> ring;
+    ring.init(smem, ns * (ENT / 2), wave);
     ring.start(chunk_src);
 
     const int el = lane & 15, q = lane >> 4;
@@ -336,28 +340,32 @@ __global__ __launch_bounds__(256, 2) void k_proj_chain(ProjPair p) {
 #pragma unroll
     for (int nt = 0; nt < ENT; ++nt) x[nt] = *reinterpret_cast<const v4f *>(hrow + 16 * nt + 4 * q);
     const float h256 = hrow[256];
-    const float *bias = a.bias[s], *wcol = a.wcol[s], *wrow = a.wx[s];
-    v4f acc[ENT];
-    float part = 0.0f;
+#pragma unroll 1
+    for (int si = 0; si < ns; ++si) {
+        const int s = s0 + si;
+        const float *bias = a.bias[s], *wcol = a.wcol[s], *wrow = a.wx[s];
+        v4f acc[ENT];
+        float part = 0.0f;
 #pragma unroll
-    for (int mt = 0; mt < ENT; ++mt) {
-        acc[mt] = h256 * *reinterpret_cast<const v4f *>(wcol + 16 * mt + 4 * q);
-        if (bias) acc[mt] += *reinterpret_cast<const v4f *>(bias + 16 * mt + 4 * q);
-        const v4f wv = *reinterpret_cast<const v4f *>(wrow + 16 * mt + 4 * q);
-        part += x[mt][0] * wv[0] + x[mt][1] * wv[1] + x[mt][2] * wv[2] + x[mt][3] * wv[3];
+        for (int mt = 0; mt < ENT; ++mt) {
+            acc[mt] = h256 * *reinterpret_cast<const v4f *>(wcol + 16 * mt + 4 * q);
+            if (bias) acc[mt] += *reinterpret_cast<const v4f *>(bias + 16 * mt + 4 * q);
+            const v4f wv = *reinterpret_cast<const v4f *>(wrow + 16 * mt + 4 * q);
+            part += x[mt][0] * wv[0] + x[mt][1] * wv[1] + x[mt][2] * wv[2] + x[mt][3] * wv[3];
+        }
+        const float out256 = reduce_q(part) + (bias ? bias[256] : 0.0f) + h256 * wrow[256];
+        if (si == 0) ring.first();
+#pragma unroll
+        for (int nt = 0; nt < ENT; nt += 2) {
+            const v4f *buf = ring.acquire(chunk_src);
+            chunk_gemm2<ENT>(buf, x[nt], x[nt + 1], acc, lane);
+            ring.release();
+        }
+        float *orow = a.P + ((size_t)(node0 + row) * NSLOT + a.slot[s]) * HS;
+#pragma unroll
+        for (int mt = 0; mt < ENT; ++mt) *reinterpret_cast<v4f *>(orow + 16 * mt + 4 * q) = acc[mt];
+        if (q == 0) orow[256] = out256;
     }
-    const float out256 = reduce_q(part) + (bias ? bias[256] : 0.0f) + h256 * wrow[256];
-    ring.first();
-#pragma unroll
-    for (int nt = 0; nt < ENT; ++nt) {
-        const v4f *buf = ring.acquire(chunk_src);
-        chunk_gemm<ENT>(buf, x[nt], acc, lane, 4);
-        ring.release();
-    }
-    float *orow = a.P + ((size_t)(node0 + row) * NSLOT + a.slot[s]) * HS;
-#pragma unroll
-    for (int mt = 0; mt < ENT; ++mt) *reinterpret_cast<v4f *>(orow + 16 * mt + 4 * q) = acc[mt];
-    if (q == 0) orow[256] = out256;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the ring's tail fetches must not outlive the workgroup's LDS
 }
 
@@ -372,10 +380,13 @@ kpd_status launch_proj_chain(const ProjPair &p, hipStream_t st) {
             KPD_REQUIRE(p.nt[nt].chain[s] && p.nt[nt].wcol[s], KPD_ERR_STATE, "projection slot %d not packed for k_proj_chain", s);
     if (!g_pchain_attr) {
         KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_chain), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    3 * ECH4 * 16));
+                                    4 * ECH4 * 16));
         g_pchain_attr = true;
     }
-    hipLaunchKernelGGL(k_proj_chain, dim3(tiles, slots), dim3(256), 3 * ECH4 * 16, st, p);
+    static const int spb = getenv("KPD_PROJ_SPB") ? std::max(1, atoi(getenv("KPD_PROJ_SPB"))) : 1;
+    ProjPair q = p;
+    q.slots_per_block = spb;
+    hipLaunchKernelGGL(k_proj_chain, dim3(tiles, cdiv(slots, spb)), dim3(256), 4 * ECH4 * 16, st, q);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
 }
