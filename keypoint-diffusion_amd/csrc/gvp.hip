@@ -104,6 +104,7 @@ extern "C" kpd_status kpd_gvp_create(const kpd_gvp_config *cfg, kpd_gvp **out) {
             for (int j = 0; j < cfg->n_update_gvps; ++j) {
                 HostGvp &g = m->upd[i][nt][j];
                 g.vin = GV; g.vout = GV; g.s_in = S; g.sout = S;
+                g.chain_pos = 1;            // register-chained node kernel: same form as a non-head message GVP
                 alloc_gvp(A, g, m->expected, pre + "node_update_fns." + kNtNameG[nt] + "." + std::to_string(j));
             }
             m->ln1w[i][nt] = A.take<float>(S); m->ln1b[i][nt] = A.take<float>(S);

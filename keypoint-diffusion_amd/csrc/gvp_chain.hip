@@ -31,6 +31,70 @@ struct ChainSmem {
 
 }  // namespace
 
+// One GVP whose scalars x and vectors Vc already sit in registers (every GVP but the head of an edge-message chain, and
+// all node-update GVPs): vec1, the [x | sh] GEMM over NTS + 1 chunks, SiLU, gates (one chunk), vec2.  acc enters holding
+// the bias of this GVP and leaves holding `next_bias` (when given) for the following one.
+template <int NTS, class Ring, class Src>
+__device__ __forceinline__ void chain_generic_gvp(Ring &ring, Src &chunk_src, const GvpW &gk, const float *next_bias,
+                                                  v4f (&x)[NTS], v4f (&acc)[NTS], v4f (&Vc)[3], int lane, int q) {
+    const v4f wh = reinterpret_cast<const v4f *>(gk.whp)[lane];
+    v4f Vh[3], sh;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        v4f t = zero4();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t = mfma16(wh[r], Vc[c][r], t);
+        Vh[c] = t;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sh[r] = sqrtf(fmaxf(Vh[0][r] * Vh[0][r] + Vh[1][r] * Vh[1][r] + Vh[2][r] * Vh[2][r], 1e-8f));
+#pragma unroll
+    for (int nt = 0; nt < NTS; ++nt) {
+        const v4f *buf = ring.acquire(chunk_src);
+        chunk_gemm<NTS>(buf, x[nt], acc, lane, 4);
+        ring.release();
+    }
+    {
+        const v4f *buf = ring.acquire(chunk_src);
+        chunk_gemm<NTS>(buf, sh, acc, lane, 4);
+        ring.release();
+    }
+    const v4f bgv = *reinterpret_cast<const v4f *>(gk.bg + 4 * q);
+    const v4f wu = reinterpret_cast<const v4f *>(gk.wup)[lane];
+#pragma unroll
+    for (int mt = 0; mt < NTS; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[mt][r] = silu(acc[mt][r]);
+    if (next_bias) {
+#pragma unroll
+        for (int mt = 0; mt < NTS; ++mt) acc[mt] = *reinterpret_cast<const v4f *>(next_bias + 16 * mt + 4 * q);
+    }
+    v4f gate;
+    {
+        const v4f *buf = ring.acquire(chunk_src) + lane;
+        v4f ga[4] = {zero4(), zero4(), zero4(), zero4()};
+#pragma unroll
+        for (int nt = 0; nt < NTS; ++nt) {
+            const v4f wg = buf[nt * 64];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ga[r] = mfma16(wg[r], x[nt][r], ga[r]);
+        }
+        ring.release();
+        gate = (ga[0] + ga[1]) + (ga[2] + ga[3]) + bgv;
+        if (gk.vec_sigmoid) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gate[r] = sigmoidf_(gate[r]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        v4f t = zero4();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t = mfma16(wu[r], Vh[c][r], t);
+        Vc[c] = gate * t;
+    }
+}
+
 // phase-cycle sums for profiles/tools/gvp_stamps.py (a.stamps is null in production)
 #define CHAIN_STAMP(idx)                                                                   \
     if (stamps && tid == 0) {                                                              \
@@ -269,69 +333,8 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
     // ---- GVP 1 .. n-1: scalars and vectors come from the previous GVP's registers ------------------------
 #pragma unroll 1
     for (int k = 1; k < n_gvps; ++k) {
-        const GvpW &gk = a.g[et][k];
-        const v4f wh = reinterpret_cast<const v4f *>(gk.whp)[lane];
-        v4f Vh[3], sh;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            v4f t = zero4();
-#pragma unroll
-            for (int r = 0; r < 4; ++r) t = mfma16(wh[r], Vc[c][r], t);
-            Vh[c] = t;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            sh[r] = sqrtf(fmaxf(Vh[0][r] * Vh[0][r] + Vh[1][r] * Vh[1][r] + Vh[2][r] * Vh[2][r], 1e-8f));
-        CHAIN_STAMP(5)
-#pragma unroll
-        for (int nt = 0; nt < NTS; ++nt) {
-            const v4f *buf = acquire();
-            chunk_gemm<NTS>(buf, x[nt], acc, lane, 4);
-            release();
-        }
-        {
-            const v4f *buf = acquire();
-            chunk_gemm<NTS>(buf, sh, acc, lane, 4);
-            release();
-        }
+        chain_generic_gvp<NTS>(ring, chunk_src, a.g[et][k], k + 1 < n_gvps ? a.g[et][k + 1].b : nullptr, x, acc, Vc, lane, q);
         CHAIN_STAMP(6)
-        const v4f bgv = *reinterpret_cast<const v4f *>(gk.bg + 4 * q);
-        const v4f wu = reinterpret_cast<const v4f *>(gk.wup)[lane];
-#pragma unroll
-        for (int mt = 0; mt < NTS; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) x[mt][r] = silu(acc[mt][r]);
-        if (k + 1 < n_gvps) {
-            const float *bn = a.g[et][k + 1].b + 4 * q;
-#pragma unroll
-            for (int mt = 0; mt < NTS; ++mt) acc[mt] = *reinterpret_cast<const v4f *>(bn + 16 * mt);
-        }
-        CHAIN_STAMP(7)
-        {
-            const v4f *buf = acquire() + lane;
-            v4f ga[4] = {zero4(), zero4(), zero4(), zero4()};
-#pragma unroll
-            for (int nt = 0; nt < NTS; ++nt) {
-                const v4f wg = buf[nt * 64];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ga[r] = mfma16(wg[r], x[nt][r], ga[r]);
-            }
-            release();
-            gate = (ga[0] + ga[1]) + (ga[2] + ga[3]) + bgv;
-            if (gk.vec_sigmoid) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) gate[r] = sigmoidf_(gate[r]);
-            }
-        }
-        CHAIN_STAMP(8)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            v4f t = zero4();
-#pragma unroll
-            for (int r = 0; r < 4; ++r) t = mfma16(wu[r], Vh[c][r], t);
-            Vc[c] = gate * t;
-        }
-        CHAIN_STAMP(9)
     }
 
     // ---- messages -> LDS: the ring is reused, so drain the (redundant) tail fetches first -----------------
@@ -406,6 +409,160 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
     CHAIN_STAMP(11)
 }
 
+// ---- node update (gvp.py:499-536), register-chained ---------------------------------------------------------
+// One wave = 16 nodes: aggregate the message pieces (per-etype sum or mean, cross-etype sum), s + msg / norm,
+// message GVPLayerNorm, the update GVP chain (chain_generic_gvp), residual, update GVPLayerNorm.  A node's S scalars
+// live on its four lanes (64 registers each), so both layer norms are in-lane sums plus two cross-lane adds; the
+// residual scalars wait in the s_tmp scratch rows (the registers are needed for the GEMM operands), the 16 residual
+// vectors stay in registers.
+template <int NTS>
+__device__ __forceinline__ void lanes_layernorm(v4f (&x)[NTS], const float *__restrict__ lw, const float *__restrict__ lb, int q) {
+    constexpr int S = 16 * NTS;
+    float sum = 0.0f;
+#pragma unroll
+    for (int nt = 0; nt < NTS; ++nt) sum += (x[nt][0] + x[nt][1]) + (x[nt][2] + x[nt][3]);
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum * (1.0f / S);
+    float var = 0.0f;
+#pragma unroll
+    for (int nt = 0; nt < NTS; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float d = x[nt][r] - mean;
+            var = fmaf(d, d, var);
+        }
+    var += __shfl_xor(var, 16);
+    var += __shfl_xor(var, 32);
+    const float rstd = 1.0f / sqrtf(var * (1.0f / S) + 1e-5f);
+#pragma unroll
+    for (int nt = 0; nt < NTS; ++nt) {
+        const v4f w = *reinterpret_cast<const v4f *>(lw + 16 * nt + 4 * q), b = *reinterpret_cast<const v4f *>(lb + 16 * nt + 4 * q);
+        x[nt] = (x[nt] - mean) * rstd * w + b;
+    }
+}
+
+// vector half of GVPLayerNorm (gvp.py:163-165): v / (sqrt(mean_i max(|v_i|^2, 1e-8) + eps) + eps)
+__device__ __forceinline__ void lanes_vecnorm(v4f (&V)[3]) {
+    float a = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a += fmaxf(V[0][r] * V[0][r] + V[1][r] * V[1][r] + V[2][r] * V[2][r], 1e-8f);
+    a += __shfl_xor(a, 16);
+    a += __shfl_xor(a, 32);
+    const float vn = sqrtf(a * (1.0f / GV) + 1e-5f) + 1e-5f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) V[c] = V[c] / vn;
+}
+
+__device__ __forceinline__ void load_vec12(const float *p, v4f (&V)[3]) {       // 4 channels x xyz -> V[c][r]
+    const v4f *vp = reinterpret_cast<const v4f *>(p);
+    const v4f t0 = vp[0], t1 = vp[1], t2 = vp[2];
+    const float f[12] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3], t2[0], t2[1], t2[2], t2[3]};
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) V[c][r] = f[3 * r + c];
+}
+
+template <int NTS>
+__global__ __launch_bounds__(256, 2) void k_gvp_node_chain(GvpNodePair p) {
+    constexpr int S = 16 * NTS, CH4 = NTS * 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int which = (int)blockIdx.x >= p.tiles0 ? 1 : 0;
+    const GvpNodeArgs &a = p.nt[which];
+    const int node0 = ((int)blockIdx.x - (which ? p.tiles0 : 0)) * TM;
+    const int n_gvps = a.n_gvps;
+
+    auto chunk_src = [&](int c) -> const v4f * {
+        const int stage = c / (NTS + 2), local = c - stage * (NTS + 2);
+        return reinterpret_cast<const v4f *>(a.g[stage].chain) + (size_t)local * CH4 + tid;
+    };
+    ChunkRing<CH4> ring;
+    ring.init(smem, n_gvps * (NTS + 2), wave);
+    ring.start(chunk_src);
+
+    const int el = lane & 15, q = lane >> 4;
+    const int vr = node0 + 16 * wave + el;
+    const bool valid = vr < a.n;
+    const int v = valid ? vr : a.n - 1;            // rows past the end repeat the last node and are not stored
+    float inv_norm = 1.0f / a.norm_const;
+    if (a.z) inv_norm = 1.0f / a.z[a.bidx[v]];
+
+    v4f x[NTS], acc[NTS], Vc[3], Vm[3];
+    {   // s + msg / norm, v + msg_v / norm
+        const float *sp = a.s + (size_t)v * S + 4 * q;
+#pragma unroll
+        for (int nt = 0; nt < NTS; ++nt) x[nt] = *reinterpret_cast<const v4f *>(sp + 16 * nt);
+        load_vec12(a.v + (size_t)v * 48 + 12 * q, Vc);
+        for (int i = 0; i < a.n_in; ++i) {
+            const int lo = a.rowptr[i][v], hi = a.rowptr[i][v + 1];
+            if (hi > lo) {
+                const float w = (a.mean ? 1.0f / (float)(hi - lo) : 1.0f) * inv_norm;
+                const float *mp = a.ms_main[i] + (size_t)v * S + 4 * q;
+                v4f m[NTS], mv[3];
+#pragma unroll
+                for (int nt = 0; nt < NTS; ++nt) m[nt] = *reinterpret_cast<const v4f *>(mp + 16 * nt);
+                load_vec12(a.mv_main[i] + (size_t)v * 48 + 12 * q, mv);
+                for (int t = lo / TM + 1; t <= (hi - 1) / TM; ++t) {       // pieces continued into later tiles
+                    const float *cp = a.ms_cont[i] + (size_t)t * S + 4 * q;
+#pragma unroll
+                    for (int nt = 0; nt < NTS; ++nt) m[nt] += *reinterpret_cast<const v4f *>(cp + 16 * nt);
+                    v4f cv[3];
+                    load_vec12(a.mv_cont[i] + (size_t)t * 48 + 12 * q, cv);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) mv[c] += cv[c];
+                }
+#pragma unroll
+                for (int nt = 0; nt < NTS; ++nt) x[nt] += m[nt] * w;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Vc[c] += mv[c] * w;
+            }
+        }
+    }
+    // message layer norm (gvp.py:519-521); its output is also the residual of the update block
+    lanes_layernorm<NTS>(x, a.ln1_w, a.ln1_b, q);
+    lanes_vecnorm(Vc);
+    float *tmp = a.s_tmp + (size_t)v * S + 4 * q;
+    if (valid) {
+#pragma unroll
+        for (int nt = 0; nt < NTS; ++nt) *reinterpret_cast<v4f *>(tmp + 16 * nt) = x[nt];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) Vm[c] = Vc[c];
+    {
+        const float *b0 = a.g[0].b + 4 * q;
+#pragma unroll
+        for (int nt = 0; nt < NTS; ++nt) acc[nt] = *reinterpret_cast<const v4f *>(b0 + 16 * nt);
+    }
+    ring.first();
+#pragma unroll 1
+    for (int k = 0; k < n_gvps; ++k)
+        chain_generic_gvp<NTS>(ring, chunk_src, a.g[k], k + 1 < n_gvps ? a.g[k + 1].b : nullptr, x, acc, Vc, lane, q);
+    // residual + update layer norm (gvp.py:524-532)
+#pragma unroll
+    for (int nt = 0; nt < NTS; ++nt) x[nt] += *reinterpret_cast<const v4f *>(tmp + 16 * nt);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) Vc[c] += Vm[c];
+    lanes_layernorm<NTS>(x, a.ln2_w, a.ln2_b, q);
+    lanes_vecnorm(Vc);
+    if (valid) {
+        float *so = a.s + (size_t)v * S + 4 * q;
+#pragma unroll
+        for (int nt = 0; nt < NTS; ++nt) *reinterpret_cast<v4f *>(so + 16 * nt) = x[nt];
+        float f[12];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) f[3 * r + c] = Vc[c][r];
+        v4f *vo = reinterpret_cast<v4f *>(a.v + (size_t)v * 48 + 12 * q);
+        vo[0] = v4f{f[0], f[1], f[2], f[3]};
+        vo[1] = v4f{f[4], f[5], f[6], f[7]};
+        vo[2] = v4f{f[8], f[9], f[10], f[11]};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the ring's tail fetches must not outlive the workgroup's LDS
+}
+
 static bool g_chain_attr = false;
 
 kpd_status launch_gvp_edge(const GvpEdgeArgs &a, int tile_cap, hipStream_t st) {
@@ -428,6 +585,28 @@ kpd_status launch_gvp_edge(const GvpEdgeArgs &a, int tile_cap, hipStream_t st) {
         hipLaunchKernelGGL(k_gvp_chain<16>, grid, dim3(256), ChainSmem<16>::FLOATS * 4, st, a);
     else
         hipLaunchKernelGGL(k_gvp_chain<8>, grid, dim3(256), ChainSmem<8>::FLOATS * 4, st, a);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+kpd_status launch_gvp_node(const GvpNodePair &p, hipStream_t st) {
+    const int tiles = p.tiles0 + cdiv(p.nt[1].n, TM);
+    if (tiles == 0) return KPD_OK;
+    const int S = p.nt[0].n ? p.nt[0].S : p.nt[1].S;
+    KPD_REQUIRE(S == 256 || S == 128, KPD_ERR_INVALID, "gvp node kernel: S=%d (supported 128, 256)", S);
+    for (int nt = 0; nt < 2; ++nt)
+        if (p.nt[nt].n)
+            for (int k = 0; k < p.nt[nt].n_gvps; ++k)
+                KPD_REQUIRE(p.nt[nt].g[k].chain && p.nt[nt].g[k].whp && p.nt[nt].g[k].wup, KPD_ERR_STATE,
+                            "update GVP %d was not prepared for the chained node kernel", k);
+    static bool attr = false;
+    if (!attr) {
+        KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gvp_node_chain<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 16 * 64 * 16));
+        KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gvp_node_chain<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 8 * 64 * 16));
+        attr = true;
+    }
+    if (S == 256) hipLaunchKernelGGL(k_gvp_node_chain<16>, dim3(tiles), dim3(256), 3 * 16 * 64 * 16, st, p);
+    else hipLaunchKernelGGL(k_gvp_node_chain<8>, dim3(tiles), dim3(256), 3 * 8 * 64 * 16, st, p);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
 }

@@ -331,95 +331,6 @@ __global__ __launch_bounds__(256, 2) void k_gvp_proj(GvpProjArgs a) {
     }
 }
 
-// ---- node update (gvp.py:499-536) ---------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gvp_node(GvpNodePair p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const GvpSmem s = gvp_smem(smem);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int which = (int)blockIdx.x >= p.tiles0 ? 1 : 0;
-    const GvpNodeArgs &a = p.nt[which];
-    const int node0 = ((int)blockIdx.x - (which ? p.tiles0 : 0)) * TM;
-    const int S = a.S, chunks = S >> 2;
-
-    // s + msg / norm -> A tile; v + msg_v / norm -> V0   (aggregation: per-etype sum or mean, cross-etype sum)
-    for (int rr = 0; rr < 16; ++rr) {
-        const int r = wave * 16 + rr, v = node0 + r;
-        float norm = a.norm_const;
-        if (v < a.n && a.z) norm = a.z[a.bidx[v]];
-        for (int c = lane; c < chunks; c += 64) {
-            f32x4_ val = {0.f, 0.f, 0.f, 0.f};
-            if (v < a.n) {
-                f32x4_ msg = {0.f, 0.f, 0.f, 0.f};
-                for (int i = 0; i < a.n_in; ++i) {
-                    const int lo = a.rowptr[i][v], hi = a.rowptr[i][v + 1];
-                    if (hi > lo) {
-                        f32x4_ m = reinterpret_cast<const f32x4_ *>(a.ms_main[i] + (size_t)v * S)[c];
-                        for (int t = lo / TM + 1; t <= (hi - 1) / TM; ++t)
-                            m += reinterpret_cast<const f32x4_ *>(a.ms_cont[i] + (size_t)t * S)[c];
-                        if (a.mean) m /= (float)(hi - lo);
-                        msg += m;
-                    }
-                }
-                val = reinterpret_cast<const f32x4_ *>(a.s + (size_t)v * S)[c] + msg / norm;
-            }
-            *reinterpret_cast<f32x4_ *>(s.A + r * SA_G + 4 * c) = val;
-        }
-        if (lane < 48) {
-            float val = 0.0f;
-            if (v < a.n) {
-                float msg = 0.0f;
-                for (int i = 0; i < a.n_in; ++i) {
-                    const int lo = a.rowptr[i][v], hi = a.rowptr[i][v + 1];
-                    if (hi > lo) {
-                        float m = a.mv_main[i][(size_t)v * 48 + lane];
-                        for (int t = lo / TM + 1; t <= (hi - 1) / TM; ++t) m += a.mv_cont[i][(size_t)t * 48 + lane];
-                        if (a.mean) m /= (float)(hi - lo);
-                        msg += m;
-                    }
-                }
-                val = a.v[(size_t)v * 48 + lane] + msg / norm;
-            }
-            s.V0[r * VST + lane] = val;
-        }
-    }
-    lds_barrier();
-    // message layer norm (gvp.py:519-521)
-    tile_layernorm(s, S, a.ln1_w, a.ln1_b, tid);
-    tile_vecnorm(s, tid);
-    lds_barrier();
-    // stash the residual of the update block: scalars to HBM scratch, vectors to V2
-    for (int rr = 0; rr < 16; ++rr) {
-        const int r = wave * 16 + rr, v = node0 + r;
-        if (v < a.n)
-            for (int c = lane; c < chunks; c += 64)
-                reinterpret_cast<f32x4_ *>(a.s_tmp + (size_t)v * S)[c] = *reinterpret_cast<const f32x4_ *>(s.A + r * SA_G + 4 * c);
-        if (lane < 48) s.V2[r * VST + lane] = s.V0[r * VST + lane];
-    }
-    lds_barrier();
-    for (int k = 0; k < a.n_gvps; ++k) gvp_stage(s, a.g[k], tid);
-    // residual + update layer norm (gvp.py:524-532)
-    for (int rr = 0; rr < 16; ++rr) {
-        const int r = wave * 16 + rr, v = node0 + r;
-        for (int c = lane; c < chunks; c += 64) {
-            f32x4_ res = {0.f, 0.f, 0.f, 0.f};
-            if (v < a.n) res = reinterpret_cast<const f32x4_ *>(a.s_tmp + (size_t)v * S)[c];
-            *reinterpret_cast<f32x4_ *>(s.A + r * SA_G + 4 * c) += res;
-        }
-        if (lane < 48) s.V0[r * VST + lane] += s.V2[r * VST + lane];
-    }
-    lds_barrier();
-    tile_layernorm(s, S, a.ln2_w, a.ln2_b, tid);
-    tile_vecnorm(s, tid);
-    lds_barrier();
-    for (int rr = 0; rr < 16; ++rr) {
-        const int r = wave * 16 + rr, v = node0 + r;
-        if (v >= a.n) continue;
-        for (int c = lane; c < chunks; c += 64)
-            reinterpret_cast<f32x4_ *>(a.s + (size_t)v * S)[c] = *reinterpret_cast<const f32x4_ *>(s.A + r * SA_G + 4 * c);
-        if (lane < 48) a.v[(size_t)v * 48 + lane] = s.V0[r * VST + lane];
-    }
-}
-
 // ---- noise prediction block (dynamics_gvp.py:38-44) ----------------------------------------------
 __global__ __launch_bounds__(256) void k_gvp_noise(GvpNoiseArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -457,8 +368,6 @@ kpd_status gvp_kernels_init() {
     if (g_gvp_attr) return KPD_OK;
     KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gvp_proj), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 TM * SA_G * 4));
-    KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gvp_node), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                GVP_LDS_BYTES));
     KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gvp_noise), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 GVP_LDS_BYTES));
     g_gvp_attr = true;
@@ -477,14 +386,6 @@ kpd_status launch_gvp_embed(const float *in, int n, int fin, const float *W, con
 kpd_status launch_gvp_proj(const GvpProjArgs &a, hipStream_t st) {
     if (a.n_slots == 0 || a.tiles_first[a.n_slots] == 0) return KPD_OK;
     hipLaunchKernelGGL(k_gvp_proj, dim3(a.tiles_first[a.n_slots]), dim3(256), TM * SA_G * 4, st, a);
-    KPD_LAUNCH_CHECK();
-    return KPD_OK;
-}
-
-kpd_status launch_gvp_node(const GvpNodePair &p, hipStream_t st) {
-    const int tiles = p.tiles0 + cdiv(p.nt[1].n, TM);
-    if (tiles == 0) return KPD_OK;
-    hipLaunchKernelGGL(k_gvp_node, dim3(tiles), dim3(256), GVP_LDS_BYTES, st, p);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
 }

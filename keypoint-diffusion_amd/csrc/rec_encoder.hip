@@ -255,6 +255,7 @@ static void alloc_conv(kpd_recenc *m, Arena &A, std::vector<HostGvp> &msg, std::
     for (int j = 0; j < c.n_update_gvps; ++j) {
         HostGvp &g = upd[j];
         g.vin = GV; g.vout = GV; g.s_in = S; g.sout = S;
+        g.chain_pos = 1;
         alloc_gvp(A, g, m->expected, pre + "node_update." + std::to_string(j));
     }
     for (int i = 0; i < 4; ++i) ln[i] = A.take<float>(S);

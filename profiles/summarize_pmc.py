@@ -14,7 +14,7 @@ for f in glob.glob(os.path.join(root, '**', '*counter_collection.csv'), recursiv
         a[0] += float(r['Counter_Value'])
         a[1] += 1
 for k in sorted(agg, key=lambda k: -sum(v[0] for v in agg[k].values())):
-    if 'kpd::k_egnn' not in k and 'kpd::k_node' not in k and 'kpd::k_gvp' not in k:
+    if 'kpd::k_egnn' not in k and 'kpd::k_node' not in k and 'kpd::k_gvp' not in k and 'kpd::k_proj' not in k:
         continue
     print(k)
     for c, (tot, n) in sorted(agg[k].items()):
