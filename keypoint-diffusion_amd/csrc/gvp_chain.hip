@@ -563,6 +563,52 @@ __global__ __launch_bounds__(256, 2) void k_gvp_node_chain(GvpNodePair p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the ring's tail fetches must not outlive the workgroup's LDS
 }
 
+// ---- per-node blocks of the first message Linear (h_src / h_dst part of to_feats_out), register-chained -------------
+// P[slot][node][:] = W_block s[node] (+ b): one 64-node tile of one slot per workgroup, the S x S block streamed as
+// two-slab chunks (gvp_host.hip packs wproj / wproj_dst in chunk order).
+template <int NTS>
+__global__ __launch_bounds__(256, 2) void k_gvp_proj_chain(GvpProjArgs a) {
+    constexpr int S = 16 * NTS, CH4 = NTS * 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int sl = 0;
+#pragma unroll
+    for (int e = 1; e < GVP_PROJ_SLOTS; ++e)
+        if (e < a.n_slots && (int)blockIdx.x >= a.tiles_first[e]) sl = e;
+    const int node0 = ((int)blockIdx.x - a.tiles_first[sl]) * TM;
+    const int n = a.n[sl];
+
+    const v4f *stream = reinterpret_cast<const v4f *>(a.wp[sl]) + tid;
+    auto chunk_src = [&](int c) -> const v4f * { return stream + (size_t)c * (2 * CH4); };
+    ChunkRing2<2 * CH4> ring;
+    ring.init(smem, NTS / 2, wave);
+    ring.start(chunk_src);
+
+    const int el = lane & 15, q = lane >> 4;
+    const int vr = node0 + 16 * wave + el;
+    const int v = min(vr, n - 1);
+    const float *sp = a.s[sl] + (size_t)v * S + 4 * q;
+    v4f x[NTS], acc[NTS];
+#pragma unroll
+    for (int nt = 0; nt < NTS; ++nt) x[nt] = *reinterpret_cast<const v4f *>(sp + 16 * nt);
+    const float *bias = a.b[sl];
+#pragma unroll
+    for (int mt = 0; mt < NTS; ++mt) acc[mt] = bias ? *reinterpret_cast<const v4f *>(bias + 16 * mt + 4 * q) : zero4();
+    ring.first();
+#pragma unroll
+    for (int nt = 0; nt < NTS; nt += 2) {
+        const v4f *buf = ring.acquire(chunk_src);
+        chunk_gemm2<NTS>(buf, x[nt], x[nt + 1], acc, lane);
+        ring.release();
+    }
+    if (vr < n) {
+        float *out = a.P[sl] + (size_t)v * S + 4 * q;
+#pragma unroll
+        for (int mt = 0; mt < NTS; ++mt) *reinterpret_cast<v4f *>(out + 16 * mt) = acc[mt];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the ring's tail fetch must not outlive the workgroup's LDS
+}
+
 static bool g_chain_attr = false;
 
 kpd_status launch_gvp_edge(const GvpEdgeArgs &a, int tile_cap, hipStream_t st) {
@@ -585,6 +631,22 @@ kpd_status launch_gvp_edge(const GvpEdgeArgs &a, int tile_cap, hipStream_t st) {
         hipLaunchKernelGGL(k_gvp_chain<16>, grid, dim3(256), ChainSmem<16>::FLOATS * 4, st, a);
     else
         hipLaunchKernelGGL(k_gvp_chain<8>, grid, dim3(256), ChainSmem<8>::FLOATS * 4, st, a);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+kpd_status launch_gvp_proj(const GvpProjArgs &a, hipStream_t st) {
+    if (a.n_slots == 0 || a.tiles_first[a.n_slots] == 0) return KPD_OK;
+    KPD_REQUIRE(a.S == 256 || a.S == 128, KPD_ERR_INVALID, "gvp projection kernel: S=%d (supported 128, 256)", a.S);
+    static bool attr = false;
+    if (!attr) {
+        KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gvp_proj_chain<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16 * 64 * 16));
+        KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gvp_proj_chain<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 8 * 64 * 16));
+        attr = true;
+    }
+    const dim3 grid(a.tiles_first[a.n_slots]);
+    if (a.S == 256) hipLaunchKernelGGL(k_gvp_proj_chain<16>, grid, dim3(256), 4 * 16 * 64 * 16, st, a);
+    else hipLaunchKernelGGL(k_gvp_proj_chain<8>, grid, dim3(256), 4 * 8 * 64 * 16, st, a);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
 }

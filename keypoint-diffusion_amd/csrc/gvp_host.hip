@@ -91,11 +91,18 @@ kpd_status load_gvp_tensor(HostGvp &g, const std::string &param, const char *nam
                 KPD_TRY(pack_chain_frag(w, 1, g.vout, g.vout, 16 * ht, std::min(16, g.h - 16 * ht), 1, g.wup + ht * 256, st));
     } else if (param == "to_feats_out.0.weight") {
         KPD_TRY(want_shape(name, shape, ndim, {g.sout, k_all}));
+        // node blocks of a split first Linear: S / 16 k-slabs in chunk order for k_gvp_proj_chain
+        auto pack_block = [&](int col0, float *dst) -> kpd_status {
+            const int nts = g.sout / 16;
+            for (int kc = 0; kc < g.S / 16; ++kc)
+                KPD_TRY(pack_chain_frag(w, k_all, 1, g.sout, col0 + 16 * kc, 16, nts, dst + (size_t)kc * nts * 256, st));
+            return KPD_OK;
+        };
         if (g.split == SPLIT_SRC) {             // [h_src S | rbf 16 | sh h]
-            KPD_TRY(pack_gemm_weight_ng(w, g.sout, k_all, 0, g.S, g.S / 8, g.wproj, st));
+            KPD_TRY(pack_block(0, g.wproj));
         } else if (g.split == SPLIT_SRC_DST) {  // [h_src S | rbf 16 | h_dst S | sh h]
-            KPD_TRY(pack_gemm_weight_ng(w, g.sout, k_all, 0, g.S, g.S / 8, g.wproj, st));
-            KPD_TRY(pack_gemm_weight_ng(w, g.sout, k_all, g.S + 16, g.S, g.S / 8, g.wproj_dst, st));
+            KPD_TRY(pack_block(0, g.wproj));
+            KPD_TRY(pack_block(g.S + 16, g.wproj_dst));
         } else if (g.chain_pos < 0) {
             KPD_TRY(pack_gemm_weight_ng(w, g.sout, k_all, 0, k_all, g.ng, g.wp, st));
         }

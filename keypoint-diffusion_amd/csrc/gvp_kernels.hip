@@ -287,50 +287,6 @@ __global__ __launch_bounds__(256) void k_gvp_embed(const float *__restrict__ in,
     }
 }
 
-// ---- source-node projection of the first message GVP ----------------------------------------
-// P[et][node][:] = W0[:, :S] s[node] + b0   (the h_src block of to_feats_out, gvp.py:545-549)
-__global__ __launch_bounds__(256, 2) void k_gvp_proj(GvpProjArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *A = smem;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    int sl = 0;
-#pragma unroll
-    for (int e = 1; e < GVP_PROJ_SLOTS; ++e)
-        if (e < a.n_slots && (int)blockIdx.x >= a.tiles_first[e]) sl = e;
-    const int node0 = ((int)blockIdx.x - a.tiles_first[sl]) * TM;
-    const int n = a.n[sl], S = a.S;
-    const float *src = a.s[sl];
-    const int chunks = S >> 2;
-    for (int rr = 0; rr < 16; ++rr) {
-        const int r = wave * 16 + rr, v = node0 + r;
-        for (int c = lane; c < chunks; c += 64) {
-            f32x4_ val = {0.f, 0.f, 0.f, 0.f};
-            if (v < n) val = reinterpret_cast<const f32x4_ *>(src + (size_t)v * S)[c];
-            *reinterpret_cast<f32x4_ *>(A + r * SA_G + 4 * c) = val;
-        }
-    }
-    lds_barrier();
-    f32x16 acc[2][2];
-    acc_zero(acc);
-    gemm_rows64_rt<SA_G>(A, a.wp[sl], S >> 3, acc, wave, lane);
-    float *out = a.P[sl];
-    const float *bias = a.b[sl];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int col = acc_col(nt, wave, lane);
-        if (col < S) {
-            const float bb = bias ? bias[col] : 0.0f;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int v = node0 + acc_row(mt, reg, lane);
-                    if (v < n) out[(size_t)v * S + col] = acc[mt][nt][reg] + bb;
-                }
-        }
-    }
-}
-
 // ---- noise prediction block (dynamics_gvp.py:38-44) ----------------------------------------------
 __global__ __launch_bounds__(256) void k_gvp_noise(GvpNoiseArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -366,8 +322,6 @@ static bool g_gvp_attr = false;
 
 kpd_status gvp_kernels_init() {
     if (g_gvp_attr) return KPD_OK;
-    KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gvp_proj), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                TM * SA_G * 4));
     KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gvp_noise), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 GVP_LDS_BYTES));
     g_gvp_attr = true;
@@ -379,13 +333,6 @@ kpd_status launch_gvp_embed(const float *in, int n, int fin, const float *W, con
     if (n == 0) return KPD_OK;
     KPD_REQUIRE(fin + 1 <= 260 && S <= 256, KPD_ERR_INVALID, "gvp embed: fin=%d S=%d", fin, S);
     hipLaunchKernelGGL(k_gvp_embed, dim3(cdiv(n, GEMB_NODES)), dim3(256), 0, st, in, n, fin, W, b, ln_w, ln_b, t, bidx, S, out);
-    KPD_LAUNCH_CHECK();
-    return KPD_OK;
-}
-
-kpd_status launch_gvp_proj(const GvpProjArgs &a, hipStream_t st) {
-    if (a.n_slots == 0 || a.tiles_first[a.n_slots] == 0) return KPD_OK;
-    hipLaunchKernelGGL(k_gvp_proj, dim3(a.tiles_first[a.n_slots]), dim3(256), TM * SA_G * 4, st, a);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
 }
