@@ -53,16 +53,18 @@ from models.dynamics_gvp import LigRecDynamicsGVP as RefGVPDyn             # noq
 from models.dynamics_gvp import NoisePredictionBlock as RefNoiseBlock      # noqa: E402
 from models.gvp import GVP as RefGVP, GVPLayerNorm as RefGVPLN, _rbf as ref_rbf, _norm_no_nan as ref_nnn   # noqa: E402
 from models.receptor_encoder_gvp import ReceptorEncoderGVP as RefRecEnc    # noqa: E402
+from models.receptor_encoder import ReceptorEncoder as RefRecEgnn          # noqa: E402
 from models.ligand_diffuser import PredefinedNoiseSchedule as RefSchedule, KeypointDiffusion as RefKD    # noqa: E402
 
 from keypoint_diffusion_amd import synth                                    # noqa: E402
 from keypoint_diffusion_amd.dynamics import LigRecDynamics                  # noqa: E402
 from keypoint_diffusion_amd.dynamics_gvp import LigRecDynamicsGVP           # noqa: E402
 from keypoint_diffusion_amd.receptor_encoder_gvp import ReceptorEncoderGVP  # noqa: E402
+from keypoint_diffusion_amd.receptor_encoder import ReceptorEncoder         # noqa: E402
 from oracle import graph_ops as G                                           # noqa: E402
 from oracle import egnn as oegnn                                            # noqa: E402
 from tests import util                                                      # noqa: E402
-from tests.golden.make_golden_cfgs import GVP_CFGS, RECENC_CFGS            # noqa: E402
+from tests.golden.make_golden_cfgs import GVP_CFGS, RECENC_CFGS, RECEGNN_CFGS, same_res_feature   # noqa: E402
 
 CUT = util.CUTOFFS_ALL_ATOM
 layout = {}
@@ -340,6 +342,64 @@ def make_rec_encoder():
         npz(f'{tag}.npz', seed=61, n_rec=n_rec, n_keypoints=K, kp_x=kp_x, kp_s=kp_s, kp_v=kp_v, rec_s=s, rec_v=v)
 
 
+# --------------------------------------------------------------------------------------------
+# EGNN receptor encoder: composed forward of the reference's own sub-modules
+# (models/receptor_encoder.py:98-154 ReceptorConv, :182-297 RecKeyConv, :483-555 ReceptorEncoder)
+# --------------------------------------------------------------------------------------------
+def make_rec_encoder_egnn():
+    for tag, cfg in RECEGNN_CFGS.items():
+        kw = dict(cfg, graph_cutoffs=CUT)
+        ref, mine = RefRecEgnn(**kw), ReceptorEncoder(**kw)
+        check_layout(tag, ref, mine)
+        synth.fill_state_dict_(ref, 71)
+        ref.eval()
+        n_rec = [33, 21]
+        K, D, k = cfg['n_keypoints'], cfg['out_n_node_feat'], cfg['k_closest']
+        g = util.make_batch(n_rec, [4, 4], seed=19, n_keypoints=K)
+        ob = util.to_obatch(g)
+        src, dst = ob.edges['rr']
+        a = same_res_feature(src, dst) if cfg['use_sameres_feat'] else None
+        rec_b = G.counts_to_batch_idx(ob.n['rec'])
+        with torch.no_grad():
+            h, x = ob.h['rec'], ob.x['rec']
+            if cfg['message_norm'] == 0:                                             # :505-509
+                z = (G.edges_per_graph(dst, ob.n['rec']).float() / ob.n['rec'].float())[rec_b].view(-1, 1)
+            else:
+                z = cfg['message_norm']
+            for conv in ref.rec_convs:                                               # ReceptorConv.forward :98-154
+                x_diff = x[src] - x[dst]
+                radial = torch.norm(x_diff, dim=1).unsqueeze(-1)
+                x_diff = x_diff / (radial + 1)
+                f = torch.cat([h[src], h[dst], radial] + ([a] if a is not None else []), dim=-1)
+                msg_h = conv.edge_mlp(f)
+                msg_h = msg_h * conv.soft_attention(msg_h)
+                h_neigh = torch.zeros(h.shape[0], msg_h.shape[1]).index_add_(0, dst, msg_h) / z
+                if conv.fix_pos:
+                    x_new = x
+                else:
+                    msg_x = torch.tanh(conv.coord_mlp(f)) * x_diff * conv.coords_range if conv.use_tanh else conv.coord_mlp(f) * x_diff
+                    x_new = x + torch.zeros_like(x).index_add_(0, dst, msg_x) / z
+                h = conv.layer_norm(conv.node_mlp(torch.cat([h, h_neigh], dim=-1)))
+                x = x_new
+            meanf = G.segment_mean_nodes(h, ob.n['rec'])                             # :526
+            kp_h0 = ref.keypoint_embedding(meanf).reshape(-1, D)                     # :529-530
+            rk = ref.rec_kp_conv                                                     # RecKeyConv.forward :182-236
+            ft_src, ft_dst = rk.fc_src(h), rk.fc_src(kp_h0)
+            x_val = ob.x['rec'] if cfg['fix_pos'] else x
+            rp = G.counts_to_ptr(ob.n['rec'])
+            pos = []
+            for b in range(len(n_rec)):
+                att = torch.exp((ft_dst[b * K:(b + 1) * K] @ ft_src[rp[b]:rp[b + 1]].T) / rk.out_feats ** 0.5)
+                pos.append((att / att.sum(1, keepdim=True)) @ x_val[rp[b]:rp[b + 1]])
+            kp_x = torch.cat(pos)
+            n_kp = torch.full((len(n_rec),), K)
+            kp_idx, rec_idx = G.knn(ob.x['rec'], kp_x, k, ob.n['rec'], n_kp)         # k_closest_feats :257-291
+            h_m = torch.zeros(kp_x.shape[0], D).index_add_(0, kp_idx, h[rec_idx]) / k
+            d_k = torch.norm(ob.x['rec'][rec_idx] - kp_x[kp_idx] + 1e-30, dim=1).view(-1, k)
+            kp_h = rk.layer_norm(rk.kp_feature_mlp(torch.cat([h_m, d_k], dim=1)))
+        npz(f'{tag}.npz', seed=71, n_rec=n_rec, n_keypoints=K, kp_x=kp_x, kp_h=kp_h, rec_h=h, rec_x=x)
+
+
 def make_schedule():
     out = {}
     for T in (100, 500, 1000):
@@ -352,11 +412,15 @@ def make_schedule():
 
 if __name__ == '__main__':
     torch.manual_seed(0)
-    make_egnn()
-    make_gvp_blocks()
-    make_gvp_dyn()
-    make_rec_encoder()
-    make_schedule()
-    with open(os.path.join(HERE, 'state_dict_layout.json'), 'w') as f:
+    makers = dict(egnn=make_egnn, gvp_blocks=make_gvp_blocks, gvp_dyn=make_gvp_dyn, rec_encoder=make_rec_encoder,
+                  rec_encoder_egnn=make_rec_encoder_egnn, schedule=make_schedule)
+    only = sys.argv[1:]                 # e.g. `make_golden.py rec_encoder_egnn`: regenerate one family, keep the others
+    lp = os.path.join(HERE, 'state_dict_layout.json')
+    if only and os.path.exists(lp):
+        layout.update(json.load(open(lp)))
+    for name, fn in makers.items():
+        if not only or name in only:
+            fn()
+    with open(lp, 'w') as f:
         json.dump(layout, f, indent=0, sort_keys=True)
     print('layouts:', {k: len(v) for k, v in layout.items()})

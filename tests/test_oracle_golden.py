@@ -12,14 +12,16 @@ import torch.nn.functional as F
 from keypoint_diffusion_amd import synth
 from keypoint_diffusion_amd.dynamics import LigRecDynamics
 from keypoint_diffusion_amd.dynamics_gvp import LigRecDynamicsGVP
+from keypoint_diffusion_amd.receptor_encoder import ReceptorEncoder
 from keypoint_diffusion_amd.receptor_encoder_gvp import ReceptorEncoderGVP
 from oracle import diffusion as odiff
 from oracle import egnn as oegnn
 from oracle import gvp as ogvp
 from oracle import rec_encoder as orec
+from oracle import rec_encoder_egnn as orecegnn
 
 from . import util
-from .golden.make_golden_cfgs import GVP_CFGS, RECENC_CFGS
+from .golden.make_golden_cfgs import GVP_CFGS, RECENC_CFGS, RECEGNN_CFGS, same_res_feature
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 CUT = util.CUTOFFS_ALL_ATOM
@@ -46,6 +48,7 @@ def test_state_dict_layout_matches_reference():
         'recenc_mean': ReceptorEncoderGVP(graph_cutoffs=CUT, **RECENC_CFGS['recenc_mean']),
         'recenc_norm10': ReceptorEncoderGVP(graph_cutoffs=CUT, **RECENC_CFGS['recenc_norm10']),
     }
+    mods.update({tag: ReceptorEncoder(graph_cutoffs=CUT, **cfg) for tag, cfg in RECEGNN_CFGS.items()})
     for tag, m in mods.items():
         mine = {k: list(v.shape) for k, v in m.state_dict().items()}
         assert mine == layout[tag], tag
@@ -135,6 +138,24 @@ def test_receptor_encoder_forward(tag):
     close(out.x['kp'], gd['kp_x'])
     close(out.h['kp'], gd['kp_s'])
     close(out.v['kp'], gd['kp_v'])
+
+
+@pytest.mark.parametrize('tag', list(RECEGNN_CFGS))
+def test_egnn_receptor_encoder_forward(tag):
+    """models/receptor_encoder.py: oracle vs the composition of the reference's sub-modules."""
+    gd = load(f'{tag}.npz')
+    cfg = dict(RECEGNN_CFGS[tag], graph_cutoffs=CUT)
+    model = synth.fill_state_dict_(ReceptorEncoder(**cfg), int(gd['seed']))
+    ob = util.to_obatch(util.make_batch(gd['n_rec'].tolist(), [4, 4], seed=19, n_keypoints=int(gd['n_keypoints'])))
+    a = same_res_feature(*ob.edges['rr']) if cfg['use_sameres_feat'] else None
+    out, rec_h, rec_x = orecegnn.rec_encoder_egnn_forward(model.state_dict(), cfg, ob, a, return_rec=True)
+    close(rec_h, gd['rec_h'])
+    close(rec_x, gd['rec_x'])
+    close(out.x['kp'], gd['kp_x'])
+    close(out.h['kp'], gd['kp_h'])
+    # the shipped egnn_20kp encoder: 68 tensors (fc_dst included although never applied upstream)
+    if tag == 'recegnn_20kp':
+        assert len(model.state_dict()) == 68
 
 
 def test_noise_schedule_and_step_terms():
