@@ -212,6 +212,40 @@ kpd_status kpd_recenc_forward(kpd_recenc *m, const kpd_rec_batch *batch, const k
                               void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * EGNN keypoint receptor encoder (once per pocket; the encoder of the egnn_20kp / egnn_40kp models).  Replaces
+ * ReceptorEncoder.forward (models/receptor_encoder.py:483-555): the ReceptorConv stack on the rr graph (:14-154),
+ * keypoint_embedding of the mean receptor feature (:526-530), RecKeyConv (:182-297, k_closest features) and the
+ * keypoint radius graph (:541).  Fields mirror ReceptorEncoder.__init__ (:383-400) + graph_cutoffs['kk'].
+ * Batch and outputs reuse kpd_rec_batch / kpd_rec_out (rec_h width = in_n_node_feat, kp_h width =
+ * out_n_node_feat, kp_v unused); rr_same_res [n_rr] is the rr `same_res` column as floats, in the order of the
+ * sorted rr edges (null without use_sameres_feat); rec_h_out [n_rec,out] / rec_x_out [n_rec,3] (optional) receive
+ * the learned receptor features / positions the reference stores as rec 'h' / 'x' (:516-517).
+ * ------------------------------------------------------------------------------------- */
+typedef struct kpd_recegnn_config {
+    int32_t n_convs, n_keypoints;
+    int32_t in_n_node_feat, hidden_n_node_feat, out_n_node_feat;   /* each in 1..256                        */
+    int32_t use_sameres_feat, use_tanh, norm, fix_pos;
+    float coords_range;
+    float message_norm;          /* 0: z = rr edges / receptor nodes per graph (no +1, :505-509)          */
+    int32_t k_closest;           /* kNN rec->kp features, 1..16 (kp_rad is not implemented)               */
+    float kk_cutoff;             /* graph_cutoffs['kk']                                                   */
+} kpd_recegnn_config;
+
+typedef struct kpd_recegnn kpd_recegnn;
+
+kpd_status kpd_recegnn_create(const kpd_recegnn_config *cfg, kpd_recegnn **out);
+void kpd_recegnn_destroy(kpd_recegnn *m);
+/* Reference state-dict names of the `rec_encoder` module, e.g. "rec_convs.2.edge_mlp.0.weight",
+ * "rec_kp_conv.kp_feature_mlp.0.bias" ("rec_kp_conv.fc_dst.weight" is accepted and ignored, as upstream never applies it). */
+kpd_status kpd_recegnn_load_weight(kpd_recegnn *m, const char *name, const float *w_dev,
+                                   const int64_t *shape, int32_t ndim, void *stream);
+kpd_status kpd_recegnn_commit(kpd_recegnn *m);
+kpd_status kpd_recegnn_reserve(kpd_recegnn *m, int32_t max_B, int32_t max_n_rec, int32_t max_n_rr,
+                               int32_t max_rec_per_graph);
+kpd_status kpd_recegnn_forward(kpd_recegnn *m, const kpd_rec_batch *batch, const float *rr_same_res,
+                               const kpd_rec_out *out, float *rec_h_out, float *rec_x_out, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Reverse-diffusion update around the denoiser.  Replaces the elementwise part of
  * KeypointDiffusion.sample_p_zs_given_zt (models/ligand_diffuser.py:515-536):
  *   z_s = z_t / alpha_ts - var_terms * eps + sigma * noise, then ligand-COM removal from

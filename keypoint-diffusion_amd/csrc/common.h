@@ -29,6 +29,11 @@ void set_error(const char *fmt, ...);
     } while (0)
 
 #define KPD_LAUNCH_CHECK() KPD_HIP(hipGetLastError())
+#define KPD_TRY(expr)                  \
+    do {                               \
+        kpd_status s_ = (expr);        \
+        if (s_ != KPD_OK) return s_;   \
+    } while (0)
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 

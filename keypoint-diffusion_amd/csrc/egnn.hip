@@ -211,12 +211,6 @@ static kpd_status expect_shape(const char *name, const int64_t *shape, int ndim,
     return KPD_OK;
 }
 
-#define KPD_TRY(expr)                  \
-    do {                               \
-        kpd_status s_ = (expr);        \
-        if (s_ != KPD_OK) return s_;   \
-    } while (0)
-
 extern "C" kpd_status kpd_egnn_load_weight(kpd_egnn *m, const char *name, const float *w, const int64_t *shape,
                                            int32_t ndim, void *stream) {
     KPD_REQUIRE(m && name && w && shape, KPD_ERR_INVALID, "null argument");

@@ -10,12 +10,6 @@
 
 namespace kpd {
 
-#define KPD_TRY(expr)                  \
-    do {                               \
-        kpd_status s_ = (expr);        \
-        if (s_ != KPD_OK) return s_;   \
-    } while (0)
-
 // How the first Linear (to_feats_out) of a message GVP is split.  Its input is
 // [h_src (S) | rbf (16) | (h_dst (S)) | sh (h)]; blocks that depend on one node only are applied per
 // node by k_gvp_proj and enter the edge stage as gathered per-row terms.

@@ -9,6 +9,7 @@
 #include "egnn_kernels.h"
 #include "gvp_host.h"
 #include "mfma_core.h"
+#include "rec_kernels.h"
 
 using namespace kpd;
 
@@ -213,6 +214,34 @@ __global__ __launch_bounds__(256) void k_kp_attention(const float *__restrict__ 
         __syncthreads();
     }
     if (tid < 3) kp_x[(size_t)kp * 3 + tid] = s_part[0][1 + tid] / s_part[0][0];
+}
+
+kpd_status launch_iota_scaled(int *out, int n, int scale, hipStream_t st) {
+    hipLaunchKernelGGL(k_iota_scaled, dim3(cdiv(n, 256)), dim3(256), 0, st, out, n, scale);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+kpd_status launch_graph_mean(const float *s, const int *ptr, int B, int S, float *out, hipStream_t st) {
+    KPD_REQUIRE(S <= 256, KPD_ERR_INVALID, "graph mean: S=%d > 256", S);
+    hipLaunchKernelGGL(k_graph_mean, dim3(B), dim3(256), 0, st, s, ptr, S, out);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+kpd_status launch_linear_rows(const float *in, int n, int S, const float *Wt, float *out, hipStream_t st) {
+    KPD_REQUIRE(S <= 256, KPD_ERR_INVALID, "linear rows: S=%d > 256", S);
+    hipLaunchKernelGGL(k_linear_rows, dim3(cdiv(n, 4)), dim3(256), 0, st, in, n, S, Wt, out);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+kpd_status launch_kp_attention(const float *ft_src, const float *ft_dst, const float *rec_x, const int *rec_ptr, int n_kp, int K,
+                               int S, float *kp_x, hipStream_t st) {
+    KPD_REQUIRE(S <= 256, KPD_ERR_INVALID, "kp attention: S=%d > 256", S);
+    hipLaunchKernelGGL(k_kp_attention, dim3(n_kp), dim3(256), 0, st, ft_src, ft_dst, rec_x, rec_ptr, K, S, kp_x);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
 }
 
 }  // namespace kpd

@@ -56,6 +56,13 @@ class KpdRecencConfig(C.Structure):
                 ('kk_cutoff', C.c_float)]
 
 
+class KpdRecegnnConfig(C.Structure):
+    _fields_ = [('n_convs', C.c_int32), ('n_keypoints', C.c_int32), ('in_n_node_feat', C.c_int32),
+                ('hidden_n_node_feat', C.c_int32), ('out_n_node_feat', C.c_int32), ('use_sameres_feat', C.c_int32),
+                ('use_tanh', C.c_int32), ('norm', C.c_int32), ('fix_pos', C.c_int32), ('coords_range', C.c_float),
+                ('message_norm', C.c_float), ('k_closest', C.c_int32), ('kk_cutoff', C.c_float)]
+
+
 class KpdRecBatch(C.Structure):
     _fields_ = [('B', C.c_int32), ('n_rec', C.c_int32), ('max_rec', C.c_int32), ('rec_ptr', C.c_void_p),
                 ('rec_x', C.c_void_p), ('rec_h', C.c_void_p), ('n_rr', C.c_int32), ('rr_src', C.c_void_p),
@@ -111,6 +118,14 @@ def lib():
     L.kpd_recenc_commit.argtypes = [C.c_void_p]
     L.kpd_recenc_reserve.argtypes = [C.c_void_p] + [C.c_int32] * 4
     L.kpd_recenc_forward.argtypes = [C.c_void_p, C.POINTER(KpdRecBatch), C.POINTER(KpdRecOut), C.c_void_p]
+    L.kpd_recegnn_create.argtypes = [C.POINTER(KpdRecegnnConfig), C.POINTER(C.c_void_p)]
+    L.kpd_recegnn_destroy.argtypes = [C.c_void_p]
+    L.kpd_recegnn_destroy.restype = None
+    L.kpd_recegnn_load_weight.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_void_p]
+    L.kpd_recegnn_commit.argtypes = [C.c_void_p]
+    L.kpd_recegnn_reserve.argtypes = [C.c_void_p] + [C.c_int32] * 4
+    L.kpd_recegnn_forward.argtypes = [C.c_void_p, C.POINTER(KpdRecBatch), C.c_void_p, C.POINTER(KpdRecOut), C.c_void_p, C.c_void_p,
+                                      C.c_void_p]
     L.kpd_build_lig_graph.argtypes = [C.POINTER(KpdBatch), C.c_float, C.c_int32, C.POINTER(KpdLigGraph), C.c_void_p]
     L.kpd_sample_update.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 8 + [C.c_int32, C.c_void_p]
     L.kpd_step_coefficients.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
@@ -128,6 +143,8 @@ EXPORTS = [
     'kpd_gvp_forward', 'kpd_gvp_debug_state',
     'kpd_recenc_create', 'kpd_recenc_destroy', 'kpd_recenc_load_weight', 'kpd_recenc_commit', 'kpd_recenc_reserve',
     'kpd_recenc_forward',
+    'kpd_recegnn_create', 'kpd_recegnn_destroy', 'kpd_recegnn_load_weight', 'kpd_recegnn_commit', 'kpd_recegnn_reserve',
+    'kpd_recegnn_forward',
 ]
 
 
@@ -344,15 +361,17 @@ def _norm_mode(message_norm):
     return 0, float(message_norm)
 
 
-def sorted_csr(src: torch.Tensor, dst: torch.Tensor, n_dst: int, device):
-    """(src, dst) sorted by (dst, src) as int32 + CSR row pointer over dst."""
+def sorted_csr(src: torch.Tensor, dst: torch.Tensor, n_dst: int, device, return_order: bool = False):
+    """(src, dst) sorted by (dst, src) as int32 + CSR row pointer over dst (+ the permutation for edge data)."""
     src, dst = src.to(device).long(), dst.to(device).long()
+    order = torch.arange(src.numel(), device=device)
     if src.numel():
         order = torch.argsort(dst * (int(src.max()) + 1) + src)
         src, dst = src[order], dst[order]
     deg = torch.bincount(dst, minlength=n_dst) if src.numel() else torch.zeros(n_dst, dtype=torch.long, device=device)
     rowptr = torch.cat([torch.zeros(1, dtype=torch.long, device=device), deg.cumsum(0)])
-    return src.int().contiguous(), dst.int().contiguous(), rowptr.int().contiguous()
+    out = (src.int().contiguous(), dst.int().contiguous(), rowptr.int().contiguous())
+    return out + (order,) if return_order else out
 
 
 class RecEncEngine:
@@ -409,6 +428,72 @@ class RecEncEngine:
         ro = KpdRecOut(_ptr(out['kp_x']), _ptr(out['kp_h']), _ptr(out['kp_v']), _ptr(out['rk_src']), _ptr(out['rk_dst']),
                        cap_kk, _ptr(out['kk_src']), _ptr(out['kk_dst']), _ptr(out['kk_per_graph']), _ptr(out['counts']))
         check(lib().kpd_recenc_forward(self._h, C.byref(bt), C.byref(ro), _stream()))
+        e_kk, e_rk = out['counts'].tolist()            # once per pocket: a host sync here is fine
+        out['kk_src'], out['kk_dst'] = out['kk_src'][:e_kk], out['kk_dst'][:e_kk]
+        out['rk_src'], out['rk_dst'] = out['rk_src'][:e_rk], out['rk_dst'][:e_rk]
+        return out
+
+
+class RecEgnnEngine:
+    """Owns one kpd_recegnn handle: weights + workspace for ReceptorEncoder.forward (models/receptor_encoder.py)."""
+
+    def __init__(self, n_convs, n_keypoints, in_n_node_feat, hidden_n_node_feat, out_n_node_feat, use_sameres_feat, use_tanh,
+                 coords_range, message_norm, k_closest, norm, fix_pos, kk_cutoff):
+        self.cfg = KpdRecegnnConfig(int(n_convs), int(n_keypoints), int(in_n_node_feat), int(hidden_n_node_feat),
+                                    int(out_n_node_feat), int(bool(use_sameres_feat)), int(bool(use_tanh)), int(bool(norm)),
+                                    int(bool(fix_pos)), float(coords_range), float(message_norm), int(k_closest), float(kk_cutoff))
+        self.D, self.K, self.k, self.ef = int(out_n_node_feat), int(n_keypoints), int(k_closest), bool(use_sameres_feat)
+        self._h = C.c_void_p()
+        check(lib().kpd_recegnn_create(C.byref(self.cfg), C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, '_h', None) and _lib is not None:
+            _lib.kpd_recegnn_destroy(self._h)
+            self._h = None
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+        L = lib()
+        st = _stream()
+        keep = []
+        for name, t in sd.items():
+            if t.numel() == 0:
+                continue
+            t = _dev_f32(t.detach(), name)
+            keep.append(t)
+            shape = (C.c_int64 * t.dim())(*t.shape)
+            check(L.kpd_recegnn_load_weight(self._h, name.encode(), t.data_ptr(), shape, t.dim(), st))
+        torch.cuda.current_stream().synchronize()
+        check(L.kpd_recegnn_commit(self._h))
+
+    def forward(self, rec_counts: torch.Tensor, rec_x, rec_h, rr_src, rr_dst, same_res=None):
+        dev = rec_x.device
+        rec_counts = rec_counts.cpu().long()
+        B, n_rec, max_rec = int(rec_counts.numel()), int(rec_counts.sum()), int(rec_counts.max())
+        if int(rec_counts.min()) < self.k:
+            raise KpdError(f'every pocket needs at least k_closest={self.k} receptor atoms (the reference stacks exactly k '
+                           f'neighbour distances per keypoint)')
+        rec_ptr = torch.cat([torch.zeros(1, dtype=torch.long), rec_counts.cumsum(0)]).int().to(dev)
+        rec_x, rec_h = _dev_f32(rec_x, 'rec x_0'), _dev_f32(rec_h, 'rec h_0')
+        s, d, rowptr, order = sorted_csr(rr_src, rr_dst, n_rec, dev, return_order=True)
+        a = None
+        if self.ef:
+            if same_res is None:
+                raise KpdError("use_sameres_feat needs g.edges['rr'].data['same_res']")
+            a = same_res.to(dev).reshape(-1)[order].float().contiguous()
+        torch.cuda.synchronize()
+        check(lib().kpd_recegnn_reserve(self._h, B, n_rec, int(s.numel()), max_rec))
+        n_kp = B * self.K
+        cap_kk = max(n_kp * min(self.K - 1, 100), 1)
+        f32 = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+        i32 = lambda n: torch.zeros(n, device=dev, dtype=torch.int32)
+        out = dict(kp_x=f32(n_kp, 3), kp_h=f32(n_kp, self.D), rk_src=i32(n_kp * self.k), rk_dst=i32(n_kp * self.k),
+                   kk_src=i32(cap_kk), kk_dst=i32(cap_kk), kk_per_graph=i32(B), counts=i32(2), rec_h=f32(n_rec, self.D),
+                   rec_x=f32(n_rec, 3))
+        bt = KpdRecBatch(B, n_rec, max_rec, _ptr(rec_ptr), _ptr(rec_x), _ptr(rec_h), int(s.numel()), _ptr(s), _ptr(d), _ptr(rowptr))
+        ro = KpdRecOut(_ptr(out['kp_x']), _ptr(out['kp_h']), None, _ptr(out['rk_src']), _ptr(out['rk_dst']), cap_kk,
+                       _ptr(out['kk_src']), _ptr(out['kk_dst']), _ptr(out['kk_per_graph']), _ptr(out['counts']))
+        check(lib().kpd_recegnn_forward(self._h, C.byref(bt), _ptr(a) if a is not None else None, C.byref(ro), _ptr(out['rec_h']),
+                                        _ptr(out['rec_x']), _stream()))
         e_kk, e_rk = out['counts'].tolist()            # once per pocket: a host sync here is fine
         out['kk_src'], out['kk_dst'] = out['kk_src'][:e_kk], out['kk_dst'][:e_kk]
         out['rk_src'], out['rk_dst'] = out['rk_src'][:e_rk], out['rk_dst'][:e_rk]

@@ -20,6 +20,7 @@ from . import hip
 from .dynamics import LigRecDynamics
 from .dynamics_gvp import LigRecDynamicsGVP
 from .receptor_encoder_fixed import FixedReceptorEncoder
+from .receptor_encoder import ReceptorEncoder
 from .receptor_encoder_gvp import ReceptorEncoderGVP
 
 
@@ -101,11 +102,8 @@ class KeypointDiffusion(nn.Module):
         self.dynamics = dyn_cls(atom_nf, rec_nf, **graph_config, **dynamics_config)
 
         if rec_encoder_type == 'learned':
-            if architecture == 'egnn':
-                raise NotImplementedError('the EGNN receptor encoder (models/receptor_encoder.py) is outside the '
-                                          'accelerated path (SURVEY.md section 8(f)); use rec_encoder_type="fixed" '
-                                          'or the GVP architecture')
-            self.rec_encoder = ReceptorEncoderGVP(**graph_config, **rec_encoder_config)
+            enc_cls = ReceptorEncoder if architecture == 'egnn' else ReceptorEncoderGVP      # ligand_diffuser.py:62-67
+            self.rec_encoder = enc_cls(**graph_config, **rec_encoder_config)
         else:
             self.rec_encoder = FixedReceptorEncoder(
                 n_vec_feats=rec_encoder_config['vector_size'] if architecture == 'gvp' else None)

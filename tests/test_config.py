@@ -8,6 +8,7 @@ import yaml
 from keypoint_diffusion_amd.dynamics import LigRecDynamics
 from keypoint_diffusion_amd.dynamics_gvp import LigRecDynamicsGVP
 from keypoint_diffusion_amd.model_setup import model_from_config
+from keypoint_diffusion_amd.receptor_encoder import ReceptorEncoder
 from keypoint_diffusion_amd.receptor_encoder_fixed import FixedReceptorEncoder
 from keypoint_diffusion_amd.receptor_encoder_gvp import ReceptorEncoderGVP
 
@@ -40,6 +41,27 @@ def test_gvp_learned_from_config():
     assert 'dynamics.noise_predictor.conv_layers.0.edge_message_fns.kp_kk_kp.2.Wu' in sd
     assert 'dynamics.noise_predictor.conv_layers.0.dropout.vector_dropout.dummy_param' in sd
     assert 'rec_encoder.keypoint_initializer.keypoint_embedding.0.weight' in sd
+
+
+def test_egnn_learned_from_config():
+    """trained_models/egnn_20kp/config.yml: no `architecture` / `rec_encoder_type` keys => egnn + learned EGNN encoder."""
+    cfg = load()
+    cfg['diffusion'].pop('architecture', None)
+    cfg['diffusion'].pop('rec_encoder_type', None)
+    cfg['rec_encoder'] = dict(coords_range=10, fix_pos=False, hidden_n_node_feat=128, in_n_node_feat=10, k_closest=5,
+                              kp_feat_scale=1.0, kp_rad=0.0, message_norm=0.0, n_convs=4, n_kk_convs=0, n_kk_heads=4, no_cg=False,
+                              norm=True, out_n_node_feat=128, use_sameres_feat=True, use_tanh=True)
+    m = model_from_config(cfg, require_dataset_dir=False)
+    assert isinstance(m.dynamics, LigRecDynamics) and isinstance(m.rec_encoder, ReceptorEncoder)
+    assert m.dynamics.rec_nf == 128                                            # keypoint width = encoder out_n_node_feat
+    sd = m.state_dict()
+    assert 'rec_encoder.rec_convs.3.coord_mlp.2.weight' in sd and 'rec_encoder.rec_kp_conv.fc_dst.weight' in sd
+    assert sd['rec_encoder.rec_convs.0.edge_mlp.0.weight'].shape == (128, 22)   # 2 x 10 + radial + same_res
+    assert sd['rec_encoder.keypoint_embedding.0.weight'].shape == (128 * 20, 128)
+    with pytest.raises(ValueError):
+        ReceptorEncoder(kp_rad=0, k_closest=0)
+    with pytest.raises(NotImplementedError):
+        ReceptorEncoder(k_closest=5, n_kk_convs=1)                             # KeyKeyConv.forward raises upstream
 
 
 def test_constructor_errors_match_reference():
