@@ -46,8 +46,13 @@ GVP_DYN = dict(vector_size=16, n_convs=6, n_hidden_scalars=256, message_norm=10.
                n_message_gvps=3, n_update_gvps=2, n_noise_gvps=4, dropout=0.1)
 GVP_ENC = dict(out_scalar_size=128, n_message_gvps=3, n_update_gvps=2, vector_size=16, n_rr_convs=4, n_rk_convs=2,
                message_norm=10.0, k_closest=5, kp_rad=0, dropout=0.1)
+EGNN_ENC = dict(coords_range=10, fix_pos=False, hidden_n_node_feat=128, k_closest=5, kp_feat_scale=1.0, kp_rad=0.0,
+                message_norm=0.0, n_convs=4, n_kk_convs=0, n_kk_heads=4, no_cg=False, norm=True, out_n_node_feat=128,
+                use_sameres_feat=True, use_tanh=True)                      # trained_models/egnn_40kp/config.yml:59-75
 WORKLOADS = {
     'egnn_all_atom': dict(arch='egnn', enc='fixed', dyn=DYNAMICS, n_kp=20, cutoffs=CUTOFFS),
+    'egnn_40kp': dict(arch='egnn', enc='learned', dyn=dict(DYNAMICS, message_norm=0.0), n_kp=40,
+                      cutoffs=dict(CUTOFFS, kl=8, ll=5)),
     'gvp_40kp': dict(arch='gvp', enc='learned', dyn=GVP_DYN, n_kp=40, cutoffs=dict(CUTOFFS, kl=8, ll=6.0)),
     'gvp_all_atom': dict(arch='gvp', enc='fixed', dyn=dict(GVP_DYN, message_norm='mean'), n_kp=20, cutoffs=CUTOFFS),
 }
@@ -55,9 +60,9 @@ WORKLOADS = {
 
 def build_model(device, workload='egnn_all_atom'):
     w = WORKLOADS[workload]
-    rec_cfg = dict(GVP_ENC) if w['arch'] == 'gvp' else {}
+    rec_cfg = dict(GVP_ENC) if w['arch'] == 'gvp' else (dict(EGNN_ENC) if w['enc'] == 'learned' else {})
     if w['enc'] == 'learned':
-        rec_cfg['in_scalar_size'] = 10
+        rec_cfg['in_scalar_size' if w['arch'] == 'gvp' else 'in_n_node_feat'] = 10
     model = KeypointDiffusion(10, 128 if w['enc'] == 'learned' else 10, None, n_timesteps=N_TIMESTEPS,
                               architecture=w['arch'], rec_encoder_type=w['enc'],
                               graph_config=dict(n_keypoints=w['n_kp'], graph_cutoffs=w['cutoffs']),
@@ -73,7 +78,10 @@ def build_batch(model, B, n_rec, n_lig, seed, device, workload='egnn_all_atom'):
     gs = synth.synth_complexes(n_rec, n_lig, w['n_kp'], w['cutoffs'], seed=seed)
     g = G.batch(gs)
     if w['enc'] == 'learned':
-        g = g.to(device)                             # the GVP encoder runs on the GPU (once per pocket)
+        if w['arch'] == 'egnn':                      # synthetic rr `same_res` column (the dataset's bool edge feature)
+            s_, d_ = g.edges(etype='rr')
+            g.edges['rr'].data['same_res'] = ((s_ // 8) == (d_ // 8)).view(-1, 1)
+        g = g.to(device)                             # the learned encoders run on the GPU (once per pocket)
     with torch.no_grad():
         g = model.encode_receptors(g)                # fixed encoder: kp := rec, kk := rr
     return g.to(device)
