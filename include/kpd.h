@@ -78,8 +78,12 @@ typedef struct kpd_lig_graph {
     int32_t *counts;           /* [dev] [2]: {E_ll, E_kl}                                 */
 } kpd_lig_graph;
 
-kpd_status kpd_build_lig_graph(const kpd_batch *batch, float ll_cutoff, int32_t kl_k,
-                               const kpd_lig_graph *out, void *stream);
+/* ll: radius graph of radius ll_cutoff (ll_k == 0, at most 200 neighbours) or kNN graph (ll_k in 1..16);
+ * kl / lk: for every keypoint its kl_k nearest ligand atoms (kl_k in 1..16) or all ligand atoms within kl_cutoff
+ * (kl_k == 0, at most 100).  Capacities: cap_ll >= n_lig * min(max_lig - 1, ll_k or 200),
+ * cap_kl >= n_kp * (kl_k or min(max_lig, 100)). */
+kpd_status kpd_build_lig_graph(const kpd_batch *batch, float ll_cutoff, int32_t ll_k, float kl_cutoff,
+                               int32_t kl_k, const kpd_lig_graph *out, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * EGNN denoiser.  Replaces LigRecDynamics.forward (models/dynamics.py:342-385) including
@@ -91,7 +95,7 @@ typedef struct kpd_egnn_config {
     int32_t n_layers, hidden_nf;       /* hidden_nf must be 256 (every shipped config)   */
     int32_t use_tanh, norm, update_kp_feat;
     float message_norm;                /* 0 => per-graph average in-degree + 1           */
-    int32_t ll_k, kl_k;                /* ll_k must be 0 (radius graph); kl_k in 1..16   */
+    int32_t ll_k, kl_k;                /* 0 = radius graph (the cutoffs below), else kNN, <= 16 */
     float ll_cutoff, kl_cutoff;
     float coords_range;                /* 10 in the reference (dynamics.py:15)           */
 } kpd_egnn_config;

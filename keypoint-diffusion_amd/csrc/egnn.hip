@@ -87,7 +87,7 @@ struct kpd_egnn {
     float *hn_main[4], *hn_cont[4], *xn_main[4], *xn_cont[4];
     int *bidx[2];
     float *z[2];
-    int *meta, *ll_deg, *ll_off, *kl_off;
+    int *meta, *ll_deg, *ll_off, *kl_off, *kl_pg;
     kpd_lig_graph lg;
 };
 
@@ -163,9 +163,10 @@ static kpd_status build_weight_arena(kpd_egnn *m) {
 extern "C" kpd_status kpd_egnn_create(const kpd_egnn_config *cfg, kpd_egnn **out) {
     KPD_REQUIRE(cfg && out, KPD_ERR_INVALID, "null argument");
     KPD_REQUIRE(cfg->hidden_nf == HID, KPD_ERR_INVALID, "hidden_nf=%d: the HIP path is built for hidden_nf=256", cfg->hidden_nf);
-    KPD_REQUIRE(cfg->ll_k == 0, KPD_ERR_INVALID, "ll_k=%d: only the radius lig-lig graph (ll_k=0) is implemented", cfg->ll_k);
-    KPD_REQUIRE(cfg->kl_k >= 1 && cfg->kl_k <= KL_KMAX, KPD_ERR_INVALID,
-                "kl_k=%d: only the kNN keypoint->ligand graph with 1 <= k <= %d is implemented", cfg->kl_k, KL_KMAX);
+    KPD_REQUIRE(cfg->ll_k >= 0 && cfg->ll_k <= KL_KMAX, KPD_ERR_INVALID, "ll_k=%d outside 0..%d (0 = radius graph)", cfg->ll_k, KL_KMAX);
+    KPD_REQUIRE(cfg->kl_k >= 0 && cfg->kl_k <= KL_KMAX, KPD_ERR_INVALID, "kl_k=%d outside 0..%d (0 = radius graph)", cfg->kl_k, KL_KMAX);
+    KPD_REQUIRE(cfg->kl_k > 0 || cfg->kl_cutoff > 0.0f, KPD_ERR_INVALID, "kl_k = 0 needs graph_cutoffs['kl'] > 0");
+    KPD_REQUIRE(cfg->ll_k > 0 || cfg->ll_cutoff > 0.0f, KPD_ERR_INVALID, "ll_k = 0 needs graph_cutoffs['ll'] > 0");
     KPD_REQUIRE(cfg->n_layers >= 1 && cfg->n_layers <= 64, KPD_ERR_INVALID, "n_layers=%d", cfg->n_layers);
     KPD_REQUIRE(cfg->atom_nf >= 1 && cfg->atom_nf <= 32, KPD_ERR_INVALID, "atom_nf=%d outside 1..32", cfg->atom_nf);
     KPD_REQUIRE(cfg->rec_nf >= 1 && (cfg->rec_nf <= 128 || cfg->rec_nf == 256), KPD_ERR_INVALID, "rec_nf=%d", cfg->rec_nf);
@@ -371,8 +372,8 @@ extern "C" kpd_status kpd_egnn_reserve(kpd_egnn *m, int32_t max_B, int32_t max_n
         return KPD_OK;
     max_B = std::max(max_B, m->cap_B); max_n_lig = std::max(max_n_lig, m->cap_lig); max_n_kp = std::max(max_n_kp, m->cap_kp);
     max_n_kk = std::max(max_n_kk, m->cap_kk); max_lig_pg = std::max(max_lig_pg, m->cap_maxlig); max_kp_pg = std::max(max_kp_pg, m->cap_maxkp);
-    const long cap_ll_l = (long)max_n_lig * std::min(max_lig_pg - 1, 200);
-    const long cap_kl_l = (long)max_n_kp * m->cfg.kl_k;
+    const long cap_ll_l = (long)max_n_lig * std::min(max_lig_pg - 1, m->cfg.ll_k > 0 ? m->cfg.ll_k : 200);
+    const long cap_kl_l = (long)max_n_kp * (m->cfg.kl_k > 0 ? m->cfg.kl_k : std::min(max_lig_pg, 100));
     KPD_REQUIRE(cap_ll_l < (1l << 30) && cap_kl_l < (1l << 30), KPD_ERR_CAPACITY, "edge capacity overflows int32");
     const int cap_ll = std::max<long>(cap_ll_l, 1), cap_kl = std::max<long>(cap_kl_l, 1);
     const int E_cap[4] = {cap_ll, cap_kl, cap_kl, std::max(max_n_kk, 1)};
@@ -392,7 +393,7 @@ extern "C" kpd_status kpd_egnn_reserve(kpd_egnn *m, int32_t max_B, int32_t max_n
         add((size_t)n[kDstNt[et]] * HS, 4); add((size_t)tiles[et] * HS, 4);
         add((size_t)n[kDstNt[et]] * 4, 4); add((size_t)tiles[et] * 4, 4);
     }
-    add(16, 4); add(max_n_lig, 4); add(max_B + 1, 4); add(max_B + 1, 4);
+    add(16, 4); add(max_n_lig, 4); add(max_B + 1, 4); add(max_B + 1, 4); add(max_B + 2, 4);
     add(cap_ll, 4); add(cap_ll, 4); add(max_n_lig + 1, 4);
     for (int i = 0; i < 4; ++i) add(cap_kl, 4);
     add(max_n_lig + 1, 4); add(max_n_kp + 1, 4); add(max_B, 4); add(8, 4);
@@ -416,6 +417,7 @@ extern "C" kpd_status kpd_egnn_reserve(kpd_egnn *m, int32_t max_B, int32_t max_n
     m->ll_deg = W.take<int>(max_n_lig);
     m->ll_off = W.take<int>(max_B + 1);
     m->kl_off = W.take<int>(max_B + 1);
+    m->kl_pg = W.take<int>(max_B + 2);
     kpd_lig_graph &g = m->lg;
     g.cap_ll = cap_ll; g.cap_kl = cap_kl;
     g.ll_src = W.take<int>(cap_ll); g.ll_dst = W.take<int>(cap_ll); g.ll_rowptr = W.take<int>(max_n_lig + 1);
@@ -449,18 +451,19 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
     KPD_HIP(hipMemcpyAsync(m->x[NT_KP], bt->kp_x, (size_t)bt->n_kp * 12, hipMemcpyDeviceToDevice, st));
     KPD_TRY(launch_node_graph_index(bt->lig_ptr, bt->B, bt->n_lig, m->bidx[NT_LIG], st));
     KPD_TRY(launch_node_graph_index(bt->kp_ptr, bt->B, bt->n_kp, m->bidx[NT_KP], st));
-    KPD_TRY(launch_lig_graph(bt, c.ll_cutoff, c.kl_k, &m->lg, m->ll_deg, m->ll_off, m->kl_off, st));
+    KPD_TRY(launch_lig_graph(bt, c.ll_cutoff, c.ll_k, c.kl_cutoff, c.kl_k, &m->lg, m->ll_deg, m->ll_off, m->kl_off, m->kl_pg, st));
     const int active = c.update_kp_feat ? 0xF : 0x3;
     KPD_TRY(launch_egnn_meta(m->lg.counts, bt->n_kk, active, bt->lig_ptr, bt->kp_ptr, m->lg.ll_per_graph, bt->kk_rowptr,
-                             bt->B, c.kl_k, c.message_norm, c.update_kp_feat, m->meta, m->z[NT_LIG], m->z[NT_KP], st));
+                             bt->B, m->kl_off, c.message_norm, c.update_kp_feat, m->meta, m->z[NT_LIG], m->z[NT_KP], st));
     KPD_TRY(launch_embed(bt->lig_h, bt->n_lig, c.atom_nf, m->le_W0, m->le_b0, 64, m->le_W1t, m->le_b1, t_dev,
                          m->bidx[NT_LIG], m->h[NT_LIG], 0, st));
     KPD_TRY(launch_embed(bt->kp_h, bt->n_kp, c.rec_nf, m->re_W0, m->re_b0, 2 * c.rec_nf, m->re_W1t, m->re_b1, t_dev,
                          m->bidx[NT_KP], m->h[NT_KP], m->rec_identity ? 1 : 0, st));
 
     // tile capacity for this batch (host-known upper bound; the kernel exits early past the device-side total)
-    const int E_cap[4] = {std::max<int>((long)bt->n_lig * std::min(bt->max_lig - 1, 200), 1), bt->n_kp * c.kl_k,
-                          bt->n_kp * c.kl_k, bt->n_kk};
+    const int e_kl_cap = bt->n_kp * (c.kl_k > 0 ? c.kl_k : std::min(bt->max_lig, 100));
+    const int E_cap[4] = {std::max<int>((long)bt->n_lig * std::min(bt->max_lig - 1, c.ll_k > 0 ? c.ll_k : 200), 1), e_kl_cap, e_kl_cap,
+                          bt->n_kk};
     int tile_cap = 0;
     for (int et = 0; et < m->n_et; ++et) tile_cap += cdiv(E_cap[et], TM);
 
@@ -664,16 +667,17 @@ extern "C" kpd_status kpd_egnn_last_counts(kpd_egnn *m, int32_t out[8], void *st
     return KPD_OK;
 }
 
-extern "C" kpd_status kpd_build_lig_graph(const kpd_batch *bt, float ll_cutoff, int32_t kl_k, const kpd_lig_graph *out,
-                                          void *stream) {
+extern "C" kpd_status kpd_build_lig_graph(const kpd_batch *bt, float ll_cutoff, int32_t ll_k, float kl_cutoff, int32_t kl_k,
+                                          const kpd_lig_graph *out, void *stream) {
     KPD_REQUIRE(bt && out, KPD_ERR_INVALID, "null argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
     // scratch: carve from a small per-call allocation (this entry point is for tests and
     // standalone use; the engines use their own workspace and never allocate per call)
     int *tmp = nullptr;
-    const size_t cnt = (size_t)bt->n_lig + 2 * ((size_t)bt->B + 1);
+    const size_t cnt = (size_t)bt->n_lig + 3 * ((size_t)bt->B + 2);
     KPD_HIP(hipMalloc(reinterpret_cast<void **>(&tmp), cnt * sizeof(int)));
-    kpd_status s = launch_lig_graph(bt, ll_cutoff, kl_k, out, tmp, tmp + bt->n_lig, tmp + bt->n_lig + bt->B + 1, st);
+    kpd_status s = launch_lig_graph(bt, ll_cutoff, ll_k, kl_cutoff, kl_k, out, tmp, tmp + bt->n_lig, tmp + bt->n_lig + bt->B + 2,
+                                    tmp + bt->n_lig + 2 * (bt->B + 2), st);
     hipError_t e = hipStreamSynchronize(st);
     (void)hipFree(tmp);
     if (s != KPD_OK) return s;

@@ -38,8 +38,8 @@ __global__ void k_node_graph_index(const int *__restrict__ ptr, int B, int n, in
 // z: per-graph message normaliser (dynamics.py:277-285).
 __global__ void k_egnn_meta(const int *__restrict__ counts, int e_kk, int active_mask, const int *__restrict__ lig_ptr,
                             const int *__restrict__ kp_ptr, const int *__restrict__ ll_per_graph,
-                            const int *__restrict__ kk_rowptr, int B, int kl_k, float message_norm, int update_kp,
-                            int *__restrict__ meta, float *__restrict__ z_lig, float *__restrict__ z_kp) {
+                            const int *__restrict__ kk_rowptr, int B, const int *__restrict__ kl_off, float message_norm,
+                            int update_kp, int *__restrict__ meta, float *__restrict__ z_lig, float *__restrict__ z_kp) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         int E[4] = {counts[0], counts[1], counts[1], e_kk};
         int run = 0;
@@ -54,7 +54,7 @@ __global__ void k_egnn_meta(const int *__restrict__ counts, int e_kk, int active
     for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
         const int nl = lig_ptr[b + 1] - lig_ptr[b], nk = kp_ptr[b + 1] - kp_ptr[b];
         if (message_norm == 0.0f) {
-            const int e_kl = nk * min(kl_k, nl);
+            const int e_kl = kl_off[b + 1] - kl_off[b];          // per-complex kl edges (kNN: nk min(k, nl); radius: counted)
             const int e_kk_b = kk_rowptr[kp_ptr[b + 1]] - kk_rowptr[kp_ptr[b]];
             z_lig[b] = (float)(ll_per_graph[b] + e_kl) / (float)nl + 1.0f;
             z_kp[b] = update_kp ? (float)(e_kl + e_kk_b) / (float)nk + 1.0f : 1.0f;
@@ -924,10 +924,10 @@ kpd_status launch_node_graph_index(const int *ptr, int B, int n, int *bidx, hipS
 }
 
 kpd_status launch_egnn_meta(const int *counts, int e_kk, int active_mask, const int *lig_ptr, const int *kp_ptr,
-                            const int *ll_per_graph, const int *kk_rowptr, int B, int kl_k, float message_norm,
+                            const int *ll_per_graph, const int *kk_rowptr, int B, const int *kl_off, float message_norm,
                             int update_kp, int *meta, float *z_lig, float *z_kp, hipStream_t st) {
     hipLaunchKernelGGL(k_egnn_meta, dim3(cdiv(B, 256)), dim3(256), 0, st, counts, e_kk, active_mask, lig_ptr, kp_ptr,
-                       ll_per_graph, kk_rowptr, B, kl_k, message_norm, update_kp, meta, z_lig, z_kp);
+                       ll_per_graph, kk_rowptr, B, kl_off, message_norm, update_kp, meta, z_lig, z_kp);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
 }

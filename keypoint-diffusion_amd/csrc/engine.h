@@ -4,8 +4,9 @@
 
 namespace kpd {
 
-kpd_status launch_lig_graph(const kpd_batch *bt, float ll_cutoff, int kl_k, const kpd_lig_graph *g,
-                            int *ll_deg_tmp, int *ll_off_tmp, int *kl_off_tmp, hipStream_t st);
+// kl_pg_tmp: [B + 2] scratch (per-complex kl counts of the radius variant)
+kpd_status launch_lig_graph(const kpd_batch *bt, float ll_cutoff, int ll_k, float kl_cutoff, int kl_k, const kpd_lig_graph *g,
+                            int *ll_deg_tmp, int *ll_off_tmp, int *kl_off_tmp, int *kl_pg_tmp, hipStream_t st);
 
 kpd_status launch_radius_graph(const float *x, const int *ptr, int B, int n_total, int max_per_graph, float r, int max_nn,
                                int cap, int *src, int *dst, int *rowptr, int *per_graph, int *deg_tmp, int *off_tmp,

@@ -44,7 +44,7 @@ struct kpd_gvp {
     float *ms_main[4], *ms_cont[4], *mv_main[4], *mv_cont[4];
     int *bidx[2];
     float *z[2];
-    int *meta4, *meta2, *ll_deg, *ll_off, *kl_off;
+    int *meta4, *meta2, *ll_deg, *ll_off, *kl_off, *kl_pg;
     kpd_lig_graph lg;
 
     int n_et(int conv) const { return (cfg.update_kp && conv != cfg.n_convs - 1) ? 4 : 2; }
@@ -55,8 +55,10 @@ extern "C" kpd_status kpd_gvp_create(const kpd_gvp_config *cfg, kpd_gvp **out) {
     KPD_REQUIRE(cfg->vector_size == GV, KPD_ERR_INVALID, "vector_size=%d: the HIP path is built for 16", cfg->vector_size);
     KPD_REQUIRE(cfg->n_hidden_scalars == 256 || cfg->n_hidden_scalars == 128, KPD_ERR_INVALID,
                 "n_hidden_scalars=%d: supported widths are 128 and 256", cfg->n_hidden_scalars);
-    KPD_REQUIRE(cfg->ll_k == 0, KPD_ERR_INVALID, "ll_k=%d: only the radius lig-lig graph is implemented", cfg->ll_k);
-    KPD_REQUIRE(cfg->kl_k >= 1 && cfg->kl_k <= KL_KMAX, KPD_ERR_INVALID, "kl_k=%d outside 1..%d", cfg->kl_k, KL_KMAX);
+    KPD_REQUIRE(cfg->ll_k >= 0 && cfg->ll_k <= KL_KMAX, KPD_ERR_INVALID, "ll_k=%d outside 0..%d (0 = radius graph)", cfg->ll_k, KL_KMAX);
+    KPD_REQUIRE(cfg->kl_k >= 0 && cfg->kl_k <= KL_KMAX, KPD_ERR_INVALID, "kl_k=%d outside 0..%d (0 = radius graph)", cfg->kl_k, KL_KMAX);
+    KPD_REQUIRE(cfg->kl_k > 0 || cfg->kl_cutoff > 0.0f, KPD_ERR_INVALID, "kl_k = 0 needs graph_cutoffs['kl'] > 0");
+    KPD_REQUIRE(cfg->ll_k > 0 || cfg->ll_cutoff > 0.0f, KPD_ERR_INVALID, "ll_k = 0 needs graph_cutoffs['ll'] > 0");
     KPD_REQUIRE(cfg->n_convs >= 1 && cfg->n_convs <= 32, KPD_ERR_INVALID, "n_convs=%d", cfg->n_convs);
     KPD_REQUIRE(cfg->update_kp || cfg->n_convs == 1, KPD_ERR_INVALID,
                 "update_kp=0 with more than one convolution cannot run in the reference (gvp.py:501, 536)");
@@ -232,7 +234,8 @@ extern "C" kpd_status kpd_gvp_reserve(kpd_gvp *m, int32_t max_B, int32_t max_n_l
         return KPD_OK;
     max_B = std::max(max_B, m->cap_B); max_n_lig = std::max(max_n_lig, m->cap_lig); max_n_kp = std::max(max_n_kp, m->cap_kp);
     max_n_kk = std::max(max_n_kk, m->cap_kk); max_lig_pg = std::max(max_lig_pg, m->cap_maxlig); max_kp_pg = std::max(max_kp_pg, m->cap_maxkp);
-    const long cap_ll_l = (long)max_n_lig * std::min(max_lig_pg - 1, 200), cap_kl_l = (long)max_n_kp * m->cfg.kl_k;
+    const long cap_ll_l = (long)max_n_lig * std::min(max_lig_pg - 1, m->cfg.ll_k > 0 ? m->cfg.ll_k : 200);
+    const long cap_kl_l = (long)max_n_kp * (m->cfg.kl_k > 0 ? m->cfg.kl_k : std::min(max_lig_pg, 100));
     KPD_REQUIRE(cap_ll_l < (1l << 30) && cap_kl_l < (1l << 30), KPD_ERR_CAPACITY, "edge capacity overflows int32");
     const int cap_ll = std::max<long>(cap_ll_l, 1), cap_kl = std::max<long>(cap_kl_l, 1);
     const int E_cap[4] = {cap_ll, cap_kl, cap_kl, std::max(max_n_kk, 1)};
@@ -246,7 +249,7 @@ extern "C" kpd_status kpd_gvp_reserve(kpd_gvp *m, int32_t max_B, int32_t max_n_l
         add((size_t)n[kSrcNtG[et]] * S);
         add((size_t)n[kDstNtG[et]] * S); add((size_t)tiles[et] * S); add((size_t)n[kDstNtG[et]] * 48); add((size_t)tiles[et] * 48);
     }
-    add(16); add(16); add(max_n_lig); add(max_B + 1); add(max_B + 1);
+    add(16); add(16); add(max_n_lig); add(max_B + 1); add(max_B + 1); add(max_B + 2);
     add(cap_ll); add(cap_ll); add(max_n_lig + 1);
     for (int i = 0; i < 4; ++i) add(cap_kl);
     add(max_n_lig + 1); add(max_n_kp + 1); add(max_B); add(8);
@@ -264,6 +267,7 @@ extern "C" kpd_status kpd_gvp_reserve(kpd_gvp *m, int32_t max_B, int32_t max_n_l
     }
     m->meta4 = W.take<int>(16); m->meta2 = W.take<int>(16);
     m->ll_deg = W.take<int>(max_n_lig); m->ll_off = W.take<int>(max_B + 1); m->kl_off = W.take<int>(max_B + 1);
+    m->kl_pg = W.take<int>(max_B + 2);
     kpd_lig_graph &g = m->lg;
     g.cap_ll = cap_ll; g.cap_kl = cap_kl;
     g.ll_src = W.take<int>(cap_ll); g.ll_dst = W.take<int>(cap_ll); g.ll_rowptr = W.take<int>(max_n_lig + 1);
@@ -294,13 +298,13 @@ extern "C" kpd_status kpd_gvp_forward(kpd_gvp *m, const kpd_batch *bt, const flo
 
     KPD_TRY(launch_node_graph_index(bt->lig_ptr, bt->B, bt->n_lig, m->bidx[0], st));
     KPD_TRY(launch_node_graph_index(bt->kp_ptr, bt->B, bt->n_kp, m->bidx[1], st));
-    KPD_TRY(launch_lig_graph(bt, c.ll_cutoff, c.kl_k, &m->lg, m->ll_deg, m->ll_off, m->kl_off, st));
+    KPD_TRY(launch_lig_graph(bt, c.ll_cutoff, c.ll_k, c.kl_cutoff, c.kl_k, &m->lg, m->ll_deg, m->ll_off, m->kl_off, m->kl_pg, st));
     // tile tables for convs over all four edge types and over ll + kl only; z for message_norm == 0
     const float mn = c.message_norm_mode == 2 ? 0.0f : 1.0f;
     KPD_TRY(launch_egnn_meta(m->lg.counts, bt->n_kk, 0xF, bt->lig_ptr, bt->kp_ptr, m->lg.ll_per_graph, bt->kk_rowptr, bt->B,
-                             c.kl_k, mn, 1, m->meta4, m->z[0], m->z[1], st));
+                             m->kl_off, mn, 1, m->meta4, m->z[0], m->z[1], st));
     KPD_TRY(launch_egnn_meta(m->lg.counts, bt->n_kk, 0x3, bt->lig_ptr, bt->kp_ptr, m->lg.ll_per_graph, bt->kk_rowptr, bt->B,
-                             c.kl_k, mn, 1, m->meta2, m->z[0], m->z[1], st));
+                             m->kl_off, mn, 1, m->meta2, m->z[0], m->z[1], st));
     KPD_TRY(launch_gvp_embed(bt->lig_h, bt->n_lig, c.n_lig_scalars, m->enc_W[0], m->enc_b[0], m->enc_lw[0], m->enc_lb[0],
                              t_dev, m->bidx[0], S, m->s[0], st));
     KPD_TRY(launch_gvp_embed(bt->kp_h, bt->n_kp, c.n_kp_scalars, m->enc_W[1], m->enc_b[1], m->enc_lw[1], m->enc_lb[1],
@@ -308,8 +312,9 @@ extern "C" kpd_status kpd_gvp_forward(kpd_gvp *m, const kpd_batch *bt, const flo
     KPD_HIP(hipMemsetAsync(m->v[0], 0, (size_t)bt->n_lig * 48 * 4, st));                      // dynamics_gvp.py:179-184
     KPD_HIP(hipMemcpyAsync(m->v[1], bt->kp_v, (size_t)bt->n_kp * 48 * 4, hipMemcpyDeviceToDevice, st));
 
-    const int E_cap[4] = {std::max<int>((long)bt->n_lig * std::min(bt->max_lig - 1, 200), 1), bt->n_kp * c.kl_k,
-                          bt->n_kp * c.kl_k, bt->n_kk};
+    const int e_kl_cap = bt->n_kp * (c.kl_k > 0 ? c.kl_k : std::min(bt->max_lig, 100));
+    const int E_cap[4] = {std::max<int>((long)bt->n_lig * std::min(bt->max_lig - 1, c.ll_k > 0 ? c.ll_k : 200), 1), e_kl_cap, e_kl_cap,
+                          bt->n_kk};
     const int *esrc[4] = {m->lg.ll_src, m->lg.kl_src, m->lg.lk_src, bt->kk_src};
     const int *edst[4] = {m->lg.ll_dst, m->lg.kl_dst, m->lg.lk_dst, bt->kk_dst};
     const int *rowptr[4] = {m->lg.ll_rowptr, m->lg.kl_rowptr, m->lg.lk_rowptr, bt->kk_rowptr};

@@ -93,15 +93,11 @@ class LigRecDynamics(nn.Module):
         """(Re)build the device engine when weights were replaced or modified in place."""
         key = self._weights_key()
         if self._engine is None or key != self._engine_key:
-            if self.ll_k != 0:
-                raise NotImplementedError('ll_k > 0 (kNN lig-lig graph) is not implemented in the HIP path')
-            if self.kl_k <= 0:
-                raise NotImplementedError('kl_k = 0 (radius keypoint->ligand graph) is not implemented in the HIP path')
             if isinstance(self.message_norm, (dict, str)):
                 raise ValueError(f'message_norm must be a number for the EGNN denoiser, got {self.message_norm!r}')
             eng = hip.EgnnEngine(self.atom_nf, self.rec_nf, self.n_layers, self.hidden_nf, self.use_tanh, self.norm,
                                  self.update_kp_feat, self.message_norm, self.ll_k, self.kl_k,
-                                 self.graph_cutoffs['ll'], self.graph_cutoffs.get('kl', 0.0))
+                                 self.graph_cutoffs.get('ll', 0.0), self.graph_cutoffs.get('kl', 0.0))
             eng.load_state_dict(self.state_dict())
             self._engine, self._engine_key = eng, key
         return self._engine

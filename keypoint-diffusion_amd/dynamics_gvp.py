@@ -84,13 +84,9 @@ class LigRecDynamicsGVP(nn.Module):
         """(Re)build the device engine when weights were replaced or modified in place."""
         key = self._weights_key()
         if self._engine is None or key != self._engine_key:
-            if self.ll_k != 0:
-                raise NotImplementedError('ll_k > 0 (kNN lig-lig graph) is not implemented in the HIP path')
-            if self.kl_k <= 0:
-                raise NotImplementedError('kl_k = 0 (radius keypoint->ligand graph) is not implemented in the HIP path')
             eng = hip.GvpEngine(self.n_lig_scalars, self.n_kp_scalars, self.vector_size, self.n_convs,
                                 self.n_hidden_scalars, self.update_kp, self.message_norm, self.ll_k, self.kl_k,
-                                self.graph_cutoffs['ll'], self.graph_cutoffs.get('kl', 0.0), self.n_message_gvps,
+                                self.graph_cutoffs.get('ll', 0.0), self.graph_cutoffs.get('kl', 0.0), self.n_message_gvps,
                                 self.n_update_gvps, self.n_noise_gvps)
             eng.load_state_dict(self.state_dict())
             self._engine, self._engine_key = eng, key

@@ -126,7 +126,8 @@ def lib():
     L.kpd_recegnn_reserve.argtypes = [C.c_void_p] + [C.c_int32] * 4
     L.kpd_recegnn_forward.argtypes = [C.c_void_p, C.POINTER(KpdRecBatch), C.c_void_p, C.POINTER(KpdRecOut), C.c_void_p, C.c_void_p,
                                       C.c_void_p]
-    L.kpd_build_lig_graph.argtypes = [C.POINTER(KpdBatch), C.c_float, C.c_int32, C.POINTER(KpdLigGraph), C.c_void_p]
+    L.kpd_build_lig_graph.argtypes = [C.POINTER(KpdBatch), C.c_float, C.c_int32, C.c_float, C.c_int32, C.POINTER(KpdLigGraph),
+                                      C.c_void_p]
     L.kpd_sample_update.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 8 + [C.c_int32, C.c_void_p]
     L.kpd_step_coefficients.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     _lib = L
@@ -201,12 +202,14 @@ class PreparedBatch:
                         _ptr(self.kk_dst), _ptr(self.kk_rowptr))
 
 
-def build_lig_graph(pb: PreparedBatch, lig_x: torch.Tensor, kp_x: torch.Tensor, ll_cutoff: float, kl_k: int):
-    """Standalone graph build (kpd_build_lig_graph); returns a dict of int32 device tensors."""
+def build_lig_graph(pb: PreparedBatch, lig_x: torch.Tensor, kp_x: torch.Tensor, ll_cutoff: float, kl_k: int, ll_k: int = 0,
+                    kl_cutoff: float = 0.0):
+    """Standalone graph build (kpd_build_lig_graph); returns a dict of int32 device tensors.  ll_k > 0: kNN lig-lig graph
+    instead of the radius graph; kl_k == 0: radius keypoint->ligand graph of radius kl_cutoff instead of kNN."""
     dev = lig_x.device
     lig_x, kp_x = _dev_f32(lig_x, 'lig_x'), _dev_f32(kp_x, 'kp_x')
-    cap_ll = max(pb.n_lig * min(pb.max_lig - 1, 200), 1)
-    cap_kl = max(pb.n_kp * kl_k, 1)
+    cap_ll = max(pb.n_lig * min(pb.max_lig - 1, ll_k if ll_k > 0 else 200), 1)
+    cap_kl = max(pb.n_kp * (kl_k if kl_k > 0 else min(pb.max_lig, 100)), 1)
     i32 = lambda n: torch.zeros(n, dtype=torch.int32, device=dev)
     out = dict(ll_src=i32(cap_ll), ll_dst=i32(cap_ll), ll_rowptr=i32(pb.n_lig + 1),
                kl_src=i32(cap_kl), kl_dst=i32(cap_kl), kl_rowptr=i32(pb.n_lig + 1),
@@ -216,7 +219,7 @@ def build_lig_graph(pb: PreparedBatch, lig_x: torch.Tensor, kp_x: torch.Tensor, 
                                       ('ll_src', 'll_dst', 'll_rowptr', 'kl_src', 'kl_dst', 'kl_rowptr',
                                        'lk_src', 'lk_dst', 'lk_rowptr', 'll_per_graph', 'counts')])
     bt = pb.struct(lig_x, None, kp_x, None)
-    check(lib().kpd_build_lig_graph(C.byref(bt), float(ll_cutoff), int(kl_k), C.byref(lg), _stream()))
+    check(lib().kpd_build_lig_graph(C.byref(bt), float(ll_cutoff), int(ll_k), float(kl_cutoff), int(kl_k), C.byref(lg), _stream()))
     return out
 
 

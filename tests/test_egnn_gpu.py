@@ -51,6 +51,32 @@ def test_lig_graph_build(cuda, n_rec, n_lig):
     assert torch.equal(out['kl_rowptr'].long().cpu()[1:] - out['kl_rowptr'].long().cpu()[:-1], deg)
 
 
+@pytest.mark.parametrize('ll_k,kl_k', [(3, 5), (0, 0), (4, 0), (30, 2)])
+@pytest.mark.parametrize('n_rec,n_lig', [([60], [20]), ([300, 150, 420], [25, 4, 37]), ([35, 600], [60, 3])])
+def test_lig_graph_variants(cuda, n_rec, n_lig, ll_k, kl_k):
+    """ll_k > 0 (kNN lig-lig graph) and kl_k = 0 (radius keypoint->ligand graph), dynamics.py:392-411."""
+    ll_k = min(ll_k, 16)
+    g = util.fixed_encode(util.make_batch(n_rec, n_lig)).to(cuda)
+    pb = g.prepared()
+    lx, kx = g.nodes['lig'].data['x_0'], g.nodes['kp'].data['x_0']
+    out = hip.build_lig_graph(pb, lx, kx, 6.0, kl_k, ll_k=ll_k, kl_cutoff=7.0)
+    torch.cuda.synchronize()
+    e = _edges_from_hip(out, pb)
+    ob = util.to_obatch(g)
+    ref = oegnn.lig_edges(ob, dict(graph_cutoffs={'ll': 6.0, 'kl': 7.0}, kl_k=kl_k, ll_k=ll_k))
+    assert torch.equal(e['ll'][0], ref['ll'][0]) and torch.equal(e['ll'][1], ref['ll'][1])          # same edges, same order
+    deg = torch.bincount(e['ll'][1], minlength=pb.n_lig)
+    assert torch.equal(out['ll_rowptr'].long().cpu()[1:] - out['ll_rowptr'].long().cpu()[:-1], deg)
+    assert torch.equal(out['ll_per_graph'].long().cpu(), og.edges_per_graph(ref['ll'][1], ob.n['lig']))
+    assert torch.equal(e['lk'][0], ref['lk'][0]) and torch.equal(e['lk'][1], ref['lk'][1])          # kp-major, oracle order
+    assert _edge_set(*e['kl']) == _edge_set(*ref['kl']) and e['kl'][0].numel() == ref['kl'][0].numel()
+    assert bool((e['kl'][1][1:] >= e['kl'][1][:-1]).all())                                          # dst-sorted
+    deg = torch.bincount(e['kl'][1], minlength=pb.n_lig)
+    assert torch.equal(out['kl_rowptr'].long().cpu()[1:] - out['kl_rowptr'].long().cpu()[:-1], deg)
+    deg = torch.bincount(e['lk'][1], minlength=pb.n_kp)
+    assert torch.equal(out['lk_rowptr'].long().cpu()[1:] - out['lk_rowptr'].long().cpu()[:-1], deg)
+
+
 def _run_pair(cuda, cfg, n_rec, n_lig, seed=3, rec_nf=10, layers=None, edge_chain=None):
     g = util.fixed_encode(util.make_batch(n_rec, n_lig, n_rec_feat=rec_nf))
     model = LigRecDynamics(10, rec_nf, graph_cutoffs=util.CUTOFFS_ALL_ATOM, **cfg)
@@ -79,6 +105,16 @@ def _run_pair(cuda, cfg, n_rec, n_lig, seed=3, rec_nf=10, layers=None, edge_chai
 def test_egnn_chained_edge_kernel(cuda):
     """The opt-in register-chained edge kernel (egnn_chain.hip, KPD_EDGE_CHAIN=1) honours the same contract."""
     (h, x), (rh, rx), _ = _run_pair(cuda, util.EGNN_C2, [300, 150, 40], [25, 9, 3], edge_chain=1)
+    assert util.rel_err(h, rh) < TOL, f'eps_h rel err {util.rel_err(h, rh)}'
+    assert util.rel_err(x, rx) < TOL, f'eps_x rel err {util.rel_err(x, rx)}'
+
+
+@pytest.mark.parametrize('ll_k,kl_k,message_norm', [(3, 5, 0), (0, 0, 0), (5, 0, 2.0)])
+def test_egnn_graph_variants(cuda, ll_k, kl_k, message_norm):
+    """The denoiser on the config-reachable graph variants (kNN lig-lig, radius keypoint->ligand): the per-complex
+    normaliser z then depends on counted kl edges."""
+    cfg = dict(util.EGNN_C2, ll_k=ll_k, kl_k=kl_k, message_norm=message_norm, n_layers=2)
+    (h, x), (rh, rx), _ = _run_pair(cuda, cfg, [300, 150, 40], [25, 9, 3])
     assert util.rel_err(h, rh) < TOL, f'eps_h rel err {util.rel_err(h, rh)}'
     assert util.rel_err(x, rx) < TOL, f'eps_x rel err {util.rel_err(x, rx)}'
 

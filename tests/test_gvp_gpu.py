@@ -52,6 +52,15 @@ def test_gvp_small_configs(cuda, tag):
     assert util.rel_err(x, rx) < TOL, util.rel_err(x, rx)
 
 
+@pytest.mark.parametrize('ll_k,kl_k,tag', [(3, 5, 'gvp_norm0'), (0, 0, 'gvp_norm0'), (4, 0, 'gvp_mean')])
+def test_gvp_graph_variants(cuda, ll_k, kl_k, tag):
+    """kNN lig-lig graph (ll_k > 0) and radius keypoint->ligand graph (kl_k = 0), dynamics_gvp.py:206-225."""
+    cfg = dict(GVP_CFGS[tag], ll_k=ll_k, kl_k=kl_k)
+    (h, x), (rh, rx) = _run(cuda, cfg, [60, 33], [12, 10])
+    assert util.rel_err(h, rh) < TOL, util.rel_err(h, rh)
+    assert util.rel_err(x, rx) < TOL, util.rel_err(x, rx)
+
+
 def test_gvp_40kp_shape(cuda):
     # 40 learned keypoints with 128 scalars + vectors, complete kk graph inside 8 A (C3 shape)
     gs = []
