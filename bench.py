@@ -205,7 +205,8 @@ def main():
         if rank == 0:
             print(json.dumps({'metric': 'denoising steps/sec', 'value': world * args.steps / elapsed, 'unit': 'steps/s',
                               'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-                              'ms_per_step': 1e3 * elapsed / args.steps, 'dtype': 'f32', 'data': 'synthetic',
+                              'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+                              'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                               'config': {'workload': args.workload + (' ragged 150-600/15-35' if args.ragged else ''),
                                          'batch_per_gpu': B, 'n_kp_total': g.num_nodes('kp'), 'n_lig_total': g.num_nodes('lig'),
                                          'n_kk': g.num_edges('kk')},
