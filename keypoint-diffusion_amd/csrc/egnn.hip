@@ -488,12 +488,11 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
     // Node-side orchestration per layer (KPD_NODE_MODE, A/B runs in profiles/tools/node_modes.sh):
     //   split  (default) k_node_layer (update only) + k_proj_chain (next layer's projections, one slot per workgroup)
     //   fused            k_node_layer does both from its resident 32-node tile
-    //   staged           k_node_update + k_node_proj (64-node LDS-staged tiles)
-    enum { MODE_SPLIT = 0, MODE_FUSED = 1, MODE_STAGED = 2 };
+    enum { MODE_SPLIT = 0, MODE_FUSED = 1 };
     static const int node_mode = [] {
         const char *e = getenv("KPD_NODE_MODE");
         if (!e) return (int)MODE_SPLIT;
-        return !strcmp(e, "fused") ? (int)MODE_FUSED : !strcmp(e, "staged") ? (int)MODE_STAGED : (int)MODE_SPLIT;
+        return !strcmp(e, "fused") ? (int)MODE_FUSED : (int)MODE_SPLIT;
     }();
     const bool fused_nodes = node_mode == MODE_FUSED;
 
@@ -525,7 +524,7 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
                     pp.n_slots[nt] = k;
                 }
                 pp.tiles0 = cdiv(n[0], TM);
-                KPD_TRY(node_mode == MODE_SPLIT ? launch_proj_chain(pp, st) : launch_node_proj(pp, st));
+                KPD_TRY(launch_proj_chain(pp, st));
             }
         }
         EdgeArgs ea;
@@ -569,7 +568,7 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
             na.wp_2 = L.wp_2[nt]; na.wx_2 = L.wx_2[nt]; na.b2 = L.b2[nt]; na.ln_w = L.ln_w[nt]; na.ln_b = L.ln_b[nt];
             na.norm = c.norm;
         };
-        if (node_mode != MODE_STAGED) {
+        {
             NodeLayerPair lp;
             memset(&lp, 0, sizeof(lp));
             const bool more = fused_nodes && li + 1 < n_layers;
@@ -586,12 +585,6 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
             lp.tiles0 = cdiv(lp.nt[0].u.n, TN);
             lp.stamps = m->stamps ? m->stamps + 16 : nullptr;
             KPD_TRY(launch_node_layer(lp, st));
-        } else {
-            NodePair np;
-            memset(&np, 0, sizeof(np));
-            for (int nt = 0; nt < m->n_upd; ++nt) fill_update(np.nt[nt], nt);
-            np.tiles0 = cdiv(n[0], TM);
-            KPD_TRY(launch_node_update(np, st));
         }
     }
     KPD_TRY(launch_decode(m->h[NT_LIG], m->x[NT_LIG], bt->lig_x, bt->n_lig, c.atom_nf, 2 * c.atom_nf, m->de_W0, m->de_b0,

@@ -309,8 +309,8 @@ kpd_status launch_egnn_chain(const EdgeArgs &a, int tile_cap, hipStream_t st) {
 
 // ---- node projections, register-chained -------------------------------------------------------------------
 // P[node][slot][:] = c (W1_block h[node] (+ b1)) for one 64-node tile and slots_per_block slots per workgroup (same
-// contract as k_node_proj, egnn_kernels.hip).  The nodes' features are read straight into B-operand registers, the
-// 256 x 256 block of the slot's weight streams through the LDS ring, feature 256 on either side is a rank-1 / dot
+// contract as the projection half of k_node_layer, egnn_kernels.hip).  The nodes' features are read straight into
+// B-operand registers, the // 256 x 256 block of the slot's weight streams through the LDS ring, feature 256 on either side is a rank-1 / dot
 // product update on the VALU.  Many small workgroups (tiles x slots) keep the hardware dispatcher balanced.
 namespace kpd {
 

@@ -10,9 +10,7 @@ constexpr int BIAS_K = 257;          // A-tile column that holds the constant 1 
 constexpr int ET_LL = 0, ET_KL = 1, ET_LK = 2, ET_KK = 3;
 constexpr int NT_LIG = 0, NT_KP = 1;
 
-constexpr int PROJ_LDS_BYTES = TM * SA * 4;
 constexpr int EDGE_LDS_BYTES = TM * SA * 4 + (TM * 2 + TM + 3 * TM + TM + 3 * TM + 2 * HS + 8) * 4;
-constexpr int NODE_LDS_BYTES = TM * SA * 4 + 3 * TM * 4;
 
 struct ProjArgs {
     const float *h;                 // [n][HS]
@@ -30,7 +28,7 @@ struct ProjPair {
     ProjArgs nt[2];
     int tiles0;                     // workgroups (64-node tiles) of nt[0]
     int n_slots[2];
-    int slots_per_block;            // consecutive slots one workgroup computes from its resident A tile
+    int slots_per_block;            // consecutive slots one workgroup computes from its resident h registers
 };
 
 struct EdgeArgs {
@@ -90,10 +88,6 @@ struct NodeLayerPair {
 constexpr int TN = 32;              // rows per workgroup of the fused node kernel
 constexpr int NODE_LAYER_LDS_BYTES = TN * SA * 4 + 3 * TN * 4;
 
-struct NodePair {
-    NodeArgs nt[2];                 // nt[1].n == 0 when only one node type is updated
-    int tiles0;
-};
 
 kpd_status egnn_kernels_init();
 kpd_status launch_node_graph_index(const int *ptr, int B, int n, int *bidx, hipStream_t st);
@@ -104,11 +98,9 @@ kpd_status launch_embed(const float *in, int n, int fin, const float *W0, const 
                         const float *b1, const float *t, const int *bidx, float *out, int identity, hipStream_t st);
 kpd_status launch_decode(const float *h, const float *x, const float *x0, int n, int atom_nf, int hid, const float *W0,
                          const float *b0, const float *W1, const float *b1, float *eps_h, float *eps_x, hipStream_t st);
-kpd_status launch_node_proj(const ProjPair &p, hipStream_t st);
 kpd_status launch_egnn_edge(const EdgeArgs &a, int tile_cap, hipStream_t st);
 kpd_status launch_egnn_chain(const EdgeArgs &a, int tile_cap, hipStream_t st);
 kpd_status launch_proj_chain(const ProjPair &p, hipStream_t st);
-kpd_status launch_node_update(const NodePair &p, hipStream_t st);
 kpd_status launch_node_layer(const NodeLayerPair &p, hipStream_t st);
 
 }  // namespace kpd

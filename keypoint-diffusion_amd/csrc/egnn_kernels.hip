@@ -1,7 +1,7 @@
 // EGNN denoiser kernels (LigRecDynamics, models/dynamics.py:9-385) for gfx950.
 //
 // Per layer (LigRecConv.forward, dynamics.py:124-207) three kernels run:
-//   k_node_proj   P[node][slot] = W1[:, h-part] . h[node] (+ b1 on dst slots)
+//   k_proj_chain  (egnn_chain.hip) P[node][slot] = W1[:, h-part] . h[node] (+ b1 on dst slots)
 //                 -- the first Linear(515, 257) of edge_mlp / coord_mlp is linear in
 //                    [h_src, h_dst, d_ij], so its two 257-wide blocks are applied once per
 //                    NODE instead of once per EDGE (3x fewer edge FLOPs);
@@ -9,10 +9,10 @@
 //                 SiLU, the 257x257 second Linear on fp32 MFMA, SiLU, soft attention,
 //                 coordinate head, and the segmented sum over destination nodes -- all in
 //                 one workgroup, intermediates never leave LDS/registers;
-//   k_node_update h' = LN(h + node_mlp([h, h_neigh / z])), x' = x + x_neigh / z.
+//   k_node_layer  h' = LN(h + node_mlp([h, h_neigh / z])), x' = x + x_neigh / z (KPD_NODE_MODE=fused: also the projections).
 // Segment pieces: a tile writes the sum of each run of equal dst either to main[dst]
 // (run starts the segment) or to cont[tile] (run continues a segment begun in an earlier
-// tile); k_node_update adds main + cont pieces in tile order => deterministic, no atomics.
+// tile); k_node_layer adds main + cont pieces in tile order => deterministic, no atomics.
 #include <stdlib.h>
 
 #include <algorithm>
@@ -145,58 +145,6 @@ __global__ __launch_bounds__(64) void k_decode(const float *__restrict__ h, cons
     if (lane < 3) eps_x[(size_t)v * 3 + lane] = x[(size_t)v * 3 + lane] - x0[(size_t)v * 3 + lane];
 }
 
-// ---- node projection ----------------------------------------------------------------------
-// LDS: A tile only.
-// One launch covers both node types: workgroups [0, tiles0) belong to p.nt[0], the rest to p.nt[1].
-__global__ __launch_bounds__(256, 2) void k_node_proj(ProjPair p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *A = smem;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int which = blockIdx.x >= p.tiles0 ? 1 : 0;
-    const ProjArgs &a = p.nt[which];
-    const int s0 = blockIdx.y * p.slots_per_block;
-    if (s0 >= p.n_slots[which]) return;
-    const int s1 = min(s0 + p.slots_per_block, p.n_slots[which]);
-    const int node0 = (blockIdx.x - (which ? p.tiles0 : 0)) * TM;
-
-    // h is padded to whole tiles (rows past n are zero), so the tile is copied unconditionally
-#pragma unroll 8
-    for (int rr = 0; rr < 16; ++rr) {
-        const int r = wave * 16 + rr;
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(a.h + (size_t)(node0 + r) * HS);
-        *reinterpret_cast<f32x4 *>(A + r * SA + 4 * lane) = src[lane];
-        if (lane < 2) *reinterpret_cast<f32x4 *>(A + r * SA + 256 + 4 * lane) = src[64 + lane];
-    }
-    lds_barrier();
-
-    const size_t prow = (size_t)NSLOT * HS;
-    for (int s = s0; s < s1; ++s) {
-        f32x16 acc[2][2];
-        acc_zero(acc);
-        gemm_rows64(A, a.wp[s], acc, wave, lane);
-        const float ex = extra_col(A, a.wx[s], tid);
-        const float *bias = a.bias[s];
-        // P is padded to whole tiles: rows past n are written unconditionally (never read back);
-        // addressing = wave-uniform base (+ compile-time row term) + one 32-bit lane offset
-        char *obase = reinterpret_cast<char *>(a.P + ((size_t)node0 * NSLOT + a.slot[s]) * HS);
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int col = acc_col(nt, wave, lane);
-            const float b = bias ? bias[col] : 0.0f;
-            const unsigned lane_off = (unsigned)((4 * (lane >> 5)) * (int)prow + col) * 4u;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const unsigned row_off = (unsigned)((32 * mt + (reg & 3) + 8 * (reg >> 2)) * (int)prow) * 4u;
-                    *reinterpret_cast<float *>(obase + row_off + lane_off) = acc[mt][nt][reg] + b;
-                }
-        }
-        if ((tid & 3) == 0)
-            *reinterpret_cast<float *>(obase + (unsigned)((tid >> 2) * (int)prow + 256) * 4u) = ex + (bias ? bias[256] : 0.0f);
-    }
-}
-
 // ---- fused edge kernel --------------------------------------------------------------------
 struct EdgeSmem {
     float *A;
@@ -221,7 +169,7 @@ __device__ __forceinline__ EdgeSmem edge_smem(float *smem) {
 }
 
 // A[r][:] = SiLU(Ps[src_r] + Pd[dst_r] + d_r * w_r)   (first Linear of edge_mlp / coord_mlp;
-// its bias is folded into Pd by k_node_proj).  Each of the NW waves owns 64 / NW rows.
+// its bias is folded into Pd by the projection kernel).  Each of the NW waves owns 64 / NW rows.
 template <int NW>
 __device__ __forceinline__ void build_edge_A(const EdgeSmem &s, const float *__restrict__ Ps, const float *__restrict__ Pd,
                                              const float *__restrict__ wr, int wave, int lane) {
@@ -481,181 +429,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
     KPD_STAMP(10)
 }
 
-__device__ __forceinline__ void store_T_silu(float *T, const f32x16 (&acc)[2][2], float ex, const float *__restrict__ b,
-                                             int tid, int wave, int lane) {
-    store_T_silu_w<4, false>(T, acc, ex, b, tid, wave, lane);
-}
-
-// ---- node update --------------------------------------------------------------------------
-struct NodeSmem {
-    float *A;
-    float *zinv, *mean, *rstd;
-};
-
-// One launch covers both updated node types (ligand tiles first: fewer, but each gathers long
-// kl segments; the keypoint tiles fill the rest of the chip).
-__global__ __launch_bounds__(256, 2) void k_node_update(NodePair p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *A = smem;
-    float *s_z = smem + TM * SA;        // [64] z of the row's graph
-    float *s_mean = s_z + TM;           // [64]
-    float *s_rstd = s_mean + TM;        // [64]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int which = blockIdx.x >= p.tiles0 ? 1 : 0;
-    const NodeArgs &a = p.nt[which];
-    const int node0 = (blockIdx.x - (which ? p.tiles0 : 0)) * TM;
-
-    // coordinates: x' = x + x_neigh / z (dynamics.py:190-192, 206)
-    if (tid < TM) {
-        const int v = node0 + tid;
-        float z = 1.0f;
-        if (v < a.n) {
-            z = a.z[a.bidx[v]];
-            float sx = 0.f, sy = 0.f, sz = 0.f;
-            for (int i = 0; i < a.n_in; ++i) {
-                const int lo = a.rowptr[i][v], hi = a.rowptr[i][v + 1];
-                if (hi > lo) {
-                    const float *p = a.xn_main[i] + (size_t)v * 4;
-                    sx += p[0]; sy += p[1]; sz += p[2];
-                    for (int t = lo / TM + 1; t <= (hi - 1) / TM; ++t) {
-                        const float *q = a.xn_cont[i] + (size_t)t * 4;
-                        sx += q[0]; sy += q[1]; sz += q[2];
-                    }
-                }
-            }
-            float *xv = a.x + (size_t)v * 3;
-            xv[0] += sx / z; xv[1] += sy / z; xv[2] += sz / z;
-        }
-        s_z[tid] = z;
-    }
-
-    // GEMM 1a: W[:, :257] . h
-    for (int rr = 0; rr < 16; ++rr) {
-        const int r = wave * 16 + rr, v = node0 + r;
-        f32x4 val = {0.f, 0.f, 0.f, 0.f}, val2 = {0.f, 0.f, 0.f, 0.f};
-        if (v < a.n) {
-            const f32x4 *src = reinterpret_cast<const f32x4 *>(a.h + (size_t)v * HS);
-            val = src[lane];
-            if (lane < 2) val2 = src[64 + lane];
-        }
-        *reinterpret_cast<f32x4 *>(A + r * SA + 4 * lane) = val;
-        if (lane < 2) *reinterpret_cast<f32x4 *>(A + r * SA + 256 + 4 * lane) = val2;
-    }
-    lds_barrier();
-    f32x16 acc[2][2];
-    acc_zero(acc);
-    gemm_rows64(A, a.wp_a, acc, wave, lane);
-    float ex = extra_col(A, a.wx_a, tid);
-    lds_barrier();
-
-    // GEMM 1b: + W[:, 257:] . (h_neigh / z); h_neigh = sum of segment pieces over the
-    // incoming edge types in fixed order (multi_update_all cross_reducer='sum')
-    for (int rr = 0; rr < 16; ++rr) {
-        const int r = wave * 16 + rr, v = node0 + r;
-        f32x4 val = {0.f, 0.f, 0.f, 0.f}, val2 = {0.f, 0.f, 0.f, 0.f};
-        if (v < a.n) {
-            for (int i = 0; i < a.n_in; ++i) {
-                const int lo = a.rowptr[i][v], hi = a.rowptr[i][v + 1];
-                if (hi > lo) {
-                    const f32x4 *p = reinterpret_cast<const f32x4 *>(a.hn_main[i] + (size_t)v * HS);
-                    val += p[lane];
-                    if (lane < 2) val2 += p[64 + lane];
-                    for (int t = lo / TM + 1; t <= (hi - 1) / TM; ++t) {
-                        const f32x4 *q = reinterpret_cast<const f32x4 *>(a.hn_cont[i] + (size_t)t * HS);
-                        val += q[lane];
-                        if (lane < 2) val2 += q[64 + lane];
-                    }
-                }
-            }
-            const float z = s_z[r];
-            val /= z;
-            val2 /= z;
-        }
-        *reinterpret_cast<f32x4 *>(A + r * SA + 4 * lane) = val;
-        if (lane < 2) *reinterpret_cast<f32x4 *>(A + r * SA + 256 + 4 * lane) = val2;
-    }
-    lds_barrier();
-    gemm_rows64(A, a.wp_b, acc, wave, lane);
-    ex += extra_col(A, a.wx_b, tid);
-    lds_barrier();
-
-    // hidden = SiLU(. + b0) -> T (pad columns 257..263 stay 0 from the h_neigh tile)
-    store_T_silu(A, acc, ex, a.b0, tid, wave, lane);
-    lds_barrier();
-
-    // GEMM 2 + bias + residual (dynamics.py:201-203)
-    acc_zero(acc);
-    gemm_rows64(A, a.wp_2, acc, wave, lane);
-    ex = extra_col(A, a.wx_2, tid);
-    lds_barrier();
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int col = acc_col(nt, wave, lane);
-        const float bb = a.b2[col];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) A[acc_row(mt, reg, lane) * SA + col] = acc[mt][nt][reg] + bb;
-    }
-    if ((tid & 3) == 0) A[(tid >> 2) * SA + 256] = ex + a.b2[256];
-    lds_barrier();
-    // residual h (row-wise, coalesced; h is padded to whole tiles, rows >= n read zeros)
-#pragma unroll 8
-    for (int rr = 0; rr < 16; ++rr) {
-        const int r = wave * 16 + rr;
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(a.h + (size_t)(node0 + r) * HS);
-        *reinterpret_cast<f32x4 *>(A + r * SA + 4 * lane) += src[lane];
-        if (lane == 0) A[r * SA + 256] += a.h[(size_t)(node0 + r) * HS + 256];
-    }
-    lds_barrier();
-
-    // LayerNorm(257) (dynamics.py:81-87, 204), biased variance, eps = 1e-5
-    if (a.norm) {
-        const int row = tid >> 2, q = tid & 3;
-        const float *tr = A + row * SA + q;
-        float sum = 0.0f;
-        for (int i = 0; i < 64; ++i) sum += tr[4 * i];
-        if (q == 0) sum += A[row * SA + 256];
-        sum += __shfl_xor(sum, 1);
-        sum += __shfl_xor(sum, 2);
-        const float mean = sum * (1.0f / HW);
-        float var = 0.0f;
-        for (int i = 0; i < 64; ++i) {
-            const float dlt = tr[4 * i] - mean;
-            var = fmaf(dlt, dlt, var);
-        }
-        if (q == 0) {
-            const float dlt = A[row * SA + 256] - mean;
-            var = fmaf(dlt, dlt, var);
-        }
-        var += __shfl_xor(var, 1);
-        var += __shfl_xor(var, 2);
-        if (q == 0) {
-            s_mean[row] = mean;
-            s_rstd[row] = 1.0f / sqrtf(var * (1.0f / HW) + 1e-5f);
-        }
-    }
-    lds_barrier();
-    for (int rr = 0; rr < 16; ++rr) {
-        const int r = wave * 16 + rr, v = node0 + r;
-        if (v >= a.n) continue;
-        f32x4 val = *reinterpret_cast<const f32x4 *>(A + r * SA + 4 * lane);
-        float last = A[r * SA + 256];
-        if (a.norm) {
-            const float mean = s_mean[r], rstd = s_rstd[r];
-            const f32x4 w = reinterpret_cast<const f32x4 *>(a.ln_w)[lane];
-            const f32x4 b = reinterpret_cast<const f32x4 *>(a.ln_b)[lane];
-            val = (val - mean) * rstd * w + b;
-            last = (last - mean) * rstd * a.ln_w[256] + a.ln_b[256];
-        }
-        f32x4 *dst = reinterpret_cast<f32x4 *>(a.h + (size_t)v * HS);
-        dst[lane] = val;
-        if (lane == 0) {
-            const f32x4 t = {last, 0.f, 0.f, 0.f};
-            dst[64] = t;
-        }
-    }
-}
 
 // ---- fused node kernel: update of layer i, then the first-layer projections of layer i + 1 ----------------
 // 32-node tiles (4 workgroups per CU) so that the 20 800 nodes of a C2 batch make 650 work items on 256
@@ -902,16 +675,12 @@ static bool g_attr_set = false;
 
 kpd_status egnn_kernels_init() {
     if (g_attr_set) return KPD_OK;
-    KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_proj), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                PROJ_LDS_BYTES));
     KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_egnn_edge<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024));
     KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_egnn_edge<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024));
     KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_layer), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024));
-    KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_update),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, NODE_LDS_BYTES));
     g_attr_set = true;
     return KPD_OK;
 }
@@ -953,18 +722,6 @@ kpd_status launch_decode(const float *h, const float *x, const float *x0, int n,
     return KPD_OK;
 }
 
-kpd_status launch_node_proj(const ProjPair &p, hipStream_t st) {
-    const int tiles = p.tiles0 + cdiv(p.nt[1].n, TM);
-    const int slots = std::max(p.n_slots[0], p.n_slots[1]);
-    if (tiles == 0 || slots == 0) return KPD_OK;
-    static const int spb = getenv("KPD_PROJ_SPB") ? std::max(1, atoi(getenv("KPD_PROJ_SPB"))) : 2;
-    ProjPair q = p;
-    q.slots_per_block = spb;
-    hipLaunchKernelGGL(k_node_proj, dim3(tiles, cdiv(slots, spb)), dim3(256), PROJ_LDS_BYTES, st, q);
-    KPD_LAUNCH_CHECK();
-    return KPD_OK;
-}
-
 kpd_status launch_egnn_edge(const EdgeArgs &a, int tile_cap, hipStream_t st) {
     if (tile_cap == 0) return KPD_OK;
     // KPD_EDGE_LDS_PAD (diagnostics): extra dynamic LDS to force one workgroup per CU
@@ -992,12 +749,5 @@ kpd_status launch_node_layer(const NodeLayerPair &p, hipStream_t st) {
     return KPD_OK;
 }
 
-kpd_status launch_node_update(const NodePair &p, hipStream_t st) {
-    const int tiles = p.tiles0 + cdiv(p.nt[1].n, TM);
-    if (tiles == 0) return KPD_OK;
-    hipLaunchKernelGGL(k_node_update, dim3(tiles), dim3(256), NODE_LDS_BYTES, st, p);
-    KPD_LAUNCH_CHECK();
-    return KPD_OK;
-}
 
 }  // namespace kpd
