@@ -170,37 +170,65 @@ __device__ __forceinline__ EdgeSmem edge_smem(float *smem) {
 
 // A[r][:] = SiLU(Ps[src_r] + Pd[dst_r] + d_r * w_r)   (first Linear of edge_mlp / coord_mlp;
 // its bias is folded into Pd by the projection kernel).  Each of the NW waves owns 64 / NW rows.
+// Split in two so that the 4-wave build (256 VGPRs per lane) can issue the gathers of the coordinate branch before the
+// attention / segmented-sum phases of the feature branch and consume them after (the 8-wave build has no registers to
+// spare for that: 61 spills, measured slower).
 template <int NW>
-__device__ __forceinline__ void build_edge_A(const EdgeSmem &s, const float *__restrict__ Ps, const float *__restrict__ Pd,
-                                             const float *__restrict__ wr, int wave, int lane) {
+struct EdgeGather {
+    static constexpr int RPW = TM / NW;
+    f32x4 ps[RPW], pd[RPW];     // columns 4 lane .. 4 lane + 3 of the wave's RPW rows
+    f32x4 tps, tpd;             // columns 256 + 4 c .. of row lane >> 2 (lanes < 4 RPW, c = lane & 3 < 2)
+};
+
+template <int NW>
+__device__ __forceinline__ void edge_gather_issue(EdgeGather<NW> &g, const EdgeSmem &s, const float *__restrict__ Ps,
+                                                  const float *__restrict__ Pd, int wave, int lane) {
     constexpr int RPW = TM / NW;
     const size_t prow = (size_t)NSLOT * HS;
-    const f32x4 w0 = reinterpret_cast<const f32x4 *>(wr)[lane];
-    // columns 0..255: one 1-KiB row segment per wave instruction, all rows of the wave in flight
+    // one 1-KiB row segment per wave instruction, all rows of the wave in flight
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
         const int r = wave * RPW + rr;
-        const float d = s.d[r];
-        const f32x4 *ps = reinterpret_cast<const f32x4 *>(Ps + s.src[r] * prow);
-        const f32x4 *pd = reinterpret_cast<const f32x4 *>(Pd + s.dst[r] * prow);
-        f32x4 v = ps[lane] + pd[lane] + d * w0;             // = c * pre-activation (P, w_r carry c)
+        g.ps[rr] = reinterpret_cast<const f32x4 *>(Ps + s.src[r] * prow)[lane];
+        g.pd[rr] = reinterpret_cast<const f32x4 *>(Pd + s.dst[r] * prow)[lane];
+    }
+    if (lane < 4 * RPW && (lane & 3) < 2) {
+        const int r = wave * RPW + (lane >> 2), c = lane & 3;
+        g.tps = reinterpret_cast<const f32x4 *>(Ps + s.src[r] * prow)[64 + c];
+        g.tpd = reinterpret_cast<const f32x4 *>(Pd + s.dst[r] * prow)[64 + c];
+    }
+}
+
+template <int NW>
+__device__ __forceinline__ void edge_gather_finish(const EdgeGather<NW> &g, const EdgeSmem &s, const float *__restrict__ wr, int wave,
+                                                   int lane) {
+    constexpr int RPW = TM / NW;
+    const f32x4 w0 = reinterpret_cast<const f32x4 *>(wr)[lane];
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int r = wave * RPW + rr;
+        f32x4 v = g.ps[rr] + g.pd[rr] + s.d[r] * w0;        // = c * pre-activation (P, w_r carry c)
         v[0] = silu_pre(v[0]); v[1] = silu_pre(v[1]); v[2] = silu_pre(v[2]); v[3] = silu_pre(v[3]);
         *reinterpret_cast<f32x4 *>(s.A + r * SA + 4 * lane) = v;
     }
     // columns 256..263 of the wave's rows in one pass (lane = row * 4 + chunk): keeping this out of the
     // row loop halves the VALU work, which on gfx950 is paid in MFMA time
-    if (lane < 4 * RPW) {
+    if (lane < 4 * RPW && (lane & 3) < 2) {
         const int r = wave * RPW + (lane >> 2), c = lane & 3;
-        if (c < 2) {
-            const f32x4 w1 = reinterpret_cast<const f32x4 *>(wr)[64 + c];
-            const f32x4 *ps = reinterpret_cast<const f32x4 *>(Ps + s.src[r] * prow);
-            const f32x4 *pd = reinterpret_cast<const f32x4 *>(Pd + s.dst[r] * prow);
-            f32x4 u = ps[64 + c] + pd[64 + c] + s.d[r] * w1;
-            u[0] = silu_pre(u[0]); u[1] = silu_pre(u[1]); u[2] = silu_pre(u[2]); u[3] = silu_pre(u[3]);
-            if (c == 0) u[BIAS_K - 256] = 1.0f;           // constant-1 column: the GEMM adds the bias row itself
-            *reinterpret_cast<f32x4 *>(s.A + r * SA + 256 + 4 * c) = u;
-        }
+        const f32x4 w1 = reinterpret_cast<const f32x4 *>(wr)[64 + c];
+        f32x4 u = g.tps + g.tpd + s.d[r] * w1;
+        u[0] = silu_pre(u[0]); u[1] = silu_pre(u[1]); u[2] = silu_pre(u[2]); u[3] = silu_pre(u[3]);
+        if (c == 0) u[BIAS_K - 256] = 1.0f;               // constant-1 column: the GEMM adds the bias row itself
+        *reinterpret_cast<f32x4 *>(s.A + r * SA + 256 + 4 * c) = u;
     }
+}
+
+template <int NW>
+__device__ __forceinline__ void build_edge_A(const EdgeSmem &s, const float *__restrict__ Ps, const float *__restrict__ Pd,
+                                             const float *__restrict__ wr, int wave, int lane) {
+    EdgeGather<NW> g;
+    edge_gather_issue<NW>(g, s, Ps, Pd, wave, lane);
+    edge_gather_finish<NW>(g, s, wr, wave, lane);
 }
 
 // T[row][col] = SiLU(acc + b[col]) for the 257 valid columns.  PRE: the accumulator already holds
@@ -312,6 +340,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
     lds_barrier();
     KPD_STAMP(2)
     store_T_silu_w<NW, true>(s.A, acc, ex, a.b_e[et], tid, wave, lane);
+    EdgeGather<NW == 4 ? 4 : TM> gc;      // (one row per wave, unused, in the 8-wave build)
+    if constexpr (NW == 4) {  // the coordinate branch's P rows start travelling now; consumed after the segmented sum below
+        edge_gather_issue<NW>(gc, s, Ps + HS, Pd + HS, wave, lane);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     lds_barrier();
     KPD_STAMP(3)
     {
@@ -376,7 +409,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
     KPD_STAMP(5)
 
     // ---- coordinate messages: msg_x = tanh(coord_mlp(f)) * x_diff * range (dynamics.py:113-120)
-    build_edge_A<NW>(s, Ps + HS, Pd + HS, a.wr_c[et], wave, lane);
+    if constexpr (NW == 4) edge_gather_finish<NW>(gc, s, a.wr_c[et], wave, lane);
+    else build_edge_A<NW>(s, Ps + HS, Pd + HS, a.wr_c[et], wave, lane);
     lds_barrier();
     KPD_STAMP(6)
     acc_zero_w<NW>(acc);
@@ -726,8 +760,9 @@ kpd_status launch_egnn_edge(const EdgeArgs &a, int tile_cap, hipStream_t st) {
     if (tile_cap == 0) return KPD_OK;
     // KPD_EDGE_LDS_PAD (diagnostics): extra dynamic LDS to force one workgroup per CU
     static const int pad = getenv("KPD_EDGE_LDS_PAD") ? atoi(getenv("KPD_EDGE_LDS_PAD")) : 0;
-    // 8 waves per workgroup (two per SIMD) by default; KPD_EDGE_NW=4 selects the 4-wave build for A/B runs
-    static const int nw = getenv("KPD_EDGE_NW") ? atoi(getenv("KPD_EDGE_NW")) : 8;
+    // 4 waves per workgroup by default: 256 VGPRs per lane leave room to keep the coordinate branch's gathered P rows in
+    // registers across the attention / segmented-sum phases (1.00 vs 1.04 ms); KPD_EDGE_NW=8 selects the 8-wave build
+    static const int nw = getenv("KPD_EDGE_NW") ? atoi(getenv("KPD_EDGE_NW")) : 4;
     if (nw == 4)
         hipLaunchKernelGGL(k_egnn_edge<4>, dim3(8 * cdiv(tile_cap, 8)), dim3(256), EDGE_LDS_BYTES + pad, st, a);
     else

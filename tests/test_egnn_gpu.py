@@ -162,3 +162,11 @@ def test_batch_independence(cuda):
         assert util.rel_err(h1.cpu(), h[off:off + nl]) < 1e-5
         assert util.rel_err(x1.cpu(), x[off:off + nl]) < 1e-5
         off += nl
+
+
+@pytest.mark.parametrize('n_rec,n_lig', [([40], [1]), ([40, 55], [1, 2]), ([8], [3]), ([300], [60])])
+def test_degenerate_shapes(cuda, n_rec, n_lig):
+    """Single-atom ligands (empty lig-lig graph), pockets smaller than one tile, the largest ligand of the datasets."""
+    cfg = dict(util.EGNN_C2, n_layers=2)
+    (h, x), (rh, rx), _ = _run_pair(cuda, cfg, n_rec, n_lig)
+    assert util.rel_err(h, rh) < TOL and util.rel_err(x, rx) < TOL

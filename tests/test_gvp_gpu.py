@@ -93,3 +93,10 @@ def test_gvp_40kp_shape(cuda):
 def test_gvp_all_atom_ragged(cuda):
     (h, x), (rh, rx) = _run(cuda, GVP_ALL_ATOM, [150, 420, 64], [15, 35, 3], rand_v=False)
     assert util.rel_err(h, rh) < TOL and util.rel_err(x, rx) < TOL
+
+
+@pytest.mark.parametrize('n_rec,n_lig', [([40], [1]), ([40, 55], [1, 2]), ([8], [3]), ([300], [60])])
+def test_gvp_degenerate_shapes(cuda, n_rec, n_lig):
+    """Single-atom ligands (empty lig-lig graph), pockets smaller than one tile, the largest ligand of the datasets."""
+    (h, x), (rh, rx) = _run(cuda, GVP_CFGS['gvp_norm0'], n_rec, n_lig)
+    assert util.rel_err(h, rh) < TOL and util.rel_err(x, rx) < TOL
