@@ -35,11 +35,8 @@ struct Arena {
 // Weight repacking helpers (pack.hip).
 // src: torch Linear weight [n_out, ld] row-major on device; uses columns [col0, col0 + K).
 kpd_status pack_gemm_weight(const float *src, int n_out, int ld, int col0, int K, float *wp, float *wx, hipStream_t st);
-// General K (padded to 8 ng) and N <= 256 (no extra column): packed block of ng*2048 floats.
-kpd_status pack_gemm_weight_ng(const float *src, int n_out, int ld, int col0, int K, int ng, float *wp, hipStream_t st);
 kpd_status scale_inplace(float *p, int n, float f, hipStream_t st);
 kpd_status patch_bias_row(float *wp, float *wx, const float *bias, float f, int k, hipStream_t st);
-kpd_status pack_gate_weight(const float *src, int vout, int K, float *dst, hipStream_t st);
 // 16x16x4 MFMA A-operand fragments of a [n][k] matrix with element (n, k) at src[n * sn + k * sk]:
 // dst[(mt * 64 + lane) * 4 + r] = element(16 mt + (lane & 15), k_base + 4 (lane >> 4) + r), zero outside
 // n < n_valid / 4 (lane >> 4) + r < k_valid.  One call packs the 16 k-rows [k_base, k_base + 16) for n_tiles

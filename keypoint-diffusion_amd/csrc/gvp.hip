@@ -69,7 +69,6 @@ extern "C" kpd_status kpd_gvp_create(const kpd_gvp_config *cfg, kpd_gvp **out) {
                 KPD_ERR_INVALID, "feature widths out of range");
     KPD_REQUIRE(cfg->message_norm_mode >= 0 && cfg->message_norm_mode <= 2, KPD_ERR_INVALID, "message_norm_mode");
     KPD_TRY(egnn_kernels_init());
-    KPD_TRY(gvp_kernels_init());
     kpd_gvp *m = new kpd_gvp();
     m->cfg = *cfg;
     m->S = cfg->n_hidden_scalars;
@@ -123,6 +122,7 @@ extern "C" kpd_status kpd_gvp_create(const kpd_gvp_config *cfg, kpd_gvp **out) {
         const bool last = j == cfg->n_noise_gvps - 1;
         g.vin = GV; g.vout = last ? 1 : GV; g.s_in = S; g.sout = last ? 64 : S;
         g.vec_sigmoid = last ? 0 : 1;
+        g.chain_pos = 1;                // register-chained noise head (gvp_chain.hip)
         alloc_gvp(A, g, m->expected, "noise_predictor.noise_predictor.gvps." + std::to_string(j));
     }
     const int fin[2] = {cfg->n_lig_scalars + 1, cfg->n_kp_scalars + 1};

@@ -13,6 +13,8 @@
 // Per 64-edge tile this leaves LDS traffic of one ds_read_b128 per four MFMAs and an LDS footprint of 79 KB
 // (the ring is reused for the final segmented sum), so two workgroups fit a CU and one's epilogues and
 // gathers overlap the other's MFMA stream.
+#include <algorithm>
+
 #include "chain_core.h"
 #include "gvp_kernels.h"
 
@@ -609,6 +611,119 @@ __global__ __launch_bounds__(256, 2) void k_gvp_proj_chain(GvpProjArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the ring's tail fetch must not outlive the workgroup's LDS
 }
 
+// ---- noise prediction block (dynamics_gvp.py:10-44), register-chained --------------------------------------------
+// n_gvps - 1 GVPs of the generic kind, then the head GVP (S scalars, 16 vectors) -> (64 scalars, 1 vector, identity vector
+// activation), eps_h = Linear(64, F) of its scalars, eps_x = its vector.  16 ligand atoms per wave; the head GVP's weights
+// (NTS + 1 k-slabs of 4 output tiles, 4 gate tiles) are read straight from global memory: ligand atoms are few.
+template <int NTS>
+__global__ __launch_bounds__(256, 2) void k_gvp_noise_chain(GvpNoiseArgs a) {
+    constexpr int S = 16 * NTS, CH4 = NTS * 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int node0 = blockIdx.x * TM;
+    const int n_gen = a.n_gvps - 1;
+
+    auto chunk_src = [&](int c) -> const v4f * {
+        const int stage = c / (NTS + 2), local = c - stage * (NTS + 2);
+        return reinterpret_cast<const v4f *>(a.g[stage].chain) + (size_t)local * CH4 + tid;
+    };
+    ChunkRing<CH4> ring;
+    ring.init(smem, std::max(n_gen, 1) * (NTS + 2), wave);
+    if (n_gen > 0) ring.start(chunk_src);
+
+    const int el = lane & 15, q = lane >> 4;
+    const int vr = node0 + 16 * wave + el;
+    const bool valid = vr < a.n;
+    const int v = valid ? vr : a.n - 1;
+    v4f x[NTS], acc[NTS], Vc[3];
+    const float *sp = a.s + (size_t)v * S + 4 * q;
+#pragma unroll
+    for (int nt = 0; nt < NTS; ++nt) x[nt] = *reinterpret_cast<const v4f *>(sp + 16 * nt);
+    load_vec12(a.v + (size_t)v * 48 + 12 * q, Vc);
+    if (n_gen > 0) {
+        const float *b0 = a.g[0].b + 4 * q;
+#pragma unroll
+        for (int nt = 0; nt < NTS; ++nt) acc[nt] = *reinterpret_cast<const v4f *>(b0 + 16 * nt);
+        ring.first();
+#pragma unroll 1
+        for (int k = 0; k < n_gen; ++k)
+            chain_generic_gvp<NTS>(ring, chunk_src, a.g[k], k + 1 < n_gen ? a.g[k + 1].b : nullptr, x, acc, Vc, lane, q);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the ring's tail fetches must not outlive the workgroup's LDS
+    }
+
+    // head GVP: vec1, [x | sh] -> 64 scalars (4 output tiles), gate and output vector (row 0 of their tiles)
+    const GvpW &gl = a.g[n_gen];
+    const v4f wh = reinterpret_cast<const v4f *>(gl.whp)[lane];
+    v4f Vh[3], sh;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        v4f t = zero4();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t = mfma16(wh[r], Vc[c][r], t);
+        Vh[c] = t;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sh[r] = sqrtf(fmaxf(Vh[0][r] * Vh[0][r] + Vh[1][r] * Vh[1][r] + Vh[2][r] * Vh[2][r], 1e-8f));
+    const v4f *wl = reinterpret_cast<const v4f *>(gl.chain) + lane;            // [slab][4 tiles][64 lanes]
+    v4f so[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) so[mt] = *reinterpret_cast<const v4f *>(gl.b + 16 * mt + 4 * q);
+#pragma unroll 4
+    for (int slab = 0; slab <= NTS; ++slab) {
+        v4f xin = sh;
+#pragma unroll
+        for (int nt = 0; nt < NTS; ++nt)
+            if (slab == nt) xin = x[nt];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const v4f w = wl[(slab * 4 + mt) * 64];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) so[mt] = mfma16(w[r], xin[r], so[mt]);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) so[mt][r] = silu(so[mt][r]);
+    const v4f *wgl = wl + (size_t)(NTS + 1) * 4 * 64;                            // gate slab: 4 k-tiles of one output tile
+    v4f ga = zero4();
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const v4f w = wgl[nt * 64];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ga = mfma16(w[r], so[nt][r], ga);
+    }
+    const v4f wu = reinterpret_cast<const v4f *>(gl.wup)[lane];
+    v4f vu[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        v4f t = zero4();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t = mfma16(wu[r], Vh[c][r], t);
+        vu[c] = t;
+    }
+    float gate = ga[0] + gl.bg[0];                                            // output vector 0 = row 0: lanes q == 0, r == 0
+    if (gl.vec_sigmoid) gate = sigmoidf_(gate);
+    if (valid && q == 0) {
+        a.eps_x[(size_t)v * 3] = gate * vu[0][0];
+        a.eps_x[(size_t)v * 3 + 1] = gate * vu[1][0];
+        a.eps_x[(size_t)v * 3 + 2] = gate * vu[2][0];
+    }
+    // eps_h = W_out s + b_out: this lane holds s[16 mt + 4 q + r]
+    for (int f = 0; f < a.F; ++f) {
+        const float *wo = a.Wout + (size_t)f * 64 + 4 * q;
+        float part = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const v4f w = *reinterpret_cast<const v4f *>(wo + 16 * mt);
+            part += so[mt][0] * w[0] + so[mt][1] * w[1] + so[mt][2] * w[2] + so[mt][3] * w[3];
+        }
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        if (valid && q == 0) a.eps_h[(size_t)v * a.F + f] = part + a.bout[f];
+    }
+}
+
 static bool g_chain_attr = false;
 
 kpd_status launch_gvp_edge(const GvpEdgeArgs &a, int tile_cap, hipStream_t st) {
@@ -647,6 +762,26 @@ kpd_status launch_gvp_proj(const GvpProjArgs &a, hipStream_t st) {
     const dim3 grid(a.tiles_first[a.n_slots]);
     if (a.S == 256) hipLaunchKernelGGL(k_gvp_proj_chain<16>, grid, dim3(256), 4 * 16 * 64 * 16, st, a);
     else hipLaunchKernelGGL(k_gvp_proj_chain<8>, grid, dim3(256), 4 * 8 * 64 * 16, st, a);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+kpd_status launch_gvp_noise(const GvpNoiseArgs &a, hipStream_t st) {
+    if (a.n == 0) return KPD_OK;
+    KPD_REQUIRE(a.S == 256 || a.S == 128, KPD_ERR_INVALID, "gvp noise head: S=%d (supported 128, 256)", a.S);
+    KPD_REQUIRE(a.n_gvps >= 1 && a.F >= 1, KPD_ERR_INVALID, "gvp noise head: n_gvps=%d F=%d", a.n_gvps, a.F);
+    const GvpW &gl = a.g[a.n_gvps - 1];
+    KPD_REQUIRE(gl.sout == 64 && gl.vout == 1 && gl.vin == GV, KPD_ERR_STATE, "noise head GVP must map (S, 16) -> (64, 1)");
+    for (int k = 0; k < a.n_gvps; ++k)
+        KPD_REQUIRE(a.g[k].chain && a.g[k].whp && a.g[k].wup, KPD_ERR_STATE, "noise GVP %d was not prepared for the chained kernel", k);
+    static bool attr = false;
+    if (!attr) {
+        KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gvp_noise_chain<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 16 * 64 * 16));
+        KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gvp_noise_chain<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 8 * 64 * 16));
+        attr = true;
+    }
+    if (a.S == 256) hipLaunchKernelGGL(k_gvp_noise_chain<16>, dim3(cdiv(a.n, TM)), dim3(256), 3 * 16 * 64 * 16, st, a);
+    else hipLaunchKernelGGL(k_gvp_noise_chain<8>, dim3(cdiv(a.n, TM)), dim3(256), 3 * 8 * 64 * 16, st, a);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
 }

@@ -19,22 +19,20 @@ struct HostGvp {
     int vin = 0, h = 0, vout = 0, s_in = 0, sout = 0;   // s_in = scalar inputs of to_feats_out (without sh)
     int split = SPLIT_NONE;
     int S = 0;                                          // width of the node blocks when split
-    float *Wh = nullptr, *Wu = nullptr, *wp = nullptr, *b = nullptr, *wg = nullptr, *bg = nullptr;
+    float *b = nullptr, *bg = nullptr;                  // to_feats_out bias (zero padded to 256), gate bias [16]
     float *wproj = nullptr, *bproj = nullptr;           // h_src block (+ bias)
     float *wproj_dst = nullptr;                         // h_dst block
-    int ng = 0;
     int vec_sigmoid = 1;
-    int chain_pos = -1;                                 // position in an edge-message chain (-1: not a message GVP)
-    float *chain = nullptr, *whp = nullptr, *wup = nullptr;   // fragments for the chained edge kernel
+    int chain_pos = 1;                                  // 0: head of an edge-message chain (split first Linear), >= 1: any other GVP
+    float *chain = nullptr, *whp = nullptr, *wup = nullptr;   // 16x16x4 A fragments for the chained kernels (gvp_chain.hip)
     int n_ht() const { return (h + 15) / 16; }
-    int chain_chunks() const { return chain_pos == 0 ? 2 + n_ht() : sout / 16 + 2; }
-    int edge_scalars() const { return split == SPLIT_NONE ? s_in : 16; }
+    // k-slabs of to_feats_out ([rbf | sh tiles] at the head of a message chain, [s_in / 16 scalar slabs | sh] otherwise) + gates
+    int chain_chunks() const { return chain_pos == 0 ? 2 + n_ht() : s_in / 16 + 2; }
     GvpW dev() const {
         GvpW w;
-        w.Wh = Wh; w.Wu = Wu; w.wp = wp; w.b = b; w.wg = wg; w.bg = bg;
+        w.b = b; w.bg = bg;
         w.vin = vin; w.h = h; w.vout = vout;
-        w.n_s = edge_scalars();
-        w.sout = sout; w.ng = ng; w.vec_sigmoid = vec_sigmoid;
+        w.sout = sout; w.vec_sigmoid = vec_sigmoid;
         w.chain = chain; w.whp = whp; w.wup = wup;
         return w;
     }

@@ -16,22 +16,13 @@ std::vector<std::string> split_dots(const std::string &s) {
 }
 
 size_t gvp_arena_bytes(int S) {
-    return ((size_t)NG_G * 2048 + 2 * GVH * GVH + 256 + 16 * 256 + 16 + 2 * (size_t)(S / 8) * 2048 + 256 +
-            (size_t)(S / 16 + 2) * (S / 16) * 256 + 12 * 256) * 4 + 16384;
+    return (256 + 16 + 2 * (size_t)(S / 8) * 2048 + 256 + (size_t)(S / 16 + 2) * (S / 16) * 256 + 12 * 256) * 4 + 16384;
 }
 
 void alloc_gvp(Arena &A, HostGvp &g, std::set<std::string> &expected, const std::string &prefix) {
     g.h = std::max(g.vin, g.vout);
-    const int k_edge = g.edge_scalars() + g.h;
-    g.ng = (k_edge + 7) / 8;
     g.b = A.take<float>(256);
     g.bg = A.take<float>(16);
-    if (g.chain_pos < 0) {      // LDS-staged form (gvp_stage: node update, noise head)
-        g.Wh = A.take<float>(g.vin * g.h);
-        g.Wu = A.take<float>(g.h * g.vout);
-        g.wp = A.take<float>((size_t)g.ng * 2048);
-        g.wg = A.take<float>((size_t)(g.sout / 16) * 256);
-    }
     if (g.split != SPLIT_NONE) {
         g.wproj = A.take<float>((size_t)(g.S / 8) * 2048);
         g.bproj = A.take<float>(256);
@@ -39,11 +30,9 @@ void alloc_gvp(Arena &A, HostGvp &g, std::set<std::string> &expected, const std:
     if (g.split == SPLIT_SRC_DST) g.wproj_dst = A.take<float>((size_t)(g.S / 8) * 2048);
     // a split first Linear exists only at the head of an edge-message chain
     if ((g.split != SPLIT_NONE) != (g.chain_pos == 0)) set_error("internal: GVP split/chain position mismatch");
-    if (g.chain_pos >= 0) {
-        g.chain = A.take<float>((size_t)g.chain_chunks() * (g.sout / 16) * 256);
-        g.whp = A.take<float>(g.chain_pos == 0 ? 9 * 256 : 256);
-        g.wup = A.take<float>((size_t)g.n_ht() * 256);
-    }
+    g.chain = A.take<float>((size_t)g.chain_chunks() * (g.sout / 16) * 256);
+    g.whp = A.take<float>(g.chain_pos == 0 ? 9 * 256 : 256);
+    g.wup = A.take<float>((size_t)g.n_ht() * 256);
     for (const char *s : {".Wh", ".Wu", ".to_feats_out.0.weight", ".to_feats_out.0.bias", ".scalar_to_vector_gates.weight",
                           ".scalar_to_vector_gates.bias"})
         expected.insert(prefix + s);
@@ -72,7 +61,6 @@ kpd_status load_gvp_tensor(HostGvp &g, const std::string &param, const char *nam
     const int k_all = g.s_in + g.h;
     if (param == "Wh") {
         KPD_TRY(want_shape(name, shape, ndim, {g.vin, g.h}));
-        if (g.chain_pos < 0) KPD_TRY(copy_pad(w, g.vin * g.h, g.Wh, g.vin * g.h, st));
         if (g.chain_pos == 0) {
             // input vectors arrive as [x_diff | 16 source | (16 destination)] (gvp.py:474-480); the kernel feeds them as
             // tiles [source], [destination], [x_diff]
@@ -80,14 +68,12 @@ kpd_status load_gvp_tensor(HostGvp &g, const std::string &param, const char *nam
             KPD_TRY(pack_chain_frag(w, 1, g.h, g.h, 1, GV, g.n_ht(), g.whp, st));
             if (dst) KPD_TRY(pack_chain_frag(w, 1, g.h, g.h, 1 + GV, GV, g.n_ht(), g.whp + 3 * 256, st));
             KPD_TRY(pack_chain_frag(w, 1, g.h, g.h, 0, 1, g.n_ht(), g.whp + 6 * 256, st));
-        } else if (g.chain_pos > 0) {
+        } else {
             KPD_TRY(pack_chain_frag(w, 1, g.h, g.h, 0, g.vin, 1, g.whp, st));
         }
     } else if (param == "Wu") {
         KPD_TRY(want_shape(name, shape, ndim, {g.h, g.vout}));
-        if (g.chain_pos < 0) KPD_TRY(copy_pad(w, g.h * g.vout, g.Wu, g.h * g.vout, st));
-        if (g.chain_pos >= 0)
-            for (int ht = 0; ht < g.n_ht(); ++ht)
+        for (int ht = 0; ht < g.n_ht(); ++ht)
                 KPD_TRY(pack_chain_frag(w, 1, g.vout, g.vout, 16 * ht, std::min(16, g.h - 16 * ht), 1, g.wup + ht * 256, st));
     } else if (param == "to_feats_out.0.weight") {
         KPD_TRY(want_shape(name, shape, ndim, {g.sout, k_all}));
@@ -103,10 +89,8 @@ kpd_status load_gvp_tensor(HostGvp &g, const std::string &param, const char *nam
         } else if (g.split == SPLIT_SRC_DST) {  // [h_src S | rbf 16 | h_dst S | sh h]
             KPD_TRY(pack_block(0, g.wproj));
             KPD_TRY(pack_block(g.S + 16, g.wproj_dst));
-        } else if (g.chain_pos < 0) {
-            KPD_TRY(pack_gemm_weight_ng(w, g.sout, k_all, 0, k_all, g.ng, g.wp, st));
         }
-        if (g.chain_pos >= 0) {
+        {
             const int nts = g.sout / 16, ch = nts * 256;
             int c = 0;
             if (g.chain_pos == 0) {
@@ -116,8 +100,8 @@ kpd_status load_gvp_tensor(HostGvp &g, const std::string &param, const char *nam
                     KPD_TRY(pack_chain_frag(w, k_all, 1, g.sout, sh0 + 16 * ht, std::min(16, g.h - 16 * ht), nts,
                                             g.chain + (size_t)(c++) * ch, st));
             } else {
-                for (int nt = 0; nt < nts; ++nt)
-                    KPD_TRY(pack_chain_frag(w, k_all, 1, g.sout, 16 * nt, 16, nts, g.chain + (size_t)(c++) * ch, st));
+                for (int kc = 0; kc < g.s_in / 16; ++kc)
+                    KPD_TRY(pack_chain_frag(w, k_all, 1, g.sout, 16 * kc, 16, nts, g.chain + (size_t)(c++) * ch, st));
                 KPD_TRY(pack_chain_frag(w, k_all, 1, g.sout, g.s_in, std::min(16, g.h), nts, g.chain + (size_t)(c++) * ch, st));
             }
         }
@@ -127,8 +111,7 @@ kpd_status load_gvp_tensor(HostGvp &g, const std::string &param, const char *nam
         KPD_TRY(copy_pad(w, g.sout, g.split != SPLIT_NONE ? g.bproj : g.b, 256, st));
     } else if (param == "scalar_to_vector_gates.weight") {
         KPD_TRY(want_shape(name, shape, ndim, {g.vout, g.sout}));
-        if (g.chain_pos < 0) KPD_TRY(pack_gate_weight(w, g.vout, g.sout, g.wg, st));
-        if (g.chain_pos >= 0) {
+        {
             float *gch = g.chain + (size_t)(g.chain_chunks() - 1) * (g.sout / 16) * 256;
             for (int nt = 0; nt < g.sout / 16; ++nt)
                 KPD_TRY(pack_chain_frag(w, g.sout, 1, g.vout, 16 * nt, 16, 1, gch + nt * 256, st));

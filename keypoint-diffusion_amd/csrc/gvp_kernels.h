@@ -6,28 +6,17 @@ namespace kpd {
 
 constexpr int GV = 16;                 // vector channels (vector_size; 16 in every config)
 constexpr int GVH = 33;                // largest hidden vector width (x_diff + 16 source + 16 destination vectors)
-constexpr int VST = 100;               // floats per row of an LDS vector buffer (33 x 3, padded)
-constexpr int NG_G = 34;               // k-groups of the widest GVP GEMM (K = 256 + 16 = 272)
-constexpr int SA_G = 276;              // LDS row stride of the GVP A tile
-constexpr int GVP_LDS_FLOATS = TM * SA_G + 3 * TM * VST + 4 * TM + 16;
-constexpr int GVP_LDS_BYTES = GVP_LDS_FLOATS * 4;
 
 // One GVP (models/gvp.py:43-116) in kernel-ready form.
 struct GvpW {
-    const float *Wh;      // [vin][h]   as stored (models/gvp.py:68)
-    const float *Wu;      // [h][vout]
-    const float *wp;      // packed to_feats_out block for the A-tile columns (ng * 2048 floats)
-    const float *b;       // [256] bias, zero padded
-    const float *wg;      // packed scalar_to_vector_gates for the 16x16x4 MFMA ([sout/16][64][4])
-    const float *bg;      // [16]
+    const float *b;       // [256] to_feats_out bias, zero padded (zero for the split head of a message chain)
+    const float *bg;      // [16] gate bias
     int vin, h, vout;
-    int n_s;              // A-tile columns holding the scalar inputs; sh goes to [n_s, n_s + h)
-    int sout;             // valid scalar outputs (256, 128 or 64)
-    int ng;               // k-groups of the packed block
+    int sout;             // scalar outputs (S, or 64 for the noise head)
     int vec_sigmoid;      // 1: sigmoid gate, 0: identity (last noise GVP)
-    // chained edge kernel (gvp_chain.hip): 16x16x4 A-operand fragments, see HostGvp / load_gvp_tensor
-    const float *chain;   // weight chunks streamed through LDS: scalar GEMM k-slabs, then the gate slab
-    const float *whp;     // Wh fragments ([3 input tiles][3 hidden tiles][256] first GVP, [256] otherwise)
+    // 16x16x4 A-operand fragments, see HostGvp / load_gvp_tensor
+    const float *chain;   // weight chunks: to_feats_out k-slabs, then the gate slab
+    const float *whp;     // Wh fragments ([3 input tiles][3 hidden tiles][256] at the head of a message chain, [256] otherwise)
     const float *wup;     // Wu fragments ([hidden tile][256])
 };
 
@@ -95,7 +84,6 @@ struct GvpNoiseArgs {
     float *eps_h, *eps_x;
 };
 
-kpd_status gvp_kernels_init();
 kpd_status launch_gvp_embed(const float *in, int n, int fin, const float *W, const float *b, const float *ln_w,
                             const float *ln_b, const float *t, const int *bidx, int S, float *out, hipStream_t st);
 kpd_status launch_gvp_proj(const GvpProjArgs &a, hipStream_t st);

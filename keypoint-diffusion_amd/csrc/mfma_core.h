@@ -15,7 +15,7 @@
 //                                                               [k = 8 g + 4 (lane >> 5) + j]
 // with zeros for k >= K or n >= N.  Output column 256 (the "+1" of hidden_nf + 1) is not
 // worth a ninth 32-wide MFMA column tile; it is a 264-long dot per row done on the VALU
-// (extra_col) against wx[k] = W[256][k].
+// (row_dot_chunks) against wx[k] = W[256][k].
 #pragma once
 #include "common.h"
 
@@ -93,47 +93,6 @@ __device__ __forceinline__ void gemm_rows64_t(const float *__restrict__ A, const
         KPD_GEMM_LOAD(ya0, ya1, yb0, yb1, g3)
     }
     if (NG_ & 1) {
-        __builtin_amdgcn_sched_barrier(0);
-        KPD_GEMM_STEP(xa0, xa1, xb0, xb1)
-    }
-}
-
-__device__ __forceinline__ void gemm_rows64(const float *__restrict__ A, const float *__restrict__ Wp,
-                                            f32x16 (&acc)[2][2], int wave, int lane) {
-    gemm_rows64_t<NG, SA>(A, Wp, acc, wave, lane);
-}
-
-// Same pipeline with a run-time number of k-groups (the GVP blocks use K = 40 ... 272).
-template <int SA_>
-__device__ __forceinline__ void gemm_rows64_rt(const float *__restrict__ A, const float *__restrict__ Wp, int ng,
-                                               f32x16 (&acc)[2][2], int wave, int lane) {
-    const int r = lane & 31, h = lane >> 5;
-    const float *a0p = A + r * SA_ + 4 * h;
-    const float *a1p = A + (32 + r) * SA_ + 4 * h;
-    const f32x4 *bp = reinterpret_cast<const f32x4 *>(Wp) + (wave * 64 + lane) * 2;
-    f32x4 xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1;
-    const int last = ng - 1;
-    KPD_GEMM_LOAD(xa0, xa1, xb0, xb1, 0)
-    {
-        const int g1 = 1 < ng ? 1 : last;
-        KPD_GEMM_LOAD(ya0, ya1, yb0, yb1, g1)
-    }
-    const int pairs = ng >> 1;
-#pragma unroll 1
-    for (int p = 0; p < pairs; ++p) {
-        const int g = 2 * p;
-        __builtin_amdgcn_sched_barrier(0);
-        KPD_GEMM_STEP(xa0, xa1, xb0, xb1)
-        __builtin_amdgcn_sched_barrier(0);
-        const int g2 = g + 2 < ng ? g + 2 : last;
-        KPD_GEMM_LOAD(xa0, xa1, xb0, xb1, g2)
-        __builtin_amdgcn_sched_barrier(0);
-        KPD_GEMM_STEP(ya0, ya1, yb0, yb1)
-        __builtin_amdgcn_sched_barrier(0);
-        const int g3 = g + 3 < ng ? g + 3 : last;
-        KPD_GEMM_LOAD(ya0, ya1, yb0, yb1, g3)
-    }
-    if (ng & 1) {
         __builtin_amdgcn_sched_barrier(0);
         KPD_GEMM_STEP(xa0, xa1, xb0, xb1)
     }
@@ -286,30 +245,6 @@ __device__ __forceinline__ float row_dot_chunks(const float *__restrict__ T, con
     return s;
 }
 
-// Output column 256 (the "+1" of hidden_nf + 1): dot of every A row with wx[k] = W[256][k] on the
-// VALU.  Four consecutive threads own row tid >> 2 and stride the 66 float4 chunks of the row.
-// Returns the full dot on all 4 lanes.
-__device__ __forceinline__ float extra_col(const float *__restrict__ A, const float *__restrict__ wx, int tid) {
-    const int row = tid >> 2, q = tid & 3;
-    const f32x4 *a = reinterpret_cast<const f32x4 *>(A + row * SA);
-    const f32x4 *w = reinterpret_cast<const f32x4 *>(wx);
-    float s = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 17; ++i) {
-        const int c = q + 4 * i;
-        if (c < KP / 4) {
-            const f32x4 av = a[c], wv = w[c];
-            s = fmaf(av[0], wv[0], s);
-            s = fmaf(av[1], wv[1], s);
-            s = fmaf(av[2], wv[2], s);
-            s = fmaf(av[3], wv[3], s);
-        }
-    }
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
-    return s;
-}
-
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
 // counter, i.e. every wave would wait at each barrier for its outstanding global stores (segment
 // pieces, projections) to be acknowledged; nothing in these kernels reads those back.
@@ -322,27 +257,5 @@ __device__ __forceinline__ int acc_row(int mt, int reg, int lane) {
     return 32 * mt + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
 }
 __device__ __forceinline__ int acc_col(int nt, int wave, int lane) { return 64 * wave + 32 * nt + (lane & 31); }
-
-// dot over the 257 valid columns of row (tid >> 2) of a T tile with a weight vector (w in LDS or
-// global, 16-B aligned).  Four consecutive threads own a row and stride its 64 float4 chunks.
-// Returns the full dot on all 4 lanes.
-__device__ __forceinline__ float row_dot257(const float *__restrict__ T, const float *__restrict__ w, int tid) {
-    const int row = tid >> 2, q = tid & 3;
-    const f32x4 *a = reinterpret_cast<const f32x4 *>(T + row * SA);
-    const f32x4 *wv = reinterpret_cast<const f32x4 *>(w);
-    float s = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const f32x4 av = a[q + 4 * i], wq = wv[q + 4 * i];
-        s = fmaf(av[0], wq[0], s);
-        s = fmaf(av[1], wq[1], s);
-        s = fmaf(av[2], wq[2], s);
-        s = fmaf(av[3], wq[3], s);
-    }
-    if (q == 0) s = fmaf(T[row * SA + 256], w[256], s);
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
-    return s;
-}
 
 }  // namespace kpd

@@ -67,32 +67,6 @@ kpd_status pack_gemm_weight(const float *src, int n_out, int ld, int col0, int K
     return KPD_OK;
 }
 
-kpd_status pack_gemm_weight_ng(const float *src, int n_out, int ld, int col0, int K, int ng, float *wp, hipStream_t st) {
-    KPD_REQUIRE(K <= 8 * ng && n_out <= 256, KPD_ERR_WEIGHTS, "pack: K=%d n_out=%d exceed %d/256", K, n_out, 8 * ng);
-    const int n = ng * 4 * 64 * 8;
-    hipLaunchKernelGGL(k_pack_gemm_weight, dim3(cdiv(n, 256)), dim3(256), 0, st, src, n_out, ld, col0, K, wp,
-                       static_cast<float *>(nullptr), n);
-    KPD_LAUNCH_CHECK();
-    return KPD_OK;
-}
-
-// scalar_to_vector_gates weight [vout][K] -> 16x16x4 MFMA B fragments: dst[(g*64 + lane)*4 + j] =
-// W[n = lane & 15][k = 16 g + 4 (lane >> 4) + j], zero for n >= vout.
-__global__ void k_pack_gate_weight(const float *__restrict__ src, int vout, int K, float *__restrict__ dst) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (K / 16) * 256) return;
-    const int j = idx & 3, lane = (idx >> 2) & 63, g = idx >> 8;
-    const int n = lane & 15, k = 16 * g + 4 * (lane >> 4) + j;
-    dst[idx] = n < vout ? src[(size_t)n * K + k] : 0.0f;
-}
-
-kpd_status pack_gate_weight(const float *src, int vout, int K, float *dst, hipStream_t st) {
-    KPD_REQUIRE(K % 16 == 0 && K <= 256 && vout <= 16, KPD_ERR_WEIGHTS, "gate weight [%d][%d] unsupported", vout, K);
-    hipLaunchKernelGGL(k_pack_gate_weight, dim3(cdiv((K / 16) * 256, 256)), dim3(256), 0, st, src, vout, K, dst);
-    KPD_LAUNCH_CHECK();
-    return KPD_OK;
-}
-
 __global__ void k_pack_chain_frag(const float *__restrict__ src, int sn, int sk, int n_valid, int k_base, int k_valid,
                                   int n_tiles, float *__restrict__ dst) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;

@@ -310,7 +310,6 @@ extern "C" kpd_status kpd_recenc_create(const kpd_recenc_config *cfg, kpd_recenc
                 "conv counts");
     KPD_REQUIRE(cfg->message_norm_mode >= 0 && cfg->message_norm_mode <= 2, KPD_ERR_INVALID, "message_norm_mode");
     KPD_TRY(egnn_kernels_init());
-    KPD_TRY(gvp_kernels_init());
     kpd_recenc *m = new kpd_recenc();
     m->cfg = *cfg;
     const int S = m->S = cfg->out_scalar_size, K = cfg->n_keypoints, F = cfg->in_scalar_size;
