@@ -240,9 +240,11 @@ def main():
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'egnn_all_atom dynamics (6 EGNN layers, hidden 256, update_kp_feat), batch of {B} '
-                                   f'synthetic {args.n_rec}-atom pockets / {args.n_lig}-atom ligands per GPU, '
+                                   f'synthetic {"150-600" if args.ragged else args.n_rec}-atom pockets / '
+                                   f'{"15-35" if args.ragged else args.n_lig}-atom ligands per GPU, '
                                    f'T={N_TIMESTEPS}, seeded random-init weights, every step taken from the t=T ligand state',
-                       'batch_per_gpu': B, 'n_rec': args.n_rec, 'n_lig': args.n_lig, 'parallelism': f'dp{world}'},
+                       'batch_per_gpu': B, 'n_rec': 'U{150..600}' if args.ragged else args.n_rec,
+                       'n_lig': 'U{15..35}' if args.ragged else args.n_lig, 'parallelism': f'dp{world}'},
             'complex_steps_per_s': steps_per_s * B,
             'ligands_per_min': steps_per_s * B * 60.0 / N_TIMESTEPS,
             'edges_per_step_layer': counts,
