@@ -270,6 +270,13 @@ kpd_status kpd_sample_update(int32_t B, const int32_t *lig_ptr, const int32_t *k
 kpd_status kpd_step_coefficients(const float *gamma, int32_t n_gamma, const float *s, const float *t,
                                  int32_t B, float *coef, void *stream);
 
+/* Sharding-invariant N(0,1) noise for the ligand rows of a batch (opt-in replacement of the global torch.randn draws of
+ * ligand_diffuser.py:367, 530-531): out [n_nodes, width] with rows of complex b =
+ * [node_ptr[b], node_ptr[b+1]).  Philox4x32-10 keyed by (seed, complex_id[b]), counter (element, step, tag): the values do
+ * not depend on batch composition or rank.  complex_id [B] device int64 (global index of the complex in the job). */
+kpd_status kpd_complex_noise(int32_t B, const int32_t *node_ptr, int32_t width, const int64_t *complex_id,
+                             uint64_t seed, int32_t step, int32_t tag, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

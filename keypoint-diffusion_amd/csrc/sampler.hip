@@ -59,9 +59,64 @@ __global__ void k_step_coef(const float *__restrict__ gamma, int n_gamma, const 
     coef[3 * b + 2] = sqrtf(sigma2_ts) * sig_s / sig_t;
 }
 
+// ---- per-complex counter-based noise ------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11) keyed by (seed, complex id), counter = (element quad within the complex, step,
+// tag); Box-Muller on the four 32-bit outputs.  The value of an element depends only on (seed, complex id, step, tag,
+// position inside the complex), never on which batch or rank the complex was placed in, so a sharded run reproduces the
+// single-process run.  The reference draws one global torch.randn over the batch (ligand_diffuser.py:367,
+// 530-531); this is the opt-in replacement, torch.randn stays the default.
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        const unsigned n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+__global__ void k_complex_noise(const int *__restrict__ ptr, int B, int width, const long long *__restrict__ complex_id,
+                                unsigned long long seed, int step, int tag, float *__restrict__ out) {
+    const int b = blockIdx.x;
+    const int lo = ptr[b], n = (ptr[b + 1] - lo) * width;
+    const unsigned long long cid = (unsigned long long)complex_id[b];
+    const unsigned k0 = (unsigned)seed ^ (unsigned)cid, k1 = (unsigned)(seed >> 32) ^ (unsigned)(cid >> 32) ^ 0x5bd1e995u;
+    float *o = out + (size_t)lo * width;
+    for (int quad = threadIdx.x; 4 * quad < n; quad += blockDim.x) {
+        unsigned c[4] = {(unsigned)quad, (unsigned)step, (unsigned)tag, 0u};
+        philox4x32_10(c, k0, k1);
+        float z[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float u1 = ((float)(c[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);        // (0, 1)
+            const float u2 = ((float)(c[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+            const float r = sqrtf(-2.0f * logf(u1));
+            float sn, cs;
+            sincosf(6.283185307179586f * u2, &sn, &cs);
+            z[2 * h] = r * cs;
+            z[2 * h + 1] = r * sn;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (4 * quad + i < n) o[4 * quad + i] = z[i];
+    }
+}
+
 }  // namespace kpd
 
 using namespace kpd;
+
+extern "C" kpd_status kpd_complex_noise(int32_t B, const int32_t *node_ptr, int32_t width, const int64_t *complex_id, uint64_t seed,
+                                        int32_t step, int32_t tag, float *out, void *stream) {
+    KPD_REQUIRE(node_ptr && complex_id && out, KPD_ERR_INVALID, "null argument");
+    KPD_REQUIRE(B >= 1 && width >= 1, KPD_ERR_INVALID, "B=%d width=%d", B, width);
+    hipLaunchKernelGGL(k_complex_noise, dim3(B), dim3(128), 0, static_cast<hipStream_t>(stream), node_ptr, B, width,
+                       reinterpret_cast<const long long *>(complex_id), (unsigned long long)seed, step, tag, out);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
 
 extern "C" kpd_status kpd_step_coefficients(const float *gamma, int32_t n_gamma, const float *s, const float *t, int32_t B,
                                             float *coef, void *stream) {

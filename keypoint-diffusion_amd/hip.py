@@ -129,6 +129,8 @@ def lib():
     L.kpd_build_lig_graph.argtypes = [C.POINTER(KpdBatch), C.c_float, C.c_int32, C.c_float, C.c_int32, C.POINTER(KpdLigGraph),
                                       C.c_void_p]
     L.kpd_sample_update.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 8 + [C.c_int32, C.c_void_p]
+    L.kpd_complex_noise.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_void_p,
+                                    C.c_void_p]
     L.kpd_step_coefficients.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     _lib = L
     return L
@@ -139,7 +141,7 @@ EXPORTS = [
     'kpd_last_error', 'kpd_version', 'kpd_build_lig_graph',
     'kpd_egnn_create', 'kpd_egnn_destroy', 'kpd_egnn_load_weight', 'kpd_egnn_commit', 'kpd_egnn_reserve',
     'kpd_egnn_forward', 'kpd_egnn_debug_state', 'kpd_egnn_last_counts', 'kpd_egnn_profile',
-    'kpd_egnn_profile_read', 'kpd_sample_update', 'kpd_step_coefficients',
+    'kpd_egnn_profile_read', 'kpd_sample_update', 'kpd_step_coefficients', 'kpd_complex_noise',
     'kpd_gvp_create', 'kpd_gvp_destroy', 'kpd_gvp_load_weight', 'kpd_gvp_commit', 'kpd_gvp_reserve',
     'kpd_gvp_forward', 'kpd_gvp_debug_state',
     'kpd_recenc_create', 'kpd_recenc_destroy', 'kpd_recenc_load_weight', 'kpd_recenc_commit', 'kpd_recenc_reserve',
@@ -512,6 +514,17 @@ def step_coefficients(gamma: torch.Tensor, s: torch.Tensor, t: torch.Tensor) -> 
     check(lib().kpd_step_coefficients(gamma.data_ptr(), int(gamma.shape[0]), s.data_ptr(), t.data_ptr(), int(s.shape[0]),
                                       coef.data_ptr(), _stream()))
     return coef
+
+
+def complex_noise(pb: PreparedBatch, width: int, complex_ids: torch.Tensor, seed: int, step: int, tag: int) -> torch.Tensor:
+    """[n_lig, width] N(0,1) noise that depends only on (seed, complex id, step, tag, position in the complex)
+    (kpd_complex_noise): a sharded run draws what the single-process run draws."""
+    if not (complex_ids.is_cuda and complex_ids.dtype == torch.int64 and complex_ids.numel() == pb.B):
+        raise KpdError('complex_ids must be an int64 GPU tensor with one id per complex')
+    out = torch.empty(pb.n_lig, int(width), device=complex_ids.device, dtype=torch.float32)
+    check(lib().kpd_complex_noise(pb.B, _ptr(pb.lig_ptr), int(width), _ptr(complex_ids.contiguous()), int(seed) & (2 ** 64 - 1),
+                                  int(step), int(tag), _ptr(out), _stream()))
+    return out
 
 
 def sample_update(pb: PreparedBatch, atom_nf, lig_x, lig_h, kp_x, eps_x, eps_h, noise_x, noise_h, coef):

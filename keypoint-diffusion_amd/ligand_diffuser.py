@@ -158,9 +158,22 @@ class KeypointDiffusion(nn.Module):
         sig_s, sig_t = self.sigma(g_s), self.sigma(g_t)
         return torch.stack([alpha_ts, sigma2_ts / alpha_ts / sig_t, sigma_ts * sig_s / sig_t], dim=1).contiguous()
 
-    def sample_p_zs_given_zt(self, s, t, g, batch_idxs=None, noise=None):
+    def use_complex_noise(self, seed):
+        """Opt in to sharding-invariant noise: every draw of the sampler becomes a function of (seed, complex id, timestep,
+        position in the complex) (kpd_complex_noise), so a run split over ranks reproduces the single-process run.
+        `seed=None` returns to the reference behaviour (one global torch.randn per draw)."""
+        self._noise_seed = None if seed is None else int(seed)
+        return self
+
+    def _draw(self, g, width, complex_ids, step, tag):
+        if getattr(self, '_noise_seed', None) is None or complex_ids is None:
+            return torch.randn(g.num_nodes('lig'), width, device=g.device)
+        return hip.complex_noise(g.prepared(), width, complex_ids, self._noise_seed, step, tag)
+
+    def sample_p_zs_given_zt(self, s, t, g, batch_idxs=None, noise=None, complex_ids=None, step=0):
         """One reverse step (ligand_diffuser.py:497-538).  `noise` = (pos_noise, feat_noise) may be
-        injected for reproducible parity tests; by default it is drawn with torch.randn as upstream."""
+        injected for reproducible parity tests; by default it is drawn with torch.randn as upstream
+        (or per complex, `use_complex_noise`, when `complex_ids` [B] int64 and the integer `step` are given)."""
         lig, kp = g.nodes['lig'].data, g.nodes['kp'].data
         for d, k in ((lig, 'x_0'), (lig, 'h_0'), (kp, 'x_0')):
             if not (d[k].is_contiguous() and d[k].dtype == torch.float32):
@@ -168,14 +181,15 @@ class KeypointDiffusion(nn.Module):
         coef = self.step_coefficients(s, t)
         eps_h, eps_x = self.dynamics(g, t, batch_idxs)
         if noise is None:
-            noise = (torch.randn(lig['x_0'].shape, device=g.device), torch.randn(lig['h_0'].shape, device=g.device))
+            noise = (self._draw(g, 3, complex_ids, step, 0), self._draw(g, lig['h_0'].shape[1], complex_ids, step, 1))
         hip.sample_update(g.prepared(), self.n_lig_features, lig['x_0'], lig['h_0'], kp['x_0'], eps_x, eps_h,
                           noise[0], noise[1], coef)
         return g
 
     @torch.no_grad()
-    def sample_from_encoded_receptors(self, g, visualize=False, init_lig_pos: torch.Tensor = None):
-        """Full reverse loop for a batch of encoded pockets (ligand_diffuser.py:342-469)."""
+    def sample_from_encoded_receptors(self, g, visualize=False, init_lig_pos: torch.Tensor = None, complex_ids=None):
+        """Full reverse loop for a batch of encoded pockets (ligand_diffuser.py:342-469).  `complex_ids` [B] int64
+        (global index of every complex in the job) selects the per-complex noise streams of `use_complex_noise`."""
         device, B = g.device, g.batch_size
         init_kp_com = G.readout_nodes(g, feat='x_0', op='mean', ntype='kp')
         bidx = G.get_batch_idxs(g)
@@ -186,8 +200,10 @@ class KeypointDiffusion(nn.Module):
         else:
             frame = G.readout_nodes(g, feat='x_0', op='mean', ntype='rec')
         g.nodes['kp'].data['x_0'] = g.nodes['kp'].data['x_0'] - frame[kp_b]
-        for feat in ('x_0', 'h_0'):
-            g.nodes['lig'].data[feat] = torch.randn(g.nodes['lig'].data[feat].shape, device=device)
+        if complex_ids is not None:
+            complex_ids = complex_ids.to(device).long()
+        for tag, feat in enumerate(('x_0', 'h_0')):
+            g.nodes['lig'].data[feat] = self._draw(g, g.nodes['lig'].data[feat].shape[1], complex_ids, self.n_timesteps, tag)
         g = self.remove_com(g, lig_b, kp_b, com='ligand')
 
         def snapshot():
@@ -204,7 +220,8 @@ class KeypointDiffusion(nn.Module):
             frames_x.append(fx), frames_h.append(fh)
         ones = torch.ones(B, device=device)
         for s in reversed(range(self.n_timesteps)):
-            g = self.sample_p_zs_given_zt(ones * (s / self.n_timesteps), ones * ((s + 1) / self.n_timesteps), g, bidx)
+            g = self.sample_p_zs_given_zt(ones * (s / self.n_timesteps), ones * ((s + 1) / self.n_timesteps), g, bidx,
+                                          complex_ids=complex_ids, step=s)
             if visualize:
                 fx, fh = snapshot()
                 frames_x.append(fx), frames_h.append(fh)

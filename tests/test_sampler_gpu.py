@@ -95,3 +95,40 @@ def test_forward_only_contract(cuda):
         model.dynamics(g, torch.tensor([0.5], device=cuda), None)          # grad enabled: backward not implemented
     with pytest.raises(NotImplementedError):
         model(g, None)
+
+
+def test_complex_noise_is_sharding_invariant(cuda):
+    """kpd_complex_noise: a complex draws the same values whatever batch it sits in; N(0,1) statistics."""
+    from keypoint_diffusion_amd import hip
+    gs = synth.synth_complexes([60, 90, 40, 75], [11, 17, 5, 23], 20, CUT, seed=3)
+    ids = torch.tensor([100, 101, 102, 103], device=cuda)
+    full = G.batch(gs).to(cuda)
+    part = G.batch(gs[2:]).to(cuda)
+    for width in (3, 10):
+        a = hip.complex_noise(full.prepared(), width, ids, 1234, 17, 1)
+        b = hip.complex_noise(part.prepared(), width, ids[2:], 1234, 17, 1)
+        assert torch.equal(a[11 + 17:], b)                                       # bitwise, independent of batch composition
+        assert not torch.equal(a, hip.complex_noise(full.prepared(), width, ids, 1234, 18, 1))       # step, tag, seed matter
+        assert not torch.equal(a, hip.complex_noise(full.prepared(), width, ids, 1234, 17, 0))
+        assert not torch.equal(a, hip.complex_noise(full.prepared(), width, ids, 1235, 17, 1))
+    big = G.batch(synth.synth_complexes([30] * 64, [60] * 64, 20, CUT, seed=5)).to(cuda)
+    z = hip.complex_noise(big.prepared(), 10, torch.arange(64, device=cuda), 7, 0, 0)
+    assert abs(float(z.mean())) < 0.02 and abs(float(z.std()) - 1.0) < 0.02
+    assert abs(float((z ** 4).mean()) - 3.0) < 0.2                               # kurtosis of a normal
+
+
+def test_sharded_sampling_reproduces_single_process(cuda):
+    """Reverse loop on [c0..c3] together vs on two shards with the same complex ids: same ligands up to fp32 summation order."""
+    model = _model('egnn', T=8).to(cuda).use_complex_noise(99)
+    gs = synth.synth_complexes([90, 140, 60, 110], [11, 17, 9, 14], 20, CUT, seed=3)
+    ids = torch.tensor([40, 41, 42, 43])
+    with torch.no_grad():
+        full = model.encode_receptors(G.batch(gs).to(cuda))
+        px, ph = model.sample_from_encoded_receptors(full, complex_ids=ids)
+        out = []
+        for lo, hi in ((0, 2), (2, 4)):
+            gsh = model.encode_receptors(G.batch(synth.synth_complexes([90, 140, 60, 110], [11, 17, 9, 14], 20, CUT, seed=3)[lo:hi]).to(cuda))
+            x, h = model.sample_from_encoded_receptors(gsh, complex_ids=ids[lo:hi])
+            out += list(zip(x, h))
+    for (x, h), fx, fh in zip(out, px, ph):
+        assert util.rel_err(x, fx) < 1e-3 and util.rel_err(h, fh) < 1e-3
