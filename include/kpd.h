@@ -277,6 +277,36 @@ kpd_status kpd_step_coefficients(const float *gamma, int32_t n_gamma, const floa
 kpd_status kpd_complex_noise(int32_t B, const int32_t *node_ptr, int32_t width, const int64_t *complex_id,
                              uint64_t seed, int32_t step, int32_t tag, float *out, void *stream);
 
+/* Input side: the receptor part of build_initial_complex_graph
+ * (data_processing/pdbbind_processing.py:221-274) for a whole batch of pockets taken from the flat dataset arrays
+ * (data_processing/crossdocked/dataset.py:62-76, 135-145): rr = torch_cluster.radius_graph(rec, r = cutoffs['rr'],
+ * max_num_neighbors = 100) per pocket (:245) and same_res = res_idx[src] == res_idx[dst] per edge (:248).
+ *   rec_x [n_rec,3], rec_ptr [B+1] (device; pocket b = rows [rec_ptr[b], rec_ptr[b+1]), at most max_rec <= 2048 each),
+ *   res_idx [n_rec] or NULL.  Out: src/dst [cap] dst-major with src ascending (global row numbers), rowptr [n_rec+1],
+ *   per_graph [B], same_res [cap] bytes or NULL, counts [2] = {n_edges, 0} (edges beyond cap are counted, not written);
+ *   scratch: kpd_rec_graph_scratch_bytes(n_rec, B) device bytes.  The complete rec -> kp edge list (:251-253) is
+ *   implicit (dst-major, every receptor atom of the pocket) and is never materialised by this library. */
+int64_t kpd_rec_graph_scratch_bytes(int32_t n_rec, int32_t B);
+kpd_status kpd_build_rec_graph(const float *rec_x, const int32_t *rec_ptr, int32_t B, int32_t n_rec, int32_t max_rec,
+                               float r, int32_t max_nn, const int32_t *res_idx, int32_t cap, int32_t *src, int32_t *dst,
+                               int32_t *rowptr, int32_t *per_graph, uint8_t *same_res, int32_t *counts, void *scratch,
+                               void *stream);
+
+/* Output side of sampling: element decode and XYZ text for a batch of sampled ligands.
+ * Replaces the tensor -> text part of write_sampled_ligands (sample.py:66-90: torch.argmax over the feature columns,
+ * dataset.lig_atom_idx_to_element) and write_xyz_file (utils.py:11-21: "<n>\n\n" + "<el> <x:.3f> <y:.3f> <z:.3f>\n"
+ * per atom), as analysis/molecule_builder.py:47-48 calls it per ligand; bond perception (openbabel / rdkit) stays with
+ * the caller.  The bytes equal Python's: "%.3f" of the exact fp32 value, round-half-even, '-0.000', 'nan', 'inf'.
+ *   pos [n_atoms,3], feat [n_atoms,F], lig_ptr [B+1] (device); symbols [F] device, each element symbol as up to four
+ *   NUL-padded bytes packed little-endian; elem [n_atoms] out (argmax, first maximum); text [capacity] out; text_ptr
+ *   [B+1] int64 out (ligand b's block = text[text_ptr[b] : text_ptr[b+1]]; text_ptr[B] is the size needed, also when it
+ *   exceeds capacity); status [1] out: bit 0 = a coordinate with |x| >= 2^53 was printed as '?', bit 1 = capacity too
+ *   small (nothing written for the ligands that do not fit); scratch: kpd_xyz_scratch_bytes(n_atoms, B) device bytes. */
+int64_t kpd_xyz_scratch_bytes(int32_t n_atoms, int32_t B);
+kpd_status kpd_xyz_emit(const float *pos, const float *feat, const int32_t *lig_ptr, int32_t n_atoms, int32_t B,
+                        int32_t F, const uint32_t *symbols, int32_t *elem, uint8_t *text, int64_t capacity,
+                        int64_t *text_ptr, int32_t *status, void *scratch, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -384,6 +384,13 @@ __global__ void k_klr_fill(const float *__restrict__ lig_x, const int *__restric
     }
 }
 
+// same-residue flag of every rr edge (pdbbind_processing.py:248: res_idx[src] == res_idx[dst])
+__global__ void k_same_res(const int *__restrict__ src, const int *__restrict__ dst, const int *__restrict__ n_edges, int cap,
+                           const int *__restrict__ res_idx, unsigned char *__restrict__ same_res) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < min(*n_edges, cap)) same_res[e] = res_idx[src[e]] == res_idx[dst[e]];
+}
+
 }  // namespace kpd
 
 using namespace kpd;
@@ -498,3 +505,27 @@ kpd_status launch_lig_graph(const kpd_batch *bt, float ll_cutoff, int ll_k, floa
                                g->ll_dst, g->ll_rowptr, g->ll_per_graph, ll_deg_tmp, ll_off_tmp, kl_off_tmp, g->counts, st);
 }
 }  // namespace kpd
+
+extern "C" int64_t kpd_rec_graph_scratch_bytes(int32_t n_rec, int32_t B) {
+    if (n_rec < 0 || B < 0) return -1;
+    return (int64_t)((size_t)n_rec + (size_t)B + 4) * (int64_t)sizeof(int);
+}
+
+extern "C" kpd_status kpd_build_rec_graph(const float *rec_x, const int32_t *rec_ptr, int32_t B, int32_t n_rec, int32_t max_rec,
+                                          float r, int32_t max_nn, const int32_t *res_idx, int32_t cap, int32_t *src, int32_t *dst,
+                                          int32_t *rowptr, int32_t *per_graph, uint8_t *same_res, int32_t *counts, void *scratch,
+                                          void *stream) {
+    KPD_REQUIRE(rec_x && rec_ptr && src && dst && rowptr && per_graph && counts && scratch, KPD_ERR_INVALID, "null argument");
+    KPD_REQUIRE(B >= 1 && n_rec >= 1 && max_nn >= 1 && cap >= 0 && r > 0.0f, KPD_ERR_INVALID, "B=%d n_rec=%d max_nn=%d cap=%d r=%g", B,
+                n_rec, max_nn, cap, (double)r);
+    KPD_REQUIRE((res_idx == nullptr) == (same_res == nullptr), KPD_ERR_INVALID, "res_idx and same_res go together");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int *deg_tmp = static_cast<int *>(scratch), *off_tmp = deg_tmp + n_rec;
+    KPD_TRY(launch_radius_graph(rec_x, rec_ptr, B, n_rec, max_rec, r, max_nn, cap, src, dst, rowptr, per_graph, deg_tmp, off_tmp,
+                                nullptr, counts, st));
+    if (same_res && cap) {
+        hipLaunchKernelGGL(k_same_res, dim3(cdiv(cap, 256)), dim3(256), 0, st, src, dst, counts, cap, res_idx, same_res);
+        KPD_LAUNCH_CHECK();
+    }
+    return KPD_OK;
+}

@@ -132,6 +132,14 @@ def lib():
     L.kpd_complex_noise.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_void_p,
                                     C.c_void_p]
     L.kpd_step_coefficients.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    L.kpd_rec_graph_scratch_bytes.argtypes = [C.c_int32, C.c_int32]
+    L.kpd_rec_graph_scratch_bytes.restype = C.c_int64
+    L.kpd_build_rec_graph.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p,
+                                      C.c_int32] + [C.c_void_p] * 8
+    L.kpd_xyz_scratch_bytes.argtypes = [C.c_int32, C.c_int32]
+    L.kpd_xyz_scratch_bytes.restype = C.c_int64
+    L.kpd_xyz_emit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                               C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -148,6 +156,7 @@ EXPORTS = [
     'kpd_recenc_forward',
     'kpd_recegnn_create', 'kpd_recegnn_destroy', 'kpd_recegnn_load_weight', 'kpd_recegnn_commit', 'kpd_recegnn_reserve',
     'kpd_recegnn_forward',
+    'kpd_xyz_scratch_bytes', 'kpd_xyz_emit', 'kpd_rec_graph_scratch_bytes', 'kpd_build_rec_graph',
 ]
 
 
@@ -525,6 +534,72 @@ def complex_noise(pb: PreparedBatch, width: int, complex_ids: torch.Tensor, seed
     check(lib().kpd_complex_noise(pb.B, _ptr(pb.lig_ptr), int(width), _ptr(complex_ids.contiguous()), int(seed) & (2 ** 64 - 1),
                                   int(step), int(tag), _ptr(out), _stream()))
     return out
+
+
+def build_rec_graph(rec_x: torch.Tensor, rec_ptr: torch.Tensor, max_rec: int, r: float, res_idx: Optional[torch.Tensor] = None,
+                    max_nn: int = 100):
+    """rr radius graph (+ same-residue flags) of a batch of pockets on the GPU (kpd_build_rec_graph).
+    rec_x [n_rec,3] fp32, rec_ptr [B+1] int32, res_idx [n_rec] int32 or None, all on the GPU.
+    Returns (src, dst, per_graph [B], same_res bool [E] or None), dst-major with global row numbers.  One host sync
+    (the edge count) — this is input-pipeline work, once per batch, not step-path work."""
+    rec_x = _dev_f32(rec_x, 'rec_x')
+    if not (rec_ptr.is_cuda and rec_ptr.dtype == torch.int32):
+        raise KpdError('rec_ptr must be an int32 GPU tensor')
+    n_rec, B = rec_x.shape[0], rec_ptr.numel() - 1
+    if res_idx is not None and not (res_idx.is_cuda and res_idx.dtype == torch.int32 and res_idx.numel() == n_rec):
+        raise KpdError('res_idx must be an int32 GPU tensor with one entry per receptor atom')
+    dev = rec_x.device
+    cap = n_rec * max(1, min(int(max_nn), int(max_rec) - 1))
+    src = torch.empty(cap, dtype=torch.int32, device=dev)
+    dst = torch.empty(cap, dtype=torch.int32, device=dev)
+    rowptr = torch.empty(n_rec + 1, dtype=torch.int32, device=dev)
+    per_graph = torch.empty(B, dtype=torch.int32, device=dev)
+    counts = torch.empty(2, dtype=torch.int32, device=dev)
+    same = torch.empty(cap, dtype=torch.uint8, device=dev) if res_idx is not None else None
+    scratch = torch.empty(int(lib().kpd_rec_graph_scratch_bytes(n_rec, B)), dtype=torch.uint8, device=dev)
+    check(lib().kpd_build_rec_graph(_ptr(rec_x), _ptr(rec_ptr), B, n_rec, int(max_rec), float(r), int(max_nn),
+                                    _ptr(res_idx.contiguous()) if res_idx is not None else None, cap, _ptr(src), _ptr(dst),
+                                    _ptr(rowptr), _ptr(per_graph), _ptr(same), _ptr(counts), _ptr(scratch), _stream()))
+    E = int(counts[0].item())
+    if E > cap:
+        raise KpdError(f'rr graph: {E} edges exceed the capacity {cap} (internal sizing error)')
+    return src[:E], dst[:E], per_graph, (same[:E].bool() if same is not None else None)
+
+
+def xyz_emit(pos: torch.Tensor, feat: torch.Tensor, lig_ptr: torch.Tensor, elements):
+    """Element decode + XYZ text of a batch of ligands on the GPU (kpd_xyz_emit).
+    pos [N,3], feat [N,F] fp32 GPU tensors, lig_ptr [B+1] int32 GPU tensor, elements: F symbols.
+    Returns (element index per atom [N] int32 GPU tensor, text bytes, text_ptr list of B+1 offsets); the only host
+    synchronisation is the copy of the finished text."""
+    pos, feat = _dev_f32(pos, 'pos'), _dev_f32(feat, 'feat')
+    if not (lig_ptr.is_cuda and lig_ptr.dtype == torch.int32 and lig_ptr.dim() == 1 and lig_ptr.numel() >= 1):
+        raise KpdError('lig_ptr must be an int32 GPU tensor of B + 1 offsets')
+    N, B, F = pos.shape[0], lig_ptr.numel() - 1, feat.shape[1] if feat.dim() == 2 else -1
+    if pos.shape != (N, 3) or feat.shape[0] != N or F != len(elements):
+        raise KpdError(f'xyz_emit: pos {tuple(pos.shape)}, feat {tuple(feat.shape)}, {len(elements)} element symbols')
+    packed = []
+    for el in elements:
+        b = el.encode('ascii')
+        if not 1 <= len(b) <= 4:
+            raise KpdError(f'element symbol {el!r} must be 1-4 ASCII characters')
+        packed.append(int.from_bytes(b.ljust(4, b'\0'), 'little'))
+    dev = pos.device
+    symbols = torch.tensor(packed, dtype=torch.int32, device=dev)        # ASCII: the top bit is never set
+    elem = torch.empty(N, dtype=torch.int32, device=dev)
+    capacity = 72 * N + 16 * B + 16         # a line is at most 71 bytes, a header at most 12
+    text = torch.empty(capacity, dtype=torch.uint8, device=dev)
+    text_ptr = torch.empty(B + 1, dtype=torch.int64, device=dev)
+    status = torch.empty(1, dtype=torch.int32, device=dev)
+    scratch = torch.empty(int(lib().kpd_xyz_scratch_bytes(N, B)), dtype=torch.uint8, device=dev)
+    check(lib().kpd_xyz_emit(_ptr(pos), _ptr(feat), _ptr(lig_ptr), N, B, F, _ptr(symbols), _ptr(elem), _ptr(text), capacity,
+                             _ptr(text_ptr), _ptr(status), _ptr(scratch), _stream()))
+    ptr = text_ptr.cpu().tolist()
+    st = int(status.item())
+    if st & 2:
+        raise KpdError('xyz_emit: text buffer too small (internal sizing error)')
+    if st & 1:
+        raise KpdError('xyz_emit: a coordinate with |x| >= 2^53 cannot be printed (diverged sample?)')
+    return elem, bytes(text[:ptr[-1]].cpu().numpy()), ptr
 
 
 def sample_update(pb: PreparedBatch, atom_nf, lig_x, lig_h, kp_x, eps_x, eps_h, noise_x, noise_h, coef):

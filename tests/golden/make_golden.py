@@ -410,9 +410,51 @@ def make_schedule():
     npz('schedule.npz', **out)
 
 
+def xyz_cases():
+    """Coordinates that exercise the text formatting: exact ties of the third decimal (round-half-even), values that
+    round to zero with a sign, denormals, large magnitudes, non-finite values, plus ordinary samples."""
+    g = torch.Generator().manual_seed(77)
+    special = torch.tensor([0.0, -0.0, 0.0005, -0.0005, 0.0625, 0.1875, -0.0625, 2.5, 1e-4, -1e-4, 4.9e-4, 5.1e-4,
+                            0.9995, 0.99951, 9.9995, 99.9995, 999.9995, 1e-45, -1e-45, 1.17549435e-38, 123456.789, -98765.4375,
+                            1.0e7, 16777216.0, 3.0e9, 8.5e15, -8.9e15, float('inf'), -float('inf'), float('nan'),
+                            0.0015, 0.0025, 0.0035, 0.0045, 1.0005, 1.0015, 2.0005, 0.4375, 0.3125, -7.0625], dtype=torch.float32)
+    ties = (torch.randint(-80000, 80000, (120,), generator=g).float() * 2 + 1) / 16      # odd/16: many exact .xxx5 ties
+    rnd = torch.randn(300, generator=g) * torch.tensor([0.01, 1.0, 30.0]).repeat(100)
+    vals = torch.cat([special, ties, rnd])
+    vals = vals[: (vals.numel() // 3) * 3]
+    pos = vals.view(-1, 3)
+    n = pos.shape[0]
+    feat = torch.randn(n, 10, generator=g)
+    feat[3] = 0.0                       # all equal: first index
+    feat[4, 2] = feat[4, 7] = 5.0       # tie of the maximum: first of them
+    feat[5, 6] = float('nan')           # NaN is the maximum for torch.argmax
+    feat[6, 9] = float('inf')
+    sizes = [1, 2, 9, 10, 11, 25, 0, 30]
+    sizes.append(n - sum(sizes))
+    return pos, feat, sizes
+
+
+def make_xyz():
+    from utils import write_xyz_file as ref_write_xyz                       # /root/reference/utils.py:11-21
+    elements = ['C', 'N', 'O', 'S', 'P', 'F', 'Cl', 'Br', 'I', 'B']         # configs/dev_config.yml:19
+    pos, feat, sizes = xyz_cases()
+    text, ptr, elem = b'', [0], []
+    a = 0
+    for n in sizes:
+        p, f = pos[a:a + n], feat[a:a + n]
+        idxs = torch.argmax(f, dim=1).tolist() if n else []                # sample.py:77
+        els = [elements[i] for i in idxs]                                   # crossdocked/dataset.py:147-149
+        text += ref_write_xyz(p, els).encode()
+        ptr.append(len(text))
+        elem += idxs
+        a += n
+    npz('xyz.npz', pos=pos, feat=feat, sizes=np.asarray(sizes, np.int64), elem=np.asarray(elem, np.int64),
+        text=np.frombuffer(text, np.uint8), text_ptr=np.asarray(ptr, np.int64))
+
+
 if __name__ == '__main__':
     torch.manual_seed(0)
-    makers = dict(egnn=make_egnn, gvp_blocks=make_gvp_blocks, gvp_dyn=make_gvp_dyn, rec_encoder=make_rec_encoder,
+    makers = dict(xyz=make_xyz, egnn=make_egnn, gvp_blocks=make_gvp_blocks, gvp_dyn=make_gvp_dyn, rec_encoder=make_rec_encoder,
                   rec_encoder_egnn=make_rec_encoder_egnn, schedule=make_schedule)
     only = sys.argv[1:]                 # e.g. `make_golden.py rec_encoder_egnn`: regenerate one family, keep the others
     lp = os.path.join(HERE, 'state_dict_layout.json')
