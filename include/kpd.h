@@ -126,6 +126,30 @@ kpd_status kpd_egnn_profile_read(kpd_egnn *m, double *total_ms, int32_t *launche
 kpd_status kpd_egnn_last_counts(kpd_egnn *m, int32_t out[8], void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * EGNN denoiser, training path: forward that keeps the layer states and the backward pass of
+ * LigRecDynamics.forward (models/dynamics.py:342-385), i.e. what torch autograd derives for the loss of
+ * KeypointDiffusion.forward (models/ligand_diffuser.py:89-175) in train.py:423-524.  Parameters are bound once by their
+ * reference state-dict names and read in place in the reference [out, in] layout (no repacking: they change every
+ * optimizer step); each parameter's gradient is ACCUMULATED (+=) into the bound buffer of the same shape, the way
+ * autograd accumulates into .grad.  grad may be NULL for a frozen parameter.
+ *   forward : eps_h [n_lig, atom_nf], eps_x [n_lig, 3]; the batch tensors and `t` must stay alive until backward.
+ *             One host read-back of the edge counts per call (they size the GEMMs).
+ *   backward: d_eps_h / d_eps_x = dL/d(eps); any of d_lig_h [n_lig, atom_nf], d_lig_x [n_lig, 3], d_kp_h [n_kp, rec_nf],
+ *             d_kp_x [n_kp, 3] may be NULL (written, not accumulated, when given).  Consumes the forward.
+ * ------------------------------------------------------------------------------------- */
+typedef struct kpd_egnn_trainer kpd_egnn_trainer;
+kpd_status kpd_egnn_trainer_create(const kpd_egnn_config *cfg, kpd_egnn_trainer **out);
+void kpd_egnn_trainer_destroy(kpd_egnn_trainer *t);
+kpd_status kpd_egnn_trainer_bind(kpd_egnn_trainer *t, const char *name, const float *weight_dev, float *grad_dev,
+                                 const int64_t *shape, int32_t ndim);
+kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *t, int32_t max_B, int32_t max_n_lig, int32_t max_n_kp,
+                                    int32_t max_n_kk, int32_t max_lig_per_graph, int32_t max_kp_per_graph);
+kpd_status kpd_egnn_trainer_forward(kpd_egnn_trainer *t, const kpd_batch *batch, const float *t_dev, float *eps_h_dev,
+                                    float *eps_x_dev, void *stream);
+kpd_status kpd_egnn_trainer_backward(kpd_egnn_trainer *t, const float *d_eps_h, const float *d_eps_x, float *d_lig_h,
+                                     float *d_lig_x, float *d_kp_h, float *d_kp_x, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * GVP denoiser.  Replaces LigRecDynamicsGVP.forward (models/dynamics_gvp.py:149-199): encoders
  * (:124-134), edge build (:201-234), the GVPMultiEdgeConv stack (models/gvp.py:343-551; GVP :43-116,
  * GVPLayerNorm :152-166) and the NoisePredictionBlock (:10-44).  Fields mirror

@@ -1,0 +1,1008 @@
+// Training path of the EGNN denoiser: forward with saved layer states + backward.
+//
+// Gradients of LigRecDynamics.forward (models/dynamics.py:342-385; LigRecEGNN :266-294, LigRecConv :89-217) with respect
+// to every parameter and to the four input tensors, for the loss of KeypointDiffusion.forward
+// (models/ligand_diffuser.py:89-175), which train.py:423-524 differentiates with torch autograd.
+//
+// Formulation.  Parameters are read in place in the reference [out, in] layout (they change every optimizer step, so
+// nothing is repacked) and gradients are accumulated in the same layout.  The first-layer split of the inference path
+// carries over to the backward pass: pre1[e] = U[src] + V[dst] + d_e w_r + b1 with U = h_src W1[:, :257]^T and
+// V = h_dst W1[:, 257:514]^T, hence dW1 and dh need only the per-node sums of dpre1 (segmented by dst, scattered by src)
+// and node-sized GEMMs; the per-edge GEMMs left are pre2 = a1 W2^T, da1 = dpre2 W2 and dW2 = dpre2^T a1.  All dense
+// products are plain fp32 GEMMs / GEMVs (rocBLAS, on the caller's stream); gather, activation, attention / coordinate
+// heads, segmented sums, LayerNorm and geometry are the kernels below.  Memory: only the node states of every layer
+// (h, x, aggregated messages) are kept between forward and backward; per-edge activations are recomputed one edge
+// type and one branch at a time into scratch sized for the largest edge type.
+#include <rocblas/rocblas.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "egnn_kernels.h"
+#include "engine.h"
+
+namespace kpd {
+namespace {
+
+constexpr int H = HW;         // 257
+constexpr int LD = HS;        // 264: row stride of every activation matrix
+
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * sigm(x); }
+__device__ __forceinline__ float silu_grad(float x) {
+    const float s = sigm(x);
+    return s * (1.0f + x * (1.0f - s));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// ---- forward kernels ---------------------------------------------------------------------------------------------------
+// x_diff = x_src - x_dst (dynamics.py:160), dij = |x_diff| (:211), n = x_diff / (dij + 1) (:169)
+__global__ void k_geom(const int *__restrict__ src, const int *__restrict__ dst, const float *__restrict__ xs,
+                       const float *__restrict__ xd, int E, float *__restrict__ xdiff, float *__restrict__ dij,
+                       float *__restrict__ nvec) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int u = src[e], v = dst[e];
+    const float dx = xs[3 * u] - xd[3 * v], dy = xs[3 * u + 1] - xd[3 * v + 1], dz = xs[3 * u + 2] - xd[3 * v + 2];
+    const float d = sqrtf(dx * dx + dy * dy + dz * dz), inv = 1.0f / (d + 1.0f);
+    xdiff[3 * e] = dx; xdiff[3 * e + 1] = dy; xdiff[3 * e + 2] = dz;
+    dij[e] = d;
+    nvec[3 * e] = dx * inv; nvec[3 * e + 1] = dy * inv; nvec[3 * e + 2] = dz * inv;
+}
+
+// pre1[e] = U[src] + V[dst] + dij w_r + b1, a1 = SiLU(pre1): the first Linear of edge_mlp / coord_mlp on
+// f = [h_src, h_dst, dij] (dynamics.py:103-105) through its per-node halves.  w_r = W1[:, 514] (stride ldw).
+__global__ void k_edge_pre1(const float *__restrict__ U, const float *__restrict__ V, const int *__restrict__ src,
+                            const int *__restrict__ dst, const float *__restrict__ dij, const float *__restrict__ wr, int ldw,
+                            const float *__restrict__ b1, long long total, float *__restrict__ pre1, float *__restrict__ a1) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int e = (int)(i / H), c = (int)(i - (long long)e * H);
+    const float v = U[(size_t)src[e] * LD + c] + V[(size_t)dst[e] * LD + c] + dij[e] * wr[(size_t)c * ldw] + b1[c];
+    pre1[(size_t)e * LD + c] = v;
+    a1[(size_t)e * LD + c] = silu_f(v);
+}
+
+// Y += b (kept: the pre-activation), A = SiLU(Y)
+__global__ void k_bias_silu(float *__restrict__ Y, const float *__restrict__ b, long long total, int cols, int ld,
+                            float *__restrict__ A) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
+    const float v = Y[(size_t)r * ld + c] + b[c];
+    Y[(size_t)r * ld + c] = v;
+    A[(size_t)r * ld + c] = silu_f(v);
+}
+
+__global__ void k_bias_add(float *__restrict__ Y, const float *__restrict__ b, long long total, int cols, int ld) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
+    Y[(size_t)r * ld + c] += b[c];
+}
+
+// one wave per row: out[r] = A[r] . w (+ bias), optionally through a sigmoid (soft attention, dynamics.py:112)
+__global__ void k_rowdot(const float *__restrict__ A, const float *__restrict__ w, const float *__restrict__ bias, int rows,
+                         int do_sigmoid, float *__restrict__ out) {
+    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    float s = 0.0f;
+    for (int c = lane; c < H; c += 64) s = fmaf(A[(size_t)r * LD + c], w[c], s);
+    s = wave_sum(s);
+    if (lane == 0) {
+        if (bias) s += bias[0];
+        out[r] = do_sigmoid ? sigm(s) : s;
+    }
+}
+
+// acc[v] += zinv[v] * sum over the edges of dst node v of M[e] * (w ? w[e] : 1): one workgroup per dst node
+// (copy_e + sum and the division by z, dynamics.py:177-192)
+__global__ void k_segsum_rows(const float *__restrict__ M, const float *__restrict__ w, const int *__restrict__ rowptr,
+                              const float *__restrict__ zinv, int accumulate, float *__restrict__ acc) {
+    const int v = blockIdx.x;
+    const int e0 = rowptr[v], e1 = rowptr[v + 1];
+    if (e0 == e1 && accumulate) return;
+    const float zi = zinv ? zinv[v] : 1.0f;
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+        float s = 0.0f;
+        for (int e = e0; e < e1; ++e) s = fmaf(M[(size_t)e * LD + c], w ? w[e] : 1.0f, s);
+        if (accumulate) acc[(size_t)v * LD + c] += s * zi;
+        else acc[(size_t)v * LD + c] = s * zi;
+    }
+}
+
+// coordinate head: sc = a2 . w3 (no bias), msg_x = tanh(sc) * range * n  or  sc * n (dynamics.py:113-120)
+__global__ void k_coord_msg(const float *__restrict__ A, const float *__restrict__ w3, const float *__restrict__ nvec, int rows,
+                            int use_tanh, float range, float *__restrict__ sc, float *__restrict__ msgx) {
+    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    float s = 0.0f;
+    for (int c = lane; c < H; c += 64) s = fmaf(A[(size_t)r * LD + c], w3[c], s);
+    s = wave_sum(s);
+    if (lane < 3) {
+        const float coef = use_tanh ? tanhf(s) * range : s;
+        msgx[3 * r + lane] = coef * nvec[3 * r + lane];
+        if (lane == 0) sc[r] = s;
+    }
+}
+
+__global__ void k_segsum3(const float *__restrict__ M, const int *__restrict__ rowptr, const float *__restrict__ zinv, int n,
+                          float *__restrict__ acc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * n) return;
+    const int v = i / 3, c = i - 3 * v;
+    float s = 0.0f;
+    for (int e = rowptr[v]; e < rowptr[v + 1]; ++e) s += M[3 * e + c];
+    acc[i] += s * zinv[v];
+}
+
+// h' = LayerNorm(h + q2 + b2) (or without the norm), one wave per node (dynamics.py:202-205)
+__global__ void k_node_out(const float *__restrict__ h, const float *__restrict__ q2, const float *__restrict__ b2,
+                           const float *__restrict__ gamma, const float *__restrict__ beta, int norm, int n,
+                           float *__restrict__ out) {
+    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= n) return;
+    float u[5], s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int c = lane + 64 * k;
+        u[k] = c < H ? h[(size_t)r * LD + c] + q2[(size_t)r * LD + c] + b2[c] : 0.0f;
+        s += u[k];
+    }
+    if (!norm) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            if (lane + 64 * k < H) out[(size_t)r * LD + lane + 64 * k] = u[k];
+        return;
+    }
+    const float mean = wave_sum(s) * (1.0f / H);
+    float q = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+        if (lane + 64 * k < H) q += (u[k] - mean) * (u[k] - mean);
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / H) + 1e-5f);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int c = lane + 64 * k;
+        if (c < H) out[(size_t)r * LD + c] = (u[k] - mean) * rstd * gamma[c] + beta[c];
+    }
+}
+
+__global__ void k_axpy3(const float *__restrict__ x, const float *__restrict__ xn, int n3, float *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n3) out[i] = x[i] + xn[i];
+}
+
+// node rows [h(256 after the encoder) | t]: out[r][0..255] = in (already there), out[r][256] = t[bidx[r]]
+__global__ void k_set_time(float *__restrict__ hmat, const float *__restrict__ t, const int *__restrict__ bidx, int n) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) hmat[(size_t)r * LD + 256] = t[bidx[r]];
+}
+
+__global__ void k_copy_rows(const float *__restrict__ src, int lds, float *__restrict__ dst, int ldd, long long total, int cols) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
+    dst[(size_t)r * ldd + c] = src[(size_t)r * lds + c];
+}
+
+__global__ void k_zinv(const float *__restrict__ z, const int *__restrict__ bidx, int n, float *__restrict__ zinv) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) zinv[r] = 1.0f / z[bidx[r]];
+}
+
+__global__ void k_fill(float *__restrict__ p, float v, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// ---- backward kernels --------------------------------------------------------------------------------------------------
+// dY *= SiLU'(pre), in place
+__global__ void k_silu_bwd(float *__restrict__ dY, const float *__restrict__ pre, long long total, int cols, int ld) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
+    dY[(size_t)r * ld + c] *= silu_grad(pre[(size_t)r * ld + c]);
+}
+
+// LayerNorm backward, one wave per node: u = h + q2 + b2 recomputed; du, and dy * xhat for the gamma gradient
+__global__ void k_ln_bwd(const float *__restrict__ h, const float *__restrict__ q2, const float *__restrict__ b2,
+                         const float *__restrict__ gamma, const float *__restrict__ dy, int n, float *__restrict__ du,
+                         float *__restrict__ dyxhat) {
+    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= n) return;
+    float u[5], s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int c = lane + 64 * k;
+        u[k] = c < H ? h[(size_t)r * LD + c] + q2[(size_t)r * LD + c] + b2[c] : 0.0f;
+        s += u[k];
+    }
+    const float mean = wave_sum(s) * (1.0f / H);
+    float q = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+        if (lane + 64 * k < H) q += (u[k] - mean) * (u[k] - mean);
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / H) + 1e-5f);
+    float g[5], xh[5], sg = 0.0f, sgx = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int c = lane + 64 * k;
+        xh[k] = c < H ? (u[k] - mean) * rstd : 0.0f;
+        const float d = c < H ? dy[(size_t)r * LD + c] : 0.0f;
+        g[k] = c < H ? d * gamma[c] : 0.0f;
+        sg += g[k];
+        sgx += g[k] * xh[k];
+        if (c < H) dyxhat[(size_t)r * LD + c] = d * xh[k];
+    }
+    sg = wave_sum(sg) * (1.0f / H);
+    sgx = wave_sum(sgx) * (1.0f / H);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int c = lane + 64 * k;
+        if (c < H) du[(size_t)r * LD + c] = rstd * (g[k] - sg - xh[k] * sgx);
+    }
+}
+
+// feature head backward, one wave per edge: msg_h = a2 * att, att = sigmoid(a2 . wa + ba), summed into h_neigh[dst] / z.
+//   dmsg = dhn[dst] * zinv[dst]; ds = (dmsg . a2) att (1 - att); da2 = dmsg att + ds wa; dpre2 = da2 SiLU'(pre2)
+__global__ void k_feat_head_bwd(const float *__restrict__ dhn, const float *__restrict__ zinv, const int *__restrict__ dst,
+                                const float *__restrict__ a2, const float *__restrict__ att, const float *__restrict__ wa,
+                                const float *__restrict__ pre2, int E, float *__restrict__ dpre2, float *__restrict__ ds_att) {
+    const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (e >= E) return;
+    const int v = dst[e];
+    const float zi = zinv[v], a = att[e];
+    float dm[5], s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int c = lane + 64 * k;
+        dm[k] = c < H ? dhn[(size_t)v * LD + c] * zi : 0.0f;
+        if (c < H) s = fmaf(dm[k], a2[(size_t)e * LD + c], s);
+    }
+    const float ds = wave_sum(s) * a * (1.0f - a);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int c = lane + 64 * k;
+        if (c < H) dpre2[(size_t)e * LD + c] = (dm[k] * a + ds * wa[c]) * silu_grad(pre2[(size_t)e * LD + c]);
+    }
+    if (lane == 0) ds_att[e] = ds;
+}
+
+// coordinate head backward, one wave per edge: msg_x = coef n, coef = tanh(sc) range (or sc), summed into x_neigh[dst] / z
+__global__ void k_coord_head_bwd(const float *__restrict__ dxo, const float *__restrict__ zinv, const int *__restrict__ dst,
+                                 const float *__restrict__ nvec, const float *__restrict__ sc, const float *__restrict__ w3,
+                                 const float *__restrict__ pre2, int E, int use_tanh, float range, float *__restrict__ dpre2,
+                                 float *__restrict__ dsc, float *__restrict__ dn) {
+    const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (e >= E) return;
+    const int v = dst[e];
+    const float zi = zinv[v];
+    const float gx = dxo[3 * v] * zi, gy = dxo[3 * v + 1] * zi, gz = dxo[3 * v + 2] * zi;
+    const float th = use_tanh ? tanhf(sc[e]) : 0.0f;
+    const float coef = use_tanh ? th * range : sc[e];
+    const float dcoef = gx * nvec[3 * e] + gy * nvec[3 * e + 1] + gz * nvec[3 * e + 2];
+    const float ds = use_tanh ? dcoef * range * (1.0f - th * th) : dcoef;
+    for (int c = lane; c < H; c += 64) dpre2[(size_t)e * LD + c] = ds * w3[c] * silu_grad(pre2[(size_t)e * LD + c]);
+    if (lane == 0) {
+        dsc[e] = ds;
+        dn[3 * e] += coef * gx; dn[3 * e + 1] += coef * gy; dn[3 * e + 2] += coef * gz;
+    }
+}
+
+// dU[src[e]] += dpre1[e] (atomic; dU zeroed by the caller)
+__global__ void k_scatter_src(const float *__restrict__ dpre1, const int *__restrict__ src, long long total, float *__restrict__ dU) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int e = (int)(i / H), c = (int)(i - (long long)e * H);
+    atomicAdd(&dU[(size_t)src[e] * LD + c], dpre1[(size_t)e * LD + c]);
+}
+
+// geometry backward: n = x_diff / (dij + 1), dij = |x_diff|; scatter to the coordinates of both end points
+__global__ void k_geom_bwd(const float *__restrict__ ddij, const float *__restrict__ dn, const float *__restrict__ xdiff,
+                           const float *__restrict__ dij, const int *__restrict__ src, const int *__restrict__ dst, int E,
+                           float *__restrict__ dxs, float *__restrict__ dxd) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const float d = dij[e], inv = 1.0f / (d + 1.0f);
+    const float x0 = xdiff[3 * e], x1 = xdiff[3 * e + 1], x2 = xdiff[3 * e + 2];
+    const float g0 = dn[3 * e], g1 = dn[3 * e + 1], g2 = dn[3 * e + 2];
+    const float dd = ddij[e] - (g0 * x0 + g1 * x1 + g2 * x2) * inv * inv;     // total gradient of dij
+    const float k = d > 0.0f ? dd / d : 0.0f;
+    const float r0 = g0 * inv + k * x0, r1 = g1 * inv + k * x1, r2 = g2 * inv + k * x2;
+    const int u = src[e], v = dst[e];
+    atomicAdd(&dxs[3 * u], r0); atomicAdd(&dxs[3 * u + 1], r1); atomicAdd(&dxs[3 * u + 2], r2);
+    atomicAdd(&dxd[3 * v], -r0); atomicAdd(&dxd[3 * v + 1], -r1); atomicAdd(&dxd[3 * v + 2], -r2);
+}
+
+__global__ void k_sum_atomic(const float *__restrict__ v, int n, float *__restrict__ out) {
+    float s = 0.0f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) s += v[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+
+__global__ void k_sub_inplace(float *__restrict__ a, const float *__restrict__ b, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] -= b[i];
+}
+
+inline dim3 grid1(long long n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
+
+struct Param {
+    const float *w = nullptr;
+    float *g = nullptr;
+    int rows = 0, cols = 0;
+};
+
+}  // namespace
+}  // namespace kpd
+
+using namespace kpd;
+
+struct kpd_egnn_trainer {
+    kpd_egnn_config cfg{};
+    std::map<std::string, Param> params;
+    rocblas_handle blas = nullptr;
+    hipStream_t st = nullptr;
+    Arena ws;
+    int n_et = 2, n_upd = 1;
+    bool rec_identity = false;
+    // capacities
+    int cap_B = 0, cap_lig = 0, cap_kp = 0, cap_kk = 0, cap_maxlig = 0, cap_maxkp = 0, cap_ll = 0, cap_kl = 0, cap_E = 0, cap_N = 0;
+    // batch of the last forward
+    kpd_batch bt{};
+    const float *t_dev = nullptr;
+    bool have_forward = false;
+    int n[2] = {0, 0}, E[4] = {0, 0, 0, 0};
+    const int *e_src[4] = {nullptr, nullptr, nullptr, nullptr}, *e_dst[4] = {nullptr, nullptr, nullptr, nullptr},
+              *e_rowptr[4] = {nullptr, nullptr, nullptr, nullptr};
+    // graph build
+    kpd_lig_graph lg{};
+    int *meta = nullptr, *ll_deg = nullptr, *ll_off = nullptr, *kl_off = nullptr, *kl_pg = nullptr, *bidx[2] = {nullptr, nullptr};
+    float *z[2] = {nullptr, nullptr}, *zinv[2] = {nullptr, nullptr};
+    // saved node states: index l = input of layer l (l = n_layers: output of the stack)
+    std::vector<float *> hs[2], xs[2], hns[2], xns[2];
+    // scratch
+    float *eb[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // [cap_E, LD] each
+    float *nb[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // [cap_N, LD] each
+    float *dact = nullptr;                                                       // [cap_N, ENC_LD]
+    float *xdiff = nullptr, *dij = nullptr, *nvec = nullptr, *att = nullptr, *sc = nullptr, *dsv = nullptr, *ddij = nullptr,
+          *dn = nullptr, *msgx = nullptr, *ones = nullptr;
+    float *dh[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}, *dx[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    float *enc1[2] = {nullptr, nullptr}, *enc2[2] = {nullptr, nullptr}, *dec1 = nullptr, *dec2 = nullptr;   // encoder / decoder scratch
+};
+
+namespace {
+
+const char *kEt[4] = {"ll", "kl", "lk", "kk"};
+const char *kNt[2] = {"lig", "kp"};
+const int kS[4] = {NT_LIG, NT_KP, NT_LIG, NT_KP};     // source node type of ll, kl, lk, kk
+const int kD[4] = {NT_LIG, NT_LIG, NT_KP, NT_KP};
+
+#define KPD_BLAS(call)                                                                            \
+    do {                                                                                          \
+        rocblas_status s_ = (call);                                                               \
+        if (s_ != rocblas_status_success) {                                                       \
+            kpd::set_error("%s:%d: %s -> rocblas status %d", __FILE__, __LINE__, #call, (int)s_); \
+            return KPD_ERR_HIP;                                                                   \
+        }                                                                                         \
+    } while (0)
+
+// row-major C[M,N] = alpha op(A) op(B) + beta C
+kpd_status gemm(kpd_egnn_trainer *T, bool tA, bool tB, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
+                float beta, float *C, int ldc, float alpha = 1.0f) {
+    if (M == 0 || N == 0) return KPD_OK;
+    if (K == 0) {
+        if (beta == 0.0f) KPD_HIP(hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, M, T->st));
+        return KPD_OK;
+    }
+    KPD_BLAS(rocblas_sgemm(T->blas, tB ? rocblas_operation_transpose : rocblas_operation_none,
+                           tA ? rocblas_operation_transpose : rocblas_operation_none, N, M, K, &alpha, B, ldb, A, lda, &beta, C, ldc));
+    return KPD_OK;
+}
+
+// y[M] (stride incy) = beta y + A[M,K] x (stride incx), A row-major
+kpd_status gemv_n(kpd_egnn_trainer *T, int M, int K, const float *A, int lda, const float *x, int incx, float beta, float *y,
+                  int incy) {
+    if (M == 0) return KPD_OK;
+    const float alpha = 1.0f;
+    KPD_BLAS(rocblas_sgemv(T->blas, rocblas_operation_transpose, K, M, &alpha, A, lda, x, incx, &beta, y, incy));
+    return KPD_OK;
+}
+
+// y[K] (stride incy) += A[M,K]^T x[M], A row-major
+kpd_status gemv_t_acc(kpd_egnn_trainer *T, int M, int K, const float *A, int lda, const float *x, float *y, int incy) {
+    if (M == 0 || !y) return KPD_OK;
+    const float alpha = 1.0f, beta = 1.0f;
+    KPD_BLAS(rocblas_sgemv(T->blas, rocblas_operation_none, K, M, &alpha, A, lda, x, 1, &beta, y, incy));
+    return KPD_OK;
+}
+
+kpd_status colsum_acc(kpd_egnn_trainer *T, int M, int K, const float *A, int lda, float *y) { return gemv_t_acc(T, M, K, A, lda, T->ones, y, 1); }
+
+kpd_status param(kpd_egnn_trainer *T, const std::string &name, int rows, int cols, Param *out) {
+    auto it = T->params.find(name);
+    KPD_REQUIRE(it != T->params.end(), KPD_ERR_WEIGHTS, "parameter %s was not bound", name.c_str());
+    KPD_REQUIRE(it->second.rows == rows && it->second.cols == cols, KPD_ERR_WEIGHTS, "parameter %s is [%d,%d], expected [%d,%d]",
+                name.c_str(), it->second.rows, it->second.cols, rows, cols);
+    *out = it->second;
+    return KPD_OK;
+}
+
+struct BranchParams {
+    Param W1, b1, W2, b2, head, head_b;     // head = soft_attention weight [1,257] (+ bias) or coord_mlp.4 weight [1,257]
+};
+
+kpd_status branch_params(kpd_egnn_trainer *T, int layer, int et, int branch, BranchParams *p) {
+    const std::string base = "egnn.conv_layers." + std::to_string(layer) + ".";
+    const std::string mlp = base + (branch == 0 ? "edge_mlp." : "coord_mlp.") + kEt[et];
+    KPD_TRY(param(T, mlp + ".0.weight", H, 2 * H + 1, &p->W1));
+    KPD_TRY(param(T, mlp + ".0.bias", H, 1, &p->b1));
+    KPD_TRY(param(T, mlp + ".2.weight", H, H, &p->W2));
+    KPD_TRY(param(T, mlp + ".2.bias", H, 1, &p->b2));
+    if (branch == 0) {
+        KPD_TRY(param(T, base + "soft_attention." + kEt[et] + ".0.weight", 1, H, &p->head));
+        KPD_TRY(param(T, base + "soft_attention." + kEt[et] + ".0.bias", 1, 1, &p->head_b));
+    } else {
+        KPD_TRY(param(T, mlp + ".4.weight", 1, H, &p->head));
+    }
+    return KPD_OK;
+}
+
+// eb[0] = pre1, eb[1] = a1, eb[2] = pre2 (+ bias), eb[3] = a2 for the E edges of `et`; nb[0] = U, nb[1] = V
+kpd_status edge_branch_fwd(kpd_egnn_trainer *T, const BranchParams &p, int et, const float *hs, const float *hd) {
+    const int E = T->E[et], ns = T->n[kS[et]], nd = T->n[kD[et]];
+    KPD_TRY(gemm(T, false, true, ns, H, H, hs, LD, p.W1.w, 2 * H + 1, 0.0f, T->nb[0], LD));
+    KPD_TRY(gemm(T, false, true, nd, H, H, hd, LD, p.W1.w + H, 2 * H + 1, 0.0f, T->nb[1], LD));
+    const long long tot = (long long)E * H;
+    hipLaunchKernelGGL(k_edge_pre1, grid1(tot), dim3(256), 0, T->st, T->nb[0], T->nb[1], T->e_src[et], T->e_dst[et], T->dij,
+                       p.W1.w + 2 * H, 2 * H + 1, p.b1.w, tot, T->eb[0], T->eb[1]);
+    KPD_LAUNCH_CHECK();
+    KPD_TRY(gemm(T, false, true, E, H, H, T->eb[1], LD, p.W2.w, H, 0.0f, T->eb[2], LD));
+    hipLaunchKernelGGL(k_bias_silu, grid1(tot), dim3(256), 0, T->st, T->eb[2], p.b2.w, tot, H, LD, T->eb[3]);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+kpd_status geom_fwd(kpd_egnn_trainer *T, int et, const float *xs, const float *xd) {
+    hipLaunchKernelGGL(k_geom, grid1(T->E[et]), dim3(256), 0, T->st, T->e_src[et], T->e_dst[et], xs, xd, T->E[et], T->xdiff, T->dij,
+                       T->nvec);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+// one LigRecConv layer forward (dynamics.py:124-207) from the saved inputs hs[l], xs[l] into hs[l+1], xs[l+1], hns[l], xns[l]
+kpd_status layer_fwd(kpd_egnn_trainer *T, int l) {
+    const kpd_egnn_config &c = T->cfg;
+    for (int k = 0; k < T->n_upd; ++k) {
+        KPD_HIP(hipMemsetAsync(T->hns[k][l], 0, (size_t)T->n[k] * LD * 4, T->st));
+        KPD_HIP(hipMemsetAsync(T->xns[k][l], 0, (size_t)T->n[k] * 12, T->st));
+    }
+    for (int et = 0; et < T->n_et; ++et) {
+        const int E = T->E[et], s = kS[et], d = kD[et];
+        if (E == 0) continue;
+        KPD_TRY(geom_fwd(T, et, T->xs[s][l], T->xs[d][l]));
+        BranchParams p;
+        KPD_TRY(branch_params(T, l, et, 0, &p));
+        KPD_TRY(edge_branch_fwd(T, p, et, T->hs[s][l], T->hs[d][l]));
+        hipLaunchKernelGGL(k_rowdot, dim3(cdiv(E, 4)), dim3(256), 0, T->st, T->eb[3], p.head.w, p.head_b.w, E, 1, T->att);
+        KPD_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_segsum_rows, dim3(T->n[d]), dim3(256), 0, T->st, T->eb[3], T->att, T->e_rowptr[et], T->zinv[d], 1,
+                           T->hns[d][l]);
+        KPD_LAUNCH_CHECK();
+        KPD_TRY(branch_params(T, l, et, 1, &p));
+        KPD_TRY(edge_branch_fwd(T, p, et, T->hs[s][l], T->hs[d][l]));
+        hipLaunchKernelGGL(k_coord_msg, dim3(cdiv(E, 4)), dim3(256), 0, T->st, T->eb[3], p.head.w, T->nvec, E, c.use_tanh,
+                           c.coords_range, T->sc, T->msgx);
+        KPD_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_segsum3, grid1(3 * T->n[d]), dim3(256), 0, T->st, T->msgx, T->e_rowptr[et], T->zinv[d], T->n[d],
+                           T->xns[d][l]);
+        KPD_LAUNCH_CHECK();
+    }
+    return KPD_OK;
+}
+
+struct NodeParams {
+    Param W1, b1, W2, b2, gamma, beta;
+};
+
+kpd_status node_params(kpd_egnn_trainer *T, int l, int nt, NodeParams *p) {
+    const std::string base = "egnn.conv_layers." + std::to_string(l) + ".";
+    KPD_TRY(param(T, base + "node_mlp." + kNt[nt] + ".0.weight", H, 2 * H, &p->W1));
+    KPD_TRY(param(T, base + "node_mlp." + kNt[nt] + ".0.bias", H, 1, &p->b1));
+    KPD_TRY(param(T, base + "node_mlp." + kNt[nt] + ".2.weight", H, H, &p->W2));
+    KPD_TRY(param(T, base + "node_mlp." + kNt[nt] + ".2.bias", H, 1, &p->b2));
+    if (T->cfg.norm) {
+        KPD_TRY(param(T, base + "layer_norm." + kNt[nt] + ".weight", H, 1, &p->gamma));
+        KPD_TRY(param(T, base + "layer_norm." + kNt[nt] + ".bias", H, 1, &p->beta));
+    }
+    return KPD_OK;
+}
+
+// node MLP of layer l for node type nt: nb[2] = q1 (+ bias), nb[3] = c1 = SiLU(q1), nb[4] = q2 (without its bias)
+kpd_status node_mlp_fwd(kpd_egnn_trainer *T, const NodeParams &p, int l, int nt) {
+    const int n = T->n[nt];
+    KPD_TRY(gemm(T, false, true, n, H, H, T->hs[nt][l], LD, p.W1.w, 2 * H, 0.0f, T->nb[2], LD));
+    KPD_TRY(gemm(T, false, true, n, H, H, T->hns[nt][l], LD, p.W1.w + H, 2 * H, 1.0f, T->nb[2], LD));
+    const long long tot = (long long)n * H;
+    hipLaunchKernelGGL(k_bias_silu, grid1(tot), dim3(256), 0, T->st, T->nb[2], p.b1.w, tot, H, LD, T->nb[3]);
+    KPD_LAUNCH_CHECK();
+    KPD_TRY(gemm(T, false, true, n, H, H, T->nb[3], LD, p.W2.w, H, 0.0f, T->nb[4], LD));
+    return KPD_OK;
+}
+
+kpd_status nodes_fwd(kpd_egnn_trainer *T, int l) {
+    for (int nt = 0; nt < 2; ++nt) {
+        const int n = T->n[nt];
+        if (nt >= T->n_upd) {       // kp not updated: every layer reads the encoder output and x_0 again (dynamics.py:288-292)
+            T->hs[nt][l + 1] = T->hs[nt][0];
+            T->xs[nt][l + 1] = T->xs[nt][0];
+            continue;
+        }
+        NodeParams p;
+        KPD_TRY(node_params(T, l, nt, &p));
+        KPD_TRY(node_mlp_fwd(T, p, l, nt));
+        hipLaunchKernelGGL(k_node_out, dim3(cdiv(n, 4)), dim3(256), 0, T->st, T->hs[nt][l], T->nb[4], p.b2.w, p.gamma.w, p.beta.w,
+                           T->cfg.norm, n, T->hs[nt][l + 1]);
+        KPD_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_axpy3, grid1(3 * n), dim3(256), 0, T->st, T->xs[nt][l], T->xns[nt][l], 3 * n, T->xs[nt][l + 1]);
+        KPD_LAUNCH_CHECK();
+    }
+    return KPD_OK;
+}
+
+// two-layer MLPs at the ends (dynamics.py:313-334): y = [SiLU](W2 SiLU(W0 x + b0) + b2)
+struct MlpParams {
+    Param W0, b0, W2, b2;
+    int fin, hid, fout;
+};
+
+kpd_status mlp_params(kpd_egnn_trainer *T, const char *name, int fin, int hid, int fout, MlpParams *p) {
+    const std::string b = name;
+    KPD_TRY(param(T, b + ".0.weight", hid, fin, &p->W0));
+    KPD_TRY(param(T, b + ".0.bias", hid, 1, &p->b0));
+    KPD_TRY(param(T, b + ".2.weight", fout, hid, &p->W2));
+    KPD_TRY(param(T, b + ".2.bias", fout, 1, &p->b2));
+    p->fin = fin; p->hid = hid; p->fout = fout;
+    return KPD_OK;
+}
+
+// pre1 [n, hid] (ld LD... hid <= 512 uses its own stride), act1, pre2 [n, fout]; final_act: out = SiLU(pre2) else out = pre2
+kpd_status mlp_fwd(kpd_egnn_trainer *T, const MlpParams &p, const float *x, int ldx, int n, float *pre1, float *act1, int ld1,
+                   float *pre2, int ld2, float *out, int ldo, bool final_act) {
+    KPD_TRY(gemm(T, false, true, n, p.hid, p.fin, x, ldx, p.W0.w, p.fin, 0.0f, pre1, ld1));
+    long long tot = (long long)n * p.hid;
+    hipLaunchKernelGGL(k_bias_silu, grid1(tot), dim3(256), 0, T->st, pre1, p.b0.w, tot, p.hid, ld1, act1);
+    KPD_LAUNCH_CHECK();
+    KPD_TRY(gemm(T, false, true, n, p.fout, p.hid, act1, ld1, p.W2.w, p.hid, 0.0f, pre2, ld2));
+    tot = (long long)n * p.fout;
+    if (final_act) {
+        KPD_REQUIRE(ld2 == ldo, KPD_ERR_INVALID, "internal: mlp_fwd strides");
+        hipLaunchKernelGGL(k_bias_silu, grid1(tot), dim3(256), 0, T->st, pre2, p.b2.w, tot, p.fout, ld2, out);
+    } else {
+        hipLaunchKernelGGL(k_bias_add, grid1(tot), dim3(256), 0, T->st, pre2, p.b2.w, tot, p.fout, ld2);
+        KPD_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_copy_rows, grid1(tot), dim3(256), 0, T->st, pre2, ld2, out, ldo, tot, p.fout);
+    }
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+// backward of mlp_fwd given dout (overwritten); pre1 / act1 / pre2 as left by mlp_fwd; dx (may be null) = gradient of x
+kpd_status mlp_bwd(kpd_egnn_trainer *T, const MlpParams &p, const float *x, int ldx, int n, const float *pre1, const float *act1,
+                   int ld1, const float *pre2, int ld2, float *dout, int ldo, bool final_act, float *dact1, float *dx, int lddx) {
+    if (final_act) {
+        const long long tot = (long long)n * p.fout;
+        KPD_REQUIRE(ld2 == ldo, KPD_ERR_INVALID, "internal: mlp_bwd strides");
+        hipLaunchKernelGGL(k_silu_bwd, grid1(tot), dim3(256), 0, T->st, dout, pre2, tot, p.fout, ldo);
+        KPD_LAUNCH_CHECK();
+    }
+    KPD_TRY(colsum_acc(T, n, p.fout, dout, ldo, p.b2.g));
+    if (p.W2.g) KPD_TRY(gemm(T, true, false, p.fout, p.hid, n, dout, ldo, act1, ld1, 1.0f, p.W2.g, p.hid));
+    KPD_TRY(gemm(T, false, false, n, p.hid, p.fout, dout, ldo, p.W2.w, p.hid, 0.0f, dact1, ld1));
+    const long long tot = (long long)n * p.hid;
+    hipLaunchKernelGGL(k_silu_bwd, grid1(tot), dim3(256), 0, T->st, dact1, pre1, tot, p.hid, ld1);
+    KPD_LAUNCH_CHECK();
+    KPD_TRY(colsum_acc(T, n, p.hid, dact1, ld1, p.b0.g));
+    if (p.W0.g) KPD_TRY(gemm(T, true, false, p.hid, p.fin, n, dact1, ld1, x, ldx, 1.0f, p.W0.g, p.fin));
+    if (dx) KPD_TRY(gemm(T, false, false, n, p.fin, p.hid, dact1, ld1, p.W0.w, p.fin, 0.0f, dx, lddx));
+    return KPD_OK;
+}
+
+constexpr int ENC_LD = 512;       // row stride of the encoder / decoder hidden activations (hid = 64, 2 rec_nf <= 512, 20)
+
+}  // namespace
+
+extern "C" kpd_status kpd_egnn_trainer_create(const kpd_egnn_config *cfg, kpd_egnn_trainer **out) {
+    KPD_REQUIRE(cfg && out, KPD_ERR_INVALID, "null argument");
+    KPD_REQUIRE(cfg->hidden_nf == 256, KPD_ERR_INVALID, "hidden_nf=%d: only 256 is supported", cfg->hidden_nf);
+    KPD_REQUIRE(cfg->atom_nf >= 1 && cfg->atom_nf <= 256 && cfg->rec_nf >= 1 && cfg->rec_nf <= 256 && cfg->n_layers >= 1 &&
+                    cfg->n_layers <= 64,
+                KPD_ERR_INVALID, "atom_nf=%d rec_nf=%d n_layers=%d", cfg->atom_nf, cfg->rec_nf, cfg->n_layers);
+    KPD_REQUIRE(cfg->ll_k >= 0 && cfg->ll_k <= 16 && cfg->kl_k >= 0 && cfg->kl_k <= KL_KMAX, KPD_ERR_INVALID, "ll_k=%d kl_k=%d",
+                cfg->ll_k, cfg->kl_k);
+    kpd_egnn_trainer *T = new kpd_egnn_trainer();
+    T->cfg = *cfg;
+    T->n_et = cfg->update_kp_feat ? 4 : 2;
+    T->n_upd = cfg->update_kp_feat ? 2 : 1;
+    T->rec_identity = cfg->rec_nf == 256;
+    if (rocblas_create_handle(&T->blas) != rocblas_status_success) {
+        delete T;
+        set_error("rocblas_create_handle failed");
+        return KPD_ERR_HIP;
+    }
+    *out = T;
+    return KPD_OK;
+}
+
+extern "C" void kpd_egnn_trainer_destroy(kpd_egnn_trainer *T) {
+    if (!T) return;
+    if (T->blas) rocblas_destroy_handle(T->blas);
+    T->ws.release();
+    delete T;
+}
+
+extern "C" kpd_status kpd_egnn_trainer_bind(kpd_egnn_trainer *T, const char *name, const float *weight, float *grad,
+                                            const int64_t *shape, int32_t ndim) {
+    KPD_REQUIRE(T && name && weight && shape && (ndim == 1 || ndim == 2), KPD_ERR_INVALID, "bad argument");
+    Param p;
+    p.w = weight;
+    p.g = grad;
+    p.rows = (int)shape[0];
+    p.cols = ndim == 2 ? (int)shape[1] : 1;
+    T->params[name] = p;
+    return KPD_OK;
+}
+
+extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_B, int32_t max_n_lig, int32_t max_n_kp,
+                                               int32_t max_n_kk, int32_t max_lig_pg, int32_t max_kp_pg) {
+    KPD_REQUIRE(T, KPD_ERR_INVALID, "null trainer");
+    KPD_REQUIRE(max_B >= 1 && max_n_lig >= 1 && max_n_kp >= 1 && max_n_kk >= 0 && max_lig_pg >= 1 && max_kp_pg >= 1, KPD_ERR_INVALID,
+                "bad capacities");
+    if (max_B <= T->cap_B && max_n_lig <= T->cap_lig && max_n_kp <= T->cap_kp && max_n_kk <= T->cap_kk && max_lig_pg <= T->cap_maxlig &&
+        max_kp_pg <= T->cap_maxkp)
+        return KPD_OK;
+    const kpd_egnn_config &c = T->cfg;
+    max_B = std::max(max_B, T->cap_B); max_n_lig = std::max(max_n_lig, T->cap_lig); max_n_kp = std::max(max_n_kp, T->cap_kp);
+    max_n_kk = std::max(max_n_kk, T->cap_kk); max_lig_pg = std::max(max_lig_pg, T->cap_maxlig); max_kp_pg = std::max(max_kp_pg, T->cap_maxkp);
+    const int cap_ll = std::max<long>((long)max_n_lig * std::min(max_lig_pg - 1, c.ll_k > 0 ? c.ll_k : 200), 1);
+    const int cap_kl = std::max<long>((long)max_n_kp * (c.kl_k > 0 ? c.kl_k : std::min(max_lig_pg, 100)), 1);
+    const int cap_E = std::max(std::max(cap_ll, cap_kl), std::max<int>(max_n_kk, 1));
+    const int cap_N = std::max(max_n_lig, max_n_kp);
+    const int L = c.n_layers;
+    const int nn[2] = {max_n_lig, max_n_kp};
+    size_t bytes = 0;
+    auto add = [&](size_t count, size_t sz) { bytes += (count * sz + 255) & ~size_t(255); };
+    for (int nt = 0; nt < 2; ++nt) {
+        for (int l = 0; l <= L; ++l) { add((size_t)nn[nt] * LD, 4); add((size_t)nn[nt] * 3, 4); }
+        for (int l = 0; l < L; ++l) { add((size_t)nn[nt] * LD, 4); add((size_t)nn[nt] * 3, 4); }
+        add(nn[nt], 4); add(max_B, 4); add(nn[nt], 4);
+        for (int k = 0; k < 2; ++k) { add((size_t)nn[nt] * LD, 4); add((size_t)nn[nt] * 3, 4); }
+        add((size_t)nn[nt] * ENC_LD, 4); add((size_t)nn[nt] * ENC_LD, 4);
+    }
+    add((size_t)max_n_lig * ENC_LD, 4); add((size_t)max_n_lig * ENC_LD, 4);
+    for (int k = 0; k < 6; ++k) add((size_t)cap_E * LD, 4);
+    for (int k = 0; k < 7; ++k) add((size_t)cap_N * LD, 4);
+    add((size_t)cap_N * ENC_LD, 4);
+    for (int k = 0; k < 3; ++k) add((size_t)cap_E * 3, 4);      // xdiff, nvec, dn
+    add((size_t)cap_E * 3, 4);                                    // msgx
+    for (int k = 0; k < 5; ++k) add(cap_E, 4);                   // dij, att, sc, dsv, ddij
+    add(std::max(cap_E, cap_N), 4);                               // ones
+    add(16, 4); add(max_n_lig, 4); add(max_B + 1, 4); add(max_B + 1, 4); add(max_B + 2, 4);
+    add(cap_ll, 4); add(cap_ll, 4); add(max_n_lig + 1, 4);
+    for (int i = 0; i < 4; ++i) add(cap_kl, 4);
+    add(max_n_lig + 1, 4); add(max_n_kp + 1, 4); add(max_B, 4); add(8, 4);
+    T->ws.release();
+    KPD_TRY(T->ws.reserve(bytes + 4096));
+    Arena &W = T->ws;
+    for (int nt = 0; nt < 2; ++nt) {
+        T->hs[nt].assign(L + 1, nullptr); T->xs[nt].assign(L + 1, nullptr);
+        T->hns[nt].assign(L, nullptr); T->xns[nt].assign(L, nullptr);
+        for (int l = 0; l <= L; ++l) { T->hs[nt][l] = W.take<float>((size_t)nn[nt] * LD); T->xs[nt][l] = W.take<float>((size_t)nn[nt] * 3); }
+        for (int l = 0; l < L; ++l) { T->hns[nt][l] = W.take<float>((size_t)nn[nt] * LD); T->xns[nt][l] = W.take<float>((size_t)nn[nt] * 3); }
+        T->bidx[nt] = W.take<int>(nn[nt]);
+        T->z[nt] = W.take<float>(max_B);
+        T->zinv[nt] = W.take<float>(nn[nt]);
+        for (int k = 0; k < 2; ++k) { T->dh[k][nt] = W.take<float>((size_t)nn[nt] * LD); T->dx[k][nt] = W.take<float>((size_t)nn[nt] * 3); }
+        T->enc1[nt] = W.take<float>((size_t)nn[nt] * ENC_LD);
+        T->enc2[nt] = W.take<float>((size_t)nn[nt] * ENC_LD);
+    }
+    T->dec1 = W.take<float>((size_t)max_n_lig * ENC_LD);
+    T->dec2 = W.take<float>((size_t)max_n_lig * ENC_LD);
+    for (int k = 0; k < 6; ++k) T->eb[k] = W.take<float>((size_t)cap_E * LD);
+    for (int k = 0; k < 7; ++k) T->nb[k] = W.take<float>((size_t)cap_N * LD);
+    T->dact = W.take<float>((size_t)cap_N * ENC_LD);
+    T->xdiff = W.take<float>((size_t)cap_E * 3); T->nvec = W.take<float>((size_t)cap_E * 3); T->dn = W.take<float>((size_t)cap_E * 3);
+    T->msgx = W.take<float>((size_t)cap_E * 3);
+    T->dij = W.take<float>(cap_E); T->att = W.take<float>(cap_E); T->sc = W.take<float>(cap_E); T->dsv = W.take<float>(cap_E);
+    T->ddij = W.take<float>(cap_E);
+    const int n_ones = std::max(cap_E, cap_N);
+    T->ones = W.take<float>(n_ones);
+    T->meta = W.take<int>(16);
+    T->ll_deg = W.take<int>(max_n_lig);
+    T->ll_off = W.take<int>(max_B + 1);
+    T->kl_off = W.take<int>(max_B + 1);
+    T->kl_pg = W.take<int>(max_B + 2);
+    kpd_lig_graph &g = T->lg;
+    g.cap_ll = cap_ll; g.cap_kl = cap_kl;
+    g.ll_src = W.take<int>(cap_ll); g.ll_dst = W.take<int>(cap_ll); g.ll_rowptr = W.take<int>(max_n_lig + 1);
+    g.kl_src = W.take<int>(cap_kl); g.kl_dst = W.take<int>(cap_kl); g.kl_rowptr = W.take<int>(max_n_lig + 1);
+    g.lk_src = W.take<int>(cap_kl); g.lk_dst = W.take<int>(cap_kl); g.lk_rowptr = W.take<int>(max_n_kp + 1);
+    g.ll_per_graph = W.take<int>(max_B);
+    g.counts = W.take<int>(8);
+    KPD_REQUIRE(g.counts != nullptr, KPD_ERR_HIP, "workspace arena too small (internal sizing error)");
+    hipLaunchKernelGGL(k_fill, grid1(n_ones), dim3(256), 0, nullptr, T->ones, 1.0f, (long long)n_ones);
+    KPD_LAUNCH_CHECK();
+    KPD_HIP(hipDeviceSynchronize());
+    T->cap_B = max_B; T->cap_lig = max_n_lig; T->cap_kp = max_n_kp; T->cap_kk = max_n_kk; T->cap_maxlig = max_lig_pg;
+    T->cap_maxkp = max_kp_pg; T->cap_ll = cap_ll; T->cap_kl = cap_kl; T->cap_E = cap_E; T->cap_N = cap_N;
+    T->have_forward = false;
+    return KPD_OK;
+}
+
+namespace {
+
+kpd_status encoders_fwd(kpd_egnn_trainer *T) {
+    const kpd_egnn_config &c = T->cfg;
+    MlpParams p;
+    KPD_TRY(mlp_params(T, "lig_encoder", c.atom_nf, 64, 256, &p));
+    KPD_TRY(mlp_fwd(T, p, T->bt.lig_h, c.atom_nf, T->n[0], T->enc1[0], T->enc2[0], ENC_LD, T->nb[0], LD, T->hs[0][0], LD, true));
+    if (T->rec_identity) {
+        const long long tot = (long long)T->n[1] * 256;
+        hipLaunchKernelGGL(k_copy_rows, grid1(tot), dim3(256), 0, T->st, T->bt.kp_h, 256, T->hs[1][0], LD, tot, 256);
+        KPD_LAUNCH_CHECK();
+    } else {
+        KPD_TRY(mlp_params(T, "rec_encoder", c.rec_nf, 2 * c.rec_nf, 256, &p));
+        KPD_TRY(mlp_fwd(T, p, T->bt.kp_h, c.rec_nf, T->n[1], T->enc1[1], T->enc2[1], ENC_LD, T->nb[1], LD, T->hs[1][0], LD, true));
+    }
+    for (int nt = 0; nt < 2; ++nt) {
+        hipLaunchKernelGGL(k_set_time, grid1(T->n[nt]), dim3(256), 0, T->st, T->hs[nt][0], T->t_dev, T->bidx[nt], T->n[nt]);
+        KPD_LAUNCH_CHECK();
+    }
+    return KPD_OK;
+}
+
+}  // namespace
+
+extern "C" kpd_status kpd_egnn_trainer_forward(kpd_egnn_trainer *T, const kpd_batch *bt, const float *t_dev, float *eps_h,
+                                               float *eps_x, void *stream) {
+    KPD_REQUIRE(T && bt && t_dev && eps_h && eps_x, KPD_ERR_INVALID, "null argument");
+    KPD_REQUIRE(bt->B >= 1 && bt->n_lig >= 1 && bt->n_kp >= 1, KPD_ERR_INVALID, "empty batch");
+    KPD_REQUIRE(bt->B <= T->cap_B && bt->n_lig <= T->cap_lig && bt->n_kp <= T->cap_kp && bt->n_kk <= T->cap_kk &&
+                    bt->max_lig <= T->cap_maxlig && bt->max_kp <= T->cap_maxkp,
+                KPD_ERR_CAPACITY, "batch exceeds the reserved workspace");
+    KPD_REQUIRE(bt->kk_rowptr && (!T->cfg.update_kp_feat || bt->n_kk == 0 || (bt->kk_src && bt->kk_dst)), KPD_ERR_INVALID, "kk edges missing");
+    const kpd_egnn_config &c = T->cfg;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    T->st = st;
+    KPD_BLAS(rocblas_set_stream(T->blas, st));
+    T->bt = *bt;
+    T->t_dev = t_dev;
+    T->n[0] = bt->n_lig; T->n[1] = bt->n_kp;
+    const int L = c.n_layers;
+    KPD_HIP(hipMemcpyAsync(T->xs[0][0], bt->lig_x, (size_t)bt->n_lig * 12, hipMemcpyDeviceToDevice, st));
+    KPD_HIP(hipMemcpyAsync(T->xs[1][0], bt->kp_x, (size_t)bt->n_kp * 12, hipMemcpyDeviceToDevice, st));
+    KPD_TRY(launch_node_graph_index(bt->lig_ptr, bt->B, bt->n_lig, T->bidx[0], st));
+    KPD_TRY(launch_node_graph_index(bt->kp_ptr, bt->B, bt->n_kp, T->bidx[1], st));
+    KPD_TRY(launch_lig_graph(bt, c.ll_cutoff, c.ll_k, c.kl_cutoff, c.kl_k, &T->lg, T->ll_deg, T->ll_off, T->kl_off, T->kl_pg, st));
+    const int active = c.update_kp_feat ? 0xF : 0x3;
+    KPD_TRY(launch_egnn_meta(T->lg.counts, bt->n_kk, active, bt->lig_ptr, bt->kp_ptr, T->lg.ll_per_graph, bt->kk_rowptr, bt->B, T->kl_off,
+                             c.message_norm, c.update_kp_feat, T->meta, T->z[0], T->z[1], st));
+    // edge counts drive GEMM shapes: one read-back per training step
+    int counts[2];
+    KPD_HIP(hipMemcpyAsync(counts, T->lg.counts, sizeof(counts), hipMemcpyDeviceToHost, st));
+    KPD_HIP(hipStreamSynchronize(st));
+    KPD_REQUIRE(counts[0] <= T->cap_ll && counts[1] <= T->cap_kl, KPD_ERR_CAPACITY, "edge lists overflow (ll %d/%d, kl %d/%d)", counts[0],
+                T->cap_ll, counts[1], T->cap_kl);
+    T->E[ET_LL] = counts[0]; T->E[ET_KL] = counts[1]; T->E[ET_LK] = counts[1]; T->E[ET_KK] = bt->n_kk;
+    T->e_src[ET_LL] = T->lg.ll_src; T->e_dst[ET_LL] = T->lg.ll_dst; T->e_rowptr[ET_LL] = T->lg.ll_rowptr;
+    T->e_src[ET_KL] = T->lg.kl_src; T->e_dst[ET_KL] = T->lg.kl_dst; T->e_rowptr[ET_KL] = T->lg.kl_rowptr;
+    T->e_src[ET_LK] = T->lg.lk_src; T->e_dst[ET_LK] = T->lg.lk_dst; T->e_rowptr[ET_LK] = T->lg.lk_rowptr;
+    T->e_src[ET_KK] = bt->kk_src; T->e_dst[ET_KK] = bt->kk_dst; T->e_rowptr[ET_KK] = bt->kk_rowptr;
+    for (int nt = 0; nt < 2; ++nt) {
+        hipLaunchKernelGGL(k_zinv, grid1(T->n[nt]), dim3(256), 0, st, T->z[nt], T->bidx[nt], T->n[nt], T->zinv[nt]);
+        KPD_LAUNCH_CHECK();
+    }
+    KPD_TRY(encoders_fwd(T));
+    for (int l = 0; l < L; ++l) {
+        KPD_TRY(layer_fwd(T, l));
+        KPD_TRY(nodes_fwd(T, l));
+    }
+    // decoder on the first 256 columns (dynamics.py:376-381); eps_x = x_out - x_0
+    MlpParams p;
+    KPD_TRY(mlp_params(T, "lig_decoder", 256, 2 * c.atom_nf, c.atom_nf, &p));
+    KPD_TRY(mlp_fwd(T, p, T->hs[0][L], LD, T->n[0], T->dec1, T->dec2, ENC_LD, T->nb[0], LD, eps_h, c.atom_nf, false));
+    KPD_HIP(hipMemcpyAsync(eps_x, T->xs[0][L], (size_t)T->n[0] * 12, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_sub_inplace, grid1(3 * T->n[0]), dim3(256), 0, st, eps_x, T->xs[0][0], 3 * T->n[0]);
+    KPD_LAUNCH_CHECK();
+    T->have_forward = true;
+    return KPD_OK;
+}
+
+namespace {
+
+// backward of the node update of layer l for node type nt: consumes dh_out / dx_out (T->dh[cur], T->dx[cur]), writes the
+// node part of dh_in / dx_in (T->dh[nxt], "="), leaves nb[5] = dL/d(h_neigh / z) rows (un-scaled by zinv) for the heads
+kpd_status node_bwd(kpd_egnn_trainer *T, int l, int nt, int cur, int nxt, float *dhn_out) {
+    const int n = T->n[nt];
+    NodeParams p;
+    KPD_TRY(node_params(T, l, nt, &p));
+    KPD_TRY(node_mlp_fwd(T, p, l, nt));                  // nb[2] = q1, nb[3] = c1, nb[4] = q2
+    float *du = T->nb[0], *tmp = T->nb[1];
+    const float *dy = T->dh[cur][nt];
+    if (T->cfg.norm) {
+        hipLaunchKernelGGL(k_ln_bwd, dim3(cdiv(n, 4)), dim3(256), 0, T->st, T->hs[nt][l], T->nb[4], p.b2.w, p.gamma.w, dy, n, du, tmp);
+        KPD_LAUNCH_CHECK();
+        KPD_TRY(colsum_acc(T, n, H, tmp, LD, p.gamma.g));
+        KPD_TRY(colsum_acc(T, n, H, dy, LD, p.beta.g));
+    } else {
+        KPD_HIP(hipMemcpyAsync(du, dy, (size_t)n * LD * 4, hipMemcpyDeviceToDevice, T->st));
+    }
+    KPD_TRY(colsum_acc(T, n, H, du, LD, p.b2.g));
+    if (p.W2.g) KPD_TRY(gemm(T, true, false, H, H, n, du, LD, T->nb[3], LD, 1.0f, p.W2.g, H));
+    float *dq1 = tmp;
+    KPD_TRY(gemm(T, false, false, n, H, H, du, LD, p.W2.w, H, 0.0f, dq1, LD));
+    const long long tot = (long long)n * H;
+    hipLaunchKernelGGL(k_silu_bwd, grid1(tot), dim3(256), 0, T->st, dq1, T->nb[2], tot, H, LD);
+    KPD_LAUNCH_CHECK();
+    KPD_TRY(colsum_acc(T, n, H, dq1, LD, p.b1.g));
+    if (p.W1.g) {
+        KPD_TRY(gemm(T, true, false, H, H, n, dq1, LD, T->hs[nt][l], LD, 1.0f, p.W1.g, 2 * H));
+        KPD_TRY(gemm(T, true, false, H, H, n, dq1, LD, T->hns[nt][l], LD, 1.0f, p.W1.g + H, 2 * H));
+    }
+    // dh_in = du (residual) + dq1 W1[:, :257];  d(h_neigh / z) = dq1 W1[:, 257:]
+    KPD_HIP(hipMemcpyAsync(T->dh[nxt][nt], du, (size_t)n * LD * 4, hipMemcpyDeviceToDevice, T->st));
+    KPD_TRY(gemm(T, false, false, n, H, H, dq1, LD, p.W1.w, 2 * H, 1.0f, T->dh[nxt][nt], LD));
+    KPD_TRY(gemm(T, false, false, n, H, H, dq1, LD, p.W1.w + H, 2 * H, 0.0f, dhn_out, LD));
+    KPD_HIP(hipMemcpyAsync(T->dx[nxt][nt], T->dx[cur][nt], (size_t)n * 12, hipMemcpyDeviceToDevice, T->st));   // x' = x + x_neigh
+    return KPD_OK;
+}
+
+// the part of the edge backward shared by both branches: eb[4] = dpre2 in; uses eb[0..1] = pre1, a1 of the branch
+kpd_status edge_branch_bwd(kpd_egnn_trainer *T, const BranchParams &p, int l, int et, int nxt, bool first_branch) {
+    const int E = T->E[et], s = kS[et], d = kD[et], ns = T->n[s], nd = T->n[d];
+    float *dpre2 = T->eb[4], *dpre1 = T->eb[5];
+    KPD_TRY(colsum_acc(T, E, H, dpre2, LD, p.b2.g));
+    if (p.W2.g) KPD_TRY(gemm(T, true, false, H, H, E, dpre2, LD, T->eb[1], LD, 1.0f, p.W2.g, H));
+    KPD_TRY(gemm(T, false, false, E, H, H, dpre2, LD, p.W2.w, H, 0.0f, dpre1, LD));
+    const long long tot = (long long)E * H;
+    hipLaunchKernelGGL(k_silu_bwd, grid1(tot), dim3(256), 0, T->st, dpre1, T->eb[0], tot, H, LD);
+    KPD_LAUNCH_CHECK();
+    KPD_TRY(colsum_acc(T, E, H, dpre1, LD, p.b1.g));
+    if (p.W1.g) KPD_TRY(gemv_t_acc(T, E, H, dpre1, LD, T->dij, p.W1.g + 2 * H, 2 * H + 1));          // column 514: the dij weights
+    KPD_TRY(gemv_n(T, E, H, dpre1, LD, p.W1.w + 2 * H, 2 * H + 1, first_branch ? 0.0f : 1.0f, T->ddij, 1));
+    // per-node sums: dV (by dst, segmented) and dU (by src, atomics)
+    float *dU = T->nb[0], *dV = T->nb[1];
+    KPD_HIP(hipMemsetAsync(dU, 0, (size_t)ns * LD * 4, T->st));
+    hipLaunchKernelGGL(k_scatter_src, grid1(tot), dim3(256), 0, T->st, dpre1, T->e_src[et], tot, dU);
+    KPD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_segsum_rows, dim3(nd), dim3(256), 0, T->st, dpre1, (const float *)nullptr, T->e_rowptr[et],
+                       (const float *)nullptr, 0, dV);
+    KPD_LAUNCH_CHECK();
+    const float *hsrc = T->hs[s][l], *hdst = T->hs[d][l];
+    if (p.W1.g) {
+        KPD_TRY(gemm(T, true, false, H, H, ns, dU, LD, hsrc, LD, 1.0f, p.W1.g, 2 * H + 1));
+        KPD_TRY(gemm(T, true, false, H, H, nd, dV, LD, hdst, LD, 1.0f, p.W1.g + H, 2 * H + 1));
+    }
+    KPD_TRY(gemm(T, false, false, ns, H, H, dU, LD, p.W1.w, 2 * H + 1, 1.0f, T->dh[nxt][s], LD));
+    KPD_TRY(gemm(T, false, false, nd, H, H, dV, LD, p.W1.w + H, 2 * H + 1, 1.0f, T->dh[nxt][d], LD));
+    return KPD_OK;
+}
+
+kpd_status layer_bwd(kpd_egnn_trainer *T, int l, int cur, int nxt, float *dhn[2]) {
+    const kpd_egnn_config &c = T->cfg;
+    for (int nt = 0; nt < T->n_upd; ++nt) KPD_TRY(node_bwd(T, l, nt, cur, nxt, dhn[nt]));
+    for (int et = 0; et < T->n_et; ++et) {
+        const int E = T->E[et], s = kS[et], d = kD[et];
+        if (E == 0) continue;
+        KPD_TRY(geom_fwd(T, et, T->xs[s][l], T->xs[d][l]));
+        KPD_HIP(hipMemsetAsync(T->dn, 0, (size_t)E * 12, T->st));
+        BranchParams p;
+        // feature branch
+        KPD_TRY(branch_params(T, l, et, 0, &p));
+        KPD_TRY(edge_branch_fwd(T, p, et, T->hs[s][l], T->hs[d][l]));
+        hipLaunchKernelGGL(k_rowdot, dim3(cdiv(E, 4)), dim3(256), 0, T->st, T->eb[3], p.head.w, p.head_b.w, E, 1, T->att);
+        KPD_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_feat_head_bwd, dim3(cdiv(E, 4)), dim3(256), 0, T->st, dhn[d], T->zinv[d], T->e_dst[et], T->eb[3], T->att,
+                           p.head.w, T->eb[2], E, T->eb[4], T->dsv);
+        KPD_LAUNCH_CHECK();
+        KPD_TRY(gemv_t_acc(T, E, H, T->eb[3], LD, T->dsv, p.head.g, 1));
+        if (p.head_b.g) {
+            hipLaunchKernelGGL(k_sum_atomic, dim3(std::min(cdiv(E, 256), 256)), dim3(256), 0, T->st, T->dsv, E, p.head_b.g);
+            KPD_LAUNCH_CHECK();
+        }
+        KPD_TRY(edge_branch_bwd(T, p, l, et, nxt, true));
+        // coordinate branch
+        KPD_TRY(branch_params(T, l, et, 1, &p));
+        KPD_TRY(edge_branch_fwd(T, p, et, T->hs[s][l], T->hs[d][l]));
+        hipLaunchKernelGGL(k_coord_msg, dim3(cdiv(E, 4)), dim3(256), 0, T->st, T->eb[3], p.head.w, T->nvec, E, c.use_tanh,
+                           c.coords_range, T->sc, T->msgx);
+        KPD_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_coord_head_bwd, dim3(cdiv(E, 4)), dim3(256), 0, T->st, T->dx[cur][d], T->zinv[d], T->e_dst[et], T->nvec,
+                           T->sc, p.head.w, T->eb[2], E, c.use_tanh, c.coords_range, T->eb[4], T->dsv, T->dn);
+        KPD_LAUNCH_CHECK();
+        KPD_TRY(gemv_t_acc(T, E, H, T->eb[3], LD, T->dsv, p.head.g, 1));
+        KPD_TRY(edge_branch_bwd(T, p, l, et, nxt, false));
+        hipLaunchKernelGGL(k_geom_bwd, grid1(E), dim3(256), 0, T->st, T->ddij, T->dn, T->xdiff, T->dij, T->e_src[et], T->e_dst[et], E,
+                           T->dx[nxt][s], T->dx[nxt][d]);
+        KPD_LAUNCH_CHECK();
+    }
+    return KPD_OK;
+}
+
+}  // namespace
+
+extern "C" kpd_status kpd_egnn_trainer_backward(kpd_egnn_trainer *T, const float *d_eps_h, const float *d_eps_x, float *d_lig_h,
+                                                float *d_lig_x, float *d_kp_h, float *d_kp_x, void *stream) {
+    KPD_REQUIRE(T && d_eps_h && d_eps_x, KPD_ERR_INVALID, "null argument");
+    KPD_REQUIRE(T->have_forward, KPD_ERR_STATE, "kpd_egnn_trainer_backward before kpd_egnn_trainer_forward");
+    const kpd_egnn_config &c = T->cfg;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    T->st = st;
+    KPD_BLAS(rocblas_set_stream(T->blas, st));
+    const int L = c.n_layers, nl = T->n[0], nk = T->n[1];
+    int cur = 0, nxt = 1;
+    if (T->n_upd == 1) {        // kp not updated: one gradient accumulator across layers (the same tensors feed every layer)
+        T->dh[1][1] = T->dh[0][1];
+        T->dx[1][1] = T->dx[0][1];
+    }
+    // decoder backward -> dh_out[lig][:, :256]; dh_out[kp] = 0; dx_out[lig] = d_eps_x; dx_out[kp] = 0
+    for (int k = 0; k < 2; ++k)
+        for (int nt = 0; nt < 2; ++nt) {
+            KPD_HIP(hipMemsetAsync(T->dh[k][nt], 0, (size_t)T->n[nt] * LD * 4, st));
+            KPD_HIP(hipMemsetAsync(T->dx[k][nt], 0, (size_t)T->n[nt] * 12, st));
+        }
+    {
+        MlpParams p;
+        KPD_TRY(mlp_params(T, "lig_decoder", 256, 2 * c.atom_nf, c.atom_nf, &p));
+        // recompute the decoder activations (scratch may have been reused) and run its backward
+        float *dout = T->nb[1];
+        KPD_TRY(mlp_fwd(T, p, T->hs[0][L], LD, nl, T->dec1, T->dec2, ENC_LD, T->nb[0], LD, dout, LD, false));
+        const long long tot = (long long)nl * c.atom_nf;
+        hipLaunchKernelGGL(k_copy_rows, grid1(tot), dim3(256), 0, st, d_eps_h, c.atom_nf, dout, LD, tot, c.atom_nf);
+        KPD_LAUNCH_CHECK();
+        KPD_TRY(mlp_bwd(T, p, T->hs[0][L], LD, nl, T->dec1, T->dec2, ENC_LD, T->nb[0], LD, dout, LD, false, T->dact, T->dh[cur][0], LD));
+        KPD_HIP(hipMemcpyAsync(T->dx[cur][0], d_eps_x, (size_t)nl * 12, hipMemcpyDeviceToDevice, st));
+    }
+    float *dhn[2] = {T->nb[5], T->nb[6]};
+    for (int l = L - 1; l >= 0; --l) {
+        KPD_TRY(layer_bwd(T, l, cur, nxt, dhn));
+        std::swap(cur, nxt);
+    }
+    // encoders (the timestep column carries no parameter gradient)
+    {
+        MlpParams p;
+        KPD_TRY(mlp_params(T, "lig_encoder", c.atom_nf, 64, 256, &p));
+        KPD_TRY(mlp_fwd(T, p, T->bt.lig_h, c.atom_nf, nl, T->enc1[0], T->enc2[0], ENC_LD, T->nb[0], LD, T->nb[1], LD, true));
+        KPD_TRY(mlp_bwd(T, p, T->bt.lig_h, c.atom_nf, nl, T->enc1[0], T->enc2[0], ENC_LD, T->nb[0], LD, T->dh[cur][0], LD, true, T->dact,
+                        d_lig_h, c.atom_nf));
+        if (T->rec_identity) {
+            if (d_kp_h) {
+                const long long tot = (long long)nk * 256;
+                hipLaunchKernelGGL(k_copy_rows, grid1(tot), dim3(256), 0, st, T->dh[cur][1], LD, d_kp_h, 256, tot, 256);
+                KPD_LAUNCH_CHECK();
+            }
+        } else {
+            KPD_TRY(mlp_params(T, "rec_encoder", c.rec_nf, 2 * c.rec_nf, 256, &p));
+            KPD_TRY(mlp_fwd(T, p, T->bt.kp_h, c.rec_nf, nk, T->enc1[1], T->enc2[1], ENC_LD, T->nb[0], LD, T->nb[1], LD, true));
+            KPD_TRY(mlp_bwd(T, p, T->bt.kp_h, c.rec_nf, nk, T->enc1[1], T->enc2[1], ENC_LD, T->nb[0], LD, T->dh[cur][1], LD, true, T->dact,
+                            d_kp_h, c.rec_nf));
+        }
+    }
+    // eps_x = x_out - x_0: the direct term
+    if (d_lig_x) {
+        KPD_HIP(hipMemcpyAsync(d_lig_x, T->dx[cur][0], (size_t)nl * 12, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_sub_inplace, grid1(3 * nl), dim3(256), 0, st, d_lig_x, d_eps_x, 3 * nl);
+        KPD_LAUNCH_CHECK();
+    }
+    if (d_kp_x) KPD_HIP(hipMemcpyAsync(d_kp_x, T->dx[cur][1], (size_t)nk * 12, hipMemcpyDeviceToDevice, st));
+    T->have_forward = false;
+    return KPD_OK;
+}

@@ -4,7 +4,9 @@
 state-dict layout of models/dynamics.py:298-385 (LigRecConv :9-87, LigRecEGNN :221-264), so a
 reference `model.pt` loads unchanged.  The modules below only own parameters; the arithmetic of
 `forward` -- encoders, per-step radius/kNN graph build, the EGNN stack and the decoder -- runs in
-libkpd_hip.so (csrc/egnn.hip).  Training (autograd through the fused kernels) is not implemented.
+libkpd_hip.so (csrc/egnn.hip).  With gradients enabled the call goes through `_EgnnTrainFn`: forward with saved
+layer states and the hand-derived backward pass of csrc/egnn_train.hip (`kpd_egnn_trainer_*`), so train.py-style
+loops differentiate the denoiser without a PyTorch implementation of it.
 """
 from typing import Dict
 
@@ -20,6 +22,30 @@ def _mlp2(n_in, n_hidden, n_out, final_act):
     if final_act:
         layers.append(nn.SiLU())
     return nn.Sequential(*layers)
+
+
+class _EgnnTrainFn(torch.autograd.Function):
+    """LigRecDynamics.forward as one autograd node: inputs (lig x, lig h, kp x, kp h) and every parameter; the backward
+    pass is kpd_egnn_trainer_backward (gradients in the reference parameter layout)."""
+
+    @staticmethod
+    def forward(ctx, module, pb, timestep, lig_x, lig_h, kp_x, kp_h, *params):
+        trainer, names = module._trainer()
+        ctx.trainer, ctx.names, ctx.params = trainer, names, params
+        ctx.inputs = (lig_x, lig_h, kp_x, kp_h, timestep)          # kept alive until backward (the C side holds pointers)
+        trainer.bind(names, params, [None] * len(params))
+        eps_h, eps_x = trainer.forward(pb, lig_x, lig_h, kp_x, kp_h, timestep)
+        return eps_h, eps_x
+
+    @staticmethod
+    def backward(ctx, d_eps_h, d_eps_x):
+        lig_x, lig_h, kp_x, kp_h, _ = ctx.inputs
+        need = ctx.needs_input_grad[3:7]
+        grads = [torch.zeros_like(p) if ctx.needs_input_grad[7 + i] else None for i, p in enumerate(ctx.params)]
+        ctx.trainer.bind(ctx.names, ctx.params, grads)
+        d_in = [torch.empty_like(t) if n else None for t, n in zip((lig_x, lig_h, kp_x, kp_h), need)]
+        ctx.trainer.backward(d_eps_h.contiguous().float(), d_eps_x.contiguous().float(), d_in[1], d_in[0], d_in[3], d_in[2])
+        return (None, None, None, *d_in, *grads)
 
 
 class LigRecConv(nn.Module):
@@ -84,6 +110,19 @@ class LigRecDynamics(nn.Module):
                                update_kp_feat=update_kp_feat, norm=norm)
         self._engine = None
         self._engine_key = None
+        self._train = None
+
+    def _trainer(self):
+        """The training engine and the parameter names in `self.parameters()` order (reference state-dict names)."""
+        if self._train is None:
+            if isinstance(self.message_norm, (dict, str)):
+                raise ValueError(f'message_norm must be a number for the EGNN denoiser, got {self.message_norm!r}')
+            cfg = hip.KpdEgnnConfig(int(self.atom_nf), int(self.rec_nf), int(self.n_layers), int(self.hidden_nf),
+                                    int(bool(self.use_tanh)), int(bool(self.norm)), int(bool(self.update_kp_feat)),
+                                    float(self.message_norm), int(self.ll_k), int(self.kl_k),
+                                    float(self.graph_cutoffs.get('ll', 0.0)), float(self.graph_cutoffs.get('kl', 0.0)), 10.0)
+            self._train = (hip.EgnnTrainer(cfg, self.atom_nf, self.rec_nf), [n for n, _ in self.named_parameters()])
+        return self._train
 
     # ---- HIP engine management ---------------------------------------------------------
     def _weights_key(self):
@@ -105,9 +144,11 @@ class LigRecDynamics(nn.Module):
     def forward(self, g: HeteroBatch, timestep: torch.Tensor, batch_idxs: Dict[str, torch.Tensor] = None):
         """Predicted noise (eps_h [N_lig, atom_nf], eps_x [N_lig, 3]); `batch_idxs` is accepted for
         signature compatibility, the per-complex offsets are taken from the graph's batch info."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError('the HIP denoiser is forward-only; call it under torch.no_grad() '
-                                      '(backward kernels are listed as next work in DESIGN.md)')
         pb = g.prepared()
         lig, kp = g.nodes['lig'].data, g.nodes['kp'].data
+        if torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or
+                                        any(t.requires_grad for t in (lig['x_0'], lig['h_0'], kp['x_0'], kp['h_0']))):
+            ins = [hip._dev_f32(t, n) for t, n in ((lig['x_0'], 'lig x_0'), (lig['h_0'], 'lig h_0'), (kp['x_0'], 'kp x_0'),
+                                                   (kp['h_0'], 'kp h_0'))]
+            return _EgnnTrainFn.apply(self, pb, hip._dev_f32(timestep, 'timestep'), *ins, *self.parameters())
         return self.engine().forward(pb, lig['x_0'], lig['h_0'], kp['x_0'], kp['h_0'], timestep)

@@ -132,6 +132,13 @@ def lib():
     L.kpd_complex_noise.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_void_p,
                                     C.c_void_p]
     L.kpd_step_coefficients.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    L.kpd_egnn_trainer_create.argtypes = [C.POINTER(KpdEgnnConfig), C.POINTER(C.c_void_p)]
+    L.kpd_egnn_trainer_destroy.argtypes = [C.c_void_p]
+    L.kpd_egnn_trainer_destroy.restype = None
+    L.kpd_egnn_trainer_bind.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32]
+    L.kpd_egnn_trainer_reserve.argtypes = [C.c_void_p] + [C.c_int32] * 6
+    L.kpd_egnn_trainer_forward.argtypes = [C.c_void_p, C.POINTER(KpdBatch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.kpd_egnn_trainer_backward.argtypes = [C.c_void_p] + [C.c_void_p] * 7
     L.kpd_rec_graph_scratch_bytes.argtypes = [C.c_int32, C.c_int32]
     L.kpd_rec_graph_scratch_bytes.restype = C.c_int64
     L.kpd_build_rec_graph.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p,
@@ -157,6 +164,8 @@ EXPORTS = [
     'kpd_recegnn_create', 'kpd_recegnn_destroy', 'kpd_recegnn_load_weight', 'kpd_recegnn_commit', 'kpd_recegnn_reserve',
     'kpd_recegnn_forward',
     'kpd_xyz_scratch_bytes', 'kpd_xyz_emit', 'kpd_rec_graph_scratch_bytes', 'kpd_build_rec_graph',
+    'kpd_egnn_trainer_create', 'kpd_egnn_trainer_destroy', 'kpd_egnn_trainer_bind', 'kpd_egnn_trainer_reserve',
+    'kpd_egnn_trainer_forward', 'kpd_egnn_trainer_backward',
 ]
 
 
@@ -301,6 +310,51 @@ class EgnnEngine:
         arr = (C.c_int32 * 8)()
         check(lib().kpd_egnn_last_counts(self._h, arr, _stream()))
         return dict(E_ll=arr[0], E_kl=arr[1], E_lk=arr[2], E_kk=arr[3], tiles=arr[4])
+
+
+class EgnnTrainer:
+    """Owns one kpd_egnn_trainer handle: forward with saved layer states + backward of LigRecDynamics.forward.
+    Parameters are bound by reference name to their live storage (read in place every step); gradients are written
+    into fresh zero tensors per backward call and handed to autograd."""
+
+    def __init__(self, cfg: 'KpdEgnnConfig', atom_nf: int, rec_nf: int):
+        self.cfg, self.atom_nf, self.rec_nf = cfg, int(atom_nf), int(rec_nf)
+        self._h = C.c_void_p()
+        check(lib().kpd_egnn_trainer_create(C.byref(self.cfg), C.byref(self._h)))
+        self._reserved = None
+
+    def __del__(self):
+        if getattr(self, '_h', None) and _lib is not None:
+            _lib.kpd_egnn_trainer_destroy(self._h)
+            self._h = None
+
+    def bind(self, names, weights, grads):
+        L = lib()
+        for name, w, g in zip(names, weights, grads):
+            if not (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()):
+                raise KpdError(f'parameter {name} must be a contiguous fp32 GPU tensor')
+            shape = (C.c_int64 * w.dim())(*w.shape)
+            check(L.kpd_egnn_trainer_bind(self._h, name.encode(), w.data_ptr(), None if g is None else g.data_ptr(), shape, w.dim()))
+
+    def reserve(self, pb: PreparedBatch):
+        key = (pb.B, pb.n_lig, pb.n_kp, pb.n_kk, pb.max_lig, pb.max_kp)
+        if self._reserved is not None and all(a <= b for a, b in zip(key, self._reserved)):
+            return
+        torch.cuda.synchronize()
+        check(lib().kpd_egnn_trainer_reserve(self._h, *key))
+        self._reserved = key if self._reserved is None else tuple(max(a, b) for a, b in zip(key, self._reserved))
+
+    def forward(self, pb: PreparedBatch, lig_x, lig_h, kp_x, kp_h, t):
+        self.reserve(pb)
+        eps_h = torch.empty(pb.n_lig, self.atom_nf, device=lig_x.device)
+        eps_x = torch.empty(pb.n_lig, 3, device=lig_x.device)
+        bt = pb.struct(lig_x, lig_h, kp_x, kp_h)
+        check(lib().kpd_egnn_trainer_forward(self._h, C.byref(bt), t.data_ptr(), eps_h.data_ptr(), eps_x.data_ptr(), _stream()))
+        return eps_h, eps_x
+
+    def backward(self, d_eps_h, d_eps_x, d_lig_h, d_lig_x, d_kp_h, d_kp_x):
+        check(lib().kpd_egnn_trainer_backward(self._h, d_eps_h.data_ptr(), d_eps_x.data_ptr(), _ptr(d_lig_h), _ptr(d_lig_x),
+                                              _ptr(d_kp_h), _ptr(d_kp_x), _stream()))
 
 
 class GvpEngine:

@@ -88,6 +88,7 @@ class KeypointDiffusion(nn.Module):
         self.n_lig_features, self.n_kp_feat, self.n_timesteps = atom_nf, rec_nf, n_timesteps
         self.lig_feat_norm_constant = lig_feat_norm_constant
         self.use_fake_atoms, self.rec_encoder_type, self.architecture = use_fake_atoms, rec_encoder_type, architecture
+        self.rl_dist_threshold = rl_dist_threshold
         if use_fake_atoms:
             raise NotImplementedError('fake atoms are unused by every shipped config (max_fake_atom_frac: 0.0) and '
                                       'the reference implementation of their removal cannot run (ligand_diffuser.py:559)')
@@ -110,8 +111,52 @@ class KeypointDiffusion(nn.Module):
 
     # ---- training entry point ----------------------------------------------------------
     def forward(self, complex_graphs, interface_points):
-        raise NotImplementedError('training (loss + backward, ligand_diffuser.py:89-175) is outside the accelerated '
-                                  'path: the HIP kernels are forward-only')
+        """Losses of one training batch (ligand_diffuser.py:89-175): {'l2', 'pos', 'feat', 'rec_encoder'}.  The noise
+        prediction is differentiated by the HIP backward pass (dynamics.LigRecDynamics under autograd); implemented
+        for the EGNN denoiser with the fixed receptor encoder (configs/dev_config.yml, trained_models/egnn_all_atom,
+        egnn_ca), where the encoder has no parameters and its loss is the constant 0 (:85-87)."""
+        if self.architecture != 'egnn' or self.rec_encoder_type != 'fixed':
+            raise NotImplementedError('training is implemented for architecture="egnn" with rec_encoder_type="fixed"; the backward '
+                                      'passes of the GVP denoiser and of the learned receptor encoders are not built yet')
+        if self.rl_dist_threshold > 0:
+            raise NotImplementedError('the receptor-ligand hinge loss (rl_dist_threshold > 0) is unused by every shipped config')
+        losses = {}
+        g = self.normalize(complex_graphs)
+        batch_size, device = g.batch_size, g.device
+        batch_idxs = G.get_batch_idxs(g)
+        g = self.rec_encoder(g, batch_idxs)
+        batch_idxs = G.get_batch_idxs(g)                      # :106-107: keypoints = receptor atoms now
+        losses['rec_encoder'] = torch.tensor(0.0, device=device, dtype=g.nodes['rec'].data['x_0'].dtype)   # loss_type 'none'
+        g = self.remove_com(g, batch_idxs['lig'], batch_idxs['kp'], com='ligand')
+        t = torch.randint(0, self.n_timesteps, size=(batch_size,), device=device).float() / self.n_timesteps
+        eps = {'h': torch.randn(g.nodes['lig'].data['h_0'].shape, device=device),
+               'x': torch.randn(g.nodes['lig'].data['x_0'].shape, device=device)}
+        gamma_t = self.gamma(t).to(device=device)
+        g = self.noised_representation(g, batch_idxs['lig'], batch_idxs['kp'], eps, gamma_t)
+        eps_h_pred, eps_x_pred = self.dynamics(g, t, batch_idxs)
+        x_loss = (eps['x'] - eps_x_pred).square().sum()
+        n_x_loss_terms = eps['x'].numel()
+        h_loss = (eps['h'] - eps_h_pred).square().sum()
+        losses['l2'] = (x_loss + h_loss) / (n_x_loss_terms + eps['h'].numel())
+        losses['pos'] = x_loss / n_x_loss_terms
+        losses['feat'] = h_loss / eps['h'].numel()
+        return losses
+
+    def noised_representation(self, g, lig_batch_idx, kp_batch_idx, eps, gamma_t):
+        """z_t = alpha_t z_0 + sigma_t eps, then ligand-COM removal (ligand_diffuser.py:205-219)."""
+        alpha_t = self.alpha(gamma_t)[lig_batch_idx][:, None]
+        sigma_t = self.sigma(gamma_t)[lig_batch_idx][:, None]
+        g.nodes['lig'].data['x_0'] = alpha_t * g.nodes['lig'].data['x_0'] + sigma_t * eps['x']
+        g.nodes['lig'].data['h_0'] = alpha_t * g.nodes['lig'].data['h_0'] + sigma_t * eps['h']
+        return self.remove_com(g, lig_batch_idx, kp_batch_idx, com='ligand')
+
+    def denoised_representation(self, g, lig_batch_idx, kp_batch_idx, eps_x_pred, eps_h_pred, gamma_t):
+        """ligand_diffuser.py:221-230."""
+        alpha_t = self.alpha(gamma_t)[lig_batch_idx][:, None]
+        sigma_t = self.sigma(gamma_t)[lig_batch_idx][:, None]
+        g.nodes['lig'].data['x_0'] = (g.nodes['lig'].data['x_0'] - sigma_t * eps_x_pred) / alpha_t
+        g.nodes['lig'].data['h_0'] = (g.nodes['lig'].data['h_0'] - sigma_t * eps_h_pred) / alpha_t
+        return g
 
     # ---- small host helpers ------------------------------------------------------------
     def normalize(self, g):

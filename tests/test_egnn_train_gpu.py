@@ -1,0 +1,110 @@
+"""Backward pass of the EGNN denoiser: gradients of every parameter and of the inputs from
+kpd_egnn_trainer_* against torch autograd through the CPU oracle (the restated LigRecDynamics.forward)."""
+import pytest
+import torch
+
+from keypoint_diffusion_amd import graph as G, synth
+from keypoint_diffusion_amd.dynamics import LigRecDynamics
+from oracle import egnn as oegnn
+from tests import util
+
+pytestmark = pytest.mark.gpu
+CUT = util.CUTOFFS_ALL_ATOM
+TOL = 2e-4          # relative to the largest entry of each gradient tensor (fp32 both sides, different summation order)
+
+
+def _case(cfg, n_rec, n_lig, rec_nf=10, seed=5):
+    gs = synth.synth_complexes(n_rec, n_lig, 20, CUT, seed=seed, n_rec_feat=rec_nf)
+    g = util.fixed_encode(G.batch(gs))
+    model = LigRecDynamics(10, rec_nf, graph_cutoffs=CUT, **cfg)
+    synth.fill_state_dict_(model, 21)
+    with torch.no_grad():               # the synthetic fill leaves the tiny xavier head: give the coordinate head some weight
+        for n, p in model.named_parameters():
+            if n.endswith('.4.weight'):
+                p.mul_(20.0)
+    t = torch.rand(len(n_rec)) * 0.9 + 0.05
+    return g, model, t
+
+
+def _oracle_grads(model, cfg, g, t, w_h, w_x):
+    ob = util.to_obatch(g)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    ins = {k: v.detach().clone().requires_grad_(True) for k, v in (('lx', ob.x['lig']), ('lh', ob.h['lig']), ('kx', ob.x['kp']),
+                                                                   ('kh', ob.h['kp']))}
+    ob.x['lig'], ob.h['lig'], ob.x['kp'], ob.h['kp'] = ins['lx'], ins['lh'], ins['kx'], ins['kh']
+    with torch.no_grad():
+        edges = oegnn.lig_edges(ob, dict(cfg, graph_cutoffs=CUT))
+    eh, ex = oegnn.egnn_dynamics_forward(sd, dict(cfg, graph_cutoffs=CUT), ob, t, edges=edges)
+    loss = (eh * w_h).sum() + (ex * w_x).sum()
+    loss.backward()
+    return eh.detach(), ex.detach(), {k: v.grad for k, v in sd.items()}, {k: v.grad for k, v in ins.items()}
+
+
+@pytest.mark.parametrize('name,cfg,rec_nf', [
+    ('c2', util.EGNN_C2, 10),
+    ('dev', dict(n_layers=2, hidden_nf=256, use_tanh=True, message_norm=0, update_kp_feat=False, norm=True, kl_k=5), 20),
+    ('notanh', dict(n_layers=2, hidden_nf=256, use_tanh=False, message_norm=3.0, update_kp_feat=True, norm=False, kl_k=0,
+                    ll_k=4), 10),
+])
+def test_gradients_match_oracle_autograd(name, cfg, rec_nf):
+    cfg = dict(cfg)
+    if name == 'c2':
+        cfg['n_layers'] = 3
+    g, model, t = _case(cfg, [60, 35, 48], [9, 14, 6], rec_nf=rec_nf)
+    gen = torch.Generator().manual_seed(2)
+    n_lig = g.num_nodes('lig')
+    w_h, w_x = torch.randn(n_lig, 10, generator=gen), torch.randn(n_lig, 3, generator=gen)
+    eh_ref, ex_ref, pg_ref, ig_ref = _oracle_grads(model, cfg, g, t, w_h, w_x)
+
+    model = model.cuda()
+    gd = g.to('cuda')
+    ins = {}
+    for nt, kx, kh in (('lig', 'lx', 'lh'), ('kp', 'kx', 'kh')):
+        for key, name_ in ((kx, 'x_0'), (kh, 'h_0')):
+            ins[key] = gd.nodes[nt].data[name_].detach().clone().requires_grad_(True)
+            gd.nodes[nt].data[name_] = ins[key]
+    eh, ex = model(gd, t.cuda(), None)
+    assert util.rel_err(eh.detach().cpu(), eh_ref) < 1e-4 and util.rel_err(ex.detach().cpu(), ex_ref) < 1e-4
+    loss = (eh * w_h.cuda()).sum() + (ex * w_x.cuda()).sum()
+    loss.backward()
+    worst = []
+    for n, p in model.named_parameters():
+        ref = pg_ref[n]
+        assert p.grad is not None, n
+        if ref is None:                     # no path to the loss (keypoint-side weights of the last layer): exactly zero
+            assert float(p.grad.abs().max()) == 0.0, n
+            continue
+        err = (p.grad.cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
+        worst.append((err, n))
+    worst.sort(reverse=True)
+    assert worst[0][0] < TOL, worst[:8]
+    for k, ref in ig_ref.items():
+        got = ins[k].grad
+        assert got is not None, k
+        err = (got.cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
+        assert err < TOL, (k, err)
+
+
+def test_training_step_reduces_loss():
+    """KeypointDiffusion.forward (ligand_diffuser.py:89-175) + an optimizer step: the train.py inner loop on the GPU."""
+    from keypoint_diffusion_amd.ligand_diffuser import KeypointDiffusion
+    cfg = dict(util.EGNN_C2, n_layers=2)
+    model = KeypointDiffusion(10, 10, None, n_timesteps=100, architecture='egnn', rec_encoder_type='fixed',
+                              graph_config=dict(n_keypoints=20, graph_cutoffs=CUT), dynamics_config=cfg,
+                              rec_encoder_config={'vector_size': 16}, precision=1e-5)
+    synth.fill_state_dict_(model, 3)
+    model = model.cuda().train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    gs = synth.synth_complexes([50, 70], [10, 13], 20, CUT, seed=11)
+    losses = []
+    for it in range(6):
+        torch.manual_seed(0)                 # same t and eps every iteration: the loss must go down
+        g = G.batch([x.to('cuda') for x in synth.synth_complexes([50, 70], [10, 13], 20, CUT, seed=11)])
+        out = model(g, None)
+        assert set(out) == {'l2', 'pos', 'feat', 'rec_encoder'} and float(out['rec_encoder']) == 0.0
+        opt.zero_grad()
+        out['l2'].backward()
+        torch.nn.utils.clip_grad_value_(model.parameters(), 1.0)       # train.py:539-543
+        opt.step()
+        losses.append(float(out['l2'].detach()))
+    assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0], losses

@@ -89,10 +89,11 @@ def test_sample_given_pocket_end_to_end(cuda):
 
 
 def test_forward_only_contract(cuda):
-    model = _model('egnn').to(cuda)
+    """What has no backward pass refuses loudly under autograd instead of returning constants."""
+    model = _model('gvp').to(cuda)
     g = model.encode_receptors(G.batch(synth.synth_complexes([30], [5], 20, CUT))).to(cuda)
     with pytest.raises(NotImplementedError):
-        model.dynamics(g, torch.tensor([0.5], device=cuda), None)          # grad enabled: backward not implemented
+        model.dynamics(g, torch.tensor([0.5], device=cuda), None)          # GVP denoiser: backward not implemented
     with pytest.raises(NotImplementedError):
         model(g, None)
 
