@@ -55,6 +55,9 @@ WORKLOADS = {
                       cutoffs=dict(CUTOFFS, kl=8, ll=5)),
     'gvp_40kp': dict(arch='gvp', enc='learned', dyn=GVP_DYN, n_kp=40, cutoffs=dict(CUTOFFS, kl=8, ll=6.0)),
     'gvp_all_atom': dict(arch='gvp', enc='fixed', dyn=dict(GVP_DYN, message_norm='mean'), n_kp=20, cutoffs=CUTOFFS),
+    # one optimisation step of train.py's inner loop (loss of KeypointDiffusion.forward, backward, clip, Adam) on the
+    # egnn_all_atom model: the backward pass of csrc/egnn_train.hip
+    'egnn_train': dict(arch='egnn', enc='fixed', dyn=DYNAMICS, n_kp=20, cutoffs=CUTOFFS),
 }
 
 
@@ -120,6 +123,75 @@ def cpu_baseline(B_sample=4, steps=2):
                       f'{steps} reverse steps after 1 warm-up, scaled to the B=64 batch'}
 
 
+def train_cpu_baseline(B_sample=2):
+    """Loss + torch autograd through the CPU oracle for B_sample complexes of the same shape (one step after a warm-up)."""
+    from oracle import egnn as oegnn
+    from tests.util import to_obatch
+    model = build_model('cpu')
+    g = build_batch(model, B_sample, 300, 25, seed=99, device='cpu')
+    ob = to_obatch(g)
+    sd = {k[len('dynamics.'):]: v.clone().requires_grad_(True) for k, v in model.state_dict().items() if k.startswith('dynamics.')}
+    cfg = dict(DYNAMICS, graph_cutoffs=CUTOFFS)
+
+    def one():
+        eh, ex = oegnn.egnn_dynamics_forward(sd, cfg, ob, torch.full((B_sample,), 0.5))
+        (eh.square().sum() + ex.square().sum()).backward()
+
+    one()
+    t0 = time.perf_counter()
+    one()
+    dt = time.perf_counter() - t0
+    return {'value': B_sample / dt / 64.0, 'unit': 'steps/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'complex_steps_per_s': B_sample / dt,
+            'sample': f'oracle forward + torch autograd backward on {B_sample} complexes of the same 300/25 shape, 1 step after '
+                      f'1 warm-up, scaled to the B=64 batch (no optimizer step on the CPU side)'}
+
+
+def run_train(args, device, rank, world, dist):
+    """Secondary workload: training steps/sec of the EGNN denoiser (fixed receptor encoder) on synthetic complexes."""
+    w = WORKLOADS['egnn_train']
+    model = build_model(device, 'egnn_train').train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    B = args.batch
+    gs = synth.synth_complexes([args.n_rec] * B, [args.n_lig] * B, w['n_kp'], w['cutoffs'], seed=1234 + rank * B)
+    template = G.batch(gs).to(device)
+
+    def step():
+        g = template.to(device)             # fresh container over the same device tensors (forward re-binds node data)
+        losses = model(g, None)
+        opt.zero_grad(set_to_none=True)
+        losses['l2'].backward()
+        torch.nn.utils.clip_grad_value_(model.parameters(), 1.0)
+        opt.step()
+        return losses['l2']
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if rank == 0:
+        out = {'metric': 'training steps/sec', 'value': world * args.steps / elapsed, 'unit': 'steps/s', 'n_gpus': world,
+               'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+               'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': f'egnn_train: loss + backward + clip + Adam on egnn_all_atom (6 layers, hidden 256), batch of {B} '
+                                      f'synthetic {args.n_rec}-atom pockets / {args.n_lig}-atom ligands per GPU, no gradient all-reduce',
+                          'batch_per_gpu': B},
+               'complex_steps_per_s': world * args.steps / elapsed * B, 'final_l2': float(last.detach())}
+        if not args.no_cpu_baseline:
+            out['cpu_baseline'] = train_cpu_baseline()
+        print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -157,6 +229,11 @@ def main():
         print(f'[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}', file=sys.stderr)
 
     torch.manual_seed(1000 + rank)
+    if args.workload == 'egnn_train':
+        run_train(args, device, rank, world, dist)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     model = build_model(device, args.workload)
     B = args.batch
     n_rec, n_lig = args.n_rec, args.n_lig

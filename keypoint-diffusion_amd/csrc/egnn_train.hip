@@ -333,6 +333,43 @@ __global__ void k_sub_inplace(float *__restrict__ a, const float *__restrict__ b
     if (i < n) a[i] -= b[i];
 }
 
+// y[c * incy] += sum over rows r of A[r][c] * (x ? x[r] : 1): bias gradients and the A^T x products of the heads.
+// Tall-skinny (hundreds of thousands of rows, <= 512 columns): a row block per workgroup, columns across threads
+// (coalesced row reads), one atomic per column and workgroup.
+constexpr int COLSUM_ROWS = 256, COLSUM_THREADS = 320;       // 320 threads: the 257 columns of a layer in one pass
+__global__ void k_colsum(const float *__restrict__ A, int lda, const float *__restrict__ x, int M, int K, float *__restrict__ y,
+                         int incy, float *__restrict__ y2) {
+    const int r0 = blockIdx.x * COLSUM_ROWS, r1 = min(M, r0 + COLSUM_ROWS);
+    for (int c = threadIdx.x; c < K; c += blockDim.x) {
+        float s0 = 0.0f, s1 = 0.0f, p0 = 0.0f, p1 = 0.0f;       // s: weighted by x (or plain), p: plain sums when both are wanted
+        int r = r0;
+        for (; r + 1 < r1; r += 2) {
+            const float a0 = A[(size_t)r * lda + c], a1 = A[(size_t)(r + 1) * lda + c];
+            s0 = fmaf(a0, x ? x[r] : 1.0f, s0);
+            s1 = fmaf(a1, x ? x[r + 1] : 1.0f, s1);
+            p0 += a0;
+            p1 += a1;
+        }
+        if (r < r1) {
+            const float a0 = A[(size_t)r * lda + c];
+            s0 = fmaf(a0, x ? x[r] : 1.0f, s0);
+            p0 += a0;
+        }
+        if (y) atomicAdd(&y[(size_t)c * incy], s0 + s1);
+        if (y2) atomicAdd(&y2[c], p0 + p1);
+    }
+}
+
+// dst[i] += sum over s of part[s][i]
+__global__ void k_reduce_parts(const float *__restrict__ part, int n_parts, int rows, int cols, float *__restrict__ dst, int ldd) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    float s = 0.0f;
+    for (int k = 0; k < n_parts; ++k) s += part[(size_t)k * rows * cols + i];
+    const int r = i / cols, c = i - r * cols;
+    dst[(size_t)r * ldd + c] += s;
+}
+
 inline dim3 grid1(long long n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
 
 struct Param {
@@ -372,6 +409,8 @@ struct kpd_egnn_trainer {
     // scratch
     float *eb[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // [cap_E, LD] each
     float *nb[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // [cap_N, LD] each
+    float *part = nullptr;                                                       // split-K partial sums of the weight-gradient GEMMs
+    size_t part_floats = 0;
     float *dact = nullptr;                                                       // [cap_N, ENC_LD]
     float *xdiff = nullptr, *dij = nullptr, *nvec = nullptr, *att = nullptr, *sc = nullptr, *dsv = nullptr, *ddij = nullptr,
           *dn = nullptr, *msgx = nullptr, *ones = nullptr;
@@ -417,15 +456,41 @@ kpd_status gemv_n(kpd_egnn_trainer *T, int M, int K, const float *A, int lda, co
     return KPD_OK;
 }
 
-// y[K] (stride incy) += A[M,K]^T x[M], A row-major
+// y[K] (stride incy) += A[M,K]^T x[M] (x = nullptr: column sums), A row-major
 kpd_status gemv_t_acc(kpd_egnn_trainer *T, int M, int K, const float *A, int lda, const float *x, float *y, int incy) {
     if (M == 0 || !y) return KPD_OK;
-    const float alpha = 1.0f, beta = 1.0f;
-    KPD_BLAS(rocblas_sgemv(T->blas, rocblas_operation_none, K, M, &alpha, A, lda, x, 1, &beta, y, incy));
+    hipLaunchKernelGGL(k_colsum, dim3(cdiv(M, COLSUM_ROWS)), dim3(COLSUM_THREADS), 0, T->st, A, lda, x, M, K, y, incy, (float *)nullptr);
+    KPD_LAUNCH_CHECK();
     return KPD_OK;
 }
 
-kpd_status colsum_acc(kpd_egnn_trainer *T, int M, int K, const float *A, int lda, float *y) { return gemv_t_acc(T, M, K, A, lda, T->ones, y, 1); }
+// y[K] (stride incy) += A^T x and y2[K] += column sums of A, in one pass over A
+kpd_status gemv_t_colsum_acc(kpd_egnn_trainer *T, int M, int K, const float *A, int lda, const float *x, float *y, int incy, float *y2) {
+    if (M == 0 || (!y && !y2)) return KPD_OK;
+    hipLaunchKernelGGL(k_colsum, dim3(cdiv(M, COLSUM_ROWS)), dim3(COLSUM_THREADS), 0, T->st, A, lda, x, M, K, y, incy, y2);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+kpd_status colsum_acc(kpd_egnn_trainer *T, int M, int K, const float *A, int lda, float *y) { return gemv_t_acc(T, M, K, A, lda, nullptr, y, 1); }
+
+// weight gradient C[M,N] += A[K,M]^T B[K,N] with K = rows of a tall activation matrix: the output is a few tiles only, so
+// K is split over GRAD_SPLIT batches (one strided-batched GEMM into partial sums) and the partials are reduced
+constexpr int GRAD_SPLIT = 48;
+kpd_status grad_gemm(kpd_egnn_trainer *T, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc) {
+    if (!C || M == 0 || N == 0 || K == 0) return KPD_OK;
+    const int chunk = K / GRAD_SPLIT;
+    if (chunk < 128 || (size_t)M * N > T->part_floats / GRAD_SPLIT) return gemm(T, true, false, M, N, K, A, lda, B, ldb, 1.0f, C, ldc);
+    const float one = 1.0f, zero = 0.0f;
+    KPD_BLAS(rocblas_sgemm_strided_batched(T->blas, rocblas_operation_none, rocblas_operation_transpose, N, M, chunk, &one, B, ldb,
+                                           (rocblas_stride)chunk * ldb, A, lda, (rocblas_stride)chunk * lda, &zero, T->part, N,
+                                           (rocblas_stride)M * N, GRAD_SPLIT));
+    hipLaunchKernelGGL(k_reduce_parts, grid1((long long)M * N), dim3(256), 0, T->st, T->part, GRAD_SPLIT, M, N, C, ldc);
+    KPD_LAUNCH_CHECK();
+    const int done = chunk * GRAD_SPLIT;
+    if (done < K) KPD_TRY(grad_gemm(T, M, N, K - done, A + (size_t)done * lda, lda, B + (size_t)done * ldb, ldb, C, ldc));
+    return KPD_OK;
+}
 
 kpd_status param(kpd_egnn_trainer *T, const std::string &name, int rows, int cols, Param *out) {
     auto it = T->params.find(name);
@@ -605,13 +670,13 @@ kpd_status mlp_bwd(kpd_egnn_trainer *T, const MlpParams &p, const float *x, int 
         KPD_LAUNCH_CHECK();
     }
     KPD_TRY(colsum_acc(T, n, p.fout, dout, ldo, p.b2.g));
-    if (p.W2.g) KPD_TRY(gemm(T, true, false, p.fout, p.hid, n, dout, ldo, act1, ld1, 1.0f, p.W2.g, p.hid));
+    if (p.W2.g) KPD_TRY(grad_gemm(T, p.fout, p.hid, n, dout, ldo, act1, ld1, p.W2.g, p.hid));
     KPD_TRY(gemm(T, false, false, n, p.hid, p.fout, dout, ldo, p.W2.w, p.hid, 0.0f, dact1, ld1));
     const long long tot = (long long)n * p.hid;
     hipLaunchKernelGGL(k_silu_bwd, grid1(tot), dim3(256), 0, T->st, dact1, pre1, tot, p.hid, ld1);
     KPD_LAUNCH_CHECK();
     KPD_TRY(colsum_acc(T, n, p.hid, dact1, ld1, p.b0.g));
-    if (p.W0.g) KPD_TRY(gemm(T, true, false, p.hid, p.fin, n, dact1, ld1, x, ldx, 1.0f, p.W0.g, p.fin));
+    if (p.W0.g) KPD_TRY(grad_gemm(T, p.hid, p.fin, n, dact1, ld1, x, ldx, p.W0.g, p.fin));
     if (dx) KPD_TRY(gemm(T, false, false, n, p.fin, p.hid, dact1, ld1, p.W0.w, p.fin, 0.0f, dx, lddx));
     return KPD_OK;
 }
@@ -691,6 +756,7 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
     for (int k = 0; k < 6; ++k) add((size_t)cap_E * LD, 4);
     for (int k = 0; k < 7; ++k) add((size_t)cap_N * LD, 4);
     add((size_t)cap_N * ENC_LD, 4);
+    add((size_t)GRAD_SPLIT * 264 * 520, 4);
     for (int k = 0; k < 3; ++k) add((size_t)cap_E * 3, 4);      // xdiff, nvec, dn
     add((size_t)cap_E * 3, 4);                                    // msgx
     for (int k = 0; k < 5; ++k) add(cap_E, 4);                   // dij, att, sc, dsv, ddij
@@ -719,6 +785,8 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
     for (int k = 0; k < 6; ++k) T->eb[k] = W.take<float>((size_t)cap_E * LD);
     for (int k = 0; k < 7; ++k) T->nb[k] = W.take<float>((size_t)cap_N * LD);
     T->dact = W.take<float>((size_t)cap_N * ENC_LD);
+    T->part_floats = (size_t)GRAD_SPLIT * 264 * 520;
+    T->part = W.take<float>(T->part_floats);
     T->xdiff = W.take<float>((size_t)cap_E * 3); T->nvec = W.take<float>((size_t)cap_E * 3); T->dn = W.take<float>((size_t)cap_E * 3);
     T->msgx = W.take<float>((size_t)cap_E * 3);
     T->dij = W.take<float>(cap_E); T->att = W.take<float>(cap_E); T->sc = W.take<float>(cap_E); T->dsv = W.take<float>(cap_E);
@@ -846,7 +914,7 @@ kpd_status node_bwd(kpd_egnn_trainer *T, int l, int nt, int cur, int nxt, float 
         KPD_HIP(hipMemcpyAsync(du, dy, (size_t)n * LD * 4, hipMemcpyDeviceToDevice, T->st));
     }
     KPD_TRY(colsum_acc(T, n, H, du, LD, p.b2.g));
-    if (p.W2.g) KPD_TRY(gemm(T, true, false, H, H, n, du, LD, T->nb[3], LD, 1.0f, p.W2.g, H));
+    if (p.W2.g) KPD_TRY(grad_gemm(T, H, H, n, du, LD, T->nb[3], LD, p.W2.g, H));
     float *dq1 = tmp;
     KPD_TRY(gemm(T, false, false, n, H, H, du, LD, p.W2.w, H, 0.0f, dq1, LD));
     const long long tot = (long long)n * H;
@@ -854,8 +922,8 @@ kpd_status node_bwd(kpd_egnn_trainer *T, int l, int nt, int cur, int nxt, float 
     KPD_LAUNCH_CHECK();
     KPD_TRY(colsum_acc(T, n, H, dq1, LD, p.b1.g));
     if (p.W1.g) {
-        KPD_TRY(gemm(T, true, false, H, H, n, dq1, LD, T->hs[nt][l], LD, 1.0f, p.W1.g, 2 * H));
-        KPD_TRY(gemm(T, true, false, H, H, n, dq1, LD, T->hns[nt][l], LD, 1.0f, p.W1.g + H, 2 * H));
+        KPD_TRY(grad_gemm(T, H, H, n, dq1, LD, T->hs[nt][l], LD, p.W1.g, 2 * H));
+        KPD_TRY(grad_gemm(T, H, H, n, dq1, LD, T->hns[nt][l], LD, p.W1.g + H, 2 * H));
     }
     // dh_in = du (residual) + dq1 W1[:, :257];  d(h_neigh / z) = dq1 W1[:, 257:]
     KPD_HIP(hipMemcpyAsync(T->dh[nxt][nt], du, (size_t)n * LD * 4, hipMemcpyDeviceToDevice, T->st));
@@ -870,13 +938,13 @@ kpd_status edge_branch_bwd(kpd_egnn_trainer *T, const BranchParams &p, int l, in
     const int E = T->E[et], s = kS[et], d = kD[et], ns = T->n[s], nd = T->n[d];
     float *dpre2 = T->eb[4], *dpre1 = T->eb[5];
     KPD_TRY(colsum_acc(T, E, H, dpre2, LD, p.b2.g));
-    if (p.W2.g) KPD_TRY(gemm(T, true, false, H, H, E, dpre2, LD, T->eb[1], LD, 1.0f, p.W2.g, H));
+    if (p.W2.g) KPD_TRY(grad_gemm(T, H, H, E, dpre2, LD, T->eb[1], LD, p.W2.g, H));
     KPD_TRY(gemm(T, false, false, E, H, H, dpre2, LD, p.W2.w, H, 0.0f, dpre1, LD));
     const long long tot = (long long)E * H;
     hipLaunchKernelGGL(k_silu_bwd, grid1(tot), dim3(256), 0, T->st, dpre1, T->eb[0], tot, H, LD);
     KPD_LAUNCH_CHECK();
-    KPD_TRY(colsum_acc(T, E, H, dpre1, LD, p.b1.g));
-    if (p.W1.g) KPD_TRY(gemv_t_acc(T, E, H, dpre1, LD, T->dij, p.W1.g + 2 * H, 2 * H + 1));          // column 514: the dij weights
+    // b1 gradient and column 514 of W1 (the dij weights) in one pass over dpre1
+    KPD_TRY(gemv_t_colsum_acc(T, E, H, dpre1, LD, T->dij, p.W1.g ? p.W1.g + 2 * H : nullptr, 2 * H + 1, p.b1.g));
     KPD_TRY(gemv_n(T, E, H, dpre1, LD, p.W1.w + 2 * H, 2 * H + 1, first_branch ? 0.0f : 1.0f, T->ddij, 1));
     // per-node sums: dV (by dst, segmented) and dU (by src, atomics)
     float *dU = T->nb[0], *dV = T->nb[1];
@@ -888,8 +956,8 @@ kpd_status edge_branch_bwd(kpd_egnn_trainer *T, const BranchParams &p, int l, in
     KPD_LAUNCH_CHECK();
     const float *hsrc = T->hs[s][l], *hdst = T->hs[d][l];
     if (p.W1.g) {
-        KPD_TRY(gemm(T, true, false, H, H, ns, dU, LD, hsrc, LD, 1.0f, p.W1.g, 2 * H + 1));
-        KPD_TRY(gemm(T, true, false, H, H, nd, dV, LD, hdst, LD, 1.0f, p.W1.g + H, 2 * H + 1));
+        KPD_TRY(grad_gemm(T, H, H, ns, dU, LD, hsrc, LD, p.W1.g, 2 * H + 1));
+        KPD_TRY(grad_gemm(T, H, H, nd, dV, LD, hdst, LD, p.W1.g + H, 2 * H + 1));
     }
     KPD_TRY(gemm(T, false, false, ns, H, H, dU, LD, p.W1.w, 2 * H + 1, 1.0f, T->dh[nxt][s], LD));
     KPD_TRY(gemm(T, false, false, nd, H, H, dV, LD, p.W1.w + H, 2 * H + 1, 1.0f, T->dh[nxt][d], LD));
