@@ -149,6 +149,7 @@ def train_cpu_baseline(B_sample=2):
 
 def run_train(args, device, rank, world, dist):
     """Secondary workload: training steps/sec of the EGNN denoiser (fixed receptor encoder) on synthetic complexes."""
+    from keypoint_diffusion_amd.dist import allreduce_gradients
     w = WORKLOADS['egnn_train']
     model = build_model(device, 'egnn_train').train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
@@ -161,6 +162,8 @@ def run_train(args, device, rank, world, dist):
         losses = model(g, None)
         opt.zero_grad(set_to_none=True)
         losses['l2'].backward()
+        if dist is not None:
+            allreduce_gradients(list(model.parameters()))
         torch.nn.utils.clip_grad_value_(model.parameters(), 1.0)
         opt.step()
         return losses['l2']
@@ -184,7 +187,7 @@ def run_train(args, device, rank, world, dist):
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
                'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                'config': {'workload': f'egnn_train: loss + backward + clip + Adam on egnn_all_atom (6 layers, hidden 256), batch of {B} '
-                                      f'synthetic {args.n_rec}-atom pockets / {args.n_lig}-atom ligands per GPU, no gradient all-reduce',
+                                      f'synthetic {args.n_rec}-atom pockets / {args.n_lig}-atom ligands per GPU, one bucketed gradient all-reduce per step when N > 1',
                           'batch_per_gpu': B},
                'complex_steps_per_s': world * args.steps / elapsed * B, 'final_l2': float(last.detach())}
         if not args.no_cpu_baseline:

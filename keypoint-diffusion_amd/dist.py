@@ -65,3 +65,40 @@ def all_gather_ligands(g: G.HeteroBatch, group=None) -> Tuple[List[torch.Tensor]
             pos.append(blk[b, 1:1 + n * 3].reshape(n, 3).clone())
             feat.append(blk[b, 1 + max_n * 3:1 + max_n * 3 + n * F].reshape(n, F).clone())
     return pos, feat
+
+
+def allreduce_gradients(params, group=None, bucket_bytes: int = 64 << 20, average: bool = True):
+    """Data-parallel training (train.py run one process per GPU): sum (or average) the `.grad` of `params` over ranks.
+
+    The gradients of the denoiser arrive all at once from one backward call (kpd_egnn_trainer_backward), so there is no
+    per-layer overlap to exploit; what matters on xGMI is few, large ring all-reduces: gradients are packed into
+    flat buckets of `bucket_bytes` (the whole 48 MB of egnn_all_atom fits one), every bucket's all-reduce is launched
+    asynchronously back to back, then results are scattered back into the `.grad` tensors.  RCCL on the GPU box, gloo in
+    the CPU tests; frozen parameters (grad None) are skipped on every rank alike."""
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return 0
+    world = dist.get_world_size(group)
+    buckets, cur, size = [], [], 0
+    for gr in grads:
+        nbytes = gr.numel() * gr.element_size()
+        if cur and size + nbytes > bucket_bytes:
+            buckets.append(cur)
+            cur, size = [], 0
+        cur.append(gr)
+        size += nbytes
+    if cur:
+        buckets.append(cur)
+    work = []
+    for b in buckets:
+        flat = torch.cat([gr.reshape(-1) for gr in b])
+        work.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True), flat, b))
+    for handle, flat, b in work:
+        handle.wait()
+        if average:
+            flat.div_(world)
+        off = 0
+        for gr in b:
+            gr.copy_(flat[off:off + gr.numel()].view_as(gr))
+            off += gr.numel()
+    return len(buckets)

@@ -9,7 +9,7 @@ import torch.multiprocessing as mp
 
 from keypoint_diffusion_amd import graph as G
 from keypoint_diffusion_amd import synth
-from keypoint_diffusion_amd.dist import all_gather_ligands, shard_complexes
+from keypoint_diffusion_amd.dist import all_gather_ligands, allreduce_gradients, shard_complexes
 
 from . import util
 
@@ -71,3 +71,44 @@ def test_all_gather_ligands_world2():
             assert p.shape == (N_LIG[i], 3) and f.shape == (N_LIG[i], 10)
             assert torch.allclose(p, gs[i].nodes['lig'].data['x_0'] + 100.0 * i, atol=1e-5)
             assert torch.allclose(f, gs[i].nodes['lig'].data['h_0'], atol=1e-6)
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in ((257, 515), (257,), (1, 257), (3, 5))]
+    gen = torch.Generator().manual_seed(100 + rank)
+    for i, p in enumerate(params):
+        p.grad = None if i == 3 else torch.randn(p.shape, generator=gen)      # one frozen parameter
+    n_buckets = allreduce_gradients(params, bucket_bytes=300 * 1024)          # forces two buckets
+    q.put((rank, n_buckets, [None if p.grad is None else p.grad.clone() for p in params]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_allreduce_gradients_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    shapes = ((257, 515), (257,), (1, 257))
+    want = []
+    for i, s in enumerate(shapes):
+        gs = []
+        for rank in range(2):
+            gen = torch.Generator().manual_seed(100 + rank)
+            for j in range(i + 1):
+                t = torch.randn(shapes[j], generator=gen)
+            gs.append(t)
+        want.append((gs[0] + gs[1]) / 2)
+    for rank, n_buckets, grads in res:
+        assert n_buckets == 2 and grads[3] is None
+        for got, ref in zip(grads[:3], want):
+            assert torch.allclose(got, ref, atol=1e-6)

@@ -108,3 +108,32 @@ def test_training_step_reduces_loss():
         opt.step()
         losses.append(float(out['l2'].detach()))
     assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0], losses
+
+
+def test_trainer_degenerate_shapes_and_errors():
+    """One-atom ligands (no ll edges), a batch that grows between calls, frozen parameters, call-order errors."""
+    from keypoint_diffusion_amd import hip
+    cfg = dict(util.EGNN_C2, n_layers=2)
+    g, model, t = _case(cfg, [30, 22], [1, 1])
+    model = model.cuda()
+    for n, p in model.named_parameters():
+        if 'lig_decoder' in n:
+            p.requires_grad_(False)                      # frozen: no gradient buffer is bound for it
+    eh, ex = model(g.to('cuda'), t.cuda(), None)
+    (eh.sum() + ex.sum()).backward()
+    assert all((p.grad is None) == ('lig_decoder' in n) for n, p in model.named_parameters())
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    # a larger batch afterwards re-reserves the workspace; gradients accumulate into .grad like autograd's
+    g2, _, t2 = _case(cfg, [60, 35, 48, 20], [9, 14, 6, 3])
+    before = model.egnn.conv_layers[0].edge_mlp['kl'][0].weight.grad.clone()
+    eh, ex = model(g2.to('cuda'), t2.cuda(), None)
+    (eh.sum() + ex.sum()).backward()
+    assert not torch.equal(before, model.egnn.conv_layers[0].edge_mlp['kl'][0].weight.grad)
+    # backward without a forward is a state error, not a crash
+    tr, _ = model._trainer()
+    with pytest.raises(hip.KpdError):
+        tr.backward(torch.zeros(1, 10).cuda(), torch.zeros(1, 3).cuda(), None, None, None, None)
+    # no_grad calls keep using the fused inference engine and agree with the training forward
+    with torch.no_grad():
+        eh_inf, ex_inf = model(g2.to('cuda'), t2.cuda(), None)
+    assert util.rel_err(eh.detach().cpu(), eh_inf.cpu()) < 1e-4 and util.rel_err(ex.detach().cpu(), ex_inf.cpu()) < 1e-4
