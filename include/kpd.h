@@ -185,6 +185,23 @@ kpd_status kpd_gvp_forward(kpd_gvp *m, const kpd_batch *batch, const float *t_de
 kpd_status kpd_gvp_debug_state(kpd_gvp *m, const char *what, float *out_dev, int64_t n_floats,
                                void *stream);
 
+/* Training path of the GVP denoiser: same contract as kpd_egnn_trainer_* above for
+ * LigRecDynamicsGVP.forward (models/dynamics_gvp.py:149-199).  Gradients flow to every parameter and to the scalar and
+ * vector input features: d_lig_h [n_lig, n_lig_scalars], d_kp_h [n_kp, n_kp_scalars], d_kp_v [n_kp, 16, 3] (each may be
+ * NULL); positions receive no gradient (they enter through the unit edge vector and the rbf code only and are data in
+ * every training configuration served).  GVPDropout (gvp.py:119-149) is the identity here: rate 0 only. */
+typedef struct kpd_gvp_trainer kpd_gvp_trainer;
+kpd_status kpd_gvp_trainer_create(const kpd_gvp_config *cfg, kpd_gvp_trainer **out);
+void kpd_gvp_trainer_destroy(kpd_gvp_trainer *t);
+kpd_status kpd_gvp_trainer_bind(kpd_gvp_trainer *t, const char *name, const float *weight_dev, float *grad_dev,
+                                const int64_t *shape, int32_t ndim);
+kpd_status kpd_gvp_trainer_reserve(kpd_gvp_trainer *t, int32_t max_B, int32_t max_n_lig, int32_t max_n_kp,
+                                   int32_t max_n_kk, int32_t max_lig_per_graph, int32_t max_kp_per_graph);
+kpd_status kpd_gvp_trainer_forward(kpd_gvp_trainer *t, const kpd_batch *batch, const float *t_dev, float *eps_h_dev,
+                                   float *eps_x_dev, void *stream);
+kpd_status kpd_gvp_trainer_backward(kpd_gvp_trainer *t, const float *d_eps_h, const float *d_eps_x, float *d_lig_h,
+                                    float *d_kp_h, float *d_kp_v, void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * GVP keypoint receptor encoder (once per pocket).  Replaces ReceptorEncoderGVP.forward
  * (models/receptor_encoder_gvp.py:212-294): scalar embedding, rec-rec GVPEdgeConv stack

@@ -49,6 +49,30 @@ class LigRecGVP(nn.Module):
                                                     vector_size=in_vector_dim, n_gvps=n_noise_gvps)
 
 
+class _GvpTrainFn(torch.autograd.Function):
+    """LigRecDynamicsGVP.forward as one autograd node (kpd_gvp_trainer_*): differentiable in the scalar / vector input
+    features and in every parameter; positions are data."""
+
+    @staticmethod
+    def forward(ctx, module, pb, timestep, lig_x, kp_x, lig_h, kp_h, kp_v, *params):
+        trainer, names = module._trainer()
+        ctx.trainer, ctx.names, ctx.params = trainer, names, params
+        ctx.inputs = (lig_x, kp_x, lig_h, kp_h, kp_v, timestep)    # kept alive until backward (the C side holds pointers)
+        trainer.bind(names, params, [None] * len(params))
+        return trainer.forward(pb, lig_x, lig_h, kp_x, kp_h, kp_v, timestep)
+
+    @staticmethod
+    def backward(ctx, d_eps_h, d_eps_x):
+        if ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
+            raise NotImplementedError('the GVP backward pass does not differentiate with respect to positions')
+        _, _, lig_h, kp_h, kp_v, _ = ctx.inputs
+        grads = [torch.zeros_like(p) if (ctx.needs_input_grad[8 + i] and p.numel()) else None for i, p in enumerate(ctx.params)]
+        ctx.trainer.bind(ctx.names, ctx.params, grads)
+        d_in = [torch.empty_like(t) if n else None for t, n in zip((lig_h, kp_h, kp_v), ctx.needs_input_grad[5:8])]
+        ctx.trainer.backward(d_eps_h.contiguous().float(), d_eps_x.contiguous().float(), *d_in)
+        return (None, None, None, None, None, *d_in, *grads)
+
+
 class LigRecDynamicsGVP(nn.Module):
 
     def __init__(self, n_lig_scalars, n_kp_scalars, vector_size: int = 16, n_convs=4, n_hidden_scalars=128,
@@ -74,8 +98,21 @@ class LigRecDynamicsGVP(nn.Module):
                                          out_scalar_dim=n_lig_scalars, update_kp=update_kp, n_convs=n_convs,
                                          n_message_gvps=n_message_gvps, n_update_gvps=n_update_gvps,
                                          n_noise_gvps=n_noise_gvps, message_norm=message_norm, dropout=dropout)
+        self.dropout = dropout
         self._engine = None
         self._engine_key = None
+        self._train = None
+
+    def _trainer(self):
+        """The training engine and the parameter names in `self.parameters()` order (reference state-dict names)."""
+        if self._train is None:
+            mode, val = hip._norm_mode(self.message_norm)
+            cfg = hip.KpdGvpConfig(int(self.n_lig_scalars), int(self.n_kp_scalars), int(self.vector_size), int(self.n_convs),
+                                   int(self.n_hidden_scalars), int(bool(self.update_kp)), mode, val, int(self.ll_k), int(self.kl_k),
+                                   float(self.graph_cutoffs.get('ll', 0.0)), float(self.graph_cutoffs.get('kl', 0.0)),
+                                   int(self.n_message_gvps), int(self.n_update_gvps), int(self.n_noise_gvps))
+            self._train = (hip.GvpTrainer(cfg), [n for n, _ in self.named_parameters()])
+        return self._train
 
     def _weights_key(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
@@ -94,10 +131,14 @@ class LigRecDynamicsGVP(nn.Module):
 
     def forward(self, g: HeteroBatch, timestep: torch.Tensor, batch_idxs: Dict[str, torch.Tensor] = None):
         """Predicted noise (eps_h [N_lig, n_lig_scalars], eps_x [N_lig, 3]) -- eval mode (dropout is the identity)."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError('the HIP denoiser is forward-only; call it under torch.no_grad()')
-        if self.training:
-            raise NotImplementedError('dropout is not implemented: call model.eval() (every sampling path does)')
         pb = g.prepared()
         lig, kp = g.nodes['lig'].data, g.nodes['kp'].data
+        if self.training and self.dropout > 0:
+            raise NotImplementedError('GVPDropout with a non-zero rate is not implemented: call model.eval(), or train with '
+                                      'dropout: 0.0 (the backward pass itself is implemented)')
+        if torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or
+                                        any(kp[k].requires_grad or (k in lig and lig[k].requires_grad) for k in ('h_0', 'v_0', 'x_0'))):
+            ins = [hip._dev_f32(t, n) for t, n in ((lig['x_0'], 'lig x_0'), (kp['x_0'], 'kp x_0'), (lig['h_0'], 'lig h_0'),
+                                                   (kp['h_0'], 'kp h_0'), (kp['v_0'], 'kp v_0'))]
+            return _GvpTrainFn.apply(self, pb, hip._dev_f32(timestep, 'timestep'), *ins, *self.parameters())
         return self.engine().forward(pb, lig['x_0'], lig['h_0'], kp['x_0'], kp['h_0'], kp['v_0'], timestep)

@@ -139,6 +139,13 @@ def lib():
     L.kpd_egnn_trainer_reserve.argtypes = [C.c_void_p] + [C.c_int32] * 6
     L.kpd_egnn_trainer_forward.argtypes = [C.c_void_p, C.POINTER(KpdBatch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.kpd_egnn_trainer_backward.argtypes = [C.c_void_p] + [C.c_void_p] * 7
+    L.kpd_gvp_trainer_create.argtypes = [C.POINTER(KpdGvpConfig), C.POINTER(C.c_void_p)]
+    L.kpd_gvp_trainer_destroy.argtypes = [C.c_void_p]
+    L.kpd_gvp_trainer_destroy.restype = None
+    L.kpd_gvp_trainer_bind.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32]
+    L.kpd_gvp_trainer_reserve.argtypes = [C.c_void_p] + [C.c_int32] * 6
+    L.kpd_gvp_trainer_forward.argtypes = [C.c_void_p, C.POINTER(KpdBatch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.kpd_gvp_trainer_backward.argtypes = [C.c_void_p] + [C.c_void_p] * 6
     L.kpd_rec_graph_scratch_bytes.argtypes = [C.c_int32, C.c_int32]
     L.kpd_rec_graph_scratch_bytes.restype = C.c_int64
     L.kpd_build_rec_graph.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p,
@@ -166,6 +173,8 @@ EXPORTS = [
     'kpd_xyz_scratch_bytes', 'kpd_xyz_emit', 'kpd_rec_graph_scratch_bytes', 'kpd_build_rec_graph',
     'kpd_egnn_trainer_create', 'kpd_egnn_trainer_destroy', 'kpd_egnn_trainer_bind', 'kpd_egnn_trainer_reserve',
     'kpd_egnn_trainer_forward', 'kpd_egnn_trainer_backward',
+    'kpd_gvp_trainer_create', 'kpd_gvp_trainer_destroy', 'kpd_gvp_trainer_bind', 'kpd_gvp_trainer_reserve',
+    'kpd_gvp_trainer_forward', 'kpd_gvp_trainer_backward',
 ]
 
 
@@ -419,6 +428,51 @@ class GvpEngine:
         out = torch.empty(max(n_floats, 1), device=device or 'cuda')
         check(lib().kpd_gvp_debug_state(self._h, what.encode(), out.data_ptr(), n_floats, _stream()))
         return out if n_floats else None
+
+
+class GvpTrainer:
+    """Owns one kpd_gvp_trainer handle: forward with saved conv states + backward of LigRecDynamicsGVP.forward."""
+
+    def __init__(self, cfg: 'KpdGvpConfig'):
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        check(lib().kpd_gvp_trainer_create(C.byref(self.cfg), C.byref(self._h)))
+        self._reserved = None
+
+    def __del__(self):
+        if getattr(self, '_h', None) and _lib is not None:
+            _lib.kpd_gvp_trainer_destroy(self._h)
+            self._h = None
+
+    def bind(self, names, weights, grads):
+        L = lib()
+        for name, w, g in zip(names, weights, grads):
+            if w.numel() == 0:                     # dropout.vector_dropout.dummy_param
+                continue
+            if not (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()):
+                raise KpdError(f'parameter {name} must be a contiguous fp32 GPU tensor')
+            shape = (C.c_int64 * w.dim())(*w.shape)
+            check(L.kpd_gvp_trainer_bind(self._h, name.encode(), w.data_ptr(), None if g is None else g.data_ptr(), shape, w.dim()))
+
+    def reserve(self, pb: PreparedBatch):
+        key = (pb.B, pb.n_lig, pb.n_kp, pb.n_kk, pb.max_lig, pb.max_kp)
+        if self._reserved is not None and all(a <= b for a, b in zip(key, self._reserved)):
+            return
+        torch.cuda.synchronize()
+        check(lib().kpd_gvp_trainer_reserve(self._h, *key))
+        self._reserved = key if self._reserved is None else tuple(max(a, b) for a, b in zip(key, self._reserved))
+
+    def forward(self, pb: PreparedBatch, lig_x, lig_h, kp_x, kp_h, kp_v, t):
+        self.reserve(pb)
+        eps_h = torch.empty(pb.n_lig, self.cfg.n_lig_scalars, device=lig_x.device)
+        eps_x = torch.empty(pb.n_lig, 3, device=lig_x.device)
+        bt = pb.struct(lig_x, lig_h, kp_x, kp_h, kp_v)
+        check(lib().kpd_gvp_trainer_forward(self._h, C.byref(bt), t.data_ptr(), eps_h.data_ptr(), eps_x.data_ptr(), _stream()))
+        return eps_h, eps_x
+
+    def backward(self, d_eps_h, d_eps_x, d_lig_h, d_kp_h, d_kp_v):
+        check(lib().kpd_gvp_trainer_backward(self._h, d_eps_h.data_ptr(), d_eps_x.data_ptr(), _ptr(d_lig_h), _ptr(d_kp_h), _ptr(d_kp_v),
+                                             _stream()))
 
 
 def _norm_mode(message_norm):

@@ -1,0 +1,102 @@
+"""Backward pass of the GVP denoiser: gradients of every parameter and of the scalar /
+vector input features from kpd_gvp_trainer_* against torch autograd through the CPU oracle."""
+import pytest
+import torch
+
+from keypoint_diffusion_amd import graph as G, synth
+from keypoint_diffusion_amd.dynamics_gvp import LigRecDynamicsGVP
+from oracle import egnn as oegnn
+from oracle import gvp as ogvp
+from tests import util
+from tests.golden.make_golden_cfgs import GVP_CFGS
+
+pytestmark = pytest.mark.gpu
+CUT = util.CUTOFFS_ALL_ATOM
+TOL = 2e-4          # relative to the largest entry of each gradient tensor
+
+
+def _case(cfg, n_rec, n_lig, n_kp_scalars):
+    g = util.fixed_encode(util.make_batch(n_rec, n_lig, seed=31), n_vec=16)
+    gen = torch.Generator().manual_seed(3)
+    g.nodes['kp'].data['v_0'] = 0.5 * torch.randn(g.num_nodes('kp'), 16, 3, generator=gen)
+    if n_kp_scalars != 10:
+        g.nodes['kp'].data['h_0'] = torch.randn(g.num_nodes('kp'), n_kp_scalars, generator=gen)
+    model = LigRecDynamicsGVP(10, n_kp_scalars, graph_cutoffs=CUT, **cfg)
+    synth.fill_state_dict_(model, 7)
+    model.eval()
+    B = g.batch_size
+    t = (torch.arange(B, dtype=torch.float32) + 1) / (B + 1)
+    return g, model, t
+
+
+def _oracle_grads(model, cfg, g, t, w_h, w_x):
+    ob = util.to_obatch(g)
+    sd = {k: v.detach().clone().requires_grad_(v.numel() > 0) for k, v in model.state_dict().items()}
+    ins = {'lh': ob.h['lig'].clone().requires_grad_(True), 'kh': ob.h['kp'].clone().requires_grad_(True),
+           'kv': ob.v['kp'].clone().requires_grad_(True)}
+    ob.h['lig'], ob.h['kp'], ob.v['kp'] = ins['lh'], ins['kh'], ins['kv']
+    ocfg = dict(cfg, graph_cutoffs=CUT)
+    with torch.no_grad():
+        edges = oegnn.lig_edges(ob, ocfg)
+    eh, ex = ogvp.gvp_dynamics_forward(sd, ocfg, ob, t, edges=edges)
+    ((eh * w_h).sum() + (ex * w_x).sum()).backward()
+    return eh.detach(), ex.detach(), {k: v.grad for k, v in sd.items()}, {k: v.grad for k, v in ins.items()}
+
+
+@pytest.mark.parametrize('tag,over', [('gvp_kp', {}), ('gvp_mean', {}), ('gvp_norm0', {}), ('gvp_norm0', dict(ll_k=3, kl_k=0))])
+def test_gradients_match_oracle_autograd(tag, over):
+    cfg = dict(GVP_CFGS[tag], dropout=0.0, **over)
+    g, model, t = _case(cfg, [26, 19, 33], [7, 10, 5], 128 if tag == 'gvp_kp' else 10)
+    gen = torch.Generator().manual_seed(2)
+    n_lig = g.num_nodes('lig')
+    w_h, w_x = torch.randn(n_lig, 10, generator=gen), torch.randn(n_lig, 3, generator=gen)
+    eh_ref, ex_ref, pg_ref, ig_ref = _oracle_grads(model, cfg, g, t, w_h, w_x)
+
+    model = model.cuda()
+    gd = g.to('cuda')
+    ins = {}
+    for key, nt, name in (('lh', 'lig', 'h_0'), ('kh', 'kp', 'h_0'), ('kv', 'kp', 'v_0')):
+        ins[key] = gd.nodes[nt].data[name].detach().clone().requires_grad_(True)
+        gd.nodes[nt].data[name] = ins[key]
+    eh, ex = model(gd, t.cuda(), None)
+    assert util.rel_err(eh.detach().cpu(), eh_ref) < 1e-4 and util.rel_err(ex.detach().cpu(), ex_ref) < 1e-4
+    ((eh * w_h.cuda()).sum() + (ex * w_x.cuda()).sum()).backward()
+    worst = []
+    for n, p in model.named_parameters():
+        if p.numel() == 0:
+            continue
+        ref = pg_ref[n]
+        assert p.grad is not None, n
+        if ref is None:
+            assert float(p.grad.abs().max()) == 0.0, n
+            continue
+        err = (p.grad.cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
+        if ref.numel() == 1:
+            err *= TOL / 5e-3               # a lone scalar is a cancelling sum over all rows
+        worst.append((err, n))
+    worst.sort(reverse=True)
+    assert worst[0][0] < TOL, worst[:8]
+    for k, ref in ig_ref.items():
+        err = (ins[k].grad.cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
+        assert err < TOL, (k, err)
+
+
+def test_gvp_training_contract():
+    """Positions are data, dropout > 0 in training mode is refused, no_grad calls keep using the fused engine."""
+    cfg = dict(GVP_CFGS['gvp_norm0'])
+    g, model, t = _case(cfg, [20, 15], [6, 4], 10)
+    model = model.cuda()
+    gd = g.to('cuda')
+    x = gd.nodes['lig'].data['x_0'].clone().requires_grad_(True)
+    gd.nodes['lig'].data['x_0'] = x
+    eh, ex = model(gd, t.cuda(), None)
+    with pytest.raises(NotImplementedError):
+        (eh.sum() + ex.sum()).backward()
+    model2 = LigRecDynamicsGVP(10, 10, graph_cutoffs=CUT, **dict(cfg, dropout=0.1)).cuda().train()
+    with pytest.raises(NotImplementedError):
+        model2(g.to('cuda'), t.cuda(), None)
+    gd = g.to('cuda')
+    eh, ex = model(gd, t.cuda(), None)
+    with torch.no_grad():
+        eh2, ex2 = model(g.to('cuda'), t.cuda(), None)
+    assert util.rel_err(eh.detach().cpu(), eh2.cpu()) < 1e-4 and util.rel_err(ex.detach().cpu(), ex2.cpu()) < 1e-4
