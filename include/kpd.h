@@ -189,12 +189,21 @@ kpd_status kpd_gvp_debug_state(kpd_gvp *m, const char *what, float *out_dev, int
  * LigRecDynamicsGVP.forward (models/dynamics_gvp.py:149-199).  Gradients flow to every parameter and to the scalar and
  * vector input features: d_lig_h [n_lig, n_lig_scalars], d_kp_h [n_kp, n_kp_scalars], d_kp_v [n_kp, 16, 3] (each may be
  * NULL); positions receive no gradient (they enter through the unit edge vector and the rbf code only and are data in
- * every training configuration served).  GVPDropout (gvp.py:119-149) is the identity here: rate 0 only. */
+ * every training configuration served). */
 typedef struct kpd_gvp_trainer kpd_gvp_trainer;
 kpd_status kpd_gvp_trainer_create(const kpd_gvp_config *cfg, kpd_gvp_trainer **out);
 void kpd_gvp_trainer_destroy(kpd_gvp_trainer *t);
 kpd_status kpd_gvp_trainer_bind(kpd_gvp_trainer *t, const char *name, const float *weight_dev, float *grad_dev,
                                 const int64_t *shape, int32_t ndim);
+/* GVPDropout of training mode (gvp.py:119-149): rate in [0, 1) and the seed of this step's masks; call before forward
+ * (0 = identity, the default).  Feature dropout is per element, vector dropout per channel, kept entries scale by
+ * 1 / (1 - rate); the masks are Philox streams keyed by (seed; conv, node type, position, kind) and are regenerated in
+ * backward.  kpd_dropout_mask writes one such stream ({0, 1 / (1 - rate)} per entry; node_type 0 = lig, 1 = kp;
+ * position 0 = aggregated messages, 1 = update residual; kind 0 = scalars [n, S] row-major, 1 = vector channels
+ * [n, 16]) so that tests can replay a step on the oracle. */
+kpd_status kpd_gvp_trainer_set_dropout(kpd_gvp_trainer *t, float rate, uint64_t seed);
+kpd_status kpd_dropout_mask(uint64_t seed, int32_t conv, int32_t node_type, int32_t position, int32_t kind, int64_t n,
+                            float rate, float *out_dev, void *stream);
 kpd_status kpd_gvp_trainer_reserve(kpd_gvp_trainer *t, int32_t max_B, int32_t max_n_lig, int32_t max_n_kp,
                                    int32_t max_n_kk, int32_t max_lig_per_graph, int32_t max_kp_per_graph);
 kpd_status kpd_gvp_trainer_forward(kpd_gvp_trainer *t, const kpd_batch *batch, const float *t_dev, float *eps_h_dev,

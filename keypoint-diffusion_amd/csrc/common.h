@@ -37,6 +37,20 @@ void set_error(const char *fmt, ...);
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Philox4x32-10 counter-based generator (per-complex sampler noise, dropout masks of the GVP training path)
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        const unsigned n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+
 // ---- geometry of the fp32-MFMA row-tile kernels ------------------------------------------
 constexpr int TM = 64;        // rows (edges or nodes) per workgroup tile
 constexpr int HID = 256;      // hidden_nf

@@ -11,8 +11,10 @@
 // Vector features are kept as [rows, 3, channels] (the reference holds [rows, channels, 3]), so that the channel
 // mixes Wh / Wu are plain GEMMs over 3 x rows; the first scalar Linear of the message function is split as in the
 // inference path (per-node block U = s_src W[:, :S]^T gathered per edge, + rbf and vector-norm blocks per edge).
-// Dropout: GVPDropout (gvp.py:119-149) acts on the aggregated messages and on the update residual in training mode;
-// this engine implements rate 0 only and the host refuses other rates under autograd.
+// Dropout: GVPDropout (gvp.py:119-149) acts on the aggregated messages and on the update residual in training mode
+// (feature dropout per element, vector dropout per channel, both scaled by 1 / (1 - rate)).  Masks come from Philox keyed
+// by a per-forward seed and the (conv, node type, position, kind) stream, so the backward pass regenerates them instead
+// of storing them; kpd_dropout_mask exposes the same stream for tests.
 #include "egnn_kernels.h"
 #include "engine.h"
 #include "train_ops.h"
@@ -271,6 +273,31 @@ __global__ void k_msg_scale(const int *__restrict__ rowptr, const float *__restr
     }
 }
 
+// keep mask of one dropout stream: element i is kept iff its Philox word >= rate * 2^32; kept elements scale by 1 / (1 - rate)
+__device__ __forceinline__ float dropout_scale(unsigned long long seed, unsigned stream, long long i, float rate) {
+    unsigned c[4] = {(unsigned)(i >> 2), (unsigned)((unsigned long long)i >> 34), stream, 0x6b70646fu};
+    philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+    const unsigned w = c[i & 3];
+    const unsigned thr = (unsigned)fminf(rate * 4294967296.0f, 4294967040.0f);
+    return w >= thr ? 1.0f / (1.0f - rate) : 0.0f;
+}
+
+// out[r, k, c] = in[r, k, c] * mask(r, c): rows x inner x cols with the mask shared over `inner` (1 for scalars, 3 for the
+// components of a vector channel)
+__global__ void k_dropout(const float *__restrict__ in, long long rows, int inner, int cols, unsigned long long seed, unsigned stream,
+                          float rate, float *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * inner * cols) return;
+    const int c = (int)(i % cols);
+    const long long r = i / ((long long)inner * cols);
+    out[i] = in[i] * dropout_scale(seed, stream, r * cols + c, rate);
+}
+
+__global__ void k_dropout_mask(long long n, unsigned long long seed, unsigned stream, float rate, float *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = dropout_scale(seed, stream, i, rate);
+}
+
 struct GvpP {
     Param Wh, Wu, Ws, bs, Wg, bg;
     int vi = 0, vo = 0, h = 0, si = 0, so = 0;
@@ -308,7 +335,8 @@ struct kpd_gvp_trainer : TrainCtx {
     float *unit = nullptr, *rbf = nullptr, *vin = nullptr, *U = nullptr, *scale = nullptr, *tmp_s = nullptr, *tmp_v = nullptr,
           *s1 = nullptr, *v1 = nullptr, *sb = nullptr, *vb = nullptr;
     float *gs[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}, *gv[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [cur/nxt][nt]
-    float *head_pre = nullptr;
+    float dropout = 0.0f;
+    unsigned long long seed = 0;
 };
 
 namespace {
@@ -405,6 +433,25 @@ kpd_status chain_bwd(kpd_gvp_trainer *T, const std::string &prefix, int n, int M
     return KPD_OK;
 }
 
+unsigned drop_stream(int conv, int nt, int pos, int kind) { return (unsigned)(((conv * 2 + nt) * 2 + pos) * 2 + kind); }
+
+// GVPDropout on (s [n, S], v [n, 3, 16]) -> (so, vo); identity copy when the rate is 0 (so / vo may alias the inputs)
+kpd_status dropout_apply(kpd_gvp_trainer *T, int conv, int nt, int pos, int n, const float *s, const float *v, float *so, float *vo) {
+    const int S = T->S;
+    if (T->dropout <= 0.0f) {
+        if (so != s) KPD_HIP(hipMemcpyAsync(so, s, (size_t)n * S * 4, hipMemcpyDeviceToDevice, T->st));
+        if (vo != v) KPD_HIP(hipMemcpyAsync(vo, v, (size_t)n * 3 * VC * 4, hipMemcpyDeviceToDevice, T->st));
+        return KPD_OK;
+    }
+    hipLaunchKernelGGL(k_dropout, grid1((long long)n * S), dim3(256), 0, T->st, s, (long long)n, 1, S, T->seed, drop_stream(conv, nt, pos, 0),
+                       T->dropout, so);
+    KPD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_dropout, grid1((long long)n * 3 * VC), dim3(256), 0, T->st, v, (long long)n, 3, VC, T->seed,
+                       drop_stream(conv, nt, pos, 1), T->dropout, vo);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
 bool conv_uses(const kpd_gvp_trainer *T, int conv, int et) {
     if (et < 2) return true;
     return T->cfg.update_kp && conv < T->cfg.n_convs - 1;           // dynamics_gvp.py:67-72
@@ -491,8 +538,8 @@ kpd_status conv_fwd(kpd_gvp_trainer *T, int conv) {
             T->vs[nt][conv + 1] = T->vs[nt][conv];
             continue;
         }
-        KPD_HIP(hipMemcpyAsync(T->sa[nt][conv], T->ss[nt][conv], (size_t)T->n[nt] * S * 4, hipMemcpyDeviceToDevice, T->st));
-        KPD_HIP(hipMemcpyAsync(T->va[nt][conv], T->vs[nt][conv], (size_t)T->n[nt] * 3 * VC * 4, hipMemcpyDeviceToDevice, T->st));
+        KPD_HIP(hipMemsetAsync(T->sa[nt][conv], 0, (size_t)T->n[nt] * S * 4, T->st));          // aggregated messages first ...
+        KPD_HIP(hipMemsetAsync(T->va[nt][conv], 0, (size_t)T->n[nt] * 3 * VC * 4, T->st));
     }
     for (int et = 0; et < 4; ++et) {
         if (!conv_uses(T, conv, et) || T->E[et] == 0) continue;
@@ -510,11 +557,18 @@ kpd_status conv_fwd(kpd_gvp_trainer *T, int conv) {
         LnP l1, l2;
         KPD_TRY(ln_params(T, cp + ".message_layer_norms." + kNtName[nt], &l1));
         KPD_TRY(ln_params(T, cp + ".update_layer_norms." + kNtName[nt], &l2));
+        // ... then dropout on them and the residual: sa = s + dropout(msg) (gvp.py:516-518)
+        KPD_TRY(dropout_apply(T, conv, nt, 0, n, T->sa[nt][conv], T->va[nt][conv], T->sa[nt][conv], T->va[nt][conv]));
+        hipLaunchKernelGGL(k_acc, grid1((long long)n * S), dim3(256), 0, T->st, T->sa[nt][conv], T->ss[nt][conv], (long long)n * S);
+        KPD_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_acc, grid1((long long)n * 3 * VC), dim3(256), 0, T->st, T->va[nt][conv], T->vs[nt][conv], (long long)n * 3 * VC);
+        KPD_LAUNCH_CHECK();
         KPD_TRY(gvp_ln_fwd(T, l1, n, T->sa[nt][conv], T->va[nt][conv], T->s1, T->v1));
         KPD_TRY(chain_fwd(T, cp + ".node_update_fns." + kNtName[nt], nu, n, T->s1, T->v1));
-        hipLaunchKernelGGL(k_add, grid1((long long)n * S), dim3(256), 0, T->st, T->s1, T->gb[nu - 1].s, (long long)n * S, T->sb);
+        KPD_TRY(dropout_apply(T, conv, nt, 1, n, T->gb[nu - 1].s, T->gb[nu - 1].V, T->tmp_s, T->tmp_v));
+        hipLaunchKernelGGL(k_add, grid1((long long)n * S), dim3(256), 0, T->st, T->s1, T->tmp_s, (long long)n * S, T->sb);
         KPD_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_add, grid1((long long)n * 3 * VC), dim3(256), 0, T->st, T->v1, T->gb[nu - 1].V, (long long)n * 3 * VC, T->vb);
+        hipLaunchKernelGGL(k_add, grid1((long long)n * 3 * VC), dim3(256), 0, T->st, T->v1, T->tmp_v, (long long)n * 3 * VC, T->vb);
         KPD_LAUNCH_CHECK();
         KPD_TRY(gvp_ln_fwd(T, l2, n, T->sb, T->vb, T->ss[nt][conv + 1], T->vs[nt][conv + 1]));
     }
@@ -542,15 +596,17 @@ kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
         // recompute s1, v1, the update chain and the second pre-norm sums
         KPD_TRY(gvp_ln_fwd(T, l1, n, T->sa[nt][conv], T->va[nt][conv], T->s1, T->v1));
         KPD_TRY(chain_fwd(T, up, nu, n, T->s1, T->v1));
-        hipLaunchKernelGGL(k_add, grid1((long long)n * S), dim3(256), 0, T->st, T->s1, T->gb[nu - 1].s, (long long)n * S, T->sb);
+        KPD_TRY(dropout_apply(T, conv, nt, 1, n, T->gb[nu - 1].s, T->gb[nu - 1].V, T->tmp_s, T->tmp_v));
+        hipLaunchKernelGGL(k_add, grid1((long long)n * S), dim3(256), 0, T->st, T->s1, T->tmp_s, (long long)n * S, T->sb);
         KPD_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_add, grid1((long long)n * 3 * VC), dim3(256), 0, T->st, T->v1, T->gb[nu - 1].V, (long long)n * 3 * VC, T->vb);
+        hipLaunchKernelGGL(k_add, grid1((long long)n * 3 * VC), dim3(256), 0, T->st, T->v1, T->tmp_v, (long long)n * 3 * VC, T->vb);
         KPD_LAUNCH_CHECK();
         // second GVPLayerNorm: d(sb, vb) -> ds[0] / dV[0]
         KPD_TRY(gvp_ln_bwd(T, l2, n, T->sb, T->vb, T->gs[cur][nt], T->gv[cur][nt], T->ds[0], T->dV[0]));
-        // residual: d s1 += d sb, d v1 += d vb -> keep them in gs/gv[nxt] for now
+        // residual: d s1 += d sb, d v1 += d vb -> keep them in gs/gv[nxt] for now; the update chain sees them through its dropout mask
         KPD_HIP(hipMemcpyAsync(T->gs[nxt][nt], T->ds[0], (size_t)n * S * 4, hipMemcpyDeviceToDevice, T->st));
         KPD_HIP(hipMemcpyAsync(T->gv[nxt][nt], T->dV[0], (size_t)n * 3 * VC * 4, hipMemcpyDeviceToDevice, T->st));
+        KPD_TRY(dropout_apply(T, conv, nt, 1, n, T->ds[0], T->dV[0], T->ds[0], T->dV[0]));
         KPD_TRY(chain_bwd(T, up, nu, n, T->s1, T->v1));
         hipLaunchKernelGGL(k_acc, grid1((long long)n * S), dim3(256), 0, T->st, T->gs[nxt][nt], T->ds[0], (long long)n * S);
         KPD_LAUNCH_CHECK();
@@ -560,8 +616,7 @@ kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
         KPD_TRY(gvp_ln_bwd(T, l1, n, T->sa[nt][conv], T->va[nt][conv], T->gs[nxt][nt], T->gv[nxt][nt], T->gs[nxt][nt], T->gv[nxt][nt]));
         // the gradient of the aggregated messages is the same tensor: keep a copy where the edge passes can read it while
         // gs/gv[nxt] accumulate the source-side contributions
-        KPD_HIP(hipMemcpyAsync(T->gs[cur][nt], T->gs[nxt][nt], (size_t)n * S * 4, hipMemcpyDeviceToDevice, T->st));
-        KPD_HIP(hipMemcpyAsync(T->gv[cur][nt], T->gv[nxt][nt], (size_t)n * 3 * VC * 4, hipMemcpyDeviceToDevice, T->st));
+        KPD_TRY(dropout_apply(T, conv, nt, 0, n, T->gs[nxt][nt], T->gv[nxt][nt], T->gs[cur][nt], T->gv[cur][nt]));
     }
     for (int et = 0; et < 4; ++et) {
         if (!conv_uses(T, conv, et) || T->E[et] == 0) continue;
@@ -714,6 +769,26 @@ extern "C" kpd_status kpd_gvp_trainer_bind(kpd_gvp_trainer *T, const char *name,
     p.rows = (int)shape[0];
     p.cols = ndim == 2 ? (int)shape[1] : 1;
     T->params[name] = p;
+    return KPD_OK;
+}
+
+extern "C" kpd_status kpd_gvp_trainer_set_dropout(kpd_gvp_trainer *T, float rate, uint64_t seed) {
+    KPD_REQUIRE(T, KPD_ERR_INVALID, "null trainer");
+    KPD_REQUIRE(rate >= 0.0f && rate < 1.0f, KPD_ERR_INVALID, "dropout rate %g outside [0, 1)", (double)rate);
+    T->have_forward = false;        // a pending forward was drawn with the previous masks: it can no longer be differentiated
+    T->dropout = rate;
+    T->seed = seed;
+    return KPD_OK;
+}
+
+extern "C" kpd_status kpd_dropout_mask(uint64_t seed, int32_t conv, int32_t node_type, int32_t position, int32_t kind, int64_t n,
+                                       float rate, float *out, void *stream) {
+    KPD_REQUIRE(out && n >= 0 && rate >= 0.0f && rate < 1.0f && conv >= 0 && (node_type | 1) == 1 && (position | 1) == 1 && (kind | 1) == 1,
+                KPD_ERR_INVALID, "bad argument");
+    if (n == 0) return KPD_OK;
+    hipLaunchKernelGGL(k_dropout_mask, grid1(n), dim3(256), 0, static_cast<hipStream_t>(stream), (long long)n, (unsigned long long)seed,
+                       drop_stream(conv, node_type, position, kind), rate, out);
+    KPD_LAUNCH_CHECK();
     return KPD_OK;
 }
 

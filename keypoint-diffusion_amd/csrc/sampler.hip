@@ -65,17 +65,6 @@ __global__ void k_step_coef(const float *__restrict__ gamma, int n_gamma, const 
 // position inside the complex), never on which batch or rank the complex was placed in, so a sharded run reproduces the
 // single-process run.  The reference draws one global torch.randn over the batch (ligand_diffuser.py:367,
 // 530-531); this is the opt-in replacement, torch.randn stays the default.
-__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const unsigned hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
-        const unsigned hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
-        const unsigned n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
-        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-}
 
 __global__ void k_complex_noise(const int *__restrict__ ptr, int B, int width, const long long *__restrict__ complex_id,
                                 unsigned long long seed, int step, int tag, float *__restrict__ out) {

@@ -59,6 +59,11 @@ class _GvpTrainFn(torch.autograd.Function):
         ctx.trainer, ctx.names, ctx.params = trainer, names, params
         ctx.inputs = (lig_x, kp_x, lig_h, kp_h, kp_v, timestep)    # kept alive until backward (the C side holds pointers)
         trainer.bind(names, params, [None] * len(params))
+        # GVPDropout is active in training mode only (gvp.py:133-134); the seed comes from torch's CPU generator, so
+        # torch.manual_seed reproduces a step
+        rate = module.dropout if module.training else 0.0
+        module.last_dropout_seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if rate > 0 else 0
+        trainer.set_dropout(rate, module.last_dropout_seed)
         return trainer.forward(pb, lig_x, lig_h, kp_x, kp_h, kp_v, timestep)
 
     @staticmethod
@@ -133,9 +138,9 @@ class LigRecDynamicsGVP(nn.Module):
         """Predicted noise (eps_h [N_lig, n_lig_scalars], eps_x [N_lig, 3]) -- eval mode (dropout is the identity)."""
         pb = g.prepared()
         lig, kp = g.nodes['lig'].data, g.nodes['kp'].data
-        if self.training and self.dropout > 0:
-            raise NotImplementedError('GVPDropout with a non-zero rate is not implemented: call model.eval(), or train with '
-                                      'dropout: 0.0 (the backward pass itself is implemented)')
+        if self.training and self.dropout > 0 and not torch.is_grad_enabled():
+            raise NotImplementedError('train-mode dropout without autograd is not a path of the reference: call model.eval() for '
+                                      'inference (every sampling path does)')
         if torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or
                                         any(kp[k].requires_grad or (k in lig and lig[k].requires_grad) for k in ('h_0', 'v_0', 'x_0'))):
             ins = [hip._dev_f32(t, n) for t, n in ((lig['x_0'], 'lig x_0'), (kp['x_0'], 'kp x_0'), (lig['h_0'], 'lig h_0'),

@@ -146,6 +146,8 @@ def lib():
     L.kpd_gvp_trainer_reserve.argtypes = [C.c_void_p] + [C.c_int32] * 6
     L.kpd_gvp_trainer_forward.argtypes = [C.c_void_p, C.POINTER(KpdBatch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.kpd_gvp_trainer_backward.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+    L.kpd_gvp_trainer_set_dropout.argtypes = [C.c_void_p, C.c_float, C.c_uint64]
+    L.kpd_dropout_mask.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]
     L.kpd_rec_graph_scratch_bytes.argtypes = [C.c_int32, C.c_int32]
     L.kpd_rec_graph_scratch_bytes.restype = C.c_int64
     L.kpd_build_rec_graph.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p,
@@ -174,7 +176,7 @@ EXPORTS = [
     'kpd_egnn_trainer_create', 'kpd_egnn_trainer_destroy', 'kpd_egnn_trainer_bind', 'kpd_egnn_trainer_reserve',
     'kpd_egnn_trainer_forward', 'kpd_egnn_trainer_backward',
     'kpd_gvp_trainer_create', 'kpd_gvp_trainer_destroy', 'kpd_gvp_trainer_bind', 'kpd_gvp_trainer_reserve',
-    'kpd_gvp_trainer_forward', 'kpd_gvp_trainer_backward',
+    'kpd_gvp_trainer_forward', 'kpd_gvp_trainer_backward', 'kpd_gvp_trainer_set_dropout', 'kpd_dropout_mask',
 ]
 
 
@@ -462,6 +464,9 @@ class GvpTrainer:
         check(lib().kpd_gvp_trainer_reserve(self._h, *key))
         self._reserved = key if self._reserved is None else tuple(max(a, b) for a, b in zip(key, self._reserved))
 
+    def set_dropout(self, rate: float, seed: int):
+        check(lib().kpd_gvp_trainer_set_dropout(self._h, float(rate), int(seed) & (2 ** 64 - 1)))
+
     def forward(self, pb: PreparedBatch, lig_x, lig_h, kp_x, kp_h, kp_v, t):
         self.reserve(pb)
         eps_h = torch.empty(pb.n_lig, self.cfg.n_lig_scalars, device=lig_x.device)
@@ -473,6 +478,14 @@ class GvpTrainer:
     def backward(self, d_eps_h, d_eps_x, d_lig_h, d_kp_h, d_kp_v):
         check(lib().kpd_gvp_trainer_backward(self._h, d_eps_h.data_ptr(), d_eps_x.data_ptr(), _ptr(d_lig_h), _ptr(d_kp_h), _ptr(d_kp_v),
                                              _stream()))
+
+
+def dropout_mask(seed: int, conv: int, node_type: int, position: int, kind: int, n: int, rate: float, device='cuda') -> torch.Tensor:
+    """One dropout stream of the GVP training path (kpd_dropout_mask): n entries in {0, 1 / (1 - rate)}."""
+    out = torch.empty(int(n), device=device, dtype=torch.float32)
+    check(lib().kpd_dropout_mask(int(seed) & (2 ** 64 - 1), int(conv), int(node_type), int(position), int(kind), int(n), float(rate),
+                                 out.data_ptr(), _stream()))
+    return out
 
 
 def _norm_mode(message_norm):

@@ -112,12 +112,12 @@ class KeypointDiffusion(nn.Module):
     # ---- training entry point ----------------------------------------------------------
     def forward(self, complex_graphs, interface_points):
         """Losses of one training batch (ligand_diffuser.py:89-175): {'l2', 'pos', 'feat', 'rec_encoder'}.  The noise
-        prediction is differentiated by the HIP backward pass (dynamics.LigRecDynamics under autograd); implemented
-        for the EGNN denoiser with the fixed receptor encoder (configs/dev_config.yml, trained_models/egnn_all_atom,
-        egnn_ca), where the encoder has no parameters and its loss is the constant 0 (:85-87)."""
-        if self.architecture != 'egnn' or self.rec_encoder_type != 'fixed':
-            raise NotImplementedError('training is implemented for architecture="egnn" with rec_encoder_type="fixed"; the backward '
-                                      'passes of the GVP denoiser and of the learned receptor encoders are not built yet')
+        prediction is differentiated by the HIP backward passes (kpd_egnn_trainer_* / kpd_gvp_trainer_* under autograd);
+        implemented with the fixed receptor encoder (configs/dev_config.yml, trained_models/{egnn,gvp}_all_atom,
+        {egnn,gvp}_ca), where the encoder has no parameters and its loss is the constant 0 (:85-87)."""
+        if self.rec_encoder_type != 'fixed':
+            raise NotImplementedError('training is implemented with rec_encoder_type="fixed"; the learned receptor encoders train '
+                                      'through an optimal-transport loss (package `ot`, absent here) and have no backward pass yet')
         if self.rl_dist_threshold > 0:
             raise NotImplementedError('the receptor-ligand hinge loss (rl_dist_threshold > 0) is unused by every shipped config')
         losses = {}

@@ -67,8 +67,10 @@ def edge_geometry(x_src, x_dst, src, dst, rbf_dmax, rbf_dim=16):
     return x_diff, d
 
 
-def multi_edge_conv(sd, p, etypes, edges, node, z_per_graph, cfg, rbf_dmax=15.0):
-    """GVPMultiEdgeConv.forward (gvp.py:459-538).  node: nt -> (s, x, v)."""
+def multi_edge_conv(sd, p, etypes, edges, node, z_per_graph, cfg, rbf_dmax=15.0, masks=None):
+    """GVPMultiEdgeConv.forward (gvp.py:459-538).  node: nt -> (s, x, v).  `masks`: training-mode GVPDropout
+    (gvp.py:119-149, applied at :516 and :527) with given keep masks, (nt, position) -> (scalar mask [N,S], channel mask
+    [N,V]) already scaled by 1 / (1 - rate); None = eval mode."""
     mn = cfg.get('message_norm', 10)
     use_mean = (mn == 'mean')                                                 # gvp.py:386-389
     dst_ntypes = sorted({SRC_DST[et][1] for et in etypes})
@@ -96,15 +98,19 @@ def multi_edge_conv(sd, p, etypes, edges, node, z_per_graph, cfg, rbf_dmax=15.0)
         s, x, v = node[nt]
         ms = agg_s[nt] / nv
         mv = agg_v[nt] / (nv.unsqueeze(-1) if isinstance(nv, torch.Tensor) else nv)
+        if masks is not None:
+            ms, mv = ms * masks[(nt, 0)][0], mv * masks[(nt, 0)][1].unsqueeze(-1)   # :516 dropout(scalar_msg, vec_msg)
         s, v = gvp_layernorm(sd, f'{p}.message_layer_norms.{nt}', s + ms, v + mv)   # :519-521
         rs, rv = gvp_chain(sd, f'{p}.node_update_fns.{nt}', cfg.get('n_update_gvps', 2), s, v)
+        if masks is not None:
+            rs, rv = rs * masks[(nt, 1)][0], rv * masks[(nt, 1)][1].unsqueeze(-1)   # :527
         s, v = gvp_layernorm(sd, f'{p}.update_layer_norms.{nt}', s + rs, v + rv)    # :530-532
         out[nt] = (s, x, v)
     return out
 
 
 def gvp_dynamics_forward(sd: Dict[str, torch.Tensor], cfg: dict, batch: OBatch, t: torch.Tensor,
-                         edges: Dict[str, tuple] = None):
+                         edges: Dict[str, tuple] = None, dropout_masks: Dict = None):
     """LigRecDynamicsGVP.forward (models/dynamics_gvp.py:149-199)."""
     lig_b = G.counts_to_batch_idx(batch.n['lig'])
     kp_b = G.counts_to_batch_idx(batch.n['kp'])
@@ -145,7 +151,8 @@ def gvp_dynamics_forward(sd: Dict[str, torch.Tensor], cfg: dict, batch: OBatch, 
                         tot = tot + G.edges_per_graph(edges[et][1], batch.n[nt])
                 zz = tot.to(torch.float32) / batch.n[nt].to(torch.float32) + 1
                 z[nt] = zz[bidx[nt]]
-        new = multi_edge_conv(sd, f'noise_predictor.conv_layers.{i}', etypes, edges, node, z, cfg)
+        masks = None if dropout_masks is None else {k[1:]: v for k, v in dropout_masks.items() if k[0] == i}
+        new = multi_edge_conv(sd, f'noise_predictor.conv_layers.{i}', etypes, edges, node, z, cfg, masks=masks)
         node = {**node, **new}
 
     s, _, v = node['lig']

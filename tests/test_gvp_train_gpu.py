@@ -82,7 +82,7 @@ def test_gradients_match_oracle_autograd(tag, over):
 
 
 def test_gvp_training_contract():
-    """Positions are data, dropout > 0 in training mode is refused, no_grad calls keep using the fused engine."""
+    """Positions are data, train-mode dropout without autograd is refused, no_grad calls keep using the fused engine."""
     cfg = dict(GVP_CFGS['gvp_norm0'])
     g, model, t = _case(cfg, [20, 15], [6, 4], 10)
     model = model.cuda()
@@ -93,10 +93,61 @@ def test_gvp_training_contract():
     with pytest.raises(NotImplementedError):
         (eh.sum() + ex.sum()).backward()
     model2 = LigRecDynamicsGVP(10, 10, graph_cutoffs=CUT, **dict(cfg, dropout=0.1)).cuda().train()
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError), torch.no_grad():
         model2(g.to('cuda'), t.cuda(), None)
     gd = g.to('cuda')
     eh, ex = model(gd, t.cuda(), None)
     with torch.no_grad():
         eh2, ex2 = model(g.to('cuda'), t.cuda(), None)
     assert util.rel_err(eh.detach().cpu(), eh2.cpu()) < 1e-4 and util.rel_err(ex.detach().cpu(), ex2.cpu()) < 1e-4
+
+
+def test_dropout_training_step_matches_oracle_with_the_same_masks():
+    """Training mode with GVPDropout 0.1 (every shipped GVP config): replay the step on the oracle with the masks the
+    library drew (kpd_dropout_mask) and compare outputs and gradients; check the masks' statistics."""
+    from keypoint_diffusion_amd import hip
+    rate = 0.1
+    cfg = dict(GVP_CFGS['gvp_kp'], dropout=rate)
+    g, model, t = _case(cfg, [26, 19, 33], [7, 10, 5], 128)
+    gen = torch.Generator().manual_seed(4)
+    n_lig, n_kp, S = g.num_nodes('lig'), g.num_nodes('kp'), cfg['n_hidden_scalars']
+    w_h, w_x = torch.randn(n_lig, 10, generator=gen), torch.randn(n_lig, 3, generator=gen)
+    model_gpu = LigRecDynamicsGVP(10, 128, graph_cutoffs=CUT, **cfg)
+    model_gpu.load_state_dict(model.state_dict())
+    model_gpu = model_gpu.cuda().train()
+    torch.manual_seed(123)
+    eh, ex = model_gpu(g.to('cuda'), t.cuda(), None)
+    ((eh * w_h.cuda()).sum() + (ex * w_x.cuda()).sum()).backward()
+    seed = model_gpu.last_dropout_seed
+    assert seed != 0
+    masks, kept = {}, []
+    for conv in range(cfg['n_convs']):
+        for nti, (nt, n) in enumerate((('lig', n_lig), ('kp', n_kp))):
+            for pos in (0, 1):
+                ms = hip.dropout_mask(seed, conv, nti, pos, 0, n * S, rate).cpu().view(n, S)
+                mv = hip.dropout_mask(seed, conv, nti, pos, 1, n * 16, rate).cpu().view(n, 16)
+                masks[(conv, nt, pos)] = (ms, mv)
+                kept.append(float((ms > 0).float().mean()))
+                assert all(u == 0.0 or abs(u - 1 / (1 - rate)) < 1e-6 for u in ms.unique().tolist())
+    assert abs(sum(kept) / len(kept) - (1 - rate)) < 0.01
+    # oracle replay
+    ob = util.to_obatch(g)
+    sd = {k: v.detach().clone().requires_grad_(v.numel() > 0) for k, v in model.state_dict().items()}
+    ocfg = dict(cfg, graph_cutoffs=CUT)
+    with torch.no_grad():
+        edges = oegnn.lig_edges(ob, ocfg)
+    eh_ref, ex_ref = ogvp.gvp_dynamics_forward(sd, ocfg, ob, t, edges=edges, dropout_masks=masks)
+    ((eh_ref * w_h).sum() + (ex_ref * w_x).sum()).backward()
+    assert util.rel_err(eh.detach().cpu(), eh_ref.detach()) < 1e-4 and util.rel_err(ex.detach().cpu(), ex_ref.detach()) < 1e-4
+    worst = []
+    for n, p in model_gpu.named_parameters():
+        ref = sd[n].grad if p.numel() else None
+        if ref is None:
+            continue
+        err = (p.grad.cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
+        worst.append((err * (TOL / 5e-3 if ref.numel() == 1 else 1.0), n))
+    worst.sort(reverse=True)
+    assert worst[0][0] < TOL, worst[:6]
+    # another step draws other masks; eval mode ignores dropout
+    eh2, _ = model_gpu(g.to('cuda'), t.cuda(), None)
+    assert model_gpu.last_dropout_seed != seed and not torch.allclose(eh2, eh)

@@ -88,14 +88,25 @@ def test_sample_given_pocket_end_to_end(cuda):
     assert len(fx) == 1 and len(fx[0]) == 9 and fx[0][0].shape == (5, 3)
 
 
-def test_forward_only_contract(cuda):
-    """What has no backward pass refuses loudly under autograd instead of returning constants."""
-    model = _model('gvp').to(cuda)
-    g = model.encode_receptors(G.batch(synth.synth_complexes([30], [5], 20, CUT))).to(cuda)
+def test_training_scope_contract(cuda):
+    """Fixed-encoder models train (EGNN and GVP denoisers have backward passes); what has none refuses loudly."""
+    model = _model('gvp').to(cuda).train()
+    g = G.batch(synth.synth_complexes([30, 22], [5, 7], 20, CUT)).to(cuda)
+    torch.manual_seed(0)
+    out = model(g, None)
+    assert set(out) == {'l2', 'pos', 'feat', 'rec_encoder'}
+    out['l2'].backward()
+    bad = [n for n, p in model.dynamics.named_parameters() if p.numel() and (p.grad is None or not torch.isfinite(p.grad).all())]
+    assert not bad, bad[:8]
+    assert any(float(p.grad.abs().max()) > 0 for p in model.dynamics.parameters() if p.numel())
+    learned = KeypointDiffusion(10, 128, None, n_timesteps=50, architecture='egnn', rec_encoder_type='learned',
+                                graph_config=dict(n_keypoints=8, graph_cutoffs=CUT), dynamics_config=dict(util.EGNN_C2, n_layers=1),
+                                rec_encoder_config=dict(n_convs=1, in_n_node_feat=10, hidden_n_node_feat=32, out_n_node_feat=128,
+                                                        use_tanh=True, coords_range=10, kp_feat_scale=1.0, message_norm=0.0,
+                                                        use_sameres_feat=False, k_closest=3, kp_rad=0.0, norm=True, fix_pos=False,
+                                                        n_kk_convs=0), precision=1e-5)
     with pytest.raises(NotImplementedError):
-        model.dynamics(g, torch.tensor([0.5], device=cuda), None)          # GVP denoiser: backward not implemented
-    with pytest.raises(NotImplementedError):
-        model(g, None)
+        learned(g, None)
 
 
 def test_complex_noise_is_sharding_invariant(cuda):
