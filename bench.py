@@ -58,6 +58,8 @@ WORKLOADS = {
     # one optimisation step of train.py's inner loop (loss of KeypointDiffusion.forward, backward, clip, Adam) on the
     # egnn_all_atom model: the backward pass of csrc/egnn_train.hip
     'egnn_train': dict(arch='egnn', enc='fixed', dyn=DYNAMICS, n_kp=20, cutoffs=CUTOFFS),
+    # same for the gvp_all_atom model in training mode (GVPDropout 0.1): the backward pass of csrc/gvp_train.hip
+    'gvp_train': dict(arch='gvp', enc='fixed', dyn=dict(GVP_DYN, message_norm='mean'), n_kp=20, cutoffs=CUTOFFS),
 }
 
 
@@ -123,18 +125,22 @@ def cpu_baseline(B_sample=4, steps=2):
                       f'{steps} reverse steps after 1 warm-up, scaled to the B=64 batch'}
 
 
-def train_cpu_baseline(B_sample=2):
+def train_cpu_baseline(workload, B_sample=2):
     """Loss + torch autograd through the CPU oracle for B_sample complexes of the same shape (one step after a warm-up)."""
     from oracle import egnn as oegnn
+    from oracle import gvp as ogvp
     from tests.util import to_obatch
-    model = build_model('cpu')
-    g = build_batch(model, B_sample, 300, 25, seed=99, device='cpu')
+    w = WORKLOADS[workload]
+    model = build_model('cpu', workload)
+    g = build_batch(model, B_sample, 300, 25, seed=99, device='cpu', workload=workload)
     ob = to_obatch(g)
-    sd = {k[len('dynamics.'):]: v.clone().requires_grad_(True) for k, v in model.state_dict().items() if k.startswith('dynamics.')}
-    cfg = dict(DYNAMICS, graph_cutoffs=CUTOFFS)
+    sd = {k[len('dynamics.'):]: v.clone().requires_grad_(v.numel() > 0) for k, v in model.state_dict().items()
+          if k.startswith('dynamics.')}
+    cfg = dict(w['dyn'], graph_cutoffs=w['cutoffs'])
+    fwd = oegnn.egnn_dynamics_forward if w['arch'] == 'egnn' else ogvp.gvp_dynamics_forward
 
     def one():
-        eh, ex = oegnn.egnn_dynamics_forward(sd, cfg, ob, torch.full((B_sample,), 0.5))
+        eh, ex = fwd(sd, cfg, ob, torch.full((B_sample,), 0.5))
         (eh.square().sum() + ex.square().sum()).backward()
 
     one()
@@ -148,10 +154,10 @@ def train_cpu_baseline(B_sample=2):
 
 
 def run_train(args, device, rank, world, dist):
-    """Secondary workload: training steps/sec of the EGNN denoiser (fixed receptor encoder) on synthetic complexes."""
+    """Secondary workloads: training steps/sec of the EGNN / GVP denoiser (fixed receptor encoder) on synthetic complexes."""
     from keypoint_diffusion_amd.dist import allreduce_gradients
-    w = WORKLOADS['egnn_train']
-    model = build_model(device, 'egnn_train').train()
+    w = WORKLOADS[args.workload]
+    model = build_model(device, args.workload).train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
     B = args.batch
     gs = synth.synth_complexes([args.n_rec] * B, [args.n_lig] * B, w['n_kp'], w['cutoffs'], seed=1234 + rank * B)
@@ -186,12 +192,13 @@ def run_train(args, device, rank, world, dist):
         out = {'metric': 'training steps/sec', 'value': world * args.steps / elapsed, 'unit': 'steps/s', 'n_gpus': world,
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
                'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-               'config': {'workload': f'egnn_train: loss + backward + clip + Adam on egnn_all_atom (6 layers, hidden 256), batch of {B} '
+               'config': {'workload': f'{args.workload}: loss + backward + clip + Adam on {w["arch"]}_all_atom (6 layers, hidden 256, '
+                                      f'training mode), batch of {B} '
                                       f'synthetic {args.n_rec}-atom pockets / {args.n_lig}-atom ligands per GPU, one bucketed gradient all-reduce per step when N > 1',
                           'batch_per_gpu': B},
                'complex_steps_per_s': world * args.steps / elapsed * B, 'final_l2': float(last.detach())}
         if not args.no_cpu_baseline:
-            out['cpu_baseline'] = train_cpu_baseline()
+            out['cpu_baseline'] = train_cpu_baseline(args.workload)
         print(json.dumps(out))
 
 
@@ -232,7 +239,7 @@ def main():
         print(f'[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}', file=sys.stderr)
 
     torch.manual_seed(1000 + rank)
-    if args.workload == 'egnn_train':
+    if args.workload in ('egnn_train', 'gvp_train'):
         run_train(args, device, rank, world, dist)
         if dist is not None:
             dist.destroy_process_group()
