@@ -213,6 +213,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--workload', default='egnn_all_atom', choices=list(WORKLOADS),
                     help='egnn_all_atom = BASELINE.json configs[1] (the contract line); the others are secondary')
+    ap.add_argument('--graph', action='store_true', help='replay the reverse step as a captured HIP graph (StepGraph)')
     ap.add_argument('--ragged', action='store_true', help='pockets 150-600 atoms, ligands 15-35 atoms (configs[4] shape)')
     args = ap.parse_args()
 
@@ -263,9 +264,17 @@ def main():
     lig, kp = g.nodes['lig'].data, g.nodes['kp'].data
     init = (lig['x_0'].clone(), lig['h_0'].clone(), kp['x_0'].clone())
 
+    step_graph = None
+    if args.graph:
+        with torch.no_grad():
+            step_graph = model.capture_step(g, bidx)
+
     def step(i):
         si = N_TIMESTEPS - 1 - (i % N_TIMESTEPS)
-        model.sample_p_zs_given_zt(ones * (si / N_TIMESTEPS), ones * ((si + 1) / N_TIMESTEPS), g, bidx)
+        if step_graph is not None:
+            step_graph.step(si / N_TIMESTEPS, (si + 1) / N_TIMESTEPS)
+        else:
+            model.sample_p_zs_given_zt(ones * (si / N_TIMESTEPS), ones * ((si + 1) / N_TIMESTEPS), g, bidx)
         lig['x_0'].copy_(init[0]), lig['h_0'].copy_(init[1]), kp['x_0'].copy_(init[2])
 
     with torch.no_grad():

