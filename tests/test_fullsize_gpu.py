@@ -83,3 +83,53 @@ def test_c5_ragged_gvp_properties(cuda):
     assert torch.isfinite(h).all() and torch.isfinite(x).all()
     assert util.rel_err(hr, h) < 1e-4
     assert util.rel_err(xr, x @ R.T) < 1e-4
+
+
+@pytest.mark.parametrize('arch', ['egnn', 'gvp'])
+def test_full_batch_gradients_directional_derivative(cuda, arch):
+    """configs[1] / configs[4]-shape batch through the training engines: the gradient along a random direction in weight
+    space matches the central finite difference of the loss computed with the fused inference engine (a size-independent
+    property: it exercises the full-size workspaces, split-K weight gradients and edge capacities)."""
+    B = 64
+    if arch == 'egnn':
+        _, g = _batch(B, [300] * B, [25] * B)
+        model = synth.fill_state_dict_(LigRecDynamics(10, 10, graph_cutoffs=CUT, **util.EGNN_C2), 0)
+        pick = ['egnn.conv_layers.2.edge_mlp.kk.2.weight', 'egnn.conv_layers.0.edge_mlp.kl.0.weight',
+                'egnn.conv_layers.4.node_mlp.lig.0.weight', 'egnn.conv_layers.1.coord_mlp.ll.2.weight', 'lig_encoder.2.weight']
+    else:
+        gen = torch.Generator().manual_seed(8)
+        n_rec = torch.randint(150, 601, (B,), generator=gen).tolist()
+        n_lig = torch.randint(15, 36, (B,), generator=gen).tolist()
+        _, g = _batch(B, n_rec, n_lig, v=16)
+        model = synth.fill_state_dict_(LigRecDynamicsGVP(10, 10, graph_cutoffs=CUT, **dict(GVP_ALL_ATOM, dropout=0.0)), 0)
+        pick = ['noise_predictor.conv_layers.1.edge_message_fns.kp_kk_kp.1.to_feats_out.0.weight',
+                'noise_predictor.conv_layers.0.edge_message_fns.kp_kl_lig.0.to_feats_out.0.weight',
+                'noise_predictor.conv_layers.3.node_update_fns.lig.0.Wh', 'noise_predictor.noise_predictor.gvps.1.to_feats_out.0.weight',
+                'lig_encoder.0.weight']
+    model = model.eval().to(cuda)
+    t = torch.linspace(0.05, 1.0, B).to(cuda)
+    gd = g.to(cuda)
+    n_lig_tot = gd.num_nodes('lig')
+    gen = torch.Generator().manual_seed(3)
+    w_h, w_x = torch.randn(n_lig_tot, 10, generator=gen).to(cuda), torch.randn(n_lig_tot, 3, generator=gen).to(cuda)
+
+    def loss():
+        eh, ex = model(gd, t, None)
+        return (eh * w_h).sum() + (ex * w_x).sum()
+
+    loss().backward()
+    params = dict(model.named_parameters())
+    dirs = {n: torch.randn(params[n].shape, generator=gen).to(cuda) for n in pick}
+    analytic = sum(float((params[n].grad.double() * dirs[n].double()).sum()) for n in pick)
+    eps = 2e-3
+    vals = []
+    with torch.no_grad():
+        for sign in (1.0, -1.0):
+            for n in pick:
+                params[n].add_(sign * eps * dirs[n])
+            vals.append(float(loss().double()))
+            for n in pick:
+                params[n].sub_(sign * eps * dirs[n])
+    numeric = (vals[0] - vals[1]) / (2 * eps)
+    assert all(torch.isfinite(p.grad).all() for p in params.values() if p.grad is not None)
+    assert abs(analytic - numeric) <= 3e-2 * max(abs(analytic), abs(numeric), 1e-3), (analytic, numeric)
