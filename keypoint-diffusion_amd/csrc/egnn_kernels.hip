@@ -704,6 +704,208 @@ __global__ __launch_bounds__(256, 3) void k_node_layer(NodeLayerPair p) {
 #undef NL_STAMP
 }
 
+// ---- node update with 8 waves per 32-node tile (update only; the projections run in k_proj_chain) -----------------------
+__global__ __launch_bounds__(512, 3) void k_node_update8(NodeLayerPair p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *A = smem;
+    float *s_z = smem + TN * SA;
+    float *s_mean = s_z + TN;
+    float *s_rstd = s_mean + TN;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int which = blockIdx.x >= p.tiles0 ? 1 : 0;
+    const NodeLayerArgs &L = p.nt[which];
+    const NodeArgs &a = L.u;
+    const int node0 = (blockIdx.x - (which ? p.tiles0 : 0)) * TN;
+    constexpr int RPW = TN / 8;          // rows per wave in the copy loops
+    constexpr int TPR = 512 / TN;        // threads per row in the row-wise passes
+    unsigned long long t_prev_ = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+#define NL_STAMP(idx)                                                                      \
+    if (p.stamps && tid == 0) {                                                            \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                      \
+        atomicAdd(&p.stamps[idx], (unsigned long long)(now_ - t_prev_));                   \
+        t_prev_ = now_;                                                                    \
+    }
+
+    auto load_h = [&]() {
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int r = wave * RPW + rr, v = node0 + r;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f}, val2 = {0.f, 0.f, 0.f, 0.f};
+            if (v < a.n) {
+                const f32x4 *src = reinterpret_cast<const f32x4 *>(a.h + (size_t)v * HS);
+                val = src[lane];
+                if (lane < 2) val2 = src[64 + lane];
+            }
+            *reinterpret_cast<f32x4 *>(A + r * SA + 4 * lane) = val;
+            if (lane < 2) *reinterpret_cast<f32x4 *>(A + r * SA + 256 + 4 * lane) = val2;
+        }
+    };
+
+    f32x16 acc;
+    {
+        // coordinates: x' = x + x_neigh / z (dynamics.py:190-192, 206)
+        if (tid < TN) {
+            const int v = node0 + tid;
+            float z = 1.0f;
+            if (v < a.n) {
+                z = a.z[a.bidx[v]];
+                float sx = 0.f, sy = 0.f, sz = 0.f;
+                for (int i = 0; i < a.n_in; ++i) {
+                    const int lo = a.rowptr[i][v], hi = a.rowptr[i][v + 1];
+                    if (hi > lo) {
+                        const float *pm = a.xn_main[i] + (size_t)v * 4;
+                        sx += pm[0]; sy += pm[1]; sz += pm[2];
+                        for (int t = lo / TM + 1; t <= (hi - 1) / TM; ++t) {
+                            const float *q = a.xn_cont[i] + (size_t)t * 4;
+                            sx += q[0]; sy += q[1]; sz += q[2];
+                        }
+                    }
+                }
+                float *xv = a.x + (size_t)v * 3;
+                xv[0] += sx / z; xv[1] += sy / z; xv[2] += sz / z;
+            }
+            s_z[tid] = z;
+        }
+        // GEMM 1a: W[:, :257] . h
+        load_h();
+        lds_barrier();
+        NL_STAMP(0)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+        gemm_rows32_t8<NG, SA>(A, a.wp_a, acc, wave, lane);
+        float ex = row_dot_chunks<TPR>(A, a.wx_a, KP / 4, tid);
+        lds_barrier();
+        NL_STAMP(1)
+        // GEMM 1b: + W[:, 257:] . (h_neigh / z); h_neigh = sum of segment pieces over the incoming edge
+        // types in fixed order (multi_update_all cross_reducer='sum')
+#pragma unroll 2
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int r = wave * RPW + rr, v = node0 + r;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f}, val2 = {0.f, 0.f, 0.f, 0.f};
+            if (v < a.n) {
+                for (int i = 0; i < a.n_in; ++i) {
+                    const int lo = a.rowptr[i][v], hi = a.rowptr[i][v + 1];
+                    if (hi > lo) {
+                        const f32x4 *pm = reinterpret_cast<const f32x4 *>(a.hn_main[i] + (size_t)v * HS);
+                        val += pm[lane];
+                        if (lane < 2) val2 += pm[64 + lane];
+                        for (int t = lo / TM + 1; t <= (hi - 1) / TM; ++t) {
+                            const f32x4 *q = reinterpret_cast<const f32x4 *>(a.hn_cont[i] + (size_t)t * HS);
+                            val += q[lane];
+                            if (lane < 2) val2 += q[64 + lane];
+                        }
+                    }
+                }
+                const float z = s_z[r];
+                val /= z;
+                val2 /= z;
+            }
+            *reinterpret_cast<f32x4 *>(A + r * SA + 4 * lane) = val;
+            if (lane < 2) *reinterpret_cast<f32x4 *>(A + r * SA + 256 + 4 * lane) = val2;
+        }
+        lds_barrier();
+        NL_STAMP(2)
+        gemm_rows32_t8<NG, SA>(A, a.wp_b, acc, wave, lane);
+        ex += row_dot_chunks<TPR>(A, a.wx_b, KP / 4, tid);
+        lds_barrier();
+        NL_STAMP(3)
+        // hidden = SiLU(. + b0) -> T (pad columns 257..263 stay 0 from the h_neigh tile)
+        {
+            const int col = 32 * wave + (lane & 31);
+            const float bb = a.b0[col];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) A[acc_row32(reg, lane) * SA + col] = silu(acc[reg] + bb);
+        }
+        if ((tid % TPR) == 0) A[(tid / TPR) * SA + 256] = silu(ex + a.b0[256]);
+        lds_barrier();
+        NL_STAMP(4)
+        // GEMM 2 + bias + residual (dynamics.py:201-203)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+        gemm_rows32_t8<NG, SA>(A, a.wp_2, acc, wave, lane);
+        ex = row_dot_chunks<TPR>(A, a.wx_2, KP / 4, tid);
+        lds_barrier();
+        NL_STAMP(5)
+        {
+            const int col = 32 * wave + (lane & 31);
+            const float bb = a.b2[col];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) A[acc_row32(reg, lane) * SA + col] = acc[reg] + bb;
+        }
+        if ((tid % TPR) == 0) A[(tid / TPR) * SA + 256] = ex + a.b2[256];
+        lds_barrier();
+        // residual h (row-wise, coalesced; the h array is padded to a whole tile, rows >= n read zeros)
+#pragma unroll 4
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int r = wave * RPW + rr;
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(a.h + (size_t)(node0 + r) * HS);
+            *reinterpret_cast<f32x4 *>(A + r * SA + 4 * lane) += src[lane];
+            if (lane == 0) A[r * SA + 256] += a.h[(size_t)(node0 + r) * HS + 256];
+        }
+        lds_barrier();
+        NL_STAMP(6)
+        // LayerNorm(257) (dynamics.py:81-87, 204), biased variance, eps = 1e-5
+        if (a.norm) {
+            const int row = tid / TPR, q = tid % TPR;
+            const float *tr = A + row * SA + q;
+            float sum = 0.0f;
+            for (int i = 0; i < 256 / TPR; ++i) sum += tr[TPR * i];
+            if (q == 0) sum += A[row * SA + 256];
+#pragma unroll
+            for (int o = 1; o < TPR; o <<= 1) sum += __shfl_xor(sum, o);
+            const float mean = sum * (1.0f / HW);
+            float var = 0.0f;
+            for (int i = 0; i < 256 / TPR; ++i) {
+                const float dlt = tr[TPR * i] - mean;
+                var = fmaf(dlt, dlt, var);
+            }
+            if (q == 0) {
+                const float dlt = A[row * SA + 256] - mean;
+                var = fmaf(dlt, dlt, var);
+            }
+#pragma unroll
+            for (int o = 1; o < TPR; o <<= 1) var += __shfl_xor(var, o);
+            if (q == 0) {
+                s_mean[row] = mean;
+                s_rstd[row] = 1.0f / sqrtf(var * (1.0f / HW) + 1e-5f);
+            }
+        }
+        lds_barrier();
+        NL_STAMP(7)
+        // normalise in place (the tile becomes the A operand of the projections) and write h' back
+#pragma unroll 2
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int r = wave * RPW + rr, v = node0 + r;
+            f32x4 val = *reinterpret_cast<const f32x4 *>(A + r * SA + 4 * lane);
+            float last = A[r * SA + 256];
+            if (a.norm) {
+                const float mean = s_mean[r], rstd = s_rstd[r];
+                const f32x4 w = reinterpret_cast<const f32x4 *>(a.ln_w)[lane];
+                const f32x4 b = reinterpret_cast<const f32x4 *>(a.ln_b)[lane];
+                val = (val - mean) * rstd * w + b;
+                last = (last - mean) * rstd * a.ln_w[256] + a.ln_b[256];
+            }
+            if (v >= a.n) {
+                val = f32x4{0.f, 0.f, 0.f, 0.f};
+                last = 0.0f;
+            }
+            *reinterpret_cast<f32x4 *>(A + r * SA + 4 * lane) = val;
+            const f32x4 t = {last, 0.f, 0.f, 0.f};
+            if (lane == 0) *reinterpret_cast<f32x4 *>(A + r * SA + 256) = t;
+            if (lane == 1) *reinterpret_cast<f32x4 *>(A + r * SA + 260) = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (v < a.n) {
+                f32x4 *dst = reinterpret_cast<f32x4 *>(a.h + (size_t)v * HS);
+                dst[lane] = val;
+                if (lane == 0) dst[64] = t;
+            }
+        }
+        lds_barrier();
+        NL_STAMP(8)
+    }
+#undef NL_STAMP
+}
+
+
 // ---- launchers ----------------------------------------------------------------------------
 static bool g_attr_set = false;
 
@@ -714,6 +916,8 @@ kpd_status egnn_kernels_init() {
     KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_egnn_edge<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024));
     KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_layer), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024));
+    KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_update8), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024));
     g_attr_set = true;
     return KPD_OK;
@@ -779,6 +983,15 @@ kpd_status launch_node_layer(const NodeLayerPair &p, hipStream_t st) {
     static const int dbg = getenv("KPD_NODE_ABLATE") ? atoi(getenv("KPD_NODE_ABLATE")) : 0;
     NodeLayerPair q = p;
     q.dbg = dbg;
+    // update-only launches (the default split node mode) take the 8-wave kernel; KPD_NODE_NW=4 keeps the 4-wave one
+    static const int nw = getenv("KPD_NODE_NW") ? atoi(getenv("KPD_NODE_NW")) : 8;
+    const bool update_only = (p.nt[0].do_update || p.nt[0].u.n == 0) && (p.nt[1].do_update || p.nt[1].u.n == 0) &&
+                             !p.nt[0].do_proj && !p.nt[1].do_proj;
+    if (nw == 8 && update_only && !p.stamps && !dbg) {
+        hipLaunchKernelGGL(k_node_update8, dim3(tiles), dim3(512), NODE_LAYER_LDS_BYTES + pad, st, q);
+        KPD_LAUNCH_CHECK();
+        return KPD_OK;
+    }
     hipLaunchKernelGGL(k_node_layer, dim3(tiles), dim3(256), NODE_LAYER_LDS_BYTES + pad, st, q);
     KPD_LAUNCH_CHECK();
     return KPD_OK;

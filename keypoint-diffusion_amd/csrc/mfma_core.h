@@ -146,6 +146,48 @@ __device__ __forceinline__ void gemm_rows32_t(const float *__restrict__ A, const
 #undef KPD_STEP32
 }
 
+// 8-wave form of gemm_rows32_t: one 32-column tile per wave (wave w reads column tile (w & 1) of the packed block of wave
+// (w >> 1) of 4).  Twice the waves per 32-row tile halve the dependent MFMA chain of a GEMM phase, which is what bounds the
+// node kernel: its grid is a single round of workgroups, so its duration is a workgroup's latency.
+template <int NG_, int SA_>
+__device__ __forceinline__ void gemm_rows32_t8(const float *__restrict__ A, const float *__restrict__ Wp, f32x16 &acc, int wave,
+                                               int lane) {
+    const int r = lane & 31, h = lane >> 5;
+    const float *a0p = A + r * SA_ + 4 * h;
+    const f32x4 *bp = reinterpret_cast<const f32x4 *>(Wp) + ((wave >> 1) * 64 + lane) * 2 + (wave & 1);
+    f32x4 a0[4], b0[4];
+#define KPD_LOAD32(S, G)                                     \
+    a0[S] = *reinterpret_cast<const f32x4 *>(a0p + 8 * (G)); \
+    b0[S] = bp[(G) * 512];
+#define KPD_STEP32(S) \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[S][j], b0[S][j], acc, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int g = i < NG_ ? i : NG_ - 1;
+        KPD_LOAD32(i, g)
+    }
+    constexpr int QUADS = NG_ / 4;
+#pragma unroll 1
+    for (int q = 0; q < QUADS; ++q) {
+        const int g = 4 * q;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_barrier(0);
+            KPD_STEP32(i)
+            __builtin_amdgcn_sched_barrier(0);
+            const int gn = g + 4 + i < NG_ ? g + 4 + i : NG_ - 1;
+            KPD_LOAD32(i, gn)
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < (NG_ & 3); ++i) {
+        __builtin_amdgcn_sched_barrier(0);
+        KPD_STEP32(i)
+    }
+#undef KPD_LOAD32
+#undef KPD_STEP32
+}
+
 __device__ __forceinline__ int acc_row32(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 // ---- wave-count-generic variants ------------------------------------------------------------------
