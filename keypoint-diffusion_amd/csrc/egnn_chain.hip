@@ -369,6 +369,131 @@ __global__ __launch_bounds__(256, 2) void k_proj_chain(ProjPair p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the ring's tail fetches must not outlive the workgroup's LDS
 }
 
+// ---- weight-stationary form -------------------------------------------------------------------------------------------
+// k_proj_chain streams a slot's 256 x 256 block through LDS for every 64-node tile (2 600 workgroups x 262 KB from L2, a
+// barrier per chunk).  Here a workgroup keeps HALF a slot (128 output features x 256 inputs = 128 KB of A-fragments)
+// resident in LDS for its whole life and walks many 128-node tiles: 8 waves x 16 nodes, features in B-operand registers,
+// no barrier and no weight refill inside the GEMM, next tile's rows prefetched during the current tile's 512 MFMAs.
+// One workgroup per CU (LDS), two waves per SIMD.
+struct ProjWs {
+    ProjPair p;
+    int blocks0;        // workgroups of node type 0
+    int bpc[2];         // workgroups per (slot, half) of each node type
+    int tpb;            // 128-node tiles per workgroup
+};
+
+constexpr int WS_TILE = 128;                                  // nodes per tile: 8 waves x 16
+constexpr int WS_W4 = 16 * 8 * 64;                            // float4 of the resident half block
+constexpr int WS_LDS_BYTES = WS_W4 * 16 + (128 + 128 + HS) * 4;
+
+__global__ __launch_bounds__(512, 1) void k_proj_ws(ProjWs qa) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    v4f *W = reinterpret_cast<v4f *>(smem);
+    float *s_wcol = smem + WS_W4 * 4, *s_bias = s_wcol + 128, *s_wrow = s_bias + 128;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int which = (int)blockIdx.x >= qa.blocks0 ? 1 : 0;
+    const ProjArgs &a = qa.p.nt[which];
+    const int local = blockIdx.x - (which ? qa.blocks0 : 0);
+    const int combo = local / qa.bpc[which], chunk = local - combo * qa.bpc[which];
+    const int s = combo >> 1, hf = combo & 1;
+    const int tiles = (a.n + WS_TILE - 1) / WS_TILE;
+    const int t0 = chunk * qa.tpb, t1 = min(tiles, t0 + qa.tpb);
+    if (t0 >= t1) return;                                     // uniform over the workgroup
+    {
+        const v4f *src = reinterpret_cast<const v4f *>(a.chain[s]);
+#pragma unroll
+        for (int j = 0; j < WS_W4 / 512; ++j) {
+            const int i = tid + 512 * j, ks = i >> 9, rem = i & 511;
+            W[i] = src[(size_t)ks * ECH4 + 8 * hf * 64 + rem];
+        }
+        const float *bias = a.bias[s];
+        if (tid < 128) {
+            s_wcol[tid] = a.wcol[s][128 * hf + tid];
+            s_bias[tid] = bias ? bias[128 * hf + tid] : 0.0f;
+        }
+        for (int i = tid; i < HS; i += 512) s_wrow[i] = i <= 256 ? a.wx[s][i] : 0.0f;
+    }
+    __syncthreads();
+    const int el = lane & 15, q = lane >> 4;
+    const float bias256 = a.bias[s] ? a.bias[s][256] : 0.0f;
+    auto load_x = [&](int t, v4f (&x)[ENT], float &x256) {
+        const int row = min(t * WS_TILE + 16 * wave + el, a.n - 1);
+        const float *hrow = a.h + (size_t)row * HS;
+#pragma unroll
+        for (int nt = 0; nt < ENT; ++nt) x[nt] = *reinterpret_cast<const v4f *>(hrow + 16 * nt + 4 * q);
+        x256 = hrow[256];
+    };
+    auto store_tile = [&](const v4f (&acc)[8], int row, float out256) {
+        if (row >= 0 && row < a.n) {
+            float *orow = a.P + ((size_t)row * NSLOT + a.slot[s]) * HS + 128 * hf;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) *reinterpret_cast<v4f *>(orow + 16 * m + 4 * q) = acc[m];
+            if (hf == 0 && q == 0) orow[256] = out256;
+        }
+    };
+    v4f x[ENT], xn[ENT], accp[8];
+    float h256, h256n, out256p = 0.0f;
+    int rowp = -1;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) accp[m] = zero4();
+    load_x(t0, xn, h256n);
+#pragma unroll 1
+    for (int t = t0; t < t1; ++t) {
+        // The rows of this tile were loaded into xn a whole tile ago; x is only ever written by these moves, so the wait the
+        // compiler places here counts the loads alone (the previous tile's stores are younger and stay in flight) and the
+        // MFMAs below never wait on memory.  (A plain copy is coalesced away and the wait sinks behind the stores.)
+#pragma unroll
+        for (int nt = 0; nt < ENT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) asm volatile("v_mov_b32 %0, %1" : "=v"(x[nt][r]) : "v"(xn[nt][r]));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(h256) : "v"(h256n));
+        __builtin_amdgcn_sched_barrier(0);
+        // the previous tile's results leave only now, after the wait above: stores share the in-order memory counter with
+        // the loads, and a store issued before that wait would be waited for as well (its full round trip, every tile)
+        store_tile(accp, rowp, out256p);
+        if (t + 1 < t1) load_x(t + 1, xn, h256n);             // in flight during this tile's MFMAs
+        v4f acc[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+            acc[m] = h256 * *reinterpret_cast<const v4f *>(s_wcol + 16 * m + 4 * q) + *reinterpret_cast<const v4f *>(s_bias + 16 * m + 4 * q);
+        float part = 0.0f;
+        if (hf == 0) {
+#pragma unroll
+            for (int nt = 0; nt < ENT; ++nt) {
+                const v4f wv = *reinterpret_cast<const v4f *>(s_wrow + 16 * nt + 4 * q);
+                part += x[nt][0] * wv[0] + x[nt][1] * wv[1] + x[nt][2] * wv[2] + x[nt][3] * wv[3];
+            }
+        }
+        // 32 batches of 4 output tiles (16 k-slabs x 2), LDS reads of batch b + 1 pinned ahead of the 16 MFMAs of batch b
+        const v4f *wp = W + lane;
+        v4f w[2][4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) w[0][m] = wp[m * 64];
+#pragma unroll
+        for (int b = 0; b < 32; ++b) {
+            if (b + 1 < 32) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) w[(b + 1) & 1][m] = wp[(4 * (b + 1) + m) * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const v4f xin = x[b >> 1];
+            const int g = b & 1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[4 * g + m] = mfma16(w[b & 1][m][r], xin[r], acc[4 * g + m]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int row = t * WS_TILE + 16 * wave + el;
+        const float out256 = hf == 0 ? reduce_q(part) + bias256 + h256 * s_wrow[256] : 0.0f;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) accp[m] = acc[m];
+        rowp = row;
+        out256p = out256;
+    }
+    store_tile(accp, rowp, out256p);
+}
+
 static bool g_pchain_attr = false;
 
 kpd_status launch_proj_chain(const ProjPair &p, hipStream_t st) {
@@ -382,6 +507,33 @@ kpd_status launch_proj_chain(const ProjPair &p, hipStream_t st) {
         KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_chain), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     4 * ECH4 * 16));
         g_pchain_attr = true;
+    }
+    static const int ws = getenv("KPD_PROJ_WS") ? atoi(getenv("KPD_PROJ_WS")) : 1;
+    if (ws) {
+        static bool attr_ws = false;
+        if (!attr_ws) {
+            KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_ws), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES));
+            attr_ws = true;
+        }
+        static const int target = getenv("KPD_PROJ_WS_BLOCKS") ? std::max(1, atoi(getenv("KPD_PROJ_WS_BLOCKS"))) : 256;
+        ProjWs q;
+        q.p = p;
+        int units = 0, tl[2];
+        for (int nt = 0; nt < 2; ++nt) {
+            tl[nt] = p.n_slots[nt] ? cdiv(p.nt[nt].n, WS_TILE) : 0;
+            units += 2 * p.n_slots[nt] * tl[nt];
+        }
+        if (units == 0) return KPD_OK;
+        q.tpb = std::max(1, cdiv(units, target));
+        int blocks[2];
+        for (int nt = 0; nt < 2; ++nt) {
+            q.bpc[nt] = std::max(1, cdiv(tl[nt], q.tpb));
+            blocks[nt] = tl[nt] ? 2 * p.n_slots[nt] * q.bpc[nt] : 0;
+        }
+        q.blocks0 = blocks[0];
+        hipLaunchKernelGGL(k_proj_ws, dim3(blocks[0] + blocks[1]), dim3(512), WS_LDS_BYTES, st, q);
+        KPD_LAUNCH_CHECK();
+        return KPD_OK;
     }
     static const int spb = getenv("KPD_PROJ_SPB") ? std::max(1, atoi(getenv("KPD_PROJ_SPB"))) : 1;
     ProjPair q = p;
