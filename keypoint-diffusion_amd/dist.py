@@ -34,36 +34,41 @@ def shard_complexes(costs: Sequence[float], world: int) -> List[range]:
 
 
 def all_gather_ligands(g: G.HeteroBatch, group=None) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
-    """Every rank returns the ligand positions / features of ALL ranks' complexes, rank-major."""
+    """Every rank returns the ligand positions / features of ALL ranks' complexes, rank-major.
+    Two collectives (sizes, then one padded block per rank), packing and unpacking without per-complex device work: the
+    block is filled by one indexed assignment, copied to the host once, and the results are views into that copy."""
     world = dist.get_world_size(group)
     # RCCL moves device tensors; gloo (CPU tests, one-GPU rehearsals) wants host tensors
     dev = g.device if dist.get_backend(group) == 'nccl' else torch.device('cpu')
-    counts = g.batch_num_nodes('lig').to(dev).int()
-    x, h = g.nodes['lig'].data['x_0'].to(dev), g.nodes['lig'].data['h_0'].to(dev)
-    F = h.shape[1]
+    counts = g.batch_num_nodes('lig').to(dev).long()
+    x, h = g.nodes['lig'].data['x_0'].to(dev).float(), g.nodes['lig'].data['h_0'].to(dev).float()
+    F, B = h.shape[1], counts.numel()
     # 1) how many complexes / atoms everybody has
-    meta = torch.tensor([counts.numel(), int(counts.max()) if counts.numel() else 0], device=dev, dtype=torch.int32)
-    metas = [torch.zeros_like(meta) for _ in range(world)]
-    dist.all_gather(metas, meta, group=group)
-    max_B = max(int(m[0]) for m in metas)
-    max_n = max(int(m[1]) for m in metas)
-    # 2) one padded block per rank: [max_B, 1 + max_n * (3 + F)]  (first column = atom count)
-    block = torch.zeros(max_B, 1 + max_n * (3 + F), device=dev, dtype=torch.float32)
-    ptr = g.node_ptr('lig').tolist()
-    for b in range(counts.numel()):
-        n = ptr[b + 1] - ptr[b]
-        block[b, 0] = n
-        block[b, 1:1 + n * 3] = x[ptr[b]:ptr[b + 1]].reshape(-1)
-        block[b, 1 + max_n * 3:1 + max_n * 3 + n * F] = h[ptr[b]:ptr[b + 1]].reshape(-1)
-    blocks = [torch.zeros_like(block) for _ in range(world)]
-    dist.all_gather(blocks, block, group=group)
+    meta = torch.stack([torch.tensor(B, device=dev), counts.max() if B else torch.tensor(0, device=dev)]).to(torch.int32)
+    metas = torch.empty(world * 2, device=dev, dtype=torch.int32)
+    dist.all_gather_into_tensor(metas, meta, group=group)
+    metas = metas.view(world, 2).cpu()
+    max_B, max_n = int(metas[:, 0].max()), int(metas[:, 1].max())
+    # 2) one padded block per rank: [max_B, 1 + max_n * (3 + F)], column 0 = atom count, then atoms x (x, h)
+    W = 3 + F
+    block = torch.zeros(max_B, 1 + max_n * W, device=dev, dtype=torch.float32)
+    if B:
+        block[:B, 0] = counts.float()
+        cid = torch.repeat_interleave(torch.arange(B, device=dev), counts)
+        start = torch.cumsum(counts, 0) - counts
+        local = torch.arange(x.shape[0], device=dev) - start[cid]
+        body = block[:, 1:].view(max_B, max_n, W)
+        body[cid, local] = torch.cat([x, h], dim=1)
+    blocks = torch.empty(world, max_B, 1 + max_n * W, device=dev, dtype=torch.float32)
+    dist.all_gather_into_tensor(blocks.view(world * max_B, -1), block, group=group)
+    blocks = blocks.cpu()
     pos, feat = [], []
     for r in range(world):
-        blk = blocks[r].cpu()
-        for b in range(int(metas[r][0])):
-            n = int(blk[b, 0])
-            pos.append(blk[b, 1:1 + n * 3].reshape(n, 3).clone())
-            feat.append(blk[b, 1 + max_n * 3:1 + max_n * 3 + n * F].reshape(n, F).clone())
+        body = blocks[r, :, 1:].view(max_B, max_n, W)
+        ns = blocks[r, :int(metas[r, 0]), 0].long().tolist()
+        for b, n in enumerate(ns):
+            pos.append(body[b, :n, :3])
+            feat.append(body[b, :n, 3:])
     return pos, feat
 
 
