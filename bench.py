@@ -197,7 +197,7 @@ def run_train(args, device, rank, world, dist):
                                       f'synthetic {args.n_rec}-atom pockets / {args.n_lig}-atom ligands per GPU, one bucketed gradient all-reduce per step when N > 1',
                           'batch_per_gpu': B},
                'complex_steps_per_s': world * args.steps / elapsed * B, 'final_l2': float(last.detach())}
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = train_cpu_baseline(args.workload)
         print(json.dumps(out))
 
