@@ -303,6 +303,7 @@ struct kpd_egnn_trainer : TrainCtx {
     // scratch
     float *eb[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // [cap_E, LD] each
     float *nb[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // [cap_N, LD] each
+    float *wsg_pack = nullptr;                                                   // packed weights of the current ws_gemm call
     float *dact = nullptr;                                                       // [cap_N, ENC_LD]
     float *xdiff = nullptr, *dij = nullptr, *nvec = nullptr, *att = nullptr, *sc = nullptr, *dsv = nullptr, *ddij = nullptr,
           *dn = nullptr, *msgx = nullptr;
@@ -316,6 +317,11 @@ const char *kEt[4] = {"ll", "kl", "lk", "kk"};
 const char *kNt[2] = {"lig", "kp"};
 const int kS[4] = {NT_LIG, NT_KP, NT_LIG, NT_KP};     // source node type of ll, kl, lk, kk
 const int kD[4] = {NT_LIG, NT_LIG, NT_KP, NT_KP};
+
+bool use_ws() {
+    static const bool on = !(getenv("KPD_TRAIN_WS") && atoi(getenv("KPD_TRAIN_WS")) == 0);
+    return on;
+}
 
 struct BranchParams {
     Param W1, b1, W2, b2, head, head_b;     // head = soft_attention weight [1,257] (+ bias) or coord_mlp.4 weight [1,257]
@@ -346,6 +352,8 @@ kpd_status edge_branch_fwd(kpd_egnn_trainer *T, const BranchParams &p, int et, c
     hipLaunchKernelGGL(k_edge_pre1, grid1(tot), dim3(256), 0, T->st, T->nb[0], T->nb[1], T->e_src[et], T->e_dst[et], T->dij,
                        p.W1.w + 2 * H, 2 * H + 1, p.b1.w, tot, T->eb[0], T->eb[1]);
     KPD_LAUNCH_CHECK();
+    // pre2 = a1 W2^T + b2, a2 = SiLU(pre2): the weight-stationary GEMM with the activation fused (KPD_TRAIN_WS=0: rocBLAS + kernel)
+    if (use_ws()) return ws_gemm(WS_BIAS_SILU, T->eb[1], E, LD, p.W2.w, H, false, p.b2.w, nullptr, T->eb[2], T->eb[3], LD, T->wsg_pack, T->st);
     KPD_TRY(gemm(T, false, true, E, H, H, T->eb[1], LD, p.W2.w, H, 0.0f, T->eb[2], LD));
     hipLaunchKernelGGL(k_bias_silu, grid1(tot), dim3(256), 0, T->st, T->eb[2], p.b2.w, tot, H, LD, T->eb[3]);
     KPD_LAUNCH_CHECK();
@@ -572,6 +580,7 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
     for (int k = 0; k < 6; ++k) add((size_t)cap_E * LD, 4);
     for (int k = 0; k < 7; ++k) add((size_t)cap_N * LD, 4);
     add((size_t)cap_N * ENC_LD, 4);
+    add((size_t)ws_gemm_pack_floats(), 4);
     add((size_t)GRAD_SPLIT * 264 * 520, 4);
     for (int k = 0; k < 3; ++k) add((size_t)cap_E * 3, 4);      // xdiff, nvec, dn
     add((size_t)cap_E * 3, 4);                                    // msgx
@@ -601,6 +610,7 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
     for (int k = 0; k < 6; ++k) T->eb[k] = W.take<float>((size_t)cap_E * LD);
     for (int k = 0; k < 7; ++k) T->nb[k] = W.take<float>((size_t)cap_N * LD);
     T->dact = W.take<float>((size_t)cap_N * ENC_LD);
+    T->wsg_pack = W.take<float>((size_t)ws_gemm_pack_floats());
     T->part_floats = (size_t)GRAD_SPLIT * 264 * 520;
     T->part = W.take<float>(T->part_floats);
     T->xdiff = W.take<float>((size_t)cap_E * 3); T->nvec = W.take<float>((size_t)cap_E * 3); T->dn = W.take<float>((size_t)cap_E * 3);
@@ -755,10 +765,15 @@ kpd_status edge_branch_bwd(kpd_egnn_trainer *T, const BranchParams &p, int l, in
     float *dpre2 = T->eb[4], *dpre1 = T->eb[5];
     KPD_TRY(colsum_acc(T, E, H, dpre2, LD, p.b2.g));
     if (p.W2.g) KPD_TRY(grad_gemm(T, H, H, E, dpre2, LD, T->eb[1], LD, p.W2.g, H));
-    KPD_TRY(gemm(T, false, false, E, H, H, dpre2, LD, p.W2.w, H, 0.0f, dpre1, LD));
     const long long tot = (long long)E * H;
-    hipLaunchKernelGGL(k_silu_bwd, grid1(tot), dim3(256), 0, T->st, dpre1, T->eb[0], tot, H, LD);
-    KPD_LAUNCH_CHECK();
+    // dpre1 = (dpre2 W2) * SiLU'(pre1)
+    if (use_ws()) {
+        KPD_TRY(ws_gemm(WS_SILU_BWD, dpre2, E, LD, p.W2.w, H, true, nullptr, T->eb[0], dpre1, nullptr, LD, T->wsg_pack, T->st));
+    } else {
+        KPD_TRY(gemm(T, false, false, E, H, H, dpre2, LD, p.W2.w, H, 0.0f, dpre1, LD));
+        hipLaunchKernelGGL(k_silu_bwd, grid1(tot), dim3(256), 0, T->st, dpre1, T->eb[0], tot, H, LD);
+        KPD_LAUNCH_CHECK();
+    }
     // b1 gradient and column 514 of W1 (the dij weights) in one pass over dpre1
     KPD_TRY(gemv_t_colsum_acc(T, E, H, dpre1, LD, T->dij, p.W1.g ? p.W1.g + 2 * H : nullptr, 2 * H + 1, p.b1.g));
     KPD_TRY(gemv_n(T, E, H, dpre1, LD, p.W1.w + 2 * H, 2 * H + 1, first_branch ? 0.0f : 1.0f, T->ddij, 1));

@@ -1,0 +1,223 @@
+// Weight-stationary tall-skinny GEMM for the training engines:  Y[rows, 257] = epilogue(X[rows, 257] op(W) (+ b)).
+//
+// The per-edge products of the EGNN training path (pre2 = a1 W2^T, da1 = dpre2 W2: hundreds of thousands of rows against
+// one 257 x 257 matrix) have the shape k_proj_ws was built for (egnn_chain.hip): a workgroup keeps half of the 256 x 256
+// block (128 outputs x 256 inputs = 128 KB of MFMA A-fragments) resident in LDS and walks 128-row tiles with eight
+// independent waves, rows in B-operand registers, no barrier and no weight refill inside the GEMM; the 257th input /
+// output are a VALU rank-1 update / dot product.  The weights change every optimizer step, so they are packed per call
+// (one launch: fragments of W or W^T by strides, column 256, row 256), and the elementwise work that followed the
+// library GEMM is fused into the epilogue:
+//   WS_BIAS_SILU   : Y = X W^T + b (kept: the pre-activation), A = SiLU(Y)
+//   WS_SILU_BWD    : Y = (X W) * SiLU'(P)            (P: the saved pre-activation of the previous Linear)
+#include "chain_core.h"
+#include "engine.h"
+
+namespace kpd {
+
+namespace {
+
+constexpr int WSG_TILE = 128;
+constexpr int WSG_W4 = 16 * 8 * 64;                           // float4 of the resident half block
+constexpr int WSG_LDS_BYTES = WSG_W4 * 16 + (128 + 128 + HS) * 4;
+constexpr int WSG_PACK_FLOATS = 16 * 16 * 64 * 4 + 256 + HS;  // fragments, column 256, row 256 (padded)
+
+__device__ __forceinline__ float wsg_sigm(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// fragments of the 256 x 256 block of M (M[n][k] = src[n * sn + k * sk]) in chain-chunk order, then M[:, 256], then M[256, :]
+__global__ void k_wsg_pack(const float *__restrict__ src, int sn, int sk, float *__restrict__ dst) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < 16 * 16 * 256) {
+        const int r = idx & 3, lane = (idx >> 2) & 63, mt = (idx >> 8) & 15, ks = idx >> 12;
+        const int n = 16 * mt + (lane & 15), k = 16 * ks + 4 * (lane >> 4) + r;
+        dst[idx] = src[(size_t)n * sn + (size_t)k * sk];
+    } else if (idx < 16 * 16 * 256 + 256) {
+        const int n = idx - 16 * 16 * 256;
+        dst[idx] = src[(size_t)n * sn + (size_t)256 * sk];
+    } else if (idx < 16 * 16 * 256 + 256 + HS) {
+        const int k = idx - 16 * 16 * 256 - 256;
+        dst[idx] = k <= 256 ? src[(size_t)256 * sn + (size_t)k * sk] : 0.0f;
+    }
+}
+
+struct WsgArgs {
+    const float *X;         // [rows, ldx], 257 columns used
+    int rows, ldx;
+    const float *pack;      // WSG_PACK_FLOATS as written by k_wsg_pack
+    const float *bias;      // [257] or null
+    const float *P;         // [rows, ldy] pre-activation for WS_SILU_BWD, else null
+    float *Y, *A;           // [rows, ldy]; A only for WS_BIAS_SILU
+    int ldy, mode, bpc, tpb;
+};
+
+template <int MODE>
+__device__ __forceinline__ void wsg_store(const WsgArgs &a, int row, int hf, int q, const v4f (&acc)[8], float out256) {
+    if (row < 0 || row >= a.rows) return;
+    float *yrow = a.Y + (size_t)row * a.ldy + 128 * hf;
+    if (MODE == WS_BIAS_SILU) {
+        float *arow = a.A + (size_t)row * a.ldy + 128 * hf;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const v4f v = acc[m];
+            v4f s;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[r] = v[r] * wsg_sigm(v[r]);
+            *reinterpret_cast<v4f *>(yrow + 16 * m + 4 * q) = v;
+            *reinterpret_cast<v4f *>(arow + 16 * m + 4 * q) = s;
+        }
+        if (hf == 0 && q == 0) {
+            yrow[256] = out256;
+            arow[256] = out256 * wsg_sigm(out256);
+        }
+    } else {
+        const float *prow = a.P + (size_t)row * a.ldy + 128 * hf;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const v4f p = *reinterpret_cast<const v4f *>(prow + 16 * m + 4 * q);
+            v4f v = acc[m];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sg = wsg_sigm(p[r]);
+                v[r] *= sg * (1.0f + p[r] * (1.0f - sg));
+            }
+            *reinterpret_cast<v4f *>(yrow + 16 * m + 4 * q) = v;
+        }
+        if (hf == 0 && q == 0) {
+            const float p = prow[256], sg = wsg_sigm(p);
+            yrow[256] = out256 * sg * (1.0f + p * (1.0f - sg));
+        }
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void k_ws_gemm(WsgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    v4f *W = reinterpret_cast<v4f *>(smem);
+    float *s_wcol = smem + WSG_W4 * 4, *s_bias = s_wcol + 128, *s_wrow = s_bias + 128;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int hf = blockIdx.x / a.bpc, chunk = blockIdx.x - hf * a.bpc;
+    const int tiles = (a.rows + WSG_TILE - 1) / WSG_TILE;
+    const int t0 = chunk * a.tpb, t1 = min(tiles, t0 + a.tpb);
+    if (t0 >= t1) return;                                     // uniform over the workgroup
+    {
+        const v4f *src = reinterpret_cast<const v4f *>(a.pack);
+#pragma unroll
+        for (int j = 0; j < WSG_W4 / 512; ++j) {
+            const int i = tid + 512 * j, ks = i >> 9, rem = i & 511;
+            W[i] = src[(size_t)ks * 1024 + 8 * hf * 64 + rem];
+        }
+        const float *wcol = a.pack + 16 * 16 * 256, *wrow = wcol + 256;
+        if (tid < 128) {
+            s_wcol[tid] = wcol[128 * hf + tid];
+            s_bias[tid] = a.bias ? a.bias[128 * hf + tid] : 0.0f;
+        }
+        for (int i = tid; i < HS; i += 512) s_wrow[i] = wrow[i];
+    }
+    __syncthreads();
+    const int el = lane & 15, q = lane >> 4;
+    const float bias256 = a.bias ? a.bias[256] : 0.0f;
+    auto load_x = [&](int t, v4f (&x)[16], float &x256) {
+        const int row = min(t * WSG_TILE + 16 * wave + el, a.rows - 1);
+        const float *xrow = a.X + (size_t)row * a.ldx;
+#pragma unroll
+        for (int nt = 0; nt < 16; ++nt) x[nt] = *reinterpret_cast<const v4f *>(xrow + 16 * nt + 4 * q);
+        x256 = xrow[256];
+    };
+    v4f x[16], xn[16], accp[8];
+    float x256, x256n, out256p = 0.0f;
+    int rowp = -1;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) accp[m] = zero4();
+    load_x(t0, xn, x256n);
+#pragma unroll 1
+    for (int t = t0; t < t1; ++t) {
+        // see k_proj_ws: x is only written by these moves, so the compiler's wait counts the row loads alone and the previous
+        // tile's stores (issued right after) never sit in front of it in the in-order memory counter
+#pragma unroll
+        for (int nt = 0; nt < 16; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) asm volatile("v_mov_b32 %0, %1" : "=v"(x[nt][r]) : "v"(xn[nt][r]));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(x256) : "v"(x256n));
+        __builtin_amdgcn_sched_barrier(0);
+        wsg_store<MODE>(a, rowp, hf, q, accp, out256p);
+        if (t + 1 < t1) load_x(t + 1, xn, x256n);
+        v4f acc[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+            acc[m] = x256 * *reinterpret_cast<const v4f *>(s_wcol + 16 * m + 4 * q) + *reinterpret_cast<const v4f *>(s_bias + 16 * m + 4 * q);
+        float part = 0.0f;
+        if (hf == 0) {
+#pragma unroll
+            for (int nt = 0; nt < 16; ++nt) {
+                const v4f wv = *reinterpret_cast<const v4f *>(s_wrow + 16 * nt + 4 * q);
+                part += x[nt][0] * wv[0] + x[nt][1] * wv[1] + x[nt][2] * wv[2] + x[nt][3] * wv[3];
+            }
+        }
+        const v4f *wp = W + lane;
+        v4f w[2][4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) w[0][m] = wp[m * 64];
+#pragma unroll
+        for (int b = 0; b < 32; ++b) {
+            if (b + 1 < 32) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) w[(b + 1) & 1][m] = wp[(4 * (b + 1) + m) * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const v4f xin = x[b >> 1];
+            const int g = b & 1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[4 * g + m] = mfma16(w[b & 1][m][r], xin[r], acc[4 * g + m]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float out256 = 0.0f;
+        if (hf == 0) {
+            part += __shfl_xor(part, 16);
+            part += __shfl_xor(part, 32);
+            out256 = part + bias256 + x256 * s_wrow[256];
+        }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) accp[m] = acc[m];
+        rowp = t * WSG_TILE + 16 * wave + el;
+        out256p = out256;
+    }
+    wsg_store<MODE>(a, rowp, hf, q, accp, out256p);
+}
+
+}  // namespace
+
+int ws_gemm_pack_floats() { return WSG_PACK_FLOATS; }
+
+// Y = epilogue(X op(W) + b): W [257, 257] with row stride ldw; transpose_w = false: Y = X W^T (W in the torch [out, in]
+// layout), true: Y = X W.  pack_scratch: ws_gemm_pack_floats() floats.
+kpd_status ws_gemm(int mode, const float *X, int rows, int ldx, const float *W, int ldw, bool transpose_w, const float *bias,
+                   const float *P, float *Y, float *A, int ldy, float *pack_scratch, hipStream_t st) {
+    if (rows == 0) return KPD_OK;
+    KPD_REQUIRE(X && W && Y && pack_scratch && (ldx & 3) == 0 && (ldy & 3) == 0 && ldx >= 260 && ldy >= 260, KPD_ERR_INVALID,
+                "ws_gemm: bad operands");
+    KPD_REQUIRE((mode == WS_BIAS_SILU && A) || (mode == WS_SILU_BWD && P), KPD_ERR_INVALID, "ws_gemm: mode %d operands", mode);
+    static bool attr = false;
+    if (!attr) {
+        KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ws_gemm<WS_BIAS_SILU>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    WSG_LDS_BYTES));
+        KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ws_gemm<WS_SILU_BWD>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    WSG_LDS_BYTES));
+        attr = true;
+    }
+    // M[n][k] of "Y = X M^T": transpose_w false -> M = W (sn = ldw, sk = 1); true -> M = W^T (sn = 1, sk = ldw)
+    hipLaunchKernelGGL(k_wsg_pack, dim3(cdiv(WSG_PACK_FLOATS, 256)), dim3(256), 0, st, W, transpose_w ? 1 : ldw, transpose_w ? ldw : 1,
+                       pack_scratch);
+    KPD_LAUNCH_CHECK();
+    WsgArgs a;
+    a.X = X; a.rows = rows; a.ldx = ldx; a.pack = pack_scratch; a.bias = bias; a.P = P; a.Y = Y; a.A = A; a.ldy = ldy; a.mode = mode;
+    const int tiles = cdiv(rows, WSG_TILE);
+    a.tpb = std::max(1, cdiv(2 * tiles, 256));
+    a.bpc = cdiv(tiles, a.tpb);
+    if (mode == WS_BIAS_SILU) hipLaunchKernelGGL(k_ws_gemm<WS_BIAS_SILU>, dim3(2 * a.bpc), dim3(512), WSG_LDS_BYTES, st, a);
+    else hipLaunchKernelGGL(k_ws_gemm<WS_SILU_BWD>, dim3(2 * a.bpc), dim3(512), WSG_LDS_BYTES, st, a);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+}  // namespace kpd
