@@ -814,7 +814,7 @@ kpd_status layer_bwd(kpd_egnn_trainer *T, int l, int cur, int nxt, float *dhn[2]
         KPD_LAUNCH_CHECK();
         KPD_TRY(gemv_t_acc(T, E, H, T->eb[3], LD, T->dsv, p.head.g, 1));
         if (p.head_b.g) {
-            hipLaunchKernelGGL(k_sum_atomic, dim3(std::min(cdiv(E, 256), 256)), dim3(256), 0, T->st, T->dsv, E, p.head_b.g);
+            hipLaunchKernelGGL(k_sum_scalar, dim3(1), dim3(1024), 0, T->st, T->dsv, E, p.head_b.g);
             KPD_LAUNCH_CHECK();
         }
         KPD_TRY(edge_branch_bwd(T, p, l, et, nxt, true));

@@ -65,11 +65,21 @@ __global__ void k_silu_bwd(float *__restrict__ dY, const float *__restrict__ pre
     dY[(size_t)r * ld + c] *= silu_grad(pre[(size_t)r * ld + c]);
 }
 
-__global__ void k_sum_atomic(const float *__restrict__ v, int n, float *__restrict__ out) {
-    float s = 0.0f;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) s += v[i];
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+// out[0] += sum of v[0..n): one workgroup, double accumulation, fixed order (a lone scalar gradient such as the attention
+// bias is a heavily cancelling sum over all edges; float atomics in arbitrary order cost it two to three digits)
+__global__ void k_sum_scalar(const float *__restrict__ v, int n, float *__restrict__ out) {
+    __shared__ double part[16];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += (double)v[i];
+#pragma unroll
+    for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += part[w];
+        out[0] += (float)t;
+    }
 }
 
 __global__ void k_sub_inplace(float *__restrict__ a, const float *__restrict__ b, int n) {

@@ -22,7 +22,7 @@ def _case(cfg, n_rec, n_lig, rec_nf=10, seed=5):
         for n, p in model.named_parameters():
             if n.endswith('.4.weight'):
                 p.mul_(20.0)
-    t = torch.rand(len(n_rec)) * 0.9 + 0.05
+    t = torch.rand(len(n_rec), generator=torch.Generator().manual_seed(seed + 100)) * 0.9 + 0.05
     return g, model, t
 
 
@@ -74,7 +74,12 @@ def test_gradients_match_oracle_autograd(name, cfg, rec_nf):
         if ref is None:                     # no path to the loss (keypoint-side weights of the last layer): exactly zero
             assert float(p.grad.abs().max()) == 0.0, n
             continue
-        err = (p.grad.cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
+        scale = ref.abs().max().item()
+        if ref.numel() == 1 and n.endswith('.bias'):
+            # a lone scalar (attention bias) is a heavily cancelling sum over all edges: both sides carry fp32 noise of the
+            # size of the terms, not of the sum -- it is judged on the scale of its companion weight gradient
+            scale = max(scale, pg_ref[n[:-4] + 'weight'].abs().max().item())
+        err = (p.grad.cpu() - ref).abs().max().item() / max(scale, 1e-12)
         worst.append((err, n))
     worst.sort(reverse=True)
     assert worst[0][0] < TOL, worst[:8]
