@@ -132,4 +132,5 @@ def test_full_batch_gradients_directional_derivative(cuda, arch):
                 params[n].sub_(sign * eps * dirs[n])
     numeric = (vals[0] - vals[1]) / (2 * eps)
     assert all(torch.isfinite(p.grad).all() for p in params.values() if p.grad is not None)
+    print(f'directional derivative {arch}: analytic {analytic:.6g} numeric {numeric:.6g}')
     assert abs(analytic - numeric) <= 3e-2 * max(abs(analytic), abs(numeric), 1e-3), (analytic, numeric)
