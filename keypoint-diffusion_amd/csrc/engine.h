@@ -51,9 +51,10 @@ kpd_status transpose2d(const float *src, int rows, int cols, float *dst, hipStre
 kpd_status copy_col_pad(const float *src, int n, int ld, int col, float *dst, int n_dst, hipStream_t st);
 
 // Weight-stationary tall-skinny GEMM with fused epilogues for the training engines (ws_gemm.hip).
-enum { WS_BIAS_SILU = 0, WS_SILU_BWD = 1 };
+enum { WS_BIAS_SILU = 0, WS_SILU_BWD = 1, WS_PLAIN = 2 };
 int ws_gemm_pack_floats();
 kpd_status ws_gemm(int mode, const float *X, int rows, int ldx, const float *W, int ldw, bool transpose_w, const float *bias,
-                   const float *P, float *Y, float *A, int ldy, float *pack_scratch, hipStream_t st);
+                   const float *P, float *Y, float *A, int ldy, float *pack_scratch, hipStream_t st, bool has257 = true,
+                   bool accumulate = false);
 
 }  // namespace kpd

@@ -335,6 +335,7 @@ struct kpd_gvp_trainer : TrainCtx {
     float *unit = nullptr, *rbf = nullptr, *vin = nullptr, *U = nullptr, *scale = nullptr, *tmp_s = nullptr, *tmp_v = nullptr,
           *s1 = nullptr, *v1 = nullptr, *sb = nullptr, *vb = nullptr;
     float *gs[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}, *gv[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [cur/nxt][nt]
+    float *wsg_pack = nullptr;
     float dropout = 0.0f;
     unsigned long long seed = 0;
 };
@@ -357,6 +358,12 @@ kpd_status gvp_params(kpd_gvp_trainer *T, const std::string &p, int vi, int vo, 
     return KPD_OK;
 }
 
+// the 256 x 256 scalar block of a GVP can take the weight-stationary GEMM (KPD_TRAIN_WS=0: library GEMMs throughout)
+bool ws_ok(const GvpP &g, int ld_s) {
+    static const bool on = !(getenv("KPD_TRAIN_WS") && atoi(getenv("KPD_TRAIN_WS")) == 0);
+    return on && g.si == 256 && g.so == 256 && ld_s == 256;
+}
+
 // GVP.forward (gvp.py:89-116).  s_in == nullptr: B.pre already holds the contribution of the scalar inputs (no bias).
 kpd_status gvp_fwd(kpd_gvp_trainer *T, const GvpP &g, int M, const float *s_in, int ld_s, const float *v_in, const GvpBuf &B,
                    bool identity) {
@@ -365,11 +372,18 @@ kpd_status gvp_fwd(kpd_gvp_trainer *T, const GvpP &g, int M, const float *s_in, 
     KPD_TRY(gemm(T, false, false, 3 * M, g.vo, g.h, B.Vh, g.h, g.Wu.w, g.vo, 0.0f, B.Vu, g.vo));
     hipLaunchKernelGGL(k_gvp_sh, grid1((long long)M * g.h), dim3(256), 0, T->st, B.Vh, (long long)M * g.h, g.h, B.sh);
     KPD_LAUNCH_CHECK();
-    if (s_in) KPD_TRY(gemm(T, false, true, M, g.so, g.si, s_in, ld_s, g.Ws.w, g.si + g.h, 0.0f, B.pre, g.so));
-    KPD_TRY(gemm(T, false, true, M, g.so, g.h, B.sh, g.h, g.Ws.w + g.si, g.si + g.h, 1.0f, B.pre, g.so));
     long long tot = (long long)M * g.so;
-    hipLaunchKernelGGL(k_bias_silu, grid1(tot), dim3(256), 0, T->st, B.pre, g.bs.w, tot, g.so, g.so, B.s);
-    KPD_LAUNCH_CHECK();
+    if (s_in && ws_ok(g, ld_s)) {
+        // the narrow vector-norm block first, then the 256 x 256 scalar block on the weight-stationary GEMM with the partial
+        // pre-activation, the bias and the SiLU fused into its epilogue
+        KPD_TRY(gemm(T, false, true, M, g.so, g.h, B.sh, g.h, g.Ws.w + g.si, g.si + g.h, 0.0f, B.pre, g.so));
+        KPD_TRY(ws_gemm(WS_BIAS_SILU, s_in, M, ld_s, g.Ws.w, g.si + g.h, false, g.bs.w, nullptr, B.pre, B.s, g.so, T->wsg_pack, T->st, false, true));
+    } else {
+        if (s_in) KPD_TRY(gemm(T, false, true, M, g.so, g.si, s_in, ld_s, g.Ws.w, g.si + g.h, 0.0f, B.pre, g.so));
+        KPD_TRY(gemm(T, false, true, M, g.so, g.h, B.sh, g.h, g.Ws.w + g.si, g.si + g.h, 1.0f, B.pre, g.so));
+        hipLaunchKernelGGL(k_bias_silu, grid1(tot), dim3(256), 0, T->st, B.pre, g.bs.w, tot, g.so, g.so, B.s);
+        KPD_LAUNCH_CHECK();
+    }
     KPD_TRY(gemm(T, false, true, M, g.vo, g.so, B.s, g.so, g.Wg.w, g.so, 0.0f, B.gate, g.vo));
     tot = (long long)M * g.vo;
     hipLaunchKernelGGL(k_bias_add, grid1(tot), dim3(256), 0, T->st, B.gate, g.bg.w, tot, g.vo, g.vo);
@@ -396,7 +410,10 @@ kpd_status gvp_bwd(kpd_gvp_trainer *T, const GvpP &g, int M, const float *s_in, 
     KPD_TRY(colsum_acc(T, M, g.so, ds, g.so, g.bs.g));
     if (s_in) {
         if (g.Ws.g) KPD_TRY(grad_gemm(T, g.so, g.si, M, ds, g.so, s_in, ld_s, g.Ws.g, g.si + g.h));
-        if (ds_in) KPD_TRY(gemm(T, false, false, M, g.si, g.so, ds, g.so, g.Ws.w, g.si + g.h, 0.0f, ds_in, g.si));
+        if (ds_in) {
+            if (ws_ok(g, ld_s)) KPD_TRY(ws_gemm(WS_PLAIN, ds, M, g.so, g.Ws.w, g.si + g.h, true, nullptr, nullptr, ds_in, nullptr, g.si, T->wsg_pack, T->st, false, false));
+            else KPD_TRY(gemm(T, false, false, M, g.si, g.so, ds, g.so, g.Ws.w, g.si + g.h, 0.0f, ds_in, g.si));
+        }
     }
     if (g.Ws.g) KPD_TRY(grad_gemm(T, g.so, g.h, M, ds, g.so, B.sh, g.h, g.Ws.g + g.si, g.si + g.h));
     KPD_TRY(gemm(T, false, false, M, g.h, g.so, ds, g.so, g.Ws.w + g.si, g.si + g.h, 0.0f, T->dsh, g.h));
@@ -843,6 +860,7 @@ extern "C" kpd_status kpd_gvp_trainer_reserve(kpd_gvp_trainer *T, int32_t max_B,
         F(T->U, N * S); F(T->scale, N); F(T->tmp_s, N * S); F(T->tmp_v, N * 3 * VC); F(T->s1, N * S); F(T->v1, N * 3 * VC);
         F(T->sb, N * std::max(S, 256)); F(T->vb, N * 3 * VC);
         F(T->part, (size_t)GRAD_SPLIT * 264 * 520);
+        F(T->wsg_pack, (size_t)ws_gemm_pack_floats());
         F(T->ones, 8);
         I(T->meta, 16); I(T->ll_deg, max_n_lig); I(T->ll_off, max_B + 1); I(T->kl_off, max_B + 1); I(T->kl_pg, max_B + 2);
         kpd_lig_graph &g = T->lg;

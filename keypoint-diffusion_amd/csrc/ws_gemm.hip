@@ -9,6 +9,9 @@
 // library GEMM is fused into the epilogue:
 //   WS_BIAS_SILU   : Y = X W^T + b (kept: the pre-activation), A = SiLU(Y)
 //   WS_SILU_BWD    : Y = (X W) * SiLU'(P)            (P: the saved pre-activation of the previous Linear)
+//   WS_PLAIN       : Y = X op(W)
+// `accumulate` adds what Y already holds before the epilogue (a partial pre-activation from another, narrow product);
+// `has257 = false` is the 256-wide form used by the GVP engine (no 257th input / output, rows may be 256 floats apart).
 #include "chain_core.h"
 #include "engine.h"
 
@@ -24,7 +27,7 @@ constexpr int WSG_PACK_FLOATS = 16 * 16 * 64 * 4 + 256 + HS;  // fragments, colu
 __device__ __forceinline__ float wsg_sigm(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // fragments of the 256 x 256 block of M (M[n][k] = src[n * sn + k * sk]) in chain-chunk order, then M[:, 256], then M[256, :]
-__global__ void k_wsg_pack(const float *__restrict__ src, int sn, int sk, float *__restrict__ dst) {
+__global__ void k_wsg_pack(const float *__restrict__ src, int sn, int sk, int has257, float *__restrict__ dst) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < 16 * 16 * 256) {
         const int r = idx & 3, lane = (idx >> 2) & 63, mt = (idx >> 8) & 15, ks = idx >> 12;
@@ -32,10 +35,10 @@ __global__ void k_wsg_pack(const float *__restrict__ src, int sn, int sk, float 
         dst[idx] = src[(size_t)n * sn + (size_t)k * sk];
     } else if (idx < 16 * 16 * 256 + 256) {
         const int n = idx - 16 * 16 * 256;
-        dst[idx] = src[(size_t)n * sn + (size_t)256 * sk];
+        dst[idx] = has257 ? src[(size_t)n * sn + (size_t)256 * sk] : 0.0f;
     } else if (idx < 16 * 16 * 256 + 256 + HS) {
         const int k = idx - 16 * 16 * 256 - 256;
-        dst[idx] = k <= 256 ? src[(size_t)256 * sn + (size_t)k * sk] : 0.0f;
+        dst[idx] = (has257 && k <= 256) ? src[(size_t)256 * sn + (size_t)k * sk] : 0.0f;
     }
 }
 
@@ -46,13 +49,19 @@ struct WsgArgs {
     const float *bias;      // [257] or null
     const float *P;         // [rows, ldy] pre-activation for WS_SILU_BWD, else null
     float *Y, *A;           // [rows, ldy]; A only for WS_BIAS_SILU
-    int ldy, mode, bpc, tpb;
+    int ldy, mode, bpc, tpb, has257, accumulate;
 };
 
 template <int MODE>
-__device__ __forceinline__ void wsg_store(const WsgArgs &a, int row, int hf, int q, const v4f (&acc)[8], float out256) {
+__device__ __forceinline__ void wsg_store(const WsgArgs &a, int row, int hf, int q, v4f (&acc)[8], float out256) {
     if (row < 0 || row >= a.rows) return;
     float *yrow = a.Y + (size_t)row * a.ldy + 128 * hf;
+    const bool tail = a.has257 && hf == 0 && q == 0;
+    if (a.accumulate) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) acc[m] += *reinterpret_cast<const v4f *>(yrow + 16 * m + 4 * q);
+        if (tail) out256 += yrow[256];
+    }
     if (MODE == WS_BIAS_SILU) {
         float *arow = a.A + (size_t)row * a.ldy + 128 * hf;
 #pragma unroll
@@ -64,11 +73,11 @@ __device__ __forceinline__ void wsg_store(const WsgArgs &a, int row, int hf, int
             *reinterpret_cast<v4f *>(yrow + 16 * m + 4 * q) = v;
             *reinterpret_cast<v4f *>(arow + 16 * m + 4 * q) = s;
         }
-        if (hf == 0 && q == 0) {
+        if (tail) {
             yrow[256] = out256;
             arow[256] = out256 * wsg_sigm(out256);
         }
-    } else {
+    } else if (MODE == WS_SILU_BWD) {
         const float *prow = a.P + (size_t)row * a.ldy + 128 * hf;
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
@@ -81,10 +90,14 @@ __device__ __forceinline__ void wsg_store(const WsgArgs &a, int row, int hf, int
             }
             *reinterpret_cast<v4f *>(yrow + 16 * m + 4 * q) = v;
         }
-        if (hf == 0 && q == 0) {
+        if (tail) {
             const float p = prow[256], sg = wsg_sigm(p);
             yrow[256] = out256 * sg * (1.0f + p * (1.0f - sg));
         }
+    } else {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) *reinterpret_cast<v4f *>(yrow + 16 * m + 4 * q) = acc[m];
+        if (tail) yrow[256] = out256;
     }
 }
 
@@ -114,13 +127,13 @@ __global__ __launch_bounds__(512, 1) void k_ws_gemm(WsgArgs a) {
     }
     __syncthreads();
     const int el = lane & 15, q = lane >> 4;
-    const float bias256 = a.bias ? a.bias[256] : 0.0f;
+    const float bias256 = (a.bias && a.has257) ? a.bias[256] : 0.0f;
     auto load_x = [&](int t, v4f (&x)[16], float &x256) {
         const int row = min(t * WSG_TILE + 16 * wave + el, a.rows - 1);
         const float *xrow = a.X + (size_t)row * a.ldx;
 #pragma unroll
         for (int nt = 0; nt < 16; ++nt) x[nt] = *reinterpret_cast<const v4f *>(xrow + 16 * nt + 4 * q);
-        x256 = xrow[256];
+        x256 = a.has257 ? xrow[256] : 0.0f;
     };
     v4f x[16], xn[16], accp[8];
     float x256, x256n, out256p = 0.0f;
@@ -145,7 +158,7 @@ __global__ __launch_bounds__(512, 1) void k_ws_gemm(WsgArgs a) {
         for (int m = 0; m < 8; ++m)
             acc[m] = x256 * *reinterpret_cast<const v4f *>(s_wcol + 16 * m + 4 * q) + *reinterpret_cast<const v4f *>(s_bias + 16 * m + 4 * q);
         float part = 0.0f;
-        if (hf == 0) {
+        if (hf == 0 && a.has257) {
 #pragma unroll
             for (int nt = 0; nt < 16; ++nt) {
                 const v4f wv = *reinterpret_cast<const v4f *>(s_wrow + 16 * nt + 4 * q);
@@ -172,7 +185,7 @@ __global__ __launch_bounds__(512, 1) void k_ws_gemm(WsgArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
         float out256 = 0.0f;
-        if (hf == 0) {
+        if (hf == 0 && a.has257) {
             part += __shfl_xor(part, 16);
             part += __shfl_xor(part, 32);
             out256 = part + bias256 + x256 * s_wrow[256];
@@ -189,33 +202,39 @@ __global__ __launch_bounds__(512, 1) void k_ws_gemm(WsgArgs a) {
 
 int ws_gemm_pack_floats() { return WSG_PACK_FLOATS; }
 
-// Y = epilogue(X op(W) + b): W [257, 257] with row stride ldw; transpose_w = false: Y = X W^T (W in the torch [out, in]
-// layout), true: Y = X W.  pack_scratch: ws_gemm_pack_floats() floats.
+// Y = epilogue(X op(W) + b): W with row stride ldw; transpose_w = false: Y = X W^T (W in the torch [out, in] layout), true:
+// Y = X W.  has257: 257 x 257 problem (else 256 x 256).  pack_scratch: ws_gemm_pack_floats() floats.
 kpd_status ws_gemm(int mode, const float *X, int rows, int ldx, const float *W, int ldw, bool transpose_w, const float *bias,
-                   const float *P, float *Y, float *A, int ldy, float *pack_scratch, hipStream_t st) {
+                   const float *P, float *Y, float *A, int ldy, float *pack_scratch, hipStream_t st, bool has257, bool accumulate) {
     if (rows == 0) return KPD_OK;
-    KPD_REQUIRE(X && W && Y && pack_scratch && (ldx & 3) == 0 && (ldy & 3) == 0 && ldx >= 260 && ldy >= 260, KPD_ERR_INVALID,
+    const int need = has257 ? 260 : 256;
+    KPD_REQUIRE(X && W && Y && pack_scratch && (ldx & 3) == 0 && (ldy & 3) == 0 && ldx >= need && ldy >= need, KPD_ERR_INVALID,
                 "ws_gemm: bad operands");
-    KPD_REQUIRE((mode == WS_BIAS_SILU && A) || (mode == WS_SILU_BWD && P), KPD_ERR_INVALID, "ws_gemm: mode %d operands", mode);
+    KPD_REQUIRE((mode == WS_BIAS_SILU && A) || (mode == WS_SILU_BWD && P) || mode == WS_PLAIN, KPD_ERR_INVALID, "ws_gemm: mode %d operands",
+                mode);
     static bool attr = false;
     if (!attr) {
         KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ws_gemm<WS_BIAS_SILU>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     WSG_LDS_BYTES));
         KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ws_gemm<WS_SILU_BWD>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     WSG_LDS_BYTES));
+        KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ws_gemm<WS_PLAIN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    WSG_LDS_BYTES));
         attr = true;
     }
     // M[n][k] of "Y = X M^T": transpose_w false -> M = W (sn = ldw, sk = 1); true -> M = W^T (sn = 1, sk = ldw)
     hipLaunchKernelGGL(k_wsg_pack, dim3(cdiv(WSG_PACK_FLOATS, 256)), dim3(256), 0, st, W, transpose_w ? 1 : ldw, transpose_w ? ldw : 1,
-                       pack_scratch);
+                       has257 ? 1 : 0, pack_scratch);
     KPD_LAUNCH_CHECK();
     WsgArgs a;
     a.X = X; a.rows = rows; a.ldx = ldx; a.pack = pack_scratch; a.bias = bias; a.P = P; a.Y = Y; a.A = A; a.ldy = ldy; a.mode = mode;
+    a.has257 = has257 ? 1 : 0; a.accumulate = accumulate ? 1 : 0;
     const int tiles = cdiv(rows, WSG_TILE);
     a.tpb = std::max(1, cdiv(2 * tiles, 256));
     a.bpc = cdiv(tiles, a.tpb);
     if (mode == WS_BIAS_SILU) hipLaunchKernelGGL(k_ws_gemm<WS_BIAS_SILU>, dim3(2 * a.bpc), dim3(512), WSG_LDS_BYTES, st, a);
-    else hipLaunchKernelGGL(k_ws_gemm<WS_SILU_BWD>, dim3(2 * a.bpc), dim3(512), WSG_LDS_BYTES, st, a);
+    else if (mode == WS_SILU_BWD) hipLaunchKernelGGL(k_ws_gemm<WS_SILU_BWD>, dim3(2 * a.bpc), dim3(512), WSG_LDS_BYTES, st, a);
+    else hipLaunchKernelGGL(k_ws_gemm<WS_PLAIN>, dim3(2 * a.bpc), dim3(512), WSG_LDS_BYTES, st, a);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
 }
