@@ -134,3 +134,47 @@ def test_full_batch_gradients_directional_derivative(cuda, arch):
     assert all(torch.isfinite(p.grad).all() for p in params.values() if p.grad is not None)
     print(f'directional derivative {arch}: analytic {analytic:.6g} numeric {numeric:.6g}')
     assert abs(analytic - numeric) <= 3e-2 * max(abs(analytic), abs(numeric), 1e-3), (analytic, numeric)
+
+
+@pytest.mark.parametrize('arch', ['egnn', 'gvp'])
+def test_permutation_equivariance_over_atoms(cuda, arch):
+    """Relabelling the ligand atoms and the keypoints inside every complex permutes the predicted noise and nothing else
+    (a property the architecture guarantees; it crosses the graph builders, whose edge order changes)."""
+    B = 6
+    n_rec, n_lig = [120, 77, 150, 64, 99, 131], [12, 25, 7, 18, 9, 30]
+    gs = synth.synth_complexes(n_rec, n_lig, 20, CUT, seed=77)
+    g = util.fixed_encode(G.batch(gs), n_vec=16 if arch == 'gvp' else None)
+    if arch == 'egnn':
+        model = synth.fill_state_dict_(LigRecDynamics(10, 10, graph_cutoffs=CUT, **dict(util.EGNN_C2, n_layers=3)), 1)
+    else:
+        model = synth.fill_state_dict_(LigRecDynamicsGVP(10, 10, graph_cutoffs=CUT, **dict(GVP_ALL_ATOM, n_convs=3)), 1)
+        g.nodes['kp'].data['v_0'] = 0.3 * torch.randn(g.num_nodes('kp'), 16, 3, generator=torch.Generator().manual_seed(5))
+    model = model.eval().to(cuda)
+    t = torch.linspace(0.1, 0.9, B)
+    gen = torch.Generator().manual_seed(9)
+
+    def perm_of(counts):
+        parts, off = [], 0
+        for n in counts:
+            parts.append(off + torch.randperm(n, generator=gen))
+            off += n
+        return torch.cat(parts)
+
+    pl, pk = perm_of(n_lig), perm_of(n_rec)
+    inv_k = torch.empty_like(pk)
+    inv_k[pk] = torch.arange(pk.numel())
+    g2 = util.fixed_encode(G.batch(synth.synth_complexes(n_rec, n_lig, 20, CUT, seed=77)), n_vec=16 if arch == 'gvp' else None)
+    for key in ('x_0', 'h_0'):
+        g2.nodes['lig'].data[key] = g.nodes['lig'].data[key][pl]
+        g2.nodes['kp'].data[key] = g.nodes['kp'].data[key][pk]
+    if arch == 'gvp':
+        g2.nodes['kp'].data['v_0'] = g.nodes['kp'].data['v_0'][pk]
+    s, d = g.edges(etype='kk')
+    g2.remove_edges(torch.arange(g2.num_edges('kk')), etype='kk')
+    g2.add_edges(inv_k[s], inv_k[d], etype='kk')                 # the same keypoint graph under the new labels
+    g2.set_batch_num_edges({'kk': g.batch_num_edges('kk')})
+    with torch.no_grad():
+        eh, ex = model(g.to(cuda), t.to(cuda), None)
+        eh2, ex2 = model(g2.to(cuda), t.to(cuda), None)
+    assert util.rel_err(eh2.cpu(), eh.cpu()[pl]) < 2e-5, util.rel_err(eh2.cpu(), eh.cpu()[pl])
+    assert util.rel_err(ex2.cpu(), ex.cpu()[pl]) < 2e-5, util.rel_err(ex2.cpu(), ex.cpu()[pl])
