@@ -705,7 +705,7 @@ __global__ __launch_bounds__(256, 3) void k_node_layer(NodeLayerPair p) {
 }
 
 // ---- node update with 8 waves per 32-node tile (update only; the projections run in k_proj_chain) -----------------------
-__global__ __launch_bounds__(512, 3) void k_node_update8(NodeLayerPair p) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_node_update8(NodeLayerPair p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *A = smem;
     float *s_z = smem + TN * SA;

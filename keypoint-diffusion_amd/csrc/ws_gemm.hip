@@ -230,8 +230,11 @@ kpd_status ws_gemm(int mode, const float *X, int rows, int ldx, const float *W, 
     a.X = X; a.rows = rows; a.ldx = ldx; a.pack = pack_scratch; a.bias = bias; a.P = P; a.Y = Y; a.A = A; a.ldy = ldy; a.mode = mode;
     a.has257 = has257 ? 1 : 0; a.accumulate = accumulate ? 1 : 0;
     const int tiles = cdiv(rows, WSG_TILE);
-    a.tpb = std::max(1, cdiv(2 * tiles, 256));
-    a.bpc = cdiv(tiles, a.tpb);
+    // one workgroup per CU, one round (see launch_proj_chain): 2 * bpc <= 256
+    for (a.tpb = std::max(1, cdiv(2 * tiles, 256));; ++a.tpb) {
+        a.bpc = cdiv(tiles, a.tpb);
+        if (2 * a.bpc <= 256 || a.tpb >= tiles) break;
+    }
     if (mode == WS_BIAS_SILU) hipLaunchKernelGGL(k_ws_gemm<WS_BIAS_SILU>, dim3(2 * a.bpc), dim3(512), WSG_LDS_BYTES, st, a);
     else if (mode == WS_SILU_BWD) hipLaunchKernelGGL(k_ws_gemm<WS_SILU_BWD>, dim3(2 * a.bpc), dim3(512), WSG_LDS_BYTES, st, a);
     else hipLaunchKernelGGL(k_ws_gemm<WS_PLAIN>, dim3(2 * a.bpc), dim3(512), WSG_LDS_BYTES, st, a);
