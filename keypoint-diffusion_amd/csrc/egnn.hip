@@ -73,6 +73,7 @@ struct kpd_egnn {
     std::set<std::string> expected, loaded;
     bool committed = false;
     int debug_layers = -1;
+    int prune_last = 1;                        // final layer: only what feeds (h_lig, x_lig) is computed ("prune=0" restores all)
     int edge_chain = -1;                       // 1: register-chained edge kernel (egnn_chain.hip); -1: KPD_EDGE_CHAIN or staged
     // optional HIP-event timing of the dominant kernel (k_egnn_edge), for bench.py's roofline
     unsigned long long *stamps = nullptr;      // device [16], diagnostics (kpd_egnn_debug_state "stamps=1")
@@ -393,7 +394,7 @@ extern "C" kpd_status kpd_egnn_reserve(kpd_egnn *m, int32_t max_B, int32_t max_n
         add((size_t)n[kDstNt[et]] * HS, 4); add((size_t)tiles[et] * HS, 4);
         add((size_t)n[kDstNt[et]] * 4, 4); add((size_t)tiles[et] * 4, 4);
     }
-    add(16, 4); add(max_n_lig, 4); add(max_B + 1, 4); add(max_B + 1, 4); add(max_B + 2, 4);
+    add(32, 4); add(max_n_lig, 4); add(max_B + 1, 4); add(max_B + 1, 4); add(max_B + 2, 4);
     add(cap_ll, 4); add(cap_ll, 4); add(max_n_lig + 1, 4);
     for (int i = 0; i < 4; ++i) add(cap_kl, 4);
     add(max_n_lig + 1, 4); add(max_n_kp + 1, 4); add(max_B, 4); add(8, 4);
@@ -413,7 +414,7 @@ extern "C" kpd_status kpd_egnn_reserve(kpd_egnn *m, int32_t max_B, int32_t max_n
         m->xn_cont[et] = W.take<float>((size_t)tiles[et] * 4);
         m->tiles_et_cap[et] = tiles[et];
     }
-    m->meta = W.take<int>(16);
+    m->meta = W.take<int>(32);                 // [0..8] all active edge types, [16..24] the final layer's subset
     m->ll_deg = W.take<int>(max_n_lig);
     m->ll_off = W.take<int>(max_B + 1);
     m->kl_off = W.take<int>(max_B + 1);
@@ -452,9 +453,16 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
     KPD_TRY(launch_node_graph_index(bt->lig_ptr, bt->B, bt->n_lig, m->bidx[NT_LIG], st));
     KPD_TRY(launch_node_graph_index(bt->kp_ptr, bt->B, bt->n_kp, m->bidx[NT_KP], st));
     KPD_TRY(launch_lig_graph(bt, c.ll_cutoff, c.ll_k, c.kl_cutoff, c.kl_k, &m->lg, m->ll_deg, m->ll_off, m->kl_off, m->kl_pg, st));
+    // LigRecEGNN.forward returns only (h_lig, x_lig) (dynamics.py:288-294): in the final layer the lk / kk messages and
+    // the keypoint update feed nothing, so that layer runs the ll + kl edge types and the ligand update only (the GVP
+    // reference drops those edge types itself, dynamics_gvp.py:67-72).  A consumer of the h_kp / x_kp debug taps asks for
+    // the full layer with "prune=0".
     const int active = c.update_kp_feat ? 0xF : 0x3;
-    KPD_TRY(launch_egnn_meta(m->lg.counts, bt->n_kk, active, bt->lig_ptr, bt->kp_ptr, m->lg.ll_per_graph, bt->kk_rowptr,
-                             bt->B, m->kl_off, c.message_norm, c.update_kp_feat, m->meta, m->z[NT_LIG], m->z[NT_KP], st));
+    const bool prune = c.update_kp_feat && m->prune_last;
+    const int active_last = prune ? 0x3 : active;
+    KPD_TRY(launch_egnn_meta(m->lg.counts, bt->n_kk, active, active_last, bt->lig_ptr, bt->kp_ptr, m->lg.ll_per_graph,
+                             bt->kk_rowptr, bt->B, m->kl_off, c.message_norm, c.update_kp_feat, m->meta, m->z[NT_LIG],
+                             m->z[NT_KP], st));
     KPD_TRY(launch_embed(bt->lig_h, bt->n_lig, c.atom_nf, m->le_W0, m->le_b0, 64, m->le_W1t, m->le_b1, t_dev,
                          m->bidx[NT_LIG], m->h[NT_LIG], 0, st));
     KPD_TRY(launch_embed(bt->kp_h, bt->n_kp, c.rec_nf, m->re_W0, m->re_b0, 2 * c.rec_nf, m->re_W1t, m->re_b1, t_dev,
@@ -464,8 +472,11 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
     const int e_kl_cap = bt->n_kp * (c.kl_k > 0 ? c.kl_k : std::min(bt->max_lig, 100));
     const int E_cap[4] = {std::max<int>((long)bt->n_lig * std::min(bt->max_lig - 1, c.ll_k > 0 ? c.ll_k : 200), 1), e_kl_cap, e_kl_cap,
                           bt->n_kk};
-    int tile_cap = 0;
-    for (int et = 0; et < m->n_et; ++et) tile_cap += cdiv(E_cap[et], TM);
+    int tile_cap = 0, tile_cap_last = 0;
+    for (int et = 0; et < m->n_et; ++et) {
+        tile_cap += cdiv(E_cap[et], TM);
+        if ((active_last >> et) & 1) tile_cap_last += cdiv(E_cap[et], TM);
+    }
 
     const int n[2] = {bt->n_lig, bt->n_kp};
     const int *esrc[4] = {m->lg.ll_src, m->lg.kl_src, m->lg.lk_src, bt->kk_src};
@@ -473,13 +484,26 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
     const int *rowptr[4] = {m->lg.ll_rowptr, m->lg.kl_rowptr, m->lg.lk_rowptr, bt->kk_rowptr};
     const int n_layers = m->debug_layers >= 0 ? std::min(m->debug_layers, c.n_layers) : c.n_layers;
 
-    // fills the projection part of a fused node launch with the first-layer weights of layer `lw`
-    auto fill_proj = [&](NodeLayerArgs &na, int nt, const LayerW &W) {
+    // projection slots a layer needs = the (edge, coord) slot pairs of the endpoints of its active edge types
+    auto slot_mask = [&](int etmask, int nt) {
+        int mk = 0;
+        for (int et = 0; et < 4; ++et)
+            if ((etmask >> et) & 1) {
+                if (kSrcNt[et] == nt) mk |= 3 << kSrcSlot[et];
+                if (kDstNt[et] == nt) mk |= 3 << kDstSlot[et];
+            }
+        return mk;
+    };
+    auto layer_etmask = [&](int li) { return li == n_layers - 1 ? active_last : active; };
+    // fills the projection part of a fused node launch with the first-layer weights of layer `li`
+    auto fill_proj = [&](NodeLayerArgs &na, int nt, int li) {
+        const LayerW &W = m->L[li];
+        const int mk = slot_mask(layer_etmask(li), nt);
         na.do_proj = 1;
         na.P = m->P[nt];
         int k = 0;
         for (int s = 0; s < NSLOT; ++s)
-            if (W.wp_p[nt][s]) {
+            if (W.wp_p[nt][s] && ((mk >> s) & 1)) {
                 na.wp[k] = W.wp_p[nt][s]; na.wx[k] = W.wx_p[nt][s]; na.bias[k] = W.b_p[nt][s]; na.slot[k] = s;
                 ++k;
             }
@@ -504,7 +528,7 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
                 memset(&lp, 0, sizeof(lp));
                 for (int nt = 0; nt < 2; ++nt) {
                     lp.nt[nt].u.n = n[nt]; lp.nt[nt].u.h = m->h[nt];
-                    fill_proj(lp.nt[nt], nt, L);
+                    fill_proj(lp.nt[nt], nt, li);
                 }
                 lp.tiles0 = cdiv(n[0], TN);
                 KPD_TRY(launch_node_layer(lp, st));
@@ -515,8 +539,9 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
                     ProjArgs &pa = pp.nt[nt];
                     pa.h = m->h[nt]; pa.n = n[nt]; pa.P = m->P[nt];
                     int k = 0;
+                    const int mk = slot_mask(layer_etmask(li), nt);
                     for (int s = 0; s < NSLOT; ++s)
-                        if (L.wp_p[nt][s]) {
+                        if (L.wp_p[nt][s] && ((mk >> s) & 1)) {
                             pa.wp[k] = L.wp_p[nt][s]; pa.wx[k] = L.wx_p[nt][s]; pa.bias[k] = L.b_p[nt][s]; pa.slot[k] = s;
                             pa.chain[k] = L.ch_p[nt][s]; pa.wcol[k] = L.wcol_p[nt][s];
                             ++k;
@@ -529,7 +554,8 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
         }
         EdgeArgs ea;
         memset(&ea, 0, sizeof(ea));
-        ea.meta = m->meta;
+        const bool last = li == n_layers - 1;
+        ea.meta = last ? m->meta + 16 : m->meta;
         ea.x[0] = m->x[0]; ea.x[1] = m->x[1]; ea.P[0] = m->P[0]; ea.P[1] = m->P[1];
         ea.use_tanh = c.use_tanh; ea.coords_range = c.coords_range;
         ea.stamps = m->stamps;
@@ -547,8 +573,8 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
         const bool prof = m->prof_on && m->prof_used + 2 <= m->prof_ev.size();
         if (prof) KPD_HIP(hipEventRecord(m->prof_ev[m->prof_used], st));
         static const bool chain_env = getenv("KPD_EDGE_CHAIN") && atoi(getenv("KPD_EDGE_CHAIN")) != 0;
-        if (m->edge_chain >= 0 ? m->edge_chain != 0 : chain_env) KPD_TRY(launch_egnn_chain(ea, tile_cap, st));
-        else KPD_TRY(launch_egnn_edge(ea, tile_cap, st));
+        if (m->edge_chain >= 0 ? m->edge_chain != 0 : chain_env) KPD_TRY(launch_egnn_chain(ea, last ? tile_cap_last : tile_cap, st));
+        else KPD_TRY(launch_egnn_edge(ea, last ? tile_cap_last : tile_cap, st));
         if (prof) {
             KPD_HIP(hipEventRecord(m->prof_ev[m->prof_used + 1], st));
             m->prof_used += 2;
@@ -557,7 +583,7 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
             na.n = n[nt]; na.h = m->h[nt]; na.x = m->x[nt]; na.bidx = m->bidx[nt]; na.z = m->z[nt];
             int k = 0;
             for (int et = 0; et < m->n_et; ++et)
-                if (kDstNt[et] == nt) {
+                if (kDstNt[et] == nt && ((layer_etmask(li) >> et) & 1)) {
                     na.rowptr[k] = rowptr[et];
                     na.hn_main[k] = m->hn_main[et]; na.hn_cont[k] = m->hn_cont[et];
                     na.xn_main[k] = m->xn_main[et]; na.xn_cont[k] = m->xn_cont[et];
@@ -575,11 +601,11 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
             for (int nt = 0; nt < 2; ++nt) {
                 NodeLayerArgs &na = lp.nt[nt];
                 na.u.n = n[nt]; na.u.h = m->h[nt];
-                if (nt < m->n_upd) {
+                if (nt < m->n_upd && !(nt == NT_KP && last && prune)) {
                     fill_update(na.u, nt);
                     na.do_update = 1;
                 }
-                if (more) fill_proj(na, nt, m->L[li + 1]);
+                if (more) fill_proj(na, nt, li + 1);
                 if (!na.do_update && !na.do_proj) na.u.n = 0;          // nothing to do for this node type
             }
             lp.tiles0 = cdiv(lp.nt[0].u.n, TN);
@@ -605,6 +631,9 @@ extern "C" kpd_status kpd_egnn_debug_state(kpd_egnn *m, const char *what, float 
     else if (w == "z_kp") src = m->z[1];
     else if (w.rfind("layers=", 0) == 0) {
         m->debug_layers = atoi(w.c_str() + 7);
+        return KPD_OK;
+    } else if (w.rfind("prune=", 0) == 0) {        // A/B switch of the final-layer pruning (tests: bit-identical eps)
+        m->prune_last = atoi(w.c_str() + 6);
         return KPD_OK;
     } else if (w.rfind("edge_chain=", 0) == 0) {   // A/B switch between the two edge kernels (tests, profiles/tools)
         m->edge_chain = atoi(w.c_str() + 11);
@@ -651,12 +680,14 @@ extern "C" kpd_status kpd_egnn_profile_read(kpd_egnn *m, double *total_ms, int32
 extern "C" kpd_status kpd_egnn_last_counts(kpd_egnn *m, int32_t out[8], void *stream) {
     KPD_REQUIRE(m && out && m->ws.base, KPD_ERR_INVALID, "null argument or no workspace");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    int host[9];
+    int host[25];
     KPD_HIP(hipMemcpyAsync(host, m->meta, sizeof(host), hipMemcpyDeviceToHost, st));
     KPD_HIP(hipStreamSynchronize(st));
     for (int i = 0; i < 4; ++i) out[i] = host[i];
     out[4] = host[8];
-    out[5] = out[6] = out[7] = 0;
+    out[5] = host[16 + 8];                                           // tiles of the final layer's edge launch
+    out[6] = host[16] + host[17] + host[18] + host[19];              // edges of the final layer's edge launch
+    out[7] = 0;
     return KPD_OK;
 }
 

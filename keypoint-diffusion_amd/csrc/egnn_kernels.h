@@ -91,7 +91,7 @@ constexpr int NODE_LAYER_LDS_BYTES = TN * SA * 4 + 3 * TN * 4;
 
 kpd_status egnn_kernels_init();
 kpd_status launch_node_graph_index(const int *ptr, int B, int n, int *bidx, hipStream_t st);
-kpd_status launch_egnn_meta(const int *counts, int e_kk, int active_mask, const int *lig_ptr, const int *kp_ptr,
+kpd_status launch_egnn_meta(const int *counts, int e_kk, int active_mask, int active_last, const int *lig_ptr, const int *kp_ptr,
                             const int *ll_per_graph, const int *kk_rowptr, int B, const int *kl_off, float message_norm,
                             int update_kp, int *meta, float *z_lig, float *z_kp, hipStream_t st);
 kpd_status launch_embed(const float *in, int n, int fin, const float *W0, const float *b0, int hid, const float *W1t,

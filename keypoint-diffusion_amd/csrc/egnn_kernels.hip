@@ -34,22 +34,26 @@ __global__ void k_node_graph_index(const int *__restrict__ ptr, int B, int n, in
     bidx[i] = lo;
 }
 
-// meta layout: [0..3] E per etype (ll, kl, lk, kk), [4..8] first tile of each etype (+total).
-// z: per-graph message normaliser (dynamics.py:277-285).
-__global__ void k_egnn_meta(const int *__restrict__ counts, int e_kk, int active_mask, const int *__restrict__ lig_ptr,
+// meta layout: [0..3] E per etype (ll, kl, lk, kk), [4..8] first tile of each etype (+total); the same nine
+// entries at [16..24] for the final layer's edge-type subset (active_last).
+// z: per-graph message normaliser (dynamics.py:277-285) -- always over ALL active edge types: the pruned
+// final layer drops messages nobody reads, not terms of a sum somebody does.
+__global__ void k_egnn_meta(const int *__restrict__ counts, int e_kk, int active_mask, int active_last, const int *__restrict__ lig_ptr,
                             const int *__restrict__ kp_ptr, const int *__restrict__ ll_per_graph,
                             const int *__restrict__ kk_rowptr, int B, const int *__restrict__ kl_off, float message_norm,
                             int update_kp, int *__restrict__ meta, float *__restrict__ z_lig, float *__restrict__ z_kp) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (blockIdx.x == 0 && threadIdx.x < 2) {
+        const int mask = threadIdx.x ? active_last : active_mask;
+        int *mt = meta + 16 * threadIdx.x;
         int E[4] = {counts[0], counts[1], counts[1], e_kk};
         int run = 0;
         for (int et = 0; et < 4; ++et) {
-            if (!((active_mask >> et) & 1)) E[et] = 0;
-            meta[et] = E[et];
-            meta[4 + et] = run;
+            if (!((mask >> et) & 1)) E[et] = 0;
+            mt[et] = E[et];
+            mt[4 + et] = run;
             run += (E[et] + TM - 1) / TM;
         }
-        meta[8] = run;
+        mt[8] = run;
     }
     for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
         const int nl = lig_ptr[b + 1] - lig_ptr[b], nk = kp_ptr[b + 1] - kp_ptr[b];
@@ -930,10 +934,10 @@ kpd_status launch_node_graph_index(const int *ptr, int B, int n, int *bidx, hipS
     return KPD_OK;
 }
 
-kpd_status launch_egnn_meta(const int *counts, int e_kk, int active_mask, const int *lig_ptr, const int *kp_ptr,
+kpd_status launch_egnn_meta(const int *counts, int e_kk, int active_mask, int active_last, const int *lig_ptr, const int *kp_ptr,
                             const int *ll_per_graph, const int *kk_rowptr, int B, const int *kl_off, float message_norm,
                             int update_kp, int *meta, float *z_lig, float *z_kp, hipStream_t st) {
-    hipLaunchKernelGGL(k_egnn_meta, dim3(cdiv(B, 256)), dim3(256), 0, st, counts, e_kk, active_mask, lig_ptr, kp_ptr,
+    hipLaunchKernelGGL(k_egnn_meta, dim3(cdiv(B, 256)), dim3(256), 0, st, counts, e_kk, active_mask, active_last, lig_ptr, kp_ptr,
                        ll_per_graph, kk_rowptr, B, kl_off, message_norm, update_kp, meta, z_lig, z_kp);
     KPD_LAUNCH_CHECK();
     return KPD_OK;

@@ -367,14 +367,20 @@ kpd_status geom_fwd(kpd_egnn_trainer *T, int et, const float *xs, const float *x
     return KPD_OK;
 }
 
+// LigRecEGNN.forward returns (h_lig, x_lig) only (dynamics.py:288-294): the final layer's lk / kk messages and its keypoint
+// update feed nothing and their gradients are exactly zero, so that layer runs (forward and backward) on ll + kl and the
+// ligand update alone -- the same pruning as the inference engine (egnn.hip).
+inline int layer_n_et(const kpd_egnn_trainer *T, int l) { return l == T->cfg.n_layers - 1 ? 2 : T->n_et; }
+inline int layer_n_upd(const kpd_egnn_trainer *T, int l) { return l == T->cfg.n_layers - 1 ? 1 : T->n_upd; }
+
 // one LigRecConv layer forward (dynamics.py:124-207) from the saved inputs hs[l], xs[l] into hs[l+1], xs[l+1], hns[l], xns[l]
 kpd_status layer_fwd(kpd_egnn_trainer *T, int l) {
     const kpd_egnn_config &c = T->cfg;
-    for (int k = 0; k < T->n_upd; ++k) {
+    for (int k = 0; k < layer_n_upd(T, l); ++k) {
         KPD_HIP(hipMemsetAsync(T->hns[k][l], 0, (size_t)T->n[k] * LD * 4, T->st));
         KPD_HIP(hipMemsetAsync(T->xns[k][l], 0, (size_t)T->n[k] * 12, T->st));
     }
-    for (int et = 0; et < T->n_et; ++et) {
+    for (int et = 0; et < layer_n_et(T, l); ++et) {
         const int E = T->E[et], s = kS[et], d = kD[et];
         if (E == 0) continue;
         KPD_TRY(geom_fwd(T, et, T->xs[s][l], T->xs[d][l]));
@@ -435,6 +441,7 @@ kpd_status nodes_fwd(kpd_egnn_trainer *T, int l) {
             T->xs[nt][l + 1] = T->xs[nt][0];
             continue;
         }
+        if (nt >= layer_n_upd(T, l)) continue;       // final layer: the keypoint output is never read
         NodeParams p;
         KPD_TRY(node_params(T, l, nt, &p));
         KPD_TRY(node_mlp_fwd(T, p, l, nt));
@@ -586,7 +593,7 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
     add((size_t)cap_E * 3, 4);                                    // msgx
     for (int k = 0; k < 5; ++k) add(cap_E, 4);                   // dij, att, sc, dsv, ddij
     add(std::max(cap_E, cap_N), 4);                               // ones
-    add(16, 4); add(max_n_lig, 4); add(max_B + 1, 4); add(max_B + 1, 4); add(max_B + 2, 4);
+    add(32, 4); add(max_n_lig, 4); add(max_B + 1, 4); add(max_B + 1, 4); add(max_B + 2, 4);
     add(cap_ll, 4); add(cap_ll, 4); add(max_n_lig + 1, 4);
     for (int i = 0; i < 4; ++i) add(cap_kl, 4);
     add(max_n_lig + 1, 4); add(max_n_kp + 1, 4); add(max_B, 4); add(8, 4);
@@ -619,7 +626,7 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
     T->ddij = W.take<float>(cap_E);
     const int n_ones = std::max(cap_E, cap_N);
     T->ones = W.take<float>(n_ones);
-    T->meta = W.take<int>(16);
+    T->meta = W.take<int>(32);
     T->ll_deg = W.take<int>(max_n_lig);
     T->ll_off = W.take<int>(max_B + 1);
     T->kl_off = W.take<int>(max_B + 1);
@@ -687,7 +694,7 @@ extern "C" kpd_status kpd_egnn_trainer_forward(kpd_egnn_trainer *T, const kpd_ba
     KPD_TRY(launch_node_graph_index(bt->kp_ptr, bt->B, bt->n_kp, T->bidx[1], st));
     KPD_TRY(launch_lig_graph(bt, c.ll_cutoff, c.ll_k, c.kl_cutoff, c.kl_k, &T->lg, T->ll_deg, T->ll_off, T->kl_off, T->kl_pg, st));
     const int active = c.update_kp_feat ? 0xF : 0x3;
-    KPD_TRY(launch_egnn_meta(T->lg.counts, bt->n_kk, active, bt->lig_ptr, bt->kp_ptr, T->lg.ll_per_graph, bt->kk_rowptr, bt->B, T->kl_off,
+    KPD_TRY(launch_egnn_meta(T->lg.counts, bt->n_kk, active, active, bt->lig_ptr, bt->kp_ptr, T->lg.ll_per_graph, bt->kk_rowptr, bt->B, T->kl_off,
                              c.message_norm, c.update_kp_feat, T->meta, T->z[0], T->z[1], st));
     // edge counts drive GEMM shapes: one read-back per training step
     int counts[2];
@@ -797,8 +804,9 @@ kpd_status edge_branch_bwd(kpd_egnn_trainer *T, const BranchParams &p, int l, in
 
 kpd_status layer_bwd(kpd_egnn_trainer *T, int l, int cur, int nxt, float *dhn[2]) {
     const kpd_egnn_config &c = T->cfg;
-    for (int nt = 0; nt < T->n_upd; ++nt) KPD_TRY(node_bwd(T, l, nt, cur, nxt, dhn[nt]));
-    for (int et = 0; et < T->n_et; ++et) {
+    // (final layer, keypoints: dh_out = dx_out = 0, so dh_in / dx_in start from the zeros the caller left in dh[nxt] / dx[nxt])
+    for (int nt = 0; nt < layer_n_upd(T, l); ++nt) KPD_TRY(node_bwd(T, l, nt, cur, nxt, dhn[nt]));
+    for (int et = 0; et < layer_n_et(T, l); ++et) {
         const int E = T->E[et], s = kS[et], d = kD[et];
         if (E == 0) continue;
         KPD_TRY(geom_fwd(T, et, T->xs[s][l], T->xs[d][l]));

@@ -249,7 +249,7 @@ extern "C" kpd_status kpd_gvp_reserve(kpd_gvp *m, int32_t max_B, int32_t max_n_l
         add((size_t)n[kSrcNtG[et]] * S);
         add((size_t)n[kDstNtG[et]] * S); add((size_t)tiles[et] * S); add((size_t)n[kDstNtG[et]] * 48); add((size_t)tiles[et] * 48);
     }
-    add(16); add(16); add(max_n_lig); add(max_B + 1); add(max_B + 1); add(max_B + 2);
+    add(32); add(16); add(max_n_lig); add(max_B + 1); add(max_B + 1); add(max_B + 2);
     add(cap_ll); add(cap_ll); add(max_n_lig + 1);
     for (int i = 0; i < 4; ++i) add(cap_kl);
     add(max_n_lig + 1); add(max_n_kp + 1); add(max_B); add(8);
@@ -265,7 +265,7 @@ extern "C" kpd_status kpd_gvp_reserve(kpd_gvp *m, int32_t max_B, int32_t max_n_l
         m->ms_main[et] = W.take<float>((size_t)n[kDstNtG[et]] * S); m->ms_cont[et] = W.take<float>((size_t)tiles[et] * S);
         m->mv_main[et] = W.take<float>((size_t)n[kDstNtG[et]] * 48); m->mv_cont[et] = W.take<float>((size_t)tiles[et] * 48);
     }
-    m->meta4 = W.take<int>(16); m->meta2 = W.take<int>(16);
+    m->meta4 = W.take<int>(32); m->meta2 = m->meta4 + 16;    // one k_egnn_meta launch fills both tables
     m->ll_deg = W.take<int>(max_n_lig); m->ll_off = W.take<int>(max_B + 1); m->kl_off = W.take<int>(max_B + 1);
     m->kl_pg = W.take<int>(max_B + 2);
     kpd_lig_graph &g = m->lg;
@@ -301,10 +301,8 @@ extern "C" kpd_status kpd_gvp_forward(kpd_gvp *m, const kpd_batch *bt, const flo
     KPD_TRY(launch_lig_graph(bt, c.ll_cutoff, c.ll_k, c.kl_cutoff, c.kl_k, &m->lg, m->ll_deg, m->ll_off, m->kl_off, m->kl_pg, st));
     // tile tables for convs over all four edge types and over ll + kl only; z for message_norm == 0
     const float mn = c.message_norm_mode == 2 ? 0.0f : 1.0f;
-    KPD_TRY(launch_egnn_meta(m->lg.counts, bt->n_kk, 0xF, bt->lig_ptr, bt->kp_ptr, m->lg.ll_per_graph, bt->kk_rowptr, bt->B,
+    KPD_TRY(launch_egnn_meta(m->lg.counts, bt->n_kk, 0xF, 0x3, bt->lig_ptr, bt->kp_ptr, m->lg.ll_per_graph, bt->kk_rowptr, bt->B,
                              m->kl_off, mn, 1, m->meta4, m->z[0], m->z[1], st));
-    KPD_TRY(launch_egnn_meta(m->lg.counts, bt->n_kk, 0x3, bt->lig_ptr, bt->kp_ptr, m->lg.ll_per_graph, bt->kk_rowptr, bt->B,
-                             m->kl_off, mn, 1, m->meta2, m->z[0], m->z[1], st));
     KPD_TRY(launch_gvp_embed(bt->lig_h, bt->n_lig, c.n_lig_scalars, m->enc_W[0], m->enc_b[0], m->enc_lw[0], m->enc_lb[0],
                              t_dev, m->bidx[0], S, m->s[0], st));
     KPD_TRY(launch_gvp_embed(bt->kp_h, bt->n_kp, c.n_kp_scalars, m->enc_W[1], m->enc_b[1], m->enc_lw[1], m->enc_lb[1],

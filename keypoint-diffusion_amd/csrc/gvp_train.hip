@@ -862,7 +862,7 @@ extern "C" kpd_status kpd_gvp_trainer_reserve(kpd_gvp_trainer *T, int32_t max_B,
         F(T->part, (size_t)GRAD_SPLIT * 264 * 520);
         F(T->wsg_pack, (size_t)ws_gemm_pack_floats());
         F(T->ones, 8);
-        I(T->meta, 16); I(T->ll_deg, max_n_lig); I(T->ll_off, max_B + 1); I(T->kl_off, max_B + 1); I(T->kl_pg, max_B + 2);
+        I(T->meta, 32); I(T->ll_deg, max_n_lig); I(T->ll_off, max_B + 1); I(T->kl_off, max_B + 1); I(T->kl_pg, max_B + 2);
         kpd_lig_graph &g = T->lg;
         I(g.ll_src, cap_ll); I(g.ll_dst, cap_ll); I(g.ll_rowptr, max_n_lig + 1);
         I(g.kl_src, cap_kl); I(g.kl_dst, cap_kl); I(g.kl_rowptr, max_n_lig + 1);
@@ -897,7 +897,7 @@ extern "C" kpd_status kpd_gvp_trainer_forward(kpd_gvp_trainer *T, const kpd_batc
     KPD_TRY(launch_node_graph_index(bt->lig_ptr, bt->B, bt->n_lig, T->bidx[0], st));
     KPD_TRY(launch_node_graph_index(bt->kp_ptr, bt->B, bt->n_kp, T->bidx[1], st));
     KPD_TRY(launch_lig_graph(bt, c.ll_cutoff, c.ll_k, c.kl_cutoff, c.kl_k, &T->lg, T->ll_deg, T->ll_off, T->kl_off, T->kl_pg, st));
-    KPD_TRY(launch_egnn_meta(T->lg.counts, bt->n_kk, 0xF, bt->lig_ptr, bt->kp_ptr, T->lg.ll_per_graph, bt->kk_rowptr, bt->B, T->kl_off,
+    KPD_TRY(launch_egnn_meta(T->lg.counts, bt->n_kk, 0xF, 0xF, bt->lig_ptr, bt->kp_ptr, T->lg.ll_per_graph, bt->kk_rowptr, bt->B, T->kl_off,
                              c.message_norm_mode == 2 ? 0.0f : 1.0f, 1, T->meta, T->z[0], T->z[1], st));
     int counts[2];
     KPD_HIP(hipMemcpyAsync(counts, T->lg.counts, sizeof(counts), hipMemcpyDeviceToHost, st));

@@ -320,7 +320,7 @@ class EgnnEngine:
     def last_counts(self):
         arr = (C.c_int32 * 8)()
         check(lib().kpd_egnn_last_counts(self._h, arr, _stream()))
-        return dict(E_ll=arr[0], E_kl=arr[1], E_lk=arr[2], E_kk=arr[3], tiles=arr[4])
+        return dict(E_ll=arr[0], E_kl=arr[1], E_lk=arr[2], E_kk=arr[3], tiles=arr[4], tiles_last=arr[5], E_last=arr[6])
 
 
 class EgnnTrainer:

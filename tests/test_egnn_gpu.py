@@ -170,3 +170,29 @@ def test_degenerate_shapes(cuda, n_rec, n_lig):
     cfg = dict(util.EGNN_C2, n_layers=2)
     (h, x), (rh, rx), _ = _run_pair(cuda, cfg, n_rec, n_lig)
     assert util.rel_err(h, rh) < TOL and util.rel_err(x, rx) < TOL
+
+
+@pytest.mark.parametrize('edge_chain', [0, 1])
+def test_final_layer_pruning_is_bit_identical(cuda, edge_chain):
+    """LigRecEGNN.forward returns (h_lig, x_lig) only (models/dynamics.py:288-294): the final layer's lk / kk messages and
+    keypoint update feed nothing.  The engine skips them; eps must be bit-for-bit what the full final layer gives."""
+    g = util.fixed_encode(util.make_batch([300, 150, 40], [25, 9, 3]))
+    model = LigRecDynamics(10, 10, graph_cutoffs=util.CUTOFFS_ALL_ATOM, **util.EGNN_C2)
+    synth.fill_state_dict_(model, 3)
+    model = model.eval().to(cuda)
+    gd = g.to(cuda)
+    t = torch.tensor([0.3, 0.6, 0.9], device=cuda)
+    eng = model.engine()
+    eng.debug(f'edge_chain={edge_chain}')
+    with torch.no_grad():
+        eng.debug('prune=0')
+        h0, x0 = model(gd, t, None)
+        c0 = eng.last_counts()
+        eng.debug('prune=1')
+        h1, x1 = model(gd, t, None)
+        c1 = eng.last_counts()
+    torch.cuda.synchronize()
+    assert torch.equal(h0, h1) and torch.equal(x0, x1)
+    e_all = c0['E_ll'] + c0['E_kl'] + c0['E_lk'] + c0['E_kk']
+    assert c0['E_last'] == e_all and c0['tiles_last'] == c0['tiles']
+    assert c1['E_last'] == c1['E_ll'] + c1['E_kl'] and 0 < c1['tiles_last'] < c1['tiles']
