@@ -3,42 +3,60 @@
 
 A *step* is one reverse-diffusion step (`KeypointDiffusion.sample_p_zs_given_zt`:
 denoiser forward + z_s update + COM removal) over one batch of B synthetic complexes that
-is already resident in HBM.  Workload = BASELINE.json configs[1]:
+is already resident in HBM.  Contract workload = BASELINE.json configs[1]:
 egnn_all_atom dynamics, B = 64 synthetic 300-atom pockets / 25-atom ligands, T = 500.
 
     python bench.py --gpus N --steps K --warmup W
-N > 1: launched by torch.distributed.run, one rank per GPU; every rank owns its own batch of B
-complexes (weak scaling, no data-path collective), one RCCL all-gather of the ligand tensors
-at the end of the timed region (the exchange the sampler performs after the last step).
-Rank 0 prints ONE JSON line.
+
+N > 1: one rank per GPU over RCCL.  Either the caller starts the ranks (torch.distributed.run: RANK /
+WORLD_SIZE / MASTER_* in the environment) or -- when WORLD_SIZE is absent -- this script starts N fresh
+rank processes itself, BEFORE anything touches the GPU, and relays rank 0's JSON line.  Every rank owns
+its own batch of B complexes (weak scaling, no data-path collective); one all-gather of the ligand
+tensors sits at the end of each timed region (the exchange the sharded sampler performs after the last
+step).  W warm-up steps, then `--repeats` regions of EXACTLY K steps, each bracketed by barrier +
+synchronize on both sides and reduced with MAX over ranks; `value` is the MEDIAN region, the spread is
+reported beside it.  Rank 0 prints ONE JSON line.
+
+At N = 1 the default run also measures (and nests under `secondary`) BASELINE.json configs[2]
+(gvp_40kp, B = 64) and the configs[4] shape (gvp_all_atom, ragged 150-600 / 15-35 atoms), each with its
+own roofline and CPU baseline, and one full sampling run end to end (`end_to_end`: receptor encoding +
+T reverse steps + host copy -> measured ligands/min).
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from keypoint_diffusion_amd import graph as G            # noqa: E402
-from keypoint_diffusion_amd import synth                 # noqa: E402
-from keypoint_diffusion_amd.ligand_diffuser import KeypointDiffusion   # noqa: E402
-
 CUTOFFS = {'kk': 8, 'kl': 6, 'll': 6, 'rk': 100, 'rr': 3.5}      # trained_models/egnn_all_atom/config.yml
 DYNAMICS = dict(hidden_nf=256, kl_k=5, ll_k=0, message_norm=0, n_layers=6, no_cg=False, norm=True,
                 update_kp_feat=True, use_tanh=True)
-N_TIMESTEPS = 500
-PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 MFMA peak (= the fp32 vector peak)
 PEAK_HBM_GBS = 8000.0
-# FLOPs the fused edge kernel is responsible for, per edge per layer: the two 257x257 second
-# Linears of edge_mlp / coord_mlp plus the attention and coordinate heads (DESIGN.md)
+# FLOPs the fused EGNN edge kernel executes per edge per layer: the two 257x257 second Linears of edge_mlp /
+# coord_mlp plus the attention and coordinate heads (the first Linears run per NODE, k_proj_ws; DESIGN.md fact 2)
 EDGE_KERNEL_FLOP_PER_EDGE = 2 * (2 * 257 * 257) + 2 * (2 * 257)
 # reference formulation of the same edge work (SURVEY.md 8(d)): both Linears of both MLPs
 EDGE_ALGO_FLOP_PER_EDGE = 2 * (515 * 257 + 257 * 257) * 2 + 4 * 257
 EDGE_ALGO_BYTES_PER_EDGE = 4 * 257 + 16          # SURVEY.md 8(d): gathered row + coords + index
+GVP_ALGO_FLOP_PER_EDGE = 460.9e3                 # SURVEY.md 8(d): 3 chained message GVPs, reference formulation
+GVP_ALGO_BYTES_PER_EDGE = 4 * 304 + 16           # SURVEY.md 8(d): 256 scalars + 48 vector floats + coords + index
+
+
+def gvp_chain_flop_per_edge(S=256, V=16, n_msg=3, rbf=16):
+    """FLOPs k_gvp_chain executes per edge: the message chain of GVPMultiEdgeConv.message (models/gvp.py:545-549) with the
+    h_src block of the first to_feats_out applied per node (k_gvp_proj_chain).  Unpadded matrix shapes; the MFMA instruction
+    count of the kernel (PMC) gives 1 % more (padding of the 17-channel hidden tile)."""
+    vi, h0 = V + 1, max(V + 1, V)                                           # [x_diff | v_src] -> hidden max(vi, vo)
+    head = 2 * (3 * vi * h0 + (rbf + h0) * S + S * V + 3 * h0 * V)         # vec1, [rbf | sh] block, gates, vec2
+    rest = 2 * (3 * V * V + (S + V) * S + S * V + 3 * V * V)
+    return head + (n_msg - 1) * rest
 
 
 # secondary workloads (BASELINE.json configs[2] and configs[4]); the JSON contract line is always configs[1]
@@ -50,25 +68,70 @@ EGNN_ENC = dict(coords_range=10, fix_pos=False, hidden_n_node_feat=128, k_closes
                 message_norm=0.0, n_convs=4, n_kk_convs=0, n_kk_heads=4, no_cg=False, norm=True, out_n_node_feat=128,
                 use_sameres_feat=True, use_tanh=True)                      # trained_models/egnn_40kp/config.yml:59-75
 WORKLOADS = {
-    'egnn_all_atom': dict(arch='egnn', enc='fixed', dyn=DYNAMICS, n_kp=20, cutoffs=CUTOFFS),
+    'egnn_all_atom': dict(arch='egnn', enc='fixed', dyn=DYNAMICS, n_kp=20, cutoffs=CUTOFFS, T=500),
     'egnn_40kp': dict(arch='egnn', enc='learned', dyn=dict(DYNAMICS, message_norm=0.0), n_kp=40,
-                      cutoffs=dict(CUTOFFS, kl=8, ll=5)),
-    'gvp_40kp': dict(arch='gvp', enc='learned', dyn=GVP_DYN, n_kp=40, cutoffs=dict(CUTOFFS, kl=8, ll=6.0)),
-    'gvp_all_atom': dict(arch='gvp', enc='fixed', dyn=dict(GVP_DYN, message_norm='mean'), n_kp=20, cutoffs=CUTOFFS),
+                      cutoffs=dict(CUTOFFS, kl=8, ll=5), T=500),
+    'gvp_40kp': dict(arch='gvp', enc='learned', dyn=GVP_DYN, n_kp=40, cutoffs=dict(CUTOFFS, kl=8, ll=6.0), T=500),
+    'gvp_all_atom': dict(arch='gvp', enc='fixed', dyn=dict(GVP_DYN, message_norm='mean'), n_kp=20, cutoffs=CUTOFFS, T=1000),
     # one optimisation step of train.py's inner loop (loss of KeypointDiffusion.forward, backward, clip, Adam) on the
     # egnn_all_atom model: the backward pass of csrc/egnn_train.hip
-    'egnn_train': dict(arch='egnn', enc='fixed', dyn=DYNAMICS, n_kp=20, cutoffs=CUTOFFS),
+    'egnn_train': dict(arch='egnn', enc='fixed', dyn=DYNAMICS, n_kp=20, cutoffs=CUTOFFS, T=500),
     # same for the gvp_all_atom model in training mode (GVPDropout 0.1): the backward pass of csrc/gvp_train.hip
-    'gvp_train': dict(arch='gvp', enc='fixed', dyn=dict(GVP_DYN, message_norm='mean'), n_kp=20, cutoffs=CUTOFFS),
+    'gvp_train': dict(arch='gvp', enc='fixed', dyn=dict(GVP_DYN, message_norm='mean'), n_kp=20, cutoffs=CUTOFFS, T=1000),
 }
+TRAFFIC_FILES = ('r02_traffic.json', 'r01_traffic.json')      # per-launch HBM bytes of the dominant kernels (PMC passes)
 
 
+# ---------------------------------------------------------------------------------------------------
+# rank launcher: `python bench.py --gpus N` without a launcher starts the N ranks itself
+# ---------------------------------------------------------------------------------------------------
+def spawn_ranks(n: int) -> int:
+    """Start n fresh rank processes of this script (one per GPU, RCCL rendezvous on 127.0.0.1) and wait for them.
+    Runs before this process has imported torch or touched the GPU: the children are ordinary new processes,
+    nothing is exec'ed over a process that holds a GPU context."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in pending:            # a rank died: the others would wait in a collective forever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------
+# models, batches
+# ---------------------------------------------------------------------------------------------------
 def build_model(device, workload='egnn_all_atom'):
+    import torch  # noqa: F401
+    from keypoint_diffusion_amd import synth
+    from keypoint_diffusion_amd.ligand_diffuser import KeypointDiffusion
     w = WORKLOADS[workload]
     rec_cfg = dict(GVP_ENC) if w['arch'] == 'gvp' else (dict(EGNN_ENC) if w['enc'] == 'learned' else {})
     if w['enc'] == 'learned':
         rec_cfg['in_scalar_size' if w['arch'] == 'gvp' else 'in_n_node_feat'] = 10
-    model = KeypointDiffusion(10, 128 if w['enc'] == 'learned' else 10, None, n_timesteps=N_TIMESTEPS,
+    model = KeypointDiffusion(10, 128 if w['enc'] == 'learned' else 10, None, n_timesteps=w['T'],
                               architecture=w['arch'], rec_encoder_type=w['enc'],
                               graph_config=dict(n_keypoints=w['n_kp'], graph_cutoffs=w['cutoffs']),
                               dynamics_config=w['dyn'], rec_encoder_config=rec_cfg, precision=1e-5)
@@ -76,57 +139,88 @@ def build_model(device, workload='egnn_all_atom'):
     return model.eval().to(device)
 
 
-def build_batch(model, B, n_rec, n_lig, seed, device, workload='egnn_all_atom'):
+def raw_batch(B, n_rec, n_lig, seed, device, workload='egnn_all_atom'):
+    """The un-encoded batch (pocket graphs + t = T ligands), on `device` when the encoder is learned."""
+    from keypoint_diffusion_amd import graph as G
+    from keypoint_diffusion_amd import synth
     w = WORKLOADS[workload]
     if isinstance(n_rec, int):
         n_rec, n_lig = [n_rec] * B, [n_lig] * B
-    gs = synth.synth_complexes(n_rec, n_lig, w['n_kp'], w['cutoffs'], seed=seed)
-    g = G.batch(gs)
+    g = G.batch(synth.synth_complexes(n_rec, n_lig, w['n_kp'], w['cutoffs'], seed=seed))
     if w['enc'] == 'learned':
         if w['arch'] == 'egnn':                      # synthetic rr `same_res` column (the dataset's bool edge feature)
             s_, d_ = g.edges(etype='rr')
             g.edges['rr'].data['same_res'] = ((s_ // 8) == (d_ // 8)).view(-1, 1)
         g = g.to(device)                             # the learned encoders run on the GPU (once per pocket)
+    return g
+
+
+def build_batch(model, B, n_rec, n_lig, seed, device, workload='egnn_all_atom'):
+    import torch
+    g = raw_batch(B, n_rec, n_lig, seed, device, workload)
     with torch.no_grad():
         g = model.encode_receptors(g)                # fixed encoder: kp := rec, kk := rr
     return g.to(device)
 
 
-def cpu_baseline(B_sample=4, steps=2):
-    """Oracle (CPU restatement of the reference path) on this box's host cores, same shape."""
+def ragged_sizes(B, rank):
+    import torch
+    gen = torch.Generator().manual_seed(77 + rank)
+    return (torch.randint(150, 601, (B,), generator=gen).tolist(), torch.randint(15, 36, (B,), generator=gen).tolist())
+
+
+# ---------------------------------------------------------------------------------------------------
+# CPU baselines (the oracle = plain-PyTorch CPU restatement of the reference path; test infrastructure, imported here only)
+# ---------------------------------------------------------------------------------------------------
+def cpu_baseline(workload='egnn_all_atom', B_sample=8, steps=3, ragged=False, B_scale=64):
+    """Oracle on this box's host cores: B_sample complexes of the workload's shape x `steps` reverse steps after one warm-up,
+    scaled to the B_scale batch.  The keypoints of the learned-encoder workloads come from the product encoder (run once on
+    the GPU, outside the timed region) -- the baseline times the per-step denoiser path only, like `value`."""
+    import torch
     from oracle import diffusion as odiff
     from oracle import egnn as oegnn
+    from oracle import gvp as ogvp
     from tests.util import to_obatch
-    model = build_model('cpu')
-    g = build_batch(model, B_sample, 300, 25, seed=99, device='cpu')
+    w = WORKLOADS[workload]
+    T = w['T']
+    enc_dev = 'cuda' if w['enc'] == 'learned' else 'cpu'
+    model = build_model(enc_dev, workload)
+    n_rec, n_lig = (300, 25)
+    if ragged:
+        n_rec, n_lig = ragged_sizes(64, 0)
+        n_rec, n_lig = n_rec[:B_sample], n_lig[:B_sample]
+    g = build_batch(model, B_sample, n_rec, n_lig, seed=99, device=enc_dev, workload=workload).to('cpu')
     ob = to_obatch(g)
-    sd = {k[len('dynamics.'):]: v for k, v in model.state_dict().items() if k.startswith('dynamics.')}
-    cfg = dict(DYNAMICS, graph_cutoffs=CUTOFFS)
-    table = odiff.gamma_table(N_TIMESTEPS, 1e-5)
+    sd = {k[len('dynamics.'):]: v.detach().cpu() for k, v in model.state_dict().items() if k.startswith('dynamics.')}
+    cfg = dict(w['dyn'], graph_cutoffs=w['cutoffs'])
+    fwd = oegnn.egnn_dynamics_forward if w['arch'] == 'egnn' else ogvp.gvp_dynamics_forward
+    table = odiff.gamma_table(T, 1e-5)
     gen = torch.Generator().manual_seed(5)
 
     def one(si):
-        s = torch.full((B_sample,), si / N_TIMESTEPS)
-        t = torch.full((B_sample,), (si + 1) / N_TIMESTEPS)
-        eh, ex = oegnn.egnn_dynamics_forward(sd, cfg, ob, t)
-        odiff.sample_step(ob, eh, ex, s, t, table, N_TIMESTEPS, torch.randn(ob.x['lig'].shape, generator=gen),
+        s = torch.full((B_sample,), si / T)
+        t = torch.full((B_sample,), (si + 1) / T)
+        eh, ex = fwd(sd, cfg, ob, t)
+        odiff.sample_step(ob, eh, ex, s, t, table, T, torch.randn(ob.x['lig'].shape, generator=gen),
                           torch.randn(ob.h['lig'].shape, generator=gen))
 
     with torch.no_grad():
-        one(N_TIMESTEPS - 1)
+        one(T - 1)
         t0 = time.perf_counter()
         for i in range(steps):
-            one(N_TIMESTEPS - 2 - i)
+            one(T - 2 - i)
         dt = time.perf_counter() - t0
     complex_steps_per_s = B_sample * steps / dt
-    return {'value': complex_steps_per_s / 64.0, 'unit': 'steps/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'complex_steps_per_s': complex_steps_per_s,
-            'sample': f'oracle (plain PyTorch fp32 CPU restatement) on {B_sample} complexes of the same 300/25 shape x '
-                      f'{steps} reverse steps after 1 warm-up, scaled to the B=64 batch'}
+    shape = 'ragged 150-600 / 15-35 atom' if ragged else '300 / 25 atom'
+    return {'value': complex_steps_per_s / B_scale, 'unit': 'steps/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'complex_steps_per_s': complex_steps_per_s, 'cpu_seconds': dt,
+            'sample': f'oracle (plain PyTorch fp32 CPU restatement of the {workload} denoiser + update) on {B_sample} complexes of '
+                      f'the same {shape} shape x {steps} reverse steps after 1 warm-up, scaled to the B={B_scale} batch'}
 
 
 def train_cpu_baseline(workload, B_sample=2):
     """Loss + torch autograd through the CPU oracle for B_sample complexes of the same shape (one step after a warm-up)."""
+    import torch
     from oracle import egnn as oegnn
     from oracle import gvp as ogvp
     from tests.util import to_obatch
@@ -153,8 +247,185 @@ def train_cpu_baseline(workload, B_sample=2):
                       f'1 warm-up, scaled to the B=64 batch (no optimizer step on the CPU side)'}
 
 
+# ---------------------------------------------------------------------------------------------------
+# timed regions
+# ---------------------------------------------------------------------------------------------------
+def timed_regions(step, n_warmup, n_steps, repeats, dist, sync_tail=None):
+    """W warm-up steps, then `repeats` regions of exactly `n_steps` steps, each bracketed by barrier + synchronize on
+    both sides; returns the per-region wall times (seconds), MAX over ranks."""
+    import torch
+    it = 0
+    for _ in range(n_warmup):
+        step(it)
+        it += 1
+    out = []
+    for _ in range(repeats):
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step(it)
+            it += 1
+        if sync_tail is not None:
+            sync_tail()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        out.append(time.perf_counter() - t0)
+    if dist is not None:
+        backend_dev = 'cpu' if dist.get_backend() == 'gloo' else 'cuda'
+        t = torch.tensor(out, device=backend_dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        out = t.cpu().tolist()
+    return out
+
+
+def load_traffic(workload):
+    for name in TRAFFIC_FILES:
+        f = os.path.join(ROOT, 'profiles', name)
+        if not os.path.exists(f):
+            continue
+        d = json.load(open(f))
+        if workload in d:
+            return d[workload].get('hbm_bytes_per_launch'), f'profiles/{name}[{workload}]'
+        if workload == 'egnn_all_atom' and 'hbm_bytes_per_launch' in d:
+            return d['hbm_bytes_per_launch'], f'profiles/{name}'
+    return None, None
+
+
+def run_sampling(args, workload, device, rank, world, dist, B, n_rec, n_lig, ragged):
+    """Steps/s of one sampling workload + the roofline of its dominant kernel.  Returns the result dict (rank 0) ."""
+    import torch
+    from keypoint_diffusion_amd import graph as G
+    w = WORKLOADS[workload]
+    T = w['T']
+    model = build_model(device, workload)
+    g = build_batch(model, B, n_rec, n_lig, seed=1234 + rank * B, device=device, workload=workload)
+    bidx = G.get_batch_idxs(g)
+    eng = model.dynamics.engine()
+    ones = torch.ones(B, device=device)
+    # Random-init weights do not denoise: left to itself the chain drives the ligand atoms apart and
+    # the lig-lig radius graph empties within ~20 steps, which would shrink the measured work.  Every
+    # step therefore starts from the t = T state (x_0, h_0 ~ N(0, I), ligand COM removed: the complete
+    # 600-edge lig-lig graph of SURVEY.md 8(d)); restoring it is three small device copies.
+    lig, kp = g.nodes['lig'].data, g.nodes['kp'].data
+    init = (lig['x_0'].clone(), lig['h_0'].clone(), kp['x_0'].clone())
+    step_graph = None
+    if args.graph:
+        with torch.no_grad():
+            step_graph = model.capture_step(g, bidx)
+
+    def step(i):
+        si = T - 1 - (i % T)
+        if step_graph is not None:
+            step_graph.step(si / T, (si + 1) / T)
+        else:
+            model.sample_p_zs_given_zt(ones * (si / T), ones * ((si + 1) / T), g, bidx)
+        lig['x_0'].copy_(init[0]), lig['h_0'].copy_(init[1]), kp['x_0'].copy_(init[2])
+
+    def tail():
+        if dist is not None:
+            from keypoint_diffusion_amd.dist import all_gather_ligands
+            all_gather_ligands(g)
+
+    with torch.no_grad():
+        for i in range(args.warmup):
+            step(i)
+        torch.cuda.synchronize()
+        eng.profile(True)
+        regions = timed_regions(step, 0, args.steps, args.repeats, dist, tail)
+        kern_ms, launches = eng.profile_read()
+        eng.profile(False)
+        counts = eng.last_counts()
+    if rank != 0:
+        return None
+    med = statistics.median(regions)
+    steps_per_s = world * args.steps / med
+    # the event-timed dominant kernel must fit inside the wall time it is part of
+    total_wall_ms = 1e3 * sum(regions)
+    assert kern_ms <= total_wall_ms * 1.001, (kern_ms, total_wall_ms)
+    e_all = counts['E_ll'] + counts['E_kl'] + counts['E_lk'] + counts['E_kk']
+    n_launch_step = w['dyn']['n_layers'] if w['arch'] == 'egnn' else w['dyn']['n_convs']
+    edges_per_step = (n_launch_step - 1) * e_all + counts['E_last']
+    edges_per_launch = edges_per_step / n_launch_step
+    avg_s = kern_ms / max(launches, 1) * 1e-3
+    if w['arch'] == 'egnn':
+        kernel, f_exec, f_algo, b_algo = 'k_egnn_edge', EDGE_KERNEL_FLOP_PER_EDGE, EDGE_ALGO_FLOP_PER_EDGE, EDGE_ALGO_BYTES_PER_EDGE
+    else:
+        kernel, f_exec, f_algo, b_algo = ('k_gvp_chain', gvp_chain_flop_per_edge(w['dyn']['n_hidden_scalars']), GVP_ALGO_FLOP_PER_EDGE,
+                                          GVP_ALGO_BYTES_PER_EDGE)
+    achieved = edges_per_launch * f_exec / avg_s / 1e12 if avg_s > 0 else 0.0
+    hbm_gbs = edges_per_launch * b_algo / avg_s / 1e9 if avg_s > 0 else 0.0
+    traffic, tsrc = load_traffic(workload + ('_ragged' if ragged else '')) if (B == 64 and (ragged or n_rec == 300)) else (None, None)
+    shape = ('150-600', '15-35') if ragged else (n_rec, n_lig)
+    desc = {'egnn_all_atom': 'egnn_all_atom dynamics (6 EGNN layers, hidden 256, update_kp_feat; fixed receptor encoder)',
+            'egnn_40kp': 'egnn_40kp (learned EGNN receptor encoder -> 40 keypoints -> EGNN dynamics)',
+            'gvp_40kp': 'gvp_40kp (learned GVP receptor encoder -> 40 keypoints -> GVP dynamics, 6 convs, 256 scalars / 16 vectors)',
+            'gvp_all_atom': 'gvp_all_atom dynamics (6 GVP convs, 256 scalars / 16 vectors, message_norm mean; fixed receptor encoder)'}
+    out = {
+        'metric': 'denoising steps/sec', 'value': steps_per_s, 'unit': 'steps/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * med / args.steps,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'{desc[workload]}, batch of {B} synthetic {shape[0]}-atom pockets / {shape[1]}-atom ligands per GPU, '
+                               f'T={T}, seeded random-init weights, every step taken from the t=T ligand state',
+                   'batch_per_gpu': B, 'n_rec': 'U{150..600}' if ragged else n_rec, 'n_lig': 'U{15..35}' if ragged else n_lig,
+                   'parallelism': f'dp{world}'},
+        'repeats': {'n': args.repeats, 'ms_per_step': [1e3 * r / args.steps for r in regions], 'statistic': 'median',
+                    'spread_pct': 100.0 * (max(regions) - min(regions)) / med},
+        'complex_steps_per_s': steps_per_s * B,
+        'ligands_per_min_derived': steps_per_s * B * 60.0 / T,
+        'edges_per_launch': {**counts, 'E_full_layer': e_all, 'launches_per_step': n_launch_step,
+                             'mean_edges_per_launch': edges_per_launch},
+        'roofline': {'kernel': kernel, 'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MATRIX_TFLOPS,
+                     'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MATRIX_TFLOPS, 'traffic': traffic,
+                     'traffic_source': tsrc,
+                     'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, 2 x FETCH_SIZE + WRITE_SIZE, separate passes; committed '
+                                     'figure, not re-measured in this run)',
+                     'avg_launch_ms': avg_s * 1e3, 'launches': launches, 'kernel_ms_total': kern_ms, 'wall_ms_total': total_wall_ms,
+                     'flop_per_edge_executed': f_exec, 'flop_per_launch': edges_per_launch * f_exec,
+                     'reference_formulation_tflops': edges_per_launch * f_algo / avg_s / 1e12 if avg_s > 0 else 0.0,
+                     'hbm': {'achieved': hbm_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': hbm_gbs / PEAK_HBM_GBS,
+                             'bytes_per_launch': edges_per_launch * b_algo}},
+    }
+    del model, g, eng
+    torch.cuda.empty_cache()
+    return out
+
+
+def run_end_to_end(device, workload='egnn_all_atom', B=64, n_rec=300, n_lig=25):
+    """One full sampling run as test.py times it (reference test.py:149, 215-232): receptor encoding + T reverse steps of the
+    whole batch + the copy of the sampled ligands to the host.  With random-init weights the chain does not denoise (the
+    ligand spreads and the lig-lig graph thins out), so this is a functional wall-clock figure, not the steady-state rate."""
+    import torch
+    w = WORKLOADS[workload]
+    model = build_model(device, workload)
+    with torch.no_grad():
+        for _ in range(2):          # first pass = warm-up (workspace reservation, first-use initialisation)
+            g = raw_batch(B, n_rec, n_lig, 4321, device, workload)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            enc = model.encode_receptors(g).to(device)
+            pos, feat = model.sample_from_encoded_receptors(enc)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+    assert len(pos) == B and all(p.device.type == 'cpu' for p in pos)
+    del model
+    torch.cuda.empty_cache()
+    return {'workload': workload, 'ligands_per_min': 60.0 * B / dt, 'wall_s': dt, 'n_ligands': B, 'n_timesteps': w['T'],
+            'includes': 'receptor encoding + all reverse steps (per-step graph rebuild, fresh noise) + final frame shift + '
+                        'device->host copy of the ligands; model build and synthetic-data generation excluded',
+            'note': 'random-init weights do not denoise: the ligand spreads over the loop and the lig-lig graph thins, so late '
+                    'steps are cheaper than the t=T step the contract line times'}
+
+
 def run_train(args, device, rank, world, dist):
     """Secondary workloads: training steps/sec of the EGNN / GVP denoiser (fixed receptor encoder) on synthetic complexes."""
+    import torch
+    from keypoint_diffusion_amd import graph as G
+    from keypoint_diffusion_amd import synth
     from keypoint_diffusion_amd.dist import allreduce_gradients
     w = WORKLOADS[args.workload]
     model = build_model(device, args.workload).train()
@@ -162,8 +433,9 @@ def run_train(args, device, rank, world, dist):
     B = args.batch
     gs = synth.synth_complexes([args.n_rec] * B, [args.n_lig] * B, w['n_kp'], w['cutoffs'], seed=1234 + rank * B)
     template = G.batch(gs).to(device)
+    last = [None]
 
-    def step():
+    def step(i):
         g = template.to(device)             # fresh container over the same device tensors (forward re-binds node data)
         losses = model(g, None)
         opt.zero_grad(set_to_none=True)
@@ -172,54 +444,61 @@ def run_train(args, device, rank, world, dist):
             allreduce_gradients(list(model.parameters()))
         torch.nn.utils.clip_grad_value_(model.parameters(), 1.0)
         opt.step()
-        return losses['l2']
+        last[0] = losses['l2']
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        last = step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    regions = timed_regions(step, args.warmup, args.steps, args.repeats, dist)
     if rank == 0:
-        out = {'metric': 'training steps/sec', 'value': world * args.steps / elapsed, 'unit': 'steps/s', 'n_gpus': world,
-               'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+        med = statistics.median(regions)
+        out = {'metric': 'training steps/sec', 'value': world * args.steps / med, 'unit': 'steps/s', 'n_gpus': world,
+               'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * med / args.steps, 'higher_is_better': True,
                'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                'config': {'workload': f'{args.workload}: loss + backward + clip + Adam on {w["arch"]}_all_atom (6 layers, hidden 256, '
                                       f'training mode), batch of {B} '
                                       f'synthetic {args.n_rec}-atom pockets / {args.n_lig}-atom ligands per GPU, one bucketed gradient all-reduce per step when N > 1',
-                          'batch_per_gpu': B},
-               'complex_steps_per_s': world * args.steps / elapsed * B, 'final_l2': float(last.detach())}
+                          'batch_per_gpu': B, 'parallelism': f'dp{world}'},
+               'repeats': {'n': args.repeats, 'ms_per_step': [1e3 * r / args.steps for r in regions], 'statistic': 'median'},
+               'complex_steps_per_s': world * args.steps / med * B, 'final_l2': float(last[0].detach())}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = train_cpu_baseline(args.workload)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=40)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=None, help='timed steps per region (default 200; 20 for the training workloads)')
+    ap.add_argument('--warmup', type=int, default=None, help='untimed warm-up steps (default 20; 3 for the training workloads)')
+    ap.add_argument('--repeats', type=int, default=3, help='timed regions of --steps steps each; the median is reported')
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--n-rec', type=int, default=300)
     ap.add_argument('--n-lig', type=int, default=25)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the configs[2] / configs[4]-shape / end-to-end measurements')
     ap.add_argument('--workload', default='egnn_all_atom', choices=list(WORKLOADS),
                     help='egnn_all_atom = BASELINE.json configs[1] (the contract line); the others are secondary')
     ap.add_argument('--graph', action='store_true', help='replay the reverse step as a captured HIP graph (StepGraph)')
     ap.add_argument('--ragged', action='store_true', help='pockets 150-600 atoms, ligands 15-35 atoms (configs[4] shape)')
     args = ap.parse_args()
+    training = args.workload in ('egnn_train', 'gvp_train')
+    if args.steps is None:
+        args.steps = 20 if training else 200
+    if args.warmup is None:
+        args.warmup = 3 if training else 20
+
+    # N ranks without a launcher: start them here, before anything in this process touches the GPU
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('KPD_BENCH_SPAWN_ECHO') == '1':        # launcher self-test (tests/test_bench_launch.py): no GPU, no torch
+        print(json.dumps({'rank': rank, 'local_rank': local_rank, 'world': world, 'gpus': args.gpus,
+                          'master': os.environ.get('MASTER_ADDR'), 'port': os.environ.get('MASTER_PORT')}), flush=True)
+        return
+    import torch
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the hot path has no CPU implementation')
     # KPD_BENCH_SHARE_GPU=1 (functional rehearsal on a one-GPU box only): every rank uses cuda:0 and the
@@ -227,6 +506,9 @@ def main():
     share = os.environ.get('KPD_BENCH_SHARE_GPU') == '1'
     if share:
         local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit(f'bench.py: rank {rank} needs cuda:{local_rank} but only {torch.cuda.device_count()} device(s) are visible '
+                         f'(KPD_BENCH_SHARE_GPU=1 rehearses N ranks on one GPU over gloo)')
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     dist = None
@@ -236,128 +518,40 @@ def main():
             dist.init_process_group('gloo')
         else:
             dist.init_process_group('nccl', device_id=device)
-    if args.gpus != world:
-        print(f'[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}', file=sys.stderr)
+        assert dist.get_world_size() == args.gpus
 
     torch.manual_seed(1000 + rank)
-    if args.workload in ('egnn_train', 'gvp_train'):
+    if training:
         run_train(args, device, rank, world, dist)
         if dist is not None:
             dist.destroy_process_group()
         return
-    model = build_model(device, args.workload)
-    B = args.batch
+
     n_rec, n_lig = args.n_rec, args.n_lig
     if args.ragged:
-        gen = torch.Generator().manual_seed(77 + rank)
-        n_rec = torch.randint(150, 601, (B,), generator=gen).tolist()
-        n_lig = torch.randint(15, 36, (B,), generator=gen).tolist()
-    g = build_batch(model, B, n_rec, n_lig, seed=1234 + rank * B, device=device, workload=args.workload)
-    bidx = G.get_batch_idxs(g)
-    eng = model.dynamics.engine()
-    is_egnn = args.workload == 'egnn_all_atom'
-    ones = torch.ones(B, device=device)
-    # Random-init weights do not denoise: left to itself the chain drives the ligand atoms apart and
-    # the lig-lig radius graph empties within ~20 steps, which would shrink the measured work.  Every
-    # step therefore starts from the t = T state (x_0, h_0 ~ N(0, I), ligand COM removed: the complete
-    # 600-edge lig-lig graph of SURVEY.md 8(d)); restoring it is three small device copies.
-    lig, kp = g.nodes['lig'].data, g.nodes['kp'].data
-    init = (lig['x_0'].clone(), lig['h_0'].clone(), kp['x_0'].clone())
-
-    step_graph = None
-    if args.graph:
-        with torch.no_grad():
-            step_graph = model.capture_step(g, bidx)
-
-    def step(i):
-        si = N_TIMESTEPS - 1 - (i % N_TIMESTEPS)
-        if step_graph is not None:
-            step_graph.step(si / N_TIMESTEPS, (si + 1) / N_TIMESTEPS)
-        else:
-            model.sample_p_zs_given_zt(ones * (si / N_TIMESTEPS), ones * ((si + 1) / N_TIMESTEPS), g, bidx)
-        lig['x_0'].copy_(init[0]), lig['h_0'].copy_(init[1]), kp['x_0'].copy_(init[2])
-
-    with torch.no_grad():
-        for i in range(args.warmup):
-            step(i)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        if is_egnn:
-            eng.profile(True)
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(args.warmup + i)
-        if dist is not None:
-            from keypoint_diffusion_amd.dist import all_gather_ligands
-            all_gather_ligands(g)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-    if not is_egnn:
-        if rank == 0:
-            print(json.dumps({'metric': 'denoising steps/sec', 'value': world * args.steps / elapsed, 'unit': 'steps/s',
-                              'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-                              'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
-                              'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-                              'config': {'workload': args.workload + (' ragged 150-600/15-35' if args.ragged else ''),
-                                         'batch_per_gpu': B, 'n_kp_total': g.num_nodes('kp'), 'n_lig_total': g.num_nodes('lig'),
-                                         'n_kk': g.num_edges('kk')},
-                              'complex_steps_per_s': world * args.steps / elapsed * B}))
-        if dist is not None:
-            dist.destroy_process_group()
-        return
-    edge_ms, edge_launches = eng.profile_read()
-    eng.profile(False)
-    counts = eng.last_counts()
-
-    if dist is not None:
-        tmax = torch.tensor([elapsed], device='cpu' if share else device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
+        n_rec, n_lig = ragged_sizes(args.batch, rank)
+    out = run_sampling(args, args.workload, device, rank, world, dist, args.batch, n_rec, n_lig, args.ragged)
     if rank == 0:
-        # HBM traffic of the dominant kernel comes from PMC counters, which need their own rocprofv3 passes
-        # (profiles/tools/collect_round.sh); the committed per-launch figure for this workload is attached
-        traffic = None
-        tfile = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-        if os.path.exists(tfile) and B == 64 and args.n_rec == 300 and args.n_lig == 25:
-            traffic = json.load(open(tfile))['hbm_bytes_per_launch']
-        steps_per_s = world * args.steps / elapsed
-        n_edges = counts['E_ll'] + counts['E_kl'] + counts['E_lk'] + counts['E_kk']
-        edge_avg_s = edge_ms / max(edge_launches, 1) * 1e-3
-        achieved = n_edges * EDGE_KERNEL_FLOP_PER_EDGE / edge_avg_s / 1e12 if edge_avg_s > 0 else 0.0
-        hbm_gbs = n_edges * EDGE_ALGO_BYTES_PER_EDGE / edge_avg_s / 1e9 if edge_avg_s > 0 else 0.0
-        out = {
-            'metric': 'denoising steps/sec', 'value': steps_per_s, 'unit': 'steps/s', 'n_gpus': world,
-            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'egnn_all_atom dynamics (6 EGNN layers, hidden 256, update_kp_feat), batch of {B} '
-                                   f'synthetic {"150-600" if args.ragged else args.n_rec}-atom pockets / '
-                                   f'{"15-35" if args.ragged else args.n_lig}-atom ligands per GPU, '
-                                   f'T={N_TIMESTEPS}, seeded random-init weights, every step taken from the t=T ligand state',
-                       'batch_per_gpu': B, 'n_rec': 'U{150..600}' if args.ragged else args.n_rec,
-                       'n_lig': 'U{15..35}' if args.ragged else args.n_lig, 'parallelism': f'dp{world}'},
-            'complex_steps_per_s': steps_per_s * B,
-            'ligands_per_min': steps_per_s * B * 60.0 / N_TIMESTEPS,
-            'edges_per_step_layer': counts,
-            'roofline': {'kernel': 'k_egnn_edge', 'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MATRIX_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MATRIX_TFLOPS, 'traffic': traffic,
-                         'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, 2 x FETCH_SIZE + WRITE_SIZE, separate passes)',
-                         'avg_launch_ms': edge_avg_s * 1e3, 'launches': edge_launches,
-                         'flop_per_launch': n_edges * EDGE_KERNEL_FLOP_PER_EDGE,
-                         'reference_formulation_tflops': n_edges * EDGE_ALGO_FLOP_PER_EDGE / edge_avg_s / 1e12
-                         if edge_avg_s > 0 else 0.0,
-                         'hbm': {'achieved': hbm_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': hbm_gbs / PEAK_HBM_GBS,
-                                 'bytes_per_launch': n_edges * EDGE_ALGO_BYTES_PER_EDGE}},
-        }
+        default_line = args.workload == 'egnn_all_atom' and not args.ragged and not args.graph
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline()
+            out['cpu_baseline'] = cpu_baseline(args.workload, ragged=args.ragged, B_scale=args.batch)
             out['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']
-        print(json.dumps(out))
+        if world == 1 and default_line and not args.no_secondary:
+            # BASELINE.json configs[2] and the configs[4] shape, same method (shorter regions), each with its roofline
+            sec_args = argparse.Namespace(**vars(args))
+            sec_args.steps, sec_args.warmup = max(20, args.steps // 2), max(5, args.warmup // 2)
+            sec = {}
+            for name, wl, ragged in (('gvp_40kp', 'gvp_40kp', False), ('gvp_all_atom_ragged', 'gvp_all_atom', True)):
+                nr, nl = ragged_sizes(64, 0) if ragged else (300, 25)
+                r = run_sampling(sec_args, wl, device, 0, 1, None, 64, nr, nl, ragged)
+                if not args.no_cpu_baseline:
+                    r['cpu_baseline'] = cpu_baseline(wl, ragged=ragged)
+                    r['gpu_over_cpu'] = r['value'] / r['cpu_baseline']['value']
+                sec[name] = r
+            out['secondary'] = sec
+            out['end_to_end'] = run_end_to_end(device)
+            out['ligands_per_min'] = out['end_to_end']['ligands_per_min']
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -122,7 +122,9 @@ kpd_status kpd_egnn_debug_state(kpd_egnn *m, const char *what, float *out_dev, i
  * stream around each of its launches while enabled (up to 8192 launches per enable). */
 kpd_status kpd_egnn_profile(kpd_egnn *m, int32_t enable);
 kpd_status kpd_egnn_profile_read(kpd_egnn *m, double *total_ms, int32_t *launches);
-/* Launch geometry of the last forward: {E_ll, E_kl, E_lk, E_kk, edge tiles}. */
+/* Launch geometry of the last forward: {E_ll, E_kl, E_lk, E_kk, edge tiles of a full layer, edge tiles and edges of the
+ * final layer} -- the final layer runs ll + kl only, since LigRecEGNN.forward returns (h_lig, x_lig) alone
+ * (models/dynamics.py:288-294). */
 kpd_status kpd_egnn_last_counts(kpd_egnn *m, int32_t out[8], void *stream);
 
 /* ---------------------------------------------------------------------------------------
@@ -184,6 +186,13 @@ kpd_status kpd_gvp_forward(kpd_gvp *m, const kpd_batch *batch, const float *t_de
 /* Debug/test taps: "convs=<n>" limits the conv stack; "s_lig", "s_kp", "v_lig", "v_kp" copy state. */
 kpd_status kpd_gvp_debug_state(kpd_gvp *m, const char *what, float *out_dev, int64_t n_floats,
                                void *stream);
+/* HIP-event timing of the dominant kernel (k_gvp_chain: the message chain of GVPMultiEdgeConv.message,
+ * models/gvp.py:459-497, 545-549) around each of its launches while enabled, and the launch geometry of the last
+ * forward {E_ll, E_kl, E_lk, E_kk, tiles of a four-edge-type conv, tiles of the final conv, edges of the final conv}
+ * (the final conv runs ll + kl only, models/dynamics_gvp.py:67-72). */
+kpd_status kpd_gvp_profile(kpd_gvp *m, int32_t enable);
+kpd_status kpd_gvp_profile_read(kpd_gvp *m, double *total_ms, int32_t *launches);
+kpd_status kpd_gvp_last_counts(kpd_gvp *m, int32_t out[8], void *stream);
 
 /* Training path of the GVP denoiser: same contract as kpd_egnn_trainer_* above for
  * LigRecDynamicsGVP.forward (models/dynamics_gvp.py:149-199).  Gradients flow to every parameter and to the scalar and

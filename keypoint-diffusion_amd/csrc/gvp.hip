@@ -37,6 +37,10 @@ struct kpd_gvp {
     bool committed = false;
     int debug_convs = -1;
     unsigned long long *stamps = nullptr;     // device [32], diagnostics
+    // optional HIP-event timing of the dominant kernel (k_gvp_chain), for bench.py's roofline
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;
+    size_t prof_used = 0;
     // workspace
     int cap_B = 0, cap_lig = 0, cap_kp = 0, cap_kk = 0, cap_maxlig = 0, cap_maxkp = 0;
     float *s[2], *v[2], *s_tmp[2];
@@ -348,7 +352,13 @@ extern "C" kpd_status kpd_gvp_forward(kpd_gvp *m, const kpd_batch *bt, const flo
             ea.ms_main[et] = m->ms_main[et]; ea.ms_cont[et] = m->ms_cont[et];
             ea.mv_main[et] = m->mv_main[et]; ea.mv_cont[et] = m->mv_cont[et];
         }
+        const bool prof = m->prof_on && m->prof_used + 2 <= m->prof_ev.size();
+        if (prof) KPD_HIP(hipEventRecord(m->prof_ev[m->prof_used], st));
         KPD_TRY(launch_gvp_edge(ea, tile_cap, st));
+        if (prof) {
+            KPD_HIP(hipEventRecord(m->prof_ev[m->prof_used + 1], st));
+            m->prof_used += 2;
+        }
 
         GvpNodePair np;
         memset(&np, 0, sizeof(np));
@@ -409,5 +419,44 @@ extern "C" kpd_status kpd_gvp_debug_state(kpd_gvp *m, const char *what, float *o
     else if (w == "v_kp") src = m->v[1];
     KPD_REQUIRE(src && out, KPD_ERR_INVALID, "unknown debug tap '%s'", what);
     KPD_HIP(hipMemcpyAsync(out, src, (size_t)n_floats * 4, hipMemcpyDeviceToDevice, st));
+    return KPD_OK;
+}
+
+extern "C" kpd_status kpd_gvp_profile(kpd_gvp *m, int32_t enable) {
+    KPD_REQUIRE(m, KPD_ERR_INVALID, "null handle");
+    if (enable && m->prof_ev.empty()) {
+        m->prof_ev.resize(2 * 8192);
+        for (hipEvent_t &e : m->prof_ev) KPD_HIP(hipEventCreate(&e));
+    }
+    m->prof_on = enable != 0;
+    m->prof_used = 0;
+    return KPD_OK;
+}
+
+extern "C" kpd_status kpd_gvp_profile_read(kpd_gvp *m, double *total_ms, int32_t *launches) {
+    KPD_REQUIRE(m && total_ms && launches, KPD_ERR_INVALID, "null argument");
+    double tot = 0.0;
+    for (size_t i = 0; i + 1 < m->prof_used; i += 2) {
+        KPD_HIP(hipEventSynchronize(m->prof_ev[i + 1]));
+        float ms = 0.0f;
+        KPD_HIP(hipEventElapsedTime(&ms, m->prof_ev[i], m->prof_ev[i + 1]));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *launches = (int32_t)(m->prof_used / 2);
+    return KPD_OK;
+}
+
+extern "C" kpd_status kpd_gvp_last_counts(kpd_gvp *m, int32_t out[8], void *stream) {
+    KPD_REQUIRE(m && out && m->meta4, KPD_ERR_INVALID, "null argument or no workspace");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int host[25];
+    KPD_HIP(hipMemcpyAsync(host, m->meta4, sizeof(host), hipMemcpyDeviceToHost, st));
+    KPD_HIP(hipStreamSynchronize(st));
+    for (int i = 0; i < 4; ++i) out[i] = host[i];
+    out[4] = host[8];                                  // tiles of a conv over all four edge types
+    out[5] = host[16 + 8];                             // tiles of the final conv (ll + kl)
+    out[6] = host[16] + host[17];                      // edges of the final conv
+    out[7] = 0;
     return KPD_OK;
 }

@@ -33,26 +33,38 @@ def shard_complexes(costs: Sequence[float], world: int) -> List[range]:
     return [range(bounds[i], max(bounds[i], bounds[i + 1])) for i in range(world)]
 
 
-def all_gather_ligands(g: G.HeteroBatch, group=None) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
-    """Every rank returns the ligand positions / features of ALL ranks' complexes, rank-major.
-    Two collectives (sizes, then one padded block per rank), packing and unpacking without per-complex device work: the
-    block is filled by one indexed assignment, copied to the host once, and the results are views into that copy."""
+def _group_device(like: torch.device, group=None) -> torch.device:
+    """RCCL moves device tensors; gloo (CPU tests, one-GPU rehearsals) wants host tensors."""
+    return like if dist.get_backend(group) == 'nccl' else torch.device('cpu')
+
+
+def gather_ligand_lists(pos: Sequence[torch.Tensor], feat: Sequence[torch.Tensor], group=None,
+                        device: Optional[torch.device] = None) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
+    """Every rank passes the ligands of ITS complexes (`pos[i]` [n_i, 3], `feat[i]` [n_i, F], any device) and receives those
+    of ALL ranks, rank-major, as host tensors -- with contiguous shards (`shard_complexes`) that is the input order.
+    Two collectives (sizes, then one padded block per rank); packing and unpacking cost no per-complex device work: the block
+    is filled by one indexed assignment, copied to the host once, and the results are views into that copy.  A rank may hold
+    no complexes at all (more ranks than complexes)."""
     world = dist.get_world_size(group)
-    # RCCL moves device tensors; gloo (CPU tests, one-GPU rehearsals) wants host tensors
-    dev = g.device if dist.get_backend(group) == 'nccl' else torch.device('cpu')
-    counts = g.batch_num_nodes('lig').to(dev).long()
-    x, h = g.nodes['lig'].data['x_0'].to(dev).float(), g.nodes['lig'].data['h_0'].to(dev).float()
-    F, B = h.shape[1], counts.numel()
-    # 1) how many complexes / atoms everybody has
-    meta = torch.stack([torch.tensor(B, device=dev), counts.max() if B else torch.tensor(0, device=dev)]).to(torch.int32)
-    metas = torch.empty(world * 2, device=dev, dtype=torch.int32)
+    like = device if device is not None else (pos[0].device if len(pos) else torch.device('cpu'))
+    dev = _group_device(like, group)
+    B = len(pos)
+    counts = torch.tensor([p.shape[0] for p in pos], dtype=torch.long, device=dev)
+    F = feat[0].shape[1] if B else 0
+    # 1) how many complexes / atoms / feature columns everybody has
+    meta = torch.tensor([B, int(counts.max()) if B else 0, F], device=dev, dtype=torch.int32)
+    metas = torch.empty(world * 3, device=dev, dtype=torch.int32)
     dist.all_gather_into_tensor(metas, meta, group=group)
-    metas = metas.view(world, 2).cpu()
-    max_B, max_n = int(metas[:, 0].max()), int(metas[:, 1].max())
+    metas = metas.view(world, 3).cpu()
+    max_B, max_n, F = int(metas[:, 0].max()), int(metas[:, 1].max()), int(metas[:, 2].max())
+    if max_B == 0:
+        return [], []
     # 2) one padded block per rank: [max_B, 1 + max_n * (3 + F)], column 0 = atom count, then atoms x (x, h)
     W = 3 + F
     block = torch.zeros(max_B, 1 + max_n * W, device=dev, dtype=torch.float32)
     if B:
+        x = torch.cat([p.to(dev).float() for p in pos], dim=0)
+        h = torch.cat([f.to(dev).float() for f in feat], dim=0)
         block[:B, 0] = counts.float()
         cid = torch.repeat_interleave(torch.arange(B, device=dev), counts)
         start = torch.cumsum(counts, 0) - counts
@@ -62,14 +74,43 @@ def all_gather_ligands(g: G.HeteroBatch, group=None) -> Tuple[List[torch.Tensor]
     blocks = torch.empty(world, max_B, 1 + max_n * W, device=dev, dtype=torch.float32)
     dist.all_gather_into_tensor(blocks.view(world * max_B, -1), block, group=group)
     blocks = blocks.cpu()
-    pos, feat = [], []
+    out_pos, out_feat = [], []
     for r in range(world):
         body = blocks[r, :, 1:].view(max_B, max_n, W)
         ns = blocks[r, :int(metas[r, 0]), 0].long().tolist()
         for b, n in enumerate(ns):
-            pos.append(body[b, :n, :3])
-            feat.append(body[b, :n, 3:])
-    return pos, feat
+            out_pos.append(body[b, :n, :3])
+            out_feat.append(body[b, :n, 3:])
+    return out_pos, out_feat
+
+
+def all_gather_ligands(g: G.HeteroBatch, group=None) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
+    """Every rank returns the ligand positions / features of ALL ranks' complexes, rank-major (one batch per rank)."""
+    counts = g.batch_num_nodes('lig').long().tolist()
+    x, h = g.nodes['lig'].data['x_0'], g.nodes['lig'].data['h_0']
+    return gather_ligand_lists(list(torch.split(x, counts)), list(torch.split(h, counts)), group=group, device=g.device)
+
+
+def sharding_active(group=None) -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
+def sharded_map(costs: Sequence[float], fn, group=None, device: Optional[torch.device] = None):
+    """The multi-GPU form of "for every complex: sample": `fn(range)` produces (positions, features) lists for the complexes
+    of this rank's contiguous, cost-balanced shard; one gather at the end hands every rank all results in input order.
+    No other collective touches the data path (complexes are independent)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    mine = shard_complexes(costs, world)[rank]
+    pos, feat = fn(mine) if len(mine) else ([], [])
+    assert len(pos) == len(mine) and len(feat) == len(mine)
+    return gather_ligand_lists(pos, feat, group=group, device=device)
+
+
+def common_seed(group=None) -> int:
+    """One 63-bit seed all ranks agree on (rank 0 draws it from torch's CPU generator, so torch.manual_seed reproduces a run)."""
+    box = [int(torch.randint(0, 2 ** 62, (1,)).item()) if dist.get_rank(group) == 0 else None]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return int(box[0])
 
 
 def allreduce_gradients(params, group=None, bucket_bytes: int = 64 << 20, average: bool = True):

@@ -111,6 +111,9 @@ def lib():
     L.kpd_gvp_reserve.argtypes = [C.c_void_p] + [C.c_int32] * 6
     L.kpd_gvp_forward.argtypes = [C.c_void_p, C.POINTER(KpdBatch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.kpd_gvp_debug_state.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p]
+    L.kpd_gvp_last_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]
+    L.kpd_gvp_profile.argtypes = [C.c_void_p, C.c_int32]
+    L.kpd_gvp_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     L.kpd_recenc_create.argtypes = [C.POINTER(KpdRecencConfig), C.POINTER(C.c_void_p)]
     L.kpd_recenc_destroy.argtypes = [C.c_void_p]
     L.kpd_recenc_destroy.restype = None
@@ -167,7 +170,7 @@ EXPORTS = [
     'kpd_egnn_forward', 'kpd_egnn_debug_state', 'kpd_egnn_last_counts', 'kpd_egnn_profile',
     'kpd_egnn_profile_read', 'kpd_sample_update', 'kpd_step_coefficients', 'kpd_complex_noise',
     'kpd_gvp_create', 'kpd_gvp_destroy', 'kpd_gvp_load_weight', 'kpd_gvp_commit', 'kpd_gvp_reserve',
-    'kpd_gvp_forward', 'kpd_gvp_debug_state',
+    'kpd_gvp_forward', 'kpd_gvp_debug_state', 'kpd_gvp_profile', 'kpd_gvp_profile_read', 'kpd_gvp_last_counts',
     'kpd_recenc_create', 'kpd_recenc_destroy', 'kpd_recenc_load_weight', 'kpd_recenc_commit', 'kpd_recenc_reserve',
     'kpd_recenc_forward',
     'kpd_recegnn_create', 'kpd_recegnn_destroy', 'kpd_recegnn_load_weight', 'kpd_recegnn_commit', 'kpd_recegnn_reserve',
@@ -430,6 +433,20 @@ class GvpEngine:
         out = torch.empty(max(n_floats, 1), device=device or 'cuda')
         check(lib().kpd_gvp_debug_state(self._h, what.encode(), out.data_ptr(), n_floats, _stream()))
         return out if n_floats else None
+
+    def profile(self, enable: bool):
+        check(lib().kpd_gvp_profile(self._h, int(enable)))
+
+    def profile_read(self):
+        """(total ms, launches) of the message-chain kernel since profile(True)."""
+        ms, n = C.c_double(), C.c_int32()
+        check(lib().kpd_gvp_profile_read(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def last_counts(self):
+        arr = (C.c_int32 * 8)()
+        check(lib().kpd_gvp_last_counts(self._h, arr, _stream()))
+        return dict(E_ll=arr[0], E_kl=arr[1], E_lk=arr[2], E_kk=arr[3], tiles=arr[4], tiles_last=arr[5], E_last=arr[6])
 
 
 class GvpTrainer:

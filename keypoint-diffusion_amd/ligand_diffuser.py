@@ -337,18 +337,58 @@ class KeypointDiffusion(nn.Module):
 
     @torch.no_grad()
     def _sample(self, ref_graphs: List[G.HeteroBatch], n_lig_atoms: List[List[int]], rec_enc_batch_size: int = 32,
-                diff_batch_size: int = 32, visualize=False, use_ref_lig_com: bool = False):
-        """Several pockets x several ligands per pocket (ligand_diffuser.py:271-340)."""
-        encoded = self.encode_receptors(G.batch(ref_graphs))
-        graphs = []
-        for i, ref in enumerate(G.unbatch(encoded)):
-            graphs.extend(G.copy_graph(ref, n_copies=len(n_lig_atoms[i]), lig_atoms_per_copy=torch.tensor(n_lig_atoms[i])))
-        lig_pos, lig_feat = [], []
-        for b in range(ceil(len(graphs) / diff_batch_size)):
-            bg = G.batch(graphs[b * diff_batch_size:(b + 1) * diff_batch_size])
-            init = G.readout_nodes(bg, feat='x_0', op='mean', ntype='lig') if use_ref_lig_com else None
-            p, f = self.sample_from_encoded_receptors(bg, visualize=visualize, init_lig_pos=init)
-            lig_pos.extend(p), lig_feat.extend(f)
+                diff_batch_size: int = 32, visualize=False, use_ref_lig_com: bool = False, group=None):
+        """Several pockets x several ligands per pocket (ligand_diffuser.py:271-340).
+
+        The flat list of (pocket, replicate) complexes it builds (:292-313) is the unit of multi-GPU work:
+        when a `torch.distributed` process group with more than one rank is initialised, every rank calls this with the SAME
+        arguments, takes a contiguous, edge-count-balanced shard of that list (`dist.shard_complexes`), encodes only the pockets
+        its shard touches, runs the reverse loop on its shard in `diff_batch_size` batches, and one all-gather of the ligand
+        tensors (`dist.gather_ligand_lists`, RCCL over xGMI) returns ALL ligands, in input order, on every rank.  Noise then comes
+        from the per-complex Philox streams keyed by the global complex index (`use_complex_noise`; switched on with a seed
+        all ranks agree on if the caller did not choose one), so the sharded run reproduces the single-process run of the same
+        seed up to fp32 summation order.  The pockets are encoded `rec_enc_batch_size` at a time."""
+        from . import dist as D
+        sharded = D.sharding_active(group)
+        if sharded and visualize:
+            raise ValueError('visualize=True returns whole trajectories and is a single-process feature')
+        # the flat complex list: (pocket index, number of ligand atoms), in input order
+        flat = [(i, int(n)) for i, sizes in enumerate(n_lig_atoms) for n in sizes]
+        device = ref_graphs[0].device
+
+        def run(mine):
+            """Ligands of the complexes `mine` (a range into `flat`)."""
+            pockets = sorted({flat[c][0] for c in mine})
+            encoded = {}
+            for lo in range(0, len(pockets), max(1, rec_enc_batch_size)):
+                chunk = pockets[lo:lo + max(1, rec_enc_batch_size)]
+                enc = self.encode_receptors(G.batch([ref_graphs[i] for i in chunk]))
+                encoded.update(zip(chunk, G.unbatch(enc)))
+            graphs = []
+            for c in mine:           # one copy_graph call per (pocket, run of replicates) keeps the reference's copy semantics
+                i, n = flat[c]
+                graphs.extend(G.copy_graph(encoded[i], n_copies=1, lig_atoms_per_copy=torch.tensor([n])))
+            pos, feat = [], []
+            for lo in range(0, len(graphs), diff_batch_size):
+                bg = G.batch(graphs[lo:lo + diff_batch_size])
+                init = G.readout_nodes(bg, feat='x_0', op='mean', ntype='lig') if use_ref_lig_com else None
+                ids = torch.arange(mine[lo], mine[lo] + bg.batch_size, dtype=torch.long)
+                p, f = self.sample_from_encoded_receptors(bg, visualize=visualize, init_lig_pos=init, complex_ids=ids)
+                pos.extend(p), feat.extend(f)
+            return pos, feat
+
+        if sharded:
+            restore = getattr(self, '_noise_seed', None)
+            if restore is None:
+                self.use_complex_noise(D.common_seed(group))
+            try:
+                # cost of a complex ~ its edges per layer: kk + kl/lk grow with the pocket, ll with the ligand (SURVEY.md 8(d))
+                costs = [600.0 + 22.7 * ref_graphs[i].num_nodes('rec') + n * n for i, n in flat]
+                lig_pos, lig_feat = D.sharded_map(costs, run, group=group, device=device)
+            finally:
+                self._noise_seed = restore
+        else:
+            lig_pos, lig_feat = run(range(len(flat)))
         samples, end = [], 0
         for i in range(len(ref_graphs)):
             start, end = end, end + len(n_lig_atoms[i])

@@ -112,3 +112,47 @@ def test_allreduce_gradients_world2():
         assert n_buckets == 2 and grads[3] is None
         for got, ref in zip(grads[:3], want):
             assert torch.allclose(got, ref, atol=1e-6)
+
+
+def _map_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from keypoint_diffusion_amd.dist import common_seed, sharded_map, sharding_active
+    assert sharding_active()
+    n_lig = [5, 9, 3, 7, 4, 11, 2]
+    costs = [600 + n * n for n in n_lig]
+    seen = []
+
+    def fn(mine):                       # stand-in for the reverse loop: ligand c = its global index, sized n_lig[c]
+        seen.extend(mine)
+        return ([torch.full((n_lig[c], 3), float(c)) for c in mine], [torch.full((n_lig[c], 10), 10.0 * c) for c in mine])
+
+    pos, feat = sharded_map(costs, fn)
+    torch.manual_seed(1000 + rank)      # ranks disagree on their generators; the common seed is rank 0's draw
+    q.put((rank, seen, [p.clone() for p in pos], [f.clone() for f in feat], common_seed()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_map_world3_returns_everything_in_input_order():
+    """The plumbing of the sharded sampler (`KeypointDiffusion._sample` under a process group): contiguous cost-balanced shards,
+    one gather, every rank ends with every complex in input order; more ranks than some shards need is fine."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    world = 3
+    procs = [ctx.Process(target=_map_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n_lig = [5, 9, 3, 7, 4, 11, 2]
+    assert sorted(c for r in res for c in r[1]) == list(range(len(n_lig)))         # each complex sampled exactly once
+    assert len({r[4] for r in res}) == 1                                             # one seed for all ranks
+    for rank, seen, pos, feat, _ in res:
+        assert list(seen) == sorted(seen) and len(pos) == len(n_lig)
+        for c, (p, f) in enumerate(zip(pos, feat)):
+            assert p.shape == (n_lig[c], 3) and f.shape == (n_lig[c], 10)
+            assert bool((p == float(c)).all()) and bool((f == 10.0 * c).all())

@@ -172,3 +172,37 @@ def test_step_graph_replays_the_eager_step(cuda, arch):
     bg = G.batch(G.copy_graph(enc, n_copies=2, lig_atoms_per_copy=torch.tensor([6, 9])))
     pos, feat = model.sample_from_encoded_receptors(bg, use_graph=True)
     assert [p.shape for p in pos] == [(6, 3), (9, 3)] and all(torch.isfinite(p).all() for p in pos)
+
+
+def test_sample_sharded_two_ranks_equals_single_process(cuda, tmp_path):
+    """`KeypointDiffusion._sample` under a 2-rank process group (both ranks on cuda:0, gloo): every rank returns ALL ligands in
+    input order, equal to the single-process run of the same noise seed up to fp32 summation order (SURVEY.md 8(e),
+    models/ligand_diffuser.py:292-324)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from . import sharded_worker as W
+    model = W.build_model(cuda).use_complex_noise(W.SEED)
+    ref = model._sample(W.pockets(cuda), W.N_LIG, rec_enc_batch_size=2, diff_batch_size=2)
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / 'shard')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, '-m', 'tests.sharded_worker', out], cwd=root, env=env))
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    for r in range(2):
+        got = torch.load(f'{out}.{r}')['samples']
+        assert len(got) == len(ref)
+        for a, b in zip(got, ref):
+            assert [tuple(p.shape) for p in a['positions']] == [tuple(p.shape) for p in b['positions']]
+            for x, fx in zip(a['positions'], b['positions']):
+                assert util.rel_err(x, fx) < 1e-3
+            for h, fh in zip(a['features'], b['features']):
+                assert util.rel_err(h, fh) < 1e-3
