@@ -73,6 +73,7 @@ struct kpd_egnn {
     std::set<std::string> expected, loaded;
     bool committed = false;
     int debug_layers = -1;
+    int tile_rows = TM;                        // edges per tile of the edge kernel (64, or 32: k_egnn_edge32, four workgroups per CU)
     int prune_last = 1;                        // final layer: only what feeds (h_lig, x_lig) is computed ("prune=0" restores all)
     int edge_chain = -1;                       // 1: register-chained edge kernel (egnn_chain.hip); -1: KPD_EDGE_CHAIN or staged
     // optional HIP-event timing of the dominant kernel (k_egnn_edge), for bench.py's roofline
@@ -176,6 +177,7 @@ extern "C" kpd_status kpd_egnn_create(const kpd_egnn_config *cfg, kpd_egnn **out
     if (st != KPD_OK) return st;
     kpd_egnn *m = new kpd_egnn();
     m->cfg = *cfg;
+    if (const char *e = getenv("KPD_EDGE_ROWS")) m->tile_rows = atoi(e) == 32 ? 32 : TM;
     m->n_et = cfg->update_kp_feat ? 4 : 2;
     m->n_upd = cfg->update_kp_feat ? 2 : 1;
     m->rec_identity = cfg->rec_nf == cfg->hidden_nf;   // dynamics.py:326-334
@@ -380,7 +382,7 @@ extern "C" kpd_status kpd_egnn_reserve(kpd_egnn *m, int32_t max_B, int32_t max_n
     const int E_cap[4] = {cap_ll, cap_kl, cap_kl, std::max(max_n_kk, 1)};
     int tiles[4], tile_cap = 0;
     for (int et = 0; et < 4; ++et) {
-        tiles[et] = cdiv(E_cap[et], TM) + 1;
+        tiles[et] = cdiv(E_cap[et], 32) + 1;          // sized for the finer of the two edge-tile sizes
         tile_cap += tiles[et];
     }
     const int n[2] = {max_n_lig, max_n_kp};
@@ -457,12 +459,14 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
     // the keypoint update feed nothing, so that layer runs the ll + kl edge types and the ligand update only (the GVP
     // reference drops those edge types itself, dynamics_gvp.py:67-72).  A consumer of the h_kp / x_kp debug taps asks for
     // the full layer with "prune=0".
+    const bool use_chain = m->edge_chain >= 0 ? m->edge_chain != 0 : (getenv("KPD_EDGE_CHAIN") && atoi(getenv("KPD_EDGE_CHAIN")) != 0);
+    const int tr = use_chain ? TM : m->tile_rows;         // the register-chained kernel walks 64-edge tiles
     const int active = c.update_kp_feat ? 0xF : 0x3;
     const bool prune = c.update_kp_feat && m->prune_last;
     const int active_last = prune ? 0x3 : active;
     KPD_TRY(launch_egnn_meta(m->lg.counts, bt->n_kk, active, active_last, bt->lig_ptr, bt->kp_ptr, m->lg.ll_per_graph,
                              bt->kk_rowptr, bt->B, m->kl_off, c.message_norm, c.update_kp_feat, m->meta, m->z[NT_LIG],
-                             m->z[NT_KP], st));
+                             m->z[NT_KP], st, tr));
     KPD_TRY(launch_embed(bt->lig_h, bt->n_lig, c.atom_nf, m->le_W0, m->le_b0, 64, m->le_W1t, m->le_b1, t_dev,
                          m->bidx[NT_LIG], m->h[NT_LIG], 0, st));
     KPD_TRY(launch_embed(bt->kp_h, bt->n_kp, c.rec_nf, m->re_W0, m->re_b0, 2 * c.rec_nf, m->re_W1t, m->re_b1, t_dev,
@@ -474,8 +478,8 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
                           bt->n_kk};
     int tile_cap = 0, tile_cap_last = 0;
     for (int et = 0; et < m->n_et; ++et) {
-        tile_cap += cdiv(E_cap[et], TM);
-        if ((active_last >> et) & 1) tile_cap_last += cdiv(E_cap[et], TM);
+        tile_cap += cdiv(E_cap[et], tr);
+        if ((active_last >> et) & 1) tile_cap_last += cdiv(E_cap[et], tr);
     }
 
     const int n[2] = {bt->n_lig, bt->n_kp};
@@ -559,6 +563,7 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
         ea.x[0] = m->x[0]; ea.x[1] = m->x[1]; ea.P[0] = m->P[0]; ea.P[1] = m->P[1];
         ea.use_tanh = c.use_tanh; ea.coords_range = c.coords_range;
         ea.stamps = m->stamps;
+        ea.tile_rows = tr;
         for (int et = 0; et < 4; ++et) {
             ea.src[et] = esrc[et]; ea.dst[et] = edst[et];
             ea.src_nt[et] = kSrcNt[et]; ea.dst_nt[et] = kDstNt[et]; ea.src_slot[et] = kSrcSlot[et]; ea.dst_slot[et] = kDstSlot[et];
@@ -572,8 +577,7 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
         }
         const bool prof = m->prof_on && m->prof_used + 2 <= m->prof_ev.size();
         if (prof) KPD_HIP(hipEventRecord(m->prof_ev[m->prof_used], st));
-        static const bool chain_env = getenv("KPD_EDGE_CHAIN") && atoi(getenv("KPD_EDGE_CHAIN")) != 0;
-        if (m->edge_chain >= 0 ? m->edge_chain != 0 : chain_env) KPD_TRY(launch_egnn_chain(ea, last ? tile_cap_last : tile_cap, st));
+        if (use_chain) KPD_TRY(launch_egnn_chain(ea, last ? tile_cap_last : tile_cap, st));
         else KPD_TRY(launch_egnn_edge(ea, last ? tile_cap_last : tile_cap, st));
         if (prof) {
             KPD_HIP(hipEventRecord(m->prof_ev[m->prof_used + 1], st));
@@ -593,6 +597,7 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
             na.wp_a = L.wp_a[nt]; na.wx_a = L.wx_a[nt]; na.wp_b = L.wp_b[nt]; na.wx_b = L.wx_b[nt]; na.b0 = L.b0[nt];
             na.wp_2 = L.wp_2[nt]; na.wx_2 = L.wx_2[nt]; na.b2 = L.b2[nt]; na.ln_w = L.ln_w[nt]; na.ln_b = L.ln_b[nt];
             na.norm = c.norm;
+            na.tile_shift = tr == 32 ? 5 : 6;
         };
         {
             NodeLayerPair lp;
@@ -634,6 +639,11 @@ extern "C" kpd_status kpd_egnn_debug_state(kpd_egnn *m, const char *what, float 
         return KPD_OK;
     } else if (w.rfind("prune=", 0) == 0) {        // A/B switch of the final-layer pruning (tests: bit-identical eps)
         m->prune_last = atoi(w.c_str() + 6);
+        return KPD_OK;
+    } else if (w.rfind("tile_rows=", 0) == 0) {    // 64 | 32: which staged edge kernel runs (A/B tests)
+        const int r = atoi(w.c_str() + 10);
+        KPD_REQUIRE(r == 32 || r == 64, KPD_ERR_INVALID, "tile_rows must be 32 or 64");
+        m->tile_rows = r;
         return KPD_OK;
     } else if (w.rfind("edge_chain=", 0) == 0) {   // A/B switch between the two edge kernels (tests, profiles/tools)
         m->edge_chain = atoi(w.c_str() + 11);

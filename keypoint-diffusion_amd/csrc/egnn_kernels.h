@@ -10,7 +10,8 @@ constexpr int BIAS_K = 257;          // A-tile column that holds the constant 1 
 constexpr int ET_LL = 0, ET_KL = 1, ET_LK = 2, ET_KK = 3;
 constexpr int NT_LIG = 0, NT_KP = 1;
 
-constexpr int EDGE_LDS_BYTES = TM * SA * 4 + (TM * 2 + TM + 3 * TM + TM + 3 * TM + 2 * HS + 8) * 4;
+constexpr int EDGE_LDS_BYTES = TM * SA * 4 + (TM * 2 + TM + 3 * TM + TM + 3 * TM + 4 * HS + 8) * 4;
+constexpr int EDGE32_LDS_BYTES = 32 * SA * 4 + (32 * 2 + 32 + 3 * 32 + 32 + 3 * 32 + 2 * HS + 8) * 4;     // k_egnn_edge32
 
 struct ProjArgs {
     const float *h;                 // [n][HS]
@@ -50,6 +51,8 @@ struct EdgeArgs {
     int use_tanh;
     float coords_range;
     unsigned long long *stamps;     // [16] phase-cycle sums, diagnostics only (null in production)
+    int tile_rows;                  // edges per tile: 64 (k_egnn_edge<NW>, k_egnn_chain) or 32 (k_egnn_edge32)
+    int ablate;                     // timing experiments only (KPD_EDGE_ABLATE), 0 in production
 };
 
 struct NodeArgs {
@@ -66,6 +69,7 @@ struct NodeArgs {
     const float *wp_2, *wx_2, *b2;
     const float *ln_w, *ln_b;
     int norm;
+    int tile_shift;                 // log2 of the edge-tile size the segment pieces (main / cont) were written with
 };
 
 // Fused node kernel (32-node tiles): [update of layer i] -> [first-layer projections of layer i + 1].
@@ -93,7 +97,7 @@ kpd_status egnn_kernels_init();
 kpd_status launch_node_graph_index(const int *ptr, int B, int n, int *bidx, hipStream_t st);
 kpd_status launch_egnn_meta(const int *counts, int e_kk, int active_mask, int active_last, const int *lig_ptr, const int *kp_ptr,
                             const int *ll_per_graph, const int *kk_rowptr, int B, const int *kl_off, float message_norm,
-                            int update_kp, int *meta, float *z_lig, float *z_kp, hipStream_t st);
+                            int update_kp, int *meta, float *z_lig, float *z_kp, hipStream_t st, int tile_rows = TM);
 kpd_status launch_embed(const float *in, int n, int fin, const float *W0, const float *b0, int hid, const float *W1t,
                         const float *b1, const float *t, const int *bidx, float *out, int identity, hipStream_t st);
 kpd_status launch_decode(const float *h, const float *x, const float *x0, int n, int atom_nf, int hid, const float *W0,

@@ -41,7 +41,7 @@ __global__ void k_node_graph_index(const int *__restrict__ ptr, int B, int n, in
 __global__ void k_egnn_meta(const int *__restrict__ counts, int e_kk, int active_mask, int active_last, const int *__restrict__ lig_ptr,
                             const int *__restrict__ kp_ptr, const int *__restrict__ ll_per_graph,
                             const int *__restrict__ kk_rowptr, int B, const int *__restrict__ kl_off, float message_norm,
-                            int update_kp, int *__restrict__ meta, float *__restrict__ z_lig, float *__restrict__ z_kp) {
+                            int update_kp, int tile_rows, int *__restrict__ meta, float *__restrict__ z_lig, float *__restrict__ z_kp) {
     if (blockIdx.x == 0 && threadIdx.x < 2) {
         const int mask = threadIdx.x ? active_last : active_mask;
         int *mt = meta + 16 * threadIdx.x;
@@ -51,7 +51,7 @@ __global__ void k_egnn_meta(const int *__restrict__ counts, int e_kk, int active
             if (!((mask >> et) & 1)) E[et] = 0;
             mt[et] = E[et];
             mt[4 + et] = run;
-            run += (E[et] + TM - 1) / TM;
+            run += (E[et] + tile_rows - 1) / tile_rows;
         }
         mt[8] = run;
     }
@@ -154,7 +154,7 @@ struct EdgeSmem {
     float *A;
     int *src, *dst;
     float *d, *xd, *att, *mx;
-    float *wv;          // [2][HS]: soft-attention row (+bias at ATT_BIAS_AT) and coordinate head row
+    float *wv;          // [4][HS]: soft-attention row (+bias at ATT_BIAS_AT), coordinate head row, W2[256, :] of edge_mlp / coord_mlp
     int *misc;          // [0] first run continues the previous tile, [2..3] segment-end mask, [4..5] head mask
 };
 
@@ -168,7 +168,7 @@ __device__ __forceinline__ EdgeSmem edge_smem(float *smem) {
     s.att = s.xd + 3 * TM;
     s.mx = s.att + TM;
     s.wv = s.mx + 3 * TM;
-    s.misc = reinterpret_cast<int *>(s.wv + 2 * HS);
+    s.misc = reinterpret_cast<int *>(s.wv + 4 * HS);
     return s;
 }
 
@@ -270,7 +270,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
     const EdgeSmem s = edge_smem(smem);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     unsigned long long t_prev_ = a.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-
     // tile decode (XCD-aware: consecutive tiles -- neighbouring edges of one complex, which
     // share P rows -- go to the same XCD / L2)
     const int T = a.meta[8];
@@ -316,13 +315,19 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
             s.misc[4] = (int)(heads & 0xffffffffu);
             s.misc[5] = (int)(heads >> 32);
         }
-    } else if (tid < TM + 66) {
-        const int i = tid - TM;          // 66 float4 = one HS row
-        reinterpret_cast<f32x4 *>(s.wv)[i] = reinterpret_cast<const f32x4 *>(a.watt[et])[i];
-    } else if (tid < TM + 132) {
-        const int i = tid - TM - 66;
-        reinterpret_cast<f32x4 *>(s.wv + HS)[i] = reinterpret_cast<const f32x4 *>(a.w3[et])[i];
+    } else {
+        // four HS rows to LDS: soft-attention row, coordinate-head row, and row 256 of W2 of either branch (the "+1" output
+        // column is a per-row dot on the VALU; from LDS it needs no global round trip next to the GEMM)
+        // (no pointer array: pointers that pass through private memory lose their address space and turn every later load
+        // through them into a flat load with full waits)
+        for (int i = tid - TM; i < 4 * 66; i += 64 * NW - TM) {
+            const int which = i / 66, j = i - which * 66;      // 66 float4 = one HS row
+            const float *row = which == 0 ? a.watt[et] : which == 1 ? a.w3[et] : which == 2 ? a.wx_e[et] : a.wx_c[et];
+            reinterpret_cast<f32x4 *>(s.wv + which * HS)[j] = reinterpret_cast<const f32x4 *>(row)[j];
+        }
     }
+    [[maybe_unused]] BPrefetch bpre;
+    if constexpr (NW == 4) gemm_b_prefetch(bpre, a.wp_e[et], wave, lane);     // lands during the gather / A-build
     lds_barrier();
     KPD_STAMP(0)
 
@@ -335,23 +340,31 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
     float ex;
 
     // ---- feature messages: m = edge_mlp(f); msg_h = m * sigmoid(att(m)) (dynamics.py:111-112)
-    build_edge_A<NW>(s, Ps, Pd, a.wr_e[et], wave, lane);
+    const int abl = a.ablate;             // timing experiments only (KPD_EDGE_ABLATE): 1 no GEMM, 2 no A-build, 4 no epilogues
+    if (!(abl & 2)) build_edge_A<NW>(s, Ps, Pd, a.wr_e[et], wave, lane);
     lds_barrier();
     KPD_STAMP(1)
     acc_zero_w<NW>(acc);
-    gemm_rows64_w<NW, NG, SA>(s.A, a.wp_e[et], acc, wave, lane);
-    ex = row_dot_chunks<TPR>(s.A, a.wx_e[et], KP / 4, tid);
+    ex = (abl & 4) ? 0.0f : row_dot_chunks<TPR>(s.A, s.wv + 2 * HS, KP / 4, tid);
+    if (!(abl & 1)) {
+        if constexpr (NW == 4) gemm_rows64_pre<NG, SA>(s.A, a.wp_e[et], acc, wave, lane, bpre);
+        else gemm_rows64_w<NW, NG, SA>(s.A, a.wp_e[et], acc, wave, lane);
+    }
+    if constexpr (NW == 4) gemm_b_prefetch(bpre, a.wp_c[et], wave, lane);     // for the coordinate GEMM, four phases away
     lds_barrier();
     KPD_STAMP(2)
-    store_T_silu_w<NW, true>(s.A, acc, ex, a.b_e[et], tid, wave, lane);
+    if (!(abl & 4)) store_T_silu_w<NW, true>(s.A, acc, ex, a.b_e[et], tid, wave, lane);
+    else if (acc[0][0][0] == 12345.0f) s.A[tid] = acc[1][NW == 4 ? 1 : 0][3] + acc[0][NW == 4 ? 1 : 0][5] + acc[1][0][7];
     EdgeGather<NW == 4 ? 4 : TM> gc;      // (one row per wave, unused, in the 8-wave build)
     if constexpr (NW == 4) {  // the coordinate branch's P rows start travelling now; consumed after the segmented sum below
+        if (!(abl & 2)) {
         edge_gather_issue<NW>(gc, s, Ps + HS, Pd + HS, wave, lane);
         __builtin_amdgcn_sched_barrier(0);
+        }
     }
     lds_barrier();
     KPD_STAMP(3)
-    {
+    if (!(abl & 4)) {
         float dot = row_dot_chunks<TPR>(s.A, s.wv, 64, tid);
         const int row = tid / TPR;
         if ((tid % TPR) == 0) {
@@ -362,7 +375,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
     }
     lds_barrier();
     KPD_STAMP(4)
-    {
+    if (!(abl & 4)) {
         // segmented sum over dst (dynamics.py:182-185): thread = column, rows in order; the run
         // boundaries are wave-uniform (endmask), LDS reads are issued 16 rows at a time
         float *hmain = a.hn_main[et], *hcont = a.hn_cont[et] + (size_t)tile_in_et * HS;
@@ -413,19 +426,25 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
     KPD_STAMP(5)
 
     // ---- coordinate messages: msg_x = tanh(coord_mlp(f)) * x_diff * range (dynamics.py:113-120)
+    if (!(abl & 2)) {
     if constexpr (NW == 4) edge_gather_finish<NW>(gc, s, a.wr_c[et], wave, lane);
     else build_edge_A<NW>(s, Ps + HS, Pd + HS, a.wr_c[et], wave, lane);
+    }
     lds_barrier();
     KPD_STAMP(6)
     acc_zero_w<NW>(acc);
-    gemm_rows64_w<NW, NG, SA>(s.A, a.wp_c[et], acc, wave, lane);
-    ex = row_dot_chunks<TPR>(s.A, a.wx_c[et], KP / 4, tid);
+    ex = (abl & 4) ? 0.0f : row_dot_chunks<TPR>(s.A, s.wv + 3 * HS, KP / 4, tid);
+    if (!(abl & 1)) {
+        if constexpr (NW == 4) gemm_rows64_pre<NG, SA>(s.A, a.wp_c[et], acc, wave, lane, bpre);
+        else gemm_rows64_w<NW, NG, SA>(s.A, a.wp_c[et], acc, wave, lane);
+    }
     lds_barrier();
     KPD_STAMP(7)
-    store_T_silu_w<NW, true>(s.A, acc, ex, a.b_c[et], tid, wave, lane);
+    if (!(abl & 4)) store_T_silu_w<NW, true>(s.A, acc, ex, a.b_c[et], tid, wave, lane);
+    else if (acc[0][0][0] == 12345.0f) s.A[tid] = acc[1][NW == 4 ? 1 : 0][3] + acc[0][NW == 4 ? 1 : 0][5] + acc[1][0][7];
     lds_barrier();
     KPD_STAMP(8)
-    {
+    if (!(abl & 4)) {
         float dot = row_dot_chunks<TPR>(s.A, s.wv + HS, 64, tid);
         const int row = tid / TPR;
         if ((tid % TPR) == 0) {
@@ -439,7 +458,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
     }
     lds_barrier();
     KPD_STAMP(9)
-    if (wave == 0) {
+    if (wave == 0 && !(abl & 4)) {
         // segmented inclusive scan across lanes (lane = row), then the last lane of every run writes
         const unsigned long long heads =
             ((unsigned long long)(unsigned)s.misc[5] << 32) | (unsigned long long)(unsigned)s.misc[4];
@@ -459,6 +478,296 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
             const int piece = __popcll(endmask & ((1ull << lane) - 1ull));
             float *out = (piece == 0 && first_is_cont) ? a.xn_cont[et] + (size_t)tile_in_et * 4
                                                        : a.xn_main[et] + (size_t)s.dst[lane] * 4;
+            out[0] = vx;
+            out[1] = vy;
+            out[2] = vz;
+        }
+    }
+    KPD_STAMP(10)
+}
+
+
+// ---- 32-row form of the fused edge kernel ---------------------------------------------------------------------
+// Same phases as k_egnn_edge<4> on tiles of 32 edges: the A / T tile is 34 KB instead of 69 KB and a wave needs 32
+// accumulator registers instead of 64, so FOUR independent workgroups share a CU (4 waves per SIMD, <= 128 VGPRs)
+// instead of two.  The f32 MFMA and the VALU are one pipe on gfx950, so the only time that pipe can win back is the
+// time in which every resident wave of a SIMD sits in a gather, an LDS round trip or a barrier at once: with two
+// co-resident workgroups that is ~15 % of the kernel (PMC: MFMA busy 67 % + VALU active 16 %), with four
+// independent ones it mostly disappears.  Price: every weight fragment streamed from L2 feeds one 32-row MFMA tile
+// instead of two (2x L2 -> CU weight traffic, ~8 B/clk/CU), and twice as many tiles pay the per-tile prologue.
+constexpr int R32 = 32;
+
+struct EdgeSmem32 {
+    float *A;
+    int *src, *dst;
+    float *d, *xd, *att, *mx, *wv;
+    int *misc;
+};
+
+__device__ __forceinline__ EdgeSmem32 edge_smem32(float *smem) {
+    EdgeSmem32 s;
+    s.A = smem;
+    s.src = reinterpret_cast<int *>(smem + R32 * SA);
+    s.dst = s.src + R32;
+    s.d = reinterpret_cast<float *>(s.dst + R32);
+    s.xd = s.d + R32;
+    s.att = s.xd + 3 * R32;
+    s.mx = s.att + R32;
+    s.wv = s.mx + 3 * R32;
+    s.misc = reinterpret_cast<int *>(s.wv + 2 * HS);
+    return s;
+}
+
+struct EdgeGather32 {
+    static constexpr int RPW = R32 / 4;
+    f32x4 ps[RPW], pd[RPW];
+    f32x4 tps, tpd;
+};
+
+__device__ __forceinline__ void edge_gather_issue32(EdgeGather32 &g, const EdgeSmem32 &s, const float *__restrict__ Ps,
+                                                    const float *__restrict__ Pd, int wave, int lane) {
+    constexpr int RPW = EdgeGather32::RPW;
+    // 32-bit byte offsets from a wave-uniform base: P is far below 4 GB, and 64-bit multiplies per row are VALU time
+    constexpr unsigned PROW_B = NSLOT * HS * 4;
+    const char *ps = reinterpret_cast<const char *>(Ps), *pd = reinterpret_cast<const char *>(Pd);
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int r = wave * RPW + rr;
+        g.ps[rr] = *reinterpret_cast<const f32x4 *>(ps + ((unsigned)s.src[r] * PROW_B + 16u * lane));
+        g.pd[rr] = *reinterpret_cast<const f32x4 *>(pd + ((unsigned)s.dst[r] * PROW_B + 16u * lane));
+    }
+    if (lane < 4 * RPW && (lane & 3) < 2) {
+        const int r = wave * RPW + (lane >> 2), c = lane & 3;
+        g.tps = *reinterpret_cast<const f32x4 *>(ps + ((unsigned)s.src[r] * PROW_B + 16u * (64 + c)));
+        g.tpd = *reinterpret_cast<const f32x4 *>(pd + ((unsigned)s.dst[r] * PROW_B + 16u * (64 + c)));
+    }
+}
+
+__device__ __forceinline__ void edge_gather_finish32(const EdgeGather32 &g, const EdgeSmem32 &s, const float *__restrict__ wr,
+                                                     int wave, int lane) {
+    constexpr int RPW = EdgeGather32::RPW;
+    const f32x4 w0 = reinterpret_cast<const f32x4 *>(wr)[lane];
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int r = wave * RPW + rr;
+        f32x4 v = g.ps[rr] + g.pd[rr] + s.d[r] * w0;
+        v[0] = silu_pre(v[0]); v[1] = silu_pre(v[1]); v[2] = silu_pre(v[2]); v[3] = silu_pre(v[3]);
+        *reinterpret_cast<f32x4 *>(s.A + r * SA + 4 * lane) = v;
+    }
+    if (lane < 4 * RPW && (lane & 3) < 2) {
+        const int r = wave * RPW + (lane >> 2), c = lane & 3;
+        const f32x4 w1 = reinterpret_cast<const f32x4 *>(wr)[64 + c];
+        f32x4 u = g.tps + g.tpd + s.d[r] * w1;
+        u[0] = silu_pre(u[0]); u[1] = silu_pre(u[1]); u[2] = silu_pre(u[2]); u[3] = silu_pre(u[3]);
+        if (c == 0) u[BIAS_K - 256] = 1.0f;
+        *reinterpret_cast<f32x4 *>(s.A + r * SA + 256 + 4 * c) = u;
+    }
+}
+
+// T[row][col] = c SiLU(.) from the accumulators of a 32-row tile (bias already inside the GEMM)
+__device__ __forceinline__ void store_T_silu32(float *T, const f32x16 (&acc)[2], float ex, int tid, int wave, int lane) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int col = acc_col(nt, wave, lane);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) T[acc_row32(reg, lane) * SA + col] = silu_pre(acc[nt][reg]);
+    }
+    if ((tid & 7) == 0) T[(tid >> 3) * SA + 256] = silu_pre(ex);
+}
+
+__global__ __launch_bounds__(256, 4) void k_egnn_edge32(EdgeArgs a) {
+    constexpr int TPR = 256 / R32;       // 8 threads per row in the row-wise passes
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const EdgeSmem32 s = edge_smem32(smem);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    unsigned long long t_prev_ = a.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+
+    const int T = a.meta[8];
+    const int chunk = (T + 7) >> 3;
+    const int bi = blockIdx.x >> 3;
+    if (bi >= chunk) return;
+    const int tile = (blockIdx.x & 7) * chunk + bi;
+    if (tile >= T) return;
+    int et = 0;
+#pragma unroll
+    for (int e = 1; e < 4; ++e)
+        if (tile >= a.meta[4 + e]) et = e;
+    const int tile_in_et = tile - a.meta[4 + et];
+    const int e0 = tile_in_et * R32;
+    const int ne = min(R32, a.meta[et] - e0);
+    const int snt = a.src_nt[et], dnt = a.dst_nt[et];
+    const int *__restrict__ esrc = a.src[et];
+    const int *__restrict__ edst = a.dst[et];
+
+    // phase 0: edge endpoints, geometry and run masks (lanes 0..31 of wave 0), head weights (waves 1..3)
+    if (tid < 64) {
+        const bool on = tid < R32;
+        const int e = e0 + min(tid, ne - 1);
+        const int u = esrc[e], v = edst[e];
+        const float *xs = a.x[snt] + (size_t)u * 3, *xd = a.x[dnt] + (size_t)v * 3;
+        const float dx = xs[0] - xd[0], dy = xs[1] - xd[1], dz = xs[2] - xd[2];
+        const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float inv = 1.0f / (d + 1.0f);
+        if (on) {
+            s.src[tid] = u;
+            s.dst[tid] = v;
+            s.d[tid] = d;
+            s.xd[3 * tid] = dx * inv;
+            s.xd[3 * tid + 1] = dy * inv;
+            s.xd[3 * tid + 2] = dz * inv;
+        }
+        const int vprev = tid > 0 ? edst[e0 + min(tid - 1, ne - 1)] : (e0 > 0 ? edst[e0 - 1] : -1);
+        const int vnext = tid + 1 < ne ? edst[e0 + tid + 1] : -2;
+        const unsigned long long heads = __ballot(tid < ne && (tid == 0 || vprev != v));
+        const unsigned long long ends = __ballot(tid < ne && vnext != v);
+        if (tid == 0) {
+            s.misc[0] = (vprev == v) ? 1 : 0;
+            s.misc[2] = (int)(ends & 0xffffffffu);
+            s.misc[4] = (int)(heads & 0xffffffffu);
+        }
+    } else if (tid < 64 + 66) {
+        const int i = tid - 64;
+        reinterpret_cast<f32x4 *>(s.wv)[i] = reinterpret_cast<const f32x4 *>(a.watt[et])[i];
+    } else if (tid < 64 + 132) {
+        const int i = tid - 64 - 66;
+        reinterpret_cast<f32x4 *>(s.wv + HS)[i] = reinterpret_cast<const f32x4 *>(a.w3[et])[i];
+    }
+    lds_barrier();
+    KPD_STAMP(0)
+
+    const float *Ps = a.P[snt] + (size_t)a.src_slot[et] * HS;
+    const float *Pd = a.P[dnt] + (size_t)a.dst_slot[et] * HS;
+    const int first_is_cont = s.misc[0];
+    const unsigned endmask = (unsigned)s.misc[2];
+    const unsigned headmask = (unsigned)s.misc[4];
+    f32x16 acc[2];
+    float ex;
+
+    // ---- feature messages (dynamics.py:111-112)
+    {
+        EdgeGather32 g;
+        edge_gather_issue32(g, s, Ps, Pd, wave, lane);
+        edge_gather_finish32(g, s, a.wr_e[et], wave, lane);
+    }
+    lds_barrier();
+    KPD_STAMP(1)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.0f;
+    gemm_rows32_t<NG, SA>(s.A, a.wp_e[et], acc, wave, lane);
+    ex = row_dot_chunks<TPR>(s.A, a.wx_e[et], KP / 4, tid);
+    lds_barrier();
+    KPD_STAMP(2)
+    store_T_silu32(s.A, acc, ex, tid, wave, lane);
+    EdgeGather32 gc;          // the coordinate branch's P rows travel during the attention / segmented-sum phases
+    edge_gather_issue32(gc, s, Ps + HS, Pd + HS, wave, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();
+    KPD_STAMP(3)
+    {
+        float dot = row_dot_chunks<TPR>(s.A, s.wv, 64, tid);
+        const int row = tid / TPR;
+        if ((tid % TPR) == 0) {
+            dot = fmaf(s.A[row * SA + 256], s.wv[256], dot);
+            s.att[row] = row < ne ? sigmoidf_(dot + s.wv[ATT_BIAS_AT]) * (1.0f / SILU_C) : 0.0f;
+        }
+    }
+    lds_barrier();
+    KPD_STAMP(4)
+    {
+        float *hmain = a.hn_main[et], *hcont = a.hn_cont[et] + (size_t)tile_in_et * HS;
+        {
+            float run = 0.0f;
+            int piece = 0;
+#pragma unroll 1
+            for (int r0 = 0; r0 < R32; r0 += 16) {
+                if (r0 >= ne) break;
+                float v[16], w[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    w[i] = s.att[r0 + i];
+                    v[i] = s.A[(r0 + i) * SA + tid];
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    run = fmaf(v[i], w[i], run);
+                    if ((endmask >> (r0 + i)) & 1u) {
+                        float *out = (piece == 0 && first_is_cont) ? hcont : hmain + (size_t)s.dst[r0 + i] * HS;
+                        out[tid] = run;
+                        run = 0.0f;
+                        ++piece;
+                    }
+                }
+            }
+        }
+        // column 256: lane = row on the last wave (lanes >= 32 carry zeros), segmented inclusive scan across lanes
+        if (wave == 3) {
+            const int rl = lane & 31;
+            const unsigned upto = rl == 31 ? ~0u : ((1u << (rl + 1)) - 1u);
+            const int start = 31 - __clz((int)((headmask & upto) | 1u));
+            float v = lane < R32 ? s.A[rl * SA + 256] * s.att[rl] : 0.0f;
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) {
+                const float t = __shfl_up(v, off);
+                if (rl - off >= start) v += t;
+            }
+            if (lane < R32 && ((endmask >> rl) & 1u)) {
+                const int pc = __popc(endmask & ((1u << rl) - 1u));
+                float *out = (pc == 0 && first_is_cont) ? hcont : hmain + (size_t)s.dst[rl] * HS;
+                out[256] = v;
+            }
+        }
+    }
+    lds_barrier();
+    KPD_STAMP(5)
+
+    // ---- coordinate messages (dynamics.py:113-120)
+    edge_gather_finish32(gc, s, a.wr_c[et], wave, lane);
+    lds_barrier();
+    KPD_STAMP(6)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.0f;
+    gemm_rows32_t<NG, SA>(s.A, a.wp_c[et], acc, wave, lane);
+    ex = row_dot_chunks<TPR>(s.A, a.wx_c[et], KP / 4, tid);
+    lds_barrier();
+    KPD_STAMP(7)
+    store_T_silu32(s.A, acc, ex, tid, wave, lane);
+    lds_barrier();
+    KPD_STAMP(8)
+    {
+        float dot = row_dot_chunks<TPR>(s.A, s.wv + HS, 64, tid);
+        const int row = tid / TPR;
+        if ((tid % TPR) == 0) {
+            dot = fmaf(s.A[row * SA + 256], s.wv[HS + 256], dot);
+            float c = a.use_tanh ? tanhf(dot) * a.coords_range : dot;
+            if (row >= ne) c = 0.0f;
+            s.mx[3 * row] = c * s.xd[3 * row];
+            s.mx[3 * row + 1] = c * s.xd[3 * row + 1];
+            s.mx[3 * row + 2] = c * s.xd[3 * row + 2];
+        }
+    }
+    lds_barrier();
+    KPD_STAMP(9)
+    if (wave == 0) {
+        const int rl = lane & 31;
+        const unsigned upto = rl == 31 ? ~0u : ((1u << (rl + 1)) - 1u);
+        const int start = 31 - __clz((int)((headmask & upto) | 1u));
+        float vx = 0.f, vy = 0.f, vz = 0.f;
+        if (lane < R32) {
+            vx = s.mx[3 * rl]; vy = s.mx[3 * rl + 1]; vz = s.mx[3 * rl + 2];
+        }
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) {
+            const float tx = __shfl_up(vx, off), ty = __shfl_up(vy, off), tz = __shfl_up(vz, off);
+            if (rl - off >= start) {
+                vx += tx;
+                vy += ty;
+                vz += tz;
+            }
+        }
+        if (lane < R32 && ((endmask >> rl) & 1u)) {
+            const int piece = __popc(endmask & ((1u << rl) - 1u));
+            float *out = (piece == 0 && first_is_cont) ? a.xn_cont[et] + (size_t)tile_in_et * 4
+                                                       : a.xn_main[et] + (size_t)s.dst[rl] * 4;
             out[0] = vx;
             out[1] = vy;
             out[2] = vz;
@@ -521,7 +830,7 @@ __global__ __launch_bounds__(256, 3) void k_node_layer(NodeLayerPair p) {
                     if (hi > lo) {
                         const float *pm = a.xn_main[i] + (size_t)v * 4;
                         sx += pm[0]; sy += pm[1]; sz += pm[2];
-                        for (int t = lo / TM + 1; t <= (hi - 1) / TM; ++t) {
+                        for (int t = (lo >> a.tile_shift) + 1; t <= ((hi - 1) >> a.tile_shift); ++t) {
                             const float *q = a.xn_cont[i] + (size_t)t * 4;
                             sx += q[0]; sy += q[1]; sz += q[2];
                         }
@@ -555,7 +864,7 @@ __global__ __launch_bounds__(256, 3) void k_node_layer(NodeLayerPair p) {
                         const f32x4 *pm = reinterpret_cast<const f32x4 *>(a.hn_main[i] + (size_t)v * HS);
                         val += pm[lane];
                         if (lane < 2) val2 += pm[64 + lane];
-                        for (int t = lo / TM + 1; t <= (hi - 1) / TM; ++t) {
+                        for (int t = (lo >> a.tile_shift) + 1; t <= ((hi - 1) >> a.tile_shift); ++t) {
                             const f32x4 *q = reinterpret_cast<const f32x4 *>(a.hn_cont[i] + (size_t)t * HS);
                             val += q[lane];
                             if (lane < 2) val2 += q[64 + lane];
@@ -759,7 +1068,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                     if (hi > lo) {
                         const float *pm = a.xn_main[i] + (size_t)v * 4;
                         sx += pm[0]; sy += pm[1]; sz += pm[2];
-                        for (int t = lo / TM + 1; t <= (hi - 1) / TM; ++t) {
+                        for (int t = (lo >> a.tile_shift) + 1; t <= ((hi - 1) >> a.tile_shift); ++t) {
                             const float *q = a.xn_cont[i] + (size_t)t * 4;
                             sx += q[0]; sy += q[1]; sz += q[2];
                         }
@@ -793,7 +1102,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                         const f32x4 *pm = reinterpret_cast<const f32x4 *>(a.hn_main[i] + (size_t)v * HS);
                         val += pm[lane];
                         if (lane < 2) val2 += pm[64 + lane];
-                        for (int t = lo / TM + 1; t <= (hi - 1) / TM; ++t) {
+                        for (int t = (lo >> a.tile_shift) + 1; t <= ((hi - 1) >> a.tile_shift); ++t) {
                             const f32x4 *q = reinterpret_cast<const f32x4 *>(a.hn_cont[i] + (size_t)t * HS);
                             val += q[lane];
                             if (lane < 2) val2 += q[64 + lane];
@@ -919,6 +1228,8 @@ kpd_status egnn_kernels_init() {
                                 160 * 1024));
     KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_egnn_edge<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024));
+    KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_egnn_edge32), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024));
     KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_layer), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024));
     KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_update8), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -936,9 +1247,9 @@ kpd_status launch_node_graph_index(const int *ptr, int B, int n, int *bidx, hipS
 
 kpd_status launch_egnn_meta(const int *counts, int e_kk, int active_mask, int active_last, const int *lig_ptr, const int *kp_ptr,
                             const int *ll_per_graph, const int *kk_rowptr, int B, const int *kl_off, float message_norm,
-                            int update_kp, int *meta, float *z_lig, float *z_kp, hipStream_t st) {
+                            int update_kp, int *meta, float *z_lig, float *z_kp, hipStream_t st, int tile_rows) {
     hipLaunchKernelGGL(k_egnn_meta, dim3(cdiv(B, 256)), dim3(256), 0, st, counts, e_kk, active_mask, active_last, lig_ptr, kp_ptr,
-                       ll_per_graph, kk_rowptr, B, kl_off, message_norm, update_kp, meta, z_lig, z_kp);
+                       ll_per_graph, kk_rowptr, B, kl_off, message_norm, update_kp, tile_rows, meta, z_lig, z_kp);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
 }
@@ -971,10 +1282,18 @@ kpd_status launch_egnn_edge(const EdgeArgs &a, int tile_cap, hipStream_t st) {
     // 4 waves per workgroup by default: 256 VGPRs per lane leave room to keep the coordinate branch's gathered P rows in
     // registers across the attention / segmented-sum phases (1.00 vs 1.04 ms); KPD_EDGE_NW=8 selects the 8-wave build
     static const int nw = getenv("KPD_EDGE_NW") ? atoi(getenv("KPD_EDGE_NW")) : 4;
+    static const int ablate = getenv("KPD_EDGE_ABLATE") ? atoi(getenv("KPD_EDGE_ABLATE")) : 0;
+    EdgeArgs b = a;
+    b.ablate = ablate;
+    if (a.tile_rows == R32) {
+        hipLaunchKernelGGL(k_egnn_edge32, dim3(8 * cdiv(tile_cap, 8)), dim3(256), EDGE32_LDS_BYTES + pad, st, b);
+        KPD_LAUNCH_CHECK();
+        return KPD_OK;
+    }
     if (nw == 4)
-        hipLaunchKernelGGL(k_egnn_edge<4>, dim3(8 * cdiv(tile_cap, 8)), dim3(256), EDGE_LDS_BYTES + pad, st, a);
+        hipLaunchKernelGGL(k_egnn_edge<4>, dim3(8 * cdiv(tile_cap, 8)), dim3(256), EDGE_LDS_BYTES + pad, st, b);
     else
-        hipLaunchKernelGGL(k_egnn_edge<8>, dim3(8 * cdiv(tile_cap, 8)), dim3(512), EDGE_LDS_BYTES + pad, st, a);
+        hipLaunchKernelGGL(k_egnn_edge<8>, dim3(8 * cdiv(tile_cap, 8)), dim3(512), EDGE_LDS_BYTES + pad, st, b);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
 }

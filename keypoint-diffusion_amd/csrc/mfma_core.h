@@ -60,6 +60,59 @@ __device__ __forceinline__ void acc_zero(f32x16 (&acc)[2][2]) {
     B1 = bp[(G) * 512 + 1];
 
 // NG_ = k-groups of 8 (K padded to 8 NG_), SA_ = LDS row stride of the A tile in floats.
+// Pointer with an explicit global address space: when address-space inference loses track of a pointer (it did for the
+// in-loop weight loads of gemm_rows64_pre) hipcc falls back to flat loads, which wait on vmcnt(0) and lgkmcnt(0) together
+// and serialise the prefetch.
+typedef __attribute__((address_space(1))) const f32x4 gf32x4;
+__device__ __forceinline__ gf32x4 *as_global(const f32x4 *p) { return (gf32x4 *)p; }
+
+// The weight fragments of k-groups 0 and 1 of a block, issued by the caller long before the GEMM (they depend on the edge
+// type only, not on the tile): the first MFMAs then wait for two LDS reads instead of an L2 round trip.
+struct BPrefetch {
+    f32x4 x0, x1, y0, y1;
+};
+__device__ __forceinline__ void gemm_b_prefetch(BPrefetch &p, const float *__restrict__ Wp, int wave, int lane) {
+    gf32x4 *bp = as_global(reinterpret_cast<const f32x4 *>(Wp) + (wave * 64 + lane) * 2);
+    p.x0 = bp[0];
+    p.x1 = bp[1];
+    p.y0 = bp[512];
+    p.y1 = bp[513];
+}
+
+template <int NG_, int SA_>
+__device__ __forceinline__ void gemm_rows64_pre(const float *__restrict__ A, const float *__restrict__ Wp,
+                                                f32x16 (&acc)[2][2], int wave, int lane, const BPrefetch &pre) {
+    static_assert(NG_ > 2, "prefetched form needs more than two k-groups");
+    const int r = lane & 31, h = lane >> 5;
+    const float *a0p = A + r * SA_ + 4 * h;
+    const float *a1p = A + (32 + r) * SA_ + 4 * h;
+    gf32x4 *bp = as_global(reinterpret_cast<const f32x4 *>(Wp) + (wave * 64 + lane) * 2);
+    f32x4 xa0, xa1, xb0 = pre.x0, xb1 = pre.x1, ya0, ya1, yb0 = pre.y0, yb1 = pre.y1;
+    xa0 = *reinterpret_cast<const f32x4 *>(a0p);
+    xa1 = *reinterpret_cast<const f32x4 *>(a1p);
+    ya0 = *reinterpret_cast<const f32x4 *>(a0p + 8);
+    ya1 = *reinterpret_cast<const f32x4 *>(a1p + 8);
+    constexpr int PAIRS = NG_ / 2;
+#pragma unroll 1
+    for (int p = 0; p < PAIRS; ++p) {
+        const int g = 2 * p;
+        __builtin_amdgcn_sched_barrier(0);
+        KPD_GEMM_STEP(xa0, xa1, xb0, xb1)
+        __builtin_amdgcn_sched_barrier(0);
+        const int g2 = g + 2 < NG_ ? g + 2 : NG_ - 1;
+        KPD_GEMM_LOAD(xa0, xa1, xb0, xb1, g2)
+        __builtin_amdgcn_sched_barrier(0);
+        KPD_GEMM_STEP(ya0, ya1, yb0, yb1)
+        __builtin_amdgcn_sched_barrier(0);
+        const int g3 = g + 3 < NG_ ? g + 3 : NG_ - 1;
+        KPD_GEMM_LOAD(ya0, ya1, yb0, yb1, g3)
+    }
+    if (NG_ & 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        KPD_GEMM_STEP(xa0, xa1, xb0, xb1)
+    }
+}
+
 template <int NG_, int SA_>
 __device__ __forceinline__ void gemm_rows64_t(const float *__restrict__ A, const float *__restrict__ Wp,
                                               f32x16 (&acc)[2][2], int wave, int lane) {
