@@ -85,6 +85,68 @@ def test_c5_ragged_gvp_properties(cuda):
     assert util.rel_err(xr, x @ R.T) < 1e-4
 
 
+def test_c3_gvp_40kp_full_batch_properties(cuda):
+    """configs[2]: gvp_40kp, B = 64 x (300 receptor atoms -> 40 learned keypoints, 25 ligand atoms): learned GVP receptor
+    encoder -> GVP denoiser (trained_models/gvp_40kp/config.yml:51-62, 90-102), through the size-independent properties of the
+    C2 test: bitwise run-to-run equality, an oracle slice (encoder and denoiser), batch independence, E(3)."""
+    from keypoint_diffusion_amd.ligand_diffuser import KeypointDiffusion
+    from oracle import gvp as ogvp
+    from oracle import rec_encoder as orec
+    from .test_gvp_gpu import GVP_40KP
+    from .test_recenc_gpu import RECENC_40KP
+    B = 64
+    cut = dict(CUT, kl=8, ll=6.0)
+    rec_cfg = {k: v for k, v in RECENC_40KP.items() if k != 'n_keypoints'}
+    model = KeypointDiffusion(10, 128, None, n_timesteps=500, architecture='gvp', rec_encoder_type='learned',
+                              graph_config=dict(n_keypoints=40, graph_cutoffs=cut), dynamics_config=GVP_40KP, rec_encoder_config=rec_cfg,
+                              precision=1e-5)
+    synth.fill_state_dict_(model, 0)
+    sd_enc = {k[len('rec_encoder.'):]: v.clone() for k, v in model.state_dict().items() if k.startswith('rec_encoder.')}
+    sd_dyn = {k[len('dynamics.'):]: v.clone() for k, v in model.state_dict().items() if k.startswith('dynamics.')}
+    model = model.eval().to(cuda)
+    raw = lambda: synth.synth_complexes([300] * B, [25] * B, 40, cut, seed=4242)
+    t = torch.linspace(0.05, 1.0, B)
+    with torch.no_grad():
+        g = model.encode_receptors(G.batch(raw()).to(cuda))
+        g2 = model.encode_receptors(G.batch(raw()).to(cuda))
+        h, x = model.dynamics(g, t.to(cuda), None)
+        hb, xb = model.dynamics(g2, t.to(cuda), None)
+    for k in ('x_0', 'h_0', 'v_0'):                                   # encoder and denoiser: no atomics, bitwise reproducible
+        assert torch.equal(g.nodes['kp'].data[k], g2.nodes['kp'].data[k]), k
+    assert torch.equal(h, hb) and torch.equal(x, xb)
+    assert g.num_nodes('kp') == 40 * B and torch.isfinite(h).all() and torch.isfinite(x).all()
+    # oracle slice, first two complexes: the encoder from the raw pockets, the denoiser from the GPU encoder's keypoints
+    sub_raw = util.to_obatch(G.batch(raw()[:2]))
+    enc_ref = orec.rec_encoder_gvp_forward(sd_enc, dict(RECENC_40KP, graph_cutoffs=cut), sub_raw)
+    kp = g.nodes['kp'].data
+    for k, ref in (('x_0', enc_ref.x['kp']), ('h_0', enc_ref.h['kp']), ('v_0', enc_ref.v['kp'])):
+        util.assert_parity(kp[k][:80].reshape(80, -1), ref.reshape(80, -1), [40, 40], 1e-4, f'kp {k}', atol_rel=1e-5)
+    sub = util.to_obatch(G.batch(G.unbatch(g.to('cpu'))[:2]))
+    rh, rx = ogvp.gvp_dynamics_forward(sd_dyn, dict(GVP_40KP, graph_cutoffs=cut), sub, t[:2])
+    util.assert_parity(h[:50], rh, [25, 25], 1e-4, 'eps_h')
+    util.assert_parity(x[:50], rx, [25, 25], 1e-4, 'eps_x')
+    # batch independence: complex 5 alone through encoder + denoiser
+    i = 5
+    with torch.no_grad():
+        g1 = model.encode_receptors(G.batch([raw()[i]]).to(cuda))
+        h1, x1 = model.dynamics(g1, t[i:i + 1].to(cuda), None)
+    assert util.rel_err(g1.nodes['kp'].data['h_0'], kp['h_0'][40 * i:40 * (i + 1)]) < 1e-5
+    assert util.rel_err(h1, h[25 * i:25 * (i + 1)]) < 1e-5 and util.rel_err(x1, x[25 * i:25 * (i + 1)]) < 1e-5
+    # E(3): rotate + translate pockets and ligands before the encoder; keypoints and their vectors follow, eps_x rotates
+    R, shift = _rot(7).to(cuda), torch.tensor([2.0, -5.0, 3.5], device=cuda)
+    gr = G.batch(raw()).to(cuda)
+    for nt in ('lig', 'rec'):
+        gr.nodes[nt].data['x_0'] = gr.nodes[nt].data['x_0'] @ R.T + shift
+    with torch.no_grad():
+        gr = model.encode_receptors(gr)
+        hr, xr = model.dynamics(gr, t.to(cuda), None)
+    assert util.rel_err(gr.nodes['kp'].data['x_0'], kp['x_0'] @ R.T + shift) < 1e-4
+    assert util.rel_err(gr.nodes['kp'].data['v_0'], kp['v_0'] @ R.T) < 1e-4
+    assert util.rel_err(gr.nodes['kp'].data['h_0'], kp['h_0']) < 1e-4
+    assert util.rel_err(hr, h) < 1e-4
+    assert util.rel_err(xr, x @ R.T) < 1e-4
+
+
 @pytest.mark.parametrize('arch', ['egnn', 'gvp'])
 def test_full_batch_gradients_directional_derivative(cuda, arch):
     """configs[1] / configs[4]-shape batch through the training engines: the gradient along a random direction in weight

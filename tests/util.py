@@ -47,3 +47,36 @@ def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
     """max |a-b| / max |b| -- the 'within 1e-4 rel fp32' measure of BASELINE.json."""
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
     return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+
+
+def per_complex_rel_err(a: torch.Tensor, b: torch.Tensor, counts) -> float:
+    """max over complexes of (max |a - b| / max |b|) taken INSIDE each complex: a small complex (a single-atom ligand, a
+    quiet pocket) is judged on its own scale instead of hiding under the largest entry of the batch."""
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    worst, off = 0.0, 0
+    for n in [int(c) for c in counts]:
+        if n:
+            ref = b[off:off + n].abs().max().clamp(min=1e-30)
+            worst = max(worst, float((a[off:off + n] - b[off:off + n]).abs().max() / ref))
+        off += n
+    assert off == a.shape[0], (off, a.shape)
+    return worst
+
+
+def elementwise_excess(a: torch.Tensor, b: torch.Tensor, rtol: float = 1e-4, atol_rel: float = 1e-6) -> float:
+    """allclose(a, b, rtol, atol = atol_rel * max |b|) as a number: max of |a - b| / (atol + rtol |b|); <= 1 passes."""
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    atol = atol_rel * float(b.abs().max().clamp(min=1e-30))
+    return float(((a - b).abs() / (atol + rtol * b.abs())).max())
+
+
+def assert_parity(got: torch.Tensor, ref: torch.Tensor, counts=None, tol: float = 1e-4, what: str = '', atol_rel: float = 1e-6):
+    """The three parity measures of the denoiser tests: whole-tensor relative error (BASELINE.json's '1e-4 rel fp32'),
+    the same per complex, and an elementwise allclose(rtol = tol, atol = atol_rel * max |ref|)."""
+    e = rel_err(got, ref)
+    assert e < tol, f'{what}: rel err {e:.3e} >= {tol}'
+    if counts is not None:
+        pc = per_complex_rel_err(got, ref, counts)
+        assert pc < tol, f'{what}: per-complex rel err {pc:.3e} >= {tol}'
+    ex = elementwise_excess(got, ref, rtol=tol, atol_rel=atol_rel)
+    assert ex <= 1.0, f'{what}: allclose(rtol={tol}, atol={atol_rel} max|ref|) violated by a factor {ex:.2f}'
