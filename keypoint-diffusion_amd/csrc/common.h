@@ -37,6 +37,12 @@ void set_error(const char *fmt, ...);
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) for kernels that need more than 64 KB of dynamic LDS: applied once per
+// (kernel, device), thread-safe; cheap enough to call before every launch.  pack.hip.
+kpd_status ensure_dynamic_lds(const void *kernel, int bytes);
+// Compute units of the current device (cached per device; 256 if the query fails).
+int cu_count();
+
 // Philox4x32-10 counter-based generator (per-complex sampler noise, dropout masks of the GVP training path)
 __device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
 #pragma unroll

@@ -291,15 +291,9 @@ __global__ __launch_bounds__(256, 2) void k_egnn_chain(EdgeArgs a) {
     ECHAIN_STAMP(10)
 }
 
-static bool g_echain_attr = false;
-
 kpd_status launch_egnn_chain(const EdgeArgs &a, int tile_cap, hipStream_t st) {
     if (tile_cap == 0) return KPD_OK;
-    if (!g_echain_attr) {
-        KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_egnn_chain), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    ECHAIN_FLOATS * 4));
-        g_echain_attr = true;
-    }
+    KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_egnn_chain), ECHAIN_FLOATS * 4));
     hipLaunchKernelGGL(k_egnn_chain, dim3(8 * cdiv(tile_cap, 8)), dim3(256), ECHAIN_FLOATS * 4, st, a);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
@@ -494,19 +488,6 @@ __global__ __launch_bounds__(512, 1) void k_proj_ws(ProjWs qa) {
     store_tile(accp, rowp, out256p);
 }
 
-static int cu_count() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                ? prop.multiProcessorCount : 256;
-    }
-    return n;
-}
-
-static bool g_pchain_attr = false;
-
 kpd_status launch_proj_chain(const ProjPair &p, hipStream_t st) {
     const int tiles = p.tiles0 + cdiv(p.nt[1].n, TM);
     const int slots = std::max(p.n_slots[0], p.n_slots[1]);
@@ -514,19 +495,12 @@ kpd_status launch_proj_chain(const ProjPair &p, hipStream_t st) {
     for (int nt = 0; nt < 2; ++nt)
         for (int s = 0; s < p.n_slots[nt]; ++s)
             KPD_REQUIRE(p.nt[nt].chain[s] && p.nt[nt].wcol[s], KPD_ERR_STATE, "projection slot %d not packed for k_proj_chain", s);
-    if (!g_pchain_attr) {
-        KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_chain), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    4 * ECH4 * 16));
-        g_pchain_attr = true;
-    }
+    KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_proj_chain), 4 * ECH4 * 16));
     static const int ws = getenv("KPD_PROJ_WS") ? atoi(getenv("KPD_PROJ_WS")) : 1;
     if (ws) {
-        static bool attr_ws = false;
-        if (!attr_ws) {
-            KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_ws), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES));
-            attr_ws = true;
-        }
-        static const int target = getenv("KPD_PROJ_WS_BLOCKS") ? std::max(1, atoi(getenv("KPD_PROJ_WS_BLOCKS"))) : cu_count();
+        KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_proj_ws), WS_LDS_BYTES));
+        static const int target_env = getenv("KPD_PROJ_WS_BLOCKS") ? std::max(1, atoi(getenv("KPD_PROJ_WS_BLOCKS"))) : 0;
+        const int target = target_env ? target_env : cu_count();
         ProjWs q;
         q.p = p;
         int units = 0, tl[2];

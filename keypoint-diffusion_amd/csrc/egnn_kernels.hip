@@ -1220,23 +1220,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 
 
 // ---- launchers ----------------------------------------------------------------------------
-static bool g_attr_set = false;
-
-kpd_status egnn_kernels_init() {
-    if (g_attr_set) return KPD_OK;
-    KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_egnn_edge<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024));
-    KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_egnn_edge<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024));
-    KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_egnn_edge32), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024));
-    KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_layer), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024));
-    KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_update8), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024));
-    g_attr_set = true;
-    return KPD_OK;
-}
+// kept for the engines' create paths: everything it used to do now happens per (kernel, device) at launch time
+kpd_status egnn_kernels_init() { return KPD_OK; }
 
 kpd_status launch_node_graph_index(const int *ptr, int B, int n, int *bidx, hipStream_t st) {
     if (n == 0) return KPD_OK;
@@ -1286,14 +1271,18 @@ kpd_status launch_egnn_edge(const EdgeArgs &a, int tile_cap, hipStream_t st) {
     EdgeArgs b = a;
     b.ablate = ablate;
     if (a.tile_rows == R32) {
+        KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_egnn_edge32), EDGE32_LDS_BYTES + pad));
         hipLaunchKernelGGL(k_egnn_edge32, dim3(8 * cdiv(tile_cap, 8)), dim3(256), EDGE32_LDS_BYTES + pad, st, b);
         KPD_LAUNCH_CHECK();
         return KPD_OK;
     }
-    if (nw == 4)
+    if (nw == 4) {
+        KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_egnn_edge<4>), EDGE_LDS_BYTES + pad));
         hipLaunchKernelGGL(k_egnn_edge<4>, dim3(8 * cdiv(tile_cap, 8)), dim3(256), EDGE_LDS_BYTES + pad, st, b);
-    else
+    } else {
+        KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_egnn_edge<8>), EDGE_LDS_BYTES + pad));
         hipLaunchKernelGGL(k_egnn_edge<8>, dim3(8 * cdiv(tile_cap, 8)), dim3(512), EDGE_LDS_BYTES + pad, st, b);
+    }
     KPD_LAUNCH_CHECK();
     return KPD_OK;
 }
@@ -1311,10 +1300,12 @@ kpd_status launch_node_layer(const NodeLayerPair &p, hipStream_t st) {
     const bool update_only = (p.nt[0].do_update || p.nt[0].u.n == 0) && (p.nt[1].do_update || p.nt[1].u.n == 0) &&
                              !p.nt[0].do_proj && !p.nt[1].do_proj;
     if (nw == 8 && update_only && !p.stamps && !dbg) {
+        KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_node_update8), NODE_LAYER_LDS_BYTES + pad));
         hipLaunchKernelGGL(k_node_update8, dim3(tiles), dim3(512), NODE_LAYER_LDS_BYTES + pad, st, q);
         KPD_LAUNCH_CHECK();
         return KPD_OK;
     }
+    KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_node_layer), NODE_LAYER_LDS_BYTES + pad));
     hipLaunchKernelGGL(k_node_layer, dim3(tiles), dim3(256), NODE_LAYER_LDS_BYTES + pad, st, q);
     KPD_LAUNCH_CHECK();
     return KPD_OK;

@@ -148,11 +148,14 @@ __global__ void k_kl_build(const float *__restrict__ lig_x, const int *__restric
         for (int l = 0; l < nl; ++l) {
             const float dx = sx[3 * l] - px, dy = sx[3 * l + 1] - py, dz = sx[3 * l + 2] - pz;
             float d = dx * dx + dy * dy + dz * dz;
+            // a diverged chain (NaN / Inf coordinates) must not leave slots of the best-list empty: non-finite distances count
+            // as "farthest" and fill free slots in index order, so every emitted index is a real atom of this complex
+            d = d < 3.0e38f ? d : 3.0e38f;
             int id = l;
             // insertion into the sorted best-list (strict < keeps the lower index on ties)
 #pragma unroll
             for (int j = 0; j < KL_KMAX; ++j) {
-                if (j < kk && d < bd[j]) {
+                if (j < kk && (d < bd[j] || bi[j] < 0)) {
                     const float td = bd[j];
                     const int ti = bi[j];
                     bd[j] = d;
@@ -250,10 +253,11 @@ __global__ void k_ll_knn_fill(const float *__restrict__ x, const int *__restrict
             if (l == i) continue;
             const float dx = sx[3 * l] - xi, dy = sx[3 * l + 1] - yi, dz = sx[3 * l + 2] - zi;
             float d = dx * dx + dy * dy + dz * dz;
+            d = d < 3.0e38f ? d : 3.0e38f;               // non-finite: farthest, fills free slots in index order (see k_kl_build)
             int id = l;
 #pragma unroll
             for (int j = 0; j < KL_KMAX; ++j) {
-                if (j < kk && d < bd[j]) {
+                if (j < kk && (d < bd[j] || bi[j] < 0)) {
                     const float td = bd[j];
                     const int ti = bi[j];
                     bd[j] = d;
@@ -428,12 +432,7 @@ kpd_status launch_knn_bipartite(const float *x, const int *x_ptr, int n_x, int m
     const int words = cdiv(max_y, 32);
     const size_t lds = (size_t)max_x * (3 * sizeof(float) + (size_t)words * sizeof(unsigned) + sizeof(int)) + 16;
     KPD_REQUIRE(lds <= 150 * 1024, KPD_ERR_INVALID, "knn needs %zu B of LDS (max_x=%d, max_y=%d)", lds, max_x, max_y);
-    static bool attr = false;
-    if (!attr) {
-        KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kl_build), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    150 * 1024));
-        attr = true;
-    }
+    KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_kl_build), 150 * 1024));
     hipLaunchKernelGGL(k_kl_build, dim3(B), dim3(256), lds, st, x, x_ptr, y, y_ptr, off_tmp, k, words, n_x, n_y, xm_src, xm_dst,
                        xm_rowptr, ym_src, ym_dst, ym_rowptr);
     KPD_LAUNCH_CHECK();
@@ -463,11 +462,7 @@ kpd_status launch_radius_bipartite(const float *x, const int *x_ptr, int n_x, in
     const int words = cdiv(max_y, 32);
     const size_t lds = (size_t)max_x * (3 * sizeof(float) + (size_t)words * sizeof(unsigned) + sizeof(int)) + (size_t)(max_y + 2) * sizeof(int);
     KPD_REQUIRE(lds <= 150 * 1024, KPD_ERR_INVALID, "radius kl graph needs %zu B of LDS (max_x=%d, max_y=%d)", lds, max_x, max_y);
-    static bool attr = false;
-    if (!attr) {
-        KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_klr_fill), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr = true;
-    }
+    KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_klr_fill), 150 * 1024));
     hipLaunchKernelGGL(k_klr_count, dim3(B), dim3(256), (size_t)max_x * 3 * sizeof(float), st, x, x_ptr, y, y_ptr, r * r, max_nn,
                        per_graph_tmp);
     KPD_LAUNCH_CHECK();

@@ -724,8 +724,6 @@ __global__ __launch_bounds__(256, 2) void k_gvp_noise_chain(GvpNoiseArgs a) {
     }
 }
 
-static bool g_chain_attr = false;
-
 kpd_status launch_gvp_edge(const GvpEdgeArgs &a, int tile_cap, hipStream_t st) {
     if (tile_cap == 0) return KPD_OK;
     for (int et = 0; et < 4; ++et)
@@ -733,13 +731,8 @@ kpd_status launch_gvp_edge(const GvpEdgeArgs &a, int tile_cap, hipStream_t st) {
             for (int k = 0; k < a.n_gvps; ++k)
                 KPD_REQUIRE(a.g[et][k].chain && a.g[et][k].whp && a.g[et][k].wup, KPD_ERR_STATE,
                             "message GVP %d of edge type %d was not prepared for the chained edge kernel", k, et);
-    if (!g_chain_attr) {
-        KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gvp_chain<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    ChainSmem<16>::FLOATS * 4));
-        KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gvp_chain<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    ChainSmem<8>::FLOATS * 4));
-        g_chain_attr = true;
-    }
+    KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_chain<16>), ChainSmem<16>::FLOATS * 4));
+    KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_chain<8>), ChainSmem<8>::FLOATS * 4));
     KPD_REQUIRE(a.S == 256 || a.S == 128, KPD_ERR_INVALID, "gvp chain kernel: S=%d (supported 128, 256)", a.S);
     const dim3 grid(8 * cdiv(tile_cap, 8));
     if (a.S == 256)
@@ -753,12 +746,8 @@ kpd_status launch_gvp_edge(const GvpEdgeArgs &a, int tile_cap, hipStream_t st) {
 kpd_status launch_gvp_proj(const GvpProjArgs &a, hipStream_t st) {
     if (a.n_slots == 0 || a.tiles_first[a.n_slots] == 0) return KPD_OK;
     KPD_REQUIRE(a.S == 256 || a.S == 128, KPD_ERR_INVALID, "gvp projection kernel: S=%d (supported 128, 256)", a.S);
-    static bool attr = false;
-    if (!attr) {
-        KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gvp_proj_chain<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16 * 64 * 16));
-        KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gvp_proj_chain<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 8 * 64 * 16));
-        attr = true;
-    }
+    KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_proj_chain<16>), 4 * 16 * 64 * 16));
+    KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_proj_chain<8>), 4 * 8 * 64 * 16));
     const dim3 grid(a.tiles_first[a.n_slots]);
     if (a.S == 256) hipLaunchKernelGGL(k_gvp_proj_chain<16>, grid, dim3(256), 4 * 16 * 64 * 16, st, a);
     else hipLaunchKernelGGL(k_gvp_proj_chain<8>, grid, dim3(256), 4 * 8 * 64 * 16, st, a);
@@ -774,12 +763,8 @@ kpd_status launch_gvp_noise(const GvpNoiseArgs &a, hipStream_t st) {
     KPD_REQUIRE(gl.sout == 64 && gl.vout == 1 && gl.vin == GV, KPD_ERR_STATE, "noise head GVP must map (S, 16) -> (64, 1)");
     for (int k = 0; k < a.n_gvps; ++k)
         KPD_REQUIRE(a.g[k].chain && a.g[k].whp && a.g[k].wup, KPD_ERR_STATE, "noise GVP %d was not prepared for the chained kernel", k);
-    static bool attr = false;
-    if (!attr) {
-        KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gvp_noise_chain<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 16 * 64 * 16));
-        KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gvp_noise_chain<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 8 * 64 * 16));
-        attr = true;
-    }
+    KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_noise_chain<16>), 3 * 16 * 64 * 16));
+    KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_noise_chain<8>), 3 * 8 * 64 * 16));
     if (a.S == 256) hipLaunchKernelGGL(k_gvp_noise_chain<16>, dim3(cdiv(a.n, TM)), dim3(256), 3 * 16 * 64 * 16, st, a);
     else hipLaunchKernelGGL(k_gvp_noise_chain<8>, dim3(cdiv(a.n, TM)), dim3(256), 3 * 8 * 64 * 16, st, a);
     KPD_LAUNCH_CHECK();
@@ -796,12 +781,8 @@ kpd_status launch_gvp_node(const GvpNodePair &p, hipStream_t st) {
             for (int k = 0; k < p.nt[nt].n_gvps; ++k)
                 KPD_REQUIRE(p.nt[nt].g[k].chain && p.nt[nt].g[k].whp && p.nt[nt].g[k].wup, KPD_ERR_STATE,
                             "update GVP %d was not prepared for the chained node kernel", k);
-    static bool attr = false;
-    if (!attr) {
-        KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gvp_node_chain<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 16 * 64 * 16));
-        KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gvp_node_chain<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 8 * 64 * 16));
-        attr = true;
-    }
+    KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_node_chain<16>), 3 * 16 * 64 * 16));
+    KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_node_chain<8>), 3 * 8 * 64 * 16));
     if (S == 256) hipLaunchKernelGGL(k_gvp_node_chain<16>, dim3(tiles), dim3(256), 3 * 16 * 64 * 16, st, p);
     else hipLaunchKernelGGL(k_gvp_node_chain<8>, dim3(tiles), dim3(256), 3 * 8 * 64 * 16, st, p);
     KPD_LAUNCH_CHECK();

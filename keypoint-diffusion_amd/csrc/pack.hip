@@ -1,6 +1,10 @@
 // Library-wide utilities: error text, device arena, weight repacking kernels.
 #include <stdarg.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "engine.h"
 
 namespace kpd {
@@ -12,6 +16,33 @@ void set_error(const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+kpd_status ensure_dynamic_lds(const void *kernel, int bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, int> done;          // (kernel, device) -> bytes granted
+    int dev = 0;
+    KPD_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    int &have = done[std::make_pair(kernel, dev)];
+    if (have >= bytes) return KPD_OK;
+    KPD_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    have = bytes;
+    return KPD_OK;
+}
+
+int cu_count() {
+    static std::mutex mu;
+    static std::map<int, int> cus;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    std::lock_guard<std::mutex> lock(mu);
+    int &n = cus[dev];
+    if (!n) {
+        hipDeviceProp_t prop;
+        n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return n;
 }
 
 kpd_status Arena::reserve(size_t bytes) {

@@ -212,16 +212,9 @@ kpd_status ws_gemm(int mode, const float *X, int rows, int ldx, const float *W, 
                 "ws_gemm: bad operands");
     KPD_REQUIRE((mode == WS_BIAS_SILU && A) || (mode == WS_SILU_BWD && P) || mode == WS_PLAIN, KPD_ERR_INVALID, "ws_gemm: mode %d operands",
                 mode);
-    static bool attr = false;
-    if (!attr) {
-        KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ws_gemm<WS_BIAS_SILU>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    WSG_LDS_BYTES));
-        KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ws_gemm<WS_SILU_BWD>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    WSG_LDS_BYTES));
-        KPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ws_gemm<WS_PLAIN>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    WSG_LDS_BYTES));
-        attr = true;
-    }
+    KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_ws_gemm<WS_BIAS_SILU>), WSG_LDS_BYTES));
+    KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_ws_gemm<WS_SILU_BWD>), WSG_LDS_BYTES));
+    KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_ws_gemm<WS_PLAIN>), WSG_LDS_BYTES));
     // M[n][k] of "Y = X M^T": transpose_w false -> M = W (sn = ldw, sk = 1); true -> M = W^T (sn = 1, sk = ldw)
     hipLaunchKernelGGL(k_wsg_pack, dim3(cdiv(WSG_PACK_FLOATS, 256)), dim3(256), 0, st, W, transpose_w ? 1 : ldw, transpose_w ? ldw : 1,
                        has257 ? 1 : 0, pack_scratch);
@@ -230,10 +223,11 @@ kpd_status ws_gemm(int mode, const float *X, int rows, int ldx, const float *W, 
     a.X = X; a.rows = rows; a.ldx = ldx; a.pack = pack_scratch; a.bias = bias; a.P = P; a.Y = Y; a.A = A; a.ldy = ldy; a.mode = mode;
     a.has257 = has257 ? 1 : 0; a.accumulate = accumulate ? 1 : 0;
     const int tiles = cdiv(rows, WSG_TILE);
-    // one workgroup per CU, one round (see launch_proj_chain): 2 * bpc <= 256
-    for (a.tpb = std::max(1, cdiv(2 * tiles, 256));; ++a.tpb) {
+    // one workgroup per CU, one round (see launch_proj_chain): 2 * bpc <= CUs of this device
+    const int cus = cu_count();
+    for (a.tpb = std::max(1, cdiv(2 * tiles, cus));; ++a.tpb) {
         a.bpc = cdiv(tiles, a.tpb);
-        if (2 * a.bpc <= 256 || a.tpb >= tiles) break;
+        if (2 * a.bpc <= cus || a.tpb >= tiles) break;
     }
     if (mode == WS_BIAS_SILU) hipLaunchKernelGGL(k_ws_gemm<WS_BIAS_SILU>, dim3(2 * a.bpc), dim3(512), WSG_LDS_BYTES, st, a);
     else if (mode == WS_SILU_BWD) hipLaunchKernelGGL(k_ws_gemm<WS_SILU_BWD>, dim3(2 * a.bpc), dim3(512), WSG_LDS_BYTES, st, a);

@@ -31,18 +31,28 @@ class _EgnnTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, pb, timestep, lig_x, lig_h, kp_x, kp_h, *params):
         trainer, names = module._trainer()
-        ctx.trainer, ctx.names, ctx.params = trainer, names, params
+        ctx.trainer, ctx.names = trainer, names
         ctx.inputs = (lig_x, lig_h, kp_x, kp_h, timestep)          # kept alive until backward (the C side holds pointers)
+        # The trainer keeps the saved layer states of ONE forward.  Every forward takes a new generation number; backward
+        # refuses to run on a workspace a later forward has overwritten.  The parameters go through save_for_backward, so
+        # autograd's version check catches an in-place update between forward and backward (the C side reads them in place).
+        trainer.generation = getattr(trainer, 'generation', 0) + 1
+        ctx.generation = trainer.generation
+        ctx.save_for_backward(*params)
         trainer.bind(names, params, [None] * len(params))
         eps_h, eps_x = trainer.forward(pb, lig_x, lig_h, kp_x, kp_h, timestep)
         return eps_h, eps_x
 
     @staticmethod
     def backward(ctx, d_eps_h, d_eps_x):
+        if ctx.generation != ctx.trainer.generation:
+            raise hip.KpdError('backward of a LigRecDynamics forward whose saved layer states were overwritten by a later grad-enabled '
+                               'forward of the same module (one forward/backward pair at a time per module)')
+        params = ctx.saved_tensors
         lig_x, lig_h, kp_x, kp_h, _ = ctx.inputs
         need = ctx.needs_input_grad[3:7]
-        grads = [torch.zeros_like(p) if ctx.needs_input_grad[7 + i] else None for i, p in enumerate(ctx.params)]
-        ctx.trainer.bind(ctx.names, ctx.params, grads)
+        grads = [torch.zeros_like(p) if ctx.needs_input_grad[7 + i] else None for i, p in enumerate(params)]
+        ctx.trainer.bind(ctx.names, params, grads)
         d_in = [torch.empty_like(t) if n else None for t, n in zip((lig_x, lig_h, kp_x, kp_h), need)]
         ctx.trainer.backward(d_eps_h.contiguous().float(), d_eps_x.contiguous().float(), d_in[1], d_in[0], d_in[3], d_in[2])
         return (None, None, None, *d_in, *grads)

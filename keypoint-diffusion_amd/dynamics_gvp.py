@@ -56,8 +56,13 @@ class _GvpTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, pb, timestep, lig_x, kp_x, lig_h, kp_h, kp_v, *params):
         trainer, names = module._trainer()
-        ctx.trainer, ctx.names, ctx.params = trainer, names, params
+        ctx.trainer, ctx.names = trainer, names
         ctx.inputs = (lig_x, kp_x, lig_h, kp_h, kp_v, timestep)    # kept alive until backward (the C side holds pointers)
+        # one forward's saved conv states per trainer: generation number + autograd's version check on the parameters
+        # (see _EgnnTrainFn in dynamics.py)
+        trainer.generation = getattr(trainer, 'generation', 0) + 1
+        ctx.generation = trainer.generation
+        ctx.save_for_backward(*params)
         trainer.bind(names, params, [None] * len(params))
         # GVPDropout is active in training mode only (gvp.py:133-134); the seed comes from torch's CPU generator, so
         # torch.manual_seed reproduces a step
@@ -70,9 +75,13 @@ class _GvpTrainFn(torch.autograd.Function):
     def backward(ctx, d_eps_h, d_eps_x):
         if ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
             raise NotImplementedError('the GVP backward pass does not differentiate with respect to positions')
+        if ctx.generation != ctx.trainer.generation:
+            raise hip.KpdError('backward of a LigRecDynamicsGVP forward whose saved conv states were overwritten by a later '
+                               'grad-enabled forward of the same module (one forward/backward pair at a time per module)')
+        params = ctx.saved_tensors
         _, _, lig_h, kp_h, kp_v, _ = ctx.inputs
-        grads = [torch.zeros_like(p) if (ctx.needs_input_grad[8 + i] and p.numel()) else None for i, p in enumerate(ctx.params)]
-        ctx.trainer.bind(ctx.names, ctx.params, grads)
+        grads = [torch.zeros_like(p) if (ctx.needs_input_grad[8 + i] and p.numel()) else None for i, p in enumerate(params)]
+        ctx.trainer.bind(ctx.names, params, grads)
         d_in = [torch.empty_like(t) if n else None for t, n in zip((lig_h, kp_h, kp_v), ctx.needs_input_grad[5:8])]
         ctx.trainer.backward(d_eps_h.contiguous().float(), d_eps_x.contiguous().float(), *d_in)
         return (None, None, None, None, None, *d_in, *grads)

@@ -104,8 +104,25 @@ class StepGraph:
         with torch.cuda.graph(self.graph):
             model.sample_p_zs_given_zt(self.s, self.t, g, bidx, noise=noise)
         self._keep = (g, noise)
+        # The captured kernels hold raw pointers into the engine's workspace arena and packed weights.  Holding the engine
+        # object keeps both allocations alive even if the module builds a new engine; the pin records what must not have
+        # changed for a replay to mean "one reverse step of this model": the arena (a larger batch re-reserves it, which
+        # frees the captured one) and the weights the engine was packed from.
+        self._model = model
+        self._engine = model.dynamics.engine()
+        self._pin = (self._engine._reserved, model.dynamics._weights_key())
+
+    def _check_pin(self):
+        dyn = self._model.dynamics
+        if dyn._engine is not self._engine or self._engine._reserved != self._pin[0]:
+            raise hip.KpdError('stale step graph: the denoiser engine was rebuilt or its workspace re-reserved (a larger batch ran) '
+                               'after capture; the captured kernels point into freed memory -- capture the step again')
+        if dyn._weights_key() != self._pin[1]:
+            raise hip.KpdError('stale step graph: the model weights changed after capture (the graph replays the weights packed at '
+                               'capture time) -- capture the step again')
 
     def step(self, s: float, t: float):
+        self._check_pin()
         self.s.fill_(s)
         self.t.fill_(t)
         self.graph.replay()

@@ -201,3 +201,35 @@ def test_final_layer_pruning_is_bit_identical(cuda, edge_chain):
     e_all = c0['E_ll'] + c0['E_kl'] + c0['E_lk'] + c0['E_kk']
     assert c0['E_last'] == e_all and c0['tiles_last'] == c0['tiles']
     assert c1['E_last'] == c1['E_ll'] + c1['E_kl'] and 0 < c1['tiles_last'] < c1['tiles']
+
+
+@pytest.mark.parametrize('ll_k', [0, 3])
+def test_non_finite_coordinates_stay_inside_their_complex(cuda, ll_k):
+    """A diverged chain (NaN / Inf ligand coordinates) must behave like the reference -- NaNs propagate inside that complex --
+    and never index outside it: the kNN builders used to leave empty best-list slots (index -1) when no distance compared finite."""
+    g = util.fixed_encode(util.make_batch([60, 45, 50], [9, 7, 11]))
+    cfg = dict(util.EGNN_C2, n_layers=2, ll_k=ll_k)
+    model = LigRecDynamics(10, 10, graph_cutoffs=util.CUTOFFS_ALL_ATOM, **cfg)
+    synth.fill_state_dict_(model, 3)
+    model = model.eval().to(cuda)
+    t = torch.tensor([0.3, 0.6, 0.9], device=cuda)
+    with torch.no_grad():
+        h_ok, x_ok = model(g.to(cuda), t, None)
+        bad = g.to(cuda)
+        x = bad.nodes['lig'].data['x_0'].clone()
+        x[9:16] = float('nan')                         # every atom of complex 1
+        x[2, 0] = float('inf')                         # one atom of complex 0
+        bad.nodes['lig'].data['x_0'] = x
+        out = hip.build_lig_graph(bad.prepared(), x, bad.nodes['kp'].data['x_0'], 6.0, 5, ll_k=ll_k, kl_cutoff=7.0)
+        h, xx = model(bad, t, None)
+    torch.cuda.synchronize()
+    E_ll, E_kl = int(out['counts'][0]), int(out['counts'][1])
+    n_lig, n_kp = 27, 155
+    for key, hi in (('ll_src', n_lig), ('ll_dst', n_lig)):
+        assert int(out[key][:E_ll].min()) >= 0 and int(out[key][:E_ll].max()) < hi
+    for key, hi in (('kl_src', n_kp), ('kl_dst', n_lig), ('lk_src', n_lig), ('lk_dst', n_kp)):
+        assert int(out[key][:E_kl].min()) >= 0 and int(out[key][:E_kl].max()) < hi
+    # the untouched complex is what it was (its edges sit in other tiles now: summation order only); NaNs stay where they were put
+    assert torch.isfinite(h[16:]).all() and torch.isfinite(xx[16:]).all()
+    assert util.rel_err(h[16:], h_ok[16:]) < 1e-5 and util.rel_err(xx[16:], x_ok[16:]) < 1e-5
+    assert torch.isnan(h[9:16]).any()

@@ -142,3 +142,25 @@ def test_trainer_degenerate_shapes_and_errors():
     with torch.no_grad():
         eh_inf, ex_inf = model(g2.to('cuda'), t2.cuda(), None)
     assert util.rel_err(eh.detach().cpu(), eh_inf.cpu()) < 1e-4 and util.rel_err(ex.detach().cpu(), ex_inf.cpu()) < 1e-4
+
+
+def test_stale_forward_cannot_be_differentiated():
+    """The trainer holds the saved layer states of ONE forward.  A backward through an output whose states a later forward has
+    overwritten must raise instead of returning the second forward's gradients; so must a backward after an in-place weight
+    update (the C side reads the parameters in place)."""
+    from keypoint_diffusion_amd import hip
+    cfg = dict(util.EGNN_C2, n_layers=2)
+    g, model, t = _case(cfg, [30, 22], [5, 7])
+    model = model.cuda()
+    eh1, ex1 = model(g.to('cuda'), t.cuda(), None)
+    g2, _, t2 = _case(cfg, [28, 25], [6, 4], seed=9)
+    eh2, ex2 = model(g2.to('cuda'), t2.cuda(), None)
+    with pytest.raises(hip.KpdError, match='overwritten'):
+        (eh1.sum() + ex1.sum()).backward()
+    (eh2.sum() + ex2.sum()).backward()                     # the latest forward is still differentiable
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+    eh3, ex3 = model(g.to('cuda'), t.cuda(), None)
+    with torch.no_grad():
+        model.lig_decoder[2].bias.add_(1.0)               # an optimizer step between forward and backward
+    with pytest.raises(RuntimeError, match='modified by an inplace operation'):
+        (eh3.sum() + ex3.sum()).backward()

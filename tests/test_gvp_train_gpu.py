@@ -154,3 +154,21 @@ def test_dropout_training_step_matches_oracle_with_the_same_masks():
     # another step draws other masks; eval mode ignores dropout
     eh2, _ = model_gpu(g.to('cuda'), t.cuda(), None)
     assert model_gpu.last_dropout_seed != seed and not torch.allclose(eh2, eh)
+
+
+def test_stale_forward_cannot_be_differentiated():
+    """As for the EGNN trainer: one forward/backward pair at a time per module, parameters unchanged in between."""
+    from keypoint_diffusion_amd import hip
+    cfg = dict(GVP_CFGS['gvp_norm0'])
+    g, model, t = _case(cfg, [20, 15], [6, 4], 10)
+    model = model.cuda()
+    eh1, ex1 = model(g.to('cuda'), t.cuda(), None)
+    eh2, ex2 = model(g.to('cuda'), t.cuda(), None)
+    with pytest.raises(hip.KpdError, match='overwritten'):
+        (eh1.sum() + ex1.sum()).backward()
+    (eh2.sum() + ex2.sum()).backward()
+    eh3, ex3 = model(g.to('cuda'), t.cuda(), None)
+    with torch.no_grad():
+        next(p for p in model.parameters() if p.numel()).mul_(1.01)
+    with pytest.raises(RuntimeError, match='modified by an inplace operation'):
+        (eh3.sum() + ex3.sum()).backward()

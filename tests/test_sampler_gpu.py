@@ -206,3 +206,25 @@ def test_sample_sharded_two_ranks_equals_single_process(cuda, tmp_path):
                 assert util.rel_err(x, fx) < 1e-3
             for h, fh in zip(a['features'], b['features']):
                 assert util.rel_err(h, fh) < 1e-3
+
+
+def test_step_graph_refuses_to_replay_after_the_engine_changed(cuda):
+    """A captured step holds raw pointers into the engine's arena and packed weights: a re-reserved workspace (larger batch) or
+    changed weights must turn `step()` into an error, never into a replay on freed or stale memory."""
+    from keypoint_diffusion_amd import hip
+    T = 20
+    model = _model('egnn', T).to(cuda)
+    small = model.encode_receptors(G.batch(synth.synth_complexes([40], [6], 20, CUT, seed=5))).to(cuda)
+    with torch.no_grad():
+        sg = model.capture_step(small)
+        sg.step(18 / T, 19 / T)                                         # fine
+        big = model.encode_receptors(G.batch(synth.synth_complexes([90, 120, 70], [14, 9, 20], 20, CUT, seed=6))).to(cuda)
+        model.dynamics(big, torch.tensor([0.5, 0.5, 0.5], device=cuda), None)      # grows the workspace: arena reallocated
+        with pytest.raises(hip.KpdError, match='stale step graph'):
+            sg.step(17 / T, 18 / T)
+        sg2 = model.capture_step(small)
+        sg2.step(17 / T, 18 / T)
+        model.dynamics.lig_decoder[2].bias.add_(0.5)                    # weights changed in place
+        with pytest.raises(hip.KpdError, match='weights changed'):
+            sg2.step(16 / T, 17 / T)
+    torch.cuda.synchronize()
