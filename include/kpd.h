@@ -233,9 +233,11 @@ typedef struct kpd_recenc_config {
     int32_t n_rr_convs, n_rk_convs, n_message_gvps, n_update_gvps;
     int32_t message_norm_mode;                 /* 0 constant, 1 'mean', 2 message_norm == 0 */
     float message_norm;
-    int32_t k_closest;                         /* kNN rec->kp, 1..16 (kp_rad is not implemented) */
+    int32_t k_closest;                         /* kNN rec->kp, 1..16, or 0 with kp_rad > 0 */
     int32_t n_keypoints;
     float rr_cutoff, rk_cutoff, kk_cutoff;     /* graph_cutoffs['rr'|'rk'|'kk'] (rbf D_max, kk radius) */
+    float kp_rad;                              /* > 0 (with k_closest == 0): radius rec->kp graph, at most 10 receptor atoms per
+                                                * keypoint in index order (receptor_encoder_gvp.py:304-306) */
 } kpd_recenc_config;
 
 typedef struct kpd_rec_batch {
@@ -290,8 +292,10 @@ typedef struct kpd_recegnn_config {
     int32_t use_sameres_feat, use_tanh, norm, fix_pos;
     float coords_range;
     float message_norm;          /* 0: z = rr edges / receptor nodes per graph (no +1, :505-509)          */
-    int32_t k_closest;           /* kNN rec->kp features, 1..16 (kp_rad is not implemented)               */
+    int32_t k_closest;           /* kNN rec->kp features, 1..16, or 0 with kp_rad > 0                     */
     float kk_cutoff;             /* graph_cutoffs['kk']                                                   */
+    float kp_rad;                /* > 0 (with k_closest == 0): keypoint features = sum of the receptor features within kp_rad (at most
+                                  * 100 atoms, index order) / (rk edges per keypoint of the complex + 1) (receptor_encoder.py:238-262) */
 } kpd_recegnn_config;
 
 typedef struct kpd_recegnn kpd_recegnn;

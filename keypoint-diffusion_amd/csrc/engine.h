@@ -15,6 +15,12 @@ kpd_status launch_knn_bipartite(const float *x, const int *x_ptr, int n_x, int m
                                 int max_y, int B, int k, int *off_tmp, int *xm_src, int *xm_dst, int *xm_rowptr, int *ym_src,
                                 int *ym_dst, int *ym_rowptr, hipStream_t st);
 
+// for every y all x of its graph within r, at most max_nn in index order (torch_cluster.radius): lists as launch_knn_bipartite;
+// per_graph_tmp [B], scratch2 [2], off_tmp [B + 1] (off_tmp[B] = total)
+kpd_status launch_radius_bipartite(const float *x, const int *x_ptr, int n_x, int max_x, const float *y, const int *y_ptr, int n_y,
+                                   int max_y, int B, float r, int max_nn, int *per_graph_tmp, int *scratch2, int *off_tmp, int *xm_src,
+                                   int *xm_dst, int *xm_rowptr, int *ym_src, int *ym_dst, int *ym_rowptr, hipStream_t st);
+
 // Grow-only device arena: one hipMalloc, carved with 256-B alignment, zero-filled.
 struct Arena {
     char *base = nullptr;

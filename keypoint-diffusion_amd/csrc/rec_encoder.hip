@@ -261,7 +261,7 @@ struct kpd_recenc {
     int cap_B = 0, cap_rec = 0, cap_rr = 0, cap_maxrec = 0;
     float *s[2], *v[2], *s_tmp[2], *Psrc, *Pdst, *ms_main, *ms_cont, *mv_main, *mv_cont;
     float *gmean, *kp_emb, *ft_src, *ft_dst, *z;
-    int *bidx[2], *kp_ptr, *meta, *off_tmp, *deg_tmp, *xm_src, *xm_dst, *xm_rowptr, *rk_rowptr, *kk_rowptr, *kk_off;
+    int *bidx[2], *kp_ptr, *meta, *off_tmp, *deg_tmp, *rad_tmp, *xm_src, *xm_dst, *xm_rowptr, *rk_rowptr, *kk_rowptr, *kk_off;
 };
 
 static void alloc_conv(kpd_recenc *m, Arena &A, std::vector<HostGvp> &msg, std::vector<HostGvp> &upd, bool use_dst,
@@ -300,8 +300,9 @@ extern "C" kpd_status kpd_recenc_create(const kpd_recenc_config *cfg, kpd_recenc
     KPD_REQUIRE(cfg->out_scalar_size == 128 || cfg->out_scalar_size == 256, KPD_ERR_INVALID, "out_scalar_size=%d: supported 128, 256",
                 cfg->out_scalar_size);
     KPD_REQUIRE(cfg->in_scalar_size >= 1 && cfg->in_scalar_size <= 64, KPD_ERR_INVALID, "in_scalar_size=%d", cfg->in_scalar_size);
-    KPD_REQUIRE(cfg->k_closest >= 1 && cfg->k_closest <= KL_KMAX, KPD_ERR_INVALID,
-                "k_closest=%d: only the kNN rec->kp graph with 1 <= k <= %d is implemented (kp_rad is not)", cfg->k_closest, KL_KMAX);
+    KPD_REQUIRE((cfg->k_closest >= 1 && cfg->k_closest <= KL_KMAX && cfg->kp_rad == 0.0f) || (cfg->k_closest == 0 && cfg->kp_rad > 0.0f),
+                KPD_ERR_INVALID, "rec->kp graph: either 1 <= k_closest <= %d with kp_rad = 0, or k_closest = 0 with kp_rad > 0 (got %d, %f)",
+                KL_KMAX, cfg->k_closest, cfg->kp_rad);
     KPD_REQUIRE(cfg->n_keypoints >= 1 && cfg->n_keypoints * cfg->out_scalar_size <= KPE_MAX, KPD_ERR_INVALID, "n_keypoints=%d",
                 cfg->n_keypoints);
     KPD_REQUIRE(cfg->n_message_gvps >= 1 && cfg->n_message_gvps <= GVP_MAX_CHAIN && cfg->n_update_gvps >= 1 &&
@@ -440,6 +441,9 @@ extern "C" kpd_status kpd_recenc_commit(kpd_recenc *m) {
     return KPD_OK;
 }
 
+// rk edges per keypoint: k of the kNN graph, or at most 10 within kp_rad (receptor_encoder_gvp.py:302-306)
+static inline int rk_per_kp(const kpd_recenc_config &c) { return c.k_closest > 0 ? c.k_closest : 10; }
+
 extern "C" kpd_status kpd_recenc_reserve(kpd_recenc *m, int32_t max_B, int32_t max_n_rec, int32_t max_n_rr, int32_t max_rec_pg) {
     KPD_REQUIRE(m, KPD_ERR_INVALID, "null handle");
     KPD_REQUIRE(max_B >= 1 && max_n_rec >= 1 && max_n_rr >= 0 && max_rec_pg >= 1, KPD_ERR_INVALID, "reserve: non-positive size");
@@ -447,7 +451,7 @@ extern "C" kpd_status kpd_recenc_reserve(kpd_recenc *m, int32_t max_B, int32_t m
     max_B = std::max(max_B, m->cap_B); max_n_rec = std::max(max_n_rec, m->cap_rec);
     max_n_rr = std::max(max_n_rr, m->cap_rr); max_rec_pg = std::max(max_rec_pg, m->cap_maxrec);
     const int S = m->S, K = m->cfg.n_keypoints, n_kp = max_B * K;
-    const int cap_rk = n_kp * m->cfg.k_closest;
+    const int cap_rk = n_kp * rk_per_kp(m->cfg);
     const int n[2] = {max_n_rec, n_kp};
     const int e_max = std::max(std::max(max_n_rr, cap_rk), 1);
     const int n_max = std::max(max_n_rec, n_kp);
@@ -457,7 +461,7 @@ extern "C" kpd_status kpd_recenc_reserve(kpd_recenc *m, int32_t max_B, int32_t m
     for (int nt = 0; nt < 2; ++nt) { add((size_t)n[nt] * S); add((size_t)n[nt] * S); add((size_t)n[nt] * 48); add(n[nt]); }
     add((size_t)n_max * S); add((size_t)n_max * S); add((size_t)n_max * S); add((size_t)tiles * S); add((size_t)n_max * 48); add((size_t)tiles * 48);
     add((size_t)max_B * S); add((size_t)n_kp * S); add((size_t)max_n_rec * S); add((size_t)n_kp * S); add(max_B);
-    add(max_B + 1); add(16); add(max_B + 1); add(n_max); add(cap_rk); add(cap_rk); add(max_n_rec + 1); add(n_kp + 1); add(n_kp + 1); add(max_B + 1);
+    add(max_B + 1); add(16); add(max_B + 1); add(n_max); add(max_B + 8); add(cap_rk); add(cap_rk); add(max_n_rec + 1); add(n_kp + 1); add(n_kp + 1); add(max_B + 1);
     KPD_TRY(m->ws.reserve(bytes));
     Arena &W = m->ws;
     for (int nt = 0; nt < 2; ++nt) {
@@ -470,6 +474,7 @@ extern "C" kpd_status kpd_recenc_reserve(kpd_recenc *m, int32_t max_B, int32_t m
     m->gmean = W.take<float>((size_t)max_B * S); m->kp_emb = W.take<float>((size_t)n_kp * S);
     m->ft_src = W.take<float>((size_t)max_n_rec * S); m->ft_dst = W.take<float>((size_t)n_kp * S); m->z = W.take<float>(max_B);
     m->kp_ptr = W.take<int>(max_B + 1); m->meta = W.take<int>(16); m->off_tmp = W.take<int>(max_B + 1); m->deg_tmp = W.take<int>(n_max);
+    m->rad_tmp = W.take<int>(max_B + 8);
     m->xm_src = W.take<int>(cap_rk); m->xm_dst = W.take<int>(cap_rk); m->xm_rowptr = W.take<int>(max_n_rec + 1);
     m->rk_rowptr = W.take<int>(n_kp + 1); m->kk_rowptr = W.take<int>(n_kp + 1); m->kk_off = W.take<int>(max_B + 1);
     KPD_REQUIRE(m->kk_off != nullptr, KPD_ERR_HIP, "recenc workspace arena too small (internal sizing error)");
@@ -573,9 +578,15 @@ extern "C" kpd_status kpd_recenc_forward(kpd_recenc *m, const kpd_rec_batch *bt,
     KPD_HIP(hipMemsetAsync(m->s[1], 0, (size_t)n_kp * S * 4, st));                                 // :90-91
     KPD_HIP(hipMemsetAsync(m->v[1], 0, (size_t)n_kp * 48 * 4, st));
 
-    // rec -> kp kNN edges (:297-321): kp-major list = rk (src rec, dst kp), dst-sorted
-    KPD_TRY(launch_knn_bipartite(bt->rec_x, bt->rec_ptr, n_rec, bt->max_rec, out->kp_x, m->kp_ptr, n_kp, K, B, c.k_closest,
-                                 m->off_tmp, m->xm_src, m->xm_dst, m->xm_rowptr, out->rk_src, out->rk_dst, m->rk_rowptr, st));
+    // rec -> kp edges (:297-321), kNN or radius (at most 10 per keypoint, index order): kp-major list = rk (src rec, dst kp),
+    // dst-sorted; off_tmp[B] = E_rk either way
+    if (c.k_closest > 0)
+        KPD_TRY(launch_knn_bipartite(bt->rec_x, bt->rec_ptr, n_rec, bt->max_rec, out->kp_x, m->kp_ptr, n_kp, K, B, c.k_closest,
+                                     m->off_tmp, m->xm_src, m->xm_dst, m->xm_rowptr, out->rk_src, out->rk_dst, m->rk_rowptr, st));
+    else
+        KPD_TRY(launch_radius_bipartite(bt->rec_x, bt->rec_ptr, n_rec, bt->max_rec, out->kp_x, m->kp_ptr, n_kp, K, B, c.kp_rad, 10,
+                                        m->rad_tmp, m->rad_tmp + B, m->off_tmp, m->xm_src, m->xm_dst, m->xm_rowptr, out->rk_src,
+                                        out->rk_dst, m->rk_rowptr, st));
     if (c.message_norm_mode == 2) {
         hipLaunchKernelGGL(k_z_indegree, dim3(cdiv(B, 256)), dim3(256), 0, st, m->rk_rowptr, m->kp_ptr, B, m->z);   // :266-269
         KPD_LAUNCH_CHECK();
@@ -584,7 +595,7 @@ extern "C" kpd_status kpd_recenc_forward(kpd_recenc *m, const kpd_rec_batch *bt,
     KPD_LAUNCH_CHECK();
     for (int i = 0; i < c.n_rk_convs; ++i) {
         float *ln[4] = {m->rk_ln1w[i], m->rk_ln1b[i], m->rk_ln2w[i], m->rk_ln2b[i]};
-        KPD_TRY(run_conv(m, 2, n_rec, n_kp, n_kp * c.k_closest, out->rk_src, out->rk_dst, m->rk_rowptr, bt->rec_x, out->kp_x,
+        KPD_TRY(run_conv(m, 2, n_rec, n_kp, n_kp * std::min(rk_per_kp(c), bt->max_rec), out->rk_src, out->rk_dst, m->rk_rowptr, bt->rec_x, out->kp_x,
                          m->rk_msg[i], m->rk_upd[i], ln, i != 0, c.rk_cutoff, st));
     }
     KPD_HIP(hipMemcpyAsync(out->kp_h, m->s[1], (size_t)n_kp * S * 4, hipMemcpyDeviceToDevice, st));

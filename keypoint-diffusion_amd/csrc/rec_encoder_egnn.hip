@@ -244,6 +244,34 @@ __global__ __launch_bounds__(RW) void k_rc_kp_feat(const float *__restrict__ h, 
     if (on) kp_h[(size_t)kp * D + tid] = y;
 }
 
+// kp_rad_feats + kp_feature_mlp + LayerNorm (:238-262, :231-236): one workgroup per keypoint; its rec->kp radius edges are
+// rk_src[rowptr[kp] .. rowptr[kp + 1]) (index order, at most 100), z = rk edges of the complex / keypoints of the complex + 1.
+__global__ __launch_bounds__(RW) void k_rc_kp_radfeat(const float *__restrict__ h, const int *__restrict__ rk_src,
+                                                      const int *__restrict__ rk_rowptr, const int *__restrict__ rk_off, int K, int D,
+                                                      const float *__restrict__ W_t, const float *__restrict__ bias,
+                                                      const float *__restrict__ ln_w, const float *__restrict__ ln_b,
+                                                      float *__restrict__ kp_h) {
+    __shared__ float s_f[RW];
+    __shared__ float s_red[2][4];
+    const int kp = blockIdx.x, tid = threadIdx.x, b = kp / K;
+    const bool on = tid < D;
+    if (on) {
+        float acc = 0.0f;
+        for (int e = rk_rowptr[kp]; e < rk_rowptr[kp + 1]; ++e) acc += h[(size_t)rk_src[e] * D + tid];      // fn.sum, :258
+        const float z = (float)(rk_off[b + 1] - rk_off[b]) / (float)K + 1.0f;                                // :259-260
+        s_f[tid] = acc / z;
+    }
+    __syncthreads();
+    float y = 0.0f;
+    if (on) {
+        y = bias[tid];
+        for (int i = 0; i < D; ++i) y = fmaf(W_t[(size_t)i * D + tid], s_f[i], y);
+        y = silu(y);
+    }
+    if (ln_w) y = block_layernorm(y, on, D, ln_w, ln_b, s_red, tid);
+    if (on) kp_h[(size_t)kp * D + tid] = y;
+}
+
 }  // namespace kpd
 
 // ---- engine -----------------------------------------------------------------------------------------
@@ -263,7 +291,7 @@ struct kpd_recegnn {
     bool committed = false;
     int cap_B = 0, cap_rec = 0, cap_rr = 0, cap_maxrec = 0;
     float *h[2], *x[2], *P, *z, *gmean, *kp_h0, *ft_src, *ft_dst;
-    int *bidx, *kp_ptr, *off_tmp, *deg_tmp, *xm_src, *xm_dst, *xm_rowptr, *rk_rowptr, *kk_rowptr, *kk_off;
+    int *bidx, *kp_ptr, *off_tmp, *deg_tmp, *rad_tmp, *xm_src, *xm_dst, *xm_rowptr, *rk_rowptr, *kk_rowptr, *kk_off;
 };
 
 extern "C" kpd_status kpd_recegnn_create(const kpd_recegnn_config *cfg, kpd_recegnn **out) {
@@ -272,8 +300,9 @@ extern "C" kpd_status kpd_recegnn_create(const kpd_recegnn_config *cfg, kpd_rece
     KPD_REQUIRE(in >= 1 && in <= RW && hid >= 1 && hid <= RW && D >= 1 && D <= RW, KPD_ERR_INVALID,
                 "feature widths (%d, %d, %d) must be in 1..%d", in, hid, D, RW);
     KPD_REQUIRE(cfg->n_convs >= 1 && cfg->n_convs <= 32, KPD_ERR_INVALID, "n_convs=%d", cfg->n_convs);
-    KPD_REQUIRE(cfg->k_closest >= 1 && cfg->k_closest <= KL_KMAX, KPD_ERR_INVALID,
-                "k_closest=%d: only the kNN rec->kp features with 1 <= k <= %d are implemented (kp_rad is not)", cfg->k_closest, KL_KMAX);
+    KPD_REQUIRE((cfg->k_closest >= 1 && cfg->k_closest <= KL_KMAX && cfg->kp_rad == 0.0f) || (cfg->k_closest == 0 && cfg->kp_rad > 0.0f),
+                KPD_ERR_INVALID, "keypoint features: either 1 <= k_closest <= %d with kp_rad = 0, or k_closest = 0 with kp_rad > 0 (got %d, %f)",
+                KL_KMAX, cfg->k_closest, cfg->kp_rad);
     KPD_REQUIRE(K >= 1 && K <= 4096, KPD_ERR_INVALID, "n_keypoints=%d", K);
     KPD_REQUIRE(cfg->message_norm >= 0.0f, KPD_ERR_INVALID, "message_norm=%f", cfg->message_norm);
     kpd_recegnn *m = new kpd_recegnn();
@@ -423,13 +452,14 @@ extern "C" kpd_status kpd_recegnn_reserve(kpd_recegnn *m, int32_t max_B, int32_t
     max_B = std::max(max_B, m->cap_B); max_n_rec = std::max(max_n_rec, m->cap_rec);
     max_n_rr = std::max(max_n_rr, m->cap_rr); max_rec_pg = std::max(max_rec_pg, m->cap_maxrec);
     const kpd_recegnn_config &c = m->cfg;
-    const int K = c.n_keypoints, D = c.out_n_node_feat, n_kp = max_B * K, cap_rk = n_kp * c.k_closest;
+    const int K = c.n_keypoints, D = c.out_n_node_feat, n_kp = max_B * K;
+    const int cap_rk = n_kp * (c.k_closest > 0 ? c.k_closest : std::min(100, max_rec_pg));      // radius: at most 100 per keypoint (:246)
     const int n_max = std::max(max_n_rec, n_kp);
     size_t bytes = 1 << 20;
     auto add = [&](size_t cnt) { bytes += ((cnt * 4 + 255) & ~size_t(255)); };
     add((size_t)max_n_rec * RW); add((size_t)max_n_rec * RW); add((size_t)max_n_rec * 3); add((size_t)max_n_rec * 3);
     add((size_t)max_n_rec * 4 * RW); add(max_B); add((size_t)max_B * D); add((size_t)n_kp * D); add((size_t)max_n_rec * D); add((size_t)n_kp * D);
-    add(max_n_rec); add(max_B + 1); add(max_B + 1); add(n_max); add(cap_rk); add(cap_rk); add(max_n_rec + 1); add(n_kp + 1); add(n_kp + 1);
+    add(max_n_rec); add(max_B + 1); add(max_B + 1); add(n_max); add(max_B + 8); add(cap_rk); add(cap_rk); add(max_n_rec + 1); add(n_kp + 1); add(n_kp + 1);
     add(max_B + 1);
     KPD_TRY(m->ws.reserve(bytes));
     Arena &W = m->ws;
@@ -439,6 +469,7 @@ extern "C" kpd_status kpd_recegnn_reserve(kpd_recegnn *m, int32_t max_B, int32_t
     m->gmean = W.take<float>((size_t)max_B * D); m->kp_h0 = W.take<float>((size_t)n_kp * D);
     m->ft_src = W.take<float>((size_t)max_n_rec * D); m->ft_dst = W.take<float>((size_t)n_kp * D);
     m->bidx = W.take<int>(max_n_rec); m->kp_ptr = W.take<int>(max_B + 1); m->off_tmp = W.take<int>(max_B + 1); m->deg_tmp = W.take<int>(n_max);
+    m->rad_tmp = W.take<int>(max_B + 8);
     m->xm_src = W.take<int>(cap_rk); m->xm_dst = W.take<int>(cap_rk); m->xm_rowptr = W.take<int>(max_n_rec + 1);
     m->rk_rowptr = W.take<int>(n_kp + 1); m->kk_rowptr = W.take<int>(n_kp + 1); m->kk_off = W.take<int>(max_B + 1);
     KPD_REQUIRE(m->kk_off != nullptr, KPD_ERR_HIP, "recegnn workspace arena too small (internal sizing error)");
@@ -500,11 +531,20 @@ extern "C" kpd_status kpd_recegnn_forward(kpd_recegnn *m, const kpd_rec_batch *b
     KPD_TRY(launch_linear_rows(m->kp_h0, n_kp, D, m->fc_src_t, m->ft_dst, st));                // fc_src on both sides (:190-191)
     KPD_TRY(launch_kp_attention(m->ft_src, m->ft_dst, c.fix_pos ? bt->rec_x : x_in, bt->rec_ptr, n_kp, K, D, out->kp_x, st));
 
-    // k nearest receptor atoms of every keypoint by the ORIGINAL positions (:262-267); kp-major = rk edges
-    KPD_TRY(launch_knn_bipartite(bt->rec_x, bt->rec_ptr, n_rec, bt->max_rec, out->kp_x, m->kp_ptr, n_kp, K, B, c.k_closest, m->off_tmp,
-                                 m->xm_src, m->xm_dst, m->xm_rowptr, out->rk_src, out->rk_dst, m->rk_rowptr, st));
-    hipLaunchKernelGGL(k_rc_kp_feat, dim3(n_kp), dim3(RW), 0, st, h_in, bt->rec_x, out->kp_x, out->rk_src, c.k_closest, D, m->kpf_W_t,
-                       m->kpf_b, m->kp_lw, m->kp_lb, out->kp_h);
+    if (c.k_closest > 0) {
+        // k nearest receptor atoms of every keypoint by the ORIGINAL positions (:262-267); kp-major = rk edges
+        KPD_TRY(launch_knn_bipartite(bt->rec_x, bt->rec_ptr, n_rec, bt->max_rec, out->kp_x, m->kp_ptr, n_kp, K, B, c.k_closest, m->off_tmp,
+                                     m->xm_src, m->xm_dst, m->xm_rowptr, out->rk_src, out->rk_dst, m->rk_rowptr, st));
+        hipLaunchKernelGGL(k_rc_kp_feat, dim3(n_kp), dim3(RW), 0, st, h_in, bt->rec_x, out->kp_x, out->rk_src, c.k_closest, D, m->kpf_W_t,
+                           m->kpf_b, m->kp_lw, m->kp_lb, out->kp_h);
+    } else {
+        // receptor atoms within kp_rad of every keypoint (original positions, at most 100, index order; :238-262)
+        KPD_TRY(launch_radius_bipartite(bt->rec_x, bt->rec_ptr, n_rec, bt->max_rec, out->kp_x, m->kp_ptr, n_kp, K, B, c.kp_rad, 100,
+                                        m->rad_tmp, m->rad_tmp + B, m->off_tmp, m->xm_src, m->xm_dst, m->xm_rowptr, out->rk_src,
+                                        out->rk_dst, m->rk_rowptr, st));
+        hipLaunchKernelGGL(k_rc_kp_radfeat, dim3(n_kp), dim3(RW), 0, st, h_in, out->rk_src, m->rk_rowptr, m->off_tmp, K, D, m->kpf_W_t,
+                           m->kpf_b, m->kp_lw, m->kp_lb, out->kp_h);
+    }
     KPD_LAUNCH_CHECK();
 
     // keypoint-keypoint radius graph (:541); counts = {E_kk, E_rk}

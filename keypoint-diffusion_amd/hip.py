@@ -53,14 +53,14 @@ class KpdRecencConfig(C.Structure):
                 ('n_rr_convs', C.c_int32), ('n_rk_convs', C.c_int32), ('n_message_gvps', C.c_int32),
                 ('n_update_gvps', C.c_int32), ('message_norm_mode', C.c_int32), ('message_norm', C.c_float),
                 ('k_closest', C.c_int32), ('n_keypoints', C.c_int32), ('rr_cutoff', C.c_float), ('rk_cutoff', C.c_float),
-                ('kk_cutoff', C.c_float)]
+                ('kk_cutoff', C.c_float), ('kp_rad', C.c_float)]
 
 
 class KpdRecegnnConfig(C.Structure):
     _fields_ = [('n_convs', C.c_int32), ('n_keypoints', C.c_int32), ('in_n_node_feat', C.c_int32),
                 ('hidden_n_node_feat', C.c_int32), ('out_n_node_feat', C.c_int32), ('use_sameres_feat', C.c_int32),
                 ('use_tanh', C.c_int32), ('norm', C.c_int32), ('fix_pos', C.c_int32), ('coords_range', C.c_float),
-                ('message_norm', C.c_float), ('k_closest', C.c_int32), ('kk_cutoff', C.c_float)]
+                ('message_norm', C.c_float), ('k_closest', C.c_int32), ('kk_cutoff', C.c_float), ('kp_rad', C.c_float)]
 
 
 class KpdRecBatch(C.Structure):
@@ -530,12 +530,13 @@ class RecEncEngine:
     """Owns one kpd_recenc handle: packed weights + workspace for ReceptorEncoderGVP.forward."""
 
     def __init__(self, in_scalar_size, out_scalar_size, vector_size, n_rr_convs, n_rk_convs, n_message_gvps, n_update_gvps,
-                 message_norm, k_closest, n_keypoints, rr_cutoff, rk_cutoff, kk_cutoff):
+                 message_norm, k_closest, n_keypoints, rr_cutoff, rk_cutoff, kk_cutoff, kp_rad=0.0):
         mode, val = _norm_mode(message_norm)
         self.cfg = KpdRecencConfig(int(in_scalar_size), int(out_scalar_size), int(vector_size), int(n_rr_convs),
                                    int(n_rk_convs), int(n_message_gvps), int(n_update_gvps), mode, val, int(k_closest),
-                                   int(n_keypoints), float(rr_cutoff), float(rk_cutoff), float(kk_cutoff))
-        self.S, self.K, self.k = int(out_scalar_size), int(n_keypoints), int(k_closest)
+                                   int(n_keypoints), float(rr_cutoff), float(rk_cutoff), float(kk_cutoff), float(kp_rad))
+        # rk edges per keypoint: k of the kNN graph, or at most 10 of the radius graph (receptor_encoder_gvp.py:306)
+        self.S, self.K, self.k = int(out_scalar_size), int(n_keypoints), int(k_closest) if k_closest else 10
         self._h = C.c_void_p()
         check(lib().kpd_recenc_create(C.byref(self.cfg), C.byref(self._h)))
 
@@ -590,11 +591,13 @@ class RecEgnnEngine:
     """Owns one kpd_recegnn handle: weights + workspace for ReceptorEncoder.forward (models/receptor_encoder.py)."""
 
     def __init__(self, n_convs, n_keypoints, in_n_node_feat, hidden_n_node_feat, out_n_node_feat, use_sameres_feat, use_tanh,
-                 coords_range, message_norm, k_closest, norm, fix_pos, kk_cutoff):
+                 coords_range, message_norm, k_closest, norm, fix_pos, kk_cutoff, kp_rad=0.0):
         self.cfg = KpdRecegnnConfig(int(n_convs), int(n_keypoints), int(in_n_node_feat), int(hidden_n_node_feat),
                                     int(out_n_node_feat), int(bool(use_sameres_feat)), int(bool(use_tanh)), int(bool(norm)),
-                                    int(bool(fix_pos)), float(coords_range), float(message_norm), int(k_closest), float(kk_cutoff))
+                                    int(bool(fix_pos)), float(coords_range), float(message_norm), int(k_closest), float(kk_cutoff),
+                                    float(kp_rad))
         self.D, self.K, self.k, self.ef = int(out_n_node_feat), int(n_keypoints), int(k_closest), bool(use_sameres_feat)
+        self.rk_cap = int(k_closest) if k_closest else 100       # rk edges per keypoint: k, or at most 100 within kp_rad (:246)
         self._h = C.c_void_p()
         check(lib().kpd_recegnn_create(C.byref(self.cfg), C.byref(self._h)))
 
@@ -638,7 +641,8 @@ class RecEgnnEngine:
         cap_kk = max(n_kp * min(self.K - 1, 100), 1)
         f32 = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
         i32 = lambda n: torch.zeros(n, device=dev, dtype=torch.int32)
-        out = dict(kp_x=f32(n_kp, 3), kp_h=f32(n_kp, self.D), rk_src=i32(n_kp * self.k), rk_dst=i32(n_kp * self.k),
+        cap_rk = n_kp * min(self.rk_cap, max_rec)
+        out = dict(kp_x=f32(n_kp, 3), kp_h=f32(n_kp, self.D), rk_src=i32(cap_rk), rk_dst=i32(cap_rk),
                    kk_src=i32(cap_kk), kk_dst=i32(cap_kk), kk_per_graph=i32(B), counts=i32(2), rec_h=f32(n_rec, self.D),
                    rec_x=f32(n_rec, 3))
         bt = KpdRecBatch(B, n_rec, max_rec, _ptr(rec_ptr), _ptr(rec_x), _ptr(rec_h), int(s.numel()), _ptr(s), _ptr(d), _ptr(rowptr))

@@ -83,11 +83,9 @@ class ReceptorEncoder(nn.Module):
         from . import hip
         key = tuple((p.data_ptr(), p._version) for p in self.parameters())
         if self._engine is None or key != self._engine_key:
-            if self.k_closest == 0:
-                raise NotImplementedError('kp_rad > 0 (radius rec->kp features) is not implemented in the HIP path')
             eng = hip.RecEgnnEngine(self.n_convs, self.n_keypoints, self.in_n_node_feat, self.hidden_n_node_feat, self.out_n_node_feat,
                                     self.use_sameres_feat, self.use_tanh, self.coords_range, self.message_norm, self.k_closest,
-                                    self.norm, self.fix_pos, self.graph_cutoffs['kk'])
+                                    self.norm, self.fix_pos, self.graph_cutoffs['kk'], kp_rad=self.kp_rad)
             eng.load_state_dict(self.state_dict())
             self._engine, self._engine_key = eng, key
         return self._engine
@@ -112,7 +110,8 @@ class ReceptorEncoder(nn.Module):
         g.remove_edges(g.edges(form='eid', etype='rk'), etype='rk')
         g.add_edges(out['rk_src'].long(), out['rk_dst'].long(), etype='rk')
         g.add_edges(out['kk_src'].long(), out['kk_dst'].long(), etype='kk')
-        edges[('rec', 'rk', 'kp')] = torch.ones_like(n_rec) * K * self.k_closest
+        # K * k_closest per complex for the kNN features (:275), counted for the radius features (:249)
+        edges[('rec', 'rk', 'kp')] = torch.bincount(out['rk_dst'].long() // K, minlength=B).to(n_rec.device)
         edges[('kp', 'kk', 'kp')] = out['kk_per_graph'].long()
         g.set_batch_num_nodes(nodes)
         g.set_batch_num_edges(edges)

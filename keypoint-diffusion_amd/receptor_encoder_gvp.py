@@ -68,14 +68,16 @@ class ReceptorEncoderGVP(nn.Module):
         from . import hip
         key = tuple((p.data_ptr(), p._version) for p in self.parameters())
         if self._engine is None or key != self._engine_key:
-            if self.rk_graph_type != 'knn':
-                raise NotImplementedError('kp_rad > 0 (radius rec->kp graph) is not implemented in the HIP path')
             if self.use_sameres_feat:
-                raise NotImplementedError('use_sameres_feat is not implemented (unused by every shipped config)')
+                # upstream this switch cannot run: forward reads g.edges['rr'].data['a'] (receptor_encoder_gvp.py:230), a key no
+                # dataset writes (pdbbind_processing.py:272 stores 'same_res'), and the rk convolutions are built with
+                # edge_feat_size = 1 but called without edge features (:176-208, :279-281)
+                raise NotImplementedError('use_sameres_feat=True cannot run in the reference GVP encoder (it reads an edge feature "a" '
+                                          'that no dataset provides); every shipped config sets it to False')
             eng = hip.RecEncEngine(self.in_scalar_size, self.out_scalar_size, self.vector_size, self.n_rr_convs,
                                    self.n_rk_convs, self.n_message_gvps, self.n_update_gvps, self.message_norm,
                                    self.k_closest, self.n_keypoints, self.graph_cutoffs['rr'], self.graph_cutoffs['rk'],
-                                   self.graph_cutoffs['kk'])
+                                   self.graph_cutoffs['kk'], kp_rad=self.kp_rad)
             eng.load_state_dict(self.state_dict())
             self._engine, self._engine_key = eng, key
         return self._engine
@@ -100,7 +102,8 @@ class ReceptorEncoderGVP(nn.Module):
         g.remove_edges(g.edges(form='eid', etype='rk'), etype='rk')
         g.add_edges(out['rk_src'].long(), out['rk_dst'].long(), etype='rk')
         g.add_edges(out['kk_src'].long(), out['kk_dst'].long(), etype='kk')
-        edges[('rec', 'rk', 'kp')] = K * torch.clamp(n_rec, max=self.k_closest)
+        # rk edges per complex: K * min(k, n_rec) for the kNN graph, counted for the radius graph (:308-313)
+        edges[('rec', 'rk', 'kp')] = torch.bincount(out['rk_dst'].long() // K, minlength=B).to(n_rec.device)
         edges[('kp', 'kk', 'kp')] = out['kk_per_graph'].long()
         g.set_batch_num_nodes(nodes)
         g.set_batch_num_edges(edges)

@@ -43,9 +43,9 @@ def receptor_conv(sd, p, h, x, src, dst, z, a: Optional[torch.Tensor], cfg):
 
 
 def rec_key_conv(sd, p, h, x_val, x0, kp_h0, n_rec, K, cfg):
-    """RecKeyConv.forward with k_closest > 0 (:182-297).  fc_src is applied to both sides (:190-191; fc_dst is unused)."""
+    """RecKeyConv.forward (:182-297), k_closest or kp_rad features.  fc_src is applied to both sides (:190-191; fc_dst is unused)."""
     D = kp_h0.shape[1]
-    k = cfg['k_closest']
+    k = cfg.get('k_closest', 0)
     ft_src = F.linear(h, sd[p + '.fc_src.weight'])
     ft_dst = F.linear(kp_h0, sd[p + '.fc_src.weight'])
     rp = G.counts_to_ptr(n_rec)
@@ -55,6 +55,14 @@ def rec_key_conv(sd, p, h, x_val, x0, kp_h0, n_rec, K, cfg):
         pos.append((a / a.sum(dim=1, keepdim=True)) @ x_val[rp[b]:rp[b + 1]])                  # :206-222
     kp_pos = torch.cat(pos, 0)
     n_kp = torch.full((n_rec.numel(),), K, dtype=torch.long)
+    if k == 0:                                                                 # kp_rad_feats (:238-262)
+        kp_idx, rec_idx = G.radius(x0, kp_pos, cfg['kp_rad'], n_rec, n_kp, max_num_neighbors=100)
+        h_m = torch.zeros(kp_pos.shape[0], D).index_add_(0, kp_idx, h[rec_idx])                # fn.sum, :258
+        z = G.edges_per_graph(kp_idx, n_kp).float() / K + 1.0                                  # :259-260
+        feat = F.silu(_lin(sd, p + '.kp_feature_mlp.0', h_m / z[G.counts_to_batch_idx(n_kp)].view(-1, 1)))
+        if cfg.get('norm', False):
+            feat = F.layer_norm(feat, (D,), sd[p + '.layer_norm.weight'], sd[p + '.layer_norm.bias'], 1e-5)
+        return kp_pos, feat, (rec_idx, kp_idx)
     kp_idx, rec_idx = G.knn(x0, kp_pos, k, n_rec, n_kp)                        # :262-267 (original positions x_0)
     h_m = G.scatter_mean(h[rec_idx], kp_idx, kp_pos.shape[0])                  # :284
     d = torch.linalg.vector_norm(x0[rec_idx] - kp_pos[kp_idx] + 1e-30, dim=1)  # :285-286
@@ -68,8 +76,8 @@ def rec_key_conv(sd, p, h, x_val, x0, kp_h0, n_rec, K, cfg):
 def rec_encoder_egnn_forward(sd: Dict[str, torch.Tensor], cfg: dict, batch: OBatch,
                              edge_feat: Optional[torch.Tensor] = None, return_rec: bool = False):
     """ReceptorEncoder.forward (:483-555).  cfg = reference ctor kwargs (+ graph_cutoffs, n_keypoints)."""
-    if cfg.get('kp_rad', 0) != 0 or cfg.get('k_closest', 0) == 0:
-        raise NotImplementedError('only the k_closest rec->kp features are restated')
+    if (cfg.get('kp_rad', 0) != 0) == (cfg.get('k_closest', 0) != 0):
+        raise ValueError('exactly one of kp_rad and k_closest must be non-zero')                # :399-402
     n_rec = batch.n['rec']
     B, K = batch.batch_size, cfg.get('n_keypoints', 10)
     D = cfg.get('out_n_node_feat', 256)

@@ -14,6 +14,10 @@ from .golden.make_golden_cfgs import RECEGNN_CFGS, same_res_feature
 pytestmark = pytest.mark.gpu
 CUT = util.CUTOFFS_ALL_ATOM
 RECEGNN_40KP = dict(RECEGNN_CFGS['recegnn_20kp'], n_keypoints=40)        # trained_models/egnn_40kp/config.yml:59-75
+# keypoint features from the receptor atoms within kp_rad (receptor_encoder.py:238-262; configs/dev_config.yml:46 sets kp_rad: 5):
+# 5 A holds ~30 atoms, 9 A in a 300-atom pocket more than the cap of 100 (:246)
+RECEGNN_RAD5 = dict(RECEGNN_CFGS['recegnn_small'], k_closest=0, kp_rad=5.0)
+RECEGNN_RAD9 = dict(RECEGNN_CFGS['recegnn_20kp'], k_closest=0, kp_rad=9.0)
 
 
 def _edge_set(s, d):
@@ -21,7 +25,8 @@ def _edge_set(s, d):
 
 
 @pytest.mark.parametrize('cfg,n_rec', [(RECEGNN_CFGS['recegnn_20kp'], [33, 21]), (RECEGNN_CFGS['recegnn_small'], [33, 21]),
-                                       (RECEGNN_CFGS['recegnn_fixpos'], [50, 5, 27]), (RECEGNN_40KP, [300, 150])])
+                                       (RECEGNN_CFGS['recegnn_fixpos'], [50, 5, 27]), (RECEGNN_40KP, [300, 150]),
+                                       (RECEGNN_RAD5, [33, 21, 2]), (RECEGNN_RAD9, [300, 150])])
 def test_egnn_receptor_encoder(cuda, cfg, n_rec):
     kw = dict(cfg, graph_cutoffs=CUT)
     model = synth.fill_state_dict_(ReceptorEncoder(**kw), 71).eval()
@@ -47,6 +52,10 @@ def test_egnn_receptor_encoder(cuda, cfg, n_rec):
     ks, kd = out.edges(etype='kk')
     assert _edge_set(ks.cpu(), kd.cpu()) == _edge_set(*ref.edges['kk'])
     assert out.batch_num_edges('kk').sum() == ks.numel() and out.batch_num_edges('rk').sum() == rs.numel()
+    if cfg.get('kp_rad', 0) > 0:
+        deg = torch.bincount(rd.cpu(), minlength=out.num_nodes('kp'))
+        assert int(deg.max()) <= 100 and (cfg is not RECEGNN_RAD9 or int(deg.max()) == 100)       # the cap of :246 is exercised
+        assert torch.equal(out.batch_num_edges('rk').cpu(), torch.bincount(rd.cpu() // cfg['n_keypoints'], minlength=len(n_rec)))
 
 
 def test_too_few_receptor_atoms_is_refused(cuda):

@@ -15,6 +15,10 @@ CUT = util.CUTOFFS_ALL_ATOM
 RECENC_40KP = dict(in_scalar_size=10, out_scalar_size=128, n_message_gvps=3, n_update_gvps=2, vector_size=16, n_rr_convs=4,
                    n_rk_convs=2, message_norm=10.0, k_closest=5, kp_rad=0, dropout=0.1, n_keypoints=40)   # gvp_40kp
 RECENC_NORM0 = dict(RECENC_CFGS['recenc_norm10'], message_norm=0)
+# radius rec->kp graph (receptor_encoder_gvp.py:304-306): at most 10 receptor atoms within kp_rad per keypoint; 7 A around a
+# keypoint of a 0.059 atoms/A^3 pocket holds ~80 atoms, so the cap is reached, 1.3 A leaves keypoints with no edge at all
+RECENC_RAD = dict(RECENC_CFGS['recenc_mean'], k_closest=0, kp_rad=7.0)
+RECENC_RAD_SPARSE = dict(RECENC_CFGS['recenc_norm10'], k_closest=0, kp_rad=1.3)
 
 
 def _edge_set(s, d):
@@ -22,7 +26,8 @@ def _edge_set(s, d):
 
 
 @pytest.mark.parametrize('cfg,n_rec', [(RECENC_CFGS['recenc_mean'], [33, 21]), (RECENC_CFGS['recenc_norm10'], [33, 21]),
-                                       (RECENC_NORM0, [50, 3, 27]), (RECENC_40KP, [300, 150])])
+                                       (RECENC_NORM0, [50, 3, 27]), (RECENC_40KP, [300, 150]), (RECENC_RAD, [120, 45]),
+                                       (RECENC_RAD_SPARSE, [60, 8])])
 def test_receptor_encoder(cuda, cfg, n_rec):
     kw = dict(cfg, graph_cutoffs=CUT)
     model = synth.fill_state_dict_(ReceptorEncoderGVP(**kw), 61).eval()
@@ -43,6 +48,12 @@ def test_receptor_encoder(cuda, cfg, n_rec):
     assert _edge_set(ks.cpu(), kd.cpu()) == _edge_set(*ref.edges['kk'])
     assert out.batch_num_edges('kk').sum() == ks.numel() and out.batch_num_edges('rk').sum() == rs.numel()
     assert out.batch_size == len(n_rec)
+    if cfg.get('kp_rad', 0) > 0:
+        deg = torch.bincount(rd.cpu(), minlength=out.num_nodes('kp'))
+        assert int(deg.max()) <= 10 and (cfg is not RECENC_RAD or int(deg.max()) == 10)      # the cap of :306 is exercised
+        assert cfg is not RECENC_RAD_SPARSE or int(deg.min()) == 0                           # and so are edgeless keypoints
+        per_graph = torch.bincount(rd.cpu() // cfg['n_keypoints'], minlength=len(n_rec))
+        assert torch.equal(out.batch_num_edges('rk').cpu(), per_graph)
 
 
 def test_learned_encoder_feeds_gvp_denoiser(cuda):
