@@ -245,18 +245,9 @@ __global__ void k_coord_head_bwd(const float *__restrict__ dxo, const float *__r
     }
 }
 
-// dU[src[e]] += dpre1[e] (atomic; dU zeroed by the caller)
-__global__ void k_scatter_src(const float *__restrict__ dpre1, const int *__restrict__ src, long long total, float *__restrict__ dU) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int e = (int)(i / H), c = (int)(i - (long long)e * H);
-    atomicAdd(&dU[(size_t)src[e] * LD + c], dpre1[(size_t)e * LD + c]);
-}
-
-// geometry backward: n = x_diff / (dij + 1), dij = |x_diff|; scatter to the coordinates of both end points
+// geometry backward: n = x_diff / (dij + 1), dij = |x_diff|; per-edge gradient of x_src (= minus that of x_dst)
 __global__ void k_geom_bwd(const float *__restrict__ ddij, const float *__restrict__ dn, const float *__restrict__ xdiff,
-                           const float *__restrict__ dij, const int *__restrict__ src, const int *__restrict__ dst, int E,
-                           float *__restrict__ dxs, float *__restrict__ dxd) {
+                           const float *__restrict__ dij, int E, float *__restrict__ redge) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
     const float d = dij[e], inv = 1.0f / (d + 1.0f);
@@ -265,9 +256,7 @@ __global__ void k_geom_bwd(const float *__restrict__ ddij, const float *__restri
     const float dd = ddij[e] - (g0 * x0 + g1 * x1 + g2 * x2) * inv * inv;     // total gradient of dij
     const float k = d > 0.0f ? dd / d : 0.0f;
     const float r0 = g0 * inv + k * x0, r1 = g1 * inv + k * x1, r2 = g2 * inv + k * x2;
-    const int u = src[e], v = dst[e];
-    atomicAdd(&dxs[3 * u], r0); atomicAdd(&dxs[3 * u + 1], r1); atomicAdd(&dxs[3 * u + 2], r2);
-    atomicAdd(&dxd[3 * v], -r0); atomicAdd(&dxd[3 * v + 1], -r1); atomicAdd(&dxd[3 * v + 2], -r2);
+    redge[3 * e] = r0; redge[3 * e + 1] = r1; redge[3 * e + 2] = r2;       // + to x_src, - to x_dst: summed per node by the caller
 }
 
 
@@ -298,6 +287,8 @@ struct kpd_egnn_trainer : TrainCtx {
     kpd_lig_graph lg{};
     int *meta = nullptr, *ll_deg = nullptr, *ll_off = nullptr, *kl_off = nullptr, *kl_pg = nullptr, *bidx[2] = {nullptr, nullptr};
     float *z[2] = {nullptr, nullptr}, *zinv[2] = {nullptr, nullptr};
+    SrcCsr scsr[4];                     // edges of each type grouped by source node (deterministic sums over out-edges)
+    int *cursor = nullptr;
     // saved node states: index l = input of layer l (l = n_layers: output of the stack)
     std::vector<float *> hs[2], xs[2], hns[2], xns[2];
     // scratch
@@ -534,6 +525,7 @@ extern "C" kpd_status kpd_egnn_trainer_create(const kpd_egnn_config *cfg, kpd_eg
         set_error("rocblas_create_handle failed");
         return KPD_ERR_HIP;
     }
+    (void)rocblas_set_atomics_mode(T->blas, rocblas_atomics_not_allowed);      // bitwise-reproducible products
     *out = T;
     return KPD_OK;
 }
@@ -597,6 +589,10 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
     add(cap_ll, 4); add(cap_ll, 4); add(max_n_lig + 1, 4);
     for (int i = 0; i < 4; ++i) add(cap_kl, 4);
     add(max_n_lig + 1, 4); add(max_n_kp + 1, 4); add(max_B, 4); add(8, 4);
+    const int cap_et[4] = {cap_ll, cap_kl, cap_kl, std::max<int>(max_n_kk, 1)};
+    for (int et = 0; et < 4; ++et) { add(cap_et[et], 4); add(nn[kS[et]] + 1, 4); }
+    add(cap_N, 4);
+    add(colpart_floats(std::max(cap_E, cap_N)), 4);
     T->ws.release();
     KPD_TRY(T->ws.reserve(bytes + 4096));
     Arena &W = T->ws;
@@ -638,7 +634,11 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
     g.lk_src = W.take<int>(cap_kl); g.lk_dst = W.take<int>(cap_kl); g.lk_rowptr = W.take<int>(max_n_kp + 1);
     g.ll_per_graph = W.take<int>(max_B);
     g.counts = W.take<int>(8);
-    KPD_REQUIRE(g.counts != nullptr, KPD_ERR_HIP, "workspace arena too small (internal sizing error)");
+    for (int et = 0; et < 4; ++et) { T->scsr[et].perm = W.take<int>(cap_et[et]); T->scsr[et].rowptr = W.take<int>(nn[kS[et]] + 1); }
+    T->cursor = W.take<int>(cap_N);
+    T->colpart_blocks = cdiv(std::max(cap_E, cap_N), COLSUM_ROWS);
+    T->colpart = W.take<float>(colpart_floats(std::max(cap_E, cap_N)));
+    KPD_REQUIRE(T->colpart != nullptr, KPD_ERR_HIP, "workspace arena too small (internal sizing error)");
     hipLaunchKernelGGL(k_fill, grid1(n_ones), dim3(256), 0, nullptr, T->ones, 1.0f, (long long)n_ones);
     KPD_LAUNCH_CHECK();
     KPD_HIP(hipDeviceSynchronize());
@@ -711,6 +711,7 @@ extern "C" kpd_status kpd_egnn_trainer_forward(kpd_egnn_trainer *T, const kpd_ba
         hipLaunchKernelGGL(k_zinv, grid1(T->n[nt]), dim3(256), 0, st, T->z[nt], T->bidx[nt], T->n[nt], T->zinv[nt]);
         KPD_LAUNCH_CHECK();
     }
+    for (int et = 0; et < T->n_et; ++et) KPD_TRY(build_src_csr(T, T->e_src[et], T->E[et], T->n[kS[et]], T->cursor, T->scsr[et]));
     KPD_TRY(encoders_fwd(T));
     for (int l = 0; l < L; ++l) {
         KPD_TRY(layer_fwd(T, l));
@@ -784,10 +785,9 @@ kpd_status edge_branch_bwd(kpd_egnn_trainer *T, const BranchParams &p, int l, in
     // b1 gradient and column 514 of W1 (the dij weights) in one pass over dpre1
     KPD_TRY(gemv_t_colsum_acc(T, E, H, dpre1, LD, T->dij, p.W1.g ? p.W1.g + 2 * H : nullptr, 2 * H + 1, p.b1.g));
     KPD_TRY(gemv_n(T, E, H, dpre1, LD, p.W1.w + 2 * H, 2 * H + 1, first_branch ? 0.0f : 1.0f, T->ddij, 1));
-    // per-node sums: dV (by dst, segmented) and dU (by src, atomics)
+    // per-node sums: dV (by dst) and dU (by src), both segmented sums in a fixed order
     float *dU = T->nb[0], *dV = T->nb[1];
-    KPD_HIP(hipMemsetAsync(dU, 0, (size_t)ns * LD * 4, T->st));
-    hipLaunchKernelGGL(k_scatter_src, grid1(tot), dim3(256), 0, T->st, dpre1, T->e_src[et], tot, dU);
+    hipLaunchKernelGGL(k_segsum_perm, dim3(ns), dim3(256), 0, T->st, dpre1, LD, 0, H, T->scsr[et].perm, T->scsr[et].rowptr, 1.0f, 0, dU, LD);
     KPD_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_segsum_rows, dim3(nd), dim3(256), 0, T->st, dpre1, (const float *)nullptr, T->e_rowptr[et],
                        (const float *)nullptr, 0, dV);
@@ -837,8 +837,14 @@ kpd_status layer_bwd(kpd_egnn_trainer *T, int l, int cur, int nxt, float *dhn[2]
         KPD_LAUNCH_CHECK();
         KPD_TRY(gemv_t_acc(T, E, H, T->eb[3], LD, T->dsv, p.head.g, 1));
         KPD_TRY(edge_branch_bwd(T, p, l, et, nxt, false));
-        hipLaunchKernelGGL(k_geom_bwd, grid1(E), dim3(256), 0, T->st, T->ddij, T->dn, T->xdiff, T->dij, T->e_src[et], T->e_dst[et], E,
-                           T->dx[nxt][s], T->dx[nxt][d]);
+        float *redge = T->msgx;                         // free again: the coordinate head consumed it above
+        hipLaunchKernelGGL(k_geom_bwd, grid1(E), dim3(256), 0, T->st, T->ddij, T->dn, T->xdiff, T->dij, E, redge);
+        KPD_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_segsum_perm, dim3(T->n[s]), dim3(64), 0, T->st, redge, 3, 0, 3, T->scsr[et].perm, T->scsr[et].rowptr, 1.0f, 1,
+                           T->dx[nxt][s], 3);
+        KPD_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_segsum_perm, dim3(T->n[d]), dim3(64), 0, T->st, redge, 3, 0, 3, (const int *)nullptr, T->e_rowptr[et], -1.0f, 1,
+                           T->dx[nxt][d], 3);
         KPD_LAUNCH_CHECK();
     }
     return KPD_OK;

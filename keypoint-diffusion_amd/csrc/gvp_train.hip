@@ -66,25 +66,6 @@ __global__ void k_gather_rows(const float *__restrict__ A, const int *__restrict
     out[i] = A[(size_t)v * cols + c] * (scale ? scale[v] : 1.0f);
 }
 
-// out[idx[r]] += A[r] (atomic), optionally only columns [c0, c0 + cols) of rows that are lda wide
-__global__ void k_scatter_rows(const float *__restrict__ A, int lda, int c0, const int *__restrict__ idx, long long total, int cols,
-                               float *__restrict__ out) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
-    atomicAdd(&out[(size_t)idx[r] * cols + c], A[(size_t)r * lda + c0 + c]);
-}
-
-// vector rows [E, 3, 17] channels 1..16 -> dv[src[e], 3, 16] (atomic)
-__global__ void k_scatter_vin(const float *__restrict__ dvin, const int *__restrict__ src, long long total, float *__restrict__ dv) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int ch = (int)(i % VC);
-    const long long ec = i / VC;
-    const int e = (int)(ec / 3), c = (int)(ec - 3LL * e);
-    atomicAdd(&dv[((size_t)src[e] * 3 + c) * VC + ch], dvin[((size_t)e * 3 + c) * VH + ch + 1]);
-}
-
 // acc[v] += scale[v] * sum over the edges of dst node v of M[e] (rows `cols` wide), one workgroup per dst node
 __global__ void k_segsum(const float *__restrict__ M, int cols, const int *__restrict__ rowptr, const float *__restrict__ scale,
                          float *__restrict__ acc) {
@@ -325,6 +306,8 @@ struct kpd_gvp_trainer : TrainCtx {
               *e_rowptr[4] = {nullptr, nullptr, nullptr, nullptr};
     kpd_lig_graph lg{};
     int *meta = nullptr, *ll_deg = nullptr, *ll_off = nullptr, *kl_off = nullptr, *kl_pg = nullptr, *bidx[2] = {nullptr, nullptr};
+    SrcCsr scsr[4];                     // edges of each type grouped by source node (deterministic sums over out-edges)
+    int *cursor = nullptr;
     float *z[2] = {nullptr, nullptr};
     // saved node state: ss[nt][i], vs[nt][i] = input of conv i (i = n_convs: output); sa / va = pre-LayerNorm sums of conv i
     std::vector<float *> ss[2], vs[2], sa[2], va[2];
@@ -659,15 +642,17 @@ kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
         KPD_TRY(gvp_bwd(T, g0, E, nullptr, 0, T->vin, T->gb[0], false, T->ds[0], T->dV[0], nullptr, T->dV[1]));
         // ds[0] = dL/dpre of the first GVP: its scalar inputs were U[src] and rbf
         if (g0.Ws.g) KPD_TRY(grad_gemm(T, S, RBF, E, T->ds[0], S, T->rbf, RBF, g0.Ws.g + S, g0.si + g0.h));
-        KPD_HIP(hipMemsetAsync(T->U, 0, (size_t)T->n[s] * S * 4, T->st));
-        hipLaunchKernelGGL(k_scatter_rows, grid1((long long)E * S), dim3(256), 0, T->st, T->ds[0], S, 0, T->e_src[et], (long long)E * S, S,
-                           T->U);
+        // sums over the out-edges of every source node, in ascending edge order (no float atomics)
+        hipLaunchKernelGGL(k_segsum_perm, dim3(T->n[s]), dim3(256), 0, T->st, T->ds[0], S, 0, S, T->scsr[et].perm, T->scsr[et].rowptr, 1.0f, 0,
+                           T->U, S);
         KPD_LAUNCH_CHECK();
         if (g0.Ws.g) KPD_TRY(grad_gemm(T, S, S, T->n[s], T->U, S, T->ss[s][conv], S, g0.Ws.g, g0.si + g0.h));
         KPD_TRY(gemm(T, false, false, T->n[s], S, S, T->U, S, g0.Ws.w, g0.si + g0.h, 1.0f, T->gs[nxt][s], S));
-        hipLaunchKernelGGL(k_scatter_vin, grid1((long long)E * 3 * VC), dim3(256), 0, T->st, T->dV[1], T->e_src[et], (long long)E * 3 * VC,
-                           T->gv[nxt][s]);
-        KPD_LAUNCH_CHECK();
+        for (int cc = 0; cc < 3; ++cc) {      // vector rows [E, 3, 17], channels 1..16 -> gv[src, 3, 16]
+            hipLaunchKernelGGL(k_segsum_perm, dim3(T->n[s]), dim3(64), 0, T->st, T->dV[1], 3 * VH, cc * VH + 1, VC, T->scsr[et].perm,
+                               T->scsr[et].rowptr, 1.0f, 1, T->gv[nxt][s] + cc * VC, 3 * VC);
+            KPD_LAUNCH_CHECK();
+        }
     }
     return KPD_OK;
 }
@@ -766,6 +751,7 @@ extern "C" kpd_status kpd_gvp_trainer_create(const kpd_gvp_config *cfg, kpd_gvp_
         set_error("rocblas_create_handle failed");
         return KPD_ERR_HIP;
     }
+    (void)rocblas_set_atomics_mode(T->blas, rocblas_atomics_not_allowed);      // bitwise-reproducible products
     *out = T;
     return KPD_OK;
 }
@@ -862,6 +848,10 @@ extern "C" kpd_status kpd_gvp_trainer_reserve(kpd_gvp_trainer *T, int32_t max_B,
         F(T->part, (size_t)GRAD_SPLIT * 264 * 520);
         F(T->wsg_pack, (size_t)ws_gemm_pack_floats());
         F(T->ones, 8);
+        const int cap_et[4] = {cap_ll, cap_kl, cap_kl, std::max<int>(max_n_kk, 1)};
+        for (int et = 0; et < 4; ++et) { I(T->scsr[et].perm, cap_et[et]); I(T->scsr[et].rowptr, nn[kSrc[et]] + 1); }
+        I(T->cursor, std::max(max_n_lig, max_n_kp));
+        F(T->colpart, colpart_floats(R));
         I(T->meta, 32); I(T->ll_deg, max_n_lig); I(T->ll_off, max_B + 1); I(T->kl_off, max_B + 1); I(T->kl_pg, max_B + 2);
         kpd_lig_graph &g = T->lg;
         I(g.ll_src, cap_ll); I(g.ll_dst, cap_ll); I(g.ll_rowptr, max_n_lig + 1);
@@ -873,6 +863,7 @@ extern "C" kpd_status kpd_gvp_trainer_reserve(kpd_gvp_trainer *T, int32_t max_B,
     KPD_REQUIRE(T->lg.counts != nullptr, KPD_ERR_HIP, "workspace arena too small (internal sizing error)");
     T->part_floats = (size_t)GRAD_SPLIT * 264 * 520;
     T->lg.cap_ll = cap_ll; T->lg.cap_kl = cap_kl;
+    T->colpart_blocks = cdiv(R, COLSUM_ROWS);
     T->cap_B = max_B; T->cap_lig = max_n_lig; T->cap_kp = max_n_kp; T->cap_kk = max_n_kk; T->cap_maxlig = max_lig_pg;
     T->cap_maxkp = max_kp_pg; T->cap_ll = cap_ll; T->cap_kl = cap_kl; T->cap_R = R;
     T->have_forward = false;
@@ -908,6 +899,7 @@ extern "C" kpd_status kpd_gvp_trainer_forward(kpd_gvp_trainer *T, const kpd_batc
     T->e_src[ET_KL] = T->lg.kl_src; T->e_dst[ET_KL] = T->lg.kl_dst; T->e_rowptr[ET_KL] = T->lg.kl_rowptr;
     T->e_src[ET_LK] = T->lg.lk_src; T->e_dst[ET_LK] = T->lg.lk_dst; T->e_rowptr[ET_LK] = T->lg.lk_rowptr;
     T->e_src[ET_KK] = bt->kk_src; T->e_dst[ET_KK] = bt->kk_dst; T->e_rowptr[ET_KK] = bt->kk_rowptr;
+    for (int et = 0; et < 4; ++et) KPD_TRY(build_src_csr(T, T->e_src[et], T->E[et], T->n[kSrc[et]], T->cursor, T->scsr[et]));
     // node state of conv 0: encoders; ligand vectors start at zero, keypoint vectors are v_0 (dynamics_gvp.py:179-189)
     KPD_TRY(encoder_fwd(T, 0));
     KPD_TRY(encoder_fwd(T, 1));

@@ -89,11 +89,13 @@ __global__ void k_sub_inplace(float *__restrict__ a, const float *__restrict__ b
 
 // y[c * incy] += sum over rows r of A[r][c] * (x ? x[r] : 1): bias gradients and the A^T x products of the heads.
 // Tall-skinny (hundreds of thousands of rows, <= 512 columns): a row block per workgroup, columns across threads
-// (coalesced row reads), one atomic per column and workgroup.
+// (coalesced row reads).  Every workgroup writes its partial sums to part[block][0 | 1][c]; k_colsum_reduce adds the blocks in
+// block order, so the result is bitwise reproducible (float atomics in arrival order were not).
 constexpr int COLSUM_ROWS = 256, COLSUM_THREADS = 320;       // 320 threads: the 257 columns of a layer in one pass
-__global__ void k_colsum(const float *__restrict__ A, int lda, const float *__restrict__ x, int M, int K, float *__restrict__ y,
-                         int incy, float *__restrict__ y2) {
+constexpr int COLSUM_LD = 512;                               // columns per partial row (K <= 512)
+__global__ void k_colsum(const float *__restrict__ A, int lda, const float *__restrict__ x, int M, int K, float *__restrict__ part) {
     const int r0 = blockIdx.x * COLSUM_ROWS, r1 = min(M, r0 + COLSUM_ROWS);
+    float *p = part + (size_t)blockIdx.x * 2 * COLSUM_LD;
     for (int c = threadIdx.x; c < K; c += blockDim.x) {
         float s0 = 0.0f, s1 = 0.0f, p0 = 0.0f, p1 = 0.0f;       // s: weighted by x (or plain), p: plain sums when both are wanted
         int r = r0;
@@ -109,8 +111,125 @@ __global__ void k_colsum(const float *__restrict__ A, int lda, const float *__re
             s0 = fmaf(a0, x ? x[r] : 1.0f, s0);
             p0 += a0;
         }
-        if (y) atomicAdd(&y[(size_t)c * incy], s0 + s1);
-        if (y2) atomicAdd(&y2[c], p0 + p1);
+        p[c] = s0 + s1;
+        p[COLSUM_LD + c] = p0 + p1;
+    }
+}
+
+// one workgroup of 64 columns x 16 block-slices: slice g adds the partials of blocks g, g + 16, ... in order, the 16 slice sums
+// are combined in slice order -- a fixed tree, so the result does not depend on timing
+__global__ __launch_bounds__(1024) void k_colsum_reduce(const float *__restrict__ part, int blocks, int K, float *__restrict__ y, int incy,
+                                                        float *__restrict__ y2) {
+    __shared__ float s_s[16][64], s_p[16][64];
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    float s = 0.0f, p = 0.0f;
+    if (c < K)
+        for (int b = g; b < blocks; b += 16) {
+            s += part[(size_t)b * 2 * COLSUM_LD + c];
+            p += part[(size_t)b * 2 * COLSUM_LD + COLSUM_LD + c];
+        }
+    s_s[g][cl] = s;
+    s_p[g][cl] = p;
+    __syncthreads();
+    if (g == 0 && c < K) {
+        float ts = 0.0f, tp = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            ts += s_s[k][cl];
+            tp += s_p[k][cl];
+        }
+        if (y) y[(size_t)c * incy] += ts;
+        if (y2) y2[c] += tp;
+    }
+}
+
+// ---- edges grouped by SOURCE node (the engines' edge lists are dst-sorted) ------------------------------------------------
+// Sums over the out-edges of a node (the gradients that flow back to h_src / x_src) used to be float atomics; they are
+// segmented sums over this index now: perm lists the edge ids of each source node in ascending order, rowptr [n_src + 1].
+// Built per forward: integer histogram (atomics on counts: order-free), scan, scatter, then every node sorts its own
+// short segment, which makes the summation order a function of the graph alone.
+struct SrcCsr {
+    int *rowptr = nullptr, *perm = nullptr;
+};
+
+__global__ void k_idx_count(const int *__restrict__ idx, int E, int *__restrict__ cnt) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E) atomicAdd(&cnt[idx[e]], 1);
+}
+
+__global__ void k_idx_scan(const int *cnt, int n, int *__restrict__ rowptr, int *cursor) {      // cnt may alias cursor
+    __shared__ int s_part[1024];
+    __shared__ int s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += blockDim.x) {
+        const int i = base + threadIdx.x;
+        const int v = i < n ? cnt[i] : 0;
+        s_part[threadIdx.x] = v;
+        __syncthreads();
+        for (int st = 1; st < (int)blockDim.x; st <<= 1) {
+            const int t = (int)threadIdx.x >= st ? s_part[threadIdx.x - st] : 0;
+            __syncthreads();
+            s_part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < n) {
+            rowptr[i] = s_carry + s_part[threadIdx.x] - v;
+            cursor[i] = rowptr[i];
+        }
+        __syncthreads();
+        if (threadIdx.x == blockDim.x - 1) s_carry += s_part[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) rowptr[n] = s_carry;
+}
+
+__global__ void k_idx_fill(const int *__restrict__ idx, int E, int *__restrict__ cursor, int *__restrict__ perm) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E) perm[atomicAdd(&cursor[idx[e]], 1)] = e;
+}
+
+// every source node orders its own segment by edge id: one wave per node, segment staged in LDS, each element's final
+// position is its rank (ids are unique); segments longer than SEG_LDS fall back to an in-place insertion sort by one lane
+constexpr int SEG_LDS = 2048;
+__global__ __launch_bounds__(64) void k_idx_sort_segments(const int *__restrict__ rowptr, int n, int *__restrict__ perm) {
+    __shared__ int s_key[SEG_LDS];
+    const int v = blockIdx.x;
+    const int lo = rowptr[v], d = rowptr[v + 1] - lo;
+    if (d <= 1) return;
+    if (d <= SEG_LDS) {
+        for (int i = threadIdx.x; i < d; i += 64) s_key[i] = perm[lo + i];
+        __syncthreads();
+        for (int i = threadIdx.x; i < d; i += 64) {
+            const int key = s_key[i];
+            int rank = 0;
+            for (int j = 0; j < d; ++j) rank += s_key[j] < key;
+            perm[lo + rank] = key;
+        }
+    } else if (threadIdx.x == 0) {
+        for (int i = lo + 1; i < lo + d; ++i) {
+            const int key = perm[i];
+            int j = i - 1;
+            while (j >= lo && perm[j] > key) {
+                perm[j + 1] = perm[j];
+                --j;
+            }
+            perm[j + 1] = key;
+        }
+    }
+}
+
+// out[v][c] (+)= alpha * sum over j in [rowptr[v], rowptr[v + 1]) of M[perm ? perm[j] : j][c0 + c], c < cols; one workgroup per node
+__global__ void k_segsum_perm(const float *__restrict__ M, int lda, int c0, int cols, const int *__restrict__ perm,
+                              const int *__restrict__ rowptr, float alpha, int accumulate, float *__restrict__ out, int ldo) {
+    const int v = blockIdx.x;
+    const int lo = rowptr[v], hi = rowptr[v + 1];
+    if (lo == hi && accumulate) return;
+    for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+        float s = 0.0f;
+        for (int j = lo; j < hi; ++j) s += M[(size_t)(perm ? perm[j] : j) * lda + c0 + c];
+        if (accumulate) out[(size_t)v * ldo + c] += alpha * s;
+        else out[(size_t)v * ldo + c] = alpha * s;
     }
 }
 
@@ -139,8 +258,12 @@ struct TrainCtx {
     float *part = nullptr;
     size_t part_floats = 0;
     float *ones = nullptr;
+    float *colpart = nullptr;          // [colpart_blocks][2][COLSUM_LD] partial column sums (k_colsum -> k_colsum_reduce)
+    int colpart_blocks = 0;
     std::map<std::string, Param> params;
 };
+
+inline size_t colpart_floats(int max_rows) { return (size_t)cdiv(std::max(max_rows, 1), COLSUM_ROWS) * 2 * COLSUM_LD; }
 
 #define KPD_BLAS(call)                                                                            \
     do {                                                                                          \
@@ -174,18 +297,39 @@ kpd_status gemv_n(TrainCtx *T, int M, int K, const float *A, int lda, const floa
 }
 
 // y[K] (stride incy) += A[M,K]^T x[M] (x = nullptr: column sums), A row-major
+kpd_status gemv_t_colsum_acc(TrainCtx *T, int M, int K, const float *A, int lda, const float *x, float *y, int incy, float *y2);
 kpd_status gemv_t_acc(TrainCtx *T, int M, int K, const float *A, int lda, const float *x, float *y, int incy) {
-    if (M == 0 || !y) return KPD_OK;
-    hipLaunchKernelGGL(k_colsum, dim3(cdiv(M, COLSUM_ROWS)), dim3(COLSUM_THREADS), 0, T->st, A, lda, x, M, K, y, incy, (float *)nullptr);
-    KPD_LAUNCH_CHECK();
-    return KPD_OK;
+    return gemv_t_colsum_acc(T, M, K, A, lda, x, y, incy, nullptr);
 }
 
 // y[K] (stride incy) += A^T x and y2[K] += column sums of A, in one pass over A
 kpd_status gemv_t_colsum_acc(TrainCtx *T, int M, int K, const float *A, int lda, const float *x, float *y, int incy, float *y2) {
     if (M == 0 || (!y && !y2)) return KPD_OK;
-    hipLaunchKernelGGL(k_colsum, dim3(cdiv(M, COLSUM_ROWS)), dim3(COLSUM_THREADS), 0, T->st, A, lda, x, M, K, y, incy, y2);
+    const int blocks = cdiv(M, COLSUM_ROWS);
+    KPD_REQUIRE(K <= COLSUM_LD && blocks <= T->colpart_blocks && T->colpart, KPD_ERR_CAPACITY,
+                "column-sum scratch too small (%d row blocks of %d, %d columns)", blocks, T->colpart_blocks, K);
+    hipLaunchKernelGGL(k_colsum, dim3(blocks), dim3(COLSUM_THREADS), 0, T->st, A, lda, x, M, K, T->colpart);
     KPD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_colsum_reduce, dim3(cdiv(K, 64)), dim3(1024), 0, T->st, T->colpart, blocks, K, y, incy, y2);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+// edges of one type grouped by source node: perm [E], rowptr [n_src + 1]; cursor: [n_src] scratch
+kpd_status build_src_csr(TrainCtx *T, const int *src, int E, int n_src, int *cursor, const SrcCsr &out) {
+    KPD_HIP(hipMemsetAsync(cursor, 0, (size_t)n_src * sizeof(int), T->st));
+    if (E > 0) {
+        hipLaunchKernelGGL(k_idx_count, grid1(E), dim3(256), 0, T->st, src, E, cursor);
+        KPD_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_idx_scan, dim3(1), dim3(1024), 0, T->st, cursor, n_src, out.rowptr, cursor);
+    KPD_LAUNCH_CHECK();
+    if (E > 0) {
+        hipLaunchKernelGGL(k_idx_fill, grid1(E), dim3(256), 0, T->st, src, E, cursor, out.perm);
+        KPD_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_idx_sort_segments, dim3(n_src), dim3(64), 0, T->st, out.rowptr, n_src, out.perm);
+        KPD_LAUNCH_CHECK();
+    }
     return KPD_OK;
 }
 

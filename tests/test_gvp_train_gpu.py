@@ -172,3 +172,24 @@ def test_stale_forward_cannot_be_differentiated():
         next(p for p in model.parameters() if p.numel()).mul_(1.01)
     with pytest.raises(RuntimeError, match='modified by an inplace operation'):
         (eh3.sum() + ex3.sum()).backward()
+
+
+def test_training_step_is_bitwise_reproducible():
+    """As for the EGNN trainer: two forward/backward passes of the same batch (dropout off) are bit-identical."""
+    cfg = dict(GVP_CFGS['gvp_norm0'])
+    g, model, t = _case(cfg, [40, 33], [9, 12], 10)
+    model = model.cuda()
+    runs = []
+    for _ in range(2):
+        gd = g.to('cuda')
+        ins = []
+        for nt, key in (('lig', 'h_0'), ('kp', 'h_0'), ('kp', 'v_0')):
+            v = gd.nodes[nt].data[key].detach().clone().requires_grad_(True)
+            gd.nodes[nt].data[key] = v
+            ins.append(v)
+        model.zero_grad(set_to_none=True)
+        eh, ex = model(gd, t.cuda(), None)
+        (eh.square().sum() + ex.square().sum()).backward()
+        runs.append([eh.detach().clone(), ex.detach().clone()] + [v.grad.clone() for v in ins] +
+                    [p.grad.clone() for p in model.parameters() if p.grad is not None])
+    assert all(torch.equal(a, b) for a, b in zip(*runs))
