@@ -6,7 +6,8 @@ namespace kpd {
 
 constexpr int NSLOT = 8;            // projection slots per node row of P
 constexpr int ATT_BIAS_AT = 260;
-constexpr int BIAS_K = 257;          // A-tile column that holds the constant 1 multiplying the bias row of edge GEMMs    // soft_attention bias is parked in the pad of its weight row
+constexpr int BIAS_K = 260;          // A-tile column that holds the constant 1 multiplying the bias row of edge GEMMs: with the last real
+                                     // feature at k = 256 it shares k-step 0 of the last k-group (mfma_core.h, TailSteps)    // soft_attention bias is parked in the pad of its weight row
 constexpr int ET_LL = 0, ET_KL = 1, ET_LK = 2, ET_KK = 3;
 constexpr int NT_LIG = 0, NT_KP = 1;
 

@@ -222,7 +222,7 @@ __device__ __forceinline__ void edge_gather_finish(const EdgeGather<NW> &g, cons
         const f32x4 w1 = reinterpret_cast<const f32x4 *>(wr)[64 + c];
         f32x4 u = g.tps + g.tpd + s.d[r] * w1;
         u[0] = silu_pre(u[0]); u[1] = silu_pre(u[1]); u[2] = silu_pre(u[2]); u[3] = silu_pre(u[3]);
-        if (c == 0) u[BIAS_K - 256] = 1.0f;               // constant-1 column: the GEMM adds the bias row itself
+        if (c == (BIAS_K - 256) / 4) u[(BIAS_K - 256) % 4] = 1.0f;   // constant-1 column: the GEMM adds the bias row itself
         *reinterpret_cast<f32x4 *>(s.A + r * SA + 256 + 4 * c) = u;
     }
 }
@@ -559,7 +559,7 @@ __device__ __forceinline__ void edge_gather_finish32(const EdgeGather32 &g, cons
         const f32x4 w1 = reinterpret_cast<const f32x4 *>(wr)[64 + c];
         f32x4 u = g.tps + g.tpd + s.d[r] * w1;
         u[0] = silu_pre(u[0]); u[1] = silu_pre(u[1]); u[2] = silu_pre(u[2]); u[3] = silu_pre(u[3]);
-        if (c == 0) u[BIAS_K - 256] = 1.0f;
+        if (c == (BIAS_K - 256) / 4) u[(BIAS_K - 256) % 4] = 1.0f;
         *reinterpret_cast<f32x4 *>(s.A + r * SA + 256 + 4 * c) = u;
     }
 }

@@ -53,6 +53,20 @@ __device__ __forceinline__ void acc_zero(f32x16 (&acc)[2][2]) {
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[j], B1[j], acc[1][1], 0, 0, 0);       \
     }
 
+// Tail group of a K = 264 tile: the 257 real features end at k = 256 and the bias "one" sits at k = 260, i.e. both live in
+// k-step j = 0 of group 32 (k = 8 g + 4 h + j, one k per lane half); steps 1..3 of that group multiply zero padding only.
+template <int NG_>
+struct TailSteps {
+    static constexpr int J = NG_ == 33 ? 1 : 4;
+};
+#define KPD_GEMM_STEP_N(A0, A1, B0, B1, NJ)                                                      \
+    _Pragma("unroll") for (int j = 0; j < (NJ); ++j) {                                            \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[j], B0[j], acc[0][0], 0, 0, 0);       \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[j], B1[j], acc[0][1], 0, 0, 0);       \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[j], B0[j], acc[1][0], 0, 0, 0);       \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[j], B1[j], acc[1][1], 0, 0, 0);       \
+    }
+
 #define KPD_GEMM_LOAD(A0, A1, B0, B1, G)                              \
     A0 = *reinterpret_cast<const f32x4 *>(a0p + 8 * (G));             \
     A1 = *reinterpret_cast<const f32x4 *>(a1p + 8 * (G));             \
@@ -109,7 +123,7 @@ __device__ __forceinline__ void gemm_rows64_pre(const float *__restrict__ A, con
     }
     if (NG_ & 1) {
         __builtin_amdgcn_sched_barrier(0);
-        KPD_GEMM_STEP(xa0, xa1, xb0, xb1)
+        KPD_GEMM_STEP_N(xa0, xa1, xb0, xb1, TailSteps<NG_>::J)
     }
 }
 
@@ -147,7 +161,7 @@ __device__ __forceinline__ void gemm_rows64_t(const float *__restrict__ A, const
     }
     if (NG_ & 1) {
         __builtin_amdgcn_sched_barrier(0);
-        KPD_GEMM_STEP(xa0, xa1, xb0, xb1)
+        KPD_GEMM_STEP_N(xa0, xa1, xb0, xb1, TailSteps<NG_>::J)
     }
 }
 
@@ -190,10 +204,14 @@ __device__ __forceinline__ void gemm_rows32_t(const float *__restrict__ A, const
             KPD_LOAD32(i, gn)
         }
     }
-#pragma unroll
-    for (int i = 0; i < (NG_ & 3); ++i) {
+    static_assert((NG_ & 3) <= 1, "tail handling assumes at most one group past the last quad");
+    if (NG_ & 3) {
         __builtin_amdgcn_sched_barrier(0);
-        KPD_STEP32(i)
+#pragma unroll
+        for (int j = 0; j < TailSteps<NG_>::J; ++j) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[0][j], b0[0][j], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[0][j], b1[0][j], acc[1], 0, 0, 0);
+        }
     }
 #undef KPD_LOAD32
 #undef KPD_STEP32
@@ -232,10 +250,11 @@ __device__ __forceinline__ void gemm_rows32_t8(const float *__restrict__ A, cons
             KPD_LOAD32(i, gn)
         }
     }
-#pragma unroll
-    for (int i = 0; i < (NG_ & 3); ++i) {
+    static_assert((NG_ & 3) <= 1, "tail handling assumes at most one group past the last quad");
+    if (NG_ & 3) {
         __builtin_amdgcn_sched_barrier(0);
-        KPD_STEP32(i)
+#pragma unroll
+        for (int j = 0; j < TailSteps<NG_>::J; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[0][j], b0[0][j], acc, 0, 0, 0);
     }
 #undef KPD_LOAD32
 #undef KPD_STEP32
