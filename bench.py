@@ -39,6 +39,9 @@ DYNAMICS = dict(hidden_nf=256, kl_k=5, ll_k=0, message_norm=0, n_layers=6, no_cg
                 update_kp_feat=True, use_tanh=True)
 PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 MFMA peak (= the fp32 vector peak)
 PEAK_HBM_GBS = 8000.0
+# What back-to-back fp32 MFMAs deliver on all CUs of this part at once (profiles/tools/gemm_loop_probe.hip, profiles/r02_gemm_loop_probe.txt:
+# 64.1 cycles per v_mfma_f32_32x32x2_f32 -- a full pipe -- at the ~2.0 GHz the chip holds under that load).  Context for `frac`, not the peak.
+SUSTAINED_F32_MFMA_TFLOPS = 132.0
 # FLOPs the fused EGNN edge kernel executes per edge per layer: the two 257x257 second Linears of edge_mlp /
 # coord_mlp plus the attention and coordinate heads (the first Linears run per NODE, k_proj_ws)
 EDGE_KERNEL_FLOP_PER_EDGE = 2 * (2 * 257 * 257) + 2 * (2 * 257)
@@ -380,7 +383,11 @@ def run_sampling(args, workload, device, rank, world, dist, B, n_rec, n_lig, rag
         'edges_per_launch': {**counts, 'E_full_layer': e_all, 'launches_per_step': n_launch_step,
                              'mean_edges_per_launch': edges_per_launch},
         'roofline': {'kernel': kernel, 'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MATRIX_TFLOPS,
-                     'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MATRIX_TFLOPS, 'traffic': traffic,
+                     'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MATRIX_TFLOPS,
+                     'peak_sustained_measured': {'value': SUSTAINED_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac_of_it': achieved / SUSTAINED_F32_MFMA_TFLOPS,
+                                                 'source': 'profiles/r02_gemm_loop_probe.txt: bare fp32 MFMA loop on every CU, 64.1 cycles per MFMA at '
+                                                           'the ~2.0 GHz the part holds under that load (DVFS); the nominal peak assumes 2.4 GHz'},
+                     'traffic': traffic,
                      'traffic_source': tsrc,
                      'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, 2 x FETCH_SIZE + WRITE_SIZE, separate passes; committed '
                                      'figure, not re-measured in this run)',

@@ -188,18 +188,20 @@ template <int NW>
 __device__ __forceinline__ void edge_gather_issue(EdgeGather<NW> &g, const EdgeSmem &s, const float *__restrict__ Ps,
                                                   const float *__restrict__ Pd, int wave, int lane) {
     constexpr int RPW = TM / NW;
-    const size_t prow = (size_t)NSLOT * HS;
-    // one 1-KiB row segment per wave instruction, all rows of the wave in flight
+    // 32-bit byte offsets from a wave-uniform base (P stays far below 4 GB): a 64-bit multiply-add per row and side is VALU
+    // time, and VALU time is MFMA time on this pipe.  One 1-KiB row segment per wave instruction, all rows in flight.
+    constexpr unsigned PROW_B = NSLOT * HS * 4;
+    const char *ps = reinterpret_cast<const char *>(Ps), *pd = reinterpret_cast<const char *>(Pd);
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
         const int r = wave * RPW + rr;
-        g.ps[rr] = reinterpret_cast<const f32x4 *>(Ps + s.src[r] * prow)[lane];
-        g.pd[rr] = reinterpret_cast<const f32x4 *>(Pd + s.dst[r] * prow)[lane];
+        g.ps[rr] = *reinterpret_cast<const f32x4 *>(ps + ((unsigned)s.src[r] * PROW_B + 16u * lane));
+        g.pd[rr] = *reinterpret_cast<const f32x4 *>(pd + ((unsigned)s.dst[r] * PROW_B + 16u * lane));
     }
     if (lane < 4 * RPW && (lane & 3) < 2) {
         const int r = wave * RPW + (lane >> 2), c = lane & 3;
-        g.tps = reinterpret_cast<const f32x4 *>(Ps + s.src[r] * prow)[64 + c];
-        g.tpd = reinterpret_cast<const f32x4 *>(Pd + s.dst[r] * prow)[64 + c];
+        g.tps = *reinterpret_cast<const f32x4 *>(ps + ((unsigned)s.src[r] * PROW_B + 16u * (64 + c)));
+        g.tpd = *reinterpret_cast<const f32x4 *>(pd + ((unsigned)s.dst[r] * PROW_B + 16u * (64 + c)));
     }
 }
 
