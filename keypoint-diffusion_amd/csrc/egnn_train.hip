@@ -199,50 +199,94 @@ __global__ void k_ln_bwd(const float *__restrict__ h, const float *__restrict__ 
     }
 }
 
-// feature head backward, one wave per edge: msg_h = a2 * att, att = sigmoid(a2 . wa + ba), summed into h_neigh[dst] / z.
-//   dmsg = dhn[dst] * zinv[dst]; ds = (dmsg . a2) att (1 - att); da2 = dmsg att + ds wa; dpre2 = da2 SiLU'(pre2)
-__global__ void k_feat_head_bwd(const float *__restrict__ dhn, const float *__restrict__ zinv, const int *__restrict__ dst,
-                                const float *__restrict__ a2, const float *__restrict__ att, const float *__restrict__ wa,
-                                const float *__restrict__ pre2, int E, float *__restrict__ dpre2, float *__restrict__ ds_att) {
-    const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (e >= E) return;
-    const int v = dst[e];
-    const float zi = zinv[v], a = att[e];
-    float dm[5], s = 0.0f;
+// Head backward kernels.  A workgroup owns HEAD_ROWS consecutive edges, its four waves take them round robin (one wave per edge at
+// a time) and keep two running column sums per lane: sum_e dpre2[e][c] (the gradient of b2) and sum_e a2[e][c] ds[e] (the gradient of
+// the head weight).  They leave through the same partial buffer and block-ordered reduction as k_colsum (train_ops.h), so the two
+// extra passes over E x 257 matrices that computed them separately are gone and the result stays bitwise reproducible.
+__device__ __forceinline__ void head_partials_out(float (&cs)[5], float (&ws)[5], float *__restrict__ part, int lane, int wave) {
+    __shared__ float s_c[4][320], s_w[4][320];
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
-        const int c = lane + 64 * k;
-        dm[k] = c < H ? dhn[(size_t)v * LD + c] * zi : 0.0f;
-        if (c < H) s = fmaf(dm[k], a2[(size_t)e * LD + c], s);
+        s_c[wave][lane + 64 * k] = cs[k];
+        s_w[wave][lane + 64 * k] = ws[k];
     }
-    const float ds = wave_sum(s) * a * (1.0f - a);
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        const int c = lane + 64 * k;
-        if (c < H) dpre2[(size_t)e * LD + c] = (dm[k] * a + ds * wa[c]) * silu_grad(pre2[(size_t)e * LD + c]);
+    __syncthreads();
+    float *p = part + (size_t)blockIdx.x * 2 * COLSUM_LD;
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+        p[c] = (s_w[0][c] + s_w[1][c]) + (s_w[2][c] + s_w[3][c]);                    // slot 0 -> y  (head weight)
+        p[COLSUM_LD + c] = (s_c[0][c] + s_c[1][c]) + (s_c[2][c] + s_c[3][c]);        // slot 1 -> y2 (b2)
     }
-    if (lane == 0) ds_att[e] = ds;
 }
 
-// coordinate head backward, one wave per edge: msg_x = coef n, coef = tanh(sc) range (or sc), summed into x_neigh[dst] / z
-__global__ void k_coord_head_bwd(const float *__restrict__ dxo, const float *__restrict__ zinv, const int *__restrict__ dst,
-                                 const float *__restrict__ nvec, const float *__restrict__ sc, const float *__restrict__ w3,
-                                 const float *__restrict__ pre2, int E, int use_tanh, float range, float *__restrict__ dpre2,
-                                 float *__restrict__ dsc, float *__restrict__ dn) {
-    const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (e >= E) return;
-    const int v = dst[e];
-    const float zi = zinv[v];
-    const float gx = dxo[3 * v] * zi, gy = dxo[3 * v + 1] * zi, gz = dxo[3 * v + 2] * zi;
-    const float th = use_tanh ? tanhf(sc[e]) : 0.0f;
-    const float coef = use_tanh ? th * range : sc[e];
-    const float dcoef = gx * nvec[3 * e] + gy * nvec[3 * e + 1] + gz * nvec[3 * e + 2];
-    const float ds = use_tanh ? dcoef * range * (1.0f - th * th) : dcoef;
-    for (int c = lane; c < H; c += 64) dpre2[(size_t)e * LD + c] = ds * w3[c] * silu_grad(pre2[(size_t)e * LD + c]);
-    if (lane == 0) {
-        dsc[e] = ds;
-        dn[3 * e] += coef * gx; dn[3 * e + 1] += coef * gy; dn[3 * e + 2] += coef * gz;
+// feature head backward: msg_h = a2 * att, att = sigmoid(a2 . wa + ba), summed into h_neigh[dst] / z.
+//   dmsg = dhn[dst] * zinv[dst]; ds = (dmsg . a2) att (1 - att); da2 = dmsg att + ds wa; dpre2 = da2 SiLU'(pre2)
+__global__ __launch_bounds__(256) void k_feat_head_bwd(const float *__restrict__ dhn, const float *__restrict__ zinv, const int *__restrict__ dst,
+                                                       const float *__restrict__ a2, const float *__restrict__ att, const float *__restrict__ wa,
+                                                       const float *__restrict__ pre2, int E, float *__restrict__ dpre2,
+                                                       float *__restrict__ ds_att, float *__restrict__ part) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int e0 = blockIdx.x * HEAD_ROWS, e1 = min(E, e0 + HEAD_ROWS);
+    float cs[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, ws[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int e = e0 + wave; e < e1; e += 4) {
+        const int v = dst[e];
+        const float zi = zinv[v], a = att[e];
+        float dm[5], av[5], s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int c = lane + 64 * k;
+            dm[k] = c < H ? dhn[(size_t)v * LD + c] * zi : 0.0f;
+            av[k] = c < H ? a2[(size_t)e * LD + c] : 0.0f;
+            s = fmaf(dm[k], av[k], s);
+        }
+        const float ds = wave_sum(s) * a * (1.0f - a);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int c = lane + 64 * k;
+            if (c < H) {
+                const float g = (dm[k] * a + ds * wa[c]) * silu_grad(pre2[(size_t)e * LD + c]);
+                dpre2[(size_t)e * LD + c] = g;
+                cs[k] += g;
+                ws[k] = fmaf(av[k], ds, ws[k]);
+            }
+        }
+        if (lane == 0) ds_att[e] = ds;
     }
+    head_partials_out(cs, ws, part, lane, wave);
+}
+
+// coordinate head backward: msg_x = coef n, coef = tanh(sc) range (or sc), summed into x_neigh[dst] / z
+__global__ __launch_bounds__(256) void k_coord_head_bwd(const float *__restrict__ dxo, const float *__restrict__ zinv, const int *__restrict__ dst,
+                                                        const float *__restrict__ nvec, const float *__restrict__ sc, const float *__restrict__ w3,
+                                                        const float *__restrict__ a2, const float *__restrict__ pre2, int E, int use_tanh,
+                                                        float range, float *__restrict__ dpre2, float *__restrict__ dsc,
+                                                        float *__restrict__ dn, float *__restrict__ part) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int e0 = blockIdx.x * HEAD_ROWS, e1 = min(E, e0 + HEAD_ROWS);
+    float cs[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, ws[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int e = e0 + wave; e < e1; e += 4) {
+        const int v = dst[e];
+        const float zi = zinv[v];
+        const float gx = dxo[3 * v] * zi, gy = dxo[3 * v + 1] * zi, gz = dxo[3 * v + 2] * zi;
+        const float th = use_tanh ? tanhf(sc[e]) : 0.0f;
+        const float coef = use_tanh ? th * range : sc[e];
+        const float dcoef = gx * nvec[3 * e] + gy * nvec[3 * e + 1] + gz * nvec[3 * e + 2];
+        const float ds = use_tanh ? dcoef * range * (1.0f - th * th) : dcoef;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int c = lane + 64 * k;
+            if (c < H) {
+                const float g = ds * w3[c] * silu_grad(pre2[(size_t)e * LD + c]);
+                dpre2[(size_t)e * LD + c] = g;
+                cs[k] += g;
+                ws[k] = fmaf(a2[(size_t)e * LD + c], ds, ws[k]);
+            }
+        }
+        if (lane == 0) {
+            dsc[e] = ds;
+            dn[3 * e] += coef * gx; dn[3 * e + 1] += coef * gy; dn[3 * e + 2] += coef * gz;
+        }
+    }
+    head_partials_out(cs, ws, part, lane, wave);
 }
 
 // geometry backward: n = x_diff / (dij + 1), dij = |x_diff|; per-edge gradient of x_src (= minus that of x_dst)
@@ -298,6 +342,18 @@ struct kpd_egnn_trainer : TrainCtx {
     float *dact = nullptr;                                                       // [cap_N, ENC_LD]
     float *xdiff = nullptr, *dij = nullptr, *nvec = nullptr, *att = nullptr, *sc = nullptr, *dsv = nullptr, *ddij = nullptr,
           *dn = nullptr, *msgx = nullptr;
+    // Kept forward activations (KPD_TRAIN_STORE, default on): pre1 / a1 / pre2 / a2 of both MLP branches of every (layer, edge
+    // type), the attention weights, the geometry and the coordinate head, so that the backward pass reads them instead of running
+    // the gather, the per-node projections and the 257 x 257 GEMM of every branch a second time (~12 % of a training step).  18 GB at
+    // C2, B = 64 -- sized for a 288-GB part; if the allocation fails the engine falls back to recomputation.
+    struct Slot {
+        float *e[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+        float *att = nullptr, *dij = nullptr, *xdiff = nullptr, *nvec = nullptr, *sc = nullptr, *msgx = nullptr;
+    };
+    bool store = false;
+    char *store_base = nullptr;
+    std::vector<Slot> slots;                       // [layer * 4 + et]
+    Slot scratch;                                  // the recomputation buffers (one edge type, one branch at a time)
     float *dh[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}, *dx[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     float *enc1[2] = {nullptr, nullptr}, *enc2[2] = {nullptr, nullptr}, *dec1 = nullptr, *dec2 = nullptr;   // encoder / decoder scratch
 };
@@ -364,6 +420,13 @@ kpd_status geom_fwd(kpd_egnn_trainer *T, int et, const float *xs, const float *x
 inline int layer_n_et(const kpd_egnn_trainer *T, int l) { return l == T->cfg.n_layers - 1 ? 2 : T->n_et; }
 inline int layer_n_upd(const kpd_egnn_trainer *T, int l) { return l == T->cfg.n_layers - 1 ? 1 : T->n_upd; }
 
+// point the per-edge buffers at the kept activations of (layer, edge type, branch), or at the scratch set when nothing is kept
+void bind_slot(kpd_egnn_trainer *T, int l, int et, int branch) {
+    const kpd_egnn_trainer::Slot &sl = T->store ? T->slots[(size_t)l * 4 + et] : T->scratch;
+    for (int k = 0; k < 4; ++k) T->eb[k] = sl.e[branch][k];
+    T->att = sl.att; T->dij = sl.dij; T->xdiff = sl.xdiff; T->nvec = sl.nvec; T->sc = sl.sc; T->msgx = sl.msgx;
+}
+
 // one LigRecConv layer forward (dynamics.py:124-207) from the saved inputs hs[l], xs[l] into hs[l+1], xs[l+1], hns[l], xns[l]
 kpd_status layer_fwd(kpd_egnn_trainer *T, int l) {
     const kpd_egnn_config &c = T->cfg;
@@ -374,6 +437,7 @@ kpd_status layer_fwd(kpd_egnn_trainer *T, int l) {
     for (int et = 0; et < layer_n_et(T, l); ++et) {
         const int E = T->E[et], s = kS[et], d = kD[et];
         if (E == 0) continue;
+        bind_slot(T, l, et, 0);
         KPD_TRY(geom_fwd(T, et, T->xs[s][l], T->xs[d][l]));
         BranchParams p;
         KPD_TRY(branch_params(T, l, et, 0, &p));
@@ -383,6 +447,7 @@ kpd_status layer_fwd(kpd_egnn_trainer *T, int l) {
         hipLaunchKernelGGL(k_segsum_rows, dim3(T->n[d]), dim3(256), 0, T->st, T->eb[3], T->att, T->e_rowptr[et], T->zinv[d], 1,
                            T->hns[d][l]);
         KPD_LAUNCH_CHECK();
+        bind_slot(T, l, et, 1);
         KPD_TRY(branch_params(T, l, et, 1, &p));
         KPD_TRY(edge_branch_fwd(T, p, et, T->hs[s][l], T->hs[d][l]));
         hipLaunchKernelGGL(k_coord_msg, dim3(cdiv(E, 4)), dim3(256), 0, T->st, T->eb[3], p.head.w, T->nvec, E, c.use_tanh,
@@ -534,6 +599,7 @@ extern "C" void kpd_egnn_trainer_destroy(kpd_egnn_trainer *T) {
     if (!T) return;
     if (T->blas) rocblas_destroy_handle(T->blas);
     T->ws.release();
+    if (T->store_base) (void)hipFree(T->store_base);
     delete T;
 }
 
@@ -636,9 +702,39 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
     g.counts = W.take<int>(8);
     for (int et = 0; et < 4; ++et) { T->scsr[et].perm = W.take<int>(cap_et[et]); T->scsr[et].rowptr = W.take<int>(nn[kS[et]] + 1); }
     T->cursor = W.take<int>(cap_N);
-    T->colpart_blocks = cdiv(std::max(cap_E, cap_N), COLSUM_ROWS);
+    T->colpart_blocks = cdiv(std::max(cap_E, cap_N), HEAD_ROWS);
     T->colpart = W.take<float>(colpart_floats(std::max(cap_E, cap_N)));
     KPD_REQUIRE(T->colpart != nullptr, KPD_ERR_HIP, "workspace arena too small (internal sizing error)");
+    for (int k = 0; k < 4; ++k) T->scratch.e[0][k] = T->scratch.e[1][k] = T->eb[k];
+    T->scratch.att = T->att; T->scratch.dij = T->dij; T->scratch.xdiff = T->xdiff; T->scratch.nvec = T->nvec; T->scratch.sc = T->sc;
+    T->scratch.msgx = T->msgx;
+    {
+        if (T->store_base) (void)hipFree(T->store_base);
+        T->store_base = nullptr;
+        T->store = false;
+        static const bool want = !(getenv("KPD_TRAIN_STORE") && atoi(getenv("KPD_TRAIN_STORE")) == 0);
+        auto al = [](size_t floats) { return (floats * 4 + 255) & ~size_t(255); };
+        size_t per_layer = 0;
+        for (int et = 0; et < T->n_et; ++et) per_layer += 8 * al((size_t)cap_et[et] * LD) + 3 * al(cap_et[et]) + 3 * al((size_t)cap_et[et] * 3);
+        const size_t total = per_layer * L;
+        if (want && hipMalloc(reinterpret_cast<void **>(&T->store_base), total) == hipSuccess) {
+            T->store = true;
+            T->slots.assign((size_t)L * 4, kpd_egnn_trainer::Slot());
+            char *p = T->store_base;
+            auto take = [&](size_t floats) { float *r = reinterpret_cast<float *>(p); p += al(floats); return r; };
+            for (int l = 0; l < L; ++l)
+                for (int et = 0; et < T->n_et; ++et) {
+                    kpd_egnn_trainer::Slot &sl = T->slots[(size_t)l * 4 + et];
+                    for (int br = 0; br < 2; ++br)
+                        for (int k = 0; k < 4; ++k) sl.e[br][k] = take((size_t)cap_et[et] * LD);
+                    sl.att = take(cap_et[et]); sl.dij = take(cap_et[et]); sl.sc = take(cap_et[et]);
+                    sl.xdiff = take((size_t)cap_et[et] * 3); sl.nvec = take((size_t)cap_et[et] * 3); sl.msgx = take((size_t)cap_et[et] * 3);
+                }
+        } else {
+            (void)hipGetLastError();              // a failed allocation is not an error: recompute instead
+            T->store_base = nullptr;
+        }
+    }
     hipLaunchKernelGGL(k_fill, grid1(n_ones), dim3(256), 0, nullptr, T->ones, 1.0f, (long long)n_ones);
     KPD_LAUNCH_CHECK();
     KPD_HIP(hipDeviceSynchronize());
@@ -770,8 +866,7 @@ kpd_status node_bwd(kpd_egnn_trainer *T, int l, int nt, int cur, int nxt, float 
 // the part of the edge backward shared by both branches: eb[4] = dpre2 in; uses eb[0..1] = pre1, a1 of the branch
 kpd_status edge_branch_bwd(kpd_egnn_trainer *T, const BranchParams &p, int l, int et, int nxt, bool first_branch) {
     const int E = T->E[et], s = kS[et], d = kD[et], ns = T->n[s], nd = T->n[d];
-    float *dpre2 = T->eb[4], *dpre1 = T->eb[5];
-    KPD_TRY(colsum_acc(T, E, H, dpre2, LD, p.b2.g));
+    float *dpre2 = T->eb[4], *dpre1 = T->eb[5];          // (the b2 gradient, the column sum of dpre2, left with the head kernel)
     if (p.W2.g) KPD_TRY(grad_gemm(T, H, H, E, dpre2, LD, T->eb[1], LD, p.W2.g, H));
     const long long tot = (long long)E * H;
     // dpre1 = (dpre2 W2) * SiLU'(pre1)
@@ -809,33 +904,43 @@ kpd_status layer_bwd(kpd_egnn_trainer *T, int l, int cur, int nxt, float *dhn[2]
     for (int et = 0; et < layer_n_et(T, l); ++et) {
         const int E = T->E[et], s = kS[et], d = kD[et];
         if (E == 0) continue;
-        KPD_TRY(geom_fwd(T, et, T->xs[s][l], T->xs[d][l]));
+        bind_slot(T, l, et, 0);
+        if (!T->store) KPD_TRY(geom_fwd(T, et, T->xs[s][l], T->xs[d][l]));
         KPD_HIP(hipMemsetAsync(T->dn, 0, (size_t)E * 12, T->st));
         BranchParams p;
         // feature branch
         KPD_TRY(branch_params(T, l, et, 0, &p));
-        KPD_TRY(edge_branch_fwd(T, p, et, T->hs[s][l], T->hs[d][l]));
-        hipLaunchKernelGGL(k_rowdot, dim3(cdiv(E, 4)), dim3(256), 0, T->st, T->eb[3], p.head.w, p.head_b.w, E, 1, T->att);
+        if (!T->store) {
+            KPD_TRY(edge_branch_fwd(T, p, et, T->hs[s][l], T->hs[d][l]));
+            hipLaunchKernelGGL(k_rowdot, dim3(cdiv(E, 4)), dim3(256), 0, T->st, T->eb[3], p.head.w, p.head_b.w, E, 1, T->att);
+            KPD_LAUNCH_CHECK();
+        }
+        KPD_REQUIRE(cdiv(E, HEAD_ROWS) <= T->colpart_blocks, KPD_ERR_CAPACITY, "column-sum scratch too small");
+        hipLaunchKernelGGL(k_feat_head_bwd, dim3(cdiv(E, HEAD_ROWS)), dim3(256), 0, T->st, dhn[d], T->zinv[d], T->e_dst[et], T->eb[3], T->att,
+                           p.head.w, T->eb[2], E, T->eb[4], T->dsv, T->colpart);
         KPD_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_feat_head_bwd, dim3(cdiv(E, 4)), dim3(256), 0, T->st, dhn[d], T->zinv[d], T->e_dst[et], T->eb[3], T->att,
-                           p.head.w, T->eb[2], E, T->eb[4], T->dsv);
+        // the kernel left the partial column sums of a2 ds (head weight gradient) and of dpre2 (b2 gradient)
+        hipLaunchKernelGGL(k_colsum_reduce, dim3(cdiv(H, 64)), dim3(1024), 0, T->st, T->colpart, cdiv(E, HEAD_ROWS), H, p.head.g, 1, p.b2.g);
         KPD_LAUNCH_CHECK();
-        KPD_TRY(gemv_t_acc(T, E, H, T->eb[3], LD, T->dsv, p.head.g, 1));
         if (p.head_b.g) {
             hipLaunchKernelGGL(k_sum_scalar, dim3(1), dim3(1024), 0, T->st, T->dsv, E, p.head_b.g);
             KPD_LAUNCH_CHECK();
         }
         KPD_TRY(edge_branch_bwd(T, p, l, et, nxt, true));
         // coordinate branch
+        bind_slot(T, l, et, 1);
         KPD_TRY(branch_params(T, l, et, 1, &p));
-        KPD_TRY(edge_branch_fwd(T, p, et, T->hs[s][l], T->hs[d][l]));
-        hipLaunchKernelGGL(k_coord_msg, dim3(cdiv(E, 4)), dim3(256), 0, T->st, T->eb[3], p.head.w, T->nvec, E, c.use_tanh,
-                           c.coords_range, T->sc, T->msgx);
+        if (!T->store) {
+            KPD_TRY(edge_branch_fwd(T, p, et, T->hs[s][l], T->hs[d][l]));
+            hipLaunchKernelGGL(k_coord_msg, dim3(cdiv(E, 4)), dim3(256), 0, T->st, T->eb[3], p.head.w, T->nvec, E, c.use_tanh,
+                               c.coords_range, T->sc, T->msgx);
+            KPD_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(k_coord_head_bwd, dim3(cdiv(E, HEAD_ROWS)), dim3(256), 0, T->st, T->dx[cur][d], T->zinv[d], T->e_dst[et], T->nvec,
+                           T->sc, p.head.w, T->eb[3], T->eb[2], E, c.use_tanh, c.coords_range, T->eb[4], T->dsv, T->dn, T->colpart);
         KPD_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_coord_head_bwd, dim3(cdiv(E, 4)), dim3(256), 0, T->st, T->dx[cur][d], T->zinv[d], T->e_dst[et], T->nvec,
-                           T->sc, p.head.w, T->eb[2], E, c.use_tanh, c.coords_range, T->eb[4], T->dsv, T->dn);
+        hipLaunchKernelGGL(k_colsum_reduce, dim3(cdiv(H, 64)), dim3(1024), 0, T->st, T->colpart, cdiv(E, HEAD_ROWS), H, p.head.g, 1, p.b2.g);
         KPD_LAUNCH_CHECK();
-        KPD_TRY(gemv_t_acc(T, E, H, T->eb[3], LD, T->dsv, p.head.g, 1));
         KPD_TRY(edge_branch_bwd(T, p, l, et, nxt, false));
         float *redge = T->msgx;                         // free again: the coordinate head consumed it above
         hipLaunchKernelGGL(k_geom_bwd, grid1(E), dim3(256), 0, T->st, T->ddij, T->dn, T->xdiff, T->dij, E, redge);

@@ -314,6 +314,17 @@ struct kpd_gvp_trainer : TrainCtx {
     float *enc_in[2] = {nullptr, nullptr}, *enc_pre[2] = {nullptr, nullptr}, *enc_act[2] = {nullptr, nullptr};
     // scratch (row capacity cap_R = max edge type / node count)
     GvpBuf gb[4];
+    // Kept forward activations of the message chains (KPD_TRAIN_STORE, default on): geometry, rbf, message inputs and the seven
+    // buffers of every message GVP per (conv, edge type), so that the backward pass does not run the chain a second time.
+    // ~8.6 KB per edge and conv (22 GB at gvp_all_atom, B = 64); falls back to recomputation if the allocation fails.
+    struct MsgSlot {
+        float *unit = nullptr, *rbf = nullptr, *vin = nullptr;
+        GvpBuf gb[4];
+    };
+    bool store = false;
+    char *store_base = nullptr;
+    std::vector<MsgSlot> slots;                    // [conv * 4 + et]
+    MsgSlot scratch;
     float *ds[2] = {nullptr, nullptr}, *dV[2] = {nullptr, nullptr}, *dVh = nullptr, *dsh = nullptr, *dgate = nullptr;
     float *unit = nullptr, *rbf = nullptr, *vin = nullptr, *U = nullptr, *scale = nullptr, *tmp_s = nullptr, *tmp_v = nullptr,
           *s1 = nullptr, *v1 = nullptr, *sb = nullptr, *vb = nullptr;
@@ -466,7 +477,21 @@ kpd_status edge_scale(kpd_gvp_trainer *T, int et) {
 }
 
 // message function of one edge type (gvp.py:540-551) forward into gb[0 .. n_message_gvps)
-kpd_status message_fwd(kpd_gvp_trainer *T, int conv, int et, GvpP *g0_out) {
+// point the message buffers at the kept activations of (conv, edge type); conv < 0: back to the scratch set (which the node-update
+// chains use as well)
+void bind_msg(kpd_gvp_trainer *T, int conv, int et) {
+    const kpd_gvp_trainer::MsgSlot &sl = (T->store && conv >= 0) ? T->slots[(size_t)conv * 4 + et] : T->scratch;
+    T->unit = sl.unit; T->rbf = sl.rbf; T->vin = sl.vin;
+    for (int j = 0; j < 4; ++j)
+        if (sl.gb[j].pre) T->gb[j] = sl.gb[j];
+}
+
+// recompute = false: the buffers already hold this chain's forward pass (kept activations); only the parameters are looked up
+kpd_status message_fwd(kpd_gvp_trainer *T, int conv, int et, GvpP *g0_out, bool recompute = true) {
+    if (!recompute) {
+        const std::string prefix0 = "noise_predictor.conv_layers." + std::to_string(conv) + ".edge_message_fns." + kCanon[et];
+        return gvp_params(T, prefix0 + ".0", VH, VC, T->S + RBF, T->S, g0_out);
+    }
     const int E = T->E[et], s = kSrc[et], d = kDst[et], S = T->S, nm = T->cfg.n_message_gvps;
     const std::string prefix = "noise_predictor.conv_layers." + std::to_string(conv) + ".edge_message_fns." + kCanon[et];
     hipLaunchKernelGGL(k_gvp_geom, grid1(E), dim3(256), 0, T->st, T->e_src[et], T->e_dst[et], s == NT_LIG ? T->bt.lig_x : T->bt.kp_x,
@@ -544,6 +569,7 @@ kpd_status conv_fwd(kpd_gvp_trainer *T, int conv) {
     for (int et = 0; et < 4; ++et) {
         if (!conv_uses(T, conv, et) || T->E[et] == 0) continue;
         const int d = kDst[et];
+        bind_msg(T, conv, et);
         KPD_TRY(message_fwd(T, conv, et, nullptr));
         KPD_TRY(edge_scale(T, et));
         hipLaunchKernelGGL(k_segsum, dim3(T->n[d]), dim3(256), 0, T->st, T->gb[nm - 1].s, S, T->e_rowptr[et], T->scale, T->sa[d][conv]);
@@ -551,6 +577,7 @@ kpd_status conv_fwd(kpd_gvp_trainer *T, int conv) {
         hipLaunchKernelGGL(k_segsum, dim3(T->n[d]), dim3(64), 0, T->st, T->gb[nm - 1].V, 3 * VC, T->e_rowptr[et], T->scale, T->va[d][conv]);
         KPD_LAUNCH_CHECK();
     }
+    bind_msg(T, -1, -1);
     for (int nt = 0; nt < 2; ++nt) {
         if (!is_dst[nt]) continue;
         const int n = T->n[nt];
@@ -623,7 +650,8 @@ kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
         const int E = T->E[et], s = kSrc[et], d = kDst[et];
         const std::string prefix = cp + ".edge_message_fns." + kCanon[et];
         GvpP g0;
-        KPD_TRY(message_fwd(T, conv, et, &g0));
+        bind_msg(T, conv, et);
+        KPD_TRY(message_fwd(T, conv, et, &g0, !T->store));
         KPD_TRY(edge_scale(T, et));
         // d(message of edge e) = scale[dst] * d(aggregate)[dst]
         hipLaunchKernelGGL(k_gather_rows, grid1((long long)E * S), dim3(256), 0, T->st, T->gs[cur][d], T->e_dst[et], T->scale,
@@ -654,6 +682,7 @@ kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
             KPD_LAUNCH_CHECK();
         }
     }
+    bind_msg(T, -1, -1);
     return KPD_OK;
 }
 
@@ -760,6 +789,7 @@ extern "C" void kpd_gvp_trainer_destroy(kpd_gvp_trainer *T) {
     if (!T) return;
     if (T->blas) rocblas_destroy_handle(T->blas);
     T->ws.release();
+    if (T->store_base) (void)hipFree(T->store_base);
     delete T;
 }
 
@@ -863,7 +893,48 @@ extern "C" kpd_status kpd_gvp_trainer_reserve(kpd_gvp_trainer *T, int32_t max_B,
     KPD_REQUIRE(T->lg.counts != nullptr, KPD_ERR_HIP, "workspace arena too small (internal sizing error)");
     T->part_floats = (size_t)GRAD_SPLIT * 264 * 520;
     T->lg.cap_ll = cap_ll; T->lg.cap_kl = cap_kl;
-    T->colpart_blocks = cdiv(R, COLSUM_ROWS);
+    T->colpart_blocks = cdiv(R, HEAD_ROWS);
+    T->scratch.unit = T->unit; T->scratch.rbf = T->rbf; T->scratch.vin = T->vin;
+    for (int j = 0; j < 4; ++j) T->scratch.gb[j] = T->gb[j];
+    {
+        if (T->store_base) (void)hipFree(T->store_base);
+        T->store_base = nullptr;
+        T->store = false;
+        static const bool want = !(getenv("KPD_TRAIN_STORE") && atoi(getenv("KPD_TRAIN_STORE")) == 0);
+        const int cap_et[4] = {cap_ll, cap_kl, cap_kl, std::max<int>(max_n_kk, 1)};
+        const int nm = c.n_message_gvps;
+        auto al = [](size_t floats) { return (floats * 4 + 255) & ~size_t(255); };
+        auto slot_bytes = [&](size_t E) {
+            size_t b = al(E * 3) + al(E * RBF) + al(E * 3 * VH);
+            for (int j = 0; j < nm; ++j) b += al(E * 3 * VH) + al(E * 3 * VC) + al(E * VH) + 2 * al(E * S) + al(E * VC) + al(E * 3 * VC);
+            return b;
+        };
+        size_t total = 0;
+        for (int conv = 0; conv < L; ++conv)
+            for (int et = 0; et < 4; ++et)
+                if (conv_uses(T, conv, et)) total += slot_bytes(cap_et[et]);
+        if (want && nm <= 4 && hipMalloc(reinterpret_cast<void **>(&T->store_base), std::max<size_t>(total, 256)) == hipSuccess) {
+            T->store = true;
+            T->slots.assign((size_t)L * 4, kpd_gvp_trainer::MsgSlot());
+            char *p = T->store_base;
+            auto take = [&](size_t floats) { float *r = reinterpret_cast<float *>(p); p += al(floats); return r; };
+            for (int conv = 0; conv < L; ++conv)
+                for (int et = 0; et < 4; ++et) {
+                    if (!conv_uses(T, conv, et)) continue;
+                    const size_t E = cap_et[et];
+                    kpd_gvp_trainer::MsgSlot &sl = T->slots[(size_t)conv * 4 + et];
+                    sl.unit = take(E * 3); sl.rbf = take(E * RBF); sl.vin = take(E * 3 * VH);
+                    for (int j = 0; j < nm; ++j) {
+                        GvpBuf &b = sl.gb[j];
+                        b.Vh = take(E * 3 * VH); b.Vu = take(E * 3 * VC); b.sh = take(E * VH); b.pre = take(E * S); b.s = take(E * S);
+                        b.gate = take(E * VC); b.V = take(E * 3 * VC);
+                    }
+                }
+        } else {
+            (void)hipGetLastError();
+            T->store_base = nullptr;
+        }
+    }
     T->cap_B = max_B; T->cap_lig = max_n_lig; T->cap_kp = max_n_kp; T->cap_kk = max_n_kk; T->cap_maxlig = max_lig_pg;
     T->cap_maxkp = max_kp_pg; T->cap_ll = cap_ll; T->cap_kl = cap_kl; T->cap_R = R;
     T->have_forward = false;

@@ -93,6 +93,7 @@ __global__ void k_sub_inplace(float *__restrict__ a, const float *__restrict__ b
 // block order, so the result is bitwise reproducible (float atomics in arrival order were not).
 constexpr int COLSUM_ROWS = 256, COLSUM_THREADS = 320;       // 320 threads: the 257 columns of a layer in one pass
 constexpr int COLSUM_LD = 512;                               // columns per partial row (K <= 512)
+constexpr int HEAD_ROWS = 64;                                // rows per workgroup of the head-backward kernels that emit partials too
 __global__ void k_colsum(const float *__restrict__ A, int lda, const float *__restrict__ x, int M, int K, float *__restrict__ part) {
     const int r0 = blockIdx.x * COLSUM_ROWS, r1 = min(M, r0 + COLSUM_ROWS);
     float *p = part + (size_t)blockIdx.x * 2 * COLSUM_LD;
@@ -263,7 +264,7 @@ struct TrainCtx {
     std::map<std::string, Param> params;
 };
 
-inline size_t colpart_floats(int max_rows) { return (size_t)cdiv(std::max(max_rows, 1), COLSUM_ROWS) * 2 * COLSUM_LD; }
+inline size_t colpart_floats(int max_rows) { return (size_t)cdiv(std::max(max_rows, 1), HEAD_ROWS) * 2 * COLSUM_LD; }
 
 #define KPD_BLAS(call)                                                                            \
     do {                                                                                          \

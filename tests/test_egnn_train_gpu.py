@@ -203,3 +203,25 @@ def test_training_step_is_bitwise_reproducible():
     names = ['eps_h', 'eps_x', 'd lig x', 'd lig h', 'd kp x', 'd kp h'] + [n for n, _ in model.named_parameters()]
     diff = [n for n, a, b in zip(names, *runs) if not torch.equal(a, b)]
     assert not diff, diff[:10]
+
+
+def test_recompute_mode_gives_the_same_gradients():
+    """KPD_TRAIN_STORE=0 (recompute the edge activations in the backward pass instead of keeping them: the low-memory mode) must
+    be bit-identical to the default.  The switch is read once per process, so the other mode runs in a child process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ('import torch, sys; sys.path.insert(0, %r)\n'
+            'from tests import test_egnn_train_gpu as T, util\n'
+            'g, model, t = T._case(dict(util.EGNN_C2, n_layers=2), [40, 33], [7, 9])\n'
+            'model = model.cuda(); eh, ex = model(g.to("cuda"), t.cuda(), None)\n'
+            '(eh.square().sum() + ex.square().sum()).backward()\n'
+            'torch.save([p.grad.cpu() for p in model.parameters()], sys.argv[1])\n' % root)
+    outs = []
+    for mode in ('1', '0'):
+        path = os.path.join(root, 'gpurun_out', f'_grads_store{mode}.pt') if os.path.isdir(os.path.join(root, 'gpurun_out')) else f'/tmp/_grads_store{mode}.pt'
+        subprocess.run([sys.executable, '-c', code, path], check=True, env=dict(os.environ, KPD_TRAIN_STORE=mode), timeout=600)
+        outs.append(torch.load(path))
+        os.remove(path)
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
