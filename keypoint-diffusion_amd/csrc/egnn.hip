@@ -20,6 +20,7 @@ struct LayerW {
     float *wp_e[4], *wx_e[4], *b_e[4], *wr_e[4], *watt[4];
     float *chain[4], *wcol_e[4], *wcol_c[4];    // chained edge kernel: W2 chunks [coord 16 | edge 16], column 256 of W2
     float *wp_c[4], *wx_c[4], *b_c[4], *wr_c[4], *w3[4];
+    void *wh_e[4], *wh_c[4];                    // f16x2 mode: the finished wp_e / wp_c blocks as f16 hi / lo planes
     // per node type, per projection slot
     float *wp_p[2][NSLOT], *wx_p[2][NSLOT], *b_p[2][NSLOT];
     float *ch_p[2][NSLOT], *wcol_p[2][NSLOT];   // k_proj_chain form of the same blocks
@@ -73,6 +74,7 @@ struct kpd_egnn {
     std::set<std::string> expected, loaded;
     bool committed = false;
     int debug_layers = -1;
+    int gemm_mode = 0;                         // 0 exact fp32 MFMA; 1 f16x2 split products in the edge kernel (KPD_GEMM=f16x2, "gemm=f16x2")
     int tile_rows = TM;                        // edges per tile of the edge kernel (64, or 32: k_egnn_edge32, four workgroups per CU)
     int prune_last = 1;                        // final layer: only what feeds (h_lig, x_lig) is computed ("prune=0" restores all)
     int edge_chain = -1;                       // 1: register-chained edge kernel (egnn_chain.hip); -1: KPD_EDGE_CHAIN or staged
@@ -103,6 +105,7 @@ static kpd_status build_weight_arena(kpd_egnn *m) {
                       c.atom_nf) * 4 + 64 * 256;
     bytes += (size_t)c.n_layers * m->n_et * (32 * 4096 + 2 * HS + 64) * 4;
     bytes += (size_t)c.n_layers * m->n_et * 4 * (16 * 4096 + HS + 64) * 4;
+    bytes += (size_t)c.n_layers * m->n_et * 2 * ((size_t)WH_HALVES * 2 + 256);
     bytes += 1 << 20;
     kpd_status st = m->warena.reserve(bytes);
     if (st != KPD_OK) return st;
@@ -118,6 +121,7 @@ static kpd_status build_weight_arena(kpd_egnn *m) {
             w.wp_e[et] = wp(); w.wx_e[et] = vec(); w.b_e[et] = vec(); w.wr_e[et] = vec(); w.watt[et] = vec();
             w.wp_c[et] = wp(); w.wx_c[et] = vec(); w.b_c[et] = vec(); w.wr_c[et] = vec(); w.w3[et] = vec();
             w.chain[et] = A.take<float>(32 * 4096); w.wcol_e[et] = vec(); w.wcol_c[et] = vec();
+            w.wh_e[et] = A.take<unsigned short>(WH_HALVES); w.wh_c[et] = A.take<unsigned short>(WH_HALVES);
             for (int var = 0; var < 2; ++var) {
                 const int ss = kSrcSlot[et] + var, ds = kDstSlot[et] + var;
                 w.wp_p[kSrcNt[et]][ss] = wp(); w.wx_p[kSrcNt[et]][ss] = vec();
@@ -178,6 +182,7 @@ extern "C" kpd_status kpd_egnn_create(const kpd_egnn_config *cfg, kpd_egnn **out
     kpd_egnn *m = new kpd_egnn();
     m->cfg = *cfg;
     if (const char *e = getenv("KPD_EDGE_ROWS")) m->tile_rows = atoi(e) == 32 ? 32 : TM;
+    if (const char *e = getenv("KPD_GEMM")) m->gemm_mode = !strcmp(e, "f16x2") ? 1 : 0;
     m->n_et = cfg->update_kp_feat ? 4 : 2;
     m->n_upd = cfg->update_kp_feat ? 2 : 1;
     m->rec_identity = cfg->rec_nf == cfg->hidden_nf;   // dynamics.py:326-334
@@ -359,6 +364,8 @@ extern "C" kpd_status kpd_egnn_commit(kpd_egnn *m) {
         for (int et = 0; et < m->n_et; ++et) {
             KPD_TRY(patch_bias_row(L.wp_e[et], L.wx_e[et], L.b_e[et], SILU_C, BIAS_K, nullptr));
             KPD_TRY(patch_bias_row(L.wp_c[et], L.wx_c[et], L.b_c[et], SILU_C, BIAS_K, nullptr));
+            KPD_TRY(pack_f16_split(L.wp_e[et], L.wh_e[et], nullptr));      // the same finished blocks for the f16x2 mode
+            KPD_TRY(pack_f16_split(L.wp_c[et], L.wh_c[et], nullptr));
         }
     KPD_HIP(hipDeviceSynchronize());
     m->committed = true;
@@ -564,6 +571,7 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
         ea.use_tanh = c.use_tanh; ea.coords_range = c.coords_range;
         ea.stamps = m->stamps;
         ea.tile_rows = tr;
+        ea.gemm_mode = (tr == TM && !use_chain) ? m->gemm_mode : 0;
         for (int et = 0; et < 4; ++et) {
             ea.src[et] = esrc[et]; ea.dst[et] = edst[et];
             ea.src_nt[et] = kSrcNt[et]; ea.dst_nt[et] = kDstNt[et]; ea.src_slot[et] = kSrcSlot[et]; ea.dst_slot[et] = kDstSlot[et];
@@ -571,6 +579,7 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
             ea.wp_e[et] = L.wp_e[et]; ea.wx_e[et] = L.wx_e[et]; ea.b_e[et] = L.b_e[et];
             ea.chain[et] = L.chain[et]; ea.wcol_e[et] = L.wcol_e[et]; ea.wcol_c[et] = L.wcol_c[et];
             ea.wp_c[et] = L.wp_c[et]; ea.wx_c[et] = L.wx_c[et]; ea.b_c[et] = L.b_c[et];
+            ea.wh_e[et] = L.wh_e[et]; ea.wh_c[et] = L.wh_c[et];
             ea.watt[et] = L.watt[et]; ea.w3[et] = L.w3[et];
             ea.hn_main[et] = m->hn_main[et]; ea.hn_cont[et] = m->hn_cont[et];
             ea.xn_main[et] = m->xn_main[et]; ea.xn_cont[et] = m->xn_cont[et];
@@ -639,6 +648,11 @@ extern "C" kpd_status kpd_egnn_debug_state(kpd_egnn *m, const char *what, float 
         return KPD_OK;
     } else if (w.rfind("prune=", 0) == 0) {        // A/B switch of the final-layer pruning (tests: bit-identical eps)
         m->prune_last = atoi(w.c_str() + 6);
+        return KPD_OK;
+    } else if (w.rfind("gemm=", 0) == 0) {         // "gemm=f32" (exact fp32 MFMA, the contract path) | "gemm=f16x2" (split f16 products)
+        const std::string v = w.substr(5);
+        KPD_REQUIRE(v == "f32" || v == "f16x2", KPD_ERR_INVALID, "gemm mode must be f32 or f16x2");
+        m->gemm_mode = v == "f16x2" ? 1 : 0;
         return KPD_OK;
     } else if (w.rfind("tile_rows=", 0) == 0) {    // 64 | 32: which staged edge kernel runs (A/B tests)
         const int r = atoi(w.c_str() + 10);

@@ -12,6 +12,8 @@ constexpr int ET_LL = 0, ET_KL = 1, ET_LK = 2, ET_KK = 3;
 constexpr int NT_LIG = 0, NT_KP = 1;
 
 constexpr int EDGE_LDS_BYTES = TM * SA * 4 + (TM * 2 + TM + 3 * TM + TM + 3 * TM + 4 * HS + 8) * 4;
+// k_egnn_edge_h: two f16 planes of 64 x 280 halves (= the T tile's region), row data, two fp32 head rows, W2 row 256 as 2 x 2 x 272 halves
+constexpr int EDGE_H_LDS_BYTES = 64 * 280 * 2 * 2 + (TM * 2 + TM + 3 * TM + TM + 3 * TM + 2 * HS + 8) * 4 + 2 * 2 * 272 * 2;
 constexpr int EDGE32_LDS_BYTES = 32 * SA * 4 + (32 * 2 + 32 + 3 * 32 + 32 + 3 * 32 + 2 * HS + 8) * 4;     // k_egnn_edge32
 
 struct ProjArgs {
@@ -52,6 +54,8 @@ struct EdgeArgs {
     int use_tanh;
     float coords_range;
     unsigned long long *stamps;     // [16] phase-cycle sums, diagnostics only (null in production)
+    const void *wh_e[4], *wh_c[4];  // f16x2 mode: W2 of edge_mlp / coord_mlp as f16 hi / lo planes (pack_f16_split)
+    int gemm_mode;                  // 0: exact fp32 MFMA (contract path), 1: f16x2 split products (opt-in)
     int tile_rows;                  // edges per tile: 64 (k_egnn_edge<NW>, k_egnn_chain) or 32 (k_egnn_edge32)
     int ablate;                     // timing experiments only (KPD_EDGE_ABLATE), 0 in production
 };

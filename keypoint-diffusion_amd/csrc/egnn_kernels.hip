@@ -489,6 +489,292 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
 }
 
 
+// ---- f16x2 form of the fused edge kernel (opt-in: KPD_GEMM=f16x2 / "gemm=f16x2") ----------------------------------------------
+// Same phases and the same fp32 epilogues as k_egnn_edge<4>; the two 257 x 257 products run as three f16 MFMA products of
+// hi / lo operand planes with fp32 accumulation (mfma_core.h, gemm_rows64_h).  The A tile is written as two f16 planes by the
+// A-build; T (fp32) reuses their LDS region after the GEMM exactly as it reuses the fp32 A tile in the exact kernel.
+constexpr int EDGE_H_REGION0_FLOATS = TM * SAH;        // two planes of TM x SAH halves = TM * SAH floats (>= the TM x SA fp32 T tile)
+static_assert(EDGE_H_REGION0_FLOATS >= TM * SA, "T tile must fit the A planes' region");
+
+__device__ __forceinline__ EdgeSmem edge_smem_h(float *smem) {
+    EdgeSmem s;
+    s.A = smem;
+    s.src = reinterpret_cast<int *>(smem + EDGE_H_REGION0_FLOATS);
+    s.dst = s.src + TM;
+    s.d = reinterpret_cast<float *>(s.dst + TM);
+    s.xd = s.d + TM;
+    s.att = s.xd + 3 * TM;
+    s.mx = s.att + TM;
+    s.wv = s.mx + 3 * TM;
+    s.misc = reinterpret_cast<int *>(s.wv + 2 * HS);
+    return s;
+}
+
+// A[r][:] = SiLU(Ps[src_r] + Pd[dst_r] + d_r w_r) as f16 hi / lo planes; columns 264..271 (K padding of the 16-wide k-steps) zero
+__device__ __forceinline__ void edge_gather_finish_h(const EdgeGather<4> &g, const EdgeSmem &s, _Float16 *Ah, const float *__restrict__ wr,
+                                                     int wave, int lane) {
+    constexpr int RPW = TM / 4;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const f32x4 w0 = reinterpret_cast<const f32x4 *>(wr)[lane];
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int r = wave * RPW + rr;
+        f32x4 v = g.ps[rr] + g.pd[rr] + s.d[r] * w0;
+        v[0] = silu_pre_x64(v[0]); v[1] = silu_pre_x64(v[1]); v[2] = silu_pre_x64(v[2]); v[3] = silu_pre_x64(v[3]);
+        unsigned h0, h1, l0, l1;
+        split_pair(v[0], v[1], h0, l0);
+        split_pair(v[2], v[3], h1, l1);
+        *reinterpret_cast<u32x2 *>(Ah + r * SAH + 4 * lane) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2 *>(Ah + PLANE_H + r * SAH + 4 * lane) = u32x2{l0, l1};
+    }
+    {   // columns 256 .. 271 of the wave's rows: lane = row * 4 + chunk of four columns
+        const int r = wave * RPW + (lane >> 2), c = lane & 3;
+        f32x4 u = {0.f, 0.f, 0.f, 0.f};
+        if (c < 2) {
+            const f32x4 w1 = reinterpret_cast<const f32x4 *>(wr)[64 + c];
+            u = g.tps + g.tpd + s.d[r] * w1;
+            u[0] = silu_pre_x64(u[0]); u[1] = silu_pre_x64(u[1]); u[2] = silu_pre_x64(u[2]); u[3] = silu_pre_x64(u[3]);
+            if (c == (BIAS_K - 256) / 4) u[(BIAS_K - 256) % 4] = H_SCALE_A;
+        }
+        unsigned h0, h1, l0, l1;
+        split_pair(u[0], u[1], h0, l0);
+        split_pair(u[2], u[3], h1, l1);
+        *reinterpret_cast<u32x2 *>(Ah + r * SAH + 256 + 4 * c) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2 *>(Ah + PLANE_H + r * SAH + 256 + 4 * c) = u32x2{l0, l1};
+    }
+}
+
+__device__ __forceinline__ void unscale_acc(f32x16 (&acc)[2][2], float &ex) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] *= H_UNSCALE;
+    ex *= H_UNSCALE;
+}
+
+__global__ __launch_bounds__(256, 2) void k_egnn_edge_h(EdgeArgs a) {
+    constexpr int NW = 4, TPR = 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const EdgeSmem s = edge_smem_h(smem);
+    _Float16 *Ah = reinterpret_cast<_Float16 *>(smem);                 // two f16 planes of the A tile; T (fp32) reuses the region
+    float *wxs = reinterpret_cast<float *>(s.misc + 8);                // W2[256, :] of edge_mlp then coord_mlp, x H_SCALE_W, 272 floats each
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    unsigned long long t_prev_ = a.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+    // tile decode (XCD-aware: consecutive tiles -- neighbouring edges of one complex, which
+    // share P rows -- go to the same XCD / L2)
+    const int T = a.meta[8];
+    const int chunk = (T + 7) >> 3;
+    const int bi = blockIdx.x >> 3;
+    if (bi >= chunk) return;
+    const int tile = (blockIdx.x & 7) * chunk + bi;
+    if (tile >= T) return;
+    int et = 0;
+#pragma unroll
+    for (int e = 1; e < 4; ++e)
+        if (tile >= a.meta[4 + e]) et = e;
+    const int tile_in_et = tile - a.meta[4 + et];
+    const int e0 = tile_in_et * TM;
+    const int ne = min(TM, a.meta[et] - e0);
+    const int snt = a.src_nt[et], dnt = a.dst_nt[et];
+    const int *__restrict__ esrc = a.src[et];
+    const int *__restrict__ edst = a.dst[et];
+
+    // phase 0: edge endpoints and geometry (dynamics.py:160-169, 209-217); head weights to LDS
+    if (tid < TM) {
+        const int e = e0 + min(tid, ne - 1);
+        const int u = esrc[e], v = edst[e];
+        s.src[tid] = u;
+        s.dst[tid] = v;
+        const float *xs = a.x[snt] + (size_t)u * 3, *xd = a.x[dnt] + (size_t)v * 3;
+        const float dx = xs[0] - xd[0], dy = xs[1] - xd[1], dz = xs[2] - xd[2];
+        const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float inv = 1.0f / (d + 1.0f);
+        s.d[tid] = d;
+        s.xd[3 * tid] = dx * inv;
+        s.xd[3 * tid + 1] = dy * inv;
+        s.xd[3 * tid + 2] = dz * inv;
+        // run structure of the dst-sorted tile as two 64-bit masks (wave 0 == rows 0..63)
+        const int vprev = tid > 0 ? edst[e0 + min(tid - 1, ne - 1)] : (e0 > 0 ? edst[e0 - 1] : -1);
+        const int vnext = tid + 1 < ne ? edst[e0 + tid + 1] : -2;
+        const unsigned long long heads = __ballot(tid < ne && (tid == 0 || vprev != v));
+        const unsigned long long ends = __ballot(tid < ne && vnext != v);
+        if (tid == 0) {
+            s.misc[0] = (vprev == v) ? 1 : 0;
+            s.misc[2] = (int)(ends & 0xffffffffu);
+            s.misc[3] = (int)(ends >> 32);
+            s.misc[4] = (int)(heads & 0xffffffffu);
+            s.misc[5] = (int)(heads >> 32);
+        }
+    } else {
+        // soft-attention and coordinate-head rows (used on T) and row 256 of either W2 scaled like the weight planes (used on A)
+        for (int i = tid - TM; i < 2 * 66; i += 64 * NW - TM) {
+            const int which = i / 66, j = i - which * 66;
+            const float *row = which == 0 ? a.watt[et] : a.w3[et];
+            reinterpret_cast<f32x4 *>(s.wv + which * HS)[j] = reinterpret_cast<const f32x4 *>(row)[j];
+        }
+        for (int i = tid - TM; i < 2 * 272; i += 64 * NW - TM) {
+            const int which = i / 272, kk = i - which * 272;
+            wxs[which * 272 + kk] = kk < KP ? H_SCALE_W * (which == 0 ? a.wx_e[et] : a.wx_c[et])[kk] : 0.0f;
+        }
+    }
+    lds_barrier();
+    KPD_STAMP(0)
+
+    const float *Ps = a.P[snt] + (size_t)a.src_slot[et] * HS;
+    const float *Pd = a.P[dnt] + (size_t)a.dst_slot[et] * HS;
+    const int first_is_cont = s.misc[0];
+    const unsigned long long endmask =
+        ((unsigned long long)(unsigned)s.misc[3] << 32) | (unsigned long long)(unsigned)s.misc[2];
+    f32x16 acc[2][WaveCols<NW>::NT];
+    float ex;
+
+    // ---- feature messages: m = edge_mlp(f); msg_h = m * sigmoid(att(m)) (dynamics.py:111-112)
+    constexpr int abl = 0;
+    {
+        EdgeGather<4> ge;
+        edge_gather_issue<4>(ge, s, Ps, Pd, wave, lane);
+        edge_gather_finish_h(ge, s, Ah, a.wr_e[et], wave, lane);
+    }
+    lds_barrier();
+    KPD_STAMP(1)
+    acc_zero_w<NW>(acc);
+    ex = row_dot_h(Ah, wxs, tid);
+    gemm_rows64_h(Ah, a.wh_e[et], acc, wave, lane);
+    unscale_acc(acc, ex);
+    lds_barrier();
+    KPD_STAMP(2)
+    if (!(abl & 4)) store_T_silu_w<NW, true>(s.A, acc, ex, a.b_e[et], tid, wave, lane);
+    else if (acc[0][0][0] == 12345.0f) s.A[tid] = acc[1][NW == 4 ? 1 : 0][3] + acc[0][NW == 4 ? 1 : 0][5] + acc[1][0][7];
+    EdgeGather<NW == 4 ? 4 : TM> gc;      // (one row per wave, unused, in the 8-wave build)
+    if constexpr (NW == 4) {  // the coordinate branch's P rows start travelling now; consumed after the segmented sum below
+        if (!(abl & 2)) {
+        edge_gather_issue<NW>(gc, s, Ps + HS, Pd + HS, wave, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    lds_barrier();
+    KPD_STAMP(3)
+    if (!(abl & 4)) {
+        float dot = row_dot_chunks<TPR>(s.A, s.wv, 64, tid);
+        const int row = tid / TPR;
+        if ((tid % TPR) == 0) {
+            dot = fmaf(s.A[row * SA + 256], s.wv[256], dot);
+            // T holds c * m, w_att carries 1 / c; the returned weight carries 1 / c so that T * att = m * sigmoid(.)
+            s.att[row] = row < ne ? sigmoidf_(dot + s.wv[ATT_BIAS_AT]) * (1.0f / SILU_C) : 0.0f;
+        }
+    }
+    lds_barrier();
+    KPD_STAMP(4)
+    if (!(abl & 4)) {
+        // segmented sum over dst (dynamics.py:182-185): thread = column, rows in order; the run
+        // boundaries are wave-uniform (endmask), LDS reads are issued 16 rows at a time
+        float *hmain = a.hn_main[et], *hcont = a.hn_cont[et] + (size_t)tile_in_et * HS;
+        if (tid < 256) {
+            float run = 0.0f;
+            int piece = 0;
+#pragma unroll 1
+            for (int r0 = 0; r0 < TM; r0 += 16) {
+                if (r0 >= ne) break;
+                float v[16], w[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    w[i] = s.att[r0 + i];
+                    v[i] = s.A[(r0 + i) * SA + tid];
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    run = fmaf(v[i], w[i], run);
+                    if ((endmask >> (r0 + i)) & 1ull) {
+                        float *out = (piece == 0 && first_is_cont) ? hcont : hmain + (size_t)s.dst[r0 + i] * HS;
+                        out[tid] = run;
+                        run = 0.0f;
+                        ++piece;
+                    }
+                }
+            }
+        }
+        // column 256: lane = row on the last wave, segmented inclusive scan across lanes
+        if (wave == NW - 1) {
+            const unsigned long long heads =
+                ((unsigned long long)(unsigned)s.misc[5] << 32) | (unsigned long long)(unsigned)s.misc[4];
+            const unsigned long long upto = lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull);
+            const int start = 63 - __clzll((long long)((heads & upto) | 1ull));
+            float v = s.A[lane * SA + 256] * s.att[lane];
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const float t = __shfl_up(v, off);
+                if (lane - off >= start) v += t;
+            }
+            if ((endmask >> lane) & 1ull) {
+                const int pc = __popcll(endmask & ((1ull << lane) - 1ull));
+                float *out = (pc == 0 && first_is_cont) ? hcont : hmain + (size_t)s.dst[lane] * HS;
+                out[256] = v;
+            }
+        }
+    }
+    lds_barrier();
+    KPD_STAMP(5)
+
+    // ---- coordinate messages: msg_x = tanh(coord_mlp(f)) * x_diff * range (dynamics.py:113-120)
+    edge_gather_finish_h(gc, s, Ah, a.wr_c[et], wave, lane);
+    lds_barrier();
+    KPD_STAMP(6)
+    acc_zero_w<NW>(acc);
+    ex = row_dot_h(Ah, wxs + 272, tid);
+    gemm_rows64_h(Ah, a.wh_c[et], acc, wave, lane);
+    unscale_acc(acc, ex);
+    lds_barrier();
+    KPD_STAMP(7)
+    if (!(abl & 4)) store_T_silu_w<NW, true>(s.A, acc, ex, a.b_c[et], tid, wave, lane);
+    else if (acc[0][0][0] == 12345.0f) s.A[tid] = acc[1][NW == 4 ? 1 : 0][3] + acc[0][NW == 4 ? 1 : 0][5] + acc[1][0][7];
+    lds_barrier();
+    KPD_STAMP(8)
+    if (!(abl & 4)) {
+        float dot = row_dot_chunks<TPR>(s.A, s.wv + HS, 64, tid);
+        const int row = tid / TPR;
+        if ((tid % TPR) == 0) {
+            dot = fmaf(s.A[row * SA + 256], s.wv[HS + 256], dot);
+            float c = a.use_tanh ? tanhf(dot) * a.coords_range : dot;
+            if (row >= ne) c = 0.0f;
+            s.mx[3 * row] = c * s.xd[3 * row];
+            s.mx[3 * row + 1] = c * s.xd[3 * row + 1];
+            s.mx[3 * row + 2] = c * s.xd[3 * row + 2];
+        }
+    }
+    lds_barrier();
+    KPD_STAMP(9)
+    if (wave == 0 && !(abl & 4)) {
+        // segmented inclusive scan across lanes (lane = row), then the last lane of every run writes
+        const unsigned long long heads =
+            ((unsigned long long)(unsigned)s.misc[5] << 32) | (unsigned long long)(unsigned)s.misc[4];
+        const unsigned long long upto = lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull);
+        const int start = 63 - __clzll((long long)((heads & upto) | 1ull));
+        float vx = s.mx[3 * lane], vy = s.mx[3 * lane + 1], vz = s.mx[3 * lane + 2];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float tx = __shfl_up(vx, off), ty = __shfl_up(vy, off), tz = __shfl_up(vz, off);
+            if (lane - off >= start) {
+                vx += tx;
+                vy += ty;
+                vz += tz;
+            }
+        }
+        if ((endmask >> lane) & 1ull) {
+            const int piece = __popcll(endmask & ((1ull << lane) - 1ull));
+            float *out = (piece == 0 && first_is_cont) ? a.xn_cont[et] + (size_t)tile_in_et * 4
+                                                       : a.xn_main[et] + (size_t)s.dst[lane] * 4;
+            out[0] = vx;
+            out[1] = vy;
+            out[2] = vz;
+        }
+    }
+    KPD_STAMP(10)
+}
+
+
+
 // ---- 32-row form of the fused edge kernel ---------------------------------------------------------------------
 // Same phases as k_egnn_edge<4> on tiles of 32 edges: the A / T tile is 34 KB instead of 69 KB and a wave needs 32
 // accumulator registers instead of 64, so FOUR independent workgroups share a CU (4 waves per SIMD, <= 128 VGPRs)
@@ -1272,6 +1558,15 @@ kpd_status launch_egnn_edge(const EdgeArgs &a, int tile_cap, hipStream_t st) {
     static const int ablate = getenv("KPD_EDGE_ABLATE") ? atoi(getenv("KPD_EDGE_ABLATE")) : 0;
     EdgeArgs b = a;
     b.ablate = ablate;
+    if (a.gemm_mode == 1) {
+        KPD_REQUIRE(a.tile_rows == TM, KPD_ERR_INVALID, "the f16x2 edge kernel walks 64-edge tiles");
+        for (int et = 0; et < 4; ++et)
+            KPD_REQUIRE(!a.src[et] || (a.wh_e[et] && a.wh_c[et]), KPD_ERR_STATE, "f16x2 weights of edge type %d were not packed", et);
+        KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_egnn_edge_h), EDGE_H_LDS_BYTES));
+        hipLaunchKernelGGL(k_egnn_edge_h, dim3(8 * cdiv(tile_cap, 8)), dim3(256), EDGE_H_LDS_BYTES, st, b);
+        KPD_LAUNCH_CHECK();
+        return KPD_OK;
+    }
     if (a.tile_rows == R32) {
         KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_egnn_edge32), EDGE32_LDS_BYTES + pad));
         hipLaunchKernelGGL(k_egnn_edge32, dim3(8 * cdiv(tile_cap, 8)), dim3(256), EDGE32_LDS_BYTES + pad, st, b);

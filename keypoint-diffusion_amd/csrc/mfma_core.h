@@ -335,6 +335,110 @@ __device__ __forceinline__ void gemm_rows64_w(const float *__restrict__ A, const
     }
 }
 
+// ---- f16x2 mode: fp32-accurate product on the f16 matrix pipe -----------------------------------------------------------
+// a ~ a_hi + a_lo, w ~ w_hi + w_lo with f16 planes (11 significand bits each, 2^-21..2^-22 relative residual); a w is taken as
+// a_hi w_hi + a_hi w_lo + a_lo w_hi (each product exact in fp32, accumulated in fp32 by the MFMA; the dropped a_lo w_lo term is
+// 2^-22 relative).  Three v_mfma_f32_32x32x16_f16 do the work of eight v_mfma_f32_32x32x2_f32 in 96 instead of 512 pipe
+// cycles, and unlike the f32 MFMA they leave the vector issue port free three quarters of the time.
+// A tile in LDS: two planes [64][SAH] of f16 (hi, then lo at + PLANE_H halves); weights: pack_f16_split (pack.hip).
+// Scaling: the f16 MFMA flushes subnormal inputs, and the lo plane of a value x is ~2^-11 |x|, subnormal below |x| = 0.125.  The A
+// planes therefore hold 2^6 a and the weight planes 2^10 w (both split after scaling): lo planes are normal down to |a| = 2e-3,
+// |w| = 1.2e-4, hi planes stay finite up to |a| = 1023, |w| = 63; what is flushed below those bounds is < 2^-11 of an already
+// negligible term.  The accumulator holds 2^16 times the product; the epilogue multiplies by 2^-16.
+constexpr float H_SCALE_A = 64.0f, H_SCALE_W = 1024.0f, H_UNSCALE = 1.0f / 65536.0f;
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+constexpr int SAH = 280;                    // halves per row of an A plane (272 used): 560-B rows, conflict-free ds_read_b128
+constexpr int PLANE_H = TM * SAH;           // halves per plane
+
+__device__ __forceinline__ h8 as_h8(const f32x4 &v) { return __builtin_bit_cast(h8, v); }
+
+// (a, b) -> packed f16 hi pair and packed f16 lo pair (v_cvt_pkrtz_f16_f32: truncation is fine, the remainder goes to lo)
+__device__ __forceinline__ void split_pair(float a, float b, unsigned &hi, unsigned &lo) {
+    typedef __fp16 hp2 __attribute__((ext_vector_type(2)));
+    const hp2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
+    const hp2 l = __builtin_amdgcn_cvt_pkrtz(a - (float)h[0], b - (float)h[1]);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+
+#define KPD_H_LOAD(S_, AH0, AH1, AL0, AL1, BH0, BL0, BH1, BL1)                              \
+    AH0 = *reinterpret_cast<const f32x4 *>(a0p + 16 * (S_));                                \
+    AH1 = *reinterpret_cast<const f32x4 *>(a1p + 16 * (S_));                                \
+    AL0 = *reinterpret_cast<const f32x4 *>(a0p + PLANE_H + 16 * (S_));                      \
+    AL1 = *reinterpret_cast<const f32x4 *>(a1p + PLANE_H + 16 * (S_));                      \
+    BH0 = bp[(S_) * 1024]; BL0 = bp[(S_) * 1024 + 1]; BH1 = bp[(S_) * 1024 + 2]; BL1 = bp[(S_) * 1024 + 3];
+
+#define KPD_H_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(A), as_h8(B), ACC, 0, 0, 0)
+// small terms first, the hi x hi product last
+#define KPD_H_STEP(AH0, AH1, AL0, AL1, BH0, BL0, BH1, BL1)                                  \
+    KPD_H_MFMA(acc[0][0], AL0, BH0); KPD_H_MFMA(acc[0][1], AL0, BH1);                       \
+    KPD_H_MFMA(acc[1][0], AL1, BH0); KPD_H_MFMA(acc[1][1], AL1, BH1);                       \
+    KPD_H_MFMA(acc[0][0], AH0, BL0); KPD_H_MFMA(acc[0][1], AH0, BL1);                       \
+    KPD_H_MFMA(acc[1][0], AH1, BL0); KPD_H_MFMA(acc[1][1], AH1, BL1);                       \
+    KPD_H_MFMA(acc[0][0], AH0, BH0); KPD_H_MFMA(acc[0][1], AH0, BH1);                       \
+    KPD_H_MFMA(acc[1][0], AH1, BH0); KPD_H_MFMA(acc[1][1], AH1, BH1);
+
+// acc[mt][nt] += A[64 x 272] W[272 x (this wave's 64 columns)], A = the two f16 planes at Ah, W = split block Wh
+__device__ __forceinline__ void gemm_rows64_h(const _Float16 *__restrict__ Ah, const void *__restrict__ Wh, f32x16 (&acc)[2][2],
+                                              int wave, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+    const _Float16 *a0p = Ah + r * SAH + 8 * h;
+    const _Float16 *a1p = Ah + (32 + r) * SAH + 8 * h;
+    gf32x4 *bp = as_global(reinterpret_cast<const f32x4 *>(Wh) + (wave * 64 + lane) * 4);      // 4 x 16 B per lane and k-step
+    f32x4 xah0, xah1, xal0, xal1, xbh0, xbl0, xbh1, xbl1, yah0, yah1, yal0, yal1, ybh0, ybl0, ybh1, ybl1;
+    KPD_H_LOAD(0, xah0, xah1, xal0, xal1, xbh0, xbl0, xbh1, xbl1)
+    KPD_H_LOAD(1, yah0, yah1, yal0, yal1, ybh0, ybl0, ybh1, ybl1)
+#pragma unroll 1
+    for (int p = 0; p < KH_STEPS / 2; ++p) {
+        const int s = 2 * p;
+        __builtin_amdgcn_sched_barrier(0);
+        KPD_H_STEP(xah0, xah1, xal0, xal1, xbh0, xbl0, xbh1, xbl1)
+        __builtin_amdgcn_sched_barrier(0);
+        const int s2 = s + 2 < KH_STEPS ? s + 2 : KH_STEPS - 1;
+        KPD_H_LOAD(s2, xah0, xah1, xal0, xal1, xbh0, xbl0, xbh1, xbl1)
+        __builtin_amdgcn_sched_barrier(0);
+        KPD_H_STEP(yah0, yah1, yal0, yal1, ybh0, ybl0, ybh1, ybl1)
+        __builtin_amdgcn_sched_barrier(0);
+        const int s3 = s + 3 < KH_STEPS ? s + 3 : KH_STEPS - 1;
+        KPD_H_LOAD(s3, yah0, yah1, yal0, yal1, ybh0, ybl0, ybh1, ybl1)
+    }
+    if (KH_STEPS & 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        KPD_H_STEP(xah0, xah1, xal0, xal1, xbh0, xbl0, xbh1, xbl1)
+    }
+}
+
+// output column 256 of the same product on the VALU: row (tid / 4) of the two A planes against w (fp32, 272 floats in LDS, already
+// carrying H_SCALE_W).  Every element is rebuilt exactly (hi + lo fits fp32) and multiplied in fp32.  (v_dot2_f32_f16 is NOT usable
+// here: measured on gfx950 it does not keep the products in fp32 -- a 1e-2 error on this column.)  Returns the dot on the 4 lanes of
+// the row.
+__device__ __forceinline__ float row_dot_h(const _Float16 *__restrict__ Ah, const float *__restrict__ w, int tid) {
+    const int row = tid >> 2, q = tid & 3;
+    const _Float16 *ahi = Ah + row * SAH, *alo = Ah + PLANE_H + row * SAH;
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int c = q + 4 * i;                       // 34 chunks of 8 elements per row
+        if (c < 34) {
+            const h8 ah = *reinterpret_cast<const h8 *>(ahi + 8 * c), al = *reinterpret_cast<const h8 *>(alo + 8 * c);
+            const f32x4 wa = *reinterpret_cast<const f32x4 *>(w + 8 * c), wb = *reinterpret_cast<const f32x4 *>(w + 8 * c + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s = fmaf((float)ah[j] + (float)al[j], wa[j], s);
+                s = fmaf((float)ah[4 + j] + (float)al[4 + j], wb[j], s);
+            }
+        }
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    return s;
+}
+
+// 2^6 SiLU in the pre-scaled form of silu_pre: the factor rides in the reciprocal's argument (an fma instead of the add)
+__device__ __forceinline__ float silu_pre_x64(float xs) {
+    return xs * __builtin_amdgcn_rcpf(fmaf(__builtin_amdgcn_exp2f(xs), 1.0f / H_SCALE_A, 1.0f / H_SCALE_A));
+}
+
 // dot of row (tid / TPR) of an LDS tile (stride SA, 16-B aligned) with a vector over the first `chunks`
 // float4 chunks; TPR consecutive threads own one row.  Returns the full dot on all TPR lanes.
 template <int TPR>

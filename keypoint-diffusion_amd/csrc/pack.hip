@@ -98,6 +98,35 @@ kpd_status pack_gemm_weight(const float *src, int n_out, int ld, int col0, int K
     return KPD_OK;
 }
 
+// f16x2 mode (mfma_core.h, gemm_rows64_h): re-pack a finished fp32 block (all scalings and the bias row already in it) into two
+// f16 planes, w ~ hi + lo, in the B-fragment order of v_mfma_f32_32x32x16_f16:
+//   Wh[(((s * 4 + wave) * 64 + lane) * 2 + nt) * 2 + plane][i] = plane(W[n = 64 wave + 32 nt + (lane & 31)][k = 16 s + 8 (lane >> 5) + i])
+// for s < KH_STEPS k-steps of 16 (K = 264 padded to 272 with zeros), i < 8.  One thread per (s, wave, lane, nt, i).
+constexpr float H_SCALE_W_PACK = 1024.0f;       // = H_SCALE_W of mfma_core.h: keeps the lo plane out of the f16 subnormal range
+__global__ void k_pack_f16_split(const float *__restrict__ wp, __fp16 *__restrict__ wh, int total) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int i = idx & 7, nt = (idx >> 3) & 1, lane = (idx >> 4) & 63, wave = (idx >> 10) & 3, s = idx >> 12;
+    const int k = 16 * s + 8 * (lane >> 5) + i, n31 = lane & 31;
+    float w = 0.0f;
+    if (k < KP) {
+        const int g = k >> 3, h = (k >> 2) & 1, j = k & 3;
+        w = H_SCALE_W_PACK * wp[((size_t)(g * 4 + wave) * 64 + (n31 + 32 * h)) * 8 + nt * 4 + j];
+    }
+    const __fp16 hi = (__fp16)w;                       // round to nearest: |w - hi| <= 2^-11 |w|
+    const __fp16 lo = (__fp16)(w - (float)hi);         // and the remainder again: |w - hi - lo| <= 2^-22 |w| (f16 normal range)
+    const size_t base = ((((size_t)(s * 4 + wave) * 64 + lane) * 2 + nt) * 2) * 8;
+    wh[base + i] = hi;
+    wh[base + 8 + i] = lo;
+}
+
+kpd_status pack_f16_split(const float *wp, void *wh, hipStream_t st) {
+    const int total = KH_STEPS * 4 * 64 * 2 * 8;
+    hipLaunchKernelGGL(k_pack_f16_split, dim3(cdiv(total, 256)), dim3(256), 0, st, wp, static_cast<__fp16 *>(wh), total);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
 __global__ void k_pack_chain_frag(const float *__restrict__ src, int sn, int sk, int n_valid, int k_base, int k_valid,
                                   int n_tiles, float *__restrict__ dst) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;

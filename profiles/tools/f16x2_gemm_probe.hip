@@ -1,0 +1,99 @@
+// Unit check of the f16x2 tile GEMM (mfma_core.h gemm_rows64_h + pack.hip pack_f16_split) against the exact fp32 tile GEMM
+// (gemm_rows64_t) and a double-precision host product, on one 64 x 264 tile with realistic magnitudes.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <vector>
+#include "../../keypoint-diffusion_amd/csrc/pack.hip"
+#include "../../keypoint-diffusion_amd/csrc/mfma_core.h"
+using namespace kpd;
+
+__global__ __launch_bounds__(256) void k_probe(const float *A, const float *Wp, const void *Wh, const float *wx, float *out32, float *outh, float *outx) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // fp32 tile
+    for (int i = tid; i < TM * SA; i += 256) smem[i] = 0.0f;
+    __syncthreads();
+    for (int i = tid; i < TM * KP; i += 256) smem[(i / KP) * SA + (i % KP)] = A[i];
+    __syncthreads();
+    f32x16 acc[2][2];
+    acc_zero(acc);
+    gemm_rows64_t<NG, SA>(smem, Wp, acc, wave, lane);
+    for (int mt = 0; mt < 2; ++mt) for (int nt = 0; nt < 2; ++nt) for (int r = 0; r < 16; ++r)
+        out32[acc_row(mt, r, lane) * 256 + acc_col(nt, wave, lane)] = acc[mt][nt][r];
+    __syncthreads();
+    // f16 planes
+    _Float16 *Ah = reinterpret_cast<_Float16 *>(smem);
+    for (int i = tid; i < TM * 272 / 2; i += 256) {
+        const int r = (2 * i) / 272, c = (2 * i) % 272;
+        const float a = c < KP ? H_SCALE_A * A[r * KP + c] : 0.0f, b = c + 1 < KP ? H_SCALE_A * A[r * KP + c + 1] : 0.0f;
+        unsigned hi, lo;
+        split_pair(a, b, hi, lo);
+        *reinterpret_cast<unsigned *>(Ah + r * SAH + c) = hi;
+        *reinterpret_cast<unsigned *>(Ah + PLANE_H + r * SAH + c) = lo;
+    }
+    __syncthreads();
+    float *wxs = smem + TM * SAH + 64;
+    for (int i = tid; i < 272; i += 256) wxs[i] = i < KP ? H_SCALE_W * wx[i] : 0.0f;
+    __syncthreads();
+    const float ex = row_dot_h(Ah, wxs, tid);
+    if ((tid & 3) == 0) outx[tid >> 2] = ex * H_UNSCALE;
+    {   // the same dot element by element
+        const int row = tid >> 2, q = tid & 3;
+        float sx = 0.0f;
+        for (int kx = q; kx < 272; kx += 4) sx = fmaf((float)Ah[row * SAH + kx] + (float)Ah[PLANE_H + row * SAH + kx], wxs[kx], sx);
+        sx += __shfl_xor(sx, 1);
+        sx += __shfl_xor(sx, 2);
+        if ((tid & 3) == 0) outx[64 + (tid >> 2)] = sx * H_UNSCALE;
+    }
+    acc_zero(acc);
+    gemm_rows64_h(Ah, Wh, acc, wave, lane);
+    for (int mt = 0; mt < 2; ++mt) for (int nt = 0; nt < 2; ++nt) for (int r = 0; r < 16; ++r)
+        outh[acc_row(mt, r, lane) * 256 + acc_col(nt, wave, lane)] = acc[mt][nt][r] * H_UNSCALE;
+}
+
+int main() {
+    std::vector<float> A(TM * KP), W(257 * KP);
+    unsigned s = 12345;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.0f - 0.5f; };
+    for (auto &v : A) v = 3.0f * rnd();
+    for (int r = 0; r < TM; ++r) for (int c = 258; c < KP; ++c) A[r * KP + c] = c == 260 ? 1.0f : 0.0f;
+    for (auto &v : W) v = 0.25f * rnd();
+    float *dA, *dW, *dWp, *dWx, *o32, *oh, *ox; void *dWh;
+    hipMalloc(&dA, A.size() * 4); hipMalloc(&dW, W.size() * 4); hipMalloc(&dWp, WP_FLOATS * 4); hipMalloc(&dWx, KP * 4 + 64);
+    hipMalloc(&dWh, WH_HALVES * 2); hipMalloc(&o32, TM * 256 * 4); hipMalloc(&oh, TM * 256 * 4); hipMalloc(&ox, 2 * TM * 4);
+    hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dW, W.data(), W.size() * 4, hipMemcpyHostToDevice);
+    pack_gemm_weight(dW, 257, KP, 0, KP, dWp, dWx, nullptr);
+    pack_f16_split(dWp, dWh, nullptr);
+    hipFuncSetAttribute((const void *)k_probe, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    hipLaunchKernelGGL(k_probe, dim3(1), dim3(256), 75 * 1024, 0, dA, dWp, dWh, dWx, o32, oh, ox);
+    hipDeviceSynchronize();
+    std::vector<float> r32(TM * 256), rh(TM * 256);
+    hipMemcpy(r32.data(), o32, r32.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(rh.data(), oh, rh.size() * 4, hipMemcpyDeviceToHost);
+    double e32 = 0, eh = 0, mx = 0;
+    for (int r = 0; r < TM; ++r) for (int n = 0; n < 256; ++n) {
+        double ref = 0;
+        for (int k = 0; k < KP; ++k) ref += (double)A[r * KP + k] * (double)W[n * KP + k];
+        mx = fmax(mx, fabs(ref));
+        e32 = fmax(e32, fabs(r32[r * 256 + n] - ref));
+        eh = fmax(eh, fabs(rh[r * 256 + n] - ref));
+    }
+    printf("max |ref| %.4f   fp32 MFMA max err %.3e (%.2e rel)   f16x2 max err %.3e (%.2e rel)\n", mx, e32, e32 / mx, eh, eh / mx);
+    std::vector<float> rx(2 * TM);
+    hipMemcpy(rx.data(), ox, 2 * TM * 4, hipMemcpyDeviceToHost);
+    for (int r = 0; r < 4; ++r) {
+        double ref = 0;
+        for (int k = 0; k < KP; ++k) ref += (double)A[r * KP + k] * (double)W[256 * KP + k];
+        printf("row %d: chunked %.6f  elementwise %.6f  host %.6f\n", r, rx[r], rx[64 + r], ref);
+    }
+    double exe = 0, exm = 0;
+    for (int r = 0; r < TM; ++r) {
+        double ref = 0;
+        for (int k = 0; k < KP; ++k) ref += (double)A[r * KP + k] * (double)W[256 * KP + k];
+        exm = fmax(exm, fabs(ref));
+        exe = fmax(exe, fabs(rx[r] - ref));
+    }
+    printf("column 256 (row_dot_h): max |ref| %.4f  max err %.3e (%.2e rel)\n", exm, exe, exe / exm);
+    printf("%s\n", hipGetErrorString(hipGetLastError()));
+    return 0;
+}
