@@ -42,6 +42,9 @@ PEAK_HBM_GBS = 8000.0
 # What back-to-back fp32 MFMAs deliver on all CUs of this part at once (profiles/tools/gemm_loop_probe.hip, profiles/r02_gemm_loop_probe.txt:
 # 64.1 cycles per v_mfma_f32_32x32x2_f32 -- a full pipe -- at the ~2.0 GHz the chip holds under that load).  Context for `frac`, not the peak.
 SUSTAINED_F32_MFMA_TFLOPS = 132.0
+# f16x2 mode (opt-in, --gemm f16x2 / KPD_GEMM=f16x2): every fp32 product of the edge kernel's GEMMs is three f16 MFMA products of hi / lo
+# operand planes with fp32 accumulation, so the bound for USEFUL flops is the dense f16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PFLOP/s) / 3
+PEAK_F16_MATRIX_TFLOPS = 2500.0
 # FLOPs the fused EGNN edge kernel executes per edge per layer: the two 257x257 second Linears of edge_mlp /
 # coord_mlp plus the attention and coordinate heads (the first Linears run per NODE, k_proj_ws)
 EDGE_KERNEL_FLOP_PER_EDGE = 2 * (2 * 257 * 257) + 2 * (2 * 257)
@@ -299,7 +302,7 @@ def load_traffic(workload):
     return None, None
 
 
-def run_sampling(args, workload, device, rank, world, dist, B, n_rec, n_lig, ragged):
+def run_sampling(args, workload, device, rank, world, dist, B, n_rec, n_lig, ragged, gemm='f32'):
     """Steps/s of one sampling workload + the roofline of its dominant kernel.  Returns the result dict (rank 0) ."""
     import torch
     from keypoint_diffusion_amd import graph as G
@@ -308,7 +311,11 @@ def run_sampling(args, workload, device, rank, world, dist, B, n_rec, n_lig, rag
     model = build_model(device, workload)
     g = build_batch(model, B, n_rec, n_lig, seed=1234 + rank * B, device=device, workload=workload)
     bidx = G.get_batch_idxs(g)
+    if gemm != 'f32' and w['arch'] != 'egnn':
+        raise SystemExit('--gemm f16x2 exists for the EGNN edge kernel only')
+    os.environ['KPD_GEMM'] = gemm                      # read by kpd_egnn_create: the engine below is built in this mode
     eng = model.dynamics.engine()
+    os.environ.pop('KPD_GEMM')
     ones = torch.ones(B, device=device)
     # Random-init weights do not denoise: left to itself the chain drives the ligand atoms apart and
     # the lig-lig radius graph empties within ~20 steps, which would shrink the measured work.  Every
@@ -355,14 +362,17 @@ def run_sampling(args, workload, device, rank, world, dist, B, n_rec, n_lig, rag
     edges_per_step = (n_launch_step - 1) * e_all + counts['E_last']
     edges_per_launch = edges_per_step / n_launch_step
     avg_s = kern_ms / max(launches, 1) * 1e-3
+    peak, bound = PEAK_F32_MATRIX_TFLOPS, 'mfma'
     if w['arch'] == 'egnn':
         kernel, f_exec, f_algo, b_algo = 'k_egnn_edge', EDGE_KERNEL_FLOP_PER_EDGE, EDGE_ALGO_FLOP_PER_EDGE, EDGE_ALGO_BYTES_PER_EDGE
+        if gemm == 'f16x2':
+            kernel, peak = 'k_egnn_edge_h', PEAK_F16_MATRIX_TFLOPS / 3.0
     else:
         kernel, f_exec, f_algo, b_algo = ('k_gvp_chain', gvp_chain_flop_per_edge(w['dyn']['n_hidden_scalars']), GVP_ALGO_FLOP_PER_EDGE,
                                           GVP_ALGO_BYTES_PER_EDGE)
     achieved = edges_per_launch * f_exec / avg_s / 1e12 if avg_s > 0 else 0.0
     hbm_gbs = edges_per_launch * b_algo / avg_s / 1e9 if avg_s > 0 else 0.0
-    traffic, tsrc = load_traffic(workload + ('_ragged' if ragged else '')) if (B == 64 and (ragged or n_rec == 300)) else (None, None)
+    traffic, tsrc = load_traffic(workload + ('_ragged' if ragged else '') + ('_f16x2' if gemm != 'f32' else '')) if (B == 64 and (ragged or n_rec == 300)) else (None, None)
     shape = ('150-600', '15-35') if ragged else (n_rec, n_lig)
     desc = {'egnn_all_atom': 'egnn_all_atom dynamics (6 EGNN layers, hidden 256, update_kp_feat; fixed receptor encoder)',
             'egnn_40kp': 'egnn_40kp (learned EGNN receptor encoder -> 40 keypoints -> EGNN dynamics)',
@@ -371,7 +381,10 @@ def run_sampling(args, workload, device, rank, world, dist, B, n_rec, n_lig, rag
     out = {
         'metric': 'denoising steps/sec', 'value': steps_per_s, 'unit': 'steps/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * med / args.steps,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32' if gemm == 'f32' else 'f32 via f16x2 split in the edge-kernel GEMMs (3 f16 MFMA products of hi/lo planes per fp32 '
+                                             'product, f32 accumulate; everything else f32)',
+        'data': 'synthetic',
         'config': {'workload': f'{desc[workload]}, batch of {B} synthetic {shape[0]}-atom pockets / {shape[1]}-atom ligands per GPU, '
                                f'T={T}, seeded random-init weights, every step taken from the t=T ligand state',
                    'batch_per_gpu': B, 'n_rec': 'U{150..600}' if ragged else n_rec, 'n_lig': 'U{15..35}' if ragged else n_lig,
@@ -382,8 +395,10 @@ def run_sampling(args, workload, device, rank, world, dist, B, n_rec, n_lig, rag
         'ligands_per_min_derived': steps_per_s * B * 60.0 / T,
         'edges_per_launch': {**counts, 'E_full_layer': e_all, 'launches_per_step': n_launch_step,
                              'mean_edges_per_launch': edges_per_launch},
-        'roofline': {'kernel': kernel, 'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MATRIX_TFLOPS,
-                     'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MATRIX_TFLOPS,
+        'roofline': {'kernel': kernel, 'bound': bound, 'achieved': achieved, 'peak': peak,
+                     'unit': 'TFLOP/s', 'frac': achieved / peak,
+                     'peak_note': 'dense fp32 MFMA peak' if gemm == 'f32' else 'dense f16 MFMA peak / 3 (three f16 products per useful fp32 product); '
+                                  'achieved counts USEFUL flops (the same 265 kFLOP/edge as the exact kernel)',
                      'peak_sustained_measured': {'value': SUSTAINED_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac_of_it': achieved / SUSTAINED_F32_MFMA_TFLOPS,
                                                  'source': 'profiles/r02_gemm_loop_probe.txt: bare fp32 MFMA loop on every CU, 64.1 cycles per MFMA at '
                                                            'the ~2.0 GHz the part holds under that load (DVFS); the nominal peak assumes 2.4 GHz'},
@@ -483,6 +498,8 @@ def main():
     ap.add_argument('--no-secondary', action='store_true', help='skip the configs[2] / configs[4]-shape / end-to-end measurements')
     ap.add_argument('--workload', default='egnn_all_atom', choices=list(WORKLOADS),
                     help='egnn_all_atom = BASELINE.json configs[1] (the contract line); the others are secondary')
+    ap.add_argument('--gemm', default='f32', choices=['f32', 'f16x2'],
+                    help='f32 = exact fp32 MFMA everywhere (the contract line); f16x2 = opt-in split-f16 products in the EGNN edge kernel')
     ap.add_argument('--graph', action='store_true', help='replay the reverse step as a captured HIP graph (StepGraph)')
     ap.add_argument('--ragged', action='store_true', help='pockets 150-600 atoms, ligands 15-35 atoms (configs[4] shape)')
     args = ap.parse_args()
@@ -537,9 +554,9 @@ def main():
     n_rec, n_lig = args.n_rec, args.n_lig
     if args.ragged:
         n_rec, n_lig = ragged_sizes(args.batch, rank)
-    out = run_sampling(args, args.workload, device, rank, world, dist, args.batch, n_rec, n_lig, args.ragged)
+    out = run_sampling(args, args.workload, device, rank, world, dist, args.batch, n_rec, n_lig, args.ragged, gemm=args.gemm)
     if rank == 0:
-        default_line = args.workload == 'egnn_all_atom' and not args.ragged and not args.graph
+        default_line = args.workload == 'egnn_all_atom' and not args.ragged and not args.graph and args.gemm == 'f32'
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.workload, ragged=args.ragged, B_scale=args.batch)
             out['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']
@@ -555,6 +572,12 @@ def main():
                     r['cpu_baseline'] = cpu_baseline(wl, ragged=ragged)
                     r['gpu_over_cpu'] = r['value'] / r['cpu_baseline']['value']
                 sec[name] = r
+            # the contract workload once more in the opt-in f16x2 mode (separately judged; parity suite runs in both modes)
+            r = run_sampling(sec_args, 'egnn_all_atom', device, 0, 1, None, 64, 300, 25, False, gemm='f16x2')
+            if 'cpu_baseline' in out:
+                r['cpu_baseline'] = out['cpu_baseline']
+                r['gpu_over_cpu'] = r['value'] / out['cpu_baseline']['value']
+            sec['egnn_all_atom_f16x2'] = r
             out['secondary'] = sec
             out['end_to_end'] = run_end_to_end(device)
             out['ligands_per_min'] = out['end_to_end']['ligands_per_min']

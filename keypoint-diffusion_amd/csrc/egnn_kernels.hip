@@ -1561,7 +1561,7 @@ kpd_status launch_egnn_edge(const EdgeArgs &a, int tile_cap, hipStream_t st) {
     if (a.gemm_mode == 1) {
         KPD_REQUIRE(a.tile_rows == TM, KPD_ERR_INVALID, "the f16x2 edge kernel walks 64-edge tiles");
         for (int et = 0; et < 4; ++et)
-            KPD_REQUIRE(!a.src[et] || (a.wh_e[et] && a.wh_c[et]), KPD_ERR_STATE, "f16x2 weights of edge type %d were not packed", et);
+            KPD_REQUIRE(!a.wp_e[et] || (a.wh_e[et] && a.wh_c[et]), KPD_ERR_STATE, "f16x2 weights of edge type %d were not packed", et);
         KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_egnn_edge_h), EDGE_H_LDS_BYTES));
         hipLaunchKernelGGL(k_egnn_edge_h, dim3(8 * cdiv(tile_cap, 8)), dim3(256), EDGE_H_LDS_BYTES, st, b);
         KPD_LAUNCH_CHECK();

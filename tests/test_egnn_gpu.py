@@ -10,7 +10,7 @@ from oracle import graph_ops as og
 
 from . import util
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures('gemm_mode')]   # both GEMM modes of the EGNN edge kernel (conftest.py)
 TOL = 1e-4          # BASELINE.json north_star: "within 1e-4 rel fp32"
 
 

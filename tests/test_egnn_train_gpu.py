@@ -8,7 +8,7 @@ from keypoint_diffusion_amd.dynamics import LigRecDynamics
 from oracle import egnn as oegnn
 from tests import util
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures('gemm_mode')]   # both GEMM modes of the EGNN edge kernel (conftest.py)
 CUT = util.CUTOFFS_ALL_ATOM
 TOL = 2e-4          # relative to the largest entry of each gradient tensor (fp32 both sides, different summation order)
 

@@ -11,7 +11,7 @@ from oracle import rec_encoder_egnn as orec
 from . import util
 from .golden.make_golden_cfgs import RECEGNN_CFGS, same_res_feature
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures('gemm_mode')]   # both GEMM modes of the EGNN edge kernel (conftest.py)
 CUT = util.CUTOFFS_ALL_ATOM
 RECEGNN_40KP = dict(RECEGNN_CFGS['recegnn_20kp'], n_keypoints=40)        # trained_models/egnn_40kp/config.yml:59-75
 # keypoint features from the receptor atoms within kp_rad (receptor_encoder.py:238-262; configs/dev_config.yml:46 sets kp_rad: 5):

@@ -13,7 +13,7 @@ from oracle import gvp as ogvp
 from . import util
 from .test_gvp_gpu import GVP_ALL_ATOM
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures('gemm_mode')]   # both GEMM modes of the EGNN edge kernel (conftest.py)
 CUT = util.CUTOFFS_ALL_ATOM
 
 

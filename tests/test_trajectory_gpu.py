@@ -18,7 +18,7 @@ from oracle import egnn as oegnn
 
 from . import util
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures('gemm_mode')]   # both GEMM modes of the EGNN edge kernel (conftest.py)
 CUT_DEV = {'rr': 3.5, 'rk': 100, 'kk': 8, 'kl': 8, 'll': 9}        # configs/dev_config.yml:35
 T = 100
 
