@@ -69,5 +69,6 @@ constexpr int WP_FLOATS = NG * 4 * 64 * 8;   // packed 256-column weight block
 constexpr int KL_KMAX = 16;   // largest supported kl_k
 constexpr int KH_STEPS = 17;  // f16x2 mode: K = 264 as 17 k-steps of 16 (v_mfma_f32_32x32x16_f16), zero padded to 272
 constexpr int WH_HALVES = KH_STEPS * 4 * 64 * 2 * 2 * 8;   // halves of one split 256-column block (hi + lo planes)
+constexpr int CHH_HALVES = 8 * 16 * 2 * 64 * 8;            // halves of one split 256 x 256 projection block (k_proj_ws_h)
 
 }  // namespace kpd

@@ -21,6 +21,7 @@ struct LayerW {
     float *chain[4], *wcol_e[4], *wcol_c[4];    // chained edge kernel: W2 chunks [coord 16 | edge 16], column 256 of W2
     float *wp_c[4], *wx_c[4], *b_c[4], *wr_c[4], *w3[4];
     void *wh_e[4], *wh_c[4];                    // f16x2 mode: the finished wp_e / wp_c blocks as f16 hi / lo planes
+    void *chh_p[2][NSLOT];                      //             and the projection blocks ch_p
     // per node type, per projection slot
     float *wp_p[2][NSLOT], *wx_p[2][NSLOT], *b_p[2][NSLOT];
     float *ch_p[2][NSLOT], *wcol_p[2][NSLOT];   // k_proj_chain form of the same blocks
@@ -106,6 +107,7 @@ static kpd_status build_weight_arena(kpd_egnn *m) {
     bytes += (size_t)c.n_layers * m->n_et * (32 * 4096 + 2 * HS + 64) * 4;
     bytes += (size_t)c.n_layers * m->n_et * 4 * (16 * 4096 + HS + 64) * 4;
     bytes += (size_t)c.n_layers * m->n_et * 2 * ((size_t)WH_HALVES * 2 + 256);
+    bytes += (size_t)c.n_layers * m->n_et * 4 * ((size_t)CHH_HALVES * 2 + 256);
     bytes += 1 << 20;
     kpd_status st = m->warena.reserve(bytes);
     if (st != KPD_OK) return st;
@@ -128,6 +130,8 @@ static kpd_status build_weight_arena(kpd_egnn *m) {
                 w.wp_p[kDstNt[et]][ds] = wp(); w.wx_p[kDstNt[et]][ds] = vec(); w.b_p[kDstNt[et]][ds] = vec();
                 w.ch_p[kSrcNt[et]][ss] = A.take<float>(16 * 4096); w.wcol_p[kSrcNt[et]][ss] = vec();
                 w.ch_p[kDstNt[et]][ds] = A.take<float>(16 * 4096); w.wcol_p[kDstNt[et]][ds] = vec();
+                w.chh_p[kSrcNt[et]][ss] = A.take<unsigned short>(CHH_HALVES);
+                w.chh_p[kDstNt[et]][ds] = A.take<unsigned short>(CHH_HALVES);
             }
             const std::string e = kEtName[et];
             for (const char *blk : {"edge_mlp.", "coord_mlp."})
@@ -367,6 +371,10 @@ extern "C" kpd_status kpd_egnn_commit(kpd_egnn *m) {
             KPD_TRY(pack_f16_split(L.wp_e[et], L.wh_e[et], nullptr));      // the same finished blocks for the f16x2 mode
             KPD_TRY(pack_f16_split(L.wp_c[et], L.wh_c[et], nullptr));
         }
+    for (LayerW &L : m->L)
+        for (int nt = 0; nt < 2; ++nt)
+            for (int s = 0; s < NSLOT; ++s)
+                if (L.ch_p[nt][s]) KPD_TRY(pack_proj_f16_split(L.ch_p[nt][s], L.chh_p[nt][s], nullptr));
     KPD_HIP(hipDeviceSynchronize());
     m->committed = true;
     return KPD_OK;
@@ -554,12 +562,13 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
                     for (int s = 0; s < NSLOT; ++s)
                         if (L.wp_p[nt][s] && ((mk >> s) & 1)) {
                             pa.wp[k] = L.wp_p[nt][s]; pa.wx[k] = L.wx_p[nt][s]; pa.bias[k] = L.b_p[nt][s]; pa.slot[k] = s;
-                            pa.chain[k] = L.ch_p[nt][s]; pa.wcol[k] = L.wcol_p[nt][s];
+                            pa.chain[k] = L.ch_p[nt][s]; pa.wcol[k] = L.wcol_p[nt][s]; pa.chain_h[k] = L.chh_p[nt][s];
                             ++k;
                         }
                     pp.n_slots[nt] = k;
                 }
                 pp.tiles0 = cdiv(n[0], TM);
+                pp.gemm_mode = m->gemm_mode;
                 KPD_TRY(launch_proj_chain(pp, st));
             }
         }

@@ -26,6 +26,7 @@ struct ProjArgs {
     int slot[NSLOT];
     const float *chain[NSLOT];      // k_proj_chain: the 256 x 256 block as 16 A-fragment chunks, and W[:, 256]
     const float *wcol[NSLOT];
+    const void *chain_h[NSLOT];     // f16x2 mode: the same block as f16 hi / lo planes (pack_proj_f16_split)
 };
 
 struct ProjPair {
@@ -33,6 +34,7 @@ struct ProjPair {
     int tiles0;                     // workgroups (64-node tiles) of nt[0]
     int n_slots[2];
     int slots_per_block;            // consecutive slots one workgroup computes from its resident h registers
+    int gemm_mode;                  // 0: exact fp32 MFMA, 1: f16x2 split (k_proj_ws_h)
 };
 
 struct EdgeArgs {

@@ -150,9 +150,11 @@ __global__ __launch_bounds__(64) void k_decode(const float *__restrict__ h, cons
 }
 
 // ---- fused edge kernel --------------------------------------------------------------------
+constexpr unsigned PROW_B = NSLOT * HS * 4;       // bytes of one node's row of P
+
 struct EdgeSmem {
     float *A;
-    int *src, *dst;
+    int *src, *dst;     // byte offsets of the endpoints' P rows (node * PROW_B)
     float *d, *xd, *att, *mx;
     float *wv;          // [4][HS]: soft-attention row (+bias at ATT_BIAS_AT), coordinate head row, W2[256, :] of edge_mlp / coord_mlp
     int *misc;          // [0] first run continues the previous tile, [2..3] segment-end mask, [4..5] head mask
@@ -188,20 +190,20 @@ template <int NW>
 __device__ __forceinline__ void edge_gather_issue(EdgeGather<NW> &g, const EdgeSmem &s, const float *__restrict__ Ps,
                                                   const float *__restrict__ Pd, int wave, int lane) {
     constexpr int RPW = TM / NW;
-    // 32-bit byte offsets from a wave-uniform base (P stays far below 4 GB): a 64-bit multiply-add per row and side is VALU
-    // time, and VALU time is MFMA time on this pipe.  One 1-KiB row segment per wave instruction, all rows in flight.
-    constexpr unsigned PROW_B = NSLOT * HS * 4;
+    // s.src / s.dst hold the P rows' 32-bit byte offsets (node * PROW_B, premultiplied in phase 0; P stays far below 4 GB):
+    // one full-rate add per row and side here instead of a quarter-rate integer multiply-add.  One 1-KiB row segment per
+    // wave instruction, all rows in flight.
     const char *ps = reinterpret_cast<const char *>(Ps), *pd = reinterpret_cast<const char *>(Pd);
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
         const int r = wave * RPW + rr;
-        g.ps[rr] = *reinterpret_cast<const f32x4 *>(ps + ((unsigned)s.src[r] * PROW_B + 16u * lane));
-        g.pd[rr] = *reinterpret_cast<const f32x4 *>(pd + ((unsigned)s.dst[r] * PROW_B + 16u * lane));
+        g.ps[rr] = *reinterpret_cast<const f32x4 *>(ps + ((unsigned)s.src[r] + 16u * lane));
+        g.pd[rr] = *reinterpret_cast<const f32x4 *>(pd + ((unsigned)s.dst[r] + 16u * lane));
     }
     if (lane < 4 * RPW && (lane & 3) < 2) {
         const int r = wave * RPW + (lane >> 2), c = lane & 3;
-        g.tps = *reinterpret_cast<const f32x4 *>(ps + ((unsigned)s.src[r] * PROW_B + 16u * (64 + c)));
-        g.tpd = *reinterpret_cast<const f32x4 *>(pd + ((unsigned)s.dst[r] * PROW_B + 16u * (64 + c)));
+        g.tps = *reinterpret_cast<const f32x4 *>(ps + ((unsigned)s.src[r] + 16u * (64 + c)));
+        g.tpd = *reinterpret_cast<const f32x4 *>(pd + ((unsigned)s.dst[r] + 16u * (64 + c)));
     }
 }
 
@@ -295,8 +297,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
     if (tid < TM) {
         const int e = e0 + min(tid, ne - 1);
         const int u = esrc[e], v = edst[e];
-        s.src[tid] = u;
-        s.dst[tid] = v;
+        s.src[tid] = (int)((unsigned)u * PROW_B);        // byte offsets of the nodes' P rows
+        s.dst[tid] = (int)((unsigned)v * PROW_B);
         const float *xs = a.x[snt] + (size_t)u * 3, *xd = a.x[dnt] + (size_t)v * 3;
         const float dx = xs[0] - xd[0], dy = xs[1] - xd[1], dz = xs[2] - xd[2];
         const float d = sqrtf(dx * dx + dy * dy + dz * dz);
@@ -397,7 +399,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
                 for (int i = 0; i < 16; ++i) {
                     run = fmaf(v[i], w[i], run);
                     if ((endmask >> (r0 + i)) & 1ull) {
-                        float *out = (piece == 0 && first_is_cont) ? hcont : hmain + (size_t)s.dst[r0 + i] * HS;
+                        float *out = (piece == 0 && first_is_cont) ? hcont : hmain + ((unsigned)s.dst[r0 + i] / (unsigned)(NSLOT * 4));
                         out[tid] = run;
                         run = 0.0f;
                         ++piece;
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
             }
             if ((endmask >> lane) & 1ull) {
                 const int pc = __popcll(endmask & ((1ull << lane) - 1ull));
-                float *out = (pc == 0 && first_is_cont) ? hcont : hmain + (size_t)s.dst[lane] * HS;
+                float *out = (pc == 0 && first_is_cont) ? hcont : hmain + ((unsigned)s.dst[lane] / (unsigned)(NSLOT * 4));
                 out[256] = v;
             }
         }
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
         if ((endmask >> lane) & 1ull) {
             const int piece = __popcll(endmask & ((1ull << lane) - 1ull));
             float *out = (piece == 0 && first_is_cont) ? a.xn_cont[et] + (size_t)tile_in_et * 4
-                                                       : a.xn_main[et] + (size_t)s.dst[lane] * 4;
+                                                       : a.xn_main[et] + (size_t)((unsigned)s.dst[lane] / PROW_B) * 4;
             out[0] = vx;
             out[1] = vy;
             out[2] = vz;
@@ -559,7 +561,8 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_h(EdgeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const EdgeSmem s = edge_smem_h(smem);
     _Float16 *Ah = reinterpret_cast<_Float16 *>(smem);                 // two f16 planes of the A tile; T (fp32) reuses the region
-    float *wxs = reinterpret_cast<float *>(s.misc + 8);                // W2[256, :] of edge_mlp then coord_mlp, x H_SCALE_W, 272 floats each
+    // W2[256, :] of edge_mlp then coord_mlp x H_SCALE_W as f16 planes: [hi 272 | lo 272] each
+    _Float16 *wxs = reinterpret_cast<_Float16 *>(s.misc + 8);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     unsigned long long t_prev_ = a.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
     // tile decode (XCD-aware: consecutive tiles -- neighbouring edges of one complex, which
@@ -585,8 +588,8 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_h(EdgeArgs a) {
     if (tid < TM) {
         const int e = e0 + min(tid, ne - 1);
         const int u = esrc[e], v = edst[e];
-        s.src[tid] = u;
-        s.dst[tid] = v;
+        s.src[tid] = (int)((unsigned)u * PROW_B);        // byte offsets of the nodes' P rows
+        s.dst[tid] = (int)((unsigned)v * PROW_B);
         const float *xs = a.x[snt] + (size_t)u * 3, *xd = a.x[dnt] + (size_t)v * 3;
         const float dx = xs[0] - xd[0], dy = xs[1] - xd[1], dz = xs[2] - xd[2];
         const float d = sqrtf(dx * dx + dy * dy + dz * dz);
@@ -616,7 +619,10 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_h(EdgeArgs a) {
         }
         for (int i = tid - TM; i < 2 * 272; i += 64 * NW - TM) {
             const int which = i / 272, kk = i - which * 272;
-            wxs[which * 272 + kk] = kk < KP ? H_SCALE_W * (which == 0 ? a.wx_e[et] : a.wx_c[et])[kk] : 0.0f;
+            const float w = kk < KP ? H_SCALE_W * (which == 0 ? a.wx_e[et] : a.wx_c[et])[kk] : 0.0f;
+            const _Float16 hi = (_Float16)w;
+            wxs[which * 544 + kk] = hi;
+            wxs[which * 544 + 272 + kk] = (_Float16)(w - (float)hi);
         }
     }
     lds_barrier();
@@ -640,7 +646,7 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_h(EdgeArgs a) {
     lds_barrier();
     KPD_STAMP(1)
     acc_zero_w<NW>(acc);
-    ex = row_dot_h(Ah, wxs, tid);
+    ex = row_dot_h2(Ah, wxs, tid);
     gemm_rows64_h(Ah, a.wh_e[et], acc, wave, lane);
     unscale_acc(acc, ex);
     lds_barrier();
@@ -687,7 +693,7 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_h(EdgeArgs a) {
                 for (int i = 0; i < 16; ++i) {
                     run = fmaf(v[i], w[i], run);
                     if ((endmask >> (r0 + i)) & 1ull) {
-                        float *out = (piece == 0 && first_is_cont) ? hcont : hmain + (size_t)s.dst[r0 + i] * HS;
+                        float *out = (piece == 0 && first_is_cont) ? hcont : hmain + ((unsigned)s.dst[r0 + i] / (unsigned)(NSLOT * 4));
                         out[tid] = run;
                         run = 0.0f;
                         ++piece;
@@ -709,7 +715,7 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_h(EdgeArgs a) {
             }
             if ((endmask >> lane) & 1ull) {
                 const int pc = __popcll(endmask & ((1ull << lane) - 1ull));
-                float *out = (pc == 0 && first_is_cont) ? hcont : hmain + (size_t)s.dst[lane] * HS;
+                float *out = (pc == 0 && first_is_cont) ? hcont : hmain + ((unsigned)s.dst[lane] / (unsigned)(NSLOT * 4));
                 out[256] = v;
             }
         }
@@ -722,7 +728,7 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_h(EdgeArgs a) {
     lds_barrier();
     KPD_STAMP(6)
     acc_zero_w<NW>(acc);
-    ex = row_dot_h(Ah, wxs + 272, tid);
+    ex = row_dot_h2(Ah, wxs + 544, tid);
     gemm_rows64_h(Ah, a.wh_c[et], acc, wave, lane);
     unscale_acc(acc, ex);
     lds_barrier();
@@ -764,7 +770,7 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_h(EdgeArgs a) {
         if ((endmask >> lane) & 1ull) {
             const int piece = __popcll(endmask & ((1ull << lane) - 1ull));
             float *out = (piece == 0 && first_is_cont) ? a.xn_cont[et] + (size_t)tile_in_et * 4
-                                                       : a.xn_main[et] + (size_t)s.dst[lane] * 4;
+                                                       : a.xn_main[et] + (size_t)((unsigned)s.dst[lane] / PROW_B) * 4;
             out[0] = vx;
             out[1] = vy;
             out[2] = vz;

@@ -127,6 +127,29 @@ kpd_status pack_f16_split(const float *wp, void *wh, hipStream_t st) {
     return KPD_OK;
 }
 
+// Projections in f16x2 mode (k_proj_ws_h, egnn_chain.hip): W[n][k] of a 256 x 256 block, read from its chained fp32 form
+// (slab kc = k >> 4: chain[kc * 4096 + ((n >> 4) * 64 + 16 * ((k & 15) >> 2) + (n & 15)) * 4 + (k & 3)]), as two f16 planes in the
+// A-fragment order of v_mfma_f32_16x16x32_f16:
+//   chh[(((kb * 16 + mt) * 2 + plane) * 64 + lane) * 8 + j] = plane(W[n = 16 mt + (lane & 15)][k = 32 kb + 8 (lane >> 4) + j])
+__global__ void k_pack_proj_f16_split(const float *__restrict__ chain, __fp16 *__restrict__ chh) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // (kb, mt, lane, j)
+    if (idx >= 8 * 16 * 64 * 8) return;
+    const int j = idx & 7, lane = (idx >> 3) & 63, mt = (idx >> 9) & 15, kb = idx >> 13;
+    const int k = 32 * kb + 8 * (lane >> 4) + j;
+    const float w = H_SCALE_W_PACK * chain[(size_t)(k >> 4) * 4096 + (mt * 64 + 16 * ((k & 15) >> 2) + (lane & 15)) * 4 + (k & 3)];
+    const __fp16 hi = (__fp16)w;
+    const __fp16 lo = (__fp16)(w - (float)hi);
+    const size_t base = (((size_t)(kb * 16 + mt) * 2) * 64 + lane) * 8 + j;
+    chh[base] = hi;
+    chh[base + 64 * 8] = lo;
+}
+
+kpd_status pack_proj_f16_split(const float *chain, void *chh, hipStream_t st) {
+    hipLaunchKernelGGL(k_pack_proj_f16_split, dim3(8 * 16 * 64 * 8 / 256), dim3(256), 0, st, chain, static_cast<__fp16 *>(chh));
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
 __global__ void k_pack_chain_frag(const float *__restrict__ src, int sn, int sk, int n_valid, int k_base, int k_valid,
                                   int n_tiles, float *__restrict__ dst) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;

@@ -2,7 +2,7 @@
 # Collect the judged evidence for one round on the GPU box (run from the repo root):
 #   bash profiles/tools/collect_round.sh r02
 # 1) the default bench line (contract line + secondary workloads + end-to-end)            -> <tag>/bench.json
-# 2) rocprofv3 --kernel-trace --stats of the contract workload and of the two GVP workloads -> <tag>/stats_*
+# 2) rocprofv3 --kernel-trace --stats of the contract workload, of its opt-in f16x2 mode and of the two GVP workloads -> <tag>/stats_*
 # 3) separate PMC passes per workload: SQ counters, FETCH_SIZE, WRITE_SIZE                  -> <tag>/pmc_*
 # 4) traffic.json: HBM bytes per launch of the dominant kernel of every workload (2 x FETCH_SIZE + WRITE_SIZE)
 # Copy the summaries into profiles/ afterwards (gpurun_out/ is scratch).
@@ -13,9 +13,10 @@ out=gpurun_out/$tag
 rm -rf $out && mkdir -p $out
 python bench.py > $out/bench.json 2> $out/bench.err
 short="--steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-secondary"
-for wl in egnn_all_atom gvp_40kp gvp_all_atom_ragged; do
+for wl in egnn_all_atom egnn_all_atom_f16x2 gvp_40kp gvp_all_atom_ragged; do
   case $wl in
     egnn_all_atom) args="";;
+    egnn_all_atom_f16x2) args="--gemm f16x2";;
     gvp_40kp) args="--workload gvp_40kp";;
     gvp_all_atom_ragged) args="--workload gvp_all_atom --ragged";;
   esac
@@ -31,7 +32,7 @@ done
 KPD_OUT=$out python - <<'PY'
 import csv, glob, json, os
 out = os.environ['KPD_OUT']
-dom = {'egnn_all_atom': 'k_egnn_edge<4>', 'gvp_40kp': 'k_gvp_chain<16>', 'gvp_all_atom_ragged': 'k_gvp_chain<16>'}
+dom = {'egnn_all_atom': 'k_egnn_edge<4>', 'egnn_all_atom_f16x2': 'k_egnn_edge_h', 'gvp_40kp': 'k_gvp_chain<16>', 'gvp_all_atom_ragged': 'k_gvp_chain<16>'}
 res = {}
 for wl, kern in dom.items():
     agg = {}

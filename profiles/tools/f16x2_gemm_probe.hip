@@ -38,6 +38,18 @@ __global__ __launch_bounds__(256) void k_probe(const float *A, const float *Wp, 
     __syncthreads();
     const float ex = row_dot_h(Ah, wxs, tid);
     if ((tid & 3) == 0) outx[tid >> 2] = ex * H_UNSCALE;
+    {   // packed-f16 dot-product form
+        _Float16 *wxh = reinterpret_cast<_Float16 *>(wxs + 272);
+        for (int i = tid; i < 272; i += 256) {
+            const float w = wxs[i];
+            const _Float16 hi = (_Float16)w;
+            wxh[i] = hi;
+            wxh[272 + i] = (_Float16)(w - (float)hi);
+        }
+        __syncthreads();
+        const float e2 = row_dot_h2(Ah, wxh, tid);
+        if ((tid & 3) == 0) outx[128 + (tid >> 2)] = e2 * H_UNSCALE;
+    }
     {   // the same dot element by element
         const int row = tid >> 2, q = tid & 3;
         float sx = 0.0f;
@@ -61,7 +73,7 @@ int main() {
     for (auto &v : W) v = 0.25f * rnd();
     float *dA, *dW, *dWp, *dWx, *o32, *oh, *ox; void *dWh;
     hipMalloc(&dA, A.size() * 4); hipMalloc(&dW, W.size() * 4); hipMalloc(&dWp, WP_FLOATS * 4); hipMalloc(&dWx, KP * 4 + 64);
-    hipMalloc(&dWh, WH_HALVES * 2); hipMalloc(&o32, TM * 256 * 4); hipMalloc(&oh, TM * 256 * 4); hipMalloc(&ox, 2 * TM * 4);
+    hipMalloc(&dWh, WH_HALVES * 2); hipMalloc(&o32, TM * 256 * 4); hipMalloc(&oh, TM * 256 * 4); hipMalloc(&ox, 3 * TM * 4);
     hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dW, W.data(), W.size() * 4, hipMemcpyHostToDevice);
     pack_gemm_weight(dW, 257, KP, 0, KP, dWp, dWx, nullptr);
     pack_f16_split(dWp, dWh, nullptr);
@@ -79,12 +91,12 @@ int main() {
         eh = fmax(eh, fabs(rh[r * 256 + n] - ref));
     }
     printf("max |ref| %.4f   fp32 MFMA max err %.3e (%.2e rel)   f16x2 max err %.3e (%.2e rel)\n", mx, e32, e32 / mx, eh, eh / mx);
-    std::vector<float> rx(2 * TM);
-    hipMemcpy(rx.data(), ox, 2 * TM * 4, hipMemcpyDeviceToHost);
+    std::vector<float> rx(3 * TM);
+    hipMemcpy(rx.data(), ox, 3 * TM * 4, hipMemcpyDeviceToHost);
     for (int r = 0; r < 4; ++r) {
         double ref = 0;
         for (int k = 0; k < KP; ++k) ref += (double)A[r * KP + k] * (double)W[256 * KP + k];
-        printf("row %d: chunked %.6f  elementwise %.6f  host %.6f\n", r, rx[r], rx[64 + r], ref);
+        printf("row %d: chunked %.7f  elementwise %.7f  dot2 %.7f  host %.7f\n", r, rx[r], rx[64 + r], rx[128 + r], ref);
     }
     double exe = 0, exm = 0;
     for (int r = 0; r < TM; ++r) {
@@ -94,6 +106,13 @@ int main() {
         exe = fmax(exe, fabs(rx[r] - ref));
     }
     printf("column 256 (row_dot_h): max |ref| %.4f  max err %.3e (%.2e rel)\n", exm, exe, exe / exm);
+    double e2m = 0;
+    for (int r = 0; r < TM; ++r) {
+        double ref = 0;
+        for (int k = 0; k < KP; ++k) ref += (double)A[r * KP + k] * (double)W[256 * KP + k];
+        e2m = fmax(e2m, fabs(rx[128 + r] - ref));
+    }
+    printf("column 256 (row_dot_h2, v_dot2_f32_f16): max err %.3e (%.2e rel)\n", e2m, e2m / exm);
     printf("%s\n", hipGetErrorString(hipGetLastError()));
     return 0;
 }
