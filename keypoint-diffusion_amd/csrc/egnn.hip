@@ -21,7 +21,8 @@ struct LayerW {
     float *chain[4], *wcol_e[4], *wcol_c[4];    // chained edge kernel: W2 chunks [coord 16 | edge 16], column 256 of W2
     float *wp_c[4], *wx_c[4], *b_c[4], *wr_c[4], *w3[4];
     void *wh_e[4], *wh_c[4];                    // f16x2 mode: the finished wp_e / wp_c blocks as f16 hi / lo planes
-    void *chh_p[2][NSLOT];                      //             and the projection blocks ch_p
+    void *chh_p[2][NSLOT];                      //             the projection blocks ch_p
+    void *wh_a[2], *wh_b[2], *wh_2[2];          //             and the node-MLP blocks wp_a / wp_b / wp_2
     // per node type, per projection slot
     float *wp_p[2][NSLOT], *wx_p[2][NSLOT], *b_p[2][NSLOT];
     float *ch_p[2][NSLOT], *wcol_p[2][NSLOT];   // k_proj_chain form of the same blocks
@@ -108,6 +109,7 @@ static kpd_status build_weight_arena(kpd_egnn *m) {
     bytes += (size_t)c.n_layers * m->n_et * 4 * (16 * 4096 + HS + 64) * 4;
     bytes += (size_t)c.n_layers * m->n_et * 2 * ((size_t)WH_HALVES * 2 + 256);
     bytes += (size_t)c.n_layers * m->n_et * 4 * ((size_t)CHH_HALVES * 2 + 256);
+    bytes += (size_t)c.n_layers * m->n_upd * 3 * ((size_t)WH_HALVES * 2 + 256);
     bytes += 1 << 20;
     kpd_status st = m->warena.reserve(bytes);
     if (st != KPD_OK) return st;
@@ -143,6 +145,8 @@ static kpd_status build_weight_arena(kpd_egnn *m) {
         for (int nt = 0; nt < m->n_upd; ++nt) {
             w.wp_a[nt] = wp(); w.wx_a[nt] = vec(); w.wp_b[nt] = wp(); w.wx_b[nt] = vec(); w.b0[nt] = vec();
             w.wp_2[nt] = wp(); w.wx_2[nt] = vec(); w.b2[nt] = vec(); w.ln_w[nt] = vec(); w.ln_b[nt] = vec();
+            w.wh_a[nt] = A.take<unsigned short>(WH_HALVES); w.wh_b[nt] = A.take<unsigned short>(WH_HALVES);
+            w.wh_2[nt] = A.take<unsigned short>(WH_HALVES);
             const std::string n = kNtName[nt];
             for (const char *s : {".0.weight", ".0.bias", ".2.weight", ".2.bias"}) m->expected.insert(pre + "node_mlp." + n + s);
             if (c.norm) {
@@ -375,6 +379,12 @@ extern "C" kpd_status kpd_egnn_commit(kpd_egnn *m) {
         for (int nt = 0; nt < 2; ++nt)
             for (int s = 0; s < NSLOT; ++s)
                 if (L.ch_p[nt][s]) KPD_TRY(pack_proj_f16_split(L.ch_p[nt][s], L.chh_p[nt][s], nullptr));
+    for (LayerW &L : m->L)
+        for (int nt = 0; nt < m->n_upd; ++nt) {
+            KPD_TRY(pack_f16_split(L.wp_a[nt], L.wh_a[nt], nullptr));
+            KPD_TRY(pack_f16_split(L.wp_b[nt], L.wh_b[nt], nullptr));
+            KPD_TRY(pack_f16_split(L.wp_2[nt], L.wh_2[nt], nullptr));
+        }
     KPD_HIP(hipDeviceSynchronize());
     m->committed = true;
     return KPD_OK;
@@ -614,6 +624,7 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
             na.n_in = k;
             na.wp_a = L.wp_a[nt]; na.wx_a = L.wx_a[nt]; na.wp_b = L.wp_b[nt]; na.wx_b = L.wx_b[nt]; na.b0 = L.b0[nt];
             na.wp_2 = L.wp_2[nt]; na.wx_2 = L.wx_2[nt]; na.b2 = L.b2[nt]; na.ln_w = L.ln_w[nt]; na.ln_b = L.ln_b[nt];
+            na.wh_a = L.wh_a[nt]; na.wh_b = L.wh_b[nt]; na.wh_2 = L.wh_2[nt];
             na.norm = c.norm;
             na.tile_shift = tr == 32 ? 5 : 6;
         };
@@ -633,6 +644,7 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
             }
             lp.tiles0 = cdiv(lp.nt[0].u.n, TN);
             lp.stamps = m->stamps ? m->stamps + 16 : nullptr;
+            lp.gemm_mode = m->gemm_mode;
             KPD_TRY(launch_node_layer(lp, st));
         }
     }

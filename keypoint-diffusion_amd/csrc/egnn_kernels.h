@@ -74,6 +74,7 @@ struct NodeArgs {
     const float *xn_main[2], *xn_cont[2];
     const float *wp_a, *wx_a, *wp_b, *wx_b, *b0;
     const float *wp_2, *wx_2, *b2;
+    const void *wh_a, *wh_b, *wh_2; // f16x2 mode: wp_a / wp_b / wp_2 as f16 hi / lo planes (pack_f16_split)
     const float *ln_w, *ln_b;
     int norm;
     int tile_shift;                 // log2 of the edge-tile size the segment pieces (main / cont) were written with
@@ -94,10 +95,14 @@ struct NodeLayerPair {
     int tiles0;                     // 32-node tiles of nt[0]
     unsigned long long *stamps;     // [16] phase-cycle sums (diagnostics only, null in production)
     int dbg;                        // ablation switches for timing experiments (KPD_NODE_ABLATE), 0 in production
+    int gemm_mode;                  // 0: exact fp32 MFMA, 1: f16x2 split (k_node_update8_h)
 };
 
 constexpr int TN = 32;              // rows per workgroup of the fused node kernel
 constexpr int NODE_LAYER_LDS_BYTES = TN * SA * 4 + 3 * TN * 4;
+// k_node_update8_h: two f16 planes of 32 x 280 halves (35 840 B) shared with the fp32 tile (34 304 B)
+constexpr int NODE_H_TILE_FLOATS = 2 * TN * 280 / 2;
+constexpr int NODE_H_LDS_BYTES = NODE_H_TILE_FLOATS * 4 + 3 * TN * 4;
 
 
 kpd_status egnn_kernels_init();

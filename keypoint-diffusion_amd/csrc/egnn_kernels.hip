@@ -1513,6 +1513,198 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 }
 
 
+// ---- node update, f16x2 split (opt-in gemm mode 1; same phases as k_node_update8) ----------------------------------------------
+// The three GEMMs run on v_mfma_f32_32x32x16_f16 over hi / lo planes (gemm_rows32_h8); the tile is kept as two f16 planes of
+// 2^6 x value while it is a GEMM operand and as fp32 (same LDS region) from the output of GEMM 2 on: bias, residual, LayerNorm and
+// the h' written back are fp32 exactly as in the exact kernel.
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_node_update8_h(NodeLayerPair p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *A = smem;                                                   // fp32 view [TN][SA] (phases after GEMM 2)
+    _Float16 *Ah = reinterpret_cast<_Float16 *>(smem);                 // plane view [2][TN][SAH]
+    constexpr int PN = TN * SAH;
+    float *s_z = smem + NODE_H_TILE_FLOATS;
+    float *s_mean = s_z + TN;
+    float *s_rstd = s_mean + TN;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int which = blockIdx.x >= p.tiles0 ? 1 : 0;
+    const NodeLayerArgs &L = p.nt[which];
+    const NodeArgs &a = L.u;
+    const int node0 = (blockIdx.x - (which ? p.tiles0 : 0)) * TN;
+    constexpr int RPW = TN / 8;
+    constexpr int TPR = 512 / TN;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+    // row r of the tile <- 2^6 (val | val2) as planes; lanes 2, 3 zero the K padding 264 .. 271
+    auto put_row = [&](int r, const f32x4 &val, const f32x4 &val2) {
+        unsigned h0, h1, l0, l1;
+        split_pair(H_SCALE_A * val[0], H_SCALE_A * val[1], h0, l0);
+        split_pair(H_SCALE_A * val[2], H_SCALE_A * val[3], h1, l1);
+        *reinterpret_cast<u32x2 *>(Ah + r * SAH + 4 * lane) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2 *>(Ah + PN + r * SAH + 4 * lane) = u32x2{l0, l1};
+        if (lane < 4) {
+            split_pair(H_SCALE_A * val2[0], H_SCALE_A * val2[1], h0, l0);
+            split_pair(H_SCALE_A * val2[2], H_SCALE_A * val2[3], h1, l1);
+            *reinterpret_cast<u32x2 *>(Ah + r * SAH + 256 + 4 * lane) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2 *>(Ah + PN + r * SAH + 256 + 4 * lane) = u32x2{l0, l1};
+        }
+    };
+    auto put_elem = [&](int row, int col, float v) {
+        const float sv = H_SCALE_A * v;
+        const _Float16 hi = (_Float16)sv;
+        Ah[row * SAH + col] = hi;
+        Ah[PN + row * SAH + col] = (_Float16)(sv - (float)hi);
+    };
+
+    f32x16 acc;
+    // coordinates: x' = x + x_neigh / z (dynamics.py:190-192, 206)
+    if (tid < TN) {
+        const int v = node0 + tid;
+        float z = 1.0f;
+        if (v < a.n) {
+            z = a.z[a.bidx[v]];
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+            for (int i = 0; i < a.n_in; ++i) {
+                const int lo = a.rowptr[i][v], hi = a.rowptr[i][v + 1];
+                if (hi > lo) {
+                    const float *pm = a.xn_main[i] + (size_t)v * 4;
+                    sx += pm[0]; sy += pm[1]; sz += pm[2];
+                    for (int t = (lo >> a.tile_shift) + 1; t <= ((hi - 1) >> a.tile_shift); ++t) {
+                        const float *q = a.xn_cont[i] + (size_t)t * 4;
+                        sx += q[0]; sy += q[1]; sz += q[2];
+                    }
+                }
+            }
+            float *xv = a.x + (size_t)v * 3;
+            xv[0] += sx / z; xv[1] += sy / z; xv[2] += sz / z;
+        }
+        s_z[tid] = z;
+    }
+    // GEMM 1a: W[:, :257] . h
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int r = wave * RPW + rr, v = node0 + r;
+        f32x4 val = {0.f, 0.f, 0.f, 0.f}, val2 = {0.f, 0.f, 0.f, 0.f};
+        if (v < a.n) {
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(a.h + (size_t)v * HS);
+            val = src[lane];
+            if (lane < 2) val2 = src[64 + lane];
+        }
+        put_row(r, val, val2);
+    }
+    lds_barrier();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    gemm_rows32_h8(Ah, PN, a.wh_a, acc, wave, lane);
+    float ex = row_dot_planes<TPR>(Ah, PN, a.wx_a, tid);
+    lds_barrier();
+    // GEMM 1b: + W[:, 257:] . (h_neigh / z); h_neigh = sum of segment pieces over the incoming edge types in fixed order
+#pragma unroll 2
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int r = wave * RPW + rr, v = node0 + r;
+        f32x4 val = {0.f, 0.f, 0.f, 0.f}, val2 = {0.f, 0.f, 0.f, 0.f};
+        if (v < a.n) {
+            for (int i = 0; i < a.n_in; ++i) {
+                const int lo = a.rowptr[i][v], hi = a.rowptr[i][v + 1];
+                if (hi > lo) {
+                    const f32x4 *pm = reinterpret_cast<const f32x4 *>(a.hn_main[i] + (size_t)v * HS);
+                    val += pm[lane];
+                    if (lane < 2) val2 += pm[64 + lane];
+                    for (int t = (lo >> a.tile_shift) + 1; t <= ((hi - 1) >> a.tile_shift); ++t) {
+                        const f32x4 *q = reinterpret_cast<const f32x4 *>(a.hn_cont[i] + (size_t)t * HS);
+                        val += q[lane];
+                        if (lane < 2) val2 += q[64 + lane];
+                    }
+                }
+            }
+            const float z = s_z[r];
+            val /= z;
+            val2 /= z;
+        }
+        put_row(r, val, val2);
+    }
+    lds_barrier();
+    gemm_rows32_h8(Ah, PN, a.wh_b, acc, wave, lane);
+    ex += row_dot_planes<TPR>(Ah, PN, a.wx_b, tid);
+    lds_barrier();
+    // hidden = SiLU(. + b0) -> planes (pad columns 257 .. 271 stay 0 from the h_neigh tile)
+    {
+        const int col = 32 * wave + (lane & 31);
+        const float bb = a.b0[col];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) put_elem(acc_row32(reg, lane), col, silu(fmaf(acc[reg], H_UNSCALE, bb)));
+    }
+    if ((tid % TPR) == 0) put_elem(tid / TPR, 256, silu(fmaf(ex, 1.0f / H_SCALE_A, a.b0[256])));
+    lds_barrier();
+    // GEMM 2 + bias + residual (dynamics.py:201-203)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    gemm_rows32_h8(Ah, PN, a.wh_2, acc, wave, lane);
+    ex = row_dot_planes<TPR>(Ah, PN, a.wx_2, tid);
+    lds_barrier();
+    {
+        const int col = 32 * wave + (lane & 31);
+        const float bb = a.b2[col];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) A[acc_row32(reg, lane) * SA + col] = fmaf(acc[reg], H_UNSCALE, bb);
+    }
+    if ((tid % TPR) == 0) A[(tid / TPR) * SA + 256] = fmaf(ex, 1.0f / H_SCALE_A, a.b2[256]);
+    lds_barrier();
+#pragma unroll 4
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int r = wave * RPW + rr;
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(a.h + (size_t)(node0 + r) * HS);
+        *reinterpret_cast<f32x4 *>(A + r * SA + 4 * lane) += src[lane];
+        if (lane == 0) A[r * SA + 256] += a.h[(size_t)(node0 + r) * HS + 256];
+    }
+    lds_barrier();
+    // LayerNorm(257) (dynamics.py:81-87, 204), biased variance, eps = 1e-5
+    if (a.norm) {
+        const int row = tid / TPR, q = tid % TPR;
+        const float *tr = A + row * SA + q;
+        float sum = 0.0f;
+        for (int i = 0; i < 256 / TPR; ++i) sum += tr[TPR * i];
+        if (q == 0) sum += A[row * SA + 256];
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) sum += __shfl_xor(sum, o);
+        const float mean = sum * (1.0f / HW);
+        float var = 0.0f;
+        for (int i = 0; i < 256 / TPR; ++i) {
+            const float dlt = tr[TPR * i] - mean;
+            var = fmaf(dlt, dlt, var);
+        }
+        if (q == 0) {
+            const float dlt = A[row * SA + 256] - mean;
+            var = fmaf(dlt, dlt, var);
+        }
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) var += __shfl_xor(var, o);
+        if (q == 0) {
+            s_mean[row] = mean;
+            s_rstd[row] = 1.0f / sqrtf(var * (1.0f / HW) + 1e-5f);
+        }
+    }
+    lds_barrier();
+    // normalise and write h' back
+#pragma unroll 2
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int r = wave * RPW + rr, v = node0 + r;
+        if (v >= a.n) continue;
+        f32x4 val = *reinterpret_cast<const f32x4 *>(A + r * SA + 4 * lane);
+        float last = A[r * SA + 256];
+        if (a.norm) {
+            const float mean = s_mean[r], rstd = s_rstd[r];
+            const f32x4 w = reinterpret_cast<const f32x4 *>(a.ln_w)[lane];
+            const f32x4 b = reinterpret_cast<const f32x4 *>(a.ln_b)[lane];
+            val = (val - mean) * rstd * w + b;
+            last = (last - mean) * rstd * a.ln_w[256] + a.ln_b[256];
+        }
+        f32x4 *dst = reinterpret_cast<f32x4 *>(a.h + (size_t)v * HS);
+        dst[lane] = val;
+        if (lane == 0) dst[64] = f32x4{last, 0.f, 0.f, 0.f};
+    }
+}
+
+
 // ---- launchers ----------------------------------------------------------------------------
 // kept for the engines' create paths: everything it used to do now happens per (kernel, device) at launch time
 kpd_status egnn_kernels_init() { return KPD_OK; }
@@ -1602,6 +1794,15 @@ kpd_status launch_node_layer(const NodeLayerPair &p, hipStream_t st) {
     static const int nw = getenv("KPD_NODE_NW") ? atoi(getenv("KPD_NODE_NW")) : 8;
     const bool update_only = (p.nt[0].do_update || p.nt[0].u.n == 0) && (p.nt[1].do_update || p.nt[1].u.n == 0) &&
                              !p.nt[0].do_proj && !p.nt[1].do_proj;
+    if (p.gemm_mode == 1 && update_only && !p.stamps && !dbg) {      // (diagnostic / fused launches keep the exact kernels)
+        for (int nt = 0; nt < 2; ++nt)
+            if (p.nt[nt].u.n > 0)
+                KPD_REQUIRE(p.nt[nt].u.wh_a && p.nt[nt].u.wh_b && p.nt[nt].u.wh_2, KPD_ERR_STATE, "node weights of type %d have no f16 planes", nt);
+        KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_node_update8_h), NODE_H_LDS_BYTES));
+        hipLaunchKernelGGL(k_node_update8_h, dim3(tiles), dim3(512), NODE_H_LDS_BYTES, st, q);
+        KPD_LAUNCH_CHECK();
+        return KPD_OK;
+    }
     if (nw == 8 && update_only && !p.stamps && !dbg) {
         KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_node_update8), NODE_LAYER_LDS_BYTES + pad));
         hipLaunchKernelGGL(k_node_update8, dim3(tiles), dim3(512), NODE_LAYER_LDS_BYTES + pad, st, q);

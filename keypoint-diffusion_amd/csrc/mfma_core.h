@@ -463,6 +463,61 @@ __device__ __forceinline__ float row_dot_h2(const _Float16 *__restrict__ Ah, con
     return s;
 }
 
+// 32-row tile, 8 waves, one 32-column tile per wave (the node kernel): A planes [32][SAH] halves (lo plane at + plane_h), B planes
+// from the pack_f16_split block (wave w of 8 = column tile w & 1 of wave w >> 1 of 4).  17 k-steps of three MFMAs; the B fragments of
+// four steps are in flight ahead of the MFMAs, the A fragments of one.
+__device__ __forceinline__ void gemm_rows32_h8(const _Float16 *__restrict__ Ah, int plane_h, const void *__restrict__ wh, f32x16 &acc,
+                                               int wave, int lane) {
+    const _Float16 *ap = Ah + (lane & 31) * SAH + 8 * (lane >> 5);
+    const gf32x4 *bp = as_global(reinterpret_cast<const f32x4 *>(wh)) + ((wave >> 1) * 64 + lane) * 4 + (wave & 1) * 2;
+    f32x4 bh[4], bl[4], ah[2], al[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        bh[i] = bp[i * 1024];
+        bl[i] = bp[i * 1024 + 1];
+    }
+    ah[0] = *reinterpret_cast<const f32x4 *>(ap);
+    al[0] = *reinterpret_cast<const f32x4 *>(ap + plane_h);
+#pragma unroll
+    for (int s = 0; s < KH_STEPS; ++s) {
+        if (s + 1 < KH_STEPS) {
+            ah[(s + 1) & 1] = *reinterpret_cast<const f32x4 *>(ap + 16 * (s + 1));
+            al[(s + 1) & 1] = *reinterpret_cast<const f32x4 *>(ap + plane_h + 16 * (s + 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(al[s & 1]), as_h8(bh[s & 3]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(ah[s & 1]), as_h8(bl[s & 3]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(ah[s & 1]), as_h8(bh[s & 3]), acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 4 < KH_STEPS) {
+            bh[s & 3] = bp[(s + 4) * 1024];
+            bl[s & 3] = bp[(s + 4) * 1024 + 1];
+        }
+    }
+}
+
+// dot of row (tid / TPR) of an f16-plane tile (planes carry H_SCALE_A) with an fp32 vector w[0 .. KP): TPR threads per row, eight
+// columns per chunk; returns H_SCALE_A x the dot on all TPR lanes
+template <int TPR>
+__device__ __forceinline__ float row_dot_planes(const _Float16 *__restrict__ Ah, int plane_h, const float *__restrict__ w, int tid) {
+    const int row = tid / TPR, q = tid % TPR;
+    const _Float16 *ahi = Ah + row * SAH, *alo = ahi + plane_h;
+    float s = 0.0f;
+#pragma unroll
+    for (int c = q; c < KP / 8; c += TPR) {
+        const h8 hi = *reinterpret_cast<const h8 *>(ahi + 8 * c), lo = *reinterpret_cast<const h8 *>(alo + 8 * c);
+        const f32x4 w0 = *reinterpret_cast<const f32x4 *>(w + 8 * c), w1 = *reinterpret_cast<const f32x4 *>(w + 8 * c + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s = fmaf((float)hi[j] + (float)lo[j], w0[j], s);
+            s = fmaf((float)hi[4 + j] + (float)lo[4 + j], w1[j], s);
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < TPR; o <<= 1) s += __shfl_xor(s, o);
+    return s;
+}
+
 // 2^6 SiLU in the pre-scaled form of silu_pre: the factor rides in the reciprocal's argument (an fma instead of the add)
 __device__ __forceinline__ float silu_pre_x64(float xs) {
     return xs * __builtin_amdgcn_rcpf(fmaf(__builtin_amdgcn_exp2f(xs), 1.0f / H_SCALE_A, 1.0f / H_SCALE_A));
