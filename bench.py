@@ -42,8 +42,8 @@ PEAK_HBM_GBS = 8000.0
 # What back-to-back fp32 MFMAs deliver on all CUs of this part at once (profiles/tools/gemm_loop_probe.hip, profiles/r02_gemm_loop_probe.txt:
 # 64.1 cycles per v_mfma_f32_32x32x2_f32 -- a full pipe -- at the ~2.0 GHz the chip holds under that load).  Context for `frac`, not the peak.
 SUSTAINED_F32_MFMA_TFLOPS = 132.0
-# f16x2 mode (opt-in, --gemm f16x2 / KPD_GEMM=f16x2): every fp32 product of the edge kernel's GEMMs is three f16 MFMA products of hi / lo
-# operand planes with fp32 accumulation, so the bound for USEFUL flops is the dense f16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PFLOP/s) / 3
+# f16x2 mode (opt-in, --gemm f16x2 / KPD_GEMM=f16x2): every fp32 product of the EGNN GEMMs (edge, projection and node-update kernels) is
+# three f16 MFMA products of hi / lo operand planes with fp32 accumulation, so the bound for USEFUL flops is the dense f16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PFLOP/s) / 3
 PEAK_F16_MATRIX_TFLOPS = 2500.0
 # FLOPs the fused EGNN edge kernel executes per edge per layer: the two 257x257 second Linears of edge_mlp /
 # coord_mlp plus the attention and coordinate heads (the first Linears run per NODE, k_proj_ws)
@@ -312,7 +312,7 @@ def run_sampling(args, workload, device, rank, world, dist, B, n_rec, n_lig, rag
     g = build_batch(model, B, n_rec, n_lig, seed=1234 + rank * B, device=device, workload=workload)
     bidx = G.get_batch_idxs(g)
     if gemm != 'f32' and w['arch'] != 'egnn':
-        raise SystemExit('--gemm f16x2 exists for the EGNN edge kernel only')
+        raise SystemExit('--gemm f16x2 exists for the EGNN denoiser only')
     os.environ['KPD_GEMM'] = gemm                      # read by kpd_egnn_create: the engine below is built in this mode
     eng = model.dynamics.engine()
     os.environ.pop('KPD_GEMM')
@@ -382,8 +382,8 @@ def run_sampling(args, workload, device, rank, world, dist, B, n_rec, n_lig, rag
         'metric': 'denoising steps/sec', 'value': steps_per_s, 'unit': 'steps/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * med / args.steps,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32' if gemm == 'f32' else 'f32 via f16x2 split in the edge-kernel GEMMs (3 f16 MFMA products of hi/lo planes per fp32 '
-                                             'product, f32 accumulate; everything else f32)',
+        'dtype': 'f32' if gemm == 'f32' else 'f32 via f16x2 split in the EGNN GEMMs (edge, projection, node update): 3 f16 MFMA products of '
+                                             'hi/lo planes per fp32 product, f32 accumulate; everything else f32',
         'data': 'synthetic',
         'config': {'workload': f'{desc[workload]}, batch of {B} synthetic {shape[0]}-atom pockets / {shape[1]}-atom ligands per GPU, '
                                f'T={T}, seeded random-init weights, every step taken from the t=T ligand state',
@@ -499,7 +499,7 @@ def main():
     ap.add_argument('--workload', default='egnn_all_atom', choices=list(WORKLOADS),
                     help='egnn_all_atom = BASELINE.json configs[1] (the contract line); the others are secondary')
     ap.add_argument('--gemm', default='f32', choices=['f32', 'f16x2'],
-                    help='f32 = exact fp32 MFMA everywhere (the contract line); f16x2 = opt-in split-f16 products in the EGNN edge kernel')
+                    help='f32 = exact fp32 MFMA everywhere (the contract line); f16x2 = opt-in split-f16 products in the EGNN GEMMs')
     ap.add_argument('--graph', action='store_true', help='replay the reverse step as a captured HIP graph (StepGraph)')
     ap.add_argument('--ragged', action='store_true', help='pockets 150-600 atoms, ligands 15-35 atoms (configs[4] shape)')
     args = ap.parse_args()

@@ -76,7 +76,8 @@ struct kpd_egnn {
     std::set<std::string> expected, loaded;
     bool committed = false;
     int debug_layers = -1;
-    int gemm_mode = 0;                         // 0 exact fp32 MFMA; 1 f16x2 split products in the edge kernel (KPD_GEMM=f16x2, "gemm=f16x2")
+    int gemm_mode = 0;                         // 0 exact fp32 MFMA; 1 f16x2 split products in the EGNN GEMMs (KPD_GEMM=f16x2, "gemm=f16x2")
+    int h_parts = 7;                           // diagnostics: which kernels take the f16x2 form (1 edge, 2 projections, 4 node update)
     int tile_rows = TM;                        // edges per tile of the edge kernel (64, or 32: k_egnn_edge32, four workgroups per CU)
     int prune_last = 1;                        // final layer: only what feeds (h_lig, x_lig) is computed ("prune=0" restores all)
     int edge_chain = -1;                       // 1: register-chained edge kernel (egnn_chain.hip); -1: KPD_EDGE_CHAIN or staged
@@ -191,6 +192,7 @@ extern "C" kpd_status kpd_egnn_create(const kpd_egnn_config *cfg, kpd_egnn **out
     m->cfg = *cfg;
     if (const char *e = getenv("KPD_EDGE_ROWS")) m->tile_rows = atoi(e) == 32 ? 32 : TM;
     if (const char *e = getenv("KPD_GEMM")) m->gemm_mode = !strcmp(e, "f16x2") ? 1 : 0;
+    if (const char *e = getenv("KPD_H_PARTS")) m->h_parts = atoi(e);
     m->n_et = cfg->update_kp_feat ? 4 : 2;
     m->n_upd = cfg->update_kp_feat ? 2 : 1;
     m->rec_identity = cfg->rec_nf == cfg->hidden_nf;   // dynamics.py:326-334
@@ -578,7 +580,7 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
                     pp.n_slots[nt] = k;
                 }
                 pp.tiles0 = cdiv(n[0], TM);
-                pp.gemm_mode = m->gemm_mode;
+                pp.gemm_mode = (m->h_parts & 2) ? m->gemm_mode : 0;
                 KPD_TRY(launch_proj_chain(pp, st));
             }
         }
@@ -590,7 +592,7 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
         ea.use_tanh = c.use_tanh; ea.coords_range = c.coords_range;
         ea.stamps = m->stamps;
         ea.tile_rows = tr;
-        ea.gemm_mode = (tr == TM && !use_chain) ? m->gemm_mode : 0;
+        ea.gemm_mode = (tr == TM && !use_chain && (m->h_parts & 1)) ? m->gemm_mode : 0;
         for (int et = 0; et < 4; ++et) {
             ea.src[et] = esrc[et]; ea.dst[et] = edst[et];
             ea.src_nt[et] = kSrcNt[et]; ea.dst_nt[et] = kDstNt[et]; ea.src_slot[et] = kSrcSlot[et]; ea.dst_slot[et] = kDstSlot[et];
@@ -644,7 +646,7 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
             }
             lp.tiles0 = cdiv(lp.nt[0].u.n, TN);
             lp.stamps = m->stamps ? m->stamps + 16 : nullptr;
-            lp.gemm_mode = m->gemm_mode;
+            lp.gemm_mode = (m->h_parts & 4) ? m->gemm_mode : 0;
             KPD_TRY(launch_node_layer(lp, st));
         }
     }
@@ -664,6 +666,11 @@ extern "C" kpd_status kpd_egnn_debug_state(kpd_egnn *m, const char *what, float 
     else if (w == "x_kp") src = m->x[1];
     else if (w == "z_lig") src = m->z[0];
     else if (w == "z_kp") src = m->z[1];
+    else if (w.size() == 4 && (w.rfind("xnm", 0) == 0 || w.rfind("xnc", 0) == 0 || w.rfind("hnm", 0) == 0 || w.rfind("hnc", 0) == 0) &&
+             w[3] >= '0' && w[3] < '4') {          // segment-sum pieces of edge type w[3] as the last layer left them
+        const int et = w[3] - '0';
+        src = w[0] == 'x' ? (w[2] == 'm' ? m->xn_main[et] : m->xn_cont[et]) : (w[2] == 'm' ? m->hn_main[et] : m->hn_cont[et]);
+    }
     else if (w.rfind("layers=", 0) == 0) {
         m->debug_layers = atoi(w.c_str() + 7);
         return KPD_OK;

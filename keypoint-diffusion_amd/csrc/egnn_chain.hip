@@ -585,18 +585,19 @@ __global__ __launch_bounds__(512, 1) void k_proj_ws_h(ProjWs qa) {
             acc[m] = (1.0f / H_UNSCALE) * (h256 * *reinterpret_cast<const v4f *>(s_wcol + 16 * m + 4 * q) + *reinterpret_cast<const v4f *>(s_bias + 16 * m + 4 * q));
         // 32 batches of two output tiles x three products; LDS reads of batch b + 1 pinned ahead of the 6 MFMAs of batch b
         const f32x4 *wp = W + lane;
-        f32x4 w[2][4];                                        // [buffer][m0 hi, m0 lo, m1 hi, m1 lo]
+        f32x4 w[3][4];                                        // [buffer][m0 hi, m0 lo, m1 hi, m1 lo]: refilled one batch after its
+                                                              // readers were issued, never right behind them (mfma_core.h, gemm_rows64_h)
 #pragma unroll
         for (int i = 0; i < 4; ++i) w[0][i] = wp[i * 64];
 #pragma unroll
         for (int b = 0; b < 32; ++b) {
             if (b + 1 < 32) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) w[(b + 1) & 1][i] = wp[(4 * (b + 1) + i) * 64];
+                for (int i = 0; i < 4; ++i) w[(b + 1) % 3][i] = wp[(4 * (b + 1) + i) * 64];
             }
             __builtin_amdgcn_sched_barrier(0);
             const int kb = b >> 2, m0 = 2 * (b & 3);
-            const f32x4 *wb = w[b & 1];
+            const f32x4 *wb = w[b % 3];
             acc[m0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(wb[1]), as_h8(xh[kb]), acc[m0], 0, 0, 0);
             acc[m0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(wb[3]), as_h8(xh[kb]), acc[m0 + 1], 0, 0, 0);
             acc[m0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(wb[0]), as_h8(xl[kb]), acc[m0], 0, 0, 0);

@@ -513,15 +513,30 @@ __device__ __forceinline__ EdgeSmem edge_smem_h(float *smem) {
 }
 
 // A[r][:] = SiLU(Ps[src_r] + Pd[dst_r] + d_r w_r) as f16 hi / lo planes; columns 264..271 (K padding of the 16-wide k-steps) zero
-__device__ __forceinline__ void edge_gather_finish_h(const EdgeGather<4> &g, const EdgeSmem &s, _Float16 *Ah, const float *__restrict__ wr,
+// BATCH_D: read the wave's RPW distances with RPW / 4 broadcast ds_read_b128 up front instead of one ds_read_b32 (and an LDS round trip)
+// per row.  OFF in production: with the batched read at both call sites of k_egnn_edge_h (0.394 instead of 0.402 ms) the FIRST forward
+// of a process differed from all later ones in a few x pieces (first segments of ll / kl tiles, ~1 % of the piece) -- at either site
+// alone, or with the per-row reads, it does not (profiles/tools/repro_layer.py, repro_pieces.py; six fresh processes each).  The
+// batched form is semantically identical, so the cause is a timing-dependent hazard that was not found; the arrangement that has
+// never shown it is the one that ships.
+#ifndef KPD_H_BATCH_D
+#define KPD_H_BATCH_D false
+#endif
+template <int NW, bool BATCH_D>
+__device__ __forceinline__ void edge_gather_finish_h(const EdgeGather<NW> &g, const EdgeSmem &s, _Float16 *Ah, const float *__restrict__ wr,
                                                      int wave, int lane) {
-    constexpr int RPW = TM / 4;
+    constexpr int RPW = TM / NW;
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     const f32x4 w0 = reinterpret_cast<const f32x4 *>(wr)[lane];
+    // the wave's RPW distances in one batch of broadcast reads (a read + wait per row costs an LDS round trip each, and the per-row
+    // addresses were being kept live -- spilled -- across the GEMM)
+    f32x4 dv[RPW / 4];
+#pragma unroll
+    for (int i = 0; i < RPW / 4; ++i) dv[i] = BATCH_D ? *reinterpret_cast<const f32x4 *>(s.d + wave * RPW + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
         const int r = wave * RPW + rr;
-        f32x4 v = g.ps[rr] + g.pd[rr] + s.d[r] * w0;
+        f32x4 v = g.ps[rr] + g.pd[rr] + (BATCH_D ? dv[rr >> 2][rr & 3] : s.d[r]) * w0;
         v[0] = silu_pre_x64(v[0]); v[1] = silu_pre_x64(v[1]); v[2] = silu_pre_x64(v[2]); v[3] = silu_pre_x64(v[3]);
         unsigned h0, h1, l0, l1;
         split_pair(v[0], v[1], h0, l0);
@@ -529,7 +544,7 @@ __device__ __forceinline__ void edge_gather_finish_h(const EdgeGather<4> &g, con
         *reinterpret_cast<u32x2 *>(Ah + r * SAH + 4 * lane) = u32x2{h0, h1};
         *reinterpret_cast<u32x2 *>(Ah + PLANE_H + r * SAH + 4 * lane) = u32x2{l0, l1};
     }
-    {   // columns 256 .. 271 of the wave's rows: lane = row * 4 + chunk of four columns
+    if (lane < 4 * RPW) {   // columns 256 .. 271 of the wave's rows: lane = row * 4 + chunk of four columns
         const int r = wave * RPW + (lane >> 2), c = lane & 3;
         f32x4 u = {0.f, 0.f, 0.f, 0.f};
         if (c < 2) {
@@ -546,18 +561,20 @@ __device__ __forceinline__ void edge_gather_finish_h(const EdgeGather<4> &g, con
     }
 }
 
-__device__ __forceinline__ void unscale_acc(f32x16 (&acc)[2][2], float &ex) {
+template <int NT>
+__device__ __forceinline__ void unscale_acc(f32x16 (&acc)[2][NT], float &ex) {
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] *= H_UNSCALE;
     ex *= H_UNSCALE;
 }
 
-__global__ __launch_bounds__(256, 2) void k_egnn_edge_h(EdgeArgs a) {
-    constexpr int NW = 4, TPR = 4;
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge_h(EdgeArgs a) {
+    constexpr int TPR = NW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const EdgeSmem s = edge_smem_h(smem);
     _Float16 *Ah = reinterpret_cast<_Float16 *>(smem);                 // two f16 planes of the A tile; T (fp32) reuses the region
@@ -639,27 +656,28 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_h(EdgeArgs a) {
     // ---- feature messages: m = edge_mlp(f); msg_h = m * sigmoid(att(m)) (dynamics.py:111-112)
     constexpr int abl = 0;
     {
-        EdgeGather<4> ge;
-        edge_gather_issue<4>(ge, s, Ps, Pd, wave, lane);
-        edge_gather_finish_h(ge, s, Ah, a.wr_e[et], wave, lane);
+        EdgeGather<NW> ge;
+        edge_gather_issue<NW>(ge, s, Ps, Pd, wave, lane);
+        edge_gather_finish_h<NW, KPD_H_BATCH_D>(ge, s, Ah, a.wr_e[et], wave, lane);
     }
     lds_barrier();
     KPD_STAMP(1)
     acc_zero_w<NW>(acc);
-    ex = row_dot_h2(Ah, wxs, tid);
-    gemm_rows64_h(Ah, a.wh_e[et], acc, wave, lane);
+    ex = row_dot_h2<TPR>(Ah, wxs, tid);
+    if constexpr (NW == 4) gemm_rows64_h(Ah, a.wh_e[et], acc, wave, lane);
+    else gemm_rows64_h8(Ah, a.wh_e[et], acc, wave, lane);
     unscale_acc(acc, ex);
     lds_barrier();
     KPD_STAMP(2)
     if (!(abl & 4)) store_T_silu_w<NW, true>(s.A, acc, ex, a.b_e[et], tid, wave, lane);
     else if (acc[0][0][0] == 12345.0f) s.A[tid] = acc[1][NW == 4 ? 1 : 0][3] + acc[0][NW == 4 ? 1 : 0][5] + acc[1][0][7];
-    EdgeGather<NW == 4 ? 4 : TM> gc;      // (one row per wave, unused, in the 8-wave build)
-    if constexpr (NW == 4) {  // the coordinate branch's P rows start travelling now; consumed after the segmented sum below
-        if (!(abl & 2)) {
+    EdgeGather<NW> gc;
+#ifndef KPD_H_LATE_GC
+    {   // the coordinate branch's P rows start travelling now; consumed after the segmented sum below
         edge_gather_issue<NW>(gc, s, Ps + HS, Pd + HS, wave, lane);
         __builtin_amdgcn_sched_barrier(0);
-        }
     }
+#endif
     lds_barrier();
     KPD_STAMP(3)
     if (!(abl & 4)) {
@@ -724,12 +742,16 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_h(EdgeArgs a) {
     KPD_STAMP(5)
 
     // ---- coordinate messages: msg_x = tanh(coord_mlp(f)) * x_diff * range (dynamics.py:113-120)
-    edge_gather_finish_h(gc, s, Ah, a.wr_c[et], wave, lane);
+#ifdef KPD_H_LATE_GC
+    edge_gather_issue<NW>(gc, s, Ps + HS, Pd + HS, wave, lane);
+#endif
+    edge_gather_finish_h<NW, KPD_H_BATCH_D>(gc, s, Ah, a.wr_c[et], wave, lane);
     lds_barrier();
     KPD_STAMP(6)
     acc_zero_w<NW>(acc);
-    ex = row_dot_h2(Ah, wxs + 544, tid);
-    gemm_rows64_h(Ah, a.wh_c[et], acc, wave, lane);
+    ex = row_dot_h2<TPR>(Ah, wxs + 544, tid);
+    if constexpr (NW == 4) gemm_rows64_h(Ah, a.wh_c[et], acc, wave, lane);
+    else gemm_rows64_h8(Ah, a.wh_c[et], acc, wave, lane);
     unscale_acc(acc, ex);
     lds_barrier();
     KPD_STAMP(7)
@@ -1760,8 +1782,14 @@ kpd_status launch_egnn_edge(const EdgeArgs &a, int tile_cap, hipStream_t st) {
         KPD_REQUIRE(a.tile_rows == TM, KPD_ERR_INVALID, "the f16x2 edge kernel walks 64-edge tiles");
         for (int et = 0; et < 4; ++et)
             KPD_REQUIRE(!a.wp_e[et] || (a.wh_e[et] && a.wh_c[et]), KPD_ERR_STATE, "f16x2 weights of edge type %d were not packed", et);
-        KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_egnn_edge_h), EDGE_H_LDS_BYTES));
-        hipLaunchKernelGGL(k_egnn_edge_h, dim3(8 * cdiv(tile_cap, 8)), dim3(256), EDGE_H_LDS_BYTES, st, b);
+        static const int nwh = getenv("KPD_EDGE_H_NW") ? atoi(getenv("KPD_EDGE_H_NW")) : 4;
+        if (nwh == 8) {
+            KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_egnn_edge_h<8>), EDGE_H_LDS_BYTES + pad));
+            hipLaunchKernelGGL(k_egnn_edge_h<8>, dim3(8 * cdiv(tile_cap, 8)), dim3(512), EDGE_H_LDS_BYTES + pad, st, b);
+        } else {
+            KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_egnn_edge_h<4>), EDGE_H_LDS_BYTES + pad));
+            hipLaunchKernelGGL(k_egnn_edge_h<4>, dim3(8 * cdiv(tile_cap, 8)), dim3(256), EDGE_H_LDS_BYTES + pad, st, b);
+        }
         KPD_LAUNCH_CHECK();
         return KPD_OK;
     }

@@ -361,57 +361,121 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned &hi, unsig
     lo = __builtin_bit_cast(unsigned, l);
 }
 
-#define KPD_H_LOAD(S_, AH0, AH1, AL0, AL1, BH0, BL0, BH1, BL1)                              \
-    AH0 = *reinterpret_cast<const f32x4 *>(a0p + 16 * (S_));                                \
-    AH1 = *reinterpret_cast<const f32x4 *>(a1p + 16 * (S_));                                \
-    AL0 = *reinterpret_cast<const f32x4 *>(a0p + PLANE_H + 16 * (S_));                      \
-    AL1 = *reinterpret_cast<const f32x4 *>(a1p + PLANE_H + 16 * (S_));                      \
-    BH0 = bp[(S_) * 1024]; BL0 = bp[(S_) * 1024 + 1]; BH1 = bp[(S_) * 1024 + 2]; BL1 = bp[(S_) * 1024 + 3];
-
 #define KPD_H_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(A), as_h8(B), ACC, 0, 0, 0)
-// small terms first, the hi x hi product last
-#define KPD_H_STEP(AH0, AH1, AL0, AL1, BH0, BL0, BH1, BL1)                                  \
-    KPD_H_MFMA(acc[0][0], AL0, BH0); KPD_H_MFMA(acc[0][1], AL0, BH1);                       \
-    KPD_H_MFMA(acc[1][0], AL1, BH0); KPD_H_MFMA(acc[1][1], AL1, BH1);                       \
-    KPD_H_MFMA(acc[0][0], AH0, BL0); KPD_H_MFMA(acc[0][1], AH0, BL1);                       \
-    KPD_H_MFMA(acc[1][0], AH1, BL0); KPD_H_MFMA(acc[1][1], AH1, BL1);                       \
-    KPD_H_MFMA(acc[0][0], AH0, BH0); KPD_H_MFMA(acc[0][1], AH0, BH1);                       \
-    KPD_H_MFMA(acc[1][0], AH1, BH0); KPD_H_MFMA(acc[1][1], AH1, BH1);
 
-// acc[mt][nt] += A[64 x 272] W[272 x (this wave's 64 columns)], A = the two f16 planes at Ah, W = split block Wh
+// acc[mt][nt] += A[64 x 272] W[272 x (this wave's 64 columns)], A = the two f16 planes at Ah, W = split block Wh.
+// A k-step is only 12 MFMAs (384 cycles) -- a fraction of an L2 round trip -- so the weight fragments of H_B_DEPTH steps are kept in
+// flight (16 VGPRs each; with two steps the loop ran at one L2 latency per step, 20 k cycles for 6.5 k of MFMA); the A fragments come
+// from LDS one step ahead.  Small terms first, the hi x hi product last.
+#ifndef KPD_H_DEPTH
+#define KPD_H_DEPTH 6
+#endif
+constexpr int H_B_DEPTH = KPD_H_DEPTH;
+// rot (wave-uniform, 0 .. KH_STEPS - 1) rotates the order of the k-steps: workgroups that start together would otherwise walk the
+// same weight lines in step and queue on the same L2 channels.
 __device__ __forceinline__ void gemm_rows64_h(const _Float16 *__restrict__ Ah, const void *__restrict__ Wh, f32x16 (&acc)[2][2],
-                                              int wave, int lane) {
+                                              int wave, int lane, int rot = 0) {
     const int r = lane & 31, h = lane >> 5;
     const _Float16 *a0p = Ah + r * SAH + 8 * h;
     const _Float16 *a1p = Ah + (32 + r) * SAH + 8 * h;
-    gf32x4 *bp = as_global(reinterpret_cast<const f32x4 *>(Wh) + (wave * 64 + lane) * 4);      // 4 x 16 B per lane and k-step
-    f32x4 xah0, xah1, xal0, xal1, xbh0, xbl0, xbh1, xbl1, yah0, yah1, yal0, yal1, ybh0, ybl0, ybh1, ybl1;
-    KPD_H_LOAD(0, xah0, xah1, xal0, xal1, xbh0, xbl0, xbh1, xbl1)
-    KPD_H_LOAD(1, yah0, yah1, yal0, yal1, ybh0, ybl0, ybh1, ybl1)
-#pragma unroll 1
-    for (int p = 0; p < KH_STEPS / 2; ++p) {
-        const int s = 2 * p;
-        __builtin_amdgcn_sched_barrier(0);
-        KPD_H_STEP(xah0, xah1, xal0, xal1, xbh0, xbl0, xbh1, xbl1)
-        __builtin_amdgcn_sched_barrier(0);
-        const int s2 = s + 2 < KH_STEPS ? s + 2 : KH_STEPS - 1;
-        KPD_H_LOAD(s2, xah0, xah1, xal0, xal1, xbh0, xbl0, xbh1, xbl1)
-        __builtin_amdgcn_sched_barrier(0);
-        KPD_H_STEP(yah0, yah1, yal0, yal1, ybh0, ybl0, ybh1, ybl1)
-        __builtin_amdgcn_sched_barrier(0);
-        const int s3 = s + 3 < KH_STEPS ? s + 3 : KH_STEPS - 1;
-        KPD_H_LOAD(s3, yah0, yah1, yal0, yal1, ybh0, ybl0, ybh1, ybl1)
+    gf32x4 *bp = as_global(reinterpret_cast<const f32x4 *>(Wh) + wave * 256 + lane);           // 4 fragments of 1 KB per wave and k-step
+    f32x4 b[H_B_DEPTH][4];          // [.][hi nt0, lo nt0, hi nt1, lo nt1]
+    f32x4 a[3][4];                  // [.][hi mt0, hi mt1, lo mt0, lo mt1]
+    auto step_of = [&](int s) {     // s-th step of this workgroup's order
+#ifdef KPD_H_STATIC
+        return s;
+#else
+        const int t = s + rot;
+        return t >= KH_STEPS ? t - KH_STEPS : t;
+#endif
+    };
+    // No load is ever issued into registers that the MFMAs issued just before it read: a fragment buffer is refilled one whole step
+    // (12 MFMAs) after its last reader was issued.  (Refilled right behind its readers, results were not reproducible run to run
+    // -- a returning load can overtake MFMAs that are still queued; profiles/tools/repro_check.py.)
+#pragma unroll
+    for (int i = 0; i < H_B_DEPTH - 1; ++i) {
+        const int st = step_of(i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[i][j] = bp[st * 1024 + j * 64];
     }
-    if (KH_STEPS & 1) {
+    {
+        const int st = step_of(0);
+        a[0][0] = *reinterpret_cast<const f32x4 *>(a0p + 16 * st);
+        a[0][1] = *reinterpret_cast<const f32x4 *>(a1p + 16 * st);
+        a[0][2] = *reinterpret_cast<const f32x4 *>(a0p + PLANE_H + 16 * st);
+        a[0][3] = *reinterpret_cast<const f32x4 *>(a1p + PLANE_H + 16 * st);
+    }
+#pragma unroll
+    for (int s = 0; s < KH_STEPS; ++s) {
+        const int cb = s % H_B_DEPTH, ca = s % 3, can = (s + 1) % 3;
+        if (s + 1 < KH_STEPS) {         // buffer last read by step s - 2
+            const int st = step_of(s + 1);
+            a[can][0] = *reinterpret_cast<const f32x4 *>(a0p + 16 * st);
+            a[can][1] = *reinterpret_cast<const f32x4 *>(a1p + 16 * st);
+            a[can][2] = *reinterpret_cast<const f32x4 *>(a0p + PLANE_H + 16 * st);
+            a[can][3] = *reinterpret_cast<const f32x4 *>(a1p + PLANE_H + 16 * st);
+        }
+        if (s + H_B_DEPTH - 1 < KH_STEPS) {   // buffer last read by step s - 1
+            const int st = step_of(s + H_B_DEPTH - 1), nb = (s + H_B_DEPTH - 1) % H_B_DEPTH;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[nb][j] = bp[st * 1024 + j * 64];
+        }
         __builtin_amdgcn_sched_barrier(0);
-        KPD_H_STEP(xah0, xah1, xal0, xal1, xbh0, xbl0, xbh1, xbl1)
+        KPD_H_MFMA(acc[0][0], a[ca][2], b[cb][0]); KPD_H_MFMA(acc[0][1], a[ca][2], b[cb][2]);
+        KPD_H_MFMA(acc[1][0], a[ca][3], b[cb][0]); KPD_H_MFMA(acc[1][1], a[ca][3], b[cb][2]);
+        KPD_H_MFMA(acc[0][0], a[ca][0], b[cb][1]); KPD_H_MFMA(acc[0][1], a[ca][0], b[cb][3]);
+        KPD_H_MFMA(acc[1][0], a[ca][1], b[cb][1]); KPD_H_MFMA(acc[1][1], a[ca][1], b[cb][3]);
+        KPD_H_MFMA(acc[0][0], a[ca][0], b[cb][0]); KPD_H_MFMA(acc[0][1], a[ca][0], b[cb][2]);
+        KPD_H_MFMA(acc[1][0], a[ca][1], b[cb][0]); KPD_H_MFMA(acc[1][1], a[ca][1], b[cb][2]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// The same product with 8 waves per 64-row tile: wave w owns columns 32 w .. 32 w + 31 (column tile w & 1 of the block of wave
+// w >> 1 of 4), two row tiles, 6 MFMAs per k-step.
+__device__ __forceinline__ void gemm_rows64_h8(const _Float16 *__restrict__ Ah, const void *__restrict__ Wh, f32x16 (&acc)[2][1],
+                                               int wave, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+    const _Float16 *a0p = Ah + r * SAH + 8 * h;
+    const _Float16 *a1p = Ah + (32 + r) * SAH + 8 * h;
+    gf32x4 *bp = as_global(reinterpret_cast<const f32x4 *>(Wh) + (wave >> 1) * 256 + (wave & 1) * 128 + lane);
+    constexpr int DEPTH = 5;
+    f32x4 b[DEPTH][2];              // [.][hi, lo]
+    f32x4 a[3][4];                  // [.][hi mt0, hi mt1, lo mt0, lo mt1]
+#pragma unroll
+    for (int i = 0; i < DEPTH - 1; ++i) {
+        b[i][0] = bp[i * 1024];
+        b[i][1] = bp[i * 1024 + 64];
+    }
+    a[0][0] = *reinterpret_cast<const f32x4 *>(a0p);
+    a[0][1] = *reinterpret_cast<const f32x4 *>(a1p);
+    a[0][2] = *reinterpret_cast<const f32x4 *>(a0p + PLANE_H);
+    a[0][3] = *reinterpret_cast<const f32x4 *>(a1p + PLANE_H);
+#pragma unroll
+    for (int s = 0; s < KH_STEPS; ++s) {
+        const int cb = s % DEPTH, ca = s % 3, can = (s + 1) % 3;
+        if (s + 1 < KH_STEPS) {         // (refill discipline of gemm_rows64_h: never right behind the readers)
+            a[can][0] = *reinterpret_cast<const f32x4 *>(a0p + 16 * (s + 1));
+            a[can][1] = *reinterpret_cast<const f32x4 *>(a1p + 16 * (s + 1));
+            a[can][2] = *reinterpret_cast<const f32x4 *>(a0p + PLANE_H + 16 * (s + 1));
+            a[can][3] = *reinterpret_cast<const f32x4 *>(a1p + PLANE_H + 16 * (s + 1));
+        }
+        if (s + DEPTH - 1 < KH_STEPS) {
+            const int nb = (s + DEPTH - 1) % DEPTH;
+            b[nb][0] = bp[(s + DEPTH - 1) * 1024];
+            b[nb][1] = bp[(s + DEPTH - 1) * 1024 + 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        KPD_H_MFMA(acc[0][0], a[ca][2], b[cb][0]); KPD_H_MFMA(acc[1][0], a[ca][3], b[cb][0]);
+        KPD_H_MFMA(acc[0][0], a[ca][0], b[cb][1]); KPD_H_MFMA(acc[1][0], a[ca][1], b[cb][1]);
+        KPD_H_MFMA(acc[0][0], a[ca][0], b[cb][0]); KPD_H_MFMA(acc[1][0], a[ca][1], b[cb][0]);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
 // output column 256 of the same product on the VALU: row (tid / 4) of the two A planes against w (fp32, 272 floats in LDS, already
-// carrying H_SCALE_W).  Every element is rebuilt exactly (hi + lo fits fp32) and multiplied in fp32.  (v_dot2_f32_f16 is NOT usable
-// here: measured on gfx950 it does not keep the products in fp32 -- a 1e-2 error on this column.)  Returns the dot on the 4 lanes of
-// the row.
+// carrying H_SCALE_W).  Every element is rebuilt exactly (hi + lo fits fp32) and multiplied in fp32: the reference form of
+// row_dot_h2 below (profiles/tools/f16x2_gemm_probe.hip compares the two).  Returns the dot on the 4 lanes of the row.
 __device__ __forceinline__ float row_dot_h(const _Float16 *__restrict__ Ah, const float *__restrict__ w, int tid) {
     const int row = tid >> 2, q = tid & 3;
     const _Float16 *ahi = Ah + row * SAH, *alo = Ah + PLANE_H + row * SAH;
@@ -437,14 +501,15 @@ __device__ __forceinline__ float row_dot_h(const _Float16 *__restrict__ Ah, cons
 // The same dot with packed f16 dot products: w as two f16 planes of 272 (hi, then lo at + 272, both carrying H_SCALE_W), three
 // v_dot2_f32_f16 per pair of elements (a_lo w_hi + a_hi w_lo + a_hi w_hi, fp32 accumulation) -- 1.5 instead of 4 VALU
 // instructions per element.
+template <int TPR>
 __device__ __forceinline__ float row_dot_h2(const _Float16 *__restrict__ Ah, const _Float16 *__restrict__ wh, int tid) {
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    const int row = tid >> 2, q = tid & 3;
+    const int row = tid / TPR, q = tid % TPR;
     const _Float16 *ahi = Ah + row * SAH, *alo = Ah + PLANE_H + row * SAH;
     float s = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        const int c = q + 4 * i;
+    for (int i = 0; i < (34 + TPR - 1) / TPR; ++i) {
+        const int c = q + TPR * i;
         if (c < 34) {
             const h8 ah = *reinterpret_cast<const h8 *>(ahi + 8 * c), al = *reinterpret_cast<const h8 *>(alo + 8 * c);
             const h8 wa = *reinterpret_cast<const h8 *>(wh + 8 * c), wl = *reinterpret_cast<const h8 *>(wh + 272 + 8 * c);
@@ -458,41 +523,41 @@ __device__ __forceinline__ float row_dot_h2(const _Float16 *__restrict__ Ah, con
             }
         }
     }
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
+#pragma unroll
+    for (int o = 1; o < TPR; o <<= 1) s += __shfl_xor(s, o);
     return s;
 }
 
 // 32-row tile, 8 waves, one 32-column tile per wave (the node kernel): A planes [32][SAH] halves (lo plane at + plane_h), B planes
 // from the pack_f16_split block (wave w of 8 = column tile w & 1 of wave w >> 1 of 4).  17 k-steps of three MFMAs; the B fragments of
-// four steps are in flight ahead of the MFMAs, the A fragments of one.
+// three steps are in flight ahead of the MFMAs, the A fragments of one.
 __device__ __forceinline__ void gemm_rows32_h8(const _Float16 *__restrict__ Ah, int plane_h, const void *__restrict__ wh, f32x16 &acc,
                                                int wave, int lane) {
     const _Float16 *ap = Ah + (lane & 31) * SAH + 8 * (lane >> 5);
-    const gf32x4 *bp = as_global(reinterpret_cast<const f32x4 *>(wh)) + ((wave >> 1) * 64 + lane) * 4 + (wave & 1) * 2;
-    f32x4 bh[4], bl[4], ah[2], al[2];
+    const gf32x4 *bp = as_global(reinterpret_cast<const f32x4 *>(wh)) + (wave >> 1) * 256 + (wave & 1) * 128 + lane;
+    f32x4 bh[4], bl[4], ah[3], al[3];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 3; ++i) {
         bh[i] = bp[i * 1024];
-        bl[i] = bp[i * 1024 + 1];
+        bl[i] = bp[i * 1024 + 64];
     }
     ah[0] = *reinterpret_cast<const f32x4 *>(ap);
     al[0] = *reinterpret_cast<const f32x4 *>(ap + plane_h);
 #pragma unroll
     for (int s = 0; s < KH_STEPS; ++s) {
-        if (s + 1 < KH_STEPS) {
-            ah[(s + 1) & 1] = *reinterpret_cast<const f32x4 *>(ap + 16 * (s + 1));
-            al[(s + 1) & 1] = *reinterpret_cast<const f32x4 *>(ap + plane_h + 16 * (s + 1));
+        if (s + 1 < KH_STEPS) {         // (refill discipline of gemm_rows64_h: never right behind the readers)
+            ah[(s + 1) % 3] = *reinterpret_cast<const f32x4 *>(ap + 16 * (s + 1));
+            al[(s + 1) % 3] = *reinterpret_cast<const f32x4 *>(ap + plane_h + 16 * (s + 1));
+        }
+        if (s + 3 < KH_STEPS) {
+            bh[(s + 3) & 3] = bp[(s + 3) * 1024];
+            bl[(s + 3) & 3] = bp[(s + 3) * 1024 + 64];
         }
         __builtin_amdgcn_sched_barrier(0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(al[s & 1]), as_h8(bh[s & 3]), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(ah[s & 1]), as_h8(bl[s & 3]), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(ah[s & 1]), as_h8(bh[s & 3]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(al[s % 3]), as_h8(bh[s & 3]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(ah[s % 3]), as_h8(bl[s & 3]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(ah[s % 3]), as_h8(bh[s & 3]), acc, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 4 < KH_STEPS) {
-            bh[s & 3] = bp[(s + 4) * 1024];
-            bl[s & 3] = bp[(s + 4) * 1024 + 1];
-        }
     }
 }
 

@@ -100,8 +100,9 @@ kpd_status pack_gemm_weight(const float *src, int n_out, int ld, int col0, int K
 
 // f16x2 mode (mfma_core.h, gemm_rows64_h): re-pack a finished fp32 block (all scalings and the bias row already in it) into two
 // f16 planes, w ~ hi + lo, in the B-fragment order of v_mfma_f32_32x32x16_f16:
-//   Wh[(((s * 4 + wave) * 64 + lane) * 2 + nt) * 2 + plane][i] = plane(W[n = 64 wave + 32 nt + (lane & 31)][k = 16 s + 8 (lane >> 5) + i])
-// for s < KH_STEPS k-steps of 16 (K = 264 padded to 272 with zeros), i < 8.  One thread per (s, wave, lane, nt, i).
+//   Wh[(((s * 4 + wave) * 2 + nt) * 2 + plane) * 64 + lane][i] = plane(W[n = 64 wave + 32 nt + (lane & 31)][k = 16 s + 8 (lane >> 5) + i])
+// for s < KH_STEPS k-steps of 16 (K = 264 padded to 272 with zeros), i < 8: every fragment load of a wave (one dwordx4 per lane)
+// covers 1 KB of contiguous memory.  One thread per (s, wave, lane, nt, i).
 constexpr float H_SCALE_W_PACK = 1024.0f;       // = H_SCALE_W of mfma_core.h: keeps the lo plane out of the f16 subnormal range
 __global__ void k_pack_f16_split(const float *__restrict__ wp, __fp16 *__restrict__ wh, int total) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -115,9 +116,9 @@ __global__ void k_pack_f16_split(const float *__restrict__ wp, __fp16 *__restric
     }
     const __fp16 hi = (__fp16)w;                       // round to nearest: |w - hi| <= 2^-11 |w|
     const __fp16 lo = (__fp16)(w - (float)hi);         // and the remainder again: |w - hi - lo| <= 2^-22 |w| (f16 normal range)
-    const size_t base = ((((size_t)(s * 4 + wave) * 64 + lane) * 2 + nt) * 2) * 8;
+    const size_t base = ((((size_t)(s * 4 + wave) * 2 + nt) * 2) * 64 + lane) * 8;
     wh[base + i] = hi;
-    wh[base + 8 + i] = lo;
+    wh[base + 64 * 8 + i] = lo;
 }
 
 kpd_status pack_f16_split(const float *wp, void *wh, hipStream_t st) {

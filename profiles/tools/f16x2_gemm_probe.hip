@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void k_probe(const float *A, const float *Wp, 
             wxh[272 + i] = (_Float16)(w - (float)hi);
         }
         __syncthreads();
-        const float e2 = row_dot_h2(Ah, wxh, tid);
+        const float e2 = row_dot_h2<4>(Ah, wxh, tid);
         if ((tid & 3) == 0) outx[128 + (tid >> 2)] = e2 * H_UNSCALE;
     }
     {   // the same dot element by element
@@ -62,6 +62,94 @@ __global__ __launch_bounds__(256) void k_probe(const float *A, const float *Wp, 
     gemm_rows64_h(Ah, Wh, acc, wave, lane);
     for (int mt = 0; mt < 2; ++mt) for (int nt = 0; nt < 2; ++nt) for (int r = 0; r < 16; ++r)
         outh[acc_row(mt, r, lane) * 256 + acc_col(nt, wave, lane)] = acc[mt][nt][r] * H_UNSCALE;
+}
+
+
+// Timing form: every workgroup repeats the tile GEMM `iters` times on planes it builds once; cycles by s_memtime on wave 0.
+__global__ __launch_bounds__(256, 2) void k_time(const void *Wh, int iters, int mode, unsigned long long *cyc, float *sink) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    _Float16 *Ah = reinterpret_cast<_Float16 *>(smem);
+    for (int i = tid; i < 2 * PLANE_H; i += 256) Ah[i] = (_Float16)(0.001f * (float)((i * 7 + blockIdx.x) & 255));
+    __syncthreads();
+    f32x16 acc[2][2];
+    acc_zero(acc);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        gemm_rows64_h(Ah, Wh, acc, wave, lane, (mode & 2) ? (int)((blockIdx.x * 5u + it) % KH_STEPS) : 0);
+        if (mode & 1) __syncthreads();
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (tid == 0) cyc[blockIdx.x] = t1 - t0;
+    float v = 0.f;
+    for (int m = 0; m < 2; ++m) for (int n = 0; n < 2; ++n) for (int r = 0; r < 16; ++r) v += acc[m][n][r];
+    if (v == 12345.678f) sink[tid] = v;
+}
+
+static void time_gemm(const void *dWh, int blocks, int lds, int iters, int mode, const char *what) {
+    unsigned long long *cyc; float *sink;
+    hipMalloc(&cyc, blocks * 8); hipMalloc(&sink, 1024);
+    hipFuncSetAttribute((const void *)k_time, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_time, dim3(blocks), dim3(256), lds, 0, dWh, 2, mode, cyc, sink);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k_time, dim3(blocks), dim3(256), lds, 0, dWh, iters, mode, cyc, sink);
+    hipEventRecord(e1);
+    hipDeviceSynchronize();
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> h(blocks);
+    hipMemcpy(h.data(), cyc, blocks * 8, hipMemcpyDeviceToHost);
+    double sum = 0; for (auto c : h) sum += (double)c;
+    const double per_gemm = sum / blocks / iters;
+    const double mfma = 17.0 * 12.0;
+    printf("%-44s %4d blocks: %8.0f ticks per tile GEMM (%5.1f per MFMA; floor 32)   kernel %.3f ms -> %.0f useful TFLOP/s\n", what, blocks,
+           per_gemm, per_gemm / mfma, ms, (double)blocks * iters * 2.0 * 64 * 264 * 256 / (ms * 1e-3) / 1e12);
+    hipFree(cyc); hipFree(sink);
+}
+
+// Two tiles per workgroup: waves 0-3 and 4-7 run the same tile GEMM on their own A planes and the SAME weight fragments, in step
+// (workgroup barriers) -- does the second reader of a weight line hit in the CU's L1?
+__global__ __launch_bounds__(512, 2) void k_time2(const void *Wh, int iters, int mode, unsigned long long *cyc, float *sink) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = wave >> 2;
+    _Float16 *Ah = reinterpret_cast<_Float16 *>(smem) + half * 2 * PLANE_H;
+    for (int i = tid & 255; i < 2 * PLANE_H; i += 256) Ah[i] = (_Float16)(0.001f * (float)((i * 7 + blockIdx.x + half) & 255));
+    __syncthreads();
+    f32x16 acc[2][2];
+    acc_zero(acc);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        gemm_rows64_h(Ah, Wh, acc, wave & 3, lane);
+        if (mode == 1) __syncthreads();
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (tid == 0) cyc[blockIdx.x] = t1 - t0;
+    float v = 0.f;
+    for (int m = 0; m < 2; ++m) for (int n = 0; n < 2; ++n) for (int r = 0; r < 16; ++r) v += acc[m][n][r];
+    if (v == 12345.678f) sink[tid] = v;
+}
+
+static void time_gemm2(const void *dWh, int iters, int mode, const char *what) {
+    const int blocks = 256;
+    unsigned long long *cyc; float *sink;
+    hipMalloc(&cyc, blocks * 8); hipMalloc(&sink, 4096);
+    hipFuncSetAttribute((const void *)k_time2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_time2, dim3(blocks), dim3(512), 150 * 1024, 0, dWh, 2, mode, cyc, sink);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k_time2, dim3(blocks), dim3(512), 150 * 1024, 0, dWh, iters, mode, cyc, sink);
+    hipEventRecord(e1);
+    hipDeviceSynchronize();
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> h(blocks);
+    hipMemcpy(h.data(), cyc, blocks * 8, hipMemcpyDeviceToHost);
+    double sum = 0; for (auto c : h) sum += (double)c;
+    const double per_gemm = sum / blocks / iters;
+    printf("%-44s %4d blocks: %8.0f ticks per PAIR of tile GEMMs (%5.1f per MFMA and SIMD; floor 32)   kernel %.3f ms -> %.0f useful TFLOP/s\n", what,
+           blocks, per_gemm, per_gemm / (2 * 17.0 * 12.0), ms, 2.0 * blocks * iters * 2.0 * 64 * 264 * 256 / (ms * 1e-3) / 1e12);
+    hipFree(cyc); hipFree(sink);
 }
 
 int main() {
@@ -90,6 +178,13 @@ int main() {
         e32 = fmax(e32, fabs(r32[r * 256 + n] - ref));
         eh = fmax(eh, fabs(rh[r * 256 + n] - ref));
     }
+    time_gemm(dWh, 256, 150 * 1024, 200, 0, "one workgroup per CU (one wave per SIMD)");
+    time_gemm(dWh, 512, 75 * 1024, 200, 0, "two workgroups per CU (two waves per SIMD)");
+    time_gemm(dWh, 512, 75 * 1024, 200, 1, "two per CU, barrier after every GEMM");
+    time_gemm(dWh, 256, 150 * 1024, 200, 2, "one per CU, k-steps rotated per workgroup");
+    time_gemm(dWh, 512, 75 * 1024, 200, 2, "two per CU, k-steps rotated per workgroup");
+    time_gemm2(dWh, 200, 0, "tile pair per workgroup, free running");
+    time_gemm2(dWh, 200, 1, "tile pair per workgroup, barrier per GEMM");
     printf("max |ref| %.4f   fp32 MFMA max err %.3e (%.2e rel)   f16x2 max err %.3e (%.2e rel)\n", mx, e32, e32 / mx, eh, eh / mx);
     std::vector<float> rx(3 * TM);
     hipMemcpy(rx.data(), ox, 3 * TM * 4, hipMemcpyDeviceToHost);
