@@ -22,6 +22,7 @@ from .dynamics_gvp import LigRecDynamicsGVP
 from .receptor_encoder_fixed import FixedReceptorEncoder
 from .receptor_encoder import ReceptorEncoder
 from .receptor_encoder_gvp import ReceptorEncoderGVP
+from .rec_encoder_loss import ReceptorEncoderLoss
 
 
 class LigandSizeDistribution:
@@ -162,16 +163,24 @@ class KeypointDiffusion(nn.Module):
         else:
             self.rec_encoder = FixedReceptorEncoder(
                 n_vec_feats=rec_encoder_config['vector_size'] if architecture == 'gvp' else None)
+        rec_encoder_loss_config = dict(rec_encoder_loss_config)
+        if rec_encoder_type == 'fixed':
+            rec_encoder_loss_config['loss_type'] = 'none'                                      # ligand_diffuser.py:85-87
+        self.rec_encoder_loss_fn = ReceptorEncoderLoss(**rec_encoder_loss_config)
 
     # ---- training entry point ----------------------------------------------------------
     def forward(self, complex_graphs, interface_points):
-        """Losses of one training batch (ligand_diffuser.py:89-175): {'l2', 'pos', 'feat', 'rec_encoder'}.  The noise
-        prediction is differentiated by the HIP backward passes (kpd_egnn_trainer_* / kpd_gvp_trainer_* under autograd);
-        implemented with the fixed receptor encoder (configs/dev_config.yml, trained_models/{egnn,gvp}_all_atom,
-        {egnn,gvp}_ca), where the encoder has no parameters and its loss is the constant 0 (:85-87)."""
-        if self.rec_encoder_type != 'fixed':
-            raise NotImplementedError('training is implemented with rec_encoder_type="fixed"; the learned receptor encoders train '
-                                      'through an optimal-transport loss (package `ot`, absent here) and have no backward pass yet')
+        """Losses of one batch (ligand_diffuser.py:89-175): {'l2', 'pos', 'feat', 'rec_encoder'}.
+
+        Fixed receptor encoder (configs/dev_config.yml, trained_models/{egnn,gvp}_all_atom, {egnn,gvp}_ca): trainable -- the
+        noise prediction is differentiated by the HIP backward passes (kpd_egnn_trainer_* / kpd_gvp_trainer_* under autograd),
+        the encoder has no parameters and its loss is the constant 0 (:85-87).
+        Learned receptor encoders ({egnn,gvp}_20kp / _40kp): EVALUATION only -- under `torch.no_grad()` (train.py's test_model)
+        all four losses are returned, the encoder loss being the optimal-transport distance of rec_encoder_loss.py; with
+        gradients enabled it raises, because the HIP encoders have no backward pass."""
+        if self.rec_encoder_type != 'fixed' and torch.is_grad_enabled():
+            raise NotImplementedError('the learned receptor encoders have no backward pass: training is implemented with '
+                                      'rec_encoder_type="fixed"; under torch.no_grad() this forward evaluates all four losses')
         if self.rl_dist_threshold > 0:
             raise NotImplementedError('the receptor-ligand hinge loss (rl_dist_threshold > 0) is unused by every shipped config')
         losses = {}
@@ -179,8 +188,9 @@ class KeypointDiffusion(nn.Module):
         batch_size, device = g.batch_size, g.device
         batch_idxs = G.get_batch_idxs(g)
         g = self.rec_encoder(g, batch_idxs)
-        batch_idxs = G.get_batch_idxs(g)                      # :106-107: keypoints = receptor atoms now
-        losses['rec_encoder'] = torch.tensor(0.0, device=device, dtype=g.nodes['rec'].data['x_0'].dtype)   # loss_type 'none'
+        if self.rec_encoder_type == 'fixed':
+            batch_idxs = G.get_batch_idxs(g)                  # :106-107: keypoints = receptor atoms now
+        losses['rec_encoder'] = self.rec_encoder_loss_fn(g, interface_points=interface_points)          # :115
         g = self.remove_com(g, batch_idxs['lig'], batch_idxs['kp'], com='ligand')
         t = torch.randint(0, self.n_timesteps, size=(batch_size,), device=device).float() / self.n_timesteps
         eps = {'h': torch.randn(g.nodes['lig'].data['h_0'].shape, device=device),

@@ -1,0 +1,75 @@
+"""Receptor-encoder loss (losses/rec_encoder_loss.py) on the CPU: closed-form cases, the assignment-problem oracle, the gradient
+through the cost matrix, constructor / loss-type behaviour of the reference."""
+import pytest
+import torch
+
+from keypoint_diffusion_amd import graph as G
+from keypoint_diffusion_amd import synth
+from keypoint_diffusion_amd.rec_encoder_loss import ReceptorEncoderLoss, compute_ot_emd
+from oracle import rec_encoder_loss as oloss
+
+from . import util
+
+
+def _cost(a, b):
+    return torch.cdist(a, b).square()
+
+
+def test_identical_point_sets_cost_nothing():
+    x = torch.randn(7, 3, generator=torch.Generator().manual_seed(0))
+    d, plan = compute_ot_emd(_cost(x, x[torch.randperm(7, generator=torch.Generator().manual_seed(1))]))
+    assert float(d) < 1e-10
+    assert torch.allclose(plan.sum(1), torch.full((7,), 1 / 7), atol=1e-7) and torch.allclose(plan.sum(0), torch.full((7,), 1 / 7), atol=1e-7)
+
+
+def test_points_on_a_line_match_the_sorted_coupling():
+    """In one dimension with a convex cost the optimal plan is the monotone one: with n | m it sends keypoint i (sorted) to the
+    i-th block of m / n sorted targets."""
+    gen = torch.Generator().manual_seed(3)
+    a = torch.sort(torch.randn(4, generator=gen) * 3)[0]
+    b = torch.sort(torch.randn(12, generator=gen) * 3)[0]
+    want = sum(float((a[i] - b[3 * i + j]) ** 2) for i in range(4) for j in range(3)) / 12
+    A = torch.stack([a, torch.zeros(4), torch.zeros(4)], 1)
+    Bm = torch.stack([b, torch.zeros(12), torch.zeros(12)], 1)
+    got = float(compute_ot_emd(_cost(A, Bm))[0])
+    assert abs(got - want) < 1e-5 * max(1.0, want)
+
+
+@pytest.mark.parametrize('n,m,seed', [(4, 12, 0), (8, 40, 1), (20, 300, 2), (40, 280, 3), (8, 30, 4), (6, 22, 5)])
+def test_linear_program_equals_assignment_oracle(n, m, seed):
+    gen = torch.Generator().manual_seed(seed)
+    kp, rec = torch.randn(n, 3, generator=gen) * 4, torch.randn(m, 3, generator=gen) * 6
+    got = float(compute_ot_emd(_cost(kp, rec))[0])
+    want = oloss.ot_value_by_assignment(kp, rec)
+    assert abs(got - want) < 1e-5 * want, (got, want)
+
+
+def test_plan_is_constant_and_the_gradient_flows_through_the_cost():
+    gen = torch.Generator().manual_seed(5)
+    kp = (torch.randn(5, 3, generator=gen) * 2).requires_grad_(True)
+    rec = torch.randn(15, 3, generator=gen) * 3
+    d, plan = compute_ot_emd(_cost(kp, rec))
+    d.backward()
+    want = 2 * (plan[:, :, None] * (kp.detach()[:, None, :] - rec[None, :, :])).sum(1)
+    assert not plan.requires_grad and torch.allclose(kp.grad, want, atol=1e-5)
+
+
+def test_loss_module_types_and_batch_mean():
+    cut = util.CUTOFFS_ALL_ATOM
+    gs = synth.synth_complexes([24, 36], [5, 4], 6, cut, seed=2)
+    g = G.batch(gs)
+    g.nodes['kp'].data['x_0'] = torch.randn(g.num_nodes('kp'), 3, generator=torch.Generator().manual_seed(8)) * 5   # as an encoder would place them
+    gs = G.unbatch(g)
+    loss = ReceptorEncoderLoss()(g)
+    want = oloss.ot_loss([u.nodes['kp'].data['x_0'] for u in gs], [u.nodes['rec'].data['x_0'] for u in gs])
+    assert abs(float(loss) - want) < 1e-5 * want
+    pts = [torch.randn(12, 3), torch.randn(18, 3)]
+    loss_if = ReceptorEncoderLoss(use_interface_points=True)(g, interface_points=pts)
+    want_if = oloss.ot_loss([u.nodes['kp'].data['x_0'] for u in gs], pts)
+    assert abs(float(loss_if) - want_if) < 1e-5 * want_if
+    assert float(ReceptorEncoderLoss('none')(g)) == 0.0
+    with pytest.raises(ValueError):
+        ReceptorEncoderLoss('sinkhorn')
+    for t in ('gaussian_repulsion', 'hinge'):                # the reference raises for these too (rec_encoder_loss.py:86, :107)
+        with pytest.raises(NotImplementedError):
+            ReceptorEncoderLoss(t)(g)

@@ -106,7 +106,20 @@ def test_training_scope_contract(cuda):
                                                         use_sameres_feat=False, k_closest=3, kp_rad=0.0, norm=True, fix_pos=False,
                                                         n_kk_convs=0), precision=1e-5)
     with pytest.raises(NotImplementedError):
-        learned(g, None)
+        learned(g, None)                                      # gradients enabled: the HIP encoders have no backward pass
+    # evaluation (train.py's test_model runs the model under no_grad): all four losses, the encoder loss being the optimal-
+    # transport distance between the learned keypoints and the receptor atoms (losses/rec_encoder_loss.py:49-69)
+    from oracle import rec_encoder_loss as oloss
+    synth.fill_state_dict_(learned, 3)
+    learned = learned.to(cuda).eval()
+    g2 = G.batch(synth.synth_complexes([30, 22], [5, 7], 8, CUT, seed=12)).to(cuda)
+    with torch.no_grad():
+        enc = learned.encode_receptors(G.batch(synth.synth_complexes([30, 22], [5, 7], 8, CUT, seed=12)).to(cuda))
+        out = learned(g2, None)
+    assert set(out) == {'l2', 'pos', 'feat', 'rec_encoder'} and all(torch.isfinite(v).all() for v in out.values())
+    units = G.unbatch(enc)
+    want = oloss.ot_loss([u.nodes['kp'].data['x_0'].cpu() for u in units], [u.nodes['rec'].data['x_0'].cpu() for u in units])
+    assert want > 0 and abs(float(out['rec_encoder']) - want) < 1e-4 * want
 
 
 def test_complex_noise_is_sharding_invariant(cuda):
