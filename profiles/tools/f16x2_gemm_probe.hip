@@ -152,6 +152,91 @@ static void time_gemm2(const void *dWh, int iters, int mode, const char *what) {
     hipFree(cyc); hipFree(sink);
 }
 
+// Can VALU work ride in the gaps of this GEMM loop?  The production loop with FILL independent VALU instructions (half v_exp_f32,
+// half v_fma_f32, eight independent chains) behind every MFMA of the same wave.
+template <int FILL>
+__device__ __forceinline__ void gemm_fill(const _Float16 *__restrict__ Ah, const void *__restrict__ Wh, f32x16 (&acc)[2][2], int wave, int lane,
+                                          float (&f)[8]) {
+    const int r = lane & 31, h = lane >> 5;
+    const _Float16 *a0p = Ah + r * SAH + 8 * h;
+    const _Float16 *a1p = Ah + (32 + r) * SAH + 8 * h;
+    gf32x4 *bp = as_global(reinterpret_cast<const f32x4 *>(Wh) + wave * 256 + lane);
+    f32x4 b[H_B_DEPTH][4], a[3][4];
+#pragma unroll
+    for (int i = 0; i < H_B_DEPTH - 1; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[i][j] = bp[i * 1024 + j * 64];
+    a[0][0] = *reinterpret_cast<const f32x4 *>(a0p); a[0][1] = *reinterpret_cast<const f32x4 *>(a1p);
+    a[0][2] = *reinterpret_cast<const f32x4 *>(a0p + PLANE_H); a[0][3] = *reinterpret_cast<const f32x4 *>(a1p + PLANE_H);
+#define FILLER(I)                                                                   \
+    _Pragma("unroll") for (int q = 0; q < FILL; ++q) {                              \
+        const int c = ((I) * FILL + q) & 7;                                         \
+        if (q & 1) f[c] = __builtin_amdgcn_exp2f(f[c]);                             \
+        else f[c] = fmaf(f[c], 0.999f, 0.001f);                                     \
+    }
+#pragma unroll
+    for (int s = 0; s < KH_STEPS; ++s) {
+        const int cb = s % H_B_DEPTH, ca = s % 3, can = (s + 1) % 3;
+        if (s + 1 < KH_STEPS) {
+            a[can][0] = *reinterpret_cast<const f32x4 *>(a0p + 16 * (s + 1)); a[can][1] = *reinterpret_cast<const f32x4 *>(a1p + 16 * (s + 1));
+            a[can][2] = *reinterpret_cast<const f32x4 *>(a0p + PLANE_H + 16 * (s + 1)); a[can][3] = *reinterpret_cast<const f32x4 *>(a1p + PLANE_H + 16 * (s + 1));
+        }
+        if (s + H_B_DEPTH - 1 < KH_STEPS) {
+            const int nb = (s + H_B_DEPTH - 1) % H_B_DEPTH;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[nb][j] = bp[(s + H_B_DEPTH - 1) * 1024 + j * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        KPD_H_MFMA(acc[0][0], a[ca][2], b[cb][0]); FILLER(0) KPD_H_MFMA(acc[0][1], a[ca][2], b[cb][2]); FILLER(1)
+        KPD_H_MFMA(acc[1][0], a[ca][3], b[cb][0]); FILLER(2) KPD_H_MFMA(acc[1][1], a[ca][3], b[cb][2]); FILLER(3)
+        KPD_H_MFMA(acc[0][0], a[ca][0], b[cb][1]); FILLER(4) KPD_H_MFMA(acc[0][1], a[ca][0], b[cb][3]); FILLER(5)
+        KPD_H_MFMA(acc[1][0], a[ca][1], b[cb][1]); FILLER(6) KPD_H_MFMA(acc[1][1], a[ca][1], b[cb][3]); FILLER(7)
+        KPD_H_MFMA(acc[0][0], a[ca][0], b[cb][0]); FILLER(8) KPD_H_MFMA(acc[0][1], a[ca][0], b[cb][2]); FILLER(9)
+        KPD_H_MFMA(acc[1][0], a[ca][1], b[cb][0]); FILLER(10) KPD_H_MFMA(acc[1][1], a[ca][1], b[cb][2]); FILLER(11)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef FILLER
+}
+
+template <int FILL>
+__global__ __launch_bounds__(256, 1) void k_time_fill(const void *Wh, int iters, unsigned long long *cyc, float *sink) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    _Float16 *Ah = reinterpret_cast<_Float16 *>(smem);
+    for (int i = tid; i < 2 * PLANE_H; i += 256) Ah[i] = (_Float16)(0.001f * (float)((i * 7 + blockIdx.x) & 255));
+    __syncthreads();
+    f32x16 acc[2][2];
+    acc_zero(acc);
+    float f[8];
+    for (int i = 0; i < 8; ++i) f[i] = 0.01f * (float)(lane + i);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) gemm_fill<FILL>(Ah, Wh, acc, wave, lane, f);
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (tid == 0) cyc[blockIdx.x] = t1 - t0;
+    float v = 0.f;
+    for (int m = 0; m < 2; ++m) for (int n = 0; n < 2; ++n) for (int r = 0; r < 16; ++r) v += acc[m][n][r];
+    for (int i = 0; i < 8; ++i) v += f[i];
+    if (v == 12345.678f) sink[tid] = v;
+}
+
+template <int FILL>
+static void time_fill(const void *dWh) {
+    const int blocks = 256, iters = 200;
+    unsigned long long *cyc; float *sink;
+    hipMalloc(&cyc, blocks * 8); hipMalloc(&sink, 4096);
+    hipFuncSetAttribute((const void *)k_time_fill<FILL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(k_time_fill<FILL>, dim3(blocks), dim3(256), 150 * 1024, 0, dWh, 2, cyc, sink);
+    hipDeviceSynchronize();
+    hipLaunchKernelGGL(k_time_fill<FILL>, dim3(blocks), dim3(256), 150 * 1024, 0, dWh, iters, cyc, sink);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h(blocks);
+    hipMemcpy(h.data(), cyc, blocks * 8, hipMemcpyDeviceToHost);
+    double sum = 0; for (auto c : h) sum += (double)c;
+    const double per = sum / blocks / iters;
+    printf("one workgroup per CU, %2d VALU fillers per MFMA (%5d per tile GEMM): %8.0f ticks per tile GEMM (%5.1f per MFMA)\n", FILL, FILL * 204, per, per / 204.0);
+    hipFree(cyc); hipFree(sink);
+}
+
 int main() {
     std::vector<float> A(TM * KP), W(257 * KP);
     unsigned s = 12345;
@@ -183,6 +268,7 @@ int main() {
     time_gemm(dWh, 512, 75 * 1024, 200, 1, "two per CU, barrier after every GEMM");
     time_gemm(dWh, 256, 150 * 1024, 200, 2, "one per CU, k-steps rotated per workgroup");
     time_gemm(dWh, 512, 75 * 1024, 200, 2, "two per CU, k-steps rotated per workgroup");
+    time_fill<0>(dWh); time_fill<2>(dWh); time_fill<4>(dWh); time_fill<6>(dWh); time_fill<8>(dWh);
     time_gemm2(dWh, 200, 0, "tile pair per workgroup, free running");
     time_gemm2(dWh, 200, 1, "tile pair per workgroup, barrier per GEMM");
     printf("max |ref| %.4f   fp32 MFMA max err %.3e (%.2e rel)   f16x2 max err %.3e (%.2e rel)\n", mx, e32, e32 / mx, eh, eh / mx);
