@@ -672,12 +672,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge_h(EdgeAr
     if (!(abl & 4)) store_T_silu_w<NW, true>(s.A, acc, ex, a.b_e[et], tid, wave, lane);
     else if (acc[0][0][0] == 12345.0f) s.A[tid] = acc[1][NW == 4 ? 1 : 0][3] + acc[0][NW == 4 ? 1 : 0][5] + acc[1][0][7];
     EdgeGather<NW> gc;
-#ifndef KPD_H_LATE_GC
     {   // the coordinate branch's P rows start travelling now; consumed after the segmented sum below
         edge_gather_issue<NW>(gc, s, Ps + HS, Pd + HS, wave, lane);
         __builtin_amdgcn_sched_barrier(0);
     }
-#endif
     lds_barrier();
     KPD_STAMP(3)
     if (!(abl & 4)) {
@@ -742,9 +740,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge_h(EdgeAr
     KPD_STAMP(5)
 
     // ---- coordinate messages: msg_x = tanh(coord_mlp(f)) * x_diff * range (dynamics.py:113-120)
-#ifdef KPD_H_LATE_GC
-    edge_gather_issue<NW>(gc, s, Ps + HS, Pd + HS, wave, lane);
-#endif
     edge_gather_finish_h<NW, KPD_H_BATCH_D>(gc, s, Ah, a.wr_c[et], wave, lane);
     lds_barrier();
     KPD_STAMP(6)

@@ -367,10 +367,7 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned &hi, unsig
 // A k-step is only 12 MFMAs (384 cycles) -- a fraction of an L2 round trip -- so the weight fragments of H_B_DEPTH steps are kept in
 // flight (16 VGPRs each; with two steps the loop ran at one L2 latency per step, 20 k cycles for 6.5 k of MFMA); the A fragments come
 // from LDS one step ahead.  Small terms first, the hi x hi product last.
-#ifndef KPD_H_DEPTH
-#define KPD_H_DEPTH 6
-#endif
-constexpr int H_B_DEPTH = KPD_H_DEPTH;
+constexpr int H_B_DEPTH = 6;
 // rot (wave-uniform, 0 .. KH_STEPS - 1) rotates the order of the k-steps: workgroups that start together would otherwise walk the
 // same weight lines in step and queue on the same L2 channels.
 __device__ __forceinline__ void gemm_rows64_h(const _Float16 *__restrict__ Ah, const void *__restrict__ Wh, f32x16 (&acc)[2][2],
@@ -382,12 +379,8 @@ __device__ __forceinline__ void gemm_rows64_h(const _Float16 *__restrict__ Ah, c
     f32x4 b[H_B_DEPTH][4];          // [.][hi nt0, lo nt0, hi nt1, lo nt1]
     f32x4 a[3][4];                  // [.][hi mt0, hi mt1, lo mt0, lo mt1]
     auto step_of = [&](int s) {     // s-th step of this workgroup's order
-#ifdef KPD_H_STATIC
-        return s;
-#else
         const int t = s + rot;
         return t >= KH_STEPS ? t - KH_STEPS : t;
-#endif
     };
     // No load is ever issued into registers that the MFMAs issued just before it read: a fragment buffer is refilled one whole step
     // (12 MFMAs) after its last reader was issued.  (Refilled right behind its readers, results were not reproducible run to run
