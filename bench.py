@@ -417,13 +417,16 @@ def run_sampling(args, workload, device, rank, world, dist, B, n_rec, n_lig, rag
     return out
 
 
-def run_end_to_end(device, workload='egnn_all_atom', B=64, n_rec=300, n_lig=25):
+def run_end_to_end(device, workload='egnn_all_atom', B=64, n_rec=300, n_lig=25, gemm='f32'):
     """One full sampling run as test.py times it (reference test.py:149, 215-232): receptor encoding + T reverse steps of the
     whole batch + the copy of the sampled ligands to the host.  With random-init weights the chain does not denoise (the
     ligand spreads and the lig-lig graph thins out), so this is a functional wall-clock figure, not the steady-state rate."""
     import torch
     w = WORKLOADS[workload]
     model = build_model(device, workload)
+    os.environ['KPD_GEMM'] = gemm                      # read at engine creation (first forward of this model)
+    model.dynamics.engine()
+    os.environ.pop('KPD_GEMM')
     with torch.no_grad():
         for _ in range(2):          # first pass = warm-up (workspace reservation, first-use initialisation)
             g = raw_batch(B, n_rec, n_lig, 4321, device, workload)
@@ -436,7 +439,7 @@ def run_end_to_end(device, workload='egnn_all_atom', B=64, n_rec=300, n_lig=25):
     assert len(pos) == B and all(p.device.type == 'cpu' for p in pos)
     del model
     torch.cuda.empty_cache()
-    return {'workload': workload, 'ligands_per_min': 60.0 * B / dt, 'wall_s': dt, 'n_ligands': B, 'n_timesteps': w['T'],
+    return {'workload': workload, 'gemm': gemm, 'ligands_per_min': 60.0 * B / dt, 'wall_s': dt, 'n_ligands': B, 'n_timesteps': w['T'],
             'includes': 'receptor encoding + all reverse steps (per-step graph rebuild, fresh noise) + final frame shift + '
                         'device->host copy of the ligands; model build and synthetic-data generation excluded',
             'note': 'random-init weights do not denoise: the ligand spreads over the loop and the lig-lig graph thins, so late '
@@ -577,6 +580,7 @@ def main():
             if 'cpu_baseline' in out:
                 r['cpu_baseline'] = out['cpu_baseline']
                 r['gpu_over_cpu'] = r['value'] / out['cpu_baseline']['value']
+            r['end_to_end'] = run_end_to_end(device, gemm='f16x2')
             sec['egnn_all_atom_f16x2'] = r
             out['secondary'] = sec
             out['end_to_end'] = run_end_to_end(device)
