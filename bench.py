@@ -311,8 +311,6 @@ def run_sampling(args, workload, device, rank, world, dist, B, n_rec, n_lig, rag
     model = build_model(device, workload)
     g = build_batch(model, B, n_rec, n_lig, seed=1234 + rank * B, device=device, workload=workload)
     bidx = G.get_batch_idxs(g)
-    if gemm != 'f32' and w['arch'] != 'egnn':
-        raise SystemExit('--gemm f16x2 exists for the EGNN denoiser only')
     os.environ['KPD_GEMM'] = gemm                      # read by kpd_egnn_create: the engine below is built in this mode
     eng = model.dynamics.engine()
     os.environ.pop('KPD_GEMM')
@@ -370,6 +368,10 @@ def run_sampling(args, workload, device, rank, world, dist, B, n_rec, n_lig, rag
     else:
         kernel, f_exec, f_algo, b_algo = ('k_gvp_chain', gvp_chain_flop_per_edge(w['dyn']['n_hidden_scalars']), GVP_ALGO_FLOP_PER_EDGE,
                                           GVP_ALGO_BYTES_PER_EDGE)
+        if gemm == 'f16x2':
+            # the 256 x 256 products of the non-head message GVPs run split (3 f16 products each); heads, gates and vector parts stay fp32:
+            # price the whole kernel against the f16 / 3 peak as for the EGNN edge kernel (a lower bound on the fraction)
+            kernel, peak = 'k_gvp_chain<16, 1>', PEAK_F16_MATRIX_TFLOPS / 3.0
     achieved = edges_per_launch * f_exec / avg_s / 1e12 if avg_s > 0 else 0.0
     hbm_gbs = edges_per_launch * b_algo / avg_s / 1e9 if avg_s > 0 else 0.0
     traffic, tsrc = load_traffic(workload + ('_ragged' if ragged else '') + ('_f16x2' if gemm != 'f32' else '')) if (B == 64 and (ragged or n_rec == 300)) else (None, None)
@@ -382,8 +384,10 @@ def run_sampling(args, workload, device, rank, world, dist, B, n_rec, n_lig, rag
         'metric': 'denoising steps/sec', 'value': steps_per_s, 'unit': 'steps/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * med / args.steps,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32' if gemm == 'f32' else 'f32 via f16x2 split in the EGNN GEMMs (edge, projection, node update): 3 f16 MFMA products of '
-                                             'hi/lo planes per fp32 product, f32 accumulate; everything else f32',
+        'dtype': 'f32' if gemm == 'f32' else ('f32 via f16x2 split in the EGNN GEMMs (edge, projection, node update): 3 f16 MFMA products of '
+                                              'hi/lo planes per fp32 product, f32 accumulate; everything else f32' if w['arch'] == 'egnn' else
+                                              'f32 via f16x2 split in the 256 x 256 products of the message chain (k_gvp_chain): 3 f16 MFMA products '
+                                              'of hi/lo planes per fp32 product, f32 accumulate; everything else f32'),
         'data': 'synthetic',
         'config': {'workload': f'{desc[workload]}, batch of {B} synthetic {shape[0]}-atom pockets / {shape[1]}-atom ligands per GPU, '
                                f'T={T}, seeded random-init weights, every step taken from the t=T ligand state',

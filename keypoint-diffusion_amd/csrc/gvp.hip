@@ -1,6 +1,7 @@
 // GVP denoiser engine behind the kpd_gvp_* C ABI (include/kpd.h).  Replaces
 // LigRecDynamicsGVP.forward (models/dynamics_gvp.py:149-199) as a whole: encoders, per-step edge
 // build, the GVPMultiEdgeConv stack (models/gvp.py:459-551) and the NoisePredictionBlock.
+#include <cstring>
 #include <string.h>
 
 #include <map>
@@ -35,6 +36,7 @@ struct kpd_gvp {
     float *out_W, *out_b;
     std::set<std::string> expected, loaded;
     bool committed = false;
+    int gemm_mode = 0;                        // 0 exact fp32; 1 f16x2 split in the message chain (KPD_GEMM=f16x2, "gemm=f16x2")
     int debug_convs = -1;
     unsigned long long *stamps = nullptr;     // device [32], diagnostics
     // optional HIP-event timing of the dominant kernel (k_gvp_chain), for bench.py's roofline
@@ -77,6 +79,7 @@ extern "C" kpd_status kpd_gvp_create(const kpd_gvp_config *cfg, kpd_gvp **out) {
     m->cfg = *cfg;
     m->S = cfg->n_hidden_scalars;
     m->V = GV;
+    if (const char *e = getenv("KPD_GEMM")) m->gemm_mode = (!strcmp(e, "f16x2") && m->S == 256) ? 1 : 0;
     const int S = m->S, C = cfg->n_convs;
     size_t per_gvp = gvp_arena_bytes(S);
     size_t bytes = per_gvp * ((size_t)C * (4 * cfg->n_message_gvps + 2 * cfg->n_update_gvps) + cfg->n_noise_gvps) +
@@ -224,6 +227,16 @@ extern "C" kpd_status kpd_gvp_commit(kpd_gvp *m) {
             set_error("weight '%s' was never loaded (%zu of %zu loaded)", n.c_str(), m->loaded.size(), m->expected.size());
             return KPD_ERR_WEIGHTS;
         }
+    // f16x2 mode: the 256 -> 256 message GVPs behind the head of every chain, re-packed from their finished fp32 chunks
+    for (auto &conv : m->msg)
+        for (auto &et : conv)
+            for (HostGvp &g : et)
+                if (g.has_h() && g.chain_h) KPD_TRY(pack_gvp_chain_h(g.chain, g.chain_h, nullptr));
+    for (auto &conv : m->upd)
+        for (auto &nt : conv)
+            for (HostGvp &g : nt)
+                if (g.has_h() && g.chain_h) KPD_TRY(pack_gvp_chain_h(g.chain, g.chain_h, nullptr));
+    KPD_HIP(hipDeviceSynchronize());
     m->committed = true;
     return KPD_OK;
 }
@@ -346,6 +359,7 @@ extern "C" kpd_status kpd_gvp_forward(kpd_gvp *m, const kpd_batch *bt, const flo
         ea.x[0] = x[0]; ea.x[1] = x[1]; ea.v[0] = m->v[0]; ea.v[1] = m->v[1];
         ea.n_gvps = c.n_message_gvps; ea.S = S; ea.rbf_dmax = 15.0f;            // gvp.py:350 default, not overridden
         ea.stamps = m->stamps;
+        ea.gemm_mode = (S == 256 && !m->stamps) ? m->gemm_mode : 0;
         for (int et = 0; et < net; ++et) {
             ea.src[et] = esrc[et]; ea.dst[et] = edst[et]; ea.Psrc[et] = m->Psrc[et];
             for (int j = 0; j < c.n_message_gvps; ++j) ea.g[et][j] = m->msg[ci][et][j].dev();
@@ -382,6 +396,7 @@ extern "C" kpd_status kpd_gvp_forward(kpd_gvp *m, const kpd_batch *bt, const flo
             for (int j = 0; j < c.n_update_gvps; ++j) na.g[j] = m->upd[ci][nt][j].dev();
         }
         np.tiles0 = cdiv(n[0], TM);
+        np.gemm_mode = S == 256 ? m->gemm_mode : 0;
         KPD_TRY(launch_gvp_node(np, st));
     }
 
@@ -400,6 +415,12 @@ extern "C" kpd_status kpd_gvp_debug_state(kpd_gvp *m, const char *what, float *o
     const std::string w(what);
     if (w.rfind("convs=", 0) == 0) {
         m->debug_convs = atoi(w.c_str() + 6);
+        return KPD_OK;
+    }
+    if (w.rfind("gemm=", 0) == 0) {              // "gemm=f32" (exact, the default) | "gemm=f16x2" (split f16 products in the message chain)
+        const std::string v = w.substr(5);
+        KPD_REQUIRE(v == "f32" || v == "f16x2", KPD_ERR_INVALID, "gemm mode must be f32 or f16x2");
+        m->gemm_mode = (v == "f16x2" && m->S == 256) ? 1 : 0;
         return KPD_OK;
     }
     if (w == "stamps=1") {

@@ -97,6 +97,104 @@ __device__ __forceinline__ void chain_generic_gvp(Ring &ring, Src &chunk_src, co
     }
 }
 
+// The same GVP with the 256 x 256 part of its [x | sh] product on v_mfma_f32_16x16x32_f16 (f16x2 mode):
+// units 0..15 of the re-packed chunk buffer (pack_gvp_chain_h) hold k-block kb = u >> 1 for output tiles 8 (u & 1) .. + 7 as hi / lo
+// planes x 2^10; the scalars of result tiles 2 kb and 2 kb + 1 of the previous product are the eight B-operand slots of a lane,
+// split into hi / lo halves x 2^6 in registers.  The accumulator works in the 2^16 domain from the bias on (the fp32 sh slab is
+// pre-scaled by 2^16) and leaves it at the SiLU.  Everything else as in chain_generic_gvp.
+template <int NTS, class Ring, class Src>
+__device__ __forceinline__ void chain_generic_gvp_h(Ring &ring, Src &chunk_src, const GvpW &gk, const float *next_bias,
+                                                    v4f (&x)[NTS], v4f (&acc)[NTS], v4f (&Vc)[3], int lane, int q) {
+    static_assert(NTS == 16, "the f16x2 form is built for 256 scalars");
+    const v4f wh = reinterpret_cast<const v4f *>(gk.whp)[lane];
+    v4f Vh[3], sh;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        v4f t = zero4();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t = mfma16(wh[r], Vc[c][r], t);
+        Vh[c] = t;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sh[r] = sqrtf(fmaxf(Vh[0][r] * Vh[0][r] + Vh[1][r] * Vh[1][r] + Vh[2][r] * Vh[2][r], 1e-8f));
+#pragma unroll
+    for (int mt = 0; mt < NTS; ++mt) acc[mt] = acc[mt] * (1.0f / H_UNSCALE);
+#pragma unroll
+    for (int kb = 0; kb < NTS / 2; ++kb) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+        split_pair(H_SCALE_A * x[2 * kb][0], H_SCALE_A * x[2 * kb][1], h0, l0);
+        split_pair(H_SCALE_A * x[2 * kb][2], H_SCALE_A * x[2 * kb][3], h1, l1);
+        split_pair(H_SCALE_A * x[2 * kb + 1][0], H_SCALE_A * x[2 * kb + 1][1], h2, l2);
+        split_pair(H_SCALE_A * x[2 * kb + 1][2], H_SCALE_A * x[2 * kb + 1][3], h3, l3);
+        const f32x4 xh = __builtin_bit_cast(f32x4, u32x4{h0, h1, h2, h3}), xl = __builtin_bit_cast(f32x4, u32x4{l0, l1, l2, l3});
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const f32x4 *wp = reinterpret_cast<const f32x4 *>(ring.acquire(chunk_src)) + lane;
+            // two batches of four output tiles; a batch's fragments are read one batch ahead into a third buffer (never refilled
+            // right behind its readers: mfma_core.h, gemm_rows64_h)
+            f32x4 w[3][8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w[0][i] = wp[i * 64];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                if (b + 1 < 2) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) w[b + 1][i] = wp[(8 * (b + 1) + i) * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[8 * half + 4 * b + m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(w[b][2 * m + 1]), as_h8(xh), acc[8 * half + 4 * b + m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[8 * half + 4 * b + m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(w[b][2 * m]), as_h8(xl), acc[8 * half + 4 * b + m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[8 * half + 4 * b + m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(w[b][2 * m]), as_h8(xh), acc[8 * half + 4 * b + m], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            ring.release();
+        }
+    }
+    {
+        const v4f *buf = ring.acquire(chunk_src);
+        chunk_gemm<NTS>(buf, sh, acc, lane, 4);           // the sh slab carries 2^16
+        ring.release();
+    }
+    const v4f bgv = *reinterpret_cast<const v4f *>(gk.bg + 4 * q);
+    const v4f wu = reinterpret_cast<const v4f *>(gk.wup)[lane];
+#pragma unroll
+    for (int mt = 0; mt < NTS; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[mt][r] = silu(acc[mt][r] * H_UNSCALE);
+    if (next_bias) {
+#pragma unroll
+        for (int mt = 0; mt < NTS; ++mt) acc[mt] = *reinterpret_cast<const v4f *>(next_bias + 16 * mt + 4 * q);
+    }
+    v4f gate;
+    {
+        const v4f *buf = ring.acquire(chunk_src) + lane;
+        v4f ga[4] = {zero4(), zero4(), zero4(), zero4()};
+#pragma unroll
+        for (int nt = 0; nt < NTS; ++nt) {
+            const v4f wg = buf[nt * 64];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ga[r] = mfma16(wg[r], x[nt][r], ga[r]);
+        }
+        ring.release();
+        gate = (ga[0] + ga[1]) + (ga[2] + ga[3]) + bgv;
+        if (gk.vec_sigmoid) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gate[r] = sigmoidf_(gate[r]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        v4f t = zero4();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t = mfma16(wu[r], Vh[c][r], t);
+        Vc[c] = gate * t;
+    }
+}
+
 // phase-cycle sums for profiles/tools/gvp_stamps.py (a.stamps is null in production)
 #define CHAIN_STAMP(idx)                                                                   \
     if (stamps && tid == 0) {                                                              \
@@ -105,7 +203,7 @@ __device__ __forceinline__ void chain_generic_gvp(Ring &ring, Src &chunk_src, co
         t_prev = t_now;                                                                    \
     }
 
-template <int NTS>
+template <int NTS, int HM = 0>
 __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
     using L = ChainSmem<NTS>;
     constexpr int S = L::S, CH4 = L::CH4, SO = L::SO;
@@ -147,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
             stage = 1 + (c - n0) / (NTS + 2);
             local = (c - n0) - (stage - 1) * (NTS + 2);
         }
-        return reinterpret_cast<const v4f *>(a.g[et][stage].chain) + (size_t)local * CH4 + tid;
+        return reinterpret_cast<const v4f *>((HM && stage > 0) ? a.g[et][stage].chain_h : a.g[et][stage].chain) + (size_t)local * CH4 + tid;
     };
     ChunkRing<CH4> ring;
     ring.init(smem, total, wave);
@@ -335,7 +433,8 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
     // ---- GVP 1 .. n-1: scalars and vectors come from the previous GVP's registers ------------------------
 #pragma unroll 1
     for (int k = 1; k < n_gvps; ++k) {
-        chain_generic_gvp<NTS>(ring, chunk_src, a.g[et][k], k + 1 < n_gvps ? a.g[et][k + 1].b : nullptr, x, acc, Vc, lane, q);
+        if constexpr (HM) chain_generic_gvp_h<NTS>(ring, chunk_src, a.g[et][k], k + 1 < n_gvps ? a.g[et][k + 1].b : nullptr, x, acc, Vc, lane, q);
+        else chain_generic_gvp<NTS>(ring, chunk_src, a.g[et][k], k + 1 < n_gvps ? a.g[et][k + 1].b : nullptr, x, acc, Vc, lane, q);
         CHAIN_STAMP(6)
     }
 
@@ -466,7 +565,7 @@ __device__ __forceinline__ void load_vec12(const float *p, v4f (&V)[3]) {       
         for (int r = 0; r < 4; ++r) V[c][r] = f[3 * r + c];
 }
 
-template <int NTS>
+template <int NTS, int HM = 0>
 __global__ __launch_bounds__(256, 2) void k_gvp_node_chain(GvpNodePair p) {
     constexpr int S = 16 * NTS, CH4 = NTS * 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -478,7 +577,7 @@ __global__ __launch_bounds__(256, 2) void k_gvp_node_chain(GvpNodePair p) {
 
     auto chunk_src = [&](int c) -> const v4f * {
         const int stage = c / (NTS + 2), local = c - stage * (NTS + 2);
-        return reinterpret_cast<const v4f *>(a.g[stage].chain) + (size_t)local * CH4 + tid;
+        return reinterpret_cast<const v4f *>(HM ? a.g[stage].chain_h : a.g[stage].chain) + (size_t)local * CH4 + tid;
     };
     ChunkRing<CH4> ring;
     ring.init(smem, n_gvps * (NTS + 2), wave);
@@ -539,8 +638,10 @@ __global__ __launch_bounds__(256, 2) void k_gvp_node_chain(GvpNodePair p) {
     }
     ring.first();
 #pragma unroll 1
-    for (int k = 0; k < n_gvps; ++k)
-        chain_generic_gvp<NTS>(ring, chunk_src, a.g[k], k + 1 < n_gvps ? a.g[k + 1].b : nullptr, x, acc, Vc, lane, q);
+    for (int k = 0; k < n_gvps; ++k) {
+        if constexpr (HM) chain_generic_gvp_h<NTS>(ring, chunk_src, a.g[k], k + 1 < n_gvps ? a.g[k + 1].b : nullptr, x, acc, Vc, lane, q);
+        else chain_generic_gvp<NTS>(ring, chunk_src, a.g[k], k + 1 < n_gvps ? a.g[k + 1].b : nullptr, x, acc, Vc, lane, q);
+    }
     // residual + update layer norm (gvp.py:524-532)
 #pragma unroll
     for (int nt = 0; nt < NTS; ++nt) x[nt] += *reinterpret_cast<const v4f *>(tmp + 16 * nt);
@@ -735,7 +836,14 @@ kpd_status launch_gvp_edge(const GvpEdgeArgs &a, int tile_cap, hipStream_t st) {
     KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_chain<8>), ChainSmem<8>::FLOATS * 4));
     KPD_REQUIRE(a.S == 256 || a.S == 128, KPD_ERR_INVALID, "gvp chain kernel: S=%d (supported 128, 256)", a.S);
     const dim3 grid(8 * cdiv(tile_cap, 8));
-    if (a.S == 256)
+    if (a.S == 256 && a.gemm_mode == 1) {
+        for (int et = 0; et < 4; ++et)
+            if (a.src[et])
+                for (int k = 1; k < a.n_gvps; ++k)
+                    KPD_REQUIRE(a.g[et][k].chain_h, KPD_ERR_STATE, "message GVP %d of edge type %d has no f16x2 chunks", k, et);
+        KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_chain<16, 1>), ChainSmem<16>::FLOATS * 4));
+        hipLaunchKernelGGL((k_gvp_chain<16, 1>), grid, dim3(256), ChainSmem<16>::FLOATS * 4, st, a);
+    } else if (a.S == 256)
         hipLaunchKernelGGL(k_gvp_chain<16>, grid, dim3(256), ChainSmem<16>::FLOATS * 4, st, a);
     else
         hipLaunchKernelGGL(k_gvp_chain<8>, grid, dim3(256), ChainSmem<8>::FLOATS * 4, st, a);
@@ -783,7 +891,14 @@ kpd_status launch_gvp_node(const GvpNodePair &p, hipStream_t st) {
                             "update GVP %d was not prepared for the chained node kernel", k);
     KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_node_chain<16>), 3 * 16 * 64 * 16));
     KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_node_chain<8>), 3 * 8 * 64 * 16));
-    if (S == 256) hipLaunchKernelGGL(k_gvp_node_chain<16>, dim3(tiles), dim3(256), 3 * 16 * 64 * 16, st, p);
+    if (S == 256 && p.gemm_mode == 1) {
+        for (int nt = 0; nt < 2; ++nt)
+            if (p.nt[nt].n)
+                for (int k = 0; k < p.nt[nt].n_gvps; ++k)
+                    KPD_REQUIRE(p.nt[nt].g[k].chain_h, KPD_ERR_STATE, "update GVP %d has no f16x2 chunks", k);
+        KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_node_chain<16, 1>), 3 * 16 * 64 * 16));
+        hipLaunchKernelGGL((k_gvp_node_chain<16, 1>), dim3(tiles), dim3(256), 3 * 16 * 64 * 16, st, p);
+    } else if (S == 256) hipLaunchKernelGGL(k_gvp_node_chain<16>, dim3(tiles), dim3(256), 3 * 16 * 64 * 16, st, p);
     else hipLaunchKernelGGL(k_gvp_node_chain<8>, dim3(tiles), dim3(256), 3 * 8 * 64 * 16, st, p);
     KPD_LAUNCH_CHECK();
     return KPD_OK;

@@ -25,6 +25,8 @@ struct HostGvp {
     int vec_sigmoid = 1;
     int chain_pos = 1;                                  // 0: head of an edge-message chain (split first Linear), >= 1: any other GVP
     float *chain = nullptr, *whp = nullptr, *wup = nullptr;   // 16x16x4 A fragments for the chained kernels (gvp_chain.hip)
+    float *chain_h = nullptr;                           // f16x2 re-pack of `chain` (256 -> 256 non-head GVPs only)
+    bool has_h() const { return chain_pos != 0 && s_in == 256 && sout == 256; }
     int n_ht() const { return (h + 15) / 16; }
     // k-slabs of to_feats_out ([rbf | sh tiles] at the head of a message chain, [s_in / 16 scalar slabs | sh] otherwise) + gates
     int chain_chunks() const { return chain_pos == 0 ? 2 + n_ht() : s_in / 16 + 2; }
@@ -34,6 +36,7 @@ struct HostGvp {
         w.vin = vin; w.h = h; w.vout = vout;
         w.sout = sout; w.vec_sigmoid = vec_sigmoid;
         w.chain = chain; w.whp = whp; w.wup = wup;
+        w.chain_h = chain_h;
         return w;
     }
 };

@@ -16,7 +16,7 @@ std::vector<std::string> split_dots(const std::string &s) {
 }
 
 size_t gvp_arena_bytes(int S) {
-    return (256 + 16 + 2 * (size_t)(S / 8) * 2048 + 256 + (size_t)(S / 16 + 2) * (S / 16) * 256 + 12 * 256) * 4 + 16384;
+    return (256 + 16 + 2 * (size_t)(S / 8) * 2048 + 256 + 2 * (size_t)(S / 16 + 2) * (S / 16) * 256 + 12 * 256) * 4 + 16384;
 }
 
 void alloc_gvp(Arena &A, HostGvp &g, std::set<std::string> &expected, const std::string &prefix) {
@@ -31,6 +31,7 @@ void alloc_gvp(Arena &A, HostGvp &g, std::set<std::string> &expected, const std:
     // a split first Linear exists only at the head of an edge-message chain
     if ((g.split != SPLIT_NONE) != (g.chain_pos == 0)) set_error("internal: GVP split/chain position mismatch");
     g.chain = A.take<float>((size_t)g.chain_chunks() * (g.sout / 16) * 256);
+    if (g.has_h()) g.chain_h = A.take<float>((size_t)g.chain_chunks() * (g.sout / 16) * 256);
     g.whp = A.take<float>(g.chain_pos == 0 ? 9 * 256 : 256);
     g.wup = A.take<float>((size_t)g.n_ht() * 256);
     for (const char *s : {".Wh", ".Wu", ".to_feats_out.0.weight", ".to_feats_out.0.bias", ".scalar_to_vector_gates.weight",

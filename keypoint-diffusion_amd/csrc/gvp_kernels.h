@@ -16,6 +16,7 @@ struct GvpW {
     int vec_sigmoid;      // 1: sigmoid gate, 0: identity (last noise GVP)
     // 16x16x4 A-operand fragments, see HostGvp / load_gvp_tensor
     const float *chain;   // weight chunks: to_feats_out k-slabs, then the gate slab
+    const float *chain_h; // f16x2 mode: the same chunks re-packed (pack_gvp_chain_h); null when the GVP has no such form
     const float *whp;     // Wh fragments ([3 input tiles][3 hidden tiles][256] at the head of a message chain, [256] otherwise)
     const float *wup;     // Wu fragments ([hidden tile][256])
 };
@@ -37,6 +38,7 @@ struct GvpEdgeArgs {
     float *ms_main[4], *ms_cont[4];   // [n_dst][S], [tiles][S]
     float *mv_main[4], *mv_cont[4];   // [n_dst][48], [tiles][48]
     unsigned long long *stamps;       // [32] phase-cycle sums (diagnostics only, null in production)
+    int gemm_mode;                    // 0: exact fp32 MFMA; 1: f16x2 split in the 256 x 256 products of the non-head message GVPs
 };
 
 struct GvpNodeArgs {
@@ -60,6 +62,7 @@ struct GvpNodeArgs {
 struct GvpNodePair {
     GvpNodeArgs nt[2];
     int tiles0;
+    int gemm_mode;                // 0 exact fp32; 1 f16x2 split in the update GVPs' 256 x 256 products
 };
 
 constexpr int GVP_PROJ_SLOTS = 8;

@@ -168,6 +168,39 @@ kpd_status pack_chain_frag(const float *src, int sn, int sk, int n_valid, int k_
     return KPD_OK;
 }
 
+// f16x2 mode of the GVP message chain (k_gvp_chain, chain_generic_gvp_h): the chunk buffer of a GVP with 256 scalar inputs and
+// outputs, re-packed.  Input (pack_chain_frag): chunk c = 16-row k-slab c of to_feats_out as 16 x 256 floats
+// [(mt * 64 + lane) * 4 + r] = W[16 mt + (lane & 15)][16 c + 4 (lane >> 4) + r]; chunks 0..15 the scalar inputs, 16 the sh slab, 17 the
+// gate slab.  Output, same size: units 0..15 = k-block kb = u >> 1 (32 inputs), feature half u & 1 (8 of the 16 output tiles) as f16
+// hi / lo planes x 2^10 in the A-fragment order of v_mfma_f32_16x16x32_f16,
+//   unit[((m * 2 + plane) * 64 + lane) * 8 + j] = plane(W[n = 16 (8 (u & 1) + m) + (lane & 15)][k(kb, lane >> 4, j)])
+// with k = 32 kb + 4 q + j for j < 4 and 32 kb + 16 + 4 q + (j - 4) for j >= 4: the slots a lane fills from result tiles 2 kb and
+// 2 kb + 1 of the previous product; unit 16 = the sh slab x 2^16 (it is added to the same accumulator by fp32 MFMAs); unit 17 = the gate
+// slab unchanged.
+__global__ void k_pack_gvp_chain_h(const float *__restrict__ chain, float *__restrict__ chain_h) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int u = idx >> 12, rem = idx & 4095;
+    if (u >= 18) return;
+    if (u >= 16) {
+        chain_h[idx] = (u == 16 ? 65536.0f : 1.0f) * chain[idx];
+        return;
+    }
+    const int j = rem & 7, lane = (rem >> 3) & 63, m = rem >> 9;          // m < 8
+    const int kb = u >> 1, mt = 8 * (u & 1) + m;
+    const float w = H_SCALE_W_PACK * chain[(size_t)(2 * kb + (j >> 2)) * 4096 + (mt * 64 + lane) * 4 + (j & 3)];
+    const __fp16 hi = (__fp16)w;
+    const __fp16 lo = (__fp16)(w - (float)hi);
+    __fp16 *dst = reinterpret_cast<__fp16 *>(chain_h + (size_t)u * 4096);
+    dst[((m * 2 + 0) * 64 + lane) * 8 + j] = hi;
+    dst[((m * 2 + 1) * 64 + lane) * 8 + j] = lo;
+}
+
+kpd_status pack_gvp_chain_h(const float *chain, float *chain_h, hipStream_t st) {
+    hipLaunchKernelGGL(k_pack_gvp_chain_h, dim3(18 * 4096 / 256), dim3(256), 0, st, chain, chain_h);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
 __global__ void k_scale_inplace(float *__restrict__ p, int n, float f) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] *= f;

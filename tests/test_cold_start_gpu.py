@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize('arch,mode', [('egnn', 'f32'), ('egnn', 'f16x2'), ('gvp', 'f32')])
+@pytest.mark.parametrize('arch,mode', [('egnn', 'f32'), ('egnn', 'f16x2'), ('gvp', 'f32'), ('gvp', 'f16x2')])
 def test_first_forward_of_a_fresh_process_equals_the_later_ones(cuda, arch, mode):
     env = dict(os.environ, KPD_GEMM=mode)
     for attempt in range(2):                                  # two fresh processes per case

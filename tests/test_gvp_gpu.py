@@ -10,7 +10,7 @@ from oracle import gvp as ogvp
 from . import util
 from .golden.make_golden_cfgs import GVP_CFGS
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures('gemm_mode')]   # both GEMM modes of the denoiser engines (conftest.py)
 TOL = 1e-4
 CUT = util.CUTOFFS_ALL_ATOM
 

@@ -10,7 +10,7 @@ from oracle import gvp as ogvp
 from tests import util
 from tests.golden.make_golden_cfgs import GVP_CFGS
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures('gemm_mode')]   # both GEMM modes of the denoiser engines (conftest.py)
 CUT = util.CUTOFFS_ALL_ATOM
 TOL = 2e-4          # relative to the largest entry of each gradient tensor
 
