@@ -42,8 +42,8 @@ PEAK_HBM_GBS = 8000.0
 # What back-to-back fp32 MFMAs deliver on all CUs of this part at once (profiles/tools/gemm_loop_probe.hip, profiles/r02_gemm_loop_probe.txt:
 # 64.1 cycles per v_mfma_f32_32x32x2_f32 -- a full pipe -- at the ~2.0 GHz the chip holds under that load).  Context for `frac`, not the peak.
 SUSTAINED_F32_MFMA_TFLOPS = 132.0
-# f16x2 mode (opt-in, --gemm f16x2 / KPD_GEMM=f16x2): every fp32 product of the EGNN GEMMs (edge, projection and node-update kernels) is
-# three f16 MFMA products of hi / lo operand planes with fp32 accumulation, so the bound for USEFUL flops is the dense f16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PFLOP/s) / 3
+# f16x2 mode (opt-in, --gemm f16x2 / KPD_GEMM=f16x2): every fp32 product of the EGNN GEMMs (edge, projection and node-update kernels) and of
+# the 256 x 256 products of the GVP message / update chains is three f16 MFMA products of hi / lo operand planes with fp32 accumulation, so the bound for USEFUL flops is the dense f16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PFLOP/s) / 3
 PEAK_F16_MATRIX_TFLOPS = 2500.0
 # FLOPs the fused EGNN edge kernel executes per edge per layer: the two 257x257 second Linears of edge_mlp /
 # coord_mlp plus the attention and coordinate heads (the first Linears run per NODE, k_proj_ws)
@@ -386,7 +386,7 @@ def run_sampling(args, workload, device, rank, world, dist, B, n_rec, n_lig, rag
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32' if gemm == 'f32' else ('f32 via f16x2 split in the EGNN GEMMs (edge, projection, node update): 3 f16 MFMA products of '
                                               'hi/lo planes per fp32 product, f32 accumulate; everything else f32' if w['arch'] == 'egnn' else
-                                              'f32 via f16x2 split in the 256 x 256 products of the message chain (k_gvp_chain): 3 f16 MFMA products '
+                                              'f32 via f16x2 split in the 256 x 256 products of the message and update chains (k_gvp_chain, k_gvp_node_chain): 3 f16 MFMA products '
                                               'of hi/lo planes per fp32 product, f32 accumulate; everything else f32'),
         'data': 'synthetic',
         'config': {'workload': f'{desc[workload]}, batch of {B} synthetic {shape[0]}-atom pockets / {shape[1]}-atom ligands per GPU, '
@@ -586,6 +586,14 @@ def main():
                 r['gpu_over_cpu'] = r['value'] / out['cpu_baseline']['value']
             r['end_to_end'] = run_end_to_end(device, gemm='f16x2')
             sec['egnn_all_atom_f16x2'] = r
+            for name, wl, ragged in (('gvp_40kp_f16x2', 'gvp_40kp', False), ('gvp_all_atom_ragged_f16x2', 'gvp_all_atom', True)):
+                nr, nl = ragged_sizes(64, 0) if ragged else (300, 25)
+                r = run_sampling(sec_args, wl, device, 0, 1, None, 64, nr, nl, ragged, gemm='f16x2')
+                base = sec[name[:-len('_f16x2')]]
+                if 'cpu_baseline' in base:
+                    r['cpu_baseline'] = base['cpu_baseline']
+                    r['gpu_over_cpu'] = r['value'] / base['cpu_baseline']['value']
+                sec[name] = r
             out['secondary'] = sec
             out['end_to_end'] = run_end_to_end(device)
             out['ligands_per_min'] = out['end_to_end']['ligands_per_min']

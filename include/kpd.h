@@ -190,7 +190,8 @@ kpd_status kpd_gvp_reserve(kpd_gvp *m, int32_t max_B, int32_t max_n_lig, int32_t
                            int32_t max_n_kk, int32_t max_lig_per_graph, int32_t max_kp_per_graph);
 kpd_status kpd_gvp_forward(kpd_gvp *m, const kpd_batch *batch, const float *t_dev,
                            float *eps_h_dev, float *eps_x_dev, void *stream);
-/* Debug/test taps: "convs=<n>" limits the conv stack; "s_lig", "s_kp", "v_lig", "v_kp" copy state. */
+/* Debug/test taps: "convs=<n>" limits the conv stack; "s_lig", "s_kp", "v_lig", "v_kp" copy state; "gemm=f32" | "gemm=f16x2" as for
+ * kpd_egnn_debug_state (the 256 x 256 products of the message / update chains; KPD_GEMM=f16x2 at create time; 256 scalars only). */
 kpd_status kpd_gvp_debug_state(kpd_gvp *m, const char *what, float *out_dev, int64_t n_floats,
                                void *stream);
 /* HIP-event timing of the dominant kernel (k_gvp_chain: the message chain of GVPMultiEdgeConv.message,

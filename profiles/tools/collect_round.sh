@@ -13,12 +13,14 @@ out=gpurun_out/$tag
 rm -rf $out && mkdir -p $out
 python bench.py > $out/bench.json 2> $out/bench.err
 short="--steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-secondary"
-for wl in egnn_all_atom egnn_all_atom_f16x2 gvp_40kp gvp_all_atom_ragged; do
+for wl in egnn_all_atom egnn_all_atom_f16x2 gvp_40kp gvp_all_atom_ragged gvp_40kp_f16x2 gvp_all_atom_ragged_f16x2; do
   case $wl in
     egnn_all_atom) args="";;
     egnn_all_atom_f16x2) args="--gemm f16x2";;
     gvp_40kp) args="--workload gvp_40kp";;
     gvp_all_atom_ragged) args="--workload gvp_all_atom --ragged";;
+    gvp_40kp_f16x2) args="--workload gvp_40kp --gemm f16x2";;
+    gvp_all_atom_ragged_f16x2) args="--workload gvp_all_atom --ragged --gemm f16x2";;
   esac
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$wl -- python bench.py --steps 40 --warmup 5 --repeats 1 --no-cpu-baseline --no-secondary $args > $out/bench_under_rocprof_$wl.json 2> $out/stats_$wl.err
   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA \
@@ -32,7 +34,8 @@ done
 KPD_OUT=$out python - <<'PY'
 import csv, glob, json, os
 out = os.environ['KPD_OUT']
-dom = {'egnn_all_atom': 'k_egnn_edge<4>', 'egnn_all_atom_f16x2': 'k_egnn_edge_h', 'gvp_40kp': 'k_gvp_chain<16>', 'gvp_all_atom_ragged': 'k_gvp_chain<16>'}
+dom = {'egnn_all_atom': 'k_egnn_edge<4>', 'egnn_all_atom_f16x2': 'k_egnn_edge_h', 'gvp_40kp': 'k_gvp_chain<16, 0>', 'gvp_all_atom_ragged': 'k_gvp_chain<16, 0>',
+       'gvp_40kp_f16x2': 'k_gvp_chain<16, 1>', 'gvp_all_atom_ragged_f16x2': 'k_gvp_chain<16, 1>'}
 res = {}
 for wl, kern in dom.items():
     agg = {}
@@ -51,4 +54,7 @@ res['note'] = ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, aver
 json.dump(res, open(f'{out}/traffic.json', 'w'), indent=1)
 print(open(f'{out}/traffic.json').read())
 PY
+rocm-smi --showuniqueid 2>/dev/null | grep -i 'unique id' > $out/gpu_id.txt
+# the raw rocprofv3 trees are only needed for the summaries above (gpurun_out/ is capped at 64 MiB)
+find $out -mindepth 1 -maxdepth 1 -type d \( -name 'pmc_*' -o -name 'stats_*' \) -exec rm -rf {} +
 tail -c 600 $out/bench.json
