@@ -231,11 +231,15 @@ extern "C" kpd_status kpd_gvp_commit(kpd_gvp *m) {
     for (auto &conv : m->msg)
         for (auto &et : conv)
             for (HostGvp &g : et)
-                if (g.has_h() && g.chain_h) KPD_TRY(pack_gvp_chain_h(g.chain, g.chain_h, nullptr));
+                {
+                    if (g.has_h() && g.chain_h) KPD_TRY(pack_gvp_chain_h(g.chain, g.chain_h, g.chain_pos == 0, g.n_ht(), nullptr));
+                    if (g.wproj_h) KPD_TRY(pack_gvp_proj_h(g.wproj, g.wproj_h, nullptr));
+                    if (g.wproj_dst_h) KPD_TRY(pack_gvp_proj_h(g.wproj_dst, g.wproj_dst_h, nullptr));
+                }
     for (auto &conv : m->upd)
         for (auto &nt : conv)
             for (HostGvp &g : nt)
-                if (g.has_h() && g.chain_h) KPD_TRY(pack_gvp_chain_h(g.chain, g.chain_h, nullptr));
+                if (g.has_h() && g.chain_h) KPD_TRY(pack_gvp_chain_h(g.chain, g.chain_h, 0, g.n_ht(), nullptr));
     KPD_HIP(hipDeviceSynchronize());
     m->committed = true;
     return KPD_OK;
@@ -345,12 +349,13 @@ extern "C" kpd_status kpd_gvp_forward(kpd_gvp *m, const kpd_batch *bt, const flo
         for (int et = 0; et < net; ++et) {
             const HostGvp &g = m->msg[ci][et][0];
             pa.tiles_first[et] = run;
-            pa.s[et] = m->s[kSrcNtG[et]]; pa.n[et] = n[kSrcNtG[et]]; pa.wp[et] = g.wproj; pa.b[et] = g.bproj; pa.P[et] = m->Psrc[et];
+            pa.s[et] = m->s[kSrcNtG[et]]; pa.n[et] = n[kSrcNtG[et]]; pa.wp[et] = g.wproj; pa.wp_h[et] = g.wproj_h; pa.b[et] = g.bproj; pa.P[et] = m->Psrc[et];
             run += cdiv(n[kSrcNtG[et]], TM);
             tile_cap += cdiv(E_cap[et], TM);
         }
         pa.n_slots = net;
         pa.tiles_first[net] = run;
+        pa.gemm_mode = S == 256 ? m->gemm_mode : 0;
         KPD_TRY(launch_gvp_proj(pa, st));
 
         GvpEdgeArgs ea;

@@ -97,11 +97,73 @@ __device__ __forceinline__ void chain_generic_gvp(Ring &ring, Src &chunk_src, co
     }
 }
 
+// ---- f16x2 building blocks (unit layouts: pack.hip, k_pack_gvp_unit_h) -------------------------------------
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+// eight scalars of a lane (result tiles 2 kb and 2 kb + 1) -> hi / lo B operands of v_mfma_f32_16x16x32_f16, x 2^6
+__device__ __forceinline__ void split8(const v4f &a, const v4f &b, f32x4 &xh, f32x4 &xl) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+    split_pair(H_SCALE_A * a[0], H_SCALE_A * a[1], h0, l0);
+    split_pair(H_SCALE_A * a[2], H_SCALE_A * a[3], h1, l1);
+    split_pair(H_SCALE_A * b[0], H_SCALE_A * b[1], h2, l2);
+    split_pair(H_SCALE_A * b[2], H_SCALE_A * b[3], h3, l3);
+    xh = __builtin_bit_cast(f32x4, u32x4{h0, h1, h2, h3});
+    xl = __builtin_bit_cast(f32x4, u32x4{l0, l1, l2, l3});
+}
+
+// acc (2^16 domain) += slab[16 k][256] . xin for one 16-row slab (rbf, sh) on v_mfma_f32_16x16x16_f16: unit kind 1
+template <int NTS>
+__device__ __forceinline__ void chunk_gemm16_h(const v4f *__restrict__ buf, v4f xin, v4f (&acc)[NTS], int lane) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    unsigned h0, h1, l0, l1;
+    split_pair(H_SCALE_A * xin[0], H_SCALE_A * xin[1], h0, l0);
+    split_pair(H_SCALE_A * xin[2], H_SCALE_A * xin[3], h1, l1);
+    const h4 xh = __builtin_bit_cast(h4, u32x2{h0, h1}), xl = __builtin_bit_cast(h4, u32x2{l0, l1});
+    const f32x2v *wp = reinterpret_cast<const f32x2v *>(buf) + lane;          // 8-B fragments
+    f32x2v w[3][8];                                                           // [batch buffer][4 tiles x (hi, lo)]
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[0][i] = wp[i * 64];
+#pragma unroll
+    for (int b = 0; b < NTS / 4; ++b) {
+        if (b + 1 < NTS / 4) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w[(b + 1) % 3][i] = wp[(8 * (b + 1) + i) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[4 * b + m] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h4, w[b % 3][2 * m + 1]), xh, acc[4 * b + m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[4 * b + m] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h4, w[b % 3][2 * m]), xl, acc[4 * b + m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[4 * b + m] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h4, w[b % 3][2 * m]), xh, acc[4 * b + m], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// gate pre-activations (16 per edge) = Wg . x over the 256 scalars, unit kind 2; returns the sum in the plain domain
+template <int NTS>
+__device__ __forceinline__ v4f gates_h(const v4f *__restrict__ buf, const v4f (&x)[NTS], int lane) {
+    const f32x4 *wp = reinterpret_cast<const f32x4 *>(buf) + lane;
+    v4f ga[3] = {zero4(), zero4(), zero4()};
+#pragma unroll
+    for (int kb = 0; kb < NTS / 2; ++kb) {
+        f32x4 xh, xl;
+        split8(x[2 * kb], x[2 * kb + 1], xh, xl);
+        const f32x4 wh = wp[(2 * kb) * 64], wl = wp[(2 * kb + 1) * 64];
+        ga[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(wl), as_h8(xh), ga[0], 0, 0, 0);
+        ga[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(wh), as_h8(xl), ga[1], 0, 0, 0);
+        ga[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(wh), as_h8(xh), ga[2], 0, 0, 0);
+    }
+    return ((ga[0] + ga[1]) + ga[2]) * H_UNSCALE;
+}
+
 // The same GVP with the 256 x 256 part of its [x | sh] product on v_mfma_f32_16x16x32_f16 (f16x2 mode):
 // units 0..15 of the re-packed chunk buffer (pack_gvp_chain_h) hold k-block kb = u >> 1 for output tiles 8 (u & 1) .. + 7 as hi / lo
 // planes x 2^10; the scalars of result tiles 2 kb and 2 kb + 1 of the previous product are the eight B-operand slots of a lane,
-// split into hi / lo halves x 2^6 in registers.  The accumulator works in the 2^16 domain from the bias on (the fp32 sh slab is
-// pre-scaled by 2^16) and leaves it at the SiLU.  Everything else as in chain_generic_gvp.
+// split into hi / lo halves x 2^6 in registers.  The sh slab (16 inputs) runs on v_mfma_f32_16x16x16_f16, the gates on the
+// 16x16x32 form again.  The accumulator works in the 2^16 domain from the bias to the SiLU.  Vector channels as in chain_generic_gvp.
 template <int NTS, class Ring, class Src>
 __device__ __forceinline__ void chain_generic_gvp_h(Ring &ring, Src &chunk_src, const GvpW &gk, const float *next_bias,
                                                     v4f (&x)[NTS], v4f (&acc)[NTS], v4f (&Vc)[3], int lane, int q) {
@@ -121,13 +183,8 @@ __device__ __forceinline__ void chain_generic_gvp_h(Ring &ring, Src &chunk_src, 
     for (int mt = 0; mt < NTS; ++mt) acc[mt] = acc[mt] * (1.0f / H_UNSCALE);
 #pragma unroll
     for (int kb = 0; kb < NTS / 2; ++kb) {
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-        split_pair(H_SCALE_A * x[2 * kb][0], H_SCALE_A * x[2 * kb][1], h0, l0);
-        split_pair(H_SCALE_A * x[2 * kb][2], H_SCALE_A * x[2 * kb][3], h1, l1);
-        split_pair(H_SCALE_A * x[2 * kb + 1][0], H_SCALE_A * x[2 * kb + 1][1], h2, l2);
-        split_pair(H_SCALE_A * x[2 * kb + 1][2], H_SCALE_A * x[2 * kb + 1][3], h3, l3);
-        const f32x4 xh = __builtin_bit_cast(f32x4, u32x4{h0, h1, h2, h3}), xl = __builtin_bit_cast(f32x4, u32x4{l0, l1, l2, l3});
+        f32x4 xh, xl;
+        split8(x[2 * kb], x[2 * kb + 1], xh, xl);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const f32x4 *wp = reinterpret_cast<const f32x4 *>(ring.acquire(chunk_src)) + lane;
@@ -156,7 +213,7 @@ __device__ __forceinline__ void chain_generic_gvp_h(Ring &ring, Src &chunk_src, 
     }
     {
         const v4f *buf = ring.acquire(chunk_src);
-        chunk_gemm<NTS>(buf, sh, acc, lane, 4);           // the sh slab carries 2^16
+        chunk_gemm16_h<NTS>(buf, sh, acc, lane);
         ring.release();
     }
     const v4f bgv = *reinterpret_cast<const v4f *>(gk.bg + 4 * q);
@@ -171,16 +228,9 @@ __device__ __forceinline__ void chain_generic_gvp_h(Ring &ring, Src &chunk_src, 
     }
     v4f gate;
     {
-        const v4f *buf = ring.acquire(chunk_src) + lane;
-        v4f ga[4] = {zero4(), zero4(), zero4(), zero4()};
-#pragma unroll
-        for (int nt = 0; nt < NTS; ++nt) {
-            const v4f wg = buf[nt * 64];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ga[r] = mfma16(wg[r], x[nt][r], ga[r]);
-        }
+        const v4f *buf = ring.acquire(chunk_src);
+        gate = gates_h<NTS>(buf, x, lane) + bgv;
         ring.release();
-        gate = (ga[0] + ga[1]) + (ga[2] + ga[3]) + bgv;
         if (gk.vec_sigmoid) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) gate[r] = sigmoidf_(gate[r]);
@@ -245,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
             stage = 1 + (c - n0) / (NTS + 2);
             local = (c - n0) - (stage - 1) * (NTS + 2);
         }
-        return reinterpret_cast<const v4f *>((HM && stage > 0) ? a.g[et][stage].chain_h : a.g[et][stage].chain) + (size_t)local * CH4 + tid;
+        return reinterpret_cast<const v4f *>(HM ? a.g[et][stage].chain_h : a.g[et][stage].chain) + (size_t)local * CH4 + tid;
     };
     ChunkRing<CH4> ring;
     ring.init(smem, total, wave);
@@ -284,6 +334,10 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
             const float *pd = a.Pdst[et] + (size_t)vd * S + 4 * q;
 #pragma unroll
             for (int mt = 0; mt < NTS; ++mt) acc[mt] += *reinterpret_cast<const v4f *>(pd + 16 * mt);
+        }
+        if constexpr (HM) {       // f16x2 mode: the accumulator works in the 2^16 domain up to the SiLU
+#pragma unroll
+            for (int mt = 0; mt < NTS; ++mt) acc[mt] = acc[mt] * (1.0f / H_UNSCALE);
         }
     }
     v4f Vc[3];          // current vectors: Vc[c][r] = v[e][4 q + r][c]
@@ -367,14 +421,16 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
         // scalar GEMM: [rbf | sh] part of to_feats_out
         {
             const v4f *buf = acquire();
-            chunk_gemm<NTS>(buf, rbf, acc, lane, 4);
+            if constexpr (HM) chunk_gemm16_h<NTS>(buf, rbf, acc, lane);
+            else chunk_gemm<NTS>(buf, rbf, acc, lane, 4);
             release();
         }
 #pragma unroll
         for (int ht = 0; ht < 3; ++ht) {
             if (ht < n_ht) {
                 const v4f *buf = acquire();
-                chunk_gemm<NTS>(buf, sh[ht], acc, lane, ht == n_ht - 1 ? tail_reg : 4);
+                if constexpr (HM) chunk_gemm16_h<NTS>(buf, sh[ht], acc, lane);       // rows past h carry zero weights
+                else chunk_gemm<NTS>(buf, sh[ht], acc, lane, ht == n_ht - 1 ? tail_reg : 4);
                 release();
             }
         }
@@ -387,7 +443,7 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
 #pragma unroll
         for (int mt = 0; mt < NTS; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) x[mt][r] = silu(acc[mt][r]);
+            for (int r = 0; r < 4; ++r) x[mt][r] = silu(HM ? acc[mt][r] * H_UNSCALE : acc[mt][r]);
         if (n_gvps > 1) {
             const float *bn = a.g[et][1].b + 4 * q;
 #pragma unroll
@@ -396,16 +452,22 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
         CHAIN_STAMP(2)
         // gates                                                                       (gvp.py:105-107)
         {
-            const v4f *buf = acquire() + lane;
-            v4f ga[4] = {zero4(), zero4(), zero4(), zero4()};
+            if constexpr (HM) {
+                const v4f *buf = acquire();
+                gate = gates_h<NTS>(buf, x, lane) + bgv;
+                release();
+            } else {
+                const v4f *buf = acquire() + lane;
+                v4f ga[4] = {zero4(), zero4(), zero4(), zero4()};
 #pragma unroll
-            for (int nt = 0; nt < NTS; ++nt) {
-                const v4f wg = buf[nt * 64];
+                for (int nt = 0; nt < NTS; ++nt) {
+                    const v4f wg = buf[nt * 64];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ga[r] = mfma16(wg[r], x[nt][r], ga[r]);
+                    for (int r = 0; r < 4; ++r) ga[r] = mfma16(wg[r], x[nt][r], ga[r]);
+                }
+                release();
+                gate = (ga[0] + ga[1]) + (ga[2] + ga[3]) + bgv;
             }
-            release();
-            gate = (ga[0] + ga[1]) + (ga[2] + ga[3]) + bgv;
             if (g0.vec_sigmoid) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) gate[r] = sigmoidf_(gate[r]);
@@ -669,7 +731,7 @@ __global__ __launch_bounds__(256, 2) void k_gvp_node_chain(GvpNodePair p) {
 // ---- per-node blocks of the first message Linear (h_src / h_dst part of to_feats_out), register-chained -------------
 // P[slot][node][:] = W_block s[node] (+ b): one 64-node tile of one slot per workgroup, the S x S block streamed as
 // two-slab chunks (gvp_host.hip packs wproj / wproj_dst in chunk order).
-template <int NTS>
+template <int NTS, int HM = 0>
 __global__ __launch_bounds__(256, 2) void k_gvp_proj_chain(GvpProjArgs a) {
     constexpr int S = 16 * NTS, CH4 = NTS * 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -681,7 +743,7 @@ __global__ __launch_bounds__(256, 2) void k_gvp_proj_chain(GvpProjArgs a) {
     const int node0 = ((int)blockIdx.x - a.tiles_first[sl]) * TM;
     const int n = a.n[sl];
 
-    const v4f *stream = reinterpret_cast<const v4f *>(a.wp[sl]) + tid;
+    const v4f *stream = reinterpret_cast<const v4f *>(HM ? a.wp_h[sl] : a.wp[sl]) + tid;
     auto chunk_src = [&](int c) -> const v4f * { return stream + (size_t)c * (2 * CH4); };
     ChunkRing2<2 * CH4> ring;
     ring.init(smem, NTS / 2, wave);
@@ -698,11 +760,43 @@ __global__ __launch_bounds__(256, 2) void k_gvp_proj_chain(GvpProjArgs a) {
 #pragma unroll
     for (int mt = 0; mt < NTS; ++mt) acc[mt] = bias ? *reinterpret_cast<const v4f *>(bias + 16 * mt + 4 * q) : zero4();
     ring.first();
+    if constexpr (HM) {       // f16x2 mode: a 32-KB chunk = one 32-wide k-block for all 16 output tiles (units 2 kb, 2 kb + 1)
 #pragma unroll
-    for (int nt = 0; nt < NTS; nt += 2) {
-        const v4f *buf = ring.acquire(chunk_src);
-        chunk_gemm2<NTS>(buf, x[nt], x[nt + 1], acc, lane);
-        ring.release();
+        for (int mt = 0; mt < NTS; ++mt) acc[mt] = acc[mt] * (1.0f / H_UNSCALE);
+#pragma unroll
+        for (int kb = 0; kb < NTS / 2; ++kb) {
+            f32x4 xh, xl;
+            split8(x[2 * kb], x[2 * kb + 1], xh, xl);
+            const f32x4 *wp = reinterpret_cast<const f32x4 *>(ring.acquire(chunk_src)) + lane;
+            f32x4 w[3][8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w[0][i] = wp[i * 64];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (b + 1 < 4) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) w[(b + 1) % 3][i] = wp[(8 * (b + 1) + i) * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[4 * b + m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(w[b % 3][2 * m + 1]), as_h8(xh), acc[4 * b + m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[4 * b + m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(w[b % 3][2 * m]), as_h8(xl), acc[4 * b + m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[4 * b + m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(w[b % 3][2 * m]), as_h8(xh), acc[4 * b + m], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            ring.release();
+        }
+#pragma unroll
+        for (int mt = 0; mt < NTS; ++mt) acc[mt] = acc[mt] * H_UNSCALE;
+    } else {
+#pragma unroll
+        for (int nt = 0; nt < NTS; nt += 2) {
+            const v4f *buf = ring.acquire(chunk_src);
+            chunk_gemm2<NTS>(buf, x[nt], x[nt + 1], acc, lane);
+            ring.release();
+        }
     }
     if (vr < n) {
         float *out = a.P[sl] + (size_t)v * S + 4 * q;
@@ -839,7 +933,7 @@ kpd_status launch_gvp_edge(const GvpEdgeArgs &a, int tile_cap, hipStream_t st) {
     if (a.S == 256 && a.gemm_mode == 1) {
         for (int et = 0; et < 4; ++et)
             if (a.src[et])
-                for (int k = 1; k < a.n_gvps; ++k)
+                for (int k = 0; k < a.n_gvps; ++k)
                     KPD_REQUIRE(a.g[et][k].chain_h, KPD_ERR_STATE, "message GVP %d of edge type %d has no f16x2 chunks", k, et);
         KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_chain<16, 1>), ChainSmem<16>::FLOATS * 4));
         hipLaunchKernelGGL((k_gvp_chain<16, 1>), grid, dim3(256), ChainSmem<16>::FLOATS * 4, st, a);
@@ -857,7 +951,11 @@ kpd_status launch_gvp_proj(const GvpProjArgs &a, hipStream_t st) {
     KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_proj_chain<16>), 4 * 16 * 64 * 16));
     KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_proj_chain<8>), 4 * 8 * 64 * 16));
     const dim3 grid(a.tiles_first[a.n_slots]);
-    if (a.S == 256) hipLaunchKernelGGL(k_gvp_proj_chain<16>, grid, dim3(256), 4 * 16 * 64 * 16, st, a);
+    if (a.S == 256 && a.gemm_mode == 1) {
+        for (int e = 0; e < a.n_slots; ++e) KPD_REQUIRE(a.wp_h[e], KPD_ERR_STATE, "projection slot %d has no f16x2 block", e);
+        KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_proj_chain<16, 1>), 4 * 16 * 64 * 16));
+        hipLaunchKernelGGL((k_gvp_proj_chain<16, 1>), grid, dim3(256), 4 * 16 * 64 * 16, st, a);
+    } else if (a.S == 256) hipLaunchKernelGGL(k_gvp_proj_chain<16>, grid, dim3(256), 4 * 16 * 64 * 16, st, a);
     else hipLaunchKernelGGL(k_gvp_proj_chain<8>, grid, dim3(256), 4 * 8 * 64 * 16, st, a);
     KPD_LAUNCH_CHECK();
     return KPD_OK;

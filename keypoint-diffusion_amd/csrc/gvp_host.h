@@ -22,11 +22,12 @@ struct HostGvp {
     float *b = nullptr, *bg = nullptr;                  // to_feats_out bias (zero padded to 256), gate bias [16]
     float *wproj = nullptr, *bproj = nullptr;           // h_src block (+ bias)
     float *wproj_dst = nullptr;                         // h_dst block
+    float *wproj_h = nullptr, *wproj_dst_h = nullptr;   // f16x2 re-packs (S = 256)
     int vec_sigmoid = 1;
     int chain_pos = 1;                                  // 0: head of an edge-message chain (split first Linear), >= 1: any other GVP
     float *chain = nullptr, *whp = nullptr, *wup = nullptr;   // 16x16x4 A fragments for the chained kernels (gvp_chain.hip)
-    float *chain_h = nullptr;                           // f16x2 re-pack of `chain` (256 -> 256 non-head GVPs only)
-    bool has_h() const { return chain_pos != 0 && s_in == 256 && sout == 256; }
+    float *chain_h = nullptr;                           // f16x2 re-pack of `chain` (GVPs with 256 scalar outputs; 256 scalar inputs unless head)
+    bool has_h() const { return sout == 256 && (chain_pos == 0 || s_in == 256); }
     int n_ht() const { return (h + 15) / 16; }
     // k-slabs of to_feats_out ([rbf | sh tiles] at the head of a message chain, [s_in / 16 scalar slabs | sh] otherwise) + gates
     int chain_chunks() const { return chain_pos == 0 ? 2 + n_ht() : s_in / 16 + 2; }

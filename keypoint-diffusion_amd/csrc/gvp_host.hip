@@ -16,7 +16,7 @@ std::vector<std::string> split_dots(const std::string &s) {
 }
 
 size_t gvp_arena_bytes(int S) {
-    return (256 + 16 + 2 * (size_t)(S / 8) * 2048 + 256 + 2 * (size_t)(S / 16 + 2) * (S / 16) * 256 + 12 * 256) * 4 + 16384;
+    return (256 + 16 + 4 * (size_t)(S / 8) * 2048 + 256 + 2 * (size_t)(S / 16 + 2) * (S / 16) * 256 + 12 * 256) * 4 + 16384;
 }
 
 void alloc_gvp(Arena &A, HostGvp &g, std::set<std::string> &expected, const std::string &prefix) {
@@ -26,8 +26,12 @@ void alloc_gvp(Arena &A, HostGvp &g, std::set<std::string> &expected, const std:
     if (g.split != SPLIT_NONE) {
         g.wproj = A.take<float>((size_t)(g.S / 8) * 2048);
         g.bproj = A.take<float>(256);
+        if (g.S == 256) g.wproj_h = A.take<float>((size_t)(g.S / 8) * 2048);
     }
-    if (g.split == SPLIT_SRC_DST) g.wproj_dst = A.take<float>((size_t)(g.S / 8) * 2048);
+    if (g.split == SPLIT_SRC_DST) {
+        g.wproj_dst = A.take<float>((size_t)(g.S / 8) * 2048);
+        if (g.S == 256) g.wproj_dst_h = A.take<float>((size_t)(g.S / 8) * 2048);
+    }
     // a split first Linear exists only at the head of an edge-message chain
     if ((g.split != SPLIT_NONE) != (g.chain_pos == 0)) set_error("internal: GVP split/chain position mismatch");
     g.chain = A.take<float>((size_t)g.chain_chunks() * (g.sout / 16) * 256);

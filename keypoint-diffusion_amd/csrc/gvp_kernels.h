@@ -70,6 +70,8 @@ struct GvpProjArgs {
     const float *s[GVP_PROJ_SLOTS];    // scalar state to project, per slot
     int n[GVP_PROJ_SLOTS];
     const float *wp[GVP_PROJ_SLOTS], *b[GVP_PROJ_SLOTS];   // b may be nullptr
+    const float *wp_h[GVP_PROJ_SLOTS];                     // f16x2 mode: wp re-packed as 16 units of kind 0 (pack.hip)
+    int gemm_mode;
     float *P[GVP_PROJ_SLOTS];
     int tiles_first[GVP_PROJ_SLOTS + 1];
     int n_slots;

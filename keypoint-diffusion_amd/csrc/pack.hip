@@ -168,35 +168,67 @@ kpd_status pack_chain_frag(const float *src, int sn, int sk, int n_valid, int k_
     return KPD_OK;
 }
 
-// f16x2 mode of the GVP message chain (k_gvp_chain, chain_generic_gvp_h): the chunk buffer of a GVP with 256 scalar inputs and
-// outputs, re-packed.  Input (pack_chain_frag): chunk c = 16-row k-slab c of to_feats_out as 16 x 256 floats
-// [(mt * 64 + lane) * 4 + r] = W[16 mt + (lane & 15)][16 c + 4 (lane >> 4) + r]; chunks 0..15 the scalar inputs, 16 the sh slab, 17 the
-// gate slab.  Output, same size: units 0..15 = k-block kb = u >> 1 (32 inputs), feature half u & 1 (8 of the 16 output tiles) as f16
-// hi / lo planes x 2^10 in the A-fragment order of v_mfma_f32_16x16x32_f16,
-//   unit[((m * 2 + plane) * 64 + lane) * 8 + j] = plane(W[n = 16 (8 (u & 1) + m) + (lane & 15)][k(kb, lane >> 4, j)])
-// with k = 32 kb + 4 q + j for j < 4 and 32 kb + 16 + 4 q + (j - 4) for j >= 4: the slots a lane fills from result tiles 2 kb and
-// 2 kb + 1 of the previous product; unit 16 = the sh slab x 2^16 (it is added to the same accumulator by fp32 MFMAs); unit 17 = the gate
-// slab unchanged.
-__global__ void k_pack_gvp_chain_h(const float *__restrict__ chain, float *__restrict__ chain_h) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int u = idx >> 12, rem = idx & 4095;
-    if (u >= 18) return;
-    if (u >= 16) {
-        chain_h[idx] = (u == 16 ? 65536.0f : 1.0f) * chain[idx];
-        return;
+// f16x2 mode of the GVP chains (k_gvp_chain<16, 1>, k_gvp_node_chain<16, 1>): the chunk buffer of a GVP with 256 scalar outputs,
+// re-packed unit by unit (a unit = one 16-KB chunk of the LDS ring, 4096 floats).  Input (pack_chain_frag): chunk c = a 16-row
+// k-slab of to_feats_out as 16 x 256 floats [(mt * 64 + lane) * 4 + r] = W[16 mt + (lane & 15)][k0(c) + 4 (lane >> 4) + r], or
+// the gate slab [nt][lane][r] = Wg[lane & 15][16 nt + 4 (lane >> 4) + r].  Three unit kinds (all planes carry 2^10, hi / lo
+// halves of a weight):
+//   kind 0, a PAIR of x slabs (2 kb, 2 kb + 1) -> units 2 kb and 2 kb + 1: unit u holds output tiles 8 (u & 1) .. + 7 of the
+//           32-wide k-block kb in the A-fragment order of v_mfma_f32_16x16x32_f16,
+//           unit[((m * 2 + plane) * 64 + lane) * 8 + j], k = 32 kb + 4 q + j (j < 4) | 32 kb + 16 + 4 q + (j - 4): the eight slots
+//           a lane fills from result tiles 2 kb and 2 kb + 1 of the previous product;
+//   kind 1, ONE 16-row slab (rbf, sh) -> one unit in the A-fragment order of v_mfma_f32_16x16x16_f16,
+//           unit[((mt * 2 + plane) * 64 + lane) * 4 + j] = W[16 mt + (lane & 15)][k0 + 4 q + j];
+//   kind 2, the gate slab -> one unit, [kb][plane][lane][8] with the k-slots of kind 0.
+__global__ void k_pack_gvp_unit_h(const float *__restrict__ chain, float *__restrict__ chain_h, int kind, int unit, int src_chunk) {
+    const int rem = blockIdx.x * blockDim.x + threadIdx.x;       // < 4096
+    __fp16 *dst = reinterpret_cast<__fp16 *>(chain_h + (size_t)unit * 4096);
+    float w;
+    int at;
+    if (kind == 0) {
+        const int j = rem & 7, lane = (rem >> 3) & 63, m = rem >> 9;
+        const int mt = 8 * (unit & 1) + m;
+        w = chain[(size_t)(src_chunk + (j >> 2)) * 4096 + (mt * 64 + lane) * 4 + (j & 3)];
+        at = ((m * 2) * 64 + lane) * 8 + j;
+        const __fp16 hi = (__fp16)(H_SCALE_W_PACK * w);
+        dst[at] = hi;
+        dst[at + 64 * 8] = (__fp16)(H_SCALE_W_PACK * w - (float)hi);
+    } else if (kind == 1) {
+        const int j = rem & 3, lane = (rem >> 2) & 63, mt = rem >> 8;
+        w = chain[(size_t)src_chunk * 4096 + (mt * 64 + lane) * 4 + j];
+        at = ((mt * 2) * 64 + lane) * 4 + j;
+        const __fp16 hi = (__fp16)(H_SCALE_W_PACK * w);
+        dst[at] = hi;
+        dst[at + 64 * 4] = (__fp16)(H_SCALE_W_PACK * w - (float)hi);
+    } else {
+        if (rem >= 8 * 64 * 8) return;
+        const int j = rem & 7, lane = (rem >> 3) & 63, kb = rem >> 9;
+        w = chain[(size_t)src_chunk * 4096 + ((2 * kb + (j >> 2)) * 64 + lane) * 4 + (j & 3)];
+        at = ((kb * 2) * 64 + lane) * 8 + j;
+        const __fp16 hi = (__fp16)(H_SCALE_W_PACK * w);
+        dst[at] = hi;
+        dst[at + 64 * 8] = (__fp16)(H_SCALE_W_PACK * w - (float)hi);
     }
-    const int j = rem & 7, lane = (rem >> 3) & 63, m = rem >> 9;          // m < 8
-    const int kb = u >> 1, mt = 8 * (u & 1) + m;
-    const float w = H_SCALE_W_PACK * chain[(size_t)(2 * kb + (j >> 2)) * 4096 + (mt * 64 + lane) * 4 + (j & 3)];
-    const __fp16 hi = (__fp16)w;
-    const __fp16 lo = (__fp16)(w - (float)hi);
-    __fp16 *dst = reinterpret_cast<__fp16 *>(chain_h + (size_t)u * 4096);
-    dst[((m * 2 + 0) * 64 + lane) * 8 + j] = hi;
-    dst[((m * 2 + 1) * 64 + lane) * 8 + j] = lo;
 }
 
-kpd_status pack_gvp_chain_h(const float *chain, float *chain_h, hipStream_t st) {
-    hipLaunchKernelGGL(k_pack_gvp_chain_h, dim3(18 * 4096 / 256), dim3(256), 0, st, chain, chain_h);
+// chain_pos == 0 (head of a message chain): chunks [rbf | n_ht sh slabs | gate]; otherwise [16 x slabs | sh | gate]
+// the 256 x 256 node block of a split first Linear (k_gvp_proj_chain): 16 x slabs -> 16 units of kind 0
+kpd_status pack_gvp_proj_h(const float *wproj, float *wproj_h, hipStream_t st) {
+    for (int u = 0; u < 16; ++u) hipLaunchKernelGGL(k_pack_gvp_unit_h, dim3(16), dim3(256), 0, st, wproj, wproj_h, 0, u, 2 * (u >> 1));
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+kpd_status pack_gvp_chain_h(const float *chain, float *chain_h, int head, int n_ht, hipStream_t st) {
+    auto unit = [&](int kind, int u, int src) { hipLaunchKernelGGL(k_pack_gvp_unit_h, dim3(16), dim3(256), 0, st, chain, chain_h, kind, u, src); };
+    if (head) {
+        for (int c = 0; c < 1 + n_ht; ++c) unit(1, c, c);
+        unit(2, 1 + n_ht, 1 + n_ht);
+    } else {
+        for (int u = 0; u < 16; ++u) unit(0, u, 2 * (u >> 1));
+        unit(1, 16, 16);
+        unit(2, 17, 17);
+    }
     KPD_LAUNCH_CHECK();
     return KPD_OK;
 }
