@@ -19,6 +19,7 @@ struct LayerW {
     // per edge type
     float *wp_e[4], *wx_e[4], *b_e[4], *wr_e[4], *watt[4];
     float *chain[4], *wcol_e[4], *wcol_c[4];    // chained edge kernel: W2 chunks [coord 16 | edge 16], column 256 of W2
+    float *chain_h[4];                          //   the same chunks as f16 hi / lo units
     float *wp_c[4], *wx_c[4], *b_c[4], *wr_c[4], *w3[4];
     void *wh_e[4], *wh_c[4];                    // f16x2 mode: the finished wp_e / wp_c blocks as f16 hi / lo planes
     void *chh_p[2][NSLOT];                      //             the projection blocks ch_p
@@ -106,7 +107,7 @@ static kpd_status build_weight_arena(kpd_egnn *m) {
     bytes += (size_t)(64 * c.atom_nf + 64 + 64 * 256 + 256 + 2 * c.rec_nf * c.rec_nf + 2 * c.rec_nf +
                       2 * c.rec_nf * 256 + 256 + 2 * c.atom_nf * 256 + 2 * c.atom_nf + 2 * c.atom_nf * c.atom_nf +
                       c.atom_nf) * 4 + 64 * 256;
-    bytes += (size_t)c.n_layers * m->n_et * (32 * 4096 + 2 * HS + 64) * 4;
+    bytes += (size_t)c.n_layers * m->n_et * (2 * 32 * 4096 + 2 * HS + 128) * 4;
     bytes += (size_t)c.n_layers * m->n_et * 4 * (16 * 4096 + HS + 64) * 4;
     bytes += (size_t)c.n_layers * m->n_et * 2 * ((size_t)WH_HALVES * 2 + 256);
     bytes += (size_t)c.n_layers * m->n_et * 4 * ((size_t)CHH_HALVES * 2 + 256);
@@ -126,6 +127,7 @@ static kpd_status build_weight_arena(kpd_egnn *m) {
             w.wp_e[et] = wp(); w.wx_e[et] = vec(); w.b_e[et] = vec(); w.wr_e[et] = vec(); w.watt[et] = vec();
             w.wp_c[et] = wp(); w.wx_c[et] = vec(); w.b_c[et] = vec(); w.wr_c[et] = vec(); w.w3[et] = vec();
             w.chain[et] = A.take<float>(32 * 4096); w.wcol_e[et] = vec(); w.wcol_c[et] = vec();
+            w.chain_h[et] = A.take<float>(32 * 4096);
             w.wh_e[et] = A.take<unsigned short>(WH_HALVES); w.wh_c[et] = A.take<unsigned short>(WH_HALVES);
             for (int var = 0; var < 2; ++var) {
                 const int ss = kSrcSlot[et] + var, ds = kDstSlot[et] + var;
@@ -376,6 +378,7 @@ extern "C" kpd_status kpd_egnn_commit(kpd_egnn *m) {
             KPD_TRY(patch_bias_row(L.wp_c[et], L.wx_c[et], L.b_c[et], SILU_C, BIAS_K, nullptr));
             KPD_TRY(pack_f16_split(L.wp_e[et], L.wh_e[et], nullptr));      // the same finished blocks for the f16x2 mode
             KPD_TRY(pack_f16_split(L.wp_c[et], L.wh_c[et], nullptr));
+            KPD_TRY(pack_egnn_chain_h(L.chain[et], L.chain_h[et], nullptr));
         }
     for (LayerW &L : m->L)
         for (int nt = 0; nt < 2; ++nt)
@@ -592,13 +595,14 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
         ea.use_tanh = c.use_tanh; ea.coords_range = c.coords_range;
         ea.stamps = m->stamps;
         ea.tile_rows = tr;
-        ea.gemm_mode = (tr == TM && !use_chain && (m->h_parts & 1)) ? m->gemm_mode : 0;
+        ea.gemm_mode = (tr == TM && (m->h_parts & 1)) ? m->gemm_mode : 0;
         for (int et = 0; et < 4; ++et) {
             ea.src[et] = esrc[et]; ea.dst[et] = edst[et];
             ea.src_nt[et] = kSrcNt[et]; ea.dst_nt[et] = kDstNt[et]; ea.src_slot[et] = kSrcSlot[et]; ea.dst_slot[et] = kDstSlot[et];
             ea.wr_e[et] = L.wr_e[et]; ea.wr_c[et] = L.wr_c[et];
             ea.wp_e[et] = L.wp_e[et]; ea.wx_e[et] = L.wx_e[et]; ea.b_e[et] = L.b_e[et];
             ea.chain[et] = L.chain[et]; ea.wcol_e[et] = L.wcol_e[et]; ea.wcol_c[et] = L.wcol_c[et];
+            ea.chain_h[et] = L.chain_h[et];
             ea.wp_c[et] = L.wp_c[et]; ea.wx_c[et] = L.wx_c[et]; ea.b_c[et] = L.b_c[et];
             ea.wh_e[et] = L.wh_e[et]; ea.wh_c[et] = L.wh_c[et];
             ea.watt[et] = L.watt[et]; ea.w3[et] = L.w3[et];

@@ -44,6 +44,9 @@ __device__ __forceinline__ float reduce_q(float v) {      // sum over the four l
         t_prev_ = now_;                                                                    \
     }
 
+// HM = 1: the 256 x 256 part of both second Linears on v_mfma_f32_16x16x32_f16 (f16x2 mode): the ring carries
+// hi / lo units (pack_egnn_chain_h), the eight k-slots of a lane per 32-wide k-block are result features of tiles 2 kb, 2 kb + 1.
+template <int HM>
 __global__ __launch_bounds__(256, 2) void k_egnn_chain(EdgeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *O = smem;                                  // [64][ESO] message staging (aliases the weight ring)
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void k_egnn_chain(EdgeArgs a) {
     const int *__restrict__ esrc = a.src[et];
     const int *__restrict__ edst = a.dst[et];
 
-    const v4f *stream = reinterpret_cast<const v4f *>(a.chain[et]) + tid;
+    const v4f *stream = reinterpret_cast<const v4f *>(HM ? a.chain_h[et] : a.chain[et]) + tid;
     auto chunk_src = [&](int c) -> const v4f * { return stream + (size_t)c * ECH4; };
     ChunkRing<ECH4> ring;
     ring.init(smem, 2 * ENT, wave);
@@ -177,11 +180,55 @@ __global__ __launch_bounds__(256, 2) void k_egnn_chain(EdgeArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
         ECHAIN_STAMP(1 + 4 * br)
+        if constexpr (HM) {
 #pragma unroll
-        for (int nt = 0; nt < ENT; ++nt) {
-            const v4f *buf = ring.acquire(chunk_src);
-            chunk_gemm<ENT>(buf, x[nt], acc, lane, 4);
-            ring.release();
+            for (int mt = 0; mt < ENT; ++mt) acc[mt] = acc[mt] * (1.0f / H_UNSCALE);
+#pragma unroll
+            for (int kb = 0; kb < ENT / 2; ++kb) {
+                f32x4 xh, xl;
+                {
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+                    split_pair(H_SCALE_A * x[2 * kb][0], H_SCALE_A * x[2 * kb][1], h0, l0);
+                    split_pair(H_SCALE_A * x[2 * kb][2], H_SCALE_A * x[2 * kb][3], h1, l1);
+                    split_pair(H_SCALE_A * x[2 * kb + 1][0], H_SCALE_A * x[2 * kb + 1][1], h2, l2);
+                    split_pair(H_SCALE_A * x[2 * kb + 1][2], H_SCALE_A * x[2 * kb + 1][3], h3, l3);
+                    xh = __builtin_bit_cast(f32x4, u32x4{h0, h1, h2, h3});
+                    xl = __builtin_bit_cast(f32x4, u32x4{l0, l1, l2, l3});
+                }
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const f32x4 *wp = reinterpret_cast<const f32x4 *>(ring.acquire(chunk_src)) + lane;
+                    f32x4 w[2][8];          // two batches of four output tiles (hi, lo); batch 1 is read while batch 0 multiplies
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) w[0][i] = wp[i * 64];
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        if (b == 0) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) w[1][i] = wp[(8 + i) * 64];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) acc[8 * half + 4 * b + m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(w[b][2 * m + 1]), as_h8(xh), acc[8 * half + 4 * b + m], 0, 0, 0);
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) acc[8 * half + 4 * b + m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(w[b][2 * m]), as_h8(xl), acc[8 * half + 4 * b + m], 0, 0, 0);
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) acc[8 * half + 4 * b + m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(w[b][2 * m]), as_h8(xh), acc[8 * half + 4 * b + m], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    ring.release();
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < ENT; ++mt) acc[mt] = acc[mt] * H_UNSCALE;
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < ENT; ++nt) {
+                const v4f *buf = ring.acquire(chunk_src);
+                chunk_gemm<ENT>(buf, x[nt], acc, lane, 4);
+                ring.release();
+            }
         }
         ECHAIN_STAMP(2 + 4 * br)
         // m = SiLU(.) (pre-scaled: registers hold c m), head dot product over all 257 features
@@ -293,8 +340,15 @@ __global__ __launch_bounds__(256, 2) void k_egnn_chain(EdgeArgs a) {
 
 kpd_status launch_egnn_chain(const EdgeArgs &a, int tile_cap, hipStream_t st) {
     if (tile_cap == 0) return KPD_OK;
-    KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_egnn_chain), ECHAIN_FLOATS * 4));
-    hipLaunchKernelGGL(k_egnn_chain, dim3(8 * cdiv(tile_cap, 8)), dim3(256), ECHAIN_FLOATS * 4, st, a);
+    if (a.gemm_mode == 1) {
+        for (int et = 0; et < 4; ++et) KPD_REQUIRE(!a.chain[et] || a.chain_h[et], KPD_ERR_STATE, "edge type %d has no f16x2 chain units", et);
+        KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_egnn_chain<1>), ECHAIN_FLOATS * 4));
+        hipLaunchKernelGGL(k_egnn_chain<1>, dim3(8 * cdiv(tile_cap, 8)), dim3(256), ECHAIN_FLOATS * 4, st, a);
+        KPD_LAUNCH_CHECK();
+        return KPD_OK;
+    }
+    KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_egnn_chain<0>), ECHAIN_FLOATS * 4));
+    hipLaunchKernelGGL(k_egnn_chain<0>, dim3(8 * cdiv(tile_cap, 8)), dim3(256), ECHAIN_FLOATS * 4, st, a);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
 }

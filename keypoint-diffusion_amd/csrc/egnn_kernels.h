@@ -50,6 +50,7 @@ struct EdgeArgs {
     const float *watt[4];
     const float *w3[4];
     const float *chain[4];          // W2 of coord_mlp then edge_mlp as 16x16x4 A-fragment chunks (egnn_chain.hip)
+    const float *chain_h[4];        // the same 32 chunks as f16 hi / lo units (pack_egnn_chain_h) for k_egnn_chain<1>
     const float *wcol_e[4], *wcol_c[4];   // W2[:, 256]
     float *hn_main[4], *hn_cont[4];
     float *xn_main[4], *xn_cont[4];

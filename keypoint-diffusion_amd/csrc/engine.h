@@ -50,6 +50,7 @@ kpd_status pack_proj_f16_split(const float *chain, void *chh, hipStream_t st);
 // f16x2 mode of the GVP chains: the chunk buffer of a GVP with 256 scalar outputs re-packed unit by unit (pack.hip, k_pack_gvp_unit_h)
 kpd_status pack_gvp_chain_h(const float *chain, float *chain_h, int head, int n_ht, hipStream_t st);
 kpd_status pack_gvp_proj_h(const float *wproj, float *wproj_h, hipStream_t st);
+kpd_status pack_egnn_chain_h(const float *chain, float *chain_h, hipStream_t st);
 kpd_status patch_bias_row(float *wp, float *wx, const float *bias, float f, int k, hipStream_t st);
 // 16x16x4 MFMA A-operand fragments of a [n][k] matrix with element (n, k) at src[n * sn + k * sk]:
 // dst[(mt * 64 + lane) * 4 + r] = element(16 mt + (lane & 15), k_base + 4 (lane >> 4) + r), zero outside
