@@ -212,10 +212,23 @@ __device__ __forceinline__ void edge_gather_finish(const EdgeGather<NW> &g, cons
                                                    int lane) {
     constexpr int RPW = TM / NW;
     const f32x4 w0 = reinterpret_cast<const f32x4 *>(wr)[lane];
+    // the wave's RPW distances in RPW / 4 broadcast reads up front instead of a read + wait per row: -1.0 % on the kernel, same-call A/B
+    // (0.877 vs 0.886 ms).  The f16x2 kernel keeps the per-row form (edge_gather_finish_h, KPD_H_BATCH_D): there the batched read came
+    // with a first-forward deviation; every detector of that (profiles/tools/repro_*.py, cold_*_check.py, tests/test_cold_start_gpu.py)
+    // is clean for this kernel.  -DKPD_F_PER_ROW_D restores the old form.
+#ifndef KPD_F_PER_ROW_D
+    f32x4 dv[(RPW + 3) / 4];
+#pragma unroll
+    for (int i = 0; i < (RPW + 3) / 4; ++i) dv[i] = *reinterpret_cast<const f32x4 *>(s.d + wave * RPW + 4 * i);
+#endif
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
         const int r = wave * RPW + rr;
+#ifndef KPD_F_PER_ROW_D
+        f32x4 v = g.ps[rr] + g.pd[rr] + dv[rr >> 2][rr & 3] * w0;   // = c * pre-activation (P, w_r carry c)
+#else
         f32x4 v = g.ps[rr] + g.pd[rr] + s.d[r] * w0;        // = c * pre-activation (P, w_r carry c)
+#endif
         v[0] = silu_pre(v[0]); v[1] = silu_pre(v[1]); v[2] = silu_pre(v[2]); v[3] = silu_pre(v[3]);
         *reinterpret_cast<f32x4 *>(s.A + r * SA + 4 * lane) = v;
     }
