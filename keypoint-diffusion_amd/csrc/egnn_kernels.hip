@@ -207,6 +207,31 @@ __device__ __forceinline__ void edge_gather_issue(EdgeGather<NW> &g, const EdgeS
     }
 }
 
+// The same gathers issued before the tile's LDS row data exists: lane (l & (RPW - 1)) of every wave loads the endpoints of row
+// wave * RPW + (l & (RPW - 1)) itself, the row's (wave-uniform) offsets are read out of those lanes (v_readlane) and the loads go
+// out while wave 0 is still in its geometry chain -- the gather latency then overlaps phase 0 and its barrier.
+template <int NW>
+__device__ __forceinline__ void edge_gather_issue_early(EdgeGather<NW> &g, const int *__restrict__ esrc, const int *__restrict__ edst, int e0,
+                                                        int ne, const float *__restrict__ Ps, const float *__restrict__ Pd, int wave, int lane) {
+    constexpr int RPW = TM / NW;
+    const int rl = min(wave * RPW + (lane & (RPW - 1)), ne - 1);
+    const int iu = esrc[e0 + rl], iv = edst[e0 + rl];
+    const char *ps = reinterpret_cast<const char *>(Ps), *pd = reinterpret_cast<const char *>(Pd);
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+        const unsigned ou = (unsigned)__builtin_amdgcn_readlane(iu, rr) * PROW_B, ov = (unsigned)__builtin_amdgcn_readlane(iv, rr) * PROW_B;
+        g.ps[rr] = *reinterpret_cast<const f32x4 *>(ps + (ou + 16u * lane));
+        g.pd[rr] = *reinterpret_cast<const f32x4 *>(pd + (ov + 16u * lane));
+    }
+    // (the cross-lane reads stay outside the branch: a lane that the branch switches off supplies nothing to ds_bpermute)
+    const unsigned ou = (unsigned)__shfl(iu, (lane >> 2) & (RPW - 1)) * PROW_B, ov = (unsigned)__shfl(iv, (lane >> 2) & (RPW - 1)) * PROW_B;
+    if (lane < 4 * RPW && (lane & 3) < 2) {
+        const int c = lane & 3;
+        g.tps = *reinterpret_cast<const f32x4 *>(ps + (ou + 16u * (64 + c)));
+        g.tpd = *reinterpret_cast<const f32x4 *>(pd + (ov + 16u * (64 + c)));
+    }
+}
+
 template <int NW>
 __device__ __forceinline__ void edge_gather_finish(const EdgeGather<NW> &g, const EdgeSmem &s, const float *__restrict__ wr, int wave,
                                                    int lane) {
@@ -306,6 +331,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
     const int *__restrict__ esrc = a.src[et];
     const int *__restrict__ edst = a.dst[et];
 
+    const float *Ps = a.P[snt] + (size_t)a.src_slot[et] * HS;
+    const float *Pd = a.P[dnt] + (size_t)a.dst_slot[et] * HS;
+    // the feature branch's P rows start travelling before the geometry chain and the first barrier (-1.1 % on the kernel, same-call
+    // A/B: 0.859 vs 0.869 ms); -DKPD_F_LATE_GATHER restores the issue after the barrier
+#ifndef KPD_F_LATE_GATHER
+    EdgeGather<NW> ge;
+    edge_gather_issue_early<NW>(ge, esrc, edst, e0, ne, Ps, Pd, wave, lane);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     // phase 0: edge endpoints and geometry (dynamics.py:160-169, 209-217); head weights to LDS
     if (tid < TM) {
         const int e = e0 + min(tid, ne - 1);
@@ -348,8 +382,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
     lds_barrier();
     KPD_STAMP(0)
 
-    const float *Ps = a.P[snt] + (size_t)a.src_slot[et] * HS;
-    const float *Pd = a.P[dnt] + (size_t)a.dst_slot[et] * HS;
     const int first_is_cont = s.misc[0];
     const unsigned long long endmask =
         ((unsigned long long)(unsigned)s.misc[3] << 32) | (unsigned long long)(unsigned)s.misc[2];
@@ -358,7 +390,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
 
     // ---- feature messages: m = edge_mlp(f); msg_h = m * sigmoid(att(m)) (dynamics.py:111-112)
     const int abl = a.ablate;             // timing experiments only (KPD_EDGE_ABLATE): 1 no GEMM, 2 no A-build, 4 no epilogues
+#ifndef KPD_F_LATE_GATHER
+    if (!(abl & 2)) edge_gather_finish<NW>(ge, s, a.wr_e[et], wave, lane);
+#else
     if (!(abl & 2)) build_edge_A<NW>(s, Ps, Pd, a.wr_e[et], wave, lane);
+#endif
     lds_barrier();
     KPD_STAMP(1)
     acc_zero_w<NW>(acc);
