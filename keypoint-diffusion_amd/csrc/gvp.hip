@@ -240,6 +240,8 @@ extern "C" kpd_status kpd_gvp_commit(kpd_gvp *m) {
         for (auto &nt : conv)
             for (HostGvp &g : nt)
                 if (g.has_h() && g.chain_h) KPD_TRY(pack_gvp_chain_h(g.chain, g.chain_h, 0, g.n_ht(), nullptr));
+    for (HostGvp &g : m->noise)
+        if (g.has_h() && g.chain_h) KPD_TRY(pack_gvp_chain_h(g.chain, g.chain_h, 0, g.n_ht(), nullptr));
     KPD_HIP(hipDeviceSynchronize());
     m->committed = true;
     return KPD_OK;
@@ -408,6 +410,7 @@ extern "C" kpd_status kpd_gvp_forward(kpd_gvp *m, const kpd_batch *bt, const flo
     GvpNoiseArgs no;
     memset(&no, 0, sizeof(no));
     no.n = bt->n_lig; no.s = m->s[0]; no.v = m->v[0]; no.n_gvps = c.n_noise_gvps; no.S = S;
+    no.gemm_mode = S == 256 ? m->gemm_mode : 0;
     for (int j = 0; j < c.n_noise_gvps; ++j) no.g[j] = m->noise[j].dev();
     no.Wout = m->out_W; no.bout = m->out_b; no.F = c.n_lig_scalars; no.eps_h = eps_h; no.eps_x = eps_x;
     KPD_TRY(launch_gvp_noise(no, st));

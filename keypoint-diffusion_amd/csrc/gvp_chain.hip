@@ -810,7 +810,7 @@ __global__ __launch_bounds__(256, 2) void k_gvp_proj_chain(GvpProjArgs a) {
 // n_gvps - 1 GVPs of the generic kind, then the head GVP (S scalars, 16 vectors) -> (64 scalars, 1 vector, identity vector
 // activation), eps_h = Linear(64, F) of its scalars, eps_x = its vector.  16 ligand atoms per wave; the head GVP's weights
 // (NTS + 1 k-slabs of 4 output tiles, 4 gate tiles) are read straight from global memory: ligand atoms are few.
-template <int NTS>
+template <int NTS, int HM = 0>
 __global__ __launch_bounds__(256, 2) void k_gvp_noise_chain(GvpNoiseArgs a) {
     constexpr int S = 16 * NTS, CH4 = NTS * 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -820,7 +820,7 @@ __global__ __launch_bounds__(256, 2) void k_gvp_noise_chain(GvpNoiseArgs a) {
 
     auto chunk_src = [&](int c) -> const v4f * {
         const int stage = c / (NTS + 2), local = c - stage * (NTS + 2);
-        return reinterpret_cast<const v4f *>(a.g[stage].chain) + (size_t)local * CH4 + tid;
+        return reinterpret_cast<const v4f *>(HM ? a.g[stage].chain_h : a.g[stage].chain) + (size_t)local * CH4 + tid;
     };
     ChunkRing<CH4> ring;
     ring.init(smem, std::max(n_gen, 1) * (NTS + 2), wave);
@@ -841,8 +841,10 @@ __global__ __launch_bounds__(256, 2) void k_gvp_noise_chain(GvpNoiseArgs a) {
         for (int nt = 0; nt < NTS; ++nt) acc[nt] = *reinterpret_cast<const v4f *>(b0 + 16 * nt);
         ring.first();
 #pragma unroll 1
-        for (int k = 0; k < n_gen; ++k)
-            chain_generic_gvp<NTS>(ring, chunk_src, a.g[k], k + 1 < n_gen ? a.g[k + 1].b : nullptr, x, acc, Vc, lane, q);
+        for (int k = 0; k < n_gen; ++k) {
+            if constexpr (HM) chain_generic_gvp_h<NTS>(ring, chunk_src, a.g[k], k + 1 < n_gen ? a.g[k + 1].b : nullptr, x, acc, Vc, lane, q);
+            else chain_generic_gvp<NTS>(ring, chunk_src, a.g[k], k + 1 < n_gen ? a.g[k + 1].b : nullptr, x, acc, Vc, lane, q);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the ring's tail fetches must not outlive the workgroup's LDS
     }
 
@@ -971,7 +973,11 @@ kpd_status launch_gvp_noise(const GvpNoiseArgs &a, hipStream_t st) {
         KPD_REQUIRE(a.g[k].chain && a.g[k].whp && a.g[k].wup, KPD_ERR_STATE, "noise GVP %d was not prepared for the chained kernel", k);
     KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_noise_chain<16>), 3 * 16 * 64 * 16));
     KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_noise_chain<8>), 3 * 8 * 64 * 16));
-    if (a.S == 256) hipLaunchKernelGGL(k_gvp_noise_chain<16>, dim3(cdiv(a.n, TM)), dim3(256), 3 * 16 * 64 * 16, st, a);
+    if (a.S == 256 && a.gemm_mode == 1 && a.n_gvps > 1) {
+        for (int k = 0; k + 1 < a.n_gvps; ++k) KPD_REQUIRE(a.g[k].chain_h, KPD_ERR_STATE, "noise GVP %d has no f16x2 chunks", k);
+        KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_noise_chain<16, 1>), 3 * 16 * 64 * 16));
+        hipLaunchKernelGGL((k_gvp_noise_chain<16, 1>), dim3(cdiv(a.n, TM)), dim3(256), 3 * 16 * 64 * 16, st, a);
+    } else if (a.S == 256) hipLaunchKernelGGL(k_gvp_noise_chain<16>, dim3(cdiv(a.n, TM)), dim3(256), 3 * 16 * 64 * 16, st, a);
     else hipLaunchKernelGGL(k_gvp_noise_chain<8>, dim3(cdiv(a.n, TM)), dim3(256), 3 * 8 * 64 * 16, st, a);
     KPD_LAUNCH_CHECK();
     return KPD_OK;

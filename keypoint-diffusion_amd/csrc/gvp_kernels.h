@@ -87,6 +87,7 @@ struct GvpNoiseArgs {
     const float *Wout, *bout;     // [F][64], [F]
     int F;
     float *eps_h, *eps_x;
+    int gemm_mode;                // 0 exact fp32; 1 f16x2 split in the generic GVPs of the head
 };
 
 kpd_status launch_gvp_embed(const float *in, int n, int fin, const float *W, const float *b, const float *ln_w,
