@@ -439,6 +439,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
             for (int r0 = 0; r0 < TM; r0 += 16) {
                 if (r0 >= ne) break;
                 float v[16], w[16];
+#ifndef KPD_F_DST_PER_RUN
+                int dvv[16];
+                {
+                    typedef int i32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const i32x4 t = *reinterpret_cast<const i32x4 *>(s.dst + r0 + 4 * j);
+                        dvv[4 * j] = t[0]; dvv[4 * j + 1] = t[1]; dvv[4 * j + 2] = t[2]; dvv[4 * j + 3] = t[3];
+                    }
+                }
+#endif
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     w[i] = s.att[r0 + i];
@@ -448,7 +459,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
                 for (int i = 0; i < 16; ++i) {
                     run = fmaf(v[i], w[i], run);
                     if ((endmask >> (r0 + i)) & 1ull) {
+#ifndef KPD_F_DST_PER_RUN
+                        float *out = (piece == 0 && first_is_cont) ? hcont : hmain + ((unsigned)dvv[i] / (unsigned)(NSLOT * 4));
+#else
                         float *out = (piece == 0 && first_is_cont) ? hcont : hmain + ((unsigned)s.dst[r0 + i] / (unsigned)(NSLOT * 4));
+#endif
                         out[tid] = run;
                         run = 0.0f;
                         ++piece;
