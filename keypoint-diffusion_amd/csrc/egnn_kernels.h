@@ -11,7 +11,7 @@ constexpr int BIAS_K = 260;          // A-tile column that holds the constant 1 
 constexpr int ET_LL = 0, ET_KL = 1, ET_LK = 2, ET_KK = 3;
 constexpr int NT_LIG = 0, NT_KP = 1;
 
-constexpr int EDGE_LDS_BYTES = TM * SA * 4 + (TM * 2 + TM + 3 * TM + TM + 3 * TM + 4 * HS + 8) * 4;
+constexpr int EDGE_LDS_BYTES = TM * SA * 4 + (TM * 2 + TM + 3 * TM + TM + 3 * TM + 4 * HS + 8 + TM) * 4;   // ... misc[8], 64 column-256 values
 // k_egnn_edge_h: two f16 planes of 64 x 280 halves (= the T tile's region), row data, two fp32 head rows, W2 row 256 as 2 x 2 x 272 halves
 constexpr int EDGE_H_LDS_BYTES = 64 * 280 * 2 * 2 + (TM * 2 + TM + 3 * TM + TM + 3 * TM + 2 * HS + 8) * 4 + 2 * 2 * 272 * 2;
 constexpr int EDGE32_LDS_BYTES = 32 * SA * 4 + (32 * 2 + 32 + 3 * 32 + 32 + 3 * 32 + 2 * HS + 8) * 4;     // k_egnn_edge32

@@ -471,6 +471,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
                 }
             }
         }
+#ifndef KPD_F_COL256_EARLY
+        // column 256: the weighted values wait in LDS for the scan at the end of the kernel (with the coordinate messages)
+        if (wave == NW - 1) reinterpret_cast<float *>(s.misc + 8)[lane] = s.A[lane * SA + 256] * s.att[lane];
+#else
         // column 256: lane = row on the last wave, segmented inclusive scan across lanes
         if (wave == NW - 1) {
             const unsigned long long heads =
@@ -489,6 +493,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
                 out[256] = v;
             }
         }
+#endif
     }
     lds_barrier();
     KPD_STAMP(5)
@@ -533,22 +538,36 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
         const unsigned long long upto = lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull);
         const int start = 63 - __clzll((long long)((heads & upto) | 1ull));
         float vx = s.mx[3 * lane], vy = s.mx[3 * lane + 1], vz = s.mx[3 * lane + 2];
+#ifndef KPD_F_COL256_EARLY
+        float vh = reinterpret_cast<const float *>(s.misc + 8)[lane];
+#endif
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const float tx = __shfl_up(vx, off), ty = __shfl_up(vy, off), tz = __shfl_up(vz, off);
+#ifndef KPD_F_COL256_EARLY
+            const float th = __shfl_up(vh, off);
+#endif
             if (lane - off >= start) {
                 vx += tx;
                 vy += ty;
                 vz += tz;
+#ifndef KPD_F_COL256_EARLY
+                vh += th;
+#endif
             }
         }
         if ((endmask >> lane) & 1ull) {
             const int piece = __popcll(endmask & ((1ull << lane) - 1ull));
+            const unsigned dsto = (unsigned)s.dst[lane];
             float *out = (piece == 0 && first_is_cont) ? a.xn_cont[et] + (size_t)tile_in_et * 4
-                                                       : a.xn_main[et] + (size_t)((unsigned)s.dst[lane] / PROW_B) * 4;
+                                                       : a.xn_main[et] + (size_t)(dsto / PROW_B) * 4;
             out[0] = vx;
             out[1] = vy;
             out[2] = vz;
+#ifndef KPD_F_COL256_EARLY
+            float *oh = (piece == 0 && first_is_cont) ? a.hn_cont[et] + (size_t)tile_in_et * HS : a.hn_main[et] + (dsto / (unsigned)(NSLOT * 4));
+            oh[256] = vh;
+#endif
         }
     }
     KPD_STAMP(10)
