@@ -11,8 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-N_REC = [90, 140, 60]
-N_LIG = [[11, 17], [9], [14, 6, 12]]
+N_REC = [90, 140, 60, 75, 120]
+N_LIG = [[11, 17], [9], [14, 6, 12], [8, 8, 15], [10, 13]]          # 11 complexes: more than 8 ranks, fewer than 2 per rank
 SEED = 99
 T = 8
 
@@ -39,12 +39,17 @@ def pockets(device):
     return out
 
 
+def run_rank(dev):
+    """What one rank of the job does once its process group is up (the body shared by the process ranks below and by the
+    thread ranks of `tests/util.py::run_threaded_world`)."""
+    model = build_model(dev).use_complex_noise(SEED)
+    return model._sample(pockets(dev), N_LIG, rec_enc_batch_size=2, diff_batch_size=2)
+
+
 def main():
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    dev = torch.device('cuda:0')
-    model = build_model(dev).use_complex_noise(SEED)
-    samples = model._sample(pockets(dev), N_LIG, rec_enc_batch_size=2, diff_batch_size=2)
+    samples = run_rank(torch.device('cuda:0'))
     torch.save({'rank': rank, 'samples': samples}, f'{sys.argv[1]}.{rank}')
     dist.barrier()
     dist.destroy_process_group()

@@ -85,6 +85,84 @@ def test_c5_ragged_gvp_properties(cuda):
     assert util.rel_err(xr, x @ R.T) < 1e-4
 
 
+def test_c4_egnn_b512_properties(cuda):
+    """configs[3] at its stated batch on ONE GPU: egnn_all_atom, B = 512 x (300, 25) -- the batch the 8-GPU run shards 64 per
+    rank, here in one engine (3.2 M edges per layer): bitwise repeatability, an oracle slice taken from the far end of the batch,
+    batch independence against complexes run alone, E(3)."""
+    B = 512
+    gs, g = _batch(B, [300] * B, [25] * B)
+    model = synth.fill_state_dict_(LigRecDynamics(10, 10, graph_cutoffs=CUT, **util.EGNN_C2), 0).eval()
+    t = torch.linspace(0.05, 1.0, B)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(cuda)
+    gd = g.to(cuda)
+    with torch.no_grad():
+        h, x = model(gd, t.to(cuda), None)
+        h2, x2 = model(gd, t.to(cuda), None)
+    assert torch.equal(h, h2) and torch.equal(x, x2)
+    assert h.shape == (B * 25, 10) and torch.isfinite(h).all() and torch.isfinite(x).all()
+    # oracle on complexes 510, 511 (the end of the flat arrays: offsets beyond every B = 64 test)
+    sub = util.to_obatch(util.fixed_encode(G.batch(gs[510:])))
+    rh, rx = oegnn.egnn_dynamics_forward(sd, dict(util.EGNN_C2, graph_cutoffs=CUT), sub, t[510:])
+    util.assert_parity(h[510 * 25:], rh, [25, 25], 1e-4, 'eps_h')
+    util.assert_parity(x[510 * 25:], rx, [25, 25], 1e-4, 'eps_x', atol_rel=1e-5)
+    # batch independence: complexes 200 and 447 alone
+    for i in (200, 447):
+        g1 = util.fixed_encode(G.batch([gs[i]])).to(cuda)
+        with torch.no_grad():
+            h1, x1 = model(g1, t[i:i + 1].to(cuda), None)
+        assert util.rel_err(h1, h[25 * i:25 * (i + 1)]) < 1e-5 and util.rel_err(x1, x[25 * i:25 * (i + 1)]) < 1e-5
+    R, shift = _rot(11).to(cuda), torch.tensor([-6.0, 3.0, 9.5], device=cuda)
+    for nt in ('lig', 'kp'):
+        gd.nodes[nt].data['x_0'] = gd.nodes[nt].data['x_0'] @ R.T + shift
+    with torch.no_grad():
+        hr, xr = model(gd, t.to(cuda), None)
+    assert util.rel_err(hr, h) < 1e-4
+    assert util.rel_err(xr, x @ R.T) < 1e-4
+
+
+def test_c5_ragged_gvp_b512_properties(cuda):
+    """configs[4] at its stated batch on ONE GPU: gvp_all_atom, B = 512 ragged pockets (150-600 atoms, ligands 15-35 atoms):
+    bitwise repeatability, an oracle slice (the two smallest pockets, wherever they fall in the batch), batch independence, E(3)."""
+    from oracle import gvp as ogvp
+    gen = torch.Generator().manual_seed(21)
+    B = 512
+    n_rec = torch.randint(150, 601, (B,), generator=gen).tolist()
+    n_lig = torch.randint(15, 36, (B,), generator=gen).tolist()
+    gs, g = _batch(B, n_rec, n_lig, v=16)
+    model = synth.fill_state_dict_(LigRecDynamicsGVP(10, 10, graph_cutoffs=CUT, **GVP_ALL_ATOM), 1).eval()
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(cuda)
+    t = torch.linspace(0.1, 1.0, B)
+    gd = g.to(cuda)
+    off = [0]
+    for n in n_lig:
+        off.append(off[-1] + n)
+    with torch.no_grad():
+        h, x = model(gd, t.to(cuda), None)
+        h2, x2 = model(gd, t.to(cuda), None)
+    assert torch.equal(h, h2) and torch.equal(x, x2)
+    assert h.shape == (off[-1], 10) and torch.isfinite(h).all() and torch.isfinite(x).all()
+    order = sorted(range(B), key=lambda i: n_rec[i])
+    for i in order[:2]:                                               # oracle on the two smallest pockets, each alone
+        sub = util.to_obatch(util.fixed_encode(G.batch([gs[i]]), n_vec=16))
+        rh, rx = ogvp.gvp_dynamics_forward(sd, dict(GVP_ALL_ATOM, graph_cutoffs=CUT), sub, t[i:i + 1])
+        util.assert_parity(h[off[i]:off[i + 1]], rh, [n_lig[i]], 1e-4, f'eps_h[{i}]')
+        util.assert_parity(x[off[i]:off[i + 1]], rx, [n_lig[i]], 1e-4, f'eps_x[{i}]', atol_rel=1e-5)
+    for i in (order[-1], 300):                                        # batch independence: the largest pocket and one from the middle
+        g1 = util.fixed_encode(G.batch([gs[i]]), n_vec=16).to(cuda)
+        with torch.no_grad():
+            h1, x1 = model(g1, t[i:i + 1].to(cuda), None)
+        assert util.rel_err(h1, h[off[i]:off[i + 1]]) < 1e-5 and util.rel_err(x1, x[off[i]:off[i + 1]]) < 1e-5
+    R, shift = _rot(13).to(cuda), torch.tensor([5.0, -2.0, 7.0], device=cuda)
+    for nt in ('lig', 'kp'):
+        gd.nodes[nt].data['x_0'] = gd.nodes[nt].data['x_0'] @ R.T + shift
+    with torch.no_grad():
+        hr, xr = model(gd, t.to(cuda), None)
+    assert util.rel_err(hr, h) < 1e-4
+    assert util.rel_err(xr, x @ R.T) < 1e-4
+
+
 def test_c3_gvp_40kp_full_batch_properties(cuda):
     """configs[2]: gvp_40kp, B = 64 x (300 receptor atoms -> 40 learned keypoints, 25 ligand atoms): learned GVP receptor
     encoder -> GVP denoiser (trained_models/gvp_40kp/config.yml:51-62, 90-102), through the size-independent properties of the

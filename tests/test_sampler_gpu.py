@@ -187,10 +187,22 @@ def test_step_graph_replays_the_eager_step(cuda, arch):
     assert [p.shape for p in pos] == [(6, 3), (9, 3)] and all(torch.isfinite(p).all() for p in pos)
 
 
-def test_sample_sharded_two_ranks_equals_single_process(cuda, tmp_path):
-    """`KeypointDiffusion._sample` under a 2-rank process group (both ranks on cuda:0, gloo): every rank returns ALL ligands in
-    input order, equal to the single-process run of the same noise seed up to fp32 summation order (SURVEY.md 8(e),
-    models/ligand_diffuser.py:292-324)."""
+def _assert_samples_equal(got, ref, tol=1e-3):
+    assert len(got) == len(ref)
+    for a, b in zip(got, ref):
+        assert [tuple(p.shape) for p in a['positions']] == [tuple(p.shape) for p in b['positions']]
+        for x, fx in zip(a['positions'], b['positions']):
+            assert util.rel_err(x, fx) < tol
+        for h, fh in zip(a['features'], b['features']):
+            assert util.rel_err(h, fh) < tol
+
+
+@pytest.mark.parametrize('world', [2, 5])
+def test_sample_sharded_process_ranks_equal_single_process(cuda, tmp_path, world):
+    """`KeypointDiffusion._sample` under a process group of `world` rank PROCESSES (all on cuda:0, gloo): every rank returns ALL
+    ligands in input order, equal to the single-process run of the same noise seed up to fp32 summation order (SURVEY.md 8(e),
+    models/ligand_diffuser.py:292-324).  Five is the most a GPU box admits next to the test runner (six GPU-holding processes);
+    the eight-rank job of configs[3] / configs[4] is rehearsed with thread ranks below."""
     import os
     import socket
     import subprocess
@@ -205,20 +217,24 @@ def test_sample_sharded_two_ranks_equals_single_process(cuda, tmp_path):
     out = str(tmp_path / 'shard')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, '-m', 'tests.sharded_worker', out], cwd=root, env=env))
     for p in procs:
         assert p.wait(timeout=600) == 0
-    for r in range(2):
-        got = torch.load(f'{out}.{r}')['samples']
-        assert len(got) == len(ref)
-        for a, b in zip(got, ref):
-            assert [tuple(p.shape) for p in a['positions']] == [tuple(p.shape) for p in b['positions']]
-            for x, fx in zip(a['positions'], b['positions']):
-                assert util.rel_err(x, fx) < 1e-3
-            for h, fh in zip(a['features'], b['features']):
-                assert util.rel_err(h, fh) < 1e-3
+    for r in range(world):
+        _assert_samples_equal(torch.load(f'{out}.{r}')['samples'], ref)
+
+
+def test_sample_sharded_world8_thread_ranks_equal_single_process(cuda):
+    """The eight-rank job (configs[3] / configs[4] run 8 ranks) on ONE card: eight thread ranks, each with its own model and
+    engines on cuda:0, run `_sample` under torch's in-process process group; every rank returns every ligand in input order,
+    equal to the single-process run.  (8 complexes of the 11 go one per rank, three ranks take two.)"""
+    from . import sharded_worker as W
+    model = W.build_model(cuda).use_complex_noise(W.SEED)
+    ref = model._sample(W.pockets(cuda), W.N_LIG, rec_enc_batch_size=2, diff_batch_size=2)
+    for got in util.run_threaded_world(8, lambda rank: W.run_rank(cuda)):
+        _assert_samples_equal(got, ref)
 
 
 def test_step_graph_refuses_to_replay_after_the_engine_changed(cuda):

@@ -80,3 +80,44 @@ def assert_parity(got: torch.Tensor, ref: torch.Tensor, counts=None, tol: float 
         assert pc < tol, f'{what}: per-complex rel err {pc:.3e} >= {tol}'
     ex = elementwise_excess(got, ref, rtol=tol, atol_rel=atol_rel)
     assert ex <= 1.0, f'{what}: allclose(rtol={tol}, atol={atol_rel} max|ref|) violated by a factor {ex:.2f}'
+
+
+def run_threaded_world(world: int, fn, timeout: float = 600.0):
+    """`fn(rank)` on `world` ranks that are THREADS of this process, joined by torch's in-process 'threaded' process group
+    (torch.testing._internal.distributed.multi_threaded_pg: every collective of torch.distributed works, each thread sees its
+    own rank / world size).  This is how more ranks than the GPU box admits GPU-holding processes (6, the test runner
+    included) are rehearsed on one card.  Returns [fn(0), ..., fn(world - 1)]; re-raises the first rank failure."""
+    import threading
+    import torch.distributed as dist
+    from torch.testing._internal.distributed import multi_threaded_pg as mt
+    mt._install_threaded_pg()
+    torch._C._distributed_c10d._set_thread_isolation_mode(True)
+    store = dist.HashStore()
+    results, errors = [None] * world, []
+
+    def worker(rank):
+        try:
+            dist.init_process_group(backend='threaded', rank=rank, world_size=world, store=store)
+            try:
+                results[rank] = fn(rank)
+                dist.barrier()
+            finally:
+                dist.destroy_process_group()
+        except BaseException as ex:                                   # noqa: B036 -- wake the other ranks, report below
+            errors.append((rank, ex))
+            mt.ProcessLocalGroup.exception_handle(ex)
+
+    threads = [threading.Thread(target=worker, args=(r,), daemon=True) for r in range(world)]
+    try:
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join(timeout)
+            assert not th.is_alive(), 'a thread rank did not finish'
+    finally:
+        torch._C._distributed_c10d._set_thread_isolation_mode(False)
+        mt.ProcessLocalGroup.reset()
+        mt._uninstall_threaded_pg()
+    if errors:
+        raise errors[0][1]
+    return results
