@@ -84,6 +84,8 @@ struct kpd_egnn {
     int edge_chain = -1;                       // 1: register-chained edge kernel (egnn_chain.hip); -1: KPD_EDGE_CHAIN or staged
     // optional HIP-event timing of the dominant kernel (k_egnn_edge), for bench.py's roofline
     unsigned long long *stamps = nullptr;      // device [16], diagnostics (kpd_egnn_debug_state "stamps=1")
+    float *edge_dbg = nullptr;                 // per-row taps of the f16x2 edge kernel's coordinate branch ("edge_dbg=1", -DKPD_EDGE_DBG builds)
+    size_t edge_dbg_floats = 0;
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;
     size_t prof_used = 0;
@@ -115,6 +117,7 @@ static kpd_status build_weight_arena(kpd_egnn *m) {
     bytes += 1 << 20;
     kpd_status st = m->warena.reserve(bytes);
     if (st != KPD_OK) return st;
+    m->warena.poison_at = 2;          // packed weights: poisoned only at KPD_POISON >= 2 (engine.h)
     Arena &A = m->warena;
     m->L.assign(c.n_layers, LayerW());
     auto wp = [&]() { return A.take<float>(WP_FLOATS); };
@@ -210,6 +213,7 @@ extern "C" kpd_status kpd_egnn_create(const kpd_egnn_config *cfg, kpd_egnn **out
 extern "C" void kpd_egnn_destroy(kpd_egnn *m) {
     if (!m) return;
     for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
+    if (m->edge_dbg) (void)hipFree(m->edge_dbg);
     m->warena.release();
     m->ws.release();
     delete m;
@@ -408,6 +412,10 @@ extern "C" kpd_status kpd_egnn_reserve(kpd_egnn *m, int32_t max_B, int32_t max_n
     const long cap_ll_l = (long)max_n_lig * std::min(max_lig_pg - 1, m->cfg.ll_k > 0 ? m->cfg.ll_k : 200);
     const long cap_kl_l = (long)max_n_kp * (m->cfg.kl_k > 0 ? m->cfg.kl_k : std::min(max_lig_pg, 100));
     KPD_REQUIRE(cap_ll_l < (1l << 30) && cap_kl_l < (1l << 30), KPD_ERR_CAPACITY, "edge capacity overflows int32");
+    // the edge kernels address a node's row of P by a 32-bit byte offset (node * NSLOT * HS * 4)
+    KPD_REQUIRE(((long)std::max(max_n_lig, max_n_kp) + TM) * NSLOT * HS * 4 < (1l << 32), KPD_ERR_CAPACITY,
+                "batch of %d / %d nodes exceeds the 4 GB addressable per node type by the edge kernel's 32-bit row offsets (split the batch)",
+                max_n_lig, max_n_kp);
     const int cap_ll = std::max<long>(cap_ll_l, 1), cap_kl = std::max<long>(cap_kl_l, 1);
     const int E_cap[4] = {cap_ll, cap_kl, cap_kl, std::max(max_n_kk, 1)};
     int tiles[4], tile_cap = 0;
@@ -435,13 +443,13 @@ extern "C" kpd_status kpd_egnn_reserve(kpd_egnn *m, int32_t max_B, int32_t max_n
     for (int nt = 0; nt < 2; ++nt) {
         m->h[nt] = W.take<float>((size_t)(n[nt] + TM) * HS);          // + one tile: kernels touch whole tiles
         m->x[nt] = W.take<float>((size_t)n[nt] * 3);
-        m->P[nt] = W.take<float>((size_t)(n[nt] + TM) * NSLOT * HS);
+        m->P[nt] = W.take_rows((size_t)(n[nt] + TM) * NSLOT, HS, HW);
         m->bidx[nt] = W.take<int>(n[nt]);
         m->z[nt] = W.take<float>(max_B);
     }
     for (int et = 0; et < 4; ++et) {
-        m->hn_main[et] = W.take<float>((size_t)n[kDstNt[et]] * HS);
-        m->hn_cont[et] = W.take<float>((size_t)tiles[et] * HS);
+        m->hn_main[et] = W.take_rows(n[kDstNt[et]], HS, HW);
+        m->hn_cont[et] = W.take_rows(tiles[et], HS, HW);
         m->xn_main[et] = W.take<float>((size_t)n[kDstNt[et]] * 4);
         m->xn_cont[et] = W.take<float>((size_t)tiles[et] * 4);
         m->tiles_et_cap[et] = tiles[et];
@@ -594,6 +602,7 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
         ea.x[0] = m->x[0]; ea.x[1] = m->x[1]; ea.P[0] = m->P[0]; ea.P[1] = m->P[1];
         ea.use_tanh = c.use_tanh; ea.coords_range = c.coords_range;
         ea.stamps = m->stamps;
+        ea.dbg = m->edge_dbg;
         ea.tile_rows = tr;
         ea.gemm_mode = (tr == TM && (m->h_parts & 1)) ? m->gemm_mode : 0;
         for (int et = 0; et < 4; ++et) {
@@ -693,6 +702,17 @@ extern "C" kpd_status kpd_egnn_debug_state(kpd_egnn *m, const char *what, float 
         return KPD_OK;
     } else if (w.rfind("edge_chain=", 0) == 0) {   // A/B switch between the two edge kernels (tests, profiles/tools)
         m->edge_chain = atoi(w.c_str() + 11);
+        return KPD_OK;
+    } else if (w == "edge_dbg=1") {          // allocate the per-row tap buffer for the current workspace ([tile_cap][64][4] floats)
+        KPD_REQUIRE(m->tile_cap > 0, KPD_ERR_STATE, "edge_dbg=1 needs a reserved workspace");
+        if (m->edge_dbg) (void)hipFree(m->edge_dbg);
+        m->edge_dbg_floats = (size_t)m->tile_cap * (TM * 4 + 3 * 4 * 64 * 12);      // per-row taps, then per-tile operand taps of rows 0..2 of every wave
+        KPD_HIP(hipMalloc(reinterpret_cast<void **>(&m->edge_dbg), m->edge_dbg_floats * 4));
+        KPD_HIP(hipMemsetAsync(m->edge_dbg, 0, m->edge_dbg_floats * 4, st));
+        return KPD_OK;
+    } else if (w == "edge_dbg") {
+        KPD_REQUIRE(m->edge_dbg && (size_t)n_floats <= m->edge_dbg_floats, KPD_ERR_INVALID, "edge_dbg not enabled or request too large");
+        KPD_HIP(hipMemcpyAsync(out, m->edge_dbg, (size_t)n_floats * 4, hipMemcpyDeviceToDevice, st));
         return KPD_OK;
     } else if (w == "stamps=1") {            // start accumulating per-phase cycle sums of the edge kernel
         if (!m->stamps) KPD_HIP(hipMalloc(reinterpret_cast<void **>(&m->stamps), 32 * sizeof(unsigned long long)));

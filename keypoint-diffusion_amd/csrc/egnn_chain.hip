@@ -340,6 +340,7 @@ __global__ __launch_bounds__(256, 2) void k_egnn_chain(EdgeArgs a) {
 
 kpd_status launch_egnn_chain(const EdgeArgs &a, int tile_cap, hipStream_t st) {
     if (tile_cap == 0) return KPD_OK;
+    if (poison_level() >= 1) KPD_TRY(poison_lds(st));      // debug only (engine.h)
     if (a.gemm_mode == 1) {
         for (int et = 0; et < 4; ++et) KPD_REQUIRE(!a.chain[et] || a.chain_h[et], KPD_ERR_STATE, "edge type %d has no f16x2 chain units", et);
         KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_egnn_chain<1>), ECHAIN_FLOATS * 4));
@@ -670,6 +671,7 @@ __global__ __launch_bounds__(512, 1) void k_proj_ws_h(ProjWs qa) {
 kpd_status launch_proj_chain(const ProjPair &p, hipStream_t st) {
     const int tiles = p.tiles0 + cdiv(p.nt[1].n, TM);
     const int slots = std::max(p.n_slots[0], p.n_slots[1]);
+    if (poison_level() >= 1) KPD_TRY(poison_lds(st));      // debug only (engine.h)
     if (tiles == 0 || slots == 0) return KPD_OK;
     for (int nt = 0; nt < 2; ++nt)
         for (int s = 0; s < p.n_slots[nt]; ++s)

@@ -61,6 +61,7 @@ struct EdgeArgs {
     int gemm_mode;                  // 0: exact fp32 MFMA (contract path), 1: f16x2 split products (opt-in)
     int tile_rows;                  // edges per tile: 64 (k_egnn_edge<NW>, k_egnn_chain) or 32 (k_egnn_edge32)
     int ablate;                     // timing experiments only (KPD_EDGE_ABLATE), 0 in production
+    float *dbg;                     // [tiles][64][4] per-row taps of the coordinate branch (builds with -DKPD_EDGE_DBG only; "edge_dbg=1")
 };
 
 struct NodeArgs {

@@ -607,18 +607,32 @@ __device__ __forceinline__ EdgeSmem edge_smem_h(float *smem) {
 #endif
 template <int NW, bool BATCH_D>
 __device__ __forceinline__ void edge_gather_finish_h(const EdgeGather<NW> &g, const EdgeSmem &s, _Float16 *Ah, const float *__restrict__ wr,
-                                                     int wave, int lane) {
+                                                     int wave, int lane, float *dbg2 = nullptr) {
     constexpr int RPW = TM / NW;
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     const f32x4 w0 = reinterpret_cast<const f32x4 *>(wr)[lane];
     // the wave's RPW distances in one batch of broadcast reads (a read + wait per row costs an LDS round trip each, and the per-row
     // addresses were being kept live -- spilled -- across the GEMM)
     f32x4 dv[RPW / 4];
+#ifdef KPD_HZ_VM0      // hazard hunt (profiles/tools/hz_variant.sh): every gathered row has landed before the first one is consumed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 #pragma unroll
     for (int i = 0; i < RPW / 4; ++i) dv[i] = BATCH_D ? *reinterpret_cast<const f32x4 *>(s.d + wave * RPW + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef KPD_HZ_LGKM0    // hazard hunt: the batched distances have landed before anything else is issued
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
         const int r = wave * RPW + rr;
+#ifdef KPD_EDGE_DBG
+        if (dbg2 && rr < 3) {       // the operands exactly as this row consumes them
+            float *o = dbg2 + ((size_t)(rr * 4 + wave) * 64 + lane) * 12;
+            *reinterpret_cast<f32x4 *>(o) = g.ps[rr];
+            *reinterpret_cast<f32x4 *>(o + 4) = g.pd[rr];
+            o[8] = BATCH_D ? dv[rr >> 2][rr & 3] : s.d[r]; o[9] = w0[0]; o[10] = __builtin_bit_cast(float, s.src[r]); o[11] = __builtin_bit_cast(float, s.dst[r]);
+        }
+#endif
         f32x4 v = g.ps[rr] + g.pd[rr] + (BATCH_D ? dv[rr >> 2][rr & 3] : s.d[r]) * w0;
         v[0] = silu_pre_x64(v[0]); v[1] = silu_pre_x64(v[1]); v[2] = silu_pre_x64(v[2]); v[3] = silu_pre_x64(v[3]);
         unsigned h0, h1, l0, l1;
@@ -747,8 +761,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge_h(EdgeAr
     KPD_STAMP(1)
     acc_zero_w<NW>(acc);
     ex = row_dot_h2<TPR>(Ah, wxs, tid);
+#ifndef KPD_HZ_NOGEMM   // hazard hunt: the kernel without its matrix products (results meaningless, run-to-run equality still telling)
     if constexpr (NW == 4) gemm_rows64_h(Ah, a.wh_e[et], acc, wave, lane);
     else gemm_rows64_h8(Ah, a.wh_e[et], acc, wave, lane);
+#endif
     unscale_acc(acc, ex);
     lds_barrier();
     KPD_STAMP(2)
@@ -823,13 +839,19 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge_h(EdgeAr
     KPD_STAMP(5)
 
     // ---- coordinate messages: msg_x = tanh(coord_mlp(f)) * x_diff * range (dynamics.py:113-120)
+#ifdef KPD_EDGE_DBG
+    edge_gather_finish_h<NW, KPD_H_BATCH_D>(gc, s, Ah, a.wr_c[et], wave, lane, a.dbg ? a.dbg + (size_t)a.meta[8] * TM * 4 + (size_t)tile * (3 * 4 * 64 * 12) : nullptr);
+#else
     edge_gather_finish_h<NW, KPD_H_BATCH_D>(gc, s, Ah, a.wr_c[et], wave, lane);
+#endif
     lds_barrier();
     KPD_STAMP(6)
     acc_zero_w<NW>(acc);
     ex = row_dot_h2<TPR>(Ah, wxs + 544, tid);
+#ifndef KPD_HZ_NOGEMM   // hazard hunt: the kernel without its matrix products (results meaningless, run-to-run equality still telling)
     if constexpr (NW == 4) gemm_rows64_h(Ah, a.wh_c[et], acc, wave, lane);
     else gemm_rows64_h8(Ah, a.wh_c[et], acc, wave, lane);
+#endif
     unscale_acc(acc, ex);
     lds_barrier();
     KPD_STAMP(7)
@@ -844,6 +866,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge_h(EdgeAr
             dot = fmaf(s.A[row * SA + 256], s.wv[HS + 256], dot);
             float c = a.use_tanh ? tanhf(dot) * a.coords_range : dot;
             if (row >= ne) c = 0.0f;
+#ifdef KPD_EDGE_DBG
+            if (a.dbg) {
+                float *o = a.dbg + ((size_t)tile * TM + row) * 4;
+                o[0] = dot; o[1] = s.d[row]; o[2] = s.A[row * SA + 256]; o[3] = s.A[row * SA + 7];
+            }
+#endif
             s.mx[3 * row] = c * s.xd[3 * row];
             s.mx[3 * row + 1] = c * s.xd[3 * row + 1];
             s.mx[3 * row + 2] = c * s.xd[3 * row + 2];
@@ -1848,6 +1876,7 @@ kpd_status launch_decode(const float *h, const float *x, const float *x0, int n,
 
 kpd_status launch_egnn_edge(const EdgeArgs &a, int tile_cap, hipStream_t st) {
     if (tile_cap == 0) return KPD_OK;
+    if (poison_level() >= 1) KPD_TRY(poison_lds(st));      // debug only (engine.h)
     // KPD_EDGE_LDS_PAD (diagnostics): extra dynamic LDS to force one workgroup per CU
     static const int pad = getenv("KPD_EDGE_LDS_PAD") ? atoi(getenv("KPD_EDGE_LDS_PAD")) : 0;
     // 4 waves per workgroup by default: 256 VGPRs per lane leave room to keep the coordinate branch's gathered P rows in
@@ -1891,6 +1920,7 @@ kpd_status launch_egnn_edge(const EdgeArgs &a, int tile_cap, hipStream_t st) {
 kpd_status launch_node_layer(const NodeLayerPair &p, hipStream_t st) {
     const int tiles = p.tiles0 + cdiv(p.nt[1].u.n, TN);
     if (tiles == 0) return KPD_OK;
+    if (poison_level() >= 1) KPD_TRY(poison_lds(st));      // debug only (engine.h)
     // KPD_NODE_LDS_PAD (diagnostics): extra dynamic LDS to lower the number of co-resident workgroups
     static const int pad = getenv("KPD_NODE_LDS_PAD") ? atoi(getenv("KPD_NODE_LDS_PAD")) : 0;
     static const int dbg = getenv("KPD_NODE_ABLATE") ? atoi(getenv("KPD_NODE_ABLATE")) : 0;

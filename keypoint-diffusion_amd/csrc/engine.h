@@ -1,5 +1,7 @@
 // Internal declarations shared between the translation units of libkpd_hip.so.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace kpd {
@@ -21,10 +23,24 @@ kpd_status launch_radius_bipartite(const float *x, const int *x_ptr, int n_x, in
                                    int max_y, int B, float r, int max_nn, int *per_graph_tmp, int *scratch2, int *off_tmp, int *xm_src,
                                    int *xm_dst, int *xm_rowptr, int *ym_src, int *ym_dst, int *ym_rowptr, hipStream_t st);
 
+// Debug poisoning (environment KPD_POISON, read once; 0 = off, the production setting):
+//   >= 1  every float buffer carved out of a WORKSPACE arena is filled with NaNs instead of the arena's zeros, and the LDS of every
+//         CU is overwritten with NaNs before each dominant-kernel launch (poison_lds): a read of memory the current forward has not
+//         written -- stale arena contents, pads assumed zero, LDS left by an earlier workgroup -- surfaces as a NaN in the output
+//         instead of as a value that happens to equal the previous forward's;
+//   >= 2  the packed-weight arenas are poisoned too (shows which pads of the packed blocks rely on the arena's zero fill).
+// Integer buffers keep the zero fill (a poisoned index would fault).  tests/test_poison_gpu.py runs the denoisers this way.
+int poison_level();
+bool poison_selected();      // KPD_POISON_ONLY=<i>: poison only the i-th float buffer carved in this process (bisecting a NaN to its buffer)
+void poison_floats(void *p, size_t bytes);
+void zero_pad_columns(float *p, size_t rows, int stride, int valid);
+kpd_status poison_lds(hipStream_t st);
+
 // Grow-only device arena: one hipMalloc, carved with 256-B alignment, zero-filled.
 struct Arena {
     char *base = nullptr;
     size_t cap = 0, used = 0;
+    int poison_at = 1;          // KPD_POISON level from which this arena's float buffers are NaN-filled (weights: 2)
     kpd_status reserve(size_t bytes);
     void release();
     void reset() { used = 0; }
@@ -34,6 +50,14 @@ struct Arena {
         if (used + bytes > cap) return nullptr;
         T *p = reinterpret_cast<T *>(base + used);
         used += bytes;
+        if (std::is_floating_point<T>::value && poison_level() >= poison_at && poison_selected()) poison_floats(p, bytes);
+        return p;
+    }
+    // rows x stride floats of which only the first `valid` columns of a row are ever written: the K-padding columns are part of
+    // the layout's contract (they must read as zero: they meet zero weight rows in a GEMM) and keep the zero fill under poisoning
+    float *take_rows(size_t rows, int stride, int valid) {
+        float *p = take<float>(rows * stride);
+        if (p && poison_level() >= poison_at) zero_pad_columns(p, rows, stride, valid);
         return p;
     }
 };

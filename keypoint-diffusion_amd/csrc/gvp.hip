@@ -89,6 +89,7 @@ extern "C" kpd_status kpd_gvp_create(const kpd_gvp_config *cfg, kpd_gvp **out) {
         delete m;
         return st;
     }
+    m->warena.poison_at = 2;          // packed weights: poisoned only at KPD_POISON >= 2 (engine.h)
     Arena &A = m->warena;
     m->msg.resize(C); m->upd.resize(C); m->ln1w.resize(C); m->ln1b.resize(C); m->ln2w.resize(C); m->ln2b.resize(C);
     for (int i = 0; i < C; ++i) {

@@ -923,6 +923,7 @@ __global__ __launch_bounds__(256, 2) void k_gvp_noise_chain(GvpNoiseArgs a) {
 
 kpd_status launch_gvp_edge(const GvpEdgeArgs &a, int tile_cap, hipStream_t st) {
     if (tile_cap == 0) return KPD_OK;
+    if (poison_level() >= 1) KPD_TRY(poison_lds(st));      // debug only (engine.h)
     for (int et = 0; et < 4; ++et)
         if (a.src[et])
             for (int k = 0; k < a.n_gvps; ++k)
@@ -949,6 +950,7 @@ kpd_status launch_gvp_edge(const GvpEdgeArgs &a, int tile_cap, hipStream_t st) {
 
 kpd_status launch_gvp_proj(const GvpProjArgs &a, hipStream_t st) {
     if (a.n_slots == 0 || a.tiles_first[a.n_slots] == 0) return KPD_OK;
+    if (poison_level() >= 1) KPD_TRY(poison_lds(st));      // debug only (engine.h)
     KPD_REQUIRE(a.S == 256 || a.S == 128, KPD_ERR_INVALID, "gvp projection kernel: S=%d (supported 128, 256)", a.S);
     KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_proj_chain<16>), 4 * 16 * 64 * 16));
     KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_proj_chain<8>), 4 * 8 * 64 * 16));
@@ -965,6 +967,7 @@ kpd_status launch_gvp_proj(const GvpProjArgs &a, hipStream_t st) {
 
 kpd_status launch_gvp_noise(const GvpNoiseArgs &a, hipStream_t st) {
     if (a.n == 0) return KPD_OK;
+    if (poison_level() >= 1) KPD_TRY(poison_lds(st));      // debug only (engine.h)
     KPD_REQUIRE(a.S == 256 || a.S == 128, KPD_ERR_INVALID, "gvp noise head: S=%d (supported 128, 256)", a.S);
     KPD_REQUIRE(a.n_gvps >= 1 && a.F >= 1, KPD_ERR_INVALID, "gvp noise head: n_gvps=%d F=%d", a.n_gvps, a.F);
     const GvpW &gl = a.g[a.n_gvps - 1];
@@ -986,6 +989,7 @@ kpd_status launch_gvp_noise(const GvpNoiseArgs &a, hipStream_t st) {
 kpd_status launch_gvp_node(const GvpNodePair &p, hipStream_t st) {
     const int tiles = p.tiles0 + cdiv(p.nt[1].n, TM);
     if (tiles == 0) return KPD_OK;
+    if (poison_level() >= 1) KPD_TRY(poison_lds(st));      // debug only (engine.h)
     const int S = p.nt[0].n ? p.nt[0].S : p.nt[1].S;
     KPD_REQUIRE(S == 256 || S == 128, KPD_ERR_INVALID, "gvp node kernel: S=%d (supported 128, 256)", S);
     for (int nt = 0; nt < 2; ++nt)

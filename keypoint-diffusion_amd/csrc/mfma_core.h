@@ -609,7 +609,11 @@ __device__ __forceinline__ float row_dot_chunks(const float *__restrict__ T, con
 // counter, i.e. every wave would wait at each barrier for its outstanding global stores (segment
 // pieces, projections) to be acknowledged; nothing in these kernels reads those back.
 __device__ __forceinline__ void lds_barrier() {
+#ifdef KPD_HZ_FULLBAR   // hazard hunt (profiles/tools/hz_variant.sh): every barrier also drains the vector-memory counter
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
 }
 
 // Row/column owned by accumulator register `reg` of tile (mt, nt) on this lane.

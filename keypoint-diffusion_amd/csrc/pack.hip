@@ -45,6 +45,52 @@ int cu_count() {
     return n;
 }
 
+int poison_level() {
+    static const int level = [] {
+        const char *e = getenv("KPD_POISON");
+        return e ? atoi(e) : 0;
+    }();
+    return level;
+}
+
+bool poison_selected() {
+    static const int only = getenv("KPD_POISON_ONLY") ? atoi(getenv("KPD_POISON_ONLY")) : -1;
+    static int counter = 0;
+    const int me = counter++;
+    return only < 0 || only == me;
+}
+
+void poison_floats(void *p, size_t bytes) {
+    (void)hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(p), 0x7fc0dead, bytes / 4);      // a quiet NaN with a recognisable payload
+}
+
+void zero_pad_columns(float *p, size_t rows, int stride, int valid) {
+    (void)hipMemset2D(p + valid, (size_t)stride * 4, 0, (size_t)(stride - valid) * 4, rows);
+}
+
+// One workgroup per 80 KB of LDS, two per CU, several rounds of them: every byte of every CU's LDS ends up holding NaNs.
+__global__ __launch_bounds__(256) void k_poison_lds(int words, unsigned *sink) {
+    extern __shared__ unsigned lds_words[];
+    for (int i = threadIdx.x; i < words; i += 256) lds_words[i] = 0x7fc0dead;
+    __syncthreads();
+    // keep the workgroup resident long enough for its siblings to land on the other CUs (and keep the stores alive)
+    unsigned acc = 0;
+    for (int r = 0; r < 64; ++r)
+        for (int i = threadIdx.x; i < words; i += 256 * 64) acc += lds_words[i] >> 31;
+    if (acc == 0xffffffffu) sink[0] = acc;
+}
+
+kpd_status poison_lds(hipStream_t st) {
+    if (getenv("KPD_POISON_ONLY")) return KPD_OK;
+    static unsigned *sink = nullptr;
+    if (!sink) KPD_HIP(hipMalloc(reinterpret_cast<void **>(&sink), 256));
+    const int bytes = 80 * 1024;
+    KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_poison_lds), bytes));
+    k_poison_lds<<<8 * cu_count(), 256, bytes, st>>>(bytes / 4, sink);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
 kpd_status Arena::reserve(size_t bytes) {
     if (bytes <= cap) {
         used = 0;

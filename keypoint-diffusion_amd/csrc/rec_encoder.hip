@@ -322,6 +322,7 @@ extern "C" kpd_status kpd_recenc_create(const kpd_recenc_config *cfg, kpd_recenc
         delete m;
         return st;
     }
+    m->warena.poison_at = 2;          // packed weights: poisoned only at KPD_POISON >= 2 (engine.h)
     Arena &A = m->warena;
     m->rr_msg.resize(cfg->n_rr_convs); m->rr_upd.resize(cfg->n_rr_convs);
     m->rk_msg.resize(cfg->n_rk_convs); m->rk_upd.resize(cfg->n_rk_convs);

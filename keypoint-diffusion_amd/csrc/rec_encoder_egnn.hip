@@ -315,6 +315,7 @@ extern "C" kpd_status kpd_recegnn_create(const kpd_recegnn_config *cfg, kpd_rece
         delete m;
         return st;
     }
+    m->warena.poison_at = 2;          // packed weights: poisoned only at KPD_POISON >= 2 (engine.h)
     Arena &A = m->warena;
     m->conv.resize(cfg->n_convs);
     for (int i = 0; i < cfg->n_convs; ++i) {

@@ -26,7 +26,7 @@ def main():
         B = 64
         gs = synth.synth_complexes([300] * B, [25] * B, 20, cut, seed=5)
         g = util.fixed_encode(G.batch(gs))
-        model = synth.fill_state_dict_(LigRecDynamics(10, 10, graph_cutoffs=cut, **util.EGNN_C2), 0)
+        make = lambda: synth.fill_state_dict_(LigRecDynamics(10, 10, graph_cutoffs=cut, **util.EGNN_C2), 0).eval().to(dev)
     else:
         B = 16
         gen = torch.Generator().manual_seed(9)
@@ -34,20 +34,41 @@ def main():
         n_lig = torch.randint(15, 36, (B,), generator=gen).tolist()
         gs = synth.synth_complexes(n_rec, n_lig, 20, cut, seed=5)
         g = util.fixed_encode(G.batch(gs), n_vec=16)
-        model = synth.fill_state_dict_(LigRecDynamicsGVP(10, 10, graph_cutoffs=cut, **GVP_ALL_ATOM), 1)
-    model = model.eval().to(dev)
+        make = lambda: synth.fill_state_dict_(LigRecDynamicsGVP(10, 10, graph_cutoffs=cut, **GVP_ALL_ATOM), 1).eval().to(dev)
+    import hashlib
+    model = make()
     gd = g.to(dev)
+    # a SECOND input of another shape (first 5 complexes, other timesteps): alternated with the first, a read of stale workspace
+    # contents returns the OTHER input's values instead of an identical copy of its own
+    g2 = util.fixed_encode(G.batch(gs[:5]), n_vec=16 if arch == 'gvp' else None).to(dev)
     t = torch.linspace(0.05, 1.0, B, device=dev)
-    outs = []
+    t2 = torch.linspace(0.9, 0.2, 5, device=dev)
+    outs, outs2 = [], []
     with torch.no_grad():
         for _ in range(n):
             h, x = model(gd, t, None)
             outs.append((h.cpu().numpy().tobytes(), x.cpu().numpy().tobytes()))
+            h, x = model(g2, t2, None)
+            outs2.append((h.cpu().numpy().tobytes(), x.cpu().numpy().tobytes()))
+        # a second engine, created after every kernel of the library has run in this process, on memory the first engine does
+        # not own: same bits
+        model_b = make()
+        hb, xb = model_b(gd, t, None)
+        outs.append((hb.cpu().numpy().tobytes(), xb.cpu().numpy().tobytes()))
+        # against the exact fp32 GEMMs on the same input (meaningful in f16x2 mode; trivially equal in f32 mode)
+        model_c = make()
+        model_c.engine().debug('gemm=f32')
+        hc, xc = model_c(gd, t, None)
+    err = max(util.rel_err(hb, hc), util.rel_err(xb, xc))
     keys = [hash(o) for o in outs]
     ref = max(set(keys), key=keys.count)
     bad = [i for i, k in enumerate(keys) if k != ref]
-    print(f'COLD_START arch={arch} mode={os.environ.get("KPD_GEMM", "f32")} runs={n} deviating={bad}')
-    sys.exit(1 if bad else 0)
+    bad2 = [i for i, o in enumerate(outs2) if o != outs2[0]]
+    nan = bool(torch.isnan(hb).any() or torch.isnan(xb).any())
+    digest = hashlib.sha1(outs[keys.index(ref)][0] + outs[keys.index(ref)][1] + outs2[0][0] + outs2[0][1]).hexdigest()[:16]
+    print(f'COLD_START arch={arch} mode={os.environ.get("KPD_GEMM", "f32")} poison={os.environ.get("KPD_POISON", "0")} runs={n} '
+          f'deviating={bad} deviating_second_input={bad2} nan={nan} vs_f32={err:.2e} digest={digest}')
+    sys.exit(1 if (bad or bad2 or nan or err > 2e-5) else 0)
 
 
 if __name__ == '__main__':

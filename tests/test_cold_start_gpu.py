@@ -14,12 +14,21 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _run(arch, mode, poison='0'):
+    env = dict(os.environ, KPD_GEMM=mode, KPD_POISON=poison)
+    p = subprocess.run([sys.executable, '-m', 'tests.cold_start_worker', arch, '4'], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=600)
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith('COLD_START')]
+    assert p.returncode == 0 and line, (p.stdout[-2000:], p.stderr[-2000:])
+    assert 'deviating=[] deviating_second_input=[] nan=False' in line[0], line[0]
+    return line[0].split('digest=')[1]
+
+
 @pytest.mark.parametrize('arch,mode', [('egnn', 'f32'), ('egnn', 'f16x2'), ('gvp', 'f32'), ('gvp', 'f16x2')])
 def test_first_forward_of_a_fresh_process_equals_the_later_ones(cuda, arch, mode):
-    env = dict(os.environ, KPD_GEMM=mode)
-    for attempt in range(2):                                  # two fresh processes per case
-        p = subprocess.run([sys.executable, '-m', 'tests.cold_start_worker', arch, '6'], cwd=ROOT, env=env, capture_output=True,
-                           text=True, timeout=600)
-        line = [ln for ln in p.stdout.splitlines() if ln.startswith('COLD_START')]
-        assert p.returncode == 0 and line, (p.stdout[-2000:], p.stderr[-2000:])
-        assert line[0].endswith('deviating=[]'), line[0]
+    """Per fresh process: the first forward equals the later ones, two alternated inputs each stay bit-stable, a second engine
+    created at the end gives the same bits, and the f16x2 mode agrees with the exact mode.  Across processes: two plain runs and
+    one with NaN-poisoned workspaces and LDS (KPD_POISON=1: any read of memory this forward has not written turns into a NaN) all
+    produce the same digest."""
+    digests = {_run(arch, mode), _run(arch, mode), _run(arch, mode, poison='1')}
+    assert len(digests) == 1, digests
