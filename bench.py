@@ -178,50 +178,125 @@ def ragged_sizes(B, rank):
 # ---------------------------------------------------------------------------------------------------
 # CPU baselines (the oracle = plain-PyTorch CPU restatement of the reference path; test infrastructure, imported here only)
 # ---------------------------------------------------------------------------------------------------
-def cpu_baseline(workload='egnn_all_atom', B_sample=8, steps=3, ragged=False, B_scale=64):
-    """Oracle on this box's host cores: B_sample complexes of the workload's shape x `steps` reverse steps after one warm-up,
-    scaled to the B_scale batch.  The keypoints of the learned-encoder workloads come from the product encoder (run once on
-    the GPU, outside the timed region) -- the baseline times the per-step denoiser path only, like `value`."""
+def host_cpu():
+    """Cores this process may actually use: physical cores, capped by the affinity mask and the cgroup CPU quota (a GPU box
+    hands one-GPU jobs a share of the host, and oversubscribing it is what made round 2's baseline swing by 2.4x)."""
+    import math
+    import torch
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or os.cpu_count() or 1
+    except Exception:                                                # noqa: BLE001
+        phys = os.cpu_count() or 1
+    usable = min(phys, len(os.sched_getaffinity(0)))
+    quota = None
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            quota = float(q) / float(per)
+    except Exception:                                                # noqa: BLE001
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                quota = q / per
+        except Exception:                                            # noqa: BLE001
+            pass
+    if quota:
+        usable = max(1, min(usable, int(math.floor(quota))))
+    model = 'unknown'
+    try:
+        for ln in open('/proc/cpuinfo'):
+            if ln.startswith('model name'):
+                model = ln.split(':', 1)[1].strip()
+                break
+    except Exception:                                                # noqa: BLE001
+        pass
+    return {'cpu_model': model, 'physical_cores': phys, 'logical_cpus': os.cpu_count(), 'affinity': len(os.sched_getaffinity(0)),
+            'cgroup_quota_cpus': quota, 'threads_used': usable, 'torch': torch.__version__}
+
+
+def _cpu_time_steps(fwd, sd, cfg, ob, T, n_warm, n_timed):
+    """Per-step wall times (s) of oracle reverse steps, every step taken from the same t = T state (as the GPU line does)."""
     import torch
     from oracle import diffusion as odiff
+    table = odiff.gamma_table(T, 1e-5)
+    gen = torch.Generator().manual_seed(5)
+    B = int(ob.n['lig'].numel())
+    times = []
+    with torch.no_grad():
+        for i in range(n_warm + n_timed):
+            si = T - 1 - (i % T)
+            s, t = torch.full((B,), si / T), torch.full((B,), (si + 1) / T)
+            work = ob.clone()
+            nx, nh = torch.randn(work.x['lig'].shape, generator=gen), torch.randn(work.h['lig'].shape, generator=gen)
+            t0 = time.perf_counter()
+            eh, ex = fwd(sd, cfg, work, t)
+            odiff.sample_step(work, eh, ex, s, t, table, T, nx, nh)
+            times.append(time.perf_counter() - t0)
+    return times[n_warm:]
+
+
+def _stats(times, B):
+    med = statistics.median(times)
+    return {'B': B, 'timed_steps': len(times), 's_per_step_median': med, 'spread_pct': 100.0 * (max(times) - min(times)) / med,
+            'complex_steps_per_s': B / med}
+
+
+def cpu_baseline(workload='egnn_all_atom', ragged=False, B_scale=64, n_timed=7, with_c1=False):
+    """the oracle (plain PyTorch fp32 CPU restatement of the reference path) on this box's host cores --
+    `torch.set_num_threads(cores this process may use)`, the workload's shape at B = 1 and B = 8, 2 warm-up steps then `n_timed`
+    timed steps each, median; `value` is the B = 8 median scaled to the B_scale batch.  `with_c1`: BASELINE configs[0] in full
+    (dev_config: 60-node C-alpha pocket, 20-atom ligand, all 100 reverse steps) is timed as well.  The keypoints of the
+    learned-encoder workloads come from the product encoder (run once on the GPU, outside the timed region): the baseline times
+    the per-step denoiser path only, like `value`."""
+    import torch
     from oracle import egnn as oegnn
     from oracle import gvp as ogvp
     from tests.util import to_obatch
-    w = WORKLOADS[workload]
-    T = w['T']
-    enc_dev = 'cuda' if w['enc'] == 'learned' else 'cpu'
-    model = build_model(enc_dev, workload)
-    n_rec, n_lig = (300, 25)
-    if ragged:
-        n_rec, n_lig = ragged_sizes(64, 0)
-        n_rec, n_lig = n_rec[:B_sample], n_lig[:B_sample]
-    g = build_batch(model, B_sample, n_rec, n_lig, seed=99, device=enc_dev, workload=workload).to('cpu')
-    ob = to_obatch(g)
-    sd = {k[len('dynamics.'):]: v.detach().cpu() for k, v in model.state_dict().items() if k.startswith('dynamics.')}
-    cfg = dict(w['dyn'], graph_cutoffs=w['cutoffs'])
-    fwd = oegnn.egnn_dynamics_forward if w['arch'] == 'egnn' else ogvp.gvp_dynamics_forward
-    table = odiff.gamma_table(T, 1e-5)
-    gen = torch.Generator().manual_seed(5)
-
-    def one(si):
-        s = torch.full((B_sample,), si / T)
-        t = torch.full((B_sample,), (si + 1) / T)
-        eh, ex = fwd(sd, cfg, ob, t)
-        odiff.sample_step(ob, eh, ex, s, t, table, T, torch.randn(ob.x['lig'].shape, generator=gen),
-                          torch.randn(ob.h['lig'].shape, generator=gen))
-
-    with torch.no_grad():
-        one(T - 1)
-        t0 = time.perf_counter()
-        for i in range(steps):
-            one(T - 2 - i)
-        dt = time.perf_counter() - t0
-    complex_steps_per_s = B_sample * steps / dt
-    shape = 'ragged 150-600 / 15-35 atom' if ragged else '300 / 25 atom'
-    return {'value': complex_steps_per_s / B_scale, 'unit': 'steps/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'complex_steps_per_s': complex_steps_per_s, 'cpu_seconds': dt,
-            'sample': f'oracle (plain PyTorch fp32 CPU restatement of the {workload} denoiser + update) on {B_sample} complexes of '
-                      f'the same {shape} shape x {steps} reverse steps after 1 warm-up, scaled to the B={B_scale} batch'}
+    cpu = host_cpu()
+    prev_threads = torch.get_num_threads()
+    torch.set_num_threads(cpu['threads_used'])
+    try:
+        w = WORKLOADS[workload]
+        T = w['T']
+        enc_dev = 'cuda' if w['enc'] == 'learned' else 'cpu'
+        model = build_model(enc_dev, workload)
+        sd = {k[len('dynamics.'):]: v.detach().cpu() for k, v in model.state_dict().items() if k.startswith('dynamics.')}
+        cfg = dict(w['dyn'], graph_cutoffs=w['cutoffs'])
+        fwd = oegnn.egnn_dynamics_forward if w['arch'] == 'egnn' else ogvp.gvp_dynamics_forward
+        cases = {}
+        for B in (1, 8):
+            n_rec, n_lig = (300, 25)
+            if ragged:
+                n_rec, n_lig = ragged_sizes(64, 0)
+                n_rec, n_lig = n_rec[:B], n_lig[:B]
+            g = build_batch(model, B, n_rec, n_lig, seed=99, device=enc_dev, workload=workload).to('cpu')
+            cases[f'B{B}'] = _stats(_cpu_time_steps(fwd, sd, cfg, to_obatch(g), T, 2, n_timed), B)
+        out = {'value': cases['B8']['complex_steps_per_s'] / B_scale, 'unit': 'steps/s', 'cores': cpu['threads_used'], 'kind': 'port',
+               'complex_steps_per_s': cases['B8']['complex_steps_per_s'], 'cases': cases, 'host': cpu,
+               'cpu_seconds': sum(c['s_per_step_median'] * (c['timed_steps'] + 2) for c in cases.values()),
+               'sample': f'oracle (plain PyTorch fp32 CPU restatement of the {workload} denoiser + update) at the '
+                         f'{"ragged 150-600 / 15-35 atom" if ragged else "300 / 25 atom"} shape, B = 1 and B = 8, 2 warm-up + {n_timed} timed '
+                         f'reverse steps each from the t = T state, median; value = the B = 8 rate scaled to the B = {B_scale} batch '
+                         f'(BASELINE.md section 2)'}
+        if with_c1:
+            from keypoint_diffusion_amd import synth
+            from keypoint_diffusion_amd import graph as G
+            from keypoint_diffusion_amd.ligand_diffuser import KeypointDiffusion
+            from tests import util
+            cut = {'rr': 3.5, 'rk': 100, 'kk': 8, 'kl': 8, 'll': 9}                # configs/dev_config.yml:35
+            m1 = KeypointDiffusion(10, 20, None, n_timesteps=100, architecture='egnn', rec_encoder_type='fixed',
+                                   graph_config=dict(n_keypoints=20, graph_cutoffs=cut), dynamics_config=util.EGNN_DEV, precision=1e-5)
+            synth.fill_state_dict_(m1, 0)
+            g1 = m1.encode_receptors(G.batch(synth.synth_complexes([60], [20], 20, cut, seed=7, n_rec_feat=20, density=synth.CA_DENSITY)))
+            sd1 = {k[len('dynamics.'):]: v.detach() for k, v in m1.state_dict().items() if k.startswith('dynamics.')}
+            ts = _cpu_time_steps(oegnn.egnn_dynamics_forward, sd1, dict(util.EGNN_DEV, graph_cutoffs=cut), to_obatch(g1), 100, 2, 100)
+            out['c1_dev_config'] = dict(_stats(ts, 1), total_s_100_steps=sum(ts),
+                                        note='configs[0]: dev_config egnn (no keypoint update), 60-node C-alpha pocket, 20-atom ligand, all 100 reverse steps')
+        return out
+    finally:
+        torch.set_num_threads(prev_threads)
 
 
 def train_cpu_baseline(workload, B_sample=2):
@@ -311,9 +386,9 @@ def run_sampling(args, workload, device, rank, world, dist, B, n_rec, n_lig, rag
     model = build_model(device, workload)
     g = build_batch(model, B, n_rec, n_lig, seed=1234 + rank * B, device=device, workload=workload)
     bidx = G.get_batch_idxs(g)
-    os.environ['KPD_GEMM'] = gemm                      # read by kpd_egnn_create: the engine below is built in this mode
+    model.dynamics.gemm_mode = gemm                    # explicit attribute: survives every engine rebuild (dynamics.engine())
     eng = model.dynamics.engine()
-    os.environ.pop('KPD_GEMM')
+    assert eng.gemm_mode() == gemm, (eng.gemm_mode(), gemm)
     ones = torch.ones(B, device=device)
     # Random-init weights do not denoise: left to itself the chain drives the ligand atoms apart and
     # the lig-lig radius graph empties within ~20 steps, which would shrink the measured work.  Every
@@ -428,9 +503,8 @@ def run_end_to_end(device, workload='egnn_all_atom', B=64, n_rec=300, n_lig=25, 
     import torch
     w = WORKLOADS[workload]
     model = build_model(device, workload)
-    os.environ['KPD_GEMM'] = gemm                      # read at engine creation (first forward of this model)
-    model.dynamics.engine()
-    os.environ.pop('KPD_GEMM')
+    model.dynamics.gemm_mode = gemm
+    assert model.dynamics.engine().gemm_mode() == gemm
     with torch.no_grad():
         for _ in range(2):          # first pass = warm-up (workspace reservation, first-use initialisation)
             g = raw_batch(B, n_rec, n_lig, 4321, device, workload)
@@ -565,7 +639,7 @@ def main():
     if rank == 0:
         default_line = args.workload == 'egnn_all_atom' and not args.ragged and not args.graph and args.gemm == 'f32'
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(args.workload, ragged=args.ragged, B_scale=args.batch)
+            out['cpu_baseline'] = cpu_baseline(args.workload, ragged=args.ragged, B_scale=args.batch, with_c1=default_line)
             out['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']
         if world == 1 and default_line and not args.no_secondary:
             # BASELINE.json configs[2] and the configs[4] shape, same method (shorter regions), each with its roofline
@@ -579,6 +653,19 @@ def main():
                     r['cpu_baseline'] = cpu_baseline(wl, ragged=ragged)
                     r['gpu_over_cpu'] = r['value'] / r['cpu_baseline']['value']
                 sec[name] = r
+            # configs[3] / configs[4] at their stated batch of 512 on this ONE GPU (the 8-GPU jobs shard it 64 per rank): per-complex
+            # cost beside the B = 64 lines above (flat from 64 up means the 8-way shard loses nothing to small batches)
+            big_args = argparse.Namespace(**vars(sec_args))
+            big_args.steps, big_args.warmup = max(10, args.steps // 8), 3
+            r = run_sampling(big_args, 'egnn_all_atom', device, 0, 1, None, 512, 300, 25, False)
+            r['per_complex_us'] = 1e3 * r['ms_per_step'] / 512
+            r['per_complex_us_at_B64'] = 1e3 * out['ms_per_step'] / 64
+            sec['egnn_all_atom_b512'] = r
+            nr, nl = ragged_sizes(512, 0)
+            r = run_sampling(big_args, 'gvp_all_atom', device, 0, 1, None, 512, nr, nl, True)
+            r['per_complex_us'] = 1e3 * r['ms_per_step'] / 512
+            r['per_complex_us_at_B64'] = 1e3 * sec['gvp_all_atom_ragged']['ms_per_step'] / 64
+            sec['gvp_all_atom_ragged_b512'] = r
             # the contract workload once more in the opt-in f16x2 mode (separately judged; parity suite runs in both modes)
             r = run_sampling(sec_args, 'egnn_all_atom', device, 0, 1, None, 64, 300, 25, False, gemm='f16x2')
             if 'cpu_baseline' in out:

@@ -130,8 +130,8 @@ kpd_status kpd_egnn_debug_state(kpd_egnn *m, const char *what, float *out_dev, i
 kpd_status kpd_egnn_profile(kpd_egnn *m, int32_t enable);
 kpd_status kpd_egnn_profile_read(kpd_egnn *m, double *total_ms, int32_t *launches);
 /* Launch geometry of the last forward: {E_ll, E_kl, E_lk, E_kk, edge tiles of a full layer, edge tiles and edges of the
- * final layer} -- the final layer runs ll + kl only, since LigRecEGNN.forward returns (h_lig, x_lig) alone
- * (models/dynamics.py:288-294). */
+ * final layer, and in out[7] the GEMM mode in effect (0 exact fp32, 1 f16x2)} -- the final layer runs ll + kl only, since
+ * LigRecEGNN.forward returns (h_lig, x_lig) alone (models/dynamics.py:288-294).  Before the first forward only out[7] is set. */
 kpd_status kpd_egnn_last_counts(kpd_egnn *m, int32_t out[8], void *stream);
 
 /* ---------------------------------------------------------------------------------------
@@ -197,7 +197,7 @@ kpd_status kpd_gvp_debug_state(kpd_gvp *m, const char *what, float *out_dev, int
 /* HIP-event timing of the dominant kernel (k_gvp_chain: the message chain of GVPMultiEdgeConv.message,
  * models/gvp.py:459-497, 545-549) around each of its launches while enabled, and the launch geometry of the last
  * forward {E_ll, E_kl, E_lk, E_kk, tiles of a four-edge-type conv, tiles of the final conv, edges of the final conv}
- * (the final conv runs ll + kl only, models/dynamics_gvp.py:67-72). */
+ * (the final conv runs ll + kl only, models/dynamics_gvp.py:67-72), out[7] = the GEMM mode in effect (0 exact fp32, 1 f16x2). */
 kpd_status kpd_gvp_profile(kpd_gvp *m, int32_t enable);
 kpd_status kpd_gvp_profile_read(kpd_gvp *m, double *total_ms, int32_t *launches);
 kpd_status kpd_gvp_last_counts(kpd_gvp *m, int32_t out[8], void *stream);

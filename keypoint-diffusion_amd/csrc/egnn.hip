@@ -77,6 +77,7 @@ struct kpd_egnn {
     std::set<std::string> expected, loaded;
     bool committed = false;
     int debug_layers = -1;
+    bool f16_ok = true;                        // the committed weights fit the f16 planes (pack.hip range guard)
     int gemm_mode = 0;                         // 0 exact fp32 MFMA; 1 f16x2 split products in the EGNN GEMMs (KPD_GEMM=f16x2, "gemm=f16x2")
     int h_parts = 7;                           // diagnostics: which kernels take the f16x2 form (1 edge, 2 projections, 4 node update)
     int tile_rows = TM;                        // edges per tile of the edge kernel (64, or 32: k_egnn_edge32, four workgroups per CU)
@@ -214,6 +215,7 @@ extern "C" void kpd_egnn_destroy(kpd_egnn *m) {
     if (!m) return;
     for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
     if (m->edge_dbg) (void)hipFree(m->edge_dbg);
+    if (m->stamps) (void)hipFree(m->stamps);
     m->warena.release();
     m->ws.release();
     delete m;
@@ -376,6 +378,7 @@ extern "C" kpd_status kpd_egnn_commit(kpd_egnn *m) {
         }
     // the bias of edge_mlp.2 / coord_mlp.2 rides in the GEMM as weight row BIAS_K against a constant-1 column of
     // the A tile (scaled by c for the pre-scaled SiLU); patched here because weight and bias arrive separately
+    F16PackScope f16_scope;
     for (LayerW &L : m->L)
         for (int et = 0; et < m->n_et; ++et) {
             KPD_TRY(patch_bias_row(L.wp_e[et], L.wx_e[et], L.b_e[et], SILU_C, BIAS_K, nullptr));
@@ -383,6 +386,8 @@ extern "C" kpd_status kpd_egnn_commit(kpd_egnn *m) {
             KPD_TRY(pack_f16_split(L.wp_e[et], L.wh_e[et], nullptr));      // the same finished blocks for the f16x2 mode
             KPD_TRY(pack_f16_split(L.wp_c[et], L.wh_c[et], nullptr));
             KPD_TRY(pack_egnn_chain_h(L.chain[et], L.chain_h[et], nullptr));
+            KPD_TRY(f16_range_check_array(L.wx_e[et], KP, nullptr));        // W2[256, :]: split inside k_egnn_edge_h
+            KPD_TRY(f16_range_check_array(L.wx_c[et], KP, nullptr));
         }
     for (LayerW &L : m->L)
         for (int nt = 0; nt < 2; ++nt)
@@ -394,6 +399,8 @@ extern "C" kpd_status kpd_egnn_commit(kpd_egnn *m) {
             KPD_TRY(pack_f16_split(L.wp_b[nt], L.wh_b[nt], nullptr));
             KPD_TRY(pack_f16_split(L.wp_2[nt], L.wh_2[nt], nullptr));
         }
+    m->f16_ok = !f16_scope.overflowed();           // (synchronises the device)
+    KPD_REQUIRE(m->f16_ok || m->gemm_mode == 0, KPD_ERR_WEIGHTS, "%s", F16_RANGE_ERROR);       // KPD_GEMM=f16x2 asked for it
     KPD_HIP(hipDeviceSynchronize());
     m->committed = true;
     return KPD_OK;
@@ -693,6 +700,7 @@ extern "C" kpd_status kpd_egnn_debug_state(kpd_egnn *m, const char *what, float 
     } else if (w.rfind("gemm=", 0) == 0) {         // "gemm=f32" (exact fp32 MFMA, the contract path) | "gemm=f16x2" (split f16 products)
         const std::string v = w.substr(5);
         KPD_REQUIRE(v == "f32" || v == "f16x2", KPD_ERR_INVALID, "gemm mode must be f32 or f16x2");
+        KPD_REQUIRE(v == "f32" || !m->committed || m->f16_ok, KPD_ERR_WEIGHTS, "%s", F16_RANGE_ERROR);
         m->gemm_mode = v == "f16x2" ? 1 : 0;
         return KPD_OK;
     } else if (w.rfind("tile_rows=", 0) == 0) {    // 64 | 32: which staged edge kernel runs (A/B tests)
@@ -754,7 +762,10 @@ extern "C" kpd_status kpd_egnn_profile_read(kpd_egnn *m, double *total_ms, int32
 }
 
 extern "C" kpd_status kpd_egnn_last_counts(kpd_egnn *m, int32_t out[8], void *stream) {
-    KPD_REQUIRE(m && out && m->ws.base, KPD_ERR_INVALID, "null argument or no workspace");
+    KPD_REQUIRE(m && out, KPD_ERR_INVALID, "null argument");
+    for (int i = 0; i < 7; ++i) out[i] = 0;
+    out[7] = m->gemm_mode;                                           // GEMM mode the next forward runs in: 0 exact fp32, 1 f16x2
+    if (!m->ws.base) return KPD_OK;                                  // no forward yet: only the mode is meaningful
     hipStream_t st = static_cast<hipStream_t>(stream);
     int host[25];
     KPD_HIP(hipMemcpyAsync(host, m->meta, sizeof(host), hipMemcpyDeviceToHost, st));
@@ -763,7 +774,6 @@ extern "C" kpd_status kpd_egnn_last_counts(kpd_egnn *m, int32_t out[8], void *st
     out[4] = host[8];
     out[5] = host[16 + 8];                                           // tiles of the final layer's edge launch
     out[6] = host[16] + host[17] + host[18] + host[19];              // edges of the final layer's edge launch
-    out[7] = 0;
     return KPD_OK;
 }
 

@@ -72,6 +72,20 @@ kpd_status pack_f16_split(const float *wp, void *wh, hipStream_t st);
 // the A-fragment order of v_mfma_f32_16x16x32_f16 (CHH_HALVES halves)
 kpd_status pack_proj_f16_split(const float *chain, void *chh, hipStream_t st);
 // f16x2 mode of the GVP chains: the chunk buffer of a GVP with 256 scalar outputs re-packed unit by unit (pack.hip, k_pack_gvp_unit_h)
+// Range guard of the f16 planes (pack.hip): bracket the f16 packing of one commit; f16_pack_end() == true means a scaled weight
+// fell outside the finite f16 range and the f16x2 mode must not be used with these weights.
+void f16_pack_begin();
+bool f16_pack_end();
+kpd_status f16_range_check_array(const float *p, int n, hipStream_t st);      // p[i] * 2^10 within the finite f16 range?
+struct F16PackScope {           // RAII around the bracket (an early error return must not keep the guard's mutex)
+    bool open = true;
+    F16PackScope() { f16_pack_begin(); }
+    bool overflowed() { open = false; return f16_pack_end(); }
+    ~F16PackScope() { if (open) (void)f16_pack_end(); }
+};
+constexpr const char *F16_RANGE_ERROR =
+    "these weights do not fit the f16x2 mode: a packed weight reaches |w| * 2^10 >= 65504 (|w| >= ~64 with the block's scalings) "
+    "or is not finite, so its f16 planes would hold inf / NaN; use the exact mode (gemm=f32, the default)";
 kpd_status pack_gvp_chain_h(const float *chain, float *chain_h, int head, int n_ht, hipStream_t st);
 kpd_status pack_gvp_proj_h(const float *wproj, float *wproj_h, hipStream_t st);
 kpd_status pack_egnn_chain_h(const float *chain, float *chain_h, hipStream_t st);

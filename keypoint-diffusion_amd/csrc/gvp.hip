@@ -36,6 +36,7 @@ struct kpd_gvp {
     float *out_W, *out_b;
     std::set<std::string> expected, loaded;
     bool committed = false;
+    bool f16_ok = true;                       // the committed weights fit the f16 planes (pack.hip range guard)
     int gemm_mode = 0;                        // 0 exact fp32; 1 f16x2 split in the message chain (KPD_GEMM=f16x2, "gemm=f16x2")
     int debug_convs = -1;
     unsigned long long *stamps = nullptr;     // device [32], diagnostics
@@ -155,6 +156,8 @@ extern "C" kpd_status kpd_gvp_create(const kpd_gvp_config *cfg, kpd_gvp **out) {
 
 extern "C" void kpd_gvp_destroy(kpd_gvp *m) {
     if (!m) return;
+    for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
+    if (m->stamps) (void)hipFree(m->stamps);
     m->warena.release();
     m->ws.release();
     delete m;
@@ -229,6 +232,7 @@ extern "C" kpd_status kpd_gvp_commit(kpd_gvp *m) {
             return KPD_ERR_WEIGHTS;
         }
     // f16x2 mode: the 256 -> 256 message GVPs behind the head of every chain, re-packed from their finished fp32 chunks
+    F16PackScope f16_scope;
     for (auto &conv : m->msg)
         for (auto &et : conv)
             for (HostGvp &g : et)
@@ -243,6 +247,8 @@ extern "C" kpd_status kpd_gvp_commit(kpd_gvp *m) {
                 if (g.has_h() && g.chain_h) KPD_TRY(pack_gvp_chain_h(g.chain, g.chain_h, 0, g.n_ht(), nullptr));
     for (HostGvp &g : m->noise)
         if (g.has_h() && g.chain_h) KPD_TRY(pack_gvp_chain_h(g.chain, g.chain_h, 0, g.n_ht(), nullptr));
+    m->f16_ok = !f16_scope.overflowed();           // (synchronises the device)
+    KPD_REQUIRE(m->f16_ok || m->gemm_mode == 0, KPD_ERR_WEIGHTS, "%s", F16_RANGE_ERROR);       // KPD_GEMM=f16x2 asked for it
     KPD_HIP(hipDeviceSynchronize());
     m->committed = true;
     return KPD_OK;
@@ -429,6 +435,7 @@ extern "C" kpd_status kpd_gvp_debug_state(kpd_gvp *m, const char *what, float *o
     if (w.rfind("gemm=", 0) == 0) {              // "gemm=f32" (exact, the default) | "gemm=f16x2" (split f16 products in the message chain)
         const std::string v = w.substr(5);
         KPD_REQUIRE(v == "f32" || v == "f16x2", KPD_ERR_INVALID, "gemm mode must be f32 or f16x2");
+        KPD_REQUIRE(v == "f32" || m->S != 256 || !m->committed || m->f16_ok, KPD_ERR_WEIGHTS, "%s", F16_RANGE_ERROR);
         m->gemm_mode = (v == "f16x2" && m->S == 256) ? 1 : 0;
         return KPD_OK;
     }
@@ -478,7 +485,10 @@ extern "C" kpd_status kpd_gvp_profile_read(kpd_gvp *m, double *total_ms, int32_t
 }
 
 extern "C" kpd_status kpd_gvp_last_counts(kpd_gvp *m, int32_t out[8], void *stream) {
-    KPD_REQUIRE(m && out && m->meta4, KPD_ERR_INVALID, "null argument or no workspace");
+    KPD_REQUIRE(m && out, KPD_ERR_INVALID, "null argument");
+    for (int i = 0; i < 7; ++i) out[i] = 0;
+    out[7] = m->gemm_mode;                             // GEMM mode the next forward runs in: 0 exact fp32, 1 f16x2
+    if (!m->meta4) return KPD_OK;                      // no forward yet: only the mode is meaningful
     hipStream_t st = static_cast<hipStream_t>(stream);
     int host[25];
     KPD_HIP(hipMemcpyAsync(host, m->meta4, sizeof(host), hipMemcpyDeviceToHost, st));
@@ -487,6 +497,5 @@ extern "C" kpd_status kpd_gvp_last_counts(kpd_gvp *m, int32_t out[8], void *stre
     out[4] = host[8];                                  // tiles of a conv over all four edge types
     out[5] = host[16 + 8];                             // tiles of the final conv (ll + kl)
     out[6] = host[16] + host[17];                      // edges of the final conv
-    out[7] = 0;
     return KPD_OK;
 }

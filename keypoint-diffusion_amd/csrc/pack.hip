@@ -150,6 +150,42 @@ kpd_status pack_gemm_weight(const float *src, int n_out, int ld, int col0, int K
 // for s < KH_STEPS k-steps of 16 (K = 264 padded to 272 with zeros), i < 8: every fragment load of a wave (one dwordx4 per lane)
 // covers 1 KB of contiguous memory.  One thread per (s, wave, lane, nt, i).
 constexpr float H_SCALE_W_PACK = 1024.0f;       // = H_SCALE_W of mfma_core.h: keeps the lo plane out of the f16 subnormal range
+
+// Range guard of the f16x2 planes: a scaled weight at or beyond the largest finite f16 (65504, i.e. |w| >= ~64 after every
+// scaling the finished block carries) would become inf in the hi plane and NaN in the lo plane.  Every f16 packing kernel
+// raises this flag instead of letting that through; the commit that ran the packing reads it (f16_pack_begin / f16_pack_end)
+// and refuses the f16x2 mode for that engine with a clear error, the exact fp32 mode is unaffected.
+__device__ unsigned g_f16_overflow;
+static std::mutex g_f16_mu;
+
+__device__ __forceinline__ void f16_range_check(float scaled) {
+    if (!(fabsf(scaled) < 65504.0f)) atomicOr(&g_f16_overflow, 1u);      // also catches NaN / inf weights
+}
+
+void f16_pack_begin() {
+    g_f16_mu.lock();
+    const unsigned zero = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_f16_overflow), &zero, sizeof(zero));
+}
+
+bool f16_pack_end() {
+    unsigned v = 1;
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_f16_overflow), sizeof(v));
+    g_f16_mu.unlock();
+    return v != 0;
+}
+
+__global__ void k_f16_range_check(const float *__restrict__ p, int n, float scale) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) f16_range_check(scale * p[i]);
+}
+
+kpd_status f16_range_check_array(const float *p, int n, hipStream_t st) {
+    hipLaunchKernelGGL(k_f16_range_check, dim3(cdiv(n, 256)), dim3(256), 0, st, p, n, H_SCALE_W_PACK);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
 __global__ void k_pack_f16_split(const float *__restrict__ wp, __fp16 *__restrict__ wh, int total) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
@@ -160,6 +196,7 @@ __global__ void k_pack_f16_split(const float *__restrict__ wp, __fp16 *__restric
         const int g = k >> 3, h = (k >> 2) & 1, j = k & 3;
         w = H_SCALE_W_PACK * wp[((size_t)(g * 4 + wave) * 64 + (n31 + 32 * h)) * 8 + nt * 4 + j];
     }
+    f16_range_check(w);
     const __fp16 hi = (__fp16)w;                       // round to nearest: |w - hi| <= 2^-11 |w|
     const __fp16 lo = (__fp16)(w - (float)hi);         // and the remainder again: |w - hi - lo| <= 2^-22 |w| (f16 normal range)
     const size_t base = ((((size_t)(s * 4 + wave) * 2 + nt) * 2) * 64 + lane) * 8;
@@ -184,6 +221,7 @@ __global__ void k_pack_proj_f16_split(const float *__restrict__ chain, __fp16 *_
     const int j = idx & 7, lane = (idx >> 3) & 63, mt = (idx >> 9) & 15, kb = idx >> 13;
     const int k = 32 * kb + 8 * (lane >> 4) + j;
     const float w = H_SCALE_W_PACK * chain[(size_t)(k >> 4) * 4096 + (mt * 64 + 16 * ((k & 15) >> 2) + (lane & 15)) * 4 + (k & 3)];
+    f16_range_check(w);
     const __fp16 hi = (__fp16)w;
     const __fp16 lo = (__fp16)(w - (float)hi);
     const size_t base = (((size_t)(kb * 16 + mt) * 2) * 64 + lane) * 8 + j;
@@ -236,6 +274,7 @@ __global__ void k_pack_gvp_unit_h(const float *__restrict__ chain, float *__rest
         const int mt = 8 * (unit & 1) + m;
         w = chain[(size_t)(src_chunk + (j >> 2)) * 4096 + (mt * 64 + lane) * 4 + (j & 3)];
         at = ((m * 2) * 64 + lane) * 8 + j;
+        f16_range_check(H_SCALE_W_PACK * w);
         const __fp16 hi = (__fp16)(H_SCALE_W_PACK * w);
         dst[at] = hi;
         dst[at + 64 * 8] = (__fp16)(H_SCALE_W_PACK * w - (float)hi);
@@ -243,6 +282,7 @@ __global__ void k_pack_gvp_unit_h(const float *__restrict__ chain, float *__rest
         const int j = rem & 3, lane = (rem >> 2) & 63, mt = rem >> 8;
         w = chain[(size_t)src_chunk * 4096 + (mt * 64 + lane) * 4 + j];
         at = ((mt * 2) * 64 + lane) * 4 + j;
+        f16_range_check(H_SCALE_W_PACK * w);
         const __fp16 hi = (__fp16)(H_SCALE_W_PACK * w);
         dst[at] = hi;
         dst[at + 64 * 4] = (__fp16)(H_SCALE_W_PACK * w - (float)hi);
@@ -251,6 +291,7 @@ __global__ void k_pack_gvp_unit_h(const float *__restrict__ chain, float *__rest
         const int j = rem & 7, lane = (rem >> 3) & 63, kb = rem >> 9;
         w = chain[(size_t)src_chunk * 4096 + ((2 * kb + (j >> 2)) * 64 + lane) * 4 + (j & 3)];
         at = ((kb * 2) * 64 + lane) * 8 + j;
+        f16_range_check(H_SCALE_W_PACK * w);
         const __fp16 hi = (__fp16)(H_SCALE_W_PACK * w);
         dst[at] = hi;
         dst[at + 64 * 8] = (__fp16)(H_SCALE_W_PACK * w - (float)hi);

@@ -115,6 +115,10 @@ class LigRecDynamicsGVP(nn.Module):
         self.dropout = dropout
         self._engine = None
         self._engine_key = None
+        # GEMM mode of the inference engine: None = the library default (exact fp32 MFMA, or what KPD_GEMM names when the engine
+        # is created); 'f32' | 'f16x2' = an explicit choice that is re-applied to EVERY engine this module builds (weights
+        # replaced, optimizer step, .to()), so a model cannot silently fall back to another mode.
+        self.gemm_mode = None
         self._train = None
 
     def _trainer(self):
@@ -129,7 +133,24 @@ class LigRecDynamicsGVP(nn.Module):
         return self._train
 
     def _weights_key(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        """(storage pointer, version counter) of every parameter: changes when weights are replaced or modified in place.
+        Walking the module tree costs ~0.7 ms of host time (348 tensors), more than a B = 1 reverse step takes on the GPU, so
+        the list of Parameter objects is cached; `.to()` / `load_state_dict` and every 64th call re-walk the tree (a Parameter
+        object swapped for another one deep inside the module is the one change the cached list cannot see at once)."""
+        n = self.__dict__.get('_key_calls', 0)
+        ps = self.__dict__.get('_param_list')
+        if ps is None or n % 64 == 0:
+            ps = self.__dict__['_param_list'] = list(self.parameters())
+        self.__dict__['_key_calls'] = n + 1
+        return tuple([(p.data_ptr(), p._version) for p in ps])
+
+    def _apply(self, fn, *a, **kw):
+        self.__dict__.pop('_param_list', None)
+        return super()._apply(fn, *a, **kw)
+
+    def load_state_dict(self, *a, **kw):
+        self.__dict__.pop('_param_list', None)
+        return super().load_state_dict(*a, **kw)
 
     def engine(self) -> 'hip.GvpEngine':
         """(Re)build the device engine when weights were replaced or modified in place."""
@@ -141,6 +162,11 @@ class LigRecDynamicsGVP(nn.Module):
                                 self.n_update_gvps, self.n_noise_gvps)
             eng.load_state_dict(self.state_dict())
             self._engine, self._engine_key = eng, key
+        if self.gemm_mode is not None and getattr(self._engine, '_mode_applied', None) != self.gemm_mode:
+            if self.gemm_mode not in ('f32', 'f16x2'):
+                raise ValueError(f"gemm_mode must be None, 'f32' or 'f16x2', got {self.gemm_mode!r}")
+            self._engine.set_gemm_mode(self.gemm_mode)            # (one library call per engine and choice, not per forward)
+            self._engine._mode_applied = self.gemm_mode
         return self._engine
 
     def forward(self, g: HeteroBatch, timestep: torch.Tensor, batch_idxs: Dict[str, torch.Tensor] = None):

@@ -325,6 +325,15 @@ class EgnnEngine:
         check(lib().kpd_egnn_last_counts(self._h, arr, _stream()))
         return dict(E_ll=arr[0], E_kl=arr[1], E_lk=arr[2], E_kk=arr[3], tiles=arr[4], tiles_last=arr[5], E_last=arr[6])
 
+    def gemm_mode(self) -> str:
+        """The GEMM mode the engine runs in, as the library reports it ('f32' = exact fp32 MFMA, 'f16x2' = split f16 products)."""
+        arr = (C.c_int32 * 8)()
+        check(lib().kpd_egnn_last_counts(self._h, arr, _stream()))
+        return 'f16x2' if arr[7] else 'f32'
+
+    def set_gemm_mode(self, mode: str):
+        self.debug(f'gemm={mode}')
+
 
 class EgnnTrainer:
     """Owns one kpd_egnn_trainer handle: forward with saved layer states + backward of LigRecDynamics.forward.
@@ -447,6 +456,15 @@ class GvpEngine:
         arr = (C.c_int32 * 8)()
         check(lib().kpd_gvp_last_counts(self._h, arr, _stream()))
         return dict(E_ll=arr[0], E_kl=arr[1], E_lk=arr[2], E_kk=arr[3], tiles=arr[4], tiles_last=arr[5], E_last=arr[6])
+
+    def gemm_mode(self) -> str:
+        """The GEMM mode the engine runs in, as the library reports it ('f16x2' needs 256 hidden scalars; otherwise 'f32')."""
+        arr = (C.c_int32 * 8)()
+        check(lib().kpd_gvp_last_counts(self._h, arr, _stream()))
+        return 'f16x2' if arr[7] else 'f32'
+
+    def set_gemm_mode(self, mode: str):
+        self.debug(f'gemm={mode}')
 
 
 class GvpTrainer:

@@ -452,9 +452,41 @@ def make_xyz():
         text=np.frombuffer(text, np.uint8), text_ptr=np.asarray(ptr, np.int64))
 
 
+def make_full_models():
+    """The YAML boundary (model_setup.py:4-63): the REFERENCE's `model_from_config` run on its nine shipped configurations
+    (trained_models/*/config.yml, configs/dev_config.yml).  Stored per configuration: the parsed configuration values (the input)
+    and key -> shape of the full `KeypointDiffusion` state dict the reference builds from them (the expected output).
+    dev_config names a dataset directory that is not shipped (data/bindingmoad_dev/); only for the ligand-size histogram file the
+    constructor opens, it is pointed at the shipped data/bindingmoad_processed/ -- no tensor shape depends on that file."""
+    import copy
+    import glob
+    import yaml
+    from model_setup import model_from_config as ref_model_from_config
+    out = {}
+    files = sorted(glob.glob(os.path.join(REF, 'trained_models', '*', 'config.yml'))) + [os.path.join(REF, 'configs', 'dev_config.yml')]
+    cwd = os.getcwd()
+    os.chdir(REF)                                   # dataset locations in the configs are relative to the repository root
+    try:
+        for f in files:
+            name = os.path.basename(os.path.dirname(f)) if f.endswith('config.yml') and 'trained_models' in f else 'dev_config'
+            cfg = yaml.safe_load(open(f))
+            given = copy.deepcopy(cfg)
+            if name == 'dev_config':
+                cfg['dataset']['location'] = 'data/bindingmoad_processed/'
+            model = ref_model_from_config(cfg)          # (mutates cfg: in_scalar_size / in_n_node_feat are written into it)
+            sd = model.state_dict()
+            out[name] = {'config': given, 'layout': {k: list(v.shape) for k, v in sd.items()},
+                         'n_tensors': len(sd), 'n_params': int(sum(p.numel() for p in model.parameters()))}
+            print(f'{name}: {len(sd)} tensors, {out[name]["n_params"]} parameters')
+    finally:
+        os.chdir(cwd)
+    with open(os.path.join(HERE, 'full_model_layouts.json'), 'w') as fh:
+        json.dump(out, fh, indent=0, sort_keys=True)
+
+
 if __name__ == '__main__':
     torch.manual_seed(0)
-    makers = dict(xyz=make_xyz, egnn=make_egnn, gvp_blocks=make_gvp_blocks, gvp_dyn=make_gvp_dyn, rec_encoder=make_rec_encoder,
+    makers = dict(full_models=make_full_models, xyz=make_xyz, egnn=make_egnn, gvp_blocks=make_gvp_blocks, gvp_dyn=make_gvp_dyn, rec_encoder=make_rec_encoder,
                   rec_encoder_egnn=make_rec_encoder_egnn, schedule=make_schedule)
     only = sys.argv[1:]                 # e.g. `make_golden.py rec_encoder_egnn`: regenerate one family, keep the others
     lp = os.path.join(HERE, 'state_dict_layout.json')
