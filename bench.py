@@ -39,9 +39,11 @@ DYNAMICS = dict(hidden_nf=256, kl_k=5, ll_k=0, message_norm=0, n_layers=6, no_cg
                 update_kp_feat=True, use_tanh=True)
 PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 MFMA peak (= the fp32 vector peak)
 PEAK_HBM_GBS = 8000.0
-# What back-to-back fp32 MFMAs deliver on all CUs of this part at once (profiles/tools/gemm_loop_probe.hip, profiles/r02_gemm_loop_probe.txt:
-# 64.1 cycles per v_mfma_f32_32x32x2_f32 -- a full pipe -- at the ~2.0 GHz the chip holds under that load).  Context for `frac`, not the peak.
-SUSTAINED_F32_MFMA_TFLOPS = 132.0
+# What back-to-back fp32 MFMAs deliver on all CUs of this part at once, measured WITH a clock trace in round 3
+# (profiles/tools/mfma_clock_trace.hip -> profiles/r03_mfma_clock_trace.txt: 64.0 cycles per v_mfma_f32_32x32x2_f32, 2.37 GHz held
+# over 2 s of continuous MFMA issue at ~697 W => 155.5 TFLOP/s).  Round 2's "132 sustained" came from single 0.7-ms launches out of
+# idle, i.e. from the clock ramp (the first launches of the trace run at 0.96 - 2.2 GHz); it is withdrawn.  Context for `frac`, not the peak.
+MEASURED_F32_MFMA_TFLOPS = 155.5
 # f16x2 mode (opt-in, --gemm f16x2 / KPD_GEMM=f16x2): every fp32 product of the EGNN GEMMs (edge, projection and node-update kernels) and of
 # the 256 x 256 products of the GVP message / update chains is three f16 MFMA products of hi / lo operand planes with fp32 accumulation, so the bound for USEFUL flops is the dense f16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PFLOP/s) / 3
 PEAK_F16_MATRIX_TFLOPS = 2500.0
@@ -478,9 +480,9 @@ def run_sampling(args, workload, device, rank, world, dist, B, n_rec, n_lig, rag
                      'unit': 'TFLOP/s', 'frac': achieved / peak,
                      'peak_note': 'dense fp32 MFMA peak' if gemm == 'f32' else 'dense f16 MFMA peak / 3 (three f16 products per useful fp32 product); '
                                   'achieved counts USEFUL flops (the same 265 kFLOP/edge as the exact kernel)',
-                     'peak_sustained_measured': {'value': SUSTAINED_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac_of_it': achieved / SUSTAINED_F32_MFMA_TFLOPS,
-                                                 'source': 'profiles/r02_gemm_loop_probe.txt: bare fp32 MFMA loop on every CU, 64.1 cycles per MFMA at '
-                                                           'the ~2.0 GHz the part holds under that load (DVFS); the nominal peak assumes 2.4 GHz'},
+                     'peak_measured': {'value': MEASURED_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac_of_it': achieved / MEASURED_F32_MFMA_TFLOPS,
+                                       'source': 'profiles/r03_mfma_clock_trace.txt: bare fp32 MFMA loop on every CU, 64.0 cycles per MFMA at the 2.37 GHz '
+                                                 'the part holds for seconds under that load (round 2 quoted 132 from launches inside the clock ramp: withdrawn)'},
                      'traffic': traffic,
                      'traffic_source': tsrc,
                      'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, 2 x FETCH_SIZE + WRITE_SIZE, separate passes; committed '

@@ -225,8 +225,10 @@ kpd_status kpd_gvp_trainer_reserve(kpd_gvp_trainer *t, int32_t max_B, int32_t ma
                                    int32_t max_n_kk, int32_t max_lig_per_graph, int32_t max_kp_per_graph);
 kpd_status kpd_gvp_trainer_forward(kpd_gvp_trainer *t, const kpd_batch *batch, const float *t_dev, float *eps_h_dev,
                                    float *eps_x_dev, void *stream);
+/* d_lig_x [n_lig, 3] / d_kp_x [n_kp, 3] (either may be null): gradients with respect to the positions, which enter through the
+ * unit edge vector and the rbf code of every edge (models/gvp.py:472-480); the edge lists themselves are not differentiable. */
 kpd_status kpd_gvp_trainer_backward(kpd_gvp_trainer *t, const float *d_eps_h, const float *d_eps_x, float *d_lig_h,
-                                    float *d_kp_h, float *d_kp_v, void *stream);
+                                    float *d_kp_h, float *d_kp_v, float *d_lig_x, float *d_kp_x, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * GVP keypoint receptor encoder (once per pocket).  Replaces ReceptorEncoderGVP.forward

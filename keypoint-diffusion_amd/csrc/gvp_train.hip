@@ -2,8 +2,9 @@
 //
 // Gradients of LigRecDynamicsGVP.forward (models/dynamics_gvp.py:149-199; LigRecGVP :46-101, GVPMultiEdgeConv
 // models/gvp.py:459-551, GVP :89-116, GVPLayerNorm :159-166, NoisePredictionBlock dynamics_gvp.py:10-44) with respect to
-// every parameter and to the scalar / vector input features (not to positions: they enter only through the unit edge
-// vector and the rbf code and are data in every training configuration this path serves).
+// every parameter, to the scalar / vector input features and -- when asked for -- to the ligand and keypoint positions, which
+// enter through the unit edge vector and the rbf code of every edge (gvp.py:472-480): learned keypoints make them a function of
+// the receptor encoder's parameters (k_gvp_geom_bwd).
 //
 // Same formulation as egnn_train.hip: parameters in place in the reference layout, gradients accumulated in that
 // layout, dense products through rocBLAS on the caller's stream, everything else in the kernels below; only node-sized
@@ -44,6 +45,51 @@ __global__ void k_gvp_geom(const int *__restrict__ src, const int *__restrict__ 
         const float q = (d - mu) / sigma;
         rbf[(size_t)e * RBF + k] = __expf(-q * q);
     }
+}
+
+// Backward of k_gvp_geom: the loss reaches the positions through the unit edge vector (channel 0 of the message input vectors,
+// dvin [E, 3, 17]) and through the rbf code (drbf [E, 16]).  With diff = x_src - x_dst, q = |diff|^2, n = sqrt(max(q, 1e-8)),
+// d = n + 1e-8:  unit = diff / d,  rbf_k = exp(-((d - mu_k) / sigma)^2);  where the clamp is active n does not depend on diff.
+// dxe[e] = dL/d diff (added to the source node's gradient, subtracted from the destination's).
+__global__ void k_gvp_geom_bwd(const int *__restrict__ src, const int *__restrict__ dst, const float *__restrict__ xs,
+                               const float *__restrict__ xd, int E, float dmax, const float *__restrict__ rbf,
+                               const float *__restrict__ drbf, const float *__restrict__ dvin, float *__restrict__ dxe) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int u = src[e], v = dst[e];
+    const float df[3] = {xs[3 * u] - xd[3 * v], xs[3 * u + 1] - xd[3 * v + 1], xs[3 * u + 2] - xd[3 * v + 2]};
+    const float q = df[0] * df[0] + df[1] * df[1] + df[2] * df[2];
+    const float n = sqrtf(fmaxf(q, 1e-8f)), d = n + 1e-8f, inv = 1.0f / d;
+    const float sigma = dmax / RBF;
+    float dd = 0.0f;
+#pragma unroll
+    for (int k = 0; k < RBF; ++k) {
+        const float mu = dmax * (float)k / (float)(RBF - 1);
+        dd += drbf[(size_t)e * RBF + k] * rbf[(size_t)e * RBF + k] * (-2.0f * (d - mu) / (sigma * sigma));
+    }
+    float du[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        du[c] = dvin[((size_t)e * 3 + c) * VH];
+        dd -= du[c] * df[c] * inv * inv;
+    }
+    const float k = q > 1e-8f ? dd / n : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dxe[3 * e + c] = du[c] * inv + k * df[c];
+}
+
+// gx[v][0..3) += sign * sum over j in [rowptr[v], rowptr[v + 1]) of dxe[perm ? perm[j] : j]: one thread per node, edges in
+// ascending order (the deterministic sums of the rest of the backward pass)
+__global__ void k_seg3(const float *__restrict__ dxe, const int *__restrict__ perm, const int *__restrict__ rowptr, int n, float sign,
+                       float *__restrict__ gx) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    float a = 0.0f, b = 0.0f, c = 0.0f;
+    for (int j = rowptr[v]; j < rowptr[v + 1]; ++j) {
+        const int e = perm ? perm[j] : j;
+        a += dxe[3 * e]; b += dxe[3 * e + 1]; c += dxe[3 * e + 2];
+    }
+    gx[3 * v] += sign * a; gx[3 * v + 1] += sign * b; gx[3 * v + 2] += sign * c;
 }
 
 // message input vectors [E, 3, 17]: channel 0 = unit edge vector, channels 1..16 = v_src[src] (gvp.py:545)
@@ -330,6 +376,8 @@ struct kpd_gvp_trainer : TrainCtx {
           *s1 = nullptr, *v1 = nullptr, *sb = nullptr, *vb = nullptr;
     float *gs[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}, *gv[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [cur/nxt][nt]
     float *wsg_pack = nullptr;
+    float *dxe = nullptr, *gx[2] = {nullptr, nullptr};     // position gradients: per edge, per node type (lig, kp)
+    bool want_x = false;
     float dropout = 0.0f;
     unsigned long long seed = 0;
 };
@@ -668,6 +716,18 @@ kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
             std::swap(T->dV[0], T->dV[1]);
         }
         KPD_TRY(gvp_bwd(T, g0, E, nullptr, 0, T->vin, T->gb[0], false, T->ds[0], T->dV[0], nullptr, T->dV[1]));
+        if (T->want_x) {
+            // positions (gvp.py:472-480): d rbf = dpre W[:, S:S+16] (dsh is free again), d unit = channel 0 of d vin
+            const float *xs = s == NT_LIG ? T->bt.lig_x : T->bt.kp_x, *xd = d == NT_LIG ? T->bt.lig_x : T->bt.kp_x;
+            KPD_TRY(gemm(T, false, false, E, RBF, S, T->ds[0], S, g0.Ws.w + S, g0.si + g0.h, 0.0f, T->dsh, RBF));
+            hipLaunchKernelGGL(k_gvp_geom_bwd, grid1(E), dim3(256), 0, T->st, T->e_src[et], T->e_dst[et], xs, xd, E, 15.0f, T->rbf, T->dsh,
+                               T->dV[1], T->dxe);
+            KPD_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_seg3, grid1(T->n[s]), dim3(256), 0, T->st, T->dxe, T->scsr[et].perm, T->scsr[et].rowptr, T->n[s], 1.0f, T->gx[s]);
+            KPD_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_seg3, grid1(T->n[d]), dim3(256), 0, T->st, T->dxe, (const int *)nullptr, T->e_rowptr[et], T->n[d], -1.0f, T->gx[d]);
+            KPD_LAUNCH_CHECK();
+        }
         // ds[0] = dL/dpre of the first GVP: its scalar inputs were U[src] and rbf
         if (g0.Ws.g) KPD_TRY(grad_gemm(T, S, RBF, E, T->ds[0], S, T->rbf, RBF, g0.Ws.g + S, g0.si + g0.h));
         // sums over the out-edges of every source node, in ascending edge order (no float atomics)
@@ -872,6 +932,7 @@ extern "C" kpd_status kpd_gvp_trainer_reserve(kpd_gvp_trainer *T, int32_t max_B,
         for (int k = 0; k < 2; ++k) { F(T->ds[k], (size_t)R * (S + RBF)); F(T->dV[k], (size_t)R * 3 * VH); }
         F(T->dVh, (size_t)R * 3 * VH); F(T->dsh, (size_t)R * VH); F(T->dgate, (size_t)R * VC);
         F(T->unit, (size_t)R * 3); F(T->rbf, (size_t)R * RBF); F(T->vin, (size_t)R * 3 * VH);
+        F(T->dxe, (size_t)R * 3); F(T->gx[0], (size_t)max_n_lig * 3); F(T->gx[1], (size_t)max_n_kp * 3);
         const size_t N = std::max(max_n_lig, max_n_kp);
         F(T->U, N * S); F(T->scale, N); F(T->tmp_s, N * S); F(T->tmp_v, N * 3 * VC); F(T->s1, N * S); F(T->v1, N * 3 * VC);
         F(T->sb, N * std::max(S, 256)); F(T->vb, N * 3 * VC);
@@ -984,7 +1045,7 @@ extern "C" kpd_status kpd_gvp_trainer_forward(kpd_gvp_trainer *T, const kpd_batc
 }
 
 extern "C" kpd_status kpd_gvp_trainer_backward(kpd_gvp_trainer *T, const float *d_eps_h, const float *d_eps_x, float *d_lig_h,
-                                               float *d_kp_h, float *d_kp_v, void *stream) {
+                                               float *d_kp_h, float *d_kp_v, float *d_lig_x, float *d_kp_x, void *stream) {
     KPD_REQUIRE(T && d_eps_h && d_eps_x, KPD_ERR_INVALID, "null argument");
     KPD_REQUIRE(T->have_forward, KPD_ERR_STATE, "kpd_gvp_trainer_backward before kpd_gvp_trainer_forward");
     const kpd_gvp_config &c = T->cfg;
@@ -993,6 +1054,9 @@ extern "C" kpd_status kpd_gvp_trainer_backward(kpd_gvp_trainer *T, const float *
     KPD_BLAS(rocblas_set_stream(T->blas, st));
     const int S = T->S, nn = c.n_noise_gvps, nl = T->n[0], nk = T->n[1], L = c.n_convs, F = c.n_lig_scalars;
     int cur = 0, nxt = 1;
+    T->want_x = d_lig_x || d_kp_x;
+    if (T->want_x)
+        for (int nt = 0; nt < 2; ++nt) KPD_HIP(hipMemsetAsync(T->gx[nt], 0, (size_t)T->n[nt] * 12, st));
     for (int k = 0; k < 2; ++k)
         for (int nt = 0; nt < 2; ++nt) {
             KPD_HIP(hipMemsetAsync(T->gs[k][nt], 0, (size_t)T->n[nt] * S * 4, st));
@@ -1031,6 +1095,8 @@ extern "C" kpd_status kpd_gvp_trainer_backward(kpd_gvp_trainer *T, const float *
         hipLaunchKernelGGL(k_v_transpose, grid1((long long)nk * 3 * VC), dim3(256), 0, st, T->gv[cur][1], (long long)nk, 0, d_kp_v);
         KPD_LAUNCH_CHECK();
     }
+    if (d_lig_x) KPD_HIP(hipMemcpyAsync(d_lig_x, T->gx[0], (size_t)nl * 12, hipMemcpyDeviceToDevice, st));
+    if (d_kp_x) KPD_HIP(hipMemcpyAsync(d_kp_x, T->gx[1], (size_t)nk * 12, hipMemcpyDeviceToDevice, st));
     T->have_forward = false;
     return KPD_OK;
 }

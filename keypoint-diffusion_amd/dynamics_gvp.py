@@ -50,8 +50,8 @@ class LigRecGVP(nn.Module):
 
 
 class _GvpTrainFn(torch.autograd.Function):
-    """LigRecDynamicsGVP.forward as one autograd node (kpd_gvp_trainer_*): differentiable in the scalar / vector input
-    features and in every parameter; positions are data."""
+    """LigRecDynamicsGVP.forward as one autograd node (kpd_gvp_trainer_*): differentiable in every parameter, in the scalar /
+    vector input features and in the ligand / keypoint positions (learned keypoints: models/receptor_encoder_gvp.py:84-87)."""
 
     @staticmethod
     def forward(ctx, module, pb, timestep, lig_x, kp_x, lig_h, kp_h, kp_v, *params):
@@ -73,18 +73,18 @@ class _GvpTrainFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_eps_h, d_eps_x):
-        if ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
-            raise NotImplementedError('the GVP backward pass does not differentiate with respect to positions')
         if ctx.generation != ctx.trainer.generation:
             raise hip.KpdError('backward of a LigRecDynamicsGVP forward whose saved conv states were overwritten by a later '
                                'grad-enabled forward of the same module (one forward/backward pair at a time per module)')
         params = ctx.saved_tensors
-        _, _, lig_h, kp_h, kp_v, _ = ctx.inputs
+        lig_x, kp_x, lig_h, kp_h, kp_v, _ = ctx.inputs
         grads = [torch.zeros_like(p) if (ctx.needs_input_grad[8 + i] and p.numel()) else None for i, p in enumerate(params)]
         ctx.trainer.bind(ctx.names, params, grads)
         d_in = [torch.empty_like(t) if n else None for t, n in zip((lig_h, kp_h, kp_v), ctx.needs_input_grad[5:8])]
-        ctx.trainer.backward(d_eps_h.contiguous().float(), d_eps_x.contiguous().float(), *d_in)
-        return (None, None, None, None, None, *d_in, *grads)
+        # positions enter through the unit edge vector and the rbf code of every edge (gvp.py:472-480); the edge lists are data
+        d_x = [torch.empty_like(t) if n else None for t, n in zip((lig_x, kp_x), ctx.needs_input_grad[3:5])]
+        ctx.trainer.backward(d_eps_h.contiguous().float(), d_eps_x.contiguous().float(), *d_in, *d_x)
+        return (None, None, None, *d_x, *d_in, *grads)
 
 
 class LigRecDynamicsGVP(nn.Module):

@@ -148,7 +148,7 @@ def lib():
     L.kpd_gvp_trainer_bind.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32]
     L.kpd_gvp_trainer_reserve.argtypes = [C.c_void_p] + [C.c_int32] * 6
     L.kpd_gvp_trainer_forward.argtypes = [C.c_void_p, C.POINTER(KpdBatch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-    L.kpd_gvp_trainer_backward.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+    L.kpd_gvp_trainer_backward.argtypes = [C.c_void_p] + [C.c_void_p] * 8
     L.kpd_gvp_trainer_set_dropout.argtypes = [C.c_void_p, C.c_float, C.c_uint64]
     L.kpd_dropout_mask.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]
     L.kpd_rec_graph_scratch_bytes.argtypes = [C.c_int32, C.c_int32]
@@ -510,9 +510,9 @@ class GvpTrainer:
         check(lib().kpd_gvp_trainer_forward(self._h, C.byref(bt), t.data_ptr(), eps_h.data_ptr(), eps_x.data_ptr(), _stream()))
         return eps_h, eps_x
 
-    def backward(self, d_eps_h, d_eps_x, d_lig_h, d_kp_h, d_kp_v):
+    def backward(self, d_eps_h, d_eps_x, d_lig_h, d_kp_h, d_kp_v, d_lig_x=None, d_kp_x=None):
         check(lib().kpd_gvp_trainer_backward(self._h, d_eps_h.data_ptr(), d_eps_x.data_ptr(), _ptr(d_lig_h), _ptr(d_kp_h), _ptr(d_kp_v),
-                                             _stream()))
+                                             _ptr(d_lig_x), _ptr(d_kp_x), _stream()))
 
 
 def dropout_mask(seed: int, conv: int, node_type: int, position: int, kind: int, n: int, rate: float, device='cuda') -> torch.Tensor:

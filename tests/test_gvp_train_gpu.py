@@ -33,8 +33,9 @@ def _oracle_grads(model, cfg, g, t, w_h, w_x):
     ob = util.to_obatch(g)
     sd = {k: v.detach().clone().requires_grad_(v.numel() > 0) for k, v in model.state_dict().items()}
     ins = {'lh': ob.h['lig'].clone().requires_grad_(True), 'kh': ob.h['kp'].clone().requires_grad_(True),
-           'kv': ob.v['kp'].clone().requires_grad_(True)}
-    ob.h['lig'], ob.h['kp'], ob.v['kp'] = ins['lh'], ins['kh'], ins['kv']
+           'kv': ob.v['kp'].clone().requires_grad_(True), 'lx': ob.x['lig'].clone().requires_grad_(True),
+           'kx': ob.x['kp'].clone().requires_grad_(True)}
+    ob.h['lig'], ob.h['kp'], ob.v['kp'], ob.x['lig'], ob.x['kp'] = ins['lh'], ins['kh'], ins['kv'], ins['lx'], ins['kx']
     ocfg = dict(cfg, graph_cutoffs=CUT)
     with torch.no_grad():
         edges = oegnn.lig_edges(ob, ocfg)
@@ -55,7 +56,7 @@ def test_gradients_match_oracle_autograd(tag, over):
     model = model.cuda()
     gd = g.to('cuda')
     ins = {}
-    for key, nt, name in (('lh', 'lig', 'h_0'), ('kh', 'kp', 'h_0'), ('kv', 'kp', 'v_0')):
+    for key, nt, name in (('lh', 'lig', 'h_0'), ('kh', 'kp', 'h_0'), ('kv', 'kp', 'v_0'), ('lx', 'lig', 'x_0'), ('kx', 'kp', 'x_0')):
         ins[key] = gd.nodes[nt].data[name].detach().clone().requires_grad_(True)
         gd.nodes[nt].data[name] = ins[key]
     eh, ex = model(gd, t.cuda(), None)
@@ -83,16 +84,10 @@ def test_gradients_match_oracle_autograd(tag, over):
 
 
 def test_gvp_training_contract():
-    """Positions are data, train-mode dropout without autograd is refused, no_grad calls keep using the fused engine."""
+    """Train-mode dropout without autograd is refused, no_grad calls keep using the fused engine."""
     cfg = dict(GVP_CFGS['gvp_norm0'])
     g, model, t = _case(cfg, [20, 15], [6, 4], 10)
     model = model.cuda()
-    gd = g.to('cuda')
-    x = gd.nodes['lig'].data['x_0'].clone().requires_grad_(True)
-    gd.nodes['lig'].data['x_0'] = x
-    eh, ex = model(gd, t.cuda(), None)
-    with pytest.raises(NotImplementedError):
-        (eh.sum() + ex.sum()).backward()
     model2 = LigRecDynamicsGVP(10, 10, graph_cutoffs=CUT, **dict(cfg, dropout=0.1)).cuda().train()
     with pytest.raises(NotImplementedError), torch.no_grad():
         model2(g.to('cuda'), t.cuda(), None)
