@@ -286,6 +286,25 @@ kpd_status kpd_recenc_reserve(kpd_recenc *m, int32_t max_B, int32_t max_n_rec, i
 kpd_status kpd_recenc_forward(kpd_recenc *m, const kpd_rec_batch *batch, const kpd_rec_out *out,
                               void *stream);
 
+/* Training engine of the same encoder (SURVEY.md 8(f) item 2 for row a8): forward with saved node states, backward with
+ * respect to every parameter given the gradients of the three outputs (keypoint positions, scalars, vectors -- what the GVP
+ * denoiser's backward pass and the optimal-transport encoder loss, losses/rec_encoder_loss.py:49-82, hand back).  Parameters are
+ * bound by reference state-dict name to live storage (read in place, gradients accumulated in place: bind zero-filled buffers);
+ * dropout as in kpd_gvp_trainer_set_dropout (GVPDropout on the aggregated messages and on the update residual of every
+ * GVPEdgeConv, models/gvp.py:316, 327).  Forward fills the same kpd_rec_out as kpd_recenc_forward; any of the three gradient
+ * pointers of backward may be null (= zero). */
+typedef struct kpd_recenc_trainer kpd_recenc_trainer;
+kpd_status kpd_recenc_trainer_create(const kpd_recenc_config *cfg, kpd_recenc_trainer **out);
+void kpd_recenc_trainer_destroy(kpd_recenc_trainer *t);
+kpd_status kpd_recenc_trainer_bind(kpd_recenc_trainer *t, const char *name, const float *weight_dev, float *grad_dev,
+                                   const int64_t *shape, int32_t ndim);
+kpd_status kpd_recenc_trainer_set_dropout(kpd_recenc_trainer *t, float rate, uint64_t seed);
+kpd_status kpd_recenc_trainer_reserve(kpd_recenc_trainer *t, int32_t max_B, int32_t max_n_rec, int32_t max_n_rr,
+                                      int32_t max_rec_per_graph);
+kpd_status kpd_recenc_trainer_forward(kpd_recenc_trainer *t, const kpd_rec_batch *batch, const kpd_rec_out *out, void *stream);
+kpd_status kpd_recenc_trainer_backward(kpd_recenc_trainer *t, const float *d_kp_x, const float *d_kp_h, const float *d_kp_v,
+                                       void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * EGNN keypoint receptor encoder (once per pocket; the encoder of the egnn_20kp / egnn_40kp models).  Replaces
  * ReceptorEncoder.forward (models/receptor_encoder.py:483-555): the ReceptorConv stack on the rr graph (:14-154),

@@ -16,326 +16,7 @@
 // (feature dropout per element, vector dropout per channel, both scaled by 1 / (1 - rate)).  Masks come from Philox keyed
 // by a per-forward seed and the (conv, node type, position, kind) stream, so the backward pass regenerates them instead
 // of storing them; kpd_dropout_mask exposes the same stream for tests.
-#include "egnn_kernels.h"
-#include "engine.h"
-#include "train_ops.h"
-
-namespace kpd {
-namespace {
-
-constexpr int VC = 16;        // vector channels
-constexpr int VH = 17;        // widest vector block (message GVP 0: x_diff + 16 channels)
-constexpr int RBF = 16;
-
-// ---- kernels ------------------------------------------------------------------------------------------------------------
-// edge geometry (gvp.py:474-480): unit vector x_diff / (|x_diff|_nonan + 1e-8) and the rbf code of that length
-__global__ void k_gvp_geom(const int *__restrict__ src, const int *__restrict__ dst, const float *__restrict__ xs,
-                           const float *__restrict__ xd, int E, float dmax, float *__restrict__ unit, float *__restrict__ rbf) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= E) return;
-    const int u = src[e], v = dst[e];
-    const float dx = xs[3 * u] - xd[3 * v], dy = xs[3 * u + 1] - xd[3 * v + 1], dz = xs[3 * u + 2] - xd[3 * v + 2];
-    const float d = sqrtf(fmaxf(dx * dx + dy * dy + dz * dz, 1e-8f)) + 1e-8f;
-    const float inv = 1.0f / d;
-    unit[3 * e] = dx * inv; unit[3 * e + 1] = dy * inv; unit[3 * e + 2] = dz * inv;
-    const float sigma = dmax / RBF;
-#pragma unroll
-    for (int k = 0; k < RBF; ++k) {
-        const float mu = dmax * (float)k / (float)(RBF - 1);
-        const float q = (d - mu) / sigma;
-        rbf[(size_t)e * RBF + k] = __expf(-q * q);
-    }
-}
-
-// Backward of k_gvp_geom: the loss reaches the positions through the unit edge vector (channel 0 of the message input vectors,
-// dvin [E, 3, 17]) and through the rbf code (drbf [E, 16]).  With diff = x_src - x_dst, q = |diff|^2, n = sqrt(max(q, 1e-8)),
-// d = n + 1e-8:  unit = diff / d,  rbf_k = exp(-((d - mu_k) / sigma)^2);  where the clamp is active n does not depend on diff.
-// dxe[e] = dL/d diff (added to the source node's gradient, subtracted from the destination's).
-__global__ void k_gvp_geom_bwd(const int *__restrict__ src, const int *__restrict__ dst, const float *__restrict__ xs,
-                               const float *__restrict__ xd, int E, float dmax, const float *__restrict__ rbf,
-                               const float *__restrict__ drbf, const float *__restrict__ dvin, float *__restrict__ dxe) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= E) return;
-    const int u = src[e], v = dst[e];
-    const float df[3] = {xs[3 * u] - xd[3 * v], xs[3 * u + 1] - xd[3 * v + 1], xs[3 * u + 2] - xd[3 * v + 2]};
-    const float q = df[0] * df[0] + df[1] * df[1] + df[2] * df[2];
-    const float n = sqrtf(fmaxf(q, 1e-8f)), d = n + 1e-8f, inv = 1.0f / d;
-    const float sigma = dmax / RBF;
-    float dd = 0.0f;
-#pragma unroll
-    for (int k = 0; k < RBF; ++k) {
-        const float mu = dmax * (float)k / (float)(RBF - 1);
-        dd += drbf[(size_t)e * RBF + k] * rbf[(size_t)e * RBF + k] * (-2.0f * (d - mu) / (sigma * sigma));
-    }
-    float du[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        du[c] = dvin[((size_t)e * 3 + c) * VH];
-        dd -= du[c] * df[c] * inv * inv;
-    }
-    const float k = q > 1e-8f ? dd / n : 0.0f;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) dxe[3 * e + c] = du[c] * inv + k * df[c];
-}
-
-// gx[v][0..3) += sign * sum over j in [rowptr[v], rowptr[v + 1]) of dxe[perm ? perm[j] : j]: one thread per node, edges in
-// ascending order (the deterministic sums of the rest of the backward pass)
-__global__ void k_seg3(const float *__restrict__ dxe, const int *__restrict__ perm, const int *__restrict__ rowptr, int n, float sign,
-                       float *__restrict__ gx) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n) return;
-    float a = 0.0f, b = 0.0f, c = 0.0f;
-    for (int j = rowptr[v]; j < rowptr[v + 1]; ++j) {
-        const int e = perm ? perm[j] : j;
-        a += dxe[3 * e]; b += dxe[3 * e + 1]; c += dxe[3 * e + 2];
-    }
-    gx[3 * v] += sign * a; gx[3 * v + 1] += sign * b; gx[3 * v + 2] += sign * c;
-}
-
-// message input vectors [E, 3, 17]: channel 0 = unit edge vector, channels 1..16 = v_src[src] (gvp.py:545)
-__global__ void k_gvp_vin(const float *__restrict__ unit, const float *__restrict__ vsrc, const int *__restrict__ src, long long total,
-                          float *__restrict__ vin) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int ch = (int)(i % VH);
-    const long long ec = i / VH;               // e * 3 + c
-    const int e = (int)(ec / 3), c = (int)(ec - 3LL * e);
-    vin[i] = ch == 0 ? unit[3 * e + c] : vsrc[((size_t)src[e] * 3 + c) * VC + ch - 1];
-}
-
-__global__ void k_gather_rows(const float *__restrict__ A, const int *__restrict__ idx, const float *__restrict__ scale, long long total,
-                              int cols, float *__restrict__ out) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
-    const int v = idx[r];
-    out[i] = A[(size_t)v * cols + c] * (scale ? scale[v] : 1.0f);
-}
-
-// acc[v] += scale[v] * sum over the edges of dst node v of M[e] (rows `cols` wide), one workgroup per dst node
-__global__ void k_segsum(const float *__restrict__ M, int cols, const int *__restrict__ rowptr, const float *__restrict__ scale,
-                         float *__restrict__ acc) {
-    const int v = blockIdx.x;
-    const int e0 = rowptr[v], e1 = rowptr[v + 1];
-    if (e0 == e1) return;
-    const float sc = scale[v];
-    for (int c = threadIdx.x; c < cols; c += blockDim.x) {
-        float s = 0.0f;
-        for (int e = e0; e < e1; ++e) s += M[(size_t)e * cols + c];
-        acc[(size_t)v * cols + c] += s * sc;
-    }
-}
-
-// sh[m, j] = sqrt(max(sum_c Vh[m, c, j]^2, 1e-8)) (_norm_no_nan, gvp.py:12-19)
-__global__ void k_gvp_sh(const float *__restrict__ Vh, long long total, int h, float *__restrict__ sh) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const long long m = i / h;
-    const int j = (int)(i - m * h);
-    const float a = Vh[(m * 3) * h + j], b = Vh[(m * 3 + 1) * h + j], c = Vh[(m * 3 + 2) * h + j];
-    sh[i] = sqrtf(fmaxf(a * a + b * b + c * c, 1e-8f));
-}
-
-// dVh[m, c, j] += dsh[m, j] * Vh[m, c, j] / sh[m, j] where the clamp is inactive
-__global__ void k_gvp_sh_bwd(const float *__restrict__ Vh, const float *__restrict__ sh, const float *__restrict__ dsh, long long total,
-                             int h, float *__restrict__ dVh) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // over [m, c, j]
-    if (i >= total) return;
-    const int j = (int)(i % h);
-    const long long m = i / (3LL * h);
-    const float s = sh[m * h + j];
-    if (s * s > 1e-8f) dVh[i] += dsh[m * h + j] * Vh[i] / s;
-}
-
-// V[m, c, u] = act(gate[m, u]) * Vu[m, c, u], act = sigmoid or identity (gvp.py:108-114)
-__global__ void k_gvp_gate(const float *__restrict__ gate, const float *__restrict__ Vu, long long total, int vo, int identity,
-                           float *__restrict__ V) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int u = (int)(i % vo);
-    const long long m = i / (3LL * vo);
-    const float g = gate[m * vo + u];
-    V[i] = (identity ? g : sigm(g)) * Vu[i];
-}
-
-// one thread per (m, u): dgate = sum_c dV Vu act'(gate); dV <- dV act(gate) (= dVu)
-__global__ void k_gvp_gate_bwd(const float *__restrict__ gate, const float *__restrict__ Vu, long long total, int vo, int identity,
-                               float *__restrict__ dV, float *__restrict__ dgate) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // over [m, u]
-    if (i >= total) return;
-    const long long m = i / vo;
-    const int u = (int)(i - m * vo);
-    const float g = gate[i];
-    const float a = identity ? g : sigm(g);
-    const float da = identity ? 1.0f : a * (1.0f - a);
-    float s = 0.0f;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const size_t k = ((size_t)m * 3 + c) * vo + u;
-        s = fmaf(dV[k], Vu[k], s);
-        dV[k] *= a;
-    }
-    dgate[i] = s * da;
-}
-
-// LayerNorm over `cols` (<= 512) columns, one wave per row
-__global__ void k_ln_fwd(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta, int rows, int cols,
-                         float *__restrict__ out) {
-    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (r >= rows) return;
-    const float *xr = x + (size_t)r * cols;
-    float s = 0.0f;
-    for (int c = lane; c < cols; c += 64) s += xr[c];
-    const float mean = wave_sum(s) / cols;
-    float q = 0.0f;
-    for (int c = lane; c < cols; c += 64) q += (xr[c] - mean) * (xr[c] - mean);
-    const float rstd = rsqrtf(wave_sum(q) / cols + 1e-5f);
-    for (int c = lane; c < cols; c += 64) out[(size_t)r * cols + c] = (xr[c] - mean) * rstd * gamma[c] + beta[c];
-}
-
-__global__ void k_ln_bwd_g(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ dy, int rows, int cols,
-                           float *__restrict__ dx, float *__restrict__ dyxhat) {
-    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (r >= rows) return;
-    const float *xr = x + (size_t)r * cols, *dyr = dy + (size_t)r * cols;
-    float s = 0.0f;
-    for (int c = lane; c < cols; c += 64) s += xr[c];
-    const float mean = wave_sum(s) / cols;
-    float q = 0.0f;
-    for (int c = lane; c < cols; c += 64) q += (xr[c] - mean) * (xr[c] - mean);
-    const float rstd = rsqrtf(wave_sum(q) / cols + 1e-5f);
-    float sg = 0.0f, sgx = 0.0f;
-    for (int c = lane; c < cols; c += 64) {
-        const float xh = (xr[c] - mean) * rstd, g = dyr[c] * gamma[c];
-        sg += g;
-        sgx += g * xh;
-    }
-    sg = wave_sum(sg) / cols;
-    sgx = wave_sum(sgx) / cols;
-    for (int c = lane; c < cols; c += 64) {
-        const float xh = (xr[c] - mean) * rstd, d = dyr[c];
-        dyxhat[(size_t)r * cols + c] = d * xh;
-        dx[(size_t)r * cols + c] = rstd * (d * gamma[c] - sg - xh * sgx);
-    }
-}
-
-// vector part of GVPLayerNorm (gvp.py:162-165): v / (sqrt(mean_ch(max(|v_ch|^2, 1e-8)) + 1e-5) + 1e-5), one thread per row
-__global__ void k_vnorm_fwd(const float *__restrict__ v, int rows, float *__restrict__ out) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    const float *p = v + (size_t)r * 3 * VC;
-    float m = 0.0f;
-#pragma unroll
-    for (int ch = 0; ch < VC; ++ch) m += fmaxf(p[ch] * p[ch] + p[VC + ch] * p[VC + ch] + p[2 * VC + ch] * p[2 * VC + ch], 1e-8f);
-    const float inv = 1.0f / (sqrtf(m / VC + 1e-5f) + 1e-5f);
-    for (int k = 0; k < 3 * VC; ++k) out[(size_t)r * 3 * VC + k] = p[k] * inv;
-}
-
-__global__ void k_vnorm_bwd(const float *__restrict__ v, const float *__restrict__ dout, int rows, float *__restrict__ dv) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    const float *p = v + (size_t)r * 3 * VC, *d = dout + (size_t)r * 3 * VC;
-    float m = 0.0f, dot = 0.0f;
-    bool live[VC];
-#pragma unroll
-    for (int ch = 0; ch < VC; ++ch) {
-        const float n2 = p[ch] * p[ch] + p[VC + ch] * p[VC + ch] + p[2 * VC + ch] * p[2 * VC + ch];
-        live[ch] = n2 > 1e-8f;
-        m += fmaxf(n2, 1e-8f);
-        dot += d[ch] * p[ch] + d[VC + ch] * p[VC + ch] + d[2 * VC + ch] * p[2 * VC + ch];
-    }
-    const float root = sqrtf(m / VC + 1e-5f), vn = root + 1e-5f, inv = 1.0f / vn;
-    // out = v / vn; dvn = -(dout . v) / vn^2; dvn/dv[ch, c] = v[ch, c] / (VC * root) where the clamp is inactive
-    const float k = -dot * inv * inv / (VC * root);
-#pragma unroll
-    for (int ch = 0; ch < VC; ++ch)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) dv[(size_t)r * 3 * VC + c * VC + ch] = d[c * VC + ch] * inv + (live[ch] ? k * p[c * VC + ch] : 0.0f);
-}
-
-__global__ void k_add(const float *__restrict__ a, const float *__restrict__ b, long long n, float *__restrict__ out) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = a[i] + b[i];
-}
-
-__global__ void k_acc(float *__restrict__ a, const float *__restrict__ b, long long n) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) a[i] += b[i];
-}
-
-// [rows, VC, 3] <-> [rows, 3, VC]
-__global__ void k_v_transpose(const float *__restrict__ in, long long rows, int to_internal, float *__restrict__ out) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * 3 * VC) return;
-    const long long r = i / (3 * VC);
-    const int k = (int)(i - r * 3 * VC);
-    if (to_internal) {          // out[r][c][ch] = in[r][ch][c]
-        const int c = k / VC, ch = k - c * VC;
-        out[i] = in[r * 3 * VC + ch * 3 + c];
-    } else {                    // out[r][ch][c] = in[r][c][ch]
-        const int ch = k / 3, c = k - ch * 3;
-        out[i] = in[r * 3 * VC + c * VC + ch];
-    }
-}
-
-// encoder input rows [h_0, t[graph]] (dynamics_gvp.py:161-169)
-__global__ void k_cat_time(const float *__restrict__ h, int F, const float *__restrict__ t, const int *__restrict__ bidx, long long total,
-                           float *__restrict__ out) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int r = (int)(i / (F + 1)), c = (int)(i - (long long)r * (F + 1));
-    out[i] = c < F ? h[(size_t)r * F + c] : t[bidx[r]];
-}
-
-// per-node scale of the aggregated messages: 'mean' -> 1 / in-degree of this edge type; else 1 / norm (constant or z[graph])
-__global__ void k_msg_scale(const int *__restrict__ rowptr, const float *__restrict__ z, const int *__restrict__ bidx, int n, int mode,
-                            float norm, float *__restrict__ scale) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n) return;
-    if (mode == 1) {
-        const int deg = rowptr[v + 1] - rowptr[v];
-        scale[v] = deg > 0 ? 1.0f / deg : 0.0f;
-    } else {
-        scale[v] = 1.0f / (mode == 2 ? z[bidx[v]] : norm);
-    }
-}
-
-// keep mask of one dropout stream: element i is kept iff its Philox word >= rate * 2^32; kept elements scale by 1 / (1 - rate)
-__device__ __forceinline__ float dropout_scale(unsigned long long seed, unsigned stream, long long i, float rate) {
-    unsigned c[4] = {(unsigned)(i >> 2), (unsigned)((unsigned long long)i >> 34), stream, 0x6b70646fu};
-    philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
-    const unsigned w = c[i & 3];
-    const unsigned thr = (unsigned)fminf(rate * 4294967296.0f, 4294967040.0f);
-    return w >= thr ? 1.0f / (1.0f - rate) : 0.0f;
-}
-
-// out[r, k, c] = in[r, k, c] * mask(r, c): rows x inner x cols with the mask shared over `inner` (1 for scalars, 3 for the
-// components of a vector channel)
-__global__ void k_dropout(const float *__restrict__ in, long long rows, int inner, int cols, unsigned long long seed, unsigned stream,
-                          float rate, float *__restrict__ out) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * inner * cols) return;
-    const int c = (int)(i % cols);
-    const long long r = i / ((long long)inner * cols);
-    out[i] = in[i] * dropout_scale(seed, stream, r * cols + c, rate);
-}
-
-__global__ void k_dropout_mask(long long n, unsigned long long seed, unsigned stream, float rate, float *__restrict__ out) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = dropout_scale(seed, stream, i, rate);
-}
-
-struct GvpP {
-    Param Wh, Wu, Ws, bs, Wg, bg;
-    int vi = 0, vo = 0, h = 0, si = 0, so = 0;
-};
-
-struct GvpBuf {
-    float *Vh = nullptr, *Vu = nullptr, *sh = nullptr, *pre = nullptr, *s = nullptr, *gate = nullptr, *V = nullptr;
-};
-
-}  // namespace
-}  // namespace kpd
+#include "gvp_train_core.h"
 
 using namespace kpd;
 
@@ -388,86 +69,6 @@ const char *kCanon[4] = {"lig_ll_lig", "kp_kl_lig", "lig_lk_kp", "kp_kk_kp"};
 const char *kNtName[2] = {"lig", "kp"};
 const int kSrc[4] = {NT_LIG, NT_KP, NT_LIG, NT_KP};
 const int kDst[4] = {NT_LIG, NT_LIG, NT_KP, NT_KP};
-
-kpd_status gvp_params(kpd_gvp_trainer *T, const std::string &p, int vi, int vo, int si, int so, GvpP *g) {
-    g->vi = vi; g->vo = vo; g->h = std::max(vi, vo); g->si = si; g->so = so;
-    KPD_TRY(param(T, p + ".Wh", vi, g->h, &g->Wh));
-    KPD_TRY(param(T, p + ".Wu", g->h, vo, &g->Wu));
-    KPD_TRY(param(T, p + ".to_feats_out.0.weight", so, si + g->h, &g->Ws));
-    KPD_TRY(param(T, p + ".to_feats_out.0.bias", so, 1, &g->bs));
-    KPD_TRY(param(T, p + ".scalar_to_vector_gates.weight", vo, so, &g->Wg));
-    KPD_TRY(param(T, p + ".scalar_to_vector_gates.bias", vo, 1, &g->bg));
-    return KPD_OK;
-}
-
-// the 256 x 256 scalar block of a GVP can take the weight-stationary GEMM (KPD_TRAIN_WS=0: library GEMMs throughout)
-bool ws_ok(const GvpP &g, int ld_s) {
-    static const bool on = !(getenv("KPD_TRAIN_WS") && atoi(getenv("KPD_TRAIN_WS")) == 0);
-    return on && g.si == 256 && g.so == 256 && ld_s == 256;
-}
-
-// GVP.forward (gvp.py:89-116).  s_in == nullptr: B.pre already holds the contribution of the scalar inputs (no bias).
-kpd_status gvp_fwd(kpd_gvp_trainer *T, const GvpP &g, int M, const float *s_in, int ld_s, const float *v_in, const GvpBuf &B,
-                   bool identity) {
-    if (M == 0) return KPD_OK;
-    KPD_TRY(gemm(T, false, false, 3 * M, g.h, g.vi, v_in, g.vi, g.Wh.w, g.h, 0.0f, B.Vh, g.h));
-    KPD_TRY(gemm(T, false, false, 3 * M, g.vo, g.h, B.Vh, g.h, g.Wu.w, g.vo, 0.0f, B.Vu, g.vo));
-    hipLaunchKernelGGL(k_gvp_sh, grid1((long long)M * g.h), dim3(256), 0, T->st, B.Vh, (long long)M * g.h, g.h, B.sh);
-    KPD_LAUNCH_CHECK();
-    long long tot = (long long)M * g.so;
-    if (s_in && ws_ok(g, ld_s)) {
-        // the narrow vector-norm block first, then the 256 x 256 scalar block on the weight-stationary GEMM with the partial
-        // pre-activation, the bias and the SiLU fused into its epilogue
-        KPD_TRY(gemm(T, false, true, M, g.so, g.h, B.sh, g.h, g.Ws.w + g.si, g.si + g.h, 0.0f, B.pre, g.so));
-        KPD_TRY(ws_gemm(WS_BIAS_SILU, s_in, M, ld_s, g.Ws.w, g.si + g.h, false, g.bs.w, nullptr, B.pre, B.s, g.so, T->wsg_pack, T->st, false, true));
-    } else {
-        if (s_in) KPD_TRY(gemm(T, false, true, M, g.so, g.si, s_in, ld_s, g.Ws.w, g.si + g.h, 0.0f, B.pre, g.so));
-        KPD_TRY(gemm(T, false, true, M, g.so, g.h, B.sh, g.h, g.Ws.w + g.si, g.si + g.h, 1.0f, B.pre, g.so));
-        hipLaunchKernelGGL(k_bias_silu, grid1(tot), dim3(256), 0, T->st, B.pre, g.bs.w, tot, g.so, g.so, B.s);
-        KPD_LAUNCH_CHECK();
-    }
-    KPD_TRY(gemm(T, false, true, M, g.vo, g.so, B.s, g.so, g.Wg.w, g.so, 0.0f, B.gate, g.vo));
-    tot = (long long)M * g.vo;
-    hipLaunchKernelGGL(k_bias_add, grid1(tot), dim3(256), 0, T->st, B.gate, g.bg.w, tot, g.vo, g.vo);
-    KPD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_gvp_gate, grid1(3 * tot), dim3(256), 0, T->st, B.gate, B.Vu, 3 * tot, g.vo, identity ? 1 : 0, B.V);
-    KPD_LAUNCH_CHECK();
-    return KPD_OK;
-}
-
-// Backward of gvp_fwd.  ds [M, so] = dL/ds' (overwritten with dL/dpre), dV [M, 3, vo] = dL/dV' (overwritten with dL/dVu);
-// ds_in [M, si] (ld so-independent: compact si) and dv_in [M, 3, vi] are written when non-null.
-kpd_status gvp_bwd(kpd_gvp_trainer *T, const GvpP &g, int M, const float *s_in, int ld_s, const float *v_in, const GvpBuf &B,
-                   bool identity, float *ds, float *dV, float *ds_in, float *dv_in) {
-    if (M == 0) return KPD_OK;
-    long long tot = (long long)M * g.vo;
-    hipLaunchKernelGGL(k_gvp_gate_bwd, grid1(tot), dim3(256), 0, T->st, B.gate, B.Vu, tot, g.vo, identity ? 1 : 0, dV, T->dgate);
-    KPD_LAUNCH_CHECK();
-    KPD_TRY(colsum_acc(T, M, g.vo, T->dgate, g.vo, g.bg.g));
-    KPD_TRY(grad_gemm(T, g.vo, g.so, M, T->dgate, g.vo, B.s, g.so, g.Wg.g, g.so));
-    KPD_TRY(gemm(T, false, false, M, g.so, g.vo, T->dgate, g.vo, g.Wg.w, g.so, 1.0f, ds, g.so));
-    tot = (long long)M * g.so;
-    hipLaunchKernelGGL(k_silu_bwd, grid1(tot), dim3(256), 0, T->st, ds, B.pre, tot, g.so, g.so);
-    KPD_LAUNCH_CHECK();
-    KPD_TRY(colsum_acc(T, M, g.so, ds, g.so, g.bs.g));
-    if (s_in) {
-        if (g.Ws.g) KPD_TRY(grad_gemm(T, g.so, g.si, M, ds, g.so, s_in, ld_s, g.Ws.g, g.si + g.h));
-        if (ds_in) {
-            if (ws_ok(g, ld_s)) KPD_TRY(ws_gemm(WS_PLAIN, ds, M, g.so, g.Ws.w, g.si + g.h, true, nullptr, nullptr, ds_in, nullptr, g.si, T->wsg_pack, T->st, false, false));
-            else KPD_TRY(gemm(T, false, false, M, g.si, g.so, ds, g.so, g.Ws.w, g.si + g.h, 0.0f, ds_in, g.si));
-        }
-    }
-    if (g.Ws.g) KPD_TRY(grad_gemm(T, g.so, g.h, M, ds, g.so, B.sh, g.h, g.Ws.g + g.si, g.si + g.h));
-    KPD_TRY(gemm(T, false, false, M, g.h, g.so, ds, g.so, g.Ws.w + g.si, g.si + g.h, 0.0f, T->dsh, g.h));
-    KPD_TRY(gemm(T, false, true, 3 * M, g.h, g.vo, dV, g.vo, g.Wu.w, g.vo, 0.0f, T->dVh, g.h));
-    tot = (long long)M * 3 * g.h;
-    hipLaunchKernelGGL(k_gvp_sh_bwd, grid1(tot), dim3(256), 0, T->st, B.Vh, B.sh, T->dsh, tot, g.h, T->dVh);
-    KPD_LAUNCH_CHECK();
-    KPD_TRY(grad_gemm(T, g.h, g.vo, 3 * M, B.Vh, g.h, dV, g.vo, g.Wu.g, g.vo));
-    KPD_TRY(grad_gemm(T, g.vi, g.h, 3 * M, v_in, g.vi, T->dVh, g.h, g.Wh.g, g.h));
-    if (dv_in) KPD_TRY(gemm(T, false, true, 3 * M, g.vi, g.h, T->dVh, g.h, g.Wh.w, g.h, 0.0f, dv_in, g.vi));
-    return KPD_OK;
-}
 
 // chain of n GVPs (S, 16) -> (S, 16) on M rows from (s0, v0): forward into gb[0..n)
 kpd_status chain_fwd(kpd_gvp_trainer *T, const std::string &prefix, int n, int M, const float *s0, const float *v0) {
@@ -563,38 +164,6 @@ kpd_status message_fwd(kpd_gvp_trainer *T, int conv, int et, GvpP *g0_out, bool 
         KPD_TRY(gvp_fwd(T, g, E, T->gb[j - 1].s, S, T->gb[j - 1].V, T->gb[j], false));
     }
     if (g0_out) *g0_out = g0;
-    return KPD_OK;
-}
-
-struct LnP {
-    Param gamma, beta;
-};
-
-kpd_status ln_params(kpd_gvp_trainer *T, const std::string &p, LnP *l) {
-    KPD_TRY(param(T, p + ".feat_norm.weight", T->S, 1, &l->gamma));
-    KPD_TRY(param(T, p + ".feat_norm.bias", T->S, 1, &l->beta));
-    return KPD_OK;
-}
-
-kpd_status gvp_ln_fwd(kpd_gvp_trainer *T, const LnP &l, int n, const float *s, const float *v, float *so, float *vo) {
-    hipLaunchKernelGGL(k_ln_fwd, dim3(cdiv(n, 4)), dim3(256), 0, T->st, s, l.gamma.w, l.beta.w, n, T->S, so);
-    KPD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_vnorm_fwd, grid1(n), dim3(256), 0, T->st, v, n, vo);
-    KPD_LAUNCH_CHECK();
-    return KPD_OK;
-}
-
-// backward of GVPLayerNorm at input (s, v): dso / dvo in, ds / dv out (may alias the inputs' gradient buffers)
-kpd_status gvp_ln_bwd(kpd_gvp_trainer *T, const LnP &l, int n, const float *s, const float *v, const float *dso, const float *dvo,
-                      float *ds, float *dv) {
-    hipLaunchKernelGGL(k_ln_bwd_g, dim3(cdiv(n, 4)), dim3(256), 0, T->st, s, l.gamma.w, dso, n, T->S, T->tmp_s, T->U);
-    KPD_LAUNCH_CHECK();
-    KPD_TRY(colsum_acc(T, n, T->S, T->U, T->S, l.gamma.g));        // U (free outside the edge passes) = dy * xhat
-    KPD_TRY(colsum_acc(T, n, T->S, dso, T->S, l.beta.g));
-    KPD_HIP(hipMemcpyAsync(ds, T->tmp_s, (size_t)n * T->S * 4, hipMemcpyDeviceToDevice, T->st));
-    hipLaunchKernelGGL(k_vnorm_bwd, grid1(n), dim3(256), 0, T->st, v, dvo, n, T->tmp_v);
-    KPD_LAUNCH_CHECK();
-    KPD_HIP(hipMemcpyAsync(dv, T->tmp_v, (size_t)n * 3 * VC * 4, hipMemcpyDeviceToDevice, T->st));
     return KPD_OK;
 }
 
@@ -721,7 +290,7 @@ kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
             const float *xs = s == NT_LIG ? T->bt.lig_x : T->bt.kp_x, *xd = d == NT_LIG ? T->bt.lig_x : T->bt.kp_x;
             KPD_TRY(gemm(T, false, false, E, RBF, S, T->ds[0], S, g0.Ws.w + S, g0.si + g0.h, 0.0f, T->dsh, RBF));
             hipLaunchKernelGGL(k_gvp_geom_bwd, grid1(E), dim3(256), 0, T->st, T->e_src[et], T->e_dst[et], xs, xd, E, 15.0f, T->rbf, T->dsh,
-                               T->dV[1], T->dxe);
+                               T->dV[1], VH, T->dxe);
             KPD_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_seg3, grid1(T->n[s]), dim3(256), 0, T->st, T->dxe, T->scsr[et].perm, T->scsr[et].rowptr, T->n[s], 1.0f, T->gx[s]);
             KPD_LAUNCH_CHECK();

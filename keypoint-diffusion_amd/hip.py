@@ -151,6 +151,14 @@ def lib():
     L.kpd_gvp_trainer_backward.argtypes = [C.c_void_p] + [C.c_void_p] * 8
     L.kpd_gvp_trainer_set_dropout.argtypes = [C.c_void_p, C.c_float, C.c_uint64]
     L.kpd_dropout_mask.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]
+    L.kpd_recenc_trainer_create.argtypes = [C.POINTER(KpdRecencConfig), C.POINTER(C.c_void_p)]
+    L.kpd_recenc_trainer_destroy.argtypes = [C.c_void_p]
+    L.kpd_recenc_trainer_destroy.restype = None
+    L.kpd_recenc_trainer_bind.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32]
+    L.kpd_recenc_trainer_set_dropout.argtypes = [C.c_void_p, C.c_float, C.c_uint64]
+    L.kpd_recenc_trainer_reserve.argtypes = [C.c_void_p] + [C.c_int32] * 4
+    L.kpd_recenc_trainer_forward.argtypes = [C.c_void_p, C.POINTER(KpdRecBatch), C.POINTER(KpdRecOut), C.c_void_p]
+    L.kpd_recenc_trainer_backward.argtypes = [C.c_void_p] + [C.c_void_p] * 4
     L.kpd_rec_graph_scratch_bytes.argtypes = [C.c_int32, C.c_int32]
     L.kpd_rec_graph_scratch_bytes.restype = C.c_int64
     L.kpd_build_rec_graph.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p,
@@ -180,6 +188,8 @@ EXPORTS = [
     'kpd_egnn_trainer_forward', 'kpd_egnn_trainer_backward',
     'kpd_gvp_trainer_create', 'kpd_gvp_trainer_destroy', 'kpd_gvp_trainer_bind', 'kpd_gvp_trainer_reserve',
     'kpd_gvp_trainer_forward', 'kpd_gvp_trainer_backward', 'kpd_gvp_trainer_set_dropout', 'kpd_dropout_mask',
+    'kpd_recenc_trainer_create', 'kpd_recenc_trainer_destroy', 'kpd_recenc_trainer_bind', 'kpd_recenc_trainer_set_dropout',
+    'kpd_recenc_trainer_reserve', 'kpd_recenc_trainer_forward', 'kpd_recenc_trainer_backward',
 ]
 
 
@@ -578,31 +588,74 @@ class RecEncEngine:
         check(L.kpd_recenc_commit(self._h))
 
     def forward(self, rec_counts: torch.Tensor, rec_x, rec_h, rr_src, rr_dst):
-        dev = rec_x.device
-        rec_counts = rec_counts.cpu().long()
-        B, n_rec, max_rec = int(rec_counts.numel()), int(rec_counts.sum()), int(rec_counts.max())
-        if int(rec_counts.min()) < 1:
-            raise KpdError('every pocket needs at least one receptor atom')
-        rec_ptr = torch.cat([torch.zeros(1, dtype=torch.long), rec_counts.cumsum(0)]).int().to(dev)
-        rec_x, rec_h = _dev_f32(rec_x, 'rec x_0'), _dev_f32(rec_h, 'rec h_0')
-        s, d, rowptr = sorted_csr(rr_src, rr_dst, n_rec, dev)
-        torch.cuda.synchronize()
-        check(lib().kpd_recenc_reserve(self._h, B, n_rec, int(s.numel()), max_rec))
-        n_kp = B * self.K
-        cap_kk = max(n_kp * min(self.K - 1, 100), 1)
-        f32 = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
-        i32 = lambda n: torch.zeros(n, device=dev, dtype=torch.int32)
-        out = dict(kp_x=f32(n_kp, 3), kp_h=f32(n_kp, self.S), kp_v=f32(n_kp, 16, 3), rk_src=i32(n_kp * self.k),
-                   rk_dst=i32(n_kp * self.k), kk_src=i32(cap_kk), kk_dst=i32(cap_kk), kk_per_graph=i32(B), counts=i32(2))
-        bt = KpdRecBatch(B, n_rec, max_rec, _ptr(rec_ptr), _ptr(rec_x), _ptr(rec_h), int(s.numel()), _ptr(s), _ptr(d),
-                         _ptr(rowptr))
-        ro = KpdRecOut(_ptr(out['kp_x']), _ptr(out['kp_h']), _ptr(out['kp_v']), _ptr(out['rk_src']), _ptr(out['rk_dst']),
-                       cap_kk, _ptr(out['kk_src']), _ptr(out['kk_dst']), _ptr(out['kk_per_graph']), _ptr(out['counts']))
-        check(lib().kpd_recenc_forward(self._h, C.byref(bt), C.byref(ro), _stream()))
-        e_kk, e_rk = out['counts'].tolist()            # once per pocket: a host sync here is fine
-        out['kk_src'], out['kk_dst'] = out['kk_src'][:e_kk], out['kk_dst'][:e_kk]
-        out['rk_src'], out['rk_dst'] = out['rk_src'][:e_rk], out['rk_dst'][:e_rk]
-        return out
+        return _recenc_call(self, lib().kpd_recenc_reserve, lib().kpd_recenc_forward, rec_counts, rec_x, rec_h, rr_src, rr_dst)
+
+
+def _recenc_call(eng, reserve_fn, forward_fn, rec_counts, rec_x, rec_h, rr_src, rr_dst):
+    """Shared by RecEncEngine.forward and RecEncTrainer.forward: batch structs, output buffers, one library call."""
+    dev = rec_x.device
+    rec_counts = rec_counts.cpu().long()
+    B, n_rec, max_rec = int(rec_counts.numel()), int(rec_counts.sum()), int(rec_counts.max())
+    if int(rec_counts.min()) < 1:
+        raise KpdError('every pocket needs at least one receptor atom')
+    rec_ptr = torch.cat([torch.zeros(1, dtype=torch.long), rec_counts.cumsum(0)]).int().to(dev)
+    rec_x, rec_h = _dev_f32(rec_x, 'rec x_0'), _dev_f32(rec_h, 'rec h_0')
+    s, d, rowptr = sorted_csr(rr_src, rr_dst, n_rec, dev)
+    torch.cuda.synchronize()
+    check(reserve_fn(eng._h, B, n_rec, int(s.numel()), max_rec))
+    n_kp = B * eng.K
+    cap_kk = max(n_kp * min(eng.K - 1, 100), 1)
+    f32 = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+    i32 = lambda n: torch.zeros(n, device=dev, dtype=torch.int32)
+    out = dict(kp_x=f32(n_kp, 3), kp_h=f32(n_kp, eng.S), kp_v=f32(n_kp, 16, 3), rk_src=i32(n_kp * eng.k),
+               rk_dst=i32(n_kp * eng.k), kk_src=i32(cap_kk), kk_dst=i32(cap_kk), kk_per_graph=i32(B), counts=i32(2))
+    bt = KpdRecBatch(B, n_rec, max_rec, _ptr(rec_ptr), _ptr(rec_x), _ptr(rec_h), int(s.numel()), _ptr(s), _ptr(d),
+                     _ptr(rowptr))
+    ro = KpdRecOut(_ptr(out['kp_x']), _ptr(out['kp_h']), _ptr(out['kp_v']), _ptr(out['rk_src']), _ptr(out['rk_dst']),
+                   cap_kk, _ptr(out['kk_src']), _ptr(out['kk_dst']), _ptr(out['kk_per_graph']), _ptr(out['counts']))
+    check(forward_fn(eng._h, C.byref(bt), C.byref(ro), _stream()))
+    e_kk, e_rk = out['counts'].tolist()            # once per pocket: a host sync here is fine
+    out['kk_src'], out['kk_dst'] = out['kk_src'][:e_kk], out['kk_dst'][:e_kk]
+    out['rk_src'], out['rk_dst'] = out['rk_src'][:e_rk], out['rk_dst'][:e_rk]
+    out['_keep'] = (rec_ptr, rec_x, rec_h, s, d, rowptr)      # the training engine reads these again in its backward pass
+    return out
+
+
+class RecEncTrainer:
+    """Owns one kpd_recenc_trainer handle: ReceptorEncoderGVP.forward with saved node states + its backward pass.  Parameters
+    are bound by reference name to live storage; gradients are accumulated into the buffers bound for the backward call."""
+
+    def __init__(self, cfg: 'KpdRecencConfig'):
+        self.cfg = cfg
+        self.S, self.K = int(cfg.out_scalar_size), int(cfg.n_keypoints)
+        self.k = int(cfg.k_closest) if cfg.k_closest else 10
+        self._h = C.c_void_p()
+        check(lib().kpd_recenc_trainer_create(C.byref(self.cfg), C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, '_h', None) and _lib is not None:
+            _lib.kpd_recenc_trainer_destroy(self._h)
+            self._h = None
+
+    def bind(self, names, weights, grads):
+        L = lib()
+        for name, w, g in zip(names, weights, grads):
+            if w.numel() == 0:                     # dropout.vector_dropout.dummy_param
+                continue
+            if not (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()):
+                raise KpdError(f'parameter {name} must be a contiguous fp32 GPU tensor')
+            shape = (C.c_int64 * w.dim())(*w.shape)
+            check(L.kpd_recenc_trainer_bind(self._h, name.encode(), w.data_ptr(), None if g is None else g.data_ptr(), shape, w.dim()))
+
+    def set_dropout(self, rate: float, seed: int):
+        check(lib().kpd_recenc_trainer_set_dropout(self._h, float(rate), int(seed) & (2 ** 64 - 1)))
+
+    def forward(self, rec_counts, rec_x, rec_h, rr_src, rr_dst):
+        return _recenc_call(self, lib().kpd_recenc_trainer_reserve, lib().kpd_recenc_trainer_forward, rec_counts, rec_x, rec_h,
+                            rr_src, rr_dst)
+
+    def backward(self, d_kp_x, d_kp_h, d_kp_v):
+        check(lib().kpd_recenc_trainer_backward(self._h, _ptr(d_kp_x), _ptr(d_kp_h), _ptr(d_kp_v), _stream()))
 
 
 class RecEgnnEngine:

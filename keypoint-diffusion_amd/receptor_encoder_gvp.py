@@ -11,6 +11,40 @@ from .graph import HeteroBatch, get_batch_info
 from .gvp import GVPEdgeConv
 
 
+class _RecEncTrainFn(torch.autograd.Function):
+    """ReceptorEncoderGVP.forward as one autograd node (kpd_recenc_trainer_*): the keypoint positions, scalars and vectors are
+    differentiable functions of every parameter; the rk / kk edge lists it also produces are data (torch_cluster ops upstream)."""
+
+    @staticmethod
+    def forward(ctx, module, rec_counts, rec_x, rec_h, rr_src, rr_dst, holder, *params):
+        trainer, names = module._trainer()
+        ctx.trainer, ctx.names = trainer, names
+        trainer.generation = getattr(trainer, 'generation', 0) + 1
+        ctx.generation = trainer.generation
+        ctx.save_for_backward(*params)
+        trainer.bind(names, params, [None] * len(params))
+        rate = module.dropout_rate if module.training else 0.0
+        module.last_dropout_seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if rate > 0 else 0
+        trainer.set_dropout(rate, module.last_dropout_seed)
+        out = trainer.forward(rec_counts, rec_x, rec_h, rr_src, rr_dst)
+        ctx.keep = out.pop('_keep')                                 # device copies the C side reads again in backward
+        holder.update(out)                                          # edge lists and counts: non-differentiable side outputs
+        return out['kp_x'], out['kp_h'], out['kp_v']
+
+    @staticmethod
+    def backward(ctx, d_x, d_h, d_v):
+        from . import hip
+        if ctx.generation != ctx.trainer.generation:
+            raise hip.KpdError('backward of a ReceptorEncoderGVP forward whose saved states were overwritten by a later grad-enabled '
+                               'forward of the same module (one forward/backward pair at a time per module)')
+        params = ctx.saved_tensors
+        grads = [torch.zeros_like(p) if (ctx.needs_input_grad[7 + i] and p.numel()) else None for i, p in enumerate(params)]
+        ctx.trainer.bind(ctx.names, params, grads)
+        c = lambda t: None if t is None else t.contiguous().float()
+        ctx.trainer.backward(c(d_x), c(d_h), c(d_v))
+        return (None,) * 7 + tuple(grads)
+
+
 class KeypointInitializer(nn.Module):
     """receptor_encoder_gvp.py:19-37."""
 
@@ -61,8 +95,24 @@ class ReceptorEncoderGVP(nn.Module):
             [GVPEdgeConv(edge_type=('rec', 'rk', 'kp'), use_dst_feats=(i != 0), rbf_dmax=graph_cutoffs['rk'], **common)
              for i in range(n_rk_convs)])
 
+        self.dropout_rate = dropout
         self._engine = None
         self._engine_key = None
+        self._train = None
+
+    def _trainer(self):
+        """The training engine and the parameter names in `self.parameters()` order (reference state-dict names)."""
+        from . import hip
+        if self._train is None:
+            if self.use_sameres_feat:
+                raise NotImplementedError('use_sameres_feat=True cannot run in the reference GVP encoder; every shipped config sets it to False')
+            mode, val = hip._norm_mode(self.message_norm)
+            cfg = hip.KpdRecencConfig(int(self.in_scalar_size), int(self.out_scalar_size), int(self.vector_size), int(self.n_rr_convs),
+                                      int(self.n_rk_convs), int(self.n_message_gvps), int(self.n_update_gvps), mode, val,
+                                      int(self.k_closest), int(self.n_keypoints), float(self.graph_cutoffs['rr']),
+                                      float(self.graph_cutoffs['rk']), float(self.graph_cutoffs['kk']), float(self.kp_rad))
+            self._train = (hip.RecEncTrainer(cfg), [n for n, _ in self.named_parameters()])
+        return self._train
 
     def engine(self):
         from . import hip
@@ -84,18 +134,24 @@ class ReceptorEncoderGVP(nn.Module):
 
     def forward(self, g: HeteroBatch, batch_idxs: Dict[str, torch.Tensor] = None) -> HeteroBatch:
         """Writes keypoint x_0 / h_0 / v_0, replaces the rk edges by the kNN edges and adds the kk radius
-        graph (receptor_encoder_gvp.py:212-294); eval mode only."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError('the HIP encoder is forward-only; call it under torch.no_grad()')
-        if self.training:
-            raise NotImplementedError('dropout is not implemented: call model.eval()')
+        graph (receptor_encoder_gvp.py:212-294).  Under autograd (parameters requiring gradients) the call runs on the
+        training engine and x_0 / h_0 / v_0 carry the graph back into the parameters; otherwise (torch.no_grad, the sampling
+        paths) it runs on the fused inference engine, which has no dropout: call model.eval() there, as every sampling path does."""
         B, K = g.batch_size, self.n_keypoints
         if g.num_nodes('kp') != B * K:
             raise ValueError(f'expected {K} keypoint nodes per complex, graph has {g.num_nodes("kp")} for {B} complexes')
         rec = g.nodes['rec'].data
         rr_src, rr_dst = g.edges(etype='rr')
         n_rec = g.batch_num_nodes('rec')
-        out = self.engine().forward(n_rec, rec['x_0'], rec['h_0'], rr_src, rr_dst)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            out = {}
+            x, h, v = _RecEncTrainFn.apply(self, n_rec, rec['x_0'], rec['h_0'], rr_src, rr_dst, out, *self.parameters())
+            out = dict(out, kp_x=x, kp_h=h, kp_v=v)
+        else:
+            if self.training and self.dropout_rate > 0:
+                raise NotImplementedError('train-mode dropout without autograd is not a path of the reference: call model.eval() for '
+                                          'inference (every sampling path does)')
+            out = self.engine().forward(n_rec, rec['x_0'], rec['h_0'], rr_src, rr_dst)
         kp = g.nodes['kp'].data
         kp['x_0'], kp['h_0'], kp['v_0'] = out['kp_x'], out['kp_h'], out['kp_v']
         nodes, edges = get_batch_info(g)
