@@ -32,6 +32,9 @@ class _EgnnTrainFn(torch.autograd.Function):
     def forward(ctx, module, pb, timestep, lig_x, lig_h, kp_x, kp_h, *params):
         trainer, names = module._trainer()
         ctx.trainer, ctx.names = trainer, names
+        # the C side keeps raw pointers into the batch structure (per-complex offsets, the kk edge list) and reads them again in the
+        # backward pass: the prepared batch must outlive the graph object the caller may drop right after the forward call
+        ctx.pb = pb
         ctx.inputs = (lig_x, lig_h, kp_x, kp_h, timestep)          # kept alive until backward (the C side holds pointers)
         # The trainer keeps the saved layer states of ONE forward.  Every forward takes a new generation number; backward
         # refuses to run on a workspace a later forward has overwritten.  The parameters go through save_for_backward, so

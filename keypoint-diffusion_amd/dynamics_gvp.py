@@ -57,6 +57,9 @@ class _GvpTrainFn(torch.autograd.Function):
     def forward(ctx, module, pb, timestep, lig_x, kp_x, lig_h, kp_h, kp_v, *params):
         trainer, names = module._trainer()
         ctx.trainer, ctx.names = trainer, names
+        # the C side keeps raw pointers into the batch structure (per-complex offsets, the kk edge list) and reads them again in the
+        # backward pass: the prepared batch must outlive the graph object the caller may drop right after the forward call
+        ctx.pb = pb
         ctx.inputs = (lig_x, kp_x, lig_h, kp_h, kp_v, timestep)    # kept alive until backward (the C side holds pointers)
         # one forward's saved conv states per trainer: generation number + autograd's version check on the parameters
         # (see _EgnnTrainFn in dynamics.py)

@@ -175,15 +175,18 @@ class KeypointDiffusion(nn.Module):
     def forward(self, complex_graphs, interface_points):
         """Losses of one batch (ligand_diffuser.py:89-175): {'l2', 'pos', 'feat', 'rec_encoder'}.
 
-        Fixed receptor encoder (configs/dev_config.yml, trained_models/{egnn,gvp}_all_atom, {egnn,gvp}_ca): trainable -- the
-        noise prediction is differentiated by the HIP backward passes (kpd_egnn_trainer_* / kpd_gvp_trainer_* under autograd),
-        the encoder has no parameters and its loss is the constant 0 (:85-87).
-        Learned receptor encoders ({egnn,gvp}_20kp / _40kp): EVALUATION only -- under `torch.no_grad()` (train.py's test_model)
-        all four losses are returned, the encoder loss being the optimal-transport distance of rec_encoder_loss.py; with
-        gradients enabled it raises, because the HIP encoders have no backward pass."""
-        if self.rec_encoder_type != 'fixed' and torch.is_grad_enabled():
-            raise NotImplementedError('the learned receptor encoders have no backward pass: training is implemented with '
-                                      'rec_encoder_type="fixed"; under torch.no_grad() this forward evaluates all four losses')
+        Trainable end to end: every fixed-encoder configuration (configs/dev_config.yml, trained_models/{egnn,gvp}_all_atom,
+        {egnn,gvp}_ca: the encoder has no parameters and its loss is the constant 0, :85-87) and the learned GVP encoder
+        (trained_models/gvp_20kp, gvp_40kp): the noise prediction is differentiated by the HIP backward passes of the denoiser
+        (kpd_egnn_trainer_* / kpd_gvp_trainer_*, the latter also with respect to the keypoint positions), the keypoints by the
+        encoder's (kpd_recenc_trainer_*), and the optimal-transport encoder loss (rec_encoder_loss.py) adds its gradient at the
+        keypoint positions.  The learned EGNN encoder (egnn_20kp, egnn_40kp) is EVALUATION only -- under `torch.no_grad()`
+        (train.py's test_model) all four losses are returned; with gradients enabled it raises, because that encoder has no
+        backward pass yet."""
+        if self.rec_encoder_type != 'fixed' and self.architecture == 'egnn' and torch.is_grad_enabled():
+            raise NotImplementedError('the learned EGNN receptor encoder has no backward pass: training is implemented for '
+                                      'rec_encoder_type="fixed" and for the learned GVP encoder; under torch.no_grad() this forward '
+                                      'evaluates all four losses')
         if self.rl_dist_threshold > 0:
             raise NotImplementedError('the receptor-ligand hinge loss (rl_dist_threshold > 0) is unused by every shipped config')
         losses = {}

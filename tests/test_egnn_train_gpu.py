@@ -225,3 +225,32 @@ def test_recompute_mode_gives_the_same_gradients():
         outs.append(torch.load(path))
         os.remove(path)
     assert all(torch.equal(a, b) for a, b in zip(*outs))
+
+
+def test_backward_after_the_caller_dropped_the_graph():
+    """The training engines keep raw pointers into the prepared batch (per-complex offsets, the kk edge list) between forward
+    and backward.  A caller that builds the graph inside a helper and keeps only the losses (train.py's step functions do) frees
+    it before backward runs: the autograd node must keep the batch alive.  (Round 3 found the use-after-free with exactly this
+    pattern: garbage gradients, once a GPU memory fault.)"""
+    import gc
+    g, model, t = _case(dict(util.EGNN_C2, n_layers=2), [40, 25, 31], [6, 9, 4])
+    model = model.cuda()
+
+    def forward_only():
+        gd = g.to('cuda')
+        eh, ex = model(gd, t.cuda(), None)
+        return eh.square().sum() + ex.square().sum()          # the graph object goes out of scope here
+
+    def grads(churn):
+        model.zero_grad(set_to_none=True)
+        loss = forward_only()
+        if churn:                                              # recycle the freed blocks before backward reads them
+            gc.collect()
+            junk = [torch.full((n,), 12345, dtype=torch.int32, device='cuda') for n in (64, 257, 1024, 4096, 9000, 20000)]
+            torch.cuda.synchronize()
+            del junk
+        loss.backward()
+        return [p.grad.clone() for p in model.parameters()]
+
+    a, b = grads(False), grads(True)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
