@@ -341,6 +341,21 @@ kpd_status kpd_recegnn_reserve(kpd_recegnn *m, int32_t max_B, int32_t max_n_rec,
 kpd_status kpd_recegnn_forward(kpd_recegnn *m, const kpd_rec_batch *batch, const float *rr_same_res,
                                const kpd_rec_out *out, float *rec_h_out, float *rec_x_out, void *stream);
 
+/* Training engine of the same encoder (SURVEY.md 8(f) item 2 for row f1): forward with saved layer states, backward with respect
+ * to every parameter given the gradients of the keypoint positions and keypoint features (either may be null = zero).  The
+ * k_closest keypoint features only (every shipped config; create refuses kp_rad > 0).  Parameters are bound as in
+ * kpd_recenc_trainer_bind.  Forward fills the same outputs as kpd_recegnn_forward. */
+typedef struct kpd_recegnn_trainer kpd_recegnn_trainer;
+kpd_status kpd_recegnn_trainer_create(const kpd_recegnn_config *cfg, kpd_recegnn_trainer **out);
+void kpd_recegnn_trainer_destroy(kpd_recegnn_trainer *t);
+kpd_status kpd_recegnn_trainer_bind(kpd_recegnn_trainer *t, const char *name, const float *weight_dev, float *grad_dev,
+                                    const int64_t *shape, int32_t ndim);
+kpd_status kpd_recegnn_trainer_reserve(kpd_recegnn_trainer *t, int32_t max_B, int32_t max_n_rec, int32_t max_n_rr,
+                                       int32_t max_rec_per_graph);
+kpd_status kpd_recegnn_trainer_forward(kpd_recegnn_trainer *t, const kpd_rec_batch *batch, const float *rr_same_res,
+                                       const kpd_rec_out *out, float *rec_h_out, float *rec_x_out, void *stream);
+kpd_status kpd_recegnn_trainer_backward(kpd_recegnn_trainer *t, const float *d_kp_x, const float *d_kp_h, void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * Reverse-diffusion update around the denoiser.  Replaces the elementwise part of
  * KeypointDiffusion.sample_p_zs_given_zt (models/ligand_diffuser.py:515-536):

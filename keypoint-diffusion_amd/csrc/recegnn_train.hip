@@ -1,0 +1,744 @@
+// Training path of the EGNN keypoint receptor encoder (the encoder of egnn_20kp / egnn_40kp): forward with saved layer
+// states + backward (SURVEY.md 8(f) item 2 for row f1).  Gradients of ReceptorEncoder.forward (models/receptor_encoder.py:483-555)
+// -- the ReceptorConv stack on the rr graph (:14-154: edge MLP + soft attention, coordinate MLP with learned receptor positions,
+// node MLP without residual, LayerNorm), keypoint_embedding of the graph-mean feature (:526-530), RecKeyConv (:182-297: fc_src on
+// both sides, attention-pooled keypoint positions over the learned receptor positions, k_closest keypoint features with their
+// keypoint-to-atom distances) -- with respect to every parameter, given the gradients of the two outputs the denoiser and the
+// encoder loss consume: keypoint positions and keypoint features.
+//
+// Formulation as in the other training engines: parameters in place in the reference layout, dense products through rocBLAS,
+// deterministic segmented sums, node-sized state per layer kept, edge activations recomputed one layer at a time.  The encoder
+// runs once per batch (~170 k rr edges at B = 64), a few per cent of a training step, so the edge rows [h_src | h_dst | d | a] are
+// materialised and the first Linear is not split.  The kNN rec->kp edges and the kk radius graph are rebuilt from positions and are
+// not differentiable, as upstream (torch_cluster); the radius keypoint features (kp_rad > 0, unused by every shipped config) are
+// not differentiated: create refuses them.
+#include "gvp_train_core.h"
+#include "rec_kernels.h"
+
+namespace kpd {
+namespace {
+
+// edge geometry of ReceptorConv (:137-142): r = |x_src - x_dst| (not squared), xd = (x_src - x_dst) / (r + 1)
+__global__ void k_rc_geom(const int *__restrict__ src, const int *__restrict__ dst, const float *__restrict__ x, int E,
+                          float *__restrict__ r, float *__restrict__ xd) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int u = src[e], v = dst[e];
+    const float dx = x[3 * u] - x[3 * v], dy = x[3 * u + 1] - x[3 * v + 1], dz = x[3 * u + 2] - x[3 * v + 2];
+    const float d = sqrtf(dx * dx + dy * dy + dz * dz), inv = 1.0f / (d + 1.0f);
+    r[e] = d;
+    xd[3 * e] = dx * inv; xd[3 * e + 1] = dy * inv; xd[3 * e + 2] = dz * inv;
+}
+
+// f[e] = [h[src] (D) | h[dst] (D) | r | same_res (optional)]   (:69-83)
+__global__ void k_rc_f(const float *__restrict__ h, const int *__restrict__ src, const int *__restrict__ dst, const float *__restrict__ r,
+                       const float *__restrict__ a, long long total, int D, int fw, float *__restrict__ f) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int e = (int)(i / fw), c = (int)(i - (long long)e * fw);
+    f[i] = c < D ? h[(size_t)src[e] * D + c] : c < 2 * D ? h[(size_t)dst[e] * D + c - D] : c == 2 * D ? r[e] : a[e];
+}
+
+// soft attention (:85-86): s = <m, w> + b, msg = m sigmoid(s); one wave per edge
+__global__ void k_rc_att(const float *__restrict__ m, const float *__restrict__ w, const float *__restrict__ b, int E, int H,
+                         float *__restrict__ s, float *__restrict__ msg) {
+    const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (e >= E) return;
+    float acc = 0.0f;
+    for (int c = lane; c < H; c += 64) acc = fmaf(m[(size_t)e * H + c], w[c], acc);
+    acc = wave_sum(acc) + b[0];
+    if (lane == 0) s[e] = acc;
+    const float g = sigm(acc);
+    for (int c = lane; c < H; c += 64) msg[(size_t)e * H + c] = m[(size_t)e * H + c] * g;
+}
+
+// coordinate head (:89-92): c = <ca, w3>, msg_x = tanh(c) range xd (or c xd); one wave per edge
+__global__ void k_rc_coord(const float *__restrict__ ca, const float *__restrict__ w3, const float *__restrict__ xd, int E, int H,
+                           int use_tanh, float range, float *__restrict__ c_out, float *__restrict__ msgx) {
+    const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (e >= E) return;
+    float acc = 0.0f;
+    for (int c = lane; c < H; c += 64) acc = fmaf(ca[(size_t)e * H + c], w3[c], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) c_out[e] = acc;
+    const float t = use_tanh ? tanhf(acc) * range : acc;
+    if (lane < 3) msgx[3 * e + lane] = t * xd[3 * e + lane];
+}
+
+__global__ void k_rc_silu(const float *__restrict__ pre, long long total, float *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) out[i] = silu_f(pre[i]);
+}
+
+__global__ void k_rc_cat2(const float *__restrict__ a, int wa, const float *__restrict__ b, int wb, long long total, float *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int w = wa + wb, r = (int)(i / w), c = (int)(i - (long long)r * w);
+    out[i] = c < wa ? a[(size_t)r * wa + c] : b[(size_t)r * wb + c - wa];
+}
+
+// x_new = x + (sum of msg_x over the in-edges) / z   (:150)
+__global__ void k_rc_xnew(const float *__restrict__ x, const float *__restrict__ msgx, const int *__restrict__ rowptr,
+                          const float *__restrict__ scale, int n, float *__restrict__ xn) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    float a = 0.f, b = 0.f, c = 0.f;
+    for (int e = rowptr[v]; e < rowptr[v + 1]; ++e) { a += msgx[3 * e]; b += msgx[3 * e + 1]; c += msgx[3 * e + 2]; }
+    xn[3 * v] = x[3 * v] + a * scale[v]; xn[3 * v + 1] = x[3 * v + 1] + b * scale[v]; xn[3 * v + 2] = x[3 * v + 2] + c * scale[v];
+}
+
+__global__ void k_rc_scale(const float *__restrict__ z, const int *__restrict__ bidx, int n, float norm, float *__restrict__ scale) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < n) scale[v] = 1.0f / (z ? z[bidx[v]] : norm);
+}
+
+__global__ void k_rc_z(const int *__restrict__ rowptr, const int *__restrict__ ptr, int B, float *__restrict__ z) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) z[b] = (float)(rowptr[ptr[b + 1]] - rowptr[ptr[b]]) / (float)(ptr[b + 1] - ptr[b]);
+}
+
+// backward of the attention gate: dmsg [E, H] in, dm [E, H] out (in place), ds [E]; one wave per edge
+__global__ void k_rc_att_bwd(const float *__restrict__ m, const float *__restrict__ s, const float *__restrict__ w, int E, int H,
+                             float *__restrict__ dmsg, float *__restrict__ ds) {
+    const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (e >= E) return;
+    const float g = sigm(s[e]);
+    float acc = 0.0f;
+    for (int c = lane; c < H; c += 64) acc = fmaf(dmsg[(size_t)e * H + c], m[(size_t)e * H + c], acc);
+    const float d_s = wave_sum(acc) * g * (1.0f - g);
+    if (lane == 0) ds[e] = d_s;
+    for (int c = lane; c < H; c += 64) dmsg[(size_t)e * H + c] = dmsg[(size_t)e * H + c] * g + d_s * w[c];
+}
+
+// backward of the coordinate head: d msg_x[e] = gx[dst] scale[dst]; dc [E], dxd [E, 3]
+__global__ void k_rc_coord_bwd(const float *__restrict__ gx, const int *__restrict__ dst, const float *__restrict__ scale,
+                               const float *__restrict__ xd, const float *__restrict__ c, int E, int use_tanh, float range,
+                               float *__restrict__ dc, float *__restrict__ dxd) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int v = dst[e];
+    const float sc = scale[v];
+    const float th = use_tanh ? tanhf(c[e]) : 0.0f, t = use_tanh ? th * range : c[e];
+    float dt = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float dm = gx[3 * v + k] * sc;
+        dt = fmaf(dm, xd[3 * e + k], dt);
+        dxd[3 * e + k] = dm * t;
+    }
+    // 1 - tanh^2 = sech^2 = 4 e / (1 + e)^2 with e = exp(-2 |c|): no cancellation near saturation (1 - th * th loses every digit there)
+    const float ex = expf(-2.0f * fabsf(c[e])), sech2 = 4.0f * ex / ((1.0f + ex) * (1.0f + ex));
+    dc[e] = use_tanh ? dt * range * sech2 : dt;
+}
+
+// dcpre[e, :] = dc[e] w3[:] SiLU'(cpre[e, :])
+__global__ void k_rc_dcpre(const float *__restrict__ dc, const float *__restrict__ w3, const float *__restrict__ cpre, long long total, int H,
+                           float *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int e = (int)(i / H), c = (int)(i - (long long)e * H);
+    out[i] = dc[e] * w3[c] * silu_grad(cpre[i]);
+}
+
+// geometry backward: xd = diff / (r + 1), r = |diff|; dr arrives in column `col` of df
+__global__ void k_rc_geom_bwd(const int *__restrict__ src, const int *__restrict__ dst, const float *__restrict__ x, const float *__restrict__ r,
+                              const float *__restrict__ dxd, const float *__restrict__ df, int fw, int col, int E, float *__restrict__ dxe) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int u = src[e], v = dst[e];
+    const float df3[3] = {x[3 * u] - x[3 * v], x[3 * u + 1] - x[3 * v + 1], x[3 * u + 2] - x[3 * v + 2]};
+    const float d = r[e], inv = 1.0f / (d + 1.0f);
+    float dr = df[(size_t)e * fw + col];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dr -= (dxd ? dxd[3 * e + k] : 0.0f) * df3[k] * inv * inv;
+    const float q = d > 0.0f ? dr / d : 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dxe[3 * e + k] = (dxd ? dxd[3 * e + k] : 0.0f) * inv + q * df3[k];
+}
+
+__global__ void k_rc_mean_bwd(const float *__restrict__ dmean, const int *__restrict__ bidx, const int *__restrict__ ptr, long long total, int D,
+                              float *__restrict__ g) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int r = (int)(i / D), c = (int)(i - (long long)r * D), b = bidx[r];
+    g[i] += dmean[(size_t)b * D + c] / (float)(ptr[b + 1] - ptr[b]);
+}
+
+// RecKeyConv attention (:188-222) with kept weights: w[r * K + k] = softmax over the graph's atoms; kp_x = sum w x_val
+__global__ __launch_bounds__(256) void k_rk_att_fwd(const float *__restrict__ ft_src, const float *__restrict__ ft_dst, const float *__restrict__ xv,
+                                                    const int *__restrict__ rec_ptr, int K, int D, float *__restrict__ w, float *__restrict__ kp_x) {
+    __shared__ float s_q[256];
+    __shared__ float s_part[256][4];
+    const int kp = blockIdx.x, g = kp / K, k = kp - g * K, tid = threadIdx.x;
+    if (tid < D) s_q[tid] = ft_dst[(size_t)kp * D + tid];
+    __syncthreads();
+    const float scale = 1.0f / sqrtf((float)D);
+    float a_sum = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+    for (int r = rec_ptr[g] + tid; r < rec_ptr[g + 1]; r += 256) {
+        const float *f = ft_src + (size_t)r * D;
+        float dot = 0.0f;
+        for (int j = 0; j < D; ++j) dot = fmaf(f[j], s_q[j], dot);
+        const float a = expf(dot * scale);
+        w[(size_t)r * K + k] = a;
+        a_sum += a;
+        ax = fmaf(a, xv[(size_t)r * 3], ax); ay = fmaf(a, xv[(size_t)r * 3 + 1], ay); az = fmaf(a, xv[(size_t)r * 3 + 2], az);
+    }
+    s_part[tid][0] = a_sum; s_part[tid][1] = ax; s_part[tid][2] = ay; s_part[tid][3] = az;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if (tid < o)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s_part[tid][c] += s_part[tid + o][c];
+        __syncthreads();
+    }
+    const float inv = 1.0f / s_part[0][0];
+    for (int r = rec_ptr[g] + tid; r < rec_ptr[g + 1]; r += 256) w[(size_t)r * K + k] *= inv;
+    if (tid < 3) kp_x[(size_t)kp * 3 + tid] = s_part[0][1 + tid] * inv;
+}
+
+// d x_val[r] += sum_k w[r, k] dkp_x[k]  (before w is overwritten by the logit gradients); one thread per atom
+__global__ void k_rk_att_bwd_val(const float *__restrict__ w, const float *__restrict__ dkp_x, const int *__restrict__ bidx, int n, int K,
+                                 float *__restrict__ gx) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int g = bidx[r];
+    float a = 0.f, b = 0.f, c = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float wk = w[(size_t)r * K + k];
+        a = fmaf(wk, dkp_x[((size_t)g * K + k) * 3], a); b = fmaf(wk, dkp_x[((size_t)g * K + k) * 3 + 1], b);
+        c = fmaf(wk, dkp_x[((size_t)g * K + k) * 3 + 2], c);
+    }
+    gx[3 * r] += a; gx[3 * r + 1] += b; gx[3 * r + 2] += c;
+}
+
+__global__ __launch_bounds__(256) void k_rk_att_bwd_logits(float *__restrict__ w, const float *__restrict__ xv, const int *__restrict__ rec_ptr, int K,
+                                                           int D, const float *__restrict__ dkp_x, const float *__restrict__ kp_x) {
+    const int kp = blockIdx.x, g = kp / K, k = kp - g * K;
+    const float dx = dkp_x[(size_t)kp * 3], dy = dkp_x[(size_t)kp * 3 + 1], dz = dkp_x[(size_t)kp * 3 + 2];
+    const float base = dx * kp_x[(size_t)kp * 3] + dy * kp_x[(size_t)kp * 3 + 1] + dz * kp_x[(size_t)kp * 3 + 2];
+    const float scale = 1.0f / sqrtf((float)D);
+    for (int r = rec_ptr[g] + threadIdx.x; r < rec_ptr[g + 1]; r += 256) {
+        const float dw = dx * xv[(size_t)r * 3] + dy * xv[(size_t)r * 3 + 1] + dz * xv[(size_t)r * 3 + 2];
+        w[(size_t)r * K + k] *= (dw - base) * scale;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rk_att_bwd_dst(const float *__restrict__ G, const float *__restrict__ ft_src, const int *__restrict__ rec_ptr,
+                                                        int K, int D, float *__restrict__ dft_dst) {
+    const int kp = blockIdx.x, g = kp / K, k = kp - g * K, s = threadIdx.x;
+    if (s >= D) return;
+    float acc = 0.0f;
+    for (int r = rec_ptr[g]; r < rec_ptr[g + 1]; ++r) acc = fmaf(G[(size_t)r * K + k], ft_src[(size_t)r * D + s], acc);
+    dft_dst[(size_t)kp * D + s] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_rk_att_bwd_src(const float *__restrict__ G, const float *__restrict__ ft_dst, const int *__restrict__ bidx,
+                                                        int K, int D, float *__restrict__ dft_src) {
+    const int r = blockIdx.x, s = threadIdx.x, g = bidx[r];
+    if (s >= D) return;
+    float acc = 0.0f;
+    for (int k = 0; k < K; ++k) acc = fmaf(G[(size_t)r * K + k], ft_dst[((size_t)g * K + k) * D + s], acc);
+    dft_src[(size_t)r * D + s] = acc;
+}
+
+// keypoint feature rows (:284-289): [mean over the k nearest atoms of h | the k distances |x0 - kp_x + 1e-30|]
+__global__ void k_rk_feat_in(const float *__restrict__ h, const float *__restrict__ x0, const float *__restrict__ kp_x, const int *__restrict__ rk_src,
+                             int k, int D, long long total, float *__restrict__ fin) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int w = D + k, kp = (int)(i / w), c = (int)(i - (long long)kp * w);
+    if (c < D) {
+        float acc = 0.0f;
+        for (int j = 0; j < k; ++j) acc += h[(size_t)rk_src[kp * k + j] * D + c];
+        fin[i] = acc / (float)k;
+    } else {
+        const int r = rk_src[kp * k + c - D];
+        const float dx = x0[(size_t)r * 3] - kp_x[(size_t)kp * 3] + 1e-30f, dy = x0[(size_t)r * 3 + 1] - kp_x[(size_t)kp * 3 + 1] + 1e-30f,
+                    dz = x0[(size_t)r * 3 + 2] - kp_x[(size_t)kp * 3 + 2] + 1e-30f;
+        fin[i] = sqrtf(dx * dx + dy * dy + dz * dz);
+    }
+}
+
+// backward of the distance columns: d kp_x[kp] -= sum_j dfin[kp, D + j] (x0[r_j] - kp_x[kp]) / d_j
+__global__ void k_rk_feat_dx(const float *__restrict__ dfin, const float *__restrict__ fin, const float *__restrict__ x0, const float *__restrict__ kp_x,
+                             const int *__restrict__ rk_src, int k, int D, int n_kp, float *__restrict__ gkx) {
+    const int kp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (kp >= n_kp) return;
+    const int w = D + k;
+    float a = 0.f, b = 0.f, c = 0.f;
+    for (int j = 0; j < k; ++j) {
+        const int r = rk_src[kp * k + j];
+        const float d = fin[(size_t)kp * w + D + j], g = d > 0.0f ? dfin[(size_t)kp * w + D + j] / d : 0.0f;
+        a += g * (x0[(size_t)r * 3] - kp_x[(size_t)kp * 3]); b += g * (x0[(size_t)r * 3 + 1] - kp_x[(size_t)kp * 3 + 1]);
+        c += g * (x0[(size_t)r * 3 + 2] - kp_x[(size_t)kp * 3 + 2]);
+    }
+    gkx[3 * kp] -= a; gkx[3 * kp + 1] -= b; gkx[3 * kp + 2] -= c;
+}
+
+// gh[r, :] += sum over the rk edges leaving atom r of dfin[kp(edge), 0:D] / k  (edges grouped by source, ascending)
+__global__ void k_rk_feat_dh(const float *__restrict__ dfin, const int *__restrict__ perm, const int *__restrict__ rowptr, int k, int D, int w,
+                             float *__restrict__ gh) {
+    const int r = blockIdx.x;
+    const int lo = rowptr[r], hi = rowptr[r + 1];
+    if (lo == hi) return;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        float acc = 0.0f;
+        for (int j = lo; j < hi; ++j) acc += dfin[(size_t)(perm[j] / k) * w + c];
+        gh[(size_t)r * D + c] += acc / (float)k;
+    }
+}
+
+}  // namespace
+}  // namespace kpd
+
+using namespace kpd;
+
+struct kpd_recegnn_trainer : TrainCtx {
+    kpd_recegnn_config cfg{};
+    Arena ws;
+    int cap_B = 0, cap_rec = 0, cap_rr = 0, cap_maxrec = 0, cap_rk = 0;
+    kpd_rec_batch bt{};
+    const float *same_res = nullptr;
+    bool have_forward = false;
+    int B = 0, n_rec = 0, n_kp = 0, E_rk = 0;
+    int *bidx = nullptr, *kp_ptr = nullptr, *rk_src = nullptr, *rk_dst = nullptr, *rk_rowptr = nullptr, *off_tmp = nullptr, *xm_src = nullptr,
+        *xm_dst = nullptr, *xm_rowptr = nullptr, *kk_rowptr = nullptr, *deg_tmp = nullptr, *kk_off = nullptr, *cursor = nullptr;
+    SrcCsr scsr_rr, scsr_rk;
+    float *z = nullptr, *scale = nullptr;
+    // saved per layer: input h / x, aggregated messages, node-MLP pre-activation, pre-LayerNorm output
+    std::vector<float *> hs, xs, hneigh, npre, hn;
+    float *gmean = nullptr, *kpe_pre = nullptr, *kp_h0 = nullptr, *ft_src = nullptr, *ft_dst = nullptr, *att = nullptr, *kp_x = nullptr,
+          *fin = nullptr, *fpre = nullptr, *fact = nullptr;
+    // edge scratch
+    float *r = nullptr, *xd = nullptr, *f = nullptr, *pre1 = nullptr, *a1 = nullptr, *pre2 = nullptr, *m = nullptr, *s = nullptr, *msg = nullptr,
+          *cpre = nullptr, *ca = nullptr, *c = nullptr, *msgx = nullptr, *df = nullptr, *dE = nullptr, *dE2 = nullptr, *dc = nullptr, *dxd = nullptr,
+          *dxe = nullptr, *ds = nullptr;
+    // node scratch / gradients
+    float *cat = nullptr, *na = nullptr, *gh[2] = {nullptr, nullptr}, *gx[2] = {nullptr, nullptr}, *gn1 = nullptr, *gn2 = nullptr, *gcat = nullptr,
+          *gkx = nullptr, *gk1 = nullptr, *gk2 = nullptr, *big = nullptr;
+    int Dmax = 0, H = 0;
+    int din(int i) const { return i == 0 ? cfg.in_n_node_feat : cfg.hidden_n_node_feat; }
+    int dout(int i) const { return i == cfg.n_convs - 1 ? cfg.out_n_node_feat : cfg.hidden_n_node_feat; }
+    int fw(int i) const { return 2 * din(i) + 1 + (cfg.use_sameres_feat ? 1 : 0); }
+};
+
+namespace {
+
+struct ConvP {
+    Param W1, b1, W2, b2, watt, batt, Wc1, bc1, w3, Wn1, bn1, Wn2, bn2, lw, lb;
+};
+
+kpd_status conv_params(kpd_recegnn_trainer *T, int i, ConvP *p) {
+    const std::string q = "rec_convs." + std::to_string(i);
+    const int H = T->H, fw = T->fw(i), Din = T->din(i), Dout = T->dout(i);
+    KPD_TRY(param(T, q + ".edge_mlp.0.weight", H, fw, &p->W1)); KPD_TRY(param(T, q + ".edge_mlp.0.bias", H, 1, &p->b1));
+    KPD_TRY(param(T, q + ".edge_mlp.2.weight", H, H, &p->W2)); KPD_TRY(param(T, q + ".edge_mlp.2.bias", H, 1, &p->b2));
+    KPD_TRY(param(T, q + ".soft_attention.0.weight", 1, H, &p->watt)); KPD_TRY(param(T, q + ".soft_attention.0.bias", 1, 1, &p->batt));
+    if (!T->cfg.fix_pos) {
+        KPD_TRY(param(T, q + ".coord_mlp.0.weight", H, fw, &p->Wc1)); KPD_TRY(param(T, q + ".coord_mlp.0.bias", H, 1, &p->bc1));
+        KPD_TRY(param(T, q + ".coord_mlp.2.weight", 1, H, &p->w3));
+    }
+    KPD_TRY(param(T, q + ".node_mlp.0.weight", H, Din + H, &p->Wn1)); KPD_TRY(param(T, q + ".node_mlp.0.bias", H, 1, &p->bn1));
+    KPD_TRY(param(T, q + ".node_mlp.2.weight", Dout, H, &p->Wn2)); KPD_TRY(param(T, q + ".node_mlp.2.bias", Dout, 1, &p->bn2));
+    if (T->cfg.norm) {
+        KPD_TRY(param(T, q + ".layer_norm.weight", Dout, 1, &p->lw)); KPD_TRY(param(T, q + ".layer_norm.bias", Dout, 1, &p->lb));
+    }
+    return KPD_OK;
+}
+
+// per-edge part of ReceptorConv layer i from (hs[i], xs[i]): leaves r, xd, f, pre1, a1, pre2, m, s, msg (and cpre, ca, c, msgx)
+kpd_status conv_edges_fwd(kpd_recegnn_trainer *T, int i, const ConvP &p) {
+    const int E = T->bt.n_rr, H = T->H, fw = T->fw(i), Din = T->din(i);
+    if (E == 0) return KPD_OK;
+    hipStream_t st = T->st;
+    hipLaunchKernelGGL(k_rc_geom, grid1(E), dim3(256), 0, st, T->bt.rr_src, T->bt.rr_dst, T->xs[i], E, T->r, T->xd);
+    KPD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_rc_f, grid1((long long)E * fw), dim3(256), 0, st, T->hs[i], T->bt.rr_src, T->bt.rr_dst, T->r, T->same_res,
+                       (long long)E * fw, Din, fw, T->f);
+    KPD_LAUNCH_CHECK();
+    const long long tot = (long long)E * H;
+    KPD_TRY(gemm(T, false, true, E, H, fw, T->f, fw, p.W1.w, fw, 0.0f, T->pre1, H));
+    hipLaunchKernelGGL(k_bias_silu, grid1(tot), dim3(256), 0, st, T->pre1, p.b1.w, tot, H, H, T->a1);
+    KPD_LAUNCH_CHECK();
+    KPD_TRY(gemm(T, false, true, E, H, H, T->a1, H, p.W2.w, H, 0.0f, T->pre2, H));
+    hipLaunchKernelGGL(k_bias_silu, grid1(tot), dim3(256), 0, st, T->pre2, p.b2.w, tot, H, H, T->m);
+    KPD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_rc_att, dim3(cdiv(E, 4)), dim3(256), 0, st, T->m, p.watt.w, p.batt.w, E, H, T->s, T->msg);
+    KPD_LAUNCH_CHECK();
+    if (!T->cfg.fix_pos) {
+        KPD_TRY(gemm(T, false, true, E, H, fw, T->f, fw, p.Wc1.w, fw, 0.0f, T->cpre, H));
+        hipLaunchKernelGGL(k_bias_silu, grid1(tot), dim3(256), 0, st, T->cpre, p.bc1.w, tot, H, H, T->ca);
+        KPD_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_rc_coord, dim3(cdiv(E, 4)), dim3(256), 0, st, T->ca, p.w3.w, T->xd, E, H, T->cfg.use_tanh, T->cfg.coords_range, T->c,
+                           T->msgx);
+        KPD_LAUNCH_CHECK();
+    }
+    return KPD_OK;
+}
+
+kpd_status conv_fwd(kpd_recegnn_trainer *T, int i) {
+    const int n = T->n_rec, H = T->H, Din = T->din(i), Dout = T->dout(i), E = T->bt.n_rr;
+    hipStream_t st = T->st;
+    ConvP p;
+    KPD_TRY(conv_params(T, i, &p));
+    KPD_TRY(conv_edges_fwd(T, i, p));
+    KPD_HIP(hipMemsetAsync(T->hneigh[i], 0, (size_t)n * H * 4, st));
+    if (E > 0) {
+        hipLaunchKernelGGL(k_segsum, dim3(n), dim3(256), 0, st, T->msg, H, T->bt.rr_rowptr, T->scale, T->hneigh[i]);       // :144-147
+        KPD_LAUNCH_CHECK();
+    }
+    if (T->cfg.fix_pos || E == 0) KPD_HIP(hipMemcpyAsync(T->xs[i + 1], T->xs[i], (size_t)n * 12, hipMemcpyDeviceToDevice, st));
+    else {
+        hipLaunchKernelGGL(k_rc_xnew, grid1(n), dim3(256), 0, st, T->xs[i], T->msgx, T->bt.rr_rowptr, T->scale, n, T->xs[i + 1]);
+        KPD_LAUNCH_CHECK();
+    }
+    // node MLP on [h, h_neigh] (no residual, :149), LayerNorm
+    hipLaunchKernelGGL(k_rc_cat2, grid1((long long)n * (Din + H)), dim3(256), 0, st, T->hs[i], Din, T->hneigh[i], H, (long long)n * (Din + H), T->cat);
+    KPD_LAUNCH_CHECK();
+    KPD_TRY(gemm(T, false, true, n, H, Din + H, T->cat, Din + H, p.Wn1.w, Din + H, 0.0f, T->npre[i], H));
+    hipLaunchKernelGGL(k_bias_silu, grid1((long long)n * H), dim3(256), 0, st, T->npre[i], p.bn1.w, (long long)n * H, H, H, T->na);
+    KPD_LAUNCH_CHECK();
+    float *out = T->cfg.norm ? T->hn[i] : T->hs[i + 1];
+    KPD_TRY(gemm(T, false, true, n, Dout, H, T->na, H, p.Wn2.w, H, 0.0f, out, Dout));
+    hipLaunchKernelGGL(k_bias_add, grid1((long long)n * Dout), dim3(256), 0, st, out, p.bn2.w, (long long)n * Dout, Dout, Dout);
+    KPD_LAUNCH_CHECK();
+    if (T->cfg.norm) {
+        hipLaunchKernelGGL(k_ln_fwd, dim3(cdiv(n, 4)), dim3(256), 0, st, T->hn[i], p.lw.w, p.lb.w, n, Dout, T->hs[i + 1]);
+        KPD_LAUNCH_CHECK();
+    }
+    return KPD_OK;
+}
+
+// gh_out [n, Dout] / gx_out [n, 3]: gradient of (hs[i + 1], xs[i + 1]); gh_in [n, Din] / gx_in [n, 3]: of (hs[i], xs[i]) (overwritten)
+kpd_status conv_bwd(kpd_recegnn_trainer *T, int i, float *gh_out, const float *gx_out, float *gh_in, float *gx_in) {
+    const int n = T->n_rec, H = T->H, Din = T->din(i), Dout = T->dout(i), E = T->bt.n_rr, fw = T->fw(i);
+    hipStream_t st = T->st;
+    ConvP p;
+    KPD_TRY(conv_params(T, i, &p));
+    // LayerNorm, node MLP
+    float *d_hn = gh_out;
+    if (T->cfg.norm) {
+        hipLaunchKernelGGL(k_ln_bwd_g, dim3(cdiv(n, 4)), dim3(256), 0, st, T->hn[i], p.lw.w, gh_out, n, Dout, T->gn1, T->gn2);
+        KPD_LAUNCH_CHECK();
+        KPD_TRY(colsum_acc(T, n, Dout, T->gn2, Dout, p.lw.g));
+        KPD_TRY(colsum_acc(T, n, Dout, gh_out, Dout, p.lb.g));
+        d_hn = T->gn1;
+    }
+    hipLaunchKernelGGL(k_rc_silu, grid1((long long)n * H), dim3(256), 0, st, T->npre[i], (long long)n * H, T->na);      // na again
+    KPD_LAUNCH_CHECK();
+    KPD_TRY(colsum_acc(T, n, Dout, d_hn, Dout, p.bn2.g));
+    if (p.Wn2.g) KPD_TRY(grad_gemm(T, Dout, H, n, d_hn, Dout, T->na, H, p.Wn2.g, H));
+    KPD_TRY(gemm(T, false, false, n, H, Dout, d_hn, Dout, p.Wn2.w, H, 0.0f, T->gn2, H));           // d na
+    hipLaunchKernelGGL(k_silu_bwd, grid1((long long)n * H), dim3(256), 0, st, T->gn2, T->npre[i], (long long)n * H, H, H);
+    KPD_LAUNCH_CHECK();
+    KPD_TRY(colsum_acc(T, n, H, T->gn2, H, p.bn1.g));
+    hipLaunchKernelGGL(k_rc_cat2, grid1((long long)n * (Din + H)), dim3(256), 0, st, T->hs[i], Din, T->hneigh[i], H, (long long)n * (Din + H), T->cat);
+    KPD_LAUNCH_CHECK();
+    if (p.Wn1.g) KPD_TRY(grad_gemm(T, H, Din + H, n, T->gn2, H, T->cat, Din + H, p.Wn1.g, Din + H));
+    KPD_TRY(gemm(T, false, false, n, Din + H, H, T->gn2, H, p.Wn1.w, Din + H, 0.0f, T->gcat, Din + H));       // d [h | h_neigh]
+    hipLaunchKernelGGL(k_copy_rows, grid1((long long)n * Din), dim3(256), 0, st, T->gcat, Din + H, gh_in, Din, (long long)n * Din, Din);
+    KPD_LAUNCH_CHECK();
+    KPD_HIP(hipMemcpyAsync(gx_in, gx_out, (size_t)n * 12, hipMemcpyDeviceToDevice, st));                        // x_new = x + ...
+    if (E == 0) return KPD_OK;
+    KPD_TRY(conv_edges_fwd(T, i, p));
+    // feature messages: d msg[e] = d h_neigh[dst] / z
+    hipLaunchKernelGGL(k_copy_rows, grid1((long long)n * H), dim3(256), 0, st, T->gcat + Din, Din + H, T->gn1, H, (long long)n * H, H);
+    KPD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_gather_rows, grid1((long long)E * H), dim3(256), 0, st, T->gn1, T->bt.rr_dst, T->scale, (long long)E * H, H, T->dE);
+    KPD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_rc_att_bwd, dim3(cdiv(E, 4)), dim3(256), 0, st, T->m, T->s, p.watt.w, E, H, T->dE, T->ds);
+    KPD_LAUNCH_CHECK();
+    KPD_TRY(gemv_t_acc(T, E, H, T->m, H, T->ds, p.watt.g, 1));
+    if (p.batt.g) {
+        hipLaunchKernelGGL(k_sum_scalar, dim3(1), dim3(1024), 0, st, T->ds, E, p.batt.g);
+        KPD_LAUNCH_CHECK();
+    }
+    const long long tot = (long long)E * H;
+    hipLaunchKernelGGL(k_silu_bwd, grid1(tot), dim3(256), 0, st, T->dE, T->pre2, tot, H, H);              // d pre2
+    KPD_LAUNCH_CHECK();
+    KPD_TRY(colsum_acc(T, E, H, T->dE, H, p.b2.g));
+    if (p.W2.g) KPD_TRY(grad_gemm(T, H, H, E, T->dE, H, T->a1, H, p.W2.g, H));
+    KPD_TRY(gemm(T, false, false, E, H, H, T->dE, H, p.W2.w, H, 0.0f, T->dE2, H));                        // d a1
+    hipLaunchKernelGGL(k_silu_bwd, grid1(tot), dim3(256), 0, st, T->dE2, T->pre1, tot, H, H);             // d pre1
+    KPD_LAUNCH_CHECK();
+    KPD_TRY(colsum_acc(T, E, H, T->dE2, H, p.b1.g));
+    if (p.W1.g) KPD_TRY(grad_gemm(T, H, fw, E, T->dE2, H, T->f, fw, p.W1.g, fw));
+    KPD_TRY(gemm(T, false, false, E, fw, H, T->dE2, H, p.W1.w, fw, 0.0f, T->df, fw));                     // d f
+    // coordinate messages: d msg_x[e] = gx_out[dst] / z
+    if (!T->cfg.fix_pos) {
+        hipLaunchKernelGGL(k_rc_coord_bwd, grid1(E), dim3(256), 0, st, gx_out, T->bt.rr_dst, T->scale, T->xd, T->c, E, T->cfg.use_tanh,
+                           T->cfg.coords_range, T->dc, T->dxd);
+        KPD_LAUNCH_CHECK();
+        KPD_TRY(gemv_t_acc(T, E, H, T->ca, H, T->dc, p.w3.g, 1));
+        hipLaunchKernelGGL(k_rc_dcpre, grid1(tot), dim3(256), 0, st, T->dc, p.w3.w, T->cpre, tot, H, T->dE);
+        KPD_LAUNCH_CHECK();
+        KPD_TRY(colsum_acc(T, E, H, T->dE, H, p.bc1.g));
+        if (p.Wc1.g) KPD_TRY(grad_gemm(T, H, fw, E, T->dE, H, T->f, fw, p.Wc1.g, fw));
+        KPD_TRY(gemm(T, false, false, E, fw, H, T->dE, H, p.Wc1.w, fw, 1.0f, T->df, fw));
+    }
+    // f = [h_src | h_dst | r | a]: node features by source (grouped index) and destination (contiguous), then the geometry
+    hipLaunchKernelGGL(k_segsum_perm, dim3(n), dim3(256), 0, st, T->df, fw, 0, Din, T->scsr_rr.perm, T->scsr_rr.rowptr, 1.0f, 1, gh_in, Din);
+    KPD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_segsum_perm, dim3(n), dim3(256), 0, st, T->df, fw, Din, Din, (const int *)nullptr, T->bt.rr_rowptr, 1.0f, 1, gh_in, Din);
+    KPD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_rc_geom_bwd, grid1(E), dim3(256), 0, st, T->bt.rr_src, T->bt.rr_dst, T->xs[i], T->r, T->cfg.fix_pos ? nullptr : T->dxd, T->df,
+                       fw, 2 * Din, E, T->dxe);
+    KPD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_seg3, grid1(n), dim3(256), 0, st, T->dxe, T->scsr_rr.perm, T->scsr_rr.rowptr, n, 1.0f, gx_in);
+    KPD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_seg3, grid1(n), dim3(256), 0, st, T->dxe, (const int *)nullptr, T->bt.rr_rowptr, n, -1.0f, gx_in);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+}  // namespace
+
+extern "C" kpd_status kpd_recegnn_trainer_create(const kpd_recegnn_config *cfg, kpd_recegnn_trainer **out) {
+    KPD_REQUIRE(cfg && out, KPD_ERR_INVALID, "null argument");
+    KPD_REQUIRE(cfg->n_convs >= 1 && cfg->n_convs <= 32 && cfg->n_keypoints >= 1 && cfg->n_keypoints <= 256, KPD_ERR_INVALID, "n_convs=%d n_keypoints=%d",
+                cfg->n_convs, cfg->n_keypoints);
+    KPD_REQUIRE(cfg->in_n_node_feat >= 1 && cfg->in_n_node_feat <= 256 && cfg->hidden_n_node_feat >= 1 && cfg->hidden_n_node_feat <= 256 &&
+                    cfg->out_n_node_feat >= 1 && cfg->out_n_node_feat <= 256, KPD_ERR_INVALID, "feature widths %d / %d / %d (1..256)",
+                cfg->in_n_node_feat, cfg->hidden_n_node_feat, cfg->out_n_node_feat);
+    KPD_REQUIRE(cfg->k_closest >= 1 && cfg->k_closest <= 16 && cfg->kp_rad == 0.0f, KPD_ERR_INVALID,
+                "the training engine differentiates the k_closest keypoint features (every shipped config); kp_rad features are inference only");
+    KPD_REQUIRE(cfg->message_norm >= 0.0f, KPD_ERR_INVALID, "message_norm=%g", (double)cfg->message_norm);
+    kpd_recegnn_trainer *T = new kpd_recegnn_trainer();
+    T->cfg = *cfg;
+    T->H = cfg->hidden_n_node_feat;
+    T->Dmax = std::max(std::max(cfg->in_n_node_feat, cfg->hidden_n_node_feat), cfg->out_n_node_feat);
+    if (rocblas_create_handle(&T->blas) != rocblas_status_success) {
+        delete T;
+        set_error("rocblas_create_handle failed");
+        return KPD_ERR_HIP;
+    }
+    (void)rocblas_set_atomics_mode(T->blas, rocblas_atomics_not_allowed);
+    *out = T;
+    return KPD_OK;
+}
+
+extern "C" void kpd_recegnn_trainer_destroy(kpd_recegnn_trainer *T) {
+    if (!T) return;
+    if (T->blas) rocblas_destroy_handle(T->blas);
+    T->ws.release();
+    delete T;
+}
+
+extern "C" kpd_status kpd_recegnn_trainer_bind(kpd_recegnn_trainer *T, const char *name, const float *weight, float *grad, const int64_t *shape,
+                                               int32_t ndim) {
+    KPD_REQUIRE(T && name && shape && (ndim == 1 || ndim == 2), KPD_ERR_INVALID, "bad argument");
+    Param p;
+    p.w = weight;
+    p.g = grad;
+    p.rows = (int)shape[0];
+    p.cols = ndim == 2 ? (int)shape[1] : 1;
+    T->params[name] = p;
+    return KPD_OK;
+}
+
+extern "C" kpd_status kpd_recegnn_trainer_reserve(kpd_recegnn_trainer *T, int32_t max_B, int32_t max_n_rec, int32_t max_n_rr, int32_t max_rec_pg) {
+    KPD_REQUIRE(T, KPD_ERR_INVALID, "null trainer");
+    KPD_REQUIRE(max_B >= 1 && max_n_rec >= 1 && max_n_rr >= 0 && max_rec_pg >= 1, KPD_ERR_INVALID, "bad capacities");
+    if (max_B <= T->cap_B && max_n_rec <= T->cap_rec && max_n_rr <= T->cap_rr && max_rec_pg <= T->cap_maxrec) return KPD_OK;
+    const kpd_recegnn_config &c = T->cfg;
+    max_B = std::max(max_B, T->cap_B); max_n_rec = std::max(max_n_rec, T->cap_rec); max_n_rr = std::max(max_n_rr, T->cap_rr);
+    max_rec_pg = std::max(max_rec_pg, T->cap_maxrec);
+    const int H = T->H, D = c.out_n_node_feat, K = c.n_keypoints, L = c.n_convs, Dm = T->Dmax, n_kp = max_B * K;
+    const int cap_rk = std::max(n_kp * c.k_closest, 1), E = std::max<int>(max_n_rr, 1), FW = 2 * Dm + 2;
+    T->hs.assign(L + 1, nullptr); T->xs.assign(L + 1, nullptr); T->hneigh.assign(L, nullptr); T->npre.assign(L, nullptr); T->hn.assign(L, nullptr);
+    T->ws.release();
+    for (int pass = 0; pass < 2; ++pass) {
+        size_t bytes = 0;
+        auto F = [&](float *&p, size_t count) {
+            if (pass == 0) bytes += (count * 4 + 255) & ~size_t(255);
+            else p = T->ws.take<float>(count);
+        };
+        auto I = [&](int *&p, size_t count) {
+            if (pass == 0) bytes += (count * 4 + 255) & ~size_t(255);
+            else p = T->ws.take<int>(count);
+        };
+        const size_t nr = max_n_rec, nk = n_kp, W = (size_t)std::max(Dm + H, D + 16);
+        for (int i = 0; i <= L; ++i) { F(T->hs[i], nr * Dm); F(T->xs[i], nr * 3); }
+        for (int i = 0; i < L; ++i) { F(T->hneigh[i], nr * H); F(T->npre[i], nr * H); F(T->hn[i], nr * Dm); }
+        F(T->gmean, (size_t)max_B * D); F(T->kpe_pre, nk * D); F(T->kp_h0, nk * D); F(T->big, nk * D); F(T->ft_src, nr * D); F(T->ft_dst, nk * D);
+        F(T->att, nr * K); F(T->kp_x, nk * 3); F(T->fin, nk * (D + 16)); F(T->fpre, nk * D); F(T->fact, nk * D);
+        F(T->r, E); F(T->xd, (size_t)E * 3); F(T->f, (size_t)E * FW); F(T->pre1, (size_t)E * H); F(T->a1, (size_t)E * H); F(T->pre2, (size_t)E * H);
+        F(T->m, (size_t)E * H); F(T->s, E); F(T->msg, (size_t)E * H); F(T->cpre, (size_t)E * H); F(T->ca, (size_t)E * H); F(T->c, E);
+        F(T->msgx, (size_t)E * 3); F(T->df, (size_t)E * FW); F(T->dE, (size_t)E * H); F(T->dE2, (size_t)E * H); F(T->dc, E); F(T->dxd, (size_t)E * 3);
+        F(T->dxe, (size_t)E * 3); F(T->ds, E);
+        F(T->cat, nr * W); F(T->na, nr * H); F(T->gcat, nr * W); F(T->gn1, nr * std::max(Dm, H)); F(T->gn2, nr * std::max(Dm, H));
+        for (int k = 0; k < 2; ++k) { F(T->gh[k], nr * Dm); F(T->gx[k], nr * 3); }
+        F(T->gkx, nk * 3); F(T->gk1, nk * (D + 16)); F(T->gk2, nk * (D + 16));
+        F(T->z, (size_t)max_B + 8); F(T->scale, nr);
+        F(T->part, (size_t)GRAD_SPLIT * 264 * 520); F(T->ones, 8); F(T->colpart, colpart_floats(std::max<int>(E, (int)std::max(nr, nk))));
+        I(T->bidx, nr); I(T->kp_ptr, max_B + 1); I(T->rk_src, cap_rk); I(T->rk_dst, cap_rk); I(T->rk_rowptr, nk + 1);
+        I(T->off_tmp, max_B + 2); I(T->xm_src, cap_rk); I(T->xm_dst, cap_rk); I(T->xm_rowptr, nr + 1); I(T->cursor, std::max(nr, nk));
+        I(T->scsr_rr.perm, E); I(T->scsr_rr.rowptr, nr + 1); I(T->scsr_rk.perm, cap_rk); I(T->scsr_rk.rowptr, nr + 1);
+        I(T->kk_rowptr, nk + 1); I(T->deg_tmp, nk); I(T->kk_off, max_B + 1);
+        if (pass == 0) KPD_TRY(T->ws.reserve(bytes + 4096));
+    }
+    KPD_REQUIRE(T->kk_off != nullptr, KPD_ERR_HIP, "workspace arena too small (internal sizing error)");
+    T->part_floats = (size_t)GRAD_SPLIT * 264 * 520;
+    T->colpart_blocks = cdiv(std::max<int>(E, std::max(max_n_rec, n_kp)), HEAD_ROWS);
+    T->cap_B = max_B; T->cap_rec = max_n_rec; T->cap_rr = max_n_rr; T->cap_maxrec = max_rec_pg; T->cap_rk = cap_rk;
+    T->have_forward = false;
+    return KPD_OK;
+}
+
+extern "C" kpd_status kpd_recegnn_trainer_forward(kpd_recegnn_trainer *T, const kpd_rec_batch *bt, const float *rr_same_res, const kpd_rec_out *out,
+                                                  float *rec_h_out, float *rec_x_out, void *stream) {
+    KPD_REQUIRE(T && bt && out, KPD_ERR_INVALID, "null argument");
+    KPD_REQUIRE(bt->B >= 1 && bt->n_rec >= 1 && bt->rec_ptr && bt->rec_x && bt->rec_h && bt->rr_rowptr, KPD_ERR_INVALID, "bad batch");
+    KPD_REQUIRE(bt->B <= T->cap_B && bt->n_rec <= T->cap_rec && bt->n_rr <= T->cap_rr && bt->max_rec <= T->cap_maxrec, KPD_ERR_CAPACITY,
+                "batch exceeds the reserved workspace (call kpd_recegnn_trainer_reserve)");
+    const kpd_recegnn_config &c = T->cfg;
+    KPD_REQUIRE(!c.use_sameres_feat || rr_same_res || bt->n_rr == 0, KPD_ERR_INVALID, "use_sameres_feat needs the rr same_res column");
+    KPD_REQUIRE(out->kp_x && out->kp_h && out->rk_src && out->rk_dst && out->kk_src && out->kk_dst && out->kk_per_graph && out->counts,
+                KPD_ERR_INVALID, "output buffers missing");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    T->st = st;
+    KPD_BLAS(rocblas_set_stream(T->blas, st));
+    T->bt = *bt;
+    T->same_res = rr_same_res;
+    const int D = c.out_n_node_feat, K = c.n_keypoints, B = bt->B, n_rec = bt->n_rec, n_kp = B * K, L = c.n_convs, k = c.k_closest;
+    T->B = B; T->n_rec = n_rec; T->n_kp = n_kp;
+    KPD_REQUIRE(out->cap_kk >= (long)n_kp * std::min(K - 1, 100), KPD_ERR_CAPACITY, "cap_kk=%d too small", out->cap_kk);
+    KPD_TRY(launch_node_graph_index(bt->rec_ptr, B, n_rec, T->bidx, st));
+    KPD_TRY(launch_iota_scaled(T->kp_ptr, B + 1, K, st));
+    KPD_TRY(build_src_csr(T, bt->rr_src, bt->n_rr, n_rec, T->cursor, T->scsr_rr));
+    if (c.message_norm == 0.0f) {
+        hipLaunchKernelGGL(k_rc_z, grid1(B), dim3(256), 0, st, bt->rr_rowptr, bt->rec_ptr, B, T->z);
+        KPD_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_rc_scale, grid1(n_rec), dim3(256), 0, st, c.message_norm == 0.0f ? T->z : (const float *)nullptr, T->bidx, n_rec,
+                       c.message_norm == 0.0f ? 1.0f : c.message_norm, T->scale);
+    KPD_LAUNCH_CHECK();
+    KPD_HIP(hipMemcpyAsync(T->hs[0], bt->rec_h, (size_t)n_rec * c.in_n_node_feat * 4, hipMemcpyDeviceToDevice, st));
+    KPD_HIP(hipMemcpyAsync(T->xs[0], bt->rec_x, (size_t)n_rec * 12, hipMemcpyDeviceToDevice, st));
+    for (int i = 0; i < L; ++i) KPD_TRY(conv_fwd(T, i));
+    if (rec_h_out) KPD_HIP(hipMemcpyAsync(rec_h_out, T->hs[L], (size_t)n_rec * D * 4, hipMemcpyDeviceToDevice, st));       // :516-517
+    if (rec_x_out) KPD_HIP(hipMemcpyAsync(rec_x_out, T->xs[L], (size_t)n_rec * 12, hipMemcpyDeviceToDevice, st));
+
+    // keypoint embedding of the graph-mean feature (:526-530): Linear(D, D K) - SiLU, 'b (k d) -> (b k) d'
+    Param Wk, bk, Wf, Wp, bp, lw, lb;
+    KPD_TRY(param(T, "keypoint_embedding.0.weight", D * K, D, &Wk)); KPD_TRY(param(T, "keypoint_embedding.0.bias", D * K, 1, &bk));
+    KPD_TRY(param(T, "rec_kp_conv.fc_src.weight", D, D, &Wf));
+    KPD_TRY(param(T, "rec_kp_conv.kp_feature_mlp.0.weight", D, D + k, &Wp)); KPD_TRY(param(T, "rec_kp_conv.kp_feature_mlp.0.bias", D, 1, &bp));
+    if (c.norm) {
+        KPD_TRY(param(T, "rec_kp_conv.layer_norm.weight", D, 1, &lw)); KPD_TRY(param(T, "rec_kp_conv.layer_norm.bias", D, 1, &lb));
+    }
+    KPD_TRY(launch_graph_mean(T->hs[L], bt->rec_ptr, B, D, T->gmean, st));
+    KPD_TRY(gemm(T, false, true, B, D * K, D, T->gmean, D, Wk.w, D, 0.0f, T->kpe_pre, D * K));
+    hipLaunchKernelGGL(k_bias_silu, grid1((long long)B * D * K), dim3(256), 0, st, T->kpe_pre, bk.w, (long long)B * D * K, D * K, D * K, T->kp_h0);
+    KPD_LAUNCH_CHECK();
+    // RecKeyConv: fc_src on both sides (:190-191), attention-pooled positions over the learned receptor positions (:200-222)
+    KPD_TRY(gemm(T, false, true, n_rec, D, D, T->hs[L], D, Wf.w, D, 0.0f, T->ft_src, D));
+    KPD_TRY(gemm(T, false, true, n_kp, D, D, T->kp_h0, D, Wf.w, D, 0.0f, T->ft_dst, D));
+    const float *xv = c.fix_pos ? bt->rec_x : T->xs[L];
+    hipLaunchKernelGGL(k_rk_att_fwd, dim3(n_kp), dim3(256), 0, st, T->ft_src, T->ft_dst, xv, bt->rec_ptr, K, D, T->att, T->kp_x);
+    KPD_LAUNCH_CHECK();
+    // k nearest receptor atoms of every keypoint by the ORIGINAL positions (:262-267); kp-major, nearest first
+    KPD_TRY(launch_knn_bipartite(bt->rec_x, bt->rec_ptr, n_rec, bt->max_rec, T->kp_x, T->kp_ptr, n_kp, K, B, k, T->off_tmp, T->xm_src, T->xm_dst,
+                                 T->xm_rowptr, T->rk_src, T->rk_dst, T->rk_rowptr, st));
+    int e_rk = 0;
+    KPD_HIP(hipMemcpyAsync(&e_rk, T->off_tmp + B, sizeof(int), hipMemcpyDeviceToHost, st));
+    KPD_HIP(hipStreamSynchronize(st));
+    KPD_REQUIRE(e_rk == n_kp * k, KPD_ERR_INVALID, "every pocket needs at least k_closest=%d receptor atoms (%d rk edges for %d keypoints)", k, e_rk, n_kp);
+    T->E_rk = e_rk;
+    KPD_TRY(build_src_csr(T, T->rk_src, e_rk, n_rec, T->cursor, T->scsr_rk));
+    hipLaunchKernelGGL(k_rk_feat_in, grid1((long long)n_kp * (D + k)), dim3(256), 0, st, T->hs[L], bt->rec_x, T->kp_x, T->rk_src, k, D,
+                       (long long)n_kp * (D + k), T->fin);
+    KPD_LAUNCH_CHECK();
+    KPD_TRY(gemm(T, false, true, n_kp, D, D + k, T->fin, D + k, Wp.w, D + k, 0.0f, T->fpre, D));
+    hipLaunchKernelGGL(k_bias_silu, grid1((long long)n_kp * D), dim3(256), 0, st, T->fpre, bp.w, (long long)n_kp * D, D, D, T->fact);
+    KPD_LAUNCH_CHECK();
+    if (c.norm) {
+        hipLaunchKernelGGL(k_ln_fwd, dim3(cdiv(n_kp, 4)), dim3(256), 0, st, T->fact, lw.w, lb.w, n_kp, D, out->kp_h);
+        KPD_LAUNCH_CHECK();
+    } else KPD_HIP(hipMemcpyAsync(out->kp_h, T->fact, (size_t)n_kp * D * 4, hipMemcpyDeviceToDevice, st));
+    KPD_HIP(hipMemcpyAsync(out->kp_x, T->kp_x, (size_t)n_kp * 12, hipMemcpyDeviceToDevice, st));
+    KPD_HIP(hipMemcpyAsync(out->rk_src, T->rk_src, (size_t)e_rk * 4, hipMemcpyDeviceToDevice, st));
+    KPD_HIP(hipMemcpyAsync(out->rk_dst, T->rk_dst, (size_t)e_rk * 4, hipMemcpyDeviceToDevice, st));
+    KPD_TRY(launch_radius_graph(T->kp_x, T->kp_ptr, B, n_kp, K, c.kk_cutoff, 100, out->cap_kk, out->kk_src, out->kk_dst, T->kk_rowptr,
+                                out->kk_per_graph, T->deg_tmp, T->kk_off, T->off_tmp, out->counts, st));
+    T->have_forward = true;
+    return KPD_OK;
+}
+
+extern "C" kpd_status kpd_recegnn_trainer_backward(kpd_recegnn_trainer *T, const float *d_kp_x, const float *d_kp_h, void *stream) {
+    KPD_REQUIRE(T, KPD_ERR_INVALID, "null trainer");
+    KPD_REQUIRE(T->have_forward, KPD_ERR_STATE, "kpd_recegnn_trainer_backward before kpd_recegnn_trainer_forward");
+    const kpd_recegnn_config &c = T->cfg;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    T->st = st;
+    KPD_BLAS(rocblas_set_stream(T->blas, st));
+    const kpd_rec_batch &bt = T->bt;
+    const int D = c.out_n_node_feat, K = c.n_keypoints, B = T->B, n_rec = T->n_rec, n_kp = T->n_kp, L = c.n_convs, k = c.k_closest;
+    Param Wk, bk, Wf, Wp, bp, lw, lb;
+    KPD_TRY(param(T, "keypoint_embedding.0.weight", D * K, D, &Wk)); KPD_TRY(param(T, "keypoint_embedding.0.bias", D * K, 1, &bk));
+    KPD_TRY(param(T, "rec_kp_conv.fc_src.weight", D, D, &Wf));
+    KPD_TRY(param(T, "rec_kp_conv.kp_feature_mlp.0.weight", D, D + k, &Wp)); KPD_TRY(param(T, "rec_kp_conv.kp_feature_mlp.0.bias", D, 1, &bp));
+    if (c.norm) {
+        KPD_TRY(param(T, "rec_kp_conv.layer_norm.weight", D, 1, &lw)); KPD_TRY(param(T, "rec_kp_conv.layer_norm.bias", D, 1, &lb));
+    }
+    int cur = 0, nxt = 1;
+    KPD_HIP(hipMemsetAsync(T->gh[cur], 0, (size_t)n_rec * D * 4, st));                  // gradient of (hs[L], xs[L])
+    KPD_HIP(hipMemsetAsync(T->gx[cur], 0, (size_t)n_rec * 12, st));
+    if (d_kp_x) KPD_HIP(hipMemcpyAsync(T->gkx, d_kp_x, (size_t)n_kp * 12, hipMemcpyDeviceToDevice, st));
+    else KPD_HIP(hipMemsetAsync(T->gkx, 0, (size_t)n_kp * 12, st));
+
+    // keypoint features: LayerNorm <- SiLU <- Linear([mean of the k nearest h | k distances])
+    if (d_kp_h) {
+        if (c.norm) {
+            hipLaunchKernelGGL(k_ln_bwd_g, dim3(cdiv(n_kp, 4)), dim3(256), 0, st, T->fact, lw.w, d_kp_h, n_kp, D, T->gk1, T->gk2);
+            KPD_LAUNCH_CHECK();
+            KPD_TRY(colsum_acc(T, n_kp, D, T->gk2, D, lw.g));
+            KPD_TRY(colsum_acc(T, n_kp, D, d_kp_h, D, lb.g));
+        } else KPD_HIP(hipMemcpyAsync(T->gk1, d_kp_h, (size_t)n_kp * D * 4, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_silu_bwd, grid1((long long)n_kp * D), dim3(256), 0, st, T->gk1, T->fpre, (long long)n_kp * D, D, D);
+        KPD_LAUNCH_CHECK();
+        KPD_TRY(colsum_acc(T, n_kp, D, T->gk1, D, bp.g));
+        if (Wp.g) KPD_TRY(grad_gemm(T, D, D + k, n_kp, T->gk1, D, T->fin, D + k, Wp.g, D + k));
+        KPD_TRY(gemm(T, false, false, n_kp, D + k, D, T->gk1, D, Wp.w, D + k, 0.0f, T->gk2, D + k));      // d [h_m | d_k]
+        hipLaunchKernelGGL(k_rk_feat_dh, dim3(n_rec), dim3(256), 0, st, T->gk2, T->scsr_rk.perm, T->scsr_rk.rowptr, k, D, D + k, T->gh[cur]);
+        KPD_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_rk_feat_dx, grid1(n_kp), dim3(256), 0, st, T->gk2, T->fin, bt.rec_x, T->kp_x, T->rk_src, k, D, n_kp, T->gkx);
+        KPD_LAUNCH_CHECK();
+    }
+    // attention-pooled positions: values (the learned receptor positions), then the logits
+    const float *xv = c.fix_pos ? bt.rec_x : T->xs[L];
+    if (!c.fix_pos) {
+        hipLaunchKernelGGL(k_rk_att_bwd_val, grid1(n_rec), dim3(256), 0, st, T->att, T->gkx, T->bidx, n_rec, K, T->gx[cur]);
+        KPD_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_rk_att_bwd_logits, dim3(n_kp), dim3(256), 0, st, T->att, xv, bt.rec_ptr, K, D, T->gkx, T->kp_x);
+    KPD_LAUNCH_CHECK();
+    float *dft_dst = T->gk1, *dft_src = T->gn1;
+    hipLaunchKernelGGL(k_rk_att_bwd_dst, dim3(n_kp), dim3(256), 0, st, T->att, T->ft_src, bt.rec_ptr, K, D, dft_dst);
+    KPD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_rk_att_bwd_src, dim3(n_rec), dim3(256), 0, st, T->att, T->ft_dst, T->bidx, K, D, dft_src);
+    KPD_LAUNCH_CHECK();
+    // ft_src = h_L Wf^T, ft_dst = kp_h0 Wf^T: one weight, two uses
+    if (Wf.g) {
+        KPD_TRY(grad_gemm(T, D, D, n_rec, dft_src, D, T->hs[L], D, Wf.g, D));
+        KPD_TRY(grad_gemm(T, D, D, n_kp, dft_dst, D, T->kp_h0, D, Wf.g, D));
+    }
+    KPD_TRY(gemm(T, false, false, n_rec, D, D, dft_src, D, Wf.w, D, 1.0f, T->gh[cur], D));
+    KPD_TRY(gemm(T, false, false, n_kp, D, D, dft_dst, D, Wf.w, D, 0.0f, T->big, D));                 // d kp_h0 as [B, D K]
+    hipLaunchKernelGGL(k_silu_bwd, grid1((long long)B * D * K), dim3(256), 0, st, T->big, T->kpe_pre, (long long)B * D * K, D * K, D * K);
+    KPD_LAUNCH_CHECK();
+    if (bk.g)
+        for (int c0 = 0; c0 < D * K; c0 += COLSUM_LD) KPD_TRY(colsum_acc(T, B, std::min(COLSUM_LD, D * K - c0), T->big + c0, D * K, bk.g + c0));
+    if (Wk.g) KPD_TRY(gemm(T, true, false, D * K, D, B, T->big, D * K, T->gmean, D, 1.0f, Wk.g, D));
+    KPD_TRY(gemm(T, false, false, B, D, D * K, T->big, D * K, Wk.w, D, 0.0f, T->gk2, D));              // d gmean
+    hipLaunchKernelGGL(k_rc_mean_bwd, grid1((long long)n_rec * D), dim3(256), 0, st, T->gk2, T->bidx, bt.rec_ptr, (long long)n_rec * D, D, T->gh[cur]);
+    KPD_LAUNCH_CHECK();
+
+    // ReceptorConv stack, last to first
+    for (int i = L - 1; i >= 0; --i) {
+        KPD_TRY(conv_bwd(T, i, T->gh[cur], T->gx[cur], T->gh[nxt], T->gx[nxt]));
+        std::swap(cur, nxt);
+    }
+    T->have_forward = false;
+    return KPD_OK;
+}

@@ -159,6 +159,14 @@ def lib():
     L.kpd_recenc_trainer_reserve.argtypes = [C.c_void_p] + [C.c_int32] * 4
     L.kpd_recenc_trainer_forward.argtypes = [C.c_void_p, C.POINTER(KpdRecBatch), C.POINTER(KpdRecOut), C.c_void_p]
     L.kpd_recenc_trainer_backward.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+    L.kpd_recegnn_trainer_create.argtypes = [C.POINTER(KpdRecegnnConfig), C.POINTER(C.c_void_p)]
+    L.kpd_recegnn_trainer_destroy.argtypes = [C.c_void_p]
+    L.kpd_recegnn_trainer_destroy.restype = None
+    L.kpd_recegnn_trainer_bind.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32]
+    L.kpd_recegnn_trainer_reserve.argtypes = [C.c_void_p] + [C.c_int32] * 4
+    L.kpd_recegnn_trainer_forward.argtypes = [C.c_void_p, C.POINTER(KpdRecBatch), C.c_void_p, C.POINTER(KpdRecOut), C.c_void_p, C.c_void_p,
+                                              C.c_void_p]
+    L.kpd_recegnn_trainer_backward.argtypes = [C.c_void_p] + [C.c_void_p] * 3
     L.kpd_rec_graph_scratch_bytes.argtypes = [C.c_int32, C.c_int32]
     L.kpd_rec_graph_scratch_bytes.restype = C.c_int64
     L.kpd_build_rec_graph.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p,
@@ -190,6 +198,8 @@ EXPORTS = [
     'kpd_gvp_trainer_forward', 'kpd_gvp_trainer_backward', 'kpd_gvp_trainer_set_dropout', 'kpd_dropout_mask',
     'kpd_recenc_trainer_create', 'kpd_recenc_trainer_destroy', 'kpd_recenc_trainer_bind', 'kpd_recenc_trainer_set_dropout',
     'kpd_recenc_trainer_reserve', 'kpd_recenc_trainer_forward', 'kpd_recenc_trainer_backward',
+    'kpd_recegnn_trainer_create', 'kpd_recegnn_trainer_destroy', 'kpd_recegnn_trainer_bind', 'kpd_recegnn_trainer_reserve',
+    'kpd_recegnn_trainer_forward', 'kpd_recegnn_trainer_backward',
 ]
 
 
@@ -692,39 +702,78 @@ class RecEgnnEngine:
         check(L.kpd_recegnn_commit(self._h))
 
     def forward(self, rec_counts: torch.Tensor, rec_x, rec_h, rr_src, rr_dst, same_res=None):
-        dev = rec_x.device
-        rec_counts = rec_counts.cpu().long()
-        B, n_rec, max_rec = int(rec_counts.numel()), int(rec_counts.sum()), int(rec_counts.max())
-        if int(rec_counts.min()) < self.k:
-            raise KpdError(f'every pocket needs at least k_closest={self.k} receptor atoms (the reference stacks exactly k '
-                           f'neighbour distances per keypoint)')
-        rec_ptr = torch.cat([torch.zeros(1, dtype=torch.long), rec_counts.cumsum(0)]).int().to(dev)
-        rec_x, rec_h = _dev_f32(rec_x, 'rec x_0'), _dev_f32(rec_h, 'rec h_0')
-        s, d, rowptr, order = sorted_csr(rr_src, rr_dst, n_rec, dev, return_order=True)
-        a = None
-        if self.ef:
-            if same_res is None:
-                raise KpdError("use_sameres_feat needs g.edges['rr'].data['same_res']")
-            a = same_res.to(dev).reshape(-1)[order].float().contiguous()
-        torch.cuda.synchronize()
-        check(lib().kpd_recegnn_reserve(self._h, B, n_rec, int(s.numel()), max_rec))
-        n_kp = B * self.K
-        cap_kk = max(n_kp * min(self.K - 1, 100), 1)
-        f32 = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
-        i32 = lambda n: torch.zeros(n, device=dev, dtype=torch.int32)
-        cap_rk = n_kp * min(self.rk_cap, max_rec)
-        out = dict(kp_x=f32(n_kp, 3), kp_h=f32(n_kp, self.D), rk_src=i32(cap_rk), rk_dst=i32(cap_rk),
-                   kk_src=i32(cap_kk), kk_dst=i32(cap_kk), kk_per_graph=i32(B), counts=i32(2), rec_h=f32(n_rec, self.D),
-                   rec_x=f32(n_rec, 3))
-        bt = KpdRecBatch(B, n_rec, max_rec, _ptr(rec_ptr), _ptr(rec_x), _ptr(rec_h), int(s.numel()), _ptr(s), _ptr(d), _ptr(rowptr))
-        ro = KpdRecOut(_ptr(out['kp_x']), _ptr(out['kp_h']), None, _ptr(out['rk_src']), _ptr(out['rk_dst']), cap_kk,
-                       _ptr(out['kk_src']), _ptr(out['kk_dst']), _ptr(out['kk_per_graph']), _ptr(out['counts']))
-        check(lib().kpd_recegnn_forward(self._h, C.byref(bt), _ptr(a) if a is not None else None, C.byref(ro), _ptr(out['rec_h']),
-                                        _ptr(out['rec_x']), _stream()))
-        e_kk, e_rk = out['counts'].tolist()            # once per pocket: a host sync here is fine
-        out['kk_src'], out['kk_dst'] = out['kk_src'][:e_kk], out['kk_dst'][:e_kk]
-        out['rk_src'], out['rk_dst'] = out['rk_src'][:e_rk], out['rk_dst'][:e_rk]
-        return out
+        return _recegnn_call(self, lib().kpd_recegnn_reserve, lib().kpd_recegnn_forward, rec_counts, rec_x, rec_h, rr_src, rr_dst, same_res)
+
+
+def _recegnn_call(eng, reserve_fn, forward_fn, rec_counts, rec_x, rec_h, rr_src, rr_dst, same_res):
+    """Shared by RecEgnnEngine.forward and RecEgnnTrainer.forward."""
+    dev = rec_x.device
+    rec_counts = rec_counts.cpu().long()
+    B, n_rec, max_rec = int(rec_counts.numel()), int(rec_counts.sum()), int(rec_counts.max())
+    if int(rec_counts.min()) < eng.k:
+        raise KpdError(f'every pocket needs at least k_closest={eng.k} receptor atoms (the reference stacks exactly k '
+                       f'neighbour distances per keypoint)')
+    rec_ptr = torch.cat([torch.zeros(1, dtype=torch.long), rec_counts.cumsum(0)]).int().to(dev)
+    rec_x, rec_h = _dev_f32(rec_x, 'rec x_0'), _dev_f32(rec_h, 'rec h_0')
+    s, d, rowptr, order = sorted_csr(rr_src, rr_dst, n_rec, dev, return_order=True)
+    a = None
+    if eng.ef:
+        if same_res is None:
+            raise KpdError("use_sameres_feat needs g.edges['rr'].data['same_res']")
+        a = same_res.to(dev).reshape(-1)[order].float().contiguous()
+    torch.cuda.synchronize()
+    check(reserve_fn(eng._h, B, n_rec, int(s.numel()), max_rec))
+    n_kp = B * eng.K
+    cap_kk = max(n_kp * min(eng.K - 1, 100), 1)
+    f32 = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+    i32 = lambda n: torch.zeros(n, device=dev, dtype=torch.int32)
+    cap_rk = n_kp * min(eng.rk_cap, max_rec)
+    out = dict(kp_x=f32(n_kp, 3), kp_h=f32(n_kp, eng.D), rk_src=i32(cap_rk), rk_dst=i32(cap_rk),
+               kk_src=i32(cap_kk), kk_dst=i32(cap_kk), kk_per_graph=i32(B), counts=i32(2), rec_h=f32(n_rec, eng.D),
+               rec_x=f32(n_rec, 3))
+    bt = KpdRecBatch(B, n_rec, max_rec, _ptr(rec_ptr), _ptr(rec_x), _ptr(rec_h), int(s.numel()), _ptr(s), _ptr(d), _ptr(rowptr))
+    ro = KpdRecOut(_ptr(out['kp_x']), _ptr(out['kp_h']), None, _ptr(out['rk_src']), _ptr(out['rk_dst']), cap_kk,
+                   _ptr(out['kk_src']), _ptr(out['kk_dst']), _ptr(out['kk_per_graph']), _ptr(out['counts']))
+    check(forward_fn(eng._h, C.byref(bt), _ptr(a) if a is not None else None, C.byref(ro), _ptr(out['rec_h']),
+                     _ptr(out['rec_x']), _stream()))
+    e_kk, e_rk = out['counts'].tolist()            # once per pocket: a host sync here is fine
+    out['kk_src'], out['kk_dst'] = out['kk_src'][:e_kk], out['kk_dst'][:e_kk]
+    out['rk_src'], out['rk_dst'] = out['rk_src'][:e_rk], out['rk_dst'][:e_rk]
+    out['_keep'] = (rec_ptr, rec_x, rec_h, s, d, rowptr, a)      # the training engine reads these again in its backward pass
+    return out
+
+
+class RecEgnnTrainer:
+    """Owns one kpd_recegnn_trainer handle: ReceptorEncoder.forward with saved layer states + its backward pass."""
+
+    def __init__(self, cfg: 'KpdRecegnnConfig'):
+        self.cfg = cfg
+        self.D, self.K, self.k, self.ef = int(cfg.out_n_node_feat), int(cfg.n_keypoints), int(cfg.k_closest), bool(cfg.use_sameres_feat)
+        self.rk_cap = self.k
+        self._h = C.c_void_p()
+        check(lib().kpd_recegnn_trainer_create(C.byref(self.cfg), C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, '_h', None) and _lib is not None:
+            _lib.kpd_recegnn_trainer_destroy(self._h)
+            self._h = None
+
+    def bind(self, names, weights, grads):
+        L = lib()
+        for name, w, g in zip(names, weights, grads):
+            if w.numel() == 0:
+                continue
+            if not (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()):
+                raise KpdError(f'parameter {name} must be a contiguous fp32 GPU tensor')
+            shape = (C.c_int64 * w.dim())(*w.shape)
+            check(L.kpd_recegnn_trainer_bind(self._h, name.encode(), w.data_ptr(), None if g is None else g.data_ptr(), shape, w.dim()))
+
+    def forward(self, rec_counts, rec_x, rec_h, rr_src, rr_dst, same_res=None):
+        return _recegnn_call(self, lib().kpd_recegnn_trainer_reserve, lib().kpd_recegnn_trainer_forward, rec_counts, rec_x, rec_h,
+                             rr_src, rr_dst, same_res)
+
+    def backward(self, d_kp_x, d_kp_h):
+        check(lib().kpd_recegnn_trainer_backward(self._h, _ptr(d_kp_x), _ptr(d_kp_h), _stream()))
 
 
 def step_coefficients(gamma: torch.Tensor, s: torch.Tensor, t: torch.Tensor) -> torch.Tensor:

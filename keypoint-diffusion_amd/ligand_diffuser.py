@@ -175,18 +175,12 @@ class KeypointDiffusion(nn.Module):
     def forward(self, complex_graphs, interface_points):
         """Losses of one batch (ligand_diffuser.py:89-175): {'l2', 'pos', 'feat', 'rec_encoder'}.
 
-        Trainable end to end: every fixed-encoder configuration (configs/dev_config.yml, trained_models/{egnn,gvp}_all_atom,
-        {egnn,gvp}_ca: the encoder has no parameters and its loss is the constant 0, :85-87) and the learned GVP encoder
-        (trained_models/gvp_20kp, gvp_40kp): the noise prediction is differentiated by the HIP backward passes of the denoiser
-        (kpd_egnn_trainer_* / kpd_gvp_trainer_*, the latter also with respect to the keypoint positions), the keypoints by the
-        encoder's (kpd_recenc_trainer_*), and the optimal-transport encoder loss (rec_encoder_loss.py) adds its gradient at the
-        keypoint positions.  The learned EGNN encoder (egnn_20kp, egnn_40kp) is EVALUATION only -- under `torch.no_grad()`
-        (train.py's test_model) all four losses are returned; with gradients enabled it raises, because that encoder has no
-        backward pass yet."""
-        if self.rec_encoder_type != 'fixed' and self.architecture == 'egnn' and torch.is_grad_enabled():
-            raise NotImplementedError('the learned EGNN receptor encoder has no backward pass: training is implemented for '
-                                      'rec_encoder_type="fixed" and for the learned GVP encoder; under torch.no_grad() this forward '
-                                      'evaluates all four losses')
+        Trainable end to end in all eight shipped configurations and dev_config: the noise prediction is differentiated by the HIP
+        backward passes of the denoisers (kpd_egnn_trainer_* / kpd_gvp_trainer_*, with respect to the keypoint positions, features
+        and vectors too), the learned keypoints by the backward passes of their encoder (kpd_recenc_trainer_* for gvp_20kp /
+        gvp_40kp, kpd_recegnn_trainer_* for egnn_20kp / egnn_40kp), and the optimal-transport encoder loss (rec_encoder_loss.py)
+        adds its gradient at the keypoint positions.  With a fixed encoder there are no encoder parameters and that loss is the
+        constant 0 (:85-87)."""
         if self.rl_dist_threshold > 0:
             raise NotImplementedError('the receptor-ligand hinge loss (rl_dist_threshold > 0) is unused by every shipped config')
         losses = {}

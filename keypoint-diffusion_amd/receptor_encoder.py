@@ -9,6 +9,37 @@ import torch.nn as nn
 from .graph import HeteroBatch, get_batch_info
 
 
+class _RecEgnnTrainFn(torch.autograd.Function):
+    """ReceptorEncoder.forward as one autograd node (kpd_recegnn_trainer_*): keypoint positions and features are differentiable
+    functions of every parameter; the rk / kk edge lists and the learned receptor h / x it also produces are side outputs."""
+
+    @staticmethod
+    def forward(ctx, module, rec_counts, rec_x, rec_h, rr_src, rr_dst, same_res, holder, *params):
+        trainer, names = module._trainer()
+        ctx.trainer, ctx.names = trainer, names
+        trainer.generation = getattr(trainer, 'generation', 0) + 1
+        ctx.generation = trainer.generation
+        ctx.save_for_backward(*params)
+        trainer.bind(names, params, [None] * len(params))
+        out = trainer.forward(rec_counts, rec_x, rec_h, rr_src, rr_dst, same_res)
+        ctx.keep = out.pop('_keep')                                 # device copies the C side reads again in backward
+        holder.update(out)
+        return out['kp_x'], out['kp_h']
+
+    @staticmethod
+    def backward(ctx, d_x, d_h):
+        from . import hip
+        if ctx.generation != ctx.trainer.generation:
+            raise hip.KpdError('backward of a ReceptorEncoder forward whose saved states were overwritten by a later grad-enabled '
+                               'forward of the same module (one forward/backward pair at a time per module)')
+        params = ctx.saved_tensors
+        grads = [torch.zeros_like(p) if (ctx.needs_input_grad[8 + i] and p.numel()) else None for i, p in enumerate(params)]
+        ctx.trainer.bind(ctx.names, params, grads)
+        c = lambda t: None if t is None else t.contiguous().float()
+        ctx.trainer.backward(c(d_x), c(d_h))
+        return (None,) * 8 + tuple(grads)
+
+
 class ReceptorConv(nn.Module):
     """receptor_encoder.py:17-66 (parameters only)."""
 
@@ -78,6 +109,18 @@ class ReceptorEncoder(nn.Module):
                                       num_heads=1, k_closest=k_closest, kp_rad=kp_rad, norm=norm)
         self._engine = None
         self._engine_key = None
+        self._train = None
+
+    def _trainer(self):
+        """The training engine and the parameter names in `self.parameters()` order (reference state-dict names)."""
+        from . import hip
+        if self._train is None:
+            cfg = hip.KpdRecegnnConfig(int(self.n_convs), int(self.n_keypoints), int(self.in_n_node_feat), int(self.hidden_n_node_feat),
+                                       int(self.out_n_node_feat), int(bool(self.use_sameres_feat)), int(bool(self.use_tanh)),
+                                       int(bool(self.norm)), int(bool(self.fix_pos)), float(self.coords_range), float(self.message_norm),
+                                       int(self.k_closest), float(self.graph_cutoffs['kk']), float(self.kp_rad))
+            self._train = (hip.RecEgnnTrainer(cfg), [n for n, _ in self.named_parameters()])
+        return self._train
 
     def engine(self):
         from . import hip
@@ -92,9 +135,7 @@ class ReceptorEncoder(nn.Module):
 
     def forward(self, g: HeteroBatch, batch_idxs: Dict[str, torch.Tensor] = None) -> HeteroBatch:
         """Writes keypoint x_0 / h_0, replaces the rk edges by the kNN edges and adds the kk radius graph
-        (receptor_encoder.py:483-555)."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError('the HIP encoder is forward-only; call it under torch.no_grad()')
+        (receptor_encoder.py:483-555).  Under autograd the call runs on the training engine; otherwise on the fused inference one."""
         B, K = g.batch_size, self.n_keypoints
         if g.num_nodes('kp') != B * K:
             raise ValueError(f'expected {K} keypoint nodes per complex, graph has {g.num_nodes("kp")} for {B} complexes')
@@ -102,7 +143,13 @@ class ReceptorEncoder(nn.Module):
         rr_src, rr_dst = g.edges(etype='rr')
         n_rec = g.batch_num_nodes('rec')
         same_res = g.edges['rr'].data['same_res'] if self.use_sameres_feat else None
-        out = self.engine().forward(n_rec, rec['x_0'], rec['h_0'], rr_src, rr_dst, same_res)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # training: keypoint x_0 / h_0 carry the graph back into the parameters (kpd_recegnn_trainer_*)
+            out = {}
+            x, h = _RecEgnnTrainFn.apply(self, n_rec, rec['x_0'], rec['h_0'], rr_src, rr_dst, same_res, out, *self.parameters())
+            out = dict(out, kp_x=x, kp_h=h)
+        else:
+            out = self.engine().forward(n_rec, rec['x_0'], rec['h_0'], rr_src, rr_dst, same_res)
         rec['x'], rec['h'] = out['rec_x'], out['rec_h']                        # :516-517
         kp = g.nodes['kp'].data
         kp['x_0'], kp['h_0'] = out['kp_x'], out['kp_h']

@@ -1,0 +1,142 @@
+"""Backward pass of the EGNN keypoint receptor encoder (SURVEY.md 8(f) item 2 for row f1): gradients of every parameter from
+kpd_recegnn_trainer_* against torch autograd through the CPU oracle (`oracle/rec_encoder_egnn.py`), for a loss on both outputs
+(keypoint positions and features); then the egnn_20kp-style model trained end to end through `KeypointDiffusion.forward`."""
+import pytest
+import torch
+
+from keypoint_diffusion_amd import graph as G
+from keypoint_diffusion_amd import synth
+from keypoint_diffusion_amd.receptor_encoder import ReceptorEncoder
+from oracle import rec_encoder_egnn as orec
+
+from . import util
+from .golden.make_golden_cfgs import RECEGNN_CFGS, same_res_feature
+
+pytestmark = pytest.mark.gpu
+CUT = util.CUTOFFS_ALL_ATOM
+TOL = 2e-4          # relative to the largest entry of each gradient tensor
+
+
+def _batch(cfg, n_rec, seed=19):
+    g = util.make_batch(n_rec, [4] * len(n_rec), seed=seed, n_keypoints=cfg['n_keypoints'])
+    src, dst = g.edges(etype='rr')
+    a = same_res_feature(src, dst)
+    g.edges['rr'].data['same_res'] = a.bool()
+    return g, a
+
+
+@pytest.mark.parametrize('name,n_rec', [('recegnn_20kp', [33, 21]), ('recegnn_small', [33, 21, 40]), ('recegnn_fixpos', [50, 5, 27])])
+def test_encoder_gradients_match_oracle_autograd(cuda, name, n_rec):
+    cfg = RECEGNN_CFGS[name]
+    kw = dict(cfg, graph_cutoffs=CUT)
+    model = synth.fill_state_dict_(ReceptorEncoder(**kw), 71).eval()
+    with torch.no_grad():                       # the synthetic fill leaves the tiny xavier coordinate head: give it some weight
+        for n, p in model.named_parameters():
+            if 'coord_mlp.2.weight' in n:
+                p.mul_(5.0)
+    g, a = _batch(cfg, n_rec)
+    n_kp, D = len(n_rec) * cfg['n_keypoints'], cfg['out_n_node_feat']
+    gen = torch.Generator().manual_seed(5)
+    w_x, w_h = torch.randn(n_kp, 3, generator=gen), torch.randn(n_kp, D, generator=gen) / D ** 0.5
+    sd = {k: v.detach().double().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    ob = util.to_obatch(g)
+    ob.x['rec'], ob.h['rec'] = ob.x['rec'].double(), ob.h['rec'].double()
+    ref = orec.rec_encoder_egnn_forward(sd, kw, ob, a.double() if cfg['use_sameres_feat'] else None)
+    ((ref.x['kp'] * w_x.double()).sum() + (ref.h['kp'] * w_h.double()).sum()).backward()
+    model = model.to(cuda)
+    gd = g.to(cuda)
+    out = model(gd, G.get_batch_idxs(gd))
+    kp = out.nodes['kp'].data
+    assert kp['x_0'].requires_grad and kp['h_0'].requires_grad
+    assert util.rel_err(kp['x_0'].detach(), ref.x['kp'].detach().float()) < 1e-4 and util.rel_err(kp['h_0'].detach(), ref.h['kp'].detach().float()) < 1e-4
+    rs, rd = out.edges(etype='rk')
+    assert torch.equal(rs.cpu(), ref.edges['rk'][0]) and torch.equal(rd.cpu(), ref.edges['rk'][1])
+    ((kp['x_0'] * w_x.to(cuda)).sum() + (kp['h_0'] * w_h.to(cuda)).sum()).backward()
+    worst, checked = [], 0
+    for n, p in model.named_parameters():
+        r = sd[n].grad
+        if r is None or float(r.abs().max()) < 1e-10:                # fc_dst: built, never applied (:190-191); a saturated tanh head
+            assert p.grad is None or float(p.grad.abs().max()) <= 1e-9, n
+            continue
+        assert p.grad is not None, n
+        scale = r.abs().max().item()
+        if r.numel() == 1 and n.endswith('.bias'):                    # lone attention bias: a cancelling sum over all edges
+            scale = max(scale, sd[n[:-4] + 'weight'].grad.abs().max().item())
+        worst.append(((p.grad.cpu().double() - r).abs().max().item() / scale, n))
+        checked += 1
+    worst.sort(reverse=True)
+    assert checked > 10 and worst[0][0] < TOL, worst[:8]
+
+
+def test_egnn_keypoint_model_trains_end_to_end(cuda):
+    """`KeypointDiffusion.forward` of an egnn_20kp-style model (learned EGNN encoder -> keypoints -> EGNN denoiser + optimal-transport
+    encoder loss) under autograd: encoder parameters receive finite gradients that match central finite differences of the
+    denoising loss one tensor at a time, and a few optimizer steps lower the loss."""
+    from keypoint_diffusion_amd.ligand_diffuser import KeypointDiffusion
+    K = 8
+    rec_cfg = dict(coords_range=10, fix_pos=False, hidden_n_node_feat=64, k_closest=4, kp_feat_scale=1.0, kp_rad=0.0, message_norm=0.0,
+                   n_convs=2, n_kk_convs=0, n_kk_heads=4, no_cg=False, norm=True, out_n_node_feat=64, use_sameres_feat=True, use_tanh=True,
+                   in_n_node_feat=10)
+    cut = dict(CUT, kl=8, ll=5)
+    model = KeypointDiffusion(10, 64, None, n_timesteps=50, architecture='egnn', rec_encoder_type='learned',
+                              graph_config=dict(n_keypoints=K, graph_cutoffs=cut), dynamics_config=dict(util.EGNN_C2, n_layers=2, message_norm=0.0),
+                              rec_encoder_config=rec_cfg, rec_encoder_loss_config=dict(loss_type='optimal_transport'), precision=1e-5)
+    synth.fill_state_dict_(model, 3)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if 'coord_mlp' in n and n.endswith(('.4.weight', 'coord_mlp.2.weight')) and p.shape[0] == 1:
+                p.mul_(20.0)
+    model = model.to(cuda).eval()
+
+    def mk():
+        g = G.batch(synth.synth_complexes([60, 45, 52], [9, 13, 7], K, cut, seed=11))
+        s, d = g.edges(etype='rr')
+        g.edges['rr'].data['same_res'] = same_res_feature(s, d).bool()
+        return g.to(cuda)
+
+    def loss(with_grad):
+        torch.manual_seed(77)
+        with torch.enable_grad() if with_grad else torch.no_grad():
+            out = model(mk(), None)
+        return out['l2'], out
+
+    total, parts = loss(True)
+    assert all(torch.isfinite(v).all() for v in parts.values()) and float(parts['rec_encoder'].detach()) > 0
+    (total + 0.01 * parts['rec_encoder']).backward()
+    params = dict(model.named_parameters())
+    assert all(torch.isfinite(p.grad).all() for p in params.values() if p.grad is not None)
+    model.zero_grad(set_to_none=True)
+    loss(True)[0].backward()
+    pick = ['rec_encoder.rec_convs.0.edge_mlp.2.weight', 'rec_encoder.rec_convs.1.node_mlp.0.weight', 'rec_encoder.rec_kp_conv.fc_src.weight',
+            'rec_encoder.rec_kp_conv.kp_feature_mlp.0.weight', 'rec_encoder.rec_convs.0.coord_mlp.0.weight', 'rec_encoder.keypoint_embedding.0.weight']
+    gen = torch.Generator().manual_seed(3)
+    strong = 0
+    for n in pick:
+        d = torch.randn(params[n].shape, generator=gen).to(cuda)
+        analytic = float((params[n].grad.double() * d.double()).sum())
+        numeric = []
+        for eps in (1e-3, 2e-4):
+            vals = []
+            with torch.no_grad():
+                for sign in (1.0, -1.0):
+                    params[n].add_(sign * eps * d)
+                    vals.append(float(loss(False)[0].double()))
+                    params[n].sub_(sign * eps * d)
+            numeric.append((vals[0] - vals[1]) / (2 * eps))
+        print(f'{n}: analytic {analytic:+.5e} numeric {numeric[0]:+.5e} {numeric[1]:+.5e}')
+        assert min(abs(analytic - v) - 5e-2 * max(abs(analytic), abs(v)) for v in numeric) <= 4e-4, (n, analytic, numeric)
+        strong += abs(analytic) > 2e-3
+    assert strong >= 2
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=2e-4)
+    hist = []
+    for it in range(6):
+        torch.manual_seed(9)
+        out = model(mk(), None)
+        l = out['l2'] + 0.1 * out['rec_encoder']
+        opt.zero_grad(set_to_none=True)
+        l.backward()
+        torch.nn.utils.clip_grad_value_(model.parameters(), 1.0)
+        opt.step()
+        hist.append(float(l.detach()))
+    assert all(h == h for h in hist) and hist[-1] < hist[0], hist
