@@ -87,7 +87,7 @@ WORKLOADS = {
     # same for the gvp_all_atom model in training mode (GVPDropout 0.1): the backward pass of csrc/gvp_train.hip
     'gvp_train': dict(arch='gvp', enc='fixed', dyn=dict(GVP_DYN, message_norm='mean'), n_kp=20, cutoffs=CUTOFFS, T=1000),
 }
-TRAFFIC_FILES = ('r02_traffic.json', 'r01_traffic.json')      # per-launch HBM bytes of the dominant kernels (PMC passes)
+TRAFFIC_FILES = ('r03_traffic.json', 'r02_traffic.json', 'r01_traffic.json')      # per-launch HBM bytes of the dominant kernels (PMC passes)
 
 
 # ---------------------------------------------------------------------------------------------------

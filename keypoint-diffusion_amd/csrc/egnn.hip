@@ -78,6 +78,9 @@ struct kpd_egnn {
     bool committed = false;
     int debug_layers = -1;
     bool f16_ok = true;                        // the committed weights fit the f16 planes (pack.hip range guard)
+    float *widen_buf = nullptr;                // hidden_nf < 256: staging of one reference tensor in the 256-wide layout
+    int *widen_map = nullptr;
+    size_t widen_floats = 0, widen_ints = 0;
     int gemm_mode = 0;                         // 0 exact fp32 MFMA; 1 f16x2 split products in the EGNN GEMMs (KPD_GEMM=f16x2, "gemm=f16x2")
     int h_parts = 7;                           // diagnostics: which kernels take the f16x2 form (1 edge, 2 projections, 4 node update)
     int tile_rows = TM;                        // edges per tile of the edge kernel (64, or 32: k_egnn_edge32, four workgroups per CU)
@@ -183,7 +186,12 @@ static kpd_status build_weight_arena(kpd_egnn *m) {
 
 extern "C" kpd_status kpd_egnn_create(const kpd_egnn_config *cfg, kpd_egnn **out) {
     KPD_REQUIRE(cfg && out, KPD_ERR_INVALID, "null argument");
-    KPD_REQUIRE(cfg->hidden_nf == HID, KPD_ERR_INVALID, "hidden_nf=%d: the HIP path is built for hidden_nf=256", cfg->hidden_nf);
+    // hidden_nf < 256 runs on the same kernels: features live in columns 0 .. hidden_nf - 1 of the 256-wide layout, the timestep
+    // stays in column 256, the columns between hold zeros (zero weight rows / columns, kpd_egnn_load_weight), LayerNorm takes its
+    // width at run time
+    KPD_REQUIRE(cfg->hidden_nf >= 1 && cfg->hidden_nf <= HID, KPD_ERR_INVALID, "hidden_nf=%d: the HIP path covers 1 .. 256", cfg->hidden_nf);
+    KPD_REQUIRE(cfg->hidden_nf == HID || cfg->rec_nf != cfg->hidden_nf, KPD_ERR_INVALID,
+                "rec_nf == hidden_nf = %d (identity keypoint encoder, dynamics.py:326-334) is implemented for hidden_nf = 256 only", cfg->hidden_nf);
     KPD_REQUIRE(cfg->ll_k >= 0 && cfg->ll_k <= KL_KMAX, KPD_ERR_INVALID, "ll_k=%d outside 0..%d (0 = radius graph)", cfg->ll_k, KL_KMAX);
     KPD_REQUIRE(cfg->kl_k >= 0 && cfg->kl_k <= KL_KMAX, KPD_ERR_INVALID, "kl_k=%d outside 0..%d (0 = radius graph)", cfg->kl_k, KL_KMAX);
     KPD_REQUIRE(cfg->kl_k > 0 || cfg->kl_cutoff > 0.0f, KPD_ERR_INVALID, "kl_k = 0 needs graph_cutoffs['kl'] > 0");
@@ -203,6 +211,15 @@ extern "C" kpd_status kpd_egnn_create(const kpd_egnn_config *cfg, kpd_egnn **out
     m->n_upd = cfg->update_kp_feat ? 2 : 1;
     m->rec_identity = cfg->rec_nf == cfg->hidden_nf;   // dynamics.py:326-334
     st = build_weight_arena(m);
+    if (st == KPD_OK && cfg->hidden_nf != HID) {
+        m->widen_floats = (size_t)HW * (2 * HW + 1);
+        m->widen_ints = (size_t)HW + 2 * HW + 1;
+        if (hipMalloc(reinterpret_cast<void **>(&m->widen_buf), m->widen_floats * 4) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void **>(&m->widen_map), m->widen_ints * 4) != hipSuccess) {
+            set_error("allocation of the weight staging buffer failed");
+            st = KPD_ERR_HIP;
+        }
+    }
     if (st != KPD_OK) {
         kpd_egnn_destroy(m);
         return st;
@@ -216,6 +233,8 @@ extern "C" void kpd_egnn_destroy(kpd_egnn *m) {
     for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
     if (m->edge_dbg) (void)hipFree(m->edge_dbg);
     if (m->stamps) (void)hipFree(m->stamps);
+    if (m->widen_buf) (void)hipFree(m->widen_buf);
+    if (m->widen_map) (void)hipFree(m->widen_map);
     m->warena.release();
     m->ws.release();
     delete m;
@@ -238,6 +257,61 @@ static kpd_status expect_shape(const char *name, const int64_t *shape, int ndim,
     return KPD_OK;
 }
 
+// ---- hidden_nf < 256: reference tensors are staged into the 256-wide layout before the packing code below sees them ----------
+// An axis of a reference tensor is a sequence of blocks: 'F' = a feature block of width hidden_nf + 1 ([hidden | timestep]) that
+// becomes 257 wide (hidden -> columns 0 .. hidden_nf - 1, timestep -> column 256, zeros between), 'P' = a block of hidden_nf rows
+// / columns padded with zeros to 256, 'R' = n entries kept as they are.
+struct AxisBlock { char type; int n; };
+
+static std::vector<int> axis_map(const std::vector<AxisBlock> &blocks, int H, int *ref_len) {
+    std::vector<int> map;        // padded index -> reference index or -1
+    int ref = 0;
+    for (const AxisBlock &b : blocks) {
+        if (b.type == 'F') {
+            for (int j = 0; j < HW; ++j) map.push_back(j < H ? ref + j : (j == HID ? ref + H : -1));
+            ref += H + 1;
+        } else if (b.type == 'P') {
+            for (int j = 0; j < HID; ++j) map.push_back(j < H ? ref + j : -1);
+            ref += H;
+        } else {
+            for (int j = 0; j < b.n; ++j) map.push_back(ref + j);
+            ref += b.n;
+        }
+    }
+    *ref_len = ref;
+    return map;
+}
+
+__global__ void k_widen(const float *__restrict__ src, int ld, const int *__restrict__ rmap, int rows, const int *__restrict__ cmap, int cols,
+                        float *__restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    const int r = rmap[i / cols], c = cmap[i % cols];
+    dst[i] = (r >= 0 && c >= 0) ? src[(size_t)r * ld + c] : 0.0f;
+}
+
+// stages w (reference shape) into m->widen_buf in the padded layout; *shape_out = the padded shape
+static kpd_status widen_weight(kpd_egnn *m, const char *name, const float *w, const int64_t *shape, int ndim, const std::vector<AxisBlock> &rows,
+                               const std::vector<AxisBlock> &cols, int64_t *shape_out, hipStream_t st) {
+    const int H = m->cfg.hidden_nf;
+    int ref_r = 0, ref_c = 0;
+    std::vector<int> rmap = axis_map(rows, H, &ref_r), cmap = cols.empty() ? std::vector<int>{0} : axis_map(cols, H, &ref_c);
+    if (cols.empty()) ref_c = 1;
+    const bool ok = cols.empty() ? (ndim == 1 && shape[0] == ref_r) : (ndim == 2 && shape[0] == ref_r && shape[1] == ref_c);
+    KPD_REQUIRE(ok, KPD_ERR_WEIGHTS, "weight %s has the wrong shape for hidden_nf=%d (expected [%d%s%s])", name, H, ref_r, cols.empty() ? "" : ", ",
+                cols.empty() ? "" : std::to_string(ref_c).c_str());
+    const int R = (int)rmap.size(), Cc = (int)cmap.size();
+    KPD_REQUIRE((size_t)R * Cc <= m->widen_floats && (size_t)(R + Cc) <= m->widen_ints, KPD_ERR_HIP, "widen scratch too small (internal sizing error)");
+    KPD_HIP(hipMemcpyAsync(m->widen_map, rmap.data(), (size_t)R * 4, hipMemcpyHostToDevice, st));
+    KPD_HIP(hipMemcpyAsync(m->widen_map + R, cmap.data(), (size_t)Cc * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_widen, dim3(cdiv(R * Cc, 256)), dim3(256), 0, st, w, ref_c, m->widen_map, R, m->widen_map + R, Cc, m->widen_buf);
+    KPD_LAUNCH_CHECK();
+    KPD_HIP(hipStreamSynchronize(st));          // rmap / cmap are host vectors that die with this call
+    shape_out[0] = R;
+    shape_out[1] = Cc;
+    return KPD_OK;
+}
+
 extern "C" kpd_status kpd_egnn_load_weight(kpd_egnn *m, const char *name, const float *w, const int64_t *shape,
                                            int32_t ndim, void *stream) {
     KPD_REQUIRE(m && name && w && shape, KPD_ERR_INVALID, "null argument");
@@ -250,6 +324,33 @@ extern "C" kpd_status kpd_egnn_load_weight(kpd_egnn *m, const char *name, const 
     }
     const std::vector<std::string> tk = split(nm, '.');
     const bool is_w = tk.back() == "weight";
+    int64_t wide_shape[2];
+    if (c.hidden_nf != HID) {
+        // which axes of this tensor carry the hidden width (reference shapes: models/dynamics.py:37-87, 313-334)
+        std::vector<AxisBlock> rows, cols;
+        bool touch = true;
+        const AxisBlock Fb{'F', 0}, Pb{'P', 0};
+        if (tk[0] == "lig_encoder" || tk[0] == "rec_encoder") {
+            if (tk[1] == "0") touch = false;
+            else { rows = {Pb}; if (is_w) cols = {{'R', tk[0] == "lig_encoder" ? 64 : 2 * c.rec_nf}}; }
+        } else if (tk[0] == "lig_decoder") {
+            if (tk[1] == "0" && is_w) { rows = {{'R', 2 * c.atom_nf}}; cols = {Pb}; }
+            else touch = false;
+        } else {
+            const std::string &blk = tk[3];
+            if (blk == "layer_norm") rows = {Fb};
+            else if (blk == "node_mlp") { rows = {Fb}; if (is_w) cols = tk[5] == "0" ? std::vector<AxisBlock>{Fb, Fb} : std::vector<AxisBlock>{Fb}; }
+            else if (blk == "soft_attention") { if (is_w) { rows = {{'R', 1}}; cols = {Fb}; } else touch = false; }
+            else if (tk[5] == "0") { rows = {Fb}; if (is_w) cols = {Fb, Fb, {'R', 1}}; }
+            else if (tk[5] == "2") { rows = {Fb}; if (is_w) cols = {Fb}; }
+            else { rows = {{'R', 1}}; cols = {Fb}; }                     // coord_mlp.<et>.4.weight
+        }
+        if (touch) {
+            KPD_TRY(widen_weight(m, name, w, shape, ndim, rows, cols, wide_shape, st));
+            w = m->widen_buf;
+            shape = wide_shape;
+        }
+    }
     if (tk[0] == "lig_encoder") {
         if (tk[1] == "0") {
             if (is_w) { KPD_TRY(expect_shape(name, shape, ndim, {64, c.atom_nf})); KPD_TRY(copy_pad(w, 64 * c.atom_nf, m->le_W0, 64 * c.atom_nf, st)); }
@@ -646,6 +747,7 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
             na.n_in = k;
             na.wp_a = L.wp_a[nt]; na.wx_a = L.wx_a[nt]; na.wp_b = L.wp_b[nt]; na.wx_b = L.wx_b[nt]; na.b0 = L.b0[nt];
             na.wp_2 = L.wp_2[nt]; na.wx_2 = L.wx_2[nt]; na.b2 = L.b2[nt]; na.ln_w = L.ln_w[nt]; na.ln_b = L.ln_b[nt];
+            na.ln_inv_n = 1.0f / (float)(c.hidden_nf + 1); na.ln_pad = (float)(HID - c.hidden_nf);
             na.wh_a = L.wh_a[nt]; na.wh_b = L.wh_b[nt]; na.wh_2 = L.wh_2[nt];
             na.norm = c.norm;
             na.tile_shift = tr == 32 ? 5 : 6;

@@ -79,6 +79,7 @@ struct NodeArgs {
     const void *wh_a, *wh_b, *wh_2; // f16x2 mode: wp_a / wp_b / wp_2 as f16 hi / lo planes (pack_f16_split)
     const float *ln_w, *ln_b;
     int norm;
+    float ln_inv_n, ln_pad;         // LayerNorm over hidden_nf + 1 features: 1 / (hidden_nf + 1), 256 - hidden_nf (pad columns hold zeros)
     int tile_shift;                 // log2 of the edge-tile size the segment pieces (main / cont) were written with
 };
 

@@ -1352,7 +1352,7 @@ __global__ __launch_bounds__(256, 3) void k_node_layer(NodeLayerPair p) {
             if (q == 0) sum += A[row * SA + 256];
 #pragma unroll
             for (int o = 1; o < TPR; o <<= 1) sum += __shfl_xor(sum, o);
-            const float mean = sum * (1.0f / HW);
+            const float mean = sum * a.ln_inv_n;
             float var = 0.0f;
             for (int i = 0; i < 256 / TPR; ++i) {
                 const float dlt = tr[TPR * i] - mean;
@@ -1366,7 +1366,7 @@ __global__ __launch_bounds__(256, 3) void k_node_layer(NodeLayerPair p) {
             for (int o = 1; o < TPR; o <<= 1) var += __shfl_xor(var, o);
             if (q == 0) {
                 s_mean[row] = mean;
-                s_rstd[row] = 1.0f / sqrtf(var * (1.0f / HW) + 1e-5f);
+                s_rstd[row] = 1.0f / sqrtf((var - a.ln_pad * mean * mean) * a.ln_inv_n + 1e-5f);      // pad columns (hidden_nf < 256) hold 0: take their (0 - mean)^2 out
             }
         }
         lds_barrier();
@@ -1588,7 +1588,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             if (q == 0) sum += A[row * SA + 256];
 #pragma unroll
             for (int o = 1; o < TPR; o <<= 1) sum += __shfl_xor(sum, o);
-            const float mean = sum * (1.0f / HW);
+            const float mean = sum * a.ln_inv_n;
             float var = 0.0f;
             for (int i = 0; i < 256 / TPR; ++i) {
                 const float dlt = tr[TPR * i] - mean;
@@ -1602,7 +1602,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             for (int o = 1; o < TPR; o <<= 1) var += __shfl_xor(var, o);
             if (q == 0) {
                 s_mean[row] = mean;
-                s_rstd[row] = 1.0f / sqrtf(var * (1.0f / HW) + 1e-5f);
+                s_rstd[row] = 1.0f / sqrtf((var - a.ln_pad * mean * mean) * a.ln_inv_n + 1e-5f);      // pad columns (hidden_nf < 256) hold 0: take their (0 - mean)^2 out
             }
         }
         lds_barrier();
@@ -1794,7 +1794,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         if (q == 0) sum += A[row * SA + 256];
 #pragma unroll
         for (int o = 1; o < TPR; o <<= 1) sum += __shfl_xor(sum, o);
-        const float mean = sum * (1.0f / HW);
+        const float mean = sum * a.ln_inv_n;
         float var = 0.0f;
         for (int i = 0; i < 256 / TPR; ++i) {
             const float dlt = tr[TPR * i] - mean;
@@ -1808,7 +1808,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         for (int o = 1; o < TPR; o <<= 1) var += __shfl_xor(var, o);
         if (q == 0) {
             s_mean[row] = mean;
-            s_rstd[row] = 1.0f / sqrtf(var * (1.0f / HW) + 1e-5f);
+            s_rstd[row] = 1.0f / sqrtf((var - a.ln_pad * mean * mean) * a.ln_inv_n + 1e-5f);      // pad columns (hidden_nf < 256) hold 0: take their (0 - mean)^2 out
         }
     }
     lds_barrier();

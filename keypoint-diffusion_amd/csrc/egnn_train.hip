@@ -270,7 +270,9 @@ __global__ __launch_bounds__(256) void k_coord_head_bwd(const float *__restrict_
         const float th = use_tanh ? tanhf(sc[e]) : 0.0f;
         const float coef = use_tanh ? th * range : sc[e];
         const float dcoef = gx * nvec[3 * e] + gy * nvec[3 * e + 1] + gz * nvec[3 * e + 2];
-        const float ds = use_tanh ? dcoef * range * (1.0f - th * th) : dcoef;
+        // 1 - tanh^2 = sech^2 = 4 e / (1 + e)^2, e = exp(-2 |sc|): exact near saturation, where 1 - th * th cancels to nothing
+        const float ex_ = expf(-2.0f * fabsf(sc[e])), sech2 = 4.0f * ex_ / ((1.0f + ex_) * (1.0f + ex_));
+        const float ds = use_tanh ? dcoef * range * sech2 : dcoef;
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
             const int c = lane + 64 * k;

@@ -7,7 +7,7 @@
 # 4) traffic.json: HBM bytes per launch of the dominant kernel of every workload (2 x FETCH_SIZE + WRITE_SIZE)
 # Copy the summaries into profiles/ afterwards (gpurun_out/ is scratch).
 set -e
-tag=${1:-r02}
+tag=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/$tag
 rm -rf $out && mkdir -p $out

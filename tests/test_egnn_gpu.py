@@ -233,3 +233,30 @@ def test_non_finite_coordinates_stay_inside_their_complex(cuda, ll_k):
     assert torch.isfinite(h[16:]).all() and torch.isfinite(xx[16:]).all()
     assert util.rel_err(h[16:], h_ok[16:]) < 1e-5 and util.rel_err(xx[16:], x_ok[16:]) < 1e-5
     assert torch.isnan(h[9:16]).any()
+
+
+@pytest.mark.parametrize('hidden_nf,norm,update_kp', [(255, True, True), (64, True, False), (100, False, True)])
+def test_other_hidden_widths(cuda, hidden_nf, norm, update_kp):
+    """hidden_nf other than 256 -- the reference's own constructor default is 255 (models/dynamics.py:300-302) -- on the same
+    kernels: features in columns 0 .. hidden_nf - 1 of the 256-wide layout, timestep in column 256, LayerNorm over hidden_nf + 1."""
+    cfg = dict(util.EGNN_C2, hidden_nf=hidden_nf, norm=norm, update_kp_feat=update_kp, n_layers=3)
+    (h, x), (rh, rx), model = _run_pair(cuda, cfg, [120, 77, 40], [25, 9, 3])
+    _check(h, x, rh, rx, [25, 9, 3])
+    assert model.egnn.conv_layers[0].edge_mlp['ll'][0].weight.shape == (hidden_nf + 1, 2 * (hidden_nf + 1) + 1)
+
+
+def test_reference_default_constructor_builds_and_runs(cuda):
+    """LigRecDynamics(atom_nf, rec_nf) with every default of the reference signature (n_layers=4, hidden_nf=255, message_norm=1, ...)."""
+    gs = synth.synth_complexes([50, 31], [8, 5], 20, util.CUTOFFS_ALL_ATOM, seed=3)
+    g = util.fixed_encode(G.batch(gs))
+    model = synth.fill_state_dict_(LigRecDynamics(10, 10, graph_cutoffs=util.CUTOFFS_ALL_ATOM, kl_k=5), 2).eval()
+    assert model.hidden_nf == 255 and model.n_layers == 4
+    t = torch.tensor([0.3, 0.7])
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    cfg = dict(n_layers=4, hidden_nf=255, use_tanh=False, message_norm=1, update_kp_feat=False, norm=False, ll_k=0, kl_k=5,
+               graph_cutoffs=util.CUTOFFS_ALL_ATOM)
+    rh, rx = oegnn.egnn_dynamics_forward(sd, cfg, util.to_obatch(g), t)
+    model = model.to(cuda)
+    with torch.no_grad():
+        h, x = model(g.to(cuda), t.to(cuda), None)
+    _check(h.cpu(), x.cpu(), rh, rx, [8, 5])
