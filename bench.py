@@ -86,6 +86,10 @@ WORKLOADS = {
     'egnn_train': dict(arch='egnn', enc='fixed', dyn=DYNAMICS, n_kp=20, cutoffs=CUTOFFS, T=500),
     # same for the gvp_all_atom model in training mode (GVPDropout 0.1): the backward pass of csrc/gvp_train.hip
     'gvp_train': dict(arch='gvp', enc='fixed', dyn=dict(GVP_DYN, message_norm='mean'), n_kp=20, cutoffs=CUTOFFS, T=1000),
+    # the same for the keypoint models (learned receptor encoder -> 40 keypoints -> denoiser; encoder + denoiser backward passes and the
+    # optimal-transport encoder loss): trained_models/gvp_40kp, egnn_40kp
+    'gvp_40kp_train': dict(arch='gvp', enc='learned', dyn=GVP_DYN, n_kp=40, cutoffs=dict(CUTOFFS, kl=8, ll=6.0), T=500),
+    'egnn_40kp_train': dict(arch='egnn', enc='learned', dyn=dict(DYNAMICS, message_norm=0.0), n_kp=40, cutoffs=dict(CUTOFFS, kl=8, ll=5), T=500),
 }
 TRAFFIC_FILES = ('r03_traffic.json', 'r02_traffic.json', 'r01_traffic.json')      # per-launch HBM bytes of the dominant kernels (PMC passes)
 
@@ -536,15 +540,15 @@ def run_train(args, device, rank, world, dist):
     model = build_model(device, args.workload).train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
     B = args.batch
-    gs = synth.synth_complexes([args.n_rec] * B, [args.n_lig] * B, w['n_kp'], w['cutoffs'], seed=1234 + rank * B)
-    template = G.batch(gs).to(device)
+    template = raw_batch(B, args.n_rec, args.n_lig, 1234 + rank * B, device, args.workload).to(device)
     last = [None]
+    enc_weight = 0.1 if w['enc'] == 'learned' else 0.0      # train.py adds the encoder loss with its configured weight
 
     def step(i):
         g = template.to(device)             # fresh container over the same device tensors (forward re-binds node data)
         losses = model(g, None)
         opt.zero_grad(set_to_none=True)
-        losses['l2'].backward()
+        (losses['l2'] + enc_weight * losses['rec_encoder'] if enc_weight else losses['l2']).backward()
         if dist is not None:
             allreduce_gradients(list(model.parameters()))
         torch.nn.utils.clip_grad_value_(model.parameters(), 1.0)
@@ -557,13 +561,13 @@ def run_train(args, device, rank, world, dist):
         out = {'metric': 'training steps/sec', 'value': world * args.steps / med, 'unit': 'steps/s', 'n_gpus': world,
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * med / args.steps, 'higher_is_better': True,
                'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-               'config': {'workload': f'{args.workload}: loss + backward + clip + Adam on {w["arch"]}_all_atom (6 layers, hidden 256, '
+               'config': {'workload': f'{args.workload}: loss + backward + clip + Adam on {w["arch"]}_{"40kp (learned encoder, encoder + optimal-transport loss included)" if w["enc"] == "learned" else "all_atom"} (6 layers, hidden 256, '
                                       f'training mode), batch of {B} '
                                       f'synthetic {args.n_rec}-atom pockets / {args.n_lig}-atom ligands per GPU, one bucketed gradient all-reduce per step when N > 1',
                           'batch_per_gpu': B, 'parallelism': f'dp{world}'},
                'repeats': {'n': args.repeats, 'ms_per_step': [1e3 * r / args.steps for r in regions], 'statistic': 'median'},
                'complex_steps_per_s': world * args.steps / med * B, 'final_l2': float(last[0].detach())}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and w['enc'] == 'fixed':
             out['cpu_baseline'] = train_cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)
 
@@ -586,7 +590,7 @@ def main():
     ap.add_argument('--graph', action='store_true', help='replay the reverse step as a captured HIP graph (StepGraph)')
     ap.add_argument('--ragged', action='store_true', help='pockets 150-600 atoms, ligands 15-35 atoms (configs[4] shape)')
     args = ap.parse_args()
-    training = args.workload in ('egnn_train', 'gvp_train')
+    training = args.workload.endswith('_train')
     if args.steps is None:
         args.steps = 20 if training else 200
     if args.warmup is None:

@@ -357,6 +357,15 @@ kpd_status kpd_recegnn_trainer_forward(kpd_recegnn_trainer *t, const kpd_rec_bat
 kpd_status kpd_recegnn_trainer_backward(kpd_recegnn_trainer *t, const float *d_kp_x, const float *d_kp_h, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Exact optimal-transport plans between small uniform point clouds, on the HOST (no device work): what the reference gets from
+ * POT's `ot.emd` in losses/rec_encoder_loss.py:11-18 (keypoints vs receptor atoms / interface points, once per complex and
+ * training batch).  n_problems independent problems; problem p: cost matrix at cost + offsets[p] (row-major [n[p], m[p]],
+ * doubles), masses 1 / n[p] and 1 / m[p]; the optimal plan is written to plan + offsets[p].  Up to n_threads host threads.
+ * ------------------------------------------------------------------------------------- */
+kpd_status kpd_ot_emd_uniform(int32_t n_problems, const int32_t *n, const int32_t *m, const int64_t *offsets,
+                              const double *cost_host, double *plan_host, int32_t n_threads);
+
+/* ---------------------------------------------------------------------------------------
  * Reverse-diffusion update around the denoiser.  Replaces the elementwise part of
  * KeypointDiffusion.sample_p_zs_given_zt (models/ligand_diffuser.py:515-536):
  *   z_s = z_t / alpha_ts - var_terms * eps + sigma * noise, then ligand-COM removal from

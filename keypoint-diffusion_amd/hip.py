@@ -167,6 +167,7 @@ def lib():
     L.kpd_recegnn_trainer_forward.argtypes = [C.c_void_p, C.POINTER(KpdRecBatch), C.c_void_p, C.POINTER(KpdRecOut), C.c_void_p, C.c_void_p,
                                               C.c_void_p]
     L.kpd_recegnn_trainer_backward.argtypes = [C.c_void_p] + [C.c_void_p] * 3
+    L.kpd_ot_emd_uniform.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
     L.kpd_rec_graph_scratch_bytes.argtypes = [C.c_int32, C.c_int32]
     L.kpd_rec_graph_scratch_bytes.restype = C.c_int64
     L.kpd_build_rec_graph.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p,
@@ -199,7 +200,7 @@ EXPORTS = [
     'kpd_recenc_trainer_create', 'kpd_recenc_trainer_destroy', 'kpd_recenc_trainer_bind', 'kpd_recenc_trainer_set_dropout',
     'kpd_recenc_trainer_reserve', 'kpd_recenc_trainer_forward', 'kpd_recenc_trainer_backward',
     'kpd_recegnn_trainer_create', 'kpd_recegnn_trainer_destroy', 'kpd_recegnn_trainer_bind', 'kpd_recegnn_trainer_reserve',
-    'kpd_recegnn_trainer_forward', 'kpd_recegnn_trainer_backward',
+    'kpd_recegnn_trainer_forward', 'kpd_recegnn_trainer_backward', 'kpd_ot_emd_uniform',
 ]
 
 
@@ -774,6 +775,25 @@ class RecEgnnTrainer:
 
     def backward(self, d_kp_x, d_kp_h):
         check(lib().kpd_recegnn_trainer_backward(self._h, _ptr(d_kp_x), _ptr(d_kp_h), _stream()))
+
+
+def ot_emd_uniform(costs, n_threads: int = 0):
+    """Exact transport plans (uniform masses) for a list of [n_i, m_i] cost matrices (numpy float64, host): kpd_ot_emd_uniform.
+    Host-side like the reference's POT call; the library spreads the problems over host threads (ctypes releases the GIL)."""
+    import numpy as np
+    if not costs:
+        return []
+    ns = np.asarray([c.shape[0] for c in costs], dtype=np.int32)
+    ms = np.asarray([c.shape[1] for c in costs], dtype=np.int32)
+    sizes = ns.astype(np.int64) * ms.astype(np.int64)
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+    flat = np.concatenate([np.ascontiguousarray(c, dtype=np.float64).reshape(-1) for c in costs])
+    plan = np.empty_like(flat)
+    if n_threads <= 0:
+        n_threads = max(1, min(len(os.sched_getaffinity(0)), 16))
+    check(lib().kpd_ot_emd_uniform(len(costs), ns.ctypes.data, ms.ctypes.data, offs.ctypes.data, flat.ctypes.data, plan.ctypes.data,
+                                   int(n_threads)))
+    return [plan[o:o + s].reshape(int(a), int(b)) for o, s, a, b in zip(offs, sizes, ns, ms)]
 
 
 def step_coefficients(gamma: torch.Tensor, s: torch.Tensor, t: torch.Tensor) -> torch.Tensor:

@@ -2,41 +2,33 @@
 the receptor atoms (or the interface points) of every complex, uniform masses on both sides, squared Euclidean cost.
 
 The reference solves the transport problem on the host with `ot.emd` (POT, exact network simplex, :11-18); POT is not in
-this image, so the same linear program -- min <P, C> s.t. P 1 = 1/n, P^T 1 = 1/m, P >= 0 -- is solved exactly with HiGHS
-through scipy.  The optimal VALUE of the program is unique, so the loss equals the reference's; as there, the plan is a
-constant and the gradient flows through the cost matrix only.  It is host-side code in both implementations (a 40 x 300
-program per complex, once per training batch): not a kernel."""
+this image, so the same linear program -- min <P, C> s.t. P 1 = 1/n, P^T 1 = 1/m, P >= 0 -- is solved exactly by the library's own
+host-side min-cost-flow solver (`kpd_ot_emd_uniform`, csrc/ot.hip: successive shortest paths with potentials, double precision, a few
+ms per 40 x 300 problem, the complexes of a batch on parallel host threads; round 2 used HiGHS through scipy, 0.45 s per complex, which
+no longer fits once these models train).  The optimal VALUE of the program is unique, so the loss equals the reference's; as there,
+the plan is a constant and the gradient flows through the cost matrix only.  Host-side code in both implementations: not a kernel."""
 from typing import List, Optional
 
-import numpy as np
 import torch
 import torch.nn as nn
 
 from . import graph as G
+from . import hip
 
 
-def _transport_plan(cost: np.ndarray) -> np.ndarray:
-    """Exact optimal plan of the uniform-mass transport problem for an [n, m] cost matrix."""
-    from scipy.optimize import linprog
-    from scipy.sparse import coo_matrix
-    n, m = cost.shape
-    if n == 0 or m == 0:
+def transport_plans(costs: List[torch.Tensor]) -> List[torch.Tensor]:
+    """Exact optimal plans (uniform masses) of a batch of [n_i, m_i] cost matrices, as constants on the costs' device."""
+    if any(c.shape[0] == 0 or c.shape[1] == 0 for c in costs):
         raise ValueError('optimal transport needs at least one point on either side')
-    rows = np.concatenate([np.repeat(np.arange(n), m), n + np.tile(np.arange(m), n)])
-    cols = np.concatenate([np.arange(n * m), np.arange(n * m)])
-    A = coo_matrix((np.ones(2 * n * m), (rows, cols)), shape=(n + m, n * m)).tocsr()
-    b = np.concatenate([np.full(n, 1.0 / n), np.full(m, 1.0 / m)])
-    # one of the n + m mass constraints is implied by the others; HiGHS handles the redundancy
-    res = linprog(cost.reshape(-1).astype(np.float64), A_eq=A, b_eq=b, bounds=(0, None), method='highs')
-    if res.status != 0:
-        raise RuntimeError(f'optimal-transport program did not solve: {res.message}')
-    return res.x.reshape(n, m)
+    plans = hip.ot_emd_uniform([c.detach().double().cpu().numpy() for c in costs])
+    return [torch.from_numpy(p).to(device=c.device, dtype=c.dtype) for p, c in zip(plans, costs)]
 
 
 def compute_ot_emd(cost_mat: torch.Tensor, device=None):
     """(sum(P * cost), P) with P the optimal plan, detached (rec_encoder_loss.py:11-18)."""
-    plan = _transport_plan(cost_mat.detach().cpu().numpy())
-    plan_t = torch.tensor(plan, device=device if device is not None else cost_mat.device).float()
+    plan_t = transport_plans([cost_mat])[0]
+    if device is not None:
+        plan_t = plan_t.to(device)
     return torch.sum(plan_t * cost_mat), plan_t
 
 
@@ -64,8 +56,9 @@ class ReceptorEncoderLoss(nn.Module):
             targets = [u.nodes['rec'].data['x_0'] for u in G.unbatch(g)]         # :49-69
         if len(targets) != len(kp):
             raise ValueError(f'{len(targets)} target point sets for {len(kp)} complexes')
+        costs = [torch.square(torch.cdist(kp_pos, tgt.to(kp_pos.device))) for kp_pos, tgt in zip(kp, targets)]
+        plans = transport_plans(costs)                         # one library call: the complexes are solved on parallel host threads
         total = 0
-        for kp_pos, tgt in zip(kp, targets):
-            cost = torch.square(torch.cdist(kp_pos, tgt.to(kp_pos.device)))
-            total = total + compute_ot_emd(cost, device=cost.device)[0]
+        for cost, plan in zip(costs, plans):
+            total = total + torch.sum(plan * cost)
         return total / len(kp)
