@@ -190,7 +190,9 @@ class KeypointDiffusion(nn.Module):
         g = self.rec_encoder(g, batch_idxs)
         if self.rec_encoder_type == 'fixed':
             batch_idxs = G.get_batch_idxs(g)                  # :106-107: keypoints = receptor atoms now
-        losses['rec_encoder'] = self.rec_encoder_loss_fn(g, interface_points=interface_points)          # :115
+        # :115; the exact transport plans are solved on host threads while the denoiser's forward is launched below
+        losses['rec_encoder'] = None
+        pending = self.rec_encoder_loss_fn.begin(g, interface_points=interface_points)
         g = self.remove_com(g, batch_idxs['lig'], batch_idxs['kp'], com='ligand')
         t = torch.randint(0, self.n_timesteps, size=(batch_size,), device=device).float() / self.n_timesteps
         eps = {'h': torch.randn(g.nodes['lig'].data['h_0'].shape, device=device),
@@ -198,6 +200,7 @@ class KeypointDiffusion(nn.Module):
         gamma_t = self.gamma(t).to(device=device)
         g = self.noised_representation(g, batch_idxs['lig'], batch_idxs['kp'], eps, gamma_t)
         eps_h_pred, eps_x_pred = self.dynamics(g, t, batch_idxs)
+        losses['rec_encoder'] = pending.finish()
         x_loss = (eps['x'] - eps_x_pred).square().sum()
         n_x_loss_terms = eps['x'].numel()
         h_loss = (eps['h'] - eps_h_pred).square().sum()
