@@ -366,6 +366,18 @@ kpd_status kpd_ot_emd_uniform(int32_t n_problems, const int32_t *n, const int32_
                               const double *cost_host, double *plan_host, int32_t n_threads);
 
 /* ---------------------------------------------------------------------------------------
+ * The fp32 GEMM the training engines run their dense products on (csrc/sgemm.hip, v_mfma_f32_32x32x2_f32; no vendor BLAS in the
+ * library): row-major C[M,N] = alpha op(A) op(B) + beta C on device pointers, any sizes, leading dimensions and alignments.  What the
+ * reference gets from torch.nn.Linear / autograd inside models/dynamics.py:37-79, models/gvp.py:166-222 during train.py; exported so
+ * that its parity against a plain fp32 product can be tested on its own.  `workspace` (device floats, may be NULL): scratch for the
+ * partial products of a K-dominated shape (a weight gradient, K = edge count), which is then cut along K over the grid and summed in a
+ * fixed order -- never with atomics.
+ * ------------------------------------------------------------------------------------- */
+kpd_status kpd_sgemm(int32_t trans_a, int32_t trans_b, int32_t M, int32_t N, int32_t K, float alpha, const float *A, int32_t lda,
+                     const float *B, int32_t ldb, float beta, float *C, int32_t ldc, float *workspace, int64_t workspace_floats,
+                     void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Reverse-diffusion update around the denoiser.  Replaces the elementwise part of
  * KeypointDiffusion.sample_p_zs_given_zt (models/ligand_diffuser.py:515-536):
  *   z_s = z_t / alpha_ts - var_terms * eps + sigma * noise, then ligand-COM removal from

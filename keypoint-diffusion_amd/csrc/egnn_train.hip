@@ -9,7 +9,7 @@
 // carries over to the backward pass: pre1[e] = U[src] + V[dst] + d_e w_r + b1 with U = h_src W1[:, :257]^T and
 // V = h_dst W1[:, 257:514]^T, hence dW1 and dh need only the per-node sums of dpre1 (segmented by dst, scattered by src)
 // and node-sized GEMMs; the per-edge GEMMs left are pre2 = a1 W2^T, da1 = dpre2 W2 and dW2 = dpre2^T a1.  All dense
-// products are plain fp32 GEMMs / GEMVs (rocBLAS, on the caller's stream); gather, activation, attention / coordinate
+// products are plain fp32 GEMMs / GEMVs (sgemm.hip: the library's own MFMA GEMM, on the caller's stream); gather, activation, attention / coordinate
 // heads, segmented sums, LayerNorm and geometry are the kernels below.  Memory: only the node states of every layer
 // (h, x, aggregated messages) are kept between forward and backward; per-edge activations are recomputed one edge
 // type and one branch at a time into scratch sized for the largest edge type.
@@ -401,7 +401,7 @@ kpd_status edge_branch_fwd(kpd_egnn_trainer *T, const BranchParams &p, int et, c
     hipLaunchKernelGGL(k_edge_pre1, grid1(tot), dim3(256), 0, T->st, T->nb[0], T->nb[1], T->e_src[et], T->e_dst[et], T->dij,
                        p.W1.w + 2 * H, 2 * H + 1, p.b1.w, tot, T->eb[0], T->eb[1]);
     KPD_LAUNCH_CHECK();
-    // pre2 = a1 W2^T + b2, a2 = SiLU(pre2): the weight-stationary GEMM with the activation fused (KPD_TRAIN_WS=0: rocBLAS + kernel)
+    // pre2 = a1 W2^T + b2, a2 = SiLU(pre2): the weight-stationary GEMM with the activation fused (KPD_TRAIN_WS=0: general GEMM + kernel)
     if (use_ws()) return ws_gemm(WS_BIAS_SILU, T->eb[1], E, LD, p.W2.w, H, false, p.b2.w, nullptr, T->eb[2], T->eb[3], LD, T->wsg_pack, T->st);
     KPD_TRY(gemm(T, false, true, E, H, H, T->eb[1], LD, p.W2.w, H, 0.0f, T->eb[2], LD));
     hipLaunchKernelGGL(k_bias_silu, grid1(tot), dim3(256), 0, T->st, T->eb[2], p.b2.w, tot, H, LD, T->eb[3]);
@@ -587,19 +587,12 @@ extern "C" kpd_status kpd_egnn_trainer_create(const kpd_egnn_config *cfg, kpd_eg
     T->n_et = cfg->update_kp_feat ? 4 : 2;
     T->n_upd = cfg->update_kp_feat ? 2 : 1;
     T->rec_identity = cfg->rec_nf == 256;
-    if (rocblas_create_handle(&T->blas) != rocblas_status_success) {
-        delete T;
-        set_error("rocblas_create_handle failed");
-        return KPD_ERR_HIP;
-    }
-    (void)rocblas_set_atomics_mode(T->blas, rocblas_atomics_not_allowed);      // bitwise-reproducible products
     *out = T;
     return KPD_OK;
 }
 
 extern "C" void kpd_egnn_trainer_destroy(kpd_egnn_trainer *T) {
     if (!T) return;
-    if (T->blas) rocblas_destroy_handle(T->blas);
     T->ws.release();
     if (T->store_base) (void)hipFree(T->store_base);
     delete T;
@@ -648,7 +641,7 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
     for (int k = 0; k < 7; ++k) add((size_t)cap_N * LD, 4);
     add((size_t)cap_N * ENC_LD, 4);
     add((size_t)ws_gemm_pack_floats(), 4);
-    add((size_t)GRAD_SPLIT * 264 * 520, 4);
+    add(GRAD_PART_FLOATS, 4);
     for (int k = 0; k < 3; ++k) add((size_t)cap_E * 3, 4);      // xdiff, nvec, dn
     add((size_t)cap_E * 3, 4);                                    // msgx
     for (int k = 0; k < 5; ++k) add(cap_E, 4);                   // dij, att, sc, dsv, ddij
@@ -682,7 +675,7 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
     for (int k = 0; k < 7; ++k) T->nb[k] = W.take<float>((size_t)cap_N * LD);
     T->dact = W.take<float>((size_t)cap_N * ENC_LD);
     T->wsg_pack = W.take<float>((size_t)ws_gemm_pack_floats());
-    T->part_floats = (size_t)GRAD_SPLIT * 264 * 520;
+    T->part_floats = GRAD_PART_FLOATS;
     T->part = W.take<float>(T->part_floats);
     T->xdiff = W.take<float>((size_t)cap_E * 3); T->nvec = W.take<float>((size_t)cap_E * 3); T->dn = W.take<float>((size_t)cap_E * 3);
     T->msgx = W.take<float>((size_t)cap_E * 3);
@@ -781,7 +774,6 @@ extern "C" kpd_status kpd_egnn_trainer_forward(kpd_egnn_trainer *T, const kpd_ba
     const kpd_egnn_config &c = T->cfg;
     hipStream_t st = static_cast<hipStream_t>(stream);
     T->st = st;
-    KPD_BLAS(rocblas_set_stream(T->blas, st));
     T->bt = *bt;
     T->t_dev = t_dev;
     T->n[0] = bt->n_lig; T->n[1] = bt->n_kp;
@@ -966,7 +958,6 @@ extern "C" kpd_status kpd_egnn_trainer_backward(kpd_egnn_trainer *T, const float
     const kpd_egnn_config &c = T->cfg;
     hipStream_t st = static_cast<hipStream_t>(stream);
     T->st = st;
-    KPD_BLAS(rocblas_set_stream(T->blas, st));
     const int L = c.n_layers, nl = T->n[0], nk = T->n[1];
     int cur = 0, nxt = 1;
     if (T->n_upd == 1) {        // kp not updated: one gradient accumulator across layers (the same tensors feed every layer)

@@ -7,7 +7,7 @@
 // the receptor encoder's parameters (k_gvp_geom_bwd).
 //
 // Same formulation as egnn_train.hip: parameters in place in the reference layout, gradients accumulated in that
-// layout, dense products through rocBLAS on the caller's stream, everything else in the kernels below; only node-sized
+// layout, dense products through sgemm.hip on the caller's stream, everything else in the kernels below; only node-sized
 // state per conv is kept between forward and backward, edge activations are recomputed one edge type at a time.
 // Vector features are kept as [rows, 3, channels] (the reference holds [rows, channels, 3]), so that the channel
 // mixes Wh / Wu are plain GEMMs over 3 x rows; the first scalar Linear of the message function is split as in the
@@ -404,19 +404,12 @@ extern "C" kpd_status kpd_gvp_trainer_create(const kpd_gvp_config *cfg, kpd_gvp_
     kpd_gvp_trainer *T = new kpd_gvp_trainer();
     T->cfg = *cfg;
     T->S = cfg->n_hidden_scalars;
-    if (rocblas_create_handle(&T->blas) != rocblas_status_success) {
-        delete T;
-        set_error("rocblas_create_handle failed");
-        return KPD_ERR_HIP;
-    }
-    (void)rocblas_set_atomics_mode(T->blas, rocblas_atomics_not_allowed);      // bitwise-reproducible products
     *out = T;
     return KPD_OK;
 }
 
 extern "C" void kpd_gvp_trainer_destroy(kpd_gvp_trainer *T) {
     if (!T) return;
-    if (T->blas) rocblas_destroy_handle(T->blas);
     T->ws.release();
     if (T->store_base) (void)hipFree(T->store_base);
     delete T;
@@ -505,7 +498,7 @@ extern "C" kpd_status kpd_gvp_trainer_reserve(kpd_gvp_trainer *T, int32_t max_B,
         const size_t N = std::max(max_n_lig, max_n_kp);
         F(T->U, N * S); F(T->scale, N); F(T->tmp_s, N * S); F(T->tmp_v, N * 3 * VC); F(T->s1, N * S); F(T->v1, N * 3 * VC);
         F(T->sb, N * std::max(S, 256)); F(T->vb, N * 3 * VC);
-        F(T->part, (size_t)GRAD_SPLIT * 264 * 520);
+        F(T->part, GRAD_PART_FLOATS);
         F(T->wsg_pack, (size_t)ws_gemm_pack_floats());
         F(T->ones, 8);
         const int cap_et[4] = {cap_ll, cap_kl, cap_kl, std::max<int>(max_n_kk, 1)};
@@ -521,7 +514,7 @@ extern "C" kpd_status kpd_gvp_trainer_reserve(kpd_gvp_trainer *T, int32_t max_B,
         if (pass == 0) KPD_TRY(T->ws.reserve(bytes + 4096));
     }
     KPD_REQUIRE(T->lg.counts != nullptr, KPD_ERR_HIP, "workspace arena too small (internal sizing error)");
-    T->part_floats = (size_t)GRAD_SPLIT * 264 * 520;
+    T->part_floats = GRAD_PART_FLOATS;
     T->lg.cap_ll = cap_ll; T->lg.cap_kl = cap_kl;
     T->colpart_blocks = cdiv(R, HEAD_ROWS);
     T->scratch.unit = T->unit; T->scratch.rbf = T->rbf; T->scratch.vin = T->vin;
@@ -582,7 +575,6 @@ extern "C" kpd_status kpd_gvp_trainer_forward(kpd_gvp_trainer *T, const kpd_batc
     const kpd_gvp_config &c = T->cfg;
     hipStream_t st = static_cast<hipStream_t>(stream);
     T->st = st;
-    KPD_BLAS(rocblas_set_stream(T->blas, st));
     T->bt = *bt;
     T->t_dev = t_dev;
     T->n[0] = bt->n_lig; T->n[1] = bt->n_kp;
@@ -620,7 +612,6 @@ extern "C" kpd_status kpd_gvp_trainer_backward(kpd_gvp_trainer *T, const float *
     const kpd_gvp_config &c = T->cfg;
     hipStream_t st = static_cast<hipStream_t>(stream);
     T->st = st;
-    KPD_BLAS(rocblas_set_stream(T->blas, st));
     const int S = T->S, nn = c.n_noise_gvps, nl = T->n[0], nk = T->n[1], L = c.n_convs, F = c.n_lig_scalars;
     int cur = 0, nxt = 1;
     T->want_x = d_lig_x || d_kp_x;

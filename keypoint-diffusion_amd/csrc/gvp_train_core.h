@@ -1,7 +1,7 @@
 // Generic pieces of the GVP training engines (gvp_train.hip: the denoiser; recenc_train.hip: the keypoint receptor encoder):
 // the elementwise / reduction kernels of GVP.forward and GVPLayerNorm and their backward passes, edge geometry forward and
-// backward, dropout streams, and GVP / GVPLayerNorm as host routines over rocBLAS products -- templates over the engine type,
-// which supplies the stream and BLAS handle (TrainCtx), the scalar width S and the scratch buffers dgate, dsh, dVh, wsg_pack,
+// backward, dropout streams, and GVP / GVPLayerNorm as host routines over sgemm.hip products -- templates over the engine type,
+// which supplies the stream (TrainCtx), the scalar width S and the scratch buffers dgate, dsh, dVh, wsg_pack,
 // tmp_s, tmp_v, U.  Vector features are [rows, 3, channels].  File-local in every translation unit that includes it.
 #pragma once
 #include "egnn_kernels.h"

@@ -6,7 +6,7 @@
 // keypoint-to-atom distances) -- with respect to every parameter, given the gradients of the two outputs the denoiser and the
 // encoder loss consume: keypoint positions and keypoint features.
 //
-// Formulation as in the other training engines: parameters in place in the reference layout, dense products through rocBLAS,
+// Formulation as in the other training engines: parameters in place in the reference layout, dense products through sgemm.hip,
 // deterministic segmented sums, node-sized state per layer kept, edge activations recomputed one layer at a time.  The encoder
 // runs once per batch (~170 k rr edges at B = 64), a few per cent of a training step, so the edge rows [h_src | h_dst | d | a] are
 // materialised and the first Linear is not split.  The kNN rec->kp edges and the kk radius graph are rebuilt from positions and are
@@ -507,19 +507,12 @@ extern "C" kpd_status kpd_recegnn_trainer_create(const kpd_recegnn_config *cfg, 
     T->cfg = *cfg;
     T->H = cfg->hidden_n_node_feat;
     T->Dmax = std::max(std::max(cfg->in_n_node_feat, cfg->hidden_n_node_feat), cfg->out_n_node_feat);
-    if (rocblas_create_handle(&T->blas) != rocblas_status_success) {
-        delete T;
-        set_error("rocblas_create_handle failed");
-        return KPD_ERR_HIP;
-    }
-    (void)rocblas_set_atomics_mode(T->blas, rocblas_atomics_not_allowed);
     *out = T;
     return KPD_OK;
 }
 
 extern "C" void kpd_recegnn_trainer_destroy(kpd_recegnn_trainer *T) {
     if (!T) return;
-    if (T->blas) rocblas_destroy_handle(T->blas);
     T->ws.release();
     delete T;
 }
@@ -570,7 +563,7 @@ extern "C" kpd_status kpd_recegnn_trainer_reserve(kpd_recegnn_trainer *T, int32_
         for (int k = 0; k < 2; ++k) { F(T->gh[k], nr * Dm); F(T->gx[k], nr * 3); }
         F(T->gkx, nk * 3); F(T->gk1, nk * (D + 16)); F(T->gk2, nk * (D + 16));
         F(T->z, (size_t)max_B + 8); F(T->scale, nr);
-        F(T->part, (size_t)GRAD_SPLIT * 264 * 520); F(T->ones, 8); F(T->colpart, colpart_floats(std::max<int>(E, (int)std::max(nr, nk))));
+        F(T->part, GRAD_PART_FLOATS); F(T->ones, 8); F(T->colpart, colpart_floats(std::max<int>(E, (int)std::max(nr, nk))));
         I(T->bidx, nr); I(T->kp_ptr, max_B + 1); I(T->rk_src, cap_rk); I(T->rk_dst, cap_rk); I(T->rk_rowptr, nk + 1);
         I(T->off_tmp, max_B + 2); I(T->xm_src, cap_rk); I(T->xm_dst, cap_rk); I(T->xm_rowptr, nr + 1); I(T->cursor, std::max(nr, nk));
         I(T->scsr_rr.perm, E); I(T->scsr_rr.rowptr, nr + 1); I(T->scsr_rk.perm, cap_rk); I(T->scsr_rk.rowptr, nr + 1);
@@ -578,7 +571,7 @@ extern "C" kpd_status kpd_recegnn_trainer_reserve(kpd_recegnn_trainer *T, int32_
         if (pass == 0) KPD_TRY(T->ws.reserve(bytes + 4096));
     }
     KPD_REQUIRE(T->kk_off != nullptr, KPD_ERR_HIP, "workspace arena too small (internal sizing error)");
-    T->part_floats = (size_t)GRAD_SPLIT * 264 * 520;
+    T->part_floats = GRAD_PART_FLOATS;
     T->colpart_blocks = cdiv(std::max<int>(E, std::max(max_n_rec, n_kp)), HEAD_ROWS);
     T->cap_B = max_B; T->cap_rec = max_n_rec; T->cap_rr = max_n_rr; T->cap_maxrec = max_rec_pg; T->cap_rk = cap_rk;
     T->have_forward = false;
@@ -597,7 +590,6 @@ extern "C" kpd_status kpd_recegnn_trainer_forward(kpd_recegnn_trainer *T, const 
                 KPD_ERR_INVALID, "output buffers missing");
     hipStream_t st = static_cast<hipStream_t>(stream);
     T->st = st;
-    KPD_BLAS(rocblas_set_stream(T->blas, st));
     T->bt = *bt;
     T->same_res = rr_same_res;
     const int D = c.out_n_node_feat, K = c.n_keypoints, B = bt->B, n_rec = bt->n_rec, n_kp = B * K, L = c.n_convs, k = c.k_closest;
@@ -671,7 +663,6 @@ extern "C" kpd_status kpd_recegnn_trainer_backward(kpd_recegnn_trainer *T, const
     const kpd_recegnn_config &c = T->cfg;
     hipStream_t st = static_cast<hipStream_t>(stream);
     T->st = st;
-    KPD_BLAS(rocblas_set_stream(T->blas, st));
     const kpd_rec_batch &bt = T->bt;
     const int D = c.out_n_node_feat, K = c.n_keypoints, B = T->B, n_rec = T->n_rec, n_kp = T->n_kp, L = c.n_convs, k = c.k_closest;
     Param Wk, bk, Wf, Wp, bp, lw, lb;

@@ -6,7 +6,7 @@
 // outputs the denoiser and the encoder loss consume: keypoint positions, scalars and vectors.
 //
 // Same formulation as gvp_train.hip (whose generic GVP / GVPLayerNorm routines it shares, gvp_train_core.h): parameters in place
-// in the reference layout, dense products through rocBLAS on the caller's stream, deterministic segmented sums (no float
+// in the reference layout, dense products through sgemm.hip on the caller's stream, deterministic segmented sums (no float
 // atomics), node-sized state kept per convolution, edge activations recomputed one convolution at a time.  The encoder runs
 // once per batch on ~170 k rr edges and ~13 k rk edges (B = 64), a few per cent of a training step: the message inputs
 // [s_src | rbf | s_dst] and [x_diff | v_src | v_dst] are simply materialised per edge instead of splitting the first Linear.
@@ -415,19 +415,12 @@ extern "C" kpd_status kpd_recenc_trainer_create(const kpd_recenc_config *cfg, kp
     kpd_recenc_trainer *T = new kpd_recenc_trainer();
     T->cfg = *cfg;
     T->S = cfg->out_scalar_size;
-    if (rocblas_create_handle(&T->blas) != rocblas_status_success) {
-        delete T;
-        set_error("rocblas_create_handle failed");
-        return KPD_ERR_HIP;
-    }
-    (void)rocblas_set_atomics_mode(T->blas, rocblas_atomics_not_allowed);
     *out = T;
     return KPD_OK;
 }
 
 extern "C" void kpd_recenc_trainer_destroy(kpd_recenc_trainer *T) {
     if (!T) return;
-    if (T->blas) rocblas_destroy_handle(T->blas);
     T->ws.release();
     delete T;
 }
@@ -498,7 +491,7 @@ extern "C" kpd_status kpd_recenc_trainer_reserve(kpd_recenc_trainer *T, int32_t 
         F(T->grs, nr * S); F(T->grv, nr * 3 * VC); F(T->gro_s, nr * S); F(T->gro_v, nr * 3 * VC);
         for (int k = 0; k < 2; ++k) { F(T->gks[k], nk * S); F(T->gkv[k], nk * 3 * VC); }
         F(T->gkx, nk * 3); F(T->z, max_B);
-        F(T->part, (size_t)GRAD_SPLIT * 264 * 520); F(T->wsg_pack, (size_t)ws_gemm_pack_floats()); F(T->ones, 8);
+        F(T->part, GRAD_PART_FLOATS); F(T->wsg_pack, (size_t)ws_gemm_pack_floats()); F(T->ones, 8);
         F(T->colpart, colpart_floats(R));
         I(T->bidx[0], nr); I(T->bidx[1], nk); I(T->kp_ptr, max_B + 1);
         I(T->rk_src, cap_rk); I(T->rk_dst, cap_rk); I(T->rk_rowptr, nk + 1);
@@ -510,7 +503,7 @@ extern "C" kpd_status kpd_recenc_trainer_reserve(kpd_recenc_trainer *T, int32_t 
         if (pass == 0) KPD_TRY(T->ws.reserve(bytes + 4096));
     }
     KPD_REQUIRE(T->kk_off != nullptr, KPD_ERR_HIP, "workspace arena too small (internal sizing error)");
-    T->part_floats = (size_t)GRAD_SPLIT * 264 * 520;
+    T->part_floats = GRAD_PART_FLOATS;
     T->colpart_blocks = cdiv(R, HEAD_ROWS);
     T->cap_B = max_B; T->cap_rec = max_n_rec; T->cap_rr = max_n_rr; T->cap_maxrec = max_rec_pg; T->cap_rk = cap_rk; T->cap_R = R;
     T->have_forward = false;
@@ -527,7 +520,6 @@ extern "C" kpd_status kpd_recenc_trainer_forward(kpd_recenc_trainer *T, const kp
     const kpd_recenc_config &c = T->cfg;
     hipStream_t st = static_cast<hipStream_t>(stream);
     T->st = st;
-    KPD_BLAS(rocblas_set_stream(T->blas, st));
     T->bt = *bt;
     const int S = T->S, K = c.n_keypoints, B = bt->B, n_rec = bt->n_rec, n_kp = B * K, F = c.in_scalar_size, Rr = c.n_rr_convs, Rk = c.n_rk_convs;
     T->B = B; T->n_rec = n_rec; T->n_kp = n_kp;
@@ -622,7 +614,6 @@ extern "C" kpd_status kpd_recenc_trainer_backward(kpd_recenc_trainer *T, const f
     const kpd_recenc_config &c = T->cfg;
     hipStream_t st = static_cast<hipStream_t>(stream);
     T->st = st;
-    KPD_BLAS(rocblas_set_stream(T->blas, st));
     const int S = T->S, K = c.n_keypoints, B = T->B, n_rec = T->n_rec, n_kp = T->n_kp, F = c.in_scalar_size, Rr = c.n_rr_convs, Rk = c.n_rk_convs;
     const kpd_rec_batch &bt = T->bt;
     // incoming gradients (null = zero); keypoint vectors arrive as [n, 16, 3]

@@ -1,0 +1,18 @@
+// General fp32 MFMA GEMM of the training engines (sgemm.hip).
+#pragma once
+#include "common.h"
+
+namespace kpd {
+
+constexpr int SGEMM_MAX_SPLIT = 256;
+
+// row-major C[M,N] = alpha op(A) op(B) + beta C.  With a scratch buffer `part`, a product whose output is a few tiles only (weight
+// gradients: K = edge count) is cut along K into slices computed by grid.z of one launch and summed in slice order (no atomics).
+kpd_status sgemm(bool tA, bool tB, int M, int N, int K, float alpha, const float *A, int lda, const float *B, int ldb, float beta,
+                 float *C, int ldc, hipStream_t st, float *part = nullptr, size_t part_floats = 0);
+// slices that give every CU about two workgroups for a [M,N] output, bounded by K / 256
+int sgemm_split_slices(int M, int N, int K);
+// y[m * incy] = beta y + sum_k A[m][k] x[k * incx]
+kpd_status sgemv_rows(int M, int K, const float *A, int lda, const float *x, int incx, float beta, float *y, int incy, hipStream_t st);
+
+}  // namespace kpd

@@ -1,0 +1,320 @@
+// General fp32 GEMM of the training engines on v_mfma_f32_32x32x2_f32:  C[M,N] = alpha op(A) op(B) + beta C, row-major, any sizes and
+// leading dimensions (the 2H+1 = 513-float rows of the EGNN first Linears, 16-wide GVP vector channels, B = 64-row keypoint products).
+//
+// Everything the training engines multiplied through the vendor BLAS runs here (train_ops.h: gemm, grad_gemm, gemv_n); the shapes the
+// weight-stationary kernels were built for stay on ws_gemm.hip.  One template, six tile shapes x three operand forms:
+//   * workgroup = 4 waves stacked along M; a wave owns WM x WN blocks of 32 x 32 (tile = 128 WM x 32 WN), K in slabs of 16;
+//   * both operands go through LDS k-major ([k][m] / [k][n], rows padded by 4 floats): the MFMA operands are then plain ds_read_b32 of
+//     32 consecutive floats per half-wave, whatever the operand's layout in memory was.  An operand that is contiguous along k in memory
+//     (A of NN / NT, B of NT) is read as float4 along k and transposed by the LDS write (4 x ds_write_b32, conflict-free with the + 4 pad);
+//     one contiguous along m / n (A of TN, B of NN / TN) is a float4 copy;
+//   * two LDS buffers, the next slab's global loads issued before the current slab's 8 x WM x WN MFMAs and written to the other buffer
+//     after them: one barrier per slab;
+//   * edges: a float4 that is misaligned (odd leading dimension / offset pointer) or crosses the matrix edge falls back to four guarded
+//     scalar loads, zero filled -- no padding contract on the caller's arrays;
+//   * split-K (weight gradients, K = edge count): grid.z slices of K write partial tiles to scratch, summed by the caller in a fixed
+//     order (train_ops.h k_reduce_parts): no atomics, bitwise reproducible.
+// The arithmetic is the exact-fp32 MFMA of the inference kernels; accumulation order is fixed by the shape alone.
+#include <algorithm>
+
+#include "engine.h"
+#include "sgemm.h"
+
+namespace kpd {
+
+namespace {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int SG_BK = 16;
+
+struct SgemmArgs {
+    const float *A, *B;
+    float *C;
+    int M, N, K, lda, ldb, ldc;
+    float alpha, beta;
+    int k_chunk;            // K range of one grid.z slice (multiple of SG_BK); == K rounded up when not split
+    long long c_slice;      // floats between the outputs of consecutive slices (split-K partials), 0 otherwise
+    int vecA, vecB;         // base pointer 16-B aligned and leading dimension a multiple of 4
+};
+
+// x or +0.0 by a bit mask: the value is consumed on both outcomes, so the load stays unconditional (a select lets the compiler sink the
+// load under a divergent branch with a wait of its own -- one round trip per element)
+__device__ __forceinline__ float masked(float x, bool keep) {
+    return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & (keep ? 0xffffffffu : 0u));
+}
+
+// Tile operand with R rows (m or n) x SG_BK: either contiguous along k in memory (KCONT: element (r, k) at p[r * ld + k]) or along r
+// (element (r, k) at p[k * ld + r]).  NV float4 per thread.
+template <int R, bool KCONT>
+struct TileLoader {
+    static constexpr int NV4 = R * SG_BK / 4;                    // float4 of the tile
+    static constexpr int NV = (NV4 + 255) / 256;
+    v4f v[NV];
+
+    // GUARD = false: the tile lies inside the matrix and float4 loads are aligned; true: any position / alignment -- every element is
+    // read from a clamped (always valid) address here and replaced by zero in store() when it lies outside: no divergent branch in
+    // either form, and nothing consumes the loaded registers before the slab's MFMAs have been issued.  Addresses are a uniform
+    // 64-bit base of the slab plus a 32-bit per-thread offset that does not change from slab to slab (one register per load).
+    template <bool GUARD>
+    __device__ __forceinline__ void load(const float *__restrict__ p, int ld, int r0, int rmax, int k0, int kmax, int tid) {
+        const float *base = KCONT ? p + (size_t)r0 * ld + k0 : p + (size_t)k0 * ld + r0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + 256 * i;
+            if (NV4 < 256 && idx >= NV4) break;
+            const int rl = KCONT ? idx / (SG_BK / 4) : 4 * (idx % (R / 4));          // tile-local row / first of 4 rows
+            const int kl = KCONT ? 4 * (idx % (SG_BK / 4)) : idx / (R / 4);          // tile-local first of 4 k / k
+            if (!GUARD) {
+                v[i] = *reinterpret_cast<const v4f *>(base + (unsigned)(KCONT ? rl * ld + kl : kl * ld + rl));
+            } else if (KCONT) {
+                const unsigned row = (unsigned)(min(rl, rmax - 1 - r0) * ld);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[i][j] = base[row + (unsigned)min(kl + j, kmax - 1 - k0)];
+            } else {
+                const unsigned row = (unsigned)(min(kl, kmax - 1 - k0) * ld);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[i][j] = base[row + (unsigned)min(rl + j, rmax - 1 - r0)];
+            }
+        }
+    }
+    // s: [SG_BK][R + 4]; the arguments of the load this store completes
+    template <bool GUARD>
+    __device__ __forceinline__ void store(float *s, int r0, int rmax, int k0, int kmax, int tid) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + 256 * i;
+            if (NV4 < 256 && idx >= NV4) break;
+            if (KCONT) {
+                const int r = idx / (SG_BK / 4), k = 4 * (idx % (SG_BK / 4));
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    s[(k + j) * (R + 4) + r] = GUARD ? masked(v[i][j], r0 + r < rmax && k0 + k + j < kmax) : v[i][j];
+            } else {
+                const int k = idx / (R / 4), r = 4 * (idx % (R / 4));
+                if (GUARD) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[i][j] = masked(v[i][j], k0 + k < kmax && r0 + r + j < rmax);
+                }
+                *reinterpret_cast<v4f *>(s + k * (R + 4) + r) = v[i];
+            }
+        }
+    }
+};
+
+template <int WM, int WN, bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void k_sgemm(SgemmArgs a) {
+    constexpr int BM = 128 * WM, BN = 32 * WN;
+    constexpr int SA_ = BM + 4, SB_ = BN + 4;
+    __shared__ __attribute__((aligned(16))) float As[2][SG_BK * SA_];
+    __shared__ __attribute__((aligned(16))) float Bs[2][SG_BK * SB_];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 31, half = lane >> 5;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int kbeg = blockIdx.z * a.k_chunk, kend = min(a.K, kbeg + a.k_chunk);
+    float *C = a.C + (size_t)blockIdx.z * a.c_slice;
+
+    // A as op(A)[m][k]: contiguous along k unless transposed; B as op(B)[k][n]: contiguous along k only when transposed
+    TileLoader<BM, !TA> la0;
+    TileLoader<BN, TB> lb0;
+    v16f acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nk = (kend - kbeg + SG_BK - 1) / SG_BK;
+    // unguarded float4 loads where the tile lies inside the matrix (uniform over the workgroup) and the slab inside the K range
+    const bool fastA = a.vecA != 0 && m0 + BM <= a.M, fastB = a.vecB != 0 && n0 + BN <= a.N;
+    auto fetch = [&](int kt, TileLoader<BM, !TA> &la, TileLoader<BN, TB> &lb) {
+        const int k0 = kbeg + kt * SG_BK;
+        const bool inside = k0 + SG_BK <= kend;
+        if (fastA && inside) la.template load<false>(a.A, a.lda, m0, a.M, k0, kend, tid);
+        else la.template load<true>(a.A, a.lda, m0, a.M, k0, kend, tid);
+        if (fastB && inside) lb.template load<false>(a.B, a.ldb, n0, a.N, k0, kend, tid);
+        else lb.template load<true>(a.B, a.ldb, n0, a.N, k0, kend, tid);
+    };
+    auto stash = [&](int kt, int buf, TileLoader<BM, !TA> &la, TileLoader<BN, TB> &lb) {
+        const int k0 = kbeg + kt * SG_BK;
+        const bool inside = k0 + SG_BK <= kend;
+        if (fastA && inside) la.template store<false>(As[buf], m0, a.M, k0, kend, tid);
+        else la.template store<true>(As[buf], m0, a.M, k0, kend, tid);
+        if (fastB && inside) lb.template store<false>(Bs[buf], n0, a.N, k0, kend, tid);
+        else lb.template store<true>(Bs[buf], n0, a.N, k0, kend, tid);
+    };
+    auto compute = [&](int buf) {
+        const float *as = As[buf] + wave * 32 * WM + col, *bs = Bs[buf] + col;
+#pragma unroll
+        for (int ks = 0; ks < SG_BK / 2; ++ks) {
+            const int k = 2 * ks + half;
+            float av[WM], bv[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) av[i] = as[k * SA_ + 32 * i];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) bv[j] = bs[k * SB_ + 32 * j];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    if (nk > 0) {
+        fetch(0, la0, lb0);
+        stash(0, 0, la0, lb0);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) fetch(kt + 1, la0, lb0);
+        compute(kt & 1);
+        if (kt + 1 < nk) stash(kt + 1, (kt + 1) & 1, la0, lb0);
+        __syncthreads();
+    }
+    // accumulator element r of lane (col, half): row 8 (r / 4) + 4 half + r % 4, column col.  beta != 0: the 16 old values of a block are
+    // read together (clamped rows) before any of them is needed
+    const bool accumulate = a.beta != 0.0f;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int n = n0 + 32 * j + col;
+            if (n >= a.N) continue;
+            const int mb = m0 + wave * 32 * WM + 32 * i + 4 * half;
+            float old[16];
+            if (accumulate) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) old[r] = C[(size_t)min(mb + 8 * (r >> 2) + (r & 3), a.M - 1) * a.ldc + n];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + 8 * (r >> 2) + (r & 3);
+                float v = a.alpha * acc[i][j][r];
+                if (accumulate) v += a.beta * old[r];
+                if (m < a.M) C[(size_t)m * a.ldc + n] = v;
+            }
+            __builtin_amdgcn_sched_barrier(0);      // one block's 16 old values at a time, not all WM x WN blocks' (registers)
+        }
+}
+
+template <int WM, int WN>
+void launch_shape(bool tA, bool tB, dim3 grid, hipStream_t st, const SgemmArgs &a) {
+    if (!tA && tB) hipLaunchKernelGGL((k_sgemm<WM, WN, false, true>), grid, dim3(256), 0, st, a);
+    else if (!tA && !tB) hipLaunchKernelGGL((k_sgemm<WM, WN, false, false>), grid, dim3(256), 0, st, a);
+    else if (tA && !tB) hipLaunchKernelGGL((k_sgemm<WM, WN, true, false>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_sgemm<WM, WN, true, true>), grid, dim3(256), 0, st, a);
+}
+
+// C = sum of the split-K partial products (in slice order) + beta C; eight loads in flight per thread
+__global__ void k_sgemm_reduce(const float *__restrict__ part, int slices, int M, int N, float beta, float *__restrict__ C, int ldc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * N) return;
+    const size_t stride = (size_t)M * N;
+    const float *p = part + i;
+    float s = 0.0f;
+    int k = 0;
+    for (; k + 8 <= slices; k += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = p[(size_t)(k + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += t[u];
+    }
+    for (; k < slices; ++k) s += p[(size_t)k * stride];
+    const int r = i / N, c = i - r * N;
+    float *dst = C + (size_t)r * ldc + c;
+    *dst = beta != 0.0f ? s + beta * *dst : s;
+}
+
+// y[m] = beta y[m] + sum_k A[m][k] x[k * incx]: one wave per row
+__global__ __launch_bounds__(256) void k_sgemv_rows(const float *__restrict__ A, int lda, int M, int K, const float *__restrict__ x,
+                                                    int incx, float beta, float *__restrict__ y, int incy) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float *a = A + (size_t)row * lda;
+    float s = 0.0f;
+    for (int k = lane; k < K; k += 64) s += a[k] * x[(size_t)k * incx];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) y[(size_t)row * incy] = beta != 0.0f ? s + beta * y[(size_t)row * incy] : s;
+}
+
+}  // namespace
+
+int sgemm_split_slices(int M, int N, int K) {
+    const int tiles = cdiv(M, 128) * cdiv(N, 128);
+    int s = std::max(1, (2 * cu_count()) / std::max(tiles, 1));
+    s = std::min(s, std::max(1, K / 256));
+    return std::min(s, SGEMM_MAX_SPLIT);
+}
+
+kpd_status sgemm(bool tA, bool tB, int M, int N, int K, float alpha, const float *A, int lda, const float *B, int ldb, float beta,
+                 float *C, int ldc, hipStream_t st, float *part, size_t part_floats) {
+    if (M <= 0 || N <= 0) return KPD_OK;
+    KPD_REQUIRE(A && B && C && K > 0, KPD_ERR_INVALID, "sgemm: null operand or empty K (M=%d N=%d K=%d)", M, N, K);
+    SgemmArgs a;
+    a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.alpha = alpha; a.beta = beta;
+    a.vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
+    a.vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
+    a.k_chunk = cdiv(K, SG_BK) * SG_BK;
+    a.c_slice = 0;
+    int slices = part ? (int)std::min<size_t>(sgemm_split_slices(M, N, K), part_floats / ((size_t)M * N)) : 1;
+    if (slices > 1) {
+        a.k_chunk = cdiv(cdiv(K, slices), SG_BK) * SG_BK;
+        slices = cdiv(K, a.k_chunk);
+    }
+    if (slices > 1) {
+        a.C = part; a.ldc = N; a.beta = 0.0f; a.c_slice = (long long)M * N;
+    } else {
+        slices = 1;
+        a.k_chunk = cdiv(K, SG_BK) * SG_BK;
+    }
+    // tile shape: the widest column tile the output fills; 256-row tiles only when they still give every CU two workgroups
+    const int wn = N > 64 ? 4 : N > 32 ? 2 : 1;
+    const int bn = 32 * wn;
+    const bool tall = (long long)cdiv(M, 256) * cdiv(N, bn) * slices >= 2ll * cu_count();
+    const dim3 grid(cdiv(M, tall ? 256 : 128), cdiv(N, bn), slices);
+    KPD_REQUIRE(grid.y <= 65535u && grid.z <= 65535u, KPD_ERR_CAPACITY, "sgemm: N = %d too wide for one launch", N);
+    if (tall) {
+        if (wn == 4) launch_shape<2, 4>(tA, tB, grid, st, a);
+        else if (wn == 2) launch_shape<2, 2>(tA, tB, grid, st, a);
+        else launch_shape<2, 1>(tA, tB, grid, st, a);
+    } else {
+        if (wn == 4) launch_shape<1, 4>(tA, tB, grid, st, a);
+        else if (wn == 2) launch_shape<1, 2>(tA, tB, grid, st, a);
+        else launch_shape<1, 1>(tA, tB, grid, st, a);
+    }
+    KPD_LAUNCH_CHECK();
+    if (slices > 1) {
+        hipLaunchKernelGGL(k_sgemm_reduce, dim3(cdiv(M * N, 256)), dim3(256), 0, st, part, slices, M, N, beta, C, ldc);
+        KPD_LAUNCH_CHECK();
+    }
+    return KPD_OK;
+}
+
+kpd_status sgemv_rows(int M, int K, const float *A, int lda, const float *x, int incx, float beta, float *y, int incy, hipStream_t st) {
+    if (M <= 0) return KPD_OK;
+    hipLaunchKernelGGL(k_sgemv_rows, dim3(cdiv(M, 4)), dim3(256), 0, st, A, lda, M, K, x, incx, beta, y, incy);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+// include/kpd.h
+extern "C" kpd_status kpd_sgemm(int32_t trans_a, int32_t trans_b, int32_t M, int32_t N, int32_t K, float alpha, const float *A, int32_t lda,
+                                const float *B, int32_t ldb, float beta, float *C, int32_t ldc, float *workspace, int64_t workspace_floats,
+                                void *stream) {
+    KPD_REQUIRE(M >= 0 && N >= 0 && K >= 0, KPD_ERR_INVALID, "kpd_sgemm: negative size");
+    KPD_REQUIRE(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N) && ldc >= N, KPD_ERR_INVALID, "kpd_sgemm: leading dimension too small");
+    KPD_REQUIRE(workspace_floats >= 0 && (workspace || workspace_floats == 0), KPD_ERR_INVALID, "kpd_sgemm: workspace size without a workspace");
+    if (M == 0 || N == 0) return KPD_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (K == 0) {
+        KPD_REQUIRE(beta == 0.0f || beta == 1.0f, KPD_ERR_INVALID, "kpd_sgemm: K = 0 needs beta 0 or 1");
+        if (beta == 0.0f) KPD_HIP(hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, M, st));
+        return KPD_OK;
+    }
+    return sgemm(trans_a != 0, trans_b != 0, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, st, workspace, (size_t)workspace_floats);
+}
+
+}  // namespace kpd

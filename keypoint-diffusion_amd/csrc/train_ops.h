@@ -1,8 +1,7 @@
 // Shared pieces of the training engines (egnn_train.hip, gvp_train.hip): parameter table entries, row-major GEMM /
-// GEMV wrappers over rocBLAS on the caller's stream, the split-K weight-gradient GEMM, and the generic elementwise,
+// GEMV wrappers over the library's own MFMA GEMM (sgemm.hip) on the caller's stream, the split-K weight-gradient GEMM, and the generic elementwise,
 // column-sum and reduction kernels.  Included by exactly those translation units; everything is file-local.
 #pragma once
-#include <rocblas/rocblas.h>
 
 #include <algorithm>
 #include <map>
@@ -10,6 +9,7 @@
 #include <vector>
 
 #include "common.h"
+#include "sgemm.h"
 
 namespace kpd {
 namespace {
@@ -252,9 +252,8 @@ struct Param {
     int rows = 0, cols = 0;
 };
 
-// what the wrappers need from an engine: the BLAS handle, the stream of the current call, split-K scratch, a ones vector
+// what the wrappers need from an engine: the stream of the current call, split-K scratch, a ones vector
 struct TrainCtx {
-    rocblas_handle blas = nullptr;
     hipStream_t st = nullptr;
     float *part = nullptr;
     size_t part_floats = 0;
@@ -266,15 +265,6 @@ struct TrainCtx {
 
 inline size_t colpart_floats(int max_rows) { return (size_t)cdiv(std::max(max_rows, 1), HEAD_ROWS) * 2 * COLSUM_LD; }
 
-#define KPD_BLAS(call)                                                                            \
-    do {                                                                                          \
-        rocblas_status s_ = (call);                                                               \
-        if (s_ != rocblas_status_success) {                                                       \
-            kpd::set_error("%s:%d: %s -> rocblas status %d", __FILE__, __LINE__, #call, (int)s_); \
-            return KPD_ERR_HIP;                                                                   \
-        }                                                                                         \
-    } while (0)
-
 // row-major C[M,N] = alpha op(A) op(B) + beta C
 kpd_status gemm(TrainCtx *T, bool tA, bool tB, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
                 float beta, float *C, int ldc, float alpha = 1.0f) {
@@ -283,18 +273,14 @@ kpd_status gemm(TrainCtx *T, bool tA, bool tB, int M, int N, int K, const float 
         if (beta == 0.0f) KPD_HIP(hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, M, T->st));
         return KPD_OK;
     }
-    KPD_BLAS(rocblas_sgemm(T->blas, tB ? rocblas_operation_transpose : rocblas_operation_none,
-                           tA ? rocblas_operation_transpose : rocblas_operation_none, N, M, K, &alpha, B, ldb, A, lda, &beta, C, ldc));
-    return KPD_OK;
+    return sgemm(tA, tB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, T->st);
 }
 
 // y[M] (stride incy) = beta y + A[M,K] x (stride incx), A row-major
 kpd_status gemv_n(TrainCtx *T, int M, int K, const float *A, int lda, const float *x, int incx, float beta, float *y,
                   int incy) {
     if (M == 0) return KPD_OK;
-    const float alpha = 1.0f;
-    KPD_BLAS(rocblas_sgemv(T->blas, rocblas_operation_transpose, K, M, &alpha, A, lda, x, incx, &beta, y, incy));
-    return KPD_OK;
+    return sgemv_rows(M, K, A, lda, x, incx, beta, y, incy, T->st);
 }
 
 // y[K] (stride incy) += A[M,K]^T x[M] (x = nullptr: column sums), A row-major
@@ -336,22 +322,13 @@ kpd_status build_src_csr(TrainCtx *T, const int *src, int E, int n_src, int *cur
 
 kpd_status colsum_acc(TrainCtx *T, int M, int K, const float *A, int lda, float *y) { return gemv_t_acc(T, M, K, A, lda, nullptr, y, 1); }
 
-// weight gradient C[M,N] += A[K,M]^T B[K,N] with K = rows of a tall activation matrix: the output is a few tiles only, so
-// K is split over GRAD_SPLIT batches (one strided-batched GEMM into partial sums) and the partials are reduced
-constexpr int GRAD_SPLIT = 48;
+constexpr size_t GRAD_PART_FLOATS = (size_t)128 * 256 * 256;     // split-K scratch of an engine: 128 slices of a 256 x 256 gradient
+
+// weight gradient C[M,N] += A[K,M]^T B[K,N] with K = rows of a tall activation matrix: the output is a few tiles only, so K is
+// cut into slices (grid.z of one launch, partial products in scratch) that are summed in slice order -- no atomics
 kpd_status grad_gemm(TrainCtx *T, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc) {
     if (!C || M == 0 || N == 0 || K == 0) return KPD_OK;
-    const int chunk = K / GRAD_SPLIT;
-    if (chunk < 128 || (size_t)M * N > T->part_floats / GRAD_SPLIT) return gemm(T, true, false, M, N, K, A, lda, B, ldb, 1.0f, C, ldc);
-    const float one = 1.0f, zero = 0.0f;
-    KPD_BLAS(rocblas_sgemm_strided_batched(T->blas, rocblas_operation_none, rocblas_operation_transpose, N, M, chunk, &one, B, ldb,
-                                           (rocblas_stride)chunk * ldb, A, lda, (rocblas_stride)chunk * lda, &zero, T->part, N,
-                                           (rocblas_stride)M * N, GRAD_SPLIT));
-    hipLaunchKernelGGL(k_reduce_parts, grid1((long long)M * N), dim3(256), 0, T->st, T->part, GRAD_SPLIT, M, N, C, ldc);
-    KPD_LAUNCH_CHECK();
-    const int done = chunk * GRAD_SPLIT;
-    if (done < K) KPD_TRY(grad_gemm(T, M, N, K - done, A + (size_t)done * lda, lda, B + (size_t)done * ldb, ldb, C, ldc));
-    return KPD_OK;
+    return sgemm(true, false, M, N, K, 1.0f, A, lda, B, ldb, 1.0f, C, ldc, T->st, T->part, T->part_floats);
 }
 
 kpd_status param(TrainCtx *T, const std::string &name, int rows, int cols, Param *out) {

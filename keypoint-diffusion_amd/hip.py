@@ -168,6 +168,8 @@ def lib():
                                               C.c_void_p]
     L.kpd_recegnn_trainer_backward.argtypes = [C.c_void_p] + [C.c_void_p] * 3
     L.kpd_ot_emd_uniform.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+    L.kpd_sgemm.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                            C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
     L.kpd_rec_graph_scratch_bytes.argtypes = [C.c_int32, C.c_int32]
     L.kpd_rec_graph_scratch_bytes.restype = C.c_int64
     L.kpd_build_rec_graph.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p,
@@ -200,7 +202,7 @@ EXPORTS = [
     'kpd_recenc_trainer_create', 'kpd_recenc_trainer_destroy', 'kpd_recenc_trainer_bind', 'kpd_recenc_trainer_set_dropout',
     'kpd_recenc_trainer_reserve', 'kpd_recenc_trainer_forward', 'kpd_recenc_trainer_backward',
     'kpd_recegnn_trainer_create', 'kpd_recegnn_trainer_destroy', 'kpd_recegnn_trainer_bind', 'kpd_recegnn_trainer_reserve',
-    'kpd_recegnn_trainer_forward', 'kpd_recegnn_trainer_backward', 'kpd_ot_emd_uniform',
+    'kpd_recegnn_trainer_forward', 'kpd_recegnn_trainer_backward', 'kpd_ot_emd_uniform', 'kpd_sgemm',
 ]
 
 
@@ -794,6 +796,29 @@ def ot_emd_uniform(costs, n_threads: int = 0):
     check(lib().kpd_ot_emd_uniform(len(costs), ns.ctypes.data, ms.ctypes.data, offs.ctypes.data, flat.ctypes.data, plan.ctypes.data,
                                    int(n_threads)))
     return [plan[o:o + s].reshape(int(a), int(b)) for o, s, a, b in zip(offs, sizes, ns, ms)]
+
+
+def sgemm(a: torch.Tensor, b: torch.Tensor, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, out: torch.Tensor = None,
+          workspace: torch.Tensor = None) -> torch.Tensor:
+    """out = alpha op(a) op(b) + beta out through kpd_sgemm (the GEMM of the training engines).  a, b, out: 2-D fp32 device tensors whose
+    last dimension is contiguous; row strides and storage offsets are passed as they are (views of wider arrays are the tested case).
+    `workspace`: contiguous fp32 device scratch that lets a K-dominated product be split along K."""
+    for t, name in ((a, 'a'), (b, 'b')):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and (t.shape[1] <= 1 or t.stride(1) == 1)):
+            raise KpdError(f'sgemm: {name} must be a 2-D fp32 device tensor with a contiguous last dimension')
+    M, K = (a.shape[1], a.shape[0]) if trans_a else tuple(a.shape)
+    K2, N = (b.shape[1], b.shape[0]) if trans_b else tuple(b.shape)
+    if K != K2:
+        raise KpdError(f'sgemm: inner sizes {K} and {K2} differ')
+    if out is None:
+        out = torch.zeros(M, N, device=a.device)
+    if tuple(out.shape) != (M, N) or not out.is_cuda or out.dtype != torch.float32 or (N > 1 and out.stride(1) != 1):
+        raise KpdError('sgemm: out must be an fp32 device tensor [M, N] with a contiguous last dimension')
+    ld = lambda t: int(t.stride(0)) if t.shape[0] > 1 else max(int(t.shape[1]), 1)
+    check(lib().kpd_sgemm(int(trans_a), int(trans_b), M, N, K, float(alpha), a.data_ptr(), ld(a), b.data_ptr(), ld(b), float(beta),
+                          out.data_ptr(), ld(out), workspace.data_ptr() if workspace is not None else None,
+                          int(workspace.numel()) if workspace is not None else 0, _stream()))
+    return out
 
 
 def step_coefficients(gamma: torch.Tensor, s: torch.Tensor, t: torch.Tensor) -> torch.Tensor:

@@ -1,0 +1,63 @@
+"""The library's own fp32 GEMM (csrc/sgemm.hip: every dense product of the training engines) against a float64 product of the same
+operands: all four operand forms, sizes that are no multiple of any tile, odd leading dimensions and misaligned views (the 513-float rows
+of the EGNN first Linears), alpha / beta, split-K through the weight-gradient shape, bitwise repeatability."""
+import pytest
+import torch
+
+from keypoint_diffusion_amd import hip
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [  # M, N, K
+    (1, 1, 1), (5, 3, 2), (64, 257, 10), (300, 16, 16), (1000, 33, 47), (129, 130, 131), (4099, 256, 256), (20800, 257, 514),
+    (37, 600, 5), (256, 256, 4096), (2, 700, 1), (70000, 16, 16), (257, 100, 50001), (16, 16, 30000),
+]
+
+
+def _operand(rows, cols, ld_extra, offset, gen, dev):
+    """[rows, cols] view with row stride cols + ld_extra starting `offset` floats into its storage."""
+    buf = torch.randn(offset + rows * (cols + ld_extra) + 8, generator=gen).to(dev)
+    return buf[offset:offset + rows * (cols + ld_extra)].view(rows, cols + ld_extra)[:, :cols]
+
+
+@pytest.mark.parametrize('trans_a,trans_b', [(False, True), (False, False), (True, False), (True, True)])
+@pytest.mark.parametrize('layout', ['aligned', 'odd_ld', 'offset'])
+def test_sgemm_matches_float64_product(trans_a, trans_b, layout):
+    dev = torch.device('cuda:0')
+    gen = torch.Generator().manual_seed(11)
+    extra, off = {'aligned': (0, 0), 'odd_ld': (1, 0), 'offset': (4, 3)}[layout]
+    for M, N, K in SHAPES:
+        a = _operand(K if trans_a else M, M if trans_a else K, extra, off, gen, dev)
+        b = _operand(N if trans_b else K, K if trans_b else N, extra, off, gen, dev)
+        c0 = _operand(M, N, extra, off, gen, dev)
+        ref = (a.double().T if trans_a else a.double()) @ (b.double().T if trans_b else b.double())
+        ws = torch.full((1 << 22,), float('nan'), device=dev) if K >= 4096 else None     # split-K scratch: contents irrelevant
+        out = hip.sgemm(a, b, trans_a, trans_b, workspace=ws)
+        scale = ref.abs().max().clamp_min(1.0)
+        tol = 1e-6 + 4e-7 * K ** 0.5                      # fp32 accumulation over K terms
+        assert ((out.double() - ref).abs().max() / scale) < tol, (M, N, K)
+        c = c0.clone() if layout == 'aligned' else c0
+        before = c.double().clone()
+        hip.sgemm(a, b, trans_a, trans_b, alpha=0.5, beta=2.0, out=c, workspace=ws)
+        ref2 = 0.5 * ref + 2.0 * before
+        assert ((c.double() - ref2).abs().max() / ref2.abs().max().clamp_min(1.0)) < 2 * tol, (M, N, K)
+
+
+def test_sgemm_leaves_the_padding_of_a_strided_output_alone():
+    dev = torch.device('cuda:0')
+    gen = torch.Generator().manual_seed(3)
+    a, b = torch.randn(300, 40, generator=gen).to(dev), torch.randn(40, 70, generator=gen).to(dev)
+    wide = torch.full((300, 96), 7.0, device=dev)
+    hip.sgemm(a, b, out=wide[:, 5:75])
+    assert torch.all(wide[:, :5] == 7.0) and torch.all(wide[:, 75:] == 7.0)
+    assert torch.allclose(wide[:, 5:75], a @ b, atol=1e-4)
+
+
+def test_sgemm_is_bitwise_repeatable_and_independent_of_other_rows():
+    dev = torch.device('cuda:0')
+    gen = torch.Generator().manual_seed(5)
+    a, b = torch.randn(5000, 300, generator=gen).to(dev), torch.randn(200, 300, generator=gen).to(dev)
+    o1, o2 = hip.sgemm(a, b, trans_b=True), hip.sgemm(a, b, trans_b=True)
+    assert torch.equal(o1, o2)
+    part = hip.sgemm(a[1000:1200], b, trans_b=True)          # other tile position, other tile shape: same bits per element
+    assert torch.equal(part, o1[1000:1200])
