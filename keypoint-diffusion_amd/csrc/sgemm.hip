@@ -2,19 +2,21 @@
 // leading dimensions (the 2H+1 = 513-float rows of the EGNN first Linears, 16-wide GVP vector channels, B = 64-row keypoint products).
 //
 // Everything the training engines multiplied through the vendor BLAS runs here (train_ops.h: gemm, grad_gemm, gemv_n); the shapes the
-// weight-stationary kernels were built for stay on ws_gemm.hip.  One template, six tile shapes x three operand forms:
-//   * workgroup = 4 waves stacked along M; a wave owns WM x WN blocks of 32 x 32 (tile = 128 WM x 32 WN), K in slabs of 16;
-//   * both operands go through LDS k-major ([k][m] / [k][n], rows padded by 4 floats): the MFMA operands are then plain ds_read_b32 of
-//     32 consecutive floats per half-wave, whatever the operand's layout in memory was.  An operand that is contiguous along k in memory
-//     (A of NN / NT, B of NT) is read as float4 along k and transposed by the LDS write (4 x ds_write_b32, conflict-free with the + 4 pad);
-//     one contiguous along m / n (A of TN, B of NN / TN) is a float4 copy;
-//   * two LDS buffers, the next slab's global loads issued before the current slab's 8 x WM x WN MFMAs and written to the other buffer
-//     after them: one barrier per slab;
-//   * edges: a float4 that is misaligned (odd leading dimension / offset pointer) or crosses the matrix edge falls back to four guarded
-//     scalar loads, zero filled -- no padding contract on the caller's arrays;
-//   * split-K (weight gradients, K = edge count): grid.z slices of K write partial tiles to scratch, summed by the caller in a fixed
-//     order (train_ops.h k_reduce_parts): no atomics, bitwise reproducible.
+// weight-stationary kernels were built for stay on ws_gemm.hip.  One template, three tile shapes x four operand forms:
+//   * workgroup = 4 waves stacked along M; a wave owns WM x WN blocks of 32 x 32 (tile = 128 WM x 32 WN; WM = 1, WN in {1, 2, 4}), K in slabs of 16;
+//   * both operands go through LDS as 16-B units in the order the direct global->LDS loads (global_load_lds_dwordx4) deliver them: an
+//     operand that is contiguous along k in memory (A of NN / NT, B of NT / TT) as units (k-quad, row) -- an MFMA operand read is 32 lanes x
+//     4 B at a 16-B stride; one contiguous along m / n (A of TN, B of NN / TN) row-major [k][row] -- 32 consecutive floats per half-wave;
+//   * interior tiles of aligned operands: three LDS stages, the loads of slab kt + 2 issued (no registers) before the MFMAs of slab kt;
+//     vmcnt counts them in order, so "one slab's worth outstanding" = slab kt + 1 has landed; one LDS-only barrier per slab;
+//   * everything else (matrix edges, odd leading dimensions / offset pointers such as the 513-float rows, the K tail): the register
+//     path -- clamped scalar or float4 loads issued before the slab's MFMAs, masked to zero and written to the same LDS layout after
+//     them; no divergent branch, no padding contract on the caller's arrays;
+//   * split-K (weight gradients, K = edge count): grid.z slices of K write partial tiles to scratch, summed in slice order by
+//     k_sgemm_reduce: no atomics, bitwise reproducible.
 // The arithmetic is the exact-fp32 MFMA of the inference kernels; accumulation order is fixed by the shape alone.
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "engine.h"
@@ -37,6 +39,7 @@ struct SgemmArgs {
     int k_chunk;            // K range of one grid.z slice (multiple of SG_BK); == K rounded up when not split
     long long c_slice;      // floats between the outputs of consecutive slices (split-K partials), 0 otherwise
     int vecA, vecB;         // base pointer 16-B aligned and leading dimension a multiple of 4
+    int direct;             // 0: never take the global->LDS path (KPD_SGEMM_DIRECT=0, A/B runs)
 };
 
 // x or +0.0 by a bit mask: the value is consumed on both outcomes, so the load stays unconditional (a select lets the compiler sink the
@@ -46,17 +49,24 @@ __device__ __forceinline__ float masked(float x, bool keep) {
 }
 
 // Tile operand with R rows (m or n) x SG_BK: either contiguous along k in memory (KCONT: element (r, k) at p[r * ld + k]) or along r
-// (element (r, k) at p[k * ld + r]).  NV float4 per thread.
+// (element (r, k) at p[k * ld + r]).  Its LDS form is made of 16-B units in the order the direct global->LDS loads deliver them:
+//   KCONT : unit (kq, r) = the four k 4 kq .. 4 kq + 3 of row r, at float4 index kq * R + r   (an MFMA operand read is 32 lanes x 4 B at a
+//           16-B stride: two lanes per bank)
+//   else  : row-major [k][R]                                                                  (32 consecutive floats per half-wave)
 template <int R, bool KCONT>
 struct TileLoader {
-    static constexpr int NV4 = R * SG_BK / 4;                    // float4 of the tile
-    static constexpr int NV = (NV4 + 255) / 256;
+    static constexpr int NV4 = R * SG_BK / 4;                    // units of the tile
+    static constexpr int NV = (NV4 + 255) / 256;                 // per thread (register path) = wave instructions per wave (direct path)
     v4f v[NV];
 
-    // GUARD = false: the tile lies inside the matrix and float4 loads are aligned; true: any position / alignment -- every element is
-    // read from a clamped (always valid) address here and replaced by zero in store() when it lies outside: no divergent branch in
-    // either form, and nothing consumes the loaded registers before the slab's MFMAs have been issued.  Addresses are a uniform
-    // 64-bit base of the slab plus a 32-bit per-thread offset that does not change from slab to slab (one register per load).
+    // float index of element (r, k) in the LDS tile
+    static __device__ __forceinline__ int at(int r, int k) { return KCONT ? ((k >> 2) * R + r) * 4 + (k & 3) : k * R + r; }
+
+    // ---- register path: any position / alignment ----
+    // GUARD = false: the tile lies inside the matrix and float4 loads are aligned; true: every element is read from a clamped (always
+    // valid) address here and replaced by zero in store() when it lies outside: no divergent branch in either form, and nothing consumes
+    // the loaded registers before the slab's MFMAs have been issued.  Addresses are a uniform 64-bit base of the slab plus a 32-bit
+    // per-thread offset that does not change from slab to slab.
     template <bool GUARD>
     __device__ __forceinline__ void load(const float *__restrict__ p, int ld, int r0, int rmax, int k0, int kmax, int tid) {
         const float *base = KCONT ? p + (size_t)r0 * ld + k0 : p + (size_t)k0 * ld + r0;
@@ -79,26 +89,37 @@ struct TileLoader {
             }
         }
     }
-    // s: [SG_BK][R + 4]; the arguments of the load this store completes
+    // the arguments of the load this store completes
     template <bool GUARD>
     __device__ __forceinline__ void store(float *s, int r0, int rmax, int k0, int kmax, int tid) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int idx = tid + 256 * i;
             if (NV4 < 256 && idx >= NV4) break;
-            if (KCONT) {
-                const int r = idx / (SG_BK / 4), k = 4 * (idx % (SG_BK / 4));
+            const int rl = KCONT ? idx / (SG_BK / 4) : 4 * (idx % (R / 4));
+            const int kl = KCONT ? 4 * (idx % (SG_BK / 4)) : idx / (R / 4);
+            if (GUARD) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    s[(k + j) * (R + 4) + r] = GUARD ? masked(v[i][j], r0 + r < rmax && k0 + k + j < kmax) : v[i][j];
-            } else {
-                const int k = idx / (R / 4), r = 4 * (idx % (R / 4));
-                if (GUARD) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[i][j] = masked(v[i][j], k0 + k < kmax && r0 + r + j < rmax);
-                }
-                *reinterpret_cast<v4f *>(s + k * (R + 4) + r) = v[i];
+                    v[i][j] = masked(v[i][j], KCONT ? (r0 + rl < rmax && k0 + kl + j < kmax) : (k0 + kl < kmax && r0 + rl + j < rmax));
             }
+            *reinterpret_cast<v4f *>(s + at(rl, kl)) = v[i];
+        }
+    }
+
+    // ---- direct path: tile inside the matrix, 16-B aligned; global -> LDS without registers ----
+    // wave instruction n of the tile covers units 64 n .. 64 n + 63 (lane = unit - 64 n); every wave issues NV of them (wave + 4 j, wrapped:
+    // a tile of fewer than 4 NV instructions is loaded twice into the same place, so that all waves have the same number in flight)
+    __device__ __forceinline__ void direct(const float *__restrict__ p, int ld, int r0, int k0, float *s, int wave, int lane) const {
+        typedef __attribute__((address_space(3))) void lds_void;
+        typedef const __attribute__((address_space(1))) void glb_void;
+        const float *base = KCONT ? p + (size_t)r0 * ld + k0 : p + (size_t)k0 * ld + r0;
+        constexpr int NI = NV4 / 64;                             // wave instructions of the tile
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int n = (wave + 4 * j) % NI, u = 64 * n + lane;
+            const unsigned off = KCONT ? (unsigned)((u % R) * ld + 4 * (u / R)) : (unsigned)((u / (R / 4)) * ld + 4 * (u % (R / 4)));
+            __builtin_amdgcn_global_load_lds((glb_void *)(base + off), (lds_void *)(s + 256 * n), 16, 0, 0);
         }
     }
 };
@@ -106,17 +127,15 @@ struct TileLoader {
 template <int WM, int WN, bool TA, bool TB>
 __global__ __launch_bounds__(256, 2) void k_sgemm(SgemmArgs a) {
     constexpr int BM = 128 * WM, BN = 32 * WN;
-    constexpr int SA_ = BM + 4, SB_ = BN + 4;
-    __shared__ __attribute__((aligned(16))) float As[2][SG_BK * SA_];
-    __shared__ __attribute__((aligned(16))) float Bs[2][SG_BK * SB_];
+    constexpr int STAGE = (BM + BN) * SG_BK;                     // floats of one LDS stage: A tile, then B tile
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // 3 stages
+    typedef TileLoader<BM, !TA> LA;                               // op(A)[m][k]: contiguous along k unless transposed
+    typedef TileLoader<BN, TB> LB;                                // op(B)[k][n]: contiguous along k only when transposed
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 31, half = lane >> 5;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int kbeg = blockIdx.z * a.k_chunk, kend = min(a.K, kbeg + a.k_chunk);
     float *C = a.C + (size_t)blockIdx.z * a.c_slice;
 
-    // A as op(A)[m][k]: contiguous along k unless transposed; B as op(B)[k][n]: contiguous along k only when transposed
-    TileLoader<BM, !TA> la0;
-    TileLoader<BN, TB> lb0;
     v16f acc[WM][WN];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -125,10 +144,28 @@ __global__ __launch_bounds__(256, 2) void k_sgemm(SgemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int nk = (kend - kbeg + SG_BK - 1) / SG_BK;
-    // unguarded float4 loads where the tile lies inside the matrix (uniform over the workgroup) and the slab inside the K range
+    const int nk = (kend - kbeg + SG_BK - 1) / SG_BK, nk_full = (kend - kbeg) / SG_BK;
+    // aligned float4 access where the tile lies inside the matrix (uniform over the workgroup) and the slab inside the K range
     const bool fastA = a.vecA != 0 && m0 + BM <= a.M, fastB = a.vecB != 0 && n0 + BN <= a.N;
-    auto fetch = [&](int kt, TileLoader<BM, !TA> &la, TileLoader<BN, TB> &lb) {
+    auto compute = [&](const float *st) {
+        const float *as = st, *bs = st + BM * SG_BK;
+#pragma unroll
+        for (int ks = 0; ks < SG_BK / 2; ++ks) {
+            const int k = 2 * ks + half;
+            float av[WM], bv[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) av[i] = as[LA::at(wave * 32 * WM + 32 * i + col, k)];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) bv[j] = bs[LB::at(32 * j + col, k)];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    LA la;
+    LB lb;
+    auto fetch = [&](int kt) {
         const int k0 = kbeg + kt * SG_BK;
         const bool inside = k0 + SG_BK <= kend;
         if (fastA && inside) la.template load<false>(a.A, a.lda, m0, a.M, k0, kend, tid);
@@ -136,41 +173,56 @@ __global__ __launch_bounds__(256, 2) void k_sgemm(SgemmArgs a) {
         if (fastB && inside) lb.template load<false>(a.B, a.ldb, n0, a.N, k0, kend, tid);
         else lb.template load<true>(a.B, a.ldb, n0, a.N, k0, kend, tid);
     };
-    auto stash = [&](int kt, int buf, TileLoader<BM, !TA> &la, TileLoader<BN, TB> &lb) {
+    auto stash = [&](int kt, float *st) {
         const int k0 = kbeg + kt * SG_BK;
         const bool inside = k0 + SG_BK <= kend;
-        if (fastA && inside) la.template store<false>(As[buf], m0, a.M, k0, kend, tid);
-        else la.template store<true>(As[buf], m0, a.M, k0, kend, tid);
-        if (fastB && inside) lb.template store<false>(Bs[buf], n0, a.N, k0, kend, tid);
-        else lb.template store<true>(Bs[buf], n0, a.N, k0, kend, tid);
+        if (fastA && inside) la.template store<false>(st, m0, a.M, k0, kend, tid);
+        else la.template store<true>(st, m0, a.M, k0, kend, tid);
+        if (fastB && inside) lb.template store<false>(st + BM * SG_BK, n0, a.N, k0, kend, tid);
+        else lb.template store<true>(st + BM * SG_BK, n0, a.N, k0, kend, tid);
     };
-    auto compute = [&](int buf) {
-        const float *as = As[buf] + wave * 32 * WM + col, *bs = Bs[buf] + col;
-#pragma unroll
-        for (int ks = 0; ks < SG_BK / 2; ++ks) {
-            const int k = 2 * ks + half;
-            float av[WM], bv[WN];
-#pragma unroll
-            for (int i = 0; i < WM; ++i) av[i] = as[k * SA_ + 32 * i];
-#pragma unroll
-            for (int j = 0; j < WN; ++j) bv[j] = bs[k * SB_ + 32 * j];
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-        }
-    };
-    if (nk > 0) {
-        fetch(0, la0, lb0);
-        stash(0, 0, la0, lb0);
-    }
-    __syncthreads();
+
+    int done = 0;                       // slabs consumed
+    if (a.direct && fastA && fastB && nk_full >= 2) {
+        // Direct path: three LDS stages, the loads of slab kt + 2 issued before the MFMAs of slab kt -- two slabs of MFMA time for a
+        // load to arrive, no registers held meanwhile.  Loads complete in order, so "at most one slab's worth outstanding" means slab
+        // kt + 1 has landed; the barrier then publishes it and retires stage kt % 3.
+        constexpr int IN_FLIGHT = LA::NV + LB::NV;
+        auto issue = [&](int kt) {
+            float *st = smem + (kt % 3) * STAGE;
+            la.direct(a.A, a.lda, m0, kbeg + kt * SG_BK, st, wave, lane);
+            lb.direct(a.B, a.ldb, n0, kbeg + kt * SG_BK, st + BM * SG_BK, wave, lane);
+        };
+        issue(0);
+        issue(1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IN_FLIGHT) : "memory");
+        __builtin_amdgcn_s_barrier();
 #pragma unroll 1
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) fetch(kt + 1, la0, lb0);
-        compute(kt & 1);
-        if (kt + 1 < nk) stash(kt + 1, (kt + 1) & 1, la0, lb0);
+        for (int kt = 0; kt < nk_full; ++kt) {
+            if (kt + 2 < nk_full) issue(kt + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(smem + (kt % 3) * STAGE);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 2 < nk_full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IN_FLIGHT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        done = nk_full;
+    }
+    // Register path: edge tiles, misaligned operands, short K, and the K tail of the direct path.  Two stages, one slab of prefetch.
+    if (done < nk) {
+        float *st0 = smem + (done % 3) * STAGE, *st1 = smem + ((done + 1) % 3) * STAGE;
+        fetch(done);
+        stash(done, st0);
         __syncthreads();
+#pragma unroll 1
+        for (int kt = done; kt < nk; ++kt) {
+            float *cur = ((kt - done) & 1) ? st1 : st0, *nxt = ((kt - done) & 1) ? st0 : st1;
+            if (kt + 1 < nk) fetch(kt + 1);
+            compute(cur);
+            if (kt + 1 < nk) stash(kt + 1, nxt);
+            __syncthreads();
+        }
     }
     // accumulator element r of lane (col, half): row 8 (r / 4) + 4 half + r % 4, column col.  beta != 0: the 16 old values of a block are
     // read together (clamped rows) before any of them is needed
@@ -180,30 +232,39 @@ __global__ __launch_bounds__(256, 2) void k_sgemm(SgemmArgs a) {
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
             const int n = n0 + 32 * j + col;
-            if (n >= a.N) continue;
-            const int mb = m0 + wave * 32 * WM + 32 * i + 4 * half;
-            float old[16];
-            if (accumulate) {
+            if (n < a.N) {
+                const int mb = m0 + wave * 32 * WM + 32 * i + 4 * half;
+                float old[16];
+                if (accumulate) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) old[r] = C[(size_t)min(mb + 8 * (r >> 2) + (r & 3), a.M - 1) * a.ldc + n];
-            }
+                    for (int r = 0; r < 16; ++r) old[r] = C[(size_t)min(mb + 8 * (r >> 2) + (r & 3), a.M - 1) * a.ldc + n];
+                }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mb + 8 * (r >> 2) + (r & 3);
-                float v = a.alpha * acc[i][j][r];
-                if (accumulate) v += a.beta * old[r];
-                if (m < a.M) C[(size_t)m * a.ldc + n] = v;
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + 8 * (r >> 2) + (r & 3);
+                    float v = a.alpha * acc[i][j][r];
+                    if (accumulate) v += a.beta * old[r];
+                    if (m < a.M) C[(size_t)m * a.ldc + n] = v;
+                }
             }
             __builtin_amdgcn_sched_barrier(0);      // one block's 16 old values at a time, not all WM x WN blocks' (registers)
         }
 }
 
+template <int WM, int WN, bool TA, bool TB>
+kpd_status launch_one(dim3 grid, hipStream_t st, const SgemmArgs &a) {
+    constexpr int bytes = 3 * (128 * WM + 32 * WN) * SG_BK * 4;
+    KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_sgemm<WM, WN, TA, TB>), bytes));
+    hipLaunchKernelGGL((k_sgemm<WM, WN, TA, TB>), grid, dim3(256), bytes, st, a);
+    return KPD_OK;
+}
+
 template <int WM, int WN>
-void launch_shape(bool tA, bool tB, dim3 grid, hipStream_t st, const SgemmArgs &a) {
-    if (!tA && tB) hipLaunchKernelGGL((k_sgemm<WM, WN, false, true>), grid, dim3(256), 0, st, a);
-    else if (!tA && !tB) hipLaunchKernelGGL((k_sgemm<WM, WN, false, false>), grid, dim3(256), 0, st, a);
-    else if (tA && !tB) hipLaunchKernelGGL((k_sgemm<WM, WN, true, false>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_sgemm<WM, WN, true, true>), grid, dim3(256), 0, st, a);
+kpd_status launch_shape(bool tA, bool tB, dim3 grid, hipStream_t st, const SgemmArgs &a) {
+    if (!tA && tB) return launch_one<WM, WN, false, true>(grid, st, a);
+    if (!tA && !tB) return launch_one<WM, WN, false, false>(grid, st, a);
+    if (tA && !tB) return launch_one<WM, WN, true, false>(grid, st, a);
+    return launch_one<WM, WN, true, true>(grid, st, a);
 }
 
 // C = sum of the split-K partial products (in slice order) + beta C; eight loads in flight per thread
@@ -270,21 +331,20 @@ kpd_status sgemm(bool tA, bool tB, int M, int N, int K, float alpha, const float
         slices = 1;
         a.k_chunk = cdiv(K, SG_BK) * SG_BK;
     }
-    // tile shape: the widest column tile the output fills; 256-row tiles only when they still give every CU two workgroups
-    const int wn = N > 64 ? 4 : N > 32 ? 2 : 1;
-    const int bn = 32 * wn;
-    const bool tall = (long long)cdiv(M, 256) * cdiv(N, bn) * slices >= 2ll * cu_count();
-    const dim3 grid(cdiv(M, tall ? 256 : 128), cdiv(N, bn), slices);
+    // tile shape (measured on the engines' shapes, profiles/r03_sgemm_bench.txt): 128-row tiles throughout (256-row tiles lose 10-15 %
+    // on every shape: half the workgroups per CU to hide the short K loops behind); 128 columns when that still gives every CU two
+    // workgroups, else 64 (node-sized products: more, smaller workgroups balance the 256 CUs better); 32 for the 16-wide vector channels
+    static const int force_wn = getenv("KPD_SGEMM_WN") ? atoi(getenv("KPD_SGEMM_WN")) : 0;          // A/B runs
+    static const int direct = getenv("KPD_SGEMM_DIRECT") ? atoi(getenv("KPD_SGEMM_DIRECT")) : 1;
+    a.direct = direct;
+    int wn = N > 64 ? 4 : N > 32 ? 2 : 1;
+    if (wn == 4 && (long long)cdiv(M, 128) * cdiv(N, 128) * slices < 2ll * cu_count()) wn = 2;
+    if (force_wn) wn = force_wn;
+    const dim3 grid(cdiv(M, 128), cdiv(N, 32 * wn), slices);
     KPD_REQUIRE(grid.y <= 65535u && grid.z <= 65535u, KPD_ERR_CAPACITY, "sgemm: N = %d too wide for one launch", N);
-    if (tall) {
-        if (wn == 4) launch_shape<2, 4>(tA, tB, grid, st, a);
-        else if (wn == 2) launch_shape<2, 2>(tA, tB, grid, st, a);
-        else launch_shape<2, 1>(tA, tB, grid, st, a);
-    } else {
-        if (wn == 4) launch_shape<1, 4>(tA, tB, grid, st, a);
-        else if (wn == 2) launch_shape<1, 2>(tA, tB, grid, st, a);
-        else launch_shape<1, 1>(tA, tB, grid, st, a);
-    }
+    if (wn == 4) KPD_TRY((launch_shape<1, 4>(tA, tB, grid, st, a)));
+    else if (wn == 2) KPD_TRY((launch_shape<1, 2>(tA, tB, grid, st, a)));
+    else KPD_TRY((launch_shape<1, 1>(tA, tB, grid, st, a)));
     KPD_LAUNCH_CHECK();
     if (slices > 1) {
         hipLaunchKernelGGL(k_sgemm_reduce, dim3(cdiv(M * N, 256)), dim3(256), 0, st, part, slices, M, N, beta, C, ldc);
