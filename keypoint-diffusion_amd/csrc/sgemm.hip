@@ -267,6 +267,49 @@ kpd_status launch_shape(bool tA, bool tB, dim3 grid, hipStream_t st, const Sgemm
     return launch_one<WM, WN, true, true>(grid, st, a);
 }
 
+// Weight gradient of a narrow Linear (the 16-wide vector channels of the GVPs): C[M,N] = alpha A[K,M]^T B[K,N] with M, N <= 32 and K = rows
+// of a tall activation matrix.  No LDS staging: lane (col, half) of a wave reads A[k + half][col] and B[k + half][col] straight into the
+// operands of one v_mfma_f32_32x32x2_f32 per two rows (16 rows in flight); the workgroup's four waves split its K range, their
+// accumulators are added in wave order through LDS, and the workgroup writes one partial [M,N] for k_sgemm_reduce.
+__global__ __launch_bounds__(256) void k_sgemm_tn_skinny(SgemmArgs a) {
+    __shared__ float red[4][32 * 33];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 31, half = lane >> 5;
+    // rows of this wave: a.k_chunk rows per workgroup, a quarter (even) per wave
+    const int per_wave = a.k_chunk / 4;
+    const int kbeg = min(a.K, (int)blockIdx.x * a.k_chunk + wave * per_wave), kend = min(a.K, kbeg + per_wave);
+    const int ca = min(col, a.M - 1), cb = min(col, a.N - 1);
+    const bool va = col < a.M, vb = col < a.N;
+    v16f acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const float *pa = a.A + ca, *pb = a.B + cb;
+    int k = kbeg;
+#pragma unroll 1
+    for (; k + 16 <= kend; k += 16) {
+        float x[8], y[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            x[u] = pa[(size_t)(k + 2 * u + half) * a.lda];
+            y[u] = pb[(size_t)(k + 2 * u + half) * a.ldb];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(masked(x[u], va), masked(y[u], vb), acc, 0, 0, 0);
+    }
+    for (; k < kend; k += 2) {
+        const int kk = min(k + half, a.K - 1);
+        const bool in = k + half < kend;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(masked(pa[(size_t)kk * a.lda], va && in), masked(pb[(size_t)kk * a.ldb], vb && in), acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][(8 * (r >> 2) + 4 * half + (r & 3)) * 33 + col] = acc[r];
+    __syncthreads();
+    float *C = a.C + (size_t)blockIdx.x * a.c_slice;
+    for (int i = tid; i < a.M * a.N; i += 256) {
+        const int m = i / a.N, n = i - m * a.N;
+        C[i] = a.alpha * (((red[0][m * 33 + n] + red[1][m * 33 + n]) + red[2][m * 33 + n]) + red[3][m * 33 + n]);
+    }
+}
+
 // C = sum of the split-K partial products (in slice order) + beta C; eight loads in flight per thread
 __global__ void k_sgemm_reduce(const float *__restrict__ part, int slices, int M, int N, float beta, float *__restrict__ C, int ldc) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -320,6 +363,18 @@ kpd_status sgemm(bool tA, bool tB, int M, int N, int K, float alpha, const float
     a.vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
     a.k_chunk = cdiv(K, SG_BK) * SG_BK;
     a.c_slice = 0;
+    if (tA && !tB && M <= 32 && N <= 32 && K >= 8192 && part && part_floats >= (size_t)cu_count() * M * N) {
+        // one partial per workgroup, about one workgroup per CU; rows per workgroup a multiple of 8 (even quarters)
+        const int groups = std::min(cu_count(), cdiv(K, 2048));
+        a.k_chunk = cdiv(cdiv(K, groups), 8) * 8;
+        const int used = cdiv(K, a.k_chunk);
+        a.C = part; a.ldc = N; a.beta = 0.0f; a.c_slice = (long long)M * N;
+        hipLaunchKernelGGL(k_sgemm_tn_skinny, dim3(used), dim3(256), 0, st, a);
+        KPD_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_sgemm_reduce, dim3(cdiv(M * N, 256)), dim3(256), 0, st, part, used, M, N, beta, C, ldc);
+        KPD_LAUNCH_CHECK();
+        return KPD_OK;
+    }
     int slices = part ? (int)std::min<size_t>(sgemm_split_slices(M, N, K), part_floats / ((size_t)M * N)) : 1;
     if (slices > 1) {
         a.k_chunk = cdiv(cdiv(K, slices), SG_BK) * SG_BK;
@@ -338,7 +393,7 @@ kpd_status sgemm(bool tA, bool tB, int M, int N, int K, float alpha, const float
     static const int direct = getenv("KPD_SGEMM_DIRECT") ? atoi(getenv("KPD_SGEMM_DIRECT")) : 1;
     a.direct = direct;
     int wn = N > 64 ? 4 : N > 32 ? 2 : 1;
-    if (wn == 4 && (long long)cdiv(M, 128) * cdiv(N, 128) * slices < 2ll * cu_count()) wn = 2;
+    if (wn == 4 && slices == 1 && (long long)cdiv(M, 128) * cdiv(N, 128) < 2ll * cu_count()) wn = 2;
     if (force_wn) wn = force_wn;
     const dim3 grid(cdiv(M, 128), cdiv(N, 32 * wn), slices);
     KPD_REQUIRE(grid.y <= 65535u && grid.z <= 65535u, KPD_ERR_CAPACITY, "sgemm: N = %d too wide for one launch", N);

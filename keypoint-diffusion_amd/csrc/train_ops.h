@@ -124,11 +124,26 @@ __global__ __launch_bounds__(1024) void k_colsum_reduce(const float *__restrict_
     __shared__ float s_s[16][64], s_p[16][64];
     const int cl = threadIdx.x & 63, g = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
     float s = 0.0f, p = 0.0f;
-    if (c < K)
-        for (int b = g; b < blocks; b += 16) {
+    if (c < K) {
+        int b = g;
+        for (; b + 48 < blocks; b += 64) {                       // four partials in flight, added in block order as below
+            float ts[4], tp[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                ts[u] = part[(size_t)(b + 16 * u) * 2 * COLSUM_LD + c];
+                tp[u] = part[(size_t)(b + 16 * u) * 2 * COLSUM_LD + COLSUM_LD + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s += ts[u];
+                p += tp[u];
+            }
+        }
+        for (; b < blocks; b += 16) {
             s += part[(size_t)b * 2 * COLSUM_LD + c];
             p += part[(size_t)b * 2 * COLSUM_LD + COLSUM_LD + c];
         }
+    }
     s_s[g][cl] = s;
     s_p[g][cl] = p;
     __syncthreads();
@@ -232,16 +247,6 @@ __global__ void k_segsum_perm(const float *__restrict__ M, int lda, int c0, int 
         if (accumulate) out[(size_t)v * ldo + c] += alpha * s;
         else out[(size_t)v * ldo + c] = alpha * s;
     }
-}
-
-// dst[i] += sum over s of part[s][i]
-__global__ void k_reduce_parts(const float *__restrict__ part, int n_parts, int rows, int cols, float *__restrict__ dst, int ldd) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * cols) return;
-    float s = 0.0f;
-    for (int k = 0; k < n_parts; ++k) s += part[(size_t)k * rows * cols + i];
-    const int r = i / cols, c = i - r * cols;
-    dst[(size_t)r * ldd + c] += s;
 }
 
 inline dim3 grid1(long long n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
