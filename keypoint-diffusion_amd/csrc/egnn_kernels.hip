@@ -1446,7 +1446,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     float *s_z = smem + TN * SA;
     float *s_mean = s_z + TN;
     float *s_rstd = s_mean + TN;
+    // the wave index as a scalar: every row-wise loop below addresses rows by wave, so row pointers, the CSR bounds of the h_neigh
+    // gather and its branches are scalar work
+#ifdef KPD_NODE_VWAVE   // A/B: the wave index as a vector register (round 2)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+#else
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+#endif
     const int which = blockIdx.x >= p.tiles0 ? 1 : 0;
     const NodeLayerArgs &L = p.nt[which];
     const NodeArgs &a = L.u;
@@ -1513,7 +1519,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         NL_STAMP(1)
         // GEMM 1b: + W[:, 257:] . (h_neigh / z); h_neigh = sum of segment pieces over the incoming edge
         // types in fixed order (multi_update_all cross_reducer='sum')
+#ifdef KPD_NODE_GATHER_U2
 #pragma unroll 2
+#else
+#pragma unroll
+#endif
         for (int rr = 0; rr < RPW; ++rr) {
             const int r = wave * RPW + rr, v = node0 + r;
             f32x4 val = {0.f, 0.f, 0.f, 0.f}, val2 = {0.f, 0.f, 0.f, 0.f};

@@ -13,7 +13,7 @@ for v in A B; do
   f=""; [ $v = B ] && f="$flags"
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $f -c $csrc/$tu -o /tmp/ab_$v.o
   list=""; for o in $objs; do if [ $o = ${tu%.hip}.o ]; then list="$list /tmp/ab_$v.o"; else list="$list $csrc/$o"; fi; done
-  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $root/libkpd_ab_$v.so $list -L/opt/rocm/lib -lrocblas -Wl,-rpath,/opt/rocm/lib
+  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $root/libkpd_ab_$v.so $list -lpthread
 done
 cd $root
 /usr/local/graft/bin/gpurun --timeout 900 -- "for rep in 1 2; do for v in A B; do cp libkpd_ab_\$v.so keypoint-diffusion_amd/csrc/libkpd_hip.so; echo -n \"\$v: \"; python bench.py --no-secondary --steps 150 --warmup 10 --no-cpu-baseline $bflags | python -c 'import json,sys; b=json.loads(sys.stdin.read()); print(round(b[\"value\"],2), \"steps/s  dominant kernel\", round(b[\"roofline\"][\"avg_launch_ms\"],4), \"ms\")'; done; done"
