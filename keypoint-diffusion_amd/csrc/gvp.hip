@@ -25,7 +25,9 @@ const char *kNtNameG[2] = {"lig", "kp"};
 
 struct kpd_gvp {
     kpd_gvp_config cfg;
-    int S, V;
+    int S, V;                                   // S: width of the kernels' scalar layout (128 or 256)
+    int St = 0;                                 // n_hidden_scalars of the model (<= S; the S - St trailing features are padding)
+    int Vt = GV;                                // vector_size of the model (<= 16 channels of the kernels' layout, likewise)
     Arena warena, ws;
     // weights
     std::vector<std::vector<std::vector<HostGvp>>> msg;   // [conv][et][j]
@@ -59,9 +61,9 @@ struct kpd_gvp {
 
 extern "C" kpd_status kpd_gvp_create(const kpd_gvp_config *cfg, kpd_gvp **out) {
     KPD_REQUIRE(cfg && out, KPD_ERR_INVALID, "null argument");
-    KPD_REQUIRE(cfg->vector_size == GV, KPD_ERR_INVALID, "vector_size=%d: the HIP path is built for 16", cfg->vector_size);
-    KPD_REQUIRE(cfg->n_hidden_scalars == 256 || cfg->n_hidden_scalars == 128, KPD_ERR_INVALID,
-                "n_hidden_scalars=%d: supported widths are 128 and 256", cfg->n_hidden_scalars);
+    KPD_REQUIRE(cfg->vector_size >= 1 && cfg->vector_size <= GV, KPD_ERR_INVALID, "vector_size=%d: supported sizes are 1 .. 16", cfg->vector_size);
+    KPD_REQUIRE(cfg->n_hidden_scalars >= 1 && cfg->n_hidden_scalars <= 256, KPD_ERR_INVALID,
+                "n_hidden_scalars=%d: supported widths are 1 .. 256", cfg->n_hidden_scalars);
     KPD_REQUIRE(cfg->ll_k >= 0 && cfg->ll_k <= KL_KMAX, KPD_ERR_INVALID, "ll_k=%d outside 0..%d (0 = radius graph)", cfg->ll_k, KL_KMAX);
     KPD_REQUIRE(cfg->kl_k >= 0 && cfg->kl_k <= KL_KMAX, KPD_ERR_INVALID, "kl_k=%d outside 0..%d (0 = radius graph)", cfg->kl_k, KL_KMAX);
     KPD_REQUIRE(cfg->kl_k > 0 || cfg->kl_cutoff > 0.0f, KPD_ERR_INVALID, "kl_k = 0 needs graph_cutoffs['kl'] > 0");
@@ -78,8 +80,12 @@ extern "C" kpd_status kpd_gvp_create(const kpd_gvp_config *cfg, kpd_gvp **out) {
     KPD_TRY(egnn_kernels_init());
     kpd_gvp *m = new kpd_gvp();
     m->cfg = *cfg;
-    m->S = cfg->n_hidden_scalars;
+    // any n_hidden_scalars up to 256 runs on the 128- or 256-wide kernels: weights are packed with zero rows / columns for the padding
+    // features (gvp_host.hip), which therefore stay exactly 0 through SiLU, gates and residuals; the two LayerNorms take the true width
+    m->St = cfg->n_hidden_scalars;
+    m->S = m->St <= 128 ? 128 : 256;
     m->V = GV;
+    m->Vt = cfg->vector_size;
     if (const char *e = getenv("KPD_GEMM")) m->gemm_mode = (!strcmp(e, "f16x2") && m->S == 256) ? 1 : 0;
     const int S = m->S, C = cfg->n_convs;
     size_t per_gvp = gvp_arena_bytes(S);
@@ -104,7 +110,7 @@ extern "C" kpd_status kpd_gvp_create(const kpd_gvp_config *cfg, kpd_gvp **out) {
                 HostGvp &g = m->msg[i][et][j];
                 g.vin = j == 0 ? GV + 1 : GV; g.vout = GV;
                 g.s_in = j == 0 ? S + 16 : S; g.sout = S;
-                g.split = j == 0 ? SPLIT_SRC : SPLIT_NONE; g.S = S;
+                g.split = j == 0 ? SPLIT_SRC : SPLIT_NONE; g.S = S; g.cut = S - m->St; g.vcut = GV - m->Vt;
                 g.chain_pos = j;
                 alloc_gvp(A, g, m->expected, pre + "edge_message_fns." + kCanon[et] + "." + std::to_string(j));
             }
@@ -113,7 +119,7 @@ extern "C" kpd_status kpd_gvp_create(const kpd_gvp_config *cfg, kpd_gvp **out) {
             m->upd[i][nt].resize(cfg->n_update_gvps);
             for (int j = 0; j < cfg->n_update_gvps; ++j) {
                 HostGvp &g = m->upd[i][nt][j];
-                g.vin = GV; g.vout = GV; g.s_in = S; g.sout = S;
+                g.vin = GV; g.vout = GV; g.s_in = S; g.sout = S; g.S = S; g.cut = S - m->St; g.vcut = GV - m->Vt;
                 g.chain_pos = 1;            // register-chained node kernel: same form as a non-head message GVP
                 alloc_gvp(A, g, m->expected, pre + "node_update_fns." + kNtNameG[nt] + "." + std::to_string(j));
             }
@@ -129,7 +135,7 @@ extern "C" kpd_status kpd_gvp_create(const kpd_gvp_config *cfg, kpd_gvp **out) {
     for (int j = 0; j < cfg->n_noise_gvps; ++j) {
         HostGvp &g = m->noise[j];
         const bool last = j == cfg->n_noise_gvps - 1;
-        g.vin = GV; g.vout = last ? 1 : GV; g.s_in = S; g.sout = last ? 64 : S;
+        g.vin = GV; g.vout = last ? 1 : GV; g.s_in = S; g.sout = last ? 64 : S; g.S = S; g.cut = S - m->St; g.vcut = GV - m->Vt;
         g.vec_sigmoid = last ? 0 : 1;
         g.chain_pos = 1;                // register-chained noise head (gvp_chain.hip)
         alloc_gvp(A, g, m->expected, "noise_predictor.noise_predictor.gvps." + std::to_string(j));
@@ -172,7 +178,7 @@ extern "C" kpd_status kpd_gvp_load_weight(kpd_gvp *m, const char *name, const fl
         set_error("unknown or unused weight name '%s' for this configuration", name);
         return KPD_ERR_WEIGHTS;
     }
-    const int S = m->S;
+    const int S = m->S, St = m->St;
     const std::vector<std::string> tk = split_dots(nm);
     auto tail_from = [&](size_t i) {
         std::string t;
@@ -183,12 +189,12 @@ extern "C" kpd_status kpd_gvp_load_weight(kpd_gvp *m, const char *name, const fl
         const int nt = tk[0] == "lig_encoder" ? 0 : 1;
         const int fin = (nt == 0 ? m->cfg.n_lig_scalars : m->cfg.n_kp_scalars) + 1;
         const bool is_w = tk[2] == "weight";
-        if (tk[1] == "0") {
-            if (is_w) { KPD_TRY(want_shape(name, shape, ndim, {S, fin})); KPD_TRY(copy_pad(w, S * fin, m->enc_W[nt], S * fin, st)); }
-            else { KPD_TRY(want_shape(name, shape, ndim, {S})); KPD_TRY(copy_pad(w, S, m->enc_b[nt], S, st)); }
+        if (tk[1] == "0") {       // rows St .. S - 1 stay zero
+            if (is_w) { KPD_TRY(want_shape(name, shape, ndim, {St, fin})); KPD_TRY(copy_pad(w, St * fin, m->enc_W[nt], S * fin, st)); }
+            else { KPD_TRY(want_shape(name, shape, ndim, {St})); KPD_TRY(copy_pad(w, St, m->enc_b[nt], S, st)); }
         } else {
-            KPD_TRY(want_shape(name, shape, ndim, {S}));
-            KPD_TRY(copy_pad(w, S, is_w ? m->enc_lw[nt] : m->enc_lb[nt], S, st));
+            KPD_TRY(want_shape(name, shape, ndim, {St}));
+            KPD_TRY(copy_pad(w, St, is_w ? m->enc_lw[nt] : m->enc_lb[nt], S, st));
         }
     } else if (tk[1] == "noise_predictor") {
         if (tk[2] == "to_scalar_output") {
@@ -213,10 +219,10 @@ extern "C" kpd_status kpd_gvp_load_weight(kpd_gvp *m, const char *name, const fl
         } else {   // message_layer_norms / update_layer_norms .<nt>.feat_norm.<param>
             const int nt = tk[4] == "lig" ? 0 : 1;
             const bool is_w = tk[6] == "weight";
-            KPD_TRY(want_shape(name, shape, ndim, {S}));
+            KPD_TRY(want_shape(name, shape, ndim, {St}));
             float *dst = blk == "message_layer_norms" ? (is_w ? m->ln1w[i][nt] : m->ln1b[i][nt])
                                                       : (is_w ? m->ln2w[i][nt] : m->ln2b[i][nt]);
-            KPD_TRY(copy_pad(w, S, dst, S, st));
+            KPD_TRY(copy_pad(w, St, dst, S, st));
         }
     }
     m->loaded.insert(nm);
@@ -334,11 +340,16 @@ extern "C" kpd_status kpd_gvp_forward(kpd_gvp *m, const kpd_batch *bt, const flo
     KPD_TRY(launch_egnn_meta(m->lg.counts, bt->n_kk, 0xF, 0x3, bt->lig_ptr, bt->kp_ptr, m->lg.ll_per_graph, bt->kk_rowptr, bt->B,
                              m->kl_off, mn, 1, m->meta4, m->z[0], m->z[1], st));
     KPD_TRY(launch_gvp_embed(bt->lig_h, bt->n_lig, c.n_lig_scalars, m->enc_W[0], m->enc_b[0], m->enc_lw[0], m->enc_lb[0],
-                             t_dev, m->bidx[0], S, m->s[0], st));
+                             t_dev, m->bidx[0], S, m->St, m->s[0], st));
     KPD_TRY(launch_gvp_embed(bt->kp_h, bt->n_kp, c.n_kp_scalars, m->enc_W[1], m->enc_b[1], m->enc_lw[1], m->enc_lb[1],
-                             t_dev, m->bidx[1], S, m->s[1], st));
+                             t_dev, m->bidx[1], S, m->St, m->s[1], st));
     KPD_HIP(hipMemsetAsync(m->v[0], 0, (size_t)bt->n_lig * 48 * 4, st));                      // dynamics_gvp.py:179-184
-    KPD_HIP(hipMemcpyAsync(m->v[1], bt->kp_v, (size_t)bt->n_kp * 48 * 4, hipMemcpyDeviceToDevice, st));
+    if (m->Vt == GV) {
+        KPD_HIP(hipMemcpyAsync(m->v[1], bt->kp_v, (size_t)bt->n_kp * 48 * 4, hipMemcpyDeviceToDevice, st));
+    } else {               // [n_kp][Vt][3] into the 16-channel rows, padding channels zero
+        KPD_HIP(hipMemsetAsync(m->v[1], 0, (size_t)bt->n_kp * 48 * 4, st));
+        KPD_HIP(hipMemcpy2DAsync(m->v[1], 48 * 4, bt->kp_v, (size_t)m->Vt * 12, (size_t)m->Vt * 12, bt->n_kp, hipMemcpyDeviceToDevice, st));
+    }
 
     const int e_kl_cap = bt->n_kp * (c.kl_k > 0 ? c.kl_k : std::min(bt->max_lig, 100));
     const int E_cap[4] = {std::max<int>((long)bt->n_lig * std::min(bt->max_lig - 1, c.ll_k > 0 ? c.ll_k : 200), 1), e_kl_cap, e_kl_cap,
@@ -407,6 +418,8 @@ extern "C" kpd_status kpd_gvp_forward(kpd_gvp *m, const kpd_batch *bt, const flo
             na.n_in = k;
             na.ln1_w = m->ln1w[ci][nt]; na.ln1_b = m->ln1b[ci][nt]; na.ln2_w = m->ln2w[ci][nt]; na.ln2_b = m->ln2b[ci][nt];
             na.n_gvps = c.n_update_gvps; na.S = S;
+            na.ln_inv_n = 1.0f / (float)m->St; na.ln_pad = (float)(S - m->St);
+            na.vn_inv_n = 1.0f / (float)m->Vt; na.vn_pad = (float)(GV - m->Vt);
             for (int j = 0; j < c.n_update_gvps; ++j) na.g[j] = m->upd[ci][nt][j].dev();
         }
         np.tiles0 = cdiv(n[0], TM);

@@ -579,14 +579,16 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
 // residual scalars wait in the s_tmp scratch rows (the registers are needed for the GEMM operands), the 16 residual
 // vectors stay in registers.
 template <int NTS>
-__device__ __forceinline__ void lanes_layernorm(v4f (&x)[NTS], const float *__restrict__ lw, const float *__restrict__ lb, int q) {
-    constexpr int S = 16 * NTS;
+__device__ __forceinline__ void lanes_layernorm(v4f (&x)[NTS], const float *__restrict__ lw, const float *__restrict__ lb, int q, float inv_n,
+                                                float pad) {
+    // inv_n = 1 / n_hidden_scalars; `pad` trailing registers hold 0 (narrower models on these kernels): their (0 - mean)^2 is taken out
+    // of the variance and their weight / bias are 0.  pad = 0 is bit-identical to the fixed-width form.
     float sum = 0.0f;
 #pragma unroll
     for (int nt = 0; nt < NTS; ++nt) sum += (x[nt][0] + x[nt][1]) + (x[nt][2] + x[nt][3]);
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
-    const float mean = sum * (1.0f / S);
+    const float mean = sum * inv_n;
     float var = 0.0f;
 #pragma unroll
     for (int nt = 0; nt < NTS; ++nt)
@@ -597,7 +599,7 @@ __device__ __forceinline__ void lanes_layernorm(v4f (&x)[NTS], const float *__re
         }
     var += __shfl_xor(var, 16);
     var += __shfl_xor(var, 32);
-    const float rstd = 1.0f / sqrtf(var * (1.0f / S) + 1e-5f);
+    const float rstd = 1.0f / sqrtf((var - pad * mean * mean) * inv_n + 1e-5f);
 #pragma unroll
     for (int nt = 0; nt < NTS; ++nt) {
         const v4f w = *reinterpret_cast<const v4f *>(lw + 16 * nt + 4 * q), b = *reinterpret_cast<const v4f *>(lb + 16 * nt + 4 * q);
@@ -606,13 +608,15 @@ __device__ __forceinline__ void lanes_layernorm(v4f (&x)[NTS], const float *__re
 }
 
 // vector half of GVPLayerNorm (gvp.py:163-165): v / (sqrt(mean_i max(|v_i|^2, 1e-8) + eps) + eps)
-__device__ __forceinline__ void lanes_vecnorm(v4f (&V)[3]) {
+// inv_n = 1 / vector_size; each of the `pad` zero padding channels (narrower models) adds the clamp value 1e-8 to the sum: taken out.
+// pad = 0 is bit-identical to the fixed 16-channel form.
+__device__ __forceinline__ void lanes_vecnorm(v4f (&V)[3], float inv_n, float pad) {
     float a = 0.0f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) a += fmaxf(V[0][r] * V[0][r] + V[1][r] * V[1][r] + V[2][r] * V[2][r], 1e-8f);
     a += __shfl_xor(a, 16);
     a += __shfl_xor(a, 32);
-    const float vn = sqrtf(a * (1.0f / GV) + 1e-5f) + 1e-5f;
+    const float vn = sqrtf((a - pad * 1e-8f) * inv_n + 1e-5f) + 1e-5f;
 #pragma unroll
     for (int c = 0; c < 3; ++c) V[c] = V[c] / vn;
 }
@@ -684,8 +688,8 @@ __global__ __launch_bounds__(256, 2) void k_gvp_node_chain(GvpNodePair p) {
         }
     }
     // message layer norm (gvp.py:519-521); its output is also the residual of the update block
-    lanes_layernorm<NTS>(x, a.ln1_w, a.ln1_b, q);
-    lanes_vecnorm(Vc);
+    lanes_layernorm<NTS>(x, a.ln1_w, a.ln1_b, q, a.ln_inv_n, a.ln_pad);
+    lanes_vecnorm(Vc, a.vn_inv_n, a.vn_pad);
     float *tmp = a.s_tmp + (size_t)v * S + 4 * q;
     if (valid) {
 #pragma unroll
@@ -709,8 +713,8 @@ __global__ __launch_bounds__(256, 2) void k_gvp_node_chain(GvpNodePair p) {
     for (int nt = 0; nt < NTS; ++nt) x[nt] += *reinterpret_cast<const v4f *>(tmp + 16 * nt);
 #pragma unroll
     for (int c = 0; c < 3; ++c) Vc[c] += Vm[c];
-    lanes_layernorm<NTS>(x, a.ln2_w, a.ln2_b, q);
-    lanes_vecnorm(Vc);
+    lanes_layernorm<NTS>(x, a.ln2_w, a.ln2_b, q, a.ln_inv_n, a.ln_pad);
+    lanes_vecnorm(Vc, a.vn_inv_n, a.vn_pad);
     if (valid) {
         float *so = a.s + (size_t)v * S + 4 * q;
 #pragma unroll

@@ -19,6 +19,9 @@ struct HostGvp {
     int vin = 0, h = 0, vout = 0, s_in = 0, sout = 0;   // s_in = scalar inputs of to_feats_out (without sh)
     int split = SPLIT_NONE;
     int S = 0;                                          // width of the node blocks when split
+    int cut = 0;                                        // n_hidden_scalars below the kernels' width S: the last `cut` entries of every
+                                                        // S-wide block are padding (zero weight rows / columns), see load_gvp_tensor
+    int vcut = 0;                                       // vector_size below the kernels' 16 channels: likewise for every 16-channel block
     float *b = nullptr, *bg = nullptr;                  // to_feats_out bias (zero padded to 256), gate bias [16]
     float *wproj = nullptr, *bproj = nullptr;           // h_src block (+ bias)
     float *wproj_dst = nullptr;                         // h_dst block

@@ -57,6 +57,8 @@ struct GvpNodeArgs {
     GvpW g[GVP_MAX_CHAIN];
     int n_gvps;
     int S;
+    float ln_inv_n, ln_pad;       // LayerNorm over the model's n_hidden_scalars = S - ln_pad features: 1 / that width, and the padding count
+    float vn_inv_n, vn_pad;       // its vector half over vector_size = 16 - vn_pad channels
 };
 
 struct GvpNodePair {
@@ -91,7 +93,7 @@ struct GvpNoiseArgs {
 };
 
 kpd_status launch_gvp_embed(const float *in, int n, int fin, const float *W, const float *b, const float *ln_w,
-                            const float *ln_b, const float *t, const int *bidx, int S, float *out, hipStream_t st);
+                            const float *ln_b, const float *t, const int *bidx, int S, int S_true, float *out, hipStream_t st);
 kpd_status launch_gvp_proj(const GvpProjArgs &a, hipStream_t st);
 // edge messages + segmented sums (gvp_chain.hip); message chains are HostGvp with chain_pos >= 0
 kpd_status launch_gvp_edge(const GvpEdgeArgs &a, int tile_cap, hipStream_t st);

@@ -455,6 +455,8 @@ class GvpEngine:
         lig_x, lig_h = _dev_f32(lig_x, 'lig x_0'), _dev_f32(lig_h, 'lig h_0')
         kp_x, kp_h, kp_v = _dev_f32(kp_x, 'kp x_0'), _dev_f32(kp_h, 'kp h_0'), _dev_f32(kp_v, 'kp v_0')
         t = _dev_f32(t, 'timestep')
+        if tuple(kp_v.shape) != (pb.n_kp, int(self.cfg.vector_size), 3):
+            raise KpdError(f'kp v_0 has shape {tuple(kp_v.shape)}, expected ({pb.n_kp}, {int(self.cfg.vector_size)}, 3)')
         eps_h = torch.empty(pb.n_lig, self.n_lig_scalars, device=lig_x.device)
         eps_x = torch.empty(pb.n_lig, 3, device=lig_x.device)
         bt = pb.struct(lig_x, lig_h, kp_x, kp_h, kp_v)

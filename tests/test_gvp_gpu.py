@@ -26,10 +26,11 @@ def _check(h, x, rh, rx, n_lig):
 
 
 def _run(cuda, cfg, n_rec, n_lig, n_kp_scalars=10, convs=None, seed=7, rand_v=True):
-    g = util.fixed_encode(util.make_batch(n_rec, n_lig, seed=31), n_vec=16)
+    nv = cfg.get('vector_size', 16)
+    g = util.fixed_encode(util.make_batch(n_rec, n_lig, seed=31), n_vec=nv)
     gen = torch.Generator().manual_seed(3)
     if rand_v:
-        g.nodes['kp'].data['v_0'] = 0.5 * torch.randn(g.num_nodes('kp'), 16, 3, generator=gen)
+        g.nodes['kp'].data['v_0'] = 0.5 * torch.randn(g.num_nodes('kp'), nv, 3, generator=gen)
     if n_kp_scalars != 10:
         g.nodes['kp'].data['h_0'] = torch.randn(g.num_nodes('kp'), n_kp_scalars, generator=gen)
     model = LigRecDynamicsGVP(10, n_kp_scalars, graph_cutoffs=CUT, **cfg)
@@ -104,3 +105,12 @@ def test_gvp_degenerate_shapes(cuda, n_rec, n_lig):
     """Single-atom ligands (empty lig-lig graph), pockets smaller than one tile, the largest ligand of the datasets."""
     (h, x), (rh, rx) = _run(cuda, GVP_CFGS['gvp_norm0'], n_rec, n_lig)
     _check(h, x, rh, rx, n_lig)
+
+
+@pytest.mark.parametrize('width,vectors', [(100, 16), (127, 16), (130, 16), (255, 16), (17, 16), (128, 8), (256, 15), (90, 5), (64, 1)])
+def test_other_widths(cuda, width, vectors):
+    """n_hidden_scalars and vector_size are free in the reference constructor (models/dynamics_gvp.py:106, defaults 128 / 16): narrower
+    models run on the 128- / 256-wide, 16-channel kernels with zero-padded weight blocks and GVPLayerNorms of the true widths."""
+    cfg = dict(GVP_40KP, n_hidden_scalars=width, vector_size=vectors, n_convs=3)
+    (h, x), (rh, rx) = _run(cuda, cfg, [40, 25, 31], [9, 12, 7])
+    _check(h, x, rh, rx, [9, 12, 7])
