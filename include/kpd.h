@@ -168,7 +168,8 @@ typedef struct kpd_gvp_config {
     int32_t n_lig_scalars, n_kp_scalars;
     int32_t vector_size;               /* 1 .. 16 (kernels are 16 channels wide; fewer are zero padded)           */
     int32_t n_convs, n_hidden_scalars; /* n_hidden_scalars 1 .. 256 (kernels are 128 / 256 wide, likewise); the   */
-                                       /* training engine kpd_gvp_trainer_* takes 128 / 256 and 16 only           */
+                                       /* training engine kpd_gvp_trainer_* takes any n_hidden_scalars <= 256 and */
+                                       /* vector_size 16 only                                                      */
     int32_t update_kp;
     int32_t message_norm_mode;         /* 0: constant message_norm, 1: 'mean', 2: message_norm == 0
                                           (per-graph average in-degree + 1, gvp.py:504-507)  */

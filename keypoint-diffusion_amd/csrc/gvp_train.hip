@@ -390,7 +390,7 @@ kpd_status noise_fwd(kpd_gvp_trainer *T, float *eps_h, float *eps_x) {
 extern "C" kpd_status kpd_gvp_trainer_create(const kpd_gvp_config *cfg, kpd_gvp_trainer **out) {
     KPD_REQUIRE(cfg && out, KPD_ERR_INVALID, "null argument");
     KPD_REQUIRE(cfg->vector_size == VC, KPD_ERR_INVALID, "vector_size=%d: only 16 is supported", cfg->vector_size);
-    KPD_REQUIRE(cfg->n_hidden_scalars == 128 || cfg->n_hidden_scalars == 256, KPD_ERR_INVALID, "n_hidden_scalars=%d", cfg->n_hidden_scalars);
+    KPD_REQUIRE(cfg->n_hidden_scalars >= 1 && cfg->n_hidden_scalars <= 256, KPD_ERR_INVALID, "n_hidden_scalars=%d outside 1 .. 256", cfg->n_hidden_scalars);
     KPD_REQUIRE(cfg->n_convs >= 1 && cfg->n_convs <= 64 && cfg->n_message_gvps >= 1 && cfg->n_message_gvps <= 4 && cfg->n_update_gvps >= 1 &&
                     cfg->n_update_gvps <= 4 && cfg->n_noise_gvps >= 1 && cfg->n_noise_gvps <= 4,
                 KPD_ERR_INVALID, "n_convs=%d gvps=%d/%d/%d", cfg->n_convs, cfg->n_message_gvps, cfg->n_update_gvps, cfg->n_noise_gvps);

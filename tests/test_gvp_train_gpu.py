@@ -44,7 +44,8 @@ def _oracle_grads(model, cfg, g, t, w_h, w_x):
     return eh.detach(), ex.detach(), {k: v.grad for k, v in sd.items()}, {k: v.grad for k, v in ins.items()}
 
 
-@pytest.mark.parametrize('tag,over', [('gvp_kp', {}), ('gvp_mean', {}), ('gvp_norm0', {}), ('gvp_norm0', dict(ll_k=3, kl_k=0))])
+@pytest.mark.parametrize('tag,over', [('gvp_kp', {}), ('gvp_mean', {}), ('gvp_norm0', {}), ('gvp_norm0', dict(ll_k=3, kl_k=0)),
+                                      ('gvp_norm0', dict(n_hidden_scalars=100)), ('gvp_mean', dict(n_hidden_scalars=37))])
 def test_gradients_match_oracle_autograd(tag, over):
     cfg = dict(GVP_CFGS[tag], dropout=0.0, **over)
     g, model, t = _case(cfg, [26, 19, 33], [7, 10, 5], 128 if tag == 'gvp_kp' else 10)
