@@ -990,7 +990,15 @@ kpd_status launch_gvp_noise(const GvpNoiseArgs &a, hipStream_t st) {
     return KPD_OK;
 }
 
-kpd_status launch_gvp_node(const GvpNodePair &p, hipStream_t st) {
+kpd_status launch_gvp_node(const GvpNodePair &pin, hipStream_t st) {
+    // a caller that does not state the model's widths (the receptor encoder: always the kernels' own) gets the full-width norms
+    GvpNodePair p = pin;
+    for (int nt = 0; nt < 2; ++nt) {
+        GvpNodeArgs &a = p.nt[nt];
+        if (a.ln_inv_n == 0.0f) { a.ln_inv_n = 1.0f / (float)std::max(a.S, 1); a.ln_pad = 0.0f; }
+        if (a.vn_inv_n == 0.0f) { a.vn_inv_n = 1.0f / (float)GV; a.vn_pad = 0.0f; }
+        KPD_REQUIRE(a.ln_pad >= 0.0f && a.vn_pad >= 0.0f && a.ln_inv_n > 0.0f && a.vn_inv_n > 0.0f, KPD_ERR_INVALID, "gvp node kernel: bad norm widths");
+    }
     const int tiles = p.tiles0 + cdiv(p.nt[1].n, TM);
     if (tiles == 0) return KPD_OK;
     if (poison_level() >= 1) KPD_TRY(poison_lds(st));      // debug only (engine.h)
