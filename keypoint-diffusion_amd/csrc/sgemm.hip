@@ -30,6 +30,7 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int SG_BK = 16;
+constexpr int SG_MAX_STAGES = 8;
 
 struct SgemmArgs {
     const float *A, *B;
@@ -40,6 +41,7 @@ struct SgemmArgs {
     long long c_slice;      // floats between the outputs of consecutive slices (split-K partials), 0 otherwise
     int vecA, vecB;         // base pointer 16-B aligned and leading dimension a multiple of 4
     int direct;             // 0: never take the global->LDS path (KPD_SGEMM_DIRECT=0, A/B runs)
+    int stages;             // LDS stages of the direct path (3 .. SG_MAX_STAGES)
 };
 
 // x or +0.0 by a bit mask: the value is consumed on both outcomes, so the load stays unconditional (a select lets the compiler sink the
@@ -128,7 +130,7 @@ template <int WM, int WN, bool TA, bool TB>
 __global__ __launch_bounds__(256, 2) void k_sgemm(SgemmArgs a) {
     constexpr int BM = 128 * WM, BN = 32 * WN;
     constexpr int STAGE = (BM + BN) * SG_BK;                     // floats of one LDS stage: A tile, then B tile
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // 3 stages
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // a.stages stages
     typedef TileLoader<BM, !TA> LA;                               // op(A)[m][k]: contiguous along k unless transposed
     typedef TileLoader<BN, TB> LB;                                // op(B)[k][n]: contiguous along k only when transposed
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 31, half = lane >> 5;
@@ -184,34 +186,49 @@ __global__ __launch_bounds__(256, 2) void k_sgemm(SgemmArgs a) {
 
     int done = 0;                       // slabs consumed
     if (a.direct && fastA && fastB && nk_full >= 2) {
-        // Direct path: three LDS stages, the loads of slab kt + 2 issued before the MFMAs of slab kt -- two slabs of MFMA time for a
-        // load to arrive, no registers held meanwhile.  Loads complete in order, so "at most one slab's worth outstanding" means slab
-        // kt + 1 has landed; the barrier then publishes it and retires stage kt % 3.
+        // Direct path: a ring of `stages` LDS stages (3 .. SG_MAX_STAGES, chosen by the host), the loads of slab kt + stages - 1 issued
+        // before the MFMAs of slab kt -- stages - 1 slabs of MFMA time for a load to arrive, no registers held meanwhile.  Loads complete
+        // in order, so "at most the slabs behind kt + 1 outstanding" means slab kt + 1 has landed; the barrier then publishes it and
+        // retires the stage of slab kt.
         constexpr int IN_FLIGHT = LA::NV + LB::NV;
+        static_assert(IN_FLIGHT * (SG_MAX_STAGES - 2) <= 63, "vmcnt immediate");
+        const int stages = a.stages;
         auto issue = [&](int kt) {
-            float *st = smem + (kt % 3) * STAGE;
+            float *st = smem + (kt % stages) * STAGE;
             la.direct(a.A, a.lda, m0, kbeg + kt * SG_BK, st, wave, lane);
             lb.direct(a.B, a.ldb, n0, kbeg + kt * SG_BK, st + BM * SG_BK, wave, lane);
         };
-        issue(0);
-        issue(1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IN_FLIGHT) : "memory");
-        __builtin_amdgcn_s_barrier();
+        // wait until at most `slabs` slabs of loads are outstanding (the counter takes an immediate)
+        auto wait_behind = [&](int slabs) {
+            switch (slabs) {
+            case 0: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(0) : "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IN_FLIGHT) : "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IN_FLIGHT) : "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * IN_FLIGHT) : "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * IN_FLIGHT) : "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * IN_FLIGHT) : "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * IN_FLIGHT) : "memory"); break;
+            }
+        };
+        const int ahead = min(stages - 1, nk_full);
+        for (int kt = 0; kt < ahead; ++kt) issue(kt);
+        wait_behind(ahead - 1);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll 1
         for (int kt = 0; kt < nk_full; ++kt) {
-            if (kt + 2 < nk_full) issue(kt + 2);
+            if (kt + stages - 1 < nk_full) issue(kt + stages - 1);
             __builtin_amdgcn_sched_barrier(0);
-            compute(smem + (kt % 3) * STAGE);
+            compute(smem + (kt % stages) * STAGE);
             __builtin_amdgcn_sched_barrier(0);
-            if (kt + 2 < nk_full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IN_FLIGHT) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // issued so far: slabs 0 .. min(kt + stages - 1, nk_full - 1); needed next: kt + 1
+            wait_behind(max(0, min(kt + stages - 1, nk_full - 1) - (kt + 1)));
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         done = nk_full;
     }
     // Register path: edge tiles, misaligned operands, short K, and the K tail of the direct path.  Two stages, one slab of prefetch.
     if (done < nk) {
-        float *st0 = smem + (done % 3) * STAGE, *st1 = smem + ((done + 1) % 3) * STAGE;
+        float *st0 = smem, *st1 = smem + STAGE;          // (every stage is free here: the direct path ended on a barrier)
         fetch(done);
         stash(done, st0);
         __syncthreads();
@@ -253,9 +270,9 @@ __global__ __launch_bounds__(256, 2) void k_sgemm(SgemmArgs a) {
 
 template <int WM, int WN, bool TA, bool TB>
 kpd_status launch_one(dim3 grid, hipStream_t st, const SgemmArgs &a) {
-    constexpr int bytes = 3 * (128 * WM + 32 * WN) * SG_BK * 4;
-    KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_sgemm<WM, WN, TA, TB>), bytes));
-    hipLaunchKernelGGL((k_sgemm<WM, WN, TA, TB>), grid, dim3(256), bytes, st, a);
+    constexpr int stage_bytes = (128 * WM + 32 * WN) * SG_BK * 4;
+    KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_sgemm<WM, WN, TA, TB>), SG_MAX_STAGES * stage_bytes));
+    hipLaunchKernelGGL((k_sgemm<WM, WN, TA, TB>), grid, dim3(256), a.stages * stage_bytes, st, a);
     return KPD_OK;
 }
 
@@ -347,8 +364,9 @@ __global__ __launch_bounds__(256) void k_sgemv_rows(const float *__restrict__ A,
 }  // namespace
 
 int sgemm_split_slices(int M, int N, int K) {
+    static const int pct = getenv("KPD_SGEMM_SPLIT_PCT") ? atoi(getenv("KPD_SGEMM_SPLIT_PCT")) : 200;      // workgroups per 100 CUs (A/B runs)
     const int tiles = cdiv(M, 128) * cdiv(N, 128);
-    int s = std::max(1, (2 * cu_count()) / std::max(tiles, 1));
+    int s = std::max(1, (pct * cu_count() / 100) / std::max(tiles, 1));
     s = std::min(s, std::max(1, K / 256));
     return std::min(s, SGEMM_MAX_SPLIT);
 }
@@ -396,6 +414,12 @@ kpd_status sgemm(bool tA, bool tB, int M, int N, int K, float alpha, const float
     if (wn == 4 && slices == 1 && (long long)cdiv(M, 128) * cdiv(N, 128) < 2ll * cu_count()) wn = 2;
     if (force_wn) wn = force_wn;
     const dim3 grid(cdiv(M, 128), cdiv(N, 32 * wn), slices);
+    // ring depth of the direct path
+    static const int force_stages = getenv("KPD_SGEMM_STAGES") ? atoi(getenv("KPD_SGEMM_STAGES")) : 0;          // A/B runs
+    const long long blocks = (long long)grid.x * grid.y * grid.z;
+    (void)blocks;
+    a.stages = 3;          // deeper rings measured slower on every shape (56 -> 71 us on the node-sized gradients at 8 stages): kept as an A/B switch
+    if (force_stages) a.stages = std::min(std::max(force_stages, 3), SG_MAX_STAGES);
     KPD_REQUIRE(grid.y <= 65535u && grid.z <= 65535u, KPD_ERR_CAPACITY, "sgemm: N = %d too wide for one launch", N);
     if (wn == 4) KPD_TRY((launch_shape<1, 4>(tA, tB, grid, st, a)));
     else if (wn == 2) KPD_TRY((launch_shape<1, 2>(tA, tB, grid, st, a)));
