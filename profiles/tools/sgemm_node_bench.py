@@ -69,3 +69,17 @@ def spread():
 
 
 print(f'four products of a branch, n = {n}: one stream {timeit(serial):7.1f} us, four streams {timeit(spread):7.1f} us')
+
+# grouping the products of the (edge type, branch) pairs that share a node feature matrix: one K = 1024 / M = 1024 product instead of four
+dUc = torch.randn(n, 4 * 264, device=dev)
+Wst = torch.randn(1024, 256, device=dev)
+out1 = torch.zeros(n, 264, device=dev)[:, :256]
+G4 = torch.zeros(1024, 256, device=dev)
+cat = dUc.view(n, 4, 264)[:, :, :256]
+t4 = timeit(lambda: [hip.sgemm(dUc[:, 264 * b:264 * b + 256], W[:, :256], False, False, beta=1.0, out=out1) for b in range(4)])
+dUflat = torch.randn(n, 1024, device=dev)
+t1 = timeit(lambda: hip.sgemm(dUflat, Wst, False, False, beta=1.0, out=out1))
+print(f'input gradients: four K = 256 products {t4:7.1f} us, one K = 1024 product {t1:7.1f} us')
+t4 = timeit(lambda: [hip.sgemm(dUc[:, 264 * b:264 * b + 256], h, True, False, beta=1.0, out=Wg[:, :256], workspace=ws) for b in range(4)])
+t1 = timeit(lambda: hip.sgemm(dUflat, h, True, False, beta=1.0, out=G4, workspace=ws))
+print(f'weight gradients: four M = 256 products {t4:7.1f} us, one M = 1024 product {t1:7.1f} us')
