@@ -373,11 +373,12 @@ kpd_status kpd_ot_emd_uniform(int32_t n_problems, const int32_t *n, const int32_
  * reference gets from torch.nn.Linear / autograd inside models/dynamics.py:37-79, models/gvp.py:166-222 during train.py; exported so
  * that its parity against a plain fp32 product can be tested on its own.  `workspace` (device floats, may be NULL): scratch for the
  * partial products of a K-dominated shape (a weight gradient, K = edge count), which is then cut along K over the grid and summed in a
- * fixed order -- never with atomics.
+ * fixed order -- never with atomics.  `colsum` (may be NULL; A^T B products only): colsum[m] += sum_k A[k][m] in the same pass over A
+ * -- the bias gradient of the Linear whose weight gradient the product is.
  * ------------------------------------------------------------------------------------- */
 kpd_status kpd_sgemm(int32_t trans_a, int32_t trans_b, int32_t M, int32_t N, int32_t K, float alpha, const float *A, int32_t lda,
-                     const float *B, int32_t ldb, float beta, float *C, int32_t ldc, float *workspace, int64_t workspace_floats,
-                     void *stream);
+                     const float *B, int32_t ldb, float beta, float *C, int32_t ldc, float *colsum, float *workspace,
+                     int64_t workspace_floats, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Reverse-diffusion update around the denoiser.  Replaces the elementwise part of

@@ -558,14 +558,12 @@ kpd_status mlp_bwd(kpd_egnn_trainer *T, const MlpParams &p, const float *x, int 
         hipLaunchKernelGGL(k_silu_bwd, grid1(tot), dim3(256), 0, T->st, dout, pre2, tot, p.fout, ldo);
         KPD_LAUNCH_CHECK();
     }
-    KPD_TRY(colsum_acc(T, n, p.fout, dout, ldo, p.b2.g));
-    if (p.W2.g) KPD_TRY(grad_gemm(T, p.fout, p.hid, n, dout, ldo, act1, ld1, p.W2.g, p.hid));
+    KPD_TRY(grad_gemm(T, p.fout, p.hid, n, dout, ldo, act1, ld1, p.W2.g, p.hid, p.b2.g));
     KPD_TRY(gemm(T, false, false, n, p.hid, p.fout, dout, ldo, p.W2.w, p.hid, 0.0f, dact1, ld1));
     const long long tot = (long long)n * p.hid;
     hipLaunchKernelGGL(k_silu_bwd, grid1(tot), dim3(256), 0, T->st, dact1, pre1, tot, p.hid, ld1);
     KPD_LAUNCH_CHECK();
-    KPD_TRY(colsum_acc(T, n, p.hid, dact1, ld1, p.b0.g));
-    if (p.W0.g) KPD_TRY(grad_gemm(T, p.hid, p.fin, n, dact1, ld1, x, ldx, p.W0.g, p.fin));
+    KPD_TRY(grad_gemm(T, p.hid, p.fin, n, dact1, ld1, x, ldx, p.W0.g, p.fin, p.b0.g));
     if (dx) KPD_TRY(gemm(T, false, false, n, p.fin, p.hid, dact1, ld1, p.W0.w, p.fin, 0.0f, dx, lddx));
     return KPD_OK;
 }
@@ -837,18 +835,14 @@ kpd_status node_bwd(kpd_egnn_trainer *T, int l, int nt, int cur, int nxt, float 
     } else {
         KPD_HIP(hipMemcpyAsync(du, dy, (size_t)n * LD * 4, hipMemcpyDeviceToDevice, T->st));
     }
-    KPD_TRY(colsum_acc(T, n, H, du, LD, p.b2.g));
-    if (p.W2.g) KPD_TRY(grad_gemm(T, H, H, n, du, LD, T->nb[3], LD, p.W2.g, H));
+    KPD_TRY(grad_gemm(T, H, H, n, du, LD, T->nb[3], LD, p.W2.g, H, p.b2.g));
     float *dq1 = tmp;
     KPD_TRY(gemm(T, false, false, n, H, H, du, LD, p.W2.w, H, 0.0f, dq1, LD));
     const long long tot = (long long)n * H;
     hipLaunchKernelGGL(k_silu_bwd, grid1(tot), dim3(256), 0, T->st, dq1, T->nb[2], tot, H, LD);
     KPD_LAUNCH_CHECK();
-    KPD_TRY(colsum_acc(T, n, H, dq1, LD, p.b1.g));
-    if (p.W1.g) {
-        KPD_TRY(grad_gemm(T, H, H, n, dq1, LD, T->hs[nt][l], LD, p.W1.g, 2 * H));
-        KPD_TRY(grad_gemm(T, H, H, n, dq1, LD, T->hns[nt][l], LD, p.W1.g + H, 2 * H));
-    }
+    KPD_TRY(grad_gemm(T, H, H, n, dq1, LD, T->hs[nt][l], LD, p.W1.g, 2 * H, p.b1.g));
+    if (p.W1.g) KPD_TRY(grad_gemm(T, H, H, n, dq1, LD, T->hns[nt][l], LD, p.W1.g + H, 2 * H));
     // dh_in = du (residual) + dq1 W1[:, :257];  d(h_neigh / z) = dq1 W1[:, 257:]
     KPD_HIP(hipMemcpyAsync(T->dh[nxt][nt], du, (size_t)n * LD * 4, hipMemcpyDeviceToDevice, T->st));
     KPD_TRY(gemm(T, false, false, n, H, H, dq1, LD, p.W1.w, 2 * H, 1.0f, T->dh[nxt][nt], LD));

@@ -352,8 +352,7 @@ kpd_status encoder_bwd(kpd_gvp_trainer *T, int nt, int cur, float *d_h) {
     KPD_TRY(colsum_acc(T, n, S, T->gs[cur][nt], S, l.beta.g));
     hipLaunchKernelGGL(k_silu_bwd, grid1((long long)n * S), dim3(256), 0, T->st, T->tmp_s, T->enc_pre[nt], (long long)n * S, S, S);
     KPD_LAUNCH_CHECK();
-    KPD_TRY(colsum_acc(T, n, S, T->tmp_s, S, b.g));
-    if (W.g) KPD_TRY(grad_gemm(T, S, F + 1, n, T->tmp_s, S, T->enc_in[nt], F + 1, W.g, F + 1));
+    KPD_TRY(grad_gemm(T, S, F + 1, n, T->tmp_s, S, T->enc_in[nt], F + 1, W.g, F + 1, b.g));
     if (d_h) {
         KPD_TRY(gemm(T, false, false, n, F + 1, S, T->tmp_s, S, W.w, F + 1, 0.0f, T->sb, F + 1));
         hipLaunchKernelGGL(k_copy_rows, grid1((long long)n * F), dim3(256), 0, T->st, T->sb, F + 1, d_h, F, (long long)n * F, F);
@@ -629,8 +628,7 @@ extern "C" kpd_status kpd_gvp_trainer_backward(kpd_gvp_trainer *T, const float *
         Param W, b;
         KPD_TRY(param(T, p + ".to_scalar_output.weight", F, kHeadS, &W));
         KPD_TRY(param(T, p + ".to_scalar_output.bias", F, 1, &b));
-        KPD_TRY(colsum_acc(T, nl, F, d_eps_h, F, b.g));
-        if (W.g) KPD_TRY(grad_gemm(T, F, kHeadS, nl, d_eps_h, F, T->gb[nn - 1].s, kHeadS, W.g, kHeadS));
+        KPD_TRY(grad_gemm(T, F, kHeadS, nl, d_eps_h, F, T->gb[nn - 1].s, kHeadS, W.g, kHeadS, b.g));
         KPD_TRY(gemm(T, false, false, nl, kHeadS, F, d_eps_h, F, W.w, kHeadS, 0.0f, T->ds[0], kHeadS));
         KPD_HIP(hipMemcpyAsync(T->dV[0], d_eps_x, (size_t)nl * 12, hipMemcpyDeviceToDevice, st));
         for (int j = nn - 1; j >= 0; --j) {

@@ -380,13 +380,11 @@ kpd_status gvp_bwd(TT *T, const GvpP &g, int M, const float *s_in, int ld_s, con
     long long tot = (long long)M * g.vo;
     hipLaunchKernelGGL(k_gvp_gate_bwd, grid1(tot), dim3(256), 0, T->st, B.gate, B.Vu, tot, g.vo, identity ? 1 : 0, dV, T->dgate);
     KPD_LAUNCH_CHECK();
-    KPD_TRY(colsum_acc(T, M, g.vo, T->dgate, g.vo, g.bg.g));
-    KPD_TRY(grad_gemm(T, g.vo, g.so, M, T->dgate, g.vo, B.s, g.so, g.Wg.g, g.so));
+    KPD_TRY(grad_gemm(T, g.vo, g.so, M, T->dgate, g.vo, B.s, g.so, g.Wg.g, g.so, g.bg.g));       // + gate bias gradient (column sums of dgate)
     KPD_TRY(gemm(T, false, false, M, g.so, g.vo, T->dgate, g.vo, g.Wg.w, g.so, 1.0f, ds, g.so));
     tot = (long long)M * g.so;
     hipLaunchKernelGGL(k_silu_bwd, grid1(tot), dim3(256), 0, T->st, ds, B.pre, tot, g.so, g.so);
     KPD_LAUNCH_CHECK();
-    KPD_TRY(colsum_acc(T, M, g.so, ds, g.so, g.bs.g));
     if (s_in) {
         if (g.Ws.g) KPD_TRY(grad_gemm(T, g.so, g.si, M, ds, g.so, s_in, ld_s, g.Ws.g, g.si + g.h));
         if (ds_in) {
@@ -394,7 +392,8 @@ kpd_status gvp_bwd(TT *T, const GvpP &g, int M, const float *s_in, int ld_s, con
             else KPD_TRY(gemm(T, false, false, M, g.si, g.so, ds, g.so, g.Ws.w, g.si + g.h, 0.0f, ds_in, g.si));
         }
     }
-    if (g.Ws.g) KPD_TRY(grad_gemm(T, g.so, g.h, M, ds, g.so, B.sh, g.h, g.Ws.g + g.si, g.si + g.h));
+    // the sh block of to_feats_out, with the bias gradient (column sums of ds) riding along
+    KPD_TRY(grad_gemm(T, g.so, g.h, M, ds, g.so, B.sh, g.h, g.Ws.g ? g.Ws.g + g.si : nullptr, g.si + g.h, g.bs.g));
     KPD_TRY(gemm(T, false, false, M, g.h, g.so, ds, g.so, g.Ws.w + g.si, g.si + g.h, 0.0f, T->dsh, g.h));
     KPD_TRY(gemm(T, false, true, 3 * M, g.h, g.vo, dV, g.vo, g.Wu.w, g.vo, 0.0f, T->dVh, g.h));
     tot = (long long)M * 3 * g.h;

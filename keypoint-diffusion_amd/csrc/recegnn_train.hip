@@ -426,15 +426,13 @@ kpd_status conv_bwd(kpd_recegnn_trainer *T, int i, float *gh_out, const float *g
     }
     hipLaunchKernelGGL(k_rc_silu, grid1((long long)n * H), dim3(256), 0, st, T->npre[i], (long long)n * H, T->na);      // na again
     KPD_LAUNCH_CHECK();
-    KPD_TRY(colsum_acc(T, n, Dout, d_hn, Dout, p.bn2.g));
-    if (p.Wn2.g) KPD_TRY(grad_gemm(T, Dout, H, n, d_hn, Dout, T->na, H, p.Wn2.g, H));
+    KPD_TRY(grad_gemm(T, Dout, H, n, d_hn, Dout, T->na, H, p.Wn2.g, H, p.bn2.g));
     KPD_TRY(gemm(T, false, false, n, H, Dout, d_hn, Dout, p.Wn2.w, H, 0.0f, T->gn2, H));           // d na
     hipLaunchKernelGGL(k_silu_bwd, grid1((long long)n * H), dim3(256), 0, st, T->gn2, T->npre[i], (long long)n * H, H, H);
     KPD_LAUNCH_CHECK();
-    KPD_TRY(colsum_acc(T, n, H, T->gn2, H, p.bn1.g));
     hipLaunchKernelGGL(k_rc_cat2, grid1((long long)n * (Din + H)), dim3(256), 0, st, T->hs[i], Din, T->hneigh[i], H, (long long)n * (Din + H), T->cat);
     KPD_LAUNCH_CHECK();
-    if (p.Wn1.g) KPD_TRY(grad_gemm(T, H, Din + H, n, T->gn2, H, T->cat, Din + H, p.Wn1.g, Din + H));
+    KPD_TRY(grad_gemm(T, H, Din + H, n, T->gn2, H, T->cat, Din + H, p.Wn1.g, Din + H, p.bn1.g));
     KPD_TRY(gemm(T, false, false, n, Din + H, H, T->gn2, H, p.Wn1.w, Din + H, 0.0f, T->gcat, Din + H));       // d [h | h_neigh]
     hipLaunchKernelGGL(k_copy_rows, grid1((long long)n * Din), dim3(256), 0, st, T->gcat, Din + H, gh_in, Din, (long long)n * Din, Din);
     KPD_LAUNCH_CHECK();
@@ -456,13 +454,11 @@ kpd_status conv_bwd(kpd_recegnn_trainer *T, int i, float *gh_out, const float *g
     const long long tot = (long long)E * H;
     hipLaunchKernelGGL(k_silu_bwd, grid1(tot), dim3(256), 0, st, T->dE, T->pre2, tot, H, H);              // d pre2
     KPD_LAUNCH_CHECK();
-    KPD_TRY(colsum_acc(T, E, H, T->dE, H, p.b2.g));
-    if (p.W2.g) KPD_TRY(grad_gemm(T, H, H, E, T->dE, H, T->a1, H, p.W2.g, H));
+    KPD_TRY(grad_gemm(T, H, H, E, T->dE, H, T->a1, H, p.W2.g, H, p.b2.g));
     KPD_TRY(gemm(T, false, false, E, H, H, T->dE, H, p.W2.w, H, 0.0f, T->dE2, H));                        // d a1
     hipLaunchKernelGGL(k_silu_bwd, grid1(tot), dim3(256), 0, st, T->dE2, T->pre1, tot, H, H);             // d pre1
     KPD_LAUNCH_CHECK();
-    KPD_TRY(colsum_acc(T, E, H, T->dE2, H, p.b1.g));
-    if (p.W1.g) KPD_TRY(grad_gemm(T, H, fw, E, T->dE2, H, T->f, fw, p.W1.g, fw));
+    KPD_TRY(grad_gemm(T, H, fw, E, T->dE2, H, T->f, fw, p.W1.g, fw, p.b1.g));
     KPD_TRY(gemm(T, false, false, E, fw, H, T->dE2, H, p.W1.w, fw, 0.0f, T->df, fw));                     // d f
     // coordinate messages: d msg_x[e] = gx_out[dst] / z
     if (!T->cfg.fix_pos) {
@@ -472,8 +468,7 @@ kpd_status conv_bwd(kpd_recegnn_trainer *T, int i, float *gh_out, const float *g
         KPD_TRY(gemv_t_acc(T, E, H, T->ca, H, T->dc, p.w3.g, 1));
         hipLaunchKernelGGL(k_rc_dcpre, grid1(tot), dim3(256), 0, st, T->dc, p.w3.w, T->cpre, tot, H, T->dE);
         KPD_LAUNCH_CHECK();
-        KPD_TRY(colsum_acc(T, E, H, T->dE, H, p.bc1.g));
-        if (p.Wc1.g) KPD_TRY(grad_gemm(T, H, fw, E, T->dE, H, T->f, fw, p.Wc1.g, fw));
+        KPD_TRY(grad_gemm(T, H, fw, E, T->dE, H, T->f, fw, p.Wc1.g, fw, p.bc1.g));
         KPD_TRY(gemm(T, false, false, E, fw, H, T->dE, H, p.Wc1.w, fw, 1.0f, T->df, fw));
     }
     // f = [h_src | h_dst | r | a]: node features by source (grouped index) and destination (contiguous), then the geometry
@@ -688,8 +683,7 @@ extern "C" kpd_status kpd_recegnn_trainer_backward(kpd_recegnn_trainer *T, const
         } else KPD_HIP(hipMemcpyAsync(T->gk1, d_kp_h, (size_t)n_kp * D * 4, hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(k_silu_bwd, grid1((long long)n_kp * D), dim3(256), 0, st, T->gk1, T->fpre, (long long)n_kp * D, D, D);
         KPD_LAUNCH_CHECK();
-        KPD_TRY(colsum_acc(T, n_kp, D, T->gk1, D, bp.g));
-        if (Wp.g) KPD_TRY(grad_gemm(T, D, D + k, n_kp, T->gk1, D, T->fin, D + k, Wp.g, D + k));
+        KPD_TRY(grad_gemm(T, D, D + k, n_kp, T->gk1, D, T->fin, D + k, Wp.g, D + k, bp.g));
         KPD_TRY(gemm(T, false, false, n_kp, D + k, D, T->gk1, D, Wp.w, D + k, 0.0f, T->gk2, D + k));      // d [h_m | d_k]
         hipLaunchKernelGGL(k_rk_feat_dh, dim3(n_rec), dim3(256), 0, st, T->gk2, T->scsr_rk.perm, T->scsr_rk.rowptr, k, D, D + k, T->gh[cur]);
         KPD_LAUNCH_CHECK();

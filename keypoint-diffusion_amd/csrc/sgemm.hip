@@ -42,6 +42,8 @@ struct SgemmArgs {
     int vecA, vecB;         // base pointer 16-B aligned and leading dimension a multiple of 4
     int direct;             // 0: never take the global->LDS path (KPD_SGEMM_DIRECT=0, A/B runs)
     int stages;             // LDS stages of the direct path (3 .. SG_MAX_STAGES)
+    float *colsum;          // op(A) = A^T only: colsum[m] += sum_k A[k][m] (the bias gradient that goes with a weight gradient), or null
+    float *cs_part;         // split-K: per-slice partial column sums [slice][M] instead (summed by k_sgemm_reduce)
 };
 
 // x or +0.0 by a bit mask: the value is consumed on both outcomes, so the load stays unconditional (a select lets the compiler sink the
@@ -165,6 +167,16 @@ __global__ __launch_bounds__(256, 2) void k_sgemm(SgemmArgs a) {
                 for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
     };
+    // column sums of the A operand ride along in the workgroups of the first column tile: thread m adds the slab's 16 values of its column
+    // from the LDS tile ([k][m] rows: conflict-free), in slab order
+    const bool sum_cols = TA && a.colsum != nullptr && blockIdx.y == 0 && tid < BM;
+    float cs = 0.0f;
+    auto add_cols = [&](const float *st) {
+        if (TA && sum_cols) {
+#pragma unroll
+            for (int k = 0; k < SG_BK; ++k) cs += st[LA::at(tid, k)];
+        }
+    };
     LA la;
     LB lb;
     auto fetch = [&](int kt) {
@@ -219,6 +231,7 @@ __global__ __launch_bounds__(256, 2) void k_sgemm(SgemmArgs a) {
             if (kt + stages - 1 < nk_full) issue(kt + stages - 1);
             __builtin_amdgcn_sched_barrier(0);
             compute(smem + (kt % stages) * STAGE);
+            add_cols(smem + (kt % stages) * STAGE);
             __builtin_amdgcn_sched_barrier(0);
             // issued so far: slabs 0 .. min(kt + stages - 1, nk_full - 1); needed next: kt + 1
             wait_behind(max(0, min(kt + stages - 1, nk_full - 1) - (kt + 1)));
@@ -237,9 +250,14 @@ __global__ __launch_bounds__(256, 2) void k_sgemm(SgemmArgs a) {
             float *cur = ((kt - done) & 1) ? st1 : st0, *nxt = ((kt - done) & 1) ? st0 : st1;
             if (kt + 1 < nk) fetch(kt + 1);
             compute(cur);
+            add_cols(cur);
             if (kt + 1 < nk) stash(kt + 1, nxt);
             __syncthreads();
         }
+    }
+    if (TA && sum_cols && m0 + tid < a.M) {
+        if (a.cs_part) a.cs_part[(size_t)blockIdx.z * a.M + m0 + tid] = cs;
+        else a.colsum[m0 + tid] += cs;              // one workgroup per column when K is not split
     }
     // accumulator element r of lane (col, half): row 8 (r / 4) + 4 half + r % 4, column col.  beta != 0: the 16 old values of a block are
     // read together (clamped rows) before any of them is needed
@@ -290,7 +308,9 @@ kpd_status launch_shape(bool tA, bool tB, dim3 grid, hipStream_t st, const Sgemm
 // accumulators are added in wave order through LDS, and the workgroup writes one partial [M,N] for k_sgemm_reduce.
 __global__ __launch_bounds__(256) void k_sgemm_tn_skinny(SgemmArgs a) {
     __shared__ float red[4][32 * 33];
+    __shared__ float red_cs[4][32];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 31, half = lane >> 5;
+    float cs = 0.0f;                                   // column sums of A over this lane's rows (colsum requested)
     // rows of this wave: a.k_chunk rows per workgroup, a quarter (even) per wave
     const int per_wave = a.k_chunk / 4;
     const int kbeg = min(a.K, (int)blockIdx.x * a.k_chunk + wave * per_wave), kend = min(a.K, kbeg + per_wave);
@@ -310,13 +330,21 @@ __global__ __launch_bounds__(256) void k_sgemm_tn_skinny(SgemmArgs a) {
             y[u] = pb[(size_t)(k + 2 * u + half) * a.ldb];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(masked(x[u], va), masked(y[u], vb), acc, 0, 0, 0);
+        for (int u = 0; u < 8; ++u) {
+            const float xa = masked(x[u], va);
+            cs += xa;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa, masked(y[u], vb), acc, 0, 0, 0);
+        }
     }
     for (; k < kend; k += 2) {
         const int kk = min(k + half, a.K - 1);
         const bool in = k + half < kend;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(masked(pa[(size_t)kk * a.lda], va && in), masked(pb[(size_t)kk * a.ldb], vb && in), acc, 0, 0, 0);
+        const float xa = masked(pa[(size_t)kk * a.lda], va && in);
+        cs += xa;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa, masked(pb[(size_t)kk * a.ldb], vb && in), acc, 0, 0, 0);
     }
+    cs += __shfl_xor(cs, 32);                           // even rows + odd rows of this wave
+    if (half == 0) red_cs[wave][col] = cs;
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[wave][(8 * (r >> 2) + 4 * half + (r & 3)) * 33 + col] = acc[r];
     __syncthreads();
@@ -325,11 +353,18 @@ __global__ __launch_bounds__(256) void k_sgemm_tn_skinny(SgemmArgs a) {
         const int m = i / a.N, n = i - m * a.N;
         C[i] = a.alpha * (((red[0][m * 33 + n] + red[1][m * 33 + n]) + red[2][m * 33 + n]) + red[3][m * 33 + n]);
     }
+    if (a.cs_part && tid < a.M) a.cs_part[(size_t)blockIdx.x * a.M + tid] = ((red_cs[0][tid] + red_cs[1][tid]) + red_cs[2][tid]) + red_cs[3][tid];
 }
 
 // C = sum of the split-K partial products (in slice order) + beta C; eight loads in flight per thread
-__global__ void k_sgemm_reduce(const float *__restrict__ part, int slices, int M, int N, float beta, float *__restrict__ C, int ldc) {
+__global__ void k_sgemm_reduce(const float *__restrict__ part, int slices, int M, int N, float beta, float *__restrict__ C, int ldc,
+                               const float *__restrict__ cs_part, float *__restrict__ colsum) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cs_part && i < M) {                             // the column sums that rode along: slices in order, added to what colsum holds
+        float s = 0.0f;
+        for (int k = 0; k < slices; ++k) s += cs_part[(size_t)k * M + i];
+        colsum[i] += s;
+    }
     if (i >= M * N) return;
     const size_t stride = (size_t)M * N;
     const float *p = part + i;
@@ -372,34 +407,38 @@ int sgemm_split_slices(int M, int N, int K) {
 }
 
 kpd_status sgemm(bool tA, bool tB, int M, int N, int K, float alpha, const float *A, int lda, const float *B, int ldb, float beta,
-                 float *C, int ldc, hipStream_t st, float *part, size_t part_floats) {
+                 float *C, int ldc, hipStream_t st, float *part, size_t part_floats, float *colsum) {
     if (M <= 0 || N <= 0) return KPD_OK;
     KPD_REQUIRE(A && B && C && K > 0, KPD_ERR_INVALID, "sgemm: null operand or empty K (M=%d N=%d K=%d)", M, N, K);
+    KPD_REQUIRE(!colsum || (tA && !tB), KPD_ERR_INVALID, "sgemm: column sums ride along with A^T B products only");
     SgemmArgs a;
+    a.colsum = colsum; a.cs_part = nullptr;
     a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.alpha = alpha; a.beta = beta;
     a.vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
     a.vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
     a.k_chunk = cdiv(K, SG_BK) * SG_BK;
     a.c_slice = 0;
-    if (tA && !tB && M <= 32 && N <= 32 && K >= 8192 && part && part_floats >= (size_t)cu_count() * M * N) {
+    if (tA && !tB && M <= 32 && N <= 32 && K >= 8192 && part && part_floats >= (size_t)cu_count() * (M * N + M)) {
         // one partial per workgroup, about one workgroup per CU; rows per workgroup a multiple of 8 (even quarters)
         const int groups = std::min(cu_count(), cdiv(K, 2048));
         a.k_chunk = cdiv(cdiv(K, groups), 8) * 8;
         const int used = cdiv(K, a.k_chunk);
         a.C = part; a.ldc = N; a.beta = 0.0f; a.c_slice = (long long)M * N;
+        if (colsum) a.cs_part = part + (size_t)used * M * N;
         hipLaunchKernelGGL(k_sgemm_tn_skinny, dim3(used), dim3(256), 0, st, a);
         KPD_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_sgemm_reduce, dim3(cdiv(M * N, 256)), dim3(256), 0, st, part, used, M, N, beta, C, ldc);
+        hipLaunchKernelGGL(k_sgemm_reduce, dim3(cdiv(M * N, 256)), dim3(256), 0, st, part, used, M, N, beta, C, ldc, (const float *)a.cs_part, colsum);
         KPD_LAUNCH_CHECK();
         return KPD_OK;
     }
-    int slices = part ? (int)std::min<size_t>(sgemm_split_slices(M, N, K), part_floats / ((size_t)M * N)) : 1;
+    int slices = part ? (int)std::min<size_t>(sgemm_split_slices(M, N, K), part_floats / ((size_t)M * N + M)) : 1;
     if (slices > 1) {
         a.k_chunk = cdiv(cdiv(K, slices), SG_BK) * SG_BK;
         slices = cdiv(K, a.k_chunk);
     }
     if (slices > 1) {
         a.C = part; a.ldc = N; a.beta = 0.0f; a.c_slice = (long long)M * N;
+        if (colsum) a.cs_part = part + (size_t)slices * M * N;
     } else {
         slices = 1;
         a.k_chunk = cdiv(K, SG_BK) * SG_BK;
@@ -426,7 +465,7 @@ kpd_status sgemm(bool tA, bool tB, int M, int N, int K, float alpha, const float
     else KPD_TRY((launch_shape<1, 1>(tA, tB, grid, st, a)));
     KPD_LAUNCH_CHECK();
     if (slices > 1) {
-        hipLaunchKernelGGL(k_sgemm_reduce, dim3(cdiv(M * N, 256)), dim3(256), 0, st, part, slices, M, N, beta, C, ldc);
+        hipLaunchKernelGGL(k_sgemm_reduce, dim3(cdiv(M * N, 256)), dim3(256), 0, st, part, slices, M, N, beta, C, ldc, (const float *)a.cs_part, colsum);
         KPD_LAUNCH_CHECK();
     }
     return KPD_OK;
@@ -441,19 +480,20 @@ kpd_status sgemv_rows(int M, int K, const float *A, int lda, const float *x, int
 
 // include/kpd.h
 extern "C" kpd_status kpd_sgemm(int32_t trans_a, int32_t trans_b, int32_t M, int32_t N, int32_t K, float alpha, const float *A, int32_t lda,
-                                const float *B, int32_t ldb, float beta, float *C, int32_t ldc, float *workspace, int64_t workspace_floats,
-                                void *stream) {
+                                const float *B, int32_t ldb, float beta, float *C, int32_t ldc, float *colsum, float *workspace,
+                                int64_t workspace_floats, void *stream) {
     KPD_REQUIRE(M >= 0 && N >= 0 && K >= 0, KPD_ERR_INVALID, "kpd_sgemm: negative size");
     KPD_REQUIRE(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N) && ldc >= N, KPD_ERR_INVALID, "kpd_sgemm: leading dimension too small");
     KPD_REQUIRE(workspace_floats >= 0 && (workspace || workspace_floats == 0), KPD_ERR_INVALID, "kpd_sgemm: workspace size without a workspace");
     if (M == 0 || N == 0) return KPD_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    KPD_REQUIRE(!colsum || (trans_a && !trans_b), KPD_ERR_INVALID, "kpd_sgemm: colsum goes with A^T B products only");
     if (K == 0) {
         KPD_REQUIRE(beta == 0.0f || beta == 1.0f, KPD_ERR_INVALID, "kpd_sgemm: K = 0 needs beta 0 or 1");
         if (beta == 0.0f) KPD_HIP(hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, M, st));
         return KPD_OK;
     }
-    return sgemm(trans_a != 0, trans_b != 0, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, st, workspace, (size_t)workspace_floats);
+    return sgemm(trans_a != 0, trans_b != 0, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, st, workspace, (size_t)workspace_floats, colsum);
 }
 
 }  // namespace kpd

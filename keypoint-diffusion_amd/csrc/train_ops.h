@@ -331,9 +331,12 @@ constexpr size_t GRAD_PART_FLOATS = (size_t)128 * 256 * 256;     // split-K scra
 
 // weight gradient C[M,N] += A[K,M]^T B[K,N] with K = rows of a tall activation matrix: the output is a few tiles only, so K is
 // cut into slices (grid.z of one launch, partial products in scratch) that are summed in slice order -- no atomics
-kpd_status grad_gemm(TrainCtx *T, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc) {
-    if (!C || M == 0 || N == 0 || K == 0) return KPD_OK;
-    return sgemm(true, false, M, N, K, 1.0f, A, lda, B, ldb, 1.0f, C, ldc, T->st, T->part, T->part_floats);
+// bias_grad (optional): += the column sums of A, i.e. the gradient of the Linear's bias, in the same pass (replaces a colsum_acc over A)
+kpd_status grad_gemm(TrainCtx *T, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
+                     float *bias_grad = nullptr) {
+    if (M == 0 || K == 0) return KPD_OK;
+    if (!C || N == 0) return bias_grad ? colsum_acc(T, K, M, A, lda, bias_grad) : KPD_OK;
+    return sgemm(true, false, M, N, K, 1.0f, A, lda, B, ldb, 1.0f, C, ldc, T->st, T->part, T->part_floats, bias_grad);
 }
 
 kpd_status param(TrainCtx *T, const std::string &name, int rows, int cols, Param *out) {

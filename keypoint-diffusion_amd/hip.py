@@ -169,7 +169,7 @@ def lib():
     L.kpd_recegnn_trainer_backward.argtypes = [C.c_void_p] + [C.c_void_p] * 3
     L.kpd_ot_emd_uniform.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
     L.kpd_sgemm.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
-                            C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
+                            C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     L.kpd_rec_graph_scratch_bytes.argtypes = [C.c_int32, C.c_int32]
     L.kpd_rec_graph_scratch_bytes.restype = C.c_int64
     L.kpd_build_rec_graph.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p,
@@ -801,10 +801,11 @@ def ot_emd_uniform(costs, n_threads: int = 0):
 
 
 def sgemm(a: torch.Tensor, b: torch.Tensor, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, out: torch.Tensor = None,
-          workspace: torch.Tensor = None) -> torch.Tensor:
+          workspace: torch.Tensor = None, colsum: torch.Tensor = None) -> torch.Tensor:
     """out = alpha op(a) op(b) + beta out through kpd_sgemm (the GEMM of the training engines).  a, b, out: 2-D fp32 device tensors whose
     last dimension is contiguous; row strides and storage offsets are passed as they are (views of wider arrays are the tested case).
-    `workspace`: contiguous fp32 device scratch that lets a K-dominated product be split along K."""
+    `workspace`: contiguous fp32 device scratch that lets a K-dominated product be split along K.  `colsum` (trans_a and not trans_b):
+    contiguous [M] tensor that receives += the column sums of a."""
     for t, name in ((a, 'a'), (b, 'b')):
         if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and (t.shape[1] <= 1 or t.stride(1) == 1)):
             raise KpdError(f'sgemm: {name} must be a 2-D fp32 device tensor with a contiguous last dimension')
@@ -818,7 +819,8 @@ def sgemm(a: torch.Tensor, b: torch.Tensor, trans_a=False, trans_b=False, alpha=
         raise KpdError('sgemm: out must be an fp32 device tensor [M, N] with a contiguous last dimension')
     ld = lambda t: int(t.stride(0)) if t.shape[0] > 1 else max(int(t.shape[1]), 1)
     check(lib().kpd_sgemm(int(trans_a), int(trans_b), M, N, K, float(alpha), a.data_ptr(), ld(a), b.data_ptr(), ld(b), float(beta),
-                          out.data_ptr(), ld(out), workspace.data_ptr() if workspace is not None else None,
+                          out.data_ptr(), ld(out), colsum.data_ptr() if colsum is not None else None,
+                          workspace.data_ptr() if workspace is not None else None,
                           int(workspace.numel()) if workspace is not None else 0, _stream()))
     return out
 

@@ -61,3 +61,26 @@ def test_sgemm_is_bitwise_repeatable_and_independent_of_other_rows():
     assert torch.equal(o1, o2)
     part = hip.sgemm(a[1000:1200], b, trans_b=True)          # other tile position, other tile shape: same bits per element
     assert torch.equal(part, o1[1000:1200])
+
+
+@pytest.mark.parametrize('M,N,K', [(256, 256, 50000), (257, 300, 777), (16, 16, 200000), (16, 256, 90000), (100, 7, 33), (130, 64, 5000)])
+@pytest.mark.parametrize('layout', ['aligned', 'odd_ld'])
+def test_column_sums_ride_along_with_a_weight_gradient(M, N, K, layout):
+    """colsum += the column sums of A in the pass that computes A^T B (bias gradient with the weight gradient), with and without the
+    split along K, through the narrow-gradient kernel too; bitwise repeatable."""
+    dev = torch.device('cuda:0')
+    gen = torch.Generator().manual_seed(2)
+    extra = 0 if layout == 'aligned' else 1
+    a, b = _operand(K, M, extra, 0, gen, dev), _operand(K, N, extra, 0, gen, dev)
+    ws = torch.full((1 << 23,), float('nan'), device=dev)
+    for workspace in (None, ws):
+        cs = torch.full((M,), 3.0, device=dev)
+        out = hip.sgemm(a, b, True, False, workspace=workspace, colsum=cs)
+        ref_cs = 3.0 + a.double().sum(0)
+        tol = 1e-6 + 4e-7 * K ** 0.5
+        assert ((cs.double() - ref_cs).abs().max() / ref_cs.abs().max().clamp_min(1.0)) < tol
+        ref = a.double().T @ b.double()
+        assert ((out.double() - ref).abs().max() / ref.abs().max().clamp_min(1.0)) < tol
+        cs2 = torch.full((M,), 3.0, device=dev)
+        out2 = hip.sgemm(a, b, True, False, workspace=workspace, colsum=cs2)
+        assert torch.equal(cs, cs2) and torch.equal(out, out2)
