@@ -559,10 +559,7 @@ kpd_status mlp_bwd(kpd_egnn_trainer *T, const MlpParams &p, const float *x, int 
         KPD_LAUNCH_CHECK();
     }
     KPD_TRY(grad_gemm(T, p.fout, p.hid, n, dout, ldo, act1, ld1, p.W2.g, p.hid, p.b2.g));
-    KPD_TRY(gemm(T, false, false, n, p.hid, p.fout, dout, ldo, p.W2.w, p.hid, 0.0f, dact1, ld1));
-    const long long tot = (long long)n * p.hid;
-    hipLaunchKernelGGL(k_silu_bwd, grid1(tot), dim3(256), 0, T->st, dact1, pre1, tot, p.hid, ld1);
-    KPD_LAUNCH_CHECK();
+    KPD_TRY(gemm(T, false, false, n, p.hid, p.fout, dout, ldo, p.W2.w, p.hid, 0.0f, dact1, ld1, 1.0f, pre1));      // * SiLU'(pre1) in the epilogue
     KPD_TRY(grad_gemm(T, p.hid, p.fin, n, dact1, ld1, x, ldx, p.W0.g, p.fin, p.b0.g));
     if (dx) KPD_TRY(gemm(T, false, false, n, p.fin, p.hid, dact1, ld1, p.W0.w, p.fin, 0.0f, dx, lddx));
     return KPD_OK;
@@ -837,10 +834,7 @@ kpd_status node_bwd(kpd_egnn_trainer *T, int l, int nt, int cur, int nxt, float 
     }
     KPD_TRY(grad_gemm(T, H, H, n, du, LD, T->nb[3], LD, p.W2.g, H, p.b2.g));
     float *dq1 = tmp;
-    KPD_TRY(gemm(T, false, false, n, H, H, du, LD, p.W2.w, H, 0.0f, dq1, LD));
-    const long long tot = (long long)n * H;
-    hipLaunchKernelGGL(k_silu_bwd, grid1(tot), dim3(256), 0, T->st, dq1, T->nb[2], tot, H, LD);
-    KPD_LAUNCH_CHECK();
+    KPD_TRY(gemm(T, false, false, n, H, H, du, LD, p.W2.w, H, 0.0f, dq1, LD, 1.0f, T->nb[2]));                    // * SiLU'(pre) in the epilogue
     KPD_TRY(grad_gemm(T, H, H, n, dq1, LD, T->hs[nt][l], LD, p.W1.g, 2 * H, p.b1.g));
     if (p.W1.g) KPD_TRY(grad_gemm(T, H, H, n, dq1, LD, T->hns[nt][l], LD, p.W1.g + H, 2 * H));
     // dh_in = du (residual) + dq1 W1[:, :257];  d(h_neigh / z) = dq1 W1[:, 257:]

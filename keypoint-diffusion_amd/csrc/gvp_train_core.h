@@ -381,10 +381,8 @@ kpd_status gvp_bwd(TT *T, const GvpP &g, int M, const float *s_in, int ld_s, con
     hipLaunchKernelGGL(k_gvp_gate_bwd, grid1(tot), dim3(256), 0, T->st, B.gate, B.Vu, tot, g.vo, identity ? 1 : 0, dV, T->dgate);
     KPD_LAUNCH_CHECK();
     KPD_TRY(grad_gemm(T, g.vo, g.so, M, T->dgate, g.vo, B.s, g.so, g.Wg.g, g.so, g.bg.g));       // + gate bias gradient (column sums of dgate)
-    KPD_TRY(gemm(T, false, false, M, g.so, g.vo, T->dgate, g.vo, g.Wg.w, g.so, 1.0f, ds, g.so));
-    tot = (long long)M * g.so;
-    hipLaunchKernelGGL(k_silu_bwd, grid1(tot), dim3(256), 0, T->st, ds, B.pre, tot, g.so, g.so);
-    KPD_LAUNCH_CHECK();
+    // ds = (ds + dgate Wg) * SiLU'(pre): the activation derivative in the product's epilogue
+    KPD_TRY(gemm(T, false, false, M, g.so, g.vo, T->dgate, g.vo, g.Wg.w, g.so, 1.0f, ds, g.so, 1.0f, B.pre));
     if (s_in) {
         if (g.Ws.g) KPD_TRY(grad_gemm(T, g.so, g.si, M, ds, g.so, s_in, ld_s, g.Ws.g, g.si + g.h));
         if (ds_in) {

@@ -427,9 +427,7 @@ kpd_status conv_bwd(kpd_recegnn_trainer *T, int i, float *gh_out, const float *g
     hipLaunchKernelGGL(k_rc_silu, grid1((long long)n * H), dim3(256), 0, st, T->npre[i], (long long)n * H, T->na);      // na again
     KPD_LAUNCH_CHECK();
     KPD_TRY(grad_gemm(T, Dout, H, n, d_hn, Dout, T->na, H, p.Wn2.g, H, p.bn2.g));
-    KPD_TRY(gemm(T, false, false, n, H, Dout, d_hn, Dout, p.Wn2.w, H, 0.0f, T->gn2, H));           // d na
-    hipLaunchKernelGGL(k_silu_bwd, grid1((long long)n * H), dim3(256), 0, st, T->gn2, T->npre[i], (long long)n * H, H, H);
-    KPD_LAUNCH_CHECK();
+    KPD_TRY(gemm(T, false, false, n, H, Dout, d_hn, Dout, p.Wn2.w, H, 0.0f, T->gn2, H, 1.0f, T->npre[i]));           // d npre = (d na) * SiLU'
     hipLaunchKernelGGL(k_rc_cat2, grid1((long long)n * (Din + H)), dim3(256), 0, st, T->hs[i], Din, T->hneigh[i], H, (long long)n * (Din + H), T->cat);
     KPD_LAUNCH_CHECK();
     KPD_TRY(grad_gemm(T, H, Din + H, n, T->gn2, H, T->cat, Din + H, p.Wn1.g, Din + H, p.bn1.g));
@@ -455,9 +453,7 @@ kpd_status conv_bwd(kpd_recegnn_trainer *T, int i, float *gh_out, const float *g
     hipLaunchKernelGGL(k_silu_bwd, grid1(tot), dim3(256), 0, st, T->dE, T->pre2, tot, H, H);              // d pre2
     KPD_LAUNCH_CHECK();
     KPD_TRY(grad_gemm(T, H, H, E, T->dE, H, T->a1, H, p.W2.g, H, p.b2.g));
-    KPD_TRY(gemm(T, false, false, E, H, H, T->dE, H, p.W2.w, H, 0.0f, T->dE2, H));                        // d a1
-    hipLaunchKernelGGL(k_silu_bwd, grid1(tot), dim3(256), 0, st, T->dE2, T->pre1, tot, H, H);             // d pre1
-    KPD_LAUNCH_CHECK();
+    KPD_TRY(gemm(T, false, false, E, H, H, T->dE, H, p.W2.w, H, 0.0f, T->dE2, H, 1.0f, T->pre1));         // d pre1 = (d a1) * SiLU'(pre1)
     KPD_TRY(grad_gemm(T, H, fw, E, T->dE2, H, T->f, fw, p.W1.g, fw, p.b1.g));
     KPD_TRY(gemm(T, false, false, E, fw, H, T->dE2, H, p.W1.w, fw, 0.0f, T->df, fw));                     // d f
     // coordinate messages: d msg_x[e] = gx_out[dst] / z
@@ -709,9 +705,7 @@ extern "C" kpd_status kpd_recegnn_trainer_backward(kpd_recegnn_trainer *T, const
         KPD_TRY(grad_gemm(T, D, D, n_kp, dft_dst, D, T->kp_h0, D, Wf.g, D));
     }
     KPD_TRY(gemm(T, false, false, n_rec, D, D, dft_src, D, Wf.w, D, 1.0f, T->gh[cur], D));
-    KPD_TRY(gemm(T, false, false, n_kp, D, D, dft_dst, D, Wf.w, D, 0.0f, T->big, D));                 // d kp_h0 as [B, D K]
-    hipLaunchKernelGGL(k_silu_bwd, grid1((long long)B * D * K), dim3(256), 0, st, T->big, T->kpe_pre, (long long)B * D * K, D * K, D * K);
-    KPD_LAUNCH_CHECK();
+    KPD_TRY(gemm(T, false, false, n_kp, D, D, dft_dst, D, Wf.w, D, 0.0f, T->big, D, 1.0f, T->kpe_pre));  // d kp_h0 as [B, D K], * SiLU'(kpe_pre: same rows)
     if (bk.g)
         for (int c0 = 0; c0 < D * K; c0 += COLSUM_LD) KPD_TRY(colsum_acc(T, B, std::min(COLSUM_LD, D * K - c0), T->big + c0, D * K, bk.g + c0));
     if (Wk.g) KPD_TRY(gemm(T, true, false, D * K, D, B, T->big, D * K, T->gmean, D, 1.0f, Wk.g, D));

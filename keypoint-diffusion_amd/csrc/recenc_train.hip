@@ -707,9 +707,7 @@ extern "C" kpd_status kpd_recenc_trainer_backward(kpd_recenc_trainer *T, const f
         hipLaunchKernelGGL(k_silu_bwd, grid1(tot), dim3(256), 0, st, T->tmp_s, T->e_pre1, tot, S, S);
         KPD_LAUNCH_CHECK();
         KPD_TRY(grad_gemm(T, S, S, n_rec, T->tmp_s, S, T->e_a0, S, W1.g, S, b1.g));
-        KPD_TRY(gemm(T, false, false, n_rec, S, S, T->tmp_s, S, W1.w, S, 0.0f, T->sb, S));
-        hipLaunchKernelGGL(k_silu_bwd, grid1(tot), dim3(256), 0, st, T->sb, T->e_pre0, tot, S, S);
-        KPD_LAUNCH_CHECK();
+        KPD_TRY(gemm(T, false, false, n_rec, S, S, T->tmp_s, S, W1.w, S, 0.0f, T->sb, S, 1.0f, T->e_pre0));      // * SiLU'(pre0) in the epilogue
         KPD_TRY(grad_gemm(T, S, F, n_rec, T->sb, S, bt.rec_h, F, W0.g, F, b0.g));
     }
     T->have_forward = false;

@@ -9,9 +9,12 @@ constexpr int SGEMM_MAX_SPLIT = 256;
 // row-major C[M,N] = alpha op(A) op(B) + beta C.  With a scratch buffer `part`, a product whose output is a few tiles only (weight
 // gradients: K = edge count) is cut along K into slices computed by grid.z of one launch and summed in slice order (no atomics).
 kpd_status sgemm(bool tA, bool tB, int M, int N, int K, float alpha, const float *A, int lda, const float *B, int ldb, float beta,
-                 float *C, int ldc, hipStream_t st, float *part = nullptr, size_t part_floats = 0, float *colsum = nullptr);
+                 float *C, int ldc, hipStream_t st, float *part = nullptr, size_t part_floats = 0, float *colsum = nullptr,
+                 const float *silu_pre = nullptr);
 // colsum (A^T B products only): colsum[m] += sum_k A[k][m] in the same pass over A -- the bias gradient of the Linear whose weight
-// gradient the product is; summed in slab / slice order like the product itself
+// gradient the product is; summed in slab / slice order like the product itself.
+// silu_pre: C = (alpha op(A) op(B) + beta C) * SiLU'(silu_pre[m][n]), silu_pre laid out like C -- the backward of an activation whose
+// pre-activation was kept, fused into the product that produces its upstream gradient
 // slices that give every CU about two workgroups for a [M,N] output, bounded by K / 256
 int sgemm_split_slices(int M, int N, int K);
 // y[m * incy] = beta y + sum_k A[m][k] x[k * incx]

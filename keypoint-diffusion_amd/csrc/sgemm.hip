@@ -44,6 +44,7 @@ struct SgemmArgs {
     int stages;             // LDS stages of the direct path (3 .. SG_MAX_STAGES)
     float *colsum;          // op(A) = A^T only: colsum[m] += sum_k A[k][m] (the bias gradient that goes with a weight gradient), or null
     float *cs_part;         // split-K: per-slice partial column sums [slice][M] instead (summed by k_sgemm_reduce)
+    const float *silu_pre;  // epilogue: C = (alpha AB + beta C) * SiLU'(silu_pre[m][n]) (same leading dimension as C), or null
 };
 
 // x or +0.0 by a bit mask: the value is consumed on both outcomes, so the load stays unconditional (a select lets the compiler sink the
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void k_sgemm(SgemmArgs a) {
     }
     // accumulator element r of lane (col, half): row 8 (r / 4) + 4 half + r % 4, column col.  beta != 0: the 16 old values of a block are
     // read together (clamped rows) before any of them is needed
-    const bool accumulate = a.beta != 0.0f;
+    const bool accumulate = a.beta != 0.0f, silu_bwd = a.silu_pre != nullptr;
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -269,16 +270,24 @@ __global__ __launch_bounds__(256, 2) void k_sgemm(SgemmArgs a) {
             const int n = n0 + 32 * j + col;
             if (n < a.N) {
                 const int mb = m0 + wave * 32 * WM + 32 * i + 4 * half;
-                float old[16];
+                float old[16], pre[16];
                 if (accumulate) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) old[r] = C[(size_t)min(mb + 8 * (r >> 2) + (r & 3), a.M - 1) * a.ldc + n];
+                }
+                if (silu_bwd) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) pre[r] = a.silu_pre[(size_t)min(mb + 8 * (r >> 2) + (r & 3), a.M - 1) * a.ldc + n];
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = mb + 8 * (r >> 2) + (r & 3);
                     float v = a.alpha * acc[i][j][r];
                     if (accumulate) v += a.beta * old[r];
+                    if (silu_bwd) {                      // the activation derivative that followed as a pass of its own (train_ops.h silu_grad)
+                        const float sg = 1.0f / (1.0f + __expf(-pre[r]));
+                        v *= sg * (1.0f + pre[r] * (1.0f - sg));
+                    }
                     if (m < a.M) C[(size_t)m * a.ldc + n] = v;
                 }
             }
@@ -407,12 +416,13 @@ int sgemm_split_slices(int M, int N, int K) {
 }
 
 kpd_status sgemm(bool tA, bool tB, int M, int N, int K, float alpha, const float *A, int lda, const float *B, int ldb, float beta,
-                 float *C, int ldc, hipStream_t st, float *part, size_t part_floats, float *colsum) {
+                 float *C, int ldc, hipStream_t st, float *part, size_t part_floats, float *colsum, const float *silu_pre) {
     if (M <= 0 || N <= 0) return KPD_OK;
     KPD_REQUIRE(A && B && C && K > 0, KPD_ERR_INVALID, "sgemm: null operand or empty K (M=%d N=%d K=%d)", M, N, K);
     KPD_REQUIRE(!colsum || (tA && !tB), KPD_ERR_INVALID, "sgemm: column sums ride along with A^T B products only");
     SgemmArgs a;
-    a.colsum = colsum; a.cs_part = nullptr;
+    a.colsum = colsum; a.cs_part = nullptr; a.silu_pre = silu_pre;
+    if (silu_pre) part = nullptr;               // the epilogue lives in the product kernel: no split along K
     a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.alpha = alpha; a.beta = beta;
     a.vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
     a.vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
@@ -493,7 +503,7 @@ extern "C" kpd_status kpd_sgemm(int32_t trans_a, int32_t trans_b, int32_t M, int
         if (beta == 0.0f) KPD_HIP(hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, M, st));
         return KPD_OK;
     }
-    return sgemm(trans_a != 0, trans_b != 0, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, st, workspace, (size_t)workspace_floats, colsum);
+    return sgemm(trans_a != 0, trans_b != 0, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, st, workspace, (size_t)workspace_floats, colsum, nullptr);
 }
 
 }  // namespace kpd

@@ -271,14 +271,21 @@ struct TrainCtx {
 inline size_t colpart_floats(int max_rows) { return (size_t)cdiv(std::max(max_rows, 1), HEAD_ROWS) * 2 * COLSUM_LD; }
 
 // row-major C[M,N] = alpha op(A) op(B) + beta C
+// silu_pre: C = (.) * SiLU'(silu_pre), element for element (silu_pre laid out like C): replaces a k_silu_bwd pass over C
 kpd_status gemm(TrainCtx *T, bool tA, bool tB, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
-                float beta, float *C, int ldc, float alpha = 1.0f) {
+                float beta, float *C, int ldc, float alpha = 1.0f, const float *silu_pre = nullptr) {
     if (M == 0 || N == 0) return KPD_OK;
+    if (K == 0 && silu_pre) {
+        KPD_REQUIRE(beta == 1.0f, KPD_ERR_INVALID, "gemm: empty K with an activation epilogue needs beta = 1");
+        hipLaunchKernelGGL(k_silu_bwd, grid1((long long)M * N), dim3(256), 0, T->st, C, silu_pre, (long long)M * N, N, ldc);
+        KPD_LAUNCH_CHECK();
+        return KPD_OK;
+    }
     if (K == 0) {
         if (beta == 0.0f) KPD_HIP(hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, M, T->st));
         return KPD_OK;
     }
-    return sgemm(tA, tB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, T->st);
+    return sgemm(tA, tB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, T->st, nullptr, 0, nullptr, silu_pre);
 }
 
 // y[M] (stride incy) = beta y + A[M,K] x (stride incx), A row-major
