@@ -70,17 +70,25 @@ __global__ void k_rowdot(const float *__restrict__ A, const float *__restrict__ 
 
 // acc[v] += zinv[v] * sum over the edges of dst node v of M[e] * (w ? w[e] : 1): one workgroup per dst node
 // (copy_e + sum and the division by z, dynamics.py:177-192)
+// acc2 (optional): acc2[v] = sum over the same edges of M[e] * w2[e], from the same loads (no zinv, always "=")
 __global__ void k_segsum_rows(const float *__restrict__ M, const float *__restrict__ w, const int *__restrict__ rowptr,
-                              const float *__restrict__ zinv, int accumulate, float *__restrict__ acc) {
+                              const float *__restrict__ zinv, int accumulate, float *__restrict__ acc, const float *__restrict__ w2,
+                              float *__restrict__ acc2) {
     const int v = blockIdx.x;
     const int e0 = rowptr[v], e1 = rowptr[v + 1];
-    if (e0 == e1 && accumulate) return;
+    if (e0 == e1 && accumulate && !acc2) return;
     const float zi = zinv ? zinv[v] : 1.0f;
     for (int c = threadIdx.x; c < H; c += blockDim.x) {
-        float s = 0.0f;
-        for (int e = e0; e < e1; ++e) s = fmaf(M[(size_t)e * LD + c], w ? w[e] : 1.0f, s);
-        if (accumulate) acc[(size_t)v * LD + c] += s * zi;
-        else acc[(size_t)v * LD + c] = s * zi;
+        float s = 0.0f, s2 = 0.0f;
+        for (int e = e0; e < e1; ++e) {
+            const float m = M[(size_t)e * LD + c];
+            s = fmaf(m, w ? w[e] : 1.0f, s);
+            if (acc2) s2 = fmaf(m, w2[e], s2);
+        }
+        if (accumulate) {
+            if (e0 != e1) acc[(size_t)v * LD + c] += s * zi;
+        } else acc[(size_t)v * LD + c] = s * zi;
+        if (acc2) acc2[(size_t)v * LD + c] = s2;
     }
 }
 
@@ -447,7 +455,7 @@ kpd_status layer_fwd(kpd_egnn_trainer *T, int l) {
         hipLaunchKernelGGL(k_rowdot, dim3(cdiv(E, 4)), dim3(256), 0, T->st, T->eb[3], p.head.w, p.head_b.w, E, 1, T->att);
         KPD_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_segsum_rows, dim3(T->n[d]), dim3(256), 0, T->st, T->eb[3], T->att, T->e_rowptr[et], T->zinv[d], 1,
-                           T->hns[d][l]);
+                           T->hns[d][l], (const float *)nullptr, (float *)nullptr);
         KPD_LAUNCH_CHECK();
         bind_slot(T, l, et, 1);
         KPD_TRY(branch_params(T, l, et, 1, &p));
@@ -859,21 +867,23 @@ kpd_status edge_branch_bwd(kpd_egnn_trainer *T, const BranchParams &p, int l, in
         hipLaunchKernelGGL(k_silu_bwd, grid1(tot), dim3(256), 0, T->st, dpre1, T->eb[0], tot, H, LD);
         KPD_LAUNCH_CHECK();
     }
-    // b1 gradient and column 514 of W1 (the dij weights) in one pass over dpre1
-    KPD_TRY(gemv_t_colsum_acc(T, E, H, dpre1, LD, T->dij, p.W1.g ? p.W1.g + 2 * H : nullptr, 2 * H + 1, p.b1.g));
     KPD_TRY(gemv_n(T, E, H, dpre1, LD, p.W1.w + 2 * H, 2 * H + 1, first_branch ? 0.0f : 1.0f, T->ddij, 1));
-    // per-node sums: dV (by dst) and dU (by src), both segmented sums in a fixed order
-    float *dU = T->nb[0], *dV = T->nb[1];
+    // per-node sums: dV (by dst) and dU (by src), both segmented sums in a fixed order.  The two gradients that are sums over ALL edges of
+    // dpre1 -- b1 (plain) and column 514 of W1 (weighted by the edge's distance) -- are taken from per-node sums as well: every edge has one
+    // destination, so sum_e dpre1[e] = sum_v dV[v] (rides along with the dV^T h_dst product) and sum_e dpre1[e] d_e = sum_v dVw[v], where dVw
+    // comes out of the same pass over dpre1 as dV.  One E x 257 pass fewer per branch.
+    float *dU = T->nb[0], *dV = T->nb[1], *dVw = T->nb[2];
     hipLaunchKernelGGL(k_segsum_perm, dim3(ns), dim3(256), 0, T->st, dpre1, LD, 0, H, T->scsr[et].perm, T->scsr[et].rowptr, 1.0f, 0, dU, LD);
     KPD_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_segsum_rows, dim3(nd), dim3(256), 0, T->st, dpre1, (const float *)nullptr, T->e_rowptr[et],
-                       (const float *)nullptr, 0, dV);
+                       (const float *)nullptr, 0, dV, (const float *)T->dij, p.W1.g ? dVw : (float *)nullptr);
     KPD_LAUNCH_CHECK();
     const float *hsrc = T->hs[s][l], *hdst = T->hs[d][l];
     if (p.W1.g) {
+        KPD_TRY(gemv_t_acc(T, nd, H, dVw, LD, nullptr, p.W1.g + 2 * H, 2 * H + 1));
         KPD_TRY(grad_gemm(T, H, H, ns, dU, LD, hsrc, LD, p.W1.g, 2 * H + 1));
-        KPD_TRY(grad_gemm(T, H, H, nd, dV, LD, hdst, LD, p.W1.g + H, 2 * H + 1));
     }
+    KPD_TRY(grad_gemm(T, H, H, nd, dV, LD, hdst, LD, p.W1.g ? p.W1.g + H : nullptr, 2 * H + 1, p.b1.g));
     KPD_TRY(gemm(T, false, false, ns, H, H, dU, LD, p.W1.w, 2 * H + 1, 1.0f, T->dh[nxt][s], LD));
     KPD_TRY(gemm(T, false, false, nd, H, H, dV, LD, p.W1.w + H, 2 * H + 1, 1.0f, T->dh[nxt][d], LD));
     return KPD_OK;
