@@ -92,6 +92,14 @@ __global__ void k_segsum_rows(const float *__restrict__ M, const float *__restri
     }
 }
 
+// out[e] (+)= part[e] + part[n + e]: the two half-row shares of a row-dot taken in the ws_gemm epilogue
+__global__ void k_add_halves(const float *__restrict__ part, int n, int accumulate, float *__restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const float s = part[e] + part[(size_t)n + e];
+    out[e] = accumulate ? out[e] + s : s;
+}
+
 // coordinate head: sc = a2 . w3 (no bias), msg_x = tanh(sc) * range * n  or  sc * n (dynamics.py:113-120)
 __global__ void k_coord_msg(const float *__restrict__ A, const float *__restrict__ w3, const float *__restrict__ nvec, int rows,
                             int use_tanh, float range, float *__restrict__ sc, float *__restrict__ msgx) {
@@ -350,6 +358,7 @@ struct kpd_egnn_trainer : TrainCtx {
     float *nb[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // [cap_N, LD] each
     float *wsg_pack = nullptr;                                                   // packed weights of the current ws_gemm call
     float *dact = nullptr;                                                       // [cap_N, ENC_LD]
+    float *ddpart = nullptr;                   // [2][cap_E] half-row shares of d dij (ws_gemm row-dot)
     float *xdiff = nullptr, *dij = nullptr, *nvec = nullptr, *att = nullptr, *sc = nullptr, *dsv = nullptr, *ddij = nullptr,
           *dn = nullptr, *msgx = nullptr;
     // Kept forward activations (KPD_TRAIN_STORE, default on): pre1 / a1 / pre2 / a2 of both MLP branches of every (layer, edge
@@ -647,7 +656,7 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
     add(GRAD_PART_FLOATS, 4);
     for (int k = 0; k < 3; ++k) add((size_t)cap_E * 3, 4);      // xdiff, nvec, dn
     add((size_t)cap_E * 3, 4);                                    // msgx
-    for (int k = 0; k < 5; ++k) add(cap_E, 4);                   // dij, att, sc, dsv, ddij
+    for (int k = 0; k < 7; ++k) add(cap_E, 4);                   // dij, att, sc, dsv, ddij, ddpart (2)
     add(std::max(cap_E, cap_N), 4);                               // ones
     add(32, 4); add(max_n_lig, 4); add(max_B + 1, 4); add(max_B + 1, 4); add(max_B + 2, 4);
     add(cap_ll, 4); add(cap_ll, 4); add(max_n_lig + 1, 4);
@@ -684,6 +693,7 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
     T->msgx = W.take<float>((size_t)cap_E * 3);
     T->dij = W.take<float>(cap_E); T->att = W.take<float>(cap_E); T->sc = W.take<float>(cap_E); T->dsv = W.take<float>(cap_E);
     T->ddij = W.take<float>(cap_E);
+    T->ddpart = W.take<float>((size_t)2 * cap_E);
     const int n_ones = std::max(cap_E, cap_N);
     T->ones = W.take<float>(n_ones);
     T->meta = W.take<int>(32);
@@ -861,13 +871,17 @@ kpd_status edge_branch_bwd(kpd_egnn_trainer *T, const BranchParams &p, int l, in
     const long long tot = (long long)E * H;
     // dpre1 = (dpre2 W2) * SiLU'(pre1)
     if (use_ws()) {
-        KPD_TRY(ws_gemm(WS_SILU_BWD, dpre2, E, LD, p.W2.w, H, true, nullptr, T->eb[0], dpre1, nullptr, LD, T->wsg_pack, T->st));
+        // ... and d dij += dpre1 . W1[:, 514] from the same registers (two half-row shares, combined below)
+        KPD_TRY(ws_gemm(WS_SILU_BWD, dpre2, E, LD, p.W2.w, H, true, nullptr, T->eb[0], dpre1, nullptr, LD, T->wsg_pack, T->st, true, false,
+                        p.W1.w + 2 * H, 2 * H + 1, T->ddpart));
+        hipLaunchKernelGGL(k_add_halves, grid1(E), dim3(256), 0, T->st, T->ddpart, E, first_branch ? 0 : 1, T->ddij);
+        KPD_LAUNCH_CHECK();
     } else {
         KPD_TRY(gemm(T, false, false, E, H, H, dpre2, LD, p.W2.w, H, 0.0f, dpre1, LD));
         hipLaunchKernelGGL(k_silu_bwd, grid1(tot), dim3(256), 0, T->st, dpre1, T->eb[0], tot, H, LD);
         KPD_LAUNCH_CHECK();
     }
-    KPD_TRY(gemv_n(T, E, H, dpre1, LD, p.W1.w + 2 * H, 2 * H + 1, first_branch ? 0.0f : 1.0f, T->ddij, 1));
+    if (!use_ws()) KPD_TRY(gemv_n(T, E, H, dpre1, LD, p.W1.w + 2 * H, 2 * H + 1, first_branch ? 0.0f : 1.0f, T->ddij, 1));
     // per-node sums: dV (by dst) and dU (by src), both segmented sums in a fixed order.  The two gradients that are sums over ALL edges of
     // dpre1 -- b1 (plain) and column 514 of W1 (weighted by the edge's distance) -- are taken from per-node sums as well: every edge has one
     // destination, so sum_e dpre1[e] = sum_v dV[v] (rides along with the dV^T h_dst product) and sum_e dpre1[e] d_e = sum_v dVw[v], where dVw

@@ -21,7 +21,7 @@ namespace {
 
 constexpr int WSG_TILE = 128;
 constexpr int WSG_W4 = 16 * 8 * 64;                           // float4 of the resident half block
-constexpr int WSG_LDS_BYTES = WSG_W4 * 16 + (128 + 128 + HS) * 4;
+constexpr int WSG_LDS_BYTES = WSG_W4 * 16 + (128 + 128 + HS + HS) * 4;      // half block, column 256, bias, row 256, row-dot vector
 constexpr int WSG_PACK_FLOATS = 16 * 16 * 64 * 4 + 256 + HS;  // fragments, column 256, row 256 (padded)
 
 __device__ __forceinline__ float wsg_sigm(float x) { return 1.0f / (1.0f + __expf(-x)); }
@@ -50,11 +50,14 @@ struct WsgArgs {
     const float *P;         // [rows, ldy] pre-activation for WS_SILU_BWD, else null
     float *Y, *A;           // [rows, ldy]; A only for WS_BIAS_SILU
     int ldy, mode, bpc, tpb, has257, accumulate;
+    const float *rd_w;      // WS_SILU_BWD: optional row-dot vector (stride rd_stride) and its output [2][rows]
+    int rd_stride;
+    float *rd_out;
 };
 
 template <int MODE>
-__device__ __forceinline__ void wsg_store(const WsgArgs &a, int row, int hf, int q, v4f (&acc)[8], float out256) {
-    if (row < 0 || row >= a.rows) return;
+__device__ __forceinline__ void wsg_store(const WsgArgs &a, int row, int hf, int q, v4f (&acc)[8], float out256, const float *s_rd) {
+    if (row < 0 || row >= a.rows) return;             // (the four lanes of a row leave together: the shuffles below stay converged)
     float *yrow = a.Y + (size_t)row * a.ldy + 128 * hf;
     const bool tail = a.has257 && hf == 0 && q == 0;
     if (a.accumulate) {
@@ -89,10 +92,24 @@ __device__ __forceinline__ void wsg_store(const WsgArgs &a, int row, int hf, int
                 v[r] *= sg * (1.0f + p[r] * (1.0f - sg));
             }
             *reinterpret_cast<v4f *>(yrow + 16 * m + 4 * q) = v;
+            acc[m] = v;
         }
+        float y256 = 0.0f;
         if (tail) {
             const float p = prow[256], sg = wsg_sigm(p);
-            yrow[256] = out256 * sg * (1.0f + p * (1.0f - sg));
+            y256 = out256 * sg * (1.0f + p * (1.0f - sg));
+            yrow[256] = y256;
+        }
+        if (a.rd_out) {                                // this half's share of the row's product with rd_w, from the finished registers
+            float dot = tail ? y256 * s_rd[256] : 0.0f;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const v4f w = *reinterpret_cast<const v4f *>(s_rd + 128 * hf + 16 * m + 4 * q);
+                dot += acc[m][0] * w[0] + acc[m][1] * w[1] + acc[m][2] * w[2] + acc[m][3] * w[3];
+            }
+            dot += __shfl_xor(dot, 16);
+            dot += __shfl_xor(dot, 32);
+            if (q == 0) a.rd_out[(size_t)hf * a.rows + row] = dot;
         }
     } else {
 #pragma unroll
@@ -105,7 +122,7 @@ template <int MODE>
 __global__ __launch_bounds__(512, 1) void k_ws_gemm(WsgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     v4f *W = reinterpret_cast<v4f *>(smem);
-    float *s_wcol = smem + WSG_W4 * 4, *s_bias = s_wcol + 128, *s_wrow = s_bias + 128;
+    float *s_wcol = smem + WSG_W4 * 4, *s_bias = s_wcol + 128, *s_wrow = s_bias + 128, *s_rd = s_wrow + HS;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int hf = blockIdx.x / a.bpc, chunk = blockIdx.x - hf * a.bpc;
     const int tiles = (a.rows + WSG_TILE - 1) / WSG_TILE;
@@ -124,6 +141,8 @@ __global__ __launch_bounds__(512, 1) void k_ws_gemm(WsgArgs a) {
             s_bias[tid] = a.bias ? a.bias[128 * hf + tid] : 0.0f;
         }
         for (int i = tid; i < HS; i += 512) s_wrow[i] = wrow[i];
+        if (MODE == WS_SILU_BWD && a.rd_out)
+            for (int i = tid; i < HS; i += 512) s_rd[i] = i < (a.has257 ? 257 : 256) ? a.rd_w[(size_t)i * a.rd_stride] : 0.0f;
     }
     __syncthreads();
     const int el = lane & 15, q = lane >> 4;
@@ -151,7 +170,7 @@ __global__ __launch_bounds__(512, 1) void k_ws_gemm(WsgArgs a) {
             for (int r = 0; r < 4; ++r) asm volatile("v_mov_b32 %0, %1" : "=v"(x[nt][r]) : "v"(xn[nt][r]));
         asm volatile("v_mov_b32 %0, %1" : "=v"(x256) : "v"(x256n));
         __builtin_amdgcn_sched_barrier(0);
-        wsg_store<MODE>(a, rowp, hf, q, accp, out256p);
+        wsg_store<MODE>(a, rowp, hf, q, accp, out256p, s_rd);
         if (t + 1 < t1) load_x(t + 1, xn, x256n);
         v4f acc[8];
 #pragma unroll
@@ -195,7 +214,7 @@ __global__ __launch_bounds__(512, 1) void k_ws_gemm(WsgArgs a) {
         rowp = t * WSG_TILE + 16 * wave + el;
         out256p = out256;
     }
-    wsg_store<MODE>(a, rowp, hf, q, accp, out256p);
+    wsg_store<MODE>(a, rowp, hf, q, accp, out256p, s_rd);
 }
 
 }  // namespace
@@ -205,7 +224,8 @@ int ws_gemm_pack_floats() { return WSG_PACK_FLOATS; }
 // Y = epilogue(X op(W) + b): W with row stride ldw; transpose_w = false: Y = X W^T (W in the torch [out, in] layout), true:
 // Y = X W.  has257: 257 x 257 problem (else 256 x 256).  pack_scratch: ws_gemm_pack_floats() floats.
 kpd_status ws_gemm(int mode, const float *X, int rows, int ldx, const float *W, int ldw, bool transpose_w, const float *bias,
-                   const float *P, float *Y, float *A, int ldy, float *pack_scratch, hipStream_t st, bool has257, bool accumulate) {
+                   const float *P, float *Y, float *A, int ldy, float *pack_scratch, hipStream_t st, bool has257, bool accumulate,
+                   const float *rowdot_w, int rowdot_stride, float *rowdot_out) {
     if (rows == 0) return KPD_OK;
     const int need = has257 ? 260 : 256;
     KPD_REQUIRE(X && W && Y && pack_scratch && (ldx & 3) == 0 && (ldy & 3) == 0 && ldx >= need && ldy >= need, KPD_ERR_INVALID,
@@ -222,6 +242,8 @@ kpd_status ws_gemm(int mode, const float *X, int rows, int ldx, const float *W, 
     WsgArgs a;
     a.X = X; a.rows = rows; a.ldx = ldx; a.pack = pack_scratch; a.bias = bias; a.P = P; a.Y = Y; a.A = A; a.ldy = ldy; a.mode = mode;
     a.has257 = has257 ? 1 : 0; a.accumulate = accumulate ? 1 : 0;
+    KPD_REQUIRE(!rowdot_out || (mode == WS_SILU_BWD && rowdot_w), KPD_ERR_INVALID, "ws_gemm: row-dot output without its mode / vector");
+    a.rd_w = rowdot_w; a.rd_stride = rowdot_stride; a.rd_out = rowdot_out;
     const int tiles = cdiv(rows, WSG_TILE);
     // one workgroup per CU, one round (see launch_proj_chain): 2 * bpc <= CUs of this device
     const int cus = cu_count();
