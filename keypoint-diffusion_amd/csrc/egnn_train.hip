@@ -92,6 +92,25 @@ __global__ void k_segsum_rows(const float *__restrict__ M, const float *__restri
     }
 }
 
+// soft attention from the head shares of the ws_gemm epilogue: att[e] = sigmoid(part[e] + part[n + e] + bias)
+__global__ void k_head_att(const float *__restrict__ part, int n, const float *__restrict__ bias, float *__restrict__ att) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    att[e] = sigm(part[e] + part[(size_t)n + e] + (bias ? bias[0] : 0.0f));
+}
+
+// k_coord_msg with the head product already taken (two shares): sc = a2 . w3, msg_x = tanh(sc) * range * n  or  sc * n
+__global__ void k_coord_msg_parts(const float *__restrict__ part, const float *__restrict__ nvec, int n, int use_tanh, float range,
+                                  float *__restrict__ sc, float *__restrict__ msgx) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const float s = part[e] + part[(size_t)n + e];
+    const float coef = use_tanh ? tanhf(s) * range : s;
+    sc[e] = s;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) msgx[3 * e + k] = coef * nvec[3 * e + k];
+}
+
 // out[e] (+)= part[e] + part[n + e]: the two half-row shares of a row-dot taken in the ws_gemm epilogue
 __global__ void k_add_halves(const float *__restrict__ part, int n, int accumulate, float *__restrict__ out) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -410,7 +429,8 @@ kpd_status branch_params(kpd_egnn_trainer *T, int layer, int et, int branch, Bra
 }
 
 // eb[0] = pre1, eb[1] = a1, eb[2] = pre2 (+ bias), eb[3] = a2 for the E edges of `et`; nb[0] = U, nb[1] = V
-kpd_status edge_branch_fwd(kpd_egnn_trainer *T, const BranchParams &p, int et, const float *hs, const float *hd) {
+// head_part (weight-stationary path only): the two half-row shares of a2 . head.w, [2][E], from the GEMM's epilogue
+kpd_status edge_branch_fwd(kpd_egnn_trainer *T, const BranchParams &p, int et, const float *hs, const float *hd, float *head_part = nullptr) {
     const int E = T->E[et], ns = T->n[kS[et]], nd = T->n[kD[et]];
     KPD_TRY(gemm(T, false, true, ns, H, H, hs, LD, p.W1.w, 2 * H + 1, 0.0f, T->nb[0], LD));
     KPD_TRY(gemm(T, false, true, nd, H, H, hd, LD, p.W1.w + H, 2 * H + 1, 0.0f, T->nb[1], LD));
@@ -419,7 +439,9 @@ kpd_status edge_branch_fwd(kpd_egnn_trainer *T, const BranchParams &p, int et, c
                        p.W1.w + 2 * H, 2 * H + 1, p.b1.w, tot, T->eb[0], T->eb[1]);
     KPD_LAUNCH_CHECK();
     // pre2 = a1 W2^T + b2, a2 = SiLU(pre2): the weight-stationary GEMM with the activation fused (KPD_TRAIN_WS=0: general GEMM + kernel)
-    if (use_ws()) return ws_gemm(WS_BIAS_SILU, T->eb[1], E, LD, p.W2.w, H, false, p.b2.w, nullptr, T->eb[2], T->eb[3], LD, T->wsg_pack, T->st);
+    if (use_ws())
+        return ws_gemm(WS_BIAS_SILU, T->eb[1], E, LD, p.W2.w, H, false, p.b2.w, nullptr, T->eb[2], T->eb[3], LD, T->wsg_pack, T->st, true, false,
+                       head_part ? p.head.w : nullptr, 1, head_part);
     KPD_TRY(gemm(T, false, true, E, H, H, T->eb[1], LD, p.W2.w, H, 0.0f, T->eb[2], LD));
     hipLaunchKernelGGL(k_bias_silu, grid1(tot), dim3(256), 0, T->st, T->eb[2], p.b2.w, tot, H, LD, T->eb[3]);
     KPD_LAUNCH_CHECK();
@@ -460,17 +482,21 @@ kpd_status layer_fwd(kpd_egnn_trainer *T, int l) {
         KPD_TRY(geom_fwd(T, et, T->xs[s][l], T->xs[d][l]));
         BranchParams p;
         KPD_TRY(branch_params(T, l, et, 0, &p));
-        KPD_TRY(edge_branch_fwd(T, p, et, T->hs[s][l], T->hs[d][l]));
-        hipLaunchKernelGGL(k_rowdot, dim3(cdiv(E, 4)), dim3(256), 0, T->st, T->eb[3], p.head.w, p.head_b.w, E, 1, T->att);
+        KPD_TRY(edge_branch_fwd(T, p, et, T->hs[s][l], T->hs[d][l], use_ws() ? T->ddpart : nullptr));
+        if (use_ws()) hipLaunchKernelGGL(k_head_att, grid1(E), dim3(256), 0, T->st, T->ddpart, E, p.head_b.w, T->att);
+        else hipLaunchKernelGGL(k_rowdot, dim3(cdiv(E, 4)), dim3(256), 0, T->st, T->eb[3], p.head.w, p.head_b.w, E, 1, T->att);
         KPD_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_segsum_rows, dim3(T->n[d]), dim3(256), 0, T->st, T->eb[3], T->att, T->e_rowptr[et], T->zinv[d], 1,
                            T->hns[d][l], (const float *)nullptr, (float *)nullptr);
         KPD_LAUNCH_CHECK();
         bind_slot(T, l, et, 1);
         KPD_TRY(branch_params(T, l, et, 1, &p));
-        KPD_TRY(edge_branch_fwd(T, p, et, T->hs[s][l], T->hs[d][l]));
-        hipLaunchKernelGGL(k_coord_msg, dim3(cdiv(E, 4)), dim3(256), 0, T->st, T->eb[3], p.head.w, T->nvec, E, c.use_tanh,
-                           c.coords_range, T->sc, T->msgx);
+        KPD_TRY(edge_branch_fwd(T, p, et, T->hs[s][l], T->hs[d][l], use_ws() ? T->ddpart : nullptr));
+        if (use_ws())
+            hipLaunchKernelGGL(k_coord_msg_parts, grid1(E), dim3(256), 0, T->st, T->ddpart, T->nvec, E, c.use_tanh, c.coords_range, T->sc, T->msgx);
+        else
+            hipLaunchKernelGGL(k_coord_msg, dim3(cdiv(E, 4)), dim3(256), 0, T->st, T->eb[3], p.head.w, T->nvec, E, c.use_tanh,
+                               c.coords_range, T->sc, T->msgx);
         KPD_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_segsum3, grid1(3 * T->n[d]), dim3(256), 0, T->st, T->msgx, T->e_rowptr[et], T->zinv[d], T->n[d],
                            T->xns[d][l]);
@@ -916,9 +942,10 @@ kpd_status layer_bwd(kpd_egnn_trainer *T, int l, int cur, int nxt, float *dhn[2]
         BranchParams p;
         // feature branch
         KPD_TRY(branch_params(T, l, et, 0, &p));
-        if (!T->store) {
-            KPD_TRY(edge_branch_fwd(T, p, et, T->hs[s][l], T->hs[d][l]));
-            hipLaunchKernelGGL(k_rowdot, dim3(cdiv(E, 4)), dim3(256), 0, T->st, T->eb[3], p.head.w, p.head_b.w, E, 1, T->att);
+        if (!T->store) {           // (the same head path as the forward pass: the two modes stay bit-identical)
+            KPD_TRY(edge_branch_fwd(T, p, et, T->hs[s][l], T->hs[d][l], use_ws() ? T->ddpart : nullptr));
+            if (use_ws()) hipLaunchKernelGGL(k_head_att, grid1(E), dim3(256), 0, T->st, T->ddpart, E, p.head_b.w, T->att);
+            else hipLaunchKernelGGL(k_rowdot, dim3(cdiv(E, 4)), dim3(256), 0, T->st, T->eb[3], p.head.w, p.head_b.w, E, 1, T->att);
             KPD_LAUNCH_CHECK();
         }
         KPD_REQUIRE(cdiv(E, HEAD_ROWS) <= T->colpart_blocks, KPD_ERR_CAPACITY, "column-sum scratch too small");
@@ -937,9 +964,12 @@ kpd_status layer_bwd(kpd_egnn_trainer *T, int l, int cur, int nxt, float *dhn[2]
         bind_slot(T, l, et, 1);
         KPD_TRY(branch_params(T, l, et, 1, &p));
         if (!T->store) {
-            KPD_TRY(edge_branch_fwd(T, p, et, T->hs[s][l], T->hs[d][l]));
-            hipLaunchKernelGGL(k_coord_msg, dim3(cdiv(E, 4)), dim3(256), 0, T->st, T->eb[3], p.head.w, T->nvec, E, c.use_tanh,
-                               c.coords_range, T->sc, T->msgx);
+            KPD_TRY(edge_branch_fwd(T, p, et, T->hs[s][l], T->hs[d][l], use_ws() ? T->ddpart : nullptr));
+            if (use_ws())
+                hipLaunchKernelGGL(k_coord_msg_parts, grid1(E), dim3(256), 0, T->st, T->ddpart, T->nvec, E, c.use_tanh, c.coords_range, T->sc, T->msgx);
+            else
+                hipLaunchKernelGGL(k_coord_msg, dim3(cdiv(E, 4)), dim3(256), 0, T->st, T->eb[3], p.head.w, T->nvec, E, c.use_tanh,
+                                   c.coords_range, T->sc, T->msgx);
             KPD_LAUNCH_CHECK();
         }
         hipLaunchKernelGGL(k_coord_head_bwd, dim3(cdiv(E, HEAD_ROWS)), dim3(256), 0, T->st, T->dx[cur][d], T->zinv[d], T->e_dst[et], T->nvec,

@@ -106,8 +106,9 @@ kpd_status copy_col_pad(const float *src, int n, int ld, int col, float *dst, in
 // Weight-stationary tall-skinny GEMM with fused epilogues for the training engines (ws_gemm.hip).
 enum { WS_BIAS_SILU = 0, WS_SILU_BWD = 1, WS_PLAIN = 2 };
 int ws_gemm_pack_floats();
-// rowdot (WS_SILU_BWD only, optional): rowdot_out[hf * rows + r] = sum over the columns of half hf of Y[r][c] * rowdot_w[c * rowdot_stride]
-// -- the product of every finished row with one more vector, taken from the registers the epilogue holds (two halves: the caller adds them)
+// rowdot (optional; WS_SILU_BWD: of Y, WS_BIAS_SILU: of the activated output A): rowdot_out[hf * rows + r] = sum over the columns of half hf
+// of the row times rowdot_w[c * rowdot_stride] -- the product of every finished row with one more vector (a head of the MLP, the
+// distance column in backward), taken from the registers the epilogue holds (two halves: the caller adds them)
 kpd_status ws_gemm(int mode, const float *X, int rows, int ldx, const float *W, int ldw, bool transpose_w, const float *bias,
                    const float *P, float *Y, float *A, int ldy, float *pack_scratch, hipStream_t st, bool has257 = true,
                    bool accumulate = false, const float *rowdot_w = nullptr, int rowdot_stride = 1, float *rowdot_out = nullptr);

@@ -67,6 +67,7 @@ __device__ __forceinline__ void wsg_store(const WsgArgs &a, int row, int hf, int
     }
     if (MODE == WS_BIAS_SILU) {
         float *arow = a.A + (size_t)row * a.ldy + 128 * hf;
+        float dot = 0.0f;
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
             const v4f v = acc[m];
@@ -75,10 +76,21 @@ __device__ __forceinline__ void wsg_store(const WsgArgs &a, int row, int hf, int
             for (int r = 0; r < 4; ++r) s[r] = v[r] * wsg_sigm(v[r]);
             *reinterpret_cast<v4f *>(yrow + 16 * m + 4 * q) = v;
             *reinterpret_cast<v4f *>(arow + 16 * m + 4 * q) = s;
+            if (a.rd_out) {
+                const v4f w = *reinterpret_cast<const v4f *>(s_rd + 128 * hf + 16 * m + 4 * q);
+                dot += s[0] * w[0] + s[1] * w[1] + s[2] * w[2] + s[3] * w[3];
+            }
         }
         if (tail) {
+            const float s256 = out256 * wsg_sigm(out256);
             yrow[256] = out256;
-            arow[256] = out256 * wsg_sigm(out256);
+            arow[256] = s256;
+            if (a.rd_out) dot += s256 * s_rd[256];
+        }
+        if (a.rd_out) {                                // this half's share of the activated row's product with rd_w (a head of the MLP)
+            dot += __shfl_xor(dot, 16);
+            dot += __shfl_xor(dot, 32);
+            if (q == 0) a.rd_out[(size_t)hf * a.rows + row] = dot;
         }
     } else if (MODE == WS_SILU_BWD) {
         const float *prow = a.P + (size_t)row * a.ldy + 128 * hf;
@@ -141,7 +153,7 @@ __global__ __launch_bounds__(512, 1) void k_ws_gemm(WsgArgs a) {
             s_bias[tid] = a.bias ? a.bias[128 * hf + tid] : 0.0f;
         }
         for (int i = tid; i < HS; i += 512) s_wrow[i] = wrow[i];
-        if (MODE == WS_SILU_BWD && a.rd_out)
+        if (MODE != WS_PLAIN && a.rd_out)
             for (int i = tid; i < HS; i += 512) s_rd[i] = i < (a.has257 ? 257 : 256) ? a.rd_w[(size_t)i * a.rd_stride] : 0.0f;
     }
     __syncthreads();
@@ -242,7 +254,7 @@ kpd_status ws_gemm(int mode, const float *X, int rows, int ldx, const float *W, 
     WsgArgs a;
     a.X = X; a.rows = rows; a.ldx = ldx; a.pack = pack_scratch; a.bias = bias; a.P = P; a.Y = Y; a.A = A; a.ldy = ldy; a.mode = mode;
     a.has257 = has257 ? 1 : 0; a.accumulate = accumulate ? 1 : 0;
-    KPD_REQUIRE(!rowdot_out || (mode == WS_SILU_BWD && rowdot_w), KPD_ERR_INVALID, "ws_gemm: row-dot output without its mode / vector");
+    KPD_REQUIRE(!rowdot_out || (mode != WS_PLAIN && rowdot_w), KPD_ERR_INVALID, "ws_gemm: row-dot output without its mode / vector");
     a.rd_w = rowdot_w; a.rd_stride = rowdot_stride; a.rd_out = rowdot_out;
     const int tiles = cdiv(rows, WSG_TILE);
     // one workgroup per CU, one round (see launch_proj_chain): 2 * bpc <= CUs of this device
