@@ -83,3 +83,26 @@ print(f'input gradients: four K = 256 products {t4:7.1f} us, one K = 1024 produc
 t4 = timeit(lambda: [hip.sgemm(dUc[:, 264 * b:264 * b + 256], h, True, False, beta=1.0, out=Wg[:, :256], workspace=ws) for b in range(4)])
 t1 = timeit(lambda: hip.sgemm(dUflat, h, True, False, beta=1.0, out=G4, workspace=ws))
 print(f'weight gradients: four M = 256 products {t4:7.1f} us, one M = 1024 product {t1:7.1f} us')
+
+# does the odd leading dimension of the weight operand (513-float rows) cost the node-sized products their direct path?
+Wa = W[:, :256].contiguous()
+for nn in (19200, 1600):
+    x = torch.randn(nn, 264, device=dev)[:, :256]
+    o = torch.zeros(nn, 264, device=dev)[:, :256]
+    t_odd = timeit(lambda: hip.sgemm(x, W[:, :256], False, False, beta=1.0, out=o))
+    t_al = timeit(lambda: hip.sgemm(x, Wa, False, False, beta=1.0, out=o))
+    t_odd_nt = timeit(lambda: hip.sgemm(x, W[:, :256], False, True, beta=0.0, out=o))
+    t_al_nt = timeit(lambda: hip.sgemm(x, Wa, False, True, beta=0.0, out=o))
+    print(f'n={nn}: NN weight ld 513 {t_odd:6.1f} us, ld 256 {t_al:6.1f} us;  NT ld 513 {t_odd_nt:6.1f} us, ld 256 {t_al_nt:6.1f} us')
+
+# all eight first-Linear blocks that share a node type's features as ONE product (padded 264-wide slots)
+for nn in (19200, 1600):
+    hh = torch.randn(nn, 264, device=dev)
+    Wst = torch.randn(2112, 264, device=dev)
+    Uc = torch.zeros(nn, 2112, device=dev)
+    dh = torch.zeros(nn, 264, device=dev)
+    G = torch.zeros(2112, 264, device=dev)
+    t_nt = timeit(lambda: hip.sgemm(hh, Wst, False, True, out=Uc))
+    t_nn = timeit(lambda: hip.sgemm(Uc, Wst, False, False, beta=1.0, out=dh))
+    t_tn = timeit(lambda: hip.sgemm(Uc, hh, True, False, out=G, workspace=ws))
+    print(f'n={nn}: grouped (8 slots)  NT {t_nt:6.1f} us  NN {t_nn:6.1f} us  TN {t_tn:6.1f} us')
