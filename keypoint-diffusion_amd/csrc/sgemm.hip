@@ -365,31 +365,42 @@ __global__ __launch_bounds__(256) void k_sgemm_tn_skinny(SgemmArgs a) {
     if (a.cs_part && tid < a.M) a.cs_part[(size_t)blockIdx.x * a.M + tid] = ((red_cs[0][tid] + red_cs[1][tid]) + red_cs[2][tid]) + red_cs[3][tid];
 }
 
-// C = sum of the split-K partial products (in slice order) + beta C; eight loads in flight per thread
+// C = sum of the split-K partial products + beta C, and colsum += the column-sum shares that rode along.  An output element is summed by
+// FOUR adjacent lanes, each over a quarter of the slices (in slice order, eight loads in flight), combined as ((q0 + q1) + q2) + q3: a
+// fixed tree, so the result depends on the slice count alone; the slice loop is a quarter as long as with one thread per element.
 __global__ void k_sgemm_reduce(const float *__restrict__ part, int slices, int M, int N, float beta, float *__restrict__ C, int ldc,
                                const float *__restrict__ cs_part, float *__restrict__ colsum) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (cs_part && i < M) {                             // the column sums that rode along: slices in order, added to what colsum holds
-        float s = 0.0f;
-        for (int k = 0; k < slices; ++k) s += cs_part[(size_t)k * M + i];
-        colsum[i] += s;
-    }
-    if (i >= M * N) return;
-    const size_t stride = (size_t)M * N;
-    const float *p = part + i;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = t >> 2, q = t & 3;
+    const int n_out = M * N, n_all = n_out + (cs_part ? M : 0);
+    const bool live = e < n_all;
+    // element e < M N: tile element, slices M N apart; e >= M N: column-sum entry e - M N, slices M apart
+    const bool is_cs = e >= n_out;
+    const float *p = is_cs ? cs_part + (e - n_out) : part + e;
+    const size_t stride = is_cs ? (size_t)M : (size_t)n_out;
+    const int per = (slices + 3) >> 2, k0 = min(slices, q * per), k1 = min(slices, k0 + per);
     float s = 0.0f;
-    int k = 0;
-    for (; k + 8 <= slices; k += 8) {
-        float t[8];
+    if (live) {
+        int k = k0;
+        for (; k + 8 <= k1; k += 8) {
+            float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = p[(size_t)(k + u) * stride];
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + u) * stride];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s += t[u];
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < k1; ++k) s += p[(size_t)k * stride];
     }
-    for (; k < slices; ++k) s += p[(size_t)k * stride];
-    const int r = i / N, c = i - r * N;
-    float *dst = C + (size_t)r * ldc + c;
-    *dst = beta != 0.0f ? s + beta * *dst : s;
+    const float s1 = __shfl_down(s, 1), s2 = __shfl_down(s, 2), s3 = __shfl_down(s, 3);
+    if (!live || q != 0) return;
+    const float sum = ((s + s1) + s2) + s3;
+    if (is_cs) {
+        colsum[e - n_out] += sum;
+    } else {
+        const int r = e / N, c = e - r * N;
+        float *dst = C + (size_t)r * ldc + c;
+        *dst = beta != 0.0f ? sum + beta * *dst : sum;
+    }
 }
 
 // y[m] = beta y[m] + sum_k A[m][k] x[k * incx]: one wave per row
@@ -437,7 +448,7 @@ kpd_status sgemm(bool tA, bool tB, int M, int N, int K, float alpha, const float
         if (colsum) a.cs_part = part + (size_t)used * M * N;
         hipLaunchKernelGGL(k_sgemm_tn_skinny, dim3(used), dim3(256), 0, st, a);
         KPD_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_sgemm_reduce, dim3(cdiv(M * N, 256)), dim3(256), 0, st, part, used, M, N, beta, C, ldc, (const float *)a.cs_part, colsum);
+        hipLaunchKernelGGL(k_sgemm_reduce, dim3(cdiv(4 * (M * N + (a.cs_part ? M : 0)), 256)), dim3(256), 0, st, part, used, M, N, beta, C, ldc, (const float *)a.cs_part, colsum);
         KPD_LAUNCH_CHECK();
         return KPD_OK;
     }
@@ -475,7 +486,7 @@ kpd_status sgemm(bool tA, bool tB, int M, int N, int K, float alpha, const float
     else KPD_TRY((launch_shape<1, 1>(tA, tB, grid, st, a)));
     KPD_LAUNCH_CHECK();
     if (slices > 1) {
-        hipLaunchKernelGGL(k_sgemm_reduce, dim3(cdiv(M * N, 256)), dim3(256), 0, st, part, slices, M, N, beta, C, ldc, (const float *)a.cs_part, colsum);
+        hipLaunchKernelGGL(k_sgemm_reduce, dim3(cdiv(4 * (M * N + (a.cs_part ? M : 0)), 256)), dim3(256), 0, st, part, slices, M, N, beta, C, ldc, (const float *)a.cs_part, colsum);
         KPD_LAUNCH_CHECK();
     }
     return KPD_OK;
