@@ -285,7 +285,8 @@ kpd_status gemm(TrainCtx *T, bool tA, bool tB, int M, int N, int K, const float 
         if (beta == 0.0f) KPD_HIP(hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, M, T->st));
         return KPD_OK;
     }
-    return sgemm(tA, tB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, T->st, nullptr, 0, nullptr, silu_pre);
+    // (the scratch lets a product of few tiles be cut along K: sgemm_split_slices; an activation epilogue keeps the product whole)
+    return sgemm(tA, tB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, T->st, T->part, T->part_floats, nullptr, silu_pre);
 }
 
 // y[M] (stride incy) = beta y + A[M,K] x (stride incx), A row-major
