@@ -425,7 +425,8 @@ int sgemm_split_slices(int M, int N, int K) {
     // a slice is at least 256 deep -- or 64 (four slabs) when the whole product is a handful of tiles (the ligand-sized products of a
     // training step: 13 row tiles, K = 257): a workgroup then spends its time in the load latency of 16 consecutive slabs, which four
     // workgroups share better than one
-    const int min_depth = tiles * 4 <= cu_count() ? 64 : 256;
+    static const int small_pct = getenv("KPD_SGEMM_SMALL_PCT") ? atoi(getenv("KPD_SGEMM_SMALL_PCT")) : 25;      // A/B runs
+    const int min_depth = tiles * 100 <= small_pct * cu_count() ? 64 : 256;
     s = std::min(s, std::max(1, K / min_depth));
     return std::min(s, SGEMM_MAX_SPLIT);
 }
