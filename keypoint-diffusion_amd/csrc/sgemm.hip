@@ -45,6 +45,10 @@ struct SgemmArgs {
     float *colsum;          // op(A) = A^T only: colsum[m] += sum_k A[k][m] (the bias gradient that goes with a weight gradient), or null
     float *cs_part;         // split-K: per-slice partial column sums [slice][M] instead (summed by k_sgemm_reduce)
     const float *silu_pre;  // epilogue: C = (alpha AB + beta C) * SiLU'(silu_pre[m][n]) (same leading dimension as C), or null
+    // Fringe: M, N above describe the TILED part of the output; one more output row xr (= M) and / or column xc (= N) -- the 257th feature
+    // of a 257-wide product -- are computed as riders (xr / xc = -1: none), so that they do not cost a row / column of tiles of their own
+    int xr, xc;
+    float *x_part;          // split-K: per slice [M column-fringe values | N row-fringe values | corner | column sum of the fringe row]
 };
 
 // x or +0.0 by a bit mask: the value is consumed on both outcomes, so the load stays unconditional (a select lets the compiler sink the
@@ -178,6 +182,44 @@ __global__ __launch_bounds__(256, 2) void k_sgemm(SgemmArgs a) {
             for (int k = 0; k < SG_BK; ++k) cs += st[LA::at(tid, k)];
         }
     };
+    // Fringe riders.  The slab's 16 values of op(A)[xr][k] and op(B)[k][xc] travel one slab ahead through a register of threads 0 .. 31
+    // into a small double-buffered LDS array; the workgroups of the first column tile take sum_k op(A)[m][k] op(B)[k][xc] for their rows
+    // from the A tile they hold, those of the first row tile sum_k op(A)[xr][k] op(B)[k][n] for their columns from the B tile, workgroup
+    // (0, 0) the corner (and the fringe row's share of the column sums).
+    __shared__ float xbuf[2][2][SG_BK];
+    const bool fringe = a.xr >= 0 || a.xc >= 0;
+    const bool ride_c = a.xc >= 0 && blockIdx.y == 0 && tid < BM, ride_r = a.xr >= 0 && blockIdx.x == 0 && tid < BN;
+    const bool ride_k = fringe && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
+    float fc = 0.0f, fr = 0.0f, fk = 0.0f, fcs = 0.0f, xv = 0.0f;
+    auto xfetch = [&](int kt) {
+        if (fringe && tid < 2 * SG_BK) {
+            const int k = kbeg + kt * SG_BK + (tid & (SG_BK - 1));
+            const bool isb = tid >= SG_BK;
+            const int kk = min(k, kend - 1);
+            const float *src = isb ? (TB ? a.B + (size_t)max(a.xc, 0) * a.ldb + kk : a.B + (size_t)kk * a.ldb + max(a.xc, 0))
+                                   : (TA ? a.A + (size_t)kk * a.lda + max(a.xr, 0) : a.A + (size_t)max(a.xr, 0) * a.lda + kk);
+            xv = masked(*src, k < kend && (isb ? a.xc >= 0 : a.xr >= 0));
+        }
+    };
+    auto xstash = [&](int kt) {
+        if (fringe && tid < 2 * SG_BK) xbuf[kt & 1][tid >> 4][tid & (SG_BK - 1)] = xv;
+    };
+    auto riders = [&](int kt, const float *st) {
+        if (!fringe) return;
+        const float *xa = xbuf[kt & 1][0], *xb = xbuf[kt & 1][1];
+        if (ride_c) {
+#pragma unroll
+            for (int k = 0; k < SG_BK; ++k) fc += st[LA::at(tid, k)] * xb[k];
+        }
+        if (ride_r) {
+#pragma unroll
+            for (int k = 0; k < SG_BK; ++k) fr += st[BM * SG_BK + LB::at(tid, k)] * xa[k];
+        }
+        if (ride_k) {
+#pragma unroll
+            for (int k = 0; k < SG_BK; ++k) { fk += xa[k] * xb[k]; fcs += xa[k]; }
+        }
+    };
     LA la;
     LB lb;
     auto fetch = [&](int kt) {
@@ -224,15 +266,20 @@ __global__ __launch_bounds__(256, 2) void k_sgemm(SgemmArgs a) {
             }
         };
         const int ahead = min(stages - 1, nk_full);
+        xfetch(0);                                     // (before the ring's loads: the in-order counter then covers it with them)
         for (int kt = 0; kt < ahead; ++kt) issue(kt);
+        xstash(0);
         wait_behind(ahead - 1);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll 1
         for (int kt = 0; kt < nk_full; ++kt) {
+            if (kt + 1 < nk) xfetch(kt + 1);
             if (kt + stages - 1 < nk_full) issue(kt + stages - 1);
             __builtin_amdgcn_sched_barrier(0);
             compute(smem + (kt % stages) * STAGE);
             add_cols(smem + (kt % stages) * STAGE);
+            riders(kt, smem + (kt % stages) * STAGE);
+            if (kt + 1 < nk) xstash(kt + 1);
             __builtin_amdgcn_sched_barrier(0);
             // issued so far: slabs 0 .. min(kt + stages - 1, nk_full - 1); needed next: kt + 1
             wait_behind(max(0, min(kt + stages - 1, nk_full - 1) - (kt + 1)));
@@ -244,16 +291,48 @@ __global__ __launch_bounds__(256, 2) void k_sgemm(SgemmArgs a) {
     if (done < nk) {
         float *st0 = smem, *st1 = smem + STAGE;          // (every stage is free here: the direct path ended on a barrier)
         fetch(done);
+        if (done == 0) xfetch(0);                      // (after the direct path the fringe values of slab `done` are in place already)
         stash(done, st0);
+        if (done == 0) xstash(0);
         __syncthreads();
 #pragma unroll 1
         for (int kt = done; kt < nk; ++kt) {
             float *cur = ((kt - done) & 1) ? st1 : st0, *nxt = ((kt - done) & 1) ? st0 : st1;
-            if (kt + 1 < nk) fetch(kt + 1);
+            if (kt + 1 < nk) { fetch(kt + 1); xfetch(kt + 1); }
             compute(cur);
             add_cols(cur);
-            if (kt + 1 < nk) stash(kt + 1, nxt);
+            riders(kt, cur);
+            if (kt + 1 < nk) { stash(kt + 1, nxt); xstash(kt + 1); }
             __syncthreads();
+        }
+    }
+    // fringe outputs: shares to scratch when K is split, else straight into C (same alpha / beta / activation-derivative as the tiles)
+    if (fringe) {
+        auto finish = [&](float v, float *dst, const float *pre) {
+            v *= a.alpha;
+            if (a.beta != 0.0f) v += a.beta * *dst;
+            if (pre) {
+                const float sg = 1.0f / (1.0f + __expf(-*pre));
+                v *= sg * (1.0f + *pre * (1.0f - sg));
+            }
+            *dst = v;
+        };
+        float *xp = a.x_part ? a.x_part + (size_t)blockIdx.z * (a.M + a.N + 2) : nullptr;
+        if (ride_c && m0 + tid < a.M) {
+            if (xp) xp[m0 + tid] = a.alpha * fc;
+            else finish(fc, a.C + (size_t)(m0 + tid) * a.ldc + a.xc, a.silu_pre ? a.silu_pre + (size_t)(m0 + tid) * a.ldc + a.xc : nullptr);
+        }
+        if (ride_r && n0 + tid < a.N) {
+            if (xp) xp[a.M + n0 + tid] = a.alpha * fr;
+            else finish(fr, a.C + (size_t)a.xr * a.ldc + n0 + tid, a.silu_pre ? a.silu_pre + (size_t)a.xr * a.ldc + n0 + tid : nullptr);
+        }
+        if (ride_k) {
+            if (xp) { xp[a.M + a.N] = a.alpha * fk; xp[a.M + a.N + 1] = fcs; }
+            else {
+                if (a.xr >= 0 && a.xc >= 0)
+                    finish(fk, a.C + (size_t)a.xr * a.ldc + a.xc, a.silu_pre ? a.silu_pre + (size_t)a.xr * a.ldc + a.xc : nullptr);
+                if (TA && a.colsum && a.xr >= 0) a.colsum[a.xr] += fcs;
+            }
         }
     }
     if (TA && sum_cols && m0 + tid < a.M) {
@@ -365,42 +444,54 @@ __global__ __launch_bounds__(256) void k_sgemm_tn_skinny(SgemmArgs a) {
     if (a.cs_part && tid < a.M) a.cs_part[(size_t)blockIdx.x * a.M + tid] = ((red_cs[0][tid] + red_cs[1][tid]) + red_cs[2][tid]) + red_cs[3][tid];
 }
 
-// C = sum of the split-K partial products + beta C, and colsum += the column-sum shares that rode along.  An output element is summed by
-// FOUR adjacent lanes, each over a quarter of the slices (in slice order, eight loads in flight), combined as ((q0 + q1) + q2) + q3: a
-// fixed tree, so the result depends on the slice count alone; the slice loop is a quarter as long as with one thread per element.
-__global__ void k_sgemm_reduce(const float *__restrict__ part, int slices, int M, int N, float beta, float *__restrict__ C, int ldc,
-                               const float *__restrict__ cs_part, float *__restrict__ colsum) {
+// Sums of the split-K shares.  Up to six kinds of output share one launch, each a run of elements whose shares lie `stride` floats apart
+// from slice to slice: the tiles (element (r, c) -> C[r][c]), the column sums of A, the column fringe (-> C[r][xc]), the row fringe
+// (-> C[xr][c]), the corner, the fringe row's column sum.  An output element is summed by FOUR adjacent lanes, each over a quarter of
+// the slices (in slice order, eight loads in flight), combined as ((q0 + q1) + q2) + q3: a fixed tree, so the result depends on the
+// slice count alone; the slice loop is a quarter as long as with one thread per element.
+struct RedSeg {
+    const float *src;       // first slice's run
+    long long stride;       // floats between slices
+    int count;              // elements of the run
+    float *dst;
+    int cols;               // > 0: element j -> dst[(j / cols) * ld + j % cols] (tiles); 0: dst[j * ld]
+    int ld;
+    int accumulate;         // 1: dst += sum (column sums); 0: dst = sum + beta dst
+};
+struct RedArgs {
+    RedSeg seg[6];
+    int n_seg, slices;
+    float beta;
+};
+
+__global__ void k_sgemm_reduce(RedArgs a) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int e = t >> 2, q = t & 3;
-    const int n_out = M * N, n_all = n_out + (cs_part ? M : 0);
-    const bool live = e < n_all;
-    // element e < M N: tile element, slices M N apart; e >= M N: column-sum entry e - M N, slices M apart
-    const bool is_cs = e >= n_out;
-    const float *p = is_cs ? cs_part + (e - n_out) : part + e;
-    const size_t stride = is_cs ? (size_t)M : (size_t)n_out;
-    const int per = (slices + 3) >> 2, k0 = min(slices, q * per), k1 = min(slices, k0 + per);
+    int e = t >> 2;
+    const int q = t & 3;
+    int si = 0;
+    while (si < a.n_seg && e >= a.seg[si].count) { e -= a.seg[si].count; ++si; }
+    const bool live = si < a.n_seg;
+    const RedSeg &g = a.seg[live ? si : 0];
+    const int per = (a.slices + 3) >> 2, k0 = min(a.slices, q * per), k1 = min(a.slices, k0 + per);
     float s = 0.0f;
     if (live) {
+        const float *p = g.src + e;
         int k = k0;
         for (; k + 8 <= k1; k += 8) {
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + u) * stride];
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + u) * g.stride];
 #pragma unroll
             for (int u = 0; u < 8; ++u) s += v[u];
         }
-        for (; k < k1; ++k) s += p[(size_t)k * stride];
+        for (; k < k1; ++k) s += p[(size_t)k * g.stride];
     }
     const float s1 = __shfl_down(s, 1), s2 = __shfl_down(s, 2), s3 = __shfl_down(s, 3);
     if (!live || q != 0) return;
     const float sum = ((s + s1) + s2) + s3;
-    if (is_cs) {
-        colsum[e - n_out] += sum;
-    } else {
-        const int r = e / N, c = e - r * N;
-        float *dst = C + (size_t)r * ldc + c;
-        *dst = beta != 0.0f ? sum + beta * *dst : sum;
-    }
+    float *dst = g.cols > 0 ? g.dst + (size_t)(e / g.cols) * g.ld + e % g.cols : g.dst + (size_t)e * g.ld;
+    if (g.accumulate) *dst += sum;
+    else *dst = a.beta != 0.0f ? sum + a.beta * *dst : sum;
 }
 
 // y[m] = beta y[m] + sum_k A[m][k] x[k * incx]: one wave per row
@@ -431,6 +522,14 @@ int sgemm_split_slices(int M, int N, int K) {
     return std::min(s, SGEMM_MAX_SPLIT);
 }
 
+static kpd_status launch_reduce(const RedArgs &r, hipStream_t st) {
+    long long total = 0;
+    for (int i = 0; i < r.n_seg; ++i) total += r.seg[i].count;
+    hipLaunchKernelGGL(k_sgemm_reduce, dim3((unsigned)cdiv((int)std::min<long long>(4 * total, 0x7fffff00), 256)), dim3(256), 0, st, r);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
 kpd_status sgemm(bool tA, bool tB, int M, int N, int K, float alpha, const float *A, int lda, const float *B, int ldb, float beta,
                  float *C, int ldc, hipStream_t st, float *part, size_t part_floats, float *colsum, const float *silu_pre) {
     if (M <= 0 || N <= 0) return KPD_OK;
@@ -438,6 +537,7 @@ kpd_status sgemm(bool tA, bool tB, int M, int N, int K, float alpha, const float
     KPD_REQUIRE(!colsum || (tA && !tB), KPD_ERR_INVALID, "sgemm: column sums ride along with A^T B products only");
     SgemmArgs a;
     a.colsum = colsum; a.cs_part = nullptr; a.silu_pre = silu_pre;
+    a.xr = a.xc = -1; a.x_part = nullptr;
     if (silu_pre) part = nullptr;               // the epilogue lives in the product kernel: no split along K
     a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.alpha = alpha; a.beta = beta;
     a.vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
@@ -453,36 +553,46 @@ kpd_status sgemm(bool tA, bool tB, int M, int N, int K, float alpha, const float
         if (colsum) a.cs_part = part + (size_t)used * M * N;
         hipLaunchKernelGGL(k_sgemm_tn_skinny, dim3(used), dim3(256), 0, st, a);
         KPD_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_sgemm_reduce, dim3(cdiv(4 * (M * N + (a.cs_part ? M : 0)), 256)), dim3(256), 0, st, part, used, M, N, beta, C, ldc, (const float *)a.cs_part, colsum);
-        KPD_LAUNCH_CHECK();
-        return KPD_OK;
+        RedArgs r;
+        r.n_seg = 0; r.slices = used; r.beta = beta;
+        r.seg[r.n_seg++] = RedSeg{part, (long long)M * N, M * N, C, N, ldc, 0};
+        if (colsum) r.seg[r.n_seg++] = RedSeg{a.cs_part, (long long)M, M, colsum, 0, 1, 1};
+        return launch_reduce(r, st);
     }
-    int slices = part ? (int)std::min<size_t>(sgemm_split_slices(M, N, K), part_floats / ((size_t)M * N + M)) : 1;
+    // Fringe: a 129- / 257- / ...-wide side is tiled over its first M - 1 (N - 1) rows (columns); the last one rides along (k_sgemm)
+    // instead of costing a row (column) of tiles of its own -- 9 tiles for the 257 x 257 weight gradients of the EGNN layers otherwise.
+    static const bool use_fringe = !(getenv("KPD_SGEMM_FRINGE") && atoi(getenv("KPD_SGEMM_FRINGE")) == 0);          // A/B runs
+    int Mt = M, Nt = N;                          // tiled part
+    if (use_fringe && M >= 129 && (M - 1) % 128 == 0) { a.xr = M - 1; Mt = M - 1; }
+    if (use_fringe && N >= 65 && (N - 1) % 64 == 0) { a.xc = N - 1; Nt = N - 1; }
+    const size_t per_slice = (size_t)Mt * Nt + (colsum ? Mt : 0) + ((a.xr >= 0 || a.xc >= 0) ? (size_t)Mt + Nt + 2 : 0);
+    int slices = part ? (int)std::min<size_t>(sgemm_split_slices(Mt, Nt, K), part_floats / per_slice) : 1;
     if (slices > 1) {
         a.k_chunk = cdiv(cdiv(K, slices), SG_BK) * SG_BK;
         slices = cdiv(K, a.k_chunk);
     }
     if (slices > 1) {
-        a.C = part; a.ldc = N; a.beta = 0.0f; a.c_slice = (long long)M * N;
-        if (colsum) a.cs_part = part + (size_t)slices * M * N;
+        a.C = part; a.ldc = Nt; a.beta = 0.0f; a.c_slice = (long long)Mt * Nt;
+        float *nxt = part + (size_t)slices * Mt * Nt;
+        if (colsum) { a.cs_part = nxt; nxt += (size_t)slices * Mt; }
+        if (a.xr >= 0 || a.xc >= 0) a.x_part = nxt;
     } else {
         slices = 1;
         a.k_chunk = cdiv(K, SG_BK) * SG_BK;
     }
+    a.M = Mt; a.N = Nt;
     // tile shape (measured on the engines' shapes, profiles/r03_sgemm_bench.txt): 128-row tiles throughout (256-row tiles lose 10-15 %
     // on every shape: half the workgroups per CU to hide the short K loops behind); 128 columns when that still gives every CU two
     // workgroups, else 64 (node-sized products: more, smaller workgroups balance the 256 CUs better); 32 for the 16-wide vector channels
     static const int force_wn = getenv("KPD_SGEMM_WN") ? atoi(getenv("KPD_SGEMM_WN")) : 0;          // A/B runs
     static const int direct = getenv("KPD_SGEMM_DIRECT") ? atoi(getenv("KPD_SGEMM_DIRECT")) : 1;
     a.direct = direct;
-    int wn = N > 64 ? 4 : N > 32 ? 2 : 1;
-    if (wn == 4 && slices == 1 && (long long)cdiv(M, 128) * cdiv(N, 128) < 2ll * cu_count()) wn = 2;
+    int wn = Nt > 64 ? 4 : Nt > 32 ? 2 : 1;
+    if (wn == 4 && slices == 1 && (long long)cdiv(Mt, 128) * cdiv(Nt, 128) < 2ll * cu_count()) wn = 2;
     if (force_wn) wn = force_wn;
-    const dim3 grid(cdiv(M, 128), cdiv(N, 32 * wn), slices);
+    const dim3 grid(cdiv(Mt, 128), cdiv(Nt, 32 * wn), slices);
     // ring depth of the direct path
     static const int force_stages = getenv("KPD_SGEMM_STAGES") ? atoi(getenv("KPD_SGEMM_STAGES")) : 0;          // A/B runs
-    const long long blocks = (long long)grid.x * grid.y * grid.z;
-    (void)blocks;
     a.stages = 3;          // deeper rings measured slower on every shape (56 -> 71 us on the node-sized gradients at 8 stages): kept as an A/B switch
     if (force_stages) a.stages = std::min(std::max(force_stages, 3), SG_MAX_STAGES);
     KPD_REQUIRE(grid.y <= 65535u && grid.z <= 65535u, KPD_ERR_CAPACITY, "sgemm: N = %d too wide for one launch", N);
@@ -491,8 +601,18 @@ kpd_status sgemm(bool tA, bool tB, int M, int N, int K, float alpha, const float
     else KPD_TRY((launch_shape<1, 1>(tA, tB, grid, st, a)));
     KPD_LAUNCH_CHECK();
     if (slices > 1) {
-        hipLaunchKernelGGL(k_sgemm_reduce, dim3(cdiv(4 * (M * N + (a.cs_part ? M : 0)), 256)), dim3(256), 0, st, part, slices, M, N, beta, C, ldc, (const float *)a.cs_part, colsum);
-        KPD_LAUNCH_CHECK();
+        RedArgs r;
+        r.n_seg = 0; r.slices = slices; r.beta = beta;
+        r.seg[r.n_seg++] = RedSeg{part, (long long)Mt * Nt, Mt * Nt, C, Nt, ldc, 0};
+        if (colsum) r.seg[r.n_seg++] = RedSeg{a.cs_part, (long long)Mt, Mt, colsum, 0, 1, 1};
+        if (a.x_part) {
+            const long long xs = (long long)Mt + Nt + 2;
+            if (a.xc >= 0) r.seg[r.n_seg++] = RedSeg{a.x_part, xs, Mt, C + a.xc, 0, ldc, 0};
+            if (a.xr >= 0) r.seg[r.n_seg++] = RedSeg{a.x_part + Mt, xs, Nt, C + (size_t)a.xr * ldc, 0, 1, 0};
+            if (a.xr >= 0 && a.xc >= 0) r.seg[r.n_seg++] = RedSeg{a.x_part + Mt + Nt, xs, 1, C + (size_t)a.xr * ldc + a.xc, 0, 1, 0};
+            if (a.xr >= 0 && colsum) r.seg[r.n_seg++] = RedSeg{a.x_part + Mt + Nt + 1, xs, 1, colsum + a.xr, 0, 1, 1};
+        }
+        return launch_reduce(r, st);
     }
     return KPD_OK;
 }

@@ -11,6 +11,7 @@ pytestmark = pytest.mark.gpu
 SHAPES = [  # M, N, K
     (1, 1, 1), (5, 3, 2), (64, 257, 10), (300, 16, 16), (1000, 33, 47), (129, 130, 131), (4099, 256, 256), (20800, 257, 514),
     (37, 600, 5), (256, 256, 4096), (2, 700, 1), (70000, 16, 16), (257, 100, 50001), (16, 16, 30000), (16, 16, 1200001), (32, 5, 9000), (1, 32, 8192),
+    (257, 257, 1600), (257, 257, 40000), (129, 65, 77), (385, 129, 300), (1000, 257, 257),        # one row / column past the tiles: the fringe riders
 ]
 
 
@@ -63,7 +64,8 @@ def test_sgemm_is_bitwise_repeatable_and_independent_of_other_rows():
     assert torch.equal(part, o1[1000:1200])
 
 
-@pytest.mark.parametrize('M,N,K', [(256, 256, 50000), (257, 300, 777), (16, 16, 200000), (16, 256, 90000), (100, 7, 33), (130, 64, 5000)])
+@pytest.mark.parametrize('M,N,K', [(256, 256, 50000), (257, 300, 777), (16, 16, 200000), (16, 256, 90000), (100, 7, 33), (130, 64, 5000),
+                                   (257, 257, 30000), (257, 257, 100), (129, 193, 7000)])
 @pytest.mark.parametrize('layout', ['aligned', 'odd_ld'])
 def test_column_sums_ride_along_with_a_weight_gradient(M, N, K, layout):
     """colsum += the column sums of A in the pass that computes A^T B (bias gradient with the weight gradient), with and without the
