@@ -54,7 +54,7 @@ class _EgnnTrainFn(torch.autograd.Function):
         params = ctx.saved_tensors
         lig_x, lig_h, kp_x, kp_h, _ = ctx.inputs
         need = ctx.needs_input_grad[3:7]
-        grads = [torch.zeros_like(p) if ctx.needs_input_grad[7 + i] else None for i, p in enumerate(params)]
+        grads = hip.zero_grads_like(params, [ctx.needs_input_grad[7 + i] for i in range(len(params))])
         ctx.trainer.bind(ctx.names, params, grads)
         d_in = [torch.empty_like(t) if n else None for t, n in zip((lig_x, lig_h, kp_x, kp_h), need)]
         ctx.trainer.backward(d_eps_h.contiguous().float(), d_eps_x.contiguous().float(), d_in[1], d_in[0], d_in[3], d_in[2])

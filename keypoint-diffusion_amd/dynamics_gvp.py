@@ -81,7 +81,7 @@ class _GvpTrainFn(torch.autograd.Function):
                                'grad-enabled forward of the same module (one forward/backward pair at a time per module)')
         params = ctx.saved_tensors
         lig_x, kp_x, lig_h, kp_h, kp_v, _ = ctx.inputs
-        grads = [torch.zeros_like(p) if (ctx.needs_input_grad[8 + i] and p.numel()) else None for i, p in enumerate(params)]
+        grads = hip.zero_grads_like(params, [ctx.needs_input_grad[8 + i] for i in range(len(params))])
         ctx.trainer.bind(ctx.names, params, grads)
         d_in = [torch.empty_like(t) if n else None for t, n in zip((lig_h, kp_h, kp_v), ctx.needs_input_grad[5:8])]
         # positions enter through the unit edge vector and the rbf code of every edge (gvp.py:472-480); the edge lists are data

@@ -802,6 +802,23 @@ def ot_emd_uniform(costs, n_threads: int = 0):
     return [plan[o:o + s].reshape(int(a), int(b)) for o, s, a, b in zip(offs, sizes, ns, ms)]
 
 
+def zero_grads_like(params, wanted):
+    """Zero-filled gradient buffers for the parameters whose flag in `wanted` is set (None for the others), carved out of ONE flat
+    allocation with one fill -- a model has a few hundred parameter tensors, and a fill kernel each is most of a millisecond per step.
+    Offsets are multiples of 64 floats (256 B), so every view is as aligned as a tensor of its own."""
+    sizes = [((p.numel() + 63) // 64) * 64 if (w and p.numel()) else 0 for p, w in zip(params, wanted)]
+    total = sum(sizes)
+    if total == 0:
+        return [None] * len(params)
+    ref = next(p for p, n in zip(params, sizes) if n)
+    flat = torch.zeros(total, device=ref.device, dtype=ref.dtype)
+    out, off = [], 0
+    for p, n in zip(params, sizes):
+        out.append(flat[off:off + p.numel()].view(p.shape) if n else None)
+        off += n
+    return out
+
+
 def sgemm(a: torch.Tensor, b: torch.Tensor, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, out: torch.Tensor = None,
           workspace: torch.Tensor = None, colsum: torch.Tensor = None) -> torch.Tensor:
     """out = alpha op(a) op(b) + beta out through kpd_sgemm (the GEMM of the training engines).  a, b, out: 2-D fp32 device tensors whose

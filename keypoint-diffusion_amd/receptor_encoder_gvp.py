@@ -38,7 +38,7 @@ class _RecEncTrainFn(torch.autograd.Function):
             raise hip.KpdError('backward of a ReceptorEncoderGVP forward whose saved states were overwritten by a later grad-enabled '
                                'forward of the same module (one forward/backward pair at a time per module)')
         params = ctx.saved_tensors
-        grads = [torch.zeros_like(p) if (ctx.needs_input_grad[7 + i] and p.numel()) else None for i, p in enumerate(params)]
+        grads = hip.zero_grads_like(params, [ctx.needs_input_grad[7 + i] for i in range(len(params))])
         ctx.trainer.bind(ctx.names, params, grads)
         c = lambda t: None if t is None else t.contiguous().float()
         ctx.trainer.backward(c(d_x), c(d_h), c(d_v))
