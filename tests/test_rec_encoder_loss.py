@@ -73,3 +73,33 @@ def test_loss_module_types_and_batch_mean():
     for t in ('gaussian_repulsion', 'hinge'):                # the reference raises for these too (rec_encoder_loss.py:86, :107)
         with pytest.raises(NotImplementedError):
             ReceptorEncoderLoss(t)(g)
+
+
+def test_ragged_keypoint_counts_and_begin_finish_halves():
+    """Complexes with different numbers of keypoints AND targets go through the padded [B, K, M] form: value against the oracle, gradient
+    against the per-complex statement sum(P * C) with the plan held constant; begin() / finish() give what forward() gives."""
+    gen = torch.Generator().manual_seed(4)
+    gs = []
+    for nk, nr in [(7, 30), (5, 41), (9, 12)]:
+        g = G.heterograph({}, {'lig': 3, 'rec': nr, 'kp': nk})
+        g.nodes['kp'].data['x_0'] = torch.randn(nk, 3, generator=gen)
+        g.nodes['rec'].data['x_0'] = 2 * torch.randn(nr, 3, generator=gen)
+        g.nodes['lig'].data['x_0'] = torch.randn(3, 3, generator=gen)
+        gs.append(g)
+    b = G.batch(gs)
+    kp = b.nodes['kp'].data['x_0'].clone().requires_grad_(True)
+    b.nodes['kp'].data['x_0'] = kp
+    fn = ReceptorEncoderLoss()
+    loss = fn(b)
+    want = oloss.ot_loss([g.nodes['kp'].data['x_0'] for g in gs], [g.nodes['rec'].data['x_0'] for g in gs])
+    assert abs(float(loss) - want) < 1e-5 * want
+    loss.backward()
+    ref, off = torch.zeros_like(kp), 0
+    for g in gs:
+        k, t = g.nodes['kp'].data['x_0'], g.nodes['rec'].data['x_0']
+        _, plan = compute_ot_emd(torch.cdist(k, t).square())
+        ref[off:off + k.shape[0]] = 2 * (plan.sum(1, keepdim=True) * k - plan @ t) / len(gs)
+        off += k.shape[0]
+    assert torch.allclose(kp.grad, ref, atol=1e-5)
+    pend = fn.begin(b)
+    assert abs(float(pend.finish()) - float(loss)) < 1e-7 and pend.finish() is pend.finish()
