@@ -92,7 +92,7 @@ def test_ragged_keypoint_counts_and_begin_finish_halves():
     fn = ReceptorEncoderLoss()
     loss = fn(b)
     want = oloss.ot_loss([g.nodes['kp'].data['x_0'] for g in gs], [g.nodes['rec'].data['x_0'] for g in gs])
-    assert abs(float(loss) - want) < 1e-5 * want
+    assert abs(float(loss.detach()) - want) < 1e-5 * want
     loss.backward()
     ref, off = torch.zeros_like(kp), 0
     for g in gs:
@@ -102,4 +102,4 @@ def test_ragged_keypoint_counts_and_begin_finish_halves():
         off += k.shape[0]
     assert torch.allclose(kp.grad, ref, atol=1e-5)
     pend = fn.begin(b)
-    assert abs(float(pend.finish()) - float(loss)) < 1e-7 and pend.finish() is pend.finish()
+    assert abs(float(pend.finish().detach()) - float(loss.detach())) < 1e-7 and pend.finish() is pend.finish()
