@@ -14,7 +14,7 @@ streams = [torch.cuda.Stream() for _ in range(NS)]
 bidx = [G.get_batch_idxs(g) for g in gs]
 ones = torch.ones(B // NS, device=dev)
 inits = [(g.nodes['lig'].data['x_0'].clone(), g.nodes['lig'].data['h_0'].clone(), g.nodes['kp'].data['x_0'].clone()) for g in gs]
-T = bench.N_TIMESTEPS
+T = bench.WORKLOADS['egnn_all_atom']['T']
 def step(i):
     si = T - 1 - (i % T)
     for k in range(NS):
