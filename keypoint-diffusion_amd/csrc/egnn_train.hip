@@ -526,10 +526,7 @@ kpd_status node_params(kpd_egnn_trainer *T, int l, int nt, NodeParams *p) {
 kpd_status node_mlp_fwd(kpd_egnn_trainer *T, const NodeParams &p, int l, int nt) {
     const int n = T->n[nt];
     KPD_TRY(gemm(T, false, true, n, H, H, T->hs[nt][l], LD, p.W1.w, 2 * H, 0.0f, T->nb[2], LD));
-    KPD_TRY(gemm(T, false, true, n, H, H, T->hns[nt][l], LD, p.W1.w + H, 2 * H, 1.0f, T->nb[2], LD));
-    const long long tot = (long long)n * H;
-    hipLaunchKernelGGL(k_bias_silu, grid1(tot), dim3(256), 0, T->st, T->nb[2], p.b1.w, tot, H, LD, T->nb[3]);
-    KPD_LAUNCH_CHECK();
+    KPD_TRY(gemm(T, false, true, n, H, H, T->hns[nt][l], LD, p.W1.w + H, 2 * H, 1.0f, T->nb[2], LD, 1.0f, nullptr, p.b1.w, T->nb[3]));      // + bias, SiLU -> nb[3]
     KPD_TRY(gemm(T, false, true, n, H, H, T->nb[3], LD, p.W2.w, H, 0.0f, T->nb[4], LD));
     return KPD_OK;
 }
@@ -574,12 +571,9 @@ kpd_status mlp_params(kpd_egnn_trainer *T, const char *name, int fin, int hid, i
 // pre1 [n, hid] (ld LD... hid <= 512 uses its own stride), act1, pre2 [n, fout]; final_act: out = SiLU(pre2) else out = pre2
 kpd_status mlp_fwd(kpd_egnn_trainer *T, const MlpParams &p, const float *x, int ldx, int n, float *pre1, float *act1, int ld1,
                    float *pre2, int ld2, float *out, int ldo, bool final_act) {
-    KPD_TRY(gemm(T, false, true, n, p.hid, p.fin, x, ldx, p.W0.w, p.fin, 0.0f, pre1, ld1));
-    long long tot = (long long)n * p.hid;
-    hipLaunchKernelGGL(k_bias_silu, grid1(tot), dim3(256), 0, T->st, pre1, p.b0.w, tot, p.hid, ld1, act1);
-    KPD_LAUNCH_CHECK();
+    KPD_TRY(gemm(T, false, true, n, p.hid, p.fin, x, ldx, p.W0.w, p.fin, 0.0f, pre1, ld1, 1.0f, nullptr, p.b0.w, act1));                   // + bias, SiLU -> act1
     KPD_TRY(gemm(T, false, true, n, p.fout, p.hid, act1, ld1, p.W2.w, p.hid, 0.0f, pre2, ld2));
-    tot = (long long)n * p.fout;
+    long long tot = (long long)n * p.fout;
     if (final_act) {
         KPD_REQUIRE(ld2 == ldo, KPD_ERR_INVALID, "internal: mlp_fwd strides");
         hipLaunchKernelGGL(k_bias_silu, grid1(tot), dim3(256), 0, T->st, pre2, p.b2.w, tot, p.fout, ld2, out);

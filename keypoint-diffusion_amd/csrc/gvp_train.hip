@@ -328,9 +328,7 @@ kpd_status encoder_fwd(kpd_gvp_trainer *T, int nt) {
     hipLaunchKernelGGL(k_cat_time, grid1(tot), dim3(256), 0, T->st, nt == 0 ? T->bt.lig_h : T->bt.kp_h, F, T->t_dev, T->bidx[nt], tot,
                        T->enc_in[nt]);
     KPD_LAUNCH_CHECK();
-    KPD_TRY(gemm(T, false, true, n, S, F + 1, T->enc_in[nt], F + 1, W.w, F + 1, 0.0f, T->enc_pre[nt], S));
-    hipLaunchKernelGGL(k_bias_silu, grid1((long long)n * S), dim3(256), 0, T->st, T->enc_pre[nt], b.w, (long long)n * S, S, S, T->enc_act[nt]);
-    KPD_LAUNCH_CHECK();
+    KPD_TRY(gemm(T, false, true, n, S, F + 1, T->enc_in[nt], F + 1, W.w, F + 1, 0.0f, T->enc_pre[nt], S, 1.0f, nullptr, b.w, T->enc_act[nt]));
     hipLaunchKernelGGL(k_ln_fwd, dim3(cdiv(n, 4)), dim3(256), 0, T->st, T->enc_act[nt], l.gamma.w, l.beta.w, n, S, T->ss[nt][0]);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
@@ -376,9 +374,7 @@ kpd_status noise_fwd(kpd_gvp_trainer *T, float *eps_h, float *eps_x) {
     KPD_TRY(param(T, p + ".to_scalar_output.weight", F, kHeadS, &W));
     KPD_TRY(param(T, p + ".to_scalar_output.bias", F, 1, &b));
     if (eps_h) {
-        KPD_TRY(gemm(T, false, true, n, F, kHeadS, T->gb[nn - 1].s, kHeadS, W.w, kHeadS, 0.0f, eps_h, F));
-        hipLaunchKernelGGL(k_bias_add, grid1((long long)n * F), dim3(256), 0, T->st, eps_h, b.w, (long long)n * F, F, F);
-        KPD_LAUNCH_CHECK();
+        KPD_TRY(gemm(T, false, true, n, F, kHeadS, T->gb[nn - 1].s, kHeadS, W.w, kHeadS, 0.0f, eps_h, F, 1.0f, nullptr, b.w));
         KPD_HIP(hipMemcpyAsync(eps_x, T->gb[nn - 1].V, (size_t)n * 12, hipMemcpyDeviceToDevice, T->st));     // [n, 3, 1]
     }
     return KPD_OK;

@@ -358,14 +358,11 @@ kpd_status gvp_fwd(TT *T, const GvpP &g, int M, const float *s_in, int ld_s, con
         KPD_TRY(ws_gemm(WS_BIAS_SILU, s_in, M, ld_s, g.Ws.w, g.si + g.h, false, g.bs.w, nullptr, B.pre, B.s, g.so, T->wsg_pack, T->st, false, true));
     } else {
         if (s_in) KPD_TRY(gemm(T, false, true, M, g.so, g.si, s_in, ld_s, g.Ws.w, g.si + g.h, 0.0f, B.pre, g.so));
-        KPD_TRY(gemm(T, false, true, M, g.so, g.h, B.sh, g.h, g.Ws.w + g.si, g.si + g.h, 1.0f, B.pre, g.so));
-        hipLaunchKernelGGL(k_bias_silu, grid1(tot), dim3(256), 0, T->st, B.pre, g.bs.w, tot, g.so, g.so, B.s);
-        KPD_LAUNCH_CHECK();
+        // + the vector-norm block, the bias and the SiLU in the epilogue: B.pre keeps the pre-activation, B.s its activation
+        KPD_TRY(gemm(T, false, true, M, g.so, g.h, B.sh, g.h, g.Ws.w + g.si, g.si + g.h, 1.0f, B.pre, g.so, 1.0f, nullptr, g.bs.w, B.s));
     }
-    KPD_TRY(gemm(T, false, true, M, g.vo, g.so, B.s, g.so, g.Wg.w, g.so, 0.0f, B.gate, g.vo));
+    KPD_TRY(gemm(T, false, true, M, g.vo, g.so, B.s, g.so, g.Wg.w, g.so, 0.0f, B.gate, g.vo, 1.0f, nullptr, g.bg.w));
     tot = (long long)M * g.vo;
-    hipLaunchKernelGGL(k_bias_add, grid1(tot), dim3(256), 0, T->st, B.gate, g.bg.w, tot, g.vo, g.vo);
-    KPD_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_gvp_gate, grid1(3 * tot), dim3(256), 0, T->st, B.gate, B.Vu, 3 * tot, g.vo, identity ? 1 : 0, B.V);
     KPD_LAUNCH_CHECK();
     return KPD_OK;

@@ -357,18 +357,12 @@ kpd_status conv_edges_fwd(kpd_recegnn_trainer *T, int i, const ConvP &p) {
                        (long long)E * fw, Din, fw, T->f);
     KPD_LAUNCH_CHECK();
     const long long tot = (long long)E * H;
-    KPD_TRY(gemm(T, false, true, E, H, fw, T->f, fw, p.W1.w, fw, 0.0f, T->pre1, H));
-    hipLaunchKernelGGL(k_bias_silu, grid1(tot), dim3(256), 0, st, T->pre1, p.b1.w, tot, H, H, T->a1);
-    KPD_LAUNCH_CHECK();
-    KPD_TRY(gemm(T, false, true, E, H, H, T->a1, H, p.W2.w, H, 0.0f, T->pre2, H));
-    hipLaunchKernelGGL(k_bias_silu, grid1(tot), dim3(256), 0, st, T->pre2, p.b2.w, tot, H, H, T->m);
-    KPD_LAUNCH_CHECK();
+    KPD_TRY(gemm(T, false, true, E, H, fw, T->f, fw, p.W1.w, fw, 0.0f, T->pre1, H, 1.0f, nullptr, p.b1.w, T->a1));        // bias + SiLU in the epilogue
+    KPD_TRY(gemm(T, false, true, E, H, H, T->a1, H, p.W2.w, H, 0.0f, T->pre2, H, 1.0f, nullptr, p.b2.w, T->m));
     hipLaunchKernelGGL(k_rc_att, dim3(cdiv(E, 4)), dim3(256), 0, st, T->m, p.watt.w, p.batt.w, E, H, T->s, T->msg);
     KPD_LAUNCH_CHECK();
     if (!T->cfg.fix_pos) {
-        KPD_TRY(gemm(T, false, true, E, H, fw, T->f, fw, p.Wc1.w, fw, 0.0f, T->cpre, H));
-        hipLaunchKernelGGL(k_bias_silu, grid1(tot), dim3(256), 0, st, T->cpre, p.bc1.w, tot, H, H, T->ca);
-        KPD_LAUNCH_CHECK();
+        KPD_TRY(gemm(T, false, true, E, H, fw, T->f, fw, p.Wc1.w, fw, 0.0f, T->cpre, H, 1.0f, nullptr, p.bc1.w, T->ca));
         hipLaunchKernelGGL(k_rc_coord, dim3(cdiv(E, 4)), dim3(256), 0, st, T->ca, p.w3.w, T->xd, E, H, T->cfg.use_tanh, T->cfg.coords_range, T->c,
                            T->msgx);
         KPD_LAUNCH_CHECK();
@@ -395,13 +389,9 @@ kpd_status conv_fwd(kpd_recegnn_trainer *T, int i) {
     // node MLP on [h, h_neigh] (no residual, :149), LayerNorm
     hipLaunchKernelGGL(k_rc_cat2, grid1((long long)n * (Din + H)), dim3(256), 0, st, T->hs[i], Din, T->hneigh[i], H, (long long)n * (Din + H), T->cat);
     KPD_LAUNCH_CHECK();
-    KPD_TRY(gemm(T, false, true, n, H, Din + H, T->cat, Din + H, p.Wn1.w, Din + H, 0.0f, T->npre[i], H));
-    hipLaunchKernelGGL(k_bias_silu, grid1((long long)n * H), dim3(256), 0, st, T->npre[i], p.bn1.w, (long long)n * H, H, H, T->na);
-    KPD_LAUNCH_CHECK();
+    KPD_TRY(gemm(T, false, true, n, H, Din + H, T->cat, Din + H, p.Wn1.w, Din + H, 0.0f, T->npre[i], H, 1.0f, nullptr, p.bn1.w, T->na));
     float *out = T->cfg.norm ? T->hn[i] : T->hs[i + 1];
-    KPD_TRY(gemm(T, false, true, n, Dout, H, T->na, H, p.Wn2.w, H, 0.0f, out, Dout));
-    hipLaunchKernelGGL(k_bias_add, grid1((long long)n * Dout), dim3(256), 0, st, out, p.bn2.w, (long long)n * Dout, Dout, Dout);
-    KPD_LAUNCH_CHECK();
+    KPD_TRY(gemm(T, false, true, n, Dout, H, T->na, H, p.Wn2.w, H, 0.0f, out, Dout, 1.0f, nullptr, p.bn2.w));
     if (T->cfg.norm) {
         hipLaunchKernelGGL(k_ln_fwd, dim3(cdiv(n, 4)), dim3(256), 0, st, T->hn[i], p.lw.w, p.lb.w, n, Dout, T->hs[i + 1]);
         KPD_LAUNCH_CHECK();
@@ -611,9 +601,7 @@ extern "C" kpd_status kpd_recegnn_trainer_forward(kpd_recegnn_trainer *T, const 
         KPD_TRY(param(T, "rec_kp_conv.layer_norm.weight", D, 1, &lw)); KPD_TRY(param(T, "rec_kp_conv.layer_norm.bias", D, 1, &lb));
     }
     KPD_TRY(launch_graph_mean(T->hs[L], bt->rec_ptr, B, D, T->gmean, st));
-    KPD_TRY(gemm(T, false, true, B, D * K, D, T->gmean, D, Wk.w, D, 0.0f, T->kpe_pre, D * K));
-    hipLaunchKernelGGL(k_bias_silu, grid1((long long)B * D * K), dim3(256), 0, st, T->kpe_pre, bk.w, (long long)B * D * K, D * K, D * K, T->kp_h0);
-    KPD_LAUNCH_CHECK();
+    KPD_TRY(gemm(T, false, true, B, D * K, D, T->gmean, D, Wk.w, D, 0.0f, T->kpe_pre, D * K, 1.0f, nullptr, bk.w, T->kp_h0));
     // RecKeyConv: fc_src on both sides (:190-191), attention-pooled positions over the learned receptor positions (:200-222)
     KPD_TRY(gemm(T, false, true, n_rec, D, D, T->hs[L], D, Wf.w, D, 0.0f, T->ft_src, D));
     KPD_TRY(gemm(T, false, true, n_kp, D, D, T->kp_h0, D, Wf.w, D, 0.0f, T->ft_dst, D));
@@ -632,9 +620,7 @@ extern "C" kpd_status kpd_recegnn_trainer_forward(kpd_recegnn_trainer *T, const 
     hipLaunchKernelGGL(k_rk_feat_in, grid1((long long)n_kp * (D + k)), dim3(256), 0, st, T->hs[L], bt->rec_x, T->kp_x, T->rk_src, k, D,
                        (long long)n_kp * (D + k), T->fin);
     KPD_LAUNCH_CHECK();
-    KPD_TRY(gemm(T, false, true, n_kp, D, D + k, T->fin, D + k, Wp.w, D + k, 0.0f, T->fpre, D));
-    hipLaunchKernelGGL(k_bias_silu, grid1((long long)n_kp * D), dim3(256), 0, st, T->fpre, bp.w, (long long)n_kp * D, D, D, T->fact);
-    KPD_LAUNCH_CHECK();
+    KPD_TRY(gemm(T, false, true, n_kp, D, D + k, T->fin, D + k, Wp.w, D + k, 0.0f, T->fpre, D, 1.0f, nullptr, bp.w, T->fact));
     if (c.norm) {
         hipLaunchKernelGGL(k_ln_fwd, dim3(cdiv(n_kp, 4)), dim3(256), 0, st, T->fact, lw.w, lb.w, n_kp, D, out->kp_h);
         KPD_LAUNCH_CHECK();

@@ -536,12 +536,8 @@ extern "C" kpd_status kpd_recenc_trainer_forward(kpd_recenc_trainer *T, const kp
         KPD_TRY(param(T, "scalar_embed.2.weight", S, S, &W1)); KPD_TRY(param(T, "scalar_embed.2.bias", S, 1, &b1));
         KPD_TRY(param(T, "scalar_norm.weight", S, 1, &lw)); KPD_TRY(param(T, "scalar_norm.bias", S, 1, &lb));
         const long long tot = (long long)n_rec * S;
-        KPD_TRY(gemm(T, false, true, n_rec, S, F, bt->rec_h, F, W0.w, F, 0.0f, T->e_pre0, S));
-        hipLaunchKernelGGL(k_bias_silu, grid1(tot), dim3(256), 0, st, T->e_pre0, b0.w, tot, S, S, T->e_a0);
-        KPD_LAUNCH_CHECK();
-        KPD_TRY(gemm(T, false, true, n_rec, S, S, T->e_a0, S, W1.w, S, 0.0f, T->e_pre1, S));
-        hipLaunchKernelGGL(k_bias_silu, grid1(tot), dim3(256), 0, st, T->e_pre1, b1.w, tot, S, S, T->e_a1);
-        KPD_LAUNCH_CHECK();
+        KPD_TRY(gemm(T, false, true, n_rec, S, F, bt->rec_h, F, W0.w, F, 0.0f, T->e_pre0, S, 1.0f, nullptr, b0.w, T->e_a0));      // bias + SiLU in the epilogue
+        KPD_TRY(gemm(T, false, true, n_rec, S, S, T->e_a0, S, W1.w, S, 0.0f, T->e_pre1, S, 1.0f, nullptr, b1.w, T->e_a1));
         hipLaunchKernelGGL(k_ln_fwd, dim3(cdiv(n_rec, 4)), dim3(256), 0, st, T->e_a1, lw.w, lb.w, n_rec, S, T->rs[0]);
         KPD_LAUNCH_CHECK();
         KPD_HIP(hipMemsetAsync(T->rv[0], 0, (size_t)n_rec * 3 * VC * 4, st));
@@ -563,9 +559,7 @@ extern "C" kpd_status kpd_recenc_trainer_forward(kpd_recenc_trainer *T, const kp
         KPD_TRY(param(T, "keypoint_initializer.dst_net.weight", S, S, &Wd));
         KPD_TRY(launch_graph_mean(T->rs[Rr], bt->rec_ptr, B, S, T->gmean, st));
         const long long tot = (long long)B * S * K;
-        KPD_TRY(gemm(T, false, true, B, S * K, S, T->gmean, S, W.w, S, 0.0f, T->kpe_pre, S * K));
-        hipLaunchKernelGGL(k_bias_silu, grid1(tot), dim3(256), 0, st, T->kpe_pre, b.w, tot, S * K, S * K, T->kpe_act);
-        KPD_LAUNCH_CHECK();
+        KPD_TRY(gemm(T, false, true, B, S * K, S, T->gmean, S, W.w, S, 0.0f, T->kpe_pre, S * K, 1.0f, nullptr, b.w, T->kpe_act));
         hipLaunchKernelGGL(k_ln_fwd, dim3(cdiv(B, 4)), dim3(256), 0, st, T->kpe_act, lw.w, lb.w, B, S * K, T->kp_emb);      // 'b (k d) -> (b k) d'
         KPD_LAUNCH_CHECK();
         KPD_TRY(gemm(T, false, true, n_rec, S, S, T->rs[Rr], S, Ws.w, S, 0.0f, T->ft_src, S));

@@ -10,11 +10,13 @@ constexpr int SGEMM_MAX_SPLIT = 256;
 // gradients: K = edge count) is cut along K into slices computed by grid.z of one launch and summed in slice order (no atomics).
 kpd_status sgemm(bool tA, bool tB, int M, int N, int K, float alpha, const float *A, int lda, const float *B, int ldb, float beta,
                  float *C, int ldc, hipStream_t st, float *part = nullptr, size_t part_floats = 0, float *colsum = nullptr,
-                 const float *silu_pre = nullptr);
+                 const float *silu_pre = nullptr, const float *bias = nullptr, float *act_out = nullptr);
 // colsum (A^T B products only): colsum[m] += sum_k A[k][m] in the same pass over A -- the bias gradient of the Linear whose weight
 // gradient the product is; summed in slab / slice order like the product itself.
 // silu_pre: C = (alpha op(A) op(B) + beta C) * SiLU'(silu_pre[m][n]), silu_pre laid out like C -- the backward of an activation whose
-// pre-activation was kept, fused into the product that produces its upstream gradient
+// pre-activation was kept, fused into the product that produces its upstream gradient.
+// bias: + bias[n]; act_out: a second output SiLU(C), laid out like C -- the Linear + bias + SiLU of a forward pass in one kernel, with
+// the pre-activation (C) kept for the backward pass
 // slices that give every CU about two workgroups for a [M,N] output, bounded by K / 256
 int sgemm_split_slices(int M, int N, int K);
 // y[m * incy] = beta y + sum_k A[m][k] x[k * incx]

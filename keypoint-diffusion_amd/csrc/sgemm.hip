@@ -45,6 +45,8 @@ struct SgemmArgs {
     float *colsum;          // op(A) = A^T only: colsum[m] += sum_k A[k][m] (the bias gradient that goes with a weight gradient), or null
     float *cs_part;         // split-K: per-slice partial column sums [slice][M] instead (summed by k_sgemm_reduce)
     const float *silu_pre;  // epilogue: C = (alpha AB + beta C) * SiLU'(silu_pre[m][n]) (same leading dimension as C), or null
+    const float *bias;      // epilogue: + bias[n] (after alpha / beta), or null
+    float *act_out;         // epilogue: act_out[m][n] = SiLU(C[m][n]) as a second output laid out like C, or null
     // Fringe: M, N above describe the TILED part of the output; one more output row xr (= M) and / or column xc (= N) -- the 257th feature
     // of a 257-wide product -- are computed as riders (xr / xc = -1: none), so that they do not cost a row / column of tiles of their own
     int xr, xc;
@@ -315,7 +317,10 @@ __global__ __launch_bounds__(256, 2) void k_sgemm(SgemmArgs a) {
                 const float sg = 1.0f / (1.0f + __expf(-*pre));
                 v *= sg * (1.0f + *pre * (1.0f - sg));
             }
+            const size_t at = dst - a.C;               // (not split here: a.C is the caller's C)
+            if (a.bias) v += a.bias[at % a.ldc];
             *dst = v;
+            if (a.act_out) a.act_out[at] = v / (1.0f + __expf(-v));
         };
         float *xp = a.x_part ? a.x_part + (size_t)blockIdx.z * (a.M + a.N + 2) : nullptr;
         if (ride_c && m0 + tid < a.M) {
@@ -349,6 +354,7 @@ __global__ __launch_bounds__(256, 2) void k_sgemm(SgemmArgs a) {
             const int n = n0 + 32 * j + col;
             if (n < a.N) {
                 const int mb = m0 + wave * 32 * WM + 32 * i + 4 * half;
+                const float bn = a.bias ? a.bias[n] : 0.0f;
                 float old[16], pre[16];
                 if (accumulate) {
 #pragma unroll
@@ -367,7 +373,11 @@ __global__ __launch_bounds__(256, 2) void k_sgemm(SgemmArgs a) {
                         const float sg = 1.0f / (1.0f + __expf(-pre[r]));
                         v *= sg * (1.0f + pre[r] * (1.0f - sg));
                     }
-                    if (m < a.M) C[(size_t)m * a.ldc + n] = v;
+                    v += bn;
+                    if (m < a.M) {
+                        C[(size_t)m * a.ldc + n] = v;
+                        if (a.act_out) a.act_out[(size_t)m * a.ldc + n] = v / (1.0f + __expf(-v));      // SiLU (train_ops.h silu_f)
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);      // one block's 16 old values at a time, not all WM x WN blocks' (registers)
@@ -531,14 +541,15 @@ static kpd_status launch_reduce(const RedArgs &r, hipStream_t st) {
 }
 
 kpd_status sgemm(bool tA, bool tB, int M, int N, int K, float alpha, const float *A, int lda, const float *B, int ldb, float beta,
-                 float *C, int ldc, hipStream_t st, float *part, size_t part_floats, float *colsum, const float *silu_pre) {
+                 float *C, int ldc, hipStream_t st, float *part, size_t part_floats, float *colsum, const float *silu_pre, const float *bias,
+                 float *act_out) {
     if (M <= 0 || N <= 0) return KPD_OK;
     KPD_REQUIRE(A && B && C && K > 0, KPD_ERR_INVALID, "sgemm: null operand or empty K (M=%d N=%d K=%d)", M, N, K);
     KPD_REQUIRE(!colsum || (tA && !tB), KPD_ERR_INVALID, "sgemm: column sums ride along with A^T B products only");
     SgemmArgs a;
-    a.colsum = colsum; a.cs_part = nullptr; a.silu_pre = silu_pre;
+    a.colsum = colsum; a.cs_part = nullptr; a.silu_pre = silu_pre; a.bias = bias; a.act_out = act_out;
     a.xr = a.xc = -1; a.x_part = nullptr;
-    if (silu_pre) part = nullptr;               // the epilogue lives in the product kernel: no split along K
+    if (silu_pre || bias || act_out) part = nullptr;          // these epilogues live in the product kernel: no split along K
     a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.alpha = alpha; a.beta = beta;
     a.vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
     a.vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
@@ -639,7 +650,7 @@ extern "C" kpd_status kpd_sgemm(int32_t trans_a, int32_t trans_b, int32_t M, int
         if (beta == 0.0f) KPD_HIP(hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, M, st));
         return KPD_OK;
     }
-    return sgemm(trans_a != 0, trans_b != 0, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, st, workspace, (size_t)workspace_floats, colsum, nullptr);
+    return sgemm(trans_a != 0, trans_b != 0, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, st, workspace, (size_t)workspace_floats, colsum, nullptr, nullptr, nullptr);
 }
 
 }  // namespace kpd

@@ -3,6 +3,8 @@
 // column-sum and reduction kernels.  Included by exactly those translation units; everything is file-local.
 #pragma once
 
+#include <stdlib.h>
+
 #include <algorithm>
 #include <map>
 #include <string>
@@ -272,9 +274,18 @@ inline size_t colpart_floats(int max_rows) { return (size_t)cdiv(std::max(max_ro
 
 // row-major C[M,N] = alpha op(A) op(B) + beta C
 // silu_pre: C = (.) * SiLU'(silu_pre), element for element (silu_pre laid out like C): replaces a k_silu_bwd pass over C
+// bias / act_out: C = (.) + bias[n], act_out = SiLU(C) (laid out like C): replaces a k_bias_silu / k_bias_add pass over C
 kpd_status gemm(TrainCtx *T, bool tA, bool tB, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
-                float beta, float *C, int ldc, float alpha = 1.0f, const float *silu_pre = nullptr) {
+                float beta, float *C, int ldc, float alpha = 1.0f, const float *silu_pre = nullptr, const float *bias = nullptr,
+                float *act_out = nullptr) {
     if (M == 0 || N == 0) return KPD_OK;
+    if (K == 0 && (bias || act_out)) {
+        KPD_REQUIRE(beta == 1.0f && !silu_pre && bias, KPD_ERR_INVALID, "gemm: empty K with a bias epilogue needs beta = 1 and a bias");
+        if (act_out) hipLaunchKernelGGL(k_bias_silu, grid1((long long)M * N), dim3(256), 0, T->st, C, bias, (long long)M * N, N, ldc, act_out);
+        else hipLaunchKernelGGL(k_bias_add, grid1((long long)M * N), dim3(256), 0, T->st, C, bias, (long long)M * N, N, ldc);
+        KPD_LAUNCH_CHECK();
+        return KPD_OK;
+    }
     if (K == 0 && silu_pre) {
         KPD_REQUIRE(beta == 1.0f, KPD_ERR_INVALID, "gemm: empty K with an activation epilogue needs beta = 1");
         hipLaunchKernelGGL(k_silu_bwd, grid1((long long)M * N), dim3(256), 0, T->st, C, silu_pre, (long long)M * N, N, ldc);
@@ -286,7 +297,19 @@ kpd_status gemm(TrainCtx *T, bool tA, bool tB, int M, int N, int K, const float 
         return KPD_OK;
     }
     // (the scratch lets a product of few tiles be cut along K: sgemm_split_slices; an activation epilogue keeps the product whole)
-    return sgemm(tA, tB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, T->st, T->part, T->part_floats, nullptr, silu_pre);
+    // a product of a handful of tiles (ligand-sized: 1 600 rows) gains more from the split along K than from a fused epilogue, and the
+    // epilogues live in the unsplit kernel: such a product takes the split and the elementwise pass
+    static const bool fuse = !(getenv("KPD_TRAIN_EPI") && atoi(getenv("KPD_TRAIN_EPI")) == 0);          // A/B runs: 0 = never fuse
+    if ((silu_pre || bias || act_out) && (!fuse || (cdiv(M, 128) * cdiv(N, 128) * 4 <= cu_count() && K >= 128))) {
+        KPD_TRY(sgemm(tA, tB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, T->st, T->part, T->part_floats));
+        const long long tot = (long long)M * N;
+        if (silu_pre) hipLaunchKernelGGL(k_silu_bwd, grid1(tot), dim3(256), 0, T->st, C, silu_pre, tot, N, ldc);
+        if (act_out) hipLaunchKernelGGL(k_bias_silu, grid1(tot), dim3(256), 0, T->st, C, bias, tot, N, ldc, act_out);
+        else if (bias) hipLaunchKernelGGL(k_bias_add, grid1(tot), dim3(256), 0, T->st, C, bias, tot, N, ldc);
+        KPD_LAUNCH_CHECK();
+        return KPD_OK;
+    }
+    return sgemm(tA, tB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, T->st, T->part, T->part_floats, nullptr, silu_pre, bias, act_out);
 }
 
 // y[M] (stride incy) = beta y + A[M,K] x (stride incx), A row-major
