@@ -9,7 +9,7 @@ make -C $csrc -j8 libkpd_hip.so > /dev/null
 objs=$(sed -n 's/^SRCS = //p' $csrc/Makefile | sed 's/\.hip/.o/g')
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $flags -c $csrc/$tu -o /tmp/hz_B.o
 list=""; for o in $objs; do if [ $o = ${tu%.hip}.o ]; then list="$list /tmp/hz_B.o"; else list="$list $csrc/$o"; fi; done
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $root/libkpd_hz_B.so $list -L/opt/rocm/lib -lrocblas -Wl,-rpath,/opt/rocm/lib
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $root/libkpd_hz_B.so $list -lpthread
 cp $csrc/libkpd_hip.so $root/libkpd_hz_A.so
 name=$(basename $script .py)
 cd $root

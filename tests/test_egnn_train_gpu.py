@@ -182,7 +182,7 @@ def test_stale_forward_cannot_be_differentiated():
 
 def test_training_step_is_bitwise_reproducible():
     """No float atomics on the training path: sums over the out-edges of a node are segmented sums over a source-grouped edge
-    index, column sums are reduced in block order, rocBLAS runs with atomics disallowed.  Two forward/backward passes of the same
+    index, column sums are reduced in block order, split-K partial products are summed in slice order.  Two forward/backward passes of the same
     batch give bit-identical outputs and gradients (parameters and inputs)."""
     g, model, t = _case(dict(util.EGNN_C2, n_layers=3), [60, 35, 48], [9, 14, 6])
     model = model.cuda()
