@@ -27,7 +27,9 @@ bool solve_transport(const double *cost, int n, int m, const double *a, const do
     std::vector<double> pi_s(n, 0.0), pi_t(m), dist(n), dsink(m), supply(a, a + n), demand(b, b + m);
     std::vector<int> prev_sink(n), prev_src(n);
     std::vector<char> done(n);
-    std::vector<std::vector<int>> servers(m);
+    // servers of a sink (sources with flow into it): a flat [m][n] table, kept in arrival order
+    std::vector<int> srv((size_t)m * n), nsrv(m, 0);
+    std::vector<double> scratch(m);
     std::fill(plan, plan + (size_t)n * m, 0.0);
     // feasible potentials: pi_t[j] = min_i c_ij keeps every forward reduced cost c_ij + pi_s[i] - pi_t[j] >= 0
     double total = 0.0, placed = 0.0;
@@ -43,7 +45,7 @@ bool solve_transport(const double *cost, int n, int m, const double *a, const do
         const double push = std::min(supply[best], demand[j]);
         if (push > 0.0) {
             plan[(size_t)best * m + j] = push;
-            servers[j].push_back(best);
+            srv[(size_t)j * n + nsrv[j]++] = best;
             supply[best] -= push;
             demand[j] -= push;
             placed += push;
@@ -64,12 +66,22 @@ bool solve_transport(const double *cost, int n, int m, const double *a, const do
             if (u < 0 || du >= best) break;
             done[u] = 1;
             const double *row = cost + (size_t)u * m;
+            // pass 1 (straight-line, vectorisable): tentative distances of all sinks through u
+            const double base = du + pi_s[u];
+            double *dj_all = scratch.data();
             for (int j = 0; j < m; ++j) {
-                const double dj = du + std::max(row[j] + pi_s[u] - pi_t[j], 0.0);
-                if (dj < dsink[j]) dsink[j] = dj;
+                const double dj = std::max(base + row[j] - pi_t[j], du);
+                dj_all[j] = dj;
+                dsink[j] = std::min(dsink[j], dj);
+            }
+            // pass 2: the sinks that can still improve the best target
+            for (int j = 0; j < m; ++j) {
+                const double dj = dj_all[j];
                 if (dj >= best) continue;
                 if (demand[j] > tiny) { best = dj; tj = j; tsrc = u; continue; }
-                for (int i2 : servers[j]) {                 // withdraw flow i2 -> j and carry on from i2
+                const int *sj = srv.data() + (size_t)j * n;
+                for (int q = 0, nq = nsrv[j]; q < nq; ++q) {      // withdraw flow i2 -> j and carry on from i2
+                    const int i2 = sj[q];
                     if (done[i2]) continue;
                     const double nd = dj + std::max(-cost[(size_t)i2 * m + j] + pi_t[j] - pi_s[i2], 0.0);
                     if (nd < dist[i2]) { dist[i2] = nd; prev_sink[i2] = j; prev_src[i2] = u; }
@@ -98,8 +110,13 @@ bool solve_transport(const double *cost, int n, int m, const double *a, const do
             x += f;
             if (x <= 0.0) {
                 x = 0.0;
-                if (was) servers[j].erase(std::find(servers[j].begin(), servers[j].end(), i));
-            } else if (!was) servers[j].push_back(i);
+                if (was) {                                 // drop i from j's servers, order of the rest kept
+                    int *sj = srv.data() + (size_t)j * n;
+                    int q = 0;
+                    while (sj[q] != i) ++q;
+                    for (--nsrv[j]; q < nsrv[j]; ++q) sj[q] = sj[q + 1];
+                }
+            } else if (!was) srv[(size_t)j * n + nsrv[j]++] = i;
         };
         add(tsrc, tj, push);
         v = tsrc;
