@@ -337,9 +337,11 @@ def train_cpu_baseline(workload, B_sample=2):
 # ---------------------------------------------------------------------------------------------------
 # timed regions
 # ---------------------------------------------------------------------------------------------------
-def timed_regions(step, n_warmup, n_steps, repeats, dist, sync_tail=None):
+def timed_regions(step, n_warmup, n_steps, repeats, dist, sync_tail=None, info=None):
     """W warm-up steps, then `repeats` regions of exactly `n_steps` steps, each bracketed by barrier + synchronize on
-    both sides; returns the per-region wall times (seconds), MAX over ranks."""
+    both sides; returns the per-region wall times (seconds), MAX over ranks.  `info` (a dict) receives what a SCALE record
+    needs to show the collective library saw every rank: `ranks_seen` (an all-reduce of ones over the process group) and
+    `per_rank_ms_per_step` (each rank's own median region, all-gathered)."""
     import torch
     it = 0
     for _ in range(n_warmup):
@@ -358,15 +360,31 @@ def timed_regions(step, n_warmup, n_steps, repeats, dist, sync_tail=None):
         if sync_tail is not None:
             sync_tail()
         torch.cuda.synchronize()
+        t_local = time.perf_counter() - t0
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-        out.append(time.perf_counter() - t0)
+        out.append((time.perf_counter() - t0, t_local))
+    local = [b for _, b in out]
+    out = [a for a, _ in out]
     if dist is not None:
         backend_dev = 'cpu' if dist.get_backend() == 'gloo' else 'cuda'
         t = torch.tensor(out, device=backend_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         out = t.cpu().tolist()
+        if info is not None:
+            ones = torch.ones(1, device=backend_dev, dtype=torch.float64)
+            dist.all_reduce(ones)
+            mine = torch.tensor([1e3 * statistics.median(local) / n_steps], device=backend_dev, dtype=torch.float64)
+            every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+            dist.all_gather(every, mine)
+            info['ranks_seen'] = int(round(float(ones.item())))
+            info['per_rank_ms_per_step'] = [float(e.item()) for e in every]
+            info['backend'] = dist.get_backend()
+    elif info is not None:
+        info['ranks_seen'] = 1
+        info['per_rank_ms_per_step'] = [1e3 * statistics.median(local) / n_steps]
+        info['backend'] = None
     return out
 
 
@@ -425,7 +443,8 @@ def run_sampling(args, workload, device, rank, world, dist, B, n_rec, n_lig, rag
             step(i)
         torch.cuda.synchronize()
         eng.profile(True)
-        regions = timed_regions(step, 0, args.steps, args.repeats, dist, tail)
+        rank_info = {}
+        regions = timed_regions(step, 0, args.steps, args.repeats, dist, tail, info=rank_info)
         kern_ms, launches = eng.profile_read()
         eng.profile(False)
         counts = eng.last_counts()
@@ -476,6 +495,8 @@ def run_sampling(args, workload, device, rank, world, dist, B, n_rec, n_lig, rag
                    'parallelism': f'dp{world}'},
         'repeats': {'n': args.repeats, 'ms_per_step': [1e3 * r / args.steps for r in regions], 'statistic': 'median',
                     'spread_pct': 100.0 * (max(regions) - min(regions)) / med},
+        'ranks_seen': rank_info.get('ranks_seen'), 'per_rank_ms_per_step': rank_info.get('per_rank_ms_per_step'),
+        'collective_backend': rank_info.get('backend'),
         'complex_steps_per_s': steps_per_s * B,
         'ligands_per_min_derived': steps_per_s * B * 60.0 / T,
         'edges_per_launch': {**counts, 'E_full_layer': e_all, 'launches_per_step': n_launch_step,
@@ -502,32 +523,134 @@ def run_sampling(args, workload, device, rank, world, dist, B, n_rec, n_lig, rag
     return out
 
 
-def run_end_to_end(device, workload='egnn_all_atom', B=64, n_rec=300, n_lig=25, gemm='f32'):
+def run_end_to_end(device, workload='egnn_all_atom', B=64, n_rec=300, n_lig=25, gemm='f32', ragged=False):
     """One full sampling run as test.py times it (reference test.py:149, 215-232): receptor encoding + T reverse steps of the
-    whole batch + the copy of the sampled ligands to the host.  With random-init weights the chain does not denoise (the
-    ligand spreads and the lig-lig graph thins out), so this is a functional wall-clock figure, not the steady-state rate."""
+    whole batch + the copy of the sampled ligands to the host.  The receptor encoder is timed on its own as well (SURVEY.md
+    8(d): "encoder timed separately"): `encoder_ms` is `encode_receptors` alone, synchronised on both sides.  With random-init
+    weights the chain does not denoise (the ligand spreads and the lig-lig graph thins out), so this is a functional
+    wall-clock figure, not the steady-state rate."""
     import torch
     w = WORKLOADS[workload]
     model = build_model(device, workload)
     model.dynamics.gemm_mode = gemm
     assert model.dynamics.engine().gemm_mode() == gemm
+    if ragged:
+        n_rec, n_lig = ragged_sizes(B, 0)
     with torch.no_grad():
         for _ in range(2):          # first pass = warm-up (workspace reservation, first-use initialisation)
             g = raw_batch(B, n_rec, n_lig, 4321, device, workload)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             enc = model.encode_receptors(g).to(device)
+            torch.cuda.synchronize()
+            t_enc = time.perf_counter() - t0
             pos, feat = model.sample_from_encoded_receptors(enc)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
     assert len(pos) == B and all(p.device.type == 'cpu' for p in pos)
     del model
     torch.cuda.empty_cache()
-    return {'workload': workload, 'gemm': gemm, 'ligands_per_min': 60.0 * B / dt, 'wall_s': dt, 'n_ligands': B, 'n_timesteps': w['T'],
+    return {'workload': workload + ('_ragged' if ragged else ''), 'gemm': gemm, 'ligands_per_min': 60.0 * B / dt, 'wall_s': dt,
+            'encoder_ms': 1e3 * t_enc, 'reverse_loop_and_copy_s': dt - t_enc, 'steps_per_s_in_loop': w['T'] / (dt - t_enc),
+            'n_ligands': B, 'n_timesteps': w['T'],
             'includes': 'receptor encoding + all reverse steps (per-step graph rebuild, fresh noise) + final frame shift + '
                         'device->host copy of the ligands; model build and synthetic-data generation excluded',
             'note': 'random-init weights do not denoise: the ligand spreads over the loop and the lig-lig graph thins, so late '
                     'steps are cheaper than the t=T step the contract line times'}
+
+
+# ---------------------------------------------------------------------------------------------------
+# the ONE line the driver parses: contract fields + roofline + cpu_baseline, everything else as bare numbers
+# ---------------------------------------------------------------------------------------------------
+FULL_RECORD = os.path.join('gpurun_out', 'bench_full_record.json')      # relative to the repo root
+COMPACT_LIMIT = 4096                                                       # bytes; the driver lost a 26.7 KB line in round 3
+
+
+def _r(x, nd=5):
+    """Round to `nd` significant digits (keeps the line short; the side file has full precision)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        return float(f'{x:.{nd}g}')
+    if isinstance(x, (list, tuple)):
+        return [_r(v, nd) for v in x]
+    return x
+
+
+def compact_line(out, full_path=None):
+    """The single JSON line bench.py prints: every contract field, `config`, `roofline` and `cpu_baseline` as the contract
+    defines them, the secondary workloads reduced to `[steps_per_s, ms_per_step, roofline_frac]`, the end-to-end runs to
+    `[ligands_per_min, encoder_ms]`.  Prose and per-case detail live in the side file `full_path`.  Pure function of the
+    record (tests/test_bench_line.py feeds it a synthetic full record and bounds the length)."""
+    cfg = out.get('config', {})
+    line = {k: _r(out.get(k)) for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
+                                        'scaling', 'vs_baseline')}
+    dtype = str(out.get('dtype', 'f32'))
+    line['dtype'] = dtype if len(dtype) <= 16 else dtype.split(' ', 1)[0] + ('+f16x2' if 'f16x2' in dtype else '')
+    line['data'] = out.get('data', 'synthetic')
+    wl = str(cfg.get('workload', ''))
+    line['config'] = {'workload': wl if len(wl) <= 260 else wl[:257] + '...',
+                      **{k: cfg[k] for k in ('batch_per_gpu', 'n_rec', 'n_lig', 'parallelism') if k in cfg}}
+    rf = out.get('roofline')
+    if rf:
+        line['roofline'] = {k: _r(rf.get(k), 9 if k == 'traffic' else 5) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic',
+                                                                                   'avg_launch_ms', 'launches', 'kernel_ms_total', 'wall_ms_total')}
+        if 'hbm' in rf:
+            line['roofline']['hbm_frac'] = _r(rf['hbm'].get('frac'))
+    cb = out.get('cpu_baseline')
+    if cb:
+        host = cb.get('host', {})
+        line['cpu_baseline'] = {'value': _r(cb.get('value')), 'unit': cb.get('unit'), 'cores': cb.get('cores'), 'kind': cb.get('kind'),
+                                'sample': 'oracle reverse steps at the same shape, B=1 and B=8, 2 warm-up + 7 timed each, median; '
+                                          'value = B=8 rate scaled to the batch' if 'cases' in cb else str(cb.get('sample', ''))[:160],
+                                'cpu_model': host.get('cpu_model'),
+                                'cases': {k: _r(v.get('complex_steps_per_s')) for k, v in cb.get('cases', {}).items()},
+                                'spread_pct': {k: _r(v.get('spread_pct'), 3) for k, v in cb.get('cases', {}).items()}}
+        if 'c1_dev_config' in cb:
+            line['cpu_baseline']['c1_total_s_100_steps'] = _r(cb['c1_dev_config'].get('total_s_100_steps'))
+    for k in ('gpu_over_cpu', 'complex_steps_per_s', 'ranks_seen', 'per_rank_ms_per_step', 'collective_backend'):
+        if out.get(k) is not None:
+            line[k] = _r(out[k])
+    rep = out.get('repeats')
+    if rep:
+        line['repeats'] = {'n': rep.get('n'), 'spread_pct': _r(rep.get('spread_pct'), 3)}
+    sec = out.get('secondary')
+    if sec:
+        line['secondary'] = {name: [_r(r.get('value')), _r(r.get('ms_per_step')), _r(r.get('roofline', {}).get('frac'), 4)]
+                             for name, r in sec.items()}
+        line['secondary_fields'] = ['steps_per_s', 'ms_per_step', 'roofline_frac']
+    e2e = {}
+    if out.get('end_to_end'):
+        e2e[out['end_to_end'].get('workload', 'egnn_all_atom')] = out['end_to_end']
+    for name, r in (out.get('end_to_end_more') or {}).items():
+        e2e[name] = r
+    if e2e:
+        line['end_to_end'] = {name: [_r(r.get('ligands_per_min')), _r(r.get('encoder_ms')), r.get('n_timesteps')] for name, r in e2e.items()}
+        line['end_to_end_fields'] = ['ligands_per_min', 'encoder_ms', 'T']
+    if out.get('ligands_per_min') is not None:
+        line['ligands_per_min'] = _r(out['ligands_per_min'])
+    if full_path:
+        line['full_record'] = full_path
+    return line
+
+
+def emit(out):
+    """Write the full record to the side file (best effort: a read-only tree must not lose the line) and print the compact line."""
+    path = None
+    try:
+        os.makedirs(os.path.join(ROOT, os.path.dirname(FULL_RECORD)), exist_ok=True)
+        with open(os.path.join(ROOT, FULL_RECORD), 'w') as f:
+            json.dump(out, f, indent=1)
+        path = FULL_RECORD
+    except OSError as e:
+        print(f'bench.py: full record not written ({e})', file=sys.stderr)
+    text = json.dumps(compact_line(out, path), separators=(',', ':'))
+    if len(text) > COMPACT_LIMIT:                         # never again hand the driver a line it cannot take
+        slim = compact_line({k: v for k, v in out.items() if k not in ('secondary', 'end_to_end_more')}, path)
+        slim['dropped'] = 'secondary (line over %d bytes): see full_record' % COMPACT_LIMIT
+        text = json.dumps(slim, separators=(',', ':'))
+    sys.stdout.flush()
+    print(text, flush=True)
 
 
 def run_train(args, device, rank, world, dist):
@@ -555,7 +678,8 @@ def run_train(args, device, rank, world, dist):
         opt.step()
         last[0] = losses['l2']
 
-    regions = timed_regions(step, args.warmup, args.steps, args.repeats, dist)
+    rank_info = {}
+    regions = timed_regions(step, args.warmup, args.steps, args.repeats, dist, info=rank_info)
     if rank == 0:
         med = statistics.median(regions)
         out = {'metric': 'training steps/sec', 'value': world * args.steps / med, 'unit': 'steps/s', 'n_gpus': world,
@@ -566,10 +690,11 @@ def run_train(args, device, rank, world, dist):
                                       f'synthetic {args.n_rec}-atom pockets / {args.n_lig}-atom ligands per GPU, one bucketed gradient all-reduce per step when N > 1',
                           'batch_per_gpu': B, 'parallelism': f'dp{world}'},
                'repeats': {'n': args.repeats, 'ms_per_step': [1e3 * r / args.steps for r in regions], 'statistic': 'median'},
-               'complex_steps_per_s': world * args.steps / med * B, 'final_l2': float(last[0].detach())}
+               'complex_steps_per_s': world * args.steps / med * B, 'final_l2': float(last[0].detach()),
+               'ranks_seen': rank_info.get('ranks_seen'), 'per_rank_ms_per_step': rank_info.get('per_rank_ms_per_step')}
         if world == 1 and not args.no_cpu_baseline and w['enc'] == 'fixed':
             out['cpu_baseline'] = train_cpu_baseline(args.workload)
-        print(json.dumps(out), flush=True)
+        emit(out)
 
 
 def main():
@@ -623,7 +748,8 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     dist = None
-    if world > 1:
+    # KPD_BENCH_DIST_AT_1=1: a ONE-rank job still initialises RCCL and takes the distributed branch (tests/test_nccl_gpu.py)
+    if world > 1 or os.environ.get('KPD_BENCH_DIST_AT_1') == '1':
         import torch.distributed as dist
         if share:
             dist.init_process_group('gloo')
@@ -690,7 +816,10 @@ def main():
             out['secondary'] = sec
             out['end_to_end'] = run_end_to_end(device)
             out['ligands_per_min'] = out['end_to_end']['ligands_per_min']
-        print(json.dumps(out), flush=True)
+            # configs[2] (learned encoder timed on its own) and the configs[4] shape at its own T = 1000, exact mode
+            out['end_to_end_more'] = {'gvp_40kp': run_end_to_end(device, 'gvp_40kp'),
+                                      'gvp_all_atom_ragged': run_end_to_end(device, 'gvp_all_atom', ragged=True)}
+        emit(out)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -92,7 +92,10 @@ def all_gather_ligands(g: G.HeteroBatch, group=None) -> Tuple[List[torch.Tensor]
 
 
 def sharding_active(group=None) -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    """True under ANY initialised process group, a single-rank one included: a one-rank job then takes exactly the code path
+    (shard -> per-complex Philox noise -> gather) and draws exactly the noise an eight-rank job does, so its ligands are
+    the eight-rank job's ligands, and the RCCL branch can be tested on a one-GPU box (tests/test_nccl_gpu.py)."""
+    return dist.is_available() and dist.is_initialized()
 
 
 def sharded_map(costs: Sequence[float], fn, group=None, device: Optional[torch.device] = None):
@@ -120,9 +123,10 @@ def allreduce_gradients(params, group=None, bucket_bytes: int = 64 << 20, averag
     per-layer overlap to exploit; what matters on xGMI is few, large ring all-reduces: gradients are packed into
     flat buckets of `bucket_bytes` (the whole 48 MB of egnn_all_atom fits one), every bucket's all-reduce is launched
     asynchronously back to back, then results are scattered back into the `.grad` tensors.  RCCL on the GPU box, gloo in
-    the CPU tests; frozen parameters (grad None) are skipped on every rank alike."""
+    the CPU tests; frozen parameters (grad None) are skipped on every rank alike.  A one-rank group still runs the collective
+    (a 48 MB pack + copy, ~0.1 ms): one code path for every world size.  Returns the number of buckets reduced."""
     grads = [p.grad for p in params if p.grad is not None]
-    if not grads or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not grads or not dist.is_initialized():
         return 0
     world = dist.get_world_size(group)
     buckets, cur, size = [], [], 0

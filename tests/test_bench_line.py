@@ -1,0 +1,111 @@
+"""The ONE JSON line bench.py prints must stay small enough for the driver to parse (round 3 lost a 26.7 KB line) and must
+carry the contract fields, `roofline` and `cpu_baseline`.  CPU-only: `compact_line` is a pure function of the full record."""
+import io
+import json
+import os
+import sys
+from contextlib import redirect_stdout
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+CONTRACT = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+            'dtype', 'data', 'config')
+ROOFLINE = ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_ms', 'launches', 'kernel_ms_total',
+            'wall_ms_total')
+
+
+def synthetic_record(n_secondary=7, prose=400, world=8):
+    """A full record shaped like run_sampling's, with worst-case prose in every free-text field and nested secondaries."""
+    text = 'x' * prose
+
+    def one(kernel):
+        return {
+            'metric': 'denoising steps/sec', 'value': 145.4372708922574, 'unit': 'steps/s', 'n_gpus': world, 'steps': 200, 'warmup': 20,
+            'ms_per_step': 6.875816589963506, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32 via f16x2 split ' + text, 'data': 'synthetic',
+            'config': {'workload': 'egnn_all_atom ' + text, 'batch_per_gpu': 64, 'n_rec': 300, 'n_lig': 25, 'parallelism': f'dp{world}'},
+            'repeats': {'n': 3, 'ms_per_step': [6.869883344988921] * 3, 'statistic': 'median', 'spread_pct': 0.20963735469261716},
+            'ranks_seen': world, 'per_rank_ms_per_step': [6.875816589963506] * world, 'collective_backend': 'nccl',
+            'complex_steps_per_s': 9307.985337104474, 'ligands_per_min_derived': 1116.9582404525368,
+            'edges_per_launch': {'E_ll': 38372, 'E_kl': 96000, 'E_lk': 96000, 'E_kk': 165934, 'mean_edges_per_launch': 352650.3333333333},
+            'roofline': {'kernel': kernel, 'bound': 'mfma', 'achieved': 109.55030878383664, 'peak': 157.3, 'unit': 'TFLOP/s',
+                         'frac': 0.6964418867376773, 'peak_note': text, 'peak_measured': {'value': 155.5, 'source': text},
+                         'traffic': 213904592.0, 'traffic_source': text, 'traffic_unit': text, 'avg_launch_ms': 0.8537751563307312,
+                         'launches': 3600, 'kernel_ms_total': 3073.5905627906322, 'wall_ms_total': 4125.999511990813,
+                         'hbm': {'achieved': 431.2, 'peak': 8000.0, 'unit': 'GB/s', 'frac': 0.053902796490101504}},
+            'cpu_baseline': {'value': 0.22535376985935593, 'unit': 'steps/s', 'cores': 16, 'kind': 'port', 'sample': text,
+                             'cases': {f'B{b}': {'B': b, 'timed_steps': 7, 's_per_step_median': 0.0653, 'spread_pct': 47.93436507151554,
+                                                 'complex_steps_per_s': 15.306476528559452} for b in (1, 8)},
+                             'host': {'cpu_model': 'AMD EPYC 9575F 64-Core Processor', 'physical_cores': 128, 'torch': '2.10.0+rocm7.0'},
+                             'c1_dev_config': {'total_s_100_steps': 1.3231211599631933, 'note': text}},
+            'gpu_over_cpu': 645.3731436710614,
+        }
+
+    out = one('k_egnn_edge')
+    out['secondary'] = {f'secondary_workload_name_{i}_f16x2': one('k_gvp_chain<16, 1>') for i in range(n_secondary)}
+    e2e = {'workload': 'egnn_all_atom', 'gemm': 'f32', 'ligands_per_min': 1244.5380179742924, 'wall_s': 3.08, 'encoder_ms': 0.31,
+           'n_ligands': 64, 'n_timesteps': 500, 'includes': text, 'note': text}
+    out['end_to_end'] = e2e
+    out['end_to_end_more'] = {'gvp_40kp': dict(e2e, workload='gvp_40kp', encoder_ms=11.7),
+                              'gvp_all_atom_ragged': dict(e2e, workload='gvp_all_atom_ragged', n_timesteps=1000)}
+    out['ligands_per_min'] = e2e['ligands_per_min']
+    return out
+
+
+def test_compact_line_is_short_and_complete():
+    rec = synthetic_record()
+    assert len(json.dumps(rec)) > 20000                       # the record itself is the size that broke round 3
+    line = bench.compact_line(rec, bench.FULL_RECORD)
+    text = json.dumps(line, separators=(',', ':'))
+    assert len(text) < 6000 and len(text) <= bench.COMPACT_LIMIT, len(text)
+    assert '\n' not in text
+    back = json.loads(text)
+    for k in CONTRACT:
+        assert k in back, k
+    assert back['config']['workload'] and 'model' not in back['config']
+    for k in ROOFLINE:
+        assert k in back['roofline'], k
+    assert abs(back['roofline']['frac'] - rec['roofline']['frac']) < 1e-4
+    assert back['roofline']['traffic'] == rec['roofline']['traffic']
+    cb = back['cpu_baseline']
+    assert cb['kind'] == 'port' and cb['cores'] == 16 and cb['sample'] and abs(cb['value'] - 0.22535) < 1e-4
+    assert set(cb['cases']) == {'B1', 'B8'} and all(isinstance(v, float) for v in cb['cases'].values())
+    assert back['ranks_seen'] == 8 and len(back['per_rank_ms_per_step']) == 8
+    assert len(back['secondary']) == 7 and all(len(v) == 3 for v in back['secondary'].values())
+    assert set(back['end_to_end']) == {'egnn_all_atom', 'gvp_40kp', 'gvp_all_atom_ragged'}
+    assert back['end_to_end']['gvp_40kp'][1] == 11.7            # encoder time reported on its own
+    assert back['full_record'] == bench.FULL_RECORD
+    assert abs(back['value'] - rec['value']) / rec['value'] < 1e-4
+
+
+def test_emit_prints_exactly_one_line_and_writes_the_side_file(tmp_path, monkeypatch):
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        bench.emit(synthetic_record())
+    lines = buf.getvalue().splitlines()
+    assert len(lines) == 1 and len(lines[0]) <= bench.COMPACT_LIMIT
+    full = json.load(open(tmp_path / bench.FULL_RECORD))
+    assert 'peak_note' in full['roofline'] and len(full['secondary']) == 7      # nothing is lost: the prose is in the side file
+
+
+def test_emit_drops_secondaries_rather_than_overflow(tmp_path, monkeypatch):
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        bench.emit(synthetic_record(n_secondary=120))
+    (line,) = buf.getvalue().splitlines()
+    back = json.loads(line)
+    assert len(line) <= bench.COMPACT_LIMIT and 'secondary' not in back and 'dropped' in back
+    assert 'roofline' in back and 'cpu_baseline' in back
+
+
+def test_training_record_goes_through_the_same_line():
+    rec = {'metric': 'training steps/sec', 'value': 15.03, 'unit': 'steps/s', 'n_gpus': 1, 'steps': 20, 'warmup': 3, 'ms_per_step': 66.5,
+           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+           'config': {'workload': 'egnn_train: ...', 'batch_per_gpu': 64, 'parallelism': 'dp1'},
+           'cpu_baseline': {'value': 0.01, 'unit': 'steps/s', 'cores': 16, 'kind': 'port', 'sample': 'y' * 500}}
+    back = json.loads(json.dumps(bench.compact_line(rec)))
+    assert back['cpu_baseline']['cores'] == 16 and len(back['cpu_baseline']['sample']) <= 160 and 'roofline' not in back
