@@ -146,7 +146,7 @@ __global__ void k_segsum3(const float *__restrict__ M, const int *__restrict__ r
 
 // h' = LayerNorm(h + q2 + b2) (or without the norm), one wave per node (dynamics.py:202-205)
 __global__ void k_node_out(const float *__restrict__ h, const float *__restrict__ q2, const float *__restrict__ b2,
-                           const float *__restrict__ gamma, const float *__restrict__ beta, int norm, int n,
+                           const float *__restrict__ gamma, const float *__restrict__ beta, int norm, int n, int hid,
                            float *__restrict__ out) {
     const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (r >= n) return;
@@ -154,7 +154,7 @@ __global__ void k_node_out(const float *__restrict__ h, const float *__restrict_
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
         const int c = lane + 64 * k;
-        u[k] = c < H ? h[(size_t)r * LD + c] + q2[(size_t)r * LD + c] + b2[c] : 0.0f;
+        u[k] = (c < hid || c == H - 1) ? h[(size_t)r * LD + c] + q2[(size_t)r * LD + c] + b2[c] : 0.0f;
         s += u[k];
     }
     if (!norm) {
@@ -163,16 +163,17 @@ __global__ void k_node_out(const float *__restrict__ h, const float *__restrict_
             if (lane + 64 * k < H) out[(size_t)r * LD + lane + 64 * k] = u[k];
         return;
     }
-    const float mean = wave_sum(s) * (1.0f / H);
+    const float inv_n = 1.0f / (float)(hid + 1);      // live columns: [0, hid) and the timestep column (hid < 256: zero padding between)
+    const float mean = wave_sum(s) * inv_n;
     float q = 0.0f;
 #pragma unroll
     for (int k = 0; k < 5; ++k)
-        if (lane + 64 * k < H) q += (u[k] - mean) * (u[k] - mean);
-    const float rstd = rsqrtf(wave_sum(q) * (1.0f / H) + 1e-5f);
+        if (lane + 64 * k < hid || lane + 64 * k == H - 1) q += (u[k] - mean) * (u[k] - mean);
+    const float rstd = rsqrtf(wave_sum(q) * inv_n + 1e-5f);
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
         const int c = lane + 64 * k;
-        if (c < H) out[(size_t)r * LD + c] = (u[k] - mean) * rstd * gamma[c] + beta[c];
+        if (c < H) out[(size_t)r * LD + c] = (c < hid || c == H - 1) ? (u[k] - mean) * rstd * gamma[c] + beta[c] : 0.0f;
     }
 }
 
@@ -197,7 +198,7 @@ __global__ void k_zinv(const float *__restrict__ z, const int *__restrict__ bidx
 
 // LayerNorm backward, one wave per node: u = h + q2 + b2 recomputed; du, and dy * xhat for the gamma gradient
 __global__ void k_ln_bwd(const float *__restrict__ h, const float *__restrict__ q2, const float *__restrict__ b2,
-                         const float *__restrict__ gamma, const float *__restrict__ dy, int n, float *__restrict__ du,
+                         const float *__restrict__ gamma, const float *__restrict__ dy, int n, int hid, float *__restrict__ du,
                          float *__restrict__ dyxhat) {
     const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (r >= n) return;
@@ -205,32 +206,34 @@ __global__ void k_ln_bwd(const float *__restrict__ h, const float *__restrict__ 
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
         const int c = lane + 64 * k;
-        u[k] = c < H ? h[(size_t)r * LD + c] + q2[(size_t)r * LD + c] + b2[c] : 0.0f;
+        u[k] = (c < hid || c == H - 1) ? h[(size_t)r * LD + c] + q2[(size_t)r * LD + c] + b2[c] : 0.0f;
         s += u[k];
     }
-    const float mean = wave_sum(s) * (1.0f / H);
+    const float inv_n = 1.0f / (float)(hid + 1);
+    const float mean = wave_sum(s) * inv_n;
     float q = 0.0f;
 #pragma unroll
     for (int k = 0; k < 5; ++k)
-        if (lane + 64 * k < H) q += (u[k] - mean) * (u[k] - mean);
-    const float rstd = rsqrtf(wave_sum(q) * (1.0f / H) + 1e-5f);
+        if (lane + 64 * k < hid || lane + 64 * k == H - 1) q += (u[k] - mean) * (u[k] - mean);
+    const float rstd = rsqrtf(wave_sum(q) * inv_n + 1e-5f);
     float g[5], xh[5], sg = 0.0f, sgx = 0.0f;
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
         const int c = lane + 64 * k;
-        xh[k] = c < H ? (u[k] - mean) * rstd : 0.0f;
-        const float d = c < H ? dy[(size_t)r * LD + c] : 0.0f;
-        g[k] = c < H ? d * gamma[c] : 0.0f;
+        const bool live = c < hid || c == H - 1;
+        xh[k] = live ? (u[k] - mean) * rstd : 0.0f;
+        const float d = live ? dy[(size_t)r * LD + c] : 0.0f;
+        g[k] = live ? d * gamma[c] : 0.0f;
         sg += g[k];
         sgx += g[k] * xh[k];
         if (c < H) dyxhat[(size_t)r * LD + c] = d * xh[k];
     }
-    sg = wave_sum(sg) * (1.0f / H);
-    sgx = wave_sum(sgx) * (1.0f / H);
+    sg = wave_sum(sg) * inv_n;
+    sgx = wave_sum(sgx) * inv_n;
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
         const int c = lane + 64 * k;
-        if (c < H) du[(size_t)r * LD + c] = rstd * (g[k] - sg - xh[k] * sgx);
+        if (c < H) du[(size_t)r * LD + c] = (c < hid || c == H - 1) ? rstd * (g[k] - sg - xh[k] * sgx) : 0.0f;
     }
 }
 
@@ -544,7 +547,7 @@ kpd_status nodes_fwd(kpd_egnn_trainer *T, int l) {
         KPD_TRY(node_params(T, l, nt, &p));
         KPD_TRY(node_mlp_fwd(T, p, l, nt));
         hipLaunchKernelGGL(k_node_out, dim3(cdiv(n, 4)), dim3(256), 0, T->st, T->hs[nt][l], T->nb[4], p.b2.w, p.gamma.w, p.beta.w,
-                           T->cfg.norm, n, T->hs[nt][l + 1]);
+                           T->cfg.norm, n, T->cfg.hidden_nf, T->hs[nt][l + 1]);
         KPD_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_axpy3, grid1(3 * n), dim3(256), 0, T->st, T->xs[nt][l], T->xns[nt][l], 3 * n, T->xs[nt][l + 1]);
         KPD_LAUNCH_CHECK();
@@ -608,7 +611,7 @@ constexpr int ENC_LD = 512;       // row stride of the encoder / decoder hidden 
 
 extern "C" kpd_status kpd_egnn_trainer_create(const kpd_egnn_config *cfg, kpd_egnn_trainer **out) {
     KPD_REQUIRE(cfg && out, KPD_ERR_INVALID, "null argument");
-    KPD_REQUIRE(cfg->hidden_nf == 256, KPD_ERR_INVALID, "hidden_nf=%d: only 256 is supported", cfg->hidden_nf);
+    KPD_REQUIRE(cfg->hidden_nf >= 1 && cfg->hidden_nf <= HID, KPD_ERR_INVALID, "hidden_nf=%d outside 1 .. %d", cfg->hidden_nf, HID);
     KPD_REQUIRE(cfg->atom_nf >= 1 && cfg->atom_nf <= 256 && cfg->rec_nf >= 1 && cfg->rec_nf <= 256 && cfg->n_layers >= 1 &&
                     cfg->n_layers <= 64,
                 KPD_ERR_INVALID, "atom_nf=%d rec_nf=%d n_layers=%d", cfg->atom_nf, cfg->rec_nf, cfg->n_layers);
@@ -618,7 +621,7 @@ extern "C" kpd_status kpd_egnn_trainer_create(const kpd_egnn_config *cfg, kpd_eg
     T->cfg = *cfg;
     T->n_et = cfg->update_kp_feat ? 4 : 2;
     T->n_upd = cfg->update_kp_feat ? 2 : 1;
-    T->rec_identity = cfg->rec_nf == 256;
+    T->rec_identity = cfg->rec_nf == cfg->hidden_nf;        // models/dynamics.py:326-334
     *out = T;
     return KPD_OK;
 }
@@ -626,6 +629,7 @@ extern "C" kpd_status kpd_egnn_trainer_create(const kpd_egnn_config *cfg, kpd_eg
 extern "C" void kpd_egnn_trainer_destroy(kpd_egnn_trainer *T) {
     if (!T) return;
     T->ws.release();
+    T->wide.release();
     if (T->store_base) (void)hipFree(T->store_base);
     delete T;
 }
@@ -633,6 +637,38 @@ extern "C" void kpd_egnn_trainer_destroy(kpd_egnn_trainer *T) {
 extern "C" kpd_status kpd_egnn_trainer_bind(kpd_egnn_trainer *T, const char *name, const float *weight, float *grad,
                                             const int64_t *shape, int32_t ndim) {
     KPD_REQUIRE(T && name && weight && shape && (ndim == 1 || ndim == 2), KPD_ERR_INVALID, "bad argument");
+    const kpd_egnn_config &c = T->cfg;
+    if (c.hidden_nf != HID) {
+        // hidden_nf < 256 (the reference's default constructor has 255, models/dynamics.py:300-302): the tensors whose axes carry the
+        // hidden width are trained through their 256-wide zero-padded form (train_ops.h, WideSet).  Which axes do: reference shapes
+        // models/dynamics.py:37-87, 313-334 -- F = [hidden | timestep] -> 257 columns with the timestep last, P = hidden -> 256.
+        const int h = c.hidden_nf;
+        const std::vector<AxisSeg> F = {{h, HID}, {1, 1}}, P = {{h, HID}};
+        auto cat = [](std::vector<AxisSeg> a, const std::vector<AxisSeg> &b) { a.insert(a.end(), b.begin(), b.end()); return a; };
+        auto R = [](int n) { return std::vector<AxisSeg>{{n, n}}; };
+        const std::vector<std::string> tk = split_name(name);
+        const bool is_w = tk.back() == "weight";
+        std::vector<AxisSeg> rows, cols;
+        bool touch = true;
+        if (tk[0] == "lig_encoder" || tk[0] == "rec_encoder") {
+            if (tk.size() < 2 || tk[1] == "0") touch = false;
+            else { rows = P; if (is_w) cols = R(tk[0] == "lig_encoder" ? 64 : 2 * c.rec_nf); }
+        } else if (tk[0] == "lig_decoder") {
+            if (tk.size() >= 2 && tk[1] == "0" && is_w) { rows = R(2 * c.atom_nf); cols = P; }
+            else touch = false;
+        } else if (tk.size() >= 6 && tk[0] == "egnn") {
+            const std::string &blk = tk[3];
+            if (blk == "layer_norm") rows = F;
+            else if (blk == "node_mlp") { rows = F; if (is_w) cols = tk[5] == "0" ? cat(F, F) : F; }
+            else if (blk == "soft_attention") { if (is_w) { rows = R(1); cols = F; } else touch = false; }
+            else if (tk[5] == "0") { rows = F; if (is_w) cols = cat(cat(F, F), R(1)); }
+            else if (tk[5] == "2") { rows = F; if (is_w) cols = F; }
+            else { rows = R(1); cols = F; }                     // coord_mlp.<et>.4.weight
+        } else {
+            touch = false;
+        }
+        if (touch) return bind_wide(T, name, weight, grad, shape, ndim, rows, cols);
+    }
     Param p;
     p.w = weight;
     p.g = grad;
@@ -780,8 +816,9 @@ kpd_status encoders_fwd(kpd_egnn_trainer *T) {
     KPD_TRY(mlp_params(T, "lig_encoder", c.atom_nf, 64, 256, &p));
     KPD_TRY(mlp_fwd(T, p, T->bt.lig_h, c.atom_nf, T->n[0], T->enc1[0], T->enc2[0], ENC_LD, T->nb[0], LD, T->hs[0][0], LD, true));
     if (T->rec_identity) {
-        const long long tot = (long long)T->n[1] * 256;
-        hipLaunchKernelGGL(k_copy_rows, grid1(tot), dim3(256), 0, T->st, T->bt.kp_h, 256, T->hs[1][0], LD, tot, 256);
+        const long long tot = (long long)T->n[1] * c.hidden_nf;
+        if (c.hidden_nf != HID) KPD_HIP(hipMemsetAsync(T->hs[1][0], 0, (size_t)T->n[1] * LD * 4, T->st));       // padding columns are zeros
+        hipLaunchKernelGGL(k_copy_rows, grid1(tot), dim3(256), 0, T->st, T->bt.kp_h, c.hidden_nf, T->hs[1][0], LD, tot, c.hidden_nf);
         KPD_LAUNCH_CHECK();
     } else {
         KPD_TRY(mlp_params(T, "rec_encoder", c.rec_nf, 2 * c.rec_nf, 256, &p));
@@ -807,6 +844,7 @@ extern "C" kpd_status kpd_egnn_trainer_forward(kpd_egnn_trainer *T, const kpd_ba
     const kpd_egnn_config &c = T->cfg;
     hipStream_t st = static_cast<hipStream_t>(stream);
     T->st = st;
+    KPD_TRY(wide_run(T, 0));                   // hidden_nf < 256: stage the current weights in the engine's widths
     T->bt = *bt;
     T->t_dev = t_dev;
     T->n[0] = bt->n_lig; T->n[1] = bt->n_kp;
@@ -863,7 +901,7 @@ kpd_status node_bwd(kpd_egnn_trainer *T, int l, int nt, int cur, int nxt, float 
     float *du = T->nb[0], *tmp = T->nb[1];
     const float *dy = T->dh[cur][nt];
     if (T->cfg.norm) {
-        hipLaunchKernelGGL(k_ln_bwd, dim3(cdiv(n, 4)), dim3(256), 0, T->st, T->hs[nt][l], T->nb[4], p.b2.w, p.gamma.w, dy, n, du, tmp);
+        hipLaunchKernelGGL(k_ln_bwd, dim3(cdiv(n, 4)), dim3(256), 0, T->st, T->hs[nt][l], T->nb[4], p.b2.w, p.gamma.w, dy, n, T->cfg.hidden_nf, du, tmp);
         KPD_LAUNCH_CHECK();
         KPD_TRY(colsum_acc(T, n, H, tmp, LD, p.gamma.g));
         KPD_TRY(colsum_acc(T, n, H, dy, LD, p.beta.g));
@@ -994,6 +1032,7 @@ extern "C" kpd_status kpd_egnn_trainer_backward(kpd_egnn_trainer *T, const float
     const kpd_egnn_config &c = T->cfg;
     hipStream_t st = static_cast<hipStream_t>(stream);
     T->st = st;
+    KPD_TRY(wide_run(T, 1));                   // hidden_nf < 256: zero the wide gradients
     const int L = c.n_layers, nl = T->n[0], nk = T->n[1];
     int cur = 0, nxt = 1;
     if (T->n_upd == 1) {        // kp not updated: one gradient accumulator across layers (the same tensors feed every layer)
@@ -1032,8 +1071,8 @@ extern "C" kpd_status kpd_egnn_trainer_backward(kpd_egnn_trainer *T, const float
                         d_lig_h, c.atom_nf));
         if (T->rec_identity) {
             if (d_kp_h) {
-                const long long tot = (long long)nk * 256;
-                hipLaunchKernelGGL(k_copy_rows, grid1(tot), dim3(256), 0, st, T->dh[cur][1], LD, d_kp_h, 256, tot, 256);
+                const long long tot = (long long)nk * c.hidden_nf;
+                hipLaunchKernelGGL(k_copy_rows, grid1(tot), dim3(256), 0, st, T->dh[cur][1], LD, d_kp_h, c.hidden_nf, tot, c.hidden_nf);
                 KPD_LAUNCH_CHECK();
             }
         } else {
@@ -1050,6 +1089,7 @@ extern "C" kpd_status kpd_egnn_trainer_backward(kpd_egnn_trainer *T, const float
         KPD_LAUNCH_CHECK();
     }
     if (d_kp_x) KPD_HIP(hipMemcpyAsync(d_kp_x, T->dx[cur][1], (size_t)nk * 12, hipMemcpyDeviceToDevice, st));
+    KPD_TRY(wide_run(T, 2));                   // hidden_nf < 256: add the wide gradients into the caller's tensors (reference shapes)
     T->have_forward = false;
     return KPD_OK;
 }

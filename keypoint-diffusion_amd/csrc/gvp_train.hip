@@ -24,6 +24,7 @@ struct kpd_gvp_trainer : TrainCtx {
     kpd_gvp_config cfg{};
     Arena ws;
     int S = 256;
+    int V = VC;                         // the model's vector_size (<= 16: narrower models run zero-padded, train_ops.h WideSet)
     int cap_B = 0, cap_lig = 0, cap_kp = 0, cap_kk = 0, cap_maxlig = 0, cap_maxkp = 0, cap_ll = 0, cap_kl = 0, cap_R = 0;
     kpd_batch bt{};
     const float *t_dev = nullptr;
@@ -103,10 +104,10 @@ kpd_status dropout_apply(kpd_gvp_trainer *T, int conv, int nt, int pos, int n, c
         if (vo != v) KPD_HIP(hipMemcpyAsync(vo, v, (size_t)n * 3 * VC * 4, hipMemcpyDeviceToDevice, T->st));
         return KPD_OK;
     }
-    hipLaunchKernelGGL(k_dropout, grid1((long long)n * S), dim3(256), 0, T->st, s, (long long)n, 1, S, T->seed, drop_stream(conv, nt, pos, 0),
+    hipLaunchKernelGGL(k_dropout, grid1((long long)n * S), dim3(256), 0, T->st, s, (long long)n, 1, S, S, T->seed, drop_stream(conv, nt, pos, 0),
                        T->dropout, so);
     KPD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_dropout, grid1((long long)n * 3 * VC), dim3(256), 0, T->st, v, (long long)n, 3, VC, T->seed,
+    hipLaunchKernelGGL(k_dropout, grid1((long long)n * 3 * VC), dim3(256), 0, T->st, v, (long long)n, 3, VC, T->V, T->seed,
                        drop_stream(conv, nt, pos, 1), T->dropout, vo);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
@@ -384,7 +385,7 @@ kpd_status noise_fwd(kpd_gvp_trainer *T, float *eps_h, float *eps_x) {
 
 extern "C" kpd_status kpd_gvp_trainer_create(const kpd_gvp_config *cfg, kpd_gvp_trainer **out) {
     KPD_REQUIRE(cfg && out, KPD_ERR_INVALID, "null argument");
-    KPD_REQUIRE(cfg->vector_size == VC, KPD_ERR_INVALID, "vector_size=%d: only 16 is supported", cfg->vector_size);
+    KPD_REQUIRE(cfg->vector_size >= 1 && cfg->vector_size <= VC, KPD_ERR_INVALID, "vector_size=%d outside 1 .. %d", cfg->vector_size, VC);
     KPD_REQUIRE(cfg->n_hidden_scalars >= 1 && cfg->n_hidden_scalars <= 256, KPD_ERR_INVALID, "n_hidden_scalars=%d outside 1 .. 256", cfg->n_hidden_scalars);
     KPD_REQUIRE(cfg->n_convs >= 1 && cfg->n_convs <= 64 && cfg->n_message_gvps >= 1 && cfg->n_message_gvps <= 4 && cfg->n_update_gvps >= 1 &&
                     cfg->n_update_gvps <= 4 && cfg->n_noise_gvps >= 1 && cfg->n_noise_gvps <= 4,
@@ -399,6 +400,7 @@ extern "C" kpd_status kpd_gvp_trainer_create(const kpd_gvp_config *cfg, kpd_gvp_
     kpd_gvp_trainer *T = new kpd_gvp_trainer();
     T->cfg = *cfg;
     T->S = cfg->n_hidden_scalars;
+    T->V = cfg->vector_size;
     *out = T;
     return KPD_OK;
 }
@@ -406,6 +408,7 @@ extern "C" kpd_status kpd_gvp_trainer_create(const kpd_gvp_config *cfg, kpd_gvp_
 extern "C" void kpd_gvp_trainer_destroy(kpd_gvp_trainer *T) {
     if (!T) return;
     T->ws.release();
+    T->wide.release();
     if (T->store_base) (void)hipFree(T->store_base);
     delete T;
 }
@@ -413,6 +416,40 @@ extern "C" void kpd_gvp_trainer_destroy(kpd_gvp_trainer *T) {
 extern "C" kpd_status kpd_gvp_trainer_bind(kpd_gvp_trainer *T, const char *name, const float *weight, float *grad, const int64_t *shape,
                                            int32_t ndim) {
     KPD_REQUIRE(T && name && shape && (ndim == 1 || ndim == 2), KPD_ERR_INVALID, "bad argument");
+    if (T->V != VC && weight) {
+        // vector_size < 16: the tensors of a GVP whose axes count vector channels (Wh [v_in, h], Wu [h, v_out], the |Vh| block of
+        // to_feats_out [S_out, S_in + h], the gates [v_out, S_out]; h = max(v_in, v_out), models/gvp.py:60-87) are trained through their
+        // 16-channel zero-padded form.  The first message GVP reads [x_diff | v_src] (v_in = V + 1 -> 17), the last noise GVP emits one vector.
+        const std::vector<std::string> tk = split_name(name);
+        int at = -1;                                         // index of the GVP's position token
+        bool msg0 = false, last = false;
+        if (tk.size() >= 7 && tk[1] == "conv_layers" && (tk[3] == "edge_message_fns" || tk[3] == "node_update_fns")) {
+            at = 5;
+            msg0 = tk[3] == "edge_message_fns" && tk[5] == "0";
+        } else if (tk.size() >= 5 && tk[1] == "noise_predictor" && tk[2] == "gvps") {
+            at = 3;
+            last = atoi(tk[3].c_str()) == T->cfg.n_noise_gvps - 1;
+        }
+        if (at >= 0) {
+            const int V = T->V;
+            const std::vector<AxisSeg> vi = msg0 ? std::vector<AxisSeg>{{V + 1, VH}} : std::vector<AxisSeg>{{V, VC}};
+            const std::vector<AxisSeg> vo = last ? std::vector<AxisSeg>{{1, 1}} : std::vector<AxisSeg>{{V, VC}};
+            const std::vector<AxisSeg> h = msg0 ? std::vector<AxisSeg>{{V + 1, VH}} : std::vector<AxisSeg>{{V, VC}};
+            const int h_ref = msg0 ? V + 1 : V;
+            const std::string &leaf = tk[at + 1];
+            std::vector<AxisSeg> rows, cols;
+            if (leaf == "Wh") { rows = vi; cols = h; }
+            else if (leaf == "Wu") { rows = h; cols = vo; }
+            else if (leaf == "to_feats_out" && tk.back() == "weight" && ndim == 2 && shape[1] > h_ref) {
+                rows = {{(int)shape[0], (int)shape[0]}};
+                cols = {{(int)shape[1] - h_ref, (int)shape[1] - h_ref}, h[0]};
+            } else if (leaf == "scalar_to_vector_gates" && !last) {
+                rows = vo;
+                if (tk.back() == "weight" && ndim == 2) cols = {{(int)shape[1], (int)shape[1]}};
+            }
+            if (!rows.empty()) return bind_wide(T, name, weight, grad, shape, ndim, rows, cols);
+        }
+    }
     Param p;
     p.w = weight;
     p.g = grad;
@@ -570,6 +607,7 @@ extern "C" kpd_status kpd_gvp_trainer_forward(kpd_gvp_trainer *T, const kpd_batc
     const kpd_gvp_config &c = T->cfg;
     hipStream_t st = static_cast<hipStream_t>(stream);
     T->st = st;
+    KPD_TRY(wide_run(T, 0));                   // vector_size < 16: stage the current weights in the engine's widths
     T->bt = *bt;
     T->t_dev = t_dev;
     T->n[0] = bt->n_lig; T->n[1] = bt->n_kp;
@@ -592,7 +630,7 @@ extern "C" kpd_status kpd_gvp_trainer_forward(kpd_gvp_trainer *T, const kpd_batc
     KPD_TRY(encoder_fwd(T, 0));
     KPD_TRY(encoder_fwd(T, 1));
     KPD_HIP(hipMemsetAsync(T->vs[0][0], 0, (size_t)bt->n_lig * 3 * VC * 4, st));
-    hipLaunchKernelGGL(k_v_transpose, grid1((long long)bt->n_kp * 3 * VC), dim3(256), 0, st, bt->kp_v, (long long)bt->n_kp, 1, T->vs[1][0]);
+    hipLaunchKernelGGL(k_v_transpose, grid1((long long)bt->n_kp * 3 * VC), dim3(256), 0, st, bt->kp_v, (long long)bt->n_kp, 1, T->V, T->vs[1][0]);
     KPD_LAUNCH_CHECK();
     for (int i = 0; i < c.n_convs; ++i) KPD_TRY(conv_fwd(T, i));
     KPD_TRY(noise_fwd(T, eps_h, eps_x));
@@ -607,6 +645,7 @@ extern "C" kpd_status kpd_gvp_trainer_backward(kpd_gvp_trainer *T, const float *
     const kpd_gvp_config &c = T->cfg;
     hipStream_t st = static_cast<hipStream_t>(stream);
     T->st = st;
+    KPD_TRY(wide_run(T, 1));                   // vector_size < 16: zero the wide gradients
     const int S = T->S, nn = c.n_noise_gvps, nl = T->n[0], nk = T->n[1], L = c.n_convs, F = c.n_lig_scalars;
     int cur = 0, nxt = 1;
     T->want_x = d_lig_x || d_kp_x;
@@ -645,8 +684,9 @@ extern "C" kpd_status kpd_gvp_trainer_backward(kpd_gvp_trainer *T, const float *
     }
     KPD_TRY(encoder_bwd(T, 0, cur, d_lig_h));
     KPD_TRY(encoder_bwd(T, 1, cur, d_kp_h));
+    KPD_TRY(wide_run(T, 2));                   // vector_size < 16: add the wide gradients into the caller's tensors (reference shapes)
     if (d_kp_v) {
-        hipLaunchKernelGGL(k_v_transpose, grid1((long long)nk * 3 * VC), dim3(256), 0, st, T->gv[cur][1], (long long)nk, 0, d_kp_v);
+        hipLaunchKernelGGL(k_v_transpose, grid1((long long)nk * 3 * VC), dim3(256), 0, st, T->gv[cur][1], (long long)nk, 0, T->V, d_kp_v);
         KPD_LAUNCH_CHECK();
     }
     if (d_lig_x) KPD_HIP(hipMemcpyAsync(d_lig_x, T->gx[0], (size_t)nl * 12, hipMemcpyDeviceToDevice, st));

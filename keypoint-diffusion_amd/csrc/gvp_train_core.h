@@ -208,18 +208,20 @@ __global__ void k_ln_bwd_g(const float *__restrict__ x, const float *__restrict_
 }
 
 // vector part of GVPLayerNorm (gvp.py:162-165): v / (sqrt(mean_ch(max(|v_ch|^2, 1e-8)) + 1e-5) + 1e-5), one thread per row
-__global__ void k_vnorm_fwd(const float *__restrict__ v, int rows, float *__restrict__ out) {
+// vl = the model's vector_size: channels vl .. 15 are zero padding (a narrower model trained in the 16-channel layout) and take no part in the mean
+__global__ void k_vnorm_fwd(const float *__restrict__ v, int rows, int vl, float *__restrict__ out) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
     const float *p = v + (size_t)r * 3 * VC;
     float m = 0.0f;
 #pragma unroll
-    for (int ch = 0; ch < VC; ++ch) m += fmaxf(p[ch] * p[ch] + p[VC + ch] * p[VC + ch] + p[2 * VC + ch] * p[2 * VC + ch], 1e-8f);
-    const float inv = 1.0f / (sqrtf(m / VC + 1e-5f) + 1e-5f);
+    for (int ch = 0; ch < VC; ++ch)
+        if (ch < vl) m += fmaxf(p[ch] * p[ch] + p[VC + ch] * p[VC + ch] + p[2 * VC + ch] * p[2 * VC + ch], 1e-8f);
+    const float inv = 1.0f / (sqrtf(m / vl + 1e-5f) + 1e-5f);
     for (int k = 0; k < 3 * VC; ++k) out[(size_t)r * 3 * VC + k] = p[k] * inv;
 }
 
-__global__ void k_vnorm_bwd(const float *__restrict__ v, const float *__restrict__ dout, int rows, float *__restrict__ dv) {
+__global__ void k_vnorm_bwd(const float *__restrict__ v, const float *__restrict__ dout, int rows, int vl, float *__restrict__ dv) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
     const float *p = v + (size_t)r * 3 * VC, *d = dout + (size_t)r * 3 * VC;
@@ -228,17 +230,20 @@ __global__ void k_vnorm_bwd(const float *__restrict__ v, const float *__restrict
 #pragma unroll
     for (int ch = 0; ch < VC; ++ch) {
         const float n2 = p[ch] * p[ch] + p[VC + ch] * p[VC + ch] + p[2 * VC + ch] * p[2 * VC + ch];
-        live[ch] = n2 > 1e-8f;
-        m += fmaxf(n2, 1e-8f);
-        dot += d[ch] * p[ch] + d[VC + ch] * p[VC + ch] + d[2 * VC + ch] * p[2 * VC + ch];
+        live[ch] = n2 > 1e-8f && ch < vl;
+        if (ch < vl) {
+            m += fmaxf(n2, 1e-8f);
+            dot += d[ch] * p[ch] + d[VC + ch] * p[VC + ch] + d[2 * VC + ch] * p[2 * VC + ch];
+        }
     }
-    const float root = sqrtf(m / VC + 1e-5f), vn = root + 1e-5f, inv = 1.0f / vn;
-    // out = v / vn; dvn = -(dout . v) / vn^2; dvn/dv[ch, c] = v[ch, c] / (VC * root) where the clamp is inactive
-    const float k = -dot * inv * inv / (VC * root);
+    const float root = sqrtf(m / vl + 1e-5f), vn = root + 1e-5f, inv = 1.0f / vn;
+    // out = v / vn; dvn = -(dout . v) / vn^2; dvn/dv[ch, c] = v[ch, c] / (vl * root) where the clamp is inactive
+    const float k = -dot * inv * inv / (vl * root);
 #pragma unroll
     for (int ch = 0; ch < VC; ++ch)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) dv[(size_t)r * 3 * VC + c * VC + ch] = d[c * VC + ch] * inv + (live[ch] ? k * p[c * VC + ch] : 0.0f);
+        for (int c = 0; c < 3; ++c)
+            dv[(size_t)r * 3 * VC + c * VC + ch] = ch < vl ? d[c * VC + ch] * inv + (live[ch] ? k * p[c * VC + ch] : 0.0f) : 0.0f;
 }
 
 __global__ void k_add(const float *__restrict__ a, const float *__restrict__ b, long long n, float *__restrict__ out) {
@@ -251,16 +256,19 @@ __global__ void k_acc(float *__restrict__ a, const float *__restrict__ b, long l
     if (i < n) a[i] += b[i];
 }
 
-// [rows, VC, 3] <-> [rows, 3, VC]
-__global__ void k_v_transpose(const float *__restrict__ in, long long rows, int to_internal, float *__restrict__ out) {
+// reference [rows, vl, 3] <-> engine [rows, 3, VC] (vl = the model's vector_size <= VC; engine channels vl .. 15 are zeros)
+__global__ void k_v_transpose(const float *__restrict__ in, long long rows, int to_internal, int vl, float *__restrict__ out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * 3 * VC) return;
-    const long long r = i / (3 * VC);
-    const int k = (int)(i - r * 3 * VC);
     if (to_internal) {          // out[r][c][ch] = in[r][ch][c]
+        if (i >= rows * 3 * VC) return;
+        const long long r = i / (3 * VC);
+        const int k = (int)(i - r * 3 * VC);
         const int c = k / VC, ch = k - c * VC;
-        out[i] = in[r * 3 * VC + ch * 3 + c];
+        out[i] = ch < vl ? in[r * 3 * vl + ch * 3 + c] : 0.0f;
     } else {                    // out[r][ch][c] = in[r][c][ch]
+        if (i >= rows * 3 * vl) return;
+        const long long r = i / (3 * vl);
+        const int k = (int)(i - r * 3 * vl);
         const int ch = k / 3, c = k - ch * 3;
         out[i] = in[r * 3 * VC + c * VC + ch];
     }
@@ -299,13 +307,14 @@ __device__ __forceinline__ float dropout_scale(unsigned long long seed, unsigned
 
 // out[r, k, c] = in[r, k, c] * mask(r, c): rows x inner x cols with the mask shared over `inner` (1 for scalars, 3 for the
 // components of a vector channel)
-__global__ void k_dropout(const float *__restrict__ in, long long rows, int inner, int cols, unsigned long long seed, unsigned stream,
+// `live` <= cols: the mask stream is laid out [rows, live] (what a model of that width draws); columns past it are padding and stay 0
+__global__ void k_dropout(const float *__restrict__ in, long long rows, int inner, int cols, int live, unsigned long long seed, unsigned stream,
                           float rate, float *__restrict__ out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * inner * cols) return;
     const int c = (int)(i % cols);
     const long long r = i / ((long long)inner * cols);
-    out[i] = in[i] * dropout_scale(seed, stream, r * cols + c, rate);
+    out[i] = c < live ? in[i] * dropout_scale(seed, stream, r * live + c, rate) : 0.0f;
 }
 
 __global__ void k_dropout_mask(long long n, unsigned long long seed, unsigned stream, float rate, float *__restrict__ out) {
@@ -416,7 +425,7 @@ template <class TT>
 kpd_status gvp_ln_fwd(TT *T, const LnP &l, int n, const float *s, const float *v, float *so, float *vo) {
     hipLaunchKernelGGL(k_ln_fwd, dim3(cdiv(n, 4)), dim3(256), 0, T->st, s, l.gamma.w, l.beta.w, n, T->S, so);
     KPD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_vnorm_fwd, grid1(n), dim3(256), 0, T->st, v, n, vo);
+    hipLaunchKernelGGL(k_vnorm_fwd, grid1(n), dim3(256), 0, T->st, v, n, T->V, vo);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
 }
@@ -430,7 +439,7 @@ kpd_status gvp_ln_bwd(TT *T, const LnP &l, int n, const float *s, const float *v
     KPD_TRY(colsum_acc(T, n, T->S, T->U, T->S, l.gamma.g));        // U (free outside the edge passes) = dy * xhat
     KPD_TRY(colsum_acc(T, n, T->S, dso, T->S, l.beta.g));
     KPD_HIP(hipMemcpyAsync(ds, T->tmp_s, (size_t)n * T->S * 4, hipMemcpyDeviceToDevice, T->st));
-    hipLaunchKernelGGL(k_vnorm_bwd, grid1(n), dim3(256), 0, T->st, v, dvo, n, T->tmp_v);
+    hipLaunchKernelGGL(k_vnorm_bwd, grid1(n), dim3(256), 0, T->st, v, dvo, n, T->V, T->tmp_v);
     KPD_LAUNCH_CHECK();
     KPD_HIP(hipMemcpyAsync(dv, T->tmp_v, (size_t)n * 3 * VC * 4, hipMemcpyDeviceToDevice, T->st));
     return KPD_OK;

@@ -288,6 +288,34 @@ __global__ void k_rk_feat_dh(const float *__restrict__ dfin, const int *__restri
     }
 }
 
+// kp_rad keypoint features (RecKeyConv.kp_rad_feats, models/receptor_encoder.py:238-264): fin[kp] = (sum of h over the receptor atoms within
+// kp_rad of the keypoint) / z, z = rk edges of the complex / keypoints of the complex + 1 (a count: no gradient; the radius search
+// itself is not differentiable upstream either).  rk edges are kp-major: rk_src[rowptr[kp] .. rowptr[kp + 1]), off = per-complex edge offsets.
+__global__ void k_rk_radfeat_in(const float *__restrict__ h, const int *__restrict__ rk_src, const int *__restrict__ rk_rowptr,
+                                const int *__restrict__ rk_off, int K, int D, long long total, float *__restrict__ fin) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int kp = (int)(i / D), c = (int)(i - (long long)kp * D), b = kp / K;
+    float acc = 0.0f;
+    for (int e = rk_rowptr[kp]; e < rk_rowptr[kp + 1]; ++e) acc += h[(size_t)rk_src[e] * D + c];
+    fin[i] = acc / ((float)(rk_off[b + 1] - rk_off[b]) / (float)K + 1.0f);
+}
+
+// gh[r, :] += sum over the rk edges leaving atom r of dfin[kp(edge)] / z(complex) (edges grouped by source, ascending)
+__global__ void k_rk_radfeat_dh(const float *__restrict__ dfin, const int *__restrict__ perm, const int *__restrict__ rowptr,
+                                const int *__restrict__ rk_dst, const int *__restrict__ rk_off, int K, int D, float *__restrict__ gh) {
+    const int r = blockIdx.x;
+    const int lo = rowptr[r], hi = rowptr[r + 1];
+    if (lo == hi) return;
+    const int b = rk_dst[perm[lo]] / K;                       // every edge of an atom stays inside its complex
+    const float zi = 1.0f / ((float)(rk_off[b + 1] - rk_off[b]) / (float)K + 1.0f);
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        float acc = 0.0f;
+        for (int j = lo; j < hi; ++j) acc += dfin[(size_t)rk_dst[perm[j]] * D + c];
+        gh[(size_t)r * D + c] += acc * zi;
+    }
+}
+
 }  // namespace
 }  // namespace kpd
 
@@ -301,6 +329,7 @@ struct kpd_recegnn_trainer : TrainCtx {
     const float *same_res = nullptr;
     bool have_forward = false;
     int B = 0, n_rec = 0, n_kp = 0, E_rk = 0;
+    int *rad_tmp = nullptr, *rk_off = nullptr;      // kp_rad features: scratch of the radius search, per-complex rk edge offsets (kept for backward)
     int *bidx = nullptr, *kp_ptr = nullptr, *rk_src = nullptr, *rk_dst = nullptr, *rk_rowptr = nullptr, *off_tmp = nullptr, *xm_src = nullptr,
         *xm_dst = nullptr, *xm_rowptr = nullptr, *kk_rowptr = nullptr, *deg_tmp = nullptr, *kk_off = nullptr, *cursor = nullptr;
     SrcCsr scsr_rr, scsr_rk;
@@ -481,8 +510,9 @@ extern "C" kpd_status kpd_recegnn_trainer_create(const kpd_recegnn_config *cfg, 
     KPD_REQUIRE(cfg->in_n_node_feat >= 1 && cfg->in_n_node_feat <= 256 && cfg->hidden_n_node_feat >= 1 && cfg->hidden_n_node_feat <= 256 &&
                     cfg->out_n_node_feat >= 1 && cfg->out_n_node_feat <= 256, KPD_ERR_INVALID, "feature widths %d / %d / %d (1..256)",
                 cfg->in_n_node_feat, cfg->hidden_n_node_feat, cfg->out_n_node_feat);
-    KPD_REQUIRE(cfg->k_closest >= 1 && cfg->k_closest <= 16 && cfg->kp_rad == 0.0f, KPD_ERR_INVALID,
-                "the training engine differentiates the k_closest keypoint features (every shipped config); kp_rad features are inference only");
+    KPD_REQUIRE((cfg->k_closest >= 1 && cfg->k_closest <= 16 && cfg->kp_rad == 0.0f) || (cfg->k_closest == 0 && cfg->kp_rad > 0.0f), KPD_ERR_INVALID,
+                "keypoint features: either 1 <= k_closest <= 16 with kp_rad = 0, or k_closest = 0 with kp_rad > 0 (got %d, %f)", cfg->k_closest,
+                (double)cfg->kp_rad);
     KPD_REQUIRE(cfg->message_norm >= 0.0f, KPD_ERR_INVALID, "message_norm=%g", (double)cfg->message_norm);
     kpd_recegnn_trainer *T = new kpd_recegnn_trainer();
     T->cfg = *cfg;
@@ -518,7 +548,7 @@ extern "C" kpd_status kpd_recegnn_trainer_reserve(kpd_recegnn_trainer *T, int32_
     max_B = std::max(max_B, T->cap_B); max_n_rec = std::max(max_n_rec, T->cap_rec); max_n_rr = std::max(max_n_rr, T->cap_rr);
     max_rec_pg = std::max(max_rec_pg, T->cap_maxrec);
     const int H = T->H, D = c.out_n_node_feat, K = c.n_keypoints, L = c.n_convs, Dm = T->Dmax, n_kp = max_B * K;
-    const int cap_rk = std::max(n_kp * c.k_closest, 1), E = std::max<int>(max_n_rr, 1), FW = 2 * Dm + 2;
+    const int cap_rk = std::max(n_kp * (c.k_closest > 0 ? c.k_closest : std::min(max_rec_pg, 100)), 1), E = std::max<int>(max_n_rr, 1), FW = 2 * Dm + 2;
     T->hs.assign(L + 1, nullptr); T->xs.assign(L + 1, nullptr); T->hneigh.assign(L, nullptr); T->npre.assign(L, nullptr); T->hn.assign(L, nullptr);
     T->ws.release();
     for (int pass = 0; pass < 2; ++pass) {
@@ -548,7 +578,7 @@ extern "C" kpd_status kpd_recegnn_trainer_reserve(kpd_recegnn_trainer *T, int32_
         I(T->bidx, nr); I(T->kp_ptr, max_B + 1); I(T->rk_src, cap_rk); I(T->rk_dst, cap_rk); I(T->rk_rowptr, nk + 1);
         I(T->off_tmp, max_B + 2); I(T->xm_src, cap_rk); I(T->xm_dst, cap_rk); I(T->xm_rowptr, nr + 1); I(T->cursor, std::max(nr, nk));
         I(T->scsr_rr.perm, E); I(T->scsr_rr.rowptr, nr + 1); I(T->scsr_rk.perm, cap_rk); I(T->scsr_rk.rowptr, nr + 1);
-        I(T->kk_rowptr, nk + 1); I(T->deg_tmp, nk); I(T->kk_off, max_B + 1);
+        I(T->kk_rowptr, nk + 1); I(T->deg_tmp, nk); I(T->kk_off, max_B + 1); I(T->rad_tmp, 2 * (size_t)max_B + 16); I(T->rk_off, max_B + 2);
         if (pass == 0) KPD_TRY(T->ws.reserve(bytes + 4096));
     }
     KPD_REQUIRE(T->kk_off != nullptr, KPD_ERR_HIP, "workspace arena too small (internal sizing error)");
@@ -608,17 +638,29 @@ extern "C" kpd_status kpd_recegnn_trainer_forward(kpd_recegnn_trainer *T, const 
     const float *xv = c.fix_pos ? bt->rec_x : T->xs[L];
     hipLaunchKernelGGL(k_rk_att_fwd, dim3(n_kp), dim3(256), 0, st, T->ft_src, T->ft_dst, xv, bt->rec_ptr, K, D, T->att, T->kp_x);
     KPD_LAUNCH_CHECK();
-    // k nearest receptor atoms of every keypoint by the ORIGINAL positions (:262-267); kp-major, nearest first
-    KPD_TRY(launch_knn_bipartite(bt->rec_x, bt->rec_ptr, n_rec, bt->max_rec, T->kp_x, T->kp_ptr, n_kp, K, B, k, T->off_tmp, T->xm_src, T->xm_dst,
-                                 T->xm_rowptr, T->rk_src, T->rk_dst, T->rk_rowptr, st));
     int e_rk = 0;
+    if (k > 0) {
+        // k nearest receptor atoms of every keypoint by the ORIGINAL positions (:262-267); kp-major, nearest first
+        KPD_TRY(launch_knn_bipartite(bt->rec_x, bt->rec_ptr, n_rec, bt->max_rec, T->kp_x, T->kp_ptr, n_kp, K, B, k, T->off_tmp, T->xm_src, T->xm_dst,
+                                     T->xm_rowptr, T->rk_src, T->rk_dst, T->rk_rowptr, st));
+    } else {
+        // receptor atoms within kp_rad of every keypoint (original positions, at most 100, index order; :238-262)
+        KPD_TRY(launch_radius_bipartite(bt->rec_x, bt->rec_ptr, n_rec, bt->max_rec, T->kp_x, T->kp_ptr, n_kp, K, B, c.kp_rad, 100, T->rad_tmp,
+                                        T->rad_tmp + B, T->off_tmp, T->xm_src, T->xm_dst, T->xm_rowptr, T->rk_src, T->rk_dst, T->rk_rowptr, st));
+    }
+    KPD_HIP(hipMemcpyAsync(T->rk_off, T->off_tmp, (size_t)(B + 1) * 4, hipMemcpyDeviceToDevice, st));     // off_tmp is reused by the kk graph below
     KPD_HIP(hipMemcpyAsync(&e_rk, T->off_tmp + B, sizeof(int), hipMemcpyDeviceToHost, st));
     KPD_HIP(hipStreamSynchronize(st));
-    KPD_REQUIRE(e_rk == n_kp * k, KPD_ERR_INVALID, "every pocket needs at least k_closest=%d receptor atoms (%d rk edges for %d keypoints)", k, e_rk, n_kp);
+    KPD_REQUIRE(k == 0 || e_rk == n_kp * k, KPD_ERR_INVALID, "every pocket needs at least k_closest=%d receptor atoms (%d rk edges for %d keypoints)", k, e_rk, n_kp);
+    KPD_REQUIRE(e_rk <= T->cap_rk, KPD_ERR_CAPACITY, "%d rk edges exceed the reserved %d", e_rk, T->cap_rk);
     T->E_rk = e_rk;
     KPD_TRY(build_src_csr(T, T->rk_src, e_rk, n_rec, T->cursor, T->scsr_rk));
-    hipLaunchKernelGGL(k_rk_feat_in, grid1((long long)n_kp * (D + k)), dim3(256), 0, st, T->hs[L], bt->rec_x, T->kp_x, T->rk_src, k, D,
-                       (long long)n_kp * (D + k), T->fin);
+    if (k > 0)
+        hipLaunchKernelGGL(k_rk_feat_in, grid1((long long)n_kp * (D + k)), dim3(256), 0, st, T->hs[L], bt->rec_x, T->kp_x, T->rk_src, k, D,
+                           (long long)n_kp * (D + k), T->fin);
+    else
+        hipLaunchKernelGGL(k_rk_radfeat_in, grid1((long long)n_kp * D), dim3(256), 0, st, T->hs[L], T->rk_src, T->rk_rowptr, T->rk_off, K, D,
+                           (long long)n_kp * D, T->fin);
     KPD_LAUNCH_CHECK();
     KPD_TRY(gemm(T, false, true, n_kp, D, D + k, T->fin, D + k, Wp.w, D + k, 0.0f, T->fpre, D, 1.0f, nullptr, bp.w, T->fact));
     if (c.norm) {
@@ -667,10 +709,16 @@ extern "C" kpd_status kpd_recegnn_trainer_backward(kpd_recegnn_trainer *T, const
         KPD_LAUNCH_CHECK();
         KPD_TRY(grad_gemm(T, D, D + k, n_kp, T->gk1, D, T->fin, D + k, Wp.g, D + k, bp.g));
         KPD_TRY(gemm(T, false, false, n_kp, D + k, D, T->gk1, D, Wp.w, D + k, 0.0f, T->gk2, D + k));      // d [h_m | d_k]
-        hipLaunchKernelGGL(k_rk_feat_dh, dim3(n_rec), dim3(256), 0, st, T->gk2, T->scsr_rk.perm, T->scsr_rk.rowptr, k, D, D + k, T->gh[cur]);
-        KPD_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_rk_feat_dx, grid1(n_kp), dim3(256), 0, st, T->gk2, T->fin, bt.rec_x, T->kp_x, T->rk_src, k, D, n_kp, T->gkx);
-        KPD_LAUNCH_CHECK();
+        if (k > 0) {
+            hipLaunchKernelGGL(k_rk_feat_dh, dim3(n_rec), dim3(256), 0, st, T->gk2, T->scsr_rk.perm, T->scsr_rk.rowptr, k, D, D + k, T->gh[cur]);
+            KPD_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_rk_feat_dx, grid1(n_kp), dim3(256), 0, st, T->gk2, T->fin, bt.rec_x, T->kp_x, T->rk_src, k, D, n_kp, T->gkx);
+            KPD_LAUNCH_CHECK();
+        } else if (T->E_rk > 0) {
+            hipLaunchKernelGGL(k_rk_radfeat_dh, dim3(n_rec), dim3(256), 0, st, T->gk2, T->scsr_rk.perm, T->scsr_rk.rowptr, T->rk_dst, T->rk_off, K, D,
+                               T->gh[cur]);
+            KPD_LAUNCH_CHECK();
+        }
     }
     // attention-pooled positions: values (the learned receptor positions), then the logits
     const float *xv = c.fix_pos ? bt.rec_x : T->xs[L];

@@ -135,6 +135,7 @@ struct kpd_recenc_trainer : TrainCtx {
     kpd_recenc_config cfg{};
     Arena ws;
     int S = 128;
+    int V = VC;                         // live vector channels (this engine: always 16)
     int cap_B = 0, cap_rec = 0, cap_rr = 0, cap_maxrec = 0, cap_rk = 0, cap_R = 0;
     kpd_rec_batch bt{};
     bool have_forward = false;
@@ -177,10 +178,10 @@ kpd_status enc_dropout(kpd_recenc_trainer *T, int conv, int pos, int n, const fl
         if (vo != v) KPD_HIP(hipMemcpyAsync(vo, v, (size_t)n * 3 * VC * 4, hipMemcpyDeviceToDevice, T->st));
         return KPD_OK;
     }
-    hipLaunchKernelGGL(k_dropout, grid1((long long)n * S), dim3(256), 0, T->st, s, (long long)n, 1, S, T->seed, enc_stream(conv, pos, 0),
+    hipLaunchKernelGGL(k_dropout, grid1((long long)n * S), dim3(256), 0, T->st, s, (long long)n, 1, S, S, T->seed, enc_stream(conv, pos, 0),
                        T->dropout, so);
     KPD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_dropout, grid1((long long)n * 3 * VC), dim3(256), 0, T->st, v, (long long)n, 3, VC, T->seed, enc_stream(conv, pos, 1),
+    hipLaunchKernelGGL(k_dropout, grid1((long long)n * 3 * VC), dim3(256), 0, T->st, v, (long long)n, 3, VC, T->V, T->seed, enc_stream(conv, pos, 1),
                        T->dropout, vo);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
@@ -590,7 +591,7 @@ extern "C" kpd_status kpd_recenc_trainer_forward(kpd_recenc_trainer *T, const kp
 
     KPD_HIP(hipMemcpyAsync(out->kp_x, T->kp_x, (size_t)n_kp * 12, hipMemcpyDeviceToDevice, st));
     KPD_HIP(hipMemcpyAsync(out->kp_h, T->ks[Rk], (size_t)n_kp * S * 4, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(k_v_transpose, grid1((long long)n_kp * 3 * VC), dim3(256), 0, st, T->kv[Rk], (long long)n_kp, 0, out->kp_v);
+    hipLaunchKernelGGL(k_v_transpose, grid1((long long)n_kp * 3 * VC), dim3(256), 0, st, T->kv[Rk], (long long)n_kp, 0, T->V, out->kp_v);
     KPD_LAUNCH_CHECK();
     KPD_HIP(hipMemcpyAsync(out->rk_src, T->rk_src, (size_t)e_rk * 4, hipMemcpyDeviceToDevice, st));
     KPD_HIP(hipMemcpyAsync(out->rk_dst, T->rk_dst, (size_t)e_rk * 4, hipMemcpyDeviceToDevice, st));
@@ -615,7 +616,7 @@ extern "C" kpd_status kpd_recenc_trainer_backward(kpd_recenc_trainer *T, const f
     if (d_kp_h) KPD_HIP(hipMemcpyAsync(T->gks[cur], d_kp_h, (size_t)n_kp * S * 4, hipMemcpyDeviceToDevice, st));
     else KPD_HIP(hipMemsetAsync(T->gks[cur], 0, (size_t)n_kp * S * 4, st));
     if (d_kp_v) {
-        hipLaunchKernelGGL(k_v_transpose, grid1((long long)n_kp * 3 * VC), dim3(256), 0, st, d_kp_v, (long long)n_kp, 1, T->gkv[cur]);
+        hipLaunchKernelGGL(k_v_transpose, grid1((long long)n_kp * 3 * VC), dim3(256), 0, st, d_kp_v, (long long)n_kp, 1, T->V, T->gkv[cur]);
         KPD_LAUNCH_CHECK();
     } else KPD_HIP(hipMemsetAsync(T->gkv[cur], 0, (size_t)n_kp * 3 * VC * 4, st));
     if (d_kp_x) KPD_HIP(hipMemcpyAsync(T->gkx, d_kp_x, (size_t)n_kp * 12, hipMemcpyDeviceToDevice, st));

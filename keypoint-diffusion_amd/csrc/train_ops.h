@@ -259,6 +259,97 @@ struct Param {
     int rows = 0, cols = 0;
 };
 
+// ---- reference tensors narrower than the engine's fixed layout -------------------------------------------------------------------
+// The engines compute in fixed widths (EGNN: 256 hidden columns + the timestep column; GVP: 16 vector channels).  A model with a
+// narrower reference shape (LigRecDynamics' default hidden_nf = 255, models/dynamics.py:300-302; vector_size < 16, models/
+// dynamics_gvp.py:106-108) is trained through zero padding: every bound tensor whose axes carry such a width gets an engine-owned
+// wide copy (weights) and a wide gradient; one batched launch stages all weights before the forward pass, one zeroes the wide
+// gradients before the backward pass and one adds them into the caller's gradient tensors, in the reference shape, after it.
+// Zero rows / columns keep the padding inert: padded activations are exactly 0 (SiLU(0) = 0, gates x 0), the normalisations
+// skip them explicitly (their kernels take the live width), and whatever reaches a padded gradient entry is dropped by the map.
+struct AxisSeg { int ref_n, wide_n; };          // ref_n consecutive reference entries at the start of wide_n engine entries
+
+struct WideDesc {
+    const float *ref_w;
+    float *ref_g, *w, *g;
+    const int *rmap, *cmap;                     // engine index -> reference index or -1
+    int R, C, ref_ld, blk0;
+};
+
+// mode 0: w = widened ref_w; 1: g = 0; 2: ref_g += the mapped entries of g
+__global__ void k_wide_batch(const WideDesc *__restrict__ tab, int n_tab, int mode) {
+    int lo = 0, hi = n_tab - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].blk0 <= (int)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const WideDesc d = tab[lo];
+    const int i = ((int)blockIdx.x - d.blk0) * 256 + (int)threadIdx.x;
+    if (i >= d.R * d.C) return;
+    const int r = d.rmap[i / d.C], c = d.cmap[i % d.C];
+    const bool live = r >= 0 && c >= 0;
+    if (mode == 0) d.w[i] = live ? d.ref_w[(size_t)r * d.ref_ld + c] : 0.0f;
+    else if (!d.g) return;
+    else if (mode == 1) d.g[i] = 0.0f;
+    else if (live) d.ref_g[(size_t)r * d.ref_ld + c] += d.g[i];
+}
+
+struct WideSet {
+    struct Entry {
+        WideDesc d{};
+        int *maps_dev = nullptr;
+        float *w_dev = nullptr, *g_dev = nullptr;
+        int ref_rows = 0, ref_cols = 0;
+    };
+    static constexpr int RING = 4;
+    std::map<std::string, int> index;
+    std::vector<Entry> e;
+    WideDesc *tab_host[RING] = {nullptr, nullptr, nullptr, nullptr}, *tab_dev[RING] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t done[RING] = {nullptr, nullptr, nullptr, nullptr};
+    int tab_cap = 0, turn = 0;
+
+    void release() {
+        for (Entry &x : e) {
+            if (x.maps_dev) (void)hipFree(x.maps_dev);
+            if (x.w_dev) (void)hipFree(x.w_dev);
+            if (x.g_dev) (void)hipFree(x.g_dev);
+        }
+        e.clear();
+        index.clear();
+        for (int k = 0; k < RING; ++k) {
+            if (tab_host[k]) (void)hipHostFree(tab_host[k]);
+            if (tab_dev[k]) (void)hipFree(tab_dev[k]);
+            if (done[k]) (void)hipEventDestroy(done[k]);
+            tab_host[k] = tab_dev[k] = nullptr;
+            done[k] = nullptr;
+        }
+        tab_cap = 0;
+    }
+};
+
+inline std::vector<std::string> split_name(const std::string &s, char c = '.') {
+    std::vector<std::string> out;
+    size_t a = 0;
+    for (;;) {
+        const size_t b = s.find(c, a);
+        out.push_back(s.substr(a, b == std::string::npos ? b : b - a));
+        if (b == std::string::npos) return out;
+        a = b + 1;
+    }
+}
+
+inline std::vector<int> axis_map(const std::vector<AxisSeg> &segs, int *ref_len) {
+    std::vector<int> map;
+    int ref = 0;
+    for (const AxisSeg &s : segs) {
+        for (int j = 0; j < s.wide_n; ++j) map.push_back(j < s.ref_n ? ref + j : -1);
+        ref += s.ref_n;
+    }
+    *ref_len = ref;
+    return map;
+}
+
 // what the wrappers need from an engine: the stream of the current call, split-K scratch, a ones vector
 struct TrainCtx {
     hipStream_t st = nullptr;
@@ -268,6 +359,7 @@ struct TrainCtx {
     float *colpart = nullptr;          // [colpart_blocks][2][COLSUM_LD] partial column sums (k_colsum -> k_colsum_reduce)
     int colpart_blocks = 0;
     std::map<std::string, Param> params;
+    WideSet wide;
 };
 
 inline size_t colpart_floats(int max_rows) { return (size_t)cdiv(std::max(max_rows, 1), HEAD_ROWS) * 2 * COLSUM_LD; }
@@ -368,6 +460,71 @@ kpd_status grad_gemm(TrainCtx *T, int M, int N, int K, const float *A, int lda, 
     if (M == 0 || K == 0) return KPD_OK;
     if (!C || N == 0) return bias_grad ? colsum_acc(T, K, M, A, lda, bias_grad) : KPD_OK;
     return sgemm(true, false, M, N, K, 1.0f, A, lda, B, ldb, 1.0f, C, ldc, T->st, T->part, T->part_floats, bias_grad);
+}
+
+// bind one reference tensor through a wide copy: `rows` / `cols` describe its axes (cols empty = a vector).  The entry (maps, wide
+// weight, wide gradient) is created at the first bind of the name; later binds only swap the caller's pointers.
+kpd_status bind_wide(TrainCtx *T, const char *name, const float *weight, float *grad, const int64_t *shape, int ndim,
+                     const std::vector<AxisSeg> &rows, const std::vector<AxisSeg> &cols) {
+    WideSet &W = T->wide;
+    int ref_r = 0, ref_c = 1;
+    auto it = W.index.find(name);
+    if (it == W.index.end()) {
+        std::vector<int> rmap = axis_map(rows, &ref_r), cmap = cols.empty() ? std::vector<int>{0} : axis_map(cols, &ref_c);
+        WideSet::Entry x;
+        x.ref_rows = ref_r; x.ref_cols = ref_c;
+        x.d.R = (int)rmap.size(); x.d.C = (int)cmap.size(); x.d.ref_ld = ref_c;
+        const size_t n = (size_t)x.d.R * x.d.C;
+        KPD_HIP(hipMalloc(reinterpret_cast<void **>(&x.maps_dev), (rmap.size() + cmap.size()) * 4));
+        KPD_HIP(hipMalloc(reinterpret_cast<void **>(&x.w_dev), n * 4));
+        KPD_HIP(hipMalloc(reinterpret_cast<void **>(&x.g_dev), n * 4));
+        KPD_HIP(hipMemcpy(x.maps_dev, rmap.data(), rmap.size() * 4, hipMemcpyHostToDevice));
+        KPD_HIP(hipMemcpy(x.maps_dev + rmap.size(), cmap.data(), cmap.size() * 4, hipMemcpyHostToDevice));
+        x.d.rmap = x.maps_dev; x.d.cmap = x.maps_dev + rmap.size(); x.d.w = x.w_dev;
+        W.e.push_back(x);
+        it = W.index.emplace(name, (int)W.e.size() - 1).first;
+    }
+    WideSet::Entry &x = W.e[it->second];
+    const bool ok = cols.empty() ? (ndim == 1 && shape[0] == x.ref_rows) : (ndim == 2 && shape[0] == x.ref_rows && shape[1] == x.ref_cols);
+    KPD_REQUIRE(ok, KPD_ERR_WEIGHTS, "parameter %s has the wrong shape for this configuration (expected [%d%s%s])", name, x.ref_rows,
+                cols.empty() ? "" : ", ", cols.empty() ? "" : std::to_string(x.ref_cols).c_str());
+    x.d.ref_w = weight; x.d.ref_g = grad; x.d.g = grad ? x.g_dev : nullptr;
+    Param p;
+    p.w = x.w_dev; p.g = x.d.g; p.rows = x.d.R; p.cols = cols.empty() ? 1 : x.d.C;
+    T->params[name] = p;
+    return KPD_OK;
+}
+
+// one batched launch over every wide entry (k_wide_batch modes); a no-op for a model in the engine's own widths
+kpd_status wide_run(TrainCtx *T, int mode) {
+    WideSet &W = T->wide;
+    const int n = (int)W.e.size();
+    if (n == 0) return KPD_OK;
+    if (n > W.tab_cap) {
+        for (int k = 0; k < WideSet::RING; ++k) {
+            if (W.done[k]) KPD_HIP(hipEventSynchronize(W.done[k]));
+            if (W.tab_host[k]) (void)hipHostFree(W.tab_host[k]);
+            if (W.tab_dev[k]) (void)hipFree(W.tab_dev[k]);
+            KPD_HIP(hipHostMalloc(reinterpret_cast<void **>(&W.tab_host[k]), (size_t)(n + 64) * sizeof(WideDesc), hipHostMallocDefault));
+            KPD_HIP(hipMalloc(reinterpret_cast<void **>(&W.tab_dev[k]), (size_t)(n + 64) * sizeof(WideDesc)));
+            if (!W.done[k]) KPD_HIP(hipEventCreateWithFlags(&W.done[k], hipEventDisableTiming));
+        }
+        W.tab_cap = n + 64;
+    }
+    const int k = W.turn;
+    W.turn = (W.turn + 1) % WideSet::RING;
+    KPD_HIP(hipEventSynchronize(W.done[k]));           // the slot's previous upload has been consumed (normally long ago)
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        W.e[i].d.blk0 = blocks;
+        W.tab_host[k][i] = W.e[i].d;
+        blocks += cdiv(W.e[i].d.R * W.e[i].d.C, 256);
+    }
+    KPD_HIP(hipMemcpyAsync(W.tab_dev[k], W.tab_host[k], (size_t)n * sizeof(WideDesc), hipMemcpyHostToDevice, T->st));
+    hipLaunchKernelGGL(k_wide_batch, dim3(blocks), dim3(256), 0, T->st, W.tab_dev[k], n, mode);
+    KPD_LAUNCH_CHECK();
+    KPD_HIP(hipEventRecord(W.done[k], T->st));
+    return KPD_OK;
 }
 
 kpd_status param(TrainCtx *T, const std::string &name, int rows, int cols, Param *out) {

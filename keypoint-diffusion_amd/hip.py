@@ -754,7 +754,7 @@ class RecEgnnTrainer:
     def __init__(self, cfg: 'KpdRecegnnConfig'):
         self.cfg = cfg
         self.D, self.K, self.k, self.ef = int(cfg.out_n_node_feat), int(cfg.n_keypoints), int(cfg.k_closest), bool(cfg.use_sameres_feat)
-        self.rk_cap = self.k
+        self.rk_cap = self.k if self.k else 100                   # rk edges per keypoint: k, or at most 100 within kp_rad
         self._h = C.c_void_p()
         check(lib().kpd_recegnn_trainer_create(C.byref(self.cfg), C.byref(self._h)))
 

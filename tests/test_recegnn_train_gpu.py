@@ -25,9 +25,12 @@ def _batch(cfg, n_rec, seed=19):
     return g, a
 
 
-@pytest.mark.parametrize('name,n_rec', [('recegnn_20kp', [33, 21]), ('recegnn_small', [33, 21, 40]), ('recegnn_fixpos', [50, 5, 27])])
-def test_encoder_gradients_match_oracle_autograd(cuda, name, n_rec):
-    cfg = RECEGNN_CFGS[name]
+@pytest.mark.parametrize('name,n_rec,over', [
+    ('recegnn_20kp', [33, 21], {}), ('recegnn_small', [33, 21, 40], {}), ('recegnn_fixpos', [50, 5, 27], {}),
+    # keypoint features from the receptor atoms within kp_rad (RecKeyConv.kp_rad_feats, receptor_encoder.py:238-264; configs/dev_config.yml:46)
+    ('recegnn_small', [33, 21, 40], dict(k_closest=0, kp_rad=5.0)), ('recegnn_20kp', [33, 21], dict(k_closest=0, kp_rad=9.0))])
+def test_encoder_gradients_match_oracle_autograd(cuda, name, n_rec, over):
+    cfg = dict(RECEGNN_CFGS[name], **over)
     kw = dict(cfg, graph_cutoffs=CUT)
     model = synth.fill_state_dict_(ReceptorEncoder(**kw), 71).eval()
     with torch.no_grad():                       # the synthetic fill leaves the tiny xavier coordinate head: give it some weight
