@@ -57,7 +57,7 @@ def rec_key_conv(sd, p, h, x_val, x0, kp_h0, n_rec, K, cfg):
     n_kp = torch.full((n_rec.numel(),), K, dtype=torch.long)
     if k == 0:                                                                 # kp_rad_feats (:238-262)
         kp_idx, rec_idx = G.radius(x0, kp_pos, cfg['kp_rad'], n_rec, n_kp, max_num_neighbors=100)
-        h_m = torch.zeros(kp_pos.shape[0], D).index_add_(0, kp_idx, h[rec_idx])                # fn.sum, :258
+        h_m = torch.zeros(kp_pos.shape[0], D, dtype=h.dtype).index_add_(0, kp_idx, h[rec_idx])                # fn.sum, :258
         z = G.edges_per_graph(kp_idx, n_kp).float() / K + 1.0                                  # :259-260
         feat = F.silu(_lin(sd, p + '.kp_feature_mlp.0', h_m / z[G.counts_to_batch_idx(n_kp)].view(-1, 1)))
         if cfg.get('norm', False):
