@@ -118,7 +118,7 @@ kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *batch, const float *t_
 /* Debug/test taps and switches.  Taps copy engine state to out_dev: "h_lig" / "h_kp" (node state, row stride 264), "x_lig" /
  * "x_kp", "z_lig" / "z_kp", "xnm<et>" / "xnc<et>" / "hnm<et>" / "hnc<et>" (segment-sum pieces of edge type et as the last layer
  * left them), "stamps".  Switches (n_floats = 0, out_dev ignored but non-null): "layers=N" (run only the first N layers),
- * "prune=0|1", "tile_rows=32|64", "edge_chain=0|1", "stamps=1", and
+ * "prune=0|1", "stamps=1", and
  *   "gemm=f32"   exact fp32 MFMA in every GEMM -- the default and the contract path;
  *   "gemm=f16x2" opt-in: every fp32 product of the edge / projection / node-update GEMMs as three f16 MFMA products of hi / lo
  *                operand planes with fp32 accumulation (same accuracy against the reference, ~2x the step rate; DESIGN.md fact

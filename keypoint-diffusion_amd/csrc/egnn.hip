@@ -18,15 +18,13 @@ namespace {
 struct LayerW {
     // per edge type
     float *wp_e[4], *wx_e[4], *b_e[4], *wr_e[4], *watt[4];
-    float *chain[4], *wcol_e[4], *wcol_c[4];    // chained edge kernel: W2 chunks [coord 16 | edge 16], column 256 of W2
-    float *chain_h[4];                          //   the same chunks as f16 hi / lo units
     float *wp_c[4], *wx_c[4], *b_c[4], *wr_c[4], *w3[4];
     void *wh_e[4], *wh_c[4];                    // f16x2 mode: the finished wp_e / wp_c blocks as f16 hi / lo planes
     void *chh_p[2][NSLOT];                      //             the projection blocks ch_p
     void *wh_a[2], *wh_b[2], *wh_2[2];          //             and the node-MLP blocks wp_a / wp_b / wp_2
     // per node type, per projection slot
     float *wp_p[2][NSLOT], *wx_p[2][NSLOT], *b_p[2][NSLOT];
-    float *ch_p[2][NSLOT], *wcol_p[2][NSLOT];   // k_proj_chain form of the same blocks
+    float *ch_p[2][NSLOT], *wcol_p[2][NSLOT];   // k_proj_ws form of the same blocks (chain-chunk fragment order, column 256 apart)
     // node MLP + LayerNorm per node type
     float *wp_a[2], *wx_a[2], *wp_b[2], *wx_b[2], *b0[2], *wp_2[2], *wx_2[2], *b2[2], *ln_w[2], *ln_b[2];
 };
@@ -83,9 +81,7 @@ struct kpd_egnn {
     size_t widen_floats = 0, widen_ints = 0;
     int gemm_mode = 0;                         // 0 exact fp32 MFMA; 1 f16x2 split products in the EGNN GEMMs (KPD_GEMM=f16x2, "gemm=f16x2")
     int h_parts = 7;                           // diagnostics: which kernels take the f16x2 form (1 edge, 2 projections, 4 node update)
-    int tile_rows = TM;                        // edges per tile of the edge kernel (64, or 32: k_egnn_edge32, four workgroups per CU)
     int prune_last = 1;                        // final layer: only what feeds (h_lig, x_lig) is computed ("prune=0" restores all)
-    int edge_chain = -1;                       // 1: register-chained edge kernel (egnn_chain.hip); -1: KPD_EDGE_CHAIN or staged
     // optional HIP-event timing of the dominant kernel (k_egnn_edge), for bench.py's roofline
     unsigned long long *stamps = nullptr;      // device [16], diagnostics (kpd_egnn_debug_state "stamps=1")
     float *edge_dbg = nullptr;                 // per-row taps of the f16x2 edge kernel's coordinate branch ("edge_dbg=1", -DKPD_EDGE_DBG builds)
@@ -113,7 +109,6 @@ static kpd_status build_weight_arena(kpd_egnn *m) {
     bytes += (size_t)(64 * c.atom_nf + 64 + 64 * 256 + 256 + 2 * c.rec_nf * c.rec_nf + 2 * c.rec_nf +
                       2 * c.rec_nf * 256 + 256 + 2 * c.atom_nf * 256 + 2 * c.atom_nf + 2 * c.atom_nf * c.atom_nf +
                       c.atom_nf) * 4 + 64 * 256;
-    bytes += (size_t)c.n_layers * m->n_et * (2 * 32 * 4096 + 2 * HS + 128) * 4;
     bytes += (size_t)c.n_layers * m->n_et * 4 * (16 * 4096 + HS + 64) * 4;
     bytes += (size_t)c.n_layers * m->n_et * 2 * ((size_t)WH_HALVES * 2 + 256);
     bytes += (size_t)c.n_layers * m->n_et * 4 * ((size_t)CHH_HALVES * 2 + 256);
@@ -133,8 +128,6 @@ static kpd_status build_weight_arena(kpd_egnn *m) {
         for (int et = 0; et < m->n_et; ++et) {
             w.wp_e[et] = wp(); w.wx_e[et] = vec(); w.b_e[et] = vec(); w.wr_e[et] = vec(); w.watt[et] = vec();
             w.wp_c[et] = wp(); w.wx_c[et] = vec(); w.b_c[et] = vec(); w.wr_c[et] = vec(); w.w3[et] = vec();
-            w.chain[et] = A.take<float>(32 * 4096); w.wcol_e[et] = vec(); w.wcol_c[et] = vec();
-            w.chain_h[et] = A.take<float>(32 * 4096);
             w.wh_e[et] = A.take<unsigned short>(WH_HALVES); w.wh_c[et] = A.take<unsigned short>(WH_HALVES);
             for (int var = 0; var < 2; ++var) {
                 const int ss = kSrcSlot[et] + var, ds = kDstSlot[et] + var;
@@ -204,7 +197,6 @@ extern "C" kpd_status kpd_egnn_create(const kpd_egnn_config *cfg, kpd_egnn **out
     if (st != KPD_OK) return st;
     kpd_egnn *m = new kpd_egnn();
     m->cfg = *cfg;
-    if (const char *e = getenv("KPD_EDGE_ROWS")) m->tile_rows = atoi(e) == 32 ? 32 : TM;
     if (const char *e = getenv("KPD_GEMM")) m->gemm_mode = !strcmp(e, "f16x2") ? 1 : 0;
     if (const char *e = getenv("KPD_H_PARTS")) m->h_parts = atoi(e);
     m->n_et = cfg->update_kp_feat ? 4 : 2;
@@ -433,7 +425,7 @@ extern "C" kpd_status kpd_egnn_load_weight(kpd_egnn *m, const char *name, const 
                     KPD_TRY(scale_inplace(L.wp_p[dnt][ds], WP_FLOATS, SILU_C, st));
                     KPD_TRY(scale_inplace(L.wx_p[dnt][ds], KP, SILU_C, st));
                     KPD_TRY(scale_inplace(var ? L.wr_c[et] : L.wr_e[et], HS, SILU_C, st));
-                    for (int side = 0; side < 2; ++side) {      // the same two blocks for k_proj_chain
+                    for (int side = 0; side < 2; ++side) {      // the same two blocks in the chunk order k_proj_ws keeps resident
                         float *ch = side ? L.ch_p[dnt][ds] : L.ch_p[snt][ss], *wc = side ? L.wcol_p[dnt][ds] : L.wcol_p[snt][ss];
                         const float *blk0 = w + side * HW;
                         for (int kc = 0; kc < 16; ++kc) KPD_TRY(pack_chain_frag(blk0, ld, 1, 256, 16 * kc, 16, 16, ch + (size_t)kc * 4096, st));
@@ -450,10 +442,6 @@ extern "C" kpd_status kpd_egnn_load_weight(kpd_egnn *m, const char *name, const 
                 if (is_w) {
                     KPD_TRY(expect_shape(name, shape, ndim, {HW, HW}));
                     KPD_TRY(pack_gemm_weight(w, HW, HW, 0, HW, var ? L.wp_c[et] : L.wp_e[et], var ? L.wx_c[et] : L.wx_e[et], st));
-                    // chained kernel (egnn_chain.hip): the 256 x 256 block as sixteen 16-row k-slabs, column 256 apart
-                    for (int kc = 0; kc < 16; ++kc)
-                        KPD_TRY(pack_chain_frag(w, HW, 1, 256, 16 * kc, 16, 16, L.chain[et] + (size_t)((var ? 0 : 16) + kc) * 4096, st));
-                    KPD_TRY(copy_col_pad(w, 256, HW, 256, var ? L.wcol_c[et] : L.wcol_e[et], HS, st));
                 } else {
                     KPD_TRY(expect_shape(name, shape, ndim, {HW}));
                     KPD_TRY(copy_pad(w, HW, var ? L.b_c[et] : L.b_e[et], HS, st));
@@ -486,7 +474,6 @@ extern "C" kpd_status kpd_egnn_commit(kpd_egnn *m) {
             KPD_TRY(patch_bias_row(L.wp_c[et], L.wx_c[et], L.b_c[et], SILU_C, BIAS_K, nullptr));
             KPD_TRY(pack_f16_split(L.wp_e[et], L.wh_e[et], nullptr));      // the same finished blocks for the f16x2 mode
             KPD_TRY(pack_f16_split(L.wp_c[et], L.wh_c[et], nullptr));
-            KPD_TRY(pack_egnn_chain_h(L.chain[et], L.chain_h[et], nullptr));
             KPD_TRY(f16_range_check_array(L.wx_e[et], KP, nullptr));        // W2[256, :]: split inside k_egnn_edge_h
             KPD_TRY(f16_range_check_array(L.wx_c[et], KP, nullptr));
         }
@@ -605,8 +592,7 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
     // the keypoint update feed nothing, so that layer runs the ll + kl edge types and the ligand update only (the GVP
     // reference drops those edge types itself, dynamics_gvp.py:67-72).  A consumer of the h_kp / x_kp debug taps asks for
     // the full layer with "prune=0".
-    const bool use_chain = m->edge_chain >= 0 ? m->edge_chain != 0 : (getenv("KPD_EDGE_CHAIN") && atoi(getenv("KPD_EDGE_CHAIN")) != 0);
-    const int tr = use_chain ? TM : m->tile_rows;         // the register-chained kernel walks 64-edge tiles
+    const int tr = TM;                                     // edges per tile of the edge kernel
     const int active = c.update_kp_feat ? 0xF : 0x3;
     const bool prune = c.update_kp_feat && m->prune_last;
     const int active_last = prune ? 0x3 : active;
@@ -645,44 +631,10 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
         return mk;
     };
     auto layer_etmask = [&](int li) { return li == n_layers - 1 ? active_last : active; };
-    // fills the projection part of a fused node launch with the first-layer weights of layer `li`
-    auto fill_proj = [&](NodeLayerArgs &na, int nt, int li) {
-        const LayerW &W = m->L[li];
-        const int mk = slot_mask(layer_etmask(li), nt);
-        na.do_proj = 1;
-        na.P = m->P[nt];
-        int k = 0;
-        for (int s = 0; s < NSLOT; ++s)
-            if (W.wp_p[nt][s] && ((mk >> s) & 1)) {
-                na.wp[k] = W.wp_p[nt][s]; na.wx[k] = W.wx_p[nt][s]; na.bias[k] = W.b_p[nt][s]; na.slot[k] = s;
-                ++k;
-            }
-        na.n_slots = k;
-    };
-    // Node-side orchestration per layer (KPD_NODE_MODE, A/B runs in profiles/tools/node_modes.sh):
-    //   split  (default) k_node_layer (update only) + k_proj_chain (next layer's projections, one slot per workgroup)
-    //   fused            k_node_layer does both from its resident 32-node tile
-    enum { MODE_SPLIT = 0, MODE_FUSED = 1 };
-    static const int node_mode = [] {
-        const char *e = getenv("KPD_NODE_MODE");
-        if (!e) return (int)MODE_SPLIT;
-        return !strcmp(e, "fused") ? (int)MODE_FUSED : (int)MODE_SPLIT;
-    }();
-    const bool fused_nodes = node_mode == MODE_FUSED;
-
     for (int li = 0; li < n_layers; ++li) {
         const LayerW &L = m->L[li];
-        if (!fused_nodes || li == 0) {
-            if (fused_nodes) {
-                NodeLayerPair lp;
-                memset(&lp, 0, sizeof(lp));
-                for (int nt = 0; nt < 2; ++nt) {
-                    lp.nt[nt].u.n = n[nt]; lp.nt[nt].u.h = m->h[nt];
-                    fill_proj(lp.nt[nt], nt, li);
-                }
-                lp.tiles0 = cdiv(n[0], TN);
-                KPD_TRY(launch_node_layer(lp, st));
-            } else {
+        {
+            {
                 ProjPair pp;
                 memset(&pp, 0, sizeof(pp));
                 for (int nt = 0; nt < 2; ++nt) {
@@ -718,8 +670,6 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
             ea.src_nt[et] = kSrcNt[et]; ea.dst_nt[et] = kDstNt[et]; ea.src_slot[et] = kSrcSlot[et]; ea.dst_slot[et] = kDstSlot[et];
             ea.wr_e[et] = L.wr_e[et]; ea.wr_c[et] = L.wr_c[et];
             ea.wp_e[et] = L.wp_e[et]; ea.wx_e[et] = L.wx_e[et]; ea.b_e[et] = L.b_e[et];
-            ea.chain[et] = L.chain[et]; ea.wcol_e[et] = L.wcol_e[et]; ea.wcol_c[et] = L.wcol_c[et];
-            ea.chain_h[et] = L.chain_h[et];
             ea.wp_c[et] = L.wp_c[et]; ea.wx_c[et] = L.wx_c[et]; ea.b_c[et] = L.b_c[et];
             ea.wh_e[et] = L.wh_e[et]; ea.wh_c[et] = L.wh_c[et];
             ea.watt[et] = L.watt[et]; ea.w3[et] = L.w3[et];
@@ -728,8 +678,7 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
         }
         const bool prof = m->prof_on && m->prof_used + 2 <= m->prof_ev.size();
         if (prof) KPD_HIP(hipEventRecord(m->prof_ev[m->prof_used], st));
-        if (use_chain) KPD_TRY(launch_egnn_chain(ea, last ? tile_cap_last : tile_cap, st));
-        else KPD_TRY(launch_egnn_edge(ea, last ? tile_cap_last : tile_cap, st));
+        KPD_TRY(launch_egnn_edge(ea, last ? tile_cap_last : tile_cap, st));
         if (prof) {
             KPD_HIP(hipEventRecord(m->prof_ev[m->prof_used + 1], st));
             m->prof_used += 2;
@@ -750,12 +699,11 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
             na.ln_inv_n = 1.0f / (float)(c.hidden_nf + 1); na.ln_pad = (float)(HID - c.hidden_nf);
             na.wh_a = L.wh_a[nt]; na.wh_b = L.wh_b[nt]; na.wh_2 = L.wh_2[nt];
             na.norm = c.norm;
-            na.tile_shift = tr == 32 ? 5 : 6;
+            na.tile_shift = 6;
         };
         {
             NodeLayerPair lp;
             memset(&lp, 0, sizeof(lp));
-            const bool more = fused_nodes && li + 1 < n_layers;
             for (int nt = 0; nt < 2; ++nt) {
                 NodeLayerArgs &na = lp.nt[nt];
                 na.u.n = n[nt]; na.u.h = m->h[nt];
@@ -763,7 +711,6 @@ extern "C" kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *bt, const f
                     fill_update(na.u, nt);
                     na.do_update = 1;
                 }
-                if (more) fill_proj(na, nt, li + 1);
                 if (!na.do_update && !na.do_proj) na.u.n = 0;          // nothing to do for this node type
             }
             lp.tiles0 = cdiv(lp.nt[0].u.n, TN);
@@ -804,14 +751,6 @@ extern "C" kpd_status kpd_egnn_debug_state(kpd_egnn *m, const char *what, float 
         KPD_REQUIRE(v == "f32" || v == "f16x2", KPD_ERR_INVALID, "gemm mode must be f32 or f16x2");
         KPD_REQUIRE(v == "f32" || !m->committed || m->f16_ok, KPD_ERR_WEIGHTS, "%s", F16_RANGE_ERROR);
         m->gemm_mode = v == "f16x2" ? 1 : 0;
-        return KPD_OK;
-    } else if (w.rfind("tile_rows=", 0) == 0) {    // 64 | 32: which staged edge kernel runs (A/B tests)
-        const int r = atoi(w.c_str() + 10);
-        KPD_REQUIRE(r == 32 || r == 64, KPD_ERR_INVALID, "tile_rows must be 32 or 64");
-        m->tile_rows = r;
-        return KPD_OK;
-    } else if (w.rfind("edge_chain=", 0) == 0) {   // A/B switch between the two edge kernels (tests, profiles/tools)
-        m->edge_chain = atoi(w.c_str() + 11);
         return KPD_OK;
     } else if (w == "edge_dbg=1") {          // allocate the per-row tap buffer for the current workspace ([tile_cap][64][4] floats)
         KPD_REQUIRE(m->tile_cap > 0, KPD_ERR_STATE, "edge_dbg=1 needs a reserved workspace");

@@ -14,7 +14,6 @@ constexpr int NT_LIG = 0, NT_KP = 1;
 constexpr int EDGE_LDS_BYTES = TM * SA * 4 + (TM * 2 + TM + 3 * TM + TM + 3 * TM + 4 * HS + 8 + TM) * 4;   // ... misc[8], 64 column-256 values
 // k_egnn_edge_h: two f16 planes of 64 x 280 halves (= the T tile's region), row data, two fp32 head rows, W2 row 256 as 2 x 2 x 272 halves
 constexpr int EDGE_H_LDS_BYTES = 64 * 280 * 2 * 2 + (TM * 2 + TM + 3 * TM + TM + 3 * TM + 2 * HS + 8) * 4 + 2 * 2 * 272 * 2;
-constexpr int EDGE32_LDS_BYTES = 32 * SA * 4 + (32 * 2 + 32 + 3 * 32 + 32 + 3 * 32 + 2 * HS + 8) * 4;     // k_egnn_edge32
 
 struct ProjArgs {
     const float *h;                 // [n][HS]
@@ -24,7 +23,7 @@ struct ProjArgs {
     const float *wx[NSLOT];
     const float *bias[NSLOT];       // nullptr for src slots
     int slot[NSLOT];
-    const float *chain[NSLOT];      // k_proj_chain: the 256 x 256 block as 16 A-fragment chunks, and W[:, 256]
+    const float *chain[NSLOT];      // k_proj_ws: the 256 x 256 block as 16 A-fragment chunks, and W[:, 256]
     const float *wcol[NSLOT];
     const void *chain_h[NSLOT];     // f16x2 mode: the same block as f16 hi / lo planes (pack_proj_f16_split)
 };
@@ -49,9 +48,6 @@ struct EdgeArgs {
     const float *wp_c[4], *wx_c[4], *b_c[4];
     const float *watt[4];
     const float *w3[4];
-    const float *chain[4];          // W2 of coord_mlp then edge_mlp as 16x16x4 A-fragment chunks (egnn_chain.hip)
-    const float *chain_h[4];        // the same 32 chunks as f16 hi / lo units (pack_egnn_chain_h) for k_egnn_chain<1>
-    const float *wcol_e[4], *wcol_c[4];   // W2[:, 256]
     float *hn_main[4], *hn_cont[4];
     float *xn_main[4], *xn_cont[4];
     int use_tanh;
@@ -59,7 +55,7 @@ struct EdgeArgs {
     unsigned long long *stamps;     // [16] phase-cycle sums, diagnostics only (null in production)
     const void *wh_e[4], *wh_c[4];  // f16x2 mode: W2 of edge_mlp / coord_mlp as f16 hi / lo planes (pack_f16_split)
     int gemm_mode;                  // 0: exact fp32 MFMA (contract path), 1: f16x2 split products (opt-in)
-    int tile_rows;                  // edges per tile: 64 (k_egnn_edge<NW>, k_egnn_chain) or 32 (k_egnn_edge32)
+    int tile_rows;                  // edges per tile: 64 (TM)
     int ablate;                     // timing experiments only (KPD_EDGE_ABLATE), 0 in production
     float *dbg;                     // [tiles][64][4] per-row taps of the coordinate branch (builds with -DKPD_EDGE_DBG only; "edge_dbg=1")
 };
@@ -118,7 +114,6 @@ kpd_status launch_embed(const float *in, int n, int fin, const float *W0, const 
 kpd_status launch_decode(const float *h, const float *x, const float *x0, int n, int atom_nf, int hid, const float *W0,
                          const float *b0, const float *W1, const float *b1, float *eps_h, float *eps_x, hipStream_t st);
 kpd_status launch_egnn_edge(const EdgeArgs &a, int tile_cap, hipStream_t st);
-kpd_status launch_egnn_chain(const EdgeArgs &a, int tile_cap, hipStream_t st);
 kpd_status launch_proj_chain(const ProjPair &p, hipStream_t st);
 kpd_status launch_node_layer(const NodeLayerPair &p, hipStream_t st);
 

@@ -1,7 +1,7 @@
 // EGNN denoiser kernels (LigRecDynamics, models/dynamics.py:9-385) for gfx950.
 //
 // Per layer (LigRecConv.forward, dynamics.py:124-207) three kernels run:
-//   k_proj_chain  (egnn_chain.hip) P[node][slot] = W1[:, h-part] . h[node] (+ b1 on dst slots)
+//   k_proj_ws     (egnn_chain.hip) P[node][slot] = W1[:, h-part] . h[node] (+ b1 on dst slots)
 //                 -- the first Linear(515, 257) of edge_mlp / coord_mlp is linear in
 //                    [h_src, h_dst, d_ij], so its two 257-wide blocks are applied once per
 //                    NODE instead of once per EDGE (3x fewer edge FLOPs);
@@ -9,10 +9,10 @@
 //                 SiLU, the 257x257 second Linear on fp32 MFMA, SiLU, soft attention,
 //                 coordinate head, and the segmented sum over destination nodes -- all in
 //                 one workgroup, intermediates never leave LDS/registers;
-//   k_node_layer  h' = LN(h + node_mlp([h, h_neigh / z])), x' = x + x_neigh / z (KPD_NODE_MODE=fused: also the projections).
+//   k_node_update8  h' = LN(h + node_mlp([h, h_neigh / z])), x' = x + x_neigh / z.
 // Segment pieces: a tile writes the sum of each run of equal dst either to main[dst]
 // (run starts the segment) or to cont[tile] (run continues a segment begun in an earlier
-// tile); k_node_layer adds main + cont pieces in tile order => deterministic, no atomics.
+// tile); k_node_update8 adds main + cont pieces in tile order => deterministic, no atomics.
 #include <stdlib.h>
 
 #include <algorithm>
@@ -909,537 +909,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge_h(EdgeAr
 
 
 
-// ---- 32-row form of the fused edge kernel ---------------------------------------------------------------------
-// Same phases as k_egnn_edge<4> on tiles of 32 edges: the A / T tile is 34 KB instead of 69 KB and a wave needs 32
-// accumulator registers instead of 64, so FOUR independent workgroups share a CU (4 waves per SIMD, <= 128 VGPRs)
-// instead of two.  The f32 MFMA and the VALU are one pipe on gfx950, so the only time that pipe can win back is the
-// time in which every resident wave of a SIMD sits in a gather, an LDS round trip or a barrier at once: with two
-// co-resident workgroups that is ~15 % of the kernel (PMC: MFMA busy 67 % + VALU active 16 %), with four
-// independent ones it mostly disappears.  Price: every weight fragment streamed from L2 feeds one 32-row MFMA tile
-// instead of two (2x L2 -> CU weight traffic, ~8 B/clk/CU), and twice as many tiles pay the per-tile prologue.
-constexpr int R32 = 32;
-
-struct EdgeSmem32 {
-    float *A;
-    int *src, *dst;
-    float *d, *xd, *att, *mx, *wv;
-    int *misc;
-};
-
-__device__ __forceinline__ EdgeSmem32 edge_smem32(float *smem) {
-    EdgeSmem32 s;
-    s.A = smem;
-    s.src = reinterpret_cast<int *>(smem + R32 * SA);
-    s.dst = s.src + R32;
-    s.d = reinterpret_cast<float *>(s.dst + R32);
-    s.xd = s.d + R32;
-    s.att = s.xd + 3 * R32;
-    s.mx = s.att + R32;
-    s.wv = s.mx + 3 * R32;
-    s.misc = reinterpret_cast<int *>(s.wv + 2 * HS);
-    return s;
-}
-
-struct EdgeGather32 {
-    static constexpr int RPW = R32 / 4;
-    f32x4 ps[RPW], pd[RPW];
-    f32x4 tps, tpd;
-};
-
-__device__ __forceinline__ void edge_gather_issue32(EdgeGather32 &g, const EdgeSmem32 &s, const float *__restrict__ Ps,
-                                                    const float *__restrict__ Pd, int wave, int lane) {
-    constexpr int RPW = EdgeGather32::RPW;
-    // 32-bit byte offsets from a wave-uniform base: P is far below 4 GB, and 64-bit multiplies per row are VALU time
-    constexpr unsigned PROW_B = NSLOT * HS * 4;
-    const char *ps = reinterpret_cast<const char *>(Ps), *pd = reinterpret_cast<const char *>(Pd);
-#pragma unroll
-    for (int rr = 0; rr < RPW; ++rr) {
-        const int r = wave * RPW + rr;
-        g.ps[rr] = *reinterpret_cast<const f32x4 *>(ps + ((unsigned)s.src[r] * PROW_B + 16u * lane));
-        g.pd[rr] = *reinterpret_cast<const f32x4 *>(pd + ((unsigned)s.dst[r] * PROW_B + 16u * lane));
-    }
-    if (lane < 4 * RPW && (lane & 3) < 2) {
-        const int r = wave * RPW + (lane >> 2), c = lane & 3;
-        g.tps = *reinterpret_cast<const f32x4 *>(ps + ((unsigned)s.src[r] * PROW_B + 16u * (64 + c)));
-        g.tpd = *reinterpret_cast<const f32x4 *>(pd + ((unsigned)s.dst[r] * PROW_B + 16u * (64 + c)));
-    }
-}
-
-__device__ __forceinline__ void edge_gather_finish32(const EdgeGather32 &g, const EdgeSmem32 &s, const float *__restrict__ wr,
-                                                     int wave, int lane) {
-    constexpr int RPW = EdgeGather32::RPW;
-    const f32x4 w0 = reinterpret_cast<const f32x4 *>(wr)[lane];
-#pragma unroll
-    for (int rr = 0; rr < RPW; ++rr) {
-        const int r = wave * RPW + rr;
-        f32x4 v = g.ps[rr] + g.pd[rr] + s.d[r] * w0;
-        v[0] = silu_pre(v[0]); v[1] = silu_pre(v[1]); v[2] = silu_pre(v[2]); v[3] = silu_pre(v[3]);
-        *reinterpret_cast<f32x4 *>(s.A + r * SA + 4 * lane) = v;
-    }
-    if (lane < 4 * RPW && (lane & 3) < 2) {
-        const int r = wave * RPW + (lane >> 2), c = lane & 3;
-        const f32x4 w1 = reinterpret_cast<const f32x4 *>(wr)[64 + c];
-        f32x4 u = g.tps + g.tpd + s.d[r] * w1;
-        u[0] = silu_pre(u[0]); u[1] = silu_pre(u[1]); u[2] = silu_pre(u[2]); u[3] = silu_pre(u[3]);
-        if (c == (BIAS_K - 256) / 4) u[(BIAS_K - 256) % 4] = 1.0f;
-        *reinterpret_cast<f32x4 *>(s.A + r * SA + 256 + 4 * c) = u;
-    }
-}
-
-// T[row][col] = c SiLU(.) from the accumulators of a 32-row tile (bias already inside the GEMM)
-__device__ __forceinline__ void store_T_silu32(float *T, const f32x16 (&acc)[2], float ex, int tid, int wave, int lane) {
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int col = acc_col(nt, wave, lane);
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) T[acc_row32(reg, lane) * SA + col] = silu_pre(acc[nt][reg]);
-    }
-    if ((tid & 7) == 0) T[(tid >> 3) * SA + 256] = silu_pre(ex);
-}
-
-__global__ __launch_bounds__(256, 4) void k_egnn_edge32(EdgeArgs a) {
-    constexpr int TPR = 256 / R32;       // 8 threads per row in the row-wise passes
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const EdgeSmem32 s = edge_smem32(smem);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    unsigned long long t_prev_ = a.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-
-    const int T = a.meta[8];
-    const int chunk = (T + 7) >> 3;
-    const int bi = blockIdx.x >> 3;
-    if (bi >= chunk) return;
-    const int tile = (blockIdx.x & 7) * chunk + bi;
-    if (tile >= T) return;
-    int et = 0;
-#pragma unroll
-    for (int e = 1; e < 4; ++e)
-        if (tile >= a.meta[4 + e]) et = e;
-    const int tile_in_et = tile - a.meta[4 + et];
-    const int e0 = tile_in_et * R32;
-    const int ne = min(R32, a.meta[et] - e0);
-    const int snt = a.src_nt[et], dnt = a.dst_nt[et];
-    const int *__restrict__ esrc = a.src[et];
-    const int *__restrict__ edst = a.dst[et];
-
-    // phase 0: edge endpoints, geometry and run masks (lanes 0..31 of wave 0), head weights (waves 1..3)
-    if (tid < 64) {
-        const bool on = tid < R32;
-        const int e = e0 + min(tid, ne - 1);
-        const int u = esrc[e], v = edst[e];
-        const float *xs = a.x[snt] + (size_t)u * 3, *xd = a.x[dnt] + (size_t)v * 3;
-        const float dx = xs[0] - xd[0], dy = xs[1] - xd[1], dz = xs[2] - xd[2];
-        const float d = sqrtf(dx * dx + dy * dy + dz * dz);
-        const float inv = 1.0f / (d + 1.0f);
-        if (on) {
-            s.src[tid] = u;
-            s.dst[tid] = v;
-            s.d[tid] = d;
-            s.xd[3 * tid] = dx * inv;
-            s.xd[3 * tid + 1] = dy * inv;
-            s.xd[3 * tid + 2] = dz * inv;
-        }
-        const int vprev = tid > 0 ? edst[e0 + min(tid - 1, ne - 1)] : (e0 > 0 ? edst[e0 - 1] : -1);
-        const int vnext = tid + 1 < ne ? edst[e0 + tid + 1] : -2;
-        const unsigned long long heads = __ballot(tid < ne && (tid == 0 || vprev != v));
-        const unsigned long long ends = __ballot(tid < ne && vnext != v);
-        if (tid == 0) {
-            s.misc[0] = (vprev == v) ? 1 : 0;
-            s.misc[2] = (int)(ends & 0xffffffffu);
-            s.misc[4] = (int)(heads & 0xffffffffu);
-        }
-    } else if (tid < 64 + 66) {
-        const int i = tid - 64;
-        reinterpret_cast<f32x4 *>(s.wv)[i] = reinterpret_cast<const f32x4 *>(a.watt[et])[i];
-    } else if (tid < 64 + 132) {
-        const int i = tid - 64 - 66;
-        reinterpret_cast<f32x4 *>(s.wv + HS)[i] = reinterpret_cast<const f32x4 *>(a.w3[et])[i];
-    }
-    lds_barrier();
-    KPD_STAMP(0)
-
-    const float *Ps = a.P[snt] + (size_t)a.src_slot[et] * HS;
-    const float *Pd = a.P[dnt] + (size_t)a.dst_slot[et] * HS;
-    const int first_is_cont = s.misc[0];
-    const unsigned endmask = (unsigned)s.misc[2];
-    const unsigned headmask = (unsigned)s.misc[4];
-    f32x16 acc[2];
-    float ex;
-
-    // ---- feature messages (dynamics.py:111-112)
-    {
-        EdgeGather32 g;
-        edge_gather_issue32(g, s, Ps, Pd, wave, lane);
-        edge_gather_finish32(g, s, a.wr_e[et], wave, lane);
-    }
-    lds_barrier();
-    KPD_STAMP(1)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.0f;
-    gemm_rows32_t<NG, SA>(s.A, a.wp_e[et], acc, wave, lane);
-    ex = row_dot_chunks<TPR>(s.A, a.wx_e[et], KP / 4, tid);
-    lds_barrier();
-    KPD_STAMP(2)
-    store_T_silu32(s.A, acc, ex, tid, wave, lane);
-    EdgeGather32 gc;          // the coordinate branch's P rows travel during the attention / segmented-sum phases
-    edge_gather_issue32(gc, s, Ps + HS, Pd + HS, wave, lane);
-    __builtin_amdgcn_sched_barrier(0);
-    lds_barrier();
-    KPD_STAMP(3)
-    {
-        float dot = row_dot_chunks<TPR>(s.A, s.wv, 64, tid);
-        const int row = tid / TPR;
-        if ((tid % TPR) == 0) {
-            dot = fmaf(s.A[row * SA + 256], s.wv[256], dot);
-            s.att[row] = row < ne ? sigmoidf_(dot + s.wv[ATT_BIAS_AT]) * (1.0f / SILU_C) : 0.0f;
-        }
-    }
-    lds_barrier();
-    KPD_STAMP(4)
-    {
-        float *hmain = a.hn_main[et], *hcont = a.hn_cont[et] + (size_t)tile_in_et * HS;
-        {
-            float run = 0.0f;
-            int piece = 0;
-#pragma unroll 1
-            for (int r0 = 0; r0 < R32; r0 += 16) {
-                if (r0 >= ne) break;
-                float v[16], w[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    w[i] = s.att[r0 + i];
-                    v[i] = s.A[(r0 + i) * SA + tid];
-                }
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    run = fmaf(v[i], w[i], run);
-                    if ((endmask >> (r0 + i)) & 1u) {
-                        float *out = (piece == 0 && first_is_cont) ? hcont : hmain + (size_t)s.dst[r0 + i] * HS;
-                        out[tid] = run;
-                        run = 0.0f;
-                        ++piece;
-                    }
-                }
-            }
-        }
-        // column 256: lane = row on the last wave (lanes >= 32 carry zeros), segmented inclusive scan across lanes
-        if (wave == 3) {
-            const int rl = lane & 31;
-            const unsigned upto = rl == 31 ? ~0u : ((1u << (rl + 1)) - 1u);
-            const int start = 31 - __clz((int)((headmask & upto) | 1u));
-            float v = lane < R32 ? s.A[rl * SA + 256] * s.att[rl] : 0.0f;
-#pragma unroll
-            for (int off = 1; off < 32; off <<= 1) {
-                const float t = __shfl_up(v, off);
-                if (rl - off >= start) v += t;
-            }
-            if (lane < R32 && ((endmask >> rl) & 1u)) {
-                const int pc = __popc(endmask & ((1u << rl) - 1u));
-                float *out = (pc == 0 && first_is_cont) ? hcont : hmain + (size_t)s.dst[rl] * HS;
-                out[256] = v;
-            }
-        }
-    }
-    lds_barrier();
-    KPD_STAMP(5)
-
-    // ---- coordinate messages (dynamics.py:113-120)
-    edge_gather_finish32(gc, s, a.wr_c[et], wave, lane);
-    lds_barrier();
-    KPD_STAMP(6)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.0f;
-    gemm_rows32_t<NG, SA>(s.A, a.wp_c[et], acc, wave, lane);
-    ex = row_dot_chunks<TPR>(s.A, a.wx_c[et], KP / 4, tid);
-    lds_barrier();
-    KPD_STAMP(7)
-    store_T_silu32(s.A, acc, ex, tid, wave, lane);
-    lds_barrier();
-    KPD_STAMP(8)
-    {
-        float dot = row_dot_chunks<TPR>(s.A, s.wv + HS, 64, tid);
-        const int row = tid / TPR;
-        if ((tid % TPR) == 0) {
-            dot = fmaf(s.A[row * SA + 256], s.wv[HS + 256], dot);
-            float c = a.use_tanh ? tanhf(dot) * a.coords_range : dot;
-            if (row >= ne) c = 0.0f;
-            s.mx[3 * row] = c * s.xd[3 * row];
-            s.mx[3 * row + 1] = c * s.xd[3 * row + 1];
-            s.mx[3 * row + 2] = c * s.xd[3 * row + 2];
-        }
-    }
-    lds_barrier();
-    KPD_STAMP(9)
-    if (wave == 0) {
-        const int rl = lane & 31;
-        const unsigned upto = rl == 31 ? ~0u : ((1u << (rl + 1)) - 1u);
-        const int start = 31 - __clz((int)((headmask & upto) | 1u));
-        float vx = 0.f, vy = 0.f, vz = 0.f;
-        if (lane < R32) {
-            vx = s.mx[3 * rl]; vy = s.mx[3 * rl + 1]; vz = s.mx[3 * rl + 2];
-        }
-#pragma unroll
-        for (int off = 1; off < 32; off <<= 1) {
-            const float tx = __shfl_up(vx, off), ty = __shfl_up(vy, off), tz = __shfl_up(vz, off);
-            if (rl - off >= start) {
-                vx += tx;
-                vy += ty;
-                vz += tz;
-            }
-        }
-        if (lane < R32 && ((endmask >> rl) & 1u)) {
-            const int piece = __popc(endmask & ((1u << rl) - 1u));
-            float *out = (piece == 0 && first_is_cont) ? a.xn_cont[et] + (size_t)tile_in_et * 4
-                                                       : a.xn_main[et] + (size_t)s.dst[rl] * 4;
-            out[0] = vx;
-            out[1] = vy;
-            out[2] = vz;
-        }
-    }
-    KPD_STAMP(10)
-}
-
-
-// ---- fused node kernel: update of layer i, then the first-layer projections of layer i + 1 ----------------
-// 32-node tiles (4 workgroups per CU) so that the 20 800 nodes of a C2 batch make 650 work items on 256
-// CUs instead of 325, and the updated h never leaves LDS between the update and the projections.
-__global__ __launch_bounds__(256, 3) void k_node_layer(NodeLayerPair p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *A = smem;
-    float *s_z = smem + TN * SA;
-    float *s_mean = s_z + TN;
-    float *s_rstd = s_mean + TN;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int which = blockIdx.x >= p.tiles0 ? 1 : 0;
-    const NodeLayerArgs &L = p.nt[which];
-    const NodeArgs &a = L.u;
-    const int node0 = (blockIdx.x - (which ? p.tiles0 : 0)) * TN;
-    constexpr int RPW = TN / 4;          // rows per wave in the copy loops
-    constexpr int TPR = 256 / TN;        // threads per row in the row-wise passes
-    unsigned long long t_prev_ = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-#define NL_STAMP(idx)                                                                      \
-    if (p.stamps && tid == 0) {                                                            \
-        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                      \
-        atomicAdd(&p.stamps[idx], (unsigned long long)(now_ - t_prev_));                   \
-        t_prev_ = now_;                                                                    \
-    }
-
-    auto load_h = [&]() {
-#pragma unroll
-        for (int rr = 0; rr < RPW; ++rr) {
-            const int r = wave * RPW + rr, v = node0 + r;
-            f32x4 val = {0.f, 0.f, 0.f, 0.f}, val2 = {0.f, 0.f, 0.f, 0.f};
-            if (v < a.n) {
-                const f32x4 *src = reinterpret_cast<const f32x4 *>(a.h + (size_t)v * HS);
-                val = src[lane];
-                if (lane < 2) val2 = src[64 + lane];
-            }
-            *reinterpret_cast<f32x4 *>(A + r * SA + 4 * lane) = val;
-            if (lane < 2) *reinterpret_cast<f32x4 *>(A + r * SA + 256 + 4 * lane) = val2;
-        }
-    };
-
-    f32x16 acc[2];
-    if (L.do_update) {
-        // coordinates: x' = x + x_neigh / z (dynamics.py:190-192, 206)
-        if (tid < TN) {
-            const int v = node0 + tid;
-            float z = 1.0f;
-            if (v < a.n) {
-                z = a.z[a.bidx[v]];
-                float sx = 0.f, sy = 0.f, sz = 0.f;
-                for (int i = 0; i < a.n_in; ++i) {
-                    const int lo = a.rowptr[i][v], hi = a.rowptr[i][v + 1];
-                    if (hi > lo) {
-                        const float *pm = a.xn_main[i] + (size_t)v * 4;
-                        sx += pm[0]; sy += pm[1]; sz += pm[2];
-                        for (int t = (lo >> a.tile_shift) + 1; t <= ((hi - 1) >> a.tile_shift); ++t) {
-                            const float *q = a.xn_cont[i] + (size_t)t * 4;
-                            sx += q[0]; sy += q[1]; sz += q[2];
-                        }
-                    }
-                }
-                float *xv = a.x + (size_t)v * 3;
-                xv[0] += sx / z; xv[1] += sy / z; xv[2] += sz / z;
-            }
-            s_z[tid] = z;
-        }
-        // GEMM 1a: W[:, :257] . h
-        load_h();
-        lds_barrier();
-        NL_STAMP(0)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.0f;
-        gemm_rows32_t<NG, SA>(A, a.wp_a, acc, wave, lane);
-        float ex = row_dot_chunks<TPR>(A, a.wx_a, KP / 4, tid);
-        lds_barrier();
-        NL_STAMP(1)
-        // GEMM 1b: + W[:, 257:] . (h_neigh / z); h_neigh = sum of segment pieces over the incoming edge
-        // types in fixed order (multi_update_all cross_reducer='sum')
-#pragma unroll 2
-        for (int rr = 0; rr < RPW; ++rr) {
-            const int r = wave * RPW + rr, v = node0 + r;
-            f32x4 val = {0.f, 0.f, 0.f, 0.f}, val2 = {0.f, 0.f, 0.f, 0.f};
-            if (v < a.n) {
-                for (int i = 0; i < a.n_in; ++i) {
-                    const int lo = a.rowptr[i][v], hi = a.rowptr[i][v + 1];
-                    if (hi > lo) {
-                        const f32x4 *pm = reinterpret_cast<const f32x4 *>(a.hn_main[i] + (size_t)v * HS);
-                        val += pm[lane];
-                        if (lane < 2) val2 += pm[64 + lane];
-                        for (int t = (lo >> a.tile_shift) + 1; t <= ((hi - 1) >> a.tile_shift); ++t) {
-                            const f32x4 *q = reinterpret_cast<const f32x4 *>(a.hn_cont[i] + (size_t)t * HS);
-                            val += q[lane];
-                            if (lane < 2) val2 += q[64 + lane];
-                        }
-                    }
-                }
-                const float z = s_z[r];
-                val /= z;
-                val2 /= z;
-            }
-            *reinterpret_cast<f32x4 *>(A + r * SA + 4 * lane) = val;
-            if (lane < 2) *reinterpret_cast<f32x4 *>(A + r * SA + 256 + 4 * lane) = val2;
-        }
-        lds_barrier();
-        NL_STAMP(2)
-        gemm_rows32_t<NG, SA>(A, a.wp_b, acc, wave, lane);
-        ex += row_dot_chunks<TPR>(A, a.wx_b, KP / 4, tid);
-        lds_barrier();
-        NL_STAMP(3)
-        // hidden = SiLU(. + b0) -> T (pad columns 257..263 stay 0 from the h_neigh tile)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int col = acc_col(nt, wave, lane);
-            const float bb = a.b0[col];
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) A[acc_row32(reg, lane) * SA + col] = silu(acc[nt][reg] + bb);
-        }
-        if ((tid % TPR) == 0) A[(tid / TPR) * SA + 256] = silu(ex + a.b0[256]);
-        lds_barrier();
-        NL_STAMP(4)
-        // GEMM 2 + bias + residual (dynamics.py:201-203)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.0f;
-        gemm_rows32_t<NG, SA>(A, a.wp_2, acc, wave, lane);
-        ex = row_dot_chunks<TPR>(A, a.wx_2, KP / 4, tid);
-        lds_barrier();
-        NL_STAMP(5)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int col = acc_col(nt, wave, lane);
-            const float bb = a.b2[col];
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) A[acc_row32(reg, lane) * SA + col] = acc[nt][reg] + bb;
-        }
-        if ((tid % TPR) == 0) A[(tid / TPR) * SA + 256] = ex + a.b2[256];
-        lds_barrier();
-        // residual h (row-wise, coalesced; the h array is padded to a whole tile, rows >= n read zeros)
-#pragma unroll 4
-        for (int rr = 0; rr < RPW; ++rr) {
-            const int r = wave * RPW + rr;
-            const f32x4 *src = reinterpret_cast<const f32x4 *>(a.h + (size_t)(node0 + r) * HS);
-            *reinterpret_cast<f32x4 *>(A + r * SA + 4 * lane) += src[lane];
-            if (lane == 0) A[r * SA + 256] += a.h[(size_t)(node0 + r) * HS + 256];
-        }
-        lds_barrier();
-        NL_STAMP(6)
-        // LayerNorm(257) (dynamics.py:81-87, 204), biased variance, eps = 1e-5
-        if (a.norm) {
-            const int row = tid / TPR, q = tid % TPR;
-            const float *tr = A + row * SA + q;
-            float sum = 0.0f;
-            for (int i = 0; i < 256 / TPR; ++i) sum += tr[TPR * i];
-            if (q == 0) sum += A[row * SA + 256];
-#pragma unroll
-            for (int o = 1; o < TPR; o <<= 1) sum += __shfl_xor(sum, o);
-            const float mean = sum * a.ln_inv_n;
-            float var = 0.0f;
-            for (int i = 0; i < 256 / TPR; ++i) {
-                const float dlt = tr[TPR * i] - mean;
-                var = fmaf(dlt, dlt, var);
-            }
-            if (q == 0) {
-                const float dlt = A[row * SA + 256] - mean;
-                var = fmaf(dlt, dlt, var);
-            }
-#pragma unroll
-            for (int o = 1; o < TPR; o <<= 1) var += __shfl_xor(var, o);
-            if (q == 0) {
-                s_mean[row] = mean;
-                s_rstd[row] = 1.0f / sqrtf((var - a.ln_pad * mean * mean) * a.ln_inv_n + 1e-5f);      // pad columns (hidden_nf < 256) hold 0: take their (0 - mean)^2 out
-            }
-        }
-        lds_barrier();
-        NL_STAMP(7)
-        // normalise in place (the tile becomes the A operand of the projections) and write h' back
-#pragma unroll 2
-        for (int rr = 0; rr < RPW; ++rr) {
-            const int r = wave * RPW + rr, v = node0 + r;
-            f32x4 val = *reinterpret_cast<const f32x4 *>(A + r * SA + 4 * lane);
-            float last = A[r * SA + 256];
-            if (a.norm) {
-                const float mean = s_mean[r], rstd = s_rstd[r];
-                const f32x4 w = reinterpret_cast<const f32x4 *>(a.ln_w)[lane];
-                const f32x4 b = reinterpret_cast<const f32x4 *>(a.ln_b)[lane];
-                val = (val - mean) * rstd * w + b;
-                last = (last - mean) * rstd * a.ln_w[256] + a.ln_b[256];
-            }
-            if (v >= a.n) {
-                val = f32x4{0.f, 0.f, 0.f, 0.f};
-                last = 0.0f;
-            }
-            *reinterpret_cast<f32x4 *>(A + r * SA + 4 * lane) = val;
-            const f32x4 t = {last, 0.f, 0.f, 0.f};
-            if (lane == 0) *reinterpret_cast<f32x4 *>(A + r * SA + 256) = t;
-            if (lane == 1) *reinterpret_cast<f32x4 *>(A + r * SA + 260) = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (v < a.n) {
-                f32x4 *dst = reinterpret_cast<f32x4 *>(a.h + (size_t)v * HS);
-                dst[lane] = val;
-                if (lane == 0) dst[64] = t;
-            }
-        }
-        lds_barrier();
-        NL_STAMP(8)
-    } else {
-        load_h();
-        lds_barrier();
-        NL_STAMP(0)
-    }
-
-    // first-layer projections of the next layer: P[node][slot] = W1[:, block] . h' (+ b1 on dst slots)
-    if (L.do_proj) {
-        const size_t prow = (size_t)NSLOT * HS;
-        for (int si = 0; si < L.n_slots; ++si) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.0f;
-            if (!(p.dbg & 1)) gemm_rows32_t<NG, SA>(A, L.wp[si], acc, wave, lane);
-            NL_STAMP(9)
-            if (p.dbg & 2) continue;
-            const float ex = row_dot_chunks<TPR>(A, L.wx[si], KP / 4, tid);
-            const float *bias = L.bias[si];
-            // P is padded to whole tiles, so rows past n are written unconditionally (never read back);
-            // addressing = wave-uniform base (+ compile-time row term) + one 32-bit lane offset
-            char *obase = reinterpret_cast<char *>(L.P + ((size_t)node0 * NSLOT + L.slot[si]) * HS);
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const int col = acc_col(nt, wave, lane);
-                const float b = bias ? bias[col] : 0.0f;
-                const unsigned lane_off = (unsigned)((4 * (lane >> 5)) * (int)prow + col) * 4u;
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const unsigned row_off = (unsigned)(((reg & 3) + 8 * (reg >> 2)) * (int)prow) * 4u;
-                    *reinterpret_cast<float *>(obase + row_off + lane_off) = acc[nt][reg] + b;
-                }
-            }
-            if ((tid % TPR) == 0)
-                *reinterpret_cast<float *>(obase + (unsigned)((tid / TPR) * (int)prow + 256) * 4u) = ex + (bias ? bias[256] : 0.0f);
-            NL_STAMP(10)
-        }
-    }
-#undef NL_STAMP
-}
-
-// ---- node update with 8 waves per 32-node tile (update only; the projections run in k_proj_chain) -----------------------
+// ---- node update: 8 waves per 32-node tile (the projections of the next layer run in k_proj_ws, egnn_chain.hip) ---------
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_node_update8(NodeLayerPair p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *A = smem;
@@ -1889,40 +1359,22 @@ kpd_status launch_egnn_edge(const EdgeArgs &a, int tile_cap, hipStream_t st) {
     if (poison_level() >= 1) KPD_TRY(poison_lds(st));      // debug only (engine.h)
     // KPD_EDGE_LDS_PAD (diagnostics): extra dynamic LDS to force one workgroup per CU
     static const int pad = getenv("KPD_EDGE_LDS_PAD") ? atoi(getenv("KPD_EDGE_LDS_PAD")) : 0;
-    // 4 waves per workgroup by default: 256 VGPRs per lane leave room to keep the coordinate branch's gathered P rows in
-    // registers across the attention / segmented-sum phases (1.00 vs 1.04 ms); KPD_EDGE_NW=8 selects the 8-wave build
-    static const int nw = getenv("KPD_EDGE_NW") ? atoi(getenv("KPD_EDGE_NW")) : 4;
     static const int ablate = getenv("KPD_EDGE_ABLATE") ? atoi(getenv("KPD_EDGE_ABLATE")) : 0;
     EdgeArgs b = a;
     b.ablate = ablate;
+    KPD_REQUIRE(a.tile_rows == TM, KPD_ERR_INVALID, "the edge kernels walk 64-edge tiles");
+    // 4 waves per workgroup: 256 VGPRs per lane leave room to keep the coordinate branch's gathered P rows in registers across
+    // the attention / segmented-sum phases (the 8-wave and the 32-row builds of rounds 1 - 3 lost to it and were removed in round 4)
     if (a.gemm_mode == 1) {
-        KPD_REQUIRE(a.tile_rows == TM, KPD_ERR_INVALID, "the f16x2 edge kernel walks 64-edge tiles");
         for (int et = 0; et < 4; ++et)
             KPD_REQUIRE(!a.wp_e[et] || (a.wh_e[et] && a.wh_c[et]), KPD_ERR_STATE, "f16x2 weights of edge type %d were not packed", et);
-        static const int nwh = getenv("KPD_EDGE_H_NW") ? atoi(getenv("KPD_EDGE_H_NW")) : 4;
-        if (nwh == 8) {
-            KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_egnn_edge_h<8>), EDGE_H_LDS_BYTES + pad));
-            hipLaunchKernelGGL(k_egnn_edge_h<8>, dim3(8 * cdiv(tile_cap, 8)), dim3(512), EDGE_H_LDS_BYTES + pad, st, b);
-        } else {
-            KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_egnn_edge_h<4>), EDGE_H_LDS_BYTES + pad));
-            hipLaunchKernelGGL(k_egnn_edge_h<4>, dim3(8 * cdiv(tile_cap, 8)), dim3(256), EDGE_H_LDS_BYTES + pad, st, b);
-        }
+        KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_egnn_edge_h<4>), EDGE_H_LDS_BYTES + pad));
+        hipLaunchKernelGGL(k_egnn_edge_h<4>, dim3(8 * cdiv(tile_cap, 8)), dim3(256), EDGE_H_LDS_BYTES + pad, st, b);
         KPD_LAUNCH_CHECK();
         return KPD_OK;
     }
-    if (a.tile_rows == R32) {
-        KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_egnn_edge32), EDGE32_LDS_BYTES + pad));
-        hipLaunchKernelGGL(k_egnn_edge32, dim3(8 * cdiv(tile_cap, 8)), dim3(256), EDGE32_LDS_BYTES + pad, st, b);
-        KPD_LAUNCH_CHECK();
-        return KPD_OK;
-    }
-    if (nw == 4) {
-        KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_egnn_edge<4>), EDGE_LDS_BYTES + pad));
-        hipLaunchKernelGGL(k_egnn_edge<4>, dim3(8 * cdiv(tile_cap, 8)), dim3(256), EDGE_LDS_BYTES + pad, st, b);
-    } else {
-        KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_egnn_edge<8>), EDGE_LDS_BYTES + pad));
-        hipLaunchKernelGGL(k_egnn_edge<8>, dim3(8 * cdiv(tile_cap, 8)), dim3(512), EDGE_LDS_BYTES + pad, st, b);
-    }
+    KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_egnn_edge<4>), EDGE_LDS_BYTES + pad));
+    hipLaunchKernelGGL(k_egnn_edge<4>, dim3(8 * cdiv(tile_cap, 8)), dim3(256), EDGE_LDS_BYTES + pad, st, b);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
 }
@@ -1933,30 +1385,19 @@ kpd_status launch_node_layer(const NodeLayerPair &p, hipStream_t st) {
     if (poison_level() >= 1) KPD_TRY(poison_lds(st));      // debug only (engine.h)
     // KPD_NODE_LDS_PAD (diagnostics): extra dynamic LDS to lower the number of co-resident workgroups
     static const int pad = getenv("KPD_NODE_LDS_PAD") ? atoi(getenv("KPD_NODE_LDS_PAD")) : 0;
-    static const int dbg = getenv("KPD_NODE_ABLATE") ? atoi(getenv("KPD_NODE_ABLATE")) : 0;
-    NodeLayerPair q = p;
-    q.dbg = dbg;
-    // update-only launches (the default split node mode) take the 8-wave kernel; KPD_NODE_NW=4 keeps the 4-wave one
-    static const int nw = getenv("KPD_NODE_NW") ? atoi(getenv("KPD_NODE_NW")) : 8;
-    const bool update_only = (p.nt[0].do_update || p.nt[0].u.n == 0) && (p.nt[1].do_update || p.nt[1].u.n == 0) &&
-                             !p.nt[0].do_proj && !p.nt[1].do_proj;
-    if (p.gemm_mode == 1 && update_only && !p.stamps && !dbg) {      // (diagnostic / fused launches keep the exact kernels)
+    for (int nt = 0; nt < 2; ++nt)
+        KPD_REQUIRE(p.nt[nt].u.n == 0 || (p.nt[nt].do_update && !p.nt[nt].do_proj), KPD_ERR_INVALID, "node launch: update-only node types expected");
+    if (p.gemm_mode == 1 && !p.stamps) {                   // (phase-stamped diagnostic launches keep the exact kernel)
         for (int nt = 0; nt < 2; ++nt)
             if (p.nt[nt].u.n > 0)
                 KPD_REQUIRE(p.nt[nt].u.wh_a && p.nt[nt].u.wh_b && p.nt[nt].u.wh_2, KPD_ERR_STATE, "node weights of type %d have no f16 planes", nt);
         KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_node_update8_h), NODE_H_LDS_BYTES));
-        hipLaunchKernelGGL(k_node_update8_h, dim3(tiles), dim3(512), NODE_H_LDS_BYTES, st, q);
+        hipLaunchKernelGGL(k_node_update8_h, dim3(tiles), dim3(512), NODE_H_LDS_BYTES, st, p);
         KPD_LAUNCH_CHECK();
         return KPD_OK;
     }
-    if (nw == 8 && update_only && !p.stamps && !dbg) {
-        KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_node_update8), NODE_LAYER_LDS_BYTES + pad));
-        hipLaunchKernelGGL(k_node_update8, dim3(tiles), dim3(512), NODE_LAYER_LDS_BYTES + pad, st, q);
-        KPD_LAUNCH_CHECK();
-        return KPD_OK;
-    }
-    KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_node_layer), NODE_LAYER_LDS_BYTES + pad));
-    hipLaunchKernelGGL(k_node_layer, dim3(tiles), dim3(256), NODE_LAYER_LDS_BYTES + pad, st, q);
+    KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_node_update8), NODE_LAYER_LDS_BYTES + pad));
+    hipLaunchKernelGGL(k_node_update8, dim3(tiles), dim3(512), NODE_LAYER_LDS_BYTES + pad, st, p);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
 }

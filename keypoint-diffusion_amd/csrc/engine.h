@@ -88,7 +88,6 @@ constexpr const char *F16_RANGE_ERROR =
     "or is not finite, so its f16 planes would hold inf / NaN; use the exact mode (gemm=f32, the default)";
 kpd_status pack_gvp_chain_h(const float *chain, float *chain_h, int head, int n_ht, hipStream_t st);
 kpd_status pack_gvp_proj_h(const float *wproj, float *wproj_h, hipStream_t st);
-kpd_status pack_egnn_chain_h(const float *chain, float *chain_h, hipStream_t st);
 kpd_status patch_bias_row(float *wp, float *wx, const float *bias, float f, int k, hipStream_t st);
 // 16x16x4 MFMA A-operand fragments of a [n][k] matrix with element (n, k) at src[n * sn + k * sk]:
 // dst[(mt * 64 + lane) * 4 + r] = element(16 mt + (lane & 15), k_base + 4 (lane >> 4) + r), zero outside

@@ -306,13 +306,6 @@ kpd_status pack_gvp_proj_h(const float *wproj, float *wproj_h, hipStream_t st) {
     return KPD_OK;
 }
 
-// the chained EGNN edge kernel's W2 chunks ([coord 16 | edge 16] x slabs, egnn_chain.hip) -> 32 units of kind 0
-kpd_status pack_egnn_chain_h(const float *chain, float *chain_h, hipStream_t st) {
-    for (int u = 0; u < 32; ++u) hipLaunchKernelGGL(k_pack_gvp_unit_h, dim3(16), dim3(256), 0, st, chain, chain_h, 0, u, 2 * (u >> 1));
-    KPD_LAUNCH_CHECK();
-    return KPD_OK;
-}
-
 kpd_status pack_gvp_chain_h(const float *chain, float *chain_h, int head, int n_ht, hipStream_t st) {
     auto unit = [&](int kind, int u, int src) { hipLaunchKernelGGL(k_pack_gvp_unit_h, dim3(16), dim3(256), 0, st, chain, chain_h, kind, u, src); };
     if (head) {

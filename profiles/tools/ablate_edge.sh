@@ -5,4 +5,3 @@ for m in 0 6 1 2 4 5 3 7; do
   echo -n "ablate=$m: "; KPD_EDGE_ABLATE=$m timeout -k 10 300 python bench.py --steps 30 --warmup 5 --repeats 1 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('ms/step', round(d['ms_per_step'],3), ' edge kernel avg ms', round(d['roofline']['avg_launch_ms'],4))"
 done
 echo -n "one workgroup per CU (KPD_EDGE_LDS_PAD=24000), ablate=0: "; KPD_EDGE_LDS_PAD=24000 python bench.py --steps 30 --warmup 5 --repeats 1 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('ms/step', round(d['ms_per_step'],3), ' edge kernel avg ms', round(d['roofline']['avg_launch_ms'],4))"
-echo -n "32-row tiles, four workgroups per CU (KPD_EDGE_ROWS=32): "; KPD_EDGE_ROWS=32 python bench.py --steps 30 --warmup 5 --repeats 1 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('ms/step', round(d['ms_per_step'],3), ' edge kernel avg ms', round(d['roofline']['avg_launch_ms'],4))"

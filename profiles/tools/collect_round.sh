@@ -7,11 +7,11 @@
 # 4) traffic.json: HBM bytes per launch of the dominant kernel of every workload (2 x FETCH_SIZE + WRITE_SIZE)
 # Copy the summaries into profiles/ afterwards (gpurun_out/ is scratch).
 set -e
-tag=${1:-r03}
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+tag=${1:-r04}
+root=$(cd "$(dirname "$0")/../.." && pwd); cd /tmp && export TMPDIR=/tmp && cd "$root"
 out=gpurun_out/$tag
 rm -rf $out && mkdir -p $out
-python bench.py > $out/bench.json 2> $out/bench.err
+python bench.py > $out/bench.json 2> $out/bench.err && cp gpurun_out/bench_full_record.json $out/bench_full.json
 short="--steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-secondary"
 for wl in egnn_all_atom egnn_all_atom_f16x2 gvp_40kp gvp_all_atom_ragged gvp_40kp_f16x2 gvp_all_atom_ragged_f16x2; do
   case $wl in

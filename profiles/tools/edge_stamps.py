@@ -10,11 +10,7 @@ model = bench.build_model(dev)
 g = bench.build_batch(model, 64, 300, 25, 1234, dev)
 eng = model.dynamics.engine()
 t = torch.full((64,), 0.9, device=dev)
-if os.environ.get('KPD_EDGE_CHAIN', '0') == '0':
-    names = ['geometry', 'A-build e', 'GEMM e', 'T-store e', 'att dot', 'reduce h', 'A-build c', 'GEMM c', 'T-store c', 'coord dot', 'reduce x']
-else:   # k_egnn_chain
-    names = ['prologue (geometry, vectors -> LDS)', 'e: gathers + f1 + acc init', 'e: GEMM chunks', 'e: SiLU + attention', '-',
-             'c: gathers + f1 + acc init', 'c: GEMM chunks', 'c: SiLU + coord head', '-', 'messages -> LDS', 'segmented sums']
+names = ['geometry', 'A-build e', 'GEMM e', 'T-store e', 'att dot', 'reduce h', 'A-build c', 'GEMM c', 'T-store c', 'coord dot', 'reduce x']
 with torch.no_grad():
     for _ in range(2):
         model.dynamics(g, t, None)

@@ -2,7 +2,7 @@
 # Kernel-trace stats of the two GVP bench workloads (run from the repo root on the GPU box).
 set -e
 tag=${1:-r01_gvp}
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+root=$(cd "$(dirname "$0")/../.." && pwd); cd /tmp && export TMPDIR=/tmp && cd "$root"
 out=gpurun_out/$tag
 rm -rf $out && mkdir -p $out
 for wl in gvp_all_atom gvp_40kp; do

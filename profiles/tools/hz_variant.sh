@@ -4,7 +4,7 @@
 # The production library is restored before the call ends; the log lands in gpurun_out/r03/<script>.log
 set -e
 flags=$1; script=$2; reps=${3:-3}; envs=${4:-KPD_GEMM=f16x2}; tu=${5:-egnn_kernels.hip}
-root=/root/repo; csrc=$root/keypoint-diffusion_amd/csrc
+root=$(cd "$(dirname "$0")/../.." && pwd); csrc=$root/keypoint-diffusion_amd/csrc
 make -C $csrc -j8 libkpd_hip.so > /dev/null
 objs=$(sed -n 's/^SRCS = //p' $csrc/Makefile | sed 's/\.hip/.o/g')
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $flags -c $csrc/$tu -o /tmp/hz_B.o

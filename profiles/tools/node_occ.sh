@@ -1,10 +1,10 @@
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+root=$(cd "$(dirname "$0")/../.." && pwd); cd /tmp && export TMPDIR=/tmp && cd "$root"
 for pad in 0 20000 50000 100000; do
   rm -rf gpurun_out/occ; KPD_NODE_LDS_PAD=$pad timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/occ -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
   echo -n "pad=$pad: "; python - <<PY
 import csv,glob
 f=glob.glob("gpurun_out/occ/*/*kernel_stats.csv")[0]
 for r in csv.DictReader(open(f)):
-    if 'node_layer' in r['Name']: print(r['Calls'], 'avg us', round(float(r['AverageNs'])/1e3,1), 'min', r['MinNs'], 'max', r['MaxNs'])
+    if 'node_update8' in r['Name']: print(r['Calls'], 'avg us', round(float(r['AverageNs'])/1e3,1), 'min', r['MinNs'], 'max', r['MaxNs'])
 PY
 done

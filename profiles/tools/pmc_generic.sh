@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: pmc_generic.sh <tag> <counters...>   -- one PMC pass of the bench workload (contract line only, short)
 # extra bench flags via $KPD_PMC_BENCH_ARGS; kernels reported: $KPD_PMC_KERNELS (regex, default egnn_edge|node_|proj)
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+root=$(cd "$(dirname "$0")/../.." && pwd); cd /tmp && export TMPDIR=/tmp && cd "$root"
 tag=$1; shift
 out=gpurun_out/$tag
 mkdir -p $out

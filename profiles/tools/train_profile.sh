@@ -3,7 +3,7 @@
 #   bash profiles/tools/train_profile.sh <tag>     -> gpurun_out/<tag>_train/{<workload>_bench.json, <workload>_kernel_stats.csv}
 set -e
 tag=${1:-r03}
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+root=$(cd "$(dirname "$0")/../.." && pwd); cd /tmp && export TMPDIR=/tmp && cd "$root"
 out=gpurun_out/${tag}_train
 mkdir -p $out
 for w in egnn_train gvp_train egnn_40kp_train gvp_40kp_train; do

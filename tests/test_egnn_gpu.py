@@ -84,7 +84,7 @@ def _check(h, x, rh, rx, n_lig):
     util.assert_parity(x, rx, n_lig, TOL, 'eps_x', atol_rel=1e-5)
 
 
-def _run_pair(cuda, cfg, n_rec, n_lig, seed=3, rec_nf=10, layers=None, edge_chain=None):
+def _run_pair(cuda, cfg, n_rec, n_lig, seed=3, rec_nf=10, layers=None):
     g = util.fixed_encode(util.make_batch(n_rec, n_lig, n_rec_feat=rec_nf))
     model = LigRecDynamics(10, rec_nf, graph_cutoffs=util.CUTOFFS_ALL_ATOM, **cfg)
     synth.fill_state_dict_(model, seed)
@@ -102,17 +102,9 @@ def _run_pair(cuda, cfg, n_rec, n_lig, seed=3, rec_nf=10, layers=None, edge_chai
     with torch.no_grad():
         if layers is not None:
             model.engine().debug(f'layers={layers}')
-        if edge_chain is not None:
-            model.engine().debug(f'edge_chain={edge_chain}')
         eps_h, eps_x = model(gd, t.to(cuda), G.get_batch_idxs(gd))
     torch.cuda.synchronize()
     return (eps_h.cpu(), eps_x.cpu()), (ref_h, ref_x), model
-
-
-def test_egnn_chained_edge_kernel(cuda):
-    """The opt-in register-chained edge kernel (egnn_chain.hip, KPD_EDGE_CHAIN=1) honours the same contract."""
-    (h, x), (rh, rx), _ = _run_pair(cuda, util.EGNN_C2, [300, 150, 40], [25, 9, 3], edge_chain=1)
-    _check(h, x, rh, rx, [25, 9, 3])
 
 
 @pytest.mark.parametrize('ll_k,kl_k,message_norm', [(3, 5, 0), (0, 0, 0), (5, 0, 2.0)])
@@ -177,8 +169,7 @@ def test_degenerate_shapes(cuda, n_rec, n_lig):
     _check(h, x, rh, rx, n_lig)
 
 
-@pytest.mark.parametrize('edge_chain', [0, 1])
-def test_final_layer_pruning_is_bit_identical(cuda, edge_chain):
+def test_final_layer_pruning_is_bit_identical(cuda):
     """LigRecEGNN.forward returns (h_lig, x_lig) only (models/dynamics.py:288-294): the final layer's lk / kk messages and
     keypoint update feed nothing.  The engine skips them; eps must be bit-for-bit what the full final layer gives."""
     g = util.fixed_encode(util.make_batch([300, 150, 40], [25, 9, 3]))
@@ -188,7 +179,6 @@ def test_final_layer_pruning_is_bit_identical(cuda, edge_chain):
     gd = g.to(cuda)
     t = torch.tensor([0.3, 0.6, 0.9], device=cuda)
     eng = model.engine()
-    eng.debug(f'edge_chain={edge_chain}')
     with torch.no_grad():
         eng.debug('prune=0')
         h0, x0 = model(gd, t, None)
