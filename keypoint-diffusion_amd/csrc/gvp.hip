@@ -500,7 +500,7 @@ extern "C" kpd_status kpd_gvp_profile_read(kpd_gvp *m, double *total_ms, int32_t
 extern "C" kpd_status kpd_gvp_last_counts(kpd_gvp *m, int32_t out[8], void *stream) {
     KPD_REQUIRE(m && out, KPD_ERR_INVALID, "null argument");
     for (int i = 0; i < 7; ++i) out[i] = 0;
-    out[7] = m->gemm_mode;                             // GEMM mode the next forward runs in: 0 exact fp32, 1 f16x2
+    out[7] = (m->gemm_mode && !m->stamps) ? 1 : 0;    // GEMM mode the next forward's dominant kernel runs in: 0 exact fp32, 1 f16x2 (a phase-stamped diagnostic run keeps the exact chain)
     if (!m->meta4) return KPD_OK;                      // no forward yet: only the mode is meaningful
     hipStream_t st = static_cast<hipStream_t>(stream);
     int host[25];

@@ -142,7 +142,16 @@ extern "C" kpd_status kpd_ot_emd_uniform(int32_t n_problems, const int32_t *n, c
     KPD_REQUIRE(n_problems >= 0 && (n_problems == 0 || (n && m && offsets && cost && plan)), KPD_ERR_INVALID, "null argument");
     for (int p = 0; p < n_problems; ++p)
         KPD_REQUIRE(n[p] >= 1 && m[p] >= 1, KPD_ERR_INVALID, "optimal transport needs at least one point on either side (problem %d: %d x %d)", p, n[p], m[p]);
+    // non-finite costs would still give a plan that satisfies the marginals (comparisons with NaN / inf just fall one way): refuse them
+    for (int p = 0; p < n_problems; ++p) {
+        const double *c = cost + offsets[p];
+        const long long cnt = (long long)n[p] * m[p];
+        for (long long i = 0; i < cnt; ++i)
+            KPD_REQUIRE(std::isfinite(c[i]), KPD_ERR_INVALID, "optimal-transport problem %d (%d x %d): cost[%lld, %lld] is not finite", p, n[p], m[p],
+                        i / m[p], i % m[p]);
+    }
     std::vector<char> ok(std::max(n_problems, 1), 1);
+    // strided shares [first, first + step, ...): a share that could not get its thread is solved by the caller below
     auto work = [&](int first, int step) {
         for (int p = first; p < n_problems; p += step) {
             std::vector<double> a(n[p], 1.0 / n[p]), b(m[p], 1.0 / m[p]);
@@ -153,7 +162,13 @@ extern "C" kpd_status kpd_ot_emd_uniform(int32_t n_problems, const int32_t *n, c
     if (T <= 1) work(0, 1);
     else {
         std::vector<std::thread> th;
-        for (int t = 0; t < T; ++t) th.emplace_back(work, t, T);
+        th.reserve(T);
+        int started = 0;
+        try {                                   // std::thread can throw (resource limits): nothing may cross the extern "C" boundary
+            for (; started < T; ++started) th.emplace_back(work, started, T);
+        } catch (...) {
+        }
+        for (int t = started; t < T; ++t) work(t, T);
         for (auto &x : th) x.join();
     }
     for (int p = 0; p < n_problems; ++p)

@@ -144,14 +144,16 @@ class LigRecDynamics(nn.Module):
     # ---- HIP engine management ---------------------------------------------------------
     def _weights_key(self):
         """(storage pointer, version counter) of every parameter: changes when weights are replaced or modified in place.
-        Walking the module tree costs ~0.7 ms of host time (348 tensors), more than a B = 1 reverse step takes on the GPU, so
-        the list of Parameter objects is cached; `.to()` / `load_state_dict` and every 64th call re-walk the tree (a Parameter
-        object swapped for another one deep inside the module is the one change the cached list cannot see at once)."""
-        n = self.__dict__.get('_key_calls', 0)
+        Walking the module tree costs ~0.7 ms of host time (hundreds of tensors), more than a B = 1 reverse step takes on the GPU,
+        so the list of Parameter objects is cached.  It is rebuilt after `.to()` / `load_state_dict` and whenever ANY module of the
+        process registered a parameter since it was built (`hip.param_generation`: `module.weight = nn.Parameter(...)`, parametrize
+        and pruning all go through `register_parameter`), so a Parameter object swapped in deep inside the module is seen by the
+        next forward."""
+        gen = hip.param_generation()
         ps = self.__dict__.get('_param_list')
-        if ps is None or n % 64 == 0:
+        if ps is None or self.__dict__.get('_param_gen') != gen:
             ps = self.__dict__['_param_list'] = list(self.parameters())
-        self.__dict__['_key_calls'] = n + 1
+            self.__dict__['_param_gen'] = gen
         return tuple([(p.data_ptr(), p._version) for p in ps])
 
     def _apply(self, fn, *a, **kw):
@@ -177,6 +179,9 @@ class LigRecDynamics(nn.Module):
             if self.gemm_mode not in ('f32', 'f16x2'):
                 raise ValueError(f"gemm_mode must be None, 'f32' or 'f16x2', got {self.gemm_mode!r}")
             self._engine.set_gemm_mode(self.gemm_mode)            # (one library call per engine and choice, not per forward)
+            if self._engine.gemm_mode() != self.gemm_mode:        # an explicit choice is never dropped silently
+                raise hip.KpdError(f'gemm_mode={self.gemm_mode!r} was requested but the engine runs {self._engine.gemm_mode()!r} '
+                                   f'(the f16x2 mode of the GVP denoiser needs n_hidden_scalars = 256)')
             self._engine._mode_applied = self.gemm_mode
         return self._engine
 

@@ -358,6 +358,22 @@ class EgnnEngine:
         self.debug(f'gemm={mode}')
 
 
+_PARAM_GEN = [0]
+
+
+def _on_register_parameter(module, name, param):
+    _PARAM_GEN[0] += 1
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_on_register_parameter)
+
+
+def param_generation() -> int:
+    """Counts `register_parameter` calls of every module in the process (a global torch hook): the cached parameter lists of the
+    denoiser modules are rebuilt when it moves, so a swapped Parameter object is never read through a stale list."""
+    return _PARAM_GEN[0]
+
+
 class EgnnTrainer:
     """Owns one kpd_egnn_trainer handle: forward with saved layer states + backward of LigRecDynamics.forward.
     Parameters are bound by reference name to their live storage (read in place every step); gradients are written

@@ -112,16 +112,23 @@ class StepGraph:
         self._model = model
         self._engine = model.dynamics.engine()
         self._pin = (self._engine._reserved, model.dynamics._weights_key())
+        ps = list(model.dynamics.parameters())
+        self._sentinels = [ps[i] for i in sorted({0, len(ps) // 2, len(ps) - 1})] if ps else []
+        self._sentinel_key = [(p.data_ptr(), p._version) for p in self._sentinels]
 
     def _check_pin(self):
-        """Every replay: the engine object and its arena are the captured ones (two attribute reads).  Every 16th replay, starting
-        with the first: the weights are the captured ones (a walk over all parameters -- host time the graph exists to avoid)."""
+        """Every replay: the engine object and its arena are the captured ones (two attribute reads) and three sentinel parameters
+        (first, middle, last) still have the captured storage and version counter -- whatever rewrites the weights as a whole
+        (an optimizer step, load_state_dict, an EMA swap, .to()) moves every one of them, so such a change raises on the NEXT
+        replay, not up to 15 replays later.  Every 16th replay, starting with the first: all weights are the captured ones (a walk
+        over all parameters -- host time the graph exists to avoid), which also catches a change to a single tensor."""
         dyn = self._model.dynamics
         self._replays = getattr(self, '_replays', -1) + 1
         if dyn._engine is not self._engine or self._engine._reserved != self._pin[0]:
             raise hip.KpdError('stale step graph: the denoiser engine was rebuilt or its workspace re-reserved (a larger batch ran) '
                                'after capture; the captured kernels point into freed memory -- capture the step again')
-        if self._replays % 16 == 0 and dyn._weights_key() != self._pin[1]:
+        if ([(p.data_ptr(), p._version) for p in self._sentinels] != self._sentinel_key or
+                (self._replays % 16 == 0 and dyn._weights_key() != self._pin[1])):
             raise hip.KpdError('stale step graph: the model weights changed after capture (the graph replays the weights packed at '
                                'capture time) -- capture the step again')
 
@@ -193,13 +200,17 @@ class KeypointDiffusion(nn.Module):
         # :115; the exact transport plans are solved on host threads while the denoiser's forward is launched below
         losses['rec_encoder'] = None
         pending = self.rec_encoder_loss_fn.begin(g, interface_points=interface_points)
-        g = self.remove_com(g, batch_idxs['lig'], batch_idxs['kp'], com='ligand')
-        t = torch.randint(0, self.n_timesteps, size=(batch_size,), device=device).float() / self.n_timesteps
-        eps = {'h': torch.randn(g.nodes['lig'].data['h_0'].shape, device=device),
-               'x': torch.randn(g.nodes['lig'].data['x_0'].shape, device=device)}
-        gamma_t = self.gamma(t).to(device=device)
-        g = self.noised_representation(g, batch_idxs['lig'], batch_idxs['kp'], eps, gamma_t)
-        eps_h_pred, eps_x_pred = self.dynamics(g, t, batch_idxs)
+        try:
+            g = self.remove_com(g, batch_idxs['lig'], batch_idxs['kp'], com='ligand')
+            t = torch.randint(0, self.n_timesteps, size=(batch_size,), device=device).float() / self.n_timesteps
+            eps = {'h': torch.randn(g.nodes['lig'].data['h_0'].shape, device=device),
+                   'x': torch.randn(g.nodes['lig'].data['x_0'].shape, device=device)}
+            gamma_t = self.gamma(t).to(device=device)
+            g = self.noised_representation(g, batch_idxs['lig'], batch_idxs['kp'], eps, gamma_t)
+            eps_h_pred, eps_x_pred = self.dynamics(g, t, batch_idxs)
+        except BaseException:
+            pending.abandon()                # the denoiser raised: do not leave the solver thread running behind the exception
+            raise
         losses['rec_encoder'] = pending.finish()
         x_loss = (eps['x'] - eps_x_pred).square().sum()
         n_x_loss_terms = eps['x'].numel()

@@ -58,6 +58,11 @@ class PendingLoss:
         except BaseException as e:          # re-raised by finish() on the caller's thread
             self._err = e
 
+    def abandon(self):
+        """Join the solver thread without using its result (the caller is unwinding an exception of its own)."""
+        if self._thread is not None:
+            self._thread.join()
+
     def finish(self) -> torch.Tensor:
         if self.value is not None:
             return self.value

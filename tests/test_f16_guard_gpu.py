@@ -69,3 +69,37 @@ def test_explicit_gemm_mode_survives_engine_rebuilds(cuda, monkeypatch):
         model.gemm_mode = 'f32'
         model(g, t, None)
         assert model.engine().gemm_mode() == 'f32'
+
+
+def test_explicit_f16x2_on_a_narrow_gvp_model_raises_instead_of_falling_back(cuda, monkeypatch):
+    """The f16x2 mode of the GVP denoiser exists for 256 hidden scalars only; the library stores f32 for a narrower model.  An
+    explicit `gemm_mode = 'f16x2'` must then raise, not run another mode silently."""
+    monkeypatch.delenv('KPD_GEMM', raising=False)
+    cfg = dict(GVP_ALL_ATOM, n_hidden_scalars=64)
+    model = synth.fill_state_dict_(LigRecDynamicsGVP(10, 10, graph_cutoffs=CUT, **cfg), 0).eval().to(cuda)
+    g = _batch(cuda, v=16)
+    t = torch.tensor([0.3, 0.8], device=cuda)
+    with torch.no_grad():
+        model(g, t, None)
+        model.gemm_mode = 'f16x2'
+        with pytest.raises(hip.KpdError, match='was requested but the engine runs'):
+            model(g, t, None)
+        model.gemm_mode = 'f32'
+        model(g, t, None)
+
+
+def test_a_swapped_parameter_object_rebuilds_the_engine_at_once(cuda, monkeypatch):
+    """`module.weight = nn.Parameter(...)` deep inside the denoiser replaces the Parameter OBJECT: the cached parameter list of the
+    engine key must not hide it (it used to, for up to 63 forwards)."""
+    monkeypatch.delenv('KPD_GEMM', raising=False)
+    model = synth.fill_state_dict_(LigRecDynamics(10, 10, graph_cutoffs=CUT, **dict(util.EGNN_C2, n_layers=2)), 0).eval().to(cuda)
+    g = _batch(cuda)
+    t = torch.tensor([0.3, 0.8], device=cuda)
+    with torch.no_grad():
+        h0, _ = model(g, t, None)
+        first = model.engine()
+        lin = model.lig_decoder[2]
+        lin.bias = torch.nn.Parameter(lin.bias.detach() + 0.5)
+        h1, _ = model(g, t, None)
+    assert model.engine() is not first
+    assert torch.allclose(h1, h0 + 0.5, atol=1e-5)

@@ -103,3 +103,18 @@ def test_ragged_keypoint_counts_and_begin_finish_halves():
     assert torch.allclose(kp.grad, ref, atol=1e-5)
     pend = fn.begin(b)
     assert abs(float(pend.finish().detach()) - float(loss.detach())) < 1e-7 and pend.finish() is pend.finish()
+
+
+def test_non_finite_costs_are_refused():
+    """kpd_ot_emd_uniform used to return a marginal-feasible plan for a cost matrix holding NaN / inf: now an error that
+    names the problem and the entry."""
+    import numpy as np
+    from keypoint_diffusion_amd import hip
+    good = np.random.default_rng(0).random((4, 6))
+    for bad_value in (np.nan, np.inf, -np.inf):
+        bad = good.copy()
+        bad[2, 3] = bad_value
+        with pytest.raises(hip.KpdError, match=r'problem 1 \(4 x 6\): cost\[2, 3\] is not finite'):
+            hip.ot_emd_uniform([good, bad], n_threads=2)
+    plans = hip.ot_emd_uniform([good, good.T.copy()], n_threads=2)
+    assert np.allclose(plans[0].sum(1), 1 / 4) and np.allclose(plans[1].sum(1), 1 / 6)
