@@ -120,9 +120,15 @@ kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *batch, const float *t_
  * left them), "stamps".  Switches (n_floats = 0, out_dev ignored but non-null): "layers=N" (run only the first N layers),
  * "prune=0|1", "stamps=1", and
  *   "gemm=f32"   exact fp32 MFMA in every GEMM -- the default and the contract path;
- *   "gemm=f16x2" opt-in: every fp32 product of the edge / projection / node-update GEMMs as three f16 MFMA products of hi / lo
- *                operand planes with fp32 accumulation (same accuracy against the reference, ~2x the step rate; DESIGN.md fact
- *                10).  The environment variable KPD_GEMM=f16x2 selects it at kpd_egnn_create time. */
+ *   "gemm=f16x2" EXPERIMENTAL, opt-in, never the default and never part of the benchmark's `value`: every fp32 product of the
+ *                edge / projection / node-update GEMMs as three f16 MFMA products of hi / lo operand planes with fp32
+ *                accumulation (the parity suite holds at the same 1e-4 in this mode, ~2x the step rate).  Status (round 4,
+ *                DESIGN.md "f16x2 mode"): a build VARIANT of its edge kernel (batched distance read) showed a first-launch
+ *                deviation of one LDS row in rounds 2 - 3; the shipped per-row form has never shown it in any detector, and a
+ *                standalone kernel with the suspected ingredients (profiles/tools/f16_lds_row_probe.hip: 20 fresh processes,
+ *                80 launches clean) does not reproduce it, so it is neither explained nor shown to be a hardware erratum.
+ *                Until it is, the mode is frozen as experimental: use it for throughput experiments, not for results you keep.
+ *                The environment variable KPD_GEMM=f16x2 selects it at kpd_egnn_create time. */
 kpd_status kpd_egnn_debug_state(kpd_egnn *m, const char *what, float *out_dev, int64_t n_floats,
                                 void *stream);
 /* HIP-event timing of the dominant kernel (the fused edge kernel), recorded on the caller's

@@ -1125,7 +1125,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 // The three GEMMs run on v_mfma_f32_32x32x16_f16 over hi / lo planes (gemm_rows32_h8); the tile is kept as two f16 planes of
 // 2^6 x value while it is a GEMM operand and as fp32 (same LDS region) from the output of GEMM 2 on: bias, residual, LayerNorm and
 // the h' written back are fp32 exactly as in the exact kernel.
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_node_update8_h(NodeLayerPair p) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 6))) void k_node_update8_h(NodeLayerPair p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *A = smem;                                                   // fp32 view [TN][SA] (phases after GEMM 2)
     _Float16 *Ah = reinterpret_cast<_Float16 *>(smem);                 // plane view [2][TN][SAH]
