@@ -630,6 +630,7 @@ extern "C" void kpd_egnn_trainer_destroy(kpd_egnn_trainer *T) {
     if (!T) return;
     T->ws.release();
     T->wide.release();
+    T->release_scratch();
     if (T->store_base) (void)hipFree(T->store_base);
     delete T;
 }
@@ -988,8 +989,7 @@ kpd_status layer_bwd(kpd_egnn_trainer *T, int l, int cur, int nxt, float *dhn[2]
         hipLaunchKernelGGL(k_colsum_reduce, dim3(cdiv(H, 64)), dim3(1024), 0, T->st, T->colpart, cdiv(E, HEAD_ROWS), H, p.head.g, 1, p.b2.g);
         KPD_LAUNCH_CHECK();
         if (p.head_b.g) {
-            hipLaunchKernelGGL(k_sum_scalar, dim3(1), dim3(1024), 0, T->st, T->dsv, E, p.head_b.g);
-            KPD_LAUNCH_CHECK();
+            KPD_TRY(sum_scalar(T, T->dsv, E, p.head_b.g));
         }
         KPD_TRY(edge_branch_bwd(T, p, l, et, nxt, true));
         // coordinate branch

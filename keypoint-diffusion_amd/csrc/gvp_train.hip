@@ -409,6 +409,7 @@ extern "C" void kpd_gvp_trainer_destroy(kpd_gvp_trainer *T) {
     if (!T) return;
     T->ws.release();
     T->wide.release();
+    T->release_scratch();
     if (T->store_base) (void)hipFree(T->store_base);
     delete T;
 }

@@ -465,8 +465,7 @@ kpd_status conv_bwd(kpd_recegnn_trainer *T, int i, float *gh_out, const float *g
     KPD_LAUNCH_CHECK();
     KPD_TRY(gemv_t_acc(T, E, H, T->m, H, T->ds, p.watt.g, 1));
     if (p.batt.g) {
-        hipLaunchKernelGGL(k_sum_scalar, dim3(1), dim3(1024), 0, st, T->ds, E, p.batt.g);
-        KPD_LAUNCH_CHECK();
+        KPD_TRY(sum_scalar(T, T->ds, E, p.batt.g));
     }
     const long long tot = (long long)E * H;
     hipLaunchKernelGGL(k_silu_bwd, grid1(tot), dim3(256), 0, st, T->dE, T->pre2, tot, H, H);              // d pre2
@@ -525,6 +524,7 @@ extern "C" kpd_status kpd_recegnn_trainer_create(const kpd_recegnn_config *cfg, 
 extern "C" void kpd_recegnn_trainer_destroy(kpd_recegnn_trainer *T) {
     if (!T) return;
     T->ws.release();
+    T->release_scratch();
     delete T;
 }
 

@@ -423,6 +423,7 @@ extern "C" kpd_status kpd_recenc_trainer_create(const kpd_recenc_config *cfg, kp
 extern "C" void kpd_recenc_trainer_destroy(kpd_recenc_trainer *T) {
     if (!T) return;
     T->ws.release();
+    T->release_scratch();
     delete T;
 }
 

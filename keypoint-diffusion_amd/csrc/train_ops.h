@@ -67,20 +67,34 @@ __global__ void k_silu_bwd(float *__restrict__ dY, const float *__restrict__ pre
     dY[(size_t)r * ld + c] *= silu_grad(pre[(size_t)r * ld + c]);
 }
 
-// out[0] += sum of v[0..n): one workgroup, double accumulation, fixed order (a lone scalar gradient such as the attention
-// bias is a heavily cancelling sum over all edges; float atomics in arbitrary order cost it two to three digits)
-__global__ void k_sum_scalar(const float *__restrict__ v, int n, float *__restrict__ out) {
-    __shared__ double part[16];
+// out[0] += sum of v[0..n): double accumulation in a fixed order (a lone scalar gradient such as the attention bias is a heavily
+// cancelling sum over all edges; float atomics in arbitrary order cost it two to three digits).  gridDim.x workgroups sum contiguous
+// chunks; the one that arrives last (an integer ticket, the only atomic) adds the chunk sums in chunk order and resets the ticket, so
+// the result depends on the chunking alone.  (One workgroup over all edges was 33 us per call, latency-bound on one CU.)
+__global__ __launch_bounds__(1024) void k_sum_scalar(const float *__restrict__ v, int n, double *__restrict__ part, int *__restrict__ ticket,
+                                                     float *__restrict__ out) {
+    __shared__ double ws[16];
+    __shared__ int s_last;
+    const int chunk = (n + (int)gridDim.x - 1) / (int)gridDim.x, i0 = (int)blockIdx.x * chunk, i1 = min(n, i0 + chunk);
     double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) s += (double)v[i];
+    for (int i = i0 + (int)threadIdx.x; i < i1; i += (int)blockDim.x) s += (double)v[i];
 #pragma unroll
     for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
         double t = 0.0;
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += part[w];
-        out[0] += (float)t;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += ws[w];
+        __hip_atomic_store(&part[blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        s_last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+        if (s_last) {
+            __threadfence();
+            double tot = 0.0;
+            for (int b = 0; b < (int)gridDim.x; ++b) tot += __hip_atomic_load(&part[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out[0] += (float)tot;
+            *ticket = 0;
+        }
     }
 }
 
@@ -96,8 +110,8 @@ __global__ void k_sub_inplace(float *__restrict__ a, const float *__restrict__ b
 constexpr int COLSUM_ROWS = 256, COLSUM_THREADS = 320;       // 320 threads: the 257 columns of a layer in one pass
 constexpr int COLSUM_LD = 512;                               // columns per partial row (K <= 512)
 constexpr int HEAD_ROWS = 64;                                // rows per workgroup of the head-backward kernels that emit partials too
-__global__ void k_colsum(const float *__restrict__ A, int lda, const float *__restrict__ x, int M, int K, float *__restrict__ part) {
-    const int r0 = blockIdx.x * COLSUM_ROWS, r1 = min(M, r0 + COLSUM_ROWS);
+__global__ void k_colsum(const float *__restrict__ A, int lda, const float *__restrict__ x, int M, int K, int rows_per_block, float *__restrict__ part) {
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
     float *p = part + (size_t)blockIdx.x * 2 * COLSUM_LD;
     for (int c = threadIdx.x; c < K; c += blockDim.x) {
         float s0 = 0.0f, s1 = 0.0f, p0 = 0.0f, p1 = 0.0f;       // s: weighted by x (or plain), p: plain sums when both are wanted
@@ -360,6 +374,14 @@ struct TrainCtx {
     int colpart_blocks = 0;
     std::map<std::string, Param> params;
     WideSet wide;
+    double *ss_part = nullptr;         // sum_scalar: chunk sums and the arrival ticket (allocated at first use, freed by release_scratch)
+    int *ss_ticket = nullptr;
+    void release_scratch() {
+        if (ss_part) (void)hipFree(ss_part);
+        if (ss_ticket) (void)hipFree(ss_ticket);
+        ss_part = nullptr;
+        ss_ticket = nullptr;
+    }
 };
 
 inline size_t colpart_floats(int max_rows) { return (size_t)cdiv(std::max(max_rows, 1), HEAD_ROWS) * 2 * COLSUM_LD; }
@@ -420,10 +442,13 @@ kpd_status gemv_t_acc(TrainCtx *T, int M, int K, const float *A, int lda, const 
 // y[K] (stride incy) += A^T x and y2[K] += column sums of A, in one pass over A
 kpd_status gemv_t_colsum_acc(TrainCtx *T, int M, int K, const float *A, int lda, const float *x, float *y, int incy, float *y2) {
     if (M == 0 || (!y && !y2)) return KPD_OK;
-    const int blocks = cdiv(M, COLSUM_ROWS);
+    // node-sized matrices (<= 20 800 rows at the contract shape) in 64-row blocks: 256-row blocks left two thirds of the CUs idle
+    // (82 workgroups, 37 us per call, ~2.4 ms of an EGNN training step); edge-sized ones keep 256 rows per block
+    const int rows_per_block = M <= 65536 ? HEAD_ROWS : COLSUM_ROWS;
+    const int blocks = cdiv(M, rows_per_block);
     KPD_REQUIRE(K <= COLSUM_LD && blocks <= T->colpart_blocks && T->colpart, KPD_ERR_CAPACITY,
                 "column-sum scratch too small (%d row blocks of %d, %d columns)", blocks, T->colpart_blocks, K);
-    hipLaunchKernelGGL(k_colsum, dim3(blocks), dim3(COLSUM_THREADS), 0, T->st, A, lda, x, M, K, T->colpart);
+    hipLaunchKernelGGL(k_colsum, dim3(blocks), dim3(COLSUM_THREADS), 0, T->st, A, lda, x, M, K, rows_per_block, T->colpart);
     KPD_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_colsum_reduce, dim3(cdiv(K, 64)), dim3(1024), 0, T->st, T->colpart, blocks, K, y, incy, y2);
     KPD_LAUNCH_CHECK();
@@ -459,7 +484,24 @@ kpd_status grad_gemm(TrainCtx *T, int M, int N, int K, const float *A, int lda, 
                      float *bias_grad = nullptr) {
     if (M == 0 || K == 0) return KPD_OK;
     if (!C || N == 0) return bias_grad ? colsum_acc(T, K, M, A, lda, bias_grad) : KPD_OK;
+    // (Round 4 tried leaving the split-K reductions pending and sending four at a time as one launch: 63.2 vs 62.4 ms per egnn_train
+    // step, same call -- a reduction is ~9 us of HBM time for its 34 MB of partials, not launch overhead; the simpler form stays.)
     return sgemm(true, false, M, N, K, 1.0f, A, lda, B, ldb, 1.0f, C, ldc, T->st, T->part, T->part_floats, bias_grad);
+}
+
+// out[0] += sum of v[0..n) (k_sum_scalar)
+kpd_status sum_scalar(TrainCtx *T, const float *v, int n, float *out) {
+    if (n <= 0 || !out) return KPD_OK;
+    constexpr int SS_MAX = 64;
+    if (!T->ss_part) {
+        KPD_HIP(hipMalloc(reinterpret_cast<void **>(&T->ss_part), SS_MAX * sizeof(double)));
+        KPD_HIP(hipMalloc(reinterpret_cast<void **>(&T->ss_ticket), sizeof(int)));
+        KPD_HIP(hipMemset(T->ss_ticket, 0, sizeof(int)));
+    }
+    const int blocks = std::max(1, std::min(SS_MAX, n / 2048));
+    hipLaunchKernelGGL(k_sum_scalar, dim3(blocks), dim3(1024), 0, T->st, v, n, T->ss_part, T->ss_ticket, out);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
 }
 
 // bind one reference tensor through a wide copy: `rows` / `cols` describe its axes (cols empty = a vector).  The entry (maps, wide
