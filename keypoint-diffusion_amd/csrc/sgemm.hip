@@ -454,6 +454,157 @@ __global__ __launch_bounds__(256) void k_sgemm_tn_skinny(SgemmArgs a) {
     if (a.cs_part && tid < a.M) a.cs_part[(size_t)blockIdx.x * a.M + tid] = ((red_cs[0][tid] + red_cs[1][tid]) + red_cs[2][tid]) + red_cs[3][tid];
 }
 
+// ---- weight gradient with the WHOLE 256 x 256 output in one workgroup ------------------------------------------------------------------
+// C[256 (+1), 256 (+1)] = A[K, 256 (+1)]^T B[K, 256 (+1)] for K = edge count (the dW2 = dpre2^T a1 products of the EGNN trainer, the
+// 256 x 256 scalar blocks of the GVP trainers).  The tiled form above cuts the output into 2 x 2 tiles of 128 x 128, so every operand
+// row is fetched twice (684 MB for the 166 k kk edges against 342 MB of operands): those products ran at HBM / MALL speed, not at
+// MFMA speed.  Here a workgroup of eight waves holds all 256 x 256 accumulators (wave (wr, wc): rows 64 wr .., columns 128 wc ..;
+// 2 x 4 blocks of 32 x 32 = 128 VGPRs per lane) and streams its K range through LDS ONCE: a slab is 16 rows of A and 16 rows of B,
+// each row one wave instruction of the direct global -> LDS load (1 KB contiguous), TN256_STAGES stages, 64 MFMAs per wave and slab.
+// One workgroup per CU (2 waves per SIMD).  Fringe row / column 256, the column sums of A and the split-K shares use
+// the formats of k_sgemm, so the same k_sgemm_reduce finishes the product.
+constexpr int TN256_STAGES = 4;        // 128 KB of LDS: three slabs (12 k MFMA cycles) of prefetch distance
+__global__ __launch_bounds__(512, 1) void k_sgemm_tn256(SgemmArgs a) {
+    constexpr int ROW = 256, SLAB = SG_BK * ROW, STAGE = 2 * SLAB, NSTAGE = TN256_STAGES;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float xbuf[2][2][SG_BK];
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 31, half = lane >> 5, wr = wave >> 1, wc = wave & 1;
+    const int kbeg = blockIdx.x * a.k_chunk, kend = min(a.K, kbeg + a.k_chunk);
+    const int nk = (kend - kbeg + SG_BK - 1) / SG_BK, nk_full = (kend - kbeg) / SG_BK;
+    v16f acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // rows wave, wave + 8 of either operand: one 1-KB instruction each (LDS destination = wave-uniform row base + 16 B per lane)
+    auto issue = [&](int kt) {
+        float *st = smem + (kt % NSTAGE) * STAGE;
+        const size_t k0 = (size_t)kbeg + (size_t)kt * SG_BK;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = wave + 8 * j;
+            __builtin_amdgcn_global_load_lds((glb_void *)(a.A + (k0 + row) * a.lda + 4 * lane), (lds_void *)(st + row * ROW), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void *)(a.B + (k0 + row) * a.ldb + 4 * lane), (lds_void *)(st + SLAB + row * ROW), 16, 0, 0);
+        }
+    };
+    auto wait_behind = [&](int slabs) {                 // at most `slabs` slabs of this wave's loads outstanding (4 instructions each)
+        if (slabs <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (slabs == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    };
+    auto compute = [&](const float *st) {
+        const float *as = st + 64 * wr + col, *bs = st + SLAB + 128 * wc + col;
+#pragma unroll
+        for (int ks = 0; ks < SG_BK / 2; ++ks) {
+            const int k = 2 * ks + half;
+            float av[2], bv[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[i] = as[k * ROW + 32 * i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[j] = bs[k * ROW + 32 * j];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    // riders (as in k_sgemm): threads 0 .. 255 own a row m of the output (column sums of A, column fringe), 256 .. 511 a column n (row
+    // fringe).  The slab's 16 values of A[:, xr] / B[:, xc] travel one slab ahead through a register of threads 0 .. 31 into xbuf.
+    // (Loading them with the slab as lane-0-only direct loads was tried: four more memory instructions per wave and slab, 9 % slower.)
+    const bool fringe = a.xr >= 0 || a.xc >= 0;
+    const bool sum_cols = a.colsum != nullptr && tid < ROW, ride_c = a.xc >= 0 && tid < ROW, ride_r = a.xr >= 0 && tid >= ROW;
+    float cs = 0.0f, fc = 0.0f, fr = 0.0f, fk = 0.0f, fcs = 0.0f, xv = 0.0f;
+    auto xfetch = [&](int kt) {
+        if (fringe && tid < 2 * SG_BK) {
+            const int k = kbeg + kt * SG_BK + (tid & (SG_BK - 1));
+            const bool isb = tid >= SG_BK;
+            const int kk = min(k, kend - 1);
+            const float *src = isb ? a.B + (size_t)kk * a.ldb + max(a.xc, 0) : a.A + (size_t)kk * a.lda + max(a.xr, 0);
+            xv = masked(*src, k < kend && (isb ? a.xc >= 0 : a.xr >= 0));
+        }
+    };
+    auto xstash = [&](int kt) {
+        if (fringe && tid < 2 * SG_BK) xbuf[kt & 1][tid >> 4][tid & (SG_BK - 1)] = xv;
+    };
+    auto riders = [&](int kt, const float *st) {
+        const float *xa = xbuf[kt & 1][0], *xb = xbuf[kt & 1][1];
+        if (sum_cols || ride_c) {
+#pragma unroll
+            for (int k = 0; k < SG_BK; ++k) {
+                const float v = st[k * ROW + tid];
+                cs += v;
+                if (ride_c) fc += v * xb[k];
+            }
+        }
+        if (ride_r) {
+#pragma unroll
+            for (int k = 0; k < SG_BK; ++k) fr += xa[k] * st[SLAB + k * ROW + tid - ROW];
+        }
+        if (fringe && tid == 0) {
+#pragma unroll
+            for (int k = 0; k < SG_BK; ++k) { fk += xa[k] * xb[k]; fcs += xa[k]; }
+        }
+    };
+
+    const int ahead = min(NSTAGE - 1, nk_full);
+    xfetch(0);
+    for (int kt = 0; kt < ahead; ++kt) issue(kt);
+    xstash(0);
+    wait_behind(ahead - 1);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll 1
+    for (int kt = 0; kt < nk_full; ++kt) {
+        if (kt + 1 < nk) xfetch(kt + 1);
+        if (kt + NSTAGE - 1 < nk_full) issue(kt + NSTAGE - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const float *st = smem + (kt % NSTAGE) * STAGE;
+        compute(st);
+        riders(kt, st);
+        if (kt + 1 < nk) xstash(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        wait_behind(min(kt + NSTAGE - 1, nk_full - 1) - (kt + 1));      // issued so far: slabs .. min(kt + NSTAGE - 1, nk_full - 1); needed next: kt + 1
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    if (nk > nk_full) {          // K tail of this range: rows past kend read a clamped address and are replaced by zero
+        float *st = smem;        // (every stage is free: the loop ended on a barrier with nothing in flight)
+        const int k0 = kbeg + nk_full * SG_BK;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int u = tid + 512 * j, op = u >> 10, row = (u & 1023) >> 6, c4 = u & 63;
+            const int k = min(k0 + row, kend - 1);
+            v4f v = *reinterpret_cast<const v4f *>((op ? a.B + (size_t)k * a.ldb : a.A + (size_t)k * a.lda) + 4 * c4);
+            const bool in = k0 + row < kend;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = masked(v[e], in);
+            *reinterpret_cast<v4f *>(st + op * SLAB + row * ROW + 4 * c4) = v;
+        }
+        __syncthreads();
+        compute(st);
+        riders(nk_full, st);
+    }
+    // shares of this K range (formats of k_sgemm: tile [256][256], column sums [M], fringe [M | N | corner | fringe-row column sum])
+    float *C = a.C + (size_t)blockIdx.x * a.c_slice;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                C[(size_t)(64 * wr + 32 * i + 8 * (r >> 2) + 4 * half + (r & 3)) * a.ldc + 128 * wc + 32 * j + col] = a.alpha * acc[i][j][r];
+    if (sum_cols && a.cs_part) a.cs_part[(size_t)blockIdx.x * a.M + tid] = cs;
+    if (a.x_part) {
+        float *xp = a.x_part + (size_t)blockIdx.x * (a.M + a.N + 2);
+        if (ride_c) xp[tid] = a.alpha * fc;
+        if (ride_r) xp[a.M + tid - ROW] = a.alpha * fr;
+        if (tid == 0) { xp[a.M + a.N] = a.alpha * fk; xp[a.M + a.N + 1] = fcs; }
+    }
+}
+
 // Sums of the split-K shares.  Up to six kinds of output share one launch, each a run of elements whose shares lie `stride` floats apart
 // from slice to slice: the tiles (element (r, c) -> C[r][c]), the column sums of A, the column fringe (-> C[r][xc]), the row fringe
 // (-> C[xr][c]), the corner, the fringe row's column sum.  An output element is summed by FOUR adjacent lanes, each over a quarter of
@@ -577,6 +728,34 @@ kpd_status sgemm(bool tA, bool tB, int M, int N, int K, float alpha, const float
     if (use_fringe && M >= 129 && (M - 1) % 128 == 0) { a.xr = M - 1; Mt = M - 1; }
     if (use_fringe && N >= 65 && (N - 1) % 64 == 0) { a.xc = N - 1; Nt = N - 1; }
     const size_t per_slice = (size_t)Mt * Nt + (colsum ? Mt : 0) + ((a.xr >= 0 || a.xc >= 0) ? (size_t)Mt + Nt + 2 : 0);
+    // edge-sized weight gradients with a 256 x 256 tiled part: the whole output in one workgroup, every operand row fetched once
+    static const bool use_tn256 = !(getenv("KPD_SGEMM_TN256") && atoi(getenv("KPD_SGEMM_TN256")) == 0);          // A/B runs
+    if (use_tn256 && tA && !tB && part && Mt == 256 && Nt == 256 && a.vecA && a.vecB && K >= 65536 && part_floats >= 2 * per_slice) {
+        int sl = (int)std::min<size_t>(std::min(std::min(cu_count(), K / 256), SGEMM_MAX_SPLIT), part_floats / per_slice);
+        a.k_chunk = cdiv(cdiv(K, sl), SG_BK) * SG_BK;
+        sl = cdiv(K, a.k_chunk);
+        a.M = Mt; a.N = Nt;
+        a.C = part; a.ldc = Nt; a.beta = 0.0f; a.c_slice = (long long)Mt * Nt;
+        float *nxt = part + (size_t)sl * Mt * Nt;
+        if (colsum) { a.cs_part = nxt; nxt += (size_t)sl * Mt; }
+        if (a.xr >= 0 || a.xc >= 0) a.x_part = nxt;
+        constexpr int lds = TN256_STAGES * 2 * SG_BK * 256 * 4;
+        KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_sgemm_tn256), lds));
+        hipLaunchKernelGGL(k_sgemm_tn256, dim3(sl), dim3(512), lds, st, a);
+        KPD_LAUNCH_CHECK();
+        RedArgs r;
+        r.n_seg = 0; r.slices = sl; r.beta = beta;
+        r.seg[r.n_seg++] = RedSeg{part, (long long)Mt * Nt, Mt * Nt, C, Nt, ldc, 0};
+        if (colsum) r.seg[r.n_seg++] = RedSeg{a.cs_part, (long long)Mt, Mt, colsum, 0, 1, 1};
+        if (a.x_part) {
+            const long long xs = (long long)Mt + Nt + 2;
+            if (a.xc >= 0) r.seg[r.n_seg++] = RedSeg{a.x_part, xs, Mt, C + a.xc, 0, ldc, 0};
+            if (a.xr >= 0) r.seg[r.n_seg++] = RedSeg{a.x_part + Mt, xs, Nt, C + (size_t)a.xr * ldc, 0, 1, 0};
+            if (a.xr >= 0 && a.xc >= 0) r.seg[r.n_seg++] = RedSeg{a.x_part + Mt + Nt, xs, 1, C + (size_t)a.xr * ldc + a.xc, 0, 1, 0};
+            if (a.xr >= 0 && colsum) r.seg[r.n_seg++] = RedSeg{a.x_part + Mt + Nt + 1, xs, 1, colsum + a.xr, 0, 1, 1};
+        }
+        return launch_reduce(r, st);
+    }
     int slices = part ? (int)std::min<size_t>(sgemm_split_slices(Mt, Nt, K), part_floats / per_slice) : 1;
     if (slices > 1) {
         a.k_chunk = cdiv(cdiv(K, slices), SG_BK) * SG_BK;

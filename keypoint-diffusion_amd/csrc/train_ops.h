@@ -475,7 +475,7 @@ kpd_status build_src_csr(TrainCtx *T, const int *src, int E, int n_src, int *cur
 
 kpd_status colsum_acc(TrainCtx *T, int M, int K, const float *A, int lda, float *y) { return gemv_t_acc(T, M, K, A, lda, nullptr, y, 1); }
 
-constexpr size_t GRAD_PART_FLOATS = (size_t)128 * 256 * 256;     // split-K scratch of an engine: 128 slices of a 256 x 256 gradient
+constexpr size_t GRAD_PART_FLOATS = (size_t)260 * (256 * 256 + 1024);     // split-K scratch of an engine: one slice per CU of a 257 x 257 gradient with its fringe and column-sum shares (k_sgemm_tn256)
 
 // weight gradient C[M,N] += A[K,M]^T B[K,N] with K = rows of a tall activation matrix: the output is a few tiles only, so K is
 // cut into slices (grid.z of one launch, partial products in scratch) that are summed in slice order -- no atomics

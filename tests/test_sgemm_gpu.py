@@ -86,3 +86,29 @@ def test_column_sums_ride_along_with_a_weight_gradient(M, N, K, layout):
         cs2 = torch.full((M,), 3.0, device=dev)
         out2 = hip.sgemm(a, b, True, False, workspace=workspace, colsum=cs2)
         assert torch.equal(cs, cs2) and torch.equal(out, out2)
+
+
+@pytest.mark.parametrize('M,N,K', [(257, 257, 32768), (257, 257, 40001), (256, 256, 166003), (257, 256, 50017), (256, 257, 33000)])
+def test_full_output_weight_gradient_kernel(M, N, K):
+    """Edge-sized weight gradients (K >= 32 768 rows of 16-B aligned activations, 256 (+ 1) x 256 (+ 1) outputs: dW2 = dpre2^T a1 of the
+    EGNN trainer with its 264-float rows, the 256 x 256 scalar blocks of the GVP trainers) take k_sgemm_tn256 -- the whole output in one
+    workgroup, every operand row fetched once.  Against a float64 product, with the fringe row / column, the column sums of A, a K tail
+    that is no multiple of the 16-row slab, accumulation into C, and bit for bit twice."""
+    dev = torch.device('cuda:0')
+    gen = torch.Generator().manual_seed(17)
+    a = torch.randn(K, 264, generator=gen).to(dev)[:, :M]            # the trainers' row stride
+    b = torch.randn(K, 264, generator=gen).to(dev)[:, :N]
+    ws = torch.full((260 * (256 * 256 + 1024),), float('nan'), device=dev)
+    ref = a.double().T @ b.double()
+    tol = 1e-6 + 4e-7 * K ** 0.5
+    outs = []
+    for _ in range(2):
+        cs = torch.full((M,), 3.0, device=dev)
+        c = torch.full((M, N + 3), 2.0, device=dev)                  # strided output, accumulated into (beta = 1 as grad_gemm does)
+        hip.sgemm(a, b, True, False, beta=1.0, out=c[:, :N], workspace=ws, colsum=cs)
+        assert torch.all(c[:, N:] == 2.0)
+        assert ((c[:, :N].double() - 2.0 - ref).abs().max() / ref.abs().max()) < tol
+        ref_cs = a.double().sum(0)
+        assert ((cs.double() - 3.0 - ref_cs).abs().max() / ref_cs.abs().max().clamp_min(1.0)) < tol
+        outs.append((c.clone(), cs.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
