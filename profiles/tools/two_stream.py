@@ -1,5 +1,6 @@
 import sys, time, copy, torch
-sys.path.insert(0, '/root/repo')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from keypoint_diffusion_amd import graph as G
 dev = torch.device('cuda', 0)
