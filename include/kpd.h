@@ -126,7 +126,9 @@ kpd_status kpd_egnn_forward(kpd_egnn *m, const kpd_batch *batch, const float *t_
  *                DESIGN.md "f16x2 mode"): a build VARIANT of its edge kernel (batched distance read) showed a first-launch
  *                deviation of one LDS row in rounds 2 - 3; the shipped per-row form has never shown it in any detector, and a
  *                standalone kernel with the suspected ingredients (profiles/tools/f16_lds_row_probe.hip: 20 fresh processes,
- *                80 launches clean) does not reproduce it, so it is neither explained nor shown to be a hardware erratum.
+ *                80 launches clean) does not reproduce it; in round 4 the variant build itself -- of today's sources and of the
+ *                round-3 sources -- is clean in 24 fresh processes on 10 GPUs (profiles/r04_f16_variant_resample.txt), so it is
+ *                neither explained nor reproducible any more, nor shown to be a hardware erratum.
  *                Until it is, the mode is frozen as experimental: use it for throughput experiments, not for results you keep.
  *                The environment variable KPD_GEMM=f16x2 selects it at kpd_egnn_create time. */
 kpd_status kpd_egnn_debug_state(kpd_egnn *m, const char *what, float *out_dev, int64_t n_floats,
