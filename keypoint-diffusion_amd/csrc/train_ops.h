@@ -324,11 +324,8 @@ struct WideSet {
     int tab_cap = 0, turn = 0;
 
     void release() {
-        for (Entry &x : e) {
-            if (x.maps_dev) (void)hipFree(x.maps_dev);
-            if (x.w_dev) (void)hipFree(x.w_dev);
-            if (x.g_dev) (void)hipFree(x.g_dev);
-        }
+        for (Entry &x : e)
+            if (x.maps_dev) (void)hipFree(x.maps_dev);          // one allocation per entry: maps, wide weight, wide gradient
         e.clear();
         index.clear();
         for (int k = 0; k < RING; ++k) {
@@ -517,11 +514,19 @@ kpd_status bind_wide(TrainCtx *T, const char *name, const float *weight, float *
         x.ref_rows = ref_r; x.ref_cols = ref_c;
         x.d.R = (int)rmap.size(); x.d.C = (int)cmap.size(); x.d.ref_ld = ref_c;
         const size_t n = (size_t)x.d.R * x.d.C;
-        KPD_HIP(hipMalloc(reinterpret_cast<void **>(&x.maps_dev), (rmap.size() + cmap.size()) * 4));
-        KPD_HIP(hipMalloc(reinterpret_cast<void **>(&x.w_dev), n * 4));
-        KPD_HIP(hipMalloc(reinterpret_cast<void **>(&x.g_dev), n * 4));
-        KPD_HIP(hipMemcpy(x.maps_dev, rmap.data(), rmap.size() * 4, hipMemcpyHostToDevice));
-        KPD_HIP(hipMemcpy(x.maps_dev + rmap.size(), cmap.data(), cmap.size() * 4, hipMemcpyHostToDevice));
+        // (one allocation for maps, weight and gradient: a failure leaves nothing behind)
+        const size_t map_bytes = ((rmap.size() + cmap.size()) * 4 + 255) & ~size_t(255), mat_bytes = (n * 4 + 255) & ~size_t(255);
+        char *blob = nullptr;
+        KPD_HIP(hipMalloc(reinterpret_cast<void **>(&blob), map_bytes + 2 * mat_bytes));
+        x.maps_dev = reinterpret_cast<int *>(blob);
+        x.w_dev = reinterpret_cast<float *>(blob + map_bytes);
+        x.g_dev = reinterpret_cast<float *>(blob + map_bytes + mat_bytes);
+        if (hipMemcpy(x.maps_dev, rmap.data(), rmap.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(x.maps_dev + rmap.size(), cmap.data(), cmap.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(blob);
+            set_error("bind_wide: copying the axis maps of %s failed", name);
+            return KPD_ERR_HIP;
+        }
         x.d.rmap = x.maps_dev; x.d.cmap = x.maps_dev + rmap.size(); x.d.w = x.w_dev;
         W.e.push_back(x);
         it = W.index.emplace(name, (int)W.e.size() - 1).first;
