@@ -677,7 +677,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge_h(EdgeAr
     _Float16 *Ah = reinterpret_cast<_Float16 *>(smem);                 // two f16 planes of the A tile; T (fp32) reuses the region
     // W2[256, :] of edge_mlp then coord_mlp x H_SCALE_W as f16 planes: [hi 272 | lo 272] each
     _Float16 *wxs = reinterpret_cast<_Float16 *>(s.misc + 8);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // (the wave index as a scalar, as in k_node_update8: the per-row LDS addresses of the A-builds become scalar base + immediate offset
+    // instead of one VGPR per row kept live -- spilled -- across the GEMMs)
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     unsigned long long t_prev_ = a.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
     // tile decode (XCD-aware: consecutive tiles -- neighbouring edges of one complex, which
     // share P rows -- go to the same XCD / L2)

@@ -635,7 +635,7 @@ template <int NTS, int HM = 0>
 __global__ __launch_bounds__(256, 2) void k_gvp_node_chain(GvpNodePair p) {
     constexpr int S = 16 * NTS, CH4 = NTS * 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = HM ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6, lane = tid & 63;      // (scalar in the f16x2 form: 2 spilled dwords otherwise; the exact form is left as measured)
     const int which = (int)blockIdx.x >= p.tiles0 ? 1 : 0;
     const GvpNodeArgs &a = p.nt[which];
     const int node0 = ((int)blockIdx.x - (which ? p.tiles0 : 0)) * TM;
