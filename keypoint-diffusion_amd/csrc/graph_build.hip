@@ -155,7 +155,8 @@ __global__ void k_kl_build(const float *__restrict__ lig_x, const int *__restric
             // insertion into the sorted best-list (strict < keeps the lower index on ties)
 #pragma unroll
             for (int j = 0; j < KL_KMAX; ++j) {
-                if (j < kk && (d < bd[j] || bi[j] < 0)) {
+                if (j >= kk) break;                       // (uniform: kk is the same for the whole workgroup)
+                if (d < bd[j] || bi[j] < 0) {
                     const float td = bd[j];
                     const int ti = bi[j];
                     bd[j] = d;
@@ -433,7 +434,10 @@ kpd_status launch_knn_bipartite(const float *x, const int *x_ptr, int n_x, int m
     const size_t lds = (size_t)max_x * (3 * sizeof(float) + (size_t)words * sizeof(unsigned) + sizeof(int)) + 16;
     KPD_REQUIRE(lds <= 150 * 1024, KPD_ERR_INVALID, "knn needs %zu B of LDS (max_x=%d, max_y=%d)", lds, max_x, max_y);
     KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_kl_build), 150 * 1024));
-    hipLaunchKernelGGL(k_kl_build, dim3(B), dim3(256), lds, st, x, x_ptr, y, y_ptr, off_tmp, k, words, n_x, n_y, xm_src, xm_dst,
+    // one thread per keypoint in phase 1: 320 threads take the 300 keypoints of an all-atom pocket in ONE pass (256 needed a second pass
+    // with 44 active threads: 43.6 -> see profiles/r04_kl_build.txt)
+    const int threads = max_y > 256 ? (max_y > 320 ? 512 : 320) : 256;
+    hipLaunchKernelGGL(k_kl_build, dim3(B), dim3(threads), lds, st, x, x_ptr, y, y_ptr, off_tmp, k, words, n_x, n_y, xm_src, xm_dst,
                        xm_rowptr, ym_src, ym_dst, ym_rowptr);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
