@@ -538,7 +538,7 @@ def run_end_to_end(device, workload='egnn_all_atom', B=64, n_rec=300, n_lig=25, 
         n_rec, n_lig = ragged_sizes(B, 0)
     with torch.no_grad():
         for _ in range(2):          # first pass = warm-up (workspace reservation, first-use initialisation)
-            g = raw_batch(B, n_rec, n_lig, 4321, device, workload)
+            g = raw_batch(B, n_rec, n_lig, 4321, device, workload).to(device)      # resident before the clock starts, like `value`'s batch
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             enc = model.encode_receptors(g).to(device)
@@ -629,6 +629,8 @@ def compact_line(out, full_path=None):
         line['end_to_end_fields'] = ['ligands_per_min', 'encoder_ms', 'T']
     if out.get('ligands_per_min') is not None:
         line['ligands_per_min'] = _r(out['ligands_per_min'])
+    if out.get('c1_gpu'):
+        line['c1_gpu_s_100_steps'] = _r(out['c1_gpu'].get('total_s_100_steps'))
     if full_path:
         line['full_record'] = full_path
     return line
@@ -651,6 +653,36 @@ def emit(out):
         text = json.dumps(slim, separators=(',', ':'))
     sys.stdout.flush()
     print(text, flush=True)
+
+
+def run_c1_gpu(device):
+    """BASELINE.json configs[0] on the GPU: configs/dev_config.yml egnn dynamics (no keypoint update, kl_k 5, ll r 9), one synthetic C-alpha
+    pocket of 60 nodes + a 20-atom ligand, all 100 reverse steps of one sampling run (encode + loop + host copy).  The CPU oracle's time for
+    the same 100 steps is `cpu_baseline.c1_dev_config`.  B = 1: a latency figure, not a throughput one."""
+    import torch
+    from keypoint_diffusion_amd import graph as G
+    from keypoint_diffusion_amd import synth
+    from keypoint_diffusion_amd.ligand_diffuser import KeypointDiffusion
+    from tests import util
+    cut = {'rr': 3.5, 'rk': 100, 'kk': 8, 'kl': 8, 'll': 9}                # configs/dev_config.yml:35
+    m1 = KeypointDiffusion(10, 20, None, n_timesteps=100, architecture='egnn', rec_encoder_type='fixed',
+                           graph_config=dict(n_keypoints=20, graph_cutoffs=cut), dynamics_config=util.EGNN_DEV, precision=1e-5)
+    synth.fill_state_dict_(m1, 0)
+    m1 = m1.eval().to(device)
+    times = []
+    with torch.no_grad():
+        for _ in range(3):          # first pass = warm-up
+            g = G.batch(synth.synth_complexes([60], [20], 20, cut, seed=7, n_rec_feat=20, density=synth.CA_DENSITY))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pos, _ = m1.sample_from_encoded_receptors(m1.encode_receptors(g).to(device))
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+    assert len(pos) == 1 and tuple(pos[0].shape) == (20, 3)
+    del m1
+    torch.cuda.empty_cache()
+    return {'total_s_100_steps': min(times[1:]), 'ms_per_step': 10.0 * min(times[1:]), 'runs_s': times,
+            'note': 'configs[0] on the GPU: one 60-node C-alpha pocket, one 20-atom ligand, 100 reverse steps end to end (B = 1: latency-bound)'}
 
 
 def run_train(args, device, rank, world, dist):
@@ -817,6 +849,7 @@ def main():
             out['end_to_end'] = run_end_to_end(device)
             out['ligands_per_min'] = out['end_to_end']['ligands_per_min']
             # configs[2] (learned encoder timed on its own) and the configs[4] shape at its own T = 1000, exact mode
+            out['c1_gpu'] = run_c1_gpu(device)
             out['end_to_end_more'] = {'gvp_40kp': run_end_to_end(device, 'gvp_40kp'),
                                       'gvp_all_atom_ragged': run_end_to_end(device, 'gvp_all_atom', ragged=True)}
         emit(out)
