@@ -51,6 +51,7 @@ def synthetic_record(n_secondary=7, prose=400, world=8):
     out['end_to_end_more'] = {'gvp_40kp': dict(e2e, workload='gvp_40kp', encoder_ms=11.7),
                               'gvp_all_atom_ragged': dict(e2e, workload='gvp_all_atom_ragged', n_timesteps=1000)}
     out['ligands_per_min'] = e2e['ligands_per_min']
+    out['c1_gpu'] = {'total_s_100_steps': 0.0758919, 'ms_per_step': 0.758919, 'runs_s': [0.3, 0.0759, 0.0761], 'note': text}
     return out
 
 
@@ -76,7 +77,7 @@ def test_compact_line_is_short_and_complete():
     assert len(back['secondary']) == 7 and all(len(v) == 3 for v in back['secondary'].values())
     assert set(back['end_to_end']) == {'egnn_all_atom', 'gvp_40kp', 'gvp_all_atom_ragged'}
     assert back['end_to_end']['gvp_40kp'][1] == 11.7            # encoder time reported on its own
-    assert back['full_record'] == bench.FULL_RECORD
+    assert back['full_record'] == bench.FULL_RECORD and abs(back['c1_gpu_s_100_steps'] - 0.075892) < 1e-6
     assert abs(back['value'] - rec['value']) / rec['value'] < 1e-4
 
 
