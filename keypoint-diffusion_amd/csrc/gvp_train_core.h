@@ -135,6 +135,72 @@ __global__ void k_gvp_sh_bwd(const float *__restrict__ Vh, const float *__restri
     if (s * s > 1e-8f) dVh[i] += dsh[m * h + j] * Vh[i] / s;
 }
 
+// Vector half of GVP.forward up to the gate (gvp.py:97-104) for one row per thread: Vh = v_in Wh, sh = |Vh| over the three components
+// (clamped, _norm_no_nan), Vu = Vh Wu.  As three launches (two <= 33-wide products through the GEMM and k_gvp_sh) the [3 M x 17]
+// arrays were read and written five times by kernels that do ~600 FMAs per row; here each is touched once.  The weights sit in LDS
+// (every lane reads the same element: broadcast), a row's 3 x VI inputs and 3 x H hidden values in registers.
+template <int VI, int H, int VO>
+__global__ __launch_bounds__(128) void k_gvp_vec_fwd(const float *__restrict__ v_in, const float *__restrict__ Wh, const float *__restrict__ Wu,
+                                                     int M, float *__restrict__ Vh, float *__restrict__ Vu, float *__restrict__ sh) {
+    __shared__ float s_wh[VI * H], s_wu[H * VO];
+    for (int i = threadIdx.x; i < VI * H; i += blockDim.x) s_wh[i] = Wh[i];
+    for (int i = threadIdx.x; i < H * VO; i += blockDim.x) s_wu[i] = Wu[i];
+    __syncthreads();
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    float sh2[H];
+#pragma unroll
+    for (int j = 0; j < H; ++j) sh2[j] = 0.0f;
+#pragma unroll 1
+    for (int c = 0; c < 3; ++c) {
+        const float *x = v_in + ((size_t)m * 3 + c) * VI;
+        float xv[VI], vh[H];
+#pragma unroll
+        for (int i = 0; i < VI; ++i) xv[i] = x[i];
+#pragma unroll
+        for (int j = 0; j < H; ++j) vh[j] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < VI; ++i) {
+            asm volatile("" ::: "memory");          // keeps the weight row's LDS reads here (hoisted, all VI x H weights would live in registers)
+#pragma unroll
+            for (int j = 0; j < H; ++j) vh[j] = fmaf(xv[i], s_wh[i * H + j], vh[j]);
+        }
+        float *oh = Vh + ((size_t)m * 3 + c) * H;
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+            oh[j] = vh[j];
+            sh2[j] = fmaf(vh[j], vh[j], sh2[j]);
+        }
+        float vu[VO];
+#pragma unroll
+        for (int u = 0; u < VO; ++u) vu[u] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < VO; ++u) vu[u] = fmaf(vh[j], s_wu[j * VO + u], vu[u]);
+        }
+        float *ou = Vu + ((size_t)m * 3 + c) * VO;
+#pragma unroll
+        for (int u = 0; u < VO; ++u) ou[u] = vu[u];
+    }
+    float *os = sh + (size_t)m * H;
+#pragma unroll
+    for (int j = 0; j < H; ++j) os[j] = sqrtf(fmaxf(sh2[j], 1e-8f));
+}
+
+inline bool vec_fused() {
+    static const bool on = !(getenv("KPD_TRAIN_VEC_FUSED") && atoi(getenv("KPD_TRAIN_VEC_FUSED")) == 0);          // A/B runs
+    return on;
+}
+
+template <int VI, int H, int VO>
+kpd_status launch_gvp_vec_fwd(const float *v_in, const float *Wh, const float *Wu, int M, float *Vh, float *Vu, float *sh, hipStream_t st) {
+    hipLaunchKernelGGL((k_gvp_vec_fwd<VI, H, VO>), dim3(cdiv(M, 128)), dim3(128), 0, st, v_in, Wh, Wu, M, Vh, Vu, sh);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
 // V[m, c, u] = act(gate[m, u]) * Vu[m, c, u], act = sigmoid or identity (gvp.py:108-114)
 __global__ void k_gvp_gate(const float *__restrict__ gate, const float *__restrict__ Vu, long long total, int vo, int identity,
                            float *__restrict__ V) {
@@ -355,10 +421,21 @@ template <class TT>
 kpd_status gvp_fwd(TT *T, const GvpP &g, int M, const float *s_in, int ld_s, const float *v_in, const GvpBuf &B,
                    bool identity) {
     if (M == 0) return KPD_OK;
-    KPD_TRY(gemm(T, false, false, 3 * M, g.h, g.vi, v_in, g.vi, g.Wh.w, g.h, 0.0f, B.Vh, g.h));
-    KPD_TRY(gemm(T, false, false, 3 * M, g.vo, g.h, B.Vh, g.h, g.Wu.w, g.vo, 0.0f, B.Vu, g.vo));
-    hipLaunchKernelGGL(k_gvp_sh, grid1((long long)M * g.h), dim3(256), 0, T->st, B.Vh, (long long)M * g.h, g.h, B.sh);
-    KPD_LAUNCH_CHECK();
+    bool fused = false;
+    if (vec_fused()) {          // the shapes the engines use: message head [x_diff | v_src] (17), plain (16), noise head (16 -> 1), encoder rk head (33)
+        fused = true;
+        if (g.vi == 17 && g.h == 17 && g.vo == 16) KPD_TRY((launch_gvp_vec_fwd<17, 17, 16>(v_in, g.Wh.w, g.Wu.w, M, B.Vh, B.Vu, B.sh, T->st)));
+        else if (g.vi == 16 && g.h == 16 && g.vo == 16) KPD_TRY((launch_gvp_vec_fwd<16, 16, 16>(v_in, g.Wh.w, g.Wu.w, M, B.Vh, B.Vu, B.sh, T->st)));
+        else if (g.vi == 16 && g.h == 16 && g.vo == 1) KPD_TRY((launch_gvp_vec_fwd<16, 16, 1>(v_in, g.Wh.w, g.Wu.w, M, B.Vh, B.Vu, B.sh, T->st)));
+        else if (g.vi == 33 && g.h == 33 && g.vo == 16) KPD_TRY((launch_gvp_vec_fwd<33, 33, 16>(v_in, g.Wh.w, g.Wu.w, M, B.Vh, B.Vu, B.sh, T->st)));
+        else fused = false;
+    }
+    if (!fused) {
+        KPD_TRY(gemm(T, false, false, 3 * M, g.h, g.vi, v_in, g.vi, g.Wh.w, g.h, 0.0f, B.Vh, g.h));
+        KPD_TRY(gemm(T, false, false, 3 * M, g.vo, g.h, B.Vh, g.h, g.Wu.w, g.vo, 0.0f, B.Vu, g.vo));
+        hipLaunchKernelGGL(k_gvp_sh, grid1((long long)M * g.h), dim3(256), 0, T->st, B.Vh, (long long)M * g.h, g.h, B.sh);
+        KPD_LAUNCH_CHECK();
+    }
     long long tot = (long long)M * g.so;
     if (s_in && ws_ok(g, ld_s)) {
         // the narrow vector-norm block first, then the 256 x 256 scalar block on the weight-stationary GEMM with the partial
@@ -399,6 +476,8 @@ kpd_status gvp_bwd(TT *T, const GvpP &g, int M, const float *s_in, int ld_s, con
     // the sh block of to_feats_out, with the bias gradient (column sums of ds) riding along
     KPD_TRY(grad_gemm(T, g.so, g.h, M, ds, g.so, B.sh, g.h, g.Ws.g ? g.Ws.g + g.si : nullptr, g.si + g.h, g.bs.g));
     KPD_TRY(gemm(T, false, false, M, g.h, g.so, ds, g.so, g.Ws.w + g.si, g.si + g.h, 0.0f, T->dsh, g.h));
+    // (The same one-row-per-thread fusion of this half -- dVh = dVu Wu^T + the norm term, dv_in = dVh Wh^T -- was built and measured:
+    // 94.5 vs 93.4 ms per gvp_train step, slower: five strided row streams per thread instead of two.  A chained MFMA form is the way there.)
     KPD_TRY(gemm(T, false, true, 3 * M, g.h, g.vo, dV, g.vo, g.Wu.w, g.vo, 0.0f, T->dVh, g.h));
     tot = (long long)M * 3 * g.h;
     hipLaunchKernelGGL(k_gvp_sh_bwd, grid1(tot), dim3(256), 0, T->st, B.Vh, B.sh, T->dsh, tot, g.h, T->dVh);
