@@ -4,6 +4,7 @@
 // which supplies the stream (TrainCtx), the scalar width S and the scratch buffers dgate, dsh, dVh, wsg_pack,
 // tmp_s, tmp_v, U.  Vector features are [rows, 3, channels].  File-local in every translation unit that includes it.
 #pragma once
+#include "chain_core.h"
 #include "egnn_kernels.h"
 #include "engine.h"
 #include "train_ops.h"
@@ -187,6 +188,143 @@ __global__ __launch_bounds__(128) void k_gvp_vec_fwd(const float *__restrict__ v
     float *os = sh + (size_t)m * H;
 #pragma unroll
     for (int j = 0; j < H; ++j) os[j] = sqrtf(fmaxf(sh2[j], 1e-8f));
+}
+
+// ---- 16-channel GVPs: the vector half as register-chained 16x16x4 MFMA products (chain_core.h conventions) --------------------------
+// A wave owns groups of 16 rows m (x 3 components).  Lane (e = lane & 15, q = lane >> 4) holds channels 4 q .. 4 q + 3 of row e as one
+// float4: that is a 16-byte piece of the row in memory (coalesced: the four q-lanes cover the row's 64 B), the B operand of a product
+// T^T[n][e] = sum_k W'[n][k] X^T[k][e], and the layout the product's result comes back in.  The 16 x 16 weights are A-fragments in
+// registers for the whole kernel.  Forward: Vh = v_in Wh, Vu = Vh Wu, sh = |Vh| over the components: one read and three writes of
+// [rows x 16] arrays instead of five passes by three launches.
+__device__ __forceinline__ v4f chain16(const v4f &w, const v4f &x) {
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], x[r], acc, 0, 0, 0);
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void k_gvp_vec16_fwd(const float *__restrict__ v_in, const float *__restrict__ Wh, const float *__restrict__ Wu,
+                                                       int M, float *__restrict__ Vh, float *__restrict__ Vu, float *__restrict__ sh) {
+    const int lane = threadIdx.x & 63, e = lane & 15, q = lane >> 4;
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), n_wv = gridDim.x * 4, G = (M + 15) >> 4;
+    v4f aWh, aWu;                 // W'[n = e][k = 4 q + r] = W[4 q + r][e]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { aWh[r] = Wh[(4 * q + r) * 16 + e]; aWu[r] = Wu[(4 * q + r) * 16 + e]; }
+    const v4f zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int g = wv; g < G; g += n_wv) {
+        const int m = 16 * g + e;
+        const bool on = m < M;
+        const size_t row0 = (size_t)min(m, M - 1) * 3;
+        v4f s2 = zero;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const size_t at = (row0 + c) * 16 + 4 * q;
+            v4f x = *reinterpret_cast<const v4f *>(v_in + at);
+            if (!on) x = zero;
+            const v4f vh = chain16(aWh, x);
+            const v4f vu = chain16(aWu, vh);
+            s2 += vh * vh;
+            if (on) {
+                *reinterpret_cast<v4f *>(Vh + at) = vh;
+                *reinterpret_cast<v4f *>(Vu + at) = vu;
+            }
+        }
+        if (on) {
+            v4f o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = sqrtf(fmaxf(s2[r], 1e-8f));
+            *reinterpret_cast<v4f *>(sh + (size_t)m * 16 + 4 * q) = o;
+        }
+    }
+}
+
+// Backward of the same half: dVh = dVu Wu^T + dsh Vh / sh (clamp inactive), dv_in = dVh Wh^T, and the two weight gradients
+// Wu.g += Vh^T dVu, Wh.g += v_in^T dVh.  The gradients are products over ROWS: their operands want "channel on lane & 15, row on (lane >> 4, r)",
+// the transpose of what a lane holds, so each 16 x 16 tile takes one trip through a 17-float-stride LDS tile of its wave.  Every wave adds
+// its groups in a fixed order and writes ONE partial per gradient; k_gvp_vec16_reduce adds the partials in wave order (no atomics).
+// dVh is not written: nothing else reads it.
+constexpr int VEC16_MAX_WAVES = 4096;
+__global__ __launch_bounds__(256) void k_gvp_vec16_bwd(const float *__restrict__ dVu, const float *__restrict__ Vh, const float *__restrict__ sh,
+                                                       const float *__restrict__ dsh, const float *__restrict__ v_in,
+                                                       const float *__restrict__ Wh, const float *__restrict__ Wu, int M,
+                                                       float *__restrict__ dv_in, float *__restrict__ part) {
+    __shared__ float s_t[4][4][16 * 17];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, e = lane & 15, q = lane >> 4;
+    const int wv = blockIdx.x * 4 + wave, n_wv = gridDim.x * 4, G = (M + 15) >> 4;
+    v4f aWuT, aWhT;               // dVh: W'[n = j][k = u] = Wu[j][u];  dv_in: W'[n = i][k = j] = Wh[i][j]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { aWuT[r] = Wu[e * 16 + 4 * q + r]; aWhT[r] = Wh[e * 16 + 4 * q + r]; }
+    const v4f zero = {0.f, 0.f, 0.f, 0.f};
+    v4f gWu = zero, gWh = zero;
+    float *t_vh = s_t[wave][0], *t_du = s_t[wave][1], *t_x = s_t[wave][2], *t_g = s_t[wave][3];
+    auto put = [&](float *t, const v4f &v) {              // row e, channels 4 q ..
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[e * 17 + 4 * q + r] = v[r];
+    };
+    auto get = [&](const float *t) {                      // channel e of rows 4 q ..
+        v4f v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = t[(4 * q + r) * 17 + e];
+        return v;
+    };
+#pragma unroll 1
+    for (int g = wv; g < G; g += n_wv) {
+        const int m = 16 * g + e;
+        const bool on = m < M;
+        const size_t mm = (size_t)min(m, M - 1);
+        v4f k;
+        {
+            const v4f s = *reinterpret_cast<const v4f *>(sh + mm * 16 + 4 * q), d = *reinterpret_cast<const v4f *>(dsh + mm * 16 + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) k[r] = (on && s[r] * s[r] > 1e-8f) ? d[r] / s[r] : 0.0f;
+        }
+#pragma unroll 1
+        for (int c = 0; c < 3; ++c) {
+            const size_t at = (mm * 3 + c) * 16 + 4 * q;
+            v4f du = *reinterpret_cast<const v4f *>(dVu + at), vh = *reinterpret_cast<const v4f *>(Vh + at),
+                x = *reinterpret_cast<const v4f *>(v_in + at);
+            if (!on) { du = zero; vh = zero; x = zero; }
+            v4f gh = chain16(aWuT, du);
+            gh += k * vh;
+            if (dv_in) {
+                const v4f dx = chain16(aWhT, gh);
+                if (on) *reinterpret_cast<v4f *>(dv_in + at) = dx;
+            }
+            put(t_vh, vh); put(t_du, du); put(t_x, x); put(t_g, gh);
+            const v4f vhT = get(t_vh), duT = get(t_du), xT = get(t_x), gT = get(t_g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                gWu = __builtin_amdgcn_mfma_f32_16x16x4f32(vhT[r], duT[r], gWu, 0, 0, 0);       // [j][u] += Vh[row][j] dVu[row][u]
+                gWh = __builtin_amdgcn_mfma_f32_16x16x4f32(xT[r], gT[r], gWh, 0, 0, 0);        // [i][j] += v_in[row][i] dVh[row][j]
+            }
+        }
+    }
+    // result element (row 4 q + r, column e) of either gradient
+    float *p = part + (size_t)wv * 512;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        p[(4 * q + r) * 16 + e] = gWu[r];
+        p[256 + (4 * q + r) * 16 + e] = gWh[r];
+    }
+}
+
+// g_u[i] += sum over waves of part[w][i], g_h[i] += ... part[w][256 + i].  16 workgroups of 32 outputs x 8 wave-slices: slice s adds
+// waves s, s + 8, ... in order, the eight slice sums are combined in slice order: a fixed tree.
+__global__ __launch_bounds__(256) void k_gvp_vec16_reduce(const float *__restrict__ part, int n_waves, float *__restrict__ g_u, float *__restrict__ g_h) {
+    __shared__ float s_p[8][32];
+    const int o = threadIdx.x & 31, sl = threadIdx.x >> 5, i = blockIdx.x * 32 + o;
+    float s = 0.0f;
+    for (int w = sl; w < n_waves; w += 8) s += part[(size_t)w * 512 + i];
+    s_p[sl][o] = s;
+    __syncthreads();
+    if (sl == 0) {
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += s_p[k][o];
+        float *dst = i < 256 ? g_u : g_h;
+        if (dst) dst[i & 255] += t;
+    }
 }
 
 inline bool vec_fused() {
@@ -425,7 +563,11 @@ kpd_status gvp_fwd(TT *T, const GvpP &g, int M, const float *s_in, int ld_s, con
     if (vec_fused()) {          // the shapes the engines use: message head [x_diff | v_src] (17), plain (16), noise head (16 -> 1), encoder rk head (33)
         fused = true;
         if (g.vi == 17 && g.h == 17 && g.vo == 16) KPD_TRY((launch_gvp_vec_fwd<17, 17, 16>(v_in, g.Wh.w, g.Wu.w, M, B.Vh, B.Vu, B.sh, T->st)));
-        else if (g.vi == 16 && g.h == 16 && g.vo == 16) KPD_TRY((launch_gvp_vec_fwd<16, 16, 16>(v_in, g.Wh.w, g.Wu.w, M, B.Vh, B.Vu, B.sh, T->st)));
+        else if (g.vi == 16 && g.h == 16 && g.vo == 16) {
+            const int blocks = std::max(1, std::min(cdiv(cdiv(M, 16), 4), 4 * cu_count()));
+            hipLaunchKernelGGL(k_gvp_vec16_fwd, dim3(blocks), dim3(256), 0, T->st, v_in, g.Wh.w, g.Wu.w, M, B.Vh, B.Vu, B.sh);
+            KPD_LAUNCH_CHECK();
+        }
         else if (g.vi == 16 && g.h == 16 && g.vo == 1) KPD_TRY((launch_gvp_vec_fwd<16, 16, 1>(v_in, g.Wh.w, g.Wu.w, M, B.Vh, B.Vu, B.sh, T->st)));
         else if (g.vi == 33 && g.h == 33 && g.vo == 16) KPD_TRY((launch_gvp_vec_fwd<33, 33, 16>(v_in, g.Wh.w, g.Wu.w, M, B.Vh, B.Vu, B.sh, T->st)));
         else fused = false;
@@ -476,6 +618,16 @@ kpd_status gvp_bwd(TT *T, const GvpP &g, int M, const float *s_in, int ld_s, con
     // the sh block of to_feats_out, with the bias gradient (column sums of ds) riding along
     KPD_TRY(grad_gemm(T, g.so, g.h, M, ds, g.so, B.sh, g.h, g.Ws.g ? g.Ws.g + g.si : nullptr, g.si + g.h, g.bs.g));
     KPD_TRY(gemm(T, false, false, M, g.h, g.so, ds, g.so, g.Ws.w + g.si, g.si + g.h, 0.0f, T->dsh, g.h));
+    if (vec_fused() && g.vi == 16 && g.h == 16 && g.vo == 16 && T->part && T->part_floats >= (size_t)VEC16_MAX_WAVES * 512) {
+        const int blocks = std::max(1, std::min(cdiv(cdiv(M, 16), 4), std::min(2 * cu_count(), VEC16_MAX_WAVES / 4)));
+        hipLaunchKernelGGL(k_gvp_vec16_bwd, dim3(blocks), dim3(256), 0, T->st, dV, B.Vh, B.sh, T->dsh, v_in, g.Wh.w, g.Wu.w, M, dv_in, T->part);
+        KPD_LAUNCH_CHECK();
+        if (g.Wu.g || g.Wh.g) {
+            hipLaunchKernelGGL(k_gvp_vec16_reduce, dim3(16), dim3(256), 0, T->st, T->part, 4 * blocks, g.Wu.g, g.Wh.g);
+            KPD_LAUNCH_CHECK();
+        }
+        return KPD_OK;
+    }
     // (The same one-row-per-thread fusion of this half -- dVh = dVu Wu^T + the norm term, dv_in = dVh Wh^T -- was built and measured:
     // 94.5 vs 93.4 ms per gvp_train step, slower: five strided row streams per thread instead of two.  A chained MFMA form is the way there.)
     KPD_TRY(gemm(T, false, true, 3 * M, g.h, g.vo, dV, g.vo, g.Wu.w, g.vo, 0.0f, T->dVh, g.h));
