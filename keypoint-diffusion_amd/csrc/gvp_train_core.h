@@ -242,7 +242,8 @@ __global__ __launch_bounds__(256) void k_gvp_vec16_fwd(const float *__restrict__
 // Backward of the same half: dVh = dVu Wu^T + dsh Vh / sh (clamp inactive), dv_in = dVh Wh^T, and the two weight gradients
 // Wu.g += Vh^T dVu, Wh.g += v_in^T dVh.  The gradients are products over ROWS: their operands want "channel on lane & 15, row on (lane >> 4, r)",
 // the transpose of what a lane holds, so each 16 x 16 tile takes one trip through a 17-float-stride LDS tile of its wave.  Every wave adds
-// its groups in a fixed order and writes ONE partial per gradient; k_gvp_vec16_reduce adds the partials in wave order (no atomics).
+// its groups in a fixed order, a workgroup adds its four waves in wave order and writes ONE partial per gradient; k_gvp_vec16_reduce adds
+// the partials in workgroup order (no atomics).
 // dVh is not written: nothing else reads it.
 constexpr int VEC16_MAX_WAVES = 4096;
 __global__ __launch_bounds__(256) void k_gvp_vec16_bwd(const float *__restrict__ dVu, const float *__restrict__ Vh, const float *__restrict__ sh,
@@ -300,28 +301,33 @@ __global__ __launch_bounds__(256) void k_gvp_vec16_bwd(const float *__restrict__
             }
         }
     }
-    // result element (row 4 q + r, column e) of either gradient
-    float *p = part + (size_t)wv * 512;
+    // result element (row 4 q + r, column e) of either gradient: the four waves' sums are added in wave order, one partial per workgroup
+    __syncthreads();                                       // (the transpose tiles are free now: reused as the exchange buffer)
+    float *xw = &s_t[0][0][0] + wave * 512;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        p[(4 * q + r) * 16 + e] = gWu[r];
-        p[256 + (4 * q + r) * 16 + e] = gWh[r];
+        xw[(4 * q + r) * 16 + e] = gWu[r];
+        xw[256 + (4 * q + r) * 16 + e] = gWh[r];
     }
+    __syncthreads();
+    const float *x0 = &s_t[0][0][0];
+    float *p = part + (size_t)blockIdx.x * 512;
+    for (int i = threadIdx.x; i < 512; i += 256) p[i] = ((x0[i] + x0[512 + i]) + x0[1024 + i]) + x0[1536 + i];
 }
 
-// g_u[i] += sum over waves of part[w][i], g_h[i] += ... part[w][256 + i].  16 workgroups of 32 outputs x 8 wave-slices: slice s adds
-// waves s, s + 8, ... in order, the eight slice sums are combined in slice order: a fixed tree.
-__global__ __launch_bounds__(256) void k_gvp_vec16_reduce(const float *__restrict__ part, int n_waves, float *__restrict__ g_u, float *__restrict__ g_h) {
-    __shared__ float s_p[8][32];
-    const int o = threadIdx.x & 31, sl = threadIdx.x >> 5, i = blockIdx.x * 32 + o;
+// g_u[i] += sum over workgroups of part[b][i], g_h[i] += ... part[b][256 + i].  32 workgroups of 16 outputs x 16 slices: slice s adds
+// partials s, s + 16, ... in order, the sixteen slice sums are combined in slice order: a fixed tree.
+__global__ __launch_bounds__(256) void k_gvp_vec16_reduce(const float *__restrict__ part, int n_part, float *__restrict__ g_u, float *__restrict__ g_h) {
+    __shared__ float s_p[16][16];
+    const int o = threadIdx.x & 15, sl = threadIdx.x >> 4, i = blockIdx.x * 16 + o;
     float s = 0.0f;
-    for (int w = sl; w < n_waves; w += 8) s += part[(size_t)w * 512 + i];
+    for (int b = sl; b < n_part; b += 16) s += part[(size_t)b * 512 + i];
     s_p[sl][o] = s;
     __syncthreads();
     if (sl == 0) {
         float t = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += s_p[k][o];
+        for (int k = 0; k < 16; ++k) t += s_p[k][o];
         float *dst = i < 256 ? g_u : g_h;
         if (dst) dst[i & 255] += t;
     }
@@ -623,7 +629,7 @@ kpd_status gvp_bwd(TT *T, const GvpP &g, int M, const float *s_in, int ld_s, con
         hipLaunchKernelGGL(k_gvp_vec16_bwd, dim3(blocks), dim3(256), 0, T->st, dV, B.Vh, B.sh, T->dsh, v_in, g.Wh.w, g.Wu.w, M, dv_in, T->part);
         KPD_LAUNCH_CHECK();
         if (g.Wu.g || g.Wh.g) {
-            hipLaunchKernelGGL(k_gvp_vec16_reduce, dim3(16), dim3(256), 0, T->st, T->part, 4 * blocks, g.Wu.g, g.Wh.g);
+            hipLaunchKernelGGL(k_gvp_vec16_reduce, dim3(32), dim3(256), 0, T->st, T->part, blocks, g.Wu.g, g.Wh.g);
             KPD_LAUNCH_CHECK();
         }
         return KPD_OK;
