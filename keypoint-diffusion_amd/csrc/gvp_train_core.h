@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void k_gvp_vec16_fwd(const float *__restrict__
 // Backward of the same half: dVh = dVu Wu^T + dsh Vh / sh (clamp inactive), dv_in = dVh Wh^T, and the two weight gradients
 // Wu.g += Vh^T dVu, Wh.g += v_in^T dVh.  The gradients are products over ROWS: their operands want "channel on lane & 15, row on (lane >> 4, r)",
 // the transpose of what a lane holds, so each 16 x 16 tile takes one trip through a 17-float-stride LDS tile of its wave.  Every wave adds
-// its groups in a fixed order, a workgroup adds its four waves in wave order and writes ONE partial per gradient; k_gvp_vec16_reduce adds
+// its groups in a fixed order, a workgroup adds its four waves in wave order and writes ONE partial per gradient; k_gvp_vec_reduce adds
 // the partials in workgroup order (no atomics).
 // dVh is not written: nothing else reads it.
 constexpr int VEC16_MAX_WAVES = 4096;
@@ -315,22 +315,209 @@ __global__ __launch_bounds__(256) void k_gvp_vec16_bwd(const float *__restrict__
     for (int i = threadIdx.x; i < 512; i += 256) p[i] = ((x0[i] + x0[512 + i]) + x0[1024 + i]) + x0[1536 + i];
 }
 
-// g_u[i] += sum over workgroups of part[b][i], g_h[i] += ... part[b][256 + i].  32 workgroups of 16 outputs x 16 slices: slice s adds
-// partials s, s + 16, ... in order, the sixteen slice sums are combined in slice order: a fixed tree.
-__global__ __launch_bounds__(256) void k_gvp_vec16_reduce(const float *__restrict__ part, int n_part, float *__restrict__ g_u, float *__restrict__ g_h) {
+// g_u[i] += sum over workgroups of part[b][i] (i < n_u), g_h[i - n_u] += ... (n_u <= i < n_u + n_h); partials `stride` floats apart.
+// Workgroups of 16 outputs x 16 slices: slice s adds partials s, s + 16, ... in order, the sixteen slice sums are combined in slice order:
+// a fixed tree.
+__global__ __launch_bounds__(256) void k_gvp_vec_reduce(const float *__restrict__ part, int n_part, int stride, int n_u, int n_h,
+                                                        float *__restrict__ g_u, float *__restrict__ g_h) {
     __shared__ float s_p[16][16];
     const int o = threadIdx.x & 15, sl = threadIdx.x >> 4, i = blockIdx.x * 16 + o;
     float s = 0.0f;
-    for (int b = sl; b < n_part; b += 16) s += part[(size_t)b * 512 + i];
+    if (i < n_u + n_h)
+        for (int b = sl; b < n_part; b += 16) s += part[(size_t)b * stride + i];
     s_p[sl][o] = s;
     __syncthreads();
-    if (sl == 0) {
+    if (sl == 0 && i < n_u + n_h) {
         float t = 0.0f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += s_p[k][o];
-        float *dst = i < 256 ? g_u : g_h;
-        if (dst) dst[i & 255] += t;
+        if (i < n_u) { if (g_u) g_u[i] += t; }
+        else if (g_h) g_h[i - n_u] += t;
     }
+}
+
+// ---- the message head GVP: 17 vector inputs [x_diff | 16 v_src], 17 hidden channels, 16 outputs (gvp.py:545, 395-415) -------------------
+// Same chained scheme on the 16 x 16 core (inputs 1 .. 16, hidden 0 .. 15); input channel 0 and hidden channel 16 are rank-1 / dot-product
+// updates on the VALU (a row's 16 core channels are spread over the four q-lanes: dots finish with two shuffles).  Rows are 17 floats
+// apart, so the core channels move as scalars (four per lane) instead of one float4.
+struct Head17W {
+    v4f core, w0, wc;             // A-fragment of the 16 x 16 core; W[0][4 q ..] (input 0 -> hidden core); W[1 + 4 q ..][16] (core inputs -> hidden 16)
+    float w016;                   // W[0][16]
+};
+__device__ __forceinline__ float sum_q(float v) {
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+__device__ __forceinline__ float sum_e(float v) {         // over the 16 rows of a lane group (same q)
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_gvp_vec17_fwd(const float *__restrict__ v_in, const float *__restrict__ Wh, const float *__restrict__ Wu,
+                                                       int M, float *__restrict__ Vh, float *__restrict__ Vu, float *__restrict__ sh) {
+    const int lane = threadIdx.x & 63, e = lane & 15, q = lane >> 4;
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), n_wv = gridDim.x * 4, G = (M + 15) >> 4;
+    v4f aWh, w0, wc, aWu, wu16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        aWh[r] = Wh[(1 + 4 * q + r) * 17 + e];            // hidden e <- input 1 + 4 q + r
+        w0[r] = Wh[4 * q + r];                             // hidden 4 q + r <- input 0
+        wc[r] = Wh[(1 + 4 * q + r) * 17 + 16];            // hidden 16 <- input 1 + 4 q + r
+        aWu[r] = Wu[(4 * q + r) * 16 + e];                // output e <- hidden 4 q + r
+        wu16[r] = Wu[16 * 16 + 4 * q + r];                // output 4 q + r <- hidden 16
+    }
+    const float w016 = Wh[16];
+    const v4f zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int g = wv; g < G; g += n_wv) {
+        const int m = 16 * g + e;
+        const bool on = m < M;
+        const size_t row0 = (size_t)min(m, M - 1) * 3;
+        v4f s2 = zero;
+        float s2_16 = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float *xr = v_in + (row0 + c) * 17;
+            float x0 = xr[0];
+            v4f xs;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xs[r] = xr[1 + 4 * q + r];
+            if (!on) { x0 = 0.0f; xs = zero; }
+            v4f vh = chain16(aWh, xs);
+            vh += x0 * w0;
+            const float vh16 = sum_q(xs[0] * wc[0] + xs[1] * wc[1] + xs[2] * wc[2] + xs[3] * wc[3]) + x0 * w016;
+            v4f vu = chain16(aWu, vh);
+            vu += vh16 * wu16;
+            s2 += vh * vh;
+            s2_16 = fmaf(vh16, vh16, s2_16);
+            if (on) {
+                float *oh = Vh + (row0 + c) * 17;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) oh[4 * q + r] = vh[r];
+                if (q == 0) oh[16] = vh16;
+                *reinterpret_cast<v4f *>(Vu + (row0 + c) * 16 + 4 * q) = vu;
+            }
+        }
+        if (on) {
+            float *os = sh + (size_t)m * 17;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) os[4 * q + r] = sqrtf(fmaxf(s2[r], 1e-8f));
+            if (q == 0) os[16] = sqrtf(fmaxf(s2_16, 1e-8f));
+        }
+    }
+}
+
+constexpr int VEC17_PART = 576;          // floats per partial: Wu.g [17][16] (272), Wh.g [17][17] (289), padding
+__global__ __launch_bounds__(256) void k_gvp_vec17_bwd(const float *__restrict__ dVu, const float *__restrict__ Vh, const float *__restrict__ sh,
+                                                       const float *__restrict__ dsh, const float *__restrict__ v_in,
+                                                       const float *__restrict__ Wh, const float *__restrict__ Wu, int M,
+                                                       float *__restrict__ dv_in, float *__restrict__ part) {
+    __shared__ float s_t[4][4][16 * 17];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, e = lane & 15, q = lane >> 4;
+    const int wv = blockIdx.x * 4 + wave, n_wv = gridDim.x * 4, G = (M + 15) >> 4;
+    v4f aWuT, wu16, aWhT, w0, wc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        aWuT[r] = Wu[e * 16 + 4 * q + r];                 // d hidden e <- d output 4 q + r
+        wu16[r] = Wu[16 * 16 + 4 * q + r];                // d hidden 16 <- d output 4 q + r
+        aWhT[r] = Wh[(1 + e) * 17 + 4 * q + r];           // d input 1 + e <- d hidden 4 q + r
+        w0[r] = Wh[4 * q + r];                             // d input 0 <- d hidden 4 q + r
+        wc[r] = Wh[(1 + 4 * q + r) * 17 + 16];            // d input 1 + 4 q + r <- d hidden 16
+    }
+    const float w016 = Wh[16];
+    const v4f zero = {0.f, 0.f, 0.f, 0.f};
+    v4f gWu = zero, gWh = zero;                            // MFMA blocks: Wu.g[j < 16][u], Wh.g[1 + i'][j < 16]
+    v4f gWu16 = zero, gWh0 = zero, gWhc = zero;            // per-lane sums: Wu.g[16][4 q ..], Wh.g[0][4 q ..], Wh.g[1 + 4 q ..][16]
+    float gWh016 = 0.0f;                                   // Wh.g[0][16] (q == 0 lanes only)
+    float *t_vh = s_t[wave][0], *t_du = s_t[wave][1], *t_x = s_t[wave][2], *t_g = s_t[wave][3];
+    auto put = [&](float *t, const v4f &v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[e * 17 + 4 * q + r] = v[r];
+    };
+    auto get = [&](const float *t) {
+        v4f v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = t[(4 * q + r) * 17 + e];
+        return v;
+    };
+#pragma unroll 1
+    for (int g = wv; g < G; g += n_wv) {
+        const int m = 16 * g + e;
+        const bool on = m < M;
+        const size_t mm = (size_t)min(m, M - 1);
+        v4f k;
+        float k16;
+        {
+            const float *sr = sh + mm * 17, *dr = dsh + mm * 17;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sv = sr[4 * q + r];
+                k[r] = (on && sv * sv > 1e-8f) ? dr[4 * q + r] / sv : 0.0f;
+            }
+            const float s16 = sr[16];
+            k16 = (on && s16 * s16 > 1e-8f) ? dr[16] / s16 : 0.0f;
+        }
+#pragma unroll 1
+        for (int c = 0; c < 3; ++c) {
+            const size_t row = mm * 3 + c;
+            v4f du = *reinterpret_cast<const v4f *>(dVu + row * 16 + 4 * q), vh, xs;
+            const float *hr = Vh + row * 17, *xr = v_in + row * 17;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { vh[r] = hr[4 * q + r]; xs[r] = xr[1 + 4 * q + r]; }
+            float vh16 = hr[16], x0 = xr[0];
+            if (!on) { du = zero; vh = zero; xs = zero; vh16 = 0.0f; x0 = 0.0f; }
+            v4f gh = chain16(aWuT, du);
+            gh += k * vh;
+            const float gh16 = sum_q(du[0] * wu16[0] + du[1] * wu16[1] + du[2] * wu16[2] + du[3] * wu16[3]) + k16 * vh16;
+            if (dv_in) {
+                v4f dxs = chain16(aWhT, gh);
+                dxs += gh16 * wc;
+                const float dx0 = sum_q(gh[0] * w0[0] + gh[1] * w0[1] + gh[2] * w0[2] + gh[3] * w0[3]) + gh16 * w016;
+                if (on) {
+                    float *od = dv_in + row * 17;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) od[1 + 4 * q + r] = dxs[r];
+                    if (q == 0) od[0] = dx0;
+                }
+            }
+            // weight gradients: the 16 x 16 blocks through transposed operands on the MFMA, the extra row / column as per-lane sums
+            put(t_vh, vh); put(t_du, du); put(t_x, xs); put(t_g, gh);
+            const v4f vhT = get(t_vh), duT = get(t_du), xT = get(t_x), gT = get(t_g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                gWu = __builtin_amdgcn_mfma_f32_16x16x4f32(vhT[r], duT[r], gWu, 0, 0, 0);       // [j][u] += Vh[row][j] dVu[row][u]
+                gWh = __builtin_amdgcn_mfma_f32_16x16x4f32(xT[r], gT[r], gWh, 0, 0, 0);        // [i'][j] += v_in[row][1 + i'] dVh[row][j]
+            }
+            gWu16 += vh16 * du;                            // Wu.g[16][u]   += Vh[row][16] dVu[row][u]
+            gWh0 += x0 * gh;                               // Wh.g[0][j]    += v_in[row][0] dVh[row][j]
+            gWhc += gh16 * xs;                             // Wh.g[1+i'][16] += v_in[row][1 + i'] dVh[row][16]
+            if (q == 0) gWh016 = fmaf(x0, gh16, gWh016);   // Wh.g[0][16]
+        }
+    }
+    // per-lane sums -> per-wave sums over the 16 rows of the lane group
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { gWu16[r] = sum_e(gWu16[r]); gWh0[r] = sum_e(gWh0[r]); gWhc[r] = sum_e(gWhc[r]); }
+    gWh016 = sum_e(gWh016);
+    __syncthreads();                                       // (the transpose tiles are free now: reused as the exchange buffer)
+    float *xw = &s_t[0][0][0] + wave * VEC17_PART;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        xw[(4 * q + r) * 16 + e] = gWu[r];                             // Wu.g[j = 4 q + r][u = e]
+        xw[272 + (1 + 4 * q + r) * 17 + e] = gWh[r];                   // Wh.g[1 + i'][j = e]
+        if (e == 0) {
+            xw[256 + 4 * q + r] = gWu16[r];                            // Wu.g[16][4 q + r]
+            xw[272 + 4 * q + r] = gWh0[r];                             // Wh.g[0][4 q + r]
+            xw[272 + (1 + 4 * q + r) * 17 + 16] = gWhc[r];             // Wh.g[1 + 4 q + r][16]
+        }
+    }
+    if (lane == 0) xw[272 + 16] = gWh016;                              // Wh.g[0][16]
+    __syncthreads();
+    const float *x0p = &s_t[0][0][0];
+    float *p = part + (size_t)blockIdx.x * VEC17_PART;
+    for (int i = threadIdx.x; i < 272 + 289; i += 256)
+        p[i] = ((x0p[i] + x0p[VEC17_PART + i]) + x0p[2 * VEC17_PART + i]) + x0p[3 * VEC17_PART + i];
 }
 
 inline bool vec_fused() {
@@ -568,7 +755,11 @@ kpd_status gvp_fwd(TT *T, const GvpP &g, int M, const float *s_in, int ld_s, con
     bool fused = false;
     if (vec_fused()) {          // the shapes the engines use: message head [x_diff | v_src] (17), plain (16), noise head (16 -> 1), encoder rk head (33)
         fused = true;
-        if (g.vi == 17 && g.h == 17 && g.vo == 16) KPD_TRY((launch_gvp_vec_fwd<17, 17, 16>(v_in, g.Wh.w, g.Wu.w, M, B.Vh, B.Vu, B.sh, T->st)));
+        if (g.vi == 17 && g.h == 17 && g.vo == 16) {
+            const int blocks = std::max(1, std::min(cdiv(cdiv(M, 16), 4), 4 * cu_count()));
+            hipLaunchKernelGGL(k_gvp_vec17_fwd, dim3(blocks), dim3(256), 0, T->st, v_in, g.Wh.w, g.Wu.w, M, B.Vh, B.Vu, B.sh);
+            KPD_LAUNCH_CHECK();
+        }
         else if (g.vi == 16 && g.h == 16 && g.vo == 16) {
             const int blocks = std::max(1, std::min(cdiv(cdiv(M, 16), 4), 4 * cu_count()));
             hipLaunchKernelGGL(k_gvp_vec16_fwd, dim3(blocks), dim3(256), 0, T->st, v_in, g.Wh.w, g.Wu.w, M, B.Vh, B.Vu, B.sh);
@@ -624,12 +815,22 @@ kpd_status gvp_bwd(TT *T, const GvpP &g, int M, const float *s_in, int ld_s, con
     // the sh block of to_feats_out, with the bias gradient (column sums of ds) riding along
     KPD_TRY(grad_gemm(T, g.so, g.h, M, ds, g.so, B.sh, g.h, g.Ws.g ? g.Ws.g + g.si : nullptr, g.si + g.h, g.bs.g));
     KPD_TRY(gemm(T, false, false, M, g.h, g.so, ds, g.so, g.Ws.w + g.si, g.si + g.h, 0.0f, T->dsh, g.h));
+    if (vec_fused() && g.vi == 17 && g.h == 17 && g.vo == 16 && T->part && T->part_floats >= (size_t)VEC16_MAX_WAVES * VEC17_PART) {
+        const int blocks = std::max(1, std::min(cdiv(cdiv(M, 16), 4), std::min(2 * cu_count(), VEC16_MAX_WAVES / 4)));
+        hipLaunchKernelGGL(k_gvp_vec17_bwd, dim3(blocks), dim3(256), 0, T->st, dV, B.Vh, B.sh, T->dsh, v_in, g.Wh.w, g.Wu.w, M, dv_in, T->part);
+        KPD_LAUNCH_CHECK();
+        if (g.Wu.g || g.Wh.g) {
+            hipLaunchKernelGGL(k_gvp_vec_reduce, dim3(cdiv(272 + 289, 16)), dim3(256), 0, T->st, T->part, blocks, VEC17_PART, 272, 289, g.Wu.g, g.Wh.g);
+            KPD_LAUNCH_CHECK();
+        }
+        return KPD_OK;
+    }
     if (vec_fused() && g.vi == 16 && g.h == 16 && g.vo == 16 && T->part && T->part_floats >= (size_t)VEC16_MAX_WAVES * 512) {
         const int blocks = std::max(1, std::min(cdiv(cdiv(M, 16), 4), std::min(2 * cu_count(), VEC16_MAX_WAVES / 4)));
         hipLaunchKernelGGL(k_gvp_vec16_bwd, dim3(blocks), dim3(256), 0, T->st, dV, B.Vh, B.sh, T->dsh, v_in, g.Wh.w, g.Wu.w, M, dv_in, T->part);
         KPD_LAUNCH_CHECK();
         if (g.Wu.g || g.Wh.g) {
-            hipLaunchKernelGGL(k_gvp_vec16_reduce, dim3(32), dim3(256), 0, T->st, T->part, blocks, g.Wu.g, g.Wh.g);
+            hipLaunchKernelGGL(k_gvp_vec_reduce, dim3(32), dim3(256), 0, T->st, T->part, blocks, 512, 256, 256, g.Wu.g, g.Wh.g);
             KPD_LAUNCH_CHECK();
         }
         return KPD_OK;
