@@ -22,6 +22,7 @@ namespace {
 
 constexpr int H = HW;         // 257
 constexpr int LD = HS;        // 264: row stride of every activation matrix
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 
 // ---- forward kernels ---------------------------------------------------------------------------------------------------
@@ -41,15 +42,32 @@ __global__ void k_geom(const int *__restrict__ src, const int *__restrict__ dst,
 
 // pre1[e] = U[src] + V[dst] + dij w_r + b1, a1 = SiLU(pre1): the first Linear of edge_mlp / coord_mlp on
 // f = [h_src, h_dst, dij] (dynamics.py:103-105) through its per-node halves.  w_r = W1[:, 514] (stride ldw).
-__global__ void k_edge_pre1(const float *__restrict__ U, const float *__restrict__ V, const int *__restrict__ src,
-                            const int *__restrict__ dst, const float *__restrict__ dij, const float *__restrict__ wr, int ldw,
-                            const float *__restrict__ b1, long long total, float *__restrict__ pre1, float *__restrict__ a1) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+// One thread per (edge, 4-column chunk): the two node rows, the radial weight column (staged contiguously in LDS with the bias) and both
+// outputs move as 16-byte pieces; columns 257 .. 263 of the outputs are written as zeros (the GEMMs read whole k-groups).
+__global__ __launch_bounds__(256) void k_edge_pre1(const float *__restrict__ U, const float *__restrict__ V, const int *__restrict__ src,
+                                                   const int *__restrict__ dst, const float *__restrict__ dij, const float *__restrict__ wr, int ldw,
+                                                   const float *__restrict__ b1, long long total, float *__restrict__ pre1, float *__restrict__ a1) {
+    __shared__ __attribute__((aligned(16))) float s_w[LD], s_b[LD];
+    for (int c = threadIdx.x; c < LD; c += 256) {
+        s_w[c] = c < H ? wr[(size_t)c * ldw] : 0.0f;
+        s_b[c] = c < H ? b1[c] : 0.0f;
+    }
+    __syncthreads();
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // total = E * (LD / 4)
     if (i >= total) return;
-    const int e = (int)(i / H), c = (int)(i - (long long)e * H);
-    const float v = U[(size_t)src[e] * LD + c] + V[(size_t)dst[e] * LD + c] + dij[e] * wr[(size_t)c * ldw] + b1[c];
-    pre1[(size_t)e * LD + c] = v;
-    a1[(size_t)e * LD + c] = silu_f(v);
+    const int e = (int)(i / (LD / 4)), c = 4 * (int)(i - (long long)e * (LD / 4));
+    const float d = dij[e];
+    const float4 u = *reinterpret_cast<const float4 *>(U + (size_t)src[e] * LD + c), v = *reinterpret_cast<const float4 *>(V + (size_t)dst[e] * LD + c);
+    const float4 w = *reinterpret_cast<const float4 *>(s_w + c), b = *reinterpret_cast<const float4 *>(s_b + c);
+    float4 p, a;
+    p.x = u.x + v.x + d * w.x + b.x;
+    p.y = c + 1 < H ? u.y + v.y + d * w.y + b.y : 0.0f;
+    p.z = c + 2 < H ? u.z + v.z + d * w.z + b.z : 0.0f;
+    p.w = c + 3 < H ? u.w + v.w + d * w.w + b.w : 0.0f;
+    if (c >= H) p.x = 0.0f;
+    a.x = silu_f(p.x); a.y = silu_f(p.y); a.z = silu_f(p.z); a.w = silu_f(p.w);
+    *reinterpret_cast<float4 *>(pre1 + (size_t)e * LD + c) = p;
+    *reinterpret_cast<float4 *>(a1 + (size_t)e * LD + c) = a;
 }
 
 
@@ -68,27 +86,69 @@ __global__ void k_rowdot(const float *__restrict__ A, const float *__restrict__ 
     }
 }
 
-// acc[v] += zinv[v] * sum over the edges of dst node v of M[e] * (w ? w[e] : 1): one workgroup per dst node
-// (copy_e + sum and the division by z, dynamics.py:177-192)
-// acc2 (optional): acc2[v] = sum over the same edges of M[e] * w2[e], from the same loads (no zinv, always "=")
-__global__ void k_segsum_rows(const float *__restrict__ M, const float *__restrict__ w, const int *__restrict__ rowptr,
-                              const float *__restrict__ zinv, int accumulate, float *__restrict__ acc, const float *__restrict__ w2,
-                              float *__restrict__ acc2) {
-    const int v = blockIdx.x;
-    const int e0 = rowptr[v], e1 = rowptr[v + 1];
-    if (e0 == e1 && accumulate && !acc2) return;
-    const float zi = zinv ? zinv[v] : 1.0f;
-    for (int c = threadIdx.x; c < H; c += blockDim.x) {
-        float s = 0.0f, s2 = 0.0f;
-        for (int e = e0; e < e1; ++e) {
-            const float m = M[(size_t)e * LD + c];
-            s = fmaf(m, w ? w[e] : 1.0f, s);
-            if (acc2) s2 = fmaf(m, w2[e], s2);
+// Segmented sums of E x 257 matrices over the edges of a node (copy_e + sum and the division by z, dynamics.py:177-192, and their
+// backward counterparts): one WAVE per node, a lane owns four columns (lane 0 column 256 too), rows are fetched four at a time and added
+// in edge order -- a fixed order per column.
+//   out[v]  (+)= (zinv ? zinv[v] : 1) * sum_j M[r_j] * (w ? w[r_j] : 1),  r_j = perm ? perm[j] : j,  j in [rowptr[v], rowptr[v + 1])
+//   out2[v]   =  sum_j M[r_j] * w2[r_j]      (optional, from the same loads)
+__global__ __launch_bounds__(256) void k_segsum264(const float *__restrict__ M, const float *__restrict__ w, const float *__restrict__ w2,
+                                                   const int *__restrict__ perm, const int *__restrict__ rowptr, const float *__restrict__ zinv,
+                                                   int accumulate, int n, float *__restrict__ out, float *__restrict__ out2) {
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (v >= n) return;
+    const int lo = rowptr[v], hi = rowptr[v + 1];
+    if (lo == hi && accumulate && !out2) return;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    float t = 0.0f, t2 = 0.0f;
+    auto add = [&](const f32x4 &m, float mt, float we, float we2) {
+        s[0] = fmaf(m[0], we, s[0]); s[1] = fmaf(m[1], we, s[1]); s[2] = fmaf(m[2], we, s[2]); s[3] = fmaf(m[3], we, s[3]);
+        t = fmaf(mt, we, t);
+        if (out2) {
+            s2[0] = fmaf(m[0], we2, s2[0]); s2[1] = fmaf(m[1], we2, s2[1]); s2[2] = fmaf(m[2], we2, s2[2]); s2[3] = fmaf(m[3], we2, s2[3]);
+            t2 = fmaf(mt, we2, t2);
         }
-        if (accumulate) {
-            if (e0 != e1) acc[(size_t)v * LD + c] += s * zi;
-        } else acc[(size_t)v * LD + c] = s * zi;
-        if (acc2) acc2[(size_t)v * LD + c] = s2;
+    };
+    int j = lo;
+    for (; j + 4 <= hi; j += 4) {
+        int r[4];
+        f32x4 m[4];
+        float mt[4], we[4], we2[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = perm ? perm[j + k] : j + k;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            m[k] = *reinterpret_cast<const f32x4 *>(M + (size_t)r[k] * LD + 4 * lane);
+            mt[k] = lane == 0 ? M[(size_t)r[k] * LD + 256] : 0.0f;
+            we[k] = w ? w[r[k]] : 1.0f;
+            we2[k] = out2 ? w2[r[k]] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) add(m[k], mt[k], we[k], we2[k]);
+    }
+    for (; j < hi; ++j) {
+        const int r = perm ? perm[j] : j;
+        const f32x4 m = *reinterpret_cast<const f32x4 *>(M + (size_t)r * LD + 4 * lane);
+        add(m, lane == 0 ? M[(size_t)r * LD + 256] : 0.0f, w ? w[r] : 1.0f, out2 ? w2[r] : 0.0f);
+    }
+    const float zi = zinv ? zinv[v] : 1.0f;
+    f32x4 *o = reinterpret_cast<f32x4 *>(out + (size_t)v * LD + 4 * lane);
+    if (accumulate) {
+        if (lo != hi) {
+            const f32x4 old = *o;
+            f32x4 nv;
+            nv[0] = old[0] + s[0] * zi; nv[1] = old[1] + s[1] * zi; nv[2] = old[2] + s[2] * zi; nv[3] = old[3] + s[3] * zi;
+            *o = nv;
+            if (lane == 0) out[(size_t)v * LD + 256] += t * zi;
+        }
+    } else {
+        f32x4 nv;
+        nv[0] = s[0] * zi; nv[1] = s[1] * zi; nv[2] = s[2] * zi; nv[3] = s[3] * zi;
+        *o = nv;
+        if (lane == 0) out[(size_t)v * LD + 256] = t * zi;
+    }
+    if (out2) {
+        *reinterpret_cast<f32x4 *>(out2 + (size_t)v * LD + 4 * lane) = s2;
+        if (lane == 0) out2[(size_t)v * LD + 256] = t2;
     }
 }
 
@@ -438,8 +498,8 @@ kpd_status edge_branch_fwd(kpd_egnn_trainer *T, const BranchParams &p, int et, c
     KPD_TRY(gemm(T, false, true, ns, H, H, hs, LD, p.W1.w, 2 * H + 1, 0.0f, T->nb[0], LD));
     KPD_TRY(gemm(T, false, true, nd, H, H, hd, LD, p.W1.w + H, 2 * H + 1, 0.0f, T->nb[1], LD));
     const long long tot = (long long)E * H;
-    hipLaunchKernelGGL(k_edge_pre1, grid1(tot), dim3(256), 0, T->st, T->nb[0], T->nb[1], T->e_src[et], T->e_dst[et], T->dij,
-                       p.W1.w + 2 * H, 2 * H + 1, p.b1.w, tot, T->eb[0], T->eb[1]);
+    hipLaunchKernelGGL(k_edge_pre1, grid1((long long)E * (LD / 4)), dim3(256), 0, T->st, T->nb[0], T->nb[1], T->e_src[et], T->e_dst[et], T->dij,
+                       p.W1.w + 2 * H, 2 * H + 1, p.b1.w, (long long)E * (LD / 4), T->eb[0], T->eb[1]);
     KPD_LAUNCH_CHECK();
     // pre2 = a1 W2^T + b2, a2 = SiLU(pre2): the weight-stationary GEMM with the activation fused (KPD_TRAIN_WS=0: general GEMM + kernel)
     if (use_ws())
@@ -489,8 +549,8 @@ kpd_status layer_fwd(kpd_egnn_trainer *T, int l) {
         if (use_ws()) hipLaunchKernelGGL(k_head_att, grid1(E), dim3(256), 0, T->st, T->ddpart, E, p.head_b.w, T->att);
         else hipLaunchKernelGGL(k_rowdot, dim3(cdiv(E, 4)), dim3(256), 0, T->st, T->eb[3], p.head.w, p.head_b.w, E, 1, T->att);
         KPD_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_segsum_rows, dim3(T->n[d]), dim3(256), 0, T->st, T->eb[3], T->att, T->e_rowptr[et], T->zinv[d], 1,
-                           T->hns[d][l], (const float *)nullptr, (float *)nullptr);
+        hipLaunchKernelGGL(k_segsum264, dim3(cdiv(T->n[d], 4)), dim3(256), 0, T->st, T->eb[3], T->att, (const float *)nullptr, (const int *)nullptr,
+                           T->e_rowptr[et], T->zinv[d], 1, T->n[d], T->hns[d][l], (float *)nullptr);
         KPD_LAUNCH_CHECK();
         bind_slot(T, l, et, 1);
         KPD_TRY(branch_params(T, l, et, 1, &p));
@@ -946,10 +1006,11 @@ kpd_status edge_branch_bwd(kpd_egnn_trainer *T, const BranchParams &p, int l, in
     // destination, so sum_e dpre1[e] = sum_v dV[v] (rides along with the dV^T h_dst product) and sum_e dpre1[e] d_e = sum_v dVw[v], where dVw
     // comes out of the same pass over dpre1 as dV.  One E x 257 pass fewer per branch.
     float *dU = T->nb[0], *dV = T->nb[1], *dVw = T->nb[2];
-    hipLaunchKernelGGL(k_segsum_perm, dim3(ns), dim3(256), 0, T->st, dpre1, LD, 0, H, T->scsr[et].perm, T->scsr[et].rowptr, 1.0f, 0, dU, LD);
+    hipLaunchKernelGGL(k_segsum264, dim3(cdiv(ns, 4)), dim3(256), 0, T->st, dpre1, (const float *)nullptr, (const float *)nullptr, T->scsr[et].perm,
+                       T->scsr[et].rowptr, (const float *)nullptr, 0, ns, dU, (float *)nullptr);
     KPD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_segsum_rows, dim3(nd), dim3(256), 0, T->st, dpre1, (const float *)nullptr, T->e_rowptr[et],
-                       (const float *)nullptr, 0, dV, (const float *)T->dij, p.W1.g ? dVw : (float *)nullptr);
+    hipLaunchKernelGGL(k_segsum264, dim3(cdiv(nd, 4)), dim3(256), 0, T->st, dpre1, (const float *)nullptr, (const float *)T->dij, (const int *)nullptr,
+                       T->e_rowptr[et], (const float *)nullptr, 0, nd, dV, p.W1.g ? dVw : (float *)nullptr);
     KPD_LAUNCH_CHECK();
     const float *hsrc = T->hs[s][l], *hdst = T->hs[d][l];
     if (p.W1.g) {
