@@ -42,11 +42,12 @@ __global__ void k_geom(const int *__restrict__ src, const int *__restrict__ dst,
 
 // pre1[e] = U[src] + V[dst] + dij w_r + b1, a1 = SiLU(pre1): the first Linear of edge_mlp / coord_mlp on
 // f = [h_src, h_dst, dij] (dynamics.py:103-105) through its per-node halves.  w_r = W1[:, 514] (stride ldw).
-// One thread per (edge, 4-column chunk): the two node rows, the radial weight column (staged contiguously in LDS with the bias) and both
+// One thread per (edge, 4-column chunk): the two node rows (U, V: row stride ldu -- slots of the layer's projection block), the radial weight column (staged contiguously in LDS with the bias) and both
 // outputs move as 16-byte pieces; columns 257 .. 263 of the outputs are written as zeros (the GEMMs read whole k-groups).
 __global__ __launch_bounds__(256) void k_edge_pre1(const float *__restrict__ U, const float *__restrict__ V, const int *__restrict__ src,
                                                    const int *__restrict__ dst, const float *__restrict__ dij, const float *__restrict__ wr, int ldw,
-                                                   const float *__restrict__ b1, long long total, float *__restrict__ pre1, float *__restrict__ a1) {
+                                                   const float *__restrict__ b1, long long total, int ldu, float *__restrict__ pre1,
+                                                   float *__restrict__ a1) {
     __shared__ __attribute__((aligned(16))) float s_w[LD], s_b[LD];
     for (int c = threadIdx.x; c < LD; c += 256) {
         s_w[c] = c < H ? wr[(size_t)c * ldw] : 0.0f;
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void k_edge_pre1(const float *__restrict__ U, 
     if (i >= total) return;
     const int e = (int)(i / (LD / 4)), c = 4 * (int)(i - (long long)e * (LD / 4));
     const float d = dij[e];
-    const float4 u = *reinterpret_cast<const float4 *>(U + (size_t)src[e] * LD + c), v = *reinterpret_cast<const float4 *>(V + (size_t)dst[e] * LD + c);
+    const float4 u = *reinterpret_cast<const float4 *>(U + (size_t)src[e] * ldu + c), v = *reinterpret_cast<const float4 *>(V + (size_t)dst[e] * ldu + c);
     const float4 w = *reinterpret_cast<const float4 *>(s_w + c), b = *reinterpret_cast<const float4 *>(s_b + c);
     float4 p, a;
     p.x = u.x + v.x + d * w.x + b.x;
@@ -90,10 +91,10 @@ __global__ void k_rowdot(const float *__restrict__ A, const float *__restrict__ 
 // backward counterparts): one WAVE per node, a lane owns four columns (lane 0 column 256 too), rows are fetched four at a time and added
 // in edge order -- a fixed order per column.
 //   out[v]  (+)= (zinv ? zinv[v] : 1) * sum_j M[r_j] * (w ? w[r_j] : 1),  r_j = perm ? perm[j] : j,  j in [rowptr[v], rowptr[v + 1])
-//   out2[v]   =  sum_j M[r_j] * w2[r_j]      (optional, from the same loads)
+//   out2[v]   =  sum_j M[r_j] * w2[r_j]      (optional, from the same loads);  out / out2 rows are ldo floats apart
 __global__ __launch_bounds__(256) void k_segsum264(const float *__restrict__ M, const float *__restrict__ w, const float *__restrict__ w2,
                                                    const int *__restrict__ perm, const int *__restrict__ rowptr, const float *__restrict__ zinv,
-                                                   int accumulate, int n, float *__restrict__ out, float *__restrict__ out2) {
+                                                   int accumulate, int n, float *__restrict__ out, float *__restrict__ out2, int ldo) {
     const int v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (v >= n) return;
     const int lo = rowptr[v], hi = rowptr[v + 1];
@@ -131,24 +132,24 @@ __global__ __launch_bounds__(256) void k_segsum264(const float *__restrict__ M, 
         add(m, lane == 0 ? M[(size_t)r * LD + 256] : 0.0f, w ? w[r] : 1.0f, out2 ? w2[r] : 0.0f);
     }
     const float zi = zinv ? zinv[v] : 1.0f;
-    f32x4 *o = reinterpret_cast<f32x4 *>(out + (size_t)v * LD + 4 * lane);
+    f32x4 *o = reinterpret_cast<f32x4 *>(out + (size_t)v * ldo + 4 * lane);
     if (accumulate) {
         if (lo != hi) {
             const f32x4 old = *o;
             f32x4 nv;
             nv[0] = old[0] + s[0] * zi; nv[1] = old[1] + s[1] * zi; nv[2] = old[2] + s[2] * zi; nv[3] = old[3] + s[3] * zi;
             *o = nv;
-            if (lane == 0) out[(size_t)v * LD + 256] += t * zi;
+            if (lane == 0) out[(size_t)v * ldo + 256] += t * zi;
         }
     } else {
         f32x4 nv;
         nv[0] = s[0] * zi; nv[1] = s[1] * zi; nv[2] = s[2] * zi; nv[3] = s[3] * zi;
         *o = nv;
-        if (lane == 0) out[(size_t)v * LD + 256] = t * zi;
+        if (lane == 0) out[(size_t)v * ldo + 256] = t * zi;
     }
     if (out2) {
-        *reinterpret_cast<f32x4 *>(out2 + (size_t)v * LD + 4 * lane) = s2;
-        if (lane == 0) out2[(size_t)v * LD + 256] = t2;
+        *reinterpret_cast<f32x4 *>(out2 + (size_t)v * ldo + 4 * lane) = s2;
+        if (lane == 0) out2[(size_t)v * ldo + 256] = t2;
     }
 }
 
@@ -408,6 +409,42 @@ __global__ void k_geom_bwd(const float *__restrict__ ddij, const float *__restri
 
 
 
+// ---- the first Linear of every edge MLP of a layer, batched per node type --------------------------------------------------------
+// pre1 = U[src] + V[dst] + ... with U = h_src W1[:, :257]^T, V = h_dst W1[:, 257:514]^T: a layer has up to 8 such per-node products
+// per node type (4 edge types x 2 branches x {src, dst} over 2 node types).  Their weight blocks are staged side by side
+// (wcat [slot][264][264], zero padded), so that per node type ONE product gives all projections (ucat [n][slot][264], the layout of the
+// inference engine's P), ONE product adds all their contributions to dh (ducat . wcat) and ONE gives all weight gradients
+// (ducat^T h, with the b1 gradients as its column sums) -- instead of 8 ligand-sized products each, which ran at a fraction of the
+// GPU (13 row tiles) and paid a split-K reduction apiece.
+struct CatSlot {
+    const float *w;             // W1 of the branch [257][515]
+    float *g, *bg;              // its gradient (or null); b1 gradient (dst slots, or null)
+    int col0, nt, slot, dvw;    // first column of the block in W1; node type; slot in wcat[nt]; index of the slot among the dst slots of nt (-1: src)
+};
+struct CatTab {
+    CatSlot s[16];
+    int n;
+};
+constexpr int CAT_LD = NSLOT * LD;            // row stride of ucat / ducat
+__global__ void k_cat_stage(CatTab t, float *__restrict__ wcat0, float *__restrict__ wcat1) {
+    const CatSlot &e = t.s[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= LD * LD) return;
+    const int r = i / LD, c = i - r * LD;
+    (e.nt ? wcat1 : wcat0)[(size_t)e.slot * LD * LD + i] = (r < H && c < H) ? e.w[(size_t)r * (2 * H + 1) + e.col0 + c] : 0.0f;
+}
+// W1.g[:, block] += dwcat[slot]; b1.g += column sums of dV (dbcat); W1.g[:, 514] += column sums of dVw (dwr).  One thread per element.
+__global__ void k_cat_scatter(CatTab t, const float *__restrict__ dwcat0, const float *__restrict__ dwcat1, const float *__restrict__ dbcat0,
+                              const float *__restrict__ dbcat1, const float *__restrict__ dwr0, const float *__restrict__ dwr1) {
+    const CatSlot &e = t.s[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= H * LD) return;
+    const int r = i / LD, c = i - r * LD;
+    if (c < H && e.g) e.g[(size_t)r * (2 * H + 1) + e.col0 + c] += (e.nt ? dwcat1 : dwcat0)[((size_t)e.slot * LD + r) * LD + c];
+    if (c == H && e.bg) e.bg[r] += (e.nt ? dbcat1 : dbcat0)[e.slot * LD + r];
+    if (c == H + 1 && e.dvw >= 0 && e.g) e.g[(size_t)r * (2 * H + 1) + 2 * H] += (e.nt ? dwr1 : dwr0)[e.dvw * LD + r];
+}
+
 }  // namespace
 }  // namespace kpd
 
@@ -454,6 +491,13 @@ struct kpd_egnn_trainer : TrainCtx {
     bool store = false;
     char *store_base = nullptr;
     std::vector<Slot> slots;                       // [layer * 4 + et]
+    // batched first-layer products of the current layer (k_cat_stage): staged weights, projections, per-node gradients and their staging
+    float *wcat[2] = {nullptr, nullptr}, *ucat[2] = {nullptr, nullptr}, *ducat[2] = {nullptr, nullptr}, *dvwcat[2] = {nullptr, nullptr},
+          *dwcat[2] = {nullptr, nullptr}, *dbcat[2] = {nullptr, nullptr}, *dwr[2] = {nullptr, nullptr};
+    CatTab cat{};
+    int cat_slots[2] = {0, 0}, cat_dvw[2] = {0, 0};
+    int cat_of[4][2][2] = {}, cat_dvw_of[4][2] = {};   // [et][branch][src | dst] -> slot on that side's node type; [et][branch] -> dvw index
+    std::vector<float *> nq[2][3];                 // kept node-MLP activations q1, c1, q2 of every (node type, layer), with the edge activations
     Slot scratch;                                  // the recomputation buffers (one edge type, one branch at a time)
     float *dh[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}, *dx[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     float *enc1[2] = {nullptr, nullptr}, *enc2[2] = {nullptr, nullptr}, *dec1 = nullptr, *dec2 = nullptr;   // encoder / decoder scratch
@@ -491,15 +535,15 @@ kpd_status branch_params(kpd_egnn_trainer *T, int layer, int et, int branch, Bra
     return KPD_OK;
 }
 
-// eb[0] = pre1, eb[1] = a1, eb[2] = pre2 (+ bias), eb[3] = a2 for the E edges of `et`; nb[0] = U, nb[1] = V
+// eb[0] = pre1, eb[1] = a1, eb[2] = pre2 (+ bias), eb[3] = a2 for the E edges of `et`; U, V: the branch's slots of the layer's projection
+// blocks (layer_project)
 // head_part (weight-stationary path only): the two half-row shares of a2 . head.w, [2][E], from the GEMM's epilogue
-kpd_status edge_branch_fwd(kpd_egnn_trainer *T, const BranchParams &p, int et, const float *hs, const float *hd, float *head_part = nullptr) {
-    const int E = T->E[et], ns = T->n[kS[et]], nd = T->n[kD[et]];
-    KPD_TRY(gemm(T, false, true, ns, H, H, hs, LD, p.W1.w, 2 * H + 1, 0.0f, T->nb[0], LD));
-    KPD_TRY(gemm(T, false, true, nd, H, H, hd, LD, p.W1.w + H, 2 * H + 1, 0.0f, T->nb[1], LD));
+kpd_status edge_branch_fwd(kpd_egnn_trainer *T, const BranchParams &p, int et, int branch, float *head_part = nullptr) {
+    const int E = T->E[et];
+    const float *U = T->ucat[kS[et]] + (size_t)T->cat_of[et][branch][0] * LD, *V = T->ucat[kD[et]] + (size_t)T->cat_of[et][branch][1] * LD;
     const long long tot = (long long)E * H;
-    hipLaunchKernelGGL(k_edge_pre1, grid1((long long)E * (LD / 4)), dim3(256), 0, T->st, T->nb[0], T->nb[1], T->e_src[et], T->e_dst[et], T->dij,
-                       p.W1.w + 2 * H, 2 * H + 1, p.b1.w, (long long)E * (LD / 4), T->eb[0], T->eb[1]);
+    hipLaunchKernelGGL(k_edge_pre1, grid1((long long)E * (LD / 4)), dim3(256), 0, T->st, U, V, T->e_src[et], T->e_dst[et], T->dij,
+                       p.W1.w + 2 * H, 2 * H + 1, p.b1.w, (long long)E * (LD / 4), CAT_LD, T->eb[0], T->eb[1]);
     KPD_LAUNCH_CHECK();
     // pre2 = a1 W2^T + b2, a2 = SiLU(pre2): the weight-stationary GEMM with the activation fused (KPD_TRAIN_WS=0: general GEMM + kernel)
     if (use_ws())
@@ -531,6 +575,70 @@ void bind_slot(kpd_egnn_trainer *T, int l, int et, int branch) {
     T->att = sl.att; T->dij = sl.dij; T->xdiff = sl.xdiff; T->nvec = sl.nvec; T->sc = sl.sc; T->msgx = sl.msgx;
 }
 
+// slots of layer l (edge types without edges get none), the staged weight blocks, and -- forward -- the projections of both node types
+kpd_status layer_stage(kpd_egnn_trainer *T, int l) {
+    CatTab &t = T->cat;
+    t.n = 0;
+    T->cat_slots[0] = T->cat_slots[1] = T->cat_dvw[0] = T->cat_dvw[1] = 0;
+    for (int et = 0; et < layer_n_et(T, l); ++et) {
+        if (T->E[et] == 0) continue;
+        for (int br = 0; br < 2; ++br) {
+            BranchParams p;
+            KPD_TRY(branch_params(T, l, et, br, &p));
+            for (int side = 0; side < 2; ++side) {
+                const int nt = side ? kD[et] : kS[et];
+                CatSlot &e = t.s[t.n++];
+                e.w = p.W1.w; e.g = p.W1.g; e.bg = side ? p.b1.g : nullptr;
+                e.col0 = side * H; e.nt = nt; e.slot = T->cat_slots[nt]++;
+                e.dvw = side ? T->cat_dvw[nt]++ : -1;
+                T->cat_of[et][br][side] = e.slot;
+                if (side) T->cat_dvw_of[et][br] = e.dvw;
+            }
+        }
+    }
+    if (t.n == 0) return KPD_OK;
+    hipLaunchKernelGGL(k_cat_stage, dim3(cdiv(LD * LD, 256), t.n), dim3(256), 0, T->st, t, T->wcat[0], T->wcat[1]);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+kpd_status layer_project(kpd_egnn_trainer *T, int l) {
+    for (int nt = 0; nt < 2; ++nt)
+        if (T->cat_slots[nt])
+            KPD_TRY(gemm(T, false, true, T->n[nt], T->cat_slots[nt] * LD, H, T->hs[nt][l], LD, T->wcat[nt], LD, 0.0f, T->ucat[nt], CAT_LD));
+    return KPD_OK;
+}
+
+// after the edge types of layer l: the weight gradients of all first Linears and their contributions to dh, one product each per node type
+kpd_status layer_cat_bwd(kpd_egnn_trainer *T, int l, int nxt) {
+    const CatTab &t = T->cat;
+    if (t.n == 0) return KPD_OK;
+    bool want = false;
+    for (int i = 0; i < t.n; ++i) want = want || t.s[i].g || t.s[i].bg;
+    for (int nt = 0; nt < 2; ++nt) {
+        const int ns = T->cat_slots[nt], n = T->n[nt];
+        if (!ns) continue;
+        if (want) {
+            KPD_HIP(hipMemsetAsync(T->dbcat[nt], 0, (size_t)NSLOT * LD * 4, T->st));
+            KPD_TRY(sgemm(true, false, ns * LD, H, n, 1.0f, T->ducat[nt], CAT_LD, T->hs[nt][l], LD, 0.0f, T->dwcat[nt], LD, T->st, T->part, T->part_floats,
+                          T->dbcat[nt]));
+            if (T->cat_dvw[nt]) {
+                const int cols = T->cat_dvw[nt] * LD;
+                KPD_HIP(hipMemsetAsync(T->dwr[nt], 0, (size_t)NSLOT * LD * 4, T->st));
+                for (int c0 = 0; c0 < cols; c0 += COLSUM_LD)
+                    KPD_TRY(colsum_acc(T, n, std::min(COLSUM_LD, cols - c0), T->dvwcat[nt] + c0, CAT_LD, T->dwr[nt] + c0));
+            }
+        }
+        KPD_TRY(gemm(T, false, false, n, H, ns * LD, T->ducat[nt], CAT_LD, T->wcat[nt], LD, 1.0f, T->dh[nxt][nt], LD));
+    }
+    if (want) {
+        hipLaunchKernelGGL(k_cat_scatter, dim3(cdiv(H * LD, 256), t.n), dim3(256), 0, T->st, t, T->dwcat[0], T->dwcat[1], T->dbcat[0], T->dbcat[1],
+                           T->dwr[0], T->dwr[1]);
+        KPD_LAUNCH_CHECK();
+    }
+    return KPD_OK;
+}
+
 // one LigRecConv layer forward (dynamics.py:124-207) from the saved inputs hs[l], xs[l] into hs[l+1], xs[l+1], hns[l], xns[l]
 kpd_status layer_fwd(kpd_egnn_trainer *T, int l) {
     const kpd_egnn_config &c = T->cfg;
@@ -538,6 +646,8 @@ kpd_status layer_fwd(kpd_egnn_trainer *T, int l) {
         KPD_HIP(hipMemsetAsync(T->hns[k][l], 0, (size_t)T->n[k] * LD * 4, T->st));
         KPD_HIP(hipMemsetAsync(T->xns[k][l], 0, (size_t)T->n[k] * 12, T->st));
     }
+    KPD_TRY(layer_stage(T, l));
+    KPD_TRY(layer_project(T, l));
     for (int et = 0; et < layer_n_et(T, l); ++et) {
         const int E = T->E[et], s = kS[et], d = kD[et];
         if (E == 0) continue;
@@ -545,16 +655,16 @@ kpd_status layer_fwd(kpd_egnn_trainer *T, int l) {
         KPD_TRY(geom_fwd(T, et, T->xs[s][l], T->xs[d][l]));
         BranchParams p;
         KPD_TRY(branch_params(T, l, et, 0, &p));
-        KPD_TRY(edge_branch_fwd(T, p, et, T->hs[s][l], T->hs[d][l], use_ws() ? T->ddpart : nullptr));
+        KPD_TRY(edge_branch_fwd(T, p, et, 0, use_ws() ? T->ddpart : nullptr));
         if (use_ws()) hipLaunchKernelGGL(k_head_att, grid1(E), dim3(256), 0, T->st, T->ddpart, E, p.head_b.w, T->att);
         else hipLaunchKernelGGL(k_rowdot, dim3(cdiv(E, 4)), dim3(256), 0, T->st, T->eb[3], p.head.w, p.head_b.w, E, 1, T->att);
         KPD_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_segsum264, dim3(cdiv(T->n[d], 4)), dim3(256), 0, T->st, T->eb[3], T->att, (const float *)nullptr, (const int *)nullptr,
-                           T->e_rowptr[et], T->zinv[d], 1, T->n[d], T->hns[d][l], (float *)nullptr);
+                           T->e_rowptr[et], T->zinv[d], 1, T->n[d], T->hns[d][l], (float *)nullptr, LD);
         KPD_LAUNCH_CHECK();
         bind_slot(T, l, et, 1);
         KPD_TRY(branch_params(T, l, et, 1, &p));
-        KPD_TRY(edge_branch_fwd(T, p, et, T->hs[s][l], T->hs[d][l], use_ws() ? T->ddpart : nullptr));
+        KPD_TRY(edge_branch_fwd(T, p, et, 1, use_ws() ? T->ddpart : nullptr));
         if (use_ws())
             hipLaunchKernelGGL(k_coord_msg_parts, grid1(E), dim3(256), 0, T->st, T->ddpart, T->nvec, E, c.use_tanh, c.coords_range, T->sc, T->msgx);
         else
@@ -585,12 +695,19 @@ kpd_status node_params(kpd_egnn_trainer *T, int l, int nt, NodeParams *p) {
     return KPD_OK;
 }
 
-// node MLP of layer l for node type nt: nb[2] = q1 (+ bias), nb[3] = c1 = SiLU(q1), nb[4] = q2 (without its bias)
-kpd_status node_mlp_fwd(kpd_egnn_trainer *T, const NodeParams &p, int l, int nt) {
+// node MLP of layer l for node type nt: q[0] = q1 (+ bias), q[1] = c1 = SiLU(q1), q[2] = q2 (without its bias) -- the kept buffers of
+// (nt, l), or nb[2..4] when nothing is kept
+struct NodeAct { float *q[3]; };
+inline NodeAct node_act(kpd_egnn_trainer *T, int l, int nt) {
+    NodeAct a;
+    for (int k = 0; k < 3; ++k) a.q[k] = T->store ? T->nq[nt][k][l] : T->nb[2 + k];
+    return a;
+}
+kpd_status node_mlp_fwd(kpd_egnn_trainer *T, const NodeParams &p, int l, int nt, const NodeAct &a) {
     const int n = T->n[nt];
-    KPD_TRY(gemm(T, false, true, n, H, H, T->hs[nt][l], LD, p.W1.w, 2 * H, 0.0f, T->nb[2], LD));
-    KPD_TRY(gemm(T, false, true, n, H, H, T->hns[nt][l], LD, p.W1.w + H, 2 * H, 1.0f, T->nb[2], LD, 1.0f, nullptr, p.b1.w, T->nb[3]));      // + bias, SiLU -> nb[3]
-    KPD_TRY(gemm(T, false, true, n, H, H, T->nb[3], LD, p.W2.w, H, 0.0f, T->nb[4], LD));
+    KPD_TRY(gemm(T, false, true, n, H, H, T->hs[nt][l], LD, p.W1.w, 2 * H, 0.0f, a.q[0], LD));
+    KPD_TRY(gemm(T, false, true, n, H, H, T->hns[nt][l], LD, p.W1.w + H, 2 * H, 1.0f, a.q[0], LD, 1.0f, nullptr, p.b1.w, a.q[1]));      // + bias, SiLU -> c1
+    KPD_TRY(gemm(T, false, true, n, H, H, a.q[1], LD, p.W2.w, H, 0.0f, a.q[2], LD));
     return KPD_OK;
 }
 
@@ -605,8 +722,9 @@ kpd_status nodes_fwd(kpd_egnn_trainer *T, int l) {
         if (nt >= layer_n_upd(T, l)) continue;       // final layer: the keypoint output is never read
         NodeParams p;
         KPD_TRY(node_params(T, l, nt, &p));
-        KPD_TRY(node_mlp_fwd(T, p, l, nt));
-        hipLaunchKernelGGL(k_node_out, dim3(cdiv(n, 4)), dim3(256), 0, T->st, T->hs[nt][l], T->nb[4], p.b2.w, p.gamma.w, p.beta.w,
+        const NodeAct na = node_act(T, l, nt);
+        KPD_TRY(node_mlp_fwd(T, p, l, nt, na));
+        hipLaunchKernelGGL(k_node_out, dim3(cdiv(n, 4)), dim3(256), 0, T->st, T->hs[nt][l], na.q[2], p.b2.w, p.gamma.w, p.beta.w,
                            T->cfg.norm, n, T->cfg.hidden_nf, T->hs[nt][l + 1]);
         KPD_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_axpy3, grid1(3 * n), dim3(256), 0, T->st, T->xs[nt][l], T->xns[nt][l], 3 * n, T->xs[nt][l + 1]);
@@ -769,6 +887,11 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
     for (int k = 0; k < 6; ++k) add((size_t)cap_E * LD, 4);
     for (int k = 0; k < 7; ++k) add((size_t)cap_N * LD, 4);
     add((size_t)cap_N * ENC_LD, 4);
+    for (int nt = 0; nt < 2; ++nt) {
+        for (int k = 0; k < 3; ++k) add((size_t)nn[nt] * CAT_LD, 4);              // ucat, ducat, dvwcat
+        add((size_t)NSLOT * LD * LD, 4); add((size_t)NSLOT * LD * LD, 4);          // wcat, dwcat
+        add((size_t)NSLOT * LD, 4); add((size_t)NSLOT * LD, 4);                    // dbcat, dwr
+    }
     add((size_t)ws_gemm_pack_floats(), 4);
     add(GRAD_PART_FLOATS, 4);
     for (int k = 0; k < 3; ++k) add((size_t)cap_E * 3, 4);      // xdiff, nvec, dn
@@ -803,6 +926,18 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
     for (int k = 0; k < 6; ++k) T->eb[k] = W.take<float>((size_t)cap_E * LD);
     for (int k = 0; k < 7; ++k) T->nb[k] = W.take<float>((size_t)cap_N * LD);
     T->dact = W.take<float>((size_t)cap_N * ENC_LD);
+    for (int nt = 0; nt < 2; ++nt) {
+        T->ucat[nt] = W.take<float>((size_t)nn[nt] * CAT_LD);
+        T->ducat[nt] = W.take<float>((size_t)nn[nt] * CAT_LD);
+        T->dvwcat[nt] = W.take<float>((size_t)nn[nt] * CAT_LD);
+        T->wcat[nt] = W.take<float>((size_t)NSLOT * LD * LD);
+        T->dwcat[nt] = W.take<float>((size_t)NSLOT * LD * LD);
+        T->dbcat[nt] = W.take<float>((size_t)NSLOT * LD);
+        T->dwr[nt] = W.take<float>((size_t)NSLOT * LD);
+        // (the padding columns 257 .. 263 of every slot are never written by the segmented sums and are read by the products: zeros)
+        KPD_HIP(hipMemset(T->ducat[nt], 0, (size_t)nn[nt] * CAT_LD * 4));
+        KPD_HIP(hipMemset(T->dvwcat[nt], 0, (size_t)nn[nt] * CAT_LD * 4));
+    }
     T->wsg_pack = W.take<float>((size_t)ws_gemm_pack_floats());
     T->part_floats = GRAD_PART_FLOATS;
     T->part = W.take<float>(T->part_floats);
@@ -841,6 +976,7 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
         auto al = [](size_t floats) { return (floats * 4 + 255) & ~size_t(255); };
         size_t per_layer = 0;
         for (int et = 0; et < T->n_et; ++et) per_layer += 8 * al((size_t)cap_et[et] * LD) + 3 * al(cap_et[et]) + 3 * al((size_t)cap_et[et] * 3);
+        for (int nt = 0; nt < T->n_upd; ++nt) per_layer += 3 * al((size_t)nn[nt] * LD);
         const size_t total = per_layer * L;
         if (want && hipMalloc(reinterpret_cast<void **>(&T->store_base), total) == hipSuccess) {
             T->store = true;
@@ -854,6 +990,12 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
                         for (int k = 0; k < 4; ++k) sl.e[br][k] = take((size_t)cap_et[et] * LD);
                     sl.att = take(cap_et[et]); sl.dij = take(cap_et[et]); sl.sc = take(cap_et[et]);
                     sl.xdiff = take((size_t)cap_et[et] * 3); sl.nvec = take((size_t)cap_et[et] * 3); sl.msgx = take((size_t)cap_et[et] * 3);
+                }
+            for (int nt = 0; nt < 2; ++nt)
+                for (int k = 0; k < 3; ++k) {
+                    T->nq[nt][k].assign(L, nullptr);
+                    if (nt < T->n_upd)
+                        for (int l = 0; l < L; ++l) T->nq[nt][k][l] = take((size_t)nn[nt] * LD);
                 }
         } else {
             (void)hipGetLastError();              // a failed allocation is not an error: recompute instead
@@ -958,20 +1100,21 @@ kpd_status node_bwd(kpd_egnn_trainer *T, int l, int nt, int cur, int nxt, float 
     const int n = T->n[nt];
     NodeParams p;
     KPD_TRY(node_params(T, l, nt, &p));
-    KPD_TRY(node_mlp_fwd(T, p, l, nt));                  // nb[2] = q1, nb[3] = c1, nb[4] = q2
+    const NodeAct na = node_act(T, l, nt);
+    if (!T->store) KPD_TRY(node_mlp_fwd(T, p, l, nt, na));          // (kept otherwise)
     float *du = T->nb[0], *tmp = T->nb[1];
     const float *dy = T->dh[cur][nt];
     if (T->cfg.norm) {
-        hipLaunchKernelGGL(k_ln_bwd, dim3(cdiv(n, 4)), dim3(256), 0, T->st, T->hs[nt][l], T->nb[4], p.b2.w, p.gamma.w, dy, n, T->cfg.hidden_nf, du, tmp);
+        hipLaunchKernelGGL(k_ln_bwd, dim3(cdiv(n, 4)), dim3(256), 0, T->st, T->hs[nt][l], na.q[2], p.b2.w, p.gamma.w, dy, n, T->cfg.hidden_nf, du, tmp);
         KPD_LAUNCH_CHECK();
         KPD_TRY(colsum_acc(T, n, H, tmp, LD, p.gamma.g));
         KPD_TRY(colsum_acc(T, n, H, dy, LD, p.beta.g));
     } else {
         KPD_HIP(hipMemcpyAsync(du, dy, (size_t)n * LD * 4, hipMemcpyDeviceToDevice, T->st));
     }
-    KPD_TRY(grad_gemm(T, H, H, n, du, LD, T->nb[3], LD, p.W2.g, H, p.b2.g));
+    KPD_TRY(grad_gemm(T, H, H, n, du, LD, na.q[1], LD, p.W2.g, H, p.b2.g));
     float *dq1 = tmp;
-    KPD_TRY(gemm(T, false, false, n, H, H, du, LD, p.W2.w, H, 0.0f, dq1, LD, 1.0f, T->nb[2]));                    // * SiLU'(pre) in the epilogue
+    KPD_TRY(gemm(T, false, false, n, H, H, du, LD, p.W2.w, H, 0.0f, dq1, LD, 1.0f, na.q[0]));                    // * SiLU'(pre) in the epilogue
     KPD_TRY(grad_gemm(T, H, H, n, dq1, LD, T->hs[nt][l], LD, p.W1.g, 2 * H, p.b1.g));
     if (p.W1.g) KPD_TRY(grad_gemm(T, H, H, n, dq1, LD, T->hns[nt][l], LD, p.W1.g + H, 2 * H));
     // dh_in = du (residual) + dq1 W1[:, :257];  d(h_neigh / z) = dq1 W1[:, 257:]
@@ -983,8 +1126,9 @@ kpd_status node_bwd(kpd_egnn_trainer *T, int l, int nt, int cur, int nxt, float 
 }
 
 // the part of the edge backward shared by both branches: eb[4] = dpre2 in; uses eb[0..1] = pre1, a1 of the branch
-kpd_status edge_branch_bwd(kpd_egnn_trainer *T, const BranchParams &p, int l, int et, int nxt, bool first_branch) {
+kpd_status edge_branch_bwd(kpd_egnn_trainer *T, const BranchParams &p, int et, int branch) {
     const int E = T->E[et], s = kS[et], d = kD[et], ns = T->n[s], nd = T->n[d];
+    const bool first_branch = branch == 0;
     float *dpre2 = T->eb[4], *dpre1 = T->eb[5];          // (the b2 gradient, the column sum of dpre2, left with the head kernel)
     if (p.W2.g) KPD_TRY(grad_gemm(T, H, H, E, dpre2, LD, T->eb[1], LD, p.W2.g, H));
     const long long tot = (long long)E * H;
@@ -1005,21 +1149,15 @@ kpd_status edge_branch_bwd(kpd_egnn_trainer *T, const BranchParams &p, int l, in
     // dpre1 -- b1 (plain) and column 514 of W1 (weighted by the edge's distance) -- are taken from per-node sums as well: every edge has one
     // destination, so sum_e dpre1[e] = sum_v dV[v] (rides along with the dV^T h_dst product) and sum_e dpre1[e] d_e = sum_v dVw[v], where dVw
     // comes out of the same pass over dpre1 as dV.  One E x 257 pass fewer per branch.
-    float *dU = T->nb[0], *dV = T->nb[1], *dVw = T->nb[2];
+    // They land in the branch's slots of the layer's gradient blocks; the products with them are taken once per node type (layer_cat_bwd).
+    float *dU = T->ducat[s] + (size_t)T->cat_of[et][branch][0] * LD, *dV = T->ducat[d] + (size_t)T->cat_of[et][branch][1] * LD;
+    float *dVw = T->dvwcat[d] + (size_t)T->cat_dvw_of[et][branch] * LD;
     hipLaunchKernelGGL(k_segsum264, dim3(cdiv(ns, 4)), dim3(256), 0, T->st, dpre1, (const float *)nullptr, (const float *)nullptr, T->scsr[et].perm,
-                       T->scsr[et].rowptr, (const float *)nullptr, 0, ns, dU, (float *)nullptr);
+                       T->scsr[et].rowptr, (const float *)nullptr, 0, ns, dU, (float *)nullptr, CAT_LD);
     KPD_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_segsum264, dim3(cdiv(nd, 4)), dim3(256), 0, T->st, dpre1, (const float *)nullptr, (const float *)T->dij, (const int *)nullptr,
-                       T->e_rowptr[et], (const float *)nullptr, 0, nd, dV, p.W1.g ? dVw : (float *)nullptr);
+                       T->e_rowptr[et], (const float *)nullptr, 0, nd, dV, p.W1.g ? dVw : (float *)nullptr, CAT_LD);
     KPD_LAUNCH_CHECK();
-    const float *hsrc = T->hs[s][l], *hdst = T->hs[d][l];
-    if (p.W1.g) {
-        KPD_TRY(gemv_t_acc(T, nd, H, dVw, LD, nullptr, p.W1.g + 2 * H, 2 * H + 1));
-        KPD_TRY(grad_gemm(T, H, H, ns, dU, LD, hsrc, LD, p.W1.g, 2 * H + 1));
-    }
-    KPD_TRY(grad_gemm(T, H, H, nd, dV, LD, hdst, LD, p.W1.g ? p.W1.g + H : nullptr, 2 * H + 1, p.b1.g));
-    KPD_TRY(gemm(T, false, false, ns, H, H, dU, LD, p.W1.w, 2 * H + 1, 1.0f, T->dh[nxt][s], LD));
-    KPD_TRY(gemm(T, false, false, nd, H, H, dV, LD, p.W1.w + H, 2 * H + 1, 1.0f, T->dh[nxt][d], LD));
     return KPD_OK;
 }
 
@@ -1027,6 +1165,8 @@ kpd_status layer_bwd(kpd_egnn_trainer *T, int l, int cur, int nxt, float *dhn[2]
     const kpd_egnn_config &c = T->cfg;
     // (final layer, keypoints: dh_out = dx_out = 0, so dh_in / dx_in start from the zeros the caller left in dh[nxt] / dx[nxt])
     for (int nt = 0; nt < layer_n_upd(T, l); ++nt) KPD_TRY(node_bwd(T, l, nt, cur, nxt, dhn[nt]));
+    KPD_TRY(layer_stage(T, l));
+    if (!T->store) KPD_TRY(layer_project(T, l));
     for (int et = 0; et < layer_n_et(T, l); ++et) {
         const int E = T->E[et], s = kS[et], d = kD[et];
         if (E == 0) continue;
@@ -1037,7 +1177,7 @@ kpd_status layer_bwd(kpd_egnn_trainer *T, int l, int cur, int nxt, float *dhn[2]
         // feature branch
         KPD_TRY(branch_params(T, l, et, 0, &p));
         if (!T->store) {           // (the same head path as the forward pass: the two modes stay bit-identical)
-            KPD_TRY(edge_branch_fwd(T, p, et, T->hs[s][l], T->hs[d][l], use_ws() ? T->ddpart : nullptr));
+            KPD_TRY(edge_branch_fwd(T, p, et, 0, use_ws() ? T->ddpart : nullptr));
             if (use_ws()) hipLaunchKernelGGL(k_head_att, grid1(E), dim3(256), 0, T->st, T->ddpart, E, p.head_b.w, T->att);
             else hipLaunchKernelGGL(k_rowdot, dim3(cdiv(E, 4)), dim3(256), 0, T->st, T->eb[3], p.head.w, p.head_b.w, E, 1, T->att);
             KPD_LAUNCH_CHECK();
@@ -1052,12 +1192,12 @@ kpd_status layer_bwd(kpd_egnn_trainer *T, int l, int cur, int nxt, float *dhn[2]
         if (p.head_b.g) {
             KPD_TRY(sum_scalar(T, T->dsv, E, p.head_b.g));
         }
-        KPD_TRY(edge_branch_bwd(T, p, l, et, nxt, true));
+        KPD_TRY(edge_branch_bwd(T, p, et, 0));
         // coordinate branch
         bind_slot(T, l, et, 1);
         KPD_TRY(branch_params(T, l, et, 1, &p));
         if (!T->store) {
-            KPD_TRY(edge_branch_fwd(T, p, et, T->hs[s][l], T->hs[d][l], use_ws() ? T->ddpart : nullptr));
+            KPD_TRY(edge_branch_fwd(T, p, et, 1, use_ws() ? T->ddpart : nullptr));
             if (use_ws())
                 hipLaunchKernelGGL(k_coord_msg_parts, grid1(E), dim3(256), 0, T->st, T->ddpart, T->nvec, E, c.use_tanh, c.coords_range, T->sc, T->msgx);
             else
@@ -1070,7 +1210,7 @@ kpd_status layer_bwd(kpd_egnn_trainer *T, int l, int cur, int nxt, float *dhn[2]
         KPD_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_colsum_reduce, dim3(cdiv(H, 64)), dim3(1024), 0, T->st, T->colpart, cdiv(E, HEAD_ROWS), H, p.head.g, 1, p.b2.g);
         KPD_LAUNCH_CHECK();
-        KPD_TRY(edge_branch_bwd(T, p, l, et, nxt, false));
+        KPD_TRY(edge_branch_bwd(T, p, et, 1));
         float *redge = T->msgx;                         // free again: the coordinate head consumed it above
         hipLaunchKernelGGL(k_geom_bwd, grid1(E), dim3(256), 0, T->st, T->ddij, T->dn, T->xdiff, T->dij, E, redge);
         KPD_LAUNCH_CHECK();
@@ -1081,7 +1221,7 @@ kpd_status layer_bwd(kpd_egnn_trainer *T, int l, int cur, int nxt, float *dhn[2]
                            T->dx[nxt][d], 3);
         KPD_LAUNCH_CHECK();
     }
-    return KPD_OK;
+    return layer_cat_bwd(T, l, nxt);
 }
 
 }  // namespace
