@@ -695,7 +695,8 @@ def run_train(args, device, rank, world, dist):
     from keypoint_diffusion_amd.dist import allreduce_gradients
     w = WORKLOADS[args.workload]
     model = build_model(device, args.workload).train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    # (train.py:430 builds a plain torch.optim.Adam; --fused-optimizer asks torch for its single-kernel implementation of the same update)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True) if args.fused_optimizer else torch.optim.Adam(model.parameters(), lr=1e-4)
     B = args.batch
     template = raw_batch(B, args.n_rec, args.n_lig, 1234 + rank * B, device, args.workload).to(device)
     last = [None]
@@ -741,6 +742,7 @@ def main():
     ap.add_argument('--n-rec', type=int, default=300)
     ap.add_argument('--n-lig', type=int, default=25)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--fused-optimizer', action='store_true', help='training workloads: torch.optim.Adam(fused=True)')
     ap.add_argument('--no-secondary', action='store_true', help='skip the configs[2] / configs[4]-shape / end-to-end measurements')
     ap.add_argument('--workload', default='egnn_all_atom', choices=list(WORKLOADS),
                     help='egnn_all_atom = BASELINE.json configs[1] (the contract line); the others are secondary')

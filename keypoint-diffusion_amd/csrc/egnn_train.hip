@@ -302,12 +302,17 @@ __global__ void k_ln_bwd(const float *__restrict__ h, const float *__restrict__ 
 // a time) and keep two running column sums per lane: sum_e dpre2[e][c] (the gradient of b2) and sum_e a2[e][c] ds[e] (the gradient of
 // the head weight).  They leave through the same partial buffer and block-ordered reduction as k_colsum (train_ops.h), so the two
 // extra passes over E x 257 matrices that computed them separately are gone and the result stays bitwise reproducible.
-__device__ __forceinline__ void head_partials_out(float (&cs)[5], float (&ws)[5], float *__restrict__ part, int lane, int wave) {
+// (a lane owns columns 4 lane .. 4 lane + 3 -- 16-byte loads and stores -- and lane 0 column 256)
+__device__ __forceinline__ void head_partials_out(const f32x4 &cs, float cs_t, const f32x4 &ws, float ws_t, float *__restrict__ part, int lane, int wave) {
     __shared__ float s_c[4][320], s_w[4][320];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        s_c[wave][lane + 64 * k] = cs[k];
-        s_w[wave][lane + 64 * k] = ws[k];
+    for (int r = 0; r < 4; ++r) {
+        s_c[wave][4 * lane + r] = cs[r];
+        s_w[wave][4 * lane + r] = ws[r];
+    }
+    if (lane == 0) {
+        s_c[wave][256] = cs_t;
+        s_w[wave][256] = ws_t;
     }
     __syncthreads();
     float *p = part + (size_t)blockIdx.x * 2 * COLSUM_LD;
@@ -325,32 +330,38 @@ __global__ __launch_bounds__(256) void k_feat_head_bwd(const float *__restrict__
                                                        float *__restrict__ ds_att, float *__restrict__ part) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int e0 = blockIdx.x * HEAD_ROWS, e1 = min(E, e0 + HEAD_ROWS);
-    float cs[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, ws[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f}, ws = {0.f, 0.f, 0.f, 0.f};
+    float cs_t = 0.0f, ws_t = 0.0f;
+    const f32x4 wv = *reinterpret_cast<const f32x4 *>(wa + 4 * lane);
+    const float wv_t = wa[256];
     for (int e = e0 + wave; e < e1; e += 4) {
         const int v = dst[e];
         const float zi = zinv[v], a = att[e];
-        float dm[5], av[5], s = 0.0f;
+        const f32x4 dm = *reinterpret_cast<const f32x4 *>(dhn + (size_t)v * LD + 4 * lane) * zi;
+        const f32x4 av = *reinterpret_cast<const f32x4 *>(a2 + (size_t)e * LD + 4 * lane);
+        const f32x4 pv = *reinterpret_cast<const f32x4 *>(pre2 + (size_t)e * LD + 4 * lane);
+        const float dm_t = lane == 0 ? dhn[(size_t)v * LD + 256] * zi : 0.0f, av_t = lane == 0 ? a2[(size_t)e * LD + 256] : 0.0f;
+        float s = fmaf(dm_t, av_t, 0.0f);
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const int c = lane + 64 * k;
-            dm[k] = c < H ? dhn[(size_t)v * LD + c] * zi : 0.0f;
-            av[k] = c < H ? a2[(size_t)e * LD + c] : 0.0f;
-            s = fmaf(dm[k], av[k], s);
-        }
+        for (int r = 0; r < 4; ++r) s = fmaf(dm[r], av[r], s);
         const float ds = wave_sum(s) * a * (1.0f - a);
+        f32x4 g;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const int c = lane + 64 * k;
-            if (c < H) {
-                const float g = (dm[k] * a + ds * wa[c]) * silu_grad(pre2[(size_t)e * LD + c]);
-                dpre2[(size_t)e * LD + c] = g;
-                cs[k] += g;
-                ws[k] = fmaf(av[k], ds, ws[k]);
-            }
+        for (int r = 0; r < 4; ++r) {
+            g[r] = (dm[r] * a + ds * wv[r]) * silu_grad(pv[r]);
+            cs[r] += g[r];
+            ws[r] = fmaf(av[r], ds, ws[r]);
         }
-        if (lane == 0) ds_att[e] = ds;
+        *reinterpret_cast<f32x4 *>(dpre2 + (size_t)e * LD + 4 * lane) = g;
+        if (lane == 0) {
+            const float gt = (dm_t * a + ds * wv_t) * silu_grad(pre2[(size_t)e * LD + 256]);
+            dpre2[(size_t)e * LD + 256] = gt;
+            cs_t += gt;
+            ws_t = fmaf(av_t, ds, ws_t);
+            ds_att[e] = ds;
+        }
     }
-    head_partials_out(cs, ws, part, lane, wave);
+    head_partials_out(cs, cs_t, ws, ws_t, part, lane, wave);
 }
 
 // coordinate head backward: msg_x = coef n, coef = tanh(sc) range (or sc), summed into x_neigh[dst] / z
@@ -361,7 +372,10 @@ __global__ __launch_bounds__(256) void k_coord_head_bwd(const float *__restrict_
                                                         float *__restrict__ dn, float *__restrict__ part) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int e0 = blockIdx.x * HEAD_ROWS, e1 = min(E, e0 + HEAD_ROWS);
-    float cs[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, ws[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f}, ws = {0.f, 0.f, 0.f, 0.f};
+    float cs_t = 0.0f, ws_t = 0.0f;
+    const f32x4 wv = *reinterpret_cast<const f32x4 *>(w3 + 4 * lane);
+    const float wv_t = w3[256];
     for (int e = e0 + wave; e < e1; e += 4) {
         const int v = dst[e];
         const float zi = zinv[v];
@@ -372,22 +386,26 @@ __global__ __launch_bounds__(256) void k_coord_head_bwd(const float *__restrict_
         // 1 - tanh^2 = sech^2 = 4 e / (1 + e)^2, e = exp(-2 |sc|): exact near saturation, where 1 - th * th cancels to nothing
         const float ex_ = expf(-2.0f * fabsf(sc[e])), sech2 = 4.0f * ex_ / ((1.0f + ex_) * (1.0f + ex_));
         const float ds = use_tanh ? dcoef * range * sech2 : dcoef;
+        const f32x4 av = *reinterpret_cast<const f32x4 *>(a2 + (size_t)e * LD + 4 * lane);
+        const f32x4 pv = *reinterpret_cast<const f32x4 *>(pre2 + (size_t)e * LD + 4 * lane);
+        f32x4 g;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const int c = lane + 64 * k;
-            if (c < H) {
-                const float g = ds * w3[c] * silu_grad(pre2[(size_t)e * LD + c]);
-                dpre2[(size_t)e * LD + c] = g;
-                cs[k] += g;
-                ws[k] = fmaf(a2[(size_t)e * LD + c], ds, ws[k]);
-            }
+        for (int r = 0; r < 4; ++r) {
+            g[r] = ds * wv[r] * silu_grad(pv[r]);
+            cs[r] += g[r];
+            ws[r] = fmaf(av[r], ds, ws[r]);
         }
+        *reinterpret_cast<f32x4 *>(dpre2 + (size_t)e * LD + 4 * lane) = g;
         if (lane == 0) {
+            const float gt = ds * wv_t * silu_grad(pre2[(size_t)e * LD + 256]);
+            dpre2[(size_t)e * LD + 256] = gt;
+            cs_t += gt;
+            ws_t = fmaf(a2[(size_t)e * LD + 256], ds, ws_t);
             dsc[e] = ds;
             dn[3 * e] += coef * gx; dn[3 * e + 1] += coef * gy; dn[3 * e + 2] += coef * gz;
         }
     }
-    head_partials_out(cs, ws, part, lane, wave);
+    head_partials_out(cs, cs_t, ws, ws_t, part, lane, wave);
 }
 
 // geometry backward: n = x_diff / (dij + 1), dij = |x_diff|; per-edge gradient of x_src (= minus that of x_dst)
@@ -1214,12 +1232,8 @@ kpd_status layer_bwd(kpd_egnn_trainer *T, int l, int cur, int nxt, float *dhn[2]
         float *redge = T->msgx;                         // free again: the coordinate head consumed it above
         hipLaunchKernelGGL(k_geom_bwd, grid1(E), dim3(256), 0, T->st, T->ddij, T->dn, T->xdiff, T->dij, E, redge);
         KPD_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_segsum_perm, dim3(T->n[s]), dim3(64), 0, T->st, redge, 3, 0, 3, T->scsr[et].perm, T->scsr[et].rowptr, 1.0f, 1,
-                           T->dx[nxt][s], 3);
-        KPD_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_segsum_perm, dim3(T->n[d]), dim3(64), 0, T->st, redge, 3, 0, 3, (const int *)nullptr, T->e_rowptr[et], -1.0f, 1,
-                           T->dx[nxt][d], 3);
-        KPD_LAUNCH_CHECK();
+        KPD_TRY(segsum(T->st, redge, 3, 0, 3, T->scsr[et].perm, T->scsr[et].rowptr, nullptr, 1.0f, true, T->n[s], T->dx[nxt][s], 3));
+        KPD_TRY(segsum(T->st, redge, 3, 0, 3, nullptr, T->e_rowptr[et], nullptr, -1.0f, true, T->n[d], T->dx[nxt][d], 3));
     }
     return layer_cat_bwd(T, l, nxt);
 }

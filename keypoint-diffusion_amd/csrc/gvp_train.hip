@@ -154,9 +154,7 @@ kpd_status message_fwd(kpd_gvp_trainer *T, int conv, int et, GvpP *g0_out, bool 
     KPD_TRY(gvp_params(T, prefix + ".0", VH, VC, S + RBF, S, &g0));
     // scalar part of the first Linear: U[src] + rbf W[:, S:S+16]^T
     KPD_TRY(gemm(T, false, true, T->n[s], S, S, T->ss[s][conv], S, g0.Ws.w, g0.si + g0.h, 0.0f, T->U, S));
-    hipLaunchKernelGGL(k_gather_rows, grid1((long long)E * S), dim3(256), 0, T->st, T->U, T->e_src[et], (const float *)nullptr,
-                       (long long)E * S, S, T->gb[0].pre);
-    KPD_LAUNCH_CHECK();
+    KPD_TRY(gather_rows(T->st, T->U, T->e_src[et], nullptr, E, S, T->gb[0].pre));
     KPD_TRY(gemm(T, false, true, E, S, RBF, T->rbf, RBF, g0.Ws.w + S, g0.si + g0.h, 1.0f, T->gb[0].pre, S));
     KPD_TRY(gvp_fwd(T, g0, E, nullptr, 0, T->vin, T->gb[0], false));
     for (int j = 1; j < nm; ++j) {
@@ -190,10 +188,8 @@ kpd_status conv_fwd(kpd_gvp_trainer *T, int conv) {
         bind_msg(T, conv, et);
         KPD_TRY(message_fwd(T, conv, et, nullptr));
         KPD_TRY(edge_scale(T, et));
-        hipLaunchKernelGGL(k_segsum, dim3(T->n[d]), dim3(256), 0, T->st, T->gb[nm - 1].s, S, T->e_rowptr[et], T->scale, T->sa[d][conv]);
-        KPD_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_segsum, dim3(T->n[d]), dim3(64), 0, T->st, T->gb[nm - 1].V, 3 * VC, T->e_rowptr[et], T->scale, T->va[d][conv]);
-        KPD_LAUNCH_CHECK();
+        KPD_TRY(segsum(T->st, T->gb[nm - 1].s, S, 0, S, nullptr, T->e_rowptr[et], T->scale, 1.0f, true, T->n[d], T->sa[d][conv], S));
+        KPD_TRY(segsum(T->st, T->gb[nm - 1].V, 3 * VC, 0, 3 * VC, nullptr, T->e_rowptr[et], T->scale, 1.0f, true, T->n[d], T->va[d][conv], 3 * VC));
     }
     bind_msg(T, -1, -1);
     for (int nt = 0; nt < 2; ++nt) {
@@ -272,12 +268,8 @@ kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
         KPD_TRY(message_fwd(T, conv, et, &g0, !T->store));
         KPD_TRY(edge_scale(T, et));
         // d(message of edge e) = scale[dst] * d(aggregate)[dst]
-        hipLaunchKernelGGL(k_gather_rows, grid1((long long)E * S), dim3(256), 0, T->st, T->gs[cur][d], T->e_dst[et], T->scale,
-                           (long long)E * S, S, T->ds[0]);
-        KPD_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_gather_rows, grid1((long long)E * 3 * VC), dim3(256), 0, T->st, T->gv[cur][d], T->e_dst[et], T->scale,
-                           (long long)E * 3 * VC, 3 * VC, T->dV[0]);
-        KPD_LAUNCH_CHECK();
+        KPD_TRY(gather_rows(T->st, T->gs[cur][d], T->e_dst[et], T->scale, E, S, T->ds[0]));
+        KPD_TRY(gather_rows(T->st, T->gv[cur][d], T->e_dst[et], T->scale, E, 3 * VC, T->dV[0]));
         for (int j = nm - 1; j >= 1; --j) {
             GvpP g;
             KPD_TRY(gvp_params(T, prefix + "." + std::to_string(j), VC, VC, S, S, &g));
@@ -301,15 +293,12 @@ kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
         // ds[0] = dL/dpre of the first GVP: its scalar inputs were U[src] and rbf
         if (g0.Ws.g) KPD_TRY(grad_gemm(T, S, RBF, E, T->ds[0], S, T->rbf, RBF, g0.Ws.g + S, g0.si + g0.h));
         // sums over the out-edges of every source node, in ascending edge order (no float atomics)
-        hipLaunchKernelGGL(k_segsum_perm, dim3(T->n[s]), dim3(256), 0, T->st, T->ds[0], S, 0, S, T->scsr[et].perm, T->scsr[et].rowptr, 1.0f, 0,
-                           T->U, S);
-        KPD_LAUNCH_CHECK();
+        KPD_TRY(segsum(T->st, T->ds[0], S, 0, S, T->scsr[et].perm, T->scsr[et].rowptr, nullptr, 1.0f, false, T->n[s], T->U, S));
         if (g0.Ws.g) KPD_TRY(grad_gemm(T, S, S, T->n[s], T->U, S, T->ss[s][conv], S, g0.Ws.g, g0.si + g0.h));
         KPD_TRY(gemm(T, false, false, T->n[s], S, S, T->U, S, g0.Ws.w, g0.si + g0.h, 1.0f, T->gs[nxt][s], S));
         for (int cc = 0; cc < 3; ++cc) {      // vector rows [E, 3, 17], channels 1..16 -> gv[src, 3, 16]
-            hipLaunchKernelGGL(k_segsum_perm, dim3(T->n[s]), dim3(64), 0, T->st, T->dV[1], 3 * VH, cc * VH + 1, VC, T->scsr[et].perm,
-                               T->scsr[et].rowptr, 1.0f, 1, T->gv[nxt][s] + cc * VC, 3 * VC);
-            KPD_LAUNCH_CHECK();
+            KPD_TRY(segsum(T->st, T->dV[1], 3 * VH, cc * VH + 1, VC, T->scsr[et].perm, T->scsr[et].rowptr, nullptr, 1.0f, true, T->n[s],
+                           T->gv[nxt][s] + cc * VC, 3 * VC));
         }
     }
     bind_msg(T, -1, -1);

@@ -92,29 +92,6 @@ __global__ void k_gvp_vin(const float *__restrict__ unit, const float *__restric
     vin[i] = ch == 0 ? unit[3 * e + c] : vsrc[((size_t)src[e] * 3 + c) * VC + ch - 1];
 }
 
-__global__ void k_gather_rows(const float *__restrict__ A, const int *__restrict__ idx, const float *__restrict__ scale, long long total,
-                              int cols, float *__restrict__ out) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
-    const int v = idx[r];
-    out[i] = A[(size_t)v * cols + c] * (scale ? scale[v] : 1.0f);
-}
-
-// acc[v] += scale[v] * sum over the edges of dst node v of M[e] (rows `cols` wide), one workgroup per dst node
-__global__ void k_segsum(const float *__restrict__ M, int cols, const int *__restrict__ rowptr, const float *__restrict__ scale,
-                         float *__restrict__ acc) {
-    const int v = blockIdx.x;
-    const int e0 = rowptr[v], e1 = rowptr[v + 1];
-    if (e0 == e1) return;
-    const float sc = scale[v];
-    for (int c = threadIdx.x; c < cols; c += blockDim.x) {
-        float s = 0.0f;
-        for (int e = e0; e < e1; ++e) s += M[(size_t)e * cols + c];
-        acc[(size_t)v * cols + c] += s * sc;
-    }
-}
-
 // sh[m, j] = sqrt(max(sum_c Vh[m, c, j]^2, 1e-8)) (_norm_no_nan, gvp.py:12-19)
 __global__ void k_gvp_sh(const float *__restrict__ Vh, long long total, int h, float *__restrict__ sh) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -532,35 +509,44 @@ kpd_status launch_gvp_vec_fwd(const float *v_in, const float *Wh, const float *W
     return KPD_OK;
 }
 
-// V[m, c, u] = act(gate[m, u]) * Vu[m, c, u], act = sigmoid or identity (gvp.py:108-114)
-__global__ void k_gvp_gate(const float *__restrict__ gate, const float *__restrict__ Vu, long long total, int vo, int identity,
-                           float *__restrict__ V) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int u = (int)(i % vo);
-    const long long m = i / (3LL * vo);
-    const float g = gate[m * vo + u];
-    V[i] = (identity ? g : sigm(g)) * Vu[i];
+// V[m, c, u] = act(gate[m, u]) * Vu[m, c, u], act = sigmoid or identity (gvp.py:108-114); one thread per VEC channels of a row
+template <int VEC>
+__global__ void k_gvp_gate(const float *__restrict__ gate, const float *__restrict__ Vu, int rows3, int vw, int identity, float *__restrict__ V) {
+    typedef float vt __attribute__((ext_vector_type(VEC)));
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // over [m * 3 + c][u / VEC]
+    if (i >= rows3 * vw) return;
+    const int mc = i / vw, u = i - mc * vw, m = mc / 3;
+    vt g = reinterpret_cast<const vt *>(gate)[m * vw + u];
+    if (!identity)
+#pragma unroll
+        for (int r = 0; r < VEC; ++r) g[r] = sigm(g[r]);
+    reinterpret_cast<vt *>(V)[i] = g * reinterpret_cast<const vt *>(Vu)[i];
 }
 
-// one thread per (m, u): dgate = sum_c dV Vu act'(gate); dV <- dV act(gate) (= dVu)
-__global__ void k_gvp_gate_bwd(const float *__restrict__ gate, const float *__restrict__ Vu, long long total, int vo, int identity,
-                               float *__restrict__ dV, float *__restrict__ dgate) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // over [m, u]
-    if (i >= total) return;
-    const long long m = i / vo;
-    const int u = (int)(i - m * vo);
-    const float g = gate[i];
-    const float a = identity ? g : sigm(g);
-    const float da = identity ? 1.0f : a * (1.0f - a);
-    float s = 0.0f;
+// one thread per (m, VEC channels): dgate = sum_c dV Vu act'(gate); dV <- dV act(gate) (= dVu)
+template <int VEC>
+__global__ void k_gvp_gate_bwd(const float *__restrict__ gate, const float *__restrict__ Vu, int rows, int vw, int identity, float *__restrict__ dV,
+                               float *__restrict__ dgate) {
+    typedef float vt __attribute__((ext_vector_type(VEC)));
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // over [m][u / VEC]
+    if (i >= rows * vw) return;
+    const int m = i / vw, u = i - m * vw;
+    vt a = reinterpret_cast<const vt *>(gate)[i], da = 1.0f;
+    if (!identity)
+#pragma unroll
+        for (int r = 0; r < VEC; ++r) {
+            a[r] = sigm(a[r]);
+            da[r] = a[r] * (1.0f - a[r]);
+        }
+    vt s = 0.0f;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const size_t k = ((size_t)m * 3 + c) * vo + u;
-        s = fmaf(dV[k], Vu[k], s);
-        dV[k] *= a;
+        const size_t k = ((size_t)m * 3 + c) * vw + u;
+        const vt d = reinterpret_cast<vt *>(dV)[k];
+        s += d * reinterpret_cast<const vt *>(Vu)[k];
+        reinterpret_cast<vt *>(dV)[k] = d * a;
     }
-    dgate[i] = s * da;
+    reinterpret_cast<vt *>(dgate)[i] = s * da;
 }
 
 // LayerNorm over `cols` (<= 512) columns, one wave per row
@@ -788,7 +774,8 @@ kpd_status gvp_fwd(TT *T, const GvpP &g, int M, const float *s_in, int ld_s, con
     }
     KPD_TRY(gemm(T, false, true, M, g.vo, g.so, B.s, g.so, g.Wg.w, g.so, 0.0f, B.gate, g.vo, 1.0f, nullptr, g.bg.w));
     tot = (long long)M * g.vo;
-    hipLaunchKernelGGL(k_gvp_gate, grid1(3 * tot), dim3(256), 0, T->st, B.gate, B.Vu, 3 * tot, g.vo, identity ? 1 : 0, B.V);
+    if ((g.vo & 3) == 0) hipLaunchKernelGGL(k_gvp_gate<4>, grid1(3 * tot / 4), dim3(256), 0, T->st, B.gate, B.Vu, 3 * M, g.vo / 4, identity ? 1 : 0, B.V);
+    else hipLaunchKernelGGL(k_gvp_gate<1>, grid1(3 * tot), dim3(256), 0, T->st, B.gate, B.Vu, 3 * M, g.vo, identity ? 1 : 0, B.V);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
 }
@@ -800,7 +787,8 @@ kpd_status gvp_bwd(TT *T, const GvpP &g, int M, const float *s_in, int ld_s, con
                    bool identity, float *ds, float *dV, float *ds_in, float *dv_in) {
     if (M == 0) return KPD_OK;
     long long tot = (long long)M * g.vo;
-    hipLaunchKernelGGL(k_gvp_gate_bwd, grid1(tot), dim3(256), 0, T->st, B.gate, B.Vu, tot, g.vo, identity ? 1 : 0, dV, T->dgate);
+    if ((g.vo & 3) == 0) hipLaunchKernelGGL(k_gvp_gate_bwd<4>, grid1(tot / 4), dim3(256), 0, T->st, B.gate, B.Vu, M, g.vo / 4, identity ? 1 : 0, dV, T->dgate);
+    else hipLaunchKernelGGL(k_gvp_gate_bwd<1>, grid1(tot), dim3(256), 0, T->st, B.gate, B.Vu, M, g.vo, identity ? 1 : 0, dV, T->dgate);
     KPD_LAUNCH_CHECK();
     KPD_TRY(grad_gemm(T, g.vo, g.so, M, T->dgate, g.vo, B.s, g.so, g.Wg.g, g.so, g.bg.g));       // + gate bias gradient (column sums of dgate)
     // ds = (ds + dgate Wg) * SiLU'(pre): the activation derivative in the product's epilogue

@@ -407,7 +407,7 @@ kpd_status conv_fwd(kpd_recegnn_trainer *T, int i) {
     KPD_TRY(conv_edges_fwd(T, i, p));
     KPD_HIP(hipMemsetAsync(T->hneigh[i], 0, (size_t)n * H * 4, st));
     if (E > 0) {
-        hipLaunchKernelGGL(k_segsum, dim3(n), dim3(256), 0, st, T->msg, H, T->bt.rr_rowptr, T->scale, T->hneigh[i]);       // :144-147
+        KPD_TRY(segsum(st, T->msg, H, 0, H, nullptr, T->bt.rr_rowptr, T->scale, 1.0f, true, n, T->hneigh[i], H));       // :144-147
         KPD_LAUNCH_CHECK();
     }
     if (T->cfg.fix_pos || E == 0) KPD_HIP(hipMemcpyAsync(T->xs[i + 1], T->xs[i], (size_t)n * 12, hipMemcpyDeviceToDevice, st));
@@ -459,7 +459,7 @@ kpd_status conv_bwd(kpd_recegnn_trainer *T, int i, float *gh_out, const float *g
     // feature messages: d msg[e] = d h_neigh[dst] / z
     hipLaunchKernelGGL(k_copy_rows, grid1((long long)n * H), dim3(256), 0, st, T->gcat + Din, Din + H, T->gn1, H, (long long)n * H, H);
     KPD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_gather_rows, grid1((long long)E * H), dim3(256), 0, st, T->gn1, T->bt.rr_dst, T->scale, (long long)E * H, H, T->dE);
+    KPD_TRY(gather_rows(st, T->gn1, T->bt.rr_dst, T->scale, E, H, T->dE));
     KPD_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_rc_att_bwd, dim3(cdiv(E, 4)), dim3(256), 0, st, T->m, T->s, p.watt.w, E, H, T->dE, T->ds);
     KPD_LAUNCH_CHECK();
@@ -486,9 +486,9 @@ kpd_status conv_bwd(kpd_recegnn_trainer *T, int i, float *gh_out, const float *g
         KPD_TRY(gemm(T, false, false, E, fw, H, T->dE, H, p.Wc1.w, fw, 1.0f, T->df, fw));
     }
     // f = [h_src | h_dst | r | a]: node features by source (grouped index) and destination (contiguous), then the geometry
-    hipLaunchKernelGGL(k_segsum_perm, dim3(n), dim3(256), 0, st, T->df, fw, 0, Din, T->scsr_rr.perm, T->scsr_rr.rowptr, 1.0f, 1, gh_in, Din);
+    KPD_TRY(segsum(st, T->df, fw, 0, Din, T->scsr_rr.perm, T->scsr_rr.rowptr, nullptr, 1.0f, true, n, gh_in, Din));
     KPD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_segsum_perm, dim3(n), dim3(256), 0, st, T->df, fw, Din, Din, (const int *)nullptr, T->bt.rr_rowptr, 1.0f, 1, gh_in, Din);
+    KPD_TRY(segsum(st, T->df, fw, Din, Din, nullptr, T->bt.rr_rowptr, nullptr, 1.0f, true, n, gh_in, Din));
     KPD_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_rc_geom_bwd, grid1(E), dim3(256), 0, st, T->bt.rr_src, T->bt.rr_dst, T->xs[i], T->r, T->cfg.fix_pos ? nullptr : T->dxd, T->df,
                        fw, 2 * Din, E, T->dxe);

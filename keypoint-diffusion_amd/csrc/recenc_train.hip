@@ -267,10 +267,8 @@ kpd_status conv_fwd(kpd_recenc_trainer *T, const Conv &c) {
     if (c.E > 0) {
         KPD_TRY(conv_message_fwd(T, c, nullptr));
         KPD_TRY(conv_scale(T, c));
-        hipLaunchKernelGGL(k_segsum, dim3(n), dim3(256), 0, T->st, T->gb[nm - 1].s, S, c.rowptr, T->scale, c.sa);
-        KPD_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_segsum, dim3(n), dim3(64), 0, T->st, T->gb[nm - 1].V, 3 * VC, c.rowptr, T->scale, c.va);
-        KPD_LAUNCH_CHECK();
+        KPD_TRY(segsum(T->st, T->gb[nm - 1].s, S, 0, S, nullptr, c.rowptr, T->scale, 1.0f, true, n, c.sa, S));
+        KPD_TRY(segsum(T->st, T->gb[nm - 1].V, 3 * VC, 0, 3 * VC, nullptr, c.rowptr, T->scale, 1.0f, true, n, c.va, 3 * VC));
     }
     KPD_TRY(enc_dropout(T, c.id, 0, n, c.sa, c.va, c.sa, c.va));
     hipLaunchKernelGGL(k_acc, grid1((long long)n * S), dim3(256), 0, T->st, c.sa, c.s_dst, (long long)n * S);
@@ -320,11 +318,8 @@ kpd_status conv_bwd(kpd_recenc_trainer *T, const Conv &c, const float *g_out_s, 
     GvpP g0;
     KPD_TRY(conv_message_fwd(T, c, &g0));
     KPD_TRY(conv_scale(T, c));
-    hipLaunchKernelGGL(k_gather_rows, grid1((long long)E * S), dim3(256), 0, T->st, T->gn_s, c.dst, T->scale, (long long)E * S, S, T->ds[0]);
-    KPD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_gather_rows, grid1((long long)E * 3 * VC), dim3(256), 0, T->st, T->gn_v, c.dst, T->scale, (long long)E * 3 * VC, 3 * VC,
-                       T->dV[0]);
-    KPD_LAUNCH_CHECK();
+    KPD_TRY(gather_rows(T->st, T->gn_s, c.dst, T->scale, E, S, T->ds[0]));
+    KPD_TRY(gather_rows(T->st, T->gn_v, c.dst, T->scale, E, 3 * VC, T->dV[0]));
     for (int j = nm - 1; j >= 1; --j) {
         GvpP g;
         KPD_TRY(gvp_params(T, c.prefix + ".edge_message." + std::to_string(j), VC, VC, S, S, &g));
@@ -335,20 +330,14 @@ kpd_status conv_bwd(kpd_recenc_trainer *T, const Conv &c, const float *g_out_s, 
     // first message GVP: ds[1] [E, si] = gradient of [s_src | rbf | s_dst], dV[1] [E, 3, vi] = gradient of [x_diff | v_src | v_dst]
     KPD_TRY(gvp_bwd(T, g0, E, T->sin, si, T->vin, T->gb[0], false, T->ds[0], T->dV[0], T->ds[1], T->dV[1]));
     // source side: sums over the out-edges of every source node, ascending edge order
-    hipLaunchKernelGGL(k_segsum_perm, dim3(c.n_src), dim3(256), 0, T->st, T->ds[1], si, 0, S, c.scsr->perm, c.scsr->rowptr, 1.0f, 1, g_src_s, S);
-    KPD_LAUNCH_CHECK();
+    KPD_TRY(segsum(T->st, T->ds[1], si, 0, S, c.scsr->perm, c.scsr->rowptr, nullptr, 1.0f, true, c.n_src, g_src_s, S));
     for (int cc = 0; cc < 3; ++cc) {
-        hipLaunchKernelGGL(k_segsum_perm, dim3(c.n_src), dim3(64), 0, T->st, T->dV[1], 3 * vi, cc * vi + 1, VC, c.scsr->perm, c.scsr->rowptr, 1.0f,
-                           1, g_src_v + cc * VC, 3 * VC);
-        KPD_LAUNCH_CHECK();
+        KPD_TRY(segsum(T->st, T->dV[1], 3 * vi, cc * vi + 1, VC, c.scsr->perm, c.scsr->rowptr, nullptr, 1.0f, true, c.n_src, g_src_v + cc * VC, 3 * VC));
     }
     if (c.use_dst) {                  // destination features: the edge list is dst-sorted, so the in-edges of a node are contiguous
-        hipLaunchKernelGGL(k_segsum_perm, dim3(n), dim3(256), 0, T->st, T->ds[1], si, S + RBF, S, (const int *)nullptr, c.rowptr, 1.0f, 1, g_dst_s, S);
-        KPD_LAUNCH_CHECK();
+        KPD_TRY(segsum(T->st, T->ds[1], si, S + RBF, S, nullptr, c.rowptr, nullptr, 1.0f, true, n, g_dst_s, S));
         for (int cc = 0; cc < 3; ++cc) {
-            hipLaunchKernelGGL(k_segsum_perm, dim3(n), dim3(64), 0, T->st, T->dV[1], 3 * vi, cc * vi + 1 + VC, VC, (const int *)nullptr, c.rowptr,
-                               1.0f, 1, g_dst_v + cc * VC, 3 * VC);
-            KPD_LAUNCH_CHECK();
+            KPD_TRY(segsum(T->st, T->dV[1], 3 * vi, cc * vi + 1 + VC, VC, nullptr, c.rowptr, nullptr, 1.0f, true, n, g_dst_v + cc * VC, 3 * VC));
         }
     }
     if (g_xd) {                       // geometry: d rbf = columns S .. S + 16 of d sin, d unit = channel 0 of d vin

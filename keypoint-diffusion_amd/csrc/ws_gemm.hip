@@ -24,7 +24,7 @@ constexpr int WSG_W4 = 16 * 8 * 64;                           // float4 of the r
 constexpr int WSG_LDS_BYTES = WSG_W4 * 16 + (128 + 128 + HS + HS) * 4;      // half block, column 256, bias, row 256, row-dot vector
 constexpr int WSG_PACK_FLOATS = 16 * 16 * 64 * 4 + 256 + HS;  // fragments, column 256, row 256 (padded)
 
-__device__ __forceinline__ float wsg_sigm(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float wsg_sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }      // (1 ulp; the division sequence cost 12 % of the kernel)
 
 // fragments of the 256 x 256 block of M (M[n][k] = src[n * sn + k * sk]) in chain-chunk order, then M[:, 256], then M[256, :]
 __global__ void k_wsg_pack(const float *__restrict__ src, int sn, int sk, int has257, float *__restrict__ dst) {
