@@ -108,8 +108,17 @@ int ws_gemm_pack_floats();
 // rowdot (optional; WS_SILU_BWD: of Y, WS_BIAS_SILU: of the activated output A): rowdot_out[hf * rows + r] = sum over the columns of half hf
 // of the row times rowdot_w[c * rowdot_stride] -- the product of every finished row with one more vector (a head of the MLP, the
 // distance column in backward), taken from the registers the epilogue holds (two halves: the caller adds them)
+// ext (256-wide form only): up to 17 extra inputs X2 (WS_BIAS_SILU) or extra outputs Y2 (WS_PLAIN) -- the vector-norm block of a GVP's
+// to_feats_out; W addresses element (n = output, k = input) of the narrow block as W[n * sn + k * sk]; ld: row stride of X2 / Y2
+struct WsgExtra {
+    const float *X2 = nullptr;
+    float *Y2 = nullptr;
+    const float *W = nullptr;
+    int sn = 0, sk = 0, n = 0, ld = 0;
+};
 kpd_status ws_gemm(int mode, const float *X, int rows, int ldx, const float *W, int ldw, bool transpose_w, const float *bias,
                    const float *P, float *Y, float *A, int ldy, float *pack_scratch, hipStream_t st, bool has257 = true,
-                   bool accumulate = false, const float *rowdot_w = nullptr, int rowdot_stride = 1, float *rowdot_out = nullptr);
+                   bool accumulate = false, const float *rowdot_w = nullptr, int rowdot_stride = 1, float *rowdot_out = nullptr,
+                   const WsgExtra *ext = nullptr);
 
 }  // namespace kpd

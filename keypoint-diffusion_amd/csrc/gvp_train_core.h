@@ -733,6 +733,12 @@ bool ws_ok(const GvpP &g, int ld_s) {
     return on && g.si == 256 && g.so == 256 && ld_s == 256;
 }
 
+// the 16 / 17 vector norms of to_feats_out's input ride along in the weight-stationary kernel (KPD_TRAIN_WS_EXTRA=0: separate products)
+inline bool ws_extra() {
+    static const bool on = !(getenv("KPD_TRAIN_WS_EXTRA") && atoi(getenv("KPD_TRAIN_WS_EXTRA")) == 0);
+    return on;
+}
+
 // GVP.forward (gvp.py:89-116).  s_in == nullptr: B.pre already holds the contribution of the scalar inputs (no bias).
 template <class TT>
 kpd_status gvp_fwd(TT *T, const GvpP &g, int M, const float *s_in, int ld_s, const float *v_in, const GvpBuf &B,
@@ -765,8 +771,15 @@ kpd_status gvp_fwd(TT *T, const GvpP &g, int M, const float *s_in, int ld_s, con
     if (s_in && ws_ok(g, ld_s)) {
         // the narrow vector-norm block first, then the 256 x 256 scalar block on the weight-stationary GEMM with the partial
         // pre-activation, the bias and the SiLU fused into its epilogue
-        KPD_TRY(gemm(T, false, true, M, g.so, g.h, B.sh, g.h, g.Ws.w + g.si, g.si + g.h, 0.0f, B.pre, g.so));
-        KPD_TRY(ws_gemm(WS_BIAS_SILU, s_in, M, ld_s, g.Ws.w, g.si + g.h, false, g.bs.w, nullptr, B.pre, B.s, g.so, T->wsg_pack, T->st, false, true));
+        if (g.h <= 17 && ws_extra()) {           // ... with the vector-norm block as extra inputs of the same kernel
+            WsgExtra x;
+            x.X2 = B.sh; x.W = g.Ws.w + g.si; x.sn = g.si + g.h; x.sk = 1; x.n = g.h; x.ld = g.h;
+            KPD_TRY(ws_gemm(WS_BIAS_SILU, s_in, M, ld_s, g.Ws.w, g.si + g.h, false, g.bs.w, nullptr, B.pre, B.s, g.so, T->wsg_pack, T->st, false, false,
+                            nullptr, 1, nullptr, &x));
+        } else {
+            KPD_TRY(gemm(T, false, true, M, g.so, g.h, B.sh, g.h, g.Ws.w + g.si, g.si + g.h, 0.0f, B.pre, g.so));
+            KPD_TRY(ws_gemm(WS_BIAS_SILU, s_in, M, ld_s, g.Ws.w, g.si + g.h, false, g.bs.w, nullptr, B.pre, B.s, g.so, T->wsg_pack, T->st, false, true));
+        }
     } else {
         if (s_in) KPD_TRY(gemm(T, false, true, M, g.so, g.si, s_in, ld_s, g.Ws.w, g.si + g.h, 0.0f, B.pre, g.so));
         // + the vector-norm block, the bias and the SiLU in the epilogue: B.pre keeps the pre-activation, B.s its activation
@@ -793,16 +806,23 @@ kpd_status gvp_bwd(TT *T, const GvpP &g, int M, const float *s_in, int ld_s, con
     KPD_TRY(grad_gemm(T, g.vo, g.so, M, T->dgate, g.vo, B.s, g.so, g.Wg.g, g.so, g.bg.g));       // + gate bias gradient (column sums of dgate)
     // ds = (ds + dgate Wg) * SiLU'(pre): the activation derivative in the product's epilogue
     KPD_TRY(gemm(T, false, false, M, g.so, g.vo, T->dgate, g.vo, g.Wg.w, g.so, 1.0f, ds, g.so, 1.0f, B.pre));
+    bool have_dsh = false;
     if (s_in) {
         if (g.Ws.g) KPD_TRY(grad_gemm(T, g.so, g.si, M, ds, g.so, s_in, ld_s, g.Ws.g, g.si + g.h));
         if (ds_in) {
-            if (ws_ok(g, ld_s)) KPD_TRY(ws_gemm(WS_PLAIN, ds, M, g.so, g.Ws.w, g.si + g.h, true, nullptr, nullptr, ds_in, nullptr, g.si, T->wsg_pack, T->st, false, false));
+            if (ws_ok(g, ld_s) && g.h <= 17 && ws_extra()) {       // ... with dsh = ds Ws[:, si:] as extra outputs of the same kernel
+                WsgExtra x;
+                x.Y2 = T->dsh; x.W = g.Ws.w + g.si; x.sn = 1; x.sk = g.si + g.h; x.n = g.h; x.ld = g.h;
+                KPD_TRY(ws_gemm(WS_PLAIN, ds, M, g.so, g.Ws.w, g.si + g.h, true, nullptr, nullptr, ds_in, nullptr, g.si, T->wsg_pack, T->st, false, false,
+                                nullptr, 1, nullptr, &x));
+                have_dsh = true;
+            } else if (ws_ok(g, ld_s)) KPD_TRY(ws_gemm(WS_PLAIN, ds, M, g.so, g.Ws.w, g.si + g.h, true, nullptr, nullptr, ds_in, nullptr, g.si, T->wsg_pack, T->st, false, false));
             else KPD_TRY(gemm(T, false, false, M, g.si, g.so, ds, g.so, g.Ws.w, g.si + g.h, 0.0f, ds_in, g.si));
         }
     }
     // the sh block of to_feats_out, with the bias gradient (column sums of ds) riding along
     KPD_TRY(grad_gemm(T, g.so, g.h, M, ds, g.so, B.sh, g.h, g.Ws.g ? g.Ws.g + g.si : nullptr, g.si + g.h, g.bs.g));
-    KPD_TRY(gemm(T, false, false, M, g.h, g.so, ds, g.so, g.Ws.w + g.si, g.si + g.h, 0.0f, T->dsh, g.h));
+    if (!have_dsh) KPD_TRY(gemm(T, false, false, M, g.h, g.so, ds, g.so, g.Ws.w + g.si, g.si + g.h, 0.0f, T->dsh, g.h));
     if (vec_fused() && g.vi == 17 && g.h == 17 && g.vo == 16 && T->part && T->part_floats >= (size_t)VEC16_MAX_WAVES * VEC17_PART) {
         const int blocks = std::max(1, std::min(cdiv(cdiv(M, 16), 4), std::min(2 * cu_count(), VEC16_MAX_WAVES / 4)));
         hipLaunchKernelGGL(k_gvp_vec17_bwd, dim3(blocks), dim3(256), 0, T->st, dV, B.Vh, B.sh, T->dsh, v_in, g.Wh.w, g.Wu.w, M, dv_in, T->part);
