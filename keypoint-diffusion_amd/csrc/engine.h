@@ -115,6 +115,11 @@ struct WsgExtra {
     float *Y2 = nullptr;
     const float *W = nullptr;
     int sn = 0, sk = 0, n = 0, ld = 0;
+    // with X2: G2[row][0..15] / G2b[row][0..15] = the shares of the two column halves of SiLU(Y) Wg^T (Wg [ng <= 16][256], row stride ldg);
+    // the consumer adds them
+    const float *Wg = nullptr;
+    float *G2 = nullptr, *G2b = nullptr;
+    int ldg = 0, ng = 0;
 };
 kpd_status ws_gemm(int mode, const float *X, int rows, int ldx, const float *W, int ldw, bool transpose_w, const float *bias,
                    const float *P, float *Y, float *A, int ldy, float *pack_scratch, hipStream_t st, bool has257 = true,

@@ -509,18 +509,28 @@ kpd_status launch_gvp_vec_fwd(const float *v_in, const float *Wh, const float *W
     return KPD_OK;
 }
 
-// V[m, c, u] = act(gate[m, u]) * Vu[m, c, u], act = sigmoid or identity (gvp.py:108-114); one thread per VEC channels of a row
+// V[m, c, u] = act(gate[m, u]) * Vu[m, c, u], act = sigmoid or identity (gvp.py:108-114); one thread per (m, VEC channels).
+// part1 (optional): gate holds the first column half's share of the gate product (ws_gemm), part1 the second's: gate <- gate + part1 + bias
 template <int VEC>
-__global__ void k_gvp_gate(const float *__restrict__ gate, const float *__restrict__ Vu, int rows3, int vw, int identity, float *__restrict__ V) {
+__global__ void k_gvp_gate(float *__restrict__ gate, const float *__restrict__ part1, const float *__restrict__ bias, const float *__restrict__ Vu,
+                           int rows, int vw, int identity, float *__restrict__ V) {
     typedef float vt __attribute__((ext_vector_type(VEC)));
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // over [m * 3 + c][u / VEC]
-    if (i >= rows3 * vw) return;
-    const int mc = i / vw, u = i - mc * vw, m = mc / 3;
-    vt g = reinterpret_cast<const vt *>(gate)[m * vw + u];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // over [m][u / VEC]
+    if (i >= rows * vw) return;
+    const int m = i / vw, u = i - m * vw;
+    vt g = reinterpret_cast<const vt *>(gate)[i];
+    if (part1) {
+        g += reinterpret_cast<const vt *>(part1)[i] + reinterpret_cast<const vt *>(bias)[u];
+        reinterpret_cast<vt *>(gate)[i] = g;
+    }
     if (!identity)
 #pragma unroll
         for (int r = 0; r < VEC; ++r) g[r] = sigm(g[r]);
-    reinterpret_cast<vt *>(V)[i] = g * reinterpret_cast<const vt *>(Vu)[i];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const size_t k = ((size_t)m * 3 + c) * vw + u;
+        reinterpret_cast<vt *>(V)[k] = g * reinterpret_cast<const vt *>(Vu)[k];
+    }
 }
 
 // one thread per (m, VEC channels): dgate = sum_c dV Vu act'(gate); dV <- dV act(gate) (= dVu)
@@ -768,12 +778,14 @@ kpd_status gvp_fwd(TT *T, const GvpP &g, int M, const float *s_in, int ld_s, con
         KPD_LAUNCH_CHECK();
     }
     long long tot = (long long)M * g.so;
+    bool gate_parts = false;
     if (s_in && ws_ok(g, ld_s)) {
         // the narrow vector-norm block first, then the 256 x 256 scalar block on the weight-stationary GEMM with the partial
         // pre-activation, the bias and the SiLU fused into its epilogue
-        if (g.h <= 17 && ws_extra()) {           // ... with the vector-norm block as extra inputs of the same kernel
-            WsgExtra x;
+        if (g.h <= 17 && ws_extra()) {           // ... with the vector-norm block as extra inputs of the same kernel, and the gate product
+            WsgExtra x;                          // (16 outputs of the activated row) taken in its epilogue
             x.X2 = B.sh; x.W = g.Ws.w + g.si; x.sn = g.si + g.h; x.sk = 1; x.n = g.h; x.ld = g.h;
+            if (g.vo == 16) { x.Wg = g.Wg.w; x.ldg = g.so; x.ng = g.vo; x.G2 = B.gate; x.G2b = T->dgate; gate_parts = true; }
             KPD_TRY(ws_gemm(WS_BIAS_SILU, s_in, M, ld_s, g.Ws.w, g.si + g.h, false, g.bs.w, nullptr, B.pre, B.s, g.so, T->wsg_pack, T->st, false, false,
                             nullptr, 1, nullptr, &x));
         } else {
@@ -785,10 +797,11 @@ kpd_status gvp_fwd(TT *T, const GvpP &g, int M, const float *s_in, int ld_s, con
         // + the vector-norm block, the bias and the SiLU in the epilogue: B.pre keeps the pre-activation, B.s its activation
         KPD_TRY(gemm(T, false, true, M, g.so, g.h, B.sh, g.h, g.Ws.w + g.si, g.si + g.h, 1.0f, B.pre, g.so, 1.0f, nullptr, g.bs.w, B.s));
     }
-    KPD_TRY(gemm(T, false, true, M, g.vo, g.so, B.s, g.so, g.Wg.w, g.so, 0.0f, B.gate, g.vo, 1.0f, nullptr, g.bg.w));
+    if (!gate_parts) KPD_TRY(gemm(T, false, true, M, g.vo, g.so, B.s, g.so, g.Wg.w, g.so, 0.0f, B.gate, g.vo, 1.0f, nullptr, g.bg.w));
     tot = (long long)M * g.vo;
-    if ((g.vo & 3) == 0) hipLaunchKernelGGL(k_gvp_gate<4>, grid1(3 * tot / 4), dim3(256), 0, T->st, B.gate, B.Vu, 3 * M, g.vo / 4, identity ? 1 : 0, B.V);
-    else hipLaunchKernelGGL(k_gvp_gate<1>, grid1(3 * tot), dim3(256), 0, T->st, B.gate, B.Vu, 3 * M, g.vo, identity ? 1 : 0, B.V);
+    const float *p1 = gate_parts ? T->dgate : nullptr;
+    if ((g.vo & 3) == 0) hipLaunchKernelGGL(k_gvp_gate<4>, grid1(tot / 4), dim3(256), 0, T->st, B.gate, p1, g.bg.w, B.Vu, M, g.vo / 4, identity ? 1 : 0, B.V);
+    else hipLaunchKernelGGL(k_gvp_gate<1>, grid1(tot), dim3(256), 0, T->st, B.gate, p1, g.bg.w, B.Vu, M, g.vo, identity ? 1 : 0, B.V);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
 }

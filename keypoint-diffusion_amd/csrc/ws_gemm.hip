@@ -17,7 +17,10 @@
 //                 more B operand, its column 16 (if any) through the rank-1 path of the 257th input;
 //   extra outputs (WsgExtra::Y2, WS_PLAIN): Y2 = X W2, 16 columns as a ninth output tile of the second half's workgroups, a 17th through
 //                 the row-dot path of the 257th output.
-// Either replaces a separate rows x 256 x 16 library product and its pass over a rows x 256 matrix.
+//   gates (WsgExtra::G2, with extra inputs): G2 / G2b[row][0..15] = the two halves' shares of A Wg^T, the product of the ACTIVATED output with a
+//                 16 x 256 matrix (scalar_to_vector_gates, gvp.py:108-111): the epilogue's registers are already the B operand of a
+//                 chained 16x16x4 MFMA, so it costs 32 MFMAs per 16 rows; the consumer adds the two halves and the bias.
+// Each replaces a separate rows x 256 x 16 library product and its pass over a rows x 256 matrix.
 #include "chain_core.h"
 #include "engine.h"
 
@@ -30,9 +33,11 @@ constexpr int WSG_W4 = 16 * 8 * 64;                           // float4 of the r
 constexpr int WSG_LDS_BYTES = WSG_W4 * 16 + (128 + 128 + HS + HS) * 4;      // half block, column 256, bias, row 256, row-dot vector
 constexpr int WSG_X4 = 16 * 64;                               // float4 of the extra fragments: one k-block of this half's 8 output tiles (extra inputs:
                                                               // 8 x 64, padded) or 16 k-blocks of one output tile (extra outputs)
-constexpr int WSG_LDS_BYTES_X = WSG_LDS_BYTES + WSG_X4 * 16;
+constexpr int WSG_G4 = 8 * 64;                                // float4 of the gate fragments of one half (8 k-blocks of 16 columns)
+constexpr int WSG_LDS_BYTES_X = WSG_LDS_BYTES + WSG_X4 * 16 + WSG_G4 * 16;
 constexpr int WSG_PACK_EXT = 16 * 16 * 64 * 4 + 256 + HS;     // offset of the extra fragments in the pack
-constexpr int WSG_PACK_FLOATS = WSG_PACK_EXT + 16 * 256;      // fragments, column 256, row 256 (padded), extra fragments
+constexpr int WSG_PACK_GATE = WSG_PACK_EXT + 16 * 256;        // offset of the gate fragments (16 k-blocks x 64 lanes x 4)
+constexpr int WSG_PACK_FLOATS = WSG_PACK_GATE + 16 * 256;     // fragments, column 256, row 256 (padded), extra fragments, gate fragments
 
 __device__ __forceinline__ float wsg_sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }      // (1 ulp; the division sequence cost 12 % of the kernel)
 
@@ -40,8 +45,9 @@ __device__ __forceinline__ float wsg_sigm(float x) { return __builtin_amdgcn_rcp
 // ext_mode 1 (extra inputs kx < ext_n <= 17, E[n][kx] = ext[n * ext_sn + kx * ext_sk]): the fragments of k-block 16 (inputs 0..15) and, in
 // the slot of M[:, 256], E[:, 16];  ext_mode 2 (extra outputs nx < ext_n <= 17, E[nx][k] = ext[nx * ext_sn + k * ext_sk]): the fragments of
 // output tile 16 for the 16 k-blocks and, in the slot of M[256, :], E[16, :]
+// gate (optional): Wg [gate_n <= 16][256] (row stride gate_ld): fragments of output tile "gates" for the 16 k-blocks of the activated output
 __global__ void k_wsg_pack(const float *__restrict__ src, int sn, int sk, int has257, float *__restrict__ dst, const float *__restrict__ ext,
-                           int ext_sn, int ext_sk, int ext_mode, int ext_n) {
+                           int ext_sn, int ext_sk, int ext_mode, int ext_n, const float *__restrict__ gate, int gate_ld, int gate_n) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < 16 * 16 * 256) {
         const int r = idx & 3, lane = (idx >> 2) & 63, mt = (idx >> 8) & 15, ks = idx >> 12;
@@ -54,7 +60,11 @@ __global__ void k_wsg_pack(const float *__restrict__ src, int sn, int sk, int ha
         const int k = idx - 16 * 16 * 256 - 256;
         dst[idx] = (has257 && k <= 256) ? src[(size_t)256 * sn + (size_t)k * sk]
                                         : (ext_mode == 2 && ext_n > 16 && k < 256) ? ext[(size_t)16 * ext_sn + (size_t)k * ext_sk] : 0.0f;
-    } else if (idx < WSG_PACK_FLOATS) {
+    } else if (idx >= WSG_PACK_GATE && idx < WSG_PACK_FLOATS) {
+        const int i = idx - WSG_PACK_GATE, r = i & 3, lane = (i >> 2) & 63, kb = i >> 8;
+        const int n = lane & 15, k = 16 * kb + 4 * (lane >> 4) + r;
+        dst[idx] = (gate && n < gate_n) ? gate[(size_t)n * gate_ld + k] : 0.0f;
+    } else if (idx < WSG_PACK_GATE) {
         const int i = idx - WSG_PACK_EXT, r = i & 3, lane = (i >> 2) & 63, t = i >> 8;       // t: output tile (mode 1) / k-block (mode 2)
         float v = 0.0f;
         if (ext_mode == 1) {
@@ -82,10 +92,38 @@ struct WsgArgs {
     const float *X2;        // extra inputs [rows, ldx2], x2n <= 17 columns (EXT = 1)
     float *Y2;              // extra outputs [rows, ldy2], y2n <= 17 columns (EXT = 2)
     int ldx2, x2n, ldy2, y2n;
+    float *G2, *G2b;        // [rows][16] gate shares of the two halves (EXT = 1, optional)
 };
 
 template <int MODE, int EXT>
-__device__ __forceinline__ void wsg_store(const WsgArgs &a, int row, int hf, int q, v4f (&acc)[8], float out256, const float *s_rd, const v4f &acc_e) {
+__device__ __forceinline__ void wsg_store(const WsgArgs &a, int row, int hf, int q, v4f (&acc)[8], float out256, const float *s_rd, const v4f &acc_e,
+                                          const v4f *Wgf, int lane) {
+    if (EXT == 1) {
+        // (no accumulate, no 257th output, no row-dot in this form.)  The activation first, for every lane -- the gate product is an MFMA and
+        // wants the whole wave -- then the stores of the valid rows.
+        v4f sv[8], ga = zero4();
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sv[m][r] = acc[m][r] * wsg_sigm(acc[m][r]);
+        if (a.G2) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const v4f wg = Wgf[m * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ga = mfma16(wg[r], sv[m][r], ga);
+            }
+        }
+        if (row < 0 || row >= a.rows) return;
+        float *yrow = a.Y + (size_t)row * a.ldy + 128 * hf, *arow = a.A + (size_t)row * a.ldy + 128 * hf;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            *reinterpret_cast<v4f *>(yrow + 16 * m + 4 * q) = acc[m];
+            *reinterpret_cast<v4f *>(arow + 16 * m + 4 * q) = sv[m];
+        }
+        if (a.G2) *reinterpret_cast<v4f *>((hf ? a.G2b : a.G2) + (size_t)row * 16 + 4 * q) = ga;
+        return;
+    }
     if (row < 0 || row >= a.rows) return;             // (the four lanes of a row leave together: the shuffles below stay converged)
     if (EXT == 2) {
         float *y2 = a.Y2 + (size_t)row * a.ldy2;
@@ -175,6 +213,7 @@ __global__ __launch_bounds__(512, 1) void k_ws_gemm(WsgArgs a) {
     v4f *W = reinterpret_cast<v4f *>(smem);
     float *s_wcol = smem + WSG_W4 * 4, *s_bias = s_wcol + 128, *s_wrow = s_bias + 128, *s_rd = s_wrow + HS;
     [[maybe_unused]] v4f *Wx = reinterpret_cast<v4f *>(s_rd + HS);      // EXT: the extra fragments
+    [[maybe_unused]] v4f *Wgf = Wx + WSG_X4;                            // EXT = 1: the gate fragments of this half
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int hf = blockIdx.x / a.bpc, chunk = blockIdx.x - hf * a.bpc;
     const int tiles = (a.rows + WSG_TILE - 1) / WSG_TILE;
@@ -193,7 +232,10 @@ __global__ __launch_bounds__(512, 1) void k_ws_gemm(WsgArgs a) {
             s_bias[tid] = a.bias ? a.bias[128 * hf + tid] : 0.0f;
         }
         for (int i = tid; i < HS; i += 512) s_wrow[i] = wrow[i];
-        if (EXT == 1) Wx[tid] = reinterpret_cast<const v4f *>(a.pack + WSG_PACK_EXT)[8 * hf * 64 + tid];                  // 8 output tiles x 64 lanes
+        if (EXT == 1) {
+            Wx[tid] = reinterpret_cast<const v4f *>(a.pack + WSG_PACK_EXT)[8 * hf * 64 + tid];                            // 8 output tiles x 64 lanes
+            Wgf[tid] = reinterpret_cast<const v4f *>(a.pack + WSG_PACK_GATE)[8 * hf * 64 + tid];                          // 8 k-blocks x 64 lanes
+        }
         if (EXT == 2) {
             Wx[tid] = reinterpret_cast<const v4f *>(a.pack + WSG_PACK_EXT)[tid];                                         // 16 k-blocks x 64 lanes
             Wx[512 + tid] = reinterpret_cast<const v4f *>(a.pack + WSG_PACK_EXT)[512 + tid];
@@ -238,7 +280,7 @@ __global__ __launch_bounds__(512, 1) void k_ws_gemm(WsgArgs a) {
             for (int r = 0; r < 4; ++r) asm volatile("v_mov_b32 %0, %1" : "=v"(x[nt][r]) : "v"(xn[nt][r]));
         asm volatile("v_mov_b32 %0, %1" : "=v"(x256) : "v"(x256n));
         __builtin_amdgcn_sched_barrier(0);
-        wsg_store<MODE, EXT>(a, rowp, hf, q, accp, out256p, s_rd, acc_ep);
+        wsg_store<MODE, EXT>(a, rowp, hf, q, accp, out256p, s_rd, acc_ep, Wgf, lane);
         if (t + 1 < t1) load_x(t + 1, xn, x256n);
         v4f acc[8];
 #pragma unroll
@@ -292,7 +334,7 @@ __global__ __launch_bounds__(512, 1) void k_ws_gemm(WsgArgs a) {
         rowp = t * WSG_TILE + 16 * wave + el;
         out256p = out256;
     }
-    wsg_store<MODE, EXT>(a, rowp, hf, q, accp, out256p, s_rd, acc_ep);
+    wsg_store<MODE, EXT>(a, rowp, hf, q, accp, out256p, s_rd, acc_ep, Wgf, lane);
 }
 
 }  // namespace
@@ -328,7 +370,8 @@ kpd_status ws_gemm(int mode, const float *X, int rows, int ldx, const float *W, 
     }
     // M[n][k] of "Y = X M^T": transpose_w false -> M = W (sn = ldw, sk = 1); true -> M = W^T (sn = 1, sk = ldw)
     hipLaunchKernelGGL(k_wsg_pack, dim3(cdiv(WSG_PACK_FLOATS, 256)), dim3(256), 0, st, W, transpose_w ? 1 : ldw, transpose_w ? ldw : 1,
-                       has257 ? 1 : 0, pack_scratch, ext ? ext->W : nullptr, ext ? ext->sn : 0, ext ? ext->sk : 0, em, ext ? ext->n : 0);
+                       has257 ? 1 : 0, pack_scratch, ext ? ext->W : nullptr, ext ? ext->sn : 0, ext ? ext->sk : 0, em, ext ? ext->n : 0,
+                       (ext && em == 1) ? ext->Wg : nullptr, ext ? ext->ldg : 0, ext ? ext->ng : 0);
     KPD_LAUNCH_CHECK();
     WsgArgs a;
     a.X = X; a.rows = rows; a.ldx = ldx; a.pack = pack_scratch; a.bias = bias; a.P = P; a.Y = Y; a.A = A; a.ldy = ldy; a.mode = mode;
@@ -337,6 +380,9 @@ kpd_status ws_gemm(int mode, const float *X, int rows, int ldx, const float *W, 
     a.rd_w = rowdot_w; a.rd_stride = rowdot_stride; a.rd_out = rowdot_out;
     a.X2 = em == 1 ? ext->X2 : nullptr; a.Y2 = em == 2 ? ext->Y2 : nullptr;
     a.ldx2 = a.ldy2 = ext ? ext->ld : 0; a.x2n = a.y2n = ext ? ext->n : 0;
+    a.G2 = (em == 1 && ext->Wg) ? ext->G2 : nullptr;
+    a.G2b = a.G2 ? ext->G2b : nullptr;
+    KPD_REQUIRE(!(ext && ext->Wg) || (em == 1 && ext->G2 && ext->G2b && ext->ng >= 1 && ext->ng <= 16 && ext->ldg >= 256), KPD_ERR_INVALID, "ws_gemm: gate block does not fit");
     const int tiles = cdiv(rows, WSG_TILE);
     // one workgroup per CU, one round (see launch_proj_chain): 2 * bpc <= CUs of this device
     const int cus = cu_count();
