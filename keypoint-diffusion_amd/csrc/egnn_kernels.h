@@ -60,6 +60,35 @@ struct EdgeArgs {
     float *dbg;                     // [tiles][64][4] per-row taps of the coordinate branch (builds with -DKPD_EDGE_DBG only; "edge_dbg=1")
 };
 
+// Forward edge kernel of the EGNN trainer (k_egnn_edge_train): the inference kernel's program on the current weights, keeping what the
+// backward pass reads.
+struct EdgeTrainArgs {
+    const int *meta;                // as EdgeArgs (64-edge tiles)
+    const int *src[4];
+    const int *dst[4];
+    const float *x[2];
+    const float *P[2];              // the layer's projection blocks [n][NSLOT][HS] of both node types (b1 folded into the dst slots)
+    int src_nt[4], dst_nt[4];
+    int slot[4][2][2];              // [et][branch][src | dst] -> slot of P on that side's node type
+    const float *wr[4][2], *wp[4][2], *wx[4][2];      // per (et, branch): radial row, packed second Linear (bias row at BIAS_K), its row 256
+    const float *watt[4], *w3[4];   // per et: soft-attention row (bias at ATT_BIAS_AT), coordinate-head row
+    float *hn_main[4], *hn_cont[4], *xn_main[4], *xn_cont[4];
+    int use_tanh;
+    float coords_range;
+    float *keep[4][2][4];           // [et][branch][pre1, a1, pre2, a2], each [E][HS]
+    float *att[4], *sc[4], *dij[4], *xdiff[4], *nvec[4];
+};
+
+struct EdgePackEntry {
+    const float *W1, *W2, *b2;      // [257][515], [257][257], [257] of the branch
+    const float *head, *head_b;     // soft_attention weight (+ bias) or coord_mlp.4 weight
+    float *wp, *wx, *wr, *head_out; // outputs (head_out: watt or w3)
+};
+struct EdgePackTab {
+    EdgePackEntry e[8];
+    int n;
+};
+
 struct NodeArgs {
     int n;
     float *h;                       // [n][HS] in/out
@@ -114,6 +143,10 @@ kpd_status launch_embed(const float *in, int n, int fin, const float *W0, const 
 kpd_status launch_decode(const float *h, const float *x, const float *x0, int n, int atom_nf, int hid, const float *W0,
                          const float *b0, const float *W1, const float *b1, float *eps_h, float *eps_x, hipStream_t st);
 kpd_status launch_egnn_edge(const EdgeArgs &a, int tile_cap, hipStream_t st);
+kpd_status launch_egnn_edge_train(const EdgeTrainArgs &a, int tile_cap, hipStream_t st);
+kpd_status launch_edge_pieces_sum(const float *hn_main, const float *hn_cont, const float *xn_main, const float *xn_cont, const int *rowptr,
+                                  const float *zinv, int n, float *hn, float *xn, hipStream_t st);
+kpd_status launch_edge_train_pack(const EdgePackTab &t, hipStream_t st);
 kpd_status launch_proj_chain(const ProjPair &p, hipStream_t st);
 kpd_status launch_node_layer(const NodeLayerPair &p, hipStream_t st);
 

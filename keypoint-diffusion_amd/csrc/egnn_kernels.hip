@@ -574,6 +574,335 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
 }
 
 
+// ---- training form of the fused edge kernel (egnn_train.hip, forward pass) -----------------------------------------------------
+// The same workgroup program as k_egnn_edge<4> -- gather P_src + P_dst + d w_r, SiLU, the 257 x 257 Linear on fp32 MFMA, SiLU, soft
+// attention / coordinate head, segmented sum over the tile's destination runs -- on the CURRENT weights (packed per step, unscaled:
+// plain SiLU instead of the pre-scaled form) and with everything the backward pass reads stored on the way: pre1, a1 (from the gather's
+// registers, one 1-KiB row segment per wave store), pre2, a2 (from the accumulators: 32 consecutive columns of two rows per store), the
+// attention weight, the coordinate scalar and the geometry.  It replaces k_edge_pre1 + k_ws_gemm<0> + the head and segmented-sum
+// kernels of the forward pass (three passes over E x 257 matrices less per branch).
+struct EdgeKeep {
+    float *pre1, *a1, *pre2, *a2;          // rows e0 .. of the branch's kept arrays [E][HS]
+};
+
+// (addresses of the kept rows: a wave-uniform row base -- scalar registers -- plus one 32-bit lane offset, so that the sixteen rows of a
+// wave cost no vector registers for addresses; the opaque asm keeps the compiler from carrying offsets from one phase to the next)
+__device__ __forceinline__ void edge_gather_finish_train(const EdgeGather<4> &g, const EdgeSmem &s, const float *__restrict__ wr, int wave, int lane,
+                                                         const EdgeKeep &k, int ne) {
+    constexpr int RPW = TM / 4;
+    const f32x4 w0 = reinterpret_cast<const f32x4 *>(wr)[lane];
+    f32x4 dv[RPW / 4];
+#pragma unroll
+    for (int i = 0; i < RPW / 4; ++i) dv[i] = *reinterpret_cast<const f32x4 *>(s.d + wave * RPW + 4 * i);
+    unsigned voff = 16u * lane;
+    asm volatile("" : "+v"(voff));
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int r = wave * RPW + rr;
+        const f32x4 v = g.ps[rr] + g.pd[rr] + dv[rr >> 2][rr & 3] * w0;          // (b1 rides in the dst projection)
+        f32x4 a;
+        a[0] = silu(v[0]); a[1] = silu(v[1]); a[2] = silu(v[2]); a[3] = silu(v[3]);
+        *reinterpret_cast<f32x4 *>(s.A + r * SA + 4 * lane) = a;
+        if (r < ne) {
+            char *p1 = reinterpret_cast<char *>(k.pre1 + (size_t)r * HS), *pa = reinterpret_cast<char *>(k.a1 + (size_t)r * HS);
+            *reinterpret_cast<f32x4 *>(p1 + voff) = v;
+            *reinterpret_cast<f32x4 *>(pa + voff) = a;
+        }
+    }
+    if (lane < 4 * RPW && (lane & 3) < 2) {
+        const int r = wave * RPW + (lane >> 2), c = lane & 3;
+        const f32x4 w1 = reinterpret_cast<const f32x4 *>(wr)[64 + c];
+        const f32x4 u = g.tps + g.tpd + s.d[r] * w1;             // column 256; the padding columns come out as exact zeros
+        f32x4 a;
+        a[0] = silu(u[0]); a[1] = silu(u[1]); a[2] = silu(u[2]); a[3] = silu(u[3]);
+        if (r < ne) {
+            const unsigned o = (unsigned)(r * HS + 256 + 4 * c) * 4u;
+            *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(k.pre1) + o) = u;
+            *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(k.a1) + o) = a;
+        }
+        if (c == (BIAS_K - 256) / 4) a[(BIAS_K - 256) % 4] = 1.0f;   // constant-1 column of the LDS tile only: the GEMM adds the bias row itself
+        *reinterpret_cast<f32x4 *>(s.A + r * SA + 256 + 4 * c) = a;
+    }
+}
+
+// T = SiLU(acc) to LDS; pre2 = acc (bias included: bias row of the GEMM) and a2 = T to the kept arrays
+__device__ __forceinline__ void store_T_train(float *T, const f32x16 (&acc)[2][2], float ex, int tid, int wave, int lane, const EdgeKeep &k, int ne) {
+    // element (row, col) of accumulator register reg of tile (mt, nt): row = 32 mt + 8 (reg >> 2) + (reg & 3) + 4 (lane >> 5),
+    // col = 64 wave + 32 nt + (lane & 31): one lane offset, everything else is a constant (groups of four rows within the 4-KiB immediate)
+    const int row0 = 4 * (lane >> 5), col0 = 64 * wave + (lane & 31);
+    unsigned off0 = (unsigned)(row0 * HS + col0) * 4u;
+    asm volatile("" : "+v"(off0));
+    char *b2 = reinterpret_cast<char *>(k.pre2), *ba = reinterpret_cast<char *>(k.a2);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const unsigned off = off0 + (unsigned)((32 * mt + 8 * q4) * HS + 32 * nt) * 4u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = 32 * mt + 8 * q4 + j + row0;
+                    const float v = acc[mt][nt][4 * q4 + j], a = silu(v);
+                    T[row * SA + col0 + 32 * nt] = a;
+                    if (row < ne) {
+                        *reinterpret_cast<float *>(b2 + (off + (unsigned)(j * HS * 4))) = v;
+                        *reinterpret_cast<float *>(ba + (off + (unsigned)(j * HS * 4))) = a;
+                    }
+                }
+            }
+    if ((tid & 3) == 0) {
+        const int row = tid >> 2;
+        const float a = silu(ex);
+        T[row * SA + 256] = a;
+        if (row < ne) {
+            k.pre2[row * HS + 256] = ex;
+            k.a2[row * HS + 256] = a;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void k_egnn_edge_train(EdgeTrainArgs a) {
+    constexpr int NW = 4, TPR = 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const EdgeSmem s = edge_smem(smem);
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int T = a.meta[8];
+    const int chunk = (T + 7) >> 3;
+    const int bi = blockIdx.x >> 3;
+    if (bi >= chunk) return;
+    const int tile = (blockIdx.x & 7) * chunk + bi;
+    if (tile >= T) return;
+    int et = 0;
+#pragma unroll
+    for (int e = 1; e < 4; ++e)
+        if (tile >= a.meta[4 + e]) et = e;
+    const int tile_in_et = tile - a.meta[4 + et];
+    const int e0 = tile_in_et * TM;
+    const int ne = min(TM, a.meta[et] - e0);
+    const int snt = a.src_nt[et], dnt = a.dst_nt[et];
+    const int *__restrict__ esrc = a.src[et];
+    const int *__restrict__ edst = a.dst[et];
+    const float *Ps_e = a.P[snt] + (size_t)a.slot[et][0][0] * HS, *Pd_e = a.P[dnt] + (size_t)a.slot[et][0][1] * HS;
+    const float *Ps_c = a.P[snt] + (size_t)a.slot[et][1][0] * HS, *Pd_c = a.P[dnt] + (size_t)a.slot[et][1][1] * HS;
+    EdgeKeep ke, kc;
+    ke.pre1 = a.keep[et][0][0] + (size_t)e0 * HS; ke.a1 = a.keep[et][0][1] + (size_t)e0 * HS;
+    ke.pre2 = a.keep[et][0][2] + (size_t)e0 * HS; ke.a2 = a.keep[et][0][3] + (size_t)e0 * HS;
+    kc.pre1 = a.keep[et][1][0] + (size_t)e0 * HS; kc.a1 = a.keep[et][1][1] + (size_t)e0 * HS;
+    kc.pre2 = a.keep[et][1][2] + (size_t)e0 * HS; kc.a2 = a.keep[et][1][3] + (size_t)e0 * HS;
+
+    EdgeGather<NW> ge;
+    edge_gather_issue_early<NW>(ge, esrc, edst, e0, ne, Ps_e, Pd_e, wave, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    // phase 0: endpoints and geometry (dynamics.py:160-169, 209-217), kept for the backward pass; head rows to LDS
+    if (tid < TM) {
+        const int e = e0 + min(tid, ne - 1);
+        const int u = esrc[e], v = edst[e];
+        s.src[tid] = (int)((unsigned)u * PROW_B);
+        s.dst[tid] = (int)((unsigned)v * PROW_B);
+        const float *xs = a.x[snt] + (size_t)u * 3, *xd = a.x[dnt] + (size_t)v * 3;
+        const float dx = xs[0] - xd[0], dy = xs[1] - xd[1], dz = xs[2] - xd[2];
+        const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float inv = 1.0f / (d + 1.0f);
+        s.d[tid] = d;
+        s.xd[3 * tid] = dx * inv;
+        s.xd[3 * tid + 1] = dy * inv;
+        s.xd[3 * tid + 2] = dz * inv;
+        if (tid < ne) {
+            a.dij[et][e] = d;
+            float *xo = a.xdiff[et] + (size_t)e * 3, *no = a.nvec[et] + (size_t)e * 3;
+            xo[0] = dx; xo[1] = dy; xo[2] = dz;
+            no[0] = dx * inv; no[1] = dy * inv; no[2] = dz * inv;
+        }
+        const int vprev = tid > 0 ? edst[e0 + min(tid - 1, ne - 1)] : (e0 > 0 ? edst[e0 - 1] : -1);
+        const int vnext = tid + 1 < ne ? edst[e0 + tid + 1] : -2;
+        const unsigned long long heads = __ballot(tid < ne && (tid == 0 || vprev != v));
+        const unsigned long long ends = __ballot(tid < ne && vnext != v);
+        if (tid == 0) {
+            s.misc[0] = (vprev == v) ? 1 : 0;
+            s.misc[2] = (int)(ends & 0xffffffffu);
+            s.misc[3] = (int)(ends >> 32);
+            s.misc[4] = (int)(heads & 0xffffffffu);
+            s.misc[5] = (int)(heads >> 32);
+        }
+    } else {
+        for (int i = tid - TM; i < 4 * 66; i += 64 * NW - TM) {
+            const int which = i / 66, j = i - which * 66;
+            const float *row = which == 0 ? a.watt[et] : which == 1 ? a.w3[et] : which == 2 ? a.wx[et][0] : a.wx[et][1];
+            reinterpret_cast<f32x4 *>(s.wv + which * HS)[j] = reinterpret_cast<const f32x4 *>(row)[j];
+        }
+    }
+    BPrefetch bpre;
+    gemm_b_prefetch(bpre, a.wp[et][0], wave, lane);
+    lds_barrier();
+
+    const int first_is_cont = s.misc[0];
+    const unsigned long long endmask = ((unsigned long long)(unsigned)s.misc[3] << 32) | (unsigned long long)(unsigned)s.misc[2];
+    f32x16 acc[2][2];
+    float ex;
+
+    // ---- feature messages (dynamics.py:103-112)
+    edge_gather_finish_train(ge, s, a.wr[et][0], wave, lane, ke, ne);
+    lds_barrier();
+    acc_zero_w<NW>(acc);
+    ex = row_dot_chunks<TPR>(s.A, s.wv + 2 * HS, KP / 4, tid);
+    gemm_rows64_pre<NG, SA>(s.A, a.wp[et][0], acc, wave, lane, bpre);
+    gemm_b_prefetch(bpre, a.wp[et][1], wave, lane);
+    lds_barrier();
+    store_T_train(s.A, acc, ex, tid, wave, lane, ke, ne);
+    lds_barrier();
+    {
+        float dot = row_dot_chunks<TPR>(s.A, s.wv, 64, tid);
+        const int row = tid / TPR;
+        if ((tid % TPR) == 0) {
+            dot = fmaf(s.A[row * SA + 256], s.wv[256], dot);
+            const float at = row < ne ? sigmoidf_(dot + s.wv[ATT_BIAS_AT]) : 0.0f;
+            s.att[row] = at;
+            if (row < ne) a.att[et][e0 + row] = at;
+        }
+    }
+    lds_barrier();
+    EdgeGather<NW> gc;
+    edge_gather_issue<NW>(gc, s, Ps_c, Pd_c, wave, lane);      // the coordinate branch's rows travel during the segmented sum
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        // segmented sum over dst (dynamics.py:182-185), as in k_egnn_edge
+        float *hmain = a.hn_main[et], *hcont = a.hn_cont[et] + (size_t)tile_in_et * HS;
+        if (tid < 256) {
+            float run = 0.0f;
+            int piece = 0;
+#pragma unroll 1
+            for (int r0 = 0; r0 < TM; r0 += 16) {
+                if (r0 >= ne) break;
+                float v[16], w[16];
+                int dvv[16];
+                {
+                    typedef int i32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const i32x4 t = *reinterpret_cast<const i32x4 *>(s.dst + r0 + 4 * j);
+                        dvv[4 * j] = t[0]; dvv[4 * j + 1] = t[1]; dvv[4 * j + 2] = t[2]; dvv[4 * j + 3] = t[3];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    w[i] = s.att[r0 + i];
+                    v[i] = s.A[(r0 + i) * SA + tid];
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    run = fmaf(v[i], w[i], run);
+                    if ((endmask >> (r0 + i)) & 1ull) {
+                        float *out = (piece == 0 && first_is_cont) ? hcont : hmain + ((unsigned)dvv[i] / (unsigned)(NSLOT * 4));
+                        out[tid] = run;
+                        run = 0.0f;
+                        ++piece;
+                    }
+                }
+            }
+        }
+        if (wave == NW - 1) reinterpret_cast<float *>(s.misc + 8)[lane] = s.A[lane * SA + 256] * s.att[lane];
+    }
+    lds_barrier();
+
+    // ---- coordinate messages (dynamics.py:113-120)
+    edge_gather_finish_train(gc, s, a.wr[et][1], wave, lane, kc, ne);
+    lds_barrier();
+    acc_zero_w<NW>(acc);
+    ex = row_dot_chunks<TPR>(s.A, s.wv + 3 * HS, KP / 4, tid);
+    gemm_rows64_pre<NG, SA>(s.A, a.wp[et][1], acc, wave, lane, bpre);
+    lds_barrier();
+    store_T_train(s.A, acc, ex, tid, wave, lane, kc, ne);
+    lds_barrier();
+    {
+        float dot = row_dot_chunks<TPR>(s.A, s.wv + HS, 64, tid);
+        const int row = tid / TPR;
+        if ((tid % TPR) == 0) {
+            dot = fmaf(s.A[row * SA + 256], s.wv[HS + 256], dot);
+            float c = a.use_tanh ? tanhf(dot) * a.coords_range : dot;
+            if (row >= ne) c = 0.0f;
+            else a.sc[et][e0 + row] = dot;
+            s.mx[3 * row] = c * s.xd[3 * row];
+            s.mx[3 * row + 1] = c * s.xd[3 * row + 1];
+            s.mx[3 * row + 2] = c * s.xd[3 * row + 2];
+        }
+    }
+    lds_barrier();
+    if (wave == 0) {
+        const unsigned long long heads = ((unsigned long long)(unsigned)s.misc[5] << 32) | (unsigned long long)(unsigned)s.misc[4];
+        const unsigned long long upto = lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull);
+        const int start = 63 - __clzll((long long)((heads & upto) | 1ull));
+        float vx = s.mx[3 * lane], vy = s.mx[3 * lane + 1], vz = s.mx[3 * lane + 2];
+        float vh = reinterpret_cast<const float *>(s.misc + 8)[lane];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float tx = __shfl_up(vx, off), ty = __shfl_up(vy, off), tz = __shfl_up(vz, off), th = __shfl_up(vh, off);
+            if (lane - off >= start) {
+                vx += tx;
+                vy += ty;
+                vz += tz;
+                vh += th;
+            }
+        }
+        if ((endmask >> lane) & 1ull) {
+            const int piece = __popcll(endmask & ((1ull << lane) - 1ull));
+            const unsigned dsto = (unsigned)s.dst[lane];
+            float *out = (piece == 0 && first_is_cont) ? a.xn_cont[et] + (size_t)tile_in_et * 4 : a.xn_main[et] + (size_t)(dsto / PROW_B) * 4;
+            out[0] = vx;
+            out[1] = vy;
+            out[2] = vz;
+            float *oh = (piece == 0 && first_is_cont) ? a.hn_cont[et] + (size_t)tile_in_et * HS : a.hn_main[et] + (dsto / (unsigned)(NSLOT * 4));
+            oh[256] = vh;
+        }
+    }
+}
+
+// h_neigh[v] += zinv[v] * (main[v] + the continuation pieces of the tiles its in-edges span), x_neigh likewise: the pieces of
+// k_egnn_edge_train summed in tile order (one wave per destination node; nodes without in-edges are left alone)
+__global__ __launch_bounds__(256) void k_edge_pieces_sum(const float *__restrict__ hn_main, const float *__restrict__ hn_cont, const float *__restrict__ xn_main,
+                                                         const float *__restrict__ xn_cont, const int *__restrict__ rowptr, const float *__restrict__ zinv,
+                                                         int n, float *__restrict__ hn, float *__restrict__ xn) {
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (v >= n) return;
+    const int lo = rowptr[v], hi = rowptr[v + 1];
+    if (hi == lo) return;
+    const float zi = zinv[v];
+    const int t0 = (lo >> 6) + 1, t1 = (hi - 1) >> 6;
+    f32x4 s = *reinterpret_cast<const f32x4 *>(hn_main + (size_t)v * HS + 4 * lane);
+    float t = lane == 0 ? hn_main[(size_t)v * HS + 256] : (lane >= 1 && lane < 4) ? xn_main[(size_t)v * 4 + lane - 1] : 0.0f;
+    for (int k = t0; k <= t1; ++k) {
+        s += *reinterpret_cast<const f32x4 *>(hn_cont + (size_t)k * HS + 4 * lane);
+        t += lane == 0 ? hn_cont[(size_t)k * HS + 256] : (lane >= 1 && lane < 4) ? xn_cont[(size_t)k * 4 + lane - 1] : 0.0f;
+    }
+    f32x4 *o = reinterpret_cast<f32x4 *>(hn + (size_t)v * HS + 4 * lane);
+    *o += s * zi;
+    if (lane == 0) hn[(size_t)v * HS + 256] += t * zi;
+    else if (lane < 4) xn[(size_t)v * 3 + lane - 1] += t * zi;
+}
+
+// The per-step weight pack of one layer for k_egnn_edge_train: for entry (et, branch) the 257 x 257 second Linear in MFMA fragment
+// order with its bias as row BIAS_K (wp, wx), the radial column of the first Linear as a row (wr); per et the two head rows (watt with
+// its bias at ATT_BIAS_AT, w3).
+__global__ void k_edge_train_pack(EdgePackTab t) {
+    const EdgePackEntry &e = t.e[blockIdx.y];
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < WP_FLOATS) {
+        const int j = idx & 3, nt = (idx >> 2) & 1, lane = (idx >> 3) & 63, wave = (idx >> 9) & 3, g = idx >> 11;
+        const int k = 8 * g + 4 * (lane >> 5) + j;
+        const int n = 64 * wave + 32 * nt + (lane & 31);
+        e.wp[idx] = k < HW ? e.W2[(size_t)n * HW + k] : k == BIAS_K ? e.b2[n] : 0.0f;
+    } else if (idx < WP_FLOATS + HS) {
+        const int k = idx - WP_FLOATS;
+        e.wx[k] = k < HW ? e.W2[(size_t)256 * HW + k] : k == BIAS_K ? e.b2[256] : 0.0f;
+    } else if (idx < WP_FLOATS + 2 * HS) {
+        const int k = idx - WP_FLOATS - HS;
+        e.wr[k] = k < HW ? e.W1[(size_t)k * (2 * HW + 1) + 2 * HW] : 0.0f;
+    } else if (idx < WP_FLOATS + 3 * HS) {
+        const int k = idx - WP_FLOATS - 2 * HS;
+        if (e.head_out) e.head_out[k] = k < HW ? e.head[k] : (k == ATT_BIAS_AT && e.head_b) ? e.head_b[0] : 0.0f;
+    }
+}
+
 // ---- f16x2 form of the fused edge kernel (opt-in: KPD_GEMM=f16x2 / "gemm=f16x2") ----------------------------------------------
 // Same phases and the same fp32 epilogues as k_egnn_edge<4>; the two 257 x 257 products run as three f16 MFMA products of
 // hi / lo operand planes with fp32 accumulation (mfma_core.h, gemm_rows64_h).  The A tile is written as two f16 planes by the
@@ -1404,5 +1733,28 @@ kpd_status launch_node_layer(const NodeLayerPair &p, hipStream_t st) {
     return KPD_OK;
 }
 
+
+kpd_status launch_egnn_edge_train(const EdgeTrainArgs &a, int tile_cap, hipStream_t st) {
+    if (tile_cap == 0) return KPD_OK;
+    KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_egnn_edge_train), EDGE_LDS_BYTES));
+    hipLaunchKernelGGL(k_egnn_edge_train, dim3(8 * cdiv(tile_cap, 8)), dim3(256), EDGE_LDS_BYTES, st, a);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+kpd_status launch_edge_pieces_sum(const float *hn_main, const float *hn_cont, const float *xn_main, const float *xn_cont, const int *rowptr,
+                                  const float *zinv, int n, float *hn, float *xn, hipStream_t st) {
+    if (n == 0) return KPD_OK;
+    hipLaunchKernelGGL(k_edge_pieces_sum, dim3(cdiv(n, 4)), dim3(256), 0, st, hn_main, hn_cont, xn_main, xn_cont, rowptr, zinv, n, hn, xn);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+kpd_status launch_edge_train_pack(const EdgePackTab &t, hipStream_t st) {
+    if (t.n == 0) return KPD_OK;
+    hipLaunchKernelGGL(k_edge_train_pack, dim3(cdiv(WP_FLOATS + 3 * HS, 256), t.n), dim3(256), 0, st, t);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
 
 }  // namespace kpd

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void k_edge_pre1(const float *__restrict__ U, 
     __shared__ __attribute__((aligned(16))) float s_w[LD], s_b[LD];
     for (int c = threadIdx.x; c < LD; c += 256) {
         s_w[c] = c < H ? wr[(size_t)c * ldw] : 0.0f;
-        s_b[c] = c < H ? b1[c] : 0.0f;
+        s_b[c] = (b1 && c < H) ? b1[c] : 0.0f;
     }
     __syncthreads();
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // total = E * (LD / 4)
@@ -435,8 +435,8 @@ __global__ void k_geom_bwd(const float *__restrict__ ddij, const float *__restri
 // (ducat^T h, with the b1 gradients as its column sums) -- instead of 8 ligand-sized products each, which ran at a fraction of the
 // GPU (13 row tiles) and paid a split-K reduction apiece.
 struct CatSlot {
-    const float *w;             // W1 of the branch [257][515]
-    float *g, *bg;              // its gradient (or null); b1 gradient (dst slots, or null)
+    const float *w, *b;         // W1 of the branch [257][515]; b1 (dst slots: it rides in the projection) or null
+    float *g, *bg;              // the gradient of W1 (or null); b1 gradient (dst slots, or null)
     int col0, nt, slot, dvw;    // first column of the block in W1; node type; slot in wcat[nt]; index of the slot among the dst slots of nt (-1: src)
 };
 struct CatTab {
@@ -444,12 +444,13 @@ struct CatTab {
     int n;
 };
 constexpr int CAT_LD = NSLOT * LD;            // row stride of ucat / ducat
-__global__ void k_cat_stage(CatTab t, float *__restrict__ wcat0, float *__restrict__ wcat1) {
+__global__ void k_cat_stage(CatTab t, float *__restrict__ wcat0, float *__restrict__ wcat1, float *__restrict__ bcat0, float *__restrict__ bcat1) {
     const CatSlot &e = t.s[blockIdx.y];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= LD * LD) return;
     const int r = i / LD, c = i - r * LD;
     (e.nt ? wcat1 : wcat0)[(size_t)e.slot * LD * LD + i] = (r < H && c < H) ? e.w[(size_t)r * (2 * H + 1) + e.col0 + c] : 0.0f;
+    if (i < LD) (e.nt ? bcat1 : bcat0)[e.slot * LD + i] = (e.b && i < H) ? e.b[i] : 0.0f;
 }
 // W1.g[:, block] += dwcat[slot]; b1.g += column sums of dV (dbcat); W1.g[:, 514] += column sums of dVw (dwr).  One thread per element.
 __global__ void k_cat_scatter(CatTab t, const float *__restrict__ dwcat0, const float *__restrict__ dwcat1, const float *__restrict__ dbcat0,
@@ -511,8 +512,12 @@ struct kpd_egnn_trainer : TrainCtx {
     std::vector<Slot> slots;                       // [layer * 4 + et]
     // batched first-layer products of the current layer (k_cat_stage): staged weights, projections, per-node gradients and their staging
     float *wcat[2] = {nullptr, nullptr}, *ucat[2] = {nullptr, nullptr}, *ducat[2] = {nullptr, nullptr}, *dvwcat[2] = {nullptr, nullptr},
-          *dwcat[2] = {nullptr, nullptr}, *dbcat[2] = {nullptr, nullptr}, *dwr[2] = {nullptr, nullptr};
+          *dwcat[2] = {nullptr, nullptr}, *dbcat[2] = {nullptr, nullptr}, *dwr[2] = {nullptr, nullptr}, *bcat[2] = {nullptr, nullptr};
     CatTab cat{};
+    // forward edge kernel (k_egnn_edge_train): per-step weight pack of the current layer, segment pieces, whether slots of a whole layer exist
+    float *epack = nullptr, *hn_main[4] = {nullptr, nullptr, nullptr, nullptr}, *hn_cont[4] = {nullptr, nullptr, nullptr, nullptr},
+          *xn_main[4] = {nullptr, nullptr, nullptr, nullptr}, *xn_cont[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool layer_slots = false, fused = false;
     int cat_slots[2] = {0, 0}, cat_dvw[2] = {0, 0};
     int cat_of[4][2][2] = {}, cat_dvw_of[4][2] = {};   // [et][branch][src | dst] -> slot on that side's node type; [et][branch] -> dvw index
     std::vector<float *> nq[2][3];                 // kept node-MLP activations q1, c1, q2 of every (node type, layer), with the edge activations
@@ -527,6 +532,12 @@ const char *kEt[4] = {"ll", "kl", "lk", "kk"};
 const char *kNt[2] = {"lig", "kp"};
 const int kS[4] = {NT_LIG, NT_KP, NT_LIG, NT_KP};     // source node type of ll, kl, lk, kk
 const int kD[4] = {NT_LIG, NT_LIG, NT_KP, NT_KP};
+
+// the forward edge pass as ONE kernel per layer (k_egnn_edge_train); KPD_TRAIN_FUSED_FWD=0: first-layer kernel + weight-stationary GEMM + heads
+bool want_fused_fwd() {
+    static const bool on = !(getenv("KPD_TRAIN_FUSED_FWD") && atoi(getenv("KPD_TRAIN_FUSED_FWD")) == 0);
+    return on;
+}
 
 bool use_ws() {
     static const bool on = !(getenv("KPD_TRAIN_WS") && atoi(getenv("KPD_TRAIN_WS")) == 0);
@@ -561,7 +572,7 @@ kpd_status edge_branch_fwd(kpd_egnn_trainer *T, const BranchParams &p, int et, i
     const float *U = T->ucat[kS[et]] + (size_t)T->cat_of[et][branch][0] * LD, *V = T->ucat[kD[et]] + (size_t)T->cat_of[et][branch][1] * LD;
     const long long tot = (long long)E * H;
     hipLaunchKernelGGL(k_edge_pre1, grid1((long long)E * (LD / 4)), dim3(256), 0, T->st, U, V, T->e_src[et], T->e_dst[et], T->dij,
-                       p.W1.w + 2 * H, 2 * H + 1, p.b1.w, (long long)E * (LD / 4), CAT_LD, T->eb[0], T->eb[1]);
+                       p.W1.w + 2 * H, 2 * H + 1, (const float *)nullptr, (long long)E * (LD / 4), CAT_LD, T->eb[0], T->eb[1]);
     KPD_LAUNCH_CHECK();
     // pre2 = a1 W2^T + b2, a2 = SiLU(pre2): the weight-stationary GEMM with the activation fused (KPD_TRAIN_WS=0: general GEMM + kernel)
     if (use_ws())
@@ -588,7 +599,7 @@ inline int layer_n_upd(const kpd_egnn_trainer *T, int l) { return l == T->cfg.n_
 
 // point the per-edge buffers at the kept activations of (layer, edge type, branch), or at the scratch set when nothing is kept
 void bind_slot(kpd_egnn_trainer *T, int l, int et, int branch) {
-    const kpd_egnn_trainer::Slot &sl = T->store ? T->slots[(size_t)l * 4 + et] : T->scratch;
+    const kpd_egnn_trainer::Slot &sl = T->layer_slots ? T->slots[(size_t)l * 4 + et] : T->scratch;
     for (int k = 0; k < 4; ++k) T->eb[k] = sl.e[branch][k];
     T->att = sl.att; T->dij = sl.dij; T->xdiff = sl.xdiff; T->nvec = sl.nvec; T->sc = sl.sc; T->msgx = sl.msgx;
 }
@@ -606,7 +617,7 @@ kpd_status layer_stage(kpd_egnn_trainer *T, int l) {
             for (int side = 0; side < 2; ++side) {
                 const int nt = side ? kD[et] : kS[et];
                 CatSlot &e = t.s[t.n++];
-                e.w = p.W1.w; e.g = p.W1.g; e.bg = side ? p.b1.g : nullptr;
+                e.w = p.W1.w; e.b = side ? p.b1.w : nullptr; e.g = p.W1.g; e.bg = side ? p.b1.g : nullptr;
                 e.col0 = side * H; e.nt = nt; e.slot = T->cat_slots[nt]++;
                 e.dvw = side ? T->cat_dvw[nt]++ : -1;
                 T->cat_of[et][br][side] = e.slot;
@@ -615,7 +626,7 @@ kpd_status layer_stage(kpd_egnn_trainer *T, int l) {
         }
     }
     if (t.n == 0) return KPD_OK;
-    hipLaunchKernelGGL(k_cat_stage, dim3(cdiv(LD * LD, 256), t.n), dim3(256), 0, T->st, t, T->wcat[0], T->wcat[1]);
+    hipLaunchKernelGGL(k_cat_stage, dim3(cdiv(LD * LD, 256), t.n), dim3(256), 0, T->st, t, T->wcat[0], T->wcat[1], T->bcat[0], T->bcat[1]);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
 }
@@ -623,7 +634,8 @@ kpd_status layer_stage(kpd_egnn_trainer *T, int l) {
 kpd_status layer_project(kpd_egnn_trainer *T, int l) {
     for (int nt = 0; nt < 2; ++nt)
         if (T->cat_slots[nt])
-            KPD_TRY(gemm(T, false, true, T->n[nt], T->cat_slots[nt] * LD, H, T->hs[nt][l], LD, T->wcat[nt], LD, 0.0f, T->ucat[nt], CAT_LD));
+            KPD_TRY(gemm(T, false, true, T->n[nt], T->cat_slots[nt] * LD, H, T->hs[nt][l], LD, T->wcat[nt], LD, 0.0f, T->ucat[nt], CAT_LD, 1.0f, nullptr,
+                         T->bcat[nt]));          // (+ b1 on the dst slots)
     return KPD_OK;
 }
 
@@ -657,6 +669,56 @@ kpd_status layer_cat_bwd(kpd_egnn_trainer *T, int l, int nxt) {
     return KPD_OK;
 }
 
+// floats of the per-layer weight pack of the forward edge kernel: per (et, branch) wp, wx, wr; per et watt, w3
+constexpr size_t EPACK_ENTRY = (size_t)WP_FLOATS + 2 * HS;
+constexpr size_t EPACK_FLOATS = 8 * EPACK_ENTRY + 8 * HS;
+
+// all edge types and both branches of layer l in one launch: messages, heads, segment pieces, kept activations.  sum_pieces: add the
+// aggregated messages into hns / xns (the forward pass; a recomputation for the backward pass only refills the kept arrays)
+kpd_status layer_edges_fused(kpd_egnn_trainer *T, int l, bool sum_pieces) {
+    const kpd_egnn_config &c = T->cfg;
+    EdgePackTab pk;
+    pk.n = 0;
+    EdgeTrainArgs a{};
+    a.meta = T->meta + (l == c.n_layers - 1 ? 16 : 0);
+    a.use_tanh = c.use_tanh; a.coords_range = c.coords_range;
+    int tiles = 0;
+    for (int nt = 0; nt < 2; ++nt) { a.x[nt] = T->xs[nt][l]; a.P[nt] = T->ucat[nt]; }
+    for (int et = 0; et < 4; ++et) {
+        a.src[et] = T->e_src[et]; a.dst[et] = T->e_dst[et];
+        a.src_nt[et] = kS[et]; a.dst_nt[et] = kD[et];
+        if (et >= layer_n_et(T, l) || T->E[et] == 0) continue;
+        tiles += cdiv(T->E[et], TM);
+        const kpd_egnn_trainer::Slot &sl = T->slots[(size_t)l * 4 + et];
+        float *heads = T->epack + 8 * EPACK_ENTRY + (size_t)et * 2 * HS;
+        a.watt[et] = heads; a.w3[et] = heads + HS;
+        for (int br = 0; br < 2; ++br) {
+            BranchParams p;
+            KPD_TRY(branch_params(T, l, et, br, &p));
+            float *base = T->epack + (size_t)(et * 2 + br) * EPACK_ENTRY;
+            EdgePackEntry &e = pk.e[pk.n++];
+            e.W1 = p.W1.w; e.W2 = p.W2.w; e.b2 = p.b2.w; e.head = p.head.w; e.head_b = br == 0 ? p.head_b.w : nullptr;
+            e.wp = base; e.wx = base + WP_FLOATS; e.wr = base + WP_FLOATS + HS; e.head_out = heads + (size_t)br * HS;
+            a.wp[et][br] = e.wp; a.wx[et][br] = e.wx; a.wr[et][br] = e.wr;
+            for (int side = 0; side < 2; ++side) a.slot[et][br][side] = T->cat_of[et][br][side];
+            for (int k = 0; k < 4; ++k) a.keep[et][br][k] = sl.e[br][k];
+        }
+        a.att[et] = sl.att; a.sc[et] = sl.sc; a.dij[et] = sl.dij; a.xdiff[et] = sl.xdiff; a.nvec[et] = sl.nvec;
+        a.hn_main[et] = T->hn_main[et]; a.hn_cont[et] = T->hn_cont[et]; a.xn_main[et] = T->xn_main[et]; a.xn_cont[et] = T->xn_cont[et];
+    }
+    if (tiles == 0) return KPD_OK;
+    KPD_TRY(launch_edge_train_pack(pk, T->st));
+    KPD_TRY(launch_egnn_edge_train(a, tiles, T->st));
+    if (sum_pieces)
+        for (int et = 0; et < layer_n_et(T, l); ++et) {
+            if (T->E[et] == 0) continue;
+            const int d = kD[et];
+            KPD_TRY(launch_edge_pieces_sum(T->hn_main[et], T->hn_cont[et], T->xn_main[et], T->xn_cont[et], T->e_rowptr[et], T->zinv[d], T->n[d],
+                                           T->hns[d][l], T->xns[d][l], T->st));
+        }
+    return KPD_OK;
+}
+
 // one LigRecConv layer forward (dynamics.py:124-207) from the saved inputs hs[l], xs[l] into hs[l+1], xs[l+1], hns[l], xns[l]
 kpd_status layer_fwd(kpd_egnn_trainer *T, int l) {
     const kpd_egnn_config &c = T->cfg;
@@ -666,6 +728,7 @@ kpd_status layer_fwd(kpd_egnn_trainer *T, int l) {
     }
     KPD_TRY(layer_stage(T, l));
     KPD_TRY(layer_project(T, l));
+    if (T->fused) return layer_edges_fused(T, l, true);
     for (int et = 0; et < layer_n_et(T, l); ++et) {
         const int E = T->E[et], s = kS[et], d = kD[et];
         if (E == 0) continue;
@@ -908,7 +971,12 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
     for (int nt = 0; nt < 2; ++nt) {
         for (int k = 0; k < 3; ++k) add((size_t)nn[nt] * CAT_LD, 4);              // ucat, ducat, dvwcat
         add((size_t)NSLOT * LD * LD, 4); add((size_t)NSLOT * LD * LD, 4);          // wcat, dwcat
-        add((size_t)NSLOT * LD, 4); add((size_t)NSLOT * LD, 4);                    // dbcat, dwr
+        add((size_t)NSLOT * LD, 4); add((size_t)NSLOT * LD, 4); add((size_t)NSLOT * LD, 4);   // dbcat, dwr, bcat
+    }
+    add(EPACK_FLOATS, 4);
+    for (int et = 0; et < 4; ++et) {
+        const int cap = et == 0 ? cap_ll : et == 3 ? std::max<int>(max_n_kk, 1) : cap_kl;
+        add((size_t)nn[kD[et]] * LD, 4); add((size_t)(cdiv(cap, TM) + 1) * LD, 4); add((size_t)nn[kD[et]] * 4, 4); add((size_t)(cdiv(cap, TM) + 1) * 4, 4);
     }
     add((size_t)ws_gemm_pack_floats(), 4);
     add(GRAD_PART_FLOATS, 4);
@@ -952,9 +1020,16 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
         T->dwcat[nt] = W.take<float>((size_t)NSLOT * LD * LD);
         T->dbcat[nt] = W.take<float>((size_t)NSLOT * LD);
         T->dwr[nt] = W.take<float>((size_t)NSLOT * LD);
+        T->bcat[nt] = W.take<float>((size_t)NSLOT * LD);
         // (the padding columns 257 .. 263 of every slot are never written by the segmented sums and are read by the products: zeros)
         KPD_HIP(hipMemset(T->ducat[nt], 0, (size_t)nn[nt] * CAT_LD * 4));
         KPD_HIP(hipMemset(T->dvwcat[nt], 0, (size_t)nn[nt] * CAT_LD * 4));
+    }
+    T->epack = W.take<float>(EPACK_FLOATS);
+    for (int et = 0; et < 4; ++et) {
+        const int cap = et == 0 ? cap_ll : et == 3 ? std::max<int>(max_n_kk, 1) : cap_kl;
+        T->hn_main[et] = W.take<float>((size_t)nn[kD[et]] * LD); T->hn_cont[et] = W.take<float>((size_t)(cdiv(cap, TM) + 1) * LD);
+        T->xn_main[et] = W.take<float>((size_t)nn[kD[et]] * 4); T->xn_cont[et] = W.take<float>((size_t)(cdiv(cap, TM) + 1) * 4);
     }
     T->wsg_pack = W.take<float>((size_t)ws_gemm_pack_floats());
     T->part_floats = GRAD_PART_FLOATS;
@@ -995,13 +1070,28 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
         size_t per_layer = 0;
         for (int et = 0; et < T->n_et; ++et) per_layer += 8 * al((size_t)cap_et[et] * LD) + 3 * al(cap_et[et]) + 3 * al((size_t)cap_et[et] * 3);
         for (int nt = 0; nt < T->n_upd; ++nt) per_layer += 3 * al((size_t)nn[nt] * LD);
-        const size_t total = per_layer * L;
-        if (want && hipMalloc(reinterpret_cast<void **>(&T->store_base), total) == hipSuccess) {
-            T->store = true;
+        // all layers (activations kept: backward recomputes nothing), else one layer's edge slots (the forward edge kernel fills a whole layer
+        // at a time; backward recomputes layer by layer), else the per-branch scratch set
+        size_t edge_layer = 0;
+        for (int et = 0; et < T->n_et; ++et) edge_layer += 8 * al((size_t)cap_et[et] * LD) + 3 * al(cap_et[et]) + 3 * al((size_t)cap_et[et] * 3);
+        int keep_layers = 0;
+        if (want && hipMalloc(reinterpret_cast<void **>(&T->store_base), per_layer * L) == hipSuccess) keep_layers = L;
+        else {
+            (void)hipGetLastError();              // a failed allocation is not an error: recompute instead
+            T->store_base = nullptr;
+            if (want_fused_fwd() && hipMalloc(reinterpret_cast<void **>(&T->store_base), edge_layer) == hipSuccess) keep_layers = 1;
+            else { (void)hipGetLastError(); T->store_base = nullptr; }
+        }
+        T->store = keep_layers == L && want;
+        T->layer_slots = keep_layers >= 1;
+        T->fused = want_fused_fwd() && T->layer_slots;
+        for (int nt = 0; nt < 2; ++nt)
+            for (int k = 0; k < 3; ++k) T->nq[nt][k].assign(L, nullptr);
+        if (T->layer_slots) {
             T->slots.assign((size_t)L * 4, kpd_egnn_trainer::Slot());
             char *p = T->store_base;
             auto take = [&](size_t floats) { float *r = reinterpret_cast<float *>(p); p += al(floats); return r; };
-            for (int l = 0; l < L; ++l)
+            for (int l = 0; l < (T->store ? L : 1); ++l)
                 for (int et = 0; et < T->n_et; ++et) {
                     kpd_egnn_trainer::Slot &sl = T->slots[(size_t)l * 4 + et];
                     for (int br = 0; br < 2; ++br)
@@ -1009,15 +1099,13 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
                     sl.att = take(cap_et[et]); sl.dij = take(cap_et[et]); sl.sc = take(cap_et[et]);
                     sl.xdiff = take((size_t)cap_et[et] * 3); sl.nvec = take((size_t)cap_et[et] * 3); sl.msgx = take((size_t)cap_et[et] * 3);
                 }
-            for (int nt = 0; nt < 2; ++nt)
-                for (int k = 0; k < 3; ++k) {
-                    T->nq[nt][k].assign(L, nullptr);
-                    if (nt < T->n_upd)
+            if (!T->store)
+                for (int l = 1; l < L; ++l)
+                    for (int et = 0; et < 4; ++et) T->slots[(size_t)l * 4 + et] = T->slots[et];         // every layer uses the one set
+            if (T->store)
+                for (int nt = 0; nt < T->n_upd; ++nt)
+                    for (int k = 0; k < 3; ++k)
                         for (int l = 0; l < L; ++l) T->nq[nt][k][l] = take((size_t)nn[nt] * LD);
-                }
-        } else {
-            (void)hipGetLastError();              // a failed allocation is not an error: recompute instead
-            T->store_base = nullptr;
         }
     }
     hipLaunchKernelGGL(k_fill, grid1(n_ones), dim3(256), 0, nullptr, T->ones, 1.0f, (long long)n_ones);
@@ -1076,7 +1164,7 @@ extern "C" kpd_status kpd_egnn_trainer_forward(kpd_egnn_trainer *T, const kpd_ba
     KPD_TRY(launch_node_graph_index(bt->kp_ptr, bt->B, bt->n_kp, T->bidx[1], st));
     KPD_TRY(launch_lig_graph(bt, c.ll_cutoff, c.ll_k, c.kl_cutoff, c.kl_k, &T->lg, T->ll_deg, T->ll_off, T->kl_off, T->kl_pg, st));
     const int active = c.update_kp_feat ? 0xF : 0x3;
-    KPD_TRY(launch_egnn_meta(T->lg.counts, bt->n_kk, active, active, bt->lig_ptr, bt->kp_ptr, T->lg.ll_per_graph, bt->kk_rowptr, bt->B, T->kl_off,
+    KPD_TRY(launch_egnn_meta(T->lg.counts, bt->n_kk, active, 0x3, bt->lig_ptr, bt->kp_ptr, T->lg.ll_per_graph, bt->kk_rowptr, bt->B, T->kl_off,
                              c.message_norm, c.update_kp_feat, T->meta, T->z[0], T->z[1], st));
     // edge counts drive GEMM shapes: one read-back per training step
     int counts[2];
@@ -1185,16 +1273,18 @@ kpd_status layer_bwd(kpd_egnn_trainer *T, int l, int cur, int nxt, float *dhn[2]
     for (int nt = 0; nt < layer_n_upd(T, l); ++nt) KPD_TRY(node_bwd(T, l, nt, cur, nxt, dhn[nt]));
     KPD_TRY(layer_stage(T, l));
     if (!T->store) KPD_TRY(layer_project(T, l));
+    const bool recompute = !T->store && !T->fused;          // per edge type and branch below; the fused kernel refills a whole layer here
+    if (!T->store && T->fused) KPD_TRY(layer_edges_fused(T, l, false));
     for (int et = 0; et < layer_n_et(T, l); ++et) {
         const int E = T->E[et], s = kS[et], d = kD[et];
         if (E == 0) continue;
         bind_slot(T, l, et, 0);
-        if (!T->store) KPD_TRY(geom_fwd(T, et, T->xs[s][l], T->xs[d][l]));
+        if (recompute) KPD_TRY(geom_fwd(T, et, T->xs[s][l], T->xs[d][l]));
         KPD_HIP(hipMemsetAsync(T->dn, 0, (size_t)E * 12, T->st));
         BranchParams p;
         // feature branch
         KPD_TRY(branch_params(T, l, et, 0, &p));
-        if (!T->store) {           // (the same head path as the forward pass: the two modes stay bit-identical)
+        if (recompute) {           // (the same head path as the forward pass: the two modes stay bit-identical)
             KPD_TRY(edge_branch_fwd(T, p, et, 0, use_ws() ? T->ddpart : nullptr));
             if (use_ws()) hipLaunchKernelGGL(k_head_att, grid1(E), dim3(256), 0, T->st, T->ddpart, E, p.head_b.w, T->att);
             else hipLaunchKernelGGL(k_rowdot, dim3(cdiv(E, 4)), dim3(256), 0, T->st, T->eb[3], p.head.w, p.head_b.w, E, 1, T->att);
@@ -1214,7 +1304,7 @@ kpd_status layer_bwd(kpd_egnn_trainer *T, int l, int cur, int nxt, float *dhn[2]
         // coordinate branch
         bind_slot(T, l, et, 1);
         KPD_TRY(branch_params(T, l, et, 1, &p));
-        if (!T->store) {
+        if (recompute) {
             KPD_TRY(edge_branch_fwd(T, p, et, 1, use_ws() ? T->ddpart : nullptr));
             if (use_ws())
                 hipLaunchKernelGGL(k_coord_msg_parts, grid1(E), dim3(256), 0, T->st, T->ddpart, T->nvec, E, c.use_tanh, c.coords_range, T->sc, T->msgx);
