@@ -587,6 +587,17 @@ struct EdgeKeep {
 
 // (addresses of the kept rows: a wave-uniform row base -- scalar registers -- plus one 32-bit lane offset, so that the sixteen rows of a
 // wave cost no vector registers for addresses; the opaque asm keeps the compiler from carrying offsets from one phase to the next)
+// (the kept arrays are written once and read in the backward pass, tens of milliseconds later; non-temporal stores for them were
+// measured -- 1.354 vs 1.283 ms per launch, not better -- and stay behind -DKPD_KEEP_NT)
+template <class V>
+__device__ __forceinline__ void keep_store(V *p, const V &v) {
+#ifdef KPD_KEEP_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 __device__ __forceinline__ void edge_gather_finish_train(const EdgeGather<4> &g, const EdgeSmem &s, const float *__restrict__ wr, int wave, int lane,
                                                          const EdgeKeep &k, int ne) {
     constexpr int RPW = TM / 4;
@@ -605,8 +616,8 @@ __device__ __forceinline__ void edge_gather_finish_train(const EdgeGather<4> &g,
         *reinterpret_cast<f32x4 *>(s.A + r * SA + 4 * lane) = a;
         if (r < ne) {
             char *p1 = reinterpret_cast<char *>(k.pre1 + (size_t)r * HS), *pa = reinterpret_cast<char *>(k.a1 + (size_t)r * HS);
-            *reinterpret_cast<f32x4 *>(p1 + voff) = v;
-            *reinterpret_cast<f32x4 *>(pa + voff) = a;
+            keep_store(reinterpret_cast<f32x4 *>(p1 + voff), v);
+            keep_store(reinterpret_cast<f32x4 *>(pa + voff), a);
         }
     }
     if (lane < 4 * RPW && (lane & 3) < 2) {
@@ -617,8 +628,8 @@ __device__ __forceinline__ void edge_gather_finish_train(const EdgeGather<4> &g,
         a[0] = silu(u[0]); a[1] = silu(u[1]); a[2] = silu(u[2]); a[3] = silu(u[3]);
         if (r < ne) {
             const unsigned o = (unsigned)(r * HS + 256 + 4 * c) * 4u;
-            *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(k.pre1) + o) = u;
-            *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(k.a1) + o) = a;
+            keep_store(reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(k.pre1) + o), u);
+            keep_store(reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(k.a1) + o), a);
         }
         if (c == (BIAS_K - 256) / 4) a[(BIAS_K - 256) % 4] = 1.0f;   // constant-1 column of the LDS tile only: the GEMM adds the bias row itself
         *reinterpret_cast<f32x4 *>(s.A + r * SA + 256 + 4 * c) = a;
@@ -646,8 +657,8 @@ __device__ __forceinline__ void store_T_train(float *T, const f32x16 (&acc)[2][2
                     const float v = acc[mt][nt][4 * q4 + j], a = silu(v);
                     T[row * SA + col0 + 32 * nt] = a;
                     if (row < ne) {
-                        *reinterpret_cast<float *>(b2 + (off + (unsigned)(j * HS * 4))) = v;
-                        *reinterpret_cast<float *>(ba + (off + (unsigned)(j * HS * 4))) = a;
+                        keep_store(reinterpret_cast<float *>(b2 + (off + (unsigned)(j * HS * 4))), v);
+                        keep_store(reinterpret_cast<float *>(ba + (off + (unsigned)(j * HS * 4))), a);
                     }
                 }
             }
@@ -656,8 +667,8 @@ __device__ __forceinline__ void store_T_train(float *T, const f32x16 (&acc)[2][2
         const float a = silu(ex);
         T[row * SA + 256] = a;
         if (row < ne) {
-            k.pre2[row * HS + 256] = ex;
-            k.a2[row * HS + 256] = a;
+            keep_store(k.pre2 + row * HS + 256, ex);
+            keep_store(k.a2 + row * HS + 256, a);
         }
     }
 }
