@@ -87,6 +87,28 @@ struct EdgePackEntry {
 struct EdgePackTab {
     EdgePackEntry e[8];
     int n;
+    int transposed;                 // 1: wp / wx hold W2^T without a bias row (backward: dpre1 = dpre2 W2)
+};
+
+// Backward edge kernel of the EGNN trainer (k_egnn_edge_bwd).  In place: dpre2 over keep[..][2], dpre1 over keep[..][0], ds over att,
+// d dij over sc, dn over nvec.
+struct EdgeBwdArgs {
+    const int *meta;                // as EdgeArgs (64-edge tiles)
+    const int *dst[4];
+    int dst_nt[4];
+    const float *dhn[2];            // dL / d(h_neigh / z) of the layer per node type [n][HS] (null where the type is not updated)
+    const float *dxo[2];            // dL / d x_out [n][3]
+    const float *zinv[2];
+    float *keep[4][2][4];           // [et][branch][pre1 -> dpre1, a1, pre2 -> dpre2, a2]
+    float *att[4], *sc[4], *nvec[4];
+    const float *dij[4];
+    const float *wa[4], *w3[4];     // head rows (padded to HS)
+    const float *wpT[4][2], *wxT[4][2], *wr[4][2];
+    float *dv_main[4][2], *dv_cont[4][2], *dvw_main[4][2], *dvw_cont[4][2];
+    float *part[2];                 // per branch: [tiles of the layer][2][part_ld] column-sum partials (head weight, b2)
+    int part_ld;
+    int use_tanh;
+    float coords_range;
 };
 
 struct NodeArgs {
@@ -147,6 +169,9 @@ kpd_status launch_egnn_edge_train(const EdgeTrainArgs &a, int tile_cap, hipStrea
 kpd_status launch_edge_pieces_sum(const float *hn_main, const float *hn_cont, const float *xn_main, const float *xn_cont, const int *rowptr,
                                   const float *zinv, int n, float *hn, float *xn, hipStream_t st);
 kpd_status launch_edge_train_pack(const EdgePackTab &t, hipStream_t st);
+kpd_status launch_egnn_edge_bwd(const EdgeBwdArgs &a, int tile_cap, hipStream_t st);
+kpd_status launch_edge_pieces_set(const float *m1, const float *c1, const float *m2, const float *c2, const int *rowptr, int n, float *o1, float *o2,
+                                  int ldo, hipStream_t st);
 kpd_status launch_proj_chain(const ProjPair &p, hipStream_t st);
 kpd_status launch_node_layer(const NodeLayerPair &p, hipStream_t st);
 

@@ -868,6 +868,368 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_train(EdgeTrainArgs a) {
     }
 }
 
+// ---- backward form (egnn_train.hip, backward pass of the edge MLPs of a layer) ---------------------------------------------------
+// Per 64-edge tile and branch: head backward (the rows of a2 / pre2 of the tile stream through registers: dpre2 = d(a2) SiLU'(pre2), written
+// to the LDS tile and, over pre2, to HBM for the dW2 product), the 257 x 257 product with W2 on fp32 MFMA, dpre1 = (dpre2 W2) SiLU'(pre1)
+// (pre1 read in the accumulator layout, dpre1 written over it for the by-source sums), its product with the radial column (d dij), and the
+// segmented sums over the tile's destination runs of dpre1 (dV) and of dij * dpre1 (the radial weight gradient's per-node share) as
+// main / continuation pieces -- the work of k_*_head_bwd, k_ws_gemm<WS_SILU_BWD>, k_add_halves and the by-destination k_segsum264 of
+// every (edge type, branch) in one launch per layer.  The column sums of dpre2 (b2 gradient) and of a2 ds (head weight gradient) leave as one
+// partial row per tile (k_colsum_reduce adds them in tile order).  In place: dpre2 over pre2, dpre1 over pre1, ds over att, d dij over sc,
+// dn over nvec -- each element is read by the one workgroup that overwrites it.
+struct EdgeBwdSmem {
+    float *A;
+    int *dst;                 // destination node of the row
+    float *zi, *sa, *dd;      // zinv[dst]; att (feature) / sc (coordinate); dij
+    float *g3, *nv;           // d x_out[dst] * zinv (3); nvec (3)
+    float *ddij;              // d dij of the row, both branches
+    float *c256;              // [2][TM]: column 256 of dpre1 and of dij * dpre1, for the scan
+    int *misc;
+};
+constexpr int EDGE_BWD_LDS_BYTES = TM * SA * 4 + (TM * (1 + 3 + 3 + 3 + 1 + 2) + 8) * 4;
+
+__device__ __forceinline__ EdgeBwdSmem edge_bwd_smem(float *smem) {
+    EdgeBwdSmem s;
+    s.A = smem;
+    s.dst = reinterpret_cast<int *>(smem + TM * SA);
+    s.zi = reinterpret_cast<float *>(s.dst + TM);
+    s.sa = s.zi + TM;
+    s.dd = s.sa + TM;
+    s.g3 = s.dd + TM;
+    s.nv = s.g3 + 3 * TM;
+    s.ddij = s.nv + 3 * TM;
+    s.c256 = s.ddij + TM;
+    s.misc = reinterpret_cast<int *>(s.c256 + 2 * TM);
+    return s;
+}
+
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+    for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ float silu_grad_(float x) {
+    const float sg = sigmoidf_(x);
+    return sg * (1.0f + x * (1.0f - sg));
+}
+
+// running column sums of a wave over its rows: dpre2 (-> b2 gradient) and a2 ds (-> head weight gradient); lane = columns 4 lane .. + 3, lane 0 column 256 too
+struct HeadSums {
+    f32x4 cs, ws;
+    float cs_t, ws_t;
+};
+
+// head backward of one branch for the wave's 16 rows: A rows <- dpre2 (zero rows past ne), dpre2 over pre2 in HBM
+template <bool FEAT>
+__device__ __forceinline__ void edge_head_bwd_rows(const EdgeBwdSmem &s, const EdgeBwdArgs &a, int et, int e0, int ne, int wave, int lane,
+                                                   const float *__restrict__ dhn, float *__restrict__ pre2, const float *__restrict__ a2,
+                                                   const float *__restrict__ wh, float *__restrict__ ds_out, float *__restrict__ dn_out, HeadSums &hs) {
+    constexpr int RPW = TM / 4, BATCH = 4;
+    const f32x4 wv = reinterpret_cast<const f32x4 *>(wh)[lane];
+    const float wv_t = wh[256];
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int b0 = 0; b0 < RPW; b0 += BATCH) {
+        f32x4 dm[BATCH], av[BATCH], pv[BATCH];
+        float dm_t[BATCH], av_t[BATCH], pv_t[BATCH];
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) {
+            const int r = wave * RPW + b0 + i, rc = min(r, ne - 1);
+            const size_t eo = (size_t)(e0 + rc) * HS;
+            av[i] = *reinterpret_cast<const f32x4 *>(a2 + eo + 4 * lane);
+            pv[i] = *reinterpret_cast<const f32x4 *>(pre2 + eo + 4 * lane);
+            av_t[i] = lane == 0 ? a2[eo + 256] : 0.0f;
+            pv_t[i] = lane == 0 ? pre2[eo + 256] : 0.0f;
+            if (FEAT) {
+                const size_t vo = (size_t)s.dst[rc] * HS;
+                dm[i] = *reinterpret_cast<const f32x4 *>(dhn + vo + 4 * lane);
+                dm_t[i] = lane == 0 ? dhn[vo + 256] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) {
+            const int r = wave * RPW + b0 + i;
+            const bool on = r < ne;
+            f32x4 g = zero;
+            float gt = 0.0f, ds = 0.0f;
+            if (FEAT) {
+                const float zi = s.zi[min(r, ne - 1)], at = s.sa[min(r, ne - 1)];
+                const f32x4 d4 = dm[i] * zi;
+                const float d_t = dm_t[i] * zi;
+                float sdot = d_t * av_t[i];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sdot = fmaf(d4[q], av[i][q], sdot);
+                ds = wave_sum64(sdot) * at * (1.0f - at);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) g[q] = (d4[q] * at + ds * wv[q]) * silu_grad_(pv[i][q]);
+                gt = (d_t * at + ds * wv_t) * silu_grad_(pv_t[i]);
+            } else {
+                const int rc = min(r, ne - 1);
+                const float sc = s.sa[rc];
+                const float gx = s.g3[3 * rc], gy = s.g3[3 * rc + 1], gz = s.g3[3 * rc + 2];
+                const float dcoef = gx * s.nv[3 * rc] + gy * s.nv[3 * rc + 1] + gz * s.nv[3 * rc + 2];
+                // 1 - tanh^2 = 4 e / (1 + e)^2, e = exp(-2 |sc|): exact near saturation, where 1 - th * th cancels to nothing
+                const float ex_ = expf(-2.0f * fabsf(sc)), sech2 = 4.0f * ex_ / ((1.0f + ex_) * (1.0f + ex_));
+                ds = a.use_tanh ? dcoef * a.coords_range * sech2 : dcoef;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) g[q] = ds * wv[q] * silu_grad_(pv[i][q]);
+                gt = ds * wv_t * silu_grad_(pv_t[i]);
+                if (on && lane == 0) {
+                    const float coef = a.use_tanh ? tanhf(sc) * a.coords_range : sc;
+                    float *dn = dn_out + (size_t)(e0 + r) * 3;         // (over nvec: the values above came from the LDS copy)
+                    dn[0] = coef * gx; dn[1] = coef * gy; dn[2] = coef * gz;
+                }
+            }
+            if (!on) { g = zero; gt = 0.0f; ds = 0.0f; }
+            *reinterpret_cast<f32x4 *>(s.A + r * SA + 4 * lane) = g;
+            if (lane < 2) {
+                f32x4 t = zero;
+                if (lane == 0) t[0] = gt;
+                *reinterpret_cast<f32x4 *>(s.A + r * SA + 256 + 4 * lane) = t;
+            }
+            if (on) {
+                *reinterpret_cast<f32x4 *>(pre2 + (size_t)(e0 + r) * HS + 4 * lane) = g;
+                if (lane == 0) {
+                    pre2[(size_t)(e0 + r) * HS + 256] = gt;
+                    if (FEAT) ds_out[e0 + r] = ds;
+                }
+            }
+            hs.cs += g;
+            hs.cs_t += gt;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hs.ws[q] = fmaf(av[i][q], ds, hs.ws[q]);
+            hs.ws_t = fmaf(av_t[i], ds, hs.ws_t);
+        }
+    }
+}
+
+// T = acc * SiLU'(pre1) to LDS and, over pre1, to HBM; rows past ne are zeros (their A rows were)
+__device__ __forceinline__ void store_T_bwd(float *T, const f32x16 (&acc)[2][2], float ex, int tid, int wave, int lane, float *__restrict__ pre1, int ne) {
+    const int row0 = 4 * (lane >> 5), col0 = 64 * wave + (lane & 31);
+    unsigned off0 = (unsigned)(row0 * HS + col0) * 4u;
+    asm volatile("" : "+v"(off0));
+    char *bp = reinterpret_cast<char *>(pre1);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            float p[2][4];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = 32 * mt + 8 * q4 + j + row0;
+                    const unsigned off = off0 + (unsigned)((32 * mt + 8 * q4 + j) * HS + 32 * nt) * 4u;
+                    p[nt][j] = row < ne ? *reinterpret_cast<const float *>(bp + off) : 0.0f;
+                }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = 32 * mt + 8 * q4 + j + row0;
+                    const unsigned off = off0 + (unsigned)((32 * mt + 8 * q4 + j) * HS + 32 * nt) * 4u;
+                    const float v = acc[mt][nt][4 * q4 + j] * silu_grad_(p[nt][j]);
+                    T[row * SA + col0 + 32 * nt] = v;
+                    if (row < ne) *reinterpret_cast<float *>(bp + off) = v;
+                }
+        }
+    if ((tid & 3) == 0) {
+        const int row = tid >> 2;
+        float v = 0.0f;
+        if (row < ne) {
+            v = ex * silu_grad_(pre1[row * HS + 256]);
+            pre1[row * HS + 256] = v;
+        }
+        T[row * SA + 256] = v;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void k_egnn_edge_bwd(EdgeBwdArgs a) {
+    constexpr int NW = 4, TPR = 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const EdgeBwdSmem s = edge_bwd_smem(smem);
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int T = a.meta[8];
+    const int chunk = (T + 7) >> 3;
+    const int bi = blockIdx.x >> 3;
+    if (bi >= chunk) return;
+    const int tile = (blockIdx.x & 7) * chunk + bi;
+    if (tile >= T) return;
+    int et = 0;
+#pragma unroll
+    for (int e = 1; e < 4; ++e)
+        if (tile >= a.meta[4 + e]) et = e;
+    const int tile_in_et = tile - a.meta[4 + et];
+    const int e0 = tile_in_et * TM;
+    const int ne = min(TM, a.meta[et] - e0);
+    const int dnt = a.dst_nt[et];
+    const int *__restrict__ edst = a.dst[et];
+
+    // phase 0: per-row scalars; run structure of the dst-sorted tile
+    if (tid < TM) {
+        const int e = e0 + min(tid, ne - 1);
+        const int v = edst[e];
+        const float zi = a.zinv[dnt][v];
+        s.dst[tid] = v;
+        s.zi[tid] = zi;
+        s.sa[tid] = a.att[et][e];
+        s.dd[tid] = a.dij[et][e];
+        s.ddij[tid] = 0.0f;
+        const float *dxo = a.dxo[dnt] + (size_t)v * 3, *nv = a.nvec[et] + (size_t)e * 3;
+        s.g3[3 * tid] = dxo[0] * zi; s.g3[3 * tid + 1] = dxo[1] * zi; s.g3[3 * tid + 2] = dxo[2] * zi;
+        s.nv[3 * tid] = nv[0]; s.nv[3 * tid + 1] = nv[1]; s.nv[3 * tid + 2] = nv[2];
+        const int vprev = tid > 0 ? edst[e0 + min(tid - 1, ne - 1)] : (e0 > 0 ? edst[e0 - 1] : -1);
+        const int vnext = tid + 1 < ne ? edst[e0 + tid + 1] : -2;
+        const unsigned long long heads = __ballot(tid < ne && (tid == 0 || vprev != v));
+        const unsigned long long ends = __ballot(tid < ne && vnext != v);
+        if (tid == 0) {
+            s.misc[0] = (vprev == v) ? 1 : 0;
+            s.misc[2] = (int)(ends & 0xffffffffu);
+            s.misc[3] = (int)(ends >> 32);
+            s.misc[4] = (int)(heads & 0xffffffffu);
+            s.misc[5] = (int)(heads >> 32);
+        }
+    }
+    BPrefetch bpre;
+    gemm_b_prefetch(bpre, a.wpT[et][0], wave, lane);
+    lds_barrier();
+    const int first_is_cont = s.misc[0];
+    const unsigned long long endmask = ((unsigned long long)(unsigned)s.misc[3] << 32) | (unsigned long long)(unsigned)s.misc[2];
+    const unsigned long long headmask = ((unsigned long long)(unsigned)s.misc[5] << 32) | (unsigned long long)(unsigned)s.misc[4];
+    f32x16 acc[2][2];
+
+#pragma unroll 1
+    for (int br = 0; br < 2; ++br) {
+        float *pre1 = a.keep[et][br][0] + (size_t)e0 * HS;
+        HeadSums hs;
+        hs.cs = f32x4{0.f, 0.f, 0.f, 0.f}; hs.ws = f32x4{0.f, 0.f, 0.f, 0.f}; hs.cs_t = 0.0f; hs.ws_t = 0.0f;
+        if (br == 0) {
+            edge_head_bwd_rows<true>(s, a, et, e0, ne, wave, lane, a.dhn[dnt], a.keep[et][0][2], a.keep[et][0][3], a.wa[et], a.att[et], nullptr, hs);
+        } else {
+            if (tid < TM) s.sa[tid] = a.sc[et][e0 + min(tid, ne - 1)];        // the coordinate scalar replaces the attention weight
+            lds_barrier();
+            edge_head_bwd_rows<false>(s, a, et, e0, ne, wave, lane, nullptr, a.keep[et][1][2], a.keep[et][1][3], a.w3[et], nullptr, a.nvec[et], hs);
+        }
+        lds_barrier();
+        acc_zero_w<NW>(acc);
+        const float ex = row_dot_chunks<TPR>(s.A, a.wxT[et][br], KP / 4, tid);
+        gemm_rows64_pre<NG, SA>(s.A, a.wpT[et][br], acc, wave, lane, bpre);
+        if (br == 0) gemm_b_prefetch(bpre, a.wpT[et][1], wave, lane);
+        lds_barrier();
+        store_T_bwd(s.A, acc, ex, tid, wave, lane, pre1, ne);
+        lds_barrier();
+        {   // d dij += dpre1 . W1[:, 514]
+            const float dot = row_dot_chunks<TPR>(s.A, a.wr[et][br], KP / 4, tid);
+            if ((tid % TPR) == 0) s.ddij[tid / TPR] += dot;
+        }
+        {   // segmented sums over dst of dpre1 (dV) and dij * dpre1 (dVw): thread = column, rows in order
+            float *m1 = a.dv_main[et][br], *c1 = a.dv_cont[et][br] + (size_t)tile_in_et * HS;
+            float *m2 = a.dvw_main[et][br], *c2 = a.dvw_cont[et][br] + (size_t)tile_in_et * HS;
+            float run = 0.0f, run2 = 0.0f;
+            int piece = 0;
+#pragma unroll 1
+            for (int r0 = 0; r0 < TM; r0 += 16) {
+                if (r0 >= ne) break;
+                float v[16], w[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    w[i] = s.dd[r0 + i];
+                    v[i] = s.A[(r0 + i) * SA + tid];
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    run += v[i];
+                    run2 = fmaf(v[i], w[i], run2);
+                    if ((endmask >> (r0 + i)) & 1ull) {
+                        const bool cont = piece == 0 && first_is_cont;
+                        const size_t vo = (size_t)s.dst[r0 + i] * HS;
+                        (cont ? c1 : m1 + vo)[tid] = run;
+                        (cont ? c2 : m2 + vo)[tid] = run2;
+                        run = 0.0f;
+                        run2 = 0.0f;
+                        ++piece;
+                    }
+                }
+            }
+            if (wave == NW - 1) {
+                const float v256 = s.A[lane * SA + 256];
+                s.c256[lane] = v256;
+                s.c256[TM + lane] = v256 * s.dd[lane];
+            }
+        }
+        lds_barrier();
+        if (wave == 0) {    // column 256: segmented inclusive scan across lanes (lane = row), the last lane of every run writes
+            const unsigned long long upto = lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull);
+            const int start = 63 - __clzll((long long)((headmask & upto) | 1ull));
+            float v1 = s.c256[lane], v2 = s.c256[TM + lane];
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const float t1 = __shfl_up(v1, off), t2 = __shfl_up(v2, off);
+                if (lane - off >= start) {
+                    v1 += t1;
+                    v2 += t2;
+                }
+            }
+            if ((endmask >> lane) & 1ull) {
+                const int piece = __popcll(endmask & ((1ull << lane) - 1ull));
+                const bool cont = piece == 0 && first_is_cont;
+                const size_t vo = (size_t)s.dst[lane] * HS;
+                (cont ? a.dv_cont[et][br] + (size_t)tile_in_et * HS : a.dv_main[et][br] + vo)[256] = v1;
+                (cont ? a.dvw_cont[et][br] + (size_t)tile_in_et * HS : a.dvw_main[et][br] + vo)[256] = v2;
+            }
+        }
+        // the tile's column sums (four waves in order) through the LDS tile, which is free now
+        {
+            float *sc = s.A, *sw = s.A + 4 * 320;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                sc[wave * 320 + 4 * lane + q] = hs.cs[q];
+                sw[wave * 320 + 4 * lane + q] = hs.ws[q];
+            }
+            if (lane == 0) {
+                sc[wave * 320 + 256] = hs.cs_t;
+                sw[wave * 320 + 256] = hs.ws_t;
+            }
+            lds_barrier();
+            float *p = a.part[br] + (size_t)tile * 2 * a.part_ld;
+            for (int c = tid; c < HW; c += 256) {
+                p[c] = (sw[c] + sw[320 + c]) + (sw[640 + c] + sw[960 + c]);                       // slot 0 -> head weight
+                p[a.part_ld + c] = (sc[c] + sc[320 + c]) + (sc[640 + c] + sc[960 + c]);          // slot 1 -> b2
+            }
+            lds_barrier();
+        }
+    }
+    if (tid < ne) a.sc[et][e0 + tid] = s.ddij[tid];          // d dij of both branches, over sc
+}
+
+// dV[v] = main[v] + the continuation pieces of the tiles v's in-edges span (zeros without in-edges), the same for dVw: the pieces of
+// k_egnn_edge_bwd in tile order, into the layer's gradient blocks (rows ldo apart)
+__global__ __launch_bounds__(256) void k_edge_pieces_set(const float *__restrict__ m1, const float *__restrict__ c1, const float *__restrict__ m2,
+                                                         const float *__restrict__ c2, const int *__restrict__ rowptr, int n, float *__restrict__ o1,
+                                                         float *__restrict__ o2, int ldo) {
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (v >= n) return;
+    const int lo = rowptr[v], hi = rowptr[v + 1];
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    float t1 = 0.0f, t2 = 0.0f;
+    if (hi > lo) {
+        s1 = *reinterpret_cast<const f32x4 *>(m1 + (size_t)v * HS + 4 * lane);
+        s2 = *reinterpret_cast<const f32x4 *>(m2 + (size_t)v * HS + 4 * lane);
+        if (lane == 0) { t1 = m1[(size_t)v * HS + 256]; t2 = m2[(size_t)v * HS + 256]; }
+        for (int k = (lo >> 6) + 1; k <= ((hi - 1) >> 6); ++k) {
+            s1 += *reinterpret_cast<const f32x4 *>(c1 + (size_t)k * HS + 4 * lane);
+            s2 += *reinterpret_cast<const f32x4 *>(c2 + (size_t)k * HS + 4 * lane);
+            if (lane == 0) { t1 += c1[(size_t)k * HS + 256]; t2 += c2[(size_t)k * HS + 256]; }
+        }
+    }
+    *reinterpret_cast<f32x4 *>(o1 + (size_t)v * ldo + 4 * lane) = s1;
+    if (lane == 0) o1[(size_t)v * ldo + 256] = t1;
+    if (o2) {
+        *reinterpret_cast<f32x4 *>(o2 + (size_t)v * ldo + 4 * lane) = s2;
+        if (lane == 0) o2[(size_t)v * ldo + 256] = t2;
+    }
+}
+
 // h_neigh[v] += zinv[v] * (main[v] + the continuation pieces of the tiles its in-edges span), x_neigh likewise: the pieces of
 // k_egnn_edge_train summed in tile order (one wave per destination node; nodes without in-edges are left alone)
 __global__ __launch_bounds__(256) void k_edge_pieces_sum(const float *__restrict__ hn_main, const float *__restrict__ hn_cont, const float *__restrict__ xn_main,
@@ -901,10 +1263,12 @@ __global__ void k_edge_train_pack(EdgePackTab t) {
         const int j = idx & 3, nt = (idx >> 2) & 1, lane = (idx >> 3) & 63, wave = (idx >> 9) & 3, g = idx >> 11;
         const int k = 8 * g + 4 * (lane >> 5) + j;
         const int n = 64 * wave + 32 * nt + (lane & 31);
-        e.wp[idx] = k < HW ? e.W2[(size_t)n * HW + k] : k == BIAS_K ? e.b2[n] : 0.0f;
+        if (t.transposed) e.wp[idx] = k < HW ? e.W2[(size_t)k * HW + n] : 0.0f;                     // "weight" of dpre1 = dpre2 W2: M[n][k] = W2[k][n], no bias
+        else e.wp[idx] = k < HW ? e.W2[(size_t)n * HW + k] : k == BIAS_K ? e.b2[n] : 0.0f;
     } else if (idx < WP_FLOATS + HS) {
         const int k = idx - WP_FLOATS;
-        e.wx[k] = k < HW ? e.W2[(size_t)256 * HW + k] : k == BIAS_K ? e.b2[256] : 0.0f;
+        if (t.transposed) e.wx[k] = k < HW ? e.W2[(size_t)k * HW + 256] : 0.0f;
+        else e.wx[k] = k < HW ? e.W2[(size_t)256 * HW + k] : k == BIAS_K ? e.b2[256] : 0.0f;
     } else if (idx < WP_FLOATS + 2 * HS) {
         const int k = idx - WP_FLOATS - HS;
         e.wr[k] = k < HW ? e.W1[(size_t)k * (2 * HW + 1) + 2 * HW] : 0.0f;
@@ -1757,6 +2121,22 @@ kpd_status launch_edge_pieces_sum(const float *hn_main, const float *hn_cont, co
                                   const float *zinv, int n, float *hn, float *xn, hipStream_t st) {
     if (n == 0) return KPD_OK;
     hipLaunchKernelGGL(k_edge_pieces_sum, dim3(cdiv(n, 4)), dim3(256), 0, st, hn_main, hn_cont, xn_main, xn_cont, rowptr, zinv, n, hn, xn);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+kpd_status launch_egnn_edge_bwd(const EdgeBwdArgs &a, int tile_cap, hipStream_t st) {
+    if (tile_cap == 0) return KPD_OK;
+    KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_egnn_edge_bwd), EDGE_BWD_LDS_BYTES));
+    hipLaunchKernelGGL(k_egnn_edge_bwd, dim3(8 * cdiv(tile_cap, 8)), dim3(256), EDGE_BWD_LDS_BYTES, st, a);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+kpd_status launch_edge_pieces_set(const float *m1, const float *c1, const float *m2, const float *c2, const int *rowptr, int n, float *o1, float *o2,
+                                  int ldo, hipStream_t st) {
+    if (n == 0) return KPD_OK;
+    hipLaunchKernelGGL(k_edge_pieces_set, dim3(cdiv(n, 4)), dim3(256), 0, st, m1, c1, m2, c2, rowptr, n, o1, o2, ldo);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
 }

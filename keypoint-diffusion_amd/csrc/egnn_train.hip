@@ -517,7 +517,10 @@ struct kpd_egnn_trainer : TrainCtx {
     // forward edge kernel (k_egnn_edge_train): per-step weight pack of the current layer, segment pieces, whether slots of a whole layer exist
     float *epack = nullptr, *hn_main[4] = {nullptr, nullptr, nullptr, nullptr}, *hn_cont[4] = {nullptr, nullptr, nullptr, nullptr},
           *xn_main[4] = {nullptr, nullptr, nullptr, nullptr}, *xn_cont[4] = {nullptr, nullptr, nullptr, nullptr};
-    bool layer_slots = false, fused = false;
+    bool layer_slots = false, fused = false, fused_b = false;
+    // backward edge kernel: pieces of the by-destination sums of dpre1 and dij * dpre1 per (edge type, branch); per-tile column-sum partials
+    float *dv_main[4][2] = {}, *dv_cont[4][2] = {}, *dvw_main[4][2] = {}, *dvw_cont[4][2] = {}, *bpart[2] = {nullptr, nullptr};
+    int bpart_tiles = 0;
     int cat_slots[2] = {0, 0}, cat_dvw[2] = {0, 0};
     int cat_of[4][2][2] = {}, cat_dvw_of[4][2] = {};   // [et][branch][src | dst] -> slot on that side's node type; [et][branch] -> dvw index
     std::vector<float *> nq[2][3];                 // kept node-MLP activations q1, c1, q2 of every (node type, layer), with the edge activations
@@ -536,6 +539,12 @@ const int kD[4] = {NT_LIG, NT_LIG, NT_KP, NT_KP};
 // the forward edge pass as ONE kernel per layer (k_egnn_edge_train); KPD_TRAIN_FUSED_FWD=0: first-layer kernel + weight-stationary GEMM + heads
 bool want_fused_fwd() {
     static const bool on = !(getenv("KPD_TRAIN_FUSED_FWD") && atoi(getenv("KPD_TRAIN_FUSED_FWD")) == 0);
+    return on;
+}
+
+// the backward edge pass of a layer as one kernel (k_egnn_edge_bwd) + the products that need whole matrices; KPD_TRAIN_FUSED_BWD=0: per-branch kernels
+bool want_fused_bwd() {
+    static const bool on = !(getenv("KPD_TRAIN_FUSED_BWD") && atoi(getenv("KPD_TRAIN_FUSED_BWD")) == 0);
     return on;
 }
 
@@ -679,6 +688,7 @@ kpd_status layer_edges_fused(kpd_egnn_trainer *T, int l, bool sum_pieces) {
     const kpd_egnn_config &c = T->cfg;
     EdgePackTab pk;
     pk.n = 0;
+    pk.transposed = 0;
     EdgeTrainArgs a{};
     a.meta = T->meta + (l == c.n_layers - 1 ? 16 : 0);
     a.use_tanh = c.use_tanh; a.coords_range = c.coords_range;
@@ -974,6 +984,15 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
         add((size_t)NSLOT * LD, 4); add((size_t)NSLOT * LD, 4); add((size_t)NSLOT * LD, 4);   // dbcat, dwr, bcat
     }
     add(EPACK_FLOATS, 4);
+    {
+        int tl = 0;
+        for (int et = 0; et < 4; ++et) {
+            const int cap = et == 0 ? cap_ll : et == 3 ? std::max<int>(max_n_kk, 1) : cap_kl;
+            tl += cdiv(cap, TM) + 1;
+            for (int k = 0; k < 4; ++k) { add((size_t)nn[kD[et]] * LD, 4); add((size_t)(cdiv(cap, TM) + 1) * LD, 4); }
+        }
+        add((size_t)tl * 2 * COLSUM_LD, 4); add((size_t)tl * 2 * COLSUM_LD, 4);
+    }
     for (int et = 0; et < 4; ++et) {
         const int cap = et == 0 ? cap_ll : et == 3 ? std::max<int>(max_n_kk, 1) : cap_kl;
         add((size_t)nn[kD[et]] * LD, 4); add((size_t)(cdiv(cap, TM) + 1) * LD, 4); add((size_t)nn[kD[et]] * 4, 4); add((size_t)(cdiv(cap, TM) + 1) * 4, 4);
@@ -1026,6 +1045,19 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
         KPD_HIP(hipMemset(T->dvwcat[nt], 0, (size_t)nn[nt] * CAT_LD * 4));
     }
     T->epack = W.take<float>(EPACK_FLOATS);
+    {
+        int tl = 0;
+        for (int et = 0; et < 4; ++et) {
+            const int cap = et == 0 ? cap_ll : et == 3 ? std::max<int>(max_n_kk, 1) : cap_kl;
+            tl += cdiv(cap, TM) + 1;
+            for (int br = 0; br < 2; ++br) {
+                T->dv_main[et][br] = W.take<float>((size_t)nn[kD[et]] * LD); T->dv_cont[et][br] = W.take<float>((size_t)(cdiv(cap, TM) + 1) * LD);
+                T->dvw_main[et][br] = W.take<float>((size_t)nn[kD[et]] * LD); T->dvw_cont[et][br] = W.take<float>((size_t)(cdiv(cap, TM) + 1) * LD);
+            }
+        }
+        T->bpart_tiles = tl;
+        T->bpart[0] = W.take<float>((size_t)tl * 2 * COLSUM_LD); T->bpart[1] = W.take<float>((size_t)tl * 2 * COLSUM_LD);
+    }
     for (int et = 0; et < 4; ++et) {
         const int cap = et == 0 ? cap_ll : et == 3 ? std::max<int>(max_n_kk, 1) : cap_kl;
         T->hn_main[et] = W.take<float>((size_t)nn[kD[et]] * LD); T->hn_cont[et] = W.take<float>((size_t)(cdiv(cap, TM) + 1) * LD);
@@ -1085,6 +1117,7 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
         T->store = keep_layers == L && want;
         T->layer_slots = keep_layers >= 1;
         T->fused = want_fused_fwd() && T->layer_slots;
+        T->fused_b = T->fused && want_fused_bwd();
         for (int nt = 0; nt < 2; ++nt)
             for (int k = 0; k < 3; ++k) T->nq[nt][k].assign(L, nullptr);
         if (T->layer_slots) {
@@ -1267,6 +1300,76 @@ kpd_status edge_branch_bwd(kpd_egnn_trainer *T, const BranchParams &p, int et, i
     return KPD_OK;
 }
 
+// the edge part of layer l's backward pass through k_egnn_edge_bwd: one launch for the head backward, the dpre2 W2 product, dpre1, d dij and
+// the by-destination sums of every (edge type, branch); then, per (edge type, branch), what needs whole matrices: dW2 = dpre2^T a1, the
+// by-source sums of dpre1, the reductions of the per-tile partials
+kpd_status layer_edges_bwd_fused(kpd_egnn_trainer *T, int l, int cur, int nxt, float *dhn[2]) {
+    const kpd_egnn_config &c = T->cfg;
+    EdgePackTab pk;
+    pk.n = 0;
+    pk.transposed = 1;
+    EdgeBwdArgs a{};
+    a.meta = T->meta + (l == c.n_layers - 1 ? 16 : 0);
+    a.use_tanh = c.use_tanh; a.coords_range = c.coords_range;
+    a.part[0] = T->bpart[0]; a.part[1] = T->bpart[1]; a.part_ld = COLSUM_LD;
+    for (int nt = 0; nt < 2; ++nt) { a.dhn[nt] = dhn[nt]; a.dxo[nt] = T->dx[cur][nt]; a.zinv[nt] = T->zinv[nt]; }
+    int tiles = 0, tile0[4] = {0, 0, 0, 0};
+    for (int et = 0; et < 4; ++et) {
+        a.dst[et] = T->e_dst[et]; a.dst_nt[et] = kD[et];
+        if (et >= layer_n_et(T, l) || T->E[et] == 0) continue;
+        tile0[et] = tiles;
+        tiles += cdiv(T->E[et], TM);
+        const kpd_egnn_trainer::Slot &sl = T->slots[(size_t)l * 4 + et];
+        float *heads = T->epack + 8 * EPACK_ENTRY + (size_t)et * 2 * HS;
+        a.wa[et] = heads; a.w3[et] = heads + HS;
+        for (int br = 0; br < 2; ++br) {
+            BranchParams p;
+            KPD_TRY(branch_params(T, l, et, br, &p));
+            float *base = T->epack + (size_t)(et * 2 + br) * EPACK_ENTRY;
+            EdgePackEntry &e = pk.e[pk.n++];
+            e.W1 = p.W1.w; e.W2 = p.W2.w; e.b2 = p.b2.w; e.head = p.head.w; e.head_b = br == 0 ? p.head_b.w : nullptr;
+            e.wp = base; e.wx = base + WP_FLOATS; e.wr = base + WP_FLOATS + HS; e.head_out = heads + (size_t)br * HS;
+            a.wpT[et][br] = e.wp; a.wxT[et][br] = e.wx; a.wr[et][br] = e.wr;
+            for (int k = 0; k < 4; ++k) a.keep[et][br][k] = sl.e[br][k];
+            a.dv_main[et][br] = T->dv_main[et][br]; a.dv_cont[et][br] = T->dv_cont[et][br];
+            a.dvw_main[et][br] = T->dvw_main[et][br]; a.dvw_cont[et][br] = T->dvw_cont[et][br];
+        }
+        a.att[et] = sl.att; a.sc[et] = sl.sc; a.dij[et] = sl.dij; a.nvec[et] = sl.nvec;
+    }
+    if (tiles == 0) return KPD_OK;
+    KPD_REQUIRE(tiles <= T->bpart_tiles, KPD_ERR_CAPACITY, "per-tile partial sums: %d tiles, room for %d", tiles, T->bpart_tiles);
+    KPD_TRY(launch_edge_train_pack(pk, T->st));
+    KPD_TRY(launch_egnn_edge_bwd(a, tiles, T->st));
+    for (int et = 0; et < layer_n_et(T, l); ++et) {
+        const int E = T->E[et], s = kS[et], d = kD[et];
+        if (E == 0) continue;
+        const kpd_egnn_trainer::Slot &sl = T->slots[(size_t)l * 4 + et];
+        for (int br = 0; br < 2; ++br) {
+            BranchParams p;
+            KPD_TRY(branch_params(T, l, et, br, &p));
+            float *dpre1 = sl.e[br][0], *a1 = sl.e[br][1], *dpre2 = sl.e[br][2];
+            hipLaunchKernelGGL(k_colsum_reduce, dim3(cdiv(H, 64)), dim3(1024), 0, T->st, T->bpart[br] + (size_t)tile0[et] * 2 * COLSUM_LD, cdiv(E, TM), H,
+                               p.head.g, 1, p.b2.g);
+            KPD_LAUNCH_CHECK();
+            if (br == 0 && p.head_b.g) KPD_TRY(sum_scalar(T, sl.att, E, p.head_b.g));           // (ds of the attention logits, left over att)
+            if (p.W2.g) KPD_TRY(grad_gemm(T, H, H, E, dpre2, LD, a1, LD, p.W2.g, H));
+            float *dU = T->ducat[s] + (size_t)T->cat_of[et][br][0] * LD, *dV = T->ducat[d] + (size_t)T->cat_of[et][br][1] * LD;
+            float *dVw = T->dvwcat[d] + (size_t)T->cat_dvw_of[et][br] * LD;
+            hipLaunchKernelGGL(k_segsum264, dim3(cdiv(T->n[s], 4)), dim3(256), 0, T->st, dpre1, (const float *)nullptr, (const float *)nullptr,
+                               T->scsr[et].perm, T->scsr[et].rowptr, (const float *)nullptr, 0, T->n[s], dU, (float *)nullptr, CAT_LD);
+            KPD_LAUNCH_CHECK();
+            KPD_TRY(launch_edge_pieces_set(T->dv_main[et][br], T->dv_cont[et][br], T->dvw_main[et][br], T->dvw_cont[et][br], T->e_rowptr[et], T->n[d], dV,
+                                           p.W1.g ? dVw : nullptr, CAT_LD, T->st));
+        }
+        float *redge = sl.msgx;
+        hipLaunchKernelGGL(k_geom_bwd, grid1(E), dim3(256), 0, T->st, sl.sc, sl.nvec, sl.xdiff, sl.dij, E, redge);       // (d dij over sc, dn over nvec)
+        KPD_LAUNCH_CHECK();
+        KPD_TRY(segsum(T->st, redge, 3, 0, 3, T->scsr[et].perm, T->scsr[et].rowptr, nullptr, 1.0f, true, T->n[s], T->dx[nxt][s], 3));
+        KPD_TRY(segsum(T->st, redge, 3, 0, 3, nullptr, T->e_rowptr[et], nullptr, -1.0f, true, T->n[d], T->dx[nxt][d], 3));
+    }
+    return KPD_OK;
+}
+
 kpd_status layer_bwd(kpd_egnn_trainer *T, int l, int cur, int nxt, float *dhn[2]) {
     const kpd_egnn_config &c = T->cfg;
     // (final layer, keypoints: dh_out = dx_out = 0, so dh_in / dx_in start from the zeros the caller left in dh[nxt] / dx[nxt])
@@ -1275,6 +1378,10 @@ kpd_status layer_bwd(kpd_egnn_trainer *T, int l, int cur, int nxt, float *dhn[2]
     if (!T->store) KPD_TRY(layer_project(T, l));
     const bool recompute = !T->store && !T->fused;          // per edge type and branch below; the fused kernel refills a whole layer here
     if (!T->store && T->fused) KPD_TRY(layer_edges_fused(T, l, false));
+    if (T->fused_b) {
+        KPD_TRY(layer_edges_bwd_fused(T, l, cur, nxt, dhn));
+        return layer_cat_bwd(T, l, nxt);
+    }
     for (int et = 0; et < layer_n_et(T, l); ++et) {
         const int E = T->E[et], s = kS[et], d = kD[et];
         if (E == 0) continue;
