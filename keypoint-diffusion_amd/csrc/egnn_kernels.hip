@@ -924,7 +924,7 @@ template <bool FEAT>
 __device__ __forceinline__ void edge_head_bwd_rows(const EdgeBwdSmem &s, const EdgeBwdArgs &a, int et, int e0, int ne, int wave, int lane,
                                                    const float *__restrict__ dhn, float *__restrict__ pre2, const float *__restrict__ a2,
                                                    const float *__restrict__ wh, float *__restrict__ ds_out, float *__restrict__ dn_out, HeadSums &hs) {
-    constexpr int RPW = TM / 4, BATCH = 4;
+    constexpr int RPW = TM / 4, BATCH = 8;
     const f32x4 wv = reinterpret_cast<const f32x4 *>(wh)[lane];
     const float wv_t = wh[256];
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -1003,41 +1003,41 @@ __device__ __forceinline__ void edge_head_bwd_rows(const EdgeBwdSmem &s, const E
     }
 }
 
-// T = acc * SiLU'(pre1) to LDS and, over pre1, to HBM; rows past ne are zeros (their A rows were)
+// T = acc * SiLU'(pre1) to LDS and, over pre1, to HBM; rows past ne are zeros (their A rows were).  All 64 values of pre1 a lane needs are
+// requested before the first is used: one memory latency per tile and branch instead of one per group of rows.
 __device__ __forceinline__ void store_T_bwd(float *T, const f32x16 (&acc)[2][2], float ex, int tid, int wave, int lane, float *__restrict__ pre1, int ne) {
     const int row0 = 4 * (lane >> 5), col0 = 64 * wave + (lane & 31);
     unsigned off0 = (unsigned)(row0 * HS + col0) * 4u;
     asm volatile("" : "+v"(off0));
     char *bp = reinterpret_cast<char *>(pre1);
+    f32x16 p[2][2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            float p[2][4];
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int reg = 0; reg < 16; ++reg) {
+                const int rl = 32 * mt + 8 * (reg >> 2) + (reg & 3);
+                p[mt][nt][reg] = rl + row0 < ne ? *reinterpret_cast<const float *>(bp + (off0 + (unsigned)(rl * HS + 32 * nt) * 4u)) : 0.0f;
+            }
+    const float p256 = ((tid & 3) == 0 && (tid >> 2) < ne) ? pre1[(tid >> 2) * HS + 256] : 0.0f;
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int row = 32 * mt + 8 * q4 + j + row0;
-                    const unsigned off = off0 + (unsigned)((32 * mt + 8 * q4 + j) * HS + 32 * nt) * 4u;
-                    p[nt][j] = row < ne ? *reinterpret_cast<const float *>(bp + off) : 0.0f;
-                }
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int row = 32 * mt + 8 * q4 + j + row0;
-                    const unsigned off = off0 + (unsigned)((32 * mt + 8 * q4 + j) * HS + 32 * nt) * 4u;
-                    const float v = acc[mt][nt][4 * q4 + j] * silu_grad_(p[nt][j]);
-                    T[row * SA + col0 + 32 * nt] = v;
-                    if (row < ne) *reinterpret_cast<float *>(bp + off) = v;
-                }
-        }
+            for (int reg = 0; reg < 16; ++reg) {
+                const int rl = 32 * mt + 8 * (reg >> 2) + (reg & 3), row = rl + row0;
+                const float v = acc[mt][nt][reg] * silu_grad_(p[mt][nt][reg]);
+                T[row * SA + col0 + 32 * nt] = v;
+                if (row < ne) *reinterpret_cast<float *>(bp + (off0 + (unsigned)(rl * HS + 32 * nt) * 4u)) = v;
+            }
     if ((tid & 3) == 0) {
         const int row = tid >> 2;
         float v = 0.0f;
         if (row < ne) {
-            v = ex * silu_grad_(pre1[row * HS + 256]);
+            v = ex * silu_grad_(p256);
             pre1[row * HS + 256] = v;
         }
         T[row * SA + 256] = v;
