@@ -227,6 +227,34 @@ def test_recompute_mode_gives_the_same_gradients():
     assert all(torch.equal(a, b) for a, b in zip(*outs))
 
 
+def test_layer_edge_kernels_match_the_per_branch_kernels():
+    """The forward / backward edge passes of a layer run as one kernel each (k_egnn_edge_train, k_egnn_edge_bwd); the per-branch kernels they
+    replaced stay behind KPD_TRAIN_FUSED_FWD=0 / KPD_TRAIN_FUSED_BWD=0.  Same gradients up to summation order (the switches are read once per
+    process: child processes), on a batch whose edge counts leave ragged last tiles and a keypoint type that is updated."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ('import torch, sys; sys.path.insert(0, %r)\n'
+            'from tests import test_egnn_train_gpu as T, util\n'
+            'g, model, t = T._case(dict(util.EGNN_C2, n_layers=3), [40, 33, 57], [7, 9, 12])\n'
+            'model = model.cuda(); eh, ex = model(g.to("cuda"), t.cuda(), None)\n'
+            '(eh.square().sum() + ex.square().sum()).backward()\n'
+            'torch.save([p.grad.cpu() for p in model.parameters()], sys.argv[1])\n' % root)
+    outs = []
+    for tag, env in (('fused', {}), ('nobwd', {'KPD_TRAIN_FUSED_BWD': '0'}), ('nofwd', {'KPD_TRAIN_FUSED_FWD': '0'})):
+        base = os.path.join(root, 'gpurun_out') if os.path.isdir(os.path.join(root, 'gpurun_out')) else '/tmp'
+        path = os.path.join(base, f'_grads_{tag}.pt')
+        subprocess.run([sys.executable, '-c', code, path], check=True, env=dict(os.environ, **env), timeout=600)
+        outs.append(torch.load(path))
+        os.remove(path)
+    top = max(float(b.abs().max()) for b in outs[0])
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            scale = max(float(b.abs().max()), 1e-3 * top)          # (a gradient that is a heavily cancelling sum is judged on the model's scale)
+            assert float((a - b).abs().max()) <= 2e-4 * scale, (float((a - b).abs().max()), scale)
+
+
 def test_backward_after_the_caller_dropped_the_graph():
     """The training engines keep raw pointers into the prepared batch (per-complex offsets, the kk edge list) between forward
     and backward.  A caller that builds the graph inside a helper and keeps only the losses (train.py's step functions do) frees
