@@ -156,8 +156,8 @@ kpd_status kpd_egnn_last_counts(kpd_egnn *m, int32_t out[8], void *stream);
  * Memory: reserve() tries to keep the edge activations of every layer (18 GB at B = 64 x (300-atom pocket, 25-atom ligand)); if that
  * allocation fails it keeps one layer's worth and recomputes layer by layer in backward (same results, bit for bit).
  * Environment switches, read once per process, for A/B measurements only (defaults are the fast paths): KPD_TRAIN_STORE=0 (recompute
- * mode), KPD_TRAIN_FUSED_FWD=0 / KPD_TRAIN_FUSED_BWD=0 (per-branch kernels instead of the per-layer edge kernels), KPD_TRAIN_WS=0 and
- * KPD_SGEMM_TN256=0 (library GEMM forms), and for the GVP trainer KPD_TRAIN_VEC_FUSED=0, KPD_TRAIN_WS_EXTRA=0.
+ * mode), KPD_TRAIN_FUSED_FWD=0 / KPD_TRAIN_FUSED_BWD=0 (per-branch kernels instead of the per-layer edge kernels),
+ * KPD_SGEMM_TN256=0 (tiled weight-gradient form), and for the GVP trainer KPD_TRAIN_WS=0, KPD_TRAIN_VEC_FUSED=0, KPD_TRAIN_WS_EXTRA=0.
  * ------------------------------------------------------------------------------------- */
 typedef struct kpd_egnn_trainer kpd_egnn_trainer;
 kpd_status kpd_egnn_trainer_create(const kpd_egnn_config *cfg, kpd_egnn_trainer **out);

@@ -4,15 +4,17 @@
 // to every parameter and to the four input tensors, for the loss of KeypointDiffusion.forward
 // (models/ligand_diffuser.py:89-175), which train.py:423-524 differentiates with torch autograd.
 //
-// Formulation.  Parameters are read in place in the reference [out, in] layout (they change every optimizer step, so
-// nothing is repacked) and gradients are accumulated in the same layout.  The first-layer split of the inference path
-// carries over to the backward pass: pre1[e] = U[src] + V[dst] + d_e w_r + b1 with U = h_src W1[:, :257]^T and
-// V = h_dst W1[:, 257:514]^T, hence dW1 and dh need only the per-node sums of dpre1 (segmented by dst, scattered by src)
-// and node-sized GEMMs; the per-edge GEMMs left are pre2 = a1 W2^T, da1 = dpre2 W2 and dW2 = dpre2^T a1.  All dense
-// products are plain fp32 GEMMs / GEMVs (sgemm.hip: the library's own MFMA GEMM, on the caller's stream); gather, activation, attention / coordinate
-// heads, segmented sums, LayerNorm and geometry are the kernels below.  Memory: only the node states of every layer
-// (h, x, aggregated messages) are kept between forward and backward; per-edge activations are recomputed one edge
-// type and one branch at a time into scratch sized for the largest edge type.
+// Formulation.  Parameters are read in place in the reference [out, in] layout (they change every optimizer step; what the kernels want
+// in another order is packed per layer and step) and gradients are accumulated in the same layout.  The first-layer split of the
+// inference path carries over to the backward pass: pre1[e] = U[src] + V[dst] + d_e w_r + b1 with U = h_src W1[:, :257]^T and
+// V = h_dst W1[:, 257:514]^T, hence dW1 and dh need only the per-node sums of dpre1 (segmented by dst, scattered by src) and node-sized
+// GEMMs -- batched over all edge MLPs of a layer per node type (layer_stage / layer_project / layer_cat_bwd).  The per-edge work of a
+// layer is two kernels (egnn_kernels.hip): k_egnn_edge_train (forward: gather, SiLU, 257 x 257 product, SiLU, heads, segment pieces,
+// keeping pre1 / a1 / pre2 / a2) and k_egnn_edge_bwd (head backward, dpre2 W2, SiLU backward, d dij, by-destination sums, in place over
+// the kept arrays); dW2 = dpre2^T a1 and the by-source sums need whole matrices and stay separate (sgemm.hip, k_segsum264).  The
+// per-branch kernels those two replaced (k_edge_pre1 + ws_gemm + head / segmented-sum kernels) remain behind KPD_TRAIN_FUSED_FWD=0 /
+// KPD_TRAIN_FUSED_BWD=0 for A/B runs and as the path of an engine that could not allocate one layer of edge slots.  Memory: the edge
+// activations of all layers when they fit (18 GB at C2, B = 64), else one layer's slots and a recomputation per layer in backward.
 #include "egnn_kernels.h"
 #include "engine.h"
 #include "train_ops.h"
@@ -72,20 +74,6 @@ __global__ __launch_bounds__(256) void k_edge_pre1(const float *__restrict__ U, 
 }
 
 
-
-// one wave per row: out[r] = A[r] . w (+ bias), optionally through a sigmoid (soft attention, dynamics.py:112)
-__global__ void k_rowdot(const float *__restrict__ A, const float *__restrict__ w, const float *__restrict__ bias, int rows,
-                         int do_sigmoid, float *__restrict__ out) {
-    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (r >= rows) return;
-    float s = 0.0f;
-    for (int c = lane; c < H; c += 64) s = fmaf(A[(size_t)r * LD + c], w[c], s);
-    s = wave_sum(s);
-    if (lane == 0) {
-        if (bias) s += bias[0];
-        out[r] = do_sigmoid ? sigm(s) : s;
-    }
-}
 
 // Segmented sums of E x 257 matrices over the edges of a node (copy_e + sum and the division by z, dynamics.py:177-192, and their
 // backward counterparts): one WAVE per node, a lane owns four columns (lane 0 column 256 too), rows are fetched four at a time and added
@@ -160,7 +148,7 @@ __global__ void k_head_att(const float *__restrict__ part, int n, const float *_
     att[e] = sigm(part[e] + part[(size_t)n + e] + (bias ? bias[0] : 0.0f));
 }
 
-// k_coord_msg with the head product already taken (two shares): sc = a2 . w3, msg_x = tanh(sc) * range * n  or  sc * n
+// coordinate head from the two half-row shares of a2 . w3 (ws_gemm epilogue): sc, msg_x = tanh(sc) * range * n  or  sc * n (dynamics.py:113-120)
 __global__ void k_coord_msg_parts(const float *__restrict__ part, const float *__restrict__ nvec, int n, int use_tanh, float range,
                                   float *__restrict__ sc, float *__restrict__ msgx) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -178,21 +166,6 @@ __global__ void k_add_halves(const float *__restrict__ part, int n, int accumula
     if (e >= n) return;
     const float s = part[e] + part[(size_t)n + e];
     out[e] = accumulate ? out[e] + s : s;
-}
-
-// coordinate head: sc = a2 . w3 (no bias), msg_x = tanh(sc) * range * n  or  sc * n (dynamics.py:113-120)
-__global__ void k_coord_msg(const float *__restrict__ A, const float *__restrict__ w3, const float *__restrict__ nvec, int rows,
-                            int use_tanh, float range, float *__restrict__ sc, float *__restrict__ msgx) {
-    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (r >= rows) return;
-    float s = 0.0f;
-    for (int c = lane; c < H; c += 64) s = fmaf(A[(size_t)r * LD + c], w3[c], s);
-    s = wave_sum(s);
-    if (lane < 3) {
-        const float coef = use_tanh ? tanhf(s) * range : s;
-        msgx[3 * r + lane] = coef * nvec[3 * r + lane];
-        if (lane == 0) sc[r] = s;
-    }
 }
 
 __global__ void k_segsum3(const float *__restrict__ M, const int *__restrict__ rowptr, const float *__restrict__ zinv, int n,
@@ -548,10 +521,6 @@ bool want_fused_bwd() {
     return on;
 }
 
-bool use_ws() {
-    static const bool on = !(getenv("KPD_TRAIN_WS") && atoi(getenv("KPD_TRAIN_WS")) == 0);
-    return on;
-}
 
 struct BranchParams {
     Param W1, b1, W2, b2, head, head_b;     // head = soft_attention weight [1,257] (+ bias) or coord_mlp.4 weight [1,257]
@@ -583,14 +552,9 @@ kpd_status edge_branch_fwd(kpd_egnn_trainer *T, const BranchParams &p, int et, i
     hipLaunchKernelGGL(k_edge_pre1, grid1((long long)E * (LD / 4)), dim3(256), 0, T->st, U, V, T->e_src[et], T->e_dst[et], T->dij,
                        p.W1.w + 2 * H, 2 * H + 1, (const float *)nullptr, (long long)E * (LD / 4), CAT_LD, T->eb[0], T->eb[1]);
     KPD_LAUNCH_CHECK();
-    // pre2 = a1 W2^T + b2, a2 = SiLU(pre2): the weight-stationary GEMM with the activation fused (KPD_TRAIN_WS=0: general GEMM + kernel)
-    if (use_ws())
-        return ws_gemm(WS_BIAS_SILU, T->eb[1], E, LD, p.W2.w, H, false, p.b2.w, nullptr, T->eb[2], T->eb[3], LD, T->wsg_pack, T->st, true, false,
-                       head_part ? p.head.w : nullptr, 1, head_part);
-    KPD_TRY(gemm(T, false, true, E, H, H, T->eb[1], LD, p.W2.w, H, 0.0f, T->eb[2], LD));
-    hipLaunchKernelGGL(k_bias_silu, grid1(tot), dim3(256), 0, T->st, T->eb[2], p.b2.w, tot, H, LD, T->eb[3]);
-    KPD_LAUNCH_CHECK();
-    return KPD_OK;
+    // pre2 = a1 W2^T + b2, a2 = SiLU(pre2): the weight-stationary GEMM with the activation (and the head's row-dot) fused
+    return ws_gemm(WS_BIAS_SILU, T->eb[1], E, LD, p.W2.w, H, false, p.b2.w, nullptr, T->eb[2], T->eb[3], LD, T->wsg_pack, T->st, true, false,
+                   head_part ? p.head.w : nullptr, 1, head_part);
 }
 
 kpd_status geom_fwd(kpd_egnn_trainer *T, int et, const float *xs, const float *xd) {
@@ -746,21 +710,16 @@ kpd_status layer_fwd(kpd_egnn_trainer *T, int l) {
         KPD_TRY(geom_fwd(T, et, T->xs[s][l], T->xs[d][l]));
         BranchParams p;
         KPD_TRY(branch_params(T, l, et, 0, &p));
-        KPD_TRY(edge_branch_fwd(T, p, et, 0, use_ws() ? T->ddpart : nullptr));
-        if (use_ws()) hipLaunchKernelGGL(k_head_att, grid1(E), dim3(256), 0, T->st, T->ddpart, E, p.head_b.w, T->att);
-        else hipLaunchKernelGGL(k_rowdot, dim3(cdiv(E, 4)), dim3(256), 0, T->st, T->eb[3], p.head.w, p.head_b.w, E, 1, T->att);
+        KPD_TRY(edge_branch_fwd(T, p, et, 0, T->ddpart));
+        hipLaunchKernelGGL(k_head_att, grid1(E), dim3(256), 0, T->st, T->ddpart, E, p.head_b.w, T->att);
         KPD_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_segsum264, dim3(cdiv(T->n[d], 4)), dim3(256), 0, T->st, T->eb[3], T->att, (const float *)nullptr, (const int *)nullptr,
                            T->e_rowptr[et], T->zinv[d], 1, T->n[d], T->hns[d][l], (float *)nullptr, LD);
         KPD_LAUNCH_CHECK();
         bind_slot(T, l, et, 1);
         KPD_TRY(branch_params(T, l, et, 1, &p));
-        KPD_TRY(edge_branch_fwd(T, p, et, 1, use_ws() ? T->ddpart : nullptr));
-        if (use_ws())
-            hipLaunchKernelGGL(k_coord_msg_parts, grid1(E), dim3(256), 0, T->st, T->ddpart, T->nvec, E, c.use_tanh, c.coords_range, T->sc, T->msgx);
-        else
-            hipLaunchKernelGGL(k_coord_msg, dim3(cdiv(E, 4)), dim3(256), 0, T->st, T->eb[3], p.head.w, T->nvec, E, c.use_tanh,
-                               c.coords_range, T->sc, T->msgx);
+        KPD_TRY(edge_branch_fwd(T, p, et, 1, T->ddpart));
+        hipLaunchKernelGGL(k_coord_msg_parts, grid1(E), dim3(256), 0, T->st, T->ddpart, T->nvec, E, c.use_tanh, c.coords_range, T->sc, T->msgx);
         KPD_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_segsum3, grid1(3 * T->n[d]), dim3(256), 0, T->st, T->msgx, T->e_rowptr[et], T->zinv[d], T->n[d],
                            T->xns[d][l]);
@@ -1271,19 +1230,11 @@ kpd_status edge_branch_bwd(kpd_egnn_trainer *T, const BranchParams &p, int et, i
     float *dpre2 = T->eb[4], *dpre1 = T->eb[5];          // (the b2 gradient, the column sum of dpre2, left with the head kernel)
     if (p.W2.g) KPD_TRY(grad_gemm(T, H, H, E, dpre2, LD, T->eb[1], LD, p.W2.g, H));
     const long long tot = (long long)E * H;
-    // dpre1 = (dpre2 W2) * SiLU'(pre1)
-    if (use_ws()) {
-        // ... and d dij += dpre1 . W1[:, 514] from the same registers (two half-row shares, combined below)
-        KPD_TRY(ws_gemm(WS_SILU_BWD, dpre2, E, LD, p.W2.w, H, true, nullptr, T->eb[0], dpre1, nullptr, LD, T->wsg_pack, T->st, true, false,
-                        p.W1.w + 2 * H, 2 * H + 1, T->ddpart));
-        hipLaunchKernelGGL(k_add_halves, grid1(E), dim3(256), 0, T->st, T->ddpart, E, first_branch ? 0 : 1, T->ddij);
-        KPD_LAUNCH_CHECK();
-    } else {
-        KPD_TRY(gemm(T, false, false, E, H, H, dpre2, LD, p.W2.w, H, 0.0f, dpre1, LD));
-        hipLaunchKernelGGL(k_silu_bwd, grid1(tot), dim3(256), 0, T->st, dpre1, T->eb[0], tot, H, LD);
-        KPD_LAUNCH_CHECK();
-    }
-    if (!use_ws()) KPD_TRY(gemv_n(T, E, H, dpre1, LD, p.W1.w + 2 * H, 2 * H + 1, first_branch ? 0.0f : 1.0f, T->ddij, 1));
+    // dpre1 = (dpre2 W2) * SiLU'(pre1), and d dij += dpre1 . W1[:, 514] from the same registers (two half-row shares, combined below)
+    KPD_TRY(ws_gemm(WS_SILU_BWD, dpre2, E, LD, p.W2.w, H, true, nullptr, T->eb[0], dpre1, nullptr, LD, T->wsg_pack, T->st, true, false,
+                    p.W1.w + 2 * H, 2 * H + 1, T->ddpart));
+    hipLaunchKernelGGL(k_add_halves, grid1(E), dim3(256), 0, T->st, T->ddpart, E, first_branch ? 0 : 1, T->ddij);
+    KPD_LAUNCH_CHECK();
     // per-node sums: dV (by dst) and dU (by src), both segmented sums in a fixed order.  The two gradients that are sums over ALL edges of
     // dpre1 -- b1 (plain) and column 514 of W1 (weighted by the edge's distance) -- are taken from per-node sums as well: every edge has one
     // destination, so sum_e dpre1[e] = sum_v dV[v] (rides along with the dV^T h_dst product) and sum_e dpre1[e] d_e = sum_v dVw[v], where dVw
@@ -1392,9 +1343,8 @@ kpd_status layer_bwd(kpd_egnn_trainer *T, int l, int cur, int nxt, float *dhn[2]
         // feature branch
         KPD_TRY(branch_params(T, l, et, 0, &p));
         if (recompute) {           // (the same head path as the forward pass: the two modes stay bit-identical)
-            KPD_TRY(edge_branch_fwd(T, p, et, 0, use_ws() ? T->ddpart : nullptr));
-            if (use_ws()) hipLaunchKernelGGL(k_head_att, grid1(E), dim3(256), 0, T->st, T->ddpart, E, p.head_b.w, T->att);
-            else hipLaunchKernelGGL(k_rowdot, dim3(cdiv(E, 4)), dim3(256), 0, T->st, T->eb[3], p.head.w, p.head_b.w, E, 1, T->att);
+            KPD_TRY(edge_branch_fwd(T, p, et, 0, T->ddpart));
+            hipLaunchKernelGGL(k_head_att, grid1(E), dim3(256), 0, T->st, T->ddpart, E, p.head_b.w, T->att);
             KPD_LAUNCH_CHECK();
         }
         KPD_REQUIRE(cdiv(E, HEAD_ROWS) <= T->colpart_blocks, KPD_ERR_CAPACITY, "column-sum scratch too small");
@@ -1412,12 +1362,8 @@ kpd_status layer_bwd(kpd_egnn_trainer *T, int l, int cur, int nxt, float *dhn[2]
         bind_slot(T, l, et, 1);
         KPD_TRY(branch_params(T, l, et, 1, &p));
         if (recompute) {
-            KPD_TRY(edge_branch_fwd(T, p, et, 1, use_ws() ? T->ddpart : nullptr));
-            if (use_ws())
-                hipLaunchKernelGGL(k_coord_msg_parts, grid1(E), dim3(256), 0, T->st, T->ddpart, T->nvec, E, c.use_tanh, c.coords_range, T->sc, T->msgx);
-            else
-                hipLaunchKernelGGL(k_coord_msg, dim3(cdiv(E, 4)), dim3(256), 0, T->st, T->eb[3], p.head.w, T->nvec, E, c.use_tanh,
-                                   c.coords_range, T->sc, T->msgx);
+            KPD_TRY(edge_branch_fwd(T, p, et, 1, T->ddpart));
+            hipLaunchKernelGGL(k_coord_msg_parts, grid1(E), dim3(256), 0, T->st, T->ddpart, T->nvec, E, c.use_tanh, c.coords_range, T->sc, T->msgx);
             KPD_LAUNCH_CHECK();
         }
         hipLaunchKernelGGL(k_coord_head_bwd, dim3(cdiv(E, HEAD_ROWS)), dim3(256), 0, T->st, T->dx[cur][d], T->zinv[d], T->e_dst[et], T->nvec,
