@@ -153,7 +153,7 @@ kpd_status kpd_egnn_last_counts(kpd_egnn *m, int32_t out[8], void *stream);
  *             One host read-back of the edge counts per call (they size the GEMMs).
  *   backward: d_eps_h / d_eps_x = dL/d(eps); any of d_lig_h [n_lig, atom_nf], d_lig_x [n_lig, 3], d_kp_h [n_kp, rec_nf],
  *             d_kp_x [n_kp, 3] may be NULL (written, not accumulated, when given).  Consumes the forward.
- * Memory: reserve() tries to keep the edge activations of every layer (18 GB at B = 64 x (300-atom pocket, 25-atom ligand)); if that
+ * Memory: reserve() tries to keep the edge activations of every layer (13.5 GB at B = 64 x (300-atom pocket, 25-atom ligand)); if that
  * allocation fails it keeps one layer's worth and recomputes layer by layer in backward (same results, bit for bit).
  * Environment switches, read once per process, for A/B measurements only (defaults are the fast paths): KPD_TRAIN_STORE=0 (recompute
  * mode), KPD_TRAIN_FUSED_FWD=0 / KPD_TRAIN_FUSED_BWD=0 (per-branch kernels instead of the per-layer edge kernels),

@@ -637,7 +637,9 @@ __device__ __forceinline__ void edge_gather_finish_train(const EdgeGather<4> &g,
 }
 
 // T = SiLU(acc) to LDS; pre2 = acc (bias included: bias row of the GEMM) and a2 = T to the kept arrays
-__device__ __forceinline__ void store_T_train(float *T, const f32x16 (&acc)[2][2], float ex, int tid, int wave, int lane, const EdgeKeep &k, int ne) {
+// keep_a2 = false: a2 is not stored (the backward edge kernel recomputes it from pre2 on the way)
+__device__ __forceinline__ void store_T_train(float *T, const f32x16 (&acc)[2][2], float ex, int tid, int wave, int lane, const EdgeKeep &k, int ne,
+                                              bool keep_a2) {
     // element (row, col) of accumulator register reg of tile (mt, nt): row = 32 mt + 8 (reg >> 2) + (reg & 3) + 4 (lane >> 5),
     // col = 64 wave + 32 nt + (lane & 31): one lane offset, everything else is a constant (groups of four rows within the 4-KiB immediate)
     const int row0 = 4 * (lane >> 5), col0 = 64 * wave + (lane & 31);
@@ -658,7 +660,7 @@ __device__ __forceinline__ void store_T_train(float *T, const f32x16 (&acc)[2][2
                     T[row * SA + col0 + 32 * nt] = a;
                     if (row < ne) {
                         keep_store(reinterpret_cast<float *>(b2 + (off + (unsigned)(j * HS * 4))), v);
-                        keep_store(reinterpret_cast<float *>(ba + (off + (unsigned)(j * HS * 4))), a);
+                        if (keep_a2) keep_store(reinterpret_cast<float *>(ba + (off + (unsigned)(j * HS * 4))), a);
                     }
                 }
             }
@@ -668,7 +670,7 @@ __device__ __forceinline__ void store_T_train(float *T, const f32x16 (&acc)[2][2
         T[row * SA + 256] = a;
         if (row < ne) {
             keep_store(k.pre2 + row * HS + 256, ex);
-            keep_store(k.a2 + row * HS + 256, a);
+            if (keep_a2) keep_store(k.a2 + row * HS + 256, a);
         }
     }
 }
@@ -760,7 +762,7 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_train(EdgeTrainArgs a) {
     gemm_rows64_pre<NG, SA>(s.A, a.wp[et][0], acc, wave, lane, bpre);
     gemm_b_prefetch(bpre, a.wp[et][1], wave, lane);
     lds_barrier();
-    store_T_train(s.A, acc, ex, tid, wave, lane, ke, ne);
+    store_T_train(s.A, acc, ex, tid, wave, lane, ke, ne, a.keep_a2 != 0);
     lds_barrier();
     {
         float dot = row_dot_chunks<TPR>(s.A, s.wv, 64, tid);
@@ -823,7 +825,7 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_train(EdgeTrainArgs a) {
     ex = row_dot_chunks<TPR>(s.A, s.wv + 3 * HS, KP / 4, tid);
     gemm_rows64_pre<NG, SA>(s.A, a.wp[et][1], acc, wave, lane, bpre);
     lds_barrier();
-    store_T_train(s.A, acc, ex, tid, wave, lane, kc, ne);
+    store_T_train(s.A, acc, ex, tid, wave, lane, kc, ne, a.keep_a2 != 0);
     lds_barrier();
     {
         float dot = row_dot_chunks<TPR>(s.A, s.wv + HS, 64, tid);
@@ -936,10 +938,12 @@ __device__ __forceinline__ void edge_head_bwd_rows(const EdgeBwdSmem &s, const E
         for (int i = 0; i < BATCH; ++i) {
             const int r = wave * RPW + b0 + i, rc = min(r, ne - 1);
             const size_t eo = (size_t)(e0 + rc) * HS;
-            av[i] = *reinterpret_cast<const f32x4 *>(a2 + eo + 4 * lane);
             pv[i] = *reinterpret_cast<const f32x4 *>(pre2 + eo + 4 * lane);
-            av_t[i] = lane == 0 ? a2[eo + 256] : 0.0f;
             pv_t[i] = lane == 0 ? pre2[eo + 256] : 0.0f;
+            if (a2) {
+                av[i] = *reinterpret_cast<const f32x4 *>(a2 + eo + 4 * lane);
+                av_t[i] = lane == 0 ? a2[eo + 256] : 0.0f;
+            }
             if (FEAT) {
                 const size_t vo = (size_t)s.dst[rc] * HS;
                 dm[i] = *reinterpret_cast<const f32x4 *>(dhn + vo + 4 * lane);
@@ -950,6 +954,11 @@ __device__ __forceinline__ void edge_head_bwd_rows(const EdgeBwdSmem &s, const E
         for (int i = 0; i < BATCH; ++i) {
             const int r = wave * RPW + b0 + i;
             const bool on = r < ne;
+            if (!a2) {              // a2 = SiLU(pre2) was not kept: the same expression the forward kernel put into its tile
+#pragma unroll
+                for (int q = 0; q < 4; ++q) av[i][q] = silu(pv[i][q]);
+                av_t[i] = lane == 0 ? silu(pv_t[i]) : 0.0f;
+            }
             f32x4 g = zero;
             float gt = 0.0f, ds = 0.0f;
             if (FEAT) {
@@ -1104,11 +1113,11 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_bwd(EdgeBwdArgs a) {
         HeadSums hs;
         hs.cs = f32x4{0.f, 0.f, 0.f, 0.f}; hs.ws = f32x4{0.f, 0.f, 0.f, 0.f}; hs.cs_t = 0.0f; hs.ws_t = 0.0f;
         if (br == 0) {
-            edge_head_bwd_rows<true>(s, a, et, e0, ne, wave, lane, a.dhn[dnt], a.keep[et][0][2], a.keep[et][0][3], a.wa[et], a.att[et], nullptr, hs);
+            edge_head_bwd_rows<true>(s, a, et, e0, ne, wave, lane, a.dhn[dnt], a.keep[et][0][2], a.have_a2 ? a.keep[et][0][3] : nullptr, a.wa[et], a.att[et], nullptr, hs);
         } else {
             if (tid < TM) s.sa[tid] = a.sc[et][e0 + min(tid, ne - 1)];        // the coordinate scalar replaces the attention weight
             lds_barrier();
-            edge_head_bwd_rows<false>(s, a, et, e0, ne, wave, lane, nullptr, a.keep[et][1][2], a.keep[et][1][3], a.w3[et], nullptr, a.nvec[et], hs);
+            edge_head_bwd_rows<false>(s, a, et, e0, ne, wave, lane, nullptr, a.keep[et][1][2], a.have_a2 ? a.keep[et][1][3] : nullptr, a.w3[et], nullptr, a.nvec[et], hs);
         }
         lds_barrier();
         acc_zero_w<NW>(acc);

@@ -14,7 +14,7 @@
 // the kept arrays); dW2 = dpre2^T a1 and the by-source sums need whole matrices and stay separate (sgemm.hip, k_segsum264).  The
 // per-branch kernels those two replaced (k_edge_pre1 + ws_gemm + head / segmented-sum kernels) remain behind KPD_TRAIN_FUSED_FWD=0 /
 // KPD_TRAIN_FUSED_BWD=0 for A/B runs and as the path of an engine that could not allocate one layer of edge slots.  Memory: the edge
-// activations of all layers when they fit (18 GB at C2, B = 64), else one layer's slots and a recomputation per layer in backward.
+// activations of all layers when they fit (13.5 GB at C2, B = 64: pre1, a1, pre2 per branch), else one layer's slots and a recomputation per layer in backward.
 #include "egnn_kernels.h"
 #include "engine.h"
 #include "train_ops.h"
@@ -474,7 +474,7 @@ struct kpd_egnn_trainer : TrainCtx {
           *dn = nullptr, *msgx = nullptr;
     // Kept forward activations (KPD_TRAIN_STORE, default on): pre1 / a1 / pre2 / a2 of both MLP branches of every (layer, edge
     // type), the attention weights, the geometry and the coordinate head, so that the backward pass reads them instead of running
-    // the gather, the per-node projections and the 257 x 257 GEMM of every branch a second time (~12 % of a training step).  18 GB at
+    // the gather, the per-node projections and the 257 x 257 GEMM of every branch a second time (~12 % of a training step).  13.5 GB at
     // C2, B = 64 -- sized for a 288-GB part; if the allocation fails the engine falls back to recomputation.
     struct Slot {
         float *e[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
@@ -656,6 +656,7 @@ kpd_status layer_edges_fused(kpd_egnn_trainer *T, int l, bool sum_pieces) {
     EdgeTrainArgs a{};
     a.meta = T->meta + (l == c.n_layers - 1 ? 16 : 0);
     a.use_tanh = c.use_tanh; a.coords_range = c.coords_range;
+    a.keep_a2 = T->fused_b ? 0 : 1;           // (the per-branch backward kernels read a2; the backward edge kernel recomputes it)
     int tiles = 0;
     for (int nt = 0; nt < 2; ++nt) { a.x[nt] = T->xs[nt][l]; a.P[nt] = T->ucat[nt]; }
     for (int et = 0; et < 4; ++et) {
@@ -1059,12 +1060,15 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
         static const bool want = !(getenv("KPD_TRAIN_STORE") && atoi(getenv("KPD_TRAIN_STORE")) == 0);
         auto al = [](size_t floats) { return (floats * 4 + 255) & ~size_t(255); };
         size_t per_layer = 0;
-        for (int et = 0; et < T->n_et; ++et) per_layer += 8 * al((size_t)cap_et[et] * LD) + 3 * al(cap_et[et]) + 3 * al((size_t)cap_et[et] * 3);
+        // (with both per-layer edge kernels a2 = SiLU(pre2) is never read from memory: three kept arrays per branch instead of four)
+        const bool no_a2 = want_fused_fwd() && want_fused_bwd();
+        const int n_keep = no_a2 ? 6 : 8;
+        for (int et = 0; et < T->n_et; ++et) per_layer += n_keep * al((size_t)cap_et[et] * LD) + 3 * al(cap_et[et]) + 3 * al((size_t)cap_et[et] * 3);
         for (int nt = 0; nt < T->n_upd; ++nt) per_layer += 3 * al((size_t)nn[nt] * LD);
         // all layers (activations kept: backward recomputes nothing), else one layer's edge slots (the forward edge kernel fills a whole layer
         // at a time; backward recomputes layer by layer), else the per-branch scratch set
         size_t edge_layer = 0;
-        for (int et = 0; et < T->n_et; ++et) edge_layer += 8 * al((size_t)cap_et[et] * LD) + 3 * al(cap_et[et]) + 3 * al((size_t)cap_et[et] * 3);
+        for (int et = 0; et < T->n_et; ++et) edge_layer += n_keep * al((size_t)cap_et[et] * LD) + 3 * al(cap_et[et]) + 3 * al((size_t)cap_et[et] * 3);
         int keep_layers = 0;
         if (want && hipMalloc(reinterpret_cast<void **>(&T->store_base), per_layer * L) == hipSuccess) keep_layers = L;
         else {
@@ -1087,7 +1091,7 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
                 for (int et = 0; et < T->n_et; ++et) {
                     kpd_egnn_trainer::Slot &sl = T->slots[(size_t)l * 4 + et];
                     for (int br = 0; br < 2; ++br)
-                        for (int k = 0; k < 4; ++k) sl.e[br][k] = take((size_t)cap_et[et] * LD);
+                        for (int k = 0; k < 4; ++k) sl.e[br][k] = (k == 3 && no_a2) ? nullptr : take((size_t)cap_et[et] * LD);
                     sl.att = take(cap_et[et]); sl.dij = take(cap_et[et]); sl.sc = take(cap_et[et]);
                     sl.xdiff = take((size_t)cap_et[et] * 3); sl.nvec = take((size_t)cap_et[et] * 3); sl.msgx = take((size_t)cap_et[et] * 3);
                 }
@@ -1263,6 +1267,7 @@ kpd_status layer_edges_bwd_fused(kpd_egnn_trainer *T, int l, int cur, int nxt, f
     a.meta = T->meta + (l == c.n_layers - 1 ? 16 : 0);
     a.use_tanh = c.use_tanh; a.coords_range = c.coords_range;
     a.part[0] = T->bpart[0]; a.part[1] = T->bpart[1]; a.part_ld = COLSUM_LD;
+    a.have_a2 = 0;
     for (int nt = 0; nt < 2; ++nt) { a.dhn[nt] = dhn[nt]; a.dxo[nt] = T->dx[cur][nt]; a.zinv[nt] = T->zinv[nt]; }
     int tiles = 0, tile0[4] = {0, 0, 0, 0};
     for (int et = 0; et < 4; ++et) {
