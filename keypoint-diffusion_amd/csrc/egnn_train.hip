@@ -923,6 +923,9 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
     const int cap_kl = std::max<long>((long)max_n_kp * (c.kl_k > 0 ? c.kl_k : std::min(max_lig_pg, 100)), 1);
     const int cap_E = std::max(std::max(cap_ll, cap_kl), std::max<int>(max_n_kk, 1));
     const int cap_N = std::max(max_n_lig, max_n_kp);
+    KPD_REQUIRE(((long)cap_N + TM) * NSLOT * HS * 4 < (1l << 32), KPD_ERR_CAPACITY,
+                "batch of %d / %d nodes exceeds the 4 GB addressable per node type by the edge kernels' 32-bit row offsets (split the batch)",
+                max_n_lig, max_n_kp);
     const int L = c.n_layers;
     const int nn[2] = {max_n_lig, max_n_kp};
     size_t bytes = 0;
