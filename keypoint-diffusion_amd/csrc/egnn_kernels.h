@@ -57,6 +57,7 @@ struct EdgeArgs {
     int gemm_mode;                  // 0: exact fp32 MFMA (contract path), 1: f16x2 split products (opt-in)
     int tile_rows;                  // edges per tile: 64 (TM)
     int ablate;                     // timing experiments only (KPD_EDGE_ABLATE), 0 in production
+    int split_slots;                // workgroup slots per XCD (set by the launcher): the tiles of an XCD's last round run one branch per work item; 0: off
     float *dbg;                     // [tiles][64][4] per-row taps of the coordinate branch (builds with -DKPD_EDGE_DBG only; "edge_dbg=1")
 };
 

@@ -317,8 +317,21 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
     const int T = a.meta[8];
     const int chunk = (T + 7) >> 3;
     const int bi = blockIdx.x >> 3;
-    if (bi >= chunk) return;
-    const int tile = (blockIdx.x & 7) * chunk + bi;
+    // Tail: an XCD's tiles fill its workgroup slots (a.split_slots: two per CU) round after round, and the last round is usually almost
+    // empty (775 tiles on 64 slots: 7 tiles keep the whole launch waiting for a full tile time).  When that remainder fits half the slots,
+    // its tiles run as TWO work items each -- the feature branch and the coordinate branch -- so the last round lasts half a tile.
+    int tl = bi, bsel = 3;                    // bit 0: feature branch, bit 1: coordinate branch
+    const int rem = a.split_slots > 0 ? chunk % a.split_slots : 0;
+    if (rem > 0 && 2 * rem <= a.split_slots) {
+        const int full = chunk - rem;
+        if (bi >= full) {
+            const int j = bi - full;
+            if (j >= 2 * rem) return;
+            tl = full + (j >> 1);
+            bsel = 1 << (j & 1);
+        }
+    } else if (bi >= chunk) return;
+    const int tile = (blockIdx.x & 7) * chunk + tl;
     if (tile >= T) return;
     int et = 0;
 #pragma unroll
@@ -337,7 +350,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
     // A/B: 0.859 vs 0.869 ms); -DKPD_F_LATE_GATHER restores the issue after the barrier
 #ifndef KPD_F_LATE_GATHER
     EdgeGather<NW> ge;
-    edge_gather_issue_early<NW>(ge, esrc, edst, e0, ne, Ps, Pd, wave, lane);
+    if (bsel & 1) edge_gather_issue_early<NW>(ge, esrc, edst, e0, ne, Ps, Pd, wave, lane);
     __builtin_amdgcn_sched_barrier(0);
 #endif
     // phase 0: edge endpoints and geometry (dynamics.py:160-169, 209-217); head weights to LDS
@@ -378,7 +391,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
         }
     }
     [[maybe_unused]] BPrefetch bpre;
-    if constexpr (NW == 4) gemm_b_prefetch(bpre, a.wp_e[et], wave, lane);     // lands during the gather / A-build
+    if constexpr (NW == 4) gemm_b_prefetch(bpre, (bsel & 1) ? a.wp_e[et] : a.wp_c[et], wave, lane);     // lands during the gather / A-build
     lds_barrier();
     KPD_STAMP(0)
 
@@ -387,9 +400,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
         ((unsigned long long)(unsigned)s.misc[3] << 32) | (unsigned long long)(unsigned)s.misc[2];
     f32x16 acc[2][WaveCols<NW>::NT];
     float ex;
+    EdgeGather<NW == 4 ? 4 : TM> gc;      // (one row per wave, unused, in the 8-wave build)
 
     // ---- feature messages: m = edge_mlp(f); msg_h = m * sigmoid(att(m)) (dynamics.py:111-112)
     const int abl = a.ablate;             // timing experiments only (KPD_EDGE_ABLATE): 1 no GEMM, 2 no A-build, 4 no epilogues
+    if (bsel & 1) {
 #ifndef KPD_F_LATE_GATHER
     if (!(abl & 2)) edge_gather_finish<NW>(ge, s, a.wr_e[et], wave, lane);
 #else
@@ -408,9 +423,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
     KPD_STAMP(2)
     if (!(abl & 4)) store_T_silu_w<NW, true>(s.A, acc, ex, a.b_e[et], tid, wave, lane);
     else if (acc[0][0][0] == 12345.0f) s.A[tid] = acc[1][NW == 4 ? 1 : 0][3] + acc[0][NW == 4 ? 1 : 0][5] + acc[1][0][7];
-    EdgeGather<NW == 4 ? 4 : TM> gc;      // (one row per wave, unused, in the 8-wave build)
     if constexpr (NW == 4) {  // the coordinate branch's P rows start travelling now; consumed after the segmented sum below
-        if (!(abl & 2)) {
+        if (!(abl & 2) && (bsel & 2)) {
         edge_gather_issue<NW>(gc, s, Ps + HS, Pd + HS, wave, lane);
         __builtin_amdgcn_sched_barrier(0);
         }
@@ -497,11 +511,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
     }
     lds_barrier();
     KPD_STAMP(5)
+    }
 
     // ---- coordinate messages: msg_x = tanh(coord_mlp(f)) * x_diff * range (dynamics.py:113-120)
+    if (bsel & 2) {
     if (!(abl & 2)) {
-    if constexpr (NW == 4) edge_gather_finish<NW>(gc, s, a.wr_c[et], wave, lane);
-    else build_edge_A<NW>(s, Ps + HS, Pd + HS, a.wr_c[et], wave, lane);
+    if constexpr (NW == 4) {
+        if (!(bsel & 1)) edge_gather_issue<NW>(gc, s, Ps + HS, Pd + HS, wave, lane);        // (a coordinate-only work item of the tail)
+        edge_gather_finish<NW>(gc, s, a.wr_c[et], wave, lane);
+    } else build_edge_A<NW>(s, Ps + HS, Pd + HS, a.wr_c[et], wave, lane);
     }
     lds_barrier();
     KPD_STAMP(6)
@@ -531,15 +549,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
     }
     lds_barrier();
     KPD_STAMP(9)
+    }
     if (wave == 0 && !(abl & 4)) {
         // segmented inclusive scan across lanes (lane = row), then the last lane of every run writes
         const unsigned long long heads =
             ((unsigned long long)(unsigned)s.misc[5] << 32) | (unsigned long long)(unsigned)s.misc[4];
         const unsigned long long upto = lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull);
         const int start = 63 - __clzll((long long)((heads & upto) | 1ull));
-        float vx = s.mx[3 * lane], vy = s.mx[3 * lane + 1], vz = s.mx[3 * lane + 2];
+        float vx = 0.0f, vy = 0.0f, vz = 0.0f;
+        if (bsel & 2) { vx = s.mx[3 * lane]; vy = s.mx[3 * lane + 1]; vz = s.mx[3 * lane + 2]; }
 #ifndef KPD_F_COL256_EARLY
-        float vh = reinterpret_cast<const float *>(s.misc + 8)[lane];
+        float vh = (bsel & 1) ? reinterpret_cast<const float *>(s.misc + 8)[lane] : 0.0f;
 #endif
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -561,12 +581,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
             const unsigned dsto = (unsigned)s.dst[lane];
             float *out = (piece == 0 && first_is_cont) ? a.xn_cont[et] + (size_t)tile_in_et * 4
                                                        : a.xn_main[et] + (size_t)(dsto / PROW_B) * 4;
-            out[0] = vx;
-            out[1] = vy;
-            out[2] = vz;
+            if (bsel & 2) {
+                out[0] = vx;
+                out[1] = vy;
+                out[2] = vz;
+            }
 #ifndef KPD_F_COL256_EARLY
             float *oh = (piece == 0 && first_is_cont) ? a.hn_cont[et] + (size_t)tile_in_et * HS : a.hn_main[et] + (dsto / (unsigned)(NSLOT * 4));
-            oh[256] = vh;
+            if (bsel & 1) oh[256] = vh;
 #endif
         }
     }
@@ -2089,7 +2111,10 @@ kpd_status launch_egnn_edge(const EdgeArgs &a, int tile_cap, hipStream_t st) {
         return KPD_OK;
     }
     KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_egnn_edge<4>), EDGE_LDS_BYTES + pad));
-    hipLaunchKernelGGL(k_egnn_edge<4>, dim3(8 * cdiv(tile_cap, 8)), dim3(256), EDGE_LDS_BYTES + pad, st, b);
+    // the tail of a launch split by branch (k_egnn_edge): two workgroup slots per CU, an eighth of them per XCD; KPD_EDGE_SPLIT=0: whole tiles only
+    static const bool split = !(getenv("KPD_EDGE_SPLIT") && atoi(getenv("KPD_EDGE_SPLIT")) == 0);
+    b.split_slots = (split && pad == 0) ? 2 * cu_count() / 8 : 0;
+    hipLaunchKernelGGL(k_egnn_edge<4>, dim3(8 * (cdiv(tile_cap, 8) + b.split_slots / 2)), dim3(256), EDGE_LDS_BYTES + pad, st, b);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
 }
