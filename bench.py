@@ -529,6 +529,7 @@ def run_end_to_end(device, workload='egnn_all_atom', B=64, n_rec=300, n_lig=25, 
     8(d): "encoder timed separately"): `encoder_ms` is `encode_receptors` alone, synchronised on both sides.  With random-init
     weights the chain does not denoise (the ligand spreads and the lig-lig graph thins out), so this is a functional
     wall-clock figure, not the steady-state rate."""
+    import gc
     import torch
     w = WORKLOADS[workload]
     model = build_model(device, workload)
@@ -536,11 +537,13 @@ def run_end_to_end(device, workload='egnn_all_atom', B=64, n_rec=300, n_lig=25, 
     assert model.dynamics.engine().gemm_mode() == gemm
     if ragged:
         n_rec, n_lig = ragged_sizes(B, 0)
+    runs = []
     with torch.no_grad():
-        for _ in range(2):          # first pass = warm-up (workspace reservation, first-use initialisation)
-            g = raw_batch(B, n_rec, n_lig, 4321, device, workload)
+        for it in range(3):         # first pass = warm-up (workspace reservation, first-use initialisation); the faster of the other two counts
+            g = raw_batch(B, n_rec, n_lig, 4321, device, workload)          # (a host hiccup -- allocator, collector -- once put 80 ms into a 1.5-ms encoder)
             if w['enc'] != 'learned':
                 g = g.to(device)                   # resident before the clock starts, like `value`'s batch (raw_batch uploads the learned-encoder case itself)
+            gc.collect()                           # (the previous pass's graphs and ligand lists: a collection of them inside the encoder's few ms read as 80 ms)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             enc = model.encode_receptors(g).to(device)
@@ -549,12 +552,15 @@ def run_end_to_end(device, workload='egnn_all_atom', B=64, n_rec=300, n_lig=25, 
             pos, feat = model.sample_from_encoded_receptors(enc)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
+            if it:
+                runs.append((dt, t_enc))
+    dt, t_enc = min(runs)
     assert len(pos) == B and all(p.device.type == 'cpu' for p in pos)
     del model
     torch.cuda.empty_cache()
     return {'workload': workload + ('_ragged' if ragged else ''), 'gemm': gemm, 'ligands_per_min': 60.0 * B / dt, 'wall_s': dt,
             'encoder_ms': 1e3 * t_enc, 'reverse_loop_and_copy_s': dt - t_enc, 'steps_per_s_in_loop': w['T'] / (dt - t_enc),
-            'n_ligands': B, 'n_timesteps': w['T'],
+            'n_ligands': B, 'n_timesteps': w['T'], 'runs_wall_s': [r[0] for r in runs],
             'includes': 'receptor encoding + all reverse steps (per-step graph rebuild, fresh noise) + final frame shift + '
                         'device->host copy of the ligands; model build and synthetic-data generation excluded',
             'note': 'random-init weights do not denoise: the ligand spreads over the loop and the lig-lig graph thins, so late '
