@@ -1080,6 +1080,7 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
             if (want_fused_fwd() && hipMalloc(reinterpret_cast<void **>(&T->store_base), edge_layer) == hipSuccess) keep_layers = 1;
             else { (void)hipGetLastError(); T->store_base = nullptr; }
         }
+        if (T->store_base && poison_level() >= 1) poison_floats(T->store_base, keep_layers == L ? per_layer * L : edge_layer);       // (debug: KPD_POISON)
         T->store = keep_layers == L && want;
         T->layer_slots = keep_layers >= 1;
         T->fused = want_fused_fwd() && T->layer_slots;
