@@ -133,6 +133,21 @@ def test_egnn_ragged_batch(cuda):
     assert c['E_kl'] == c['E_lk'] and c['tiles'] > 0
 
 
+@pytest.mark.parametrize('n_rec,n_lig,regime', [
+    ([400, 380, 420], [25, 30, 20], 'whole'),                                # ~390 tiles: 48 per XCD -- more than half its 64 slots: whole tiles only
+    ([500, 520, 480, 510], [25, 30, 20, 28], 'rounds+split'),                # ~650 tiles: 81 per XCD -- a full round + 17 tiles that run split
+])
+def test_edge_tile_regimes(cuda, n_rec, n_lig, regime):
+    """k_egnn_edge runs the tiles of an XCD's last round of workgroup slots as two work items (one per branch) when they fit half the
+    slots.  Parity in the two regimes the small cases above do not reach: a launch whose remainder is too large to split, and one with
+    full rounds followed by a split remainder (n_layers = 2 keeps the CPU oracle short)."""
+    cfg = dict(util.EGNN_C2, n_layers=2)
+    (h, x), (rh, rx), model = _run_pair(cuda, cfg, n_rec, n_lig)
+    _check(h, x, rh, rx, n_lig)
+    per_xcd = (model.engine().last_counts()['tiles'] + 7) // 8
+    assert (32 < per_xcd % 64 < 64 and per_xcd < 64) if regime == 'whole' else (per_xcd > 64 and 0 < per_xcd % 64 <= 32), per_xcd
+
+
 def test_egnn_dev_config_no_kp_update(cuda):
     # configs/dev_config.yml: update_kp_feat False, C-alpha pocket (rec_nf 20), ll cutoff from graph section
     (h, x), (rh, rx), _ = _run_pair(cuda, util.EGNN_DEV, [60], [20], rec_nf=20)
