@@ -95,6 +95,59 @@ TRAFFIC_FILES = ('r04_traffic.json', 'r03_traffic.json', 'r02_traffic.json', 'r0
 
 
 # ---------------------------------------------------------------------------------------------------
+# what the line attests about the process that produced it
+# ---------------------------------------------------------------------------------------------------
+# KPD_* variables that do not change what the kernels compute or how fast (launcher rehearsal switches of this script)
+HARMLESS_ENV = ('KPD_BENCH_SPAWN_ECHO', 'KPD_BENCH_SHARE_GPU', 'KPD_BENCH_DIST_AT_1')
+
+
+class BenchRefused(SystemExit):
+    """bench.py will not print a line it cannot stand behind (exit code 2)."""
+
+    def __init__(self, why):
+        print(f'bench.py: refused -- {why}', file=sys.stderr, flush=True)
+        super().__init__(2)
+
+
+def attest_environment(environ, build_flags, allow_tools=False):
+    """Every KPD_* variable other than this script's own rehearsal switches selects a different kernel path (KPD_GEMM), a memory mode
+    (KPD_TRAIN_STORE), NaN poisoning (KPD_POISON), another library (KPD_LIB) or -- in the TOOLS build of the library only -- an A/B or
+    ablation switch (KPD_EDGE_ABLATE can tell the contract kernel to skip its GEMM).  A run with any of them set, or on a library whose
+    kpd_build_flags() is not 0, is refused unless `--tools` marks it as a diagnostic run; either way the line lists what was set.
+    Pure function (tests/test_bench_line.py)."""
+    seen = sorted(k for k in environ if k.startswith('KPD_'))
+    altering = [k for k in seen if k not in HARMLESS_ENV]
+    if not allow_tools:
+        if altering:
+            raise BenchRefused(f'performance-altering variables are set: {", ".join(altering)} (use the flags of this script, e.g. --gemm; '
+                               f'--tools marks a diagnostic run)')
+        if build_flags != 0:
+            raise BenchRefused(f'libkpd_hip.so is not the product build (kpd_build_flags() = {build_flags}: TOOLS build)')
+    return {'env': seen, 'build': 'product' if build_flags == 0 else 'tools', 'attested': not altering and build_flags == 0}
+
+
+def check_record(out):
+    """A roofline fraction outside (0, 1] means the accounting or the run is wrong (work skipped, wrong peak, a kernel that did not
+    run): refuse to print it.  Applies to the contract line and to every secondary."""
+    def one(name, r):
+        rf = (r or {}).get('roofline')
+        if rf is None:
+            return
+        frac = rf.get('frac')
+        if frac is None or not (0.0 < frac <= 1.0):
+            raise BenchRefused(f'roofline.frac of {name} is {frac}: outside (0, 1]')
+        hb = (rf.get('hbm') or {}).get('frac')
+        if hb is not None and not (0.0 <= hb <= 1.0):
+            raise BenchRefused(f'roofline.hbm.frac of {name} is {hb}: outside [0, 1]')
+    one('the contract workload', out)
+    for name, r in (out.get('secondary') or {}).items():
+        one(name, r)
+    for name, r in (out.get('hbm_kernels') or {}).get('kernels', {}).items():
+        if not (0.0 <= r.get('frac', 0.0) <= 1.0):
+            raise BenchRefused(f'hbm_kernels[{name}].frac is {r.get("frac")}: outside [0, 1]')
+
+
+# ---------------------------------------------------------------------------------------------------
 # rank launcher: `python bench.py --gpus N` without a launcher starts the N ranks itself
 # ---------------------------------------------------------------------------------------------------
 def spawn_ranks(n: int) -> int:
@@ -220,6 +273,11 @@ def host_cpu():
         pass
     return {'cpu_model': model, 'physical_cores': phys, 'logical_cpus': os.cpu_count(), 'affinity': len(os.sched_getaffinity(0)),
             'cgroup_quota_cpus': quota, 'threads_used': usable, 'torch': torch.__version__}
+
+
+def rank_cpu_threads(usable_cores, local_world):
+    """CPU threads one rank of `local_world` ranks on this host may use (at least one)."""
+    return max(1, int(usable_cores) // max(1, int(local_world)))
 
 
 def _cpu_time_steps(fwd, sd, cfg, ob, T, n_warm, n_timed):
@@ -571,6 +629,7 @@ def run_end_to_end(device, workload='egnn_all_atom', B=64, n_rec=300, n_lig=25, 
 # the ONE line the driver parses: contract fields + roofline + cpu_baseline, everything else as bare numbers
 # ---------------------------------------------------------------------------------------------------
 FULL_RECORD = os.path.join('gpurun_out', 'bench_full_record.json')      # relative to the repo root
+ATTEST = {}                                                                # filled by main() (attest_environment)
 COMPACT_LIMIT = 4096                                                       # bytes; the driver lost a 26.7 KB line in round 3
 
 
@@ -616,6 +675,13 @@ def compact_line(out, full_path=None):
                                 'spread_pct': {k: _r(v.get('spread_pct'), 3) for k, v in cb.get('cases', {}).items()}}
         if 'c1_dev_config' in cb:
             line['cpu_baseline']['c1_total_s_100_steps'] = _r(cb['c1_dev_config'].get('total_s_100_steps'))
+    if rf:
+        line['roofline']['traffic_measured'] = bool(rf.get('traffic_measured', False))      # false: `traffic` is the committed PMC figure
+    att = out.get('attest') or {}
+    line['env'] = att.get('env', [])
+    line['build'] = att.get('build', 'product')
+    if not att.get('attested', True):
+        line['attested'] = False                 # a --tools diagnostic run: never a contract line
     for k in ('gpu_over_cpu', 'complex_steps_per_s', 'ranks_seen', 'per_rank_ms_per_step', 'collective_backend'):
         if out.get(k) is not None:
             line[k] = _r(out[k])
@@ -647,6 +713,8 @@ def compact_line(out, full_path=None):
 def emit(out):
     """Write the full record to the side file (best effort: a read-only tree must not lose the line) and print the compact line."""
     path = None
+    out.setdefault('attest', dict(ATTEST))
+    check_record(out)
     try:
         os.makedirs(os.path.join(ROOT, os.path.dirname(FULL_RECORD)), exist_ok=True)
         with open(os.path.join(ROOT, FULL_RECORD), 'w') as f:
@@ -756,6 +824,8 @@ def main():
                     help='f32 = exact fp32 MFMA everywhere (the contract line); f16x2 = opt-in split-f16 products in the EGNN GEMMs')
     ap.add_argument('--graph', action='store_true', help='replay the reverse step as a captured HIP graph (StepGraph)')
     ap.add_argument('--ragged', action='store_true', help='pockets 150-600 atoms, ligands 15-35 atoms (configs[4] shape)')
+    ap.add_argument('--tools', action='store_true', help='diagnostic run (profiles/tools): KPD_* switches and the TOOLS build of the library are '
+                                                         'allowed; the line then carries "attested": false and is not a contract line')
     args = ap.parse_args()
     training = args.workload.endswith('_train')
     if args.steps is None:
@@ -777,6 +847,10 @@ def main():
     import torch
     if world != args.gpus:
         raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks')
+    if world > 1:
+        # N ranks share one host: each takes its share of the cores for the synthetic-batch generation and the torch-side
+        # setup, instead of N x all-cores thread pools oversubscribing the box while the others wait in the first barrier
+        torch.set_num_threads(rank_cpu_threads(host_cpu()['threads_used'], int(os.environ.get('LOCAL_WORLD_SIZE', world))))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the hot path has no CPU implementation')
     # KPD_BENCH_SHARE_GPU=1 (functional rehearsal on a one-GPU box only): every rank uses cuda:0 and the
@@ -799,6 +873,8 @@ def main():
             dist.init_process_group('nccl', device_id=device)
         assert dist.get_world_size() == args.gpus
 
+    from keypoint_diffusion_amd import hip
+    ATTEST.update(attest_environment(os.environ, int(hip.lib().kpd_build_flags()), allow_tools=args.tools))
     torch.manual_seed(1000 + rank)
     if training:
         run_train(args, device, rank, world, dist)

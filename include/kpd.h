@@ -39,6 +39,12 @@ typedef enum kpd_status {
 
 const char *kpd_last_error(void);
 int kpd_version(void);
+/* 0 = the product build.  Bit 0 set = the TOOLS build (`make tools`, -DKPD_TOOLS): the only build in which the A/B, ablation and
+ * LDS-padding switches of profiles/tools are read from the environment (KPD_EDGE_ABLATE, KPD_EDGE_SPLIT, KPD_*_LDS_PAD,
+ * KPD_SGEMM_*, KPD_TRAIN_EPI / _WS / _VEC_FUSED, ...).  bench.py refuses to print a contract line from a library whose flags are not 0.
+ * (No reference counterpart: the reference has no build variants; the check exists because a timing library must be able to attest
+ * that its kernels cannot be told to skip work.) */
+int kpd_build_flags(void);
 
 /* ---------------------------------------------------------------------------------------
  * Batch of complexes (the tensors the reference keeps in a batched DGL heterograph).

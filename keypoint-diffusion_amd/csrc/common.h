@@ -37,6 +37,21 @@ void set_error(const char *fmt, ...);
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// A/B, ablation and debugging switches are read from the environment only in the TOOLS build (`make tools`, -DKPD_TOOLS:
+// profiles/tools/*.sh load it through KPD_LIB); in the product library every one of them is its default, a compile-time
+// constant, and the variable names are not even in the binary (tests/test_abi.py checks that).  kpd_build_flags() tells the two apart.
+#ifdef KPD_TOOLS
+#include <stdlib.h>
+static inline int tool_env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+#define KPD_TOOL_SWITCH(expr, dflt) (expr)
+#else
+static constexpr int tool_env_int(const char *, int dflt) { return dflt; }
+#define KPD_TOOL_SWITCH(expr, dflt) (dflt)
+#endif
+
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) for kernels that need more than 64 KB of dynamic LDS: applied once per
 // (kernel, device), thread-safe; cheap enough to call before every launch.  pack.hip.
 kpd_status ensure_dynamic_lds(const void *kernel, int bytes);

@@ -198,7 +198,7 @@ extern "C" kpd_status kpd_egnn_create(const kpd_egnn_config *cfg, kpd_egnn **out
     kpd_egnn *m = new kpd_egnn();
     m->cfg = *cfg;
     if (const char *e = getenv("KPD_GEMM")) m->gemm_mode = !strcmp(e, "f16x2") ? 1 : 0;
-    if (const char *e = getenv("KPD_H_PARTS")) m->h_parts = atoi(e);
+    m->h_parts = tool_env_int("KPD_H_PARTS", m->h_parts);      // (TOOLS build only)
     m->n_et = cfg->update_kp_feat ? 4 : 2;
     m->n_upd = cfg->update_kp_feat ? 2 : 1;
     m->rec_identity = cfg->rec_nf == cfg->hidden_nf;   // dynamics.py:326-334

@@ -280,7 +280,7 @@ kpd_status launch_proj_chain(const ProjPair &p, hipStream_t st) {
         for (int s = 0; s < p.n_slots[nt]; ++s)
             KPD_REQUIRE(p.nt[nt].chain[s] && p.nt[nt].wcol[s], KPD_ERR_STATE, "projection slot %d not packed", s);
     KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_proj_ws), WS_LDS_BYTES));
-    static const int target_env = getenv("KPD_PROJ_WS_BLOCKS") ? std::max(1, atoi(getenv("KPD_PROJ_WS_BLOCKS"))) : 0;
+    static const int target_env = std::max(0, tool_env_int("KPD_PROJ_WS_BLOCKS", 0));      // (TOOLS build only)
     const int target = target_env ? target_env : cu_count();
     ProjWs q;
     q.p = p;

@@ -240,20 +240,14 @@ __device__ __forceinline__ void edge_gather_finish(const EdgeGather<NW> &g, cons
     // the wave's RPW distances in RPW / 4 broadcast reads up front instead of a read + wait per row: -1.0 % on the kernel, same-call A/B
     // (0.877 vs 0.886 ms).  The f16x2 kernel keeps the per-row form (edge_gather_finish_h, KPD_H_BATCH_D): there the batched read came
     // with a first-forward deviation; every detector of that (profiles/tools/repro_*.py, cold_*_check.py, tests/test_cold_start_gpu.py)
-    // is clean for this kernel.  -DKPD_F_PER_ROW_D restores the old form.
-#ifndef KPD_F_PER_ROW_D
+    // is clean for this kernel.
     f32x4 dv[(RPW + 3) / 4];
 #pragma unroll
     for (int i = 0; i < (RPW + 3) / 4; ++i) dv[i] = *reinterpret_cast<const f32x4 *>(s.d + wave * RPW + 4 * i);
-#endif
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
         const int r = wave * RPW + rr;
-#ifndef KPD_F_PER_ROW_D
         f32x4 v = g.ps[rr] + g.pd[rr] + dv[rr >> 2][rr & 3] * w0;   // = c * pre-activation (P, w_r carry c)
-#else
-        f32x4 v = g.ps[rr] + g.pd[rr] + s.d[r] * w0;        // = c * pre-activation (P, w_r carry c)
-#endif
         v[0] = silu_pre(v[0]); v[1] = silu_pre(v[1]); v[2] = silu_pre(v[2]); v[3] = silu_pre(v[3]);
         *reinterpret_cast<f32x4 *>(s.A + r * SA + 4 * lane) = v;
     }
@@ -347,12 +341,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
     const float *Ps = a.P[snt] + (size_t)a.src_slot[et] * HS;
     const float *Pd = a.P[dnt] + (size_t)a.dst_slot[et] * HS;
     // the feature branch's P rows start travelling before the geometry chain and the first barrier (-1.1 % on the kernel, same-call
-    // A/B: 0.859 vs 0.869 ms); -DKPD_F_LATE_GATHER restores the issue after the barrier
-#ifndef KPD_F_LATE_GATHER
+    // A/B: 0.859 vs 0.869 ms)
     EdgeGather<NW> ge;
     if (bsel & 1) edge_gather_issue_early<NW>(ge, esrc, edst, e0, ne, Ps, Pd, wave, lane);
     __builtin_amdgcn_sched_barrier(0);
-#endif
     // phase 0: edge endpoints and geometry (dynamics.py:160-169, 209-217); head weights to LDS
     if (tid < TM) {
         const int e = e0 + min(tid, ne - 1);
@@ -403,13 +395,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
     EdgeGather<NW == 4 ? 4 : TM> gc;      // (one row per wave, unused, in the 8-wave build)
 
     // ---- feature messages: m = edge_mlp(f); msg_h = m * sigmoid(att(m)) (dynamics.py:111-112)
-    const int abl = a.ablate;             // timing experiments only (KPD_EDGE_ABLATE): 1 no GEMM, 2 no A-build, 4 no epilogues
+    // timing experiments of the TOOLS build only (KPD_EDGE_ABLATE: 1 no GEMM, 2 no A-build, 4 no epilogues); the constant 0 in the product
+    const int abl = KPD_TOOL_SWITCH(a.ablate, 0);
     if (bsel & 1) {
-#ifndef KPD_F_LATE_GATHER
     if (!(abl & 2)) edge_gather_finish<NW>(ge, s, a.wr_e[et], wave, lane);
-#else
-    if (!(abl & 2)) build_edge_A<NW>(s, Ps, Pd, a.wr_e[et], wave, lane);
-#endif
     lds_barrier();
     KPD_STAMP(1)
     acc_zero_w<NW>(acc);
@@ -453,7 +442,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
             for (int r0 = 0; r0 < TM; r0 += 16) {
                 if (r0 >= ne) break;
                 float v[16], w[16];
-#ifndef KPD_F_DST_PER_RUN
                 int dvv[16];
                 {
                     typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -463,7 +451,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
                         dvv[4 * j] = t[0]; dvv[4 * j + 1] = t[1]; dvv[4 * j + 2] = t[2]; dvv[4 * j + 3] = t[3];
                     }
                 }
-#endif
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     w[i] = s.att[r0 + i];
@@ -473,11 +460,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
                 for (int i = 0; i < 16; ++i) {
                     run = fmaf(v[i], w[i], run);
                     if ((endmask >> (r0 + i)) & 1ull) {
-#ifndef KPD_F_DST_PER_RUN
                         float *out = (piece == 0 && first_is_cont) ? hcont : hmain + ((unsigned)dvv[i] / (unsigned)(NSLOT * 4));
-#else
-                        float *out = (piece == 0 && first_is_cont) ? hcont : hmain + ((unsigned)s.dst[r0 + i] / (unsigned)(NSLOT * 4));
-#endif
                         out[tid] = run;
                         run = 0.0f;
                         ++piece;
@@ -485,29 +468,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
                 }
             }
         }
-#ifndef KPD_F_COL256_EARLY
         // column 256: the weighted values wait in LDS for the scan at the end of the kernel (with the coordinate messages)
         if (wave == NW - 1) reinterpret_cast<float *>(s.misc + 8)[lane] = s.A[lane * SA + 256] * s.att[lane];
-#else
-        // column 256: lane = row on the last wave, segmented inclusive scan across lanes
-        if (wave == NW - 1) {
-            const unsigned long long heads =
-                ((unsigned long long)(unsigned)s.misc[5] << 32) | (unsigned long long)(unsigned)s.misc[4];
-            const unsigned long long upto = lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull);
-            const int start = 63 - __clzll((long long)((heads & upto) | 1ull));
-            float v = s.A[lane * SA + 256] * s.att[lane];
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const float t = __shfl_up(v, off);
-                if (lane - off >= start) v += t;
-            }
-            if ((endmask >> lane) & 1ull) {
-                const int pc = __popcll(endmask & ((1ull << lane) - 1ull));
-                float *out = (pc == 0 && first_is_cont) ? hcont : hmain + ((unsigned)s.dst[lane] / (unsigned)(NSLOT * 4));
-                out[256] = v;
-            }
-        }
-#endif
     }
     lds_barrier();
     KPD_STAMP(5)
@@ -558,22 +520,16 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
         const int start = 63 - __clzll((long long)((heads & upto) | 1ull));
         float vx = 0.0f, vy = 0.0f, vz = 0.0f;
         if (bsel & 2) { vx = s.mx[3 * lane]; vy = s.mx[3 * lane + 1]; vz = s.mx[3 * lane + 2]; }
-#ifndef KPD_F_COL256_EARLY
         float vh = (bsel & 1) ? reinterpret_cast<const float *>(s.misc + 8)[lane] : 0.0f;
-#endif
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const float tx = __shfl_up(vx, off), ty = __shfl_up(vy, off), tz = __shfl_up(vz, off);
-#ifndef KPD_F_COL256_EARLY
             const float th = __shfl_up(vh, off);
-#endif
             if (lane - off >= start) {
                 vx += tx;
                 vy += ty;
                 vz += tz;
-#ifndef KPD_F_COL256_EARLY
                 vh += th;
-#endif
             }
         }
         if ((endmask >> lane) & 1ull) {
@@ -586,10 +542,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
                 out[1] = vy;
                 out[2] = vz;
             }
-#ifndef KPD_F_COL256_EARLY
             float *oh = (piece == 0 && first_is_cont) ? a.hn_cont[et] + (size_t)tile_in_et * HS : a.hn_main[et] + (dsto / (unsigned)(NSLOT * 4));
             if (bsel & 1) oh[256] = vh;
-#endif
         }
     }
     KPD_STAMP(10)
@@ -610,14 +564,10 @@ struct EdgeKeep {
 // (addresses of the kept rows: a wave-uniform row base -- scalar registers -- plus one 32-bit lane offset, so that the sixteen rows of a
 // wave cost no vector registers for addresses; the opaque asm keeps the compiler from carrying offsets from one phase to the next)
 // (the kept arrays are written once and read in the backward pass, tens of milliseconds later; non-temporal stores for them were
-// measured -- 1.354 vs 1.283 ms per launch, not better -- and stay behind -DKPD_KEEP_NT)
+// measured -- 1.354 vs 1.283 ms per launch, not better -- and removed)
 template <class V>
 __device__ __forceinline__ void keep_store(V *p, const V &v) {
-#ifdef KPD_KEEP_NT
-    __builtin_nontemporal_store(v, p);
-#else
     *p = v;
-#endif
 }
 
 __device__ __forceinline__ void edge_gather_finish_train(const EdgeGather<4> &g, const EdgeSmem &s, const float *__restrict__ wr, int wave, int lane,
@@ -1655,11 +1605,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     float *s_rstd = s_mean + TN;
     // the wave index as a scalar: every row-wise loop below addresses rows by wave, so row pointers, the CSR bounds of the h_neigh
     // gather and its branches are scalar work
-#ifdef KPD_NODE_VWAVE   // A/B: the wave index as a vector register (round 2)
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-#else
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-#endif
     const int which = blockIdx.x >= p.tiles0 ? 1 : 0;
     const NodeLayerArgs &L = p.nt[which];
     const NodeArgs &a = L.u;
@@ -1726,11 +1672,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         NL_STAMP(1)
         // GEMM 1b: + W[:, 257:] . (h_neigh / z); h_neigh = sum of segment pieces over the incoming edge
         // types in fixed order (multi_update_all cross_reducer='sum')
-#ifdef KPD_NODE_GATHER_U2
-#pragma unroll 2
-#else
 #pragma unroll
-#endif
         for (int rr = 0; rr < RPW; ++rr) {
             const int r = wave * RPW + rr, v = node0 + r;
             f32x4 val = {0.f, 0.f, 0.f, 0.f}, val2 = {0.f, 0.f, 0.f, 0.f};
@@ -2095,8 +2037,8 @@ kpd_status launch_egnn_edge(const EdgeArgs &a, int tile_cap, hipStream_t st) {
     if (tile_cap == 0) return KPD_OK;
     if (poison_level() >= 1) KPD_TRY(poison_lds(st));      // debug only (engine.h)
     // KPD_EDGE_LDS_PAD (diagnostics): extra dynamic LDS to force one workgroup per CU
-    static const int pad = getenv("KPD_EDGE_LDS_PAD") ? atoi(getenv("KPD_EDGE_LDS_PAD")) : 0;
-    static const int ablate = getenv("KPD_EDGE_ABLATE") ? atoi(getenv("KPD_EDGE_ABLATE")) : 0;
+    static const int pad = tool_env_int("KPD_EDGE_LDS_PAD", 0);
+    static const int ablate = tool_env_int("KPD_EDGE_ABLATE", 0);
     EdgeArgs b = a;
     b.ablate = ablate;
     KPD_REQUIRE(a.tile_rows == TM, KPD_ERR_INVALID, "the edge kernels walk 64-edge tiles");
@@ -2112,7 +2054,7 @@ kpd_status launch_egnn_edge(const EdgeArgs &a, int tile_cap, hipStream_t st) {
     }
     KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_egnn_edge<4>), EDGE_LDS_BYTES + pad));
     // the tail of a launch split by branch (k_egnn_edge): two workgroup slots per CU, an eighth of them per XCD; KPD_EDGE_SPLIT=0: whole tiles only
-    static const bool split = !(getenv("KPD_EDGE_SPLIT") && atoi(getenv("KPD_EDGE_SPLIT")) == 0);
+    static const bool split = tool_env_int("KPD_EDGE_SPLIT", 1) != 0;
     b.split_slots = (split && pad == 0) ? 2 * cu_count() / 8 : 0;
     hipLaunchKernelGGL(k_egnn_edge<4>, dim3(8 * (cdiv(tile_cap, 8) + b.split_slots / 2)), dim3(256), EDGE_LDS_BYTES + pad, st, b);
     KPD_LAUNCH_CHECK();
@@ -2124,7 +2066,7 @@ kpd_status launch_node_layer(const NodeLayerPair &p, hipStream_t st) {
     if (tiles == 0) return KPD_OK;
     if (poison_level() >= 1) KPD_TRY(poison_lds(st));      // debug only (engine.h)
     // KPD_NODE_LDS_PAD (diagnostics): extra dynamic LDS to lower the number of co-resident workgroups
-    static const int pad = getenv("KPD_NODE_LDS_PAD") ? atoi(getenv("KPD_NODE_LDS_PAD")) : 0;
+    static const int pad = tool_env_int("KPD_NODE_LDS_PAD", 0);
     for (int nt = 0; nt < 2; ++nt)
         KPD_REQUIRE(p.nt[nt].u.n == 0 || (p.nt[nt].do_update && !p.nt[nt].do_proj), KPD_ERR_INVALID, "node launch: update-only node types expected");
     if (p.gemm_mode == 1 && !p.stamps) {                   // (phase-stamped diagnostic launches keep the exact kernel)

@@ -511,13 +511,13 @@ const int kD[4] = {NT_LIG, NT_LIG, NT_KP, NT_KP};
 
 // the forward edge pass as ONE kernel per layer (k_egnn_edge_train); KPD_TRAIN_FUSED_FWD=0: first-layer kernel + weight-stationary GEMM + heads
 bool want_fused_fwd() {
-    static const bool on = !(getenv("KPD_TRAIN_FUSED_FWD") && atoi(getenv("KPD_TRAIN_FUSED_FWD")) == 0);
+    static const bool on = tool_env_int("KPD_TRAIN_FUSED_FWD", 1) != 0;
     return on;
 }
 
 // the backward edge pass of a layer as one kernel (k_egnn_edge_bwd) + the products that need whole matrices; KPD_TRAIN_FUSED_BWD=0: per-branch kernels
 bool want_fused_bwd() {
-    static const bool on = !(getenv("KPD_TRAIN_FUSED_BWD") && atoi(getenv("KPD_TRAIN_FUSED_BWD")) == 0);
+    static const bool on = tool_env_int("KPD_TRAIN_FUSED_BWD", 1) != 0;
     return on;
 }
 

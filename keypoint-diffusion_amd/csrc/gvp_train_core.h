@@ -498,7 +498,7 @@ __global__ __launch_bounds__(256) void k_gvp_vec17_bwd(const float *__restrict__
 }
 
 inline bool vec_fused() {
-    static const bool on = !(getenv("KPD_TRAIN_VEC_FUSED") && atoi(getenv("KPD_TRAIN_VEC_FUSED")) == 0);          // A/B runs
+    static const bool on = tool_env_int("KPD_TRAIN_VEC_FUSED", 1) != 0;          // A/B runs
     return on;
 }
 
@@ -739,13 +739,13 @@ kpd_status gvp_params(TT *T, const std::string &p, int vi, int vo, int si, int s
 
 // the 256 x 256 scalar block of a GVP can take the weight-stationary GEMM (KPD_TRAIN_WS=0: library GEMMs throughout)
 bool ws_ok(const GvpP &g, int ld_s) {
-    static const bool on = !(getenv("KPD_TRAIN_WS") && atoi(getenv("KPD_TRAIN_WS")) == 0);
+    static const bool on = tool_env_int("KPD_TRAIN_WS", 1) != 0;
     return on && g.si == 256 && g.so == 256 && ld_s == 256;
 }
 
 // the 16 / 17 vector norms of to_feats_out's input ride along in the weight-stationary kernel (KPD_TRAIN_WS_EXTRA=0: separate products)
 inline bool ws_extra() {
-    static const bool on = !(getenv("KPD_TRAIN_WS_EXTRA") && atoi(getenv("KPD_TRAIN_WS_EXTRA")) == 0);
+    static const bool on = tool_env_int("KPD_TRAIN_WS_EXTRA", 1) != 0;
     return on;
 }
 

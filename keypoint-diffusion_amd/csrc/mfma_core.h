@@ -108,13 +108,8 @@ __device__ __forceinline__ void gemm_rows64_pre(const float *__restrict__ A, con
     ya1 = *reinterpret_cast<const f32x4 *>(a1p + 8);
     constexpr int PAIRS = NG_ / 2;
     // fully unrolled: every LDS / global address of the k-loop becomes an immediate offset and the 9 VALU + 8 SALU instructions of index
-    // math per pair of k-groups disappear (same-call A/B, round 3: 0.8498 vs 0.8542 ms on the edge kernel, -0.5 %); -DKPD_GEMM_ROLLED
-    // restores the loop
-#ifndef KPD_GEMM_ROLLED
+    // math per pair of k-groups disappear (same-call A/B, round 3: 0.8498 vs 0.8542 ms on the edge kernel, -0.5 %)
 #pragma unroll
-#else
-#pragma unroll 1
-#endif
     for (int p = 0; p < PAIRS; ++p) {
         const int g = 2 * p;
         __builtin_amdgcn_sched_barrier(0);

@@ -54,7 +54,7 @@ int poison_level() {
 }
 
 bool poison_selected() {
-    static const int only = getenv("KPD_POISON_ONLY") ? atoi(getenv("KPD_POISON_ONLY")) : -1;
+    static const int only = tool_env_int("KPD_POISON_ONLY", -1);      // (TOOLS build: bisecting a NaN to its buffer)
     static int counter = 0;
     const int me = counter++;
     return only < 0 || only == me;
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_poison_lds(int words, unsigned *sink) {
 }
 
 kpd_status poison_lds(hipStream_t st) {
-    if (getenv("KPD_POISON_ONLY")) return KPD_OK;
+    if (tool_env_int("KPD_POISON_ONLY", -1) >= 0) return KPD_OK;
     static unsigned *sink = nullptr;
     if (!sink) KPD_HIP(hipMalloc(reinterpret_cast<void **>(&sink), 256));
     const int bytes = 80 * 1024;
@@ -390,3 +390,10 @@ kpd_status transpose2d(const float *src, int rows, int cols, float *dst, hipStre
 
 extern "C" const char *kpd_last_error(void) { return kpd::g_err; }
 extern "C" int kpd_version(void) { return 100; }
+extern "C" int kpd_build_flags(void) {
+#ifdef KPD_TOOLS
+    return 1;
+#else
+    return 0;
+#endif
+}

@@ -671,13 +671,13 @@ __global__ __launch_bounds__(256) void k_sgemv_rows(const float *__restrict__ A,
 }  // namespace
 
 int sgemm_split_slices(int M, int N, int K) {
-    static const int pct = getenv("KPD_SGEMM_SPLIT_PCT") ? atoi(getenv("KPD_SGEMM_SPLIT_PCT")) : 200;      // workgroups per 100 CUs (A/B runs)
+    static const int pct = tool_env_int("KPD_SGEMM_SPLIT_PCT", 200);      // workgroups per 100 CUs (A/B runs)
     const int tiles = cdiv(M, 128) * cdiv(N, 128);
     int s = std::max(1, (pct * cu_count() / 100) / std::max(tiles, 1));
     // a slice is at least 256 deep -- or 64 (four slabs) when the whole product is a handful of tiles (the ligand-sized products of a
     // training step: 13 row tiles, K = 257): a workgroup then spends its time in the load latency of 16 consecutive slabs, which four
     // workgroups share better than one
-    static const int small_pct = getenv("KPD_SGEMM_SMALL_PCT") ? atoi(getenv("KPD_SGEMM_SMALL_PCT")) : 25;      // A/B runs
+    static const int small_pct = tool_env_int("KPD_SGEMM_SMALL_PCT", 25);      // A/B runs
     const int min_depth = tiles * 100 <= small_pct * cu_count() ? 64 : 256;
     s = std::min(s, std::max(1, K / min_depth));
     return std::min(s, SGEMM_MAX_SPLIT);
@@ -723,13 +723,13 @@ kpd_status sgemm(bool tA, bool tB, int M, int N, int K, float alpha, const float
     }
     // Fringe: a 129- / 257- / ...-wide side is tiled over its first M - 1 (N - 1) rows (columns); the last one rides along (k_sgemm)
     // instead of costing a row (column) of tiles of its own -- 9 tiles for the 257 x 257 weight gradients of the EGNN layers otherwise.
-    static const bool use_fringe = !(getenv("KPD_SGEMM_FRINGE") && atoi(getenv("KPD_SGEMM_FRINGE")) == 0);          // A/B runs
+    static const bool use_fringe = tool_env_int("KPD_SGEMM_FRINGE", 1) != 0;          // A/B runs
     int Mt = M, Nt = N;                          // tiled part
     if (use_fringe && M >= 129 && (M - 1) % 128 == 0) { a.xr = M - 1; Mt = M - 1; }
     if (use_fringe && N >= 65 && (N - 1) % 64 == 0) { a.xc = N - 1; Nt = N - 1; }
     const size_t per_slice = (size_t)Mt * Nt + (colsum ? Mt : 0) + ((a.xr >= 0 || a.xc >= 0) ? (size_t)Mt + Nt + 2 : 0);
     // edge-sized weight gradients with a 256 x 256 tiled part: the whole output in one workgroup, every operand row fetched once
-    static const bool use_tn256 = !(getenv("KPD_SGEMM_TN256") && atoi(getenv("KPD_SGEMM_TN256")) == 0);          // A/B runs
+    static const bool use_tn256 = tool_env_int("KPD_SGEMM_TN256", 1) != 0;          // A/B runs
     if (use_tn256 && tA && !tB && part && Mt == 256 && Nt == 256 && a.vecA && a.vecB && K >= 65536 && part_floats >= 2 * per_slice) {
         int sl = (int)std::min<size_t>(std::min(std::min(cu_count(), K / 256), SGEMM_MAX_SPLIT), part_floats / per_slice);
         a.k_chunk = cdiv(cdiv(K, sl), SG_BK) * SG_BK;
@@ -774,15 +774,15 @@ kpd_status sgemm(bool tA, bool tB, int M, int N, int K, float alpha, const float
     // tile shape (measured on the engines' shapes, profiles/r03_sgemm_bench.txt): 128-row tiles throughout (256-row tiles lose 10-15 %
     // on every shape: half the workgroups per CU to hide the short K loops behind); 128 columns when that still gives every CU two
     // workgroups, else 64 (node-sized products: more, smaller workgroups balance the 256 CUs better); 32 for the 16-wide vector channels
-    static const int force_wn = getenv("KPD_SGEMM_WN") ? atoi(getenv("KPD_SGEMM_WN")) : 0;          // A/B runs
-    static const int direct = getenv("KPD_SGEMM_DIRECT") ? atoi(getenv("KPD_SGEMM_DIRECT")) : 1;
+    static const int force_wn = tool_env_int("KPD_SGEMM_WN", 0);          // A/B runs
+    static const int direct = tool_env_int("KPD_SGEMM_DIRECT", 1);
     a.direct = direct;
     int wn = Nt > 64 ? 4 : Nt > 32 ? 2 : 1;
     if (wn == 4 && slices == 1 && (long long)cdiv(Mt, 128) * cdiv(Nt, 128) < 2ll * cu_count()) wn = 2;
     if (force_wn) wn = force_wn;
     const dim3 grid(cdiv(Mt, 128), cdiv(Nt, 32 * wn), slices);
     // ring depth of the direct path
-    static const int force_stages = getenv("KPD_SGEMM_STAGES") ? atoi(getenv("KPD_SGEMM_STAGES")) : 0;          // A/B runs
+    static const int force_stages = tool_env_int("KPD_SGEMM_STAGES", 0);          // A/B runs
     a.stages = 3;          // deeper rings measured slower on every shape (56 -> 71 us on the node-sized gradients at 8 stages): kept as an A/B switch
     if (force_stages) a.stages = std::min(std::max(force_stages, 3), SG_MAX_STAGES);
     KPD_REQUIRE(grid.y <= 65535u && grid.z <= 65535u, KPD_ERR_CAPACITY, "sgemm: N = %d too wide for one launch", N);

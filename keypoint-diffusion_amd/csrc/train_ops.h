@@ -469,7 +469,7 @@ kpd_status gemm(TrainCtx *T, bool tA, bool tB, int M, int N, int K, const float 
     // (the scratch lets a product of few tiles be cut along K: sgemm_split_slices; an activation epilogue keeps the product whole)
     // a product of a handful of tiles (ligand-sized: 1 600 rows) gains more from the split along K than from a fused epilogue, and the
     // epilogues live in the unsplit kernel: such a product takes the split and the elementwise pass
-    static const bool fuse = !(getenv("KPD_TRAIN_EPI") && atoi(getenv("KPD_TRAIN_EPI")) == 0);          // A/B runs: 0 = never fuse
+    static const bool fuse = tool_env_int("KPD_TRAIN_EPI", 1) != 0;          // A/B runs (TOOLS build): 0 = never fuse
     if ((silu_pre || bias || act_out) && (!fuse || (cdiv(M, 128) * cdiv(N, 128) * 4 <= cu_count() && K >= 128))) {
         KPD_TRY(sgemm(tA, tB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, T->st, T->part, T->part_floats));
         const long long tot = (long long)M * N;

@@ -11,7 +11,9 @@ from typing import Dict, Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libkpd_hip.so')
+# KPD_LIB: another build of the same library (profiles/tools load the TOOLS build, csrc/tools_build/libkpd_hip.so, this way);
+# bench.py refuses to run with it set and checks kpd_build_flags() == 0
+LIB_PATH = os.environ.get('KPD_LIB') or os.path.join(_HERE, 'csrc', 'libkpd_hip.so')
 _lib = None
 
 c_int_p = C.POINTER(C.c_int32)
@@ -90,6 +92,7 @@ def lib():
     L = C.CDLL(LIB_PATH)
     L.kpd_last_error.restype = C.c_char_p
     L.kpd_version.restype = C.c_int
+    L.kpd_build_flags.restype = C.c_int
     for name in EXPORTS:
         getattr(L, name)          # AttributeError if a declared symbol is not exported
     L.kpd_egnn_create.argtypes = [C.POINTER(KpdEgnnConfig), C.POINTER(C.c_void_p)]
@@ -184,7 +187,7 @@ def lib():
 
 # every symbol include/kpd.h declares (checked by tests/test_abi.py against the header text)
 EXPORTS = [
-    'kpd_last_error', 'kpd_version', 'kpd_build_lig_graph',
+    'kpd_last_error', 'kpd_version', 'kpd_build_flags', 'kpd_build_lig_graph',
     'kpd_egnn_create', 'kpd_egnn_destroy', 'kpd_egnn_load_weight', 'kpd_egnn_commit', 'kpd_egnn_reserve',
     'kpd_egnn_forward', 'kpd_egnn_debug_state', 'kpd_egnn_last_counts', 'kpd_egnn_profile',
     'kpd_egnn_profile_read', 'kpd_sample_update', 'kpd_step_coefficients', 'kpd_complex_noise',

@@ -1,6 +1,8 @@
 """Per-phase cycles of k_egnn_edge with two co-resident workgroups per CU (production) and with one
 (KPD_EDGE_LDS_PAD forces one workgroup per CU): how much of the non-GEMM time hides behind the partner's MFMAs."""
 import os, subprocess, sys
+# (the KPD_* switches of this tool exist only in the TOOLS build: `make -C keypoint-diffusion_amd/csrc tools`)
+os.environ.setdefault('KPD_LIB', os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'keypoint-diffusion_amd', 'csrc', 'tools_build', 'libkpd_hip.so'))
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 

@@ -1,6 +1,8 @@
 """Edge-sized weight-gradient products C[257, 257] += A[K, 257]^T B[K, 257] (264-float rows, as the EGNN trainer calls them) through
 kpd_sgemm: TFLOP/s of the product + its split-K reduction.  KPD_SGEMM_TN256=0 selects the tiled kernel, default the full-output one."""
 import os, sys, time
+# (the KPD_* switches of this tool exist only in the TOOLS build: `make -C keypoint-diffusion_amd/csrc tools`)
+os.environ.setdefault('KPD_LIB', os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'keypoint-diffusion_amd', 'csrc', 'tools_build', 'libkpd_hip.so'))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from keypoint_diffusion_amd import hip

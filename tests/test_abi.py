@@ -30,6 +30,19 @@ def test_version_and_error_string_without_gpu():
     assert isinstance(lib.kpd_last_error(), bytes)
 
 
+def test_product_build_has_no_ablation_or_ab_switches():
+    """The shipped library is the product build: kpd_build_flags() == 0 and the names of the A/B, ablation and LDS-padding switches of
+    profiles/tools (read from the environment only by the TOOLS build, `make tools`) are not even in the binary.  What the product does
+    read: KPD_GEMM (the opt-in f16x2 mode), KPD_TRAIN_STORE (recompute instead of keeping activations), KPD_POISON (NaN-poisoned
+    workspaces for the read-before-write tests) -- bench.py refuses to run with any of them set."""
+    assert hip.lib().kpd_build_flags() == 0
+    blob = open(hip.LIB_PATH, 'rb').read()
+    names = set(re.findall(rb'KPD_[A-Z0-9_]{3,}', blob))
+    assert names <= {b'KPD_GEMM', b'KPD_TRAIN_STORE', b'KPD_POISON'}, sorted(names)
+    for gone in (b'KPD_EDGE_ABLATE', b'KPD_EDGE_SPLIT', b'KPD_EDGE_LDS_PAD', b'KPD_NODE_LDS_PAD', b'KPD_SGEMM_', b'KPD_TRAIN_FUSED', b'KPD_H_PARTS'):
+        assert gone not in blob, gone
+
+
 def test_product_has_no_cpu_fallback():
     """The product path must fail loudly off-GPU rather than compute on the CPU."""
     import pytest

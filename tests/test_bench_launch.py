@@ -24,6 +24,22 @@ def test_bench_spawns_n_ranks_itself():
     assert len({d['port'] for d in lines}) == 1
 
 
+def test_bench_spawns_eight_ranks():
+    """The driver's N = 8 run: eight rank processes, local ranks 0..7, one rendezvous port (echo mode: no GPU, no torch)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '2'], capture_output=True, text=True,
+                       env=_clean_env(KPD_BENCH_SPAWN_ECHO='1'), timeout=120)
+    assert r.returncode == 0, r.stderr
+    lines = sorted((json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith('{')), key=lambda d: d['rank'])
+    assert [d['rank'] for d in lines] == list(range(8)) and [d['local_rank'] for d in lines] == list(range(8))
+    assert all(d['world'] == 8 and d['gpus'] == 8 and d['master'] == '127.0.0.1' for d in lines) and len({d['port'] for d in lines}) == 1
+
+
+def test_rank_thread_share():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.rank_cpu_threads(128, 8) == 16 and bench.rank_cpu_threads(16, 8) == 2 and bench.rank_cpu_threads(4, 8) == 1
+
+
 def test_bench_honours_an_external_launcher():
     """Under torch.distributed.run the environment already names the rank: no second level of spawning."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4'], capture_output=True, text=True,

@@ -110,3 +110,50 @@ def test_training_record_goes_through_the_same_line():
            'cpu_baseline': {'value': 0.01, 'unit': 'steps/s', 'cores': 16, 'kind': 'port', 'sample': 'y' * 500}}
     back = json.loads(json.dumps(bench.compact_line(rec)))
     assert back['cpu_baseline']['cores'] == 16 and len(back['cpu_baseline']['sample']) <= 160 and 'roofline' not in back
+
+
+def test_line_at_eight_ranks_keeps_every_rank_and_fits():
+    """N = 8: `ranks_seen`, `collective_backend` and all eight per-rank times stay in the <= 4 KB line, secondaries and all."""
+    rec = synthetic_record(world=8)
+    rec['per_rank_ms_per_step'] = [6.8758165 + 0.0123456 * r for r in range(8)]          # one slow rank must stay visible
+    rec['per_rank_ms_per_step'][5] = 9.87654321
+    text = json.dumps(bench.compact_line(rec, bench.FULL_RECORD), separators=(',', ':'))
+    assert len(text) <= bench.COMPACT_LIMIT, len(text)
+    back = json.loads(text)
+    assert back['n_gpus'] == 8 and back['ranks_seen'] == 8 and back['collective_backend'] == 'nccl'
+    assert len(back['per_rank_ms_per_step']) == 8 and abs(back['per_rank_ms_per_step'][5] - 9.8765) < 1e-3
+    assert back['config']['parallelism'] == 'dp8'
+
+
+def test_line_attests_environment_and_build():
+    rec = synthetic_record()
+    back = json.loads(json.dumps(bench.compact_line(rec)))
+    assert back['env'] == [] and back['build'] == 'product' and 'attested' not in back
+    assert back['roofline']['traffic_measured'] is False
+    att = bench.attest_environment({'PATH': '/bin', 'KPD_BENCH_SHARE_GPU': '1'}, 0)
+    assert att == {'env': ['KPD_BENCH_SHARE_GPU'], 'build': 'product', 'attested': True}
+    rec['attest'] = bench.attest_environment({'KPD_EDGE_ABLATE': '1'}, 1, allow_tools=True)
+    back = json.loads(json.dumps(bench.compact_line(rec)))
+    assert back['env'] == ['KPD_EDGE_ABLATE'] and back['build'] == 'tools' and back['attested'] is False
+
+
+def test_bench_refuses_altering_variables_and_tools_builds():
+    import pytest
+    for env, flags in (({'KPD_EDGE_ABLATE': '1'}, 0), ({'KPD_GEMM': 'f16x2'}, 0), ({'KPD_LIB': '/x.so'}, 0), ({'KPD_POISON': '1'}, 0), ({}, 1)):
+        with pytest.raises(SystemExit) as e:
+            bench.attest_environment(env, flags)
+        assert e.value.code == 2
+
+
+def test_bench_refuses_a_roofline_fraction_above_one(tmp_path, monkeypatch):
+    import pytest
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    for mutate in (lambda r: r['roofline'].update(frac=1.2), lambda r: r['roofline'].update(frac=0.0),
+                   lambda r: next(iter(r['secondary'].values()))['roofline'].update(frac=1.01),
+                   lambda r: r['roofline']['hbm'].update(frac=1.5)):
+        rec = synthetic_record()
+        mutate(rec)
+        buf = io.StringIO()
+        with redirect_stdout(buf), pytest.raises(SystemExit) as e:
+            bench.emit(rec)
+        assert e.value.code == 2 and buf.getvalue() == ''            # nothing printed

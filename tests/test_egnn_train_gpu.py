@@ -227,11 +227,11 @@ def test_recompute_mode_gives_the_same_gradients():
     assert all(torch.equal(a, b) for a, b in zip(*outs))
 
 
-def test_layer_edge_kernels_match_the_per_branch_kernels():
-    """The forward / backward edge passes of a layer run as one kernel each (k_egnn_edge_train, k_egnn_edge_bwd); the per-branch kernels they
-    replaced stay behind KPD_TRAIN_FUSED_FWD=0 / KPD_TRAIN_FUSED_BWD=0.  Same gradients up to summation order (the switches are read once per
-    process: child processes), on a batch whose edge counts leave ragged last tiles and a keypoint type that is updated.  A fourth child runs
-    the default path on NaN-poisoned workspaces and must reproduce the default's bits."""
+def test_layer_edge_kernels_on_poisoned_workspaces():
+    """The forward / backward edge passes of a layer run as one kernel each (k_egnn_edge_train, k_egnn_edge_bwd); their gradients are checked
+    against the oracle's autograd above.  Here: a child process runs the same step on NaN-poisoned workspaces (KPD_POISON=1, read once per
+    process) and must reproduce the default run's bits -- a read of memory this step has not written would surface as a NaN or as different
+    bits -- on a batch whose edge counts leave ragged last tiles and a keypoint type that is updated."""
     import os
     import subprocess
     import sys
@@ -243,19 +243,14 @@ def test_layer_edge_kernels_match_the_per_branch_kernels():
             '(eh.square().sum() + ex.square().sum()).backward()\n'
             'torch.save([p.grad.cpu() for p in model.parameters()], sys.argv[1])\n' % root)
     outs = []
-    for tag, env in (('fused', {}), ('nobwd', {'KPD_TRAIN_FUSED_BWD': '0'}), ('nofwd', {'KPD_TRAIN_FUSED_FWD': '0'}), ('poison', {'KPD_POISON': '1'})):
+    for tag, env in (('default', {}), ('poison', {'KPD_POISON': '1'})):
         base = os.path.join(root, 'gpurun_out') if os.path.isdir(os.path.join(root, 'gpurun_out')) else '/tmp'
         path = os.path.join(base, f'_grads_{tag}.pt')
         subprocess.run([sys.executable, '-c', code, path], check=True, env=dict(os.environ, **env), timeout=600)
         outs.append(torch.load(path))
         os.remove(path)
-    # NaN-poisoned workspaces (engine.h): a read of memory this step has not written would surface as a NaN or as different bits
-    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[3]))
-    top = max(float(b.abs().max()) for b in outs[0])
-    for other in outs[1:3]:
-        for a, b in zip(outs[0], other):
-            scale = max(float(b.abs().max()), 1e-3 * top)          # (a gradient that is a heavily cancelling sum is judged on the model's scale)
-            assert float((a - b).abs().max()) <= 2e-4 * scale, (float((a - b).abs().max()), scale)
+    assert all(torch.isfinite(a).all() for a in outs[0])
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
 
 
 def test_backward_after_the_caller_dropped_the_graph():
