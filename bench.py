@@ -303,11 +303,13 @@ def _cpu_time_steps(fwd, sd, cfg, ob, T, n_warm, n_timed):
 
 def _stats(times, B):
     med = statistics.median(times)
-    return {'B': B, 'timed_steps': len(times), 's_per_step_median': med, 'spread_pct': 100.0 * (max(times) - min(times)) / med,
-            'complex_steps_per_s': B / med}
+    q = statistics.quantiles(times, n=4) if len(times) >= 4 else [min(times), med, max(times)]
+    # spread = interquartile range over the median (one preempted step out of fifteen no longer sets it); the full range beside it
+    return {'B': B, 'timed_steps': len(times), 's_per_step_median': med, 'spread_pct': 100.0 * (q[2] - q[0]) / med, 'spread_statistic': 'IQR / median',
+            'range_pct': 100.0 * (max(times) - min(times)) / med, 'complex_steps_per_s': B / med}
 
 
-def cpu_baseline(workload='egnn_all_atom', ragged=False, B_scale=64, n_timed=7, with_c1=False):
+def cpu_baseline(workload='egnn_all_atom', ragged=False, B_scale=64, n_timed=15, with_c1=False):
     """the oracle (plain PyTorch fp32 CPU restatement of the reference path) on this box's host cores --
     `torch.set_num_threads(cores this process may use)`, the workload's shape at B = 1 and B = 8, 2 warm-up steps then `n_timed`
     timed steps each, median; `value` is the B = 8 median scaled to the B_scale batch.  `with_c1`: BASELINE configs[0] in full
@@ -597,7 +599,7 @@ def run_end_to_end(device, workload='egnn_all_atom', B=64, n_rec=300, n_lig=25, 
         n_rec, n_lig = ragged_sizes(B, 0)
     runs = []
     with torch.no_grad():
-        for it in range(3):         # first pass = warm-up (workspace reservation, first-use initialisation); the faster of the other two counts
+        for it in range(4):         # first pass = warm-up (workspace reservation, first-use initialisation); the MEDIAN of the other three counts
             g = raw_batch(B, n_rec, n_lig, 4321, device, workload)          # (a host hiccup -- allocator, collector -- once put 80 ms into a 1.5-ms encoder)
             if w['enc'] != 'learned':
                 g = g.to(device)                   # resident before the clock starts, like `value`'s batch (raw_batch uploads the learned-encoder case itself)
@@ -612,13 +614,18 @@ def run_end_to_end(device, workload='egnn_all_atom', B=64, n_rec=300, n_lig=25, 
             dt = time.perf_counter() - t0
             if it:
                 runs.append((dt, t_enc))
-    dt, t_enc = min(runs)
+    # median of the three timed passes for both figures (the contract `value` and the CPU baseline are medians too); the spread says
+    # when a host hiccup sat in one of them
+    dt = statistics.median(r[0] for r in runs)
+    t_enc = statistics.median(r[1] for r in runs)
+    spread = 100.0 * (max(r[0] for r in runs) - min(r[0] for r in runs)) / dt
     assert len(pos) == B and all(p.device.type == 'cpu' for p in pos)
     del model
     torch.cuda.empty_cache()
     return {'workload': workload + ('_ragged' if ragged else ''), 'gemm': gemm, 'ligands_per_min': 60.0 * B / dt, 'wall_s': dt,
             'encoder_ms': 1e3 * t_enc, 'reverse_loop_and_copy_s': dt - t_enc, 'steps_per_s_in_loop': w['T'] / (dt - t_enc),
-            'n_ligands': B, 'n_timesteps': w['T'], 'runs_wall_s': [r[0] for r in runs],
+            'n_ligands': B, 'n_timesteps': w['T'], 'runs_wall_s': [r[0] for r in runs], 'runs_encoder_ms': [1e3 * r[1] for r in runs],
+            'statistic': 'median of 3 timed passes', 'spread_pct': spread,
             'includes': 'receptor encoding + all reverse steps (per-step graph rebuild, fresh noise) + final frame shift + '
                         'device->host copy of the ligands; model build and synthetic-data generation excluded',
             'note': 'random-init weights do not denoise: the ligand spreads over the loop and the lig-lig graph thins, so late '
@@ -668,8 +675,9 @@ def compact_line(out, full_path=None):
     if cb:
         host = cb.get('host', {})
         line['cpu_baseline'] = {'value': _r(cb.get('value')), 'unit': cb.get('unit'), 'cores': cb.get('cores'), 'kind': cb.get('kind'),
-                                'sample': 'oracle reverse steps at the same shape, B=1 and B=8, 2 warm-up + 7 timed each, median; '
-                                          'value = B=8 rate scaled to the batch' if 'cases' in cb else str(cb.get('sample', ''))[:160],
+                                'sample': 'oracle reverse steps at the same shape, B=1 and B=8, 2 warm-up + %d timed each, median (spread = IQR/median); '
+                                          'value = B=8 rate scaled to the batch' % max([c.get('timed_steps', 0) for c in cb['cases'].values()] + [0])
+                                          if 'cases' in cb else str(cb.get('sample', ''))[:160],
                                 'cpu_model': host.get('cpu_model'),
                                 'cases': {k: _r(v.get('complex_steps_per_s')) for k, v in cb.get('cases', {}).items()},
                                 'spread_pct': {k: _r(v.get('spread_pct'), 3) for k, v in cb.get('cases', {}).items()}}
@@ -699,8 +707,9 @@ def compact_line(out, full_path=None):
     for name, r in (out.get('end_to_end_more') or {}).items():
         e2e[name] = r
     if e2e:
-        line['end_to_end'] = {name: [_r(r.get('ligands_per_min')), _r(r.get('encoder_ms')), r.get('n_timesteps')] for name, r in e2e.items()}
-        line['end_to_end_fields'] = ['ligands_per_min', 'encoder_ms', 'T']
+        line['end_to_end'] = {name: [_r(r.get('ligands_per_min')), _r(r.get('encoder_ms')), r.get('n_timesteps'), _r(r.get('spread_pct'), 3)]
+                              for name, r in e2e.items()}
+        line['end_to_end_fields'] = ['ligands_per_min (median of 3)', 'encoder_ms', 'T', 'spread_pct']
     if out.get('ligands_per_min') is not None:
         line['ligands_per_min'] = _r(out['ligands_per_min'])
     if out.get('c1_gpu'):

@@ -141,10 +141,14 @@ class LigRecDynamicsGVP(nn.Module):
         so the list of Parameter objects is cached.  It is rebuilt after `.to()` / `load_state_dict` and whenever ANY module of the
         process registered a parameter since it was built (`hip.param_generation`: `module.weight = nn.Parameter(...)`, parametrize
         and pruning all go through `register_parameter`), so a Parameter object swapped in deep inside the module is seen by the
-        next forward."""
+        next forward.  Unsupported as an immediate trigger: writes into `module._parameters` that bypass `register_parameter` (seen by
+        the periodic re-walk below)."""
         gen = hip.param_generation()
         ps = self.__dict__.get('_param_list')
-        if ps is None or self.__dict__.get('_param_gen') != gen:
+        # every 256th call walks the tree again whatever the hook said: mutations that bypass `register_parameter` (a direct
+        # `module._parameters[name] = p`, `__setstate__` / deepcopy swaps) are then seen after at most 256 forwards instead of never
+        n = self.__dict__['_param_calls'] = self.__dict__.get('_param_calls', 0) + 1
+        if ps is None or self.__dict__.get('_param_gen') != gen or (n & 255) == 0:
             ps = self.__dict__['_param_list'] = list(self.parameters())
             self.__dict__['_param_gen'] = gen
         return tuple([(p.data_ptr(), p._version) for p in ps])

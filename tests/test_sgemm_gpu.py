@@ -88,12 +88,16 @@ def test_column_sums_ride_along_with_a_weight_gradient(M, N, K, layout):
         assert torch.equal(cs, cs2) and torch.equal(out, out2)
 
 
-@pytest.mark.parametrize('M,N,K', [(257, 257, 32768), (257, 257, 40001), (256, 256, 166003), (257, 256, 50017), (256, 257, 33000)])
+@pytest.mark.parametrize('M,N,K', [(257, 257, 65536), (257, 257, 70001), (257, 256, 66017), (256, 257, 131075), (256, 256, 166003),
+                                   (257, 257, 65553), (257, 257, 65535)])
 def test_full_output_weight_gradient_kernel(M, N, K):
-    """Edge-sized weight gradients (K >= 32 768 rows of 16-B aligned activations, 256 (+ 1) x 256 (+ 1) outputs: dW2 = dpre2^T a1 of the
+    """Edge-sized weight gradients (K >= 65 536 rows of 16-B aligned activations, 256 (+ 1) x 256 (+ 1) outputs: dW2 = dpre2^T a1 of the
     EGNN trainer with its 264-float rows, the 256 x 256 scalar blocks of the GVP trainers) take k_sgemm_tn256 -- the whole output in one
-    workgroup, every operand row fetched once.  Against a float64 product, with the fringe row / column, the column sums of A, a K tail
-    that is no multiple of the 16-row slab, accumulation into C, and bit for bit twice."""
+    workgroup, every operand row fetched once (dispatch: sgemm.hip, `K >= 65536`).  Every 257-wide case here sits above that threshold, so
+    the kernel's fringe riders (row / column 256, the corner, the fringe row's column sum, the x_part layout) are what runs: 65 536 = whole
+    16-row slabs, 70 001 / 66 017 / 131 075 = K tails that are no multiple of 16, 65 553 = a last split-K slice of ONE row (no full slab
+    in it); 65 535 pins the other side of the dispatch (the tiled kernel, same checks).  Against a float64 product, with the column sums
+    of A, accumulation into a strided C, and bit for bit twice."""
     dev = torch.device('cuda:0')
     gen = torch.Generator().manual_seed(17)
     a = torch.randn(K, 264, generator=gen).to(dev)[:, :M]            # the trainers' row stride
