@@ -70,7 +70,7 @@ __device__ __forceinline__ void chunk_gemm2(const v4f *__restrict__ buf, v4f xa,
 }
 
 // Weight-chunk ring of a 256-thread workgroup: chunks travel global -> LDS by LDS-DMA (global_load_lds_dwordx4: no
-// staging registers, no ds_write), two chunks ahead of the one being consumed, through three buffers.
+// staging registers, no ds_write), NBUF - 1 chunks ahead of the one being consumed, through NBUF buffers (below: NBUF = 3).
 //   src(c)     this thread's source address of chunk c (CH4 float4 per chunk, thread t owns t + 256 j)
 //   start()    begin chunks 0 and 1;   first()  chunk 0 is in LDS for every wave
 //   acquire()  every wave has passed the barrier that ended chunk cur - 1, so buffer (cur + 2) % 3 is free: start chunk
@@ -80,10 +80,12 @@ __device__ __forceinline__ void chunk_gemm2(const v4f *__restrict__ buf, v4f xa,
 //   drain()    before the ring memory is reused for something else
 // MFMA streams run at priority 0 and everything else at 2: epilogues, gathers and ring hand-offs are short and
 // latency bound, and a wave stuck behind another workgroup's full-rate MFMA stream stalls its own workgroup.
-template <int CH4>
+template <int CH4, int NBUF = 3>
 struct ChunkRing {
     static constexpr int PT = CH4 / 256;
+    static constexpr int AHEAD = NBUF - 1;          // chunks in flight beyond the one being consumed
     static_assert(PT == 2 || PT == 4, "chunk size");
+    static_assert(NBUF == 3 || NBUF == 4, "ring depth");
     typedef __attribute__((address_space(3))) void lds_void;
     typedef const __attribute__((address_space(1))) void glb_void;
     v4f *ring;
@@ -106,11 +108,14 @@ struct ChunkRing {
     }
     template <class F>
     __device__ __forceinline__ void start(F &&src) {
-        fetch(src, 0, 0);
-        fetch(src, 1, 1);
+#pragma unroll
+        for (int c = 0; c < AHEAD; ++c) fetch(src, c, c);
     }
+    // this thread's pieces of everything but the AHEAD - 1 most recent chunks have landed
     __device__ __forceinline__ void wait_landed() {
-        if (PT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        constexpr int n = (AHEAD - 1) * PT;
+        if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     }
     __device__ __forceinline__ void first() {
@@ -119,12 +124,12 @@ struct ChunkRing {
     }
     template <class F>
     __device__ __forceinline__ const v4f *acquire(F &&src) {
-        int b2 = cur + 2;
-        b2 -= 3 * (b2 / 3);
-        fetch(src, cur + 2, b2);
+        int b2 = cur + AHEAD;
+        b2 -= NBUF * (b2 / NBUF);
+        fetch(src, cur + AHEAD, b2);
         __builtin_amdgcn_sched_barrier(0);      // keep the fetch at the head of the chunk
         __builtin_amdgcn_s_setprio(0);
-        return ring + (cur - 3 * (cur / 3)) * CH4;
+        return ring + (cur - NBUF * (cur / NBUF)) * CH4;
     }
     __device__ __forceinline__ void release() {
         __builtin_amdgcn_s_setprio(2);
@@ -189,5 +194,70 @@ struct ChunkRing2 {
         lds_barrier();
     }
 };
+
+// ---- GVPLayerNorm halves and the 12-float vector rows of the register-chained node kernels (gvp_chain.hip, gvp_coop.hip) ---------
+// A node's S scalars live on its four lanes (x[nt][r] = s[node][16 nt + 4 (lane >> 4) + r]), so a layer norm is in-lane sums plus
+// two cross-lane adds.
+template <int NTS>
+__device__ __forceinline__ void lanes_ln_stats(const v4f (&x)[NTS], float inv_n, float pad, float &mean, float &rstd) {
+    // inv_n = 1 / n_hidden_scalars; `pad` trailing registers hold 0 (narrower models on these kernels): their (0 - mean)^2 is taken out
+    // of the variance and their weight / bias are 0.  pad = 0 is bit-identical to the fixed-width form.
+    float sum = 0.0f;
+#pragma unroll
+    for (int nt = 0; nt < NTS; ++nt) sum += (x[nt][0] + x[nt][1]) + (x[nt][2] + x[nt][3]);
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    mean = sum * inv_n;
+    float var = 0.0f;
+#pragma unroll
+    for (int nt = 0; nt < NTS; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float d = x[nt][r] - mean;
+            var = fmaf(d, d, var);
+        }
+    var += __shfl_xor(var, 16);
+    var += __shfl_xor(var, 32);
+    rstd = 1.0f / sqrtf((var - pad * mean * mean) * inv_n + 1e-5f);
+}
+
+// one 16-column tile of the normalised row (columns 16 nt + 4 q ..): what lanes_layernorm leaves in x[nt]
+__device__ __forceinline__ v4f lanes_ln_tile(v4f xt, const float *__restrict__ lw, const float *__restrict__ lb, int nt, int q, float mean, float rstd) {
+    const v4f w = *reinterpret_cast<const v4f *>(lw + 16 * nt + 4 * q), b = *reinterpret_cast<const v4f *>(lb + 16 * nt + 4 * q);
+    return (xt - mean) * rstd * w + b;
+}
+
+template <int NTS>
+__device__ __forceinline__ void lanes_layernorm(v4f (&x)[NTS], const float *__restrict__ lw, const float *__restrict__ lb, int q, float inv_n,
+                                                float pad) {
+    float mean, rstd;
+    lanes_ln_stats<NTS>(x, inv_n, pad, mean, rstd);
+#pragma unroll
+    for (int nt = 0; nt < NTS; ++nt) x[nt] = lanes_ln_tile(x[nt], lw, lb, nt, q, mean, rstd);
+}
+
+// vector half of GVPLayerNorm (gvp.py:163-165): v / (sqrt(mean_i max(|v_i|^2, 1e-8) + eps) + eps)
+// inv_n = 1 / vector_size; each of the `pad` zero padding channels (narrower models) adds the clamp value 1e-8 to the sum: taken out.
+// pad = 0 is bit-identical to the fixed 16-channel form.
+__device__ __forceinline__ void lanes_vecnorm(v4f (&V)[3], float inv_n, float pad) {
+    float a = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a += fmaxf(V[0][r] * V[0][r] + V[1][r] * V[1][r] + V[2][r] * V[2][r], 1e-8f);
+    a += __shfl_xor(a, 16);
+    a += __shfl_xor(a, 32);
+    const float vn = sqrtf((a - pad * 1e-8f) * inv_n + 1e-5f) + 1e-5f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) V[c] = V[c] / vn;
+}
+
+__device__ __forceinline__ void load_vec12(const float *p, v4f (&V)[3]) {       // 4 channels x xyz -> V[c][r]
+    const v4f *vp = reinterpret_cast<const v4f *>(p);
+    const v4f t0 = vp[0], t1 = vp[1], t2 = vp[2];
+    const float f[12] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3], t2[0], t2[1], t2[2], t2[3]};
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) V[c][r] = f[3 * r + c];
+}
 
 }  // namespace kpd

@@ -42,6 +42,7 @@ struct kpd_gvp {
     int gemm_mode = 0;                        // 0 exact fp32; 1 f16x2 split in the message chain (KPD_GEMM=f16x2, "gemm=f16x2")
     int debug_convs = -1;
     unsigned long long *stamps = nullptr;     // device [32], diagnostics
+    int coop_rows = 0;                        // row limit of the cooperative node-side kernels (0: default; kpd_gvp_debug_state "coop_rows=N")
     // optional HIP-event timing of the dominant kernel (k_gvp_chain), for bench.py's roofline
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;
@@ -376,6 +377,7 @@ extern "C" kpd_status kpd_gvp_forward(kpd_gvp *m, const kpd_batch *bt, const flo
         pa.n_slots = net;
         pa.tiles_first[net] = run;
         pa.gemm_mode = S == 256 ? m->gemm_mode : 0;
+        pa.coop_rows = m->coop_rows;
         KPD_TRY(launch_gvp_proj(pa, st));
 
         GvpEdgeArgs ea;
@@ -424,6 +426,7 @@ extern "C" kpd_status kpd_gvp_forward(kpd_gvp *m, const kpd_batch *bt, const flo
         }
         np.tiles0 = cdiv(n[0], TM);
         np.gemm_mode = S == 256 ? m->gemm_mode : 0;
+        np.coop_rows = m->coop_rows;
         KPD_TRY(launch_gvp_node(np, st));
     }
 
@@ -431,6 +434,7 @@ extern "C" kpd_status kpd_gvp_forward(kpd_gvp *m, const kpd_batch *bt, const flo
     memset(&no, 0, sizeof(no));
     no.n = bt->n_lig; no.s = m->s[0]; no.v = m->v[0]; no.n_gvps = c.n_noise_gvps; no.S = S;
     no.gemm_mode = S == 256 ? m->gemm_mode : 0;
+    no.coop_rows = m->coop_rows;
     for (int j = 0; j < c.n_noise_gvps; ++j) no.g[j] = m->noise[j].dev();
     no.Wout = m->out_W; no.bout = m->out_b; no.F = c.n_lig_scalars; no.eps_h = eps_h; no.eps_x = eps_x;
     KPD_TRY(launch_gvp_noise(no, st));
@@ -443,6 +447,10 @@ extern "C" kpd_status kpd_gvp_debug_state(kpd_gvp *m, const char *what, float *o
     const std::string w(what);
     if (w.rfind("convs=", 0) == 0) {
         m->debug_convs = atoi(w.c_str() + 6);
+        return KPD_OK;
+    }
+    if (w.rfind("coop_rows=", 0) == 0) {         // row limit of the cooperative node-side kernels: 0 default, -1 never, N up to N rows
+        m->coop_rows = atoi(w.c_str() + 10);
         return KPD_OK;
     }
     if (w.rfind("gemm=", 0) == 0) {              // "gemm=f32" (exact, the default) | "gemm=f16x2" (split f16 products in the message chain)

@@ -22,12 +22,16 @@ namespace kpd {
 
 namespace {
 
+#ifndef KPD_CHAIN_NBUF
+#define KPD_CHAIN_NBUF 3          // buffers of the edge kernel's weight ring (chain_core.h)
+#endif
+
 template <int NTS>
 struct ChainSmem {
     static constexpr int S = 16 * NTS;
     static constexpr int CH4 = NTS * 64;                 // float4 per chunk
     static constexpr int SO = S + 4;                     // row stride of the output staging tile
-    static constexpr int REGION0 = (3 * CH4 * 4 > TM * SO) ? 3 * CH4 * 4 : TM * SO;   // ring / output tile (floats)
+    static constexpr int REGION0 = (KPD_CHAIN_NBUF * CH4 * 4 > TM * SO) ? KPD_CHAIN_NBUF * CH4 * 4 : TM * SO;   // ring / output tile (floats)
     static constexpr int FLOATS = REGION0 + TM * 48 + TM + 16;
 };
 
@@ -297,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
         }
         return reinterpret_cast<const v4f *>(HM ? a.g[et][stage].chain_h : a.g[et][stage].chain) + (size_t)local * CH4 + tid;
     };
-    ChunkRing<CH4> ring;
+    ChunkRing<CH4, KPD_CHAIN_NBUF> ring;
     ring.init(smem, total, wave);
     ring.start(chunk_src);
     auto acquire = [&]() -> const v4f * { return ring.acquire(chunk_src); };
@@ -519,51 +523,46 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
     lds_barrier();
     CHAIN_STAMP(10)
 
-    // ---- segmented sums over dst: scalars (thread = column), then the 48 vector floats ------------------
-    const int first_is_cont = misc[0];
-    const unsigned long long endmask =
-        ((unsigned long long)(unsigned)misc[3] << 32) | (unsigned long long)(unsigned)misc[2];
-    if (tid < S) {
-        float *smain = a.ms_main[et], *scont = a.ms_cont[et] + (size_t)tile_in_et * S;
-        float run = 0.0f;
-        int piece = 0;
-#pragma unroll 1
-        for (int r0 = 0; r0 < TM; r0 += 16) {
-            if (r0 >= ne) break;
-            float v[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = O[(r0 + i) * SO + tid];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if (r0 + i < ne) run += v[i];
-                if ((endmask >> (r0 + i)) & 1ull) {
-                    float *out = (piece == 0 && first_is_cont) ? scont : smain + (size_t)sdst[r0 + i] * S;
-                    out[tid] = run;
-                    run = 0.0f;
-                    ++piece;
-                }
-            }
-        }
-    }
-    // the vector sums run on the last wave's spare lanes when S leaves one, else after the scalar pass
+    // ---- segmented sums over dst: scalars (thread = column) and the 48 vector floats in ONE pass over the rows --------
+    // (the vector columns ride on the first 48 threads -- S = 256 -- or on the last wave's spare lanes; a second pass for them
+    // kept wave 0, and with it the workgroup's slot, 5 k cycles longer).  The run structure is wave-uniform: as scalars.
+    const int first_is_cont = __builtin_amdgcn_readfirstlane(misc[0]);
+    const unsigned long long endmask = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(misc[3]) << 32) |
+                                       (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(misc[2]);
     const int vt = S < 256 ? tid - 192 : tid;
-    if (vt >= 0 && vt < 48) {
+    const bool do_s = tid < S, do_v = vt >= 0 && vt < 48;
+    if (do_s || do_v) {
+        float *smain = a.ms_main[et], *scont = a.ms_cont[et] + (size_t)tile_in_et * S;
         float *vmain = a.mv_main[et], *vcont = a.mv_cont[et] + (size_t)tile_in_et * 48;
-        float run = 0.0f;
+        const int vcol = do_v ? vt : 0, scol = do_s ? tid : 0;
+        float run = 0.0f, runv = 0.0f;
         int piece = 0;
 #pragma unroll 1
         for (int r0 = 0; r0 < TM; r0 += 16) {
             if (r0 >= ne) break;
-            float v[16];
+            float v[16], u[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = Vout[(r0 + i) * 48 + vt];
+            for (int i = 0; i < 16; ++i) v[i] = O[(r0 + i) * SO + scol];
+            if (__builtin_amdgcn_readfirstlane(wave == (S < 256 ? 3 : 0))) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) u[i] = Vout[(r0 + i) * 48 + vcol];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) u[i] = 0.0f;
+            }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                if (r0 + i < ne) run += v[i];
+                if (r0 + i < ne) {
+                    run += v[i];
+                    runv += u[i];
+                }
                 if ((endmask >> (r0 + i)) & 1ull) {
-                    float *out = (piece == 0 && first_is_cont) ? vcont : vmain + (size_t)sdst[r0 + i] * 48;
-                    out[vt] = run;
+                    const bool cont = piece == 0 && first_is_cont;
+                    const int dv = sdst[r0 + i];
+                    if (do_s) (cont ? scont : smain + (size_t)dv * S)[tid] = run;
+                    if (do_v) (cont ? vcont : vmain + (size_t)dv * 48)[vt] = runv;
                     run = 0.0f;
+                    runv = 0.0f;
                     ++piece;
                 }
             }
@@ -578,59 +577,6 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
 // live on its four lanes (64 registers each), so both layer norms are in-lane sums plus two cross-lane adds; the
 // residual scalars wait in the s_tmp scratch rows (the registers are needed for the GEMM operands), the 16 residual
 // vectors stay in registers.
-template <int NTS>
-__device__ __forceinline__ void lanes_layernorm(v4f (&x)[NTS], const float *__restrict__ lw, const float *__restrict__ lb, int q, float inv_n,
-                                                float pad) {
-    // inv_n = 1 / n_hidden_scalars; `pad` trailing registers hold 0 (narrower models on these kernels): their (0 - mean)^2 is taken out
-    // of the variance and their weight / bias are 0.  pad = 0 is bit-identical to the fixed-width form.
-    float sum = 0.0f;
-#pragma unroll
-    for (int nt = 0; nt < NTS; ++nt) sum += (x[nt][0] + x[nt][1]) + (x[nt][2] + x[nt][3]);
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
-    const float mean = sum * inv_n;
-    float var = 0.0f;
-#pragma unroll
-    for (int nt = 0; nt < NTS; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float d = x[nt][r] - mean;
-            var = fmaf(d, d, var);
-        }
-    var += __shfl_xor(var, 16);
-    var += __shfl_xor(var, 32);
-    const float rstd = 1.0f / sqrtf((var - pad * mean * mean) * inv_n + 1e-5f);
-#pragma unroll
-    for (int nt = 0; nt < NTS; ++nt) {
-        const v4f w = *reinterpret_cast<const v4f *>(lw + 16 * nt + 4 * q), b = *reinterpret_cast<const v4f *>(lb + 16 * nt + 4 * q);
-        x[nt] = (x[nt] - mean) * rstd * w + b;
-    }
-}
-
-// vector half of GVPLayerNorm (gvp.py:163-165): v / (sqrt(mean_i max(|v_i|^2, 1e-8) + eps) + eps)
-// inv_n = 1 / vector_size; each of the `pad` zero padding channels (narrower models) adds the clamp value 1e-8 to the sum: taken out.
-// pad = 0 is bit-identical to the fixed 16-channel form.
-__device__ __forceinline__ void lanes_vecnorm(v4f (&V)[3], float inv_n, float pad) {
-    float a = 0.0f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) a += fmaxf(V[0][r] * V[0][r] + V[1][r] * V[1][r] + V[2][r] * V[2][r], 1e-8f);
-    a += __shfl_xor(a, 16);
-    a += __shfl_xor(a, 32);
-    const float vn = sqrtf((a - pad * 1e-8f) * inv_n + 1e-5f) + 1e-5f;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) V[c] = V[c] / vn;
-}
-
-__device__ __forceinline__ void load_vec12(const float *p, v4f (&V)[3]) {       // 4 channels x xyz -> V[c][r]
-    const v4f *vp = reinterpret_cast<const v4f *>(p);
-    const v4f t0 = vp[0], t1 = vp[1], t2 = vp[2];
-    const float f[12] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3], t2[0], t2[1], t2[2], t2[3]};
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) V[c][r] = f[3 * r + c];
-}
-
 template <int NTS, int HM = 0>
 __global__ __launch_bounds__(256, 2) void k_gvp_node_chain(GvpNodePair p) {
     constexpr int S = 16 * NTS, CH4 = NTS * 64;
@@ -956,6 +902,11 @@ kpd_status launch_gvp_proj(const GvpProjArgs &a, hipStream_t st) {
     if (a.n_slots == 0 || a.tiles_first[a.n_slots] == 0) return KPD_OK;
     if (poison_level() >= 1) KPD_TRY(poison_lds(st));      // debug only (engine.h)
     KPD_REQUIRE(a.S == 256 || a.S == 128, KPD_ERR_INVALID, "gvp projection kernel: S=%d (supported 128, 256)", a.S);
+    if (!(a.S == 256 && a.gemm_mode == 1)) {
+        long rows = 0;
+        for (int e = 0; e < a.n_slots; ++e) rows += a.n[e];
+        if (rows <= coop_rows_max(a.coop_rows)) return launch_gvp_proj_coop(a, st);
+    }
     KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_proj_chain<16>), 4 * 16 * 64 * 16));
     KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_proj_chain<8>), 4 * 8 * 64 * 16));
     const dim3 grid(a.tiles_first[a.n_slots]);
@@ -978,6 +929,7 @@ kpd_status launch_gvp_noise(const GvpNoiseArgs &a, hipStream_t st) {
     KPD_REQUIRE(gl.sout == 64 && gl.vout == 1 && gl.vin == GV, KPD_ERR_STATE, "noise head GVP must map (S, 16) -> (64, 1)");
     for (int k = 0; k < a.n_gvps; ++k)
         KPD_REQUIRE(a.g[k].chain && a.g[k].whp && a.g[k].wup, KPD_ERR_STATE, "noise GVP %d was not prepared for the chained kernel", k);
+    if (!(a.S == 256 && a.gemm_mode == 1 && a.n_gvps > 1) && a.n <= coop_rows_max(a.coop_rows)) return launch_gvp_noise_coop(a, st);
     KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_noise_chain<16>), 3 * 16 * 64 * 16));
     KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_noise_chain<8>), 3 * 8 * 64 * 16));
     if (a.S == 256 && a.gemm_mode == 1 && a.n_gvps > 1) {
@@ -1009,6 +961,7 @@ kpd_status launch_gvp_node(const GvpNodePair &pin, hipStream_t st) {
             for (int k = 0; k < p.nt[nt].n_gvps; ++k)
                 KPD_REQUIRE(p.nt[nt].g[k].chain && p.nt[nt].g[k].whp && p.nt[nt].g[k].wup, KPD_ERR_STATE,
                             "update GVP %d was not prepared for the chained node kernel", k);
+    if (!(S == 256 && p.gemm_mode == 1) && p.nt[0].n + p.nt[1].n <= coop_rows_max(p.coop_rows)) return launch_gvp_node_coop(p, st);
     KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_node_chain<16>), 3 * 16 * 64 * 16));
     KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_node_chain<8>), 3 * 8 * 64 * 16));
     if (S == 256 && p.gemm_mode == 1) {

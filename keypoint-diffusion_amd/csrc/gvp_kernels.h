@@ -65,6 +65,7 @@ struct GvpNodePair {
     GvpNodeArgs nt[2];
     int tiles0;
     int gemm_mode;                // 0 exact fp32; 1 f16x2 split in the update GVPs' 256 x 256 products
+    int coop_rows;                // launches of at most this many rows take the cooperative form (0: COOP_ROWS_DEFAULT, < 0: never)
 };
 
 constexpr int GVP_PROJ_SLOTS = 8;
@@ -78,6 +79,7 @@ struct GvpProjArgs {
     int tiles_first[GVP_PROJ_SLOTS + 1];
     int n_slots;
     int S;
+    int coop_rows;                // as GvpNodePair::coop_rows
 };
 
 struct GvpNoiseArgs {
@@ -90,6 +92,7 @@ struct GvpNoiseArgs {
     int F;
     float *eps_h, *eps_x;
     int gemm_mode;                // 0 exact fp32; 1 f16x2 split in the generic GVPs of the head
+    int coop_rows;                // as GvpNodePair::coop_rows
 };
 
 kpd_status launch_gvp_embed(const float *in, int n, int fin, const float *W, const float *b, const float *ln_w,
@@ -99,5 +102,15 @@ kpd_status launch_gvp_proj(const GvpProjArgs &a, hipStream_t st);
 kpd_status launch_gvp_edge(const GvpEdgeArgs &a, int tile_cap, hipStream_t st);
 kpd_status launch_gvp_node(const GvpNodePair &p, hipStream_t st);
 kpd_status launch_gvp_noise(const GvpNoiseArgs &a, hipStream_t st);
+
+// Cooperative (column-split) forms of the three node-side launches (gvp_coop.hip): 16 rows per workgroup, the four waves split the
+// output columns.  launch_gvp_node / _proj / _noise take them in the exact fp32 mode whenever the launch has at most coop_rows_max()
+// rows -- a function of the row count (and the engine's setting) alone, so results stay bitwise repeatable; the two forms agree to rounding (gate sums).
+constexpr int COOP_ROWS_DEFAULT = 8192;
+// the row limit a launch uses: its own coop_rows field when set (kpd_gvp_debug_state "coop_rows=N": tests run both forms), else the default
+int coop_rows_max(int requested);
+kpd_status launch_gvp_node_coop(const GvpNodePair &p, hipStream_t st);
+kpd_status launch_gvp_proj_coop(const GvpProjArgs &a, hipStream_t st);
+kpd_status launch_gvp_noise_coop(const GvpNoiseArgs &a, hipStream_t st);
 
 }  // namespace kpd

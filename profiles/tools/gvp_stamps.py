@@ -7,9 +7,10 @@ import bench
 dev = torch.device('cuda:0')
 wl = sys.argv[1] if len(sys.argv) > 1 else 'gvp_all_atom'
 model = bench.build_model(dev, wl)
-g = bench.build_batch(model, 64, 300, 25, 1234, dev, workload=wl)
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+g = bench.build_batch(model, B, 300, 25, 1234, dev, workload=wl)
 eng = model.dynamics.engine()
-t = torch.full((64,), 0.9, device=dev)
+t = torch.full((B,), 0.9, device=dev)
 with torch.no_grad():
     for _ in range(2):
         model.dynamics(g, t, None)
@@ -31,6 +32,8 @@ else:
                             'GVP1+ vec2', 'messages -> LDS', 'segmented sums']))
     kernel = 'k_gvp_chain'
 tot = sum(vals)
-print(wl, kernel, 'phase shares (wave 0 of every workgroup):')
+print(wl, f'B={B}', kernel, 'phase shares (wave 0 of every workgroup):')
+tiles_total = n * sum(eng.last_counts()[k] for k in ('tiles',)) * 5 + n * eng.last_counts()['tiles_last']
+print(f'  {tiles_total} tile executions; {tot / tiles_total / 100e6 * 1e6:.1f} us of wave-0 time per tile (100-MHz s_memtime clock)')
 for i in sorted(names):
     print(f'  {names[i]:34s} {100 * vals[i] / tot:5.1f} %   {vals[i] / 1e6:10.1f} Mcycles')

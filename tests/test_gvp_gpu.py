@@ -114,3 +114,40 @@ def test_other_widths(cuda, width, vectors):
     cfg = dict(GVP_40KP, n_hidden_scalars=width, vector_size=vectors, n_convs=3)
     (h, x), (rh, rx) = _run(cuda, cfg, [40, 25, 31], [9, 12, 7])
     _check(h, x, rh, rx, [9, 12, 7])
+
+
+@pytest.mark.parametrize('tag,n_rec,n_lig,nkp', [('gvp_all_atom', [37, 64, 21], [9, 17, 5], 10), ('gvp_kp', [26, 19], [7, 10], 128),
+                                                 ('gvp_s128', [33, 18, 50], [16, 3, 11], 10)])
+def test_node_side_kernel_forms(cuda, tag, n_rec, n_lig, nkp):
+    """The node update, noise head and per-node projections exist in two forms (gvp_kernels.h): register-chained (one wave = 16 rows x all
+    columns, gvp_chain.hip) and cooperative (four waves split the columns of 16 rows, gvp_coop.hip); a launch takes the cooperative one up
+    to COOP_ROWS_DEFAULT rows.  Both forms against the oracle on the same inputs (engine switch `coop_rows=`: -1 never, 1 << 30 always), at
+    256 and 128 hidden scalars, ragged row counts that leave partly filled 16- and 64-row workgroups; they agree with each other to
+    rounding (the gate product is summed in four partials in the cooperative form) and each is bitwise repeatable."""
+    cfg = {'gvp_all_atom': GVP_ALL_ATOM, 'gvp_kp': GVP_CFGS['gvp_kp'], 'gvp_s128': dict(GVP_ALL_ATOM, n_hidden_scalars=128, n_convs=3)}[tag]
+    nv = cfg.get('vector_size', 16)
+    g = util.fixed_encode(util.make_batch(n_rec, n_lig, seed=41), n_vec=nv)
+    gen = torch.Generator().manual_seed(5)
+    g.nodes['kp'].data['v_0'] = 0.5 * torch.randn(g.num_nodes('kp'), nv, 3, generator=gen)
+    if nkp != 10:
+        g.nodes['kp'].data['h_0'] = torch.randn(g.num_nodes('kp'), nkp, generator=gen)
+    model = LigRecDynamicsGVP(10, nkp, graph_cutoffs=CUT, **cfg)
+    synth.fill_state_dict_(model, 9)
+    model.eval()
+    B = g.batch_size
+    t = (torch.arange(B, dtype=torch.float32) + 1) / (B + 1)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    rh, rx = ogvp.gvp_dynamics_forward(sd, dict(cfg, graph_cutoffs=CUT), util.to_obatch(g), t)
+    model = model.to(cuda)
+    gd = g.to(cuda)
+    outs = {}
+    with torch.no_grad():
+        for form, rows in (('chained', -1), ('cooperative', 1 << 30)):
+            model.engine().debug(f'coop_rows={rows}')
+            h, x = model(gd, t.to(cuda), G.get_batch_idxs(gd))
+            h2, x2 = model(gd, t.to(cuda), G.get_batch_idxs(gd))
+            assert torch.equal(h, h2) and torch.equal(x, x2), form
+            outs[form] = (h.cpu(), x.cpu())
+            _check(h.cpu(), x.cpu(), rh, rx, n_lig)
+        model.engine().debug('coop_rows=0')
+    assert util.rel_err(outs['chained'][0], outs['cooperative'][0]) < 1e-5 and util.rel_err(outs['chained'][1], outs['cooperative'][1]) < 1e-5
