@@ -461,6 +461,84 @@ def load_traffic(workload):
     return None, None
 
 
+KERNEL_STATS_ROUNDS = ('r05', 'r04')      # profiles/<round>_kernel_stats_<workload>.csv: rocprofv3 --kernel-trace --stats of `bench.py --workload ...`
+
+
+def load_kernel_stats(tag):
+    """{kernel name up to '(': (calls, average ns)} from the newest committed rocprofv3 statistics of this workload, and the file's name."""
+    import csv
+    for rnd in KERNEL_STATS_ROUNDS:
+        f = os.path.join(ROOT, 'profiles', f'{rnd}_kernel_stats_{tag}.csv')
+        if os.path.exists(f):
+            rows = {}
+            for r in csv.DictReader(open(f)):
+                name = r['Name'].split('(')[0].replace('void ', '').strip()
+                rows[name] = (int(r['Calls']), float(r['AverageNs']))
+            return rows, f'profiles/{rnd}_kernel_stats_{tag}.csv'
+    return None, None
+
+
+def hbm_kernel_report(arch, dyn, tag, B, NL, NK, counts, rec_nf):
+    """the genuinely bandwidth-bound kernels of a reverse step -- graph build, embed / decode, sampler update -- each
+    with its ALGORITHMIC bytes per launch (every array it must read or write, once; live sizes of this run), the rocprofv3 average
+    duration of the committed statistics of the same command, achieved GB/s and the fraction of the 8 TB/s HBM peak.  They move a few
+    MB per launch at most, so all of them are bounded by launch + memory LATENCY (a launch of 5 us cannot exceed bytes / 5 us), not by
+    bandwidth: `regime` says so per kernel.  Together they are ~2 % of a step."""
+    stats, src = load_kernel_stats(tag)
+    if stats is None:
+        return None
+    F = 10
+    E_ll, E_kl = counts['E_ll'], counts['E_kl']
+    i4 = 4
+    if arch == 'egnn':
+        W = 264                                    # row stride of the 257-wide state
+        emb_w_lig = (F * 64 + 64 + 64 * 256 + 256) * 4
+        emb_w_kp = 0 if rec_nf == 256 else (rec_nf * 2 * rec_nf + 2 * rec_nf + 2 * rec_nf * 256 + 256) * 4
+        table = [
+            ('k_node_graph_index', 2, i4 * (NL + NK) / 2 + i4 * (B + 1)),
+            ('k_ll_count', 1, 12 * NL + i4 * (B + 1) + i4 * NL + i4 * B),
+            ('k_scan_graph_counts', 1, 3 * i4 * B),
+            ('k_ll_fill', 1, 12 * NL + 2 * i4 * NL + i4 * (B + 1) + 2 * i4 * E_ll + i4 * (NL + 1)),
+            ('k_kl_offsets', 1, 3 * i4 * (B + 1)),
+            ('k_kl_build', 1, 12 * (NL + NK) + 2 * i4 * (B + 1) + 4 * i4 * E_kl + i4 * (NL + NK + 2)),
+            ('k_egnn_meta', 1, 8 * i4 * B),
+            ('k_embed', 2, (4 * F * NL + emb_w_lig + 4 * W * NL + 4 * rec_nf * NK + emb_w_kp + 4 * W * NK) / 2),
+            ('k_decode', 1, 4 * W * NL + 24 * NL + (256 * 20 + 20 + 20 * F + F) * 4 + 4 * (F + 3) * NL),
+            ('k_step_coef', 1, 3 * i4 * B + 4 * 8 * B),
+            ('k_sample_update', 1, 4 * (3 + F) * NL * 4 + 2 * 12 * NK),
+        ]
+    else:
+        S = dyn['n_hidden_scalars']
+        table = [
+            ('k_node_graph_index', 2, i4 * (NL + NK) / 2 + i4 * (B + 1)),
+            ('k_ll_count', 1, 12 * NL + i4 * (B + 1) + i4 * NL + i4 * B),
+            ('k_scan_graph_counts', 1, 3 * i4 * B),
+            ('k_ll_fill', 1, 12 * NL + 2 * i4 * NL + i4 * (B + 1) + 2 * i4 * E_ll + i4 * (NL + 1)),
+            ('k_kl_offsets', 1, 3 * i4 * (B + 1)),
+            ('k_kl_build', 1, 12 * (NL + NK) + 2 * i4 * (B + 1) + 4 * i4 * E_kl + i4 * (NL + NK + 2)),
+            ('k_egnn_meta', 1, 8 * i4 * B),
+            ('k_gvp_embed', 2, (4 * F * NL + 4 * rec_nf * NK + ((F + 1) * S + (rec_nf + 1) * S + 6 * S) * 4 + 4 * S * (NL + NK)) / 2),
+            ('k_step_coef', 1, 3 * i4 * B + 4 * 8 * B),
+            ('k_sample_update', 1, 4 * (3 + F) * NL * 4 + 2 * 12 * NK),
+        ]
+    kernels, tot_b, tot_ns = {}, 0.0, 0.0
+    for name, per_step, nbytes in table:
+        hit = [v for k, v in stats.items() if k.split('::')[-1] == name]
+        if not hit:
+            continue
+        ns = hit[0][1]
+        gbs = nbytes / ns                                  # bytes / ns = GB/s
+        kernels[name] = {'bytes': nbytes, 'avg_us': ns / 1e3, 'per_step': per_step, 'gb_s': gbs, 'frac': gbs / PEAK_HBM_GBS,
+                         'regime': 'latency (a %.1f-us launch moving %.2f MB)' % (ns / 1e3, nbytes / 1e6) if gbs / PEAK_HBM_GBS < 0.10 else 'bandwidth'}
+        tot_b += per_step * nbytes
+        tot_ns += per_step * ns
+    if not kernels:
+        return None
+    return {'kernels': kernels, 'bytes_per_step': tot_b, 'us_per_step': tot_ns / 1e3, 'gb_s': tot_b / tot_ns, 'frac': tot_b / tot_ns / PEAK_HBM_GBS,
+            'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'durations_from': src, 'durations_measured_in_this_run': False,
+            'note': 'algorithmic bytes per launch (live sizes) / rocprofv3 AverageNs of the committed statistics of the same command'}
+
+
 def run_sampling(args, workload, device, rank, world, dist, B, n_rec, n_lig, ragged, gemm='f32'):
     """Steps/s of one sampling workload + the roofline of its dominant kernel.  Returns the result dict (rank 0) ."""
     import torch
@@ -578,6 +656,11 @@ def run_sampling(args, workload, device, rank, world, dist, B, n_rec, n_lig, rag
                      'hbm': {'achieved': hbm_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': hbm_gbs / PEAK_HBM_GBS,
                              'bytes_per_launch': edges_per_launch * b_algo}},
     }
+    if gemm == 'f32' and B == 64 and (ragged or n_rec == 300):
+        rep = hbm_kernel_report(w['arch'], w['dyn'], workload + ('_ragged' if ragged else ''), B, int(g.num_nodes('lig')), int(g.num_nodes('kp')),
+                                counts, int(g.nodes['kp'].data['h_0'].shape[1]))
+        if rep:
+            out['hbm_kernels'] = rep
     del model, g, eng
     torch.cuda.empty_cache()
     return out
@@ -671,6 +754,9 @@ def compact_line(out, full_path=None):
                                                                                    'avg_launch_ms', 'launches', 'kernel_ms_total', 'wall_ms_total')}
         if 'hbm' in rf:
             line['roofline']['hbm_frac'] = _r(rf['hbm'].get('frac'))
+        if 'edge_kernels' in rf:             # training lines: the two per-layer edge kernels by their own HIP events
+            line['roofline']['edge_kernels'] = {k: [_r(v.get('avg_launch_ms')), _r(v.get('frac'), 4)] for k, v in rf['edge_kernels'].items()}
+            line['roofline']['edge_kernels_fields'] = ['avg_launch_ms', 'frac']
     cb = out.get('cpu_baseline')
     if cb:
         host = cb.get('host', {})
@@ -710,6 +796,11 @@ def compact_line(out, full_path=None):
         line['end_to_end'] = {name: [_r(r.get('ligands_per_min')), _r(r.get('encoder_ms')), r.get('n_timesteps'), _r(r.get('spread_pct'), 3)]
                               for name, r in e2e.items()}
         line['end_to_end_fields'] = ['ligands_per_min (median of 3)', 'encoder_ms', 'T', 'spread_pct']
+    hk = out.get('hbm_kernels')
+    if hk:
+        # graph build + embed / decode + sampler update together, algorithmic bytes over rocprof time, fraction of 8 TB/s
+        line['hbm_kernels_frac'] = _r(hk.get('frac'), 3)
+        line['hbm_kernels_us_per_step'] = _r(hk.get('us_per_step'), 4)
     if out.get('ligands_per_min') is not None:
         line['ligands_per_min'] = _r(out['ligands_per_min'])
     if out.get('c1_gpu'):
@@ -797,9 +888,17 @@ def run_train(args, device, rank, world, dist):
         last[0] = losses['l2']
 
     rank_info = {}
-    regions = timed_regions(step, args.warmup, args.steps, args.repeats, dist, info=rank_info)
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    trainer = model.dynamics._trainer()[0] if hasattr(model.dynamics, '_trainer') else None
+    egnn_prof = w['arch'] == 'egnn' and trainer is not None and hasattr(trainer, 'profile')
+    if egnn_prof:
+        trainer.profile(True)
+    regions = timed_regions(step, 0, args.steps, args.repeats, dist, info=rank_info)
     if rank == 0:
         med = statistics.median(regions)
+        n_steps_total = args.steps * args.repeats
         out = {'metric': 'training steps/sec', 'value': world * args.steps / med, 'unit': 'steps/s', 'n_gpus': world,
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * med / args.steps, 'higher_is_better': True,
                'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
@@ -807,9 +906,53 @@ def run_train(args, device, rank, world, dist):
                                       f'training mode), batch of {B} '
                                       f'synthetic {args.n_rec}-atom pockets / {args.n_lig}-atom ligands per GPU, one bucketed gradient all-reduce per step when N > 1',
                           'batch_per_gpu': B, 'parallelism': f'dp{world}'},
-               'repeats': {'n': args.repeats, 'ms_per_step': [1e3 * r / args.steps for r in regions], 'statistic': 'median'},
+               'repeats': {'n': args.repeats, 'ms_per_step': [1e3 * r / args.steps for r in regions], 'statistic': 'median',
+                           'spread_pct': 100.0 * (max(regions) - min(regions)) / med},
                'complex_steps_per_s': world * args.steps / med * B, 'final_l2': float(last[0].detach()),
                'ranks_seen': rank_info.get('ranks_seen'), 'per_rank_ms_per_step': rank_info.get('per_rank_ms_per_step')}
+        # ---- roofline of the step: executed FLOPs of the denoiser's forward (the same accounting as the sampling lines: first Linears per
+        # node) x 3 (backward = one product for the input gradient and one for the weight gradient per forward product) over the step time,
+        # against the dense fp32 MFMA peak; beside it the two per-layer edge kernels of the EGNN trainer by their own HIP events
+        NL, NK = int(template.num_nodes('lig')), int(template.num_nodes('rec')) if w['enc'] == 'fixed' else B * w['n_kp']      # fixed encoder: kp := rec
+        L = w['dyn']['n_layers'] if w['arch'] == 'egnn' else w['dyn']['n_convs']
+        if w['arch'] == 'egnn':
+            prof = trainer.profile_read() if egnn_prof else None
+            if egnn_prof:
+                trainer.profile(False)
+            edges_step = prof['fwd'][2] / max(n_steps_total, 1) if prof else 0.0
+            f_edge = edges_step * EDGE_KERNEL_FLOP_PER_EDGE
+            f_proj = 2 * 257 * 257 * ((L - 1) * 8 * (NL + NK) + 6 * NL + 2 * NK)
+            f_node = 2 * (514 * 257 + 257 * 257) * ((L - 1) * (NL + NK) + NL)
+            f_fwd = f_edge + f_proj + f_node
+        else:
+            c = trainer.last_counts() if hasattr(trainer, 'last_counts') else dict(E_ll=0, E_kl=0, E_lk=0, E_kk=0)
+            S = w['dyn']['n_hidden_scalars']
+            e_all, e_last = c['E_ll'] + c['E_kl'] + c['E_lk'] + c['E_kk'], c['E_ll'] + c['E_kl']
+            edges_step = (L - 1) * e_all + e_last
+            f_edge = edges_step * gvp_chain_flop_per_edge(S)
+            f_proj = 2 * S * S * ((L - 1) * 2 * (NL + NK) + NL + NK)          # h_src block of the first message Linear, per source node and edge type
+            f_node = 301.2e3 * ((L - 1) * (NL + NK) + NL)                      # two update GVPs per destination node
+            f_fwd = f_edge + f_proj + f_node
+        f_step = 3.0 * f_fwd
+        t_step = med / args.steps
+        ach = f_step / t_step / 1e12
+        rf = {'kernel': 'whole training step (forward + backward + clip + Adam)', 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MATRIX_TFLOPS,
+              'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MATRIX_TFLOPS, 'traffic': None, 'traffic_measured': False,
+              'flop_per_step_executed': f_step, 'flop_forward_executed': f_fwd, 'flop_forward_parts': {'edge': f_edge, 'projections': f_proj, 'node': f_node},
+              'edges_per_step': edges_step, 'avg_launch_ms': 1e3 * t_step, 'launches': n_steps_total, 'kernel_ms_total': 1e3 * sum(regions),
+              'wall_ms_total': 1e3 * sum(regions),
+              'note': 'executed FLOPs = 3 x the forward (first Linears counted per node, as the kernels compute them); optimizer, loss and the '
+                      'encoder of the keypoint models are in the time but not in the FLOPs, so frac is a lower bound'}
+        if w['arch'] == 'egnn' and egnn_prof and prof['fwd'][1] and prof['bwd'][1]:
+            kern = {}
+            for tag, name in (('fwd', 'k_egnn_edge_train'), ('bwd', 'k_egnn_edge_bwd')):
+                ms, n_l, edges = prof[tag]
+                a_k = edges * EDGE_KERNEL_FLOP_PER_EDGE / (ms * 1e-3) / 1e12          # both kernels run the 257 x 257 products of both branches once
+                kern[name] = {'avg_launch_ms': ms / n_l, 'launches': n_l, 'achieved': a_k, 'frac': a_k / PEAK_F32_MATRIX_TFLOPS,
+                              'ms_per_step': ms / n_steps_total}
+            rf['edge_kernels'] = kern
+            assert sum(k['ms_per_step'] for k in kern.values()) <= 1e3 * t_step * 1.001
+        out['roofline'] = rf
         if world == 1 and not args.no_cpu_baseline and w['enc'] == 'fixed':
             out['cpu_baseline'] = train_cpu_baseline(args.workload)
         emit(out)

@@ -98,7 +98,8 @@ kpd_status kpd_build_lig_graph(const kpd_batch *batch, float ll_cutoff, int32_t 
  * ------------------------------------------------------------------------------------- */
 typedef struct kpd_egnn_config {
     int32_t atom_nf, rec_nf;
-    int32_t n_layers, hidden_nf;       /* hidden_nf must be 256 (every shipped config)   */
+    int32_t n_layers, hidden_nf;       /* hidden_nf 1 .. 256 (the kernels are 256 + 1 wide; narrower models run zero padded: the reference's
+                                          default ctor is 255); > 256 is refused (INTEGRATION.md section 1 lists the limits) */
     int32_t use_tanh, norm, update_kp_feat;
     float message_norm;                /* 0 => per-graph average in-degree + 1           */
     int32_t ll_k, kl_k;                /* 0 = radius graph (the cutoffs below), else kNN, <= 16 */
@@ -161,9 +162,11 @@ kpd_status kpd_egnn_last_counts(kpd_egnn *m, int32_t out[8], void *stream);
  *             d_kp_x [n_kp, 3] may be NULL (written, not accumulated, when given).  Consumes the forward.
  * Memory: reserve() tries to keep the edge activations of every layer (13.5 GB at B = 64 x (300-atom pocket, 25-atom ligand)); if that
  * allocation fails it keeps one layer's worth and recomputes layer by layer in backward (same results, bit for bit).
- * Environment switches, read once per process, for A/B measurements only (defaults are the fast paths): KPD_TRAIN_STORE=0 (recompute
- * mode), KPD_TRAIN_FUSED_FWD=0 / KPD_TRAIN_FUSED_BWD=0 (per-branch kernels instead of the per-layer edge kernels),
- * KPD_SGEMM_TN256=0 (tiled weight-gradient form), and for the GVP trainer KPD_TRAIN_WS=0, KPD_TRAIN_VEC_FUSED=0, KPD_TRAIN_WS_EXTRA=0.
+ * Environment: KPD_TRAIN_STORE=0 (read once per process) selects the recompute mode.  The A/B switches of profiles/tools
+ * (KPD_TRAIN_FUSED_*, KPD_SGEMM_*, KPD_TRAIN_WS*, KPD_TRAIN_VEC_FUSED) exist only in the TOOLS build of the library (kpd_build_flags).
+ * profile / profile_read: HIP-event time of the two per-layer edge kernels of a training step on their launch stream, as
+ * kpd_egnn_profile does for the inference kernel: index 0 = forward (k_egnn_edge_train), 1 = backward (k_egnn_edge_bwd); `edges` =
+ * edges those launches processed (for a FLOP count).  No reference counterpart (bench.py's roofline of the training lines).
  * ------------------------------------------------------------------------------------- */
 typedef struct kpd_egnn_trainer kpd_egnn_trainer;
 kpd_status kpd_egnn_trainer_create(const kpd_egnn_config *cfg, kpd_egnn_trainer **out);
@@ -176,6 +179,8 @@ kpd_status kpd_egnn_trainer_forward(kpd_egnn_trainer *t, const kpd_batch *batch,
                                     float *eps_x_dev, void *stream);
 kpd_status kpd_egnn_trainer_backward(kpd_egnn_trainer *t, const float *d_eps_h, const float *d_eps_x, float *d_lig_h,
                                      float *d_lig_x, float *d_kp_h, float *d_kp_x, void *stream);
+kpd_status kpd_egnn_trainer_profile(kpd_egnn_trainer *t, int32_t enable);
+kpd_status kpd_egnn_trainer_profile_read(kpd_egnn_trainer *t, double total_ms[2], int32_t launches[2], double edges[2]);
 
 /* ---------------------------------------------------------------------------------------
  * GVP denoiser.  Replaces LigRecDynamicsGVP.forward (models/dynamics_gvp.py:149-199): encoders
@@ -187,8 +192,8 @@ typedef struct kpd_gvp_config {
     int32_t n_lig_scalars, n_kp_scalars;
     int32_t vector_size;               /* 1 .. 16 (kernels are 16 channels wide; fewer are zero padded)           */
     int32_t n_convs, n_hidden_scalars; /* n_hidden_scalars 1 .. 256 (kernels are 128 / 256 wide, likewise); the   */
-                                       /* training engine kpd_gvp_trainer_* takes any n_hidden_scalars <= 256 and */
-                                       /* vector_size 16 only                                                      */
+                                       /* training engine kpd_gvp_trainer_* takes the same ranges (narrower models */
+                                       /* through zero-padded wide parameter copies)                               */
     int32_t update_kp;
     int32_t message_norm_mode;         /* 0: constant message_norm, 1: 'mean', 2: message_norm == 0
                                           (per-graph average in-degree + 1, gvp.py:504-507)  */
@@ -248,6 +253,9 @@ kpd_status kpd_gvp_trainer_forward(kpd_gvp_trainer *t, const kpd_batch *batch, c
                                    float *eps_x_dev, void *stream);
 /* d_lig_x [n_lig, 3] / d_kp_x [n_kp, 3] (either may be null): gradients with respect to the positions, which enter through the
  * unit edge vector and the rbf code of every edge (models/gvp.py:472-480); the edge lists themselves are not differentiable. */
+/* E_ll, E_kl, E_lk, E_kk of the last forward (host values the forward already read back: no synchronisation).  No reference counterpart
+ * (bench.py's FLOP count of the training lines). */
+kpd_status kpd_gvp_trainer_last_counts(kpd_gvp_trainer *t, int32_t out[4]);
 kpd_status kpd_gvp_trainer_backward(kpd_gvp_trainer *t, const float *d_eps_h, const float *d_eps_x, float *d_lig_h,
                                     float *d_kp_h, float *d_kp_v, float *d_lig_x, float *d_kp_x, void *stream);
 
@@ -260,7 +268,7 @@ kpd_status kpd_gvp_trainer_backward(kpd_gvp_trainer *t, const float *d_eps_h, co
  * ------------------------------------------------------------------------------------- */
 typedef struct kpd_recenc_config {
     int32_t in_scalar_size, out_scalar_size;   /* out_scalar_size in {128, 256}            */
-    int32_t vector_size;                       /* must be 16                               */
+    int32_t vector_size;                       /* 1 .. 16 (16-channel kernels, fewer are zero padded); kp_v of kpd_rec_out is [n_kp][vector_size][3] */
     int32_t n_rr_convs, n_rk_convs, n_message_gvps, n_update_gvps;
     int32_t message_norm_mode;                 /* 0 constant, 1 'mean', 2 message_norm == 0 */
     float message_norm;

@@ -444,6 +444,25 @@ using namespace kpd;
 
 struct kpd_egnn_trainer : TrainCtx {
     kpd_egnn_config cfg{};
+    // HIP-event timing of the two per-layer edge kernels (kpd_egnn_trainer_profile): (start, stop) pairs, which kernel, how many edges
+    std::vector<hipEvent_t> prof_ev;
+    std::vector<int> prof_tag;
+    std::vector<double> prof_edges;
+    bool prof_on = false;
+    size_t prof_used = 0;
+    template <class F>
+    kpd_status timed(int tag, double edges, F &&launch) {
+        const bool on = prof_on && prof_used + 2 <= prof_ev.size();
+        if (on) KPD_HIP(hipEventRecord(prof_ev[prof_used], st));
+        KPD_TRY(launch());
+        if (on) {
+            KPD_HIP(hipEventRecord(prof_ev[prof_used + 1], st));
+            prof_tag[prof_used / 2] = tag;
+            prof_edges[prof_used / 2] = edges;
+            prof_used += 2;
+        }
+        return KPD_OK;
+    }
     Arena ws;
     int n_et = 2, n_upd = 1;
     bool rec_identity = false;
@@ -683,7 +702,11 @@ kpd_status layer_edges_fused(kpd_egnn_trainer *T, int l, bool sum_pieces) {
     }
     if (tiles == 0) return KPD_OK;
     KPD_TRY(launch_edge_train_pack(pk, T->st));
-    KPD_TRY(launch_egnn_edge_train(a, tiles, T->st));
+    {
+        double edges = 0.0;
+        for (int et = 0; et < layer_n_et(T, l); ++et) edges += T->E[et];
+        KPD_TRY(T->timed(0, edges, [&] { return launch_egnn_edge_train(a, tiles, T->st); }));
+    }
     if (sum_pieces)
         for (int et = 0; et < layer_n_et(T, l); ++et) {
             if (T->E[et] == 0) continue;
@@ -855,8 +878,38 @@ extern "C" kpd_status kpd_egnn_trainer_create(const kpd_egnn_config *cfg, kpd_eg
     return KPD_OK;
 }
 
+extern "C" kpd_status kpd_egnn_trainer_profile(kpd_egnn_trainer *T, int32_t enable) {
+    KPD_REQUIRE(T, KPD_ERR_INVALID, "null handle");
+    if (enable && T->prof_ev.empty()) {
+        T->prof_ev.resize(2 * 4096);
+        T->prof_tag.assign(4096, 0);
+        T->prof_edges.assign(4096, 0.0);
+        for (hipEvent_t &e : T->prof_ev) KPD_HIP(hipEventCreate(&e));
+    }
+    T->prof_on = enable != 0;
+    T->prof_used = 0;
+    return KPD_OK;
+}
+
+extern "C" kpd_status kpd_egnn_trainer_profile_read(kpd_egnn_trainer *T, double total_ms[2], int32_t launches[2], double edges[2]) {
+    KPD_REQUIRE(T && total_ms && launches && edges, KPD_ERR_INVALID, "null argument");
+    total_ms[0] = total_ms[1] = edges[0] = edges[1] = 0.0;
+    launches[0] = launches[1] = 0;
+    for (size_t i = 0; i + 1 < T->prof_used; i += 2) {
+        KPD_HIP(hipEventSynchronize(T->prof_ev[i + 1]));
+        float ms = 0.0f;
+        KPD_HIP(hipEventElapsedTime(&ms, T->prof_ev[i], T->prof_ev[i + 1]));
+        const int tag = T->prof_tag[i / 2];
+        total_ms[tag] += ms;
+        edges[tag] += T->prof_edges[i / 2];
+        ++launches[tag];
+    }
+    return KPD_OK;
+}
+
 extern "C" void kpd_egnn_trainer_destroy(kpd_egnn_trainer *T) {
     if (!T) return;
+    for (hipEvent_t &e : T->prof_ev) (void)hipEventDestroy(e);
     T->ws.release();
     T->wide.release();
     T->release_scratch();
@@ -1299,7 +1352,11 @@ kpd_status layer_edges_bwd_fused(kpd_egnn_trainer *T, int l, int cur, int nxt, f
     if (tiles == 0) return KPD_OK;
     KPD_REQUIRE(tiles <= T->bpart_tiles, KPD_ERR_CAPACITY, "per-tile partial sums: %d tiles, room for %d", tiles, T->bpart_tiles);
     KPD_TRY(launch_edge_train_pack(pk, T->st));
-    KPD_TRY(launch_egnn_edge_bwd(a, tiles, T->st));
+    {
+        double edges = 0.0;
+        for (int et = 0; et < layer_n_et(T, l); ++et) edges += T->E[et];
+        KPD_TRY(T->timed(1, edges, [&] { return launch_egnn_edge_bwd(a, tiles, T->st); }));
+    }
     for (int et = 0; et < layer_n_et(T, l); ++et) {
         const int E = T->E[et], s = kS[et], d = kD[et];
         if (E == 0) continue;

@@ -628,6 +628,12 @@ extern "C" kpd_status kpd_gvp_trainer_forward(kpd_gvp_trainer *T, const kpd_batc
     return KPD_OK;
 }
 
+extern "C" kpd_status kpd_gvp_trainer_last_counts(kpd_gvp_trainer *T, int32_t out[4]) {
+    KPD_REQUIRE(T && out, KPD_ERR_INVALID, "null argument");
+    for (int et = 0; et < 4; ++et) out[et] = T->E[et];
+    return KPD_OK;
+}
+
 extern "C" kpd_status kpd_gvp_trainer_backward(kpd_gvp_trainer *T, const float *d_eps_h, const float *d_eps_x, float *d_lig_h,
                                                float *d_kp_h, float *d_kp_v, float *d_lig_x, float *d_kp_x, void *stream) {
     KPD_REQUIRE(T && d_eps_h && d_eps_x, KPD_ERR_INVALID, "null argument");

@@ -279,12 +279,14 @@ static void alloc_conv(kpd_recenc *m, Arena &A, std::vector<HostGvp> &msg, std::
         g.split = j == 0 ? (use_dst ? SPLIT_SRC_DST : SPLIT_SRC) : SPLIT_NONE;
         g.S = S;
         g.chain_pos = j;
+        g.vcut = GV - c.vector_size;             // narrower models: every 16-channel block carries vector_size channels (gvp_host.hip)
         alloc_gvp(A, g, m->expected, pre + "edge_message." + std::to_string(j));
     }
     for (int j = 0; j < c.n_update_gvps; ++j) {
         HostGvp &g = upd[j];
         g.vin = GV; g.vout = GV; g.s_in = S; g.sout = S;
         g.chain_pos = 1;
+        g.vcut = GV - c.vector_size;
         alloc_gvp(A, g, m->expected, pre + "node_update." + std::to_string(j));
     }
     for (int i = 0; i < 4; ++i) ln[i] = A.take<float>(S);
@@ -296,7 +298,7 @@ static void alloc_conv(kpd_recenc *m, Arena &A, std::vector<HostGvp> &msg, std::
 
 extern "C" kpd_status kpd_recenc_create(const kpd_recenc_config *cfg, kpd_recenc **out) {
     KPD_REQUIRE(cfg && out, KPD_ERR_INVALID, "null argument");
-    KPD_REQUIRE(cfg->vector_size == GV, KPD_ERR_INVALID, "vector_size=%d: the HIP path is built for 16", cfg->vector_size);
+    KPD_REQUIRE(cfg->vector_size >= 1 && cfg->vector_size <= GV, KPD_ERR_INVALID, "vector_size=%d outside 1 .. %d", cfg->vector_size, GV);
     KPD_REQUIRE(cfg->out_scalar_size == 128 || cfg->out_scalar_size == 256, KPD_ERR_INVALID, "out_scalar_size=%d: supported 128, 256",
                 cfg->out_scalar_size);
     KPD_REQUIRE(cfg->in_scalar_size >= 1 && cfg->in_scalar_size <= 64, KPD_ERR_INVALID, "in_scalar_size=%d", cfg->in_scalar_size);
@@ -524,6 +526,8 @@ static kpd_status run_conv(kpd_recenc *m, int et, int n_src, int n_dst, int n_ed
     na.ms_main[0] = m->ms_main; na.ms_cont[0] = m->ms_cont; na.mv_main[0] = m->mv_main; na.mv_cont[0] = m->mv_cont;
     na.ln1_w = ln[0]; na.ln1_b = ln[1]; na.ln2_w = ln[2]; na.ln2_b = ln[3];
     na.n_gvps = c.n_update_gvps; na.S = S;
+    na.ln_inv_n = 1.0f / (float)S; na.ln_pad = 0.0f;
+    na.vn_inv_n = 1.0f / (float)c.vector_size; na.vn_pad = (float)(GV - c.vector_size);      // vector half of GVPLayerNorm over the model's channels
     for (int j = 0; j < c.n_update_gvps; ++j) na.g[j] = upd[j].dev();
     np.tiles0 = dnt == 0 ? cdiv(n_dst, TM) : 0;
     KPD_TRY(launch_gvp_node(np, st));
@@ -600,7 +604,9 @@ extern "C" kpd_status kpd_recenc_forward(kpd_recenc *m, const kpd_rec_batch *bt,
                          m->rk_msg[i], m->rk_upd[i], ln, i != 0, c.rk_cutoff, st));
     }
     KPD_HIP(hipMemcpyAsync(out->kp_h, m->s[1], (size_t)n_kp * S * 4, hipMemcpyDeviceToDevice, st));
-    KPD_HIP(hipMemcpyAsync(out->kp_v, m->v[1], (size_t)n_kp * 48 * 4, hipMemcpyDeviceToDevice, st));
+    // kp v_0 [n_kp][vector_size][3]: the leading channels of the 16-channel rows
+    if (c.vector_size == GV) KPD_HIP(hipMemcpyAsync(out->kp_v, m->v[1], (size_t)n_kp * 48 * 4, hipMemcpyDeviceToDevice, st));
+    else KPD_HIP(hipMemcpy2DAsync(out->kp_v, (size_t)c.vector_size * 12, m->v[1], 48 * 4, (size_t)c.vector_size * 12, n_kp, hipMemcpyDeviceToDevice, st));
 
     // keypoint-keypoint radius graph (:285-292); counts = {E_kk, E_rk}
     KPD_TRY(launch_radius_graph(out->kp_x, m->kp_ptr, B, n_kp, K, c.kk_cutoff, 100, out->cap_kk, out->kk_src, out->kk_dst,

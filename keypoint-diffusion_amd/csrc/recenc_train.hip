@@ -135,7 +135,7 @@ struct kpd_recenc_trainer : TrainCtx {
     kpd_recenc_config cfg{};
     Arena ws;
     int S = 128;
-    int V = VC;                         // live vector channels (this engine: always 16)
+    int V = VC;                         // the model's vector_size (<= 16: narrower models run zero-padded, train_ops.h WideSet)
     int cap_B = 0, cap_rec = 0, cap_rr = 0, cap_maxrec = 0, cap_rk = 0, cap_R = 0;
     kpd_rec_batch bt{};
     bool have_forward = false;
@@ -391,7 +391,7 @@ kpd_status colsum_wide(kpd_recenc_trainer *T, int rows, int cols, const float *A
 
 extern "C" kpd_status kpd_recenc_trainer_create(const kpd_recenc_config *cfg, kpd_recenc_trainer **out) {
     KPD_REQUIRE(cfg && out, KPD_ERR_INVALID, "null argument");
-    KPD_REQUIRE(cfg->vector_size == VC, KPD_ERR_INVALID, "vector_size=%d: only 16 is supported", cfg->vector_size);
+    KPD_REQUIRE(cfg->vector_size >= 1 && cfg->vector_size <= VC, KPD_ERR_INVALID, "vector_size=%d outside 1 .. %d", cfg->vector_size, VC);
     KPD_REQUIRE(cfg->out_scalar_size >= 16 && cfg->out_scalar_size <= 256, KPD_ERR_INVALID, "out_scalar_size=%d (16..256)", cfg->out_scalar_size);
     KPD_REQUIRE(cfg->in_scalar_size >= 1 && cfg->in_scalar_size <= 256, KPD_ERR_INVALID, "in_scalar_size=%d", cfg->in_scalar_size);
     KPD_REQUIRE(cfg->n_rr_convs >= 0 && cfg->n_rr_convs <= 16 && cfg->n_rk_convs >= 1 && cfg->n_rk_convs <= 16 && cfg->n_message_gvps >= 1 &&
@@ -405,6 +405,7 @@ extern "C" kpd_status kpd_recenc_trainer_create(const kpd_recenc_config *cfg, kp
     kpd_recenc_trainer *T = new kpd_recenc_trainer();
     T->cfg = *cfg;
     T->S = cfg->out_scalar_size;
+    T->V = cfg->vector_size;
     *out = T;
     return KPD_OK;
 }
@@ -412,6 +413,7 @@ extern "C" kpd_status kpd_recenc_trainer_create(const kpd_recenc_config *cfg, kp
 extern "C" void kpd_recenc_trainer_destroy(kpd_recenc_trainer *T) {
     if (!T) return;
     T->ws.release();
+    T->wide.release();
     T->release_scratch();
     delete T;
 }
@@ -419,6 +421,33 @@ extern "C" void kpd_recenc_trainer_destroy(kpd_recenc_trainer *T) {
 extern "C" kpd_status kpd_recenc_trainer_bind(kpd_recenc_trainer *T, const char *name, const float *weight, float *grad, const int64_t *shape,
                                               int32_t ndim) {
     KPD_REQUIRE(T && name && shape && (ndim == 1 || ndim == 2), KPD_ERR_INVALID, "bad argument");
+    if (T->V != VC && weight) {
+        // vector_size < 16: GVP tensors whose axes count vector channels are trained through their 16-channel zero-padded form (as in
+        // gvp_train.hip).  The first message GVP of a conv reads [x_diff | v_src] (1 + V channels) or, in the rk convs after the first,
+        // [x_diff | v_src | v_dst] (1 + 2 V; models/gvp.py:206-213, 323-337): the destination block keeps its own 16-channel slot.
+        const std::vector<std::string> tk = split_name(name);
+        if (tk.size() >= 5 && (tk[0] == "rr_conv_layers" || tk[0] == "rk_conv_layers") && (tk[2] == "edge_message" || tk[2] == "node_update")) {
+            const int V = T->V;
+            const bool msg0 = tk[2] == "edge_message" && tk[3] == "0";
+            const bool use_dst = msg0 && tk[0] == "rk_conv_layers" && tk[1] != "0";
+            std::vector<AxisSeg> vi = msg0 ? std::vector<AxisSeg>{{V + 1, VC + 1}} : std::vector<AxisSeg>{{V, VC}};
+            if (use_dst) vi.push_back({V, VC});
+            const int h_ref = msg0 ? (use_dst ? 2 * V + 1 : V + 1) : V, h_wide = msg0 ? (use_dst ? VHE : VC + 1) : VC;
+            const std::vector<AxisSeg> h = {{h_ref, h_wide}}, vo = {{V, VC}};
+            const std::string &leaf = tk[4];
+            std::vector<AxisSeg> rows, cols;
+            if (leaf == "Wh") { rows = vi; cols = h; }
+            else if (leaf == "Wu") { rows = h; cols = vo; }
+            else if (leaf == "to_feats_out" && tk.back() == "weight" && ndim == 2 && shape[1] > h_ref) {
+                rows = {{(int)shape[0], (int)shape[0]}};
+                cols = {{(int)shape[1] - h_ref, (int)shape[1] - h_ref}, h[0]};
+            } else if (leaf == "scalar_to_vector_gates") {
+                rows = vo;
+                if (tk.back() == "weight" && ndim == 2) cols = {{(int)shape[1], (int)shape[1]}};
+            }
+            if (!rows.empty()) return bind_wide(T, name, weight, grad, shape, ndim, rows, cols);
+        }
+    }
     Param p;
     p.w = weight;
     p.g = grad;
@@ -511,6 +540,7 @@ extern "C" kpd_status kpd_recenc_trainer_forward(kpd_recenc_trainer *T, const kp
     const kpd_recenc_config &c = T->cfg;
     hipStream_t st = static_cast<hipStream_t>(stream);
     T->st = st;
+    KPD_TRY(wide_run(T, 0));                   // vector_size < 16: stage the current weights in the engine's widths
     T->bt = *bt;
     const int S = T->S, K = c.n_keypoints, B = bt->B, n_rec = bt->n_rec, n_kp = B * K, F = c.in_scalar_size, Rr = c.n_rr_convs, Rk = c.n_rk_convs;
     T->B = B; T->n_rec = n_rec; T->n_kp = n_kp;
@@ -599,6 +629,7 @@ extern "C" kpd_status kpd_recenc_trainer_backward(kpd_recenc_trainer *T, const f
     const kpd_recenc_config &c = T->cfg;
     hipStream_t st = static_cast<hipStream_t>(stream);
     T->st = st;
+    KPD_TRY(wide_run(T, 1));                   // vector_size < 16: zero the wide gradients
     const int S = T->S, K = c.n_keypoints, B = T->B, n_rec = T->n_rec, n_kp = T->n_kp, F = c.in_scalar_size, Rr = c.n_rr_convs, Rk = c.n_rk_convs;
     const kpd_rec_batch &bt = T->bt;
     // incoming gradients (null = zero); keypoint vectors arrive as [n, 16, 3]
@@ -695,6 +726,7 @@ extern "C" kpd_status kpd_recenc_trainer_backward(kpd_recenc_trainer *T, const f
         KPD_TRY(gemm(T, false, false, n_rec, S, S, T->tmp_s, S, W1.w, S, 0.0f, T->sb, S, 1.0f, T->e_pre0));      // * SiLU'(pre0) in the epilogue
         KPD_TRY(grad_gemm(T, S, F, n_rec, T->sb, S, bt.rec_h, F, W0.g, F, b0.g));
     }
+    KPD_TRY(wide_run(T, 2));                   // vector_size < 16: add the wide gradients into the caller's tensors (reference shapes)
     T->have_forward = false;
     return KPD_OK;
 }

@@ -145,6 +145,8 @@ def lib():
     L.kpd_egnn_trainer_reserve.argtypes = [C.c_void_p] + [C.c_int32] * 6
     L.kpd_egnn_trainer_forward.argtypes = [C.c_void_p, C.POINTER(KpdBatch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.kpd_egnn_trainer_backward.argtypes = [C.c_void_p] + [C.c_void_p] * 7
+    L.kpd_egnn_trainer_profile.argtypes = [C.c_void_p, C.c_int32]
+    L.kpd_egnn_trainer_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
     L.kpd_gvp_trainer_create.argtypes = [C.POINTER(KpdGvpConfig), C.POINTER(C.c_void_p)]
     L.kpd_gvp_trainer_destroy.argtypes = [C.c_void_p]
     L.kpd_gvp_trainer_destroy.restype = None
@@ -199,7 +201,7 @@ EXPORTS = [
     'kpd_recegnn_forward',
     'kpd_xyz_scratch_bytes', 'kpd_xyz_emit', 'kpd_rec_graph_scratch_bytes', 'kpd_build_rec_graph',
     'kpd_egnn_trainer_create', 'kpd_egnn_trainer_destroy', 'kpd_egnn_trainer_bind', 'kpd_egnn_trainer_reserve',
-    'kpd_egnn_trainer_forward', 'kpd_egnn_trainer_backward',
+    'kpd_egnn_trainer_forward', 'kpd_egnn_trainer_backward', 'kpd_egnn_trainer_profile', 'kpd_egnn_trainer_profile_read', 'kpd_gvp_trainer_last_counts',
     'kpd_gvp_trainer_create', 'kpd_gvp_trainer_destroy', 'kpd_gvp_trainer_bind', 'kpd_gvp_trainer_reserve',
     'kpd_gvp_trainer_forward', 'kpd_gvp_trainer_backward', 'kpd_gvp_trainer_set_dropout', 'kpd_dropout_mask',
     'kpd_recenc_trainer_create', 'kpd_recenc_trainer_destroy', 'kpd_recenc_trainer_bind', 'kpd_recenc_trainer_set_dropout',
@@ -421,6 +423,15 @@ class EgnnTrainer:
         check(lib().kpd_egnn_trainer_backward(self._h, d_eps_h.data_ptr(), d_eps_x.data_ptr(), _ptr(d_lig_h), _ptr(d_lig_x),
                                               _ptr(d_kp_h), _ptr(d_kp_x), _stream()))
 
+    def profile(self, enable: bool):
+        check(lib().kpd_egnn_trainer_profile(self._h, int(enable)))
+
+    def profile_read(self):
+        """{'fwd' | 'bwd': (total ms, launches, edges)} of k_egnn_edge_train / k_egnn_edge_bwd since profile(True)."""
+        ms, n, e = (C.c_double * 2)(), (C.c_int32 * 2)(), (C.c_double * 2)()
+        check(lib().kpd_egnn_trainer_profile_read(self._h, ms, n, e))
+        return {'fwd': (ms[0], n[0], e[0]), 'bwd': (ms[1], n[1], e[1])}
+
 
 class GvpEngine:
     """Owns one kpd_gvp handle: packed weights + workspace for LigRecDynamicsGVP.forward."""
@@ -558,6 +569,11 @@ class GvpTrainer:
         check(lib().kpd_gvp_trainer_backward(self._h, d_eps_h.data_ptr(), d_eps_x.data_ptr(), _ptr(d_lig_h), _ptr(d_kp_h), _ptr(d_kp_v),
                                              _ptr(d_lig_x), _ptr(d_kp_x), _stream()))
 
+    def last_counts(self):
+        arr = (C.c_int32 * 4)()
+        check(lib().kpd_gvp_trainer_last_counts(self._h, arr))
+        return dict(E_ll=arr[0], E_kl=arr[1], E_lk=arr[2], E_kk=arr[3])
+
 
 def dropout_mask(seed: int, conv: int, node_type: int, position: int, kind: int, n: int, rate: float, device='cuda') -> torch.Tensor:
     """One dropout stream of the GVP training path (kpd_dropout_mask): n entries in {0, 1 / (1 - rate)}."""
@@ -641,7 +657,7 @@ def _recenc_call(eng, reserve_fn, forward_fn, rec_counts, rec_x, rec_h, rr_src, 
     cap_kk = max(n_kp * min(eng.K - 1, 100), 1)
     f32 = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
     i32 = lambda n: torch.zeros(n, device=dev, dtype=torch.int32)
-    out = dict(kp_x=f32(n_kp, 3), kp_h=f32(n_kp, eng.S), kp_v=f32(n_kp, 16, 3), rk_src=i32(n_kp * eng.k),
+    out = dict(kp_x=f32(n_kp, 3), kp_h=f32(n_kp, eng.S), kp_v=f32(n_kp, int(eng.cfg.vector_size), 3), rk_src=i32(n_kp * eng.k),
                rk_dst=i32(n_kp * eng.k), kk_src=i32(cap_kk), kk_dst=i32(cap_kk), kk_per_graph=i32(B), counts=i32(2))
     bt = KpdRecBatch(B, n_rec, max_rec, _ptr(rec_ptr), _ptr(rec_x), _ptr(rec_h), int(s.numel()), _ptr(s), _ptr(d),
                      _ptr(rowptr))

@@ -27,7 +27,12 @@ def _edge_set(s, d):
 
 @pytest.mark.parametrize('cfg,n_rec', [(RECENC_CFGS['recenc_mean'], [33, 21]), (RECENC_CFGS['recenc_norm10'], [33, 21]),
                                        (RECENC_NORM0, [50, 3, 27]), (RECENC_40KP, [300, 150]), (RECENC_RAD, [120, 45]),
-                                       (RECENC_RAD_SPARSE, [60, 8])])
+                                       (RECENC_RAD_SPARSE, [60, 8]),
+                                       # vector_size < 16 (the reference accepts any, receptor_encoder_gvp.py:99-114): the 16-channel kernels run
+                                       # the model zero-padded; the rk convs after the first read [x_diff | v_src | v_dst] = 1 + 2 V channels
+                                       (dict(RECENC_CFGS['recenc_norm10'], vector_size=8), [33, 21]),
+                                       (dict(RECENC_CFGS['recenc_mean'], vector_size=5), [40, 3, 27]),
+                                       (dict(RECENC_40KP, vector_size=1), [120, 45])])
 def test_receptor_encoder(cuda, cfg, n_rec):
     kw = dict(cfg, graph_cutoffs=CUT)
     model = synth.fill_state_dict_(ReceptorEncoderGVP(**kw), 61).eval()

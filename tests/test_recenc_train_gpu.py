@@ -18,20 +18,23 @@ CUT = util.CUTOFFS_ALL_ATOM
 TOL = 2e-4          # relative to the largest entry of each gradient tensor
 
 
-def _weights(n_kp, S, seed):
+def _weights(n_kp, S, seed, V=16):
     gen = torch.Generator().manual_seed(seed)
-    return (torch.randn(n_kp, 3, generator=gen), torch.randn(n_kp, S, generator=gen) / S ** 0.5, torch.randn(n_kp, 16, 3, generator=gen) / 4)
+    return (torch.randn(n_kp, 3, generator=gen), torch.randn(n_kp, S, generator=gen) / S ** 0.5, torch.randn(n_kp, V, 3, generator=gen) / 4)
 
 
 @pytest.mark.parametrize('cfg,n_rec', [(RECENC_CFGS['recenc_mean'], [33, 21]), (RECENC_CFGS['recenc_norm10'], [33, 21]),
-                                       (RECENC_NORM0, [50, 3, 27]), (RECENC_40KP, [150, 90]), (RECENC_RAD, [120, 45])])
+                                       (RECENC_NORM0, [50, 3, 27]), (RECENC_40KP, [150, 90]), (RECENC_RAD, [120, 45]),
+                                       # vector_size < 16 (round 4: trained through zero-padded wide copies, csrc/train_ops.h WideSet)
+                                       (dict(RECENC_CFGS['recenc_norm10'], vector_size=8), [33, 21]),
+                                       (dict(RECENC_CFGS['recenc_mean'], vector_size=5), [33, 21])])
 def test_encoder_gradients_match_oracle_autograd(cuda, cfg, n_rec):
     cfg = dict(cfg, dropout=0.0)
     kw = dict(cfg, graph_cutoffs=CUT)
     model = synth.fill_state_dict_(ReceptorEncoderGVP(**kw), 61).eval()
     g = util.make_batch(n_rec, [4] * len(n_rec), seed=17, n_keypoints=cfg['n_keypoints'])
     n_kp, S = len(n_rec) * cfg['n_keypoints'], cfg['out_scalar_size']
-    w_x, w_h, w_v = _weights(n_kp, S, 5)
+    w_x, w_h, w_v = _weights(n_kp, S, 5, cfg.get('vector_size', 16))
     # oracle, differentiated by torch autograd
     sd = {k: v.detach().clone().requires_grad_(v.numel() > 0) for k, v in model.state_dict().items()}
     ref = orec.rec_encoder_gvp_forward(sd, kw, util.to_obatch(g))
