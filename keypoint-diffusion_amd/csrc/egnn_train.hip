@@ -10,11 +10,11 @@
 // V = h_dst W1[:, 257:514]^T, hence dW1 and dh need only the per-node sums of dpre1 (segmented by dst, scattered by src) and node-sized
 // GEMMs -- batched over all edge MLPs of a layer per node type (layer_stage / layer_project / layer_cat_bwd).  The per-edge work of a
 // layer is two kernels (egnn_kernels.hip): k_egnn_edge_train (forward: gather, SiLU, 257 x 257 product, SiLU, heads, segment pieces,
-// keeping pre1 / a1 / pre2 / a2) and k_egnn_edge_bwd (head backward, dpre2 W2, SiLU backward, d dij, by-destination sums, in place over
-// the kept arrays); dW2 = dpre2^T a1 and the by-source sums need whole matrices and stay separate (sgemm.hip, k_segsum264).  The
-// per-branch kernels those two replaced (k_edge_pre1 + ws_gemm + head / segmented-sum kernels) remain behind KPD_TRAIN_FUSED_FWD=0 /
-// KPD_TRAIN_FUSED_BWD=0 for A/B runs and as the path of an engine that could not allocate one layer of edge slots.  Memory: the edge
-// activations of all layers when they fit (13.5 GB at C2, B = 64: pre1, a1, pre2 per branch), else one layer's slots and a recomputation per layer in backward.
+// keeping pre1 / a1 / pre2) and k_egnn_edge_bwd (head backward, dpre2 W2, SiLU backward, d dij, by-destination sums, in place over
+// the kept arrays); dW2 = dpre2^T a1 and the by-source sums need whole matrices and stay separate (sgemm.hip, k_segsum264).  (The
+// per-branch kernels those two replaced in round 4 -- k_edge_pre1 + ws_gemm + head / segmented-sum kernels -- were removed in round 5.)
+// Memory: the edge activations of all layers when they fit (13.5 GB at C2, B = 64: pre1, a1, pre2 per branch), else one layer's slots
+// (3 GB) and a recomputation per layer in backward; less than that is an out-of-memory error of kpd_egnn_trainer_reserve.
 #include "egnn_kernels.h"
 #include "engine.h"
 #include "train_ops.h"
@@ -26,52 +26,6 @@ constexpr int H = HW;         // 257
 constexpr int LD = HS;        // 264: row stride of every activation matrix
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-
-// ---- forward kernels ---------------------------------------------------------------------------------------------------
-// x_diff = x_src - x_dst (dynamics.py:160), dij = |x_diff| (:211), n = x_diff / (dij + 1) (:169)
-__global__ void k_geom(const int *__restrict__ src, const int *__restrict__ dst, const float *__restrict__ xs,
-                       const float *__restrict__ xd, int E, float *__restrict__ xdiff, float *__restrict__ dij,
-                       float *__restrict__ nvec) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= E) return;
-    const int u = src[e], v = dst[e];
-    const float dx = xs[3 * u] - xd[3 * v], dy = xs[3 * u + 1] - xd[3 * v + 1], dz = xs[3 * u + 2] - xd[3 * v + 2];
-    const float d = sqrtf(dx * dx + dy * dy + dz * dz), inv = 1.0f / (d + 1.0f);
-    xdiff[3 * e] = dx; xdiff[3 * e + 1] = dy; xdiff[3 * e + 2] = dz;
-    dij[e] = d;
-    nvec[3 * e] = dx * inv; nvec[3 * e + 1] = dy * inv; nvec[3 * e + 2] = dz * inv;
-}
-
-// pre1[e] = U[src] + V[dst] + dij w_r + b1, a1 = SiLU(pre1): the first Linear of edge_mlp / coord_mlp on
-// f = [h_src, h_dst, dij] (dynamics.py:103-105) through its per-node halves.  w_r = W1[:, 514] (stride ldw).
-// One thread per (edge, 4-column chunk): the two node rows (U, V: row stride ldu -- slots of the layer's projection block), the radial weight column (staged contiguously in LDS with the bias) and both
-// outputs move as 16-byte pieces; columns 257 .. 263 of the outputs are written as zeros (the GEMMs read whole k-groups).
-__global__ __launch_bounds__(256) void k_edge_pre1(const float *__restrict__ U, const float *__restrict__ V, const int *__restrict__ src,
-                                                   const int *__restrict__ dst, const float *__restrict__ dij, const float *__restrict__ wr, int ldw,
-                                                   const float *__restrict__ b1, long long total, int ldu, float *__restrict__ pre1,
-                                                   float *__restrict__ a1) {
-    __shared__ __attribute__((aligned(16))) float s_w[LD], s_b[LD];
-    for (int c = threadIdx.x; c < LD; c += 256) {
-        s_w[c] = c < H ? wr[(size_t)c * ldw] : 0.0f;
-        s_b[c] = (b1 && c < H) ? b1[c] : 0.0f;
-    }
-    __syncthreads();
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // total = E * (LD / 4)
-    if (i >= total) return;
-    const int e = (int)(i / (LD / 4)), c = 4 * (int)(i - (long long)e * (LD / 4));
-    const float d = dij[e];
-    const float4 u = *reinterpret_cast<const float4 *>(U + (size_t)src[e] * ldu + c), v = *reinterpret_cast<const float4 *>(V + (size_t)dst[e] * ldu + c);
-    const float4 w = *reinterpret_cast<const float4 *>(s_w + c), b = *reinterpret_cast<const float4 *>(s_b + c);
-    float4 p, a;
-    p.x = u.x + v.x + d * w.x + b.x;
-    p.y = c + 1 < H ? u.y + v.y + d * w.y + b.y : 0.0f;
-    p.z = c + 2 < H ? u.z + v.z + d * w.z + b.z : 0.0f;
-    p.w = c + 3 < H ? u.w + v.w + d * w.w + b.w : 0.0f;
-    if (c >= H) p.x = 0.0f;
-    a.x = silu_f(p.x); a.y = silu_f(p.y); a.z = silu_f(p.z); a.w = silu_f(p.w);
-    *reinterpret_cast<float4 *>(pre1 + (size_t)e * LD + c) = p;
-    *reinterpret_cast<float4 *>(a1 + (size_t)e * LD + c) = a;
-}
 
 
 
@@ -139,43 +93,6 @@ __global__ __launch_bounds__(256) void k_segsum264(const float *__restrict__ M, 
         *reinterpret_cast<f32x4 *>(out2 + (size_t)v * ldo + 4 * lane) = s2;
         if (lane == 0) out2[(size_t)v * ldo + 256] = t2;
     }
-}
-
-// soft attention from the head shares of the ws_gemm epilogue: att[e] = sigmoid(part[e] + part[n + e] + bias)
-__global__ void k_head_att(const float *__restrict__ part, int n, const float *__restrict__ bias, float *__restrict__ att) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    att[e] = sigm(part[e] + part[(size_t)n + e] + (bias ? bias[0] : 0.0f));
-}
-
-// coordinate head from the two half-row shares of a2 . w3 (ws_gemm epilogue): sc, msg_x = tanh(sc) * range * n  or  sc * n (dynamics.py:113-120)
-__global__ void k_coord_msg_parts(const float *__restrict__ part, const float *__restrict__ nvec, int n, int use_tanh, float range,
-                                  float *__restrict__ sc, float *__restrict__ msgx) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    const float s = part[e] + part[(size_t)n + e];
-    const float coef = use_tanh ? tanhf(s) * range : s;
-    sc[e] = s;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) msgx[3 * e + k] = coef * nvec[3 * e + k];
-}
-
-// out[e] (+)= part[e] + part[n + e]: the two half-row shares of a row-dot taken in the ws_gemm epilogue
-__global__ void k_add_halves(const float *__restrict__ part, int n, int accumulate, float *__restrict__ out) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    const float s = part[e] + part[(size_t)n + e];
-    out[e] = accumulate ? out[e] + s : s;
-}
-
-__global__ void k_segsum3(const float *__restrict__ M, const int *__restrict__ rowptr, const float *__restrict__ zinv, int n,
-                          float *__restrict__ acc) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 3 * n) return;
-    const int v = i / 3, c = i - 3 * v;
-    float s = 0.0f;
-    for (int e = rowptr[v]; e < rowptr[v + 1]; ++e) s += M[3 * e + c];
-    acc[i] += s * zinv[v];
 }
 
 // h' = LayerNorm(h + q2 + b2) (or without the norm), one wave per node (dynamics.py:202-205)
@@ -269,116 +186,6 @@ __global__ void k_ln_bwd(const float *__restrict__ h, const float *__restrict__ 
         const int c = lane + 64 * k;
         if (c < H) du[(size_t)r * LD + c] = (c < hid || c == H - 1) ? rstd * (g[k] - sg - xh[k] * sgx) : 0.0f;
     }
-}
-
-// Head backward kernels.  A workgroup owns HEAD_ROWS consecutive edges, its four waves take them round robin (one wave per edge at
-// a time) and keep two running column sums per lane: sum_e dpre2[e][c] (the gradient of b2) and sum_e a2[e][c] ds[e] (the gradient of
-// the head weight).  They leave through the same partial buffer and block-ordered reduction as k_colsum (train_ops.h), so the two
-// extra passes over E x 257 matrices that computed them separately are gone and the result stays bitwise reproducible.
-// (a lane owns columns 4 lane .. 4 lane + 3 -- 16-byte loads and stores -- and lane 0 column 256)
-__device__ __forceinline__ void head_partials_out(const f32x4 &cs, float cs_t, const f32x4 &ws, float ws_t, float *__restrict__ part, int lane, int wave) {
-    __shared__ float s_c[4][320], s_w[4][320];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        s_c[wave][4 * lane + r] = cs[r];
-        s_w[wave][4 * lane + r] = ws[r];
-    }
-    if (lane == 0) {
-        s_c[wave][256] = cs_t;
-        s_w[wave][256] = ws_t;
-    }
-    __syncthreads();
-    float *p = part + (size_t)blockIdx.x * 2 * COLSUM_LD;
-    for (int c = threadIdx.x; c < H; c += blockDim.x) {
-        p[c] = (s_w[0][c] + s_w[1][c]) + (s_w[2][c] + s_w[3][c]);                    // slot 0 -> y  (head weight)
-        p[COLSUM_LD + c] = (s_c[0][c] + s_c[1][c]) + (s_c[2][c] + s_c[3][c]);        // slot 1 -> y2 (b2)
-    }
-}
-
-// feature head backward: msg_h = a2 * att, att = sigmoid(a2 . wa + ba), summed into h_neigh[dst] / z.
-//   dmsg = dhn[dst] * zinv[dst]; ds = (dmsg . a2) att (1 - att); da2 = dmsg att + ds wa; dpre2 = da2 SiLU'(pre2)
-__global__ __launch_bounds__(256) void k_feat_head_bwd(const float *__restrict__ dhn, const float *__restrict__ zinv, const int *__restrict__ dst,
-                                                       const float *__restrict__ a2, const float *__restrict__ att, const float *__restrict__ wa,
-                                                       const float *__restrict__ pre2, int E, float *__restrict__ dpre2,
-                                                       float *__restrict__ ds_att, float *__restrict__ part) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int e0 = blockIdx.x * HEAD_ROWS, e1 = min(E, e0 + HEAD_ROWS);
-    f32x4 cs = {0.f, 0.f, 0.f, 0.f}, ws = {0.f, 0.f, 0.f, 0.f};
-    float cs_t = 0.0f, ws_t = 0.0f;
-    const f32x4 wv = *reinterpret_cast<const f32x4 *>(wa + 4 * lane);
-    const float wv_t = wa[256];
-    for (int e = e0 + wave; e < e1; e += 4) {
-        const int v = dst[e];
-        const float zi = zinv[v], a = att[e];
-        const f32x4 dm = *reinterpret_cast<const f32x4 *>(dhn + (size_t)v * LD + 4 * lane) * zi;
-        const f32x4 av = *reinterpret_cast<const f32x4 *>(a2 + (size_t)e * LD + 4 * lane);
-        const f32x4 pv = *reinterpret_cast<const f32x4 *>(pre2 + (size_t)e * LD + 4 * lane);
-        const float dm_t = lane == 0 ? dhn[(size_t)v * LD + 256] * zi : 0.0f, av_t = lane == 0 ? a2[(size_t)e * LD + 256] : 0.0f;
-        float s = fmaf(dm_t, av_t, 0.0f);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s = fmaf(dm[r], av[r], s);
-        const float ds = wave_sum(s) * a * (1.0f - a);
-        f32x4 g;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            g[r] = (dm[r] * a + ds * wv[r]) * silu_grad(pv[r]);
-            cs[r] += g[r];
-            ws[r] = fmaf(av[r], ds, ws[r]);
-        }
-        *reinterpret_cast<f32x4 *>(dpre2 + (size_t)e * LD + 4 * lane) = g;
-        if (lane == 0) {
-            const float gt = (dm_t * a + ds * wv_t) * silu_grad(pre2[(size_t)e * LD + 256]);
-            dpre2[(size_t)e * LD + 256] = gt;
-            cs_t += gt;
-            ws_t = fmaf(av_t, ds, ws_t);
-            ds_att[e] = ds;
-        }
-    }
-    head_partials_out(cs, cs_t, ws, ws_t, part, lane, wave);
-}
-
-// coordinate head backward: msg_x = coef n, coef = tanh(sc) range (or sc), summed into x_neigh[dst] / z
-__global__ __launch_bounds__(256) void k_coord_head_bwd(const float *__restrict__ dxo, const float *__restrict__ zinv, const int *__restrict__ dst,
-                                                        const float *__restrict__ nvec, const float *__restrict__ sc, const float *__restrict__ w3,
-                                                        const float *__restrict__ a2, const float *__restrict__ pre2, int E, int use_tanh,
-                                                        float range, float *__restrict__ dpre2, float *__restrict__ dsc,
-                                                        float *__restrict__ dn, float *__restrict__ part) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int e0 = blockIdx.x * HEAD_ROWS, e1 = min(E, e0 + HEAD_ROWS);
-    f32x4 cs = {0.f, 0.f, 0.f, 0.f}, ws = {0.f, 0.f, 0.f, 0.f};
-    float cs_t = 0.0f, ws_t = 0.0f;
-    const f32x4 wv = *reinterpret_cast<const f32x4 *>(w3 + 4 * lane);
-    const float wv_t = w3[256];
-    for (int e = e0 + wave; e < e1; e += 4) {
-        const int v = dst[e];
-        const float zi = zinv[v];
-        const float gx = dxo[3 * v] * zi, gy = dxo[3 * v + 1] * zi, gz = dxo[3 * v + 2] * zi;
-        const float th = use_tanh ? tanhf(sc[e]) : 0.0f;
-        const float coef = use_tanh ? th * range : sc[e];
-        const float dcoef = gx * nvec[3 * e] + gy * nvec[3 * e + 1] + gz * nvec[3 * e + 2];
-        // 1 - tanh^2 = sech^2 = 4 e / (1 + e)^2, e = exp(-2 |sc|): exact near saturation, where 1 - th * th cancels to nothing
-        const float ex_ = expf(-2.0f * fabsf(sc[e])), sech2 = 4.0f * ex_ / ((1.0f + ex_) * (1.0f + ex_));
-        const float ds = use_tanh ? dcoef * range * sech2 : dcoef;
-        const f32x4 av = *reinterpret_cast<const f32x4 *>(a2 + (size_t)e * LD + 4 * lane);
-        const f32x4 pv = *reinterpret_cast<const f32x4 *>(pre2 + (size_t)e * LD + 4 * lane);
-        f32x4 g;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            g[r] = ds * wv[r] * silu_grad(pv[r]);
-            cs[r] += g[r];
-            ws[r] = fmaf(av[r], ds, ws[r]);
-        }
-        *reinterpret_cast<f32x4 *>(dpre2 + (size_t)e * LD + 4 * lane) = g;
-        if (lane == 0) {
-            const float gt = ds * wv_t * silu_grad(pre2[(size_t)e * LD + 256]);
-            dpre2[(size_t)e * LD + 256] = gt;
-            cs_t += gt;
-            ws_t = fmaf(a2[(size_t)e * LD + 256], ds, ws_t);
-            dsc[e] = ds;
-            dn[3 * e] += coef * gx; dn[3 * e + 1] += coef * gy; dn[3 * e + 2] += coef * gz;
-        }
-    }
-    head_partials_out(cs, cs_t, ws, ws_t, part, lane, wave);
 }
 
 // geometry backward: n = x_diff / (dij + 1), dij = |x_diff|; per-edge gradient of x_src (= minus that of x_dst)
@@ -484,13 +291,8 @@ struct kpd_egnn_trainer : TrainCtx {
     // saved node states: index l = input of layer l (l = n_layers: output of the stack)
     std::vector<float *> hs[2], xs[2], hns[2], xns[2];
     // scratch
-    float *eb[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // [cap_E, LD] each
     float *nb[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // [cap_N, LD] each
-    float *wsg_pack = nullptr;                                                   // packed weights of the current ws_gemm call
     float *dact = nullptr;                                                       // [cap_N, ENC_LD]
-    float *ddpart = nullptr;                   // [2][cap_E] half-row shares of d dij (ws_gemm row-dot)
-    float *xdiff = nullptr, *dij = nullptr, *nvec = nullptr, *att = nullptr, *sc = nullptr, *dsv = nullptr, *ddij = nullptr,
-          *dn = nullptr, *msgx = nullptr;
     // Kept forward activations (KPD_TRAIN_STORE, default on): pre1 / a1 / pre2 / a2 of both MLP branches of every (layer, edge
     // type), the attention weights, the geometry and the coordinate head, so that the backward pass reads them instead of running
     // the gather, the per-node projections and the 257 x 257 GEMM of every branch a second time (~12 % of a training step).  13.5 GB at
@@ -509,14 +311,12 @@ struct kpd_egnn_trainer : TrainCtx {
     // forward edge kernel (k_egnn_edge_train): per-step weight pack of the current layer, segment pieces, whether slots of a whole layer exist
     float *epack = nullptr, *hn_main[4] = {nullptr, nullptr, nullptr, nullptr}, *hn_cont[4] = {nullptr, nullptr, nullptr, nullptr},
           *xn_main[4] = {nullptr, nullptr, nullptr, nullptr}, *xn_cont[4] = {nullptr, nullptr, nullptr, nullptr};
-    bool layer_slots = false, fused = false, fused_b = false;
     // backward edge kernel: pieces of the by-destination sums of dpre1 and dij * dpre1 per (edge type, branch); per-tile column-sum partials
     float *dv_main[4][2] = {}, *dv_cont[4][2] = {}, *dvw_main[4][2] = {}, *dvw_cont[4][2] = {}, *bpart[2] = {nullptr, nullptr};
     int bpart_tiles = 0;
     int cat_slots[2] = {0, 0}, cat_dvw[2] = {0, 0};
     int cat_of[4][2][2] = {}, cat_dvw_of[4][2] = {};   // [et][branch][src | dst] -> slot on that side's node type; [et][branch] -> dvw index
     std::vector<float *> nq[2][3];                 // kept node-MLP activations q1, c1, q2 of every (node type, layer), with the edge activations
-    Slot scratch;                                  // the recomputation buffers (one edge type, one branch at a time)
     float *dh[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}, *dx[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     float *enc1[2] = {nullptr, nullptr}, *enc2[2] = {nullptr, nullptr}, *dec1 = nullptr, *dec2 = nullptr;   // encoder / decoder scratch
 };
@@ -527,18 +327,6 @@ const char *kEt[4] = {"ll", "kl", "lk", "kk"};
 const char *kNt[2] = {"lig", "kp"};
 const int kS[4] = {NT_LIG, NT_KP, NT_LIG, NT_KP};     // source node type of ll, kl, lk, kk
 const int kD[4] = {NT_LIG, NT_LIG, NT_KP, NT_KP};
-
-// the forward edge pass as ONE kernel per layer (k_egnn_edge_train); KPD_TRAIN_FUSED_FWD=0: first-layer kernel + weight-stationary GEMM + heads
-bool want_fused_fwd() {
-    static const bool on = tool_env_int("KPD_TRAIN_FUSED_FWD", 1) != 0;
-    return on;
-}
-
-// the backward edge pass of a layer as one kernel (k_egnn_edge_bwd) + the products that need whole matrices; KPD_TRAIN_FUSED_BWD=0: per-branch kernels
-bool want_fused_bwd() {
-    static const bool on = tool_env_int("KPD_TRAIN_FUSED_BWD", 1) != 0;
-    return on;
-}
 
 
 struct BranchParams {
@@ -561,40 +349,11 @@ kpd_status branch_params(kpd_egnn_trainer *T, int layer, int et, int branch, Bra
     return KPD_OK;
 }
 
-// eb[0] = pre1, eb[1] = a1, eb[2] = pre2 (+ bias), eb[3] = a2 for the E edges of `et`; U, V: the branch's slots of the layer's projection
-// blocks (layer_project)
-// head_part (weight-stationary path only): the two half-row shares of a2 . head.w, [2][E], from the GEMM's epilogue
-kpd_status edge_branch_fwd(kpd_egnn_trainer *T, const BranchParams &p, int et, int branch, float *head_part = nullptr) {
-    const int E = T->E[et];
-    const float *U = T->ucat[kS[et]] + (size_t)T->cat_of[et][branch][0] * LD, *V = T->ucat[kD[et]] + (size_t)T->cat_of[et][branch][1] * LD;
-    const long long tot = (long long)E * H;
-    hipLaunchKernelGGL(k_edge_pre1, grid1((long long)E * (LD / 4)), dim3(256), 0, T->st, U, V, T->e_src[et], T->e_dst[et], T->dij,
-                       p.W1.w + 2 * H, 2 * H + 1, (const float *)nullptr, (long long)E * (LD / 4), CAT_LD, T->eb[0], T->eb[1]);
-    KPD_LAUNCH_CHECK();
-    // pre2 = a1 W2^T + b2, a2 = SiLU(pre2): the weight-stationary GEMM with the activation (and the head's row-dot) fused
-    return ws_gemm(WS_BIAS_SILU, T->eb[1], E, LD, p.W2.w, H, false, p.b2.w, nullptr, T->eb[2], T->eb[3], LD, T->wsg_pack, T->st, true, false,
-                   head_part ? p.head.w : nullptr, 1, head_part);
-}
-
-kpd_status geom_fwd(kpd_egnn_trainer *T, int et, const float *xs, const float *xd) {
-    hipLaunchKernelGGL(k_geom, grid1(T->E[et]), dim3(256), 0, T->st, T->e_src[et], T->e_dst[et], xs, xd, T->E[et], T->xdiff, T->dij,
-                       T->nvec);
-    KPD_LAUNCH_CHECK();
-    return KPD_OK;
-}
-
 // LigRecEGNN.forward returns (h_lig, x_lig) only (dynamics.py:288-294): the final layer's lk / kk messages and its keypoint
 // update feed nothing and their gradients are exactly zero, so that layer runs (forward and backward) on ll + kl and the
 // ligand update alone -- the same pruning as the inference engine (egnn.hip).
 inline int layer_n_et(const kpd_egnn_trainer *T, int l) { return l == T->cfg.n_layers - 1 ? 2 : T->n_et; }
 inline int layer_n_upd(const kpd_egnn_trainer *T, int l) { return l == T->cfg.n_layers - 1 ? 1 : T->n_upd; }
-
-// point the per-edge buffers at the kept activations of (layer, edge type, branch), or at the scratch set when nothing is kept
-void bind_slot(kpd_egnn_trainer *T, int l, int et, int branch) {
-    const kpd_egnn_trainer::Slot &sl = T->layer_slots ? T->slots[(size_t)l * 4 + et] : T->scratch;
-    for (int k = 0; k < 4; ++k) T->eb[k] = sl.e[branch][k];
-    T->att = sl.att; T->dij = sl.dij; T->xdiff = sl.xdiff; T->nvec = sl.nvec; T->sc = sl.sc; T->msgx = sl.msgx;
-}
 
 // slots of layer l (edge types without edges get none), the staged weight blocks, and -- forward -- the projections of both node types
 kpd_status layer_stage(kpd_egnn_trainer *T, int l) {
@@ -675,7 +434,7 @@ kpd_status layer_edges_fused(kpd_egnn_trainer *T, int l, bool sum_pieces) {
     EdgeTrainArgs a{};
     a.meta = T->meta + (l == c.n_layers - 1 ? 16 : 0);
     a.use_tanh = c.use_tanh; a.coords_range = c.coords_range;
-    a.keep_a2 = T->fused_b ? 0 : 1;           // (the per-branch backward kernels read a2; the backward edge kernel recomputes it)
+    a.keep_a2 = 0;                            // (the backward edge kernel recomputes a2 = SiLU(pre2) from the pre2 rows it streams)
     int tiles = 0;
     for (int nt = 0; nt < 2; ++nt) { a.x[nt] = T->xs[nt][l]; a.P[nt] = T->ucat[nt]; }
     for (int et = 0; et < 4; ++et) {
@@ -719,37 +478,13 @@ kpd_status layer_edges_fused(kpd_egnn_trainer *T, int l, bool sum_pieces) {
 
 // one LigRecConv layer forward (dynamics.py:124-207) from the saved inputs hs[l], xs[l] into hs[l+1], xs[l+1], hns[l], xns[l]
 kpd_status layer_fwd(kpd_egnn_trainer *T, int l) {
-    const kpd_egnn_config &c = T->cfg;
     for (int k = 0; k < layer_n_upd(T, l); ++k) {
         KPD_HIP(hipMemsetAsync(T->hns[k][l], 0, (size_t)T->n[k] * LD * 4, T->st));
         KPD_HIP(hipMemsetAsync(T->xns[k][l], 0, (size_t)T->n[k] * 12, T->st));
     }
     KPD_TRY(layer_stage(T, l));
     KPD_TRY(layer_project(T, l));
-    if (T->fused) return layer_edges_fused(T, l, true);
-    for (int et = 0; et < layer_n_et(T, l); ++et) {
-        const int E = T->E[et], s = kS[et], d = kD[et];
-        if (E == 0) continue;
-        bind_slot(T, l, et, 0);
-        KPD_TRY(geom_fwd(T, et, T->xs[s][l], T->xs[d][l]));
-        BranchParams p;
-        KPD_TRY(branch_params(T, l, et, 0, &p));
-        KPD_TRY(edge_branch_fwd(T, p, et, 0, T->ddpart));
-        hipLaunchKernelGGL(k_head_att, grid1(E), dim3(256), 0, T->st, T->ddpart, E, p.head_b.w, T->att);
-        KPD_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_segsum264, dim3(cdiv(T->n[d], 4)), dim3(256), 0, T->st, T->eb[3], T->att, (const float *)nullptr, (const int *)nullptr,
-                           T->e_rowptr[et], T->zinv[d], 1, T->n[d], T->hns[d][l], (float *)nullptr, LD);
-        KPD_LAUNCH_CHECK();
-        bind_slot(T, l, et, 1);
-        KPD_TRY(branch_params(T, l, et, 1, &p));
-        KPD_TRY(edge_branch_fwd(T, p, et, 1, T->ddpart));
-        hipLaunchKernelGGL(k_coord_msg_parts, grid1(E), dim3(256), 0, T->st, T->ddpart, T->nvec, E, c.use_tanh, c.coords_range, T->sc, T->msgx);
-        KPD_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_segsum3, grid1(3 * T->n[d]), dim3(256), 0, T->st, T->msgx, T->e_rowptr[et], T->zinv[d], T->n[d],
-                           T->xns[d][l]);
-        KPD_LAUNCH_CHECK();
-    }
-    return KPD_OK;
+    return layer_edges_fused(T, l, true);
 }
 
 struct NodeParams {
@@ -1013,11 +748,7 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
         const int cap = et == 0 ? cap_ll : et == 3 ? std::max<int>(max_n_kk, 1) : cap_kl;
         add((size_t)nn[kD[et]] * LD, 4); add((size_t)(cdiv(cap, TM) + 1) * LD, 4); add((size_t)nn[kD[et]] * 4, 4); add((size_t)(cdiv(cap, TM) + 1) * 4, 4);
     }
-    add((size_t)ws_gemm_pack_floats(), 4);
     add(GRAD_PART_FLOATS, 4);
-    for (int k = 0; k < 3; ++k) add((size_t)cap_E * 3, 4);      // xdiff, nvec, dn
-    add((size_t)cap_E * 3, 4);                                    // msgx
-    for (int k = 0; k < 7; ++k) add(cap_E, 4);                   // dij, att, sc, dsv, ddij, ddpart (2)
     add(std::max(cap_E, cap_N), 4);                               // ones
     add(32, 4); add(max_n_lig, 4); add(max_B + 1, 4); add(max_B + 1, 4); add(max_B + 2, 4);
     add(cap_ll, 4); add(cap_ll, 4); add(max_n_lig + 1, 4);
@@ -1044,7 +775,6 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
     }
     T->dec1 = W.take<float>((size_t)max_n_lig * ENC_LD);
     T->dec2 = W.take<float>((size_t)max_n_lig * ENC_LD);
-    for (int k = 0; k < 6; ++k) T->eb[k] = W.take<float>((size_t)cap_E * LD);
     for (int k = 0; k < 7; ++k) T->nb[k] = W.take<float>((size_t)cap_N * LD);
     T->dact = W.take<float>((size_t)cap_N * ENC_LD);
     for (int nt = 0; nt < 2; ++nt) {
@@ -1079,14 +809,8 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
         T->hn_main[et] = W.take<float>((size_t)nn[kD[et]] * LD); T->hn_cont[et] = W.take<float>((size_t)(cdiv(cap, TM) + 1) * LD);
         T->xn_main[et] = W.take<float>((size_t)nn[kD[et]] * 4); T->xn_cont[et] = W.take<float>((size_t)(cdiv(cap, TM) + 1) * 4);
     }
-    T->wsg_pack = W.take<float>((size_t)ws_gemm_pack_floats());
     T->part_floats = GRAD_PART_FLOATS;
     T->part = W.take<float>(T->part_floats);
-    T->xdiff = W.take<float>((size_t)cap_E * 3); T->nvec = W.take<float>((size_t)cap_E * 3); T->dn = W.take<float>((size_t)cap_E * 3);
-    T->msgx = W.take<float>((size_t)cap_E * 3);
-    T->dij = W.take<float>(cap_E); T->att = W.take<float>(cap_E); T->sc = W.take<float>(cap_E); T->dsv = W.take<float>(cap_E);
-    T->ddij = W.take<float>(cap_E);
-    T->ddpart = W.take<float>((size_t)2 * cap_E);
     const int n_ones = std::max(cap_E, cap_N);
     T->ones = W.take<float>(n_ones);
     T->meta = W.take<int>(32);
@@ -1106,9 +830,6 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
     T->colpart_blocks = cdiv(std::max(cap_E, cap_N), HEAD_ROWS);
     T->colpart = W.take<float>(colpart_floats(std::max(cap_E, cap_N)));
     KPD_REQUIRE(T->colpart != nullptr, KPD_ERR_HIP, "workspace arena too small (internal sizing error)");
-    for (int k = 0; k < 4; ++k) T->scratch.e[0][k] = T->scratch.e[1][k] = T->eb[k];
-    T->scratch.att = T->att; T->scratch.dij = T->dij; T->scratch.xdiff = T->xdiff; T->scratch.nvec = T->nvec; T->scratch.sc = T->sc;
-    T->scratch.msgx = T->msgx;
     {
         if (T->store_base) (void)hipFree(T->store_base);
         T->store_base = nullptr;
@@ -1116,13 +837,13 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
         static const bool want = !(getenv("KPD_TRAIN_STORE") && atoi(getenv("KPD_TRAIN_STORE")) == 0);
         auto al = [](size_t floats) { return (floats * 4 + 255) & ~size_t(255); };
         size_t per_layer = 0;
-        // (with both per-layer edge kernels a2 = SiLU(pre2) is never read from memory: three kept arrays per branch instead of four)
-        const bool no_a2 = want_fused_fwd() && want_fused_bwd();
-        const int n_keep = no_a2 ? 6 : 8;
+        // (a2 = SiLU(pre2) is never read from memory -- the backward edge kernel recomputes it from the pre2 rows it streams: three kept
+        // arrays per branch, pre1 / a1 / pre2)
+        const int n_keep = 6;
         for (int et = 0; et < T->n_et; ++et) per_layer += n_keep * al((size_t)cap_et[et] * LD) + 3 * al(cap_et[et]) + 3 * al((size_t)cap_et[et] * 3);
         for (int nt = 0; nt < T->n_upd; ++nt) per_layer += 3 * al((size_t)nn[nt] * LD);
         // all layers (activations kept: backward recomputes nothing), else one layer's edge slots (the forward edge kernel fills a whole layer
-        // at a time; backward recomputes layer by layer), else the per-branch scratch set
+        // at a time; backward recomputes layer by layer).  Less than one layer's slots (3 GB at C2, B = 64) is an out-of-memory error.
         size_t edge_layer = 0;
         for (int et = 0; et < T->n_et; ++et) edge_layer += n_keep * al((size_t)cap_et[et] * LD) + 3 * al(cap_et[et]) + 3 * al((size_t)cap_et[et] * 3);
         int keep_layers = 0;
@@ -1130,17 +851,15 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
         else {
             (void)hipGetLastError();              // a failed allocation is not an error: recompute instead
             T->store_base = nullptr;
-            if (want_fused_fwd() && hipMalloc(reinterpret_cast<void **>(&T->store_base), edge_layer) == hipSuccess) keep_layers = 1;
+            if (hipMalloc(reinterpret_cast<void **>(&T->store_base), edge_layer) == hipSuccess) keep_layers = 1;
             else { (void)hipGetLastError(); T->store_base = nullptr; }
         }
+        KPD_REQUIRE(keep_layers >= 1, KPD_ERR_HIP, "out of device memory: the edge activations of one layer (%zu MB) do not fit", edge_layer >> 20);
         if (T->store_base && poison_level() >= 1) poison_floats(T->store_base, keep_layers == L ? per_layer * L : edge_layer);       // (debug: KPD_POISON)
         T->store = keep_layers == L && want;
-        T->layer_slots = keep_layers >= 1;
-        T->fused = want_fused_fwd() && T->layer_slots;
-        T->fused_b = T->fused && want_fused_bwd();
         for (int nt = 0; nt < 2; ++nt)
             for (int k = 0; k < 3; ++k) T->nq[nt][k].assign(L, nullptr);
-        if (T->layer_slots) {
+        {
             T->slots.assign((size_t)L * 4, kpd_egnn_trainer::Slot());
             char *p = T->store_base;
             auto take = [&](size_t floats) { float *r = reinterpret_cast<float *>(p); p += al(floats); return r; };
@@ -1148,7 +867,7 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
                 for (int et = 0; et < T->n_et; ++et) {
                     kpd_egnn_trainer::Slot &sl = T->slots[(size_t)l * 4 + et];
                     for (int br = 0; br < 2; ++br)
-                        for (int k = 0; k < 4; ++k) sl.e[br][k] = (k == 3 && no_a2) ? nullptr : take((size_t)cap_et[et] * LD);
+                        for (int k = 0; k < 4; ++k) sl.e[br][k] = k == 3 ? nullptr : take((size_t)cap_et[et] * LD);
                     sl.att = take(cap_et[et]); sl.dij = take(cap_et[et]); sl.sc = take(cap_et[et]);
                     sl.xdiff = take((size_t)cap_et[et] * 3); sl.nvec = take((size_t)cap_et[et] * 3); sl.msgx = take((size_t)cap_et[et] * 3);
                 }
@@ -1284,34 +1003,6 @@ kpd_status node_bwd(kpd_egnn_trainer *T, int l, int nt, int cur, int nxt, float 
     return KPD_OK;
 }
 
-// the part of the edge backward shared by both branches: eb[4] = dpre2 in; uses eb[0..1] = pre1, a1 of the branch
-kpd_status edge_branch_bwd(kpd_egnn_trainer *T, const BranchParams &p, int et, int branch) {
-    const int E = T->E[et], s = kS[et], d = kD[et], ns = T->n[s], nd = T->n[d];
-    const bool first_branch = branch == 0;
-    float *dpre2 = T->eb[4], *dpre1 = T->eb[5];          // (the b2 gradient, the column sum of dpre2, left with the head kernel)
-    if (p.W2.g) KPD_TRY(grad_gemm(T, H, H, E, dpre2, LD, T->eb[1], LD, p.W2.g, H));
-    const long long tot = (long long)E * H;
-    // dpre1 = (dpre2 W2) * SiLU'(pre1), and d dij += dpre1 . W1[:, 514] from the same registers (two half-row shares, combined below)
-    KPD_TRY(ws_gemm(WS_SILU_BWD, dpre2, E, LD, p.W2.w, H, true, nullptr, T->eb[0], dpre1, nullptr, LD, T->wsg_pack, T->st, true, false,
-                    p.W1.w + 2 * H, 2 * H + 1, T->ddpart));
-    hipLaunchKernelGGL(k_add_halves, grid1(E), dim3(256), 0, T->st, T->ddpart, E, first_branch ? 0 : 1, T->ddij);
-    KPD_LAUNCH_CHECK();
-    // per-node sums: dV (by dst) and dU (by src), both segmented sums in a fixed order.  The two gradients that are sums over ALL edges of
-    // dpre1 -- b1 (plain) and column 514 of W1 (weighted by the edge's distance) -- are taken from per-node sums as well: every edge has one
-    // destination, so sum_e dpre1[e] = sum_v dV[v] (rides along with the dV^T h_dst product) and sum_e dpre1[e] d_e = sum_v dVw[v], where dVw
-    // comes out of the same pass over dpre1 as dV.  One E x 257 pass fewer per branch.
-    // They land in the branch's slots of the layer's gradient blocks; the products with them are taken once per node type (layer_cat_bwd).
-    float *dU = T->ducat[s] + (size_t)T->cat_of[et][branch][0] * LD, *dV = T->ducat[d] + (size_t)T->cat_of[et][branch][1] * LD;
-    float *dVw = T->dvwcat[d] + (size_t)T->cat_dvw_of[et][branch] * LD;
-    hipLaunchKernelGGL(k_segsum264, dim3(cdiv(ns, 4)), dim3(256), 0, T->st, dpre1, (const float *)nullptr, (const float *)nullptr, T->scsr[et].perm,
-                       T->scsr[et].rowptr, (const float *)nullptr, 0, ns, dU, (float *)nullptr, CAT_LD);
-    KPD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_segsum264, dim3(cdiv(nd, 4)), dim3(256), 0, T->st, dpre1, (const float *)nullptr, (const float *)T->dij, (const int *)nullptr,
-                       T->e_rowptr[et], (const float *)nullptr, 0, nd, dV, p.W1.g ? dVw : (float *)nullptr, CAT_LD);
-    KPD_LAUNCH_CHECK();
-    return KPD_OK;
-}
-
 // the edge part of layer l's backward pass through k_egnn_edge_bwd: one launch for the head backward, the dpre2 W2 product, dpre1, d dij and
 // the by-destination sums of every (edge type, branch); then, per (edge type, branch), what needs whole matrices: dW2 = dpre2^T a1, the
 // by-source sums of dpre1, the reductions of the per-tile partials
@@ -1388,62 +1079,12 @@ kpd_status layer_edges_bwd_fused(kpd_egnn_trainer *T, int l, int cur, int nxt, f
 }
 
 kpd_status layer_bwd(kpd_egnn_trainer *T, int l, int cur, int nxt, float *dhn[2]) {
-    const kpd_egnn_config &c = T->cfg;
     // (final layer, keypoints: dh_out = dx_out = 0, so dh_in / dx_in start from the zeros the caller left in dh[nxt] / dx[nxt])
     for (int nt = 0; nt < layer_n_upd(T, l); ++nt) KPD_TRY(node_bwd(T, l, nt, cur, nxt, dhn[nt]));
     KPD_TRY(layer_stage(T, l));
     if (!T->store) KPD_TRY(layer_project(T, l));
-    const bool recompute = !T->store && !T->fused;          // per edge type and branch below; the fused kernel refills a whole layer here
-    if (!T->store && T->fused) KPD_TRY(layer_edges_fused(T, l, false));
-    if (T->fused_b) {
-        KPD_TRY(layer_edges_bwd_fused(T, l, cur, nxt, dhn));
-        return layer_cat_bwd(T, l, nxt);
-    }
-    for (int et = 0; et < layer_n_et(T, l); ++et) {
-        const int E = T->E[et], s = kS[et], d = kD[et];
-        if (E == 0) continue;
-        bind_slot(T, l, et, 0);
-        if (recompute) KPD_TRY(geom_fwd(T, et, T->xs[s][l], T->xs[d][l]));
-        KPD_HIP(hipMemsetAsync(T->dn, 0, (size_t)E * 12, T->st));
-        BranchParams p;
-        // feature branch
-        KPD_TRY(branch_params(T, l, et, 0, &p));
-        if (recompute) {           // (the same head path as the forward pass: the two modes stay bit-identical)
-            KPD_TRY(edge_branch_fwd(T, p, et, 0, T->ddpart));
-            hipLaunchKernelGGL(k_head_att, grid1(E), dim3(256), 0, T->st, T->ddpart, E, p.head_b.w, T->att);
-            KPD_LAUNCH_CHECK();
-        }
-        KPD_REQUIRE(cdiv(E, HEAD_ROWS) <= T->colpart_blocks, KPD_ERR_CAPACITY, "column-sum scratch too small");
-        hipLaunchKernelGGL(k_feat_head_bwd, dim3(cdiv(E, HEAD_ROWS)), dim3(256), 0, T->st, dhn[d], T->zinv[d], T->e_dst[et], T->eb[3], T->att,
-                           p.head.w, T->eb[2], E, T->eb[4], T->dsv, T->colpart);
-        KPD_LAUNCH_CHECK();
-        // the kernel left the partial column sums of a2 ds (head weight gradient) and of dpre2 (b2 gradient)
-        hipLaunchKernelGGL(k_colsum_reduce, dim3(cdiv(H, 64)), dim3(1024), 0, T->st, T->colpart, cdiv(E, HEAD_ROWS), H, p.head.g, 1, p.b2.g);
-        KPD_LAUNCH_CHECK();
-        if (p.head_b.g) {
-            KPD_TRY(sum_scalar(T, T->dsv, E, p.head_b.g));
-        }
-        KPD_TRY(edge_branch_bwd(T, p, et, 0));
-        // coordinate branch
-        bind_slot(T, l, et, 1);
-        KPD_TRY(branch_params(T, l, et, 1, &p));
-        if (recompute) {
-            KPD_TRY(edge_branch_fwd(T, p, et, 1, T->ddpart));
-            hipLaunchKernelGGL(k_coord_msg_parts, grid1(E), dim3(256), 0, T->st, T->ddpart, T->nvec, E, c.use_tanh, c.coords_range, T->sc, T->msgx);
-            KPD_LAUNCH_CHECK();
-        }
-        hipLaunchKernelGGL(k_coord_head_bwd, dim3(cdiv(E, HEAD_ROWS)), dim3(256), 0, T->st, T->dx[cur][d], T->zinv[d], T->e_dst[et], T->nvec,
-                           T->sc, p.head.w, T->eb[3], T->eb[2], E, c.use_tanh, c.coords_range, T->eb[4], T->dsv, T->dn, T->colpart);
-        KPD_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_colsum_reduce, dim3(cdiv(H, 64)), dim3(1024), 0, T->st, T->colpart, cdiv(E, HEAD_ROWS), H, p.head.g, 1, p.b2.g);
-        KPD_LAUNCH_CHECK();
-        KPD_TRY(edge_branch_bwd(T, p, et, 1));
-        float *redge = T->msgx;                         // free again: the coordinate head consumed it above
-        hipLaunchKernelGGL(k_geom_bwd, grid1(E), dim3(256), 0, T->st, T->ddij, T->dn, T->xdiff, T->dij, E, redge);
-        KPD_LAUNCH_CHECK();
-        KPD_TRY(segsum(T->st, redge, 3, 0, 3, T->scsr[et].perm, T->scsr[et].rowptr, nullptr, 1.0f, true, T->n[s], T->dx[nxt][s], 3));
-        KPD_TRY(segsum(T->st, redge, 3, 0, 3, nullptr, T->e_rowptr[et], nullptr, -1.0f, true, T->n[d], T->dx[nxt][d], 3));
-    }
+    if (!T->store) KPD_TRY(layer_edges_fused(T, l, false));          // recompute mode: refill this layer's slots
+    KPD_TRY(layer_edges_bwd_fused(T, l, cur, nxt, dhn));
     return layer_cat_bwd(T, l, nxt);
 }
 
