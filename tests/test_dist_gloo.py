@@ -17,6 +17,30 @@ N_REC = [20, 35, 12, 28, 16]
 N_LIG = [5, 9, 3, 7, 4]
 
 
+def _plain(o):
+    """Tensors by value (numpy) for the result queue: a torch tensor in a multiprocessing Queue travels as a file descriptor that the
+    parent fetches from the LIVE child, and a child that has already left (barrier, destroy, exit) made q.get() fail with EOFError --
+    one run in ten on a busy host."""
+    if isinstance(o, torch.Tensor):
+        return o.detach().cpu().numpy().copy()
+    if isinstance(o, (list, tuple)):
+        return type(o)(_plain(x) for x in o)
+    if isinstance(o, dict):
+        return {k: _plain(v) for k, v in o.items()}
+    return o
+
+
+def _torchify(o):
+    import numpy as np
+    if isinstance(o, np.ndarray):
+        return torch.from_numpy(o)
+    if isinstance(o, (list, tuple)):
+        return type(o)(_torchify(x) for x in o)
+    if isinstance(o, dict):
+        return {k: _torchify(v) for k, v in o.items()}
+    return o
+
+
 def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -37,7 +61,7 @@ def _worker(rank, world, port, q):
         g.nodes['lig'].data['x_0'][off:off + N_LIG[i]] += 100.0 * i
         off += N_LIG[i]
     pos, feat = all_gather_ligands(g)
-    q.put((rank, [p.clone() for p in pos], [f.clone() for f in feat]))
+    q.put(_plain((rank, [p.clone() for p in pos], [f.clone() for f in feat])))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -60,7 +84,7 @@ def test_all_gather_ligands_world2():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in range(2)]
+    res = [_torchify(q.get(timeout=120)) for _ in range(2)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -82,7 +106,7 @@ def _grad_worker(rank, world, port, q):
     for i, p in enumerate(params):
         p.grad = None if i == 3 else torch.randn(p.shape, generator=gen)      # one frozen parameter
     n_buckets = allreduce_gradients(params, bucket_bytes=300 * 1024)          # forces two buckets
-    q.put((rank, n_buckets, [None if p.grad is None else p.grad.clone() for p in params]))
+    q.put(_plain((rank, n_buckets, [None if p.grad is None else p.grad.clone() for p in params])))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -94,7 +118,7 @@ def test_allreduce_gradients_world2():
     procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda r: r[0])
+    res = sorted([_torchify(q.get(timeout=120)) for _ in range(2)], key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -129,7 +153,7 @@ def _map_worker(rank, world, port, q):
 
     pos, feat = sharded_map(costs, fn)
     torch.manual_seed(1000 + rank)      # ranks disagree on their generators; the common seed is rank 0's draw
-    q.put((rank, seen, [p.clone() for p in pos], [f.clone() for f in feat], common_seed()))
+    q.put(_plain((rank, seen, [p.clone() for p in pos], [f.clone() for f in feat], common_seed())))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -144,7 +168,7 @@ def test_sharded_map_world3_returns_everything_in_input_order():
     procs = [ctx.Process(target=_map_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    res = sorted([_torchify(q.get(timeout=120)) for _ in range(world)], key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -230,7 +254,7 @@ def _s8_proc(rank, world, port, q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     torch.set_num_threads(1)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    q.put((rank, _s8_rank_body(rank)))
+    q.put(_plain((rank, _s8_rank_body(rank))))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -244,7 +268,7 @@ def test_sample_shards_over_world8_gloo_processes():
     procs = [ctx.Process(target=_s8_proc, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r[0])
+    res = sorted([_torchify(q.get(timeout=300)) for _ in range(world)], key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
