@@ -25,9 +25,6 @@ namespace {
 #ifndef KPD_CHAIN_NBUF
 #define KPD_CHAIN_NBUF 3          // buffers of the edge kernel's weight ring (chain_core.h)
 #endif
-#ifndef KPD_CHAIN_SWAVE
-#define KPD_CHAIN_SWAVE 1         // the wave index of the edge kernel as a scalar (ring hand-offs and LDS-DMA bases become scalar work)
-#endif
 
 template <int NTS>
 struct ChainSmem {
@@ -270,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
     int *sdst = reinterpret_cast<int *>(Vout + TM * 48);
     int *misc = sdst + TM;
 
-    const int tid = threadIdx.x, wave = KPD_CHAIN_SWAVE ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     unsigned long long *stamps = a.stamps;
     unsigned long long t_prev = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
     const int T = a.meta[8];
@@ -302,10 +299,10 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
             stage = 1 + (c - n0) / (NTS + 2);
             local = (c - n0) - (stage - 1) * (NTS + 2);
         }
-        return reinterpret_cast<const v4f *>(HM ? a.g[et][stage].chain_h : a.g[et][stage].chain) + (size_t)local * CH4;      // (wave-uniform)
+        return reinterpret_cast<const v4f *>(HM ? a.g[et][stage].chain_h : a.g[et][stage].chain) + (size_t)local * CH4 + tid;
     };
     ChunkRing<CH4, KPD_CHAIN_NBUF> ring;
-    ring.init(smem, total, wave, tid);
+    ring.init(smem, total, wave);
     ring.start(chunk_src);
     auto acquire = [&]() -> const v4f * { return ring.acquire(chunk_src); };
     auto release = [&]() { ring.release(); };
@@ -592,10 +589,10 @@ __global__ __launch_bounds__(256, 2) void k_gvp_node_chain(GvpNodePair p) {
 
     auto chunk_src = [&](int c) -> const v4f * {
         const int stage = c / (NTS + 2), local = c - stage * (NTS + 2);
-        return reinterpret_cast<const v4f *>(HM ? a.g[stage].chain_h : a.g[stage].chain) + (size_t)local * CH4;      // (wave-uniform)
+        return reinterpret_cast<const v4f *>(HM ? a.g[stage].chain_h : a.g[stage].chain) + (size_t)local * CH4 + tid;
     };
     ChunkRing<CH4> ring;
-    ring.init(smem, n_gvps * (NTS + 2), wave, tid);
+    ring.init(smem, n_gvps * (NTS + 2), wave);
     ring.start(chunk_src);
 
     const int el = lane & 15, q = lane >> 4;
@@ -773,10 +770,10 @@ __global__ __launch_bounds__(256, 2) void k_gvp_noise_chain(GvpNoiseArgs a) {
 
     auto chunk_src = [&](int c) -> const v4f * {
         const int stage = c / (NTS + 2), local = c - stage * (NTS + 2);
-        return reinterpret_cast<const v4f *>(HM ? a.g[stage].chain_h : a.g[stage].chain) + (size_t)local * CH4;      // (wave-uniform)
+        return reinterpret_cast<const v4f *>(HM ? a.g[stage].chain_h : a.g[stage].chain) + (size_t)local * CH4 + tid;
     };
     ChunkRing<CH4> ring;
-    ring.init(smem, std::max(n_gen, 1) * (NTS + 2), wave, tid);
+    ring.init(smem, std::max(n_gen, 1) * (NTS + 2), wave);
     if (n_gen > 0) ring.start(chunk_src);
 
     const int el = lane & 15, q = lane >> 4;

@@ -90,12 +90,17 @@ struct ChunkRing {
     typedef const __attribute__((address_space(1))) void glb_void;
     v4f *ring;
     int cur, total, wave;
+    unsigned toff;          // this thread's offset inside a 256-thread piece (float4 units)
 
-    __device__ __forceinline__ void init(float *smem, int total_chunks, int wave_) {
+    // wave_: the (wave-uniform) wave index; tid: the thread index.  src(c) returns the wave-UNIFORM base of chunk c: the thread offset is
+    // added here as a 32-bit lane offset, so that every piece is a scalar-base + lane-offset load (the pieces are 4 KB apart, past the
+    // 12-bit immediate: with a per-thread 64-bit pointer each of them cost a 64-bit vector add)
+    __device__ __forceinline__ void init(float *smem, int total_chunks, int wave_, int tid = -1) {
         ring = reinterpret_cast<v4f *>(smem);
         cur = 0;
         total = total_chunks;
         wave = wave_;
+        toff = tid < 0 ? 0u : (unsigned)tid;
         __builtin_amdgcn_s_setprio(2);
     }
     template <class F>
@@ -103,8 +108,11 @@ struct ChunkRing {
         const v4f *g = src(min(c, total - 1));
         v4f *dst = ring + b * CH4 + 64 * wave;
 #pragma unroll
-        for (int j = 0; j < PT; ++j)
-            __builtin_amdgcn_global_load_lds((glb_void *)(g + 256 * j), (lds_void *)(dst + 256 * j), 16, 0, 0);
+        for (int j = 0; j < PT; ++j) {
+            const v4f *gj = g + 256 * j;
+            asm volatile("" : "+s"(gj));          // the piece's base stays a scalar pair (else hipcc folds it into a per-thread 64-bit pointer)
+            __builtin_amdgcn_global_load_lds((glb_void *)(gj + toff), (lds_void *)(dst + 256 * j), 16, 0, 0);
+        }
     }
     template <class F>
     __device__ __forceinline__ void start(F &&src) {
