@@ -14,6 +14,24 @@ namespace kpd {
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ v4f mfma16(float a, float b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+// One-instruction square root / reciprocal (v_sqrt_f32, v_rcp_f32: 1 ulp) for the per-row geometry and the vector norms of the chained
+// kernels.  The IEEE-exact sqrtf / division of hipcc are ~8 / ~10 VALU instructions each, and on gfx950 a VALU instruction is time the
+// fp32 MFMA pipe of the same SIMD does not get: 33 of them per edge-kernel tile were 9 % of its VALU work.
+__device__ __forceinline__ float sqrt1(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float rcp1(float x) { return __builtin_amdgcn_rcpf(x); }
+// SiLU of the four values of a result tile with the three non-transcendental steps as float4 operations (hipcc turns them into
+// v_pk_mul_f32 / v_pk_add_f32: 6 VALU + 8 transcendental instructions per four values instead of 12 + 8).  Same operations, same bits as silu().
+__device__ __forceinline__ v4f silu4(v4f x) {
+    const v4f t = x * -1.4426950408889634f;
+    v4f e;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(t[r]);
+    const v4f d = e + 1.0f;
+    v4f q;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) q[r] = __builtin_amdgcn_rcpf(d[r]);
+    return x * q;
+}
 __device__ __forceinline__ v4f zero4() { return v4f{0.f, 0.f, 0.f, 0.f}; }
 
 // acc[mt] += chunk[16 mt .. +15][16 k] * xin  (xin[r] = X^T[4 (lane >> 4) + r][e]); nreg < 4 limits the k-steps of a

@@ -56,7 +56,7 @@ __device__ __forceinline__ void chain_generic_gvp(Ring &ring, Src &chunk_src, co
         Vh[c] = t;
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sh[r] = sqrtf(fmaxf(Vh[0][r] * Vh[0][r] + Vh[1][r] * Vh[1][r] + Vh[2][r] * Vh[2][r], 1e-8f));
+    for (int r = 0; r < 4; ++r) sh[r] = sqrt1(fmaxf(Vh[0][r] * Vh[0][r] + Vh[1][r] * Vh[1][r] + Vh[2][r] * Vh[2][r], 1e-8f));
 #pragma unroll
     for (int nt = 0; nt < NTS; ++nt) {
         const v4f *buf = ring.acquire(chunk_src);
@@ -71,12 +71,12 @@ __device__ __forceinline__ void chain_generic_gvp(Ring &ring, Src &chunk_src, co
     const v4f bgv = *reinterpret_cast<const v4f *>(gk.bg + 4 * q);
     const v4f wu = reinterpret_cast<const v4f *>(gk.wup)[lane];
 #pragma unroll
-    for (int mt = 0; mt < NTS; ++mt)
+    for (int mt = 0; mt < NTS; ++mt) x[mt] = silu4(acc[mt]);
+    {   // the next GVP's bias -- or, after the last one, this GVP's again (never used): an unconditional load, because a conditional one
+        // made hipcc copy all 64 accumulator registers before the branch in every GVP
+        const float *nb = next_bias ? next_bias : gk.b;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) x[mt][r] = silu(acc[mt][r]);
-    if (next_bias) {
-#pragma unroll
-        for (int mt = 0; mt < NTS; ++mt) acc[mt] = *reinterpret_cast<const v4f *>(next_bias + 16 * mt + 4 * q);
+        for (int mt = 0; mt < NTS; ++mt) acc[mt] = *reinterpret_cast<const v4f *>(nb + 16 * mt + 4 * q);
     }
     v4f gate;
     {
@@ -185,7 +185,7 @@ __device__ __forceinline__ void chain_generic_gvp_h(Ring &ring, Src &chunk_src, 
         Vh[c] = t;
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sh[r] = sqrtf(fmaxf(Vh[0][r] * Vh[0][r] + Vh[1][r] * Vh[1][r] + Vh[2][r] * Vh[2][r], 1e-8f));
+    for (int r = 0; r < 4; ++r) sh[r] = sqrt1(fmaxf(Vh[0][r] * Vh[0][r] + Vh[1][r] * Vh[1][r] + Vh[2][r] * Vh[2][r], 1e-8f));
 #pragma unroll
     for (int mt = 0; mt < NTS; ++mt) acc[mt] = acc[mt] * (1.0f / H_UNSCALE);
 #pragma unroll
@@ -354,16 +354,17 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
         const GvpW &g0 = a.g[et][0];
         const float *xs = a.x[snt] + (size_t)u * 3, *xd = a.x[dnt] + (size_t)vd * 3;
         const float dx = xs[0] - xd[0], dy = xs[1] - xd[1], dz = xs[2] - xd[2];
-        const float dij = sqrtf(fmaxf(dx * dx + dy * dy + dz * dz, 1e-8f)) + 1e-8f;
-        const float xdv[3] = {dx / dij, dy / dij, dz / dij};
+        const float dij = sqrt1(fmaxf(dx * dx + dy * dy + dz * dz, 1e-8f)) + 1e-8f;
+        const float inv_dij = rcp1(dij);
+        const float xdv[3] = {dx * inv_dij, dy * inv_dij, dz * inv_dij};
         v4f rbf;
-        {
-            const float sigma = a.rbf_dmax / 16.0f;
+        {   // exp(-((d - mu_i) / sigma)^2), mu = linspace(0, D_max, 16), sigma = D_max / 16 (gvp.py:26-41): one multiply per centre
+            // and exp2 of the scaled square instead of three IEEE divisions and a full-range expf per value
+            const float inv_sigma = 16.0f / a.rbf_dmax, mu_step = a.rbf_dmax * (1.0f / 15.0f);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float mu = a.rbf_dmax * (float)(4 * q + r) / 15.0f;
-                const float zz = (dij - mu) / sigma;
-                rbf[r] = expf(-zz * zz);
+                const float zz = (dij - mu_step * (float)(4 * q + r)) * inv_sigma;
+                rbf[r] = __builtin_amdgcn_exp2f(-1.4426950408889634f * (zz * zz));
             }
         }
         // vectors of the two end points: 12 consecutive floats (4 channels x xyz) per lane
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    sh[ht][r] = sqrtf(fmaxf(Vh[ht][0][r] * Vh[ht][0][r] + Vh[ht][1][r] * Vh[ht][1][r] + Vh[ht][2][r] * Vh[ht][2][r], 1e-8f));
+                    sh[ht][r] = sqrt1(fmaxf(Vh[ht][0][r] * Vh[ht][0][r] + Vh[ht][1][r] * Vh[ht][1][r] + Vh[ht][2][r] * Vh[ht][2][r], 1e-8f));
             } else {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) Vh[ht][c] = zero4();
@@ -448,11 +449,9 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
 #pragma unroll
         for (int ht = 0; ht < 3; ++ht) wu[ht] = ht < n_ht ? wup[ht * 64] : zero4();
 #pragma unroll
-        for (int mt = 0; mt < NTS; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) x[mt][r] = silu(HM ? acc[mt][r] * H_UNSCALE : acc[mt][r]);
-        if (n_gvps > 1) {
-            const float *bn = a.g[et][1].b + 4 * q;
+        for (int mt = 0; mt < NTS; ++mt) x[mt] = silu4(HM ? acc[mt] * H_UNSCALE : acc[mt]);
+        {   // (unconditional: see chain_generic_gvp)
+            const float *bn = a.g[et][n_gvps > 1 ? 1 : 0].b + 4 * q;
 #pragma unroll
             for (int mt = 0; mt < NTS; ++mt) acc[mt] = *reinterpret_cast<const v4f *>(bn + 16 * mt);
         }
@@ -555,10 +554,10 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                if (r0 + i < ne) {
-                    run += v[i];
-                    runv += u[i];
-                }
+                // (rows past ne carry a repeated edge; they follow the last run end -- endmask has no bit there -- so what they add to the
+                // running sums is never stored: no per-row select needed)
+                run += v[i];
+                runv += u[i];
                 if ((endmask >> (r0 + i)) & 1ull) {
                     const bool cont = piece == 0 && first_is_cont;
                     const int dv = sdst[r0 + i];
@@ -813,7 +812,7 @@ __global__ __launch_bounds__(256, 2) void k_gvp_noise_chain(GvpNoiseArgs a) {
         Vh[c] = t;
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sh[r] = sqrtf(fmaxf(Vh[0][r] * Vh[0][r] + Vh[1][r] * Vh[1][r] + Vh[2][r] * Vh[2][r], 1e-8f));
+    for (int r = 0; r < 4; ++r) sh[r] = sqrt1(fmaxf(Vh[0][r] * Vh[0][r] + Vh[1][r] * Vh[1][r] + Vh[2][r] * Vh[2][r], 1e-8f));
     const v4f *wl = reinterpret_cast<const v4f *>(gl.chain) + lane;            // [slab][4 tiles][64 lanes]
     v4f so[4];
 #pragma unroll

@@ -126,15 +126,13 @@ __device__ __forceinline__ void coop_generic_gvp(Coop<NTS> &C, const GvpW &gk, c
         Vh[c] = t;
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sh[r] = sqrtf(fmaxf(Vh[0][r] * Vh[0][r] + Vh[1][r] * Vh[1][r] + Vh[2][r] * Vh[2][r], 1e-8f));
+    for (int r = 0; r < 4; ++r) sh[r] = sqrt1(fmaxf(Vh[0][r] * Vh[0][r] + Vh[1][r] * Vh[1][r] + Vh[2][r] * Vh[2][r], 1e-8f));
     coop_slab_gemm<NTS, NTS + 1>(wbase, [&](int s) -> v4f { return s < NTS ? x[s < NTS ? s : 0] : sh; }, acc);
     const v4f bgv = *reinterpret_cast<const v4f *>(gk.bg + 4 * q);
     const v4f wu = reinterpret_cast<const v4f *>(gk.wup)[lane];
     v4f own[TPW];
 #pragma unroll
-    for (int j = 0; j < TPW; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) own[j][r] = silu(acc[j][r]);
+    for (int j = 0; j < TPW; ++j) own[j] = silu4(acc[j]);
     if (next_bias) {
 #pragma unroll
         for (int j = 0; j < TPW; ++j) acc[j] = *reinterpret_cast<const v4f *>(next_bias + 16 * (w * TPW + j) + 4 * q);
@@ -335,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void k_gvp_noise_coop(GvpNoiseArgs a) {
         Vh[c] = t;
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sh[r] = sqrtf(fmaxf(Vh[0][r] * Vh[0][r] + Vh[1][r] * Vh[1][r] + Vh[2][r] * Vh[2][r], 1e-8f));
+    for (int r = 0; r < 4; ++r) sh[r] = sqrt1(fmaxf(Vh[0][r] * Vh[0][r] + Vh[1][r] * Vh[1][r] + Vh[2][r] * Vh[2][r], 1e-8f));
     const v4f *wl = reinterpret_cast<const v4f *>(gl.chain) + lane;            // [slab][4 tiles][64 lanes], then the gate slab
     v4f so = *reinterpret_cast<const v4f *>(gl.b + 16 * wave + 4 * q);
     {
