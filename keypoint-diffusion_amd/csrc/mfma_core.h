@@ -100,7 +100,19 @@ __device__ __forceinline__ void gemm_rows64_pre(const float *__restrict__ A, con
     const int r = lane & 31, h = lane >> 5;
     const float *a0p = A + r * SA_ + 4 * h;
     const float *a1p = A + (32 + r) * SA_ + 4 * h;
-    gf32x4 *bp = as_global(reinterpret_cast<const f32x4 *>(Wp) + (wave * 64 + lane) * 2);
+    // weight fragments of k-group G: scalar base Wp + 8 KB * G (the opaque asm keeps it in scalar registers) + this lane's 32-bit offset.
+    // As `bp[G * 512]` on a per-lane 64-bit pointer every group past the 4-KB immediate range cost two 64-bit vector adds (3 VALU + 2 hazard
+    // nops) inside the MFMA stream: 64 of them per tile.
+    const unsigned b_lane = (unsigned)(wave * 64 + lane) * 32u;
+#define KPD_GEMM_LOAD_S(A0, A1, B0, B1, G)                                                              \
+    A0 = *reinterpret_cast<const f32x4 *>(a0p + 8 * (G));                                               \
+    A1 = *reinterpret_cast<const f32x4 *>(a1p + 8 * (G));                                               \
+    {                                                                                                   \
+        const char *gb_ = reinterpret_cast<const char *>(Wp) + (size_t)(G) * 8192;                      \
+        asm volatile("" : "+s"(gb_));                                                                   \
+        B0 = *reinterpret_cast<gf32x4 *>((__attribute__((address_space(1))) const char *)gb_ + b_lane);        \
+        B1 = *reinterpret_cast<gf32x4 *>((__attribute__((address_space(1))) const char *)gb_ + b_lane + 16u);  \
+    }
     f32x4 xa0, xa1, xb0 = pre.x0, xb1 = pre.x1, ya0, ya1, yb0 = pre.y0, yb1 = pre.y1;
     xa0 = *reinterpret_cast<const f32x4 *>(a0p);
     xa1 = *reinterpret_cast<const f32x4 *>(a1p);
@@ -116,18 +128,19 @@ __device__ __forceinline__ void gemm_rows64_pre(const float *__restrict__ A, con
         KPD_GEMM_STEP(xa0, xa1, xb0, xb1)
         __builtin_amdgcn_sched_barrier(0);
         const int g2 = g + 2 < NG_ ? g + 2 : NG_ - 1;
-        KPD_GEMM_LOAD(xa0, xa1, xb0, xb1, g2)
+        KPD_GEMM_LOAD_S(xa0, xa1, xb0, xb1, g2)
         __builtin_amdgcn_sched_barrier(0);
         KPD_GEMM_STEP(ya0, ya1, yb0, yb1)
         __builtin_amdgcn_sched_barrier(0);
         const int g3 = g + 3 < NG_ ? g + 3 : NG_ - 1;
-        KPD_GEMM_LOAD(ya0, ya1, yb0, yb1, g3)
+        KPD_GEMM_LOAD_S(ya0, ya1, yb0, yb1, g3)
     }
     if (NG_ & 1) {
         __builtin_amdgcn_sched_barrier(0);
         KPD_GEMM_STEP_N(xa0, xa1, xb0, xb1, TailSteps<NG_>::J)
     }
 }
+#undef KPD_GEMM_LOAD_S
 
 template <int NG_, int SA_>
 __device__ __forceinline__ void gemm_rows64_t(const float *__restrict__ A, const float *__restrict__ Wp,
