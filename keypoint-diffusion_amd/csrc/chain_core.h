@@ -26,7 +26,7 @@ __device__ __forceinline__ v4f silu4(v4f x) {
     v4f e;
 #pragma unroll
     for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(t[r]);
-    const v4f d = e + 1.0f;
+    const v4f d = e + 1.0f;          // (spelling this as v_pk_add_f32 by inline asm, as silu_pre4 of mfma_core.h does, costs k_gvp_chain its last registers: 8 B scratch)
     v4f q;
 #pragma unroll
     for (int r = 0; r < 4; ++r) q[r] = __builtin_amdgcn_rcpf(d[r]);
@@ -38,12 +38,16 @@ __device__ __forceinline__ v4f zero4() { return v4f{0.f, 0.f, 0.f, 0.f}; }
 // partially filled slab.  Four output tiles per LDS batch so that consecutive MFMAs never hit the same accumulator;
 // the reads of batch g + 1 are pinned ahead of the 16 MFMAs of batch g (hipcc otherwise sinks them to two MFMAs before
 // their first use and every batch eats the LDS latency).
-template <int NTS>
-__device__ __forceinline__ void chunk_gemm(const v4f *__restrict__ buf, v4f xin, v4f (&acc)[NTS], int lane, int nreg) {
+// `after_first_reads` runs once, right behind the first batch of LDS reads: the ring's refill (address arithmetic + LDS-DMA issue) goes
+// there, so that a chunk starts with its own operand reads instead of waiting behind the hand-off of a chunk two ahead.
+template <int NTS, class H>
+__device__ __forceinline__ void chunk_gemm(const v4f *__restrict__ buf, v4f xin, v4f (&acc)[NTS], int lane, int nreg, H &&after_first_reads) {
     const v4f *wp = buf + lane;
     v4f w[2][4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) w[0][m] = wp[m * 64];
+    __builtin_amdgcn_sched_barrier(0);
+    after_first_reads();
 #pragma unroll
     for (int g = 0; g < NTS / 4; ++g) {
         if (g + 1 < NTS / 4) {
@@ -60,6 +64,10 @@ __device__ __forceinline__ void chunk_gemm(const v4f *__restrict__ buf, v4f xin,
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+}
+template <int NTS>
+__device__ __forceinline__ void chunk_gemm(const v4f *__restrict__ buf, v4f xin, v4f (&acc)[NTS], int lane, int nreg) {
+    chunk_gemm<NTS>(buf, xin, acc, lane, nreg, [] {});
 }
 
 // Two consecutive k-slabs (buf, buf + NTS * 64) against xa, xb with one read pipeline across both.
@@ -108,6 +116,7 @@ struct ChunkRing {
     typedef const __attribute__((address_space(1))) void glb_void;
     v4f *ring;
     int cur, total, wave;
+    int bi;                 // buffer of chunk cur (cur mod NBUF as a counter: no division per chunk)
     unsigned toff;          // this thread's offset inside a 256-thread piece (float4 units)
 
     // wave_: the (wave-uniform) wave index; tid: the thread index.  src(c) returns the wave-UNIFORM base of chunk c: the thread offset is
@@ -116,14 +125,18 @@ struct ChunkRing {
     __device__ __forceinline__ void init(float *smem, int total_chunks, int wave_, int tid = -1) {
         ring = reinterpret_cast<v4f *>(smem);
         cur = 0;
+        bi = 0;
         total = total_chunks;
         wave = wave_;
         toff = tid < 0 ? 0u : (unsigned)tid;
         __builtin_amdgcn_s_setprio(2);
     }
-    template <class F>
-    __device__ __forceinline__ void fetch(F &&src, int c, int b) {
-        const v4f *g = src(min(c, total - 1));
+    __device__ __forceinline__ int ahead_buffer() const {
+        const int b2 = bi + AHEAD;
+        return b2 >= NBUF ? b2 - NBUF : b2;
+    }
+    // the chunk at the wave-uniform address g into buffer b
+    __device__ __forceinline__ void fetch_ptr(const v4f *g, int b) {
         v4f *dst = ring + b * CH4 + 64 * wave;
 #pragma unroll
         for (int j = 0; j < PT; ++j) {
@@ -132,6 +145,8 @@ struct ChunkRing {
             __builtin_amdgcn_global_load_lds((glb_void *)(gj + toff), (lds_void *)(dst + 256 * j), 16, 0, 0);
         }
     }
+    template <class F>
+    __device__ __forceinline__ void fetch(F &&src, int c, int b) { fetch_ptr(src(min(c, total - 1)), b); }
     template <class F>
     __device__ __forceinline__ void start(F &&src) {
 #pragma unroll
@@ -150,18 +165,27 @@ struct ChunkRing {
     }
     template <class F>
     __device__ __forceinline__ const v4f *acquire(F &&src) {
-        int b2 = cur + AHEAD;
-        b2 -= NBUF * (b2 / NBUF);
-        fetch(src, cur + AHEAD, b2);
+        fetch(src, cur + AHEAD, ahead_buffer());
         __builtin_amdgcn_sched_barrier(0);      // keep the fetch at the head of the chunk
         __builtin_amdgcn_s_setprio(0);
-        return ring + (cur - NBUF * (cur / NBUF)) * CH4;
+        return ring + bi * CH4;
+    }
+    // Explicit-source form: the caller knows where the chunk AHEAD of the current one lives (a compile-time offset from a per-GVP base
+    // pointer in the chained GVP kernels), so the hand-off needs no chunk -> (stage, local) arithmetic and no pointer fetch from the
+    // argument block; and the refill can be issued BEHIND the chunk's first operand reads (chunk_gemm's hook):
+    //   buf = current();  chunk_gemm(buf, ..., [&] { prefetch(address of chunk cur + AHEAD); });  release();
+    __device__ __forceinline__ const v4f *current() const { return ring + bi * CH4; }
+    __device__ __forceinline__ void prefetch(const v4f *g_ahead) {
+        fetch_ptr(g_ahead, ahead_buffer());
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(0);
     }
     __device__ __forceinline__ void release() {
         __builtin_amdgcn_s_setprio(2);
         wait_landed();
         lds_barrier();
         ++cur;
+        bi = bi + 1 == NBUF ? 0 : bi + 1;
     }
     __device__ __forceinline__ void drain() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

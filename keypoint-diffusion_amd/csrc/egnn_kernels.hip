@@ -260,7 +260,7 @@ __device__ __forceinline__ void edge_gather_finish(const EdgeGather<NW> &g, cons
     for (int rr = 0; rr < RPW; ++rr) {
         const int r = wave * RPW + rr;
         f32x4 v = g.ps[rr] + g.pd[rr] + dv[rr >> 2][rr & 3] * w0;   // = c * pre-activation (P, w_r carry c)
-        v[0] = silu_pre(v[0]); v[1] = silu_pre(v[1]); v[2] = silu_pre(v[2]); v[3] = silu_pre(v[3]);
+        v = silu_pre4(v);
         *reinterpret_cast<f32x4 *>(s.A + r * SA + 4 * lane) = v;
     }
     // columns 256..263 of the wave's rows in one pass (lane = row * 4 + chunk): keeping this out of the
@@ -294,10 +294,19 @@ __device__ __forceinline__ void store_T_silu_w(float *T, const f32x16 (&acc)[2][
         const int col = acc_col_w<NW>(nt, wave, lane);
         const float bb = PRE ? 0.0f : b[col];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 2; ++mt) {
+            if constexpr (PRE) {
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg)
-                T[acc_row(mt, reg, lane) * SA + col] = PRE ? silu_pre(acc[mt][nt][reg]) : silu(acc[mt][nt][reg] + bb);
+                for (int r4 = 0; r4 < 16; r4 += 4) {
+                    const f32x4 y = silu_pre4(f32x4{acc[mt][nt][r4], acc[mt][nt][r4 + 1], acc[mt][nt][r4 + 2], acc[mt][nt][r4 + 3]});
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) T[acc_row(mt, r4 + i, lane) * SA + col] = y[i];
+                }
+            } else {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) T[acc_row(mt, reg, lane) * SA + col] = silu(acc[mt][nt][reg] + bb);
+            }
+        }
     }
     if ((tid % TPR) == 0) T[(tid / TPR) * SA + 256] = PRE ? silu_pre(ex) : silu(ex + b[256]);
 }

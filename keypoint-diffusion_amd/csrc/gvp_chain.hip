@@ -43,9 +43,13 @@ struct ChainSmem {
 // One GVP whose scalars x and vectors Vc already sit in registers (every GVP but the head of an edge-message chain, and
 // all node-update GVPs): vec1, the [x | sh] GEMM over NTS + 1 chunks, SiLU, gates (one chunk), vec2.  acc enters holding
 // the bias of this GVP and leaves holding `next_bias` (when given) for the following one.
-template <int NTS, class Ring, class Src>
-__device__ __forceinline__ void chain_generic_gvp(Ring &ring, Src &chunk_src, const GvpW &gk, const float *next_bias,
+template <int NTS, class Ring>
+__device__ __forceinline__ void chain_generic_gvp(Ring &ring, const v4f *cb, const v4f *nb, const GvpW &gk, const float *next_bias,
                                                   v4f (&x)[NTS], v4f (&acc)[NTS], v4f (&Vc)[3], int lane, int q) {
+    // cb: this GVP's chunks (NTS scalar slabs, the sh slab, the gate slab); nb: the next GVP's -- or, after the last one, cb + NTS chunks,
+    // so that the two refills past the end re-read chunks that exist.  The chunk two ahead of local chunk i:
+    constexpr int CH4 = NTS * 64;
+    auto ahead = [&](int i) -> const v4f * { return i + 2 < NTS + 2 ? cb + (size_t)(i + 2) * CH4 : nb + (size_t)(i + 2 - (NTS + 2)) * CH4; };
     const v4f wh = reinterpret_cast<const v4f *>(gk.whp)[lane];
     v4f Vh[3], sh;
 #pragma unroll
@@ -59,34 +63,35 @@ __device__ __forceinline__ void chain_generic_gvp(Ring &ring, Src &chunk_src, co
     for (int r = 0; r < 4; ++r) sh[r] = sqrt1(fmaxf(Vh[0][r] * Vh[0][r] + Vh[1][r] * Vh[1][r] + Vh[2][r] * Vh[2][r], 1e-8f));
 #pragma unroll
     for (int nt = 0; nt < NTS; ++nt) {
-        const v4f *buf = ring.acquire(chunk_src);
-        chunk_gemm<NTS>(buf, x[nt], acc, lane, 4);
+        chunk_gemm<NTS>(ring.current(), x[nt], acc, lane, 4, [&] { ring.prefetch(ahead(nt)); });
         ring.release();
     }
-    {
-        const v4f *buf = ring.acquire(chunk_src);
-        chunk_gemm<NTS>(buf, sh, acc, lane, 4);
-        ring.release();
-    }
+    chunk_gemm<NTS>(ring.current(), sh, acc, lane, 4, [&] { ring.prefetch(ahead(NTS)); });
+    ring.release();
     const v4f bgv = *reinterpret_cast<const v4f *>(gk.bg + 4 * q);
     const v4f wu = reinterpret_cast<const v4f *>(gk.wup)[lane];
 #pragma unroll
     for (int mt = 0; mt < NTS; ++mt) x[mt] = silu4(acc[mt]);
     {   // the next GVP's bias -- or, after the last one, this GVP's again (never used): an unconditional load, because a conditional one
         // made hipcc copy all 64 accumulator registers before the branch in every GVP
-        const float *nb = next_bias ? next_bias : gk.b;
+        const float *nbias = next_bias ? next_bias : gk.b;
 #pragma unroll
-        for (int mt = 0; mt < NTS; ++mt) acc[mt] = *reinterpret_cast<const v4f *>(nb + 16 * mt + 4 * q);
+        for (int mt = 0; mt < NTS; ++mt) acc[mt] = *reinterpret_cast<const v4f *>(nbias + 16 * mt + 4 * q);
     }
     v4f gate;
     {
-        const v4f *buf = ring.acquire(chunk_src) + lane;
+        const v4f *buf = ring.current() + lane;
         v4f ga[4] = {zero4(), zero4(), zero4(), zero4()};
+        v4f wg[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) wg[nt] = buf[nt * 64];
+        __builtin_amdgcn_sched_barrier(0);
+        ring.prefetch(ahead(NTS + 1));
 #pragma unroll
         for (int nt = 0; nt < NTS; ++nt) {
-            const v4f wg = buf[nt * 64];
+            const v4f wv = nt < 4 ? wg[nt < 4 ? nt : 0] : buf[nt * 64];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ga[r] = mfma16(wg[r], x[nt][r], ga[r]);
+            for (int r = 0; r < 4; ++r) ga[r] = mfma16(wv[r], x[nt][r], ga[r]);
         }
         ring.release();
         gate = (ga[0] + ga[1]) + (ga[2] + ga[3]) + bgv;
@@ -502,7 +507,11 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
 #pragma unroll 1
     for (int k = 1; k < n_gvps; ++k) {
         if constexpr (HM) chain_generic_gvp_h<NTS>(ring, chunk_src, a.g[et][k], k + 1 < n_gvps ? a.g[et][k + 1].b : nullptr, x, acc, Vc, lane, q);
-        else chain_generic_gvp<NTS>(ring, chunk_src, a.g[et][k], k + 1 < n_gvps ? a.g[et][k + 1].b : nullptr, x, acc, Vc, lane, q);
+        else {
+            const v4f *cb = reinterpret_cast<const v4f *>(a.g[et][k].chain);
+            const v4f *nb = k + 1 < n_gvps ? reinterpret_cast<const v4f *>(a.g[et][k + 1].chain) : cb + (size_t)NTS * CH4;
+            chain_generic_gvp<NTS>(ring, cb, nb, a.g[et][k], k + 1 < n_gvps ? a.g[et][k + 1].b : nullptr, x, acc, Vc, lane, q);
+        }
         CHAIN_STAMP(6)
     }
 
@@ -654,7 +663,11 @@ __global__ __launch_bounds__(256, 2) void k_gvp_node_chain(GvpNodePair p) {
 #pragma unroll 1
     for (int k = 0; k < n_gvps; ++k) {
         if constexpr (HM) chain_generic_gvp_h<NTS>(ring, chunk_src, a.g[k], k + 1 < n_gvps ? a.g[k + 1].b : nullptr, x, acc, Vc, lane, q);
-        else chain_generic_gvp<NTS>(ring, chunk_src, a.g[k], k + 1 < n_gvps ? a.g[k + 1].b : nullptr, x, acc, Vc, lane, q);
+        else {
+            const v4f *cb = reinterpret_cast<const v4f *>(a.g[k].chain);
+            const v4f *nb = k + 1 < n_gvps ? reinterpret_cast<const v4f *>(a.g[k + 1].chain) : cb + (size_t)NTS * CH4;
+            chain_generic_gvp<NTS>(ring, cb, nb, a.g[k], k + 1 < n_gvps ? a.g[k + 1].b : nullptr, x, acc, Vc, lane, q);
+        }
     }
     // residual + update layer norm (gvp.py:524-532)
 #pragma unroll
@@ -795,7 +808,11 @@ __global__ __launch_bounds__(256, 2) void k_gvp_noise_chain(GvpNoiseArgs a) {
 #pragma unroll 1
         for (int k = 0; k < n_gen; ++k) {
             if constexpr (HM) chain_generic_gvp_h<NTS>(ring, chunk_src, a.g[k], k + 1 < n_gen ? a.g[k + 1].b : nullptr, x, acc, Vc, lane, q);
-            else chain_generic_gvp<NTS>(ring, chunk_src, a.g[k], k + 1 < n_gen ? a.g[k + 1].b : nullptr, x, acc, Vc, lane, q);
+            else {
+                const v4f *cb = reinterpret_cast<const v4f *>(a.g[k].chain);
+                const v4f *nb = k + 1 < n_gen ? reinterpret_cast<const v4f *>(a.g[k + 1].chain) : cb + (size_t)NTS * CH4;
+                chain_generic_gvp<NTS>(ring, cb, nb, a.g[k], k + 1 < n_gen ? a.g[k + 1].b : nullptr, x, acc, Vc, lane, q);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the ring's tail fetches must not outlive the workgroup's LDS
     }
