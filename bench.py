@@ -91,7 +91,7 @@ WORKLOADS = {
     'gvp_40kp_train': dict(arch='gvp', enc='learned', dyn=GVP_DYN, n_kp=40, cutoffs=dict(CUTOFFS, kl=8, ll=6.0), T=500),
     'egnn_40kp_train': dict(arch='egnn', enc='learned', dyn=dict(DYNAMICS, message_norm=0.0), n_kp=40, cutoffs=dict(CUTOFFS, kl=8, ll=5), T=500),
 }
-TRAFFIC_FILES = ('r04_traffic.json', 'r03_traffic.json', 'r02_traffic.json', 'r01_traffic.json')      # per-launch HBM bytes of the dominant kernels (PMC passes)
+TRAFFIC_FILES = ('r05_traffic.json', 'r04_traffic.json', 'r03_traffic.json', 'r02_traffic.json', 'r01_traffic.json')      # per-launch HBM bytes of the dominant kernels (PMC passes)
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -7,7 +7,7 @@
 # 4) traffic.json: HBM bytes per launch of the dominant kernel of every workload (2 x FETCH_SIZE + WRITE_SIZE)
 # Copy the summaries into profiles/ afterwards (gpurun_out/ is scratch).
 set -e
-tag=${1:-r04}
+tag=${1:-r05}
 root=$(cd "$(dirname "$0")/../.." && pwd); cd /tmp && export TMPDIR=/tmp && cd "$root"
 out=gpurun_out/$tag
 rm -rf $out && mkdir -p $out
