@@ -121,16 +121,30 @@ struct TileLoader {
     // ---- direct path: tile inside the matrix, 16-B aligned; global -> LDS without registers ----
     // wave instruction n of the tile covers units 64 n .. 64 n + 63 (lane = unit - 64 n); every wave issues NV of them (wave + 4 j, wrapped:
     // a tile of fewer than 4 NV instructions is loaded twice into the same place, so that all waves have the same number in flight)
-    __device__ __forceinline__ void direct(const float *__restrict__ p, int ld, int r0, int k0, float *s, int wave, int lane) const {
-        typedef __attribute__((address_space(3))) void lds_void;
-        typedef const __attribute__((address_space(1))) void glb_void;
-        const float *base = KCONT ? p + (size_t)r0 * ld + k0 : p + (size_t)k0 * ld + r0;
+    // The per-thread element offsets and the per-wave LDS slots of those instructions do not change from slab to slab: plan() computes them
+    // once, direct() adds them to the slab's wave-uniform base (scalar base + 32-bit lane offset loads: no vector address arithmetic in
+    // the k-loop -- recomputed per slab it was ~40 VALU instructions and four v_readfirstlane between the MFMAs).
+    unsigned doff[NV];
+    int dslot[NV];
+    __device__ __forceinline__ void plan(int ld, int wave, int lane) {
         constexpr int NI = NV4 / 64;                             // wave instructions of the tile
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int n = (wave + 4 * j) % NI, u = 64 * n + lane;
-            const unsigned off = KCONT ? (unsigned)((u % R) * ld + 4 * (u / R)) : (unsigned)((u / (R / 4)) * ld + 4 * (u % (R / 4)));
-            __builtin_amdgcn_global_load_lds((glb_void *)(base + off), (lds_void *)(s + 256 * n), 16, 0, 0);
+            doff[j] = 4u * (KCONT ? (unsigned)((u % R) * ld + 4 * (u / R)) : (unsigned)((u / (R / 4)) * ld + 4 * (u % (R / 4))));      // bytes
+            dslot[j] = 256 * n;
+        }
+    }
+    // base: the slab's wave-uniform origin (KCONT: p + r0 ld + k0, else p + k0 ld + r0); s: the tile's place in the LDS stage
+    __device__ __forceinline__ void direct(const float *base, float *s) const {
+        typedef __attribute__((address_space(3))) void lds_void;
+        typedef const __attribute__((address_space(1))) void glb_void;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const char *b = reinterpret_cast<const char *>(base);
+            unsigned o = doff[j];
+            asm volatile("" : "+s"(b), "+v"(o));          // (scalar base, 32-bit lane offset: the addressing mode the load has; a hoisted 64-bit extension of the offset turns it back into a vector add)
+            __builtin_amdgcn_global_load_lds((glb_void *)(b + o), (lds_void *)(s + dslot[j]), 16, 0, 0);
         }
     }
 };
@@ -142,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void k_sgemm(SgemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];  // a.stages stages
     typedef TileLoader<BM, !TA> LA;                               // op(A)[m][k]: contiguous along k unless transposed
     typedef TileLoader<BN, TB> LB;                                // op(B)[k][n]: contiguous along k only when transposed
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 31, half = lane >> 5;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, col = lane & 31, half = lane >> 5;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int kbeg = blockIdx.z * a.k_chunk, kend = min(a.K, kbeg + a.k_chunk);
     float *C = a.C + (size_t)blockIdx.z * a.c_slice;
@@ -158,20 +172,27 @@ __global__ __launch_bounds__(256, 2) void k_sgemm(SgemmArgs a) {
     const int nk = (kend - kbeg + SG_BK - 1) / SG_BK, nk_full = (kend - kbeg) / SG_BK;
     // aligned float4 access where the tile lies inside the matrix (uniform over the workgroup) and the slab inside the K range
     const bool fastA = a.vecA != 0 && m0 + BM <= a.M, fastB = a.vecB != 0 && n0 + BN <= a.N;
+    // All operand reads of the slab are issued before its first MFMA (8 (WM + WN) registers) and pinned there: the MFMAs then wait on the
+    // LDS counter as it drains, one exposed LDS latency per slab.  Read next to their use (where hipcc sinks them) every k-step paid a full
+    // `s_waitcnt lgkmcnt(0)` round trip in front of its 4 WM WN / 4 MFMAs.
     auto compute = [&](const float *st) {
         const float *as = st, *bs = st + BM * SG_BK;
+        float av[SG_BK / 2][WM], bv[SG_BK / 2][WN];
 #pragma unroll
         for (int ks = 0; ks < SG_BK / 2; ++ks) {
             const int k = 2 * ks + half;
-            float av[WM], bv[WN];
 #pragma unroll
-            for (int i = 0; i < WM; ++i) av[i] = as[LA::at(wave * 32 * WM + 32 * i + col, k)];
+            for (int i = 0; i < WM; ++i) av[ks][i] = as[LA::at(wave * 32 * WM + 32 * i + col, k)];
 #pragma unroll
-            for (int j = 0; j < WN; ++j) bv[j] = bs[LB::at(32 * j + col, k)];
+            for (int j = 0; j < WN; ++j) bv[ks][j] = bs[LB::at(32 * j + col, k)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < SG_BK / 2; ++ks) {
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks][i], bv[ks][j], acc[i][j], 0, 0, 0);
         }
     };
     // column sums of the A operand ride along in the workgroups of the first column tile: thread m adds the slab's 16 values of its column
@@ -250,10 +271,20 @@ __global__ __launch_bounds__(256, 2) void k_sgemm(SgemmArgs a) {
         constexpr int IN_FLIGHT = LA::NV + LB::NV;
         static_assert(IN_FLIGHT * (SG_MAX_STAGES - 2) <= 63, "vmcnt immediate");
         const int stages = a.stages;
-        auto issue = [&](int kt) {
-            float *st = smem + (kt % stages) * STAGE;
-            la.direct(a.A, a.lda, m0, kbeg + kt * SG_BK, st, wave, lane);
-            lb.direct(a.B, a.ldb, n0, kbeg + kt * SG_BK, st + BM * SG_BK, wave, lane);
+        la.plan(a.lda, wave, lane);
+        lb.plan(a.ldb, wave, lane);
+        // wave-uniform origins of the next slab to issue, and the steps from slab to slab; the ring positions as counters (no `% stages`)
+        const float *pa = !TA ? a.A + (size_t)m0 * a.lda + kbeg : a.A + (size_t)kbeg * a.lda + m0;
+        const float *pb = TB ? a.B + (size_t)n0 * a.ldb + kbeg : a.B + (size_t)kbeg * a.ldb + n0;
+        const size_t step_a = !TA ? (size_t)SG_BK : (size_t)SG_BK * a.lda, step_b = TB ? (size_t)SG_BK : (size_t)SG_BK * a.ldb;
+        int si_issue = 0, si_comp = 0;
+        auto issue = [&](int) {
+            float *st = smem + si_issue * STAGE;
+            la.direct(pa, st);
+            lb.direct(pb, st + BM * SG_BK);
+            pa += step_a;
+            pb += step_b;
+            si_issue = si_issue + 1 == stages ? 0 : si_issue + 1;
         };
         // wait until at most `slabs` slabs of loads are outstanding (the counter takes an immediate)
         auto wait_behind = [&](int slabs) {
@@ -278,9 +309,11 @@ __global__ __launch_bounds__(256, 2) void k_sgemm(SgemmArgs a) {
             if (kt + 1 < nk) xfetch(kt + 1);
             if (kt + stages - 1 < nk_full) issue(kt + stages - 1);
             __builtin_amdgcn_sched_barrier(0);
-            compute(smem + (kt % stages) * STAGE);
-            add_cols(smem + (kt % stages) * STAGE);
-            riders(kt, smem + (kt % stages) * STAGE);
+            const float *st_c = smem + si_comp * STAGE;
+            si_comp = si_comp + 1 == stages ? 0 : si_comp + 1;
+            compute(st_c);
+            add_cols(st_c);
+            riders(kt, st_c);
             if (kt + 1 < nk) xstash(kt + 1);
             __builtin_amdgcn_sched_barrier(0);
             // issued so far: slabs 0 .. min(kt + stages - 1, nk_full - 1); needed next: kt + 1
