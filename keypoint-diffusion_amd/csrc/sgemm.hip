@@ -172,27 +172,23 @@ __global__ __launch_bounds__(256, 2) void k_sgemm(SgemmArgs a) {
     const int nk = (kend - kbeg + SG_BK - 1) / SG_BK, nk_full = (kend - kbeg) / SG_BK;
     // aligned float4 access where the tile lies inside the matrix (uniform over the workgroup) and the slab inside the K range
     const bool fastA = a.vecA != 0 && m0 + BM <= a.M, fastB = a.vecB != 0 && n0 + BN <= a.N;
-    // All operand reads of the slab are issued before its first MFMA (8 (WM + WN) registers) and pinned there: the MFMAs then wait on the
-    // LDS counter as it drains, one exposed LDS latency per slab.  Read next to their use (where hipcc sinks them) every k-step paid a full
-    // `s_waitcnt lgkmcnt(0)` round trip in front of its 4 WM WN / 4 MFMAs.
+    // (Issuing all operand reads of a slab before its first MFMA -- 8 (WM + WN) registers, one exposed LDS latency per slab -- was measured in
+    // round 5 and is SLOWER: 314 vs 265 us on the 166k x 256 x 256 product; it costs an occupancy step and queues 40 LDS reads in front of the
+    // first MFMA.  The reads stay next to their k-step; the second wave of the SIMD covers their latency.)
     auto compute = [&](const float *st) {
         const float *as = st, *bs = st + BM * SG_BK;
-        float av[SG_BK / 2][WM], bv[SG_BK / 2][WN];
 #pragma unroll
         for (int ks = 0; ks < SG_BK / 2; ++ks) {
             const int k = 2 * ks + half;
+            float av[WM], bv[WN];
 #pragma unroll
-            for (int i = 0; i < WM; ++i) av[ks][i] = as[LA::at(wave * 32 * WM + 32 * i + col, k)];
+            for (int i = 0; i < WM; ++i) av[i] = as[LA::at(wave * 32 * WM + 32 * i + col, k)];
 #pragma unroll
-            for (int j = 0; j < WN; ++j) bv[ks][j] = bs[LB::at(32 * j + col, k)];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ks = 0; ks < SG_BK / 2; ++ks) {
+            for (int j = 0; j < WN; ++j) bv[j] = bs[LB::at(32 * j + col, k)];
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks][i], bv[ks][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
     };
     // column sums of the A operand ride along in the workgroups of the first column tile: thread m adds the slab's 16 values of its column
