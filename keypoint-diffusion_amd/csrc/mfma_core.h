@@ -108,10 +108,15 @@ __device__ __forceinline__ void gemm_b_prefetch(BPrefetch &p, const float *__res
     p.y1 = bp[513];
 }
 
+#ifndef KPD_GEMM_SETS
+#define KPD_GEMM_SETS 2          // operand register sets of gemm_rows64_pre: fragments of k-group g + SETS are requested behind the MFMAs of group g
+                                 // (3 sets -- two groups of cover for the L2 round trip -- measured in round 5: 0.8130 vs 0.8132 ms, no difference)
+#endif
 template <int NG_, int SA_>
 __device__ __forceinline__ void gemm_rows64_pre(const float *__restrict__ A, const float *__restrict__ Wp,
                                                 f32x16 (&acc)[2][2], int wave, int lane, const BPrefetch &pre) {
-    static_assert(NG_ > 2, "prefetched form needs more than two k-groups");
+    static_assert(NG_ > KPD_GEMM_SETS, "prefetched form needs more k-groups than operand sets");
+    constexpr int NS = KPD_GEMM_SETS;
     const int r = lane & 31, h = lane >> 5;
     const float *a0p = A + r * SA_ + 4 * h;
     const float *a1p = A + (32 + r) * SA_ + 4 * h;
@@ -128,34 +133,31 @@ __device__ __forceinline__ void gemm_rows64_pre(const float *__restrict__ A, con
         B0 = *reinterpret_cast<gf32x4 *>((__attribute__((address_space(1))) const char *)gb_ + b_lane);        \
         B1 = *reinterpret_cast<gf32x4 *>((__attribute__((address_space(1))) const char *)gb_ + b_lane + 16u);  \
     }
-    f32x4 xa0, xa1, xb0 = pre.x0, xb1 = pre.x1, ya0, ya1, yb0 = pre.y0, yb1 = pre.y1;
-    xa0 = *reinterpret_cast<const f32x4 *>(a0p);
-    xa1 = *reinterpret_cast<const f32x4 *>(a1p);
-    ya0 = *reinterpret_cast<const f32x4 *>(a0p + 8);
-    ya1 = *reinterpret_cast<const f32x4 *>(a1p + 8);
-    constexpr int PAIRS = NG_ / 2;
-    // fully unrolled: every LDS / global address of the k-loop becomes an immediate offset and the 9 VALU + 8 SALU instructions of index
-    // math per pair of k-groups disappear (same-call A/B, round 3: 0.8498 vs 0.8542 ms on the edge kernel, -0.5 %)
+    // NS operand sets rotate (fully unrolled: set indices are compile-time, no register moves): the fragments of k-group g + NS are requested
+    // right behind the MFMAs of group g, so a weight load from L2 has NS - 1 groups (1 024 cycles each) to land.
+    f32x4 sa0[NS], sa1[NS], sb0[NS], sb1[NS];
+    sb0[0] = pre.x0; sb1[0] = pre.x1;
+    sb0[1] = pre.y0; sb1[1] = pre.y1;
+    sa0[0] = *reinterpret_cast<const f32x4 *>(a0p);
+    sa1[0] = *reinterpret_cast<const f32x4 *>(a1p);
+    sa0[1] = *reinterpret_cast<const f32x4 *>(a0p + 8);
+    sa1[1] = *reinterpret_cast<const f32x4 *>(a1p + 8);
 #pragma unroll
-    for (int p = 0; p < PAIRS; ++p) {
-        const int g = 2 * p;
+    for (int i = 2; i < NS; ++i) { KPD_GEMM_LOAD_S(sa0[i], sa1[i], sb0[i], sb1[i], i) }
+#pragma unroll
+    for (int g = 0; g < NG_; ++g) {
+        const int st = g % NS;
         __builtin_amdgcn_sched_barrier(0);
-        KPD_GEMM_STEP(xa0, xa1, xb0, xb1)
+        if ((NG_ & 1) && g == NG_ - 1) {
+            KPD_GEMM_STEP_N(sa0[st], sa1[st], sb0[st], sb1[st], TailSteps<NG_>::J)
+        } else {
+            KPD_GEMM_STEP(sa0[st], sa1[st], sb0[st], sb1[st])
+        }
         __builtin_amdgcn_sched_barrier(0);
-        const int g2 = g + 2 < NG_ ? g + 2 : NG_ - 1;
-        KPD_GEMM_LOAD_S(xa0, xa1, xb0, xb1, g2)
-        __builtin_amdgcn_sched_barrier(0);
-        KPD_GEMM_STEP(ya0, ya1, yb0, yb1)
-        __builtin_amdgcn_sched_barrier(0);
-        const int g3 = g + 3 < NG_ ? g + 3 : NG_ - 1;
-        KPD_GEMM_LOAD_S(ya0, ya1, yb0, yb1, g3)
+        if (g + NS < NG_) { KPD_GEMM_LOAD_S(sa0[st], sa1[st], sb0[st], sb1[st], g + NS) }
     }
-    if (NG_ & 1) {
-        __builtin_amdgcn_sched_barrier(0);
-        KPD_GEMM_STEP_N(xa0, xa1, xb0, xb1, TailSteps<NG_>::J)
-    }
-}
 #undef KPD_GEMM_LOAD_S
+}
 
 template <int NG_, int SA_>
 __device__ __forceinline__ void gemm_rows64_t(const float *__restrict__ A, const float *__restrict__ Wp,

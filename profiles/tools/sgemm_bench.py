@@ -6,7 +6,7 @@ import torch
 from keypoint_diffusion_amd import hip
 
 dev = torch.device('cuda:0')
-ws = torch.zeros(128 * 256 * 256, device=dev)
+ws = torch.zeros(260 * (256 * 256 + 1024), device=dev)      # as the trainers' split-K scratch (GRAD_PART_FLOATS): the edge-sized TN products need it for their full slice count
 SHAPES = [  # name, tA, tB, M, N, K
     ('edge fwd NT', False, True, 166000, 256, 256), ('edge bwd NN', False, False, 166000, 256, 256),
     ('node fwd NT', False, True, 20800, 256, 256), ('node bwd NN', False, False, 20800, 256, 512),
