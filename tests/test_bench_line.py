@@ -157,3 +157,21 @@ def test_bench_refuses_a_roofline_fraction_above_one(tmp_path, monkeypatch):
         with redirect_stdout(buf), pytest.raises(SystemExit) as e:
             bench.emit(rec)
         assert e.value.code == 2 and buf.getvalue() == ''            # nothing printed
+
+
+def test_hbm_kernel_report_from_committed_statistics():
+    """the bandwidth-bound kernels of a step (graph build, embed / decode, sampler update) with algorithmic bytes over the
+    rocprofv3 durations of the committed statistics: every fraction inside [0, 1], the summary in the compact line."""
+    counts = dict(E_ll=38372, E_kl=96000, E_lk=96000, E_kk=165934)
+    rep = bench.hbm_kernel_report('egnn', bench.DYNAMICS, 'egnn_all_atom', 64, 1600, 19200, counts, 10)
+    assert rep is not None and rep['durations_from'].startswith('profiles/r0') and rep['durations_measured_in_this_run'] is False
+    for name in ('k_kl_build', 'k_embed', 'k_decode', 'k_sample_update', 'k_ll_fill'):
+        k = rep['kernels'][name]
+        assert k['bytes'] > 0 and k['avg_us'] > 0 and 0.0 <= k['frac'] <= 1.0 and k['regime']
+    assert 0.0 < rep['frac'] < 0.2 and 50 < rep['us_per_step'] < 400          # a few MB in ~0.1 ms: latency-bound launches
+    rec = synthetic_record()
+    rec['hbm_kernels'] = rep
+    back = json.loads(json.dumps(bench.compact_line(rec)))
+    assert abs(back['hbm_kernels_frac'] - rep['frac']) < 1e-3 and back['hbm_kernels_us_per_step'] > 0
+    gv = bench.hbm_kernel_report('gvp', bench.GVP_DYN, 'gvp_40kp', 64, 1600, 2560, dict(E_ll=38400, E_kl=17920, E_lk=17920, E_kk=99840), 128)
+    assert gv is not None and 'k_gvp_embed' in gv['kernels']
