@@ -309,6 +309,34 @@ def _stats(times, B):
             'range_pct': 100.0 * (max(times) - min(times)) / med, 'complex_steps_per_s': B / med}
 
 
+PARITY_TOL = 1e-4          # BASELINE.json north_star: "within 1e-4 rel fp32" (max |a - b| / max |b|, tests/util.py rel_err)
+
+
+def product_vs_oracle(model, fwd, sd, cfg, g_cpu, tol=PARITY_TOL):
+    """The oracle as the checker of the thing being measured: one denoiser forward of the product (HIP path, cuda:0, exact fp32 mode) on the
+    B = 8 sample the baseline was just timed on, at t = 1, against the oracle's output for the same inputs.  A line whose kernels do not
+    compute the reference's function is refused (round 5: a missed hardware hazard in a hand-scheduled SiLU gave wrong, run-to-run
+    different outputs at an unchanged speed -- the bench line looked fine)."""
+    import torch
+    from keypoint_diffusion_amd import graph as G
+    from tests.util import rel_err, to_obatch
+    ob = to_obatch(g_cpu)
+    t = torch.ones(int(ob.n['lig'].numel()))
+    with torch.no_grad():
+        ref_h, ref_x = fwd(sd, cfg, ob, t)
+        m = model.to('cuda')
+        m.dynamics.gemm_mode = 'f32'                   # this model instance belongs to the baseline leg; the timed one is untouched
+        gd = g_cpu.to('cuda')
+        eps_h, eps_x = m.dynamics(gd, t.to('cuda'), G.get_batch_idxs(gd))
+        torch.cuda.synchronize()
+    eh, ex = rel_err(eps_h, ref_h), rel_err(eps_x, ref_x)
+    rec = {'vs': 'oracle', 'what': 'denoiser forward at t = 1 on the B = 8 baseline sample, exact fp32 mode', 'rel_err_h': eh, 'rel_err_x': ex,
+           'tol': tol, 'ok': bool(eh < tol and ex < tol)}
+    if not rec['ok']:
+        raise BenchRefused(f'the product path disagrees with the oracle on the baseline sample: rel err {eh:.3g} (h), {ex:.3g} (x) > {tol:g}')
+    return rec
+
+
 def cpu_baseline(workload='egnn_all_atom', ragged=False, B_scale=64, n_timed=15, with_c1=False):
     """the oracle (plain PyTorch fp32 CPU restatement of the reference path) on this box's host cores --
     `torch.set_num_threads(cores this process may use)`, the workload's shape at B = 1 and B = 8, 2 warm-up steps then `n_timed`
@@ -339,9 +367,11 @@ def cpu_baseline(workload='egnn_all_atom', ragged=False, B_scale=64, n_timed=15,
                 n_rec, n_lig = n_rec[:B], n_lig[:B]
             g = build_batch(model, B, n_rec, n_lig, seed=99, device=enc_dev, workload=workload).to('cpu')
             cases[f'B{B}'] = _stats(_cpu_time_steps(fwd, sd, cfg, to_obatch(g), T, 2, n_timed), B)
+            if B == 8:
+                parity = product_vs_oracle(model, fwd, sd, cfg, g)
         out = {'value': cases['B8']['complex_steps_per_s'] / B_scale, 'unit': 'steps/s', 'cores': cpu['threads_used'], 'kind': 'port',
                'complex_steps_per_s': cases['B8']['complex_steps_per_s'], 'cases': cases, 'host': cpu,
-               'cpu_seconds': sum(c['s_per_step_median'] * (c['timed_steps'] + 2) for c in cases.values()),
+               'cpu_seconds': sum(c['s_per_step_median'] * (c['timed_steps'] + 2) for c in cases.values()), 'parity': parity,
                'sample': f'oracle (plain PyTorch fp32 CPU restatement of the {workload} denoiser + update) at the '
                          f'{"ragged 150-600 / 15-35 atom" if ragged else "300 / 25 atom"} shape, B = 1 and B = 8, 2 warm-up + {n_timed} timed '
                          f'reverse steps each from the t = T state, median; value = the B = 8 rate scaled to the B = {B_scale} batch '
@@ -767,6 +797,8 @@ def compact_line(out, full_path=None):
                                 'cpu_model': host.get('cpu_model'),
                                 'cases': {k: _r(v.get('complex_steps_per_s')) for k, v in cb.get('cases', {}).items()},
                                 'spread_pct': {k: _r(v.get('spread_pct'), 3) for k, v in cb.get('cases', {}).items()}}
+        if cb.get('parity'):                 # the oracle as the checker of the measured path (product_vs_oracle): [rel err h, rel err x, tolerance]
+            line['parity_vs_oracle'] = [_r(cb['parity'].get('rel_err_h'), 3), _r(cb['parity'].get('rel_err_x'), 3), cb['parity'].get('tol')]
         if 'c1_dev_config' in cb:
             line['cpu_baseline']['c1_total_s_100_steps'] = _r(cb['c1_dev_config'].get('total_s_100_steps'))
     if rf:

@@ -43,9 +43,11 @@ struct ChainSmem {
 // One GVP whose scalars x and vectors Vc already sit in registers (every GVP but the head of an edge-message chain, and
 // all node-update GVPs): vec1, the [x | sh] GEMM over NTS + 1 chunks, SiLU, gates (one chunk), vec2.  acc enters holding
 // the bias of this GVP and leaves holding `next_bias` (when given) for the following one.
-template <int NTS, class Ring>
+// TR = 1 (training forward): tg names where this GVP's activations go (GvpTrainGvp), erow the lane's edge row, live whether it exists.
+template <int NTS, class Ring, int TR = 0>
 __device__ __forceinline__ void chain_generic_gvp(Ring &ring, const v4f *cb, const v4f *nb, const GvpW &gk, const float *next_bias,
-                                                  v4f (&x)[NTS], v4f (&acc)[NTS], v4f (&Vc)[3], int lane, int q) {
+                                                  v4f (&x)[NTS], v4f (&acc)[NTS], v4f (&Vc)[3], int lane, int q,
+                                                  const GvpTrainGvp *tg = nullptr, size_t erow = 0, bool live = false) {
     // cb: this GVP's chunks (NTS scalar slabs, the sh slab, the gate slab); nb: the next GVP's -- or, after the last one, cb + NTS chunks,
     // so that the two refills past the end re-read chunks that exist.  The chunk two ahead of local chunk i:
     constexpr int CH4 = NTS * 64;
@@ -61,6 +63,13 @@ __device__ __forceinline__ void chain_generic_gvp(Ring &ring, const v4f *cb, con
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) sh[r] = sqrt1(fmaxf(Vh[0][r] * Vh[0][r] + Vh[1][r] * Vh[1][r] + Vh[2][r] * Vh[2][r], 1e-8f));
+    if constexpr (TR) {
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) *reinterpret_cast<v4f *>(tg->Vh + (erow * 3 + c) * 16 + 4 * q) = Vh[c];
+            *reinterpret_cast<v4f *>(tg->sh + erow * 16 + 4 * q) = sh;
+        }
+    }
 #pragma unroll
     for (int nt = 0; nt < NTS; ++nt) {
         chunk_gemm<NTS>(ring.current(), x[nt], acc, lane, 4, [&] { ring.prefetch(ahead(nt)); });
@@ -70,8 +79,22 @@ __device__ __forceinline__ void chain_generic_gvp(Ring &ring, const v4f *cb, con
     ring.release();
     const v4f bgv = *reinterpret_cast<const v4f *>(gk.bg + 4 * q);
     const v4f wu = reinterpret_cast<const v4f *>(gk.wup)[lane];
+    if constexpr (TR) {
+        if (live) {
+            float *pr = tg->pre + erow * (16 * NTS) + 4 * q;
+#pragma unroll
+            for (int mt = 0; mt < NTS; ++mt) *reinterpret_cast<v4f *>(pr + 16 * mt) = acc[mt];
+        }
+    }
 #pragma unroll
     for (int mt = 0; mt < NTS; ++mt) x[mt] = silu4(acc[mt]);
+    if constexpr (TR) {
+        if (live) {
+            float *sr = tg->s + erow * (16 * NTS) + 4 * q;
+#pragma unroll
+            for (int mt = 0; mt < NTS; ++mt) *reinterpret_cast<v4f *>(sr + 16 * mt) = x[mt];
+        }
+    }
     {   // the next GVP's bias -- or, after the last one, this GVP's again (never used): an unconditional load, because a conditional one
         // made hipcc copy all 64 accumulator registers before the branch in every GVP
         const float *nbias = next_bias ? next_bias : gk.b;
@@ -95,6 +118,9 @@ __device__ __forceinline__ void chain_generic_gvp(Ring &ring, const v4f *cb, con
         }
         ring.release();
         gate = (ga[0] + ga[1]) + (ga[2] + ga[3]) + bgv;
+        if constexpr (TR) {
+            if (live) *reinterpret_cast<v4f *>(tg->gate + erow * 16 + 4 * q) = gate;          // before the sigmoid (k_gvp_gate_bwd applies it)
+        }
         if (gk.vec_sigmoid) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) gate[r] = sigmoidf_(gate[r]);
@@ -106,6 +132,12 @@ __device__ __forceinline__ void chain_generic_gvp(Ring &ring, const v4f *cb, con
 #pragma unroll
         for (int r = 0; r < 4; ++r) t = mfma16(wu[r], Vh[c][r], t);
         Vc[c] = gate * t;
+        if constexpr (TR) {
+            if (live) {
+                *reinterpret_cast<v4f *>(tg->Vu + (erow * 3 + c) * 16 + 4 * q) = t;
+                *reinterpret_cast<v4f *>(tg->V + (erow * 3 + c) * 16 + 4 * q) = Vc[c];
+            }
+        }
     }
 }
 
@@ -265,7 +297,9 @@ __device__ __forceinline__ void chain_generic_gvp_h(Ring &ring, Src &chunk_src, 
         t_prev = t_now;                                                                    \
     }
 
-template <int NTS, int HM = 0>
+// TR = 1: the training forward (a.train, gvp_kernels.h) -- the same chain on current weights, every activation the backward pass reads stored
+// on the way (8.5 KB per edge), node vectors and vector pieces in the trainers' [3][16] layout.
+template <int NTS, int HM = 0, int TR = 0>
 __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
     using L = ChainSmem<NTS>;
     constexpr int S = L::S, CH4 = L::CH4, SO = L::SO;
@@ -320,6 +354,9 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
     const int row = 16 * wave + el;
     const int eidx = e0 + min(row, ne - 1);
     const int u = esrc[eidx], vd = edst[eidx];
+    [[maybe_unused]] const bool live = row < ne;                        // (training form: rows past the end are not stored)
+    [[maybe_unused]] const size_t erow = (size_t)eidx;
+    [[maybe_unused]] const GvpTrainSlot *tsl = TR ? a.train + et : nullptr;
 
     // run boundaries of the dst-sorted tile for the segmented sum (wave 0, one lane per row)
     if (tid < TM) {
@@ -374,7 +411,10 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
         }
         // vectors of the two end points: 12 consecutive floats (4 channels x xyz) per lane
         v4f Vs[3], Vd[3];
-        {
+        if constexpr (TR) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Vs[c] = *reinterpret_cast<const v4f *>(a.v[snt] + (size_t)u * 48 + 16 * c + 4 * q);
+        } else {
             const v4f *vs = reinterpret_cast<const v4f *>(a.v[snt] + (size_t)u * 48 + 12 * q);
             const v4f t0 = vs[0], t1 = vs[1], t2 = vs[2];
             const float f[12] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3], t2[0], t2[1], t2[2], t2[3]};
@@ -428,6 +468,29 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
         }
         const int tail = h0 - 16 * (n_ht - 1);            // valid rows of the last hidden tile
         const int tail_reg = min(4, tail);
+        if constexpr (TR) {       // geometry, message input vectors [x_diff | source], hidden vectors and their norms (17 channels)
+            if (live) {
+                if (q == 0) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        tsl->unit[erow * 3 + c] = xdv[c];
+                        tsl->vin[(erow * 3 + c) * 17] = xdv[c];
+                        tsl->g[0].Vh[(erow * 3 + c) * 17 + 16] = Vh[1][c][0];
+                    }
+                    tsl->g[0].sh[erow * 17 + 16] = sh[1][0];
+                }
+                *reinterpret_cast<v4f *>(tsl->rbf + erow * 16 + 4 * q) = rbf;
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        tsl->vin[(erow * 3 + c) * 17 + 1 + 4 * q + r] = Vs[c][r];
+                        tsl->g[0].Vh[(erow * 3 + c) * 17 + 4 * q + r] = Vh[0][c][r];
+                    }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tsl->g[0].sh[erow * 17 + 4 * q + r] = sh[0][r];
+            }
+        }
 
         ring.first();
         CHAIN_STAMP(0)
@@ -453,8 +516,22 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
         v4f wu[3];
 #pragma unroll
         for (int ht = 0; ht < 3; ++ht) wu[ht] = ht < n_ht ? wup[ht * 64] : zero4();
+        if constexpr (TR) {
+            if (live) {
+                float *pr = tsl->g[0].pre + erow * S + 4 * q;
+#pragma unroll
+                for (int mt = 0; mt < NTS; ++mt) *reinterpret_cast<v4f *>(pr + 16 * mt) = acc[mt];
+            }
+        }
 #pragma unroll
         for (int mt = 0; mt < NTS; ++mt) x[mt] = silu4(HM ? acc[mt] * H_UNSCALE : acc[mt]);
+        if constexpr (TR) {
+            if (live) {
+                float *sr = tsl->g[0].s + erow * S + 4 * q;
+#pragma unroll
+                for (int mt = 0; mt < NTS; ++mt) *reinterpret_cast<v4f *>(sr + 16 * mt) = x[mt];
+            }
+        }
         {   // (unconditional: see chain_generic_gvp)
             const float *bn = a.g[et][n_gvps > 1 ? 1 : 0].b + 4 * q;
 #pragma unroll
@@ -479,6 +556,9 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
                 release();
                 gate = (ga[0] + ga[1]) + (ga[2] + ga[3]) + bgv;
             }
+            if constexpr (TR) {
+                if (live) *reinterpret_cast<v4f *>(tsl->g[0].gate + erow * 16 + 4 * q) = gate;
+            }
             if (g0.vec_sigmoid) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) gate[r] = sigmoidf_(gate[r]);
@@ -499,6 +579,12 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
                 }
             }
             Vc[c] = gate * t;
+            if constexpr (TR) {
+                if (live) {
+                    *reinterpret_cast<v4f *>(tsl->g[0].Vu + (erow * 3 + c) * 16 + 4 * q) = t;
+                    *reinterpret_cast<v4f *>(tsl->g[0].V + (erow * 3 + c) * 16 + 4 * q) = Vc[c];
+                }
+            }
         }
         CHAIN_STAMP(4)
     }
@@ -510,7 +596,9 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
         else {
             const v4f *cb = reinterpret_cast<const v4f *>(a.g[et][k].chain);
             const v4f *nb = k + 1 < n_gvps ? reinterpret_cast<const v4f *>(a.g[et][k + 1].chain) : cb + (size_t)NTS * CH4;
-            chain_generic_gvp<NTS>(ring, cb, nb, a.g[et][k], k + 1 < n_gvps ? a.g[et][k + 1].b : nullptr, x, acc, Vc, lane, q);
+            if constexpr (TR) chain_generic_gvp<NTS, decltype(ring), 1>(ring, cb, nb, a.g[et][k], k + 1 < n_gvps ? a.g[et][k + 1].b : nullptr, x, acc, Vc, lane, q,
+                                                                         &tsl->g[k], erow, live);
+            else chain_generic_gvp<NTS>(ring, cb, nb, a.g[et][k], k + 1 < n_gvps ? a.g[et][k + 1].b : nullptr, x, acc, Vc, lane, q);
         }
         CHAIN_STAMP(6)
     }
@@ -521,15 +609,20 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
         float *orow = O + row * SO + 4 * q;
 #pragma unroll
         for (int mt = 0; mt < NTS; ++mt) *reinterpret_cast<v4f *>(orow + 16 * mt) = x[mt];
-        float f[12];
+        if constexpr (TR) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
+            for (int c = 0; c < 3; ++c) *reinterpret_cast<v4f *>(Vout + row * 48 + 16 * c + 4 * q) = Vc[c];
+        } else {
+            float f[12];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) f[3 * r + c] = Vc[c][r];
-        v4f *vo = reinterpret_cast<v4f *>(Vout + row * 48 + 12 * q);
-        vo[0] = v4f{f[0], f[1], f[2], f[3]};
-        vo[1] = v4f{f[4], f[5], f[6], f[7]};
-        vo[2] = v4f{f[8], f[9], f[10], f[11]};
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) f[3 * r + c] = Vc[c][r];
+            v4f *vo = reinterpret_cast<v4f *>(Vout + row * 48 + 12 * q);
+            vo[0] = v4f{f[0], f[1], f[2], f[3]};
+            vo[1] = v4f{f[4], f[5], f[6], f[7]};
+            vo[2] = v4f{f[8], f[9], f[10], f[11]};
+        }
     }
     lds_barrier();
     CHAIN_STAMP(10)
@@ -901,6 +994,7 @@ kpd_status launch_gvp_edge(const GvpEdgeArgs &a, int tile_cap, hipStream_t st) {
     KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_chain<16>), ChainSmem<16>::FLOATS * 4));
     KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_chain<8>), ChainSmem<8>::FLOATS * 4));
     KPD_REQUIRE(a.S == 256 || a.S == 128, KPD_ERR_INVALID, "gvp chain kernel: S=%d (supported 128, 256)", a.S);
+    KPD_REQUIRE(!a.train || (a.S == 256 && a.gemm_mode == 0), KPD_ERR_INVALID, "gvp chain kernel: the training form runs at S = 256 in the exact fp32 mode");
     const dim3 grid(8 * cdiv(tile_cap, 8));
     if (a.S == 256 && a.gemm_mode == 1) {
         for (int et = 0; et < 4; ++et)
@@ -909,6 +1003,12 @@ kpd_status launch_gvp_edge(const GvpEdgeArgs &a, int tile_cap, hipStream_t st) {
                     KPD_REQUIRE(a.g[et][k].chain_h, KPD_ERR_STATE, "message GVP %d of edge type %d has no f16x2 chunks", k, et);
         KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_chain<16, 1>), ChainSmem<16>::FLOATS * 4));
         hipLaunchKernelGGL((k_gvp_chain<16, 1>), grid, dim3(256), ChainSmem<16>::FLOATS * 4, st, a);
+    } else if (a.S == 256 && a.train) {
+        KPD_REQUIRE(!a.use_dst, KPD_ERR_INVALID, "gvp chain kernel: the training form has no destination-feature inputs");
+        for (int et = 0; et < 4; ++et)
+            KPD_REQUIRE(!a.src[et] || (a.g[et][0].h == 17 && a.n_gvps <= 4), KPD_ERR_INVALID, "gvp chain kernel: the training form wants a 17-channel head GVP");
+        KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_chain<16, 0, 1>), ChainSmem<16>::FLOATS * 4));
+        hipLaunchKernelGGL((k_gvp_chain<16, 0, 1>), grid, dim3(256), ChainSmem<16>::FLOATS * 4, st, a);
     } else if (a.S == 256)
         hipLaunchKernelGGL(k_gvp_chain<16>, grid, dim3(256), ChainSmem<16>::FLOATS * 4, st, a);
     else

@@ -23,6 +23,17 @@ struct GvpW {
 
 constexpr int GVP_MAX_CHAIN = 4;
 
+// Training forward (gvp_train.hip): where the chained edge kernel leaves what the backward pass reads, per edge type and message GVP, in
+// the trainer's layouts -- rows = edges; scalars [E][256]; vectors [E][3][channels] with 17 channels at the head GVP's input / hidden
+// side ([x_diff | 16 source channels]) and 16 elsewhere; the gate before its sigmoid.
+struct GvpTrainGvp {
+    float *Vh, *Vu, *sh, *pre, *s, *gate, *V;
+};
+struct GvpTrainSlot {
+    float *unit, *rbf, *vin;          // [E][3], [E][16], [E][3][17]
+    GvpTrainGvp g[4];
+};
+
 struct GvpEdgeArgs {
     const int *meta;              // [9]: E[4], first tile[5]
     const int *src[4], *dst[4];
@@ -39,6 +50,8 @@ struct GvpEdgeArgs {
     float *mv_main[4], *mv_cont[4];   // [n_dst][48], [tiles][48]
     unsigned long long *stamps;       // [32] phase-cycle sums (diagnostics only, null in production)
     int gemm_mode;                    // 0: exact fp32 MFMA; 1: f16x2 split in the 256 x 256 products of the non-head message GVPs
+    const GvpTrainSlot *train;        // non-null: the training form of the kernel -- node vectors v arrive as [n][3][16], the vector pieces
+                                      // mv_main / mv_cont leave as [3][16], and every activation the backward pass reads is stored (device table [4])
 };
 
 struct GvpNodeArgs {

@@ -16,6 +16,9 @@
 // (feature dropout per element, vector dropout per channel, both scaled by 1 / (1 - rate)).  Masks come from Philox keyed
 // by a per-forward seed and the (conv, node type, position, kind) stream, so the backward pass regenerates them instead
 // of storing them; kpd_dropout_mask exposes the same stream for tests.
+#include <cstring>
+
+#include "gvp_kernels.h"
 #include "gvp_train_core.h"
 
 using namespace kpd;
@@ -62,6 +65,35 @@ struct kpd_gvp_trainer : TrainCtx {
     bool want_x = false;
     float dropout = 0.0f;
     unsigned long long seed = 0;
+    // Fused message forward (S = 256 with kept activations): one projection launch, ONE launch of the inference path's register-chained edge
+    // kernel in its training form (k_gvp_chain<16, 0, 1>: all edge types of the conv, the whole 3-GVP chain, activations stored on the way)
+    // and one launch that sums the per-tile message pieces, per conv.  The chain's weights are re-packed into the kernels' fragment order
+    // from the current parameters by one launch per forward (descriptor table built once per binding).
+    struct PackDesc {
+        const float *src;
+        float *dst;
+        int kind, sn, sk, n_valid, k_base, k_valid, n_tiles;      // kind 0: fragments (pack.hip, k_pack_chain_frag); 1: dst[i < k_valid] = i < n_valid ? src[i] : 0
+    };
+    struct ChainPack {
+        GvpW g[4];
+        const float *wproj = nullptr, *bproj = nullptr;
+    };
+    bool fused = false, pack_dirty = true;
+    float *pack_base = nullptr;
+    std::vector<ChainPack> packs;                  // [conv * 4 + et]
+    PackDesc *desc_dev = nullptr;
+    int n_desc = 0, desc_cap = 0;
+    GvpTrainSlot *slots_dev = nullptr;             // [conv * 4 + et]
+    float *Psrc[4] = {nullptr, nullptr, nullptr, nullptr};
+    float *ms_main[4] = {nullptr, nullptr, nullptr, nullptr}, *ms_cont[4] = {nullptr, nullptr, nullptr, nullptr};
+    float *mv_main[4] = {nullptr, nullptr, nullptr, nullptr}, *mv_cont[4] = {nullptr, nullptr, nullptr, nullptr};
+    void release_fused() {
+        if (pack_base) (void)hipFree(pack_base);
+        if (desc_dev) (void)hipFree(desc_dev);
+        if (slots_dev) (void)hipFree(slots_dev);
+        pack_base = nullptr; desc_dev = nullptr; slots_dev = nullptr;
+        fused = false; pack_dirty = true; n_desc = desc_cap = 0;
+    }
 };
 
 namespace {
@@ -166,6 +198,177 @@ kpd_status message_fwd(kpd_gvp_trainer *T, int conv, int et, GvpP *g0_out, bool 
     return KPD_OK;
 }
 
+// ---- fused message forward -----------------------------------------------------------------------------------------------------
+// every weight block of every message chain into the chained kernels' A-fragment order: block (x, y) = tile x of descriptor y
+__global__ void k_gvp_train_pack(const kpd_gvp_trainer::PackDesc *__restrict__ descs) {
+    const kpd_gvp_trainer::PackDesc d = descs[blockIdx.y];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (d.kind == 1) {
+        if (idx < d.k_valid) d.dst[idx] = idx < d.n_valid ? d.src[idx] : 0.0f;
+        return;
+    }
+    if ((int)blockIdx.x >= d.n_tiles) return;
+    const int r = idx & 3, lane = (idx >> 2) & 63, mt = idx >> 8;
+    const int n = 16 * mt + (lane & 15), i = 4 * (lane >> 4) + r;
+    d.dst[idx] = (n < d.n_valid && i < d.k_valid) ? d.src[(size_t)n * d.sn + (size_t)(d.k_base + i) * d.sk] : 0.0f;
+}
+
+// sa[v] / va[v] = sum over the edge types into this node type of scale(v) x (main piece + the pieces continued into later tiles): the
+// aggregation k_gvp_node_chain does in its prologue (gvp_chain.hip), as the trainers' pre-dropout message sums.  One wave per node.
+struct CombineArgs {
+    int n, n_in, mode;
+    float norm;
+    const int *rowptr[2];
+    const float *ms_main[2], *ms_cont[2], *mv_main[2], *mv_cont[2];
+    const float *z;
+    const int *bidx;
+    float *sa, *va;
+};
+__global__ __launch_bounds__(256) void k_gvp_msg_combine(CombineArgs a) {
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (v >= a.n) return;
+    v4f s = zero4(), w = zero4();
+    for (int i = 0; i < a.n_in; ++i) {
+        const int lo = a.rowptr[i][v], hi = a.rowptr[i][v + 1];
+        if (hi <= lo) continue;
+        const float sc = a.mode == 1 ? 1.0f / (float)(hi - lo) : 1.0f / (a.mode == 2 ? a.z[a.bidx[v]] : a.norm);
+        v4f m = *reinterpret_cast<const v4f *>(a.ms_main[i] + (size_t)v * 256 + 4 * lane), mv = zero4();
+        if (lane < 12) mv = *reinterpret_cast<const v4f *>(a.mv_main[i] + (size_t)v * 48 + 4 * lane);
+        for (int t = lo / TM + 1; t <= (hi - 1) / TM; ++t) {
+            m += *reinterpret_cast<const v4f *>(a.ms_cont[i] + (size_t)t * 256 + 4 * lane);
+            if (lane < 12) mv += *reinterpret_cast<const v4f *>(a.mv_cont[i] + (size_t)t * 48 + 4 * lane);
+        }
+        s += m * sc;
+        w += mv * sc;
+    }
+    *reinterpret_cast<v4f *>(a.sa + (size_t)v * 256 + 4 * lane) = s;
+    if (lane < 12) *reinterpret_cast<v4f *>(a.va + (size_t)v * 48 + 4 * lane) = w;
+}
+
+constexpr size_t PK_CHUNK = 16 * 256;                                   // floats of one weight chunk (16 output tiles)
+constexpr size_t PK_HEAD = 4 * PK_CHUNK + 9 * 256 + 2 * 256 + 256 + 64 + 16 * PK_CHUNK + 256;      // chain | whp | wup | b | bg | wproj | bproj
+constexpr size_t PK_GENERIC = 18 * PK_CHUNK + 256 + 256 + 256 + 64;                                  // chain | whp | wup | b | bg
+inline size_t pack_floats_per_chain(int nm) { return PK_HEAD + (size_t)(nm - 1) * PK_GENERIC; }
+
+// carve the pack arena and (re)build the descriptor table from the bound parameters
+kpd_status build_pack_table(kpd_gvp_trainer *T) {
+    const int L = T->cfg.n_convs, nm = T->cfg.n_message_gvps, S = T->S;
+    std::vector<kpd_gvp_trainer::PackDesc> descs;
+    auto frag = [&](const float *src, int sn, int sk, int n_valid, int k_base, int k_valid, int n_tiles, float *dst) {
+        descs.push_back(kpd_gvp_trainer::PackDesc{src, dst, 0, sn, sk, n_valid, k_base, k_valid, n_tiles});
+    };
+    auto copy = [&](const float *src, int n, int total, float *dst) { descs.push_back(kpd_gvp_trainer::PackDesc{src, dst, 1, 0, 0, n, 0, total, 1}); };
+    T->packs.assign((size_t)L * 4, kpd_gvp_trainer::ChainPack());
+    float *p = T->pack_base;
+    auto take = [&](size_t n) { float *r = p; p += n; return r; };
+    for (int conv = 0; conv < L; ++conv)
+        for (int et = 0; et < 4; ++et) {
+            if (!conv_uses(T, conv, et)) continue;
+            kpd_gvp_trainer::ChainPack &cp = T->packs[(size_t)conv * 4 + et];
+            const std::string prefix = "noise_predictor.conv_layers." + std::to_string(conv) + ".edge_message_fns." + kCanon[et];
+            for (int j = 0; j < nm; ++j) {
+                GvpP g;
+                const bool head = j == 0;
+                KPD_TRY(gvp_params(T, prefix + "." + std::to_string(j), head ? VH : VC, VC, head ? S + RBF : S, S, &g));
+                const int k_all = g.si + g.h, chunks = head ? 4 : 18;
+                float *chain = take((size_t)chunks * PK_CHUNK), *whp = take(head ? 9 * 256 : 256), *wup = take(head ? 2 * 256 : 256);
+                float *b = take(256), *bg = take(64);
+                GvpW &w = cp.g[j];
+                w.b = b; w.bg = bg; w.vin = g.vi; w.h = g.h; w.vout = g.vo; w.sout = S; w.vec_sigmoid = 1;
+                w.chain = chain; w.chain_h = nullptr; w.whp = whp; w.wup = wup;
+                if (head) {
+                    // Wh [17 in][17 hidden]: input tiles [source 1..16] (slot 0) and [x_diff 0] (slot 2) x two hidden tiles; Wu [17][16]
+                    frag(g.Wh.w, 1, VH, VH, 1, 16, 2, whp);
+                    frag(g.Wh.w, 1, VH, VH, 0, 1, 2, whp + 6 * 256);
+                    frag(g.Wu.w, 1, VC, VC, 0, 16, 1, wup);
+                    frag(g.Wu.w, 1, VC, VC, 16, 1, 1, wup + 256);
+                    // to_feats_out [256][256 src | 16 rbf | 17 sh]: the source block per node (k_gvp_proj_chain), rbf and sh per edge
+                    float *wproj = take(16 * PK_CHUNK), *bproj = take(256);
+                    for (int kc = 0; kc < 16; ++kc) frag(g.Ws.w, k_all, 1, S, 16 * kc, 16, 16, wproj + (size_t)kc * PK_CHUNK);
+                    copy(g.bs.w, S, 256, bproj);               // the bias rides with the per-node projection; b stays zero (arena memset)
+                    cp.wproj = wproj; cp.bproj = bproj;
+                    frag(g.Ws.w, k_all, 1, S, S, 16, 16, chain);
+                    frag(g.Ws.w, k_all, 1, S, S + RBF, 16, 16, chain + PK_CHUNK);
+                    frag(g.Ws.w, k_all, 1, S, S + RBF + 16, 1, 16, chain + 2 * PK_CHUNK);
+                } else {
+                    frag(g.Wh.w, 1, VC, VC, 0, 16, 1, whp);
+                    frag(g.Wu.w, 1, VC, VC, 0, 16, 1, wup);
+                    for (int kc = 0; kc < 16; ++kc) frag(g.Ws.w, k_all, 1, S, 16 * kc, 16, 16, chain + (size_t)kc * PK_CHUNK);
+                    frag(g.Ws.w, k_all, 1, S, S, 16, 16, chain + 16 * PK_CHUNK);
+                    copy(g.bs.w, S, 256, b);
+                }
+                float *gch = chain + (size_t)(chunks - 1) * PK_CHUNK;
+                for (int nt = 0; nt < 16; ++nt) frag(g.Wg.w, S, 1, VC, 16 * nt, 16, 1, gch + nt * 256);
+                copy(g.bg.w, VC, 16, bg);
+            }
+        }
+    if ((int)descs.size() > T->desc_cap) {
+        if (T->desc_dev) (void)hipFree(T->desc_dev);
+        T->desc_dev = nullptr;
+        KPD_HIP(hipMalloc(reinterpret_cast<void **>(&T->desc_dev), descs.size() * sizeof(kpd_gvp_trainer::PackDesc)));
+        T->desc_cap = (int)descs.size();
+    }
+    KPD_HIP(hipMemcpy(T->desc_dev, descs.data(), descs.size() * sizeof(kpd_gvp_trainer::PackDesc), hipMemcpyHostToDevice));
+    T->n_desc = (int)descs.size();
+    T->pack_dirty = false;
+    return KPD_OK;
+}
+
+// once per forward: the current parameters into the pack arena
+kpd_status pack_chains(kpd_gvp_trainer *T) {
+    if (T->pack_dirty) KPD_TRY(build_pack_table(T));
+    if (T->n_desc == 0) return KPD_OK;
+    hipLaunchKernelGGL(k_gvp_train_pack, dim3(16, T->n_desc), dim3(256), 0, T->st, T->desc_dev);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+// the messages of one conv, all edge types: per-node projections, the chained edge kernel in its training form, the piece sums into sa / va
+kpd_status conv_messages_fused(kpd_gvp_trainer *T, int conv, const bool (&is_dst)[2]) {
+    const int S = T->S, nm = T->cfg.n_message_gvps;
+    const bool all4 = conv_uses(T, conv, 2);
+    GvpProjArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    GvpEdgeArgs ea;
+    memset(&ea, 0, sizeof(ea));
+    ea.meta = all4 ? T->meta : T->meta + 16;
+    ea.x[0] = T->bt.lig_x; ea.x[1] = T->bt.kp_x; ea.v[0] = T->vs[0][conv]; ea.v[1] = T->vs[1][conv];
+    ea.n_gvps = nm; ea.S = S; ea.rbf_dmax = 15.0f; ea.train = T->slots_dev + (size_t)conv * 4;
+    int run = 0, tiles = 0;
+    for (int et = 0; et < (all4 ? 4 : 2); ++et) {
+        const kpd_gvp_trainer::ChainPack &cp = T->packs[(size_t)conv * 4 + et];
+        const int s = kSrc[et];
+        pa.s[pa.n_slots] = T->ss[s][conv]; pa.n[pa.n_slots] = T->n[s]; pa.wp[pa.n_slots] = cp.wproj; pa.b[pa.n_slots] = cp.bproj;
+        pa.P[pa.n_slots] = T->Psrc[et]; pa.tiles_first[pa.n_slots] = run;
+        run += cdiv(T->n[s], TM);
+        ++pa.n_slots;
+        ea.src[et] = T->e_src[et]; ea.dst[et] = T->e_dst[et]; ea.Psrc[et] = T->Psrc[et];
+        for (int j = 0; j < nm; ++j) ea.g[et][j] = cp.g[j];
+        ea.ms_main[et] = T->ms_main[et]; ea.ms_cont[et] = T->ms_cont[et]; ea.mv_main[et] = T->mv_main[et]; ea.mv_cont[et] = T->mv_cont[et];
+        tiles += cdiv(T->E[et], TM);
+    }
+    pa.tiles_first[pa.n_slots] = run;
+    pa.S = S;
+    KPD_TRY(launch_gvp_proj(pa, T->st));
+    KPD_TRY(launch_gvp_edge(ea, tiles, T->st));
+    for (int nt = 0; nt < 2; ++nt) {
+        if (!is_dst[nt]) continue;
+        CombineArgs ca;
+        memset(&ca, 0, sizeof(ca));
+        ca.n = T->n[nt]; ca.mode = T->cfg.message_norm_mode; ca.norm = T->cfg.message_norm; ca.z = T->z[nt]; ca.bidx = T->bidx[nt];
+        ca.sa = T->sa[nt][conv]; ca.va = T->va[nt][conv];
+        for (int et = 0; et < (all4 ? 4 : 2); ++et) {
+            if (kDst[et] != nt) continue;
+            const int i = ca.n_in++;
+            ca.rowptr[i] = T->e_rowptr[et];
+            ca.ms_main[i] = T->ms_main[et]; ca.ms_cont[i] = T->ms_cont[et]; ca.mv_main[i] = T->mv_main[et]; ca.mv_cont[i] = T->mv_cont[et];
+        }
+        hipLaunchKernelGGL(k_gvp_msg_combine, dim3(cdiv(ca.n, 4)), dim3(256), 0, T->st, ca);
+        KPD_LAUNCH_CHECK();
+    }
+    return KPD_OK;
+}
+
 // one GVPMultiEdgeConv forward (gvp.py:459-538): ss/vs[conv] -> ss/vs[conv + 1]; keeps sa/va[conv] (pre-LayerNorm sums)
 kpd_status conv_fwd(kpd_gvp_trainer *T, int conv) {
     const int S = T->S, nm = T->cfg.n_message_gvps, nu = T->cfg.n_update_gvps;
@@ -179,11 +382,13 @@ kpd_status conv_fwd(kpd_gvp_trainer *T, int conv) {
             T->vs[nt][conv + 1] = T->vs[nt][conv];
             continue;
         }
+        if (T->fused) continue;
         KPD_HIP(hipMemsetAsync(T->sa[nt][conv], 0, (size_t)T->n[nt] * S * 4, T->st));          // aggregated messages first ...
         KPD_HIP(hipMemsetAsync(T->va[nt][conv], 0, (size_t)T->n[nt] * 3 * VC * 4, T->st));
     }
+    if (T->fused) KPD_TRY(conv_messages_fused(T, conv, is_dst));
     for (int et = 0; et < 4; ++et) {
-        if (!conv_uses(T, conv, et) || T->E[et] == 0) continue;
+        if (T->fused || !conv_uses(T, conv, et) || T->E[et] == 0) continue;
         const int d = kDst[et];
         bind_msg(T, conv, et);
         KPD_TRY(message_fwd(T, conv, et, nullptr));
@@ -400,12 +605,14 @@ extern "C" void kpd_gvp_trainer_destroy(kpd_gvp_trainer *T) {
     T->wide.release();
     T->release_scratch();
     if (T->store_base) (void)hipFree(T->store_base);
+    T->release_fused();
     delete T;
 }
 
 extern "C" kpd_status kpd_gvp_trainer_bind(kpd_gvp_trainer *T, const char *name, const float *weight, float *grad, const int64_t *shape,
                                            int32_t ndim) {
     KPD_REQUIRE(T && name && shape && (ndim == 1 || ndim == 2), KPD_ERR_INVALID, "bad argument");
+    T->pack_dirty = true;                       // (the fused forward's descriptor table names parameter addresses)
     if (T->V != VC && weight) {
         // vector_size < 16: the tensors of a GVP whose axes count vector channels (Wh [v_in, h], Wu [h, v_out], the |Vh| block of
         // to_feats_out [S_out, S_in + h], the gates [v_out, S_out]; h = max(v_in, v_out), models/gvp.py:60-87) are trained through their
@@ -579,6 +786,50 @@ extern "C" kpd_status kpd_gvp_trainer_reserve(kpd_gvp_trainer *T, int32_t max_B,
             (void)hipGetLastError();
             T->store_base = nullptr;
         }
+        // the fused message forward wants the kept activations (it writes them) and the 256-wide kernels
+        T->release_fused();
+        static const bool want_fused = tool_env_int("KPD_TRAIN_FUSED", 1) != 0;      // TOOLS build: A/B against the per-GVP path
+        if (T->store && S == 256 && want_fused) {
+            size_t floats = 0;
+            for (int conv = 0; conv < L; ++conv)
+                for (int et = 0; et < 4; ++et)
+                    if (conv_uses(T, conv, et)) floats += pack_floats_per_chain(nm);
+            const size_t pack_floats = floats;
+            size_t off_P[4], off_main[4], off_cont[4], off_vmain[4], off_vcont[4];
+            for (int et = 0; et < 4; ++et) {
+                const size_t tiles = (size_t)cap_et[et] / TM + 2;
+                off_P[et] = floats; floats += (size_t)nn[kSrc[et]] * 256;
+                off_main[et] = floats; floats += (size_t)nn[kDst[et]] * 256;
+                off_cont[et] = floats; floats += tiles * 256;
+                off_vmain[et] = floats; floats += (size_t)nn[kDst[et]] * 48;
+                off_vcont[et] = floats; floats += tiles * 48;
+            }
+            std::vector<GvpTrainSlot> hs((size_t)L * 4);
+            memset(hs.data(), 0, hs.size() * sizeof(GvpTrainSlot));
+            for (size_t i = 0; i < hs.size(); ++i) {
+                const kpd_gvp_trainer::MsgSlot &sl = T->slots[i];
+                hs[i].unit = sl.unit; hs[i].rbf = sl.rbf; hs[i].vin = sl.vin;
+                for (int j = 0; j < nm; ++j) {
+                    const GvpBuf &b = sl.gb[j];
+                    hs[i].g[j] = GvpTrainGvp{b.Vh, b.Vu, b.sh, b.pre, b.s, b.gate, b.V};
+                }
+            }
+            if (hipMalloc(reinterpret_cast<void **>(&T->pack_base), floats * 4) == hipSuccess &&
+                hipMalloc(reinterpret_cast<void **>(&T->slots_dev), hs.size() * sizeof(GvpTrainSlot)) == hipSuccess) {
+                KPD_HIP(hipMemset(T->pack_base, 0, pack_floats * 4));           // zero biases of the head GVPs, unused fragment tiles
+                KPD_HIP(hipMemcpy(T->slots_dev, hs.data(), hs.size() * sizeof(GvpTrainSlot), hipMemcpyHostToDevice));
+                for (int et = 0; et < 4; ++et) {
+                    T->Psrc[et] = T->pack_base + off_P[et];
+                    T->ms_main[et] = T->pack_base + off_main[et]; T->ms_cont[et] = T->pack_base + off_cont[et];
+                    T->mv_main[et] = T->pack_base + off_vmain[et]; T->mv_cont[et] = T->pack_base + off_vcont[et];
+                }
+                T->fused = true;
+                T->pack_dirty = true;
+            } else {
+                (void)hipGetLastError();
+                T->release_fused();
+            }
+        }
     }
     T->cap_B = max_B; T->cap_lig = max_n_lig; T->cap_kp = max_n_kp; T->cap_kk = max_n_kk; T->cap_maxlig = max_lig_pg;
     T->cap_maxkp = max_kp_pg; T->cap_ll = cap_ll; T->cap_kl = cap_kl; T->cap_R = R;
@@ -604,7 +855,8 @@ extern "C" kpd_status kpd_gvp_trainer_forward(kpd_gvp_trainer *T, const kpd_batc
     KPD_TRY(launch_node_graph_index(bt->lig_ptr, bt->B, bt->n_lig, T->bidx[0], st));
     KPD_TRY(launch_node_graph_index(bt->kp_ptr, bt->B, bt->n_kp, T->bidx[1], st));
     KPD_TRY(launch_lig_graph(bt, c.ll_cutoff, c.ll_k, c.kl_cutoff, c.kl_k, &T->lg, T->ll_deg, T->ll_off, T->kl_off, T->kl_pg, st));
-    KPD_TRY(launch_egnn_meta(T->lg.counts, bt->n_kk, 0xF, 0xF, bt->lig_ptr, bt->kp_ptr, T->lg.ll_per_graph, bt->kk_rowptr, bt->B, T->kl_off,
+    // (tile tables for the fused message forward: all four edge types at meta[0..8], the ligand-bound pair of the last conv at meta[16..24])
+    KPD_TRY(launch_egnn_meta(T->lg.counts, bt->n_kk, 0xF, 0x3, bt->lig_ptr, bt->kp_ptr, T->lg.ll_per_graph, bt->kk_rowptr, bt->B, T->kl_off,
                              c.message_norm_mode == 2 ? 0.0f : 1.0f, 1, T->meta, T->z[0], T->z[1], st));
     int counts[2];
     KPD_HIP(hipMemcpyAsync(counts, T->lg.counts, sizeof(counts), hipMemcpyDeviceToHost, st));
@@ -622,6 +874,7 @@ extern "C" kpd_status kpd_gvp_trainer_forward(kpd_gvp_trainer *T, const kpd_batc
     KPD_HIP(hipMemsetAsync(T->vs[0][0], 0, (size_t)bt->n_lig * 3 * VC * 4, st));
     hipLaunchKernelGGL(k_v_transpose, grid1((long long)bt->n_kp * 3 * VC), dim3(256), 0, st, bt->kp_v, (long long)bt->n_kp, 1, T->V, T->vs[1][0]);
     KPD_LAUNCH_CHECK();
+    if (T->fused) KPD_TRY(pack_chains(T));
     for (int i = 0; i < c.n_convs; ++i) KPD_TRY(conv_fwd(T, i));
     KPD_TRY(noise_fwd(T, eps_h, eps_x));
     T->have_forward = true;

@@ -32,19 +32,16 @@ __device__ __forceinline__ float silu(float x) { return x * __builtin_amdgcn_rcp
 // v_exp_f32 + v_add + v_rcp_f32 + v_mul -- one VALU multiply fewer per element than silu().
 constexpr float SILU_C = -1.4426950408889634f;
 __device__ __forceinline__ float silu_pre(float xs) { return xs * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(xs)); }
-// four / sixteen values at a time with the non-transcendental steps as vector operations (v_pk_add_f32 / v_pk_mul_f32: one instruction per
-// two values); same operations, same bits as silu_pre
+// four values at a time; same operations, same bits as silu_pre.
+// (Round 5 spelled the 1 + e step out as inline-asm v_pk_add_f32 to save 190 VALU issues per tile for 0.16 %.  gfx950 needs one wait state
+//  between a transcendental (v_exp_f32) and a non-transcendental consumer of its result; hipcc inserts it for its own instructions but
+//  does not look inside an asm block, so wherever the scheduler put the second v_exp_f32 right before the asm the add read a stale register:
+//  wrong and run-to-run different outputs, caught by tests/test_cold_start_gpu.py.  No instruction-bearing inline asm next to compiler
+//  code: hazards are the compiler's to track.)
 typedef float silu_f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ silu_f32x4 silu_pre4(silu_f32x4 v) {
-    typedef float f32x2_ __attribute__((ext_vector_type(2)));
-    // (1 + e as two v_pk_add_f32: hipcc keeps these adds scalar on its own -- the exponentials come out of single-lane v_exp_f32 -- so the
-    //  packed form is spelled out; the ones live in one register pair for the whole kernel)
-    const f32x2_ one2 = {1.0f, 1.0f};
-    f32x2_ e01 = {__builtin_amdgcn_exp2f(v[0]), __builtin_amdgcn_exp2f(v[1])}, e23 = {__builtin_amdgcn_exp2f(v[2]), __builtin_amdgcn_exp2f(v[3])};
-    f32x2_ d01, d23;
-    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d01) : "v"(e01), "v"(one2));
-    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d23) : "v"(e23), "v"(one2));
-    const silu_f32x4 q = {__builtin_amdgcn_rcpf(d01[0]), __builtin_amdgcn_rcpf(d01[1]), __builtin_amdgcn_rcpf(d23[0]), __builtin_amdgcn_rcpf(d23[1])};
+    const silu_f32x4 q = {__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[0])), __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[1])),
+                          __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[2])), __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[3]))};
     return v * q;
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }

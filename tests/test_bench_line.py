@@ -175,3 +175,11 @@ def test_hbm_kernel_report_from_committed_statistics():
     assert abs(back['hbm_kernels_frac'] - rep['frac']) < 1e-3 and back['hbm_kernels_us_per_step'] > 0
     gv = bench.hbm_kernel_report('gvp', bench.GVP_DYN, 'gvp_40kp', 64, 1600, 2560, dict(E_ll=38400, E_kl=17920, E_lk=17920, E_kk=99840), 128)
     assert gv is not None and 'k_gvp_embed' in gv['kernels']
+
+
+def test_line_carries_the_parity_check_of_the_baseline_leg():
+    rec = synthetic_record(n_secondary=0)
+    rec['cpu_baseline']['parity'] = {'vs': 'oracle', 'what': 'x' * 200, 'rel_err_h': 3.21987e-6, 'rel_err_x': 1.5e-6, 'tol': bench.PARITY_TOL, 'ok': True}
+    line = bench.compact_line(rec)
+    assert line['parity_vs_oracle'] == [3.22e-6, 1.5e-6, 1e-4]
+    assert 'parity_vs_oracle' not in bench.compact_line(synthetic_record(n_secondary=0))
