@@ -675,6 +675,204 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
     CHAIN_STAMP(11)
 }
 
+// ---- backward of the message chains (training; autograd of gvp.py:89-116 under :540-551), register-chained --------------------------
+// The same tiling as k_gvp_chain run in reverse: a wave carries the gradients of its 16 edges' messages from the aggregated-message
+// gradient of the destination node down to the head GVP, through registers.  Per GVP: gate backward (kept gate / Vu), the scalar gradient
+// through the gates (Wg^T, one chunk), SiLU' at the kept pre-activation, ds_in = W[:, :256]^T dpre over 16 chunks (the forward's GEMM with
+// the transposed k-slabs), d|Vh| = W[:, 256:]^T dpre (one chunk of one-tile slabs), and the 16-channel vector half (Wu^T, the norm term,
+// Wh^T) as 16x16 MFMAs.  What the weight-gradient products need -- dpre, dgate, dVu, d|Vh| per GVP, drbf at the head -- is stored on the
+// way (1.3 KB per edge and GVP); the products themselves (K = edges) stay with sgemm.hip and the vector-weight kernels.  Replaces, per
+// GVP and edge type, a gate kernel, a K = 16 GEMM with the SiLU' epilogue and a weight-stationary 256 x 256 GEMM, each a pass over
+// [E, 256] arrays.
+__device__ __forceinline__ v4f silu_grad4(v4f p) {          // d SiLU(p) / dp = s (1 + p (1 - s)), s = sigmoid(p)
+    v4f s;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[r] = sigmoidf_(p[r]);
+    return s * (1.0f + p * (1.0f - s));
+}
+
+// gate backward of one GVP from the kept gate pre-activation and Vu: dgate (stored), dVu (stored, returned in dV)
+__device__ __forceinline__ v4f gate_bwd_lane(const GvpTrainGvp *f, const GvpBwdGvp *o, v4f (&dV)[3], size_t erow, bool live, int q) {
+    const v4f gp = *reinterpret_cast<const v4f *>(f->gate + erow * 16 + 4 * q);
+    v4f Vu[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) Vu[c] = *reinterpret_cast<const v4f *>(f->Vu + (erow * 3 + c) * 16 + 4 * q);
+    v4f sg;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sg[r] = sigmoidf_(gp[r]);
+    v4f dgate = (dV[0] * Vu[0] + dV[1] * Vu[1] + dV[2] * Vu[2]) * (sg * (1.0f - sg));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dV[c] = dV[c] * sg;
+    if (live) {
+        *reinterpret_cast<v4f *>(o->dgate + erow * 16 + 4 * q) = dgate;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) *reinterpret_cast<v4f *>(o->dVu + (erow * 3 + c) * 16 + 4 * q) = dV[c];
+    }
+    return dgate;
+}
+
+// one 16-output product over the 16 NTS registers of x against a chunk of one-tile slabs (the gate form of chain_generic_gvp)
+template <int NTS, class H>
+__device__ __forceinline__ v4f chunk_tile_product(const v4f *__restrict__ buf0, const v4f (&x)[NTS], int lane, H &&after_first_reads) {
+    const v4f *buf = buf0 + lane;
+    v4f ga[4] = {zero4(), zero4(), zero4(), zero4()};
+    v4f wg[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) wg[nt] = buf[nt * 64];
+    __builtin_amdgcn_sched_barrier(0);
+    after_first_reads();
+#pragma unroll
+    for (int nt = 0; nt < NTS; ++nt) {
+        const v4f wv = nt < 4 ? wg[nt < 4 ? nt : 0] : buf[nt * 64];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ga[r] = mfma16(wv[r], x[nt][r], ga[r]);
+    }
+    return (ga[0] + ga[1]) + (ga[2] + ga[3]);
+}
+
+template <int NTS>
+__global__ __launch_bounds__(256, 2) void k_gvp_chain_bwd(GvpEdgeBwdArgs a) {
+    constexpr int S = 16 * NTS, CH4 = NTS * 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int T = a.meta[8];
+    const int chunk_tiles = (T + 7) >> 3;
+    const int bi = blockIdx.x >> 3;
+    if (bi >= chunk_tiles) return;
+    const int tile = (blockIdx.x & 7) * chunk_tiles + bi;
+    if (tile >= T) return;
+    int et = 0;
+#pragma unroll
+    for (int e = 1; e < 4; ++e)
+        if (tile >= a.meta[4 + e]) et = e;
+    const int e0 = (tile - a.meta[4 + et]) * TM;
+    const int ne = min(TM, a.meta[et] - e0);
+    const int dnt = (et >= 2) ? 1 : 0;
+    const int n_gvps = a.n_gvps;
+    const GvpTrainSlot *fs = a.fwd + et;
+    const GvpBwdSlot *os = a.out + et;
+
+    // chunk sequence: GVP n - 1 .. 1 (NTS + 2 chunks each), then the head's four
+    constexpr int NG = NTS + 2;
+    const int total = (n_gvps - 1) * NG + 4;
+    const v4f *first = reinterpret_cast<const v4f *>(a.g[et][n_gvps - 1].chain);
+    auto chunk_src = [&](int c) -> const v4f * { return first + (size_t)c * CH4; };       // (chunks 0 and 1 only: every GVP has at least four)
+    ChunkRing<CH4, KPD_CHAIN_NBUF> ring;
+    ring.init(smem, total, wave, tid);
+    ring.start(chunk_src);
+
+    const int el = lane & 15, q = lane >> 4;
+    const int row = 16 * wave + el;
+    const bool live = row < ne;
+    const size_t erow = (size_t)(e0 + min(row, ne - 1));
+    const int vd = a.dst[et][erow];
+    float sc;
+    if (a.mode == 1) sc = 1.0f / (float)(a.rowptr[et][vd + 1] - a.rowptr[et][vd]);
+    else sc = 1.0f / (a.mode == 2 ? a.z[dnt][a.bidx[dnt][vd]] : a.norm);
+
+    // gradient of this edge's message = scale x gradient of the destination's aggregated messages
+    v4f acc[NTS], x[NTS], dV[3];
+    {
+        const float *gsp = a.gs[dnt] + (size_t)vd * S + 4 * q;
+#pragma unroll
+        for (int mt = 0; mt < NTS; ++mt) acc[mt] = *reinterpret_cast<const v4f *>(gsp + 16 * mt) * sc;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dV[c] = *reinterpret_cast<const v4f *>(a.gv[dnt] + (size_t)vd * 48 + 16 * c + 4 * q) * sc;
+    }
+    ring.first();
+
+#pragma unroll 1
+    for (int k = n_gvps - 1; k >= 1; --k) {
+        const GvpBwdW &w = a.g[et][k];
+        const GvpTrainGvp *f = &fs->g[k];
+        const GvpBwdGvp *o = &os->g[k];
+        const v4f *cb = reinterpret_cast<const v4f *>(w.chain), *nb = reinterpret_cast<const v4f *>(a.g[et][k - 1].chain);
+        auto ahead = [&](int i) -> const v4f * { return i + 2 < NG ? cb + (size_t)(i + 2) * CH4 : nb + (size_t)(i + 2 - NG) * CH4; };
+        const v4f dgate = gate_bwd_lane(f, o, dV, erow, live, q);
+        // kept pre-activation: requested before the gate chunk, used behind it
+        {
+            const float *pr = f->pre + erow * S + 4 * q;
+#pragma unroll
+            for (int mt = 0; mt < NTS; ++mt) x[mt] = *reinterpret_cast<const v4f *>(pr + 16 * mt);
+        }
+        chunk_gemm<NTS>(ring.current(), dgate, acc, lane, 4, [&] { ring.prefetch(ahead(0)); });
+        ring.release();
+#pragma unroll
+        for (int mt = 0; mt < NTS; ++mt) x[mt] = acc[mt] * silu_grad4(x[mt]);
+        if (live) {
+            float *dp = o->dpre + erow * S + 4 * q;
+#pragma unroll
+            for (int mt = 0; mt < NTS; ++mt) *reinterpret_cast<v4f *>(dp + 16 * mt) = x[mt];
+        }
+#pragma unroll
+        for (int mt = 0; mt < NTS; ++mt) acc[mt] = zero4();
+#pragma unroll
+        for (int nt = 0; nt < NTS; ++nt) {
+            chunk_gemm<NTS>(ring.current(), x[nt], acc, lane, 4, [&] { ring.prefetch(ahead(1 + nt)); });
+            ring.release();
+        }
+        const v4f dsh = chunk_tile_product<NTS>(ring.current(), x, lane, [&] { ring.prefetch(ahead(NTS + 1)); });
+        ring.release();
+        // vector half: dVh = Wu dVu + dsh Vh / |Vh| (where the clamp of the norm is inactive), dv_in = Wh dVh
+        v4f Vh[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Vh[c] = *reinterpret_cast<const v4f *>(f->Vh + (erow * 3 + c) * 16 + 4 * q);
+        const v4f sh = *reinterpret_cast<const v4f *>(f->sh + erow * 16 + 4 * q);
+        if (live) *reinterpret_cast<v4f *>(o->dsh + erow * 16 + 4 * q) = dsh;
+        const v4f wut = reinterpret_cast<const v4f *>(w.wut)[lane], wht = reinterpret_cast<const v4f *>(w.wht)[lane];
+        v4f nrm;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) nrm[r] = sh[r] * sh[r] > 1e-8f ? dsh[r] * rcp1(sh[r]) : 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            v4f t = zero4();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t = mfma16(wut[r], dV[c][r], t);
+            t += nrm * Vh[c];
+            v4f u = zero4();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) u = mfma16(wht[r], t[r], u);
+            dV[c] = u;
+        }
+    }
+
+    // head GVP: gates, SiLU', the rbf and |Vh| blocks; its source-scalar block and its 17-channel vector half are the caller's
+    {
+        const GvpTrainGvp *f = &fs->g[0];
+        const GvpBwdGvp *o = &os->g[0];
+        const v4f *hb = reinterpret_cast<const v4f *>(a.g[et][0].chain);
+        auto ahead = [&](int i) -> const v4f * { return hb + (size_t)(i + 2 < 4 ? i + 2 : 3) * CH4; };
+        const v4f dgate = gate_bwd_lane(f, o, dV, erow, live, q);
+        {
+            const float *pr = f->pre + erow * S + 4 * q;
+#pragma unroll
+            for (int mt = 0; mt < NTS; ++mt) x[mt] = *reinterpret_cast<const v4f *>(pr + 16 * mt);
+        }
+        chunk_gemm<NTS>(ring.current(), dgate, acc, lane, 4, [&] { ring.prefetch(ahead(0)); });
+        ring.release();
+#pragma unroll
+        for (int mt = 0; mt < NTS; ++mt) x[mt] = acc[mt] * silu_grad4(x[mt]);
+        if (live) {
+            float *dp = o->dpre + erow * S + 4 * q;
+#pragma unroll
+            for (int mt = 0; mt < NTS; ++mt) *reinterpret_cast<v4f *>(dp + 16 * mt) = x[mt];
+        }
+        const v4f drbf = chunk_tile_product<NTS>(ring.current(), x, lane, [&] { ring.prefetch(ahead(1)); });
+        ring.release();
+        const v4f dsh0 = chunk_tile_product<NTS>(ring.current(), x, lane, [&] { ring.prefetch(ahead(2)); });
+        ring.release();
+        const v4f dsh1 = chunk_tile_product<NTS>(ring.current(), x, lane, [&] { ring.prefetch(ahead(3)); });
+        ring.release();
+        if (live) {
+            *reinterpret_cast<v4f *>(os->drbf + erow * 16 + 4 * q) = drbf;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o->dsh[erow * 17 + 4 * q + r] = dsh0[r];
+            if (q == 0) o->dsh[erow * 17 + 16] = dsh1[0];
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the ring's tail fetches must not outlive the workgroup's LDS
+}
+
 // ---- node update (gvp.py:499-536), register-chained ---------------------------------------------------------
 // One wave = 16 nodes: aggregate the message pieces (per-etype sum or mean, cross-etype sum), s + msg / norm,
 // message GVPLayerNorm, the update GVP chain (chain_generic_gvp), residual, update GVPLayerNorm.  A node's S scalars
@@ -1013,6 +1211,22 @@ kpd_status launch_gvp_edge(const GvpEdgeArgs &a, int tile_cap, hipStream_t st) {
         hipLaunchKernelGGL(k_gvp_chain<16>, grid, dim3(256), ChainSmem<16>::FLOATS * 4, st, a);
     else
         hipLaunchKernelGGL(k_gvp_chain<8>, grid, dim3(256), ChainSmem<8>::FLOATS * 4, st, a);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+kpd_status launch_gvp_edge_bwd(const GvpEdgeBwdArgs &a, int tile_cap, hipStream_t st) {
+    if (tile_cap == 0) return KPD_OK;
+    if (poison_level() >= 1) KPD_TRY(poison_lds(st));      // debug only (engine.h)
+    KPD_REQUIRE(a.n_gvps >= 1 && a.n_gvps <= GVP_MAX_CHAIN && a.fwd && a.out && a.meta, KPD_ERR_INVALID, "gvp chain backward: bad arguments");
+    for (int et = 0; et < 4; ++et)
+        if (a.dst[et])
+            for (int k = 0; k < a.n_gvps; ++k)
+                KPD_REQUIRE(a.g[et][k].chain && (k == 0 || (a.g[et][k].wut && a.g[et][k].wht)), KPD_ERR_STATE,
+                            "message GVP %d of edge type %d was not packed for the chained backward kernel", k, et);
+    const int lds = KPD_CHAIN_NBUF * 16 * 64 * 16;
+    KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_chain_bwd<16>), lds));
+    hipLaunchKernelGGL(k_gvp_chain_bwd<16>, dim3(8 * cdiv(tile_cap, 8)), dim3(256), lds, st, a);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
 }

@@ -54,6 +54,40 @@ struct GvpEdgeArgs {
                                       // mv_main / mv_cont leave as [3][16], and every activation the backward pass reads is stored (device table [4])
 };
 
+// ---- backward of the message chains (training) ----------------------------------------------------------------------------------
+// One message GVP in backward form (packed from the current parameters by the trainer): 16-KB chunks in consumption order --
+//   generic GVP: Wg^T (scalar gradient from the gates), 16 k-slabs of to_feats_out[:, :256]^T, the |Vh| block^T (16 one-tile slabs);
+//   head GVP:    Wg^T, the rbf block^T, the two |Vh| tiles^T (its source-scalar block is differentiated per node by the caller);
+// and the 16 x 16 fragments of Wu^T / Wh^T (generic GVPs only: the head's vector half stays with k_gvp_vec17_bwd).
+struct GvpBwdW {
+    const float *chain, *wut, *wht;
+};
+// per edge type and message GVP: what the kernel leaves for the weight-gradient products and the vector-weight kernels (rows = edges)
+struct GvpBwdGvp {
+    float *dpre;          // [E][256]  dL/d pre-activation of to_feats_out
+    float *dgate;         // [E][16]   dL/d gate pre-activation
+    float *dVu;           // [E][3][16] dL/d (Vh Wu)
+    float *dsh;           // [E][16], head: [E][17]  dL/d |Vh|
+};
+struct GvpBwdSlot {
+    GvpBwdGvp g[4];
+    float *drbf;          // [E][16] dL/d rbf code (head GVP)
+};
+struct GvpEdgeBwdArgs {
+    const int *meta;              // as GvpEdgeArgs
+    const int *dst[4], *rowptr[4];
+    const float *gs[2], *gv[2];   // gradients of the aggregated messages per destination node type: [n][256], [n][3][16]
+    const float *z[2];            // per-graph normaliser (mode 2)
+    const int *bidx[2];
+    int mode;                     // message_norm_mode: 0 constant, 1 per-edge-type mean, 2 z[graph]
+    float norm;
+    GvpBwdW g[4][GVP_MAX_CHAIN];
+    int n_gvps;
+    const GvpTrainSlot *fwd;      // [4] kept activations (device table)
+    const GvpBwdSlot *out;        // [4] (device table)
+};
+kpd_status launch_gvp_edge_bwd(const GvpEdgeBwdArgs &a, int tile_cap, hipStream_t st);
+
 struct GvpNodeArgs {
     int n;
     float *s;                     // [n][S] in/out

@@ -76,6 +76,7 @@ struct kpd_gvp_trainer : TrainCtx {
     };
     struct ChainPack {
         GvpW g[4];
+        GvpBwdW bw[4];                               // the same GVPs in backward form (k_gvp_chain_bwd)
         const float *wproj = nullptr, *bproj = nullptr;
     };
     bool fused = false, pack_dirty = true;
@@ -84,6 +85,8 @@ struct kpd_gvp_trainer : TrainCtx {
     PackDesc *desc_dev = nullptr;
     int n_desc = 0, desc_cap = 0;
     GvpTrainSlot *slots_dev = nullptr;             // [conv * 4 + et]
+    GvpBwdSlot bslots[4];                          // per edge type: what the fused message backward leaves for the weight-gradient products
+    GvpBwdSlot *bslots_dev = nullptr;              // [4]
     float *Psrc[4] = {nullptr, nullptr, nullptr, nullptr};
     float *ms_main[4] = {nullptr, nullptr, nullptr, nullptr}, *ms_cont[4] = {nullptr, nullptr, nullptr, nullptr};
     float *mv_main[4] = {nullptr, nullptr, nullptr, nullptr}, *mv_cont[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -91,7 +94,8 @@ struct kpd_gvp_trainer : TrainCtx {
         if (pack_base) (void)hipFree(pack_base);
         if (desc_dev) (void)hipFree(desc_dev);
         if (slots_dev) (void)hipFree(slots_dev);
-        pack_base = nullptr; desc_dev = nullptr; slots_dev = nullptr;
+        if (bslots_dev) (void)hipFree(bslots_dev);
+        pack_base = nullptr; desc_dev = nullptr; slots_dev = nullptr; bslots_dev = nullptr;
         fused = false; pack_dirty = true; n_desc = desc_cap = 0;
     }
 };
@@ -246,8 +250,8 @@ __global__ __launch_bounds__(256) void k_gvp_msg_combine(CombineArgs a) {
 }
 
 constexpr size_t PK_CHUNK = 16 * 256;                                   // floats of one weight chunk (16 output tiles)
-constexpr size_t PK_HEAD = 4 * PK_CHUNK + 9 * 256 + 2 * 256 + 256 + 64 + 16 * PK_CHUNK + 256;      // chain | whp | wup | b | bg | wproj | bproj
-constexpr size_t PK_GENERIC = 18 * PK_CHUNK + 256 + 256 + 256 + 64;                                  // chain | whp | wup | b | bg
+constexpr size_t PK_HEAD = 4 * PK_CHUNK + 9 * 256 + 2 * 256 + 256 + 64 + 16 * PK_CHUNK + 256 + 4 * PK_CHUNK;      // chain | whp | wup | b | bg | wproj | bproj | backward chain
+constexpr size_t PK_GENERIC = 18 * PK_CHUNK + 256 + 256 + 256 + 64 + 18 * PK_CHUNK + 512;                            // chain | whp | wup | b | bg | backward chain | Wu^T | Wh^T
 inline size_t pack_floats_per_chain(int nm) { return PK_HEAD + (size_t)(nm - 1) * PK_GENERIC; }
 
 // carve the pack arena and (re)build the descriptor table from the bound parameters
@@ -300,6 +304,25 @@ kpd_status build_pack_table(kpd_gvp_trainer *T) {
                 float *gch = chain + (size_t)(chunks - 1) * PK_CHUNK;
                 for (int nt = 0; nt < 16; ++nt) frag(g.Wg.w, S, 1, VC, 16 * nt, 16, 1, gch + nt * 256);
                 copy(g.bg.w, VC, 16, bg);
+                // backward form (gvp_kernels.h, GvpBwdW): Wg^T, then the transposed k-slabs of to_feats_out and its narrow blocks as one-tile slabs
+                float *bch = take((size_t)chunks * PK_CHUNK);
+                GvpBwdW &bw = cp.bw[j];
+                bw.chain = bch; bw.wut = nullptr; bw.wht = nullptr;
+                frag(g.Wg.w, 1, S, S, 0, 16, 16, bch);
+                if (head) {
+                    for (int nt = 0; nt < 16; ++nt) {
+                        frag(g.Ws.w + S, 1, k_all, 16, 16 * nt, 16, 1, bch + PK_CHUNK + nt * 256);                       // rbf block
+                        frag(g.Ws.w + S + RBF, 1, k_all, 16, 16 * nt, 16, 1, bch + 2 * PK_CHUNK + nt * 256);             // |Vh| channels 0..15
+                        frag(g.Ws.w + S + RBF + 16, 1, k_all, 1, 16 * nt, 16, 1, bch + 3 * PK_CHUNK + nt * 256);        // |Vh| channel 16
+                    }
+                } else {
+                    for (int c = 0; c < 16; ++c) frag(g.Ws.w, 1, k_all, S, 16 * c, 16, 16, bch + (size_t)(1 + c) * PK_CHUNK);
+                    for (int nt = 0; nt < 16; ++nt) frag(g.Ws.w + S, 1, k_all, 16, 16 * nt, 16, 1, bch + 17 * PK_CHUNK + nt * 256);
+                    float *wut = take(256), *wht = take(256);
+                    frag(g.Wu.w, VC, 1, VC, 0, 16, 1, wut);          // dVh[h] = sum_o Wu[h][o] dVu[o]
+                    frag(g.Wh.w, VC, 1, VC, 0, 16, 1, wht);          // dv_in[i] = sum_h Wh[i][h] dVh[h]
+                    bw.wut = wut; bw.wht = wht;
+                }
             }
         }
     if ((int)descs.size() > T->desc_cap) {
@@ -421,6 +444,38 @@ kpd_status conv_fwd(kpd_gvp_trainer *T, int conv) {
     return KPD_OK;
 }
 
+// What is left of gvp_bwd (gvp_train_core.h) for a message GVP after k_gvp_chain_bwd: the parameter gradients, from the kernel's dpre / dgate /
+// dVu / d|Vh| and the kept activations -- the gate matrix, to_feats_out's scalar block (s_in: null at the head, whose source block is
+// differentiated per node) and its |Vh| block with the bias, and Wu / Wh through the vector kernels (which also leave dv_in: read at the
+// head -- the gradient of [x_diff | v_src] -- and redundant elsewhere).
+kpd_status gvp_bwd_rest(kpd_gvp_trainer *T, const GvpP &g, int M, const float *s_in, const float *v_in, const GvpBuf &B, const GvpBwdGvp &o,
+                        float *dv_in) {
+    if (M == 0) return KPD_OK;
+    KPD_TRY(grad_gemm(T, g.vo, g.so, M, o.dgate, g.vo, B.s, g.so, g.Wg.g, g.so, g.bg.g));
+    if (s_in && g.Ws.g) KPD_TRY(grad_gemm(T, g.so, g.si, M, o.dpre, g.so, s_in, g.si, g.Ws.g, g.si + g.h));
+    KPD_TRY(grad_gemm(T, g.so, g.h, M, o.dpre, g.so, B.sh, g.h, g.Ws.g ? g.Ws.g + g.si : nullptr, g.si + g.h, g.bs.g));
+    if (g.vi == 17) {
+        KPD_REQUIRE(T->part && T->part_floats >= (size_t)VEC16_MAX_WAVES * VEC17_PART, KPD_ERR_STATE, "split-sum scratch too small for the vector kernels");
+        const int blocks = std::max(1, std::min(cdiv(cdiv(M, 16), 4), std::min(2 * cu_count(), VEC16_MAX_WAVES / 4)));
+        hipLaunchKernelGGL(k_gvp_vec17_bwd, dim3(blocks), dim3(256), 0, T->st, o.dVu, B.Vh, B.sh, o.dsh, v_in, g.Wh.w, g.Wu.w, M, dv_in, T->part);
+        KPD_LAUNCH_CHECK();
+        if (g.Wu.g || g.Wh.g) {
+            hipLaunchKernelGGL(k_gvp_vec_reduce, dim3(cdiv(272 + 289, 16)), dim3(256), 0, T->st, T->part, blocks, VEC17_PART, 272, 289, g.Wu.g, g.Wh.g);
+            KPD_LAUNCH_CHECK();
+        }
+        return KPD_OK;
+    }
+    KPD_REQUIRE(T->part && T->part_floats >= (size_t)VEC16_MAX_WAVES * 512, KPD_ERR_STATE, "split-sum scratch too small for the vector kernels");
+    const int blocks = std::max(1, std::min(cdiv(cdiv(M, 16), 4), std::min(2 * cu_count(), VEC16_MAX_WAVES / 4)));
+    hipLaunchKernelGGL(k_gvp_vec16_bwd, dim3(blocks), dim3(256), 0, T->st, o.dVu, B.Vh, B.sh, o.dsh, v_in, g.Wh.w, g.Wu.w, M, dv_in, T->part);
+    KPD_LAUNCH_CHECK();
+    if (g.Wu.g || g.Wh.g) {
+        hipLaunchKernelGGL(k_gvp_vec_reduce, dim3(32), dim3(256), 0, T->st, T->part, blocks, 512, 256, 256, g.Wu.g, g.Wh.g);
+        KPD_LAUNCH_CHECK();
+    }
+    return KPD_OK;
+}
+
 // backward of conv: gs/gv[cur] = gradients of the conv outputs, gs/gv[nxt] = gradients of its inputs
 kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
     const int S = T->S, nm = T->cfg.n_message_gvps, nu = T->cfg.n_update_gvps;
@@ -464,6 +519,23 @@ kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
         // gs/gv[nxt] accumulate the source-side contributions
         KPD_TRY(dropout_apply(T, conv, nt, 0, n, T->gs[nxt][nt], T->gv[nxt][nt], T->gs[cur][nt], T->gv[cur][nt]));
     }
+    if (T->fused) {
+        // every edge type's message chain backward in one launch, gradients through registers (k_gvp_chain_bwd, gvp_chain.hip)
+        const bool all4 = conv_uses(T, conv, 2);
+        GvpEdgeBwdArgs ba;
+        memset(&ba, 0, sizeof(ba));
+        ba.meta = all4 ? T->meta : T->meta + 16;
+        int tiles = 0;
+        for (int et = 0; et < (all4 ? 4 : 2); ++et) {
+            ba.dst[et] = T->e_dst[et]; ba.rowptr[et] = T->e_rowptr[et];
+            for (int j = 0; j < nm; ++j) ba.g[et][j] = T->packs[(size_t)conv * 4 + et].bw[j];
+            tiles += cdiv(T->E[et], TM);
+        }
+        for (int nt = 0; nt < 2; ++nt) { ba.gs[nt] = T->gs[cur][nt]; ba.gv[nt] = T->gv[cur][nt]; ba.z[nt] = T->z[nt]; ba.bidx[nt] = T->bidx[nt]; }
+        ba.mode = T->cfg.message_norm_mode; ba.norm = T->cfg.message_norm; ba.n_gvps = nm;
+        ba.fwd = T->slots_dev + (size_t)conv * 4; ba.out = T->bslots_dev;
+        KPD_TRY(launch_gvp_edge_bwd(ba, tiles, T->st));
+    }
     for (int et = 0; et < 4; ++et) {
         if (!conv_uses(T, conv, et) || T->E[et] == 0) continue;
         const int E = T->E[et], s = kSrc[et], d = kDst[et];
@@ -471,23 +543,40 @@ kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
         GvpP g0;
         bind_msg(T, conv, et);
         KPD_TRY(message_fwd(T, conv, et, &g0, !T->store));
-        KPD_TRY(edge_scale(T, et));
-        // d(message of edge e) = scale[dst] * d(aggregate)[dst]
-        KPD_TRY(gather_rows(T->st, T->gs[cur][d], T->e_dst[et], T->scale, E, S, T->ds[0]));
-        KPD_TRY(gather_rows(T->st, T->gv[cur][d], T->e_dst[et], T->scale, E, 3 * VC, T->dV[0]));
-        for (int j = nm - 1; j >= 1; --j) {
-            GvpP g;
-            KPD_TRY(gvp_params(T, prefix + "." + std::to_string(j), VC, VC, S, S, &g));
-            KPD_TRY(gvp_bwd(T, g, E, T->gb[j - 1].s, S, T->gb[j - 1].V, T->gb[j], false, T->ds[0], T->dV[0], T->ds[1], T->dV[1]));
-            std::swap(T->ds[0], T->ds[1]);
-            std::swap(T->dV[0], T->dV[1]);
+        const float *dpre0 = nullptr, *drbf = nullptr;          // dL/dpre of the head GVP [E, S]; dL/d rbf [E, 16] (positions wanted)
+        if (T->fused) {
+            const GvpBwdSlot &bs = T->bslots[et];
+            for (int j = nm - 1; j >= 1; --j) {
+                GvpP g;
+                KPD_TRY(gvp_params(T, prefix + "." + std::to_string(j), VC, VC, S, S, &g));
+                KPD_TRY(gvp_bwd_rest(T, g, E, T->gb[j - 1].s, T->gb[j - 1].V, T->gb[j], bs.g[j], T->dV[0]));
+            }
+            KPD_TRY(gvp_bwd_rest(T, g0, E, nullptr, T->vin, T->gb[0], bs.g[0], T->dV[1]));
+            dpre0 = bs.g[0].dpre;
+            drbf = bs.drbf;
+        } else {
+            KPD_TRY(edge_scale(T, et));
+            // d(message of edge e) = scale[dst] * d(aggregate)[dst]
+            KPD_TRY(gather_rows(T->st, T->gs[cur][d], T->e_dst[et], T->scale, E, S, T->ds[0]));
+            KPD_TRY(gather_rows(T->st, T->gv[cur][d], T->e_dst[et], T->scale, E, 3 * VC, T->dV[0]));
+            for (int j = nm - 1; j >= 1; --j) {
+                GvpP g;
+                KPD_TRY(gvp_params(T, prefix + "." + std::to_string(j), VC, VC, S, S, &g));
+                KPD_TRY(gvp_bwd(T, g, E, T->gb[j - 1].s, S, T->gb[j - 1].V, T->gb[j], false, T->ds[0], T->dV[0], T->ds[1], T->dV[1]));
+                std::swap(T->ds[0], T->ds[1]);
+                std::swap(T->dV[0], T->dV[1]);
+            }
+            KPD_TRY(gvp_bwd(T, g0, E, nullptr, 0, T->vin, T->gb[0], false, T->ds[0], T->dV[0], nullptr, T->dV[1]));
+            dpre0 = T->ds[0];
+            if (T->want_x) {        // d rbf = dpre W[:, S:S+16] (dsh is free again)
+                KPD_TRY(gemm(T, false, false, E, RBF, S, T->ds[0], S, g0.Ws.w + S, g0.si + g0.h, 0.0f, T->dsh, RBF));
+                drbf = T->dsh;
+            }
         }
-        KPD_TRY(gvp_bwd(T, g0, E, nullptr, 0, T->vin, T->gb[0], false, T->ds[0], T->dV[0], nullptr, T->dV[1]));
         if (T->want_x) {
-            // positions (gvp.py:472-480): d rbf = dpre W[:, S:S+16] (dsh is free again), d unit = channel 0 of d vin
+            // positions (gvp.py:472-480): through the rbf code and through the unit vector = channel 0 of d vin
             const float *xs = s == NT_LIG ? T->bt.lig_x : T->bt.kp_x, *xd = d == NT_LIG ? T->bt.lig_x : T->bt.kp_x;
-            KPD_TRY(gemm(T, false, false, E, RBF, S, T->ds[0], S, g0.Ws.w + S, g0.si + g0.h, 0.0f, T->dsh, RBF));
-            hipLaunchKernelGGL(k_gvp_geom_bwd, grid1(E), dim3(256), 0, T->st, T->e_src[et], T->e_dst[et], xs, xd, E, 15.0f, T->rbf, T->dsh,
+            hipLaunchKernelGGL(k_gvp_geom_bwd, grid1(E), dim3(256), 0, T->st, T->e_src[et], T->e_dst[et], xs, xd, E, 15.0f, T->rbf, drbf,
                                T->dV[1], VH, T->dxe);
             KPD_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_seg3, grid1(T->n[s]), dim3(256), 0, T->st, T->dxe, T->scsr[et].perm, T->scsr[et].rowptr, T->n[s], 1.0f, T->gx[s]);
@@ -495,10 +584,10 @@ kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
             hipLaunchKernelGGL(k_seg3, grid1(T->n[d]), dim3(256), 0, T->st, T->dxe, (const int *)nullptr, T->e_rowptr[et], T->n[d], -1.0f, T->gx[d]);
             KPD_LAUNCH_CHECK();
         }
-        // ds[0] = dL/dpre of the first GVP: its scalar inputs were U[src] and rbf
-        if (g0.Ws.g) KPD_TRY(grad_gemm(T, S, RBF, E, T->ds[0], S, T->rbf, RBF, g0.Ws.g + S, g0.si + g0.h));
+        // dpre0 = dL/dpre of the first GVP: its scalar inputs were U[src] and rbf
+        if (g0.Ws.g) KPD_TRY(grad_gemm(T, S, RBF, E, dpre0, S, T->rbf, RBF, g0.Ws.g + S, g0.si + g0.h));
         // sums over the out-edges of every source node, in ascending edge order (no float atomics)
-        KPD_TRY(segsum(T->st, T->ds[0], S, 0, S, T->scsr[et].perm, T->scsr[et].rowptr, nullptr, 1.0f, false, T->n[s], T->U, S));
+        KPD_TRY(segsum(T->st, dpre0, S, 0, S, T->scsr[et].perm, T->scsr[et].rowptr, nullptr, 1.0f, false, T->n[s], T->U, S));
         if (g0.Ws.g) KPD_TRY(grad_gemm(T, S, S, T->n[s], T->U, S, T->ss[s][conv], S, g0.Ws.g, g0.si + g0.h));
         KPD_TRY(gemm(T, false, false, T->n[s], S, S, T->U, S, g0.Ws.w, g0.si + g0.h, 1.0f, T->gs[nxt][s], S));
         for (int cc = 0; cc < 3; ++cc) {      // vector rows [E, 3, 17], channels 1..16 -> gv[src, 3, 16]
@@ -804,6 +893,9 @@ extern "C" kpd_status kpd_gvp_trainer_reserve(kpd_gvp_trainer *T, int32_t max_B,
                 off_vmain[et] = floats; floats += (size_t)nn[kDst[et]] * 48;
                 off_vcont[et] = floats; floats += tiles * 48;
             }
+            size_t off_b[4];
+            const size_t bwd_per_edge = (size_t)nm * (256 + 16 + 48 + 17) + 16;
+            for (int et = 0; et < 4; ++et) { off_b[et] = floats; floats += (size_t)cap_et[et] * bwd_per_edge + 64; }
             std::vector<GvpTrainSlot> hs((size_t)L * 4);
             memset(hs.data(), 0, hs.size() * sizeof(GvpTrainSlot));
             for (size_t i = 0; i < hs.size(); ++i) {
@@ -815,7 +907,22 @@ extern "C" kpd_status kpd_gvp_trainer_reserve(kpd_gvp_trainer *T, int32_t max_B,
                 }
             }
             if (hipMalloc(reinterpret_cast<void **>(&T->pack_base), floats * 4) == hipSuccess &&
-                hipMalloc(reinterpret_cast<void **>(&T->slots_dev), hs.size() * sizeof(GvpTrainSlot)) == hipSuccess) {
+                hipMalloc(reinterpret_cast<void **>(&T->slots_dev), hs.size() * sizeof(GvpTrainSlot)) == hipSuccess &&
+                hipMalloc(reinterpret_cast<void **>(&T->bslots_dev), 4 * sizeof(GvpBwdSlot)) == hipSuccess) {
+                for (int et = 0; et < 4; ++et) {
+                    float *p = T->pack_base + off_b[et];
+                    const size_t E = cap_et[et];
+                    GvpBwdSlot &bs = T->bslots[et];
+                    memset(&bs, 0, sizeof(bs));
+                    for (int j = 0; j < nm; ++j) {
+                        bs.g[j].dpre = p; p += E * 256;
+                        bs.g[j].dgate = p; p += E * 16;
+                        bs.g[j].dVu = p; p += E * 48;
+                        bs.g[j].dsh = p; p += (E * 17 + 3) & ~size_t(3);          // (keeps the next block 16-byte aligned)
+                    }
+                    bs.drbf = p;
+                }
+                KPD_HIP(hipMemcpy(T->bslots_dev, T->bslots, 4 * sizeof(GvpBwdSlot), hipMemcpyHostToDevice));
                 KPD_HIP(hipMemset(T->pack_base, 0, pack_floats * 4));           // zero biases of the head GVPs, unused fragment tiles
                 KPD_HIP(hipMemcpy(T->slots_dev, hs.data(), hs.size() * sizeof(GvpTrainSlot), hipMemcpyHostToDevice));
                 for (int et = 0; et < 4; ++et) {
