@@ -249,6 +249,9 @@ __global__ __launch_bounds__(256) void k_gvp_msg_combine(CombineArgs a) {
     if (lane < 12) *reinterpret_cast<v4f *>(a.va + (size_t)v * 48 + 4 * lane) = w;
 }
 
+// split-sum scratch: one share per CU of a batched message-chain weight gradient (256 x 256 + the narrow riders, wgrad_batch) with slack for
+// the rounding of the per-product slice counts
+constexpr size_t GVP_PART_FLOATS = std::max<size_t>(GRAD_PART_FLOATS, (size_t)320 * (256 * 256 + 256 * 17 + 256 + 16 * 256));
 constexpr size_t PK_CHUNK = 16 * 256;                                   // floats of one weight chunk (16 output tiles)
 constexpr size_t PK_HEAD = 4 * PK_CHUNK + 9 * 256 + 2 * 256 + 256 + 64 + 16 * PK_CHUNK + 256 + 4 * PK_CHUNK;      // chain | whp | wup | b | bg | wproj | bproj | backward chain
 constexpr size_t PK_GENERIC = 18 * PK_CHUNK + 256 + 256 + 256 + 64 + 18 * PK_CHUNK + 512;                            // chain | whp | wup | b | bg | backward chain | Wu^T | Wh^T
@@ -448,12 +451,18 @@ kpd_status conv_fwd(kpd_gvp_trainer *T, int conv) {
 // dVu / d|Vh| and the kept activations -- the gate matrix, to_feats_out's scalar block (s_in: null at the head, whose source block is
 // differentiated per node) and its |Vh| block with the bias, and Wu / Wh through the vector kernels (which also leave dv_in: read at the
 // head -- the gradient of [x_diff | v_src] -- and redundant elsewhere).
+// skip: REST_SKIP_WG -- the gate matrix's gradient rides in another product (only its bias is summed here); REST_SKIP_WS -- so do
+// to_feats_out's blocks and bias (wgrad_batch, sgemm.hip)
+constexpr int REST_SKIP_WG = 1, REST_SKIP_WS = 2;
 kpd_status gvp_bwd_rest(kpd_gvp_trainer *T, const GvpP &g, int M, const float *s_in, const float *v_in, const GvpBuf &B, const GvpBwdGvp &o,
-                        float *dv_in) {
+                        float *dv_in, int skip) {
     if (M == 0) return KPD_OK;
-    KPD_TRY(grad_gemm(T, g.vo, g.so, M, o.dgate, g.vo, B.s, g.so, g.Wg.g, g.so, g.bg.g));
-    if (s_in && g.Ws.g) KPD_TRY(grad_gemm(T, g.so, g.si, M, o.dpre, g.so, s_in, g.si, g.Ws.g, g.si + g.h));
-    KPD_TRY(grad_gemm(T, g.so, g.h, M, o.dpre, g.so, B.sh, g.h, g.Ws.g ? g.Ws.g + g.si : nullptr, g.si + g.h, g.bs.g));
+    if (!(skip & REST_SKIP_WG)) KPD_TRY(grad_gemm(T, g.vo, g.so, M, o.dgate, g.vo, B.s, g.so, g.Wg.g, g.so, g.bg.g));
+    else if (g.bg.g) KPD_TRY(colsum_acc(T, M, g.vo, o.dgate, g.vo, g.bg.g));
+    if (!(skip & REST_SKIP_WS)) {
+        if (s_in && g.Ws.g) KPD_TRY(grad_gemm(T, g.so, g.si, M, o.dpre, g.so, s_in, g.si, g.Ws.g, g.si + g.h));
+        KPD_TRY(grad_gemm(T, g.so, g.h, M, o.dpre, g.so, B.sh, g.h, g.Ws.g ? g.Ws.g + g.si : nullptr, g.si + g.h, g.bs.g));
+    }
     if (g.vi == 17) {
         KPD_REQUIRE(T->part && T->part_floats >= (size_t)VEC16_MAX_WAVES * VEC17_PART, KPD_ERR_STATE, "split-sum scratch too small for the vector kernels");
         const int blocks = std::max(1, std::min(cdiv(cdiv(M, 16), 4), std::min(2 * cu_count(), VEC16_MAX_WAVES / 4)));
@@ -536,6 +545,7 @@ kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
         ba.fwd = T->slots_dev + (size_t)conv * 4; ba.out = T->bslots_dev;
         KPD_TRY(launch_gvp_edge_bwd(ba, tiles, T->st));
     }
+    std::vector<WgradItem> wq;
     for (int et = 0; et < 4; ++et) {
         if (!conv_uses(T, conv, et) || T->E[et] == 0) continue;
         const int E = T->E[et], s = kSrc[et], d = kDst[et];
@@ -545,13 +555,30 @@ kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
         KPD_TRY(message_fwd(T, conv, et, &g0, !T->store));
         const float *dpre0 = nullptr, *drbf = nullptr;          // dL/dpre of the head GVP [E, S]; dL/d rbf [E, 16] (positions wanted)
         if (T->fused) {
+            // Parameter gradients.  The 256 x 256 block of GVP j's to_feats_out (dpre_j^T s_{j-1}) takes its |Vh| block and bias and the gate
+            // matrix of GVP j - 1 (dgate_{j-1}^T s_{j-1}: the same s) along as narrow riders; the products of all edge types wait in wq and
+            // go out as one launch per conv (wgrad_batch).
             const GvpBwdSlot &bs = T->bslots[et];
+            GvpP gp[4];
+            gp[0] = g0;
+            for (int j = 1; j < nm; ++j) KPD_TRY(gvp_params(T, prefix + "." + std::to_string(j), VC, VC, S, S, &gp[j]));
+            int skip[4] = {0, 0, 0, 0};
             for (int j = nm - 1; j >= 1; --j) {
-                GvpP g;
-                KPD_TRY(gvp_params(T, prefix + "." + std::to_string(j), VC, VC, S, S, &g));
-                KPD_TRY(gvp_bwd_rest(T, g, E, T->gb[j - 1].s, T->gb[j - 1].V, T->gb[j], bs.g[j], T->dV[0]));
+                if (gp[j].Ws.g && gp[j].bs.g && gp[j - 1].Wg.g) {
+                    WgradItem it;
+                    memset(&it, 0, sizeof(it));
+                    it.A = bs.g[j].dpre; it.lda = S; it.B = T->gb[j - 1].s; it.ldb = S; it.K = E;
+                    it.C = gp[j].Ws.g; it.ldc = gp[j].si + gp[j].h;
+                    it.B2 = T->gb[j].sh; it.ldb2 = gp[j].h; it.nb2 = gp[j].h; it.Cx1 = gp[j].Ws.g + gp[j].si; it.ldx1 = it.ldc;
+                    it.colsum = gp[j].bs.g;
+                    it.A2 = bs.g[j - 1].dgate; it.lda2 = VC; it.na2 = VC; it.Cx2 = gp[j - 1].Wg.g; it.ldx2 = S;
+                    wq.push_back(it);
+                    skip[j] |= REST_SKIP_WS;
+                    skip[j - 1] |= REST_SKIP_WG;
+                }
+                KPD_TRY(gvp_bwd_rest(T, gp[j], E, T->gb[j - 1].s, T->gb[j - 1].V, T->gb[j], bs.g[j], T->dV[0], skip[j]));
             }
-            KPD_TRY(gvp_bwd_rest(T, g0, E, nullptr, T->vin, T->gb[0], bs.g[0], T->dV[1]));
+            KPD_TRY(gvp_bwd_rest(T, g0, E, nullptr, T->vin, T->gb[0], bs.g[0], T->dV[1], skip[0]));
             dpre0 = bs.g[0].dpre;
             drbf = bs.drbf;
         } else {
@@ -595,6 +622,7 @@ kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
                            T->gv[nxt][s] + cc * VC, 3 * VC));
         }
     }
+    for (size_t i = 0; i < wq.size(); i += 8) KPD_TRY(wgrad_batch(wq.data() + i, (int)std::min<size_t>(8, wq.size() - i), T->part, T->part_floats, T->st));
     bind_msg(T, -1, -1);
     return KPD_OK;
 }
@@ -816,7 +844,7 @@ extern "C" kpd_status kpd_gvp_trainer_reserve(kpd_gvp_trainer *T, int32_t max_B,
         const size_t N = std::max(max_n_lig, max_n_kp);
         F(T->U, N * S); F(T->scale, N); F(T->tmp_s, N * S); F(T->tmp_v, N * 3 * VC); F(T->s1, N * S); F(T->v1, N * 3 * VC);
         F(T->sb, N * std::max(S, 256)); F(T->vb, N * 3 * VC);
-        F(T->part, GRAD_PART_FLOATS);
+        F(T->part, GVP_PART_FLOATS);
         F(T->wsg_pack, (size_t)ws_gemm_pack_floats());
         F(T->ones, 8);
         const int cap_et[4] = {cap_ll, cap_kl, cap_kl, std::max<int>(max_n_kk, 1)};
@@ -832,7 +860,7 @@ extern "C" kpd_status kpd_gvp_trainer_reserve(kpd_gvp_trainer *T, int32_t max_B,
         if (pass == 0) KPD_TRY(T->ws.reserve(bytes + 4096));
     }
     KPD_REQUIRE(T->lg.counts != nullptr, KPD_ERR_HIP, "workspace arena too small (internal sizing error)");
-    T->part_floats = GRAD_PART_FLOATS;
+    T->part_floats = GVP_PART_FLOATS;
     T->lg.cap_ll = cap_ll; T->lg.cap_kl = cap_kl;
     T->colpart_blocks = cdiv(R, HEAD_ROWS);
     T->scratch.unit = T->unit; T->scratch.rbf = T->rbf; T->scratch.vin = T->vin;
@@ -887,6 +915,7 @@ extern "C" kpd_status kpd_gvp_trainer_reserve(kpd_gvp_trainer *T, int32_t max_B,
             size_t off_P[4], off_main[4], off_cont[4], off_vmain[4], off_vcont[4];
             for (int et = 0; et < 4; ++et) {
                 const size_t tiles = (size_t)cap_et[et] / TM + 2;
+                floats = (floats + 63) & ~size_t(63);
                 off_P[et] = floats; floats += (size_t)nn[kSrc[et]] * 256;
                 off_main[et] = floats; floats += (size_t)nn[kDst[et]] * 256;
                 off_cont[et] = floats; floats += tiles * 256;
@@ -895,7 +924,11 @@ extern "C" kpd_status kpd_gvp_trainer_reserve(kpd_gvp_trainer *T, int32_t max_B,
             }
             size_t off_b[4];
             const size_t bwd_per_edge = (size_t)nm * (256 + 16 + 48 + 17) + 16;
-            for (int et = 0; et < 4; ++et) { off_b[et] = floats; floats += (size_t)cap_et[et] * bwd_per_edge + 64; }
+            for (int et = 0; et < 4; ++et) {
+                floats = (floats + 63) & ~size_t(63);          // (256-byte aligned blocks: the kernels store float4)
+                off_b[et] = floats;
+                floats += (((size_t)cap_et[et] * bwd_per_edge + 16 * (size_t)nm) + 63) & ~size_t(63);
+            }
             std::vector<GvpTrainSlot> hs((size_t)L * 4);
             memset(hs.data(), 0, hs.size() * sizeof(GvpTrainSlot));
             for (size_t i = 0; i < hs.size(); ++i) {

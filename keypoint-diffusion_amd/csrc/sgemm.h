@@ -19,6 +19,25 @@ kpd_status sgemm(bool tA, bool tB, int M, int N, int K, float alpha, const float
 // the pre-activation (C) kept for the backward pass
 // slices that give every CU about two workgroups for a [M,N] output, bounded by K / 256
 int sgemm_split_slices(int M, int N, int K);
+// Weight gradients of edge-sized products with a 256 x 256 output, several per launch (k_wgrad_tnx), every output ACCUMULATED (+=):
+//   C [256, 256] += A^T B;   Cx1 [256, nb2] += A^T B2 (nb2 <= 31);   colsum [256] += column sums of A;   Cx2 [na2, 256] += A2^T B (na2 <= 32)
+// A, B: [K, 256] (16-byte aligned, leading dimensions multiples of 4); B2 [K, ldb2], A2 [K, lda2] any alignment.
+struct WgradItem {
+    const float *A, *B;
+    int lda, ldb, K;
+    float *C;
+    int ldc;
+    const float *B2;
+    int ldb2, nb2;
+    float *Cx1;
+    int ldx1;
+    float *colsum;
+    const float *A2;
+    int lda2, na2;
+    float *Cx2;
+    int ldx2;
+};
+kpd_status wgrad_batch(const WgradItem *items, int n, float *part, size_t part_floats, hipStream_t st);
 // y[m * incy] = beta y + sum_k A[m][k] x[k * incx]
 kpd_status sgemv_rows(int M, int K, const float *A, int lda, const float *x, int incx, float beta, float *y, int incy, hipStream_t st);
 

@@ -20,6 +20,8 @@
 #include <algorithm>
 
 #include "engine.h"
+#include <cstring>
+
 #include "sgemm.h"
 
 namespace kpd {
@@ -634,6 +636,163 @@ __global__ __launch_bounds__(512, 1) void k_sgemm_tn256(SgemmArgs a) {
     }
 }
 
+// ---- weight gradients of a GVP message chain, several products per launch -----------------------------------------------------------------
+// k_sgemm_tn256 with two narrow products riding on the operand slabs it streams anyway, as MFMA blocks instead of VALU riders:
+//   C  [256, 256] += A^T B      (to_feats_out's scalar block: A = dpre of GVP j, B = the kept scalars of GVP j - 1)
+//   X1 [256, nb2] += A^T B2     (its |Vh| block: B2 = the kept vector norms, nb2 <= 31; column 31 of the B2 tile is 1: the bias gradient)
+//   X2 [na2, 256] += A2^T B     (the gate matrix of GVP j - 1: A2 = its dgate, na2 <= 32)
+// Wave (wr, wc) adds one 32 x 32 block of X1 (rows 64 wr + 32 wc ..) and one of X2 (columns 128 wc + 32 wr ..) to its 2 x 4 blocks of C,
+// re-using an A and a B fragment it has already read: + 2 LDS reads and + 2 MFMAs per 8.  The narrow operands travel one slab ahead
+// through one register per thread and operand into a 2 x 2 KB LDS tile.  Before, each of the two narrow products was a launch of its own
+// over the same [E, 256] arrays, bandwidth-bound at a third of HBM speed.
+// Several products share one launch (block -> (product, K slice) by a prefix table), each with a share of the CUs proportional to its K:
+// a conv's six edge-sized products then write 256 partial tiles together instead of 256 each, and the reductions read a sixth.
+struct WgradProd {
+    const float *A, *B, *B2, *A2;
+    int lda, ldb, ldb2, lda2, nb2, na2, K, k_chunk, slices, first;
+    float *part;            // main [slices][65536] | x1 [slices][256 nb2] | colsum [slices][256] | x2 [slices][na2 256]
+};
+constexpr int WGRAD_MAX = 8;
+struct WgradBatch {
+    int n;
+    WgradProd p[WGRAD_MAX];
+};
+
+__global__ __launch_bounds__(512, 1) void k_wgrad_tnx(WgradBatch bt) {
+    constexpr int ROW = 256, SLAB = SG_BK * ROW, STAGE = 2 * SLAB, NSTAGE = TN256_STAGES;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float xbuf[2][2][SG_BK][32];          // [slab parity][B2 | A2][k][column]
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < WGRAD_MAX; ++i)
+        if (i < bt.n && (int)blockIdx.x >= bt.p[i].first) pi = i;
+    const WgradProd &a = bt.p[pi];
+    const int slice = (int)blockIdx.x - a.first;
+    if (slice >= a.slices) return;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, col = lane & 31, half = lane >> 5, wr = wave >> 1, wc = wave & 1;
+    const int kbeg = slice * a.k_chunk, kend = min(a.K, kbeg + a.k_chunk);
+    const int nk = (kend - kbeg + SG_BK - 1) / SG_BK, nk_full = (kend - kbeg) / SG_BK;
+    v16f acc[2][4], ax1, ax2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        ax1[r] = 0.0f; ax2[r] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j][r] = 0.0f;
+    }
+    auto issue = [&](int kt) {
+        float *st = smem + (kt % NSTAGE) * STAGE;
+        const size_t k0 = (size_t)kbeg + (size_t)kt * SG_BK;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = wave + 8 * j;
+            __builtin_amdgcn_global_load_lds((glb_void *)(a.A + (k0 + row) * a.lda + 4 * lane), (lds_void *)(st + row * ROW), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void *)(a.B + (k0 + row) * a.ldb + 4 * lane), (lds_void *)(st + SLAB + row * ROW), 16, 0, 0);
+        }
+    };
+    auto wait_behind = [&](int slabs) {
+        if (slabs <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (slabs == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    };
+    // the narrow operands of slab kt: thread t carries element (k = t >> 5, c = t & 31) of the B2 tile and of the A2 tile
+    const int xk = tid >> 5, xc = tid & 31;
+    const bool b2_live = a.B2 != nullptr && xc < a.nb2, a2_live = a.A2 != nullptr && xc < a.na2;
+    const float *b2p = a.B2 ? a.B2 + min(xc, max(a.nb2 - 1, 0)) : a.A, *a2p = a.A2 ? a.A2 + min(xc, max(a.na2 - 1, 0)) : a.A;
+    const int ld2b = a.B2 ? a.ldb2 : a.lda, ld2a = a.A2 ? a.lda2 : a.lda;
+    float xvb = 0.0f, xva = 0.0f;
+    auto xfetch = [&](int kt) {
+        const int k = kbeg + kt * SG_BK + xk;
+        const size_t kk = (size_t)min(k, kend - 1);
+        const bool in = k < kend;
+        xvb = xc == 31 ? (in ? 1.0f : 0.0f) : masked(b2p[kk * ld2b], in && b2_live);
+        xva = masked(a2p[kk * ld2a], in && a2_live);
+    };
+    auto xstash = [&](int kt) {
+        xbuf[kt & 1][0][xk][xc] = xvb;
+        xbuf[kt & 1][1][xk][xc] = xva;
+    };
+    auto compute = [&](const float *st, int kt) {
+        const float *as = st + 64 * wr + col, *bs = st + SLAB + 128 * wc + col;
+        const float *xb = &xbuf[kt & 1][0][0][col], *xa = &xbuf[kt & 1][1][0][col];
+#pragma unroll
+        for (int ks = 0; ks < SG_BK / 2; ++ks) {
+            const int k = 2 * ks + half;
+            float av[2], bv[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[i] = as[k * ROW + 32 * i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[j] = bs[k * ROW + 32 * j];
+            const float b2 = xb[k * 32], a2 = xa[k * 32];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            ax1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wc ? av[1] : av[0], b2, ax1, 0, 0, 0);
+            const float bsel = wr == 0 ? bv[0] : wr == 1 ? bv[1] : wr == 2 ? bv[2] : bv[3];
+            ax2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, bsel, ax2, 0, 0, 0);
+        }
+    };
+
+    const int ahead = min(NSTAGE - 1, nk_full);
+    xfetch(0);
+    for (int kt = 0; kt < ahead; ++kt) issue(kt);
+    xstash(0);
+    wait_behind(ahead - 1);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll 1
+    for (int kt = 0; kt < nk_full; ++kt) {
+        if (kt + 1 < nk) xfetch(kt + 1);
+        if (kt + NSTAGE - 1 < nk_full) issue(kt + NSTAGE - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const float *st = smem + (kt % NSTAGE) * STAGE;
+        compute(st, kt);
+        if (kt + 1 < nk) xstash(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        wait_behind(min(kt + NSTAGE - 1, nk_full - 1) - (kt + 1));
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    if (nk > nk_full) {          // K tail of this range: rows past kend read a clamped address and are replaced by zero
+        float *st = smem;
+        const int k0 = kbeg + nk_full * SG_BK;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int u = tid + 512 * j, op = u >> 10, row = (u & 1023) >> 6, c4 = u & 63;
+            const int k = min(k0 + row, kend - 1);
+            v4f v = *reinterpret_cast<const v4f *>((op ? a.B + (size_t)k * a.ldb : a.A + (size_t)k * a.lda) + 4 * c4);
+            const bool in = k0 + row < kend;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = masked(v[e], in);
+            *reinterpret_cast<v4f *>(st + op * SLAB + row * ROW + 4 * c4) = v;
+        }
+        __syncthreads();
+        compute(st, nk_full);
+    }
+    // shares of this K range
+    float *C = a.part + (size_t)slice * (ROW * ROW);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                C[(size_t)(64 * wr + 32 * i + 8 * (r >> 2) + 4 * half + (r & 3)) * ROW + 128 * wc + 32 * j + col] = acc[i][j][r];
+    float *x1 = a.part + (size_t)a.slices * (ROW * ROW) + (size_t)slice * (ROW * a.nb2);
+    float *cs = a.part + (size_t)a.slices * (ROW * ROW + ROW * a.nb2) + (size_t)slice * ROW;
+    float *x2 = a.part + (size_t)a.slices * (ROW * ROW + ROW * a.nb2 + ROW) + (size_t)slice * (a.na2 * ROW);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rr = 8 * (r >> 2) + 4 * half + (r & 3);
+        const int m = 64 * wr + 32 * wc + rr;
+        if (col < a.nb2) x1[m * a.nb2 + col] = ax1[r];
+        if (col == 31) cs[m] = ax1[r];
+        if (rr < a.na2) x2[rr * ROW + 128 * wc + 32 * wr + col] = ax2[r];
+    }
+}
+
 // Sums of the split-K shares.  Up to six kinds of output share one launch, each a run of elements whose shares lie `stride` floats apart
 // from slice to slice: the tiles (element (r, c) -> C[r][c]), the column sums of A, the column fringe (-> C[r][xc]), the row fringe
 // (-> C[xr][c]), the corner, the fringe row's column sum.  An output element is summed by FOUR adjacent lanes, each over a quarter of
@@ -832,6 +991,64 @@ kpd_status sgemm(bool tA, bool tB, int M, int N, int K, float alpha, const float
             if (a.xr >= 0 && colsum) r.seg[r.n_seg++] = RedSeg{a.x_part + Mt + Nt + 1, xs, 1, colsum + a.xr, 0, 1, 1};
         }
         return launch_reduce(r, st);
+    }
+    return KPD_OK;
+}
+
+kpd_status wgrad_batch(const WgradItem *items, int n, float *part, size_t part_floats, hipStream_t st) {
+    if (n <= 0) return KPD_OK;
+    KPD_REQUIRE(n <= WGRAD_MAX && part, KPD_ERR_INVALID, "wgrad_batch: %d products (at most %d) / no scratch", n, WGRAD_MAX);
+    WgradBatch bt;
+    memset(&bt, 0, sizeof(bt));
+    long long ksum = 0;
+    for (int i = 0; i < n; ++i) {
+        const WgradItem &it = items[i];
+        KPD_REQUIRE(it.A && it.B && it.C && it.K >= 1 && (it.lda & 3) == 0 && (it.ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(it.A) & 15) == 0 &&
+                        (reinterpret_cast<uintptr_t>(it.B) & 15) == 0 && it.nb2 >= 0 && it.nb2 <= 31 && it.na2 >= 0 && it.na2 <= 32 &&
+                        (it.nb2 == 0 || (it.B2 && it.Cx1)) && (it.na2 == 0 || (it.A2 && it.Cx2)),
+                    KPD_ERR_INVALID, "wgrad_batch: bad product %d", i);
+        ksum += it.K;
+    }
+    const int cus = cu_count();
+    size_t used = 0;
+    int first = 0;
+    for (int i = 0; i < n; ++i) {
+        const WgradItem &it = items[i];
+        WgradProd &p = bt.p[i];
+        p.A = it.A; p.B = it.B; p.B2 = it.nb2 ? it.B2 : nullptr; p.A2 = it.na2 ? it.A2 : nullptr;
+        p.lda = it.lda; p.ldb = it.ldb; p.ldb2 = it.ldb2; p.lda2 = it.lda2; p.nb2 = it.nb2; p.na2 = it.na2; p.K = it.K;
+        const size_t per_slice = (size_t)256 * 256 + 256 * it.nb2 + 256 + (size_t)it.na2 * 256;
+        // a share of the CUs proportional to K, a slice at least 256 rows deep
+        int sl = (int)std::max<long long>(1, ((long long)cus * it.K + ksum / 2) / ksum);
+        sl = std::min(sl, std::max(1, it.K / 256));
+        sl = (int)std::min<size_t>(sl, (part_floats - used) / per_slice / (size_t)(n - i));
+        KPD_REQUIRE(sl >= 1, KPD_ERR_CAPACITY, "wgrad_batch: split-sum scratch too small");
+        p.k_chunk = cdiv(cdiv(it.K, sl), SG_BK) * SG_BK;
+        p.slices = cdiv(it.K, p.k_chunk);
+        p.first = first;
+        first += p.slices;
+        p.part = part + used;
+        used += (size_t)p.slices * per_slice;
+    }
+    bt.n = n;
+    constexpr int lds = TN256_STAGES * 2 * SG_BK * 256 * 4;
+    KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_wgrad_tnx), lds));
+    hipLaunchKernelGGL(k_wgrad_tnx, dim3(first), dim3(512), lds, st, bt);
+    KPD_LAUNCH_CHECK();
+    for (int i = 0; i < n; ++i) {
+        const WgradItem &it = items[i];
+        const WgradProd &p = bt.p[i];
+        RedArgs r;
+        r.n_seg = 0; r.slices = p.slices; r.beta = 1.0f;
+        float *q = p.part;
+        r.seg[r.n_seg++] = RedSeg{q, 65536, 65536, it.C, 256, it.ldc, 0};
+        q += (size_t)p.slices * 65536;
+        if (it.nb2) r.seg[r.n_seg++] = RedSeg{q, (long long)256 * it.nb2, 256 * it.nb2, it.Cx1, it.nb2, it.ldx1, 0};
+        q += (size_t)p.slices * 256 * it.nb2;
+        if (it.colsum) r.seg[r.n_seg++] = RedSeg{q, 256, 256, it.colsum, 0, 1, 1};
+        q += (size_t)p.slices * 256;
+        if (it.na2) r.seg[r.n_seg++] = RedSeg{q, (long long)it.na2 * 256, it.na2 * 256, it.Cx2, 256, it.ldx2, 0};
+        KPD_TRY(launch_reduce(r, st));
     }
     return KPD_OK;
 }
