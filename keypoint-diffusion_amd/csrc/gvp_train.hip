@@ -451,14 +451,13 @@ kpd_status conv_fwd(kpd_gvp_trainer *T, int conv) {
 // dVu / d|Vh| and the kept activations -- the gate matrix, to_feats_out's scalar block (s_in: null at the head, whose source block is
 // differentiated per node) and its |Vh| block with the bias, and Wu / Wh through the vector kernels (which also leave dv_in: read at the
 // head -- the gradient of [x_diff | v_src] -- and redundant elsewhere).
-// skip: REST_SKIP_WG -- the gate matrix's gradient rides in another product (only its bias is summed here); REST_SKIP_WS -- so do
-// to_feats_out's blocks and bias (wgrad_batch, sgemm.hip)
+// skip: REST_SKIP_WG -- the gradients of the gate matrix and its bias ride in another product; REST_SKIP_WS -- so do to_feats_out's blocks
+// and bias (wgrad_batch, sgemm.hip)
 constexpr int REST_SKIP_WG = 1, REST_SKIP_WS = 2;
 kpd_status gvp_bwd_rest(kpd_gvp_trainer *T, const GvpP &g, int M, const float *s_in, const float *v_in, const GvpBuf &B, const GvpBwdGvp &o,
                         float *dv_in, int skip) {
     if (M == 0) return KPD_OK;
     if (!(skip & REST_SKIP_WG)) KPD_TRY(grad_gemm(T, g.vo, g.so, M, o.dgate, g.vo, B.s, g.so, g.Wg.g, g.so, g.bg.g));
-    else if (g.bg.g) KPD_TRY(colsum_acc(T, M, g.vo, o.dgate, g.vo, g.bg.g));
     if (!(skip & REST_SKIP_WS)) {
         if (s_in && g.Ws.g) KPD_TRY(grad_gemm(T, g.so, g.si, M, o.dpre, g.so, s_in, g.si, g.Ws.g, g.si + g.h));
         KPD_TRY(grad_gemm(T, g.so, g.h, M, o.dpre, g.so, B.sh, g.h, g.Ws.g ? g.Ws.g + g.si : nullptr, g.si + g.h, g.bs.g));
@@ -545,7 +544,7 @@ kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
         ba.fwd = T->slots_dev + (size_t)conv * 4; ba.out = T->bslots_dev;
         KPD_TRY(launch_gvp_edge_bwd(ba, tiles, T->st));
     }
-    std::vector<WgradItem> wq;
+    std::vector<WgradItem> wq, wq_top;
     for (int et = 0; et < 4; ++et) {
         if (!conv_uses(T, conv, et) || T->E[et] == 0) continue;
         const int E = T->E[et], s = kSrc[et], d = kDst[et];
@@ -553,6 +552,7 @@ kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
         GvpP g0;
         bind_msg(T, conv, et);
         KPD_TRY(message_fwd(T, conv, et, &g0, !T->store));
+        bool rbf_done = false;
         const float *dpre0 = nullptr, *drbf = nullptr;          // dL/dpre of the head GVP [E, S]; dL/d rbf [E, 16] (positions wanted)
         if (T->fused) {
             // Parameter gradients.  The 256 x 256 block of GVP j's to_feats_out (dpre_j^T s_{j-1}) takes its |Vh| block and bias and the gate
@@ -563,6 +563,21 @@ kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
             gp[0] = g0;
             for (int j = 1; j < nm; ++j) KPD_TRY(gvp_params(T, prefix + "." + std::to_string(j), VC, VC, S, S, &gp[j]));
             int skip[4] = {0, 0, 0, 0};
+            // ... and the head's rbf and |Vh| blocks with its bias (dpre_0^T [rbf | sh_0 | 1]) share a rider-only pass with the gate matrix of
+            // the chain's last GVP (dgate^T s of that GVP)
+            if (g0.Ws.g && g0.bs.g && gp[nm - 1].Wg.g) {
+                WgradItem it;
+                memset(&it, 0, sizeof(it));
+                it.A = bs.g[0].dpre; it.lda = S; it.B = T->gb[nm - 1].s; it.ldb = S; it.K = E;
+                it.B2 = T->rbf; it.ldb2 = RBF; it.nb2 = RBF; it.Cx1 = g0.Ws.g + S; it.ldx1 = g0.si + g0.h;
+                it.colsum = g0.bs.g;
+                it.B3 = T->gb[0].sh; it.ldb3 = g0.h; it.nb3 = g0.h; it.Cx3 = g0.Ws.g + g0.si; it.ldx3 = g0.si + g0.h;
+                it.A2 = bs.g[nm - 1].dgate; it.lda2 = VC; it.na2 = VC; it.Cx2 = gp[nm - 1].Wg.g; it.ldx2 = S; it.colsum2 = gp[nm - 1].bg.g;
+                wq_top.push_back(it);
+                skip[0] |= REST_SKIP_WS;
+                skip[nm - 1] |= REST_SKIP_WG;
+                rbf_done = true;
+            }
             for (int j = nm - 1; j >= 1; --j) {
                 if (gp[j].Ws.g && gp[j].bs.g && gp[j - 1].Wg.g) {
                     WgradItem it;
@@ -571,7 +586,7 @@ kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
                     it.C = gp[j].Ws.g; it.ldc = gp[j].si + gp[j].h;
                     it.B2 = T->gb[j].sh; it.ldb2 = gp[j].h; it.nb2 = gp[j].h; it.Cx1 = gp[j].Ws.g + gp[j].si; it.ldx1 = it.ldc;
                     it.colsum = gp[j].bs.g;
-                    it.A2 = bs.g[j - 1].dgate; it.lda2 = VC; it.na2 = VC; it.Cx2 = gp[j - 1].Wg.g; it.ldx2 = S;
+                    it.A2 = bs.g[j - 1].dgate; it.lda2 = VC; it.na2 = VC; it.Cx2 = gp[j - 1].Wg.g; it.ldx2 = S; it.colsum2 = gp[j - 1].bg.g;
                     wq.push_back(it);
                     skip[j] |= REST_SKIP_WS;
                     skip[j - 1] |= REST_SKIP_WG;
@@ -612,7 +627,7 @@ kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
             KPD_LAUNCH_CHECK();
         }
         // dpre0 = dL/dpre of the first GVP: its scalar inputs were U[src] and rbf
-        if (g0.Ws.g) KPD_TRY(grad_gemm(T, S, RBF, E, dpre0, S, T->rbf, RBF, g0.Ws.g + S, g0.si + g0.h));
+        if (g0.Ws.g && !rbf_done) KPD_TRY(grad_gemm(T, S, RBF, E, dpre0, S, T->rbf, RBF, g0.Ws.g + S, g0.si + g0.h));
         // sums over the out-edges of every source node, in ascending edge order (no float atomics)
         KPD_TRY(segsum(T->st, dpre0, S, 0, S, T->scsr[et].perm, T->scsr[et].rowptr, nullptr, 1.0f, false, T->n[s], T->U, S));
         if (g0.Ws.g) KPD_TRY(grad_gemm(T, S, S, T->n[s], T->U, S, T->ss[s][conv], S, g0.Ws.g, g0.si + g0.h));
@@ -623,6 +638,8 @@ kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
         }
     }
     for (size_t i = 0; i < wq.size(); i += 8) KPD_TRY(wgrad_batch(wq.data() + i, (int)std::min<size_t>(8, wq.size() - i), T->part, T->part_floats, T->st));
+    for (size_t i = 0; i < wq_top.size(); i += 8)
+        KPD_TRY(wgrad_batch(wq_top.data() + i, (int)std::min<size_t>(8, wq_top.size() - i), T->part, T->part_floats, T->st));
     bind_msg(T, -1, -1);
     return KPD_OK;
 }

@@ -19,9 +19,11 @@ kpd_status sgemm(bool tA, bool tB, int M, int N, int K, float alpha, const float
 // the pre-activation (C) kept for the backward pass
 // slices that give every CU about two workgroups for a [M,N] output, bounded by K / 256
 int sgemm_split_slices(int M, int N, int K);
-// Weight gradients of edge-sized products with a 256 x 256 output, several per launch (k_wgrad_tnx), every output ACCUMULATED (+=):
-//   C [256, 256] += A^T B;   Cx1 [256, nb2] += A^T B2 (nb2 <= 31);   colsum [256] += column sums of A;   Cx2 [na2, 256] += A2^T B (na2 <= 32)
-// A, B: [K, 256] (16-byte aligned, leading dimensions multiples of 4); B2 [K, ldb2], A2 [K, lda2] any alignment.
+// Weight gradients of a GVP message chain, several products per launch (k_wgrad_tnx), every output ACCUMULATED (+=):
+//   C [256, 256] += A^T B;   Cx1 [256, nb2] += A^T B2 (nb2 <= 31);   colsum [256] += column sums of A;
+//   Cx2 [na2, 256] += A2^T B (na2 <= 32);   colsum2 [na2] += column sums of A2
+//   C == nullptr ("top" products, all of a batch or none): no 256 x 256 block, and a second narrow block Cx3 [256, nb3] += A^T B3 (nb3 <= 32)
+// A, B: [K, 256] (16-byte aligned, leading dimensions multiples of 4); the narrow operands [K, ld] at any alignment.
 struct WgradItem {
     const float *A, *B;
     int lda, ldb, K;
@@ -36,6 +38,11 @@ struct WgradItem {
     int lda2, na2;
     float *Cx2;
     int ldx2;
+    float *colsum2;
+    const float *B3;
+    int ldb3, nb3;
+    float *Cx3;
+    int ldx3;
 };
 kpd_status wgrad_batch(const WgradItem *items, int n, float *part, size_t part_floats, hipStream_t st);
 // y[m * incy] = beta y + sum_k A[m][k] x[k * incx]

@@ -648,9 +648,10 @@ __global__ __launch_bounds__(512, 1) void k_sgemm_tn256(SgemmArgs a) {
 // Several products share one launch (block -> (product, K slice) by a prefix table), each with a share of the CUs proportional to its K:
 // a conv's six edge-sized products then write 256 partial tiles together instead of 256 each, and the reductions read a sixth.
 struct WgradProd {
-    const float *A, *B, *B2, *A2;
-    int lda, ldb, ldb2, lda2, nb2, na2, K, k_chunk, slices, first;
-    float *part;            // main [slices][65536] | x1 [slices][256 nb2] | colsum [slices][256] | x2 [slices][na2 256]
+    const float *A, *B, *B2, *A2, *B3;
+    int lda, ldb, ldb2, lda2, ldb3, nb2, na2, nb3, K, k_chunk, slices, first;
+    float *part;            // MAIN: main [slices][65536] | x1 [slices][256 nb2] | colsum [slices][256] | x2 [slices][na2 256] | colsum2 [slices][32]
+                            // TOP:  x1 [slices][256 nb2] | colsum [slices][256] | x3 [slices][256 nb3] | x2 [slices][na2 256] | colsum2 [slices][32]
 };
 constexpr int WGRAD_MAX = 8;
 struct WgradBatch {
@@ -658,10 +659,13 @@ struct WgradBatch {
     WgradProd p[WGRAD_MAX];
 };
 
+// TOP = 1: the riders alone (no 256 x 256 block), with a second narrow block X3 [256, nb3] += A^T B3 -- the head GVP of a chain (A = its dpre,
+// B2 = the rbf code, B3 = its 17 vector norms) sharing a pass with the gate matrix of the chain's last GVP (A2 = its dgate, B = its scalars).
+template <int TOP>
 __global__ __launch_bounds__(512, 1) void k_wgrad_tnx(WgradBatch bt) {
     constexpr int ROW = 256, SLAB = SG_BK * ROW, STAGE = 2 * SLAB, NSTAGE = TN256_STAGES;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ float xbuf[2][2][SG_BK][32];          // [slab parity][B2 | A2][k][column]
+    __shared__ float xbuf[2][3][SG_BK][32];          // [slab parity][B2 | A2 | B3][k][column]
     typedef __attribute__((address_space(3))) void lds_void;
     typedef const __attribute__((address_space(1))) void glb_void;
     int pi = 0;
@@ -674,14 +678,14 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_tnx(WgradBatch bt) {
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, col = lane & 31, half = lane >> 5, wr = wave >> 1, wc = wave & 1;
     const int kbeg = slice * a.k_chunk, kend = min(a.K, kbeg + a.k_chunk);
     const int nk = (kend - kbeg + SG_BK - 1) / SG_BK, nk_full = (kend - kbeg) / SG_BK;
-    v16f acc[2][4], ax1, ax2;
+    v16f acc[TOP ? 1 : 2][TOP ? 1 : 4], ax1, ax2, ax3;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        ax1[r] = 0.0f; ax2[r] = 0.0f;
+        ax1[r] = 0.0f; ax2[r] = 0.0f; ax3[r] = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < (TOP ? 1 : 2); ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j][r] = 0.0f;
+            for (int j = 0; j < (TOP ? 1 : 4); ++j) acc[i][j][r] = 0.0f;
     }
     auto issue = [&](int kt) {
         float *st = smem + (kt % NSTAGE) * STAGE;
@@ -698,42 +702,53 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_tnx(WgradBatch bt) {
         else if (slabs == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     };
-    // the narrow operands of slab kt: thread t carries element (k = t >> 5, c = t & 31) of the B2 tile and of the A2 tile
+    // the narrow operands of slab kt: thread t carries element (k = t >> 5, c = t & 31) of the B2, A2 (and B3) tiles
     const int xk = tid >> 5, xc = tid & 31;
-    const bool b2_live = a.B2 != nullptr && xc < a.nb2, a2_live = a.A2 != nullptr && xc < a.na2;
+    const bool b2_live = a.B2 != nullptr && xc < a.nb2, a2_live = a.A2 != nullptr && xc < a.na2, b3_live = TOP && a.B3 != nullptr && xc < a.nb3;
     const float *b2p = a.B2 ? a.B2 + min(xc, max(a.nb2 - 1, 0)) : a.A, *a2p = a.A2 ? a.A2 + min(xc, max(a.na2 - 1, 0)) : a.A;
-    const int ld2b = a.B2 ? a.ldb2 : a.lda, ld2a = a.A2 ? a.lda2 : a.lda;
-    float xvb = 0.0f, xva = 0.0f;
+    const float *b3p = (TOP && a.B3) ? a.B3 + min(xc, max(a.nb3 - 1, 0)) : a.A;
+    const int ld2b = a.B2 ? a.ldb2 : a.lda, ld2a = a.A2 ? a.lda2 : a.lda, ld3b = (TOP && a.B3) ? a.ldb3 : a.lda;
+    float xvb = 0.0f, xva = 0.0f, xv3 = 0.0f, cs2 = 0.0f;
     auto xfetch = [&](int kt) {
         const int k = kbeg + kt * SG_BK + xk;
         const size_t kk = (size_t)min(k, kend - 1);
         const bool in = k < kend;
         xvb = xc == 31 ? (in ? 1.0f : 0.0f) : masked(b2p[kk * ld2b], in && b2_live);
         xva = masked(a2p[kk * ld2a], in && a2_live);
+        if (TOP) xv3 = masked(b3p[kk * ld3b], in && b3_live);
     };
     auto xstash = [&](int kt) {
         xbuf[kt & 1][0][xk][xc] = xvb;
         xbuf[kt & 1][1][xk][xc] = xva;
+        if (TOP) xbuf[kt & 1][2][xk][xc] = xv3;
+        cs2 += xva;                                   // column sums of A2 (the gate bias gradient): this thread's row of every slab
     };
     auto compute = [&](const float *st, int kt) {
         const float *as = st + 64 * wr + col, *bs = st + SLAB + 128 * wc + col;
-        const float *xb = &xbuf[kt & 1][0][0][col], *xa = &xbuf[kt & 1][1][0][col];
+        const float *xb = &xbuf[kt & 1][0][0][col], *xa = &xbuf[kt & 1][1][0][col], *x3 = &xbuf[kt & 1][2][0][col];
 #pragma unroll
         for (int ks = 0; ks < SG_BK / 2; ++ks) {
             const int k = 2 * ks + half;
-            float av[2], bv[4];
+            if constexpr (TOP) {
+                const float av = as[k * ROW + 32 * wc], bv = bs[k * ROW + 32 * wr];
+                ax1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xb[k * 32], ax1, 0, 0, 0);
+                ax3 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, x3[k * 32], ax3, 0, 0, 0);
+                ax2 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[k * 32], bv, ax2, 0, 0, 0);
+            } else {
+                float av[2], bv[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) av[i] = as[k * ROW + 32 * i];
+                for (int i = 0; i < 2; ++i) av[i] = as[k * ROW + 32 * i];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bv[j] = bs[k * ROW + 32 * j];
-            const float b2 = xb[k * 32], a2 = xa[k * 32];
+                for (int j = 0; j < 4; ++j) bv[j] = bs[k * ROW + 32 * j];
+                const float b2 = xb[k * 32], a2 = xa[k * 32];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-            ax1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wc ? av[1] : av[0], b2, ax1, 0, 0, 0);
-            const float bsel = wr == 0 ? bv[0] : wr == 1 ? bv[1] : wr == 2 ? bv[2] : bv[3];
-            ax2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, bsel, ax2, 0, 0, 0);
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                ax1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wc ? av[1] : av[0], b2, ax1, 0, 0, 0);
+                const float bsel = wr == 0 ? bv[0] : wr == 1 ? bv[1] : wr == 2 ? bv[2] : bv[3];
+                ax2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, bsel, ax2, 0, 0, 0);
+            }
         }
     };
 
@@ -772,24 +787,45 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_tnx(WgradBatch bt) {
         compute(st, nk_full);
     }
     // shares of this K range
-    float *C = a.part + (size_t)slice * (ROW * ROW);
+    float *q = a.part;
+    if constexpr (!TOP) {
+        float *C = q + (size_t)slice * (ROW * ROW);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                C[(size_t)(64 * wr + 32 * i + 8 * (r >> 2) + 4 * half + (r & 3)) * ROW + 128 * wc + 32 * j + col] = acc[i][j][r];
-    float *x1 = a.part + (size_t)a.slices * (ROW * ROW) + (size_t)slice * (ROW * a.nb2);
-    float *cs = a.part + (size_t)a.slices * (ROW * ROW + ROW * a.nb2) + (size_t)slice * ROW;
-    float *x2 = a.part + (size_t)a.slices * (ROW * ROW + ROW * a.nb2 + ROW) + (size_t)slice * (a.na2 * ROW);
+                for (int r = 0; r < 16; ++r)
+                    C[(size_t)(64 * wr + 32 * i + 8 * (r >> 2) + 4 * half + (r & 3)) * ROW + 128 * wc + 32 * j + col] = acc[i][j][r];
+        q += (size_t)a.slices * (ROW * ROW);
+    }
+    float *x1 = q + (size_t)slice * (ROW * a.nb2);
+    q += (size_t)a.slices * (ROW * a.nb2);
+    float *cs = q + (size_t)slice * ROW;
+    q += (size_t)a.slices * ROW;
+    float *x3 = q + (size_t)slice * (ROW * a.nb3);
+    if (TOP) q += (size_t)a.slices * (ROW * a.nb3);
+    float *x2 = q + (size_t)slice * (a.na2 * ROW);
+    q += (size_t)a.slices * (a.na2 * ROW);
+    float *c2 = q + (size_t)slice * 32;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int rr = 8 * (r >> 2) + 4 * half + (r & 3);
         const int m = 64 * wr + 32 * wc + rr;
         if (col < a.nb2) x1[m * a.nb2 + col] = ax1[r];
         if (col == 31) cs[m] = ax1[r];
+        if (TOP && col < a.nb3) x3[m * a.nb3 + col] = ax3[r];
         if (rr < a.na2) x2[rr * ROW + 128 * wc + 32 * wr + col] = ax2[r];
+    }
+    // column sums of A2: the 16 row-in-slab shares of a column, in row order
+    __syncthreads();
+    xbuf[0][0][xk][xc] = cs2;
+    __syncthreads();
+    if (tid < 32) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < SG_BK; ++k) sum += xbuf[0][0][k][tid];
+        c2[tid] = sum;
     }
 }
 
@@ -1001,12 +1037,14 @@ kpd_status wgrad_batch(const WgradItem *items, int n, float *part, size_t part_f
     WgradBatch bt;
     memset(&bt, 0, sizeof(bt));
     long long ksum = 0;
+    const bool top = items[0].C == nullptr;
     for (int i = 0; i < n; ++i) {
         const WgradItem &it = items[i];
-        KPD_REQUIRE(it.A && it.B && it.C && it.K >= 1 && (it.lda & 3) == 0 && (it.ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(it.A) & 15) == 0 &&
-                        (reinterpret_cast<uintptr_t>(it.B) & 15) == 0 && it.nb2 >= 0 && it.nb2 <= 31 && it.na2 >= 0 && it.na2 <= 32 &&
-                        (it.nb2 == 0 || (it.B2 && it.Cx1)) && (it.na2 == 0 || (it.A2 && it.Cx2)),
+        KPD_REQUIRE(it.A && it.B && it.K >= 1 && (it.lda & 3) == 0 && (it.ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(it.A) & 15) == 0 &&
+                        (reinterpret_cast<uintptr_t>(it.B) & 15) == 0 && it.nb2 >= 0 && it.nb2 <= 31 && it.na2 >= 0 && it.na2 <= 32 && it.nb3 >= 0 &&
+                        it.nb3 <= 32 && (it.nb2 == 0 || (it.B2 && it.Cx1)) && (it.na2 == 0 || (it.A2 && it.Cx2)) && (it.nb3 == 0 || (it.B3 && it.Cx3)),
                     KPD_ERR_INVALID, "wgrad_batch: bad product %d", i);
+        KPD_REQUIRE((it.C == nullptr) == top && (top || it.nb3 == 0), KPD_ERR_INVALID, "wgrad_batch: products with and without a 256 x 256 block in one batch");
         ksum += it.K;
     }
     const int cus = cu_count();
@@ -1015,9 +1053,9 @@ kpd_status wgrad_batch(const WgradItem *items, int n, float *part, size_t part_f
     for (int i = 0; i < n; ++i) {
         const WgradItem &it = items[i];
         WgradProd &p = bt.p[i];
-        p.A = it.A; p.B = it.B; p.B2 = it.nb2 ? it.B2 : nullptr; p.A2 = it.na2 ? it.A2 : nullptr;
-        p.lda = it.lda; p.ldb = it.ldb; p.ldb2 = it.ldb2; p.lda2 = it.lda2; p.nb2 = it.nb2; p.na2 = it.na2; p.K = it.K;
-        const size_t per_slice = (size_t)256 * 256 + 256 * it.nb2 + 256 + (size_t)it.na2 * 256;
+        p.A = it.A; p.B = it.B; p.B2 = it.nb2 ? it.B2 : nullptr; p.A2 = it.na2 ? it.A2 : nullptr; p.B3 = it.nb3 ? it.B3 : nullptr;
+        p.lda = it.lda; p.ldb = it.ldb; p.ldb2 = it.ldb2; p.lda2 = it.lda2; p.ldb3 = it.ldb3; p.nb2 = it.nb2; p.na2 = it.na2; p.nb3 = it.nb3; p.K = it.K;
+        const size_t per_slice = (top ? 0 : (size_t)256 * 256) + 256 * it.nb2 + 256 + 256 * it.nb3 + (size_t)it.na2 * 256 + 32;
         // a share of the CUs proportional to K, a slice at least 256 rows deep
         int sl = (int)std::max<long long>(1, ((long long)cus * it.K + ksum / 2) / ksum);
         sl = std::min(sl, std::max(1, it.K / 256));
@@ -1032,8 +1070,13 @@ kpd_status wgrad_batch(const WgradItem *items, int n, float *part, size_t part_f
     }
     bt.n = n;
     constexpr int lds = TN256_STAGES * 2 * SG_BK * 256 * 4;
-    KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_wgrad_tnx), lds));
-    hipLaunchKernelGGL(k_wgrad_tnx, dim3(first), dim3(512), lds, st, bt);
+    if (top) {
+        KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_wgrad_tnx<1>), lds));
+        hipLaunchKernelGGL(k_wgrad_tnx<1>, dim3(first), dim3(512), lds, st, bt);
+    } else {
+        KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_wgrad_tnx<0>), lds));
+        hipLaunchKernelGGL(k_wgrad_tnx<0>, dim3(first), dim3(512), lds, st, bt);
+    }
     KPD_LAUNCH_CHECK();
     for (int i = 0; i < n; ++i) {
         const WgradItem &it = items[i];
@@ -1041,14 +1084,20 @@ kpd_status wgrad_batch(const WgradItem *items, int n, float *part, size_t part_f
         RedArgs r;
         r.n_seg = 0; r.slices = p.slices; r.beta = 1.0f;
         float *q = p.part;
-        r.seg[r.n_seg++] = RedSeg{q, 65536, 65536, it.C, 256, it.ldc, 0};
-        q += (size_t)p.slices * 65536;
+        if (!top) {
+            r.seg[r.n_seg++] = RedSeg{q, 65536, 65536, it.C, 256, it.ldc, 0};
+            q += (size_t)p.slices * 65536;
+        }
         if (it.nb2) r.seg[r.n_seg++] = RedSeg{q, (long long)256 * it.nb2, 256 * it.nb2, it.Cx1, it.nb2, it.ldx1, 0};
         q += (size_t)p.slices * 256 * it.nb2;
         if (it.colsum) r.seg[r.n_seg++] = RedSeg{q, 256, 256, it.colsum, 0, 1, 1};
         q += (size_t)p.slices * 256;
+        if (it.nb3) r.seg[r.n_seg++] = RedSeg{q, (long long)256 * it.nb3, 256 * it.nb3, it.Cx3, it.nb3, it.ldx3, 0};
+        q += (size_t)p.slices * 256 * it.nb3;
         if (it.na2) r.seg[r.n_seg++] = RedSeg{q, (long long)it.na2 * 256, it.na2 * 256, it.Cx2, 256, it.ldx2, 0};
-        KPD_TRY(launch_reduce(r, st));
+        q += (size_t)p.slices * it.na2 * 256;
+        if (it.na2 && it.colsum2) r.seg[r.n_seg++] = RedSeg{q, 32, it.na2, it.colsum2, 0, 1, 1};
+        if (r.n_seg) KPD_TRY(launch_reduce(r, st));
     }
     return KPD_OK;
 }
