@@ -256,6 +256,11 @@ kpd_status kpd_gvp_trainer_forward(kpd_gvp_trainer *t, const kpd_batch *batch, c
 /* E_ll, E_kl, E_lk, E_kk of the last forward (host values the forward already read back: no synchronisation).  No reference counterpart
  * (bench.py's FLOP count of the training lines). */
 kpd_status kpd_gvp_trainer_last_counts(kpd_gvp_trainer *t, int32_t out[4]);
+/* Which form the edge messages of the convs run in with the current reservation: 1 = the register-chained kernels (one forward, one
+ * backward and two batched weight-gradient launches per conv: n_hidden_scalars = 256 and the kept-activation memory was granted),
+ * 0 = one GVP at a time through the GEMM kernels (any width; recomputation when memory is short).  Same gradients to rounding.  No
+ * reference counterpart (tests assert that the path they mean to cover is the one that ran). */
+kpd_status kpd_gvp_trainer_message_path(kpd_gvp_trainer *t, int32_t *path);
 kpd_status kpd_gvp_trainer_backward(kpd_gvp_trainer *t, const float *d_eps_h, const float *d_eps_x, float *d_lig_h,
                                     float *d_kp_h, float *d_kp_v, float *d_lig_x, float *d_kp_x, void *stream);
 

@@ -1044,6 +1044,12 @@ extern "C" kpd_status kpd_gvp_trainer_last_counts(kpd_gvp_trainer *T, int32_t ou
     return KPD_OK;
 }
 
+extern "C" kpd_status kpd_gvp_trainer_message_path(kpd_gvp_trainer *T, int32_t *path) {
+    KPD_REQUIRE(T && path, KPD_ERR_INVALID, "null argument");
+    *path = T->fused ? 1 : 0;
+    return KPD_OK;
+}
+
 extern "C" kpd_status kpd_gvp_trainer_backward(kpd_gvp_trainer *T, const float *d_eps_h, const float *d_eps_x, float *d_lig_h,
                                                float *d_kp_h, float *d_kp_v, float *d_lig_x, float *d_kp_x, void *stream) {
     KPD_REQUIRE(T && d_eps_h && d_eps_x, KPD_ERR_INVALID, "null argument");

@@ -155,6 +155,7 @@ def lib():
     L.kpd_gvp_trainer_forward.argtypes = [C.c_void_p, C.POINTER(KpdBatch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.kpd_gvp_trainer_backward.argtypes = [C.c_void_p] + [C.c_void_p] * 8
     L.kpd_gvp_trainer_set_dropout.argtypes = [C.c_void_p, C.c_float, C.c_uint64]
+    L.kpd_gvp_trainer_message_path.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     L.kpd_dropout_mask.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]
     L.kpd_recenc_trainer_create.argtypes = [C.POINTER(KpdRecencConfig), C.POINTER(C.c_void_p)]
     L.kpd_recenc_trainer_destroy.argtypes = [C.c_void_p]
@@ -202,6 +203,7 @@ EXPORTS = [
     'kpd_xyz_scratch_bytes', 'kpd_xyz_emit', 'kpd_rec_graph_scratch_bytes', 'kpd_build_rec_graph',
     'kpd_egnn_trainer_create', 'kpd_egnn_trainer_destroy', 'kpd_egnn_trainer_bind', 'kpd_egnn_trainer_reserve',
     'kpd_egnn_trainer_forward', 'kpd_egnn_trainer_backward', 'kpd_egnn_trainer_profile', 'kpd_egnn_trainer_profile_read', 'kpd_gvp_trainer_last_counts',
+    'kpd_gvp_trainer_message_path',
     'kpd_gvp_trainer_create', 'kpd_gvp_trainer_destroy', 'kpd_gvp_trainer_bind', 'kpd_gvp_trainer_reserve',
     'kpd_gvp_trainer_forward', 'kpd_gvp_trainer_backward', 'kpd_gvp_trainer_set_dropout', 'kpd_dropout_mask',
     'kpd_recenc_trainer_create', 'kpd_recenc_trainer_destroy', 'kpd_recenc_trainer_bind', 'kpd_recenc_trainer_set_dropout',
@@ -573,6 +575,12 @@ class GvpTrainer:
         arr = (C.c_int32 * 4)()
         check(lib().kpd_gvp_trainer_last_counts(self._h, arr))
         return dict(E_ll=arr[0], E_kl=arr[1], E_lk=arr[2], E_kk=arr[3])
+
+    def message_path(self) -> int:
+        """1: the convs' edge messages run through the register-chained kernels (hidden width 256), 0: one GVP at a time."""
+        v = C.c_int32(0)
+        check(lib().kpd_gvp_trainer_message_path(self._h, C.byref(v)))
+        return int(v.value)
 
 
 def dropout_mask(seed: int, conv: int, node_type: int, position: int, kind: int, n: int, rate: float, device='cuda') -> torch.Tensor:

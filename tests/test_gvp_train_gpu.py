@@ -45,10 +45,17 @@ def _oracle_grads(model, cfg, g, t, w_h, w_x):
 
 
 @pytest.mark.parametrize('tag,over', [('gvp_kp', {}), ('gvp_mean', {}), ('gvp_norm0', {}), ('gvp_norm0', dict(ll_k=3, kl_k=0)),
-                                      ('gvp_norm0', dict(n_hidden_scalars=100)), ('gvp_mean', dict(n_hidden_scalars=37))])
+                                      ('gvp_norm0', dict(n_hidden_scalars=100)), ('gvp_mean', dict(n_hidden_scalars=37)),
+                                      # hidden width 256 = the register-chained message kernels, in every normalisation mode and chain length,
+                                      # and once at a size with many tiles per edge type and several K slices per weight gradient
+                                      ('gvp_mean', dict(n_hidden_scalars=256)), ('gvp_norm0', dict(n_hidden_scalars=256)),
+                                      ('gvp_norm0', dict(n_hidden_scalars=256, ll_k=3, kl_k=0, n_message_gvps=1)),
+                                      ('gvp_kp', dict(n_convs=2, sizes=([150, 97], [25, 18])))])
 def test_gradients_match_oracle_autograd(tag, over):
+    over = dict(over)
+    n_rec, n_lig = over.pop('sizes', ([26, 19, 33], [7, 10, 5]))
     cfg = dict(GVP_CFGS[tag], dropout=0.0, **over)
-    g, model, t = _case(cfg, [26, 19, 33], [7, 10, 5], 128 if tag == 'gvp_kp' else 10)
+    g, model, t = _case(cfg, n_rec, n_lig, 128 if tag == 'gvp_kp' else 10)
     gen = torch.Generator().manual_seed(2)
     n_lig = g.num_nodes('lig')
     w_h, w_x = torch.randn(n_lig, 10, generator=gen), torch.randn(n_lig, 3, generator=gen)
@@ -61,6 +68,8 @@ def test_gradients_match_oracle_autograd(tag, over):
         ins[key] = gd.nodes[nt].data[name].detach().clone().requires_grad_(True)
         gd.nodes[nt].data[name] = ins[key]
     eh, ex = model(gd, t.cuda(), None)
+    # hidden width 256: the register-chained message kernels (forward, backward, batched weight gradients); else one GVP at a time
+    assert model._trainer()[0].message_path() == (1 if cfg['n_hidden_scalars'] == 256 else 0)
     assert util.rel_err(eh.detach().cpu(), eh_ref) < 1e-4 and util.rel_err(ex.detach().cpu(), ex_ref) < 1e-4
     ((eh * w_h.cuda()).sum() + (ex * w_x.cuda()).sum()).backward()
     worst = []
