@@ -661,11 +661,16 @@ struct WgradBatch {
 
 // TOP = 1: the riders alone (no 256 x 256 block), with a second narrow block X3 [256, nb3] += A^T B3 -- the head GVP of a chain (A = its dpre,
 // B2 = the rbf code, B3 = its 17 vector norms) sharing a pass with the gate matrix of the chain's last GVP (A2 = its dgate, B = its scalars).
+// The narrow operands travel like the wide ones: one 4-byte LDS-DMA instruction per wave, tile and slab (thread t carries element
+// (k = t >> 5, c = t & 31); columns past the operand's width read a clamped address -- they feed output columns nobody stores -- and column 31
+// of the B2 tile reads a constant 1), NSTAGE - 1 slabs ahead.  (Through registers one slab ahead, the rider-only form waited an HBM round
+// trip per 1.3-us slab: 479 us for a conv's four products; the slab ring hides it.)
+__device__ const float kWgradOne = 1.0f;
 template <int TOP>
 __global__ __launch_bounds__(512, 1) void k_wgrad_tnx(WgradBatch bt) {
-    constexpr int ROW = 256, SLAB = SG_BK * ROW, STAGE = 2 * SLAB, NSTAGE = TN256_STAGES;
+    constexpr int ROW = 256, SLAB = SG_BK * ROW, STAGE = 2 * SLAB, NSTAGE = TN256_STAGES, NXT = TOP ? 3 : 2, PER_SLAB = 4 + NXT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ float xbuf[2][3][SG_BK][32];          // [slab parity][B2 | A2 | B3][k][column]
+    __shared__ float xbuf[NSTAGE][3][SG_BK][32];          // [stage][B2 | A2 | B3][k][column]
     typedef __attribute__((address_space(3))) void lds_void;
     typedef const __attribute__((address_space(1))) void glb_void;
     int pi = 0;
@@ -687,8 +692,15 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_tnx(WgradBatch bt) {
 #pragma unroll
             for (int j = 0; j < (TOP ? 1 : 4); ++j) acc[i][j][r] = 0.0f;
     }
+    // this thread's element of the narrow tiles: row xk of the slab, column xc
+    const int xk = tid >> 5, xc = tid & 31;
+    const bool b2_live = a.B2 != nullptr && xc < a.nb2, a2_live = a.A2 != nullptr && xc < a.na2, b3_live = TOP && a.B3 != nullptr && xc < a.nb3;
+    const float *b2p = xc == 31 ? &kWgradOne : a.B2 ? a.B2 + min(xc, max(a.nb2 - 1, 0)) : a.A;
+    const float *a2p = a.A2 ? a.A2 + min(xc, max(a.na2 - 1, 0)) : a.A, *b3p = (TOP && a.B3) ? a.B3 + min(xc, max(a.nb3 - 1, 0)) : a.A;
+    const size_t ld2b = xc == 31 ? 0 : a.B2 ? a.ldb2 : a.lda, ld2a = a.A2 ? a.lda2 : a.lda, ld3b = (TOP && a.B3) ? a.ldb3 : a.lda;
     auto issue = [&](int kt) {
-        float *st = smem + (kt % NSTAGE) * STAGE;
+        const int sg = kt % NSTAGE;
+        float *st = smem + sg * STAGE;
         const size_t k0 = (size_t)kbeg + (size_t)kt * SG_BK;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -696,36 +708,21 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_tnx(WgradBatch bt) {
             __builtin_amdgcn_global_load_lds((glb_void *)(a.A + (k0 + row) * a.lda + 4 * lane), (lds_void *)(st + row * ROW), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((glb_void *)(a.B + (k0 + row) * a.ldb + 4 * lane), (lds_void *)(st + SLAB + row * ROW), 16, 0, 0);
         }
+        // rows 2 wave, 2 wave + 1 of the narrow tiles: 64 consecutive floats of LDS per wave and tile
+        __builtin_amdgcn_global_load_lds((glb_void *)(b2p + (k0 + xk) * ld2b), (lds_void *)(&xbuf[sg][0][2 * wave][0]), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void *)(a2p + (k0 + xk) * ld2a), (lds_void *)(&xbuf[sg][1][2 * wave][0]), 4, 0, 0);
+        if (TOP) __builtin_amdgcn_global_load_lds((glb_void *)(b3p + (k0 + xk) * ld3b), (lds_void *)(&xbuf[sg][2][2 * wave][0]), 4, 0, 0);
     };
-    auto wait_behind = [&](int slabs) {
+    auto wait_behind = [&](int slabs) {                 // at most `slabs` slabs of this wave's loads outstanding (PER_SLAB instructions each)
         if (slabs <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (slabs == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (slabs == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_SLAB) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_SLAB) : "memory");
     };
-    // the narrow operands of slab kt: thread t carries element (k = t >> 5, c = t & 31) of the B2, A2 (and B3) tiles
-    const int xk = tid >> 5, xc = tid & 31;
-    const bool b2_live = a.B2 != nullptr && xc < a.nb2, a2_live = a.A2 != nullptr && xc < a.na2, b3_live = TOP && a.B3 != nullptr && xc < a.nb3;
-    const float *b2p = a.B2 ? a.B2 + min(xc, max(a.nb2 - 1, 0)) : a.A, *a2p = a.A2 ? a.A2 + min(xc, max(a.na2 - 1, 0)) : a.A;
-    const float *b3p = (TOP && a.B3) ? a.B3 + min(xc, max(a.nb3 - 1, 0)) : a.A;
-    const int ld2b = a.B2 ? a.ldb2 : a.lda, ld2a = a.A2 ? a.lda2 : a.lda, ld3b = (TOP && a.B3) ? a.ldb3 : a.lda;
-    float xvb = 0.0f, xva = 0.0f, xv3 = 0.0f, cs2 = 0.0f;
-    auto xfetch = [&](int kt) {
-        const int k = kbeg + kt * SG_BK + xk;
-        const size_t kk = (size_t)min(k, kend - 1);
-        const bool in = k < kend;
-        xvb = xc == 31 ? (in ? 1.0f : 0.0f) : masked(b2p[kk * ld2b], in && b2_live);
-        xva = masked(a2p[kk * ld2a], in && a2_live);
-        if (TOP) xv3 = masked(b3p[kk * ld3b], in && b3_live);
-    };
-    auto xstash = [&](int kt) {
-        xbuf[kt & 1][0][xk][xc] = xvb;
-        xbuf[kt & 1][1][xk][xc] = xva;
-        if (TOP) xbuf[kt & 1][2][xk][xc] = xv3;
-        cs2 += xva;                                   // column sums of A2 (the gate bias gradient): this thread's row of every slab
-    };
-    auto compute = [&](const float *st, int kt) {
+    float cs2 = 0.0f;
+    auto compute = [&](const float *st, int sg) {
         const float *as = st + 64 * wr + col, *bs = st + SLAB + 128 * wc + col;
-        const float *xb = &xbuf[kt & 1][0][0][col], *xa = &xbuf[kt & 1][1][0][col], *x3 = &xbuf[kt & 1][2][0][col];
+        const float *xb = &xbuf[sg][0][0][col], *xa = &xbuf[sg][1][0][col], *x3 = &xbuf[sg][2][0][col];
+        cs2 += masked(xbuf[sg][1][xk][xc], a2_live);          // column sums of A2 (the gate bias gradient): this thread's row of every slab
 #pragma unroll
         for (int ks = 0; ks < SG_BK / 2; ++ks) {
             const int k = 2 * ks + half;
@@ -753,25 +750,20 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_tnx(WgradBatch bt) {
     };
 
     const int ahead = min(NSTAGE - 1, nk_full);
-    xfetch(0);
     for (int kt = 0; kt < ahead; ++kt) issue(kt);
-    xstash(0);
     wait_behind(ahead - 1);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll 1
     for (int kt = 0; kt < nk_full; ++kt) {
-        if (kt + 1 < nk) xfetch(kt + 1);
         if (kt + NSTAGE - 1 < nk_full) issue(kt + NSTAGE - 1);
         __builtin_amdgcn_sched_barrier(0);
-        const float *st = smem + (kt % NSTAGE) * STAGE;
-        compute(st, kt);
-        if (kt + 1 < nk) xstash(kt + 1);
+        compute(smem + (kt % NSTAGE) * STAGE, kt % NSTAGE);
         __builtin_amdgcn_sched_barrier(0);
         wait_behind(min(kt + NSTAGE - 1, nk_full - 1) - (kt + 1));
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     if (nk > nk_full) {          // K tail of this range: rows past kend read a clamped address and are replaced by zero
-        float *st = smem;
+        float *st = smem;        // (every stage is free: the loop ended on a barrier with nothing in flight)
         const int k0 = kbeg + nk_full * SG_BK;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -783,8 +775,15 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_tnx(WgradBatch bt) {
             for (int e = 0; e < 4; ++e) v[e] = masked(v[e], in);
             *reinterpret_cast<v4f *>(st + op * SLAB + row * ROW + 4 * c4) = v;
         }
+        {
+            const bool in = k0 + xk < kend;
+            const size_t kk = (size_t)min(k0 + xk, kend - 1);
+            xbuf[0][0][xk][xc] = xc == 31 ? (in ? 1.0f : 0.0f) : masked(b2p[kk * ld2b], in && b2_live);
+            xbuf[0][1][xk][xc] = masked(a2p[kk * ld2a], in && a2_live);
+            if (TOP) xbuf[0][2][xk][xc] = masked(b3p[kk * ld3b], in && b3_live);
+        }
         __syncthreads();
-        compute(st, nk_full);
+        compute(st, 0);
     }
     // shares of this K range
     float *q = a.part;
