@@ -47,7 +47,7 @@ struct ChainSmem {
 template <int NTS, class Ring, int TR = 0>
 __device__ __forceinline__ void chain_generic_gvp(Ring &ring, const v4f *cb, const v4f *nb, const GvpW &gk, const float *next_bias,
                                                   v4f (&x)[NTS], v4f (&acc)[NTS], v4f (&Vc)[3], int lane, int q,
-                                                  const GvpTrainGvp *tg = nullptr, size_t erow = 0, bool live = false) {
+                                                  const GvpTrainGvp *tg = nullptr, size_t erow = 0, bool live = false, int skip = 0) {
     // cb: this GVP's chunks (NTS scalar slabs, the sh slab, the gate slab); nb: the next GVP's -- or, after the last one, cb + NTS chunks,
     // so that the two refills past the end re-read chunks that exist.  The chunk two ahead of local chunk i:
     constexpr int CH4 = NTS * 64;
@@ -64,7 +64,7 @@ __device__ __forceinline__ void chain_generic_gvp(Ring &ring, const v4f *cb, con
 #pragma unroll
     for (int r = 0; r < 4; ++r) sh[r] = sqrt1(fmaxf(Vh[0][r] * Vh[0][r] + Vh[1][r] * Vh[1][r] + Vh[2][r] * Vh[2][r], 1e-8f));
     if constexpr (TR) {
-        if (live) {
+        if (live && !(skip & 4)) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) *reinterpret_cast<v4f *>(tg->Vh + (erow * 3 + c) * 16 + 4 * q) = Vh[c];
             *reinterpret_cast<v4f *>(tg->sh + erow * 16 + 4 * q) = sh;
@@ -80,7 +80,7 @@ __device__ __forceinline__ void chain_generic_gvp(Ring &ring, const v4f *cb, con
     const v4f bgv = *reinterpret_cast<const v4f *>(gk.bg + 4 * q);
     const v4f wu = reinterpret_cast<const v4f *>(gk.wup)[lane];
     if constexpr (TR) {
-        if (live) {
+        if (live && !(skip & 1)) {
             float *pr = tg->pre + erow * (16 * NTS) + 4 * q;
 #pragma unroll
             for (int mt = 0; mt < NTS; ++mt) *reinterpret_cast<v4f *>(pr + 16 * mt) = acc[mt];
@@ -89,7 +89,7 @@ __device__ __forceinline__ void chain_generic_gvp(Ring &ring, const v4f *cb, con
 #pragma unroll
     for (int mt = 0; mt < NTS; ++mt) x[mt] = silu4(acc[mt]);
     if constexpr (TR) {
-        if (live) {
+        if (live && !(skip & 2)) {
             float *sr = tg->s + erow * (16 * NTS) + 4 * q;
 #pragma unroll
             for (int mt = 0; mt < NTS; ++mt) *reinterpret_cast<v4f *>(sr + 16 * mt) = x[mt];
@@ -119,7 +119,7 @@ __device__ __forceinline__ void chain_generic_gvp(Ring &ring, const v4f *cb, con
         ring.release();
         gate = (ga[0] + ga[1]) + (ga[2] + ga[3]) + bgv;
         if constexpr (TR) {
-            if (live) *reinterpret_cast<v4f *>(tg->gate + erow * 16 + 4 * q) = gate;          // before the sigmoid (k_gvp_gate_bwd applies it)
+            if (live && !(skip & 4)) *reinterpret_cast<v4f *>(tg->gate + erow * 16 + 4 * q) = gate;          // before the sigmoid (k_gvp_gate_bwd applies it)
         }
         if (gk.vec_sigmoid) {
 #pragma unroll
@@ -133,7 +133,7 @@ __device__ __forceinline__ void chain_generic_gvp(Ring &ring, const v4f *cb, con
         for (int r = 0; r < 4; ++r) t = mfma16(wu[r], Vh[c][r], t);
         Vc[c] = gate * t;
         if constexpr (TR) {
-            if (live) {
+            if (live && !(skip & 4)) {
                 *reinterpret_cast<v4f *>(tg->Vu + (erow * 3 + c) * 16 + 4 * q) = t;
                 *reinterpret_cast<v4f *>(tg->V + (erow * 3 + c) * 16 + 4 * q) = Vc[c];
             }
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
         const int tail = h0 - 16 * (n_ht - 1);            // valid rows of the last hidden tile
         const int tail_reg = min(4, tail);
         if constexpr (TR) {       // geometry, message input vectors [x_diff | source], hidden vectors and their norms (17 channels)
-            if (live) {
+            if (live && !(a.train_skip & 4)) {
                 if (q == 0) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
 #pragma unroll
         for (int ht = 0; ht < 3; ++ht) wu[ht] = ht < n_ht ? wup[ht * 64] : zero4();
         if constexpr (TR) {
-            if (live) {
+            if (live && !(a.train_skip & 1)) {
                 float *pr = tsl->g[0].pre + erow * S + 4 * q;
 #pragma unroll
                 for (int mt = 0; mt < NTS; ++mt) *reinterpret_cast<v4f *>(pr + 16 * mt) = acc[mt];
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
 #pragma unroll
         for (int mt = 0; mt < NTS; ++mt) x[mt] = silu4(HM ? acc[mt] * H_UNSCALE : acc[mt]);
         if constexpr (TR) {
-            if (live) {
+            if (live && !(a.train_skip & 2)) {
                 float *sr = tsl->g[0].s + erow * S + 4 * q;
 #pragma unroll
                 for (int mt = 0; mt < NTS; ++mt) *reinterpret_cast<v4f *>(sr + 16 * mt) = x[mt];
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
                 gate = (ga[0] + ga[1]) + (ga[2] + ga[3]) + bgv;
             }
             if constexpr (TR) {
-                if (live) *reinterpret_cast<v4f *>(tsl->g[0].gate + erow * 16 + 4 * q) = gate;
+                if (live && !(a.train_skip & 4)) *reinterpret_cast<v4f *>(tsl->g[0].gate + erow * 16 + 4 * q) = gate;
             }
             if (g0.vec_sigmoid) {
 #pragma unroll
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
             }
             Vc[c] = gate * t;
             if constexpr (TR) {
-                if (live) {
+                if (live && !(a.train_skip & 4)) {
                     *reinterpret_cast<v4f *>(tsl->g[0].Vu + (erow * 3 + c) * 16 + 4 * q) = t;
                     *reinterpret_cast<v4f *>(tsl->g[0].V + (erow * 3 + c) * 16 + 4 * q) = Vc[c];
                 }
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
             const v4f *cb = reinterpret_cast<const v4f *>(a.g[et][k].chain);
             const v4f *nb = k + 1 < n_gvps ? reinterpret_cast<const v4f *>(a.g[et][k + 1].chain) : cb + (size_t)NTS * CH4;
             if constexpr (TR) chain_generic_gvp<NTS, decltype(ring), 1>(ring, cb, nb, a.g[et][k], k + 1 < n_gvps ? a.g[et][k + 1].b : nullptr, x, acc, Vc, lane, q,
-                                                                         &tsl->g[k], erow, live);
+                                                                         &tsl->g[k], erow, live, a.train_skip);
             else chain_generic_gvp<NTS>(ring, cb, nb, a.g[et][k], k + 1 < n_gvps ? a.g[et][k + 1].b : nullptr, x, acc, Vc, lane, q);
         }
         CHAIN_STAMP(6)
@@ -879,7 +879,39 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain_bwd(GvpEdgeBwdArgs a) {
 // live on its four lanes (64 registers each), so both layer norms are in-lane sums plus two cross-lane adds; the
 // residual scalars wait in the s_tmp scratch rows (the registers are needed for the GEMM operands), the 16 residual
 // vectors stay in registers.
-template <int NTS, int HM = 0>
+// GVPDropout scale (0 or 1 / (1 - rate)) of the four consecutive elements i0 .. i0 + 3 (i0 a multiple of 4) of one Philox stream: they
+// share one counter (gvp_train_core.h, dropout_scale -- the same bits)
+__device__ __forceinline__ v4f dropout_scale4(unsigned long long seed, unsigned stream, long long i0, float rate) {
+    unsigned c[4] = {(unsigned)(i0 >> 2), (unsigned)((unsigned long long)i0 >> 34), stream, 0x6b70646fu};
+    philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+    const unsigned thr = (unsigned)fminf(rate * 4294967296.0f, 4294967040.0f);
+    const float keep = 1.0f / (1.0f - rate);
+    return v4f{c[0] >= thr ? keep : 0.0f, c[1] >= thr ? keep : 0.0f, c[2] >= thr ? keep : 0.0f, c[3] >= thr ? keep : 0.0f};
+}
+__device__ __forceinline__ float dropout_scale1(unsigned long long seed, unsigned stream, long long i, float rate) {
+    unsigned c[4] = {(unsigned)(i >> 2), (unsigned)((unsigned long long)i >> 34), stream, 0x6b70646fu};
+    philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+    const unsigned thr = (unsigned)fminf(rate * 4294967296.0f, 4294967040.0f);
+    return c[i & 3] >= thr ? 1.0f / (1.0f - rate) : 0.0f;
+}
+// scalars x (row v of an [n][16 NTS] array) and vectors V ([n][live] masks shared by the three components; channels past `live` are padding)
+template <int NTS>
+__device__ __forceinline__ void lanes_dropout(v4f (&x)[NTS], v4f (&V)[3], const GvpNodeTrain &t, int pos, int v, int q) {
+    if (t.rate <= 0.0f) return;
+#pragma unroll
+    for (int nt = 0; nt < NTS; ++nt) x[nt] = x[nt] * dropout_scale4(t.seed, t.stream[2 * pos], (long long)v * (16 * NTS) + 16 * nt + 4 * q, t.rate);
+    v4f m;
+    if (t.live_v == 16) m = dropout_scale4(t.seed, t.stream[2 * pos + 1], (long long)v * 16 + 4 * q, t.rate);
+    else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m[r] = 4 * q + r < t.live_v ? dropout_scale1(t.seed, t.stream[2 * pos + 1], (long long)v * t.live_v + 4 * q + r, t.rate) : 0.0f;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) V[c] = V[c] * m;
+}
+
+// TR = 1: the training form (GvpNodeTrain, gvp_kernels.h)
+template <int NTS, int HM = 0, int TR = 0>
 __global__ __launch_bounds__(256, 2) void k_gvp_node_chain(GvpNodePair p) {
     constexpr int S = 16 * NTS, CH4 = NTS * 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -905,7 +937,49 @@ __global__ __launch_bounds__(256, 2) void k_gvp_node_chain(GvpNodePair p) {
     if (a.z) inv_norm = 1.0f / a.z[a.bidx[v]];
 
     v4f x[NTS], acc[NTS], Vc[3], Vm[3];
-    {   // s + msg / norm, v + msg_v / norm
+    if constexpr (TR) {   // s + dropout(msg / norm), v + dropout(msg_v / norm); the sums are kept
+        const GvpNodeTrain &t = a.tr;
+#pragma unroll
+        for (int nt = 0; nt < NTS; ++nt) x[nt] = zero4();
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Vc[c] = zero4();
+        for (int i = 0; i < a.n_in; ++i) {
+            const int lo = a.rowptr[i][v], hi = a.rowptr[i][v + 1];
+            if (hi > lo) {
+                const float w = (a.mean ? 1.0f / (float)(hi - lo) : 1.0f) * inv_norm;
+                const float *mp = a.ms_main[i] + (size_t)v * S + 4 * q;
+                v4f m[NTS], mv[3];
+#pragma unroll
+                for (int nt = 0; nt < NTS; ++nt) m[nt] = *reinterpret_cast<const v4f *>(mp + 16 * nt);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) mv[c] = *reinterpret_cast<const v4f *>(a.mv_main[i] + (size_t)v * 48 + 16 * c + 4 * q);
+                for (int tl = lo / TM + 1; tl <= (hi - 1) / TM; ++tl) {       // pieces continued into later tiles
+                    const float *cp = a.ms_cont[i] + (size_t)tl * S + 4 * q;
+#pragma unroll
+                    for (int nt = 0; nt < NTS; ++nt) m[nt] += *reinterpret_cast<const v4f *>(cp + 16 * nt);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) mv[c] += *reinterpret_cast<const v4f *>(a.mv_cont[i] + (size_t)tl * 48 + 16 * c + 4 * q);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NTS; ++nt) x[nt] += m[nt] * w;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Vc[c] += mv[c] * w;
+            }
+        }
+        lanes_dropout<NTS>(x, Vc, t, 0, v, q);
+        const float *sp = t.s_in + (size_t)v * S + 4 * q;
+#pragma unroll
+        for (int nt = 0; nt < NTS; ++nt) x[nt] += *reinterpret_cast<const v4f *>(sp + 16 * nt);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Vc[c] += *reinterpret_cast<const v4f *>(t.v_in + (size_t)v * 48 + 16 * c + 4 * q);
+        if (valid) {
+            float *so = t.sa + (size_t)v * S + 4 * q;
+#pragma unroll
+            for (int nt = 0; nt < NTS; ++nt) *reinterpret_cast<v4f *>(so + 16 * nt) = x[nt];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) *reinterpret_cast<v4f *>(t.va + (size_t)v * 48 + 16 * c + 4 * q) = Vc[c];
+        }
+    } else {   // s + msg / norm, v + msg_v / norm
         const float *sp = a.s + (size_t)v * S + 4 * q;
 #pragma unroll
         for (int nt = 0; nt < NTS; ++nt) x[nt] = *reinterpret_cast<const v4f *>(sp + 16 * nt);
@@ -938,10 +1012,14 @@ __global__ __launch_bounds__(256, 2) void k_gvp_node_chain(GvpNodePair p) {
     // message layer norm (gvp.py:519-521); its output is also the residual of the update block
     lanes_layernorm<NTS>(x, a.ln1_w, a.ln1_b, q, a.ln_inv_n, a.ln_pad);
     lanes_vecnorm(Vc, a.vn_inv_n, a.vn_pad);
-    float *tmp = a.s_tmp + (size_t)v * S + 4 * q;
+    float *tmp = (TR ? a.tr.s1 : a.s_tmp) + (size_t)v * S + 4 * q;
     if (valid) {
 #pragma unroll
         for (int nt = 0; nt < NTS; ++nt) *reinterpret_cast<v4f *>(tmp + 16 * nt) = x[nt];
+        if constexpr (TR) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) *reinterpret_cast<v4f *>(a.tr.v1 + (size_t)v * 48 + 16 * c + 4 * q) = Vc[c];
+        }
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) Vm[c] = Vc[c];
@@ -957,17 +1035,37 @@ __global__ __launch_bounds__(256, 2) void k_gvp_node_chain(GvpNodePair p) {
         else {
             const v4f *cb = reinterpret_cast<const v4f *>(a.g[k].chain);
             const v4f *nb = k + 1 < n_gvps ? reinterpret_cast<const v4f *>(a.g[k + 1].chain) : cb + (size_t)NTS * CH4;
-            chain_generic_gvp<NTS>(ring, cb, nb, a.g[k], k + 1 < n_gvps ? a.g[k + 1].b : nullptr, x, acc, Vc, lane, q);
+            if constexpr (TR) chain_generic_gvp<NTS, decltype(ring), 1>(ring, cb, nb, a.g[k], k + 1 < n_gvps ? a.g[k + 1].b : nullptr, x, acc, Vc, lane, q,
+                                                                         &a.tr.g[k], (size_t)v, valid);
+            else chain_generic_gvp<NTS>(ring, cb, nb, a.g[k], k + 1 < n_gvps ? a.g[k + 1].b : nullptr, x, acc, Vc, lane, q);
         }
     }
     // residual + update layer norm (gvp.py:524-532)
+    if constexpr (TR) lanes_dropout<NTS>(x, Vc, a.tr, 1, v, q);
 #pragma unroll
     for (int nt = 0; nt < NTS; ++nt) x[nt] += *reinterpret_cast<const v4f *>(tmp + 16 * nt);
 #pragma unroll
     for (int c = 0; c < 3; ++c) Vc[c] += Vm[c];
+    if constexpr (TR) {
+        if (valid) {
+            float *so = a.tr.sb + (size_t)v * S + 4 * q;
+#pragma unroll
+            for (int nt = 0; nt < NTS; ++nt) *reinterpret_cast<v4f *>(so + 16 * nt) = x[nt];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) *reinterpret_cast<v4f *>(a.tr.vb + (size_t)v * 48 + 16 * c + 4 * q) = Vc[c];
+        }
+    }
     lanes_layernorm<NTS>(x, a.ln2_w, a.ln2_b, q, a.ln_inv_n, a.ln_pad);
     lanes_vecnorm(Vc, a.vn_inv_n, a.vn_pad);
-    if (valid) {
+    if constexpr (TR) {
+        if (valid) {
+            float *so = a.tr.s_out + (size_t)v * S + 4 * q;
+#pragma unroll
+            for (int nt = 0; nt < NTS; ++nt) *reinterpret_cast<v4f *>(so + 16 * nt) = x[nt];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) *reinterpret_cast<v4f *>(a.tr.v_out + (size_t)v * 48 + 16 * c + 4 * q) = Vc[c];
+        }
+    } else if (valid) {
         float *so = a.s + (size_t)v * S + 4 * q;
 #pragma unroll
         for (int nt = 0; nt < NTS; ++nt) *reinterpret_cast<v4f *>(so + 16 * nt) = x[nt];
@@ -1206,7 +1304,9 @@ kpd_status launch_gvp_edge(const GvpEdgeArgs &a, int tile_cap, hipStream_t st) {
         for (int et = 0; et < 4; ++et)
             KPD_REQUIRE(!a.src[et] || (a.g[et][0].h == 17 && a.n_gvps <= 4), KPD_ERR_INVALID, "gvp chain kernel: the training form wants a 17-channel head GVP");
         KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_chain<16, 0, 1>), ChainSmem<16>::FLOATS * 4));
-        hipLaunchKernelGGL((k_gvp_chain<16, 0, 1>), grid, dim3(256), ChainSmem<16>::FLOATS * 4, st, a);
+        GvpEdgeArgs b = a;
+        b.train_skip = tool_env_int("KPD_TR_SKIP", 0);          // (TOOLS build: timing experiments; a compile-time 0 in the product)
+        hipLaunchKernelGGL((k_gvp_chain<16, 0, 1>), grid, dim3(256), ChainSmem<16>::FLOATS * 4, st, b);
     } else if (a.S == 256)
         hipLaunchKernelGGL(k_gvp_chain<16>, grid, dim3(256), ChainSmem<16>::FLOATS * 4, st, a);
     else
@@ -1294,6 +1394,14 @@ kpd_status launch_gvp_node(const GvpNodePair &pin, hipStream_t st) {
             for (int k = 0; k < p.nt[nt].n_gvps; ++k)
                 KPD_REQUIRE(p.nt[nt].g[k].chain && p.nt[nt].g[k].whp && p.nt[nt].g[k].wup, KPD_ERR_STATE,
                             "update GVP %d was not prepared for the chained node kernel", k);
+    if (p.nt[0].train || p.nt[1].train) {
+        KPD_REQUIRE(S == 256 && p.gemm_mode == 0 && (p.nt[0].n == 0 || p.nt[0].train) && (p.nt[1].n == 0 || p.nt[1].train), KPD_ERR_INVALID,
+                    "gvp node kernel: the training form runs at S = 256 in the exact fp32 mode, for both node types of a launch");
+        KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_node_chain<16, 0, 1>), 3 * 16 * 64 * 16));
+        hipLaunchKernelGGL((k_gvp_node_chain<16, 0, 1>), dim3(tiles), dim3(256), 3 * 16 * 64 * 16, st, p);
+        KPD_LAUNCH_CHECK();
+        return KPD_OK;
+    }
     if (!(S == 256 && p.gemm_mode == 1) && p.nt[0].n + p.nt[1].n <= coop_rows_max(p.coop_rows)) return launch_gvp_node_coop(p, st);
     KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_node_chain<16>), 3 * 16 * 64 * 16));
     KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_node_chain<8>), 3 * 8 * 64 * 16));

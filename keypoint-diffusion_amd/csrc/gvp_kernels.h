@@ -50,6 +50,7 @@ struct GvpEdgeArgs {
     float *mv_main[4], *mv_cont[4];   // [n_dst][48], [tiles][48]
     unsigned long long *stamps;       // [32] phase-cycle sums (diagnostics only, null in production)
     int gemm_mode;                    // 0: exact fp32 MFMA; 1: f16x2 split in the 256 x 256 products of the non-head message GVPs
+    int train_skip;                   // TOOLS build only (KPD_TR_SKIP): bit 0 / 1 / 2 = leave out the pre / s / remaining stores of the training form (timing experiments)
     const GvpTrainSlot *train;        // non-null: the training form of the kernel -- node vectors v arrive as [n][3][16], the vector pieces
                                       // mv_main / mv_cont leave as [3][16], and every activation the backward pass reads is stored (device table [4])
 };
@@ -88,6 +89,22 @@ struct GvpEdgeBwdArgs {
 };
 kpd_status launch_gvp_edge_bwd(const GvpEdgeBwdArgs &a, int tile_cap, hipStream_t st);
 
+// Training form of the node update (k_gvp_node_chain<16, 0, 1>): the conv's input state is read only, everything the backward pass reads is
+// kept, GVPDropout (gvp.py:119-149) acts on the aggregated messages and on the update residual with the trainers' Philox streams
+// (gvp_train_core.h, dropout_scale), vectors travel as [n][3][16].
+struct GvpNodeTrain {
+    const float *s_in, *v_in;         // [n][256], [n][3][16]
+    float *s_out, *v_out;             // the conv's output state
+    float *sa, *va;                   // s + dropout(aggregated messages): input of the message LayerNorm
+    float *s1, *v1;                   // its output (the residual of the update block)
+    float *sb, *vb;                   // s1 + dropout(update chain): input of the update LayerNorm
+    GvpTrainGvp g[GVP_MAX_CHAIN];     // the update GVPs' activations
+    float rate;                       // dropout rate (0: none)
+    unsigned long long seed;
+    unsigned stream[4];               // Philox streams: message scalars / vectors, update scalars / vectors
+    int live_v;                       // the model's vector_size (layout of the vector masks)
+};
+
 struct GvpNodeArgs {
     int n;
     float *s;                     // [n][S] in/out
@@ -106,6 +123,8 @@ struct GvpNodeArgs {
     int S;
     float ln_inv_n, ln_pad;       // LayerNorm over the model's n_hidden_scalars = S - ln_pad features: 1 / that width, and the padding count
     float vn_inv_n, vn_pad;       // its vector half over vector_size = 16 - vn_pad channels
+    int train;                    // 1: the training form (tr; mv_main / mv_cont as [3][16])
+    GvpNodeTrain tr;
 };
 
 struct GvpNodePair {

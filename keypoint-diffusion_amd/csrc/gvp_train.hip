@@ -85,6 +85,15 @@ struct kpd_gvp_trainer : TrainCtx {
     PackDesc *desc_dev = nullptr;
     int n_desc = 0, desc_cap = 0;
     GvpTrainSlot *slots_dev = nullptr;             // [conv * 4 + et]
+    // Fused node update (k_gvp_node_chain<16, 0, 1>): one launch per conv for both node types -- message sums, dropout, the two layer norms and
+    // the update chain; what the backward pass reads is kept per (conv, node type) instead of being recomputed there.
+    struct NodeSlot {
+        float *s1 = nullptr, *v1 = nullptr, *sb = nullptr, *vb = nullptr;
+        GvpBuf gb[4];
+    };
+    std::vector<NodeSlot> nslots;                  // [conv * 2 + nt]
+    struct NodePack { GvpW g[4]; };
+    std::vector<NodePack> npacks;                  // [conv * 2 + nt]: the update GVPs in the kernels' fragment order
     GvpBwdSlot bslots[4];                          // per edge type: what the fused message backward leaves for the weight-gradient products
     GvpBwdSlot *bslots_dev = nullptr;              // [4]
     float *Psrc[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -217,38 +226,6 @@ __global__ void k_gvp_train_pack(const kpd_gvp_trainer::PackDesc *__restrict__ d
     d.dst[idx] = (n < d.n_valid && i < d.k_valid) ? d.src[(size_t)n * d.sn + (size_t)(d.k_base + i) * d.sk] : 0.0f;
 }
 
-// sa[v] / va[v] = sum over the edge types into this node type of scale(v) x (main piece + the pieces continued into later tiles): the
-// aggregation k_gvp_node_chain does in its prologue (gvp_chain.hip), as the trainers' pre-dropout message sums.  One wave per node.
-struct CombineArgs {
-    int n, n_in, mode;
-    float norm;
-    const int *rowptr[2];
-    const float *ms_main[2], *ms_cont[2], *mv_main[2], *mv_cont[2];
-    const float *z;
-    const int *bidx;
-    float *sa, *va;
-};
-__global__ __launch_bounds__(256) void k_gvp_msg_combine(CombineArgs a) {
-    const int v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (v >= a.n) return;
-    v4f s = zero4(), w = zero4();
-    for (int i = 0; i < a.n_in; ++i) {
-        const int lo = a.rowptr[i][v], hi = a.rowptr[i][v + 1];
-        if (hi <= lo) continue;
-        const float sc = a.mode == 1 ? 1.0f / (float)(hi - lo) : 1.0f / (a.mode == 2 ? a.z[a.bidx[v]] : a.norm);
-        v4f m = *reinterpret_cast<const v4f *>(a.ms_main[i] + (size_t)v * 256 + 4 * lane), mv = zero4();
-        if (lane < 12) mv = *reinterpret_cast<const v4f *>(a.mv_main[i] + (size_t)v * 48 + 4 * lane);
-        for (int t = lo / TM + 1; t <= (hi - 1) / TM; ++t) {
-            m += *reinterpret_cast<const v4f *>(a.ms_cont[i] + (size_t)t * 256 + 4 * lane);
-            if (lane < 12) mv += *reinterpret_cast<const v4f *>(a.mv_cont[i] + (size_t)t * 48 + 4 * lane);
-        }
-        s += m * sc;
-        w += mv * sc;
-    }
-    *reinterpret_cast<v4f *>(a.sa + (size_t)v * 256 + 4 * lane) = s;
-    if (lane < 12) *reinterpret_cast<v4f *>(a.va + (size_t)v * 48 + 4 * lane) = w;
-}
-
 // split-sum scratch: one share per CU of a batched message-chain weight gradient (256 x 256 + the narrow riders, wgrad_batch) with slack for
 // the rounding of the per-product slice counts
 constexpr size_t GVP_PART_FLOATS = std::max<size_t>(GRAD_PART_FLOATS, (size_t)320 * (256 * 256 + 256 * 17 + 256 + 16 * 256));
@@ -256,6 +233,7 @@ constexpr size_t PK_CHUNK = 16 * 256;                                   // float
 constexpr size_t PK_HEAD = 4 * PK_CHUNK + 9 * 256 + 2 * 256 + 256 + 64 + 16 * PK_CHUNK + 256 + 4 * PK_CHUNK;      // chain | whp | wup | b | bg | wproj | bproj | backward chain
 constexpr size_t PK_GENERIC = 18 * PK_CHUNK + 256 + 256 + 256 + 64 + 18 * PK_CHUNK + 512;                            // chain | whp | wup | b | bg | backward chain | Wu^T | Wh^T
 inline size_t pack_floats_per_chain(int nm) { return PK_HEAD + (size_t)(nm - 1) * PK_GENERIC; }
+constexpr size_t PK_NODE_GVP = 18 * PK_CHUNK + 256 + 256 + 256 + 64;                                  // an update GVP: chain | whp | wup | b | bg
 
 // carve the pack arena and (re)build the descriptor table from the bound parameters
 kpd_status build_pack_table(kpd_gvp_trainer *T) {
@@ -328,6 +306,29 @@ kpd_status build_pack_table(kpd_gvp_trainer *T) {
                 }
             }
         }
+    const int nu = T->cfg.n_update_gvps;
+    T->npacks.assign((size_t)L * 2, kpd_gvp_trainer::NodePack());
+    for (int conv = 0; conv < L; ++conv)
+        for (int nt = 0; nt < 2; ++nt) {
+            if (!conv_uses(T, conv, nt == 0 ? 0 : 2)) continue;          // (lig is the destination of ll / kl, kp of lk / kk)
+            const std::string prefix = "noise_predictor.conv_layers." + std::to_string(conv) + ".node_update_fns." + kNtName[nt];
+            for (int j = 0; j < nu; ++j) {
+                GvpP g;
+                KPD_TRY(gvp_params(T, prefix + "." + std::to_string(j), VC, VC, S, S, &g));
+                const int k_all = g.si + g.h;
+                float *chain = take(18 * PK_CHUNK), *whp = take(256), *wup = take(256), *b = take(256), *bg = take(64);
+                GvpW &w = T->npacks[(size_t)conv * 2 + nt].g[j];
+                w.b = b; w.bg = bg; w.vin = g.vi; w.h = g.h; w.vout = g.vo; w.sout = S; w.vec_sigmoid = 1;
+                w.chain = chain; w.chain_h = nullptr; w.whp = whp; w.wup = wup;
+                frag(g.Wh.w, 1, VC, VC, 0, 16, 1, whp);
+                frag(g.Wu.w, 1, VC, VC, 0, 16, 1, wup);
+                for (int kc = 0; kc < 16; ++kc) frag(g.Ws.w, k_all, 1, S, 16 * kc, 16, 16, chain + (size_t)kc * PK_CHUNK);
+                frag(g.Ws.w, k_all, 1, S, S, 16, 16, chain + 16 * PK_CHUNK);
+                for (int nt2 = 0; nt2 < 16; ++nt2) frag(g.Wg.w, S, 1, VC, 16 * nt2, 16, 1, chain + 17 * PK_CHUNK + nt2 * 256);
+                copy(g.bs.w, S, 256, b);
+                copy(g.bg.w, VC, 16, bg);
+            }
+        }
     if ((int)descs.size() > T->desc_cap) {
         if (T->desc_dev) (void)hipFree(T->desc_dev);
         T->desc_dev = nullptr;
@@ -349,8 +350,8 @@ kpd_status pack_chains(kpd_gvp_trainer *T) {
     return KPD_OK;
 }
 
-// the messages of one conv, all edge types: per-node projections, the chained edge kernel in its training form, the piece sums into sa / va
-kpd_status conv_messages_fused(kpd_gvp_trainer *T, int conv, const bool (&is_dst)[2]) {
+// the messages of one conv, all edge types: per-node projections, then the chained edge kernel in its training form (message pieces per tile)
+kpd_status conv_messages_fused(kpd_gvp_trainer *T, int conv) {
     const int S = T->S, nm = T->cfg.n_message_gvps;
     const bool all4 = conv_uses(T, conv, 2);
     GvpProjArgs pa;
@@ -377,22 +378,52 @@ kpd_status conv_messages_fused(kpd_gvp_trainer *T, int conv, const bool (&is_dst
     pa.S = S;
     KPD_TRY(launch_gvp_proj(pa, T->st));
     KPD_TRY(launch_gvp_edge(ea, tiles, T->st));
+    return KPD_OK;
+}
+
+// the node update of one conv, both node types, from the message pieces of conv_messages_fused
+kpd_status conv_nodes_fused(kpd_gvp_trainer *T, int conv, const bool (&is_dst)[2]) {
+    const int S = T->S, nu = T->cfg.n_update_gvps;
+    const bool all4 = conv_uses(T, conv, 2);
+    const std::string cp = "noise_predictor.conv_layers." + std::to_string(conv);
+    GvpNodePair np;
+    memset(&np, 0, sizeof(np));
     for (int nt = 0; nt < 2; ++nt) {
         if (!is_dst[nt]) continue;
-        CombineArgs ca;
-        memset(&ca, 0, sizeof(ca));
-        ca.n = T->n[nt]; ca.mode = T->cfg.message_norm_mode; ca.norm = T->cfg.message_norm; ca.z = T->z[nt]; ca.bidx = T->bidx[nt];
-        ca.sa = T->sa[nt][conv]; ca.va = T->va[nt][conv];
+        GvpNodeArgs &na = np.nt[nt];
+        LnP l1, l2;
+        KPD_TRY(ln_params(T, cp + ".message_layer_norms." + kNtName[nt], &l1));
+        KPD_TRY(ln_params(T, cp + ".update_layer_norms." + kNtName[nt], &l2));
+        na.n = T->n[nt]; na.bidx = T->bidx[nt];
+        na.mean = T->cfg.message_norm_mode == 1;
+        na.z = T->cfg.message_norm_mode == 2 ? T->z[nt] : nullptr;
+        na.norm_const = T->cfg.message_norm_mode == 0 ? T->cfg.message_norm : 1.0f;
         for (int et = 0; et < (all4 ? 4 : 2); ++et) {
             if (kDst[et] != nt) continue;
-            const int i = ca.n_in++;
-            ca.rowptr[i] = T->e_rowptr[et];
-            ca.ms_main[i] = T->ms_main[et]; ca.ms_cont[i] = T->ms_cont[et]; ca.mv_main[i] = T->mv_main[et]; ca.mv_cont[i] = T->mv_cont[et];
+            const int k = na.n_in++;
+            na.rowptr[k] = T->e_rowptr[et];
+            na.ms_main[k] = T->ms_main[et]; na.ms_cont[k] = T->ms_cont[et]; na.mv_main[k] = T->mv_main[et]; na.mv_cont[k] = T->mv_cont[et];
         }
-        hipLaunchKernelGGL(k_gvp_msg_combine, dim3(cdiv(ca.n, 4)), dim3(256), 0, T->st, ca);
-        KPD_LAUNCH_CHECK();
+        na.ln1_w = l1.gamma.w; na.ln1_b = l1.beta.w; na.ln2_w = l2.gamma.w; na.ln2_b = l2.beta.w;
+        na.n_gvps = nu; na.S = S;
+        na.ln_inv_n = 1.0f / (float)S; na.ln_pad = 0.0f;
+        na.vn_inv_n = 1.0f / (float)T->V; na.vn_pad = (float)(VC - T->V);
+        const kpd_gvp_trainer::NodeSlot &ns = T->nslots[(size_t)conv * 2 + nt];
+        for (int j = 0; j < nu; ++j) {
+            na.g[j] = T->npacks[(size_t)conv * 2 + nt].g[j];
+            const GvpBuf &b = ns.gb[j];
+            na.tr.g[j] = GvpTrainGvp{b.Vh, b.Vu, b.sh, b.pre, b.s, b.gate, b.V};
+        }
+        na.train = 1;
+        GvpNodeTrain &t = na.tr;
+        t.s_in = T->ss[nt][conv]; t.v_in = T->vs[nt][conv]; t.s_out = T->ss[nt][conv + 1]; t.v_out = T->vs[nt][conv + 1];
+        t.sa = T->sa[nt][conv]; t.va = T->va[nt][conv]; t.s1 = ns.s1; t.v1 = ns.v1; t.sb = ns.sb; t.vb = ns.vb;
+        t.rate = T->dropout; t.seed = T->seed; t.live_v = T->V;
+        t.stream[0] = drop_stream(conv, nt, 0, 0); t.stream[1] = drop_stream(conv, nt, 0, 1);
+        t.stream[2] = drop_stream(conv, nt, 1, 0); t.stream[3] = drop_stream(conv, nt, 1, 1);
     }
-    return KPD_OK;
+    np.tiles0 = cdiv(np.nt[0].n, TM);
+    return launch_gvp_node(np, T->st);
 }
 
 // one GVPMultiEdgeConv forward (gvp.py:459-538): ss/vs[conv] -> ss/vs[conv + 1]; keeps sa/va[conv] (pre-LayerNorm sums)
@@ -412,7 +443,10 @@ kpd_status conv_fwd(kpd_gvp_trainer *T, int conv) {
         KPD_HIP(hipMemsetAsync(T->sa[nt][conv], 0, (size_t)T->n[nt] * S * 4, T->st));          // aggregated messages first ...
         KPD_HIP(hipMemsetAsync(T->va[nt][conv], 0, (size_t)T->n[nt] * 3 * VC * 4, T->st));
     }
-    if (T->fused) KPD_TRY(conv_messages_fused(T, conv, is_dst));
+    if (T->fused) {
+        KPD_TRY(conv_messages_fused(T, conv));
+        return conv_nodes_fused(T, conv, is_dst);
+    }
     for (int et = 0; et < 4; ++et) {
         if (T->fused || !conv_uses(T, conv, et) || T->E[et] == 0) continue;
         const int d = kDst[et];
@@ -502,21 +536,29 @@ kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
         KPD_TRY(ln_params(T, cp + ".message_layer_norms." + kNtName[nt], &l1));
         KPD_TRY(ln_params(T, cp + ".update_layer_norms." + kNtName[nt], &l2));
         const std::string up = cp + ".node_update_fns." + kNtName[nt];
-        // recompute s1, v1, the update chain and the second pre-norm sums
-        KPD_TRY(gvp_ln_fwd(T, l1, n, T->sa[nt][conv], T->va[nt][conv], T->s1, T->v1));
-        KPD_TRY(chain_fwd(T, up, nu, n, T->s1, T->v1));
-        KPD_TRY(dropout_apply(T, conv, nt, 1, n, T->gb[nu - 1].s, T->gb[nu - 1].V, T->tmp_s, T->tmp_v));
-        hipLaunchKernelGGL(k_add, grid1((long long)n * S), dim3(256), 0, T->st, T->s1, T->tmp_s, (long long)n * S, T->sb);
-        KPD_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_add, grid1((long long)n * 3 * VC), dim3(256), 0, T->st, T->v1, T->tmp_v, (long long)n * 3 * VC, T->vb);
-        KPD_LAUNCH_CHECK();
+        const float *s1 = T->s1, *v1 = T->v1, *sb = T->sb, *vb = T->vb;
+        if (T->fused) {
+            // kept by the fused node update (conv_nodes_fused)
+            const kpd_gvp_trainer::NodeSlot &ns = T->nslots[(size_t)conv * 2 + nt];
+            s1 = ns.s1; v1 = ns.v1; sb = ns.sb; vb = ns.vb;
+            for (int j = 0; j < nu; ++j) T->gb[j] = ns.gb[j];
+        } else {
+            // recompute s1, v1, the update chain and the second pre-norm sums
+            KPD_TRY(gvp_ln_fwd(T, l1, n, T->sa[nt][conv], T->va[nt][conv], T->s1, T->v1));
+            KPD_TRY(chain_fwd(T, up, nu, n, T->s1, T->v1));
+            KPD_TRY(dropout_apply(T, conv, nt, 1, n, T->gb[nu - 1].s, T->gb[nu - 1].V, T->tmp_s, T->tmp_v));
+            hipLaunchKernelGGL(k_add, grid1((long long)n * S), dim3(256), 0, T->st, T->s1, T->tmp_s, (long long)n * S, T->sb);
+            KPD_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_add, grid1((long long)n * 3 * VC), dim3(256), 0, T->st, T->v1, T->tmp_v, (long long)n * 3 * VC, T->vb);
+            KPD_LAUNCH_CHECK();
+        }
         // second GVPLayerNorm: d(sb, vb) -> ds[0] / dV[0]
-        KPD_TRY(gvp_ln_bwd(T, l2, n, T->sb, T->vb, T->gs[cur][nt], T->gv[cur][nt], T->ds[0], T->dV[0]));
+        KPD_TRY(gvp_ln_bwd(T, l2, n, sb, vb, T->gs[cur][nt], T->gv[cur][nt], T->ds[0], T->dV[0]));
         // residual: d s1 += d sb, d v1 += d vb -> keep them in gs/gv[nxt] for now; the update chain sees them through its dropout mask
         KPD_HIP(hipMemcpyAsync(T->gs[nxt][nt], T->ds[0], (size_t)n * S * 4, hipMemcpyDeviceToDevice, T->st));
         KPD_HIP(hipMemcpyAsync(T->gv[nxt][nt], T->dV[0], (size_t)n * 3 * VC * 4, hipMemcpyDeviceToDevice, T->st));
         KPD_TRY(dropout_apply(T, conv, nt, 1, n, T->ds[0], T->dV[0], T->ds[0], T->dV[0]));
-        KPD_TRY(chain_bwd(T, up, nu, n, T->s1, T->v1));
+        KPD_TRY(chain_bwd(T, up, nu, n, s1, v1));
         hipLaunchKernelGGL(k_acc, grid1((long long)n * S), dim3(256), 0, T->st, T->gs[nxt][nt], T->ds[0], (long long)n * S);
         KPD_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_acc, grid1((long long)n * 3 * VC), dim3(256), 0, T->st, T->gv[nxt][nt], T->dV[0], (long long)n * 3 * VC);
@@ -928,7 +970,17 @@ extern "C" kpd_status kpd_gvp_trainer_reserve(kpd_gvp_trainer *T, int32_t max_B,
             for (int conv = 0; conv < L; ++conv)
                 for (int et = 0; et < 4; ++et)
                     if (conv_uses(T, conv, et)) floats += pack_floats_per_chain(nm);
+            const int nu = c.n_update_gvps;
+            for (int conv = 0; conv < L; ++conv)
+                for (int nt = 0; nt < 2; ++nt)
+                    if (conv_uses(T, conv, nt == 0 ? 0 : 2)) floats += (size_t)nu * PK_NODE_GVP;
             const size_t pack_floats = floats;
+            // kept node-update activations per (conv, destination node type): s1, v1, sb, vb and the seven buffers of every update GVP
+            std::vector<size_t> off_n((size_t)L * 2, 0);
+            const size_t node_per_row = 2 * (256 + 48) + (size_t)nu * (3 * 16 + 3 * 16 + 16 + 256 + 256 + 16 + 3 * 16);
+            for (int conv = 0; conv < L; ++conv)
+                for (int nt = 0; nt < 2; ++nt)
+                    if (conv_uses(T, conv, nt == 0 ? 0 : 2)) { off_n[(size_t)conv * 2 + nt] = floats; floats += (size_t)nn[nt] * node_per_row; }
             size_t off_P[4], off_main[4], off_cont[4], off_vmain[4], off_vcont[4];
             for (int et = 0; et < 4; ++et) {
                 const size_t tiles = (size_t)cap_et[et] / TM + 2;
@@ -973,6 +1025,20 @@ extern "C" kpd_status kpd_gvp_trainer_reserve(kpd_gvp_trainer *T, int32_t max_B,
                     bs.drbf = p;
                 }
                 KPD_HIP(hipMemcpy(T->bslots_dev, T->bslots, 4 * sizeof(GvpBwdSlot), hipMemcpyHostToDevice));
+                T->nslots.assign((size_t)L * 2, kpd_gvp_trainer::NodeSlot());
+                for (int conv = 0; conv < L; ++conv)
+                    for (int nt = 0; nt < 2; ++nt) {
+                        if (!conv_uses(T, conv, nt == 0 ? 0 : 2)) continue;
+                        float *p = T->pack_base + off_n[(size_t)conv * 2 + nt];
+                        const size_t n = nn[nt];
+                        kpd_gvp_trainer::NodeSlot &ns = T->nslots[(size_t)conv * 2 + nt];
+                        ns.s1 = p; p += n * 256; ns.v1 = p; p += n * 48; ns.sb = p; p += n * 256; ns.vb = p; p += n * 48;
+                        for (int j = 0; j < nu; ++j) {
+                            GvpBuf &b = ns.gb[j];
+                            b.Vh = p; p += n * 48; b.Vu = p; p += n * 48; b.sh = p; p += n * 16; b.pre = p; p += n * 256; b.s = p; p += n * 256;
+                            b.gate = p; p += n * 16; b.V = p; p += n * 48;
+                        }
+                    }
                 KPD_HIP(hipMemset(T->pack_base, 0, pack_floats * 4));           // zero biases of the head GVPs, unused fragment tiles
                 KPD_HIP(hipMemcpy(T->slots_dev, hs.data(), hs.size() * sizeof(GvpTrainSlot), hipMemcpyHostToDevice));
                 for (int et = 0; et < 4; ++et) {
