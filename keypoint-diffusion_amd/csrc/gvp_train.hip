@@ -674,10 +674,9 @@ kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
         KPD_TRY(segsum(T->st, dpre0, S, 0, S, T->scsr[et].perm, T->scsr[et].rowptr, nullptr, 1.0f, false, T->n[s], T->U, S));
         if (g0.Ws.g) KPD_TRY(grad_gemm(T, S, S, T->n[s], T->U, S, T->ss[s][conv], S, g0.Ws.g, g0.si + g0.h));
         KPD_TRY(gemm(T, false, false, T->n[s], S, S, T->U, S, g0.Ws.w, g0.si + g0.h, 1.0f, T->gs[nxt][s], S));
-        for (int cc = 0; cc < 3; ++cc) {      // vector rows [E, 3, 17], channels 1..16 -> gv[src, 3, 16]
-            KPD_TRY(segsum(T->st, T->dV[1], 3 * VH, cc * VH + 1, VC, T->scsr[et].perm, T->scsr[et].rowptr, nullptr, 1.0f, true, T->n[s],
-                           T->gv[nxt][s] + cc * VC, 3 * VC));
-        }
+        // vector rows [E, 3, 17], channels 1..16 -> gv[src, 3, 16]
+        hipLaunchKernelGGL(k_segsum_vin, dim3(cdiv(T->n[s], 4)), dim3(256), 0, T->st, T->dV[1], T->scsr[et].perm, T->scsr[et].rowptr, T->n[s], T->gv[nxt][s]);
+        KPD_LAUNCH_CHECK();
     }
     for (size_t i = 0; i < wq.size(); i += 8) KPD_TRY(wgrad_batch(wq.data() + i, (int)std::min<size_t>(8, wq.size() - i), T->part, T->part_floats, T->st));
     for (size_t i = 0; i < wq_top.size(); i += 8)

@@ -92,6 +92,29 @@ __global__ void k_gvp_vin(const float *__restrict__ unit, const float *__restric
     vin[i] = ch == 0 ? unit[3 * e + c] : vsrc[((size_t)src[e] * 3 + c) * VC + ch - 1];
 }
 
+// gv[v, c, ch] += sum over the out-edges j of source node v (ascending edge order) of dvin[perm[j], c, 1 + ch]: the gradient of the source
+// vectors from that of the message inputs [x_diff | v_src] ([E, 3, 17], channels 1..16), the three components in one launch.  A quarter
+// wave per node, a lane per (component, channel) pair (48 of 64).
+__global__ __launch_bounds__(256) void k_segsum_vin(const float *__restrict__ dvin, const int *__restrict__ perm, const int *__restrict__ rowptr, int n,
+                                                    float *__restrict__ gv) {
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (v >= n || lane >= 3 * VC) return;
+    const int lo = rowptr[v], hi = rowptr[v + 1];
+    if (lo == hi) return;
+    const int off = (lane / VC) * VH + 1 + lane % VC;
+    float s = 0.0f;
+    int j = lo;
+    for (; j + 4 <= hi; j += 4) {
+        float m[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m[k] = dvin[(size_t)perm[j + k] * (3 * VH) + off];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s += m[k];
+    }
+    for (; j < hi; ++j) s += dvin[(size_t)perm[j] * (3 * VH) + off];
+    gv[(size_t)v * (3 * VC) + lane] += s;
+}
+
 // sh[m, j] = sqrt(max(sum_c Vh[m, c, j]^2, 1e-8)) (_norm_no_nan, gvp.py:12-19)
 __global__ void k_gvp_sh(const float *__restrict__ Vh, long long total, int h, float *__restrict__ sh) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -893,14 +916,16 @@ kpd_status gvp_ln_fwd(TT *T, const LnP &l, int n, const float *s, const float *v
 template <class TT>
 kpd_status gvp_ln_bwd(TT *T, const LnP &l, int n, const float *s, const float *v, const float *dso, const float *dvo,
                       float *ds, float *dv) {
-    hipLaunchKernelGGL(k_ln_bwd_g, dim3(cdiv(n, 4)), dim3(256), 0, T->st, s, l.gamma.w, dso, n, T->S, T->tmp_s, T->U);
+    // (through tmp_s / tmp_v only when the outputs alias the incoming gradients: dso is read again for the bias gradient)
+    float *os = ds == dso ? T->tmp_s : ds, *ov = dv == dvo ? T->tmp_v : dv;
+    hipLaunchKernelGGL(k_ln_bwd_g, dim3(cdiv(n, 4)), dim3(256), 0, T->st, s, l.gamma.w, dso, n, T->S, os, T->U);
     KPD_LAUNCH_CHECK();
     KPD_TRY(colsum_acc(T, n, T->S, T->U, T->S, l.gamma.g));        // U (free outside the edge passes) = dy * xhat
     KPD_TRY(colsum_acc(T, n, T->S, dso, T->S, l.beta.g));
-    KPD_HIP(hipMemcpyAsync(ds, T->tmp_s, (size_t)n * T->S * 4, hipMemcpyDeviceToDevice, T->st));
-    hipLaunchKernelGGL(k_vnorm_bwd, grid1(n), dim3(256), 0, T->st, v, dvo, n, T->V, T->tmp_v);
+    if (os != ds) KPD_HIP(hipMemcpyAsync(ds, os, (size_t)n * T->S * 4, hipMemcpyDeviceToDevice, T->st));
+    hipLaunchKernelGGL(k_vnorm_bwd, grid1(n), dim3(256), 0, T->st, v, dvo, n, T->V, ov);
     KPD_LAUNCH_CHECK();
-    KPD_HIP(hipMemcpyAsync(dv, T->tmp_v, (size_t)n * 3 * VC * 4, hipMemcpyDeviceToDevice, T->st));
+    if (ov != dv) KPD_HIP(hipMemcpyAsync(dv, ov, (size_t)n * 3 * VC * 4, hipMemcpyDeviceToDevice, T->st));
     return KPD_OK;
 }
 

@@ -732,19 +732,20 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_tnx(WgradBatch bt) {
                 ax3 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, x3[k * 32], ax3, 0, 0, 0);
                 ax2 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[k * 32], bv, ax2, 0, 0, 0);
             } else {
+                // (fragment i of this wave is row block i ^ wc, fragment j column block j ^ wr: fragment 0 is then the one the riders pair
+                //  with, without a select in the MFMA stream)
                 float av[2], bv[4];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) av[i] = as[k * ROW + 32 * i];
+                for (int i = 0; i < 2; ++i) av[i] = as[k * ROW + 32 * (i ^ wc)];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) bv[j] = bs[k * ROW + 32 * j];
+                for (int j = 0; j < 4; ++j) bv[j] = bs[k * ROW + 32 * (j ^ wr)];
                 const float b2 = xb[k * 32], a2 = xa[k * 32];
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-                ax1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wc ? av[1] : av[0], b2, ax1, 0, 0, 0);
-                const float bsel = wr == 0 ? bv[0] : wr == 1 ? bv[1] : wr == 2 ? bv[2] : bv[3];
-                ax2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, bsel, ax2, 0, 0, 0);
+                ax1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], b2, ax1, 0, 0, 0);
+                ax2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, bv[0], ax2, 0, 0, 0);
             }
         }
     };
@@ -795,7 +796,7 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_tnx(WgradBatch bt) {
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    C[(size_t)(64 * wr + 32 * i + 8 * (r >> 2) + 4 * half + (r & 3)) * ROW + 128 * wc + 32 * j + col] = acc[i][j][r];
+                    C[(size_t)(64 * wr + 32 * (i ^ wc) + 8 * (r >> 2) + 4 * half + (r & 3)) * ROW + 128 * wc + 32 * (j ^ wr) + col] = acc[i][j][r];
         q += (size_t)a.slices * (ROW * ROW);
     }
     float *x1 = q + (size_t)slice * (ROW * a.nb2);
