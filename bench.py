@@ -639,7 +639,7 @@ def run_sampling(args, workload, device, rank, world, dist, B, n_rec, n_lig, rag
         if gemm == 'f16x2':
             # the 256 x 256 products of the non-head message GVPs run split (3 f16 products each); heads, gates and vector parts stay fp32:
             # price the whole kernel against the f16 / 3 peak as for the EGNN edge kernel (a lower bound on the fraction)
-            kernel, peak = 'k_gvp_chain<16, 1>', PEAK_F16_MATRIX_TFLOPS / 3.0
+            kernel, peak = 'k_gvp_chain<16, 1, 0>', PEAK_F16_MATRIX_TFLOPS / 3.0
     achieved = edges_per_launch * f_exec / avg_s / 1e12 if avg_s > 0 else 0.0
     hbm_gbs = edges_per_launch * b_algo / avg_s / 1e9 if avg_s > 0 else 0.0
     traffic, tsrc = load_traffic(workload + ('_ragged' if ragged else '') + ('_f16x2' if gemm != 'f32' else '')) if (B == 64 and (ragged or n_rec == 300)) else (None, None)

@@ -730,6 +730,60 @@ __device__ __forceinline__ v4f chunk_tile_product(const v4f *__restrict__ buf0, 
     return (ga[0] + ga[1]) + (ga[2] + ga[3]);
 }
 
+// backward of one generic GVP: acc holds dL/ds of its outputs on entry and dL/ds of its inputs on exit, dV likewise for the vectors; x is scratch
+template <int NTS, class Ring>
+__device__ __forceinline__ void chain_generic_gvp_bwd(Ring &ring, const v4f *cb, const v4f *nb, const GvpBwdW &w, const GvpTrainGvp *f, const GvpBwdGvp *o,
+                                                      v4f (&x)[NTS], v4f (&acc)[NTS], v4f (&dV)[3], size_t erow, bool live, int lane, int q) {
+    constexpr int S = 16 * NTS, CH4 = NTS * 64, NG = NTS + 2;
+    auto ahead = [&](int i) -> const v4f * { return i + 2 < NG ? cb + (size_t)(i + 2) * CH4 : nb + (size_t)(i + 2 - NG) * CH4; };
+    const v4f dgate = gate_bwd_lane(f, o, dV, erow, live, q);
+    // kept pre-activation: requested before the gate chunk, used behind it
+    {
+        const float *pr = f->pre + erow * S + 4 * q;
+#pragma unroll
+        for (int mt = 0; mt < NTS; ++mt) x[mt] = *reinterpret_cast<const v4f *>(pr + 16 * mt);
+    }
+    chunk_gemm<NTS>(ring.current(), dgate, acc, lane, 4, [&] { ring.prefetch(ahead(0)); });
+    ring.release();
+#pragma unroll
+    for (int mt = 0; mt < NTS; ++mt) x[mt] = acc[mt] * silu_grad4(x[mt]);
+    if (live) {
+        float *dp = o->dpre + erow * S + 4 * q;
+#pragma unroll
+        for (int mt = 0; mt < NTS; ++mt) *reinterpret_cast<v4f *>(dp + 16 * mt) = x[mt];
+    }
+#pragma unroll
+    for (int mt = 0; mt < NTS; ++mt) acc[mt] = zero4();
+#pragma unroll
+    for (int nt = 0; nt < NTS; ++nt) {
+        chunk_gemm<NTS>(ring.current(), x[nt], acc, lane, 4, [&] { ring.prefetch(ahead(1 + nt)); });
+        ring.release();
+    }
+    const v4f dsh = chunk_tile_product<NTS>(ring.current(), x, lane, [&] { ring.prefetch(ahead(NTS + 1)); });
+    ring.release();
+    // vector half: dVh = Wu dVu + dsh Vh / |Vh| (where the clamp of the norm is inactive), dv_in = Wh dVh
+    v4f Vh[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) Vh[c] = *reinterpret_cast<const v4f *>(f->Vh + (erow * 3 + c) * 16 + 4 * q);
+    const v4f sh = *reinterpret_cast<const v4f *>(f->sh + erow * 16 + 4 * q);
+    if (live) *reinterpret_cast<v4f *>(o->dsh + erow * 16 + 4 * q) = dsh;
+    const v4f wut = reinterpret_cast<const v4f *>(w.wut)[lane], wht = reinterpret_cast<const v4f *>(w.wht)[lane];
+    v4f nrm;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) nrm[r] = sh[r] * sh[r] > 1e-8f ? dsh[r] * rcp1(sh[r]) : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        v4f t = zero4();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t = mfma16(wut[r], dV[c][r], t);
+        t += nrm * Vh[c];
+        v4f u = zero4();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) u = mfma16(wht[r], t[r], u);
+        dV[c] = u;
+    }
+}
+
 template <int NTS>
 __global__ __launch_bounds__(256, 2) void k_gvp_chain_bwd(GvpEdgeBwdArgs a) {
     constexpr int S = 16 * NTS, CH4 = NTS * 64;
@@ -783,57 +837,8 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain_bwd(GvpEdgeBwdArgs a) {
 
 #pragma unroll 1
     for (int k = n_gvps - 1; k >= 1; --k) {
-        const GvpBwdW &w = a.g[et][k];
-        const GvpTrainGvp *f = &fs->g[k];
-        const GvpBwdGvp *o = &os->g[k];
-        const v4f *cb = reinterpret_cast<const v4f *>(w.chain), *nb = reinterpret_cast<const v4f *>(a.g[et][k - 1].chain);
-        auto ahead = [&](int i) -> const v4f * { return i + 2 < NG ? cb + (size_t)(i + 2) * CH4 : nb + (size_t)(i + 2 - NG) * CH4; };
-        const v4f dgate = gate_bwd_lane(f, o, dV, erow, live, q);
-        // kept pre-activation: requested before the gate chunk, used behind it
-        {
-            const float *pr = f->pre + erow * S + 4 * q;
-#pragma unroll
-            for (int mt = 0; mt < NTS; ++mt) x[mt] = *reinterpret_cast<const v4f *>(pr + 16 * mt);
-        }
-        chunk_gemm<NTS>(ring.current(), dgate, acc, lane, 4, [&] { ring.prefetch(ahead(0)); });
-        ring.release();
-#pragma unroll
-        for (int mt = 0; mt < NTS; ++mt) x[mt] = acc[mt] * silu_grad4(x[mt]);
-        if (live) {
-            float *dp = o->dpre + erow * S + 4 * q;
-#pragma unroll
-            for (int mt = 0; mt < NTS; ++mt) *reinterpret_cast<v4f *>(dp + 16 * mt) = x[mt];
-        }
-#pragma unroll
-        for (int mt = 0; mt < NTS; ++mt) acc[mt] = zero4();
-#pragma unroll
-        for (int nt = 0; nt < NTS; ++nt) {
-            chunk_gemm<NTS>(ring.current(), x[nt], acc, lane, 4, [&] { ring.prefetch(ahead(1 + nt)); });
-            ring.release();
-        }
-        const v4f dsh = chunk_tile_product<NTS>(ring.current(), x, lane, [&] { ring.prefetch(ahead(NTS + 1)); });
-        ring.release();
-        // vector half: dVh = Wu dVu + dsh Vh / |Vh| (where the clamp of the norm is inactive), dv_in = Wh dVh
-        v4f Vh[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) Vh[c] = *reinterpret_cast<const v4f *>(f->Vh + (erow * 3 + c) * 16 + 4 * q);
-        const v4f sh = *reinterpret_cast<const v4f *>(f->sh + erow * 16 + 4 * q);
-        if (live) *reinterpret_cast<v4f *>(o->dsh + erow * 16 + 4 * q) = dsh;
-        const v4f wut = reinterpret_cast<const v4f *>(w.wut)[lane], wht = reinterpret_cast<const v4f *>(w.wht)[lane];
-        v4f nrm;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) nrm[r] = sh[r] * sh[r] > 1e-8f ? dsh[r] * rcp1(sh[r]) : 0.0f;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            v4f t = zero4();
-#pragma unroll
-            for (int r = 0; r < 4; ++r) t = mfma16(wut[r], dV[c][r], t);
-            t += nrm * Vh[c];
-            v4f u = zero4();
-#pragma unroll
-            for (int r = 0; r < 4; ++r) u = mfma16(wht[r], t[r], u);
-            dV[c] = u;
-        }
+        const v4f *cb = reinterpret_cast<const v4f *>(a.g[et][k].chain), *nb = reinterpret_cast<const v4f *>(a.g[et][k - 1].chain);
+        chain_generic_gvp_bwd<NTS>(ring, cb, nb, a.g[et][k], &fs->g[k], &os->g[k], x, acc, dV, erow, live, lane, q);
     }
 
     // head GVP: gates, SiLU', the rbf and |Vh| blocks; its source-scalar block and its 17-channel vector half are the caller's
@@ -869,6 +874,47 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain_bwd(GvpEdgeBwdArgs a) {
             for (int r = 0; r < 4; ++r) o->dsh[erow * 17 + 4 * q + r] = dsh0[r];
             if (q == 0) o->dsh[erow * 17 + 16] = dsh1[0];
         }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the ring's tail fetches must not outlive the workgroup's LDS
+}
+
+// the same for a node-update chain: rows = nodes of one type, every GVP generic, gradients in and out through node-sized arrays
+template <int NTS>
+__global__ __launch_bounds__(256, 2) void k_gvp_node_chain_bwd(GvpNodeBwdArgs a) {
+    constexpr int S = 16 * NTS, CH4 = NTS * 64, NG = NTS + 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int n_gvps = a.n_gvps;
+    const v4f *first = reinterpret_cast<const v4f *>(a.g[n_gvps - 1].chain);
+    auto chunk_src = [&](int c) -> const v4f * { return first + (size_t)c * CH4; };
+    ChunkRing<CH4, KPD_CHAIN_NBUF> ring;
+    ring.init(smem, n_gvps * NG, wave, tid);
+    ring.start(chunk_src);
+    const int el = lane & 15, q = lane >> 4;
+    const int vr = (int)blockIdx.x * TM + 16 * wave + el;
+    const bool live = vr < a.n;
+    const size_t erow = (size_t)min(vr, a.n - 1);
+    v4f acc[NTS], x[NTS], dV[3];
+    {
+        const float *gsp = a.ds + erow * S + 4 * q;
+#pragma unroll
+        for (int mt = 0; mt < NTS; ++mt) acc[mt] = *reinterpret_cast<const v4f *>(gsp + 16 * mt);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dV[c] = *reinterpret_cast<const v4f *>(a.dV + erow * 48 + 16 * c + 4 * q);
+    }
+    ring.first();
+#pragma unroll 1
+    for (int k = n_gvps - 1; k >= 0; --k) {
+        const v4f *cb = reinterpret_cast<const v4f *>(a.g[k].chain);
+        const v4f *nb = k > 0 ? reinterpret_cast<const v4f *>(a.g[k - 1].chain) : cb;          // (past the end: chunks that exist, never consumed)
+        chain_generic_gvp_bwd<NTS>(ring, cb, nb, a.g[k], &a.f[k], &a.o[k], x, acc, dV, erow, live, lane, q);
+    }
+    if (live) {
+        float *so = a.ds_in + erow * S + 4 * q;
+#pragma unroll
+        for (int mt = 0; mt < NTS; ++mt) *reinterpret_cast<v4f *>(so + 16 * mt) = acc[mt];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) *reinterpret_cast<v4f *>(a.dv_in + erow * 48 + 16 * c + 4 * q) = dV[c];
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the ring's tail fetches must not outlive the workgroup's LDS
 }
@@ -1327,6 +1373,19 @@ kpd_status launch_gvp_edge_bwd(const GvpEdgeBwdArgs &a, int tile_cap, hipStream_
     const int lds = KPD_CHAIN_NBUF * 16 * 64 * 16;
     KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_chain_bwd<16>), lds));
     hipLaunchKernelGGL(k_gvp_chain_bwd<16>, dim3(8 * cdiv(tile_cap, 8)), dim3(256), lds, st, a);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
+}
+
+kpd_status launch_gvp_node_bwd(const GvpNodeBwdArgs &a, hipStream_t st) {
+    if (a.n == 0) return KPD_OK;
+    if (poison_level() >= 1) KPD_TRY(poison_lds(st));      // debug only (engine.h)
+    KPD_REQUIRE(a.n_gvps >= 1 && a.n_gvps <= GVP_MAX_CHAIN && a.ds && a.dV && a.ds_in && a.dv_in, KPD_ERR_INVALID, "gvp node chain backward: bad arguments");
+    for (int k = 0; k < a.n_gvps; ++k)
+        KPD_REQUIRE(a.g[k].chain && a.g[k].wut && a.g[k].wht && a.f[k].pre && a.o[k].dpre, KPD_ERR_STATE, "update GVP %d was not prepared for the chained backward kernel", k);
+    const int lds = KPD_CHAIN_NBUF * 16 * 64 * 16;
+    KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_gvp_node_chain_bwd<16>), lds));
+    hipLaunchKernelGGL(k_gvp_node_chain_bwd<16>, dim3(cdiv(a.n, TM)), dim3(256), lds, st, a);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
 }

@@ -89,6 +89,19 @@ struct GvpEdgeBwdArgs {
 };
 kpd_status launch_gvp_edge_bwd(const GvpEdgeBwdArgs &a, int tile_cap, hipStream_t st);
 
+// backward of a node-update chain (all GVPs of the generic kind) for one node type: ds / dV = gradients of its outputs (after the update
+// dropout), ds_in / dv_in = gradients of its inputs (the message LayerNorm's outputs)
+struct GvpNodeBwdArgs {
+    int n;
+    const float *ds, *dV;         // [n][256], [n][3][16]
+    float *ds_in, *dv_in;
+    GvpBwdW g[GVP_MAX_CHAIN];     // chain: Wg^T, 16 k-slabs of to_feats_out[:, :256]^T, the |Vh| block^T; wut, wht
+    int n_gvps;
+    GvpTrainGvp f[GVP_MAX_CHAIN]; // kept activations of the update GVPs
+    GvpBwdGvp o[GVP_MAX_CHAIN];   // dpre, dgate, dVu, d|Vh| per GVP
+};
+kpd_status launch_gvp_node_bwd(const GvpNodeBwdArgs &a, hipStream_t st);
+
 // Training form of the node update (k_gvp_node_chain<16, 0, 1>): the conv's input state is read only, everything the backward pass reads is
 // kept, GVPDropout (gvp.py:119-149) acts on the aggregated messages and on the update residual with the trainers' Philox streams
 // (gvp_train_core.h, dropout_scale), vectors travel as [n][3][16].

@@ -92,7 +92,8 @@ struct kpd_gvp_trainer : TrainCtx {
         GvpBuf gb[4];
     };
     std::vector<NodeSlot> nslots;                  // [conv * 2 + nt]
-    struct NodePack { GvpW g[4]; };
+    struct NodePack { GvpW g[4]; GvpBwdW bw[4]; };
+    GvpBwdGvp nbslots[2][4];                       // per node type and update GVP: dpre / dgate / dVu / d|Vh| of the fused node-chain backward
     std::vector<NodePack> npacks;                  // [conv * 2 + nt]: the update GVPs in the kernels' fragment order
     GvpBwdSlot bslots[4];                          // per edge type: what the fused message backward leaves for the weight-gradient products
     GvpBwdSlot *bslots_dev = nullptr;              // [4]
@@ -233,7 +234,7 @@ constexpr size_t PK_CHUNK = 16 * 256;                                   // float
 constexpr size_t PK_HEAD = 4 * PK_CHUNK + 9 * 256 + 2 * 256 + 256 + 64 + 16 * PK_CHUNK + 256 + 4 * PK_CHUNK;      // chain | whp | wup | b | bg | wproj | bproj | backward chain
 constexpr size_t PK_GENERIC = 18 * PK_CHUNK + 256 + 256 + 256 + 64 + 18 * PK_CHUNK + 512;                            // chain | whp | wup | b | bg | backward chain | Wu^T | Wh^T
 inline size_t pack_floats_per_chain(int nm) { return PK_HEAD + (size_t)(nm - 1) * PK_GENERIC; }
-constexpr size_t PK_NODE_GVP = 18 * PK_CHUNK + 256 + 256 + 256 + 64;                                  // an update GVP: chain | whp | wup | b | bg
+constexpr size_t PK_NODE_GVP = 18 * PK_CHUNK + 256 + 256 + 256 + 64 + 18 * PK_CHUNK + 512;          // an update GVP: chain | whp | wup | b | bg | backward chain | Wu^T | Wh^T
 
 // carve the pack arena and (re)build the descriptor table from the bound parameters
 kpd_status build_pack_table(kpd_gvp_trainer *T) {
@@ -327,6 +328,14 @@ kpd_status build_pack_table(kpd_gvp_trainer *T) {
                 for (int nt2 = 0; nt2 < 16; ++nt2) frag(g.Wg.w, S, 1, VC, 16 * nt2, 16, 1, chain + 17 * PK_CHUNK + nt2 * 256);
                 copy(g.bs.w, S, 256, b);
                 copy(g.bg.w, VC, 16, bg);
+                float *bch = take(18 * PK_CHUNK), *wut = take(256), *wht = take(256);
+                GvpBwdW &bw = T->npacks[(size_t)conv * 2 + nt].bw[j];
+                bw.chain = bch; bw.wut = wut; bw.wht = wht;
+                frag(g.Wg.w, 1, S, S, 0, 16, 16, bch);
+                for (int c = 0; c < 16; ++c) frag(g.Ws.w, 1, k_all, S, 16 * c, 16, 16, bch + (size_t)(1 + c) * PK_CHUNK);
+                for (int nt2 = 0; nt2 < 16; ++nt2) frag(g.Ws.w + S, 1, k_all, 16, 16 * nt2, 16, 1, bch + 17 * PK_CHUNK + nt2 * 256);
+                frag(g.Wu.w, VC, 1, VC, 0, 16, 1, wut);
+                frag(g.Wh.w, VC, 1, VC, 0, 16, 1, wht);
             }
         }
     if ((int)descs.size() > T->desc_cap) {
@@ -521,6 +530,7 @@ kpd_status gvp_bwd_rest(kpd_gvp_trainer *T, const GvpP &g, int M, const float *s
 // backward of conv: gs/gv[cur] = gradients of the conv outputs, gs/gv[nxt] = gradients of its inputs
 kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
     const int S = T->S, nm = T->cfg.n_message_gvps, nu = T->cfg.n_update_gvps;
+    std::vector<WgradItem> wq, wq_top;          // weight-gradient products of this conv, sent out together at the end (wgrad_batch)
     const std::string cp = "noise_predictor.conv_layers." + std::to_string(conv);
     bool is_dst[2] = {false, false};
     for (int et = 0; et < 4; ++et)
@@ -558,7 +568,55 @@ kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
         KPD_HIP(hipMemcpyAsync(T->gs[nxt][nt], T->ds[0], (size_t)n * S * 4, hipMemcpyDeviceToDevice, T->st));
         KPD_HIP(hipMemcpyAsync(T->gv[nxt][nt], T->dV[0], (size_t)n * 3 * VC * 4, hipMemcpyDeviceToDevice, T->st));
         KPD_TRY(dropout_apply(T, conv, nt, 1, n, T->ds[0], T->dV[0], T->ds[0], T->dV[0]));
-        KPD_TRY(chain_bwd(T, up, nu, n, s1, v1));
+        bool chained = false;
+        if (T->fused) {
+            GvpP gp[4];
+            bool grads = true;
+            for (int j = 0; j < nu; ++j) {
+                KPD_TRY(gvp_params(T, up + "." + std::to_string(j), VC, VC, S, S, &gp[j]));
+                grads = grads && gp[j].Ws.g && gp[j].bs.g && gp[j].Wg.g;
+            }
+            if (grads) {
+                // the update chain's backward in one launch (k_gvp_node_chain_bwd), its weight gradients with the conv's batched products
+                const kpd_gvp_trainer::NodeSlot &ns = T->nslots[(size_t)conv * 2 + nt];
+                const kpd_gvp_trainer::NodePack &pk = T->npacks[(size_t)conv * 2 + nt];
+                GvpNodeBwdArgs nb;
+                memset(&nb, 0, sizeof(nb));
+                nb.n = n; nb.ds = T->ds[0]; nb.dV = T->dV[0]; nb.ds_in = T->ds[1]; nb.dv_in = T->dV[1]; nb.n_gvps = nu;
+                for (int j = 0; j < nu; ++j) {
+                    const GvpBuf &b = ns.gb[j];
+                    nb.g[j] = pk.bw[j];
+                    nb.f[j] = GvpTrainGvp{b.Vh, b.Vu, b.sh, b.pre, b.s, b.gate, b.V};
+                    nb.o[j] = T->nbslots[nt][j];
+                }
+                KPD_TRY(launch_gvp_node_bwd(nb, T->st));
+                std::swap(T->ds[0], T->ds[1]);
+                std::swap(T->dV[0], T->dV[1]);
+                for (int j = nu - 1; j >= 0; --j) {
+                    const GvpBwdGvp &o = T->nbslots[nt][j];
+                    WgradItem it;
+                    memset(&it, 0, sizeof(it));
+                    it.A = o.dpre; it.lda = S; it.B = j > 0 ? ns.gb[j - 1].s : s1; it.ldb = S; it.K = n;
+                    it.C = gp[j].Ws.g; it.ldc = gp[j].si + gp[j].h;
+                    it.B2 = ns.gb[j].sh; it.ldb2 = gp[j].h; it.nb2 = gp[j].h; it.Cx1 = gp[j].Ws.g + gp[j].si; it.ldx1 = it.ldc;
+                    it.colsum = gp[j].bs.g;
+                    if (j > 0) { it.A2 = T->nbslots[nt][j - 1].dgate; it.lda2 = VC; it.na2 = VC; it.Cx2 = gp[j - 1].Wg.g; it.ldx2 = S; it.colsum2 = gp[j - 1].bg.g; }
+                    wq.push_back(it);
+                    // Wu / Wh through the vector kernel (its dv_in is not needed here: scratch)
+                    KPD_TRY(gvp_bwd_rest(T, gp[j], n, nullptr, j > 0 ? ns.gb[j - 1].V : v1, ns.gb[j], o, T->dV[1], REST_SKIP_WG | REST_SKIP_WS));
+                }
+                {   // the last GVP's gate matrix: rider-only
+                    const GvpBwdGvp &o = T->nbslots[nt][nu - 1];
+                    WgradItem it;
+                    memset(&it, 0, sizeof(it));
+                    it.A = o.dpre; it.lda = S; it.B = ns.gb[nu - 1].s; it.ldb = S; it.K = n;
+                    it.A2 = o.dgate; it.lda2 = VC; it.na2 = VC; it.Cx2 = gp[nu - 1].Wg.g; it.ldx2 = S; it.colsum2 = gp[nu - 1].bg.g;
+                    wq_top.push_back(it);
+                }
+                chained = true;
+            }
+        }
+        if (!chained) KPD_TRY(chain_bwd(T, up, nu, n, s1, v1));
         hipLaunchKernelGGL(k_acc, grid1((long long)n * S), dim3(256), 0, T->st, T->gs[nxt][nt], T->ds[0], (long long)n * S);
         KPD_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_acc, grid1((long long)n * 3 * VC), dim3(256), 0, T->st, T->gv[nxt][nt], T->dV[0], (long long)n * 3 * VC);
@@ -586,7 +644,6 @@ kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
         ba.fwd = T->slots_dev + (size_t)conv * 4; ba.out = T->bslots_dev;
         KPD_TRY(launch_gvp_edge_bwd(ba, tiles, T->st));
     }
-    std::vector<WgradItem> wq, wq_top;
     for (int et = 0; et < 4; ++et) {
         if (!conv_uses(T, conv, et) || T->E[et] == 0) continue;
         const int E = T->E[et], s = kSrc[et], d = kDst[et];
@@ -997,6 +1054,8 @@ extern "C" kpd_status kpd_gvp_trainer_reserve(kpd_gvp_trainer *T, int32_t max_B,
                 off_b[et] = floats;
                 floats += (((size_t)cap_et[et] * bwd_per_edge + 16 * (size_t)nm) + 63) & ~size_t(63);
             }
+            size_t off_nb[2];
+            for (int nt = 0; nt < 2; ++nt) { off_nb[nt] = floats; floats += (size_t)nn[nt] * nu * (256 + 16 + 48 + 16); }
             std::vector<GvpTrainSlot> hs((size_t)L * 4);
             memset(hs.data(), 0, hs.size() * sizeof(GvpTrainSlot));
             for (size_t i = 0; i < hs.size(); ++i) {
@@ -1024,6 +1083,14 @@ extern "C" kpd_status kpd_gvp_trainer_reserve(kpd_gvp_trainer *T, int32_t max_B,
                     bs.drbf = p;
                 }
                 KPD_HIP(hipMemcpy(T->bslots_dev, T->bslots, 4 * sizeof(GvpBwdSlot), hipMemcpyHostToDevice));
+                for (int nt = 0; nt < 2; ++nt) {
+                    float *p = T->pack_base + off_nb[nt];
+                    const size_t n = nn[nt];
+                    for (int j = 0; j < nu; ++j) {
+                        GvpBwdGvp &o = T->nbslots[nt][j];
+                        o.dpre = p; p += n * 256; o.dgate = p; p += n * 16; o.dVu = p; p += n * 48; o.dsh = p; p += n * 16;
+                    }
+                }
                 T->nslots.assign((size_t)L * 2, kpd_gvp_trainer::NodeSlot());
                 for (int conv = 0; conv < L; ++conv)
                     for (int nt = 0; nt < 2; ++nt) {

@@ -34,8 +34,8 @@ done
 KPD_OUT=$out python - <<'PY'
 import csv, glob, json, os
 out = os.environ['KPD_OUT']
-dom = {'egnn_all_atom': 'k_egnn_edge<4>', 'egnn_all_atom_f16x2': 'k_egnn_edge_h', 'gvp_40kp': 'k_gvp_chain<16, 0>', 'gvp_all_atom_ragged': 'k_gvp_chain<16, 0>',
-       'gvp_40kp_f16x2': 'k_gvp_chain<16, 1>', 'gvp_all_atom_ragged_f16x2': 'k_gvp_chain<16, 1>'}
+dom = {'egnn_all_atom': 'k_egnn_edge<4>', 'egnn_all_atom_f16x2': 'k_egnn_edge_h', 'gvp_40kp': 'k_gvp_chain<16, 0, 0>', 'gvp_all_atom_ragged': 'k_gvp_chain<16, 0, 0>',
+       'gvp_40kp_f16x2': 'k_gvp_chain<16, 1, 0>', 'gvp_all_atom_ragged_f16x2': 'k_gvp_chain<16, 1, 0>'}
 res = {}
 for wl, kern in dom.items():
     agg = {}

@@ -44,7 +44,7 @@ def synthetic_record(n_secondary=7, prose=400, world=8):
         }
 
     out = one('k_egnn_edge')
-    out['secondary'] = {f'secondary_workload_name_{i}_f16x2': one('k_gvp_chain<16, 1>') for i in range(n_secondary)}
+    out['secondary'] = {f'secondary_workload_name_{i}_f16x2': one('k_gvp_chain<16, 1, 0>') for i in range(n_secondary)}
     e2e = {'workload': 'egnn_all_atom', 'gemm': 'f32', 'ligands_per_min': 1244.5380179742924, 'wall_s': 3.08, 'encoder_ms': 0.31,
            'n_ligands': 64, 'n_timesteps': 500, 'includes': text, 'note': text}
     out['end_to_end'] = e2e
