@@ -15,6 +15,8 @@
 // per-branch kernels those two replaced in round 4 -- k_edge_pre1 + ws_gemm + head / segmented-sum kernels -- were removed in round 5.)
 // Memory: the edge activations of all layers when they fit (13.5 GB at C2, B = 64: pre1, a1, pre2 per branch), else one layer's slots
 // (3 GB) and a recomputation per layer in backward; less than that is an out-of-memory error of kpd_egnn_trainer_reserve.
+#include <cstring>
+
 #include "egnn_kernels.h"
 #include "engine.h"
 #include "train_ops.h"
@@ -1048,6 +1050,7 @@ kpd_status layer_edges_bwd_fused(kpd_egnn_trainer *T, int l, int cur, int nxt, f
         for (int et = 0; et < layer_n_et(T, l); ++et) edges += T->E[et];
         KPD_TRY(T->timed(1, edges, [&] { return launch_egnn_edge_bwd(a, tiles, T->st); }));
     }
+    std::vector<Grad257Item> wq;
     for (int et = 0; et < layer_n_et(T, l); ++et) {
         const int E = T->E[et], s = kS[et], d = kD[et];
         if (E == 0) continue;
@@ -1060,7 +1063,9 @@ kpd_status layer_edges_bwd_fused(kpd_egnn_trainer *T, int l, int cur, int nxt, f
                                p.head.g, 1, p.b2.g);
             KPD_LAUNCH_CHECK();
             if (br == 0 && p.head_b.g) KPD_TRY(sum_scalar(T, sl.att, E, p.head_b.g));           // (ds of the attention logits, left over att)
-            if (p.W2.g) KPD_TRY(grad_gemm(T, H, H, E, dpre2, LD, a1, LD, p.W2.g, H));
+            if (p.W2.g) {       // dW2 += dpre2^T a1: with the layer's other edge-sized products in one launch below
+                wq.push_back(Grad257Item{dpre2, a1, LD, LD, E, p.W2.g, H, nullptr});
+            }
             float *dU = T->ducat[s] + (size_t)T->cat_of[et][br][0] * LD, *dV = T->ducat[d] + (size_t)T->cat_of[et][br][1] * LD;
             float *dVw = T->dvwcat[d] + (size_t)T->cat_dvw_of[et][br] * LD;
             hipLaunchKernelGGL(k_segsum264, dim3(cdiv(T->n[s], 4)), dim3(256), 0, T->st, dpre1, (const float *)nullptr, (const float *)nullptr,
@@ -1075,6 +1080,9 @@ kpd_status layer_edges_bwd_fused(kpd_egnn_trainer *T, int l, int cur, int nxt, f
         KPD_TRY(segsum(T->st, redge, 3, 0, 3, T->scsr[et].perm, T->scsr[et].rowptr, nullptr, 1.0f, true, T->n[s], T->dx[nxt][s], 3));
         KPD_TRY(segsum(T->st, redge, 3, 0, 3, nullptr, T->e_rowptr[et], nullptr, -1.0f, true, T->n[d], T->dx[nxt][d], 3));
     }
+    // the second-Linear weight gradients of every (edge type, branch) of the layer: one launch, a share of the CUs per product proportional
+    // to its edge count (sgemm.hip, grad257_batch) instead of a launch, 256 partial tiles and a reduction each
+    for (size_t i = 0; i < wq.size(); i += 8) KPD_TRY(grad257_batch(wq.data() + i, (int)std::min<size_t>(8, wq.size() - i), T->part, T->part_floats, T->st));
     return KPD_OK;
 }
 

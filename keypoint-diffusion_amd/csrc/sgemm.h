@@ -45,6 +45,16 @@ struct WgradItem {
     int ldx3;
 };
 kpd_status wgrad_batch(const WgradItem *items, int n, float *part, size_t part_floats, hipStream_t st);
+// 257 x 257 weight gradients C += A^T B (A, B: [K, >= 257] with 16-byte aligned rows; colsum [257] += column sums of A, optional), up to
+// eight per launch of k_sgemm_tn256_batch: the EGNN trainer's second-Linear gradients of a layer
+struct Grad257Item {
+    const float *A, *B;
+    int lda, ldb, K;
+    float *C;
+    int ldc;
+    float *colsum;
+};
+kpd_status grad257_batch(const Grad257Item *items, int n, float *part, size_t part_floats, hipStream_t st);
 // y[m * incy] = beta y + sum_k A[m][k] x[k * incx]
 kpd_status sgemv_rows(int M, int K, const float *A, int lda, const float *x, int incx, float beta, float *y, int incy, hipStream_t st);
 

@@ -495,14 +495,14 @@ __global__ __launch_bounds__(256) void k_sgemm_tn_skinny(SgemmArgs a) {
 // One workgroup per CU (2 waves per SIMD).  Fringe row / column 256, the column sums of A and the split-K shares use
 // the formats of k_sgemm, so the same k_sgemm_reduce finishes the product.
 constexpr int TN256_STAGES = 4;        // 128 KB of LDS: three slabs (12 k MFMA cycles) of prefetch distance
-__global__ __launch_bounds__(512, 1) void k_sgemm_tn256(SgemmArgs a) {
+__device__ __forceinline__ void tn256_body(const SgemmArgs &a, const int slice) {
     constexpr int ROW = 256, SLAB = SG_BK * ROW, STAGE = 2 * SLAB, NSTAGE = TN256_STAGES;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float xbuf[2][2][SG_BK];
     typedef __attribute__((address_space(3))) void lds_void;
     typedef const __attribute__((address_space(1))) void glb_void;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 31, half = lane >> 5, wr = wave >> 1, wc = wave & 1;
-    const int kbeg = blockIdx.x * a.k_chunk, kend = min(a.K, kbeg + a.k_chunk);
+    const int kbeg = slice * a.k_chunk, kend = min(a.K, kbeg + a.k_chunk);
     const int nk = (kend - kbeg + SG_BK - 1) / SG_BK, nk_full = (kend - kbeg) / SG_BK;
     v16f acc[2][4];
 #pragma unroll
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(512, 1) void k_sgemm_tn256(SgemmArgs a) {
         riders(nk_full, st);
     }
     // shares of this K range (formats of k_sgemm: tile [256][256], column sums [M], fringe [M | N | corner | fringe-row column sum])
-    float *C = a.C + (size_t)blockIdx.x * a.c_slice;
+    float *C = a.C + (size_t)slice * a.c_slice;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -627,13 +627,32 @@ __global__ __launch_bounds__(512, 1) void k_sgemm_tn256(SgemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 C[(size_t)(64 * wr + 32 * i + 8 * (r >> 2) + 4 * half + (r & 3)) * a.ldc + 128 * wc + 32 * j + col] = a.alpha * acc[i][j][r];
-    if (sum_cols && a.cs_part) a.cs_part[(size_t)blockIdx.x * a.M + tid] = cs;
+    if (sum_cols && a.cs_part) a.cs_part[(size_t)slice * a.M + tid] = cs;
     if (a.x_part) {
-        float *xp = a.x_part + (size_t)blockIdx.x * (a.M + a.N + 2);
+        float *xp = a.x_part + (size_t)slice * (a.M + a.N + 2);
         if (ride_c) xp[tid] = a.alpha * fc;
         if (ride_r) xp[a.M + tid - ROW] = a.alpha * fr;
         if (tid == 0) { xp[a.M + a.N] = a.alpha * fk; xp[a.M + a.N + 1] = fcs; }
     }
+}
+
+__global__ __launch_bounds__(512, 1) void k_sgemm_tn256(SgemmArgs a) { tn256_body(a, (int)blockIdx.x); }
+
+// Several such products in one launch: block -> (product, K slice) by a prefix table, every product with a share of the workgroups
+// proportional to its K (the eight dW2 of an EGNN layer: 256 partial tiles and one pass of the CUs together instead of 256 and a pass each;
+// the ligand-ligand products, too shallow for a launch of their own, ride along).
+constexpr int TN256_BATCH = 8;
+struct Tn256Batch {
+    int n;
+    int first[TN256_BATCH + 1];
+    SgemmArgs p[TN256_BATCH];
+};
+__global__ __launch_bounds__(512, 1) void k_sgemm_tn256_batch(Tn256Batch b) {
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < TN256_BATCH; ++i)
+        if (i < b.n && (int)blockIdx.x >= b.first[i]) pi = i;
+    tn256_body(b.p[pi], (int)blockIdx.x - b.first[pi]);
 }
 
 // ---- weight gradients of a GVP message chain, several products per launch -----------------------------------------------------------------
@@ -666,11 +685,13 @@ struct WgradBatch {
 // of the B2 tile reads a constant 1), NSTAGE - 1 slabs ahead.  (Through registers one slab ahead, the rider-only form waited an HBM round
 // trip per 1.3-us slab: 479 us for a conv's four products; the slab ring hides it.)
 __device__ const float kWgradOne = 1.0f;
-template <int TOP>
+// RID = 0 (with TOP = 0): the 256 x 256 blocks alone -- the EGNN trainer's dW2 = dpre2^T a1 products, eight per layer in one launch
+template <int TOP, int RID = 1>
 __global__ __launch_bounds__(512, 1) void k_wgrad_tnx(WgradBatch bt) {
-    constexpr int ROW = 256, SLAB = SG_BK * ROW, STAGE = 2 * SLAB, NSTAGE = TN256_STAGES, NXT = TOP ? 3 : 2, PER_SLAB = 4 + NXT;
+    constexpr int ROW = 256, SLAB = SG_BK * ROW, STAGE = 2 * SLAB, NSTAGE = TN256_STAGES, NXT = !RID ? 0 : TOP ? 3 : 2, PER_SLAB = 4 + NXT;
+    static_assert(RID || !TOP, "a product without a 256 x 256 block is its riders");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ float xbuf[NSTAGE][3][SG_BK][32];          // [stage][B2 | A2 | B3][k][column]
+    __shared__ float xbuf[RID ? NSTAGE : 1][3][SG_BK][32];          // [stage][B2 | A2 | B3][k][column]
     typedef __attribute__((address_space(3))) void lds_void;
     typedef const __attribute__((address_space(1))) void glb_void;
     int pi = 0;
@@ -708,10 +729,12 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_tnx(WgradBatch bt) {
             __builtin_amdgcn_global_load_lds((glb_void *)(a.A + (k0 + row) * a.lda + 4 * lane), (lds_void *)(st + row * ROW), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((glb_void *)(a.B + (k0 + row) * a.ldb + 4 * lane), (lds_void *)(st + SLAB + row * ROW), 16, 0, 0);
         }
-        // rows 2 wave, 2 wave + 1 of the narrow tiles: 64 consecutive floats of LDS per wave and tile
-        __builtin_amdgcn_global_load_lds((glb_void *)(b2p + (k0 + xk) * ld2b), (lds_void *)(&xbuf[sg][0][2 * wave][0]), 4, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_void *)(a2p + (k0 + xk) * ld2a), (lds_void *)(&xbuf[sg][1][2 * wave][0]), 4, 0, 0);
-        if (TOP) __builtin_amdgcn_global_load_lds((glb_void *)(b3p + (k0 + xk) * ld3b), (lds_void *)(&xbuf[sg][2][2 * wave][0]), 4, 0, 0);
+        if constexpr (RID) {
+            // rows 2 wave, 2 wave + 1 of the narrow tiles: 64 consecutive floats of LDS per wave and tile
+            __builtin_amdgcn_global_load_lds((glb_void *)(b2p + (k0 + xk) * ld2b), (lds_void *)(&xbuf[sg][0][2 * wave][0]), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void *)(a2p + (k0 + xk) * ld2a), (lds_void *)(&xbuf[sg][1][2 * wave][0]), 4, 0, 0);
+            if (TOP) __builtin_amdgcn_global_load_lds((glb_void *)(b3p + (k0 + xk) * ld3b), (lds_void *)(&xbuf[sg][2][2 * wave][0]), 4, 0, 0);
+        }
     };
     auto wait_behind = [&](int slabs) {                 // at most `slabs` slabs of this wave's loads outstanding (PER_SLAB instructions each)
         if (slabs <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -721,8 +744,9 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_tnx(WgradBatch bt) {
     float cs2 = 0.0f;
     auto compute = [&](const float *st, int sg) {
         const float *as = st + 64 * wr + col, *bs = st + SLAB + 128 * wc + col;
-        const float *xb = &xbuf[sg][0][0][col], *xa = &xbuf[sg][1][0][col], *x3 = &xbuf[sg][2][0][col];
-        cs2 += masked(xbuf[sg][1][xk][xc], a2_live);          // column sums of A2 (the gate bias gradient): this thread's row of every slab
+        const int sx = RID ? sg : 0;
+        const float *xb = &xbuf[sx][0][0][col], *xa = &xbuf[sx][1][0][col], *x3 = &xbuf[sx][2][0][col];
+        if constexpr (RID) cs2 += masked(xbuf[sx][1][xk][xc], a2_live);          // column sums of A2 (the gate bias gradient): this thread's row of every slab
 #pragma unroll
         for (int ks = 0; ks < SG_BK / 2; ++ks) {
             const int k = 2 * ks + half;
@@ -739,13 +763,14 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_tnx(WgradBatch bt) {
                 for (int i = 0; i < 2; ++i) av[i] = as[k * ROW + 32 * (i ^ wc)];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) bv[j] = bs[k * ROW + 32 * (j ^ wr)];
-                const float b2 = xb[k * 32], a2 = xa[k * 32];
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-                ax1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], b2, ax1, 0, 0, 0);
-                ax2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, bv[0], ax2, 0, 0, 0);
+                if constexpr (RID) {
+                    ax1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], xb[k * 32], ax1, 0, 0, 0);
+                    ax2 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[k * 32], bv[0], ax2, 0, 0, 0);
+                }
             }
         }
     };
@@ -776,7 +801,7 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_tnx(WgradBatch bt) {
             for (int e = 0; e < 4; ++e) v[e] = masked(v[e], in);
             *reinterpret_cast<v4f *>(st + op * SLAB + row * ROW + 4 * c4) = v;
         }
-        {
+        if constexpr (RID) {
             const bool in = k0 + xk < kend;
             const size_t kk = (size_t)min(k0 + xk, kend - 1);
             xbuf[0][0][xk][xc] = xc == 31 ? (in ? 1.0f : 0.0f) : masked(b2p[kk * ld2b], in && b2_live);
@@ -799,6 +824,7 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_tnx(WgradBatch bt) {
                     C[(size_t)(64 * wr + 32 * (i ^ wc) + 8 * (r >> 2) + 4 * half + (r & 3)) * ROW + 128 * wc + 32 * (j ^ wr) + col] = acc[i][j][r];
         q += (size_t)a.slices * (ROW * ROW);
     }
+    if constexpr (!RID) return;
     float *x1 = q + (size_t)slice * (ROW * a.nb2);
     q += (size_t)a.slices * (ROW * a.nb2);
     float *cs = q + (size_t)slice * ROW;
@@ -1031,6 +1057,68 @@ kpd_status sgemm(bool tA, bool tB, int M, int N, int K, float alpha, const float
     return KPD_OK;
 }
 
+kpd_status grad257_batch(const Grad257Item *items, int n, float *part, size_t part_floats, hipStream_t st) {
+    if (n <= 0) return KPD_OK;
+    KPD_REQUIRE(n <= TN256_BATCH && part, KPD_ERR_INVALID, "grad257_batch: %d products (at most %d) / no scratch", n, TN256_BATCH);
+    Tn256Batch bt;
+    memset(&bt, 0, sizeof(bt));
+    long long ksum = 0;
+    for (int i = 0; i < n; ++i) {
+        const Grad257Item &it = items[i];
+        KPD_REQUIRE(it.A && it.B && it.C && it.K >= 1 && (it.lda & 3) == 0 && (it.ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(it.A) & 15) == 0 &&
+                        (reinterpret_cast<uintptr_t>(it.B) & 15) == 0 && it.ldc >= 257,
+                    KPD_ERR_INVALID, "grad257_batch: bad product %d", i);
+        ksum += it.K;
+    }
+    const int cus = cu_count();
+    const size_t per_slice = (size_t)256 * 256 + 256 + (256 + 256 + 2);
+    size_t used = 0;
+    int first = 0;
+    for (int i = 0; i < n; ++i) {
+        const Grad257Item &it = items[i];
+        SgemmArgs &a = bt.p[i];
+        a.A = it.A; a.B = it.B; a.M = 256; a.N = 256; a.K = it.K; a.lda = it.lda; a.ldb = it.ldb; a.alpha = 1.0f; a.beta = 0.0f;
+        a.vecA = a.vecB = 1; a.direct = 1; a.stages = 3;
+        a.colsum = it.colsum; a.silu_pre = nullptr; a.bias = nullptr; a.act_out = nullptr;
+        a.xr = 256; a.xc = 256;
+        int sl = (int)std::max<long long>(1, ((long long)cus * it.K + ksum / 2) / ksum);
+        sl = std::min(sl, std::max(1, it.K / 256));
+        sl = (int)std::min<size_t>(sl, (part_floats - used) / per_slice / (size_t)(n - i));
+        KPD_REQUIRE(sl >= 1, KPD_ERR_CAPACITY, "grad257_batch: split-sum scratch too small");
+        a.k_chunk = cdiv(cdiv(it.K, sl), SG_BK) * SG_BK;
+        sl = cdiv(it.K, a.k_chunk);
+        float *q = part + used;
+        a.C = q; a.ldc = 256; a.c_slice = 65536;
+        a.cs_part = q + (size_t)sl * 65536;                 // (written only when colsum is wanted; the room is there either way)
+        a.x_part = a.cs_part + (size_t)sl * 256;
+        bt.first[i] = first;
+        first += sl;
+        used += (size_t)sl * per_slice;
+    }
+    bt.first[n] = first;
+    bt.n = n;
+    constexpr int lds = TN256_STAGES * 2 * SG_BK * 256 * 4;
+    KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_sgemm_tn256_batch), lds));
+    hipLaunchKernelGGL(k_sgemm_tn256_batch, dim3(first), dim3(512), lds, st, bt);
+    KPD_LAUNCH_CHECK();
+    for (int i = 0; i < n; ++i) {
+        const Grad257Item &it = items[i];
+        const SgemmArgs &a = bt.p[i];
+        const int sl = bt.first[i + 1] - bt.first[i];
+        RedArgs r;
+        r.n_seg = 0; r.slices = sl; r.beta = 1.0f;
+        r.seg[r.n_seg++] = RedSeg{a.C, 65536, 65536, it.C, 256, it.ldc, 0};
+        if (it.colsum) r.seg[r.n_seg++] = RedSeg{a.cs_part, 256, 256, it.colsum, 0, 1, 1};
+        const long long xs = 256 + 256 + 2;
+        r.seg[r.n_seg++] = RedSeg{a.x_part, xs, 256, it.C + 256, 0, it.ldc, 0};
+        r.seg[r.n_seg++] = RedSeg{a.x_part + 256, xs, 256, it.C + (size_t)256 * it.ldc, 0, 1, 0};
+        r.seg[r.n_seg++] = RedSeg{a.x_part + 512, xs, 1, it.C + (size_t)256 * it.ldc + 256, 0, 1, 0};
+        if (it.colsum) r.seg[r.n_seg++] = RedSeg{a.x_part + 513, xs, 1, it.colsum + 256, 0, 1, 1};
+        KPD_TRY(launch_reduce(r, st));
+    }
+    return KPD_OK;
+}
+
 kpd_status wgrad_batch(const WgradItem *items, int n, float *part, size_t part_floats, hipStream_t st) {
     if (n <= 0) return KPD_OK;
     KPD_REQUIRE(n <= WGRAD_MAX && part, KPD_ERR_INVALID, "wgrad_batch: %d products (at most %d) / no scratch", n, WGRAD_MAX);
@@ -1038,6 +1126,7 @@ kpd_status wgrad_batch(const WgradItem *items, int n, float *part, size_t part_f
     memset(&bt, 0, sizeof(bt));
     long long ksum = 0;
     const bool top = items[0].C == nullptr;
+    bool riders = top;
     for (int i = 0; i < n; ++i) {
         const WgradItem &it = items[i];
         KPD_REQUIRE(it.A && it.B && it.K >= 1 && (it.lda & 3) == 0 && (it.ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(it.A) & 15) == 0 &&
@@ -1046,6 +1135,7 @@ kpd_status wgrad_batch(const WgradItem *items, int n, float *part, size_t part_f
                     KPD_ERR_INVALID, "wgrad_batch: bad product %d", i);
         KPD_REQUIRE((it.C == nullptr) == top && (top || it.nb3 == 0), KPD_ERR_INVALID, "wgrad_batch: products with and without a 256 x 256 block in one batch");
         ksum += it.K;
+        riders = riders || it.nb2 || it.na2 || it.colsum;
     }
     const int cus = cu_count();
     size_t used = 0;
@@ -1055,7 +1145,7 @@ kpd_status wgrad_batch(const WgradItem *items, int n, float *part, size_t part_f
         WgradProd &p = bt.p[i];
         p.A = it.A; p.B = it.B; p.B2 = it.nb2 ? it.B2 : nullptr; p.A2 = it.na2 ? it.A2 : nullptr; p.B3 = it.nb3 ? it.B3 : nullptr;
         p.lda = it.lda; p.ldb = it.ldb; p.ldb2 = it.ldb2; p.lda2 = it.lda2; p.ldb3 = it.ldb3; p.nb2 = it.nb2; p.na2 = it.na2; p.nb3 = it.nb3; p.K = it.K;
-        const size_t per_slice = (top ? 0 : (size_t)256 * 256) + 256 * it.nb2 + 256 + 256 * it.nb3 + (size_t)it.na2 * 256 + 32;
+        const size_t per_slice = (top ? 0 : (size_t)256 * 256) + (riders ? 256 * it.nb2 + 256 + 256 * it.nb3 + (size_t)it.na2 * 256 + 32 : 0);
         // a share of the CUs proportional to K, a slice at least 256 rows deep
         int sl = (int)std::max<long long>(1, ((long long)cus * it.K + ksum / 2) / ksum);
         sl = std::min(sl, std::max(1, it.K / 256));
@@ -1073,9 +1163,12 @@ kpd_status wgrad_batch(const WgradItem *items, int n, float *part, size_t part_f
     if (top) {
         KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_wgrad_tnx<1>), lds));
         hipLaunchKernelGGL(k_wgrad_tnx<1>, dim3(first), dim3(512), lds, st, bt);
-    } else {
+    } else if (riders) {
         KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_wgrad_tnx<0>), lds));
         hipLaunchKernelGGL(k_wgrad_tnx<0>, dim3(first), dim3(512), lds, st, bt);
+    } else {
+        KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_wgrad_tnx<0, 0>), lds));
+        hipLaunchKernelGGL((k_wgrad_tnx<0, 0>), dim3(first), dim3(512), lds, st, bt);
     }
     KPD_LAUNCH_CHECK();
     for (int i = 0; i < n; ++i) {
@@ -1087,6 +1180,10 @@ kpd_status wgrad_batch(const WgradItem *items, int n, float *part, size_t part_f
         if (!top) {
             r.seg[r.n_seg++] = RedSeg{q, 65536, 65536, it.C, 256, it.ldc, 0};
             q += (size_t)p.slices * 65536;
+        }
+        if (!riders) {
+            KPD_TRY(launch_reduce(r, st));
+            continue;
         }
         if (it.nb2) r.seg[r.n_seg++] = RedSeg{q, (long long)256 * it.nb2, 256 * it.nb2, it.Cx1, it.nb2, it.ldx1, 0};
         q += (size_t)p.slices * 256 * it.nb2;
