@@ -412,6 +412,39 @@ kpd_status kpd_sgemm(int32_t trans_a, int32_t trans_b, int32_t M, int32_t N, int
                      const float *B, int32_t ldb, float beta, float *C, int32_t ldc, float *colsum, float *workspace,
                      int64_t workspace_floats, void *stream);
 
+/* The batched weight gradients of the training engines (csrc/sgemm.hip: k_wgrad_tnx, k_sgemm_tn256_batch), exported like kpd_sgemm so that
+ * their parity against plain fp32 products can be tested on their own.  Up to eight products of one kind per call, every output ACCUMULATED
+ * (+=), split along K over the CUs in proportion to the products' K and summed in a fixed order (no atomics).  A, B: [K, >= 256] device
+ * arrays with 16-byte aligned rows (lda, ldb multiples of 4).
+ *   kind 0 (GVP message / update chains: autograd of models/gvp.py:100-111 with respect to to_feats_out and scalar_to_vector_gates):
+ *       C [256, 256] += A^T B;  Cx1 [256, nb2] += A^T B2 (nb2 <= 31);  colsum [256] += column sums of A;
+ *       Cx2 [na2, 256] += A2^T B (na2 <= 32);  colsum2 [na2] += column sums of A2;
+ *       C == NULL for all products of the call: no 256 x 256 block, and Cx3 [256, nb3] += A^T B3 (nb3 <= 32) as a second narrow block.
+ *       Unused narrow operands: widths 0 and NULL pointers.
+ *   kind 1 (EGNN second Linears, models/dynamics.py:37-79): C [257, 257] += A[:, :257]^T B[:, :257], colsum [257] += column sums of A (or
+ *       NULL); the narrow fields are ignored. */
+typedef struct {
+    const float *A, *B;
+    int32_t lda, ldb, K;
+    float *C;
+    int32_t ldc;
+    const float *B2;
+    int32_t ldb2, nb2;
+    float *Cx1;
+    int32_t ldx1;
+    float *colsum;
+    const float *A2;
+    int32_t lda2, na2;
+    float *Cx2;
+    int32_t ldx2;
+    float *colsum2;
+    const float *B3;
+    int32_t ldb3, nb3;
+    float *Cx3;
+    int32_t ldx3;
+} kpd_wgrad_item;
+kpd_status kpd_wgrad_batch(int32_t kind, int32_t n, const kpd_wgrad_item *items, float *workspace, int64_t workspace_floats, void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * Reverse-diffusion update around the denoiser.  Replaces the elementwise part of
  * KeypointDiffusion.sample_p_zs_given_zt (models/ligand_diffuser.py:515-536):

@@ -1224,4 +1224,23 @@ extern "C" kpd_status kpd_sgemm(int32_t trans_a, int32_t trans_b, int32_t M, int
     return sgemm(trans_a != 0, trans_b != 0, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, st, workspace, (size_t)workspace_floats, colsum, nullptr, nullptr, nullptr);
 }
 
+// include/kpd.h
+extern "C" kpd_status kpd_wgrad_batch(int32_t kind, int32_t n, const kpd_wgrad_item *items, float *workspace, int64_t workspace_floats, void *stream) {
+    KPD_REQUIRE((kind == 0 || kind == 1) && n >= 0 && n <= 8 && (n == 0 || items) && workspace && workspace_floats > 0, KPD_ERR_INVALID,
+                "kpd_wgrad_batch: kind %d, %d products", kind, n);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (kind == 1) {
+        Grad257Item g[8];
+        for (int i = 0; i < n; ++i) g[i] = Grad257Item{items[i].A, items[i].B, items[i].lda, items[i].ldb, items[i].K, items[i].C, items[i].ldc, items[i].colsum};
+        return grad257_batch(g, n, workspace, (size_t)workspace_floats, st);
+    }
+    WgradItem w[8];
+    for (int i = 0; i < n; ++i) {
+        const kpd_wgrad_item &s = items[i];
+        w[i] = WgradItem{s.A, s.B, s.lda, s.ldb, s.K, s.C, s.ldc, s.B2, s.ldb2, s.nb2, s.Cx1, s.ldx1, s.colsum, s.A2, s.lda2, s.na2, s.Cx2, s.ldx2, s.colsum2,
+                         s.B3, s.ldb3, s.nb3, s.Cx3, s.ldx3};
+    }
+    return wgrad_batch(w, n, workspace, (size_t)workspace_floats, st);
+}
+
 }  // namespace kpd

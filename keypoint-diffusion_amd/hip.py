@@ -65,6 +65,13 @@ class KpdRecegnnConfig(C.Structure):
                 ('message_norm', C.c_float), ('k_closest', C.c_int32), ('kk_cutoff', C.c_float), ('kp_rad', C.c_float)]
 
 
+class KpdWgradItem(C.Structure):
+    _fields_ = [('A', C.c_void_p), ('B', C.c_void_p), ('lda', C.c_int32), ('ldb', C.c_int32), ('K', C.c_int32), ('C', C.c_void_p), ('ldc', C.c_int32),
+                ('B2', C.c_void_p), ('ldb2', C.c_int32), ('nb2', C.c_int32), ('Cx1', C.c_void_p), ('ldx1', C.c_int32), ('colsum', C.c_void_p),
+                ('A2', C.c_void_p), ('lda2', C.c_int32), ('na2', C.c_int32), ('Cx2', C.c_void_p), ('ldx2', C.c_int32), ('colsum2', C.c_void_p),
+                ('B3', C.c_void_p), ('ldb3', C.c_int32), ('nb3', C.c_int32), ('Cx3', C.c_void_p), ('ldx3', C.c_int32)]
+
+
 class KpdRecBatch(C.Structure):
     _fields_ = [('B', C.c_int32), ('n_rec', C.c_int32), ('max_rec', C.c_int32), ('rec_ptr', C.c_void_p),
                 ('rec_x', C.c_void_p), ('rec_h', C.c_void_p), ('n_rr', C.c_int32), ('rr_src', C.c_void_p),
@@ -156,6 +163,7 @@ def lib():
     L.kpd_gvp_trainer_backward.argtypes = [C.c_void_p] + [C.c_void_p] * 8
     L.kpd_gvp_trainer_set_dropout.argtypes = [C.c_void_p, C.c_float, C.c_uint64]
     L.kpd_gvp_trainer_message_path.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    L.kpd_wgrad_batch.argtypes = [C.c_int32, C.c_int32, C.POINTER(KpdWgradItem), C.c_void_p, C.c_int64, C.c_void_p]
     L.kpd_dropout_mask.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]
     L.kpd_recenc_trainer_create.argtypes = [C.POINTER(KpdRecencConfig), C.POINTER(C.c_void_p)]
     L.kpd_recenc_trainer_destroy.argtypes = [C.c_void_p]
@@ -203,7 +211,7 @@ EXPORTS = [
     'kpd_xyz_scratch_bytes', 'kpd_xyz_emit', 'kpd_rec_graph_scratch_bytes', 'kpd_build_rec_graph',
     'kpd_egnn_trainer_create', 'kpd_egnn_trainer_destroy', 'kpd_egnn_trainer_bind', 'kpd_egnn_trainer_reserve',
     'kpd_egnn_trainer_forward', 'kpd_egnn_trainer_backward', 'kpd_egnn_trainer_profile', 'kpd_egnn_trainer_profile_read', 'kpd_gvp_trainer_last_counts',
-    'kpd_gvp_trainer_message_path',
+    'kpd_gvp_trainer_message_path', 'kpd_wgrad_batch',
     'kpd_gvp_trainer_create', 'kpd_gvp_trainer_destroy', 'kpd_gvp_trainer_bind', 'kpd_gvp_trainer_reserve',
     'kpd_gvp_trainer_forward', 'kpd_gvp_trainer_backward', 'kpd_gvp_trainer_set_dropout', 'kpd_dropout_mask',
     'kpd_recenc_trainer_create', 'kpd_recenc_trainer_destroy', 'kpd_recenc_trainer_bind', 'kpd_recenc_trainer_set_dropout',
@@ -885,6 +893,25 @@ def sgemm(a: torch.Tensor, b: torch.Tensor, trans_a=False, trans_b=False, alpha=
                           workspace.data_ptr() if workspace is not None else None,
                           int(workspace.numel()) if workspace is not None else 0, _stream()))
     return out
+
+
+def wgrad_batch(kind: int, items, workspace: torch.Tensor):
+    """kpd_wgrad_batch: `items` = list of dicts with the fields of kpd_wgrad_item (tensors or None, ints); leading dimensions are taken from
+    the tensors' row strides.  Outputs are accumulated in place."""
+    arr = (KpdWgradItem * len(items))()
+    ld = lambda t: int(t.stride(0)) if t.shape[0] > 1 else max(int(t.shape[-1]), 1)
+    p = lambda t: t.data_ptr() if t is not None else None
+    for k, it in enumerate(items):
+        e = arr[k]
+        e.A, e.B, e.lda, e.ldb, e.K = p(it['A']), p(it['B']), ld(it['A']), ld(it['B']), int(it['A'].shape[0])
+        c = it.get('C')
+        e.C, e.ldc = p(c), ld(c) if c is not None else 0
+        for src, ldf, nf, dst, ldd in (('B2', 'ldb2', 'nb2', 'Cx1', 'ldx1'), ('A2', 'lda2', 'na2', 'Cx2', 'ldx2'), ('B3', 'ldb3', 'nb3', 'Cx3', 'ldx3')):
+            t, o = it.get(src), it.get(dst)
+            setattr(e, src, p(t)); setattr(e, ldf, ld(t) if t is not None else 0); setattr(e, nf, int(it.get(nf, 0)))
+            setattr(e, dst, p(o)); setattr(e, ldd, ld(o) if o is not None else 0)
+        e.colsum, e.colsum2 = p(it.get('colsum')), p(it.get('colsum2'))
+    check(lib().kpd_wgrad_batch(int(kind), len(items), arr, workspace.data_ptr(), int(workspace.numel()), _stream()))
 
 
 def step_coefficients(gamma: torch.Tensor, s: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
