@@ -2,7 +2,7 @@
 # Same-call A/B of the GVP trainer's message / node path (TOOLS build; run on the GPU box from the repo root):
 #   A = KPD_TRAIN_FUSED=0: one GVP at a time through the GEMM kernels (the path of rounds 3 - 4, still taken at hidden widths other than 256)
 #   B = KPD_TRAIN_FUSED=1: the register-chained kernels + batched weight gradients (the default)
-cd /tmp && export TMPDIR=/tmp && cd "$(cd "$(dirname "$0")/../.." && pwd)"
+root=$(cd "$(dirname "$0")/../.." && pwd); cd /tmp && export TMPDIR=/tmp && cd "$root"
 export KPD_LIB=$PWD/keypoint-diffusion_amd/csrc/tools_build/libkpd_hip.so
 for rep in 1 2; do
   for f in 0 1; do
