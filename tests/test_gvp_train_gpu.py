@@ -179,11 +179,19 @@ def test_stale_forward_cannot_be_differentiated():
         (eh3.sum() + ex3.sum()).backward()
 
 
-def test_training_step_is_bitwise_reproducible():
-    """As for the EGNN trainer: two forward/backward passes of the same batch (dropout off) are bit-identical."""
-    cfg = dict(GVP_CFGS['gvp_norm0'])
-    g, model, t = _case(cfg, [40, 33], [9, 12], 10)
+@pytest.mark.parametrize('tag,over,sizes', [('gvp_norm0', {}, ([40, 33], [9, 12])),
+                                            # the chained kernels and the K-split batched weight gradients (several slices per product)
+                                            ('gvp_kp', dict(dropout=0.0, n_convs=2), ([150, 97], [25, 18])),
+                                            ('gvp_kp', dict(dropout=0.2, n_convs=2), ([60, 45], [12, 9]))])
+def test_training_step_is_bitwise_reproducible(tag, over, sizes):
+    """As for the EGNN trainer: two forward/backward passes of the same batch are bit-identical -- with dropout on too (the masks are a
+    function of the seed, which the module draws from torch's generator: re-seeded before each pass)."""
+    cfg = dict(GVP_CFGS[tag], **over)
+    g, model, t = _case(cfg, sizes[0], sizes[1], 128 if tag == 'gvp_kp' else 10)
     model = model.cuda()
+    if cfg['dropout'] > 0:
+        model.train()
+    assert model._trainer()[0].message_path() in (0, 1)
     runs = []
     for _ in range(2):
         gd = g.to('cuda')
@@ -193,6 +201,7 @@ def test_training_step_is_bitwise_reproducible():
             gd.nodes[nt].data[key] = v
             ins.append(v)
         model.zero_grad(set_to_none=True)
+        torch.manual_seed(123)
         eh, ex = model(gd, t.cuda(), None)
         (eh.square().sum() + ex.square().sum()).backward()
         runs.append([eh.detach().clone(), ex.detach().clone()] + [v.grad.clone() for v in ins] +
