@@ -1106,6 +1106,12 @@ extern "C" kpd_status kpd_gvp_trainer_reserve(kpd_gvp_trainer *T, int32_t max_B,
                         }
                     }
                 KPD_HIP(hipMemset(T->pack_base, 0, pack_floats * 4));           // zero biases of the head GVPs, unused fragment tiles
+                // (debug, KPD_POISON: every activation / piece / gradient buffer behind the packs starts as NaNs, and so do the kept message
+                //  activations: a read of something this step has not written shows -- tests/test_gvp_train_gpu.py)
+                if (poison_level() >= 1) {
+                    poison_floats(T->pack_base + pack_floats, (floats - pack_floats) * 4);
+                    poison_floats(T->store_base, total);
+                }
                 KPD_HIP(hipMemcpy(T->slots_dev, hs.data(), hs.size() * sizeof(GvpTrainSlot), hipMemcpyHostToDevice));
                 for (int et = 0; et < 4; ++et) {
                     T->Psrc[et] = T->pack_base + off_P[et];

@@ -207,3 +207,32 @@ def test_training_step_is_bitwise_reproducible(tag, over, sizes):
         runs.append([eh.detach().clone(), ex.detach().clone()] + [v.grad.clone() for v in ins] +
                     [p.grad.clone() for p in model.parameters() if p.grad is not None])
     assert all(torch.equal(a, b) for a, b in zip(*runs))
+
+
+def test_chained_kernels_on_poisoned_workspaces():
+    """The chained message / node kernels and the batched weight gradients keep their activations, message pieces and gradient staging in
+    buffers of the trainer's own.  A child process runs a training step with all of them (and the LDS of every CU) NaN-filled first
+    (KPD_POISON=1) and must reproduce the default run's bits: a read of memory this step has not written would surface as a NaN or as
+    different bits.  Ragged last tiles, nodes without in-edges of a type (kl_k = 3: most ligand atoms of the larger complexes), dropout on."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ('import torch, sys; sys.path.insert(0, %r)\n'
+            'from tests import test_gvp_train_gpu as T\n'
+            'cfg = dict(T.GVP_CFGS["gvp_kp"], n_convs=2, dropout=0.1, kl_k=3)\n'
+            'g, model, t = T._case(cfg, [70, 33, 57], [14, 9, 12], 128)\n'
+            'model = model.cuda().train(); torch.manual_seed(5)\n'
+            'eh, ex = model(g.to("cuda"), t.cuda(), None)\n'
+            'assert model._trainer()[0].message_path() == 1\n'
+            '(eh.square().sum() + ex.square().sum()).backward()\n'
+            'torch.save([eh.detach().cpu(), ex.detach().cpu()] + [p.grad.cpu() for p in model.parameters() if p.grad is not None], sys.argv[1])\n' % root)
+    outs = []
+    for tag, env in (('default', {}), ('poison', {'KPD_POISON': '1'})):
+        base = os.path.join(root, 'gpurun_out') if os.path.isdir(os.path.join(root, 'gpurun_out')) else '/tmp'
+        path = os.path.join(base, f'_gvp_grads_{tag}.pt')
+        subprocess.run([sys.executable, '-c', code, path], check=True, env=dict(os.environ, **env), timeout=600)
+        outs.append(torch.load(path))
+        os.remove(path)
+    assert all(torch.isfinite(a).all() for a in outs[0])
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
