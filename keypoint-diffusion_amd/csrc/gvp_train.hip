@@ -728,6 +728,8 @@ kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
         // dpre0 = dL/dpre of the first GVP: its scalar inputs were U[src] and rbf
         if (g0.Ws.g && !rbf_done) KPD_TRY(grad_gemm(T, S, RBF, E, dpre0, S, T->rbf, RBF, g0.Ws.g + S, g0.si + g0.h));
         // sums over the out-edges of every source node, in ascending edge order (no float atomics)
+        // (the source block's gradient U^T s_src stays a product of its own: as one more item of the conv's batched launch it cost that
+        //  launch more -- 7.4 -> 8.3 ms per step -- than the 22 small products it replaced -- 0.6)
         KPD_TRY(segsum(T->st, dpre0, S, 0, S, T->scsr[et].perm, T->scsr[et].rowptr, nullptr, 1.0f, false, T->n[s], T->U, S));
         if (g0.Ws.g) KPD_TRY(grad_gemm(T, S, S, T->n[s], T->U, S, T->ss[s][conv], S, g0.Ws.g, g0.si + g0.h));
         KPD_TRY(gemm(T, false, false, T->n[s], S, S, T->U, S, g0.Ws.w, g0.si + g0.h, 1.0f, T->gs[nxt][s], S));
@@ -1206,8 +1208,8 @@ extern "C" kpd_status kpd_gvp_trainer_backward(kpd_gvp_trainer *T, const float *
             KPD_HIP(hipMemsetAsync(T->gs[k][nt], 0, (size_t)T->n[nt] * S * 4, st));
             KPD_HIP(hipMemsetAsync(T->gv[k][nt], 0, (size_t)T->n[nt] * 3 * VC * 4, st));
         }
-    // noise block (recomputed: the conv recomputation reuses its buffers)
-    KPD_TRY(noise_fwd(T, nullptr, nullptr));
+    // noise block: recomputed when the per-GVP conv path ran in between (it reuses these buffers); the chained path leaves them alone
+    if (!T->fused) KPD_TRY(noise_fwd(T, nullptr, nullptr));
     {
         const std::string p = "noise_predictor.noise_predictor";
         Param W, b;

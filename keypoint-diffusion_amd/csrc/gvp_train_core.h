@@ -623,6 +623,59 @@ __global__ void k_ln_bwd_g(const float *__restrict__ x, const float *__restrict_
     }
 }
 
+// The same backward with the two parameter gradients' row sums taken on the way: a workgroup owns LN_GP_ROWS rows (a wave every fourth of them,
+// one after the other: 64 rows per workgroup left the node-sized launches with one workgroup per CU and 16 dependent rows per wave -- 93 us against
+// the 16 us of k_ln_bwd_g), keeps sum_r dy xhat and sum_r dy per column in registers and leaves them as part[block][0 | 1][c] -- the partial format
+// of k_colsum, so k_colsum_reduce finishes gamma.grad and beta.grad in one launch (instead of a dy * xhat array, two column-sum launches over it
+// and over dy, and their two reductions).  cols <= 256.
+constexpr int LN_GP_ROWS = 8;
+__global__ __launch_bounds__(256) void k_ln_bwd_gp(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ dy, int rows, int cols,
+                                                   float *__restrict__ dx, float *__restrict__ part) {
+    __shared__ float s_gx[4][256], s_g[4][256];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r0 = blockIdx.x * LN_GP_ROWS, r1 = min(rows, r0 + LN_GP_ROWS);
+    float agx[4] = {0.0f, 0.0f, 0.0f, 0.0f}, ag[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int r = r0 + wave; r < r1; r += 4) {
+        const float *xr = x + (size_t)r * cols, *dyr = dy + (size_t)r * cols;
+        float s = 0.0f;
+        for (int c = lane; c < cols; c += 64) s += xr[c];
+        const float mean = wave_sum(s) / cols;
+        float q = 0.0f;
+        for (int c = lane; c < cols; c += 64) q += (xr[c] - mean) * (xr[c] - mean);
+        const float rstd = rsqrtf(wave_sum(q) / cols + 1e-5f);
+        float sg = 0.0f, sgx = 0.0f;
+        for (int c = lane; c < cols; c += 64) {
+            const float xh = (xr[c] - mean) * rstd, g = dyr[c] * gamma[c];
+            sg += g;
+            sgx += g * xh;
+        }
+        sg = wave_sum(sg) / cols;
+        sgx = wave_sum(sgx) / cols;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = lane + 64 * j;
+            if (c < cols) {
+                const float xh = (xr[c] - mean) * rstd, d = dyr[c];
+                agx[j] += d * xh;
+                ag[j] += d;
+                dx[(size_t)r * cols + c] = rstd * (d * gamma[c] - sg - xh * sgx);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s_gx[wave][lane + 64 * j] = agx[j];
+        s_g[wave][lane + 64 * j] = ag[j];
+    }
+    __syncthreads();
+    const int c = threadIdx.x;
+    if (c < cols) {
+        float *p = part + (size_t)blockIdx.x * 2 * COLSUM_LD;
+        p[c] = ((s_gx[0][c] + s_gx[1][c]) + s_gx[2][c]) + s_gx[3][c];
+        p[COLSUM_LD + c] = ((s_g[0][c] + s_g[1][c]) + s_g[2][c]) + s_g[3][c];
+    }
+}
+
 // vector part of GVPLayerNorm (gvp.py:162-165): v / (sqrt(mean_ch(max(|v_ch|^2, 1e-8)) + 1e-5) + 1e-5), one thread per row
 // vl = the model's vector_size: channels vl .. 15 are zero padding (a narrower model trained in the 16-channel layout) and take no part in the mean
 __global__ void k_vnorm_fwd(const float *__restrict__ v, int rows, int vl, float *__restrict__ out) {
@@ -918,10 +971,18 @@ kpd_status gvp_ln_bwd(TT *T, const LnP &l, int n, const float *s, const float *v
                       float *ds, float *dv) {
     // (through tmp_s / tmp_v only when the outputs alias the incoming gradients: dso is read again for the bias gradient)
     float *os = ds == dso ? T->tmp_s : ds, *ov = dv == dvo ? T->tmp_v : dv;
-    hipLaunchKernelGGL(k_ln_bwd_g, dim3(cdiv(n, 4)), dim3(256), 0, T->st, s, l.gamma.w, dso, n, T->S, os, T->U);
-    KPD_LAUNCH_CHECK();
-    KPD_TRY(colsum_acc(T, n, T->S, T->U, T->S, l.gamma.g));        // U (free outside the edge passes) = dy * xhat
-    KPD_TRY(colsum_acc(T, n, T->S, dso, T->S, l.beta.g));
+    const int blocks = cdiv(n, LN_GP_ROWS);
+    if (T->S <= 256 && l.gamma.g && l.beta.g && T->colpart && blocks <= T->colpart_blocks) {
+        hipLaunchKernelGGL(k_ln_bwd_gp, dim3(blocks), dim3(256), 0, T->st, s, l.gamma.w, dso, n, T->S, os, T->colpart);
+        KPD_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_colsum_reduce, dim3(cdiv(T->S, 64)), dim3(1024), 0, T->st, T->colpart, blocks, T->S, l.gamma.g, 1, l.beta.g);
+        KPD_LAUNCH_CHECK();
+    } else {
+        hipLaunchKernelGGL(k_ln_bwd_g, dim3(cdiv(n, 4)), dim3(256), 0, T->st, s, l.gamma.w, dso, n, T->S, os, T->U);
+        KPD_LAUNCH_CHECK();
+        KPD_TRY(colsum_acc(T, n, T->S, T->U, T->S, l.gamma.g));        // U (free outside the edge passes) = dy * xhat
+        KPD_TRY(colsum_acc(T, n, T->S, dso, T->S, l.beta.g));
+    }
     if (os != ds) KPD_HIP(hipMemcpyAsync(ds, os, (size_t)n * T->S * 4, hipMemcpyDeviceToDevice, T->st));
     hipLaunchKernelGGL(k_vnorm_bwd, grid1(n), dim3(256), 0, T->st, v, dvo, n, T->V, ov);
     KPD_LAUNCH_CHECK();
