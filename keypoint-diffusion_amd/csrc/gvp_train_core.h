@@ -690,29 +690,29 @@ __global__ void k_vnorm_fwd(const float *__restrict__ v, int rows, int vl, float
     for (int k = 0; k < 3 * VC; ++k) out[(size_t)r * 3 * VC + k] = p[k] * inv;
 }
 
-__global__ void k_vnorm_bwd(const float *__restrict__ v, const float *__restrict__ dout, int rows, int vl, float *__restrict__ dv) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    const float *p = v + (size_t)r * 3 * VC, *d = dout + (size_t)r * 3 * VC;
-    float m = 0.0f, dot = 0.0f;
-    bool live[VC];
+// Sixteen lanes per row (lane = channel, its three components), four rows per wave: the row sums are 16-lane shuffles and every access is a 64-byte
+// piece of the row (one thread per row read and wrote its 2 x 48 floats 192 bytes apart from its neighbours': 29 us for 19 200 rows).
+// dv may be dout (every thread reads its three gradient entries before it writes them).
+__global__ __launch_bounds__(256) void k_vnorm_bwd(const float *__restrict__ v, const float *dout, int rows, int vl, float *dv) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, r = t >> 4, ch = t & 15;
+    const bool in = r < rows;
+    const size_t base = (size_t)(in ? r : rows - 1) * 3 * VC + ch;
+    const float p0 = v[base], p1 = v[base + VC], p2 = v[base + 2 * VC], d0 = dout[base], d1 = dout[base + VC], d2 = dout[base + 2 * VC];
+    const float n2 = p0 * p0 + p1 * p1 + p2 * p2;
+    const bool used = ch < vl, live = n2 > 1e-8f && used;
+    float m = used ? fmaxf(n2, 1e-8f) : 0.0f, dot = used ? d0 * p0 + d1 * p1 + d2 * p2 : 0.0f;
 #pragma unroll
-    for (int ch = 0; ch < VC; ++ch) {
-        const float n2 = p[ch] * p[ch] + p[VC + ch] * p[VC + ch] + p[2 * VC + ch] * p[2 * VC + ch];
-        live[ch] = n2 > 1e-8f && ch < vl;
-        if (ch < vl) {
-            m += fmaxf(n2, 1e-8f);
-            dot += d[ch] * p[ch] + d[VC + ch] * p[VC + ch] + d[2 * VC + ch] * p[2 * VC + ch];
-        }
+    for (int o = 8; o >= 1; o >>= 1) {
+        m += __shfl_xor(m, o);
+        dot += __shfl_xor(dot, o);
     }
     const float root = sqrtf(m / vl + 1e-5f), vn = root + 1e-5f, inv = 1.0f / vn;
     // out = v / vn; dvn = -(dout . v) / vn^2; dvn/dv[ch, c] = v[ch, c] / (vl * root) where the clamp is inactive
     const float k = -dot * inv * inv / (vl * root);
-#pragma unroll
-    for (int ch = 0; ch < VC; ++ch)
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-            dv[(size_t)r * 3 * VC + c * VC + ch] = ch < vl ? d[c * VC + ch] * inv + (live[ch] ? k * p[c * VC + ch] : 0.0f) : 0.0f;
+    if (!in) return;
+    dv[base] = used ? d0 * inv + (live ? k * p0 : 0.0f) : 0.0f;
+    dv[base + VC] = used ? d1 * inv + (live ? k * p1 : 0.0f) : 0.0f;
+    dv[base + 2 * VC] = used ? d2 * inv + (live ? k * p2 : 0.0f) : 0.0f;
 }
 
 __global__ void k_add(const float *__restrict__ a, const float *__restrict__ b, long long n, float *__restrict__ out) {
@@ -970,7 +970,7 @@ template <class TT>
 kpd_status gvp_ln_bwd(TT *T, const LnP &l, int n, const float *s, const float *v, const float *dso, const float *dvo,
                       float *ds, float *dv) {
     // (through tmp_s / tmp_v only when the outputs alias the incoming gradients: dso is read again for the bias gradient)
-    float *os = ds == dso ? T->tmp_s : ds, *ov = dv == dvo ? T->tmp_v : dv;
+    float *os = ds == dso ? T->tmp_s : ds, *ov = dv;          // (the vector kernel works in place)
     const int blocks = cdiv(n, LN_GP_ROWS);
     if (T->S <= 256 && l.gamma.g && l.beta.g && T->colpart && blocks <= T->colpart_blocks) {
         hipLaunchKernelGGL(k_ln_bwd_gp, dim3(blocks), dim3(256), 0, T->st, s, l.gamma.w, dso, n, T->S, os, T->colpart);
@@ -984,7 +984,7 @@ kpd_status gvp_ln_bwd(TT *T, const LnP &l, int n, const float *s, const float *v
         KPD_TRY(colsum_acc(T, n, T->S, dso, T->S, l.beta.g));
     }
     if (os != ds) KPD_HIP(hipMemcpyAsync(ds, os, (size_t)n * T->S * 4, hipMemcpyDeviceToDevice, T->st));
-    hipLaunchKernelGGL(k_vnorm_bwd, grid1(n), dim3(256), 0, T->st, v, dvo, n, T->V, ov);
+    hipLaunchKernelGGL(k_vnorm_bwd, grid1((long long)n * 16), dim3(256), 0, T->st, v, dvo, n, T->V, ov);
     KPD_LAUNCH_CHECK();
     if (ov != dv) KPD_HIP(hipMemcpyAsync(dv, ov, (size_t)n * 3 * VC * 4, hipMemcpyDeviceToDevice, T->st));
     return KPD_OK;
