@@ -602,8 +602,8 @@ kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
                     it.colsum = gp[j].bs.g;
                     if (j > 0) { it.A2 = T->nbslots[nt][j - 1].dgate; it.lda2 = VC; it.na2 = VC; it.Cx2 = gp[j - 1].Wg.g; it.ldx2 = S; it.colsum2 = gp[j - 1].bg.g; }
                     wq.push_back(it);
-                    // Wu / Wh through the vector kernel (its dv_in is not needed here: scratch)
-                    KPD_TRY(gvp_bwd_rest(T, gp[j], n, nullptr, j > 0 ? ns.gb[j - 1].V : v1, ns.gb[j], o, T->dV[1], REST_SKIP_WG | REST_SKIP_WS));
+                    // Wu / Wh through the vector kernel (its dv_in is not needed here)
+                    KPD_TRY(gvp_bwd_rest(T, gp[j], n, nullptr, j > 0 ? ns.gb[j - 1].V : v1, ns.gb[j], o, nullptr, REST_SKIP_WG | REST_SKIP_WS));
                 }
                 {   // the last GVP's gate matrix: rider-only
                     const GvpBwdGvp &o = T->nbslots[nt][nu - 1];
@@ -690,7 +690,7 @@ kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
                     skip[j] |= REST_SKIP_WS;
                     skip[j - 1] |= REST_SKIP_WG;
                 }
-                KPD_TRY(gvp_bwd_rest(T, gp[j], E, T->gb[j - 1].s, T->gb[j - 1].V, T->gb[j], bs.g[j], T->dV[0], skip[j]));
+                KPD_TRY(gvp_bwd_rest(T, gp[j], E, T->gb[j - 1].s, T->gb[j - 1].V, T->gb[j], bs.g[j], nullptr, skip[j]));       // (dv_in: the chained kernel had it)
             }
             KPD_TRY(gvp_bwd_rest(T, g0, E, nullptr, T->vin, T->gb[0], bs.g[0], T->dV[1], skip[0]));
             dpre0 = bs.g[0].dpre;
