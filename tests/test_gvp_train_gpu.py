@@ -50,7 +50,10 @@ def _oracle_grads(model, cfg, g, t, w_h, w_x):
                                       # and once at a size with many tiles per edge type and several K slices per weight gradient
                                       ('gvp_mean', dict(n_hidden_scalars=256)), ('gvp_norm0', dict(n_hidden_scalars=256)),
                                       ('gvp_norm0', dict(n_hidden_scalars=256, ll_k=3, kl_k=0, n_message_gvps=1)),
-                                      ('gvp_kp', dict(n_convs=2, sizes=([150, 97], [25, 18])))])
+                                      ('gvp_kp', dict(n_convs=2, sizes=([150, 97], [25, 18]))),
+                                      # single-atom ligands: no ligand-ligand edges at all; a model that does not update the keypoints (one conv)
+                                      ('gvp_kp', dict(n_convs=2, sizes=([30, 22], [1, 1]))),
+                                      ('gvp_kp', dict(n_convs=1, update_kp=False))])
 def test_gradients_match_oracle_autograd(tag, over):
     over = dict(over)
     n_rec, n_lig = over.pop('sizes', ([26, 19, 33], [7, 10, 5]))
