@@ -875,7 +875,7 @@ struct RedArgs {
     float beta;
 };
 
-__global__ void k_sgemm_reduce(RedArgs a) {
+__device__ __forceinline__ void reduce_body(const RedArgs &a) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     int e = t >> 2;
     const int q = t & 3;
@@ -904,6 +904,13 @@ __global__ void k_sgemm_reduce(RedArgs a) {
     if (g.accumulate) *dst += sum;
     else *dst = a.beta != 0.0f ? sum + a.beta * *dst : sum;
 }
+__global__ void k_sgemm_reduce(RedArgs a) { reduce_body(a); }
+// the reductions of a batched product launch (wgrad_batch, grad257_batch) in one launch: blockIdx.y = product
+constexpr int RED_BATCH = 8;
+struct RedBatch {
+    RedArgs r[RED_BATCH];
+};
+__global__ void k_sgemm_reduce_batch(RedBatch b) { reduce_body(b.r[blockIdx.y]); }
 
 // y[m] = beta y[m] + sum_k A[m][k] x[k * incx]: one wave per row
 __global__ __launch_bounds__(256) void k_sgemv_rows(const float *__restrict__ A, int lda, int M, int K, const float *__restrict__ x,
@@ -931,6 +938,19 @@ int sgemm_split_slices(int M, int N, int K) {
     const int min_depth = tiles * 100 <= small_pct * cu_count() ? 64 : 256;
     s = std::min(s, std::max(1, K / min_depth));
     return std::min(s, SGEMM_MAX_SPLIT);
+}
+
+static kpd_status launch_reduce_batch(const RedBatch &b, int n, hipStream_t st) {
+    long long most = 0;
+    for (int p = 0; p < n; ++p) {
+        long long total = 0;
+        for (int i = 0; i < b.r[p].n_seg; ++i) total += b.r[p].seg[i].count;
+        most = std::max(most, total);
+    }
+    if (n == 0 || most == 0) return KPD_OK;
+    hipLaunchKernelGGL(k_sgemm_reduce_batch, dim3((unsigned)cdiv((int)std::min<long long>(4 * most, 0x7fffff00), 256), n), dim3(256), 0, st, b);
+    KPD_LAUNCH_CHECK();
+    return KPD_OK;
 }
 
 static kpd_status launch_reduce(const RedArgs &r, hipStream_t st) {
@@ -1101,11 +1121,13 @@ kpd_status grad257_batch(const Grad257Item *items, int n, float *part, size_t pa
     KPD_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k_sgemm_tn256_batch), lds));
     hipLaunchKernelGGL(k_sgemm_tn256_batch, dim3(first), dim3(512), lds, st, bt);
     KPD_LAUNCH_CHECK();
+    RedBatch rb;
+    memset(&rb, 0, sizeof(rb));
     for (int i = 0; i < n; ++i) {
         const Grad257Item &it = items[i];
         const SgemmArgs &a = bt.p[i];
         const int sl = bt.first[i + 1] - bt.first[i];
-        RedArgs r;
+        RedArgs &r = rb.r[i];
         r.n_seg = 0; r.slices = sl; r.beta = 1.0f;
         r.seg[r.n_seg++] = RedSeg{a.C, 65536, 65536, it.C, 256, it.ldc, 0};
         if (it.colsum) r.seg[r.n_seg++] = RedSeg{a.cs_part, 256, 256, it.colsum, 0, 1, 1};
@@ -1114,9 +1136,8 @@ kpd_status grad257_batch(const Grad257Item *items, int n, float *part, size_t pa
         r.seg[r.n_seg++] = RedSeg{a.x_part + 256, xs, 256, it.C + (size_t)256 * it.ldc, 0, 1, 0};
         r.seg[r.n_seg++] = RedSeg{a.x_part + 512, xs, 1, it.C + (size_t)256 * it.ldc + 256, 0, 1, 0};
         if (it.colsum) r.seg[r.n_seg++] = RedSeg{a.x_part + 513, xs, 1, it.colsum + 256, 0, 1, 1};
-        KPD_TRY(launch_reduce(r, st));
     }
-    return KPD_OK;
+    return launch_reduce_batch(rb, n, st);
 }
 
 kpd_status wgrad_batch(const WgradItem *items, int n, float *part, size_t part_floats, hipStream_t st) {
@@ -1171,20 +1192,19 @@ kpd_status wgrad_batch(const WgradItem *items, int n, float *part, size_t part_f
         hipLaunchKernelGGL((k_wgrad_tnx<0, 0>), dim3(first), dim3(512), lds, st, bt);
     }
     KPD_LAUNCH_CHECK();
+    RedBatch rb;
+    memset(&rb, 0, sizeof(rb));
     for (int i = 0; i < n; ++i) {
         const WgradItem &it = items[i];
         const WgradProd &p = bt.p[i];
-        RedArgs r;
+        RedArgs &r = rb.r[i];
         r.n_seg = 0; r.slices = p.slices; r.beta = 1.0f;
         float *q = p.part;
         if (!top) {
             r.seg[r.n_seg++] = RedSeg{q, 65536, 65536, it.C, 256, it.ldc, 0};
             q += (size_t)p.slices * 65536;
         }
-        if (!riders) {
-            KPD_TRY(launch_reduce(r, st));
-            continue;
-        }
+        if (!riders) continue;
         if (it.nb2) r.seg[r.n_seg++] = RedSeg{q, (long long)256 * it.nb2, 256 * it.nb2, it.Cx1, it.nb2, it.ldx1, 0};
         q += (size_t)p.slices * 256 * it.nb2;
         if (it.colsum) r.seg[r.n_seg++] = RedSeg{q, 256, 256, it.colsum, 0, 1, 1};
@@ -1194,9 +1214,8 @@ kpd_status wgrad_batch(const WgradItem *items, int n, float *part, size_t part_f
         if (it.na2) r.seg[r.n_seg++] = RedSeg{q, (long long)it.na2 * 256, it.na2 * 256, it.Cx2, 256, it.ldx2, 0};
         q += (size_t)p.slices * it.na2 * 256;
         if (it.na2 && it.colsum2) r.seg[r.n_seg++] = RedSeg{q, 32, it.na2, it.colsum2, 0, 1, 1};
-        if (r.n_seg) KPD_TRY(launch_reduce(r, st));
     }
-    return KPD_OK;
+    return launch_reduce_batch(rb, n, st);
 }
 
 kpd_status sgemv_rows(int M, int K, const float *A, int lda, const float *x, int incx, float beta, float *y, int incy, hipStream_t st) {
