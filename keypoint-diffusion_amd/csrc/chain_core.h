@@ -13,6 +13,16 @@ namespace kpd {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+// Pointers read from a device-resident table (the trainers' activation slots) are generic to the compiler: every access through them becomes
+// a FLAT instruction, which counts in vmcnt AND lgkmcnt -- each wait for an LDS read in the MFMA loops then also waits for the stores in flight.
+// G() states the address space; the accesses come out as global_load / global_store.
+typedef __attribute__((address_space(1))) float gfloat;
+typedef __attribute__((address_space(1))) v4f gv4f;
+typedef float v4f_u4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef __attribute__((address_space(1))) v4f_u4 gv4f_u;          // a 16-byte access at a 4-byte aligned address (rows of 17 floats)
+__device__ __forceinline__ gfloat *G(float *p) { return (gfloat *)p; }
+__device__ __forceinline__ const gfloat *G(const float *p) { return (const gfloat *)p; }
+
 __device__ __forceinline__ v4f mfma16(float a, float b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 // One-instruction square root / reciprocal (v_sqrt_f32, v_rcp_f32: 1 ulp) for the per-row geometry and the vector norms of the chained
 // kernels.  The IEEE-exact sqrtf / division of hipcc are ~8 / ~10 VALU instructions each, and on gfx950 a VALU instruction is time the

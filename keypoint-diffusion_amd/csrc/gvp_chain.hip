@@ -66,8 +66,8 @@ __device__ __forceinline__ void chain_generic_gvp(Ring &ring, const v4f *cb, con
     if constexpr (TR) {
         if (live && !(skip & 4)) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) *reinterpret_cast<v4f *>(tg->Vh + (erow * 3 + c) * 16 + 4 * q) = Vh[c];
-            *reinterpret_cast<v4f *>(tg->sh + erow * 16 + 4 * q) = sh;
+            for (int c = 0; c < 3; ++c) *reinterpret_cast<gv4f *>(G(tg->Vh) + (erow * 3 + c) * 16 + 4 * q) = Vh[c];
+            *reinterpret_cast<gv4f *>(G(tg->sh) + erow * 16 + 4 * q) = sh;
         }
     }
 #pragma unroll
@@ -81,18 +81,18 @@ __device__ __forceinline__ void chain_generic_gvp(Ring &ring, const v4f *cb, con
     const v4f wu = reinterpret_cast<const v4f *>(gk.wup)[lane];
     if constexpr (TR) {
         if (live && !(skip & 1)) {
-            float *pr = tg->pre + erow * (16 * NTS) + 4 * q;
+            gfloat *pr = G(tg->pre) + erow * (16 * NTS) + 4 * q;
 #pragma unroll
-            for (int mt = 0; mt < NTS; ++mt) *reinterpret_cast<v4f *>(pr + 16 * mt) = acc[mt];
+            for (int mt = 0; mt < NTS; ++mt) *reinterpret_cast<gv4f *>(pr + 16 * mt) = acc[mt];
         }
     }
 #pragma unroll
     for (int mt = 0; mt < NTS; ++mt) x[mt] = silu4(acc[mt]);
     if constexpr (TR) {
         if (live && !(skip & 2)) {
-            float *sr = tg->s + erow * (16 * NTS) + 4 * q;
+            gfloat *sr = G(tg->s) + erow * (16 * NTS) + 4 * q;
 #pragma unroll
-            for (int mt = 0; mt < NTS; ++mt) *reinterpret_cast<v4f *>(sr + 16 * mt) = x[mt];
+            for (int mt = 0; mt < NTS; ++mt) *reinterpret_cast<gv4f *>(sr + 16 * mt) = x[mt];
         }
     }
     {   // the next GVP's bias -- or, after the last one, this GVP's again (never used): an unconditional load, because a conditional one
@@ -119,7 +119,7 @@ __device__ __forceinline__ void chain_generic_gvp(Ring &ring, const v4f *cb, con
         ring.release();
         gate = (ga[0] + ga[1]) + (ga[2] + ga[3]) + bgv;
         if constexpr (TR) {
-            if (live && !(skip & 4)) *reinterpret_cast<v4f *>(tg->gate + erow * 16 + 4 * q) = gate;          // before the sigmoid (k_gvp_gate_bwd applies it)
+            if (live && !(skip & 4)) *reinterpret_cast<gv4f *>(G(tg->gate) + erow * 16 + 4 * q) = gate;          // before the sigmoid (k_gvp_gate_bwd applies it)
         }
         if (gk.vec_sigmoid) {
 #pragma unroll
@@ -134,8 +134,8 @@ __device__ __forceinline__ void chain_generic_gvp(Ring &ring, const v4f *cb, con
         Vc[c] = gate * t;
         if constexpr (TR) {
             if (live && !(skip & 4)) {
-                *reinterpret_cast<v4f *>(tg->Vu + (erow * 3 + c) * 16 + 4 * q) = t;
-                *reinterpret_cast<v4f *>(tg->V + (erow * 3 + c) * 16 + 4 * q) = Vc[c];
+                *reinterpret_cast<gv4f *>(G(tg->Vu) + (erow * 3 + c) * 16 + 4 * q) = t;
+                *reinterpret_cast<gv4f *>(G(tg->V) + (erow * 3 + c) * 16 + 4 * q) = Vc[c];
             }
         }
     }
@@ -473,22 +473,21 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
                 if (q == 0) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        tsl->unit[erow * 3 + c] = xdv[c];
-                        tsl->vin[(erow * 3 + c) * 17] = xdv[c];
-                        tsl->g[0].Vh[(erow * 3 + c) * 17 + 16] = Vh[1][c][0];
+                        G(tsl->unit)[erow * 3 + c] = xdv[c];
+                        G(tsl->vin)[(erow * 3 + c) * 17] = xdv[c];
+                        G(tsl->g[0].Vh)[(erow * 3 + c) * 17 + 16] = Vh[1][c][0];
                     }
-                    tsl->g[0].sh[erow * 17 + 16] = sh[1][0];
+                    G(tsl->g[0].sh)[erow * 17 + 16] = sh[1][0];
                 }
-                *reinterpret_cast<v4f *>(tsl->rbf + erow * 16 + 4 * q) = rbf;
+                *reinterpret_cast<gv4f *>(G(tsl->rbf) + erow * 16 + 4 * q) = rbf;
+                // 17-float rows: four consecutive channels as ONE 16-byte store at a 4-byte-aligned address (the hardware takes it; as four
+                // 4-byte stores these three arrays were 30 of the head's store instructions and wrote 0.7 GB per launch in partial sectors)
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        tsl->vin[(erow * 3 + c) * 17 + 1 + 4 * q + r] = Vs[c][r];
-                        tsl->g[0].Vh[(erow * 3 + c) * 17 + 4 * q + r] = Vh[0][c][r];
-                    }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) tsl->g[0].sh[erow * 17 + 4 * q + r] = sh[0][r];
+                for (int c = 0; c < 3; ++c) {
+                    *reinterpret_cast<gv4f_u *>(G(tsl->vin) + (erow * 3 + c) * 17 + 1 + 4 * q) = Vs[c];
+                    *reinterpret_cast<gv4f_u *>(G(tsl->g[0].Vh) + (erow * 3 + c) * 17 + 4 * q) = Vh[0][c];
+                }
+                *reinterpret_cast<gv4f_u *>(G(tsl->g[0].sh) + erow * 17 + 4 * q) = sh[0];
             }
         }
 
@@ -518,18 +517,18 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
         for (int ht = 0; ht < 3; ++ht) wu[ht] = ht < n_ht ? wup[ht * 64] : zero4();
         if constexpr (TR) {
             if (live && !(a.train_skip & 1)) {
-                float *pr = tsl->g[0].pre + erow * S + 4 * q;
+                gfloat *pr = G(tsl->g[0].pre) + erow * S + 4 * q;
 #pragma unroll
-                for (int mt = 0; mt < NTS; ++mt) *reinterpret_cast<v4f *>(pr + 16 * mt) = acc[mt];
+                for (int mt = 0; mt < NTS; ++mt) *reinterpret_cast<gv4f *>(pr + 16 * mt) = acc[mt];
             }
         }
 #pragma unroll
         for (int mt = 0; mt < NTS; ++mt) x[mt] = silu4(HM ? acc[mt] * H_UNSCALE : acc[mt]);
         if constexpr (TR) {
             if (live && !(a.train_skip & 2)) {
-                float *sr = tsl->g[0].s + erow * S + 4 * q;
+                gfloat *sr = G(tsl->g[0].s) + erow * S + 4 * q;
 #pragma unroll
-                for (int mt = 0; mt < NTS; ++mt) *reinterpret_cast<v4f *>(sr + 16 * mt) = x[mt];
+                for (int mt = 0; mt < NTS; ++mt) *reinterpret_cast<gv4f *>(sr + 16 * mt) = x[mt];
             }
         }
         {   // (unconditional: see chain_generic_gvp)
@@ -557,7 +556,7 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
                 gate = (ga[0] + ga[1]) + (ga[2] + ga[3]) + bgv;
             }
             if constexpr (TR) {
-                if (live && !(a.train_skip & 4)) *reinterpret_cast<v4f *>(tsl->g[0].gate + erow * 16 + 4 * q) = gate;
+                if (live && !(a.train_skip & 4)) *reinterpret_cast<gv4f *>(G(tsl->g[0].gate) + erow * 16 + 4 * q) = gate;
             }
             if (g0.vec_sigmoid) {
 #pragma unroll
@@ -581,8 +580,8 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
             Vc[c] = gate * t;
             if constexpr (TR) {
                 if (live && !(a.train_skip & 4)) {
-                    *reinterpret_cast<v4f *>(tsl->g[0].Vu + (erow * 3 + c) * 16 + 4 * q) = t;
-                    *reinterpret_cast<v4f *>(tsl->g[0].V + (erow * 3 + c) * 16 + 4 * q) = Vc[c];
+                    *reinterpret_cast<gv4f *>(G(tsl->g[0].Vu) + (erow * 3 + c) * 16 + 4 * q) = t;
+                    *reinterpret_cast<gv4f *>(G(tsl->g[0].V) + (erow * 3 + c) * 16 + 4 * q) = Vc[c];
                 }
             }
         }
@@ -693,10 +692,10 @@ __device__ __forceinline__ v4f silu_grad4(v4f p) {          // d SiLU(p) / dp = 
 
 // gate backward of one GVP from the kept gate pre-activation and Vu: dgate (stored), dVu (stored, returned in dV)
 __device__ __forceinline__ v4f gate_bwd_lane(const GvpTrainGvp *f, const GvpBwdGvp *o, v4f (&dV)[3], size_t erow, bool live, int q) {
-    const v4f gp = *reinterpret_cast<const v4f *>(f->gate + erow * 16 + 4 * q);
+    const v4f gp = *reinterpret_cast<const gv4f *>(G(f->gate) + erow * 16 + 4 * q);
     v4f Vu[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) Vu[c] = *reinterpret_cast<const v4f *>(f->Vu + (erow * 3 + c) * 16 + 4 * q);
+    for (int c = 0; c < 3; ++c) Vu[c] = *reinterpret_cast<const gv4f *>(G(f->Vu) + (erow * 3 + c) * 16 + 4 * q);
     v4f sg;
 #pragma unroll
     for (int r = 0; r < 4; ++r) sg[r] = sigmoidf_(gp[r]);
@@ -704,9 +703,9 @@ __device__ __forceinline__ v4f gate_bwd_lane(const GvpTrainGvp *f, const GvpBwdG
 #pragma unroll
     for (int c = 0; c < 3; ++c) dV[c] = dV[c] * sg;
     if (live) {
-        *reinterpret_cast<v4f *>(o->dgate + erow * 16 + 4 * q) = dgate;
+        *reinterpret_cast<gv4f *>(G(o->dgate) + erow * 16 + 4 * q) = dgate;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) *reinterpret_cast<v4f *>(o->dVu + (erow * 3 + c) * 16 + 4 * q) = dV[c];
+        for (int c = 0; c < 3; ++c) *reinterpret_cast<gv4f *>(G(o->dVu) + (erow * 3 + c) * 16 + 4 * q) = dV[c];
     }
     return dgate;
 }
@@ -739,18 +738,18 @@ __device__ __forceinline__ void chain_generic_gvp_bwd(Ring &ring, const v4f *cb,
     const v4f dgate = gate_bwd_lane(f, o, dV, erow, live, q);
     // kept pre-activation: requested before the gate chunk, used behind it
     {
-        const float *pr = f->pre + erow * S + 4 * q;
+        const gfloat *pr = G(f->pre) + erow * S + 4 * q;
 #pragma unroll
-        for (int mt = 0; mt < NTS; ++mt) x[mt] = *reinterpret_cast<const v4f *>(pr + 16 * mt);
+        for (int mt = 0; mt < NTS; ++mt) x[mt] = *reinterpret_cast<const gv4f *>(pr + 16 * mt);
     }
     chunk_gemm<NTS>(ring.current(), dgate, acc, lane, 4, [&] { ring.prefetch(ahead(0)); });
     ring.release();
 #pragma unroll
     for (int mt = 0; mt < NTS; ++mt) x[mt] = acc[mt] * silu_grad4(x[mt]);
     if (live) {
-        float *dp = o->dpre + erow * S + 4 * q;
+        gfloat *dp = G(o->dpre) + erow * S + 4 * q;
 #pragma unroll
-        for (int mt = 0; mt < NTS; ++mt) *reinterpret_cast<v4f *>(dp + 16 * mt) = x[mt];
+        for (int mt = 0; mt < NTS; ++mt) *reinterpret_cast<gv4f *>(dp + 16 * mt) = x[mt];
     }
 #pragma unroll
     for (int mt = 0; mt < NTS; ++mt) acc[mt] = zero4();
@@ -764,9 +763,9 @@ __device__ __forceinline__ void chain_generic_gvp_bwd(Ring &ring, const v4f *cb,
     // vector half: dVh = Wu dVu + dsh Vh / |Vh| (where the clamp of the norm is inactive), dv_in = Wh dVh
     v4f Vh[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) Vh[c] = *reinterpret_cast<const v4f *>(f->Vh + (erow * 3 + c) * 16 + 4 * q);
-    const v4f sh = *reinterpret_cast<const v4f *>(f->sh + erow * 16 + 4 * q);
-    if (live) *reinterpret_cast<v4f *>(o->dsh + erow * 16 + 4 * q) = dsh;
+    for (int c = 0; c < 3; ++c) Vh[c] = *reinterpret_cast<const gv4f *>(G(f->Vh) + (erow * 3 + c) * 16 + 4 * q);
+    const v4f sh = *reinterpret_cast<const gv4f *>(G(f->sh) + erow * 16 + 4 * q);
+    if (live) *reinterpret_cast<gv4f *>(G(o->dsh) + erow * 16 + 4 * q) = dsh;
     const v4f wut = reinterpret_cast<const v4f *>(w.wut)[lane], wht = reinterpret_cast<const v4f *>(w.wht)[lane];
     v4f nrm;
 #pragma unroll
@@ -849,18 +848,18 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain_bwd(GvpEdgeBwdArgs a) {
         auto ahead = [&](int i) -> const v4f * { return hb + (size_t)(i + 2 < 4 ? i + 2 : 3) * CH4; };
         const v4f dgate = gate_bwd_lane(f, o, dV, erow, live, q);
         {
-            const float *pr = f->pre + erow * S + 4 * q;
+            const gfloat *pr = G(f->pre) + erow * S + 4 * q;
 #pragma unroll
-            for (int mt = 0; mt < NTS; ++mt) x[mt] = *reinterpret_cast<const v4f *>(pr + 16 * mt);
+            for (int mt = 0; mt < NTS; ++mt) x[mt] = *reinterpret_cast<const gv4f *>(pr + 16 * mt);
         }
         chunk_gemm<NTS>(ring.current(), dgate, acc, lane, 4, [&] { ring.prefetch(ahead(0)); });
         ring.release();
 #pragma unroll
         for (int mt = 0; mt < NTS; ++mt) x[mt] = acc[mt] * silu_grad4(x[mt]);
         if (live) {
-            float *dp = o->dpre + erow * S + 4 * q;
+            gfloat *dp = G(o->dpre) + erow * S + 4 * q;
 #pragma unroll
-            for (int mt = 0; mt < NTS; ++mt) *reinterpret_cast<v4f *>(dp + 16 * mt) = x[mt];
+            for (int mt = 0; mt < NTS; ++mt) *reinterpret_cast<gv4f *>(dp + 16 * mt) = x[mt];
         }
         const v4f drbf = chunk_tile_product<NTS>(ring.current(), x, lane, [&] { ring.prefetch(ahead(1)); });
         ring.release();
@@ -869,10 +868,10 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain_bwd(GvpEdgeBwdArgs a) {
         const v4f dsh1 = chunk_tile_product<NTS>(ring.current(), x, lane, [&] { ring.prefetch(ahead(3)); });
         ring.release();
         if (live) {
-            *reinterpret_cast<v4f *>(os->drbf + erow * 16 + 4 * q) = drbf;
+            *reinterpret_cast<gv4f *>(G(os->drbf) + erow * 16 + 4 * q) = drbf;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o->dsh[erow * 17 + 4 * q + r] = dsh0[r];
-            if (q == 0) o->dsh[erow * 17 + 16] = dsh1[0];
+            for (int r = 0; r < 4; ++r) G(o->dsh)[erow * 17 + 4 * q + r] = dsh0[r];
+            if (q == 0) G(o->dsh)[erow * 17 + 16] = dsh1[0];
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the ring's tail fetches must not outlive the workgroup's LDS
