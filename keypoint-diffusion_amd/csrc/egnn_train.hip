@@ -294,6 +294,8 @@ struct kpd_egnn_trainer : TrainCtx {
     std::vector<float *> hs[2], xs[2], hns[2], xns[2];
     // scratch
     float *nb[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // [cap_N, LD] each
+    float *nbw[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};     // per node type: du, dq1 of node_bwd and (recompute mode) the node MLP's hidden activation, kept until the layer's batched weight gradients ran
+    std::vector<Grad257Item> wq_nodes;                               // the node MLPs' weight gradients of the current layer (grad257_batch)
     float *dact = nullptr;                                                       // [cap_N, ENC_LD]
     // Kept forward activations (KPD_TRAIN_STORE, default on): pre1 / a1 / pre2 / a2 of both MLP branches of every (layer, edge
     // type), the attention weights, the geometry and the coordinate head, so that the backward pass reads them instead of running
@@ -511,7 +513,7 @@ kpd_status node_params(kpd_egnn_trainer *T, int l, int nt, NodeParams *p) {
 struct NodeAct { float *q[3]; };
 inline NodeAct node_act(kpd_egnn_trainer *T, int l, int nt) {
     NodeAct a;
-    for (int k = 0; k < 3; ++k) a.q[k] = T->store ? T->nq[nt][k][l] : T->nb[2 + k];
+    for (int k = 0; k < 3; ++k) a.q[k] = T->store ? T->nq[nt][k][l] : k == 1 ? T->nbw[nt][2] : T->nb[2 + k];       // (q[1] outlives node_bwd: its weight gradient is batched)
     return a;
 }
 kpd_status node_mlp_fwd(kpd_egnn_trainer *T, const NodeParams &p, int l, int nt, const NodeAct &a) {
@@ -729,7 +731,7 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
     }
     add((size_t)max_n_lig * ENC_LD, 4); add((size_t)max_n_lig * ENC_LD, 4);
     for (int k = 0; k < 6; ++k) add((size_t)cap_E * LD, 4);
-    for (int k = 0; k < 7; ++k) add((size_t)cap_N * LD, 4);
+    for (int k = 0; k < 7 + 6; ++k) add((size_t)cap_N * LD, 4);          // nb[7] + nbw[2][3]
     add((size_t)cap_N * ENC_LD, 4);
     for (int nt = 0; nt < 2; ++nt) {
         for (int k = 0; k < 3; ++k) add((size_t)nn[nt] * CAT_LD, 4);              // ucat, ducat, dvwcat
@@ -778,6 +780,8 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
     T->dec1 = W.take<float>((size_t)max_n_lig * ENC_LD);
     T->dec2 = W.take<float>((size_t)max_n_lig * ENC_LD);
     for (int k = 0; k < 7; ++k) T->nb[k] = W.take<float>((size_t)cap_N * LD);
+    for (int nt = 0; nt < 2; ++nt)
+        for (int k = 0; k < 3; ++k) T->nbw[nt][k] = W.take<float>((size_t)cap_N * LD);
     T->dact = W.take<float>((size_t)cap_N * ENC_LD);
     for (int nt = 0; nt < 2; ++nt) {
         T->ucat[nt] = W.take<float>((size_t)nn[nt] * CAT_LD);
@@ -982,8 +986,12 @@ kpd_status node_bwd(kpd_egnn_trainer *T, int l, int nt, int cur, int nxt, float 
     KPD_TRY(node_params(T, l, nt, &p));
     const NodeAct na = node_act(T, l, nt);
     if (!T->store) KPD_TRY(node_mlp_fwd(T, p, l, nt, na));          // (kept otherwise)
-    float *du = T->nb[0], *tmp = T->nb[1];
+    float *du = T->nbw[nt][0], *tmp = T->nbw[nt][1];
     const float *dy = T->dh[cur][nt];
+    // The three 257 x 257 weight gradients of this node MLP wait for the other node type's and go out as ONE launch (layer_bwd): as split-K
+    // products of their own (K = node count, nine 128 x 128 output tiles each) they ran at a quarter of the MFMA peak.  Their operands are kept
+    // activations and the per-type buffers above (nbw), in both memory modes: the two modes stay bit-identical.
+    const bool batch = p.W2.g && p.b2.g && p.W1.g && p.b1.g;
     if (T->cfg.norm) {
         hipLaunchKernelGGL(k_ln_bwd, dim3(cdiv(n, 4)), dim3(256), 0, T->st, T->hs[nt][l], na.q[2], p.b2.w, p.gamma.w, dy, n, T->cfg.hidden_nf, du, tmp);
         KPD_LAUNCH_CHECK();
@@ -992,11 +1000,17 @@ kpd_status node_bwd(kpd_egnn_trainer *T, int l, int nt, int cur, int nxt, float 
     } else {
         KPD_HIP(hipMemcpyAsync(du, dy, (size_t)n * LD * 4, hipMemcpyDeviceToDevice, T->st));
     }
-    KPD_TRY(grad_gemm(T, H, H, n, du, LD, na.q[1], LD, p.W2.g, H, p.b2.g));
+    if (batch) T->wq_nodes.push_back(Grad257Item{du, na.q[1], LD, LD, n, p.W2.g, H, p.b2.g});
+    else KPD_TRY(grad_gemm(T, H, H, n, du, LD, na.q[1], LD, p.W2.g, H, p.b2.g));
     float *dq1 = tmp;
     KPD_TRY(gemm(T, false, false, n, H, H, du, LD, p.W2.w, H, 0.0f, dq1, LD, 1.0f, na.q[0]));                    // * SiLU'(pre) in the epilogue
-    KPD_TRY(grad_gemm(T, H, H, n, dq1, LD, T->hs[nt][l], LD, p.W1.g, 2 * H, p.b1.g));
-    if (p.W1.g) KPD_TRY(grad_gemm(T, H, H, n, dq1, LD, T->hns[nt][l], LD, p.W1.g + H, 2 * H));
+    if (batch) {
+        T->wq_nodes.push_back(Grad257Item{dq1, T->hs[nt][l], LD, LD, n, p.W1.g, 2 * H, p.b1.g});
+        T->wq_nodes.push_back(Grad257Item{dq1, T->hns[nt][l], LD, LD, n, p.W1.g + H, 2 * H, nullptr});
+    } else {
+        KPD_TRY(grad_gemm(T, H, H, n, dq1, LD, T->hs[nt][l], LD, p.W1.g, 2 * H, p.b1.g));
+        if (p.W1.g) KPD_TRY(grad_gemm(T, H, H, n, dq1, LD, T->hns[nt][l], LD, p.W1.g + H, 2 * H));
+    }
     // dh_in = du (residual) + dq1 W1[:, :257];  d(h_neigh / z) = dq1 W1[:, 257:]
     KPD_HIP(hipMemcpyAsync(T->dh[nxt][nt], du, (size_t)n * LD * 4, hipMemcpyDeviceToDevice, T->st));
     KPD_TRY(gemm(T, false, false, n, H, H, dq1, LD, p.W1.w, 2 * H, 1.0f, T->dh[nxt][nt], LD));
@@ -1088,7 +1102,9 @@ kpd_status layer_edges_bwd_fused(kpd_egnn_trainer *T, int l, int cur, int nxt, f
 
 kpd_status layer_bwd(kpd_egnn_trainer *T, int l, int cur, int nxt, float *dhn[2]) {
     // (final layer, keypoints: dh_out = dx_out = 0, so dh_in / dx_in start from the zeros the caller left in dh[nxt] / dx[nxt])
+    T->wq_nodes.clear();
     for (int nt = 0; nt < layer_n_upd(T, l); ++nt) KPD_TRY(node_bwd(T, l, nt, cur, nxt, dhn[nt]));
+    KPD_TRY(grad257_batch(T->wq_nodes.data(), (int)T->wq_nodes.size(), T->part, T->part_floats, T->st));
     KPD_TRY(layer_stage(T, l));
     if (!T->store) KPD_TRY(layer_project(T, l));
     if (!T->store) KPD_TRY(layer_edges_fused(T, l, false));          // recompute mode: refill this layer's slots
