@@ -190,6 +190,66 @@ __global__ void k_ln_bwd(const float *__restrict__ h, const float *__restrict__ 
     }
 }
 
+// The same with the row sums of the two parameter gradients taken on the way (as k_ln_bwd_gp of the GVP trainers): a workgroup owns LNP_ROWS
+// rows, a wave every fourth of them, and leaves sum_r dy xhat / sum_r dy per column as part[block][0 | 1][c] in k_colsum's partial format --
+// one k_colsum_reduce then finishes gamma.grad and beta.grad (instead of a dy * xhat array, two column-sum launches and two reductions).
+constexpr int LNP_ROWS = 8;
+__global__ __launch_bounds__(256) void k_ln_bwd_p(const float *__restrict__ h, const float *__restrict__ q2, const float *__restrict__ b2,
+                                                  const float *__restrict__ gamma, const float *__restrict__ dy, int n, int hid, float *__restrict__ du,
+                                                  float *__restrict__ part) {
+    __shared__ float s_gx[4][320], s_g[4][320];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r0 = blockIdx.x * LNP_ROWS, r1 = min(n, r0 + LNP_ROWS);
+    float agx[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, ag[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    const float inv_n = 1.0f / (float)(hid + 1);
+    for (int r = r0 + wave; r < r1; r += 4) {
+        float u[5], s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int c = lane + 64 * k;
+            u[k] = (c < hid || c == H - 1) ? h[(size_t)r * LD + c] + q2[(size_t)r * LD + c] + b2[c] : 0.0f;
+            s += u[k];
+        }
+        const float mean = wave_sum(s) * inv_n;
+        float q = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            if (lane + 64 * k < hid || lane + 64 * k == H - 1) q += (u[k] - mean) * (u[k] - mean);
+        const float rstd = rsqrtf(wave_sum(q) * inv_n + 1e-5f);
+        float g[5], xh[5], sg = 0.0f, sgx = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int c = lane + 64 * k;
+            const bool live = c < hid || c == H - 1;
+            xh[k] = live ? (u[k] - mean) * rstd : 0.0f;
+            const float d = live ? dy[(size_t)r * LD + c] : 0.0f;
+            g[k] = live ? d * gamma[c] : 0.0f;
+            sg += g[k];
+            sgx += g[k] * xh[k];
+            agx[k] += d * xh[k];
+            ag[k] += c < H ? dy[(size_t)r * LD + c] : 0.0f;          // (the bias gradient sums dy over all H columns, as colsum_acc(dy) did)
+        }
+        sg = wave_sum(sg) * inv_n;
+        sgx = wave_sum(sgx) * inv_n;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int c = lane + 64 * k;
+            if (c < H) du[(size_t)r * LD + c] = (c < hid || c == H - 1) ? rstd * (g[k] - sg - xh[k] * sgx) : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        s_gx[wave][lane + 64 * k] = agx[k];
+        s_g[wave][lane + 64 * k] = ag[k];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += 256) {
+        float *p = part + (size_t)blockIdx.x * 2 * COLSUM_LD;
+        p[c] = ((s_gx[0][c] + s_gx[1][c]) + s_gx[2][c]) + s_gx[3][c];
+        p[COLSUM_LD + c] = ((s_g[0][c] + s_g[1][c]) + s_g[2][c]) + s_g[3][c];
+    }
+}
+
 // geometry backward: n = x_diff / (dij + 1), dij = |x_diff|; per-edge gradient of x_src (= minus that of x_dst)
 __global__ void k_geom_bwd(const float *__restrict__ ddij, const float *__restrict__ dn, const float *__restrict__ xdiff,
                            const float *__restrict__ dij, int E, float *__restrict__ redge) {
@@ -993,10 +1053,18 @@ kpd_status node_bwd(kpd_egnn_trainer *T, int l, int nt, int cur, int nxt, float 
     // activations and the per-type buffers above (nbw), in both memory modes: the two modes stay bit-identical.
     const bool batch = p.W2.g && p.b2.g && p.W1.g && p.b1.g;
     if (T->cfg.norm) {
-        hipLaunchKernelGGL(k_ln_bwd, dim3(cdiv(n, 4)), dim3(256), 0, T->st, T->hs[nt][l], na.q[2], p.b2.w, p.gamma.w, dy, n, T->cfg.hidden_nf, du, tmp);
-        KPD_LAUNCH_CHECK();
-        KPD_TRY(colsum_acc(T, n, H, tmp, LD, p.gamma.g));
-        KPD_TRY(colsum_acc(T, n, H, dy, LD, p.beta.g));
+        const int blocks = cdiv(n, LNP_ROWS);
+        if (p.gamma.g && p.beta.g && T->colpart && blocks <= T->colpart_blocks) {
+            hipLaunchKernelGGL(k_ln_bwd_p, dim3(blocks), dim3(256), 0, T->st, T->hs[nt][l], na.q[2], p.b2.w, p.gamma.w, dy, n, T->cfg.hidden_nf, du, T->colpart);
+            KPD_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_colsum_reduce, dim3(cdiv(H, 64)), dim3(1024), 0, T->st, T->colpart, blocks, H, p.gamma.g, 1, p.beta.g);
+            KPD_LAUNCH_CHECK();
+        } else {
+            hipLaunchKernelGGL(k_ln_bwd, dim3(cdiv(n, 4)), dim3(256), 0, T->st, T->hs[nt][l], na.q[2], p.b2.w, p.gamma.w, dy, n, T->cfg.hidden_nf, du, tmp);
+            KPD_LAUNCH_CHECK();
+            KPD_TRY(colsum_acc(T, n, H, tmp, LD, p.gamma.g));
+            KPD_TRY(colsum_acc(T, n, H, dy, LD, p.beta.g));
+        }
     } else {
         KPD_HIP(hipMemcpyAsync(du, dy, (size_t)n * LD * 4, hipMemcpyDeviceToDevice, T->st));
     }
