@@ -1133,6 +1133,9 @@ kpd_status layer_edges_bwd_fused(kpd_egnn_trainer *T, int l, int cur, int nxt, f
         KPD_TRY(T->timed(1, edges, [&] { return launch_egnn_edge_bwd(a, tiles, T->st); }));
     }
     std::vector<Grad257Item> wq;
+    ColsumRedBatch crb;
+    memset(&crb, 0, sizeof(crb));
+    int n_crb = 0;
     for (int et = 0; et < layer_n_et(T, l); ++et) {
         const int E = T->E[et], s = kS[et], d = kD[et];
         if (E == 0) continue;
@@ -1141,9 +1144,7 @@ kpd_status layer_edges_bwd_fused(kpd_egnn_trainer *T, int l, int cur, int nxt, f
             BranchParams p;
             KPD_TRY(branch_params(T, l, et, br, &p));
             float *dpre1 = sl.e[br][0], *a1 = sl.e[br][1], *dpre2 = sl.e[br][2];
-            hipLaunchKernelGGL(k_colsum_reduce, dim3(cdiv(H, 64)), dim3(1024), 0, T->st, T->bpart[br] + (size_t)tile0[et] * 2 * COLSUM_LD, cdiv(E, TM), H,
-                               p.head.g, 1, p.b2.g);
-            KPD_LAUNCH_CHECK();
+            crb.r[n_crb++] = ColsumRedBatch::One{T->bpart[br] + (size_t)tile0[et] * 2 * COLSUM_LD, cdiv(E, TM), H, 1, p.head.g, p.b2.g};       // (one launch below)
             if (br == 0 && p.head_b.g) KPD_TRY(sum_scalar(T, sl.att, E, p.head_b.g));           // (ds of the attention logits, left over att)
             if (p.W2.g) {       // dW2 += dpre2^T a1: with the layer's other edge-sized products in one launch below
                 wq.push_back(Grad257Item{dpre2, a1, LD, LD, E, p.W2.g, H, nullptr});
@@ -1164,6 +1165,10 @@ kpd_status layer_edges_bwd_fused(kpd_egnn_trainer *T, int l, int cur, int nxt, f
     }
     // the second-Linear weight gradients of every (edge type, branch) of the layer: one launch, a share of the CUs per product proportional
     // to its edge count (sgemm.hip, grad257_batch) instead of a launch, 256 partial tiles and a reduction each
+    if (n_crb) {          // head and second-bias gradients of every (edge type, branch): the per-tile partials of k_egnn_edge_bwd, summed in one launch
+        hipLaunchKernelGGL(k_colsum_reduce_batch, dim3(cdiv(H, 64), n_crb), dim3(1024), 0, T->st, crb);
+        KPD_LAUNCH_CHECK();
+    }
     for (size_t i = 0; i < wq.size(); i += 8) KPD_TRY(grad257_batch(wq.data() + i, (int)std::min<size_t>(8, wq.size() - i), T->part, T->part_floats, T->st));
     return KPD_OK;
 }

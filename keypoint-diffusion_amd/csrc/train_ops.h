@@ -136,8 +136,8 @@ __global__ void k_colsum(const float *__restrict__ A, int lda, const float *__re
 
 // one workgroup of 64 columns x 16 block-slices: slice g adds the partials of blocks g, g + 16, ... in order, the 16 slice sums
 // are combined in slice order -- a fixed tree, so the result does not depend on timing
-__global__ __launch_bounds__(1024) void k_colsum_reduce(const float *__restrict__ part, int blocks, int K, float *__restrict__ y, int incy,
-                                                        float *__restrict__ y2) {
+__device__ __forceinline__ void colsum_reduce_body(const float *__restrict__ part, int blocks, int K, float *__restrict__ y, int incy,
+                                                   float *__restrict__ y2) {
     __shared__ float s_s[16][64], s_p[16][64];
     const int cl = threadIdx.x & 63, g = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
     float s = 0.0f, p = 0.0f;
@@ -174,6 +174,22 @@ __global__ __launch_bounds__(1024) void k_colsum_reduce(const float *__restrict_
         if (y) y[(size_t)c * incy] += ts;
         if (y2) y2[c] += tp;
     }
+}
+__global__ __launch_bounds__(1024) void k_colsum_reduce(const float *__restrict__ part, int blocks, int K, float *__restrict__ y, int incy,
+                                                        float *__restrict__ y2) {
+    colsum_reduce_body(part, blocks, K, y, incy, y2);
+}
+// several such reductions in one launch (blockIdx.y = which): the per-(edge type, branch) head / bias gradients of an EGNN layer
+struct ColsumRedBatch {
+    struct One {
+        const float *part;
+        int blocks, K, incy;
+        float *y, *y2;
+    } r[8];
+};
+__global__ __launch_bounds__(1024) void k_colsum_reduce_batch(ColsumRedBatch b) {
+    const ColsumRedBatch::One &o = b.r[blockIdx.y];
+    colsum_reduce_body(o.part, o.blocks, o.K, o.y, o.incy, o.y2);
 }
 
 // ---- edges grouped by SOURCE node (the engines' edge lists are dst-sorted) ------------------------------------------------
