@@ -173,8 +173,17 @@ kpd_status launch_edge_pieces_sum(const float *hn_main, const float *hn_cont, co
                                   const float *zinv, int n, float *hn, float *xn, hipStream_t st);
 kpd_status launch_edge_train_pack(const EdgePackTab &t, hipStream_t st);
 kpd_status launch_egnn_edge_bwd(const EdgeBwdArgs &a, int tile_cap, hipStream_t st);
-kpd_status launch_edge_pieces_set(const float *m1, const float *c1, const float *m2, const float *c2, const int *rowptr, int n, float *o1, float *o2,
-                                  int ldo, hipStream_t st);
+// dV / dVw of up to eight (edge type, branch) pairs from the per-tile pieces of k_egnn_edge_bwd (o2 may be null)
+struct EdgePiecesBatch {
+    struct One {
+        const float *m1, *c1, *m2, *c2;
+        const int *rowptr;
+        int n;
+        float *o1, *o2;
+    } e[8];
+    int ldo;
+};
+kpd_status launch_edge_pieces_set(const EdgePiecesBatch &b, int count, hipStream_t st);
 kpd_status launch_proj_chain(const ProjPair &p, hipStream_t st);
 kpd_status launch_node_layer(const NodeLayerPair &p, hipStream_t st);
 

@@ -1208,9 +1208,13 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_bwd(EdgeBwdArgs a) {
 
 // dV[v] = main[v] + the continuation pieces of the tiles v's in-edges span (zeros without in-edges), the same for dVw: the pieces of
 // k_egnn_edge_bwd in tile order, into the layer's gradient blocks (rows ldo apart)
-__global__ __launch_bounds__(256) void k_edge_pieces_set(const float *__restrict__ m1, const float *__restrict__ c1, const float *__restrict__ m2,
-                                                         const float *__restrict__ c2, const int *__restrict__ rowptr, int n, float *__restrict__ o1,
-                                                         float *__restrict__ o2, int ldo) {
+// (one launch for the (edge type, branch) pairs of a layer: blockIdx.y = pair)
+__global__ __launch_bounds__(256) void k_edge_pieces_set(EdgePiecesBatch b) {
+    const EdgePiecesBatch::One &e = b.e[blockIdx.y];
+    const float *__restrict__ m1 = e.m1, *__restrict__ c1 = e.c1, *__restrict__ m2 = e.m2, *__restrict__ c2 = e.c2;
+    const int *__restrict__ rowptr = e.rowptr;
+    float *__restrict__ o1 = e.o1, *__restrict__ o2 = e.o2;
+    const int n = e.n, ldo = b.ldo;
     const int v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (v >= n) return;
     const int lo = rowptr[v], hi = rowptr[v + 1];
@@ -2132,10 +2136,12 @@ kpd_status launch_egnn_edge_bwd(const EdgeBwdArgs &a, int tile_cap, hipStream_t 
     return KPD_OK;
 }
 
-kpd_status launch_edge_pieces_set(const float *m1, const float *c1, const float *m2, const float *c2, const int *rowptr, int n, float *o1, float *o2,
-                                  int ldo, hipStream_t st) {
-    if (n == 0) return KPD_OK;
-    hipLaunchKernelGGL(k_edge_pieces_set, dim3(cdiv(n, 4)), dim3(256), 0, st, m1, c1, m2, c2, rowptr, n, o1, o2, ldo);
+kpd_status launch_edge_pieces_set(const EdgePiecesBatch &b, int count, hipStream_t st) {
+    int most = 0;
+    for (int i = 0; i < count; ++i) most = std::max(most, b.e[i].n);
+    if (count == 0 || most == 0) return KPD_OK;
+    KPD_REQUIRE(count <= 8, KPD_ERR_INVALID, "edge pieces: %d pairs in one launch (at most 8)", count);
+    hipLaunchKernelGGL(k_edge_pieces_set, dim3(cdiv(most, 4), count), dim3(256), 0, st, b);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
 }

@@ -1135,7 +1135,10 @@ kpd_status layer_edges_bwd_fused(kpd_egnn_trainer *T, int l, int cur, int nxt, f
     std::vector<Grad257Item> wq;
     ColsumRedBatch crb;
     memset(&crb, 0, sizeof(crb));
-    int n_crb = 0;
+    EdgePiecesBatch epb;
+    memset(&epb, 0, sizeof(epb));
+    epb.ldo = CAT_LD;
+    int n_crb = 0, n_epb = 0;
     for (int et = 0; et < layer_n_et(T, l); ++et) {
         const int E = T->E[et], s = kS[et], d = kD[et];
         if (E == 0) continue;
@@ -1154,8 +1157,8 @@ kpd_status layer_edges_bwd_fused(kpd_egnn_trainer *T, int l, int cur, int nxt, f
             hipLaunchKernelGGL(k_segsum264, dim3(cdiv(T->n[s], 4)), dim3(256), 0, T->st, dpre1, (const float *)nullptr, (const float *)nullptr,
                                T->scsr[et].perm, T->scsr[et].rowptr, (const float *)nullptr, 0, T->n[s], dU, (float *)nullptr, CAT_LD);
             KPD_LAUNCH_CHECK();
-            KPD_TRY(launch_edge_pieces_set(T->dv_main[et][br], T->dv_cont[et][br], T->dvw_main[et][br], T->dvw_cont[et][br], T->e_rowptr[et], T->n[d], dV,
-                                           p.W1.g ? dVw : nullptr, CAT_LD, T->st));
+            epb.e[n_epb++] = EdgePiecesBatch::One{T->dv_main[et][br], T->dv_cont[et][br], T->dvw_main[et][br], T->dvw_cont[et][br], T->e_rowptr[et], T->n[d], dV,
+                                                  p.W1.g ? dVw : nullptr};
         }
         float *redge = sl.msgx;
         hipLaunchKernelGGL(k_geom_bwd, grid1(E), dim3(256), 0, T->st, sl.sc, sl.nvec, sl.xdiff, sl.dij, E, redge);       // (d dij over sc, dn over nvec)
@@ -1165,6 +1168,7 @@ kpd_status layer_edges_bwd_fused(kpd_egnn_trainer *T, int l, int cur, int nxt, f
     }
     // the second-Linear weight gradients of every (edge type, branch) of the layer: one launch, a share of the CUs per product proportional
     // to its edge count (sgemm.hip, grad257_batch) instead of a launch, 256 partial tiles and a reduction each
+    KPD_TRY(launch_edge_pieces_set(epb, n_epb, T->st));          // the by-destination gradient blocks of every (edge type, branch): one launch
     if (n_crb) {          // head and second-bias gradients of every (edge type, branch): the per-tile partials of k_egnn_edge_bwd, summed in one launch
         hipLaunchKernelGGL(k_colsum_reduce_batch, dim3(cdiv(H, 64), n_crb), dim3(1024), 0, T->st, crb);
         KPD_LAUNCH_CHECK();
