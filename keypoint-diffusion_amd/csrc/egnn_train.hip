@@ -250,6 +250,48 @@ __global__ __launch_bounds__(256) void k_ln_bwd_p(const float *__restrict__ h, c
     }
 }
 
+// dx[nt][v] += sum over the edge types that leave type nt of the per-edge position gradients of v's out-edges (by-source index, ascending edge
+// order) - sum over the edge types that enter it of those of v's in-edges: one thread per node, both node types and all edge types of a layer in
+// one launch, in a fixed order (no atomics).  Replaces two 3-wide segment-sum launches per edge type.
+struct DxGatherArgs {
+    const float *redge[4];
+    const int *perm[4], *srowptr[4], *drowptr[4];
+    int live[4], src_nt[4], dst_nt[4];
+    int n[2];
+    float *dx[2];
+};
+__global__ __launch_bounds__(256) void k_dx_gather(DxGatherArgs a) {
+    // sixteen lanes per node: lane i takes edges i, i + 16, ... of every list; the lane sums are combined by a fixed shuffle tree
+    const int nt = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x, v = t >> 4, l16 = t & 15;
+    const bool in = v < a.n[nt];
+    const int vv = in ? v : 0;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int et = 0; et < 4; ++et) {
+        if (!a.live[et] || !in) continue;
+        const float *r = a.redge[et];
+        if (a.src_nt[et] == nt) {
+            for (int j = a.srowptr[et][vv] + l16; j < a.srowptr[et][vv + 1]; j += 16) {
+                const int e = a.perm[et][j];
+                s0 += r[3 * e]; s1 += r[3 * e + 1]; s2 += r[3 * e + 2];
+            }
+        }
+        if (a.dst_nt[et] == nt) {
+            for (int j = a.drowptr[et][vv] + l16; j < a.drowptr[et][vv + 1]; j += 16) { s0 -= r[3 * j]; s1 -= r[3 * j + 1]; s2 -= r[3 * j + 2]; }
+        }
+    }
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) {
+        s0 += __shfl_xor(s0, o);
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+    }
+    if (in && l16 == 0) {
+        float *o = a.dx[nt] + 3 * (size_t)v;
+        o[0] += s0; o[1] += s1; o[2] += s2;
+    }
+}
+
 // geometry backward: n = x_diff / (dij + 1), dij = |x_diff|; per-edge gradient of x_src (= minus that of x_dst)
 __global__ void k_geom_bwd(const float *__restrict__ ddij, const float *__restrict__ dn, const float *__restrict__ xdiff,
                            const float *__restrict__ dij, int E, float *__restrict__ redge) {
@@ -1135,6 +1177,8 @@ kpd_status layer_edges_bwd_fused(kpd_egnn_trainer *T, int l, int cur, int nxt, f
     std::vector<Grad257Item> wq;
     ColsumRedBatch crb;
     memset(&crb, 0, sizeof(crb));
+    DxGatherArgs dxa;
+    memset(&dxa, 0, sizeof(dxa));
     EdgePiecesBatch epb;
     memset(&epb, 0, sizeof(epb));
     epb.ldo = CAT_LD;
@@ -1163,8 +1207,13 @@ kpd_status layer_edges_bwd_fused(kpd_egnn_trainer *T, int l, int cur, int nxt, f
         float *redge = sl.msgx;
         hipLaunchKernelGGL(k_geom_bwd, grid1(E), dim3(256), 0, T->st, sl.sc, sl.nvec, sl.xdiff, sl.dij, E, redge);       // (d dij over sc, dn over nvec)
         KPD_LAUNCH_CHECK();
-        KPD_TRY(segsum(T->st, redge, 3, 0, 3, T->scsr[et].perm, T->scsr[et].rowptr, nullptr, 1.0f, true, T->n[s], T->dx[nxt][s], 3));
-        KPD_TRY(segsum(T->st, redge, 3, 0, 3, nullptr, T->e_rowptr[et], nullptr, -1.0f, true, T->n[d], T->dx[nxt][d], 3));
+        dxa.redge[et] = redge; dxa.perm[et] = T->scsr[et].perm; dxa.srowptr[et] = T->scsr[et].rowptr; dxa.drowptr[et] = T->e_rowptr[et];
+        dxa.live[et] = 1; dxa.src_nt[et] = s; dxa.dst_nt[et] = d;
+    }
+    {   // position gradients of both node types from every edge type's per-edge gradients: one launch
+        for (int nt = 0; nt < 2; ++nt) { dxa.n[nt] = T->n[nt]; dxa.dx[nt] = T->dx[nxt][nt]; }
+        hipLaunchKernelGGL(k_dx_gather, dim3(cdiv(std::max(T->n[0], T->n[1]), 16), 2), dim3(256), 0, T->st, dxa);
+        KPD_LAUNCH_CHECK();
     }
     // the second-Linear weight gradients of every (edge type, branch) of the layer: one launch, a share of the CUs per product proportional
     // to its edge count (sgemm.hip, grad257_batch) instead of a launch, 256 partial tiles and a reduction each
