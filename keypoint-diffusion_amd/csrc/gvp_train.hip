@@ -95,6 +95,9 @@ struct kpd_gvp_trainer : TrainCtx {
     struct NodePack { GvpW g[4]; GvpBwdW bw[4]; };
     GvpBwdGvp nbslots[2][4];                       // per node type and update GVP: dpre / dgate / dVu / d|Vh| of the fused node-chain backward
     std::vector<NodePack> npacks;                  // [conv * 2 + nt]: the update GVPs in the kernels' fragment order
+    float *vpart = nullptr;                        // [16][VEC_PART_REGION]: partial sums of the vector-weight kernels of a conv (one region per call)
+    VecRedBatch vred;                              // ... and their pending reductions (one launch per 16: flush_vec_reduce)
+    int n_vred = 0;
     GvpBwdSlot bslots[4];                          // per edge type: what the fused message backward leaves for the weight-gradient products
     GvpBwdSlot *bslots_dev = nullptr;              // [4]
     float *Psrc[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -490,6 +493,15 @@ kpd_status conv_fwd(kpd_gvp_trainer *T, int conv) {
     return KPD_OK;
 }
 
+// the pending reductions of the vector-weight kernels (k_gvp_vec16_bwd / k_gvp_vec17_bwd partials in T->vpart) in one launch
+kpd_status flush_vec_reduce(kpd_gvp_trainer *T) {
+    if (T->n_vred == 0) return KPD_OK;
+    hipLaunchKernelGGL(k_gvp_vec_reduce_batch, dim3(cdiv(272 + 289, 16), T->n_vred), dim3(256), 0, T->st, T->vred);
+    KPD_LAUNCH_CHECK();
+    T->n_vred = 0;
+    return KPD_OK;
+}
+
 // What is left of gvp_bwd (gvp_train_core.h) for a message GVP after k_gvp_chain_bwd: the parameter gradients, from the kernel's dpre / dgate /
 // dVu / d|Vh| and the kept activations -- the gate matrix, to_feats_out's scalar block (s_in: null at the head, whose source block is
 // differentiated per node) and its |Vh| block with the bias, and Wu / Wh through the vector kernels (which also leave dv_in: read at the
@@ -505,25 +517,19 @@ kpd_status gvp_bwd_rest(kpd_gvp_trainer *T, const GvpP &g, int M, const float *s
         if (s_in && g.Ws.g) KPD_TRY(grad_gemm(T, g.so, g.si, M, o.dpre, g.so, s_in, g.si, g.Ws.g, g.si + g.h));
         KPD_TRY(grad_gemm(T, g.so, g.h, M, o.dpre, g.so, B.sh, g.h, g.Ws.g ? g.Ws.g + g.si : nullptr, g.si + g.h, g.bs.g));
     }
+    // Wu / Wh: every call leaves its per-workgroup partials in a region of its own; the reductions wait and go out sixteen per launch
+    const int blocks = std::max(1, std::min(cdiv(cdiv(M, 16), 4), std::min(std::min(2 * cu_count(), 512), VEC16_MAX_WAVES / 4)));
+    if (T->n_vred == 16) KPD_TRY(flush_vec_reduce(T));
+    float *part = T->vpart + (size_t)T->n_vred * VEC_PART_REGION;
     if (g.vi == 17) {
-        KPD_REQUIRE(T->part && T->part_floats >= (size_t)VEC16_MAX_WAVES * VEC17_PART, KPD_ERR_STATE, "split-sum scratch too small for the vector kernels");
-        const int blocks = std::max(1, std::min(cdiv(cdiv(M, 16), 4), std::min(2 * cu_count(), VEC16_MAX_WAVES / 4)));
-        hipLaunchKernelGGL(k_gvp_vec17_bwd, dim3(blocks), dim3(256), 0, T->st, o.dVu, B.Vh, B.sh, o.dsh, v_in, g.Wh.w, g.Wu.w, M, dv_in, T->part);
+        hipLaunchKernelGGL(k_gvp_vec17_bwd, dim3(blocks), dim3(256), 0, T->st, o.dVu, B.Vh, B.sh, o.dsh, v_in, g.Wh.w, g.Wu.w, M, dv_in, part);
         KPD_LAUNCH_CHECK();
-        if (g.Wu.g || g.Wh.g) {
-            hipLaunchKernelGGL(k_gvp_vec_reduce, dim3(cdiv(272 + 289, 16)), dim3(256), 0, T->st, T->part, blocks, VEC17_PART, 272, 289, g.Wu.g, g.Wh.g);
-            KPD_LAUNCH_CHECK();
-        }
+        if (g.Wu.g || g.Wh.g) T->vred.r[T->n_vred++] = VecRedBatch::One{part, blocks, VEC17_PART, 272, 289, g.Wu.g, g.Wh.g};
         return KPD_OK;
     }
-    KPD_REQUIRE(T->part && T->part_floats >= (size_t)VEC16_MAX_WAVES * 512, KPD_ERR_STATE, "split-sum scratch too small for the vector kernels");
-    const int blocks = std::max(1, std::min(cdiv(cdiv(M, 16), 4), std::min(2 * cu_count(), VEC16_MAX_WAVES / 4)));
-    hipLaunchKernelGGL(k_gvp_vec16_bwd, dim3(blocks), dim3(256), 0, T->st, o.dVu, B.Vh, B.sh, o.dsh, v_in, g.Wh.w, g.Wu.w, M, dv_in, T->part);
+    hipLaunchKernelGGL(k_gvp_vec16_bwd, dim3(blocks), dim3(256), 0, T->st, o.dVu, B.Vh, B.sh, o.dsh, v_in, g.Wh.w, g.Wu.w, M, dv_in, part);
     KPD_LAUNCH_CHECK();
-    if (g.Wu.g || g.Wh.g) {
-        hipLaunchKernelGGL(k_gvp_vec_reduce, dim3(32), dim3(256), 0, T->st, T->part, blocks, 512, 256, 256, g.Wu.g, g.Wh.g);
-        KPD_LAUNCH_CHECK();
-    }
+    if (g.Wu.g || g.Wh.g) T->vred.r[T->n_vred++] = VecRedBatch::One{part, blocks, 512, 256, 256, g.Wu.g, g.Wh.g};
     return KPD_OK;
 }
 
@@ -531,6 +537,7 @@ kpd_status gvp_bwd_rest(kpd_gvp_trainer *T, const GvpP &g, int M, const float *s
 kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
     const int S = T->S, nm = T->cfg.n_message_gvps, nu = T->cfg.n_update_gvps;
     std::vector<WgradItem> wq, wq_top;          // weight-gradient products of this conv, sent out together at the end (wgrad_batch)
+    T->n_vred = 0;
     const std::string cp = "noise_predictor.conv_layers." + std::to_string(conv);
     bool is_dst[2] = {false, false};
     for (int et = 0; et < 4; ++et)
@@ -737,6 +744,7 @@ kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
         hipLaunchKernelGGL(k_segsum_vin, dim3(cdiv(T->n[s], 4)), dim3(256), 0, T->st, T->dV[1], T->scsr[et].perm, T->scsr[et].rowptr, T->n[s], T->gv[nxt][s]);
         KPD_LAUNCH_CHECK();
     }
+    KPD_TRY(flush_vec_reduce(T));
     for (size_t i = 0; i < wq.size(); i += 8) KPD_TRY(wgrad_batch(wq.data() + i, (int)std::min<size_t>(8, wq.size() - i), T->part, T->part_floats, T->st));
     for (size_t i = 0; i < wq_top.size(); i += 8)
         KPD_TRY(wgrad_batch(wq_top.data() + i, (int)std::min<size_t>(8, wq_top.size() - i), T->part, T->part_floats, T->st));
@@ -1056,6 +1064,8 @@ extern "C" kpd_status kpd_gvp_trainer_reserve(kpd_gvp_trainer *T, int32_t max_B,
                 off_b[et] = floats;
                 floats += (((size_t)cap_et[et] * bwd_per_edge + 16 * (size_t)nm) + 63) & ~size_t(63);
             }
+            const size_t off_vp = floats;
+            floats += 16 * VEC_PART_REGION;
             size_t off_nb[2];
             for (int nt = 0; nt < 2; ++nt) { off_nb[nt] = floats; floats += (size_t)nn[nt] * nu * (256 + 16 + 48 + 16); }
             std::vector<GvpTrainSlot> hs((size_t)L * 4);
@@ -1085,6 +1095,8 @@ extern "C" kpd_status kpd_gvp_trainer_reserve(kpd_gvp_trainer *T, int32_t max_B,
                     bs.drbf = p;
                 }
                 KPD_HIP(hipMemcpy(T->bslots_dev, T->bslots, 4 * sizeof(GvpBwdSlot), hipMemcpyHostToDevice));
+                T->vpart = T->pack_base + off_vp;
+                T->n_vred = 0;
                 for (int nt = 0; nt < 2; ++nt) {
                     float *p = T->pack_base + off_nb[nt];
                     const size_t n = nn[nt];

@@ -336,6 +336,34 @@ __global__ __launch_bounds__(256) void k_gvp_vec_reduce(const float *__restrict_
     }
 }
 
+// several such reductions in one launch (blockIdx.y = which): the vector-weight gradients of a conv's GVPs, each with a partial region of its own
+struct VecRedBatch {
+    struct One {
+        const float *part;
+        int n_part, stride, n_u, n_h;
+        float *g_u, *g_h;
+    };
+    One r[16];
+};
+__global__ __launch_bounds__(256) void k_gvp_vec_reduce_batch(VecRedBatch b) {
+    const VecRedBatch::One &a = b.r[blockIdx.y];
+    __shared__ float s_p[16][16];
+    const int o = threadIdx.x & 15, sl = threadIdx.x >> 4, i = blockIdx.x * 16 + o;
+    float s = 0.0f;
+    if (i < a.n_u + a.n_h)
+        for (int k = sl; k < a.n_part; k += 16) s += a.part[(size_t)k * a.stride + i];
+    s_p[sl][o] = s;
+    __syncthreads();
+    if (sl == 0 && i < a.n_u + a.n_h) {
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += s_p[k][o];
+        if (i < a.n_u) { if (a.g_u) a.g_u[i] += t; }
+        else if (a.g_h) a.g_h[i - a.n_u] += t;
+    }
+}
+constexpr size_t VEC_PART_REGION = (size_t)512 * 576;          // floats of one call's partials: at most 2 x 256 workgroups x VEC17_PART
+
 // ---- the message head GVP: 17 vector inputs [x_diff | 16 v_src], 17 hidden channels, 16 outputs (gvp.py:545, 395-415) -------------------
 // Same chained scheme on the 16 x 16 core (inputs 1 .. 16, hidden 0 .. 15); input channel 0 and hidden channel 16 are rank-1 / dot-product
 // updates on the VALU (a row's 16 core channels are spread over the four q-lanes: dots finish with two shuffles).  Rows are 17 floats
