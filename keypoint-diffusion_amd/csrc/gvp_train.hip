@@ -569,12 +569,10 @@ kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
             hipLaunchKernelGGL(k_add, grid1((long long)n * 3 * VC), dim3(256), 0, T->st, T->v1, T->tmp_v, (long long)n * 3 * VC, T->vb);
             KPD_LAUNCH_CHECK();
         }
-        // second GVPLayerNorm: d(sb, vb) -> ds[0] / dV[0]
-        KPD_TRY(gvp_ln_bwd(T, l2, n, sb, vb, T->gs[cur][nt], T->gv[cur][nt], T->ds[0], T->dV[0]));
-        // residual: d s1 += d sb, d v1 += d vb -> keep them in gs/gv[nxt] for now; the update chain sees them through its dropout mask
-        KPD_HIP(hipMemcpyAsync(T->gs[nxt][nt], T->ds[0], (size_t)n * S * 4, hipMemcpyDeviceToDevice, T->st));
-        KPD_HIP(hipMemcpyAsync(T->gv[nxt][nt], T->dV[0], (size_t)n * 3 * VC * 4, hipMemcpyDeviceToDevice, T->st));
-        KPD_TRY(dropout_apply(T, conv, nt, 1, n, T->ds[0], T->dV[0], T->ds[0], T->dV[0]));
+        // second GVPLayerNorm: d(sb, vb) -> gs/gv[nxt] (the residual: d s1 += d sb, d v1 += d vb); the update chain sees the same gradients
+        // through its dropout mask -> ds[0] / dV[0] (a copy when the rate is 0)
+        KPD_TRY(gvp_ln_bwd(T, l2, n, sb, vb, T->gs[cur][nt], T->gv[cur][nt], T->gs[nxt][nt], T->gv[nxt][nt]));
+        KPD_TRY(dropout_apply(T, conv, nt, 1, n, T->gs[nxt][nt], T->gv[nxt][nt], T->ds[0], T->dV[0]));
         bool chained = false;
         if (T->fused) {
             GvpP gp[4];
