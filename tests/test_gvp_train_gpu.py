@@ -239,3 +239,24 @@ def test_chained_kernels_on_poisoned_workspaces():
         os.remove(path)
     assert all(torch.isfinite(a).all() for a in outs[0])
     assert all(torch.equal(a, b) for a, b in zip(*outs))
+
+
+def test_chained_path_survives_a_growing_reservation():
+    """A larger batch after a smaller one makes the trainer reserve again (activation slots, packs, gradient staging are re-carved and the weight
+    pack's descriptor table rebuilt): the step on the larger batch must equal the same step on a fresh model, bit for bit."""
+    cfg = dict(GVP_CFGS['gvp_kp'], n_convs=2, dropout=0.0)
+    g_small, model, t_small = _case(cfg, [20, 15], [5, 4], 128)
+    g_big, fresh, t_big = _case(cfg, [90, 70, 55], [14, 9, 11], 128)
+    model, fresh = model.cuda(), fresh.cuda()
+
+    def step(m, g, t):
+        m.zero_grad(set_to_none=True)
+        eh, ex = m(g.to('cuda'), t.cuda(), None)
+        (eh.square().sum() + ex.square().sum()).backward()
+        return [eh.detach().clone(), ex.detach().clone()] + [p.grad.clone() for p in m.parameters() if p.grad is not None]
+
+    step(model, g_small, t_small)
+    grown = step(model, g_big, t_big)
+    assert model._trainer()[0].message_path() == 1
+    direct = step(fresh, g_big, t_big)
+    assert all(torch.equal(a, b) for a, b in zip(grown, direct))
