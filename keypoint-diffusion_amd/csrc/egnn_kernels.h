@@ -169,8 +169,16 @@ kpd_status launch_decode(const float *h, const float *x, const float *x0, int n,
                          const float *b0, const float *W1, const float *b1, float *eps_h, float *eps_x, hipStream_t st);
 kpd_status launch_egnn_edge(const EdgeArgs &a, int tile_cap, hipStream_t st);
 kpd_status launch_egnn_edge_train(const EdgeTrainArgs &a, int tile_cap, hipStream_t st);
-kpd_status launch_edge_pieces_sum(const float *hn_main, const float *hn_cont, const float *xn_main, const float *xn_cont, const int *rowptr,
-                                  const float *zinv, int n, float *hn, float *xn, hipStream_t st);
+// h_neigh / x_neigh of both node types += zinv x (the per-tile message pieces of every live edge type into that type), in edge-type order
+struct EdgePiecesSumArgs {
+    const float *hn_main[4], *hn_cont[4], *xn_main[4], *xn_cont[4];
+    const int *rowptr[4];
+    int live[4], dst_nt[4];
+    const float *zinv[2];
+    int n[2];                     // 0: this node type receives nothing in this launch
+    float *hn[2], *xn[2];
+};
+kpd_status launch_edge_pieces_sum(const EdgePiecesSumArgs &a, hipStream_t st);
 kpd_status launch_edge_train_pack(const EdgePackTab &t, hipStream_t st);
 kpd_status launch_egnn_edge_bwd(const EdgeBwdArgs &a, int tile_cap, hipStream_t st);
 // dV / dVw of up to eight (edge type, branch) pairs from the per-tile pieces of k_egnn_edge_bwd (o2 may be null)

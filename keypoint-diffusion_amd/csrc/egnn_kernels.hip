@@ -1240,25 +1240,31 @@ __global__ __launch_bounds__(256) void k_edge_pieces_set(EdgePiecesBatch b) {
 
 // h_neigh[v] += zinv[v] * (main[v] + the continuation pieces of the tiles its in-edges span), x_neigh likewise: the pieces of
 // k_egnn_edge_train summed in tile order (one wave per destination node; nodes without in-edges are left alone)
-__global__ __launch_bounds__(256) void k_edge_pieces_sum(const float *__restrict__ hn_main, const float *__restrict__ hn_cont, const float *__restrict__ xn_main,
-                                                         const float *__restrict__ xn_cont, const int *__restrict__ rowptr, const float *__restrict__ zinv,
-                                                         int n, float *__restrict__ hn, float *__restrict__ xn) {
-    const int v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (v >= n) return;
-    const int lo = rowptr[v], hi = rowptr[v + 1];
-    if (hi == lo) return;
-    const float zi = zinv[v];
-    const int t0 = (lo >> 6) + 1, t1 = (hi - 1) >> 6;
-    f32x4 s = *reinterpret_cast<const f32x4 *>(hn_main + (size_t)v * HS + 4 * lane);
-    float t = lane == 0 ? hn_main[(size_t)v * HS + 256] : (lane >= 1 && lane < 4) ? xn_main[(size_t)v * 4 + lane - 1] : 0.0f;
-    for (int k = t0; k <= t1; ++k) {
-        s += *reinterpret_cast<const f32x4 *>(hn_cont + (size_t)k * HS + 4 * lane);
-        t += lane == 0 ? hn_cont[(size_t)k * HS + 256] : (lane >= 1 && lane < 4) ? xn_cont[(size_t)k * 4 + lane - 1] : 0.0f;
+// (all edge types of a layer in one launch: blockIdx.y = destination node type, its edge types added in edge-type order as separate launches did)
+__global__ __launch_bounds__(256) void k_edge_pieces_sum(EdgePiecesSumArgs a) {
+    const int nt = blockIdx.y, v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (v >= a.n[nt]) return;
+    const float zi = a.zinv[nt][v];
+    float *hn = a.hn[nt], *xn = a.xn[nt];
+#pragma unroll
+    for (int et = 0; et < 4; ++et) {
+        if (!a.live[et] || a.dst_nt[et] != nt) continue;
+        const float *__restrict__ hn_main = a.hn_main[et], *__restrict__ hn_cont = a.hn_cont[et], *__restrict__ xn_main = a.xn_main[et],
+                    *__restrict__ xn_cont = a.xn_cont[et];
+        const int lo = a.rowptr[et][v], hi = a.rowptr[et][v + 1];
+        if (hi == lo) continue;
+        const int t0 = (lo >> 6) + 1, t1 = (hi - 1) >> 6;
+        f32x4 s = *reinterpret_cast<const f32x4 *>(hn_main + (size_t)v * HS + 4 * lane);
+        float t = lane == 0 ? hn_main[(size_t)v * HS + 256] : (lane >= 1 && lane < 4) ? xn_main[(size_t)v * 4 + lane - 1] : 0.0f;
+        for (int k = t0; k <= t1; ++k) {
+            s += *reinterpret_cast<const f32x4 *>(hn_cont + (size_t)k * HS + 4 * lane);
+            t += lane == 0 ? hn_cont[(size_t)k * HS + 256] : (lane >= 1 && lane < 4) ? xn_cont[(size_t)k * 4 + lane - 1] : 0.0f;
+        }
+        f32x4 *o = reinterpret_cast<f32x4 *>(hn + (size_t)v * HS + 4 * lane);
+        *o += s * zi;
+        if (lane == 0) hn[(size_t)v * HS + 256] += t * zi;
+        else if (lane < 4) xn[(size_t)v * 3 + lane - 1] += t * zi;
     }
-    f32x4 *o = reinterpret_cast<f32x4 *>(hn + (size_t)v * HS + 4 * lane);
-    *o += s * zi;
-    if (lane == 0) hn[(size_t)v * HS + 256] += t * zi;
-    else if (lane < 4) xn[(size_t)v * 3 + lane - 1] += t * zi;
 }
 
 // The per-step weight pack of one layer for k_egnn_edge_train: for entry (et, branch) the 257 x 257 second Linear in MFMA fragment
@@ -2120,10 +2126,10 @@ kpd_status launch_egnn_edge_train(const EdgeTrainArgs &a, int tile_cap, hipStrea
     return KPD_OK;
 }
 
-kpd_status launch_edge_pieces_sum(const float *hn_main, const float *hn_cont, const float *xn_main, const float *xn_cont, const int *rowptr,
-                                  const float *zinv, int n, float *hn, float *xn, hipStream_t st) {
-    if (n == 0) return KPD_OK;
-    hipLaunchKernelGGL(k_edge_pieces_sum, dim3(cdiv(n, 4)), dim3(256), 0, st, hn_main, hn_cont, xn_main, xn_cont, rowptr, zinv, n, hn, xn);
+kpd_status launch_edge_pieces_sum(const EdgePiecesSumArgs &a, hipStream_t st) {
+    const int most = std::max(a.n[0], a.n[1]);
+    if (most == 0) return KPD_OK;
+    hipLaunchKernelGGL(k_edge_pieces_sum, dim3(cdiv(most, 4), 2), dim3(256), 0, st, a);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
 }

@@ -572,13 +572,18 @@ kpd_status layer_edges_fused(kpd_egnn_trainer *T, int l, bool sum_pieces) {
         for (int et = 0; et < layer_n_et(T, l); ++et) edges += T->E[et];
         KPD_TRY(T->timed(0, edges, [&] { return launch_egnn_edge_train(a, tiles, T->st); }));
     }
-    if (sum_pieces)
+    if (sum_pieces) {
+        EdgePiecesSumArgs pa;
+        memset(&pa, 0, sizeof(pa));
         for (int et = 0; et < layer_n_et(T, l); ++et) {
             if (T->E[et] == 0) continue;
             const int d = kD[et];
-            KPD_TRY(launch_edge_pieces_sum(T->hn_main[et], T->hn_cont[et], T->xn_main[et], T->xn_cont[et], T->e_rowptr[et], T->zinv[d], T->n[d],
-                                           T->hns[d][l], T->xns[d][l], T->st));
+            pa.hn_main[et] = T->hn_main[et]; pa.hn_cont[et] = T->hn_cont[et]; pa.xn_main[et] = T->xn_main[et]; pa.xn_cont[et] = T->xn_cont[et];
+            pa.rowptr[et] = T->e_rowptr[et]; pa.live[et] = 1; pa.dst_nt[et] = d;
+            pa.zinv[d] = T->zinv[d]; pa.n[d] = T->n[d]; pa.hn[d] = T->hns[d][l]; pa.xn[d] = T->xns[d][l];
         }
+        KPD_TRY(launch_edge_pieces_sum(pa, T->st));
+    }
     return KPD_OK;
 }
 

@@ -516,7 +516,10 @@ kpd_status gemv_t_colsum_acc(TrainCtx *T, int M, int K, const float *A, int lda,
     if (M == 0 || (!y && !y2)) return KPD_OK;
     // node-sized matrices (<= 20 800 rows at the contract shape) in 64-row blocks: 256-row blocks left two thirds of the CUs idle
     // (82 workgroups, 37 us per call, ~2.4 ms of an EGNN training step); edge-sized ones keep 256 rows per block
-    const int rows_per_block = M <= 65536 ? HEAD_ROWS : COLSUM_ROWS;
+    // ... and 16-row blocks when such a matrix is wide as well (the EGNN trainer's 1 088-column sums over 19 200 nodes: 300 workgroups each
+    // walked 64 rows four column passes long -- 61 us, latency-bound at 1.4 TB/s)
+    int rows_per_block = M <= 65536 ? HEAD_ROWS : COLSUM_ROWS;
+    if (M <= 65536 && K >= 512 && cdiv(M, 16) <= T->colpart_blocks) rows_per_block = 16;
     const int blocks = cdiv(M, rows_per_block);
     KPD_REQUIRE(K <= COLSUM_LD && blocks <= T->colpart_blocks && T->colpart, KPD_ERR_CAPACITY,
                 "column-sum scratch too small (%d row blocks of %d, %d columns)", blocks, T->colpart_blocks, K);
