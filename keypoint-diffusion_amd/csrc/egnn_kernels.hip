@@ -1240,12 +1240,14 @@ __global__ __launch_bounds__(256) void k_edge_pieces_set(EdgePiecesBatch b) {
 
 // h_neigh[v] += zinv[v] * (main[v] + the continuation pieces of the tiles its in-edges span), x_neigh likewise: the pieces of
 // k_egnn_edge_train summed in tile order (one wave per destination node; nodes without in-edges are left alone)
-// (all edge types of a layer in one launch: blockIdx.y = destination node type, its edge types added in edge-type order as separate launches did)
+// All edge types of a layer in one launch: blockIdx.y = destination node type; a node's row is the sum over its edge types, in edge-type
+// order, and is WRITTEN (zeros for a node nothing points at): no memset of h_neigh / x_neigh in front.
 __global__ __launch_bounds__(256) void k_edge_pieces_sum(EdgePiecesSumArgs a) {
     const int nt = blockIdx.y, v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (v >= a.n[nt]) return;
     const float zi = a.zinv[nt][v];
-    float *hn = a.hn[nt], *xn = a.xn[nt];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float tacc = 0.0f;
 #pragma unroll
     for (int et = 0; et < 4; ++et) {
         if (!a.live[et] || a.dst_nt[et] != nt) continue;
@@ -1260,11 +1262,12 @@ __global__ __launch_bounds__(256) void k_edge_pieces_sum(EdgePiecesSumArgs a) {
             s += *reinterpret_cast<const f32x4 *>(hn_cont + (size_t)k * HS + 4 * lane);
             t += lane == 0 ? hn_cont[(size_t)k * HS + 256] : (lane >= 1 && lane < 4) ? xn_cont[(size_t)k * 4 + lane - 1] : 0.0f;
         }
-        f32x4 *o = reinterpret_cast<f32x4 *>(hn + (size_t)v * HS + 4 * lane);
-        *o += s * zi;
-        if (lane == 0) hn[(size_t)v * HS + 256] += t * zi;
-        else if (lane < 4) xn[(size_t)v * 3 + lane - 1] += t * zi;
+        acc += s * zi;
+        tacc += t * zi;
     }
+    *reinterpret_cast<f32x4 *>(a.hn[nt] + (size_t)v * HS + 4 * lane) = acc;
+    if (lane == 0) a.hn[nt][(size_t)v * HS + 256] = tacc;
+    else if (lane < 4) a.xn[nt][(size_t)v * 3 + lane - 1] = tacc;
 }
 
 // The per-step weight pack of one layer for k_egnn_edge_train: for entry (et, branch) the 257 x 257 second Linear in MFMA fragment

@@ -565,7 +565,7 @@ kpd_status layer_edges_fused(kpd_egnn_trainer *T, int l, bool sum_pieces) {
         a.att[et] = sl.att; a.sc[et] = sl.sc; a.dij[et] = sl.dij; a.xdiff[et] = sl.xdiff; a.nvec[et] = sl.nvec;
         a.hn_main[et] = T->hn_main[et]; a.hn_cont[et] = T->hn_cont[et]; a.xn_main[et] = T->xn_main[et]; a.xn_cont[et] = T->xn_cont[et];
     }
-    if (tiles == 0) return KPD_OK;
+    if (tiles == 0 && !sum_pieces) return KPD_OK;          // (with sum_pieces the neighbour sums are still written: zeros)
     KPD_TRY(launch_edge_train_pack(pk, T->st));
     {
         double edges = 0.0;
@@ -580,7 +580,9 @@ kpd_status layer_edges_fused(kpd_egnn_trainer *T, int l, bool sum_pieces) {
             const int d = kD[et];
             pa.hn_main[et] = T->hn_main[et]; pa.hn_cont[et] = T->hn_cont[et]; pa.xn_main[et] = T->xn_main[et]; pa.xn_cont[et] = T->xn_cont[et];
             pa.rowptr[et] = T->e_rowptr[et]; pa.live[et] = 1; pa.dst_nt[et] = d;
-            pa.zinv[d] = T->zinv[d]; pa.n[d] = T->n[d]; pa.hn[d] = T->hns[d][l]; pa.xn[d] = T->xns[d][l];
+        }
+        for (int k = 0; k < layer_n_upd(T, l); ++k) {          // every updated node type gets its rows written, edges or not
+            pa.zinv[k] = T->zinv[k]; pa.n[k] = T->n[k]; pa.hn[k] = T->hns[k][l]; pa.xn[k] = T->xns[k][l];
         }
         KPD_TRY(launch_edge_pieces_sum(pa, T->st));
     }
@@ -589,10 +591,7 @@ kpd_status layer_edges_fused(kpd_egnn_trainer *T, int l, bool sum_pieces) {
 
 // one LigRecConv layer forward (dynamics.py:124-207) from the saved inputs hs[l], xs[l] into hs[l+1], xs[l+1], hns[l], xns[l]
 kpd_status layer_fwd(kpd_egnn_trainer *T, int l) {
-    for (int k = 0; k < layer_n_upd(T, l); ++k) {
-        KPD_HIP(hipMemsetAsync(T->hns[k][l], 0, (size_t)T->n[k] * LD * 4, T->st));
-        KPD_HIP(hipMemsetAsync(T->xns[k][l], 0, (size_t)T->n[k] * 12, T->st));
-    }
+    // (h_neigh / x_neigh of the layer are written whole by k_edge_pieces_sum: no memset; their padding columns keep the arena's zeros)
     KPD_TRY(layer_stage(T, l));
     KPD_TRY(layer_project(T, l));
     return layer_edges_fused(T, l, true);
