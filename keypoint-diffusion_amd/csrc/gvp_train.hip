@@ -95,6 +95,8 @@ struct kpd_gvp_trainer : TrainCtx {
     struct NodePack { GvpW g[4]; GvpBwdW bw[4]; };
     GvpBwdGvp nbslots[2][4];                       // per node type and update GVP: dpre / dgate / dVu / d|Vh| of the fused node-chain backward
     std::vector<NodePack> npacks;                  // [conv * 2 + nt]: the update GVPs in the kernels' fragment order
+    float *Uet[4] = {nullptr, nullptr, nullptr, nullptr}, *dvin_et[4] = {nullptr, nullptr, nullptr, nullptr};      // per edge type: by-source sums of the head GVP's dpre [n_src][256];
+                                                   // gradient of its input vectors [E][3][17] -- kept until the conv's batched launches ran
     float *vpart = nullptr;                        // [16][VEC_PART_REGION]: partial sums of the vector-weight kernels of a conv (one region per call)
     VecRedBatch vred;                              // ... and their pending reductions (one launch per 16: flush_vec_reduce)
     int n_vred = 0;
@@ -536,7 +538,9 @@ kpd_status gvp_bwd_rest(kpd_gvp_trainer *T, const GvpP &g, int M, const float *s
 // backward of conv: gs/gv[cur] = gradients of the conv outputs, gs/gv[nxt] = gradients of its inputs
 kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
     const int S = T->S, nm = T->cfg.n_message_gvps, nu = T->cfg.n_update_gvps;
-    std::vector<WgradItem> wq, wq_top;          // weight-gradient products of this conv, sent out together at the end (wgrad_batch)
+    std::vector<WgradItem> wq, wq_top, wq_u;    // weight-gradient products of this conv, sent out together at the end (wgrad_batch)
+    SegsumVinArgs sva;
+    memset(&sva, 0, sizeof(sva));
     T->n_vred = 0;
     const std::string cp = "noise_predictor.conv_layers." + std::to_string(conv);
     bool is_dst[2] = {false, false};
@@ -697,7 +701,7 @@ kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
                 }
                 KPD_TRY(gvp_bwd_rest(T, gp[j], E, T->gb[j - 1].s, T->gb[j - 1].V, T->gb[j], bs.g[j], nullptr, skip[j]));       // (dv_in: the chained kernel had it)
             }
-            KPD_TRY(gvp_bwd_rest(T, g0, E, nullptr, T->vin, T->gb[0], bs.g[0], T->dV[1], skip[0]));
+            KPD_TRY(gvp_bwd_rest(T, g0, E, nullptr, T->vin, T->gb[0], bs.g[0], T->dvin_et[et], skip[0]));
             dpre0 = bs.g[0].dpre;
             drbf = bs.drbf;
         } else {
@@ -723,7 +727,7 @@ kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
             // positions (gvp.py:472-480): through the rbf code and through the unit vector = channel 0 of d vin
             const float *xs = s == NT_LIG ? T->bt.lig_x : T->bt.kp_x, *xd = d == NT_LIG ? T->bt.lig_x : T->bt.kp_x;
             hipLaunchKernelGGL(k_gvp_geom_bwd, grid1(E), dim3(256), 0, T->st, T->e_src[et], T->e_dst[et], xs, xd, E, 15.0f, T->rbf, drbf,
-                               T->dV[1], VH, T->dxe);
+                               T->fused ? T->dvin_et[et] : T->dV[1], VH, T->dxe);
             KPD_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_seg3, grid1(T->n[s]), dim3(256), 0, T->st, T->dxe, T->scsr[et].perm, T->scsr[et].rowptr, T->n[s], 1.0f, T->gx[s]);
             KPD_LAUNCH_CHECK();
@@ -733,14 +737,30 @@ kpd_status conv_bwd(kpd_gvp_trainer *T, int conv, int cur, int nxt) {
         // dpre0 = dL/dpre of the first GVP: its scalar inputs were U[src] and rbf
         if (g0.Ws.g && !rbf_done) KPD_TRY(grad_gemm(T, S, RBF, E, dpre0, S, T->rbf, RBF, g0.Ws.g + S, g0.si + g0.h));
         // sums over the out-edges of every source node, in ascending edge order (no float atomics)
-        // (the source block's gradient U^T s_src stays a product of its own: as one more item of the conv's batched launch it cost that
-        //  launch more -- 7.4 -> 8.3 ms per step -- than the 22 small products it replaced -- 0.6)
-        KPD_TRY(segsum(T->st, dpre0, S, 0, S, T->scsr[et].perm, T->scsr[et].rowptr, nullptr, 1.0f, false, T->n[s], T->U, S));
-        if (g0.Ws.g) KPD_TRY(grad_gemm(T, S, S, T->n[s], T->U, S, T->ss[s][conv], S, g0.Ws.g, g0.si + g0.h));
-        KPD_TRY(gemm(T, false, false, T->n[s], S, S, T->U, S, g0.Ws.w, g0.si + g0.h, 1.0f, T->gs[nxt][s], S));
+        // (the source block's gradient U^T s_src: as one more item of the conv's rider-carrying batched launch it cost that launch more -- 7.4 -> 8.3
+        //  ms per step -- than the 22 small products it replaced -- 0.6; the four of a conv go out as a batch of their own, without riders)
+        float *U = T->fused ? T->Uet[et] : T->U;
+        KPD_TRY(segsum(T->st, dpre0, S, 0, S, T->scsr[et].perm, T->scsr[et].rowptr, nullptr, 1.0f, false, T->n[s], U, S));
+        if (g0.Ws.g && T->fused) {          // U^T s_src of the conv's edge types: one rider-less batched launch below
+            WgradItem it;
+            memset(&it, 0, sizeof(it));
+            it.A = U; it.lda = S; it.B = T->ss[s][conv]; it.ldb = S; it.K = T->n[s]; it.C = g0.Ws.g; it.ldc = g0.si + g0.h;
+            wq_u.push_back(it);
+        } else if (g0.Ws.g) KPD_TRY(grad_gemm(T, S, S, T->n[s], U, S, T->ss[s][conv], S, g0.Ws.g, g0.si + g0.h));
+        KPD_TRY(gemm(T, false, false, T->n[s], S, S, U, S, g0.Ws.w, g0.si + g0.h, 1.0f, T->gs[nxt][s], S));
         // vector rows [E, 3, 17], channels 1..16 -> gv[src, 3, 16]
-        hipLaunchKernelGGL(k_segsum_vin, dim3(cdiv(T->n[s], 4)), dim3(256), 0, T->st, T->dV[1], T->scsr[et].perm, T->scsr[et].rowptr, T->n[s], T->gv[nxt][s]);
+        if (T->fused) {
+            sva.dvin[et] = T->dvin_et[et]; sva.perm[et] = T->scsr[et].perm; sva.rowptr[et] = T->scsr[et].rowptr; sva.live[et] = 1; sva.src_nt[et] = s;
+        } else {
+            hipLaunchKernelGGL(k_segsum_vin, dim3(cdiv(T->n[s], 4)), dim3(256), 0, T->st, T->dV[1], T->scsr[et].perm, T->scsr[et].rowptr, T->n[s], T->gv[nxt][s]);
+            KPD_LAUNCH_CHECK();
+        }
+    }
+    if (T->fused) {          // the source vectors' gradients of every edge type: one launch
+        for (int nt = 0; nt < 2; ++nt) { sva.n[nt] = T->n[nt]; sva.gv[nt] = T->gv[nxt][nt]; }
+        hipLaunchKernelGGL(k_segsum_vin_all, dim3(cdiv(std::max(T->n[0], T->n[1]), 4), 2), dim3(256), 0, T->st, sva);
         KPD_LAUNCH_CHECK();
+        for (size_t i = 0; i < wq_u.size(); i += 8) KPD_TRY(wgrad_batch(wq_u.data() + i, (int)std::min<size_t>(8, wq_u.size() - i), T->part, T->part_floats, T->st));
     }
     KPD_TRY(flush_vec_reduce(T));
     for (size_t i = 0; i < wq.size(); i += 8) KPD_TRY(wgrad_batch(wq.data() + i, (int)std::min<size_t>(8, wq.size() - i), T->part, T->part_floats, T->st));
@@ -1062,6 +1082,11 @@ extern "C" kpd_status kpd_gvp_trainer_reserve(kpd_gvp_trainer *T, int32_t max_B,
                 off_b[et] = floats;
                 floats += (((size_t)cap_et[et] * bwd_per_edge + 16 * (size_t)nm) + 63) & ~size_t(63);
             }
+            size_t off_U[4], off_dvin[4];
+            for (int et = 0; et < 4; ++et) {
+                off_U[et] = floats; floats += (size_t)nn[kSrc[et]] * 256;
+                off_dvin[et] = floats; floats += (((size_t)cap_et[et] * 3 * VH) + 63) & ~size_t(63);
+            }
             const size_t off_vp = floats;
             floats += 16 * VEC_PART_REGION;
             size_t off_nb[2];
@@ -1093,6 +1118,7 @@ extern "C" kpd_status kpd_gvp_trainer_reserve(kpd_gvp_trainer *T, int32_t max_B,
                     bs.drbf = p;
                 }
                 KPD_HIP(hipMemcpy(T->bslots_dev, T->bslots, 4 * sizeof(GvpBwdSlot), hipMemcpyHostToDevice));
+                for (int et = 0; et < 4; ++et) { T->Uet[et] = T->pack_base + off_U[et]; T->dvin_et[et] = T->pack_base + off_dvin[et]; }
                 T->vpart = T->pack_base + off_vp;
                 T->n_vred = 0;
                 for (int nt = 0; nt < 2; ++nt) {

@@ -115,6 +115,44 @@ __global__ __launch_bounds__(256) void k_segsum_vin(const float *__restrict__ dv
     gv[(size_t)v * (3 * VC) + lane] += s;
 }
 
+// the same for all edge types of a conv in one launch: blockIdx.y = source node type, its edge types added in edge-type order (as the separate
+// launches did)
+struct SegsumVinArgs {
+    const float *dvin[4];
+    const int *perm[4], *rowptr[4];
+    int live[4], src_nt[4];
+    int n[2];
+    float *gv[2];
+};
+__global__ __launch_bounds__(256) void k_segsum_vin_all(SegsumVinArgs a) {
+    const int nt = blockIdx.y, v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (v >= a.n[nt] || lane >= 3 * VC) return;
+    const int off = (lane / VC) * VH + 1 + lane % VC;
+    float acc = a.gv[nt][(size_t)v * (3 * VC) + lane];
+    bool any = false;
+#pragma unroll
+    for (int et = 0; et < 4; ++et) {
+        if (!a.live[et] || a.src_nt[et] != nt) continue;
+        const int lo = a.rowptr[et][v], hi = a.rowptr[et][v + 1];
+        if (lo == hi) continue;
+        const float *dvin = a.dvin[et];
+        const int *perm = a.perm[et];
+        float s = 0.0f;
+        int j = lo;
+        for (; j + 4 <= hi; j += 4) {
+            float m[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) m[k] = dvin[(size_t)perm[j + k] * (3 * VH) + off];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s += m[k];
+        }
+        for (; j < hi; ++j) s += dvin[(size_t)perm[j] * (3 * VH) + off];
+        acc += s;
+        any = true;
+    }
+    if (any) a.gv[nt][(size_t)v * (3 * VC) + lane] = acc;
+}
+
 // sh[m, j] = sqrt(max(sum_c Vh[m, c, j]^2, 1e-8)) (_norm_no_nan, gvp.py:12-19)
 __global__ void k_gvp_sh(const float *__restrict__ Vh, long long total, int h, float *__restrict__ sh) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
