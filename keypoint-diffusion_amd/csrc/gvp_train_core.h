@@ -695,8 +695,9 @@ __global__ void k_ln_bwd_g(const float *__restrict__ x, const float *__restrict_
 // of k_colsum, so k_colsum_reduce finishes gamma.grad and beta.grad in one launch (instead of a dy * xhat array, two column-sum launches over it
 // and over dy, and their two reductions).  cols <= 256.
 constexpr int LN_GP_ROWS = 8;
-__global__ __launch_bounds__(256) void k_ln_bwd_gp(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ dy, int rows, int cols,
-                                                   float *__restrict__ dx, float *__restrict__ part) {
+// dx may be dy: a lane writes only the entries it has read itself, after its last read of them.
+__global__ __launch_bounds__(256) void k_ln_bwd_gp(const float *__restrict__ x, const float *__restrict__ gamma, const float *dy, int rows, int cols,
+                                                   float *dx, float *__restrict__ part) {
     __shared__ float s_gx[4][256], s_g[4][256];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r0 = blockIdx.x * LN_GP_ROWS, r1 = min(rows, r0 + LN_GP_ROWS);
@@ -1039,6 +1040,7 @@ kpd_status gvp_ln_bwd(TT *T, const LnP &l, int n, const float *s, const float *v
     float *os = ds == dso ? T->tmp_s : ds, *ov = dv;          // (the vector kernel works in place)
     const int blocks = cdiv(n, LN_GP_ROWS);
     if (T->S <= 256 && l.gamma.g && l.beta.g && T->colpart && blocks <= T->colpart_blocks) {
+        os = ds;          // (in place when ds == dso: see the kernel)
         hipLaunchKernelGGL(k_ln_bwd_gp, dim3(blocks), dim3(256), 0, T->st, s, l.gamma.w, dso, n, T->S, os, T->colpart);
         KPD_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_colsum_reduce, dim3(cdiv(T->S, 64)), dim3(1024), 0, T->st, T->colpart, blocks, T->S, l.gamma.g, 1, l.beta.g);
