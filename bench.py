@@ -901,8 +901,15 @@ def run_train(args, device, rank, world, dist):
     from keypoint_diffusion_amd.dist import allreduce_gradients
     w = WORKLOADS[args.workload]
     model = build_model(device, args.workload).train()
-    # (train.py:430 builds a plain torch.optim.Adam; --fused-optimizer asks torch for its single-kernel implementation of the same update)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True) if args.fused_optimizer else torch.optim.Adam(model.parameters(), lr=1e-4)
+    # train.py:430 builds a plain torch.optim.Adam and :541-543 clips and steps; the product's drop-ins for the two calls (optim.py: one launch
+    # each, same arithmetic -- tests/test_optim_gpu.py) are the default, --torch-optimizer keeps torch's, --fused-optimizer torch's fused=True
+    from keypoint_diffusion_amd import optim as kpd_optim
+    native_opt = not (args.torch_optimizer or args.fused_optimizer)
+    if native_opt:
+        opt, clip_grads = kpd_optim.Adam(model.parameters(), lr=1e-4), kpd_optim.clip_grad_value_
+    else:
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True) if args.fused_optimizer else torch.optim.Adam(model.parameters(), lr=1e-4)
+        clip_grads = torch.nn.utils.clip_grad_value_
     B = args.batch
     template = raw_batch(B, args.n_rec, args.n_lig, 1234 + rank * B, device, args.workload).to(device)
     last = [None]
@@ -915,7 +922,7 @@ def run_train(args, device, rank, world, dist):
         (losses['l2'] + enc_weight * losses['rec_encoder'] if enc_weight else losses['l2']).backward()
         if dist is not None:
             allreduce_gradients(list(model.parameters()))
-        torch.nn.utils.clip_grad_value_(model.parameters(), 1.0)
+        clip_grads(model.parameters(), 1.0)
         opt.step()
         last[0] = losses['l2']
 
@@ -937,7 +944,9 @@ def run_train(args, device, rank, world, dist):
                'config': {'workload': f'{args.workload}: loss + backward + clip + Adam on {w["arch"]}_{"40kp (learned encoder, encoder + optimal-transport loss included)" if w["enc"] == "learned" else "all_atom"} (6 layers, hidden 256, '
                                       f'training mode), batch of {B} '
                                       f'synthetic {args.n_rec}-atom pockets / {args.n_lig}-atom ligands per GPU, one bucketed gradient all-reduce per step when N > 1',
-                          'batch_per_gpu': B, 'parallelism': f'dp{world}'},
+                          'batch_per_gpu': B, 'parallelism': f'dp{world}',
+                          'optimizer': 'keypoint_diffusion_amd.optim.Adam + clip_grad_value_ (kpd_adam_step)' if native_opt else
+                                       f'torch.optim.Adam{"(fused=True)" if args.fused_optimizer else ""} + torch.nn.utils.clip_grad_value_'},
                'repeats': {'n': args.repeats, 'ms_per_step': [1e3 * r / args.steps for r in regions], 'statistic': 'median',
                            'spread_pct': 100.0 * (max(regions) - min(regions)) / med},
                'complex_steps_per_s': world * args.steps / med * B, 'final_l2': float(last[0].detach()),
@@ -1001,6 +1010,8 @@ def main():
     ap.add_argument('--n-lig', type=int, default=25)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--fused-optimizer', action='store_true', help='training workloads: torch.optim.Adam(fused=True)')
+    ap.add_argument('--torch-optimizer', action='store_true', help='training workloads: torch.optim.Adam + torch.nn.utils.clip_grad_value_ instead '
+                                                                   'of keypoint_diffusion_amd.optim (one launch each)')
     ap.add_argument('--no-secondary', action='store_true', help='skip the configs[2] / configs[4]-shape / end-to-end measurements')
     ap.add_argument('--workload', default='egnn_all_atom', choices=list(WORKLOADS),
                     help='egnn_all_atom = BASELINE.json configs[1] (the contract line); the others are secondary')

@@ -446,6 +446,24 @@ typedef struct {
 kpd_status kpd_wgrad_batch(int32_t kind, int32_t n, const kpd_wgrad_item *items, float *workspace, int64_t workspace_floats, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * The optimizer step of the training loop.  Replaces torch.nn.utils.clip_grad_value_(model.parameters(), clip_value) +
+ * torch.optim.Adam(...).step() of train.py:430-433, 541-543 (torch/optim/adam.py, default flags: no amsgrad, no maximize) for every
+ * parameter tensor in ONE launch; same arithmetic element for element (csrc/optim.hip).  `params_dev`: DEVICE array of n_params entries
+ * -- device pointers to a parameter, its gradient, exp_avg, exp_avg_sq (fp32, contiguous) and the element count -- that the caller
+ * keeps current (gradient tensors may move from step to step); max_numel = the largest count.  mode 0: Adam step number `step` (>= 1),
+ * with the gradients clamped to +- clip_value first when clip_value > 0 (written back, as clip_grad_value_ does); mode 1: the clamp
+ * alone.  No host synchronisation.
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+    float *p;
+    const float *g;
+    float *m, *v;
+    int64_t n;
+} kpd_adam_param;
+kpd_status kpd_adam_step(const kpd_adam_param *params_dev, int32_t n_params, int64_t max_numel, int32_t mode, double lr, double beta1, double beta2,
+                         double eps, double weight_decay, int64_t step, double clip_value, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Reverse-diffusion update around the denoiser.  Replaces the elementwise part of
  * KeypointDiffusion.sample_p_zs_given_zt (models/ligand_diffuser.py:515-536):
  *   z_s = z_t / alpha_ts - var_terms * eps + sigma * noise, then ligand-COM removal from

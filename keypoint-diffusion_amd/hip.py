@@ -164,6 +164,8 @@ def lib():
     L.kpd_gvp_trainer_set_dropout.argtypes = [C.c_void_p, C.c_float, C.c_uint64]
     L.kpd_gvp_trainer_message_path.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     L.kpd_wgrad_batch.argtypes = [C.c_int32, C.c_int32, C.POINTER(KpdWgradItem), C.c_void_p, C.c_int64, C.c_void_p]
+    L.kpd_adam_step.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64,
+                                C.c_double, C.c_void_p]
     L.kpd_dropout_mask.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]
     L.kpd_recenc_trainer_create.argtypes = [C.POINTER(KpdRecencConfig), C.POINTER(C.c_void_p)]
     L.kpd_recenc_trainer_destroy.argtypes = [C.c_void_p]
@@ -211,7 +213,7 @@ EXPORTS = [
     'kpd_xyz_scratch_bytes', 'kpd_xyz_emit', 'kpd_rec_graph_scratch_bytes', 'kpd_build_rec_graph',
     'kpd_egnn_trainer_create', 'kpd_egnn_trainer_destroy', 'kpd_egnn_trainer_bind', 'kpd_egnn_trainer_reserve',
     'kpd_egnn_trainer_forward', 'kpd_egnn_trainer_backward', 'kpd_egnn_trainer_profile', 'kpd_egnn_trainer_profile_read', 'kpd_gvp_trainer_last_counts',
-    'kpd_gvp_trainer_message_path', 'kpd_wgrad_batch',
+    'kpd_gvp_trainer_message_path', 'kpd_wgrad_batch', 'kpd_adam_step',
     'kpd_gvp_trainer_create', 'kpd_gvp_trainer_destroy', 'kpd_gvp_trainer_bind', 'kpd_gvp_trainer_reserve',
     'kpd_gvp_trainer_forward', 'kpd_gvp_trainer_backward', 'kpd_gvp_trainer_set_dropout', 'kpd_dropout_mask',
     'kpd_recenc_trainer_create', 'kpd_recenc_trainer_destroy', 'kpd_recenc_trainer_bind', 'kpd_recenc_trainer_set_dropout',
@@ -893,6 +895,14 @@ def sgemm(a: torch.Tensor, b: torch.Tensor, trans_a=False, trans_b=False, alpha=
                           workspace.data_ptr() if workspace is not None else None,
                           int(workspace.numel()) if workspace is not None else 0, _stream()))
     return out
+
+
+def adam_step(table_dev: torch.Tensor, max_numel: int, mode: int, lr=0.0, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, step=1, clip_value=0.0):
+    """kpd_adam_step over a device table [n, 5] of int64 (parameter, gradient, exp_avg, exp_avg_sq pointers, element count): optim.py builds it."""
+    if not (table_dev.is_cuda and table_dev.dtype == torch.int64 and table_dev.dim() == 2 and table_dev.shape[1] == 5 and table_dev.is_contiguous()):
+        raise KpdError('adam_step: the table must be a contiguous int64 device tensor [n, 5]')
+    check(lib().kpd_adam_step(table_dev.data_ptr(), int(table_dev.shape[0]), int(max_numel), int(mode), float(lr), float(beta1), float(beta2), float(eps),
+                              float(weight_decay), int(step), float(clip_value), _stream()))
 
 
 def wgrad_batch(kind: int, items, workspace: torch.Tensor):
