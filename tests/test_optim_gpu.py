@@ -117,3 +117,39 @@ def test_training_loop_with_either_optimizer(cuda):
     assert la[-1] < la[0] and all(abs(x - y) <= 1e-4 * abs(x) for x, y in zip(la, lb)), (la, lb)
     worst = max(float((a - b).abs().max() / b.abs().max().clamp(min=1e-6)) for a, b in zip(pa, pb) if a.numel())
     assert worst < 1e-3, worst
+
+
+def test_planned_steps_follow_moving_gradients(cuda):
+    """After a first step in which every tensor took part, steps reuse the uploaded address table (optim.py, _StepPlan / _ClipPlan) and must notice
+    every way it can go stale: gradients written in place (addresses stand), new gradient tensors, a strided gradient, a parameter that moved."""
+    ref, mine = _params(5), _params(5)
+    o_ref, o_mine = torch.optim.Adam(ref, lr=2e-3), optim.Adam(mine, lr=2e-3)
+    keep = []
+    for t in range(9):
+        gen = torch.Generator().manual_seed(200 + t)
+        for a, b in zip(mine, ref):
+            g = (2.0 * torch.randn(*a.shape, generator=gen)).cuda()
+            if t in (1, 2, 6) and a.grad is not None:                       # in place: the table stays valid
+                a.grad.copy_(g); b.grad.copy_(g)
+            elif t == 4 and a.dim() == 2:                                   # strided gradients on both sides
+                a.grad, b.grad = g.t().contiguous().t(), g.t().contiguous().t()
+                assert not a.grad.is_contiguous()
+            else:                                                           # new tensors (the old ones kept alive, so the addresses differ)
+                keep.append(a.grad)
+                a.grad, b.grad = g.clone(), g.clone()
+        if t == 7:                                                          # a parameter re-seated on new memory
+            mine[2].data = mine[2].data.clone()
+        torch.nn.utils.clip_grad_value_(ref, 1.0)
+        optim.clip_grad_value_(mine, 1.0)
+        o_ref.step()
+        o_mine.step()
+        torch.cuda.synchronize()
+        if t in (1, 2, 6):
+            assert o_mine._plans, 'the planned form was expected to be in use'
+        assert all(torch.equal(a.grad, b.grad) for a, b in zip(mine, ref)), t
+        assert _close([p.data for p in mine], [p.data for p in ref]), t
+    for a, b in zip(mine, ref):
+        if a.numel():
+            sa, sb = o_mine.state[a], o_ref.state[b]
+            assert float(sa['step']) == float(sb['step']) == 9.0
+            assert _close([sa['exp_avg'], sa['exp_avg_sq']], [sb['exp_avg'], sb['exp_avg_sq']])
