@@ -20,29 +20,60 @@ namespace {
 
 constexpr int OPT_CHUNK = 4096;
 
-// block (x, y): elements [x OPT_CHUNK, (x + 1) OPT_CHUNK) of parameter y (blocks past a parameter's end leave at once)
-__global__ __launch_bounds__(256) void k_adam(const kpd_adam_param *__restrict__ params, int mode, float clip, float wd, float one_minus_b1, float b2,
-                                              float one_minus_b2, float step_size, float inv_sqrt_bc2, float eps) {
+struct AdamK {
+    int mode;
+    float clip, wd, one_minus_b1, b2, one_minus_b2, step_size, inv_sqrt_bc2, eps;
+};
+
+__device__ __forceinline__ void adam_elem(const AdamK &k, float &g, float &p, float &m, float &v) {
+    if (k.clip > 0.0f) g = fminf(fmaxf(g, -k.clip), k.clip);
+    if (k.mode == 1) return;
+    float ge = g;
+    if (k.wd != 0.0f) ge = fmaf(k.wd, p, ge);
+    m = m + (ge - m) * k.one_minus_b1;
+    v = v * k.b2 + k.one_minus_b2 * ge * ge;
+    const float denom = sqrtf(v) * k.inv_sqrt_bc2 + k.eps;
+    p = p - k.step_size * (m / denom);
+}
+
+// block (x, y): elements [x OPT_CHUNK, (x + 1) OPT_CHUNK) of parameter y (blocks past a parameter's end leave at once); 16 bytes per lane where the
+// four arrays are 16-byte aligned (torch's allocator: always), scalars otherwise and for the last n % 4 elements
+__global__ __launch_bounds__(256) void k_adam(const kpd_adam_param *__restrict__ params, AdamK k) {
     const kpd_adam_param q = params[blockIdx.y];
     const long long start = (long long)blockIdx.x * OPT_CHUNK;
     if (start >= q.n) return;
     const long long end = q.n < start + OPT_CHUNK ? q.n : start + OPT_CHUNK;
-    for (long long i = start + threadIdx.x; i < end; i += 256) {
-        float g = q.g[i];
-        if (clip > 0.0f) {
-            g = fminf(fmaxf(g, -clip), clip);
-            const_cast<float *>(q.g)[i] = g;
+    float *gp = const_cast<float *>(q.g);
+    const bool vec = (((uintptr_t)q.p | (uintptr_t)q.g | (k.mode == 1 ? 0 : ((uintptr_t)q.m | (uintptr_t)q.v))) & 15) == 0;
+    long long i = start;
+    if (vec) {
+        const long long end4 = start + ((end - start) & ~3LL);
+        for (long long j = start + 4 * threadIdx.x; j < end4; j += 1024) {
+            float4 g = *reinterpret_cast<const float4 *>(gp + j), p, m, v;
+            if (k.mode == 0) {
+                p = *reinterpret_cast<const float4 *>(q.p + j);
+                m = *reinterpret_cast<const float4 *>(q.m + j);
+                v = *reinterpret_cast<const float4 *>(q.v + j);
+            }
+            adam_elem(k, g.x, p.x, m.x, v.x);
+            adam_elem(k, g.y, p.y, m.y, v.y);
+            adam_elem(k, g.z, p.z, m.z, v.z);
+            adam_elem(k, g.w, p.w, m.w, v.w);
+            if (k.clip > 0.0f) *reinterpret_cast<float4 *>(gp + j) = g;
+            if (k.mode == 0) {
+                *reinterpret_cast<float4 *>(q.p + j) = p;
+                *reinterpret_cast<float4 *>(q.m + j) = m;
+                *reinterpret_cast<float4 *>(q.v + j) = v;
+            }
         }
-        if (mode == 1) continue;
-        const float p = q.p[i];
-        if (wd != 0.0f) g = fmaf(wd, p, g);
-        float m = q.m[i], v = q.v[i];
-        m = m + (g - m) * one_minus_b1;
-        v = v * b2 + one_minus_b2 * g * g;
-        q.m[i] = m;
-        q.v[i] = v;
-        const float denom = sqrtf(v) * inv_sqrt_bc2 + eps;
-        q.p[i] = p - step_size * (m / denom);
+        i = end4;
+    }
+    for (i += threadIdx.x; i < end; i += 256) {
+        float g = gp[i], p = 0.0f, m = 0.0f, v = 0.0f;
+        if (k.mode == 0) p = q.p[i], m = q.m[i], v = q.v[i];
+        adam_elem(k, g, p, m, v);
+        if (k.clip > 0.0f) gp[i] = g;
+        if (k.mode == 0) q.p[i] = p, q.m[i] = m, q.v[i] = v;
     }
 }
 
@@ -58,9 +89,10 @@ extern "C" kpd_status kpd_adam_step(const kpd_adam_param *params_dev, int32_t n_
     KPD_REQUIRE(mode == 0 || clip_value > 0.0, KPD_ERR_INVALID, "kpd_adam_step: the clamp alone needs a clip value");
     if (n_params == 0 || max_numel == 0) return KPD_OK;
     const double bc1 = mode == 1 ? 1.0 : 1.0 - pow(beta1, (double)step), bc2 = mode == 1 ? 1.0 : 1.0 - pow(beta2, (double)step);
+    const AdamK k{mode, (float)clip_value, (float)weight_decay, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)(lr / bc1),
+                  (float)(1.0 / sqrt(bc2)), (float)eps};
     hipLaunchKernelGGL(k_adam, dim3((unsigned)((max_numel + OPT_CHUNK - 1) / OPT_CHUNK), (unsigned)n_params), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       params_dev, mode, (float)clip_value, (float)weight_decay, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)(lr / bc1),
-                       (float)(1.0 / sqrt(bc2)), (float)eps);
+                       params_dev, k);
     KPD_LAUNCH_CHECK();
     return KPD_OK;
 }
