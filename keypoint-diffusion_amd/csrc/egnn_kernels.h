@@ -79,6 +79,7 @@ struct EdgeTrainArgs {
     float *keep[4][2][4];           // [et][branch][pre1, a1, pre2, a2], each [E][HS]
     float *att[4], *sc[4], *dij[4], *xdiff[4], *nvec[4];
     int keep_a2;                    // 0: a2 is not written (k_egnn_edge_bwd recomputes it from pre2)
+    unsigned long long *stamps;     // [64] phase-cycle sums of both training edge kernels (TOOLS build, KPD_TRAIN_STAMPS; null in production)
 };
 
 struct EdgePackEntry {
@@ -112,6 +113,7 @@ struct EdgeBwdArgs {
     int use_tanh;
     float coords_range;
     int have_a2;                    // 0: keep[..][3] was not written by the forward kernel: a2 = SiLU(pre2) on the way
+    unsigned long long *stamps;     // as EdgeTrainArgs (slots 32 ..)
 };
 
 struct NodeArgs {

@@ -578,6 +578,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
 // registers, one 1-KiB row segment per wave store), pre2, a2 (from the accumulators: 32 consecutive columns of two rows per store), the
 // attention weight, the coordinate scalar and the geometry.  It replaces k_edge_pre1 + k_ws_gemm<0> + the head and segmented-sum
 // kernels of the forward pass (three passes over E x 257 matrices less per branch).
+// phase-cycle sums of the training edge kernels (a.stamps is null in production: profiles/tools/train_stamps.sh)
+#define TRAIN_STAMP(idx)                                                                   \
+    if (a.stamps && tid == 0) {                                                            \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                      \
+        atomicAdd(&a.stamps[idx], (unsigned long long)(now_ - t_prev_));                   \
+        t_prev_ = now_;                                                                    \
+    }
+
 struct EdgeKeep {
     float *pre1, *a1, *pre2, *a2;          // rows e0 .. of the branch's kept arrays [E][HS]
 };
@@ -673,6 +681,7 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_train(EdgeTrainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const EdgeSmem s = edge_smem(smem);
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    unsigned long long t_prev_ = a.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
     const int T = a.meta[8];
     const int chunk = (T + 7) >> 3;
     const int bi = blockIdx.x >> 3;
@@ -741,6 +750,7 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_train(EdgeTrainArgs a) {
     BPrefetch bpre;
     gemm_b_prefetch(bpre, a.wp[et][0], wave, lane);
     lds_barrier();
+    TRAIN_STAMP(0)
 
     // (the run structure is wave-uniform: as scalars -- three vector registers less in a kernel that sat at 256 with 6 spilled)
     const int first_is_cont = __builtin_amdgcn_readfirstlane(s.misc[0]);
@@ -752,13 +762,16 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_train(EdgeTrainArgs a) {
     // ---- feature messages (dynamics.py:103-112)
     edge_gather_finish_train(ge, s, a.wr[et][0], wave, lane, ke, ne);
     lds_barrier();
+    TRAIN_STAMP(1)
     acc_zero_w<NW>(acc);
     ex = row_dot_chunks<TPR>(s.A, s.wv + 2 * HS, KP / 4, tid);
     gemm_rows64_pre<NG, SA>(s.A, a.wp[et][0], acc, wave, lane, bpre);
     gemm_b_prefetch(bpre, a.wp[et][1], wave, lane);
     lds_barrier();
+    TRAIN_STAMP(2)
     store_T_train(s.A, acc, ex, tid, wave, lane, ke, ne, a.keep_a2 != 0);
     lds_barrier();
+    TRAIN_STAMP(3)
     {
         float dot = row_dot_chunks<TPR>(s.A, s.wv, 64, tid);
         const int row = tid / TPR;
@@ -770,6 +783,7 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_train(EdgeTrainArgs a) {
         }
     }
     lds_barrier();
+    TRAIN_STAMP(4)
     EdgeGather<NW> gc;
     edge_gather_issue<NW>(gc, s, Ps_c, Pd_c, wave, lane);      // the coordinate branch's rows travel during the segmented sum
     __builtin_amdgcn_sched_barrier(0);
@@ -812,16 +826,20 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_train(EdgeTrainArgs a) {
         if (wave == NW - 1) reinterpret_cast<float *>(s.misc + 8)[lane] = s.A[lane * SA + 256] * s.att[lane];
     }
     lds_barrier();
+    TRAIN_STAMP(5)
 
     // ---- coordinate messages (dynamics.py:113-120)
     edge_gather_finish_train(gc, s, a.wr[et][1], wave, lane, kc, ne);
     lds_barrier();
+    TRAIN_STAMP(6)
     acc_zero_w<NW>(acc);
     ex = row_dot_chunks<TPR>(s.A, s.wv + 3 * HS, KP / 4, tid);
     gemm_rows64_pre<NG, SA>(s.A, a.wp[et][1], acc, wave, lane, bpre);
     lds_barrier();
+    TRAIN_STAMP(7)
     store_T_train(s.A, acc, ex, tid, wave, lane, kc, ne, a.keep_a2 != 0);
     lds_barrier();
+    TRAIN_STAMP(8)
     {
         float dot = row_dot_chunks<TPR>(s.A, s.wv + HS, 64, tid);
         const int row = tid / TPR;
@@ -863,6 +881,8 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_train(EdgeTrainArgs a) {
             oh[256] = vh;
         }
     }
+    TRAIN_STAMP(9)
+    if (a.stamps && tid == 0) atomicAdd(&a.stamps[15], 1ull);
 }
 
 // ---- backward form (egnn_train.hip, backward pass of the edge MLPs of a layer) ---------------------------------------------------
@@ -1053,6 +1073,7 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_bwd(EdgeBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const EdgeBwdSmem s = edge_bwd_smem(smem);
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    unsigned long long t_prev_ = a.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
     const int T = a.meta[8];
     const int chunk = (T + 7) >> 3;
     const int bi = blockIdx.x >> 3;
@@ -1097,6 +1118,7 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_bwd(EdgeBwdArgs a) {
     BPrefetch bpre;
     gemm_b_prefetch(bpre, a.wpT[et][0], wave, lane);
     lds_barrier();
+    TRAIN_STAMP(32)
     const int first_is_cont = s.misc[0];
     const unsigned long long endmask = ((unsigned long long)(unsigned)s.misc[3] << 32) | (unsigned long long)(unsigned)s.misc[2];
     const unsigned long long headmask = ((unsigned long long)(unsigned)s.misc[5] << 32) | (unsigned long long)(unsigned)s.misc[4];
@@ -1115,13 +1137,16 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_bwd(EdgeBwdArgs a) {
             edge_head_bwd_rows<false>(s, a, et, e0, ne, wave, lane, nullptr, a.keep[et][1][2], a.have_a2 ? a.keep[et][1][3] : nullptr, a.w3[et], nullptr, a.nvec[et], hs);
         }
         lds_barrier();
+        TRAIN_STAMP(33 + 8 * br)
         acc_zero_w<NW>(acc);
         const float ex = row_dot_chunks<TPR>(s.A, a.wxT[et][br], KP / 4, tid);
         gemm_rows64_pre<NG, SA>(s.A, a.wpT[et][br], acc, wave, lane, bpre);
         if (br == 0) gemm_b_prefetch(bpre, a.wpT[et][1], wave, lane);
         lds_barrier();
+        TRAIN_STAMP(34 + 8 * br)
         store_T_bwd(s.A, acc, ex, tid, wave, lane, pre1, ne);
         lds_barrier();
+        TRAIN_STAMP(35 + 8 * br)
         {   // d dij += dpre1 . W1[:, 514]
             const float dot = row_dot_chunks<TPR>(s.A, a.wr[et][br], KP / 4, tid);
             if ((tid % TPR) == 0) s.ddij[tid / TPR] += dot;
@@ -1162,6 +1187,7 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_bwd(EdgeBwdArgs a) {
             }
         }
         lds_barrier();
+        TRAIN_STAMP(36 + 8 * br)
         if (wave == 0) {    // column 256: segmented inclusive scan across lanes (lane = row), the last lane of every run writes
             const unsigned long long upto = lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull);
             const int start = 63 - __clzll((long long)((headmask & upto) | 1ull));
@@ -1202,8 +1228,10 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_bwd(EdgeBwdArgs a) {
             }
             lds_barrier();
         }
+        TRAIN_STAMP(37 + 8 * br)
     }
     if (tid < ne) a.sc[et][e0 + tid] = s.ddij[tid];          // d dij of both branches, over sc
+    if (a.stamps && tid == 0) atomicAdd(&a.stamps[63], 1ull);
 }
 
 // dV[v] = main[v] + the continuation pieces of the tiles v's in-edges span (zeros without in-edges), the same for dVw: the pieces of

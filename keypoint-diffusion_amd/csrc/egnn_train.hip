@@ -357,6 +357,7 @@ struct kpd_egnn_trainer : TrainCtx {
     kpd_egnn_config cfg{};
     // HIP-event timing of the two per-layer edge kernels (kpd_egnn_trainer_profile): (start, stop) pairs, which kernel, how many edges
     std::vector<hipEvent_t> prof_ev;
+    unsigned long long *stamps = nullptr;      // TOOLS build, KPD_TRAIN_STAMPS=1: phase-cycle sums of the two edge kernels (printed by profile_read)
     std::vector<int> prof_tag;
     std::vector<double> prof_edges;
     bool prof_on = false;
@@ -541,6 +542,7 @@ kpd_status layer_edges_fused(kpd_egnn_trainer *T, int l, bool sum_pieces) {
     a.meta = T->meta + (l == c.n_layers - 1 ? 16 : 0);
     a.use_tanh = c.use_tanh; a.coords_range = c.coords_range;
     a.keep_a2 = 0;                            // (the backward edge kernel recomputes a2 = SiLU(pre2) from the pre2 rows it streams)
+    a.stamps = T->stamps;
     int tiles = 0;
     for (int nt = 0; nt < 2; ++nt) { a.x[nt] = T->xs[nt][l]; a.P[nt] = T->ucat[nt]; }
     for (int et = 0; et < 4; ++et) {
@@ -733,6 +735,8 @@ extern "C" kpd_status kpd_egnn_trainer_profile(kpd_egnn_trainer *T, int32_t enab
     }
     T->prof_on = enable != 0;
     T->prof_used = 0;
+    if (enable && !T->stamps && tool_env_int("KPD_TRAIN_STAMPS", 0)) KPD_HIP(hipMalloc(reinterpret_cast<void **>(&T->stamps), 64 * sizeof(unsigned long long)));
+    if (T->stamps) KPD_HIP(hipMemset(T->stamps, 0, 64 * sizeof(unsigned long long)));
     return KPD_OK;
 }
 
@@ -749,6 +753,20 @@ extern "C" kpd_status kpd_egnn_trainer_profile_read(kpd_egnn_trainer *T, double 
         edges[tag] += T->prof_edges[i / 2];
         ++launches[tag];
     }
+    if (T->stamps) {
+        unsigned long long h[64];
+        KPD_HIP(hipDeviceSynchronize());
+        KPD_HIP(hipMemcpy(h, T->stamps, sizeof h, hipMemcpyDeviceToHost));
+        static const char *fn[10] = {"geometry + run structure", "gather -> pre1, a1 (feature)", "GEMM (feature)", "pre2 / a2 stores (feature)", "attention head",
+                                     "segmented sum", "gather -> pre1, a1 (coordinate)", "GEMM (coordinate)", "pre2 / a2 stores (coordinate)", "coordinate head + scan"};
+        static const char *bn[5] = {"head rows -> dpre2", "row dots + GEMM", "dpre1 = acc SiLU'(pre1)", "d dij + segmented sums", "column 256 scan + column sums"};
+        const double tf = (double)h[15], tb = (double)h[63];
+        fprintf(stderr, "k_egnn_edge_train: %.0f tiles, s_memtime ticks per tile and phase (100 MHz)\n", tf);
+        for (int i = 0; i < 10; ++i) fprintf(stderr, "  %-36s %8.1f\n", fn[i], tf > 0 ? (double)h[i] / tf : 0.0);
+        fprintf(stderr, "k_egnn_edge_bwd: %.0f tiles\n  %-36s %8.1f\n", tb, "row scalars + run structure", tb > 0 ? (double)h[32] / tb : 0.0);
+        for (int br = 0; br < 2; ++br)
+            for (int i = 0; i < 5; ++i) fprintf(stderr, "  [%s] %-29s %8.1f\n", br ? "coord" : "feat", bn[i], tb > 0 ? (double)h[33 + 8 * br + i] / tb : 0.0);
+    }
     return KPD_OK;
 }
 
@@ -759,6 +777,7 @@ extern "C" void kpd_egnn_trainer_destroy(kpd_egnn_trainer *T) {
     T->wide.release();
     T->release_scratch();
     if (T->store_base) (void)hipFree(T->store_base);
+    if (T->stamps) (void)hipFree(T->stamps);
     delete T;
 }
 
@@ -1146,6 +1165,7 @@ kpd_status layer_edges_bwd_fused(kpd_egnn_trainer *T, int l, int cur, int nxt, f
     a.use_tanh = c.use_tanh; a.coords_range = c.coords_range;
     a.part[0] = T->bpart[0]; a.part[1] = T->bpart[1]; a.part_ld = COLSUM_LD;
     a.have_a2 = 0;
+    a.stamps = T->stamps;
     for (int nt = 0; nt < 2; ++nt) { a.dhn[nt] = dhn[nt]; a.dxo[nt] = T->dx[cur][nt]; a.zinv[nt] = T->zinv[nt]; }
     int tiles = 0, tile0[4] = {0, 0, 0, 0};
     for (int et = 0; et < 4; ++et) {
