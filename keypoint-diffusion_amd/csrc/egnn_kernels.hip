@@ -696,6 +696,7 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_train(EdgeTrainArgs a) {
     const int e0 = tile_in_et * TM;
     const int ne = min(TM, a.meta[et] - e0);
     const int snt = a.src_nt[et], dnt = a.dst_nt[et];
+    const int ne1 = (a.skip & 1) ? 0 : ne, ne2 = (a.skip & 2) ? 0 : ne;      // rows whose kept values are stored (a.skip = 0 outside timing experiments)
     const int *__restrict__ esrc = a.src[et];
     const int *__restrict__ edst = a.dst[et];
     const float *Ps_e = a.P[snt] + (size_t)a.slot[et][0][0] * HS, *Pd_e = a.P[dnt] + (size_t)a.slot[et][0][1] * HS;
@@ -723,7 +724,7 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_train(EdgeTrainArgs a) {
         s.xd[3 * tid] = dx * inv;
         s.xd[3 * tid + 1] = dy * inv;
         s.xd[3 * tid + 2] = dz * inv;
-        if (tid < ne) {
+        if (tid < ne && !(a.skip & 4)) {
             a.dij[et][e] = d;
             float *xo = a.xdiff[et] + (size_t)e * 3, *no = a.nvec[et] + (size_t)e * 3;
             xo[0] = dx; xo[1] = dy; xo[2] = dz;
@@ -760,7 +761,7 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_train(EdgeTrainArgs a) {
     float ex;
 
     // ---- feature messages (dynamics.py:103-112)
-    edge_gather_finish_train(ge, s, a.wr[et][0], wave, lane, ke, ne);
+    edge_gather_finish_train(ge, s, a.wr[et][0], wave, lane, ke, ne1);
     lds_barrier();
     TRAIN_STAMP(1)
     acc_zero_w<NW>(acc);
@@ -769,7 +770,7 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_train(EdgeTrainArgs a) {
     gemm_b_prefetch(bpre, a.wp[et][1], wave, lane);
     lds_barrier();
     TRAIN_STAMP(2)
-    store_T_train(s.A, acc, ex, tid, wave, lane, ke, ne, a.keep_a2 != 0);
+    store_T_train(s.A, acc, ex, tid, wave, lane, ke, ne2, a.keep_a2 != 0);
     lds_barrier();
     TRAIN_STAMP(3)
     {
@@ -829,7 +830,7 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_train(EdgeTrainArgs a) {
     TRAIN_STAMP(5)
 
     // ---- coordinate messages (dynamics.py:113-120)
-    edge_gather_finish_train(gc, s, a.wr[et][1], wave, lane, kc, ne);
+    edge_gather_finish_train(gc, s, a.wr[et][1], wave, lane, kc, ne1);
     lds_barrier();
     TRAIN_STAMP(6)
     acc_zero_w<NW>(acc);
@@ -837,7 +838,7 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_train(EdgeTrainArgs a) {
     gemm_rows64_pre<NG, SA>(s.A, a.wp[et][1], acc, wave, lane, bpre);
     lds_barrier();
     TRAIN_STAMP(7)
-    store_T_train(s.A, acc, ex, tid, wave, lane, kc, ne, a.keep_a2 != 0);
+    store_T_train(s.A, acc, ex, tid, wave, lane, kc, ne2, a.keep_a2 != 0);
     lds_barrier();
     TRAIN_STAMP(8)
     {
@@ -1011,7 +1012,7 @@ __device__ __forceinline__ void edge_head_bwd_rows(const EdgeBwdSmem &s, const E
                 if (lane == 0) t[0] = gt;
                 *reinterpret_cast<f32x4 *>(s.A + r * SA + 256 + 4 * lane) = t;
             }
-            if (on) {
+            if (on && !(a.skip & 8)) {
                 *reinterpret_cast<f32x4 *>(pre2 + (size_t)(e0 + r) * HS + 4 * lane) = g;
                 if (lane == 0) {
                     pre2[(size_t)(e0 + r) * HS + 256] = gt;
@@ -1029,7 +1030,8 @@ __device__ __forceinline__ void edge_head_bwd_rows(const EdgeBwdSmem &s, const E
 
 // T = acc * SiLU'(pre1) to LDS and, over pre1, to HBM; rows past ne are zeros (their A rows were).  All 64 values of pre1 a lane needs are
 // requested before the first is used: one memory latency per tile and branch instead of one per group of rows.
-__device__ __forceinline__ void store_T_bwd(float *T, const f32x16 (&acc)[2][2], float ex, int tid, int wave, int lane, float *__restrict__ pre1, int ne) {
+__device__ __forceinline__ void store_T_bwd(float *T, const f32x16 (&acc)[2][2], float ex, int tid, int wave, int lane, float *__restrict__ pre1, int ne,
+                                            int ne_st) {
     const int row0 = 4 * (lane >> 5), col0 = 64 * wave + (lane & 31);
     unsigned off0 = (unsigned)(row0 * HS + col0) * 4u;
     asm volatile("" : "+v"(off0));
@@ -1055,7 +1057,7 @@ __device__ __forceinline__ void store_T_bwd(float *T, const f32x16 (&acc)[2][2],
                 const int rl = 32 * mt + 8 * (reg >> 2) + (reg & 3), row = rl + row0;
                 const float v = acc[mt][nt][reg] * silu_grad_(p[mt][nt][reg]);
                 T[row * SA + col0 + 32 * nt] = v;
-                if (row < ne) *reinterpret_cast<float *>(bp + (off0 + (unsigned)(rl * HS + 32 * nt) * 4u)) = v;
+                if (row < ne_st) *reinterpret_cast<float *>(bp + (off0 + (unsigned)(rl * HS + 32 * nt) * 4u)) = v;
             }
     if ((tid & 3) == 0) {
         const int row = tid >> 2;
@@ -1144,7 +1146,7 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_bwd(EdgeBwdArgs a) {
         if (br == 0) gemm_b_prefetch(bpre, a.wpT[et][1], wave, lane);
         lds_barrier();
         TRAIN_STAMP(34 + 8 * br)
-        store_T_bwd(s.A, acc, ex, tid, wave, lane, pre1, ne);
+        store_T_bwd(s.A, acc, ex, tid, wave, lane, pre1, ne, (a.skip & 16) ? 0 : ne);
         lds_barrier();
         TRAIN_STAMP(35 + 8 * br)
         {   // d dij += dpre1 . W1[:, 514]

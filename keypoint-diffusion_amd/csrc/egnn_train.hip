@@ -543,6 +543,7 @@ kpd_status layer_edges_fused(kpd_egnn_trainer *T, int l, bool sum_pieces) {
     a.use_tanh = c.use_tanh; a.coords_range = c.coords_range;
     a.keep_a2 = 0;                            // (the backward edge kernel recomputes a2 = SiLU(pre2) from the pre2 rows it streams)
     a.stamps = T->stamps;
+    a.skip = tool_env_int("KPD_TR_SKIP", 0);
     int tiles = 0;
     for (int nt = 0; nt < 2; ++nt) { a.x[nt] = T->xs[nt][l]; a.P[nt] = T->ucat[nt]; }
     for (int et = 0; et < 4; ++et) {
@@ -1166,6 +1167,7 @@ kpd_status layer_edges_bwd_fused(kpd_egnn_trainer *T, int l, int cur, int nxt, f
     a.part[0] = T->bpart[0]; a.part[1] = T->bpart[1]; a.part_ld = COLSUM_LD;
     a.have_a2 = 0;
     a.stamps = T->stamps;
+    a.skip = tool_env_int("KPD_TR_SKIP", 0);
     for (int nt = 0; nt < 2; ++nt) { a.dhn[nt] = dhn[nt]; a.dxo[nt] = T->dx[cur][nt]; a.zinv[nt] = T->zinv[nt]; }
     int tiles = 0, tile0[4] = {0, 0, 0, 0};
     for (int et = 0; et < 4; ++et) {
