@@ -830,21 +830,26 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_train(EdgeTrainArgs a) {
     TRAIN_STAMP(5)
 
     // ---- coordinate messages (dynamics.py:113-120)
-    edge_gather_finish_train(gc, s, a.wr[et][1], wave, lane, kc, ne1);
+    // (the second branch takes the thread index through an opaque copy: with the plain one the compiler keeps LDS addresses of the first
+    //  branch alive across its GEMM for re-use here, and at 256 registers that meant three spilled -- each reload a vmcnt(0) in the store stream)
+    int tid_c = tid;
+    asm volatile("" : "+v"(tid_c));
+    const int lane_c = tid_c & 63;
+    edge_gather_finish_train(gc, s, a.wr[et][1], wave, lane_c, kc, ne1);
     lds_barrier();
     TRAIN_STAMP(6)
     acc_zero_w<NW>(acc);
-    ex = row_dot_chunks<TPR>(s.A, s.wv + 3 * HS, KP / 4, tid);
-    gemm_rows64_pre<NG, SA>(s.A, a.wp[et][1], acc, wave, lane, bpre);
+    ex = row_dot_chunks<TPR>(s.A, s.wv + 3 * HS, KP / 4, tid_c);
+    gemm_rows64_pre<NG, SA>(s.A, a.wp[et][1], acc, wave, lane_c, bpre);
     lds_barrier();
     TRAIN_STAMP(7)
-    store_T_train(s.A, acc, ex, tid, wave, lane, kc, ne2, a.keep_a2 != 0);
+    store_T_train(s.A, acc, ex, tid_c, wave, lane_c, kc, ne2, a.keep_a2 != 0);
     lds_barrier();
     TRAIN_STAMP(8)
     {
-        float dot = row_dot_chunks<TPR>(s.A, s.wv + HS, 64, tid);
-        const int row = tid / TPR;
-        if ((tid % TPR) == 0) {
+        float dot = row_dot_chunks<TPR>(s.A, s.wv + HS, 64, tid_c);
+        const int row = tid_c / TPR;
+        if ((tid_c % TPR) == 0) {
             dot = fmaf(s.A[row * SA + 256], s.wv[HS + 256], dot);
             float c = a.use_tanh ? tanhf(dot) * a.coords_range : dot;
             if (row >= ne) c = 0.0f;
