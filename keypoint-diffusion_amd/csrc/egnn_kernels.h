@@ -78,7 +78,6 @@ struct EdgeTrainArgs {
     float coords_range;
     float *keep[4][2][4];           // [et][branch][pre1, a1, pre2, a2], each [E][HS]
     float *att[4], *sc[4], *dij[4], *xdiff[4], *nvec[4];
-    int keep_a2;                    // 0: a2 is not written (k_egnn_edge_bwd recomputes it from pre2)
     unsigned long long *stamps;     // [64] phase-cycle sums of both training edge kernels (TOOLS build, KPD_TRAIN_STAMPS; null in production)
     int skip;                       // TOOLS build (KPD_TR_SKIP): bit 0 / 1 / 2 = leave out the pre1 + a1 / pre2 / geometry stores (timing experiments; results are wrong)
 };
@@ -113,7 +112,6 @@ struct EdgeBwdArgs {
     int part_ld;
     int use_tanh;
     float coords_range;
-    int have_a2;                    // 0: keep[..][3] was not written by the forward kernel: a2 = SiLU(pre2) on the way
     unsigned long long *stamps;     // as EdgeTrainArgs (slots 32 ..)
     int skip;                       // TOOLS build (KPD_TR_SKIP): bit 3 / 4 = leave out the dpre2 / dpre1 stores
 };

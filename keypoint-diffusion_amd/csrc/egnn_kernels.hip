@@ -587,7 +587,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_egnn_edge(EdgeArgs
     }
 
 struct EdgeKeep {
-    float *pre1, *a1, *pre2, *a2;          // rows e0 .. of the branch's kept arrays [E][HS]
+    float *pre1, *a1, *pre2;               // rows e0 .. of the branch's kept arrays [E][HS]
 };
 
 // (addresses of the kept rows: a wave-uniform row base -- scalar registers -- plus one 32-bit lane offset, so that the sixteen rows of a
@@ -638,15 +638,14 @@ __device__ __forceinline__ void edge_gather_finish_train(const EdgeGather<4> &g,
 }
 
 // T = SiLU(acc) to LDS; pre2 = acc (bias included: bias row of the GEMM) and a2 = T to the kept arrays
-// keep_a2 = false: a2 is not stored (the backward edge kernel recomputes it from pre2 on the way)
-__device__ __forceinline__ void store_T_train(float *T, const f32x16 (&acc)[2][2], float ex, int tid, int wave, int lane, const EdgeKeep &k, int ne,
-                                              bool keep_a2) {
+// (a2 is not stored: the backward edge kernel recomputes it from the pre2 rows it streams anyway)
+__device__ __forceinline__ void store_T_train(float *T, const f32x16 (&acc)[2][2], float ex, int tid, int wave, int lane, const EdgeKeep &k, int ne) {
     // element (row, col) of accumulator register reg of tile (mt, nt): row = 32 mt + 8 (reg >> 2) + (reg & 3) + 4 (lane >> 5),
     // col = 64 wave + 32 nt + (lane & 31): one lane offset, everything else is a constant (groups of four rows within the 4-KiB immediate)
     const int row0 = 4 * (lane >> 5), col0 = 64 * wave + (lane & 31);
     unsigned off0 = (unsigned)(row0 * HS + col0) * 4u;
     asm volatile("" : "+v"(off0));
-    char *b2 = reinterpret_cast<char *>(k.pre2), *ba = reinterpret_cast<char *>(k.a2);
+    char *b2 = reinterpret_cast<char *>(k.pre2);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -659,20 +658,14 @@ __device__ __forceinline__ void store_T_train(float *T, const f32x16 (&acc)[2][2
                     const int row = 32 * mt + 8 * q4 + j + row0;
                     const float v = acc[mt][nt][4 * q4 + j], a = silu(v);
                     T[row * SA + col0 + 32 * nt] = a;
-                    if (row < ne) {
-                        keep_store(reinterpret_cast<float *>(b2 + (off + (unsigned)(j * HS * 4))), v);
-                        if (keep_a2) keep_store(reinterpret_cast<float *>(ba + (off + (unsigned)(j * HS * 4))), a);
-                    }
+                    if (row < ne) keep_store(reinterpret_cast<float *>(b2 + (off + (unsigned)(j * HS * 4))), v);
                 }
             }
     if ((tid & 3) == 0) {
         const int row = tid >> 2;
         const float a = silu(ex);
         T[row * SA + 256] = a;
-        if (row < ne) {
-            keep_store(k.pre2 + row * HS + 256, ex);
-            if (keep_a2) keep_store(k.a2 + row * HS + 256, a);
-        }
+        if (row < ne) keep_store(k.pre2 + row * HS + 256, ex);
     }
 }
 
@@ -703,9 +696,9 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_train(EdgeTrainArgs a) {
     const float *Ps_c = a.P[snt] + (size_t)a.slot[et][1][0] * HS, *Pd_c = a.P[dnt] + (size_t)a.slot[et][1][1] * HS;
     EdgeKeep ke, kc;
     ke.pre1 = a.keep[et][0][0] + (size_t)e0 * HS; ke.a1 = a.keep[et][0][1] + (size_t)e0 * HS;
-    ke.pre2 = a.keep[et][0][2] + (size_t)e0 * HS; ke.a2 = a.keep[et][0][3] + (size_t)e0 * HS;
+    ke.pre2 = a.keep[et][0][2] + (size_t)e0 * HS;
     kc.pre1 = a.keep[et][1][0] + (size_t)e0 * HS; kc.a1 = a.keep[et][1][1] + (size_t)e0 * HS;
-    kc.pre2 = a.keep[et][1][2] + (size_t)e0 * HS; kc.a2 = a.keep[et][1][3] + (size_t)e0 * HS;
+    kc.pre2 = a.keep[et][1][2] + (size_t)e0 * HS;
 
     EdgeGather<NW> ge;
     edge_gather_issue_early<NW>(ge, esrc, edst, e0, ne, Ps_e, Pd_e, wave, lane);
@@ -770,7 +763,7 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_train(EdgeTrainArgs a) {
     gemm_b_prefetch(bpre, a.wp[et][1], wave, lane);
     lds_barrier();
     TRAIN_STAMP(2)
-    store_T_train(s.A, acc, ex, tid, wave, lane, ke, ne2, a.keep_a2 != 0);
+    store_T_train(s.A, acc, ex, tid, wave, lane, ke, ne2);
     lds_barrier();
     TRAIN_STAMP(3)
     {
@@ -843,7 +836,7 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_train(EdgeTrainArgs a) {
     gemm_rows64_pre<NG, SA>(s.A, a.wp[et][1], acc, wave, lane_c, bpre);
     lds_barrier();
     TRAIN_STAMP(7)
-    store_T_train(s.A, acc, ex, tid_c, wave, lane_c, kc, ne2, a.keep_a2 != 0);
+    store_T_train(s.A, acc, ex, tid_c, wave, lane_c, kc, ne2);
     lds_barrier();
     TRAIN_STAMP(8)
     {
@@ -945,26 +938,22 @@ struct HeadSums {
 // head backward of one branch for the wave's 16 rows: A rows <- dpre2 (zero rows past ne), dpre2 over pre2 in HBM
 template <bool FEAT>
 __device__ __forceinline__ void edge_head_bwd_rows(const EdgeBwdSmem &s, const EdgeBwdArgs &a, int et, int e0, int ne, int wave, int lane,
-                                                   const float *__restrict__ dhn, float *__restrict__ pre2, const float *__restrict__ a2,
+                                                   const float *__restrict__ dhn, float *__restrict__ pre2,
                                                    const float *__restrict__ wh, float *__restrict__ ds_out, float *__restrict__ dn_out, HeadSums &hs) {
-    constexpr int RPW = TM / 4, BATCH = 8;
+    constexpr int RPW = TM / 4, BATCH = 8;         // (16 rows in one batch -- one memory round trip per branch instead of two -- spills 440 B: measured on the ISA, not run)
     const f32x4 wv = reinterpret_cast<const f32x4 *>(wh)[lane];
     const float wv_t = wh[256];
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
     for (int b0 = 0; b0 < RPW; b0 += BATCH) {
-        f32x4 dm[BATCH], av[BATCH], pv[BATCH];
-        float dm_t[BATCH], av_t[BATCH], pv_t[BATCH];
+        f32x4 dm[BATCH], pv[BATCH];
+        float dm_t[BATCH], pv_t[BATCH];
 #pragma unroll
         for (int i = 0; i < BATCH; ++i) {
             const int r = wave * RPW + b0 + i, rc = min(r, ne - 1);
             const size_t eo = (size_t)(e0 + rc) * HS;
             pv[i] = *reinterpret_cast<const f32x4 *>(pre2 + eo + 4 * lane);
             pv_t[i] = lane == 0 ? pre2[eo + 256] : 0.0f;
-            if (a2) {
-                av[i] = *reinterpret_cast<const f32x4 *>(a2 + eo + 4 * lane);
-                av_t[i] = lane == 0 ? a2[eo + 256] : 0.0f;
-            }
             if (FEAT) {
                 const size_t vo = (size_t)s.dst[rc] * HS;
                 dm[i] = *reinterpret_cast<const f32x4 *>(dhn + vo + 4 * lane);
@@ -975,20 +964,20 @@ __device__ __forceinline__ void edge_head_bwd_rows(const EdgeBwdSmem &s, const E
         for (int i = 0; i < BATCH; ++i) {
             const int r = wave * RPW + b0 + i;
             const bool on = r < ne;
-            if (!a2) {              // a2 = SiLU(pre2) was not kept: the same expression the forward kernel put into its tile
+            // a2 = SiLU(pre2) is not kept: the same expression the forward kernel put into its tile
+            f32x4 av;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) av[i][q] = silu(pv[i][q]);
-                av_t[i] = lane == 0 ? silu(pv_t[i]) : 0.0f;
-            }
+            for (int q = 0; q < 4; ++q) av[q] = silu(pv[i][q]);
+            const float av_t = lane == 0 ? silu(pv_t[i]) : 0.0f;
             f32x4 g = zero;
             float gt = 0.0f, ds = 0.0f;
             if (FEAT) {
                 const float zi = s.zi[min(r, ne - 1)], at = s.sa[min(r, ne - 1)];
                 const f32x4 d4 = dm[i] * zi;
                 const float d_t = dm_t[i] * zi;
-                float sdot = d_t * av_t[i];
+                float sdot = d_t * av_t;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) sdot = fmaf(d4[q], av[i][q], sdot);
+                for (int q = 0; q < 4; ++q) sdot = fmaf(d4[q], av[q], sdot);
                 ds = wave_sum64(sdot) * at * (1.0f - at);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) g[q] = (d4[q] * at + ds * wv[q]) * silu_grad_(pv[i][q]);
@@ -1027,8 +1016,8 @@ __device__ __forceinline__ void edge_head_bwd_rows(const EdgeBwdSmem &s, const E
             hs.cs += g;
             hs.cs_t += gt;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) hs.ws[q] = fmaf(av[i][q], ds, hs.ws[q]);
-            hs.ws_t = fmaf(av_t[i], ds, hs.ws_t);
+            for (int q = 0; q < 4; ++q) hs.ws[q] = fmaf(av[q], ds, hs.ws[q]);
+            hs.ws_t = fmaf(av_t, ds, hs.ws_t);
         }
     }
 }
@@ -1137,11 +1126,11 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_bwd(EdgeBwdArgs a) {
         HeadSums hs;
         hs.cs = f32x4{0.f, 0.f, 0.f, 0.f}; hs.ws = f32x4{0.f, 0.f, 0.f, 0.f}; hs.cs_t = 0.0f; hs.ws_t = 0.0f;
         if (br == 0) {
-            edge_head_bwd_rows<true>(s, a, et, e0, ne, wave, lane, a.dhn[dnt], a.keep[et][0][2], a.have_a2 ? a.keep[et][0][3] : nullptr, a.wa[et], a.att[et], nullptr, hs);
+            edge_head_bwd_rows<true>(s, a, et, e0, ne, wave, lane, a.dhn[dnt], a.keep[et][0][2], a.wa[et], a.att[et], nullptr, hs);
         } else {
             if (tid < TM) s.sa[tid] = a.sc[et][e0 + min(tid, ne - 1)];        // the coordinate scalar replaces the attention weight
             lds_barrier();
-            edge_head_bwd_rows<false>(s, a, et, e0, ne, wave, lane, nullptr, a.keep[et][1][2], a.have_a2 ? a.keep[et][1][3] : nullptr, a.w3[et], nullptr, a.nvec[et], hs);
+            edge_head_bwd_rows<false>(s, a, et, e0, ne, wave, lane, nullptr, a.keep[et][1][2], a.w3[et], nullptr, a.nvec[et], hs);
         }
         lds_barrier();
         TRAIN_STAMP(33 + 8 * br)

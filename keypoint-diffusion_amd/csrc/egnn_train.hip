@@ -541,7 +541,6 @@ kpd_status layer_edges_fused(kpd_egnn_trainer *T, int l, bool sum_pieces) {
     EdgeTrainArgs a{};
     a.meta = T->meta + (l == c.n_layers - 1 ? 16 : 0);
     a.use_tanh = c.use_tanh; a.coords_range = c.coords_range;
-    a.keep_a2 = 0;                            // (the backward edge kernel recomputes a2 = SiLU(pre2) from the pre2 rows it streams)
     a.stamps = T->stamps;
     a.skip = tool_env_int("KPD_TR_SKIP", 0);
     int tiles = 0;
@@ -758,8 +757,8 @@ extern "C" kpd_status kpd_egnn_trainer_profile_read(kpd_egnn_trainer *T, double 
         unsigned long long h[64];
         KPD_HIP(hipDeviceSynchronize());
         KPD_HIP(hipMemcpy(h, T->stamps, sizeof h, hipMemcpyDeviceToHost));
-        static const char *fn[10] = {"geometry + run structure", "gather -> pre1, a1 (feature)", "GEMM (feature)", "pre2 / a2 stores (feature)", "attention head",
-                                     "segmented sum", "gather -> pre1, a1 (coordinate)", "GEMM (coordinate)", "pre2 / a2 stores (coordinate)", "coordinate head + scan"};
+        static const char *fn[10] = {"geometry + run structure", "gather -> pre1, a1 (feature)", "GEMM (feature)", "pre2 stores (feature)", "attention head",
+                                     "segmented sum", "gather -> pre1, a1 (coordinate)", "GEMM (coordinate)", "pre2 stores (coordinate)", "coordinate head + scan"};
         static const char *bn[5] = {"head rows -> dpre2", "row dots + GEMM", "dpre1 = acc SiLU'(pre1)", "d dij + segmented sums", "column 256 scan + column sums"};
         const double tf = (double)h[15], tb = (double)h[63];
         fprintf(stderr, "k_egnn_edge_train: %.0f tiles, s_memtime ticks per tile and phase (100 MHz)\n", tf);
@@ -1165,7 +1164,6 @@ kpd_status layer_edges_bwd_fused(kpd_egnn_trainer *T, int l, int cur, int nxt, f
     a.meta = T->meta + (l == c.n_layers - 1 ? 16 : 0);
     a.use_tanh = c.use_tanh; a.coords_range = c.coords_range;
     a.part[0] = T->bpart[0]; a.part[1] = T->bpart[1]; a.part_ld = COLSUM_LD;
-    a.have_a2 = 0;
     a.stamps = T->stamps;
     a.skip = tool_env_int("KPD_TR_SKIP", 0);
     for (int nt = 0; nt < 2; ++nt) { a.dhn[nt] = dhn[nt]; a.dxo[nt] = T->dx[cur][nt]; a.zinv[nt] = T->zinv[nt]; }
