@@ -901,8 +901,9 @@ struct EdgeBwdSmem {
     float *ddij;              // d dij of the row, both branches
     float *c256;              // [2][TM]: column 256 of dpre1 and of dij * dpre1, for the scan
     int *misc;
+    float *wv;                // [4][HS]: row 256 of W2^T and the radial column of W1, per branch -- the vectors of the per-row dots
 };
-constexpr int EDGE_BWD_LDS_BYTES = TM * SA * 4 + (TM * (1 + 3 + 3 + 3 + 1 + 2) + 8) * 4;
+constexpr int EDGE_BWD_LDS_BYTES = TM * SA * 4 + (TM * (1 + 3 + 3 + 3 + 1 + 2) + 8 + 4 * HS) * 4;
 
 __device__ __forceinline__ EdgeBwdSmem edge_bwd_smem(float *smem) {
     EdgeBwdSmem s;
@@ -916,6 +917,7 @@ __device__ __forceinline__ EdgeBwdSmem edge_bwd_smem(float *smem) {
     s.ddij = s.nv + 3 * TM;
     s.c256 = s.ddij + TM;
     s.misc = reinterpret_cast<int *>(s.c256 + 2 * TM);
+    s.wv = reinterpret_cast<float *>(s.misc + 8);
     return s;
 }
 
@@ -1110,6 +1112,14 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_bwd(EdgeBwdArgs a) {
             s.misc[4] = (int)(heads & 0xffffffffu);
             s.misc[5] = (int)(heads >> 32);
         }
+    } else {
+        // the four vectors of the per-row dots to LDS, as the forward kernels do: read from global memory inside row_dot_chunks they were
+        // 17 dependent L2 round trips per call (a guarded load and a vmcnt(0) per chunk), four calls per tile
+        for (int i = tid - TM; i < 4 * 66; i += 64 * NW - TM) {
+            const int which = i / 66, j = i - which * 66;
+            const float *row = which == 0 ? a.wxT[et][0] : which == 1 ? a.wxT[et][1] : which == 2 ? a.wr[et][0] : a.wr[et][1];
+            reinterpret_cast<f32x4 *>(s.wv + which * HS)[j] = reinterpret_cast<const f32x4 *>(row)[j];
+        }
     }
     BPrefetch bpre;
     gemm_b_prefetch(bpre, a.wpT[et][0], wave, lane);
@@ -1135,7 +1145,7 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_bwd(EdgeBwdArgs a) {
         lds_barrier();
         TRAIN_STAMP(33 + 8 * br)
         acc_zero_w<NW>(acc);
-        const float ex = row_dot_chunks<TPR>(s.A, a.wxT[et][br], KP / 4, tid);
+        const float ex = row_dot_chunks<TPR>(s.A, s.wv + br * HS, KP / 4, tid);
         gemm_rows64_pre<NG, SA>(s.A, a.wpT[et][br], acc, wave, lane, bpre);
         if (br == 0) gemm_b_prefetch(bpre, a.wpT[et][1], wave, lane);
         lds_barrier();
@@ -1144,7 +1154,7 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_bwd(EdgeBwdArgs a) {
         lds_barrier();
         TRAIN_STAMP(35 + 8 * br)
         {   // d dij += dpre1 . W1[:, 514]
-            const float dot = row_dot_chunks<TPR>(s.A, a.wr[et][br], KP / 4, tid);
+            const float dot = row_dot_chunks<TPR>(s.A, s.wv + (2 + br) * HS, KP / 4, tid);
             if ((tid % TPR) == 0) s.ddij[tid / TPR] += dot;
         }
         {   // segmented sums over dst of dpre1 (dV) and dij * dpre1 (dVw): thread = column, rows in order
