@@ -154,7 +154,7 @@ struct NodeLayerPair {
 };
 
 constexpr int TN = 32;              // rows per workgroup of the fused node kernel
-constexpr int NODE_LAYER_LDS_BYTES = TN * SA * 4 + 3 * TN * 4;
+constexpr int NODE_LAYER_LDS_BYTES = TN * SA * 4 + 3 * TN * 4 + 3 * HS * 4;        // tile, z / mean / rstd per row, the three row-dot vectors
 // k_node_update8_h: two f16 planes of 32 x 280 halves (35 840 B) shared with the fp32 tile (34 304 B)
 constexpr int NODE_H_TILE_FLOATS = 2 * TN * 280 / 2;
 constexpr int NODE_H_LDS_BYTES = NODE_H_TILE_FLOATS * 4 + 3 * TN * 4;

@@ -1673,6 +1673,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     float *s_z = smem + TN * SA;
     float *s_mean = s_z + TN;
     float *s_rstd = s_mean + TN;
+    float *s_wx = s_rstd + TN;           // [3][HS]: row 256 of the three weight matrices, the vectors of the per-row dots (from global memory
+                                         // inside row_dot_chunks they were five dependent L2 round trips per call)
     // the wave index as a scalar: every row-wise loop below addresses rows by wave, so row pointers, the CSR bounds of the h_neigh
     // gather and its branches are scalar work
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -1690,20 +1692,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         t_prev_ = now_;                                                                    \
     }
 
+    // rows of h to the tile: all of a wave's loads in flight together (the h array is padded to a whole tile; rows >= n hold zeros)
     auto load_h = [&]() {
+        f32x4 val[RPW], val2[RPW];
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
-            const int r = wave * RPW + rr, v = node0 + r;
-            f32x4 val = {0.f, 0.f, 0.f, 0.f}, val2 = {0.f, 0.f, 0.f, 0.f};
-            if (v < a.n) {
-                const f32x4 *src = reinterpret_cast<const f32x4 *>(a.h + (size_t)v * HS);
-                val = src[lane];
-                if (lane < 2) val2 = src[64 + lane];
-            }
-            *reinterpret_cast<f32x4 *>(A + r * SA + 4 * lane) = val;
-            if (lane < 2) *reinterpret_cast<f32x4 *>(A + r * SA + 256 + 4 * lane) = val2;
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(a.h + (size_t)(node0 + wave * RPW + rr) * HS);
+            val[rr] = src[lane];
+            val2[rr] = src[64 + (lane & 1)];
+        }
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int r = wave * RPW + rr;
+            *reinterpret_cast<f32x4 *>(A + r * SA + 4 * lane) = val[rr];
+            if (lane < 2) *reinterpret_cast<f32x4 *>(A + r * SA + 256 + 4 * lane) = val2[rr];
         }
     };
+    // edge types whose pieces a node sums: n_in is 1 or 2; with one, the second slot repeats the first and is masked out
+    const int two = a.n_in > 1 ? 1 : 0;
+    const int *__restrict__ rp0 = a.rowptr[0], *__restrict__ rp1 = a.rowptr[two];
 
     f32x16 acc;
     {
@@ -1712,23 +1719,35 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             const int v = node0 + tid;
             float z = 1.0f;
             if (v < a.n) {
+                // bounds and main pieces of both edge types requested together (a main piece exists for every node; it is used only where
+                // the node has in-edges of the type), continuation pieces -- runs that cross a tile boundary -- in a loop behind them
+                const int lo0 = rp0[v], hi0 = rp0[v + 1], lo1 = rp1[v], hi1 = two ? rp1[v + 1] : lo1;
+                const float *pm0 = a.xn_main[0] + (size_t)v * 4, *pm1 = a.xn_main[two] + (size_t)v * 4;
+                const float m0x = pm0[0], m0y = pm0[1], m0z = pm0[2], m1x = pm1[0], m1y = pm1[1], m1z = pm1[2];
                 z = a.z[a.bidx[v]];
                 float sx = 0.f, sy = 0.f, sz = 0.f;
-                for (int i = 0; i < a.n_in; ++i) {
-                    const int lo = a.rowptr[i][v], hi = a.rowptr[i][v + 1];
-                    if (hi > lo) {
-                        const float *pm = a.xn_main[i] + (size_t)v * 4;
-                        sx += pm[0]; sy += pm[1]; sz += pm[2];
-                        for (int t = (lo >> a.tile_shift) + 1; t <= ((hi - 1) >> a.tile_shift); ++t) {
-                            const float *q = a.xn_cont[i] + (size_t)t * 4;
-                            sx += q[0]; sy += q[1]; sz += q[2];
-                        }
+                if (hi0 > lo0) {
+                    sx += m0x; sy += m0y; sz += m0z;
+                    for (int t = (lo0 >> a.tile_shift) + 1; t <= ((hi0 - 1) >> a.tile_shift); ++t) {
+                        const float *q = a.xn_cont[0] + (size_t)t * 4;
+                        sx += q[0]; sy += q[1]; sz += q[2];
+                    }
+                }
+                if (hi1 > lo1) {
+                    sx += m1x; sy += m1y; sz += m1z;
+                    for (int t = (lo1 >> a.tile_shift) + 1; t <= ((hi1 - 1) >> a.tile_shift); ++t) {
+                        const float *q = a.xn_cont[two] + (size_t)t * 4;
+                        sx += q[0]; sy += q[1]; sz += q[2];
                     }
                 }
                 float *xv = a.x + (size_t)v * 3;
                 xv[0] += sx / z; xv[1] += sy / z; xv[2] += sz / z;
             }
             s_z[tid] = z;
+        } else if (tid >= 512 - 3 * 66) {
+            const int i = tid - (512 - 3 * 66), which = i / 66, j = i - which * 66;
+            const float *row = which == 0 ? a.wx_a : which == 1 ? a.wx_b : a.wx_2;
+            reinterpret_cast<f32x4 *>(s_wx + which * HS)[j] = reinterpret_cast<const f32x4 *>(row)[j];
         }
         // GEMM 1a: W[:, :257] . h
         load_h();
@@ -1737,40 +1756,67 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
         gemm_rows32_t8<NG, SA>(A, a.wp_a, acc, wave, lane);
-        float ex = row_dot_chunks<TPR>(A, a.wx_a, KP / 4, tid);
+        float ex = row_dot_chunks<TPR>(A, s_wx, KP / 4, tid);
         lds_barrier();
         NL_STAMP(1)
         // GEMM 1b: + W[:, 257:] . (h_neigh / z); h_neigh = sum of segment pieces over the incoming edge
         // types in fixed order (multi_update_all cross_reducer='sum')
+        {
+            // (the bounds of a wave's four rows are scalar loads, the main pieces of both edge types of all four rows travel together; before,
+            //  every row and edge type was a chain bounds -> branch -> piece, a quarter of the kernel's time)
+            constexpr int GB = 2;        // rows per batch: 16 registers per row next to the live accumulators, in a kernel held to 80
 #pragma unroll
-        for (int rr = 0; rr < RPW; ++rr) {
-            const int r = wave * RPW + rr, v = node0 + r;
-            f32x4 val = {0.f, 0.f, 0.f, 0.f}, val2 = {0.f, 0.f, 0.f, 0.f};
-            if (v < a.n) {
-                for (int i = 0; i < a.n_in; ++i) {
-                    const int lo = a.rowptr[i][v], hi = a.rowptr[i][v + 1];
-                    if (hi > lo) {
-                        const f32x4 *pm = reinterpret_cast<const f32x4 *>(a.hn_main[i] + (size_t)v * HS);
-                        val += pm[lane];
-                        if (lane < 2) val2 += pm[64 + lane];
-                        for (int t = (lo >> a.tile_shift) + 1; t <= ((hi - 1) >> a.tile_shift); ++t) {
-                            const f32x4 *q = reinterpret_cast<const f32x4 *>(a.hn_cont[i] + (size_t)t * HS);
-                            val += q[lane];
-                            if (lane < 2) val2 += q[64 + lane];
-                        }
-                    }
+            for (int r0 = 0; r0 < RPW; r0 += GB) {
+                int lo0[GB], hi0[GB], lo1[GB], hi1[GB];
+                f32x4 m0[GB], m1[GB];
+                float t0[GB], t1[GB];            // columns 256 .. 263 of the row: one float on each of eight lanes
+#pragma unroll
+                for (int rr = 0; rr < GB; ++rr) {
+                    const int v = min(node0 + wave * RPW + r0 + rr, a.n - 1);
+                    lo0[rr] = rp0[v]; hi0[rr] = rp0[v + 1];
+                    lo1[rr] = rp1[v]; hi1[rr] = two ? rp1[v + 1] : lo1[rr];
+                    const f32x4 *p0 = reinterpret_cast<const f32x4 *>(a.hn_main[0] + (size_t)v * HS);
+                    const f32x4 *p1 = reinterpret_cast<const f32x4 *>(a.hn_main[two] + (size_t)v * HS);
+                    m0[rr] = p0[lane]; t0[rr] = reinterpret_cast<const float *>(p0)[256 + (lane & 7)];
+                    m1[rr] = p1[lane]; t1[rr] = reinterpret_cast<const float *>(p1)[256 + (lane & 7)];
                 }
-                const float z = s_z[r];
-                val /= z;
-                val2 /= z;
+#pragma unroll
+                for (int rr = 0; rr < GB; ++rr) {
+                    const int r = wave * RPW + r0 + rr, v = node0 + r;
+                    f32x4 val = {0.f, 0.f, 0.f, 0.f};
+                    float val2 = 0.0f;
+                    if (v < a.n) {
+                        if (hi0[rr] > lo0[rr]) {
+                            val += m0[rr];
+                            val2 += t0[rr];
+                            for (int t = (lo0[rr] >> a.tile_shift) + 1; t <= ((hi0[rr] - 1) >> a.tile_shift); ++t) {
+                                const f32x4 *q = reinterpret_cast<const f32x4 *>(a.hn_cont[0] + (size_t)t * HS);
+                                val += q[lane];
+                                val2 += reinterpret_cast<const float *>(q)[256 + (lane & 7)];
+                            }
+                        }
+                        if (hi1[rr] > lo1[rr]) {
+                            val += m1[rr];
+                            val2 += t1[rr];
+                            for (int t = (lo1[rr] >> a.tile_shift) + 1; t <= ((hi1[rr] - 1) >> a.tile_shift); ++t) {
+                                const f32x4 *q = reinterpret_cast<const f32x4 *>(a.hn_cont[two] + (size_t)t * HS);
+                                val += q[lane];
+                                val2 += reinterpret_cast<const float *>(q)[256 + (lane & 7)];
+                            }
+                        }
+                        const float z = s_z[r];
+                        val /= z;
+                        val2 /= z;
+                    }
+                    *reinterpret_cast<f32x4 *>(A + r * SA + 4 * lane) = val;
+                    if (lane < 8) A[r * SA + 256 + lane] = val2;
+                }
             }
-            *reinterpret_cast<f32x4 *>(A + r * SA + 4 * lane) = val;
-            if (lane < 2) *reinterpret_cast<f32x4 *>(A + r * SA + 256 + 4 * lane) = val2;
         }
         lds_barrier();
         NL_STAMP(2)
         gemm_rows32_t8<NG, SA>(A, a.wp_b, acc, wave, lane);
-        ex += row_dot_chunks<TPR>(A, a.wx_b, KP / 4, tid);
+        ex += row_dot_chunks<TPR>(A, s_wx + HS, KP / 4, tid);
         lds_barrier();
         NL_STAMP(3)
         // hidden = SiLU(. + b0) -> T (pad columns 257..263 stay 0 from the h_neigh tile)
@@ -1787,7 +1833,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
         gemm_rows32_t8<NG, SA>(A, a.wp_2, acc, wave, lane);
-        ex = row_dot_chunks<TPR>(A, a.wx_2, KP / 4, tid);
+        ex = row_dot_chunks<TPR>(A, s_wx + 2 * HS, KP / 4, tid);
         lds_barrier();
         NL_STAMP(5)
         {
