@@ -22,6 +22,14 @@ typedef float v4f_u4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef __attribute__((address_space(1))) v4f_u4 gv4f_u;          // a 16-byte access at a 4-byte aligned address (rows of 17 floats)
 __device__ __forceinline__ gfloat *G(float *p) { return (gfloat *)p; }
 __device__ __forceinline__ const gfloat *G(const float *p) { return (const gfloat *)p; }
+// The tables themselves (device arrays of pointers, written by the host before the launch and never by a kernel): read through a plain global
+// pointer, a wave-uniform entry is still a VECTOR load -- the compiler may not use the scalar unit once the kernel has stored anything -- followed
+// by s_waitcnt vmcnt(0), which in the training kernels drains the tens of activation stores in flight: a store round trip per pointer, 28 times
+// per tile in k_gvp_chain<16, 0, 1>.  CT() states that the table is constant memory: the entries arrive by s_load (lgkmcnt), next to the stores.
+template <class T>
+__device__ __forceinline__ const __attribute__((address_space(4))) T *CT(const T *p) {
+    return (const __attribute__((address_space(4))) T *)p;
+}
 
 __device__ __forceinline__ v4f mfma16(float a, float b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 // One-instruction square root / reciprocal (v_sqrt_f32, v_rcp_f32: 1 ulp) for the per-row geometry and the vector norms of the chained

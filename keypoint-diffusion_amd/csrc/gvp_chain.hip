@@ -20,6 +20,12 @@
 
 namespace kpd {
 
+typedef const __attribute__((address_space(4))) GvpTrainGvp cTrainGvp;        // entries of the trainers' slot tables, read as constant memory (CT, chain_core.h)
+typedef const __attribute__((address_space(4))) GvpTrainSlot cTrainSlot;
+typedef const __attribute__((address_space(4))) GvpBwdGvp cBwdGvp;
+typedef const __attribute__((address_space(4))) GvpBwdSlot cBwdSlot;
+
+
 namespace {
 
 #ifndef KPD_CHAIN_NBUF
@@ -44,10 +50,11 @@ struct ChainSmem {
 // all node-update GVPs): vec1, the [x | sh] GEMM over NTS + 1 chunks, SiLU, gates (one chunk), vec2.  acc enters holding
 // the bias of this GVP and leaves holding `next_bias` (when given) for the following one.
 // TR = 1 (training forward): tg names where this GVP's activations go (GvpTrainGvp), erow the lane's edge row, live whether it exists.
-template <int NTS, class Ring, int TR = 0>
+// (TG: const GvpTrainGvp in the kernel's arguments -- the node kernels -- or in a constant-memory slot table -- the edge kernel)
+template <int NTS, class Ring, int TR = 0, class TG = cTrainGvp>
 __device__ __forceinline__ void chain_generic_gvp(Ring &ring, const v4f *cb, const v4f *nb, const GvpW &gk, const float *next_bias,
                                                   v4f (&x)[NTS], v4f (&acc)[NTS], v4f (&Vc)[3], int lane, int q,
-                                                  const GvpTrainGvp *tg = nullptr, size_t erow = 0, bool live = false, int skip = 0) {
+                                                  TG *tg = nullptr, size_t erow = 0, bool live = false, int skip = 0) {
     // cb: this GVP's chunks (NTS scalar slabs, the sh slab, the gate slab); nb: the next GVP's -- or, after the last one, cb + NTS chunks,
     // so that the two refills past the end re-read chunks that exist.  The chunk two ahead of local chunk i:
     constexpr int CH4 = NTS * 64;
@@ -356,7 +363,7 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain(GvpEdgeArgs a) {
     const int u = esrc[eidx], vd = edst[eidx];
     [[maybe_unused]] const bool live = row < ne;                        // (training form: rows past the end are not stored)
     [[maybe_unused]] const size_t erow = (size_t)eidx;
-    [[maybe_unused]] const GvpTrainSlot *tsl = TR ? a.train + et : nullptr;
+    [[maybe_unused]] cTrainSlot *tsl = TR ? CT(a.train + et) : nullptr;
 
     // run boundaries of the dst-sorted tile for the segmented sum (wave 0, one lane per row)
     if (tid < TM) {
@@ -691,7 +698,8 @@ __device__ __forceinline__ v4f silu_grad4(v4f p) {          // d SiLU(p) / dp = 
 }
 
 // gate backward of one GVP from the kept gate pre-activation and Vu: dgate (stored), dVu (stored, returned in dV)
-__device__ __forceinline__ v4f gate_bwd_lane(const GvpTrainGvp *f, const GvpBwdGvp *o, v4f (&dV)[3], size_t erow, bool live, int q) {
+template <class TF, class TO>
+__device__ __forceinline__ v4f gate_bwd_lane(TF *f, TO *o, v4f (&dV)[3], size_t erow, bool live, int q) {
     const v4f gp = *reinterpret_cast<const gv4f *>(G(f->gate) + erow * 16 + 4 * q);
     v4f Vu[3];
 #pragma unroll
@@ -730,8 +738,8 @@ __device__ __forceinline__ v4f chunk_tile_product(const v4f *__restrict__ buf0, 
 }
 
 // backward of one generic GVP: acc holds dL/ds of its outputs on entry and dL/ds of its inputs on exit, dV likewise for the vectors; x is scratch
-template <int NTS, class Ring>
-__device__ __forceinline__ void chain_generic_gvp_bwd(Ring &ring, const v4f *cb, const v4f *nb, const GvpBwdW &w, const GvpTrainGvp *f, const GvpBwdGvp *o,
+template <int NTS, class Ring, class TF, class TO>
+__device__ __forceinline__ void chain_generic_gvp_bwd(Ring &ring, const v4f *cb, const v4f *nb, const GvpBwdW &w, TF *f, TO *o,
                                                       v4f (&x)[NTS], v4f (&acc)[NTS], v4f (&dV)[3], size_t erow, bool live, int lane, int q) {
     constexpr int S = 16 * NTS, CH4 = NTS * 64, NG = NTS + 2;
     auto ahead = [&](int i) -> const v4f * { return i + 2 < NG ? cb + (size_t)(i + 2) * CH4 : nb + (size_t)(i + 2 - NG) * CH4; };
@@ -802,8 +810,8 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain_bwd(GvpEdgeBwdArgs a) {
     const int ne = min(TM, a.meta[et] - e0);
     const int dnt = (et >= 2) ? 1 : 0;
     const int n_gvps = a.n_gvps;
-    const GvpTrainSlot *fs = a.fwd + et;
-    const GvpBwdSlot *os = a.out + et;
+    cTrainSlot *fs = CT(a.fwd + et);
+    cBwdSlot *os = CT(a.out + et);
 
     // chunk sequence: GVP n - 1 .. 1 (NTS + 2 chunks each), then the head's four
     constexpr int NG = NTS + 2;
@@ -842,8 +850,8 @@ __global__ __launch_bounds__(256, 2) void k_gvp_chain_bwd(GvpEdgeBwdArgs a) {
 
     // head GVP: gates, SiLU', the rbf and |Vh| blocks; its source-scalar block and its 17-channel vector half are the caller's
     {
-        const GvpTrainGvp *f = &fs->g[0];
-        const GvpBwdGvp *o = &os->g[0];
+        cTrainGvp *f = &fs->g[0];
+        cBwdGvp *o = &os->g[0];
         const v4f *hb = reinterpret_cast<const v4f *>(a.g[et][0].chain);
         auto ahead = [&](int i) -> const v4f * { return hb + (size_t)(i + 2 < 4 ? i + 2 : 3) * CH4; };
         const v4f dgate = gate_bwd_lane(f, o, dV, erow, live, q);
