@@ -1132,30 +1132,36 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_bwd(EdgeBwdArgs a) {
 
 #pragma unroll 1
     for (int br = 0; br < 2; ++br) {
+        // (an opaque copy of the thread index per branch: see k_egnn_edge_train -- nothing derived from it is carried across the loop)
+        int tid_b = tid;
+#ifndef KPD_BWD_LAUNDER_OFF
+        asm volatile("" : "+v"(tid_b));
+#endif
+        const int lane_b = tid_b & 63;
         float *pre1 = a.keep[et][br][0] + (size_t)e0 * HS;
         HeadSums hs;
         hs.cs = f32x4{0.f, 0.f, 0.f, 0.f}; hs.ws = f32x4{0.f, 0.f, 0.f, 0.f}; hs.cs_t = 0.0f; hs.ws_t = 0.0f;
         if (br == 0) {
-            edge_head_bwd_rows<true>(s, a, et, e0, ne, wave, lane, a.dhn[dnt], a.keep[et][0][2], a.wa[et], a.att[et], nullptr, hs);
+            edge_head_bwd_rows<true>(s, a, et, e0, ne, wave, lane_b, a.dhn[dnt], a.keep[et][0][2], a.wa[et], a.att[et], nullptr, hs);
         } else {
-            if (tid < TM) s.sa[tid] = a.sc[et][e0 + min(tid, ne - 1)];        // the coordinate scalar replaces the attention weight
+            if (tid_b < TM) s.sa[tid_b] = a.sc[et][e0 + min(tid_b, ne - 1)];        // the coordinate scalar replaces the attention weight
             lds_barrier();
-            edge_head_bwd_rows<false>(s, a, et, e0, ne, wave, lane, nullptr, a.keep[et][1][2], a.w3[et], nullptr, a.nvec[et], hs);
+            edge_head_bwd_rows<false>(s, a, et, e0, ne, wave, lane_b, nullptr, a.keep[et][1][2], a.w3[et], nullptr, a.nvec[et], hs);
         }
         lds_barrier();
         TRAIN_STAMP(33 + 8 * br)
         acc_zero_w<NW>(acc);
-        const float ex = row_dot_chunks<TPR>(s.A, s.wv + br * HS, KP / 4, tid);
-        gemm_rows64_pre<NG, SA>(s.A, a.wpT[et][br], acc, wave, lane, bpre);
-        if (br == 0) gemm_b_prefetch(bpre, a.wpT[et][1], wave, lane);
+        const float ex = row_dot_chunks<TPR>(s.A, s.wv + br * HS, KP / 4, tid_b);
+        gemm_rows64_pre<NG, SA>(s.A, a.wpT[et][br], acc, wave, lane_b, bpre);
+        if (br == 0) gemm_b_prefetch(bpre, a.wpT[et][1], wave, lane_b);
         lds_barrier();
         TRAIN_STAMP(34 + 8 * br)
-        store_T_bwd(s.A, acc, ex, tid, wave, lane, pre1, ne, (a.skip & 16) ? 0 : ne);
+        store_T_bwd(s.A, acc, ex, tid_b, wave, lane_b, pre1, ne, (a.skip & 16) ? 0 : ne);
         lds_barrier();
         TRAIN_STAMP(35 + 8 * br)
         {   // d dij += dpre1 . W1[:, 514]
-            const float dot = row_dot_chunks<TPR>(s.A, s.wv + (2 + br) * HS, KP / 4, tid);
-            if ((tid % TPR) == 0) s.ddij[tid / TPR] += dot;
+            const float dot = row_dot_chunks<TPR>(s.A, s.wv + (2 + br) * HS, KP / 4, tid_b);
+            if ((tid_b % TPR) == 0) s.ddij[tid_b / TPR] += dot;
         }
         {   // segmented sums over dst of dpre1 (dV) and dij * dpre1 (dVw): thread = column, rows in order
             float *m1 = a.dv_main[et][br], *c1 = a.dv_cont[et][br] + (size_t)tile_in_et * HS;
@@ -1169,7 +1175,7 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_bwd(EdgeBwdArgs a) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     w[i] = s.dd[r0 + i];
-                    v[i] = s.A[(r0 + i) * SA + tid];
+                    v[i] = s.A[(r0 + i) * SA + tid_b];
                 }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
@@ -1178,8 +1184,8 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_bwd(EdgeBwdArgs a) {
                     if ((endmask >> (r0 + i)) & 1ull) {
                         const bool cont = piece == 0 && first_is_cont;
                         const size_t vo = (size_t)s.dst[r0 + i] * HS;
-                        (cont ? c1 : m1 + vo)[tid] = run;
-                        (cont ? c2 : m2 + vo)[tid] = run2;
+                        (cont ? c1 : m1 + vo)[tid_b] = run;
+                        (cont ? c2 : m2 + vo)[tid_b] = run2;
                         run = 0.0f;
                         run2 = 0.0f;
                         ++piece;
@@ -1187,29 +1193,29 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_bwd(EdgeBwdArgs a) {
                 }
             }
             if (wave == NW - 1) {
-                const float v256 = s.A[lane * SA + 256];
-                s.c256[lane] = v256;
-                s.c256[TM + lane] = v256 * s.dd[lane];
+                const float v256 = s.A[lane_b * SA + 256];
+                s.c256[lane_b] = v256;
+                s.c256[TM + lane_b] = v256 * s.dd[lane_b];
             }
         }
         lds_barrier();
         TRAIN_STAMP(36 + 8 * br)
-        if (wave == 0) {    // column 256: segmented inclusive scan across lanes (lane = row), the last lane of every run writes
-            const unsigned long long upto = lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull);
+        if (wave == 0) {    // column 256: segmented inclusive scan across lanes (lane_b = row), the last lane_b of every run writes
+            const unsigned long long upto = lane_b == 63 ? ~0ull : ((1ull << (lane_b + 1)) - 1ull);
             const int start = 63 - __clzll((long long)((headmask & upto) | 1ull));
-            float v1 = s.c256[lane], v2 = s.c256[TM + lane];
+            float v1 = s.c256[lane_b], v2 = s.c256[TM + lane_b];
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
                 const float t1 = __shfl_up(v1, off), t2 = __shfl_up(v2, off);
-                if (lane - off >= start) {
+                if (lane_b - off >= start) {
                     v1 += t1;
                     v2 += t2;
                 }
             }
-            if ((endmask >> lane) & 1ull) {
-                const int piece = __popcll(endmask & ((1ull << lane) - 1ull));
+            if ((endmask >> lane_b) & 1ull) {
+                const int piece = __popcll(endmask & ((1ull << lane_b) - 1ull));
                 const bool cont = piece == 0 && first_is_cont;
-                const size_t vo = (size_t)s.dst[lane] * HS;
+                const size_t vo = (size_t)s.dst[lane_b] * HS;
                 (cont ? a.dv_cont[et][br] + (size_t)tile_in_et * HS : a.dv_main[et][br] + vo)[256] = v1;
                 (cont ? a.dvw_cont[et][br] + (size_t)tile_in_et * HS : a.dvw_main[et][br] + vo)[256] = v2;
             }
@@ -1219,16 +1225,16 @@ __global__ __launch_bounds__(256, 2) void k_egnn_edge_bwd(EdgeBwdArgs a) {
             float *sc = s.A, *sw = s.A + 4 * 320;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                sc[wave * 320 + 4 * lane + q] = hs.cs[q];
-                sw[wave * 320 + 4 * lane + q] = hs.ws[q];
+                sc[wave * 320 + 4 * lane_b + q] = hs.cs[q];
+                sw[wave * 320 + 4 * lane_b + q] = hs.ws[q];
             }
-            if (lane == 0) {
+            if (lane_b == 0) {
                 sc[wave * 320 + 256] = hs.cs_t;
                 sw[wave * 320 + 256] = hs.ws_t;
             }
             lds_barrier();
             float *p = a.part[br] + (size_t)tile * 2 * a.part_ld;
-            for (int c = tid; c < HW; c += 256) {
+            for (int c = tid_b; c < HW; c += 256) {
                 p[c] = (sw[c] + sw[320 + c]) + (sw[640 + c] + sw[960 + c]);                       // slot 0 -> head weight
                 p[a.part_ld + c] = (sc[c] + sc[320 + c]) + (sc[640 + c] + sc[960 + c]);          // slot 1 -> b2
             }
