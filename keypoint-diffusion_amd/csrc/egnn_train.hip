@@ -31,70 +31,55 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 
 
-// Segmented sums of E x 257 matrices over the edges of a node (copy_e + sum and the division by z, dynamics.py:177-192, and their
-// backward counterparts): one WAVE per node, a lane owns four columns (lane 0 column 256 too), rows are fetched four at a time and added
-// in edge order -- a fixed order per column.
-//   out[v]  (+)= (zinv ? zinv[v] : 1) * sum_j M[r_j] * (w ? w[r_j] : 1),  r_j = perm ? perm[j] : j,  j in [rowptr[v], rowptr[v + 1])
-//   out2[v]   =  sum_j M[r_j] * w2[r_j]      (optional, from the same loads);  out / out2 rows are ldo floats apart
-__global__ __launch_bounds__(256) void k_segsum264(const float *__restrict__ M, const float *__restrict__ w, const float *__restrict__ w2,
-                                                   const int *__restrict__ perm, const int *__restrict__ rowptr, const float *__restrict__ zinv,
-                                                   int accumulate, int n, float *__restrict__ out, float *__restrict__ out2, int ldo) {
+// By-source sums of the E x 257 gradient matrices of a layer (the backward of the gather h[src] in front of the edge MLPs): one WAVE per node, a
+// lane owns four columns (lane 0 column 256 too), rows are fetched four at a time through the by-source permutation and added in edge order -- a
+// fixed order per column.   out[v] = sum_j M[perm[j]],  j in [rowptr[v], rowptr[v + 1]);  out rows are ldo floats apart.
+// All (edge type, branch) pairs of a layer in one launch (blockIdx.y = pair): eight launches of very different sizes before -- the ligand-sized
+// ones pure latency, every one with its own tail.
+constexpr int SEGSUM_BATCH = 8;
+struct SegsumSrcBatch {
+    struct One {
+        const float *M;
+        const int *perm, *rowptr;
+        int n;
+        float *out;
+    } e[SEGSUM_BATCH];
+    int ldo;
+};
+__global__ __launch_bounds__(256) void k_segsum264(SegsumSrcBatch b) {
+    const SegsumSrcBatch::One &e = b.e[blockIdx.y];
+    const float *__restrict__ M = e.M;
+    const int *__restrict__ perm = e.perm;
     const int v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (v >= n) return;
-    const int lo = rowptr[v], hi = rowptr[v + 1];
-    if (lo == hi && accumulate && !out2) return;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-    float t = 0.0f, t2 = 0.0f;
-    auto add = [&](const f32x4 &m, float mt, float we, float we2) {
-        s[0] = fmaf(m[0], we, s[0]); s[1] = fmaf(m[1], we, s[1]); s[2] = fmaf(m[2], we, s[2]); s[3] = fmaf(m[3], we, s[3]);
-        t = fmaf(mt, we, t);
-        if (out2) {
-            s2[0] = fmaf(m[0], we2, s2[0]); s2[1] = fmaf(m[1], we2, s2[1]); s2[2] = fmaf(m[2], we2, s2[2]); s2[3] = fmaf(m[3], we2, s2[3]);
-            t2 = fmaf(mt, we2, t2);
-        }
-    };
+    if (v >= e.n) return;
+    const int lo = e.rowptr[v], hi = e.rowptr[v + 1];
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    float t = 0.0f;
     int j = lo;
     for (; j + 4 <= hi; j += 4) {
         int r[4];
         f32x4 m[4];
-        float mt[4], we[4], we2[4];
+        float mt[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) r[k] = perm ? perm[j + k] : j + k;
+        for (int k = 0; k < 4; ++k) r[k] = perm[j + k];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             m[k] = *reinterpret_cast<const f32x4 *>(M + (size_t)r[k] * LD + 4 * lane);
             mt[k] = lane == 0 ? M[(size_t)r[k] * LD + 256] : 0.0f;
-            we[k] = w ? w[r[k]] : 1.0f;
-            we2[k] = out2 ? w2[r[k]] : 0.0f;
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) add(m[k], mt[k], we[k], we2[k]);
+        for (int k = 0; k < 4; ++k) {
+            s += m[k];
+            t += mt[k];
+        }
     }
     for (; j < hi; ++j) {
-        const int r = perm ? perm[j] : j;
-        const f32x4 m = *reinterpret_cast<const f32x4 *>(M + (size_t)r * LD + 4 * lane);
-        add(m, lane == 0 ? M[(size_t)r * LD + 256] : 0.0f, w ? w[r] : 1.0f, out2 ? w2[r] : 0.0f);
+        const int r = perm[j];
+        s += *reinterpret_cast<const f32x4 *>(M + (size_t)r * LD + 4 * lane);
+        if (lane == 0) t += M[(size_t)r * LD + 256];
     }
-    const float zi = zinv ? zinv[v] : 1.0f;
-    f32x4 *o = reinterpret_cast<f32x4 *>(out + (size_t)v * ldo + 4 * lane);
-    if (accumulate) {
-        if (lo != hi) {
-            const f32x4 old = *o;
-            f32x4 nv;
-            nv[0] = old[0] + s[0] * zi; nv[1] = old[1] + s[1] * zi; nv[2] = old[2] + s[2] * zi; nv[3] = old[3] + s[3] * zi;
-            *o = nv;
-            if (lane == 0) out[(size_t)v * ldo + 256] += t * zi;
-        }
-    } else {
-        f32x4 nv;
-        nv[0] = s[0] * zi; nv[1] = s[1] * zi; nv[2] = s[2] * zi; nv[3] = s[3] * zi;
-        *o = nv;
-        if (lane == 0) out[(size_t)v * ldo + 256] = t * zi;
-    }
-    if (out2) {
-        *reinterpret_cast<f32x4 *>(out2 + (size_t)v * ldo + 4 * lane) = s2;
-        if (lane == 0) out2[(size_t)v * ldo + 256] = t2;
-    }
+    *reinterpret_cast<f32x4 *>(e.out + (size_t)v * b.ldo + 4 * lane) = s;
+    if (lane == 0) e.out[(size_t)v * b.ldo + 256] = t;
 }
 
 // h' = LayerNorm(h + q2 + b2) (or without the norm), one wave per node (dynamics.py:202-205)
@@ -1206,7 +1191,10 @@ kpd_status layer_edges_bwd_fused(kpd_egnn_trainer *T, int l, int cur, int nxt, f
     EdgePiecesBatch epb;
     memset(&epb, 0, sizeof(epb));
     epb.ldo = CAT_LD;
-    int n_crb = 0, n_epb = 0;
+    int n_crb = 0, n_epb = 0, n_ssb = 0, ssb_rows = 0;
+    SegsumSrcBatch ssb;
+    memset(&ssb, 0, sizeof(ssb));
+    ssb.ldo = CAT_LD;
     for (int et = 0; et < layer_n_et(T, l); ++et) {
         const int E = T->E[et], s = kS[et], d = kD[et];
         if (E == 0) continue;
@@ -1222,9 +1210,8 @@ kpd_status layer_edges_bwd_fused(kpd_egnn_trainer *T, int l, int cur, int nxt, f
             }
             float *dU = T->ducat[s] + (size_t)T->cat_of[et][br][0] * LD, *dV = T->ducat[d] + (size_t)T->cat_of[et][br][1] * LD;
             float *dVw = T->dvwcat[d] + (size_t)T->cat_dvw_of[et][br] * LD;
-            hipLaunchKernelGGL(k_segsum264, dim3(cdiv(T->n[s], 4)), dim3(256), 0, T->st, dpre1, (const float *)nullptr, (const float *)nullptr,
-                               T->scsr[et].perm, T->scsr[et].rowptr, (const float *)nullptr, 0, T->n[s], dU, (float *)nullptr, CAT_LD);
-            KPD_LAUNCH_CHECK();
+            ssb.e[n_ssb++] = SegsumSrcBatch::One{dpre1, T->scsr[et].perm, T->scsr[et].rowptr, T->n[s], dU};          // (one launch below)
+            ssb_rows = std::max(ssb_rows, T->n[s]);
             epb.e[n_epb++] = EdgePiecesBatch::One{T->dv_main[et][br], T->dv_cont[et][br], T->dvw_main[et][br], T->dvw_cont[et][br], T->e_rowptr[et], T->n[d], dV,
                                                   p.W1.g ? dVw : nullptr};
         }
@@ -1241,6 +1228,10 @@ kpd_status layer_edges_bwd_fused(kpd_egnn_trainer *T, int l, int cur, int nxt, f
     }
     // the second-Linear weight gradients of every (edge type, branch) of the layer: one launch, a share of the CUs per product proportional
     // to its edge count (sgemm.hip, grad257_batch) instead of a launch, 256 partial tiles and a reduction each
+    if (n_ssb) {          // the by-source gradient blocks of every (edge type, branch): one launch
+        hipLaunchKernelGGL(k_segsum264, dim3(cdiv(ssb_rows, 4), n_ssb), dim3(256), 0, T->st, ssb);
+        KPD_LAUNCH_CHECK();
+    }
     KPD_TRY(launch_edge_pieces_set(epb, n_epb, T->st));          // the by-destination gradient blocks of every (edge type, branch): one launch
     if (n_crb) {          // head and second-bias gradients of every (edge type, branch): the per-tile partials of k_egnn_edge_bwd, summed in one launch
         hipLaunchKernelGGL(k_colsum_reduce_batch, dim3(cdiv(H, 64), n_crb), dim3(1024), 0, T->st, crb);
