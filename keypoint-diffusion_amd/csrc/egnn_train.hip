@@ -342,6 +342,7 @@ struct kpd_egnn_trainer : TrainCtx {
     kpd_egnn_config cfg{};
     // HIP-event timing of the two per-layer edge kernels (kpd_egnn_trainer_profile): (start, stop) pairs, which kernel, how many edges
     std::vector<hipEvent_t> prof_ev;
+    float *wsg_pack = nullptr;                 // per-call weight pack of ws_gemm (node MLPs)
     unsigned long long *stamps = nullptr;      // TOOLS build, KPD_TRAIN_STAMPS=1: phase-cycle sums of the two edge kernels (printed by profile_read)
     std::vector<int> prof_tag;
     std::vector<double> prof_edges;
@@ -609,8 +610,21 @@ inline NodeAct node_act(kpd_egnn_trainer *T, int l, int nt) {
     for (int k = 0; k < 3; ++k) a.q[k] = T->store ? T->nq[nt][k][l] : k == 1 ? T->nbw[nt][2] : T->nb[2 + k];       // (q[1] outlives node_bwd: its weight gradient is batched)
     return a;
 }
+// The node MLPs' products are [n, 257] x [257, 257]: K is seventeen 16-row slabs, and in the tiled kernel (600 workgroups of 128 x 64 outputs, every one
+// filling its LDS ring and draining its accumulators for 17 slabs of work) a receptor-sized product took 86 us -- 30 - 60 TFLOP/s.  ws_gemm.hip keeps half of
+// the weight matrix resident in a workgroup's LDS and walks 128-row tiles (the shape k_proj_ws has in the inference engine), with the same fused epilogues.
+// Ligand-sized products (13 row tiles) stay on the tiled kernel.
+inline bool node_ws(const kpd_egnn_trainer *T, int n) {
+    static const int on = tool_env_int("KPD_NODE_WS", 1);          // A/B runs
+    return on && T->wsg_pack && n >= 4096;
+}
 kpd_status node_mlp_fwd(kpd_egnn_trainer *T, const NodeParams &p, int l, int nt, const NodeAct &a) {
     const int n = T->n[nt];
+    if (node_ws(T, n)) {
+        KPD_TRY(ws_gemm(WS_PLAIN, T->hs[nt][l], n, LD, p.W1.w, 2 * H, false, nullptr, nullptr, a.q[0], nullptr, LD, T->wsg_pack, T->st));
+        KPD_TRY(ws_gemm(WS_BIAS_SILU, T->hns[nt][l], n, LD, p.W1.w + H, 2 * H, false, p.b1.w, nullptr, a.q[0], a.q[1], LD, T->wsg_pack, T->st, true, true));
+        return ws_gemm(WS_PLAIN, a.q[1], n, LD, p.W2.w, H, false, nullptr, nullptr, a.q[2], nullptr, LD, T->wsg_pack, T->st);
+    }
     KPD_TRY(gemm(T, false, true, n, H, H, T->hs[nt][l], LD, p.W1.w, 2 * H, 0.0f, a.q[0], LD));
     KPD_TRY(gemm(T, false, true, n, H, H, T->hns[nt][l], LD, p.W1.w + H, 2 * H, 1.0f, a.q[0], LD, 1.0f, nullptr, p.b1.w, a.q[1]));      // + bias, SiLU -> c1
     KPD_TRY(gemm(T, false, true, n, H, H, a.q[1], LD, p.W2.w, H, 0.0f, a.q[2], LD));
@@ -872,6 +886,7 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
     for (int et = 0; et < 4; ++et) { add(cap_et[et], 4); add(nn[kS[et]] + 1, 4); }
     add(cap_N, 4);
     add(colpart_floats(std::max(cap_E, cap_N)), 4);
+    add((size_t)ws_gemm_pack_floats(), 4);
     T->ws.release();
     KPD_TRY(T->ws.reserve(bytes + 4096));
     Arena &W = T->ws;
@@ -945,7 +960,8 @@ extern "C" kpd_status kpd_egnn_trainer_reserve(kpd_egnn_trainer *T, int32_t max_
     T->cursor = W.take<int>(cap_N);
     T->colpart_blocks = cdiv(std::max(cap_E, cap_N), HEAD_ROWS);
     T->colpart = W.take<float>(colpart_floats(std::max(cap_E, cap_N)));
-    KPD_REQUIRE(T->colpart != nullptr, KPD_ERR_HIP, "workspace arena too small (internal sizing error)");
+    T->wsg_pack = W.take<float>((size_t)ws_gemm_pack_floats());
+    KPD_REQUIRE(T->colpart != nullptr && T->wsg_pack != nullptr, KPD_ERR_HIP, "workspace arena too small (internal sizing error)");
     {
         if (T->store_base) (void)hipFree(T->store_base);
         T->store_base = nullptr;
@@ -1121,7 +1137,9 @@ kpd_status node_bwd(kpd_egnn_trainer *T, int l, int nt, int cur, int nxt, float 
     if (batch) T->wq_nodes.push_back(Grad257Item{du, na.q[1], LD, LD, n, p.W2.g, H, p.b2.g});
     else KPD_TRY(grad_gemm(T, H, H, n, du, LD, na.q[1], LD, p.W2.g, H, p.b2.g));
     float *dq1 = tmp;
-    KPD_TRY(gemm(T, false, false, n, H, H, du, LD, p.W2.w, H, 0.0f, dq1, LD, 1.0f, na.q[0]));                    // * SiLU'(pre) in the epilogue
+    const bool ws = node_ws(T, n);
+    if (ws) KPD_TRY(ws_gemm(WS_SILU_BWD, du, n, LD, p.W2.w, H, true, nullptr, na.q[0], dq1, nullptr, LD, T->wsg_pack, T->st));
+    else KPD_TRY(gemm(T, false, false, n, H, H, du, LD, p.W2.w, H, 0.0f, dq1, LD, 1.0f, na.q[0]));                    // * SiLU'(pre) in the epilogue
     if (batch) {
         T->wq_nodes.push_back(Grad257Item{dq1, T->hs[nt][l], LD, LD, n, p.W1.g, 2 * H, p.b1.g});
         T->wq_nodes.push_back(Grad257Item{dq1, T->hns[nt][l], LD, LD, n, p.W1.g + H, 2 * H, nullptr});
@@ -1131,8 +1149,13 @@ kpd_status node_bwd(kpd_egnn_trainer *T, int l, int nt, int cur, int nxt, float 
     }
     // dh_in = du (residual) + dq1 W1[:, :257];  d(h_neigh / z) = dq1 W1[:, 257:]
     KPD_HIP(hipMemcpyAsync(T->dh[nxt][nt], du, (size_t)n * LD * 4, hipMemcpyDeviceToDevice, T->st));
-    KPD_TRY(gemm(T, false, false, n, H, H, dq1, LD, p.W1.w, 2 * H, 1.0f, T->dh[nxt][nt], LD));
-    KPD_TRY(gemm(T, false, false, n, H, H, dq1, LD, p.W1.w + H, 2 * H, 0.0f, dhn_out, LD));
+    if (ws) {
+        KPD_TRY(ws_gemm(WS_PLAIN, dq1, n, LD, p.W1.w, 2 * H, true, nullptr, nullptr, T->dh[nxt][nt], nullptr, LD, T->wsg_pack, T->st, true, true));
+        KPD_TRY(ws_gemm(WS_PLAIN, dq1, n, LD, p.W1.w + H, 2 * H, true, nullptr, nullptr, dhn_out, nullptr, LD, T->wsg_pack, T->st));
+    } else {
+        KPD_TRY(gemm(T, false, false, n, H, H, dq1, LD, p.W1.w, 2 * H, 1.0f, T->dh[nxt][nt], LD));
+        KPD_TRY(gemm(T, false, false, n, H, H, dq1, LD, p.W1.w + H, 2 * H, 0.0f, dhn_out, LD));
+    }
     KPD_HIP(hipMemcpyAsync(T->dx[nxt][nt], T->dx[cur][nt], (size_t)n * 12, hipMemcpyDeviceToDevice, T->st));   // x' = x + x_neigh
     return KPD_OK;
 }
