@@ -280,3 +280,46 @@ def test_backward_after_the_caller_dropped_the_graph():
 
     a, b = grads(False), grads(True)
     assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+def test_large_batches_take_the_weight_stationary_node_products():
+    """From 4 096 receptor nodes on, the node MLPs' n x 257 x 257 products (forward and backward) run on the weight-stationary kernel with fused
+    epilogues instead of the tiled GEMM (egnn_train.hip, node_ws).  The oracle is too slow at that size, so the check is additivity: a linear
+    functional of the outputs over 16 complexes in ONE batch (4 960 receptor nodes) has the parameter gradients of the same complexes in two
+    batches of 8 (2 480 nodes each: the tiled path) added up, and every complex keeps its outputs."""
+    cfg = dict(util.EGNN_C2, n_layers=2)
+    n_rec, n_lig = [310] * 16, [12 + (i % 5) for i in range(16)]
+    gs = synth.synth_complexes(n_rec, n_lig, 20, CUT, seed=9, n_rec_feat=10)
+    model = LigRecDynamics(10, 10, graph_cutoffs=CUT, **cfg)
+    synth.fill_state_dict_(model, 21)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith('.4.weight'):
+                p.mul_(20.0)
+    model = model.cuda()
+    t = torch.rand(16, generator=torch.Generator().manual_seed(3)) * 0.9 + 0.05
+    gen = torch.Generator().manual_seed(4)
+    w_h = [torch.randn(n, 10, generator=gen) for n in n_lig]
+    w_x = [torch.randn(n, 3, generator=gen) for n in n_lig]
+
+    def run(idx):
+        g = util.fixed_encode(G.batch([gs[i] for i in idx])).to('cuda')
+        assert (g.num_nodes('kp') >= 4096) == (len(idx) == 16)
+        model.zero_grad(set_to_none=True)
+        eh, ex = model(g, t[idx].cuda(), None)
+        wh, wx = torch.cat([w_h[i] for i in idx]).cuda(), torch.cat([w_x[i] for i in idx]).cuda()
+        ((eh * wh).sum() + (ex * wx).sum()).backward()
+        return eh.detach().cpu(), ex.detach().cpu(), {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters()}
+
+    eh, ex, g_all = run(list(range(16)))
+    eh_a, ex_a, g_a = run(list(range(8)))
+    eh_b, ex_b, g_b = run(list(range(8, 16)))
+    assert util.rel_err(eh, torch.cat([eh_a, eh_b])) < 2e-5 and util.rel_err(ex, torch.cat([ex_a, ex_b])) < 2e-5
+    worst = {}
+    for n in g_all:
+        ref = g_a[n] + g_b[n]
+        scale = float(ref.abs().max())
+        if scale > 0:
+            worst[n] = float((g_all[n] - ref).abs().max()) / scale
+    bad = {n: e for n, e in worst.items() if e > TOL}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
