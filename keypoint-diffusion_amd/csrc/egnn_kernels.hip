@@ -2191,6 +2191,15 @@ kpd_status launch_node_layer(const NodeLayerPair &p, hipStream_t st) {
     static const int pad = tool_env_int("KPD_NODE_LDS_PAD", 0);
     for (int nt = 0; nt < 2; ++nt)
         KPD_REQUIRE(p.nt[nt].u.n == 0 || (p.nt[nt].do_update && !p.nt[nt].do_proj), KPD_ERR_INVALID, "node launch: update-only node types expected");
+    // k_node_update8 reads the segment bounds of (up to) two incoming edge types unconditionally: an updated node type has at least one, with its arrays
+    for (int nt = 0; nt < 2; ++nt) {
+        const NodeArgs &u = p.nt[nt].u;
+        if (u.n == 0) continue;
+        KPD_REQUIRE(u.n_in >= 1 && u.n_in <= 2, KPD_ERR_INVALID, "node launch: node type %d has %d incoming edge types (1 or 2 expected)", nt, u.n_in);
+        for (int i = 0; i < u.n_in; ++i)
+            KPD_REQUIRE(u.rowptr[i] && u.hn_main[i] && u.hn_cont[i] && u.xn_main[i] && u.xn_cont[i], KPD_ERR_INVALID,
+                        "node launch: segment arrays of incoming edge type %d of node type %d are missing", i, nt);
+    }
     if (p.gemm_mode == 1 && !p.stamps) {                   // (phase-stamped diagnostic launches keep the exact kernel)
         for (int nt = 0; nt < 2; ++nt)
             if (p.nt[nt].u.n > 0)
